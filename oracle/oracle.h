@@ -1,0 +1,112 @@
+/*
+ * oracle/oracle.h -- C API of the CPU oracle.
+ *
+ * TEST INFRASTRUCTURE ONLY.  This is a dependency-free CPU restatement of the
+ * reference (shichaoy/cube_slam) hot path, used as the parity checker by
+ * tests/, __graft_entry__.smoke() and the cpu_baseline leg of bench.py.  The
+ * product (cube_slam_amd/, include/) never includes, links or calls anything
+ * in this directory.
+ *
+ * PARITY UNPINNED: the reference has no tests/golden vectors for this path and
+ * cannot be compiled in this environment (needs OpenCV/Eigen/ROS, all absent),
+ * see DESIGN.md "Oracle".  Third-party semantics (OpenCV imgproc/features2d,
+ * Eigen) are restated from their published algorithms; every function cites
+ * the reference file:line it follows.
+ */
+#ifndef CUBESLAM_ORACLE_H
+#define CUBESLAM_ORACLE_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ------------------------------------------------------------------ cuboid */
+
+typedef struct orc_cuboid_opts {
+    int consider_config_1;             /* detect_3d_cuboid.h:71 */
+    int consider_config_2;             /* :72 */
+    int whether_sample_cam_roll_pitch; /* :73 */
+    int whether_sample_bbox_height;    /* :74 */
+    int max_cuboid_num;                /* :76 */
+    double nominal_skew_ratio;         /* :77 */
+    double max_cut_skew;               /* :78 */
+    /* extensions (defaults reproduce box_proposal_detail.cpp:126-128,197) */
+    double yaw_range_deg;              /* 45 */
+    double yaw_step_deg;               /* 6  */
+    int canny_low;                     /* 80 */
+    int canny_high;                    /* 200 */
+    /* 0: yaw_init from the raw camera pose for every box (pinned, what the
+     *    product implements); 1: the reference's stateful cam_pose carry-over
+     *    between boxes (box_proposal_detail.cpp:126 reads cam_pose, which
+     *    :237/:485 overwrite while sampling roll/pitch). */
+    int stateful_cam_pose;
+} orc_cuboid_opts;
+
+typedef struct orc_cuboid {
+    double pos[3];
+    double scale[3];
+    double rotY;
+    double box_config_type[2];
+    int32_t box_corners_2d[16];       /* 2x8 row-major (x0..x7, y0..y7) */
+    double box_corners_3d_world[24];  /* 3x8 row-major */
+    double rect_detect_2d[4];
+    double edge_distance_error;
+    double edge_angle_error;
+    double normalized_error;
+    double skew_ratio;
+    double down_expand_height;
+    double camera_roll_delta;
+    double camera_pitch_delta;
+} orc_cuboid;
+
+void orc_cuboid_default_opts(orc_cuboid_opts *o);
+
+/* cv::cvtColor(BGR2GRAY) on u8 */
+void orc_bgr2gray(const uint8_t *bgr, int w, int h, uint8_t *gray);
+
+/* cv::Canny(gray(roi), low, high) with aperture 3, L1 gradient.  edges: 0/255, w*h */
+void orc_canny_roi(const uint8_t *gray, int W, int H, int x0, int y0, int w, int h,
+                   int low, int high, uint8_t *edges);
+
+/* cv::distanceTransform(src, CV_DIST_L2, 3); zero pixels of src are sources */
+void orc_dist_transform_3x3(const uint8_t *src, int w, int h, float *dist);
+
+/* merge_break_lines (object_3d_util.cpp:300-376); out has room for n*4; returns rows */
+int orc_merge_break_lines(const double *lines, int n, double dist_thre, double angle_thre_deg,
+                          double len_thre, double *out);
+
+/* box_edge_sum_dists / box_edge_alignment_angle_error on one proposal
+ * corners: 2x8 row-major (already shifted for sum_dists); config 1 or 2 */
+double orc_box_edge_sum_dists(const float *dist_map, int w, int h, const double *corners_shift, int config_id);
+double orc_box_edge_angle_error(const double *vp_bound_angles /*3x2*/, const double *corners, int config_id);
+
+/* fuse_normalize_scores_v2; keep has room n; scores has room n; returns kept count */
+int orc_fuse_normalize_scores(const double *dist_err, const double *angle_err, int n, double weight_vp_angle,
+                              int whether_normalize, int *keep, double *scores);
+
+/*
+ * detect_3d_cuboid::detect_cuboid (box_proposal_detail.cpp:56-557).
+ *   gray: H x W u8.  K: 3x3 row-major.  Twc: 4x4 row-major.  boxes: nb x 5.  lines: nl x 4.
+ *   out: nb * max_cuboid_num records, counts[nb].
+ * Optional debug outputs (may be NULL):
+ *   dbg_rows     : room for dbg_rows_cap rows of 25 doubles
+ *                  [cfg, vp1pos, yaw, top_id, dist/diag, angle, hExp, roll, pitch, x0..x7, y0..y7]
+ *                  for every valid proposal, in reference order, all boxes / height samples concatenated
+ *   dbg_row_count: per (box,height-sample) count, room for nb*3
+ * returns 0 or <0 on bad input.
+ */
+int orc_detect_cuboid(const uint8_t *gray, int W, int H, const double *K, const double *Twc,
+                      const double *boxes, int nb, const double *lines, int nl,
+                      const orc_cuboid_opts *opts, orc_cuboid *out, int *counts,
+                      double *dbg_rows, long dbg_rows_cap, int *dbg_row_count);
+
+/* full-frame helper used by tests: Canny+DT of one ROI as detect_cuboid does it */
+void orc_canny_dt_roi(const uint8_t *gray, int W, int H, int x0, int y0, int w, int h, int low, int high,
+                      float *dist);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,152 @@
+"""ctypes binding of the CPU oracle (oracle/liboracle.so).
+
+TEST INFRASTRUCTURE ONLY: imported by tests/, __graft_entry__.smoke() and the
+cpu_baseline leg of bench.py.  Never imported by cube_slam_amd/.
+"""
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIB = None
+
+
+def build():
+    subprocess.check_call(["make", "-s", "-C", _HERE])
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        path = os.path.join(_HERE, "liboracle.so")
+        if not os.path.exists(path):
+            build()
+        _LIB = C.CDLL(path)
+        _LIB.orc_box_edge_sum_dists.restype = C.c_double
+        _LIB.orc_box_edge_angle_error.restype = C.c_double
+    return _LIB
+
+
+class CuboidOpts(C.Structure):
+    _fields_ = [
+        ("consider_config_1", C.c_int), ("consider_config_2", C.c_int),
+        ("whether_sample_cam_roll_pitch", C.c_int), ("whether_sample_bbox_height", C.c_int),
+        ("max_cuboid_num", C.c_int),
+        ("nominal_skew_ratio", C.c_double), ("max_cut_skew", C.c_double),
+        ("yaw_range_deg", C.c_double), ("yaw_step_deg", C.c_double),
+        ("canny_low", C.c_int), ("canny_high", C.c_int), ("stateful_cam_pose", C.c_int),
+    ]
+
+
+class Cuboid(C.Structure):
+    _fields_ = [
+        ("pos", C.c_double * 3), ("scale", C.c_double * 3), ("rotY", C.c_double),
+        ("box_config_type", C.c_double * 2), ("box_corners_2d", C.c_int32 * 16),
+        ("box_corners_3d_world", C.c_double * 24), ("rect_detect_2d", C.c_double * 4),
+        ("edge_distance_error", C.c_double), ("edge_angle_error", C.c_double),
+        ("normalized_error", C.c_double), ("skew_ratio", C.c_double),
+        ("down_expand_height", C.c_double), ("camera_roll_delta", C.c_double),
+        ("camera_pitch_delta", C.c_double),
+    ]
+
+
+CUBOID_DTYPE = np.dtype([
+    ("pos", "f8", 3), ("scale", "f8", 3), ("rotY", "f8"), ("box_config_type", "f8", 2),
+    ("box_corners_2d", "i4", (2, 8)), ("box_corners_3d_world", "f8", (3, 8)), ("rect_detect_2d", "f8", 4),
+    ("edge_distance_error", "f8"), ("edge_angle_error", "f8"), ("normalized_error", "f8"),
+    ("skew_ratio", "f8"), ("down_expand_height", "f8"), ("camera_roll_delta", "f8"),
+    ("camera_pitch_delta", "f8")], align=True)
+assert CUBOID_DTYPE.itemsize == C.sizeof(Cuboid)
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+def cuboid_opts(**kw):
+    o = CuboidOpts()
+    lib().orc_cuboid_default_opts(C.byref(o))
+    for k, v in kw.items():
+        if not hasattr(o, k):
+            raise KeyError(k)
+        setattr(o, k, v)
+    return o
+
+
+def bgr2gray(bgr):
+    bgr = np.ascontiguousarray(bgr, np.uint8)
+    h, w = bgr.shape[:2]
+    g = np.empty((h, w), np.uint8)
+    lib().orc_bgr2gray(_p(bgr, C.c_uint8), w, h, _p(g, C.c_uint8))
+    return g
+
+
+def canny_roi(gray, x0, y0, w, h, low=80, high=200):
+    gray = np.ascontiguousarray(gray, np.uint8)
+    H, W = gray.shape
+    e = np.empty((h, w), np.uint8)
+    lib().orc_canny_roi(_p(gray, C.c_uint8), W, H, x0, y0, w, h, low, high, _p(e, C.c_uint8))
+    return e
+
+
+def dist_transform(src):
+    src = np.ascontiguousarray(src, np.uint8)
+    h, w = src.shape
+    d = np.empty((h, w), np.float32)
+    lib().orc_dist_transform_3x3(_p(src, C.c_uint8), w, h, _p(d, C.c_float))
+    return d
+
+
+def canny_dt_roi(gray, x0, y0, w, h, low=80, high=200):
+    gray = np.ascontiguousarray(gray, np.uint8)
+    H, W = gray.shape
+    d = np.empty((h, w), np.float32)
+    lib().orc_canny_dt_roi(_p(gray, C.c_uint8), W, H, x0, y0, w, h, low, high, _p(d, C.c_float))
+    return d
+
+
+def merge_break_lines(lines, dist_thre=20.0, angle_thre_deg=5.0, len_thre=30.0):
+    lines = np.ascontiguousarray(lines, np.float64).reshape(-1, 4)
+    out = np.empty_like(lines)
+    n = lib().orc_merge_break_lines(_p(lines, C.c_double), len(lines), C.c_double(dist_thre),
+                                    C.c_double(angle_thre_deg), C.c_double(len_thre), _p(out, C.c_double))
+    return out[:n].copy()
+
+
+def fuse_normalize_scores(dist_err, angle_err, weight_vp_angle=0.8, normalize=True):
+    d = np.ascontiguousarray(dist_err, np.float64)
+    a = np.ascontiguousarray(angle_err, np.float64)
+    keep = np.empty(len(d), np.int32)
+    sc = np.empty(len(d), np.float64)
+    n = lib().orc_fuse_normalize_scores(_p(d, C.c_double), _p(a, C.c_double), len(d), C.c_double(weight_vp_angle),
+                                        int(normalize), _p(keep, C.c_int), _p(sc, C.c_double))
+    return keep[:n].copy(), sc[:n].copy()
+
+
+def detect_cuboid(gray, K, Twc, boxes, lines, opts=None, debug=False, rows_cap=400000):
+    """Returns (list per box of structured arrays, debug dict or None)."""
+    opts = opts or cuboid_opts()
+    gray = np.ascontiguousarray(gray, np.uint8)
+    H, W = gray.shape
+    K = np.ascontiguousarray(K, np.float64).reshape(3, 3)
+    Twc = np.ascontiguousarray(Twc, np.float64).reshape(4, 4)
+    boxes = np.ascontiguousarray(boxes, np.float64).reshape(-1, 5)
+    lines = np.ascontiguousarray(lines, np.float64).reshape(-1, 4)
+    nb = len(boxes)
+    out = np.zeros((nb, max(1, opts.max_cuboid_num)), CUBOID_DTYPE)
+    counts = np.zeros(nb, np.int32)
+    rows = np.zeros((rows_cap, 25), np.float64) if debug else None
+    rc = np.zeros(nb * 3 + 1, np.int32)
+    r = lib().orc_detect_cuboid(_p(gray, C.c_uint8), W, H, _p(K, C.c_double), _p(Twc, C.c_double),
+                                _p(boxes, C.c_double), nb, _p(lines, C.c_double), len(lines), C.byref(opts),
+                                out.ctypes.data_as(C.c_void_p), _p(counts, C.c_int),
+                                _p(rows, C.c_double) if debug else None, rows_cap, _p(rc, C.c_int))
+    if r != 0:
+        raise RuntimeError("orc_detect_cuboid failed: %d" % r)
+    res = [out[i, :counts[i]].copy() for i in range(nb)]
+    dbg = None
+    if debug:
+        dbg = {"row_count": rc, "rows": rows[: int(rc.sum())].copy()}
+    return res, dbg
