@@ -1,0 +1,102 @@
+// common.h -- context, error handling and per-kernel hipEvent timing shared by all paths of libcubeslam_hip.so
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdio>
+#include <cstring>
+#include <map>
+#include <string>
+#include <vector>
+
+#include "../../include/cubeslam_hip.h"
+
+struct cs_timing_rec {
+    double total_ms = 0;
+    long count = 0;
+};
+
+struct cs_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    std::string err;
+    bool timing = false;
+    std::map<std::string, cs_timing_rec> timings;
+    struct pending_ev { std::string name; hipEvent_t a, b; };
+    std::vector<pending_ev> pending;
+    std::vector<hipEvent_t> pool;
+
+    hipEvent_t get_event() {
+        if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
+        hipEvent_t e; hipEventCreate(&e); return e;
+    }
+    void begin(const char *name) {
+        if (!timing) return;
+        pending_ev p; p.name = name; p.a = get_event(); p.b = get_event();
+        hipEventRecord(p.a, stream);
+        pending.push_back(p);
+    }
+    void end() {
+        if (!timing) return;
+        hipEventRecord(pending.back().b, stream);
+    }
+    void flush() {
+        if (pending.empty()) return;
+        hipStreamSynchronize(stream);
+        for (auto &p : pending) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, p.a, p.b) == hipSuccess) { auto &r = timings[p.name]; r.total_ms += ms; r.count++; }
+            pool.push_back(p.a); pool.push_back(p.b);
+        }
+        pending.clear();
+    }
+};
+
+#define CS_HIP(ctx, call)                                                                         \
+    do {                                                                                          \
+        hipError_t e__ = (call);                                                                  \
+        if (e__ != hipSuccess) {                                                                  \
+            char b__[512];                                                                        \
+            snprintf(b__, sizeof b__, "%s:%d: %s -> %s", __FILE__, __LINE__, #call, hipGetErrorString(e__)); \
+            (ctx)->err = b__;                                                                     \
+            return CS_ERR_HIP;                                                                    \
+        }                                                                                         \
+    } while (0)
+
+// Launch helper: named, timed when ctx->timing is on.
+#define CS_LAUNCH(ctx, name, kernel, grid, block, shmem, ...)                         \
+    do {                                                                              \
+        (ctx)->begin(name);                                                           \
+        hipLaunchKernelGGL(kernel, grid, block, shmem, (ctx)->stream, __VA_ARGS__);   \
+        (ctx)->end();                                                                 \
+    } while (0)
+
+template <class T> static inline int cs_dalloc(cs_ctx *ctx, T **p, size_t n) {
+    if (n == 0) n = 1;
+    CS_HIP(ctx, hipMalloc((void **)p, n * sizeof(T)));
+    return CS_OK;
+}
+template <class T> static inline int cs_h2d(cs_ctx *ctx, T *d, const T *h, size_t n) {
+    if (n == 0) return CS_OK;
+    CS_HIP(ctx, hipMemcpyAsync(d, h, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream));
+    return CS_OK;
+}
+template <class T> static inline int cs_d2h(cs_ctx *ctx, T *h, const T *d, size_t n) {
+    if (n == 0) return CS_OK;
+    CS_HIP(ctx, hipMemcpyAsync(h, d, n * sizeof(T), hipMemcpyDeviceToHost, ctx->stream));
+    return CS_OK;
+}
+
+// ---- device helpers -------------------------------------------------------------------------------------------
+// 64-lane inclusive min-scan with DPP (row_shr 1/2/4/8 inside 16-lane rows, then row_bcast:15 / row_bcast:31).
+__device__ __forceinline__ int wave_incl_min_scan(int x) {
+    const int id = 0x7fffffff;
+    int t;
+    t = __builtin_amdgcn_update_dpp(id, x, 0x111, 0xf, 0xf, false); x = min(x, t); // row_shr:1
+    t = __builtin_amdgcn_update_dpp(id, x, 0x112, 0xf, 0xf, false); x = min(x, t); // row_shr:2
+    t = __builtin_amdgcn_update_dpp(id, x, 0x114, 0xf, 0xf, false); x = min(x, t); // row_shr:4
+    t = __builtin_amdgcn_update_dpp(id, x, 0x118, 0xf, 0xf, false); x = min(x, t); // row_shr:8
+    t = __builtin_amdgcn_update_dpp(id, x, 0x142, 0xa, 0xf, false); x = min(x, t); // row_bcast:15 -> rows 1,3
+    t = __builtin_amdgcn_update_dpp(id, x, 0x143, 0xc, 0xf, false); x = min(x, t); // row_bcast:31 -> rows 2,3
+    return x;
+}
+__device__ __forceinline__ int lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }

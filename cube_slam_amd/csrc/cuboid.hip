@@ -1,0 +1,1373 @@
+// cuboid.hip -- detect_3d_cuboid proposal sweep on MI355X (gfx950).
+//
+// Replaces detect_3d_cuboid::detect_cuboid (reference detect_3d_cuboid/src/box_proposal_detail.cpp:56-557) and its
+// callees in object_3d_util.cpp / matrix_utils.cpp.  Built with -ffp-contract=off: the reference is compiled
+// without FMA and int() truncation of samples lying exactly on integer box borders depends on it.
+//
+// Pipeline for a batch of frames (unit = (frame, box, height-sample)):
+//   cuboid_frame_prep   per frame : roll/pitch/yaw sample lists (linespace accumulation, matrix_utils.cpp:349-363),
+//                                   per-(roll,pitch) camera tables (set_cam_pose :42-54), align_left_right_edges
+//   cuboid_unit_lines   per unit  : lines inside ROI, merge_break_lines (object_3d_util.cpp:300-376), angles, midpoints
+//   cuboid_canny_nms    per pixel : Sobel + L1 magnitude + direction NMS (cv::Canny 80/200), LDS-tiled
+//   cuboid_canny_union/mark/resolve : hysteresis as union-find connected components (same result as the stack flood)
+//   cuboid_dt           per unit  : 3x3 chamfer distance transform, one wave per ROI, rows as DPP min-plus scans
+//   cuboid_vp           per (unit,roll,pitch,yaw): getVanishingPoints + VP_support_edge_infos (:380-425,:602-607)
+//   cuboid_sweep_score  per hypothesis: corner construction with all reject tests (:254-418) then, for the compacted
+//                                   valid ones, box_edge_sum_dists + box_edge_alignment_angle_error (:427-492)
+//   cuboid_select       per box   : fuse_normalize_scores_v2 (:495-565) by radix selection, 2D->3D
+//                                   (change_2d_corner_to_3d_object :610-648), final ranking (:517-536)
+#include "common.h"
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <vector>
+
+namespace {
+
+constexpr int ROLL_CAP = 8;
+constexpr int RP_CAP = ROLL_CAP * ROLL_CAP;
+constexpr int SWEEP_HB = 1024;  // hypotheses per sweep workgroup
+constexpr int NMS_TW = 64, NMS_TH = 16;
+constexpr int DT_INIT = INT_MAX >> 2;
+constexpr int DT_HV = 62587;    // cvRound(0.955f * 65536)
+constexpr int DT_DIAG = 89738;  // cvRound(1.3693f * 65536)  (checked against the float product on the host at create())
+constexpr double PI = 3.14159265358979323846;
+
+struct Calib { double K[9]; double invK[9]; };
+
+struct FrameInfo {   // host-filled
+    double euler[3]; // raw camera roll/pitch/yaw (quat_to_euler_zyx(Quaterniond(R)), computed with the host libm)
+    double T[16];
+    int line_off, n_lines;
+};
+struct FrameDyn {    // device-filled by cuboid_frame_prep
+    int n_roll, n_pitch, n_yaw, pad;
+    double roll[ROLL_CAP], pitch[ROLL_CAP];
+};
+struct CamRP { double T[16]; double KinvR[9]; double gps[4]; double roll, pitch; };
+
+struct Unit {        // host-filled plan of one (frame, box, height-sample)
+    int frame, box, hs, n_hs;
+    int left, top, right, width_raw, height_raw;
+    int down_expand, down_y_expan;
+    int n_tops, top_start, top_step;
+    int roi_x, roi_y, roi_w, roi_h, roi_r, roi_b;
+    int hyp_cap;
+    int vp_off;      // entries
+    int line_off;    // rows in merged-line storage
+    double diag;
+    long pix_off;
+    long hyp_off;
+};
+struct UnitDyn { int n_merged, n_valid, n_kept, branch_b; double pad; };
+
+struct Opts {
+    int cfg1, cfg2, sample_rp, max_cuboid_num;
+    double nominal_skew_ratio, max_cut_skew, yaw_range_deg, yaw_step_deg;
+    int canny_low, canny_high, yaw_cap, pad;
+};
+
+struct V2 { double x, y; };
+
+// ------------------------------------------------------------------------------------------------ small device math
+__device__ __forceinline__ double cof3(const double *a, int i, int j) {
+    int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+    return a[i1 * 3 + j1] * a[i2 * 3 + j2] - a[i1 * 3 + j2] * a[i2 * 3 + j1];
+}
+__host__ __device__ inline void inv3_cof(const double *a, double *r) { // Eigen fixed 3x3 inverse: cofactors * (1/det)
+    auto cf = [&](int i, int j) {
+        int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3;
+        return a[i1 * 3 + j1] * a[i2 * 3 + j2] - a[i1 * 3 + j2] * a[i2 * 3 + j1];
+    };
+    double c00 = cf(0, 0), c10 = cf(1, 0), c20 = cf(2, 0);
+    double det = (c00 * a[0] + c10 * a[3]) + c20 * a[6];
+    double invdet = 1.0 / det;
+    r[0] = c00 * invdet; r[1] = c10 * invdet; r[2] = c20 * invdet;
+    r[3] = cf(0, 1) * invdet; r[4] = cf(1, 1) * invdet; r[5] = cf(2, 1) * invdet;
+    r[6] = cf(0, 2) * invdet; r[7] = cf(1, 2) * invdet; r[8] = cf(2, 2) * invdet;
+}
+__device__ __forceinline__ double normalize_to_pi(double a) { // matrix_utils.cpp:326-335
+    if (a > PI / 2) return a - PI;
+    else if (a < -PI / 2) return a + PI;
+    else return a;
+}
+__device__ __forceinline__ double dist2(V2 a, V2 b) { double dx = a.x - b.x, dy = a.y - b.y; return sqrt(dx * dx + dy * dy); }
+__device__ __forceinline__ bool inside_box(V2 p, double l, double t, double r, double b) {
+    return l <= p.x && p.x <= r && t <= p.y && p.y <= b;
+}
+__device__ __forceinline__ V2 seg_hit_boundary(V2 ps, V2 pe, double bx0, double by0, double bx1, double by1) { // object_3d_util.cpp:194-230
+    V2 direc{pe.x - ps.x, pe.y - ps.y};
+    V2 hit{-1, -1};
+    if (by0 == by1) {
+        double lambd = (by0 - ps.y) / direc.y;
+        if (lambd >= 0) {
+            V2 t{ps.x + lambd * direc.x, ps.y + lambd * direc.y};
+            if ((bx0 <= t.x) && (t.x <= bx1)) { hit = t; hit.y = by0; }
+        }
+    }
+    if (bx0 == bx1) {
+        double lambd = (bx0 - ps.x) / direc.x;
+        if (lambd >= 0) {
+            V2 t{ps.x + lambd * direc.x, ps.y + lambd * direc.y};
+            if ((by0 <= t.y) && (t.y <= by1)) { hit = t; hit.x = bx0; }
+        }
+    }
+    return hit;
+}
+__device__ __forceinline__ V2 line_intersect_inf(V2 p1s, V2 p1e, V2 p2s, V2 p2e) { // :233-252, infinite_line=true
+    double X2_X1 = p1e.x - p1s.x, Y2_Y1 = p1e.y - p1s.y;
+    double X4_X3 = p2e.x - p2s.x, Y4_Y3 = p2e.y - p2s.y;
+    double X1_X3 = p1s.x - p2s.x, Y1_Y3 = p1s.y - p2s.y;
+    double u_a = (X4_X3 * Y1_Y3 - Y4_Y3 * X1_X3) / (Y4_Y3 * X2_X1 - X4_X3 * Y2_Y1);
+    double INT_X = p1s.x + X2_X1 * u_a;
+    double INT_Y = p1s.y + Y2_Y1 * u_a;
+    return V2{INT_X * 1.0, INT_Y * 1.0};
+}
+
+// ------------------------------------------------------------------------------------------------ frame prep
+__device__ inline int linespace_dev(double starting, double ending, double step, double *res, int cap) { // matrix_utils.cpp:349-363
+    int n = 0;
+    while (starting <= ending) {
+        if (n < cap) res[n] = starting;
+        n++;
+        starting += step;
+        if (n > 1000) break;
+    }
+    return n < cap ? n : cap;
+}
+
+__global__ void __launch_bounds__(64) cuboid_frame_prep(const FrameInfo *fi, FrameDyn *fd, CamRP *cam, double *yaw, Calib cal, Opts o,
+                                                        const double *lines_in, double *lines_al) {
+    const int f = blockIdx.x, tid = threadIdx.x;
+    const FrameInfo &F = fi[f];
+    FrameDyn &D = fd[f];
+    if (tid == 0) {
+        if (o.sample_rp) { // box_proposal_detail.cpp:217-221
+            D.n_roll = linespace_dev(F.euler[0] - 6.0 / 180.0 * PI, F.euler[0] + 6.0 / 180.0 * PI, 3.0 / 180.0 * PI, D.roll, ROLL_CAP);
+            D.n_pitch = linespace_dev(F.euler[1] - 6.0 / 180.0 * PI, F.euler[1] + 6.0 / 180.0 * PI, 3.0 / 180.0 * PI, D.pitch, ROLL_CAP);
+        } else {
+            D.n_roll = 1; D.n_pitch = 1; D.roll[0] = F.euler[0]; D.pitch[0] = F.euler[1];
+        }
+        double yaw_init = F.euler[2] - 90.0 / 180.0 * PI; // :126 (pinned to the raw pose for every box)
+        D.n_yaw = linespace_dev(yaw_init - o.yaw_range_deg / 180.0 * PI, yaw_init + o.yaw_range_deg / 180.0 * PI,
+                                o.yaw_step_deg / 180.0 * PI, yaw + (long)f * o.yaw_cap, o.yaw_cap);
+    }
+    __syncthreads();
+    if (tid < D.n_roll * D.n_pitch) {
+        CamRP &C = cam[(long)f * RP_CAP + tid];
+        int ri = tid / D.n_pitch, pi = tid % D.n_pitch;
+        double R[9];
+        if (o.sample_rp) { // euler_zyx_to_rot matrix_utils.cpp:74-89
+            double roll = D.roll[ri], pitch = D.pitch[pi], yw = F.euler[2];
+            double cp = cos(pitch), sp = sin(pitch), sr = sin(roll), cr = cos(roll), sy = sin(yw), cy = cos(yw);
+            R[0] = cp * cy; R[1] = (sr * sp * cy) - (cr * sy); R[2] = (cr * sp * cy) + (sr * sy);
+            R[3] = cp * sy; R[4] = (sr * sp * sy) + (cr * cy); R[5] = (cr * sp * sy) - (sr * cy);
+            R[6] = -sp;     R[7] = sr * cp;                    R[8] = cr * cp;
+        } else
+            for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) R[i * 3 + j] = F.T[i * 4 + j];
+        for (int i = 0; i < 16; i++) C.T[i] = F.T[i];
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) C.T[i * 4 + j] = R[i * 3 + j];
+        double invR[9];
+        inv3_cof(R, invR);
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) {
+                double s = cal.K[i * 3 + 0] * invR[0 * 3 + j];
+                s = s + cal.K[i * 3 + 1] * invR[1 * 3 + j];
+                s = s + cal.K[i * 3 + 2] * invR[2 * 3 + j];
+                C.KinvR[i * 3 + j] = s;
+            }
+        for (int i = 0; i < 4; i++) { // transToWolrd^T * (0,0,1,0), :99-100
+            double s = C.T[0 * 4 + i] * 0.0;
+            s = s + C.T[1 * 4 + i] * 0.0;
+            s = s + C.T[2 * 4 + i] * 1.0;
+            s = s + C.T[3 * 4 + i] * 0.0;
+            C.gps[i] = s;
+        }
+        C.roll = D.roll[ri]; C.pitch = D.pitch[pi];
+    }
+    for (int i = tid; i < F.n_lines; i += 64) { // align_left_right_edges object_3d_util.cpp:147-158
+        const double *s = lines_in + (long)(F.line_off + i) * 4;
+        double *d = lines_al + (long)(F.line_off + i) * 4;
+        if (s[2] < s[0]) { d[0] = s[2]; d[1] = s[3]; d[2] = s[0]; d[3] = s[1]; }
+        else { d[0] = s[0]; d[1] = s[1]; d[2] = s[2]; d[3] = s[3]; }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ lines per unit
+// One wave per unit.  merge_break_lines is order dependent (restart after every merge, removed row replaced by the
+// last one), so each round finds the FIRST (seg1,seg2) in row-major order that merges: lane = seg1, serial seg2.
+__global__ void __launch_bounds__(64) cuboid_unit_lines(const Unit *units, UnitDyn *ud, const FrameInfo *fi, const double *lines_al,
+                                                        double *mlines, double *mangle, double *mmid, int *status) {
+    __shared__ double L[CS_MAX_ROI_LINES][4];
+    __shared__ double ang[CS_MAX_ROI_LINES];
+    __shared__ int s_total;
+    const int u = blockIdx.x, lane = threadIdx.x;
+    const Unit &U = units[u];
+    const FrameInfo &F = fi[U.frame];
+    const double l = U.roi_x, t = U.roi_y, r = U.roi_r, b = U.roi_b;
+    int total = 0;
+    for (int base = 0; base < F.n_lines; base += 64) { // ordered compaction of the lines inside the expanded box (:166-174)
+        int i = base + lane;
+        bool in = false;
+        double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        if (i < F.n_lines) {
+            const double *s = lines_al + (long)(F.line_off + i) * 4;
+            a0 = s[0]; a1 = s[1]; a2 = s[2]; a3 = s[3];
+            in = inside_box(V2{a0, a1}, l, t, r, b) && inside_box(V2{a2, a3}, l, t, r, b);
+        }
+        unsigned long long m = __ballot(in);
+        int pos = total + __popcll(m & ((1ull << lane) - 1));
+        if (in && pos < CS_MAX_ROI_LINES) { L[pos][0] = a0; L[pos][1] = a1; L[pos][2] = a2; L[pos][3] = a3; }
+        total += __popcll(m);
+    }
+    if (total > CS_MAX_ROI_LINES) { if (lane == 0) atomicMin(status, CS_ERR_CAPACITY); total = CS_MAX_ROI_LINES; }
+    __syncthreads();
+    const double angle_thre = 5.0 / 180.0 * PI, dist_thre = 20.0, len_thre = 30.0; // :177-179
+    bool can = true;
+    int counter = 0;
+    while (can && counter < 500) {
+        counter++;
+        can = false;
+        for (int i = lane; i < total; i += 64) ang[i] = atan2(L[i][3] - L[i][1], L[i][2] - L[i][0]);
+        __syncthreads();
+        int hit1 = -1, hit2 = -1;
+        for (int base = 0; base < total - 1; base += 64) {
+            int s1 = base + lane, f2 = -1;
+            if (s1 < total - 1) {
+                double a1 = ang[s1];
+                double x10 = L[s1][0], y10 = L[s1][1], x11 = L[s1][2], y11 = L[s1][3];
+                for (int s2 = s1 + 1; s2 < total; s2++) {
+                    double diff = fabs(a1 - ang[s2]);
+                    double angle_diff = fmin(diff, PI - diff);
+                    if (angle_diff < angle_thre) {
+                        double x20 = L[s2][0], y20 = L[s2][1], x21 = L[s2][2], y21 = L[s2][3];
+                        double d12 = dist2(V2{x11, y11}, V2{x20, y20});
+                        double d21 = dist2(V2{x21, y21}, V2{x10, y10});
+                        if ((d12 < dist_thre) || (d21 < dist_thre)) {
+                            V2 ms = (x10 < x20) ? V2{x10, y10} : V2{x20, y20};
+                            V2 me = (x11 > x21) ? V2{x11, y11} : V2{x21, y21};
+                            double merged_angle = atan2(me.y - ms.y, me.x - ms.x);
+                            double temp = fabs(a1 - merged_angle);
+                            double mad = fmin(temp, PI - temp);
+                            if (mad < angle_thre) { f2 = s2; break; }
+                        }
+                    }
+                }
+            }
+            unsigned long long m = __ballot(f2 >= 0);
+            if (m) {
+                int first = __ffsll((long long)m) - 1;
+                hit1 = base + first;
+                hit2 = __shfl(f2, first);
+                break;
+            }
+        }
+        if (hit1 >= 0) {
+            if (lane == 0) {
+                int s1 = hit1, s2 = hit2;
+                V2 ms = (L[s1][0] < L[s2][0]) ? V2{L[s1][0], L[s1][1]} : V2{L[s2][0], L[s2][1]};
+                V2 me = (L[s1][2] > L[s2][2]) ? V2{L[s1][2], L[s1][3]} : V2{L[s2][2], L[s2][3]};
+                L[s1][0] = ms.x; L[s1][1] = ms.y; L[s1][2] = me.x; L[s1][3] = me.y;
+                for (int k = 0; k < 4; k++) L[s2][k] = L[total - 1][k]; // fast_RemoveRow matrix_utils.cpp:172-176
+            }
+            total--;
+            can = true;
+        }
+        __syncthreads();
+    }
+    // drop short lines (:358-373), then angles and midpoints (box_proposal_detail.cpp:185-191)
+    int nout = 0;
+    for (int base = 0; base < total; base += 64) {
+        int i = base + lane;
+        bool keep = false;
+        double a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+        if (i < total) {
+            a0 = L[i][0]; a1 = L[i][1]; a2 = L[i][2]; a3 = L[i][3];
+            double dx = a2 - a0, dy = a3 - a1;
+            keep = sqrt(dx * dx + dy * dy) > len_thre;
+        }
+        unsigned long long m = __ballot(keep);
+        int pos = nout + __popcll(m & ((1ull << lane) - 1));
+        if (keep) {
+            long o = (long)U.line_off + pos;
+            mlines[o * 4 + 0] = a0; mlines[o * 4 + 1] = a1; mlines[o * 4 + 2] = a2; mlines[o * 4 + 3] = a3;
+            mangle[o] = atan2(a3 - a1, a2 - a0);
+            mmid[o * 2 + 0] = (a0 + a2) / 2;
+            mmid[o * 2 + 1] = (a1 + a3) / 2;
+        }
+        nout += __popcll(m);
+    }
+    if (lane == 0) ud[u].n_merged = nout;
+}
+
+// ------------------------------------------------------------------------------------------------ Canny
+// NMS codes in emap: 0 none, 1 weak candidate (mag > low, local max), 2 strong candidate (mag > high).
+__global__ void __launch_bounds__(256) cuboid_canny_nms(const Unit *units, const uint8_t *gray, int W, int H, uint8_t *emap, int *lab,
+                                                        int low, int high) {
+    const Unit &U = units[blockIdx.y];
+    const int tiles_x = (U.roi_w + NMS_TW - 1) / NMS_TW, tiles_y = (U.roi_h + NMS_TH - 1) / NMS_TH;
+    if ((int)blockIdx.x >= tiles_x * tiles_y) return;
+    const int tx0 = (blockIdx.x % tiles_x) * NMS_TW, ty0 = (blockIdx.x / tiles_x) * NMS_TH;
+    __shared__ uint8_t g[NMS_TH + 4][NMS_TW + 4];
+    __shared__ short mg[NMS_TH + 2][NMS_TW + 2];
+    const uint8_t *img = gray + (long)U.frame * W * H;
+    const int tid = threadIdx.x;
+    for (int i = tid; i < (NMS_TH + 4) * (NMS_TW + 4); i += 256) {
+        int ly = i / (NMS_TW + 4), lx = i % (NMS_TW + 4);
+        int X = U.roi_x + tx0 + lx - 2, Y = U.roi_y + ty0 + ly - 2;
+        X = X < 0 ? 0 : (X >= W ? W - 1 : X); // BORDER_REPLICATE at the image border; real pixels outside the ROI view
+        Y = Y < 0 ? 0 : (Y >= H ? H - 1 : Y);
+        g[ly][lx] = img[(long)Y * W + X];
+    }
+    __syncthreads();
+    for (int i = tid; i < (NMS_TH + 2) * (NMS_TW + 2); i += 256) {
+        int ly = i / (NMS_TW + 2), lx = i % (NMS_TW + 2);
+        int x = tx0 + lx - 1, y = ty0 + ly - 1; // ROI coordinates
+        int m = 0;
+        if (x >= 0 && x < U.roi_w && y >= 0 && y < U.roi_h) {
+            int gy = ly + 1, gx = lx + 1;
+            int dx = (g[gy - 1][gx + 1] + 2 * g[gy][gx + 1] + g[gy + 1][gx + 1]) - (g[gy - 1][gx - 1] + 2 * g[gy][gx - 1] + g[gy + 1][gx - 1]);
+            int dy = (g[gy + 1][gx - 1] + 2 * g[gy + 1][gx] + g[gy + 1][gx + 1]) - (g[gy - 1][gx - 1] + 2 * g[gy - 1][gx] + g[gy - 1][gx + 1]);
+            m = abs(dx) + abs(dy);
+        }
+        mg[ly][lx] = (short)m;
+    }
+    __syncthreads();
+    const int lx = tid & 63;
+    for (int ly = tid >> 6; ly < NMS_TH; ly += 4) {
+        int x = tx0 + lx, y = ty0 + ly;
+        if (x >= U.roi_w || y >= U.roi_h) continue;
+        int gy = ly + 2, gx = lx + 2, my = ly + 1, mx = lx + 1;
+        int m = mg[my][mx];
+        uint8_t code = 0;
+        if (m > low) {
+            int xs = (g[gy - 1][gx + 1] + 2 * g[gy][gx + 1] + g[gy + 1][gx + 1]) - (g[gy - 1][gx - 1] + 2 * g[gy][gx - 1] + g[gy + 1][gx - 1]);
+            int ys = (g[gy + 1][gx - 1] + 2 * g[gy + 1][gx] + g[gy + 1][gx + 1]) - (g[gy - 1][gx - 1] + 2 * g[gy - 1][gx] + g[gy - 1][gx + 1]);
+            const int TG22 = 13573; // (int)(0.41421356237309504 * (1<<15) + 0.5)
+            int ax = abs(xs), ay = abs(ys) << 15;
+            int tg22x = ax * TG22;
+            bool keep;
+            if (ay < tg22x) keep = m > mg[my][mx - 1] && m >= mg[my][mx + 1];
+            else {
+                int tg67x = tg22x + (ax << 16);
+                if (ay > tg67x) keep = m > mg[my - 1][mx] && m >= mg[my + 1][mx];
+                else {
+                    int s = (xs ^ ys) < 0 ? -1 : 1;
+                    keep = m > mg[my - 1][mx - s] && m > mg[my + 1][mx + s];
+                }
+            }
+            if (keep) code = m > high ? 2 : 1;
+        }
+        long p = (long)y * U.roi_w + x;
+        emap[U.pix_off + p] = code;
+        if (code) lab[U.pix_off + p] = (int)p;
+    }
+}
+
+__device__ __forceinline__ int lab_load(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ int uf_find(const int *lab, int x) {
+    while (true) {
+        int v = lab_load(lab + x);
+        if (v < 0 || v == x) return x;
+        x = v;
+    }
+}
+__device__ inline void uf_union(int *lab, int a, int b) {
+    while (true) {
+        a = uf_find(lab, a);
+        b = uf_find(lab, b);
+        if (a == b) return;
+        if (a < b) { int t = a; a = b; b = t; } // a > b: hook a under b
+        int old = atomicMin(lab + a, b);
+        if (old == a) return;
+        a = old; // a was no longer a root: keep uniting (old, b)
+    }
+}
+
+// stage 0: union with W / NW / N / NE candidate neighbours; stage 1: strong pixels mark their root (negative label);
+// stage 2: candidates become 255 iff their root is marked.  Kernel boundaries are the global syncs.
+__global__ void __launch_bounds__(256) cuboid_canny_cc(const Unit *units, uint8_t *emap, int *lab, int stage) {
+    const Unit &U = units[blockIdx.y];
+    const long A = (long)U.roi_w * U.roi_h;
+    uint8_t *em = emap + U.pix_off;
+    int *lb = lab + U.pix_off;
+    for (int k = 0; k < 4; k++) {
+        long p = (long)blockIdx.x * 1024 + k * 256 + threadIdx.x;
+        if (p >= A) return;
+        uint8_t c = em[p];
+        if (!c) continue;
+        if (stage == 0) {
+            int x = (int)(p % U.roi_w), y = (int)(p / U.roi_w);
+            if (x > 0 && em[p - 1]) uf_union(lb, (int)p, (int)p - 1);
+            if (y > 0) {
+                long q = p - U.roi_w;
+                if (x > 0 && em[q - 1]) uf_union(lb, (int)p, (int)q - 1);
+                if (em[q]) uf_union(lb, (int)p, (int)q);
+                if (x + 1 < U.roi_w && em[q + 1]) uf_union(lb, (int)p, (int)q + 1);
+            }
+        } else if (stage == 1) {
+            if (c == 2) { int r = uf_find(lb, (int)p); __hip_atomic_store(lb + r, -1 - r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        } else {
+            int r = uf_find(lb, (int)p);
+            em[p] = lab_load(lb + r) < 0 ? 255 : 0;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ distance transform
+// cv::distanceTransform(255 - canny, CV_DIST_L2, 3) == distanceTransform_3x3: forward/backward raster passes of
+//   t[j] = min(c[j], t[j-1] + HV)  ==  j*HV + prefix_min(c[k] - k*HV)   (integers, so any evaluation order is exact)
+// One wave per ROI; rows sequential, columns in 64-wide segments scanned with DPP.  The int map of the forward pass
+// and the final float map share the `dist` arena (in place).
+__global__ void __launch_bounds__(256) cuboid_dt(const Unit *units, int n_units, const uint8_t *emap, float *dist, int wbuf) {
+    extern __shared__ int s_rows[];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int u = blockIdx.x * 4 + wave;
+    if (u >= n_units) return;
+    const Unit &U = units[u];
+    const int w = U.roi_w, h = U.roi_h;
+    int *bufA = s_rows + (long)wave * 2 * wbuf, *bufB = bufA + wbuf; // index j+1; [0] and [w+1] are the INIT border columns
+    const uint8_t *em = emap + U.pix_off;
+    int *tmp = (int *)(dist + U.pix_off);
+    float *out = dist + U.pix_off;
+    for (int j = lane; j < w + 2; j += 64) { bufA[j] = DT_INIT; bufB[j] = DT_INIT; }
+    __builtin_amdgcn_wave_barrier();
+    int *up = bufA, *cur = bufB;
+    for (int i = 0; i < h; i++) {
+        int carry = DT_INIT + DT_HV; // tmp[-1] - (-1)*HV
+        for (int j0 = 0; j0 < w; j0 += 64) {
+            int j = j0 + lane;
+            int uval = INT_MAX;
+            if (j < w) {
+                int c = 0;
+                if (em[(long)i * w + j] == 0) { // not an edge pixel -> src != 0
+                    c = up[j] + DT_DIAG;
+                    int t = up[j + 1] + DT_HV; if (c > t) c = t;
+                    t = up[j + 2] + DT_DIAG; if (c > t) c = t;
+                }
+                uval = c - j * DT_HV;
+            }
+            int s = wave_incl_min_scan(uval);
+            int v = min(s, carry);
+            carry = __builtin_amdgcn_readlane(v, 63);
+            if (j < w) { int t = v + j * DT_HV; cur[j + 1] = t; tmp[(long)i * w + j] = t; }
+        }
+        __builtin_amdgcn_wave_barrier();
+        int *sw = up; up = cur; cur = sw;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+    for (int j = lane; j < w + 2; j += 64) { bufA[j] = DT_INIT; bufB[j] = DT_INIT; }
+    __builtin_amdgcn_wave_barrier();
+    int *down = bufA; cur = bufB;
+    const float scale = 1.f / 65536.f;
+    const int nseg = (w + 63) / 64;
+    for (int i = h - 1; i >= 0; i--) {
+        int carry = DT_INIT + w * DT_HV; // tmp[w] + w*HV
+        for (int sg = nseg - 1; sg >= 0; sg--) {
+            int j = sg * 64 + (63 - lane); // descending j along the lanes: suffix scan == prefix scan
+            int uval = INT_MAX;
+            if (j < w) {
+                int c = tmp[(long)i * w + j];
+                int t = down[j + 2] + DT_DIAG; if (c > t) c = t;
+                t = down[j + 1] + DT_HV; if (c > t) c = t;
+                t = down[j] + DT_DIAG; if (c > t) c = t;
+                uval = c + j * DT_HV;
+            }
+            int s = wave_incl_min_scan(uval);
+            int v = min(s, carry);
+            carry = __builtin_amdgcn_readlane(v, 63);
+            if (j < w) { int t = v - j * DT_HV; cur[j + 1] = t; out[(long)i * w + j] = (float)t * scale; }
+        }
+        __builtin_amdgcn_wave_barrier();
+        int *sw = down; down = cur; cur = sw;
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ vanishing points
+struct VPEntry { double vp[6]; double ang[6]; }; // vp1.x vp1.y vp2.x ... ; per VP two boundary-edge angles (NaN = none)
+
+__global__ void __launch_bounds__(256) cuboid_vp(const Unit *units, const UnitDyn *ud, const FrameDyn *fd, const CamRP *cam, const double *yaw,
+                                                 Opts o, const double *mangle, const double *mmid, VPEntry *vpt) {
+    const Unit &U = units[blockIdx.y];
+    const FrameDyn &D = fd[U.frame];
+    const int n_rp = D.n_roll * D.n_pitch;
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= n_rp * D.n_yaw) return;
+    const int rp = e / D.n_yaw, yi = e % D.n_yaw;
+    const CamRP &C = cam[(long)U.frame * RP_CAP + rp];
+    const double y = yaw[(long)U.frame * o.yaw_cap + yi];
+    const double cy = cos(y), sy = sin(y);
+    VPEntry E;
+    { // getVanishingPoints object_3d_util.cpp:602-607
+        const double d[3][3] = {{cy, sy, 0}, {-sy, cy, 0}, {0, 0, 1}};
+        for (int k = 0; k < 3; k++) {
+            double r[3];
+            for (int i = 0; i < 3; i++) {
+                double s = C.KinvR[i * 3 + 0] * d[k][0];
+                s = s + C.KinvR[i * 3 + 1] * d[k][1];
+                s = s + C.KinvR[i * 3 + 2] * d[k][2];
+                r[i] = s;
+            }
+            E.vp[k * 2 + 0] = r[0] / r[2];
+            E.vp[k * 2 + 1] = r[1] / r[2];
+        }
+    }
+    const int n = ud[blockIdx.y].n_merged;
+    const double *ang = mangle + U.line_off, *mid = mmid + (long)U.line_off * 2;
+    for (int vp = 0; vp < 3; vp++) { // VP_support_edge_infos :380-425
+        double thre = (vp != 2 ? 15.0 : 10.0) / 180.0 * PI; // box_proposal_detail.cpp:79-80
+        double vx = E.vp[vp * 2], vy = E.vp[vp * 2 + 1];
+        int cnt = 0, lo = -1, hi = -1;
+        double base = 0, vlo = 0, vhi = 0;
+        for (int k = 0; k < n; k++) {
+            double a_raw = atan2(mid[k * 2 + 1] - vy, mid[k * 2] - vx);
+            double a_norm = normalize_to_pi(a_raw);
+            double dd = fabs(ang[k] - a_norm);
+            dd = fmin(dd, PI - dd);
+            if (dd < thre) {
+                if (cnt == 0) base = a_raw;
+                double sh = a_raw; // smooth_jump_angles :175-189
+                if ((a_raw - base) < -PI) sh = a_raw + 2 * PI;
+                else if ((a_raw - base) > PI) sh = a_raw - 2 * PI;
+                if (cnt == 0) { lo = hi = k; vlo = vhi = sh; }
+                else { if (sh > vlo) { vlo = sh; lo = k; } if (sh < vhi) { vhi = sh; hi = k; } }
+                cnt++;
+            }
+        }
+        if (cnt > 0) {
+            int low_id = lo, top_id = hi;
+            if (vp > 0) { int t = low_id; low_id = top_id; top_id = t; }
+            E.ang[vp * 2] = ang[low_id];
+            E.ang[vp * 2 + 1] = ang[top_id];
+        } else {
+            E.ang[vp * 2] = __longlong_as_double(0x7ff8000000000000ll);
+            E.ang[vp * 2 + 1] = __longlong_as_double(0x7ff8000000000000ll);
+        }
+    }
+    vpt[(long)U.vp_off + e] = E;
+}
+
+// ------------------------------------------------------------------------------------------------ sweep + score
+__constant__ int c_vis1[9][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 0}, {1, 5}, {2, 4}, {3, 7}, {4, 7}, {4, 5}}; // box_proposal_detail.cpp:432
+__constant__ int c_vis2[7][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 0}, {1, 5}, {2, 4}, {4, 5}};                 // :442
+__constant__ int c_vpe1[3][4] = {{0, 1, 7, 4}, {3, 0, 4, 5}, {3, 7, 1, 5}};                               // :434
+__constant__ int c_vpe2[3][4] = {{0, 1, 2, 3}, {3, 0, 4, 5}, {2, 4, 1, 5}};                               // :444
+
+// corner construction with every reject test of box_proposal_detail.cpp:254-418; returns vp_1_position (0 = rejected)
+__device__ inline int make_corners(const Unit &U, const VPEntry &E, int top_x, int cfg, V2 c[8]) {
+    const double shorted_edge_thre = 20; // :81
+    const V2 vp_1{E.vp[0], E.vp[1]}, vp_2{E.vp[2], E.vp[3]}, vp_3{E.vp[4], E.vp[5]};
+    const double left = U.left, right = U.right, top = U.top, down = U.down_y_expan;
+    V2 c1{(double)top_x, top};
+    int vp_1_position = 0;
+    V2 c2 = seg_hit_boundary(vp_1, c1, right, top, right, down);
+    if (c2.x == -1) {
+        c2 = seg_hit_boundary(vp_1, c1, left, top, left, down);
+        if (c2.x != -1) vp_1_position = 2;
+    } else
+        vp_1_position = 1;
+    if (!(vp_1_position > 0)) return 0;
+    if (dist2(c1, c2) < shorted_edge_thre) return 0;
+    V2 c3, c4;
+    if (cfg == 1) {
+        if (vp_1_position == 1) c4 = seg_hit_boundary(vp_2, c1, left, top, left, down);
+        else c4 = seg_hit_boundary(vp_2, c1, right, top, right, down);
+        if (c4.y == -1) return 0;
+        if (dist2(c1, c4) < shorted_edge_thre) return 0;
+        c3 = line_intersect_inf(vp_2, c2, vp_1, c4);
+        if (!inside_box(c3, left, top, right, down)) return 0;
+        if ((dist2(c3, c4) < shorted_edge_thre) || (dist2(c3, c2) < shorted_edge_thre)) return 0;
+    } else {
+        if (vp_1_position == 1) c3 = seg_hit_boundary(vp_2, c2, left, top, left, down);
+        else c3 = seg_hit_boundary(vp_2, c2, right, top, right, down);
+        if (c3.y == -1) return 0;
+        if (dist2(c2, c3) < shorted_edge_thre) return 0;
+        c4 = line_intersect_inf(vp_1, c3, vp_2, c1);
+        if (!inside_box(c4, left, (double)U.roi_y, right, (double)U.roi_b)) return 0; // :347 uses the expanded y-range
+        if ((dist2(c3, c4) < shorted_edge_thre) || (dist2(c4, c1) < shorted_edge_thre)) return 0;
+    }
+    const double el = U.roi_x, et = U.roi_y, er = U.roi_r, eb = U.roi_b;
+    V2 c5 = seg_hit_boundary(vp_3, c3, left, down, right, down);
+    if (c5.y == -1) return 0;
+    if (dist2(c3, c5) < shorted_edge_thre) return 0;
+    V2 c6 = line_intersect_inf(vp_2, c5, vp_3, c2);
+    if (!inside_box(c6, el, et, er, eb)) return 0;
+    if ((dist2(c6, c2) < shorted_edge_thre) || (dist2(c6, c5) < shorted_edge_thre)) return 0;
+    V2 c7 = line_intersect_inf(vp_1, c6, vp_3, c1);
+    if (!inside_box(c7, el, et, er, eb)) return 0;
+    if ((dist2(c7, c1) < shorted_edge_thre) || (dist2(c7, c6) < shorted_edge_thre)) return 0;
+    V2 c8 = line_intersect_inf(vp_1, c5, vp_2, c7);
+    if (!inside_box(c8, el, et, er, eb)) return 0;
+    if ((dist2(c8, c4) < shorted_edge_thre) || (dist2(c8, c5) < shorted_edge_thre) || (dist2(c8, c7) < shorted_edge_thre)) return 0;
+    c[0] = c1; c[1] = c2; c[2] = c3; c[3] = c4; c[4] = c5; c[5] = c6; c[6] = c7; c[7] = c8;
+    return vp_1_position;
+}
+
+// box_edge_sum_dists object_3d_util.cpp:427-453: float accumulation in edge/sample order; dist_map.at<float>(int(y),int(x))
+// has no bounds check and corners may sit on x==w or y==h: flat index clamped to the buffer.
+__device__ inline double edge_sum_dists(const float *dm, int w, int h, const double *cx, const double *cy, int cfg) {
+    const int ne = cfg == 1 ? 9 : 7;
+    const bool reweight = cfg != 1;
+    float sum_dist = 0;
+    const long last = (long)w * h - 1;
+    for (int e = 0; e < ne; e++) {
+        int ia = cfg == 1 ? c_vis1[e][0] : c_vis2[e][0], ib = cfg == 1 ? c_vis1[e][1] : c_vis2[e][1];
+        double x1 = cx[ia], y1 = cy[ia], x2 = cx[ib], y2 = cy[ib];
+#pragma unroll
+        for (int si = 0; si < 11; si++) {
+            const double s = (double)si;
+            double px = s / 10.0 * x1 + (1 - s / 10.0) * x2;
+            double py = s / 10.0 * y1 + (1 - s / 10.0) * y2;
+            long idx = (long)int(py) * w + int(px);
+            idx = idx < 0 ? 0 : (idx > last ? last : idx);
+            float dist1 = dm[idx];
+            if (reweight) {
+                if ((4 <= e) && (e <= 5)) dist1 = dist1 * 3.0 / 2.0;
+                if (6 == e) dist1 = dist1 * 2.0;
+            }
+            sum_dist = sum_dist + dist1;
+        }
+    }
+    return double(sum_dist);
+}
+// box_edge_alignment_angle_error :455-492
+__device__ inline double edge_angle_error(const VPEntry &E, const double *cx, const double *cy, int cfg) {
+    double total = 0;
+    const double not_found_penalty = 30.0 / 180.0 * PI * 2;
+    for (int vp = 0; vp < 3; vp++) {
+        double valid[2];
+        int nv = 0;
+        for (int i = 0; i < 2; i++) if (!isnan(E.ang[vp * 2 + i])) valid[nv++] = E.ang[vp * 2 + i];
+        if (nv > 0) {
+            for (int ee = 0; ee < 2; ee++) {
+                int a = cfg == 1 ? c_vpe1[vp][2 * ee] : c_vpe2[vp][2 * ee], b = cfg == 1 ? c_vpe1[vp][2 * ee + 1] : c_vpe2[vp][2 * ee + 1];
+                double ang = normalize_to_pi(atan2(cy[b] - cy[a], cx[b] - cx[a]));
+                double best = 100;
+                for (int i = 0; i < nv; i++) {
+                    double t = fabs(ang - valid[i]);
+                    t = fmin(t, PI - t);
+                    if (t < best) best = t;
+                }
+                total = total + best;
+            }
+        } else
+            total = total + not_found_penalty;
+    }
+    return total;
+}
+
+// hypothesis index h = ((rp*n_yaw + yaw)*n_tops + top)*2 + (cfg-1)   (the reference's loop nest :229-285)
+// SoA outputs over the global hypothesis index g = hyp_off + h:
+//   flag[g] u8: 0 rejected, 1/2 = vp_1_position; derr[g], aerr[g]; corners[p*hyp_total + g], p = 0..15 (x0..x7,y0..y7)
+// Grid is 1-D and XCD-aware: workgroup b runs on XCD b%8 (observed dispatch rule), so all workgroups of one unit are
+// given the same b%8 and the unit's distance map is fetched into a single XCD's L2.
+__global__ void __launch_bounds__(256) cuboid_sweep_score(const Unit *units, int n_units, int blocks_per_unit, const FrameDyn *fd,
+                                                          const double *yaw, Opts o, const VPEntry *vpt, const float *dist, uint8_t *flag,
+                                                          double *derr, double *aerr, double *corners, long hyp_total) {
+    __shared__ int s_list[SWEEP_HB];
+    __shared__ int s_count;
+    const int b = blockIdx.x;
+    const int xcd = b & 7, slot = b >> 3;
+    const int u = (slot / blocks_per_unit) * 8 + xcd, blk = slot % blocks_per_unit;
+    if (u >= n_units) return;
+    const Unit &U = units[u];
+    const FrameDyn &D = fd[U.frame];
+    const int n_yaw = D.n_yaw, n_rp = D.n_roll * D.n_pitch;
+    const int n_hyp = n_rp * n_yaw * U.n_tops * 2;
+    const int h0 = blk * SWEEP_HB;
+    if (h0 >= U.hyp_cap) return;
+    if (threadIdx.x == 0) s_count = 0;
+    __syncthreads();
+    for (int r = 0; r < SWEEP_HB / 256; r++) {
+        int h = h0 + r * 256 + threadIdx.x;
+        if (h >= U.hyp_cap) break;
+        long g = U.hyp_off + h;
+        int pos = 0;
+        if (h < n_hyp) {
+            int cfg = (h & 1) + 1, q = h >> 1;
+            int ti = q % U.n_tops; q /= U.n_tops;
+            if ((cfg == 1 && o.cfg1) || (cfg == 2 && o.cfg2)) {
+                const VPEntry &E = vpt[(long)U.vp_off + q];
+                V2 c[8];
+                pos = make_corners(U, E, U.top_start + ti * U.top_step, cfg, c);
+                if (pos) {
+#pragma unroll
+                    for (int k = 0; k < 8; k++) { corners[(long)k * hyp_total + g] = c[k].x; corners[(long)(8 + k) * hyp_total + g] = c[k].y; }
+                    s_list[atomicAdd(&s_count, 1)] = h;
+                }
+            }
+        }
+        flag[g] = (uint8_t)pos;
+    }
+    __threadfence_block();
+    __syncthreads();
+    const int cnt = s_count;
+    const float *dm = dist + U.pix_off;
+    for (int s = threadIdx.x; s < cnt; s += 256) {
+        int h = s_list[s];
+        long g = U.hyp_off + h;
+        int cfg = (h & 1) + 1, q = (h >> 1) / U.n_tops;
+        double cx[8], cy[8], sx[8], sy[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            cx[k] = corners[(long)k * hyp_total + g]; cy[k] = corners[(long)(8 + k) * hyp_total + g];
+            sx[k] = cx[k] - U.roi_x; sy[k] = cy[k] - U.roi_y; // :423-425
+        }
+        double sum_dist = edge_sum_dists(dm, U.roi_w, U.roi_h, sx, sy, cfg);
+        derr[g] = sum_dist / U.diag; // :451
+        aerr[g] = edge_angle_error(vpt[(long)U.vp_off + q], cx, cy, cfg);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ selection
+__device__ __forceinline__ unsigned long long dkey(double x) { // order-preserving map double -> u64
+    unsigned long long b = (unsigned long long)__double_as_longlong(x);
+    return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
+}
+// k-th smallest (0-based) key among hypotheses with flag != 0; 8-bit MSB-first radix select.  All threads return it.
+__device__ unsigned long long block_select_kth(const double *vals, const uint8_t *flag, int n, int k, int *hist /*256*/, int *s_misc) {
+    unsigned long long prefix = 0, mask = 0;
+    for (int pass = 0; pass < 8; pass++) {
+        int shift = 56 - 8 * pass;
+        for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
+        __syncthreads();
+        for (int i = threadIdx.x; i < n; i += blockDim.x)
+            if (flag[i]) {
+                unsigned long long key = dkey(vals[i]);
+                if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1);
+            }
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            int acc = 0, bin = 0;
+            for (; bin < 256; bin++) { if (acc + hist[bin] > k) break; acc += hist[bin]; }
+            s_misc[0] = bin; s_misc[1] = k - acc;
+        }
+        __syncthreads();
+        prefix |= (unsigned long long)s_misc[0] << shift;
+        mask |= 0xffull << shift;
+        k = s_misc[1];
+        __syncthreads();
+    }
+    return prefix;
+}
+// ordered exclusive count of predicate over [0,n) (in index order); returns total; cb(i, rank) for elements with pred
+template <class P, class F> __device__ int block_ordered_visit(int n, P pred, F cb, int *s_wave /*>= nwaves+1*/) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    int running = 0;
+    for (int base = 0; base < n; base += blockDim.x) {
+        int i = base + threadIdx.x;
+        bool p = i < n && pred(i);
+        unsigned long long m = __ballot(p);
+        if (lane == 0) s_wave[wave] = __popcll(m);
+        __syncthreads();
+        int off = running, tot = 0;
+        for (int w2 = 0; w2 < nw; w2++) { int c = s_wave[w2]; if (w2 < wave) off += c; tot += c; }
+        if (p) cb(i, off + __popcll(m & ((1ull << lane) - 1)));
+        running += tot;
+        __syncthreads();
+    }
+    return running;
+}
+
+struct Conv3D { double pos[3], scale[3]; };
+__device__ inline void plane_hit(const double *T, const double *invK, const double *pl, double px, double py, double *o3) { // object_3d_util.cpp:574-585
+    double ray[3];
+    for (int i = 0; i < 3; i++) {
+        double s = invK[i * 3] * px;
+        s = s + invK[i * 3 + 1] * py;
+        s = s + invK[i * 3 + 2] * 1.0;
+        ray[i] = s;
+    }
+    double den = pl[0] * ray[0];
+    den = den + pl[1] * ray[1];
+    den = den + pl[2] * ray[2];
+    double frac = -pl[3] / den;
+    double s4[4] = {frac * ray[0], frac * ray[1], frac * ray[2], 1.0};
+    double w[4];
+    for (int i = 0; i < 4; i++) {
+        double a = T[i * 4] * s4[0];
+        a = a + T[i * 4 + 1] * s4[1];
+        a = a + T[i * 4 + 2] * s4[2];
+        a = a + T[i * 4 + 3] * s4[3];
+        w[i] = a;
+    }
+    o3[0] = w[0] / w[3]; o3[1] = w[1] / w[3]; o3[2] = w[2] / w[3];
+}
+// change_2d_corner_to_3d_object :610-648 (position and scale part)
+__device__ inline void corners_to_3d(const double *cx, const double *cy, const CamRP &C, const double *invK, Conv3D &o) {
+    double g[4][3];
+    for (int i = 0; i < 4; i++) plane_hit(C.T, invK, C.gps, cx[4 + i], cy[4 + i], g[i]);
+    auto nrm = [](const double *a, const double *b) {
+        double dx = a[0] - b[0], dy = a[1] - b[1], dz = a[2] - b[2];
+        return sqrt(dx * dx + dy * dy + dz * dz);
+    };
+    double length_half = nrm(g[0], g[3]) / 2;
+    double width_half = nrm(g[0], g[1]) / 2;
+    double d[3] = {g[0][0] - g[1][0], g[0][1] - g[1][1], g[0][2] - g[1][2]};
+    double nw[3] = {d[1] * 1.0 - d[2] * 0.0, d[2] * 0.0 - d[0] * 1.0, d[0] * 0.0 - d[1] * 0.0};
+    double nn = sqrt(nw[0] * nw[0] + nw[1] * nw[1] + nw[2] * nw[2]);
+    nw[0] /= nn; nw[1] /= nn; nw[2] /= nn;
+    double dist = -((nw[0] * g[0][0] + nw[1] * g[0][1]) + nw[2] * g[0][2]);
+    double pw[4] = {nw[0], nw[1], nw[2], dist};
+    if (dist < 0) for (int i = 0; i < 4; i++) pw[i] = -pw[i];
+    double ps[4];
+    for (int i = 0; i < 4; i++) {
+        double s = C.T[0 * 4 + i] * pw[0];
+        s = s + C.T[1 * 4 + i] * pw[1];
+        s = s + C.T[2 * 4 + i] * pw[2];
+        s = s + C.T[3 * 4 + i] * pw[3];
+        ps[i] = s;
+    }
+    double top[3];
+    plane_hit(C.T, invK, ps, cx[1], cy[1], top);
+    double height_half = top[2] / 2;
+    o.pos[0] = (((g[0][0] + g[1][0]) + g[2][0]) + g[3][0]) / 4.0;
+    o.pos[1] = (((g[0][1] + g[1][1]) + g[2][1]) + g[3][1]) / 4.0;
+    o.pos[2] = height_half;
+    o.scale[0] = length_half; o.scale[1] = width_half; o.scale[2] = height_half;
+}
+
+// flag bits after selection: bits 0-1 vp_1_position, bit 2 kept by fuse_normalize, bit 3 candidate for final ranking
+__global__ void __launch_bounds__(256) cuboid_select(const Unit *units, UnitDyn *ud, const int *box_first_unit, const FrameDyn *fd,
+                                                     const FrameInfo *fi, const CamRP *cam, const double *yaw, Calib cal, Opts o,
+                                                     uint8_t *flag, const double *derr, const double *aerr, const double *corners,
+                                                     long hyp_total, double *score, double *nscore, cs_cuboid *out, int *counts) {
+    __shared__ int hist[256];
+    __shared__ int s_misc[8];
+    __shared__ int s_wave[8];
+    __shared__ double s_red[4][4];
+    __shared__ double s_best[4];
+    __shared__ int s_bi[4][2];
+    __shared__ int s_branch[4];
+    const int box = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int u0 = box_first_unit[box];
+    const int n_hs = units[u0].n_hs;
+    const FrameDyn &D = fd[units[u0].frame];
+    const FrameInfo &FI = fi[units[u0].frame];
+    const int n_rp = D.n_roll * D.n_pitch;
+    const double weight_vp_angle = 0.8, weight_skew_error = 1.5; // box_proposal_detail.cpp:86-87
+    int n_cand_total = 0;
+
+    for (int hs = 0; hs < n_hs; hs++) {
+        const int u = u0 + hs;
+        const Unit &U = units[u];
+        const int n_hyp = n_rp * D.n_yaw * U.n_tops * 2;
+        uint8_t *fl = flag + U.hyp_off;
+        const double *de = derr + U.hyp_off, *ae = aerr + U.hyp_off;
+        // ---- fuse_normalize_scores_v2 (object_3d_util.cpp:495-565)
+        int n = block_ordered_visit(n_hyp, [&](int i) { return fl[i] != 0; }, [&](int, int) {}, s_wave);
+        int branch_b = 0, n_kept = 0;
+        if (n > 4) {
+            int breaking_num = (int)round(float(n) / 3.0 * 2.0);
+            int k = breaking_num - 1; // elements kept per criterion
+            unsigned long long vd = block_select_kth(de, fl, n_hyp, k - 1, hist, s_misc);
+            unsigned long long va = block_select_kth(ae, fl, n_hyp, k - 1, hist, s_misc);
+            unsigned long long va1 = block_select_kth(ae, fl, n_hyp, k, hist, s_misc);
+            int n_less = block_ordered_visit(n_hyp, [&](int i) { return fl[i] && dkey(de[i]) < vd; }, [&](int, int) {}, s_wave);
+            int need_eq = k - n_less; // ties at the threshold are kept in index order (std::partial_sort tie order pinned, D3)
+            block_ordered_visit(n_hyp, [&](int i) { return fl[i] && dkey(de[i]) == vd; },
+                                [&](int i, int rank) { if (rank < need_eq) fl[i] |= 4; }, s_wave);
+            block_ordered_visit(n_hyp, [&](int i) { return fl[i] && dkey(de[i]) < vd; }, [&](int i, int) { fl[i] |= 4; }, s_wave);
+            __syncthreads();
+            if (va1 > va) { // angle criterion active: keep set = {angle <= a_k}, intersect
+                for (int i = tid; i < n_hyp; i += 256) if ((fl[i] & 4) && !(dkey(ae[i]) <= va)) fl[i] &= ~4;
+            } else
+                branch_b = 1; // final_keep_inds = dist_keep_inds, in (dist, index) order
+        } else {
+            for (int i = tid; i < n_hyp; i += 256) if (fl[i]) fl[i] |= 4;
+        }
+        __syncthreads();
+        // min / max over the kept set
+        double mn_d = 1e6, mx_d = -1, mn_a = 1e6, mx_a = -1;
+        int cntk = 0;
+        for (int i = tid; i < n_hyp; i += 256)
+            if (fl[i] & 4) {
+                double td = de[i], ta = ae[i];
+                mn_d = fmin(mn_d, td); mx_d = fmax(mx_d, td); mn_a = fmin(mn_a, ta); mx_a = fmax(mx_a, ta);
+                cntk++;
+            }
+        for (int off = 32; off > 0; off >>= 1) {
+            mn_d = fmin(mn_d, __shfl_xor(mn_d, off)); mx_d = fmax(mx_d, __shfl_xor(mx_d, off));
+            mn_a = fmin(mn_a, __shfl_xor(mn_a, off)); mx_a = fmax(mx_a, __shfl_xor(mx_a, off));
+            cntk += __shfl_xor(cntk, off);
+        }
+        if (lane == 0) { s_red[wave][0] = mn_d; s_red[wave][1] = mx_d; s_red[wave][2] = mn_a; s_red[wave][3] = mx_a; s_wave[wave] = cntk; }
+        __syncthreads();
+        mn_d = fmin(fmin(s_red[0][0], s_red[1][0]), fmin(s_red[2][0], s_red[3][0]));
+        mx_d = fmax(fmax(s_red[0][1], s_red[1][1]), fmax(s_red[2][1], s_red[3][1]));
+        mn_a = fmin(fmin(s_red[0][2], s_red[1][2]), fmin(s_red[2][2], s_red[3][2]));
+        mx_a = fmax(fmax(s_red[0][3], s_red[1][3]), fmax(s_red[2][3], s_red[3][3]));
+        n_kept = s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        __syncthreads();
+        // normalised score, 2D->3D, skew penalty, final-ranking candidate score
+        int ncand = 0;
+        for (int i = tid; i < n_hyp; i += 256) {
+            if (!(fl[i] & 4)) continue;
+            double dk = de[i], ak = ae[i], comb;
+            if (n_kept > 1) { // whether_normalize_two_errors = true (:85)
+                comb = (dk - mn_d) / (mx_d - mn_d);
+                if ((mx_a - mn_a) > 0) ak = (ak - mn_a) / (mx_a - mn_a);
+                comb = (comb + weight_vp_angle * ak) / (1 + weight_vp_angle);
+            } else
+                comb = (dk + weight_vp_angle * ak) / (1 + weight_vp_angle);
+            long g = U.hyp_off + i;
+            int rp = (i >> 1) / U.n_tops / D.n_yaw;
+            double cx[8], cy[8];
+            for (int k = 0; k < 8; k++) { cx[k] = corners[(long)k * hyp_total + g]; cy[k] = corners[(long)(8 + k) * hyp_total + g]; }
+            Conv3D c3;
+            corners_to_3d(cx, cy, cam[(long)U.frame * RP_CAP + rp], cal.invK, c3);
+            if (c3.scale[0] < 0 || c3.scale[1] < 0 || c3.scale[2] < 0) continue; // :493
+            double mxs = c3.scale[0] < c3.scale[1] ? c3.scale[1] : c3.scale[0];   // Eigen maxCoeff / minCoeff
+            double mns = c3.scale[1] < c3.scale[0] ? c3.scale[1] : c3.scale[0];
+            double skew_ratio = mxs / mns;
+            double dsk = skew_ratio - o.nominal_skew_ratio;
+            double skew_error = weight_skew_error * ((dsk < 0.0) ? 0.0 : dsk); // std::max(a,0.0): (a<b)?b:a
+            if (skew_ratio > o.max_cut_skew) skew_error = 100;
+            nscore[g] = comb;
+            score[g] = comb + weight_skew_error * skew_error; // :526
+            fl[i] |= 8;
+            ncand++;
+        }
+        for (int off = 32; off > 0; off >>= 1) ncand += __shfl_xor(ncand, off);
+        if (lane == 0) s_wave[wave] = ncand;
+        __syncthreads();
+        n_cand_total += s_wave[0] + s_wave[1] + s_wave[2] + s_wave[3];
+        if (tid == 0) { ud[u].n_valid = n; ud[u].n_kept = n_kept; ud[u].branch_b = branch_b; s_branch[hs] = branch_b; }
+        __syncthreads();
+    }
+
+    // ---- final ranking :517-536: best max_cuboid_num by (score, position in raw_obj_proposals)
+    const int kout = n_cand_total < o.max_cuboid_num ? n_cand_total : o.max_cuboid_num;
+    for (int pick = 0; pick < kout; pick++) {
+        double bs = 0, bd = 0; int bhs = -1, bi = -1;
+        for (int hs = 0; hs < n_hs; hs++) {
+            const Unit &U = units[u0 + hs];
+            const int n_hyp = n_rp * D.n_yaw * U.n_tops * 2;
+            const uint8_t *fl = flag + U.hyp_off;
+            const int bb = s_branch[hs];
+            for (int i = tid; i < n_hyp; i += 256) {
+                if (!(fl[i] & 8)) continue;
+                double s = score[U.hyp_off + i], dd = bb ? derr[U.hyp_off + i] : 0.0;
+                bool better = bi < 0 || s < bs || (s == bs && (hs < bhs || (hs == bhs && (dd < bd || (dd == bd && i < bi)))));
+                if (better) { bs = s; bd = dd; bhs = hs; bi = i; }
+            }
+        }
+        for (int off = 32; off > 0; off >>= 1) {
+            double s2 = __shfl_xor(bs, off), d2 = __shfl_xor(bd, off);
+            int hs2 = __shfl_xor(bhs, off), i2 = __shfl_xor(bi, off);
+            bool better = i2 >= 0 && (bi < 0 || s2 < bs || (s2 == bs && (hs2 < bhs || (hs2 == bhs && (d2 < bd || (d2 == bd && i2 < bi))))));
+            if (better) { bs = s2; bd = d2; bhs = hs2; bi = i2; }
+        }
+        if (lane == 0) { s_best[wave] = bs; s_red[wave][0] = bd; s_bi[wave][0] = bhs; s_bi[wave][1] = bi; }
+        __syncthreads();
+        if (tid == 0) {
+            for (int w2 = 1; w2 < 4; w2++) {
+                double s2 = s_best[w2], d2 = s_red[w2][0];
+                int hs2 = s_bi[w2][0], i2 = s_bi[w2][1];
+                bool better = i2 >= 0 && (bi < 0 || s2 < bs || (s2 == bs && (hs2 < bhs || (hs2 == bhs && (d2 < bd || (d2 == bd && i2 < bi))))));
+                if (better) { bs = s2; bd = d2; bhs = hs2; bi = i2; }
+            }
+            const Unit &U = units[u0 + bhs];
+            long g = U.hyp_off + bi;
+            flag[g] &= ~8;
+            // full record: change_2d_corner_to_3d_object + fields (:489-513)
+            int cfg = (bi & 1) + 1, q = (bi >> 1) / U.n_tops;
+            int yi = q % D.n_yaw, rp = q / D.n_yaw;
+            const CamRP &C = cam[(long)U.frame * RP_CAP + rp];
+            double cx[8], cy[8];
+            for (int k = 0; k < 8; k++) { cx[k] = corners[(long)k * hyp_total + g]; cy[k] = corners[(long)(8 + k) * hyp_total + g]; }
+            Conv3D c3;
+            corners_to_3d(cx, cy, C, cal.invK, c3);
+            cs_cuboid &O = out[(long)box * o.max_cuboid_num + pick];
+            for (int k = 0; k < 3; k++) { O.pos[k] = c3.pos[k]; O.scale[k] = c3.scale[k]; }
+            O.rotY = yaw[(long)U.frame * o.yaw_cap + yi];
+            int vp1 = flag[g] & 3;
+            O.box_config_type[0] = cfg; O.box_config_type[1] = vp1;
+            const int map1[8] = {6, 5, 8, 7, 2, 3, 4, 1}, map2[8] = {5, 6, 7, 8, 3, 2, 1, 4}; // object_3d_util.cpp:637-640
+            for (int k = 0; k < 8; k++) {
+                int src = (vp1 == 1 ? map1[k] : map2[k]) - 1;
+                O.box_corners_2d[k] = (int)cx[src];
+                O.box_corners_2d[8 + k] = (int)cy[src];
+            }
+            { // compute3D_BoxCorner :41-50
+                const double body[3][8] = {{1, 1, -1, -1, 1, 1, -1, -1}, {1, -1, -1, 1, 1, -1, -1, 1}, {-1, -1, -1, -1, 1, 1, 1, 1}};
+                double cyw = cos(O.rotY), syw = sin(O.rotY);
+                double rot[3][3] = {{cyw, -syw, 0}, {syw, cyw, 0}, {0, 0, 1}};
+                double rs[3][3];
+                for (int i = 0; i < 3; i++)
+                    for (int j = 0; j < 3; j++) {
+                        double s = rot[i][0] * (j == 0 ? O.scale[0] : 0.0);
+                        s = s + rot[i][1] * (j == 1 ? O.scale[1] : 0.0);
+                        s = s + rot[i][2] * (j == 2 ? O.scale[2] : 0.0);
+                        rs[i][j] = s;
+                    }
+                for (int k = 0; k < 8; k++) {
+                    double wv[4];
+                    for (int i = 0; i < 3; i++) {
+                        double s = rs[i][0] * body[0][k];
+                        s = s + rs[i][1] * body[1][k];
+                        s = s + rs[i][2] * body[2][k];
+                        s = s + O.pos[i] * 1.0;
+                        wv[i] = s;
+                    }
+                    wv[3] = ((0.0 * body[0][k] + 0.0 * body[1][k]) + 0.0 * body[2][k]) + 1.0;
+                    for (int i = 0; i < 3; i++) O.box_corners_3d_world[i * 8 + k] = wv[i] / wv[3];
+                }
+            }
+            O.rect_detect_2d[0] = U.left; O.rect_detect_2d[1] = U.top; O.rect_detect_2d[2] = U.width_raw; O.rect_detect_2d[3] = U.height_raw;
+            O.edge_distance_error = derr[g]; O.edge_angle_error = aerr[g];
+            O.normalized_error = nscore[g];
+            double mxs = c3.scale[0] < c3.scale[1] ? c3.scale[1] : c3.scale[0];
+            double mns = c3.scale[1] < c3.scale[0] ? c3.scale[1] : c3.scale[0];
+            O.skew_ratio = mxs / mns;
+            O.down_expand_height = U.down_expand;
+            if (o.sample_rp) { O.camera_roll_delta = C.roll - FI.euler[0]; O.camera_pitch_delta = C.pitch - FI.euler[1]; }
+            else { O.camera_roll_delta = 0; O.camera_pitch_delta = 0; }
+        }
+        __syncthreads();
+    }
+    if (tid == 0) counts[box] = kout;
+}
+
+__global__ void cuboid_bgr2gray(const uint8_t *bgr, int stride, int w, int h, uint8_t *gray) { // cvtColor(CV_BGR2GRAY), :62-66
+    int x = blockIdx.x * blockDim.x + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    const uint8_t *p = bgr + (long)y * stride + 3 * x;
+    gray[(long)y * w + x] = (uint8_t)((p[0] * 1868 + p[1] * 9617 + p[2] * 4899 + 8192) >> 14);
+}
+
+// ------------------------------------------------------------------------------------------------ host side
+static void host_euler_from_T(const double *T, double *euler) { // set_cam_pose :45-48 with the host libm
+    double m[3][3];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) m[i][j] = T[i * 4 + j];
+    double qw, qx, qy, qz, q[3];
+    double t = m[0][0] + m[1][1] + m[2][2];
+    if (t > 0) { // Eigen::Quaterniond(Matrix3d)
+        t = std::sqrt(t + 1.0);
+        qw = 0.5 * t; t = 0.5 / t;
+        qx = (m[2][1] - m[1][2]) * t; qy = (m[0][2] - m[2][0]) * t; qz = (m[1][0] - m[0][1]) * t;
+    } else {
+        int i = 0;
+        if (m[1][1] > m[0][0]) i = 1;
+        if (m[2][2] > m[i][i]) i = 2;
+        int j = (i + 1) % 3, k = (j + 1) % 3;
+        t = std::sqrt(m[i][i] - m[j][j] - m[k][k] + 1.0);
+        q[i] = 0.5 * t; t = 0.5 / t;
+        qw = (m[k][j] - m[j][k]) * t;
+        q[j] = (m[j][i] + m[i][j]) * t;
+        q[k] = (m[k][i] + m[i][k]) * t;
+        qx = q[0]; qy = q[1]; qz = q[2];
+    }
+    euler[0] = std::atan2(2 * (qw * qx + qy * qz), 1 - 2 * (qx * qx + qy * qy)); // quat_to_euler_zyx matrix_utils.cpp:35-46
+    euler[1] = std::asin(2 * (qw * qy - qz * qx));
+    euler[2] = std::atan2(2 * (qw * qz + qx * qy), 1 - 2 * (qy * qy + qz * qz));
+}
+
+} // namespace
+
+struct cs_cuboid_batch {
+    int n_frames = 0, W = 0, H = 0, n_boxes = 0, n_units = 0;
+    Opts o{};
+    Calib cal{};
+    std::vector<Unit> units;
+    std::vector<int> box_first_unit;
+    long pix_total = 0, hyp_total = 0, vp_total = 0, line_rows = 0;
+    int max_tiles = 0, max_cc_blocks = 0, max_vp_blocks = 0, blocks_per_unit = 0;
+    // device
+    uint8_t *d_gray = nullptr, *d_emap = nullptr, *d_flag = nullptr;
+    int *d_lab = nullptr; // aliases d_dist
+    float *d_dist = nullptr;
+    FrameInfo *d_fi = nullptr; FrameDyn *d_fd = nullptr; CamRP *d_cam = nullptr;
+    double *d_yaw = nullptr, *d_lines_in = nullptr, *d_lines_al = nullptr, *d_mlines = nullptr, *d_mangle = nullptr, *d_mmid = nullptr;
+    Unit *d_units = nullptr; UnitDyn *d_ud = nullptr; int *d_box_first = nullptr, *d_status = nullptr, *d_counts = nullptr;
+    VPEntry *d_vp = nullptr;
+    double *d_derr = nullptr, *d_aerr = nullptr, *d_corners = nullptr, *d_score = nullptr, *d_nscore = nullptr;
+    cs_cuboid *d_out = nullptr;
+};
+
+extern "C" {
+
+void cs_cuboid_default_opts(cs_cuboid_opts *o) {
+    if (!o) return;
+    o->consider_config_1 = 1; o->consider_config_2 = 1;
+    o->whether_sample_cam_roll_pitch = 0; o->whether_sample_bbox_height = 0;
+    o->max_cuboid_num = 1; o->nominal_skew_ratio = 1; o->max_cut_skew = 3;
+    o->yaw_range_deg = 45; o->yaw_step_deg = 6; o->canny_low = 80; o->canny_high = 200;
+}
+
+void cs_cuboid_batch_destroy(cs_ctx *ctx, cs_cuboid_batch *b) {
+    if (!b) return;
+    if (ctx) { hipSetDevice(ctx->device); hipStreamSynchronize(ctx->stream); }
+    void *ptrs[] = {b->d_gray, b->d_emap, b->d_flag, b->d_dist, b->d_fi, b->d_fd, b->d_cam, b->d_yaw, b->d_lines_in, b->d_lines_al,
+                    b->d_mlines, b->d_mangle, b->d_mmid, b->d_units, b->d_ud, b->d_box_first, b->d_status, b->d_counts, b->d_vp,
+                    b->d_derr, b->d_aerr, b->d_corners, b->d_score, b->d_nscore, b->d_out};
+    for (void *p : ptrs) if (p) hipFree(p);
+    delete b;
+}
+
+int cs_cuboid_batch_create(cs_ctx *ctx, int n_frames, int width, int height, const uint8_t *gray, const double *K, const double *Twc,
+                           const int *box_offsets, const double *boxes, const int *line_offsets, const double *lines,
+                           const cs_cuboid_opts *opts, cs_cuboid_batch **out) {
+    if (!ctx || !out || n_frames <= 0 || width <= 0 || height <= 0 || !gray || !K || !Twc || !box_offsets || !line_offsets || !opts)
+        return CS_ERR_BAD_ARG;
+    if (opts->max_cuboid_num < 1 || !(opts->yaw_step_deg > 0)) return CS_ERR_BAD_ARG;
+    *out = nullptr;
+    CS_HIP(ctx, hipSetDevice(ctx->device));
+    cs_cuboid_batch *b = new (std::nothrow) cs_cuboid_batch();
+    if (!b) return CS_ERR_NOMEM;
+    b->n_frames = n_frames; b->W = width; b->H = height;
+    Opts &o = b->o;
+    o.cfg1 = opts->consider_config_1; o.cfg2 = opts->consider_config_2; o.sample_rp = opts->whether_sample_cam_roll_pitch;
+    o.max_cuboid_num = opts->max_cuboid_num; o.nominal_skew_ratio = opts->nominal_skew_ratio; o.max_cut_skew = opts->max_cut_skew;
+    o.yaw_range_deg = opts->yaw_range_deg; o.yaw_step_deg = opts->yaw_step_deg;
+    o.canny_low = opts->canny_low; o.canny_high = opts->canny_high;
+    {
+        double cap = std::floor(2.0 * opts->yaw_range_deg / opts->yaw_step_deg) + 3;
+        o.yaw_cap = (int)std::min(1001.0, std::max(1.0, cap));
+    }
+    for (int i = 0; i < 9; i++) b->cal.K[i] = K[i];
+    inv3_cof(b->cal.K, b->cal.invK); // set_calibration box_proposal_detail.cpp:36-40
+    if ((int)std::lrint((double)(0.955f * 65536)) != DT_HV || (int)std::lrint((double)(1.3693f * 65536)) != DT_DIAG) {
+        ctx->err = "chamfer constants mismatch"; delete b; return CS_ERR_BAD_ARG;
+    }
+    const int n_boxes = box_offsets[n_frames], n_lines = line_offsets[n_frames];
+    b->n_boxes = n_boxes;
+    std::vector<FrameInfo> fi(n_frames);
+    for (int f = 0; f < n_frames; f++) {
+        for (int i = 0; i < 16; i++) fi[f].T[i] = Twc[(long)f * 16 + i];
+        host_euler_from_T(fi[f].T, fi[f].euler);
+        fi[f].line_off = line_offsets[f]; fi[f].n_lines = line_offsets[f + 1] - line_offsets[f];
+    }
+    const int rp_cap = o.sample_rp ? 25 : 1; // 5x5 at most (linespace +-6 deg step 3 deg gives 4 or 5 per axis)
+    int status = CS_OK;
+    for (int f = 0; f < n_frames && status == CS_OK; f++)
+        for (int bi = box_offsets[f]; bi < box_offsets[f + 1]; bi++) {
+            const double *bb = boxes + (long)bi * 5;
+            // box_proposal_detail.cpp:107-123
+            int left_x_raw = (int)bb[0], top_y_raw = (int)bb[1], obj_width_raw = (int)bb[2], obj_height_raw = (int)bb[3];
+            int right_x_raw = (int)(left_x_raw + bb[2]);
+            int hs_list[3], n_hs = 0;
+            hs_list[n_hs++] = 0;
+            if (opts->whether_sample_bbox_height) {
+                int r = std::max(std::min(20, obj_height_raw - 90), 20);
+                r = std::min(r, height - top_y_raw - obj_height_raw - 1);
+                if (r > 10) hs_list[n_hs++] = (int)std::round(r / 2);
+                hs_list[n_hs++] = r;
+            }
+            b->box_first_unit.push_back((int)b->units.size());
+            for (int hs = 0; hs < n_hs; hs++) {
+                Unit U{};
+                U.frame = f; U.box = bi; U.hs = hs; U.n_hs = n_hs;
+                U.left = left_x_raw; U.top = top_y_raw; U.right = right_x_raw; U.width_raw = obj_width_raw; U.height_raw = obj_height_raw;
+                U.down_expand = hs_list[hs];
+                int obj_height_expan = obj_height_raw + U.down_expand; // :139-141
+                U.down_y_expan = top_y_raw + obj_height_expan;
+                U.diag = std::sqrt((double)(obj_width_raw * obj_width_raw + obj_height_expan * obj_height_expan));
+                int res = (int)std::round((double)std::min(20, obj_width_raw / 10)); // :144-146
+                {
+                    int s = left_x_raw + 5, e = right_x_raw - 5, n = 0;
+                    while (s <= e) { n++; s += res; if (n > 1000) break; }
+                    U.n_tops = n; U.top_start = left_x_raw + 5; U.top_step = res;
+                }
+                int ew = std::min(std::max(std::min(20, obj_width_raw - 100), 10), std::max(std::min(20, obj_height_expan - 100), 10)); // :155
+                U.roi_x = std::max(0, left_x_raw - ew);
+                U.roi_r = std::min(width - 1, right_x_raw + ew);
+                U.roi_y = std::max(0, top_y_raw - ew);
+                U.roi_b = std::min(height - 1, U.down_y_expan + ew);
+                U.roi_w = U.roi_r - U.roi_x; U.roi_h = U.roi_b - U.roi_y;
+                if (U.roi_w <= 0 || U.roi_h <= 0 || U.roi_x + U.roi_w > width || U.roi_y + U.roi_h > height) { status = CS_ERR_BAD_ARG; break; }
+                U.pix_off = b->pix_total; b->pix_total += ((long)U.roi_w * U.roi_h + 63) / 64 * 64;
+                U.hyp_cap = rp_cap * o.yaw_cap * U.n_tops * 2;
+                U.hyp_off = b->hyp_total; b->hyp_total += ((long)U.hyp_cap + 63) / 64 * 64;
+                U.vp_off = (int)b->vp_total; b->vp_total += (long)rp_cap * o.yaw_cap;
+                U.line_off = (int)b->line_rows; b->line_rows += std::min(fi[f].n_lines, CS_MAX_ROI_LINES);
+                b->max_tiles = std::max(b->max_tiles, ((U.roi_w + NMS_TW - 1) / NMS_TW) * ((U.roi_h + NMS_TH - 1) / NMS_TH));
+                b->max_cc_blocks = std::max(b->max_cc_blocks, (int)(((long)U.roi_w * U.roi_h + 1023) / 1024));
+                b->blocks_per_unit = std::max(b->blocks_per_unit, (U.hyp_cap + SWEEP_HB - 1) / SWEEP_HB);
+                b->units.push_back(U);
+            }
+        }
+    if (status != CS_OK) { ctx->err = "box ROI outside the image"; delete b; return status; }
+    b->n_units = (int)b->units.size();
+    b->max_vp_blocks = (rp_cap * o.yaw_cap + 255) / 256;
+    if (b->vp_total > INT_MAX || b->line_rows > INT_MAX) { delete b; return CS_ERR_CAPACITY; }
+
+#define A_(call) do { int r__ = (call); if (r__ != CS_OK) { cs_cuboid_batch_destroy(ctx, b); return r__; } } while (0)
+    const size_t npx = (size_t)n_frames * width * height;
+    A_(cs_dalloc(ctx, &b->d_gray, npx));
+    A_(cs_dalloc(ctx, &b->d_emap, (size_t)b->pix_total));
+    A_(cs_dalloc(ctx, &b->d_dist, (size_t)b->pix_total));
+    b->d_lab = (int *)b->d_dist;
+    A_(cs_dalloc(ctx, &b->d_fi, (size_t)n_frames));
+    A_(cs_dalloc(ctx, &b->d_fd, (size_t)n_frames));
+    A_(cs_dalloc(ctx, &b->d_cam, (size_t)n_frames * RP_CAP));
+    A_(cs_dalloc(ctx, &b->d_yaw, (size_t)n_frames * o.yaw_cap));
+    A_(cs_dalloc(ctx, &b->d_lines_in, (size_t)n_lines * 4));
+    A_(cs_dalloc(ctx, &b->d_lines_al, (size_t)n_lines * 4));
+    A_(cs_dalloc(ctx, &b->d_mlines, (size_t)b->line_rows * 4));
+    A_(cs_dalloc(ctx, &b->d_mangle, (size_t)b->line_rows));
+    A_(cs_dalloc(ctx, &b->d_mmid, (size_t)b->line_rows * 2));
+    A_(cs_dalloc(ctx, &b->d_units, (size_t)b->n_units));
+    A_(cs_dalloc(ctx, &b->d_ud, (size_t)b->n_units));
+    A_(cs_dalloc(ctx, &b->d_box_first, (size_t)n_boxes));
+    A_(cs_dalloc(ctx, &b->d_status, (size_t)1));
+    A_(cs_dalloc(ctx, &b->d_counts, (size_t)n_boxes));
+    A_(cs_dalloc(ctx, &b->d_vp, (size_t)b->vp_total));
+    A_(cs_dalloc(ctx, &b->d_flag, (size_t)b->hyp_total));
+    A_(cs_dalloc(ctx, &b->d_derr, (size_t)b->hyp_total));
+    A_(cs_dalloc(ctx, &b->d_aerr, (size_t)b->hyp_total));
+    A_(cs_dalloc(ctx, &b->d_corners, (size_t)b->hyp_total * 16));
+    A_(cs_dalloc(ctx, &b->d_score, (size_t)b->hyp_total));
+    A_(cs_dalloc(ctx, &b->d_nscore, (size_t)b->hyp_total));
+    A_(cs_dalloc(ctx, &b->d_out, (size_t)n_boxes * o.max_cuboid_num));
+    A_(cs_h2d(ctx, b->d_gray, gray, npx));
+    A_(cs_h2d(ctx, b->d_fi, fi.data(), (size_t)n_frames));
+    A_(cs_h2d(ctx, b->d_lines_in, lines, (size_t)n_lines * 4));
+    A_(cs_h2d(ctx, b->d_units, b->units.data(), (size_t)b->n_units));
+    A_(cs_h2d(ctx, b->d_box_first, b->box_first_unit.data(), (size_t)n_boxes));
+    { hipError_t e = hipStreamSynchronize(ctx->stream); if (e != hipSuccess) { ctx->err = hipGetErrorString(e); cs_cuboid_batch_destroy(ctx, b); return CS_ERR_HIP; } }
+#undef A_
+    *out = b;
+    return CS_OK;
+}
+
+int cs_cuboid_batch_run(cs_ctx *ctx, cs_cuboid_batch *b) {
+    if (!ctx || !b) return CS_ERR_BAD_ARG;
+    CS_HIP(ctx, hipSetDevice(ctx->device));
+    CS_HIP(ctx, hipMemsetAsync(b->d_status, 0, sizeof(int), ctx->stream));
+    CS_HIP(ctx, hipMemsetAsync(b->d_out, 0, sizeof(cs_cuboid) * (size_t)std::max(1, b->n_boxes * b->o.max_cuboid_num), ctx->stream));
+    if (b->n_units == 0) return CS_OK;
+    const int U = b->n_units;
+    CS_LAUNCH(ctx, "cuboid_frame_prep", cuboid_frame_prep, dim3(b->n_frames), dim3(64), 0, b->d_fi, b->d_fd, b->d_cam, b->d_yaw, b->cal, b->o,
+              b->d_lines_in, b->d_lines_al);
+    CS_LAUNCH(ctx, "cuboid_unit_lines", cuboid_unit_lines, dim3(U), dim3(64), 0, b->d_units, b->d_ud, b->d_fi, b->d_lines_al, b->d_mlines,
+              b->d_mangle, b->d_mmid, b->d_status);
+    CS_LAUNCH(ctx, "cuboid_canny_nms", cuboid_canny_nms, dim3(b->max_tiles, U), dim3(256), 0, b->d_units, b->d_gray, b->W, b->H, b->d_emap,
+              b->d_lab, b->o.canny_low, b->o.canny_high);
+    for (int stage = 0; stage < 3; stage++)
+        CS_LAUNCH(ctx, "cuboid_canny_cc", cuboid_canny_cc, dim3(b->max_cc_blocks, U), dim3(256), 0, b->d_units, b->d_emap, b->d_lab, stage);
+    const int wbuf = b->W + 2;
+    CS_LAUNCH(ctx, "cuboid_dt", cuboid_dt, dim3((U + 3) / 4), dim3(256), (size_t)wbuf * 2 * 4 * sizeof(int), b->d_units, U, b->d_emap, b->d_dist, wbuf);
+    CS_LAUNCH(ctx, "cuboid_vp", cuboid_vp, dim3(b->max_vp_blocks, U), dim3(256), 0, b->d_units, b->d_ud, b->d_fd, b->d_cam, b->d_yaw, b->o,
+              b->d_mangle, b->d_mmid, b->d_vp);
+    const int groups = (U + 7) / 8;
+    CS_LAUNCH(ctx, "cuboid_sweep_score", cuboid_sweep_score, dim3(groups * b->blocks_per_unit * 8), dim3(256), 0, b->d_units, U,
+              b->blocks_per_unit, b->d_fd, b->d_yaw, b->o, b->d_vp, b->d_dist, b->d_flag, b->d_derr, b->d_aerr, b->d_corners, b->hyp_total);
+    CS_LAUNCH(ctx, "cuboid_select", cuboid_select, dim3(b->n_boxes), dim3(256), 0, b->d_units, b->d_ud, b->d_box_first, b->d_fd, b->d_fi,
+              b->d_cam, b->d_yaw, b->cal, b->o, b->d_flag, b->d_derr, b->d_aerr, b->d_corners, b->hyp_total, b->d_score, b->d_nscore,
+              b->d_out, b->d_counts);
+    CS_HIP(ctx, hipGetLastError());
+    return CS_OK;
+}
+
+int cs_cuboid_batch_read(cs_ctx *ctx, cs_cuboid_batch *b, cs_cuboid *out, int *counts) {
+    if (!ctx || !b || !out || !counts) return CS_ERR_BAD_ARG;
+    int status = 0;
+    int r = cs_d2h(ctx, out, b->d_out, (size_t)b->n_boxes * b->o.max_cuboid_num); if (r) return r;
+    r = cs_d2h(ctx, counts, b->d_counts, (size_t)b->n_boxes); if (r) return r;
+    r = cs_d2h(ctx, &status, b->d_status, 1); if (r) return r;
+    CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (status != 0) { ctx->err = "more than CS_MAX_ROI_LINES lines inside one box"; return status; }
+    return CS_OK;
+}
+
+int cs_cuboid_batch_stats(cs_ctx *ctx, cs_cuboid_batch *b, long *n_units, long *roi_pixels, long *n_hypotheses, long *n_valid) {
+    if (!ctx || !b) return CS_ERR_BAD_ARG;
+    std::vector<UnitDyn> ud(b->n_units);
+    std::vector<FrameDyn> fd(b->n_frames);
+    int r = cs_d2h(ctx, ud.data(), b->d_ud, ud.size()); if (r) return r;
+    r = cs_d2h(ctx, fd.data(), b->d_fd, fd.size()); if (r) return r;
+    CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    long px = 0, hy = 0, va = 0;
+    for (int u = 0; u < b->n_units; u++) {
+        const Unit &U = b->units[u];
+        const FrameDyn &D = fd[U.frame];
+        px += (long)U.roi_w * U.roi_h;
+        hy += (long)D.n_roll * D.n_pitch * D.n_yaw * U.n_tops * 2;
+        va += ud[u].n_valid;
+    }
+    if (n_units) *n_units = b->n_units;
+    if (roi_pixels) *roi_pixels = px;
+    if (n_hypotheses) *n_hypotheses = hy;
+    if (n_valid) *n_valid = va;
+    return CS_OK;
+}
+
+int cs_cuboid_batch_unit(cs_ctx *ctx, cs_cuboid_batch *b, int unit, int dims[12], uint8_t *edges, float *dist, double *rows, long rows_cap,
+                         double *merged, long merged_cap) {
+    if (!ctx || !b || unit < 0 || unit >= b->n_units || !dims) return CS_ERR_BAD_ARG;
+    const Unit &U = b->units[unit];
+    UnitDyn ud; FrameDyn fd; FrameInfo fi;
+    int r = cs_d2h(ctx, &ud, b->d_ud + unit, 1); if (r) return r;
+    r = cs_d2h(ctx, &fd, b->d_fd + U.frame, 1); if (r) return r;
+    r = cs_d2h(ctx, &fi, b->d_fi + U.frame, 1); if (r) return r;
+    CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const long A = (long)U.roi_w * U.roi_h;
+    dims[0] = U.roi_x; dims[1] = U.roi_y; dims[2] = U.roi_w; dims[3] = U.roi_h; dims[4] = U.hyp_cap; dims[5] = ud.n_valid;
+    dims[6] = ud.n_merged; dims[7] = fd.n_yaw; dims[8] = U.frame; dims[9] = U.box; dims[10] = U.hs; dims[11] = U.n_hs;
+    if (edges) { r = cs_d2h(ctx, edges, b->d_emap + U.pix_off, (size_t)A); if (r) return r; }
+    if (dist) { r = cs_d2h(ctx, dist, b->d_dist + U.pix_off, (size_t)A); if (r) return r; }
+    if (merged) { r = cs_d2h(ctx, merged, b->d_mlines + (long)U.line_off * 4, (size_t)std::min<long>(merged_cap, ud.n_merged) * 4); if (r) return r; }
+    if (rows) {
+        const int n_hyp = fd.n_roll * fd.n_pitch * fd.n_yaw * U.n_tops * 2;
+        std::vector<uint8_t> fl(n_hyp);
+        std::vector<double> de(n_hyp), ae(n_hyp), co((size_t)n_hyp * 16), yw(b->o.yaw_cap);
+        r = cs_d2h(ctx, fl.data(), b->d_flag + U.hyp_off, (size_t)n_hyp); if (r) return r;
+        r = cs_d2h(ctx, de.data(), b->d_derr + U.hyp_off, (size_t)n_hyp); if (r) return r;
+        r = cs_d2h(ctx, ae.data(), b->d_aerr + U.hyp_off, (size_t)n_hyp); if (r) return r;
+        for (int p = 0; p < 16; p++) { r = cs_d2h(ctx, co.data() + (size_t)p * n_hyp, b->d_corners + (long)p * b->hyp_total + U.hyp_off, (size_t)n_hyp); if (r) return r; }
+        r = cs_d2h(ctx, yw.data(), b->d_yaw + (long)U.frame * b->o.yaw_cap, (size_t)b->o.yaw_cap); if (r) return r;
+        CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        long nr = 0;
+        for (int h = 0; h < n_hyp && nr < rows_cap; h++) {
+            if (!(fl[h] & 3)) continue;
+            int cfg = (h & 1) + 1, q = h >> 1;
+            int ti = q % U.n_tops; q /= U.n_tops;
+            int yi = q % fd.n_yaw, rp = q / fd.n_yaw;
+            double *row = rows + nr * 25;
+            row[0] = cfg; row[1] = fl[h] & 3; row[2] = yw[yi]; row[3] = ti; row[4] = de[h]; row[5] = ae[h]; row[6] = U.down_expand;
+            row[7] = b->o.sample_rp ? fd.roll[rp / fd.n_pitch] : fi.euler[0];
+            row[8] = b->o.sample_rp ? fd.pitch[rp % fd.n_pitch] : fi.euler[1];
+            for (int p = 0; p < 16; p++) row[9 + p] = co[(size_t)p * n_hyp + h];
+            nr++;
+        }
+    }
+    CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CS_OK;
+}
+
+int cs_cuboid_detect(cs_ctx *ctx, const uint8_t *img, int width, int height, int channels, int stride, const double *K, const double *Twc,
+                     const double *boxes, int n_boxes, const double *lines, int n_lines, const cs_cuboid_opts *opts, cs_cuboid *out,
+                     int *counts) {
+    if (!ctx || !img || width <= 0 || height <= 0 || (channels != 1 && channels != 3) || stride < width * channels || n_boxes < 0 ||
+        n_lines < 0 || !opts || !out || !counts)
+        return CS_ERR_BAD_ARG;
+    if (n_boxes == 0) return CS_OK;
+    std::vector<uint8_t> gray((size_t)width * height);
+    if (channels == 1) {
+        for (int y = 0; y < height; y++) memcpy(&gray[(size_t)y * width], img + (size_t)y * stride, (size_t)width);
+    } else {
+        CS_HIP(ctx, hipSetDevice(ctx->device));
+        uint8_t *d_bgr = nullptr, *d_g = nullptr;
+        CS_HIP(ctx, hipMalloc((void **)&d_bgr, (size_t)stride * height));
+        if (hipMalloc((void **)&d_g, (size_t)width * height) != hipSuccess) { hipFree(d_bgr); return CS_ERR_NOMEM; }
+        hipMemcpyAsync(d_bgr, img, (size_t)stride * height, hipMemcpyHostToDevice, ctx->stream);
+        CS_LAUNCH(ctx, "cuboid_bgr2gray", cuboid_bgr2gray, dim3((width + 255) / 256, height), dim3(256), 0, d_bgr, stride, width, height, d_g);
+        hipMemcpyAsync(gray.data(), d_g, (size_t)width * height, hipMemcpyDeviceToHost, ctx->stream);
+        hipError_t e = hipStreamSynchronize(ctx->stream);
+        hipFree(d_bgr); hipFree(d_g);
+        if (e != hipSuccess) { ctx->err = hipGetErrorString(e); return CS_ERR_HIP; }
+    }
+    int bo[2] = {0, n_boxes}, lo[2] = {0, n_lines};
+    cs_cuboid_batch *b = nullptr;
+    double dummy[4] = {0, 0, 0, 0};
+    int r = cs_cuboid_batch_create(ctx, 1, width, height, gray.data(), K, Twc, bo, boxes, lo, n_lines ? lines : dummy, opts, &b);
+    if (r != CS_OK) return r;
+    r = cs_cuboid_batch_run(ctx, b);
+    if (r == CS_OK) r = cs_cuboid_batch_read(ctx, b, out, counts);
+    cs_cuboid_batch_destroy(ctx, b);
+    return r;
+}
+
+} // extern "C"

@@ -1,0 +1,150 @@
+"""Python host-side mirror of detect_3d_cuboid (reference detect_3d_cuboid/include/detect_3d_cuboid/detect_3d_cuboid.h:53-79)
+over the C-ABI.  Same member names and argument meaning as the reference class; the work runs in HIP kernels."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, lib
+
+
+class CuboidOpts(C.Structure):
+    _fields_ = [
+        ("consider_config_1", C.c_int), ("consider_config_2", C.c_int),
+        ("whether_sample_cam_roll_pitch", C.c_int), ("whether_sample_bbox_height", C.c_int),
+        ("max_cuboid_num", C.c_int),
+        ("nominal_skew_ratio", C.c_double), ("max_cut_skew", C.c_double),
+        ("yaw_range_deg", C.c_double), ("yaw_step_deg", C.c_double),
+        ("canny_low", C.c_int), ("canny_high", C.c_int),
+    ]
+
+
+CUBOID_DTYPE = np.dtype([
+    ("pos", "f8", 3), ("scale", "f8", 3), ("rotY", "f8"), ("box_config_type", "f8", 2),
+    ("box_corners_2d", "i4", (2, 8)), ("box_corners_3d_world", "f8", (3, 8)), ("rect_detect_2d", "f8", 4),
+    ("edge_distance_error", "f8"), ("edge_angle_error", "f8"), ("normalized_error", "f8"),
+    ("skew_ratio", "f8"), ("down_expand_height", "f8"), ("camera_roll_delta", "f8"),
+    ("camera_pitch_delta", "f8")], align=True)
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+class detect_3d_cuboid:
+    """Drop-in for the reference class: set_calibration(), then detect_cuboid(img, transToWolrd, obj_bbox_coors, edges)."""
+
+    def __init__(self, ctx=None, device=0):
+        self.ctx = ctx or _lib.Context(device)
+        self.consider_config_1 = True
+        self.consider_config_2 = True
+        self.whether_sample_cam_roll_pitch = False
+        self.whether_sample_bbox_height = False
+        self.max_cuboid_num = 1
+        self.nominal_skew_ratio = 1.0
+        self.max_cut_skew = 3.0
+        self.yaw_range_deg = 45.0
+        self.yaw_step_deg = 6.0
+        self.Kalib = None
+
+    def set_calibration(self, Kalib):
+        self.Kalib = np.ascontiguousarray(Kalib, np.float64).reshape(3, 3)
+
+    def opts(self):
+        o = CuboidOpts()
+        lib().cs_cuboid_default_opts(C.byref(o))
+        o.consider_config_1 = int(self.consider_config_1)
+        o.consider_config_2 = int(self.consider_config_2)
+        o.whether_sample_cam_roll_pitch = int(self.whether_sample_cam_roll_pitch)
+        o.whether_sample_bbox_height = int(self.whether_sample_bbox_height)
+        o.max_cuboid_num = int(self.max_cuboid_num)
+        o.nominal_skew_ratio = float(self.nominal_skew_ratio)
+        o.max_cut_skew = float(self.max_cut_skew)
+        o.yaw_range_deg = float(self.yaw_range_deg)
+        o.yaw_step_deg = float(self.yaw_step_deg)
+        return o
+
+    def detect_cuboid(self, rgb_img, transToWolrd, obj_bbox_coors, edges):
+        """Returns all_object_cuboids: one structured array (<= max_cuboid_num records, best first) per 2-D box."""
+        if self.Kalib is None:
+            raise ValueError("set_calibration() first")
+        img = np.ascontiguousarray(rgb_img, np.uint8)
+        ch = 1 if img.ndim == 2 else img.shape[2]
+        H, W = img.shape[:2]
+        T = np.ascontiguousarray(transToWolrd, np.float64).reshape(4, 4)
+        boxes = np.ascontiguousarray(obj_bbox_coors, np.float64).reshape(-1, 5)
+        lines = np.ascontiguousarray(edges, np.float64).reshape(-1, 4)
+        nb = len(boxes)
+        out = np.zeros((max(nb, 1), self.max_cuboid_num), CUBOID_DTYPE)
+        counts = np.zeros(max(nb, 1), np.int32)
+        o = self.opts()
+        r = lib().cs_cuboid_detect(self.ctx.ptr, _p(img, C.c_uint8), W, H, ch, W * ch, _p(self.Kalib, C.c_double), _p(T, C.c_double),
+                                   _p(boxes, C.c_double), nb, _p(lines, C.c_double), len(lines), C.byref(o),
+                                   out.ctypes.data_as(C.c_void_p), _p(counts, C.c_int))
+        check(self.ctx.ptr, r, "cs_cuboid_detect")
+        return [out[i, :counts[i]].copy() for i in range(nb)]
+
+
+class CuboidBatch:
+    """Device-resident batch (BASELINE config 4): frames stay in HBM, run() only launches kernels."""
+
+    def __init__(self, ctx, grays, K, Twcs, boxes_list, lines_list, opts):
+        self.ctx = ctx
+        grays = np.ascontiguousarray(grays, np.uint8)
+        self.F, self.H, self.W = grays.shape
+        K = np.ascontiguousarray(K, np.float64).reshape(3, 3)
+        T = np.ascontiguousarray(Twcs, np.float64).reshape(self.F, 16)
+        bo = np.zeros(self.F + 1, np.int32)
+        lo = np.zeros(self.F + 1, np.int32)
+        for f in range(self.F):
+            bo[f + 1] = bo[f] + len(boxes_list[f])
+            lo[f + 1] = lo[f] + len(lines_list[f])
+        boxes = np.ascontiguousarray(np.concatenate([np.asarray(b, np.float64).reshape(-1, 5) for b in boxes_list] + [np.zeros((0, 5))]))
+        lines = np.ascontiguousarray(np.concatenate([np.asarray(l, np.float64).reshape(-1, 4) for l in lines_list] + [np.zeros((1, 4))]))
+        self.n_boxes = int(bo[-1])
+        self.max_cuboid_num = opts.max_cuboid_num
+        self._b = C.c_void_p()
+        r = lib().cs_cuboid_batch_create(ctx.ptr, self.F, self.W, self.H, _p(grays, C.c_uint8), _p(K, C.c_double), _p(T, C.c_double),
+                                         _p(bo, C.c_int), _p(boxes, C.c_double), _p(lo, C.c_int), _p(lines, C.c_double),
+                                         C.byref(opts), C.byref(self._b))
+        check(ctx.ptr, r, "cs_cuboid_batch_create")
+
+    def run(self):
+        check(self.ctx.ptr, lib().cs_cuboid_batch_run(self.ctx.ptr, self._b), "cs_cuboid_batch_run")
+
+    def read(self):
+        out = np.zeros((max(self.n_boxes, 1), self.max_cuboid_num), CUBOID_DTYPE)
+        counts = np.zeros(max(self.n_boxes, 1), np.int32)
+        check(self.ctx.ptr, lib().cs_cuboid_batch_read(self.ctx.ptr, self._b, out.ctypes.data_as(C.c_void_p), _p(counts, C.c_int)),
+              "cs_cuboid_batch_read")
+        return [out[i, :counts[i]].copy() for i in range(self.n_boxes)]
+
+    def stats(self):
+        v = [C.c_long() for _ in range(4)]
+        check(self.ctx.ptr, lib().cs_cuboid_batch_stats(self.ctx.ptr, self._b, *[C.byref(x) for x in v]), "cs_cuboid_batch_stats")
+        return dict(zip(("n_units", "roi_pixels", "n_hypotheses", "n_valid"), [x.value for x in v]))
+
+    def unit(self, u, rows_cap=400000):
+        dims = (C.c_int * 12)()
+        check(self.ctx.ptr, lib().cs_cuboid_batch_unit(self.ctx.ptr, self._b, u, dims, None, None, None, 0, None, 0), "cs_cuboid_batch_unit")
+        x, y, w, h, cap, nvalid, nmerged, nyaw, frame, box, hs, n_hs = list(dims)
+        edges = np.zeros((h, w), np.uint8)
+        dist = np.zeros((h, w), np.float32)
+        rows = np.zeros((max(nvalid, 1), 25), np.float64)
+        merged = np.zeros((max(nmerged, 1), 4), np.float64)
+        check(self.ctx.ptr, lib().cs_cuboid_batch_unit(self.ctx.ptr, self._b, u, dims, _p(edges, C.c_uint8), _p(dist, C.c_float),
+                                                       _p(rows, C.c_double), max(nvalid, 1), _p(merged, C.c_double), max(nmerged, 1)),
+              "cs_cuboid_batch_unit")
+        return {"roi": (x, y, w, h), "frame": frame, "box": box, "hs": hs, "n_hs": n_hs, "n_valid": nvalid, "n_yaw": nyaw, "edges": edges, "dist": dist, "rows": rows[:nvalid],
+                "merged": merged[:nmerged]}
+
+    def close(self):
+        if self._b:
+            lib().cs_cuboid_batch_destroy(self.ctx.ptr, self._b)
+            self._b = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

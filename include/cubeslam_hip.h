@@ -1,0 +1,142 @@
+/*
+ * cubeslam_hip.h -- C-ABI of libcubeslam_hip.so: MI355X (gfx950) kernels for CubeSLAM's per-frame hot path.
+ *
+ * Plain C, POD pointers and sizes only.  Every entry point cites the reference (shichaoy/cube_slam) interface
+ * it replaces.  All functions return 0 (CS_OK) or a negative cs_status; they never throw and never fall back to
+ * a CPU path: without a usable HIP device cs_create() fails with CS_ERR_NO_DEVICE.
+ *
+ * Threading: one cs_ctx per host thread / HIP stream (the reference objects are not re-entrant either:
+ * detect_3d_cuboid.h:55-57 keeps cam_pose state, ORBextractor.h:85 keeps the pyramid).
+ */
+#ifndef CUBESLAM_HIP_H
+#define CUBESLAM_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define CS_VERSION 100
+
+typedef enum cs_status {
+    CS_OK = 0,
+    CS_ERR_NO_DEVICE = -1,   /* no HIP device / runtime error at create */
+    CS_ERR_BAD_ARG = -2,     /* null pointer, negative size, ROI outside image (cv::Rect assert in the reference) */
+    CS_ERR_HIP = -3,         /* a HIP runtime call failed; see cs_last_error() */
+    CS_ERR_CAPACITY = -4,    /* an internal fixed capacity was exceeded (e.g. > CS_MAX_ROI_LINES lines in one box) */
+    CS_ERR_NOMEM = -5
+} cs_status;
+
+typedef struct cs_ctx cs_ctx;
+
+/* Creates a context bound to HIP device `device_id` with its own stream. */
+int cs_create(int device_id, cs_ctx **out);
+void cs_destroy(cs_ctx *ctx);
+const char *cs_last_error(const cs_ctx *ctx);
+int cs_version(void);
+/* Blocks until all work queued on the context's stream is done. */
+int cs_sync(cs_ctx *ctx);
+
+/* Per-kernel hipEvent timing on the context's stream (replaces ca::Profiler::tictoc,
+ * dependency/tictoc_profiler/src/profiler.cpp:40-67).  Disabled by default. */
+int cs_timing_enable(cs_ctx *ctx, int on);
+int cs_timing_reset(cs_ctx *ctx);
+/* total milliseconds and launch count recorded for kernel `name` since the last reset; unknown name -> 0,0 */
+int cs_timing_get(cs_ctx *ctx, const char *name, double *total_ms, long *count);
+
+/* ===================================================================== detect_3d_cuboid
+ * Replaces detect_3d_cuboid::detect_cuboid (detect_3d_cuboid/include/detect_3d_cuboid/detect_3d_cuboid.h:62-63,
+ * detect_3d_cuboid/src/box_proposal_detail.cpp:56-557) and everything it calls in object_3d_util.cpp. */
+
+#define CS_MAX_ROI_LINES 1024
+
+typedef struct cs_cuboid_opts {          /* public members of class detect_3d_cuboid, detect_3d_cuboid.h:65-79 */
+    int consider_config_1;
+    int consider_config_2;
+    int whether_sample_cam_roll_pitch;
+    int whether_sample_bbox_height;
+    int max_cuboid_num;
+    double nominal_skew_ratio;
+    double max_cut_skew;
+    /* extensions; the defaults reproduce the constants hard-coded at box_proposal_detail.cpp:126-128,197 */
+    double yaw_range_deg;                /* 45 */
+    double yaw_step_deg;                 /* 6  */
+    int canny_low;                       /* 80 */
+    int canny_high;                      /* 200 */
+} cs_cuboid_opts;
+
+typedef struct cs_cuboid {               /* class cuboid, detect_3d_cuboid.h:15-36 */
+    double pos[3];
+    double scale[3];
+    double rotY;
+    double box_config_type[2];
+    int32_t box_corners_2d[16];          /* 2x8 row-major */
+    double box_corners_3d_world[24];     /* 3x8 row-major */
+    double rect_detect_2d[4];
+    double edge_distance_error;
+    double edge_angle_error;
+    double normalized_error;
+    double skew_ratio;
+    double down_expand_height;
+    double camera_roll_delta;
+    double camera_pitch_delta;
+} cs_cuboid;
+
+void cs_cuboid_default_opts(cs_cuboid_opts *opts);
+
+/*
+ * One frame, host buffers in / host buffers out (the drop-in call; H2D + kernels + D2H).
+ *   img      : height x width x channels u8, row stride `stride` bytes; channels 1 (gray) or 3 (BGR, converted like
+ *              cv::cvtColor(CV_BGR2GRAY), box_proposal_detail.cpp:62-66)
+ *   K        : 3x3 row-major calibration (set_calibration, box_proposal_detail.cpp:36-40)
+ *   Twc      : 4x4 row-major camera-to-world (transToWolrd)
+ *   boxes    : n_boxes x 5  [x y w h prob], 0-based (obj_bbox_coors)
+ *   lines    : n_lines x 4  [x1 y1 x2 y2] (all_lines_raw; copied, like the by-value MatrixXd of the reference)
+ *   out      : n_boxes * max_cuboid_num records; box b's cuboids are out[b*max_cuboid_num + i], i < counts[b],
+ *              sorted by combined score (ObjectSet order, box_proposal_detail.cpp:517-536)
+ */
+int cs_cuboid_detect(cs_ctx *ctx, const uint8_t *img, int width, int height, int channels, int stride,
+                     const double *K, const double *Twc, const double *boxes, int n_boxes,
+                     const double *lines, int n_lines, const cs_cuboid_opts *opts,
+                     cs_cuboid *out, int *counts);
+
+/*
+ * Batched, device-resident form (BASELINE config 4: many frames x boxes).  create() uploads everything to HBM and
+ * plans the arenas; run() only launches kernels on the context's stream (asynchronous); read() synchronises and
+ * copies results back.  All frames share width/height/K/opts.
+ *   gray        : n_frames x height x width u8, densely packed
+ *   Twc         : n_frames x 16
+ *   box_offsets : n_frames+1 prefix offsets into `boxes` (rows)
+ *   line_offsets: n_frames+1 prefix offsets into `lines` (rows)
+ */
+typedef struct cs_cuboid_batch cs_cuboid_batch;
+int cs_cuboid_batch_create(cs_ctx *ctx, int n_frames, int width, int height, const uint8_t *gray,
+                           const double *K, const double *Twc, const int *box_offsets, const double *boxes,
+                           const int *line_offsets, const double *lines, const cs_cuboid_opts *opts,
+                           cs_cuboid_batch **out);
+int cs_cuboid_batch_run(cs_ctx *ctx, cs_cuboid_batch *b);
+/* out: total_boxes * max_cuboid_num, counts: total_boxes */
+int cs_cuboid_batch_read(cs_ctx *ctx, cs_cuboid_batch *b, cs_cuboid *out, int *counts);
+void cs_cuboid_batch_destroy(cs_ctx *ctx, cs_cuboid_batch *b);
+
+/* Workload facts for roofline accounting (valid after run + sync): number of (box, height-sample) units, total ROI
+ * pixels A, total enumerated hypotheses, total valid proposals. */
+int cs_cuboid_batch_stats(cs_ctx *ctx, cs_cuboid_batch *b, long *n_units, long *roi_pixels, long *n_hypotheses,
+                          long *n_valid);
+
+/* Introspection for parity tests (after run).  unit = index over (frame, box, height-sample) in that order.
+ *   dims    : [roi_x, roi_y, roi_w, roi_h, n_hyp_capacity, n_valid, n_merged_lines, n_yaw, frame, box, height_sample, n_height_samples]
+ *   edges   : roi_w*roi_h u8 Canny output (0/255), may be NULL
+ *   dist    : roi_w*roi_h f32 distance map, may be NULL
+ *   rows    : n_valid x 25 doubles in the reference's row layout
+ *             [cfg, vp1pos, yaw, top_id, dist/diag, angle, hExp, roll, pitch, x0..x7, y0..y7], may be NULL (cap rows_cap)
+ *   merged  : n_merged_lines x 4 doubles, may be NULL (cap merged_cap rows)
+ */
+int cs_cuboid_batch_unit(cs_ctx *ctx, cs_cuboid_batch *b, int unit, int dims[12], uint8_t *edges, float *dist,
+                         double *rows, long rows_cap, double *merged, long merged_cap);
+
+#ifdef __cplusplus
+}
+#endif
+#endif
