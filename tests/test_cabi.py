@@ -1,0 +1,60 @@
+"""CPU tests of the drop-in boundary: the C-ABI library loads and exports every symbol include/*.h declares
+(no compute calls without a GPU), struct layouts match the Python mirrors, and there is no CPU fallback."""
+import ctypes as C
+import glob
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared_functions():
+    names = []
+    for h in glob.glob(os.path.join(ROOT, "include", "*.h")):
+        src = open(h).read()
+        src = re.sub(r"/\*.*?\*/", "", src, flags=re.S)
+        names += re.findall(r"\b(cs_[a-z0-9_]+)\s*\(", src)
+    return sorted(set(names))
+
+
+def test_library_exports_every_declared_symbol():
+    from cube_slam_amd import _lib
+    lib = _lib.lib()
+    names = _declared_functions()
+    assert len(names) >= 15
+    missing = [n for n in names if not hasattr(lib, n)]
+    assert not missing, missing
+
+
+def test_no_cpu_fallback_without_device():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from cube_slam_amd import _lib
+    with pytest.raises(_lib.CubeSlamError):
+        _lib.Context(0)
+
+
+def test_struct_layouts():
+    import numpy as np
+    from cube_slam_amd import cuboid
+    from oracle import pyoracle
+    assert cuboid.CUBOID_DTYPE.itemsize == 416 == pyoracle.CUBOID_DTYPE.itemsize
+    assert C.sizeof(cuboid.CuboidOpts) == 64
+    o = cuboid.CuboidOpts()
+    from cube_slam_amd import _lib
+    _lib.lib().cs_cuboid_default_opts(C.byref(o))
+    assert (o.consider_config_1, o.consider_config_2, o.max_cuboid_num, o.yaw_step_deg, o.canny_low, o.canny_high) == (1, 1, 1, 6.0, 80, 200)
+    assert np.dtype(cuboid.CUBOID_DTYPE).fields["box_corners_3d_world"][1] == 136
+
+
+def test_product_does_not_import_oracle():
+    """The oracle is test infrastructure: nothing under cube_slam_amd/ or include/ may reference it."""
+    bad = []
+    for pat in ("cube_slam_amd/**/*.py", "cube_slam_amd/**/*.hip", "cube_slam_amd/**/*.h", "cube_slam_amd/**/*.cpp", "include/*.h"):
+        for f in glob.glob(os.path.join(ROOT, pat), recursive=True):
+            if re.search(r"oracle|liboracle", open(f).read()):
+                bad.append(f)
+    assert not bad, bad
