@@ -361,56 +361,77 @@ __global__ void __launch_bounds__(256) cuboid_canny_nms(const Unit *units, const
         }
         long p = (long)y * U.roi_w + x;
         emap[U.pix_off + p] = code;
-        if (code) lab[U.pix_off + p] = (int)p;
+        if (code) lab[U.pix_off + p] = code == 2 ? (int)p : (int)(p + (long)U.roi_w * U.roi_h);
     }
 }
 
 __device__ __forceinline__ int lab_load(const int *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
-__device__ __forceinline__ int uf_find(const int *lab, int x) {
+// Union-find over candidate pixels.  Node id of pixel p: p if strong (mag > high), p + A if weak; lab[p] holds the parent
+// id; the root of a component is its smallest id, so a component contains a strong pixel iff its root id < A.
+__device__ __forceinline__ int uf_find(int *lab, int x, int A) { // with path halving (ids only ever decrease along a path)
     while (true) {
-        int v = lab_load(lab + x);
-        if (v < 0 || v == x) return x;
-        x = v;
+        int *px = lab + (x >= A ? x - A : x);
+        int v = lab_load(px);
+        if (v == x) return x;
+        int g = lab_load(lab + (v >= A ? v - A : v));
+        if (g == v) return v;
+        atomicMin(px, g);
+        x = g;
     }
 }
-__device__ inline void uf_union(int *lab, int a, int b) {
+__device__ inline void uf_union(int *lab, int a, int b, int A) {
     while (true) {
-        a = uf_find(lab, a);
-        b = uf_find(lab, b);
+        a = uf_find(lab, a, A);
+        b = uf_find(lab, b, A);
         if (a == b) return;
         if (a < b) { int t = a; a = b; b = t; } // a > b: hook a under b
-        int old = atomicMin(lab + a, b);
+        int old = atomicMin(lab + (a >= A ? a - A : a), b);
         if (old == a) return;
         a = old; // a was no longer a root: keep uniting (old, b)
     }
 }
 
-// stage 0: union with W / NW / N / NE candidate neighbours; stage 1: strong pixels mark their root (negative label);
-// stage 2: candidates become 255 iff their root is marked.  Kernel boundaries are the global syncs.
+// stage 0: union with W / NW / N / NE candidate neighbours; stage 1: candidates become 255 iff their root is a strong
+// pixel.  The kernel boundary is the global sync.  16 pixels per thread (one 16-byte load; edge maps are sparse).
 __global__ void __launch_bounds__(256) cuboid_canny_cc(const Unit *units, uint8_t *emap, int *lab, int stage) {
+    __shared__ int s_list[4096];
+    __shared__ int s_n;
     const Unit &U = units[blockIdx.y];
     const long A = (long)U.roi_w * U.roi_h;
+    if ((long)blockIdx.x * 4096 >= A) return;
     uint8_t *em = emap + U.pix_off;
     int *lb = lab + U.pix_off;
-    for (int k = 0; k < 4; k++) {
-        long p = (long)blockIdx.x * 1024 + k * 256 + threadIdx.x;
-        if (p >= A) return;
-        uint8_t c = em[p];
-        if (!c) continue;
-        if (stage == 0) {
-            int x = (int)(p % U.roi_w), y = (int)(p / U.roi_w);
-            if (x > 0 && em[p - 1]) uf_union(lb, (int)p, (int)p - 1);
-            if (y > 0) {
-                long q = p - U.roi_w;
-                if (x > 0 && em[q - 1]) uf_union(lb, (int)p, (int)q - 1);
-                if (em[q]) uf_union(lb, (int)p, (int)q);
-                if (x + 1 < U.roi_w && em[q + 1]) uf_union(lb, (int)p, (int)q + 1);
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    const long p0 = ((long)blockIdx.x * 256 + threadIdx.x) * 16;
+    if (p0 < A) {
+        uint4 v = *reinterpret_cast<const uint4 *>(em + p0); // pix_off and the arena padding are multiples of 64
+        if ((v.x | v.y | v.z | v.w) != 0) {
+            const unsigned wd[4] = {v.x, v.y, v.z, v.w};
+            for (int k = 0; k < 16; k++) {
+                unsigned c = (wd[k >> 2] >> ((k & 3) * 8)) & 255u;
+                if (c && p0 + k < A) s_list[atomicAdd(&s_n, 1)] = (int)(p0 + k) * 2 + (c == 2 ? 1 : 0);
             }
-        } else if (stage == 1) {
-            if (c == 2) { int r = uf_find(lb, (int)p); __hip_atomic_store(lb + r, -1 - r, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+        }
+    }
+    __syncthreads();
+    const int n = s_n, iA = (int)A;
+    for (int e = threadIdx.x; e < n; e += 256) { // one candidate per thread: the dependent L2 round trips run in parallel
+        const int p = s_list[e] >> 1;
+        const int idp = (s_list[e] & 1) ? p : p + iA;
+        if (stage == 0) {
+            int x = p % U.roi_w, y = p / U.roi_w;
+            auto nid = [&](int q) { uint8_t cq = em[q]; return cq == 0 ? -1 : (cq == 2 ? q : q + iA); };
+            int nb;
+            if (x > 0 && (nb = nid(p - 1)) >= 0) uf_union(lb, idp, nb, iA);
+            if (y > 0) {
+                int q = p - U.roi_w;
+                if (x > 0 && (nb = nid(q - 1)) >= 0) uf_union(lb, idp, nb, iA);
+                if ((nb = nid(q)) >= 0) uf_union(lb, idp, nb, iA);
+                if (x + 1 < U.roi_w && (nb = nid(q + 1)) >= 0) uf_union(lb, idp, nb, iA);
+            }
         } else {
-            int r = uf_find(lb, (int)p);
-            em[p] = lab_load(lb + r) < 0 ? 255 : 0;
+            em[p] = uf_find(lb, idp, iA) < iA ? 255 : 0;
         }
     }
 }
@@ -482,6 +503,85 @@ __global__ void __launch_bounds__(256) cuboid_dt(const Unit *units, int n_units,
         __builtin_amdgcn_wave_barrier();
         int *sw = down; down = cur; cur = sw;
     }
+}
+
+// Workgroup-per-ROI variant (ROI width <= 1024): thread = column, rows sequential, ONE barrier per row.  Per row every
+// wave publishes its segment minimum and its first raw value; after the barrier each wave rebuilds its carry-in and the
+// two boundary neighbours of the row it just finished from those, so the up-row lives in registers (DPP wave shifts).
+// BWD runs the same recurrence on the mirrored image (scan position jj = tid <-> column W64-1-tid).
+template <bool BWD>
+__device__ __forceinline__ void dt_block_pass(const Unit &U, const uint8_t *em, int *tmp, float *out, int (*s_tot)[16], int (*s_first)[16]) {
+    const int w = U.roi_w, h = U.roi_h;
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6, W64 = nw * 64;
+    const int lo = BWD ? W64 - w : 0, hi = BWD ? W64 : w;
+    const bool active = tid >= lo && tid < hi;
+    const int j = BWD ? W64 - 1 - tid : tid;
+    const int init_carry = DT_INIT - (lo - 1) * DT_HV;
+    const int jl = 64 * wave - 1, jr = 64 * (wave + 1);
+    const bool l_act = jl >= lo && jl < hi, r_act = jr >= lo && jr < hi;
+    const float scale = 1.f / 65536.f;
+    int prev = DT_INIT, left_b = DT_INIT, right_b = DT_INIT;
+    auto row_of = [&](int r) { return BWD ? h - 1 - r : r; };
+    auto fetch = [&](int r) -> int { // input of scan row r for this thread's column (0 when out of range)
+        if (!active || r >= h) return 0;
+        long o = (long)row_of(r) * w + j;
+        return BWD ? tmp[o] : (int)em[o];
+    };
+    auto do_row = [&](int r, int curv) {
+        const int i = row_of(r);
+        int nl = __builtin_amdgcn_update_dpp(left_b, prev, 0x138, 0xf, 0xf, false);  // wave_shr:1 -> value of lane-1
+        int nr = __builtin_amdgcn_update_dpp(right_b, prev, 0x130, 0xf, 0xf, false); // wave_shl:1 -> value of lane+1
+        int uval = INT_MAX;
+        if (active) {
+            int c;
+            if (!BWD && curv != 0) c = 0; // edge pixel: source
+            else {
+                c = nl + DT_DIAG;
+                int t = prev + DT_HV; if (c > t) c = t;
+                t = nr + DT_DIAG; if (c > t) c = t;
+                if (BWD && c > curv) c = curv;
+            }
+            uval = c - tid * DT_HV;
+        }
+        int sc = wave_incl_min_scan(uval);
+        const int b = r & 1;
+        if (lane == 63) s_tot[b][wave] = sc;
+        if (lane == 0) s_first[b][wave] = uval;
+        __syncthreads();
+        int t = (lane < wave) ? s_tot[b][lane] : INT_MAX;
+        t = wave_incl_min_scan(t);
+        int carry = min(init_carry, __builtin_amdgcn_readlane(t, 63));
+        int v = min(sc, carry);
+        int val = DT_INIT;
+        if (active) {
+            val = v + tid * DT_HV;
+            if (BWD) out[(long)i * w + j] = (float)val * scale; else tmp[(long)i * w + j] = val;
+        }
+        prev = val;
+        left_b = l_act ? carry + jl * DT_HV : DT_INIT;
+        if (r_act) { int m2 = min(carry, s_tot[b][wave]); m2 = min(m2, s_first[b][wave + 1]); right_b = m2 + jr * DT_HV; }
+        else right_b = DT_INIT;
+    };
+    // rows in groups of 4 with the next group's inputs already in flight (global latency >> one row step)
+    int c0 = fetch(0), c1 = fetch(1), c2 = fetch(2), c3 = fetch(3);
+    for (int r = 0; r < h; r += 4) {
+        int n0 = fetch(r + 4), n1 = fetch(r + 5), n2 = fetch(r + 6), n3 = fetch(r + 7);
+        do_row(r, c0);
+        if (r + 1 < h) do_row(r + 1, c1);
+        if (r + 2 < h) do_row(r + 2, c2);
+        if (r + 3 < h) do_row(r + 3, c3);
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+    }
+}
+__global__ void __launch_bounds__(1024) cuboid_dt_block(const Unit *units, const uint8_t *emap, float *dist) {
+    __shared__ int s_tot[2][16], s_first[2][16];
+    const Unit &U = units[blockIdx.x];
+    const uint8_t *em = emap + U.pix_off;
+    int *tmp = (int *)(dist + U.pix_off);
+    dt_block_pass<false>(U, em, tmp, nullptr, s_tot, s_first);
+    __threadfence_block();
+    __syncthreads();
+    dt_block_pass<true>(U, em, tmp, dist + U.pix_off, s_tot, s_first);
 }
 
 // ------------------------------------------------------------------------------------------------ vanishing points
@@ -725,29 +825,41 @@ __device__ __forceinline__ unsigned long long dkey(double x) { // order-preservi
     unsigned long long b = (unsigned long long)__double_as_longlong(x);
     return (b >> 63) ? ~b : (b | 0x8000000000000000ull);
 }
-// k-th smallest (0-based) key among hypotheses with flag != 0; 8-bit MSB-first radix select.  All threads return it.
-__device__ unsigned long long block_select_kth(const double *vals, const uint8_t *flag, int n, int k, int *hist /*256*/, int *s_misc) {
+// The valid hypotheses of a unit are compacted (in order) into key arrays; every thread caches its first SEL_R entries
+// (entry e = tid + 256*k) in registers so the 8-bit radix-select passes run out of registers + LDS histograms.
+constexpr int SEL_R = 8;
+struct KeyCache { unsigned long long v[SEL_R]; };
+template <class F> __device__ __forceinline__ void for_keys(const KeyCache &c, const unsigned long long *gl, int n, F f) {
+#pragma unroll
+    for (int k = 0; k < SEL_R; k++) { int e = threadIdx.x + 256 * k; if (e < n) f(c.v[k], e); }
+    for (int e = threadIdx.x + 256 * SEL_R; e < n; e += 256) f(gl[e], e);
+}
+// k-th smallest (0-based) of n keys; MSB-first 8-bit radix select.  All threads return it.  blockDim.x == 256.
+__device__ unsigned long long block_select_kth(const KeyCache &c, const unsigned long long *gl, int n, int k, int *hist /*256*/, int *s_misc) {
     unsigned long long prefix = 0, mask = 0;
+    const int lane = threadIdx.x & 63;
     for (int pass = 0; pass < 8; pass++) {
         int shift = 56 - 8 * pass;
-        for (int i = threadIdx.x; i < 256; i += blockDim.x) hist[i] = 0;
+        hist[threadIdx.x] = 0;
         __syncthreads();
-        for (int i = threadIdx.x; i < n; i += blockDim.x)
-            if (flag[i]) {
-                unsigned long long key = dkey(vals[i]);
-                if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1);
+        for_keys(c, gl, n, [&](unsigned long long key, int) { if ((key & mask) == prefix) atomicAdd(&hist[(key >> shift) & 255], 1); });
+        __syncthreads();
+        if (threadIdx.x < 64) { // wave 0: 4 bins per lane, inclusive scan over lanes, locate the bin holding rank k
+            int h0 = hist[4 * lane], h1 = hist[4 * lane + 1], h2 = hist[4 * lane + 2], h3 = hist[4 * lane + 3];
+            int sum = h0 + h1 + h2 + h3, inc = sum;
+            for (int off = 1; off < 64; off <<= 1) { int t = __shfl_up(inc, off); if (lane >= off) inc += t; }
+            unsigned long long m = __ballot(inc > k);
+            int first = __ffsll((long long)m) - 1;
+            if (lane == first) {
+                int acc = inc - sum, bin = 4 * lane;
+                if (acc + h0 > k) {} else { acc += h0; bin++; if (acc + h1 > k) {} else { acc += h1; bin++; if (acc + h2 > k) {} else { acc += h2; bin++; } } }
+                s_misc[0] = bin; s_misc[1] = k - acc;
             }
-        __syncthreads();
-        if (threadIdx.x == 0) {
-            int acc = 0, bin = 0;
-            for (; bin < 256; bin++) { if (acc + hist[bin] > k) break; acc += hist[bin]; }
-            s_misc[0] = bin; s_misc[1] = k - acc;
         }
         __syncthreads();
         prefix |= (unsigned long long)s_misc[0] << shift;
         mask |= 0xffull << shift;
         k = s_misc[1];
-        __syncthreads();
     }
     return prefix;
 }
@@ -832,7 +944,8 @@ __device__ inline void corners_to_3d(const double *cx, const double *cy, const C
 __global__ void __launch_bounds__(256) cuboid_select(const Unit *units, UnitDyn *ud, const int *box_first_unit, const FrameDyn *fd,
                                                      const FrameInfo *fi, const CamRP *cam, const double *yaw, Calib cal, Opts o,
                                                      uint8_t *flag, const double *derr, const double *aerr, const double *corners,
-                                                     long hyp_total, double *score, double *nscore, cs_cuboid *out, int *counts) {
+                                                     long hyp_total, double *score, double *nscore, unsigned long long *ckey_d, unsigned long long *ckey_a,
+                                                     int *cidx, cs_cuboid *out, int *counts) {
     __shared__ int hist[256];
     __shared__ int s_misc[8];
     __shared__ int s_wave[8];
@@ -856,37 +969,69 @@ __global__ void __launch_bounds__(256) cuboid_select(const Unit *units, UnitDyn 
         uint8_t *fl = flag + U.hyp_off;
         const double *de = derr + U.hyp_off, *ae = aerr + U.hyp_off;
         // ---- fuse_normalize_scores_v2 (object_3d_util.cpp:495-565)
-        int n = block_ordered_visit(n_hyp, [&](int i) { return fl[i] != 0; }, [&](int, int) {}, s_wave);
+        unsigned long long *ckd = ckey_d + U.hyp_off, *cka = ckey_a + U.hyp_off;
+        int *ch = cidx + U.hyp_off;
+        const int n = block_ordered_visit(n_hyp, [&](int i) { return fl[i] != 0; },
+                                          [&](int i, int r) { ckd[r] = dkey(de[i]); cka[r] = dkey(ae[i]); ch[r] = i; }, s_wave);
+        __syncthreads();
+        KeyCache kd, ka;
+#pragma unroll
+        for (int k = 0; k < SEL_R; k++) { int e = tid + 256 * k; kd.v[k] = e < n ? ckd[e] : 0; ka.v[k] = e < n ? cka[e] : 0; }
         int branch_b = 0, n_kept = 0;
         if (n > 4) {
             int breaking_num = (int)round(float(n) / 3.0 * 2.0);
             int k = breaking_num - 1; // elements kept per criterion
-            unsigned long long vd = block_select_kth(de, fl, n_hyp, k - 1, hist, s_misc);
-            unsigned long long va = block_select_kth(ae, fl, n_hyp, k - 1, hist, s_misc);
-            unsigned long long va1 = block_select_kth(ae, fl, n_hyp, k, hist, s_misc);
-            int n_less = block_ordered_visit(n_hyp, [&](int i) { return fl[i] && dkey(de[i]) < vd; }, [&](int, int) {}, s_wave);
-            int need_eq = k - n_less; // ties at the threshold are kept in index order (std::partial_sort tie order pinned, D3)
-            block_ordered_visit(n_hyp, [&](int i) { return fl[i] && dkey(de[i]) == vd; },
-                                [&](int i, int rank) { if (rank < need_eq) fl[i] |= 4; }, s_wave);
-            block_ordered_visit(n_hyp, [&](int i) { return fl[i] && dkey(de[i]) < vd; }, [&](int i, int) { fl[i] |= 4; }, s_wave);
+            unsigned long long vd = block_select_kth(kd, ckd, n, k - 1, hist, s_misc);
+            unsigned long long va = block_select_kth(ka, cka, n, k - 1, hist, s_misc);
+            unsigned long long va1 = block_select_kth(ka, cka, n, k, hist, s_misc);
             __syncthreads();
-            if (va1 > va) { // angle criterion active: keep set = {angle <= a_k}, intersect
-                for (int i = tid; i < n_hyp; i += 256) if ((fl[i] & 4) && !(dkey(ae[i]) <= va)) fl[i] &= ~4;
-            } else
-                branch_b = 1; // final_keep_inds = dist_keep_inds, in (dist, index) order
+            if (tid == 0) { s_misc[2] = 0; s_misc[3] = 0; s_misc[4] = INT_MAX; }
+            __syncthreads();
+            {
+                int nl = 0, ne = 0;
+                for_keys(kd, ckd, n, [&](unsigned long long key, int) { nl += key < vd; ne += key == vd; });
+                for (int off = 32; off > 0; off >>= 1) { nl += __shfl_xor(nl, off); ne += __shfl_xor(ne, off); }
+                if (lane == 0) { atomicAdd(&s_misc[2], nl); atomicAdd(&s_misc[3], ne); }
+            }
+            __syncthreads();
+            const int need_eq = k - s_misc[2]; // ties at the threshold are kept in index order (std::partial_sort tie order pinned, D3)
+            if (need_eq < s_misc[3] && tid == 0) { // rare: more ties than room -> keep the first need_eq of them
+                int seen = 0;
+                for (int e = 0; e < n; e++) if (ckd[e] == vd && ++seen == need_eq) { s_misc[4] = e; break; }
+            }
+            __syncthreads();
+            const int e_star = s_misc[4];
+            const bool use_angle = va1 > va; // angle criterion active: keep set = {angle <= a_k}, intersect
+            if (!use_angle) branch_b = 1;    // final_keep_inds = dist_keep_inds, in (dist, index) order
+#pragma unroll
+            for (int kk = 0; kk < SEL_R; kk++) {
+                int e = tid + 256 * kk;
+                if (e < n) {
+                    bool ok = kd.v[kk] < vd || (kd.v[kk] == vd && e <= e_star);
+                    if (use_angle) ok = ok && ka.v[kk] <= va;
+                    if (ok) fl[ch[e]] |= 4;
+                }
+            }
+            for (int e = tid + 256 * SEL_R; e < n; e += 256) {
+                bool ok = ckd[e] < vd || (ckd[e] == vd && e <= e_star);
+                if (use_angle) ok = ok && cka[e] <= va;
+                if (ok) fl[ch[e]] |= 4;
+            }
         } else {
-            for (int i = tid; i < n_hyp; i += 256) if (fl[i]) fl[i] |= 4;
+            for (int e = tid; e < n; e += 256) fl[ch[e]] |= 4;
         }
         __syncthreads();
         // min / max over the kept set
         double mn_d = 1e6, mx_d = -1, mn_a = 1e6, mx_a = -1;
         int cntk = 0;
-        for (int i = tid; i < n_hyp; i += 256)
+        for (int e = tid; e < n; e += 256) {
+            const int i = ch[e];
             if (fl[i] & 4) {
                 double td = de[i], ta = ae[i];
                 mn_d = fmin(mn_d, td); mx_d = fmax(mx_d, td); mn_a = fmin(mn_a, ta); mx_a = fmax(mx_a, ta);
                 cntk++;
             }
+        }
         for (int off = 32; off > 0; off >>= 1) {
             mn_d = fmin(mn_d, __shfl_xor(mn_d, off)); mx_d = fmax(mx_d, __shfl_xor(mx_d, off));
             mn_a = fmin(mn_a, __shfl_xor(mn_a, off)); mx_a = fmax(mx_a, __shfl_xor(mx_a, off));
@@ -902,7 +1047,8 @@ __global__ void __launch_bounds__(256) cuboid_select(const Unit *units, UnitDyn 
         __syncthreads();
         // normalised score, 2D->3D, skew penalty, final-ranking candidate score
         int ncand = 0;
-        for (int i = tid; i < n_hyp; i += 256) {
+        for (int e = tid; e < n; e += 256) {
+            const int i = ch[e];
             if (!(fl[i] & 4)) continue;
             double dk = de[i], ak = ae[i], comb;
             if (n_kept > 1) { // whether_normalize_two_errors = true (:85)
@@ -1073,7 +1219,7 @@ struct cs_cuboid_batch {
     std::vector<Unit> units;
     std::vector<int> box_first_unit;
     long pix_total = 0, hyp_total = 0, vp_total = 0, line_rows = 0;
-    int max_tiles = 0, max_cc_blocks = 0, max_vp_blocks = 0, blocks_per_unit = 0;
+    int max_tiles = 0, max_cc_blocks = 0, max_vp_blocks = 0, blocks_per_unit = 0, max_roi_w = 0;
     // device
     uint8_t *d_gray = nullptr, *d_emap = nullptr, *d_flag = nullptr;
     int *d_lab = nullptr; // aliases d_dist
@@ -1083,6 +1229,7 @@ struct cs_cuboid_batch {
     Unit *d_units = nullptr; UnitDyn *d_ud = nullptr; int *d_box_first = nullptr, *d_status = nullptr, *d_counts = nullptr;
     VPEntry *d_vp = nullptr;
     double *d_derr = nullptr, *d_aerr = nullptr, *d_corners = nullptr, *d_score = nullptr, *d_nscore = nullptr;
+    unsigned long long *d_ckd = nullptr, *d_cka = nullptr; int *d_cidx = nullptr;
     cs_cuboid *d_out = nullptr;
 };
 
@@ -1101,7 +1248,7 @@ void cs_cuboid_batch_destroy(cs_ctx *ctx, cs_cuboid_batch *b) {
     if (ctx) { hipSetDevice(ctx->device); hipStreamSynchronize(ctx->stream); }
     void *ptrs[] = {b->d_gray, b->d_emap, b->d_flag, b->d_dist, b->d_fi, b->d_fd, b->d_cam, b->d_yaw, b->d_lines_in, b->d_lines_al,
                     b->d_mlines, b->d_mangle, b->d_mmid, b->d_units, b->d_ud, b->d_box_first, b->d_status, b->d_counts, b->d_vp,
-                    b->d_derr, b->d_aerr, b->d_corners, b->d_score, b->d_nscore, b->d_out};
+                    b->d_derr, b->d_aerr, b->d_corners, b->d_score, b->d_nscore, b->d_ckd, b->d_cka, b->d_cidx, b->d_out};
     for (void *p : ptrs) if (p) hipFree(p);
     delete b;
 }
@@ -1182,8 +1329,9 @@ int cs_cuboid_batch_create(cs_ctx *ctx, int n_frames, int width, int height, con
                 U.hyp_off = b->hyp_total; b->hyp_total += ((long)U.hyp_cap + 63) / 64 * 64;
                 U.vp_off = (int)b->vp_total; b->vp_total += (long)rp_cap * o.yaw_cap;
                 U.line_off = (int)b->line_rows; b->line_rows += std::min(fi[f].n_lines, CS_MAX_ROI_LINES);
+                b->max_roi_w = std::max(b->max_roi_w, U.roi_w);
                 b->max_tiles = std::max(b->max_tiles, ((U.roi_w + NMS_TW - 1) / NMS_TW) * ((U.roi_h + NMS_TH - 1) / NMS_TH));
-                b->max_cc_blocks = std::max(b->max_cc_blocks, (int)(((long)U.roi_w * U.roi_h + 1023) / 1024));
+                b->max_cc_blocks = std::max(b->max_cc_blocks, (int)(((long)U.roi_w * U.roi_h + 4095) / 4096));
                 b->blocks_per_unit = std::max(b->blocks_per_unit, (U.hyp_cap + SWEEP_HB - 1) / SWEEP_HB);
                 b->units.push_back(U);
             }
@@ -1220,6 +1368,9 @@ int cs_cuboid_batch_create(cs_ctx *ctx, int n_frames, int width, int height, con
     A_(cs_dalloc(ctx, &b->d_corners, (size_t)b->hyp_total * 16));
     A_(cs_dalloc(ctx, &b->d_score, (size_t)b->hyp_total));
     A_(cs_dalloc(ctx, &b->d_nscore, (size_t)b->hyp_total));
+    A_(cs_dalloc(ctx, &b->d_ckd, (size_t)b->hyp_total));
+    A_(cs_dalloc(ctx, &b->d_cka, (size_t)b->hyp_total));
+    A_(cs_dalloc(ctx, &b->d_cidx, (size_t)b->hyp_total));
     A_(cs_dalloc(ctx, &b->d_out, (size_t)n_boxes * o.max_cuboid_num));
     A_(cs_h2d(ctx, b->d_gray, gray, npx));
     A_(cs_h2d(ctx, b->d_fi, fi.data(), (size_t)n_frames));
@@ -1245,10 +1396,14 @@ int cs_cuboid_batch_run(cs_ctx *ctx, cs_cuboid_batch *b) {
               b->d_mangle, b->d_mmid, b->d_status);
     CS_LAUNCH(ctx, "cuboid_canny_nms", cuboid_canny_nms, dim3(b->max_tiles, U), dim3(256), 0, b->d_units, b->d_gray, b->W, b->H, b->d_emap,
               b->d_lab, b->o.canny_low, b->o.canny_high);
-    for (int stage = 0; stage < 3; stage++)
+    for (int stage = 0; stage < 2; stage++)
         CS_LAUNCH(ctx, "cuboid_canny_cc", cuboid_canny_cc, dim3(b->max_cc_blocks, U), dim3(256), 0, b->d_units, b->d_emap, b->d_lab, stage);
-    const int wbuf = b->W + 2;
-    CS_LAUNCH(ctx, "cuboid_dt", cuboid_dt, dim3((U + 3) / 4), dim3(256), (size_t)wbuf * 2 * 4 * sizeof(int), b->d_units, U, b->d_emap, b->d_dist, wbuf);
+    if (b->max_roi_w <= 1024) {
+        CS_LAUNCH(ctx, "cuboid_dt", cuboid_dt_block, dim3(U), dim3(64 * ((b->max_roi_w + 63) / 64)), 0, b->d_units, b->d_emap, b->d_dist);
+    } else { // very wide ROIs: one wave per ROI, segments scanned serially
+        const int wbuf = b->W + 2;
+        CS_LAUNCH(ctx, "cuboid_dt", cuboid_dt, dim3((U + 3) / 4), dim3(256), (size_t)wbuf * 2 * 4 * sizeof(int), b->d_units, U, b->d_emap, b->d_dist, wbuf);
+    }
     CS_LAUNCH(ctx, "cuboid_vp", cuboid_vp, dim3(b->max_vp_blocks, U), dim3(256), 0, b->d_units, b->d_ud, b->d_fd, b->d_cam, b->d_yaw, b->o,
               b->d_mangle, b->d_mmid, b->d_vp);
     const int groups = (U + 7) / 8;
@@ -1256,7 +1411,7 @@ int cs_cuboid_batch_run(cs_ctx *ctx, cs_cuboid_batch *b) {
               b->blocks_per_unit, b->d_fd, b->d_yaw, b->o, b->d_vp, b->d_dist, b->d_flag, b->d_derr, b->d_aerr, b->d_corners, b->hyp_total);
     CS_LAUNCH(ctx, "cuboid_select", cuboid_select, dim3(b->n_boxes), dim3(256), 0, b->d_units, b->d_ud, b->d_box_first, b->d_fd, b->d_fi,
               b->d_cam, b->d_yaw, b->cal, b->o, b->d_flag, b->d_derr, b->d_aerr, b->d_corners, b->hyp_total, b->d_score, b->d_nscore,
-              b->d_out, b->d_counts);
+              b->d_ckd, b->d_cka, b->d_cidx, b->d_out, b->d_counts);
     CS_HIP(ctx, hipGetLastError());
     return CS_OK;
 }
