@@ -1,0 +1,628 @@
+// orb.hip -- ORB_SLAM2::ORBextractor on MI355X (gfx950).
+//
+// Replaces ORBextractor::operator() (reference orb_object_slam/src/ORBextractor.cc:1036-1099) and what it calls.
+// Built with -ffp-contract=off (the float rotation px*b + py*a feeds cvRound).  OpenCV semantics assumed: DESIGN.md section 7.
+//
+//   orb_resize       level l from l-1: cv::resize INTER_LINEAR 8-bit fixed point, coefficient tables built on the host
+//   orb_fast_score   S(p) = max over the 16 nine-pixel arcs of min(v - ring) / min(ring - v): p is a FAST-9/16 corner for
+//                    threshold t iff S > t and cv::FAST's cornerScore is S - 1 -- one threshold-free map serves both the
+//                    iniThFAST pass and the minThFAST fallback (:809-817)
+//   orb_cells        per 30x30-ish cell: strict 3x3 NMS inside the cell's own FAST window, threshold fallback per cell,
+//                    count (pass 0) / ordered emit (pass 1) with ballot prefix sums
+//   orb_scan_*       exclusive scans of the cell counts -> one compact candidate array for the whole batch
+//   (host)           DistributeOctTree, index based (orb_quadtree.h)
+//   orb_angle        IC_Angle: one wave per keypoint, a patch row per lane, integer moments, cv::fastAtan2
+//   orb_blur         7x7 sigma-2 Gaussian, 8-bit fixed point, LDS tile
+//   orb_desc         steered rBRIEF: one wave per keypoint, lane = test, 4 x ballot -> 4 x u64
+#include "common.h"
+#include "orb_quadtree.h"
+
+#include <cfloat>
+#include <cmath>
+
+namespace {
+
+constexpr int MAXL = 16;
+constexpr int HALF_PATCH = 15, PATCH = 31, EDGE_T = 19, MINB = EDGE_T - 3; // ORBextractor.cc:70-72,776
+constexpr int TW = 64, TH = 16;
+
+struct Lvl {
+    int w, h;
+    long off;                 // byte offset of this level inside one frame's pyramid
+    int nCols, nRows, wCell, hCell, maxBX, maxBY;
+    int cell_off;             // first cell of this level inside one frame's cell array
+    int tab_x, tab_y;         // offsets of the resize tables
+    float scale; int patch;   // mvScaleFactor[level], scaledPatchSize
+};
+struct Pyr {
+    int nlevels, cells_per_frame, ini_th, min_th;
+    long frame_stride;
+    int umax[HALF_PATCH + 1];
+    int gk[7];
+    Lvl l[MAXL];
+};
+
+__constant__ int c_ring[16][2] = {{0, 3}, {1, 3}, {2, 2}, {3, 1}, {3, 0}, {3, -1}, {2, -2}, {1, -3}, {0, -3}, {-1, -3}, {-2, -2}, {-3, -1}, {-3, 0}, {-3, 1}, {-2, 2}, {-1, 3}};
+__device__ const int d_pattern[1024] = {
+#include "orb_pattern.inc"
+};
+
+__global__ void __launch_bounds__(256) orb_resize(Pyr P, int level, uint8_t *pyr, const int *xofs, const short *ialpha, const int *yofs, const short *ibeta) {
+    const Lvl &D = P.l[level], &S = P.l[level - 1];
+    const int dx = blockIdx.x * 64 + (threadIdx.x & 63), dy = blockIdx.y * 4 + (threadIdx.x >> 6);
+    if (dx >= D.w || dy >= D.h) return;
+    uint8_t *base = pyr + (long)blockIdx.z * P.frame_stride;
+    const uint8_t *src = base + S.off;
+    const int sx = xofs[D.tab_x + dx], sy = yofs[D.tab_y + dy];
+    const int sx1 = min(sx + 1, S.w - 1), sy1 = min(sy + 1, S.h - 1);
+    const int a0 = ialpha[(D.tab_x + dx) * 2], a1 = ialpha[(D.tab_x + dx) * 2 + 1];
+    const int b0 = ibeta[(D.tab_y + dy) * 2], b1 = ibeta[(D.tab_y + dy) * 2 + 1];
+    const int r0 = src[(long)sy * S.w + sx] * a0 + src[(long)sy * S.w + sx1] * a1;
+    const int r1 = src[(long)sy1 * S.w + sx] * a0 + src[(long)sy1 * S.w + sx1] * a1;
+    base[D.off + (long)dy * D.w + dx] = (uint8_t)((((b0 * (r0 >> 4)) >> 16) + ((b1 * (r1 >> 4)) >> 16) + 2) >> 2);
+}
+
+// grid (tiles of the largest level, level, frame)
+__global__ void __launch_bounds__(256) orb_fast_score(Pyr P, const uint8_t *pyr, uint8_t *smap) {
+    const Lvl &L = P.l[blockIdx.y];
+    const int tiles_x = (L.w + TW - 1) / TW, tiles_y = (L.h + TH - 1) / TH;
+    if ((int)blockIdx.x >= tiles_x * tiles_y) return;
+    const int tx0 = (blockIdx.x % tiles_x) * TW, ty0 = (blockIdx.x / tiles_x) * TH;
+    __shared__ uint8_t g[TH + 6][TW + 8];
+    const uint8_t *img = pyr + (long)blockIdx.z * P.frame_stride + L.off;
+    for (int i = threadIdx.x; i < (TH + 6) * (TW + 6); i += 256) {
+        int ly = i / (TW + 6), lx = i % (TW + 6);
+        int X = tx0 + lx - 3, Y = ty0 + ly - 3;
+        g[ly][lx] = (X >= 0 && X < L.w && Y >= 0 && Y < L.h) ? img[(long)Y * L.w + X] : 0;
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & 63;
+    for (int ly = threadIdx.x >> 6; ly < TH; ly += 4) {
+        const int x = tx0 + lx, y = ty0 + ly;
+        if (x >= L.w || y >= L.h) continue;
+        int S = 0;
+        if (x >= 3 && y >= 3 && x < L.w - 3 && y < L.h - 3) {
+            const int v = g[ly + 3][lx + 3];
+            int d[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) d[k] = v - (int)g[ly + 3 + c_ring[k][1]][lx + 3 + c_ring[k][0]];
+            int lo2[16], hi2[16], lo4[16], hi4[16];
+#pragma unroll
+            for (int k = 0; k < 16; k++) { lo2[k] = min(d[k], d[(k + 1) & 15]); hi2[k] = max(d[k], d[(k + 1) & 15]); }
+#pragma unroll
+            for (int k = 0; k < 16; k++) { lo4[k] = min(lo2[k], lo2[(k + 2) & 15]); hi4[k] = max(hi2[k], hi2[(k + 2) & 15]); }
+            int sd = -1000, sb = 1000;
+#pragma unroll
+            for (int k = 0; k < 16; k++) {
+                int lo9 = min(min(lo4[k], lo4[(k + 4) & 15]), d[(k + 8) & 15]); // min over ring[k..k+8]
+                int hi9 = max(max(hi4[k], hi4[(k + 4) & 15]), d[(k + 8) & 15]);
+                sd = max(sd, lo9);  // darker arc: v - p > t on the whole arc
+                sb = min(sb, hi9);  // brighter arc: p - v > t  <=>  max(v - p) < -t
+            }
+            S = max(max(sd, -sb), 0);
+        }
+        smap[(long)blockIdx.z * P.frame_stride + L.off + (long)y * L.w + x] = (uint8_t)S;
+    }
+}
+
+// One wave per cell.  pass 0: survivors count + chosen threshold; pass 1: ordered emit at cell_base[cell] + rank.
+__global__ void __launch_bounds__(64) orb_cells(Pyr P, const uint8_t *smap, int pass, int *cell_count, const int *cell_base, float *cand) {
+    __shared__ uint8_t s[64][64];
+    const int f = blockIdx.y, lane = threadIdx.x;
+    int c = blockIdx.x, lv = 0;
+    while (lv + 1 < P.nlevels && c >= P.l[lv + 1].cell_off) lv++;
+    const Lvl &L = P.l[lv];
+    c -= L.cell_off;
+    if (c >= L.nCols * L.nRows) return;
+    const int ci = c / L.nCols, cj = c % L.nCols;
+    const int cell = f * P.cells_per_frame + blockIdx.x;
+    // cell window handed to cv::FAST (:790-807); FAST itself skips a 3-px frame of that window
+    const int iniX = MINB + cj * L.wCell, iniY = MINB + ci * L.hCell;
+    int maxX = iniX + L.wCell + 6, maxY = iniY + L.hCell + 6;
+    bool skip = iniY >= L.maxBY - 3 || iniX >= L.maxBX - 6;
+    if (maxX > L.maxBX) maxX = L.maxBX;
+    if (maxY > L.maxBY) maxY = L.maxBY;
+    const int ax0 = iniX + 3, ay0 = iniY + 3, aw = maxX - 3 - ax0, ah = maxY - 3 - ay0;
+    if (skip || aw <= 0 || ah <= 0) { if (pass == 0 && lane == 0) cell_count[cell] = 0; return; }
+    const uint8_t *S = smap + (long)f * P.frame_stride + L.off;
+    for (int i = lane; i < (ah + 2) * (aw + 2); i += 64) {
+        int ly = i / (aw + 2), lx = i % (aw + 2);
+        int X = ax0 + lx - 1, Y = ay0 + ly - 1;
+        bool in = lx >= 1 && lx <= aw && ly >= 1 && ly <= ah;
+        s[ly][lx] = in ? S[(long)Y * L.w + X] : 0;
+    }
+    __syncthreads();
+    int th = P.ini_th, total = 0;
+    for (int attempt = 0; attempt < 2; attempt++) {
+        if (pass == 1) { th = cell_count[cell] >> 24; }
+        const int base = pass == 1 ? cell_base[cell] : 0;
+        total = 0;
+        for (int p0 = 0; p0 < aw * ah; p0 += 64) {
+            const int p = p0 + lane;
+            bool keep = false;
+            int ly = 0, lx = 0, sc = 0;
+            if (p < aw * ah) {
+                ly = p / aw + 1; lx = p % aw + 1;
+                const int v = s[ly][lx];
+                if (v > th) {
+                    sc = v - 1; // cornerScore
+                    keep = true;
+#pragma unroll
+                    for (int dy = -1; dy <= 1; dy++)
+#pragma unroll
+                        for (int dx = -1; dx <= 1; dx++) {
+                            if (dx == 0 && dy == 0) continue;
+                            const int q = s[ly + dy][lx + dx];
+                            const int qs = q > th ? q - 1 : 0;
+                            keep = keep && sc > qs;
+                        }
+                }
+            }
+            unsigned long long m = __ballot(keep);
+            if (pass == 1 && keep) {
+                long o = (long)base + total + __popcll(m & ((1ull << lane) - 1));
+                cand[o * 3 + 0] = (float)(ax0 + lx - 1 - MINB); // view column + j*wCell  (:821-826)
+                cand[o * 3 + 1] = (float)(ay0 + ly - 1 - MINB);
+                cand[o * 3 + 2] = (float)sc;
+            }
+            total += __popcll(m);
+        }
+        if (pass == 1 || total > 0 || attempt == 1) break;
+        th = P.min_th; // :813-817
+    }
+    if (pass == 0 && lane == 0) cell_count[cell] = total | (th << 24);
+}
+
+// exclusive scan of the cell counts of one (frame, level) -> cell_base (relative), level_total
+__global__ void __launch_bounds__(64) orb_scan_cells(Pyr P, const int *cell_count, int *cell_base, int *level_total) {
+    const int f = blockIdx.y, lv = blockIdx.x, lane = threadIdx.x;
+    const Lvl &L = P.l[lv];
+    const int n = L.nCols * L.nRows, c0 = f * P.cells_per_frame + L.cell_off;
+    int run = 0;
+    for (int b = 0; b < n; b += 64) {
+        int i = b + lane;
+        int v = i < n ? (cell_count[c0 + i] & 0xffffff) : 0, inc = v;
+        for (int off = 1; off < 64; off <<= 1) { int t = __shfl_up(inc, off); if (lane >= off) inc += t; }
+        if (i < n) cell_base[c0 + i] = run + inc - v;
+        run += __shfl(inc, 63);
+    }
+    if (lane == 0) level_total[f * P.nlevels + lv] = run;
+}
+// exclusive scan over all (frame, level) totals (single wave) and rebase of the cells
+__global__ void __launch_bounds__(64) orb_scan_levels(int n, const int *level_total, int *level_base) {
+    const int lane = threadIdx.x;
+    int run = 0;
+    for (int b = 0; b < n; b += 64) {
+        int i = b + lane;
+        int v = i < n ? level_total[i] : 0, inc = v;
+        for (int off = 1; off < 64; off <<= 1) { int t = __shfl_up(inc, off); if (lane >= off) inc += t; }
+        if (i < n) level_base[i] = run + inc - v;
+        run += __shfl(inc, 63);
+    }
+    if (lane == 0) level_base[n] = run;
+}
+__global__ void orb_rebase_cells(Pyr P, int n_frames, const int *level_base, int *cell_base) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n_frames * P.cells_per_frame) return;
+    int f = i / P.cells_per_frame, c = i % P.cells_per_frame, lv = 0;
+    while (lv + 1 < P.nlevels && c >= P.l[lv + 1].cell_off) lv++;
+    cell_base[i] += level_base[f * P.nlevels + lv];
+}
+
+struct SelKP { float x, y, response; int level, frame; }; // level coordinates (minBorder already added)
+
+__device__ __forceinline__ float fast_atan2f(float y, float x) { // cv::fastAtan2
+    const float p1 = 0.9997878412794807f * (float)(180 / 3.1415926535897932384626433832795);
+    const float p3 = -0.3258083974640975f * (float)(180 / 3.1415926535897932384626433832795);
+    const float p5 = 0.1555786518463281f * (float)(180 / 3.1415926535897932384626433832795);
+    const float p7 = -0.04432655554792128f * (float)(180 / 3.1415926535897932384626433832795);
+    float ax = fabsf(x), ay = fabsf(y), a, c, c2;
+    if (ax >= ay) { c = ay / (ax + (float)DBL_EPSILON); c2 = c * c; a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c; }
+    else { c = ax / (ay + (float)DBL_EPSILON); c2 = c * c; a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c; }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+
+// IC_Angle (:74-101): one wave per keypoint, lane = patch row v = lane-15
+__global__ void __launch_bounds__(256) orb_angle(Pyr P, const uint8_t *pyr, const SelKP *sel, int n, float *angle) {
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (k >= n) return;
+    const SelKP kp = sel[k];
+    const Lvl &L = P.l[kp.level];
+    const uint8_t *img = pyr + (long)kp.frame * P.frame_stride + L.off;
+    const int cx = __float2int_rn(kp.x), cy = __float2int_rn(kp.y);
+    int m10 = 0, m01 = 0;
+    if (lane < PATCH) {
+        const int v = lane - HALF_PATCH, d = P.umax[v < 0 ? -v : v];
+        const uint8_t *row = img + (long)(cy + v) * L.w + cx;
+        int s1 = 0;
+        for (int u = -d; u <= d; u++) { int val = row[u]; s1 += val; m10 += u * val; }
+        m01 = v * s1;
+    }
+    for (int off = 32; off > 0; off >>= 1) { m10 += __shfl_xor(m10, off); m01 += __shfl_xor(m01, off); }
+    if (lane == 0) angle[k] = fast_atan2f((float)m01, (float)m10);
+}
+
+__device__ __forceinline__ int reflect101(int p, int len) {
+    if (len == 1) return 0;
+    while (p < 0 || p >= len) { if (p < 0) p = -p; else p = 2 * len - 2 - p; }
+    return p;
+}
+// GaussianBlur(7x7, sigma 2, BORDER_REFLECT_101) on u8 (:1078-1079): two 8-bit fixed point passes, (v + 2^15) >> 16
+__global__ void __launch_bounds__(256) orb_blur(Pyr P, const uint8_t *pyr, uint8_t *blur) {
+    const Lvl &L = P.l[blockIdx.y];
+    const int tiles_x = (L.w + TW - 1) / TW, tiles_y = (L.h + TH - 1) / TH;
+    if ((int)blockIdx.x >= tiles_x * tiles_y) return;
+    const int tx0 = (blockIdx.x % tiles_x) * TW, ty0 = (blockIdx.x / tiles_x) * TH;
+    __shared__ uint8_t g[TH + 6][TW + 8];
+    __shared__ int hp[TH + 6][TW];
+    const uint8_t *img = pyr + (long)blockIdx.z * P.frame_stride + L.off;
+    for (int i = threadIdx.x; i < (TH + 6) * (TW + 6); i += 256) {
+        int ly = i / (TW + 6), lx = i % (TW + 6);
+        int X = reflect101(tx0 + lx - 3, L.w), Y = reflect101(ty0 + ly - 3, L.h);
+        g[ly][lx] = img[(long)Y * L.w + X];
+    }
+    __syncthreads();
+    for (int i = threadIdx.x; i < (TH + 6) * TW; i += 256) {
+        int ly = i / TW, lx = i % TW, sum = 0;
+#pragma unroll
+        for (int t = 0; t < 7; t++) sum += g[ly][lx + t] * P.gk[t];
+        hp[ly][lx] = sum;
+    }
+    __syncthreads();
+    const int lx = threadIdx.x & 63;
+    for (int ly = threadIdx.x >> 6; ly < TH; ly += 4) {
+        const int x = tx0 + lx, y = ty0 + ly;
+        if (x >= L.w || y >= L.h) continue;
+        int sum = 0;
+#pragma unroll
+        for (int t = 0; t < 7; t++) sum += hp[ly + t][lx] * P.gk[t];
+        int v = (sum + (1 << 15)) >> 16;
+        blur[(long)blockIdx.z * P.frame_stride + L.off + (long)y * L.w + x] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+    }
+}
+
+// float sin/cos of the keypoint angle: evaluated in double with +,-,* only and rounded to float, so that host oracle
+// and device agree bit for bit
+__device__ __forceinline__ void sincos_f(float angle, float &so, float &co) {
+    const double x = (double)angle;
+    const double TWO_OVER_PI = 0.63661977236758134308, PIO2_HI = 1.57079632679489655800, PIO2_LO = 6.12323399573676603587e-17;
+    const double kd = floor(x * TWO_OVER_PI + 0.5);
+    const int k = (int)kd;
+    const double r = (x - kd * PIO2_HI) - kd * PIO2_LO;
+    const double r2 = r * r;
+    const double sp = -1.0 / 6.0 + r2 * (1.0 / 120.0 + r2 * (-1.0 / 5040.0 + r2 * (1.0 / 362880.0 + r2 * (-1.0 / 39916800.0 + r2 * (1.0 / 6227020800.0 + r2 * (-1.0 / 1307674368000.0))))));
+    const double cp = -1.0 / 2.0 + r2 * (1.0 / 24.0 + r2 * (-1.0 / 720.0 + r2 * (1.0 / 40320.0 + r2 * (-1.0 / 3628800.0 + r2 * (1.0 / 479001600.0 + r2 * (-1.0 / 87178291200.0 + r2 * (1.0 / 20922789888000.0)))))));
+    const double s = r + r * r2 * sp;
+    const double c = 1.0 + r2 * cp;
+    double ss, cc;
+    switch (k & 3) {
+    case 0: ss = s; cc = c; break;
+    case 1: ss = c; cc = -s; break;
+    case 2: ss = -s; cc = -c; break;
+    default: ss = -c; cc = s; break;
+    }
+    so = (float)ss; co = (float)cc;
+}
+
+// computeOrbDescriptor (:104-150) + keypoint finalisation (:1085-1096).  One wave per keypoint; lane l evaluates tests
+// 64r + l (r = 0..3), each ballot is 8 descriptor bytes.
+__global__ void __launch_bounds__(256) orb_desc(Pyr P, const uint8_t *blur, const SelKP *sel, const float *angle, int n, cs_keypoint *kps,
+                                                unsigned long long *desc) {
+    const int k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (k >= n) return;
+    const SelKP kp = sel[k];
+    const Lvl &L = P.l[kp.level];
+    const uint8_t *img = blur + (long)kp.frame * P.frame_stride + L.off;
+    const float ang = angle[k];
+    const float factorPI = (float)(3.1415926535897932384626433832795 / 180.f);
+    float a, b;
+    sincos_f(ang * factorPI, b, a);
+    const long cidx = (long)__float2int_rn(kp.y) * L.w + __float2int_rn(kp.x);
+    const long last = (long)L.w * L.h - 1;
+    for (int r = 0; r < 4; r++) {
+        const int t = r * 64 + lane;
+        int val[2];
+#pragma unroll
+        for (int e = 0; e < 2; e++) {
+            const float px = (float)d_pattern[4 * t + 2 * e], py = (float)d_pattern[4 * t + 2 * e + 1];
+            long o = cidx + (long)__float2int_rn(px * b + py * a) * L.w + __float2int_rn(px * a - py * b);
+            o = o < 0 ? 0 : (o > last ? last : o); // unchecked addressing of the reference, clamped
+            val[e] = img[o];
+        }
+        unsigned long long m = __ballot(val[0] < val[1]);
+        if (lane == 0) desc[(long)k * 4 + r] = m;
+    }
+    if (lane == 0) {
+        cs_keypoint o;
+        o.x = kp.x; o.y = kp.y;
+        if (kp.level != 0) { o.x = kp.x * L.scale; o.y = kp.y * L.scale; }
+        o.size = (float)L.patch; o.angle = ang; o.response = kp.response; o.octave = kp.level; o.class_id = -1;
+        kps[k] = o;
+    }
+}
+
+static inline int h_cvRound(double v) { return (int)std::lrint(v); }
+static inline int h_cvFloor(double v) { int i = (int)v; return i - (i > v); }
+static inline int h_cvCeil(double v) { int i = (int)v; return i + (i < v); }
+
+} // namespace
+
+struct cs_orb {
+    int nfeatures = 0, nlevels = 0, W = 0, H = 0, max_frames = 0, n_frames = 0;
+    float scaleFactor = 0;
+    std::vector<float> mvScaleFactor, mvInvScaleFactor, mvLevelSigma2, mvInvLevelSigma2;
+    std::vector<int> mnFeaturesPerLevel;
+    Pyr P{};
+    int max_tiles = 0;
+    long cand_cap = 0; // total candidates capacity (all frames)
+    // device
+    uint8_t *d_pyr = nullptr, *d_smap = nullptr, *d_blur = nullptr;
+    int *d_xofs = nullptr, *d_yofs = nullptr, *d_cell_count = nullptr, *d_cell_base = nullptr, *d_level_total = nullptr, *d_level_base = nullptr;
+    short *d_ialpha = nullptr, *d_ibeta = nullptr;
+    float *d_cand = nullptr, *d_angle = nullptr;
+    SelKP *d_sel = nullptr;
+    cs_keypoint *d_kps = nullptr;
+    unsigned long long *d_desc = nullptr;
+    long sel_cap = 0;
+    // host results of the last run
+    std::vector<int> level_base;          // n_frames*nlevels + 1
+    std::vector<cs_orb_host::Cand> cand;  // compact candidates
+    std::vector<SelKP> sel;
+    std::vector<int> frame_first;         // n_frames + 1 offsets into sel
+};
+
+extern "C" {
+
+void cs_orb_destroy(cs_ctx *ctx, cs_orb *e) {
+    if (!e) return;
+    if (ctx) { hipSetDevice(ctx->device); hipStreamSynchronize(ctx->stream); }
+    void *ptrs[] = {e->d_pyr, e->d_smap, e->d_blur, e->d_xofs, e->d_yofs, e->d_cell_count, e->d_cell_base, e->d_level_total, e->d_level_base,
+                    e->d_ialpha, e->d_ibeta, e->d_cand, e->d_angle, e->d_sel, e->d_kps, e->d_desc};
+    for (void *p : ptrs) if (p) hipFree(p);
+    delete e;
+}
+
+int cs_orb_create(cs_ctx *ctx, int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST, int width, int height,
+                  int max_frames, cs_orb **out) {
+    if (!ctx || !out || nfeatures < 1 || nlevels < 1 || nlevels > MAXL || !(scaleFactor > 1.0f) || width < 64 || height < 64 || max_frames < 1 ||
+        iniThFAST < 0 || iniThFAST > 255 || minThFAST < 0 || minThFAST > 255)
+        return CS_ERR_BAD_ARG;
+    *out = nullptr;
+    CS_HIP(ctx, hipSetDevice(ctx->device));
+    cs_orb *e = new (std::nothrow) cs_orb();
+    if (!e) return CS_ERR_NOMEM;
+    e->nfeatures = nfeatures; e->nlevels = nlevels; e->W = width; e->H = height; e->max_frames = max_frames; e->scaleFactor = scaleFactor;
+    // constructor tables, ORBextractor.cc:412-471
+    e->mvScaleFactor.resize(nlevels); e->mvLevelSigma2.resize(nlevels); e->mvInvScaleFactor.resize(nlevels); e->mvInvLevelSigma2.resize(nlevels);
+    e->mvScaleFactor[0] = 1.0f; e->mvLevelSigma2[0] = 1.0f;
+    for (int i = 1; i < nlevels; i++) { e->mvScaleFactor[i] = e->mvScaleFactor[i - 1] * scaleFactor; e->mvLevelSigma2[i] = e->mvScaleFactor[i] * e->mvScaleFactor[i]; }
+    for (int i = 0; i < nlevels; i++) { e->mvInvScaleFactor[i] = 1.0f / e->mvScaleFactor[i]; e->mvInvLevelSigma2[i] = 1.0f / e->mvLevelSigma2[i]; }
+    e->mnFeaturesPerLevel.resize(nlevels);
+    {
+        float factor = 1.0f / scaleFactor;
+        float nDesired = nfeatures * (1 - factor) / (1 - (float)std::pow((double)factor, (double)nlevels));
+        int sum = 0;
+        for (int level = 0; level < nlevels - 1; level++) { e->mnFeaturesPerLevel[level] = h_cvRound(nDesired); sum += e->mnFeaturesPerLevel[level]; nDesired *= factor; }
+        e->mnFeaturesPerLevel[nlevels - 1] = std::max(nfeatures - sum, 0);
+    }
+    Pyr &P = e->P;
+    P.nlevels = nlevels; P.ini_th = iniThFAST; P.min_th = minThFAST;
+    {
+        int v, v0, vmax = h_cvFloor(HALF_PATCH * std::sqrt(2.f) / 2 + 1), vmin = h_cvCeil(HALF_PATCH * std::sqrt(2.f) / 2);
+        const double hp2 = HALF_PATCH * HALF_PATCH;
+        for (v = 0; v <= vmax; ++v) P.umax[v] = h_cvRound(std::sqrt(hp2 - v * v));
+        for (v = HALF_PATCH, v0 = 0; v >= vmin; --v) { while (P.umax[v0] == P.umax[v0 + 1]) ++v0; P.umax[v] = v0; ++v0; }
+    }
+    { // cv::getGaussianKernel(7, 2, CV_32F) scaled to 8-bit fixed point
+        float cf[7];
+        double scale2X = -0.5 / (2.0 * 2.0), sum = 0;
+        for (int i = 0; i < 7; i++) { double x = i - 3.0; cf[i] = (float)std::exp(scale2X * x * x); sum += cf[i]; }
+        sum = 1. / sum;
+        for (int i = 0; i < 7; i++) { cf[i] = (float)(cf[i] * sum); P.gk[i] = h_cvRound(cf[i] * 256.f); }
+    }
+    std::vector<int> xofs, yofs;
+    std::vector<short> ialpha, ibeta;
+    long off = 0;
+    int cells = 0;
+    e->max_tiles = 0;
+    long cand_per_frame = 0;
+    auto sat_short = [](float v) { int i = h_cvRound(v); return (short)(i < -32768 ? -32768 : (i > 32767 ? 32767 : i)); };
+    for (int l = 0; l < nlevels; l++) {
+        Lvl &L = P.l[l];
+        float scale = e->mvInvScaleFactor[l];
+        L.w = h_cvRound((float)width * scale); L.h = h_cvRound((float)height * scale); // :1105-1106
+        L.off = off; off += ((long)L.w * L.h + 63) / 64 * 64;
+        L.maxBX = L.w - EDGE_T + 3; L.maxBY = L.h - EDGE_T + 3; // :778-779
+        const float fw = (float)(L.maxBX - MINB), fh = (float)(L.maxBY - MINB);
+        L.nCols = (int)(fw / 30.f); L.nRows = (int)(fh / 30.f);
+        if (L.nCols < 1 || L.nRows < 1) { L.nCols = L.nRows = 0; L.wCell = L.hCell = 1; }
+        else { L.wCell = (int)std::ceil(fw / L.nCols); L.hCell = (int)std::ceil(fh / L.nRows); }
+        if (L.wCell > 58 || L.hCell > 58) { delete e; return CS_ERR_CAPACITY; }
+        L.cell_off = cells; cells += L.nCols * L.nRows;
+        L.scale = e->mvScaleFactor[l]; L.patch = (int)(PATCH * e->mvScaleFactor[l]);
+        L.tab_x = (int)xofs.size(); L.tab_y = (int)yofs.size();
+        if (l > 0) { // cv::resize INTER_LINEAR coefficient tables (imgwarp.cpp), source = level l-1
+            const int sw = P.l[l - 1].w, sh = P.l[l - 1].h;
+            const double scale_x = 1. / ((double)L.w / sw), scale_y = 1. / ((double)L.h / sh);
+            for (int dx = 0; dx < L.w; dx++) {
+                float fx = (float)((dx + 0.5) * scale_x - 0.5);
+                int sx = h_cvFloor(fx);
+                fx -= sx;
+                if (sx < 0) { fx = 0; sx = 0; }
+                if (sx >= sw - 1) { fx = 0; sx = sw - 1; }
+                xofs.push_back(sx); ialpha.push_back(sat_short((1.f - fx) * 2048)); ialpha.push_back(sat_short(fx * 2048));
+            }
+            for (int dy = 0; dy < L.h; dy++) {
+                float fy = (float)((dy + 0.5) * scale_y - 0.5);
+                int sy = h_cvFloor(fy);
+                fy -= sy;
+                if (sy < 0) { fy = 0; sy = 0; }
+                if (sy >= sh - 1) { fy = 0; sy = sh - 1; }
+                yofs.push_back(sy); ibeta.push_back(sat_short((1.f - fy) * 2048)); ibeta.push_back(sat_short(fy * 2048));
+            }
+        }
+        e->max_tiles = std::max(e->max_tiles, ((L.w + TW - 1) / TW) * ((L.h + TH - 1) / TH));
+        cand_per_frame += (long)((L.w + 1) / 2) * ((L.h + 1) / 2);
+    }
+    P.frame_stride = off; P.cells_per_frame = cells;
+    e->cand_cap = cand_per_frame * max_frames;
+    e->sel_cap = (long)(nfeatures + 4 * nlevels + 64) * max_frames * 2;
+#define A_(call) do { int r__ = (call); if (r__ != CS_OK) { cs_orb_destroy(ctx, e); return r__; } } while (0)
+    A_(cs_dalloc(ctx, &e->d_pyr, (size_t)off * max_frames));
+    A_(cs_dalloc(ctx, &e->d_smap, (size_t)off * max_frames));
+    A_(cs_dalloc(ctx, &e->d_blur, (size_t)off * max_frames));
+    A_(cs_dalloc(ctx, &e->d_xofs, xofs.size()));
+    A_(cs_dalloc(ctx, &e->d_yofs, yofs.size()));
+    A_(cs_dalloc(ctx, &e->d_ialpha, ialpha.size()));
+    A_(cs_dalloc(ctx, &e->d_ibeta, ibeta.size()));
+    A_(cs_dalloc(ctx, &e->d_cell_count, (size_t)cells * max_frames));
+    A_(cs_dalloc(ctx, &e->d_cell_base, (size_t)cells * max_frames));
+    A_(cs_dalloc(ctx, &e->d_level_total, (size_t)nlevels * max_frames));
+    A_(cs_dalloc(ctx, &e->d_level_base, (size_t)nlevels * max_frames + 1));
+    A_(cs_dalloc(ctx, &e->d_cand, (size_t)e->cand_cap * 3));
+    A_(cs_dalloc(ctx, &e->d_sel, (size_t)e->sel_cap));
+    A_(cs_dalloc(ctx, &e->d_angle, (size_t)e->sel_cap));
+    A_(cs_dalloc(ctx, &e->d_kps, (size_t)e->sel_cap));
+    A_(cs_dalloc(ctx, &e->d_desc, (size_t)e->sel_cap * 4));
+    A_(cs_h2d(ctx, e->d_xofs, xofs.data(), xofs.size()));
+    A_(cs_h2d(ctx, e->d_yofs, yofs.data(), yofs.size()));
+    A_(cs_h2d(ctx, e->d_ialpha, ialpha.data(), ialpha.size()));
+    A_(cs_h2d(ctx, e->d_ibeta, ibeta.data(), ibeta.size()));
+    { hipError_t er = hipStreamSynchronize(ctx->stream); if (er != hipSuccess) { ctx->err = hipGetErrorString(er); cs_orb_destroy(ctx, e); return CS_ERR_HIP; } }
+#undef A_
+    *out = e;
+    return CS_OK;
+}
+
+int cs_orb_get_table(const cs_orb *e, int which, void *out) {
+    if (!e || !out) return CS_ERR_BAD_ARG;
+    const std::vector<float> *t = which == 0 ? &e->mvScaleFactor : which == 1 ? &e->mvInvScaleFactor : which == 2 ? &e->mvLevelSigma2 : which == 3 ? &e->mvInvLevelSigma2 : nullptr;
+    if (t) { memcpy(out, t->data(), t->size() * sizeof(float)); return CS_OK; }
+    if (which == 4) { memcpy(out, e->mnFeaturesPerLevel.data(), e->mnFeaturesPerLevel.size() * sizeof(int)); return CS_OK; }
+    return CS_ERR_BAD_ARG;
+}
+
+int cs_orb_upload(cs_ctx *ctx, cs_orb *e, const uint8_t *gray, int n_frames, int stride) {
+    if (!ctx || !e || !gray || n_frames < 1 || n_frames > e->max_frames || stride < e->W) return CS_ERR_BAD_ARG;
+    CS_HIP(ctx, hipSetDevice(ctx->device));
+    e->n_frames = n_frames;
+    for (int f = 0; f < n_frames; f++) // level 0 = the image itself (copyMakeBorder only adds the border, :1119-1123)
+        CS_HIP(ctx, hipMemcpy2DAsync(e->d_pyr + (long)f * e->P.frame_stride, (size_t)e->W, gray + (size_t)f * stride * e->H, (size_t)stride, (size_t)e->W,
+                                     (size_t)e->H, hipMemcpyHostToDevice, ctx->stream));
+    CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CS_OK;
+}
+
+int cs_orb_run(cs_ctx *ctx, cs_orb *e) {
+    if (!ctx || !e || e->n_frames < 1) return CS_ERR_BAD_ARG;
+    CS_HIP(ctx, hipSetDevice(ctx->device));
+    const Pyr &P = e->P;
+    const int F = e->n_frames, NL = P.nlevels;
+    // ---- GPU phase A: pyramid, FAST score map, per-cell NMS + ordered compaction
+    for (int l = 1; l < NL; l++)
+        CS_LAUNCH(ctx, "orb_resize", orb_resize, dim3((P.l[l].w + 63) / 64, (P.l[l].h + 3) / 4, F), dim3(256), 0, P, l, e->d_pyr, e->d_xofs, e->d_ialpha,
+                  e->d_yofs, e->d_ibeta);
+    CS_LAUNCH(ctx, "orb_fast_score", orb_fast_score, dim3(e->max_tiles, NL, F), dim3(256), 0, P, e->d_pyr, e->d_smap);
+    CS_LAUNCH(ctx, "orb_cells", orb_cells, dim3(P.cells_per_frame, F), dim3(64), 0, P, e->d_smap, 0, e->d_cell_count, e->d_cell_base, e->d_cand);
+    CS_LAUNCH(ctx, "orb_scan", orb_scan_cells, dim3(NL, F), dim3(64), 0, P, e->d_cell_count, e->d_cell_base, e->d_level_total);
+    CS_LAUNCH(ctx, "orb_scan", orb_scan_levels, dim3(1), dim3(64), 0, F * NL, e->d_level_total, e->d_level_base);
+    CS_LAUNCH(ctx, "orb_scan", orb_rebase_cells, dim3((F * P.cells_per_frame + 255) / 256), dim3(256), 0, P, F, e->d_level_base, e->d_cell_base);
+    e->level_base.resize((size_t)F * NL + 1);
+    int r = cs_d2h(ctx, e->level_base.data(), e->d_level_base, e->level_base.size()); if (r) return r;
+    CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const long total = e->level_base[(size_t)F * NL];
+    if (total > e->cand_cap) { ctx->err = "ORB candidate capacity exceeded"; return CS_ERR_CAPACITY; }
+    CS_LAUNCH(ctx, "orb_cells", orb_cells, dim3(P.cells_per_frame, F), dim3(64), 0, P, e->d_smap, 1, e->d_cell_count, e->d_cell_base, e->d_cand);
+    e->cand.resize((size_t)std::max<long>(total, 1));
+    r = cs_d2h(ctx, (float *)e->cand.data(), e->d_cand, (size_t)total * 3); if (r) return r;
+    hipEvent_t ev_cand = ctx->get_event();
+    CS_HIP(ctx, hipEventRecord(ev_cand, ctx->stream));
+    // the blur does not depend on the selection: queued behind the candidate copy, it overlaps the host quadtree
+    CS_LAUNCH(ctx, "orb_blur", orb_blur, dim3(e->max_tiles, NL, F), dim3(256), 0, P, e->d_pyr, e->d_blur);
+    CS_HIP(ctx, hipEventSynchronize(ev_cand));
+    ctx->pool.push_back(ev_cand);
+    // ---- host: DistributeOctTree per (frame, level), ORBextractor.cc:831-832
+    e->sel.clear();
+    e->frame_first.assign((size_t)F + 1, 0);
+    {
+        std::vector<std::vector<SelKP>> per((size_t)F * NL);
+#pragma omp parallel
+        {
+            cs_orb_host::QuadTree qt;
+            std::vector<int> idx;
+#pragma omp for schedule(dynamic, 1)
+            for (int fl = 0; fl < F * NL; fl++) {
+                const int f = fl / NL, l = fl % NL;
+                const Lvl &L = P.l[l];
+                const long b0 = e->level_base[fl], n = e->level_base[fl + 1] - b0;
+                if (n <= 0 || L.nCols == 0) continue;
+                const cs_orb_host::Cand *K = e->cand.data() + b0;
+                qt.distribute(K, (int)n, MINB, L.maxBX, MINB, L.maxBY, e->mnFeaturesPerLevel[l], idx);
+                std::vector<SelKP> &o = per[fl];
+                o.reserve(idx.size());
+                for (int id : idx) o.push_back(SelKP{K[id].x + MINB, K[id].y + MINB, K[id].response, l, f}); // :841-844
+            }
+        }
+        for (int f = 0; f < F; f++) {
+            e->frame_first[f] = (int)e->sel.size();
+            for (int l = 0; l < NL; l++) e->sel.insert(e->sel.end(), per[(size_t)f * NL + l].begin(), per[(size_t)f * NL + l].end());
+        }
+        e->frame_first[F] = (int)e->sel.size();
+    }
+    const int n = (int)e->sel.size();
+    if (n > e->sel_cap) { ctx->err = "ORB keypoint capacity exceeded"; return CS_ERR_CAPACITY; }
+    if (n == 0) return CS_OK;
+    // ---- GPU phase B: orientation, descriptors
+    r = cs_h2d(ctx, e->d_sel, e->sel.data(), (size_t)n); if (r) return r;
+    CS_LAUNCH(ctx, "orb_angle", orb_angle, dim3((n + 3) / 4), dim3(256), 0, P, e->d_pyr, e->d_sel, n, e->d_angle);
+    CS_LAUNCH(ctx, "orb_desc", orb_desc, dim3((n + 3) / 4), dim3(256), 0, P, e->d_blur, e->d_sel, e->d_angle, n, e->d_kps, e->d_desc);
+    CS_HIP(ctx, hipGetLastError());
+    return CS_OK;
+}
+
+int cs_orb_read(cs_ctx *ctx, cs_orb *e, cs_keypoint *kps, uint8_t *desc, int cap_per_frame, int *counts) {
+    if (!ctx || !e || !kps || !desc || !counts || cap_per_frame < 1) return CS_ERR_BAD_ARG;
+    int status = CS_OK;
+    for (int f = 0; f < e->n_frames; f++) {
+        const int b0 = e->frame_first[f], n = e->frame_first[f + 1] - b0;
+        counts[f] = std::min(n, cap_per_frame);
+        if (n > cap_per_frame) status = CS_ERR_CAPACITY;
+        int r = cs_d2h(ctx, kps + (size_t)f * cap_per_frame, e->d_kps + b0, (size_t)counts[f]); if (r) return r;
+        r = cs_d2h(ctx, desc + (size_t)f * cap_per_frame * 32, (const uint8_t *)(e->d_desc + (size_t)b0 * 4), (size_t)counts[f] * 32); if (r) return r;
+    }
+    CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return status;
+}
+
+int cs_orb_extract(cs_ctx *ctx, cs_orb *e, const uint8_t *gray, int n_frames, int stride, cs_keypoint *kps, uint8_t *desc, int cap_per_frame,
+                   int *counts) {
+    int r = cs_orb_upload(ctx, e, gray, n_frames, stride);
+    if (r == CS_OK) r = cs_orb_run(ctx, e);
+    if (r == CS_OK) r = cs_orb_read(ctx, e, kps, desc, cap_per_frame, counts);
+    return r;
+}
+
+int cs_orb_get_level(cs_ctx *ctx, cs_orb *e, int frame, int level, int blurred, uint8_t *out, int *w, int *h) {
+    if (!ctx || !e || frame < 0 || frame >= e->n_frames || level < 0 || level >= e->nlevels || !w || !h) return CS_ERR_BAD_ARG;
+    const Lvl &L = e->P.l[level];
+    *w = L.w; *h = L.h;
+    if (out) {
+        int r = cs_d2h(ctx, out, (blurred ? e->d_blur : e->d_pyr) + (long)frame * e->P.frame_stride + L.off, (size_t)L.w * L.h); if (r) return r;
+        CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return CS_OK;
+}
+
+int cs_orb_get_candidates(cs_ctx *ctx, cs_orb *e, int frame, int level, float *xyr, int cap, int *n) {
+    if (!ctx || !e || frame < 0 || frame >= e->n_frames || level < 0 || level >= e->nlevels || !n) return CS_ERR_BAD_ARG;
+    const size_t fl = (size_t)frame * e->nlevels + level;
+    if (e->level_base.size() <= fl + 1) return CS_ERR_BAD_ARG;
+    const long b0 = e->level_base[fl], cnt = e->level_base[fl + 1] - b0;
+    *n = (int)cnt;
+    if (xyr) for (long i = 0; i < cnt && i < cap; i++) { xyr[i * 3] = e->cand[b0 + i].x; xyr[i * 3 + 1] = e->cand[b0 + i].y; xyr[i * 3 + 2] = e->cand[b0 + i].response; }
+    return CS_OK;
+}
+
+} // extern "C"

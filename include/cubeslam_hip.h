@@ -136,6 +136,44 @@ int cs_cuboid_batch_stats(cs_ctx *ctx, cs_cuboid_batch *b, long *n_units, long *
 int cs_cuboid_batch_unit(cs_ctx *ctx, cs_cuboid_batch *b, int unit, int dims[12], uint8_t *edges, float *dist,
                          double *rows, long rows_cap, double *merged, long merged_cap);
 
+/* ===================================================================== ORBextractor
+ * Replaces ORB_SLAM2::ORBextractor (orb_object_slam/include/ORBextractor.h:46-117, src/ORBextractor.cc):
+ * constructor tables (:412-471), ComputePyramid (:1101-1125), ComputeKeyPointsOctTree (:766-853), IC_Angle (:74-101),
+ * 7x7 Gaussian blur + steered rBRIEF (:104-150,:1069-1098).  FAST scores / cell NMS / orientation / blur / descriptors
+ * run on the GPU; the order-dependent quadtree selection (DistributeOctTree :540-763) runs on the host between the two
+ * GPU phases. */
+typedef struct cs_keypoint {             /* cv::KeyPoint layout, 28 bytes */
+    float x, y;                          /* pt */
+    float size;
+    float angle;                         /* degrees, cv::fastAtan2 */
+    float response;                      /* FAST corner score */
+    int32_t octave;
+    int32_t class_id;                    /* -1 */
+} cs_keypoint;
+
+typedef struct cs_orb cs_orb;
+/* ORBextractor(nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST) for images of width x height; up to max_frames
+ * frames are processed per call (device buffers are sized once). */
+int cs_orb_create(cs_ctx *ctx, int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST,
+                  int width, int height, int max_frames, cs_orb **out);
+void cs_orb_destroy(cs_ctx *ctx, cs_orb *e);
+/* GetScaleFactors / GetInverseScaleFactors / GetScaleSigmaSquares / GetInverseScaleSigmaSquares (ORBextractor.h:63-83);
+ * which = 0..3, out has nlevels floats.  which = 4: mnFeaturesPerLevel as ints (out reinterpreted as int32). */
+int cs_orb_get_table(const cs_orb *e, int which, void *out);
+/* ORBextractor::operator() for n_frames gray images (host, row stride `stride`).  Per frame f: counts[f] keypoints at
+ * kps[f*cap_per_frame ...] and descriptors at desc[(f*cap_per_frame + i)*32], level-major order (:1065-1098).
+ * Returns CS_ERR_CAPACITY if a frame yields more than cap_per_frame keypoints. */
+int cs_orb_extract(cs_ctx *ctx, cs_orb *e, const uint8_t *gray, int n_frames, int stride,
+                   cs_keypoint *kps, uint8_t *desc, int cap_per_frame, int *counts);
+/* Device-resident form: upload once, run() = both GPU phases + host quadtree, read() = D2H of the results. */
+int cs_orb_upload(cs_ctx *ctx, cs_orb *e, const uint8_t *gray, int n_frames, int stride);
+int cs_orb_run(cs_ctx *ctx, cs_orb *e);
+int cs_orb_read(cs_ctx *ctx, cs_orb *e, cs_keypoint *kps, uint8_t *desc, int cap_per_frame, int *counts);
+/* Introspection for parity tests (after run): pyramid level (mvImagePyramid, ORBextractor.h:85) or its blurred copy;
+ * the FAST keypoints handed to DistributeOctTree (x, y, response; cell-major order). */
+int cs_orb_get_level(cs_ctx *ctx, cs_orb *e, int frame, int level, int blurred, uint8_t *out, int *w, int *h);
+int cs_orb_get_candidates(cs_ctx *ctx, cs_orb *e, int frame, int level, float *xyr, int cap, int *n);
+
 #ifdef __cplusplus
 }
 #endif

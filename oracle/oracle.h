@@ -106,6 +106,29 @@ int orc_detect_cuboid(const uint8_t *gray, int W, int H, const double *K, const 
 void orc_canny_dt_roi(const uint8_t *gray, int W, int H, int x0, int y0, int w, int h, int low, int high,
                       float *dist);
 
+/* ------------------------------------------------------------------ ORB extractor
+ * ORB_SLAM2::ORBextractor (orb_object_slam/src/ORBextractor.cc, include/ORBextractor.h). */
+typedef struct orc_keypoint { /* cv::KeyPoint layout (28 bytes) */
+    float x, y, size, angle, response;
+    int32_t octave, class_id;
+} orc_keypoint;
+typedef struct orc_orb orc_orb;
+
+orc_orb *orc_orb_create(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST);
+void orc_orb_destroy(orc_orb *e);
+/* ORBextractor::operator() (:1036-1099); returns the number of keypoints (<= cap), desc: n x 32 */
+int orc_orb_extract(orc_orb *e, const uint8_t *gray, int W, int H, orc_keypoint *kps, uint8_t *desc, int cap);
+/* introspection of the last extract() */
+int orc_orb_features_per_level(orc_orb *e, int *out);
+int orc_orb_level_dims(orc_orb *e, int level, int *w, int *h);
+int orc_orb_get_level(orc_orb *e, int level, int blurred, uint8_t *out);
+int orc_orb_get_candidates(orc_orb *e, int level, float *xyr, int cap); /* pre-quadtree FAST keypoints: x,y,response */
+/* cv::FAST(img, kps, threshold, true) on a w x h view; xyr gets x,y,score triplets; returns count */
+int orc_fast(const uint8_t *img, int stride, int w, int h, int threshold, float *xyr, int cap);
+float orc_fast_atan2(float y, float x);
+/* the float cos/sin the descriptor rotation uses (correctly rounded to float via a double evaluation) */
+void orc_sincos_f(float angle_rad, float *s, float *c);
+
 #ifdef __cplusplus
 }
 #endif

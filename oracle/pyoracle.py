@@ -150,3 +150,71 @@ def detect_cuboid(gray, K, Twc, boxes, lines, opts=None, debug=False, rows_cap=4
     if debug:
         dbg = {"row_count": rc, "rows": rows[: int(rc.sum())].copy()}
     return res, dbg
+
+
+# ----------------------------------------------------------------------------------------------- ORB extractor
+KEYPOINT_DTYPE = np.dtype([("x", "f4"), ("y", "f4"), ("size", "f4"), ("angle", "f4"), ("response", "f4"),
+                           ("octave", "i4"), ("class_id", "i4")])
+assert KEYPOINT_DTYPE.itemsize == 28
+
+
+class ORBextractor:
+    """Oracle ORB_SLAM2::ORBextractor (orb_object_slam/include/ORBextractor.h:51-61)."""
+
+    def __init__(self, nfeatures=2000, scaleFactor=1.2, nlevels=8, iniThFAST=20, minThFAST=7):
+        l = lib()
+        l.orc_orb_create.restype = C.c_void_p
+        self.nlevels = nlevels
+        self.nfeatures = nfeatures
+        self._e = C.c_void_p(l.orc_orb_create(nfeatures, C.c_float(scaleFactor), nlevels, iniThFAST, minThFAST))
+
+    def __call__(self, gray):
+        gray = np.ascontiguousarray(gray, np.uint8)
+        H, W = gray.shape
+        cap = self.nfeatures * 2 + 64
+        kps = np.zeros(cap, KEYPOINT_DTYPE)
+        desc = np.zeros((cap, 32), np.uint8)
+        n = lib().orc_orb_extract(self._e, _p(gray, C.c_uint8), W, H, kps.ctypes.data_as(C.c_void_p), _p(desc, C.c_uint8), cap)
+        return kps[:n].copy(), desc[:n].copy()
+
+    def features_per_level(self):
+        out = np.zeros(self.nlevels, np.int32)
+        lib().orc_orb_features_per_level(self._e, _p(out, C.c_int))
+        return out
+
+    def level(self, l, blurred=False):
+        w, h = C.c_int(), C.c_int()
+        lib().orc_orb_level_dims(self._e, l, C.byref(w), C.byref(h))
+        out = np.zeros((h.value, w.value), np.uint8)
+        r = lib().orc_orb_get_level(self._e, l, int(blurred), _p(out, C.c_uint8))
+        return out if r == 0 else None
+
+    def candidates(self, l, cap=200000):
+        out = np.zeros((cap, 3), np.float32)
+        n = lib().orc_orb_get_candidates(self._e, l, _p(out, C.c_float), cap)
+        return out[:n].copy()
+
+    def __del__(self):
+        try:
+            lib().orc_orb_destroy(self._e)
+        except Exception:
+            pass
+
+
+def fast(img, threshold):
+    img = np.ascontiguousarray(img, np.uint8)
+    h, w = img.shape
+    out = np.zeros((w * h, 3), np.float32)
+    n = lib().orc_fast(_p(img, C.c_uint8), w, w, h, threshold, _p(out, C.c_float), w * h)
+    return out[:n].copy()
+
+
+def fast_atan2(y, x):
+    lib().orc_fast_atan2.restype = C.c_float
+    return lib().orc_fast_atan2(C.c_float(y), C.c_float(x))
+
+
+def sincos_f(a):
+    s, c = C.c_float(), C.c_float()
+    lib().orc_sincos_f(C.c_float(a), C.byref(s), C.byref(c))
+    return s.value, c.value

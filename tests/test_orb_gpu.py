@@ -1,0 +1,64 @@
+"""GPU parity: HIP ORBextractor vs the CPU oracle, bit-exact (keypoints, angles, descriptors), through the C-ABI."""
+import numpy as np
+import pytest
+
+from cube_slam_amd import synth
+from cube_slam_amd.orb import ORBextractor
+
+pytestmark = pytest.mark.gpu
+
+
+def _check_frame(oracle, ext, ora, img, f):
+    rk, rd = ora(img)
+    for l in range(ext.nlevels):
+        lv = ora.level(l)
+        assert np.array_equal(ext.level(f, l), lv), "pyramid level %d" % l
+        assert np.array_equal(ext.candidates(f, l), ora.candidates(l)), "FAST candidates level %d" % l
+        bl = ora.level(l, blurred=True)
+        if bl is not None:
+            assert np.array_equal(ext.level(f, l, blurred=True), bl), "blurred level %d" % l
+    return rk, rd
+
+
+@pytest.mark.parametrize("W,H,nfeat,kind", [(640, 480, 1000, "texture"), (1241, 376, 2000, "texture"), (640, 480, 500, "scene"), (752, 480, 1200, "texture")])
+def test_extract_bit_exact(ctx, oracle, W, H, nfeat, kind):
+    imgs = []
+    for i in range(2):
+        if kind == "texture":
+            imgs.append(synth.texture_image(40 + i, W, H, shift=3 * i))
+        else:
+            imgs.append(synth.cuboid_scene(50 + i, W=W, H=H)["gray"])
+    ext = ORBextractor(nfeat, 1.2, 8, 20, 7, W, H, max_frames=2, ctx=ctx)
+    ora = oracle.ORBextractor(nfeat, 1.2, 8, 20, 7)
+    assert np.array_equal(ext.features_per_level(), ora.features_per_level())
+    got = ext.extract_batch(np.stack(imgs))
+    for f, img in enumerate(imgs):
+        rk, rd = _check_frame(oracle, ext, ora, img, f)
+        gk, gd = got[f]
+        assert len(gk) == len(rk) and len(gk) > 0
+        assert gk.tobytes() == rk.tobytes(), "keypoints (x, y, size, angle, response, octave) bit-exact"
+        assert np.array_equal(gd, rd), "descriptors bit-exact"
+    ext.close()
+
+
+def test_flat_image_and_thresholds(ctx, oracle):
+    W, H = 640, 480
+    flat = np.full((H, W), 77, np.uint8)
+    ext = ORBextractor(1000, 1.2, 8, 20, 7, W, H, ctx=ctx)
+    k, d = ext(flat)
+    assert len(k) == 0 and d.shape == (0, 32)
+    # low-contrast texture: most cells fall back to minThFAST
+    img = (128 + (synth.texture_image(3, W, H).astype(np.int32) - 128) // 6).astype(np.uint8)
+    ora = oracle.ORBextractor(1000, 1.2, 8, 20, 7)
+    rk, rd = ora(img)
+    gk, gd = ext(img)
+    assert gk.tobytes() == rk.tobytes() and np.array_equal(gd, rd)
+    ext.close()
+    # other pyramid parameters
+    ext2 = ORBextractor(800, 1.5, 4, 30, 10, W, H, ctx=ctx)
+    ora2 = oracle.ORBextractor(800, 1.5, 4, 30, 10)
+    img2 = synth.texture_image(9, W, H)
+    rk, rd = ora2(img2)
+    gk, gd = ext2(img2)
+    assert gk.tobytes() == rk.tobytes() and np.array_equal(gd, rd)
+    ext2.close()
