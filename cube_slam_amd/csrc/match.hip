@@ -1,0 +1,492 @@
+// match.hip -- ORB_SLAM2::ORBmatcher Hamming searches on MI355X (gfx950).
+//
+// Replaces ORBmatcher::SearchByProjection (both overloads), SearchForInitialization and DescriptorDistance
+// (reference orb_object_slam/src/ORBmatcher.cc:50-142, :429-542, :1373-1522, :1905-1921) and the Frame grid
+// (src/Frame.cc:303-318, :404-459, :525-535).
+//
+//   match_grid        counting sort of the keypoints into the 64x48 grid, per-cell lists in keypoint order
+//   match_project     per last-frame map point: Rcw*x+tcw (cv::gemm: double accumulate, one rounding), pinhole projection,
+//                     window radius th*scale[octave]
+//   match_candidates  one wave per query: lane = grid cell of the window (ix outer, iy inner = the reference's candidate
+//                     order), level + |dx|<r,|dy|<r filters, ordered compaction by a wave prefix sum, 256-bit Hamming
+//                     distance as 4 x popcount(u64).  pass 0 counts, pass 1 fills a CSR list (idx, dist).
+//   match_knn2        all-pairs best / second best, train descriptors staged through LDS
+// The greedy claim / ratio / rotation-histogram logic of the reference is sequential over the queries (a candidate claimed by
+// an earlier query is skipped by later ones); it runs on the host over the CSR lists.
+#include "common.h"
+
+#include <algorithm>
+#include <climits>
+#include <cmath>
+#include <vector>
+
+namespace {
+constexpr int GRID_ROWS = 48, GRID_COLS = 64, NCELL = GRID_ROWS * GRID_COLS; // Frame.h:32-33
+constexpr int TH_HIGH = 100, TH_LOW = 50, HISTO_LENGTH = 30;                // ORBmatcher.cc:42-44
+
+struct FrameP { int N; float minX, maxX, minY, maxY, wInv, hInv; };
+
+__global__ void __launch_bounds__(1024) match_grid(FrameP F, const cs_keypoint *keys, int *cell_start /*NCELL+1*/, int *cell_items, int *kp_cell) {
+    __shared__ int cnt[NCELL];
+    __shared__ int s_part[1024];
+    const int tid = threadIdx.x;
+    for (int c = tid; c < NCELL; c += 1024) cnt[c] = 0;
+    __syncthreads();
+    for (int i = tid; i < F.N; i += 1024) { // PosInGrid, Frame.cc:525-535
+        int px = (int)roundf((keys[i].x - F.minX) * F.wInv), py = (int)roundf((keys[i].y - F.minY) * F.hInv);
+        int c = (px < 0 || px >= GRID_COLS || py < 0 || py >= GRID_ROWS) ? -1 : px * GRID_ROWS + py;
+        kp_cell[i] = c;
+        if (c >= 0) atomicAdd(&cnt[c], 1);
+    }
+    __syncthreads();
+    // exclusive scan over the cells: 3 cells per thread
+    int c0 = cnt[tid * 3], c1 = cnt[tid * 3 + 1], c2 = cnt[tid * 3 + 2];
+    s_part[tid] = c0 + c1 + c2;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        int v = tid >= off ? s_part[tid - off] : 0;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    int base = s_part[tid] - (c0 + c1 + c2);
+    cell_start[tid * 3] = base; cell_start[tid * 3 + 1] = base + c0; cell_start[tid * 3 + 2] = base + c0 + c1;
+    if (tid == 1023) cell_start[NCELL] = s_part[1023];
+    __syncthreads();
+    cnt[tid * 3] = base; cnt[tid * 3 + 1] = base + c0; cnt[tid * 3 + 2] = base + c0 + c1; // running fill positions
+    __syncthreads();
+    for (int i = tid; i < F.N; i += 1024) { int c = kp_cell[i]; if (c >= 0) cell_items[atomicAdd(&cnt[c], 1)] = i; }
+    __syncthreads();
+    // mGrid[x][y] holds the indices in push_back order = ascending keypoint index: sort each (tiny) cell list
+    for (int c = tid; c < NCELL; c += 1024) {
+        int b = cell_start[c], e = cnt[c];
+        for (int i = b + 1; i < e; i++) {
+            int v = cell_items[i], j = i - 1;
+            while (j >= b && cell_items[j] > v) { cell_items[j + 1] = cell_items[j]; j--; }
+            cell_items[j + 1] = v;
+        }
+    }
+}
+
+struct Query { float x, y, r; int minLevel, maxLevel, valid; };
+
+__global__ void match_project(int n, const float *world_pos, const uint8_t *valid, const int *octave, const float *T, float fx, float fy, float cx,
+                              float cy, const float *scale_factors, float th, FrameP F, Query *q) {
+    int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Query Q{0, 0, 0, 0, 0, 0};
+    if (valid[i]) {
+        float x3Dc[3];
+        for (int r = 0; r < 3; r++) {
+            double s = 0;
+            for (int k = 0; k < 3; k++) s += (double)T[r * 4 + k] * (double)world_pos[i * 3 + k];
+            x3Dc[r] = (float)(s * 1.0 + (double)T[r * 4 + 3] * 1.0);
+        }
+        const float xc = x3Dc[0], yc = x3Dc[1];
+        const float invzc = (float)(1.0 / x3Dc[2]);
+        if (!(invzc < 0)) {
+            float u = fx * xc * invzc + cx;
+            float v = fy * yc * invzc + cy;
+            if (!(u < F.minX || u > F.maxX) && !(v < F.minY || v > F.maxY)) {
+                int o = octave[i];
+                Q.x = u; Q.y = v; Q.r = th * scale_factors[o]; Q.minLevel = o - 1; Q.maxLevel = o + 1; Q.valid = 1;
+            }
+        }
+    }
+    q[i] = Q;
+}
+
+__device__ __forceinline__ int hamming256(const unsigned long long *a, unsigned long long b0, unsigned long long b1, unsigned long long b2,
+                                          unsigned long long b3) {
+    return __popcll(a[0] ^ b0) + __popcll(a[1] ^ b1) + __popcll(a[2] ^ b2) + __popcll(a[3] ^ b3);
+}
+
+// GetFeaturesInArea (Frame.cc:404-459) for every query + distances.  pass 0: counts[q]; pass 1: CSR fill.
+__global__ void __launch_bounds__(256) match_candidates(FrameP F, const cs_keypoint *keys, const unsigned long long *desc, const int *cell_start,
+                                                        const int *cell_items, int nq, const Query *q, const unsigned long long *qdesc, int pass,
+                                                        int *counts, const int *offsets, int2 *cands) {
+    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (qi >= nq) return;
+    const Query Q = q[qi];
+    int total = 0;
+    if (Q.valid) {
+        const float x = Q.x, y = Q.y, r = Q.r;
+        const int nMinCellX = max(0, (int)floorf((x - F.minX - r) * F.wInv));
+        const int nMaxCellX = min(GRID_COLS - 1, (int)ceilf((x - F.minX + r) * F.wInv));
+        const int nMinCellY = max(0, (int)floorf((y - F.minY - r) * F.hInv));
+        const int nMaxCellY = min(GRID_ROWS - 1, (int)ceilf((y - F.minY + r) * F.hInv));
+        if (!(nMinCellX >= GRID_COLS || nMaxCellX < 0 || nMinCellY >= GRID_ROWS || nMaxCellY < 0)) {
+            const bool bCheckLevels = (Q.minLevel > 0) || (Q.maxLevel >= 0);
+            const int ny = nMaxCellY - nMinCellY + 1, ncell = (nMaxCellX - nMinCellX + 1) * ny;
+            unsigned long long d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+            if (pass == 1 && qdesc) { d0 = qdesc[(long)qi * 4]; d1 = qdesc[(long)qi * 4 + 1]; d2 = qdesc[(long)qi * 4 + 2]; d3 = qdesc[(long)qi * 4 + 3]; }
+            const long base = pass == 1 ? offsets[qi] : 0;
+            for (int k0 = 0; k0 < ncell; k0 += 64) {
+                const int k = k0 + lane;
+                int b = 0, e = 0;
+                if (k < ncell) { int c = (nMinCellX + k / ny) * GRID_ROWS + nMinCellY + k % ny; b = cell_start[c]; e = cell_start[c + 1]; }
+                int mine = 0;
+                for (int p = b; p < e; p++) {
+                    const cs_keypoint kp = keys[cell_items[p]];
+                    bool ok = true;
+                    if (bCheckLevels) { if (kp.octave < Q.minLevel) ok = false; if (Q.maxLevel >= 0 && kp.octave > Q.maxLevel) ok = false; }
+                    const float distx = kp.x - x, disty = kp.y - y;
+                    ok = ok && fabsf(distx) < r && fabsf(disty) < r;
+                    mine += ok;
+                }
+                int inc = mine;
+                for (int off = 1; off < 64; off <<= 1) { int t = __shfl_up(inc, off); if (lane >= off) inc += t; }
+                if (pass == 1 && mine) {
+                    long o = base + total + inc - mine;
+                    for (int p = b; p < e; p++) {
+                        const int id = cell_items[p];
+                        const cs_keypoint kp = keys[id];
+                        bool ok = true;
+                        if (bCheckLevels) { if (kp.octave < Q.minLevel) ok = false; if (Q.maxLevel >= 0 && kp.octave > Q.maxLevel) ok = false; }
+                        const float distx = kp.x - x, disty = kp.y - y;
+                        ok = ok && fabsf(distx) < r && fabsf(disty) < r;
+                        if (ok) { cands[o] = make_int2(id, hamming256(desc + (long)id * 4, d0, d1, d2, d3)); o++; }
+                    }
+                }
+                total += __shfl(inc, 63);
+            }
+        }
+    }
+    if (pass == 0 && lane == 0) counts[qi] = total;
+}
+
+__global__ void __launch_bounds__(1024) match_scan(int n, const int *counts, int *offsets) { // exclusive scan, single block
+    __shared__ int s[1024];
+    __shared__ int s_run;
+    if (threadIdx.x == 0) s_run = 0;
+    __syncthreads();
+    for (int b = 0; b < n; b += 1024) {
+        int i = b + threadIdx.x, v = i < n ? counts[i] : 0;
+        s[threadIdx.x] = v;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            int t = threadIdx.x >= off ? s[threadIdx.x - off] : 0;
+            __syncthreads();
+            s[threadIdx.x] += t;
+            __syncthreads();
+        }
+        if (i < n) offsets[i] = s_run + s[threadIdx.x] - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) s_run += s[1023];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) offsets[n] = s_run;
+}
+
+__global__ void __launch_bounds__(256) match_knn2(const unsigned long long *q, int nq, const unsigned long long *t, int nt, int *best_idx, int *best_dist,
+                                                  int *second_dist) {
+    __shared__ unsigned long long tile[256 * 4];
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    unsigned long long a[4] = {0, 0, 0, 0};
+    if (i < nq) for (int k = 0; k < 4; k++) a[k] = q[(long)i * 4 + k];
+    int b = INT_MAX, b2 = INT_MAX, bi = -1;
+    for (int j0 = 0; j0 < nt; j0 += 256) {
+        const int nj = min(256, nt - j0);
+        __syncthreads();
+        for (int k = threadIdx.x; k < nj * 4; k += 256) tile[k] = t[(long)j0 * 4 + k];
+        __syncthreads();
+        if (i < nq)
+            for (int j = 0; j < nj; j++) {
+                int d = hamming256(a, tile[j * 4], tile[j * 4 + 1], tile[j * 4 + 2], tile[j * 4 + 3]);
+                if (d < b) { b2 = b; b = d; bi = j0 + j; }
+                else if (d < b2) b2 = d;
+            }
+    }
+    if (i < nq) { best_idx[i] = bi; best_dist[i] = b; second_dist[i] = b2; }
+}
+
+static void three_maxima(const int *sizes, int L, int &ind1, int &ind2, int &ind3) { // ORBmatcher.cc:1860-1901
+    int max1 = 0, max2 = 0, max3 = 0;
+    for (int i = 0; i < L; i++) {
+        const int s = sizes[i];
+        if (s > max1) { max3 = max2; max2 = max1; max1 = s; ind3 = ind2; ind2 = ind1; ind1 = i; }
+        else if (s > max2) { max3 = max2; max2 = s; ind3 = ind2; ind2 = i; }
+        else if (s > max3) { max3 = s; ind3 = i; }
+    }
+    if (max2 < 0.1f * (float)max1) { ind2 = -1; ind3 = -1; }
+    else if (max3 < 0.1f * (float)max1) ind3 = -1;
+}
+static inline int rot_bin(float a1, float a2) { // :1483-1491
+    const float factor = 1.0f / HISTO_LENGTH;
+    float rot = a1 - a2;
+    if (rot < 0.0) rot += 360.0f;
+    int bin = (int)std::round(rot * factor);
+    if (bin == HISTO_LENGTH) bin = 0;
+    return bin;
+}
+} // namespace
+
+struct cs_matcher {
+    int max_kp = 0, max_q = 0; long max_cand = 0;
+    FrameP F{};
+    std::vector<cs_keypoint> keys; // host copy of mvKeysUn (angles / octaves / points for the resolve pass)
+    cs_keypoint *d_keys = nullptr; unsigned long long *d_desc = nullptr, *d_qdesc = nullptr;
+    int *d_cell_start = nullptr, *d_cell_items = nullptr, *d_kp_cell = nullptr, *d_counts = nullptr, *d_offsets = nullptr;
+    Query *d_q = nullptr; int2 *d_cands = nullptr;
+    float *d_f = nullptr; uint8_t *d_u8 = nullptr; int *d_i = nullptr; // staging for projection inputs
+    std::vector<int> offsets; std::vector<int2> cands;
+};
+
+static int run_candidates(cs_ctx *ctx, cs_matcher *m, int nq, bool with_desc) {
+    if (nq == 0) { m->offsets.assign(1, 0); m->cands.clear(); return CS_OK; }
+    CS_LAUNCH(ctx, "match_candidates", match_candidates, dim3((nq + 3) / 4), dim3(256), 0, m->F, m->d_keys, m->d_desc, m->d_cell_start, m->d_cell_items, nq,
+              m->d_q, with_desc ? m->d_qdesc : nullptr, 0, m->d_counts, m->d_offsets, m->d_cands);
+    CS_LAUNCH(ctx, "match_scan", match_scan, dim3(1), dim3(1024), 0, nq, m->d_counts, m->d_offsets);
+    m->offsets.resize((size_t)nq + 1);
+    int r = cs_d2h(ctx, m->offsets.data(), m->d_offsets, (size_t)nq + 1); if (r) return r;
+    CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const long total = m->offsets[nq];
+    if (total > m->max_cand) { ctx->err = "matcher candidate capacity exceeded"; return CS_ERR_CAPACITY; }
+    CS_LAUNCH(ctx, "match_candidates", match_candidates, dim3((nq + 3) / 4), dim3(256), 0, m->F, m->d_keys, m->d_desc, m->d_cell_start, m->d_cell_items, nq,
+              m->d_q, with_desc ? m->d_qdesc : nullptr, 1, m->d_counts, m->d_offsets, m->d_cands);
+    m->cands.resize((size_t)std::max<long>(total, 1));
+    r = cs_d2h(ctx, m->cands.data(), m->d_cands, (size_t)total); if (r) return r;
+    CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CS_OK;
+}
+
+extern "C" {
+
+void cs_matcher_destroy(cs_ctx *ctx, cs_matcher *m) {
+    if (!m) return;
+    if (ctx) { hipSetDevice(ctx->device); hipStreamSynchronize(ctx->stream); }
+    void *ptrs[] = {m->d_keys, m->d_desc, m->d_qdesc, m->d_cell_start, m->d_cell_items, m->d_kp_cell, m->d_counts, m->d_offsets, m->d_q, m->d_cands,
+                    m->d_f, m->d_u8, m->d_i};
+    for (void *p : ptrs) if (p) hipFree(p);
+    delete m;
+}
+
+int cs_matcher_create(cs_ctx *ctx, int max_keypoints, int max_queries, long max_candidates, cs_matcher **out) {
+    if (!ctx || !out || max_keypoints < 1 || max_queries < 1 || max_candidates < 1) return CS_ERR_BAD_ARG;
+    *out = nullptr;
+    CS_HIP(ctx, hipSetDevice(ctx->device));
+    cs_matcher *m = new (std::nothrow) cs_matcher();
+    if (!m) return CS_ERR_NOMEM;
+    m->max_kp = max_keypoints; m->max_q = max_queries; m->max_cand = max_candidates;
+#define A_(call) do { int r__ = (call); if (r__ != CS_OK) { cs_matcher_destroy(ctx, m); return r__; } } while (0)
+    A_(cs_dalloc(ctx, &m->d_keys, (size_t)max_keypoints));
+    A_(cs_dalloc(ctx, &m->d_desc, (size_t)max_keypoints * 4));
+    A_(cs_dalloc(ctx, &m->d_qdesc, (size_t)max_queries * 4));
+    A_(cs_dalloc(ctx, &m->d_cell_start, (size_t)NCELL + 1));
+    A_(cs_dalloc(ctx, &m->d_cell_items, (size_t)max_keypoints));
+    A_(cs_dalloc(ctx, &m->d_kp_cell, (size_t)max_keypoints));
+    A_(cs_dalloc(ctx, &m->d_counts, (size_t)max_queries));
+    A_(cs_dalloc(ctx, &m->d_offsets, (size_t)max_queries + 1));
+    A_(cs_dalloc(ctx, &m->d_q, (size_t)max_queries));
+    A_(cs_dalloc(ctx, &m->d_cands, (size_t)max_candidates));
+    A_(cs_dalloc(ctx, &m->d_f, (size_t)max_queries * 3 + 64));
+    A_(cs_dalloc(ctx, &m->d_u8, (size_t)max_queries));
+    A_(cs_dalloc(ctx, &m->d_i, (size_t)max_queries));
+#undef A_
+    *out = m;
+    return CS_OK;
+}
+
+int cs_matcher_set_frame(cs_ctx *ctx, cs_matcher *m, const cs_keypoint *keysUn, const uint8_t *desc, int N, float minX, float maxX, float minY,
+                         float maxY) {
+    if (!ctx || !m || !keysUn || !desc || N < 0 || N > m->max_kp || !(maxX > minX) || !(maxY > minY)) return CS_ERR_BAD_ARG;
+    CS_HIP(ctx, hipSetDevice(ctx->device));
+    m->F.N = N; m->F.minX = minX; m->F.maxX = maxX; m->F.minY = minY; m->F.maxY = maxY;
+    m->F.wInv = static_cast<float>(GRID_COLS) / static_cast<float>(maxX - minX); // Frame.cc:285-286
+    m->F.hInv = static_cast<float>(GRID_ROWS) / static_cast<float>(maxY - minY);
+    m->keys.assign(keysUn, keysUn + N);
+    int r = cs_h2d(ctx, m->d_keys, keysUn, (size_t)N); if (r) return r;
+    r = cs_h2d(ctx, (uint8_t *)m->d_desc, desc, (size_t)N * 32); if (r) return r;
+    CS_LAUNCH(ctx, "match_grid", match_grid, dim3(1), dim3(1024), 0, m->F, m->d_keys, m->d_cell_start, m->d_cell_items, m->d_kp_cell);
+    CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CS_OK;
+}
+
+int cs_matcher_features_in_area(cs_ctx *ctx, cs_matcher *m, float x, float y, float r, int minLevel, int maxLevel, int *out, int cap, int *n) {
+    if (!ctx || !m || !n) return CS_ERR_BAD_ARG;
+    Query Q{x, y, r, minLevel, maxLevel, 1};
+    int rr = cs_h2d(ctx, m->d_q, &Q, 1); if (rr) return rr;
+    rr = run_candidates(ctx, m, 1, false); if (rr) return rr;
+    *n = m->offsets[1];
+    if (out) for (int i = 0; i < *n && i < cap; i++) out[i] = m->cands[i].x;
+    return CS_OK;
+}
+
+int cs_match_by_projection_frame(cs_ctx *ctx, cs_matcher *m, int n_last, const float *world_pos, const uint8_t *valid, const uint8_t *blocks,
+                                 const uint8_t *mp_desc, const int *last_octave, const float *last_angle, const float *Tcw, float fx, float fy, float cx,
+                                 float cy, const float *scale_factors, int n_levels, float th, int check_orientation, int *train_match, int *nmatches) {
+    if (!ctx || !m || n_last < 0 || n_last > m->max_q || !world_pos || !valid || !blocks || !mp_desc || !last_octave || !last_angle || !Tcw ||
+        !scale_factors || n_levels < 1 || n_levels > 32 || !train_match || !nmatches)
+        return CS_ERR_BAD_ARG;
+    CS_HIP(ctx, hipSetDevice(ctx->device));
+    for (int i = 0; i < n_last; i++) if (valid[i] && (last_octave[i] < 0 || last_octave[i] >= n_levels)) return CS_ERR_BAD_ARG;
+    for (int i = 0; i < m->F.N; i++) train_match[i] = -1;
+    *nmatches = 0;
+    if (n_last == 0) return CS_OK;
+    float *d_T = m->d_f + (size_t)m->max_q * 3, *d_sf = d_T + 12;
+    int r = cs_h2d(ctx, m->d_f, world_pos, (size_t)n_last * 3); if (r) return r;
+    r = cs_h2d(ctx, d_T, Tcw, 12); if (r) return r;
+    r = cs_h2d(ctx, d_sf, scale_factors, (size_t)n_levels); if (r) return r;
+    r = cs_h2d(ctx, m->d_u8, valid, (size_t)n_last); if (r) return r;
+    r = cs_h2d(ctx, m->d_i, last_octave, (size_t)n_last); if (r) return r;
+    r = cs_h2d(ctx, (uint8_t *)m->d_qdesc, mp_desc, (size_t)n_last * 32); if (r) return r;
+    CS_LAUNCH(ctx, "match_project", match_project, dim3((n_last + 255) / 256), dim3(256), 0, n_last, m->d_f, m->d_u8, m->d_i, d_T, fx, fy, cx, cy, d_sf, th,
+              m->F, m->d_q);
+    r = run_candidates(ctx, m, n_last, true); if (r) return r;
+    // sequential greedy pass (:1397-1494)
+    int nm = 0;
+    std::vector<int> rot_items[HISTO_LENGTH];
+    for (int i = 0; i < n_last; i++) {
+        const int b = m->offsets[i], e = m->offsets[i + 1];
+        if (e == b) continue;
+        int bestDist = 256, bestIdx2 = -1;
+        for (int p = b; p < e; p++) {
+            const int i2 = m->cands[p].x;
+            if (train_match[i2] >= 0 && blocks[train_match[i2]]) continue;
+            const int dist = m->cands[p].y;
+            if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+        }
+        if (bestDist <= TH_HIGH) {
+            train_match[bestIdx2] = i;
+            nm++;
+            if (check_orientation) rot_items[rot_bin(last_angle[i], m->keys[bestIdx2].angle)].push_back(bestIdx2);
+        }
+    }
+    if (check_orientation) {
+        int sizes[HISTO_LENGTH], ind1 = -1, ind2 = -1, ind3 = -1;
+        for (int i = 0; i < HISTO_LENGTH; i++) sizes[i] = (int)rot_items[i].size();
+        three_maxima(sizes, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++)
+            if (i != ind1 && i != ind2 && i != ind3)
+                for (int id : rot_items[i]) { train_match[id] = -1; nm--; }
+    }
+    *nmatches = nm;
+    return CS_OK;
+}
+
+int cs_match_local_map(cs_ctx *ctx, cs_matcher *m, int n_mp, const float *proj_xy, const float *view_cos, const int *pred_level, const uint8_t *in_view,
+                       const uint8_t *blocks, const uint8_t *mp_desc, const float *scale_factors, int n_levels, float th, float nnratio,
+                       const uint8_t *train_blocked, int *train_match, int *nmatches) {
+    if (!ctx || !m || n_mp < 0 || n_mp > m->max_q || !proj_xy || !view_cos || !pred_level || !in_view || !blocks || !mp_desc || !scale_factors ||
+        !train_match || !nmatches)
+        return CS_ERR_BAD_ARG;
+    CS_HIP(ctx, hipSetDevice(ctx->device));
+    for (int i = 0; i < m->F.N; i++) train_match[i] = -1;
+    *nmatches = 0;
+    if (n_mp == 0) return CS_OK;
+    const bool bFactor = th != 1.0;
+    std::vector<Query> q((size_t)n_mp);
+    for (int i = 0; i < n_mp; i++) { // :58-78 (window radius from the viewing cosine)
+        Query Q{0, 0, 0, 0, 0, 0};
+        if (in_view[i]) {
+            if (pred_level[i] < 0 || pred_level[i] >= n_levels) return CS_ERR_BAD_ARG;
+            float r = view_cos[i] > 0.998 ? 2.5f : 4.0f;
+            if (bFactor) r *= th;
+            Q.x = proj_xy[i * 2]; Q.y = proj_xy[i * 2 + 1]; Q.r = r * scale_factors[pred_level[i]];
+            Q.minLevel = pred_level[i] - 1; Q.maxLevel = pred_level[i]; Q.valid = 1;
+        }
+        q[i] = Q;
+    }
+    int r = cs_h2d(ctx, m->d_q, q.data(), (size_t)n_mp); if (r) return r;
+    r = cs_h2d(ctx, (uint8_t *)m->d_qdesc, mp_desc, (size_t)n_mp * 32); if (r) return r;
+    r = run_candidates(ctx, m, n_mp, true); if (r) return r;
+    int nm = 0;
+    for (int i = 0; i < n_mp; i++) { // :86-140
+        const int b = m->offsets[i], e = m->offsets[i + 1];
+        if (e == b) continue;
+        int bestDist = 256, bestLevel = -1, bestDist2 = 256, bestLevel2 = -1, bestIdx = -1;
+        for (int p = b; p < e; p++) {
+            const int idx = m->cands[p].x;
+            if (train_blocked && train_blocked[idx]) continue;
+            if (train_match[idx] >= 0 && blocks[train_match[idx]]) continue;
+            const int dist = m->cands[p].y;
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestLevel2 = bestLevel; bestLevel = m->keys[idx].octave; bestIdx = idx; }
+            else if (dist < bestDist2) { bestLevel2 = m->keys[idx].octave; bestDist2 = dist; }
+        }
+        if (bestDist <= TH_HIGH) {
+            if (bestLevel == bestLevel2 && bestDist > nnratio * bestDist2) continue;
+            train_match[bestIdx] = i;
+            nm++;
+        }
+    }
+    *nmatches = nm;
+    return CS_OK;
+}
+
+int cs_match_for_initialization(cs_ctx *ctx, cs_matcher *m, const cs_keypoint *keys1, const uint8_t *desc1, int N1, float *prev, int window_size,
+                                float nnratio, int check_orientation, int *vnMatches12, int *nmatches) {
+    if (!ctx || !m || !keys1 || !desc1 || N1 < 0 || N1 > m->max_q || !prev || !vnMatches12 || !nmatches) return CS_ERR_BAD_ARG;
+    CS_HIP(ctx, hipSetDevice(ctx->device));
+    for (int i = 0; i < N1; i++) vnMatches12[i] = -1;
+    *nmatches = 0;
+    if (N1 == 0) return CS_OK;
+    std::vector<Query> q((size_t)N1);
+    for (int i = 0; i < N1; i++) { // :441-449: level-0 keypoints only, window around vbPrevMatched
+        Query Q{0, 0, 0, 0, 0, 0};
+        if (!(keys1[i].octave > 0)) { Q.x = prev[i * 2]; Q.y = prev[i * 2 + 1]; Q.r = (float)window_size; Q.minLevel = keys1[i].octave; Q.maxLevel = keys1[i].octave; Q.valid = 1; }
+        q[i] = Q;
+    }
+    int r = cs_h2d(ctx, m->d_q, q.data(), (size_t)N1); if (r) return r;
+    r = cs_h2d(ctx, (uint8_t *)m->d_qdesc, desc1, (size_t)N1 * 32); if (r) return r;
+    r = run_candidates(ctx, m, N1, true); if (r) return r;
+    const int N2 = m->F.N;
+    int nm = 0;
+    std::vector<int> vMatchedDistance((size_t)N2, INT_MAX), vnMatches21((size_t)N2, -1);
+    std::vector<int> rot_items[HISTO_LENGTH];
+    for (int i1 = 0; i1 < N1; i1++) { // :451-504
+        const int b = m->offsets[i1], e = m->offsets[i1 + 1];
+        if (e == b) continue;
+        int bestDist = INT_MAX, bestDist2 = INT_MAX, bestIdx2 = -1;
+        for (int p = b; p < e; p++) {
+            const int i2 = m->cands[p].x, dist = m->cands[p].y;
+            if (vMatchedDistance[i2] <= dist) continue;
+            if (dist < bestDist) { bestDist2 = bestDist; bestDist = dist; bestIdx2 = i2; }
+            else if (dist < bestDist2) bestDist2 = dist;
+        }
+        if (bestDist <= TH_LOW && bestDist < (float)bestDist2 * nnratio) {
+            if (vnMatches21[bestIdx2] >= 0) { vnMatches12[vnMatches21[bestIdx2]] = -1; nm--; }
+            vnMatches12[i1] = bestIdx2;
+            vnMatches21[bestIdx2] = i1;
+            vMatchedDistance[bestIdx2] = bestDist;
+            nm++;
+            if (check_orientation) rot_items[rot_bin(keys1[i1].angle, m->keys[bestIdx2].angle)].push_back(i1);
+        }
+    }
+    if (check_orientation) {
+        int sizes[HISTO_LENGTH], ind1 = -1, ind2 = -1, ind3 = -1;
+        for (int i = 0; i < HISTO_LENGTH; i++) sizes[i] = (int)rot_items[i].size();
+        three_maxima(sizes, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int idx1 : rot_items[i]) if (vnMatches12[idx1] >= 0) { vnMatches12[idx1] = -1; nm--; }
+        }
+    }
+    for (int i1 = 0; i1 < N1; i1++)
+        if (vnMatches12[i1] >= 0) { prev[i1 * 2] = m->keys[vnMatches12[i1]].x; prev[i1 * 2 + 1] = m->keys[vnMatches12[i1]].y; }
+    *nmatches = nm;
+    return CS_OK;
+}
+
+int cs_hamming_knn2(cs_ctx *ctx, const uint8_t *q, int nq, const uint8_t *t, int nt, int *best_idx, int *best_dist, int *second_dist) {
+    if (!ctx || !q || !t || nq < 0 || nt < 0 || !best_idx || !best_dist || !second_dist) return CS_ERR_BAD_ARG;
+    if (nq == 0) return CS_OK;
+    CS_HIP(ctx, hipSetDevice(ctx->device));
+    unsigned long long *dq = nullptr, *dt = nullptr; int *dres = nullptr;
+    int r = cs_dalloc(ctx, &dq, (size_t)nq * 4); if (r) return r;
+    r = cs_dalloc(ctx, &dt, (size_t)std::max(nt, 1) * 4); if (r) { hipFree(dq); return r; }
+    r = cs_dalloc(ctx, &dres, (size_t)nq * 3); if (r) { hipFree(dq); hipFree(dt); return r; }
+    r = cs_h2d(ctx, (uint8_t *)dq, q, (size_t)nq * 32);
+    if (!r) r = cs_h2d(ctx, (uint8_t *)dt, t, (size_t)nt * 32);
+    if (!r) {
+        CS_LAUNCH(ctx, "match_knn2", match_knn2, dim3((nq + 255) / 256), dim3(256), 0, dq, nq, dt, nt, dres, dres + nq, dres + 2 * nq);
+        r = cs_d2h(ctx, best_idx, dres, (size_t)nq);
+        if (!r) r = cs_d2h(ctx, best_dist, dres + nq, (size_t)nq);
+        if (!r) r = cs_d2h(ctx, second_dist, dres + 2 * nq, (size_t)nq);
+        hipError_t e = hipStreamSynchronize(ctx->stream);
+        if (!r && e != hipSuccess) { ctx->err = hipGetErrorString(e); r = CS_ERR_HIP; }
+    }
+    hipFree(dq); hipFree(dt); hipFree(dres);
+    return r;
+}
+
+} // extern "C"

@@ -1,0 +1,85 @@
+"""Python host-side mirror of ORB_SLAM2::ORBmatcher's Hamming searches (reference orb_object_slam/include/ORBmatcher.h:43-89)."""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import check, lib
+from .orb import KEYPOINT_DTYPE
+
+
+def _p(a, t):
+    return a.ctypes.data_as(C.POINTER(t))
+
+
+class ORBmatcher:
+    TH_HIGH, TH_LOW, HISTO_LENGTH = 100, 50, 30
+
+    def __init__(self, nnratio=0.6, checkOri=True, ctx=None, device=0, max_keypoints=8192, max_queries=16384, max_candidates=4000000):
+        self.ctx = ctx or _lib.Context(device)
+        self.mfNNratio, self.mbCheckOrientation = nnratio, checkOri
+        self._m = C.c_void_p()
+        check(self.ctx.ptr, lib().cs_matcher_create(self.ctx.ptr, max_keypoints, max_queries, C.c_long(max_candidates), C.byref(self._m)), "cs_matcher_create")
+        self.N = 0
+
+    def set_frame(self, keysUn, descriptors, bounds):
+        """The frame that is searched (CurrentFrame / F / F2): mvKeysUn, mDescriptors, (mnMinX, mnMaxX, mnMinY, mnMaxY)."""
+        k = np.ascontiguousarray(keysUn, KEYPOINT_DTYPE); d = np.ascontiguousarray(descriptors, np.uint8)
+        self.N = len(k)
+        check(self.ctx.ptr, lib().cs_matcher_set_frame(self.ctx.ptr, self._m, k.ctypes.data_as(C.c_void_p), _p(d, C.c_uint8), self.N,
+                                                       *[C.c_float(b) for b in bounds]), "cs_matcher_set_frame")
+
+    def GetFeaturesInArea(self, x, y, r, minLevel=-1, maxLevel=-1):
+        out = np.zeros(max(self.N, 1), np.int32); n = C.c_int()
+        check(self.ctx.ptr, lib().cs_matcher_features_in_area(self.ctx.ptr, self._m, C.c_float(x), C.c_float(y), C.c_float(r), minLevel, maxLevel,
+                                                              _p(out, C.c_int), len(out), C.byref(n)), "cs_matcher_features_in_area")
+        return out[:n.value].copy()
+
+    def SearchByProjectionFrame(self, world_pos, valid, blocks, mp_desc, last_octave, last_angle, Tcw, fx, fy, cx, cy, scale_factors, th):
+        wp = np.ascontiguousarray(world_pos, np.float32); va = np.ascontiguousarray(valid, np.uint8); bl = np.ascontiguousarray(blocks, np.uint8)
+        md = np.ascontiguousarray(mp_desc, np.uint8); lo = np.ascontiguousarray(last_octave, np.int32); la = np.ascontiguousarray(last_angle, np.float32)
+        T = np.ascontiguousarray(Tcw, np.float32).reshape(-1)[:12].copy(); sf = np.ascontiguousarray(scale_factors, np.float32)
+        tm = np.zeros(max(self.N, 1), np.int32); n = C.c_int()
+        check(self.ctx.ptr, lib().cs_match_by_projection_frame(self.ctx.ptr, self._m, len(va), _p(wp, C.c_float), _p(va, C.c_uint8), _p(bl, C.c_uint8),
+                                                               _p(md, C.c_uint8), _p(lo, C.c_int), _p(la, C.c_float), _p(T, C.c_float), C.c_float(fx),
+                                                               C.c_float(fy), C.c_float(cx), C.c_float(cy), _p(sf, C.c_float), len(sf), C.c_float(th),
+                                                               int(self.mbCheckOrientation), _p(tm, C.c_int), C.byref(n)), "cs_match_by_projection_frame")
+        return tm[:self.N].copy(), n.value
+
+    def SearchByProjectionLocalMap(self, proj_xy, view_cos, pred_level, in_view, blocks, mp_desc, scale_factors, th, train_blocked=None):
+        pxy = np.ascontiguousarray(proj_xy, np.float32); vc = np.ascontiguousarray(view_cos, np.float32); pl = np.ascontiguousarray(pred_level, np.int32)
+        iv = np.ascontiguousarray(in_view, np.uint8); bl = np.ascontiguousarray(blocks, np.uint8); md = np.ascontiguousarray(mp_desc, np.uint8)
+        sf = np.ascontiguousarray(scale_factors, np.float32)
+        tb = None if train_blocked is None else np.ascontiguousarray(train_blocked, np.uint8)
+        tm = np.zeros(max(self.N, 1), np.int32); n = C.c_int()
+        check(self.ctx.ptr, lib().cs_match_local_map(self.ctx.ptr, self._m, len(iv), _p(pxy, C.c_float), _p(vc, C.c_float), _p(pl, C.c_int), _p(iv, C.c_uint8),
+                                                     _p(bl, C.c_uint8), _p(md, C.c_uint8), _p(sf, C.c_float), len(sf), C.c_float(th), C.c_float(self.mfNNratio),
+                                                     None if tb is None else _p(tb, C.c_uint8), _p(tm, C.c_int), C.byref(n)), "cs_match_local_map")
+        return tm[:self.N].copy(), n.value
+
+    def SearchForInitialization(self, keys1Un, desc1, vbPrevMatched, windowSize=100):
+        k1 = np.ascontiguousarray(keys1Un, KEYPOINT_DTYPE); d1 = np.ascontiguousarray(desc1, np.uint8)
+        prev = np.ascontiguousarray(vbPrevMatched, np.float32).copy()
+        m12 = np.zeros(max(len(k1), 1), np.int32); n = C.c_int()
+        check(self.ctx.ptr, lib().cs_match_for_initialization(self.ctx.ptr, self._m, k1.ctypes.data_as(C.c_void_p), _p(d1, C.c_uint8), len(k1), _p(prev, C.c_float),
+                                                              int(windowSize), C.c_float(self.mfNNratio), int(self.mbCheckOrientation), _p(m12, C.c_int),
+                                                              C.byref(n)), "cs_match_for_initialization")
+        return m12[:len(k1)].copy(), prev, n.value
+
+    def close(self):
+        if self._m:
+            lib().cs_matcher_destroy(self.ctx.ptr, self._m)
+            self._m = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def hamming_knn2(ctx, q, t):
+    q = np.ascontiguousarray(q, np.uint8); t = np.ascontiguousarray(t, np.uint8)
+    bi = np.zeros(max(len(q), 1), np.int32); bd = np.zeros(max(len(q), 1), np.int32); sd = np.zeros(max(len(q), 1), np.int32)
+    check(ctx.ptr, lib().cs_hamming_knn2(ctx.ptr, _p(q, C.c_uint8), len(q), _p(t, C.c_uint8), len(t), _p(bi, C.c_int), _p(bd, C.c_int), _p(sd, C.c_int)), "cs_hamming_knn2")
+    return bi[:len(q)], bd[:len(q)], sd[:len(q)]

@@ -174,6 +174,40 @@ int cs_orb_read(cs_ctx *ctx, cs_orb *e, cs_keypoint *kps, uint8_t *desc, int cap
 int cs_orb_get_level(cs_ctx *ctx, cs_orb *e, int frame, int level, int blurred, uint8_t *out, int *w, int *h);
 int cs_orb_get_candidates(cs_ctx *ctx, cs_orb *e, int frame, int level, float *xyr, int cap, int *n);
 
+/* ===================================================================== ORBmatcher
+ * Replaces the Hamming searches of ORB_SLAM2::ORBmatcher (orb_object_slam/include/ORBmatcher.h:43-89, src/ORBmatcher.cc)
+ * and the Frame grid they use (src/Frame.cc:303-318 AssignFeaturesToGrid, :404-459 GetFeaturesInArea, :525-535 PosInGrid).
+ * GPU: 64x48 grid build, projection, per-query candidate lists (grid order) with 256-bit Hamming distances.
+ * Host: the order-dependent greedy claim / ratio / rotation-histogram pass over those lists (sequential in the reference).
+ * Monocular paths (mvuRight < 0). */
+typedef struct cs_matcher cs_matcher;
+int cs_matcher_create(cs_ctx *ctx, int max_keypoints, int max_queries, long max_candidates, cs_matcher **out);
+void cs_matcher_destroy(cs_ctx *ctx, cs_matcher *m);
+/* The frame searched in (CurrentFrame / F / F2): mvKeysUn, mDescriptors, mnMinX..mnMaxY. */
+int cs_matcher_set_frame(cs_ctx *ctx, cs_matcher *m, const cs_keypoint *keysUn, const uint8_t *desc, int N,
+                         float minX, float maxX, float minY, float maxY);
+/* Frame::GetFeaturesInArea(x, y, r, minLevel, maxLevel) on the frame set above; *n = count (may exceed cap). */
+int cs_matcher_features_in_area(cs_ctx *ctx, cs_matcher *m, float x, float y, float r, int minLevel, int maxLevel,
+                                int *out, int cap, int *n);
+/* ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono=true) (ORBmatcher.cc:1373-1522).
+ * Per last-frame keypoint i: valid[i] (map point present, not outlier/dynamic), world_pos (float xyz), blocks[i] (map point
+ * has Observations() > 0), the map point descriptor, LastFrame.mvKeys[i].octave and mvKeysUn[i].angle.  Tcw: 3x4 float
+ * row-major.  train_match[N] receives the last-frame index matched to each current keypoint or -1. */
+int cs_match_by_projection_frame(cs_ctx *ctx, cs_matcher *m, int n_last, const float *world_pos, const uint8_t *valid,
+                                 const uint8_t *blocks, const uint8_t *mp_desc, const int *last_octave, const float *last_angle,
+                                 const float *Tcw, float fx, float fy, float cx, float cy, const float *scale_factors, int n_levels,
+                                 float th, int check_orientation, int *train_match, int *nmatches);
+/* ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*>&, th) (:50-142). */
+int cs_match_local_map(cs_ctx *ctx, cs_matcher *m, int n_mp, const float *proj_xy, const float *view_cos, const int *pred_level,
+                       const uint8_t *in_view, const uint8_t *blocks, const uint8_t *mp_desc, const float *scale_factors, int n_levels,
+                       float th, float nnratio, const uint8_t *train_blocked, int *train_match, int *nmatches);
+/* ORBmatcher::SearchForInitialization(F1, F2, vbPrevMatched, vnMatches12, windowSize) (:429-542); F2 = the frame set above. */
+int cs_match_for_initialization(cs_ctx *ctx, cs_matcher *m, const cs_keypoint *keys1Un, const uint8_t *desc1, int N1,
+                                float *prev_matched, int window_size, float nnratio, int check_orientation,
+                                int *matches12, int *nmatches);
+/* ORBmatcher::DescriptorDistance over all pairs: exact best / second-best per query (first index wins ties). */
+int cs_hamming_knn2(cs_ctx *ctx, const uint8_t *q, int nq, const uint8_t *t, int nt, int *best_idx, int *best_dist, int *second_dist);
+
 #ifdef __cplusplus
 }
 #endif

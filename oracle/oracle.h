@@ -129,6 +129,35 @@ float orc_fast_atan2(float y, float x);
 /* the float cos/sin the descriptor rotation uses (correctly rounded to float via a double evaluation) */
 void orc_sincos_f(float angle_rad, float *s, float *c);
 
+/* ------------------------------------------------------------------ ORB matcher
+ * ORB_SLAM2::ORBmatcher (orb_object_slam/src/ORBmatcher.cc) + Frame grid (src/Frame.cc:303-318,404-459,525-535). */
+typedef struct orc_frame {      /* the parts of ORB_SLAM2::Frame the matchers read */
+    int N;
+    const orc_keypoint *keysUn; /* mvKeysUn */
+    const uint8_t *desc;        /* mDescriptors, N x 32 */
+    float minX, maxX, minY, maxY; /* mnMinX .. mnMaxY */
+} orc_frame;
+
+int orc_descriptor_distance(const uint8_t *a, const uint8_t *b);                 /* ORBmatcher.cc:1905-1921 */
+int orc_get_features_in_area(const orc_frame *F, float x, float y, float r, int minLevel, int maxLevel, int *out, int cap);
+/* SearchByProjection(Frame &Cur, const Frame &Last, th, bMono=true) (:1373-1522).  Per last-frame keypoint: valid (has a
+ * non-outlier, non-dynamic map point), world_pos (float xyz), the map point's descriptor, its octave and angle; blocks[i]
+ * = map point has Observations() > 0.  train_match[N_cur] receives the last-frame index or -1.  Returns nmatches. */
+int orc_search_by_projection_frame(const orc_frame *cur, int n_last, const float *world_pos, const uint8_t *valid,
+                                   const uint8_t *blocks, const uint8_t *mp_desc, const int *last_octave, const float *last_angle,
+                                   const float *Tcw12, float fx, float fy, float cx, float cy, const float *scale_factors,
+                                   float th, int check_orientation, int *train_match);
+/* SearchByProjection(Frame &F, vector<MapPoint*>, th) (:50-142): proj_xy (mTrackProjX/Y), view_cos, pred_level, in_view,
+ * blocks, mp_desc per map point; train_blocked[N] marks keypoints that already hold a map point with observations. */
+int orc_search_local_map(const orc_frame *F, int n_mp, const float *proj_xy, const float *view_cos, const int *pred_level,
+                         const uint8_t *in_view, const uint8_t *blocks, const uint8_t *mp_desc, const float *scale_factors,
+                         float th, float nnratio, const uint8_t *train_blocked, int *train_match);
+/* SearchForInitialization (:429-542): prev_matched is N1 x 2 in/out; matches12[N1] out.  Returns nmatches. */
+int orc_search_for_initialization(const orc_frame *F1, const orc_frame *F2, float *prev_matched, int window_size, float nnratio,
+                                  int check_orientation, int *matches12);
+/* exact 2-NN in Hamming space over all pairs (first index wins ties) */
+void orc_hamming_knn2(const uint8_t *q, int nq, const uint8_t *t, int nt, int *best_idx, int *best_dist, int *second_dist);
+
 #ifdef __cplusplus
 }
 #endif

@@ -218,3 +218,65 @@ def sincos_f(a):
     s, c = C.c_float(), C.c_float()
     lib().orc_sincos_f(C.c_float(a), C.byref(s), C.byref(c))
     return s.value, c.value
+
+
+# ----------------------------------------------------------------------------------------------- ORB matcher
+class Frame(C.Structure):
+    _fields_ = [("N", C.c_int), ("keysUn", C.c_void_p), ("desc", C.c_void_p),
+                ("minX", C.c_float), ("maxX", C.c_float), ("minY", C.c_float), ("maxY", C.c_float)]
+
+
+def make_frame(keys, desc, bounds):
+    keys = np.ascontiguousarray(keys, KEYPOINT_DTYPE)
+    desc = np.ascontiguousarray(desc, np.uint8)
+    f = Frame(len(keys), keys.ctypes.data, desc.ctypes.data, *[float(b) for b in bounds])
+    f._keep = (keys, desc)
+    return f
+
+
+def descriptor_distance(a, b):
+    a = np.ascontiguousarray(a, np.uint8); b = np.ascontiguousarray(b, np.uint8)
+    return lib().orc_descriptor_distance(_p(a, C.c_uint8), _p(b, C.c_uint8))
+
+
+def get_features_in_area(frame, x, y, r, minLevel=-1, maxLevel=-1):
+    out = np.zeros(max(frame.N, 1), np.int32)
+    n = lib().orc_get_features_in_area(C.byref(frame), C.c_float(x), C.c_float(y), C.c_float(r), minLevel, maxLevel, _p(out, C.c_int), len(out))
+    return out[:n].copy()
+
+
+def search_by_projection_frame(cur, world_pos, valid, blocks, mp_desc, last_octave, last_angle, Tcw, fx, fy, cx, cy, scale_factors, th, check_ori=True):
+    wp = np.ascontiguousarray(world_pos, np.float32); va = np.ascontiguousarray(valid, np.uint8); bl = np.ascontiguousarray(blocks, np.uint8)
+    md = np.ascontiguousarray(mp_desc, np.uint8); lo = np.ascontiguousarray(last_octave, np.int32); la = np.ascontiguousarray(last_angle, np.float32)
+    T = np.ascontiguousarray(Tcw, np.float32).reshape(-1)[:12].copy(); sf = np.ascontiguousarray(scale_factors, np.float32)
+    tm = np.zeros(max(cur.N, 1), np.int32)
+    n = lib().orc_search_by_projection_frame(C.byref(cur), len(va), _p(wp, C.c_float), _p(va, C.c_uint8), _p(bl, C.c_uint8), _p(md, C.c_uint8),
+                                             _p(lo, C.c_int), _p(la, C.c_float), _p(T, C.c_float), C.c_float(fx), C.c_float(fy), C.c_float(cx),
+                                             C.c_float(cy), _p(sf, C.c_float), C.c_float(th), int(check_ori), _p(tm, C.c_int))
+    return tm[:cur.N].copy(), n
+
+
+def search_local_map(F, proj_xy, view_cos, pred_level, in_view, blocks, mp_desc, scale_factors, th, nnratio, train_blocked=None):
+    pxy = np.ascontiguousarray(proj_xy, np.float32); vc = np.ascontiguousarray(view_cos, np.float32); pl = np.ascontiguousarray(pred_level, np.int32)
+    iv = np.ascontiguousarray(in_view, np.uint8); bl = np.ascontiguousarray(blocks, np.uint8); md = np.ascontiguousarray(mp_desc, np.uint8)
+    sf = np.ascontiguousarray(scale_factors, np.float32)
+    tb = None if train_blocked is None else np.ascontiguousarray(train_blocked, np.uint8)
+    tm = np.zeros(max(F.N, 1), np.int32)
+    n = lib().orc_search_local_map(C.byref(F), len(iv), _p(pxy, C.c_float), _p(vc, C.c_float), _p(pl, C.c_int), _p(iv, C.c_uint8), _p(bl, C.c_uint8),
+                                   _p(md, C.c_uint8), _p(sf, C.c_float), C.c_float(th), C.c_float(nnratio), None if tb is None else _p(tb, C.c_uint8),
+                                   _p(tm, C.c_int))
+    return tm[:F.N].copy(), n
+
+
+def search_for_initialization(F1, F2, prev_matched, window_size=100, nnratio=0.9, check_ori=True):
+    prev = np.ascontiguousarray(prev_matched, np.float32).copy()
+    m12 = np.zeros(max(F1.N, 1), np.int32)
+    n = lib().orc_search_for_initialization(C.byref(F1), C.byref(F2), _p(prev, C.c_float), int(window_size), C.c_float(nnratio), int(check_ori), _p(m12, C.c_int))
+    return m12[:F1.N].copy(), prev, n
+
+
+def hamming_knn2(q, t):
+    q = np.ascontiguousarray(q, np.uint8); t = np.ascontiguousarray(t, np.uint8)
+    bi = np.zeros(len(q), np.int32); bd = np.zeros(len(q), np.int32); sd = np.zeros(len(q), np.int32)
+    lib().orc_hamming_knn2(_p(q, C.c_uint8), len(q), _p(t, C.c_uint8), len(t), _p(bi, C.c_int), _p(bd, C.c_int), _p(sd, C.c_int))
+    return bi, bd, sd
