@@ -52,6 +52,19 @@ def cuboid_synth():
     print("cuboid_synth written")
 
 
+def orb_cabinet():
+    """line_lbd/data/cabinet.png (640x480, the reference's LSD demo image) -> gray fixture + oracle ORB output digest."""
+    import hashlib
+    from PIL import Image
+    rgb = np.asarray(Image.open(os.path.join(REF, "line_lbd/data/cabinet.png")).convert("RGB"))
+    gray = po.bgr2gray(np.ascontiguousarray(rgb[:, :, ::-1]))
+    k, d = po.ORBextractor(1000, 1.2, 8, 20, 7)(gray)
+    np.savez_compressed(os.path.join(HERE, "orb_cabinet.npz"), gray=gray, n=len(k), kp_sha=hashlib.sha256(k.tobytes()).hexdigest(),
+                        desc_sha=hashlib.sha256(d.tobytes()).hexdigest(), kp_head=k[:16], desc_head=d[:16])
+    print("orb_cabinet:", len(k), "keypoints")
+
+
 if __name__ == "__main__":
     cuboid_ref()
     cuboid_synth()
+    orb_cabinet()
