@@ -1,0 +1,1074 @@
+// ba.hip -- g2o object bundle adjustment (Levenberg-Marquardt, BlockSolver_6_3 with Schur) on MI355X (gfx950).
+//
+// Replaces SparseOptimizer::optimize as driven by Optimizer::BundleAdjustment / LocalBACameraPointObjects (reference
+// orb_object_slam/src/Optimizer.cc:64-251, :826-1534; vendored g2o core/optimization_algorithm_levenberg.cpp:61-189,
+// core/block_solver.hpp:354-604, core/base_binary_edge.hpp:55-320, core/base_unary_edge.hpp:82-123; CubeSLAM types
+// orb_object_slam/src/g2o_Object.cpp).  fp64 throughout, like g2o.  Deterministic: every reduction has a fixed order
+// (thread per landmark, wave per pose block / Schur block with shuffle trees), no floating-point atomics.
+//
+//   ba_err_*          computeActiveErrors: reprojection / cuboid bbox / point-in-cuboid residuals + robust chi2 partials
+//   ba_lin_lm         thread per landmark: analytic 2x3 / 2x6 Jacobians of its observations, Hll, bl, Hpl blocks
+//   ba_lin_pose       wave per pose block: sum_obs Jj^T W Jj and Jj^T W r (lane = observation, shuffle-tree reduce)
+//   ba_num_cols       thread per (cuboid edge, perturbed dimension): central difference with delta 1e-9 through the same
+//                     oplus (exp map, exptwist_norollpitch) as g2o's numeric linearizeOplus
+//   ba_lin_pose_edges thread per pose block: camera-cuboid and point-cuboid terms into Hpp / b
+//   ba_lm_dinv        thread per landmark: (Hll + lambda I)^-1 and D^-1 b_l
+//   ba_schur_slots    wave per block of the reduced camera system: Hpp - sum_l B D^-1 B^T (lane = contributing landmark)
+//   ba_schur_b        wave per pose block: b_p - sum B D^-1 b_l
+//   (all-reduce)      one sum over [Schur blocks | b | scalars] across ranks when landmarks are sharded (RCCL via callback)
+//   ba_band_*         block-band Cholesky (reverse Cuthill-McKee order from the host) + two triangular sweeps, one workgroup
+//   ba_backsub        thread per landmark: x_l = D^-1 (b_l - B^T x_p)
+//   ba_update         oplus per vertex (cameras: exp(dx) * T; cuboids: T * exp(dx) with the fix-roll-pitch / height / scale flags)
+#include "common.h"
+
+#include <algorithm>
+#include <cmath>
+#include <limits>
+#include <map>
+#include <queue>
+#include <vector>
+
+namespace {
+
+struct Quat { double x, y, z, w; };
+struct SE3 { Quat r; double t[3]; };
+struct Cuboid { SE3 pose; double scale[3]; };
+#define HD __host__ __device__ inline
+
+HD Quat qmul(const Quat &a, const Quat &b) {
+    return Quat{a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y, a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z,
+                a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x, a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z};
+}
+HD void qrot(const Quat &q, const double *v, double *o) { // Eigen QuaternionBase::_transformVector
+    double uv[3] = {q.y * v[2] - q.z * v[1], q.z * v[0] - q.x * v[2], q.x * v[1] - q.y * v[0]};
+    uv[0] += uv[0]; uv[1] += uv[1]; uv[2] += uv[2];
+    o[0] = v[0] + q.w * uv[0] + (q.y * uv[2] - q.z * uv[1]);
+    o[1] = v[1] + q.w * uv[1] + (q.z * uv[0] - q.x * uv[2]);
+    o[2] = v[2] + q.w * uv[2] + (q.x * uv[1] - q.y * uv[0]);
+}
+HD void qtoR(const Quat &q, double R[3][3]) {
+    const double tx = 2 * q.x, ty = 2 * q.y, tz = 2 * q.z;
+    const double twx = tx * q.w, twy = ty * q.w, twz = tz * q.w, txx = tx * q.x, txy = ty * q.x, txz = tz * q.x, tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
+    R[0][0] = 1 - (tyy + tzz); R[0][1] = txy - twz; R[0][2] = txz + twy;
+    R[1][0] = txy + twz; R[1][1] = 1 - (txx + tzz); R[1][2] = tyz - twx;
+    R[2][0] = txz - twy; R[2][1] = tyz + twx; R[2][2] = 1 - (txx + tyy);
+}
+HD Quat qfromR(const double m[3][3]) { // Eigen Quaterniond(Matrix3d)
+    Quat q;
+    double t = m[0][0] + m[1][1] + m[2][2];
+    if (t > 0) {
+        t = sqrt(t + 1.0); q.w = 0.5 * t; t = 0.5 / t;
+        q.x = (m[2][1] - m[1][2]) * t; q.y = (m[0][2] - m[2][0]) * t; q.z = (m[1][0] - m[0][1]) * t;
+    } else {
+        int i = 0;
+        if (m[1][1] > m[0][0]) i = 1;
+        if (m[2][2] > m[i][i]) i = 2;
+        int j = (i + 1) % 3, k = (j + 1) % 3;
+        double v[3];
+        t = sqrt(m[i][i] - m[j][j] - m[k][k] + 1.0);
+        v[i] = 0.5 * t; t = 0.5 / t;
+        q.w = (m[k][j] - m[j][k]) * t; v[j] = (m[j][i] + m[i][j]) * t; v[k] = (m[k][i] + m[i][k]) * t;
+        q.x = v[0]; q.y = v[1]; q.z = v[2];
+    }
+    return q;
+}
+HD void normalize_rotation(SE3 &T) { // se3quat.h:331-336
+    if (T.r.w < 0) { T.r.x *= -1; T.r.y *= -1; T.r.z *= -1; T.r.w *= -1; }
+    double n = sqrt(T.r.x * T.r.x + T.r.y * T.r.y + T.r.z * T.r.z + T.r.w * T.r.w);
+    T.r.x /= n; T.r.y /= n; T.r.z /= n; T.r.w /= n;
+}
+HD SE3 se3_mul(const SE3 &a, const SE3 &b) {
+    SE3 r = a;
+    double rt[3];
+    qrot(a.r, b.t, rt);
+    r.t[0] += rt[0]; r.t[1] += rt[1]; r.t[2] += rt[2];
+    r.r = qmul(a.r, b.r);
+    normalize_rotation(r);
+    return r;
+}
+HD SE3 se3_inv(const SE3 &a) {
+    SE3 r;
+    r.r = Quat{-a.r.x, -a.r.y, -a.r.z, a.r.w};
+    double nt[3] = {a.t[0] * -1., a.t[1] * -1., a.t[2] * -1.};
+    qrot(r.r, nt, r.t);
+    return r;
+}
+HD void se3_map(const SE3 &T, const double *p, double *o) { qrot(T.r, p, o); o[0] += T.t[0]; o[1] += T.t[1]; o[2] += T.t[2]; }
+HD SE3 se3_load(const double *v) { SE3 T; T.t[0] = v[0]; T.t[1] = v[1]; T.t[2] = v[2]; T.r = Quat{v[3], v[4], v[5], v[6]}; return T; }
+HD void se3_store(const SE3 &T, double *v) { v[0] = T.t[0]; v[1] = T.t[1]; v[2] = T.t[2]; v[3] = T.r.x; v[4] = T.r.y; v[5] = T.r.z; v[6] = T.r.w; }
+HD void mat3mul(const double a[3][3], const double b[3][3], double c[3][3]) {
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) c[i][j] = (a[i][0] * b[0][j] + a[i][1] * b[1][j]) + a[i][2] * b[2][j];
+}
+HD SE3 se3_exp(const double *u) { // SE3Quat::exp se3quat.h:272-306
+    const double om[3] = {u[0], u[1], u[2]}, up[3] = {u[3], u[4], u[5]};
+    const double theta = sqrt(om[0] * om[0] + om[1] * om[1] + om[2] * om[2]);
+    double O[3][3] = {{0, -om[2], om[1]}, {om[2], 0, -om[0]}, {-om[1], om[0], 0}}, O2[3][3], R[3][3], V[3][3];
+    mat3mul(O, O, O2);
+    if (theta < 0.00001) {
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { R[i][j] = ((i == j ? 1.0 : 0.0) + O[i][j]) + O2[i][j]; V[i][j] = R[i][j]; }
+    } else {
+        const double a = sin(theta) / theta, b = (1 - cos(theta)) / (theta * theta), c = (theta - sin(theta)) / (theta * theta * theta);
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) {
+                R[i][j] = ((i == j ? 1.0 : 0.0) + a * O[i][j]) + b * O2[i][j];
+                V[i][j] = ((i == j ? 1.0 : 0.0) + b * O[i][j]) + c * O2[i][j];
+            }
+    }
+    SE3 T;
+    T.r = qfromR(R);
+    for (int i = 0; i < 3; i++) T.t[i] = (V[i][0] * up[0] + V[i][1] * up[1]) + V[i][2] * up[2];
+    normalize_rotation(T);
+    return T;
+}
+HD SE3 exptwist_norollpitch(const double *u) { // g2o_Object.cpp:24-54
+    const double om[3] = {u[0], u[1], u[2]}, up[3] = {u[3], u[4], u[5]};
+    const double theta = sqrt(om[0] * om[0] + om[1] * om[1] + om[2] * om[2]);
+    double O[3][3] = {{0, -om[2], om[1]}, {om[2], 0, -om[0]}, {-om[1], om[0], 0}}, O2[3][3], V[3][3];
+    double R[3][3] = {{cos(om[2]), -sin(om[2]), 0}, {sin(om[2]), cos(om[2]), 0}, {0, 0, 1}};
+    if (theta < 0.00001) { for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) V[i][j] = R[i][j]; }
+    else {
+        mat3mul(O, O, O2);
+        const double b = (1 - cos(theta)) / (theta * theta), c = (theta - sin(theta)) / (theta * theta * theta);
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) V[i][j] = ((i == j ? 1.0 : 0.0) + b * O[i][j]) + c * O2[i][j];
+    }
+    SE3 T;
+    T.r = qfromR(R);
+    for (int i = 0; i < 3; i++) T.t[i] = (V[i][0] * up[0] + V[i][1] * up[1]) + V[i][2] * up[2];
+    normalize_rotation(T);
+    return T;
+}
+HD Cuboid cuboid_oplus(const Cuboid &e, const double *upd, int flags, const double *fixedscale) { // VertexCuboidFixScale::oplusImpl g2o_Object.cpp:88-116
+    Cuboid n;
+    n.pose.r = Quat{0, 0, 0, 1}; n.pose.t[0] = n.pose.t[1] = n.pose.t[2] = 0;
+    if (flags & 2) {
+        n.pose.r = e.pose.r;
+        for (int i = 0; i < 3; i++) n.pose.t[i] = e.pose.t[i] + upd[3 + i];
+    } else if (flags & 1) {
+        double u2[6] = {0, 0, upd[2], upd[3], upd[4], upd[5]};
+        n.pose = se3_mul(e.pose, exptwist_norollpitch(u2));
+    } else
+        n.pose = se3_mul(e.pose, se3_exp(upd));
+    if (flags & 4) n.pose.t[1] = e.pose.t[1];
+    for (int i = 0; i < 3; i++) n.scale[i] = (flags & 8) ? fixedscale[i] : e.scale[i];
+    return n;
+}
+HD void project_bbox(const Cuboid &c, const SE3 &Tcw, const double *K, double *out) { // cuboid::projectOntoImageBbox g2o_Object.h:189-220
+    const double body[3][8] = {{1, 1, -1, -1, 1, 1, -1, -1}, {1, -1, -1, 1, 1, -1, -1, 1}, {-1, -1, -1, -1, 1, 1, 1, 1}};
+    double Ro[3][3], Rc[3][3], rs[3][3];
+    qtoR(c.pose.r, Ro);
+    qtoR(Tcw.r, Rc);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) rs[i][j] = Ro[i][j] * c.scale[j];
+    double mnx = 0, mny = 0, mxx = 0, mxy = 0;
+    for (int k = 0; k < 8; k++) {
+        double pw[3], pc[3], h[3];
+        for (int i = 0; i < 3; i++) pw[i] = ((rs[i][0] * body[0][k] + rs[i][1] * body[1][k]) + rs[i][2] * body[2][k]) + c.pose.t[i];
+        for (int i = 0; i < 3; i++) pc[i] = ((Rc[i][0] * pw[0] + Rc[i][1] * pw[1]) + Rc[i][2] * pw[2]) + Tcw.t[i];
+        for (int i = 0; i < 3; i++) h[i] = (K[i * 3] * pc[0] + K[i * 3 + 1] * pc[1]) + K[i * 3 + 2] * pc[2];
+        const double u = h[0] / h[2], v = h[1] / h[2];
+        if (k == 0) { mnx = mxx = u; mny = mxy = v; }
+        else { mnx = fmin(mnx, u); mxx = fmax(mxx, u); mny = fmin(mny, v); mxy = fmax(mxy, v); }
+    }
+    out[0] = (mxx + mnx) / 2; out[1] = (mxy + mny) / 2; out[2] = mxx - mnx; out[3] = mxy - mny;
+}
+HD void huber(double e, double delta, double *rho) { // RobustKernelHuber::robustify robust_kernel_impl.cpp:78-91
+    const double dsqr = delta * delta;
+    if (e <= dsqr) { rho[0] = e; rho[1] = 1.; rho[2] = 0.; }
+    else { const double sq = sqrt(e); rho[0] = 2 * sq * delta - dsqr; rho[1] = delta / sq; rho[2] = -0.5 * rho[1] / e; }
+}
+
+struct Params { // device-side view of the graph
+    int n_cams, L, n_cub, P, n_obs, n_cobs, n_pc, lm_b, lm_e, o_b, o_e, pose_edges; // this rank: landmarks [lm_b, lm_e), obs [o_b, o_e)
+    double fx, fy, cx, cy, huber_mono, huber_obj, margin_ratio, K[9];
+    double *cam, *pts, *cub, *cub_scale;           // estimates: 7 / 3 / 7 (+3)
+    const int *cam_idx; const uint8_t *cub_flags;
+    const int *o_cam, *o_pt; const double *o_uv, *o_w; const int *lm_off;
+    const int *c_cam, *c_cub; const double *c_bbox, *c_info;
+    const int *pc_cub, *pc_off; const double *pc_pts;
+    double *e_obs, *e_cobs, *e_pc;
+    double *Hpl, *Hll, *bl, *Dinv, *db, *Hpp, *bp, *Hoff; // Hoff: one 6x6 block per camera-cuboid edge (camera rows, cuboid cols)
+    double *Jc, *Jp;                                       // numeric Jacobian columns: cobs x 12 x 4, pc x 6 x 3
+    double *x;                                             // 6P + 3L
+};
+
+__device__ inline Cuboid load_cuboid(const Params &G, int i) {
+    Cuboid c; c.pose = se3_load(G.cub + (long)i * 7);
+    for (int k = 0; k < 3; k++) c.scale[k] = G.cub_scale[i * 3 + k];
+    return c;
+}
+__device__ inline void err_cobs_eval(const Params &G, int o, const SE3 &T, const Cuboid &c, double *e) { // EdgeSE3CuboidFixScaleProj::computeError
+    double bb[4];
+    project_bbox(c, T, G.K, bb);
+    for (int k = 0; k < 4; k++) e[k] = bb[k] - G.c_bbox[o * 4 + k];
+}
+__device__ inline void err_pc_eval(const Params &G, int o, const Cuboid &c, double *e) { // EdgePointCuboidOnlyObjectFixScale::computeError
+    double acc[3] = {0, 0, 0};
+    const int b0 = G.pc_off[o], b1 = G.pc_off[o + 1];
+    const SE3 inv = se3_inv(c.pose);
+    const double ratio = G.margin_ratio;
+    for (int i = b0; i < b1; i++) {
+        double lp[3];
+        se3_map(inv, G.pc_pts + (long)i * 3, lp);
+        for (int k = 0; k < 3; k++) { // cuboid::point_boundary_error g2o_Object.cpp:280-298
+            const double a = fabs(lp[k]) * 1.0;
+            double er;
+            if (a < c.scale[k]) er = 0;
+            else if (a < (ratio + 1) * c.scale[k]) er = a - c.scale[k];
+            else er = ratio * c.scale[k];
+            acc[k] += fabs(er);
+        }
+    }
+    if (b1 > b0) for (int k = 0; k < 3; k++) acc[k] = acc[k] / (double)(b1 - b0);
+    for (int k = 0; k < 3; k++) e[k] = 1.0 * (acc[k] / c.scale[k]);
+}
+
+// block partial sums, then a fixed-order final sum on the host side of the tiny partial array
+__device__ inline void block_sum_store(double v, double *partials) {
+    __shared__ double s[4];
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = (s[0] + s[1]) + (s[2] + s[3]);
+}
+
+__global__ void __launch_bounds__(256) ba_err_obs(Params G, double *partials) {
+    const int o = G.o_b + blockIdx.x * 256 + threadIdx.x;
+    double chi = 0;
+    if (o < G.o_e) { // EdgeSE3ProjectXYZ::computeError
+        const SE3 T = se3_load(G.cam + (long)G.o_cam[o] * 7);
+        double pc[3];
+        se3_map(T, G.pts + (long)G.o_pt[o] * 3, pc);
+        const double e0 = G.o_uv[o * 2] - (pc[0] / pc[2] * G.fx + G.cx), e1 = G.o_uv[o * 2 + 1] - (pc[1] / pc[2] * G.fy + G.cy);
+        G.e_obs[(long)o * 2] = e0; G.e_obs[(long)o * 2 + 1] = e1;
+        chi = (e0 * e0 + e1 * e1) * G.o_w[o];
+        if (G.huber_mono > 0) { double rho[3]; huber(chi, G.huber_mono, rho); chi = rho[0]; }
+    }
+    block_sum_store(chi, partials);
+}
+__global__ void __launch_bounds__(256) ba_err_pose_edges(Params G, double *partials) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    double chi = 0;
+    if (t < G.n_cobs) {
+        double e[4];
+        err_cobs_eval(G, t, se3_load(G.cam + (long)G.c_cam[t] * 7), load_cuboid(G, G.c_cub[t]), e);
+        const double *w = G.c_info + (long)t * 4;
+        for (int k = 0; k < 4; k++) G.e_cobs[(long)t * 4 + k] = e[k];
+        chi = ((e[0] * w[0] * e[0] + e[1] * w[1] * e[1]) + e[2] * w[2] * e[2]) + e[3] * w[3] * e[3];
+        if (G.huber_obj > 0) { double rho[3]; huber(chi, G.huber_obj, rho); chi = rho[0]; }
+    } else if (t < G.n_cobs + G.n_pc) {
+        const int o = t - G.n_cobs;
+        double e[3];
+        err_pc_eval(G, o, load_cuboid(G, G.pc_cub[o]), e);
+        for (int k = 0; k < 3; k++) G.e_pc[(long)o * 3 + k] = e[k];
+        chi = (e[0] * e[0] + e[1] * e[1]) + e[2] * e[2];
+    }
+    block_sum_store(chi, partials);
+}
+
+// analytic Jacobians of one reprojection edge (EdgeSE3ProjectXYZ::linearizeOplus types_six_dof_expmap.cpp:135-171) + weights
+__device__ inline void obs_jac(const Params &G, int o, double Ji[2][3], double Jj[2][6], double omr[2], double &W) {
+    const SE3 T = se3_load(G.cam + (long)G.o_cam[o] * 7);
+    double pc[3], R[3][3];
+    se3_map(T, G.pts + (long)G.o_pt[o] * 3, pc);
+    qtoR(T.r, R);
+    const double X = pc[0], Y = pc[1], Z = pc[2], Z2 = Z * Z, fx = G.fx, fy = G.fy;
+    const double tmp[2][3] = {{fx, 0, -X / Z * fx}, {0, fy, -Y / Z * fy}};
+    for (int r = 0; r < 2; r++) for (int c = 0; c < 3; c++) Ji[r][c] = ((-1. / Z * tmp[r][0]) * R[0][c] + (-1. / Z * tmp[r][1]) * R[1][c]) + (-1. / Z * tmp[r][2]) * R[2][c];
+    Jj[0][0] = X * Y / Z2 * fx; Jj[0][1] = -(1 + (X * X / Z2)) * fx; Jj[0][2] = Y / Z * fx; Jj[0][3] = -1. / Z * fx; Jj[0][4] = 0; Jj[0][5] = X / Z2 * fx;
+    Jj[1][0] = (1 + Y * Y / Z2) * fy; Jj[1][1] = -X * Y / Z2 * fy; Jj[1][2] = -X / Z * fy; Jj[1][3] = 0; Jj[1][4] = -1. / Z * fy; Jj[1][5] = Y / Z2 * fy;
+    const double e0 = G.e_obs[(long)o * 2], e1 = G.e_obs[(long)o * 2 + 1], w = G.o_w[o];
+    double rw = 1.0;
+    if (G.huber_mono > 0) { double rho[3]; huber((e0 * e0 + e1 * e1) * w, G.huber_mono, rho); rw = rho[1]; }
+    omr[0] = -w * e0 * rw; omr[1] = -w * e1 * rw; // omega_r = -Omega e, scaled by rho' (base_binary_edge.hpp:77,96)
+    W = rw * w;                                   // robustInformation = rho' * Omega (base_edge.h:96-102)
+}
+
+__global__ void __launch_bounds__(256) ba_lin_lm(Params G) { // thread per landmark of this rank
+    const int li = G.lm_b + blockIdx.x * 256 + threadIdx.x;
+    if (li >= G.lm_e) return;
+    double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
+    for (int o = G.lm_off[li]; o < G.lm_off[li + 1]; o++) {
+        double Ji[2][3], Jj[2][6], omr[2], W;
+        obs_jac(G, o, Ji, Jj, omr, W);
+        for (int a = 0; a < 3; a++) {
+            b[a] += Ji[0][a] * omr[0] + Ji[1][a] * omr[1];
+            for (int c = 0; c < 3; c++) H[a * 3 + c] += (Ji[0][a] * W) * Ji[0][c] + (Ji[1][a] * W) * Ji[1][c];
+        }
+        double *hx = G.Hpl + (long)o * 18; // Hpl block (pose rows, landmark cols) = Jj^T W Ji
+        for (int a = 0; a < 6; a++) for (int c = 0; c < 3; c++) hx[a * 3 + c] = (Jj[0][a] * W) * Ji[0][c] + (Jj[1][a] * W) * Ji[1][c];
+    }
+    for (int k = 0; k < 9; k++) G.Hll[(long)li * 9 + k] = H[k];
+    for (int k = 0; k < 3; k++) G.bl[(long)li * 3 + k] = b[k];
+}
+
+// wave per pose block: observations of this rank that involve the camera (CSR pose_off / pose_obs)
+__global__ void __launch_bounds__(256) ba_lin_pose(Params G, const int *pose_off, const int *pose_obs) {
+    const int pi = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (pi >= G.P) return;
+    double acc[42];
+#pragma unroll
+    for (int k = 0; k < 42; k++) acc[k] = 0;
+    for (int q = pose_off[pi] + lane; q < pose_off[pi + 1]; q += 64) {
+        double Ji[2][3], Jj[2][6], omr[2], W;
+        obs_jac(G, pose_obs[q], Ji, Jj, omr, W);
+#pragma unroll
+        for (int a = 0; a < 6; a++) {
+            acc[36 + a] += Jj[0][a] * omr[0] + Jj[1][a] * omr[1];
+#pragma unroll
+            for (int c = 0; c < 6; c++) acc[a * 6 + c] += (Jj[0][a] * W) * Jj[0][c] + (Jj[1][a] * W) * Jj[1][c];
+        }
+    }
+#pragma unroll
+    for (int k = 0; k < 42; k++) for (int off = 32; off > 0; off >>= 1) acc[k] += __shfl_xor(acc[k], off);
+    if (lane == 0) {
+        for (int k = 0; k < 36; k++) G.Hpp[(long)pi * 36 + k] = acc[k];
+        for (int k = 0; k < 6; k++) G.bp[(long)pi * 6 + k] = acc[36 + k];
+    }
+}
+
+// numeric Jacobian columns (base_binary_edge.hpp:216-320, base_unary_edge.hpp:82-123): delta = 1e-9, central difference
+__global__ void __launch_bounds__(256) ba_num_cols(Params G) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    const double delta = 1e-9, scalar = 1.0 / (2 * delta);
+    if (t < G.n_cobs * 12) {
+        const int o = t / 12, d = t % 12;
+        const int ci = G.c_cam[o], oi = G.c_cub[o];
+        const SE3 T = se3_load(G.cam + (long)ci * 7);
+        const Cuboid C = load_cuboid(G, oi);
+        double add[6] = {0, 0, 0, 0, 0, 0}, e1[4], e2[4];
+        if (d < 6) { // camera: VertexSE3Expmap::oplusImpl = exp(update) * estimate
+            if (G.cam_idx[ci] < 0) return;
+            add[d] = delta; err_cobs_eval(G, o, se3_mul(se3_exp(add), T), C, e1);
+            add[d] = -delta; err_cobs_eval(G, o, se3_mul(se3_exp(add), T), C, e2);
+        } else {
+            add[d - 6] = delta; err_cobs_eval(G, o, T, cuboid_oplus(C, add, G.cub_flags[oi], G.cub_scale + (long)oi * 3), e1);
+            add[d - 6] = -delta; err_cobs_eval(G, o, T, cuboid_oplus(C, add, G.cub_flags[oi], G.cub_scale + (long)oi * 3), e2);
+        }
+        for (int k = 0; k < 4; k++) G.Jc[((long)o * 12 + d) * 4 + k] = scalar * (e1[k] - e2[k]);
+    } else if (t < G.n_cobs * 12 + G.n_pc * 6) {
+        const int u = t - G.n_cobs * 12, o = u / 6, d = u % 6, oi = G.pc_cub[o];
+        const Cuboid C = load_cuboid(G, oi);
+        double add[6] = {0, 0, 0, 0, 0, 0}, e1[3], e2[3];
+        add[d] = delta; err_pc_eval(G, o, cuboid_oplus(C, add, G.cub_flags[oi], G.cub_scale + (long)oi * 3), e1);
+        add[d] = -delta; err_pc_eval(G, o, cuboid_oplus(C, add, G.cub_flags[oi], G.cub_scale + (long)oi * 3), e2);
+        for (int k = 0; k < 3; k++) G.Jp[((long)o * 6 + d) * 3 + k] = scalar * (e1[k] - e2[k]);
+    }
+}
+
+// thread per pose block: adds the camera-cuboid / point-cuboid terms (constructQuadraticForm) in edge order; thread per
+// camera-cuboid edge: the off-diagonal Hpp block.  pe_off/pe_list: per pose block, incident edges encoded as
+// (edge << 2) | kind, kind 0 = cobs seen from the camera, 1 = cobs seen from the cuboid, 2 = point-cuboid edge
+__global__ void __launch_bounds__(256) ba_lin_pose_edges(Params G, const int *pe_off, const int *pe_list) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < G.P) {
+        double H[36], b[6];
+        for (int k = 0; k < 36; k++) H[k] = G.Hpp[(long)t * 36 + k];
+        for (int k = 0; k < 6; k++) b[k] = G.bp[(long)t * 6 + k];
+        for (int q = pe_off[t]; q < pe_off[t + 1]; q++) {
+            const int kind = pe_list[q] & 3, o = pe_list[q] >> 2;
+            if (kind < 2) {
+                const double *J = G.Jc + ((long)o * 12 + (kind ? 6 : 0)) * 4; // column-major: J[d*4 + k]
+                const double *e = G.e_cobs + (long)o * 4, *w = G.c_info + (long)o * 4;
+                double rw = 1.0;
+                if (G.huber_obj > 0) { double rho[3]; huber(((e[0] * w[0] * e[0] + e[1] * w[1] * e[1]) + e[2] * w[2] * e[2]) + e[3] * w[3] * e[3], G.huber_obj, rho); rw = rho[1]; }
+                for (int a = 0; a < 6; a++) {
+                    double sb = 0;
+                    for (int k = 0; k < 4; k++) sb += J[a * 4 + k] * (-w[k] * e[k] * rw);
+                    b[a] += sb;
+                    for (int c = 0; c < 6; c++) { double sh = 0; for (int k = 0; k < 4; k++) sh += (J[a * 4 + k] * (rw * w[k])) * J[c * 4 + k]; H[a * 6 + c] += sh; }
+                }
+            } else {
+                const double *J = G.Jp + (long)o * 18, *e = G.e_pc + (long)o * 3; // information = I, no kernel
+                for (int a = 0; a < 6; a++) {
+                    b[a] += ((J[a * 3] * -e[0]) + (J[a * 3 + 1] * -e[1])) + (J[a * 3 + 2] * -e[2]);
+                    for (int c = 0; c < 6; c++) H[a * 6 + c] += ((J[a * 3] * J[c * 3]) + (J[a * 3 + 1] * J[c * 3 + 1])) + (J[a * 3 + 2] * J[c * 3 + 2]);
+                }
+            }
+        }
+        for (int k = 0; k < 36; k++) G.Hpp[(long)t * 36 + k] = H[k];
+        for (int k = 0; k < 6; k++) G.bp[(long)t * 6 + k] = b[k];
+    } else if (t < G.P + G.n_cobs) {
+        const int o = t - G.P;
+        if (G.cam_idx[G.c_cam[o]] < 0) return;
+        const double *Ja = G.Jc + (long)o * 48, *Jb = Ja + 24, *e = G.e_cobs + (long)o * 4, *w = G.c_info + (long)o * 4;
+        double rw = 1.0;
+        if (G.huber_obj > 0) { double rho[3]; huber(((e[0] * w[0] * e[0] + e[1] * w[1] * e[1]) + e[2] * w[2] * e[2]) + e[3] * w[3] * e[3], G.huber_obj, rho); rw = rho[1]; }
+        for (int a = 0; a < 6; a++) for (int c = 0; c < 6; c++) { double sh = 0; for (int k = 0; k < 4; k++) sh += (Ja[a * 4 + k] * (rw * w[k])) * Jb[c * 4 + k]; G.Hoff[(long)o * 36 + a * 6 + c] = sh; }
+    }
+}
+
+__global__ void __launch_bounds__(256) ba_lm_dinv(Params G, double lambda) { // block_solver.hpp:383-395
+    const int li = G.lm_b + blockIdx.x * 256 + threadIdx.x;
+    if (li >= G.lm_e) return;
+    double D[9], Di[9];
+    for (int k = 0; k < 9; k++) D[k] = G.Hll[(long)li * 9 + k];
+    D[0] += lambda; D[4] += lambda; D[8] += lambda;
+    auto cf = [&](int i, int j) { int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3; return D[i1 * 3 + j1] * D[i2 * 3 + j2] - D[i1 * 3 + j2] * D[i2 * 3 + j1]; };
+    const double c00 = cf(0, 0), c10 = cf(1, 0), c20 = cf(2, 0);
+    const double det = (c00 * D[0] + c10 * D[3]) + c20 * D[6], inv = 1.0 / det;
+    Di[0] = c00 * inv; Di[1] = c10 * inv; Di[2] = c20 * inv;
+    Di[3] = cf(0, 1) * inv; Di[4] = cf(1, 1) * inv; Di[5] = cf(2, 1) * inv;
+    Di[6] = cf(0, 2) * inv; Di[7] = cf(1, 2) * inv; Di[8] = cf(2, 2) * inv;
+    const double *b = G.bl + (long)li * 3;
+    for (int k = 0; k < 9; k++) G.Dinv[(long)li * 9 + k] = Di[k];
+    for (int a = 0; a < 3; a++) G.db[(long)li * 3 + a] = (Di[a * 3] * b[0] + Di[a * 3 + 1] * b[1]) + Di[a * 3 + 2] * b[2];
+}
+
+// wave per block of the reduced system.  slot s < P: diagonal block of pose s; P <= s < P + n_cobs: camera-cuboid block;
+// the rest: camera-camera blocks created by shared landmarks.  trip_*: contributing (obs_u, obs_v) pairs, this rank only.
+__global__ void __launch_bounds__(256) ba_schur_slots(Params G, int n_slots, const int *slot_off, const int2 *trips, double lambda, double *S) {
+    const int s = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (s >= n_slots) return;
+    double acc[36];
+#pragma unroll
+    for (int k = 0; k < 36; k++) acc[k] = 0;
+    for (int q = slot_off[s] + lane; q < slot_off[s + 1]; q += 64) {
+        const int u = trips[q].x, v = trips[q].y;
+        const double *Bi = G.Hpl + (long)u * 18, *Bj = G.Hpl + (long)v * 18, *Di = G.Dinv + (long)G.o_pt[u] * 9;
+        double BD[18];
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+            for (int c = 0; c < 3; c++) BD[a * 3 + c] = (Bi[a * 3] * Di[c] + Bi[a * 3 + 1] * Di[3 + c]) + Bi[a * 3 + 2] * Di[6 + c];
+#pragma unroll
+        for (int a = 0; a < 6; a++)
+#pragma unroll
+            for (int c = 0; c < 6; c++) acc[a * 6 + c] -= (BD[a * 3] * Bj[c * 3] + BD[a * 3 + 1] * Bj[c * 3 + 1]) + BD[a * 3 + 2] * Bj[c * 3 + 2];
+    }
+#pragma unroll
+    for (int k = 0; k < 36; k++) for (int off = 32; off > 0; off >>= 1) acc[k] += __shfl_xor(acc[k], off);
+    if (lane == 0) {
+        if (s < G.P) for (int k = 0; k < 36; k++) acc[k] += G.Hpp[(long)s * 36 + k] + ((G.pose_edges && (k % 7) == 0) ? lambda : 0.0); // setLambda on rank 0 only
+        else if (s < G.P + G.n_cobs) { if (G.pose_edges && G.cam_idx[G.c_cam[s - G.P]] >= 0) for (int k = 0; k < 36; k++) acc[k] += G.Hoff[(long)(s - G.P) * 36 + k]; }
+        for (int k = 0; k < 36; k++) S[(long)s * 36 + k] = acc[k];
+    }
+}
+__global__ void __launch_bounds__(256) ba_schur_b(Params G, const int *pose_off, const int *pose_obs, double *bs) {
+    const int pi = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (pi >= G.P) return;
+    double acc[6] = {0, 0, 0, 0, 0, 0};
+    for (int q = pose_off[pi] + lane; q < pose_off[pi + 1]; q += 64) {
+        const int o = pose_obs[q];
+        const double *Bi = G.Hpl + (long)o * 18, *d = G.db + (long)G.o_pt[o] * 3;
+#pragma unroll
+        for (int a = 0; a < 6; a++) acc[a] -= (Bi[a * 3] * d[0] + Bi[a * 3 + 1] * d[1]) + Bi[a * 3 + 2] * d[2];
+    }
+#pragma unroll
+    for (int k = 0; k < 6; k++) for (int off = 32; off > 0; off >>= 1) acc[k] += __shfl_xor(acc[k], off);
+    if (lane == 0) for (int k = 0; k < 6; k++) bs[(long)pi * 6 + k] = G.bp[(long)pi * 6 + k] + acc[k];
+}
+
+// scatter the (all-reduced) blocks into the permuted lower band: band[(row * (B+1) + (row - col)) * 36]
+__global__ void ba_band_fill(int n_slots, const int *slot_row, const int *slot_col, const uint8_t *slot_tr, int B, const double *S, double *band) {
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= n_slots * 36) return;
+    const int s = t / 36, k = t % 36, r = k / 6, c = k % 6;
+    if (slot_row[s] < 0) return;
+    const double v = slot_tr[s] ? S[(long)s * 36 + c * 6 + r] : S[t];
+    band[((long)slot_row[s] * (B + 1) + (slot_row[s] - slot_col[s])) * 36 + k] = v;
+}
+
+// right-looking block Cholesky of the band, one workgroup; status != 0 if a pivot is not positive
+__global__ void __launch_bounds__(512) ba_band_chol(int n, int B, double *band, int *status) {
+    extern __shared__ double sh[];
+    double *Ljj = sh, *Lcol = sh + 36; // Lcol: B blocks of the current column
+    const int tid = threadIdx.x;
+    __shared__ int s_fail;
+    if (tid == 0) s_fail = 0;
+    __syncthreads();
+    for (int j = 0; j < n; j++) {
+        double *Ajj = band + ((long)j * (B + 1)) * 36;
+        if (tid == 0) { // dense Cholesky of the 6x6 diagonal block
+            double A[36];
+            for (int k = 0; k < 36; k++) A[k] = Ajj[k];
+            for (int c = 0; c < 6; c++) {
+                double d = A[c * 6 + c];
+                for (int t = 0; t < c; t++) d -= A[c * 6 + t] * A[c * 6 + t];
+                if (!(d > 0)) { s_fail = 1; d = 1; }
+                d = sqrt(d);
+                A[c * 6 + c] = d;
+                for (int r = c + 1; r < 6; r++) { double v = A[r * 6 + c]; for (int t = 0; t < c; t++) v -= A[r * 6 + t] * A[c * 6 + t]; A[r * 6 + c] = v / d; }
+                for (int r = 0; r < c; r++) A[r * 6 + c] = 0;
+            }
+            for (int k = 0; k < 36; k++) { Ajj[k] = A[k]; Ljj[k] = A[k]; }
+        }
+        __syncthreads();
+        const int nb = min(B, n - 1 - j);
+        for (int t = tid; t < nb * 6; t += 512) { // L_ij = A_ij Ljj^-T, one block row per task
+            const int bi = t / 6, r = t % 6, i = j + 1 + bi;
+            double *Aij = band + ((long)i * (B + 1) + (i - j)) * 36;
+            double row[6];
+            for (int c = 0; c < 6; c++) { double v = Aij[r * 6 + c]; for (int q = 0; q < c; q++) v -= row[q] * Ljj[c * 6 + q]; row[c] = v / Ljj[c * 6 + c]; }
+            for (int c = 0; c < 6; c++) { Aij[r * 6 + c] = row[c]; Lcol[bi * 36 + r * 6 + c] = row[c]; }
+        }
+        __syncthreads();
+        const int npair = nb * (nb + 1) / 2;
+        for (int t = tid; t < npair * 36; t += 512) { // A_ii' -= L_ij L_i'j^T for j < i' <= i
+            const int pr = t / 36, k = t % 36, r = k / 6, c = k % 6;
+            int bi = (int)((sqrt(8.0 * pr + 1.0) - 1.0) * 0.5);
+            while (bi * (bi + 1) / 2 > pr) bi--;
+            while ((bi + 1) * (bi + 2) / 2 <= pr) bi++;
+            const int bk = pr - bi * (bi + 1) / 2; // bk <= bi
+            const int i = j + 1 + bi, i2 = j + 1 + bk;
+            const double *Li = Lcol + bi * 36 + r * 6, *Lk = Lcol + bk * 36 + c * 6;
+            double v = 0;
+#pragma unroll
+            for (int q = 0; q < 6; q++) v += Li[q] * Lk[q];
+            band[((long)i * (B + 1) + (i - i2)) * 36 + k] -= v;
+        }
+        __syncthreads();
+    }
+    if (tid == 0) *status = s_fail;
+}
+// L y = b then L^T x = y, right-looking sweeps; rhs is permuted in place: xperm[pos] (6 doubles per block)
+__global__ void __launch_bounds__(512) ba_band_solve(int n, int B, const double *band, double *xp) {
+    __shared__ double y[6];
+    const int tid = threadIdx.x;
+    for (int j = 0; j < n; j++) {
+        const double *Ljj = band + ((long)j * (B + 1)) * 36;
+        if (tid == 0) { for (int r = 0; r < 6; r++) { double v = xp[(long)j * 6 + r]; for (int t = 0; t < r; t++) v -= Ljj[r * 6 + t] * y[t]; y[r] = v / Ljj[r * 6 + r]; } for (int r = 0; r < 6; r++) xp[(long)j * 6 + r] = y[r]; }
+        __syncthreads();
+        const int nb = min(B, n - 1 - j);
+        for (int t = tid; t < nb * 6; t += 512) {
+            const int i = j + 1 + t / 6, r = t % 6;
+            const double *Lij = band + ((long)i * (B + 1) + (i - j)) * 36 + r * 6;
+            double v = 0;
+            for (int q = 0; q < 6; q++) v += Lij[q] * y[q];
+            xp[(long)i * 6 + r] -= v;
+        }
+        __syncthreads();
+    }
+    for (int i = n - 1; i >= 0; i--) {
+        const double *Lii = band + ((long)i * (B + 1)) * 36;
+        if (tid == 0) { for (int r = 5; r >= 0; r--) { double v = xp[(long)i * 6 + r]; for (int t = r + 1; t < 6; t++) v -= Lii[t * 6 + r] * y[t]; y[r] = v / Lii[r * 6 + r]; } for (int r = 0; r < 6; r++) xp[(long)i * 6 + r] = y[r]; }
+        __syncthreads();
+        const int nb = min(B, i);
+        for (int t = tid; t < nb * 6; t += 512) {
+            const int jj = i - 1 - t / 6, c = t % 6; // y_jj -= L_i,jj^T x_i
+            const double *Lij = band + ((long)i * (B + 1) + (i - jj)) * 36;
+            double v = 0;
+            for (int q = 0; q < 6; q++) v += Lij[q * 6 + c] * y[q];
+            xp[(long)jj * 6 + c] -= v;
+        }
+        __syncthreads();
+    }
+}
+__global__ void ba_permute(int P, const int *pos, const double *src, double *dst, int forward) { // forward: dst[pos[i]] = src[i]
+    const int t = blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= P * 6) return;
+    const int i = t / 6, k = t % 6;
+    if (forward) dst[(long)pos[i] * 6 + k] = src[t]; else dst[t] = src[(long)pos[i] * 6 + k];
+}
+
+__global__ void __launch_bounds__(256) ba_backsub(Params G) { // x_l = Dinv (b_l - B^T x_p), block_solver.hpp:459-485
+    const int li = G.lm_b + blockIdx.x * 256 + threadIdx.x;
+    if (li >= G.lm_e) return;
+    double cl[3] = {G.bl[(long)li * 3], G.bl[(long)li * 3 + 1], G.bl[(long)li * 3 + 2]};
+    for (int o = G.lm_off[li]; o < G.lm_off[li + 1]; o++) {
+        const int pi = G.cam_idx[G.o_cam[o]];
+        if (pi < 0) continue;
+        const double *Bi = G.Hpl + (long)o * 18, *xpp = G.x + (long)pi * 6;
+        for (int c = 0; c < 3; c++) { double s = 0; for (int a = 0; a < 6; a++) s += Bi[a * 3 + c] * xpp[a]; cl[c] -= s; }
+    }
+    const double *Di = G.Dinv + (long)li * 9;
+    for (int a = 0; a < 3; a++) G.x[(long)G.P * 6 + (long)li * 3 + a] = (Di[a * 3] * cl[0] + Di[a * 3 + 1] * cl[1]) + Di[a * 3 + 2] * cl[2];
+}
+
+// sum_j x_j (lambda x_j + b_j) (computeScale :182-189): landmark part of this rank + pose part (b_p partial; lambda term once)
+__global__ void __launch_bounds__(256) ba_scale(Params G, double lambda, double *partials) {
+    const long t = (long)blockIdx.x * 256 + threadIdx.x, nP = (long)G.P * 6, nL = (long)(G.lm_e - G.lm_b) * 3;
+    double v = 0;
+    if (t < nP) v = G.x[t] * ((G.pose_edges ? lambda * G.x[t] : 0.0) + G.bp[t]);
+    else if (t < nP + nL) { const long k = (long)G.lm_b * 3 + (t - nP); v = G.x[nP + k] * (lambda * G.x[nP + k] + G.bl[k]); }
+    block_sum_store(v, partials);
+}
+__global__ void __launch_bounds__(256) ba_update(Params G) { // SparseOptimizer::update -> oplus per vertex
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t < G.n_cams) {
+        const int pi = G.cam_idx[t];
+        if (pi < 0) return;
+        SE3 T = se3_mul(se3_exp(G.x + (long)pi * 6), se3_load(G.cam + (long)t * 7)); // VertexSE3Expmap::oplusImpl types_six_dof_expmap.h:73-91
+        se3_store(T, G.cam + (long)t * 7);
+    } else if (t < G.n_cams + G.n_cub) {
+        const int i = t - G.n_cams, pi = G.P - G.n_cub + i;
+        Cuboid c = cuboid_oplus(load_cuboid(G, i), G.x + (long)pi * 6, G.cub_flags[i], G.cub_scale + (long)i * 3);
+        se3_store(c.pose, G.cub + (long)i * 7);
+    } else {
+        const long k = (long)(t - G.n_cams - G.n_cub);
+        if (k < (long)(G.lm_e - G.lm_b) * 3) { const long q = (long)G.lm_b * 3 + k; G.pts[q] += G.x[(long)G.P * 6 + q]; } // VertexSBAPointXYZ::oplusImpl
+    }
+}
+__global__ void __launch_bounds__(256) ba_maxdiag(Params G, double *partials) { // max |H_jj| of this rank's landmark blocks (computeLambdaInit)
+    const int li = G.lm_b + blockIdx.x * 256 + threadIdx.x;
+    double v = 0;
+    if (li < G.lm_e) v = fmax(fmax(fabs(G.Hll[(long)li * 9]), fabs(G.Hll[(long)li * 9 + 4])), fabs(G.Hll[(long)li * 9 + 8]));
+    __shared__ double s[4];
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off));
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) partials[blockIdx.x] = fmax(fmax(s[0], s[1]), fmax(s[2], s[3]));
+}
+
+} // namespace
+
+struct cs_ba {
+    Params G{};
+    int rank = 0, world = 1, n_slots = 0, B = 0, max_part = 0;
+    cs_allreduce_fn allreduce = nullptr; void *ar_user = nullptr;
+    std::vector<void *> owned;
+    int *d_pose_off = nullptr, *d_pose_obs = nullptr, *d_pe_off = nullptr, *d_pe_list = nullptr, *d_slot_off = nullptr, *d_slot_row = nullptr, *d_slot_col = nullptr,
+        *d_pos = nullptr, *d_status = nullptr;
+    int2 *d_trips = nullptr; uint8_t *d_slot_tr = nullptr;
+    double *d_reduce = nullptr, *d_band = nullptr, *d_xperm = nullptr, *d_partials = nullptr, *d_scal = nullptr;
+    double *d_bak_cam = nullptr, *d_bak_pts = nullptr, *d_bak_cub = nullptr;
+    long reduce_len = 0, band_len = 0;
+    std::vector<int> obs_perm; // sorted-by-landmark position -> caller's observation index
+    std::vector<double> h_partials;
+};
+
+namespace {
+template <class T> int dalloc_copy(cs_ctx *ctx, cs_ba *b, T **d, const T *h, size_t n) {
+    int r = cs_dalloc(ctx, d, n); if (r) return r;
+    b->owned.push_back(*d);
+    if (h && n) { r = cs_h2d(ctx, *d, h, n); if (r) return r; }
+    return CS_OK;
+}
+static double sum_partials(cs_ctx *ctx, cs_ba *b, int n, bool is_max = false) {
+    b->h_partials.resize((size_t)std::max(n, 1));
+    hipMemcpyAsync(b->h_partials.data(), b->d_partials, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream);
+    hipStreamSynchronize(ctx->stream);
+    double s = 0;
+    for (int i = 0; i < n; i++) s = is_max ? std::max(s, b->h_partials[i]) : s + b->h_partials[i];
+    return s;
+}
+// sum of k host scalars across ranks (uses the device all-reduce callback)
+static int allreduce_scalars(cs_ctx *ctx, cs_ba *b, double *v, int k) {
+    if (b->world <= 1 || !b->allreduce) return CS_OK;
+    int r = cs_h2d(ctx, b->d_scal, v, (size_t)k); if (r) return r;
+    CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (b->allreduce(b->ar_user, b->d_scal, k) != 0) { ctx->err = "all-reduce callback failed"; return CS_ERR_HIP; }
+    r = cs_d2h(ctx, v, b->d_scal, (size_t)k); if (r) return r;
+    CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CS_OK;
+}
+static int ba_compute_errors(cs_ctx *ctx, cs_ba *b, double *chi2) { // computeActiveErrors + activeRobustChi2
+    const Params &G = b->G;
+    double chi = 0;
+    const int nb1 = (G.o_e - G.o_b + 255) / 256;
+    if (nb1 > 0) { CS_LAUNCH(ctx, "ba_err_obs", ba_err_obs, dim3(nb1), dim3(256), 0, G, b->d_partials); chi += sum_partials(ctx, b, nb1); }
+    if (G.pose_edges && G.n_cobs + G.n_pc > 0) {
+        const int nb2 = (G.n_cobs + G.n_pc + 255) / 256;
+        CS_LAUNCH(ctx, "ba_err_pose_edges", ba_err_pose_edges, dim3(nb2), dim3(256), 0, G, b->d_partials);
+        chi += sum_partials(ctx, b, nb2);
+    }
+    int r = allreduce_scalars(ctx, b, &chi, 1); if (r) return r;
+    *chi2 = chi;
+    return CS_OK;
+}
+static int ba_build_system(cs_ctx *ctx, cs_ba *b) { // BlockSolver::buildSystem
+    const Params &G = b->G;
+    const int nl = G.lm_e - G.lm_b;
+    if (nl > 0) CS_LAUNCH(ctx, "ba_lin_lm", ba_lin_lm, dim3((nl + 255) / 256), dim3(256), 0, G);
+    if (G.P > 0) CS_LAUNCH(ctx, "ba_lin_pose", ba_lin_pose, dim3((G.P + 3) / 4), dim3(256), 0, G, b->d_pose_off, b->d_pose_obs);
+    if (G.pose_edges && G.n_cobs + G.n_pc > 0) {
+        CS_LAUNCH(ctx, "ba_num_cols", ba_num_cols, dim3((G.n_cobs * 12 + G.n_pc * 6 + 255) / 256), dim3(256), 0, G);
+        CS_LAUNCH(ctx, "ba_lin_pose_edges", ba_lin_pose_edges, dim3((G.P + G.n_cobs + 255) / 256), dim3(256), 0, G, b->d_pe_off, b->d_pe_list);
+    }
+    return CS_OK;
+}
+static int ba_schur(cs_ctx *ctx, cs_ba *b, double lambda) { // Schur part of BlockSolver::solve, result in d_reduce = [slots | bschur]
+    const Params &G = b->G;
+    const int nl = G.lm_e - G.lm_b;
+    if (nl > 0) CS_LAUNCH(ctx, "ba_lm_dinv", ba_lm_dinv, dim3((nl + 255) / 256), dim3(256), 0, G, lambda);
+    CS_LAUNCH(ctx, "ba_schur_slots", ba_schur_slots, dim3((b->n_slots + 3) / 4), dim3(256), 0, G, b->n_slots, b->d_slot_off, b->d_trips, lambda, b->d_reduce);
+    CS_LAUNCH(ctx, "ba_schur_b", ba_schur_b, dim3((G.P + 3) / 4), dim3(256), 0, G, b->d_pose_off, b->d_pose_obs, b->d_reduce + (long)b->n_slots * 36);
+    return CS_OK;
+}
+static int ba_solve(cs_ctx *ctx, cs_ba *b, double lambda, bool *ok) { // BlockSolver::solve
+    const Params &G = b->G;
+    int r = ba_schur(ctx, b, lambda); if (r) return r;
+    if (b->world > 1 && b->allreduce) {
+        CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->begin("ba_allreduce");
+        int rc = b->allreduce(b->ar_user, b->d_reduce, b->reduce_len);
+        ctx->end();
+        if (rc != 0) { ctx->err = "all-reduce callback failed"; return CS_ERR_HIP; }
+    }
+    CS_HIP(ctx, hipMemsetAsync(b->d_band, 0, sizeof(double) * (size_t)b->band_len, ctx->stream));
+    CS_LAUNCH(ctx, "ba_band_fill", ba_band_fill, dim3((b->n_slots * 36 + 255) / 256), dim3(256), 0, b->n_slots, b->d_slot_row, b->d_slot_col, b->d_slot_tr, b->B, b->d_reduce,
+              b->d_band);
+    CS_LAUNCH(ctx, "ba_band_chol", ba_band_chol, dim3(1), dim3(512), sizeof(double) * (36 + (size_t)std::max(b->B, 1) * 36), G.P, b->B, b->d_band, b->d_status);
+    CS_LAUNCH(ctx, "ba_permute", ba_permute, dim3((G.P * 6 + 255) / 256), dim3(256), 0, G.P, b->d_pos, b->d_reduce + (long)b->n_slots * 36, b->d_xperm, 1);
+    CS_LAUNCH(ctx, "ba_band_solve", ba_band_solve, dim3(1), dim3(512), 0, G.P, b->B, b->d_band, b->d_xperm);
+    CS_LAUNCH(ctx, "ba_permute", ba_permute, dim3((G.P * 6 + 255) / 256), dim3(256), 0, G.P, b->d_pos, b->d_xperm, G.x, 0);
+    const int nl = G.lm_e - G.lm_b;
+    if (nl > 0) CS_LAUNCH(ctx, "ba_backsub", ba_backsub, dim3((nl + 255) / 256), dim3(256), 0, G);
+    int status = 0;
+    r = cs_d2h(ctx, &status, b->d_status, 1); if (r) return r;
+    CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *ok = status == 0;
+    return CS_OK;
+}
+} // namespace
+
+extern "C" {
+
+void cs_ba_destroy(cs_ctx *ctx, cs_ba *b) {
+    if (!b) return;
+    if (ctx) { hipSetDevice(ctx->device); hipStreamSynchronize(ctx->stream); }
+    for (void *p : b->owned) if (p) hipFree(p);
+    delete b;
+}
+int cs_ba_set_allreduce(cs_ba *b, cs_allreduce_fn fn, void *user) {
+    if (!b) return CS_ERR_BAD_ARG;
+    b->allreduce = fn; b->ar_user = user;
+    return CS_OK;
+}
+
+int cs_ba_create(cs_ctx *ctx, const cs_ba_problem *p, int rank, int world, cs_ba **out) {
+    if (!ctx || !p || !out || world < 1 || rank < 0 || rank >= world || p->n_cams < 1 || p->n_points < 0 || p->n_cuboids < 0 || p->n_obs < 0) return CS_ERR_BAD_ARG;
+    *out = nullptr;
+    CS_HIP(ctx, hipSetDevice(ctx->device));
+    cs_ba *b = new (std::nothrow) cs_ba();
+    if (!b) return CS_ERR_NOMEM;
+    b->rank = rank; b->world = world;
+    Params &G = b->G;
+    G.n_cams = p->n_cams; G.L = p->n_points; G.n_cub = p->n_cuboids; G.n_obs = p->n_obs; G.n_cobs = p->n_cobs; G.n_pc = p->n_pc;
+    G.fx = p->fx; G.fy = p->fy; G.cx = p->cx; G.cy = p->cy; G.huber_mono = p->huber_mono; G.huber_obj = p->huber_obj; G.margin_ratio = p->max_outside_margin_ratio;
+    for (int i = 0; i < 9; i++) G.K[i] = p->K[i];
+    G.pose_edges = rank == 0; // camera-cuboid and point-cuboid edges (and setLambda on the pose diagonal) live on rank 0
+    // index mapping: non-fixed cameras, then cuboids (sparse_optimizer.cpp:166-190: non-marginalised first, by vertex id)
+    std::vector<int> cam_idx(p->n_cams, -1);
+    int P = 0;
+    for (int i = 0; i < p->n_cams; i++) if (!p->cam_fixed[i]) cam_idx[i] = P++;
+    const int first_cub = P;
+    P += p->n_cuboids;
+    G.P = P;
+    if (P < 1) { delete b; return CS_ERR_BAD_ARG; }
+    // observations sorted by landmark (stable): CSR by landmark
+    for (int o = 0; o < p->n_obs; o++) if (p->obs_point[o] < 0 || p->obs_point[o] >= p->n_points || p->obs_cam[o] < 0 || p->obs_cam[o] >= p->n_cams) { delete b; return CS_ERR_BAD_ARG; }
+    b->obs_perm.resize(p->n_obs);
+    for (int o = 0; o < p->n_obs; o++) b->obs_perm[o] = o;
+    std::stable_sort(b->obs_perm.begin(), b->obs_perm.end(), [&](int a, int c) { return p->obs_point[a] < p->obs_point[c]; });
+    std::vector<int> o_cam(p->n_obs), o_pt(p->n_obs), lm_off(p->n_points + 1, 0);
+    std::vector<double> o_uv((size_t)p->n_obs * 2), o_w(p->n_obs);
+    for (int q = 0; q < p->n_obs; q++) {
+        const int o = b->obs_perm[q];
+        o_cam[q] = p->obs_cam[o]; o_pt[q] = p->obs_point[o]; o_uv[q * 2] = p->obs_uv[o * 2]; o_uv[q * 2 + 1] = p->obs_uv[o * 2 + 1]; o_w[q] = p->obs_inv_sigma2[o];
+        lm_off[o_pt[q] + 1]++;
+    }
+    for (int l = 0; l < p->n_points; l++) lm_off[l + 1] += lm_off[l];
+    G.lm_b = (int)((long)p->n_points * rank / world); G.lm_e = (int)((long)p->n_points * (rank + 1) / world);
+    G.o_b = lm_off[G.lm_b]; G.o_e = lm_off[G.lm_e];
+    // per pose block: this rank's observations (ascending)
+    std::vector<int> pose_off(P + 1, 0), pose_obs;
+    for (int q = G.o_b; q < G.o_e; q++) if (cam_idx[o_cam[q]] >= 0) pose_off[cam_idx[o_cam[q]] + 1]++;
+    for (int i = 0; i < P; i++) pose_off[i + 1] += pose_off[i];
+    pose_obs.resize(std::max(pose_off[P], 1));
+    { std::vector<int> pos(pose_off.begin(), pose_off.end() - 1); for (int q = G.o_b; q < G.o_e; q++) { int pi = cam_idx[o_cam[q]]; if (pi >= 0) pose_obs[pos[pi]++] = q; } }
+    // pose-edge incidence (edge order: camera-cuboid edges, then point-cuboid edges)
+    std::vector<std::vector<int>> pe(P);
+    for (int o = 0; o < p->n_cobs; o++) {
+        if (p->cobs_cam[o] < 0 || p->cobs_cam[o] >= p->n_cams || p->cobs_cuboid[o] < 0 || p->cobs_cuboid[o] >= p->n_cuboids) { delete b; return CS_ERR_BAD_ARG; }
+        if (cam_idx[p->cobs_cam[o]] >= 0) pe[cam_idx[p->cobs_cam[o]]].push_back((o << 2) | 0);
+        pe[first_cub + p->cobs_cuboid[o]].push_back((o << 2) | 1);
+    }
+    for (int o = 0; o < p->n_pc; o++) pe[first_cub + p->pc_cuboid[o]].push_back((o << 2) | 2);
+    std::vector<int> pe_off(P + 1, 0), pe_list;
+    for (int i = 0; i < P; i++) { pe_off[i + 1] = pe_off[i] + (int)pe[i].size(); pe_list.insert(pe_list.end(), pe[i].begin(), pe[i].end()); }
+    if (pe_list.empty()) pe_list.push_back(0);
+    // Schur pattern (BlockSolver::buildStructure block_solver.hpp:143-295) over ALL landmarks (identical on every rank);
+    // the contributing (obs_u, obs_v) pairs only for this rank's landmarks
+    std::map<std::pair<int, int>, int> slot_of;
+    std::vector<std::pair<int, int>> slot_rc;
+    for (int i = 0; i < P; i++) { slot_of[std::make_pair(i, i)] = i; slot_rc.push_back(std::make_pair(i, i)); }
+    for (int o = 0; o < p->n_cobs; o++) { // one block per camera-cuboid edge, slot P + o (fixed cameras: unused block)
+        const int pi = cam_idx[p->cobs_cam[o]], pj = first_cub + p->cobs_cuboid[o];
+        slot_rc.push_back(pi >= 0 ? std::make_pair(pi, pj) : std::make_pair(-1, -1)); // fixed camera: dead block
+        if (pi >= 0) slot_of[std::make_pair(pi, pj)] = P + o;
+    }
+    std::vector<std::vector<int2>> slot_trips;
+    slot_trips.resize(slot_rc.size());
+    for (int l = 0; l < p->n_points; l++) {
+        const bool mine = l >= G.lm_b && l < G.lm_e;
+        for (int u = lm_off[l]; u < lm_off[l + 1]; u++) {
+            const int i1 = cam_idx[o_cam[u]];
+            if (i1 < 0) continue;
+            for (int v = lm_off[l]; v < lm_off[l + 1]; v++) {
+                const int i2 = cam_idx[o_cam[v]];
+                if (i2 < i1 || (i2 == i1 && v != u)) continue;
+                auto key = std::make_pair(i1, i2);
+                auto it = slot_of.find(key);
+                int s;
+                if (it == slot_of.end()) { s = (int)slot_rc.size(); slot_of[key] = s; slot_rc.push_back(key); slot_trips.emplace_back(); }
+                else s = it->second;
+                if (mine) slot_trips[s].push_back(make_int2(u, v));
+            }
+        }
+    }
+    b->n_slots = (int)slot_rc.size();
+    std::vector<int> slot_off(b->n_slots + 1, 0);
+    std::vector<int2> trips;
+    for (int s = 0; s < b->n_slots; s++) { slot_off[s + 1] = slot_off[s] + (int)slot_trips[s].size(); trips.insert(trips.end(), slot_trips[s].begin(), slot_trips[s].end()); }
+    if (trips.empty()) trips.push_back(make_int2(0, 0));
+    // ordering of the pose blocks: reverse Cuthill-McKee on the block graph, then the band width
+    std::vector<std::vector<int>> adj(P);
+    for (auto &rc : slot_rc) if (rc.first != rc.second && rc.first >= 0) { adj[rc.first].push_back(rc.second); adj[rc.second].push_back(rc.first); }
+    for (auto &a : adj) { std::sort(a.begin(), a.end()); a.erase(std::unique(a.begin(), a.end()), a.end()); }
+    std::vector<int> order; order.reserve(P);
+    { std::vector<char> seen(P, 0);
+      for (int c0 = 0; c0 < P; c0++) {
+          if (seen[c0]) continue;
+          int start = c0;
+          { std::vector<char> s2(P, 0); std::queue<int> q; q.push(c0); s2[c0] = 1;
+            while (!q.empty()) { int u = q.front(); q.pop(); if (adj[u].size() < adj[start].size()) start = u; for (int v : adj[u]) if (!s2[v] && !seen[v]) { s2[v] = 1; q.push(v); } } }
+          std::queue<int> q; q.push(start); seen[start] = 1;
+          while (!q.empty()) {
+              int u = q.front(); q.pop(); order.push_back(u);
+              std::vector<int> nb;
+              for (int v : adj[u]) if (!seen[v]) { seen[v] = 1; nb.push_back(v); }
+              std::sort(nb.begin(), nb.end(), [&](int a, int c) { return adj[a].size() != adj[c].size() ? adj[a].size() < adj[c].size() : a < c; });
+              for (int v : nb) q.push(v);
+          }
+      }
+      std::reverse(order.begin(), order.end()); }
+    std::vector<int> pos(P);
+    for (int i = 0; i < P; i++) pos[order[i]] = i;
+    std::vector<int> slot_row(b->n_slots), slot_col(b->n_slots);
+    std::vector<uint8_t> slot_tr(b->n_slots);
+    int B = 0;
+    for (int s = 0; s < b->n_slots; s++) {
+        if (slot_rc[s].first < 0) { slot_row[s] = slot_col[s] = -1; slot_tr[s] = 0; continue; }
+        const int a = pos[slot_rc[s].first], c = pos[slot_rc[s].second];
+        if (a >= c) { slot_row[s] = a; slot_col[s] = c; slot_tr[s] = 0; } else { slot_row[s] = c; slot_col[s] = a; slot_tr[s] = 1; }
+        B = std::max(B, slot_row[s] - slot_col[s]);
+    }
+    if (B > 1000) { ctx->err = "reduced camera system band too wide for the band solver"; delete b; return CS_ERR_CAPACITY; }
+    b->B = B;
+    b->band_len = (long)P * (B + 1) * 36;
+    b->reduce_len = (long)b->n_slots * 36 + (long)P * 6;
+    const int nl = G.lm_e - G.lm_b;
+    b->max_part = std::max(std::max((G.o_e - G.o_b + 255) / 256, (p->n_cobs + p->n_pc + 255) / 256), std::max((int)(((long)P * 6 + (long)nl * 3 + 255) / 256), (nl + 255) / 256)) + 1;
+
+#define A_(call) do { int r__ = (call); if (r__ != CS_OK) { cs_ba_destroy(ctx, b); return r__; } } while (0)
+    int *d_cam_idx, *d_o_cam, *d_o_pt, *d_lm_off, *d_c_cam, *d_c_cub, *d_pc_cub, *d_pc_off;
+    double *d_o_uv, *d_o_w, *d_c_bbox, *d_c_info, *d_pc_pts;
+    uint8_t *d_flags;
+    const double zero4[4] = {0, 0, 0, 0}; const int zero2[2] = {0, 0};
+    A_(dalloc_copy(ctx, b, &G.cam, p->cam_pose, (size_t)p->n_cams * 7));
+    A_(dalloc_copy(ctx, b, &G.pts, p->points, (size_t)std::max(p->n_points, 1) * 3));
+    A_(dalloc_copy(ctx, b, &G.cub, p->cuboid_pose, (size_t)std::max(p->n_cuboids, 1) * 7));
+    A_(dalloc_copy(ctx, b, &G.cub_scale, p->cuboid_scale, (size_t)std::max(p->n_cuboids, 1) * 3));
+    A_(dalloc_copy(ctx, b, &d_flags, p->cuboid_flags, (size_t)std::max(p->n_cuboids, 1)));
+    A_(dalloc_copy(ctx, b, &d_cam_idx, cam_idx.data(), cam_idx.size()));
+    A_(dalloc_copy(ctx, b, &d_o_cam, o_cam.data(), (size_t)std::max(p->n_obs, 1)));
+    A_(dalloc_copy(ctx, b, &d_o_pt, o_pt.data(), (size_t)std::max(p->n_obs, 1)));
+    A_(dalloc_copy(ctx, b, &d_o_uv, o_uv.data(), (size_t)std::max(p->n_obs, 1) * 2));
+    A_(dalloc_copy(ctx, b, &d_o_w, o_w.data(), (size_t)std::max(p->n_obs, 1)));
+    A_(dalloc_copy(ctx, b, &d_lm_off, lm_off.data(), lm_off.size()));
+    A_(dalloc_copy(ctx, b, &d_c_cam, p->n_cobs ? p->cobs_cam : zero2, (size_t)std::max(p->n_cobs, 1)));
+    A_(dalloc_copy(ctx, b, &d_c_cub, p->n_cobs ? p->cobs_cuboid : zero2, (size_t)std::max(p->n_cobs, 1)));
+    A_(dalloc_copy(ctx, b, &d_c_bbox, p->n_cobs ? p->cobs_bbox : zero4, (size_t)std::max(p->n_cobs, 1) * 4));
+    A_(dalloc_copy(ctx, b, &d_c_info, p->n_cobs ? p->cobs_info : zero4, (size_t)std::max(p->n_cobs, 1) * 4));
+    A_(dalloc_copy(ctx, b, &d_pc_cub, p->n_pc ? p->pc_cuboid : zero2, (size_t)std::max(p->n_pc, 1)));
+    A_(dalloc_copy(ctx, b, &d_pc_off, p->n_pc ? p->pc_offsets : zero2, (size_t)p->n_pc + 1));
+    const int n_pcp = p->n_pc ? p->pc_offsets[p->n_pc] : 0;
+    A_(dalloc_copy(ctx, b, &d_pc_pts, n_pcp ? p->pc_points : zero4, (size_t)std::max(n_pcp, 1) * 3));
+    G.cam_idx = d_cam_idx; G.cub_flags = d_flags; G.o_cam = d_o_cam; G.o_pt = d_o_pt; G.o_uv = d_o_uv; G.o_w = d_o_w; G.lm_off = d_lm_off;
+    G.c_cam = d_c_cam; G.c_cub = d_c_cub; G.c_bbox = d_c_bbox; G.c_info = d_c_info; G.pc_cub = d_pc_cub; G.pc_off = d_pc_off; G.pc_pts = d_pc_pts;
+    A_(dalloc_copy(ctx, b, &G.e_obs, (const double *)nullptr, (size_t)std::max(p->n_obs, 1) * 2));
+    A_(dalloc_copy(ctx, b, &G.e_cobs, (const double *)nullptr, (size_t)std::max(p->n_cobs, 1) * 4));
+    A_(dalloc_copy(ctx, b, &G.e_pc, (const double *)nullptr, (size_t)std::max(p->n_pc, 1) * 3));
+    A_(dalloc_copy(ctx, b, &G.Hpl, (const double *)nullptr, (size_t)std::max(p->n_obs, 1) * 18));
+    A_(dalloc_copy(ctx, b, &G.Hll, (const double *)nullptr, (size_t)std::max(p->n_points, 1) * 9));
+    A_(dalloc_copy(ctx, b, &G.bl, (const double *)nullptr, (size_t)std::max(p->n_points, 1) * 3));
+    A_(dalloc_copy(ctx, b, &G.Dinv, (const double *)nullptr, (size_t)std::max(p->n_points, 1) * 9));
+    A_(dalloc_copy(ctx, b, &G.db, (const double *)nullptr, (size_t)std::max(p->n_points, 1) * 3));
+    A_(dalloc_copy(ctx, b, &G.Hpp, (const double *)nullptr, (size_t)P * 36));
+    A_(dalloc_copy(ctx, b, &G.bp, (const double *)nullptr, (size_t)P * 6));
+    A_(dalloc_copy(ctx, b, &G.Hoff, (const double *)nullptr, (size_t)std::max(p->n_cobs, 1) * 36));
+    A_(dalloc_copy(ctx, b, &G.Jc, (const double *)nullptr, (size_t)std::max(p->n_cobs, 1) * 48));
+    A_(dalloc_copy(ctx, b, &G.Jp, (const double *)nullptr, (size_t)std::max(p->n_pc, 1) * 18));
+    A_(dalloc_copy(ctx, b, &G.x, (const double *)nullptr, (size_t)P * 6 + (size_t)std::max(p->n_points, 1) * 3));
+    A_(dalloc_copy(ctx, b, &b->d_pose_off, pose_off.data(), pose_off.size()));
+    A_(dalloc_copy(ctx, b, &b->d_pose_obs, pose_obs.data(), pose_obs.size()));
+    A_(dalloc_copy(ctx, b, &b->d_pe_off, pe_off.data(), pe_off.size()));
+    A_(dalloc_copy(ctx, b, &b->d_pe_list, pe_list.data(), pe_list.size()));
+    A_(dalloc_copy(ctx, b, &b->d_slot_off, slot_off.data(), slot_off.size()));
+    A_(dalloc_copy(ctx, b, &b->d_trips, trips.data(), trips.size()));
+    A_(dalloc_copy(ctx, b, &b->d_slot_row, slot_row.data(), slot_row.size()));
+    A_(dalloc_copy(ctx, b, &b->d_slot_col, slot_col.data(), slot_col.size()));
+    A_(dalloc_copy(ctx, b, &b->d_slot_tr, slot_tr.data(), slot_tr.size()));
+    A_(dalloc_copy(ctx, b, &b->d_pos, pos.data(), pos.size()));
+    A_(dalloc_copy(ctx, b, &b->d_status, (const int *)nullptr, 1));
+    A_(dalloc_copy(ctx, b, &b->d_reduce, (const double *)nullptr, (size_t)b->reduce_len));
+    A_(dalloc_copy(ctx, b, &b->d_band, (const double *)nullptr, (size_t)b->band_len));
+    A_(dalloc_copy(ctx, b, &b->d_xperm, (const double *)nullptr, (size_t)P * 6));
+    A_(dalloc_copy(ctx, b, &b->d_partials, (const double *)nullptr, (size_t)b->max_part));
+    A_(dalloc_copy(ctx, b, &b->d_scal, (const double *)nullptr, (size_t)std::max(64, world)));
+    A_(dalloc_copy(ctx, b, &b->d_bak_cam, (const double *)nullptr, (size_t)p->n_cams * 7));
+    A_(dalloc_copy(ctx, b, &b->d_bak_pts, (const double *)nullptr, (size_t)std::max(p->n_points, 1) * 3));
+    A_(dalloc_copy(ctx, b, &b->d_bak_cub, (const double *)nullptr, (size_t)std::max(p->n_cuboids, 1) * 7));
+#undef A_
+    // estimates enter through SE3Quat(Vector7d): normalizeRotation (se3quat.h:64-67) -- done on the host copy
+    {
+        std::vector<double> cam(p->cam_pose, p->cam_pose + (size_t)p->n_cams * 7), cub(p->cuboid_pose, p->cuboid_pose + (size_t)p->n_cuboids * 7);
+        for (int i = 0; i < p->n_cams; i++) { SE3 T = se3_load(&cam[(size_t)i * 7]); normalize_rotation(T); se3_store(T, &cam[(size_t)i * 7]); }
+        for (int i = 0; i < p->n_cuboids; i++) { SE3 T = se3_load(&cub[(size_t)i * 7]); normalize_rotation(T); se3_store(T, &cub[(size_t)i * 7]); }
+        int r = cs_h2d(ctx, G.cam, cam.data(), cam.size());
+        if (!r && !cub.empty()) r = cs_h2d(ctx, G.cub, cub.data(), cub.size());
+        hipError_t e = hipStreamSynchronize(ctx->stream);
+        if (r || e != hipSuccess) { cs_ba_destroy(ctx, b); return r ? r : CS_ERR_HIP; }
+    }
+    *out = b;
+    return CS_OK;
+}
+
+int cs_ba_errors(cs_ctx *ctx, cs_ba *b, double *chi2, double *err_obs, double *err_cobs, double *err_pc) {
+    if (!ctx || !b || !chi2) return CS_ERR_BAD_ARG;
+    CS_HIP(ctx, hipSetDevice(ctx->device));
+    int r = ba_compute_errors(ctx, b, chi2); if (r) return r;
+    const Params &G = b->G;
+    if (err_obs) { // back to the caller's observation order
+        std::vector<double> e((size_t)std::max(G.n_obs, 1) * 2);
+        r = cs_d2h(ctx, e.data(), G.e_obs, (size_t)G.n_obs * 2); if (r) return r;
+        CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (int q = G.o_b; q < G.o_e; q++) { err_obs[(size_t)b->obs_perm[q] * 2] = e[(size_t)q * 2]; err_obs[(size_t)b->obs_perm[q] * 2 + 1] = e[(size_t)q * 2 + 1]; }
+    }
+    if (err_cobs && G.pose_edges) { r = cs_d2h(ctx, err_cobs, G.e_cobs, (size_t)G.n_cobs * 4); if (r) return r; }
+    if (err_pc && G.pose_edges) { r = cs_d2h(ctx, err_pc, G.e_pc, (size_t)G.n_pc * 3); if (r) return r; }
+    CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CS_OK;
+}
+
+int cs_ba_reduced_dense(cs_ctx *ctx, cs_ba *b, double lambda, double *H, double *bvec, int *Pout) {
+    if (!ctx || !b || !H || !bvec || !Pout) return CS_ERR_BAD_ARG;
+    CS_HIP(ctx, hipSetDevice(ctx->device));
+    double chi;
+    int r = ba_compute_errors(ctx, b, &chi); if (r) return r;
+    r = ba_build_system(ctx, b); if (r) return r;
+    r = ba_schur(ctx, b, lambda); if (r) return r;
+    std::vector<double> red((size_t)b->reduce_len);
+    std::vector<int> row(b->n_slots), col(b->n_slots), pos(b->G.P);
+    std::vector<uint8_t> tr(b->n_slots);
+    r = cs_d2h(ctx, red.data(), b->d_reduce, red.size()); if (r) return r;
+    r = cs_d2h(ctx, row.data(), b->d_slot_row, row.size()); if (r) return r;
+    r = cs_d2h(ctx, col.data(), b->d_slot_col, col.size()); if (r) return r;
+    r = cs_d2h(ctx, tr.data(), b->d_slot_tr, tr.size()); if (r) return r;
+    r = cs_d2h(ctx, pos.data(), b->d_pos, pos.size()); if (r) return r;
+    CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const int P = b->G.P, n = P * 6;
+    std::vector<int> inv(P);
+    for (int i = 0; i < P; i++) inv[pos[i]] = i;
+    std::fill(H, H + (size_t)n * n, 0.0);
+    for (int s = 0; s < b->n_slots; s++) {
+        if (row[s] < 0) continue;
+        int i = inv[row[s]], j = inv[col[s]];
+        if (tr[s]) std::swap(i, j); // the slot holds block (rows i, cols j) in pose numbering
+        for (int a = 0; a < 6; a++) for (int c = 0; c < 6; c++) {
+            const double v = red[(size_t)s * 36 + a * 6 + c];
+            H[(size_t)(i * 6 + a) * n + j * 6 + c] += v;
+            if (i != j) H[(size_t)(j * 6 + c) * n + i * 6 + a] += v;
+        }
+    }
+    for (int i = 0; i < n; i++) bvec[i] = red[(size_t)b->n_slots * 36 + i];
+    *Pout = P;
+    return CS_OK;
+}
+
+int cs_ba_read(cs_ctx *ctx, cs_ba *b, double *cam_pose, double *points, double *cuboid_pose) {
+    if (!ctx || !b) return CS_ERR_BAD_ARG;
+    const Params &G = b->G;
+    int r;
+    if (cam_pose) { r = cs_d2h(ctx, cam_pose, G.cam, (size_t)G.n_cams * 7); if (r) return r; }
+    if (points) { r = cs_d2h(ctx, points + (size_t)G.lm_b * 3, G.pts + (size_t)G.lm_b * 3, (size_t)(G.lm_e - G.lm_b) * 3); if (r) return r; }
+    if (cuboid_pose) { r = cs_d2h(ctx, cuboid_pose, G.cub, (size_t)G.n_cub * 7); if (r) return r; }
+    CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CS_OK;
+}
+
+int cs_ba_optimize(cs_ctx *ctx, cs_ba *b, int iterations, const volatile int *stop_flag, cs_ba_stats *st) {
+    if (!ctx || !b || iterations < 0) return CS_ERR_BAD_ARG;
+    CS_HIP(ctx, hipSetDevice(ctx->device));
+    if (b->world > 1 && !b->allreduce) { ctx->err = "sharded BA needs cs_ba_set_allreduce"; return CS_ERR_BAD_ARG; }
+    const Params &G = b->G;
+    cs_ba_stats S;
+    memset(&S, 0, sizeof(S));
+    double lambda = 0, ni = 2;
+    int nBad = 0, r;
+    const int nl = G.lm_e - G.lm_b;
+    auto terminate = [&]() { return stop_flag && *stop_flag; }; // sparse_optimizer.cpp:376, optimization_algorithm_levenberg.cpp:149
+    for (int it = 0; it < iterations && !terminate(); it++) { // OptimizationAlgorithmLevenberg::solve :61-164
+        double currentChi, tempChi;
+        r = ba_compute_errors(ctx, b, &currentChi); if (r) return r;
+        tempChi = currentChi;
+        const double iniChi = currentChi;
+        if (it == 0) S.chi2_init = currentChi;
+        r = ba_build_system(ctx, b); if (r) return r;
+        if (it == 0) { // computeLambdaInit :166-180: tau * max |diag(H)| over all active vertices
+            std::vector<double> v((size_t)G.P * 6 + (size_t)b->world, 0.0), hpp((size_t)G.P * 36);
+            r = cs_d2h(ctx, hpp.data(), G.Hpp, hpp.size()); if (r) return r;
+            double mxl = 0;
+            if (nl > 0) { CS_LAUNCH(ctx, "ba_maxdiag", ba_maxdiag, dim3((nl + 255) / 256), dim3(256), 0, G, b->d_partials); mxl = sum_partials(ctx, b, (nl + 255) / 256, true); }
+            CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            double mx = mxl;
+            if (b->world > 1) { // pose diagonals are sums over ranks; landmark maxima travel in per-rank slots of the same sum
+                std::vector<double> buf((size_t)G.P * 6 + b->world, 0.0);
+                for (int i = 0; i < G.P; i++) for (int k = 0; k < 6; k++) buf[(size_t)i * 6 + k] = hpp[(size_t)i * 36 + k * 7];
+                buf[(size_t)G.P * 6 + b->rank] = mxl;
+                for (size_t o0 = 0; o0 < buf.size(); o0 += 64) { int k = (int)std::min<size_t>(64, buf.size() - o0); r = allreduce_scalars(ctx, b, &buf[o0], k); if (r) return r; }
+                mx = 0;
+                for (double d : buf) mx = std::max(mx, std::fabs(d));
+            } else
+                for (int i = 0; i < G.P; i++) for (int k = 0; k < 6; k++) mx = std::max(mx, std::fabs(hpp[(size_t)i * 36 + k * 7]));
+            lambda = 1e-5 * mx; ni = 2; nBad = 0;
+        }
+        double rho = 0;
+        int qmax = 0;
+        do {
+            // push(): back up the estimates
+            CS_HIP(ctx, hipMemcpyAsync(b->d_bak_cam, G.cam, sizeof(double) * (size_t)G.n_cams * 7, hipMemcpyDeviceToDevice, ctx->stream));
+            if (G.L) CS_HIP(ctx, hipMemcpyAsync(b->d_bak_pts, G.pts, sizeof(double) * (size_t)G.L * 3, hipMemcpyDeviceToDevice, ctx->stream));
+            if (G.n_cub) CS_HIP(ctx, hipMemcpyAsync(b->d_bak_cub, G.cub, sizeof(double) * (size_t)G.n_cub * 7, hipMemcpyDeviceToDevice, ctx->stream));
+            bool ok2 = true;
+            r = ba_solve(ctx, b, lambda, &ok2); if (r) return r;
+            const int nbs = (int)(((long)G.P * 6 + (long)nl * 3 + 255) / 256);
+            CS_LAUNCH(ctx, "ba_scale", ba_scale, dim3(nbs), dim3(256), 0, G, lambda, b->d_partials);
+            double scale = sum_partials(ctx, b, nbs);
+            r = allreduce_scalars(ctx, b, &scale, 1); if (r) return r;
+            CS_LAUNCH(ctx, "ba_update", ba_update, dim3((G.n_cams + G.n_cub + nl * 3 + 255) / 256), dim3(256), 0, G);
+            r = ba_compute_errors(ctx, b, &tempChi); if (r) return r;
+            if (!ok2) tempChi = std::numeric_limits<double>::max();
+            rho = (currentChi - tempChi);
+            scale += 1e-3;
+            rho /= scale;
+            if (rho > 0 && std::isfinite(tempChi)) {
+                double alpha = 1. - std::pow((2 * rho - 1), 3);
+                alpha = (std::min)(alpha, 2. / 3.);
+                const double scaleFactor = (std::max)(1. / 3., alpha);
+                lambda *= scaleFactor;
+                ni = 2;
+                currentChi = tempChi; // discardTop
+            } else {
+                lambda *= ni;
+                ni *= 2; // pop(): restore
+                CS_HIP(ctx, hipMemcpyAsync(G.cam, b->d_bak_cam, sizeof(double) * (size_t)G.n_cams * 7, hipMemcpyDeviceToDevice, ctx->stream));
+                if (G.L) CS_HIP(ctx, hipMemcpyAsync(G.pts, b->d_bak_pts, sizeof(double) * (size_t)G.L * 3, hipMemcpyDeviceToDevice, ctx->stream));
+                if (G.n_cub) CS_HIP(ctx, hipMemcpyAsync(G.cub, b->d_bak_cub, sizeof(double) * (size_t)G.n_cub * 7, hipMemcpyDeviceToDevice, ctx->stream));
+            }
+            qmax++;
+            S.lm_trials++;
+        } while (rho < 0 && qmax < 10 && !terminate());
+        S.iterations = it + 1;
+        if (it < 64) S.chi2_trace[it] = currentChi;
+        S.chi2_final = currentChi;
+        if (qmax == 10 || rho == 0) break;
+        if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0; // stop criterion :155-161
+        if (nBad >= 3) break;
+    }
+    S.lambda_final = lambda;
+    CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (st) *st = S;
+    return CS_OK;
+}
+
+} // extern "C"

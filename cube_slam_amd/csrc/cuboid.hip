@@ -201,7 +201,6 @@ __global__ void __launch_bounds__(64) cuboid_unit_lines(const Unit *units, UnitD
                                                         double *mlines, double *mangle, double *mmid, int *status) {
     __shared__ double L[CS_MAX_ROI_LINES][4];
     __shared__ double ang[CS_MAX_ROI_LINES];
-    __shared__ int s_total;
     const int u = blockIdx.x, lane = threadIdx.x;
     const Unit &U = units[u];
     const FrameInfo &F = fi[U.frame];

@@ -130,3 +130,128 @@ def texture_image(seed, W, H, shift=0):
     im = np.clip(128 + 48 * im, 0, 255)
     s = int(shift) % 1024
     return np.ascontiguousarray(np.rint(im[:, s:s + W]).astype(np.uint8))
+
+
+# ----------------------------------------------------------------------------------------------- object BA
+KITTI_OBJ_HALF = np.array([1.9420, 0.8143, 0.7631])  # orb_object_slam/src/Optimizer.cc:994
+
+
+def _quat_from_R(R):
+    t = np.trace(R)
+    if t > 0:
+        s = math.sqrt(t + 1.0) * 2
+        q = np.array([(R[2, 1] - R[1, 2]) / s, (R[0, 2] - R[2, 0]) / s, (R[1, 0] - R[0, 1]) / s, 0.25 * s])
+    else:
+        i = int(np.argmax(np.diag(R))); j = (i + 1) % 3; k = (j + 1) % 3
+        s = math.sqrt(R[i, i] - R[j, j] - R[k, k] + 1.0) * 2
+        q = np.zeros(4)
+        q[i] = 0.25 * s; q[3] = (R[k, j] - R[j, k]) / s; q[j] = (R[j, i] + R[i, j]) / s; q[k] = (R[k, i] + R[i, k]) / s
+    if q[3] < 0:
+        q = -q
+    return q / np.linalg.norm(q)
+
+
+def _rot(axis, a):
+    c, s = math.cos(a), math.sin(a)
+    if axis == 0:
+        return np.array([[1, 0, 0], [0, c, -s], [0, s, c]])
+    if axis == 1:
+        return np.array([[c, 0, s], [0, 1, 0], [-s, 0, c]])
+    return np.array([[c, -s, 0], [s, c, 0], [0, 0, 1]])
+
+
+def _pose7(R, t):
+    return np.concatenate([t, _quat_from_R(R)])
+
+
+def ba_problem(seed, n_kf=1000, n_points=100000, n_cuboids=500, k_obs=5, W=1241, H=376, noise_px=1.0):
+    """Chain trajectory in a KITTI-like camera world (x right, y down, z forward; ground at y = +1.65):
+    keyframes 0.5 m apart on a gentle curve, points in a corridor each seen by ~k_obs consecutive keyframes, cuboids
+    (cars) along the road seen by ~10 keyframes through 2-D boxes and owning ~40 fixed surface points.
+    Returns a dict of numpy arrays (the SoA layout of cs_ba_problem)."""
+    rng = np.random.default_rng(seed)
+    K = K_KITTI
+    fx, fy, cx, cy = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
+    step, cam_h = 0.5, 1.65
+    yaw = 0.15 * np.sin(np.arange(n_kf) * step / 40.0)  # heading about the y axis
+    cz = np.cumsum(np.cos(yaw)) * step
+    cxw = np.cumsum(np.sin(yaw)) * step
+    centers = np.stack([cxw, np.zeros(n_kf), cz], axis=1)
+    Rwc = [_rot(1, a) for a in yaw]
+    cam_true = np.stack([_pose7(R.T, -R.T @ c) for R, c in zip(Rwc, centers)])
+
+    def project(i, Xw):
+        Xc = (Rwc[i].T @ (Xw - centers[i]).T).T
+        z = Xc[:, 2]
+        return np.stack([fx * Xc[:, 0] / z + cx, fy * Xc[:, 1] / z + cy], axis=1), z
+
+    # points: uniformly in the corridor around the path
+    s = rng.uniform(3, n_kf * step + 25, n_points)
+    ki = np.clip((s / step).astype(int), 0, n_kf - 1)
+    lat = rng.uniform(-15, 15, n_points)
+    pts = np.stack([cxw[ki] + lat, rng.uniform(cam_h - 3.0, cam_h, n_points), s], axis=1)
+    obs_cam, obs_pt, obs_uv, obs_w = [], [], [], []
+    for p in range(n_points):
+        first = max(0, int((pts[p, 2] - 30) / step))
+        got = 0
+        for i in range(first, min(n_kf, first + 80)):
+            uv, z = project(i, pts[p:p + 1])
+            if 2.0 < z[0] < 40.0 and 0 <= uv[0, 0] < W and 0 <= uv[0, 1] < H:
+                octave = int(rng.integers(0, 8))
+                obs_cam.append(i); obs_pt.append(p); obs_uv.append(uv[0] + rng.normal(0, noise_px, 2))
+                obs_w.append(float(np.float32(1.0) / (np.float32(1.2) ** np.float32(octave)) ** 2))
+                got += 1
+                if got >= k_obs:
+                    break
+    # cuboids: object z axis = world up (-y): R_align maps object (x fwd, y left, z up) into the camera world
+    R_align = np.array([[0, -1, 0], [0, 0, -1], [1, 0, 0]], float)
+    cub_pose, cobs_cam, cobs_cub, cobs_bbox, cobs_info, pc_cub, pc_off, pc_pts = [], [], [], [], [], [], [0], []
+    body = np.array([[1, 1, -1, -1, 1, 1, -1, -1], [1, -1, -1, 1, 1, -1, -1, 1], [-1, -1, -1, -1, 1, 1, 1, 1]], float)
+    for c in range(n_cuboids):
+        sc = rng.uniform(12, n_kf * step + 5)
+        k0 = int(np.clip(sc / step, 0, n_kf - 1))
+        side = rng.choice([-1.0, 1.0]) * rng.uniform(3.0, 6.0)
+        centre = np.array([cxw[k0] + side, cam_h - KITTI_OBJ_HALF[2], sc])
+        Ro = R_align @ _rot(2, rng.uniform(-0.3, 0.3) + (math.pi if rng.uniform() < 0.5 else 0.0))
+        cub_pose.append(_pose7(Ro, centre))
+        corners = (Ro @ (body * KITTI_OBJ_HALF[:, None])).T + centre
+        n_seen = 0
+        for i in range(max(0, k0 - 70), k0):
+            uv, z = project(i, corners)
+            if z.min() < 4 or z.max() > 40:
+                continue
+            x0, y0, x1, y1 = uv[:, 0].min(), uv[:, 1].min(), uv[:, 0].max(), uv[:, 1].max()
+            if x0 > 10 and y0 > 10 and x1 < W - 10 and y1 < H - 10:
+                bb = np.array([(x0 + x1) / 2, (y0 + y1) / 2, x1 - x0, y1 - y0]) + rng.normal(0, 3.0, 4)
+                q = rng.uniform(0.5, 1.0)
+                cobs_cam.append(i); cobs_cub.append(c); cobs_bbox.append(bb); cobs_info.append(np.full(4, (0.5 * q) ** 2))
+                n_seen += 1
+                if n_seen >= 10:
+                    break
+        local = rng.uniform(-1, 1, (40, 3)) * KITTI_OBJ_HALF
+        face = rng.integers(0, 3, 40)
+        local[np.arange(40), face] = np.sign(local[np.arange(40), face]) * KITTI_OBJ_HALF[face]
+        pc_cub.append(c); pc_pts.append((Ro @ local.T).T + centre + rng.normal(0, 0.05, (40, 3))); pc_off.append(pc_off[-1] + 40)
+    # perturbed initial estimates
+    cam_init = cam_true.copy()
+    for i in range(1, n_kf):
+        dR = _rot(0, rng.normal(0, math.radians(0.5))) @ _rot(1, rng.normal(0, math.radians(0.5))) @ _rot(2, rng.normal(0, math.radians(0.5)))
+        c_i = centers[i] + rng.normal(0, 0.05, 3)
+        Rn = Rwc[i] @ dR
+        cam_init[i] = _pose7(Rn.T, -Rn.T @ c_i)
+    cub_init = np.array(cub_pose).reshape(-1, 7).copy()
+    for c in range(len(cub_init)):
+        cub_init[c, :3] += rng.normal(0, 0.2, 3) * np.array([1, 0, 1])
+    cam_fixed = np.zeros(n_kf, np.uint8); cam_fixed[0] = 1
+    n_c = len(cub_init)
+    return {
+        "cam_pose": cam_init, "cam_fixed": cam_fixed, "points": pts + rng.normal(0, 0.05, pts.shape),
+        "cuboid_pose": cub_init, "cuboid_scale": np.tile(KITTI_OBJ_HALF, (n_c, 1)), "cuboid_flags": np.full(n_c, 1 | 8, np.uint8),
+        "obs_cam": np.array(obs_cam, np.int32), "obs_point": np.array(obs_pt, np.int32), "obs_uv": np.array(obs_uv, np.float64).reshape(-1, 2),
+        "obs_inv_sigma2": np.array(obs_w, np.float64), "fx": fx, "fy": fy, "cx": cx, "cy": cy, "huber_mono": math.sqrt(5.991),
+        "cobs_cam": np.array(cobs_cam, np.int32), "cobs_cuboid": np.array(cobs_cub, np.int32), "cobs_bbox": np.array(cobs_bbox, np.float64).reshape(-1, 4),
+        "cobs_info": np.array(cobs_info, np.float64).reshape(-1, 4), "K": K.copy(), "huber_obj": math.sqrt(900.0),
+        "pc_cuboid": np.array(pc_cub, np.int32), "pc_offsets": np.array(pc_off, np.int32),
+        "pc_points": np.concatenate(pc_pts).reshape(-1, 3) if pc_pts else np.zeros((0, 3)), "max_outside_margin_ratio": 2.0,
+        "cam_true": cam_true, "points_true": pts, "cuboid_true": np.array(cub_pose).reshape(-1, 7),
+    }

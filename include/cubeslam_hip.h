@@ -208,6 +208,54 @@ int cs_match_for_initialization(cs_ctx *ctx, cs_matcher *m, const cs_keypoint *k
 /* ORBmatcher::DescriptorDistance over all pairs: exact best / second-best per query (first index wins ties). */
 int cs_hamming_knn2(cs_ctx *ctx, const uint8_t *q, int nq, const uint8_t *t, int nt, int *best_idx, int *best_dist, int *second_dist);
 
+/* ===================================================================== object bundle adjustment
+ * Replaces the g2o machinery behind ORB_SLAM2::Optimizer::BundleAdjustment (orb_object_slam/include/Optimizer.h:39-41,
+ * src/Optimizer.cc:64-251) and Optimizer::LocalBACameraPointObjects (:826-1534): SparseOptimizer::optimize with
+ * OptimizationAlgorithmLevenberg + BlockSolver_6_3 (Schur) (vendored g2o core/optimization_algorithm_levenberg.cpp:61-189,
+ * core/block_solver.hpp:143-604) over VertexSE3Expmap / VertexSBAPointXYZ / VertexCuboidFixScale vertices and
+ * EdgeSE3ProjectXYZ / EdgeSE3CuboidFixScaleProj / EdgePointCuboidOnlyObjectFixScale edges (types_six_dof_expmap.*,
+ * orb_object_slam/include/g2o_Object.h, src/g2o_Object.cpp).  Residuals, Jacobians (analytic for reprojection, central
+ * differences with delta 1e-9 for the cuboid edges, as g2o does), Hessian blocks, the block-Schur reduction, the reduced
+ * solve (block-band Cholesky) and the landmark back-substitution run on the GPU; the LM control loop runs on the host.
+ * Poses are 7-vectors [tx ty tz qx qy qz qw] (SE3Quat::toVector). */
+typedef struct cs_ba_problem {
+    int n_cams; const double *cam_pose; const uint8_t *cam_fixed;                /* VertexSE3Expmap, world-to-camera */
+    int n_points; const double *points;                                         /* VertexSBAPointXYZ, marginalised */
+    int n_cuboids; const double *cuboid_pose; const double *cuboid_scale;       /* VertexCuboidFixScale (pose + fixedscale / scale) */
+    const uint8_t *cuboid_flags;  /* bit0 whether_fixrollpitch, bit1 whether_fixrotation, bit2 whether_fixheight, bit3 fixedscale set */
+    int n_obs; const int *obs_cam; const int *obs_point; const double *obs_uv; const double *obs_inv_sigma2; /* EdgeSE3ProjectXYZ */
+    double fx, fy, cx, cy, huber_mono;                                          /* Huber delta (sqrt(5.991)), 0 = no kernel */
+    int n_cobs; const int *cobs_cam; const int *cobs_cuboid; const double *cobs_bbox; const double *cobs_info; /* EdgeSE3CuboidFixScaleProj */
+    double K[9], huber_obj;
+    int n_pc; const int *pc_cuboid; const int *pc_offsets; const double *pc_points; double max_outside_margin_ratio; /* EdgePointCuboidOnlyObjectFixScale */
+} cs_ba_problem;
+
+typedef struct cs_ba_stats {
+    int iterations;            /* calls of OptimizationAlgorithmLevenberg::solve executed */
+    int lm_trials;             /* linear solves (accepted + rejected trials) */
+    double chi2_init, chi2_final, lambda_final;
+    double chi2_trace[64];
+} cs_ba_stats;
+
+typedef struct cs_ba cs_ba;
+/* all-reduce(sum) of n doubles in device memory across the ranks of a multi-GPU run; NULL for a single GPU */
+typedef int (*cs_allreduce_fn)(void *user, double *device_buf, long n);
+
+/* Builds the solver structure (index mapping, Schur pattern, ordering; BlockSolver::buildStructure) and uploads the graph.
+ * rank/world: landmarks (and their observations) are sharded across `world` ranks, cameras and cuboids are replicated;
+ * with world > 1 an all-reduce callback must be set. */
+int cs_ba_create(cs_ctx *ctx, const cs_ba_problem *p, int rank, int world, cs_ba **out);
+void cs_ba_destroy(cs_ctx *ctx, cs_ba *b);
+int cs_ba_set_allreduce(cs_ba *b, cs_allreduce_fn fn, void *user);
+/* SparseOptimizer::optimize(iterations).  stop_flag (may be NULL) is polled between LM trials like g2o's forceStopFlag. */
+int cs_ba_optimize(cs_ctx *ctx, cs_ba *b, int iterations, const volatile int *stop_flag, cs_ba_stats *stats);
+/* current estimates (any pointer may be NULL) */
+int cs_ba_read(cs_ctx *ctx, cs_ba *b, double *cam_pose, double *points, double *cuboid_pose);
+/* computeActiveErrors + activeRobustChi2 at the current estimates (this rank's share when sharded); err_* may be NULL */
+int cs_ba_errors(cs_ctx *ctx, cs_ba *b, double *chi2, double *err_obs, double *err_cobs, double *err_pc);
+/* Dense copy of this rank's reduced camera system (before the all-reduce) for lambda: H (6P x 6P row-major), b (6P); *P out */
+int cs_ba_reduced_dense(cs_ctx *ctx, cs_ba *b, double lambda, double *H, double *bvec, int *P);
+
 #ifdef __cplusplus
 }
 #endif

@@ -1,0 +1,632 @@
+/*
+ * oracle/ba_oracle.cpp -- CPU oracle for the g2o object bundle adjustment (BlockSolver_6_3 + Levenberg + Schur).
+ *
+ * TEST INFRASTRUCTURE ONLY (see oracle.h).  PARITY UNPINNED: restated from the vendored g2o under
+ * /root/reference/orb_object_slam/Thirdparty/g2o/g2o (core/optimization_algorithm_levenberg.cpp:61-189,
+ * core/block_solver.hpp:354-604, core/base_binary_edge.hpp:55-320, core/base_unary_edge.hpp:43-123,
+ * core/sparse_optimizer.cpp:61-114, core/robust_kernel_impl.cpp:78-91, types/se3quat.h, types/types_six_dof_expmap.*)
+ * and the CubeSLAM types of orb_object_slam/{include/g2o_Object.h, src/g2o_Object.cpp}.
+ * The linear solve replaces Eigen::SimplicialLDLT (un-vendored) by an exact block-envelope Cholesky after a reverse
+ * Cuthill-McKee ordering: any exact factorisation gives the same step up to round-off.
+ * Edges are processed in the order: point observations, camera-cuboid, point-cuboid (the reference's insertion order).
+ */
+#include "oracle.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <map>
+#include <queue>
+#include <vector>
+
+namespace {
+
+struct Quat { double x, y, z, w; };
+struct SE3 { Quat r; double t[3]; };
+typedef double M3[3][3];
+
+static inline Quat qmul(const Quat &a, const Quat &b) { // Eigen quaternion product
+    return Quat{a.w * b.x + a.x * b.w + a.y * b.z - a.z * b.y, a.w * b.y + a.y * b.w + a.z * b.x - a.x * b.z,
+                a.w * b.z + a.z * b.w + a.x * b.y - a.y * b.x, a.w * b.w - a.x * b.x - a.y * b.y - a.z * b.z};
+}
+static inline void qrot(const Quat &q, const double *v, double *o) { // Eigen QuaternionBase::_transformVector
+    double uv[3] = {q.y * v[2] - q.z * v[1], q.z * v[0] - q.x * v[2], q.x * v[1] - q.y * v[0]};
+    uv[0] += uv[0]; uv[1] += uv[1]; uv[2] += uv[2];
+    o[0] = v[0] + q.w * uv[0] + (q.y * uv[2] - q.z * uv[1]);
+    o[1] = v[1] + q.w * uv[1] + (q.z * uv[0] - q.x * uv[2]);
+    o[2] = v[2] + q.w * uv[2] + (q.x * uv[1] - q.y * uv[0]);
+}
+static inline void qtoR(const Quat &q, M3 R) { // Eigen toRotationMatrix
+    const double tx = 2 * q.x, ty = 2 * q.y, tz = 2 * q.z;
+    const double twx = tx * q.w, twy = ty * q.w, twz = tz * q.w, txx = tx * q.x, txy = ty * q.x, txz = tz * q.x, tyy = ty * q.y, tyz = tz * q.y, tzz = tz * q.z;
+    R[0][0] = 1 - (tyy + tzz); R[0][1] = txy - twz; R[0][2] = txz + twy;
+    R[1][0] = txy + twz; R[1][1] = 1 - (txx + tzz); R[1][2] = tyz - twx;
+    R[2][0] = txz - twy; R[2][1] = tyz + twx; R[2][2] = 1 - (txx + tyy);
+}
+static inline Quat qfromR(const M3 m) { // Eigen Quaterniond(Matrix3d)
+    Quat q;
+    double t = m[0][0] + m[1][1] + m[2][2];
+    if (t > 0) {
+        t = std::sqrt(t + 1.0); q.w = 0.5 * t; t = 0.5 / t;
+        q.x = (m[2][1] - m[1][2]) * t; q.y = (m[0][2] - m[2][0]) * t; q.z = (m[1][0] - m[0][1]) * t;
+    } else {
+        int i = 0;
+        if (m[1][1] > m[0][0]) i = 1;
+        if (m[2][2] > m[i][i]) i = 2;
+        int j = (i + 1) % 3, k = (j + 1) % 3;
+        double v[3];
+        t = std::sqrt(m[i][i] - m[j][j] - m[k][k] + 1.0);
+        v[i] = 0.5 * t; t = 0.5 / t;
+        q.w = (m[k][j] - m[j][k]) * t; v[j] = (m[j][i] + m[i][j]) * t; v[k] = (m[k][i] + m[i][k]) * t;
+        q.x = v[0]; q.y = v[1]; q.z = v[2];
+    }
+    return q;
+}
+static inline void normalize_rotation(SE3 &T) { // se3quat.h:331-336
+    if (T.r.w < 0) { T.r.x *= -1; T.r.y *= -1; T.r.z *= -1; T.r.w *= -1; }
+    double n = std::sqrt(T.r.x * T.r.x + T.r.y * T.r.y + T.r.z * T.r.z + T.r.w * T.r.w);
+    T.r.x /= n; T.r.y /= n; T.r.z /= n; T.r.w /= n;
+}
+static inline SE3 se3_mul(const SE3 &a, const SE3 &b) { // se3quat.h:110-116
+    SE3 r = a;
+    double rt[3];
+    qrot(a.r, b.t, rt);
+    r.t[0] += rt[0]; r.t[1] += rt[1]; r.t[2] += rt[2];
+    r.r = qmul(a.r, b.r);
+    normalize_rotation(r);
+    return r;
+}
+static inline SE3 se3_inv(const SE3 &a) { // :129-134
+    SE3 r;
+    r.r = Quat{-a.r.x, -a.r.y, -a.r.z, a.r.w};
+    double nt[3] = {a.t[0] * -1., a.t[1] * -1., a.t[2] * -1.};
+    qrot(r.r, nt, r.t);
+    return r;
+}
+static inline void se3_map(const SE3 &T, const double *p, double *o) { qrot(T.r, p, o); o[0] += T.t[0]; o[1] += T.t[1]; o[2] += T.t[2]; }
+static inline SE3 se3_from7(const double *v) { // [t, qx qy qz qw], normalizeRotation
+    SE3 T; T.t[0] = v[0]; T.t[1] = v[1]; T.t[2] = v[2]; T.r = Quat{v[3], v[4], v[5], v[6]};
+    normalize_rotation(T);
+    return T;
+}
+static inline void se3_to7(const SE3 &T, double *v) { v[0] = T.t[0]; v[1] = T.t[1]; v[2] = T.t[2]; v[3] = T.r.x; v[4] = T.r.y; v[5] = T.r.z; v[6] = T.r.w; }
+
+static inline void mat3mul(const M3 a, const M3 b, M3 c) {
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) c[i][j] = (a[i][0] * b[0][j] + a[i][1] * b[1][j]) + a[i][2] * b[2][j];
+}
+static SE3 se3_exp(const double *u) { // se3quat.h:272-306
+    const double om[3] = {u[0], u[1], u[2]}, up[3] = {u[3], u[4], u[5]};
+    const double theta = std::sqrt(om[0] * om[0] + om[1] * om[1] + om[2] * om[2]);
+    M3 O = {{0, -om[2], om[1]}, {om[2], 0, -om[0]}, {-om[1], om[0], 0}}, O2, R, V;
+    mat3mul(O, O, O2);
+    if (theta < 0.00001) {
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { R[i][j] = ((i == j ? 1.0 : 0.0) + O[i][j]) + O2[i][j]; V[i][j] = R[i][j]; }
+    } else {
+        const double a = std::sin(theta) / theta, b = (1 - std::cos(theta)) / (theta * theta), c = (theta - std::sin(theta)) / (std::pow(theta, 3));
+        for (int i = 0; i < 3; i++)
+            for (int j = 0; j < 3; j++) {
+                R[i][j] = ((i == j ? 1.0 : 0.0) + a * O[i][j]) + b * O2[i][j];
+                V[i][j] = ((i == j ? 1.0 : 0.0) + b * O[i][j]) + c * O2[i][j];
+            }
+    }
+    SE3 T;
+    T.r = qfromR(R);
+    for (int i = 0; i < 3; i++) T.t[i] = (V[i][0] * up[0] + V[i][1] * up[1]) + V[i][2] * up[2];
+    normalize_rotation(T);
+    return T;
+}
+static SE3 exptwist_norollpitch(const double *u) { // g2o_Object.cpp:24-54
+    const double om[3] = {u[0], u[1], u[2]}, up[3] = {u[3], u[4], u[5]};
+    const double theta = std::sqrt(om[0] * om[0] + om[1] * om[1] + om[2] * om[2]);
+    M3 O = {{0, -om[2], om[1]}, {om[2], 0, -om[0]}, {-om[1], om[0], 0}}, O2, V;
+    M3 R = {{std::cos(om[2]), -std::sin(om[2]), 0}, {std::sin(om[2]), std::cos(om[2]), 0}, {0, 0, 1}};
+    if (theta < 0.00001) { for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) V[i][j] = R[i][j]; }
+    else {
+        mat3mul(O, O, O2);
+        const double b = (1 - std::cos(theta)) / (theta * theta), c = (theta - std::sin(theta)) / (std::pow(theta, 3));
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) V[i][j] = ((i == j ? 1.0 : 0.0) + b * O[i][j]) + c * O2[i][j];
+    }
+    SE3 T;
+    T.r = qfromR(R);
+    for (int i = 0; i < 3; i++) T.t[i] = (V[i][0] * up[0] + V[i][1] * up[1]) + V[i][2] * up[2];
+    normalize_rotation(T);
+    return T;
+}
+
+struct Cuboid { SE3 pose; double scale[3]; };
+
+// VertexCuboidFixScale::oplusImpl g2o_Object.cpp:88-116
+static Cuboid cuboid_oplus(const Cuboid &e, const double *upd, int flags, const double *fixedscale) {
+    Cuboid n;
+    n.pose.r = Quat{0, 0, 0, 1}; n.pose.t[0] = n.pose.t[1] = n.pose.t[2] = 0;
+    if (flags & 2) { // whether_fixrotation
+        n.pose.r = e.pose.r;
+        for (int i = 0; i < 3; i++) n.pose.t[i] = e.pose.t[i] + upd[3 + i];
+    } else if (flags & 1) { // whether_fixrollpitch
+        double u2[6] = {0, 0, upd[2], upd[3], upd[4], upd[5]};
+        n.pose = se3_mul(e.pose, exptwist_norollpitch(u2));
+    } else
+        n.pose = se3_mul(e.pose, se3_exp(upd));
+    if (flags & 4) n.pose.t[1] = e.pose.t[1]; // whether_fixheight keeps y (:107-108)
+    for (int i = 0; i < 3; i++) n.scale[i] = (flags & 8) ? fixedscale[i] : e.scale[i];
+    return n;
+}
+
+// cuboid::projectOntoImageBbox g2o_Object.h:189-220 -> [cx, cy, w, h]
+static void project_bbox(const Cuboid &c, const SE3 &Tcw, const double *K, double *out) {
+    static const double body[3][8] = {{1, 1, -1, -1, 1, 1, -1, -1}, {1, -1, -1, 1, 1, -1, -1, 1}, {-1, -1, -1, -1, 1, 1, 1, 1}};
+    M3 Ro, Rc;
+    qtoR(c.pose.r, Ro);
+    qtoR(Tcw.r, Rc);
+    double rs[3][3];
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) rs[i][j] = Ro[i][j] * c.scale[j];
+    double mnx = 0, mny = 0, mxx = 0, mxy = 0;
+    for (int k = 0; k < 8; k++) {
+        double pw[3], pc[3];
+        for (int i = 0; i < 3; i++) pw[i] = ((rs[i][0] * body[0][k] + rs[i][1] * body[1][k]) + rs[i][2] * body[2][k]) + c.pose.t[i];
+        for (int i = 0; i < 3; i++) pc[i] = ((Rc[i][0] * pw[0] + Rc[i][1] * pw[1]) + Rc[i][2] * pw[2]) + Tcw.t[i];
+        double h[3];
+        for (int i = 0; i < 3; i++) h[i] = (K[i * 3] * pc[0] + K[i * 3 + 1] * pc[1]) + K[i * 3 + 2] * pc[2];
+        const double u = h[0] / h[2], v = h[1] / h[2];
+        if (k == 0) { mnx = mxx = u; mny = mxy = v; }
+        else { mnx = std::min(mnx, u); mxx = std::max(mxx, u); mny = std::min(mny, v); mxy = std::max(mxy, v); }
+    }
+    out[0] = (mxx + mnx) / 2; out[1] = (mxy + mny) / 2; out[2] = mxx - mnx; out[3] = mxy - mny;
+}
+
+struct State {
+    std::vector<SE3> cams; std::vector<double> pts; std::vector<Cuboid> cubs;
+};
+
+struct BA {
+    const orc_ba_problem *p;
+    State s;
+    std::vector<State> stack;
+    int P = 0, L = 0;                  // non-fixed pose blocks (cams then cuboids), landmarks
+    std::vector<int> cam_idx, cub_idx; // hessian block index or -1
+    // errors
+    std::vector<double> e_obs, e_cobs, e_pc;
+    // linear system
+    std::vector<double> Hpp_diag;      // P x 36
+    std::map<std::pair<int, int>, std::vector<double>> Hpp_off; // (i<j) -> 36, row-major block of rows i cols j
+    std::vector<double> Hll;           // L x 9
+    std::vector<double> Hpl;           // n_obs x 18 (6x3 row-major), valid if cam not fixed
+    std::vector<double> b;             // 6P + 3L
+    std::vector<double> x;             // 6P + 3L
+    std::vector<std::vector<int>> lm_obs; // per landmark: observation ids
+
+    explicit BA(const orc_ba_problem *pp) : p(pp) {
+        s.cams.resize(p->n_cams); s.cubs.resize(p->n_cuboids); s.pts.assign(p->points, p->points + (size_t)p->n_points * 3);
+        for (int i = 0; i < p->n_cams; i++) s.cams[i] = se3_from7(p->cam_pose + (size_t)i * 7);
+        for (int i = 0; i < p->n_cuboids; i++) { s.cubs[i].pose = se3_from7(p->cuboid_pose + (size_t)i * 7); for (int k = 0; k < 3; k++) s.cubs[i].scale[k] = p->cuboid_scale[i * 3 + k]; }
+        cam_idx.assign(p->n_cams, -1); cub_idx.assign(p->n_cuboids, -1);
+        for (int i = 0; i < p->n_cams; i++) if (!p->cam_fixed[i]) cam_idx[i] = P++;
+        for (int i = 0; i < p->n_cuboids; i++) cub_idx[i] = P++;
+        L = p->n_points;
+        lm_obs.resize(L);
+        for (int o = 0; o < p->n_obs; o++) lm_obs[p->obs_point[o]].push_back(o);
+        e_obs.resize((size_t)p->n_obs * 2); e_cobs.resize((size_t)p->n_cobs * 4); e_pc.resize((size_t)p->n_pc * 3);
+    }
+
+    void err_obs(int o, const SE3 &T, const double *X, double *e) const { // EdgeSE3ProjectXYZ::computeError
+        double pc[3];
+        se3_map(T, X, pc);
+        const double px = pc[0] / pc[2], py = pc[1] / pc[2];
+        e[0] = p->obs_uv[o * 2] - (px * p->fx + p->cx);
+        e[1] = p->obs_uv[o * 2 + 1] - (py * p->fy + p->cy);
+    }
+    void err_cobs(int o, const SE3 &T, const Cuboid &c, double *e) const { // EdgeSE3CuboidFixScaleProj::computeError
+        double bb[4];
+        project_bbox(c, T, p->K, bb);
+        for (int k = 0; k < 4; k++) e[k] = bb[k] - p->cobs_bbox[o * 4 + k];
+    }
+    void err_pc(int o, const Cuboid &c, double *e) const { // EdgePointCuboidOnlyObjectFixScale::computeError g2o_Object.cpp:336-354
+        double acc[3] = {0, 0, 0};
+        const int b0 = p->pc_offsets[o], b1 = p->pc_offsets[o + 1];
+        const SE3 inv = se3_inv(c.pose);
+        const double ratio = p->max_outside_margin_ratio;
+        for (int i = b0; i < b1; i++) {
+            double lp[3];
+            se3_map(inv, p->pc_points + (size_t)i * 3, lp);
+            for (int k = 0; k < 3; k++) {
+                const double a = std::fabs(lp[k]) * 1.0;
+                double er;
+                if (a < c.scale[k]) er = 0;
+                else if (a < (ratio + 1) * c.scale[k]) er = a - c.scale[k];
+                else er = ratio * c.scale[k];
+                acc[k] += std::fabs(er);
+            }
+        }
+        if (b1 > b0) for (int k = 0; k < 3; k++) acc[k] = acc[k] / (double)(b1 - b0);
+        for (int k = 0; k < 3; k++) e[k] = 1.0 * (acc[k] / c.scale[k]);
+    }
+    void compute_errors() {
+        for (int o = 0; o < p->n_obs; o++) err_obs(o, s.cams[p->obs_cam[o]], &s.pts[(size_t)p->obs_point[o] * 3], &e_obs[(size_t)o * 2]);
+        for (int o = 0; o < p->n_cobs; o++) err_cobs(o, s.cams[p->cobs_cam[o]], s.cubs[p->cobs_cuboid[o]], &e_cobs[(size_t)o * 4]);
+        for (int o = 0; o < p->n_pc; o++) err_pc(o, s.cubs[p->pc_cuboid[o]], &e_pc[(size_t)o * 3]);
+    }
+    static void huber(double e, double delta, double *rho) { // robust_kernel_impl.cpp:78-91
+        const double dsqr = delta * delta;
+        if (e <= dsqr) { rho[0] = e; rho[1] = 1.; rho[2] = 0.; }
+        else { const double sq = std::sqrt(e); rho[0] = 2 * sq * delta - dsqr; rho[1] = delta / sq; rho[2] = -0.5 * rho[1] / e; }
+    }
+    double chi2_obs(int o) const { const double *e = &e_obs[(size_t)o * 2]; return (e[0] * e[0] + e[1] * e[1]) * p->obs_inv_sigma2[o]; }
+    double chi2_cobs(int o) const { const double *e = &e_cobs[(size_t)o * 4]; const double *w = p->cobs_info + (size_t)o * 4; return ((e[0] * w[0] * e[0] + e[1] * w[1] * e[1]) + e[2] * w[2] * e[2]) + e[3] * w[3] * e[3]; }
+    double chi2_pc(int o) const { const double *e = &e_pc[(size_t)o * 3]; return (e[0] * e[0] + e[1] * e[1]) + e[2] * e[2]; }
+    double robust_chi2() const { // sparse_optimizer.cpp:100-114
+        double chi = 0, rho[3];
+        for (int o = 0; o < p->n_obs; o++) { double c = chi2_obs(o); if (p->huber_mono > 0) { huber(c, p->huber_mono, rho); chi += rho[0]; } else chi += c; }
+        for (int o = 0; o < p->n_cobs; o++) { double c = chi2_cobs(o); if (p->huber_obj > 0) { huber(c, p->huber_obj, rho); chi += rho[0]; } else chi += c; }
+        for (int o = 0; o < p->n_pc; o++) chi += chi2_pc(o);
+        return chi;
+    }
+
+    double *hpp_block(int i, int j) { // i <= j
+        if (i == j) return &Hpp_diag[(size_t)i * 36];
+        auto &v = Hpp_off[std::make_pair(i, j)];
+        if (v.empty()) v.assign(36, 0.0);
+        return v.data();
+    }
+    // BlockSolver::buildSystem (block_solver.hpp:502-560): linearizeOplus + constructQuadraticForm per edge
+    void build_system(int lm_begin, int lm_end, bool with_pose_edges) {
+        Hpp_diag.assign((size_t)P * 36, 0.0); Hpp_off.clear(); Hll.assign((size_t)L * 9, 0.0); Hpl.assign((size_t)p->n_obs * 18, 0.0);
+        b.assign((size_t)P * 6 + (size_t)L * 3, 0.0);
+        double rho[3];
+        for (int o = 0; o < p->n_obs; o++) {
+            const int li = p->obs_point[o];
+            if (li < lm_begin || li >= lm_end) continue;
+            const int ci = p->obs_cam[o], pi = cam_idx[ci];
+            const SE3 &T = s.cams[ci];
+            double pc[3];
+            se3_map(T, &s.pts[(size_t)li * 3], pc);
+            const double X = pc[0], Y = pc[1], Z = pc[2], Z2 = Z * Z, fx = p->fx, fy = p->fy;
+            M3 R; qtoR(T.r, R);
+            // EdgeSE3ProjectXYZ::linearizeOplus types_six_dof_expmap.cpp:135-171
+            const double tmp[2][3] = {{fx, 0, -X / Z * fx}, {0, fy, -Y / Z * fy}};
+            double Ji[2][3], Jj[2][6];
+            for (int r = 0; r < 2; r++) for (int c = 0; c < 3; c++) Ji[r][c] = ((-1. / Z * tmp[r][0]) * R[0][c] + (-1. / Z * tmp[r][1]) * R[1][c]) + (-1. / Z * tmp[r][2]) * R[2][c];
+            Jj[0][0] = X * Y / Z2 * fx; Jj[0][1] = -(1 + (X * X / Z2)) * fx; Jj[0][2] = Y / Z * fx; Jj[0][3] = -1. / Z * fx; Jj[0][4] = 0; Jj[0][5] = X / Z2 * fx;
+            Jj[1][0] = (1 + Y * Y / Z2) * fy; Jj[1][1] = -X * Y / Z2 * fy; Jj[1][2] = -X / Z * fy; Jj[1][3] = 0; Jj[1][4] = -1. / Z * fy; Jj[1][5] = Y / Z2 * fy;
+            const double *e = &e_obs[(size_t)o * 2];
+            double w = p->obs_inv_sigma2[o], rw = 1.0;
+            if (p->huber_mono > 0) { huber(chi2_obs(o), p->huber_mono, rho); rw = rho[1]; }
+            const double omr[2] = {-w * e[0] * rw, -w * e[1] * rw}; // omega_r = -omega*e, *= rho[1]
+            const double W = rw * w;                                 // weightedOmega = rho[1]*information (diag)
+            double *bl = &b[(size_t)P * 6 + (size_t)li * 3], *hl = &Hll[(size_t)li * 9];
+            for (int a = 0; a < 3; a++) {
+                bl[a] += Ji[0][a] * omr[0] + Ji[1][a] * omr[1];
+                for (int c = 0; c < 3; c++) hl[a * 3 + c] += (Ji[0][a] * W) * Ji[0][c] + (Ji[1][a] * W) * Ji[1][c];
+            }
+            if (pi >= 0) {
+                double *bp = &b[(size_t)pi * 6], *hp = &Hpp_diag[(size_t)pi * 36], *hx = &Hpl[(size_t)o * 18];
+                for (int a = 0; a < 6; a++) {
+                    bp[a] += Jj[0][a] * omr[0] + Jj[1][a] * omr[1];
+                    for (int c = 0; c < 6; c++) hp[a * 6 + c] += (Jj[0][a] * W) * Jj[0][c] + (Jj[1][a] * W) * Jj[1][c];
+                    for (int c = 0; c < 3; c++) hx[a * 3 + c] += (Jj[0][a] * W) * Ji[0][c] + (Jj[1][a] * W) * Ji[1][c];
+                }
+            }
+        }
+        if (!with_pose_edges) return;
+        const double delta = 1e-9, scalar = 1.0 / (2 * delta);
+        for (int o = 0; o < p->n_cobs; o++) { // EdgeSE3CuboidFixScaleProj: numeric Jacobians base_binary_edge.hpp:216-320
+            const int ci = p->cobs_cam[o], oi = p->cobs_cuboid[o], pi = cam_idx[ci], pj = cub_idx[oi];
+            double Ja[4][6], Jb[4][6];
+            for (int d = 0; d < 6; d++) {
+                double add[6] = {0, 0, 0, 0, 0, 0}, e1[4], e2[4];
+                if (pi >= 0) {
+                    add[d] = delta; err_cobs(o, se3_mul(se3_exp(add), s.cams[ci]), s.cubs[oi], e1);
+                    add[d] = -delta; err_cobs(o, se3_mul(se3_exp(add), s.cams[ci]), s.cubs[oi], e2);
+                    for (int k = 0; k < 4; k++) Ja[k][d] = scalar * (e1[k] - e2[k]);
+                }
+                add[d] = delta; err_cobs(o, s.cams[ci], cuboid_oplus(s.cubs[oi], add, p->cuboid_flags[oi], p->cuboid_scale + (size_t)oi * 3), e1);
+                add[d] = -delta; err_cobs(o, s.cams[ci], cuboid_oplus(s.cubs[oi], add, p->cuboid_flags[oi], p->cuboid_scale + (size_t)oi * 3), e2);
+                for (int k = 0; k < 4; k++) Jb[k][d] = scalar * (e1[k] - e2[k]);
+            }
+            const double *e = &e_cobs[(size_t)o * 4], *w = p->cobs_info + (size_t)o * 4;
+            double rw = 1.0;
+            if (p->huber_obj > 0) { huber(chi2_cobs(o), p->huber_obj, rho); rw = rho[1]; }
+            double omr[4], W[4];
+            for (int k = 0; k < 4; k++) { omr[k] = -w[k] * e[k] * rw; W[k] = rw * w[k]; }
+            auto accum = [&](const double J1[4][6], const double J2[4][6], double *blk) {
+                for (int a = 0; a < 6; a++) for (int c = 0; c < 6; c++) {
+                    double sacc = 0;
+                    for (int k = 0; k < 4; k++) sacc += (J1[k][a] * W[k]) * J2[k][c];
+                    blk[a * 6 + c] += sacc;
+                }
+            };
+            if (pi >= 0) {
+                for (int a = 0; a < 6; a++) { double sacc = 0; for (int k = 0; k < 4; k++) sacc += Ja[k][a] * omr[k]; b[(size_t)pi * 6 + a] += sacc; }
+                accum(Ja, Ja, hpp_block(pi, pi));
+                accum(Ja, Jb, hpp_block(pi, pj)); // cameras precede cuboids: pi < pj
+            }
+            for (int a = 0; a < 6; a++) { double sacc = 0; for (int k = 0; k < 4; k++) sacc += Jb[k][a] * omr[k]; b[(size_t)pj * 6 + a] += sacc; }
+            accum(Jb, Jb, hpp_block(pj, pj));
+        }
+        for (int o = 0; o < p->n_pc; o++) { // EdgePointCuboidOnlyObjectFixScale: base_unary_edge.hpp:82-123, no robust kernel, information = I
+            const int oi = p->pc_cuboid[o], pj = cub_idx[oi];
+            double J[3][6];
+            for (int d = 0; d < 6; d++) {
+                double add[6] = {0, 0, 0, 0, 0, 0}, e1[3], e2[3];
+                add[d] = delta; err_pc(o, cuboid_oplus(s.cubs[oi], add, p->cuboid_flags[oi], p->cuboid_scale + (size_t)oi * 3), e1);
+                add[d] = -delta; err_pc(o, cuboid_oplus(s.cubs[oi], add, p->cuboid_flags[oi], p->cuboid_scale + (size_t)oi * 3), e2);
+                for (int k = 0; k < 3; k++) J[k][d] = scalar * (e1[k] - e2[k]);
+            }
+            const double *e = &e_pc[(size_t)o * 3];
+            double *blk = hpp_block(pj, pj);
+            for (int a = 0; a < 6; a++) {
+                b[(size_t)pj * 6 + a] += ((J[0][a] * -e[0]) + (J[1][a] * -e[1])) + (J[2][a] * -e[2]);
+                for (int c = 0; c < 6; c++) blk[a * 6 + c] += ((J[0][a] * J[0][c]) + (J[1][a] * J[1][c])) + (J[2][a] * J[2][c]);
+            }
+        }
+    }
+
+    // reduced camera system for landmarks [lm_begin, lm_end): Hs (block map upper incl. diag), bs
+    void schur(double lambda, bool lambda_on_poses, int lm_begin, int lm_end, std::map<std::pair<int, int>, std::vector<double>> &Hs, std::vector<double> &bs,
+               std::vector<double> *Dinv_out) {
+        Hs.clear();
+        for (int i = 0; i < P; i++) {
+            std::vector<double> d(&Hpp_diag[(size_t)i * 36], &Hpp_diag[(size_t)i * 36] + 36);
+            if (lambda_on_poses) for (int k = 0; k < 6; k++) d[k * 7] += lambda;
+            Hs[std::make_pair(i, i)] = d;
+        }
+        for (auto &kv : Hpp_off) Hs[kv.first] = kv.second;
+        bs.assign(b.begin(), b.begin() + (size_t)P * 6);
+        if (Dinv_out) Dinv_out->assign((size_t)L * 9, 0.0);
+        for (int li = lm_begin; li < lm_end; li++) { // block_solver.hpp:378-432
+            double D[9], Di[9];
+            for (int k = 0; k < 9; k++) D[k] = Hll[(size_t)li * 9 + k];
+            D[0] += lambda; D[4] += lambda; D[8] += lambda;
+            { // Eigen fixed 3x3 inverse
+                auto cf = [&](int i, int j) { int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3; return D[i1 * 3 + j1] * D[i2 * 3 + j2] - D[i1 * 3 + j2] * D[i2 * 3 + j1]; };
+                double c00 = cf(0, 0), c10 = cf(1, 0), c20 = cf(2, 0);
+                double det = (c00 * D[0] + c10 * D[3]) + c20 * D[6], inv = 1.0 / det;
+                Di[0] = c00 * inv; Di[1] = c10 * inv; Di[2] = c20 * inv;
+                Di[3] = cf(0, 1) * inv; Di[4] = cf(1, 1) * inv; Di[5] = cf(2, 1) * inv;
+                Di[6] = cf(0, 2) * inv; Di[7] = cf(1, 2) * inv; Di[8] = cf(2, 2) * inv;
+            }
+            if (Dinv_out) for (int k = 0; k < 9; k++) (*Dinv_out)[(size_t)li * 9 + k] = Di[k];
+            const double *bl = &b[(size_t)P * 6 + (size_t)li * 3];
+            double db[3];
+            for (int a = 0; a < 3; a++) db[a] = (Di[a * 3] * bl[0] + Di[a * 3 + 1] * bl[1]) + Di[a * 3 + 2] * bl[2];
+            const std::vector<int> &obs = lm_obs[li];
+            for (size_t u = 0; u < obs.size(); u++) {
+                const int i1 = cam_idx[p->obs_cam[obs[u]]];
+                if (i1 < 0) continue;
+                const double *Bi = &Hpl[(size_t)obs[u] * 18];
+                double BD[18];
+                for (int a = 0; a < 6; a++) for (int c = 0; c < 3; c++) BD[a * 3 + c] = (Bi[a * 3] * Di[c] + Bi[a * 3 + 1] * Di[3 + c]) + Bi[a * 3 + 2] * Di[6 + c];
+                for (int a = 0; a < 6; a++) bs[(size_t)i1 * 6 + a] -= (Bi[a * 3] * db[0] + Bi[a * 3 + 1] * db[1]) + Bi[a * 3 + 2] * db[2];
+                for (size_t v = 0; v < obs.size(); v++) {
+                    const int i2 = cam_idx[p->obs_cam[obs[v]]];
+                    if (i2 < i1 || (i2 == i1 && v != u)) continue; // a landmark is seen at most once per keyframe (map<KeyFrame*, size_t>)
+                    const double *Bj = &Hpl[(size_t)obs[v] * 18];
+                    auto &blk = Hs[std::make_pair(i1, i2)];
+                    if (blk.empty()) blk.assign(36, 0.0);
+                    for (int a = 0; a < 6; a++) for (int c = 0; c < 6; c++)
+                        blk[a * 6 + c] -= (BD[a * 3] * Bj[c * 3] + BD[a * 3 + 1] * Bj[c * 3 + 1]) + BD[a * 3 + 2] * Bj[c * 3 + 2];
+                }
+            }
+        }
+    }
+
+    // exact solve of the block-sparse SPD system (upper blocks given): RCM ordering + block-envelope Cholesky
+    bool solve_reduced(const std::map<std::pair<int, int>, std::vector<double>> &Hs, const std::vector<double> &bs, double *xp) const {
+        const int n = P;
+        if (n == 0) return true;
+        std::vector<std::vector<int>> adj(n);
+        for (auto &kv : Hs) if (kv.first.first != kv.first.second) { adj[kv.first.first].push_back(kv.first.second); adj[kv.first.second].push_back(kv.first.first); }
+        std::vector<int> order; order.reserve(n);
+        std::vector<char> seen(n, 0);
+        for (int comp = 0; comp < n; comp++) {
+            if (seen[comp]) continue;
+            int start = comp; // pseudo-peripheral-ish: lowest degree in the component reached from comp
+            {
+                std::vector<int> comp_nodes; std::queue<int> q; std::vector<char> s2(n, 0);
+                q.push(comp); s2[comp] = 1;
+                while (!q.empty()) { int u = q.front(); q.pop(); comp_nodes.push_back(u); for (int v : adj[u]) if (!s2[v] && !seen[v]) { s2[v] = 1; q.push(v); } }
+                for (int u : comp_nodes) if (adj[u].size() < adj[start].size()) start = u;
+            }
+            std::queue<int> q; q.push(start); seen[start] = 1;
+            while (!q.empty()) {
+                int u = q.front(); q.pop(); order.push_back(u);
+                std::vector<int> nb;
+                for (int v : adj[u]) if (!seen[v]) { seen[v] = 1; nb.push_back(v); }
+                std::sort(nb.begin(), nb.end(), [&](int a, int c) { return adj[a].size() != adj[c].size() ? adj[a].size() < adj[c].size() : a < c; });
+                for (int v : nb) q.push(v);
+            }
+        }
+        std::reverse(order.begin(), order.end());
+        std::vector<int> pos(n);
+        for (int i = 0; i < n; i++) pos[order[i]] = i;
+        std::vector<int> first(n);
+        for (int i = 0; i < n; i++) first[i] = i;
+        for (auto &kv : Hs) { int a = pos[kv.first.first], c = pos[kv.first.second]; if (a > c) std::swap(a, c); first[c] = std::min(first[c], a); }
+        std::vector<size_t> rowoff(n + 1, 0);
+        for (int i = 0; i < n; i++) rowoff[i + 1] = rowoff[i] + (size_t)(i - first[i] + 1);
+        std::vector<double> Lm(rowoff[n] * 36, 0.0); // row i holds blocks (i, first[i]..i), lower triangle
+        auto blk = [&](int i, int j) { return &Lm[(rowoff[i] + (size_t)(j - first[i])) * 36]; };
+        for (auto &kv : Hs) {
+            int a = pos[kv.first.first], c = pos[kv.first.second];
+            const double *src = kv.second.data();
+            if (a == c) { double *d = blk(a, a); for (int k = 0; k < 36; k++) d[k] = src[k]; }
+            else if (a > c) { double *d = blk(a, c); for (int k = 0; k < 36; k++) d[k] = src[k]; }                                   // block (first,second) sits at rows a cols c
+            else { double *d = blk(c, a); for (int r = 0; r < 6; r++) for (int q2 = 0; q2 < 6; q2++) d[r * 6 + q2] = src[q2 * 6 + r]; } // transpose
+        }
+        for (int i = 0; i < n; i++) {
+            for (int j = first[i]; j <= i; j++) {
+                double *Aij = blk(i, j);
+                const int k0 = std::max(first[i], first[j]);
+                for (int k = k0; k < j; k++) {
+                    const double *Lik = blk(i, k), *Ljk = blk(j, k);
+                    for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) {
+                        double sacc = 0;
+                        for (int t = 0; t < 6; t++) sacc += Lik[r * 6 + t] * Ljk[c * 6 + t];
+                        Aij[r * 6 + c] -= sacc;
+                    }
+                }
+                if (j < i) { // Aij <- Aij * Ljj^-T
+                    const double *Ljj = blk(j, j);
+                    for (int r = 0; r < 6; r++)
+                        for (int c = 0; c < 6; c++) {
+                            double v = Aij[r * 6 + c];
+                            for (int t = 0; t < c; t++) v -= Aij[r * 6 + t] * Ljj[c * 6 + t];
+                            Aij[r * 6 + c] = v / Ljj[c * 6 + c];
+                        }
+                } else { // dense Cholesky of the diagonal block
+                    for (int c = 0; c < 6; c++) {
+                        double d = Aij[c * 6 + c];
+                        for (int t = 0; t < c; t++) d -= Aij[c * 6 + t] * Aij[c * 6 + t];
+                        if (!(d > 0)) return false;
+                        d = std::sqrt(d);
+                        Aij[c * 6 + c] = d;
+                        for (int r = c + 1; r < 6; r++) {
+                            double v = Aij[r * 6 + c];
+                            for (int t = 0; t < c; t++) v -= Aij[r * 6 + t] * Aij[c * 6 + t];
+                            Aij[r * 6 + c] = v / d;
+                        }
+                        for (int r = 0; r < c; r++) Aij[r * 6 + c] = 0;
+                    }
+                }
+            }
+        }
+        std::vector<double> y((size_t)n * 6);
+        for (int i = 0; i < n; i++) for (int k = 0; k < 6; k++) y[(size_t)i * 6 + k] = bs[(size_t)order[i] * 6 + k];
+        for (int i = 0; i < n; i++) { // forward
+            for (int j = first[i]; j < i; j++) { const double *Lij = blk(i, j); for (int r = 0; r < 6; r++) for (int t = 0; t < 6; t++) y[(size_t)i * 6 + r] -= Lij[r * 6 + t] * y[(size_t)j * 6 + t]; }
+            const double *Lii = blk(i, i);
+            for (int r = 0; r < 6; r++) { double v = y[(size_t)i * 6 + r]; for (int t = 0; t < r; t++) v -= Lii[r * 6 + t] * y[(size_t)i * 6 + t]; y[(size_t)i * 6 + r] = v / Lii[r * 6 + r]; }
+        }
+        for (int i = n - 1; i >= 0; i--) { // backward
+            const double *Lii = blk(i, i);
+            for (int r = 5; r >= 0; r--) { double v = y[(size_t)i * 6 + r]; for (int t = r + 1; t < 6; t++) v -= Lii[t * 6 + r] * y[(size_t)i * 6 + t]; y[(size_t)i * 6 + r] = v / Lii[r * 6 + r]; }
+            for (int j = first[i]; j < i; j++) { const double *Lij = blk(i, j); for (int r = 0; r < 6; r++) for (int t = 0; t < 6; t++) y[(size_t)j * 6 + t] -= Lij[r * 6 + t] * y[(size_t)i * 6 + r]; }
+        }
+        for (int i = 0; i < n; i++) for (int k = 0; k < 6; k++) xp[(size_t)order[i] * 6 + k] = y[(size_t)i * 6 + k];
+        return true;
+    }
+
+    bool solve(double lambda) { // BlockSolver::solve with Schur (block_solver.hpp:354-486)
+        std::map<std::pair<int, int>, std::vector<double>> Hs;
+        std::vector<double> bs, Dinv;
+        schur(lambda, true, 0, L, Hs, bs, &Dinv);
+        x.assign((size_t)P * 6 + (size_t)L * 3, 0.0);
+        if (!solve_reduced(Hs, bs, x.data())) return false;
+        for (int li = 0; li < L; li++) { // xl = Dinv (bl - Bt xp)
+            double cl[3] = {b[(size_t)P * 6 + (size_t)li * 3], b[(size_t)P * 6 + (size_t)li * 3 + 1], b[(size_t)P * 6 + (size_t)li * 3 + 2]};
+            for (int o : lm_obs[li]) {
+                const int i1 = cam_idx[p->obs_cam[o]];
+                if (i1 < 0) continue;
+                const double *Bi = &Hpl[(size_t)o * 18], *xp = &x[(size_t)i1 * 6];
+                for (int c = 0; c < 3; c++) { double sacc = 0; for (int a = 0; a < 6; a++) sacc += Bi[a * 3 + c] * xp[a]; cl[c] -= sacc; }
+            }
+            const double *Di = &Dinv[(size_t)li * 9];
+            for (int a = 0; a < 3; a++) x[(size_t)P * 6 + (size_t)li * 3 + a] = (Di[a * 3] * cl[0] + Di[a * 3 + 1] * cl[1]) + Di[a * 3 + 2] * cl[2];
+        }
+        return true;
+    }
+    void update() { // SparseOptimizer::update: oplus per active vertex
+        for (int i = 0; i < p->n_cams; i++) if (cam_idx[i] >= 0) s.cams[i] = se3_mul(se3_exp(&x[(size_t)cam_idx[i] * 6]), s.cams[i]); // VertexSE3Expmap::oplusImpl
+        for (int i = 0; i < p->n_cuboids; i++) s.cubs[i] = cuboid_oplus(s.cubs[i], &x[(size_t)cub_idx[i] * 6], p->cuboid_flags[i], p->cuboid_scale + (size_t)i * 3);
+        for (int i = 0; i < L; i++) for (int k = 0; k < 3; k++) s.pts[(size_t)i * 3 + k] += x[(size_t)P * 6 + (size_t)i * 3 + k];
+    }
+    double lambda_init() const { // optimization_algorithm_levenberg.cpp:166-180
+        double mx = 0;
+        for (int i = 0; i < P; i++) for (int k = 0; k < 6; k++) mx = std::max(std::fabs(Hpp_diag[(size_t)i * 36 + k * 7]), mx);
+        for (int i = 0; i < L; i++) for (int k = 0; k < 3; k++) mx = std::max(std::fabs(Hll[(size_t)i * 9 + k * 4]), mx);
+        return 1e-5 * mx;
+    }
+};
+
+} // namespace
+
+extern "C" {
+
+double orc_ba_errors(const orc_ba_problem *p, double *err_obs, double *err_cobs, double *err_pc) {
+    BA ba(p);
+    ba.compute_errors();
+    if (err_obs) std::memcpy(err_obs, ba.e_obs.data(), ba.e_obs.size() * sizeof(double));
+    if (err_cobs) std::memcpy(err_cobs, ba.e_cobs.data(), ba.e_cobs.size() * sizeof(double));
+    if (err_pc) std::memcpy(err_pc, ba.e_pc.data(), ba.e_pc.size() * sizeof(double));
+    return ba.robust_chi2();
+}
+
+int orc_ba_reduced_dense(const orc_ba_problem *p, int lm_begin, int lm_end, int with_pose_edges, double lambda, double *H, double *bvec) {
+    BA ba(p);
+    ba.compute_errors();
+    ba.build_system(lm_begin, lm_end, with_pose_edges != 0);
+    std::map<std::pair<int, int>, std::vector<double>> Hs;
+    std::vector<double> bs;
+    ba.schur(lambda, with_pose_edges != 0, lm_begin, lm_end, Hs, bs, nullptr);
+    const int n = ba.P * 6;
+    std::fill(H, H + (size_t)n * n, 0.0);
+    for (auto &kv : Hs) {
+        const int i = kv.first.first, j = kv.first.second;
+        for (int r = 0; r < 6; r++) for (int c = 0; c < 6; c++) {
+            H[(size_t)(i * 6 + r) * n + j * 6 + c] = kv.second[r * 6 + c];
+            if (i != j) H[(size_t)(j * 6 + c) * n + i * 6 + r] = kv.second[r * 6 + c];
+        }
+    }
+    for (int i = 0; i < n; i++) bvec[i] = bs[i];
+    return ba.P;
+}
+
+int orc_ba_optimize(const orc_ba_problem *p, int iterations, double *cam_pose_out, double *points_out, double *cuboid_pose_out, orc_ba_stats *st) {
+    BA ba(p);
+    orc_ba_stats S;
+    std::memset(&S, 0, sizeof(S));
+    double lambda = 0, ni = 2;
+    int nBad = 0;
+    for (int it = 0; it < iterations; it++) { // OptimizationAlgorithmLevenberg::solve :61-164
+        ba.compute_errors();
+        double currentChi = ba.robust_chi2(), tempChi = currentChi;
+        const double iniChi = currentChi;
+        if (it == 0) S.chi2_init = currentChi;
+        ba.build_system(0, ba.L, true);
+        if (it == 0) { lambda = ba.lambda_init(); ni = 2; nBad = 0; }
+        double rho = 0;
+        int qmax = 0;
+        do {
+            ba.stack.push_back(ba.s);
+            bool ok2 = ba.solve(lambda);
+            ba.update();
+            ba.compute_errors();
+            tempChi = ba.robust_chi2();
+            if (!ok2) tempChi = std::numeric_limits<double>::max();
+            rho = (currentChi - tempChi);
+            double scale = 0;
+            for (size_t j = 0; j < ba.x.size(); j++) scale += ba.x[j] * (lambda * ba.x[j] + ba.b[j]);
+            scale += 1e-3;
+            rho /= scale;
+            if (rho > 0 && std::isfinite(tempChi)) {
+                double alpha = 1. - std::pow((2 * rho - 1), 3);
+                alpha = (std::min)(alpha, 2. / 3.);
+                double scaleFactor = (std::max)(1. / 3., alpha);
+                lambda *= scaleFactor;
+                ni = 2;
+                currentChi = tempChi;
+                ba.stack.pop_back();
+            } else {
+                lambda *= ni;
+                ni *= 2;
+                ba.s = ba.stack.back(); ba.stack.pop_back();
+            }
+            qmax++;
+            S.lm_trials++;
+        } while (rho < 0 && qmax < 10);
+        S.iterations = it + 1;
+        if (it < 64) S.chi2_trace[it] = currentChi;
+        S.chi2_final = currentChi;
+        if (qmax == 10 || rho == 0) break;
+        if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
+        if (nBad >= 3) break;
+    }
+    S.lambda_final = lambda;
+    if (st) *st = S;
+    for (int i = 0; i < p->n_cams; i++) se3_to7(ba.s.cams[i], cam_pose_out + (size_t)i * 7);
+    for (int i = 0; i < p->n_cuboids; i++) se3_to7(ba.s.cubs[i].pose, cuboid_pose_out + (size_t)i * 7);
+    std::memcpy(points_out, ba.s.pts.data(), ba.s.pts.size() * sizeof(double));
+    return 0;
+}
+
+} // extern "C"

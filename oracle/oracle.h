@@ -158,6 +158,47 @@ int orc_search_for_initialization(const orc_frame *F1, const orc_frame *F2, floa
 /* exact 2-NN in Hamming space over all pairs (first index wins ties) */
 void orc_hamming_knn2(const uint8_t *q, int nq, const uint8_t *t, int nt, int *best_idx, int *best_dist, int *second_dist);
 
+/* ------------------------------------------------------------------ object bundle adjustment
+ * g2o machinery restated for BlockSolver_6_3 + Levenberg (vendored g2o core/{block_solver.hpp,
+ * optimization_algorithm_levenberg.cpp,sparse_optimizer.cpp,base_*_edge.hpp,robust_kernel_impl.cpp}, types/{se3quat.h,
+ * types_six_dof_expmap.*,types_sba.h}) with the CubeSLAM vertices/edges of orb_object_slam/{include/g2o_Object.h,
+ * src/g2o_Object.cpp} as Optimizer::BundleAdjustment / LocalBACameraPointObjects (src/Optimizer.cc:64-251,826-1534) use them.
+ * Poses are 7-vectors [tx ty tz qx qy qz qw] (SE3Quat::toVector). */
+typedef struct orc_ba_problem {
+    /* VertexSE3Expmap: world-to-camera poses */
+    int n_cams; const double *cam_pose; const uint8_t *cam_fixed;
+    /* VertexSBAPointXYZ, marginalised */
+    int n_points; const double *points;
+    /* VertexCuboidFixScale: object-to-world pose + half scale; per-vertex flags */
+    int n_cuboids; const double *cuboid_pose; const double *cuboid_scale; /* n x 3, also used as fixedscale when fixedscale[0] > 0 */
+    const uint8_t *cuboid_flags; /* bit0 whether_fixrollpitch, bit1 whether_fixrotation, bit2 whether_fixheight, bit3 fixedscale set */
+    /* EdgeSE3ProjectXYZ (mono): information = inv_sigma2 * I, Huber(delta_mono) if > 0 */
+    int n_obs; const int *obs_cam; const int *obs_point; const double *obs_uv; const double *obs_inv_sigma2;
+    double fx, fy, cx, cy, huber_mono;
+    /* EdgeSE3CuboidFixScaleProj: measurement = bbox [cx cy w h], information = diag(info4), Huber(delta_obj) if > 0 */
+    int n_cobs; const int *cobs_cam; const int *cobs_cuboid; const double *cobs_bbox; const double *cobs_info;
+    double K[9], huber_obj;
+    /* EdgePointCuboidOnlyObjectFixScale (unary, information = I): fixed world points per edge */
+    int n_pc; const int *pc_cuboid; const int *pc_offsets; const double *pc_points; double max_outside_margin_ratio;
+} orc_ba_problem;
+
+typedef struct orc_ba_stats {
+    int iterations;            /* LM iterations executed (calls of OptimizationAlgorithmLevenberg::solve) */
+    int lm_trials;             /* total solve() trials inside them */
+    double chi2_init, chi2_final, lambda_final;
+    double chi2_trace[64];     /* robust chi2 after each iteration */
+} orc_ba_stats;
+
+/* SparseOptimizer::optimize(iterations); outputs may alias nothing; stop_flag may be NULL */
+int orc_ba_optimize(const orc_ba_problem *p, int iterations, double *cam_pose_out, double *points_out, double *cuboid_pose_out,
+                    orc_ba_stats *stats);
+/* computeActiveErrors + activeRobustChi2 at the given estimates; err_* may be NULL */
+double orc_ba_errors(const orc_ba_problem *p, double *err_obs, double *err_cobs, double *err_pc);
+/* Dense reduced camera system (Schur complement) restricted to the landmarks [lm_begin, lm_end) and, when with_pose_edges,
+ * the camera-cuboid / point-cuboid edges; lambda is added to the landmark blocks always and to the pose diagonal when
+ * with_pose_edges.  H is (6P)x(6P) row-major, b is 6P, P = number of non-fixed cameras + cuboids.  Returns P. */
+int orc_ba_reduced_dense(const orc_ba_problem *p, int lm_begin, int lm_end, int with_pose_edges, double lambda, double *H, double *b);
+
 #ifdef __cplusplus
 }
 #endif

@@ -280,3 +280,74 @@ def hamming_knn2(q, t):
     bi = np.zeros(len(q), np.int32); bd = np.zeros(len(q), np.int32); sd = np.zeros(len(q), np.int32)
     lib().orc_hamming_knn2(_p(q, C.c_uint8), len(q), _p(t, C.c_uint8), len(t), _p(bi, C.c_int), _p(bd, C.c_int), _p(sd, C.c_int))
     return bi, bd, sd
+
+
+# ----------------------------------------------------------------------------------------------- object BA
+class BAProblem(C.Structure):
+    _fields_ = [("n_cams", C.c_int), ("cam_pose", C.c_void_p), ("cam_fixed", C.c_void_p),
+                ("n_points", C.c_int), ("points", C.c_void_p),
+                ("n_cuboids", C.c_int), ("cuboid_pose", C.c_void_p), ("cuboid_scale", C.c_void_p), ("cuboid_flags", C.c_void_p),
+                ("n_obs", C.c_int), ("obs_cam", C.c_void_p), ("obs_point", C.c_void_p), ("obs_uv", C.c_void_p), ("obs_inv_sigma2", C.c_void_p),
+                ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double), ("huber_mono", C.c_double),
+                ("n_cobs", C.c_int), ("cobs_cam", C.c_void_p), ("cobs_cuboid", C.c_void_p), ("cobs_bbox", C.c_void_p), ("cobs_info", C.c_void_p),
+                ("K", C.c_double * 9), ("huber_obj", C.c_double),
+                ("n_pc", C.c_int), ("pc_cuboid", C.c_void_p), ("pc_offsets", C.c_void_p), ("pc_points", C.c_void_p),
+                ("max_outside_margin_ratio", C.c_double)]
+
+
+class BAStats(C.Structure):
+    _fields_ = [("iterations", C.c_int), ("lm_trials", C.c_int), ("chi2_init", C.c_double), ("chi2_final", C.c_double),
+                ("lambda_final", C.c_double), ("chi2_trace", C.c_double * 64)]
+
+
+def ba_struct(d, cls=BAProblem):
+    """Builds the C problem struct from the dict made by cube_slam_amd.synth.ba_problem (keeps the arrays alive)."""
+    keep = {}
+
+    def arr(name, dt):
+        a = np.ascontiguousarray(d[name], dt)
+        keep[name] = a
+        return a.ctypes.data
+
+    p = cls()
+    p.n_cams = len(d["cam_pose"]); p.cam_pose = arr("cam_pose", np.float64); p.cam_fixed = arr("cam_fixed", np.uint8)
+    p.n_points = len(d["points"]); p.points = arr("points", np.float64)
+    p.n_cuboids = len(d["cuboid_pose"]); p.cuboid_pose = arr("cuboid_pose", np.float64); p.cuboid_scale = arr("cuboid_scale", np.float64)
+    p.cuboid_flags = arr("cuboid_flags", np.uint8)
+    p.n_obs = len(d["obs_cam"]); p.obs_cam = arr("obs_cam", np.int32); p.obs_point = arr("obs_point", np.int32); p.obs_uv = arr("obs_uv", np.float64)
+    p.obs_inv_sigma2 = arr("obs_inv_sigma2", np.float64)
+    p.fx, p.fy, p.cx, p.cy, p.huber_mono = d["fx"], d["fy"], d["cx"], d["cy"], d["huber_mono"]
+    p.n_cobs = len(d["cobs_cam"]); p.cobs_cam = arr("cobs_cam", np.int32); p.cobs_cuboid = arr("cobs_cuboid", np.int32)
+    p.cobs_bbox = arr("cobs_bbox", np.float64); p.cobs_info = arr("cobs_info", np.float64)
+    for i, v in enumerate(np.asarray(d["K"], np.float64).reshape(-1)):
+        p.K[i] = v
+    p.huber_obj = d["huber_obj"]
+    p.n_pc = len(d["pc_cuboid"]); p.pc_cuboid = arr("pc_cuboid", np.int32); p.pc_offsets = arr("pc_offsets", np.int32); p.pc_points = arr("pc_points", np.float64)
+    p.max_outside_margin_ratio = d["max_outside_margin_ratio"]
+    p._keep = keep
+    return p
+
+
+def ba_optimize(d, iterations):
+    p = ba_struct(d)
+    cam = np.zeros((p.n_cams, 7)); pts = np.zeros((p.n_points, 3)); cub = np.zeros((max(p.n_cuboids, 1), 7))
+    st = BAStats()
+    lib().orc_ba_optimize(C.byref(p), iterations, _p(cam, C.c_double), _p(pts, C.c_double), _p(cub, C.c_double), C.byref(st))
+    return cam, pts, cub[:p.n_cuboids], {"iterations": st.iterations, "lm_trials": st.lm_trials, "chi2_init": st.chi2_init, "chi2_final": st.chi2_final,
+                                          "lambda_final": st.lambda_final, "chi2_trace": list(st.chi2_trace)[:st.iterations]}
+
+
+def ba_errors(d):
+    p = ba_struct(d)
+    eo = np.zeros((p.n_obs, 2)); ec = np.zeros((max(p.n_cobs, 1), 4)); ep = np.zeros((max(p.n_pc, 1), 3))
+    lib().orc_ba_errors.restype = C.c_double
+    chi = lib().orc_ba_errors(C.byref(p), _p(eo, C.c_double), _p(ec, C.c_double), _p(ep, C.c_double))
+    return chi, eo, ec[:p.n_cobs], ep[:p.n_pc]
+
+
+def ba_reduced_dense(d, lm_begin, lm_end, with_pose_edges, lam):
+    p = ba_struct(d)
+    P = int((1 - np.asarray(d["cam_fixed"])).sum()) + p.n_cuboids
+    Hm = np.zeros((6 * P, 6 * P)); b = np.zeros(6 * P)
+    lib().orc_ba_reduced_dense(C.byref(p), lm_begin, lm_end, int(with_pose_edges), C.c_double(lam), _p(Hm, C.c_double), _p(b, C.c_double))
+    return Hm, b
