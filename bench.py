@@ -1,10 +1,11 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the hot path on N MI355X GPUs of one node (contract in the task statement).
 
-Workload at N=1 (BASELINE.json configs[1]): detect_3d_cuboid on synthetic 640x480 frames with 3 boxes each and a
-180-yaw x 3-VP proposal sweep (yaw step 0.5 deg over +-45 deg), `--frames` frames resident in HBM per GPU; one step =
-one pass of the whole cuboid path (Canny + distance transform + line merge + VP support + sweep/score + selection) over
-that batch.  N>1: every rank owns its own block of frames (no data-path collective, weak scaling).
+Workload at N=1 (BASELINE.json configs[1]): synthetic 640x480 frames with 3 boxes each, `--frames` frames resident in HBM per
+GPU; one step = one pass of the front-end over that batch: ORBextractor (1000 features, 8 levels, FAST 20/7) + detect_3d_cuboid
+with a 180-yaw x 3-VP proposal sweep (yaw step 0.5 deg over +-45 deg; Canny + distance transform + line merge + VP support +
+sweep/score + selection).  N>1: every rank owns its own block of frames (no data-path collective, weak scaling).
+The second half of BASELINE's metric (BA iterations/s at 1k keyframes) is measured in the same run and reported under "ba".
 """
 import argparse
 import json
@@ -32,20 +33,80 @@ def make_frames(n_frames, n_boxes, seed0):
     return scenes
 
 
-def cpu_baseline(scenes, yaw_step, budget_s=12.0):
+def cpu_baseline(scenes, yaw_step, budget_s=12.0, with_orb=True, nfeat=1000):
     """Reference CPU path (the oracle restatement, single thread like the reference) on a bounded sample."""
     from oracle import pyoracle as po
     o = po.cuboid_opts(yaw_step_deg=yaw_step)
+    ext = po.ORBextractor(nfeat, 1.2, 8, 20, 7) if with_orb else None
     po.detect_cuboid(scenes[0]["gray"], scenes[0]["K"], scenes[0]["Twc"], scenes[0]["boxes"], scenes[0]["lines"], opts=o)
     t0 = time.perf_counter()
     n = 0
     while time.perf_counter() - t0 < budget_s:
         s = scenes[n % len(scenes)]
+        if ext is not None:
+            ext(s["gray"])
         po.detect_cuboid(s["gray"], s["K"], s["Twc"], s["boxes"], s["lines"], opts=o)
         n += 1
     dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "%d frames of the same workload in %.1f s, oracle/cuboid_oracle.cpp, 1 thread" % (n, dt)}
+            "sample": "%d frames of the same workload in %.1f s, oracle/{orb,cuboid}_oracle.cpp, 1 thread" % (n, dt)}
+
+
+def ba_bench(ctx, rank, world, iters, with_cpu):
+    """LM iterations/s of the object BA at 1000 keyframes / 100k points / 500 cuboids."""
+    from cube_slam_amd import synth
+    from cube_slam_amd.ba import BundleAdjuster
+    d = synth.ba_problem(20260923, n_kf=1000, n_points=100000, n_cuboids=500)
+    allreduce = None
+    if world > 1:
+        import torch
+        import torch.distributed as dist
+
+        class _Dev:  # wraps the raw device pointer for torch (no copy)
+            def __init__(self, ptr, n):
+                self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 3}
+
+        def allreduce(ptr, n):
+            t = torch.as_tensor(_Dev(ptr, n), device="cuda")
+            dist.all_reduce(t)
+            torch.cuda.synchronize()
+    ba = BundleAdjuster(d, ctx=ctx, rank=rank, world=world, allreduce=allreduce)
+    ba.optimize(1)  # warm-up (also pages the kernels in)
+    ba.close()
+    ba = BundleAdjuster(d, ctx=ctx, rank=rank, world=world, allreduce=allreduce)
+    ctx.timing(True); ctx.timing_reset()
+    ctx.sync()
+    t0 = time.perf_counter()
+    st = ba.optimize(iters)
+    ctx.sync()
+    dt = time.perf_counter() - t0
+    names = ("ba_err_obs", "ba_lin_lm", "ba_lin_pose", "ba_num_cols", "ba_lin_pose_edges", "ba_lm_dinv", "ba_schur_slots", "ba_schur_b", "ba_chol_factor",
+             "ba_chol_solve", "ba_backsub", "ba_update", "ba_allreduce")
+    kern = {}
+    for nme in names:
+        ms, n = ctx.timing_get(nme)
+        if n:
+            kern[nme] = round(1e3 * ms / n, 2)
+    ctx.timing(False)
+    O, Lm, C = len(d["obs_cam"]), len(d["points"]), len(d["cam_pose"])
+    # algorithmic bytes of the Schur kernel per launch (SURVEY 8d): read Hpl 144*O + Dinv 72*L, write 288*nnzb
+    out = {"metric": "BA LM iterations/s @1k keyframes (100k points, 500 cuboids, %d observations)" % O, "value": st["iterations"] / dt,
+           "unit": "iterations/s", "lm_trials_per_s": st["lm_trials"] / dt, "iterations": st["iterations"], "lm_trials": st["lm_trials"],
+           "chi2_init": st["chi2_init"], "chi2_final": st["chi2_final"], "ms_per_iteration": 1e3 * dt / max(st["iterations"], 1), "kernels_us": kern}
+    if "ba_schur_slots" in kern:
+        alg = 144.0 * O / world + 72.0 * Lm / world + 288.0 * 5 * C
+        ach = alg / (kern["ba_schur_slots"] * 1e-6) / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": "ba_schur_slots", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
+                           "traffic": None, "algorithmic_bytes_per_launch": alg}
+    if with_cpu:
+        from oracle import pyoracle as po
+        t0 = time.perf_counter()
+        _, _, _, rst = po.ba_optimize(d, 4)
+        dtc = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": rst["iterations"] / dtc, "unit": "iterations/s", "cores": 1, "kind": "port",
+                               "sample": "%d LM iterations of the same graph in %.1f s, oracle/ba_oracle.cpp, 1 thread" % (rst["iterations"], dtc)}
+    ba.close()
+    return out
 
 
 def main():
@@ -57,6 +118,10 @@ def main():
     ap.add_argument("--boxes", type=int, default=3)
     ap.add_argument("--yaw-step", type=float, default=0.5)
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-ba", action="store_true")
+    ap.add_argument("--no-orb", action="store_true")
+    ap.add_argument("--ba-iters", type=int, default=10)
+    ap.add_argument("--orb-features", type=int, default=1000)
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -79,6 +144,17 @@ def main():
     batch = CuboidBatch(ctx, np.stack([s["gray"] for s in scenes]), scenes[0]["K"], np.stack([s["Twc"] for s in scenes]),
                         [s["boxes"] for s in scenes], [s["lines"] for s in scenes], det.opts())
 
+    orb = None
+    if not args.no_orb:
+        from cube_slam_amd.orb import ORBextractor
+        orb = ORBextractor(args.orb_features, 1.2, 8, 20, 7, 640, 480, max_frames=args.frames, ctx=ctx)
+        orb.upload(np.stack([s["gray"] for s in scenes]))
+
+    def step():
+        if orb is not None:
+            orb.run()
+        batch.run()
+
     def barrier():
         ctx.sync()
         torch.cuda.synchronize()
@@ -86,13 +162,13 @@ def main():
             dist.barrier()
 
     for _ in range(args.warmup):
-        batch.run()
+        step()
     barrier()
     ctx.timing(True)
     ctx.timing_reset()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        batch.run()
+        step()
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -100,7 +176,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kernels = {}
-    for name in ("cuboid_frame_prep", "cuboid_unit_lines", "cuboid_canny_nms", "cuboid_canny_cc", "cuboid_dt", "cuboid_vp",
+    for name in ("host_orb_quadtree", "host_omp_threads", "orb_resize", "orb_fast_score", "orb_cells", "orb_scan", "orb_blur", "orb_angle", "orb_desc", "cuboid_frame_prep", "cuboid_unit_lines", "cuboid_canny_nms", "cuboid_canny_cc", "cuboid_dt", "cuboid_vp",
                  "cuboid_sweep_score", "cuboid_select"):
         ms, n = ctx.timing_get(name)
         kernels[name] = {"avg_us": 1e3 * ms / max(n, 1), "launches": n}
@@ -108,6 +184,10 @@ def main():
     st = batch.stats()
     got = batch.read()
     assert sum(len(g) for g in got) > 0
+    n_kp = sum(len(k) for k, _ in orb.read()) if orb is not None else 0
+    ba_out = None
+    if not args.no_ba:
+        ba_out = ba_bench(ctx, rank, world, args.ba_iters, with_cpu=(rank == 0 and world == 1 and not args.no_cpu))
 
     if rank == 0:
         total_frames = args.frames * world * args.steps
@@ -117,12 +197,13 @@ def main():
         k_us = kernels["cuboid_sweep_score"]["avg_us"]
         achieved = alg_bytes / (k_us * 1e-6) / 1e9 if k_us > 0 else 0.0
         out = {
-            "metric": "frames/sec front-end (cuboid stage: Canny+DT+sweep+score+select) @640x480",
+            "metric": "frames/sec front-end (%scuboid: Canny+DT+sweep+score+select) @640x480" % ("ORB extract + " if orb is not None else ""),
             "value": total_frames / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
             "config": {"workload": "detect_3d_cuboid: 640x480 frames x %d boxes, 180-yaw x 3-VP sweep (yaw step %.2f deg), "
                                    "%d frames resident per GPU" % (args.boxes, args.yaw_step, args.frames),
+                       "orb": None if orb is None else {"nfeatures": args.orb_features, "levels": 8, "keypoints_per_step": n_kp},
                        "frames_per_gpu": args.frames, "boxes_per_frame": args.boxes,
                        "hypotheses_per_step": st["n_hypotheses"], "valid_proposals_per_step": st["n_valid"],
                        "roi_pixels_per_step": st["roi_pixels"], "parallelism": "frames sharded, no collective"},
@@ -132,8 +213,10 @@ def main():
             "kernels_us": {k: round(v["avg_us"], 2) for k, v in kernels.items()},
         }
         if not args.no_cpu and world == 1:
-            out["cpu_baseline"] = cpu_baseline(scenes[:16], args.yaw_step)
+            out["cpu_baseline"] = cpu_baseline(scenes[:16], args.yaw_step, with_orb=orb is not None, nfeat=args.orb_features)
             out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
+        if ba_out is not None:
+            out["ba"] = ba_out
         print(json.dumps(out))
     batch.close()
     if world > 1:

@@ -457,27 +457,28 @@ __global__ void __launch_bounds__(256) ba_schur_b(Params G, const int *pose_off,
     if (lane == 0) for (int k = 0; k < 6; k++) bs[(long)pi * 6 + k] = G.bp[(long)pi * 6 + k] + acc[k];
 }
 
-// scatter the (all-reduced) blocks into the permuted lower band: band[(row * (B+1) + (row - col)) * 36]
-__global__ void ba_band_fill(int n_slots, const int *slot_row, const int *slot_col, const uint8_t *slot_tr, int B, const double *S, double *band) {
+// scatter the (all-reduced) blocks of the reduced system into the factor storage Lb = [P diagonal blocks | off-diagonal
+// blocks column by column in elimination order]; slot_dst[s] = destination block (-1: dead), slot_tr[s] = transpose
+__global__ void ba_chol_fill(int n_slots, const int *slot_dst, const uint8_t *slot_tr, const double *S, double *Lb) {
     const int t = blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= n_slots * 36) return;
     const int s = t / 36, k = t % 36, r = k / 6, c = k % 6;
-    if (slot_row[s] < 0) return;
-    const double v = slot_tr[s] ? S[(long)s * 36 + c * 6 + r] : S[t];
-    band[((long)slot_row[s] * (B + 1) + (slot_row[s] - slot_col[s])) * 36 + k] = v;
+    if (slot_dst[s] < 0) return;
+    Lb[(long)slot_dst[s] * 36 + k] = slot_tr[s] ? S[(long)s * 36 + c * 6 + r] : S[t];
 }
 
-// right-looking block Cholesky of the band, one workgroup; status != 0 if a pivot is not positive
-__global__ void __launch_bounds__(512) ba_band_chol(int n, int B, double *band, int *status) {
+// Right-looking sparse block Cholesky in a minimum-degree elimination order (symbolic factorisation on the host:
+// col_off/rows = structure of every column of L, upd_tgt = destination block of every update pair).  One workgroup.
+__global__ void __launch_bounds__(512) ba_chol_factor(int n, const int *col_off, const int *pair_off, const int *upd_tgt, double *Lb, int *status) {
     extern __shared__ double sh[];
-    double *Ljj = sh, *Lcol = sh + 36; // Lcol: B blocks of the current column
-    const int tid = threadIdx.x;
+    double *Ljj = sh, *Lcol = sh + 36;
     __shared__ int s_fail;
+    const int tid = threadIdx.x;
     if (tid == 0) s_fail = 0;
     __syncthreads();
     for (int j = 0; j < n; j++) {
-        double *Ajj = band + ((long)j * (B + 1)) * 36;
-        if (tid == 0) { // dense Cholesky of the 6x6 diagonal block
+        double *Ajj = Lb + (long)j * 36;
+        if (tid == 0) {
             double A[36];
             for (int k = 0; k < 36; k++) A[k] = Ajj[k];
             for (int c = 0; c < 6; c++) {
@@ -492,62 +493,66 @@ __global__ void __launch_bounds__(512) ba_band_chol(int n, int B, double *band, 
             for (int k = 0; k < 36; k++) { Ajj[k] = A[k]; Ljj[k] = A[k]; }
         }
         __syncthreads();
-        const int nb = min(B, n - 1 - j);
-        for (int t = tid; t < nb * 6; t += 512) { // L_ij = A_ij Ljj^-T, one block row per task
-            const int bi = t / 6, r = t % 6, i = j + 1 + bi;
-            double *Aij = band + ((long)i * (B + 1) + (i - j)) * 36;
+        const int c0 = col_off[j], m = col_off[j + 1] - c0;
+        for (int t = tid; t < m * 6; t += 512) { // L_ij = A_ij Ljj^-T
+            const int bi = t / 6, r = t % 6;
+            double *Aij = Lb + ((long)n + c0 + bi) * 36;
             double row[6];
             for (int c = 0; c < 6; c++) { double v = Aij[r * 6 + c]; for (int q = 0; q < c; q++) v -= row[q] * Ljj[c * 6 + q]; row[c] = v / Ljj[c * 6 + c]; }
             for (int c = 0; c < 6; c++) { Aij[r * 6 + c] = row[c]; Lcol[bi * 36 + r * 6 + c] = row[c]; }
         }
         __syncthreads();
-        const int npair = nb * (nb + 1) / 2;
-        for (int t = tid; t < npair * 36; t += 512) { // A_ii' -= L_ij L_i'j^T for j < i' <= i
+        const int npair = m * (m + 1) / 2, p0 = pair_off[j];
+        for (int t = tid; t < npair * 36; t += 512) { // A(rows[bi], rows[bk]) -= L_bi L_bk^T, bk <= bi
             const int pr = t / 36, k = t % 36, r = k / 6, c = k % 6;
             int bi = (int)((sqrt(8.0 * pr + 1.0) - 1.0) * 0.5);
             while (bi * (bi + 1) / 2 > pr) bi--;
             while ((bi + 1) * (bi + 2) / 2 <= pr) bi++;
-            const int bk = pr - bi * (bi + 1) / 2; // bk <= bi
-            const int i = j + 1 + bi, i2 = j + 1 + bk;
+            const int bk = pr - bi * (bi + 1) / 2;
             const double *Li = Lcol + bi * 36 + r * 6, *Lk = Lcol + bk * 36 + c * 6;
             double v = 0;
 #pragma unroll
             for (int q = 0; q < 6; q++) v += Li[q] * Lk[q];
-            band[((long)i * (B + 1) + (i - i2)) * 36 + k] -= v;
+            Lb[(long)upd_tgt[p0 + pr] * 36 + k] -= v;
         }
         __syncthreads();
     }
     if (tid == 0) *status = s_fail;
 }
-// L y = b then L^T x = y, right-looking sweeps; rhs is permuted in place: xperm[pos] (6 doubles per block)
-__global__ void __launch_bounds__(512) ba_band_solve(int n, int B, const double *band, double *xp) {
+// L y = b (column sweep), then L^T x = y (gather per column); xp is the right-hand side in elimination order, in place
+__global__ void __launch_bounds__(256) ba_chol_solve(int n, const int *col_off, const int *rows, const double *Lb, double *xp) {
     __shared__ double y[6];
     const int tid = threadIdx.x;
     for (int j = 0; j < n; j++) {
-        const double *Ljj = band + ((long)j * (B + 1)) * 36;
+        const double *Ljj = Lb + (long)j * 36;
         if (tid == 0) { for (int r = 0; r < 6; r++) { double v = xp[(long)j * 6 + r]; for (int t = 0; t < r; t++) v -= Ljj[r * 6 + t] * y[t]; y[r] = v / Ljj[r * 6 + r]; } for (int r = 0; r < 6; r++) xp[(long)j * 6 + r] = y[r]; }
         __syncthreads();
-        const int nb = min(B, n - 1 - j);
-        for (int t = tid; t < nb * 6; t += 512) {
-            const int i = j + 1 + t / 6, r = t % 6;
-            const double *Lij = band + ((long)i * (B + 1) + (i - j)) * 36 + r * 6;
+        const int c0 = col_off[j], m = col_off[j + 1] - c0;
+        for (int t = tid; t < m * 6; t += 256) {
+            const int bi = t / 6, r = t % 6;
+            const double *Lij = Lb + ((long)n + c0 + bi) * 36 + r * 6;
             double v = 0;
             for (int q = 0; q < 6; q++) v += Lij[q] * y[q];
-            xp[(long)i * 6 + r] -= v;
+            xp[(long)rows[c0 + bi] * 6 + r] -= v;
         }
         __syncthreads();
     }
-    for (int i = n - 1; i >= 0; i--) {
-        const double *Lii = band + ((long)i * (B + 1)) * 36;
-        if (tid == 0) { for (int r = 5; r >= 0; r--) { double v = xp[(long)i * 6 + r]; for (int t = r + 1; t < 6; t++) v -= Lii[t * 6 + r] * y[t]; y[r] = v / Lii[r * 6 + r]; } for (int r = 0; r < 6; r++) xp[(long)i * 6 + r] = y[r]; }
+    for (int j = n - 1; j >= 0; j--) {
+        const int c0 = col_off[j], m = col_off[j + 1] - c0;
+        if (tid < 6) { // y_c = x_j[c] - sum_i (L_ij^T x_i)[c]
+            double v = xp[(long)j * 6 + tid];
+            for (int bi = 0; bi < m; bi++) {
+                const double *Lij = Lb + ((long)n + c0 + bi) * 36, *xi = xp + (long)rows[c0 + bi] * 6;
+                for (int q = 0; q < 6; q++) v -= Lij[q * 6 + tid] * xi[q];
+            }
+            y[tid] = v;
+        }
         __syncthreads();
-        const int nb = min(B, i);
-        for (int t = tid; t < nb * 6; t += 512) {
-            const int jj = i - 1 - t / 6, c = t % 6; // y_jj -= L_i,jj^T x_i
-            const double *Lij = band + ((long)i * (B + 1) + (i - jj)) * 36;
-            double v = 0;
-            for (int q = 0; q < 6; q++) v += Lij[q * 6 + c] * y[q];
-            xp[(long)jj * 6 + c] -= v;
+        if (tid == 0) {
+            const double *Ljj = Lb + (long)j * 36;
+            double x[6];
+            for (int r = 5; r >= 0; r--) { double v = y[r]; for (int t = r + 1; t < 6; t++) v -= Ljj[t * 6 + r] * x[t]; x[r] = v / Ljj[r * 6 + r]; }
+            for (int r = 0; r < 6; r++) xp[(long)j * 6 + r] = x[r];
         }
         __syncthreads();
     }
@@ -612,15 +617,16 @@ __global__ void __launch_bounds__(256) ba_maxdiag(Params G, double *partials) { 
 
 struct cs_ba {
     Params G{};
-    int rank = 0, world = 1, n_slots = 0, B = 0, max_part = 0;
+    int rank = 0, world = 1, n_slots = 0, max_col = 0, max_part = 0;
     cs_allreduce_fn allreduce = nullptr; void *ar_user = nullptr;
     std::vector<void *> owned;
-    int *d_pose_off = nullptr, *d_pose_obs = nullptr, *d_pe_off = nullptr, *d_pe_list = nullptr, *d_slot_off = nullptr, *d_slot_row = nullptr, *d_slot_col = nullptr,
-        *d_pos = nullptr, *d_status = nullptr;
+    int *d_pose_off = nullptr, *d_pose_obs = nullptr, *d_pe_off = nullptr, *d_pe_list = nullptr, *d_slot_off = nullptr, *d_slot_dst = nullptr, *d_col_off = nullptr,
+        *d_rows = nullptr, *d_pair_off = nullptr, *d_upd_tgt = nullptr, *d_pos = nullptr, *d_status = nullptr;
     int2 *d_trips = nullptr; uint8_t *d_slot_tr = nullptr;
     double *d_reduce = nullptr, *d_band = nullptr, *d_xperm = nullptr, *d_partials = nullptr, *d_scal = nullptr;
     double *d_bak_cam = nullptr, *d_bak_pts = nullptr, *d_bak_cub = nullptr;
-    long reduce_len = 0, band_len = 0;
+    long reduce_len = 0, band_len = 0; // band_len: doubles of the factor storage
+    std::vector<int> h_slot_dst, h_pos, h_col_off, h_rows; std::vector<uint8_t> h_slot_tr;
     std::vector<int> obs_perm; // sorted-by-landmark position -> caller's observation index
     std::vector<double> h_partials;
 };
@@ -694,11 +700,11 @@ static int ba_solve(cs_ctx *ctx, cs_ba *b, double lambda, bool *ok) { // BlockSo
         if (rc != 0) { ctx->err = "all-reduce callback failed"; return CS_ERR_HIP; }
     }
     CS_HIP(ctx, hipMemsetAsync(b->d_band, 0, sizeof(double) * (size_t)b->band_len, ctx->stream));
-    CS_LAUNCH(ctx, "ba_band_fill", ba_band_fill, dim3((b->n_slots * 36 + 255) / 256), dim3(256), 0, b->n_slots, b->d_slot_row, b->d_slot_col, b->d_slot_tr, b->B, b->d_reduce,
-              b->d_band);
-    CS_LAUNCH(ctx, "ba_band_chol", ba_band_chol, dim3(1), dim3(512), sizeof(double) * (36 + (size_t)std::max(b->B, 1) * 36), G.P, b->B, b->d_band, b->d_status);
+    CS_LAUNCH(ctx, "ba_chol_fill", ba_chol_fill, dim3((b->n_slots * 36 + 255) / 256), dim3(256), 0, b->n_slots, b->d_slot_dst, b->d_slot_tr, b->d_reduce, b->d_band);
+    CS_LAUNCH(ctx, "ba_chol_factor", ba_chol_factor, dim3(1), dim3(512), sizeof(double) * (36 + (size_t)std::max(b->max_col, 1) * 36), G.P, b->d_col_off, b->d_pair_off,
+              b->d_upd_tgt, b->d_band, b->d_status);
     CS_LAUNCH(ctx, "ba_permute", ba_permute, dim3((G.P * 6 + 255) / 256), dim3(256), 0, G.P, b->d_pos, b->d_reduce + (long)b->n_slots * 36, b->d_xperm, 1);
-    CS_LAUNCH(ctx, "ba_band_solve", ba_band_solve, dim3(1), dim3(512), 0, G.P, b->B, b->d_band, b->d_xperm);
+    CS_LAUNCH(ctx, "ba_chol_solve", ba_chol_solve, dim3(1), dim3(256), 0, G.P, b->d_col_off, b->d_rows, b->d_band, b->d_xperm);
     CS_LAUNCH(ctx, "ba_permute", ba_permute, dim3((G.P * 6 + 255) / 256), dim3(256), 0, G.P, b->d_pos, b->d_xperm, G.x, 0);
     const int nl = G.lm_e - G.lm_b;
     if (nl > 0) CS_LAUNCH(ctx, "ba_backsub", ba_backsub, dim3((nl + 255) / 256), dim3(256), 0, G);
@@ -810,41 +816,73 @@ int cs_ba_create(cs_ctx *ctx, const cs_ba_problem *p, int rank, int world, cs_ba
     std::vector<int2> trips;
     for (int s = 0; s < b->n_slots; s++) { slot_off[s + 1] = slot_off[s] + (int)slot_trips[s].size(); trips.insert(trips.end(), slot_trips[s].begin(), slot_trips[s].end()); }
     if (trips.empty()) trips.push_back(make_int2(0, 0));
-    // ordering of the pose blocks: reverse Cuthill-McKee on the block graph, then the band width
+    // ordering of the pose blocks: minimum degree on the block graph (the reference lets Eigen::SimplicialLDLT order with AMD,
+    // linear_solver_eigen.h:60-75); the simulated elimination also yields the structure of every column of L
     std::vector<std::vector<int>> adj(P);
     for (auto &rc : slot_rc) if (rc.first != rc.second && rc.first >= 0) { adj[rc.first].push_back(rc.second); adj[rc.second].push_back(rc.first); }
     for (auto &a : adj) { std::sort(a.begin(), a.end()); a.erase(std::unique(a.begin(), a.end()), a.end()); }
-    std::vector<int> order; order.reserve(P);
-    { std::vector<char> seen(P, 0);
-      for (int c0 = 0; c0 < P; c0++) {
-          if (seen[c0]) continue;
-          int start = c0;
-          { std::vector<char> s2(P, 0); std::queue<int> q; q.push(c0); s2[c0] = 1;
-            while (!q.empty()) { int u = q.front(); q.pop(); if (adj[u].size() < adj[start].size()) start = u; for (int v : adj[u]) if (!s2[v] && !seen[v]) { s2[v] = 1; q.push(v); } } }
-          std::queue<int> q; q.push(start); seen[start] = 1;
-          while (!q.empty()) {
-              int u = q.front(); q.pop(); order.push_back(u);
-              std::vector<int> nb;
-              for (int v : adj[u]) if (!seen[v]) { seen[v] = 1; nb.push_back(v); }
-              std::sort(nb.begin(), nb.end(), [&](int a, int c) { return adj[a].size() != adj[c].size() ? adj[a].size() < adj[c].size() : a < c; });
-              for (int v : nb) q.push(v);
-          }
-      }
-      std::reverse(order.begin(), order.end()); }
-    std::vector<int> pos(P);
-    for (int i = 0; i < P; i++) pos[order[i]] = i;
-    std::vector<int> slot_row(b->n_slots), slot_col(b->n_slots);
-    std::vector<uint8_t> slot_tr(b->n_slots);
-    int B = 0;
-    for (int s = 0; s < b->n_slots; s++) {
-        if (slot_rc[s].first < 0) { slot_row[s] = slot_col[s] = -1; slot_tr[s] = 0; continue; }
-        const int a = pos[slot_rc[s].first], c = pos[slot_rc[s].second];
-        if (a >= c) { slot_row[s] = a; slot_col[s] = c; slot_tr[s] = 0; } else { slot_row[s] = c; slot_col[s] = a; slot_tr[s] = 1; }
-        B = std::max(B, slot_row[s] - slot_col[s]);
+    std::vector<int> pos(P, -1), order; order.reserve(P);
+    std::vector<std::vector<int>> col_struct(P); // by elimination position: neighbour node ids at elimination time
+    {
+        std::vector<char> gone(P, 0);
+        for (int k = 0; k < P; k++) {
+            int v = -1;
+            for (int i = 0; i < P; i++) if (!gone[i] && (v < 0 || adj[i].size() < adj[v].size())) v = i;
+            gone[v] = 1; pos[v] = k; order.push_back(v);
+            std::vector<int> nb = adj[v];
+            col_struct[k] = nb;
+            for (int a : nb) { // remove v, connect the neighbours pairwise (sorted-vector sets)
+                std::vector<int> &s = adj[a];
+                std::vector<int> merged;
+                merged.reserve(s.size() + nb.size());
+                std::set_union(s.begin(), s.end(), nb.begin(), nb.end(), std::back_inserter(merged));
+                merged.erase(std::remove_if(merged.begin(), merged.end(), [&](int x) { return x == v || x == a; }), merged.end());
+                s.swap(merged);
+            }
+            adj[v].clear();
+        }
     }
-    if (B > 1000) { ctx->err = "reduced camera system band too wide for the band solver"; delete b; return CS_ERR_CAPACITY; }
-    b->B = B;
-    b->band_len = (long)P * (B + 1) * 36;
+    std::vector<int> col_off(P + 1, 0), rows, pair_off(P + 1, 0);
+    int max_col = 0;
+    for (int k = 0; k < P; k++) {
+        std::vector<int> r;
+        for (int v : col_struct[k]) r.push_back(pos[v]);
+        std::sort(r.begin(), r.end());
+        rows.insert(rows.end(), r.begin(), r.end());
+        col_off[k + 1] = (int)rows.size();
+        pair_off[k + 1] = pair_off[k] + (int)(r.size() * (r.size() + 1) / 2);
+        max_col = std::max(max_col, (int)r.size());
+    }
+    if ((size_t)(36 + (size_t)max_col * 36) * sizeof(double) > 150 * 1024) { ctx->err = "reduced camera system too dense for the LDS column buffer"; delete b; return CS_ERR_CAPACITY; }
+    auto find_block = [&](int col, int row) { // storage index of L(row, col), row > col
+        const int *lo = &rows[col_off[col]], *hi = &rows[col_off[col + 1]];
+        const int *it = std::lower_bound(lo, hi, row);
+        return (it != hi && *it == row) ? P + (int)(it - &rows[0]) : -1;
+    };
+    std::vector<int> upd_tgt((size_t)std::max(pair_off[P], 1));
+    for (int k = 0; k < P; k++) {
+        const int m = col_off[k + 1] - col_off[k];
+        for (int bi = 0; bi < m; bi++)
+            for (int bk = 0; bk <= bi; bk++) {
+                const int ri = rows[col_off[k] + bi], rk = rows[col_off[k] + bk];
+                upd_tgt[(size_t)pair_off[k] + bi * (bi + 1) / 2 + bk] = bi == bk ? ri : find_block(rk, ri);
+            }
+    }
+    std::vector<int> slot_dst(b->n_slots);
+    std::vector<uint8_t> slot_tr(b->n_slots);
+    for (int s = 0; s < b->n_slots; s++) {
+        slot_tr[s] = 0;
+        if (slot_rc[s].first < 0) { slot_dst[s] = -1; continue; }
+        const int a = pos[slot_rc[s].first], c = pos[slot_rc[s].second];
+        if (a == c) slot_dst[s] = a;
+        else if (a > c) slot_dst[s] = find_block(c, a);            // block (rows first, cols second) sits below the diagonal as is
+        else { slot_dst[s] = find_block(a, c); slot_tr[s] = 1; }   // stored transposed
+        if (slot_dst[s] < 0) { ctx->err = "internal: Schur block outside the symbolic factor"; delete b; return CS_ERR_BAD_ARG; }
+    }
+    b->max_col = max_col;
+    b->band_len = ((long)P + (long)rows.size()) * 36;
+    b->h_slot_dst = slot_dst; b->h_slot_tr = slot_tr; b->h_pos = pos; b->h_col_off = col_off; b->h_rows = rows;
+    if (rows.empty()) rows.push_back(0);
     b->reduce_len = (long)b->n_slots * 36 + (long)P * 6;
     const int nl = G.lm_e - G.lm_b;
     b->max_part = std::max(std::max((G.o_e - G.o_b + 255) / 256, (p->n_cobs + p->n_pc + 255) / 256), std::max((int)(((long)P * 6 + (long)nl * 3 + 255) / 256), (nl + 255) / 256)) + 1;
@@ -895,9 +933,12 @@ int cs_ba_create(cs_ctx *ctx, const cs_ba_problem *p, int rank, int world, cs_ba
     A_(dalloc_copy(ctx, b, &b->d_pe_list, pe_list.data(), pe_list.size()));
     A_(dalloc_copy(ctx, b, &b->d_slot_off, slot_off.data(), slot_off.size()));
     A_(dalloc_copy(ctx, b, &b->d_trips, trips.data(), trips.size()));
-    A_(dalloc_copy(ctx, b, &b->d_slot_row, slot_row.data(), slot_row.size()));
-    A_(dalloc_copy(ctx, b, &b->d_slot_col, slot_col.data(), slot_col.size()));
+    A_(dalloc_copy(ctx, b, &b->d_slot_dst, slot_dst.data(), slot_dst.size()));
     A_(dalloc_copy(ctx, b, &b->d_slot_tr, slot_tr.data(), slot_tr.size()));
+    A_(dalloc_copy(ctx, b, &b->d_col_off, col_off.data(), col_off.size()));
+    A_(dalloc_copy(ctx, b, &b->d_rows, rows.data(), rows.size()));
+    A_(dalloc_copy(ctx, b, &b->d_pair_off, pair_off.data(), pair_off.size()));
+    A_(dalloc_copy(ctx, b, &b->d_upd_tgt, upd_tgt.data(), upd_tgt.size()));
     A_(dalloc_copy(ctx, b, &b->d_pos, pos.data(), pos.size()));
     A_(dalloc_copy(ctx, b, &b->d_status, (const int *)nullptr, 1));
     A_(dalloc_copy(ctx, b, &b->d_reduce, (const double *)nullptr, (size_t)b->reduce_len));
@@ -948,22 +989,20 @@ int cs_ba_reduced_dense(cs_ctx *ctx, cs_ba *b, double lambda, double *H, double 
     r = ba_build_system(ctx, b); if (r) return r;
     r = ba_schur(ctx, b, lambda); if (r) return r;
     std::vector<double> red((size_t)b->reduce_len);
-    std::vector<int> row(b->n_slots), col(b->n_slots), pos(b->G.P);
-    std::vector<uint8_t> tr(b->n_slots);
     r = cs_d2h(ctx, red.data(), b->d_reduce, red.size()); if (r) return r;
-    r = cs_d2h(ctx, row.data(), b->d_slot_row, row.size()); if (r) return r;
-    r = cs_d2h(ctx, col.data(), b->d_slot_col, col.size()); if (r) return r;
-    r = cs_d2h(ctx, tr.data(), b->d_slot_tr, tr.size()); if (r) return r;
-    r = cs_d2h(ctx, pos.data(), b->d_pos, pos.size()); if (r) return r;
     CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const int P = b->G.P, n = P * 6;
     std::vector<int> inv(P);
-    for (int i = 0; i < P; i++) inv[pos[i]] = i;
+    for (int i = 0; i < P; i++) inv[b->h_pos[i]] = i;
+    std::vector<int> blk_col((size_t)b->h_rows.size() + 1, 0); // column (elimination position) of every off-diagonal block
+    for (int k = 0; k < P; k++) for (int q = b->h_col_off[k]; q < b->h_col_off[k + 1]; q++) blk_col[q] = k;
     std::fill(H, H + (size_t)n * n, 0.0);
     for (int s = 0; s < b->n_slots; s++) {
-        if (row[s] < 0) continue;
-        int i = inv[row[s]], j = inv[col[s]];
-        if (tr[s]) std::swap(i, j); // the slot holds block (rows i, cols j) in pose numbering
+        const int dst = b->h_slot_dst[s];
+        if (dst < 0) continue;
+        int i, j; // the slot holds block (rows i, cols j) in pose numbering
+        if (dst < P) i = j = inv[dst];
+        else { const int q = dst - P, rowp = b->h_rows[q], colp = blk_col[q]; if (b->h_slot_tr[s]) { i = inv[colp]; j = inv[rowp]; } else { i = inv[rowp]; j = inv[colp]; } }
         for (int a = 0; a < 6; a++) for (int c = 0; c < 6; c++) {
             const double v = red[(size_t)s * 36 + a * 6 + c];
             H[(size_t)(i * 6 + a) * n + j * 6 + c] += v;

@@ -18,7 +18,9 @@
 #include "orb_quadtree.h"
 
 #include <cfloat>
+#include <chrono>
 #include <cmath>
+#include <omp.h>
 
 namespace {
 
@@ -544,11 +546,12 @@ int cs_orb_run(cs_ctx *ctx, cs_orb *e) {
     CS_HIP(ctx, hipEventSynchronize(ev_cand));
     ctx->pool.push_back(ev_cand);
     // ---- host: DistributeOctTree per (frame, level), ORBextractor.cc:831-832
+    const auto t_host0 = std::chrono::steady_clock::now();
     e->sel.clear();
     e->frame_first.assign((size_t)F + 1, 0);
     {
         std::vector<std::vector<SelKP>> per((size_t)F * NL);
-#pragma omp parallel
+#pragma omp parallel num_threads(std::min(omp_get_max_threads(), std::max(1, std::min(64, F * NL / 4))))
         {
             cs_orb_host::QuadTree qt;
             std::vector<int> idx;
@@ -572,6 +575,13 @@ int cs_orb_run(cs_ctx *ctx, cs_orb *e) {
         e->frame_first[F] = (int)e->sel.size();
     }
     const int n = (int)e->sel.size();
+    if (ctx->timing) { // host section accounted like a kernel ("host_" prefix), in ms
+        auto &rec = ctx->timings["host_orb_quadtree"];
+        rec.total_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count();
+        rec.count++;
+        ctx->timings["host_omp_threads"].total_ms = omp_get_max_threads();
+        ctx->timings["host_omp_threads"].count = 1;
+    }
     if (n > e->sel_cap) { ctx->err = "ORB keypoint capacity exceeded"; return CS_ERR_CAPACITY; }
     if (n == 0) return CS_OK;
     // ---- GPU phase B: orientation, descriptors

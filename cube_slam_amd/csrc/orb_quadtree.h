@@ -22,10 +22,11 @@ class QuadTree {
         const int nIni = (int)std::round(static_cast<float>(maxX - minX) / (maxY - minY));
         if (nIni < 1 || n == 0) return;
         const float hX = static_cast<float>(maxX - minX) / nIni;
-        nodes_.clear(); head_ = tail_ = -1; size_ = 0;
+        nodes_.clear(); nodes_.reserve((size_t)4 * N + 64); head_ = tail_ = -1; size_ = 0;
         perm_.resize(n); tmp_.resize(n);
         // root nodes: bucket the candidates by x / hX (stable)
-        std::vector<int> cnt(nIni + 1, 0);
+        cnt_.assign(nIni + 1, 0);
+        std::vector<int> &cnt = cnt_;
         bucket_.resize(n);
         for (int i = 0; i < n; i++) { int b = (int)(K[i].x / hX); if (b >= nIni) b = nIni - 1; bucket_[i] = b; cnt[b + 1]++; }
         for (int b = 0; b < nIni; b++) cnt[b + 1] += cnt[b];
@@ -39,14 +40,15 @@ class QuadTree {
             nd.no_more = (nd.end - nd.begin) == 1;
             push_back(add(nd));
         }
-        std::vector<std::pair<int, int>> expand, prev_expand; // (size, node id); node ids grow with creation order
+        std::vector<std::pair<int, int>> &expand = expand_, &prev_expand = prev_expand_; // (size, node id); node ids grow with creation order
+        std::vector<int> &pass = pass_;
         bool finish = false;
         while (!finish) {
             const int prev_size = size_;
             int n_to_expand = 0;
             expand.clear();
             // one pass over the nodes that existed at pass start, in list order; children go to the front
-            std::vector<int> pass;
+            pass.clear();
             for (int id = head_; id >= 0; id = nodes_[id].next) pass.push_back(id);
             for (int id : pass) {
                 if (nodes_[id].no_more) continue;
@@ -84,7 +86,8 @@ class QuadTree {
   private:
     struct Node { int x0, y0, x1, y1, begin, end, prev, next; bool no_more; };
     std::vector<Node> nodes_;
-    std::vector<int> perm_, tmp_, bucket_;
+    std::vector<int> perm_, tmp_, bucket_, cnt_, pass_;
+    std::vector<std::pair<int, int>> expand_, prev_expand_;
     int head_ = -1, tail_ = -1, size_ = 0;
 
     int add(const Node &n) { nodes_.push_back(n); return (int)nodes_.size() - 1; }

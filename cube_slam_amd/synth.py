@@ -190,25 +190,41 @@ def ba_problem(seed, n_kf=1000, n_points=100000, n_cuboids=500, k_obs=5, W=1241,
     ki = np.clip((s / step).astype(int), 0, n_kf - 1)
     lat = rng.uniform(-15, 15, n_points)
     pts = np.stack([cxw[ki] + lat, rng.uniform(cam_h - 3.0, cam_h, n_points), s], axis=1)
-    obs_cam, obs_pt, obs_uv, obs_w = [], [], [], []
-    for p in range(n_points):
-        first = max(0, int((pts[p, 2] - 30) / step))
-        got = 0
-        for i in range(first, min(n_kf, first + 80)):
-            uv, z = project(i, pts[p:p + 1])
-            if 2.0 < z[0] < 40.0 and 0 <= uv[0, 0] < W and 0 <= uv[0, 1] < H:
-                octave = int(rng.integers(0, 8))
-                obs_cam.append(i); obs_pt.append(p); obs_uv.append(uv[0] + rng.normal(0, noise_px, 2))
-                obs_w.append(float(np.float32(1.0) / (np.float32(1.2) ** np.float32(octave)) ** 2))
-                got += 1
-                if got >= k_obs:
-                    break
+    # observations: for each point the first k_obs consecutive keyframes (from ~30 m before it) that see it
+    Rwc_all = np.stack(Rwc)
+    first = np.maximum(0, ((pts[:, 2] - 30) / step).astype(int))
+    got = np.zeros(n_points, int)
+    oc, op, ou, ow = [], [], [], []
+    for j in range(80):
+        ki_j = first + j
+        ok = (ki_j < n_kf) & (got < k_obs)
+        kk = np.minimum(ki_j, n_kf - 1)
+        Xc = np.einsum("nji,nj->ni", Rwc_all[kk], pts - centers[kk])
+        z = Xc[:, 2]
+        with np.errstate(divide="ignore", invalid="ignore"):
+            u = fx * Xc[:, 0] / z + cx
+            v = fy * Xc[:, 1] / z + cy
+        ok &= (z > 2.0) & (z < 40.0) & (u >= 0) & (u < W) & (v >= 0) & (v < H)
+        idx = np.nonzero(ok)[0]
+        if len(idx) == 0:
+            continue
+        octave = rng.integers(0, 8, len(idx))
+        oc.append(kk[idx]); op.append(idx)
+        ou.append(np.stack([u[idx], v[idx]], axis=1) + rng.normal(0, noise_px, (len(idx), 2)))
+        ow.append((np.float32(1.0) / (np.float32(1.2) ** octave.astype(np.float32)) ** 2).astype(np.float64))
+        got[idx] += 1
+    obs_cam = np.concatenate(oc) if oc else np.zeros(0, int)
+    obs_pt = np.concatenate(op) if op else np.zeros(0, int)
+    obs_uv = np.concatenate(ou) if ou else np.zeros((0, 2))
+    obs_w = np.concatenate(ow) if ow else np.zeros(0)
+    order = np.lexsort((obs_cam, obs_pt))  # landmark-major like the reference's loop over map points
+    obs_cam, obs_pt, obs_uv, obs_w = obs_cam[order], obs_pt[order], obs_uv[order], obs_w[order]
     # cuboids: object z axis = world up (-y): R_align maps object (x fwd, y left, z up) into the camera world
     R_align = np.array([[0, -1, 0], [0, 0, -1], [1, 0, 0]], float)
     cub_pose, cobs_cam, cobs_cub, cobs_bbox, cobs_info, pc_cub, pc_off, pc_pts = [], [], [], [], [], [], [0], []
     body = np.array([[1, 1, -1, -1, 1, 1, -1, -1], [1, -1, -1, 1, 1, -1, -1, 1], [-1, -1, -1, -1, 1, 1, 1, 1]], float)
     for c in range(n_cuboids):
-        sc = rng.uniform(12, n_kf * step + 5)
+        sc = rng.uniform(min(12.0, n_kf * step), max(13.0, n_kf * step + 5))
         k0 = int(np.clip(sc / step, 0, n_kf - 1))
         side = rng.choice([-1.0, 1.0]) * rng.uniform(3.0, 6.0)
         centre = np.array([cxw[k0] + side, cam_h - KITTI_OBJ_HALF[2], sc])
