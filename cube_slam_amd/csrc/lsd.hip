@@ -1,0 +1,461 @@
+// lsd.hip -- LSD line segment detector of line_lbd on MI355X (gfx950) + host.
+//
+// Replaces line_lbd_detect::detect_raw_lines / detect_filter_lines (reference line_lbd/class/line_lbd_allclass.cpp:125-148,
+// 200-221) -> LSDDetector::detectImpl (libs/LSDDetector.cpp:153-287) -> LineSegmentDetectorImpl::flsd (libs/lsd.cpp:440-536).
+//   lsd_blur_h / lsd_blur_v   GaussianBlur(7x7, sigma 0.75) on the double image, REFLECT_101, symmetric summation order
+//   lsd_resize                cv::resize(0.8, 0.8, INTER_LINEAR) on CV_64F with float coefficients (tables from the host)
+//   lsd_gradient              ll_angle (:538-585): 2x2 gradient, norm, level-line angle via cv::fastAtan2, NOTDEF below rho
+// Host, per frame (OpenMP across frames): 1024-bin pseudo-ordering (:588-634) and the sequential part of the algorithm --
+// region_grow (each accepted pixel updates the region angle that the next test uses, :665-683), region2rect, refine,
+// rect_improve, rect_nfa, nfa -- which has no order-preserving parallel form.  Double precision as in the reference.
+#include "common.h"
+
+#include <cfloat>
+#include <chrono>
+#include <cmath>
+#include <omp.h>
+#include <vector>
+
+namespace {
+constexpr double NOTDEF = -1024.0, PI_ = 3.1415926535897932384626433832795, DEG_TO_RADS = PI_ / 180;
+constexpr int KH = 3; // half kernel: ceil(0.75 * sqrt(6 ln 10)) = 3
+
+__host__ __device__ inline float fast_atan2f_(float y, float x) { // cv::fastAtan2
+    const float p1 = 0.9997878412794807f * (float)(180 / PI_), p3 = -0.3258083974640975f * (float)(180 / PI_), p5 = 0.1555786518463281f * (float)(180 / PI_),
+                p7 = -0.04432655554792128f * (float)(180 / PI_);
+    float ax = fabsf(x), ay = fabsf(y), a, c, c2;
+    if (ax >= ay) { c = ay / (ax + (float)DBL_EPSILON); c2 = c * c; a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c; }
+    else { c = ax / (ay + (float)DBL_EPSILON); c2 = c * c; a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c; }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+__device__ __forceinline__ int reflect101d(int p, int len) { if (len == 1) return 0; while (p < 0 || p >= len) { if (p < 0) p = -p; else p = 2 * len - 2 - p; } return p; }
+
+struct GK { double k[2 * KH + 1]; };
+
+__global__ void __launch_bounds__(256) lsd_blur_h(const uint8_t *gray, int W, int H, GK g, double *tmp) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    const uint8_t *row = gray + ((long)blockIdx.z * H + y) * W;
+    double s = g.k[KH] * row[x];
+    for (int t = 1; t <= KH; t++) s += g.k[KH + t] * ((double)row[reflect101d(x - t, W)] + (double)row[reflect101d(x + t, W)]);
+    tmp[((long)blockIdx.z * H + y) * W + x] = s;
+}
+__global__ void __launch_bounds__(256) lsd_blur_v(const double *tmp, int W, int H, GK g, double *blur) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    const double *img = tmp + (long)blockIdx.z * H * W;
+    double s = g.k[KH] * img[(long)y * W + x];
+    for (int t = 1; t <= KH; t++) s += g.k[KH + t] * (img[(long)reflect101d(y - t, H) * W + x] + img[(long)reflect101d(y + t, H) * W + x]);
+    blur[((long)blockIdx.z * H + y) * W + x] = s;
+}
+__global__ void __launch_bounds__(256) lsd_resize(const double *blur, int W, int H, int w, int h, const int *xofs, const float *ax, const int *yofs, const float *ay,
+                                                  double *scaled) {
+    const int dx = blockIdx.x * 256 + threadIdx.x, dy = blockIdx.y;
+    if (dx >= w) return;
+    const double *src = blur + (long)blockIdx.z * H * W;
+    const int sx0 = xofs[dx], sx1 = min(sx0 + 1, W - 1), sy0 = yofs[dy], sy1 = min(sy0 + 1, H - 1);
+    const double r0 = src[(long)sy0 * W + sx0] * ax[dx * 2] + src[(long)sy0 * W + sx1] * ax[dx * 2 + 1];
+    const double r1 = src[(long)sy1 * W + sx0] * ax[dx * 2] + src[(long)sy1 * W + sx1] * ax[dx * 2 + 1];
+    scaled[((long)blockIdx.z * h + dy) * w + dx] = r0 * ay[dy * 2] + r1 * ay[dy * 2 + 1];
+}
+__global__ void __launch_bounds__(256) lsd_gradient(const double *scaled, int w, int h, double threshold, double *modgrad, double *angles) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= w) return;
+    const double *img = scaled + (long)blockIdx.z * w * h;
+    const long o = ((long)blockIdx.z * h + y) * w + x;
+    if (x >= w - 1 || y >= h - 1) { modgrad[o] = 0; angles[o] = NOTDEF; return; } // down / right boundaries undefined (:553-554)
+    const int addr = y * w + x;
+    const double DA = img[addr + w + 1] - img[addr], BC = img[addr + 1] - img[addr + w];
+    const double gx = DA + BC, gy = DA - BC;
+    const double norm = sqrt((gx * gx + gy * gy) / 4);
+    modgrad[o] = norm;
+    angles[o] = norm <= threshold ? NOTDEF : fast_atan2f_(float(gx), float(-gy)) * DEG_TO_RADS;
+}
+
+// ------------------------------------------------------------------------------------------------ host: sequential LSD stages
+struct RectH { double x1, y1, x2, y2, width, x, y, theta, dx, dy, prec, p; };
+
+class LsdHost {
+  public:
+    int w = 0, h = 0;
+    const double *angles = nullptr, *modgrad = nullptr;
+    std::vector<unsigned char> used;
+    std::vector<int> rx, ry;          // region points (structure of arrays)
+    std::vector<double> rang, rmod;
+    double LOG_NT = 0;
+
+    inline bool aligned(int address, double theta, double prec) const { // isAligned lsd.cpp:1138-1154
+        if (address < 0) return false;
+        const double a = angles[address];
+        if (a == NOTDEF) return false;
+        double n_theta = theta - a;
+        if (n_theta < 0) n_theta = -n_theta;
+        if (n_theta > (3 * PI_) / 2) { n_theta -= 2 * PI_; if (n_theta < 0) n_theta = -n_theta; }
+        return n_theta <= prec;
+    }
+    static double sdiff(double a, double b) { double d = a - b; while (d <= -PI_) d += 2 * PI_; while (d > PI_) d -= 2 * PI_; return d; }
+    static double dist(double x1, double y1, double x2, double y2) { return std::sqrt((x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1)); }
+
+    void grow(int sx, int sy, int &n, double &reg_angle, double prec) { // region_grow :637-688
+        n = 1;
+        int addr = sx + sy * w;
+        rx[0] = sx; ry[0] = sy; rang[0] = angles[addr]; rmod[0] = modgrad[addr];
+        reg_angle = angles[addr];
+        float sumdx = float(std::cos(reg_angle)), sumdy = float(std::sin(reg_angle));
+        used[addr] = 1;
+        for (int i = 0; i < n; ++i) {
+            const int x0 = std::max(rx[i] - 1, 0), x1 = std::min(rx[i] + 1, w - 1), y0 = std::max(ry[i] - 1, 0), y1 = std::min(ry[i] + 1, h - 1);
+            for (int yy = y0; yy <= y1; ++yy) {
+                int c = x0 + yy * w;
+                for (int xx = x0; xx <= x1; ++xx, ++c)
+                    if (used[c] != 1 && aligned(c, reg_angle, prec)) {
+                        used[c] = 1;
+                        const double a = angles[c];
+                        rx[n] = xx; ry[n] = yy; rang[n] = a; rmod[n] = modgrad[c];
+                        ++n;
+                        sumdx += std::cos(float(a));
+                        sumdy += std::sin(float(a));
+                        reg_angle = fast_atan2f_(sumdy, sumdx) * DEG_TO_RADS;
+                    }
+            }
+        }
+    }
+    void to_rect(int n, double reg_angle, double prec, double p, RectH &rec) const { // region2rect :690-746 + get_theta :748-784
+        double x = 0, y = 0, sum = 0;
+        for (int i = 0; i < n; ++i) { x += double(rx[i]) * rmod[i]; y += double(ry[i]) * rmod[i]; sum += rmod[i]; }
+        x /= sum; y /= sum;
+        double Ixx = 0, Iyy = 0, Ixy = 0;
+        for (int i = 0; i < n; ++i) { const double dx = (double)rx[i] - x, dy = (double)ry[i] - y, wg = rmod[i]; Ixx += dy * dy * wg; Iyy += dx * dx * wg; Ixy -= dx * dy * wg; }
+        const double lambda = 0.5 * (Ixx + Iyy - std::sqrt((Ixx - Iyy) * (Ixx - Iyy) + 4.0 * Ixy * Ixy));
+        double theta = (std::fabs(Ixx) > std::fabs(Iyy)) ? double(fast_atan2f_(float(lambda - Ixx), float(Ixy))) : double(fast_atan2f_(float(Ixy), float(lambda - Iyy)));
+        theta *= DEG_TO_RADS;
+        if (std::fabs(sdiff(theta, reg_angle)) > prec) theta += PI_;
+        const double dx = std::cos(theta), dy = std::sin(theta);
+        double l_min = 0, l_max = 0, w_min = 0, w_max = 0;
+        for (int i = 0; i < n; ++i) {
+            const double ddx = double(rx[i]) - x, ddy = double(ry[i]) - y, l = ddx * dx + ddy * dy, ww = -ddx * dy + ddy * dx;
+            if (l > l_max) l_max = l; else if (l < l_min) l_min = l;
+            if (ww > w_max) w_max = ww; else if (ww < w_min) w_min = ww;
+        }
+        rec.x1 = x + l_min * dx; rec.y1 = y + l_min * dy; rec.x2 = x + l_max * dx; rec.y2 = y + l_max * dy;
+        rec.width = w_max - w_min; rec.x = x; rec.y = y; rec.theta = theta; rec.dx = dx; rec.dy = dy; rec.prec = prec; rec.p = p;
+        if (rec.width < 1.0) rec.width = 1.0;
+    }
+    bool shrink(int &n, double reg_angle, double prec, double p, RectH &rec, double density, double density_th) { // reduce_region_radius :834-871
+        const double xc = double(rx[0]), yc = double(ry[0]);
+        auto dsq = [](double x1, double y1, double x2, double y2) { return (x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1); };
+        const double r1 = dsq(xc, yc, rec.x1, rec.y1), r2 = dsq(xc, yc, rec.x2, rec.y2);
+        double radSq = r1 > r2 ? r1 : r2;
+        while (density < density_th) {
+            radSq *= 0.75 * 0.75;
+            for (int i = 0; i < n; ++i)
+                if (dsq(xc, yc, double(rx[i]), double(ry[i])) > radSq) {
+                    used[rx[i] + ry[i] * w] = 0;
+                    std::swap(rx[i], rx[n - 1]); std::swap(ry[i], ry[n - 1]); std::swap(rang[i], rang[n - 1]); std::swap(rmod[i], rmod[n - 1]);
+                    --n; --i;
+                }
+            if (n < 2) return false;
+            to_rect(n, reg_angle, prec, p, rec);
+            density = double(n) / (dist(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
+        }
+        return true;
+    }
+    bool refine(int &n, double reg_angle, double prec, double p, RectH &rec, double density_th) { // :786-832
+        double density = double(n) / (dist(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
+        if (density >= density_th) return true;
+        const double xc = double(rx[0]), yc = double(ry[0]), ang_c = rang[0];
+        double sum = 0, s_sum = 0;
+        int cnt = 0;
+        for (int i = 0; i < n; ++i) {
+            used[rx[i] + ry[i] * w] = 0;
+            if (dist(xc, yc, rx[i], ry[i]) < rec.width) { const double d = sdiff(rang[i], ang_c); sum += d; s_sum += d * d; ++cnt; }
+        }
+        const double mean_angle = sum / double(cnt);
+        const double tau = 2.0 * std::sqrt((s_sum - 2.0 * mean_angle * sum) / double(cnt) + mean_angle * mean_angle);
+        grow(rx[0], ry[0], n, reg_angle, tau);
+        if (n < 2) return false;
+        to_rect(n, reg_angle, prec, p, rec);
+        density = double(n) / (dist(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
+        if (density < density_th) return shrink(n, reg_angle, prec, p, rec, density, density_th);
+        return true;
+    }
+    static bool deq(double a, double b) {
+        if (a == b) return true;
+        double ad = std::fabs(a - b), aa = std::fabs(a), bb = std::fabs(b), am = (aa > bb) ? aa : bb;
+        if (am < DBL_MIN) am = DBL_MIN;
+        return (ad / am) <= (100.0 * DBL_EPSILON);
+    }
+    static double lgam(double x) { // log_gamma :70,124-160
+        if (x > 15.0) return 0.918938533204673 + (x - 0.5) * std::log(x) - x + 0.5 * x * std::log(x * std::sinh(1 / x) + 1 / (810.0 * std::pow(x, 6.0)));
+        static const double q[7] = {75122.6331530, 80916.6278952, 36308.2951477, 8687.24529705, 1168.92649479, 83.8676043424, 2.50662827511};
+        double a = (x + 0.5) * std::log(x + 5.5) - (x + 5.5), b = 0;
+        for (int n = 0; n < 7; ++n) { a -= std::log(x + double(n)); b += q[n] * std::pow(x, double(n)); }
+        return a + std::log(b);
+    }
+    double nfa(int n, int k, double p) const { // :1100-1136
+        if (n == 0 || k == 0) return -LOG_NT;
+        if (n == k) return -LOG_NT - double(n) * std::log10(p);
+        const double p_term = p / (1 - p);
+        const double l1 = (double(n) + 1) - lgam(double(k) + 1) - lgam(double(n - k) + 1) + double(k) * std::log(p) + double(n - k) * std::log(1.0 - p);
+        double term = std::exp(l1);
+        if (deq(term, 0)) { if (k > n * p) return -l1 / M_LN10 - LOG_NT; else return -LOG_NT; }
+        double tail = term;
+        for (int i = k + 1; i <= n; ++i) {
+            const double bt = double(n - i + 1) / double(i), mt = bt * p_term;
+            term *= mt;
+            tail += term;
+            if (bt < 1) { const double err = term * ((1 - std::pow(mt, double(n - i + 1))) / (1 - mt) - 1); if (err < 0.1 * std::fabs(-std::log10(tail) - LOG_NT) * tail) break; }
+        }
+        return -std::log10(tail) - LOG_NT;
+    }
+    double rect_nfa(const RectH &rec) const { // :977-1098, integer-division and tailp->p.x quirks kept (:1057-1065)
+        int total = 0, alg = 0;
+        const double hw = rec.width / 2.0, dyhw = rec.dy * hw, dxhw = rec.dx * hw;
+        int vx[4] = {int(rec.x1 - dyhw), int(rec.x2 - dyhw), int(rec.x2 + dyhw), int(rec.x1 + dyhw)};
+        int vy[4] = {int(rec.y1 + dxhw), int(rec.y2 + dxhw), int(rec.y2 - dxhw), int(rec.y1 - dxhw)};
+        for (int i = 1; i < 4; i++) // insertion sort by (x, y): the four keys are ordered exactly like std::sort with AsmallerB_XoverY would
+            for (int j = i; j > 0 && (vx[j] < vx[j - 1] || (vx[j] == vx[j - 1] && vy[j] < vy[j - 1])); j--) { std::swap(vx[j], vx[j - 1]); std::swap(vy[j], vy[j - 1]); }
+        bool taken[4] = {false, false, false, false};
+        int mn = 0, mx = 0;
+        for (int i = 1; i < 4; ++i) { if (vy[mn] > vy[i]) mn = i; if (vy[mx] < vy[i]) mx = i; }
+        taken[mn] = true;
+        int lm = -1, rm = -1, tp = -1;
+        for (int i = 0; i < 4; ++i) if (!taken[i]) { if (lm < 0) lm = i; else if (vx[lm] > vx[i]) lm = i; }
+        taken[lm] = true;
+        for (int i = 0; i < 4; ++i) if (!taken[i]) { if (rm < 0) rm = i; else if (vx[rm] < vx[i]) rm = i; }
+        taken[rm] = true;
+        for (int i = 0; i < 4; ++i) if (!taken[i]) { if (tp < 0) tp = i; else if (vx[tp] > vx[i]) tp = i; }
+        const double flstep = (vy[mn] != vy[lm]) ? (vx[mn] - vx[lm]) / (vy[mn] - vy[lm]) : 0;
+        const double slstep = (vy[lm] != vx[tp]) ? (vx[lm] - vx[tp]) / (vy[lm] - vx[tp]) : 0;
+        const double frstep = (vy[mn] != vy[rm]) ? (vx[mn] - vx[rm]) / (vy[mn] - vy[rm]) : 0;
+        const double srstep = (vy[rm] != vx[tp]) ? (vx[rm] - vx[tp]) / (vy[rm] - vx[tp]) : 0;
+        double lstep = flstep, rstep = frstep, left_x = vx[mn], right_x = vx[mn];
+        for (int y = vy[mn]; y <= vy[mx]; ++y) {
+            if (y < 0 || y >= h) continue;
+            int adx = y * w + int(left_x);
+            for (int x = int(left_x); x <= int(right_x); ++x, ++adx) {
+                if (x < 0 || x >= w) continue;
+                ++total;
+                if (aligned(adx, rec.theta, rec.prec)) ++alg;
+            }
+            if (y >= vy[lm]) lstep = slstep;
+            if (y >= vy[rm]) rstep = srstep;
+            left_x += lstep; right_x += rstep;
+        }
+        return nfa(total, alg, rec.p);
+    }
+    double improve(RectH &rec) const { // rect_improve :873-975, log_eps = 0
+        const double delta = 0.5, d2 = delta / 2.0;
+        double best = rect_nfa(rec);
+        if (best > 0) return best;
+        RectH r = rec;
+        for (int n = 0; n < 5; ++n) { r.p /= 2; r.prec = r.p * PI_; double v = rect_nfa(r); if (v > best) { best = v; rec = r; } }
+        if (best > 0) return best;
+        r = rec;
+        for (int n = 0; n < 5; ++n) if ((r.width - delta) >= 0.5) { r.width -= delta; double v = rect_nfa(r); if (v > best) { rec = r; best = v; } }
+        if (best > 0) return best;
+        for (int side = 0; side < 2; side++) {
+            const double sg = side == 0 ? 1.0 : -1.0;
+            r = rec;
+            for (int n = 0; n < 5; ++n) if ((r.width - delta) >= 0.5) {
+                if (side == 0) { r.x1 += -r.dy * d2; r.y1 += r.dx * d2; r.x2 += -r.dy * d2; r.y2 += r.dx * d2; }
+                else { r.x1 -= -r.dy * d2; r.y1 -= r.dx * d2; r.x2 -= -r.dy * d2; r.y2 -= r.dx * d2; }
+                r.width -= delta;
+                double v = rect_nfa(r); if (v > best) { rec = r; best = v; } }
+            (void)sg;
+            if (best > 0) return best;
+        }
+        r = rec;
+        for (int n = 0; n < 5; ++n) if ((r.width - delta) >= 0.5) { r.p /= 2; r.prec = r.p * PI_; double v = rect_nfa(r); if (v > best) { rec = r; best = v; } }
+        return best;
+    }
+    // flsd :464-535 (LSD_REFINE_ADV, scale 0.8): segments as x1 y1 x2 y2 floats
+    void run(int w_, int h_, const double *ang, const double *mod, std::vector<float> &lines) {
+        w = w_; h = h_; angles = ang; modgrad = mod;
+        const size_t n = (size_t)w * h;
+        const double prec = PI_ * 22.5 / 180, p = 22.5 / 180;
+        // pseudo-ordering (:588-634): 1024 bins by gradient norm, descending bins, pixel order inside a bin
+        double max_grad = -1;
+        for (size_t i = 0; i < n; i++) if (ang[i] != NOTDEF && mod[i] > max_grad) max_grad = mod[i];
+        const double bin_coef = (max_grad > 0) ? double(1024 - 1) / max_grad : 0;
+        std::vector<int> cnt(1025, 0), order((size_t)(w - 1) * (h - 1));
+        for (int y = 0; y < h - 1; ++y) for (int x = 0; x < w - 1; ++x) cnt[1023 - int(mod[(size_t)y * w + x] * bin_coef) + 1]++;
+        for (int i = 0; i < 1024; i++) cnt[i + 1] += cnt[i];
+        for (int y = 0; y < h - 1; ++y) for (int x = 0; x < w - 1; ++x) order[cnt[1023 - int(mod[(size_t)y * w + x] * bin_coef)]++] = x + y * w;
+        LOG_NT = 5 * (std::log10(double(w)) + std::log10(double(h))) / 2 + std::log10(11.0);
+        const int min_reg_size = int(-LOG_NT / std::log10(p));
+        used.assign(n, 0);
+        rx.resize(n); ry.resize(n); rang.resize(n); rmod.resize(n);
+        lines.clear();
+        for (size_t i = 0; i < order.size(); ++i) {
+            const int adx = order[i];
+            if (used[adx] != 0 || ang[adx] == NOTDEF) continue;
+            int rn; double reg_angle;
+            grow(adx % w, adx / w, rn, reg_angle, prec);
+            if (rn < min_reg_size) continue;
+            RectH rec;
+            to_rect(rn, reg_angle, prec, p, rec);
+            if (!refine(rn, reg_angle, prec, p, rec, 0.7)) continue;
+            if (improve(rec) <= 0) continue;
+            rec.x1 += 0.5; rec.y1 += 0.5; rec.x2 += 0.5; rec.y2 += 0.5;
+            rec.x1 /= 0.8; rec.y1 /= 0.8; rec.x2 /= 0.8; rec.y2 /= 0.8;
+            lines.push_back(float(rec.x1)); lines.push_back(float(rec.y1)); lines.push_back(float(rec.x2)); lines.push_back(float(rec.y2));
+        }
+    }
+};
+
+static void to_keylines(const std::vector<float> &lines, int W, int H, std::vector<cs_keyline> &out) { // LSDDetector.cpp:75-101,205-263
+    out.clear();
+    const float thre = 10;
+    int cls = -1;
+    for (size_t k = 0; k + 3 < lines.size(); k += 4) {
+        float e[4] = {lines[k], lines[k + 1], lines[k + 2], lines[k + 3]};
+        for (int q = 0; q < 4; q++) { const int lim = (q & 1) ? H : W; if (e[q] < 0) e[q] = 0; if (e[q] >= lim) e[q] = (float)lim - 1.0f; }
+        const float os = std::pow((float)1, 0);
+        cs_keyline kl;
+        memset(&kl, 0, sizeof(kl));
+        kl.startPointX = e[0] * os; kl.startPointY = e[1] * os; kl.endPointX = e[2] * os; kl.endPointY = e[3] * os;
+        if (((kl.startPointX < thre) && (kl.endPointX < thre)) || ((kl.startPointX > W - thre) && (kl.endPointX > W - thre)) ||
+            ((kl.startPointY < thre) && (kl.endPointY < thre)) || ((kl.startPointY > H - thre) && (kl.endPointY > H - thre)))
+            continue;
+        kl.sPointInOctaveX = e[0]; kl.sPointInOctaveY = e[1]; kl.ePointInOctaveX = e[2]; kl.ePointInOctaveY = e[3];
+        kl.lineLength = (float)std::sqrt(std::pow(e[0] - e[2], 2) + std::pow(e[1] - e[3], 2));
+        const int x1 = (int)std::lrint(e[0]), y1 = (int)std::lrint(e[1]), x2 = (int)std::lrint(e[2]), y2 = (int)std::lrint(e[3]);
+        kl.numOfPixels = std::max(std::abs(x2 - x1), std::abs(y2 - y1)) + 1; // cv::LineIterator(...).count, 8-connected
+        kl.angle = std::atan2((kl.endPointY - kl.startPointY), (kl.endPointX - kl.startPointX));
+        kl.class_id = ++cls; kl.octave = 0;
+        kl.size = (kl.endPointX - kl.startPointX) * (kl.endPointY - kl.startPointY);
+        kl.response = kl.lineLength / std::max(W, H);
+        kl.pt_x = (kl.endPointX + kl.startPointX) / 2; kl.pt_y = (kl.endPointY + kl.startPointY) / 2;
+        out.push_back(kl);
+    }
+}
+} // namespace
+
+struct cs_lsd {
+    int W = 0, H = 0, w = 0, h = 0, max_frames = 0, n_frames = 0;
+    GK gk{};
+    double threshold = 0;
+    uint8_t *d_gray = nullptr; double *d_tmp = nullptr, *d_blur = nullptr, *d_scaled = nullptr, *d_mod = nullptr, *d_ang = nullptr;
+    int *d_xofs = nullptr, *d_yofs = nullptr; float *d_ax = nullptr, *d_ay = nullptr;
+    std::vector<double> h_mod, h_ang;
+    std::vector<std::vector<cs_keyline>> keylines;
+};
+
+static int lsd_run(cs_ctx *ctx, cs_lsd *l, const uint8_t *gray, int n_frames, int stride) {
+    if (!ctx || !l || !gray || n_frames < 1 || n_frames > l->max_frames || stride < l->W) return CS_ERR_BAD_ARG;
+    CS_HIP(ctx, hipSetDevice(ctx->device));
+    const int W = l->W, H = l->H, w = l->w, h = l->h, F = n_frames;
+    l->n_frames = F;
+    CS_HIP(ctx, hipMemcpy2DAsync(l->d_gray, (size_t)W, gray, (size_t)stride, (size_t)W, (size_t)H * F, hipMemcpyHostToDevice, ctx->stream));
+    CS_LAUNCH(ctx, "lsd_blur_h", lsd_blur_h, dim3((W + 255) / 256, H, F), dim3(256), 0, l->d_gray, W, H, l->gk, l->d_tmp);
+    CS_LAUNCH(ctx, "lsd_blur_v", lsd_blur_v, dim3((W + 255) / 256, H, F), dim3(256), 0, l->d_tmp, W, H, l->gk, l->d_blur);
+    CS_LAUNCH(ctx, "lsd_resize", lsd_resize, dim3((w + 255) / 256, h, F), dim3(256), 0, l->d_blur, W, H, w, h, l->d_xofs, l->d_ax, l->d_yofs, l->d_ay, l->d_scaled);
+    CS_LAUNCH(ctx, "lsd_gradient", lsd_gradient, dim3((w + 255) / 256, h, F), dim3(256), 0, l->d_scaled, w, h, l->threshold, l->d_mod, l->d_ang);
+    const size_t n = (size_t)w * h;
+    l->h_mod.resize(n * F); l->h_ang.resize(n * F);
+    int r = cs_d2h(ctx, l->h_mod.data(), l->d_mod, n * F); if (r) return r;
+    r = cs_d2h(ctx, l->h_ang.data(), l->d_ang, n * F); if (r) return r;
+    CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const auto t0 = std::chrono::steady_clock::now();
+    l->keylines.assign((size_t)F, {});
+#pragma omp parallel num_threads(std::min(omp_get_max_threads(), std::max(1, std::min(64, F))))
+    {
+        LsdHost host;
+        std::vector<float> lines;
+#pragma omp for schedule(dynamic, 1)
+        for (int f = 0; f < F; f++) {
+            host.run(w, h, l->h_ang.data() + n * f, l->h_mod.data() + n * f, lines);
+            to_keylines(lines, W, H, l->keylines[f]);
+        }
+    }
+    if (ctx->timing) { auto &rec = ctx->timings["host_lsd_regions"]; rec.total_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); rec.count++; }
+    return CS_OK;
+}
+
+extern "C" {
+
+void cs_lsd_destroy(cs_ctx *ctx, cs_lsd *l) {
+    if (!l) return;
+    if (ctx) { hipSetDevice(ctx->device); hipStreamSynchronize(ctx->stream); }
+    void *ptrs[] = {l->d_gray, l->d_tmp, l->d_blur, l->d_scaled, l->d_mod, l->d_ang, l->d_xofs, l->d_yofs, l->d_ax, l->d_ay};
+    for (void *p : ptrs) if (p) hipFree(p);
+    delete l;
+}
+
+int cs_lsd_create(cs_ctx *ctx, int width, int height, int max_frames, cs_lsd **out) {
+    if (!ctx || !out || width < 16 || height < 16 || max_frames < 1) return CS_ERR_BAD_ARG;
+    *out = nullptr;
+    CS_HIP(ctx, hipSetDevice(ctx->device));
+    cs_lsd *l = new (std::nothrow) cs_lsd();
+    if (!l) return CS_ERR_NOMEM;
+    l->W = width; l->H = height; l->max_frames = max_frames;
+    const double SCALE = 0.8, sigma = 0.6 / SCALE; // lsd.cpp:185-187 defaults, flsd :451-457
+    if ((int)std::ceil(sigma * std::sqrt(2 * 3.0 * std::log(10.0))) != KH) { delete l; return CS_ERR_BAD_ARG; }
+    { double sum = 0, s2 = -0.5 / (sigma * sigma); for (int i = 0; i < 2 * KH + 1; i++) { double x = i - (2 * KH) * 0.5; l->gk.k[i] = std::exp(s2 * x * x); sum += l->gk.k[i]; } sum = 1. / sum; for (int i = 0; i < 2 * KH + 1; i++) l->gk.k[i] *= sum; }
+    l->w = (int)std::lrint(width * SCALE); l->h = (int)std::lrint(height * SCALE);
+    l->threshold = 2.0 / std::sin(PI_ * 22.5 / 180); // rho = QUANT / sin(prec)
+    const double sx = 1. / SCALE;
+    std::vector<int> xofs(l->w), yofs(l->h);
+    std::vector<float> ax((size_t)l->w * 2), ay((size_t)l->h * 2);
+    auto fl = [](double v) { int i = (int)v; return i - (i > v); };
+    for (int dx = 0; dx < l->w; dx++) { float fx = (float)((dx + 0.5) * sx - 0.5); int s = fl(fx); fx -= s; if (s < 0) { fx = 0; s = 0; } if (s >= width - 1) { fx = 0; s = width - 1; } xofs[dx] = s; ax[dx * 2] = 1.f - fx; ax[dx * 2 + 1] = fx; }
+    for (int dy = 0; dy < l->h; dy++) { float fy = (float)((dy + 0.5) * sx - 0.5); int s = fl(fy); fy -= s; if (s < 0) { fy = 0; s = 0; } if (s >= height - 1) { fy = 0; s = height - 1; } yofs[dy] = s; ay[dy * 2] = 1.f - fy; ay[dy * 2 + 1] = fy; }
+    const size_t N = (size_t)width * height * max_frames, n = (size_t)l->w * l->h * max_frames;
+#define A_(call) do { int r__ = (call); if (r__ != CS_OK) { cs_lsd_destroy(ctx, l); return r__; } } while (0)
+    A_(cs_dalloc(ctx, &l->d_gray, N)); A_(cs_dalloc(ctx, &l->d_tmp, N)); A_(cs_dalloc(ctx, &l->d_blur, N));
+    A_(cs_dalloc(ctx, &l->d_scaled, n)); A_(cs_dalloc(ctx, &l->d_mod, n)); A_(cs_dalloc(ctx, &l->d_ang, n));
+    A_(cs_dalloc(ctx, &l->d_xofs, xofs.size())); A_(cs_dalloc(ctx, &l->d_yofs, yofs.size())); A_(cs_dalloc(ctx, &l->d_ax, ax.size())); A_(cs_dalloc(ctx, &l->d_ay, ay.size()));
+    A_(cs_h2d(ctx, l->d_xofs, xofs.data(), xofs.size())); A_(cs_h2d(ctx, l->d_yofs, yofs.data(), yofs.size()));
+    A_(cs_h2d(ctx, l->d_ax, ax.data(), ax.size())); A_(cs_h2d(ctx, l->d_ay, ay.data(), ay.size()));
+#undef A_
+    { hipError_t e = hipStreamSynchronize(ctx->stream); if (e != hipSuccess) { cs_lsd_destroy(ctx, l); return CS_ERR_HIP; } }
+    *out = l;
+    return CS_OK;
+}
+
+int cs_lsd_detect(cs_ctx *ctx, cs_lsd *l, const uint8_t *gray, int n_frames, int stride, cs_keyline *out, int cap, int *counts) {
+    if (!out || !counts || cap < 1) return CS_ERR_BAD_ARG;
+    int r = lsd_run(ctx, l, gray, n_frames, stride); if (r) return r;
+    int status = CS_OK;
+    for (int f = 0; f < n_frames; f++) {
+        const int n = (int)l->keylines[f].size();
+        counts[f] = std::min(n, cap);
+        if (n > cap) status = CS_ERR_CAPACITY;
+        memcpy(out + (size_t)f * cap, l->keylines[f].data(), sizeof(cs_keyline) * (size_t)counts[f]);
+    }
+    return status;
+}
+
+int cs_lsd_detect_filter_lines(cs_ctx *ctx, cs_lsd *l, const uint8_t *gray, int n_frames, int stride, float length_thres, float *lines, int cap, int *counts) {
+    if (!lines || !counts || cap < 1) return CS_ERR_BAD_ARG;
+    int r = lsd_run(ctx, l, gray, n_frames, stride); if (r) return r;
+    int status = CS_OK;
+    for (int f = 0; f < n_frames; f++) { // filter_lines :200-207 + keylines_to_mat :26-36
+        int n = 0;
+        for (const cs_keyline &k : l->keylines[f])
+            if (k.octave == 0 && k.lineLength > length_thres) {
+                if (n < cap) { float *o = lines + ((size_t)f * cap + n) * 4; o[0] = k.startPointX * 1.f; o[1] = k.startPointY * 1.f; o[2] = k.endPointX * 1.f; o[3] = k.endPointY * 1.f; }
+                n++;
+            }
+        counts[f] = std::min(n, cap);
+        if (n > cap) status = CS_ERR_CAPACITY;
+    }
+    return status;
+}
+
+int cs_lsd_get_maps(cs_ctx *ctx, cs_lsd *l, int frame, double *scaled, double *modgrad, double *angles, int *sw, int *sh) {
+    if (!ctx || !l || frame < 0 || frame >= l->n_frames || !sw || !sh) return CS_ERR_BAD_ARG;
+    *sw = l->w; *sh = l->h;
+    const size_t n = (size_t)l->w * l->h;
+    int r;
+    if (scaled) { r = cs_d2h(ctx, scaled, l->d_scaled + n * frame, n); if (r) return r; }
+    if (modgrad) { r = cs_d2h(ctx, modgrad, l->d_mod + n * frame, n); if (r) return r; }
+    if (angles) { r = cs_d2h(ctx, angles, l->d_ang + n * frame, n); if (r) return r; }
+    CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CS_OK;
+}
+
+} // extern "C"

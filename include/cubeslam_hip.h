@@ -256,6 +256,29 @@ int cs_ba_errors(cs_ctx *ctx, cs_ba *b, double *chi2, double *err_obs, double *e
 /* Dense copy of this rank's reduced camera system (before the all-reduce) for lambda: H (6P x 6P row-major), b (6P); *P out */
 int cs_ba_reduced_dense(cs_ctx *ctx, cs_ba *b, double lambda, double *H, double *bvec, int *P);
 
+/* ===================================================================== LSD line detector
+ * Replaces line_lbd_detect::detect_raw_lines / detect_filter_lines (line_lbd/include/line_lbd/line_lbd_allclass.h:37-52,
+ * class/line_lbd_allclass.cpp:125-148,200-221) with use_LSD = true, one octave: LSDDetector::detectImpl
+ * (libs/LSDDetector.cpp:153-287) over LineSegmentDetectorImpl (libs/lsd.cpp; LSD_REFINE_ADV, default parameters).
+ * GPU: Gaussian blur + 0.8x bilinear resize in double, level-line angles and gradient norms (ll_angle).  Host (one thread
+ * per frame): the pseudo-ordering and the inherently sequential region growing / rectangle / NFA stages. */
+typedef struct cs_keyline {              /* the KeyLine fields (line_descriptor/descriptor.hpp:105-150) */
+    float angle; int32_t class_id; int32_t octave; float pt_x, pt_y; float response; float size;
+    float startPointX, startPointY, endPointX, endPointY;
+    float sPointInOctaveX, sPointInOctaveY, ePointInOctaveX, ePointInOctaveY;
+    float lineLength; int32_t numOfPixels;
+} cs_keyline;
+typedef struct cs_lsd cs_lsd;
+int cs_lsd_create(cs_ctx *ctx, int width, int height, int max_frames, cs_lsd **out);
+void cs_lsd_destroy(cs_ctx *ctx, cs_lsd *l);
+/* detect_raw_lines on n_frames gray images: per frame counts[f] KeyLines at out[f*cap_per_frame ...] */
+int cs_lsd_detect(cs_ctx *ctx, cs_lsd *l, const uint8_t *gray, int n_frames, int stride, cs_keyline *out, int cap_per_frame, int *counts);
+/* detect_filter_lines(gray, linesmat): octave 0, lineLength > length_thres; lines: [f][cap_per_frame][4] floats (CV_32F N x 4) */
+int cs_lsd_detect_filter_lines(cs_ctx *ctx, cs_lsd *l, const uint8_t *gray, int n_frames, int stride, float length_thres,
+                               float *lines, int cap_per_frame, int *counts);
+/* introspection after a detect call: scaled image, gradient norm and level-line angle maps (sw x sh doubles each) */
+int cs_lsd_get_maps(cs_ctx *ctx, cs_lsd *l, int frame, double *scaled, double *modgrad, double *angles, int *sw, int *sh);
+
 #ifdef __cplusplus
 }
 #endif

@@ -199,6 +199,24 @@ double orc_ba_errors(const orc_ba_problem *p, double *err_obs, double *err_cobs,
  * with_pose_edges.  H is (6P)x(6P) row-major, b is 6P, P = number of non-fixed cameras + cuboids.  Returns P. */
 int orc_ba_reduced_dense(const orc_ba_problem *p, int lm_begin, int lm_end, int with_pose_edges, double lambda, double *H, double *b);
 
+/* ------------------------------------------------------------------ LSD line detection
+ * line_lbd_detect::detect_filter_lines (line_lbd/class/line_lbd_allclass.cpp:125-148,200-221) ->
+ * LSDDetector::detectImpl (libs/LSDDetector.cpp:153-287, one octave) -> LineSegmentDetectorImpl (libs/lsd.cpp, LSD_REFINE_ADV,
+ * scale 0.8, sigma_scale 0.6, quant 2, ang_th 22.5, log_eps 0, density_th 0.7, 1024 bins). */
+typedef struct orc_keyline { /* the KeyLine fields detectImpl fills (descriptor.hpp:105-150) */
+    float angle; int32_t class_id; int32_t octave; float pt_x, pt_y; float response; float size;
+    float startPointX, startPointY, endPointX, endPointY;
+    float sPointInOctaveX, sPointInOctaveY, ePointInOctaveX, ePointInOctaveY;
+    float lineLength; int32_t numOfPixels;
+} orc_keyline;
+/* detect_raw_lines: all KeyLines (cap entries); returns count */
+int orc_lsd_detect(const uint8_t *gray, int W, int H, orc_keyline *out, int cap);
+/* detect_filter_lines(gray, linesmat): octave 0 and lineLength > length_thres; lines: n x 4 floats; returns n */
+int orc_lsd_detect_filter_lines(const uint8_t *gray, int W, int H, float length_thres, float *lines, int cap);
+/* introspection: the scaled image (double), gradient norm, level-line angle (NOTDEF = -1024) and the pseudo-ordered
+ * coordinate list (x + y*width) of ll_angle; sw/sh out.  Any pointer may be NULL. */
+int orc_lsd_maps(const uint8_t *gray, int W, int H, int *sw, int *sh, double *scaled, double *modgrad, double *angles, int *order, int *n_order);
+
 #ifdef __cplusplus
 }
 #endif

@@ -351,3 +351,39 @@ def ba_reduced_dense(d, lm_begin, lm_end, with_pose_edges, lam):
     Hm = np.zeros((6 * P, 6 * P)); b = np.zeros(6 * P)
     lib().orc_ba_reduced_dense(C.byref(p), lm_begin, lm_end, int(with_pose_edges), C.c_double(lam), _p(Hm, C.c_double), _p(b, C.c_double))
     return Hm, b
+
+
+# ----------------------------------------------------------------------------------------------- LSD
+KEYLINE_DTYPE = np.dtype([("angle", "f4"), ("class_id", "i4"), ("octave", "i4"), ("pt", "f4", 2), ("response", "f4"), ("size", "f4"),
+                          ("startPointX", "f4"), ("startPointY", "f4"), ("endPointX", "f4"), ("endPointY", "f4"),
+                          ("sPointInOctaveX", "f4"), ("sPointInOctaveY", "f4"), ("ePointInOctaveX", "f4"), ("ePointInOctaveY", "f4"),
+                          ("lineLength", "f4"), ("numOfPixels", "i4")])
+assert KEYLINE_DTYPE.itemsize == 68
+
+
+def lsd_detect(gray, cap=20000):
+    gray = np.ascontiguousarray(gray, np.uint8)
+    H, W = gray.shape
+    out = np.zeros(cap, KEYLINE_DTYPE)
+    n = lib().orc_lsd_detect(_p(gray, C.c_uint8), W, H, out.ctypes.data_as(C.c_void_p), cap)
+    return out[:n].copy()
+
+
+def lsd_detect_filter_lines(gray, length_thres=15.0, cap=20000):
+    gray = np.ascontiguousarray(gray, np.uint8)
+    H, W = gray.shape
+    out = np.zeros((cap, 4), np.float32)
+    n = lib().orc_lsd_detect_filter_lines(_p(gray, C.c_uint8), W, H, C.c_float(length_thres), _p(out, C.c_float), cap)
+    return out[:n].copy()
+
+
+def lsd_maps(gray):
+    gray = np.ascontiguousarray(gray, np.uint8)
+    H, W = gray.shape
+    sw, sh, no = C.c_int(), C.c_int(), C.c_int()
+    lib().orc_lsd_maps(_p(gray, C.c_uint8), W, H, C.byref(sw), C.byref(sh), None, None, None, None, None)
+    n = sw.value * sh.value
+    sc = np.zeros(n); mg = np.zeros(n); an = np.zeros(n); order = np.zeros(n, np.int32)
+    lib().orc_lsd_maps(_p(gray, C.c_uint8), W, H, C.byref(sw), C.byref(sh), _p(sc, C.c_double), _p(mg, C.c_double), _p(an, C.c_double), _p(order, C.c_int), C.byref(no))
+    shape = (sh.value, sw.value)
+    return sc.reshape(shape), mg.reshape(shape), an.reshape(shape), order[:no.value].copy()
