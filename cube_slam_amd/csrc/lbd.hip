@@ -1,0 +1,230 @@
+// lbd.hip -- LBD line descriptor (and its brute-force Hamming matcher) of line_lbd on MI355X (gfx950).
+//
+// Replaces BinaryDescriptor::compute / computeImpl / computeLBD (reference line_lbd/libs/binary_descriptor.cpp:588-790,
+// 1146-1509) for one octave and line_lbd_detect::match_line_descrip (class/line_lbd_allclass.cpp:339-356).
+// Built with -ffp-contract=off: the reference accumulates in float with separate multiplies and adds.
+//   lbd_blur5     GaussianBlur(5x5, sigma 1) on u8, 8-bit fixed point, LDS tile              (computeGaussianPyramid :352-370)
+//   lbd_sobel     Sobel 3x3 -> int16 dx, dy, BORDER_REFLECT_101                              (computeSobel :373-402)
+//   lbd_rows      thread per (line, support-region row): walks the row (numOfPixels samples, rounded + clamped coordinates),
+//                 sequential float sums of the positive / negative projections on dL and dO   (:1272-1335)
+//   lbd_desc      thread per line: the 63 rows in order into the 9 bands with the local Gaussian weights, mean/std per band,
+//                 the two normalisations with the 0.4 clip, 32 band-pair comparisons -> 32 bytes (:1337-1478, :405-416)
+#include "common.h"
+
+#include <cmath>
+#include <vector>
+
+namespace {
+constexpr int NB = 9, WB = 7, HLSP = NB * WB;
+__constant__ int c_comb[32][2] = {{0, 1}, {0, 2}, {0, 3}, {0, 4}, {0, 5}, {0, 6}, {1, 2}, {1, 3}, {1, 4}, {1, 5}, {1, 6}, {2, 3}, {2, 4}, {2, 5}, {2, 6}, {2, 7},
+                                  {2, 8}, {3, 4}, {3, 5}, {3, 6}, {3, 7}, {3, 8}, {4, 5}, {4, 6}, {4, 7}, {4, 8}, {5, 6}, {5, 7}, {5, 8}, {6, 7}, {6, 8}, {7, 8}};
+struct LbdW { float gL[WB * 3]; float gG[HLSP]; int k5[5]; };
+
+__device__ __forceinline__ int refl(int p, int len) { if (len == 1) return 0; while (p < 0 || p >= len) { if (p < 0) p = -p; else p = 2 * len - 2 - p; } return p; }
+
+__global__ void __launch_bounds__(256) lbd_blur5(const uint8_t *gray, int W, int H, LbdW wts, uint8_t *blur) {
+    __shared__ uint8_t g[16 + 4][64 + 4];
+    __shared__ int hp[16 + 4][64];
+    const int tx0 = blockIdx.x * 64, ty0 = blockIdx.y * 16;
+    for (int i = threadIdx.x; i < 20 * 68; i += 256) { int ly = i / 68, lx = i % 68; g[ly][lx] = gray[(long)refl(ty0 + ly - 2, H) * W + refl(tx0 + lx - 2, W)]; }
+    __syncthreads();
+    for (int i = threadIdx.x; i < 20 * 64; i += 256) { int ly = i / 64, lx = i % 64, s = 0; for (int t = 0; t < 5; t++) s += g[ly][lx + t] * wts.k5[t]; hp[ly][lx] = s; }
+    __syncthreads();
+    const int lx = threadIdx.x & 63;
+    for (int ly = threadIdx.x >> 6; ly < 16; ly += 4) {
+        const int x = tx0 + lx, y = ty0 + ly;
+        if (x >= W || y >= H) continue;
+        int s = 0;
+        for (int t = 0; t < 5; t++) s += hp[ly + t][lx] * wts.k5[t];
+        int v = (s + (1 << 15)) >> 16;
+        blur[(long)y * W + x] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+    }
+}
+__global__ void __launch_bounds__(256) lbd_sobel(const uint8_t *blur, int W, int H, short *dx, short *dy) {
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
+    if (x >= W) return;
+    auto P = [&](int xx, int yy) { return (int)blur[(long)refl(yy, H) * W + refl(xx, W)]; };
+    dx[(long)y * W + x] = (short)((P(x + 1, y - 1) + 2 * P(x + 1, y) + P(x + 1, y + 1)) - (P(x - 1, y - 1) + 2 * P(x - 1, y) + P(x - 1, y + 1)));
+    dy[(long)y * W + x] = (short)((P(x - 1, y + 1) + 2 * P(x, y + 1) + P(x + 1, y + 1)) - (P(x - 1, y - 1) + 2 * P(x, y - 1) + P(x + 1, y - 1)));
+}
+
+__device__ __forceinline__ void sincos_fd(float angle, float &so, float &co) { // same evaluation as orb.hip
+    const double x = (double)angle;
+    const double TWO_OVER_PI = 0.63661977236758134308, PIO2_HI = 1.57079632679489655800, PIO2_LO = 6.12323399573676603587e-17;
+    const double kd = floor(x * TWO_OVER_PI + 0.5);
+    const int k = (int)kd;
+    const double r = (x - kd * PIO2_HI) - kd * PIO2_LO, r2 = r * r;
+    const double sp = -1.0 / 6.0 + r2 * (1.0 / 120.0 + r2 * (-1.0 / 5040.0 + r2 * (1.0 / 362880.0 + r2 * (-1.0 / 39916800.0 + r2 * (1.0 / 6227020800.0 + r2 * (-1.0 / 1307674368000.0))))));
+    const double cp = -1.0 / 2.0 + r2 * (1.0 / 24.0 + r2 * (-1.0 / 720.0 + r2 * (1.0 / 40320.0 + r2 * (-1.0 / 3628800.0 + r2 * (1.0 / 479001600.0 + r2 * (-1.0 / 87178291200.0 + r2 * (1.0 / 20922789888000.0)))))));
+    const double s = r + r * r2 * sp, c = 1.0 + r2 * cp;
+    double ss, cc;
+    switch (k & 3) { case 0: ss = s; cc = c; break; case 1: ss = c; cc = -s; break; case 2: ss = -s; cc = -c; break; default: ss = -c; cc = s; break; }
+    so = (float)ss; co = (float)cc;
+}
+
+// block = one line (64 threads: lane = support-region row hID); rowsums: [line][hID][4] = pgdL, ngdL, pgdO, ngdO (unweighted)
+__global__ void __launch_bounds__(64) lbd_rows(const cs_keyline *kls, const short *dxImg, const short *dyImg, int W, int H, float *rowsums) {
+    const int li = blockIdx.x, hID = threadIdx.x;
+    if (hID >= HLSP) return;
+    const cs_keyline L = kls[li];
+    const short realWidth = (short)W, imageWidth = realWidth - 1, imageHeight = (short)(H - 1);
+    const short lengthOfLSP = (short)L.numOfPixels, halfWidth = (lengthOfLSP - 1) / 2, halfHeight = (HLSP - 1) / 2;
+    const float mx = (float)(0.5 * (L.sPointInOctaveX + L.ePointInOctaveX)), my = (float)(0.5 * (L.sPointInOctaveY + L.ePointInOctaveY));
+    float dL0, dL1;
+    sincos_fd(L.angle, dL1, dL0);
+    const float dO0 = -dL1, dO1 = dL0;
+    float sCorX = -dL0 * halfWidth + dL1 * halfHeight + mx, sCorY = -dL1 * halfWidth - dL0 * halfHeight + my;
+    for (int r = 0; r < hID; r++) { sCorX -= dL1; sCorY += dL0; } // sCorX0 -= dL[1]; sCorY0 += dL[0] once per previous row (:1337-1338)
+    float pL = 0, nL = 0, pO = 0, nO = 0;
+    for (short wID = 0; wID < lengthOfLSP; wID++) {
+        short t = (short)round((double)sCorX);
+        const short xCor = (t < 0) ? 0 : (t > imageWidth) ? imageWidth : t;
+        t = (short)round((double)sCorY);
+        const short yCor = (t < 0) ? 0 : (t > imageHeight) ? imageHeight : t;
+        const short dx = dxImg[yCor * realWidth + xCor], dy = dyImg[yCor * realWidth + xCor];
+        const float gDL = dx * dL0 + dy * dL1, gDO = dx * dO0 + dy * dO1;
+        if (gDL > 0) pL += gDL; else nL -= gDL;
+        if (gDO > 0) pO += gDO; else nO -= gDO;
+        sCorX += dL0; sCorY += dL1;
+    }
+    float *o = rowsums + ((long)li * HLSP + hID) * 4;
+    o[0] = pL; o[1] = nL; o[2] = pO; o[3] = nO;
+}
+
+__global__ void __launch_bounds__(64) lbd_desc(int n, const float *rowsums, LbdW wts, uint8_t *desc, float *fdesc) {
+    const int li = blockIdx.x * 64 + threadIdx.x;
+    if (li >= n) return;
+    float bs[8][NB];
+    for (int q = 0; q < 8; q++) for (int b = 0; b < NB; b++) bs[q][b] = 0;
+    for (int hID = 0; hID < HLSP; hID++) {
+        const float *r = rowsums + ((long)li * HLSP + hID) * 4;
+        float coef = wts.gG[hID];
+        const float pL = coef * r[0], nL = coef * r[1], pL2 = pL * pL, nL2 = nL * nL, pO = coef * r[2], nO = coef * r[3], pO2 = pO * pO, nO2 = nO * nO;
+        auto add = [&](int band, float c) {
+            bs[0][band] += c * pL; bs[1][band] += c * nL; bs[2][band] += c * c * pL2; bs[3][band] += c * c * nL2;
+            bs[4][band] += c * pO; bs[5][band] += c * nO; bs[6][band] += c * c * pO2; bs[7][band] += c * c * nO2;
+        };
+        int band = hID / WB;
+        add(band, wts.gL[hID % WB + WB]);
+        band--;
+        if (band >= 0) add(band, wts.gL[hID % WB + 2 * WB]);
+        band = band + 2;
+        if (band < NB) add(band, wts.gL[hID % WB]);
+    }
+    float d[NB * 8];
+    const float invN2 = (float)(1.0 / (WB * 2.0)), invN3 = (float)(1.0 / (WB * 3.0));
+    for (int b = 0; b < NB; b++) {
+        const float invN = (b == 0 || b == NB - 1) ? invN2 : invN3;
+        float t = bs[0][b] * invN; d[b * 8] = t; d[b * 8 + 4] = sqrtf(bs[2][b] * invN - t * t);
+        t = bs[1][b] * invN; d[b * 8 + 1] = t; d[b * 8 + 5] = sqrtf(bs[3][b] * invN - t * t);
+        t = bs[4][b] * invN; d[b * 8 + 2] = t; d[b * 8 + 6] = sqrtf(bs[6][b] * invN - t * t);
+        t = bs[5][b] * invN; d[b * 8 + 3] = t; d[b * 8 + 7] = sqrtf(bs[7][b] * invN - t * t);
+    }
+    float tM = 0, tS = 0;
+    for (int b = 0; b < NB; b++) {
+        const float *e = d + b * 8;
+        tM += e[0] * e[0]; tM += e[1] * e[1]; tM += e[2] * e[2]; tM += e[3] * e[3];
+        tS += e[4] * e[4]; tS += e[5] * e[5]; tS += e[6] * e[6]; tS += e[7] * e[7];
+    }
+    tM = 1 / sqrtf(tM); tS = 1 / sqrtf(tS);
+    for (int b = 0; b < NB; b++) { float *e = d + b * 8; for (int q = 0; q < 4; q++) e[q] = e[q] * tM; for (int q = 4; q < 8; q++) e[q] = e[q] * tS; }
+    for (int i = 0; i < NB * 8; i++) if (d[i] > 0.4) d[i] = (float)0.4;
+    float t = 0;
+    for (int i = 0; i < NB * 8; i++) t += d[i] * d[i];
+    t = 1 / sqrtf(t);
+    for (int i = 0; i < NB * 8; i++) d[i] = d[i] * t;
+    if (fdesc) for (int i = 0; i < NB * 8; i++) fdesc[(long)li * 72 + i] = d[i];
+    for (int c = 0; c < 32; c++) {
+        const float *f1 = d + 8 * c_comb[c][0], *f2 = d + 8 * c_comb[c][1];
+        int r = 0;
+        for (int i = 0; i < 8; i++) if (f1[i] > f2[i]) r += 1 << i;
+        desc[(long)li * 32 + c] = (uint8_t)r;
+    }
+}
+
+static LbdW make_weights() { // BinaryDescriptor constructor :218-260 (integer divisions intended) + getGaussianKernel(5, 1)
+    LbdW w;
+    double u = (WB * 3 - 1) / 2, sigma = (WB * 2 + 1) / 2, inv = -1 / (2 * sigma * sigma);
+    for (int i = 0; i < WB * 3; i++) { double dis = i - u; w.gL[i] = (float)std::exp(dis * dis * inv); }
+    u = (NB * WB - 1) / 2; sigma = u; inv = -1 / (2 * sigma * sigma);
+    for (int i = 0; i < HLSP; i++) { double dis = i - u; w.gG[i] = (float)std::exp(dis * dis * inv); }
+    float cf[5]; double sum = 0, s2 = -0.5;
+    for (int i = 0; i < 5; i++) { double x = i - 2.0; cf[i] = (float)std::exp(s2 * x * x); sum += cf[i]; }
+    sum = 1. / sum;
+    for (int i = 0; i < 5; i++) { cf[i] = (float)(cf[i] * sum); w.k5[i] = (int)std::lrint(cf[i] * 256.f); }
+    return w;
+}
+
+struct Bufs { uint8_t *gray = nullptr, *blur = nullptr; short *dx = nullptr, *dy = nullptr; };
+static void free_bufs(Bufs &b) { if (b.gray) hipFree(b.gray); if (b.blur) hipFree(b.blur); if (b.dx) hipFree(b.dx); if (b.dy) hipFree(b.dy); b = Bufs(); }
+static int run_maps(cs_ctx *ctx, const uint8_t *gray, int W, int H, int stride, const LbdW &w, Bufs &b) {
+    const size_t N = (size_t)W * H;
+    int r = cs_dalloc(ctx, &b.gray, N); if (r) return r;
+    r = cs_dalloc(ctx, &b.blur, N); if (r) return r;
+    r = cs_dalloc(ctx, &b.dx, N); if (r) return r;
+    r = cs_dalloc(ctx, &b.dy, N); if (r) return r;
+    CS_HIP(ctx, hipMemcpy2DAsync(b.gray, (size_t)W, gray, (size_t)stride, (size_t)W, (size_t)H, hipMemcpyHostToDevice, ctx->stream));
+    CS_LAUNCH(ctx, "lbd_blur5", lbd_blur5, dim3((W + 63) / 64, (H + 15) / 16), dim3(256), 0, b.gray, W, H, w, b.blur);
+    CS_LAUNCH(ctx, "lbd_sobel", lbd_sobel, dim3((W + 255) / 256, H), dim3(256), 0, b.blur, W, H, b.dx, b.dy);
+    return CS_OK;
+}
+} // namespace
+
+extern "C" {
+
+int cs_lbd_maps(cs_ctx *ctx, const uint8_t *gray, int width, int height, int stride, uint8_t *blur, int16_t *dx, int16_t *dy) {
+    if (!ctx || !gray || width < 8 || height < 8 || stride < width) return CS_ERR_BAD_ARG;
+    CS_HIP(ctx, hipSetDevice(ctx->device));
+    Bufs b;
+    const LbdW w = make_weights();
+    int r = run_maps(ctx, gray, width, height, stride, w, b);
+    const size_t N = (size_t)width * height;
+    if (!r && blur) r = cs_d2h(ctx, blur, b.blur, N);
+    if (!r && dx) r = cs_d2h(ctx, (short *)dx, b.dx, N);
+    if (!r && dy) r = cs_d2h(ctx, (short *)dy, b.dy, N);
+    hipStreamSynchronize(ctx->stream);
+    free_bufs(b);
+    return r;
+}
+
+int cs_lbd_compute(cs_ctx *ctx, const uint8_t *gray, int width, int height, int stride, const cs_keyline *keylines, int n, uint8_t *desc, float *float_desc) {
+    if (!ctx || !gray || width < 8 || height < 8 || width > 32767 || height > 32767 || stride < width || n < 0 || (n && (!keylines || !desc))) return CS_ERR_BAD_ARG;
+    if (n == 0) return CS_OK; // the reference prints "keypoint list is empty" and returns (:619-623)
+    for (int i = 0; i < n; i++) if (keylines[i].numOfPixels < 0 || keylines[i].numOfPixels > 32767) return CS_ERR_BAD_ARG;
+    CS_HIP(ctx, hipSetDevice(ctx->device));
+    Bufs b;
+    const LbdW w = make_weights();
+    int r = run_maps(ctx, gray, width, height, stride, w, b);
+    cs_keyline *d_kl = nullptr; float *d_rows = nullptr, *d_f = nullptr; uint8_t *d_desc = nullptr;
+    if (!r) r = cs_dalloc(ctx, &d_kl, (size_t)n);
+    if (!r) r = cs_dalloc(ctx, &d_rows, (size_t)n * HLSP * 4);
+    if (!r) r = cs_dalloc(ctx, &d_desc, (size_t)n * 32);
+    if (!r && float_desc) r = cs_dalloc(ctx, &d_f, (size_t)n * 72);
+    if (!r) r = cs_h2d(ctx, d_kl, keylines, (size_t)n);
+    if (!r) {
+        CS_LAUNCH(ctx, "lbd_rows", lbd_rows, dim3(n), dim3(64), 0, d_kl, b.dx, b.dy, width, height, d_rows);
+        CS_LAUNCH(ctx, "lbd_desc", lbd_desc, dim3((n + 63) / 64), dim3(64), 0, n, d_rows, w, d_desc, d_f);
+        r = cs_d2h(ctx, desc, d_desc, (size_t)n * 32);
+        if (!r && float_desc) r = cs_d2h(ctx, float_desc, d_f, (size_t)n * 72);
+    }
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (!r && e != hipSuccess) { ctx->err = hipGetErrorString(e); r = CS_ERR_HIP; }
+    free_bufs(b);
+    if (d_kl) hipFree(d_kl); if (d_rows) hipFree(d_rows); if (d_desc) hipFree(d_desc); if (d_f) hipFree(d_f);
+    return r;
+}
+
+int cs_lbd_match(cs_ctx *ctx, const uint8_t *q, int nq, const uint8_t *t, int nt, float dist_thres, int *query_idx, int *train_idx, int *distance, int *n_matches) {
+    if (!ctx || !n_matches || nq < 0 || nt < 0) return CS_ERR_BAD_ARG;
+    *n_matches = 0;
+    if (nq == 0 || nt == 0) return CS_OK;
+    std::vector<int> bi(nq), bd(nq), sd(nq);
+    int r = cs_hamming_knn2(ctx, q, nq, t, nt, bi.data(), bd.data(), sd.data()); if (r) return r;
+    int m = 0;
+    for (int i = 0; i < nq; i++) // match_line_descrip :339-356: keep matches[i].distance < matching_dist_thres
+        if ((float)bd[i] < dist_thres) { if (query_idx) query_idx[m] = i; if (train_idx) train_idx[m] = bi[i]; if (distance) distance[m] = bd[i]; m++; }
+    *n_matches = m;
+    return CS_OK;
+}
+
+} // extern "C"

@@ -59,6 +59,37 @@ class line_lbd_detect:
         shape = (sh.value, sw.value)
         return sc.reshape(shape), mg.reshape(shape), an.reshape(shape)
 
+    # ---- LBD descriptors (use_LSD path of detect_descrip_lines, line_lbd_allclass.cpp:222-269) and their matcher (:339-356)
+    def get_line_descriptors(self, gray, keylines, want_float=False):
+        g = np.ascontiguousarray(gray, np.uint8)
+        kl = np.ascontiguousarray(keylines, KEYLINE_DTYPE); n = len(kl)
+        desc = np.zeros((n, 32), np.uint8); fd = np.zeros((n, 72), np.float32) if want_float else None
+        check(self.ctx.ptr, lib().cs_lbd_compute(self.ctx.ptr, _p(g, C.c_uint8), g.shape[1], g.shape[0], g.shape[1], kl.ctypes.data_as(C.c_void_p), n,
+                                                 _p(desc, C.c_uint8), _p(fd, C.c_float) if want_float else None), "cs_lbd_compute")
+        return (desc, fd) if want_float else desc
+
+    def detect_descrip_lines(self, gray):
+        """-> (keylines, descriptors) of one gray image: descriptors of all raw lines, then the octave-0 lines longer
+        than line_length_thres are kept (line_lbd_allclass.cpp:222-269)."""
+        kl = self.detect_raw_lines(gray)
+        desc = self.get_line_descriptors(gray, kl)
+        keep = (kl["octave"] == 0) & (kl["lineLength"] > self.line_length_thres)
+        return kl[keep], desc[keep]
+
+    def match_line_descrip(self, desc_q, desc_t, matching_dist_thres=25.0):
+        """-> (query_idx, train_idx, distance) of the good matches (BinaryDescriptorMatcher::match + distance threshold)."""
+        q = np.ascontiguousarray(desc_q, np.uint8).reshape(-1, 32); t = np.ascontiguousarray(desc_t, np.uint8).reshape(-1, 32)
+        qi = np.zeros(len(q), np.int32); ti = np.zeros(len(q), np.int32); d = np.zeros(len(q), np.int32); m = C.c_int()
+        check(self.ctx.ptr, lib().cs_lbd_match(self.ctx.ptr, _p(q, C.c_uint8), len(q), _p(t, C.c_uint8), len(t), C.c_float(matching_dist_thres),
+                                               _p(qi, C.c_int), _p(ti, C.c_int), _p(d, C.c_int), C.byref(m)), "cs_lbd_match")
+        return qi[:m.value], ti[:m.value], d[:m.value]
+
+    def lbd_maps(self, gray):
+        g = np.ascontiguousarray(gray, np.uint8); H, W = g.shape
+        b = np.zeros((H, W), np.uint8); dx = np.zeros((H, W), np.int16); dy = np.zeros((H, W), np.int16)
+        check(self.ctx.ptr, lib().cs_lbd_maps(self.ctx.ptr, _p(g, C.c_uint8), W, H, W, _p(b, C.c_uint8), _p(dx, C.c_int16), _p(dy, C.c_int16)), "cs_lbd_maps")
+        return b, dx, dy
+
     def close(self):
         if self._l:
             lib().cs_lsd_destroy(self.ctx.ptr, self._l)

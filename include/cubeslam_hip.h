@@ -279,6 +279,19 @@ int cs_lsd_detect_filter_lines(cs_ctx *ctx, cs_lsd *l, const uint8_t *gray, int 
 /* introspection after a detect call: scaled image, gradient norm and level-line angle maps (sw x sh doubles each) */
 int cs_lsd_get_maps(cs_ctx *ctx, cs_lsd *l, int frame, double *scaled, double *modgrad, double *angles, int *sw, int *sh);
 
+/* ===================================================================== LBD line descriptor + matcher
+ * Replaces BinaryDescriptor::compute (line_lbd/libs/binary_descriptor.cpp:588-790,1146-1509; what
+ * line_lbd_detect::get_line_descriptors / detect_descrip_lines call, class/line_lbd_allclass.cpp:192-269) for one octave, and
+ * line_lbd_detect::match_line_descrip (:339-356) = BinaryDescriptorMatcher::match (exact 1-NN in 256-bit Hamming space,
+ * libs/binary_descriptor_matcher.cpp:196-262) followed by the distance threshold. */
+int cs_lbd_compute(cs_ctx *ctx, const uint8_t *gray, int width, int height, int stride, const cs_keyline *keylines, int n,
+                   uint8_t *desc /* n x 32 */, float *float_desc /* n x 72 or NULL */);
+/* good matches: for every query whose nearest train descriptor is closer than dist_thres: (query, train, distance) */
+int cs_lbd_match(cs_ctx *ctx, const uint8_t *q, int nq, const uint8_t *t, int nt, float dist_thres,
+                 int *query_idx, int *train_idx, int *distance, int *n_matches);
+/* introspection: the blurred image and the Sobel derivative maps of the last cs_lbd_compute-like pass over `gray` */
+int cs_lbd_maps(cs_ctx *ctx, const uint8_t *gray, int width, int height, int stride, uint8_t *blur, int16_t *dx, int16_t *dy);
+
 #ifdef __cplusplus
 }
 #endif

@@ -217,6 +217,13 @@ int orc_lsd_detect_filter_lines(const uint8_t *gray, int W, int H, float length_
  * coordinate list (x + y*width) of ll_angle; sw/sh out.  Any pointer may be NULL. */
 int orc_lsd_maps(const uint8_t *gray, int W, int H, int *sw, int *sh, double *scaled, double *modgrad, double *angles, int *order, int *n_order);
 
+/* ------------------------------------------------------------------ LBD line descriptor
+ * BinaryDescriptor::compute -> computeImpl (line_lbd/libs/binary_descriptor.cpp:603-790, useDetectionData = false, one octave):
+ * computeGaussianPyramid (:352-370, GaussianBlur 5x5 sigma 1), computeSobel (:373-402), computeLBD (:1146-1509),
+ * binaryConversion (:405-416) with the 32 band pairs of `combinations` (:74-107). */
+int orc_lbd_compute(const uint8_t *gray, int W, int H, const orc_keyline *kl, int n, uint8_t *desc, float *fdesc);
+int orc_lbd_maps(const uint8_t *gray, int W, int H, uint8_t *blur, int16_t *dx, int16_t *dy);
+
 #ifdef __cplusplus
 }
 #endif

@@ -387,3 +387,19 @@ def lsd_maps(gray):
     lib().orc_lsd_maps(_p(gray, C.c_uint8), W, H, C.byref(sw), C.byref(sh), _p(sc, C.c_double), _p(mg, C.c_double), _p(an, C.c_double), _p(order, C.c_int), C.byref(no))
     shape = (sh.value, sw.value)
     return sc.reshape(shape), mg.reshape(shape), an.reshape(shape), order[:no.value].copy()
+
+
+def lbd_compute(gray, keylines, want_float=False):
+    """BinaryDescriptor::compute for one octave -> (n, 32) u8 (and (n, 72) f32)."""
+    gray = np.ascontiguousarray(gray, np.uint8); H, W = gray.shape
+    kl = np.ascontiguousarray(keylines, KEYLINE_DTYPE); n = len(kl)
+    desc = np.zeros((n, 32), np.uint8); fd = np.zeros((n, 72), np.float32)
+    lib().orc_lbd_compute(_p(gray, C.c_uint8), W, H, kl.ctypes.data_as(C.c_void_p), n, _p(desc, C.c_uint8), _p(fd, C.c_float))
+    return (desc, fd) if want_float else desc
+
+
+def lbd_maps(gray):
+    gray = np.ascontiguousarray(gray, np.uint8); H, W = gray.shape
+    b = np.zeros((H, W), np.uint8); dx = np.zeros((H, W), np.int16); dy = np.zeros((H, W), np.int16)
+    lib().orc_lbd_maps(_p(gray, C.c_uint8), W, H, _p(b, C.c_uint8), _p(dx, C.c_int16), _p(dy, C.c_int16))
+    return b, dx, dy
