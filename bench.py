@@ -2,8 +2,8 @@
 """bench.py -- throughput of the hot path on N MI355X GPUs of one node (contract in the task statement).
 
 Workload at N=1 (BASELINE.json configs[1]): synthetic 640x480 frames with 3 boxes each, `--frames` frames resident in HBM per
-GPU; one step = one pass of the front-end over that batch: ORBextractor (1000 features, 8 levels, FAST 20/7) + detect_3d_cuboid
-with a 180-yaw x 3-VP proposal sweep (yaw step 0.5 deg over +-45 deg; Canny + distance transform + line merge + VP support +
+GPU; one step = one pass of the front-end over that batch: ORBextractor (1000 features, 8 levels, FAST 20/7) + LSD line
+detection with LBD descriptors (line_lbd defaults) + detect_3d_cuboid with a 180-yaw x 3-VP proposal sweep (yaw step 0.5 deg over +-45 deg; Canny + distance transform + line merge + VP support +
 sweep/score + selection).  N>1: every rank owns its own block of frames (no data-path collective, weak scaling).
 The second half of BASELINE's metric (BA iterations/s at 1k keyframes) is measured in the same run and reported under "ba".
 """
@@ -33,7 +33,7 @@ def make_frames(n_frames, n_boxes, seed0):
     return scenes
 
 
-def cpu_baseline(scenes, yaw_step, budget_s=12.0, with_orb=True, nfeat=1000):
+def cpu_baseline(scenes, yaw_step, budget_s=12.0, with_orb=True, nfeat=1000, with_lines=True):
     """Reference CPU path (the oracle restatement, single thread like the reference) on a bounded sample."""
     from oracle import pyoracle as po
     o = po.cuboid_opts(yaw_step_deg=yaw_step)
@@ -45,11 +45,13 @@ def cpu_baseline(scenes, yaw_step, budget_s=12.0, with_orb=True, nfeat=1000):
         s = scenes[n % len(scenes)]
         if ext is not None:
             ext(s["gray"])
+        if with_lines:
+            po.lbd_compute(s["gray"], po.lsd_detect(s["gray"]))
         po.detect_cuboid(s["gray"], s["K"], s["Twc"], s["boxes"], s["lines"], opts=o)
         n += 1
     dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "%d frames of the same workload in %.1f s, oracle/{orb,cuboid}_oracle.cpp, 1 thread" % (n, dt)}
+            "sample": "%d frames of the same workload in %.1f s, oracle/{orb,lsd,lbd,cuboid}_oracle.cpp, 1 thread" % (n, dt)}
 
 
 def ba_bench(ctx, rank, world, iters, with_cpu):
@@ -120,6 +122,7 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-ba", action="store_true")
     ap.add_argument("--no-orb", action="store_true")
+    ap.add_argument("--no-lines", action="store_true")
     ap.add_argument("--ba-iters", type=int, default=10)
     ap.add_argument("--orb-features", type=int, default=1000)
     args = ap.parse_args()
@@ -150,9 +153,17 @@ def main():
         orb = ORBextractor(args.orb_features, 1.2, 8, 20, 7, 640, 480, max_frames=args.frames, ctx=ctx)
         orb.upload(np.stack([s["gray"] for s in scenes]))
 
+    lsd = None
+    if not args.no_lines:
+        from cube_slam_amd.lsd import line_lbd_detect
+        lsd = line_lbd_detect(640, 480, max_frames=args.frames, ctx=ctx)
+        lsd.upload(np.stack([s["gray"] for s in scenes]))
+
     def step():
         if orb is not None:
             orb.run()
+        if lsd is not None:
+            lsd.run(with_lbd=True)
         batch.run()
 
     def barrier():
@@ -176,7 +187,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kernels = {}
-    for name in ("host_orb_quadtree", "host_omp_threads", "orb_resize", "orb_fast_score", "orb_cells", "orb_scan", "orb_blur", "orb_angle", "orb_desc", "cuboid_frame_prep", "cuboid_unit_lines", "cuboid_canny_nms", "cuboid_canny_cc", "cuboid_dt", "cuboid_vp",
+    for name in ("host_orb_quadtree", "host_omp_threads", "orb_resize", "orb_fast_score", "orb_cells", "orb_scan", "orb_blur", "orb_angle", "orb_desc", "host_lsd_regions", "lsd_blur_h", "lsd_blur_v", "lsd_resize", "lsd_gradient", "lbd_blur5", "lbd_sobel", "lbd_rows", "lbd_desc", "cuboid_frame_prep", "cuboid_unit_lines", "cuboid_canny_nms", "cuboid_canny_cc", "cuboid_dt", "cuboid_vp",
                  "cuboid_sweep_score", "cuboid_select"):
         ms, n = ctx.timing_get(name)
         kernels[name] = {"avg_us": 1e3 * ms / max(n, 1), "launches": n}
@@ -185,6 +196,7 @@ def main():
     got = batch.read()
     assert sum(len(g) for g in got) > 0
     n_kp = sum(len(k) for k, _ in orb.read()) if orb is not None else 0
+    n_lines = sum(len(lsd.read(f, with_desc=False)) for f in range(args.frames)) if lsd is not None else 0
     ba_out = None
     if not args.no_ba:
         ba_out = ba_bench(ctx, rank, world, args.ba_iters, with_cpu=(rank == 0 and world == 1 and not args.no_cpu))
@@ -197,12 +209,13 @@ def main():
         k_us = kernels["cuboid_sweep_score"]["avg_us"]
         achieved = alg_bytes / (k_us * 1e-6) / 1e9 if k_us > 0 else 0.0
         out = {
-            "metric": "frames/sec front-end (%scuboid: Canny+DT+sweep+score+select) @640x480" % ("ORB extract + " if orb is not None else ""),
+            "metric": "frames/sec front-end (%s%scuboid: Canny+DT+sweep+score+select) @640x480" % ("ORB extract + " if orb is not None else "", "LSD+LBD lines + " if lsd is not None else ""),
             "value": total_frames / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "detect_3d_cuboid: 640x480 frames x %d boxes, 180-yaw x 3-VP sweep (yaw step %.2f deg), "
-                                   "%d frames resident per GPU" % (args.boxes, args.yaw_step, args.frames),
+            "config": {"workload": "front-end per frame: ORB extract + LSD/LBD lines + detect_3d_cuboid: 640x480 frames x %d boxes, 180-yaw x 3-VP sweep "
+                                   "(yaw step %.2f deg), %d frames resident per GPU" % (args.boxes, args.yaw_step, args.frames),
+                       "lines": None if lsd is None else {"keylines_per_step": n_lines, "descriptor": "LBD 32 B"},
                        "orb": None if orb is None else {"nfeatures": args.orb_features, "levels": 8, "keypoints_per_step": n_kp},
                        "frames_per_gpu": args.frames, "boxes_per_frame": args.boxes,
                        "hypotheses_per_step": st["n_hypotheses"], "valid_proposals_per_step": st["n_valid"],
@@ -213,7 +226,7 @@ def main():
             "kernels_us": {k: round(v["avg_us"], 2) for k, v in kernels.items()},
         }
         if not args.no_cpu and world == 1:
-            out["cpu_baseline"] = cpu_baseline(scenes[:16], args.yaw_step, with_orb=orb is not None, nfeat=args.orb_features)
+            out["cpu_baseline"] = cpu_baseline(scenes[:16], args.yaw_step, with_orb=orb is not None, nfeat=args.orb_features, with_lines=lsd is not None)
             out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
         if ba_out is not None:
             out["ba"] = ba_out

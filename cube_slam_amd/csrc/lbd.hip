@@ -26,6 +26,7 @@ __global__ void __launch_bounds__(256) lbd_blur5(const uint8_t *gray, int W, int
     __shared__ uint8_t g[16 + 4][64 + 4];
     __shared__ int hp[16 + 4][64];
     const int tx0 = blockIdx.x * 64, ty0 = blockIdx.y * 16;
+    gray += (long)blockIdx.z * W * H; blur += (long)blockIdx.z * W * H;
     for (int i = threadIdx.x; i < 20 * 68; i += 256) { int ly = i / 68, lx = i % 68; g[ly][lx] = gray[(long)refl(ty0 + ly - 2, H) * W + refl(tx0 + lx - 2, W)]; }
     __syncthreads();
     for (int i = threadIdx.x; i < 20 * 64; i += 256) { int ly = i / 64, lx = i % 64, s = 0; for (int t = 0; t < 5; t++) s += g[ly][lx + t] * wts.k5[t]; hp[ly][lx] = s; }
@@ -43,6 +44,7 @@ __global__ void __launch_bounds__(256) lbd_blur5(const uint8_t *gray, int W, int
 __global__ void __launch_bounds__(256) lbd_sobel(const uint8_t *blur, int W, int H, short *dx, short *dy) {
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
     if (x >= W) return;
+    blur += (long)blockIdx.z * W * H; dx += (long)blockIdx.z * W * H; dy += (long)blockIdx.z * W * H;
     auto P = [&](int xx, int yy) { return (int)blur[(long)refl(yy, H) * W + refl(xx, W)]; };
     dx[(long)y * W + x] = (short)((P(x + 1, y - 1) + 2 * P(x + 1, y) + P(x + 1, y + 1)) - (P(x - 1, y - 1) + 2 * P(x - 1, y) + P(x - 1, y + 1)));
     dy[(long)y * W + x] = (short)((P(x - 1, y + 1) + 2 * P(x, y + 1) + P(x + 1, y + 1)) - (P(x - 1, y - 1) + 2 * P(x, y - 1) + P(x + 1, y - 1)));
@@ -63,10 +65,11 @@ __device__ __forceinline__ void sincos_fd(float angle, float &so, float &co) { /
 }
 
 // block = one line (64 threads: lane = support-region row hID); rowsums: [line][hID][4] = pgdL, ngdL, pgdO, ngdO (unweighted)
-__global__ void __launch_bounds__(64) lbd_rows(const cs_keyline *kls, const short *dxImg, const short *dyImg, int W, int H, float *rowsums) {
+__global__ void __launch_bounds__(64) lbd_rows(const cs_keyline *kls, const int *line_frame, const short *dxImg, const short *dyImg, int W, int H, float *rowsums) {
     const int li = blockIdx.x, hID = threadIdx.x;
     if (hID >= HLSP) return;
     const cs_keyline L = kls[li];
+    if (line_frame) { const long o = (long)line_frame[li] * W * H; dxImg += o; dyImg += o; }
     const short realWidth = (short)W, imageWidth = realWidth - 1, imageHeight = (short)(H - 1);
     const short lengthOfLSP = (short)L.numOfPixels, halfWidth = (lengthOfLSP - 1) / 2, halfHeight = (HLSP - 1) / 2;
     const float mx = (float)(0.5 * (L.sPointInOctaveX + L.ePointInOctaveX)), my = (float)(0.5 * (L.sPointInOctaveY + L.ePointInOctaveY));
@@ -155,18 +158,34 @@ static LbdW make_weights() { // BinaryDescriptor constructor :218-260 (integer d
     return w;
 }
 
+} // namespace
+
+// batched entry points shared with lsd.hip (frames resident in HBM)
+int cs_lbd_batch_maps(cs_ctx *ctx, const uint8_t *d_gray, int W, int H, int F, uint8_t *d_blur, short *d_dx, short *d_dy) {
+    const LbdW w = make_weights();
+    CS_LAUNCH(ctx, "lbd_blur5", lbd_blur5, dim3((W + 63) / 64, (H + 15) / 16, F), dim3(256), 0, d_gray, W, H, w, d_blur);
+    CS_LAUNCH(ctx, "lbd_sobel", lbd_sobel, dim3((W + 255) / 256, H, F), dim3(256), 0, d_blur, W, H, d_dx, d_dy);
+    return CS_OK;
+}
+int cs_lbd_batch_desc(cs_ctx *ctx, const cs_keyline *d_kl, const int *d_line_frame, int n, const short *d_dx, const short *d_dy, int W, int H, float *d_rows, uint8_t *d_desc, float *d_f) {
+    if (n <= 0) return CS_OK;
+    const LbdW w = make_weights();
+    CS_LAUNCH(ctx, "lbd_rows", lbd_rows, dim3(n), dim3(64), 0, d_kl, d_line_frame, d_dx, d_dy, W, H, d_rows);
+    CS_LAUNCH(ctx, "lbd_desc", lbd_desc, dim3((n + 63) / 64), dim3(64), 0, n, d_rows, w, d_desc, d_f);
+    return CS_OK;
+}
+
+namespace {
 struct Bufs { uint8_t *gray = nullptr, *blur = nullptr; short *dx = nullptr, *dy = nullptr; };
 static void free_bufs(Bufs &b) { if (b.gray) hipFree(b.gray); if (b.blur) hipFree(b.blur); if (b.dx) hipFree(b.dx); if (b.dy) hipFree(b.dy); b = Bufs(); }
-static int run_maps(cs_ctx *ctx, const uint8_t *gray, int W, int H, int stride, const LbdW &w, Bufs &b) {
+static int run_maps(cs_ctx *ctx, const uint8_t *gray, int W, int H, int stride, Bufs &b) {
     const size_t N = (size_t)W * H;
     int r = cs_dalloc(ctx, &b.gray, N); if (r) return r;
     r = cs_dalloc(ctx, &b.blur, N); if (r) return r;
     r = cs_dalloc(ctx, &b.dx, N); if (r) return r;
     r = cs_dalloc(ctx, &b.dy, N); if (r) return r;
     CS_HIP(ctx, hipMemcpy2DAsync(b.gray, (size_t)W, gray, (size_t)stride, (size_t)W, (size_t)H, hipMemcpyHostToDevice, ctx->stream));
-    CS_LAUNCH(ctx, "lbd_blur5", lbd_blur5, dim3((W + 63) / 64, (H + 15) / 16), dim3(256), 0, b.gray, W, H, w, b.blur);
-    CS_LAUNCH(ctx, "lbd_sobel", lbd_sobel, dim3((W + 255) / 256, H), dim3(256), 0, b.blur, W, H, b.dx, b.dy);
-    return CS_OK;
+    return cs_lbd_batch_maps(ctx, b.gray, W, H, 1, b.blur, b.dx, b.dy);
 }
 } // namespace
 
@@ -176,8 +195,7 @@ int cs_lbd_maps(cs_ctx *ctx, const uint8_t *gray, int width, int height, int str
     if (!ctx || !gray || width < 8 || height < 8 || stride < width) return CS_ERR_BAD_ARG;
     CS_HIP(ctx, hipSetDevice(ctx->device));
     Bufs b;
-    const LbdW w = make_weights();
-    int r = run_maps(ctx, gray, width, height, stride, w, b);
+    int r = run_maps(ctx, gray, width, height, stride, b);
     const size_t N = (size_t)width * height;
     if (!r && blur) r = cs_d2h(ctx, blur, b.blur, N);
     if (!r && dx) r = cs_d2h(ctx, (short *)dx, b.dx, N);
@@ -193,8 +211,7 @@ int cs_lbd_compute(cs_ctx *ctx, const uint8_t *gray, int width, int height, int 
     for (int i = 0; i < n; i++) if (keylines[i].numOfPixels < 0 || keylines[i].numOfPixels > 32767) return CS_ERR_BAD_ARG;
     CS_HIP(ctx, hipSetDevice(ctx->device));
     Bufs b;
-    const LbdW w = make_weights();
-    int r = run_maps(ctx, gray, width, height, stride, w, b);
+    int r = run_maps(ctx, gray, width, height, stride, b);
     cs_keyline *d_kl = nullptr; float *d_rows = nullptr, *d_f = nullptr; uint8_t *d_desc = nullptr;
     if (!r) r = cs_dalloc(ctx, &d_kl, (size_t)n);
     if (!r) r = cs_dalloc(ctx, &d_rows, (size_t)n * HLSP * 4);
@@ -202,9 +219,8 @@ int cs_lbd_compute(cs_ctx *ctx, const uint8_t *gray, int width, int height, int 
     if (!r && float_desc) r = cs_dalloc(ctx, &d_f, (size_t)n * 72);
     if (!r) r = cs_h2d(ctx, d_kl, keylines, (size_t)n);
     if (!r) {
-        CS_LAUNCH(ctx, "lbd_rows", lbd_rows, dim3(n), dim3(64), 0, d_kl, b.dx, b.dy, width, height, d_rows);
-        CS_LAUNCH(ctx, "lbd_desc", lbd_desc, dim3((n + 63) / 64), dim3(64), 0, n, d_rows, w, d_desc, d_f);
-        r = cs_d2h(ctx, desc, d_desc, (size_t)n * 32);
+        r = cs_lbd_batch_desc(ctx, d_kl, nullptr, n, b.dx, b.dy, width, height, d_rows, d_desc, d_f);
+        if (!r) r = cs_d2h(ctx, desc, d_desc, (size_t)n * 32);
         if (!r && float_desc) r = cs_d2h(ctx, float_desc, d_f, (size_t)n * 72);
     }
     hipError_t e = hipStreamSynchronize(ctx->stream);

@@ -340,25 +340,60 @@ struct cs_lsd {
     double threshold = 0;
     uint8_t *d_gray = nullptr; double *d_tmp = nullptr, *d_blur = nullptr, *d_scaled = nullptr, *d_mod = nullptr, *d_ang = nullptr;
     int *d_xofs = nullptr, *d_yofs = nullptr; float *d_ax = nullptr, *d_ay = nullptr;
-    std::vector<double> h_mod, h_ang;
+    double *h_mod = nullptr, *h_ang = nullptr; // pinned
     std::vector<std::vector<cs_keyline>> keylines;
+    // LBD descriptors of the detected lines (optional second half of cs_lsd_run)
+    uint8_t *d_lblur = nullptr; short *d_dx = nullptr, *d_dy = nullptr;
+    cs_keyline *d_kl = nullptr; int *d_line_frame = nullptr; float *d_rows = nullptr; uint8_t *d_desc = nullptr;
+    size_t line_cap = 0;
+    std::vector<int> line_off;       // per frame offset into the concatenated line list
+    std::vector<uint8_t> h_desc;     // concatenated n x 32
+    bool have_desc = false;
 };
 
-static int lsd_run(cs_ctx *ctx, cs_lsd *l, const uint8_t *gray, int n_frames, int stride) {
+int cs_lbd_batch_maps(cs_ctx *ctx, const uint8_t *d_gray, int W, int H, int F, uint8_t *d_blur, short *d_dx, short *d_dy);
+int cs_lbd_batch_desc(cs_ctx *ctx, const cs_keyline *d_kl, const int *d_line_frame, int n, const short *d_dx, const short *d_dy, int W, int H, float *d_rows, uint8_t *d_desc, float *d_f);
+
+static void lsd_free_lines(cs_lsd *l) {
+    void *ptrs[] = {l->d_kl, l->d_line_frame, l->d_rows, l->d_desc};
+    for (void *p : ptrs) if (p) hipFree(p);
+    l->d_kl = nullptr; l->d_line_frame = nullptr; l->d_rows = nullptr; l->d_desc = nullptr; l->line_cap = 0;
+}
+
+static int lsd_upload(cs_ctx *ctx, cs_lsd *l, const uint8_t *gray, int n_frames, int stride) {
     if (!ctx || !l || !gray || n_frames < 1 || n_frames > l->max_frames || stride < l->W) return CS_ERR_BAD_ARG;
     CS_HIP(ctx, hipSetDevice(ctx->device));
-    const int W = l->W, H = l->H, w = l->w, h = l->h, F = n_frames;
-    l->n_frames = F;
-    CS_HIP(ctx, hipMemcpy2DAsync(l->d_gray, (size_t)W, gray, (size_t)stride, (size_t)W, (size_t)H * F, hipMemcpyHostToDevice, ctx->stream));
+    l->n_frames = n_frames; l->have_desc = false;
+    for (int f = 0; f < n_frames; f++) // every frame is `height` rows of `stride` bytes
+        CS_HIP(ctx, hipMemcpy2DAsync(l->d_gray + (size_t)f * l->W * l->H, (size_t)l->W, gray + (size_t)f * stride * l->H, (size_t)stride, (size_t)l->W, (size_t)l->H, hipMemcpyHostToDevice, ctx->stream));
+    return CS_OK;
+}
+
+static int lsd_run(cs_ctx *ctx, cs_lsd *l, int with_lbd) {
+    if (!ctx || !l || l->n_frames < 1) return CS_ERR_BAD_ARG;
+    CS_HIP(ctx, hipSetDevice(ctx->device));
+    const int W = l->W, H = l->H, w = l->w, h = l->h, F = l->n_frames;
+    l->have_desc = false;
     CS_LAUNCH(ctx, "lsd_blur_h", lsd_blur_h, dim3((W + 255) / 256, H, F), dim3(256), 0, l->d_gray, W, H, l->gk, l->d_tmp);
     CS_LAUNCH(ctx, "lsd_blur_v", lsd_blur_v, dim3((W + 255) / 256, H, F), dim3(256), 0, l->d_tmp, W, H, l->gk, l->d_blur);
     CS_LAUNCH(ctx, "lsd_resize", lsd_resize, dim3((w + 255) / 256, h, F), dim3(256), 0, l->d_blur, W, H, w, h, l->d_xofs, l->d_ax, l->d_yofs, l->d_ay, l->d_scaled);
     CS_LAUNCH(ctx, "lsd_gradient", lsd_gradient, dim3((w + 255) / 256, h, F), dim3(256), 0, l->d_scaled, w, h, l->threshold, l->d_mod, l->d_ang);
     const size_t n = (size_t)w * h;
-    l->h_mod.resize(n * F); l->h_ang.resize(n * F);
-    int r = cs_d2h(ctx, l->h_mod.data(), l->d_mod, n * F); if (r) return r;
-    r = cs_d2h(ctx, l->h_ang.data(), l->d_ang, n * F); if (r) return r;
-    CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    int r = cs_d2h(ctx, l->h_mod, l->d_mod, n * F); if (r) return r;
+    r = cs_d2h(ctx, l->h_ang, l->d_ang, n * F); if (r) return r;
+    hipEvent_t ev = ctx->get_event();
+    CS_HIP(ctx, hipEventRecord(ev, ctx->stream));
+    if (with_lbd) { // the derivative maps only depend on the gray frames: they run while the host grows regions
+        if (!l->d_lblur) {
+            const size_t N = (size_t)W * H * l->max_frames;
+            r = cs_dalloc(ctx, &l->d_lblur, N); if (r) return r;
+            r = cs_dalloc(ctx, &l->d_dx, N); if (r) return r;
+            r = cs_dalloc(ctx, &l->d_dy, N); if (r) return r;
+        }
+        r = cs_lbd_batch_maps(ctx, l->d_gray, W, H, F, l->d_lblur, l->d_dx, l->d_dy); if (r) return r;
+    }
+    CS_HIP(ctx, hipEventSynchronize(ev));
+    ctx->pool.push_back(ev);
     const auto t0 = std::chrono::steady_clock::now();
     l->keylines.assign((size_t)F, {});
 #pragma omp parallel num_threads(std::min(omp_get_max_threads(), std::max(1, std::min(64, F))))
@@ -367,11 +402,39 @@ static int lsd_run(cs_ctx *ctx, cs_lsd *l, const uint8_t *gray, int n_frames, in
         std::vector<float> lines;
 #pragma omp for schedule(dynamic, 1)
         for (int f = 0; f < F; f++) {
-            host.run(w, h, l->h_ang.data() + n * f, l->h_mod.data() + n * f, lines);
+            host.run(w, h, l->h_ang + n * f, l->h_mod + n * f, lines);
             to_keylines(lines, W, H, l->keylines[f]);
         }
     }
     if (ctx->timing) { auto &rec = ctx->timings["host_lsd_regions"]; rec.total_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); rec.count++; }
+    l->line_off.assign((size_t)F + 1, 0);
+    for (int f = 0; f < F; f++) l->line_off[f + 1] = l->line_off[f] + (int)l->keylines[f].size();
+    if (with_lbd) {
+        const int nl = l->line_off[F];
+        l->h_desc.assign((size_t)nl * 32, 0);
+        if (nl > 0) {
+            if ((size_t)nl > l->line_cap) {
+                lsd_free_lines(l);
+                const size_t cap = (size_t)nl + nl / 4 + 256;
+                r = cs_dalloc(ctx, &l->d_kl, cap); if (r) return r;
+                r = cs_dalloc(ctx, &l->d_line_frame, cap); if (r) return r;
+                r = cs_dalloc(ctx, &l->d_rows, cap * 63 * 4); if (r) return r;
+                r = cs_dalloc(ctx, &l->d_desc, cap * 32); if (r) return r;
+                l->line_cap = cap;
+            }
+            std::vector<int> lf((size_t)nl);
+            for (int f = 0; f < F; f++) {
+                r = cs_h2d(ctx, l->d_kl + l->line_off[f], l->keylines[f].data(), l->keylines[f].size()); if (r) return r;
+                for (int i = l->line_off[f]; i < l->line_off[f + 1]; i++) lf[i] = f;
+            }
+            r = cs_h2d(ctx, l->d_line_frame, lf.data(), (size_t)nl); if (r) return r;
+            CS_HIP(ctx, hipStreamSynchronize(ctx->stream)); // lf is a local
+            r = cs_lbd_batch_desc(ctx, l->d_kl, l->d_line_frame, nl, l->d_dx, l->d_dy, W, H, l->d_rows, l->d_desc, nullptr); if (r) return r;
+            r = cs_d2h(ctx, l->h_desc.data(), l->d_desc, (size_t)nl * 32); if (r) return r;
+        }
+        CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        l->have_desc = true;
+    }
     return CS_OK;
 }
 
@@ -380,8 +443,11 @@ extern "C" {
 void cs_lsd_destroy(cs_ctx *ctx, cs_lsd *l) {
     if (!l) return;
     if (ctx) { hipSetDevice(ctx->device); hipStreamSynchronize(ctx->stream); }
-    void *ptrs[] = {l->d_gray, l->d_tmp, l->d_blur, l->d_scaled, l->d_mod, l->d_ang, l->d_xofs, l->d_yofs, l->d_ax, l->d_ay};
+    void *ptrs[] = {l->d_gray, l->d_tmp, l->d_blur, l->d_scaled, l->d_mod, l->d_ang, l->d_xofs, l->d_yofs, l->d_ax, l->d_ay, l->d_lblur, l->d_dx, l->d_dy};
     for (void *p : ptrs) if (p) hipFree(p);
+    lsd_free_lines(l);
+    if (l->h_mod) hipHostFree(l->h_mod);
+    if (l->h_ang) hipHostFree(l->h_ang);
     delete l;
 }
 
@@ -408,6 +474,7 @@ int cs_lsd_create(cs_ctx *ctx, int width, int height, int max_frames, cs_lsd **o
     A_(cs_dalloc(ctx, &l->d_gray, N)); A_(cs_dalloc(ctx, &l->d_tmp, N)); A_(cs_dalloc(ctx, &l->d_blur, N));
     A_(cs_dalloc(ctx, &l->d_scaled, n)); A_(cs_dalloc(ctx, &l->d_mod, n)); A_(cs_dalloc(ctx, &l->d_ang, n));
     A_(cs_dalloc(ctx, &l->d_xofs, xofs.size())); A_(cs_dalloc(ctx, &l->d_yofs, yofs.size())); A_(cs_dalloc(ctx, &l->d_ax, ax.size())); A_(cs_dalloc(ctx, &l->d_ay, ay.size()));
+    if (hipHostMalloc((void **)&l->h_mod, n * sizeof(double), hipHostMallocDefault) != hipSuccess || hipHostMalloc((void **)&l->h_ang, n * sizeof(double), hipHostMallocDefault) != hipSuccess) { cs_lsd_destroy(ctx, l); return CS_ERR_NOMEM; }
     A_(cs_h2d(ctx, l->d_xofs, xofs.data(), xofs.size())); A_(cs_h2d(ctx, l->d_yofs, yofs.data(), yofs.size()));
     A_(cs_h2d(ctx, l->d_ax, ax.data(), ax.size())); A_(cs_h2d(ctx, l->d_ay, ay.data(), ay.size()));
 #undef A_
@@ -418,7 +485,8 @@ int cs_lsd_create(cs_ctx *ctx, int width, int height, int max_frames, cs_lsd **o
 
 int cs_lsd_detect(cs_ctx *ctx, cs_lsd *l, const uint8_t *gray, int n_frames, int stride, cs_keyline *out, int cap, int *counts) {
     if (!out || !counts || cap < 1) return CS_ERR_BAD_ARG;
-    int r = lsd_run(ctx, l, gray, n_frames, stride); if (r) return r;
+    int r = lsd_upload(ctx, l, gray, n_frames, stride); if (r) return r;
+    r = lsd_run(ctx, l, 0); if (r) return r;
     int status = CS_OK;
     for (int f = 0; f < n_frames; f++) {
         const int n = (int)l->keylines[f].size();
@@ -431,7 +499,8 @@ int cs_lsd_detect(cs_ctx *ctx, cs_lsd *l, const uint8_t *gray, int n_frames, int
 
 int cs_lsd_detect_filter_lines(cs_ctx *ctx, cs_lsd *l, const uint8_t *gray, int n_frames, int stride, float length_thres, float *lines, int cap, int *counts) {
     if (!lines || !counts || cap < 1) return CS_ERR_BAD_ARG;
-    int r = lsd_run(ctx, l, gray, n_frames, stride); if (r) return r;
+    int r = lsd_upload(ctx, l, gray, n_frames, stride); if (r) return r;
+    r = lsd_run(ctx, l, 0); if (r) return r;
     int status = CS_OK;
     for (int f = 0; f < n_frames; f++) { // filter_lines :200-207 + keylines_to_mat :26-36
         int n = 0;
@@ -444,6 +513,25 @@ int cs_lsd_detect_filter_lines(cs_ctx *ctx, cs_lsd *l, const uint8_t *gray, int 
         if (n > cap) status = CS_ERR_CAPACITY;
     }
     return status;
+}
+
+int cs_lsd_upload(cs_ctx *ctx, cs_lsd *l, const uint8_t *gray, int n_frames, int stride) {
+    int r = lsd_upload(ctx, l, gray, n_frames, stride); if (r) return r;
+    CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CS_OK;
+}
+
+int cs_lsd_run(cs_ctx *ctx, cs_lsd *l, int with_lbd) { return lsd_run(ctx, l, with_lbd); }
+
+int cs_lsd_read(cs_ctx *ctx, cs_lsd *l, int frame, cs_keyline *out, int cap, int *count, uint8_t *desc) {
+    if (!ctx || !l || frame < 0 || frame >= l->n_frames || !count || (int)l->keylines.size() <= frame || (desc && !l->have_desc)) return CS_ERR_BAD_ARG;
+    const int n = (int)l->keylines[frame].size();
+    *count = n;
+    if (!out) return CS_OK; // size query
+    if (n > cap) return CS_ERR_CAPACITY;
+    memcpy(out, l->keylines[frame].data(), sizeof(cs_keyline) * (size_t)n);
+    if (desc) memcpy(desc, l->h_desc.data() + (size_t)l->line_off[frame] * 32, (size_t)n * 32);
+    return CS_OK;
 }
 
 int cs_lsd_get_maps(cs_ctx *ctx, cs_lsd *l, int frame, double *scaled, double *modgrad, double *angles, int *sw, int *sh) {

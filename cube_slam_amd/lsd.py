@@ -35,6 +35,23 @@ class line_lbd_detect:
         assert g.shape[1:] == (self.H, self.W) and len(g) <= self.max_frames
         return g
 
+    # ---- resident-batch form (bench.py): upload once, run many times
+    def upload(self, gray):
+        g = self._imgs(gray)
+        self._n = len(g)
+        check(self.ctx.ptr, lib().cs_lsd_upload(self.ctx.ptr, self._l, _p(g, C.c_uint8), len(g), self.W), "cs_lsd_upload")
+
+    def run(self, with_lbd=True):
+        check(self.ctx.ptr, lib().cs_lsd_run(self.ctx.ptr, self._l, int(with_lbd)), "cs_lsd_run")
+
+    def read(self, frame, with_desc=True):
+        n = C.c_int()
+        check(self.ctx.ptr, lib().cs_lsd_read(self.ctx.ptr, self._l, frame, None, 0, C.byref(n), None), "cs_lsd_read")
+        kl = np.zeros(n.value, KEYLINE_DTYPE); desc = np.zeros((n.value, 32), np.uint8)
+        check(self.ctx.ptr, lib().cs_lsd_read(self.ctx.ptr, self._l, frame, kl.ctypes.data_as(C.c_void_p), n.value, C.byref(n),
+                                              _p(desc, C.c_uint8) if with_desc else None), "cs_lsd_read")
+        return (kl, desc) if with_desc else kl
+
     def detect_raw_lines(self, gray):
         g = self._imgs(gray)
         out = np.zeros((len(g), self.cap), KEYLINE_DTYPE); counts = np.zeros(len(g), np.int32)

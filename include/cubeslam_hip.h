@@ -279,6 +279,13 @@ int cs_lsd_detect_filter_lines(cs_ctx *ctx, cs_lsd *l, const uint8_t *gray, int 
 /* introspection after a detect call: scaled image, gradient norm and level-line angle maps (sw x sh doubles each) */
 int cs_lsd_get_maps(cs_ctx *ctx, cs_lsd *l, int frame, double *scaled, double *modgrad, double *angles, int *sw, int *sh);
 
+/* Resident-batch form of the line front-end (what bench.py times): frames stay in HBM; cs_lsd_run detects the KeyLines of every
+ * uploaded frame and, with_lbd != 0, their LBD descriptors (= line_lbd_detect::detect_descrip_lines before its length filter,
+ * class/line_lbd_allclass.cpp:222-256); cs_lsd_read returns one frame's lines (out == NULL: count only) and descriptors. */
+int cs_lsd_upload(cs_ctx *ctx, cs_lsd *l, const uint8_t *gray, int n_frames, int stride);
+int cs_lsd_run(cs_ctx *ctx, cs_lsd *l, int with_lbd);
+int cs_lsd_read(cs_ctx *ctx, cs_lsd *l, int frame, cs_keyline *out, int cap, int *count, uint8_t *desc /* cap x 32 or NULL */);
+
 /* ===================================================================== LBD line descriptor + matcher
  * Replaces BinaryDescriptor::compute (line_lbd/libs/binary_descriptor.cpp:588-790,1146-1509; what
  * line_lbd_detect::get_line_descriptors / detect_descrip_lines call, class/line_lbd_allclass.cpp:192-269) for one octave, and

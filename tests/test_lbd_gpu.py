@@ -64,3 +64,17 @@ def test_match_line_descrip(ctx, oracle):
     assert len(qi) > 5
     assert len(det.match_line_descrip(da, db[:0])[0]) == 0
     det.close()
+
+
+def test_resident_batch_lines_and_descriptors(ctx, oracle):
+    imgs = _images()
+    det = line_lbd_detect(640, 480, max_frames=3, ctx=ctx)
+    det.upload(np.stack(imgs))
+    det.run(with_lbd=True)
+    det.run(with_lbd=True)  # re-running on the resident frames gives the same answer
+    for f, img in enumerate(imgs):
+        kl, desc = det.read(f)
+        ref = oracle.lsd_detect(img)
+        assert kl.tobytes() == ref.tobytes()
+        assert np.array_equal(desc, oracle.lbd_compute(img, ref))
+    det.close()
