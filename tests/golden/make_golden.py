@@ -64,7 +64,19 @@ def orb_cabinet():
     print("orb_cabinet:", len(k), "keypoints")
 
 
+def lines_cabinet():
+    """LSD KeyLines + LBD descriptors of the cabinet fixture (gray array already decoded in orb_cabinet.npz)."""
+    import hashlib
+    gray = np.load(os.path.join(HERE, "orb_cabinet.npz"))["gray"]
+    kl = po.lsd_detect(gray)
+    desc = po.lbd_compute(gray, kl)
+    np.savez_compressed(os.path.join(HERE, "lines_cabinet.npz"), n_lines=len(kl), keylines_sha256=hashlib.sha256(kl.tobytes()).hexdigest(),
+                        desc=desc, filter15=po.lsd_detect_filter_lines(gray, 15.0), keylines_head=kl[:16])
+    print("lines_cabinet:", len(kl), "lines")
+
+
 if __name__ == "__main__":
     cuboid_ref()
     cuboid_synth()
     orb_cabinet()
+    lines_cabinet()
