@@ -187,7 +187,7 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kernels = {}
-    for name in ("host_orb_quadtree", "host_omp_threads", "orb_resize", "orb_fast_score", "orb_cells", "orb_scan", "orb_blur", "orb_angle", "orb_desc", "host_lsd_regions", "lsd_blur_h", "lsd_blur_v", "lsd_resize", "lsd_gradient", "lbd_blur5", "lbd_sobel", "lbd_rows", "lbd_desc", "cuboid_frame_prep", "cuboid_unit_lines", "cuboid_canny_nms", "cuboid_canny_cc", "cuboid_dt", "cuboid_vp",
+    for name in ("host_orb_quadtree", "orb_resize", "orb_fast_score", "orb_cells", "orb_scan", "orb_blur", "orb_angle", "orb_desc", "host_lsd_regions", "lsd_blur_h", "lsd_blur_v", "lsd_resize", "lsd_gradient", "lbd_blur5", "lbd_sobel", "lbd_rows", "lbd_desc", "cuboid_frame_prep", "cuboid_unit_lines", "cuboid_canny_nms", "cuboid_canny_cc", "cuboid_dt", "cuboid_vp",
                  "cuboid_sweep_score", "cuboid_select"):
         ms, n = ctx.timing_get(name)
         kernels[name] = {"avg_us": 1e3 * ms / max(n, 1), "launches": n}
@@ -224,10 +224,11 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_kernel_us": k_us,
                          "algorithmic_bytes_per_launch": alg_bytes},
             "kernels_us": {k: round(v["avg_us"], 2) for k, v in kernels.items()},
+            "host_threads": _lib.lib().cs_host_thread_count(),
         }
         if not args.no_cpu and world == 1:
             out["cpu_baseline"] = cpu_baseline(scenes[:16], args.yaw_step, with_orb=orb is not None, nfeat=args.orb_features, with_lines=lsd is not None)
-            out["cpu_baseline"]["host_cores_available"] = os.cpu_count()
+            out["cpu_baseline"]["host_cores_available"] = _lib.lib().cs_host_thread_count()
         if ba_out is not None:
             out["ba"] = ba_out
         print(json.dumps(out))

@@ -15,11 +15,14 @@ struct cs_timing_rec {
     long count = 0;
 };
 
+int cs_host_threads(); // ctx.hip
+
 struct cs_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     std::string err;
     bool timing = false;
+    int host_threads = 1; // CPUs this process may really use (affinity mask and cgroup CPU quota), see cs_host_threads()
     std::map<std::string, cs_timing_rec> timings;
     struct pending_ev { std::string name; hipEvent_t a, b; };
     std::vector<pending_ev> pending;

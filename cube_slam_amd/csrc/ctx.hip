@@ -1,7 +1,38 @@
 // ctx.hip -- context lifecycle + timing queries of the C-ABI (include/cubeslam_hip.h)
 #include "common.h"
 
+#include <sched.h>
+
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+
+// CPUs the host stages (ORB quadtree, LSD region growing) may use: the affinity mask, capped by the cgroup CPU quota
+// (v2 cpu.max, v1 cpu.cfs_quota_us / cpu.cfs_period_us) -- running more threads than the quota only gets them throttled --
+// and overridable with CUBESLAM_HOST_THREADS.
+int cs_host_threads() {
+    if (const char *e = getenv("CUBESLAM_HOST_THREADS")) { int v = atoi(e); if (v > 0) return v; }
+    int n = 1;
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof(set), &set) == 0) n = CPU_COUNT(&set);
+    double quota = -1, period = 100000;
+    if (FILE *f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char q[64] = {0};
+        if (fscanf(f, "%63s %lf", q, &period) == 2 && q[0] != 'm') quota = atof(q);
+        fclose(f);
+    } else {
+        double qv = -1, pv = -1;
+        if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_quota_us", "r")) { if (fscanf(g, "%lf", &qv) != 1) qv = -1; fclose(g); }
+        if (FILE *g = fopen("/sys/fs/cgroup/cpu/cpu.cfs_period_us", "r")) { if (fscanf(g, "%lf", &pv) != 1) pv = -1; fclose(g); }
+        if (qv > 0 && pv > 0) { quota = qv; period = pv; }
+    }
+    if (quota > 0 && period > 0) n = std::min(n, std::max(1, (int)std::floor(quota / period)));
+    return std::max(1, n);
+}
+
 extern "C" {
+
+int cs_host_thread_count(void) { return cs_host_threads(); }
 
 int cs_version(void) { return CS_VERSION; }
 
@@ -15,6 +46,7 @@ int cs_create(int device_id, cs_ctx **out) {
     cs_ctx *c = new (std::nothrow) cs_ctx();
     if (!c) return CS_ERR_NOMEM;
     c->device = device_id;
+    c->host_threads = cs_host_threads();
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return CS_ERR_NO_DEVICE; }
     *out = c;
     return CS_OK;

@@ -396,7 +396,7 @@ static int lsd_run(cs_ctx *ctx, cs_lsd *l, int with_lbd) {
     ctx->pool.push_back(ev);
     const auto t0 = std::chrono::steady_clock::now();
     l->keylines.assign((size_t)F, {});
-#pragma omp parallel num_threads(std::min(omp_get_max_threads(), std::max(1, std::min(64, F))))
+#pragma omp parallel num_threads(std::max(1, std::min(ctx->host_threads, F)))
     {
         LsdHost host;
         std::vector<float> lines;

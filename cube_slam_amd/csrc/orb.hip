@@ -551,7 +551,7 @@ int cs_orb_run(cs_ctx *ctx, cs_orb *e) {
     e->frame_first.assign((size_t)F + 1, 0);
     {
         std::vector<std::vector<SelKP>> per((size_t)F * NL);
-#pragma omp parallel num_threads(std::min(omp_get_max_threads(), std::max(1, std::min(64, F * NL / 4))))
+#pragma omp parallel num_threads(std::max(1, std::min(ctx->host_threads, F * NL / 4)))
         {
             cs_orb_host::QuadTree qt;
             std::vector<int> idx;
@@ -579,7 +579,7 @@ int cs_orb_run(cs_ctx *ctx, cs_orb *e) {
         auto &rec = ctx->timings["host_orb_quadtree"];
         rec.total_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_host0).count();
         rec.count++;
-        ctx->timings["host_omp_threads"].total_ms = omp_get_max_threads();
+        ctx->timings["host_omp_threads"].total_ms = ctx->host_threads;
         ctx->timings["host_omp_threads"].count = 1;
     }
     if (n > e->sel_cap) { ctx->err = "ORB keypoint capacity exceeded"; return CS_ERR_CAPACITY; }

@@ -37,6 +37,8 @@ const char *cs_last_error(const cs_ctx *ctx);
 int cs_version(void);
 /* Blocks until all work queued on the context's stream is done. */
 int cs_sync(cs_ctx *ctx);
+/* CPU threads the host stages use (affinity mask capped by the cgroup CPU quota; env CUBESLAM_HOST_THREADS overrides) */
+int cs_host_thread_count(void);
 
 /* Per-kernel hipEvent timing on the context's stream (replaces ca::Profiler::tictoc,
  * dependency/tictoc_profiler/src/profiler.cpp:40-67).  Disabled by default. */
