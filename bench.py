@@ -156,18 +156,26 @@ def main():
     lsd = None
     if not args.no_lines:
         from cube_slam_amd.lsd import line_lbd_detect
-        lsd = line_lbd_detect(640, 480, max_frames=args.frames, ctx=ctx)
+        # the line path has its own context (= HIP stream) and host thread: its host stage (region growing) overlaps the ORB and
+        # cuboid kernels of the same step
+        ctx_lines = _lib.Context(local_rank)
+        lsd = line_lbd_detect(640, 480, max_frames=args.frames, ctx=ctx_lines)
         lsd.upload(np.stack([s["gray"] for s in scenes]))
+        from concurrent.futures import ThreadPoolExecutor
+        pool = ThreadPoolExecutor(1)
 
     def step():
+        fut = pool.submit(lsd.run, True) if lsd is not None else None
         if orb is not None:
             orb.run()
-        if lsd is not None:
-            lsd.run(with_lbd=True)
         batch.run()
+        if fut is not None:
+            fut.result()
 
     def barrier():
         ctx.sync()
+        if lsd is not None:
+            ctx_lines.sync()
         torch.cuda.synchronize()
         if world > 1:
             dist.barrier()
@@ -175,8 +183,9 @@ def main():
     for _ in range(args.warmup):
         step()
     barrier()
-    ctx.timing(True)
-    ctx.timing_reset()
+    for c in ([ctx, ctx_lines] if lsd is not None else [ctx]):
+        c.timing(True)
+        c.timing_reset()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         step()
@@ -190,8 +199,12 @@ def main():
     for name in ("host_orb_quadtree", "orb_resize", "orb_fast_score", "orb_cells", "orb_scan", "orb_blur", "orb_angle", "orb_desc", "host_lsd_regions", "lsd_blur_h", "lsd_blur_v", "lsd_resize", "lsd_gradient", "lbd_blur5", "lbd_sobel", "lbd_rows", "lbd_desc", "cuboid_frame_prep", "cuboid_unit_lines", "cuboid_canny_nms", "cuboid_canny_cc", "cuboid_dt", "cuboid_vp",
                  "cuboid_sweep_score", "cuboid_select"):
         ms, n = ctx.timing_get(name)
+        if n == 0 and lsd is not None:
+            ms, n = ctx_lines.timing_get(name)
         kernels[name] = {"avg_us": 1e3 * ms / max(n, 1), "launches": n}
     ctx.timing(False)
+    if lsd is not None:
+        ctx_lines.timing(False)
     st = batch.stats()
     got = batch.read()
     assert sum(len(g) for g in got) > 0

@@ -16,6 +16,7 @@ struct cs_timing_rec {
 };
 
 int cs_host_threads(); // ctx.hip
+void cs_omp_prepare();  // ctx.hip: call before an OpenMP region of a host stage
 
 struct cs_ctx {
     int device = 0;

@@ -60,18 +60,59 @@ __global__ void __launch_bounds__(256) lsd_resize(const double *blur, int W, int
     const double r1 = src[(long)sy1 * W + sx0] * ax[dx * 2] + src[(long)sy1 * W + sx1] * ax[dx * 2 + 1];
     scaled[((long)blockIdx.z * h + dy) * w + dx] = r0 * ay[dy * 2] + r1 * ay[dy * 2 + 1];
 }
-__global__ void __launch_bounds__(256) lsd_gradient(const double *scaled, int w, int h, double threshold, double *modgrad, double *angles) {
+// also counts the defined pixels of its 256-pixel row segment: seg_cnt[(frame * h + y) * gridDim.x + blockIdx.x]
+__global__ void __launch_bounds__(256) lsd_gradient(const double *scaled, int w, int h, double threshold, double *modgrad, double *angles, int *seg_cnt) {
+    __shared__ int wc[4];
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-    if (x >= w) return;
-    const double *img = scaled + (long)blockIdx.z * w * h;
+    bool def = false;
+    if (x < w) {
+        const double *img = scaled + (long)blockIdx.z * w * h;
+        const long o = ((long)blockIdx.z * h + y) * w + x;
+        if (x >= w - 1 || y >= h - 1) { modgrad[o] = 0; angles[o] = NOTDEF; } // down / right boundaries undefined (:553-554)
+        else {
+            const int addr = y * w + x;
+            const double DA = img[addr + w + 1] - img[addr], BC = img[addr + 1] - img[addr + w];
+            const double gx = DA + BC, gy = DA - BC;
+            const double norm = sqrt((gx * gx + gy * gy) / 4);
+            modgrad[o] = norm;
+            def = !(norm <= threshold);
+            angles[o] = def ? fast_atan2f_(float(gx), float(-gy)) * DEG_TO_RADS : NOTDEF;
+        }
+    }
+    const unsigned long long m = __ballot(def);
+    if ((threadIdx.x & 63) == 0) wc[threadIdx.x >> 6] = __popcll(m);
+    __syncthreads();
+    if (threadIdx.x == 0) seg_cnt[((long)blockIdx.z * h + y) * gridDim.x + blockIdx.x] = wc[0] + wc[1] + wc[2] + wc[3];
+}
+// exclusive scan of n ints in one workgroup (out has n + 1 entries, out[n] = total)
+__global__ void __launch_bounds__(1024) lsd_scan(const int *in, int n, int *out) {
+    __shared__ int part[1024];
+    const int t = threadIdx.x, chunk = (n + 1023) / 1024, b = t * chunk, e = min(n, b + chunk);
+    int s = 0;
+    for (int i = b; i < e; i++) s += in[i];
+    part[t] = s;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) { int v = t >= d ? part[t - d] : 0; __syncthreads(); part[t] += v; __syncthreads(); }
+    int run = part[t] - s;
+    for (int i = b; i < e; i++) { out[i] = run; run += in[i]; }
+    if (t == 1023) out[n] = part[1023];
+}
+// ordered compaction of the defined pixels (address order inside a frame): address, level-line angle, gradient norm
+__global__ void __launch_bounds__(256) lsd_emit(const double *modgrad, const double *angles, int w, int h, const int *seg_base, int *c_addr, double *c_ang, double *c_mod) {
+    __shared__ int wc[4];
+    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
     const long o = ((long)blockIdx.z * h + y) * w + x;
-    if (x >= w - 1 || y >= h - 1) { modgrad[o] = 0; angles[o] = NOTDEF; return; } // down / right boundaries undefined (:553-554)
-    const int addr = y * w + x;
-    const double DA = img[addr + w + 1] - img[addr], BC = img[addr + 1] - img[addr + w];
-    const double gx = DA + BC, gy = DA - BC;
-    const double norm = sqrt((gx * gx + gy * gy) / 4);
-    modgrad[o] = norm;
-    angles[o] = norm <= threshold ? NOTDEF : fast_atan2f_(float(gx), float(-gy)) * DEG_TO_RADS;
+    double a = NOTDEF;
+    if (x < w) a = angles[o];
+    const bool def = a != NOTDEF;
+    const unsigned long long m = __ballot(def);
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) wc[wv] = __popcll(m);
+    __syncthreads();
+    if (!def) return;
+    int pos = seg_base[((long)blockIdx.z * h + y) * gridDim.x + blockIdx.x] + __popcll(m & ((1ull << (threadIdx.x & 63)) - 1));
+    for (int i = 0; i < wv; i++) pos += wc[i];
+    c_addr[pos] = y * w + x; c_ang[pos] = a; c_mod[pos] = modgrad[o];
 }
 
 // ------------------------------------------------------------------------------------------------ host: sequential LSD stages
@@ -271,24 +312,30 @@ class LsdHost {
         for (int n = 0; n < 5; ++n) if ((r.width - delta) >= 0.5) { r.p /= 2; r.prec = r.p * PI_; double v = rect_nfa(r); if (v > best) { rec = r; best = v; } }
         return best;
     }
-    // flsd :464-535 (LSD_REFINE_ADV, scale 0.8): segments as x1 y1 x2 y2 floats
-    void run(int w_, int h_, const double *ang, const double *mod, std::vector<float> &lines) {
-        w = w_; h = h_; angles = ang; modgrad = mod;
+    std::vector<double> dang, dmod; // dense maps of this thread, NOTDEF / untouched outside the current frame's defined pixels
+    std::vector<int> order;
+    int cnt[1025];
+    // flsd :464-535 (LSD_REFINE_ADV, scale 0.8): segments as x1 y1 x2 y2 floats.  Input: the frame's defined pixels in address
+    // order (the undefined ones are skipped by the reference's seed loop and fail every alignment test, so they never matter).
+    void run(int w_, int h_, int ne, const int *e_addr, const double *e_ang, const double *e_mod, std::vector<float> &lines) {
+        w = w_; h = h_;
         const size_t n = (size_t)w * h;
+        if (dang.size() != n) { dang.assign(n, NOTDEF); dmod.assign(n, 0.0); used.assign(n, 0); rx.resize(n); ry.resize(n); rang.resize(n); rmod.resize(n); }
+        angles = dang.data(); modgrad = dmod.data();
         const double prec = PI_ * 22.5 / 180, p = 22.5 / 180;
-        // pseudo-ordering (:588-634): 1024 bins by gradient norm, descending bins, pixel order inside a bin
+        // pseudo-ordering (:588-634): 1024 bins by gradient norm, descending bins, pixel (address) order inside a bin
         double max_grad = -1;
-        for (size_t i = 0; i < n; i++) if (ang[i] != NOTDEF && mod[i] > max_grad) max_grad = mod[i];
+        for (int i = 0; i < ne; i++) { dang[e_addr[i]] = e_ang[i]; dmod[e_addr[i]] = e_mod[i]; if (e_mod[i] > max_grad) max_grad = e_mod[i]; }
         const double bin_coef = (max_grad > 0) ? double(1024 - 1) / max_grad : 0;
-        std::vector<int> cnt(1025, 0), order((size_t)(w - 1) * (h - 1));
-        for (int y = 0; y < h - 1; ++y) for (int x = 0; x < w - 1; ++x) cnt[1023 - int(mod[(size_t)y * w + x] * bin_coef) + 1]++;
+        for (int i = 0; i < 1025; i++) cnt[i] = 0;
+        for (int i = 0; i < ne; i++) cnt[1023 - int(e_mod[i] * bin_coef) + 1]++;
         for (int i = 0; i < 1024; i++) cnt[i + 1] += cnt[i];
-        for (int y = 0; y < h - 1; ++y) for (int x = 0; x < w - 1; ++x) order[cnt[1023 - int(mod[(size_t)y * w + x] * bin_coef)]++] = x + y * w;
+        order.resize((size_t)ne);
+        for (int i = 0; i < ne; i++) order[cnt[1023 - int(e_mod[i] * bin_coef)]++] = e_addr[i];
         LOG_NT = 5 * (std::log10(double(w)) + std::log10(double(h))) / 2 + std::log10(11.0);
         const int min_reg_size = int(-LOG_NT / std::log10(p));
-        used.assign(n, 0);
-        rx.resize(n); ry.resize(n); rang.resize(n); rmod.resize(n);
         lines.clear();
+        const double *ang = angles;
         for (size_t i = 0; i < order.size(); ++i) {
             const int adx = order[i];
             if (used[adx] != 0 || ang[adx] == NOTDEF) continue;
@@ -303,6 +350,7 @@ class LsdHost {
             rec.x1 /= 0.8; rec.y1 /= 0.8; rec.x2 /= 0.8; rec.y2 /= 0.8;
             lines.push_back(float(rec.x1)); lines.push_back(float(rec.y1)); lines.push_back(float(rec.x2)); lines.push_back(float(rec.y2));
         }
+        for (int i = 0; i < ne; i++) { dang[e_addr[i]] = NOTDEF; used[e_addr[i]] = 0; } // leave the dense maps clean for the next frame
     }
 };
 
@@ -340,7 +388,11 @@ struct cs_lsd {
     double threshold = 0;
     uint8_t *d_gray = nullptr; double *d_tmp = nullptr, *d_blur = nullptr, *d_scaled = nullptr, *d_mod = nullptr, *d_ang = nullptr;
     int *d_xofs = nullptr, *d_yofs = nullptr; float *d_ax = nullptr, *d_ay = nullptr;
-    double *h_mod = nullptr, *h_ang = nullptr; // pinned
+    int nbx = 0;                                            // 256-pixel segments per scaled row
+    int *d_seg_cnt = nullptr, *d_seg_base = nullptr;        // per (frame, row, segment) defined-pixel count / exclusive scan
+    int *d_caddr = nullptr; double *d_cang = nullptr, *d_cmod = nullptr; size_t ccap = 0;   // compacted defined pixels (device)
+    int *h_caddr = nullptr; double *h_cang = nullptr, *h_cmod = nullptr; size_t hcap = 0;   // same, pinned host
+    std::vector<int> frame_base;
     std::vector<std::vector<cs_keyline>> keylines;
     // LBD descriptors of the detected lines (optional second half of cs_lsd_run)
     uint8_t *d_lblur = nullptr; short *d_dx = nullptr, *d_dy = nullptr;
@@ -377,10 +429,39 @@ static int lsd_run(cs_ctx *ctx, cs_lsd *l, int with_lbd) {
     CS_LAUNCH(ctx, "lsd_blur_h", lsd_blur_h, dim3((W + 255) / 256, H, F), dim3(256), 0, l->d_gray, W, H, l->gk, l->d_tmp);
     CS_LAUNCH(ctx, "lsd_blur_v", lsd_blur_v, dim3((W + 255) / 256, H, F), dim3(256), 0, l->d_tmp, W, H, l->gk, l->d_blur);
     CS_LAUNCH(ctx, "lsd_resize", lsd_resize, dim3((w + 255) / 256, h, F), dim3(256), 0, l->d_blur, W, H, w, h, l->d_xofs, l->d_ax, l->d_yofs, l->d_ay, l->d_scaled);
-    CS_LAUNCH(ctx, "lsd_gradient", lsd_gradient, dim3((w + 255) / 256, h, F), dim3(256), 0, l->d_scaled, w, h, l->threshold, l->d_mod, l->d_ang);
-    const size_t n = (size_t)w * h;
-    int r = cs_d2h(ctx, l->h_mod, l->d_mod, n * F); if (r) return r;
-    r = cs_d2h(ctx, l->h_ang, l->d_ang, n * F); if (r) return r;
+    const int nbx = l->nbx, n_seg = F * h * nbx;
+    CS_LAUNCH(ctx, "lsd_gradient", lsd_gradient, dim3(nbx, h, F), dim3(256), 0, l->d_scaled, w, h, l->threshold, l->d_mod, l->d_ang, l->d_seg_cnt);
+    CS_LAUNCH(ctx, "lsd_scan", lsd_scan, dim3(1), dim3(1024), 0, l->d_seg_cnt, n_seg, l->d_seg_base);
+    // only the defined pixels (gradient above rho) go to the host: frame bases first, then the compacted (address, angle, norm) lists
+    l->frame_base.assign((size_t)F + 1, 0);
+    CS_HIP(ctx, hipMemcpy2DAsync(l->frame_base.data(), sizeof(int), l->d_seg_base, sizeof(int) * (size_t)h * nbx, sizeof(int), (size_t)F + 1, hipMemcpyDeviceToHost, ctx->stream));
+    CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const size_t total = (size_t)l->frame_base[F];
+    int r;
+    if (total > l->ccap) {
+        void *old[] = {l->d_caddr, l->d_cang, l->d_cmod};
+        for (void *q : old) if (q) hipFree(q);
+        l->d_caddr = nullptr; l->d_cang = nullptr; l->d_cmod = nullptr; l->ccap = 0;
+        const size_t cap = total + total / 4 + 4096;
+        r = cs_dalloc(ctx, &l->d_caddr, cap); if (r) return r;
+        r = cs_dalloc(ctx, &l->d_cang, cap); if (r) return r;
+        r = cs_dalloc(ctx, &l->d_cmod, cap); if (r) return r;
+        l->ccap = cap;
+    }
+    if (total > l->hcap) {
+        if (l->h_caddr) hipHostFree(l->h_caddr); if (l->h_cang) hipHostFree(l->h_cang); if (l->h_cmod) hipHostFree(l->h_cmod);
+        l->h_caddr = nullptr; l->h_cang = nullptr; l->h_cmod = nullptr; l->hcap = 0;
+        const size_t cap = total + total / 4 + 4096;
+        if (hipHostMalloc((void **)&l->h_caddr, cap * sizeof(int), hipHostMallocDefault) != hipSuccess || hipHostMalloc((void **)&l->h_cang, cap * sizeof(double), hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc((void **)&l->h_cmod, cap * sizeof(double), hipHostMallocDefault) != hipSuccess) return CS_ERR_NOMEM;
+        l->hcap = cap;
+    }
+    if (total > 0) {
+        CS_LAUNCH(ctx, "lsd_emit", lsd_emit, dim3(nbx, h, F), dim3(256), 0, l->d_mod, l->d_ang, w, h, l->d_seg_base, l->d_caddr, l->d_cang, l->d_cmod);
+        r = cs_d2h(ctx, l->h_caddr, l->d_caddr, total); if (r) return r;
+        r = cs_d2h(ctx, l->h_cang, l->d_cang, total); if (r) return r;
+        r = cs_d2h(ctx, l->h_cmod, l->d_cmod, total); if (r) return r;
+    }
     hipEvent_t ev = ctx->get_event();
     CS_HIP(ctx, hipEventRecord(ev, ctx->stream));
     if (with_lbd) { // the derivative maps only depend on the gray frames: they run while the host grows regions
@@ -396,13 +477,15 @@ static int lsd_run(cs_ctx *ctx, cs_lsd *l, int with_lbd) {
     ctx->pool.push_back(ev);
     const auto t0 = std::chrono::steady_clock::now();
     l->keylines.assign((size_t)F, {});
+    cs_omp_prepare();
 #pragma omp parallel num_threads(std::max(1, std::min(ctx->host_threads, F)))
     {
         LsdHost host;
         std::vector<float> lines;
 #pragma omp for schedule(dynamic, 1)
         for (int f = 0; f < F; f++) {
-            host.run(w, h, l->h_ang + n * f, l->h_mod + n * f, lines);
+            const int b0 = l->frame_base[f];
+            host.run(w, h, l->frame_base[f + 1] - b0, l->h_caddr + b0, l->h_cang + b0, l->h_cmod + b0, lines);
             to_keylines(lines, W, H, l->keylines[f]);
         }
     }
@@ -446,8 +529,11 @@ void cs_lsd_destroy(cs_ctx *ctx, cs_lsd *l) {
     void *ptrs[] = {l->d_gray, l->d_tmp, l->d_blur, l->d_scaled, l->d_mod, l->d_ang, l->d_xofs, l->d_yofs, l->d_ax, l->d_ay, l->d_lblur, l->d_dx, l->d_dy};
     for (void *p : ptrs) if (p) hipFree(p);
     lsd_free_lines(l);
-    if (l->h_mod) hipHostFree(l->h_mod);
-    if (l->h_ang) hipHostFree(l->h_ang);
+    void *more[] = {l->d_seg_cnt, l->d_seg_base, l->d_caddr, l->d_cang, l->d_cmod};
+    for (void *p : more) if (p) hipFree(p);
+    if (l->h_caddr) hipHostFree(l->h_caddr);
+    if (l->h_cang) hipHostFree(l->h_cang);
+    if (l->h_cmod) hipHostFree(l->h_cmod);
     delete l;
 }
 
@@ -474,7 +560,8 @@ int cs_lsd_create(cs_ctx *ctx, int width, int height, int max_frames, cs_lsd **o
     A_(cs_dalloc(ctx, &l->d_gray, N)); A_(cs_dalloc(ctx, &l->d_tmp, N)); A_(cs_dalloc(ctx, &l->d_blur, N));
     A_(cs_dalloc(ctx, &l->d_scaled, n)); A_(cs_dalloc(ctx, &l->d_mod, n)); A_(cs_dalloc(ctx, &l->d_ang, n));
     A_(cs_dalloc(ctx, &l->d_xofs, xofs.size())); A_(cs_dalloc(ctx, &l->d_yofs, yofs.size())); A_(cs_dalloc(ctx, &l->d_ax, ax.size())); A_(cs_dalloc(ctx, &l->d_ay, ay.size()));
-    if (hipHostMalloc((void **)&l->h_mod, n * sizeof(double), hipHostMallocDefault) != hipSuccess || hipHostMalloc((void **)&l->h_ang, n * sizeof(double), hipHostMallocDefault) != hipSuccess) { cs_lsd_destroy(ctx, l); return CS_ERR_NOMEM; }
+    l->nbx = (l->w + 255) / 256;
+    A_(cs_dalloc(ctx, &l->d_seg_cnt, (size_t)max_frames * l->h * l->nbx)); A_(cs_dalloc(ctx, &l->d_seg_base, (size_t)max_frames * l->h * l->nbx + 1));
     A_(cs_h2d(ctx, l->d_xofs, xofs.data(), xofs.size())); A_(cs_h2d(ctx, l->d_yofs, yofs.data(), yofs.size()));
     A_(cs_h2d(ctx, l->d_ax, ax.data(), ax.size())); A_(cs_h2d(ctx, l->d_ay, ay.data(), ay.size()));
 #undef A_

@@ -551,6 +551,7 @@ int cs_orb_run(cs_ctx *ctx, cs_orb *e) {
     e->frame_first.assign((size_t)F + 1, 0);
     {
         std::vector<std::vector<SelKP>> per((size_t)F * NL);
+    cs_omp_prepare();
 #pragma omp parallel num_threads(std::max(1, std::min(ctx->host_threads, F * NL / 4)))
         {
             cs_orb_host::QuadTree qt;
