@@ -197,7 +197,7 @@ def main():
         elapsed = float(t.item())
     kernels = {}
     for name in ("host_orb_quadtree", "orb_resize", "orb_fast_score", "orb_cells", "orb_scan", "orb_blur", "orb_angle", "orb_desc", "host_lsd_regions", "lsd_blur_h", "lsd_blur_v", "lsd_resize", "lsd_gradient", "lbd_blur5", "lbd_sobel", "lbd_rows", "lbd_desc", "cuboid_frame_prep", "cuboid_unit_lines", "cuboid_canny_nms", "cuboid_canny_cc", "cuboid_dt", "cuboid_vp",
-                 "cuboid_sweep_score", "cuboid_select"):
+                 "cuboid_sweep_corners", "cuboid_sweep_score", "cuboid_select"):
         ms, n = ctx.timing_get(name)
         if n == 0 and lsd is not None:
             ms, n = ctx_lines.timing_get(name)
@@ -216,9 +216,9 @@ def main():
 
     if rank == 0:
         total_frames = args.frames * world * args.steps
-        # algorithmic bytes of one cuboid_sweep_score launch: each distance-map ROI read once (4*A),
-        # per valid proposal 16 corner doubles + 2 error doubles + per hypothesis 1 flag byte written.
-        alg_bytes = 4.0 * st["roi_pixels"] + 145.0 * st["n_valid"] + 1.0 * st["n_hypotheses"]
+        # algorithmic bytes of one cuboid_sweep_score launch (SURVEY 8d "edge scoring kernel"): each distance-map ROI
+        # read once (4*A); per surviving proposal 16 corner doubles read, 2 error doubles written.
+        alg_bytes = 4.0 * st["roi_pixels"] + 144.0 * st["n_valid"]
         k_us = kernels["cuboid_sweep_score"]["avg_us"]
         achieved = alg_bytes / (k_us * 1e-6) / 1e9 if k_us > 0 else 0.0
         out = {

@@ -703,51 +703,62 @@ __device__ inline int make_corners(const Unit &U, const VPEntry &E, int top_x, i
     return vp_1_position;
 }
 
-// box_edge_sum_dists object_3d_util.cpp:427-453: float accumulation in edge/sample order; dist_map.at<float>(int(y),int(x))
-// has no bounds check and corners may sit on x==w or y==h: flat index clamped to the buffer.
-__device__ inline double edge_sum_dists(const float *dm, int w, int h, const double *cx, const double *cy, int cfg) {
-    const int ne = cfg == 1 ? 9 : 7;
-    const bool reweight = cfg != 1;
-    float sum_dist = 0;
-    const long last = (long)w * h - 1;
-    for (int e = 0; e < ne; e++) {
-        int ia = cfg == 1 ? c_vis1[e][0] : c_vis2[e][0], ib = cfg == 1 ? c_vis1[e][1] : c_vis2[e][1];
-        double x1 = cx[ia], y1 = cy[ia], x2 = cx[ib], y2 = cy[ib];
+// box_edge_sum_dists (object_3d_util.cpp:427-453) + box_edge_alignment_angle_error (:455-492) of one proposal whose corners sit
+// in this thread's LDS column sc[k*256] (k = 0..7 x, 8..15 y; image coordinates).  Edges are a real loop (corner indices from the
+// constant tables, uniform per workgroup), the 11 samples of an edge are unrolled: ~50 live registers instead of ~220 when the
+// compiler unrolls all 99 samples, which is what lets 8 waves per SIMD hide the gather latency.
+//  * sample point = s/10*p1 + (1-s/10)*p2 in double, operation order of the reference; dist_map.at<float>(int(y),int(x)) has no
+//    bounds check and corners may sit on x==w / y==h: flat index clamped to the buffer;
+//  * float accumulation in edge/sample order; the cfg-2 weights `dist*3.0/2.0` and `dist*2.0` (float -> double -> float) equal
+//    the float products dist*1.5f and dist*2.0f bit for bit (3*x and x/2 are exact in double, so both round 1.5*x once).
+template <int CFG> __device__ __forceinline__ void edge_gather(const double *sc, int e, const float *dm, int w, int last, double rx, double ry, float (&v)[11]) {
+    const int ia = CFG == 1 ? c_vis1[e][0] : c_vis2[e][0], ib = CFG == 1 ? c_vis1[e][1] : c_vis2[e][1];
+    const double x1 = sc[ia * 256] - rx, y1 = sc[(8 + ia) * 256] - ry, x2 = sc[ib * 256] - rx, y2 = sc[(8 + ib) * 256] - ry; // :423-425
 #pragma unroll
-        for (int si = 0; si < 11; si++) {
-            const double s = (double)si;
-            double px = s / 10.0 * x1 + (1 - s / 10.0) * x2;
-            double py = s / 10.0 * y1 + (1 - s / 10.0) * y2;
-            long idx = (long)int(py) * w + int(px);
-            idx = idx < 0 ? 0 : (idx > last ? last : idx);
-            float dist1 = dm[idx];
-            if (reweight) {
-                if ((4 <= e) && (e <= 5)) dist1 = dist1 * 3.0 / 2.0;
-                if (6 == e) dist1 = dist1 * 2.0;
-            }
-            sum_dist = sum_dist + dist1;
-        }
+    for (int si = 0; si < 11; si++) {
+        const double s = (double)si;
+        const double px = s / 10.0 * x1 + (1 - s / 10.0) * x2;
+        const double py = s / 10.0 * y1 + (1 - s / 10.0) * y2;
+        int idx = __mul24(int(py), w) + int(px);
+        idx = min(max(idx, 0), last);
+        v[si] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(dm) + ((unsigned)idx << 2));
     }
-    return double(sum_dist);
 }
-// box_edge_alignment_angle_error :455-492
-__device__ inline double edge_angle_error(const VPEntry &E, const double *cx, const double *cy, int cfg) {
+template <int CFG> __device__ __forceinline__ float edge_weight(int e) { return (CFG == 2 && (e == 4 || e == 5)) ? 1.5f : ((CFG == 2 && e == 6) ? 2.0f : 1.0f); }
+// software-pipelined over edges: the 11 gathers of edge e+1 are in flight while the values of edge e are added
+template <int CFG> __device__ __forceinline__ float edge_sum_dists_lds(const double *sc, const float *dm, int w, int last, double rx, double ry) {
+    constexpr int NE = CFG == 1 ? 9 : 7;
+    float sum_dist = 0;
+    float v[11];
+    edge_gather<CFG>(sc, 0, dm, w, last, rx, ry, v);
+#pragma unroll 1
+    for (int e = 1; e < NE; e++) {
+        float nv[11];
+        edge_gather<CFG>(sc, e, dm, w, last, rx, ry, nv);
+        const float wgt = edge_weight<CFG>(e - 1);
+#pragma unroll
+        for (int si = 0; si < 11; si++) { float d = v[si]; if (CFG == 2) d = d * wgt; sum_dist = sum_dist + d; v[si] = nv[si]; }
+    }
+    const float wgt = edge_weight<CFG>(NE - 1);
+#pragma unroll
+    for (int si = 0; si < 11; si++) { float d = v[si]; if (CFG == 2) d = d * wgt; sum_dist = sum_dist + d; }
+    return sum_dist;
+}
+template <int CFG> __device__ __forceinline__ double edge_angle_error_lds(const VPEntry &E, const double *sc) {
     double total = 0;
     const double not_found_penalty = 30.0 / 180.0 * PI * 2;
+#pragma unroll 1
     for (int vp = 0; vp < 3; vp++) {
-        double valid[2];
-        int nv = 0;
-        for (int i = 0; i < 2; i++) if (!isnan(E.ang[vp * 2 + i])) valid[nv++] = E.ang[vp * 2 + i];
-        if (nv > 0) {
+        const double a0 = E.ang[vp * 2], a1 = E.ang[vp * 2 + 1];
+        const bool v0 = !isnan(a0), v1 = !isnan(a1);
+        if (v0 || v1) {
+#pragma unroll 1
             for (int ee = 0; ee < 2; ee++) {
-                int a = cfg == 1 ? c_vpe1[vp][2 * ee] : c_vpe2[vp][2 * ee], b = cfg == 1 ? c_vpe1[vp][2 * ee + 1] : c_vpe2[vp][2 * ee + 1];
-                double ang = normalize_to_pi(atan2(cy[b] - cy[a], cx[b] - cx[a]));
+                const int a = CFG == 1 ? c_vpe1[vp][2 * ee] : c_vpe2[vp][2 * ee], b = CFG == 1 ? c_vpe1[vp][2 * ee + 1] : c_vpe2[vp][2 * ee + 1];
+                const double ang = normalize_to_pi(atan2(sc[(8 + b) * 256] - sc[(8 + a) * 256], sc[b * 256] - sc[a * 256]));
                 double best = 100;
-                for (int i = 0; i < nv; i++) {
-                    double t = fabs(ang - valid[i]);
-                    t = fmin(t, PI - t);
-                    if (t < best) best = t;
-                }
+                if (v0) { double t = fabs(ang - a0); t = fmin(t, PI - t); if (t < best) best = t; }
+                if (v1) { double t = fabs(ang - a1); t = fmin(t, PI - t); if (t < best) best = t; }
                 total = total + best;
             }
         } else
@@ -759,13 +770,18 @@ __device__ inline double edge_angle_error(const VPEntry &E, const double *cx, co
 // hypothesis index h = ((rp*n_yaw + yaw)*n_tops + top)*2 + (cfg-1)   (the reference's loop nest :229-285)
 // SoA outputs over the global hypothesis index g = hyp_off + h:
 //   flag[g] u8: 0 rejected, 1/2 = vp_1_position; derr[g], aerr[g]; corners[p*hyp_total + g], p = 0..15 (x0..x7,y0..y7)
-// Grid is 1-D and XCD-aware: workgroup b runs on XCD b%8 (observed dispatch rule), so all workgroups of one unit are
+// Both grids are 1-D and XCD-aware: workgroup b runs on XCD b%8 (observed dispatch rule), so all workgroups of one unit are
 // given the same b%8 and the unit's distance map is fetched into a single XCD's L2.
-__global__ void __launch_bounds__(256) cuboid_sweep_score(const Unit *units, int n_units, int blocks_per_unit, const FrameDyn *fd,
-                                                          const double *yaw, Opts o, const VPEntry *vpt, const float *dist, uint8_t *flag,
-                                                          double *derr, double *aerr, double *corners, long hyp_total) {
-    __shared__ int s_list[SWEEP_HB];
-    __shared__ int s_count;
+//
+// cuboid_sweep_corners: corner construction with all reject tests for SWEEP_HB hypotheses per workgroup; the surviving
+// hypotheses are appended to the unit's two proposal lists -- configuration 1 grows from vlist[hyp_off] upwards, configuration 2
+// from vlist[hyp_off + hyp_cap - 1] downwards, counts in vcount[2u], vcount[2u+1] -- so that the scoring workgroups are
+// configuration-uniform.  The order inside a list only decides which thread scores which proposal.
+__global__ void __launch_bounds__(256) cuboid_sweep_corners(const Unit *units, int n_units, int blocks_per_unit, const FrameDyn *fd, Opts o,
+                                                            const VPEntry *vpt, uint8_t *flag, double *corners, long hyp_total, int *vcount,
+                                                            int *vlist) {
+    __shared__ int s_list[2][SWEEP_HB / 2];
+    __shared__ int s_count[2], s_base[2];
     const int b = blockIdx.x;
     const int xcd = b & 7, slot = b >> 3;
     const int u = (slot / blocks_per_unit) * 8 + xcd, blk = slot % blocks_per_unit;
@@ -776,7 +792,7 @@ __global__ void __launch_bounds__(256) cuboid_sweep_score(const Unit *units, int
     const int n_hyp = n_rp * n_yaw * U.n_tops * 2;
     const int h0 = blk * SWEEP_HB;
     if (h0 >= U.hyp_cap) return;
-    if (threadIdx.x == 0) s_count = 0;
+    if (threadIdx.x < 2) s_count[threadIdx.x] = 0;
     __syncthreads();
     for (int r = 0; r < SWEEP_HB / 256; r++) {
         int h = h0 + r * 256 + threadIdx.x;
@@ -793,29 +809,55 @@ __global__ void __launch_bounds__(256) cuboid_sweep_score(const Unit *units, int
                 if (pos) {
 #pragma unroll
                     for (int k = 0; k < 8; k++) { corners[(long)k * hyp_total + g] = c[k].x; corners[(long)(8 + k) * hyp_total + g] = c[k].y; }
-                    s_list[atomicAdd(&s_count, 1)] = h;
+                    s_list[cfg - 1][atomicAdd(&s_count[cfg - 1], 1)] = h;
                 }
             }
         }
         flag[g] = (uint8_t)pos;
     }
-    __threadfence_block();
     __syncthreads();
-    const int cnt = s_count;
-    const float *dm = dist + U.pix_off;
-    for (int s = threadIdx.x; s < cnt; s += 256) {
-        int h = s_list[s];
-        long g = U.hyp_off + h;
-        int cfg = (h & 1) + 1, q = (h >> 1) / U.n_tops;
-        double cx[8], cy[8], sx[8], sy[8];
+    const int c1 = s_count[0], c2 = s_count[1];
+    if (c1 + c2 == 0) return;
+    if (threadIdx.x < 2 && s_count[threadIdx.x] > 0) s_base[threadIdx.x] = atomicAdd(&vcount[2 * u + threadIdx.x], s_count[threadIdx.x]);
+    __syncthreads();
+    int *d1 = vlist + U.hyp_off + s_base[0], *d2 = vlist + U.hyp_off + U.hyp_cap - 1 - s_base[1];
+    for (int s = threadIdx.x; s < c1; s += 256) d1[s] = s_list[0][s];
+    for (int s = threadIdx.x; s < c2; s += 256) d2[-s] = s_list[1][s];
+}
+
+// cuboid_sweep_score: the edge-scoring kernel.  One thread per surviving proposal: box_edge_sum_dists (99 / 77 distance-map
+// samples, float accumulation in the reference's order) and box_edge_alignment_angle_error.  SCORE_PB proposals per workgroup;
+// a unit's workgroups cover its configuration-1 list first, then its configuration-2 list.
+constexpr int SCORE_PB = 256;
+template <int CFG> __device__ __forceinline__ void score_one(const Unit &U, int h, const VPEntry *vpt, const float *dist, const double *corners, long hyp_total,
+                                                             double *sc, double *derr, double *aerr) {
+    const long g = U.hyp_off + h;
+    const int q = (h >> 1) / U.n_tops;
 #pragma unroll
-        for (int k = 0; k < 8; k++) {
-            cx[k] = corners[(long)k * hyp_total + g]; cy[k] = corners[(long)(8 + k) * hyp_total + g];
-            sx[k] = cx[k] - U.roi_x; sy[k] = cy[k] - U.roi_y; // :423-425
-        }
-        double sum_dist = edge_sum_dists(dm, U.roi_w, U.roi_h, sx, sy, cfg);
-        derr[g] = sum_dist / U.diag; // :451
-        aerr[g] = edge_angle_error(vpt[(long)U.vp_off + q], cx, cy, cfg);
+    for (int k = 0; k < 16; k++) sc[k * 256] = corners[(long)k * hyp_total + g];
+    const float sum_dist = edge_sum_dists_lds<CFG>(sc, dist + U.pix_off, U.roi_w, U.roi_w * U.roi_h - 1, (double)U.roi_x, (double)U.roi_y);
+    derr[g] = double(sum_dist) / U.diag; // :451
+    aerr[g] = edge_angle_error_lds<CFG>(vpt[(long)U.vp_off + q], sc);
+}
+__global__ void __launch_bounds__(256) cuboid_sweep_score(const Unit *units, int n_units, int blocks_per_unit, const VPEntry *vpt, const float *dist,
+                                                          const double *corners, long hyp_total, const int *vcount, const int *vlist, double *derr,
+                                                          double *aerr) {
+    __shared__ double s_c[16 * 256]; // the thread's proposal corners: column threadIdx.x, no sharing between threads
+    double *sc = s_c + threadIdx.x;
+    const int b = blockIdx.x;
+    const int xcd = b & 7, slot = b >> 3;
+    const int u = (slot / blocks_per_unit) * 8 + xcd;
+    int blk = slot % blocks_per_unit;
+    if (u >= n_units) return;
+    const int c1 = vcount[2 * u], c2 = vcount[2 * u + 1];
+    const int nb1 = (c1 + SCORE_PB - 1) / SCORE_PB;
+    const Unit &U = units[u];
+    if (blk < nb1) {
+        const int s = blk * SCORE_PB + threadIdx.x;
+        if (s < c1) score_one<1>(U, vlist[U.hyp_off + s], vpt, dist, corners, hyp_total, sc, derr, aerr);
+    } else {
+        const int s = (blk - nb1) * SCORE_PB + threadIdx.x;
+        if (s < c2) score_one<2>(U, vlist[U.hyp_off + U.hyp_cap - 1 - s], vpt, dist, corners, hyp_total, sc, derr, aerr);
     }
 }
 
@@ -1227,6 +1269,7 @@ struct cs_cuboid_batch {
     double *d_yaw = nullptr, *d_lines_in = nullptr, *d_lines_al = nullptr, *d_mlines = nullptr, *d_mangle = nullptr, *d_mmid = nullptr;
     Unit *d_units = nullptr; UnitDyn *d_ud = nullptr; int *d_box_first = nullptr, *d_status = nullptr, *d_counts = nullptr;
     VPEntry *d_vp = nullptr;
+    int *d_vcount = nullptr, *d_vlist = nullptr; // per unit: number of surviving proposals and their hypothesis indices
     double *d_derr = nullptr, *d_aerr = nullptr, *d_corners = nullptr, *d_score = nullptr, *d_nscore = nullptr;
     unsigned long long *d_ckd = nullptr, *d_cka = nullptr; int *d_cidx = nullptr;
     cs_cuboid *d_out = nullptr;
@@ -1247,7 +1290,7 @@ void cs_cuboid_batch_destroy(cs_ctx *ctx, cs_cuboid_batch *b) {
     if (ctx) { hipSetDevice(ctx->device); hipStreamSynchronize(ctx->stream); }
     void *ptrs[] = {b->d_gray, b->d_emap, b->d_flag, b->d_dist, b->d_fi, b->d_fd, b->d_cam, b->d_yaw, b->d_lines_in, b->d_lines_al,
                     b->d_mlines, b->d_mangle, b->d_mmid, b->d_units, b->d_ud, b->d_box_first, b->d_status, b->d_counts, b->d_vp,
-                    b->d_derr, b->d_aerr, b->d_corners, b->d_score, b->d_nscore, b->d_ckd, b->d_cka, b->d_cidx, b->d_out};
+                    b->d_derr, b->d_aerr, b->d_corners, b->d_score, b->d_nscore, b->d_ckd, b->d_cka, b->d_cidx, b->d_out, b->d_vcount, b->d_vlist};
     for (void *p : ptrs) if (p) hipFree(p);
     delete b;
 }
@@ -1362,6 +1405,8 @@ int cs_cuboid_batch_create(cs_ctx *ctx, int n_frames, int width, int height, con
     A_(cs_dalloc(ctx, &b->d_counts, (size_t)n_boxes));
     A_(cs_dalloc(ctx, &b->d_vp, (size_t)b->vp_total));
     A_(cs_dalloc(ctx, &b->d_flag, (size_t)b->hyp_total));
+    A_(cs_dalloc(ctx, &b->d_vcount, (size_t)std::max<size_t>(1, 2 * b->units.size())));
+    A_(cs_dalloc(ctx, &b->d_vlist, (size_t)b->hyp_total));
     A_(cs_dalloc(ctx, &b->d_derr, (size_t)b->hyp_total));
     A_(cs_dalloc(ctx, &b->d_aerr, (size_t)b->hyp_total));
     A_(cs_dalloc(ctx, &b->d_corners, (size_t)b->hyp_total * 16));
@@ -1406,8 +1451,12 @@ int cs_cuboid_batch_run(cs_ctx *ctx, cs_cuboid_batch *b) {
     CS_LAUNCH(ctx, "cuboid_vp", cuboid_vp, dim3(b->max_vp_blocks, U), dim3(256), 0, b->d_units, b->d_ud, b->d_fd, b->d_cam, b->d_yaw, b->o,
               b->d_mangle, b->d_mmid, b->d_vp);
     const int groups = (U + 7) / 8;
-    CS_LAUNCH(ctx, "cuboid_sweep_score", cuboid_sweep_score, dim3(groups * b->blocks_per_unit * 8), dim3(256), 0, b->d_units, U,
-              b->blocks_per_unit, b->d_fd, b->d_yaw, b->o, b->d_vp, b->d_dist, b->d_flag, b->d_derr, b->d_aerr, b->d_corners, b->hyp_total);
+    CS_HIP(ctx, hipMemsetAsync(b->d_vcount, 0, sizeof(int) * 2 * (size_t)U, ctx->stream));
+    CS_LAUNCH(ctx, "cuboid_sweep_corners", cuboid_sweep_corners, dim3(groups * b->blocks_per_unit * 8), dim3(256), 0, b->d_units, U,
+              b->blocks_per_unit, b->d_fd, b->o, b->d_vp, b->d_flag, b->d_corners, b->hyp_total, b->d_vcount, b->d_vlist);
+    const int score_bpu = b->blocks_per_unit * (SWEEP_HB / SCORE_PB) + 1; // +1: each of the two lists may end in a partial workgroup
+    CS_LAUNCH(ctx, "cuboid_sweep_score", cuboid_sweep_score, dim3(groups * score_bpu * 8), dim3(256), 0, b->d_units, U, score_bpu, b->d_vp,
+              b->d_dist, b->d_corners, b->hyp_total, b->d_vcount, b->d_vlist, b->d_derr, b->d_aerr);
     CS_LAUNCH(ctx, "cuboid_select", cuboid_select, dim3(b->n_boxes), dim3(256), 0, b->d_units, b->d_ud, b->d_box_first, b->d_fd, b->d_fi,
               b->d_cam, b->d_yaw, b->cal, b->o, b->d_flag, b->d_derr, b->d_aerr, b->d_corners, b->hyp_total, b->d_score, b->d_nscore,
               b->d_ckd, b->d_cka, b->d_cidx, b->d_out, b->d_counts);
