@@ -711,11 +711,15 @@ __device__ inline int make_corners(const Unit &U, const VPEntry &E, int top_x, i
 //    bounds check and corners may sit on x==w / y==h: flat index clamped to the buffer;
 //  * float accumulation in edge/sample order; the cfg-2 weights `dist*3.0/2.0` and `dist*2.0` (float -> double -> float) equal
 //    the float products dist*1.5f and dist*2.0f bit for bit (3*x and x/2 are exact in double, so both round 1.5*x once).
-template <int CFG> __device__ __forceinline__ void edge_gather(const double *sc, int e, const float *dm, int w, int last, double rx, double ry, float (&v)[11]) {
+// The end samples of an edge are its corners (s = 0: 0*p1 + 1*p2 = p2, s = 10: 1*p1 + 0*p2 = p1, exactly), and every corner ends
+// two or three edges: the 8 corner pixels are fetched once (scp, the thread's LDS column of floats) and only the 9 interior
+// samples of an edge are gathered.
+template <int CFG> __device__ __forceinline__ void edge_gather(const double *sc, const float *scp, int e, const float *dm, int w, int last, double rx, double ry, float (&v)[11]) {
     const int ia = CFG == 1 ? c_vis1[e][0] : c_vis2[e][0], ib = CFG == 1 ? c_vis1[e][1] : c_vis2[e][1];
     const double x1 = sc[ia * 256] - rx, y1 = sc[(8 + ia) * 256] - ry, x2 = sc[ib * 256] - rx, y2 = sc[(8 + ib) * 256] - ry; // :423-425
+    v[0] = scp[ib * 256]; v[10] = scp[ia * 256];
 #pragma unroll
-    for (int si = 0; si < 11; si++) {
+    for (int si = 1; si < 10; si++) {
         const double s = (double)si;
         const double px = s / 10.0 * x1 + (1 - s / 10.0) * x2;
         const double py = s / 10.0 * y1 + (1 - s / 10.0) * y2;
@@ -726,15 +730,22 @@ template <int CFG> __device__ __forceinline__ void edge_gather(const double *sc,
 }
 template <int CFG> __device__ __forceinline__ float edge_weight(int e) { return (CFG == 2 && (e == 4 || e == 5)) ? 1.5f : ((CFG == 2 && e == 6) ? 2.0f : 1.0f); }
 // software-pipelined over edges: the 11 gathers of edge e+1 are in flight while the values of edge e are added
-template <int CFG> __device__ __forceinline__ float edge_sum_dists_lds(const double *sc, const float *dm, int w, int last, double rx, double ry) {
+template <int CFG> __device__ __forceinline__ float edge_sum_dists_lds(const double *sc, float *scp, const float *dm, int w, int last, double rx, double ry) {
     constexpr int NE = CFG == 1 ? 9 : 7;
     float sum_dist = 0;
     float v[11];
-    edge_gather<CFG>(sc, 0, dm, w, last, rx, ry, v);
+#pragma unroll
+    for (int k = 0; k < 8; k++) { // corner pixels (corners 6 and 7 are not on a visible edge of configuration 2)
+        if (CFG == 2 && k >= 6) break;
+        int idx = __mul24(int(sc[(8 + k) * 256] - ry), w) + int(sc[k * 256] - rx);
+        idx = min(max(idx, 0), last);
+        scp[k * 256] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(dm) + ((unsigned)idx << 2));
+    }
+    edge_gather<CFG>(sc, scp, 0, dm, w, last, rx, ry, v);
 #pragma unroll 1
     for (int e = 1; e < NE; e++) {
         float nv[11];
-        edge_gather<CFG>(sc, e, dm, w, last, rx, ry, nv);
+        edge_gather<CFG>(sc, scp, e, dm, w, last, rx, ry, nv);
         const float wgt = edge_weight<CFG>(e - 1);
 #pragma unroll
         for (int si = 0; si < 11; si++) { float d = v[si]; if (CFG == 2) d = d * wgt; sum_dist = sum_dist + d; v[si] = nv[si]; }
@@ -776,12 +787,14 @@ template <int CFG> __device__ __forceinline__ double edge_angle_error_lds(const 
 // cuboid_sweep_corners: corner construction with all reject tests for SWEEP_HB hypotheses per workgroup; the surviving
 // hypotheses are appended to the unit's two proposal lists -- configuration 1 grows from vlist[hyp_off] upwards, configuration 2
 // from vlist[hyp_off + hyp_cap - 1] downwards, counts in vcount[2u], vcount[2u+1] -- so that the scoring workgroups are
-// configuration-uniform.  The order inside a list only decides which thread scores which proposal.
+// configuration-uniform.  Ordered compaction (ballot ranks, no atomics inside the workgroup): a list is in hypothesis order inside
+// every workgroup's segment; the order only decides which thread scores which proposal.
 __global__ void __launch_bounds__(256) cuboid_sweep_corners(const Unit *units, int n_units, int blocks_per_unit, const FrameDyn *fd, Opts o,
                                                             const VPEntry *vpt, uint8_t *flag, double *corners, long hyp_total, int *vcount,
                                                             int *vlist) {
     __shared__ int s_list[2][SWEEP_HB / 2];
-    __shared__ int s_count[2], s_base[2];
+    __shared__ int s_wc[2][SWEEP_HB / 64]; // survivors per (round, wave) and configuration
+    __shared__ int s_base[2];
     const int b = blockIdx.x;
     const int xcd = b & 7, slot = b >> 3;
     const int u = (slot / blocks_per_unit) * 8 + xcd, blk = slot % blocks_per_unit;
@@ -792,33 +805,45 @@ __global__ void __launch_bounds__(256) cuboid_sweep_corners(const Unit *units, i
     const int n_hyp = n_rp * n_yaw * U.n_tops * 2;
     const int h0 = blk * SWEEP_HB;
     if (h0 >= U.hyp_cap) return;
-    if (threadIdx.x < 2) s_count[threadIdx.x] = 0;
-    __syncthreads();
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    int rank[SWEEP_HB / 256]; // rank among the survivors of the same configuration in this wave and round, -1 = rejected
     for (int r = 0; r < SWEEP_HB / 256; r++) {
         int h = h0 + r * 256 + threadIdx.x;
-        if (h >= U.hyp_cap) break;
-        long g = U.hyp_off + h;
         int pos = 0;
-        if (h < n_hyp) {
-            int cfg = (h & 1) + 1, q = h >> 1;
-            int ti = q % U.n_tops; q /= U.n_tops;
-            if ((cfg == 1 && o.cfg1) || (cfg == 2 && o.cfg2)) {
-                const VPEntry &E = vpt[(long)U.vp_off + q];
-                V2 c[8];
-                pos = make_corners(U, E, U.top_start + ti * U.top_step, cfg, c);
-                if (pos) {
+        if (h < U.hyp_cap) {
+            long g = U.hyp_off + h;
+            if (h < n_hyp) {
+                int cfg = (h & 1) + 1, q = h >> 1;
+                int ti = q % U.n_tops; q /= U.n_tops;
+                if ((cfg == 1 && o.cfg1) || (cfg == 2 && o.cfg2)) {
+                    const VPEntry &E = vpt[(long)U.vp_off + q];
+                    V2 c[8];
+                    pos = make_corners(U, E, U.top_start + ti * U.top_step, cfg, c);
+                    if (pos) {
 #pragma unroll
-                    for (int k = 0; k < 8; k++) { corners[(long)k * hyp_total + g] = c[k].x; corners[(long)(8 + k) * hyp_total + g] = c[k].y; }
-                    s_list[cfg - 1][atomicAdd(&s_count[cfg - 1], 1)] = h;
+                        for (int k = 0; k < 8; k++) { corners[(long)k * hyp_total + g] = c[k].x; corners[(long)(8 + k) * hyp_total + g] = c[k].y; }
+                    }
                 }
             }
+            flag[g] = (uint8_t)pos;
         }
-        flag[g] = (uint8_t)pos;
+        // h0 and r*256 are even, so lane parity = configuration: even lanes are configuration 1
+        const unsigned long long m = __ballot(pos != 0);
+        const unsigned long long mine = (lane & 1) ? (m & 0xAAAAAAAAAAAAAAAAull) : (m & 0x5555555555555555ull);
+        rank[r] = pos ? __popcll(mine & ((1ull << lane) - 1)) : -1;
+        if (lane < 2) s_wc[lane][r * 4 + wave] = __popcll(m & (lane ? 0xAAAAAAAAAAAAAAAAull : 0x5555555555555555ull));
     }
     __syncthreads();
-    const int c1 = s_count[0], c2 = s_count[1];
+    // ordered compaction: list position = survivors of the same configuration in earlier (round, wave) pairs + rank
+    const int c = lane & 1;
+    int before = 0, total[2] = {0, 0};
+    for (int i = 0; i < SWEEP_HB / 64; i++) { total[0] += s_wc[0][i]; total[1] += s_wc[1][i]; }
+    for (int r = 0; r < SWEEP_HB / 256; r++) {
+        for (int w = 0; w < 4; w++) { if (w == wave && rank[r] >= 0) s_list[c][before + rank[r]] = h0 + r * 256 + threadIdx.x; before += s_wc[c][r * 4 + w]; }
+    }
+    const int c1 = total[0], c2 = total[1];
     if (c1 + c2 == 0) return;
-    if (threadIdx.x < 2 && s_count[threadIdx.x] > 0) s_base[threadIdx.x] = atomicAdd(&vcount[2 * u + threadIdx.x], s_count[threadIdx.x]);
+    if (threadIdx.x < 2 && total[threadIdx.x] > 0) s_base[threadIdx.x] = atomicAdd(&vcount[2 * u + threadIdx.x], total[threadIdx.x]);
     __syncthreads();
     int *d1 = vlist + U.hyp_off + s_base[0], *d2 = vlist + U.hyp_off + U.hyp_cap - 1 - s_base[1];
     for (int s = threadIdx.x; s < c1; s += 256) d1[s] = s_list[0][s];
@@ -830,12 +855,12 @@ __global__ void __launch_bounds__(256) cuboid_sweep_corners(const Unit *units, i
 // a unit's workgroups cover its configuration-1 list first, then its configuration-2 list.
 constexpr int SCORE_PB = 256;
 template <int CFG> __device__ __forceinline__ void score_one(const Unit &U, int h, const VPEntry *vpt, const float *dist, const double *corners, long hyp_total,
-                                                             double *sc, double *derr, double *aerr) {
+                                                             double *sc, float *scp, double *derr, double *aerr) {
     const long g = U.hyp_off + h;
     const int q = (h >> 1) / U.n_tops;
 #pragma unroll
     for (int k = 0; k < 16; k++) sc[k * 256] = corners[(long)k * hyp_total + g];
-    const float sum_dist = edge_sum_dists_lds<CFG>(sc, dist + U.pix_off, U.roi_w, U.roi_w * U.roi_h - 1, (double)U.roi_x, (double)U.roi_y);
+    const float sum_dist = edge_sum_dists_lds<CFG>(sc, scp, dist + U.pix_off, U.roi_w, U.roi_w * U.roi_h - 1, (double)U.roi_x, (double)U.roi_y);
     derr[g] = double(sum_dist) / U.diag; // :451
     aerr[g] = edge_angle_error_lds<CFG>(vpt[(long)U.vp_off + q], sc);
 }
@@ -843,7 +868,9 @@ __global__ void __launch_bounds__(256) cuboid_sweep_score(const Unit *units, int
                                                           const double *corners, long hyp_total, const int *vcount, const int *vlist, double *derr,
                                                           double *aerr) {
     __shared__ double s_c[16 * 256]; // the thread's proposal corners: column threadIdx.x, no sharing between threads
+    __shared__ float s_cp[8 * 256];  // distance-map values at the corners
     double *sc = s_c + threadIdx.x;
+    float *scp = s_cp + threadIdx.x;
     const int b = blockIdx.x;
     const int xcd = b & 7, slot = b >> 3;
     const int u = (slot / blocks_per_unit) * 8 + xcd;
@@ -854,10 +881,10 @@ __global__ void __launch_bounds__(256) cuboid_sweep_score(const Unit *units, int
     const Unit &U = units[u];
     if (blk < nb1) {
         const int s = blk * SCORE_PB + threadIdx.x;
-        if (s < c1) score_one<1>(U, vlist[U.hyp_off + s], vpt, dist, corners, hyp_total, sc, derr, aerr);
+        if (s < c1) score_one<1>(U, vlist[U.hyp_off + s], vpt, dist, corners, hyp_total, sc, scp, derr, aerr);
     } else {
         const int s = (blk - nb1) * SCORE_PB + threadIdx.x;
-        if (s < c2) score_one<2>(U, vlist[U.hyp_off + U.hyp_cap - 1 - s], vpt, dist, corners, hyp_total, sc, derr, aerr);
+        if (s < c2) score_one<2>(U, vlist[U.hyp_off + U.hyp_cap - 1 - s], vpt, dist, corners, hyp_total, sc, scp, derr, aerr);
     }
 }
 
