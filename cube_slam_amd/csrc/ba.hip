@@ -457,6 +457,246 @@ __global__ void __launch_bounds__(256) ba_schur_b(Params G, const int *pose_off,
     if (lane == 0) for (int k = 0; k < 6; k++) bs[(long)pi * 6 + k] = G.bp[(long)pi * 6 + k] + acc[k];
 }
 
+// ------------------------------------------------------------------------------------------------ band path of the reduced solve
+// When no two cuboids share a block of the reduced system (always true for the graphs Optimizer.cc builds: cuboids only meet
+// cameras) the cuboids are eliminated like landmarks -- 6x6 blocks, independent, in parallel -- and what remains is a system
+// over the cameras whose blocks couple cameras that share a landmark or a cuboid.  For a trajectory that is block-banded with a
+// small half-width Bc (9 for the 1k-keyframe benchmark graph), and it is factored by ONE workgroup that keeps the active
+// (Bc+1) x (Bc+1) window of blocks in LDS: no global-memory round trip on the critical path of a column (the sparse kernel
+// below pays three per column).  Exact same system as BlockSolver::solve, different elimination order (round-off only).
+struct CubInv { double D[36]; double g[6]; };
+
+// D_q = (H_qq)^-1 (Cholesky inverse), g_q = D_q b_q.  S: slots, bs: right-hand side of the reduced system (6P)
+__global__ void __launch_bounds__(64) ba_cub_inv(int C, int Q, const double *S, const double *bs, double *cubD, double *cubg, int *status) {
+    const int q = blockIdx.x * 64 + threadIdx.x;
+    if (q >= Q) return;
+    double A[36], Li[36];
+    const double *H = S + (long)(C + q) * 36;
+    for (int k = 0; k < 36; k++) A[k] = H[k];
+    bool fail = false;
+    for (int c = 0; c < 6; c++) { // A = L L^T, in place (lower)
+        double d = A[c * 6 + c];
+        for (int t = 0; t < c; t++) d -= A[c * 6 + t] * A[c * 6 + t];
+        if (!(d > 0)) { fail = true; d = 1; }
+        d = sqrt(d);
+        A[c * 6 + c] = d;
+        for (int r = c + 1; r < 6; r++) { double v = A[r * 6 + c]; for (int t = 0; t < c; t++) v -= A[r * 6 + t] * A[c * 6 + t]; A[r * 6 + c] = v / d; }
+    }
+    for (int c = 0; c < 6; c++) // Li = L^-1 (lower)
+        for (int r = 0; r < 6; r++) {
+            if (r < c) { Li[r * 6 + c] = 0; continue; }
+            double v = r == c ? 1.0 : 0.0;
+            for (int t = c; t < r; t++) v -= A[r * 6 + t] * Li[t * 6 + c];
+            Li[r * 6 + c] = v / A[r * 6 + r];
+        }
+    double *D = cubD + (long)q * 36, *g = cubg + (long)q * 6;
+    for (int r = 0; r < 6; r++)
+        for (int c = 0; c < 6; c++) { double v = 0; for (int t = (r > c ? r : c); t < 6; t++) v += Li[t * 6 + r] * Li[t * 6 + c]; D[r * 6 + c] = v; }
+    const double *bq = bs + (long)(C + q) * 6;
+    for (int r = 0; r < 6; r++) { double v = 0; for (int c = 0; c < 6; c++) v += D[r * 6 + c] * bq[c]; g[r] = v; }
+    if (fail) *status = 1;
+}
+// band[target] = camera block of the reduced system - sum over the cuboids seen by both cameras of H_iq D_q H_kq^T.
+// One thread per (target block, element); fixed summation order.  ct_list: (cuboid, slot of edge (i,q), slot of edge (k,q)).
+__global__ void __launch_bounds__(256) ba_band_assemble(int n_targets, const int *tgt_slot, const uint8_t *tgt_tr, const int *ct_off, const int *ct_list, const double *S,
+                                                        const double *cubD, double *band) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= n_targets * 36) return;
+    const int tg = t / 36, k = t % 36, r = k / 6, c = k % 6;
+    double acc = 0;
+    const int sl = tgt_slot[tg];
+    if (sl >= 0) acc = tgt_tr[tg] ? S[(long)sl * 36 + c * 6 + r] : S[(long)sl * 36 + k];
+    for (int e = ct_off[tg]; e < ct_off[tg + 1]; e++) {
+        const double *D = cubD + (long)ct_list[e * 3] * 36, *Hi = S + (long)ct_list[e * 3 + 1] * 36 + r * 6, *Hk = S + (long)ct_list[e * 3 + 2] * 36 + c * 6;
+        double v = 0;
+        for (int a = 0; a < 6; a++) { double w = 0; for (int bb = 0; bb < 6; bb++) w += D[a * 6 + bb] * Hk[bb]; v += Hi[a] * w; }
+        acc -= v;
+    }
+    band[t] = acc;
+}
+// rhs_i = b_i - sum over the cuboids seen by camera i of H_iq g_q.  cr_list: (cuboid, slot)
+__global__ void __launch_bounds__(256) ba_band_rhs(int C, const int *cr_off, const int *cr_list, const double *S, const double *bs, const double *cubg, double *rhs) {
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= C * 6) return;
+    const int i = t / 6, r = t % 6;
+    double acc = bs[t];
+    for (int e = cr_off[i]; e < cr_off[i + 1]; e++) {
+        const double *g = cubg + (long)cr_list[e * 2] * 6, *H = S + (long)cr_list[e * 2 + 1] * 36 + r * 6;
+        double v = 0;
+        for (int a = 0; a < 6; a++) v += H[a] * g[a];
+        acc -= v;
+    }
+    rhs[t] = acc;
+}
+// x_q = g_q - D_q sum over the cameras that see cuboid q of H_iq^T x_i.  cq_list: (slot, camera)
+__global__ void __launch_bounds__(64) ba_cub_back(int C, int Q, const int *cq_off, const int *cq_list, const double *S, const double *cubD, const double *cubg, double *x) {
+    const int q = blockIdx.x * 64 + threadIdx.x;
+    if (q >= Q) return;
+    double w[6] = {0, 0, 0, 0, 0, 0};
+    for (int e = cq_off[q]; e < cq_off[q + 1]; e++) {
+        const double *H = S + (long)cq_list[e * 2] * 36, *xi = x + (long)cq_list[e * 2 + 1] * 6;
+        for (int c = 0; c < 6; c++) { double v = 0; for (int r = 0; r < 6; r++) v += H[r * 6 + c] * xi[r]; w[c] += v; }
+    }
+    const double *D = cubD + (long)q * 36, *g = cubg + (long)q * 6;
+    for (int r = 0; r < 6; r++) { double v = 0; for (int c = 0; c < 6; c++) v += D[r * 6 + c] * w[c]; x[(long)(C + q) * 6 + r] = g[r] - v; }
+}
+// Block-band Cholesky + both triangular solves in one workgroup.  A: C columns x (Bc+1) blocks (block d of column j = block
+// (j+d, j), row-major 6x6), Lf: same layout, receives L; rhs: in b (6C), out x; ybuf: 12C scratch (y_j, 1/diag L_jj).  LDS: a ring of Bc+2 columns (the extra slot
+// receives column j+Bc+1 while column j is processed) and the matching right-hand-side window.
+// workgroup barrier that orders LDS traffic only: __syncthreads() also drains the global-memory counter, i.e. every barrier
+// would wait for the stores of the finished column and the prefetch loads of the next one to be acknowledged by the L2
+// (measured: 5.4 us per column with __syncthreads()); global data written here is never re-read by this kernel
+// through a cached path before the kernel ends (Lf / ybuf are read back with non-temporal loads long after they were written)
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
+__global__ void __launch_bounds__(256) ba_band_chol(int C, int Bc, const double *A, double *Lf, double *rhs, double *ybuf, int *status) {
+    extern __shared__ double sh[];
+    const int NB = Bc + 1, NS = Bc + 2, CS = NB * 36;
+    double *W = sh, *bw = W + (long)NS * CS, *yj = bw + NS * 6, *Linv = yj + 6, *part = Linv + 6; // part: 8 x 6 partial sums (back substitution)
+    int *pair_d = (int *)(part + 48); // pair -> (di << 8 | dk)
+    const int tid = threadIdx.x;
+    for (int pr = tid; pr < Bc * (Bc + 1) / 2; pr += 256) {
+        int di = (int)((sqrt(8.0 * pr + 1.0) - 1.0) * 0.5);
+        while (di * (di + 1) / 2 > pr) di--;
+        while ((di + 1) * (di + 2) / 2 <= pr) di++;
+        pair_d[pr] = ((di + 1) << 8) | (pr - di * (di + 1) / 2 + 1);
+    }
+    const int n0 = C < NB ? C : NB;
+    for (int i = tid; i < n0 * CS; i += 256) W[i] = A[i];           // columns 0..n0-1 sit in slots 0..n0-1
+    for (int i = tid; i < n0 * 6; i += 256) bw[i] = rhs[i];
+    __syncthreads();
+    bool fail = false;
+    for (int j = 0; j < C; j++) {
+        double *Wc = W + (long)(j % NS) * CS;
+        const int nd = (C - 1 - j) < Bc ? (C - 1 - j) : Bc;
+        const int cn = j + Bc + 1;
+        // next column: loads issued now, stored to the free LDS slot at the end of the step (global latency off the critical path)
+        double pf[4] = {0, 0, 0, 0}, pfb = 0;
+        if (cn < C) {
+            const double *src = A + (long)cn * CS;
+#pragma unroll
+            for (int u = 0; u < 4; u++) if (tid + u * 256 < CS) pf[u] = src[tid + u * 256];
+            if (tid < 6) pfb = rhs[(long)cn * 6 + tid];
+        }
+        if (tid == 0) { // L_jj and y_j = L_jj^-1 b_j; 1/sqrt(pivot) from v_rsq_f64 + two Newton steps (the six pivots are a serial chain)
+            double M[36];
+            for (int k = 0; k < 36; k++) M[k] = Wc[k];
+            for (int c = 0; c < 6; c++) {
+                double d = M[c * 6 + c];
+                for (int t = 0; t < c; t++) d -= M[c * 6 + t] * M[c * 6 + t];
+                if (!(d > 0)) { fail = true; d = 1; }
+                double inv = __builtin_amdgcn_rsq(d);
+                inv = inv * (1.5 - (0.5 * d) * (inv * inv));
+                inv = inv * (1.5 - (0.5 * d) * (inv * inv));
+                M[c * 6 + c] = d * inv; Linv[c] = inv;
+                for (int r = c + 1; r < 6; r++) { double v = M[r * 6 + c]; for (int t = 0; t < c; t++) v -= M[r * 6 + t] * M[c * 6 + t]; M[r * 6 + c] = v * inv; }
+                for (int r = 0; r < c; r++) M[r * 6 + c] = 0;
+            }
+            double y[6];
+            const double *bj = bw + (j % NS) * 6;
+            for (int r = 0; r < 6; r++) { double v = bj[r]; for (int t = 0; t < r; t++) v -= M[r * 6 + t] * y[t]; y[r] = v * Linv[r]; }
+            for (int k = 0; k < 36; k++) Wc[k] = M[k];
+            for (int r = 0; r < 6; r++) yj[r] = y[r];
+        }
+        lds_barrier();
+        for (int t = tid; t < nd * 6; t += 256) { // L_d = A_d L_jj^-T, one block row per thread
+            double *blk = Wc + (1 + t / 6) * 36 + (t % 6) * 6;
+            double row[6];
+            for (int c = 0; c < 6; c++) { double v = blk[c]; for (int q = 0; q < c; q++) v -= row[q] * Wc[c * 6 + q]; row[c] = v * Linv[c]; }
+            for (int c = 0; c < 6; c++) blk[c] = row[c];
+        }
+        lds_barrier();
+        const int npair = nd * (nd + 1) / 2;
+        for (int t = tid; t < npair * 6 + nd * 6; t += 256) {
+            if (t < npair * 6) { // row r of block (j+di, j+dk) -= (row r of L_di) L_dk^T: the row of L_di stays in registers
+                const int pr = t / 6, r = t % 6, di = pair_d[pr] >> 8, dk = pair_d[pr] & 255;
+                const double *Li = Wc + di * 36 + r * 6, *Lk = Wc + dk * 36;
+                double a[6];
+#pragma unroll
+                for (int q = 0; q < 6; q++) a[q] = Li[q];
+                double *T = W + (long)((j + dk) % NS) * CS + (di - dk) * 36 + r * 6;
+                double tv[6];
+#pragma unroll
+                for (int c = 0; c < 6; c++) tv[c] = T[c];
+#pragma unroll
+                for (int c = 0; c < 6; c++) { // fused multiply-adds: the solver's round-off is not part of the parity contract
+#pragma unroll
+                    for (int q = 0; q < 6; q++) tv[c] = __builtin_fma(-a[q], Lk[c * 6 + q], tv[c]);
+                }
+#pragma unroll
+                for (int c = 0; c < 6; c++) T[c] = tv[c];
+            } else { // b_{j+d} -= L_d y_j
+                const int u = t - npair * 6, d = 1 + u / 6, r = u % 6;
+                const double *Ld = Wc + d * 36 + r * 6;
+                double v = 0;
+#pragma unroll
+                for (int q = 0; q < 6; q++) v += Ld[q] * yj[q];
+                bw[((j + d) % NS) * 6 + r] -= v;
+            }
+        }
+        for (int i = tid; i < (nd + 1) * 36; i += 256) Lf[(long)j * CS + i] = Wc[i];
+        if (tid < 12) ybuf[(long)j * 12 + tid] = tid < 6 ? yj[tid] : Linv[tid - 6]; // a buffer this kernel has not read before: no stale L1 line possible
+        if (cn < C) {
+            double *dst = W + (long)(cn % NS) * CS;
+#pragma unroll
+            for (int u = 0; u < 4; u++) if (tid + u * 256 < CS) dst[tid + u * 256] = pf[u];
+            if (tid < 6) bw[(cn % NS) * 6 + tid] = pfb;
+        }
+        lds_barrier();
+    }
+    // L^T x = y, last column first; xw: ring of solved blocks (re-uses the right-hand-side window); the columns of L come back
+    // from global memory through two LDS buffers, column j-1 is in flight while column j is used
+    double *xw = bw, *Lbuf = W, *ybuf2 = W + 2 * (long)CS; // ybuf2: 2 x 12 (y_j, 1/diag)
+    {
+        const int j = C - 1;
+        for (int i = tid; i < 36; i += 256) Lbuf[(long)(j & 1) * CS + i] = __builtin_nontemporal_load(Lf + (long)j * CS + i);
+        if (tid < 12) ybuf2[(j & 1) * 12 + tid] = __builtin_nontemporal_load(ybuf + (long)j * 12 + tid);
+    }
+    lds_barrier();
+    for (int j = C - 1; j >= 0; j--) {
+        const int nd = (C - 1 - j) < Bc ? (C - 1 - j) : Bc;
+        const double *Lc = Lbuf + (long)(j & 1) * CS, *yl = ybuf2 + (j & 1) * 12;
+        double pf[4] = {0, 0, 0, 0}, pfy = 0;
+        const int jn = j - 1, ndn = (C - 1 - jn) < Bc ? (C - 1 - jn) : Bc;
+        if (j > 0) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) if (tid + u * 256 < (ndn + 1) * 36) pf[u] = __builtin_nontemporal_load(Lf + (long)jn * CS + tid + u * 256);
+            if (tid < 12) pfy = __builtin_nontemporal_load(ybuf + (long)jn * 12 + tid);
+        }
+        if (tid < 48) { // partial sums over d = 1 + part, 9 + part, ...
+            const int c = tid % 6, pt = tid / 6;
+            double v = 0;
+            for (int d = 1 + pt; d <= nd; d += 8) { const double *Ld = Lc + d * 36, *xd = xw + ((j + d) % NS) * 6; for (int q = 0; q < 6; q++) v += Ld[q * 6 + c] * xd[q]; }
+            part[pt * 6 + c] = v;
+        }
+        lds_barrier();
+        if (tid < 64) { // lanes 0..5 of wave 0 hold s_c; back substitution with L_jj^T by lane broadcasts
+            const int c = tid < 6 ? tid : 0;
+            double sv = yl[c];
+            for (int pt = 0; pt < 8; pt++) sv -= part[pt * 6 + c];
+            double lcol[6]; // lcol[r] = L[r][c]
+#pragma unroll
+            for (int r = 0; r < 6; r++) lcol[r] = Lc[r * 6 + c];
+            const double inv = yl[6 + c];
+            double xv = 0;
+#pragma unroll
+            for (int k = 5; k >= 0; k--) {
+                const double cand = sv * inv;
+                const double xk = __shfl(cand, k); // x_k, final because lanes > k already contributed
+                if (tid == k) xv = xk;
+                if (tid < k) sv -= lcol[k] * xk; // s_c -= L[k][c] x_k
+            }
+            if (tid < 6) { xw[(j % NS) * 6 + tid] = xv; rhs[(long)j * 6 + tid] = xv; }
+        }
+        if (j > 0) {
+#pragma unroll
+            for (int u = 0; u < 4; u++) if (tid + u * 256 < (ndn + 1) * 36) Lbuf[(long)(jn & 1) * CS + tid + u * 256] = pf[u];
+            if (tid < 12) ybuf2[(jn & 1) * 12 + tid] = pfy;
+        }
+        lds_barrier();
+    }
+    if (tid == 0 && fail) *status = 1;
+}
+
 // scatter the (all-reduced) blocks of the reduced system into the factor storage Lb = [P diagonal blocks | off-diagonal
 // blocks column by column in elimination order]; slot_dst[s] = destination block (-1: dead), slot_tr[s] = transpose
 __global__ void ba_chol_fill(int n_slots, const int *slot_dst, const uint8_t *slot_tr, const double *S, double *Lb) {
@@ -626,6 +866,11 @@ struct cs_ba {
     double *d_reduce = nullptr, *d_band = nullptr, *d_xperm = nullptr, *d_partials = nullptr, *d_scal = nullptr;
     double *d_bak_cam = nullptr, *d_bak_pts = nullptr, *d_bak_cub = nullptr;
     long reduce_len = 0, band_len = 0; // band_len: doubles of the factor storage
+    // band path (see ba_band_chol): cuboids eliminated first, cameras block-banded with half-width band_bc
+    bool use_band = false; int band_C = 0, band_Q = 0, band_bc = 0, band_targets = 0;
+    int *d_tgt_slot = nullptr, *d_ct_off = nullptr, *d_ct_list = nullptr, *d_cr_off = nullptr, *d_cr_list = nullptr, *d_cq_off = nullptr, *d_cq_list = nullptr;
+    uint8_t *d_tgt_tr = nullptr;
+    double *d_bandA = nullptr, *d_bandL = nullptr, *d_cubD = nullptr, *d_cubg = nullptr, *d_brhs = nullptr, *d_ybuf = nullptr;
     std::vector<int> h_slot_dst, h_pos, h_col_off, h_rows; std::vector<uint8_t> h_slot_tr;
     std::vector<int> obs_perm; // sorted-by-landmark position -> caller's observation index
     std::vector<double> h_partials;
@@ -699,6 +944,27 @@ static int ba_solve(cs_ctx *ctx, cs_ba *b, double lambda, bool *ok) { // BlockSo
         ctx->end();
         if (rc != 0) { ctx->err = "all-reduce callback failed"; return CS_ERR_HIP; }
     }
+    const int nl = G.lm_e - G.lm_b;
+    if (b->use_band) {
+        const int C = b->band_C, Q = b->band_Q, Bc = b->band_bc;
+        const double *S = b->d_reduce, *bs = b->d_reduce + (long)b->n_slots * 36;
+        CS_HIP(ctx, hipMemsetAsync(b->d_status, 0, sizeof(int), ctx->stream));
+        if (Q > 0) CS_LAUNCH(ctx, "ba_cub_inv", ba_cub_inv, dim3((Q + 63) / 64), dim3(64), 0, C, Q, S, bs, b->d_cubD, b->d_cubg, b->d_status);
+        CS_LAUNCH(ctx, "ba_band_assemble", ba_band_assemble, dim3((b->band_targets * 36 + 255) / 256), dim3(256), 0, b->band_targets, b->d_tgt_slot, b->d_tgt_tr, b->d_ct_off,
+                  b->d_ct_list, S, b->d_cubD, b->d_bandA);
+        CS_LAUNCH(ctx, "ba_band_rhs", ba_band_rhs, dim3((C * 6 + 255) / 256), dim3(256), 0, C, b->d_cr_off, b->d_cr_list, S, bs, b->d_cubg, b->d_brhs);
+        const size_t lds = sizeof(double) * ((size_t)(Bc + 2) * (Bc + 1) * 36 + (size_t)(Bc + 2) * 6 + 6 + 6 + 48) + sizeof(int) * (size_t)std::max(1, Bc * (Bc + 1) / 2);
+        if (lds > 64 * 1024) CS_HIP(ctx, hipFuncSetAttribute((const void *)ba_band_chol, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+        CS_LAUNCH(ctx, "ba_band_chol", ba_band_chol, dim3(1), dim3(256), lds, C, Bc, b->d_bandA, b->d_bandL, b->d_brhs, b->d_ybuf, b->d_status);
+        CS_HIP(ctx, hipMemcpyAsync(G.x, b->d_brhs, sizeof(double) * (size_t)C * 6, hipMemcpyDeviceToDevice, ctx->stream));
+        if (Q > 0) CS_LAUNCH(ctx, "ba_cub_back", ba_cub_back, dim3((Q + 63) / 64), dim3(64), 0, C, Q, b->d_cq_off, b->d_cq_list, S, b->d_cubD, b->d_cubg, G.x);
+        if (nl > 0) CS_LAUNCH(ctx, "ba_backsub", ba_backsub, dim3((nl + 255) / 256), dim3(256), 0, G);
+        int status = 0;
+        r = cs_d2h(ctx, &status, b->d_status, 1); if (r) return r;
+        CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        *ok = status == 0;
+        return CS_OK;
+    }
     CS_HIP(ctx, hipMemsetAsync(b->d_band, 0, sizeof(double) * (size_t)b->band_len, ctx->stream));
     CS_LAUNCH(ctx, "ba_chol_fill", ba_chol_fill, dim3((b->n_slots * 36 + 255) / 256), dim3(256), 0, b->n_slots, b->d_slot_dst, b->d_slot_tr, b->d_reduce, b->d_band);
     CS_LAUNCH(ctx, "ba_chol_factor", ba_chol_factor, dim3(1), dim3(512), sizeof(double) * (36 + (size_t)std::max(b->max_col, 1) * 36), G.P, b->d_col_off, b->d_pair_off,
@@ -706,7 +972,6 @@ static int ba_solve(cs_ctx *ctx, cs_ba *b, double lambda, bool *ok) { // BlockSo
     CS_LAUNCH(ctx, "ba_permute", ba_permute, dim3((G.P * 6 + 255) / 256), dim3(256), 0, G.P, b->d_pos, b->d_reduce + (long)b->n_slots * 36, b->d_xperm, 1);
     CS_LAUNCH(ctx, "ba_chol_solve", ba_chol_solve, dim3(1), dim3(256), 0, G.P, b->d_col_off, b->d_rows, b->d_band, b->d_xperm);
     CS_LAUNCH(ctx, "ba_permute", ba_permute, dim3((G.P * 6 + 255) / 256), dim3(256), 0, G.P, b->d_pos, b->d_xperm, G.x, 0);
-    const int nl = G.lm_e - G.lm_b;
     if (nl > 0) CS_LAUNCH(ctx, "ba_backsub", ba_backsub, dim3((nl + 255) / 256), dim3(256), 0, G);
     int status = 0;
     r = cs_d2h(ctx, &status, b->d_status, 1); if (r) return r;
@@ -816,6 +1081,62 @@ int cs_ba_create(cs_ctx *ctx, const cs_ba_problem *p, int rank, int world, cs_ba
     std::vector<int2> trips;
     for (int s = 0; s < b->n_slots; s++) { slot_off[s + 1] = slot_off[s] + (int)slot_trips[s].size(); trips.insert(trips.end(), slot_trips[s].begin(), slot_trips[s].end()); }
     if (trips.empty()) trips.push_back(make_int2(0, 0));
+    // ---- band path plan: cuboids eliminated first, cameras in index order; used when the camera system is narrow-banded
+    std::vector<int> tgt_slot, ct_off, ct_list, cr_off, cr_list, cq_off, cq_list;
+    std::vector<uint8_t> tgt_tr;
+    {
+        const int C = first_cub, Q = p->n_cuboids;
+        bool okb = C >= 1;
+        int Bc = 0;
+        for (auto &rc : slot_rc) {
+            if (rc.first < 0) continue;
+            if (rc.first >= C && rc.second >= C && rc.first != rc.second) okb = false; // two cuboids in one block: not a graph Optimizer.cc builds
+            if (rc.first < C && rc.second < C) Bc = std::max(Bc, std::abs(rc.first - rc.second));
+        }
+        std::vector<std::vector<std::pair<int, int>>> cub_edges(Q); // (camera, slot), alive edges only
+        for (int o = 0; o < p->n_cobs; o++) { const int pi = cam_idx[p->cobs_cam[o]]; if (pi >= 0) cub_edges[p->cobs_cuboid[o]].push_back(std::make_pair(pi, P + o)); }
+        for (auto &e : cub_edges) { std::stable_sort(e.begin(), e.end()); if (!e.empty()) Bc = std::max(Bc, e.back().first - e.front().first); }
+        const char *force = getenv("CUBESLAM_BA_SOLVER"); // "sparse" / "band": pick the path (tests run both)
+        const int BAND_MAX = 20; // (Bc+2)(Bc+1) blocks of 288 B must fit the 160 KB LDS
+        if (force && !strcmp(force, "sparse")) okb = false;
+        if (Bc > BAND_MAX) okb = false;
+        if (force && !strcmp(force, "band") && !okb) { ctx->err = "CUBESLAM_BA_SOLVER=band: the reduced camera system is not narrow-banded"; delete b; return CS_ERR_CAPACITY; }
+        if (okb) {
+            b->use_band = true; b->band_C = C; b->band_Q = Q; b->band_bc = Bc; b->band_targets = C * (Bc + 1);
+            tgt_slot.assign((size_t)C * (Bc + 1), -1); tgt_tr.assign((size_t)C * (Bc + 1), 0);
+            for (int s2 = 0; s2 < (int)slot_rc.size(); s2++) {
+                const int r0 = slot_rc[s2].first, c0 = slot_rc[s2].second;
+                if (r0 < 0 || r0 >= C || c0 >= C) continue;
+                if (s2 >= P && s2 < P + p->n_cobs) continue;
+                // stored block = (rows r0, cols c0); the band keeps block (i, k) with i >= k
+                if (r0 >= c0) { tgt_slot[(size_t)c0 * (Bc + 1) + (r0 - c0)] = s2; tgt_tr[(size_t)c0 * (Bc + 1) + (r0 - c0)] = 0; }
+                else { tgt_slot[(size_t)r0 * (Bc + 1) + (c0 - r0)] = s2; tgt_tr[(size_t)r0 * (Bc + 1) + (c0 - r0)] = 1; }
+            }
+            std::vector<std::vector<int>> ct((size_t)C * (Bc + 1));
+            std::vector<std::vector<int>> cr(C);
+            cq_off.assign(Q + 1, 0);
+            for (int q = 0; q < Q; q++) {
+                const auto &e = cub_edges[q];
+                for (size_t a = 0; a < e.size(); a++) {
+                    cr[e[a].first].push_back(q); cr[e[a].first].push_back(e[a].second);
+                    cq_list.push_back(e[a].second); cq_list.push_back(e[a].first);
+                    for (size_t c2 = 0; c2 < e.size(); c2++) {
+                        if (e[a].first < e[c2].first) continue; // target block (i, k) with i >= k; equal cameras: every ordered pair
+                        auto &l = ct[(size_t)e[c2].first * (Bc + 1) + (e[a].first - e[c2].first)];
+                        l.push_back(q); l.push_back(e[a].second); l.push_back(e[c2].second);
+                    }
+                }
+                cq_off[q + 1] = (int)(cq_list.size() / 2);
+            }
+            ct_off.assign(ct.size() + 1, 0);
+            for (size_t t = 0; t < ct.size(); t++) { ct_off[t + 1] = ct_off[t] + (int)(ct[t].size() / 3); ct_list.insert(ct_list.end(), ct[t].begin(), ct[t].end()); }
+            cr_off.assign(C + 1, 0);
+            for (int i = 0; i < C; i++) { cr_off[i + 1] = cr_off[i] + (int)(cr[i].size() / 2); cr_list.insert(cr_list.end(), cr[i].begin(), cr[i].end()); }
+            if (ct_list.empty()) ct_list.assign(3, 0);
+            if (cr_list.empty()) cr_list.assign(2, 0);
+            if (cq_list.empty()) cq_list.assign(2, 0);
+        }
+    }
     // ordering of the pose blocks: minimum degree on the block graph (the reference lets Eigen::SimplicialLDLT order with AMD,
     // linear_solver_eigen.h:60-75); the simulated elimination also yields the structure of every column of L
     std::vector<std::vector<int>> adj(P);
@@ -941,6 +1262,23 @@ int cs_ba_create(cs_ctx *ctx, const cs_ba_problem *p, int rank, int world, cs_ba
     A_(dalloc_copy(ctx, b, &b->d_upd_tgt, upd_tgt.data(), upd_tgt.size()));
     A_(dalloc_copy(ctx, b, &b->d_pos, pos.data(), pos.size()));
     A_(dalloc_copy(ctx, b, &b->d_status, (const int *)nullptr, 1));
+    if (b->use_band) {
+        const size_t nt = (size_t)b->band_targets;
+        A_(dalloc_copy(ctx, b, &b->d_tgt_slot, tgt_slot.data(), tgt_slot.size()));
+        A_(dalloc_copy(ctx, b, &b->d_tgt_tr, tgt_tr.data(), tgt_tr.size()));
+        A_(dalloc_copy(ctx, b, &b->d_ct_off, ct_off.data(), ct_off.size()));
+        A_(dalloc_copy(ctx, b, &b->d_ct_list, ct_list.data(), ct_list.size()));
+        A_(dalloc_copy(ctx, b, &b->d_cr_off, cr_off.data(), cr_off.size()));
+        A_(dalloc_copy(ctx, b, &b->d_cr_list, cr_list.data(), cr_list.size()));
+        A_(dalloc_copy(ctx, b, &b->d_cq_off, cq_off.data(), cq_off.size()));
+        A_(dalloc_copy(ctx, b, &b->d_cq_list, cq_list.data(), cq_list.size()));
+        A_(dalloc_copy(ctx, b, &b->d_bandA, (const double *)nullptr, nt * 36));
+        A_(dalloc_copy(ctx, b, &b->d_bandL, (const double *)nullptr, nt * 36));
+        A_(dalloc_copy(ctx, b, &b->d_cubD, (const double *)nullptr, (size_t)std::max(b->band_Q, 1) * 36));
+        A_(dalloc_copy(ctx, b, &b->d_cubg, (const double *)nullptr, (size_t)std::max(b->band_Q, 1) * 6));
+        A_(dalloc_copy(ctx, b, &b->d_brhs, (const double *)nullptr, (size_t)b->band_C * 6));
+        A_(dalloc_copy(ctx, b, &b->d_ybuf, (const double *)nullptr, (size_t)b->band_C * 12));
+    }
     A_(dalloc_copy(ctx, b, &b->d_reduce, (const double *)nullptr, (size_t)b->reduce_len));
     A_(dalloc_copy(ctx, b, &b->d_band, (const double *)nullptr, (size_t)b->band_len));
     A_(dalloc_copy(ctx, b, &b->d_xperm, (const double *)nullptr, (size_t)P * 6));
