@@ -76,3 +76,36 @@ def test_all_cameras_fixed_but_one_and_stop_flag(ctx, oracle):
     st2 = ba.optimize(5, C.byref(stop))  # forceStopFlag already raised: no iteration runs
     assert st2["iterations"] == 0
     ba.close()
+
+
+def test_band_and_sparse_solvers_agree(ctx, small, monkeypatch):
+    """The two reduced-solve paths (cuboid elimination + LDS-window block-band Cholesky; minimum-degree sparse block Cholesky)
+    solve the same damped system: identical LM decisions, chi2 within round-off."""
+    res = {}
+    for solver in ("band", "sparse"):
+        monkeypatch.setenv("CUBESLAM_BA_SOLVER", solver)
+        ba = BundleAdjuster(small, ctx=ctx)
+        st = ba.optimize(6)
+        cam, pts, cub = ba.read()
+        res[solver] = (st, cam, pts, cub)
+        ba.close()
+    a, b = res["band"], res["sparse"]
+    assert a[0]["iterations"] == b[0]["iterations"] and a[0]["lm_trials"] == b[0]["lm_trials"]
+    assert np.allclose(a[0]["chi2_trace"], b[0]["chi2_trace"], rtol=1e-4)
+    assert abs(a[0]["chi2_final"] - b[0]["chi2_final"]) <= 1e-5 * b[0]["chi2_final"]
+    assert np.allclose(a[1], b[1], rtol=0, atol=1e-4) and np.allclose(a[3], b[3], rtol=0, atol=1e-4)
+    # a graph whose cameras are not narrow-banded (one landmark seen by the first and the last keyframe) takes the sparse path
+    wide = dict(small)
+    far = int(np.nonzero(1 - np.asarray(small["cam_fixed"]))[0][-1])
+    wide["obs_cam"] = np.concatenate([small["obs_cam"], [1, far]]).astype(np.int32)
+    wide["obs_point"] = np.concatenate([small["obs_point"], [0, 0]]).astype(np.int32)
+    wide["obs_uv"] = np.concatenate([small["obs_uv"], [[600.0, 170.0], [610.0, 171.0]]])
+    wide["obs_inv_sigma2"] = np.concatenate([small["obs_inv_sigma2"], [1.0, 1.0]])
+    monkeypatch.setenv("CUBESLAM_BA_SOLVER", "band")
+    with pytest.raises(Exception):
+        BundleAdjuster(wide, ctx=ctx)
+    monkeypatch.delenv("CUBESLAM_BA_SOLVER")
+    ba = BundleAdjuster(wide, ctx=ctx)
+    st = ba.optimize(2)
+    assert st["chi2_final"] <= st["chi2_init"]
+    ba.close()
