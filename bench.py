@@ -220,6 +220,13 @@ def main():
         # read once (4*A); per surviving proposal 16 corner doubles read, 2 error doubles written.
         alg_bytes = 4.0 * st["roi_pixels"] + 144.0 * st["n_valid"]
         k_us = kernels["cuboid_sweep_score"]["avg_us"]
+        traffic = None  # HBM-side bytes per launch: from the committed rocprofv3 --pmc pass of this workload (bench.py cannot host the profiler)
+        try:
+            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["cuboid_sweep_score"]
+            if args.frames == 128 and args.boxes == 3 and args.yaw_step == 0.5:
+                traffic = tj["read_bytes"] + tj["write_bytes"]
+        except Exception:
+            traffic = None
         achieved = alg_bytes / (k_us * 1e-6) / 1e9 if k_us > 0 else 0.0
         out = {
             "metric": "frames/sec front-end (%s%scuboid: Canny+DT+sweep+score+select) @640x480" % ("ORB extract + " if orb is not None else "", "LSD+LBD lines + " if lsd is not None else ""),
@@ -234,7 +241,7 @@ def main():
                        "hypotheses_per_step": st["n_hypotheses"], "valid_proposals_per_step": st["n_valid"],
                        "roi_pixels_per_step": st["roi_pixels"], "parallelism": "frames sharded, no collective"},
             "roofline": {"bound": "hbm", "kernel": "cuboid_sweep_score", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None, "avg_kernel_us": k_us,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_kernel_us": k_us,
                          "algorithmic_bytes_per_launch": alg_bytes},
             "kernels_us": {k: round(v["avg_us"], 2) for k, v in kernels.items()},
             "host_threads": _lib.lib().cs_host_thread_count(),

@@ -84,18 +84,44 @@ __global__ void __launch_bounds__(256) lsd_gradient(const double *scaled, int w,
     __syncthreads();
     if (threadIdx.x == 0) seg_cnt[((long)blockIdx.z * h + y) * gridDim.x + blockIdx.x] = wc[0] + wc[1] + wc[2] + wc[3];
 }
-// exclusive scan of n ints in one workgroup (out has n + 1 entries, out[n] = total)
-__global__ void __launch_bounds__(1024) lsd_scan(const int *in, int n, int *out) {
-    __shared__ int part[1024];
-    const int t = threadIdx.x, chunk = (n + 1023) / 1024, b = t * chunk, e = min(n, b + chunk);
-    int s = 0;
-    for (int i = b; i < e; i++) s += in[i];
-    part[t] = s;
+// exclusive scan of n ints (out has n + 1 entries, out[n] = total) in three coalesced passes: 1024-element blocks, their totals, add
+__global__ void __launch_bounds__(1024) lsd_scan_blocks(const int *in, int n, int *out, int *block_tot) {
+    __shared__ int ws[16];
+    const int i = blockIdx.x * 1024 + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int v = i < n ? in[i] : 0;
+    int sc = v;
+    for (int d = 1; d < 64; d <<= 1) { int t = __shfl_up(sc, d); if (lane >= d) sc += t; }
+    if (lane == 63) ws[wave] = sc;
     __syncthreads();
-    for (int d = 1; d < 1024; d <<= 1) { int v = t >= d ? part[t - d] : 0; __syncthreads(); part[t] += v; __syncthreads(); }
-    int run = part[t] - s;
-    for (int i = b; i < e; i++) { out[i] = run; run += in[i]; }
-    if (t == 1023) out[n] = part[1023];
+    int base = 0;
+    for (int k = 0; k < wave; k++) base += ws[k];
+    if (i < n) out[i] = base + sc - v;
+    if (threadIdx.x == 1023) block_tot[blockIdx.x] = base + sc;
+}
+__global__ void __launch_bounds__(1024) lsd_scan_top(int *block_tot, int nblk, int *total_out) { // in place: exclusive scan of the block totals (nblk <= 1024 per pass chunk)
+    __shared__ int ws[16];
+    __shared__ int carry;
+    if (threadIdx.x == 0) carry = 0;
+    __syncthreads();
+    for (int b0 = 0; b0 < nblk; b0 += 1024) {
+        const int i = b0 + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+        const int v = i < nblk ? block_tot[i] : 0;
+        int sc = v;
+        for (int d = 1; d < 64; d <<= 1) { int t = __shfl_up(sc, d); if (lane >= d) sc += t; }
+        if (lane == 63) ws[wave] = sc;
+        __syncthreads();
+        int base = carry;
+        for (int k = 0; k < wave; k++) base += ws[k];
+        if (i < nblk) block_tot[i] = base + sc - v;
+        __syncthreads();
+        if (threadIdx.x == 1023) carry = base + sc;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) *total_out = carry;
+}
+__global__ void __launch_bounds__(1024) lsd_scan_add(int *out, int n, const int *block_base) {
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    if (i < n) out[i] += block_base[blockIdx.x];
 }
 // ordered compaction of the defined pixels (address order inside a frame): address, level-line angle, gradient norm
 __global__ void __launch_bounds__(256) lsd_emit(const double *modgrad, const double *angles, int w, int h, const int *seg_base, int *c_addr, double *c_ang, double *c_mod) {
@@ -390,6 +416,7 @@ struct cs_lsd {
     int *d_xofs = nullptr, *d_yofs = nullptr; float *d_ax = nullptr, *d_ay = nullptr;
     int nbx = 0;                                            // 256-pixel segments per scaled row
     int *d_seg_cnt = nullptr, *d_seg_base = nullptr;        // per (frame, row, segment) defined-pixel count / exclusive scan
+    int *d_blk_tot = nullptr;                               // totals of the 1024-segment scan blocks
     int *d_caddr = nullptr; double *d_cang = nullptr, *d_cmod = nullptr; size_t ccap = 0;   // compacted defined pixels (device)
     int *h_caddr = nullptr; double *h_cang = nullptr, *h_cmod = nullptr; size_t hcap = 0;   // same, pinned host
     std::vector<int> frame_base;
@@ -431,7 +458,10 @@ static int lsd_run(cs_ctx *ctx, cs_lsd *l, int with_lbd) {
     CS_LAUNCH(ctx, "lsd_resize", lsd_resize, dim3((w + 255) / 256, h, F), dim3(256), 0, l->d_blur, W, H, w, h, l->d_xofs, l->d_ax, l->d_yofs, l->d_ay, l->d_scaled);
     const int nbx = l->nbx, n_seg = F * h * nbx;
     CS_LAUNCH(ctx, "lsd_gradient", lsd_gradient, dim3(nbx, h, F), dim3(256), 0, l->d_scaled, w, h, l->threshold, l->d_mod, l->d_ang, l->d_seg_cnt);
-    CS_LAUNCH(ctx, "lsd_scan", lsd_scan, dim3(1), dim3(1024), 0, l->d_seg_cnt, n_seg, l->d_seg_base);
+    const int nblk = (n_seg + 1023) / 1024;
+    CS_LAUNCH(ctx, "lsd_scan", lsd_scan_blocks, dim3(nblk), dim3(1024), 0, l->d_seg_cnt, n_seg, l->d_seg_base, l->d_blk_tot);
+    CS_LAUNCH(ctx, "lsd_scan", lsd_scan_top, dim3(1), dim3(1024), 0, l->d_blk_tot, nblk, l->d_seg_base + n_seg);
+    CS_LAUNCH(ctx, "lsd_scan", lsd_scan_add, dim3(nblk), dim3(1024), 0, l->d_seg_base, n_seg, l->d_blk_tot);
     // only the defined pixels (gradient above rho) go to the host: frame bases first, then the compacted (address, angle, norm) lists
     l->frame_base.assign((size_t)F + 1, 0);
     CS_HIP(ctx, hipMemcpy2DAsync(l->frame_base.data(), sizeof(int), l->d_seg_base, sizeof(int) * (size_t)h * nbx, sizeof(int), (size_t)F + 1, hipMemcpyDeviceToHost, ctx->stream));
@@ -529,7 +559,7 @@ void cs_lsd_destroy(cs_ctx *ctx, cs_lsd *l) {
     void *ptrs[] = {l->d_gray, l->d_tmp, l->d_blur, l->d_scaled, l->d_mod, l->d_ang, l->d_xofs, l->d_yofs, l->d_ax, l->d_ay, l->d_lblur, l->d_dx, l->d_dy};
     for (void *p : ptrs) if (p) hipFree(p);
     lsd_free_lines(l);
-    void *more[] = {l->d_seg_cnt, l->d_seg_base, l->d_caddr, l->d_cang, l->d_cmod};
+    void *more[] = {l->d_seg_cnt, l->d_seg_base, l->d_blk_tot, l->d_caddr, l->d_cang, l->d_cmod};
     for (void *p : more) if (p) hipFree(p);
     if (l->h_caddr) hipHostFree(l->h_caddr);
     if (l->h_cang) hipHostFree(l->h_cang);
@@ -562,6 +592,7 @@ int cs_lsd_create(cs_ctx *ctx, int width, int height, int max_frames, cs_lsd **o
     A_(cs_dalloc(ctx, &l->d_xofs, xofs.size())); A_(cs_dalloc(ctx, &l->d_yofs, yofs.size())); A_(cs_dalloc(ctx, &l->d_ax, ax.size())); A_(cs_dalloc(ctx, &l->d_ay, ay.size()));
     l->nbx = (l->w + 255) / 256;
     A_(cs_dalloc(ctx, &l->d_seg_cnt, (size_t)max_frames * l->h * l->nbx)); A_(cs_dalloc(ctx, &l->d_seg_base, (size_t)max_frames * l->h * l->nbx + 1));
+    A_(cs_dalloc(ctx, &l->d_blk_tot, ((size_t)max_frames * l->h * l->nbx + 1023) / 1024 + 1));
     A_(cs_h2d(ctx, l->d_xofs, xofs.data(), xofs.size())); A_(cs_h2d(ctx, l->d_yofs, yofs.data(), yofs.size()));
     A_(cs_h2d(ctx, l->d_ax, ax.data(), ax.size())); A_(cs_h2d(ctx, l->d_ay, ay.data(), ay.size()));
 #undef A_
