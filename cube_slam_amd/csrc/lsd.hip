@@ -13,6 +13,7 @@
 #include <cfloat>
 #include <chrono>
 #include <cmath>
+#include <mutex>
 #include <omp.h>
 #include <vector>
 
@@ -505,6 +506,10 @@ static int lsd_run(cs_ctx *ctx, cs_lsd *l, int with_lbd) {
     }
     CS_HIP(ctx, hipEventSynchronize(ev));
     ctx->pool.push_back(ev);
+    // one host stage at a time per process: two line detectors that alternate batches (bench.py) overlap their GPU phases with
+    // the other's region growing instead of splitting the host cores between two OpenMP teams
+    static std::mutex host_stage;
+    std::unique_lock<std::mutex> host_lock(host_stage);
     const auto t0 = std::chrono::steady_clock::now();
     l->keylines.assign((size_t)F, {});
     cs_omp_prepare();
@@ -520,6 +525,7 @@ static int lsd_run(cs_ctx *ctx, cs_lsd *l, int with_lbd) {
         }
     }
     if (ctx->timing) { auto &rec = ctx->timings["host_lsd_regions"]; rec.total_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); rec.count++; }
+    host_lock.unlock();
     l->line_off.assign((size_t)F + 1, 0);
     for (int f = 0; f < F; f++) l->line_off[f + 1] = l->line_off[f] + (int)l->keylines[f].size();
     if (with_lbd) {
