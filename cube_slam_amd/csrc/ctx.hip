@@ -10,7 +10,7 @@
 
 // CPUs the host stages (ORB quadtree, LSD region growing) may use: the affinity mask, capped by the cgroup CPU quota
 // (v2 cpu.max, v1 cpu.cfs_quota_us / cpu.cfs_period_us) -- running more threads than the quota only gets them throttled --
-// and overridable with CUBESLAM_HOST_THREADS.
+// divided by the number of ranks on the node (LOCAL_WORLD_SIZE), and overridable with CUBESLAM_HOST_THREADS.
 int cs_host_threads() {
     if (const char *e = getenv("CUBESLAM_HOST_THREADS")) { int v = atoi(e); if (v > 0) return v; }
     int n = 1;
@@ -28,6 +28,8 @@ int cs_host_threads() {
         if (qv > 0 && pv > 0) { quota = qv; period = pv; }
     }
     if (quota > 0 && period > 0) n = std::min(n, std::max(1, (int)std::floor(quota / period)));
+    // one process per GPU (torchrun sets LOCAL_WORLD_SIZE): the ranks of a node share the host cores
+    if (const char *e = getenv("LOCAL_WORLD_SIZE")) { int w = atoi(e); if (w > 1) n = std::max(1, n / w); }
     return std::max(1, n);
 }
 

@@ -109,3 +109,51 @@ def test_band_and_sparse_solvers_agree(ctx, small, monkeypatch):
     st = ba.optimize(2)
     assert st["chi2_final"] <= st["chi2_init"]
     ba.close()
+
+
+def test_allreduce_callback_on_device_pointer(ctx, small):
+    """The multi-GPU exchange of bench.py on one GPU: a 1-rank RCCL group all-reduces the reduced camera system in place through
+    the device pointer the library hands to the callback (zero-copy torch view); with one rank the sum is the identity, so the
+    result must equal the run without a callback."""
+    import os
+    import torch
+    import torch.distributed as dist
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29533")
+    created = not dist.is_initialized()
+    if created:
+        dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    calls = []
+
+    class _Dev:
+        def __init__(self, ptr, n):
+            self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 3}
+
+    def allreduce(ptr, n):
+        t = torch.as_tensor(_Dev(ptr, n), device="cuda")
+        assert t.data_ptr() == ptr and t.dtype == torch.float64
+        dist.all_reduce(t)
+        torch.cuda.synchronize()
+        calls.append(n)
+
+    try:
+        # rank 0 of a 2-rank job owns the landmarks [0, L/2) and all pose edges; with a 1-rank group its partial sums are the
+        # whole sum, i.e. the problem restricted to those landmarks -- which a plain single-rank solver must reproduce
+        from cube_slam_amd.ba import shard_landmarks
+        lo, hi = shard_landmarks(len(small["points"]), 0, 2)
+        keep = small["obs_point"] < hi
+        half = dict(small)
+        half["points"] = small["points"][:hi]
+        for k in ("obs_cam", "obs_point", "obs_uv", "obs_inv_sigma2"):
+            half[k] = small[k][keep]
+        ref = BundleAdjuster(half, ctx=ctx)
+        st_ref = ref.optimize(3); cam_ref, pts_ref, cub_ref = ref.read(); ref.close()
+        ba = BundleAdjuster(small, ctx=ctx, rank=0, world=2, allreduce=allreduce)
+        st = ba.optimize(3)
+        cam, pts, cub = ba.read()
+        ba.close()
+        assert len(calls) >= 3 and st["iterations"] == st_ref["iterations"]
+        assert np.allclose(st["chi2_trace"], st_ref["chi2_trace"], rtol=1e-9)
+        assert np.allclose(cam, cam_ref, rtol=0, atol=1e-9) and np.allclose(pts[:hi], pts_ref, rtol=0, atol=1e-9) and np.allclose(cub, cub_ref, rtol=0, atol=1e-9)
+    finally:
+        if created:
+            dist.destroy_process_group()
