@@ -22,6 +22,7 @@
 #include "common.h"
 
 #include <algorithm>
+#include <cfloat>
 #include <cmath>
 #include <limits>
 #include <map>
@@ -855,6 +856,170 @@ __global__ void __launch_bounds__(256) ba_maxdiag(Params G, double *partials) { 
 
 } // namespace
 
+// ------------------------------------------------------------------------------------------------ Optimizer::PoseOptimization
+// One workgroup per frame runs the whole routine (Optimizer.cc:253-472): 4 rounds x up to 10 Levenberg-Marquardt iterations of a
+// single 6-dof pose over the frame's map-point matches, inlier / outlier re-classification after every round.  Edges are strided
+// over the 256 threads; the 6x6 normal equations and chi2 are reduced in a fixed order (thread partials in edge order, then a
+// shuffle tree, then the four wave results); thread 0 solves the damped system and every LM decision is broadcast through LDS.
+struct PoseFrame { int e0, e1; double fx, fy, cx, cy, bf; };
+__device__ __forceinline__ void pose_edge_eval(const SE3 &T, const double *Xw, const double *ob, const PoseFrame &F, double *e) {
+    double pc[3];
+    se3_map(T, Xw, pc);
+    const double invz = 1.0 / pc[2];
+    e[0] = ob[0] - (pc[0] * invz * F.fx + F.cx);
+    e[1] = ob[1] - (pc[1] * invz * F.fy + F.cy);
+    e[2] = ob[2] >= 0 ? ob[2] - ((pc[0] * invz * F.fx + F.cx) - F.bf * invz) : 0.0;
+}
+__device__ __forceinline__ double pose_edge_chi2(const double *e, double w, bool stereo) {
+    return stereo ? ((e[0] * w * e[0] + e[1] * w * e[1]) + e[2] * w * e[2]) : (e[0] * w * e[0] + e[1] * w * e[1]);
+}
+template <int N> __device__ __forceinline__ void pose_block_reduce(double (&v)[N], double *s_red /* 4 x N */, double *s_out /* N */) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int k = 0; k < N; k++) for (int off = 32; off > 0; off >>= 1) v[k] += __shfl_xor(v[k], off);
+    if (lane == 0) for (int k = 0; k < N; k++) s_red[wave * N + k] = v[k];
+    __syncthreads();
+    if (threadIdx.x < N) s_out[threadIdx.x] = (s_red[threadIdx.x] + s_red[N + threadIdx.x]) + (s_red[2 * N + threadIdx.x] + s_red[3 * N + threadIdx.x]);
+    __syncthreads();
+}
+__global__ void __launch_bounds__(256) pose_opt_kernel(const PoseFrame *frames, const double *Xw, const double *obs, const double *wgt, const double *pose_in, double *pose_out,
+                                                       uint8_t *outlier, int *n_inliers, double *err /* per edge x 3 */) {
+    __shared__ double s_red[4 * 28], s_sys[28]; // 21 upper-triangle entries of H, 6 of b, 1 chi2
+    __shared__ double s_x[6], s_T[7];
+    __shared__ int s_flag;
+    const PoseFrame F = frames[blockIdx.x];
+    const int n = F.e1 - F.e0, tid = threadIdx.x;
+    const double *X = Xw + (long)F.e0 * 3, *O = obs + (long)F.e0 * 3, *W = wgt + F.e0;
+    double *E = err + (long)F.e0 * 3;
+    uint8_t *out = outlier + F.e0;
+    for (int i = tid; i < n; i += 256) out[i] = 0;
+    SE3 T0 = se3_load(pose_in + (long)blockIdx.x * 7);
+    normalize_rotation(T0);
+    if (n < 3) { if (tid == 0) { se3_store(T0, pose_out + (long)blockIdx.x * 7); n_inliers[blockIdx.x] = 0; } return; }
+    const double dMono = (double)(float)sqrt(5.991), dStereo = (double)(float)sqrt(7.815);
+    bool robust = true;
+    SE3 T = T0;
+    int nBadEdges = 0;
+    __syncthreads();
+    auto chi2_sum = [&](const SE3 &Tc) -> double { // computeActiveErrors + activeRobustChi2
+        double v[1] = {0};
+        for (int i = tid; i < n; i += 256) {
+            if (out[i]) continue;
+            double e[3];
+            pose_edge_eval(Tc, X + (long)i * 3, O + (long)i * 3, F, e);
+            E[(long)i * 3] = e[0]; E[(long)i * 3 + 1] = e[1]; E[(long)i * 3 + 2] = e[2];
+            const bool st = O[(long)i * 3 + 2] >= 0;
+            double c = pose_edge_chi2(e, W[i], st);
+            if (robust) { const double d = st ? dStereo : dMono, dsqr = d * d; if (c > dsqr) c = 2 * sqrt(c) * d - dsqr; }
+            v[0] += c;
+        }
+        pose_block_reduce<1>(v, s_red, s_sys + 27);
+        return s_sys[27];
+    };
+    for (int round = 0; round < 4; round++) {
+        T = T0;
+        double lambda = 0, ni = 2;
+        int nBad = 0;
+        for (int it = 0; it < 10; it++) { // OptimizationAlgorithmLevenberg::solve
+            double currentChi = chi2_sum(T);
+            const double iniChi = currentChi;
+            double acc[27];
+#pragma unroll
+            for (int k = 0; k < 27; k++) acc[k] = 0;
+            for (int i = tid; i < n; i += 256) { // linearizeOplus + constructQuadraticForm
+                if (out[i]) continue;
+                double pc[3], J[18];
+                se3_map(T, X + (long)i * 3, pc);
+                const double x = pc[0], y = pc[1], invz = 1.0 / pc[2], invz_2 = invz * invz;
+                J[0] = x * y * invz_2 * F.fx; J[1] = -(1 + (x * x * invz_2)) * F.fx; J[2] = y * invz * F.fx; J[3] = -invz * F.fx; J[4] = 0; J[5] = x * invz_2 * F.fx;
+                J[6] = (1 + y * y * invz_2) * F.fy; J[7] = -x * y * invz_2 * F.fy; J[8] = -x * invz * F.fy; J[9] = 0; J[10] = -invz * F.fy; J[11] = y * invz_2 * F.fy;
+                const bool st = O[(long)i * 3 + 2] >= 0;
+                if (st) { J[12] = J[0] - F.bf * y * invz_2; J[13] = J[1] + F.bf * x * invz_2; J[14] = J[2]; J[15] = J[3]; J[16] = 0; J[17] = J[5] - F.bf * invz_2; }
+                else { for (int k = 12; k < 18; k++) J[k] = 0; }
+                const double e[3] = {E[(long)i * 3], E[(long)i * 3 + 1], E[(long)i * 3 + 2]}, w = W[i];
+                double rw = 1.0;
+                if (robust) { const double c = pose_edge_chi2(e, w, st), d = st ? dStereo : dMono; if (c > d * d) rw = d / sqrt(c); }
+                int k = 0;
+#pragma unroll
+                for (int a = 0; a < 6; a++) {
+#pragma unroll
+                    for (int c2 = a; c2 < 6; c2++) { acc[k] += (J[a] * (rw * w) * J[c2] + J[6 + a] * (rw * w) * J[6 + c2]) + J[12 + a] * (rw * w) * J[12 + c2]; k++; }
+                }
+#pragma unroll
+                for (int a = 0; a < 6; a++) acc[21 + a] += rw * ((J[a] * (-(w * e[0])) + J[6 + a] * (-(w * e[1]))) + J[12 + a] * (-(w * e[2])));
+            }
+            pose_block_reduce<27>(acc, s_red, s_sys);
+            if (it == 0) { double mx = 0; int k = 0; for (int a = 0; a < 6; a++) { mx = fmax(fabs(s_sys[k]), mx); k += 6 - a; } lambda = 1e-5 * mx; ni = 2; nBad = 0; }
+            double rho = 0;
+            int qmax = 0;
+            do {
+                const SE3 backup = T;
+                if (tid == 0) { // (H + lambda I) x = b, Cholesky
+                    double L[36], y6[6], x6[6] = {0, 0, 0, 0, 0, 0};
+                    int k = 0;
+                    for (int a = 0; a < 6; a++) for (int c2 = a; c2 < 6; c2++) { L[c2 * 6 + a] = s_sys[k]; L[a * 6 + c2] = s_sys[k]; k++; }
+                    for (int a = 0; a < 6; a++) L[a * 6 + a] += lambda;
+                    bool ok = true;
+                    for (int c2 = 0; c2 < 6 && ok; c2++) {
+                        double d = L[c2 * 6 + c2];
+                        for (int t = 0; t < c2; t++) d -= L[c2 * 6 + t] * L[c2 * 6 + t];
+                        if (!(d > 0)) { ok = false; break; }
+                        d = sqrt(d); L[c2 * 6 + c2] = d;
+                        for (int r = c2 + 1; r < 6; r++) { double v = L[r * 6 + c2]; for (int t = 0; t < c2; t++) v -= L[r * 6 + t] * L[c2 * 6 + t]; L[r * 6 + c2] = v / d; }
+                    }
+                    if (ok) {
+                        for (int r = 0; r < 6; r++) { double v = s_sys[21 + r]; for (int t = 0; t < r; t++) v -= L[r * 6 + t] * y6[t]; y6[r] = v / L[r * 6 + r]; }
+                        for (int r = 5; r >= 0; r--) { double v = y6[r]; for (int t = r + 1; t < 6; t++) v -= L[t * 6 + r] * x6[t]; x6[r] = v / L[r * 6 + r]; }
+                    }
+                    for (int r = 0; r < 6; r++) s_x[r] = x6[r];
+                    s_flag = ok ? 1 : 0;
+                    const SE3 Tn = ok ? se3_mul(se3_exp(x6), T) : T; // VertexSE3Expmap::oplusImpl
+                    se3_store(Tn, s_T);
+                }
+                __syncthreads();
+                const bool ok2 = s_flag != 0;
+                T = se3_load(s_T);
+                double tempChi = chi2_sum(T);
+                if (!ok2) tempChi = DBL_MAX;
+                rho = currentChi - tempChi;
+                double scale = 0;
+                for (int j = 0; j < 6; j++) scale += s_x[j] * (lambda * s_x[j] + s_sys[21 + j]);
+                scale += 1e-3;
+                rho /= scale;
+                if (rho > 0 && isfinite(tempChi)) {
+                    double alpha = 1. - pow((2 * rho - 1), 3);
+                    alpha = fmin(alpha, 2. / 3.);
+                    lambda *= fmax(1. / 3., alpha);
+                    ni = 2; currentChi = tempChi;
+                } else { lambda *= ni; ni *= 2; T = backup; }
+                qmax++;
+                __syncthreads(); // s_x / s_sys[21..] are rewritten by the next trial
+            } while (rho < 0 && qmax < 10);
+            if (qmax == 10 || rho == 0) break;
+            if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
+            if (nBad >= 3) break;
+        }
+        // classification (Optimizer.cc:401-431): outliers are re-evaluated at the final estimate, inliers keep the error of the last trial
+        double cnt[1] = {0};
+        for (int i = tid; i < n; i += 256) {
+            double e[3];
+            if (out[i]) { pose_edge_eval(T, X + (long)i * 3, O + (long)i * 3, F, e); E[(long)i * 3] = e[0]; E[(long)i * 3 + 1] = e[1]; E[(long)i * 3 + 2] = e[2]; }
+            else { e[0] = E[(long)i * 3]; e[1] = E[(long)i * 3 + 1]; e[2] = E[(long)i * 3 + 2]; }
+            const bool st = O[(long)i * 3 + 2] >= 0;
+            const float chi2 = (float)pose_edge_chi2(e, W[i], st);
+            const bool bad = chi2 > (st ? 7.815f : 5.991f);
+            out[i] = bad ? 1 : 0;
+            cnt[0] += bad ? 1.0 : 0.0;
+        }
+        pose_block_reduce<1>(cnt, s_red, s_sys + 27);
+        nBadEdges = (int)s_sys[27];
+        __syncthreads();
+        if (round == 2) robust = false;
+        if (n < 10) break;
+    }
+    if (tid == 0) { se3_store(T, pose_out + (long)blockIdx.x * 7); n_inliers[blockIdx.x] = n - nBadEdges; }
+}
+
 struct cs_ba {
     Params G{};
     int rank = 0, world = 1, n_slots = 0, max_col = 0, max_part = 0;
@@ -1446,6 +1611,39 @@ int cs_ba_optimize(cs_ctx *ctx, cs_ba *b, int iterations, const volatile int *st
     CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     if (st) *st = S;
     return CS_OK;
+}
+
+int cs_pose_optimization(cs_ctx *ctx, int n_frames, const int *edge_off, const double *Xw, const double *obs, const double *inv_sigma2, const double *intrinsics,
+                         const double *pose_in, double *pose_out, uint8_t *outlier, int *n_inliers) {
+    if (!ctx || n_frames < 0 || !edge_off || (n_frames && (!intrinsics || !pose_in || !pose_out || !n_inliers))) return CS_ERR_BAD_ARG;
+    if (n_frames == 0) return CS_OK;
+    CS_HIP(ctx, hipSetDevice(ctx->device));
+    const int ne = edge_off[n_frames];
+    for (int f = 0; f < n_frames; f++) if (edge_off[f + 1] < edge_off[f]) return CS_ERR_BAD_ARG;
+    if (ne > 0 && (!Xw || !obs || !inv_sigma2 || !outlier)) return CS_ERR_BAD_ARG;
+    std::vector<PoseFrame> fr((size_t)n_frames);
+    for (int f = 0; f < n_frames; f++) { fr[f].e0 = edge_off[f]; fr[f].e1 = edge_off[f + 1]; fr[f].fx = intrinsics[f * 5]; fr[f].fy = intrinsics[f * 5 + 1]; fr[f].cx = intrinsics[f * 5 + 2]; fr[f].cy = intrinsics[f * 5 + 3]; fr[f].bf = intrinsics[f * 5 + 4]; }
+    PoseFrame *d_fr = nullptr; double *d_X = nullptr, *d_o = nullptr, *d_w = nullptr, *d_pi = nullptr, *d_po = nullptr, *d_err = nullptr; uint8_t *d_out = nullptr; int *d_ni = nullptr;
+    const size_t ne1 = (size_t)std::max(ne, 1);
+    int r = cs_dalloc(ctx, &d_fr, (size_t)n_frames);
+    if (!r) r = cs_dalloc(ctx, &d_X, ne1 * 3); if (!r) r = cs_dalloc(ctx, &d_o, ne1 * 3); if (!r) r = cs_dalloc(ctx, &d_w, ne1); if (!r) r = cs_dalloc(ctx, &d_err, ne1 * 3);
+    if (!r) r = cs_dalloc(ctx, &d_pi, (size_t)n_frames * 7); if (!r) r = cs_dalloc(ctx, &d_po, (size_t)n_frames * 7); if (!r) r = cs_dalloc(ctx, &d_out, ne1); if (!r) r = cs_dalloc(ctx, &d_ni, (size_t)n_frames);
+    if (!r) r = cs_h2d(ctx, d_fr, fr.data(), fr.size());
+    if (!r && ne) { r = cs_h2d(ctx, d_X, Xw, (size_t)ne * 3); if (!r) r = cs_h2d(ctx, d_o, obs, (size_t)ne * 3); if (!r) r = cs_h2d(ctx, d_w, inv_sigma2, (size_t)ne); }
+    if (!r) r = cs_h2d(ctx, d_pi, pose_in, (size_t)n_frames * 7);
+    if (!r) {
+        ctx->begin("pose_opt_kernel");
+        hipLaunchKernelGGL(pose_opt_kernel, dim3(n_frames), dim3(256), 0, ctx->stream, d_fr, d_X, d_o, d_w, d_pi, d_po, d_out, d_ni, d_err);
+        ctx->end();
+        r = cs_d2h(ctx, pose_out, d_po, (size_t)n_frames * 7);
+        if (!r && ne) r = cs_d2h(ctx, outlier, d_out, (size_t)ne);
+        if (!r) r = cs_d2h(ctx, n_inliers, d_ni, (size_t)n_frames);
+    }
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (!r && e != hipSuccess) { ctx->err = hipGetErrorString(e); r = CS_ERR_HIP; }
+    void *ptrs[] = {d_fr, d_X, d_o, d_w, d_pi, d_po, d_err, d_out, d_ni};
+    for (void *q : ptrs) if (q) hipFree(q);
+    return r;
 }
 
 } // extern "C"

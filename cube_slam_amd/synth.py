@@ -271,3 +271,30 @@ def ba_problem(seed, n_kf=1000, n_points=100000, n_cuboids=500, k_obs=5, W=1241,
         "pc_points": np.concatenate(pc_pts).reshape(-1, 3) if pc_pts else np.zeros((0, 3)), "max_outside_margin_ratio": 2.0,
         "cam_true": cam_true, "points_true": pts, "cuboid_true": np.array(cub_pose).reshape(-1, 7),
     }
+
+
+def pose_frame(seed, n=800, outlier_frac=0.15, stereo_frac=0.0, noise_px=1.0, W=1241, H=376):
+    """One tracking frame for Optimizer::PoseOptimization: n map points in front of a KITTI-like camera, pixel noise by octave,
+    a fraction of gross outliers (wrong matches), the initial pose perturbed like a constant-velocity prediction."""
+    rng = np.random.default_rng(seed)
+    K = K_KITTI
+    fx, fy, cx, cy = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
+    bf = 386.1448
+    R = _rot(1, rng.uniform(-0.2, 0.2)) @ _rot(0, rng.uniform(-0.05, 0.05))
+    t = rng.uniform(-1, 1, 3)
+    u = rng.uniform(20, W - 20, n); v = rng.uniform(20, H - 20, n); z = rng.uniform(4, 60, n)
+    Xc = np.stack([(u - cx) / fx * z, (v - cy) / fy * z, z], axis=1)
+    Xw = (R.T @ (Xc - t).T).T  # Tcw = [R t]
+    octave = rng.integers(0, 8, n)
+    sig = 1.2 ** octave
+    obs = np.stack([u + rng.normal(0, noise_px, n) * sig, v + rng.normal(0, noise_px, n) * sig, np.full(n, -1.0)], axis=1)
+    st = rng.random(n) < stereo_frac
+    obs[st, 2] = obs[st, 0] - bf / z[st] + rng.normal(0, noise_px, st.sum()) * sig[st]
+    bad = rng.random(n) < outlier_frac
+    obs[bad, 0] += rng.uniform(15, 80, bad.sum()) * rng.choice([-1, 1], bad.sum())
+    obs[bad, 1] += rng.uniform(15, 60, bad.sum()) * rng.choice([-1, 1], bad.sum())
+    Xw = Xw.astype(np.float32).astype(np.float64); obs = obs.astype(np.float32).astype(np.float64)  # the reference reads float Mats
+    dR = _rot(1, rng.normal(0, 0.01)) @ _rot(0, rng.normal(0, 0.005)) @ _rot(2, rng.normal(0, 0.005))
+    pose0 = _pose7(dR @ R, dR @ t + rng.normal(0, 0.05, 3))
+    return {"Xw": Xw, "obs": obs, "inv_sigma2": (1.0 / (sig * sig)).astype(np.float32).astype(np.float64), "intr": np.array([fx, fy, cx, cy, bf]),
+            "pose": pose0, "pose_true": _pose7(R, t), "is_outlier": bad}

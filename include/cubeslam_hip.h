@@ -301,6 +301,15 @@ int cs_lbd_match(cs_ctx *ctx, const uint8_t *q, int nq, const uint8_t *t, int nt
 /* introspection: the blurred image and the Sobel derivative maps of the last cs_lbd_compute-like pass over `gray` */
 int cs_lbd_maps(cs_ctx *ctx, const uint8_t *gray, int width, int height, int stride, uint8_t *blur, int16_t *dx, int16_t *dy);
 
+/* ===================================================================== Optimizer::PoseOptimization  
+ * Replaces ORB_SLAM2::Optimizer::PoseOptimization(Frame*) (orb_object_slam/include/Optimizer.h:51, src/Optimizer.cc:253-472) for a
+ * batch of frames: frame f owns the matches [edge_off[f], edge_off[f+1]) -- Xw (world point), obs (u, v, u_right; u_right < 0 =
+ * monocular, Optimizer.cc:303), inv_sigma2 (mvInvLevelSigma2[octave]); intrinsics n_frames x 5 = fx fy cx cy bf; poses = Tcw as
+ * [t, qx qy qz qw].  Out: optimised pose, per-match mvbOutlier flags, n_inliers[f] = nInitialCorrespondences - nBad (:471).
+ * One workgroup per frame runs the 4 x 10 Levenberg-Marquardt rounds with the re-classification in between. */
+int cs_pose_optimization(cs_ctx *ctx, int n_frames, const int *edge_off, const double *Xw, const double *obs, const double *inv_sigma2, const double *intrinsics,
+                         const double *pose_in, double *pose_out, uint8_t *outlier, int *n_inliers);
+
 #ifdef __cplusplus
 }
 #endif

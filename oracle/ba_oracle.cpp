@@ -630,3 +630,145 @@ int orc_ba_optimize(const orc_ba_problem *p, int iterations, double *cam_pose_ou
 }
 
 } // extern "C"
+
+// ------------------------------------------------------------------------------------------------ Optimizer::PoseOptimization
+// Restated from /root/reference/orb_object_slam/src/Optimizer.cc:253-472 and the g2o pieces it reaches: EdgeSE3ProjectXYZOnlyPose /
+// EdgeStereoSE3ProjectXYZOnlyPose (types_six_dof_expmap.h:104-162, .cpp:298-392), BaseUnaryEdge::constructQuadraticForm
+// (base_unary_edge.hpp:43-76), RobustKernelHuber, OptimizationAlgorithmLevenberg::solve, VertexSE3Expmap::oplusImpl.
+// One 6-dof vertex, N unary edges.  Quirks kept: the estimate is reset to the frame's pose before each of the 4 rounds; inlier
+// edges are classified with the error left by the last computeActiveErrors() (the state of the last LM trial, accepted or not),
+// outlier (level-1) edges are re-evaluated at the final estimate; chi2 is compared as float; the Huber kernel is dropped after
+// the third round; `optimizer.edges().size() < 10` ends the rounds early.
+namespace {
+struct PoseOpt {
+    int n; const double *Xw, *obs, *w; double fx, fy, cx, cy, bf;
+    SE3 T;
+    std::vector<double> err;      // n x 3, as left by the last evaluation of each edge
+    std::vector<uint8_t> level1;  // edge excluded from the optimisation
+    bool robust = true;
+    bool stereo(int i) const { return obs[(size_t)i * 3 + 2] >= 0; }
+    void eval(int i) { // computeError
+        double pc[3];
+        se3_map(T, Xw + (size_t)i * 3, pc);
+        const double invz = 1.0 / pc[2];
+        double *e = &err[(size_t)i * 3];
+        e[0] = obs[(size_t)i * 3] - (pc[0] * invz * fx + cx);
+        e[1] = obs[(size_t)i * 3 + 1] - (pc[1] * invz * fy + cy);
+        e[2] = stereo(i) ? obs[(size_t)i * 3 + 2] - ((pc[0] * invz * fx + cx) - bf * invz) : 0.0;
+    }
+    double chi2(int i) const { const double *e = &err[(size_t)i * 3]; return stereo(i) ? ((e[0] * w[i] * e[0] + e[1] * w[i] * e[1]) + e[2] * w[i] * e[2]) : (e[0] * w[i] * e[0] + e[1] * w[i] * e[1]); }
+    double delta(int i) const { return stereo(i) ? (double)(float)std::sqrt(7.815) : (double)(float)std::sqrt(5.991); } // const float deltaMono = sqrt(5.991)
+    void compute_active_errors() { for (int i = 0; i < n; i++) if (!level1[i]) eval(i); }
+    double active_robust_chi2() const {
+        double chi = 0, rho[3];
+        for (int i = 0; i < n; i++) if (!level1[i]) { const double c = chi2(i); if (robust) { BA::huber(c, delta(i), rho); chi += rho[0]; } else chi += c; }
+        return chi;
+    }
+    void build(double *H, double *b) const { // linearizeOplus + constructQuadraticForm over the active edges, in edge order
+        for (int k = 0; k < 36; k++) H[k] = 0;
+        for (int k = 0; k < 6; k++) b[k] = 0;
+        for (int i = 0; i < n; i++) {
+            if (level1[i]) continue;
+            double pc[3], J[18];
+            se3_map(T, Xw + (size_t)i * 3, pc);
+            const double x = pc[0], y = pc[1], invz = 1.0 / pc[2], invz_2 = invz * invz;
+            J[0] = x * y * invz_2 * fx; J[1] = -(1 + (x * x * invz_2)) * fx; J[2] = y * invz * fx; J[3] = -invz * fx; J[4] = 0; J[5] = x * invz_2 * fx;
+            J[6] = (1 + y * y * invz_2) * fy; J[7] = -x * y * invz_2 * fy; J[8] = -x * invz * fy; J[9] = 0; J[10] = -invz * fy; J[11] = y * invz_2 * fy;
+            const int dim = stereo(i) ? 3 : 2;
+            if (dim == 3) { J[12] = J[0] - bf * y * invz_2; J[13] = J[1] + bf * x * invz_2; J[14] = J[2]; J[15] = J[3]; J[16] = 0; J[17] = J[5] - bf * invz_2; }
+            double rw = 1.0, rho[3];
+            if (robust) { BA::huber(chi2(i), delta(i), rho); rw = rho[1]; }
+            const double *e = &err[(size_t)i * 3];
+            for (int a = 0; a < 6; a++) {
+                double acc = 0;
+                for (int d = 0; d < dim; d++) acc += J[d * 6 + a] * (-(w[i] * e[d]));
+                b[a] += rw * acc;
+                for (int c = 0; c < 6; c++) { double h = 0; for (int d = 0; d < dim; d++) h += J[d * 6 + a] * (rw * w[i]) * J[d * 6 + c]; H[a * 6 + c] += h; }
+            }
+        }
+    }
+    static bool solve6(const double *H, const double *b, double lambda, double *x) { // dense SPD solve (LinearSolverDense -> Eigen LDLT)
+        double L[36];
+        for (int k = 0; k < 36; k++) L[k] = H[k];
+        for (int k = 0; k < 6; k++) L[k * 6 + k] += lambda;
+        for (int c = 0; c < 6; c++) {
+            double d = L[c * 6 + c];
+            for (int t = 0; t < c; t++) d -= L[c * 6 + t] * L[c * 6 + t];
+            if (!(d > 0)) return false;
+            d = std::sqrt(d); L[c * 6 + c] = d;
+            for (int r = c + 1; r < 6; r++) { double v = L[r * 6 + c]; for (int t = 0; t < c; t++) v -= L[r * 6 + t] * L[c * 6 + t]; L[r * 6 + c] = v / d; }
+        }
+        double y[6];
+        for (int r = 0; r < 6; r++) { double v = b[r]; for (int t = 0; t < r; t++) v -= L[r * 6 + t] * y[t]; y[r] = v / L[r * 6 + r]; }
+        for (int r = 5; r >= 0; r--) { double v = y[r]; for (int t = r + 1; t < 6; t++) v -= L[t * 6 + r] * x[t]; x[r] = v / L[r * 6 + r]; }
+        return true;
+    }
+    int optimize(int iterations) { // SparseOptimizer::optimize + OptimizationAlgorithmLevenberg::solve
+        double lambda = 0, ni = 2;
+        int nBad = 0, done = 0;
+        for (int it = 0; it < iterations; it++) {
+            compute_active_errors();
+            double currentChi = active_robust_chi2(), tempChi = currentChi;
+            const double iniChi = currentChi;
+            double H[36], b[6], x[6] = {0, 0, 0, 0, 0, 0};
+            build(H, b);
+            if (it == 0) { double mx = 0; for (int k = 0; k < 6; k++) mx = std::max(std::fabs(H[k * 6 + k]), mx); lambda = 1e-5 * mx; ni = 2; nBad = 0; }
+            double rho = 0;
+            int qmax = 0;
+            do {
+                const SE3 backup = T;
+                const bool ok2 = solve6(H, b, lambda, x);
+                if (ok2) T = se3_mul(se3_exp(x), T); // oplus; a failed solve leaves x = 0 (block_solver.hpp: _x is zeroed on failure paths)
+                compute_active_errors();
+                tempChi = active_robust_chi2();
+                if (!ok2) tempChi = std::numeric_limits<double>::max();
+                rho = currentChi - tempChi;
+                double scale = 0;
+                for (int j = 0; j < 6; j++) scale += x[j] * (lambda * x[j] + b[j]);
+                scale += 1e-3;
+                rho /= scale;
+                if (rho > 0 && std::isfinite(tempChi)) {
+                    double alpha = 1. - std::pow((2 * rho - 1), 3);
+                    alpha = (std::min)(alpha, 2. / 3.);
+                    lambda *= (std::max)(1. / 3., alpha);
+                    ni = 2; currentChi = tempChi;
+                } else { lambda *= ni; ni *= 2; T = backup; }
+                qmax++;
+            } while (rho < 0 && qmax < 10);
+            done = it + 1;
+            if (qmax == 10 || rho == 0) break;
+            if ((iniChi - currentChi) * 1e3 < iniChi) nBad++; else nBad = 0;
+            if (nBad >= 3) break;
+        }
+        return done;
+    }
+};
+} // namespace
+
+extern "C" int orc_pose_optimization(int n, const double *Xw, const double *obs, const double *inv_sigma2, double fx, double fy, double cx, double cy, double bf,
+                                     const double *pose_in, double *pose_out, uint8_t *outlier) {
+    PoseOpt P;
+    P.n = n; P.Xw = Xw; P.obs = obs; P.w = inv_sigma2; P.fx = fx; P.fy = fy; P.cx = cx; P.cy = cy; P.bf = bf;
+    P.err.assign((size_t)n * 3, 0.0); P.level1.assign((size_t)n, 0);
+    for (int i = 0; i < n; i++) outlier[i] = 0;
+    const SE3 T0 = se3_from7(pose_in);
+    P.T = T0;
+    if (n < 3) { se3_to7(T0, pose_out); return 0; } // Optimizer.cc:385-386 (pose untouched)
+    const float chi2Mono = 5.991f, chi2Stereo = 7.815f;
+    int nBad = 0;
+    for (int it = 0; it < 4; it++) {
+        P.T = T0;
+        P.optimize(10);
+        nBad = 0;
+        for (int i = 0; i < n; i++) {
+            if (outlier[i]) P.eval(i);
+            const float chi2 = (float)P.chi2(i);
+            if (chi2 > (P.stereo(i) ? chi2Stereo : chi2Mono)) { outlier[i] = 1; P.level1[i] = 1; nBad++; }
+            else { outlier[i] = 0; P.level1[i] = 0; }
+        }
+        if (it == 2) P.robust = false;
+        if (n < 10) break;
+    }
+    se3_to7(P.T, pose_out);
+    return n - nBad;
+}

@@ -224,6 +224,12 @@ int orc_lsd_maps(const uint8_t *gray, int W, int H, int *sw, int *sh, double *sc
 int orc_lbd_compute(const uint8_t *gray, int W, int H, const orc_keyline *kl, int n, uint8_t *desc, float *fdesc);
 int orc_lbd_maps(const uint8_t *gray, int W, int H, uint8_t *blur, int16_t *dx, int16_t *dy);
 
+/* ------------------------------------------------------------------ Optimizer::PoseOptimization (orb_object_slam/src/Optimizer.cc:253-472)
+ * One frame: n map-point matches (Xw n x 3; obs n x 3 = u, v, u_right with u_right < 0 for monocular observations; inv_sigma2 n),
+ * pose = [t, qx qy qz qw] of Tcw.  outlier: n flags (mvbOutlier).  Returns nInitialCorrespondences - nBad. */
+int orc_pose_optimization(int n, const double *Xw, const double *obs, const double *inv_sigma2, double fx, double fy, double cx, double cy, double bf,
+                          const double *pose_in, double *pose_out, uint8_t *outlier);
+
 #ifdef __cplusplus
 }
 #endif

@@ -403,3 +403,16 @@ def lbd_maps(gray):
     b = np.zeros((H, W), np.uint8); dx = np.zeros((H, W), np.int16); dy = np.zeros((H, W), np.int16)
     lib().orc_lbd_maps(_p(gray, C.c_uint8), W, H, _p(b, C.c_uint8), _p(dx, C.c_int16), _p(dy, C.c_int16))
     return b, dx, dy
+
+
+def pose_optimization(Xw, obs, inv_sigma2, intr, pose):
+    """Optimizer::PoseOptimization for one frame -> (pose_out[7], outlier[n] u8, n_inliers)."""
+    Xw = np.ascontiguousarray(Xw, np.float64).reshape(-1, 3); obs = np.ascontiguousarray(obs, np.float64).reshape(-1, 3)
+    w = np.ascontiguousarray(inv_sigma2, np.float64); pose = np.ascontiguousarray(pose, np.float64)
+    n = len(Xw)
+    out = np.zeros(7); flags = np.zeros(max(n, 1), np.uint8)
+    fx, fy, cx, cy, bf = [float(v) for v in intr]
+    lib().orc_pose_optimization.restype = C.c_int
+    r = lib().orc_pose_optimization(n, _p(Xw, C.c_double), _p(obs, C.c_double), _p(w, C.c_double), C.c_double(fx), C.c_double(fy), C.c_double(cx), C.c_double(cy), C.c_double(bf),
+                                    _p(pose, C.c_double), _p(out, C.c_double), _p(flags, C.c_uint8))
+    return out, flags[:n], r
