@@ -544,11 +544,6 @@ __global__ void __launch_bounds__(64) ba_cub_back(int C, int Q, const int *cq_of
 // Block-band Cholesky + both triangular solves in one workgroup.  A: C columns x (Bc+1) blocks (block d of column j = block
 // (j+d, j), row-major 6x6), Lf: same layout, receives L; rhs: in b (6C), out x; ybuf: 12C scratch (y_j, 1/diag L_jj).  LDS: a ring of Bc+2 columns (the extra slot
 // receives column j+Bc+1 while column j is processed) and the matching right-hand-side window.
-// workgroup barrier that orders LDS traffic only: __syncthreads() also drains the global-memory counter, i.e. every barrier
-// would wait for the stores of the finished column and the prefetch loads of the next one to be acknowledged by the L2
-// (measured: 5.4 us per column with __syncthreads()); global data written here is never re-read by this kernel
-// through a cached path before the kernel ends (Lf / ybuf are read back with non-temporal loads long after they were written)
-__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }
 __global__ void __launch_bounds__(256) ba_band_chol(int C, int Bc, const double *A, double *Lf, double *rhs, double *ybuf, int *status) {
     extern __shared__ double sh[];
     const int NB = Bc + 1, NS = Bc + 2, CS = NB * 36;

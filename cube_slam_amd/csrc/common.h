@@ -104,3 +104,9 @@ __device__ __forceinline__ int wave_incl_min_scan(int x) {
     return x;
 }
 __device__ __forceinline__ int lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
+
+// Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the global-memory counter (s_waitcnt vmcnt(0)), so
+// in a loop that stores a result row / column to global memory and prefetches the next one, every barrier would wait for those
+// round trips (measured: 5.4 us per column in ba_band_chol, 3.5 us per row in orb_blur).  Only valid where no thread reads,
+// through a cached path, global data another thread of the workgroup wrote before the barrier.
+__device__ __forceinline__ void lds_barrier() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); }

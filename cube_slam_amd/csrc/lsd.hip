@@ -339,12 +339,15 @@ class LsdHost {
         for (int n = 0; n < 5; ++n) if ((r.width - delta) >= 0.5) { r.p /= 2; r.prec = r.p * PI_; double v = rect_nfa(r); if (v > best) { rec = r; best = v; } }
         return best;
     }
+    bool timed = false;
+    double t_sort = 0, t_grow = 0, t_rect = 0; long n_seeds = 0, n_regions = 0, n_pix = 0; // stage timers (ms) of this thread, reported by the caller
     std::vector<double> dang, dmod; // dense maps of this thread, NOTDEF / untouched outside the current frame's defined pixels
     std::vector<int> order;
     int cnt[1025];
     // flsd :464-535 (LSD_REFINE_ADV, scale 0.8): segments as x1 y1 x2 y2 floats.  Input: the frame's defined pixels in address
     // order (the undefined ones are skipped by the reference's seed loop and fail every alignment test, so they never matter).
     void run(int w_, int h_, int ne, const int *e_addr, const double *e_ang, const double *e_mod, std::vector<float> &lines) {
+        const auto tt0 = timed ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
         w = w_; h = h_;
         const size_t n = (size_t)w * h;
         if (dang.size() != n) { dang.assign(n, NOTDEF); dmod.assign(n, 0.0); used.assign(n, 0); rx.resize(n); ry.resize(n); rang.resize(n); rmod.resize(n); }
@@ -363,12 +366,18 @@ class LsdHost {
         const int min_reg_size = int(-LOG_NT / std::log10(p));
         lines.clear();
         const double *ang = angles;
+        if (timed) t_sort += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tt0).count();
         for (size_t i = 0; i < order.size(); ++i) {
             const int adx = order[i];
             if (used[adx] != 0 || ang[adx] == NOTDEF) continue;
             int rn; double reg_angle;
+            const auto tg0 = timed ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
             grow(adx % w, adx / w, rn, reg_angle, prec);
+            const auto tg1 = timed ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
+            if (timed) { t_grow += std::chrono::duration<double, std::milli>(tg1 - tg0).count(); n_seeds++; n_pix += rn; }
             if (rn < min_reg_size) continue;
+            n_regions++;
+            struct RT { bool on; double &acc; std::chrono::steady_clock::time_point t0; ~RT() { if (on) acc += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); } } rt{timed, t_rect, tg1};
             RectH rec;
             to_rect(rn, reg_angle, prec, p, rec);
             if (!refine(rn, reg_angle, prec, p, rec, 0.7)) continue;
@@ -516,12 +525,22 @@ static int lsd_run(cs_ctx *ctx, cs_lsd *l, int with_lbd) {
 #pragma omp parallel num_threads(std::max(1, std::min(ctx->host_threads, F)))
     {
         LsdHost host;
+        host.timed = ctx->timing;
         std::vector<float> lines;
 #pragma omp for schedule(dynamic, 1)
         for (int f = 0; f < F; f++) {
             const int b0 = l->frame_base[f];
             host.run(w, h, l->frame_base[f + 1] - b0, l->h_caddr + b0, l->h_cang + b0, l->h_cmod + b0, lines);
             to_keylines(lines, W, H, l->keylines[f]);
+        }
+        if (ctx->timing) {
+#pragma omp critical
+            { // CPU-milliseconds summed over the threads (divide by the thread count for wall time)
+                ctx->timings["host_lsd_cpu_sort"].total_ms += host.t_sort; ctx->timings["host_lsd_cpu_grow"].total_ms += host.t_grow; ctx->timings["host_lsd_cpu_rect"].total_ms += host.t_rect;
+                ctx->timings["host_lsd_n_seeds"].total_ms += (double)host.n_seeds; ctx->timings["host_lsd_n_regions"].total_ms += (double)host.n_regions; ctx->timings["host_lsd_n_pix"].total_ms += (double)host.n_pix;
+                ctx->timings["host_lsd_n_def"].total_ms += (double)l->frame_base[F] / omp_get_num_threads();
+                for (const char *k : {"host_lsd_cpu_sort", "host_lsd_cpu_grow", "host_lsd_cpu_rect", "host_lsd_n_seeds", "host_lsd_n_regions", "host_lsd_n_pix", "host_lsd_n_def"}) ctx->timings[k].count = 1;
+            }
         }
     }
     if (ctx->timing) { auto &rec = ctx->timings["host_lsd_regions"]; rec.total_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); rec.count++; }

@@ -23,3 +23,6 @@ for _ in range(5):
 t2 = time.perf_counter()
 print("OMP", os.environ.get("OMP_NUM_THREADS"), "F", F, "lsd.run %.1f ms (host %.1f)  orb.run %.1f ms (host %.1f)" % (
     (t1 - t0) / 5 * 1e3, ctx.timing_get("host_lsd_regions")[0] / 5, (t2 - t1) / 5 * 1e3, ctx.timing_get("host_orb_quadtree")[0] / 5))
+
+for k in ("host_lsd_cpu_sort", "host_lsd_cpu_grow", "host_lsd_cpu_rect", "host_lsd_n_seeds", "host_lsd_n_regions", "host_lsd_n_pix", "host_lsd_n_def"):
+    print(k, ctx.timing_get(k)[0] / 5)
