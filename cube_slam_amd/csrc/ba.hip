@@ -573,25 +573,37 @@ __global__ void __launch_bounds__(256) ba_band_chol(int C, int Bc, const double 
             for (int u = 0; u < 4; u++) if (tid + u * 256 < CS) pf[u] = src[tid + u * 256];
             if (tid < 6) pfb = rhs[(long)cn * 6 + tid];
         }
-        if (tid == 0) { // L_jj and y_j = L_jj^-1 b_j; 1/sqrt(pivot) from v_rsq_f64 + two Newton steps (the six pivots are a serial chain)
-            double M[36];
-            for (int k = 0; k < 36; k++) M[k] = Wc[k];
+        if (tid < 64) { // L_jj and y_j = L_jj^-1 b_j by lanes 0..5 of wave 0 (lane r = row r); 1/sqrt(pivot) from v_rsq_f64 + two Newton steps
+            const int r = tid < 6 ? tid : 0;
+            double m[6], l[6], invs[6], yv[6];
+#pragma unroll
+            for (int t = 0; t < 6; t++) { m[t] = Wc[r * 6 + t]; l[t] = 0; }
+            const double br = bw[(j % NS) * 6 + r];
+#pragma unroll
             for (int c = 0; c < 6; c++) {
-                double d = M[c * 6 + c];
-                for (int t = 0; t < c; t++) d -= M[c * 6 + t] * M[c * 6 + t];
+                double dsum = m[c], v = m[c];
+#pragma unroll
+                for (int t = 0; t < c; t++) { const double lct = __shfl(l[t], c); dsum = __builtin_fma(-l[t], l[t], dsum); v = __builtin_fma(-l[t], lct, v); }
+                double d = __shfl(dsum, c);
                 if (!(d > 0)) { fail = true; d = 1; }
                 double inv = __builtin_amdgcn_rsq(d);
                 inv = inv * (1.5 - (0.5 * d) * (inv * inv));
                 inv = inv * (1.5 - (0.5 * d) * (inv * inv));
-                M[c * 6 + c] = d * inv; Linv[c] = inv;
-                for (int r = c + 1; r < 6; r++) { double v = M[r * 6 + c]; for (int t = 0; t < c; t++) v -= M[r * 6 + t] * M[c * 6 + t]; M[r * 6 + c] = v * inv; }
-                for (int r = 0; r < c; r++) M[r * 6 + c] = 0;
+                l[c] = r == c ? d * inv : (r > c ? v * inv : 0.0);
+                invs[c] = inv;
             }
-            double y[6];
-            const double *bj = bw + (j % NS) * 6;
-            for (int r = 0; r < 6; r++) { double v = bj[r]; for (int t = 0; t < r; t++) v -= M[r * 6 + t] * y[t]; y[r] = v * Linv[r]; }
-            for (int k = 0; k < 36; k++) Wc[k] = M[k];
-            for (int r = 0; r < 6; r++) yj[r] = y[r];
+#pragma unroll
+            for (int t = 0; t < 6; t++) { // y_t = (b_t - sum_{u<t} L[t][u] y_u) / L[t][t], computed by lane t, broadcast
+                double sacc = br;
+#pragma unroll
+                for (int u = 0; u < t; u++) sacc = __builtin_fma(-l[u], yv[u], sacc);
+                yv[t] = __shfl(sacc * invs[t], t);
+            }
+            if (tid < 6) {
+#pragma unroll
+                for (int t = 0; t < 6; t++) Wc[r * 6 + t] = l[t];
+                Linv[r] = invs[r]; yj[r] = yv[r];
+            }
         }
         lds_barrier();
         for (int t = tid; t < nd * 6; t += 256) { // L_d = A_d L_jj^-T, one block row per thread
@@ -639,56 +651,73 @@ __global__ void __launch_bounds__(256) ba_band_chol(int C, int Bc, const double 
         }
         lds_barrier();
     }
-    // L^T x = y, last column first; xw: ring of solved blocks (re-uses the right-hand-side window); the columns of L come back
-    // from global memory through two LDS buffers, column j-1 is in flight while column j is used
-    double *xw = bw, *Lbuf = W, *ybuf2 = W + 2 * (long)CS; // ybuf2: 2 x 12 (y_j, 1/diag)
+    // L^T x = y, last column first.  The columns of L come back from global memory in chunks of KC columns through two LDS
+    // buffers (the whole workgroup loads chunk k+1 into registers while chunk k is used, one barrier per chunk); inside a chunk
+    // wave 0 works alone, without barriers: lane = part * 6 + c sums L_d^T x_{j+d} over the blocks d = 1 + part, 9 + part,
+    // 17 + part, shuffles reduce the 8 parts, lanes 0..5 finish with L_jj^T by lane broadcasts.  Solved blocks: LDS ring xw.
+    __syncthreads(); // every store to Lf / ybuf has completed
     {
-        const int j = C - 1;
-        for (int i = tid; i < 36; i += 256) Lbuf[(long)(j & 1) * CS + i] = __builtin_nontemporal_load(Lf + (long)j * CS + i);
-        if (tid < 12) ybuf2[(j & 1) * 12 + tid] = __builtin_nontemporal_load(ybuf + (long)j * 12 + tid);
-    }
-    lds_barrier();
-    for (int j = C - 1; j >= 0; j--) {
-        const int nd = (C - 1 - j) < Bc ? (C - 1 - j) : Bc;
-        const double *Lc = Lbuf + (long)(j & 1) * CS, *yl = ybuf2 + (j & 1) * 12;
-        double pf[4] = {0, 0, 0, 0}, pfy = 0;
-        const int jn = j - 1, ndn = (C - 1 - jn) < Bc ? (C - 1 - jn) : Bc;
-        if (j > 0) {
+        double *xw = bw;
+        const int KC = (NS - 1) / 2, CB = KC * CS;           // chunk: KC columns of CS doubles; buffers W[0..CB) and W[CB..2CB), >= CS doubles left for ych
+        double *ych = W + 2 * (long)CB;                      // 2 x KC x 12 (y_j, 1/diag) -- fits: NS*CS >= 2*CB + 24*KC for Bc >= 1
+        const int nchunk = (C + KC - 1) / KC;
+        auto chunk_lo = [&](int ch) { return C - (ch + 1) * KC < 0 ? 0 : C - (ch + 1) * KC; }; // chunk ch covers columns [lo, hi)
+        auto chunk_hi = [&](int ch) { return C - ch * KC; };
+        constexpr int PF = 12; // doubles per thread per chunk: KC * CS <= 11 * 756 / 2 ... checked by the host (Bc <= 20 -> CB <= 8316 -> 33 per thread)
+        double pf[36], pfy = 0;
+        auto issue = [&](int ch) {
+            const int lo = chunk_lo(ch), n = (chunk_hi(ch) - lo) * CS;
 #pragma unroll
-            for (int u = 0; u < 4; u++) if (tid + u * 256 < (ndn + 1) * 36) pf[u] = __builtin_nontemporal_load(Lf + (long)jn * CS + tid + u * 256);
-            if (tid < 12) pfy = __builtin_nontemporal_load(ybuf + (long)jn * 12 + tid);
-        }
-        if (tid < 48) { // partial sums over d = 1 + part, 9 + part, ...
-            const int c = tid % 6, pt = tid / 6;
-            double v = 0;
-            for (int d = 1 + pt; d <= nd; d += 8) { const double *Ld = Lc + d * 36, *xd = xw + ((j + d) % NS) * 6; for (int q = 0; q < 6; q++) v += Ld[q * 6 + c] * xd[q]; }
-            part[pt * 6 + c] = v;
-        }
+            for (int u = 0; u < 36; u++) { const int i = tid + u * 256; pf[u] = i < n ? __builtin_nontemporal_load(Lf + (long)lo * CS + i) : 0.0; }
+            const int ny = (chunk_hi(ch) - lo) * 12;
+            pfy = tid < ny ? __builtin_nontemporal_load(ybuf + (long)lo * 12 + tid) : 0.0;
+        };
+        auto commit = [&](int ch) {
+            const int lo = chunk_lo(ch), n = (chunk_hi(ch) - lo) * CS;
+            double *dst = W + (long)(ch & 1) * CB;
+#pragma unroll
+            for (int u = 0; u < 36; u++) { const int i = tid + u * 256; if (i < n) dst[i] = pf[u]; }
+            const int ny = (chunk_hi(ch) - lo) * 12;
+            if (tid < ny) ych[(ch & 1) * KC * 12 + tid] = pfy;
+        };
+        (void)PF;
+        issue(0); commit(0);
         lds_barrier();
-        if (tid < 64) { // lanes 0..5 of wave 0 hold s_c; back substitution with L_jj^T by lane broadcasts
-            const int c = tid < 6 ? tid : 0;
-            double sv = yl[c];
-            for (int pt = 0; pt < 8; pt++) sv -= part[pt * 6 + c];
-            double lcol[6]; // lcol[r] = L[r][c]
+        const int c = tid % 6, pt = tid / 6; // wave 0: pt 0..10, parts 8.. idle
+        const bool work = tid < 48;
+        for (int ch = 0; ch < nchunk; ch++) {
+            if (ch + 1 < nchunk) issue(ch + 1);
+            if (tid < 64) {
+                const int lo = chunk_lo(ch);
+                const double *Lb0 = W + (long)(ch & 1) * CB, *yb0 = ych + (ch & 1) * KC * 12;
+                for (int j = chunk_hi(ch) - 1; j >= lo; j--) {
+                    const int nd = (C - 1 - j) < Bc ? (C - 1 - j) : Bc;
+                    const double *Lc = Lb0 + (long)(j - lo) * CS, *yl = yb0 + (j - lo) * 12;
+                    double v = 0;
+                    for (int d = 1 + pt; work && d <= nd; d += 8) {
+                        const double *Ld = Lc + d * 36 + c, *xd = xw + ((j + d) % NS) * 6;
 #pragma unroll
-            for (int r = 0; r < 6; r++) lcol[r] = Lc[r * 6 + c];
-            const double inv = yl[6 + c];
-            double xv = 0;
+                        for (int q = 0; q < 6; q++) v = __builtin_fma(Ld[q * 6], xd[q], v);
+                    }
+                    v += __shfl_down(v, 24); v += __shfl_down(v, 12); v += __shfl_down(v, 6); // lanes 0..5: sum over the parts
+                    double lcol[6];
 #pragma unroll
-            for (int k = 5; k >= 0; k--) {
-                const double cand = sv * inv;
-                const double xk = __shfl(cand, k); // x_k, final because lanes > k already contributed
-                if (tid == k) xv = xk;
-                if (tid < k) sv -= lcol[k] * xk; // s_c -= L[k][c] x_k
+                    for (int r = 0; r < 6; r++) lcol[r] = Lc[r * 6 + c];
+                    const double inv = yl[6 + c];
+                    double sv = yl[c] - v, xv = 0;
+#pragma unroll
+                    for (int k = 5; k >= 0; k--) {
+                        const double xk = __shfl(sv * inv, k); // x_k, final because lanes > k already contributed
+                        if (tid == k) xv = xk;
+                        if (tid < k) sv = __builtin_fma(-lcol[k], xk, sv); // s_c -= L[k][c] x_k
+                    }
+                    if (tid < 6) { xw[(j % NS) * 6 + tid] = xv; rhs[(long)j * 6 + tid] = xv; }
+                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                }
             }
-            if (tid < 6) { xw[(j % NS) * 6 + tid] = xv; rhs[(long)j * 6 + tid] = xv; }
+            if (ch + 1 < nchunk) commit(ch + 1);
+            lds_barrier();
         }
-        if (j > 0) {
-#pragma unroll
-            for (int u = 0; u < 4; u++) if (tid + u * 256 < (ndn + 1) * 36) Lbuf[(long)(jn & 1) * CS + tid + u * 256] = pf[u];
-            if (tid < 12) ybuf2[(jn & 1) * 12 + tid] = pfy;
-        }
-        lds_barrier();
     }
     if (tid == 0 && fail) *status = 1;
 }
