@@ -359,8 +359,8 @@ __global__ void __launch_bounds__(256) cuboid_canny_nms(const Unit *units, const
             if (keep) code = m > high ? 2 : 1;
         }
         long p = (long)y * U.roi_w + x;
-        emap[U.pix_off + p] = code;
-        if (code) lab[U.pix_off + p] = code == 2 ? (int)p : (int)(p + (long)U.roi_w * U.roi_h);
+        // the map is zero-filled before the launch; only edge candidates are written (byte stores of whole rows were the bulk of this kernel's time)
+        if (code) { emap[U.pix_off + p] = code; lab[U.pix_off + p] = code == 2 ? (int)p : (int)(p + (long)U.roi_w * U.roi_h); }
     }
 }
 
@@ -546,7 +546,7 @@ __device__ __forceinline__ void dt_block_pass(const Unit &U, const uint8_t *em, 
         const int b = r & 1;
         if (lane == 63) s_tot[b][wave] = sc;
         if (lane == 0) s_first[b][wave] = uval;
-        __syncthreads();
+        lds_barrier(); // LDS-only: __syncthreads() would also wait for the previous row's global store and the prefetched loads
         int t = (lane < wave) ? s_tot[b][lane] : INT_MAX;
         t = wave_incl_min_scan(t);
         int carry = min(init_carry, __builtin_amdgcn_readlane(t, 63));
@@ -1465,6 +1465,7 @@ int cs_cuboid_batch_run(cs_ctx *ctx, cs_cuboid_batch *b) {
               b->d_lines_in, b->d_lines_al);
     CS_LAUNCH(ctx, "cuboid_unit_lines", cuboid_unit_lines, dim3(U), dim3(64), 0, b->d_units, b->d_ud, b->d_fi, b->d_lines_al, b->d_mlines,
               b->d_mangle, b->d_mmid, b->d_status);
+    CS_HIP(ctx, hipMemsetAsync(b->d_emap, 0, (size_t)b->pix_total, ctx->stream));
     CS_LAUNCH(ctx, "cuboid_canny_nms", cuboid_canny_nms, dim3(b->max_tiles, U), dim3(256), 0, b->d_units, b->d_gray, b->W, b->H, b->d_emap,
               b->d_lab, b->o.canny_low, b->o.canny_high);
     for (int stage = 0; stage < 2; stage++)
