@@ -416,6 +416,310 @@ static inline int h_cvRound(double v) { return (int)std::lrint(v); }
 static inline int h_cvFloor(double v) { int i = (int)v; return i - (i > v); }
 static inline int h_cvCeil(double v) { int i = (int)v; return i + (i < v); }
 
+// ------------------------------------------------------------------------------------------------ keypoint distribution on the device
+// ORBextractor::DistributeOctTree / ExtractorNode::DivideNode (reference ORBextractor.cc:483-538, :540-763), one workgroup per
+// (frame, level).  Same selection and the same output order as the host version (orb_quadtree.h), re-expressed without a linked
+// list: a pass of the first phase replaces the list by [children of the last expandable node, n4..n1, ..., children of the first
+// expandable node] ++ [nodes that are not expandable, in order] (validated against the sequential list surgery on random inputs);
+// the second phase (largest nodes first until the quota is reached) is sequential by nature and runs in wave 0, with the point
+// partition of every split done by the wave.  Node records live in global memory (int4: x0|y0<<16, x1|y1<<16, begin, end), the
+// lists in LDS.  Equal-size ties of the second phase are broken by creation order.
+struct QtLevel { int N, minX, maxX, minY, maxY, node_off, capn, slot_off; };
+struct QtParams { QtLevel l[MAXL]; int nlevels, nodes_per_frame, slots_per_frame; };
+
+__device__ __forceinline__ int qt_quadrant(const float *K, int idx, int mx, int my) {
+    const float x = K[idx * 3], y = K[idx * 3 + 1];
+    return (x < mx) ? ((y < my) ? 0 : 2) : ((y < my) ? 1 : 3);
+}
+// stable 4-way partition of perm[begin, end) by one wave; c[4] = sizes.  cls(idx) -> 0..3
+template <class F> __device__ __forceinline__ void qt_wave_partition(int *perm, int *tmp, int begin, int end, F cls, int (&c)[4]) {
+    const int lane = threadIdx.x & 63;
+    int cnt[4] = {0, 0, 0, 0};
+    for (int p0 = begin; p0 < end; p0 += 64) { // counts
+        const int p = p0 + lane;
+        const int q = p < end ? cls(perm[p]) : -1;
+#pragma unroll
+        for (int k = 0; k < 4; k++) cnt[k] += __popcll(__ballot(q == k));
+    }
+    int pos[4] = {begin, begin + cnt[0], begin + cnt[0] + cnt[1], begin + cnt[0] + cnt[1] + cnt[2]};
+    for (int p0 = begin; p0 < end; p0 += 64) {
+        const int p = p0 + lane;
+        const int v = p < end ? perm[p] : 0;
+        const int q = p < end ? cls(v) : -1;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const unsigned long long m = __ballot(q == k);
+            if (q == k) tmp[pos[k] + __popcll(m & ((1ull << lane) - 1))] = v;
+            pos[k] += __popcll(m);
+        }
+    }
+    __threadfence_block();
+    for (int p = begin + lane; p < end; p += 64) perm[p] = tmp[p];
+    __threadfence_block();
+#pragma unroll
+    for (int k = 0; k < 4; k++) c[k] = cnt[k];
+}
+__device__ __forceinline__ void qt_child_box(const int4 nd, int k, int &x0, int &y0, int &x1, int &y1) { // DivideNode :483-538
+    const int px0 = nd.x & 0xffff, py0 = nd.x >> 16, px1 = nd.y & 0xffff, py1 = nd.y >> 16;
+    const int halfX = (int)ceilf(static_cast<float>(px1 - px0) / 2), halfY = (int)ceilf(static_cast<float>(py1 - py0) / 2);
+    const int mx = px0 + halfX, my = py0 + halfY;
+    x0 = (k & 1) ? mx : px0; x1 = (k & 1) ? px1 : mx;
+    y0 = (k & 2) ? my : py0; y1 = (k & 2) ? py1 : my;
+}
+__global__ void __launch_bounds__(256) orb_quadtree(QtParams Q, const int *level_base, const float *cand, int *perm_all, int *tmp_all, int4 *nodes_all, SelKP *slots, int *slot_cnt,
+                                                   int *status) {
+    extern __shared__ int qsh[];
+    const int lv = blockIdx.x, f = blockIdx.y, fl = f * Q.nlevels + lv, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const QtLevel L = Q.l[lv];
+    const int b0 = level_base[fl], n = level_base[fl + 1] - b0;
+    const float *K = cand + (long)b0 * 3;
+    int *perm = perm_all + b0, *tmp = tmp_all + b0;
+    int4 *nodes = nodes_all + (long)f * Q.nodes_per_frame + L.node_off;
+    SelKP *out = slots + (long)f * Q.slots_per_frame + L.slot_off;
+    const int N = L.N, CAPL = 4 * N + 16, CAPV = N + 8, CAPN = L.capn;
+    // LDS carve-up (ints)
+    short *listA = (short *)qsh, *listB = listA + CAPL, *Elist = listB + CAPL, *front = Elist + CAPL;          // 4 x CAPL shorts
+    unsigned long long *cnt64 = (unsigned long long *)(front + CAPL);                                            // CAPV
+    unsigned long long *vkA = cnt64 + CAPV, *vkB = vkA + CAPV;                                                    // 2 x CAPV keys (size << 32 | id)
+    int *P = (int *)(vkB + CAPV);                                                                                // CAPV + 1 prefix of child counts
+    int *Pv = P + CAPV + 1;                                                                                      // CAPV + 1 prefix of children with > 1 point
+    unsigned *dead = (unsigned *)(Pv + CAPV + 1);                                                                // (CAPN + 31) / 32
+    short *order = (short *)(dead + (CAPN + 31) / 32);                                                           // CAPV
+    __shared__ int s_i[16];
+    __shared__ int s_w[8];
+    if (tid == 0) slot_cnt[fl] = 0;
+    const int nIni = (int)roundf(static_cast<float>(L.maxX - L.minX) / (L.maxY - L.minY));
+    if (n <= 0 || nIni < 1) return;
+    if (nIni > 4) { if (tid == 0) *status = 2; return; } // host path handles panoramas
+    const float hX = static_cast<float>(L.maxX - L.minX) / nIni;
+    for (int i = tid; i < n; i += 256) perm[i] = i;
+    for (int i = tid; i < (CAPN + 31) / 32; i += 256) dead[i] = 0;
+    __syncthreads();
+    int n_nodes = 0, n_list = 0; // uniform across the workgroup (recomputed identically by every thread from LDS broadcasts)
+    short *list = listA, *nlist = listB;
+    // ---- root nodes (:551-586): stable bucket by x / hX, wave 0
+    if (wave == 0) {
+        int c[4];
+        qt_wave_partition(perm, tmp, 0, n, [&](int idx) { int b = (int)(K[idx * 3] / hX); return b >= nIni ? nIni - 1 : b; }, c);
+        if (lane == 0) {
+            int beg = 0, cntn = 0;
+            for (int b = 0; b < nIni; b++) {
+                if (c[b] > 0) {
+                    const int x0 = (int)(hX * static_cast<float>(b)), x1 = (int)(hX * static_cast<float>(b + 1));
+                    nodes[cntn] = make_int4(x0 | (0 << 16), x1 | ((L.maxY - L.minY) << 16), beg, beg + c[b]);
+                    listA[cntn] = (short)cntn;
+                    cntn++;
+                }
+                beg += c[b];
+            }
+            s_i[0] = cntn;
+        }
+    }
+    __threadfence_block();
+    __syncthreads();
+    n_nodes = s_i[0]; n_list = n_nodes;
+    bool finish = false, overflow = false;
+    int n_vk = 0; // entries in vkA
+    while (!finish) {
+        const int prev_size = n_list;
+        // ---- a. expandable nodes (more than one point) keep list order in Elist; the others go to the tail of the new list later
+        //      ordered compaction by the whole workgroup
+        int nE = 0, nKeepBefore = 0;
+        {
+            int baseE = 0;
+            for (int i0 = 0; i0 < n_list; i0 += 256) {
+                const int i = i0 + tid;
+                int id = -1; bool ex = false;
+                if (i < n_list) { id = list[i]; const int4 nd = nodes[id]; ex = (nd.w - nd.z) > 1; }
+                const unsigned long long m = __ballot(ex);
+                if (lane == 0) s_w[wave] = __popcll(m);
+                __syncthreads();
+                int wb = 0;
+                for (int w = 0; w < wave; w++) wb += s_w[w];
+                const int tot = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+                if (ex) Elist[baseE + wb + __popcll(m & ((1ull << lane) - 1))] = (short)id;
+                baseE += tot;
+                __syncthreads();
+            }
+            nE = baseE;
+            (void)nKeepBefore;
+        }
+        if (nE >= CAPV) { overflow = true; break; }
+        // ---- b. split the points of every expandable node (one wave per node), child sizes packed 4 x 16 bit
+        for (int e = wave; e < nE; e += 4) {
+            const int4 nd = nodes[Elist[e]];
+            int x0, y0, x1, y1;
+            qt_child_box(nd, 0, x0, y0, x1, y1); // (x1, y1) of child 0 = the split point (mx, my)
+            const int mx = x1, my = y1;
+            int c[4];
+            qt_wave_partition(perm, tmp, nd.z, nd.w, [&](int idx) { return qt_quadrant(K, idx, mx, my); }, c);
+            if (lane == 0) cnt64[e] = (unsigned long long)c[0] | ((unsigned long long)c[1] << 16) | ((unsigned long long)c[2] << 32) | ((unsigned long long)c[3] << 48);
+        }
+        __threadfence_block();
+        __syncthreads();
+        // ---- c. prefix sums over the expandable nodes (children, children with more than one point): wave 0, 64 at a time
+        if (wave == 0) {
+            int runK = 0, runV = 0;
+            for (int e0 = 0; e0 < nE; e0 += 64) {
+                const int e = e0 + lane;
+                int k = 0, v = 0;
+                if (e < nE) { const unsigned long long c = cnt64[e]; for (int q = 0; q < 4; q++) { const int s = (int)((c >> (16 * q)) & 0xffff); k += s > 0; v += s > 1; } }
+                int ik = k, iv = v;
+                for (int d = 1; d < 64; d <<= 1) { const int a = __shfl_up(ik, d), b2 = __shfl_up(iv, d); if (lane >= d) { ik += a; iv += b2; } }
+                if (e < nE) { P[e] = runK + ik - k; Pv[e] = runV + iv - v; }
+                runK += __shfl(ik, 63); runV += __shfl(iv, 63);
+            }
+            if (lane == 0) { P[nE] = runK; Pv[nE] = runV; }
+        }
+        __syncthreads();
+        const int T = P[nE], nV = Pv[nE];
+        const int n_keep = n_list - nE;
+        if (n_nodes + T > CAPN || T + n_keep > CAPL) { overflow = true; break; }
+        // ---- d. child records, new list, (size, id) entries in creation order
+        for (int e = tid; e < nE; e += 256) {
+            const int4 nd = nodes[Elist[e]];
+            const unsigned long long c = cnt64[e];
+            int beg = nd.z, j = 0, jv = 0;
+            int kk = 0;
+            for (int q = 0; q < 4; q++) kk += ((c >> (16 * q)) & 0xffff) > 0;
+            for (int q = 0; q < 4; q++) {
+                const int s = (int)((c >> (16 * q)) & 0xffff);
+                if (s > 0) {
+                    int x0, y0, x1, y1;
+                    qt_child_box(nd, q, x0, y0, x1, y1);
+                    const int id = n_nodes + P[e] + j;
+                    nodes[id] = make_int4(x0 | (y0 << 16), x1 | (y1 << 16), beg, beg + s);
+                    nlist[(T - P[e] - kk) + (kk - 1 - j)] = (short)id;
+                    if (s > 1) { if (Pv[e] + jv < CAPV) vkA[Pv[e] + jv] = ((unsigned long long)s << 32) | (unsigned)id; jv++; }
+                    j++;
+                }
+                beg += s;
+            }
+        }
+        // non-expandable nodes keep their order behind the children: ordered compaction again
+        {
+            int baseK = T;
+            for (int i0 = 0; i0 < n_list; i0 += 256) {
+                const int i = i0 + tid;
+                int id = -1; bool kp = false;
+                if (i < n_list) { id = list[i]; const int4 nd = nodes[id]; kp = (nd.w - nd.z) <= 1; }
+                const unsigned long long m = __ballot(kp);
+                if (lane == 0) s_w[wave] = __popcll(m);
+                __syncthreads();
+                int wb = 0;
+                for (int w = 0; w < wave; w++) wb += s_w[w];
+                const int tot = s_w[0] + s_w[1] + s_w[2] + s_w[3];
+                if (kp) nlist[baseK + wb + __popcll(m & ((1ull << lane) - 1))] = (short)id;
+                baseK += tot;
+                __syncthreads();
+            }
+        }
+        __threadfence_block();
+        __syncthreads();
+        n_nodes += T;
+        n_list = T + n_keep;
+        n_vk = nV < CAPV ? nV : CAPV;
+        { short *t = list; list = nlist; nlist = t; }
+        if (n_list >= N || n_list == prev_size) finish = true;
+        else if (n_list + nV * 3 > N) {
+            if (nV >= CAPV) { overflow = true; break; }
+            // ---- second phase (:676-741), wave 0: split the largest nodes first until the quota is reached
+            if (wave == 0) {
+                int cur = n_list, nfront = 0, nn = n_nodes, nvk = n_vk;
+                unsigned long long *vk = vkA, *vn = vkB;
+                bool fin = false, ovf = false;
+                while (!fin && !ovf) {
+                    const int ps = cur, m = nvk;
+                    // rank sort ascending by (size, id): order[rank] = entry
+                    for (int i = lane; i < m; i += 64) {
+                        const unsigned long long ki = vk[i];
+                        int rnk = 0;
+                        for (int j = 0; j < m; j++) rnk += vk[j] < ki;
+                        order[rnk] = (short)i;
+                    }
+                    __threadfence_block();
+                    int nvn = 0;
+                    for (int j = m - 1; j >= 0; j--) {
+                        const int id = (int)(vk[order[j]] & 0xffffffffu);
+                        const int4 nd = nodes[id];
+                        int x0, y0, x1, y1;
+                        qt_child_box(nd, 0, x0, y0, x1, y1);
+                        const int mx = x1, my = y1;
+                        int c[4];
+                        qt_wave_partition(perm, tmp, nd.z, nd.w, [&](int idx) { return qt_quadrant(K, idx, mx, my); }, c);
+                        int kk = (c[0] > 0) + (c[1] > 0) + (c[2] > 0) + (c[3] > 0);
+                        if (nn + kk > CAPN || nfront + kk > CAPL || nvn + kk > CAPV) { ovf = true; break; }
+                        if (lane == 0) {
+                            int beg = nd.z, jn = 0;
+                            for (int q = 0; q < 4; q++) {
+                                if (c[q] > 0) {
+                                    qt_child_box(nd, q, x0, y0, x1, y1);
+                                    nodes[nn + jn] = make_int4(x0 | (y0 << 16), x1 | (y1 << 16), beg, beg + c[q]);
+                                    front[nfront + jn] = (short)(nn + jn);
+                                    jn++;
+                                }
+                                beg += c[q];
+                            }
+                            dead[id >> 5] |= 1u << (id & 31);
+                        }
+                        { int jn = 0; for (int q = 0; q < 4; q++) if (c[q] > 0) { if (c[q] > 1) { if (lane == 0) vn[nvn] = ((unsigned long long)c[q] << 32) | (unsigned)(nn + jn); nvn++; } jn++; } }
+                        nn += kk; nfront += kk; cur += kk - 1;
+                        __threadfence_block();
+                        if (cur >= N) break;
+                    }
+                    if (cur >= N || cur == ps) fin = true;
+                    { unsigned long long *t = vk; vk = vn; vn = t; }
+                    nvk = nvn;
+                }
+                // final list: pushed children newest first, then the survivors of the first-phase list
+                int o = 0;
+                if (!ovf) {
+                    for (int k0 = nfront - 1; k0 >= 0; k0 -= 64) {
+                        const int k = k0 - lane;
+                        int id = -1; bool al = false;
+                        if (k >= 0) { id = front[k]; al = !((dead[id >> 5] >> (id & 31)) & 1u); }
+                        const unsigned long long mm = __ballot(al);
+                        if (al) nlist[o + __popcll(mm & ((1ull << lane) - 1))] = (short)id;
+                        o += __popcll(mm);
+                    }
+                    for (int i0 = 0; i0 < n_list; i0 += 64) {
+                        const int i = i0 + lane;
+                        int id = -1; bool al = false;
+                        if (i < n_list) { id = list[i]; al = !((dead[id >> 5] >> (id & 31)) & 1u); }
+                        const unsigned long long mm = __ballot(al);
+                        if (al) nlist[o + __popcll(mm & ((1ull << lane) - 1))] = (short)id;
+                        o += __popcll(mm);
+                    }
+                }
+                if (lane == 0) { s_i[1] = o; s_i[2] = ovf ? 1 : 0; }
+            }
+            __threadfence_block();
+            __syncthreads();
+            if (s_i[2]) { overflow = true; break; }
+            n_list = s_i[1];
+            { short *t = list; list = nlist; nlist = t; }
+            finish = true;
+        }
+    }
+    if (overflow) { if (tid == 0) { *status = 1; slot_cnt[fl] = 0; } return; }
+    // ---- best response per node, first wins ties (:744-760); keypoint in level coordinates (:841-844)
+    for (int i = tid; i < n_list; i += 256) {
+        const int4 nd = nodes[list[i]];
+        int best = perm[nd.z];
+        float mxr = K[best * 3 + 2];
+        for (int p = nd.z + 1; p < nd.w; p++) { const int idx = perm[p]; const float rr = K[idx * 3 + 2]; if (rr > mxr) { best = idx; mxr = rr; } }
+        out[i] = SelKP{K[best * 3] + L.minX, K[best * 3 + 1] + L.minY, K[best * 3 + 2], lv, f};
+    }
+    if (tid == 0) slot_cnt[fl] = n_list;
+}
+// slotted selections -> contiguous level-major list per frame
+__global__ void __launch_bounds__(256) orb_compact_sel(QtParams Q, const SelKP *slots, const int *slot_cnt, const int *sel_base, SelKP *sel) {
+    const int lv = blockIdx.x, f = blockIdx.y, fl = f * Q.nlevels + lv;
+    const SelKP *src = slots + (long)f * Q.slots_per_frame + Q.l[lv].slot_off;
+    const int n = slot_cnt[fl], b = sel_base[fl];
+    for (int i = threadIdx.x; i < n; i += 256) sel[b + i] = src[i];
+}
+
 } // namespace
 
 struct cs_orb {
@@ -432,6 +736,11 @@ struct cs_orb {
     short *d_ialpha = nullptr, *d_ibeta = nullptr;
     float *d_cand = nullptr, *d_angle = nullptr;
     SelKP *d_sel = nullptr;
+    // device keypoint distribution (orb_quadtree): scratch + slotted results
+    QtParams Q{}; bool gpu_quadtree = false; size_t qt_lds = 0;
+    int *d_qperm = nullptr, *d_qtmp = nullptr, *d_slot_cnt = nullptr, *d_sel_base = nullptr, *d_qstatus = nullptr; int4 *d_qnodes = nullptr; SelKP *d_slots = nullptr;
+    std::vector<int> sel_base;
+    bool cand_valid = false; // host copy of the candidates is current (device quadtree skips the copy)
     cs_keypoint *d_kps = nullptr;
     unsigned long long *d_desc = nullptr;
     long sel_cap = 0;
@@ -448,7 +757,8 @@ void cs_orb_destroy(cs_ctx *ctx, cs_orb *e) {
     if (!e) return;
     if (ctx) { hipSetDevice(ctx->device); hipStreamSynchronize(ctx->stream); }
     void *ptrs[] = {e->d_pyr, e->d_smap, e->d_blur, e->d_xofs, e->d_yofs, e->d_cell_count, e->d_cell_base, e->d_level_total, e->d_level_base,
-                    e->d_ialpha, e->d_ibeta, e->d_cand, e->d_angle, e->d_sel, e->d_kps, e->d_desc};
+                    e->d_ialpha, e->d_ibeta, e->d_cand, e->d_angle, e->d_sel, e->d_kps, e->d_desc, e->d_qperm, e->d_qtmp, e->d_slot_cnt, e->d_sel_base, e->d_qstatus,
+                    e->d_qnodes, e->d_slots};
     for (void *p : ptrs) if (p) hipFree(p);
     delete e;
 }
@@ -556,6 +866,32 @@ int cs_orb_create(cs_ctx *ctx, int nfeatures, float scaleFactor, int nlevels, in
     A_(cs_dalloc(ctx, &e->d_angle, (size_t)e->sel_cap));
     A_(cs_dalloc(ctx, &e->d_kps, (size_t)e->sel_cap));
     A_(cs_dalloc(ctx, &e->d_desc, (size_t)e->sel_cap * 4));
+    { // device quadtree plan: per level quota, node pool and result slots; LDS need of the largest level
+        QtParams &Q = e->Q;
+        Q.nlevels = nlevels;
+        int node_off = 0, slot_off = 0, maxN = 0;
+        bool ok = true;
+        for (int l = 0; l < nlevels; l++) {
+            const Lvl &L = e->P.l[l];
+            QtLevel &q = Q.l[l];
+            q.N = e->mnFeaturesPerLevel[l]; q.minX = MINB; q.maxX = L.maxBX; q.minY = MINB; q.maxY = L.maxBY;
+            q.capn = 12 * std::max(q.N, 1) + 64; q.node_off = node_off; q.slot_off = slot_off;
+            node_off += q.capn; slot_off += 4 * std::max(q.N, 1) + 16;
+            maxN = std::max(maxN, q.N);
+            if (L.maxBX >= 32768 || L.maxBY >= 32768) ok = false;
+        }
+        Q.nodes_per_frame = node_off; Q.slots_per_frame = slot_off;
+        const int CAPL = 4 * std::max(maxN, 1) + 16, CAPV = std::max(maxN, 1) + 8, CAPN = 12 * std::max(maxN, 1) + 64;
+        e->qt_lds = (size_t)8 * CAPL + (size_t)8 * CAPV * 3 + (size_t)4 * (CAPV + 1) * 2 + (size_t)4 * ((CAPN + 31) / 32) + (size_t)2 * CAPV + 64;
+        const char *force = getenv("CUBESLAM_ORB_QUADTREE"); // "host": keep DistributeOctTree on the host (tests compare both)
+        e->gpu_quadtree = ok && maxN >= 1 && CAPN < 32768 && e->qt_lds <= 150 * 1024 && !(force && !strcmp(force, "host"));
+        if (e->gpu_quadtree) {
+            A_(cs_dalloc(ctx, &e->d_qperm, (size_t)e->cand_cap)); A_(cs_dalloc(ctx, &e->d_qtmp, (size_t)e->cand_cap));
+            A_(cs_dalloc(ctx, &e->d_qnodes, (size_t)Q.nodes_per_frame * max_frames)); A_(cs_dalloc(ctx, &e->d_slots, (size_t)Q.slots_per_frame * max_frames));
+            A_(cs_dalloc(ctx, &e->d_slot_cnt, (size_t)nlevels * max_frames)); A_(cs_dalloc(ctx, &e->d_sel_base, (size_t)nlevels * max_frames + 1));
+            A_(cs_dalloc(ctx, &e->d_qstatus, (size_t)1));
+        }
+    }
     A_(cs_h2d(ctx, e->d_xofs, xofs.data(), xofs.size()));
     A_(cs_h2d(ctx, e->d_yofs, yofs.data(), yofs.size()));
     A_(cs_h2d(ctx, e->d_ialpha, ialpha.data(), ialpha.size()));
@@ -606,13 +942,44 @@ int cs_orb_run(cs_ctx *ctx, cs_orb *e) {
     const long total = e->level_base[(size_t)F * NL];
     if (total > e->cand_cap) { ctx->err = "ORB candidate capacity exceeded"; return CS_ERR_CAPACITY; }
     CS_LAUNCH(ctx, "orb_cells", orb_cells, dim3(P.cells_per_frame, F), dim3(64), 0, P, e->d_smap, 1, e->d_cell_count, e->d_cell_base, e->d_cand);
+    bool on_device = e->gpu_quadtree;
+    if (on_device) {
+        // ---- DistributeOctTree on the device: no candidate round trip; the blur runs behind it
+        CS_HIP(ctx, hipMemsetAsync(e->d_qstatus, 0, sizeof(int), ctx->stream));
+        if (e->qt_lds > 64 * 1024) CS_HIP(ctx, hipFuncSetAttribute((const void *)orb_quadtree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->qt_lds));
+        CS_LAUNCH(ctx, "orb_quadtree", orb_quadtree, dim3(NL, F), dim3(256), e->qt_lds, e->Q, e->d_level_base, e->d_cand, e->d_qperm, e->d_qtmp, e->d_qnodes, e->d_slots,
+                  e->d_slot_cnt, e->d_qstatus);
+        CS_LAUNCH(ctx, "orb_scan", orb_scan_levels, dim3(1), dim3(64), 0, F * NL, e->d_slot_cnt, e->d_sel_base);
+        e->sel_base.resize((size_t)F * NL + 1);
+        int qstatus = 0;
+        r = cs_d2h(ctx, e->sel_base.data(), e->d_sel_base, e->sel_base.size()); if (r) return r;
+        r = cs_d2h(ctx, &qstatus, e->d_qstatus, 1); if (r) return r;
+        CS_LAUNCH(ctx, "orb_blur", orb_blur, dim3(e->max_blur_blocks, NL, F), dim3(64), 0, P, e->d_pyr, e->d_blur);
+        CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        e->cand_valid = false;
+        if (qstatus != 0) on_device = false; // panorama / pool overflow: redo this batch on the host
+        else {
+            const int n = e->sel_base[(size_t)F * NL];
+            e->frame_first.assign((size_t)F + 1, 0);
+            for (int f = 0; f <= F; f++) e->frame_first[f] = e->sel_base[(size_t)std::min(f, F) * NL];
+            if (n > e->sel_cap) { ctx->err = "ORB keypoint capacity exceeded"; return CS_ERR_CAPACITY; }
+            if (n == 0) return CS_OK;
+            CS_LAUNCH(ctx, "orb_compact_sel", orb_compact_sel, dim3(NL, F), dim3(256), 0, e->Q, e->d_slots, e->d_slot_cnt, e->d_sel_base, e->d_sel);
+            CS_LAUNCH(ctx, "orb_angle", orb_angle, dim3((n + 3) / 4), dim3(256), 0, P, e->d_pyr, e->d_sel, n, e->d_angle);
+            CS_LAUNCH(ctx, "orb_desc", orb_desc, dim3((n + 3) / 4), dim3(256), 0, P, e->d_blur, e->d_sel, e->d_angle, n, e->d_kps, e->d_desc);
+            CS_HIP(ctx, hipGetLastError());
+            return CS_OK;
+        }
+    }
+    const bool blur_done = e->gpu_quadtree; // the device attempt already ran the blur
     e->cand.resize((size_t)std::max<long>(total, 1));
     r = cs_d2h(ctx, (float *)e->cand.data(), e->d_cand, (size_t)total * 3); if (r) return r;
     hipEvent_t ev_cand = ctx->get_event();
     CS_HIP(ctx, hipEventRecord(ev_cand, ctx->stream));
     // the blur does not depend on the selection: queued behind the candidate copy, it overlaps the host quadtree
-    CS_LAUNCH(ctx, "orb_blur", orb_blur, dim3(e->max_blur_blocks, NL, F), dim3(64), 0, P, e->d_pyr, e->d_blur);
+    if (!blur_done) CS_LAUNCH(ctx, "orb_blur", orb_blur, dim3(e->max_blur_blocks, NL, F), dim3(64), 0, P, e->d_pyr, e->d_blur);
     CS_HIP(ctx, hipEventSynchronize(ev_cand));
+    e->cand_valid = true;
     ctx->pool.push_back(ev_cand);
     // ---- host: DistributeOctTree per (frame, level), ORBextractor.cc:831-832
     const auto t_host0 = std::chrono::steady_clock::now();
@@ -701,6 +1068,13 @@ int cs_orb_get_candidates(cs_ctx *ctx, cs_orb *e, int frame, int level, float *x
     if (e->level_base.size() <= fl + 1) return CS_ERR_BAD_ARG;
     const long b0 = e->level_base[fl], cnt = e->level_base[fl + 1] - b0;
     *n = (int)cnt;
+    if (xyr && !e->cand_valid) { // the device quadtree does not copy the candidates to the host: fetch them now
+        const long total = e->level_base.back();
+        e->cand.resize((size_t)std::max<long>(total, 1));
+        int r = cs_d2h(ctx, (float *)e->cand.data(), e->d_cand, (size_t)total * 3); if (r) return r;
+        CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        e->cand_valid = true;
+    }
     if (xyr) for (long i = 0; i < cnt && i < cap; i++) { xyr[i * 3] = e->cand[b0 + i].x; xyr[i * 3 + 1] = e->cand[b0 + i].y; xyr[i * 3 + 2] = e->cand[b0 + i].response; }
     return CS_OK;
 }

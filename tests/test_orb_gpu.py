@@ -62,3 +62,24 @@ def test_flat_image_and_thresholds(ctx, oracle):
     gk, gd = ext2(img2)
     assert gk.tobytes() == rk.tobytes() and np.array_equal(gd, rd)
     ext2.close()
+
+
+def test_device_and_host_quadtree_agree(ctx, monkeypatch):
+    """DistributeOctTree on the device (default) and on the host select the same keypoints in the same order."""
+    from cube_slam_amd import synth
+    from cube_slam_amd.orb import ORBextractor
+    imgs = np.stack([synth.texture_image(31 + i, 640, 480, shift=5 * i) for i in range(3)] + [synth.cuboid_scene(9)["gray"]])
+    res = {}
+    for mode in ("host", "device"):
+        if mode == "host":
+            monkeypatch.setenv("CUBESLAM_ORB_QUADTREE", "host")
+        else:
+            monkeypatch.delenv("CUBESLAM_ORB_QUADTREE", raising=False)
+        for nfeat in (300, 2000):
+            e = ORBextractor(nfeat, 1.2, 8, 20, 7, 640, 480, max_frames=len(imgs), ctx=ctx)
+            e.upload(imgs); e.run()
+            res[(mode, nfeat)] = e.read()
+    for nfeat in (300, 2000):
+        for (ka, da), (kb, db) in zip(res[("host", nfeat)], res[("device", nfeat)]):
+            assert len(ka) == len(kb) and len(ka) > 50
+            assert ka.tobytes() == kb.tobytes() and np.array_equal(da, db)
