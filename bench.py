@@ -156,34 +156,23 @@ def main():
     lsd = None
     if not args.no_lines:
         from cube_slam_amd.lsd import line_lbd_detect
-        # the line path has its own context (= HIP stream) and host thread: its host stage (region growing) overlaps the ORB and
-        # cuboid kernels of the same step
-        # of the same step.  Two detectors alternate steps (each with its own stream): the GPU phases of one step (gradient maps before,
-        # LBD descriptors after the host stage) overlap the region growing of the neighbouring step; the library serialises the
-        # host stages, so the cores are never split between two OpenMP teams.
+        # The library's front-end runner (cs_frontend_*, csrc/frontend.hip) runs ORB + cuboid on this thread and the line path on worker
+        # threads with their own contexts (= HIP streams).  Two detectors alternate steps: the GPU phases of one step (gradient maps
+        # before, LBD descriptors after the host stage) overlap the region growing of the neighbouring step; the library serialises
+        # the host stages, so the cores are never split between two OpenMP teams.
         ctx_lines = [_lib.Context(local_rank), _lib.Context(local_rank)]
         lsds = [line_lbd_detect(640, 480, max_frames=args.frames, ctx=c) for c in ctx_lines]
         for d_ in lsds:
             d_.upload(np.stack([s["gray"] for s in scenes]))
         lsd = lsds[0]
-        from concurrent.futures import ThreadPoolExecutor
-        pool = ThreadPoolExecutor(2)
-    pending = []
-    step_no = [0]
+    from cube_slam_amd.frontend import Frontend
+    fe = Frontend(ctx, orb=orb, batch=batch, line_detectors=lsds if lsd is not None else ())
 
     def step():
-        if lsd is not None:
-            if len(pending) >= 2:
-                pending.pop(0).result()  # at most two line passes in flight
-            pending.append(pool.submit(lsds[step_no[0] % 2].run, True))
-            step_no[0] += 1
-        if orb is not None:
-            orb.run()
-        batch.run()
+        fe.step()
 
     def drain():
-        while pending:
-            pending.pop(0).result()
+        fe.drain()
 
     def barrier():
         drain()

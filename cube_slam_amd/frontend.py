@@ -1,0 +1,34 @@
+"""ctypes wrapper of the batch front-end runner (cs_frontend_*, cube_slam_amd/csrc/frontend.hip): ORB + cuboid on the caller's
+context, LSD + LBD on worker threads with their own contexts.  Plumbing for bench.py and the tests."""
+import ctypes as C
+
+from ._lib import check, lib
+
+
+class Frontend:
+    def __init__(self, ctx, orb=None, batch=None, line_detectors=()):
+        """line_detectors: line_lbd_detect objects, each created on its own Context and holding the same uploaded frames."""
+        self.ctx, self.orb, self.batch, self.lines = ctx, orb, batch, list(line_detectors)
+        n = len(self.lines)
+        ctxs = (C.c_void_p * max(n, 1))(*[d.ctx.ptr for d in self.lines])
+        lsds = (C.c_void_p * max(n, 1))(*[d._l for d in self.lines])
+        self._fe = C.c_void_p()
+        check(ctx.ptr, lib().cs_frontend_create(ctx.ptr, orb._e if orb is not None else None, batch._b if batch is not None else None, n, ctxs, lsds, C.byref(self._fe)),
+              "cs_frontend_create")
+
+    def step(self):
+        check(self.ctx.ptr, lib().cs_frontend_step(self._fe), "cs_frontend_step")
+
+    def drain(self):
+        check(self.ctx.ptr, lib().cs_frontend_drain(self._fe), "cs_frontend_drain")
+
+    def close(self):
+        if self._fe:
+            lib().cs_frontend_destroy(self._fe)
+            self._fe = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

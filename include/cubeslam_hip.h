@@ -310,6 +310,19 @@ int cs_lbd_maps(cs_ctx *ctx, const uint8_t *gray, int width, int height, int str
 int cs_pose_optimization(cs_ctx *ctx, int n_frames, const int *edge_off, const double *Xw, const double *obs, const double *inv_sigma2, const double *intrinsics,
                          const double *pose_in, double *pose_out, uint8_t *outlier, int *n_inliers);
 
+/* ===================================================================== batch front-end runner
+ * One pass of the per-frame path (ORBextractor::operator(), line_lbd_detect::detect_descrip_lines, detect_3d_cuboid::detect_cuboid --
+ * what Tracking / main_obj.cpp call per frame, object_slam/src/main_obj.cpp:395-470) over a batch that is resident in HBM.  Handles
+ * are borrowed: orb / batch run on `ctx` in the calling thread, every line detector on its own context in a worker thread; with two
+ * detectors (both holding the same frames) consecutive passes alternate between them, so the host stage of LSD overlaps GPU work.
+ * cs_frontend_step returns when ORB and the cuboid batch of this pass are done; cs_frontend_drain waits for the line passes. */
+typedef struct cs_frontend cs_frontend;
+int cs_frontend_create(cs_ctx *ctx, cs_orb *orb /* nullable */, cs_cuboid_batch *batch /* nullable */, int n_line_workers, cs_ctx *const *line_ctx,
+                       cs_lsd *const *lsd, cs_frontend **out);
+int cs_frontend_step(cs_frontend *fe);
+int cs_frontend_drain(cs_frontend *fe);
+void cs_frontend_destroy(cs_frontend *fe);
+
 #ifdef __cplusplus
 }
 #endif
