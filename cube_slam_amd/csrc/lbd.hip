@@ -22,32 +22,163 @@ struct LbdW { float gL[WB * 3]; float gG[HLSP]; int k5[5]; };
 
 __device__ __forceinline__ int refl(int p, int len) { if (len == 1) return 0; while (p < 0 || p >= len) { if (p < 0) p = -p; else p = 2 * len - 2 - p; } return p; }
 
-__global__ void __launch_bounds__(256) lbd_blur5(const uint8_t *gray, int W, int H, LbdW wts, uint8_t *blur) {
-    __shared__ uint8_t g[16 + 4][64 + 4];
-    __shared__ int hp[16 + 4][64];
-    const int tx0 = blockIdx.x * 64, ty0 = blockIdx.y * 16;
-    gray += (long)blockIdx.z * W * H; blur += (long)blockIdx.z * W * H;
-    for (int i = threadIdx.x; i < 20 * 68; i += 256) { int ly = i / 68, lx = i % 68; g[ly][lx] = gray[(long)refl(ty0 + ly - 2, H) * W + refl(tx0 + lx - 2, W)]; }
-    __syncthreads();
-    for (int i = threadIdx.x; i < 20 * 64; i += 256) { int ly = i / 64, lx = i % 64, s = 0; for (int t = 0; t < 5; t++) s += g[ly][lx + t] * wts.k5[t]; hp[ly][lx] = s; }
-    __syncthreads();
-    const int lx = threadIdx.x & 63;
-    for (int ly = threadIdx.x >> 6; ly < 16; ly += 4) {
-        const int x = tx0 + lx, y = ty0 + ly;
-        if (x >= W || y >= H) continue;
-        int s = 0;
-        for (int t = 0; t < 5; t++) s += hp[ly + t][lx] * wts.k5[t];
-        int v = (s + (1 << 15)) >> 16;
-        blur[(long)y * W + x] = (uint8_t)(v < 0 ? 0 : (v > 255 ? 255 : v));
+// Row-streaming filters (same scheme as orb_blur in orb.hip): ONE WAVE owns a 256-column strip and LBD_ROWS output rows, every
+// lane four neighbouring columns; each input row is loaded once (next rows already in flight), goes through an LDS line, the
+// vertical window stays in registers, and results leave as dword / 8-byte stores (64-B byte stores per wave are several times
+// slower).  Arithmetic identical to the tile versions they replace.
+constexpr int LBD_ROWS = 64;
+// GaussianBlur(5x5, sigma 1), 8-bit fixed point, BORDER_REFLECT_101
+__global__ void __launch_bounds__(64) lbd_blur5(const uint8_t *gray, int W, int H, LbdW wts, uint8_t *blur) {
+    const int strips = (W + 255) / 256;
+    const int sx = (blockIdx.x % strips) * 256, y0 = (blockIdx.x / strips) * LBD_ROWS, tid = threadIdx.x;
+    if (y0 >= H) return;
+    const int rows = min(LBD_ROWS, H - y0);
+    __shared__ uint32_t line32[(256 + 16) / 4]; // column sx + c at byte 4 + c
+    uint8_t *line = reinterpret_cast<uint8_t *>(line32);
+    const uint8_t *img = gray + (long)blockIdx.z * W * H;
+    uint8_t *out = blur + (long)blockIdx.z * W * H;
+    int xc[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) xc[c] = refl(sx + 4 * tid + c, W);
+    const int xh = tid < 2 ? refl(sx - 2 + tid, W) : refl(sx + 256 + (tid - 2), W); // halo columns, lanes 0..3
+    const int x = sx + 4 * tid;
+    int k[5];
+#pragma unroll
+    for (int t = 0; t < 5; t++) k[t] = wts.k5[t];
+    int ring[4][5];
+#pragma unroll
+    for (int c = 0; c < 4; c++)
+#pragma unroll
+        for (int t = 0; t < 5; t++) ring[c][t] = 0;
+    constexpr int G = 4;
+    const int total = rows + 4;
+    uint32_t cur[G], nxt[G]; uint8_t curh[G], nxth[G];
+    auto fetch = [&](int r0, uint32_t (&a)[G], uint8_t (&hh)[G]) {
+#pragma unroll
+        for (int u = 0; u < G; u++) {
+            a[u] = 0; hh[u] = 0;
+            if (r0 + u < total) {
+                const uint8_t *row = img + (long)refl(y0 + r0 + u - 2, H) * W;
+                a[u] = (uint32_t)row[xc[0]] | ((uint32_t)row[xc[1]] << 8) | ((uint32_t)row[xc[2]] << 16) | ((uint32_t)row[xc[3]] << 24);
+                if (tid < 4) hh[u] = row[xh];
+            }
+        }
+    };
+    fetch(0, cur, curh);
+    for (int r0 = 0; r0 < total; r0 += G) {
+        fetch(r0 + G, nxt, nxth);
+#pragma unroll
+        for (int u = 0; u < G; u++) {
+            const int r = r0 + u;
+            if (r < total) {
+                line32[1 + tid] = cur[u];
+                if (tid < 2) line[2 + tid] = curh[u];                   // sx - 2, sx - 1 at bytes 2, 3
+                else if (tid < 4) line[4 + 256 + (tid - 2)] = curh[u];  // sx + 256, sx + 257
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const uint32_t w0 = line32[tid], w1 = line32[tid + 1], w2 = line32[tid + 2];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                int px[12];
+#pragma unroll
+                for (int b2 = 0; b2 < 4; b2++) { px[b2] = (w0 >> (8 * b2)) & 255; px[4 + b2] = (w1 >> (8 * b2)) & 255; px[8 + b2] = (w2 >> (8 * b2)) & 255; }
+                uint32_t packed = 0;
+#pragma unroll
+                for (int c = 0; c < 4; c++) { // column x + c: taps at span bytes c + 2 .. c + 6
+                    int h = 0;
+#pragma unroll
+                    for (int t = 0; t < 5; t++) h += px[c + 2 + t] * k[t];
+#pragma unroll
+                    for (int t = 0; t < 4; t++) ring[c][t] = ring[c][t + 1];
+                    ring[c][4] = h;
+                    int sum = 0;
+#pragma unroll
+                    for (int t = 0; t < 5; t++) sum += ring[c][t] * k[t];
+                    const int v = (sum + (1 << 15)) >> 16;
+                    packed |= (uint32_t)(v < 0 ? 0 : (v > 255 ? 255 : v)) << (8 * c);
+                }
+                if (r >= 4 && x < W) {
+                    uint8_t *dst = out + (long)(y0 + r - 4) * W + x;
+                    if (x + 3 < W) *reinterpret_cast<uint32_t *>(dst) = packed;
+                    else for (int c = 0; c < 4 && x + c < W; c++) dst[c] = (uint8_t)(packed >> (8 * c));
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < G; u++) { cur[u] = nxt[u]; curh[u] = nxth[u]; }
     }
 }
-__global__ void __launch_bounds__(256) lbd_sobel(const uint8_t *blur, int W, int H, short *dx, short *dy) {
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-    if (x >= W) return;
-    blur += (long)blockIdx.z * W * H; dx += (long)blockIdx.z * W * H; dy += (long)blockIdx.z * W * H;
-    auto P = [&](int xx, int yy) { return (int)blur[(long)refl(yy, H) * W + refl(xx, W)]; };
-    dx[(long)y * W + x] = (short)((P(x + 1, y - 1) + 2 * P(x + 1, y) + P(x + 1, y + 1)) - (P(x - 1, y - 1) + 2 * P(x - 1, y) + P(x - 1, y + 1)));
-    dy[(long)y * W + x] = (short)((P(x - 1, y + 1) + 2 * P(x, y + 1) + P(x + 1, y + 1)) - (P(x - 1, y - 1) + 2 * P(x, y - 1) + P(x + 1, y - 1)));
+// Sobel 3x3 -> int16 dx, dy, BORDER_REFLECT_101
+__global__ void __launch_bounds__(64) lbd_sobel(const uint8_t *blur, int W, int H, short *dxo, short *dyo) {
+    const int strips = (W + 255) / 256;
+    const int sx = (blockIdx.x % strips) * 256, y0 = (blockIdx.x / strips) * LBD_ROWS, tid = threadIdx.x;
+    if (y0 >= H) return;
+    const int rows = min(LBD_ROWS, H - y0);
+    __shared__ uint32_t line32[(256 + 16) / 4];
+    uint8_t *line = reinterpret_cast<uint8_t *>(line32);
+    const uint8_t *img = blur + (long)blockIdx.z * W * H;
+    short *odx = dxo + (long)blockIdx.z * W * H, *ody = dyo + (long)blockIdx.z * W * H;
+    int xc[4];
+#pragma unroll
+    for (int c = 0; c < 4; c++) xc[c] = refl(sx + 4 * tid + c, W);
+    const int xh = tid < 1 ? refl(sx - 1, W) : refl(sx + 256, W); // lanes 0, 1
+    const int x = sx + 4 * tid;
+    int win[3][6]; // rows y-1, y, y+1; columns x-1 .. x+4
+#pragma unroll
+    for (int i = 0; i < 3; i++)
+#pragma unroll
+        for (int c = 0; c < 6; c++) win[i][c] = 0;
+    constexpr int G = 4;
+    const int total = rows + 2;
+    uint32_t cur[G], nxt[G]; uint8_t curh[G], nxth[G];
+    auto fetch = [&](int r0, uint32_t (&a)[G], uint8_t (&hh)[G]) {
+#pragma unroll
+        for (int u = 0; u < G; u++) {
+            a[u] = 0; hh[u] = 0;
+            if (r0 + u < total) {
+                const uint8_t *row = img + (long)refl(y0 + r0 + u - 1, H) * W;
+                a[u] = (uint32_t)row[xc[0]] | ((uint32_t)row[xc[1]] << 8) | ((uint32_t)row[xc[2]] << 16) | ((uint32_t)row[xc[3]] << 24);
+                if (tid < 2) hh[u] = row[xh];
+            }
+        }
+    };
+    fetch(0, cur, curh);
+    for (int r0 = 0; r0 < total; r0 += G) {
+        fetch(r0 + G, nxt, nxth);
+#pragma unroll
+        for (int u = 0; u < G; u++) {
+            const int r = r0 + u;
+            if (r < total) {
+                line32[1 + tid] = cur[u];
+                if (tid == 0) line[3] = curh[u];              // sx - 1
+                else if (tid == 1) line[4 + 256] = curh[u];   // sx + 256
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                const uint32_t w0 = line32[tid], w1 = line32[tid + 1], w2 = line32[tid + 2];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+#pragma unroll
+                for (int c = 0; c < 6; c++) { win[0][c] = win[1][c]; win[1][c] = win[2][c]; }
+                win[2][0] = (w0 >> 24) & 255;                 // span byte 3 = column x - 1
+#pragma unroll
+                for (int c = 0; c < 4; c++) win[2][1 + c] = (w1 >> (8 * c)) & 255;
+                win[2][5] = w2 & 255;                         // column x + 4
+                if (r >= 2 && x < W) {
+                    short vx[4], vy[4];
+#pragma unroll
+                    for (int c = 0; c < 4; c++) { // P(x + c + dx, y + dy) = win[1 + dy][1 + c + dx]
+                        vx[c] = (short)((win[0][c + 2] + 2 * win[1][c + 2] + win[2][c + 2]) - (win[0][c] + 2 * win[1][c] + win[2][c]));
+                        vy[c] = (short)((win[2][c] + 2 * win[2][c + 1] + win[2][c + 2]) - (win[0][c] + 2 * win[0][c + 1] + win[0][c + 2]));
+                    }
+                    const long o = (long)(y0 + r - 2) * W + x;
+                    if (x + 3 < W) {
+                        const uint2 px2 = make_uint2((uint32_t)(uint16_t)vx[0] | ((uint32_t)(uint16_t)vx[1] << 16), (uint32_t)(uint16_t)vx[2] | ((uint32_t)(uint16_t)vx[3] << 16));
+                        const uint2 py2 = make_uint2((uint32_t)(uint16_t)vy[0] | ((uint32_t)(uint16_t)vy[1] << 16), (uint32_t)(uint16_t)vy[2] | ((uint32_t)(uint16_t)vy[3] << 16));
+                        __builtin_memcpy(odx + o, &px2, 8); __builtin_memcpy(ody + o, &py2, 8);
+                    } else
+                        for (int c = 0; c < 4 && x + c < W; c++) { odx[o + c] = vx[c]; ody[o + c] = vy[c]; }
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < G; u++) { cur[u] = nxt[u]; curh[u] = nxth[u]; }
+    }
 }
 
 __device__ __forceinline__ void sincos_fd(float angle, float &so, float &co) { // same evaluation as orb.hip
@@ -163,8 +294,9 @@ static LbdW make_weights() { // BinaryDescriptor constructor :218-260 (integer d
 // batched entry points shared with lsd.hip (frames resident in HBM)
 int cs_lbd_batch_maps(cs_ctx *ctx, const uint8_t *d_gray, int W, int H, int F, uint8_t *d_blur, short *d_dx, short *d_dy) {
     const LbdW w = make_weights();
-    CS_LAUNCH(ctx, "lbd_blur5", lbd_blur5, dim3((W + 63) / 64, (H + 15) / 16, F), dim3(256), 0, d_gray, W, H, w, d_blur);
-    CS_LAUNCH(ctx, "lbd_sobel", lbd_sobel, dim3((W + 255) / 256, H, F), dim3(256), 0, d_blur, W, H, d_dx, d_dy);
+    const int nblk = ((W + 255) / 256) * ((H + LBD_ROWS - 1) / LBD_ROWS);
+    CS_LAUNCH(ctx, "lbd_blur5", lbd_blur5, dim3(nblk, 1, F), dim3(64), 0, d_gray, W, H, w, d_blur);
+    CS_LAUNCH(ctx, "lbd_sobel", lbd_sobel, dim3(nblk, 1, F), dim3(64), 0, d_blur, W, H, d_dx, d_dy);
     return CS_OK;
 }
 int cs_lbd_batch_desc(cs_ctx *ctx, const cs_keyline *d_kl, const int *d_line_frame, int n, const short *d_dx, const short *d_dy, int W, int H, float *d_rows, uint8_t *d_desc, float *d_f) {
