@@ -2,7 +2,7 @@
 //
 // Replaces line_lbd_detect::detect_raw_lines / detect_filter_lines (reference line_lbd/class/line_lbd_allclass.cpp:125-148,
 // 200-221) -> LSDDetector::detectImpl (libs/LSDDetector.cpp:153-287) -> LineSegmentDetectorImpl::flsd (libs/lsd.cpp:440-536).
-//   lsd_blur_h / lsd_blur_v   GaussianBlur(7x7, sigma 0.75) on the double image, REFLECT_101, symmetric summation order
+//   lsd_blur_hv               GaussianBlur(7x7, sigma 0.75) u8 -> double, REFLECT_101, symmetric summation order, both passes fused
 //   lsd_resize                cv::resize(0.8, 0.8, INTER_LINEAR) on CV_64F with float coefficients (tables from the host)
 //   lsd_gradient              ll_angle (:538-585): 2x2 gradient, norm, level-line angle via cv::fastAtan2, NOTDEF below rho
 // Host, per frame (OpenMP across frames): 1024-bin pseudo-ordering (:588-634) and the sequential part of the algorithm --
@@ -35,21 +35,70 @@ __device__ __forceinline__ int reflect101d(int p, int len) { if (len == 1) retur
 
 struct GK { double k[2 * KH + 1]; };
 
-__global__ void __launch_bounds__(256) lsd_blur_h(const uint8_t *gray, int W, int H, GK g, double *tmp) {
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-    if (x >= W) return;
-    const uint8_t *row = gray + ((long)blockIdx.z * H + y) * W;
-    double s = g.k[KH] * row[x];
-    for (int t = 1; t <= KH; t++) s += g.k[KH + t] * ((double)row[reflect101d(x - t, W)] + (double)row[reflect101d(x + t, W)]);
-    tmp[((long)blockIdx.z * H + y) * W + x] = s;
-}
-__global__ void __launch_bounds__(256) lsd_blur_v(const double *tmp, int W, int H, GK g, double *blur) {
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-    if (x >= W) return;
-    const double *img = tmp + (long)blockIdx.z * H * W;
-    double s = g.k[KH] * img[(long)y * W + x];
-    for (int t = 1; t <= KH; t++) s += g.k[KH + t] * (img[(long)reflect101d(y - t, H) * W + x] + img[(long)reflect101d(y + t, H) * W + x]);
-    blur[((long)blockIdx.z * H + y) * W + x] = s;
+// GaussianBlur(7x7, sigma 0.75) of the u8 frame into doubles, both passes in one row-streaming kernel: one wave per 64-column
+// strip and LSD_ROWS output rows, one column per lane.  Every input row is loaded once (8 rows in flight), filtered horizontally
+// from an LDS line of bytes, and the last seven horizontal results stay in registers for the vertical pass -- the double
+// intermediate image (8 B written + 8 B x 7 read per pixel in the two-kernel version) never exists.  Summation order of both
+// passes as in OpenCV's symmetric filters: centre tap first, then k[t] * (left + right) for t = 1..3.
+constexpr int LSD_ROWS = 64;
+__global__ void __launch_bounds__(64) lsd_blur_hv(const uint8_t *gray, int W, int H, GK g, double *blur) {
+    const int strips = (W + 63) / 64;
+    const int sx = (blockIdx.x % strips) * 64, y0 = (blockIdx.x / strips) * LSD_ROWS, tid = threadIdx.x;
+    if (y0 >= H) return;
+    const int rows = min(LSD_ROWS, H - y0);
+    __shared__ uint8_t line[64 + 8]; // column sx + c at byte 3 + c
+    const uint8_t *img = gray + (long)blockIdx.z * W * H;
+    double *out = blur + (long)blockIdx.z * W * H;
+    const int xc = reflect101d(sx + tid, W);
+    const int xh = tid < 3 ? reflect101d(sx - 3 + tid, W) : reflect101d(sx + 64 + (tid - 3), W); // halo columns, lanes 0..5
+    const int x = sx + tid;
+    double ring[7] = {0, 0, 0, 0, 0, 0, 0};
+    constexpr int G = 8;
+    const int total = rows + 6;
+    uint8_t cur[G], nxt[G], curh[G], nxth[G];
+    auto fetch = [&](int r0, uint8_t (&a)[G], uint8_t (&hh)[G]) {
+#pragma unroll
+        for (int u = 0; u < G; u++) {
+            a[u] = 0; hh[u] = 0;
+            if (r0 + u < total) {
+                const uint8_t *row = img + (long)reflect101d(y0 + r0 + u - 3, H) * W;
+                a[u] = row[xc];
+                if (tid < 6) hh[u] = row[xh];
+            }
+        }
+    };
+    fetch(0, cur, curh);
+    for (int r0 = 0; r0 < total; r0 += G) {
+        fetch(r0 + G, nxt, nxth);
+#pragma unroll
+        for (int u = 0; u < G; u++) {
+            const int r = r0 + u;
+            if (r < total) {
+                line[3 + tid] = cur[u];
+                if (tid < 3) line[tid] = curh[u];
+                else if (tid < 6) line[3 + 64 + (tid - 3)] = curh[u];
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                double px[7];
+#pragma unroll
+                for (int t = 0; t < 7; t++) px[t] = (double)line[tid + t]; // columns x-3 .. x+3
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                double h = g.k[KH] * px[3];
+#pragma unroll
+                for (int t = 1; t <= KH; t++) h += g.k[KH + t] * (px[3 - t] + px[3 + t]);
+#pragma unroll
+                for (int t = 0; t < 6; t++) ring[t] = ring[t + 1];
+                ring[6] = h;
+                if (r >= 6 && x < W) {
+                    double v = g.k[KH] * ring[3];
+#pragma unroll
+                    for (int t = 1; t <= KH; t++) v += g.k[KH + t] * (ring[3 - t] + ring[3 + t]);
+                    out[(long)(y0 + r - 6) * W + x] = v;
+                }
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < G; u++) { cur[u] = nxt[u]; curh[u] = nxth[u]; }
+    }
 }
 __global__ void __launch_bounds__(256) lsd_resize(const double *blur, int W, int H, int w, int h, const int *xofs, const float *ax, const int *yofs, const float *ay,
                                                   double *scaled) {
@@ -463,8 +512,7 @@ static int lsd_run(cs_ctx *ctx, cs_lsd *l, int with_lbd) {
     CS_HIP(ctx, hipSetDevice(ctx->device));
     const int W = l->W, H = l->H, w = l->w, h = l->h, F = l->n_frames;
     l->have_desc = false;
-    CS_LAUNCH(ctx, "lsd_blur_h", lsd_blur_h, dim3((W + 255) / 256, H, F), dim3(256), 0, l->d_gray, W, H, l->gk, l->d_tmp);
-    CS_LAUNCH(ctx, "lsd_blur_v", lsd_blur_v, dim3((W + 255) / 256, H, F), dim3(256), 0, l->d_tmp, W, H, l->gk, l->d_blur);
+    CS_LAUNCH(ctx, "lsd_blur_hv", lsd_blur_hv, dim3(((W + 63) / 64) * ((H + LSD_ROWS - 1) / LSD_ROWS), 1, F), dim3(64), 0, l->d_gray, W, H, l->gk, l->d_blur);
     CS_LAUNCH(ctx, "lsd_resize", lsd_resize, dim3((w + 255) / 256, h, F), dim3(256), 0, l->d_blur, W, H, w, h, l->d_xofs, l->d_ax, l->d_yofs, l->d_ay, l->d_scaled);
     const int nbx = l->nbx, n_seg = F * h * nbx;
     CS_LAUNCH(ctx, "lsd_gradient", lsd_gradient, dim3(nbx, h, F), dim3(256), 0, l->d_scaled, w, h, l->threshold, l->d_mod, l->d_ang, l->d_seg_cnt);
@@ -612,7 +660,7 @@ int cs_lsd_create(cs_ctx *ctx, int width, int height, int max_frames, cs_lsd **o
     for (int dy = 0; dy < l->h; dy++) { float fy = (float)((dy + 0.5) * sx - 0.5); int s = fl(fy); fy -= s; if (s < 0) { fy = 0; s = 0; } if (s >= height - 1) { fy = 0; s = height - 1; } yofs[dy] = s; ay[dy * 2] = 1.f - fy; ay[dy * 2 + 1] = fy; }
     const size_t N = (size_t)width * height * max_frames, n = (size_t)l->w * l->h * max_frames;
 #define A_(call) do { int r__ = (call); if (r__ != CS_OK) { cs_lsd_destroy(ctx, l); return r__; } } while (0)
-    A_(cs_dalloc(ctx, &l->d_gray, N)); A_(cs_dalloc(ctx, &l->d_tmp, N)); A_(cs_dalloc(ctx, &l->d_blur, N));
+    A_(cs_dalloc(ctx, &l->d_gray, N)); A_(cs_dalloc(ctx, &l->d_blur, N));
     A_(cs_dalloc(ctx, &l->d_scaled, n)); A_(cs_dalloc(ctx, &l->d_mod, n)); A_(cs_dalloc(ctx, &l->d_ang, n));
     A_(cs_dalloc(ctx, &l->d_xofs, xofs.size())); A_(cs_dalloc(ctx, &l->d_yofs, yofs.size())); A_(cs_dalloc(ctx, &l->d_ax, ax.size())); A_(cs_dalloc(ctx, &l->d_ay, ay.size()));
     l->nbx = (l->w + 255) / 256;
