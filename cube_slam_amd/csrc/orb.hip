@@ -141,11 +141,19 @@ __global__ void __launch_bounds__(64) orb_cells(Pyr P, const uint8_t *smap, int 
     const int ax0 = iniX + 3, ay0 = iniY + 3, aw = maxX - 3 - ax0, ah = maxY - 3 - ay0;
     if (skip || aw <= 0 || ah <= 0) { if (pass == 0 && lane == 0) cell_count[cell] = 0; return; }
     const uint8_t *S = smap + (long)f * P.frame_stride + L.off;
+    if (pass == 1 && (cell_count[cell] & 0xffffff) == 0) return; // nothing to emit
+    bool any = false;
     for (int i = lane; i < (ah + 2) * (aw + 2); i += 64) {
         int ly = i / (aw + 2), lx = i % (aw + 2);
         int X = ax0 + lx - 1, Y = ay0 + ly - 1;
         bool in = lx >= 1 && lx <= aw && ly >= 1 && ly <= ah;
-        s[ly][lx] = in ? S[(long)Y * L.w + X] : 0;
+        const uint8_t v = in ? S[(long)Y * L.w + X] : 0;
+        s[ly][lx] = v;
+        any = any || v != 0;
+    }
+    if (!__any(any)) { // the score map only holds scores above min(iniTh, minTh): an all-zero cell has no corner at either threshold
+        if (pass == 0 && lane == 0) cell_count[cell] = 0 | (P.min_th << 24);
+        return;
     }
     __syncthreads();
     int th = P.ini_th, total = 0;
