@@ -655,7 +655,9 @@ __constant__ int c_vpe2[3][4] = {{0, 1, 2, 3}, {3, 0, 4, 5}, {2, 4, 1, 5}};     
 
 // corner construction with every reject test of box_proposal_detail.cpp:254-418; returns vp_1_position (0 = rejected)
 __device__ inline int make_corners(const Unit &U, const VPEntry &E, int top_x, int cfg, V2 c[8]) {
-    const double shorted_edge_thre = 20; // :81
+    // `dist(a, b) < 20` (shorted_edge_thre :81) without the square root: sqrt is monotone and correctly rounded, and the largest double
+    // whose root rounds below 20 is pred(pred(400)), so sqrt(d2) < 20 <=> d2 < pred(400) = 0x4078ffffffffffff (tests/test_cabi.py checks it)
+    auto short_edge = [](V2 a, V2 b) { const double dx = a.x - b.x, dy = a.y - b.y; return dx * dx + dy * dy < __longlong_as_double(0x4078ffffffffffffll); };
     const V2 vp_1{E.vp[0], E.vp[1]}, vp_2{E.vp[2], E.vp[3]}, vp_3{E.vp[4], E.vp[5]};
     const double left = U.left, right = U.right, top = U.top, down = U.down_y_expan;
     V2 c1{(double)top_x, top};
@@ -667,38 +669,38 @@ __device__ inline int make_corners(const Unit &U, const VPEntry &E, int top_x, i
     } else
         vp_1_position = 1;
     if (!(vp_1_position > 0)) return 0;
-    if (dist2(c1, c2) < shorted_edge_thre) return 0;
+    if (short_edge(c1, c2)) return 0;
     V2 c3, c4;
     if (cfg == 1) {
         if (vp_1_position == 1) c4 = seg_hit_boundary(vp_2, c1, left, top, left, down);
         else c4 = seg_hit_boundary(vp_2, c1, right, top, right, down);
         if (c4.y == -1) return 0;
-        if (dist2(c1, c4) < shorted_edge_thre) return 0;
+        if (short_edge(c1, c4)) return 0;
         c3 = line_intersect_inf(vp_2, c2, vp_1, c4);
         if (!inside_box(c3, left, top, right, down)) return 0;
-        if ((dist2(c3, c4) < shorted_edge_thre) || (dist2(c3, c2) < shorted_edge_thre)) return 0;
+        if ((short_edge(c3, c4)) || (short_edge(c3, c2))) return 0;
     } else {
         if (vp_1_position == 1) c3 = seg_hit_boundary(vp_2, c2, left, top, left, down);
         else c3 = seg_hit_boundary(vp_2, c2, right, top, right, down);
         if (c3.y == -1) return 0;
-        if (dist2(c2, c3) < shorted_edge_thre) return 0;
+        if (short_edge(c2, c3)) return 0;
         c4 = line_intersect_inf(vp_1, c3, vp_2, c1);
         if (!inside_box(c4, left, (double)U.roi_y, right, (double)U.roi_b)) return 0; // :347 uses the expanded y-range
-        if ((dist2(c3, c4) < shorted_edge_thre) || (dist2(c4, c1) < shorted_edge_thre)) return 0;
+        if ((short_edge(c3, c4)) || (short_edge(c4, c1))) return 0;
     }
     const double el = U.roi_x, et = U.roi_y, er = U.roi_r, eb = U.roi_b;
     V2 c5 = seg_hit_boundary(vp_3, c3, left, down, right, down);
     if (c5.y == -1) return 0;
-    if (dist2(c3, c5) < shorted_edge_thre) return 0;
+    if (short_edge(c3, c5)) return 0;
     V2 c6 = line_intersect_inf(vp_2, c5, vp_3, c2);
     if (!inside_box(c6, el, et, er, eb)) return 0;
-    if ((dist2(c6, c2) < shorted_edge_thre) || (dist2(c6, c5) < shorted_edge_thre)) return 0;
+    if ((short_edge(c6, c2)) || (short_edge(c6, c5))) return 0;
     V2 c7 = line_intersect_inf(vp_1, c6, vp_3, c1);
     if (!inside_box(c7, el, et, er, eb)) return 0;
-    if ((dist2(c7, c1) < shorted_edge_thre) || (dist2(c7, c6) < shorted_edge_thre)) return 0;
+    if ((short_edge(c7, c1)) || (short_edge(c7, c6))) return 0;
     V2 c8 = line_intersect_inf(vp_1, c5, vp_2, c7);
     if (!inside_box(c8, el, et, er, eb)) return 0;
-    if ((dist2(c8, c4) < shorted_edge_thre) || (dist2(c8, c5) < shorted_edge_thre) || (dist2(c8, c7) < shorted_edge_thre)) return 0;
+    if ((short_edge(c8, c4)) || (short_edge(c8, c5)) || (short_edge(c8, c7))) return 0;
     c[0] = c1; c[1] = c2; c[2] = c3; c[3] = c4; c[4] = c5; c[5] = c6; c[6] = c7; c[7] = c8;
     return vp_1_position;
 }

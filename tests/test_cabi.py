@@ -58,3 +58,22 @@ def test_product_does_not_import_oracle():
             if re.search(r"#\s*include[^\n]*oracle|^\s*(from|import)\s+oracle|liboracle|orc_[a-z]+\(", open(f).read(), flags=re.M):
                 bad.append(f)
     assert not bad, bad
+
+
+def test_short_edge_threshold_without_sqrt():
+    """cuboid_sweep_corners tests `dist < 20` as `dx*dx + dy*dy < pred(400)`: equivalent for correctly rounded sqrt."""
+    import struct
+    import numpy as np
+    T = struct.unpack("<d", struct.pack("<Q", 0x4078ffffffffffff))[0]
+    assert T == np.nextafter(400.0, 0.0)
+    below = T
+    for _ in range(2000):
+        below = np.nextafter(below, 0.0)
+        assert np.sqrt(below) < 20.0
+    above = T
+    for _ in range(2000):
+        assert not (np.sqrt(above) < 20.0)
+        above = np.nextafter(above, 1e9)
+    rng = np.random.default_rng(0)
+    d2 = np.concatenate([rng.uniform(0, 800, 200000), 400.0 + rng.normal(0, 1e-12, 200000)])
+    assert np.array_equal(np.sqrt(d2) < 20.0, d2 < T)
