@@ -880,6 +880,92 @@ __global__ void __launch_bounds__(256) ba_maxdiag(Params G, double *partials) { 
 
 } // namespace
 
+// ------------------------------------------------------------------------------------------------ 9-dof g2o::cuboid (object_slam's graph)
+// class cuboid / VertexCuboid / EdgeSE3Cuboid of object_slam/include/object_slam/g2o_Object.h:23-252, SE3Quat::log of
+// Thirdparty/g2o/g2o/types/se3quat.h:229-266.  A cuboid is 10 doubles: [t, qx qy qz qw, half scale].
+HD void se3_log(const SE3 &T, double *res) {
+    double R[3][3]; qtoR(T.r, R);
+    const double d = 0.5 * (R[0][0] + R[1][1] + R[2][2] - 1);
+    const double dR[3] = {R[2][1] - R[1][2], R[0][2] - R[2][0], R[1][0] - R[0][1]};
+    double om[3], coef;
+    if (d > 0.99999) { for (int i = 0; i < 3; i++) om[i] = 0.5 * dR[i]; coef = 1. / 12.; }
+    else {
+        const double theta = acos(d);
+        for (int i = 0; i < 3; i++) om[i] = theta / (2 * sqrt(1 - d * d)) * dR[i];
+        coef = (1 - theta / (2 * tan(theta / 2))) / (theta * theta);
+    }
+    const double O[3][3] = {{0, -om[2], om[1]}, {om[2], 0, -om[0]}, {-om[1], om[0], 0}};
+    double O2[3][3];
+    mat3mul(O, O, O2);
+    for (int i = 0; i < 3; i++) {
+        double v[3];
+        for (int j = 0; j < 3; j++) v[j] = ((i == j ? 1.0 : 0.0) - 0.5 * O[i][j]) + coef * O2[i][j];
+        res[i] = om[i];
+        res[i + 3] = (v[0] * T.t[0] + v[1] * T.t[1]) + v[2] * T.t[2];
+    }
+}
+struct Cub9 { SE3 pose; double scale[3]; };
+HD Cub9 cub9_load(const double *v) { Cub9 c; c.pose = se3_load(v); c.scale[0] = v[7]; c.scale[1] = v[8]; c.scale[2] = v[9]; return c; }
+HD void cub9_store(const Cub9 &c, double *v) { se3_store(c.pose, v); v[7] = c.scale[0]; v[8] = c.scale[1]; v[9] = c.scale[2]; }
+HD Cub9 cub9_oplus(Cub9 c, const double *upd) { // VertexCuboid::oplusImpl -> cuboid::exp_update
+    Cub9 r;
+    normalize_rotation(c.pose);
+    r.pose = se3_mul(c.pose, se3_exp(upd));
+    for (int k = 0; k < 3; k++) r.scale[k] = c.scale[k] + upd[6 + k];
+    return r;
+}
+HD void cub9_edge_error(const SE3 &Tcw, Cub9 g, Cub9 m, double *err) { // EdgeSE3Cuboid::computeError
+    const double PI_ = 3.14159265358979323846;
+    normalize_rotation(g.pose); normalize_rotation(m.pose);
+    Cub9 e;
+    e.pose = se3_mul(se3_inv(Tcw), m.pose); // transform_from
+    double best = 0; int lbl = -1;
+    for (int i = 0; i < 4; i++) { // min_log_error over rotate_cuboid(-90, 0, 90, 180 degrees)
+        const double yaw_angle = (double)(i - 1) * PI_ / 2.0;
+        SE3 rot; rot.r = Quat{0, 0, sin(yaw_angle * 0.5), cos(yaw_angle * 0.5)}; rot.t[0] = rot.t[1] = rot.t[2] = 0;
+        normalize_rotation(rot);
+        Cub9 rc; rc.pose = se3_mul(e.pose, rot);
+        const bool swp = (yaw_angle == PI_ / 2.0) || (yaw_angle == -PI_ / 2.0) || (yaw_angle == 3 * PI_ / 2.0);
+        rc.scale[0] = swp ? m.scale[1] : m.scale[0]; rc.scale[1] = swp ? m.scale[0] : m.scale[1]; rc.scale[2] = m.scale[2];
+        double ei[9];
+        se3_log(se3_mul(se3_inv(rc.pose), g.pose), ei); // cube_log_error
+        for (int k = 0; k < 3; k++) ei[6 + k] = g.scale[k] - rc.scale[k];
+        double nn = 0; for (int k = 0; k < 9; k++) nn += ei[k] * ei[k];
+        nn = sqrt(nn);
+        if (lbl < 0 || nn < best) { best = nn; lbl = i; for (int k = 0; k < 9; k++) err[k] = ei[k]; }
+    }
+}
+__global__ void __launch_bounds__(64) cub9_oplus_kernel(int n, const double *cub, const double *upd, double *out) {
+    const int i = blockIdx.x * 64 + threadIdx.x;
+    if (i >= n) return;
+    cub9_store(cub9_oplus(cub9_load(cub + (long)i * 10), upd + (long)i * 9), out + (long)i * 10);
+}
+// thread per (edge, column): column 0 = the error itself, 1..6 camera dofs, 7..15 cuboid dofs (central differences, delta 1e-9)
+__global__ void __launch_bounds__(64) cub9_edge_kernel(int n, int with_jac, const double *cam_Tcw, const double *cub_global, const double *cub_meas, double *err, double *Jcam,
+                                                       double *Jcub) {
+    const int ncol = with_jac ? 16 : 1;
+    const int t = blockIdx.x * 64 + threadIdx.x;
+    if (t >= n * ncol) return;
+    const int i = t / ncol, col = t % ncol;
+    SE3 T = se3_load(cam_Tcw + (long)i * 7);
+    normalize_rotation(T);
+    const Cub9 G = cub9_load(cub_global + (long)i * 10), M = cub9_load(cub_meas + (long)i * 10);
+    if (col == 0) { cub9_edge_error(T, G, M, err + (long)i * 9); return; }
+    const double delta = 1e-9, scalar = 1.0 / (2 * delta);
+    double e1[9], e2[9];
+    if (col <= 6) {
+        double add[6] = {0, 0, 0, 0, 0, 0};
+        add[col - 1] = delta; cub9_edge_error(se3_mul(se3_exp(add), T), G, M, e1);
+        add[col - 1] = -delta; cub9_edge_error(se3_mul(se3_exp(add), T), G, M, e2);
+        for (int k = 0; k < 9; k++) Jcam[(long)i * 54 + k * 6 + (col - 1)] = scalar * (e1[k] - e2[k]);
+    } else {
+        double add[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0};
+        add[col - 7] = delta; cub9_edge_error(T, cub9_oplus(G, add), M, e1);
+        add[col - 7] = -delta; cub9_edge_error(T, cub9_oplus(G, add), M, e2);
+        for (int k = 0; k < 9; k++) Jcub[(long)i * 81 + k * 9 + (col - 7)] = scalar * (e1[k] - e2[k]);
+    }
+}
+
 // ------------------------------------------------------------------------------------------------ Optimizer::PoseOptimization
 // One workgroup per frame runs the whole routine (Optimizer.cc:253-472): 4 rounds x up to 10 Levenberg-Marquardt iterations of a
 // single 6-dof pose over the frame's map-point matches, inlier / outlier re-classification after every round.  Edges are strided
@@ -1666,6 +1752,42 @@ int cs_pose_optimization(cs_ctx *ctx, int n_frames, const int *edge_off, const d
     hipError_t e = hipStreamSynchronize(ctx->stream);
     if (!r && e != hipSuccess) { ctx->err = hipGetErrorString(e); r = CS_ERR_HIP; }
     void *ptrs[] = {d_fr, d_X, d_o, d_w, d_pi, d_po, d_err, d_out, d_ni};
+    for (void *q : ptrs) if (q) hipFree(q);
+    return r;
+}
+
+int cs_cuboid9_oplus(cs_ctx *ctx, int n, const double *cub, const double *upd, double *out) {
+    if (!ctx || n < 0 || (n && (!cub || !upd || !out))) return CS_ERR_BAD_ARG;
+    if (n == 0) return CS_OK;
+    CS_HIP(ctx, hipSetDevice(ctx->device));
+    double *d_c = nullptr, *d_u = nullptr, *d_o = nullptr;
+    int r = cs_dalloc(ctx, &d_c, (size_t)n * 10); if (!r) r = cs_dalloc(ctx, &d_u, (size_t)n * 9); if (!r) r = cs_dalloc(ctx, &d_o, (size_t)n * 10);
+    if (!r) r = cs_h2d(ctx, d_c, cub, (size_t)n * 10); if (!r) r = cs_h2d(ctx, d_u, upd, (size_t)n * 9);
+    if (!r) { hipLaunchKernelGGL(cub9_oplus_kernel, dim3((n + 63) / 64), dim3(64), 0, ctx->stream, n, d_c, d_u, d_o); r = cs_d2h(ctx, out, d_o, (size_t)n * 10); }
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (!r && e != hipSuccess) { ctx->err = hipGetErrorString(e); r = CS_ERR_HIP; }
+    if (d_c) hipFree(d_c); if (d_u) hipFree(d_u); if (d_o) hipFree(d_o);
+    return r;
+}
+
+int cs_cuboid9_edge_linearize(cs_ctx *ctx, int n, const double *cam_Tcw, const double *cub_global, const double *cub_meas_local, double *err, double *Jcam, double *Jcub) {
+    if (!ctx || n < 0 || (n && (!cam_Tcw || !cub_global || !cub_meas_local || !err)) || ((Jcam == nullptr) != (Jcub == nullptr))) return CS_ERR_BAD_ARG;
+    if (n == 0) return CS_OK;
+    CS_HIP(ctx, hipSetDevice(ctx->device));
+    const int with_jac = Jcam != nullptr;
+    double *d_T = nullptr, *d_g = nullptr, *d_m = nullptr, *d_e = nullptr, *d_jc = nullptr, *d_jq = nullptr;
+    int r = cs_dalloc(ctx, &d_T, (size_t)n * 7); if (!r) r = cs_dalloc(ctx, &d_g, (size_t)n * 10); if (!r) r = cs_dalloc(ctx, &d_m, (size_t)n * 10); if (!r) r = cs_dalloc(ctx, &d_e, (size_t)n * 9);
+    if (!r && with_jac) { r = cs_dalloc(ctx, &d_jc, (size_t)n * 54); if (!r) r = cs_dalloc(ctx, &d_jq, (size_t)n * 81); }
+    if (!r) r = cs_h2d(ctx, d_T, cam_Tcw, (size_t)n * 7); if (!r) r = cs_h2d(ctx, d_g, cub_global, (size_t)n * 10); if (!r) r = cs_h2d(ctx, d_m, cub_meas_local, (size_t)n * 10);
+    if (!r) {
+        const int nt = n * (with_jac ? 16 : 1);
+        hipLaunchKernelGGL(cub9_edge_kernel, dim3((nt + 63) / 64), dim3(64), 0, ctx->stream, n, with_jac, d_T, d_g, d_m, d_e, d_jc, d_jq);
+        r = cs_d2h(ctx, err, d_e, (size_t)n * 9);
+        if (!r && with_jac) { r = cs_d2h(ctx, Jcam, d_jc, (size_t)n * 54); if (!r) r = cs_d2h(ctx, Jcub, d_jq, (size_t)n * 81); }
+    }
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (!r && e != hipSuccess) { ctx->err = hipGetErrorString(e); r = CS_ERR_HIP; }
+    void *ptrs[] = {d_T, d_g, d_m, d_e, d_jc, d_jq};
     for (void *q : ptrs) if (q) hipFree(q);
     return r;
 }

@@ -323,6 +323,14 @@ int cs_frontend_step(cs_frontend *fe);
 int cs_frontend_drain(cs_frontend *fe);
 void cs_frontend_destroy(cs_frontend *fe);
 
+/* ===================================================================== 9-dof g2o::cuboid of object_slam
+ * Replaces, for batches, g2o::VertexCuboid::oplusImpl (object_slam/include/object_slam/g2o_Object.h:193-204: pose * exp(update[0:6]),
+ * scale + update[6:9]) and g2o::EdgeSE3Cuboid::computeError (:227-252: cuboid::min_log_error of the measured cuboid moved to the
+ * world by the camera, :77-101) with the numeric Jacobians BaseBinaryEdge::linearizeOplus builds for it (central differences, 1e-9;
+ * Jcam n x 9 x 6, Jcub n x 9 x 9, row-major; pass both NULL for residuals only).  cuboid = [t, qx qy qz qw, half scale] (10 doubles). */
+int cs_cuboid9_oplus(cs_ctx *ctx, int n, const double *cub, const double *upd, double *out);
+int cs_cuboid9_edge_linearize(cs_ctx *ctx, int n, const double *cam_Tcw, const double *cub_global, const double *cub_meas_local, double *err, double *Jcam, double *Jcub);
+
 #ifdef __cplusplus
 }
 #endif

@@ -772,3 +772,109 @@ extern "C" int orc_pose_optimization(int n, const double *Xw, const double *obs,
     se3_to7(P.T, pose_out);
     return n - nBad;
 }
+
+// ------------------------------------------------------------------------------------------------ 9-dof g2o::cuboid (object_slam's graph)
+// Restated from /root/reference/object_slam/include/object_slam/g2o_Object.h:23-191 (class cuboid: exp_update, cube_log_error,
+// min_log_error, rotate_cuboid, transform_from), :193-224 (VertexCuboid::oplusImpl) and :227-252 (EdgeSE3Cuboid::computeError);
+// SE3Quat::log from Thirdparty/g2o/g2o/types/se3quat.h:229-266.  A cuboid is 10 doubles: [t, qx qy qz qw, half scale].
+namespace {
+static void se3_log(const SE3 &T, double *res) { // se3quat.h:229-266
+    M3 R; qtoR(T.r, R);
+    const double d = 0.5 * (R[0][0] + R[1][1] + R[2][2] - 1);
+    const double dR[3] = {R[2][1] - R[1][2], R[0][2] - R[2][0], R[1][0] - R[0][1]}; // deltaR, se3_ops.hpp
+    double om[3];
+    M3 Vinv;
+    auto build = [&](double coef) { // V_inv = I - 0.5 Omega + coef Omega^2
+        M3 O = {{0, -om[2], om[1]}, {om[2], 0, -om[0]}, {-om[1], om[0], 0}}, O2;
+        mat3mul(O, O, O2);
+        for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Vinv[i][j] = ((i == j ? 1.0 : 0.0) - 0.5 * O[i][j]) + coef * O2[i][j];
+    };
+    if (d > 0.99999) { for (int i = 0; i < 3; i++) om[i] = 0.5 * dR[i]; build(1. / 12.); }
+    else {
+        const double theta = std::acos(d);
+        for (int i = 0; i < 3; i++) om[i] = theta / (2 * std::sqrt(1 - d * d)) * dR[i];
+        build((1 - theta / (2 * std::tan(theta / 2))) / (theta * theta));
+    }
+    for (int i = 0; i < 3; i++) { res[i] = om[i]; res[i + 3] = (Vinv[i][0] * T.t[0] + Vinv[i][1] * T.t[1]) + Vinv[i][2] * T.t[2]; }
+}
+struct Cub9 { SE3 pose; double scale[3]; };
+static Cub9 cub9_load(const double *v) { Cub9 c; c.pose.t[0] = v[0]; c.pose.t[1] = v[1]; c.pose.t[2] = v[2]; c.pose.r = Quat{v[3], v[4], v[5], v[6]}; c.scale[0] = v[7]; c.scale[1] = v[8]; c.scale[2] = v[9]; return c; }
+static void cub9_store(const Cub9 &c, double *v) { se3_to7(c.pose, v); v[7] = c.scale[0]; v[8] = c.scale[1]; v[9] = c.scale[2]; }
+static Cub9 cub9_rotate(const Cub9 &c, double yaw_angle) { // rotate_cuboid :105-116
+    Cub9 r;
+    SE3 rot; rot.r = Quat{0, 0, std::sin(yaw_angle * 0.5), std::cos(yaw_angle * 0.5)}; rot.t[0] = rot.t[1] = rot.t[2] = 0;
+    normalize_rotation(rot); // SE3Quat(q, t) constructor
+    r.pose = se3_mul(c.pose, rot);
+    r.scale[0] = c.scale[0]; r.scale[1] = c.scale[1]; r.scale[2] = c.scale[2];
+    if ((yaw_angle == M_PI / 2.0) || (yaw_angle == -M_PI / 2.0) || (yaw_angle == 3 * M_PI / 2.0)) std::swap(r.scale[0], r.scale[1]);
+    return r;
+}
+static void cub9_log_error(const Cub9 &self, const Cub9 &newone, double *res) { // cube_log_error :66-74
+    const SE3 diff = se3_mul(se3_inv(newone.pose), self.pose);
+    se3_log(diff, res);
+    for (int i = 0; i < 3; i++) res[6 + i] = self.scale[i] - newone.scale[i];
+}
+static void cub9_min_log_error(const Cub9 &self, const Cub9 &newone, double *res) { // min_log_error :77-101
+    const double ang[4] = {-1, 0, 1, 2};
+    double best = 0; int lbl = -1; double errs[4][9];
+    for (int i = 0; i < 4; i++) {
+        cub9_log_error(self, cub9_rotate(newone, ang[i] * M_PI / 2.0), errs[i]);
+        double nn = 0; for (int k = 0; k < 9; k++) nn += errs[i][k] * errs[i][k];
+        nn = std::sqrt(nn);
+        if (lbl < 0 || nn < best) { best = nn; lbl = i; } // minCoeff: first minimum
+    }
+    for (int k = 0; k < 9; k++) res[k] = errs[lbl][k];
+}
+} // namespace
+
+extern "C" int orc_cuboid9_oplus(int n, const double *cub, const double *upd, double *out) { // VertexCuboid::oplusImpl -> exp_update :58-64
+    for (int i = 0; i < n; i++) {
+        Cub9 c = cub9_load(cub + (size_t)i * 10), r;
+        normalize_rotation(c.pose);
+        r.pose = se3_mul(c.pose, se3_exp(upd + (size_t)i * 9));
+        for (int k = 0; k < 3; k++) r.scale[k] = c.scale[k] + upd[(size_t)i * 9 + 6 + k];
+        cub9_store(r, out + (size_t)i * 10);
+    }
+    return 0;
+}
+extern "C" int orc_cuboid9_edge_error(int n, const double *cam_Tcw, const double *cub_global, const double *cub_meas_local, double *err) { // EdgeSE3Cuboid::computeError
+    for (int i = 0; i < n; i++) {
+        SE3 Tcw = se3_from7(cam_Tcw + (size_t)i * 7);
+        const SE3 Twc = se3_inv(Tcw);
+        Cub9 g = cub9_load(cub_global + (size_t)i * 10), m = cub9_load(cub_meas_local + (size_t)i * 10), e;
+        normalize_rotation(g.pose); normalize_rotation(m.pose);
+        e.pose = se3_mul(Twc, m.pose); // transform_from :119-125
+        for (int k = 0; k < 3; k++) e.scale[k] = m.scale[k];
+        cub9_min_log_error(g, e, err + (size_t)i * 9);
+    }
+    return 0;
+}
+// numeric Jacobians of EdgeSE3Cuboid the way BaseBinaryEdge::linearizeOplus does (base_binary_edge.hpp:55-120): central differences, delta 1e-9,
+// column d of vertex i: (e(+delta) - e(-delta)) / (2 delta).  Jcam: 9 x 6 (row-major), Jcub: 9 x 9.
+extern "C" int orc_cuboid9_edge_linearize(int n, const double *cam_Tcw, const double *cub_global, const double *cub_meas_local, double *err, double *Jcam, double *Jcub) {
+    const double delta = 1e-9, scalar = 1.0 / (2 * delta);
+    for (int i = 0; i < n; i++) {
+        const double *T7 = cam_Tcw + (size_t)i * 7, *G = cub_global + (size_t)i * 10, *M = cub_meas_local + (size_t)i * 10;
+        orc_cuboid9_edge_error(1, T7, G, M, err + (size_t)i * 9);
+        for (int d = 0; d < 6; d++) {
+            double e1[9], e2[9], add[6] = {0, 0, 0, 0, 0, 0}, Tp[7];
+            for (int sgn = 0; sgn < 2; sgn++) {
+                add[d] = sgn == 0 ? delta : -delta;
+                SE3 T = se3_mul(se3_exp(add), se3_from7(T7)); // VertexSE3Expmap::oplusImpl
+                se3_to7(T, Tp);
+                orc_cuboid9_edge_error(1, Tp, G, M, sgn == 0 ? e1 : e2);
+            }
+            for (int k = 0; k < 9; k++) Jcam[(size_t)i * 54 + k * 6 + d] = scalar * (e1[k] - e2[k]);
+        }
+        for (int d = 0; d < 9; d++) {
+            double e1[9], e2[9], add[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, Gp[10];
+            for (int sgn = 0; sgn < 2; sgn++) {
+                add[d] = sgn == 0 ? delta : -delta;
+                orc_cuboid9_oplus(1, G, add, Gp);
+                orc_cuboid9_edge_error(1, T7, Gp, M, sgn == 0 ? e1 : e2);
+            }
+            for (int k = 0; k < 9; k++) Jcub[(size_t)i * 81 + k * 9 + d] = scalar * (e1[k] - e2[k]);
+        }
+    }
+    return 0;
+}

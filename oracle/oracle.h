@@ -230,6 +230,14 @@ int orc_lbd_maps(const uint8_t *gray, int W, int H, uint8_t *blur, int16_t *dx, 
 int orc_pose_optimization(int n, const double *Xw, const double *obs, const double *inv_sigma2, double fx, double fy, double cx, double cy, double bf,
                           const double *pose_in, double *pose_out, uint8_t *outlier);
 
+/* ------------------------------------------------------------------ 9-dof g2o::cuboid of object_slam (g2o_Object.h:23-252)
+ * cuboid = 10 doubles [t, qx qy qz qw, half scale].  oplus: VertexCuboid::oplusImpl (pose * exp(update[0:6]), scale + update[6:9]);
+ * edge_error: EdgeSE3Cuboid::computeError (min_log_error over the four 90-degree rotations of the measured cuboid moved to the
+ * world by the camera); edge_linearize: its numeric Jacobians as g2o computes them (central differences, 1e-9). */
+int orc_cuboid9_oplus(int n, const double *cub, const double *upd, double *out);
+int orc_cuboid9_edge_error(int n, const double *cam_Tcw, const double *cub_global, const double *cub_meas_local, double *err);
+int orc_cuboid9_edge_linearize(int n, const double *cam_Tcw, const double *cub_global, const double *cub_meas_local, double *err, double *Jcam, double *Jcub);
+
 #ifdef __cplusplus
 }
 #endif

@@ -416,3 +416,22 @@ def pose_optimization(Xw, obs, inv_sigma2, intr, pose):
     r = lib().orc_pose_optimization(n, _p(Xw, C.c_double), _p(obs, C.c_double), _p(w, C.c_double), C.c_double(fx), C.c_double(fy), C.c_double(cx), C.c_double(cy), C.c_double(bf),
                                     _p(pose, C.c_double), _p(out, C.c_double), _p(flags, C.c_uint8))
     return out, flags[:n], r
+
+
+def cuboid9_oplus(cub, upd):
+    cub = np.ascontiguousarray(cub, np.float64).reshape(-1, 10); upd = np.ascontiguousarray(upd, np.float64).reshape(-1, 9)
+    out = np.zeros_like(cub)
+    lib().orc_cuboid9_oplus(len(cub), _p(cub, C.c_double), _p(upd, C.c_double), _p(out, C.c_double))
+    return out
+
+
+def cuboid9_edge_linearize(cam_Tcw, cub_global, cub_meas, jac=True):
+    T = np.ascontiguousarray(cam_Tcw, np.float64).reshape(-1, 7); g = np.ascontiguousarray(cub_global, np.float64).reshape(-1, 10)
+    m = np.ascontiguousarray(cub_meas, np.float64).reshape(-1, 10)
+    n = len(T)
+    err = np.zeros((n, 9)); Jc = np.zeros((n, 9, 6)); Jq = np.zeros((n, 9, 9))
+    if jac:
+        lib().orc_cuboid9_edge_linearize(n, _p(T, C.c_double), _p(g, C.c_double), _p(m, C.c_double), _p(err, C.c_double), _p(Jc, C.c_double), _p(Jq, C.c_double))
+        return err, Jc, Jq
+    lib().orc_cuboid9_edge_error(n, _p(T, C.c_double), _p(g, C.c_double), _p(m, C.c_double), _p(err, C.c_double))
+    return err
