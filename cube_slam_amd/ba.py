@@ -18,7 +18,8 @@ class BAProblem(C.Structure):
                 ("n_cobs", C.c_int), ("cobs_cam", C.c_void_p), ("cobs_cuboid", C.c_void_p), ("cobs_bbox", C.c_void_p), ("cobs_info", C.c_void_p),
                 ("K", C.c_double * 9), ("huber_obj", C.c_double),
                 ("n_pc", C.c_int), ("pc_cuboid", C.c_void_p), ("pc_offsets", C.c_void_p), ("pc_points", C.c_void_p),
-                ("max_outside_margin_ratio", C.c_double)]
+                ("max_outside_margin_ratio", C.c_double),
+                ("obs_ur", C.c_void_p), ("bf", C.c_double), ("huber_stereo", C.c_double)]
 
 
 class BAStats(C.Structure):
@@ -52,6 +53,9 @@ def problem_struct(d):
     p.huber_obj = d["huber_obj"]
     p.n_pc = len(d["pc_cuboid"]); p.pc_cuboid = arr("pc_cuboid", np.int32); p.pc_offsets = arr("pc_offsets", np.int32); p.pc_points = arr("pc_points", np.float64)
     p.max_outside_margin_ratio = d["max_outside_margin_ratio"]
+    if d.get("obs_ur") is not None:  # stereo observations (EdgeStereoSE3ProjectXYZ): u_right >= 0
+        p.obs_ur = arr("obs_ur", np.float64)
+    p.bf, p.huber_stereo = d.get("bf", 0.0), d.get("huber_stereo", 0.0)
     p._keep = keep
     return p
 
@@ -97,7 +101,7 @@ class BundleAdjuster:
 
     def errors(self):
         chi = C.c_double()
-        eo = np.zeros((max(self.p.n_obs, 1), 2)); ec = np.zeros((max(self.p.n_cobs, 1), 4)); ep = np.zeros((max(self.p.n_pc, 1), 3))
+        eo = np.zeros((max(self.p.n_obs, 1), 3)); ec = np.zeros((max(self.p.n_cobs, 1), 4)); ep = np.zeros((max(self.p.n_pc, 1), 3))
         check(self.ctx.ptr, lib().cs_ba_errors(self.ctx.ptr, self._b, C.byref(chi), eo.ctypes.data_as(C.c_void_p), ec.ctypes.data_as(C.c_void_p),
                                                ep.ctypes.data_as(C.c_void_p)), "cs_ba_errors")
         return chi.value, eo[:self.p.n_obs], ec[:self.p.n_cobs], ep[:self.p.n_pc]

@@ -179,10 +179,10 @@ HD void huber(double e, double delta, double *rho) { // RobustKernelHuber::robus
 
 struct Params { // device-side view of the graph
     int n_cams, L, n_cub, P, n_obs, n_cobs, n_pc, lm_b, lm_e, o_b, o_e, pose_edges; // this rank: landmarks [lm_b, lm_e), obs [o_b, o_e)
-    double fx, fy, cx, cy, huber_mono, huber_obj, margin_ratio, K[9];
+    double fx, fy, cx, cy, huber_mono, huber_obj, margin_ratio, K[9], bf, huber_stereo;
     double *cam, *pts, *cub, *cub_scale;           // estimates: 7 / 3 / 7 (+3)
     const int *cam_idx; const uint8_t *cub_flags;
-    const int *o_cam, *o_pt; const double *o_uv, *o_w; const int *lm_off;
+    const int *o_cam, *o_pt; const double *o_uv, *o_w, *o_ur; const int *lm_off; // o_ur: right-image u of a stereo edge (< 0 or NULL array: monocular)
     const int *c_cam, *c_cub; const double *c_bbox, *c_info;
     const int *pc_cub, *pc_off; const double *pc_pts;
     double *e_obs, *e_cobs, *e_pc;
@@ -231,6 +231,7 @@ __device__ inline void block_sum_store(double v, double *partials) {
     if (threadIdx.x == 0) partials[blockIdx.x] = (s[0] + s[1]) + (s[2] + s[3]);
 }
 
+__device__ inline bool obs_stereo(const Params &G, int o) { return G.o_ur && G.o_ur[o] >= 0; }
 __global__ void __launch_bounds__(256) ba_err_obs(Params G, double *partials) {
     const int o = G.o_b + blockIdx.x * 256 + threadIdx.x;
     double chi = 0;
@@ -238,10 +239,19 @@ __global__ void __launch_bounds__(256) ba_err_obs(Params G, double *partials) {
         const SE3 T = se3_load(G.cam + (long)G.o_cam[o] * 7);
         double pc[3];
         se3_map(T, G.pts + (long)G.o_pt[o] * 3, pc);
-        const double e0 = G.o_uv[o * 2] - (pc[0] / pc[2] * G.fx + G.cx), e1 = G.o_uv[o * 2 + 1] - (pc[1] / pc[2] * G.fy + G.cy);
-        G.e_obs[(long)o * 2] = e0; G.e_obs[(long)o * 2 + 1] = e1;
-        chi = (e0 * e0 + e1 * e1) * G.o_w[o];
-        if (G.huber_mono > 0) { double rho[3]; huber(chi, G.huber_mono, rho); chi = rho[0]; }
+        double e0, e1, e2 = 0.0, delta = G.huber_mono;
+        if (obs_stereo(G, o)) { // EdgeStereoSE3ProjectXYZ::cam_project (types_six_dof_expmap.cpp:182-189): invz and bf are floats there
+            const float invz = (float)(1.0 / pc[2]);
+            const double u = pc[0] * invz * G.fx + G.cx;
+            e0 = G.o_uv[o * 2] - u; e1 = G.o_uv[o * 2 + 1] - (pc[1] * invz * G.fy + G.cy); e2 = G.o_ur[o] - (u - (double)(float)G.bf * invz);
+            chi = ((e0 * e0 + e1 * e1) + e2 * e2) * G.o_w[o];
+            delta = G.huber_stereo;
+        } else {
+            e0 = G.o_uv[o * 2] - (pc[0] / pc[2] * G.fx + G.cx); e1 = G.o_uv[o * 2 + 1] - (pc[1] / pc[2] * G.fy + G.cy);
+            chi = (e0 * e0 + e1 * e1) * G.o_w[o];
+        }
+        G.e_obs[(long)o * 3] = e0; G.e_obs[(long)o * 3 + 1] = e1; G.e_obs[(long)o * 3 + 2] = e2;
+        if (delta > 0) { double rho[3]; huber(chi, delta, rho); chi = rho[0]; }
     }
     block_sum_store(chi, partials);
 }
@@ -265,22 +275,36 @@ __global__ void __launch_bounds__(256) ba_err_pose_edges(Params G, double *parti
     block_sum_store(chi, partials);
 }
 
-// analytic Jacobians of one reprojection edge (EdgeSE3ProjectXYZ::linearizeOplus types_six_dof_expmap.cpp:135-171) + weights
-__device__ inline void obs_jac(const Params &G, int o, double Ji[2][3], double Jj[2][6], double omr[2], double &W) {
+// analytic Jacobians of one reprojection edge + weights.  Monocular: EdgeSE3ProjectXYZ::linearizeOplus (types_six_dof_expmap.cpp:135-171),
+// third row exactly zero.  Stereo: EdgeStereoSE3ProjectXYZ::linearizeOplus (:220-266).
+__device__ inline void obs_jac(const Params &G, int o, double Ji[3][3], double Jj[3][6], double omr[3], double &W) {
     const SE3 T = se3_load(G.cam + (long)G.o_cam[o] * 7);
     double pc[3], R[3][3];
     se3_map(T, G.pts + (long)G.o_pt[o] * 3, pc);
     qtoR(T.r, R);
     const double X = pc[0], Y = pc[1], Z = pc[2], Z2 = Z * Z, fx = G.fx, fy = G.fy;
-    const double tmp[2][3] = {{fx, 0, -X / Z * fx}, {0, fy, -Y / Z * fy}};
-    for (int r = 0; r < 2; r++) for (int c = 0; c < 3; c++) Ji[r][c] = ((-1. / Z * tmp[r][0]) * R[0][c] + (-1. / Z * tmp[r][1]) * R[1][c]) + (-1. / Z * tmp[r][2]) * R[2][c];
+    const bool st = obs_stereo(G, o);
+    if (!st) {
+        const double tmp[2][3] = {{fx, 0, -X / Z * fx}, {0, fy, -Y / Z * fy}};
+        for (int r = 0; r < 2; r++) for (int c = 0; c < 3; c++) Ji[r][c] = ((-1. / Z * tmp[r][0]) * R[0][c] + (-1. / Z * tmp[r][1]) * R[1][c]) + (-1. / Z * tmp[r][2]) * R[2][c];
+        for (int c = 0; c < 3; c++) Ji[2][c] = 0;
+    } else {
+        for (int c = 0; c < 3; c++) {
+            Ji[0][c] = -fx * R[0][c] / Z + fx * X * R[2][c] / Z2;
+            Ji[1][c] = -fy * R[1][c] / Z + fy * Y * R[2][c] / Z2;
+            Ji[2][c] = Ji[0][c] - G.bf * R[2][c] / Z2;
+        }
+    }
     Jj[0][0] = X * Y / Z2 * fx; Jj[0][1] = -(1 + (X * X / Z2)) * fx; Jj[0][2] = Y / Z * fx; Jj[0][3] = -1. / Z * fx; Jj[0][4] = 0; Jj[0][5] = X / Z2 * fx;
     Jj[1][0] = (1 + Y * Y / Z2) * fy; Jj[1][1] = -X * Y / Z2 * fy; Jj[1][2] = -X / Z * fy; Jj[1][3] = 0; Jj[1][4] = -1. / Z * fy; Jj[1][5] = Y / Z2 * fy;
-    const double e0 = G.e_obs[(long)o * 2], e1 = G.e_obs[(long)o * 2 + 1], w = G.o_w[o];
+    if (st) { Jj[2][0] = Jj[0][0] - G.bf * Y / Z2; Jj[2][1] = Jj[0][1] + G.bf * X / Z2; Jj[2][2] = Jj[0][2]; Jj[2][3] = Jj[0][3]; Jj[2][4] = 0; Jj[2][5] = Jj[0][5] - G.bf / Z2; }
+    else for (int c = 0; c < 6; c++) Jj[2][c] = 0;
+    const double e0 = G.e_obs[(long)o * 3], e1 = G.e_obs[(long)o * 3 + 1], e2 = G.e_obs[(long)o * 3 + 2], w = G.o_w[o];
+    const double delta = st ? G.huber_stereo : G.huber_mono;
     double rw = 1.0;
-    if (G.huber_mono > 0) { double rho[3]; huber((e0 * e0 + e1 * e1) * w, G.huber_mono, rho); rw = rho[1]; }
-    omr[0] = -w * e0 * rw; omr[1] = -w * e1 * rw; // omega_r = -Omega e, scaled by rho' (base_binary_edge.hpp:77,96)
-    W = rw * w;                                   // robustInformation = rho' * Omega (base_edge.h:96-102)
+    if (delta > 0) { double rho[3]; huber(st ? ((e0 * e0 + e1 * e1) + e2 * e2) * w : (e0 * e0 + e1 * e1) * w, delta, rho); rw = rho[1]; }
+    omr[0] = -w * e0 * rw; omr[1] = -w * e1 * rw; omr[2] = -w * e2 * rw; // omega_r = -Omega e, scaled by rho' (base_binary_edge.hpp:77,96)
+    W = rw * w;                                                          // robustInformation = rho' * Omega (base_edge.h:96-102)
 }
 
 __global__ void __launch_bounds__(256) ba_lin_lm(Params G) { // thread per landmark of this rank
@@ -288,14 +312,14 @@ __global__ void __launch_bounds__(256) ba_lin_lm(Params G) { // thread per landm
     if (li >= G.lm_e) return;
     double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
     for (int o = G.lm_off[li]; o < G.lm_off[li + 1]; o++) {
-        double Ji[2][3], Jj[2][6], omr[2], W;
+        double Ji[3][3], Jj[3][6], omr[3], W;
         obs_jac(G, o, Ji, Jj, omr, W);
-        for (int a = 0; a < 3; a++) {
-            b[a] += Ji[0][a] * omr[0] + Ji[1][a] * omr[1];
-            for (int c = 0; c < 3; c++) H[a * 3 + c] += (Ji[0][a] * W) * Ji[0][c] + (Ji[1][a] * W) * Ji[1][c];
+        for (int a = 0; a < 3; a++) { // third row: zero for monocular edges, so their sums are unchanged by it
+            b[a] += (Ji[0][a] * omr[0] + Ji[1][a] * omr[1]) + Ji[2][a] * omr[2];
+            for (int c = 0; c < 3; c++) H[a * 3 + c] += ((Ji[0][a] * W) * Ji[0][c] + (Ji[1][a] * W) * Ji[1][c]) + (Ji[2][a] * W) * Ji[2][c];
         }
         double *hx = G.Hpl + (long)o * 18; // Hpl block (pose rows, landmark cols) = Jj^T W Ji
-        for (int a = 0; a < 6; a++) for (int c = 0; c < 3; c++) hx[a * 3 + c] = (Jj[0][a] * W) * Ji[0][c] + (Jj[1][a] * W) * Ji[1][c];
+        for (int a = 0; a < 6; a++) for (int c = 0; c < 3; c++) hx[a * 3 + c] = ((Jj[0][a] * W) * Ji[0][c] + (Jj[1][a] * W) * Ji[1][c]) + (Jj[2][a] * W) * Ji[2][c];
     }
     for (int k = 0; k < 9; k++) G.Hll[(long)li * 9 + k] = H[k];
     for (int k = 0; k < 3; k++) G.bl[(long)li * 3 + k] = b[k];
@@ -309,13 +333,13 @@ __global__ void __launch_bounds__(256) ba_lin_pose(Params G, const int *pose_off
 #pragma unroll
     for (int k = 0; k < 42; k++) acc[k] = 0;
     for (int q = pose_off[pi] + lane; q < pose_off[pi + 1]; q += 64) {
-        double Ji[2][3], Jj[2][6], omr[2], W;
+        double Ji[3][3], Jj[3][6], omr[3], W;
         obs_jac(G, pose_obs[q], Ji, Jj, omr, W);
 #pragma unroll
         for (int a = 0; a < 6; a++) {
-            acc[36 + a] += Jj[0][a] * omr[0] + Jj[1][a] * omr[1];
+            acc[36 + a] += (Jj[0][a] * omr[0] + Jj[1][a] * omr[1]) + Jj[2][a] * omr[2];
 #pragma unroll
-            for (int c = 0; c < 6; c++) acc[a * 6 + c] += (Jj[0][a] * W) * Jj[0][c] + (Jj[1][a] * W) * Jj[1][c];
+            for (int c = 0; c < 6; c++) acc[a * 6 + c] += ((Jj[0][a] * W) * Jj[0][c] + (Jj[1][a] * W) * Jj[1][c]) + (Jj[2][a] * W) * Jj[2][c];
         }
     }
 #pragma unroll
@@ -1279,7 +1303,7 @@ int cs_ba_create(cs_ctx *ctx, const cs_ba_problem *p, int rank, int world, cs_ba
     b->rank = rank; b->world = world;
     Params &G = b->G;
     G.n_cams = p->n_cams; G.L = p->n_points; G.n_cub = p->n_cuboids; G.n_obs = p->n_obs; G.n_cobs = p->n_cobs; G.n_pc = p->n_pc;
-    G.fx = p->fx; G.fy = p->fy; G.cx = p->cx; G.cy = p->cy; G.huber_mono = p->huber_mono; G.huber_obj = p->huber_obj; G.margin_ratio = p->max_outside_margin_ratio;
+    G.fx = p->fx; G.fy = p->fy; G.cx = p->cx; G.cy = p->cy; G.huber_mono = p->huber_mono; G.huber_obj = p->huber_obj; G.bf = p->bf; G.huber_stereo = p->huber_stereo; G.margin_ratio = p->max_outside_margin_ratio;
     for (int i = 0; i < 9; i++) G.K[i] = p->K[i];
     G.pose_edges = rank == 0; // camera-cuboid and point-cuboid edges (and setLambda on the pose diagonal) live on rank 0
     // index mapping: non-fixed cameras, then cuboids (sparse_optimizer.cpp:166-190: non-marginalised first, by vertex id)
@@ -1296,10 +1320,10 @@ int cs_ba_create(cs_ctx *ctx, const cs_ba_problem *p, int rank, int world, cs_ba
     for (int o = 0; o < p->n_obs; o++) b->obs_perm[o] = o;
     std::stable_sort(b->obs_perm.begin(), b->obs_perm.end(), [&](int a, int c) { return p->obs_point[a] < p->obs_point[c]; });
     std::vector<int> o_cam(p->n_obs), o_pt(p->n_obs), lm_off(p->n_points + 1, 0);
-    std::vector<double> o_uv((size_t)p->n_obs * 2), o_w(p->n_obs);
+    std::vector<double> o_uv((size_t)p->n_obs * 2), o_w(p->n_obs), o_ur(p->obs_ur ? p->n_obs : 0);
     for (int q = 0; q < p->n_obs; q++) {
         const int o = b->obs_perm[q];
-        o_cam[q] = p->obs_cam[o]; o_pt[q] = p->obs_point[o]; o_uv[q * 2] = p->obs_uv[o * 2]; o_uv[q * 2 + 1] = p->obs_uv[o * 2 + 1]; o_w[q] = p->obs_inv_sigma2[o];
+        o_cam[q] = p->obs_cam[o]; o_pt[q] = p->obs_point[o]; o_uv[q * 2] = p->obs_uv[o * 2]; o_uv[q * 2 + 1] = p->obs_uv[o * 2 + 1]; o_w[q] = p->obs_inv_sigma2[o]; if (p->obs_ur) o_ur[q] = p->obs_ur[o];
         lm_off[o_pt[q] + 1]++;
     }
     for (int l = 0; l < p->n_points; l++) lm_off[l + 1] += lm_off[l];
@@ -1485,7 +1509,7 @@ int cs_ba_create(cs_ctx *ctx, const cs_ba_problem *p, int rank, int world, cs_ba
 
 #define A_(call) do { int r__ = (call); if (r__ != CS_OK) { cs_ba_destroy(ctx, b); return r__; } } while (0)
     int *d_cam_idx, *d_o_cam, *d_o_pt, *d_lm_off, *d_c_cam, *d_c_cub, *d_pc_cub, *d_pc_off;
-    double *d_o_uv, *d_o_w, *d_c_bbox, *d_c_info, *d_pc_pts;
+    double *d_o_uv, *d_o_w, *d_o_ur = nullptr, *d_c_bbox, *d_c_info, *d_pc_pts;
     uint8_t *d_flags;
     const double zero4[4] = {0, 0, 0, 0}; const int zero2[2] = {0, 0};
     A_(dalloc_copy(ctx, b, &G.cam, p->cam_pose, (size_t)p->n_cams * 7));
@@ -1497,6 +1521,7 @@ int cs_ba_create(cs_ctx *ctx, const cs_ba_problem *p, int rank, int world, cs_ba
     A_(dalloc_copy(ctx, b, &d_o_cam, o_cam.data(), (size_t)std::max(p->n_obs, 1)));
     A_(dalloc_copy(ctx, b, &d_o_pt, o_pt.data(), (size_t)std::max(p->n_obs, 1)));
     A_(dalloc_copy(ctx, b, &d_o_uv, o_uv.data(), (size_t)std::max(p->n_obs, 1) * 2));
+    if (p->obs_ur && p->n_obs > 0) A_(dalloc_copy(ctx, b, &d_o_ur, o_ur.data(), (size_t)p->n_obs));
     A_(dalloc_copy(ctx, b, &d_o_w, o_w.data(), (size_t)std::max(p->n_obs, 1)));
     A_(dalloc_copy(ctx, b, &d_lm_off, lm_off.data(), lm_off.size()));
     A_(dalloc_copy(ctx, b, &d_c_cam, p->n_cobs ? p->cobs_cam : zero2, (size_t)std::max(p->n_cobs, 1)));
@@ -1507,9 +1532,9 @@ int cs_ba_create(cs_ctx *ctx, const cs_ba_problem *p, int rank, int world, cs_ba
     A_(dalloc_copy(ctx, b, &d_pc_off, p->n_pc ? p->pc_offsets : zero2, (size_t)p->n_pc + 1));
     const int n_pcp = p->n_pc ? p->pc_offsets[p->n_pc] : 0;
     A_(dalloc_copy(ctx, b, &d_pc_pts, n_pcp ? p->pc_points : zero4, (size_t)std::max(n_pcp, 1) * 3));
-    G.cam_idx = d_cam_idx; G.cub_flags = d_flags; G.o_cam = d_o_cam; G.o_pt = d_o_pt; G.o_uv = d_o_uv; G.o_w = d_o_w; G.lm_off = d_lm_off;
+    G.cam_idx = d_cam_idx; G.cub_flags = d_flags; G.o_cam = d_o_cam; G.o_pt = d_o_pt; G.o_uv = d_o_uv; G.o_w = d_o_w; G.o_ur = d_o_ur; G.lm_off = d_lm_off;
     G.c_cam = d_c_cam; G.c_cub = d_c_cub; G.c_bbox = d_c_bbox; G.c_info = d_c_info; G.pc_cub = d_pc_cub; G.pc_off = d_pc_off; G.pc_pts = d_pc_pts;
-    A_(dalloc_copy(ctx, b, &G.e_obs, (const double *)nullptr, (size_t)std::max(p->n_obs, 1) * 2));
+    A_(dalloc_copy(ctx, b, &G.e_obs, (const double *)nullptr, (size_t)std::max(p->n_obs, 1) * 3));
     A_(dalloc_copy(ctx, b, &G.e_cobs, (const double *)nullptr, (size_t)std::max(p->n_cobs, 1) * 4));
     A_(dalloc_copy(ctx, b, &G.e_pc, (const double *)nullptr, (size_t)std::max(p->n_pc, 1) * 3));
     A_(dalloc_copy(ctx, b, &G.Hpl, (const double *)nullptr, (size_t)std::max(p->n_obs, 1) * 18));
@@ -1583,10 +1608,10 @@ int cs_ba_errors(cs_ctx *ctx, cs_ba *b, double *chi2, double *err_obs, double *e
     int r = ba_compute_errors(ctx, b, chi2); if (r) return r;
     const Params &G = b->G;
     if (err_obs) { // back to the caller's observation order
-        std::vector<double> e((size_t)std::max(G.n_obs, 1) * 2);
-        r = cs_d2h(ctx, e.data(), G.e_obs, (size_t)G.n_obs * 2); if (r) return r;
+        std::vector<double> e((size_t)std::max(G.n_obs, 1) * 3);
+        r = cs_d2h(ctx, e.data(), G.e_obs, (size_t)G.n_obs * 3); if (r) return r;
         CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        for (int q = G.o_b; q < G.o_e; q++) { err_obs[(size_t)b->obs_perm[q] * 2] = e[(size_t)q * 2]; err_obs[(size_t)b->obs_perm[q] * 2 + 1] = e[(size_t)q * 2 + 1]; }
+        for (int q = G.o_b; q < G.o_e; q++) for (int k = 0; k < 3; k++) err_obs[(size_t)b->obs_perm[q] * 3 + k] = e[(size_t)q * 3 + k];
     }
     if (err_cobs && G.pose_edges) { r = cs_d2h(ctx, err_cobs, G.e_cobs, (size_t)G.n_cobs * 4); if (r) return r; }
     if (err_pc && G.pose_edges) { r = cs_d2h(ctx, err_pc, G.e_pc, (size_t)G.n_pc * 3); if (r) return r; }

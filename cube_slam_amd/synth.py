@@ -164,10 +164,12 @@ def _pose7(R, t):
     return np.concatenate([t, _quat_from_R(R)])
 
 
-def ba_problem(seed, n_kf=1000, n_points=100000, n_cuboids=500, k_obs=5, W=1241, H=376, noise_px=1.0):
+def ba_problem(seed, n_kf=1000, n_points=100000, n_cuboids=500, k_obs=5, W=1241, H=376, noise_px=1.0, stereo_frac=0.0):
     """Chain trajectory in a KITTI-like camera world (x right, y down, z forward; ground at y = +1.65):
     keyframes 0.5 m apart on a gentle curve, points in a corridor each seen by ~k_obs consecutive keyframes, cuboids
     (cars) along the road seen by ~10 keyframes through 2-D boxes and owning ~40 fixed surface points.
+    stereo_frac > 0 turns that share of the observations into stereo ones (u_right = u - bf/z, close points only, as
+    Frame::ComputeStereoMatches yields them); the other arrays do not depend on it.
     Returns a dict of numpy arrays (the SoA layout of cs_ba_problem)."""
     rng = np.random.default_rng(seed)
     K = K_KITTI
@@ -194,7 +196,7 @@ def ba_problem(seed, n_kf=1000, n_points=100000, n_cuboids=500, k_obs=5, W=1241,
     Rwc_all = np.stack(Rwc)
     first = np.maximum(0, ((pts[:, 2] - 30) / step).astype(int))
     got = np.zeros(n_points, int)
-    oc, op, ou, ow = [], [], [], []
+    oc, op, ou, ow, oz = [], [], [], [], []
     for j in range(80):
         ki_j = first + j
         ok = (ki_j < n_kf) & (got < k_obs)
@@ -209,7 +211,7 @@ def ba_problem(seed, n_kf=1000, n_points=100000, n_cuboids=500, k_obs=5, W=1241,
         if len(idx) == 0:
             continue
         octave = rng.integers(0, 8, len(idx))
-        oc.append(kk[idx]); op.append(idx)
+        oc.append(kk[idx]); op.append(idx); oz.append(z[idx])
         ou.append(np.stack([u[idx], v[idx]], axis=1) + rng.normal(0, noise_px, (len(idx), 2)))
         ow.append((np.float32(1.0) / (np.float32(1.2) ** octave.astype(np.float32)) ** 2).astype(np.float64))
         got[idx] += 1
@@ -219,6 +221,14 @@ def ba_problem(seed, n_kf=1000, n_points=100000, n_cuboids=500, k_obs=5, W=1241,
     obs_w = np.concatenate(ow) if ow else np.zeros(0)
     order = np.lexsort((obs_cam, obs_pt))  # landmark-major like the reference's loop over map points
     obs_cam, obs_pt, obs_uv, obs_w = obs_cam[order], obs_pt[order], obs_uv[order], obs_w[order]
+    stereo = {}
+    if stereo_frac > 0:
+        rs = np.random.default_rng(seed + 7919)  # own stream: the monocular arrays stay what they are without stereo
+        bf = 386.1448
+        obs_z = (np.concatenate(oz) if oz else np.zeros(0))[order]
+        is_st = (rs.uniform(size=len(obs_z)) < stereo_frac) & (obs_z < 35.0)
+        ur = obs_uv[:, 0] - bf / np.maximum(obs_z, 1e-3) + rs.normal(0, noise_px, len(obs_z))
+        stereo = {"obs_ur": np.where(is_st & (ur >= 0), ur, -1.0), "bf": bf, "huber_stereo": math.sqrt(7.815)}
     # cuboids: object z axis = world up (-y): R_align maps object (x fwd, y left, z up) into the camera world
     R_align = np.array([[0, -1, 0], [0, 0, -1], [1, 0, 0]], float)
     cub_pose, cobs_cam, cobs_cub, cobs_bbox, cobs_info, pc_cub, pc_off, pc_pts = [], [], [], [], [], [], [0], []
@@ -269,7 +279,7 @@ def ba_problem(seed, n_kf=1000, n_points=100000, n_cuboids=500, k_obs=5, W=1241,
         "cobs_info": np.array(cobs_info, np.float64).reshape(-1, 4), "K": K.copy(), "huber_obj": math.sqrt(900.0),
         "pc_cuboid": np.array(pc_cub, np.int32), "pc_offsets": np.array(pc_off, np.int32),
         "pc_points": np.concatenate(pc_pts).reshape(-1, 3) if pc_pts else np.zeros((0, 3)), "max_outside_margin_ratio": 2.0,
-        "cam_true": cam_true, "points_true": pts, "cuboid_true": np.array(cub_pose).reshape(-1, 7),
+        "cam_true": cam_true, "points_true": pts, "cuboid_true": np.array(cub_pose).reshape(-1, 7), **stereo,
     }
 
 

@@ -230,6 +230,9 @@ typedef struct cs_ba_problem {
     int n_cobs; const int *cobs_cam; const int *cobs_cuboid; const double *cobs_bbox; const double *cobs_info; /* EdgeSE3CuboidFixScaleProj */
     double K[9], huber_obj;
     int n_pc; const int *pc_cuboid; const int *pc_offsets; const double *pc_points; double max_outside_margin_ratio; /* EdgePointCuboidOnlyObjectFixScale */
+    /* EdgeStereoSE3ProjectXYZ (types_six_dof_expmap.h:195-232, Optimizer.cc:158-184): obs_ur[o] >= 0 makes observation o a stereo edge
+     * (u, v, u_right) with information inv_sigma2 * I3 and Huber(huber_stereo = sqrt(7.815)); NULL = all monocular */
+    const double *obs_ur; double bf, huber_stereo;
 } cs_ba_problem;
 
 typedef struct cs_ba_stats {

@@ -206,16 +206,27 @@ struct BA {
         L = p->n_points;
         lm_obs.resize(L);
         for (int o = 0; o < p->n_obs; o++) lm_obs[p->obs_point[o]].push_back(o);
-        e_obs.resize((size_t)p->n_obs * 2); e_cobs.resize((size_t)p->n_cobs * 4); e_pc.resize((size_t)p->n_pc * 3);
+        e_obs.resize((size_t)p->n_obs * 3); e_cobs.resize((size_t)p->n_cobs * 4); e_pc.resize((size_t)p->n_pc * 3);
     }
 
     void err_obs(int o, const SE3 &T, const double *X, double *e) const { // EdgeSE3ProjectXYZ::computeError
         double pc[3];
         se3_map(T, X, pc);
+        if (stereo(o)) { // EdgeStereoSE3ProjectXYZ::cam_project (types_six_dof_expmap.cpp:182-189): invz and bf are rounded to float there
+            const float invz = (float)(1.0 / pc[2]);
+            const double u = pc[0] * invz * p->fx + p->cx;
+            e[0] = p->obs_uv[o * 2] - u;
+            e[1] = p->obs_uv[o * 2 + 1] - (pc[1] * invz * p->fy + p->cy);
+            e[2] = p->obs_ur[o] - (u - (double)(float)p->bf * invz);
+            return;
+        }
         const double px = pc[0] / pc[2], py = pc[1] / pc[2];
         e[0] = p->obs_uv[o * 2] - (px * p->fx + p->cx);
         e[1] = p->obs_uv[o * 2 + 1] - (py * p->fy + p->cy);
+        e[2] = 0.0;
     }
+    bool stereo(int o) const { return p->obs_ur && p->obs_ur[o] >= 0; }
+    double obs_delta(int o) const { return stereo(o) ? p->huber_stereo : p->huber_mono; }
     void err_cobs(int o, const SE3 &T, const Cuboid &c, double *e) const { // EdgeSE3CuboidFixScaleProj::computeError
         double bb[4];
         project_bbox(c, T, p->K, bb);
@@ -242,7 +253,7 @@ struct BA {
         for (int k = 0; k < 3; k++) e[k] = 1.0 * (acc[k] / c.scale[k]);
     }
     void compute_errors() {
-        for (int o = 0; o < p->n_obs; o++) err_obs(o, s.cams[p->obs_cam[o]], &s.pts[(size_t)p->obs_point[o] * 3], &e_obs[(size_t)o * 2]);
+        for (int o = 0; o < p->n_obs; o++) err_obs(o, s.cams[p->obs_cam[o]], &s.pts[(size_t)p->obs_point[o] * 3], &e_obs[(size_t)o * 3]);
         for (int o = 0; o < p->n_cobs; o++) err_cobs(o, s.cams[p->cobs_cam[o]], s.cubs[p->cobs_cuboid[o]], &e_cobs[(size_t)o * 4]);
         for (int o = 0; o < p->n_pc; o++) err_pc(o, s.cubs[p->pc_cuboid[o]], &e_pc[(size_t)o * 3]);
     }
@@ -251,12 +262,12 @@ struct BA {
         if (e <= dsqr) { rho[0] = e; rho[1] = 1.; rho[2] = 0.; }
         else { const double sq = std::sqrt(e); rho[0] = 2 * sq * delta - dsqr; rho[1] = delta / sq; rho[2] = -0.5 * rho[1] / e; }
     }
-    double chi2_obs(int o) const { const double *e = &e_obs[(size_t)o * 2]; return (e[0] * e[0] + e[1] * e[1]) * p->obs_inv_sigma2[o]; }
+    double chi2_obs(int o) const { const double *e = &e_obs[(size_t)o * 3]; return stereo(o) ? ((e[0] * e[0] + e[1] * e[1]) + e[2] * e[2]) * p->obs_inv_sigma2[o] : (e[0] * e[0] + e[1] * e[1]) * p->obs_inv_sigma2[o]; }
     double chi2_cobs(int o) const { const double *e = &e_cobs[(size_t)o * 4]; const double *w = p->cobs_info + (size_t)o * 4; return ((e[0] * w[0] * e[0] + e[1] * w[1] * e[1]) + e[2] * w[2] * e[2]) + e[3] * w[3] * e[3]; }
     double chi2_pc(int o) const { const double *e = &e_pc[(size_t)o * 3]; return (e[0] * e[0] + e[1] * e[1]) + e[2] * e[2]; }
     double robust_chi2() const { // sparse_optimizer.cpp:100-114
         double chi = 0, rho[3];
-        for (int o = 0; o < p->n_obs; o++) { double c = chi2_obs(o); if (p->huber_mono > 0) { huber(c, p->huber_mono, rho); chi += rho[0]; } else chi += c; }
+        for (int o = 0; o < p->n_obs; o++) { double c = chi2_obs(o); if (obs_delta(o) > 0) { huber(c, obs_delta(o), rho); chi += rho[0]; } else chi += c; }
         for (int o = 0; o < p->n_cobs; o++) { double c = chi2_cobs(o); if (p->huber_obj > 0) { huber(c, p->huber_obj, rho); chi += rho[0]; } else chi += c; }
         for (int o = 0; o < p->n_pc; o++) chi += chi2_pc(o);
         return chi;
@@ -283,27 +294,40 @@ struct BA {
             const double X = pc[0], Y = pc[1], Z = pc[2], Z2 = Z * Z, fx = p->fx, fy = p->fy;
             M3 R; qtoR(T.r, R);
             // EdgeSE3ProjectXYZ::linearizeOplus types_six_dof_expmap.cpp:135-171
-            const double tmp[2][3] = {{fx, 0, -X / Z * fx}, {0, fy, -Y / Z * fy}};
-            double Ji[2][3], Jj[2][6];
-            for (int r = 0; r < 2; r++) for (int c = 0; c < 3; c++) Ji[r][c] = ((-1. / Z * tmp[r][0]) * R[0][c] + (-1. / Z * tmp[r][1]) * R[1][c]) + (-1. / Z * tmp[r][2]) * R[2][c];
+            double Ji[3][3], Jj[3][6];
+            const bool st = stereo(o);
+            if (!st) { // EdgeSE3ProjectXYZ::linearizeOplus types_six_dof_expmap.cpp:135-171
+                const double tmp[2][3] = {{fx, 0, -X / Z * fx}, {0, fy, -Y / Z * fy}};
+                for (int r = 0; r < 2; r++) for (int c = 0; c < 3; c++) Ji[r][c] = ((-1. / Z * tmp[r][0]) * R[0][c] + (-1. / Z * tmp[r][1]) * R[1][c]) + (-1. / Z * tmp[r][2]) * R[2][c];
+                for (int c = 0; c < 3; c++) Ji[2][c] = 0;
+            } else { // EdgeStereoSE3ProjectXYZ::linearizeOplus :220-266
+                const double bf = p->bf;
+                for (int c = 0; c < 3; c++) {
+                    Ji[0][c] = -fx * R[0][c] / Z + fx * X * R[2][c] / Z2;
+                    Ji[1][c] = -fy * R[1][c] / Z + fy * Y * R[2][c] / Z2;
+                    Ji[2][c] = Ji[0][c] - bf * R[2][c] / Z2;
+                }
+            }
             Jj[0][0] = X * Y / Z2 * fx; Jj[0][1] = -(1 + (X * X / Z2)) * fx; Jj[0][2] = Y / Z * fx; Jj[0][3] = -1. / Z * fx; Jj[0][4] = 0; Jj[0][5] = X / Z2 * fx;
             Jj[1][0] = (1 + Y * Y / Z2) * fy; Jj[1][1] = -X * Y / Z2 * fy; Jj[1][2] = -X / Z * fy; Jj[1][3] = 0; Jj[1][4] = -1. / Z * fy; Jj[1][5] = Y / Z2 * fy;
-            const double *e = &e_obs[(size_t)o * 2];
+            if (st) { Jj[2][0] = Jj[0][0] - p->bf * Y / Z2; Jj[2][1] = Jj[0][1] + p->bf * X / Z2; Jj[2][2] = Jj[0][2]; Jj[2][3] = Jj[0][3]; Jj[2][4] = 0; Jj[2][5] = Jj[0][5] - p->bf / Z2; }
+            else for (int c = 0; c < 6; c++) Jj[2][c] = 0;
+            const double *e = &e_obs[(size_t)o * 3];
             double w = p->obs_inv_sigma2[o], rw = 1.0;
-            if (p->huber_mono > 0) { huber(chi2_obs(o), p->huber_mono, rho); rw = rho[1]; }
-            const double omr[2] = {-w * e[0] * rw, -w * e[1] * rw}; // omega_r = -omega*e, *= rho[1]
-            const double W = rw * w;                                 // weightedOmega = rho[1]*information (diag)
+            if (obs_delta(o) > 0) { huber(chi2_obs(o), obs_delta(o), rho); rw = rho[1]; }
+            const double omr[3] = {-w * e[0] * rw, -w * e[1] * rw, -w * e[2] * rw}; // omega_r = -omega*e, *= rho[1]
+            const double W = rw * w;                                                  // weightedOmega = rho[1]*information (diag)
             double *bl = &b[(size_t)P * 6 + (size_t)li * 3], *hl = &Hll[(size_t)li * 9];
-            for (int a = 0; a < 3; a++) {
-                bl[a] += Ji[0][a] * omr[0] + Ji[1][a] * omr[1];
-                for (int c = 0; c < 3; c++) hl[a * 3 + c] += (Ji[0][a] * W) * Ji[0][c] + (Ji[1][a] * W) * Ji[1][c];
+            for (int a = 0; a < 3; a++) { // the third row is exactly zero for monocular edges: adding it leaves the two-row sums unchanged
+                bl[a] += (Ji[0][a] * omr[0] + Ji[1][a] * omr[1]) + Ji[2][a] * omr[2];
+                for (int c = 0; c < 3; c++) hl[a * 3 + c] += ((Ji[0][a] * W) * Ji[0][c] + (Ji[1][a] * W) * Ji[1][c]) + (Ji[2][a] * W) * Ji[2][c];
             }
             if (pi >= 0) {
                 double *bp = &b[(size_t)pi * 6], *hp = &Hpp_diag[(size_t)pi * 36], *hx = &Hpl[(size_t)o * 18];
                 for (int a = 0; a < 6; a++) {
-                    bp[a] += Jj[0][a] * omr[0] + Jj[1][a] * omr[1];
-                    for (int c = 0; c < 6; c++) hp[a * 6 + c] += (Jj[0][a] * W) * Jj[0][c] + (Jj[1][a] * W) * Jj[1][c];
-                    for (int c = 0; c < 3; c++) hx[a * 3 + c] += (Jj[0][a] * W) * Ji[0][c] + (Jj[1][a] * W) * Ji[1][c];
+                    bp[a] += (Jj[0][a] * omr[0] + Jj[1][a] * omr[1]) + Jj[2][a] * omr[2];
+                    for (int c = 0; c < 6; c++) hp[a * 6 + c] += ((Jj[0][a] * W) * Jj[0][c] + (Jj[1][a] * W) * Jj[1][c]) + (Jj[2][a] * W) * Jj[2][c];
+                    for (int c = 0; c < 3; c++) hx[a * 3 + c] += ((Jj[0][a] * W) * Ji[0][c] + (Jj[1][a] * W) * Ji[1][c]) + (Jj[2][a] * W) * Ji[2][c];
                 }
             }
         }

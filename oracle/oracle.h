@@ -180,6 +180,8 @@ typedef struct orc_ba_problem {
     double K[9], huber_obj;
     /* EdgePointCuboidOnlyObjectFixScale (unary, information = I): fixed world points per edge */
     int n_pc; const int *pc_cuboid; const int *pc_offsets; const double *pc_points; double max_outside_margin_ratio;
+    /* EdgeStereoSE3ProjectXYZ: obs_ur[o] >= 0 makes observation o a stereo edge (u, v, u_right), information = inv_sigma2 * I3, Huber(huber_stereo); NULL = all monocular */
+    const double *obs_ur; double bf, huber_stereo;
 } orc_ba_problem;
 
 typedef struct orc_ba_stats {

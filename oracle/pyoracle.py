@@ -292,7 +292,8 @@ class BAProblem(C.Structure):
                 ("n_cobs", C.c_int), ("cobs_cam", C.c_void_p), ("cobs_cuboid", C.c_void_p), ("cobs_bbox", C.c_void_p), ("cobs_info", C.c_void_p),
                 ("K", C.c_double * 9), ("huber_obj", C.c_double),
                 ("n_pc", C.c_int), ("pc_cuboid", C.c_void_p), ("pc_offsets", C.c_void_p), ("pc_points", C.c_void_p),
-                ("max_outside_margin_ratio", C.c_double)]
+                ("max_outside_margin_ratio", C.c_double),
+                ("obs_ur", C.c_void_p), ("bf", C.c_double), ("huber_stereo", C.c_double)]
 
 
 class BAStats(C.Structure):
@@ -324,6 +325,9 @@ def ba_struct(d, cls=BAProblem):
     p.huber_obj = d["huber_obj"]
     p.n_pc = len(d["pc_cuboid"]); p.pc_cuboid = arr("pc_cuboid", np.int32); p.pc_offsets = arr("pc_offsets", np.int32); p.pc_points = arr("pc_points", np.float64)
     p.max_outside_margin_ratio = d["max_outside_margin_ratio"]
+    if d.get("obs_ur") is not None:  # stereo observations (EdgeStereoSE3ProjectXYZ): u_right >= 0
+        p.obs_ur = arr("obs_ur", np.float64)
+    p.bf, p.huber_stereo = d.get("bf", 0.0), d.get("huber_stereo", 0.0)
     p._keep = keep
     return p
 
@@ -339,7 +343,7 @@ def ba_optimize(d, iterations):
 
 def ba_errors(d):
     p = ba_struct(d)
-    eo = np.zeros((p.n_obs, 2)); ec = np.zeros((max(p.n_cobs, 1), 4)); ep = np.zeros((max(p.n_pc, 1), 3))
+    eo = np.zeros((p.n_obs, 3)); ec = np.zeros((max(p.n_cobs, 1), 4)); ep = np.zeros((max(p.n_pc, 1), 3))
     lib().orc_ba_errors.restype = C.c_double
     chi = lib().orc_ba_errors(C.byref(p), _p(eo, C.c_double), _p(ec, C.c_double), _p(ep, C.c_double))
     return chi, eo, ec[:p.n_cobs], ep[:p.n_pc]

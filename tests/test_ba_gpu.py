@@ -157,3 +157,37 @@ def test_allreduce_callback_on_device_pointer(ctx, small):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_stereo_edges_match_oracle(ctx, oracle):
+    """Mixed EdgeSE3ProjectXYZ / EdgeStereoSE3ProjectXYZ graph (Optimizer.cc:120-184): residuals incl. the float reciprocal of
+    the stereo projection, the reduced system and the LM trajectory."""
+    d = synth.ba_problem(21, n_kf=30, n_points=1200, n_cuboids=0, stereo_frac=0.6)
+    assert (d["obs_ur"] >= 0).sum() > 1000 and (d["obs_ur"] < 0).sum() > 1000
+    ba = BundleAdjuster(d, ctx=ctx)
+    chi, eo, _, _ = ba.errors()
+    rchi, reo, _, _ = oracle.ba_errors(d)
+    assert eo.shape == reo.shape == (len(d["obs_cam"]), 3)
+    assert np.array_equal(eo[:, 2] == 0, d["obs_ur"] < 0)
+    assert np.allclose(eo, reo, rtol=1e-12, atol=1e-11) and abs(chi - rchi) <= 1e-11 * rchi
+    H, b = ba.reduced_dense(2.5)
+    rH, rb = oracle.ba_reduced_dense(d, 0, len(d["points"]), True, 2.5)
+    assert np.allclose(H, rH, rtol=1e-9, atol=1e-10 * np.abs(rH).max()) and np.allclose(b, rb, rtol=1e-9, atol=1e-10 * np.abs(rb).max())
+    st = ba.optimize(10)
+    cam, pts, _ = ba.read()
+    rcam, rpts, _, rst = oracle.ba_optimize(d, 10)
+    assert st["iterations"] == rst["iterations"] and st["lm_trials"] == rst["lm_trials"]
+    assert np.allclose(st["chi2_trace"], rst["chi2_trace"], rtol=1e-8)
+    assert abs(st["chi2_final"] - rst["chi2_final"]) <= REL * rst["chi2_final"] and st["chi2_final"] < 0.1 * st["chi2_init"]
+    assert np.allclose(cam, rcam, rtol=0, atol=1e-7) and np.allclose(pts, rpts, rtol=0, atol=1e-6)
+    ba.close()
+
+
+def test_all_mono_ur_array_is_the_mono_problem(ctx, small):
+    """obs_ur = all -1 (no stereo match anywhere) must reproduce the monocular run bit for bit."""
+    m = dict(small); m["obs_ur"] = np.full(len(small["obs_cam"]), -1.0); m["bf"] = 386.1448; m["huber_stereo"] = 7.815 ** 0.5
+    a = BundleAdjuster(small, ctx=ctx); b = BundleAdjuster(m, ctx=ctx)
+    sa, sb = a.optimize(5), b.optimize(5)
+    assert sa["chi2_trace"] == sb["chi2_trace"]
+    assert all(np.array_equal(x, y) for x, y in zip(a.read(), b.read()))
+    a.close(); b.close()

@@ -28,8 +28,136 @@ def test_reprojection_error_known_answer(oracle):
     d["pc_cuboid"] = np.zeros(0, np.int32); d["pc_offsets"] = np.zeros(1, np.int32); d["pc_points"] = np.zeros((0, 3))
     chi, eo, _, _ = oracle.ba_errors(d)
     exp = np.array([[1.0, 0.0], [-fx * 1.0 / 2.0, 0.0], [-fx * 2.0 / 4.0, fy * 0.5 / 4.0]])
-    assert np.allclose(eo, exp, rtol=0, atol=1e-12)
+    assert eo.shape == (3, 3) and np.all(eo[:, 2] == 0), "third component is the stereo residual: zero on monocular edges"
+    assert np.allclose(eo[:, :2], exp, rtol=0, atol=1e-12)
     assert np.isclose(chi, (exp[0] ** 2).sum() + (exp[1] ** 2).sum() + 0.5 * (exp[2] ** 2).sum(), rtol=1e-14)
+
+
+def _bare(d):
+    d = dict(d)
+    for k in ("cobs_cam", "cobs_cuboid"):
+        d[k] = np.zeros(0, np.int32)
+    d["cobs_bbox"] = np.zeros((0, 4)); d["cobs_info"] = np.zeros((0, 4))
+    d["pc_cuboid"] = np.zeros(0, np.int32); d["pc_offsets"] = np.zeros(1, np.int32); d["pc_points"] = np.zeros((0, 3))
+    d["cuboid_pose"] = np.zeros((0, 7)); d["cuboid_scale"] = np.zeros((0, 3)); d["cuboid_flags"] = np.zeros(0, np.uint8)
+    return d
+
+
+def test_stereo_error_known_answer(oracle):
+    """EdgeStereoSE3ProjectXYZ::computeError = (u, v, ur) - cam_project(T * X, bf), with the reference's float invz
+    (types_six_dof_expmap.cpp:182-189); chi2 = e^T e * invSigma2 and Huber(sqrt(7.815)) (Optimizer.cc:158-184)."""
+    d = _bare(_tiny())
+    d["cam_pose"] = np.array([[0, 0, 0, 0, 0, 0, 1.0], [0.5, 0, 0, 0, 0, 0, 1.0]])
+    d["cam_fixed"] = np.array([1, 0], np.uint8)
+    d["points"] = np.array([[0.3, -0.2, 3.0], [1.0, -0.5, 7.0]])
+    d["obs_cam"] = np.array([0, 1, 1], np.int32); d["obs_point"] = np.array([0, 0, 1], np.int32)
+    fx, fy, cx, cy, bf = d["fx"], d["fy"], d["cx"], d["cy"], 386.1448
+    d["obs_uv"] = np.array([[cx + 70.0, cy - 50.0], [cx + 190.0, cy - 47.0], [cx + 150.0, cy - 50.0]])
+    d["obs_ur"] = np.array([cx + 70.0 - 120.0, -1.0, cx + 150.0 - 60.0])  # observation 1 stays monocular
+    d["obs_inv_sigma2"] = np.array([1.0, 0.8, 0.5]); d["bf"] = bf
+    d["huber_mono"] = 0.0; d["huber_stereo"] = 0.0
+    chi, eo, _, _ = oracle.ba_errors(d)
+    exp = np.zeros((3, 3))
+    for o, (c, pt) in enumerate(zip(d["obs_cam"], d["obs_point"])):
+        X = d["points"][pt] + d["cam_pose"][c, :3]
+        if d["obs_ur"][o] >= 0:
+            invz = np.float64(np.float32(1.0 / X[2]))
+            u = X[0] * invz * fx + cx
+            exp[o] = [d["obs_uv"][o, 0] - u, d["obs_uv"][o, 1] - (X[1] * invz * fy + cy), d["obs_ur"][o] - (u - np.float64(np.float32(bf)) * invz)]
+        else:
+            exp[o, :2] = d["obs_uv"][o] - [X[0] / X[2] * fx + cx, X[1] / X[2] * fy + cy]
+    assert np.array_equal(eo, exp), "bit-exact incl. the float reciprocal"
+    assert abs(eo[0, 2] - (d["obs_ur"][0] - (fx * 0.1 + cx - bf / 3.0))) < 1e-4, "and close to the exact-arithmetic value"
+    assert np.isclose(chi, ((exp ** 2).sum(1) * d["obs_inv_sigma2"]).sum(), rtol=1e-14)
+    d["huber_stereo"] = 7.815 ** 0.5
+    d["huber_mono"] = 5.991 ** 0.5
+    chi_r, _, _, _ = oracle.ba_errors(d)
+    e2 = (exp ** 2).sum(1) * d["obs_inv_sigma2"]
+    dl = np.where(d["obs_ur"] >= 0, d["huber_stereo"], d["huber_mono"])
+    assert (e2 > dl * dl).any() and np.isclose(chi_r, np.where(e2 <= dl * dl, e2, 2 * dl * np.sqrt(e2) - dl * dl).sum(), rtol=1e-14)
+
+
+def _qmul(a, b):  # (x, y, z, w)
+    ax, ay, az, aw = a; bx, by, bz, bw = b
+    return np.array([aw * bx + ax * bw + ay * bz - az * by, aw * by - ax * bz + ay * bw + az * bx, aw * bz + ax * by - ay * bx + az * bw, aw * bw - ax * bx - ay * by - az * bz])
+
+
+def _oplus_axis(pose, k, h):
+    """VertexSE3Expmap::oplusImpl = exp(delta) * T for delta = h * e_k, delta = (omega, upsilon) (se3quat.h:181-235)."""
+    t, q = pose[:3].copy(), pose[3:].copy()
+    if k >= 3:
+        t[k - 3] += h
+        return np.concatenate([t, q])
+    dq = np.zeros(4); dq[k] = np.sin(h / 2); dq[3] = np.cos(h / 2)
+    x, y, z, w = dq
+    R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)], [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                  [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+    return np.concatenate([R @ t, _qmul(dq, q)])
+
+
+def test_stereo_normal_equations_match_finite_differences(oracle):
+    """Analytic Jacobians of mono and stereo edges (types_six_dof_expmap.cpp:135-171, :220-266) against central differences
+    of the residuals: J^T W J + lambda I, Schur-reduced onto the cameras in numpy, must equal the oracle's reduced system."""
+    d = _bare(_tiny(n_kf=3, n_points=14, n_cuboids=0, stereo_frac=0.6))
+    d["huber_mono"] = 0.0; d["huber_stereo"] = 0.0
+    st = d["obs_ur"] >= 0
+    assert st.sum() >= 5 and (~st).sum() >= 3
+    L, n = len(d["points"]), len(d["obs_cam"])
+    free = [i for i in range(len(d["cam_pose"])) if not d["cam_fixed"][i]]
+    P = len(free)
+
+    fx, fy, cx, cy, bf = d["fx"], d["fy"], d["cx"], d["cy"], d["bf"]
+
+    def res(dd):  # exact-arithmetic residuals (the reference's float reciprocal makes its own residual a staircase at 1e-5 px)
+        out = np.zeros((n, 3))
+        for o in range(n):
+            t, (x, y, z, w) = dd["cam_pose"][dd["obs_cam"][o], :3], dd["cam_pose"][dd["obs_cam"][o], 3:]
+            R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)], [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                          [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]])
+            X = R @ dd["points"][dd["obs_point"][o]] + t
+            u = fx * X[0] / X[2] + cx
+            out[o, :2] = dd["obs_uv"][o] - [u, fy * X[1] / X[2] + cy]
+            if st[o]:
+                out[o, 2] = dd["obs_ur"][o] - (u - bf / X[2])
+        return out.reshape(-1)
+
+    e0 = res(d)
+    assert np.allclose(e0, oracle.ba_errors(d)[1].reshape(-1), rtol=0, atol=1e-3)
+    J = np.zeros((3 * n, 6 * P + 3 * L))
+    h = 1e-6
+    for a, ci in enumerate(free):
+        for k in range(6):
+            dp = dict(d); dm = dict(d)
+            cp = d["cam_pose"].copy(); cp[ci] = _oplus_axis(cp[ci], k, h); dp["cam_pose"] = cp
+            cm = d["cam_pose"].copy(); cm[ci] = _oplus_axis(cm[ci], k, -h); dm["cam_pose"] = cm
+            J[:, 6 * a + k] = (res(dp) - res(dm)) / (2 * h)
+    for i in range(L):
+        for k in range(3):
+            dp = dict(d); dm = dict(d)
+            pp = d["points"].copy(); pp[i, k] += h; dp["points"] = pp
+            pm = d["points"].copy(); pm[i, k] -= h; dm["points"] = pm
+            J[:, 6 * P + 3 * i + k] = (res(dp) - res(dm)) / (2 * h)
+    Wd = np.repeat(d["obs_inv_sigma2"], 3)
+    lam = 0.8
+    Hf = J.T @ (Wd[:, None] * J) + lam * np.eye(J.shape[1])
+    bf_ = -J.T @ (Wd * e0)
+    A, B, Cm = Hf[:6 * P, :6 * P], Hf[:6 * P, 6 * P:], Hf[6 * P:, 6 * P:]
+    Hs = A - B @ np.linalg.solve(Cm, B.T)
+    bs = bf_[:6 * P] - B @ np.linalg.solve(Cm, bf_[6 * P:])
+    H, b = oracle.ba_reduced_dense(d, 0, L, True, lam)
+    assert np.allclose(H, Hs, rtol=1e-5, atol=1e-5 * np.abs(Hs).max()) and np.allclose(b, bs, rtol=1e-5, atol=1e-5 * np.abs(bs).max())
+
+
+def test_stereo_ba_converges_and_mono_unchanged(oracle):
+    """A mixed mono/stereo graph converges on noise-free data; obs_ur = None and obs_ur = all -1 are the same problem."""
+    d = _tiny(n_kf=8, n_points=200, n_cuboids=0, noise_px=0.0, stereo_frac=0.5)
+    cam, pts, cub, st = oracle.ba_optimize(d, 15)
+    assert st["chi2_final"] < 1e-6 * st["chi2_init"]
+    m = _tiny(n_kf=8, n_points=200, n_cuboids=2)
+    assert "obs_ur" not in m
+    m2 = dict(m); m2["obs_ur"] = np.full(len(m["obs_cam"]), -1.0); m2["bf"] = 386.1448; m2["huber_stereo"] = 7.815 ** 0.5
+    a = oracle.ba_optimize(m, 6); b = oracle.ba_optimize(m2, 6)
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and a[3]["chi2_trace"] == b[3]["chi2_trace"]
 
 
 def test_huber_chi2_matches_definition(oracle):
