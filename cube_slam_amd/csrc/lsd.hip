@@ -227,7 +227,7 @@ class LsdHost {
             for (int yy = y0; yy <= y1; ++yy) {
                 int c = x0 + yy * w;
                 for (int xx = x0; xx <= x1; ++xx, ++c)
-                    if (used[c] != 1 && aligned(c, reg_angle, prec)) {
+                    if (used[c] == 0 && aligned(c, reg_angle, prec)) { // 0 = defined and free; undefined pixels carry 2 and never reach the angle test
                         used[c] = 1;
                         const double a = angles[c];
                         rx[n] = xx; ry[n] = yy; rang[n] = a; rmod[n] = modgrad[c];
@@ -311,11 +311,21 @@ class LsdHost {
         for (int n = 0; n < 7; ++n) { a -= std::log(x + double(n)); b += q[n] * std::pow(x, double(n)); }
         return a + std::log(b);
     }
+    // log_gamma is only ever asked for integer arguments (pixel counts): the values are computed once per thread by the same
+    // function and kept (each costs 14 pow + 16 log calls, and rect_nfa runs ~115 times per frame)
+    mutable std::vector<double> lg_memo;
+    double lgam_int(int x) const {
+        if (x < 0 || x >= (1 << 20)) return lgam(double(x));
+        if ((size_t)x >= lg_memo.size()) lg_memo.resize(std::max<size_t>((size_t)x + 1, lg_memo.size() * 2 + 1024), -1.0);
+        double &v = lg_memo[x];
+        if (v < 0) v = lgam(double(x)); // lgam(x) >= 0 for the integers >= 1 (lgam(1) = lgam(2) = ~1e-10 in this approximation is re-evaluated, harmless)
+        return v;
+    }
     double nfa(int n, int k, double p) const { // :1100-1136
         if (n == 0 || k == 0) return -LOG_NT;
         if (n == k) return -LOG_NT - double(n) * std::log10(p);
         const double p_term = p / (1 - p);
-        const double l1 = (double(n) + 1) - lgam(double(k) + 1) - lgam(double(n - k) + 1) + double(k) * std::log(p) + double(n - k) * std::log(1.0 - p);
+        const double l1 = (double(n) + 1) - lgam_int(k + 1) - lgam_int(n - k + 1) + double(k) * std::log(p) + double(n - k) * std::log(1.0 - p);
         double term = std::exp(l1);
         if (deq(term, 0)) { if (k > n * p) return -l1 / M_LN10 - LOG_NT; else return -LOG_NT; }
         double tail = term;
@@ -327,8 +337,13 @@ class LsdHost {
         }
         return -std::log10(tail) - LOG_NT;
     }
-    double rect_nfa(const RectH &rec) const { // :977-1098, integer-division and tailp->p.x quirks kept (:1057-1065)
-        int total = 0, alg = 0;
+    // Pixel walk of rect_nfa (:977-1098, integer-division and tailp->p.x quirks kept :1057-1065): number of pixels of the rectangle inside
+    // the image and, for each of the np tolerances, how many of them are aligned with rec.theta.  The row spans are contiguous, the
+    // alignment test is written without branches (same IEEE operations as isAligned), so the compiler vectorises the inner loop;
+    // several tolerances share one walk because rect_improve's first loop only halves the tolerance of an unchanged rectangle.
+    template <int NP> int rect_count(const RectH &rec, const double *precs, int *algs) const {
+        int total = 0, alg[NP];
+        for (int k = 0; k < NP; k++) alg[k] = 0;
         const double hw = rec.width / 2.0, dyhw = rec.dy * hw, dxhw = rec.dx * hw;
         int vx[4] = {int(rec.x1 - dyhw), int(rec.x2 - dyhw), int(rec.x2 + dyhw), int(rec.x1 + dyhw)};
         int vy[4] = {int(rec.y1 + dxhw), int(rec.y2 + dxhw), int(rec.y2 - dxhw), int(rec.y1 - dxhw)};
@@ -349,18 +364,32 @@ class LsdHost {
         const double frstep = (vy[mn] != vy[rm]) ? (vx[mn] - vx[rm]) / (vy[mn] - vy[rm]) : 0;
         const double srstep = (vy[rm] != vx[tp]) ? (vx[rm] - vx[tp]) / (vy[rm] - vx[tp]) : 0;
         double lstep = flstep, rstep = frstep, left_x = vx[mn], right_x = vx[mn];
+        const double theta = rec.theta, two_pi = 2 * PI_, wrap = (3 * PI_) / 2;
         for (int y = vy[mn]; y <= vy[mx]; ++y) {
-            if (y < 0 || y >= h) continue;
-            int adx = y * w + int(left_x);
-            for (int x = int(left_x); x <= int(right_x); ++x, ++adx) {
-                if (x < 0 || x >= w) continue;
-                ++total;
-                if (aligned(adx, rec.theta, rec.prec)) ++alg;
+            if (y < 0 || y >= h) continue; // (the reference skips the edge stepping for these rows too)
+            const int xa = std::max(int(left_x), 0), xb = std::min(int(right_x), w - 1);
+            if (xb >= xa) {
+                total += xb - xa + 1;
+                const double *row = angles + (size_t)y * w;
+                for (int x = xa; x <= xb; ++x) { // isAligned :1138-1154
+                    const double a = row[x];
+                    double d = std::fabs(theta - a);
+                    const double d2 = std::fabs(d - two_pi);
+                    d = d > wrap ? d2 : d;
+                    const int def = a != NOTDEF;
+                    for (int k = 0; k < NP; k++) alg[k] += def & (d <= precs[k]);
+                }
             }
             if (y >= vy[lm]) lstep = slstep;
             if (y >= vy[rm]) rstep = srstep;
             left_x += lstep; right_x += rstep;
         }
+        for (int k = 0; k < NP; k++) algs[k] = alg[k];
+        return total;
+    }
+    double rect_nfa(const RectH &rec) const {
+        int alg;
+        const int total = rect_count<1>(rec, &rec.prec, &alg);
         return nfa(total, alg, rec.p);
     }
     double improve(RectH &rec) const { // rect_improve :873-975, log_eps = 0
@@ -368,24 +397,32 @@ class LsdHost {
         double best = rect_nfa(rec);
         if (best > 0) return best;
         RectH r = rec;
-        for (int n = 0; n < 5; ++n) { r.p /= 2; r.prec = r.p * PI_; double v = rect_nfa(r); if (v > best) { best = v; rec = r; } }
+        { // five halvings of the tolerance: one walk, five counts
+            RectH rs[5]; double precs[5]; int algs[5];
+            for (int n = 0; n < 5; ++n) { r.p /= 2; r.prec = r.p * PI_; rs[n] = r; precs[n] = r.prec; }
+            const int total = rect_count<5>(rec, precs, algs);
+            for (int n = 0; n < 5; ++n) { const double v = nfa(total, algs[n], rs[n].p); if (v > best) { best = v; rec = rs[n]; } }
+        }
         if (best > 0) return best;
         r = rec;
         for (int n = 0; n < 5; ++n) if ((r.width - delta) >= 0.5) { r.width -= delta; double v = rect_nfa(r); if (v > best) { rec = r; best = v; } }
         if (best > 0) return best;
         for (int side = 0; side < 2; side++) {
-            const double sg = side == 0 ? 1.0 : -1.0;
             r = rec;
             for (int n = 0; n < 5; ++n) if ((r.width - delta) >= 0.5) {
                 if (side == 0) { r.x1 += -r.dy * d2; r.y1 += r.dx * d2; r.x2 += -r.dy * d2; r.y2 += r.dx * d2; }
                 else { r.x1 -= -r.dy * d2; r.y1 -= r.dx * d2; r.x2 -= -r.dy * d2; r.y2 -= r.dx * d2; }
                 r.width -= delta;
                 double v = rect_nfa(r); if (v > best) { rec = r; best = v; } }
-            (void)sg;
             if (best > 0) return best;
         }
         r = rec;
-        for (int n = 0; n < 5; ++n) if ((r.width - delta) >= 0.5) { r.p /= 2; r.prec = r.p * PI_; double v = rect_nfa(r); if (v > best) { rec = r; best = v; } }
+        if ((r.width - delta) >= 0.5) { // the width does not change in this loop: again one walk for the five tolerances
+            RectH rs[5]; double precs[5]; int algs[5];
+            for (int n = 0; n < 5; ++n) { r.p /= 2; r.prec = r.p * PI_; rs[n] = r; precs[n] = r.prec; }
+            const int total = rect_count<5>(rec, precs, algs);
+            for (int n = 0; n < 5; ++n) { const double v = nfa(total, algs[n], rs[n].p); if (v > best) { best = v; rec = rs[n]; } }
+        }
         return best;
     }
     bool timed = false;
@@ -399,12 +436,12 @@ class LsdHost {
         const auto tt0 = timed ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
         w = w_; h = h_;
         const size_t n = (size_t)w * h;
-        if (dang.size() != n) { dang.assign(n, NOTDEF); dmod.assign(n, 0.0); used.assign(n, 0); rx.resize(n); ry.resize(n); rang.resize(n); rmod.resize(n); }
+        if (dang.size() != n) { dang.assign(n, NOTDEF); dmod.assign(n, 0.0); used.assign(n, 2); rx.resize(n); ry.resize(n); rang.resize(n); rmod.resize(n); }
         angles = dang.data(); modgrad = dmod.data();
         const double prec = PI_ * 22.5 / 180, p = 22.5 / 180;
         // pseudo-ordering (:588-634): 1024 bins by gradient norm, descending bins, pixel (address) order inside a bin
         double max_grad = -1;
-        for (int i = 0; i < ne; i++) { dang[e_addr[i]] = e_ang[i]; dmod[e_addr[i]] = e_mod[i]; if (e_mod[i] > max_grad) max_grad = e_mod[i]; }
+        for (int i = 0; i < ne; i++) { dang[e_addr[i]] = e_ang[i]; dmod[e_addr[i]] = e_mod[i]; used[e_addr[i]] = 0; if (e_mod[i] > max_grad) max_grad = e_mod[i]; }
         const double bin_coef = (max_grad > 0) ? double(1024 - 1) / max_grad : 0;
         for (int i = 0; i < 1025; i++) cnt[i] = 0;
         for (int i = 0; i < ne; i++) cnt[1023 - int(e_mod[i] * bin_coef) + 1]++;
@@ -435,7 +472,7 @@ class LsdHost {
             rec.x1 /= 0.8; rec.y1 /= 0.8; rec.x2 /= 0.8; rec.y2 /= 0.8;
             lines.push_back(float(rec.x1)); lines.push_back(float(rec.y1)); lines.push_back(float(rec.x2)); lines.push_back(float(rec.y2));
         }
-        for (int i = 0; i < ne; i++) { dang[e_addr[i]] = NOTDEF; used[e_addr[i]] = 0; } // leave the dense maps clean for the next frame
+        for (int i = 0; i < ne; i++) { dang[e_addr[i]] = NOTDEF; used[e_addr[i]] = 2; } // leave the dense maps clean for the next frame
     }
 };
 
