@@ -4,11 +4,12 @@
 // 1146-1509) for one octave and line_lbd_detect::match_line_descrip (class/line_lbd_allclass.cpp:339-356).
 // Built with -ffp-contract=off: the reference accumulates in float with separate multiplies and adds.
 //   lbd_blur5     GaussianBlur(5x5, sigma 1) on u8, 8-bit fixed point, LDS tile              (computeGaussianPyramid :352-370)
-//   lbd_sobel     Sobel 3x3 -> int16 dx, dy, BORDER_REFLECT_101                              (computeSobel :373-402)
-//   lbd_rows      thread per (line, support-region row): walks the row (numOfPixels samples, rounded + clamped coordinates),
-//                 sequential float sums of the positive / negative projections on dL and dO   (:1272-1335)
-//   lbd_desc      thread per line: the 63 rows in order into the 9 bands with the local Gaussian weights, mean/std per band,
-//                 the two normalisations with the 0.4 clip, 32 band-pair comparisons -> 32 bytes (:1337-1478, :405-416)
+//   lbd_sobel     Sobel 3x3 -> int16 dx, dy (interleaved), REFLECT_101                              (computeSobel :373-402)
+//   lbd_line_desc workgroup (one wave) per line.  Walk: lane = support-region row, numOfPixels samples with rounded + clamped
+//                 coordinates, sequential float sums of the positive / negative projections on dL and dO (:1272-1335), gathers
+//                 issued eight samples at a time.  Descriptor: the 63 row sums stay in LDS; lane = band accumulator (72 of them,
+//                 in-order sums over the <= 21 rows of a band with the local Gaussian weights), mean/std per band, the two
+//                 normalisations with the 0.4 clip, 32 band-pair comparisons -> 32 bytes (:1337-1478, :405-416)
 #include "common.h"
 
 #include <cmath>
@@ -106,8 +107,9 @@ __global__ void __launch_bounds__(64) lbd_blur5(const uint8_t *gray, int W, int 
         for (int u = 0; u < G; u++) { cur[u] = nxt[u]; curh[u] = nxth[u]; }
     }
 }
-// Sobel 3x3 -> int16 dx, dy, BORDER_REFLECT_101
-__global__ void __launch_bounds__(64) lbd_sobel(const uint8_t *blur, int W, int H, short *dxo, short *dyo) {
+// Sobel 3x3 -> int16 dx, dy, BORDER_REFLECT_101.  One interleaved map (dx low half, dy high half of a dword): the line walk reads
+// both derivatives of a sample with a single gather, and its cost is the number of gathered lanes.
+__global__ void __launch_bounds__(64) lbd_sobel(const uint8_t *blur, int W, int H, uint32_t *dxyo) {
     const int strips = (W + 255) / 256;
     const int sx = (blockIdx.x % strips) * 256, y0 = (blockIdx.x / strips) * LBD_ROWS, tid = threadIdx.x;
     if (y0 >= H) return;
@@ -115,7 +117,7 @@ __global__ void __launch_bounds__(64) lbd_sobel(const uint8_t *blur, int W, int 
     __shared__ uint32_t line32[(256 + 16) / 4];
     uint8_t *line = reinterpret_cast<uint8_t *>(line32);
     const uint8_t *img = blur + (long)blockIdx.z * W * H;
-    short *odx = dxo + (long)blockIdx.z * W * H, *ody = dyo + (long)blockIdx.z * W * H;
+    uint32_t *oxy = dxyo + (long)blockIdx.z * W * H;
     int xc[4];
 #pragma unroll
     for (int c = 0; c < 4; c++) xc[c] = refl(sx + 4 * tid + c, W);
@@ -167,12 +169,12 @@ __global__ void __launch_bounds__(64) lbd_sobel(const uint8_t *blur, int W, int 
                         vy[c] = (short)((win[2][c] + 2 * win[2][c + 1] + win[2][c + 2]) - (win[0][c] + 2 * win[0][c + 1] + win[0][c + 2]));
                     }
                     const long o = (long)(y0 + r - 2) * W + x;
-                    if (x + 3 < W) {
-                        const uint2 px2 = make_uint2((uint32_t)(uint16_t)vx[0] | ((uint32_t)(uint16_t)vx[1] << 16), (uint32_t)(uint16_t)vx[2] | ((uint32_t)(uint16_t)vx[3] << 16));
-                        const uint2 py2 = make_uint2((uint32_t)(uint16_t)vy[0] | ((uint32_t)(uint16_t)vy[1] << 16), (uint32_t)(uint16_t)vy[2] | ((uint32_t)(uint16_t)vy[3] << 16));
-                        __builtin_memcpy(odx + o, &px2, 8); __builtin_memcpy(ody + o, &py2, 8);
-                    } else
-                        for (int c = 0; c < 4 && x + c < W; c++) { odx[o + c] = vx[c]; ody[o + c] = vy[c]; }
+                    uint32_t pk[4];
+#pragma unroll
+                    for (int c = 0; c < 4; c++) pk[c] = (uint32_t)(uint16_t)vx[c] | ((uint32_t)(uint16_t)vy[c] << 16);
+                    if (x + 3 < W && (o & 3) == 0) *reinterpret_cast<uint4 *>(oxy + o) = make_uint4(pk[0], pk[1], pk[2], pk[3]);
+                    else
+                        for (int c = 0; c < 4 && x + c < W; c++) oxy[o + c] = pk[c];
                 }
             }
         }
@@ -195,12 +197,13 @@ __device__ __forceinline__ void sincos_fd(float angle, float &so, float &co) { /
     so = (float)ss; co = (float)cc;
 }
 
-// block = one line (64 threads: lane = support-region row hID); rowsums: [line][hID][4] = pgdL, ngdL, pgdO, ngdO (unweighted)
-__global__ void __launch_bounds__(64) lbd_rows(const cs_keyline *kls, const int *line_frame, const short *dxImg, const short *dyImg, int W, int H, float *rowsums) {
+// block = one line (64 threads: lane = support-region row hID for the walk, then band accumulators / descriptor elements)
+__global__ void __launch_bounds__(64) lbd_line_desc(const cs_keyline *kls, const int *line_frame, const uint32_t *dxyImg, int W, int H, LbdW wts, uint8_t *desc, float *fdesc) {
+    __shared__ float s_row[HLSP * 4], s_bs[8 * NB], s_d[8 * NB];
     const int li = blockIdx.x, hID = threadIdx.x;
-    if (hID >= HLSP) return;
+    if (hID < HLSP) {
     const cs_keyline L = kls[li];
-    if (line_frame) { const long o = (long)line_frame[li] * W * H; dxImg += o; dyImg += o; }
+    if (line_frame) dxyImg += (long)line_frame[li] * W * H;
     const short realWidth = (short)W, imageWidth = realWidth - 1, imageHeight = (short)(H - 1);
     const short lengthOfLSP = (short)L.numOfPixels, halfWidth = (lengthOfLSP - 1) / 2, halfHeight = (HLSP - 1) / 2;
     const float mx = (float)(0.5 * (L.sPointInOctaveX + L.ePointInOctaveX)), my = (float)(0.5 * (L.sPointInOctaveY + L.ePointInOctaveY));
@@ -210,69 +213,84 @@ __global__ void __launch_bounds__(64) lbd_rows(const cs_keyline *kls, const int 
     float sCorX = -dL0 * halfWidth + dL1 * halfHeight + mx, sCorY = -dL1 * halfWidth - dL0 * halfHeight + my;
     for (int r = 0; r < hID; r++) { sCorX -= dL1; sCorY += dL0; } // sCorX0 -= dL[1]; sCorY0 += dL[0] once per previous row (:1337-1338)
     float pL = 0, nL = 0, pO = 0, nO = 0;
-    for (short wID = 0; wID < lengthOfLSP; wID++) {
-        short t = (short)round((double)sCorX);
-        const short xCor = (t < 0) ? 0 : (t > imageWidth) ? imageWidth : t;
-        t = (short)round((double)sCorY);
-        const short yCor = (t < 0) ? 0 : (t > imageHeight) ? imageHeight : t;
-        const short dx = dxImg[yCor * realWidth + xCor], dy = dyImg[yCor * realWidth + xCor];
-        const float gDL = dx * dL0 + dy * dL1, gDO = dx * dO0 + dy * dO1;
-        if (gDL > 0) pL += gDL; else nL -= gDL;
-        if (gDO > 0) pO += gDO; else nO -= gDO;
-        sCorX += dL0; sCorY += dL1;
+    // The walk is a chain of dependent float additions (coordinates and sums, order of the reference), but the gradient samples do
+    // not depend on the sums: eight positions are generated, their sixteen gathers issued together, then accumulated in order --
+    // one exposed memory latency per eight samples instead of one per sample (this kernel is latency-bound: ~3k short waves).
+    // (short)round((double)x) == (short)roundf(x): float -> double is exact and both round half away from zero.
+    constexpr int U = 8;
+    for (int w0 = 0; w0 < lengthOfLSP; w0 += U) {
+        int off[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) {
+            short t = (short)roundf(sCorX);
+            const short xCor = (t < 0) ? 0 : (t > imageWidth) ? imageWidth : t;
+            t = (short)roundf(sCorY);
+            const short yCor = (t < 0) ? 0 : (t > imageHeight) ? imageHeight : t;
+            off[u] = yCor * realWidth + xCor;
+            sCorX += dL0; sCorY += dL1;
+        }
+        uint32_t gv[U];
+#pragma unroll
+        for (int u = 0; u < U; u++) gv[u] = dxyImg[off[u]]; // positions past the end are valid pixels, their values unused
+#pragma unroll
+        for (int u = 0; u < U; u++)
+            if (w0 + u < lengthOfLSP) {
+                const short dx = (short)(gv[u] & 0xffff), dy = (short)(gv[u] >> 16);
+                const float gDL = dx * dL0 + dy * dL1, gDO = dx * dO0 + dy * dO1;
+                if (gDL > 0) pL += gDL; else nL -= gDL;
+                if (gDO > 0) pO += gDO; else nO -= gDO;
+            }
     }
-    float *o = rowsums + ((long)li * HLSP + hID) * 4;
-    o[0] = pL; o[1] = nL; o[2] = pO; o[3] = nO;
-}
-
-__global__ void __launch_bounds__(64) lbd_desc(int n, const float *rowsums, LbdW wts, uint8_t *desc, float *fdesc) {
-    const int li = blockIdx.x * 64 + threadIdx.x;
-    if (li >= n) return;
-    float bs[8][NB];
-    for (int q = 0; q < 8; q++) for (int b = 0; b < NB; b++) bs[q][b] = 0;
-    for (int hID = 0; hID < HLSP; hID++) {
-        const float *r = rowsums + ((long)li * HLSP + hID) * 4;
-        float coef = wts.gG[hID];
-        const float pL = coef * r[0], nL = coef * r[1], pL2 = pL * pL, nL2 = nL * nL, pO = coef * r[2], nO = coef * r[3], pO2 = pO * pO, nO2 = nO * nO;
-        auto add = [&](int band, float c) {
-            bs[0][band] += c * pL; bs[1][band] += c * nL; bs[2][band] += c * c * pL2; bs[3][band] += c * c * nL2;
-            bs[4][band] += c * pO; bs[5][band] += c * nO; bs[6][band] += c * c * pO2; bs[7][band] += c * c * nO2;
-        };
-        int band = hID / WB;
-        add(band, wts.gL[hID % WB + WB]);
-        band--;
-        if (band >= 0) add(band, wts.gL[hID % WB + 2 * WB]);
-        band = band + 2;
-        if (band < NB) add(band, wts.gL[hID % WB]);
+    // ---- descriptor of the line (:1337-1478, :405-416): the 63 row sums never leave the workgroup
+    s_row[hID * 4] = pL; s_row[hID * 4 + 1] = nL; s_row[hID * 4 + 2] = pO; s_row[hID * 4 + 3] = nO;
     }
-    float d[NB * 8];
+    __syncthreads();
+    // 72 band accumulators (quantity q of band b), each the in-order sum over the <= 21 rows that touch band b: lanes 0..63 own
+    // accumulator `lane`, lanes 0..7 also own 64 + lane.  Same additions in the same order as the row-major loop of the reference.
+    for (int a = threadIdx.x; a < 8 * NB; a += 64) {
+        const int q = a / NB, bnd = a % NB;
+        float acc = 0;
+        const int h0 = max(0, WB * (bnd - 1)), h1 = min(HLSP, WB * (bnd + 2));
+        for (int h = h0; h < h1; h++) {
+            const int rel = h / WB - bnd; // -1: the row's band + 1 is bnd; 0: own band; +1: the row's band - 1 is bnd
+            const float c = wts.gL[h % WB + (rel == 0 ? WB : (rel == 1 ? 2 * WB : 0))];
+            const float coef = wts.gG[h];
+            const float v = coef * s_row[h * 4 + (q & 1) + ((q >> 2) << 1)]; // q: 0 pL 1 nL 2 pL2 3 nL2 4 pO 5 nO 6 pO2 7 nO2
+            if (q & 2) acc += c * c * (v * v); else acc += c * v;
+        }
+        s_bs[a] = acc;
+    }
+    __syncthreads();
     const float invN2 = (float)(1.0 / (WB * 2.0)), invN3 = (float)(1.0 / (WB * 3.0));
-    for (int b = 0; b < NB; b++) {
-        const float invN = (b == 0 || b == NB - 1) ? invN2 : invN3;
-        float t = bs[0][b] * invN; d[b * 8] = t; d[b * 8 + 4] = sqrtf(bs[2][b] * invN - t * t);
-        t = bs[1][b] * invN; d[b * 8 + 1] = t; d[b * 8 + 5] = sqrtf(bs[3][b] * invN - t * t);
-        t = bs[4][b] * invN; d[b * 8 + 2] = t; d[b * 8 + 6] = sqrtf(bs[6][b] * invN - t * t);
-        t = bs[5][b] * invN; d[b * 8 + 3] = t; d[b * 8 + 7] = sqrtf(bs[7][b] * invN - t * t);
+    for (int i = threadIdx.x; i < NB * 8; i += 64) { // d[b*8 + k]: k 0..3 means of pL nL pO nO, k 4..7 their standard deviations
+        const int bnd = i / 8, k = i % 8, k4 = k & 3;
+        const float invN = (bnd == 0 || bnd == NB - 1) ? invN2 : invN3;
+        const int qm = (k4 & 1) + ((k4 >> 1) << 2); // pL -> 0, nL -> 1, pO -> 4, nO -> 5
+        const float t = s_bs[qm * NB + bnd] * invN;
+        s_d[i] = (k < 4) ? t : sqrtf(s_bs[(qm + 2) * NB + bnd] * invN - t * t);
     }
-    float tM = 0, tS = 0;
-    for (int b = 0; b < NB; b++) {
-        const float *e = d + b * 8;
+    __syncthreads();
+    float tM = 0, tS = 0; // every lane repeats the two ordered sums (LDS broadcasts)
+    for (int bnd = 0; bnd < NB; bnd++) {
+        const float *e = s_d + bnd * 8;
         tM += e[0] * e[0]; tM += e[1] * e[1]; tM += e[2] * e[2]; tM += e[3] * e[3];
         tS += e[4] * e[4]; tS += e[5] * e[5]; tS += e[6] * e[6]; tS += e[7] * e[7];
     }
     tM = 1 / sqrtf(tM); tS = 1 / sqrtf(tS);
-    for (int b = 0; b < NB; b++) { float *e = d + b * 8; for (int q = 0; q < 4; q++) e[q] = e[q] * tM; for (int q = 4; q < 8; q++) e[q] = e[q] * tS; }
-    for (int i = 0; i < NB * 8; i++) if (d[i] > 0.4) d[i] = (float)0.4;
+    __syncthreads();
+    for (int i = threadIdx.x; i < NB * 8; i += 64) { float v = s_d[i] * ((i & 4) ? tS : tM); if (v > 0.4) v = (float)0.4; s_d[i] = v; }
+    __syncthreads();
     float t = 0;
-    for (int i = 0; i < NB * 8; i++) t += d[i] * d[i];
+    for (int i = 0; i < NB * 8; i++) t += s_d[i] * s_d[i];
     t = 1 / sqrtf(t);
-    for (int i = 0; i < NB * 8; i++) d[i] = d[i] * t;
-    if (fdesc) for (int i = 0; i < NB * 8; i++) fdesc[(long)li * 72 + i] = d[i];
-    for (int c = 0; c < 32; c++) {
-        const float *f1 = d + 8 * c_comb[c][0], *f2 = d + 8 * c_comb[c][1];
+    __syncthreads();
+    for (int i = threadIdx.x; i < NB * 8; i += 64) { const float v = s_d[i] * t; s_d[i] = v; if (fdesc) fdesc[(long)li * 72 + i] = v; }
+    __syncthreads();
+    if (threadIdx.x < 32) {
+        const float *f1 = s_d + 8 * c_comb[threadIdx.x][0], *f2 = s_d + 8 * c_comb[threadIdx.x][1];
         int r = 0;
         for (int i = 0; i < 8; i++) if (f1[i] > f2[i]) r += 1 << i;
-        desc[(long)li * 32 + c] = (uint8_t)r;
+        desc[(long)li * 32 + threadIdx.x] = (uint8_t)r;
     }
 }
 
@@ -292,32 +310,30 @@ static LbdW make_weights() { // BinaryDescriptor constructor :218-260 (integer d
 } // namespace
 
 // batched entry points shared with lsd.hip (frames resident in HBM)
-int cs_lbd_batch_maps(cs_ctx *ctx, const uint8_t *d_gray, int W, int H, int F, uint8_t *d_blur, short *d_dx, short *d_dy) {
+int cs_lbd_batch_maps(cs_ctx *ctx, const uint8_t *d_gray, int W, int H, int F, uint8_t *d_blur, uint32_t *d_dxy) {
     const LbdW w = make_weights();
     const int nblk = ((W + 255) / 256) * ((H + LBD_ROWS - 1) / LBD_ROWS);
     CS_LAUNCH(ctx, "lbd_blur5", lbd_blur5, dim3(nblk, 1, F), dim3(64), 0, d_gray, W, H, w, d_blur);
-    CS_LAUNCH(ctx, "lbd_sobel", lbd_sobel, dim3(nblk, 1, F), dim3(64), 0, d_blur, W, H, d_dx, d_dy);
+    CS_LAUNCH(ctx, "lbd_sobel", lbd_sobel, dim3(nblk, 1, F), dim3(64), 0, d_blur, W, H, d_dxy);
     return CS_OK;
 }
-int cs_lbd_batch_desc(cs_ctx *ctx, const cs_keyline *d_kl, const int *d_line_frame, int n, const short *d_dx, const short *d_dy, int W, int H, float *d_rows, uint8_t *d_desc, float *d_f) {
+int cs_lbd_batch_desc(cs_ctx *ctx, const cs_keyline *d_kl, const int *d_line_frame, int n, const uint32_t *d_dxy, int W, int H, uint8_t *d_desc, float *d_f) {
     if (n <= 0) return CS_OK;
     const LbdW w = make_weights();
-    CS_LAUNCH(ctx, "lbd_rows", lbd_rows, dim3(n), dim3(64), 0, d_kl, d_line_frame, d_dx, d_dy, W, H, d_rows);
-    CS_LAUNCH(ctx, "lbd_desc", lbd_desc, dim3((n + 63) / 64), dim3(64), 0, n, d_rows, w, d_desc, d_f);
+    CS_LAUNCH(ctx, "lbd_line_desc", lbd_line_desc, dim3(n), dim3(64), 0, d_kl, d_line_frame, d_dxy, W, H, w, d_desc, d_f);
     return CS_OK;
 }
 
 namespace {
-struct Bufs { uint8_t *gray = nullptr, *blur = nullptr; short *dx = nullptr, *dy = nullptr; };
-static void free_bufs(Bufs &b) { if (b.gray) hipFree(b.gray); if (b.blur) hipFree(b.blur); if (b.dx) hipFree(b.dx); if (b.dy) hipFree(b.dy); b = Bufs(); }
+struct Bufs { uint8_t *gray = nullptr, *blur = nullptr; uint32_t *dxy = nullptr; };
+static void free_bufs(Bufs &b) { if (b.gray) hipFree(b.gray); if (b.blur) hipFree(b.blur); if (b.dxy) hipFree(b.dxy); b = Bufs(); }
 static int run_maps(cs_ctx *ctx, const uint8_t *gray, int W, int H, int stride, Bufs &b) {
     const size_t N = (size_t)W * H;
     int r = cs_dalloc(ctx, &b.gray, N); if (r) return r;
     r = cs_dalloc(ctx, &b.blur, N); if (r) return r;
-    r = cs_dalloc(ctx, &b.dx, N); if (r) return r;
-    r = cs_dalloc(ctx, &b.dy, N); if (r) return r;
+    r = cs_dalloc(ctx, &b.dxy, N); if (r) return r;
     CS_HIP(ctx, hipMemcpy2DAsync(b.gray, (size_t)W, gray, (size_t)stride, (size_t)W, (size_t)H, hipMemcpyHostToDevice, ctx->stream));
-    return cs_lbd_batch_maps(ctx, b.gray, W, H, 1, b.blur, b.dx, b.dy);
+    return cs_lbd_batch_maps(ctx, b.gray, W, H, 1, b.blur, b.dxy);
 }
 } // namespace
 
@@ -330,8 +346,12 @@ int cs_lbd_maps(cs_ctx *ctx, const uint8_t *gray, int width, int height, int str
     int r = run_maps(ctx, gray, width, height, stride, b);
     const size_t N = (size_t)width * height;
     if (!r && blur) r = cs_d2h(ctx, blur, b.blur, N);
-    if (!r && dx) r = cs_d2h(ctx, (short *)dx, b.dx, N);
-    if (!r && dy) r = cs_d2h(ctx, (short *)dy, b.dy, N);
+    if (!r && (dx || dy)) {
+        std::vector<uint32_t> xy(N);
+        r = cs_d2h(ctx, xy.data(), b.dxy, N);
+        hipStreamSynchronize(ctx->stream);
+        if (!r) for (size_t i = 0; i < N; i++) { if (dx) dx[i] = (int16_t)(xy[i] & 0xffff); if (dy) dy[i] = (int16_t)(xy[i] >> 16); }
+    }
     hipStreamSynchronize(ctx->stream);
     free_bufs(b);
     return r;
@@ -344,21 +364,20 @@ int cs_lbd_compute(cs_ctx *ctx, const uint8_t *gray, int width, int height, int 
     CS_HIP(ctx, hipSetDevice(ctx->device));
     Bufs b;
     int r = run_maps(ctx, gray, width, height, stride, b);
-    cs_keyline *d_kl = nullptr; float *d_rows = nullptr, *d_f = nullptr; uint8_t *d_desc = nullptr;
+    cs_keyline *d_kl = nullptr; float *d_f = nullptr; uint8_t *d_desc = nullptr;
     if (!r) r = cs_dalloc(ctx, &d_kl, (size_t)n);
-    if (!r) r = cs_dalloc(ctx, &d_rows, (size_t)n * HLSP * 4);
     if (!r) r = cs_dalloc(ctx, &d_desc, (size_t)n * 32);
     if (!r && float_desc) r = cs_dalloc(ctx, &d_f, (size_t)n * 72);
     if (!r) r = cs_h2d(ctx, d_kl, keylines, (size_t)n);
     if (!r) {
-        r = cs_lbd_batch_desc(ctx, d_kl, nullptr, n, b.dx, b.dy, width, height, d_rows, d_desc, d_f);
+        r = cs_lbd_batch_desc(ctx, d_kl, nullptr, n, b.dxy, width, height, d_desc, d_f);
         if (!r) r = cs_d2h(ctx, desc, d_desc, (size_t)n * 32);
         if (!r && float_desc) r = cs_d2h(ctx, float_desc, d_f, (size_t)n * 72);
     }
     hipError_t e = hipStreamSynchronize(ctx->stream);
     if (!r && e != hipSuccess) { ctx->err = hipGetErrorString(e); r = CS_ERR_HIP; }
     free_bufs(b);
-    if (d_kl) hipFree(d_kl); if (d_rows) hipFree(d_rows); if (d_desc) hipFree(d_desc); if (d_f) hipFree(d_f);
+    if (d_kl) hipFree(d_kl); if (d_desc) hipFree(d_desc); if (d_f) hipFree(d_f);
     return r;
 }
 

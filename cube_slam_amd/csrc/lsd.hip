@@ -518,21 +518,21 @@ struct cs_lsd {
     std::vector<int> frame_base;
     std::vector<std::vector<cs_keyline>> keylines;
     // LBD descriptors of the detected lines (optional second half of cs_lsd_run)
-    uint8_t *d_lblur = nullptr; short *d_dx = nullptr, *d_dy = nullptr;
-    cs_keyline *d_kl = nullptr; int *d_line_frame = nullptr; float *d_rows = nullptr; uint8_t *d_desc = nullptr;
+    uint8_t *d_lblur = nullptr; uint32_t *d_dxy = nullptr; // LBD: blurred frames, interleaved Sobel dx | dy << 16
+    cs_keyline *d_kl = nullptr; int *d_line_frame = nullptr; uint8_t *d_desc = nullptr;
     size_t line_cap = 0;
     std::vector<int> line_off;       // per frame offset into the concatenated line list
     std::vector<uint8_t> h_desc;     // concatenated n x 32
     bool have_desc = false;
 };
 
-int cs_lbd_batch_maps(cs_ctx *ctx, const uint8_t *d_gray, int W, int H, int F, uint8_t *d_blur, short *d_dx, short *d_dy);
-int cs_lbd_batch_desc(cs_ctx *ctx, const cs_keyline *d_kl, const int *d_line_frame, int n, const short *d_dx, const short *d_dy, int W, int H, float *d_rows, uint8_t *d_desc, float *d_f);
+int cs_lbd_batch_maps(cs_ctx *ctx, const uint8_t *d_gray, int W, int H, int F, uint8_t *d_blur, uint32_t *d_dxy);
+int cs_lbd_batch_desc(cs_ctx *ctx, const cs_keyline *d_kl, const int *d_line_frame, int n, const uint32_t *d_dxy, int W, int H, uint8_t *d_desc, float *d_f);
 
 static void lsd_free_lines(cs_lsd *l) {
-    void *ptrs[] = {l->d_kl, l->d_line_frame, l->d_rows, l->d_desc};
+    void *ptrs[] = {l->d_kl, l->d_line_frame, l->d_desc};
     for (void *p : ptrs) if (p) hipFree(p);
-    l->d_kl = nullptr; l->d_line_frame = nullptr; l->d_rows = nullptr; l->d_desc = nullptr; l->line_cap = 0;
+    l->d_kl = nullptr; l->d_line_frame = nullptr; l->d_desc = nullptr; l->line_cap = 0;
 }
 
 static int lsd_upload(cs_ctx *ctx, cs_lsd *l, const uint8_t *gray, int n_frames, int stride) {
@@ -593,10 +593,9 @@ static int lsd_run(cs_ctx *ctx, cs_lsd *l, int with_lbd) {
         if (!l->d_lblur) {
             const size_t N = (size_t)W * H * l->max_frames;
             r = cs_dalloc(ctx, &l->d_lblur, N); if (r) return r;
-            r = cs_dalloc(ctx, &l->d_dx, N); if (r) return r;
-            r = cs_dalloc(ctx, &l->d_dy, N); if (r) return r;
+            r = cs_dalloc(ctx, &l->d_dxy, N); if (r) return r;
         }
-        r = cs_lbd_batch_maps(ctx, l->d_gray, W, H, F, l->d_lblur, l->d_dx, l->d_dy); if (r) return r;
+        r = cs_lbd_batch_maps(ctx, l->d_gray, W, H, F, l->d_lblur, l->d_dxy); if (r) return r;
     }
     CS_HIP(ctx, hipEventSynchronize(ev));
     ctx->pool.push_back(ev);
@@ -641,7 +640,6 @@ static int lsd_run(cs_ctx *ctx, cs_lsd *l, int with_lbd) {
                 const size_t cap = (size_t)nl + nl / 4 + 256;
                 r = cs_dalloc(ctx, &l->d_kl, cap); if (r) return r;
                 r = cs_dalloc(ctx, &l->d_line_frame, cap); if (r) return r;
-                r = cs_dalloc(ctx, &l->d_rows, cap * 63 * 4); if (r) return r;
                 r = cs_dalloc(ctx, &l->d_desc, cap * 32); if (r) return r;
                 l->line_cap = cap;
             }
@@ -652,7 +650,7 @@ static int lsd_run(cs_ctx *ctx, cs_lsd *l, int with_lbd) {
             }
             r = cs_h2d(ctx, l->d_line_frame, lf.data(), (size_t)nl); if (r) return r;
             CS_HIP(ctx, hipStreamSynchronize(ctx->stream)); // lf is a local
-            r = cs_lbd_batch_desc(ctx, l->d_kl, l->d_line_frame, nl, l->d_dx, l->d_dy, W, H, l->d_rows, l->d_desc, nullptr); if (r) return r;
+            r = cs_lbd_batch_desc(ctx, l->d_kl, l->d_line_frame, nl, l->d_dxy, W, H, l->d_desc, nullptr); if (r) return r;
             r = cs_d2h(ctx, l->h_desc.data(), l->d_desc, (size_t)nl * 32); if (r) return r;
         }
         CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -666,7 +664,7 @@ extern "C" {
 void cs_lsd_destroy(cs_ctx *ctx, cs_lsd *l) {
     if (!l) return;
     if (ctx) { hipSetDevice(ctx->device); hipStreamSynchronize(ctx->stream); }
-    void *ptrs[] = {l->d_gray, l->d_tmp, l->d_blur, l->d_scaled, l->d_mod, l->d_ang, l->d_xofs, l->d_yofs, l->d_ax, l->d_ay, l->d_lblur, l->d_dx, l->d_dy};
+    void *ptrs[] = {l->d_gray, l->d_tmp, l->d_blur, l->d_scaled, l->d_mod, l->d_ang, l->d_xofs, l->d_yofs, l->d_ax, l->d_ay, l->d_lblur, l->d_dxy};
     for (void *p : ptrs) if (p) hipFree(p);
     lsd_free_lines(l);
     void *more[] = {l->d_seg_cnt, l->d_seg_base, l->d_blk_tot, l->d_caddr, l->d_cang, l->d_cmod};

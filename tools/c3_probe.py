@@ -26,6 +26,6 @@ t2 = time.perf_counter()
 nk = sum(len(k) for k, _ in orb.read()); nl = sum(len(lsd.read(f, with_desc=False)) for f in range(F))
 print("F=%d  orb.run %.2f ms (%d keypoints)  lsd+lbd %.2f ms (%d lines)" % (F, (t1 - t0) / 5 * 1e3, nk, (t2 - t1) / 5 * 1e3, nl))
 for k in ("host_orb_quadtree", "orb_quadtree", "orb_compact_sel", "orb_resize", "orb_fast_score", "orb_cells", "orb_blur", "orb_angle", "orb_desc", "host_lsd_regions", "host_lsd_cpu_sort", "host_lsd_cpu_grow",
-          "host_lsd_cpu_rect", "host_lsd_n_def", "lsd_blur_hv", "lsd_resize", "lsd_gradient", "lsd_emit", "lbd_blur5", "lbd_sobel", "lbd_rows", "lbd_desc"):
+          "host_lsd_cpu_rect", "host_lsd_n_def", "lsd_blur_hv", "lsd_resize", "lsd_gradient", "lsd_emit", "lbd_blur5", "lbd_sobel", "lbd_line_desc"):
     ms, n = ctx.timing_get(k)
     print("  %-22s %10.3f ms total / 5 runs = %8.3f" % (k, ms, ms / 5))

@@ -26,3 +26,8 @@ print("OMP", os.environ.get("OMP_NUM_THREADS"), "F", F, "lsd.run %.1f ms (host %
 
 for k in ("host_lsd_cpu_sort", "host_lsd_cpu_grow", "host_lsd_cpu_rect", "host_lsd_n_seeds", "host_lsd_n_regions", "host_lsd_n_pix", "host_lsd_n_def"):
     print(k, ctx.timing_get(k)[0] / 5)
+for k in ("lsd_blur_hv", "lsd_resize", "lsd_gradient", "lsd_scan_blocks", "lsd_scan_top", "lsd_scan_add", "lsd_emit", "lbd_blur5", "lbd_sobel", "lbd_line_desc",
+          "orb_resize", "orb_fast_score", "orb_cells", "orb_scan", "orb_quadtree", "orb_compact_sel", "orb_blur", "orb_angle", "orb_desc"):
+    t = ctx.timing_get(k)
+    if t[1]:
+        print("%-18s %8.1f us/call" % (k, t[0] / t[1] * 1e3))
