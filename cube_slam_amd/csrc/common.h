@@ -105,6 +105,12 @@ __device__ __forceinline__ int wave_incl_min_scan(int x) {
 }
 __device__ __forceinline__ int lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)); }
 
+// Four neighbouring pixels of a u8 row with one load.  gfx950 runs global memory in unaligned-access mode (a dword load may start at
+// any byte; tools/ubench/unaligned_load.hip checks it on the device), and one dword gather costs the texture-address unit a quarter
+// of four byte gathers.
+typedef uint32_t __attribute__((aligned(1))) cs_u32_unaligned;
+__device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *p) { return *reinterpret_cast<const cs_u32_unaligned *>(p); }
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the global-memory counter (s_waitcnt vmcnt(0)), so
 // in a loop that stores a result row / column to global memory and prefetches the next one, every barrier would wait for those
 // round trips (measured: 5.4 us per column in ba_band_chol, 3.5 us per row in orb_blur).  Only valid where no thread reads,

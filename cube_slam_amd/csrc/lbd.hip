@@ -43,6 +43,7 @@ __global__ void __launch_bounds__(64) lbd_blur5(const uint8_t *gray, int W, int 
     for (int c = 0; c < 4; c++) xc[c] = refl(sx + 4 * tid + c, W);
     const int xh = tid < 2 ? refl(sx - 2 + tid, W) : refl(sx + 256 + (tid - 2), W); // halo columns, lanes 0..3
     const int x = sx + 4 * tid;
+    const bool inner = x + 3 < W; // the lane's four columns exist: one unaligned dword load per row
     int k[5];
 #pragma unroll
     for (int t = 0; t < 5; t++) k[t] = wts.k5[t];
@@ -60,7 +61,7 @@ __global__ void __launch_bounds__(64) lbd_blur5(const uint8_t *gray, int W, int 
             a[u] = 0; hh[u] = 0;
             if (r0 + u < total) {
                 const uint8_t *row = img + (long)refl(y0 + r0 + u - 2, H) * W;
-                a[u] = (uint32_t)row[xc[0]] | ((uint32_t)row[xc[1]] << 8) | ((uint32_t)row[xc[2]] << 16) | ((uint32_t)row[xc[3]] << 24);
+                a[u] = inner ? load_u32_unaligned(row + x) : ((uint32_t)row[xc[0]] | ((uint32_t)row[xc[1]] << 8) | ((uint32_t)row[xc[2]] << 16) | ((uint32_t)row[xc[3]] << 24));
                 if (tid < 4) hh[u] = row[xh];
             }
         }
@@ -123,6 +124,7 @@ __global__ void __launch_bounds__(64) lbd_sobel(const uint8_t *blur, int W, int 
     for (int c = 0; c < 4; c++) xc[c] = refl(sx + 4 * tid + c, W);
     const int xh = tid < 1 ? refl(sx - 1, W) : refl(sx + 256, W); // lanes 0, 1
     const int x = sx + 4 * tid;
+    const bool inner = x + 3 < W; // the lane's four columns exist: one unaligned dword load per row
     int win[3][6]; // rows y-1, y, y+1; columns x-1 .. x+4
 #pragma unroll
     for (int i = 0; i < 3; i++)
@@ -137,7 +139,7 @@ __global__ void __launch_bounds__(64) lbd_sobel(const uint8_t *blur, int W, int 
             a[u] = 0; hh[u] = 0;
             if (r0 + u < total) {
                 const uint8_t *row = img + (long)refl(y0 + r0 + u - 1, H) * W;
-                a[u] = (uint32_t)row[xc[0]] | ((uint32_t)row[xc[1]] << 8) | ((uint32_t)row[xc[2]] << 16) | ((uint32_t)row[xc[3]] << 24);
+                a[u] = inner ? load_u32_unaligned(row + x) : ((uint32_t)row[xc[0]] | ((uint32_t)row[xc[1]] << 8) | ((uint32_t)row[xc[2]] << 16) | ((uint32_t)row[xc[3]] << 24));
                 if (tid < 2) hh[u] = row[xh];
             }
         }

@@ -76,48 +76,70 @@ __global__ void __launch_bounds__(256) orb_fast_score(Pyr P, const uint8_t *pyr,
     const int tiles_x = (L.w + TW - 1) / TW, tiles_y = (L.h + TH - 1) / TH;
     if ((int)blockIdx.x >= tiles_x * tiles_y) return;
     const int tx0 = (blockIdx.x % tiles_x) * TW, ty0 = (blockIdx.x / tiles_x) * TH;
-    __shared__ uint8_t g[TH + 6][TW + 8];
+    __shared__ uint32_t g32[TH + 6][(TW + 8) / 4];
+    __shared__ unsigned short s_list[TW * TH];
+    __shared__ int s_n;
+    uint8_t (*g)[TW + 8] = reinterpret_cast<uint8_t (*)[TW + 8]>(g32);
     const int tq = min(P.ini_th, P.min_th);
     const uint8_t *img = pyr + (long)blockIdx.z * P.frame_stride + L.off;
-    for (int i = threadIdx.x; i < (TH + 6) * (TW + 6); i += 256) {
-        int ly = i / (TW + 6), lx = i % (TW + 6);
-        int X = tx0 + lx - 3, Y = ty0 + ly - 3;
-        g[ly][lx] = (X >= 0 && X < L.w && Y >= 0 && Y < L.h) ? img[(long)Y * L.w + X] : 0;
+    if (threadIdx.x == 0) s_n = 0;
+    // tile + 3-pixel halo as dwords (unaligned loads); a dword that leaves the image row falls back to guarded bytes
+    for (int i = threadIdx.x; i < (TH + 6) * ((TW + 8) / 4); i += 256) {
+        const int ly = i / ((TW + 8) / 4), k4 = i % ((TW + 8) / 4);
+        const int X = tx0 + 4 * k4 - 3, Y = ty0 + ly - 3;
+        uint32_t v = 0;
+        if (Y >= 0 && Y < L.h) {
+            const uint8_t *row = img + (long)Y * L.w;
+            if (X >= 0 && X + 3 < L.w) v = load_u32_unaligned(row + X);
+            else
+                for (int c = 0; c < 4; c++) if (X + c >= 0 && X + c < L.w) v |= (uint32_t)row[X + c] << (8 * c);
+        }
+        g32[ly][k4] = v;
     }
     __syncthreads();
+    // pass 1: the compass test on every pixel; the few that pass are appended to the workgroup's list, so that the min/max network
+    // below runs with full waves instead of once per wave that holds a single candidate
     const int lx = threadIdx.x & 63;
     for (int ly = threadIdx.x >> 6; ly < TH; ly += 4) {
         const int x = tx0 + lx, y = ty0 + ly;
-        if (x >= L.w || y >= L.h) continue;
-        int S = 0;
         bool cand = false;
-        int v = 0;
         if (x >= 3 && y >= 3 && x < L.w - 3 && y < L.h - 3) {
-            v = g[ly + 3][lx + 3];
+            const int v = g[ly + 3][lx + 3];
             const int d0 = v - (int)g[ly + 6][lx + 3], d4 = v - (int)g[ly + 3][lx + 6], d8 = v - (int)g[ly][lx + 3], d12 = v - (int)g[ly + 3][lx];
             const bool k0 = d0 > tq, k4 = d4 > tq, k8 = d8 > tq, k12 = d12 > tq, b0 = d0 < -tq, b4 = d4 < -tq, b8 = d8 < -tq, b12 = d12 < -tq;
             cand = (k0 && k4) || (k4 && k8) || (k8 && k12) || (k12 && k0) || (b0 && b4) || (b4 && b8) || (b8 && b12) || (b12 && b0);
         }
-        if (cand) {
-            int d[16];
-#pragma unroll
-            for (int k = 0; k < 16; k++) d[k] = v - (int)g[ly + 3 + c_ring[k][1]][lx + 3 + c_ring[k][0]];
-            int lo2[16], hi2[16], lo4[16], hi4[16];
-#pragma unroll
-            for (int k = 0; k < 16; k++) { lo2[k] = min(d[k], d[(k + 1) & 15]); hi2[k] = max(d[k], d[(k + 1) & 15]); }
-#pragma unroll
-            for (int k = 0; k < 16; k++) { lo4[k] = min(lo2[k], lo2[(k + 2) & 15]); hi4[k] = max(hi2[k], hi2[(k + 2) & 15]); }
-            int sd = -1000, sb = 1000;
-#pragma unroll
-            for (int k = 0; k < 16; k++) {
-                int lo9 = min(min(lo4[k], lo4[(k + 4) & 15]), d[(k + 8) & 15]); // min over ring[k..k+8]
-                int hi9 = max(max(hi4[k], hi4[(k + 4) & 15]), d[(k + 8) & 15]);
-                sd = max(sd, lo9);  // darker arc: v - p > t on the whole arc
-                sb = min(sb, hi9);  // brighter arc: p - v > t  <=>  max(v - p) < -t
-            }
-            S = max(max(sd, -sb), 0);
+        const unsigned long long m = __ballot(cand);
+        if (m) {
+            int base = 0;
+            if (lx == 0) base = atomicAdd(&s_n, __popcll(m));
+            base = __shfl(base, 0);
+            if (cand) s_list[base + __popcll(m & ((1ull << lx) - 1))] = (unsigned short)(ly << 8 | lx);
         }
-        if (S > tq) smap[(long)blockIdx.z * P.frame_stride + L.off + (long)y * L.w + x] = (uint8_t)S; // the map is zero-filled before the launch
+    }
+    __syncthreads();
+    const int n = s_n;
+    for (int i = threadIdx.x; i < n; i += 256) {
+        const int ly = s_list[i] >> 8, px = s_list[i] & 255;
+        const int v = g[ly + 3][px + 3];
+        int d[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) d[k] = v - (int)g[ly + 3 + c_ring[k][1]][px + 3 + c_ring[k][0]];
+        int lo2[16], hi2[16], lo4[16], hi4[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) { lo2[k] = min(d[k], d[(k + 1) & 15]); hi2[k] = max(d[k], d[(k + 1) & 15]); }
+#pragma unroll
+        for (int k = 0; k < 16; k++) { lo4[k] = min(lo2[k], lo2[(k + 2) & 15]); hi4[k] = max(hi2[k], hi2[(k + 2) & 15]); }
+        int sd = -1000, sb = 1000;
+#pragma unroll
+        for (int k = 0; k < 16; k++) {
+            int lo9 = min(min(lo4[k], lo4[(k + 4) & 15]), d[(k + 8) & 15]); // min over ring[k..k+8]
+            int hi9 = max(max(hi4[k], hi4[(k + 4) & 15]), d[(k + 8) & 15]);
+            sd = max(sd, lo9);  // darker arc: v - p > t on the whole arc
+            sb = min(sb, hi9);  // brighter arc: p - v > t  <=>  max(v - p) < -t
+        }
+        const int S = max(max(sd, -sb), 0);
+        if (S > tq) smap[(long)blockIdx.z * P.frame_stride + L.off + (long)(ty0 + ly) * L.w + tx0 + px] = (uint8_t)S; // the map is zero-filled before the launch
     }
 }
 
@@ -295,6 +317,7 @@ __global__ void __launch_bounds__(64) orb_blur(Pyr P, const uint8_t *pyr, uint8_
     for (int c = 0; c < 4; c++) xc[c] = reflect101(sx + 4 * tid + c, L.w);
     const int xh = tid < 3 ? reflect101(sx - 3 + tid, L.w) : reflect101(sx + 256 + (tid - 3), L.w); // halo columns, lanes 0..5
     const int x = sx + 4 * tid;
+    const bool inner = x + 3 < L.w; // the lane's four columns exist (x >= 0 always): one unaligned dword load per row
     int k[7];
 #pragma unroll
     for (int t = 0; t < 7; t++) k[t] = P.gk[t];
@@ -312,7 +335,7 @@ __global__ void __launch_bounds__(64) orb_blur(Pyr P, const uint8_t *pyr, uint8_
             a[u] = 0; hh[u] = 0;
             if (r0 + u < total) {
                 const uint8_t *row = img + (long)reflect101(y0 + r0 + u - 3, L.h) * L.w;
-                a[u] = (uint32_t)row[xc[0]] | ((uint32_t)row[xc[1]] << 8) | ((uint32_t)row[xc[2]] << 16) | ((uint32_t)row[xc[3]] << 24);
+                a[u] = inner ? load_u32_unaligned(row + x) : ((uint32_t)row[xc[0]] | ((uint32_t)row[xc[1]] << 8) | ((uint32_t)row[xc[2]] << 16) | ((uint32_t)row[xc[3]] << 24));
                 if (tid < 6) hh[u] = row[xh];
             }
         }
