@@ -111,6 +111,15 @@ __device__ __forceinline__ int lane_id() { return __builtin_amdgcn_mbcnt_hi(~0u,
 typedef uint32_t __attribute__((aligned(1))) cs_u32_unaligned;
 __device__ __forceinline__ uint32_t load_u32_unaligned(const uint8_t *p) { return *reinterpret_cast<const cs_u32_unaligned *>(p); }
 
+// four consecutive bytes of the 12-byte window w0 w1 w2 starting at byte START (0..8), as one dword
+template <int START> __device__ __forceinline__ uint32_t win4(uint32_t w0, uint32_t w1, uint32_t w2) {
+    if (START == 0) return w0;
+    if (START < 4) return __builtin_amdgcn_alignbyte(w1, w0, START);
+    if (START == 4) return w1;
+    if (START < 8) return __builtin_amdgcn_alignbyte(w2, w1, START - 4);
+    return w2;
+}
+
 // Workgroup barrier that orders LDS traffic only.  __syncthreads() also drains the global-memory counter (s_waitcnt vmcnt(0)), so
 // in a loop that stores a result row / column to global memory and prefetches the next one, every barrier would wait for those
 // round trips (measured: 5.4 us per column in ba_band_chol, 3.5 us per row in orb_blur).  Only valid where no thread reads,

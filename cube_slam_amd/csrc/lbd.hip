@@ -47,6 +47,7 @@ __global__ void __launch_bounds__(64) lbd_blur5(const uint8_t *gray, int W, int 
     int k[5];
 #pragma unroll
     for (int t = 0; t < 5; t++) k[t] = wts.k5[t];
+    const uint32_t kA = (uint32_t)k[0] | (uint32_t)k[1] << 8 | (uint32_t)k[2] << 16 | (uint32_t)k[3] << 24;
     int ring[4][5];
 #pragma unroll
     for (int c = 0; c < 4; c++)
@@ -79,23 +80,21 @@ __global__ void __launch_bounds__(64) lbd_blur5(const uint8_t *gray, int W, int 
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 const uint32_t w0 = line32[tid], w1 = line32[tid + 1], w2 = line32[tid + 2];
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                int px[12];
-#pragma unroll
-                for (int b2 = 0; b2 < 4; b2++) { px[b2] = (w0 >> (8 * b2)) & 255; px[4 + b2] = (w1 >> (8 * b2)) & 255; px[8 + b2] = (w2 >> (8 * b2)) & 255; }
+                // column x + c: taps at bytes c + 2 .. c + 6 of the 12-byte window (same dot4 / mul24 scheme as orb_blur)
                 uint32_t packed = 0;
+                const uint32_t t4[4] = {win4<2>(w0, w1, w2), win4<3>(w0, w1, w2), win4<4>(w0, w1, w2), win4<5>(w0, w1, w2)}; // taps 0..3 of column c
+                const uint32_t t5[4] = {win4<6>(w0, w1, w2), win4<7>(w0, w1, w2), win4<8>(w0, w1, w2), win4<8>(w0, w1, w2) >> 8};     // tap 4 in the low byte
 #pragma unroll
-                for (int c = 0; c < 4; c++) { // column x + c: taps at span bytes c + 2 .. c + 6
-                    int h = 0;
-#pragma unroll
-                    for (int t = 0; t < 5; t++) h += px[c + 2 + t] * k[t];
+                for (int c = 0; c < 4; c++) {
+                    const uint32_t h = __builtin_amdgcn_udot4(t4[c], kA, __umul24(t5[c] & 255u, (uint32_t)k[4]), false);
 #pragma unroll
                     for (int t = 0; t < 4; t++) ring[c][t] = ring[c][t + 1];
-                    ring[c][4] = h;
-                    int sum = 0;
+                    ring[c][4] = (int)h;
+                    uint32_t sum = 1u << 15;
 #pragma unroll
-                    for (int t = 0; t < 5; t++) sum += ring[c][t] * k[t];
-                    const int v = (sum + (1 << 15)) >> 16;
-                    packed |= (uint32_t)(v < 0 ? 0 : (v > 255 ? 255 : v)) << (8 * c);
+                    for (int t = 0; t < 5; t++) sum = __umul24((uint32_t)ring[c][t], (uint32_t)k[t]) + sum;
+                    const uint32_t v = sum >> 16;
+                    packed |= (v > 255u ? 255u : v) << (8 * c);
                 }
                 if (r >= 4 && x < W) {
                     uint8_t *dst = out + (long)(y0 + r - 4) * W + x;

@@ -321,6 +321,7 @@ __global__ void __launch_bounds__(64) orb_blur(Pyr P, const uint8_t *pyr, uint8_
     int k[7];
 #pragma unroll
     for (int t = 0; t < 7; t++) k[t] = P.gk[t];
+    const uint32_t kA = (uint32_t)k[0] | (uint32_t)k[1] << 8 | (uint32_t)k[2] << 16 | (uint32_t)k[3] << 24, kB = (uint32_t)k[4] | (uint32_t)k[5] << 8 | (uint32_t)k[6] << 16;
     int ring[4][7];
 #pragma unroll
     for (int c = 0; c < 4; c++)
@@ -353,23 +354,24 @@ __global__ void __launch_bounds__(64) orb_blur(Pyr P, const uint8_t *pyr, uint8_
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
                 const uint32_t w0 = line32[tid], w1 = line32[tid + 1], w2 = line32[tid + 2];
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); // reads done before the next row overwrites the line
-                int px[12];
-#pragma unroll
-                for (int b2 = 0; b2 < 4; b2++) { px[b2] = (w0 >> (8 * b2)) & 255; px[4 + b2] = (w1 >> (8 * b2)) & 255; px[8 + b2] = (w2 >> (8 * b2)) & 255; }
+                // column sx + 4 tid + c: taps at bytes c + 1 .. c + 7 of the 12-byte window w0 w1 w2.  The 8-bit weights ride in two
+                // dwords (kA = k0..k3, kB = k4..k6, 0): two byte-aligns and two v_dot4_u32_u8 per column; the vertical taps are
+                // 24-bit multiply-adds (h < 2^16, k < 2^8).  A plain int product compiles to v_mul_lo_u32, a quarter-rate instruction
+                // -- 52 of them per row made this kernel four times slower than its memory traffic.
                 uint32_t packed = 0;
+                const uint32_t lo4[4] = {win4<1>(w0, w1, w2), win4<2>(w0, w1, w2), win4<3>(w0, w1, w2), win4<4>(w0, w1, w2)};
+                const uint32_t hi4[4] = {win4<5>(w0, w1, w2), win4<6>(w0, w1, w2), win4<7>(w0, w1, w2), win4<8>(w0, w1, w2)};
 #pragma unroll
-                for (int c = 0; c < 4; c++) { // column sx + 4 tid + c: taps at bytes 4 tid + c + 1 .. + 7 of the line = px[c + 1 .. c + 7]
-                    int h = 0;
-#pragma unroll
-                    for (int t = 0; t < 7; t++) h += px[c + 1 + t] * k[t];
+                for (int c = 0; c < 4; c++) {
+                    const uint32_t h = __builtin_amdgcn_udot4(lo4[c], kA, __builtin_amdgcn_udot4(hi4[c], kB, 0u, false), false);
 #pragma unroll
                     for (int t = 0; t < 6; t++) ring[c][t] = ring[c][t + 1];
-                    ring[c][6] = h;
-                    int sum = 0;
+                    ring[c][6] = (int)h;
+                    uint32_t sum = 1u << 15;
 #pragma unroll
-                    for (int t = 0; t < 7; t++) sum += ring[c][t] * k[t];
-                    const int v = (sum + (1 << 15)) >> 16;
-                    packed |= (uint32_t)(v < 0 ? 0 : (v > 255 ? 255 : v)) << (8 * c);
+                    for (int t = 0; t < 7; t++) sum = __umul24((uint32_t)ring[c][t], (uint32_t)k[t]) + sum;
+                    const uint32_t v = sum >> 16; // <= 255: the weights sum to 256 in each direction
+                    packed |= (v > 255u ? 255u : v) << (8 * c);
                 }
                 if (r >= 6 && x < L.w) {
                     uint8_t *dst = out + (long)(y0 + r - 6) * L.w + x;
