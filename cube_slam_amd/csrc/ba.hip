@@ -565,14 +565,49 @@ __global__ void __launch_bounds__(64) ba_cub_back(int C, int Q, const int *cq_of
     const double *D = cubD + (long)q * 36, *g = cubg + (long)q * 6;
     for (int r = 0; r < 6; r++) { double v = 0; for (int c = 0; c < 6; c++) v += D[r * 6 + c] * w[c]; x[(long)(C + q) * 6 + r] = g[r] - v; }
 }
-// Block-band Cholesky + both triangular solves in one workgroup.  A: C columns x (Bc+1) blocks (block d of column j = block
-// (j+d, j), row-major 6x6), Lf: same layout, receives L; rhs: in b (6C), out x; ybuf: 12C scratch (y_j, 1/diag L_jj).  LDS: a ring of Bc+2 columns (the extra slot
-// receives column j+Bc+1 while column j is processed) and the matching right-hand-side window.
-__global__ void __launch_bounds__(256) ba_band_chol(int C, int Bc, const double *A, double *Lf, double *rhs, double *ybuf, int *status) {
-    extern __shared__ double sh[];
+// ---- block-band Cholesky of the camera system.  A: C columns x (Bc+1) blocks (block d of column j = block (j+d, j), row-major 6x6).
+// The elimination is a serial chain over the columns (each step: 6x6 pivot, Bc panel blocks, Bc(Bc+1)/2 trailing blocks, all in
+// LDS), so it is run from BOTH ends at once ("twisted" factorisation): workgroup 0 eliminates columns 0, 1, 2, ... of A,
+// workgroup 1 eliminates C-1, C-2, ... (the same band algorithm on the index-reversed matrix, whose columns are gathered from A
+// with a transpose), each stopping before a middle group of R = Bc cameras.  Neither side creates fill outside the band, the
+// middle group receives the Schur updates of both sides (ba_band_mid adds them, factors the dense 6R x 6R block and solves it),
+// and the two back substitutions again run concurrently.  Half the chain length, three launches instead of one.
+// A "side" sees the principal submatrix of its ne eliminated columns plus the R tail (middle) columns, in its own (local) order.
+struct BandView {
+    const double *A, *rhs; // the assembled band and right-hand side (original order)
+    int C, Bc, n, ne, rev; // n = ne + tail columns; rev: local column j is original column C-1-j
+    int lf_base;           // first column of this side in the factor storage Lf / ybuf
+};
+__device__ __forceinline__ double band_a(const BandView &V, int cn, int i) { // element i (block d = i/36) of local column cn
+    const int d = i / 36;
+    if (cn + d >= V.n) return 0.0; // rows outside the side's submatrix
+    if (!V.rev) return V.A[(long)cn * ((V.Bc + 1) * 36) + i];
+    if (cn >= V.ne) return 0.0;    // middle x middle blocks (and the middle right-hand side) are counted once, by the forward side
+    const int e = i - d * 36, r = e / 6, c = e - r * 6, o = V.C - 1 - cn;
+    return V.A[(long)(o - d) * ((V.Bc + 1) * 36) + d * 36 + c * 6 + r]; // reversed block (cn+d, cn) = A(o, o-d)^T ... stored in column o-d
+}
+__device__ __forceinline__ double band_b(const BandView &V, int cn, int t) {
+    if (cn >= V.n) return 0.0;
+    if (!V.rev) return V.rhs[(long)cn * 6 + t];
+    return cn < V.ne ? V.rhs[(long)(V.C - 1 - cn) * 6 + t] : 0.0;
+}
+struct BandLds { double *W, *bw, *yj, *Linv, *part; int *pair_d; };
+__device__ __forceinline__ BandLds band_lds(double *sh, int Bc) {
     const int NB = Bc + 1, NS = Bc + 2, CS = NB * 36;
-    double *W = sh, *bw = W + (long)NS * CS, *yj = bw + NS * 6, *Linv = yj + 6, *part = Linv + 6; // part: 8 x 6 partial sums (back substitution)
-    int *pair_d = (int *)(part + 48); // pair -> (di << 8 | dk)
+    BandLds L;
+    L.W = sh; L.bw = L.W + (long)NS * CS; L.yj = L.bw + NS * 6; L.Linv = L.yj + 6; L.part = L.Linv + 6; // part: 8 x 6 partial sums (back substitution)
+    L.pair_d = (int *)(L.part + 48); // pair -> (di << 8 | dk)
+    return L;
+}
+static size_t band_lds_bytes(int Bc) { return sizeof(double) * ((size_t)(Bc + 2) * (Bc + 1) * 36 + (size_t)(Bc + 2) * 6 + 6 + 6 + 48) + sizeof(int) * (size_t)std::max(1, Bc * (Bc + 1) / 2); }
+
+// Eliminates local columns 0..ne-1 (L to Lf, y_j and 1/diag to ybuf), forward solve fused.  LDS: a ring of Bc+2 columns (the extra
+// slot receives column j+Bc+1 while column j is processed) and the matching right-hand-side window.  On return the window holds
+// the updated tail columns ne..n-1.
+__device__ __forceinline__ bool band_factor(const BandView &V, const BandLds &S, double *Lf, double *ybuf) {
+    const int Bc = V.Bc, NB = Bc + 1, NS = Bc + 2, CS = NB * 36;
+    double *W = S.W, *bw = S.bw, *yj = S.yj, *Linv = S.Linv;
+    int *pair_d = S.pair_d;
     const int tid = threadIdx.x;
     for (int pr = tid; pr < Bc * (Bc + 1) / 2; pr += 256) {
         int di = (int)((sqrt(8.0 * pr + 1.0) - 1.0) * 0.5);
@@ -580,22 +615,21 @@ __global__ void __launch_bounds__(256) ba_band_chol(int C, int Bc, const double 
         while ((di + 1) * (di + 2) / 2 <= pr) di++;
         pair_d[pr] = ((di + 1) << 8) | (pr - di * (di + 1) / 2 + 1);
     }
-    const int n0 = C < NB ? C : NB;
-    for (int i = tid; i < n0 * CS; i += 256) W[i] = A[i];           // columns 0..n0-1 sit in slots 0..n0-1
-    for (int i = tid; i < n0 * 6; i += 256) bw[i] = rhs[i];
+    const int n0 = V.n < NB ? V.n : NB;
+    for (int i = tid; i < n0 * CS; i += 256) W[i] = band_a(V, i / CS, i % CS); // columns 0..n0-1 sit in slots 0..n0-1
+    for (int i = tid; i < n0 * 6; i += 256) bw[i] = band_b(V, i / 6, i % 6);
     __syncthreads();
     bool fail = false;
-    for (int j = 0; j < C; j++) {
+    for (int j = 0; j < V.ne; j++) {
         double *Wc = W + (long)(j % NS) * CS;
-        const int nd = (C - 1 - j) < Bc ? (C - 1 - j) : Bc;
+        const int nd = (V.n - 1 - j) < Bc ? (V.n - 1 - j) : Bc;
         const int cn = j + Bc + 1;
         // next column: loads issued now, stored to the free LDS slot at the end of the step (global latency off the critical path)
         double pf[4] = {0, 0, 0, 0}, pfb = 0;
-        if (cn < C) {
-            const double *src = A + (long)cn * CS;
+        if (cn < V.n) {
 #pragma unroll
-            for (int u = 0; u < 4; u++) if (tid + u * 256 < CS) pf[u] = src[tid + u * 256];
-            if (tid < 6) pfb = rhs[(long)cn * 6 + tid];
+            for (int u = 0; u < 4; u++) if (tid + u * 256 < CS) pf[u] = band_a(V, cn, tid + u * 256);
+            if (tid < 6) pfb = band_b(V, cn, tid);
         }
         if (tid < 64) { // L_jj and y_j = L_jj^-1 b_j by lanes 0..5 of wave 0 (lane r = row r); 1/sqrt(pivot) from v_rsq_f64 + two Newton steps
             const int r = tid < 6 ? tid : 0;
@@ -665,9 +699,9 @@ __global__ void __launch_bounds__(256) ba_band_chol(int C, int Bc, const double 
                 bw[((j + d) % NS) * 6 + r] -= v;
             }
         }
-        for (int i = tid; i < (nd + 1) * 36; i += 256) Lf[(long)j * CS + i] = Wc[i];
-        if (tid < 12) ybuf[(long)j * 12 + tid] = tid < 6 ? yj[tid] : Linv[tid - 6]; // a buffer this kernel has not read before: no stale L1 line possible
-        if (cn < C) {
+        for (int i = tid; i < (nd + 1) * 36; i += 256) Lf[(long)(V.lf_base + j) * CS + i] = Wc[i];
+        if (tid < 12) ybuf[(long)(V.lf_base + j) * 12 + tid] = tid < 6 ? yj[tid] : Linv[tid - 6]; // a buffer this kernel has not read before: no stale L1 line possible
+        if (cn < V.n) {
             double *dst = W + (long)(cn % NS) * CS;
 #pragma unroll
             for (int u = 0; u < 4; u++) if (tid + u * 256 < CS) dst[tid + u * 256] = pf[u];
@@ -675,75 +709,161 @@ __global__ void __launch_bounds__(256) ba_band_chol(int C, int Bc, const double 
         }
         lds_barrier();
     }
-    // L^T x = y, last column first.  The columns of L come back from global memory in chunks of KC columns through two LDS
-    // buffers (the whole workgroup loads chunk k+1 into registers while chunk k is used, one barrier per chunk); inside a chunk
-    // wave 0 works alone, without barriers: lane = part * 6 + c sums L_d^T x_{j+d} over the blocks d = 1 + part, 9 + part,
-    // 17 + part, shuffles reduce the 8 parts, lanes 0..5 finish with L_jj^T by lane broadcasts.  Solved blocks: LDS ring xw.
-    __syncthreads(); // every store to Lf / ybuf has completed
-    {
-        double *xw = bw;
-        const int KC = (NS - 1) / 2, CB = KC * CS;           // chunk: KC columns of CS doubles; buffers W[0..CB) and W[CB..2CB), >= CS doubles left for ych
-        double *ych = W + 2 * (long)CB;                      // 2 x KC x 12 (y_j, 1/diag) -- fits: NS*CS >= 2*CB + 24*KC for Bc >= 1
-        const int nchunk = (C + KC - 1) / KC;
-        auto chunk_lo = [&](int ch) { return C - (ch + 1) * KC < 0 ? 0 : C - (ch + 1) * KC; }; // chunk ch covers columns [lo, hi)
-        auto chunk_hi = [&](int ch) { return C - ch * KC; };
-        constexpr int PF = 12; // doubles per thread per chunk: KC * CS <= 11 * 756 / 2 ... checked by the host (Bc <= 20 -> CB <= 8316 -> 33 per thread)
-        double pf[36], pfy = 0;
-        auto issue = [&](int ch) {
-            const int lo = chunk_lo(ch), n = (chunk_hi(ch) - lo) * CS;
+    return fail;
+}
+
+// L^T x = y for the local columns ne-1 .. 0, last first; xtail (may be NULL when n == ne): solved tail blocks in local order.
+// The columns of L come back from global memory in chunks of KC columns through two LDS buffers (the whole workgroup loads chunk
+// k+1 into registers while chunk k is used, one barrier per chunk); inside a chunk wave 0 works alone, without barriers: lane =
+// part * 6 + c sums L_d^T x_{j+d} over the blocks d = 1 + part, 9 + part, 17 + part, shuffles reduce the 8 parts, lanes 0..5
+// finish with L_jj^T by lane broadcasts.  Solved blocks: LDS ring xw; xout in original order.
+__device__ __forceinline__ void band_back(const BandView &V, const BandLds &S, const double *Lf, const double *ybuf, const double *xtail, int xtail_rev, double *xout) {
+    const int Bc = V.Bc, NB = Bc + 1, NS = Bc + 2, CS = NB * 36, C = V.ne;
+    double *W = S.W;
+    const int tid = threadIdx.x;
+    double *xw = S.bw;
+    const int R = V.n - V.ne;
+    for (int i = tid; i < R * 6; i += 256) { const int t = i / 6; xw[((V.ne + t) % NS) * 6 + i % 6] = xtail[(long)(xtail_rev ? R - 1 - t : t) * 6 + i % 6]; }
+    const int KC = (NS - 1) / 2, CB = KC * CS;           // chunk: KC columns of CS doubles; buffers W[0..CB) and W[CB..2CB), >= CS doubles left for ych
+    double *ych = W + 2 * (long)CB;                      // 2 x KC x 12 (y_j, 1/diag) -- fits: NS*CS >= 2*CB + 24*KC for Bc >= 1
+    const int nchunk = (C + KC - 1) / KC;
+    auto chunk_lo = [&](int ch) { return C - (ch + 1) * KC < 0 ? 0 : C - (ch + 1) * KC; }; // chunk ch covers columns [lo, hi)
+    auto chunk_hi = [&](int ch) { return C - ch * KC; };
+    double pf[36], pfy = 0; // doubles per thread per chunk: Bc <= 20 -> CB <= 8316 -> 33 per thread (checked by the host)
+    auto issue = [&](int ch) {
+        const int lo = chunk_lo(ch), n = (chunk_hi(ch) - lo) * CS;
 #pragma unroll
-            for (int u = 0; u < 36; u++) { const int i = tid + u * 256; pf[u] = i < n ? __builtin_nontemporal_load(Lf + (long)lo * CS + i) : 0.0; }
-            const int ny = (chunk_hi(ch) - lo) * 12;
-            pfy = tid < ny ? __builtin_nontemporal_load(ybuf + (long)lo * 12 + tid) : 0.0;
-        };
-        auto commit = [&](int ch) {
-            const int lo = chunk_lo(ch), n = (chunk_hi(ch) - lo) * CS;
-            double *dst = W + (long)(ch & 1) * CB;
+        for (int u = 0; u < 36; u++) { const int i = tid + u * 256; pf[u] = i < n ? __builtin_nontemporal_load(Lf + (long)(V.lf_base + lo) * CS + i) : 0.0; }
+        const int ny = (chunk_hi(ch) - lo) * 12;
+        pfy = tid < ny ? __builtin_nontemporal_load(ybuf + (long)(V.lf_base + lo) * 12 + tid) : 0.0;
+    };
+    auto commit = [&](int ch) {
+        const int lo = chunk_lo(ch), n = (chunk_hi(ch) - lo) * CS;
+        double *dst = W + (long)(ch & 1) * CB;
 #pragma unroll
-            for (int u = 0; u < 36; u++) { const int i = tid + u * 256; if (i < n) dst[i] = pf[u]; }
-            const int ny = (chunk_hi(ch) - lo) * 12;
-            if (tid < ny) ych[(ch & 1) * KC * 12 + tid] = pfy;
-        };
-        (void)PF;
-        issue(0); commit(0);
-        lds_barrier();
-        const int c = tid % 6, pt = tid / 6; // wave 0: pt 0..10, parts 8.. idle
-        const bool work = tid < 48;
-        for (int ch = 0; ch < nchunk; ch++) {
-            if (ch + 1 < nchunk) issue(ch + 1);
-            if (tid < 64) {
-                const int lo = chunk_lo(ch);
-                const double *Lb0 = W + (long)(ch & 1) * CB, *yb0 = ych + (ch & 1) * KC * 12;
-                for (int j = chunk_hi(ch) - 1; j >= lo; j--) {
-                    const int nd = (C - 1 - j) < Bc ? (C - 1 - j) : Bc;
-                    const double *Lc = Lb0 + (long)(j - lo) * CS, *yl = yb0 + (j - lo) * 12;
-                    double v = 0;
-                    for (int d = 1 + pt; work && d <= nd; d += 8) {
-                        const double *Ld = Lc + d * 36 + c, *xd = xw + ((j + d) % NS) * 6;
+        for (int u = 0; u < 36; u++) { const int i = tid + u * 256; if (i < n) dst[i] = pf[u]; }
+        const int ny = (chunk_hi(ch) - lo) * 12;
+        if (tid < ny) ych[(ch & 1) * KC * 12 + tid] = pfy;
+    };
+    if (nchunk > 0) { issue(0); commit(0); }
+    lds_barrier();
+    const int c = tid % 6, pt = tid / 6; // wave 0: pt 0..10, parts 8.. idle
+    const bool work = tid < 48;
+    for (int ch = 0; ch < nchunk; ch++) {
+        if (ch + 1 < nchunk) issue(ch + 1);
+        if (tid < 64) {
+            const int lo = chunk_lo(ch);
+            const double *Lb0 = W + (long)(ch & 1) * CB, *yb0 = ych + (ch & 1) * KC * 12;
+            for (int j = chunk_hi(ch) - 1; j >= lo; j--) {
+                const int nd = (V.n - 1 - j) < Bc ? (V.n - 1 - j) : Bc;
+                const double *Lc = Lb0 + (long)(j - lo) * CS, *yl = yb0 + (j - lo) * 12;
+                double v = 0;
+                for (int d = 1 + pt; work && d <= nd; d += 8) {
+                    const double *Ld = Lc + d * 36 + c, *xd = xw + ((j + d) % NS) * 6;
 #pragma unroll
-                        for (int q = 0; q < 6; q++) v = __builtin_fma(Ld[q * 6], xd[q], v);
-                    }
-                    v += __shfl_down(v, 24); v += __shfl_down(v, 12); v += __shfl_down(v, 6); // lanes 0..5: sum over the parts
-                    double lcol[6];
-#pragma unroll
-                    for (int r = 0; r < 6; r++) lcol[r] = Lc[r * 6 + c];
-                    const double inv = yl[6 + c];
-                    double sv = yl[c] - v, xv = 0;
-#pragma unroll
-                    for (int k = 5; k >= 0; k--) {
-                        const double xk = __shfl(sv * inv, k); // x_k, final because lanes > k already contributed
-                        if (tid == k) xv = xk;
-                        if (tid < k) sv = __builtin_fma(-lcol[k], xk, sv); // s_c -= L[k][c] x_k
-                    }
-                    if (tid < 6) { xw[(j % NS) * 6 + tid] = xv; rhs[(long)j * 6 + tid] = xv; }
-                    asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                    for (int q = 0; q < 6; q++) v = __builtin_fma(Ld[q * 6], xd[q], v);
                 }
+                v += __shfl_down(v, 24); v += __shfl_down(v, 12); v += __shfl_down(v, 6); // lanes 0..5: sum over the parts
+                double lcol[6];
+#pragma unroll
+                for (int r = 0; r < 6; r++) lcol[r] = Lc[r * 6 + c];
+                const double inv = yl[6 + c];
+                double sv = yl[c] - v, xv = 0;
+#pragma unroll
+                for (int k = 5; k >= 0; k--) {
+                    const double xk = __shfl(sv * inv, k); // x_k, final because lanes > k already contributed
+                    if (tid == k) xv = xk;
+                    if (tid < k) sv = __builtin_fma(-lcol[k], xk, sv); // s_c -= L[k][c] x_k
+                }
+                if (tid < 6) { xw[(j % NS) * 6 + tid] = xv; xout[(long)(V.rev ? V.C - 1 - j : j) * 6 + tid] = xv; }
+                asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
-            if (ch + 1 < nchunk) commit(ch + 1);
-            lds_barrier();
         }
+        if (ch + 1 < nchunk) commit(ch + 1);
+        lds_barrier();
     }
-    if (tid == 0 && fail) *status = 1;
+}
+
+// one workgroup, whole chain (short systems, or CUBESLAM_BA_SOLVER=band1).  rhs: in b (6C), out x; ybuf: 12C scratch
+__global__ void __launch_bounds__(256) ba_band_chol(int C, int Bc, const double *A, double *Lf, double *rhs, double *ybuf, int *status) {
+    extern __shared__ double sh[];
+    const BandLds S = band_lds(sh, Bc);
+    const BandView V{A, rhs, C, Bc, C, C, 0, 0};
+    const bool fail = band_factor(V, S, Lf, ybuf);
+    __syncthreads(); // every store to Lf / ybuf has completed
+    band_back(V, S, Lf, ybuf, nullptr, 0, rhs);
+    if (threadIdx.x == 0 && fail) *status = 1;
+}
+__device__ __forceinline__ BandView band_side(int side, int C, int Bc, const double *A, const double *rhs) { // side 0: columns [0, neF); side 1: the other end
+    const int R = Bc, neF = (C - R) / 2, neB = C - R - neF;
+    return side == 0 ? BandView{A, rhs, C, Bc, neF + R, neF, 0, 0} : BandView{A, rhs, C, Bc, neB + R, neB, 1, neF};
+}
+// mid: per side R columns of CS doubles (the updated tail columns, local order) followed by 6R right-hand-side entries
+__global__ void __launch_bounds__(256) ba_band_twist_factor(int C, int Bc, const double *A, const double *rhs, double *Lf, double *ybuf, double *mid, int *status) {
+    extern __shared__ double sh[];
+    const BandLds S = band_lds(sh, Bc);
+    const BandView V = band_side(blockIdx.x, C, Bc, A, rhs);
+    const bool fail = band_factor(V, S, Lf, ybuf);
+    const int NS = Bc + 2, CS = (Bc + 1) * 36, R = V.n - V.ne;
+    double *m = mid + (long)blockIdx.x * ((long)R * CS + R * 6);
+    for (int i = threadIdx.x; i < R * CS; i += 256) m[i] = S.W[(long)((V.ne + i / CS) % NS) * CS + i % CS];
+    for (int i = threadIdx.x; i < R * 6; i += 256) m[(long)R * CS + i] = S.bw[((V.ne + i / 6) % NS) * 6 + i % 6];
+    if (threadIdx.x == 0 && fail) *status = 1;
+}
+// middle group: M = tail(forward) + reversed tail(backward), dense Cholesky in LDS (N = 6R <= 120), two triangular solves.  xm: 6R
+__global__ void __launch_bounds__(256) ba_band_mid(int C, int Bc, const double *mid, double *xm, double *xout, int *status) {
+    extern __shared__ double sh[];
+    const int R = Bc, N = 6 * R, CS = (Bc + 1) * 36, tid = threadIdx.x;
+    double *M = sh, *bv = M + (long)N * N;
+    const double *m0 = mid, *m1 = mid + ((long)R * CS + R * 6);
+    for (int i = tid; i < N * N; i += 256) M[i] = 0;
+    __syncthreads();
+    for (int i = tid; i < R * R * 36; i += 256) { // forward side: block (t+d, t) as stored
+        const int t = i / (R * 36), d = (i / 36) % R, e = i % 36, r = e / 6, c = e % 6;
+        if (t + d < R) M[(long)((t + d) * 6 + r) * N + t * 6 + c] = m0[(long)t * CS + d * 36 + e];
+    }
+    __syncthreads();
+    for (int i = tid; i < R * R * 36; i += 256) { // backward side: its block (t+d, t) is the transposed original block (R-1-t, R-1-t-d)
+        const int t = i / (R * 36), d = (i / 36) % R, e = i % 36, r = e / 6, c = e % 6;
+        if (t + d < R) { const int bb = R - 1 - t, aa = bb - d; M[(long)(bb * 6 + c) * N + aa * 6 + r] += m1[(long)t * CS + d * 36 + e]; }
+    }
+    for (int i = tid; i < N; i += 256) bv[i] = m0[(long)R * CS + i] + m1[(long)R * CS + (R - 1 - i / 6) * 6 + i % 6];
+    __syncthreads();
+    __shared__ int s_fail;
+    if (tid == 0) s_fail = 0;
+    for (int k = 0; k < N; k++) { // right-looking Cholesky, lower triangle
+        if (tid == 0) { double d = M[(long)k * N + k]; if (!(d > 0)) { s_fail = 1; d = 1; } M[(long)k * N + k] = sqrt(d); }
+        __syncthreads();
+        const double dk = M[(long)k * N + k];
+        for (int i = k + 1 + tid; i < N; i += 256) M[(long)i * N + k] /= dk;
+        __syncthreads();
+        const int m = N - 1 - k; // trailing rows k+1..N-1: element (i, j), j <= i
+        for (int e = tid; e < m * m; e += 256) { const int i = k + 1 + e / m, j = k + 1 + e % m; if (j <= i) M[(long)i * N + j] = __builtin_fma(-M[(long)i * N + k], M[(long)j * N + k], M[(long)i * N + j]); }
+        __syncthreads();
+    }
+    for (int k = 0; k < N; k++) { // L y = b
+        if (tid == 0) bv[k] /= M[(long)k * N + k];
+        __syncthreads();
+        const double yk = bv[k];
+        for (int i = k + 1 + tid; i < N; i += 256) bv[i] = __builtin_fma(-M[(long)i * N + k], yk, bv[i]);
+        __syncthreads();
+    }
+    for (int k = N - 1; k >= 0; k--) { // L^T x = y
+        if (tid == 0) bv[k] /= M[(long)k * N + k];
+        __syncthreads();
+        const double xk = bv[k];
+        for (int i = tid; i < k; i += 256) bv[i] = __builtin_fma(-M[(long)k * N + i], xk, bv[i]);
+        __syncthreads();
+    }
+    const int neF = (C - R) / 2;
+    for (int i = tid; i < N; i += 256) { xm[i] = bv[i]; xout[(long)neF * 6 + i] = bv[i]; }
+    if (tid == 0 && s_fail) *status = 1;
+}
+__global__ void __launch_bounds__(256) ba_band_twist_back(int C, int Bc, const double *Lf, const double *ybuf, const double *xm, double *xout) {
+    extern __shared__ double sh[];
+    const BandLds S = band_lds(sh, Bc);
+    const BandView V = band_side(blockIdx.x, C, Bc, nullptr, nullptr);
+    band_back(V, S, Lf, ybuf, xm, blockIdx.x, xout);
 }
 
 // scatter the (all-reduced) blocks of the reduced system into the factor storage Lb = [P diagonal blocks | off-diagonal
@@ -1166,10 +1286,10 @@ struct cs_ba {
     double *d_bak_cam = nullptr, *d_bak_pts = nullptr, *d_bak_cub = nullptr;
     long reduce_len = 0, band_len = 0; // band_len: doubles of the factor storage
     // band path (see ba_band_chol): cuboids eliminated first, cameras block-banded with half-width band_bc
-    bool use_band = false; int band_C = 0, band_Q = 0, band_bc = 0, band_targets = 0;
+    bool use_band = false, band_twist = false; int band_C = 0, band_Q = 0, band_bc = 0, band_targets = 0;
     int *d_tgt_slot = nullptr, *d_ct_off = nullptr, *d_ct_list = nullptr, *d_cr_off = nullptr, *d_cr_list = nullptr, *d_cq_off = nullptr, *d_cq_list = nullptr;
     uint8_t *d_tgt_tr = nullptr;
-    double *d_bandA = nullptr, *d_bandL = nullptr, *d_cubD = nullptr, *d_cubg = nullptr, *d_brhs = nullptr, *d_ybuf = nullptr;
+    double *d_bandA = nullptr, *d_bandL = nullptr, *d_cubD = nullptr, *d_cubg = nullptr, *d_brhs = nullptr, *d_ybuf = nullptr, *d_mid = nullptr, *d_xmid = nullptr;
     std::vector<int> h_slot_dst, h_pos, h_col_off, h_rows; std::vector<uint8_t> h_slot_tr;
     std::vector<int> obs_perm; // sorted-by-landmark position -> caller's observation index
     std::vector<double> h_partials;
@@ -1252,9 +1372,21 @@ static int ba_solve(cs_ctx *ctx, cs_ba *b, double lambda, bool *ok) { // BlockSo
         CS_LAUNCH(ctx, "ba_band_assemble", ba_band_assemble, dim3((b->band_targets * 36 + 255) / 256), dim3(256), 0, b->band_targets, b->d_tgt_slot, b->d_tgt_tr, b->d_ct_off,
                   b->d_ct_list, S, b->d_cubD, b->d_bandA);
         CS_LAUNCH(ctx, "ba_band_rhs", ba_band_rhs, dim3((C * 6 + 255) / 256), dim3(256), 0, C, b->d_cr_off, b->d_cr_list, S, bs, b->d_cubg, b->d_brhs);
-        const size_t lds = sizeof(double) * ((size_t)(Bc + 2) * (Bc + 1) * 36 + (size_t)(Bc + 2) * 6 + 6 + 6 + 48) + sizeof(int) * (size_t)std::max(1, Bc * (Bc + 1) / 2);
-        if (lds > 64 * 1024) CS_HIP(ctx, hipFuncSetAttribute((const void *)ba_band_chol, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-        CS_LAUNCH(ctx, "ba_band_chol", ba_band_chol, dim3(1), dim3(256), lds, C, Bc, b->d_bandA, b->d_bandL, b->d_brhs, b->d_ybuf, b->d_status);
+        const size_t lds = band_lds_bytes(Bc);
+        if (b->band_twist) { // both ends at once (see the comment above band_factor)
+            const size_t lds_mid = sizeof(double) * ((size_t)36 * Bc * Bc + 6 * (size_t)Bc);
+            if (lds > 64 * 1024) {
+                CS_HIP(ctx, hipFuncSetAttribute((const void *)ba_band_twist_factor, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+                CS_HIP(ctx, hipFuncSetAttribute((const void *)ba_band_twist_back, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            }
+            if (lds_mid > 64 * 1024) CS_HIP(ctx, hipFuncSetAttribute((const void *)ba_band_mid, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mid));
+            CS_LAUNCH(ctx, "ba_band_twist_factor", ba_band_twist_factor, dim3(2), dim3(256), lds, C, Bc, b->d_bandA, b->d_brhs, b->d_bandL, b->d_ybuf, b->d_mid, b->d_status);
+            CS_LAUNCH(ctx, "ba_band_mid", ba_band_mid, dim3(1), dim3(256), lds_mid, C, Bc, b->d_mid, b->d_xmid, b->d_brhs, b->d_status);
+            CS_LAUNCH(ctx, "ba_band_twist_back", ba_band_twist_back, dim3(2), dim3(256), lds, C, Bc, b->d_bandL, b->d_ybuf, b->d_xmid, b->d_brhs);
+        } else {
+            if (lds > 64 * 1024) CS_HIP(ctx, hipFuncSetAttribute((const void *)ba_band_chol, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
+            CS_LAUNCH(ctx, "ba_band_chol", ba_band_chol, dim3(1), dim3(256), lds, C, Bc, b->d_bandA, b->d_bandL, b->d_brhs, b->d_ybuf, b->d_status);
+        }
         CS_HIP(ctx, hipMemcpyAsync(G.x, b->d_brhs, sizeof(double) * (size_t)C * 6, hipMemcpyDeviceToDevice, ctx->stream));
         if (Q > 0) CS_LAUNCH(ctx, "ba_cub_back", ba_cub_back, dim3((Q + 63) / 64), dim3(64), 0, C, Q, b->d_cq_off, b->d_cq_list, S, b->d_cubD, b->d_cubg, G.x);
         if (nl > 0) CS_LAUNCH(ctx, "ba_backsub", ba_backsub, dim3((nl + 255) / 256), dim3(256), 0, G);
@@ -1395,13 +1527,14 @@ int cs_ba_create(cs_ctx *ctx, const cs_ba_problem *p, int rank, int world, cs_ba
         std::vector<std::vector<std::pair<int, int>>> cub_edges(Q); // (camera, slot), alive edges only
         for (int o = 0; o < p->n_cobs; o++) { const int pi = cam_idx[p->cobs_cam[o]]; if (pi >= 0) cub_edges[p->cobs_cuboid[o]].push_back(std::make_pair(pi, P + o)); }
         for (auto &e : cub_edges) { std::stable_sort(e.begin(), e.end()); if (!e.empty()) Bc = std::max(Bc, e.back().first - e.front().first); }
-        const char *force = getenv("CUBESLAM_BA_SOLVER"); // "sparse" / "band": pick the path (tests run both)
+        const char *force = getenv("CUBESLAM_BA_SOLVER"); // "sparse" / "band" / "band1" (band, one workgroup): pick the path (tests run all)
         const int BAND_MAX = 20; // (Bc+2)(Bc+1) blocks of 288 B must fit the 160 KB LDS
         if (force && !strcmp(force, "sparse")) okb = false;
         if (Bc > BAND_MAX) okb = false;
-        if (force && !strcmp(force, "band") && !okb) { ctx->err = "CUBESLAM_BA_SOLVER=band: the reduced camera system is not narrow-banded"; delete b; return CS_ERR_CAPACITY; }
+        if (force && (!strcmp(force, "band") || !strcmp(force, "band1")) && !okb) { ctx->err = "CUBESLAM_BA_SOLVER=band: the reduced camera system is not narrow-banded"; delete b; return CS_ERR_CAPACITY; }
         if (okb) {
             b->use_band = true; b->band_C = C; b->band_Q = Q; b->band_bc = Bc; b->band_targets = C * (Bc + 1);
+            b->band_twist = Bc >= 1 && C >= 6 * (Bc + 1) && !(force && !strcmp(force, "band1")); // two-sided elimination once the chain is long enough to split
             tgt_slot.assign((size_t)C * (Bc + 1), -1); tgt_tr.assign((size_t)C * (Bc + 1), 0);
             for (int s2 = 0; s2 < (int)slot_rc.size(); s2++) {
                 const int r0 = slot_rc[s2].first, c0 = slot_rc[s2].second;
@@ -1578,6 +1711,8 @@ int cs_ba_create(cs_ctx *ctx, const cs_ba_problem *p, int rank, int world, cs_ba
         A_(dalloc_copy(ctx, b, &b->d_cubg, (const double *)nullptr, (size_t)std::max(b->band_Q, 1) * 6));
         A_(dalloc_copy(ctx, b, &b->d_brhs, (const double *)nullptr, (size_t)b->band_C * 6));
         A_(dalloc_copy(ctx, b, &b->d_ybuf, (const double *)nullptr, (size_t)b->band_C * 12));
+        A_(dalloc_copy(ctx, b, &b->d_mid, (const double *)nullptr, 2 * ((size_t)b->band_bc * (b->band_bc + 1) * 36 + (size_t)b->band_bc * 6) + 8));
+        A_(dalloc_copy(ctx, b, &b->d_xmid, (const double *)nullptr, (size_t)b->band_bc * 6 + 8));
     }
     A_(dalloc_copy(ctx, b, &b->d_reduce, (const double *)nullptr, (size_t)b->reduce_len));
     A_(dalloc_copy(ctx, b, &b->d_band, (const double *)nullptr, (size_t)b->band_len));
