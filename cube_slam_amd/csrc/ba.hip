@@ -591,11 +591,16 @@ __device__ __forceinline__ double band_b(const BandView &V, int cn, int t) {
     if (!V.rev) return V.rhs[(long)cn * 6 + t];
     return cn < V.ne ? V.rhs[(long)(V.C - 1 - cn) * 6 + t] : 0.0;
 }
+// value of lane - n (DPP row_shr:n inside each row of 16 lanes; 0.0 where the row has no such lane)
+template <int CTRL> __device__ __forceinline__ double dpp_f64(double v) {
+    const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false), hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
 struct BandLds { double *W, *bw, *yj, *Linv, *part; int *pair_d; };
 __device__ __forceinline__ BandLds band_lds(double *sh, int Bc) {
     const int NB = Bc + 1, NS = Bc + 2, CS = NB * 36;
     BandLds L;
-    L.W = sh; L.bw = L.W + (long)NS * CS; L.yj = L.bw + NS * 6; L.Linv = L.yj + 6; L.part = L.Linv + 6; // part: 8 x 6 partial sums (back substitution)
+    L.W = sh; L.bw = L.W + (long)NS * CS; L.yj = L.bw + NS * 6; L.Linv = L.yj + 6; L.part = L.Linv + 6; // part: 48 doubles; the factor of the current diagonal block (36)
     L.pair_d = (int *)(L.part + 48); // pair -> (di << 8 | dk)
     return L;
 }
@@ -604,82 +609,194 @@ static size_t band_lds_bytes(int Bc) { return sizeof(double) * ((size_t)(Bc + 2)
 // Eliminates local columns 0..ne-1 (L to Lf, y_j and 1/diag to ybuf), forward solve fused.  LDS: a ring of Bc+2 columns (the extra
 // slot receives column j+Bc+1 while column j is processed) and the matching right-hand-side window.  On return the window holds
 // the updated tail columns ne..n-1.
-__device__ __forceinline__ bool band_factor(const BandView &V, const BandLds &S, double *Lf, double *ybuf) {
+typedef double band_v4d __attribute__((ext_vector_type(4)));
+template <int NT> __device__ __forceinline__ bool band_factor(const BandView &V, const BandLds &S, double *Lf, double *ybuf) {
     const int Bc = V.Bc, NB = Bc + 1, NS = Bc + 2, CS = NB * 36;
     double *W = S.W, *bw = S.bw, *yj = S.yj, *Linv = S.Linv;
     int *pair_d = S.pair_d;
-    const int tid = threadIdx.x;
-    for (int pr = tid; pr < Bc * (Bc + 1) / 2; pr += 256) {
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    for (int pr = tid; pr < Bc * (Bc + 1) / 2; pr += NT) {
         int di = (int)((sqrt(8.0 * pr + 1.0) - 1.0) * 0.5);
         while (di * (di + 1) / 2 > pr) di--;
         while ((di + 1) * (di + 2) / 2 <= pr) di++;
         pair_d[pr] = ((di + 1) << 8) | (pr - di * (di + 1) / 2 + 1);
     }
     const int n0 = V.n < NB ? V.n : NB;
-    for (int i = tid; i < n0 * CS; i += 256) W[i] = band_a(V, i / CS, i % CS); // columns 0..n0-1 sit in slots 0..n0-1
-    for (int i = tid; i < n0 * 6; i += 256) bw[i] = band_b(V, i / 6, i % 6);
+    for (int i = tid; i < n0 * CS; i += NT) W[i] = band_a(V, i / CS, i % CS); // columns 0..n0-1 sit in slots 0..n0-1
+    for (int i = tid; i < n0 * 6; i += NT) bw[i] = band_b(V, i / 6, i % 6);
+    // prefetch addressing of this thread's (up to four) elements of a column, hoisted out of the chain: element i of local column cn
+    // lives at pk[u] + cn * cstep and exists while cn < plim[u]
+    long pk[4]; int plim[4];
+    const long cstep = V.rev ? -(long)CS : (long)CS;
+#pragma unroll
+    for (int u = 0; u < 4; u++) {
+        const int i = tid + u * NT, d = i / 36, e = i - d * 36, r = e / 6, c = e - r * 6;
+        plim[u] = i < CS ? (V.rev ? min(V.n - d, V.ne) : V.n - d) : 0;
+        pk[u] = V.rev ? (long)(V.C - 1 - d) * CS + d * 36 + c * 6 + r : (long)i;
+    }
+    // trailing update on the matrix cores (Bc <= 10): T -= P P^T with P = the nd*6 x 6 panel, as 16x16 tiles of v_mfma_f64_16x16x4_f64
+    // (lower tiles only, K = 6 padded to 8).  Every wave owns up to two tiles; where its operands and results live inside a column
+    // of the window does not depend on the column, so it is worked out once: offsets inside the column for the two A and two B
+    // operand values, and for the four results (block distance dk of the target column, offset inside it, first panel block di that
+    // must exist).  C/D layout of the f64 MFMA: col = lane & 15, row = (lane >> 4) + 4 * reg.
+    const bool use_mfma = Bc <= 10;
+    int ta_off[2], tb_off[2], ta_di[2], tb_di[2], t_dk[2][4], t_in[2][4], t_di[2][4];
+    const int k0 = lane >> 4;
+#pragma unroll
+    for (int q = 0; q < 2; q++) {
+        const int tl = wave + q * (NT / 64);
+        int ti = 0;
+        while ((ti + 1) * (ti + 2) / 2 <= tl) ti++;
+        const int tj = tl - ti * (ti + 1) / 2;
+        const bool on = use_mfma && tl < 10;
+        const int arow = ti * 16 + (lane & 15), bcol = tj * 16 + (lane & 15);
+        ta_off[q] = (1 + arow / 6) * 36 + (arow % 6) * 6 + k0; ta_di[q] = on ? arow / 6 + 1 : 99;
+        tb_off[q] = (1 + bcol / 6) * 36 + (bcol % 6) * 6 + k0; tb_di[q] = on ? bcol / 6 + 1 : 99;
+#pragma unroll
+        for (int g = 0; g < 4; g++) {
+            const int row = ti * 16 + k0 + 4 * g, col = bcol, di = row / 6 + 1, dk = col / 6 + 1;
+            t_dk[q][g] = dk * CS; t_in[q][g] = (di - dk) * 36 + (row % 6) * 6 + col % 6; // slot distance in doubles, offset inside the column
+            t_di[q][g] = (on && col <= row) ? di : 99; // needs panel block di (and dk <= di)
+        }
+    }
+    const int NSCS = NS * CS;
+    const int p_off = (1 + lane / 6) * 36 + (lane % 6) * 6, p_dd = 1 + lane / 6, p_r = lane % 6; // panel row / right-hand-side row of this lane (wave-local index)
     __syncthreads();
+#ifdef BAND_PROF
+    unsigned long long pt_[8] = {0, 0, 0, 0, 0, 0, 0, 0}, p0_ = 0, p1_;
+#define BP(k) do { p1_ = __builtin_readcyclecounter(); pt_[k] += p1_ - p0_; p0_ = p1_; } while (0)
+    p0_ = __builtin_readcyclecounter();
+#else
+#define BP(k) do { } while (0)
+#endif
     bool fail = false;
+    int sj = 0, sjcs = 0; // j % NS, and times CS
     for (int j = 0; j < V.ne; j++) {
-        double *Wc = W + (long)(j % NS) * CS;
+        double *Wc = W + (long)sj * CS;
         const int nd = (V.n - 1 - j) < Bc ? (V.n - 1 - j) : Bc;
-        const int cn = j + Bc + 1;
+        const int cn = j + Bc + 1, scn = sj == 0 ? NS - 1 : sj - 1; // slot of column cn = (j + NS - 1) % NS
         // next column: loads issued now, stored to the free LDS slot at the end of the step (global latency off the critical path)
         double pf[4] = {0, 0, 0, 0}, pfb = 0;
         if (cn < V.n) {
 #pragma unroll
-            for (int u = 0; u < 4; u++) if (tid + u * 256 < CS) pf[u] = band_a(V, cn, tid + u * 256);
+            for (int u = 0; u < 4; u++) if (cn < plim[u]) pf[u] = V.A[pk[u] + cn * cstep];
             if (tid < 6) pfb = band_b(V, cn, tid);
         }
-        if (tid < 64) { // L_jj and y_j = L_jj^-1 b_j by lanes 0..5 of wave 0 (lane r = row r); 1/sqrt(pivot) from v_rsq_f64 + two Newton steps
-            const int r = tid < 6 ? tid : 0;
-            double m[6], l[6], invs[6], yv[6];
+        // L_jj = chol(A_jj), its inverse and y_j = L_jj^-1 b_j: every lane of WAVE 0 computes them in its own registers from LDS
+        // broadcasts (six v_rsq_f64 + two Newton steps, ~150 fused multiply-adds) and goes straight on to its panel rows, which
+        // with the explicit inverse are independent dot products instead of a 16-deep dependent chain -- no cross-lane traffic and no
+        // barrier between the pivot and the panel (a shuffle-based version on six lanes cost 0.86 us per column).  The other waves wait.
+        BP(0);
+        if (tid < 64) {
+            double Lr[6][6], Mi[6][6], invs[6], yv[6];
 #pragma unroll
-            for (int t = 0; t < 6; t++) { m[t] = Wc[r * 6 + t]; l[t] = 0; }
-            const double br = bw[(j % NS) * 6 + r];
+            for (int r = 0; r < 6; r++)
+#pragma unroll
+                for (int c = 0; c <= r; c++) Lr[r][c] = Wc[r * 6 + c];
 #pragma unroll
             for (int c = 0; c < 6; c++) {
-                double dsum = m[c], v = m[c];
+                double d = Lr[c][c];
 #pragma unroll
-                for (int t = 0; t < c; t++) { const double lct = __shfl(l[t], c); dsum = __builtin_fma(-l[t], l[t], dsum); v = __builtin_fma(-l[t], lct, v); }
-                double d = __shfl(dsum, c);
+                for (int t = 0; t < c; t++) d = __builtin_fma(-Lr[c][t], Lr[c][t], d);
                 if (!(d > 0)) { fail = true; d = 1; }
                 double inv = __builtin_amdgcn_rsq(d);
                 inv = inv * (1.5 - (0.5 * d) * (inv * inv));
                 inv = inv * (1.5 - (0.5 * d) * (inv * inv));
-                l[c] = r == c ? d * inv : (r > c ? v * inv : 0.0);
                 invs[c] = inv;
+                Lr[c][c] = d * inv;
+#pragma unroll
+                for (int r = c + 1; r < 6; r++) {
+                    double v = Lr[r][c];
+#pragma unroll
+                    for (int t = 0; t < c; t++) v = __builtin_fma(-Lr[r][t], Lr[c][t], v);
+                    Lr[r][c] = v * inv;
+                }
             }
 #pragma unroll
-            for (int t = 0; t < 6; t++) { // y_t = (b_t - sum_{u<t} L[t][u] y_u) / L[t][t], computed by lane t, broadcast
-                double sacc = br;
+            for (int c = 0; c < 6; c++) { // Mi = L_jj^-1 (lower triangular), column by column
+                Mi[c][c] = invs[c];
 #pragma unroll
-                for (int u = 0; u < t; u++) sacc = __builtin_fma(-l[u], yv[u], sacc);
-                yv[t] = __shfl(sacc * invs[t], t);
+                for (int r = c + 1; r < 6; r++) {
+                    double v = 0;
+#pragma unroll
+                    for (int t = c; t < r; t++) v = __builtin_fma(Lr[r][t], Mi[t][c], v);
+                    Mi[r][c] = -invs[r] * v;
+                }
             }
-            if (tid < 6) {
 #pragma unroll
-                for (int t = 0; t < 6; t++) Wc[r * 6 + t] = l[t];
-                Linv[r] = invs[r]; yj[r] = yv[r];
+            for (int t = 0; t < 6; t++) { // y = L_jj^-1 b
+                double sacc = 0;
+#pragma unroll
+                for (int u = 0; u <= t; u++) sacc = __builtin_fma(Mi[t][u], bw[sj * 6 + u], sacc);
+                yv[t] = sacc;
+            }
+            BP(1);
+            for (int t = tid; t < nd * 6; t += 64) { // L_d = A_d L_jj^-T = A_d Mi^T, one block row per lane
+                double *blk = Wc + (t == tid ? p_off : (1 + t / 6) * 36 + (t % 6) * 6);
+                double a[6], row[6];
+#pragma unroll
+                for (int c = 0; c < 6; c++) a[c] = blk[c];
+#pragma unroll
+                for (int c = 0; c < 6; c++) {
+                    double v = 0;
+#pragma unroll
+                    for (int q = 0; q <= c; q++) v = __builtin_fma(a[q], Mi[c][q], v);
+                    row[c] = v;
+                }
+#pragma unroll
+                for (int c = 0; c < 6; c++) blk[c] = row[c];
+            }
+            if (tid == 0) { // published next to the window (not over A_jj, which slower lanes may still be reading)
+#pragma unroll
+                for (int r = 0; r < 6; r++) {
+#pragma unroll
+                    for (int c = 0; c < 6; c++) S.part[r * 6 + c] = c <= r ? Lr[r][c] : 0.0;
+                    Linv[r] = invs[r]; yj[r] = yv[r];
+                }
             }
         }
+        BP(2);
         lds_barrier();
-        for (int t = tid; t < nd * 6; t += 256) { // L_d = A_d L_jj^-T, one block row per thread
-            double *blk = Wc + (1 + t / 6) * 36 + (t % 6) * 6;
-            double row[6];
-            for (int c = 0; c < 6; c++) { double v = blk[c]; for (int q = 0; q < c; q++) v -= row[q] * Wc[c * 6 + q]; row[c] = v * Linv[c]; }
-            for (int c = 0; c < 6; c++) blk[c] = row[c];
-        }
-        lds_barrier();
+        BP(3);
+        if (use_mfma) {
+#pragma unroll
+            for (int q = 0; q < 2; q++) {
+                if (ta_di[q] > 20) continue; // this wave has no such tile (uniform over the wave)
+                double a0 = 0, a1 = 0, b0 = 0, b1 = 0;
+                if (ta_di[q] <= nd) { a0 = -Wc[ta_off[q]]; if (k0 < 2) a1 = -Wc[ta_off[q] + 4]; } // K = 6: k0, k0 + 4 < 6
+                if (tb_di[q] <= nd) { b0 = Wc[tb_off[q]]; if (k0 < 2) b1 = Wc[tb_off[q] + 4]; }
+                band_v4d acc;
+                double *tp[4];
+#pragma unroll
+                for (int g = 0; g < 4; g++) {
+                    const unsigned x = (unsigned)(sjcs + t_dk[q][g]);
+                    tp[g] = W + (int)(min(x, x - (unsigned)NSCS) + (unsigned)t_in[q][g]); // ((sj + dk) mod NS) * CS + offset, no multiply
+                    acc[g] = t_di[q][g] <= nd ? *tp[g] : 0.0;
+                }
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a0, b0, acc, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f64_16x16x4f64(a1, b1, acc, 0, 0, 0);
+#pragma unroll
+                for (int g = 0; g < 4; g++) if (t_di[q][g] <= nd) *tp[g] = acc[g];
+            }
+            if (wave == NT / 64 - 1 && lane < nd * 6) { // b_{j+d} -= L_d y_j
+                const double *Ld = Wc + p_off;
+                double v = 0;
+#pragma unroll
+                for (int q = 0; q < 6; q++) v += Ld[q] * yj[q];
+                int sl = sj + p_dd; if (sl >= NS) sl -= NS;
+                bw[sl * 6 + p_r] -= v;
+            }
+        } else {
         const int npair = nd * (nd + 1) / 2;
-        for (int t = tid; t < npair * 6 + nd * 6; t += 256) {
+        for (int t = tid; t < npair * 6 + nd * 6; t += NT) {
             if (t < npair * 6) { // row r of block (j+di, j+dk) -= (row r of L_di) L_dk^T: the row of L_di stays in registers
                 const int pr = t / 6, r = t % 6, di = pair_d[pr] >> 8, dk = pair_d[pr] & 255;
                 const double *Li = Wc + di * 36 + r * 6, *Lk = Wc + dk * 36;
                 double a[6];
 #pragma unroll
                 for (int q = 0; q < 6; q++) a[q] = Li[q];
-                double *T = W + (long)((j + dk) % NS) * CS + (di - dk) * 36 + r * 6;
+                int sl = sj + dk; if (sl >= NS) sl -= NS;
+                double *T = W + (long)sl * CS + (di - dk) * 36 + r * 6;
                 double tv[6];
 #pragma unroll
                 for (int c = 0; c < 6; c++) tv[c] = T[c];
@@ -696,19 +813,30 @@ __device__ __forceinline__ bool band_factor(const BandView &V, const BandLds &S,
                 double v = 0;
 #pragma unroll
                 for (int q = 0; q < 6; q++) v += Ld[q] * yj[q];
-                bw[((j + d) % NS) * 6 + r] -= v;
+                int sl = sj + d; if (sl >= NS) sl -= NS;
+                bw[sl * 6 + r] -= v;
             }
         }
-        for (int i = tid; i < (nd + 1) * 36; i += 256) Lf[(long)(V.lf_base + j) * CS + i] = Wc[i];
-        if (tid < 12) ybuf[(long)(V.lf_base + j) * 12 + tid] = tid < 6 ? yj[tid] : Linv[tid - 6]; // a buffer this kernel has not read before: no stale L1 line possible
-        if (cn < V.n) {
-            double *dst = W + (long)(cn % NS) * CS;
-#pragma unroll
-            for (int u = 0; u < 4; u++) if (tid + u * 256 < CS) dst[tid + u * 256] = pf[u];
-            if (tid < 6) bw[(cn % NS) * 6 + tid] = pfb;
         }
+        BP(6);
+        for (int i = tid; i < (nd + 1) * 36; i += NT) Lf[(long)(V.lf_base + j) * CS + i] = i < 36 ? S.part[i] : Wc[i];
+        if (tid < 12) ybuf[(long)(V.lf_base + j) * 12 + tid] = tid < 6 ? yj[tid] : Linv[tid - 6]; // a buffer this kernel has not read before: no stale L1 line possible
+        BP(7);
+        if (cn < V.n) {
+            double *dst = W + (long)scn * CS;
+#pragma unroll
+            for (int u = 0; u < 4; u++) if (tid + u * NT < CS) dst[tid + u * NT] = pf[u];
+            if (tid < 6) bw[scn * 6 + tid] = pfb;
+        }
+        BP(4);
         lds_barrier();
+        BP(5);
+        if (++sj == NS) sj = 0;
+        sjcs = sj * CS;
     }
+#ifdef BAND_PROF
+    if (tid == 0) printf("band_factor side %d cols %d cycles: top %llu pivot %llu panel %llu bar1 %llu mfma %llu store %llu commit %llu bar2 %llu\n", V.rev, V.ne, pt_[0], pt_[1], pt_[2], pt_[3], pt_[6], pt_[7], pt_[4], pt_[5]);
+#endif
     return fail;
 }
 
@@ -717,23 +845,24 @@ __device__ __forceinline__ bool band_factor(const BandView &V, const BandLds &S,
 // k+1 into registers while chunk k is used, one barrier per chunk); inside a chunk wave 0 works alone, without barriers: lane =
 // part * 6 + c sums L_d^T x_{j+d} over the blocks d = 1 + part, 9 + part, 17 + part, shuffles reduce the 8 parts, lanes 0..5
 // finish with L_jj^T by lane broadcasts.  Solved blocks: LDS ring xw; xout in original order.
-__device__ __forceinline__ void band_back(const BandView &V, const BandLds &S, const double *Lf, const double *ybuf, const double *xtail, int xtail_rev, double *xout) {
+template <int NT> __device__ __forceinline__ void band_back(const BandView &V, const BandLds &S, const double *Lf, const double *ybuf, const double *xtail, int xtail_rev, double *xout) {
     const int Bc = V.Bc, NB = Bc + 1, NS = Bc + 2, CS = NB * 36, C = V.ne;
     double *W = S.W;
     const int tid = threadIdx.x;
     double *xw = S.bw;
     const int R = V.n - V.ne;
-    for (int i = tid; i < R * 6; i += 256) { const int t = i / 6; xw[((V.ne + t) % NS) * 6 + i % 6] = xtail[(long)(xtail_rev ? R - 1 - t : t) * 6 + i % 6]; }
+    for (int i = tid; i < R * 6; i += NT) { const int t = i / 6; xw[((V.ne + t) % NS) * 6 + i % 6] = xtail[(long)(xtail_rev ? R - 1 - t : t) * 6 + i % 6]; }
     const int KC = (NS - 1) / 2, CB = KC * CS;           // chunk: KC columns of CS doubles; buffers W[0..CB) and W[CB..2CB), >= CS doubles left for ych
     double *ych = W + 2 * (long)CB;                      // 2 x KC x 12 (y_j, 1/diag) -- fits: NS*CS >= 2*CB + 24*KC for Bc >= 1
     const int nchunk = (C + KC - 1) / KC;
     auto chunk_lo = [&](int ch) { return C - (ch + 1) * KC < 0 ? 0 : C - (ch + 1) * KC; }; // chunk ch covers columns [lo, hi)
     auto chunk_hi = [&](int ch) { return C - ch * KC; };
-    double pf[36], pfy = 0; // doubles per thread per chunk: Bc <= 20 -> CB <= 8316 -> 33 per thread (checked by the host)
+    constexpr int UPF = (9216 + NT - 1) / NT; // doubles per thread per chunk: Bc <= 20 -> CB <= 8316 (checked by the host)
+    double pf[UPF], pfy = 0;
     auto issue = [&](int ch) {
         const int lo = chunk_lo(ch), n = (chunk_hi(ch) - lo) * CS;
 #pragma unroll
-        for (int u = 0; u < 36; u++) { const int i = tid + u * 256; pf[u] = i < n ? __builtin_nontemporal_load(Lf + (long)(V.lf_base + lo) * CS + i) : 0.0; }
+        for (int u = 0; u < UPF; u++) { const int i = tid + u * NT; pf[u] = i < n ? __builtin_nontemporal_load(Lf + (long)(V.lf_base + lo) * CS + i) : 0.0; }
         const int ny = (chunk_hi(ch) - lo) * 12;
         pfy = tid < ny ? __builtin_nontemporal_load(ybuf + (long)(V.lf_base + lo) * 12 + tid) : 0.0;
     };
@@ -741,14 +870,14 @@ __device__ __forceinline__ void band_back(const BandView &V, const BandLds &S, c
         const int lo = chunk_lo(ch), n = (chunk_hi(ch) - lo) * CS;
         double *dst = W + (long)(ch & 1) * CB;
 #pragma unroll
-        for (int u = 0; u < 36; u++) { const int i = tid + u * 256; if (i < n) dst[i] = pf[u]; }
+        for (int u = 0; u < UPF; u++) { const int i = tid + u * NT; if (i < n) dst[i] = pf[u]; }
         const int ny = (chunk_hi(ch) - lo) * 12;
         if (tid < ny) ych[(ch & 1) * KC * 12 + tid] = pfy;
     };
     if (nchunk > 0) { issue(0); commit(0); }
     lds_barrier();
-    const int c = tid % 6, pt = tid / 6; // wave 0: pt 0..10, parts 8.. idle
-    const bool work = tid < 48;
+    const int c = (tid >> 3) < 6 ? (tid >> 3) : 0, pt = tid & 7; // wave 0: lane = c * 8 + part, lanes 48..63 idle
+    const bool work = tid < 48, last = work && pt == 7;           // lane c*8+7 ends up with the sum over the 8 parts
     for (int ch = 0; ch < nchunk; ch++) {
         if (ch + 1 < nchunk) issue(ch + 1);
         if (tid < 64) {
@@ -763,7 +892,8 @@ __device__ __forceinline__ void band_back(const BandView &V, const BandLds &S, c
 #pragma unroll
                     for (int q = 0; q < 6; q++) v = __builtin_fma(Ld[q * 6], xd[q], v);
                 }
-                v += __shfl_down(v, 24); v += __shfl_down(v, 12); v += __shfl_down(v, 6); // lanes 0..5: sum over the parts
+                // sum over the 8 parts inside each group of 8 lanes: DPP row shifts (register moves), not ds_bpermute round trips
+                v += dpp_f64<0x114>(v); v += dpp_f64<0x112>(v); v += dpp_f64<0x111>(v);
                 double lcol[6];
 #pragma unroll
                 for (int r = 0; r < 6; r++) lcol[r] = Lc[r * 6 + c];
@@ -771,11 +901,11 @@ __device__ __forceinline__ void band_back(const BandView &V, const BandLds &S, c
                 double sv = yl[c] - v, xv = 0;
 #pragma unroll
                 for (int k = 5; k >= 0; k--) {
-                    const double xk = __shfl(sv * inv, k); // x_k, final because lanes > k already contributed
-                    if (tid == k) xv = xk;
-                    if (tid < k) sv = __builtin_fma(-lcol[k], xk, sv); // s_c -= L[k][c] x_k
+                    const double xk = __shfl(sv * inv, k * 8 + 7); // x_k, final because the lanes of columns > k already contributed
+                    if (c == k) xv = xk;
+                    if (c < k) sv = __builtin_fma(-lcol[k], xk, sv); // s_c -= L[k][c] x_k
                 }
-                if (tid < 6) { xw[(j % NS) * 6 + tid] = xv; xout[(long)(V.rev ? V.C - 1 - j : j) * 6 + tid] = xv; }
+                if (last) { xw[(j % NS) * 6 + c] = xv; xout[(long)(V.rev ? V.C - 1 - j : j) * 6 + c] = xv; }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             }
         }
@@ -784,14 +914,15 @@ __device__ __forceinline__ void band_back(const BandView &V, const BandLds &S, c
     }
 }
 
+constexpr int BAND_NT = 384; // 6 waves: the nd(nd+1)/2 * 6 + nd * 6 = 324 work items of a trailing update (Bc = 9) fit one pass
 // one workgroup, whole chain (short systems, or CUBESLAM_BA_SOLVER=band1).  rhs: in b (6C), out x; ybuf: 12C scratch
-__global__ void __launch_bounds__(256) ba_band_chol(int C, int Bc, const double *A, double *Lf, double *rhs, double *ybuf, int *status) {
+__global__ void __launch_bounds__(BAND_NT) ba_band_chol(int C, int Bc, const double *A, double *Lf, double *rhs, double *ybuf, int *status) {
     extern __shared__ double sh[];
     const BandLds S = band_lds(sh, Bc);
     const BandView V{A, rhs, C, Bc, C, C, 0, 0};
-    const bool fail = band_factor(V, S, Lf, ybuf);
+    const bool fail = band_factor<BAND_NT>(V, S, Lf, ybuf);
     __syncthreads(); // every store to Lf / ybuf has completed
-    band_back(V, S, Lf, ybuf, nullptr, 0, rhs);
+    band_back<BAND_NT>(V, S, Lf, ybuf, nullptr, 0, rhs);
     if (threadIdx.x == 0 && fail) *status = 1;
 }
 __device__ __forceinline__ BandView band_side(int side, int C, int Bc, const double *A, const double *rhs) { // side 0: columns [0, neF); side 1: the other end
@@ -799,15 +930,15 @@ __device__ __forceinline__ BandView band_side(int side, int C, int Bc, const dou
     return side == 0 ? BandView{A, rhs, C, Bc, neF + R, neF, 0, 0} : BandView{A, rhs, C, Bc, neB + R, neB, 1, neF};
 }
 // mid: per side R columns of CS doubles (the updated tail columns, local order) followed by 6R right-hand-side entries
-__global__ void __launch_bounds__(256) ba_band_twist_factor(int C, int Bc, const double *A, const double *rhs, double *Lf, double *ybuf, double *mid, int *status) {
+__global__ void __launch_bounds__(BAND_NT) ba_band_twist_factor(int C, int Bc, const double *A, const double *rhs, double *Lf, double *ybuf, double *mid, int *status) {
     extern __shared__ double sh[];
     const BandLds S = band_lds(sh, Bc);
     const BandView V = band_side(blockIdx.x, C, Bc, A, rhs);
-    const bool fail = band_factor(V, S, Lf, ybuf);
+    const bool fail = band_factor<BAND_NT>(V, S, Lf, ybuf);
     const int NS = Bc + 2, CS = (Bc + 1) * 36, R = V.n - V.ne;
     double *m = mid + (long)blockIdx.x * ((long)R * CS + R * 6);
-    for (int i = threadIdx.x; i < R * CS; i += 256) m[i] = S.W[(long)((V.ne + i / CS) % NS) * CS + i % CS];
-    for (int i = threadIdx.x; i < R * 6; i += 256) m[(long)R * CS + i] = S.bw[((V.ne + i / 6) % NS) * 6 + i % 6];
+    for (int i = threadIdx.x; i < R * CS; i += BAND_NT) m[i] = S.W[(long)((V.ne + i / CS) % NS) * CS + i % CS];
+    for (int i = threadIdx.x; i < R * 6; i += BAND_NT) m[(long)R * CS + i] = S.bw[((V.ne + i / 6) % NS) * 6 + i % 6];
     if (threadIdx.x == 0 && fail) *status = 1;
 }
 // middle group: M = tail(forward) + reversed tail(backward), dense Cholesky in LDS (N = 6R <= 120), two triangular solves.  xm: 6R
@@ -825,7 +956,11 @@ __global__ void __launch_bounds__(256) ba_band_mid(int C, int Bc, const double *
     __syncthreads();
     for (int i = tid; i < R * R * 36; i += 256) { // backward side: its block (t+d, t) is the transposed original block (R-1-t, R-1-t-d)
         const int t = i / (R * 36), d = (i / 36) % R, e = i % 36, r = e / 6, c = e % 6;
-        if (t + d < R) { const int bb = R - 1 - t, aa = bb - d; M[(long)(bb * 6 + c) * N + aa * 6 + r] += m1[(long)t * CS + d * 36 + e]; }
+        if (t + d < R && (d > 0 || r >= c)) { // diagonal blocks: only their lower triangle is maintained by the factor kernels
+            const int bb = R - 1 - t, aa = bb - d;
+            if (d > 0) M[(long)(bb * 6 + c) * N + aa * 6 + r] += m1[(long)t * CS + d * 36 + e];
+            else M[(long)(bb * 6 + r) * N + bb * 6 + c] += m1[(long)t * CS + e];
+        }
     }
     for (int i = tid; i < N; i += 256) bv[i] = m0[(long)R * CS + i] + m1[(long)R * CS + (R - 1 - i / 6) * 6 + i % 6];
     __syncthreads();
@@ -859,11 +994,11 @@ __global__ void __launch_bounds__(256) ba_band_mid(int C, int Bc, const double *
     for (int i = tid; i < N; i += 256) { xm[i] = bv[i]; xout[(long)neF * 6 + i] = bv[i]; }
     if (tid == 0 && s_fail) *status = 1;
 }
-__global__ void __launch_bounds__(256) ba_band_twist_back(int C, int Bc, const double *Lf, const double *ybuf, const double *xm, double *xout) {
+__global__ void __launch_bounds__(BAND_NT) ba_band_twist_back(int C, int Bc, const double *Lf, const double *ybuf, const double *xm, double *xout) {
     extern __shared__ double sh[];
     const BandLds S = band_lds(sh, Bc);
     const BandView V = band_side(blockIdx.x, C, Bc, nullptr, nullptr);
-    band_back(V, S, Lf, ybuf, xm, blockIdx.x, xout);
+    band_back<BAND_NT>(V, S, Lf, ybuf, xm, blockIdx.x, xout);
 }
 
 // scatter the (all-reduced) blocks of the reduced system into the factor storage Lb = [P diagonal blocks | off-diagonal
@@ -1380,12 +1515,12 @@ static int ba_solve(cs_ctx *ctx, cs_ba *b, double lambda, bool *ok) { // BlockSo
                 CS_HIP(ctx, hipFuncSetAttribute((const void *)ba_band_twist_back, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             }
             if (lds_mid > 64 * 1024) CS_HIP(ctx, hipFuncSetAttribute((const void *)ba_band_mid, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mid));
-            CS_LAUNCH(ctx, "ba_band_twist_factor", ba_band_twist_factor, dim3(2), dim3(256), lds, C, Bc, b->d_bandA, b->d_brhs, b->d_bandL, b->d_ybuf, b->d_mid, b->d_status);
+            CS_LAUNCH(ctx, "ba_band_twist_factor", ba_band_twist_factor, dim3(2), dim3(BAND_NT), lds, C, Bc, b->d_bandA, b->d_brhs, b->d_bandL, b->d_ybuf, b->d_mid, b->d_status);
             CS_LAUNCH(ctx, "ba_band_mid", ba_band_mid, dim3(1), dim3(256), lds_mid, C, Bc, b->d_mid, b->d_xmid, b->d_brhs, b->d_status);
-            CS_LAUNCH(ctx, "ba_band_twist_back", ba_band_twist_back, dim3(2), dim3(256), lds, C, Bc, b->d_bandL, b->d_ybuf, b->d_xmid, b->d_brhs);
+            CS_LAUNCH(ctx, "ba_band_twist_back", ba_band_twist_back, dim3(2), dim3(BAND_NT), lds, C, Bc, b->d_bandL, b->d_ybuf, b->d_xmid, b->d_brhs);
         } else {
             if (lds > 64 * 1024) CS_HIP(ctx, hipFuncSetAttribute((const void *)ba_band_chol, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
-            CS_LAUNCH(ctx, "ba_band_chol", ba_band_chol, dim3(1), dim3(256), lds, C, Bc, b->d_bandA, b->d_bandL, b->d_brhs, b->d_ybuf, b->d_status);
+            CS_LAUNCH(ctx, "ba_band_chol", ba_band_chol, dim3(1), dim3(BAND_NT), lds, C, Bc, b->d_bandA, b->d_bandL, b->d_brhs, b->d_ybuf, b->d_status);
         }
         CS_HIP(ctx, hipMemcpyAsync(G.x, b->d_brhs, sizeof(double) * (size_t)C * 6, hipMemcpyDeviceToDevice, ctx->stream));
         if (Q > 0) CS_LAUNCH(ctx, "ba_cub_back", ba_cub_back, dim3((Q + 63) / 64), dim3(64), 0, C, Q, b->d_cq_off, b->d_cq_list, S, b->d_cubD, b->d_cubg, G.x);
