@@ -644,12 +644,14 @@ static int lsd_run(cs_ctx *ctx, cs_lsd *l, int with_lbd) {
                 l->line_cap = cap;
             }
             std::vector<int> lf((size_t)nl);
+            std::vector<cs_keyline> kl((size_t)nl); // one upload for the whole batch (128 per-frame copies cost more than the descriptors)
             for (int f = 0; f < F; f++) {
-                r = cs_h2d(ctx, l->d_kl + l->line_off[f], l->keylines[f].data(), l->keylines[f].size()); if (r) return r;
+                std::copy(l->keylines[f].begin(), l->keylines[f].end(), kl.begin() + l->line_off[f]);
                 for (int i = l->line_off[f]; i < l->line_off[f + 1]; i++) lf[i] = f;
             }
+            r = cs_h2d(ctx, l->d_kl, kl.data(), (size_t)nl); if (r) return r;
             r = cs_h2d(ctx, l->d_line_frame, lf.data(), (size_t)nl); if (r) return r;
-            CS_HIP(ctx, hipStreamSynchronize(ctx->stream)); // lf is a local
+            CS_HIP(ctx, hipStreamSynchronize(ctx->stream)); // kl, lf are locals
             r = cs_lbd_batch_desc(ctx, l->d_kl, l->d_line_frame, nl, l->d_dxy, W, H, l->d_desc, nullptr); if (r) return r;
             r = cs_d2h(ctx, l->h_desc.data(), l->d_desc, (size_t)nl * 32); if (r) return r;
         }
