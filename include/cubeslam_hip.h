@@ -334,6 +334,29 @@ void cs_frontend_destroy(cs_frontend *fe);
 int cs_cuboid9_oplus(cs_ctx *ctx, int n, const double *cub, const double *upd, double *out);
 int cs_cuboid9_edge_linearize(cs_ctx *ctx, int n, const double *cam_Tcw, const double *cub_global, const double *cub_meas_local, double *err, double *Jcam, double *Jcub);
 
+/* ===================================================================== object association after detect_cuboid
+ * cs_associate_keypoints replaces the keypoint -> local cuboid association of Tracking::DetectCuboid
+ * (orb_object_slam/src/Tracking.cc:1717-1775, with bboxOverlapratio detect_3d_cuboid/src/object_3d_util.cpp:650-654) for a batch of
+ * keyframes: boxes are cv::Rect (x, y, w, h) of pKF->local_cuboids in order, keypoints mvKeys[i].pt.  Out: keypoint_associate_objectID
+ * (index of the single non-overlapped box that contains the rounded keypoint, else -1), keypoint_inany_object (only meaningful with
+ * enable_ground_height_scale, may be NULL) and the per-box `overlapped` flags (IoU > 0.15 with an earlier unflagged box, may be NULL).
+ * At most 64 boxes per frame. */
+int cs_associate_keypoints(cs_ctx *ctx, int n_frames, const int *kp_off, const float *kp_xy, const int *box_off, const int *boxes, int enable_ground_height_scale,
+                           int *assoc, uint8_t *inany, uint8_t *overlapped);
+/* Tracking::AssociateCuboids (Tracking.cc:1848-1990, use_truth_trackid = false) on index arrays instead of MapObject* / MapPoint*:
+ * candidates (cand_id = the id a candidate gets as a landmark, its GetPotentialMapPoints() as CSR cand_off / cand_pts) are taken
+ * in order against LocalObjectsLandmarks (landmark_id, landmark_bad = isBad()), counting for every landmark the candidate's points
+ * whose MapObjObservations (CSR pobs_off / pobs_obj / pobs_cnt, pobs_cnt NULL = all 1) contain it; the first landmark in list
+ * order with the strictly largest count above the threshold absorbs the candidate (MergeIntoLandmark), otherwise the candidate
+ * becomes a landmark (SetAsLandmark) and joins the list before the NEXT candidate; both add one vote per point
+ * (MapPoint::AddObjectObservation, MapPoint.cc:219-242), which later candidates see.  Out: assoc[i] = landmark id candidate i ends
+ * up in, created[i]; best_object / max_vote (n_points, in/out, may be NULL) follow the `best_object` bookkeeping of the points;
+ * the changed votes come back as (point, object, new count) triples (upd_*, may be NULL; *n_upd = their number).  Host code: the
+ * loop is serial by construction. */
+int cs_associate_cuboids(int n_cand, const int *cand_id, const int *cand_off, const int *cand_pts, int n_landmarks, const int *landmark_id, const uint8_t *landmark_bad,
+                         int n_points, const int *pobs_off, const int *pobs_obj, const int *pobs_cnt, int *best_object, int *max_vote, int largest_shared_num_points_thres,
+                         int *assoc, uint8_t *created, int upd_cap, int *upd_point, int *upd_obj, int *upd_cnt, int *n_upd);
+
 #ifdef __cplusplus
 }
 #endif

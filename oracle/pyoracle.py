@@ -439,3 +439,83 @@ def cuboid9_edge_linearize(cam_Tcw, cub_global, cub_meas, jac=True):
         return err, Jc, Jq
     lib().orc_cuboid9_edge_error(n, _p(T, C.c_double), _p(g, C.c_double), _p(m, C.c_double), _p(err, C.c_double))
     return err
+
+
+# ----------------------------------------------------------------------------------------------- object association
+def bbox_overlap_ratio(r1, r2):
+    """bboxOverlapratio (detect_3d_cuboid/src/object_3d_util.cpp:650-654): int areas, float ratio; cv::Rect & cv::Rect is empty when the
+    intersection has no positive width and height."""
+    x1, y1 = max(r1[0], r2[0]), max(r1[1], r2[1])
+    w, h = min(r1[0] + r1[2], r2[0] + r2[2]) - x1, min(r1[1] + r1[3], r2[1] + r2[3]) - y1
+    ov = w * h if (w > 0 and h > 0) else 0
+    with np.errstate(divide="ignore", invalid="ignore"):
+        return np.float32(ov) / np.float32(r1[2] * r1[3] + r2[2] * r2[3] - ov)
+
+
+def associate_keypoints(kp_xy, boxes, enable_ground_height_scale=False):
+    """Keypoint -> local cuboid association of Tracking::DetectCuboid (orb_object_slam/src/Tracking.cc:1717-1775) for one keyframe.
+    Point2f -> Point2i inside Rect::contains is cv::saturate_cast<int>(float) = cvRound (round half to even).  Pure Python: small cases."""
+    boxes = [tuple(int(v) for v in b) for b in boxes]
+    nb = len(boxes)
+    ov = [False] * nb
+    for i in range(nb):
+        if not ov[i]:
+            for j in range(i + 1, nb):
+                if not ov[j] and float(bbox_overlap_ratio(boxes[i], boxes[j])) > 0.15:
+                    ov[i] = True; ov[j] = True
+    assoc = np.full(len(kp_xy), -1, np.int32)
+    inany = np.zeros(len(kp_xy), np.uint8)
+    for k, (x, y) in enumerate(np.asarray(kp_xy, np.float32).reshape(-1, 2)):
+        px, py = int(np.rint(np.float32(x))), int(np.rint(np.float32(y)))
+        times = 0
+        for j, (bx, by, bw, bh) in enumerate(boxes):
+            inside = bx <= px < bx + bw and by <= py < by + bh
+            if enable_ground_height_scale:
+                if inside:
+                    inany[k] = 1
+                    if not ov[j]:
+                        times += 1
+                        assoc[k] = j if times == 1 else -1
+            elif (not ov[j]) and inside:
+                times += 1
+                assoc[k] = j if times == 1 else -1
+    return assoc, inany, np.array(ov, np.uint8)
+
+
+def associate_cuboids(cand_id, cand_pts, landmark_id, landmark_bad, point_votes, thres, best_object=None, max_vote=None):
+    """Tracking::AssociateCuboids (Tracking.cc:1848-1990, use_truth_trackid off) on ids.  cand_pts: list of point-id lists
+    (GetPotentialMapPoints); point_votes: list of dicts object id -> count (MapPoint::MapObjObservations), updated in place like
+    SetAsLandmark / MergeIntoLandmark -> MapPoint::AddObjectObservation do (MapObject.cc:100-115, MapPoint.cc:219-242)."""
+    L = list(landmark_id)
+    bad = {o: bool(b) for o, b in zip(landmark_id, landmark_bad)}
+    assoc, created = [], []
+    last_new = None
+
+    def add(p, obj):
+        point_votes[p][obj] = point_votes[p].get(obj, 0) + 1
+        if best_object is not None and point_votes[p][obj] > max_vote[p]:
+            best_object[p] = obj; max_vote[p] = point_votes[p][obj]
+
+    for cid, pts in zip(cand_id, cand_pts):
+        if last_new is not None:
+            L.append(last_new); bad[last_new] = False
+        last_new = None
+        best = None
+        if L:
+            counter = {}
+            for p in pts:
+                for o in point_votes[p]:
+                    counter[o] = counter.get(o, 0) + 1
+            largest = thres
+            for o in L:
+                if not bad[o] and o in counter and counter[o] > largest:
+                    largest = counter[o]; best = o
+        if best is None:
+            for p in pts:
+                add(p, cid)
+            assoc.append(cid); created.append(1); last_new = cid
+        else:
+            for p in pts:
+                add(p, best)
+            assoc.append(best); created.append(0)
+    return np.array(assoc, np.int32), np.array(created, np.uint8)
