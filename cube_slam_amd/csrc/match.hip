@@ -200,6 +200,52 @@ __global__ void __launch_bounds__(256) match_knn2(const unsigned long long *q, i
     if (i < nq) { best_idx[i] = bi; best_dist[i] = b; second_dist[i] = b2; }
 }
 
+// SearchForTriangulation (:679-850): one wave per keypoint of KF1; lanes stride over the KF2 features of the same vocabulary node
+// (ascending index).  The reference keeps the LAST candidate that reaches the running minimum (`dist > bestDist -> continue` lets
+// equal distances through and the winner only changes on a candidate that passes the geometric tests), i.e. among the candidates
+// that pass every test the smallest distance and, for equal distances, the largest index: min over the key dist << 20 | (2^20-1 - idx2).
+struct TriP { float F12[9]; float ex, ey; int only_stereo; };
+__global__ void __launch_bounds__(256) match_triangulation(int N1, const cs_keypoint *keys1, const unsigned long long *desc1, const int *node1, const uint8_t *skip1,
+                                                           const float *ur1, const cs_keypoint *keys2, const unsigned long long *desc2, const uint8_t *skip2,
+                                                           const float *ur2, const int *node_start2, const int *node_items2, int n_nodes, TriP P,
+                                                           const float *scale2, const float *sigma2_2, int *matches12) {
+    const int i1 = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (i1 >= N1) return;
+    unsigned best = 0xffffffffu;
+    const int nd = node1[i1];
+    const bool stereo1 = ur1[i1] >= 0;
+    if (nd >= 0 && nd < n_nodes && !skip1[i1] && !(P.only_stereo && !stereo1)) {
+        const cs_keypoint kp1 = keys1[i1];
+        const unsigned long long a0 = desc1[(long)i1 * 4], a1 = desc1[(long)i1 * 4 + 1], a2 = desc1[(long)i1 * 4 + 2], a3 = desc1[(long)i1 * 4 + 3];
+        // epipolar line l = x1' F12 (CheckDistEpipolarLine :152-169), float, no contraction
+        const float a = kp1.x * P.F12[0] + kp1.y * P.F12[3] + P.F12[6];
+        const float b = kp1.x * P.F12[1] + kp1.y * P.F12[4] + P.F12[7];
+        const float c = kp1.x * P.F12[2] + kp1.y * P.F12[5] + P.F12[8];
+        const float den = a * a + b * b;
+        for (int p = node_start2[nd] + lane; p < node_start2[nd + 1]; p += 64) {
+            const int i2 = node_items2[p];
+            if (skip2[i2]) continue;
+            const bool stereo2 = ur2[i2] >= 0;
+            if (P.only_stereo && !stereo2) continue;
+            const int dist = hamming256(desc2 + (long)i2 * 4, a0, a1, a2, a3);
+            if (dist > TH_LOW) continue;
+            const cs_keypoint kp2 = keys2[i2];
+            if (!stereo1 && !stereo2) {
+                const float dx = P.ex - kp2.x, dy = P.ey - kp2.y;
+                if (dx * dx + dy * dy < 100 * scale2[kp2.octave]) continue;
+            }
+            const float num = a * kp2.x + b * kp2.y + c;
+            if (den == 0) continue;
+            const float dsqr = num * num / den;
+            if (!((double)dsqr < 3.84 * (double)sigma2_2[kp2.octave])) continue;
+            const unsigned key = ((unsigned)dist << 20) | (0xfffffu - (unsigned)i2);
+            best = min(best, key);
+        }
+    }
+    for (int off = 32; off > 0; off >>= 1) best = min(best, (unsigned)__shfl_xor((int)best, off));
+    if (lane == 0) matches12[i1] = best == 0xffffffffu ? -1 : (int)(0xfffffu - (best & 0xfffffu));
+}
+
 static void three_maxima(const int *sizes, int L, int &ind1, int &ind2, int &ind3) { // ORBmatcher.cc:1860-1901
     int max1 = 0, max2 = 0, max3 = 0;
     for (int i = 0; i < L; i++) {
@@ -463,6 +509,127 @@ int cs_match_for_initialization(cs_ctx *ctx, cs_matcher *m, const cs_keypoint *k
     }
     for (int i1 = 0; i1 < N1; i1++)
         if (vnMatches12[i1] >= 0) { prev[i1 * 2] = m->keys[vnMatches12[i1]].x; prev[i1 * 2 + 1] = m->keys[vnMatches12[i1]].y; }
+    *nmatches = nm;
+    return CS_OK;
+}
+
+int cs_match_fuse(cs_ctx *ctx, cs_matcher *m, const float *u_right, const float *inv_level_sigma2, int n_levels, const uint8_t *keys_static, int n_mp, const float *uv,
+                  const float *ur, const int *pred_level, const uint8_t *valid, const uint8_t *mp_desc, const float *scale_factors, float th, int *best_idx,
+                  int *best_dist, int *n_fused) {
+    if (!ctx || !m || n_mp < 0 || n_mp > m->max_q || !u_right || !inv_level_sigma2 || n_levels < 1 || (n_mp && (!uv || !ur || !pred_level || !valid || !mp_desc)) ||
+        !scale_factors || !best_idx || !best_dist || !n_fused)
+        return CS_ERR_BAD_ARG;
+    CS_HIP(ctx, hipSetDevice(ctx->device));
+    *n_fused = 0;
+    if (n_mp == 0) return CS_OK;
+    std::vector<Query> q((size_t)n_mp);
+    for (int i = 0; i < n_mp; i++) { // :921-926: GetFeaturesInArea(u, v, th * scale[level]) without level limits
+        Query Q{0, 0, 0, -1, -1, 0};
+        if (valid[i]) {
+            if (pred_level[i] < 0 || pred_level[i] >= n_levels) return CS_ERR_BAD_ARG;
+            Q.x = uv[i * 2]; Q.y = uv[i * 2 + 1]; Q.r = th * scale_factors[pred_level[i]]; Q.valid = 1;
+        }
+        q[i] = Q;
+    }
+    int r = cs_h2d(ctx, m->d_q, q.data(), (size_t)n_mp); if (r) return r;
+    r = cs_h2d(ctx, (uint8_t *)m->d_qdesc, mp_desc, (size_t)n_mp * 32); if (r) return r;
+    r = run_candidates(ctx, m, n_mp, true); if (r) return r;
+    int nf = 0;
+    for (int i = 0; i < n_mp; i++) { // :934-981: the tests that need per-keypoint data of the key frame, first minimum wins
+        int bestDist = 256, bestIdx = -1;
+        if (valid[i]) {
+            const float u = uv[i * 2], v = uv[i * 2 + 1];
+            for (int p = m->offsets[i]; p < m->offsets[i + 1]; p++) {
+                const int idx = m->cands[p].x;
+                const cs_keypoint &kp = m->keys[idx];
+                const int kpLevel = kp.octave;
+                if (kpLevel < pred_level[i] - 1 || kpLevel > pred_level[i]) continue;
+                if (keys_static && !keys_static[idx]) continue;
+                if (kpLevel < 0 || kpLevel >= n_levels) return CS_ERR_BAD_ARG;
+                if (u_right[idx] >= 0) {
+                    const float ex = u - kp.x, ey = v - kp.y, er = ur[i] - u_right[idx];
+                    const float e2 = ex * ex + ey * ey + er * er;
+                    if (e2 * inv_level_sigma2[kpLevel] > 7.8) continue;
+                } else {
+                    const float ex = u - kp.x, ey = v - kp.y;
+                    const float e2 = ex * ex + ey * ey;
+                    if (e2 * inv_level_sigma2[kpLevel] > 5.99) continue;
+                }
+                const int dist = m->cands[p].y;
+                if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+            }
+        }
+        best_idx[i] = bestIdx; best_dist[i] = bestDist;
+        if (bestDist <= TH_LOW) nf++;
+    }
+    *n_fused = nf;
+    return CS_OK;
+}
+
+int cs_match_for_triangulation(cs_ctx *ctx, const cs_keypoint *keys1Un, const uint8_t *desc1, int N1, const int *node1, const uint8_t *skip1, const float *u_right1,
+                               const cs_keypoint *keys2Un, const uint8_t *desc2, int N2, const int *node2, const uint8_t *skip2, const float *u_right2,
+                               const float *F12, float ex, float ey, const float *scale_factors2, const float *level_sigma2_2, int n_levels, int only_stereo,
+                               int check_orientation, int *matches12, int *nmatches) {
+    if (!ctx || N1 < 0 || N2 < 0 || N2 >= (1 << 20) || !matches12 || !nmatches || !F12 || !scale_factors2 || !level_sigma2_2 || n_levels < 1 ||
+        (N1 && (!keys1Un || !desc1 || !node1 || !skip1 || !u_right1)) || (N2 && (!keys2Un || !desc2 || !node2 || !skip2 || !u_right2)))
+        return CS_ERR_BAD_ARG;
+    *nmatches = 0;
+    for (int i = 0; i < N1; i++) matches12[i] = -1;
+    if (N1 == 0 || N2 == 0) return CS_OK;
+    for (int i = 0; i < N2; i++) if (keys2Un[i].octave < 0 || keys2Un[i].octave >= n_levels) return CS_ERR_BAD_ARG;
+    CS_HIP(ctx, hipSetDevice(ctx->device));
+    // KF2 features by node (counting sort keeps the ascending index order inside a node); node ids are compacted to 0..n_nodes-1
+    std::vector<int> ids;
+    for (int i = 0; i < N2; i++) if (node2[i] >= 0) ids.push_back(node2[i]);
+    std::sort(ids.begin(), ids.end()); ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+    const int n_nodes = (int)ids.size();
+    auto compact = [&](int nd) { if (nd < 0) return -1; auto it = std::lower_bound(ids.begin(), ids.end(), nd); return (it != ids.end() && *it == nd) ? (int)(it - ids.begin()) : -1; };
+    std::vector<int> start((size_t)n_nodes + 1, 0), items, n1c((size_t)N1);
+    std::vector<int> n2c((size_t)N2);
+    for (int i = 0; i < N2; i++) { n2c[i] = compact(node2[i]); if (n2c[i] >= 0) start[n2c[i] + 1]++; }
+    for (int k = 0; k < n_nodes; k++) start[k + 1] += start[k];
+    items.resize((size_t)std::max(start[n_nodes], 1));
+    { std::vector<int> pos(start.begin(), start.end() - 1); for (int i = 0; i < N2; i++) if (n2c[i] >= 0) items[pos[n2c[i]]++] = i; }
+    for (int i = 0; i < N1; i++) n1c[i] = compact(node1[i]);
+    cs_keypoint *d_k1 = nullptr, *d_k2 = nullptr; unsigned long long *d_d1 = nullptr, *d_d2 = nullptr; int *d_n1 = nullptr, *d_st = nullptr, *d_it = nullptr, *d_m = nullptr;
+    uint8_t *d_s1 = nullptr, *d_s2 = nullptr; float *d_u1 = nullptr, *d_u2 = nullptr, *d_sc = nullptr, *d_sg = nullptr;
+    int r = cs_dalloc(ctx, &d_k1, (size_t)N1);
+#define TA_(call) if (!r) r = (call)
+    TA_(cs_dalloc(ctx, &d_k2, (size_t)N2)); TA_(cs_dalloc(ctx, &d_d1, (size_t)N1 * 4)); TA_(cs_dalloc(ctx, &d_d2, (size_t)N2 * 4));
+    TA_(cs_dalloc(ctx, &d_n1, (size_t)N1)); TA_(cs_dalloc(ctx, &d_st, (size_t)n_nodes + 1)); TA_(cs_dalloc(ctx, &d_it, items.size())); TA_(cs_dalloc(ctx, &d_m, (size_t)N1));
+    TA_(cs_dalloc(ctx, &d_s1, (size_t)N1)); TA_(cs_dalloc(ctx, &d_s2, (size_t)N2)); TA_(cs_dalloc(ctx, &d_u1, (size_t)N1)); TA_(cs_dalloc(ctx, &d_u2, (size_t)N2));
+    TA_(cs_dalloc(ctx, &d_sc, (size_t)n_levels)); TA_(cs_dalloc(ctx, &d_sg, (size_t)n_levels));
+    TA_(cs_h2d(ctx, d_k1, keys1Un, (size_t)N1)); TA_(cs_h2d(ctx, d_k2, keys2Un, (size_t)N2));
+    TA_(cs_h2d(ctx, (uint8_t *)d_d1, desc1, (size_t)N1 * 32)); TA_(cs_h2d(ctx, (uint8_t *)d_d2, desc2, (size_t)N2 * 32));
+    TA_(cs_h2d(ctx, d_n1, n1c.data(), (size_t)N1)); TA_(cs_h2d(ctx, d_st, start.data(), start.size())); TA_(cs_h2d(ctx, d_it, items.data(), items.size()));
+    TA_(cs_h2d(ctx, d_s1, skip1, (size_t)N1)); TA_(cs_h2d(ctx, d_s2, skip2, (size_t)N2)); TA_(cs_h2d(ctx, d_u1, u_right1, (size_t)N1)); TA_(cs_h2d(ctx, d_u2, u_right2, (size_t)N2));
+    TA_(cs_h2d(ctx, d_sc, scale_factors2, (size_t)n_levels)); TA_(cs_h2d(ctx, d_sg, level_sigma2_2, (size_t)n_levels));
+#undef TA_
+    if (!r) {
+        TriP P; for (int k = 0; k < 9; k++) P.F12[k] = F12[k];
+        P.ex = ex; P.ey = ey; P.only_stereo = only_stereo;
+        CS_LAUNCH(ctx, "match_triangulation", match_triangulation, dim3((N1 + 3) / 4), dim3(256), 0, N1, d_k1, d_d1, d_n1, d_s1, d_u1, d_k2, d_d2, d_s2, d_u2, d_st, d_it, n_nodes, P,
+                  d_sc, d_sg, d_m);
+        r = cs_d2h(ctx, matches12, d_m, (size_t)N1);
+    }
+    hipError_t e = hipStreamSynchronize(ctx->stream);
+    if (!r && e != hipSuccess) { ctx->err = hipGetErrorString(e); r = CS_ERR_HIP; }
+    void *ptrs[] = {d_k1, d_k2, d_d1, d_d2, d_n1, d_st, d_it, d_m, d_s1, d_s2, d_u1, d_u2, d_sc, d_sg};
+    for (void *p : ptrs) if (p) hipFree(p);
+    if (r) return r;
+    int nm = 0;
+    for (int i = 0; i < N1; i++) if (matches12[i] >= 0) nm++;
+    if (check_orientation) { // :801-830
+        std::vector<int> rotHist[HISTO_LENGTH];
+        for (int i = 0; i < N1; i++) if (matches12[i] >= 0) rotHist[rot_bin(keys1Un[i].angle, keys2Un[matches12[i]].angle)].push_back(i);
+        int sizes[HISTO_LENGTH], ind1 = -1, ind2 = -1, ind3 = -1;
+        for (int i = 0; i < HISTO_LENGTH; i++) sizes[i] = (int)rotHist[i].size();
+        three_maxima(sizes, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int j : rotHist[i]) { matches12[j] = -1; nm--; }
+        }
+    }
     *nmatches = nm;
     return CS_OK;
 }

@@ -66,6 +66,33 @@ class ORBmatcher:
                                                               C.byref(n)), "cs_match_for_initialization")
         return m12[:len(k1)].copy(), prev, n.value
 
+    def Fuse(self, u_right, inv_level_sigma2, uv, ur, pred_level, valid, mp_desc, scale_factors, th=3.0, keys_static=None):
+        """ORBmatcher::Fuse(pKF, vpMapPoints, th), the search (ORBmatcher.cc:921-983) against the key frame given to set_frame: per map
+        point (bestIdx, bestDist); the third value is nFused."""
+        uvv = np.ascontiguousarray(uv, np.float32); urr = np.ascontiguousarray(ur, np.float32); pl = np.ascontiguousarray(pred_level, np.int32)
+        va = np.ascontiguousarray(valid, np.uint8); md = np.ascontiguousarray(mp_desc, np.uint8); sf = np.ascontiguousarray(scale_factors, np.float32)
+        kr = np.ascontiguousarray(u_right, np.float32); isg = np.ascontiguousarray(inv_level_sigma2, np.float32)
+        ks = None if keys_static is None else np.ascontiguousarray(keys_static, np.uint8)
+        bi = np.zeros(max(len(va), 1), np.int32); bd = np.zeros(max(len(va), 1), np.int32); n = C.c_int()
+        check(self.ctx.ptr, lib().cs_match_fuse(self.ctx.ptr, self._m, _p(kr, C.c_float), _p(isg, C.c_float), len(isg), None if ks is None else _p(ks, C.c_uint8), len(va),
+                                                _p(uvv, C.c_float), _p(urr, C.c_float), _p(pl, C.c_int), _p(va, C.c_uint8), _p(md, C.c_uint8), _p(sf, C.c_float), C.c_float(th),
+                                                _p(bi, C.c_int), _p(bd, C.c_int), C.byref(n)), "cs_match_fuse")
+        return bi[:len(va)].copy(), bd[:len(va)].copy(), n.value
+
+    def SearchForTriangulation(self, keys1Un, desc1, node1, skip1, ur1, keys2Un, desc2, node2, skip2, ur2, F12, ex, ey, scale_factors2, level_sigma2_2, bOnlyStereo=False):
+        """ORBmatcher::SearchForTriangulation(pKF1, pKF2, F12, vMatchedPairs, bOnlyStereo) (ORBmatcher.cc:679-850): matches12 and nmatches."""
+        k1 = np.ascontiguousarray(keys1Un, KEYPOINT_DTYPE); d1 = np.ascontiguousarray(desc1, np.uint8); k2 = np.ascontiguousarray(keys2Un, KEYPOINT_DTYPE)
+        d2 = np.ascontiguousarray(desc2, np.uint8)
+        n1 = np.ascontiguousarray(node1, np.int32); s1 = np.ascontiguousarray(skip1, np.uint8); u1 = np.ascontiguousarray(ur1, np.float32)
+        n2 = np.ascontiguousarray(node2, np.int32); s2 = np.ascontiguousarray(skip2, np.uint8); u2 = np.ascontiguousarray(ur2, np.float32)
+        Fm = np.ascontiguousarray(F12, np.float32).reshape(-1); sf = np.ascontiguousarray(scale_factors2, np.float32); sg = np.ascontiguousarray(level_sigma2_2, np.float32)
+        m12 = np.zeros(max(len(k1), 1), np.int32); n = C.c_int()
+        check(self.ctx.ptr, lib().cs_match_for_triangulation(self.ctx.ptr, k1.ctypes.data_as(C.c_void_p), _p(d1, C.c_uint8), len(k1), _p(n1, C.c_int), _p(s1, C.c_uint8),
+                                                             _p(u1, C.c_float), k2.ctypes.data_as(C.c_void_p), _p(d2, C.c_uint8), len(k2), _p(n2, C.c_int), _p(s2, C.c_uint8),
+                                                             _p(u2, C.c_float), _p(Fm, C.c_float), C.c_float(ex), C.c_float(ey), _p(sf, C.c_float), _p(sg, C.c_float), len(sf),
+                                                             int(bOnlyStereo), int(self.mbCheckOrientation), _p(m12, C.c_int), C.byref(n)), "cs_match_for_triangulation")
+        return m12[:len(k1)].copy(), n.value
+
     def close(self):
         if self._m:
             lib().cs_matcher_destroy(self.ctx.ptr, self._m)

@@ -207,6 +207,23 @@ int cs_match_local_map(cs_ctx *ctx, cs_matcher *m, int n_mp, const float *proj_x
 int cs_match_for_initialization(cs_ctx *ctx, cs_matcher *m, const cs_keypoint *keys1Un, const uint8_t *desc1, int N1,
                                 float *prev_matched, int window_size, float nnratio, int check_orientation,
                                 int *matches12, int *nmatches);
+/* ORBmatcher::Fuse(KeyFrame*, const vector<MapPoint*>&, th) (ORBmatcher.cc:852-1003), the search: for every valid map point (the
+ * caller did the preamble :871-919 -- projection u, v, ur = u - bf/z, image bounds, distance and viewing-angle tests, PredictScale) the
+ * keypoint of the key frame set with cs_matcher_set_frame that has the smallest descriptor distance among GetFeaturesInArea(u, v,
+ * th * scale[level]), after the level (:941), KeysStatic (:944), and chi-square tests (stereo 7.8 / mono 5.99, :947-971); first one
+ * wins ties.  u_right = mvuRight, inv_level_sigma2 = mvInvLevelSigma2.  best_idx -1 / best_dist 256: none; *n_fused = number with
+ * best_dist <= TH_LOW (what the reference returns).  Replace / AddObservation (:985-1000) stay with the caller's map. */
+int cs_match_fuse(cs_ctx *ctx, cs_matcher *m, const float *u_right, const float *inv_level_sigma2, int n_levels, const uint8_t *keys_static, int n_mp, const float *uv,
+                  const float *ur, const int *pred_level, const uint8_t *valid, const uint8_t *mp_desc, const float *scale_factors, float th, int *best_idx,
+                  int *best_dist, int *n_fused);
+/* ORBmatcher::SearchForTriangulation (ORBmatcher.cc:679-850).  node1 / node2: vocabulary node of every feature (the DBoW2 FeatureVector
+ * built by KeyFrame::ComputeBoW, -1 = none; DBoW2 itself is out of scope); skip = the feature already has a map point (or is
+ * not static); u_right < 0 = monocular; F12 row-major 3x3 (float), (ex, ey) the epipole of KF1's centre in KF2 (:686-692).
+ * matches12[N1] = index in KF2 or -1 (vMatchedPairs = the pairs with matches12 >= 0). */
+int cs_match_for_triangulation(cs_ctx *ctx, const cs_keypoint *keys1Un, const uint8_t *desc1, int N1, const int *node1, const uint8_t *skip1, const float *u_right1,
+                               const cs_keypoint *keys2Un, const uint8_t *desc2, int N2, const int *node2, const uint8_t *skip2, const float *u_right2,
+                               const float *F12, float ex, float ey, const float *scale_factors2, const float *level_sigma2_2, int n_levels, int only_stereo,
+                               int check_orientation, int *matches12, int *nmatches);
 /* ORBmatcher::DescriptorDistance over all pairs: exact best / second-best per query (first index wins ties). */
 int cs_hamming_knn2(cs_ctx *ctx, const uint8_t *q, int nq, const uint8_t *t, int nt, int *best_idx, int *best_dist, int *second_dist);
 

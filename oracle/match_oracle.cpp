@@ -9,6 +9,7 @@
 #include <algorithm>
 #include <climits>
 #include <cmath>
+#include <map>
 #include <vector>
 
 namespace {
@@ -242,3 +243,118 @@ void orc_hamming_knn2(const uint8_t *q, int nq, const uint8_t *t, int nt, int *b
 }
 
 } // extern "C"
+
+// ---------------------------------------------------------------------------------------------- Fuse / SearchForTriangulation
+// ORBmatcher::Fuse(KeyFrame*, vector<MapPoint*>, th) (:852-1003), the search part: the map-point preamble (projection, image bounds,
+// distance / viewing-angle tests, PredictScale) is the caller's and arrives as valid / u / v / ur / pred_level; what Replace /
+// AddObservation do with (bestIdx, bestDist) is map bookkeeping outside this function.  Returns the number of map points with
+// bestDist <= TH_LOW (nFused).
+int orc_fuse(const orc_frame *F, const float *u_right, const float *inv_level_sigma2, const uint8_t *keys_static, int n_mp, const float *uv, const float *ur,
+             const int *pred_level, const uint8_t *valid, const uint8_t *mp_desc, const float *scale_factors, float th, int *best_idx, int *best_dist) {
+    Grid g(F);
+    int nFused = 0;
+    std::vector<int> vIndices;
+    for (int i = 0; i < n_mp; i++) {
+        best_idx[i] = -1; best_dist[i] = 256;
+        if (!valid[i]) continue;
+        const int nPredictedLevel = pred_level[i];
+        const float u = uv[i * 2], v = uv[i * 2 + 1];
+        const float radius = th * scale_factors[nPredictedLevel];
+        g.area(u, v, radius, -1, -1, vIndices);
+        if (vIndices.empty()) continue;
+        int bestDist = 256, bestIdx = -1;
+        for (int idx : vIndices) {
+            const orc_keypoint &kp = F->keysUn[idx];
+            const int kpLevel = kp.octave;
+            if (kpLevel < nPredictedLevel - 1 || kpLevel > nPredictedLevel) continue;
+            if (keys_static && !keys_static[idx]) continue;
+            if (u_right[idx] >= 0) { // stereo reprojection test :954-966
+                const float ex = u - kp.x, ey = v - kp.y, er = ur[i] - u_right[idx];
+                const float e2 = ex * ex + ey * ey + er * er;
+                if (e2 * inv_level_sigma2[kpLevel] > 7.8) continue;
+            } else {
+                const float ex = u - kp.x, ey = v - kp.y;
+                const float e2 = ex * ex + ey * ey;
+                if (e2 * inv_level_sigma2[kpLevel] > 5.99) continue;
+            }
+            const int dist = descriptor_distance(mp_desc + (size_t)i * 32, F->desc + (size_t)idx * 32);
+            if (dist < bestDist) { bestDist = dist; bestIdx = idx; }
+        }
+        best_idx[i] = bestIdx; best_dist[i] = bestDist;
+        if (bestDist <= TH_LOW) nFused++;
+    }
+    return nFused;
+}
+
+// ORBmatcher::SearchForTriangulation (:679-850).  node1 / node2: the DBoW2 FeatureVector node of every feature (-1: none); inside a
+// node the features are visited in ascending index (FeatureVector::addFeature appends while features are transformed in index
+// order).  skip = has a map point; vbMatched2 is never set in the reference, so the keypoints of KF1 are independent.
+int orc_search_for_triangulation(const orc_frame *F1, const int *node1, const uint8_t *skip1, const float *u_right1, const uint8_t *static1, const orc_frame *F2,
+                                 const int *node2, const uint8_t *skip2, const float *u_right2, const uint8_t *static2, const float *F12, float ex, float ey,
+                                 const float *scale_factors2, const float *level_sigma2_2, int only_stereo, int check_orientation, int *matches12) {
+    std::map<int, std::vector<int>> fv1, fv2;
+    for (int i = 0; i < F1->N; i++) if (node1[i] >= 0) fv1[node1[i]].push_back(i);
+    for (int i = 0; i < F2->N; i++) if (node2[i] >= 0) fv2[node2[i]].push_back(i);
+    int nmatches = 0;
+    for (int i = 0; i < F1->N; i++) matches12[i] = -1;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = 1.0f / HISTO_LENGTH;
+    auto f1it = fv1.begin(), f1end = fv1.end();
+    auto f2it = fv2.begin(), f2end = fv2.end();
+    while (f1it != f1end && f2it != f2end) {
+        if (f1it->first == f2it->first) {
+            for (int idx1 : f1it->second) {
+                if (skip1[idx1]) continue;
+                if (static1 && !static1[idx1]) continue;
+                const bool bStereo1 = u_right1[idx1] >= 0;
+                if (only_stereo && !bStereo1) continue;
+                const orc_keypoint &kp1 = F1->keysUn[idx1];
+                int bestDist = TH_LOW, bestIdx2 = -1;
+                for (int idx2 : f2it->second) {
+                    if (skip2[idx2]) continue;
+                    const bool bStereo2 = u_right2[idx2] >= 0;
+                    if (only_stereo && !bStereo2) continue;
+                    if (static2 && !static2[idx2]) continue;
+                    const int dist = descriptor_distance(F1->desc + (size_t)idx1 * 32, F2->desc + (size_t)idx2 * 32);
+                    if (dist > TH_LOW || dist > bestDist) continue;
+                    const orc_keypoint &kp2 = F2->keysUn[idx2];
+                    if (!bStereo1 && !bStereo2) {
+                        const float distex = ex - kp2.x, distey = ey - kp2.y;
+                        if (distex * distex + distey * distey < 100 * scale_factors2[kp2.octave]) continue;
+                    }
+                    // CheckDistEpipolarLine :152-169
+                    const float a = kp1.x * F12[0] + kp1.y * F12[3] + F12[6];
+                    const float b = kp1.x * F12[1] + kp1.y * F12[4] + F12[7];
+                    const float c = kp1.x * F12[2] + kp1.y * F12[5] + F12[8];
+                    const float num = a * kp2.x + b * kp2.y + c;
+                    const float den = a * a + b * b;
+                    if (den == 0) continue;
+                    const float dsqr = num * num / den;
+                    if (dsqr < 3.84 * level_sigma2_2[kp2.octave]) { bestIdx2 = idx2; bestDist = dist; }
+                }
+                if (bestIdx2 >= 0) {
+                    matches12[idx1] = bestIdx2;
+                    nmatches++;
+                    if (check_orientation) {
+                        float rot = kp1.angle - F2->keysUn[bestIdx2].angle;
+                        if (rot < 0.0) rot += 360.0f;
+                        int bin = (int)std::round(rot * factor);
+                        if (bin == HISTO_LENGTH) bin = 0;
+                        rotHist[bin].push_back(idx1);
+                    }
+                }
+            }
+            ++f1it; ++f2it;
+        } else if (f1it->first < f2it->first) f1it = fv1.lower_bound(f2it->first);
+        else f2it = fv2.lower_bound(f1it->first);
+    }
+    if (check_orientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int j : rotHist[i]) { matches12[j] = -1; nmatches--; }
+        }
+    }
+    return nmatches;
+}

@@ -155,6 +155,15 @@ int orc_search_local_map(const orc_frame *F, int n_mp, const float *proj_xy, con
 /* SearchForInitialization (:429-542): prev_matched is N1 x 2 in/out; matches12[N1] out.  Returns nmatches. */
 int orc_search_for_initialization(const orc_frame *F1, const orc_frame *F2, float *prev_matched, int window_size, float nnratio,
                                   int check_orientation, int *matches12);
+/* ORBmatcher::Fuse(KeyFrame*, vector<MapPoint*>, th) (:852-1003), search part: per valid map point (u, v, ur projections and
+ * predicted level from the caller) the keypoint of the key frame with the smallest descriptor distance among GetFeaturesInArea(u, v,
+ * th * scale[level]) that passes the level and chi-square tests (first one wins ties).  best_dist 256 / best_idx -1: none.  Returns nFused. */
+int orc_fuse(const orc_frame *F, const float *u_right, const float *inv_level_sigma2, const uint8_t *keys_static, int n_mp, const float *uv, const float *ur,
+             const int *pred_level, const uint8_t *valid, const uint8_t *mp_desc, const float *scale_factors, float th, int *best_idx, int *best_dist);
+/* ORBmatcher::SearchForTriangulation (:679-850); node = DBoW2 FeatureVector node id of every feature (-1 none), F12 row-major 3x3. */
+int orc_search_for_triangulation(const orc_frame *F1, const int *node1, const uint8_t *skip1, const float *u_right1, const uint8_t *static1, const orc_frame *F2,
+                                 const int *node2, const uint8_t *skip2, const float *u_right2, const uint8_t *static2, const float *F12, float ex, float ey,
+                                 const float *scale_factors2, const float *level_sigma2_2, int only_stereo, int check_orientation, int *matches12);
 /* exact 2-NN in Hamming space over all pairs (first index wins ties) */
 void orc_hamming_knn2(const uint8_t *q, int nq, const uint8_t *t, int nt, int *best_idx, int *best_dist, int *second_dist);
 

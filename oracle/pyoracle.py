@@ -275,6 +275,28 @@ def search_for_initialization(F1, F2, prev_matched, window_size=100, nnratio=0.9
     return m12[:F1.N].copy(), prev, n
 
 
+def fuse(F, u_right, inv_level_sigma2, n_mp_uv, ur, pred_level, valid, mp_desc, scale_factors, th, keys_static=None):
+    uv = np.ascontiguousarray(n_mp_uv, np.float32); urr = np.ascontiguousarray(ur, np.float32); pl = np.ascontiguousarray(pred_level, np.int32)
+    va = np.ascontiguousarray(valid, np.uint8); md = np.ascontiguousarray(mp_desc, np.uint8); sf = np.ascontiguousarray(scale_factors, np.float32)
+    kr = np.ascontiguousarray(u_right, np.float32); isg = np.ascontiguousarray(inv_level_sigma2, np.float32)
+    ks = None if keys_static is None else np.ascontiguousarray(keys_static, np.uint8)
+    bi = np.zeros(max(len(va), 1), np.int32); bd = np.zeros(max(len(va), 1), np.int32)
+    n = lib().orc_fuse(C.byref(F), _p(kr, C.c_float), _p(isg, C.c_float), None if ks is None else _p(ks, C.c_uint8), len(va), _p(uv, C.c_float), _p(urr, C.c_float),
+                       _p(pl, C.c_int), _p(va, C.c_uint8), _p(md, C.c_uint8), _p(sf, C.c_float), C.c_float(th), _p(bi, C.c_int), _p(bd, C.c_int))
+    return bi[:len(va)].copy(), bd[:len(va)].copy(), n
+
+
+def search_for_triangulation(F1, node1, skip1, ur1, F2, node2, skip2, ur2, F12, ex, ey, scale_factors2, level_sigma2_2, only_stereo=False, check_ori=True):
+    n1 = np.ascontiguousarray(node1, np.int32); s1 = np.ascontiguousarray(skip1, np.uint8); u1 = np.ascontiguousarray(ur1, np.float32)
+    n2 = np.ascontiguousarray(node2, np.int32); s2 = np.ascontiguousarray(skip2, np.uint8); u2 = np.ascontiguousarray(ur2, np.float32)
+    Fm = np.ascontiguousarray(F12, np.float32).reshape(-1); sf = np.ascontiguousarray(scale_factors2, np.float32); sg = np.ascontiguousarray(level_sigma2_2, np.float32)
+    m12 = np.zeros(max(F1.N, 1), np.int32)
+    n = lib().orc_search_for_triangulation(C.byref(F1), _p(n1, C.c_int), _p(s1, C.c_uint8), _p(u1, C.c_float), None, C.byref(F2), _p(n2, C.c_int), _p(s2, C.c_uint8),
+                                           _p(u2, C.c_float), None, _p(Fm, C.c_float), C.c_float(ex), C.c_float(ey), _p(sf, C.c_float), _p(sg, C.c_float),
+                                           int(only_stereo), int(check_ori), _p(m12, C.c_int))
+    return m12[:F1.N].copy(), n
+
+
 def hamming_knn2(q, t):
     q = np.ascontiguousarray(q, np.uint8); t = np.ascontiguousarray(t, np.uint8)
     bi = np.zeros(len(q), np.int32); bd = np.zeros(len(q), np.int32); sd = np.zeros(len(q), np.int32)

@@ -103,3 +103,65 @@ def test_search_for_initialization(ctx, oracle, frames):
     e12, _, en = m.SearchForInitialization(k1[:0], d1[:0], prev[:0], 100)
     assert len(e12) == 0 and en == 0
     m.close()
+
+
+def test_fuse_search(ctx, oracle, frames):
+    """ORBmatcher::Fuse search part: per map point the best keypoint after the level / chi-square tests, mono and stereo keypoints mixed."""
+    (k1, d1), (k2, d2) = frames
+    rng = np.random.default_rng(4)
+    n = len(k1)
+    uv = np.stack([k1["x"] - 4 + rng.normal(0, 0.8, n), k1["y"] + rng.normal(0, 0.8, n)], axis=1).astype(np.float32)
+    z = rng.uniform(4, 40, n).astype(np.float32)
+    bf = np.float32(386.1448)
+    ur = (uv[:, 0] - bf / z).astype(np.float32)
+    pred = np.clip(k1["octave"] + rng.integers(0, 2, n), 0, 7).astype(np.int32)  # the matching keypoint is at level pred or pred - 1
+    valid = (rng.uniform(size=n) < 0.9).astype(np.uint8)
+    u_right2 = np.where(rng.uniform(size=len(k2)) < 0.5, k2["x"] - bf / rng.uniform(4, 40, len(k2)), -1.0).astype(np.float32)
+    inv_sigma2 = (1.0 / (SF * SF)).astype(np.float32)
+    static = (rng.uniform(size=len(k2)) < 0.95).astype(np.uint8)
+    m = ORBmatcher(ctx=ctx)
+    m.set_frame(k2, d2, BOUNDS)
+    F2 = oracle.make_frame(k2, d2, BOUNDS)
+    for th, ks in ((3.0, None), (5.0, static)):
+        gi, gd, ng = m.Fuse(u_right2, inv_sigma2, uv, ur, pred, valid, d1, SF, th, ks)
+        ri, rd, nr = oracle.fuse(F2, u_right2, inv_sigma2, uv, ur, pred, valid, d1, SF, th, ks)
+        assert np.array_equal(gi, ri) and np.array_equal(gd, rd) and ng == nr
+        assert ng > 150 and (gi[valid == 0] == -1).all()
+    m.close()
+
+
+def test_search_for_triangulation(ctx, oracle, frames):
+    """ORBmatcher::SearchForTriangulation: same-node candidates, epipole / epipolar-line tests, the reference's last-minimum tie rule,
+    rotation histogram.  The vocabulary node of a feature is emulated by a coarse image cell (a few hundred features per node)."""
+    (k1, d1), (k2, d2) = frames
+    rng = np.random.default_rng(6)
+    node = lambda k, dx: ((np.clip(k["x"] + dx, 0, W - 1) // 120).astype(np.int32) * 4 + (k["y"] // 100).astype(np.int32))
+    node1, node2 = node(k1, 0.0), node(k2, 4.0)
+    node1[rng.uniform(size=len(k1)) < 0.05] = -1
+    skip1 = (rng.uniform(size=len(k1)) < 0.3).astype(np.uint8); skip2 = (rng.uniform(size=len(k2)) < 0.3).astype(np.uint8)
+    bf = 386.1448
+    ur1 = np.where(rng.uniform(size=len(k1)) < 0.3, k1["x"] - bf / rng.uniform(4, 40, len(k1)), -1.0).astype(np.float32)
+    ur2 = np.where(rng.uniform(size=len(k2)) < 0.3, k2["x"] - bf / rng.uniform(4, 40, len(k2)), -1.0).astype(np.float32)
+    # pure sideways translation between the key frames: F12 = [t]_x in normalised coordinates -> horizontal epipolar lines, epipole at infinity
+    Kinv = np.linalg.inv(np.array([[FX, 0, CX], [0, FY, CY], [0, 0, 1]]))
+    tx = np.array([[0, 0, 0], [0, 0, -1.0], [0, 1.0, 0]])
+    F12 = (Kinv.T @ tx @ Kinv).astype(np.float32)
+    sigma2 = (SF * SF).astype(np.float32)
+    F1o = oracle.make_frame(k1, d1, BOUNDS); F2o = oracle.make_frame(k2, d2, BOUNDS)
+    for only_stereo, (ex, ey) in ((False, (-5000.0, 170.0)), (False, (600.0, 170.0)), (True, (-5000.0, 170.0))):
+        m = ORBmatcher(0.6, True, ctx=ctx)
+        g12, ng = m.SearchForTriangulation(k1, d1, node1, skip1, ur1, k2, d2, node2, skip2, ur2, F12, ex, ey, SF, sigma2, only_stereo)
+        r12, nr = oracle.search_for_triangulation(F1o, node1, skip1, ur1, F2o, node2, skip2, ur2, F12, ex, ey, SF, sigma2, only_stereo, True)
+        assert np.array_equal(g12, r12) and ng == nr
+        assert ng > (20 if only_stereo else 150)
+        assert (g12[skip1 == 1] == -1).all() and (g12[node1 < 0] == -1).all()
+        m.close()
+    # duplicate descriptors in KF2 inside one node: the reference keeps the last one that reaches the minimum
+    k2b = np.concatenate([k2, k2[:50]]); d2b = np.concatenate([d2, d2[:50]])
+    node2b = np.concatenate([node2, node2[:50]]); skip2b = np.concatenate([skip2, np.zeros(50, np.uint8)]); ur2b = np.concatenate([ur2, ur2[:50]])
+    F2b = oracle.make_frame(k2b, d2b, BOUNDS)
+    m = ORBmatcher(0.6, False, ctx=ctx)
+    g12, ng = m.SearchForTriangulation(k1, d1, node1, skip1, ur1, k2b, d2b, node2b, skip2b, ur2b, F12, -5000.0, 170.0, SF, sigma2, False)
+    r12, nr = oracle.search_for_triangulation(F1o, node1, skip1, ur1, F2b, node2b, skip2b, ur2b, F12, -5000.0, 170.0, SF, sigma2, False, False)
+    assert np.array_equal(g12, r12) and ng == nr and (g12 >= len(k2)).sum() > 5
+    m.close()

@@ -1,0 +1,84 @@
+"""CPU known-answer tests of the matcher oracle (oracle/match_oracle.cpp): Fuse search and SearchForTriangulation rules on hand-built frames."""
+import numpy as np
+
+from cube_slam_amd.orb import KEYPOINT_DTYPE
+
+BOUNDS = (0.0, 640.0, 0.0, 480.0)
+SF = np.float32(1.2) ** np.arange(8, dtype=np.float32)
+
+
+def _keys(xy, octave=0, angle=0.0):
+    k = np.zeros(len(xy), KEYPOINT_DTYPE)
+    k["x"] = [p[0] for p in xy]; k["y"] = [p[1] for p in xy]
+    k["octave"] = octave; k["angle"] = angle; k["size"] = 31
+    return k
+
+
+def _desc(rng, n):
+    return rng.integers(0, 256, (n, 32), dtype=np.uint8)
+
+
+def _flip(d, nbits):
+    d = d.copy()
+    for b in range(nbits):
+        d[b // 8] ^= np.uint8(1 << (b % 8))
+    return d
+
+
+def test_fuse_rules(oracle):
+    rng = np.random.default_rng(0)
+    keys = _keys([(100, 100), (101, 100), (100.5, 100), (300, 300)], octave=np.array([0, 0, 2, 0]))
+    base = _desc(rng, 1)[0]
+    desc = np.stack([_flip(base, 5), _flip(base, 5), base, _desc(rng, 1)[0]])  # kp 2 matches exactly but sits two levels up
+    F = oracle.make_frame(keys, desc, BOUNDS)
+    inv_s2 = (1.0 / (SF * SF)).astype(np.float32)
+    mono = np.full(4, -1.0, np.float32)
+    uv = np.array([[100.2, 100.0]], np.float32)
+    bi, bd, n = oracle.fuse(F, mono, inv_s2, uv, [50.0], [0], [1], base[None], SF, 3.0)
+    assert (bi[0], bd[0], n) == (0, 5, 1), "level filter drops kp 2; kps 0 and 1 tie at 5 bits, the first in GetFeaturesInArea order wins"
+    bi, bd, n = oracle.fuse(F, mono, inv_s2, uv, [50.0], [2], [1], base[None], SF, 3.0)
+    assert (bi[0], bd[0], n) == (2, 0, 1), "predicted level 2 accepts levels 1..2"
+    far = np.array([[102.6, 100.0]], np.float32)  # ex^2 = 6.76 / 2.56 > 5.99 for kp 0/1 at level 0; radius th * 1.0 = 3 still covers them
+    bi, bd, n = oracle.fuse(F, mono, inv_s2, far, [50.0], [0], [1], base[None], SF, 3.0)
+    assert (bi[0], n) == (1, 1), "kp 0 fails the chi-square test (2.6^2 > 5.99), kp 1 (1.6^2) passes"
+    stereo = np.array([40.0, -1, -1, -1], np.float32)
+    bi, bd, n = oracle.fuse(F, stereo, inv_s2, uv, [49.0], [0], [1], base[None], SF, 3.0)
+    bi2, _, _ = oracle.fuse(F, stereo, inv_s2, uv, [42.0], [0], [1], base[None], SF, 3.0)
+    assert bi[0] == 1 and bi2[0] == 0, "er = 9 rejects the stereo keypoint (81 > 7.8), er = 2 keeps it (4.04 < 7.8)"
+    bi, bd, n = oracle.fuse(F, mono, inv_s2, uv, [50.0], [0], [0], base[None], SF, 3.0)
+    assert (bi[0], bd[0], n) == (-1, 256, 0), "invalid map points are skipped"
+    bi, bd, n = oracle.fuse(F, mono, inv_s2, uv, [50.0], [0], [1], _flip(base, 70)[None], SF, 3.0)
+    assert bd[0] == 65 and n == 0, "a best distance above TH_LOW = 50 is reported but not counted as fused"
+
+
+def test_triangulation_rules(oracle):
+    rng = np.random.default_rng(1)
+    k1 = _keys([(100, 100)])
+    base = _desc(rng, 1)[0]
+    # KF2: same-node candidates on the epipolar line y = 100 (pure x translation), one off the line, one in another node
+    k2 = _keys([(110, 100), (120, 100), (130, 100), (140, 130), (150, 100)])
+    d2 = np.stack([_flip(base, 10), _flip(base, 4), _flip(base, 4), base, base])
+    node1 = [7]; node2 = [7, 7, 7, 7, 8]
+    F12 = np.array([[0, 0, 0], [0, 0, -1], [0, 1, 0]], np.float32)  # l = x1' F12 = (0, -1, y1): distance to the line y = y1
+    sig2 = (SF * SF).astype(np.float32)
+    F1 = oracle.make_frame(k1, base[None], BOUNDS); F2 = oracle.make_frame(k2, d2, BOUNDS)
+    no = np.zeros(5, np.uint8); mono1 = [-1.0]; mono2 = np.full(5, -1.0, np.float32)
+    m, n = oracle.search_for_triangulation(F1, node1, [0], mono1, F2, node2, no, mono2, F12, -1e4, 100.0, SF, sig2, False, False)
+    assert (m[0], n) == (2, 1), "kp 3 (exact) is 30 px off the epipolar line, kp 4 is in another node; 1 and 2 tie at 4 bits and the LAST one stays"
+    skip2 = np.array([0, 0, 1, 0, 0], np.uint8)
+    m, _ = oracle.search_for_triangulation(F1, node1, [0], mono1, F2, node2, skip2, mono2, F12, -1e4, 100.0, SF, sig2, False, False)
+    assert m[0] == 1, "features that already have a map point are skipped"
+    m, _ = oracle.search_for_triangulation(F1, node1, [0], mono1, F2, node2, no, mono2, F12, 121.0, 100.0, SF, sig2, False, False)
+    assert m[0] == 0, "mono-mono pairs closer than 10 px (sqrt(100 * scale)) to the epipole are rejected: kps 1 and 2"
+    st2 = np.array([-1, 100.0, -1, -1, -1], np.float32)
+    m, _ = oracle.search_for_triangulation(F1, node1, [0], mono1, F2, node2, no, st2, F12, 121.0, 100.0, SF, sig2, False, False)
+    assert m[0] == 1, "a stereo keypoint is exempt from the epipole test"
+    m, n = oracle.search_for_triangulation(F1, node1, [0], mono1, F2, node2, no, st2, F12, -1e4, 100.0, SF, sig2, True, False)
+    assert (m[0], n) == (-1, 0), "bOnlyStereo needs both keypoints stereo"
+    m, n = oracle.search_for_triangulation(F1, [-1], [0], mono1, F2, node2, no, mono2, F12, -1e4, 100.0, SF, sig2, False, False)
+    assert n == 0
+    k2hi = k2.copy(); k2hi["octave"][3] = 7  # sigma2 = 1.2^14 = 12.8: 30^2 = 900 > 3.84 * 12.8 still rejects; 6 px off passes at level 7
+    k2hi["y"][3] = 106
+    F2h = oracle.make_frame(k2hi, d2, BOUNDS)
+    m, _ = oracle.search_for_triangulation(F1, node1, [0], mono1, F2h, node2, no, mono2, F12, -1e4, 100.0, SF, sig2, False, False)
+    assert m[0] == 3, "36 < 3.84 * 12.84: coarse-level keypoints tolerate a larger epipolar distance, and the exact descriptor wins"
