@@ -186,7 +186,7 @@ struct Params { // device-side view of the graph
     const int *c_cam, *c_cub; const double *c_bbox, *c_info;
     const int *pc_cub, *pc_off; const double *pc_pts;
     double *e_obs, *e_cobs, *e_pc;
-    double *Hpl, *Hll, *bl, *Dinv, *db, *Hpp, *bp, *Hoff; // Hoff: one 6x6 block per camera-cuboid edge (camera rows, cuboid cols)
+    double *Hpl, *HplD, *Hll, *bl, *Dinv, *db, *Hpp, *bp, *Hoff; // HplD: B D^-1 per observation (6x3), refreshed with every damping value; // Hoff: one 6x6 block per camera-cuboid edge (camera rows, cuboid cols)
     double *Jc, *Jp;                                       // numeric Jacobian columns: cobs x 12 x 4, pc x 6 x 3
     double *x;                                             // 6P + 3L
 };
@@ -440,24 +440,74 @@ __global__ void __launch_bounds__(256) ba_lm_dinv(Params G, double lambda) { // 
 
 // wave per block of the reduced system.  slot s < P: diagonal block of pose s; P <= s < P + n_cobs: camera-cuboid block;
 // the rest: camera-camera blocks created by shared landmarks.  trip_*: contributing (obs_u, obs_v) pairs, this rank only.
+// B D^-1 of every observation of this rank (6x3 per observation): each is used by all the pairs its observation takes part in
+// (k(k+1)/2 pairs for a landmark seen k times), so it is formed once here instead of once per pair
+__global__ void __launch_bounds__(256) ba_schur_bd(Params G) { // thread per row of a block: neighbouring lanes touch neighbouring 24-byte rows
+    const long t = (long)G.o_b * 6 + (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long)G.o_e * 6) return;
+    const int u = (int)(t / 6);
+    const double *Bi = G.Hpl + t * 3, *Di = G.Dinv + (long)G.o_pt[u] * 9;
+    const double b0 = Bi[0], b1 = Bi[1], b2 = Bi[2];
+    double *o = G.HplD + t * 3;
+#pragma unroll
+    for (int c = 0; c < 3; c++) o[c] = (b0 * Di[c] + b1 * Di[3 + c]) + b2 * Di[6 + c];
+}
+// 18 doubles of a 6x3 block with nine 16-byte loads (blocks are 144 bytes apart in 256-byte-aligned arenas): the pair loop is bound by
+// the number of gathered lanes per load instruction, not by their width
+__device__ __forceinline__ void load_block18(const double *p, double (&v)[18]) {
+    const double2 *q = reinterpret_cast<const double2 *>(__builtin_assume_aligned(p, 16));
+#pragma unroll
+    for (int k = 0; k < 9; k++) { const double2 t = q[k]; v[2 * k] = t.x; v[2 * k + 1] = t.y; }
+}
+// The 64 pairs of a wave iteration need 128 blocks of 144 bytes from arbitrary places.  A lane fetching its own two blocks makes
+// every load instruction touch 64 different cache lines (the gather cost is per line touched per instruction: 18 instructions x 64
+// lines); instead the wave fetches the 128 blocks cooperatively -- 16 bytes per lane, nine consecutive lanes on one block, so an
+// instruction touches ~11 lines -- into LDS, and every lane then reads its pair from there.  Same arithmetic, same lane -> pair
+// assignment and the same reduction as a per-lane gather, so the sums are bit-identical to it.
 __global__ void __launch_bounds__(256) ba_schur_slots(Params G, int n_slots, const int *slot_off, const int2 *trips, double lambda, double *S) {
-    const int s = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (s >= n_slots) return;
+    __shared__ double2 s_blk[4][64 * 9]; // one operand at a time (B D^-1 of the 64 pairs, then B): 9 KB per wave keeps 16 waves per CU
+    __shared__ int s_idx[4][128];
+    const int wv = threadIdx.x >> 6, s = blockIdx.x * 4 + wv, lane = threadIdx.x & 63;
+    if (s >= n_slots) return; // whole wave; no workgroup barrier below
+    double2 *sb = s_blk[wv];
+    int *si = s_idx[wv];
     double acc[36];
 #pragma unroll
     for (int k = 0; k < 36; k++) acc[k] = 0;
-    for (int q = slot_off[s] + lane; q < slot_off[s + 1]; q += 64) {
-        const int u = trips[q].x, v = trips[q].y;
-        const double *Bi = G.Hpl + (long)u * 18, *Bj = G.Hpl + (long)v * 18, *Di = G.Dinv + (long)G.o_pt[u] * 9;
-        double BD[18];
+    const int qe = slot_off[s + 1];
+    int2 tn = (slot_off[s] + lane < qe) ? trips[slot_off[s] + lane] : make_int2(-1, -1); // the pair list is read one iteration ahead
+    for (int q0 = slot_off[s]; q0 < qe; q0 += 64) {
+        const int2 t = tn;
+        const bool valid = t.x >= 0;
+        if (q0 + 64 < qe) tn = (q0 + 64 + lane < qe) ? trips[q0 + 64 + lane] : make_int2(-1, -1);
+        si[lane] = t.x; si[64 + lane] = t.y;
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        double BD[18], Bj[18];
 #pragma unroll
-        for (int a = 0; a < 6; a++)
+        for (int half = 0; half < 2; half++) {
+            double2 pv[9]; // all requests first, then the LDS stores: a store right after its load would expose every round trip
 #pragma unroll
-            for (int c = 0; c < 3; c++) BD[a * 3 + c] = (Bi[a * 3] * Di[c] + Bi[a * 3 + 1] * Di[3 + c]) + Bi[a * 3 + 2] * Di[6 + c];
+            for (int it = 0; it < 9; it++) {
+                const int p = it * 64 + lane, blk = (p * 7282) >> 16, piece = p - blk * 9; // p / 9 for p < 1152
+                const int id = max(si[half * 64 + blk], 0); // pairs past the end of the list read block 0; their lanes do not accumulate
+                pv[it] = reinterpret_cast<const double2 *>(__builtin_assume_aligned((half == 0 ? G.HplD : G.Hpl) + (long)id * 18, 16))[piece];
+            }
 #pragma unroll
-        for (int a = 0; a < 6; a++)
+            for (int it = 0; it < 9; it++) sb[it * 64 + lane] = pv[it];
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
 #pragma unroll
-            for (int c = 0; c < 6; c++) acc[a * 6 + c] -= (BD[a * 3] * Bj[c * 3] + BD[a * 3 + 1] * Bj[c * 3 + 1]) + BD[a * 3 + 2] * Bj[c * 3 + 2];
+            for (int k = 0; k < 9; k++) { const double2 a = sb[lane * 9 + k]; if (half == 0) { BD[2 * k] = a.x; BD[2 * k + 1] = a.y; } else { Bj[2 * k] = a.x; Bj[2 * k + 1] = a.y; } }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
+        if (valid) {
+#pragma unroll
+            for (int a = 0; a < 6; a++)
+#pragma unroll
+                for (int c = 0; c < 6; c++) acc[a * 6 + c] -= (BD[a * 3] * Bj[c * 3] + BD[a * 3 + 1] * Bj[c * 3 + 1]) + BD[a * 3 + 2] * Bj[c * 3 + 2];
+        }
     }
 #pragma unroll
     for (int k = 0; k < 36; k++) for (int off = 32; off > 0; off >>= 1) acc[k] += __shfl_xor(acc[k], off);
@@ -467,15 +517,23 @@ __global__ void __launch_bounds__(256) ba_schur_slots(Params G, int n_slots, con
         for (int k = 0; k < 36; k++) S[(long)s * 36 + k] = acc[k];
     }
 }
-__global__ void __launch_bounds__(256) ba_schur_b(Params G, const int *pose_off, const int *pose_obs, double *bs) {
+// w_o = B_o (D^-1 b_l) per observation (6 doubles), thread per row: coalesced reads of the 24-byte rows; the per-pose sums below then
+// gather 48 bytes per observation instead of 168
+__global__ void __launch_bounds__(256) ba_schur_bw(Params G, double *w) {
+    const long t = (long)G.o_b * 6 + (long)blockIdx.x * 256 + threadIdx.x;
+    if (t >= (long)G.o_e * 6) return;
+    const int u = (int)(t / 6);
+    const double *Bi = G.Hpl + t * 3, *d = G.db + (long)G.o_pt[u] * 3;
+    w[t] = (Bi[0] * d[0] + Bi[1] * d[1]) + Bi[2] * d[2];
+}
+__global__ void __launch_bounds__(256) ba_schur_b(Params G, const int *pose_off, const int *pose_obs, const double *w, double *bs) {
     const int pi = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (pi >= G.P) return;
     double acc[6] = {0, 0, 0, 0, 0, 0};
     for (int q = pose_off[pi] + lane; q < pose_off[pi + 1]; q += 64) {
-        const int o = pose_obs[q];
-        const double *Bi = G.Hpl + (long)o * 18, *d = G.db + (long)G.o_pt[o] * 3;
-#pragma unroll
-        for (int a = 0; a < 6; a++) acc[a] -= (Bi[a * 3] * d[0] + Bi[a * 3 + 1] * d[1]) + Bi[a * 3 + 2] * d[2];
+        const double2 *wo = reinterpret_cast<const double2 *>(__builtin_assume_aligned(w + (long)pose_obs[q] * 6, 16));
+        const double2 w0 = wo[0], w1 = wo[1], w2 = wo[2];
+        acc[0] -= w0.x; acc[1] -= w0.y; acc[2] -= w1.x; acc[3] -= w1.y; acc[4] -= w2.x; acc[5] -= w2.y;
     }
 #pragma unroll
     for (int k = 0; k < 6; k++) for (int off = 32; off > 0; off >>= 1) acc[k] += __shfl_xor(acc[k], off);
@@ -1424,7 +1482,7 @@ struct cs_ba {
     bool use_band = false, band_twist = false; int band_C = 0, band_Q = 0, band_bc = 0, band_targets = 0;
     int *d_tgt_slot = nullptr, *d_ct_off = nullptr, *d_ct_list = nullptr, *d_cr_off = nullptr, *d_cr_list = nullptr, *d_cq_off = nullptr, *d_cq_list = nullptr;
     uint8_t *d_tgt_tr = nullptr;
-    double *d_bandA = nullptr, *d_bandL = nullptr, *d_cubD = nullptr, *d_cubg = nullptr, *d_brhs = nullptr, *d_ybuf = nullptr, *d_mid = nullptr, *d_xmid = nullptr;
+    double *d_bandA = nullptr, *d_bandL = nullptr, *d_cubD = nullptr, *d_cubg = nullptr, *d_brhs = nullptr, *d_ybuf = nullptr, *d_mid = nullptr, *d_xmid = nullptr, *d_bw = nullptr;
     std::vector<int> h_slot_dst, h_pos, h_col_off, h_rows; std::vector<uint8_t> h_slot_tr;
     std::vector<int> obs_perm; // sorted-by-landmark position -> caller's observation index
     std::vector<double> h_partials;
@@ -1484,8 +1542,10 @@ static int ba_schur(cs_ctx *ctx, cs_ba *b, double lambda) { // Schur part of Blo
     const Params &G = b->G;
     const int nl = G.lm_e - G.lm_b;
     if (nl > 0) CS_LAUNCH(ctx, "ba_lm_dinv", ba_lm_dinv, dim3((nl + 255) / 256), dim3(256), 0, G, lambda);
+    if (G.o_e > G.o_b) CS_LAUNCH(ctx, "ba_schur_bd", ba_schur_bd, dim3((int)(((long)(G.o_e - G.o_b) * 6 + 255) / 256)), dim3(256), 0, G);
     CS_LAUNCH(ctx, "ba_schur_slots", ba_schur_slots, dim3((b->n_slots + 3) / 4), dim3(256), 0, G, b->n_slots, b->d_slot_off, b->d_trips, lambda, b->d_reduce);
-    CS_LAUNCH(ctx, "ba_schur_b", ba_schur_b, dim3((G.P + 3) / 4), dim3(256), 0, G, b->d_pose_off, b->d_pose_obs, b->d_reduce + (long)b->n_slots * 36);
+    if (G.o_e > G.o_b) CS_LAUNCH(ctx, "ba_schur_bw", ba_schur_bw, dim3((int)(((long)(G.o_e - G.o_b) * 6 + 255) / 256)), dim3(256), 0, G, b->d_bw);
+    CS_LAUNCH(ctx, "ba_schur_b", ba_schur_b, dim3((G.P + 3) / 4), dim3(256), 0, G, b->d_pose_off, b->d_pose_obs, b->d_bw, b->d_reduce + (long)b->n_slots * 36);
     return CS_OK;
 }
 static int ba_solve(cs_ctx *ctx, cs_ba *b, double lambda, bool *ok) { // BlockSolver::solve
@@ -1806,6 +1866,8 @@ int cs_ba_create(cs_ctx *ctx, const cs_ba_problem *p, int rank, int world, cs_ba
     A_(dalloc_copy(ctx, b, &G.e_cobs, (const double *)nullptr, (size_t)std::max(p->n_cobs, 1) * 4));
     A_(dalloc_copy(ctx, b, &G.e_pc, (const double *)nullptr, (size_t)std::max(p->n_pc, 1) * 3));
     A_(dalloc_copy(ctx, b, &G.Hpl, (const double *)nullptr, (size_t)std::max(p->n_obs, 1) * 18));
+    A_(dalloc_copy(ctx, b, &G.HplD, (const double *)nullptr, (size_t)std::max(p->n_obs, 1) * 18));
+    A_(dalloc_copy(ctx, b, &b->d_bw, (const double *)nullptr, (size_t)std::max(p->n_obs, 1) * 6));
     A_(dalloc_copy(ctx, b, &G.Hll, (const double *)nullptr, (size_t)std::max(p->n_points, 1) * 9));
     A_(dalloc_copy(ctx, b, &G.bl, (const double *)nullptr, (size_t)std::max(p->n_points, 1) * 3));
     A_(dalloc_copy(ctx, b, &G.Dinv, (const double *)nullptr, (size_t)std::max(p->n_points, 1) * 9));
