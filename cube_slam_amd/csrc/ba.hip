@@ -1548,7 +1548,7 @@ static int ba_schur(cs_ctx *ctx, cs_ba *b, double lambda) { // Schur part of Blo
     CS_LAUNCH(ctx, "ba_schur_b", ba_schur_b, dim3((G.P + 3) / 4), dim3(256), 0, G, b->d_pose_off, b->d_pose_obs, b->d_bw, b->d_reduce + (long)b->n_slots * 36);
     return CS_OK;
 }
-static int ba_solve(cs_ctx *ctx, cs_ba *b, double lambda, bool *ok) { // BlockSolver::solve
+static int ba_solve(cs_ctx *ctx, cs_ba *b, double lambda, bool *ok, bool defer_status = false) { // BlockSolver::solve; defer_status: the caller reads d_status later
     const Params &G = b->G;
     int r = ba_schur(ctx, b, lambda); if (r) return r;
     if (b->world > 1 && b->allreduce) {
@@ -1585,6 +1585,7 @@ static int ba_solve(cs_ctx *ctx, cs_ba *b, double lambda, bool *ok) { // BlockSo
         CS_HIP(ctx, hipMemcpyAsync(G.x, b->d_brhs, sizeof(double) * (size_t)C * 6, hipMemcpyDeviceToDevice, ctx->stream));
         if (Q > 0) CS_LAUNCH(ctx, "ba_cub_back", ba_cub_back, dim3((Q + 63) / 64), dim3(64), 0, C, Q, b->d_cq_off, b->d_cq_list, S, b->d_cubD, b->d_cubg, G.x);
         if (nl > 0) CS_LAUNCH(ctx, "ba_backsub", ba_backsub, dim3((nl + 255) / 256), dim3(256), 0, G);
+        if (defer_status) return CS_OK;
         int status = 0;
         r = cs_d2h(ctx, &status, b->d_status, 1); if (r) return r;
         CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1599,6 +1600,7 @@ static int ba_solve(cs_ctx *ctx, cs_ba *b, double lambda, bool *ok) { // BlockSo
     CS_LAUNCH(ctx, "ba_chol_solve", ba_chol_solve, dim3(1), dim3(256), 0, G.P, b->d_col_off, b->d_rows, b->d_band, b->d_xperm);
     CS_LAUNCH(ctx, "ba_permute", ba_permute, dim3((G.P * 6 + 255) / 256), dim3(256), 0, G.P, b->d_pos, b->d_xperm, G.x, 0);
     if (nl > 0) CS_LAUNCH(ctx, "ba_backsub", ba_backsub, dim3((nl + 255) / 256), dim3(256), 0, G);
+    if (defer_status) return CS_OK;
     int status = 0;
     r = cs_d2h(ctx, &status, b->d_status, 1); if (r) return r;
     CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -1914,7 +1916,7 @@ int cs_ba_create(cs_ctx *ctx, const cs_ba_problem *p, int rank, int world, cs_ba
     A_(dalloc_copy(ctx, b, &b->d_reduce, (const double *)nullptr, (size_t)b->reduce_len));
     A_(dalloc_copy(ctx, b, &b->d_band, (const double *)nullptr, (size_t)b->band_len));
     A_(dalloc_copy(ctx, b, &b->d_xperm, (const double *)nullptr, (size_t)P * 6));
-    A_(dalloc_copy(ctx, b, &b->d_partials, (const double *)nullptr, (size_t)b->max_part));
+    A_(dalloc_copy(ctx, b, &b->d_partials, (const double *)nullptr, (size_t)b->max_part * 3)); // three regions: scale | chi2 of the observations | chi2 of the pose edges
     A_(dalloc_copy(ctx, b, &b->d_scal, (const double *)nullptr, (size_t)std::max(64, world)));
     A_(dalloc_copy(ctx, b, &b->d_bak_cam, (const double *)nullptr, (size_t)p->n_cams * 7));
     A_(dalloc_copy(ctx, b, &b->d_bak_pts, (const double *)nullptr, (size_t)std::max(p->n_points, 1) * 3));
@@ -2002,13 +2004,15 @@ int cs_ba_optimize(cs_ctx *ctx, cs_ba *b, int iterations, const volatile int *st
     const Params &G = b->G;
     cs_ba_stats S;
     memset(&S, 0, sizeof(S));
-    double lambda = 0, ni = 2;
+    double lambda = 0, ni = 2, currentChi = 0;
     int nBad = 0, r;
     const int nl = G.lm_e - G.lm_b;
     auto terminate = [&]() { return stop_flag && *stop_flag; }; // sparse_optimizer.cpp:376, optimization_algorithm_levenberg.cpp:149
     for (int it = 0; it < iterations && !terminate(); it++) { // OptimizationAlgorithmLevenberg::solve :61-164
-        double currentChi, tempChi;
-        r = ba_compute_errors(ctx, b, &currentChi); if (r) return r;
+        // computeActiveErrors: after an accepted trial the residual arrays and chi2 on the device are those of the current state (every
+        // way out of the trial loop with a rejected last trial also leaves this loop), so only the first iteration evaluates them
+        double tempChi;
+        if (it == 0) { r = ba_compute_errors(ctx, b, &currentChi); if (r) return r; }
         tempChi = currentChi;
         const double iniChi = currentChi;
         if (it == 0) S.chi2_init = currentChi;
@@ -2039,13 +2043,37 @@ int cs_ba_optimize(cs_ctx *ctx, cs_ba *b, int iterations, const volatile int *st
             if (G.L) CS_HIP(ctx, hipMemcpyAsync(b->d_bak_pts, G.pts, sizeof(double) * (size_t)G.L * 3, hipMemcpyDeviceToDevice, ctx->stream));
             if (G.n_cub) CS_HIP(ctx, hipMemcpyAsync(b->d_bak_cub, G.cub, sizeof(double) * (size_t)G.n_cub * 7, hipMemcpyDeviceToDevice, ctx->stream));
             bool ok2 = true;
-            r = ba_solve(ctx, b, lambda, &ok2); if (r) return r;
             const int nbs = (int)(((long)G.P * 6 + (long)nl * 3 + 255) / 256);
-            CS_LAUNCH(ctx, "ba_scale", ba_scale, dim3(nbs), dim3(256), 0, G, lambda, b->d_partials);
-            double scale = sum_partials(ctx, b, nbs);
-            r = allreduce_scalars(ctx, b, &scale, 1); if (r) return r;
-            CS_LAUNCH(ctx, "ba_update", ba_update, dim3((G.n_cams + G.n_cub + nl * 3 + 255) / 256), dim3(256), 0, G);
-            r = ba_compute_errors(ctx, b, &tempChi); if (r) return r;
+            double scale;
+            if (b->world == 1) { // one host round trip per trial: solve, scale, update and the new residuals are enqueued back to back
+                r = ba_solve(ctx, b, lambda, &ok2, true); if (r) return r;
+                const int nb1 = (G.o_e - G.o_b + 255) / 256, nb2 = (G.pose_edges && G.n_cobs + G.n_pc > 0) ? (G.n_cobs + G.n_pc + 255) / 256 : 0, mp = b->max_part;
+                CS_LAUNCH(ctx, "ba_scale", ba_scale, dim3(nbs), dim3(256), 0, G, lambda, b->d_partials);
+                CS_LAUNCH(ctx, "ba_update", ba_update, dim3((G.n_cams + G.n_cub + nl * 3 + 255) / 256), dim3(256), 0, G);
+                if (nb1 > 0) CS_LAUNCH(ctx, "ba_err_obs", ba_err_obs, dim3(nb1), dim3(256), 0, G, b->d_partials + mp);
+                if (nb2 > 0) CS_LAUNCH(ctx, "ba_err_pose_edges", ba_err_pose_edges, dim3(nb2), dim3(256), 0, G, b->d_partials + 2 * mp);
+                int status = 0;
+                b->h_partials.resize((size_t)mp * 3);
+                r = cs_d2h(ctx, &status, b->d_status, 1); if (r) return r;
+                r = cs_d2h(ctx, b->h_partials.data(), b->d_partials, (size_t)mp * 3); if (r) return r;
+                CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                ok2 = status == 0;
+                scale = 0;
+                for (int i = 0; i < nbs; i++) scale += b->h_partials[i];
+                double chi = 0, c1 = 0, c2 = 0; // same order of additions as ba_compute_errors
+                for (int i = 0; i < nb1; i++) c1 += b->h_partials[(size_t)mp + i];
+                for (int i = 0; i < nb2; i++) c2 += b->h_partials[(size_t)2 * mp + i];
+                if (nb1 > 0) chi += c1;
+                if (nb2 > 0) chi += c2;
+                tempChi = chi;
+            } else {
+                r = ba_solve(ctx, b, lambda, &ok2); if (r) return r;
+                CS_LAUNCH(ctx, "ba_scale", ba_scale, dim3(nbs), dim3(256), 0, G, lambda, b->d_partials);
+                scale = sum_partials(ctx, b, nbs);
+                r = allreduce_scalars(ctx, b, &scale, 1); if (r) return r;
+                CS_LAUNCH(ctx, "ba_update", ba_update, dim3((G.n_cams + G.n_cub + nl * 3 + 255) / 256), dim3(256), 0, G);
+                r = ba_compute_errors(ctx, b, &tempChi); if (r) return r;
+            }
             if (!ok2) tempChi = std::numeric_limits<double>::max();
             rho = (currentChi - tempChi);
             scale += 1e-3;
