@@ -442,15 +442,17 @@ __global__ void __launch_bounds__(256) ba_lm_dinv(Params G, double lambda) { // 
 // the rest: camera-camera blocks created by shared landmarks.  trip_*: contributing (obs_u, obs_v) pairs, this rank only.
 // B D^-1 of every observation of this rank (6x3 per observation): each is used by all the pairs its observation takes part in
 // (k(k+1)/2 pairs for a landmark seen k times), so it is formed once here instead of once per pair
-__global__ void __launch_bounds__(256) ba_schur_bd(Params G) { // thread per row of a block: neighbouring lanes touch neighbouring 24-byte rows
+__global__ void __launch_bounds__(256) ba_schur_bd(Params G, double *w) { // thread per row of a block: neighbouring lanes touch neighbouring 24-byte rows
     const long t = (long)G.o_b * 6 + (long)blockIdx.x * 256 + threadIdx.x;
     if (t >= (long)G.o_e * 6) return;
     const int u = (int)(t / 6);
-    const double *Bi = G.Hpl + t * 3, *Di = G.Dinv + (long)G.o_pt[u] * 9;
+    const long pt = G.o_pt[u];
+    const double *Bi = G.Hpl + t * 3, *Di = G.Dinv + pt * 9, *d = G.db + pt * 3;
     const double b0 = Bi[0], b1 = Bi[1], b2 = Bi[2];
     double *o = G.HplD + t * 3;
 #pragma unroll
     for (int c = 0; c < 3; c++) o[c] = (b0 * Di[c] + b1 * Di[3 + c]) + b2 * Di[6 + c];
+    w[t] = (b0 * d[0] + b1 * d[1]) + b2 * d[2]; // row of B (D^-1 b_l): summed per pose by ba_schur_b
 }
 // 18 doubles of a 6x3 block with nine 16-byte loads (blocks are 144 bytes apart in 256-byte-aligned arenas): the pair loop is bound by
 // the number of gathered lanes per load instruction, not by their width
@@ -517,15 +519,7 @@ __global__ void __launch_bounds__(256) ba_schur_slots(Params G, int n_slots, con
         for (int k = 0; k < 36; k++) S[(long)s * 36 + k] = acc[k];
     }
 }
-// w_o = B_o (D^-1 b_l) per observation (6 doubles), thread per row: coalesced reads of the 24-byte rows; the per-pose sums below then
-// gather 48 bytes per observation instead of 168
-__global__ void __launch_bounds__(256) ba_schur_bw(Params G, double *w) {
-    const long t = (long)G.o_b * 6 + (long)blockIdx.x * 256 + threadIdx.x;
-    if (t >= (long)G.o_e * 6) return;
-    const int u = (int)(t / 6);
-    const double *Bi = G.Hpl + t * 3, *d = G.db + (long)G.o_pt[u] * 3;
-    w[t] = (Bi[0] * d[0] + Bi[1] * d[1]) + Bi[2] * d[2];
-}
+// per-pose sums of the rows w = B (D^-1 b_l) that ba_schur_bd wrote (48 bytes per observation instead of a 168-byte gather)
 __global__ void __launch_bounds__(256) ba_schur_b(Params G, const int *pose_off, const int *pose_obs, const double *w, double *bs) {
     const int pi = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (pi >= G.P) return;
@@ -1542,9 +1536,8 @@ static int ba_schur(cs_ctx *ctx, cs_ba *b, double lambda) { // Schur part of Blo
     const Params &G = b->G;
     const int nl = G.lm_e - G.lm_b;
     if (nl > 0) CS_LAUNCH(ctx, "ba_lm_dinv", ba_lm_dinv, dim3((nl + 255) / 256), dim3(256), 0, G, lambda);
-    if (G.o_e > G.o_b) CS_LAUNCH(ctx, "ba_schur_bd", ba_schur_bd, dim3((int)(((long)(G.o_e - G.o_b) * 6 + 255) / 256)), dim3(256), 0, G);
+    if (G.o_e > G.o_b) CS_LAUNCH(ctx, "ba_schur_bd", ba_schur_bd, dim3((int)(((long)(G.o_e - G.o_b) * 6 + 255) / 256)), dim3(256), 0, G, b->d_bw);
     CS_LAUNCH(ctx, "ba_schur_slots", ba_schur_slots, dim3((b->n_slots + 3) / 4), dim3(256), 0, G, b->n_slots, b->d_slot_off, b->d_trips, lambda, b->d_reduce);
-    if (G.o_e > G.o_b) CS_LAUNCH(ctx, "ba_schur_bw", ba_schur_bw, dim3((int)(((long)(G.o_e - G.o_b) * 6 + 255) / 256)), dim3(256), 0, G, b->d_bw);
     CS_LAUNCH(ctx, "ba_schur_b", ba_schur_b, dim3((G.P + 3) / 4), dim3(256), 0, G, b->d_pose_off, b->d_pose_obs, b->d_bw, b->d_reduce + (long)b->n_slots * 36);
     return CS_OK;
 }
@@ -1576,13 +1569,13 @@ static int ba_solve(cs_ctx *ctx, cs_ba *b, double lambda, bool *ok, bool defer_s
             }
             if (lds_mid > 64 * 1024) CS_HIP(ctx, hipFuncSetAttribute((const void *)ba_band_mid, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_mid));
             CS_LAUNCH(ctx, "ba_band_twist_factor", ba_band_twist_factor, dim3(2), dim3(BAND_NT), lds, C, Bc, b->d_bandA, b->d_brhs, b->d_bandL, b->d_ybuf, b->d_mid, b->d_status);
-            CS_LAUNCH(ctx, "ba_band_mid", ba_band_mid, dim3(1), dim3(256), lds_mid, C, Bc, b->d_mid, b->d_xmid, b->d_brhs, b->d_status);
-            CS_LAUNCH(ctx, "ba_band_twist_back", ba_band_twist_back, dim3(2), dim3(BAND_NT), lds, C, Bc, b->d_bandL, b->d_ybuf, b->d_xmid, b->d_brhs);
+            CS_LAUNCH(ctx, "ba_band_mid", ba_band_mid, dim3(1), dim3(256), lds_mid, C, Bc, b->d_mid, b->d_xmid, G.x, b->d_status);
+            CS_LAUNCH(ctx, "ba_band_twist_back", ba_band_twist_back, dim3(2), dim3(BAND_NT), lds, C, Bc, b->d_bandL, b->d_ybuf, b->d_xmid, G.x);
         } else {
             if (lds > 64 * 1024) CS_HIP(ctx, hipFuncSetAttribute((const void *)ba_band_chol, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             CS_LAUNCH(ctx, "ba_band_chol", ba_band_chol, dim3(1), dim3(BAND_NT), lds, C, Bc, b->d_bandA, b->d_bandL, b->d_brhs, b->d_ybuf, b->d_status);
         }
-        CS_HIP(ctx, hipMemcpyAsync(G.x, b->d_brhs, sizeof(double) * (size_t)C * 6, hipMemcpyDeviceToDevice, ctx->stream));
+        if (!b->band_twist) CS_HIP(ctx, hipMemcpyAsync(G.x, b->d_brhs, sizeof(double) * (size_t)C * 6, hipMemcpyDeviceToDevice, ctx->stream));
         if (Q > 0) CS_LAUNCH(ctx, "ba_cub_back", ba_cub_back, dim3((Q + 63) / 64), dim3(64), 0, C, Q, b->d_cq_off, b->d_cq_list, S, b->d_cubD, b->d_cubg, G.x);
         if (nl > 0) CS_LAUNCH(ctx, "ba_backsub", ba_backsub, dim3((nl + 255) / 256), dim3(256), 0, G);
         if (defer_status) return CS_OK;
