@@ -648,15 +648,16 @@ template <int CTRL> __device__ __forceinline__ double dpp_f64(double v) {
     const int lo = __builtin_amdgcn_update_dpp(0, __double2loint(v), CTRL, 0xf, 0xf, false), hi = __builtin_amdgcn_update_dpp(0, __double2hiint(v), CTRL, 0xf, 0xf, false);
     return __hiloint2double(hi, lo);
 }
+constexpr int BAND_YB = 28; // doubles per column in ybuf: y_j (6), lower triangle of L_jj^-1 (21), pad
 struct BandLds { double *W, *bw, *yj, *Linv, *part; int *pair_d; };
 __device__ __forceinline__ BandLds band_lds(double *sh, int Bc) {
     const int NB = Bc + 1, NS = Bc + 2, CS = NB * 36;
     BandLds L;
-    L.W = sh; L.bw = L.W + (long)NS * CS; L.yj = L.bw + NS * 6; L.Linv = L.yj + 6; L.part = L.Linv + 6; // part: 48 doubles; the factor of the current diagonal block (36)
-    L.pair_d = (int *)(L.part + 48); // pair -> (di << 8 | dk)
+    L.W = sh; L.bw = L.W + (long)NS * CS; L.yj = L.bw + NS * 6; L.Linv = L.yj + 6; L.part = L.Linv + 6; // part: 64 doubles; the factor of the current diagonal block (36) and the lower triangle of its inverse (21)
+    L.pair_d = (int *)(L.part + 64); // pair -> (di << 8 | dk)
     return L;
 }
-static size_t band_lds_bytes(int Bc) { return sizeof(double) * ((size_t)(Bc + 2) * (Bc + 1) * 36 + (size_t)(Bc + 2) * 6 + 6 + 6 + 48) + sizeof(int) * (size_t)std::max(1, Bc * (Bc + 1) / 2); }
+static size_t band_lds_bytes(int Bc) { return sizeof(double) * ((size_t)(Bc + 2) * (Bc + 1) * 36 + (size_t)(Bc + 2) * 6 + 6 + 6 + 64) + sizeof(int) * (size_t)std::max(1, Bc * (Bc + 1) / 2); }
 
 // Eliminates local columns 0..ne-1 (L to Lf, y_j and 1/diag to ybuf), forward solve fused.  LDS: a ring of Bc+2 columns (the extra
 // slot receives column j+Bc+1 while column j is processed) and the matching right-hand-side window.  On return the window holds
@@ -664,7 +665,7 @@ static size_t band_lds_bytes(int Bc) { return sizeof(double) * ((size_t)(Bc + 2)
 typedef double band_v4d __attribute__((ext_vector_type(4)));
 template <int NT> __device__ __forceinline__ bool band_factor(const BandView &V, const BandLds &S, double *Lf, double *ybuf) {
     const int Bc = V.Bc, NB = Bc + 1, NS = Bc + 2, CS = NB * 36;
-    double *W = S.W, *bw = S.bw, *yj = S.yj, *Linv = S.Linv;
+    double *W = S.W, *bw = S.bw, *yj = S.yj;
     int *pair_d = S.pair_d;
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     for (int pr = tid; pr < Bc * (Bc + 1) / 2; pr += NT) {
@@ -696,7 +697,7 @@ template <int NT> __device__ __forceinline__ bool band_factor(const BandView &V,
     const int k0 = lane >> 4;
 #pragma unroll
     for (int q = 0; q < 2; q++) {
-        const int tl = wave + q * (NT / 64);
+        const int tl = wave >= 1 ? (wave - 1) + q * (NT / 64 - 1) : 99; // wave 0 owns the pivot and its bookkeeping, the other five the ten tiles
         int ti = 0;
         while ((ti + 1) * (ti + 2) / 2 <= tl) ti++;
         const int tj = tl - ti * (ti + 1) / 2;
@@ -739,8 +740,8 @@ template <int NT> __device__ __forceinline__ bool band_factor(const BandView &V,
         // with the explicit inverse are independent dot products instead of a 16-deep dependent chain -- no cross-lane traffic and no
         // barrier between the pivot and the panel (a shuffle-based version on six lanes cost 0.86 us per column).  The other waves wait.
         BP(0);
+        double Lr[6][6], Mi[6][6], invs[6], yv[6];
         if (tid < 64) {
-            double Lr[6][6], Mi[6][6], invs[6], yv[6];
 #pragma unroll
             for (int r = 0; r < 6; r++)
 #pragma unroll
@@ -798,13 +799,9 @@ template <int NT> __device__ __forceinline__ bool band_factor(const BandView &V,
 #pragma unroll
                 for (int c = 0; c < 6; c++) blk[c] = row[c];
             }
-            if (tid == 0) { // published next to the window (not over A_jj, which slower lanes may still be reading)
+            if (tid == 0) { // the other waves only need y_j before the barrier
 #pragma unroll
-                for (int r = 0; r < 6; r++) {
-#pragma unroll
-                    for (int c = 0; c < 6; c++) S.part[r * 6 + c] = c <= r ? Lr[r][c] : 0.0;
-                    Linv[r] = invs[r]; yj[r] = yv[r];
-                }
+                for (int r = 0; r < 6; r++) yj[r] = yv[r];
             }
         }
         BP(2);
@@ -871,8 +868,16 @@ template <int NT> __device__ __forceinline__ bool band_factor(const BandView &V,
         }
         }
         BP(6);
-        for (int i = tid; i < (nd + 1) * 36; i += NT) Lf[(long)(V.lf_base + j) * CS + i] = i < 36 ? S.part[i] : Wc[i];
-        if (tid < 12) ybuf[(long)(V.lf_base + j) * 12 + tid] = tid < 6 ? yj[tid] : Linv[tid - 6]; // a buffer this kernel has not read before: no stale L1 line possible
+        for (int i = 36 + tid; i < (nd + 1) * 36; i += NT) Lf[(long)(V.lf_base + j) * CS + i] = Wc[i]; // the panel; the diagonal block comes from wave 0's registers
+        if (tid == 0) { // L_jj, y_j and L_jj^-1 (lower, packed) straight from registers to global memory, while the other waves update
+            double *Lo = Lf + (long)(V.lf_base + j) * CS, *yo = ybuf + (long)(V.lf_base + j) * BAND_YB; // buffers this kernel has not read before: no stale L1 line possible
+#pragma unroll
+            for (int r = 0; r < 6; r++) {
+                yo[r] = yv[r];
+#pragma unroll
+                for (int c = 0; c < 6; c++) { Lo[r * 6 + c] = c <= r ? Lr[r][c] : 0.0; if (c <= r) yo[6 + r * (r + 1) / 2 + c] = Mi[r][c]; }
+            }
+        }
         BP(7);
         if (cn < V.n) {
             double *dst = W + (long)scn * CS;
@@ -905,7 +910,7 @@ template <int NT> __device__ __forceinline__ void band_back(const BandView &V, c
     const int R = V.n - V.ne;
     for (int i = tid; i < R * 6; i += NT) { const int t = i / 6; xw[((V.ne + t) % NS) * 6 + i % 6] = xtail[(long)(xtail_rev ? R - 1 - t : t) * 6 + i % 6]; }
     const int KC = (NS - 1) / 2, CB = KC * CS;           // chunk: KC columns of CS doubles; buffers W[0..CB) and W[CB..2CB), >= CS doubles left for ych
-    double *ych = W + 2 * (long)CB;                      // 2 x KC x 12 (y_j, 1/diag) -- fits: NS*CS >= 2*CB + 24*KC for Bc >= 1
+    double *ych = W + 2 * (long)CB;                      // 2 x KC x BAND_YB (y_j, L_jj^-1) -- fits: (NS - 2 KC) * CS >= CS >= 56 * KC for Bc >= 1
     const int nchunk = (C + KC - 1) / KC;
     auto chunk_lo = [&](int ch) { return C - (ch + 1) * KC < 0 ? 0 : C - (ch + 1) * KC; }; // chunk ch covers columns [lo, hi)
     auto chunk_hi = [&](int ch) { return C - ch * KC; };
@@ -915,16 +920,16 @@ template <int NT> __device__ __forceinline__ void band_back(const BandView &V, c
         const int lo = chunk_lo(ch), n = (chunk_hi(ch) - lo) * CS;
 #pragma unroll
         for (int u = 0; u < UPF; u++) { const int i = tid + u * NT; pf[u] = i < n ? __builtin_nontemporal_load(Lf + (long)(V.lf_base + lo) * CS + i) : 0.0; }
-        const int ny = (chunk_hi(ch) - lo) * 12;
-        pfy = tid < ny ? __builtin_nontemporal_load(ybuf + (long)(V.lf_base + lo) * 12 + tid) : 0.0;
+        const int ny = (chunk_hi(ch) - lo) * BAND_YB;
+        pfy = tid < ny ? __builtin_nontemporal_load(ybuf + (long)(V.lf_base + lo) * BAND_YB + tid) : 0.0;
     };
     auto commit = [&](int ch) {
         const int lo = chunk_lo(ch), n = (chunk_hi(ch) - lo) * CS;
         double *dst = W + (long)(ch & 1) * CB;
 #pragma unroll
         for (int u = 0; u < UPF; u++) { const int i = tid + u * NT; if (i < n) dst[i] = pf[u]; }
-        const int ny = (chunk_hi(ch) - lo) * 12;
-        if (tid < ny) ych[(ch & 1) * KC * 12 + tid] = pfy;
+        const int ny = (chunk_hi(ch) - lo) * BAND_YB;
+        if (tid < ny) ych[(ch & 1) * KC * BAND_YB + tid] = pfy;
     };
     if (nchunk > 0) { issue(0); commit(0); }
     lds_barrier();
@@ -934,31 +939,42 @@ template <int NT> __device__ __forceinline__ void band_back(const BandView &V, c
         if (ch + 1 < nchunk) issue(ch + 1);
         if (tid < 64) {
             const int lo = chunk_lo(ch);
-            const double *Lb0 = W + (long)(ch & 1) * CB, *yb0 = ych + (ch & 1) * KC * 12;
+            const double *Lb0 = W + (long)(ch & 1) * CB, *yb0 = ych + (ch & 1) * KC * BAND_YB;
+            int sj = (chunk_hi(ch) - 1) % NS; // slot of column j in the ring of solved blocks, kept incrementally
             for (int j = chunk_hi(ch) - 1; j >= lo; j--) {
                 const int nd = (V.n - 1 - j) < Bc ? (V.n - 1 - j) : Bc;
-                const double *Lc = Lb0 + (long)(j - lo) * CS, *yl = yb0 + (j - lo) * 12;
-                double v = 0;
-                for (int d = 1 + pt; work && d <= nd; d += 8) {
-                    const double *Ld = Lc + d * 36 + c, *xd = xw + ((j + d) % NS) * 6;
+                const double *Lc = Lb0 + (long)(j - lo) * CS, *yl = yb0 + (j - lo) * BAND_YB;
+                // v_c = sum_d (L_d^T x_{j+d})_c: this lane's blocks d = 1 + pt, 9 + pt, 17 + pt, an independent accumulator each
+                // (a dependent v_fma_f64 costs 40 cycles), then DPP row shifts over the 8 parts
+                double va[3] = {0, 0, 0};
 #pragma unroll
-                    for (int q = 0; q < 6; q++) v = __builtin_fma(Ld[q * 6], xd[q], v);
+                for (int u = 0; u < 3; u++) {
+                    const int d = 1 + pt + 8 * u;
+                    if (work && d <= nd) {
+                        int sl = sj + d; if (sl >= NS) sl -= NS; if (sl >= NS) sl -= NS;
+                        const double *Ld = Lc + d * 36 + c, *xd = xw + sl * 6;
+#pragma unroll
+                        for (int q = 0; q < 6; q++) va[u] = __builtin_fma(Ld[q * 6], xd[q], va[u]);
+                    }
                 }
-                // sum over the 8 parts inside each group of 8 lanes: DPP row shifts (register moves), not ds_bpermute round trips
+                double v = (va[0] + va[1]) + va[2];
                 v += dpp_f64<0x114>(v); v += dpp_f64<0x112>(v); v += dpp_f64<0x111>(v);
-                double lcol[6];
+                // x_j = L_jj^-T (y_j - v) with the explicit inverse from the factorisation: six independent broadcasts and a 3 + 3
+                // multiply-add tree per lane instead of a six-step substitution chain
+                const double sv = yl[c] - v;
+                double s6[6];
 #pragma unroll
-                for (int r = 0; r < 6; r++) lcol[r] = Lc[r * 6 + c];
-                const double inv = yl[6 + c];
-                double sv = yl[c] - v, xv = 0;
+                for (int k = 0; k < 6; k++) s6[k] = __shfl(sv, k * 8 + 7);
+                double e = 0, o = 0;
 #pragma unroll
-                for (int k = 5; k >= 0; k--) {
-                    const double xk = __shfl(sv * inv, k * 8 + 7); // x_k, final because the lanes of columns > k already contributed
-                    if (c == k) xv = xk;
-                    if (c < k) sv = __builtin_fma(-lcol[k], xk, sv); // s_c -= L[k][c] x_k
+                for (int k = 0; k < 6; k++) {
+                    const double m = k >= c ? yl[6 + k * (k + 1) / 2 + c] : 0.0; // (L^-1)[k][c]
+                    if (k & 1) o = __builtin_fma(m, s6[k], o); else e = __builtin_fma(m, s6[k], e);
                 }
-                if (last) { xw[(j % NS) * 6 + c] = xv; xout[(long)(V.rev ? V.C - 1 - j : j) * 6 + c] = xv; }
+                const double xv = e + o;
+                if (last) { xw[sj * 6 + c] = xv; xout[(long)(V.rev ? V.C - 1 - j : j) * 6 + c] = xv; }
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+                sj = sj == 0 ? NS - 1 : sj - 1;
             }
         }
         if (ch + 1 < nchunk) commit(ch + 1);
@@ -967,7 +983,7 @@ template <int NT> __device__ __forceinline__ void band_back(const BandView &V, c
 }
 
 constexpr int BAND_NT = 384; // 6 waves: the nd(nd+1)/2 * 6 + nd * 6 = 324 work items of a trailing update (Bc = 9) fit one pass
-// one workgroup, whole chain (short systems, or CUBESLAM_BA_SOLVER=band1).  rhs: in b (6C), out x; ybuf: 12C scratch
+// one workgroup, whole chain (short systems, or CUBESLAM_BA_SOLVER=band1).  rhs: in b (6C), out x; ybuf: 28C scratch
 __global__ void __launch_bounds__(BAND_NT) ba_band_chol(int C, int Bc, const double *A, double *Lf, double *rhs, double *ybuf, int *status) {
     extern __shared__ double sh[];
     const BandLds S = band_lds(sh, Bc);
@@ -1902,7 +1918,7 @@ int cs_ba_create(cs_ctx *ctx, const cs_ba_problem *p, int rank, int world, cs_ba
         A_(dalloc_copy(ctx, b, &b->d_cubD, (const double *)nullptr, (size_t)std::max(b->band_Q, 1) * 36));
         A_(dalloc_copy(ctx, b, &b->d_cubg, (const double *)nullptr, (size_t)std::max(b->band_Q, 1) * 6));
         A_(dalloc_copy(ctx, b, &b->d_brhs, (const double *)nullptr, (size_t)b->band_C * 6));
-        A_(dalloc_copy(ctx, b, &b->d_ybuf, (const double *)nullptr, (size_t)b->band_C * 12));
+        A_(dalloc_copy(ctx, b, &b->d_ybuf, (const double *)nullptr, (size_t)b->band_C * BAND_YB));
         A_(dalloc_copy(ctx, b, &b->d_mid, (const double *)nullptr, 2 * ((size_t)b->band_bc * (b->band_bc + 1) * 36 + (size_t)b->band_bc * 6) + 8));
         A_(dalloc_copy(ctx, b, &b->d_xmid, (const double *)nullptr, (size_t)b->band_bc * 6 + 8));
     }
