@@ -16,7 +16,11 @@ struct cs_timing_rec {
 };
 
 int cs_host_threads(); // ctx.hip
-void cs_omp_prepare();  // ctx.hip: call before an OpenMP region of a host stage
+void cs_omp_prepare();
+// orb.hip: device-resident results of the last cs_orb_run for one frame (keypoints in mvKeys order, 4 x u64 descriptors), for
+// consumers inside the library that must not round-trip through the host (match.hip)
+struct cs_orb;
+int cs_orb_device_frame(const cs_orb *e, int frame, const cs_keypoint **d_kps, const unsigned long long **d_desc, int *n);  // ctx.hip: call before an OpenMP region of a host stage
 
 struct cs_ctx {
     int device = 0;

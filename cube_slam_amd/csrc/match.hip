@@ -18,6 +18,7 @@
 #include <algorithm>
 #include <climits>
 #include <cmath>
+#include <cstring>
 #include <vector>
 
 namespace {
@@ -66,6 +67,37 @@ __global__ void __launch_bounds__(1024) match_grid(FrameP F, const cs_keypoint *
             cell_items[j + 1] = v;
         }
     }
+}
+
+// cv::undistortPoints(src, dst, K, D, Mat(), K) as Frame::UndistortKeyPoints / ComputeImageBounds call it (Frame.cc:546-609): the
+// classic cvUndistortPoints of OpenCV 2.4 - 3.2 -- normalise with the double copies of the float intrinsics, five fixed-point
+// iterations of the Brown model (k1 k2 p1 p2 k3), re-project with P = K, round to float.  (Later OpenCV versions stop the iteration on
+// a reprojection-error criterion; the reference's target version is not pinned)  -ffp-contract=off: plain double ops.
+struct UndP { double fx, fy, cx, cy, k[5]; int identity; };
+__host__ __device__ inline void undistort_point(const UndP &U, float xin, float yin, float &xo, float &yo) {
+    if (U.identity) { xo = xin; yo = yin; return; }
+    const double ifx = 1. / U.fx, ify = 1. / U.fy;
+    double x = ((double)xin - U.cx) * ifx, y = ((double)yin - U.cy) * ify;
+    const double x0 = x, y0 = y;
+    for (int j = 0; j < 5; j++) {
+        const double r2 = x * x + y * y;
+        const double icdist = (1 + ((0.0 * r2 + 0.0) * r2 + 0.0) * r2) / (1 + ((U.k[4] * r2 + U.k[1]) * r2 + U.k[0]) * r2);
+        const double deltaX = 2 * U.k[2] * x * y + U.k[3] * (r2 + 2 * x * x);
+        const double deltaY = U.k[2] * (r2 + 2 * y * y) + 2 * U.k[3] * x * y;
+        x = (x0 - deltaX) * icdist;
+        y = (y0 - deltaY) * icdist;
+    }
+    const double xx = U.fx * x + 0.0 * y + U.cx, yy = 0.0 * x + U.fy * y + U.cy, ww = 1. / (0.0 * x + 0.0 * y + 1.0);
+    xo = (float)(xx * ww); yo = (float)(yy * ww);
+}
+__global__ void match_undistort(int n, const cs_keypoint *in, UndP U, cs_keypoint *out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    cs_keypoint k = in[i];
+    float x, y;
+    undistort_point(U, k.x, k.y, x, y);
+    k.x = x; k.y = y;
+    out[i] = k;
 }
 
 struct Query { float x, y, r; int minLevel, maxLevel, valid; };
@@ -345,6 +377,46 @@ int cs_matcher_set_frame(cs_ctx *ctx, cs_matcher *m, const cs_keypoint *keysUn, 
     r = cs_h2d(ctx, (uint8_t *)m->d_desc, desc, (size_t)N * 32); if (r) return r;
     CS_LAUNCH(ctx, "match_grid", match_grid, dim3(1), dim3(1024), 0, m->F, m->d_keys, m->d_cell_start, m->d_cell_items, m->d_kp_cell);
     CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CS_OK;
+}
+
+static UndP make_undp(const float *K4, const float *dist5) {
+    UndP U; U.fx = K4[0]; U.fy = K4[1]; U.cx = K4[2]; U.cy = K4[3];
+    for (int i = 0; i < 5; i++) U.k[i] = dist5 ? (double)dist5[i] : 0.0;
+    U.identity = !dist5 || dist5[0] == 0.0f; // Frame.cc:548: only the first coefficient is looked at
+    return U;
+}
+int cs_frame_image_bounds(int cols, int rows, const float *K4, const float *dist5, float *bounds) { // Frame::ComputeImageBounds (Frame.cc:578-609)
+    if (!K4 || !bounds || cols < 1 || rows < 1) return CS_ERR_BAD_ARG;
+    const UndP U = make_undp(K4, dist5);
+    if (U.identity) { bounds[0] = 0.0f; bounds[1] = (float)cols; bounds[2] = 0.0f; bounds[3] = (float)rows; return CS_OK; }
+    const float cx[4] = {0.0f, (float)cols, 0.0f, (float)cols}, cy[4] = {0.0f, 0.0f, (float)rows, (float)rows};
+    float ux[4], uy[4];
+    for (int i = 0; i < 4; i++) undistort_point(U, cx[i], cy[i], ux[i], uy[i]);
+    bounds[0] = std::min(ux[0], ux[2]); bounds[1] = std::max(ux[1], ux[3]); bounds[2] = std::min(uy[0], uy[1]); bounds[3] = std::max(uy[2], uy[3]);
+    return CS_OK;
+}
+int cs_matcher_set_frame_from_orb(cs_ctx *ctx, cs_matcher *m, const cs_orb *orb, int frame, const float *K4, const float *dist5, float minX, float maxX, float minY,
+                                  float maxY, cs_keypoint *keysUn_out, int *n_out) {
+    if (!ctx || !m || !orb || !K4 || !(maxX > minX) || !(maxY > minY)) return CS_ERR_BAD_ARG;
+    const cs_keypoint *d_k = nullptr; const unsigned long long *d_d = nullptr; int N = 0;
+    int r = cs_orb_device_frame(orb, frame, &d_k, &d_d, &N); if (r) return r;
+    if (N > m->max_kp) return CS_ERR_CAPACITY;
+    CS_HIP(ctx, hipSetDevice(ctx->device));
+    m->F.N = N; m->F.minX = minX; m->F.maxX = maxX; m->F.minY = minY; m->F.maxY = maxY;
+    m->F.wInv = static_cast<float>(GRID_COLS) / static_cast<float>(maxX - minX); // Frame.cc:285-286
+    m->F.hInv = static_cast<float>(GRID_ROWS) / static_cast<float>(maxY - minY);
+    // UndistortKeyPoints + the descriptors, device to device; AssignFeaturesToGrid on the undistorted keypoints
+    if (N > 0) {
+        CS_LAUNCH(ctx, "match_undistort", match_undistort, dim3((N + 255) / 256), dim3(256), 0, N, d_k, make_undp(K4, dist5), m->d_keys);
+        CS_HIP(ctx, hipMemcpyAsync(m->d_desc, d_d, (size_t)N * 32, hipMemcpyDeviceToDevice, ctx->stream));
+    }
+    CS_LAUNCH(ctx, "match_grid", match_grid, dim3(1), dim3(1024), 0, m->F, m->d_keys, m->d_cell_start, m->d_cell_items, m->d_kp_cell);
+    m->keys.resize((size_t)N); // the host resolve passes read angle / octave / point of the candidates
+    r = cs_d2h(ctx, m->keys.data(), m->d_keys, (size_t)N); if (r) return r;
+    CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (keysUn_out) memcpy(keysUn_out, m->keys.data(), sizeof(cs_keypoint) * (size_t)N);
+    if (n_out) *n_out = N;
     return CS_OK;
 }
 

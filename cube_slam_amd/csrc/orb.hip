@@ -836,6 +836,13 @@ struct cs_orb {
     std::vector<int> frame_first;         // n_frames + 1 offsets into sel
 };
 
+int cs_orb_device_frame(const cs_orb *e, int frame, const cs_keypoint **d_kps, const unsigned long long **d_desc, int *n) {
+    if (!e || frame < 0 || frame >= e->n_frames || (int)e->frame_first.size() <= frame + 1) return CS_ERR_BAD_ARG;
+    const int b0 = e->frame_first[frame];
+    *d_kps = e->d_kps + b0; *d_desc = e->d_desc + (size_t)b0 * 4; *n = e->frame_first[frame + 1] - b0;
+    return CS_OK;
+}
+
 extern "C" {
 
 void cs_orb_destroy(cs_ctx *ctx, cs_orb *e) {

@@ -29,6 +29,20 @@ class ORBmatcher:
         check(self.ctx.ptr, lib().cs_matcher_set_frame(self.ctx.ptr, self._m, k.ctypes.data_as(C.c_void_p), _p(d, C.c_uint8), self.N,
                                                        *[C.c_float(b) for b in bounds]), "cs_matcher_set_frame")
 
+    def set_frame_from_orb(self, orb, frame, K4, dist5=None, bounds=None, width=None, height=None):
+        """Frame post-processing on the device: keypoints / descriptors of frame `frame` of the extractor's last run are undistorted
+        (Frame::UndistortKeyPoints) and binned (AssignFeaturesToGrid) without leaving HBM.  Returns (mvKeysUn, bounds)."""
+        k4 = np.ascontiguousarray(K4, np.float32)
+        d5 = None if dist5 is None else np.ascontiguousarray(dist5, np.float32)
+        if bounds is None:
+            bounds = frame_image_bounds(width, height, k4, d5)
+        out = np.zeros(max(orb.cap, 1), KEYPOINT_DTYPE); n = C.c_int()
+        check(self.ctx.ptr, lib().cs_matcher_set_frame_from_orb(self.ctx.ptr, self._m, orb._e, int(frame), _p(k4, C.c_float), None if d5 is None else _p(d5, C.c_float),
+                                                                *[C.c_float(float(b)) for b in bounds], out.ctypes.data_as(C.c_void_p), C.byref(n)),
+              "cs_matcher_set_frame_from_orb")
+        self.N = n.value
+        return out[:n.value].copy(), tuple(float(b) for b in bounds)
+
     def GetFeaturesInArea(self, x, y, r, minLevel=-1, maxLevel=-1):
         out = np.zeros(max(self.N, 1), np.int32); n = C.c_int()
         check(self.ctx.ptr, lib().cs_matcher_features_in_area(self.ctx.ptr, self._m, C.c_float(x), C.c_float(y), C.c_float(r), minLevel, maxLevel,
@@ -110,3 +124,14 @@ def hamming_knn2(ctx, q, t):
     bi = np.zeros(max(len(q), 1), np.int32); bd = np.zeros(max(len(q), 1), np.int32); sd = np.zeros(max(len(q), 1), np.int32)
     check(ctx.ptr, lib().cs_hamming_knn2(ctx.ptr, _p(q, C.c_uint8), len(q), _p(t, C.c_uint8), len(t), _p(bi, C.c_int), _p(bd, C.c_int), _p(sd, C.c_int)), "cs_hamming_knn2")
     return bi[:len(q)], bd[:len(q)], sd[:len(q)]
+
+
+def frame_image_bounds(cols, rows, K4, dist5=None):
+    """Frame::ComputeImageBounds -> (mnMinX, mnMaxX, mnMinY, mnMaxY)."""
+    k4 = np.ascontiguousarray(K4, np.float32)
+    d5 = None if dist5 is None else np.ascontiguousarray(dist5, np.float32)
+    b = np.zeros(4, np.float32)
+    r = lib().cs_frame_image_bounds(int(cols), int(rows), _p(k4, C.c_float), None if d5 is None else _p(d5, C.c_float), _p(b, C.c_float))
+    if r != 0:
+        raise RuntimeError("cs_frame_image_bounds failed: %d" % r)
+    return b

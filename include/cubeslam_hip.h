@@ -188,6 +188,15 @@ void cs_matcher_destroy(cs_ctx *ctx, cs_matcher *m);
 /* The frame searched in (CurrentFrame / F / F2): mvKeysUn, mDescriptors, mnMinX..mnMaxY. */
 int cs_matcher_set_frame(cs_ctx *ctx, cs_matcher *m, const cs_keypoint *keysUn, const uint8_t *desc, int N,
                          float minX, float maxX, float minY, float maxY);
+/* Frame post-processing without a host round trip: the keypoints and descriptors of frame `frame` of the last
+ * cs_orb_run stay in HBM; Frame::UndistortKeyPoints (Frame.cc:546-576: copy when dist[0] == 0, else cv::undistortPoints(K, dist, P = K),
+ * classic five-iteration form) and Frame::AssignFeaturesToGrid (:303-318) run on the device and the matcher is ready for the searches.
+ * K4 = fx fy cx cy, dist5 = k1 k2 p1 p2 k3 (NULL = none); bounds from cs_frame_image_bounds.  keysUn_out (nullable, room for the
+ * frame's keypoints) receives mvKeysUn. */
+int cs_matcher_set_frame_from_orb(cs_ctx *ctx, cs_matcher *m, const cs_orb *orb, int frame, const float *K4, const float *dist5, float minX, float maxX, float minY,
+                                  float maxY, cs_keypoint *keysUn_out, int *n_out);
+/* Frame::ComputeImageBounds (Frame.cc:578-609): bounds = mnMinX, mnMaxX, mnMinY, mnMaxY of the undistorted image corners. */
+int cs_frame_image_bounds(int cols, int rows, const float *K4, const float *dist5, float *bounds);
 /* Frame::GetFeaturesInArea(x, y, r, minLevel, maxLevel) on the frame set above; *n = count (may exceed cap). */
 int cs_matcher_features_in_area(cs_ctx *ctx, cs_matcher *m, float x, float y, float r, int minLevel, int maxLevel,
                                 int *out, int cap, int *n);

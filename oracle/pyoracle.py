@@ -275,6 +275,41 @@ def search_for_initialization(F1, F2, prev_matched, window_size=100, nnratio=0.9
     return m12[:F1.N].copy(), prev, n
 
 
+def undistort_points(xy, K4, dist5):
+    """cv::undistortPoints(src, dst, K, D, Mat(), K) in its classic five-iteration form (OpenCV 2.4 - 3.2 cvUndistortPoints), as
+    Frame::UndistortKeyPoints / ComputeImageBounds use it (orb_object_slam/src/Frame.cc:546-609).  The intrinsics and coefficients are
+    floats widened to double, the result is rounded to float.  dist5 = k1 k2 p1 p2 k3; dist5[0] == 0 means `mvKeysUn = mvKeys`.
+    THIRD-PARTY algorithm restated from memory (the OpenCV sources are not in the reference tree): parity unpinned for this function."""
+    xy = np.asarray(xy, np.float32).reshape(-1, 2)
+    if dist5 is None or np.float32(dist5[0]) == 0:
+        return xy.copy()
+    fx, fy, cx, cy = [np.float64(np.float32(v)) for v in K4]
+    k = [np.float64(np.float32(v)) for v in dist5]
+    ifx, ify = 1.0 / fx, 1.0 / fy
+    x = (xy[:, 0].astype(np.float64) - cx) * ifx
+    y = (xy[:, 1].astype(np.float64) - cy) * ify
+    x0, y0 = x.copy(), y.copy()
+    for _ in range(5):
+        r2 = x * x + y * y
+        icdist = (1 + ((0.0 * r2 + 0.0) * r2 + 0.0) * r2) / (1 + ((k[4] * r2 + k[1]) * r2 + k[0]) * r2)
+        dX = 2 * k[2] * x * y + k[3] * (r2 + 2 * x * x)
+        dY = k[2] * (r2 + 2 * y * y) + 2 * k[3] * x * y
+        x = (x0 - dX) * icdist
+        y = (y0 - dY) * icdist
+    xx = fx * x + 0.0 * y + cx
+    yy = 0.0 * x + fy * y + cy
+    ww = 1.0 / (0.0 * x + 0.0 * y + 1.0)
+    return np.stack([(xx * ww).astype(np.float32), (yy * ww).astype(np.float32)], axis=1)
+
+
+def image_bounds(cols, rows, K4, dist5):
+    """Frame::ComputeImageBounds (Frame.cc:578-609) -> (mnMinX, mnMaxX, mnMinY, mnMaxY) as float32."""
+    if dist5 is None or np.float32(dist5[0]) == 0:
+        return np.array([0, cols, 0, rows], np.float32)
+    c = undistort_points([[0, 0], [cols, 0], [0, rows], [cols, rows]], K4, dist5)
+    return np.array([min(c[0, 0], c[2, 0]), max(c[1, 0], c[3, 0]), min(c[0, 1], c[1, 1]), max(c[2, 1], c[3, 1])], np.float32)
+
+
 def fuse(F, u_right, inv_level_sigma2, n_mp_uv, ur, pred_level, valid, mp_desc, scale_factors, th, keys_static=None):
     uv = np.ascontiguousarray(n_mp_uv, np.float32); urr = np.ascontiguousarray(ur, np.float32); pl = np.ascontiguousarray(pred_level, np.int32)
     va = np.ascontiguousarray(valid, np.uint8); md = np.ascontiguousarray(mp_desc, np.uint8); sf = np.ascontiguousarray(scale_factors, np.float32)

@@ -165,3 +165,39 @@ def test_search_for_triangulation(ctx, oracle, frames):
     r12, nr = oracle.search_for_triangulation(F1o, node1, skip1, ur1, F2b, node2b, skip2b, ur2b, F12, -5000.0, 170.0, SF, sigma2, False, False)
     assert np.array_equal(g12, r12) and ng == nr and (g12 >= len(k2)).sum() > 5
     m.close()
+
+
+def test_frame_postprocessing_on_device(ctx, oracle):
+    """ORB extractor -> matcher without a host round trip: UndistortKeyPoints + AssignFeaturesToGrid on the device.
+    mvKeysUn bit-exact vs the oracle's cv::undistortPoints restatement, searches identical to the host-fed matcher."""
+    from cube_slam_amd.orb import ORBextractor
+    from cube_slam_amd.matcher import frame_image_bounds
+    Wt, Ht = 640, 480
+    imgs = np.stack([synth.texture_image(5 + i, Wt, Ht, shift=3 * i) for i in range(2)])
+    orb = ORBextractor(1000, 1.2, 8, 20, 7, Wt, Ht, max_frames=2, ctx=ctx)
+    res = orb.extract_batch(imgs)
+    K4 = (517.3, 516.5, 318.6, 255.3)
+    rng = np.random.default_rng(9)
+    for dist in (None, (0.2624, -0.9531, -0.0054, 0.0026, 1.1633)):
+        for f in range(2):
+            keys, desc = res[f]
+            m = ORBmatcher(ctx=ctx)
+            keysUn, bounds = m.set_frame_from_orb(orb, f, K4, dist, width=Wt, height=Ht)
+            exp_xy = oracle.undistort_points(np.stack([keys["x"], keys["y"]], axis=1), K4, dist)
+            assert len(keysUn) == len(keys) and np.array_equal(keysUn["x"], exp_xy[:, 0]) and np.array_equal(keysUn["y"], exp_xy[:, 1])
+            for fld in ("angle", "octave", "response", "size"):
+                assert np.array_equal(keysUn[fld], keys[fld])
+            assert np.array_equal(np.array(bounds, np.float32), oracle.image_bounds(Wt, Ht, K4, dist))
+            if dist is not None:
+                assert np.abs(keysUn["x"] - keys["x"]).max() > 1.0
+            ref = ORBmatcher(ctx=ctx)
+            ref.set_frame(keysUn, desc, bounds)
+            Fo = oracle.make_frame(keysUn, desc, bounds)
+            for _ in range(15):
+                x, y, r = rng.uniform(-20, Wt + 20), rng.uniform(-20, Ht + 20), rng.uniform(2, 90)
+                a = m.GetFeaturesInArea(x, y, r); b = ref.GetFeaturesInArea(x, y, r)
+                assert np.array_equal(a, b) and np.array_equal(a, oracle.get_features_in_area(Fo, x, y, r))
+            bi, bd, _ = hamming_knn2(ctx, desc[:50], desc)
+            assert (bd == 0).all()
+            m.close(); ref.close()
+    orb.close()

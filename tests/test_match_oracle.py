@@ -82,3 +82,30 @@ def test_triangulation_rules(oracle):
     F2h = oracle.make_frame(k2hi, d2, BOUNDS)
     m, _ = oracle.search_for_triangulation(F1, node1, [0], mono1, F2h, node2, no, mono2, F12, -1e4, 100.0, SF, sig2, False, False)
     assert m[0] == 3, "36 < 3.84 * 12.84: coarse-level keypoints tolerate a larger epipolar distance, and the exact descriptor wins"
+
+
+def test_undistort_points_properties(oracle):
+    """cv::undistortPoints (classic five-iteration form): identity without distortion, inverse of the Brown model, image bounds."""
+    K4 = (517.3, 516.5, 318.6, 255.3)  # TUM1.yaml-like
+    D = (0.2624, -0.9531, -0.0054, 0.0026, 1.1633)
+    rng = np.random.default_rng(2)
+    pts = np.stack([rng.uniform(0, 640, 500), rng.uniform(0, 480, 500)], axis=1).astype(np.float32)
+    assert np.array_equal(oracle.undistort_points(pts, K4, None), pts)
+    assert np.array_equal(oracle.undistort_points(pts, K4, (0.0, 0.5, 0.1, 0.1, 0.0)), pts), "only dist[0] decides (Frame.cc:548)"
+    und = oracle.undistort_points(pts, K4, D).astype(np.float64)
+    fx, fy, cx, cy = K4
+    x, y = (und[:, 0] - cx) / fx, (und[:, 1] - cy) / fy
+    r2 = x * x + y * y
+    rad = 1 + D[0] * r2 + D[1] * r2 ** 2 + D[4] * r2 ** 3
+    xd = x * rad + 2 * D[2] * x * y + D[3] * (r2 + 2 * x * x)
+    yd = y * rad + D[2] * (r2 + 2 * y * y) + 2 * D[3] * x * y
+    back = np.stack([xd * fx + cx, yd * fy + cy], axis=1)
+    near = np.hypot(pts[:, 0] - cx, pts[:, 1] - cy) < 250
+    assert np.abs(back - pts)[near].max() < 0.05, "distorting the undistorted points returns the input (five iterations: a few 1e-2 px)"
+    assert np.abs(und - pts).max() > 3, "and the correction is not a no-op"
+    b = oracle.image_bounds(640, 480, K4, D)
+    c = oracle.undistort_points([[0, 0], [640, 0], [0, 480], [640, 480]], K4, D)
+    assert b[0] == min(c[0, 0], c[2, 0]) and b[3] == max(c[2, 1], c[3, 1])
+    assert np.array_equal(oracle.image_bounds(640, 480, K4, None), np.array([0, 640, 0, 480], np.float32))
+    from cube_slam_amd.matcher import frame_image_bounds
+    assert np.array_equal(frame_image_bounds(640, 480, K4, D), b) and np.array_equal(frame_image_bounds(640, 480, K4, None), oracle.image_bounds(640, 480, K4, None))
