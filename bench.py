@@ -144,7 +144,7 @@ def main():
     from cube_slam_amd import _lib
     from cube_slam_amd.cuboid import CuboidBatch, detect_3d_cuboid
 
-    ctx = _lib.Context(local_rank)
+    ctx = _lib.Context(local_rank, priority=1)  # ORB + cuboid: the path a tracking thread waits for
     scenes = make_frames(args.frames, args.boxes, seed0=1000 + 100000 * rank)
     det = detect_3d_cuboid(ctx)
     det.set_calibration(scenes[0]["K"])
@@ -165,7 +165,7 @@ def main():
         # threads with their own contexts (= HIP streams).  Two detectors alternate steps: the GPU phases of one step (gradient maps
         # before, LBD descriptors after the host stage) overlap the region growing of the neighbouring step; the library serialises
         # the host stages, so the cores are never split between two OpenMP teams.
-        ctx_lines = [_lib.Context(local_rank), _lib.Context(local_rank)]
+        ctx_lines = [_lib.Context(local_rank, priority=-1), _lib.Context(local_rank, priority=-1)]  # device phases of the line detectors: background
         lsds = [line_lbd_detect(640, 480, max_frames=args.frames, ctx=c) for c in ctx_lines]
         for d_ in lsds:
             d_.upload(np.stack([s["gray"] for s in scenes]))

@@ -42,9 +42,9 @@ def check(ctx, r, what):
 class Context:
     """cs_ctx wrapper: one HIP device + stream."""
 
-    def __init__(self, device=0):
+    def __init__(self, device=0, priority=0):
         self._ctx = C.c_void_p()
-        r = lib().cs_create(int(device), C.byref(self._ctx))
+        r = lib().cs_create_with_priority(int(device), int(priority), C.byref(self._ctx))
         if r != CS_OK:
             raise CubeSlamError("cs_create(device=%d) failed: %s (no HIP device? this package has no CPU path)" % (device, STATUS.get(r, r)))
 

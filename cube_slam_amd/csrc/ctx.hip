@@ -47,7 +47,7 @@ int cs_host_thread_count(void) { return cs_host_threads(); }
 
 int cs_version(void) { return CS_VERSION; }
 
-int cs_create(int device_id, cs_ctx **out) {
+int cs_create_with_priority(int device_id, int priority, cs_ctx **out) {
     if (!out) return CS_ERR_BAD_ARG;
     *out = nullptr;
     int n = 0;
@@ -58,10 +58,17 @@ int cs_create(int device_id, cs_ctx **out) {
     if (!c) return CS_ERR_NOMEM;
     c->device = device_id;
     c->host_threads = cs_host_threads();
-    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) { delete c; return CS_ERR_NO_DEVICE; }
+    int lo = 0, hi = 0; // numerically lower = higher priority
+    hipError_t e = hipSuccess;
+    if (priority != 0 && hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi)
+        e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, priority > 0 ? hi : lo);
+    else
+        e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { (void)hipGetLastError(); delete c; return CS_ERR_NO_DEVICE; }
     *out = c;
     return CS_OK;
 }
+int cs_create(int device_id, cs_ctx **out) { return cs_create_with_priority(device_id, 0, out); }
 
 void cs_destroy(cs_ctx *ctx) {
     if (!ctx) return;

@@ -32,6 +32,9 @@ typedef struct cs_ctx cs_ctx;
 
 /* Creates a context bound to HIP device `device_id` with its own stream. */
 int cs_create(int device_id, cs_ctx **out);
+/* Same with a stream priority: > 0 highest, < 0 lowest, 0 default.  The batch front-end runs ORB + cuboid (what the tracking thread waits
+ * for) on a high-priority stream and the line detectors' device phases, which overlap their own host stage, on low-priority ones. */
+int cs_create_with_priority(int device_id, int priority, cs_ctx **out);
 void cs_destroy(cs_ctx *ctx);
 const char *cs_last_error(const cs_ctx *ctx);
 int cs_version(void);
