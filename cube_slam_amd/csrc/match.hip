@@ -278,6 +278,19 @@ __global__ void __launch_bounds__(256) match_triangulation(int N1, const cs_keyp
     if (lane == 0) matches12[i1] = best == 0xffffffffu ? -1 : (int)(0xfffffu - (best & 0xfffffu));
 }
 
+// SearchByBoW (:171-310): distances of every key-frame feature to the frame features of its vocabulary node, one wave per key-frame
+// feature, written to that feature's slice of a CSR buffer (the slice length is the node's size); the greedy claim order is the host's.
+__global__ void __launch_bounds__(256) match_bow_dists(int NK, const unsigned long long *descK, const int *nodeK, const unsigned long long *descF, const int *node_start,
+                                                       const int *node_items, const int *out_off, int *dists) {
+    const int ik = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (ik >= NK) return;
+    const int nd = nodeK[ik];
+    if (nd < 0) return;
+    const unsigned long long a0 = descK[(long)ik * 4], a1 = descK[(long)ik * 4 + 1], a2 = descK[(long)ik * 4 + 2], a3 = descK[(long)ik * 4 + 3];
+    const int b = node_start[nd], n = node_start[nd + 1] - b;
+    for (int p = lane; p < n; p += 64) dists[out_off[ik] + p] = hamming256(descF + (long)node_items[b + p] * 4, a0, a1, a2, a3);
+}
+
 static void three_maxima(const int *sizes, int L, int &ind1, int &ind2, int &ind3) { // ORBmatcher.cc:1860-1901
     int max1 = 0, max2 = 0, max3 = 0;
     for (int i = 0; i < L; i++) {
@@ -700,6 +713,81 @@ int cs_match_for_triangulation(cs_ctx *ctx, const cs_keypoint *keys1Un, const ui
         for (int i = 0; i < HISTO_LENGTH; i++) {
             if (i == ind1 || i == ind2 || i == ind3) continue;
             for (int j : rotHist[i]) { matches12[j] = -1; nm--; }
+        }
+    }
+    *nmatches = nm;
+    return CS_OK;
+}
+
+int cs_match_by_bow(cs_ctx *ctx, const cs_keypoint *keysKF, const uint8_t *descKF, int NK, const int *nodeKF, const uint8_t *skipKF, const cs_keypoint *keysF,
+                    const uint8_t *descF, int NF, const int *nodeF, const uint8_t *skipF, float nnratio, int check_orientation, int *matchesF, int *nmatches) {
+    if (!ctx || NK < 0 || NF < 0 || !matchesF || !nmatches || (NK && (!keysKF || !descKF || !nodeKF || !skipKF)) || (NF && (!keysF || !descF || !nodeF))) return CS_ERR_BAD_ARG;
+    *nmatches = 0;
+    for (int i = 0; i < NF; i++) matchesF[i] = -1;
+    if (NK == 0 || NF == 0) return CS_OK;
+    CS_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<int> ids;
+    for (int i = 0; i < NF; i++) if (nodeF[i] >= 0) ids.push_back(nodeF[i]);
+    std::sort(ids.begin(), ids.end()); ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
+    const int n_nodes = (int)ids.size();
+    auto compact = [&](int nd) { if (nd < 0) return -1; auto it = std::lower_bound(ids.begin(), ids.end(), nd); return (it != ids.end() && *it == nd) ? (int)(it - ids.begin()) : -1; };
+    std::vector<int> start((size_t)n_nodes + 1, 0), items, nkc((size_t)NK), nfc((size_t)NF), off((size_t)NK + 1, 0);
+    for (int i = 0; i < NF; i++) { nfc[i] = compact(nodeF[i]); if (nfc[i] >= 0) start[nfc[i] + 1]++; }
+    for (int k = 0; k < n_nodes; k++) start[k + 1] += start[k];
+    items.resize((size_t)std::max(start[n_nodes], 1));
+    { std::vector<int> pos(start.begin(), start.end() - 1); for (int i = 0; i < NF; i++) if (nfc[i] >= 0) items[pos[nfc[i]]++] = i; }
+    for (int i = 0; i < NK; i++) { nkc[i] = skipKF[i] ? -1 : compact(nodeKF[i]); off[i + 1] = off[i] + (nkc[i] >= 0 ? start[nkc[i] + 1] - start[nkc[i]] : 0); }
+    const int total = off[NK];
+    std::vector<int> dists((size_t)std::max(total, 1));
+    if (total > 0) {
+        unsigned long long *d_dk = nullptr, *d_df = nullptr; int *d_nk = nullptr, *d_st = nullptr, *d_it = nullptr, *d_off = nullptr, *d_di = nullptr;
+        int r = cs_dalloc(ctx, &d_dk, (size_t)NK * 4);
+#define BA_(call) if (!r) r = (call)
+        BA_(cs_dalloc(ctx, &d_df, (size_t)NF * 4)); BA_(cs_dalloc(ctx, &d_nk, (size_t)NK)); BA_(cs_dalloc(ctx, &d_st, start.size())); BA_(cs_dalloc(ctx, &d_it, items.size()));
+        BA_(cs_dalloc(ctx, &d_off, off.size())); BA_(cs_dalloc(ctx, &d_di, (size_t)total));
+        BA_(cs_h2d(ctx, (uint8_t *)d_dk, descKF, (size_t)NK * 32)); BA_(cs_h2d(ctx, (uint8_t *)d_df, descF, (size_t)NF * 32)); BA_(cs_h2d(ctx, d_nk, nkc.data(), (size_t)NK));
+        BA_(cs_h2d(ctx, d_st, start.data(), start.size())); BA_(cs_h2d(ctx, d_it, items.data(), items.size())); BA_(cs_h2d(ctx, d_off, off.data(), off.size()));
+#undef BA_
+        if (!r) {
+            CS_LAUNCH(ctx, "match_bow_dists", match_bow_dists, dim3((NK + 3) / 4), dim3(256), 0, NK, d_dk, d_nk, d_df, d_st, d_it, d_off, d_di);
+            r = cs_d2h(ctx, dists.data(), d_di, (size_t)total);
+        }
+        hipError_t e = hipStreamSynchronize(ctx->stream);
+        if (!r && e != hipSuccess) { ctx->err = hipGetErrorString(e); r = CS_ERR_HIP; }
+        void *ptrs[] = {d_dk, d_df, d_nk, d_st, d_it, d_off, d_di};
+        for (void *p : ptrs) if (p) hipFree(p);
+        if (r) return r;
+    }
+    // greedy resolve in the reference's order: nodes ascending (std::map), key-frame features ascending inside a node
+    std::vector<std::pair<int, int>> order; // (original node id, kf index)
+    for (int i = 0; i < NK; i++) if (nkc[i] >= 0) order.push_back(std::make_pair(nodeKF[i], i));
+    std::sort(order.begin(), order.end());
+    int nm = 0;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    for (const auto &ok : order) {
+        const int ik = ok.second, nd = nkc[ik], b = start[nd], n = start[nd + 1] - b;
+        int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+        for (int p = 0; p < n; p++) {
+            const int iF = items[b + p];
+            if (matchesF[iF] >= 0) continue;
+            if (skipF && skipF[iF]) continue;
+            const int dist = dists[off[ik] + p];
+            if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = iF; }
+            else if (dist < bestDist2) bestDist2 = dist;
+        }
+        if (bestDist1 <= TH_LOW && static_cast<float>(bestDist1) < nnratio * static_cast<float>(bestDist2)) {
+            matchesF[bestIdxF] = ik;
+            if (check_orientation) rotHist[rot_bin(keysKF[ik].angle, keysF[bestIdxF].angle)].push_back(bestIdxF);
+            nm++;
+        }
+    }
+    if (check_orientation) {
+        int sizes[HISTO_LENGTH], ind1 = -1, ind2 = -1, ind3 = -1;
+        for (int i = 0; i < HISTO_LENGTH; i++) sizes[i] = (int)rotHist[i].size();
+        three_maxima(sizes, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int j : rotHist[i]) { matchesF[j] = -1; nm--; }
         }
     }
     *nmatches = nm;

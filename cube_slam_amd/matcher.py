@@ -107,6 +107,19 @@ class ORBmatcher:
                                                              int(bOnlyStereo), int(self.mbCheckOrientation), _p(m12, C.c_int), C.byref(n)), "cs_match_for_triangulation")
         return m12[:len(k1)].copy(), n.value
 
+    def SearchByBoW(self, keysKF, descKF, nodeKF, skipKF, keysF, descF, nodeF, skipF=None):
+        """ORBmatcher::SearchByBoW(pKF, F, vpMapPointMatches) (ORBmatcher.cc:171-310): per frame feature the key-frame feature whose map
+        point it receives (-1 none), and nmatches."""
+        kk = np.ascontiguousarray(keysKF, KEYPOINT_DTYPE); dk = np.ascontiguousarray(descKF, np.uint8); kf = np.ascontiguousarray(keysF, KEYPOINT_DTYPE)
+        df = np.ascontiguousarray(descF, np.uint8)
+        nk = np.ascontiguousarray(nodeKF, np.int32); sk = np.ascontiguousarray(skipKF, np.uint8); nf = np.ascontiguousarray(nodeF, np.int32)
+        sf = None if skipF is None else np.ascontiguousarray(skipF, np.uint8)
+        mf = np.zeros(max(len(kf), 1), np.int32); n = C.c_int()
+        check(self.ctx.ptr, lib().cs_match_by_bow(self.ctx.ptr, kk.ctypes.data_as(C.c_void_p), _p(dk, C.c_uint8), len(kk), _p(nk, C.c_int), _p(sk, C.c_uint8),
+                                                  kf.ctypes.data_as(C.c_void_p), _p(df, C.c_uint8), len(kf), _p(nf, C.c_int), None if sf is None else _p(sf, C.c_uint8),
+                                                  C.c_float(self.mfNNratio), int(self.mbCheckOrientation), _p(mf, C.c_int), C.byref(n)), "cs_match_by_bow")
+        return mf[:len(kf)].copy(), n.value
+
     def close(self):
         if self._m:
             lib().cs_matcher_destroy(self.ctx.ptr, self._m)

@@ -236,6 +236,11 @@ int cs_match_for_triangulation(cs_ctx *ctx, const cs_keypoint *keys1Un, const ui
                                const cs_keypoint *keys2Un, const uint8_t *desc2, int N2, const int *node2, const uint8_t *skip2, const float *u_right2,
                                const float *F12, float ex, float ey, const float *scale_factors2, const float *level_sigma2_2, int n_levels, int only_stereo,
                                int check_orientation, int *matches12, int *nmatches);
+/* ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) (ORBmatcher.cc:171-310): node = vocabulary node of every feature
+ * (-1 none; DBoW2 is out of scope); skipKF = no usable map point (NULL / bad / dynamic / not static); skipF (nullable) = !KeysStatic.
+ * matchesF[NF] = index of the key-frame feature whose map point the frame feature receives, -1 none. */
+int cs_match_by_bow(cs_ctx *ctx, const cs_keypoint *keysKF, const uint8_t *descKF, int NK, const int *nodeKF, const uint8_t *skipKF, const cs_keypoint *keysF,
+                    const uint8_t *descF, int NF, const int *nodeF, const uint8_t *skipF, float nnratio, int check_orientation, int *matchesF, int *nmatches);
 /* ORBmatcher::DescriptorDistance over all pairs: exact best / second-best per query (first index wins ties). */
 int cs_hamming_knn2(cs_ctx *ctx, const uint8_t *q, int nq, const uint8_t *t, int nt, int *best_idx, int *best_dist, int *second_dist);
 

@@ -358,3 +358,58 @@ int orc_search_for_triangulation(const orc_frame *F1, const int *node1, const ui
     }
     return nmatches;
 }
+
+// ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) (:171-310).  nodeKF / nodeF: FeatureVector node of every feature;
+// skipKF: no usable map point (NULL / bad / dynamic / not static); skipF: KeysStatic says no.  matchesF[idxF] = index of the KF feature
+// whose map point the frame feature receives, -1 none.  F features claimed by an earlier KF feature of the node are skipped.
+int orc_search_by_bow(const orc_frame *KF, const int *nodeKF, const uint8_t *skipKF, const orc_frame *F, const int *nodeF, const uint8_t *skipF, float nnratio,
+                      int check_orientation, int *matchesF) {
+    std::map<int, std::vector<int>> fvK, fvF;
+    for (int i = 0; i < KF->N; i++) if (nodeKF[i] >= 0) fvK[nodeKF[i]].push_back(i);
+    for (int i = 0; i < F->N; i++) if (nodeF[i] >= 0) fvF[nodeF[i]].push_back(i);
+    for (int i = 0; i < F->N; i++) matchesF[i] = -1;
+    int nmatches = 0;
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = 1.0f / HISTO_LENGTH;
+    auto KFit = fvK.begin(), KFend = fvK.end();
+    auto Fit = fvF.begin(), Fend = fvF.end();
+    while (KFit != KFend && Fit != Fend) {
+        if (KFit->first == Fit->first) {
+            for (int realIdxKF : KFit->second) {
+                if (skipKF[realIdxKF]) continue;
+                int bestDist1 = 256, bestIdxF = -1, bestDist2 = 256;
+                for (int realIdxF : Fit->second) {
+                    if (matchesF[realIdxF] >= 0) continue;
+                    if (skipF && skipF[realIdxF]) continue;
+                    const int dist = descriptor_distance(KF->desc + (size_t)realIdxKF * 32, F->desc + (size_t)realIdxF * 32);
+                    if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdxF = realIdxF; }
+                    else if (dist < bestDist2) bestDist2 = dist;
+                }
+                if (bestDist1 <= TH_LOW) {
+                    if (static_cast<float>(bestDist1) < nnratio * static_cast<float>(bestDist2)) {
+                        matchesF[bestIdxF] = realIdxKF;
+                        if (check_orientation) {
+                            float rot = KF->keysUn[realIdxKF].angle - F->keysUn[bestIdxF].angle;
+                            if (rot < 0.0) rot += 360.0f;
+                            int bin = (int)std::round(rot * factor);
+                            if (bin == HISTO_LENGTH) bin = 0;
+                            rotHist[bin].push_back(bestIdxF);
+                        }
+                        nmatches++;
+                    }
+                }
+            }
+            ++KFit; ++Fit;
+        } else if (KFit->first < Fit->first) KFit = fvK.lower_bound(Fit->first);
+        else Fit = fvF.lower_bound(KFit->first);
+    }
+    if (check_orientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int j : rotHist[i]) { matchesF[j] = -1; nmatches--; }
+        }
+    }
+    return nmatches;
+}

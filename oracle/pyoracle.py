@@ -332,6 +332,15 @@ def search_for_triangulation(F1, node1, skip1, ur1, F2, node2, skip2, ur2, F12, 
     return m12[:F1.N].copy(), n
 
 
+def search_by_bow(KF, nodeKF, skipKF, F, nodeF, skipF, nnratio, check_ori=True):
+    nk = np.ascontiguousarray(nodeKF, np.int32); sk = np.ascontiguousarray(skipKF, np.uint8); nf = np.ascontiguousarray(nodeF, np.int32)
+    sf = None if skipF is None else np.ascontiguousarray(skipF, np.uint8)
+    mf = np.zeros(max(F.N, 1), np.int32)
+    n = lib().orc_search_by_bow(C.byref(KF), _p(nk, C.c_int), _p(sk, C.c_uint8), C.byref(F), _p(nf, C.c_int), None if sf is None else _p(sf, C.c_uint8), C.c_float(nnratio),
+                                int(check_ori), _p(mf, C.c_int))
+    return mf[:F.N].copy(), n
+
+
 def hamming_knn2(q, t):
     q = np.ascontiguousarray(q, np.uint8); t = np.ascontiguousarray(t, np.uint8)
     bi = np.zeros(len(q), np.int32); bd = np.zeros(len(q), np.int32); sd = np.zeros(len(q), np.int32)

@@ -201,3 +201,30 @@ def test_frame_postprocessing_on_device(ctx, oracle):
             assert (bd == 0).all()
             m.close(); ref.close()
     orb.close()
+
+
+def test_search_by_bow(ctx, oracle, frames):
+    """ORBmatcher::SearchByBoW(KeyFrame, Frame): same-node candidates, greedy claims in (node, index) order, ratio test, rotation histogram."""
+    (k1, d1), (k2, d2) = frames
+    rng = np.random.default_rng(8)
+    node = lambda k, dx: ((np.clip(k["x"] + dx, 0, W - 1) // 60).astype(np.int32) * 8 + (k["y"] // 50).astype(np.int32))
+    node1, node2 = node(k1, 0.0), node(k2, 4.0)
+    node2[rng.uniform(size=len(k2)) < 0.03] = -1
+    skip1 = (rng.uniform(size=len(k1)) < 0.25).astype(np.uint8)
+    skip2 = (rng.uniform(size=len(k2)) < 0.05).astype(np.uint8)
+    KFo = oracle.make_frame(k1, d1, BOUNDS); Fo = oracle.make_frame(k2, d2, BOUNDS)
+    for ratio, ori, sf in ((0.75, True, None), (0.9, False, skip2), (0.6, True, skip2)):
+        m = ORBmatcher(ratio, ori, ctx=ctx)
+        g, ng = m.SearchByBoW(k1, d1, node1, skip1, k2, d2, node2, sf)
+        r, nr = oracle.search_by_bow(KFo, node1, skip1, Fo, node2, sf, ratio, ori)
+        assert np.array_equal(g, r) and ng == nr and ng > 100
+        assert (skip1[g[g >= 0]] == 0).all()
+        m.close()
+    # two key-frame features with the same descriptor in one node: the first claims the best frame feature, the second must move on
+    k1b = np.concatenate([k1[:300], k1[:300]]); d1b = np.concatenate([d1[:300], d1[:300]]); n1b = np.concatenate([node1[:300], node1[:300]])
+    KFb = oracle.make_frame(k1b, d1b, BOUNDS)
+    m = ORBmatcher(0.95, False, ctx=ctx)
+    g, ng = m.SearchByBoW(k1b, d1b, n1b, np.zeros(600, np.uint8), k2, d2, node2, None)
+    r, nr = oracle.search_by_bow(KFb, n1b, np.zeros(600, np.uint8), Fo, node2, None, 0.95, False)
+    assert np.array_equal(g, r) and ng == nr and (g >= 300).sum() > 0 and len(set(g[g >= 0])) == (g >= 0).sum()
+    m.close()

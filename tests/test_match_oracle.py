@@ -109,3 +109,19 @@ def test_undistort_points_properties(oracle):
     assert np.array_equal(oracle.image_bounds(640, 480, K4, None), np.array([0, 640, 0, 480], np.float32))
     from cube_slam_amd.matcher import frame_image_bounds
     assert np.array_equal(frame_image_bounds(640, 480, K4, D), b) and np.array_equal(frame_image_bounds(640, 480, K4, None), oracle.image_bounds(640, 480, K4, None))
+
+
+def test_search_by_bow_claim_order(oracle):
+    rng = np.random.default_rng(3)
+    base = _desc(rng, 1)[0]
+    kf = _keys([(10, 10), (20, 20), (30, 30)]); dkf = np.stack([base, base, _flip(base, 3)])
+    fr = _keys([(11, 10), (21, 20), (31, 30), (41, 40)]); dfr = np.stack([_flip(base, 2), _flip(base, 8), _flip(base, 30), _desc(rng, 1)[0]])
+    KF = oracle.make_frame(kf, dkf, BOUNDS); F = oracle.make_frame(fr, dfr, BOUNDS)
+    m, n = oracle.search_by_bow(KF, [5, 5, 5], [0, 0, 0], F, [5, 5, 5, 6], None, 0.9, False)
+    # kf0: best f0 (2) vs second f1 (8): 2 < 0.9*8 -> claims f0.  kf1 (same descriptor): f0 taken, best f1 (8) vs f2 (30) -> claims f1.
+    # kf2 (3 bits off base): f0, f1 taken, only f2 at distance ~27..33 with second best 256 -> passes the ratio test if <= TH_LOW
+    assert list(m[:2]) == [0, 1] and m[3] == -1 and n == int((m >= 0).sum())
+    m2, n2 = oracle.search_by_bow(KF, [5, 5, 5], [0, 1, 0], F, [5, 5, 5, 6], None, 0.9, False)
+    assert m2[0] == 0 and m2[1] != 1, "a key-frame feature without a usable map point does not claim anything"
+    m3, n3 = oracle.search_by_bow(KF, [5, 5, 5], [0, 0, 0], F, [5, 5, 5, 6], None, 0.2, False)
+    assert m3[0] == -1, "2 < 0.2 * 8 fails: the ratio test uses the second best of the UNCLAIMED candidates"
