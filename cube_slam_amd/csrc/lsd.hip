@@ -612,6 +612,9 @@ static int lsd_run(cs_ctx *ctx, cs_lsd *l, int with_lbd) {
     std::unique_lock<std::mutex> host_lock(host_stage);
     const auto t0 = std::chrono::steady_clock::now();
     l->keylines.assign((size_t)F, {});
+    std::vector<int> lpt((size_t)F);
+    for (int f = 0; f < F; f++) lpt[f] = f;
+    std::stable_sort(lpt.begin(), lpt.end(), [&](int a, int b) { return l->frame_base[a + 1] - l->frame_base[a] > l->frame_base[b + 1] - l->frame_base[b]; });
     cs_omp_prepare();
 #pragma omp parallel num_threads(std::max(1, std::min(ctx->host_threads, F)))
     {
@@ -619,7 +622,8 @@ static int lsd_run(cs_ctx *ctx, cs_lsd *l, int with_lbd) {
         host.timed = ctx->timing;
         std::vector<float> lines;
 #pragma omp for schedule(dynamic, 1)
-        for (int f = 0; f < F; f++) {
+        for (int fi = 0; fi < F; fi++) {
+            const int f = lpt[fi]; // most defined pixels first: the tail of the dynamic schedule is made of the cheapest frames
             const int b0 = l->frame_base[f];
             host.run(w, h, l->frame_base[f + 1] - b0, l->h_caddr + b0, l->h_cang + b0, l->h_cmod + b0, lines);
             to_keylines(lines, W, H, l->keylines[f]);
