@@ -583,6 +583,128 @@ __global__ void __launch_bounds__(1024) cuboid_dt_block(const Unit *units, const
     dt_block_pass<true>(U, em, tmp, dist + U.pix_off, s_tot, s_first);
 }
 
+// Wave-per-ROI variant, no barrier at all: a lane owns C CONSECUTIVE scan positions (s = lane*C + k), so a row needs one wave scan
+// (of the lanes' local minima) instead of one per 64-column segment, the previous row stays in registers, and the only cross-lane
+// traffic per row is two DPP wave shifts (neighbours) plus the scan.  Rows are sequential; the inputs of the next G rows are
+// already in flight.  The int map between the passes lives in its own arena in a lane-major layout ([row][k][lane]), so both
+// passes touch it with fully coalesced accesses: the backward pass runs the same recurrence on the mirrored image and its lane
+// l, slot k is the forward pass's lane 63-l, slot C-1-k.  The edge map is read with unaligned dwords.
+template <int C, bool BWD>
+__device__ __forceinline__ void dt_wave_pass(const Unit &U, const uint8_t *em, int *tmp, float *out, float *lbuf) {
+    const int w = U.roi_w, h = U.roi_h, lane = threadIdx.x & 63;
+    constexpr int WC = 64 * C, NW = (C + 3) / 4 + 1; // dwords that cover C bytes at any byte offset
+    // scan position s <-> column j: forward j = s, backward j = WC-1-s.  Active: j < w.
+    int jcol[C]; bool act[C]; int sHV[C];
+#pragma unroll
+    for (int k = 0; k < C; k++) { const int sp = lane * C + k; jcol[k] = BWD ? WC - 1 - sp : sp; act[k] = jcol[k] < w; sHV[k] = sp * DT_HV; }
+    const int lo = BWD ? WC - w : 0;
+    const int init_carry = DT_INIT - (lo - 1) * DT_HV;
+    const bool any_act = BWD ? act[C - 1] : act[0];
+    const float scale = 1.f / 65536.f;
+    int P[C];
+#pragma unroll
+    for (int k = 0; k < C; k++) P[k] = DT_INIT;
+    constexpr int G = BWD ? 4 : 8;
+    // forward input: bytes em[i*w + lane*C .. +C-1] (unaligned dwords); backward input: tmp[(i*C + C-1-k)*64 + 63-lane]
+    uint32_t fin[G][NW] = {}; int bin[G][C] = {};
+    auto fetch = [&](int r0) {
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const int r = r0 + g;
+            if (r < h) {
+                const int i = BWD ? h - 1 - r : r;
+                if (!BWD) {
+                    if (any_act) {
+                        const uint8_t *p = em + (long)i * w + lane * C;
+#pragma unroll
+                        for (int q = 0; q < NW; q++) fin[g][q] = (q * 4 < C) ? load_u32_unaligned(p + q * 4) : 0u;
+                    }
+                } else {
+#pragma unroll
+                    for (int k = 0; k < C; k++) bin[g][k] = tmp[((long)i * C + (C - 1 - k)) * 64 + (63 - lane)];
+                }
+            }
+        }
+    };
+    fetch(0);
+    // backward pass output: a lane's C floats are strided against its neighbours' (C dword stores per row, each a 64-line gather for the
+    // texture path); the row goes through a per-wave LDS line instead and leaves as C coalesced stores one row later -- the LDS reads of
+    // the previous row are issued before this row's arithmetic and consumed after it
+    float ob[C];
+    int oi = -1; // image row held in ob / in the LDS line (oi & 1)
+    auto flush_store = [&]() {
+        if (oi < 0) return;
+#pragma unroll
+        for (int q = 0; q < C; q++) { const int j = q * 64 + lane; if (j < w) out[(long)oi * w + j] = ob[q]; }
+    };
+    int rows_done = 0;
+    for (int r0 = 0; r0 < h; r0 += G) {
+        uint32_t cf[G][NW]; int cb[G][C];
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+#pragma unroll
+            for (int q = 0; q < NW; q++) cf[g][q] = fin[g][q];
+#pragma unroll
+            for (int k = 0; k < C; k++) cb[g][k] = bin[g][k];
+        }
+        fetch(r0 + G);
+#pragma unroll
+        for (int g = 0; g < G; g++) {
+            const int r = r0 + g;
+            if (r >= h) break;
+            const int i = BWD ? h - 1 - r : r;
+            if (BWD && rows_done > 0) { // previous row: LDS line -> registers (waited for at the end of this row)
+                const float *lb = lbuf + ((rows_done - 1) & 1) * WC;
+#pragma unroll
+                for (int q = 0; q < C; q++) ob[q] = lb[q * 64 + lane];
+                oi = h - 1 - (r - 1);
+            }
+            const int left = __builtin_amdgcn_update_dpp(DT_INIT, P[C - 1], 0x138, 0xf, 0xf, false); // wave_shr:1 -> lane-1's last position
+            const int right = __builtin_amdgcn_update_dpp(DT_INIT, P[0], 0x130, 0xf, 0xf, false);    // wave_shl:1 -> lane+1's first position
+            int u[C], m = INT_MAX;
+#pragma unroll
+            for (int k = 0; k < C; k++) {
+                const int pl = k == 0 ? left : P[k - 1], pr = k == C - 1 ? right : P[k + 1];
+                int c = min(min(pl + DT_DIAG, P[k] + DT_HV), pr + DT_DIAG);
+                if (!BWD) { const int byte = (cf[g][k >> 2] >> (8 * (k & 3))) & 255; if (byte != 0) c = 0; } // edge pixel: source
+                else c = min(c, cb[g][k]);
+                u[k] = act[k] ? c - sHV[k] : INT_MAX;
+                m = min(m, u[k]);
+            }
+            const int incl = wave_incl_min_scan(m);
+            const int excl = __builtin_amdgcn_update_dpp(INT_MAX, incl, 0x138, 0xf, 0xf, false);
+            int run = min(excl, init_carry);
+#pragma unroll
+            for (int k = 0; k < C; k++) {
+                run = min(run, u[k]);
+                const int t = run + sHV[k];
+                P[k] = act[k] ? t : DT_INIT;
+                if (!BWD) tmp[((long)i * C + k) * 64 + lane] = t;
+                else lbuf[(rows_done & 1) * WC + jcol[k]] = (float)t * scale; // inactive positions land beyond column w of the line: never stored
+            }
+            if (BWD) { flush_store(); rows_done++; }
+        }
+    }
+    if (BWD && rows_done > 0) { // the last row
+        const float *lb = lbuf + ((rows_done - 1) & 1) * WC;
+#pragma unroll
+        for (int q = 0; q < C; q++) ob[q] = lb[q * 64 + lane];
+        oi = 0;
+        flush_store();
+    }
+}
+template <int C>
+__global__ void __launch_bounds__(256) cuboid_dt_wave(const Unit *units, int n_units, const uint8_t *emap, int *tmp_arena, const long *tmp_off, float *dist) {
+    const int u = blockIdx.x * 4 + (threadIdx.x >> 6);
+    if (u >= n_units) return;
+    const Unit &U = units[u];
+    int *tmp = tmp_arena + tmp_off[u];
+    __shared__ float s_line[4][2 * 64 * C];
+    dt_wave_pass<C, false>(U, emap + U.pix_off, tmp, nullptr, nullptr);
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup"); // the wave's own stores, read back by other lanes of the wave
+    dt_wave_pass<C, true>(U, nullptr, tmp, dist + U.pix_off, s_line[threadIdx.x >> 6]);
+}
+
 // ------------------------------------------------------------------------------------------------ vanishing points
 struct VPEntry { double vp[6]; double ang[6]; }; // vp1.x vp1.y vp2.x ... ; per VP two boundary-edge angles (NaN = none)
 
@@ -1294,6 +1416,7 @@ struct cs_cuboid_batch {
     uint8_t *d_gray = nullptr, *d_emap = nullptr, *d_flag = nullptr;
     int *d_lab = nullptr; // aliases d_dist
     float *d_dist = nullptr;
+    int *d_dttmp = nullptr; long *d_dttmp_off = nullptr; int dt_C = 0; // wave-per-ROI distance transform: int map between the passes, lane-major
     FrameInfo *d_fi = nullptr; FrameDyn *d_fd = nullptr; CamRP *d_cam = nullptr;
     double *d_yaw = nullptr, *d_lines_in = nullptr, *d_lines_al = nullptr, *d_mlines = nullptr, *d_mangle = nullptr, *d_mmid = nullptr;
     Unit *d_units = nullptr; UnitDyn *d_ud = nullptr; int *d_box_first = nullptr, *d_status = nullptr, *d_counts = nullptr;
@@ -1317,7 +1440,7 @@ void cs_cuboid_default_opts(cs_cuboid_opts *o) {
 void cs_cuboid_batch_destroy(cs_ctx *ctx, cs_cuboid_batch *b) {
     if (!b) return;
     if (ctx) { hipSetDevice(ctx->device); hipStreamSynchronize(ctx->stream); }
-    void *ptrs[] = {b->d_gray, b->d_emap, b->d_flag, b->d_dist, b->d_fi, b->d_fd, b->d_cam, b->d_yaw, b->d_lines_in, b->d_lines_al,
+    void *ptrs[] = {b->d_gray, b->d_emap, b->d_flag, b->d_dist, b->d_dttmp, b->d_dttmp_off, b->d_fi, b->d_fd, b->d_cam, b->d_yaw, b->d_lines_in, b->d_lines_al,
                     b->d_mlines, b->d_mangle, b->d_mmid, b->d_units, b->d_ud, b->d_box_first, b->d_status, b->d_counts, b->d_vp,
                     b->d_derr, b->d_aerr, b->d_corners, b->d_score, b->d_nscore, b->d_ckd, b->d_cka, b->d_cidx, b->d_out, b->d_vcount, b->d_vlist};
     for (void *p : ptrs) if (p) hipFree(p);
@@ -1415,7 +1538,21 @@ int cs_cuboid_batch_create(cs_ctx *ctx, int n_frames, int width, int height, con
 #define A_(call) do { int r__ = (call); if (r__ != CS_OK) { cs_cuboid_batch_destroy(ctx, b); return r__; } } while (0)
     const size_t npx = (size_t)n_frames * width * height;
     A_(cs_dalloc(ctx, &b->d_gray, npx));
-    A_(cs_dalloc(ctx, &b->d_emap, (size_t)b->pix_total));
+    A_(cs_dalloc(ctx, &b->d_emap, (size_t)b->pix_total + 256)); // slack: the wave distance transform reads whole dwords at the row ends
+    {
+        static const int CS_[] = {4, 5, 6, 8, 10, 12, 16, 20};
+        const int need = (b->max_roi_w + 63) / 64;
+        for (int c : CS_) if (c >= need) { b->dt_C = c; break; }
+        const char *dte = getenv("CUBESLAM_DT"); // "block": the workgroup-per-ROI variant
+        if (dte && !strcmp(dte, "block")) b->dt_C = 0;
+        if (b->dt_C) {
+            std::vector<long> off(b->units.size() + 1, 0);
+            for (size_t u = 0; u < b->units.size(); u++) off[u + 1] = off[u] + (long)b->units[u].roi_h * b->dt_C * 64;
+            A_(cs_dalloc(ctx, &b->d_dttmp, (size_t)std::max<long>(off.back(), 1)));
+            A_(cs_dalloc(ctx, &b->d_dttmp_off, off.size()));
+            A_(cs_h2d(ctx, b->d_dttmp_off, off.data(), off.size()));
+        }
+    }
     A_(cs_dalloc(ctx, &b->d_dist, (size_t)b->pix_total));
     b->d_lab = (int *)b->d_dist;
     A_(cs_dalloc(ctx, &b->d_fi, (size_t)n_frames));
@@ -1472,7 +1609,14 @@ int cs_cuboid_batch_run(cs_ctx *ctx, cs_cuboid_batch *b) {
               b->d_lab, b->o.canny_low, b->o.canny_high);
     for (int stage = 0; stage < 2; stage++)
         CS_LAUNCH(ctx, "cuboid_canny_cc", cuboid_canny_cc, dim3(b->max_cc_blocks, U), dim3(256), 0, b->d_units, b->d_emap, b->d_lab, stage);
-    if (b->max_roi_w <= 1024) {
+    if (b->dt_C) {
+        const dim3 g((U + 3) / 4), t(256);
+        switch (b->dt_C) {
+#define DTW_(c) case c: CS_LAUNCH(ctx, "cuboid_dt", cuboid_dt_wave<c>, g, t, 0, b->d_units, U, b->d_emap, b->d_dttmp, b->d_dttmp_off, b->d_dist); break;
+            DTW_(4) DTW_(5) DTW_(6) DTW_(8) DTW_(10) DTW_(12) DTW_(16) DTW_(20)
+#undef DTW_
+        }
+    } else if (b->max_roi_w <= 1024) {
         CS_LAUNCH(ctx, "cuboid_dt", cuboid_dt_block, dim3(U), dim3(64 * ((b->max_roi_w + 63) / 64)), 0, b->d_units, b->d_emap, b->d_dist);
     } else { // very wide ROIs: one wave per ROI, segments scanned serially
         const int wbuf = b->W + 2;

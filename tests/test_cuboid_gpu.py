@@ -106,3 +106,27 @@ def test_edge_cases(ctx, oracle):
     got = det.detect_cuboid(s["gray"], s["Twc"], boxes, s["lines"])
     ref, _ = oracle.detect_cuboid(s["gray"], s["K"], s["Twc"], boxes, s["lines"], opts=_oracle_opts(oracle, det))
     _cmp_cuboids(got, ref)
+
+
+@pytest.mark.parametrize("W,H", [(640, 480), (1241, 376)])
+def test_distance_transform_variants_agree(ctx, oracle, monkeypatch, W, H):
+    """The wave-per-ROI distance transform (default, ROI width <= 1280) and the workgroup-per-ROI one (CUBESLAM_DT=block) are the same
+    integer recurrence: identical maps, also for a wide ROI that needs more columns per lane, and both equal to the oracle."""
+    det = detect_3d_cuboid(ctx)
+    s = synth.cuboid_scene(42, n_boxes=3, W=W, H=H)
+    boxes = np.array(s["boxes"], np.float64)
+    boxes = np.concatenate([boxes, [[5, 5, W - 30, H - 60, 0.5]]])  # one ROI almost as wide as the image
+    det.set_calibration(s["K"])
+    maps = {}
+    for mode in ("wave", "block"):
+        if mode == "block":
+            monkeypatch.setenv("CUBESLAM_DT", "block")
+        b = CuboidBatch(ctx, s["gray"][None], s["K"], s["Twc"][None], [boxes], [s["lines"]], det.opts())
+        b.run()
+        maps[mode] = [(b.unit(u)["roi"], b.unit(u)["dist"].copy()) for u in range(len(boxes))]
+        b.close()
+    monkeypatch.delenv("CUBESLAM_DT")
+    for (roi, a), (_, c) in zip(maps["wave"], maps["block"]):
+        x, y, w, h = roi
+        assert np.array_equal(a, c) and np.array_equal(a, oracle.canny_dt_roi(s["gray"], x, y, w, h))
+    assert max(r[0][2] for r in maps["wave"]) > 560
