@@ -1,0 +1,125 @@
+// orb_slam_mirrors.hpp -- dependency-free C++ host-side mirrors of the orb_object_slam / line_lbd entry points on the hot path, over
+// the C-ABI (include/cubeslam_hip.h): same class names, constructor arguments, method names and member defaults as the reference;
+// plain arrays where the reference passes cv::Mat / KeyFrame*.  The adapters with the reference's exact signatures
+// are thin wrappers around these and compile only in a tree that provides OpenCV / Eigen / the ORB-SLAM2 map classes.
+//   cubeslam::ORBextractor      ORB_SLAM2::ORBextractor      (orb_object_slam/include/ORBextractor.h:44-112)
+//   cubeslam::line_lbd_detect   line_lbd_detect              (line_lbd/include/line_lbd/line_lbd_allclass.h:22-70)
+//   cubeslam::Optimizer         ORB_SLAM2::Optimizer         (orb_object_slam/include/Optimizer.h:39-62): BundleAdjustment over the
+//                               flattened graph (cs_ba_problem), PoseOptimization over flattened matches
+#pragma once
+#include <cstdint>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "../../include/cubeslam_hip.h"
+#include "detect_3d_cuboid.hpp" // cubeslam::Context
+
+namespace cubeslam {
+
+inline void check(cs_ctx *ctx, int r, const char *what) {
+    if (r != CS_OK) throw std::runtime_error(std::string(what) + " failed (" + std::to_string(r) + "): " + cs_last_error(ctx));
+}
+
+class ORBextractor {
+  public:
+    // ORBextractor(int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST) + the image size the device buffers are for
+    ORBextractor(Context &c, int nfeatures, float scaleFactor, int nlevels, int iniThFAST, int minThFAST, int width, int height)
+        : ctx_(c), nfeatures_(nfeatures), nlevels_(nlevels), W_(width), H_(height) {
+        check(ctx_.ctx, cs_orb_create(ctx_.ctx, nfeatures, scaleFactor, nlevels, iniThFAST, minThFAST, width, height, 1, &e_), "cs_orb_create");
+    }
+    ~ORBextractor() { cs_orb_destroy(ctx_.ctx, e_); }
+    ORBextractor(const ORBextractor &) = delete;
+    ORBextractor &operator=(const ORBextractor &) = delete;
+    // operator()(InputArray image, InputArray mask, vector<KeyPoint>& keypoints, OutputArray descriptors): mask is ignored like in the
+    // reference (:1036-1040); descriptors = keypoints.size() x 32 bytes
+    void operator()(const uint8_t *gray, int stride, std::vector<cs_keypoint> &keypoints, std::vector<uint8_t> &descriptors) {
+        const int cap = nfeatures_ + 4 * nlevels_ + 64;
+        keypoints.resize((size_t)cap); descriptors.resize((size_t)cap * 32);
+        int n = 0;
+        check(ctx_.ctx, cs_orb_extract(ctx_.ctx, e_, gray, 1, stride, keypoints.data(), descriptors.data(), cap, &n), "cs_orb_extract");
+        keypoints.resize((size_t)n); descriptors.resize((size_t)n * 32);
+    }
+    int GetLevels() const { return nlevels_; }
+    std::vector<float> GetScaleFactors() const { return table(0); }
+    std::vector<float> GetInverseScaleFactors() const { return table(1); }
+    std::vector<float> GetScaleSigmaSquares() const { return table(2); }
+    std::vector<float> GetInverseScaleSigmaSquares() const { return table(3); }
+    cs_orb *handle() { return e_; }
+
+  private:
+    std::vector<float> table(int which) const { std::vector<float> t((size_t)nlevels_); cs_orb_get_table(e_, which, t.data()); return t; }
+    Context &ctx_;
+    cs_orb *e_ = nullptr;
+    int nfeatures_, nlevels_, W_, H_;
+};
+
+class line_lbd_detect {
+  public:
+    line_lbd_detect(Context &c, int width, int height) : ctx_(c), W_(width), H_(height) { check(ctx_.ctx, cs_lsd_create(ctx_.ctx, width, height, 1, &l_), "cs_lsd_create"); }
+    ~line_lbd_detect() { cs_lsd_destroy(ctx_.ctx, l_); }
+    line_lbd_detect(const line_lbd_detect &) = delete;
+    line_lbd_detect &operator=(const line_lbd_detect &) = delete;
+    // detect_raw_lines(const cv::Mat& gray_img, std::vector<KeyLine>& keylines_out)
+    void detect_raw_lines(const uint8_t *gray, int stride, std::vector<cs_keyline> &keylines_out) {
+        keylines_out.resize(cap_);
+        int n = 0;
+        check(ctx_.ctx, cs_lsd_detect(ctx_.ctx, l_, gray, 1, stride, keylines_out.data(), (int)cap_, &n), "cs_lsd_detect");
+        keylines_out.resize((size_t)n);
+    }
+    // detect_filter_lines(const cv::Mat& gray_img, cv::Mat& linesmat_out): rows of x1 y1 x2 y2 (CV_32F), lineLength > line_length_thres
+    void detect_filter_lines(const uint8_t *gray, int stride, std::vector<float> &linesmat_out) {
+        linesmat_out.resize(cap_ * 4);
+        int n = 0;
+        check(ctx_.ctx, cs_lsd_detect_filter_lines(ctx_.ctx, l_, gray, 1, stride, (float)line_length_thres, linesmat_out.data(), (int)cap_, &n), "cs_lsd_detect_filter_lines");
+        linesmat_out.resize((size_t)n * 4);
+    }
+    // get_line_descriptors(gray, keylines, descriptors): 32-byte LBD per KeyLine
+    void get_line_descriptors(const uint8_t *gray, int stride, const std::vector<cs_keyline> &keylines, std::vector<uint8_t> &line_descrips) {
+        line_descrips.assign(keylines.size() * 32, 0);
+        if (keylines.empty()) return;
+        check(ctx_.ctx, cs_lbd_compute(ctx_.ctx, gray, W_, H_, stride, keylines.data(), (int)keylines.size(), line_descrips.data(), nullptr), "cs_lbd_compute");
+    }
+    // public members of the reference class, same names and defaults (line_lbd_allclass.h:27-31, constructor line_lbd/class/line_lbd_allclass.cpp:117-123)
+    bool use_LSD = false; // the EDLine detector is not on the hot path: every method here runs the LSD detector
+    float line_length_thres = 50;
+    int numoctaves_ = 1;
+    float octaveratio_ = 2.0f;
+
+  private:
+    Context &ctx_;
+    cs_lsd *l_ = nullptr;
+    int W_, H_;
+    size_t cap_ = 20000;
+};
+
+struct Optimizer {
+    // Optimizer::BundleAdjustment / LocalBACameraPointObjects: the caller flattens key frames, map points, objects and their edges into
+    // cs_ba_problem; estimates come back in the same order.  pbStopFlag is polled where g2o polls forceStopFlag.
+    static cs_ba_stats BundleAdjustment(Context &c, const cs_ba_problem &problem, int nIterations, const volatile int *pbStopFlag, std::vector<double> &cam_pose,
+                                        std::vector<double> &points, std::vector<double> &cuboid_pose) {
+        cs_ba *b = nullptr;
+        check(c.ctx, cs_ba_create(c.ctx, &problem, 0, 1, &b), "cs_ba_create");
+        cs_ba_stats st{};
+        int r = cs_ba_optimize(c.ctx, b, nIterations, pbStopFlag, &st);
+        cam_pose.assign((size_t)problem.n_cams * 7, 0.0); points.assign((size_t)problem.n_points * 3, 0.0); cuboid_pose.assign((size_t)(problem.n_cuboids > 0 ? problem.n_cuboids : 1) * 7, 0.0);
+        if (r == CS_OK) r = cs_ba_read(c.ctx, b, cam_pose.data(), points.data(), cuboid_pose.data());
+        cs_ba_destroy(c.ctx, b);
+        check(c.ctx, r, "cs_ba_optimize");
+        cuboid_pose.resize((size_t)problem.n_cuboids * 7);
+        return st;
+    }
+    // Optimizer::PoseOptimization(Frame*): matched map points Xw (n x 3), observations (u, v, u_right or < 0) (n x 3), invSigma2 (n),
+    // intrinsics (fx fy cx cy bf), pose [t, q] in / out, mvbOutlier out; returns nInitialCorrespondences - nBad
+    static int PoseOptimization(Context &c, int n, const double *Xw, const double *obs, const double *inv_sigma2, const double intr[5], const double pose_in[7],
+                                double pose_out[7], std::vector<uint8_t> &mvbOutlier) {
+        const int off[2] = {0, n};
+        int n_inl = 0;
+        mvbOutlier.assign((size_t)n + 1, 0);
+        check(c.ctx, cs_pose_optimization(c.ctx, 1, off, Xw, obs, inv_sigma2, intr, pose_in, pose_out, mvbOutlier.data(), &n_inl), "cs_pose_optimization");
+        mvbOutlier.resize((size_t)n);
+        return n_inl;
+    }
+};
+
+} // namespace cubeslam
