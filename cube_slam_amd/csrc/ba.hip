@@ -466,11 +466,15 @@ __device__ __forceinline__ void load_block18(const double *p, double (&v)[18]) {
 // lines); instead the wave fetches the 128 blocks cooperatively -- 16 bytes per lane, nine consecutive lanes on one block, so an
 // instruction touches ~11 lines -- into LDS, and every lane then reads its pair from there.  Same arithmetic, same lane -> pair
 // assignment and the same reduction as a per-lane gather, so the sums are bit-identical to it.
-__global__ void __launch_bounds__(256) ba_schur_slots(Params G, int n_slots, const int *slot_off, const int2 *trips, double lambda, double *S) {
+__global__ void __launch_bounds__(256) ba_schur_slots(Params G, int n_slots, const int *slot_perm, const int *slot_off, const int2 *trips, double lambda, double *S) {
     __shared__ double2 s_blk[4][64 * 9]; // one operand at a time (B D^-1 of the 64 pairs, then B): 9 KB per wave keeps 16 waves per CU
     __shared__ int s_idx[4][128];
-    const int wv = threadIdx.x >> 6, s = blockIdx.x * 4 + wv, lane = threadIdx.x & 63;
-    if (s >= n_slots) return; // whole wave; no workgroup barrier below
+    const int wv = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    if (blockIdx.x * 4 + wv >= n_slots) return; // whole wave; no workgroup barrier below
+    // slot_perm: workgroup b runs on XCD b % 8 (observed dispatch rule), and the permutation gives every XCD a contiguous range of
+    // the trajectory, so the B / B D^-1 blocks of a camera's observations -- shared by the ~Bc slots of that camera -- are fetched
+    // into one XCD's L2 instead of all eight (fabric reads 557 MB -> see DESIGN.md 7.5); speed only, the sums do not change
+    const int s = slot_perm[blockIdx.x * 4 + wv];
     double2 *sb = s_blk[wv];
     int *si = s_idx[wv];
     double acc[36];
@@ -1482,7 +1486,7 @@ struct cs_ba {
     int rank = 0, world = 1, n_slots = 0, max_col = 0, max_part = 0;
     cs_allreduce_fn allreduce = nullptr; void *ar_user = nullptr;
     std::vector<void *> owned;
-    int *d_pose_off = nullptr, *d_pose_obs = nullptr, *d_pe_off = nullptr, *d_pe_list = nullptr, *d_slot_off = nullptr, *d_slot_dst = nullptr, *d_col_off = nullptr,
+    int *d_pose_off = nullptr, *d_pose_obs = nullptr, *d_pe_off = nullptr, *d_pe_list = nullptr, *d_slot_off = nullptr, *d_slot_perm = nullptr, *d_slot_dst = nullptr, *d_col_off = nullptr,
         *d_rows = nullptr, *d_pair_off = nullptr, *d_upd_tgt = nullptr, *d_pos = nullptr, *d_status = nullptr;
     int2 *d_trips = nullptr; uint8_t *d_slot_tr = nullptr;
     double *d_reduce = nullptr, *d_band = nullptr, *d_xperm = nullptr, *d_partials = nullptr, *d_scal = nullptr;
@@ -1553,7 +1557,7 @@ static int ba_schur(cs_ctx *ctx, cs_ba *b, double lambda) { // Schur part of Blo
     const int nl = G.lm_e - G.lm_b;
     if (nl > 0) CS_LAUNCH(ctx, "ba_lm_dinv", ba_lm_dinv, dim3((nl + 255) / 256), dim3(256), 0, G, lambda);
     if (G.o_e > G.o_b) CS_LAUNCH(ctx, "ba_schur_bd", ba_schur_bd, dim3((int)(((long)(G.o_e - G.o_b) * 6 + 255) / 256)), dim3(256), 0, G, b->d_bw);
-    CS_LAUNCH(ctx, "ba_schur_slots", ba_schur_slots, dim3((b->n_slots + 3) / 4), dim3(256), 0, G, b->n_slots, b->d_slot_off, b->d_trips, lambda, b->d_reduce);
+    CS_LAUNCH(ctx, "ba_schur_slots", ba_schur_slots, dim3((b->n_slots + 3) / 4), dim3(256), 0, G, b->n_slots, b->d_slot_perm, b->d_slot_off, b->d_trips, lambda, b->d_reduce);
     CS_LAUNCH(ctx, "ba_schur_b", ba_schur_b, dim3((G.P + 3) / 4), dim3(256), 0, G, b->d_pose_off, b->d_pose_obs, b->d_bw, b->d_reduce + (long)b->n_slots * 36);
     return CS_OK;
 }
@@ -1894,6 +1898,26 @@ int cs_ba_create(cs_ctx *ctx, const cs_ba_problem *p, int rank, int world, cs_ba
     A_(dalloc_copy(ctx, b, &b->d_pe_off, pe_off.data(), pe_off.size()));
     A_(dalloc_copy(ctx, b, &b->d_pe_list, pe_list.data(), pe_list.size()));
     A_(dalloc_copy(ctx, b, &b->d_slot_off, slot_off.data(), slot_off.size()));
+    { // XCD-aware slot order for ba_schur_slots: sort by the smaller pose index of the block, cut into 8 contiguous ranges, deal range x to
+      // the workgroups with blockIdx % 8 == x (4 slots per workgroup)
+        const int ns = b->n_slots;
+        std::vector<int> by_pose((size_t)ns), perm((size_t)((ns + 3) / 4) * 4, 0);
+        for (int i = 0; i < ns; i++) by_pose[i] = i;
+        auto keyf = [&](int q) { const int a = slot_rc[q].first, c = slot_rc[q].second; return a < 0 ? (1 << 30) : std::min(a, c); };
+        std::stable_sort(by_pose.begin(), by_pose.end(), [&](int x, int y) { return keyf(x) < keyf(y); });
+        const int nblk = (ns + 3) / 4;
+        int next = 0;
+        for (int x = 0; x < 8; x++) // blocks x, x+8, x+16, ... take consecutive slots of the sorted list
+            for (int blk = x; blk < nblk; blk += 8)
+                for (int k = 0; k < 4; k++) perm[(size_t)blk * 4 + k] = next < ns ? by_pose[next++] : -1;
+        // the tail entries (-1) are never read: the kernel stops at n_slots positions -- make the first n_slots positions a permutation
+        std::vector<int> flat; flat.reserve(ns);
+        for (int v : perm) if (v >= 0) flat.push_back(v);
+        std::vector<int> fin((size_t)ns);
+        // positions [0, ns) must all be valid: fill in block order, skipping the holes of the partially filled last blocks
+        { size_t w = 0; for (size_t i = 0; i < perm.size() && w < (size_t)ns; i++) if (perm[i] >= 0) fin[w++] = perm[i]; }
+        A_(dalloc_copy(ctx, b, &b->d_slot_perm, fin.data(), fin.size()));
+    }
     A_(dalloc_copy(ctx, b, &b->d_trips, trips.data(), trips.size()));
     A_(dalloc_copy(ctx, b, &b->d_slot_dst, slot_dst.data(), slot_dst.size()));
     A_(dalloc_copy(ctx, b, &b->d_slot_tr, slot_tr.data(), slot_tr.size()));
