@@ -103,8 +103,15 @@ def ba_bench(ctx, rank, world, iters, with_cpu):
     if "ba_schur_slots" in kern:
         alg = 144.0 * O / world + 72.0 * Lm / world + 288.0 * 5 * C
         ach = alg / (kern["ba_schur_slots"] * 1e-6) / 1e9
+        traffic = None
+        if world == 1 and (len(d["cam_pose"]), len(d["points"])) == (1000, 100000):  # the committed PMC pass is of exactly this graph on one GPU
+            try:
+                tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["ba_schur_slots"]
+                traffic = tj["read_bytes"] + tj["write_bytes"]
+            except Exception:
+                traffic = None
         out["roofline"] = {"bound": "hbm", "kernel": "ba_schur_slots", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                           "traffic": None, "algorithmic_bytes_per_launch": alg}
+                           "traffic": traffic, "algorithmic_bytes_per_launch": alg}
     if with_cpu:
         from oracle import pyoracle as po
         t0 = time.perf_counter()
