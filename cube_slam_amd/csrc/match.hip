@@ -719,33 +719,35 @@ int cs_match_for_triangulation(cs_ctx *ctx, const cs_keypoint *keys1Un, const ui
     return CS_OK;
 }
 
-int cs_match_by_bow(cs_ctx *ctx, const cs_keypoint *keysKF, const uint8_t *descKF, int NK, const int *nodeKF, const uint8_t *skipKF, const cs_keypoint *keysF,
-                    const uint8_t *descF, int NF, const int *nodeF, const uint8_t *skipF, float nnratio, int check_orientation, int *matchesF, int *nmatches) {
-    if (!ctx || NK < 0 || NF < 0 || !matchesF || !nmatches || (NK && (!keysKF || !descKF || !nodeKF || !skipKF)) || (NF && (!keysF || !descF || !nodeF))) return CS_ERR_BAD_ARG;
-    *nmatches = 0;
-    for (int i = 0; i < NF; i++) matchesF[i] = -1;
-    if (NK == 0 || NF == 0) return CS_OK;
+// Shared by both SearchByBoW overloads: distances of every non-skipped K feature to the F features of its vocabulary node.
+struct BowDists {
+    std::vector<int> start, items, nkc, off, dists; // node CSR over F, compact node of every K feature (-1 none), slice offsets, distances
+    std::vector<std::pair<int, int>> order;         // (original node id, K index): the reference's visiting order
+};
+static int bow_node_dists(cs_ctx *ctx, const uint8_t *descK, int NK, const int *nodeK, const uint8_t *skipK, const uint8_t *descF, int NF, const int *nodeF, BowDists &B) {
     CS_HIP(ctx, hipSetDevice(ctx->device));
     std::vector<int> ids;
     for (int i = 0; i < NF; i++) if (nodeF[i] >= 0) ids.push_back(nodeF[i]);
     std::sort(ids.begin(), ids.end()); ids.erase(std::unique(ids.begin(), ids.end()), ids.end());
     const int n_nodes = (int)ids.size();
     auto compact = [&](int nd) { if (nd < 0) return -1; auto it = std::lower_bound(ids.begin(), ids.end(), nd); return (it != ids.end() && *it == nd) ? (int)(it - ids.begin()) : -1; };
-    std::vector<int> start((size_t)n_nodes + 1, 0), items, nkc((size_t)NK), nfc((size_t)NF), off((size_t)NK + 1, 0);
+    std::vector<int> &start = B.start, &items = B.items, &nkc = B.nkc, &off = B.off, &dists = B.dists;
+    std::vector<int> nfc((size_t)NF);
+    start.assign((size_t)n_nodes + 1, 0); nkc.assign((size_t)NK, -1); off.assign((size_t)NK + 1, 0);
     for (int i = 0; i < NF; i++) { nfc[i] = compact(nodeF[i]); if (nfc[i] >= 0) start[nfc[i] + 1]++; }
     for (int k = 0; k < n_nodes; k++) start[k + 1] += start[k];
     items.resize((size_t)std::max(start[n_nodes], 1));
     { std::vector<int> pos(start.begin(), start.end() - 1); for (int i = 0; i < NF; i++) if (nfc[i] >= 0) items[pos[nfc[i]]++] = i; }
-    for (int i = 0; i < NK; i++) { nkc[i] = skipKF[i] ? -1 : compact(nodeKF[i]); off[i + 1] = off[i] + (nkc[i] >= 0 ? start[nkc[i] + 1] - start[nkc[i]] : 0); }
+    for (int i = 0; i < NK; i++) { nkc[i] = skipK[i] ? -1 : compact(nodeK[i]); off[i + 1] = off[i] + (nkc[i] >= 0 ? start[nkc[i] + 1] - start[nkc[i]] : 0); }
     const int total = off[NK];
-    std::vector<int> dists((size_t)std::max(total, 1));
+    dists.resize((size_t)std::max(total, 1));
     if (total > 0) {
         unsigned long long *d_dk = nullptr, *d_df = nullptr; int *d_nk = nullptr, *d_st = nullptr, *d_it = nullptr, *d_off = nullptr, *d_di = nullptr;
         int r = cs_dalloc(ctx, &d_dk, (size_t)NK * 4);
 #define BA_(call) if (!r) r = (call)
         BA_(cs_dalloc(ctx, &d_df, (size_t)NF * 4)); BA_(cs_dalloc(ctx, &d_nk, (size_t)NK)); BA_(cs_dalloc(ctx, &d_st, start.size())); BA_(cs_dalloc(ctx, &d_it, items.size()));
         BA_(cs_dalloc(ctx, &d_off, off.size())); BA_(cs_dalloc(ctx, &d_di, (size_t)total));
-        BA_(cs_h2d(ctx, (uint8_t *)d_dk, descKF, (size_t)NK * 32)); BA_(cs_h2d(ctx, (uint8_t *)d_df, descF, (size_t)NF * 32)); BA_(cs_h2d(ctx, d_nk, nkc.data(), (size_t)NK));
+        BA_(cs_h2d(ctx, (uint8_t *)d_dk, descK, (size_t)NK * 32)); BA_(cs_h2d(ctx, (uint8_t *)d_df, descF, (size_t)NF * 32)); BA_(cs_h2d(ctx, d_nk, nkc.data(), (size_t)NK));
         BA_(cs_h2d(ctx, d_st, start.data(), start.size())); BA_(cs_h2d(ctx, d_it, items.data(), items.size())); BA_(cs_h2d(ctx, d_off, off.data(), off.size()));
 #undef BA_
         if (!r) {
@@ -758,10 +760,23 @@ int cs_match_by_bow(cs_ctx *ctx, const cs_keypoint *keysKF, const uint8_t *descK
         for (void *p : ptrs) if (p) hipFree(p);
         if (r) return r;
     }
-    // greedy resolve in the reference's order: nodes ascending (std::map), key-frame features ascending inside a node
-    std::vector<std::pair<int, int>> order; // (original node id, kf index)
-    for (int i = 0; i < NK; i++) if (nkc[i] >= 0) order.push_back(std::make_pair(nodeKF[i], i));
-    std::sort(order.begin(), order.end());
+    // the reference's order: nodes ascending (std::map), K features ascending inside a node
+    for (int i = 0; i < NK; i++) if (nkc[i] >= 0) B.order.push_back(std::make_pair(nodeK[i], i));
+    std::sort(B.order.begin(), B.order.end());
+    return CS_OK;
+}
+
+int cs_match_by_bow(cs_ctx *ctx, const cs_keypoint *keysKF, const uint8_t *descKF, int NK, const int *nodeKF, const uint8_t *skipKF, const cs_keypoint *keysF,
+                    const uint8_t *descF, int NF, const int *nodeF, const uint8_t *skipF, float nnratio, int check_orientation, int *matchesF, int *nmatches) {
+    if (!ctx || NK < 0 || NF < 0 || !matchesF || !nmatches || (NK && (!keysKF || !descKF || !nodeKF || !skipKF)) || (NF && (!keysF || !descF || !nodeF))) return CS_ERR_BAD_ARG;
+    *nmatches = 0;
+    for (int i = 0; i < NF; i++) matchesF[i] = -1;
+    if (NK == 0 || NF == 0) return CS_OK;
+    BowDists B;
+    if (int r = bow_node_dists(ctx, descKF, NK, nodeKF, skipKF, descF, NF, nodeF, B)) return r;
+    const std::vector<int> &start = B.start, &items = B.items, &nkc = B.nkc, &off = B.off, &dists = B.dists;
+    const std::vector<std::pair<int, int>> &order = B.order;
+    // greedy resolve in the reference's order
     int nm = 0;
     std::vector<int> rotHist[HISTO_LENGTH];
     for (const auto &ok : order) {
@@ -788,6 +803,47 @@ int cs_match_by_bow(cs_ctx *ctx, const cs_keypoint *keysKF, const uint8_t *descK
         for (int i = 0; i < HISTO_LENGTH; i++) {
             if (i == ind1 || i == ind2 || i == ind3) continue;
             for (int j : rotHist[i]) { matchesF[j] = -1; nm--; }
+        }
+    }
+    *nmatches = nm;
+    return CS_OK;
+}
+
+int cs_match_by_bow_kf(cs_ctx *ctx, const cs_keypoint *keys1, const uint8_t *desc1, int N1, const int *node1, const uint8_t *skip1, const cs_keypoint *keys2,
+                       const uint8_t *desc2, int N2, const int *node2, const uint8_t *skip2, float nnratio, int check_orientation, int *matches12, int *nmatches) {
+    if (!ctx || N1 < 0 || N2 < 0 || !nmatches || (N1 && (!keys1 || !desc1 || !node1 || !skip1 || !matches12)) || (N2 && (!keys2 || !desc2 || !node2 || !skip2))) return CS_ERR_BAD_ARG;
+    *nmatches = 0;
+    for (int i = 0; i < N1; i++) matches12[i] = -1;
+    if (N1 == 0 || N2 == 0) return CS_OK;
+    BowDists B;
+    if (int r = bow_node_dists(ctx, desc1, N1, node1, skip1, desc2, N2, node2, B)) return r;
+    std::vector<uint8_t> matched2((size_t)N2, 0); // vbMatched2 (:556)
+    std::vector<int> rotHist[HISTO_LENGTH];
+    int nm = 0;
+    for (const auto &ok : B.order) {
+        const int i1 = ok.second, nd = B.nkc[i1], b = B.start[nd], n = B.start[nd + 1] - b;
+        int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
+        for (int p = 0; p < n; p++) {
+            const int i2 = B.items[b + p];
+            if (matched2[i2] || skip2[i2]) continue; // :598-602
+            const int dist = B.dists[B.off[i1] + p];
+            if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdx2 = i2; }
+            else if (dist < bestDist2) bestDist2 = dist;
+        }
+        if (bestDist1 < TH_LOW && static_cast<float>(bestDist1) < nnratio * static_cast<float>(bestDist2)) { // strict, unlike :268
+            matches12[i1] = bestIdx2;
+            matched2[bestIdx2] = 1;
+            if (check_orientation) rotHist[rot_bin(keys1[i1].angle, keys2[bestIdx2].angle)].push_back(i1);
+            nm++;
+        }
+    }
+    if (check_orientation) {
+        int sizes[HISTO_LENGTH], ind1 = -1, ind2 = -1, ind3 = -1;
+        for (int i = 0; i < HISTO_LENGTH; i++) sizes[i] = (int)rotHist[i].size();
+        three_maxima(sizes, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int j : rotHist[i]) { matches12[j] = -1; nm--; }
         }
     }
     *nmatches = nm;

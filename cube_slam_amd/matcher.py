@@ -120,6 +120,19 @@ class ORBmatcher:
                                                   C.c_float(self.mfNNratio), int(self.mbCheckOrientation), _p(mf, C.c_int), C.byref(n)), "cs_match_by_bow")
         return mf[:len(kf)].copy(), n.value
 
+    def SearchByBoWKeyFrames(self, keys1, desc1, node1, skip1, keys2, desc2, node2, skip2):
+        """ORBmatcher::SearchByBoW(pKF1, pKF2, vpMatches12) (ORBmatcher.cc:544-677): per KF1 feature the KF2 feature whose map point it is matched
+        to (-1 none), and nmatches.  skip = the feature has no usable map point."""
+        k1 = np.ascontiguousarray(keys1, KEYPOINT_DTYPE); d1 = np.ascontiguousarray(desc1, np.uint8); k2 = np.ascontiguousarray(keys2, KEYPOINT_DTYPE)
+        d2 = np.ascontiguousarray(desc2, np.uint8)
+        n1 = np.ascontiguousarray(node1, np.int32); s1 = np.ascontiguousarray(skip1, np.uint8); n2 = np.ascontiguousarray(node2, np.int32)
+        s2 = np.ascontiguousarray(skip2, np.uint8)
+        m12 = np.zeros(max(len(k1), 1), np.int32); n = C.c_int()
+        check(self.ctx.ptr, lib().cs_match_by_bow_kf(self.ctx.ptr, k1.ctypes.data_as(C.c_void_p), _p(d1, C.c_uint8), len(k1), _p(n1, C.c_int), _p(s1, C.c_uint8),
+                                                     k2.ctypes.data_as(C.c_void_p), _p(d2, C.c_uint8), len(k2), _p(n2, C.c_int), _p(s2, C.c_uint8),
+                                                     C.c_float(self.mfNNratio), int(self.mbCheckOrientation), _p(m12, C.c_int), C.byref(n)), "cs_match_by_bow_kf")
+        return m12[:len(k1)].copy(), n.value
+
     def close(self):
         if self._m:
             lib().cs_matcher_destroy(self.ctx.ptr, self._m)

@@ -241,6 +241,12 @@ int cs_match_for_triangulation(cs_ctx *ctx, const cs_keypoint *keys1Un, const ui
  * matchesF[NF] = index of the key-frame feature whose map point the frame feature receives, -1 none. */
 int cs_match_by_bow(cs_ctx *ctx, const cs_keypoint *keysKF, const uint8_t *descKF, int NK, const int *nodeKF, const uint8_t *skipKF, const cs_keypoint *keysF,
                     const uint8_t *descF, int NF, const int *nodeF, const uint8_t *skipF, float nnratio, int check_orientation, int *matchesF, int *nmatches);
+/* ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vpMatches12) (ORBmatcher.cc:544-677), the loop-closing overload: skip1 / skip2 =
+ * the feature has no usable map point (NULL or isBad, :580-584, :598-603); a KF2 feature is claimed once (vbMatched2); the acceptance
+ * test is bestDist1 < TH_LOW (strict here, :625) and the ratio test; the rotation histogram holds KF1 indices.  matches12[N1] = index
+ * of the KF2 feature whose map point vpMatches12[idx1] receives, -1 none. */
+int cs_match_by_bow_kf(cs_ctx *ctx, const cs_keypoint *keys1, const uint8_t *desc1, int N1, const int *node1, const uint8_t *skip1, const cs_keypoint *keys2,
+                       const uint8_t *desc2, int N2, const int *node2, const uint8_t *skip2, float nnratio, int check_orientation, int *matches12, int *nmatches);
 /* ORBmatcher::DescriptorDistance over all pairs: exact best / second-best per query (first index wins ties). */
 int cs_hamming_knn2(cs_ctx *ctx, const uint8_t *q, int nq, const uint8_t *t, int nt, int *best_idx, int *best_dist, int *second_dist);
 

@@ -413,3 +413,58 @@ int orc_search_by_bow(const orc_frame *KF, const int *nodeKF, const uint8_t *ski
     }
     return nmatches;
 }
+
+// ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, vpMatches12) (ORBmatcher.cc:544-677).  skip = feature without a usable map point.
+int orc_search_by_bow_kf(const orc_frame *K1, const int *node1, const uint8_t *skip1, const orc_frame *K2, const int *node2, const uint8_t *skip2, float nnratio,
+                         int check_orientation, int *matches12) {
+    std::map<int, std::vector<int>> fv1, fv2;
+    for (int i = 0; i < K1->N; i++) if (node1[i] >= 0) fv1[node1[i]].push_back(i);
+    for (int i = 0; i < K2->N; i++) if (node2[i] >= 0) fv2[node2[i]].push_back(i);
+    for (int i = 0; i < K1->N; i++) matches12[i] = -1;
+    std::vector<bool> vbMatched2((size_t)K2->N, false);
+    std::vector<int> rotHist[HISTO_LENGTH];
+    const float factor = 1.0f / HISTO_LENGTH;
+    int nmatches = 0;
+    auto f1it = fv1.begin(), f1end = fv1.end();
+    auto f2it = fv2.begin(), f2end = fv2.end();
+    while (f1it != f1end && f2it != f2end) {
+        if (f1it->first == f2it->first) {
+            for (int idx1 : f1it->second) {
+                if (skip1[idx1]) continue;
+                const uint8_t *d1 = K1->desc + (size_t)idx1 * 32;
+                int bestDist1 = 256, bestIdx2 = -1, bestDist2 = 256;
+                for (int idx2 : f2it->second) {
+                    if (vbMatched2[idx2] || skip2[idx2]) continue;
+                    const int dist = descriptor_distance(d1, K2->desc + (size_t)idx2 * 32);
+                    if (dist < bestDist1) { bestDist2 = bestDist1; bestDist1 = dist; bestIdx2 = idx2; }
+                    else if (dist < bestDist2) bestDist2 = dist;
+                }
+                if (bestDist1 < TH_LOW) {
+                    if (static_cast<float>(bestDist1) < nnratio * static_cast<float>(bestDist2)) {
+                        matches12[idx1] = bestIdx2;
+                        vbMatched2[bestIdx2] = true;
+                        if (check_orientation) {
+                            float rot = K1->keysUn[idx1].angle - K2->keysUn[bestIdx2].angle;
+                            if (rot < 0.0) rot += 360.0f;
+                            int bin = (int)std::round(rot * factor);
+                            if (bin == HISTO_LENGTH) bin = 0;
+                            rotHist[bin].push_back(idx1);
+                        }
+                        nmatches++;
+                    }
+                }
+            }
+            ++f1it; ++f2it;
+        } else if (f1it->first < f2it->first) f1it = fv1.lower_bound(f2it->first);
+        else f2it = fv2.lower_bound(f1it->first);
+    }
+    if (check_orientation) {
+        int ind1 = -1, ind2 = -1, ind3 = -1;
+        three_maxima(rotHist, HISTO_LENGTH, ind1, ind2, ind3);
+        for (int i = 0; i < HISTO_LENGTH; i++) {
+            if (i == ind1 || i == ind2 || i == ind3) continue;
+            for (int j : rotHist[i]) { matches12[j] = -1; nmatches--; }
+        }
+    }
+    return nmatches;
+}

@@ -167,6 +167,8 @@ int orc_search_for_triangulation(const orc_frame *F1, const int *node1, const ui
 /* ORBmatcher::SearchByBoW(KeyFrame*, Frame&, vpMapPointMatches) (:171-310) with the FeatureVector given as a node id per feature. */
 int orc_search_by_bow(const orc_frame *KF, const int *nodeKF, const uint8_t *skipKF, const orc_frame *F, const int *nodeF, const uint8_t *skipF, float nnratio,
                       int check_orientation, int *matchesF);
+int orc_search_by_bow_kf(const orc_frame *K1, const int *node1, const uint8_t *skip1, const orc_frame *K2, const int *node2, const uint8_t *skip2, float nnratio,
+                         int check_orientation, int *matches12);
 /* exact 2-NN in Hamming space over all pairs (first index wins ties) */
 void orc_hamming_knn2(const uint8_t *q, int nq, const uint8_t *t, int nt, int *best_idx, int *best_dist, int *second_dist);
 

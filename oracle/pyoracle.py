@@ -341,6 +341,15 @@ def search_by_bow(KF, nodeKF, skipKF, F, nodeF, skipF, nnratio, check_ori=True):
     return mf[:F.N].copy(), n
 
 
+def search_by_bow_kf(K1, node1, skip1, K2, node2, skip2, nnratio, check_ori=True):
+    n1 = np.ascontiguousarray(node1, np.int32); s1 = np.ascontiguousarray(skip1, np.uint8)
+    n2 = np.ascontiguousarray(node2, np.int32); s2 = np.ascontiguousarray(skip2, np.uint8)
+    m12 = np.zeros(max(K1.N, 1), np.int32)
+    n = lib().orc_search_by_bow_kf(C.byref(K1), _p(n1, C.c_int), _p(s1, C.c_uint8), C.byref(K2), _p(n2, C.c_int), _p(s2, C.c_uint8), C.c_float(nnratio),
+                                   int(check_ori), _p(m12, C.c_int))
+    return m12[:K1.N].copy(), n
+
+
 def hamming_knn2(q, t):
     q = np.ascontiguousarray(q, np.uint8); t = np.ascontiguousarray(t, np.uint8)
     bi = np.zeros(len(q), np.int32); bd = np.zeros(len(q), np.int32); sd = np.zeros(len(q), np.int32)

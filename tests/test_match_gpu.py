@@ -228,3 +228,26 @@ def test_search_by_bow(ctx, oracle, frames):
     r, nr = oracle.search_by_bow(KFb, n1b, np.zeros(600, np.uint8), Fo, node2, None, 0.95, False)
     assert np.array_equal(g, r) and ng == nr and (g >= 300).sum() > 0 and len(set(g[g >= 0])) == (g >= 0).sum()
     m.close()
+
+
+def test_search_by_bow_key_frames(ctx, oracle, frames):
+    """ORBmatcher::SearchByBoW(KeyFrame, KeyFrame) (:544-677): matches12 indexed by KF1, claims on KF2, strict TH_LOW."""
+    (k1, d1), (k2, d2) = frames
+    rng = np.random.default_rng(9)
+    node = lambda k, dx: ((np.clip(k["x"] + dx, 0, W - 1) // 60).astype(np.int32) * 8 + (k["y"] // 50).astype(np.int32))
+    node1, node2 = node(k1, 0.0), node(k2, 4.0)
+    node1[rng.uniform(size=len(k1)) < 0.03] = -1
+    skip1 = (rng.uniform(size=len(k1)) < 0.2).astype(np.uint8)
+    skip2 = (rng.uniform(size=len(k2)) < 0.2).astype(np.uint8)
+    K1 = oracle.make_frame(k1, d1, BOUNDS); K2 = oracle.make_frame(k2, d2, BOUNDS)
+    for ratio, ori in ((0.75, True), (0.9, False), (0.6, True)):
+        m = ORBmatcher(ratio, ori, ctx=ctx)
+        g, ng = m.SearchByBoWKeyFrames(k1, d1, node1, skip1, k2, d2, node2, skip2)
+        r, nr = oracle.search_by_bow_kf(K1, node1, skip1, K2, node2, skip2, ratio, ori)
+        assert np.array_equal(g, r) and ng == nr == int((g >= 0).sum()) and ng > 80
+        assert (skip1[g >= 0] == 0).all() and (skip2[g[g >= 0]] == 0).all() and len(set(g[g >= 0])) == ng
+        m.close()
+    m = ORBmatcher(0.9, True, ctx=ctx)
+    g, ng = m.SearchByBoWKeyFrames(k1[:0], d1[:0], node1[:0], skip1[:0], k2, d2, node2, skip2)
+    assert len(g) == 0 and ng == 0
+    m.close()

@@ -125,3 +125,22 @@ def test_search_by_bow_claim_order(oracle):
     assert m2[0] == 0 and m2[1] != 1, "a key-frame feature without a usable map point does not claim anything"
     m3, n3 = oracle.search_by_bow(KF, [5, 5, 5], [0, 0, 0], F, [5, 5, 5, 6], None, 0.2, False)
     assert m3[0] == -1, "2 < 0.2 * 8 fails: the ratio test uses the second best of the UNCLAIMED candidates"
+
+
+def test_search_by_bow_key_frames(oracle):
+    """ORBmatcher::SearchByBoW(KeyFrame, KeyFrame) (:544-677): claims on KF2, the strict TH_LOW test, the orientation filter over KF1 indices."""
+    rng = np.random.default_rng(4)
+    base = _desc(rng, 1)[0]
+    k1 = _keys([(10, 10), (20, 20), (30, 30), (40, 40)]); d1 = np.stack([base, base, _flip(base, 3), _desc(rng, 1)[0]])
+    k2 = _keys([(11, 10), (21, 20), (31, 30), (41, 40)]); d2 = np.stack([_flip(base, 2), _flip(base, 8), _flip(base, 30), _desc(rng, 1)[0]])
+    K1 = oracle.make_frame(k1, d1, BOUNDS); K2 = oracle.make_frame(k2, d2, BOUNDS)
+    z = [0, 0, 0, 0]
+    m, n = oracle.search_by_bow_kf(K1, [5, 5, 5, 7], z, K2, [5, 5, 5, 6], z, 0.9, False)
+    assert list(m[:2]) == [0, 1] and m[3] == -1 and n == int((m >= 0).sum()), "first claims the best, the twin moves on; nodes 7 / 6 never meet"
+    m2, _ = oracle.search_by_bow_kf(K1, [5, 5, 5, 7], z, K2, [5, 5, 5, 6], [1, 0, 0, 0], 0.9, False)
+    assert m2[0] == 1, "a KF2 feature without a map point is no candidate"
+    # exactly TH_LOW = 50 bits apart: accepted by the frame overload (<=, :268), rejected by this one (<, :625)
+    far = _flip(base, 50)
+    Ka = oracle.make_frame(_keys([(10, 10)]), np.stack([base]), BOUNDS); Kb = oracle.make_frame(_keys([(10, 10)]), np.stack([far]), BOUNDS)
+    assert oracle.search_by_bow_kf(Ka, [1], [0], Kb, [1], [0], 0.9, False)[1] == 0
+    assert oracle.search_by_bow(Ka, [1], [0], Kb, [1], None, 0.9, False)[1] == 1
