@@ -308,3 +308,131 @@ def pose_frame(seed, n=800, outlier_frac=0.15, stereo_frac=0.0, noise_px=1.0, W=
     pose0 = _pose7(dR @ R, dR @ t + rng.normal(0, 0.05, 3))
     return {"Xw": Xw, "obs": obs, "inv_sigma2": (1.0 / (sig * sig)).astype(np.float32).astype(np.float64), "intr": np.array([fx, fy, cx, cy, bf]),
             "pose": pose0, "pose_true": _pose7(R, t), "is_outlier": bad}
+
+
+def ba_dyn_problem(seed, n_kf=12, n_points=400, n_objects=3, pts_per_obj=30, fix_points=False, fix_cams=False, W=1241, H=376, noise_px=1.0, dt=0.1,
+                   stereo_frac=0.3):
+    """A dynamic-object local BA window in the layout of cs_ba_dyn_problem (Optimizer::LocalBACameraPointObjectsDynamic,
+    orb_object_slam/src/Optimizer.cc:1537-2573).  Ground-based world (z up, build_worldframe_on_ground): the camera drives along +x at 1.65 m,
+    cars move on the plane with a planar velocity (EdgeObjectMotion's bicycle model), every car has one VertexCuboidFixScale per key frame
+    that sees it (whether_fixrotation, KITTI fixed scale), dynamic points live in the car frame, static points in the world."""
+    rng = np.random.default_rng(seed)
+    K = K_KITTI
+    fx, fy, cx, cy = K[0, 0], K[1, 1], K[0, 2], K[1, 2]
+    bf = 386.1448
+    Rwc0 = np.array([[0, 0, 1], [-1, 0, 0], [0, -1, 0]], float)  # camera axes (x right, y down, z forward) in the world (x forward, y left, z up)
+    cam_speed = 8.0
+    centers = np.stack([np.arange(n_kf) * cam_speed * dt, 0.05 * np.sin(np.arange(n_kf) * 0.7), np.full(n_kf, 1.65)], axis=1)
+    Rwc = [Rwc0 @ _rot(1, 0.01 * math.sin(0.5 * i)) for i in range(n_kf)]
+    cam_true = np.stack([_pose7(R.T, -R.T @ c) for R, c in zip(Rwc, centers)])
+
+    def project(i, Xw):
+        Xc = (Rwc[i].T @ (np.atleast_2d(Xw) - centers[i]).T).T
+        z = Xc[:, 2]
+        return np.stack([fx * Xc[:, 0] / z + cx, fy * Xc[:, 1] / z + cy], axis=1), z
+
+    def inv_sigma2(n):
+        octave = rng.integers(0, 8, n)
+        return (np.float32(1.0) / (np.float32(1.2) ** octave.astype(np.float32)) ** 2).astype(np.float64)
+
+    # static points and their (mono / stereo) observations, landmark-major
+    pts = np.stack([rng.uniform(5, 45, n_points) + centers[-1, 0] * rng.uniform(0, 1, n_points), rng.uniform(-12, 12, n_points), rng.uniform(0, 4, n_points)], axis=1)
+    oc, op, ou, our, ow = [], [], [], [], []
+    for j in range(n_points):
+        seen = 0
+        for i in range(n_kf):
+            uv, z = project(i, pts[j])
+            if z[0] < 2 or z[0] > 45 or not (0 <= uv[0, 0] < W and 0 <= uv[0, 1] < H) or rng.uniform() < 0.3:
+                continue
+            m = uv[0] + rng.normal(0, noise_px, 2)
+            ur = m[0] - bf / z[0] + rng.normal(0, noise_px)
+            st = rng.uniform() < stereo_frac and z[0] < 35 and ur >= 0
+            oc.append(i); op.append(j); ou.append(m); our.append(ur if st else -1.0); seen += 1
+        ow.append(inv_sigma2(seen))
+    # cars: pose per key frame from the motion model the edge uses, object vertices only where the box is inside the image
+    body = np.array([[1, 1, -1, -1, 1, 1, -1, -1], [1, -1, -1, 1, 1, -1, -1, 1], [-1, -1, -1, -1, 1, 1, 1, 1]], float)
+    obj_pose, obj_key, vel_true = [], [], []
+    cobs_cam, cobs_obj, cobs_bbox, cobs_info = [], [], [], []
+    mot_from, mot_to, mot_vel, mot_dt = [], [], [], []
+    dpts, dobs_cam, dobs_obj, dobs_pt, dobs_uv, dobs_w = [], [], [], [], [], []
+    pc_obj, pc_off, pc_pts = [], [0], []
+    veh_len = 2.71
+    for c in range(n_objects):
+        v, steer = rng.uniform(5, 11), rng.uniform(-0.05, 0.05)
+        yaw = rng.uniform(-0.15, 0.15)
+        pos = np.array([rng.uniform(12, 22), rng.choice([-1.0, 1.0]) * rng.uniform(2.5, 5.0), KITTI_OBJ_HALF[2]])
+        quality = rng.uniform(0.6, 1.0)
+        vel_true.append([v, steer])
+        local = rng.uniform(-1, 1, (pts_per_obj, 3)) * KITTI_OBJ_HALF * 1.15  # some a little outside the box: UnaryLocalPoint is non-zero there
+        first_dp = len(dpts)
+        dpts.extend(local)
+        dp_seen = np.zeros(pts_per_obj, int)
+        prev = None
+        for i in range(n_kf):
+            Ro = _rot(2, yaw)
+            corners = (Ro @ (body * KITTI_OBJ_HALF[:, None])).T + pos
+            uv, z = project(i, corners)
+            x0, y0, x1, y1 = uv[:, 0].min(), uv[:, 1].min(), uv[:, 0].max(), uv[:, 1].max()
+            if z.min() > 3 and x0 > 10 and y0 > 10 and x1 < W - 10 and y1 < H - 10:
+                oi = len(obj_pose)
+                obj_pose.append(_pose7(Ro, pos.copy())); obj_key.append((c, i))
+                cobs_cam.append(i); cobs_obj.append(oi)
+                cobs_bbox.append(np.array([(x0 + x1) / 2, (y0 + y1) / 2, x1 - x0, y1 - y0]) + rng.normal(0, 3.0, 4))
+                cobs_info.append(np.full(4, (2.0 * quality) ** 2))  # camera_object_BA_weight^2 * meas_quality^2
+                if prev is not None:
+                    mot_from.append(prev[0]); mot_to.append(oi); mot_vel.append(c); mot_dt.append((i - prev[1]) * dt)
+                prev = (oi, i)
+                wpts = (Ro @ local.T).T + pos
+                puv, pz = project(i, wpts)
+                for k in range(pts_per_obj):
+                    if pz[k] > 2 and 0 <= puv[k, 0] < W and 0 <= puv[k, 1] < H and rng.uniform() < 0.8:
+                        dobs_cam.append(i); dobs_obj.append(oi); dobs_pt.append(first_dp + k); dobs_uv.append(puv[k] + rng.normal(0, noise_px, 2)); dp_seen[k] += 1
+            # bicycle model of EdgeObjectMotion applied to the back-wheel centre (g2o_Object.cpp:255-263)
+            back = pos[:2] - veh_len * 0.5 * np.array([math.cos(yaw), math.sin(yaw)]) + v * dt * np.array([math.cos(yaw), math.sin(yaw)])
+            yaw = yaw + math.tan(steer) * dt / veh_len * v
+            pos = np.array([back[0] + veh_len * 0.5 * math.cos(yaw), back[1] + veh_len * 0.5 * math.sin(yaw), pos[2]])
+        if prev is not None:  # EdgePointCuboidOnlyObjectFixScale on the car's last object vertex: world points on its surface
+            Tl = np.array(obj_pose[prev[0]])
+            n_pc_pts = 15
+            surf = rng.uniform(-1, 1, (n_pc_pts, 3)) * KITTI_OBJ_HALF
+            face = rng.integers(0, 3, n_pc_pts)
+            surf[np.arange(n_pc_pts), face] = np.sign(surf[np.arange(n_pc_pts), face]) * KITTI_OBJ_HALF[face]
+            Rl = _rot(2, 2 * math.atan2(Tl[5], Tl[6]))
+            pc_obj.append(prev[0]); pc_pts.append((Rl @ surf.T).T + Tl[:3] + rng.normal(0, 0.1, (n_pc_pts, 3))); pc_off.append(pc_off[-1] + n_pc_pts)
+    dobs_w = inv_sigma2(len(dobs_cam))
+    # perturbed initial estimates
+    cam_init = cam_true.copy()
+    for i in range(2, n_kf):
+        dR = _rot(0, rng.normal(0, math.radians(0.3))) @ _rot(1, rng.normal(0, math.radians(0.3))) @ _rot(2, rng.normal(0, math.radians(0.3)))
+        c_i = centers[i] + rng.normal(0, 0.04, 3)
+        Rn = Rwc[i] @ dR
+        cam_init[i] = _pose7(Rn.T, -Rn.T @ c_i)
+    cam_fixed = np.zeros(n_kf, np.uint8); cam_fixed[:2] = 1
+    if fix_cams:
+        cam_fixed[:] = 1
+        cam_init = cam_true.copy()
+    obj_true = np.array(obj_pose).reshape(-1, 7)
+    obj_init = obj_true.copy()
+    obj_init[:, :3] += rng.normal(0, 0.25, (len(obj_init), 3)) * np.array([1, 1, 0.2])
+    n_o = len(obj_init)
+    vel_true = np.array(vel_true).reshape(-1, 2)
+    return {
+        "cam_pose": cam_init, "cam_fixed": cam_fixed,
+        "obj_pose": obj_init, "obj_scale": np.tile(KITTI_OBJ_HALF, (n_o, 1)), "obj_flags": np.full(n_o, 2 | 8, np.uint8), "obj_key": np.array(obj_key, np.int32).reshape(-1, 2),
+        "vel": vel_true * rng.uniform(0.7, 1.2, vel_true.shape) * np.array([1.0, 0.0]),  # (linear_esti, 0), Optimizer.cc:2231
+        "points": pts + rng.normal(0, 0.08, pts.shape), "dpoints": np.array(dpts).reshape(-1, 3) + rng.normal(0, 0.08, (len(dpts), 3)), "fix_points": int(fix_points),
+        "obs_cam": np.array(oc, np.int32), "obs_point": np.array(op, np.int32), "obs_uv": np.array(ou, np.float64).reshape(-1, 2), "obs_ur": np.array(our, np.float64),
+        "obs_inv_sigma2": np.concatenate(ow) if ow else np.zeros(0), "obs_level": np.zeros(len(oc), np.uint8),
+        "fx": fx, "fy": fy, "cx": cx, "cy": cy, "bf": bf, "huber_mono": math.sqrt(5.991), "huber_stereo": math.sqrt(7.815),
+        "ulp_info": 10.0, "ulp_scale": KITTI_OBJ_HALF.copy(), "ulp_ratio": 2.0,
+        "dobs_cam": np.array(dobs_cam, np.int32), "dobs_obj": np.array(dobs_obj, np.int32), "dobs_point": np.array(dobs_pt, np.int32),
+        "dobs_uv": np.array(dobs_uv, np.float64).reshape(-1, 2), "dobs_inv_sigma2": np.asarray(dobs_w, np.float64), "dobs_level": np.zeros(len(dobs_cam), np.uint8),
+        "K": K.copy(), "huber_dyn": math.sqrt(5.991),
+        "mot_from": np.array(mot_from, np.int32), "mot_to": np.array(mot_to, np.int32), "mot_vel": np.array(mot_vel, np.int32), "mot_dt": np.array(mot_dt, np.float64),
+        "mot_info": np.array([1.0, 1.0, 5.0]) ** 2 * 0.5 ** 2,  # (inv_sigma .* inv_sigma), inv_sigma = (1, 1, 5) * object_velocity_BA_weight
+        "cobs_cam": np.array(cobs_cam, np.int32), "cobs_obj": np.array(cobs_obj, np.int32), "cobs_bbox": np.array(cobs_bbox, np.float64).reshape(-1, 4),
+        "cobs_info": np.array(cobs_info, np.float64).reshape(-1, 4), "cobs_level": np.zeros(len(cobs_cam), np.uint8), "huber_obj": math.sqrt(900.0),
+        "pc_obj": np.array(pc_obj, np.int32), "pc_offsets": np.array(pc_off, np.int32), "pc_points": np.concatenate(pc_pts).reshape(-1, 3) if pc_pts else np.zeros((0, 3)),
+        "pc_ratio": 2.0,
+        "cam_true": cam_true, "obj_true": obj_true, "vel_true": vel_true, "points_true": pts, "dpoints_true": np.array(dpts).reshape(-1, 3),
+    }

@@ -301,6 +301,49 @@ int cs_ba_errors(cs_ctx *ctx, cs_ba *b, double *chi2, double *err_obs, double *e
 /* Dense copy of this rank's reduced camera system (before the all-reduce) for lambda: H (6P x 6P row-major), b (6P); *P out */
 int cs_ba_reduced_dense(cs_ctx *ctx, cs_ba *b, double lambda, double *H, double *bvec, int *P);
 
+/* ===================================================================== dynamic-object bundle adjustment
+ * Replaces the g2o machinery behind ORB_SLAM2::Optimizer::LocalBACameraPointObjectsDynamic (orb_object_slam/include/Optimizer.h:57-58,
+ * src/Optimizer.cc:1537-2573): SparseOptimizer::optimize with OptimizationAlgorithmLevenberg + BlockSolverX + LinearSolverDense (:1670-1678)
+ * over VertexSE3Expmap (key frames), one VertexCuboidFixScale per (object, key frame) (:1729-1786), VelocityPlanarVelocity (:2160-2165),
+ * static VertexSBAPointXYZ (world frame, :1819-1830) and dynamic ones (object frame, :1934-1945), both marginalised, and the edges
+ * EdgeSE3ProjectXYZ / EdgeStereoSE3ProjectXYZ (:1843-1906), UnaryLocalPoint (:1947-1955), EdgeDynamicPointCuboidCamera (:1977-1993),
+ * EdgePointCuboidOnlyObjectFixScale (:2096-2115), EdgeObjectMotion (:2192-2202), EdgeSE3CuboidFixScaleProj (:2279-2298)
+ * (orb_object_slam/include/g2o_Object.h, src/g2o_Object.cpp).  The caller builds the graph (the map bookkeeping of :1540-1665 stays in the
+ * reference) and flattens it into the arrays below; indices refer to these arrays.  *_level[o] != 0 = setLevel(1) (NULL: all zero);
+ * obs_ur NULL or < 0 = monocular; every information matrix of the reference is diagonal.  The two stages of :2353-2415 are two handles:
+ * optimize(5), read + errors, then a second problem with the levels / removed kernels, optimize(10). */
+typedef struct cs_ba_dyn_problem {
+    int n_cams; const double *cam_pose; const uint8_t *cam_fixed;                               /* world-to-camera 7-vectors */
+    int n_objs; const double *obj_pose; const double *obj_scale; const uint8_t *obj_flags;      /* object-to-world; flags as in cs_ba_problem */
+    int n_vels; const double *vel;                                                              /* [linear velocity, steering angle] */
+    int n_points; const double *points;
+    int n_dpoints; const double *dpoints;                                                       /* MapPoint::PosToObj */
+    int fix_points;                                                                             /* fixPoint: setFixed(true) instead of setMarginalized(true) */
+    int n_obs; const int *obs_cam; const int *obs_point; const double *obs_uv; const double *obs_ur; const double *obs_inv_sigma2; const uint8_t *obs_level;
+    double fx, fy, cx, cy, bf, huber_mono, huber_stereo;
+    double ulp_info, ulp_scale[3], ulp_ratio;                                                   /* UnaryLocalPoint: info * I, objectscale, max_outside_margin_ratio */
+    int n_dobs; const int *dobs_cam; const int *dobs_obj; const int *dobs_point; const double *dobs_uv; const double *dobs_inv_sigma2; const uint8_t *dobs_level;
+    double K[9], huber_dyn;
+    int n_mot; const int *mot_from; const int *mot_to; const int *mot_vel; const double *mot_dt; double mot_info[3];
+    int n_cobs; const int *cobs_cam; const int *cobs_obj; const double *cobs_bbox; const double *cobs_info; const uint8_t *cobs_level; double huber_obj;
+    int n_pc; const int *pc_obj; const int *pc_offsets; const double *pc_points; double pc_ratio;
+} cs_ba_dyn_problem;
+
+typedef struct cs_ba_dyn cs_ba_dyn;
+/* initializeOptimization: index mapping (non-fixed cameras, object poses, velocities; landmarks = static then dynamic points), the
+ * pose-landmark slot lists, upload.  CS_ERR_BAD_ARG for an index out of range or a pose system above 4000 scalars. */
+int cs_ba_dyn_create(cs_ctx *ctx, const cs_ba_dyn_problem *p, cs_ba_dyn **out);
+void cs_ba_dyn_destroy(cs_ctx *ctx, cs_ba_dyn *b);
+/* SparseOptimizer::optimize(iterations); stop_flag as in cs_ba_optimize */
+int cs_ba_dyn_optimize(cs_ctx *ctx, cs_ba_dyn *b, int iterations, const volatile int *stop_flag, cs_ba_stats *stats);
+/* current estimates (any pointer may be NULL) */
+int cs_ba_dyn_read(cs_ctx *ctx, cs_ba_dyn *b, double *cam_pose, double *obj_pose, double *vel, double *points, double *dpoints);
+/* computeError of every edge + activeRobustChi2 over the active ones: e_obs n x 3 (third 0 for mono), e_dobs n x 2, e_mot n x 3,
+ * e_cobs n x 4, e_pc n x 3, e_ulp n_dpoints x 3; any output may be NULL */
+int cs_ba_dyn_errors(cs_ctx *ctx, cs_ba_dyn *b, double *chi2, double *e_obs, double *e_dobs, double *e_mot, double *e_cobs, double *e_pc, double *e_ulp);
+/* dense reduced pose system for lambda at the current estimates: H (n x n row-major), bvec (n); *n out (H NULL: query) */
+int cs_ba_dyn_reduced_dense(cs_ctx *ctx, cs_ba_dyn *b, double lambda, double *H, double *bvec, int *n);
+
 /* ===================================================================== LSD line detector
  * Replaces line_lbd_detect::detect_raw_lines / detect_filter_lines (line_lbd/include/line_lbd/line_lbd_allclass.h:37-52,
  * class/line_lbd_allclass.cpp:125-148,200-221) with use_LSD = true, one octave: LSDDetector::detectImpl

@@ -254,6 +254,46 @@ int orc_cuboid9_oplus(int n, const double *cub, const double *upd, double *out);
 int orc_cuboid9_edge_error(int n, const double *cam_Tcw, const double *cub_global, const double *cub_meas_local, double *err);
 int orc_cuboid9_edge_linearize(int n, const double *cam_Tcw, const double *cub_global, const double *cub_meas_local, double *err, double *Jcam, double *Jcub);
 
+/* --------------------------------------------------------------------------------------------------------------------
+ * Optimizer::LocalBACameraPointObjectsDynamic (orb_object_slam/src/Optimizer.cc:1537-2573): the graph it hands to g2o
+ * (BlockSolverX + LinearSolverDense + Levenberg) -- key-frame poses, one VertexCuboidFixScale per (object, key frame),
+ * one VelocityPlanarVelocity per object, static points (world frame) and dynamic points (object frame), both marginalised.
+ * Indices refer to the arrays of this struct; *_level[o] != 0 takes edge o out of the optimisation (setLevel(1));
+ * NULL level arrays = all zero; obs_ur NULL or < 0 = monocular.  All information matrices are diagonal in the reference. */
+typedef struct orc_badyn_problem {
+    int n_cams; const double *cam_pose; const uint8_t *cam_fixed;                               /* VertexSE3Expmap (:1689-1711) */
+    int n_objs; const double *obj_pose; const double *obj_scale; const uint8_t *obj_flags;      /* VertexCuboidFixScale (:1729-1786), flags as in orc_ba_problem */
+    int n_vels; const double *vel;                                                              /* VelocityPlanarVelocity [v, steer] (:2160-2165) */
+    int n_points; const double *points;                                                         /* static VertexSBAPointXYZ (:1819-1830) */
+    int n_dpoints; const double *dpoints;                                                       /* dynamic points, PosToObj (:1934-1945) */
+    int fix_points;                                                                             /* fixPoint: points fixed instead of marginalised */
+    /* EdgeSE3ProjectXYZ / EdgeStereoSE3ProjectXYZ (:1843-1906) */
+    int n_obs; const int *obs_cam; const int *obs_point; const double *obs_uv; const double *obs_ur; const double *obs_inv_sigma2; const uint8_t *obs_level;
+    double fx, fy, cx, cy, bf, huber_mono, huber_stereo;
+    /* UnaryLocalPoint, one per dynamic point (:1947-1955): information = ulp_info * I */
+    double ulp_info, ulp_scale[3], ulp_ratio;
+    /* EdgeDynamicPointCuboidCamera (:1977-1993): vertices (camera, object pose, dynamic point), information = inv_sigma2 * I2 */
+    int n_dobs; const int *dobs_cam; const int *dobs_obj; const int *dobs_point; const double *dobs_uv; const double *dobs_inv_sigma2; const uint8_t *dobs_level;
+    double K[9], huber_dyn;
+    /* EdgeObjectMotion (:2192-2202): vertices (object pose from, object pose to, velocity), information = diag(mot_info), no kernel */
+    int n_mot; const int *mot_from; const int *mot_to; const int *mot_vel; const double *mot_dt; double mot_info[3];
+    /* EdgeSE3CuboidFixScaleProj (:2279-2298): information = diag(cobs_info[o*4..]), Huber(huber_obj) */
+    int n_cobs; const int *cobs_cam; const int *cobs_obj; const double *cobs_bbox; const double *cobs_info; const uint8_t *cobs_level; double huber_obj;
+    /* EdgePointCuboidOnlyObjectFixScale (:2096-2115): information = I, no kernel */
+    int n_pc; const int *pc_obj; const int *pc_offsets; const double *pc_points; double pc_ratio;
+} orc_badyn_problem;
+
+/* computeError of every edge (inactive ones too) + activeRobustChi2 over the level-0 edges; any output may be NULL.
+ * e_obs n x 3 (third 0 for mono), e_dobs n x 2, e_mot n x 3, e_cobs n x 4, e_pc n x 3, e_ulp n_dpoints x 3 */
+double orc_badyn_errors(const orc_badyn_problem *p, double *e_obs, double *e_dobs, double *e_mot, double *e_cobs, double *e_pc, double *e_ulp);
+/* reduced pose system (Hpp + lambda I - Hpl (Hll + lambda I)^-1 Hlp, bp - Hpl (Hll + lambda I)^-1 bl) at the given estimates, dense row-major;
+ * pose scalars are ordered cameras (6 each, non-fixed), object poses (6), velocities (2).  Returns the dimension; H may be NULL to query it. */
+int orc_badyn_reduced_dense(const orc_badyn_problem *p, double lambda, double *H, double *bvec);
+/* one linear step with a given damping (computeActiveErrors, buildSystem, solve, update); returns 1 if the factorisation failed */
+int orc_badyn_step(const orc_badyn_problem *p, double lambda, double *cam_pose, double *obj_pose, double *vel, double *points, double *dpoints);
+/* SparseOptimizer::optimize(iterations) */
+int orc_badyn_optimize(const orc_badyn_problem *p, int iterations, double *cam_pose, double *obj_pose, double *vel, double *points, double *dpoints, orc_ba_stats *stats);
+
 #ifdef __cplusplus
 }
 #endif

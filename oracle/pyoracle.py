@@ -432,6 +432,110 @@ def ba_reduced_dense(d, lm_begin, lm_end, with_pose_edges, lam):
     return Hm, b
 
 
+# ----------------------------------------------------------------------------------------------- dynamic-object BA
+class BADynProblem(C.Structure):
+    _fields_ = [("n_cams", C.c_int), ("cam_pose", C.c_void_p), ("cam_fixed", C.c_void_p),
+                ("n_objs", C.c_int), ("obj_pose", C.c_void_p), ("obj_scale", C.c_void_p), ("obj_flags", C.c_void_p),
+                ("n_vels", C.c_int), ("vel", C.c_void_p),
+                ("n_points", C.c_int), ("points", C.c_void_p),
+                ("n_dpoints", C.c_int), ("dpoints", C.c_void_p),
+                ("fix_points", C.c_int),
+                ("n_obs", C.c_int), ("obs_cam", C.c_void_p), ("obs_point", C.c_void_p), ("obs_uv", C.c_void_p), ("obs_ur", C.c_void_p), ("obs_inv_sigma2", C.c_void_p),
+                ("obs_level", C.c_void_p),
+                ("fx", C.c_double), ("fy", C.c_double), ("cx", C.c_double), ("cy", C.c_double), ("bf", C.c_double), ("huber_mono", C.c_double), ("huber_stereo", C.c_double),
+                ("ulp_info", C.c_double), ("ulp_scale", C.c_double * 3), ("ulp_ratio", C.c_double),
+                ("n_dobs", C.c_int), ("dobs_cam", C.c_void_p), ("dobs_obj", C.c_void_p), ("dobs_point", C.c_void_p), ("dobs_uv", C.c_void_p), ("dobs_inv_sigma2", C.c_void_p),
+                ("dobs_level", C.c_void_p),
+                ("K", C.c_double * 9), ("huber_dyn", C.c_double),
+                ("n_mot", C.c_int), ("mot_from", C.c_void_p), ("mot_to", C.c_void_p), ("mot_vel", C.c_void_p), ("mot_dt", C.c_void_p), ("mot_info", C.c_double * 3),
+                ("n_cobs", C.c_int), ("cobs_cam", C.c_void_p), ("cobs_obj", C.c_void_p), ("cobs_bbox", C.c_void_p), ("cobs_info", C.c_void_p), ("cobs_level", C.c_void_p),
+                ("huber_obj", C.c_double),
+                ("n_pc", C.c_int), ("pc_obj", C.c_void_p), ("pc_offsets", C.c_void_p), ("pc_points", C.c_void_p), ("pc_ratio", C.c_double)]
+
+
+def badyn_struct(d, cls=BADynProblem):
+    """C struct from the dict made by cube_slam_amd.synth.ba_dyn_problem (keeps the arrays alive)."""
+    keep = {}
+
+    def arr(name, dt, n_min=1):
+        a = np.ascontiguousarray(d[name], dt)
+        if a.size == 0:
+            a = np.zeros(n_min, dt)
+        keep[name] = a
+        return a.ctypes.data
+
+    p = cls()
+    p.n_cams = len(d["cam_pose"]); p.cam_pose = arr("cam_pose", np.float64); p.cam_fixed = arr("cam_fixed", np.uint8)
+    p.n_objs = len(d["obj_pose"]); p.obj_pose = arr("obj_pose", np.float64); p.obj_scale = arr("obj_scale", np.float64); p.obj_flags = arr("obj_flags", np.uint8)
+    p.n_vels = len(d["vel"]); p.vel = arr("vel", np.float64)
+    p.n_points = len(d["points"]); p.points = arr("points", np.float64)
+    p.n_dpoints = len(d["dpoints"]); p.dpoints = arr("dpoints", np.float64)
+    p.fix_points = int(d["fix_points"])
+    p.n_obs = len(d["obs_cam"]); p.obs_cam = arr("obs_cam", np.int32); p.obs_point = arr("obs_point", np.int32); p.obs_uv = arr("obs_uv", np.float64)
+    if d.get("obs_ur") is not None:
+        p.obs_ur = arr("obs_ur", np.float64)
+    p.obs_inv_sigma2 = arr("obs_inv_sigma2", np.float64)
+    if d.get("obs_level") is not None:
+        p.obs_level = arr("obs_level", np.uint8)
+    p.fx, p.fy, p.cx, p.cy, p.bf, p.huber_mono, p.huber_stereo = d["fx"], d["fy"], d["cx"], d["cy"], d["bf"], d["huber_mono"], d["huber_stereo"]
+    p.ulp_info, p.ulp_ratio = d["ulp_info"], d["ulp_ratio"]
+    for i in range(3):
+        p.ulp_scale[i] = d["ulp_scale"][i]; p.mot_info[i] = d["mot_info"][i]
+    p.n_dobs = len(d["dobs_cam"]); p.dobs_cam = arr("dobs_cam", np.int32); p.dobs_obj = arr("dobs_obj", np.int32); p.dobs_point = arr("dobs_point", np.int32)
+    p.dobs_uv = arr("dobs_uv", np.float64); p.dobs_inv_sigma2 = arr("dobs_inv_sigma2", np.float64)
+    if d.get("dobs_level") is not None:
+        p.dobs_level = arr("dobs_level", np.uint8)
+    for i, v in enumerate(np.asarray(d["K"], np.float64).reshape(-1)):
+        p.K[i] = v
+    p.huber_dyn = d["huber_dyn"]
+    p.n_mot = len(d["mot_from"]); p.mot_from = arr("mot_from", np.int32); p.mot_to = arr("mot_to", np.int32); p.mot_vel = arr("mot_vel", np.int32); p.mot_dt = arr("mot_dt", np.float64)
+    p.n_cobs = len(d["cobs_cam"]); p.cobs_cam = arr("cobs_cam", np.int32); p.cobs_obj = arr("cobs_obj", np.int32); p.cobs_bbox = arr("cobs_bbox", np.float64)
+    p.cobs_info = arr("cobs_info", np.float64)
+    if d.get("cobs_level") is not None:
+        p.cobs_level = arr("cobs_level", np.uint8)
+    p.huber_obj = d["huber_obj"]
+    p.n_pc = len(d["pc_obj"]); p.pc_obj = arr("pc_obj", np.int32); p.pc_offsets = arr("pc_offsets", np.int32, 2); p.pc_points = arr("pc_points", np.float64)
+    p.pc_ratio = d["pc_ratio"]
+    p._keep = keep
+    return p
+
+
+def badyn_errors(d):
+    p = badyn_struct(d)
+    e = [np.zeros((max(n, 1), k)) for n, k in ((p.n_obs, 3), (p.n_dobs, 2), (p.n_mot, 3), (p.n_cobs, 4), (p.n_pc, 3), (p.n_dpoints, 3))]
+    lib().orc_badyn_errors.restype = C.c_double
+    chi = lib().orc_badyn_errors(C.byref(p), *[_p(a, C.c_double) for a in e])
+    ns = (p.n_obs, p.n_dobs, p.n_mot, p.n_cobs, p.n_pc, p.n_dpoints)
+    return chi, dict(zip(("obs", "dobs", "mot", "cobs", "pc", "ulp"), [a[:n] for a, n in zip(e, ns)]))
+
+
+def badyn_reduced_dense(d, lam):
+    p = badyn_struct(d)
+    n = lib().orc_badyn_reduced_dense(C.byref(p), C.c_double(lam), None, None)
+    Hm = np.zeros((max(n, 1), max(n, 1))); b = np.zeros(max(n, 1))
+    lib().orc_badyn_reduced_dense(C.byref(p), C.c_double(lam), _p(Hm, C.c_double), _p(b, C.c_double))
+    return Hm[:n, :n], b[:n]
+
+
+def badyn_step(d, lam):
+    p = badyn_struct(d)
+    out = [np.zeros((max(n, 1), k)) for n, k in ((p.n_cams, 7), (p.n_objs, 7), (p.n_vels, 2), (p.n_points, 3), (p.n_dpoints, 3))]
+    rc = lib().orc_badyn_step(C.byref(p), C.c_double(lam), *[_p(a, C.c_double) for a in out])
+    ns = (p.n_cams, p.n_objs, p.n_vels, p.n_points, p.n_dpoints)
+    return dict(zip(("cam_pose", "obj_pose", "vel", "points", "dpoints"), [a[:n] for a, n in zip(out, ns)])), rc
+
+
+def badyn_optimize(d, iterations):
+    p = badyn_struct(d)
+    out = [np.zeros((max(n, 1), k)) for n, k in ((p.n_cams, 7), (p.n_objs, 7), (p.n_vels, 2), (p.n_points, 3), (p.n_dpoints, 3))]
+    st = BAStats()
+    lib().orc_badyn_optimize(C.byref(p), iterations, *[_p(a, C.c_double) for a in out], C.byref(st))
+    ns = (p.n_cams, p.n_objs, p.n_vels, p.n_points, p.n_dpoints)
+    res = dict(zip(("cam_pose", "obj_pose", "vel", "points", "dpoints"), [a[:n] for a, n in zip(out, ns)]))
+    return res, {"iterations": st.iterations, "lm_trials": st.lm_trials, "chi2_init": st.chi2_init, "chi2_final": st.chi2_final, "lambda_final": st.lambda_final,
+                 "chi2_trace": list(st.chi2_trace)[:st.iterations]}
+
+
 # ----------------------------------------------------------------------------------------------- LSD
 KEYLINE_DTYPE = np.dtype([("angle", "f4"), ("class_id", "i4"), ("octave", "i4"), ("pt", "f4", 2), ("response", "f4"), ("size", "f4"),
                           ("startPointX", "f4"), ("startPointY", "f4"), ("endPointX", "f4"), ("endPointY", "f4"),
