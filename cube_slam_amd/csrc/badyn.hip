@@ -7,17 +7,25 @@
 //                     robustified J^T W J / J^T W e accumulated with fp64 atomics into the dense pose system, the landmark blocks and
 //                     the edge's own pose-landmark slot(s)
 //   badyn_schur_init  S = Hpp + lambda I, bs = bp
-//   badyn_schur       thread per landmark: (Hll + lambda I)^-1, S -= B D^-1 B^T over the landmark's slot pairs, bs -= B D^-1 bl
-//   badyn_chol_solve  one workgroup: right-looking dense Cholesky of S (column in LDS, trailing update by rows), forward substitution
-//                     fused into the elimination, row-oriented backward substitution
+//   badyn_dinv / badyn_bd / badyn_schur_blocks / badyn_schur_rhs   the Schur complement as gathers: 3x3 inverses per landmark, B D^-1 per
+//                     slot, one wave per 6x6 target block summing over the slot pairs the host listed for it, one thread per reduced
+//                     right-hand-side row (a first version with fp64 atomics from a thread per landmark took 21 ms on 2 200 landmarks:
+//                     all landmarks of a camera pair hit the same 36 words)
+//   badyn_chol_panel / badyn_chol_update / badyn_chol_tri   blocked right-looking Cholesky of S (32 columns per step: every workgroup
+//                     factors the 32x32 pivot block in LDS and solves its rows of the panel, then 32x32 tiles of the trailing matrix are
+//                     updated by independent workgroups), then one workgroup for both triangular solves (a single-workgroup
+//                     column-by-column version -- badyn_chol_solve, CUBESLAM_BADYN_CHOL=simple -- took 26 ms at 840 unknowns: every
+//                     trailing update waits for its own global load)
 //   badyn_backsub     thread per landmark, badyn_update thread per vertex (oplus), badyn_diag gathers diag(H) for computeLambdaInit
 // The windows this runs on are small (10-30 key frames, a few object tracks): the pose system has a few hundred to a few thousand scalars,
 // so everything is latency-bound; the dense factorisation is the only super-linear step and stays on one CU.
 #include "common.h"
 #include "badyn_math.h"
+#include "badyn_lists.h"
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <vector>
@@ -46,9 +54,35 @@ __global__ void __launch_bounds__(256) badyn_schur_init(DynG G, double lambda) {
     if (i < n2) { const int r = (int)(i / G.NP), c = (int)(i % G.NP); G.S[i] = G.Hpp[i] + (r == c ? lambda : 0.0); }
     if (i < G.NP) G.bs[i] = G.bp[i];
 }
-__global__ void __launch_bounds__(64) badyn_schur(DynG G, double lambda) {
+__global__ void __launch_bounds__(64) badyn_dinv(DynG G, double lambda) {
     const int li = blockIdx.x * 64 + threadIdx.x;
-    if (li < G.L) dyn_schur_item(G, li, lambda);
+    if (li < G.L) dyn_dinv_item(G, li, lambda);
+}
+__global__ void __launch_bounds__(64) badyn_bd(DynG G, int n_slots) {
+    const int s = blockIdx.x * 64 + threadIdx.x;
+    if (s < n_slots) dyn_bd_item(G, s);
+}
+__global__ void __launch_bounds__(256) badyn_schur_blocks(DynG G) { // one workgroup per target block: 7 groups of 36 lanes share its pair list
+    __shared__ double part[7][36];
+    const int g = threadIdx.x / 36, e = threadIdx.x % 36;
+    if (g < 7) part[g][e] = dyn_schur_block_partial(G, blockIdx.x, e, g, 7);
+    __syncthreads();
+    if (threadIdx.x < 36) {
+        double acc = 0;
+        for (int k = 0; k < 7; k++) acc += part[k][e];
+        dyn_schur_block_store(G, blockIdx.x, e, acc);
+    }
+}
+__global__ void __launch_bounds__(64) badyn_schur_rhs(DynG G) { // one wave per pose vertex: 10 groups of 6 lanes share its slot list
+    __shared__ double part[10][6];
+    const int g = threadIdx.x / 6, a = threadIdx.x % 6;
+    if (g < 10) part[g][a] = dyn_rhs_partial(G, blockIdx.x, a, g, 10);
+    __syncthreads();
+    if (threadIdx.x < 6) {
+        double acc = 0;
+        for (int k = 0; k < 10; k++) acc += part[k][a];
+        dyn_rhs_store(G, blockIdx.x, a, acc);
+    }
 }
 __global__ void __launch_bounds__(64) badyn_backsub(DynG G) {
     const int li = blockIdx.x * 64 + threadIdx.x;
@@ -105,12 +139,163 @@ __global__ void __launch_bounds__(1024) badyn_chol_solve(int n, double *A, doubl
     for (int i = tid; i < n; i += T) x[i] = rhs[i];
 }
 
+
+// ---- blocked Cholesky: A (n x n row-major, lower triangle) -> strictly-lower panels in place, pivot blocks in Dg (one 32x32 row-major
+// block per step, the upper part zero).
+constexpr int CB = 32;
+__global__ void __launch_bounds__(256) badyn_chol_panel(int n, int jb, double *A, double *Dg, int *status) {
+    __shared__ double Ld[CB][CB + 1];
+    const int tid = threadIdx.x, nb = min(CB, n - jb);
+    for (int e = tid; e < CB * CB; e += 256) { const int r = e / CB, c = e % CB; Ld[r][c] = (r < nb && c <= r) ? A[(long)(jb + r) * n + jb + c] : 0.0; }
+    __syncthreads();
+    __shared__ int s_fail;
+    __shared__ double rdiag[CB];
+    if (tid == 0) s_fail = 0;
+    __syncthreads();
+    if (tid < 64) { // wave 0 factors the pivot block (every workgroup its own copy): lane r keeps row r in registers, pivots travel by readlane
+        const int r = tid & 31;
+        double v[CB];
+#pragma unroll
+        for (int c = 0; c < CB; c++) v[c] = (r >= nb && c == r) ? 1.0 : Ld[r][c]; // rows beyond a ragged last block: identity
+        bool bad = false;
+#pragma unroll
+        for (int c = 0; c < CB; c++) {
+            const double d = __shfl(v[c], c);
+            bad = bad || !(d > 0);
+            const double rt = sqrt(d);
+            if (r == c) v[c] = rt; else if (r > c) v[c] = v[c] / rt;
+#pragma unroll
+            for (int k = c + 1; k < CB; k++) {
+                const double lkc = __shfl(v[c], k);
+                if (r >= k) v[k] -= v[c] * lkc;
+            }
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        if (tid < CB) {
+#pragma unroll
+            for (int c = 0; c < CB; c++) Ld[r][c] = c <= r ? v[c] : 0.0;
+            double dr = 1.0;
+#pragma unroll
+            for (int c = 0; c < CB; c++) if (c == r) dr = v[c];
+            rdiag[r] = 1.0 / dr;
+        }
+        if (bad && tid == 0) s_fail = 1;
+    }
+    __syncthreads();
+    if (s_fail) { if (blockIdx.x == 0 && tid == 0) *status = 1; return; }
+    if (blockIdx.x == 0) for (int e = tid; e < CB * CB; e += 256) Dg[(long)(jb / CB) * CB * CB + e] = Ld[e / CB][e % CB];
+    const int i = jb + nb + blockIdx.x * 256 + tid; // this thread's row of the panel: x L^T = a
+    if (i >= n) return;
+    double x[CB];
+    double *row = A + (long)i * n + jb;
+#pragma unroll
+    for (int c = 0; c < CB; c++) x[c] = c < nb ? row[c] : 0.0;
+    // right-looking: once x_t is final every later column takes its share at once (independent FMAs instead of one chain per column);
+    // the pivot divisions are multiplications by the reciprocals wave 0 left in LDS
+#pragma unroll
+    for (int t = 0; t < CB; t++) {
+        x[t] = x[t] * rdiag[t];
+#pragma unroll
+        for (int c = t + 1; c < CB; c++) x[c] -= x[t] * Ld[c][t];
+        __builtin_amdgcn_sched_barrier(0); // without it the scheduler hoists all 496 LDS reads and spills 600 registers
+    }
+#pragma unroll
+    for (int c = 0; c < CB; c++) if (c < nb) row[c] = x[c];
+}
+// trailing update: tile (ti, tk), tk <= ti, of the rows / columns behind the panel: A_ik -= P_i P_k^T
+__global__ void __launch_bounds__(256) badyn_chol_update(int n, int jb, double *A) {
+    const int ti = blockIdx.y, tk = blockIdx.x;
+    if (tk > ti) return;
+    __shared__ double Pi[CB][CB + 1], Pk[CB][CB + 1];
+    const int tid = threadIdx.x, nb = min(CB, n - jb), r0 = jb + nb + ti * CB, k0 = jb + nb + tk * CB;
+    for (int e = tid; e < CB * CB; e += 256) {
+        const int r = e / CB, c = e % CB;
+        Pi[r][c] = (r0 + r < n && c < nb) ? A[(long)(r0 + r) * n + jb + c] : 0.0;
+        Pk[r][c] = (k0 + r < n && c < nb) ? A[(long)(k0 + r) * n + jb + c] : 0.0;
+    }
+    __syncthreads();
+    const int r = tid >> 3, c4 = (tid & 7) * 4;
+    double acc[4] = {0, 0, 0, 0};
+#pragma unroll 8
+    for (int t = 0; t < CB; t++) {
+        const double pi = Pi[r][t];
+        for (int q = 0; q < 4; q++) acc[q] += pi * Pk[c4 + q][t];
+    }
+    const int i = r0 + r;
+    if (i >= n) return;
+    for (int q = 0; q < 4; q++) { const int k = k0 + c4 + q; if (k <= i) A[(long)i * n + k] -= acc[q]; }
+}
+// both triangular solves with the factor left by the two kernels above: L y = b (blocks ascending), L^T x = y (descending)
+__global__ void __launch_bounds__(1024) badyn_chol_tri(int n, const double *A, const double *Dg, double *x) {
+    extern __shared__ double lds[];
+    double *rhs = lds;               // n
+    double *Ld = lds + n;            // CB x (CB + 1)
+    const int tid = threadIdx.x, T = blockDim.x;
+    for (int i = tid; i < n; i += T) rhs[i] = x[i];
+    const int nblk = (n + CB - 1) / CB;
+    for (int bi = 0; bi < nblk; bi++) {
+        const int jb = bi * CB, nb = min(CB, n - jb);
+        __syncthreads();
+        for (int e = tid; e < CB * CB; e += T) Ld[(e / CB) * (CB + 1) + e % CB] = Dg[(long)bi * CB * CB + e];
+        __syncthreads();
+        if (tid < 64) { // pivot block: lane c owns y_c, the solved values travel by shuffle
+            double acc = tid < nb ? rhs[jb + tid] : 0.0;
+            const double rd = tid < nb ? 1.0 / Ld[tid * (CB + 1) + tid] : 0.0;
+            for (int t = 0; t < nb; t++) {
+                const double yt = __shfl(acc, t) * __shfl(rd, t);
+                if (tid == t) acc = yt;
+                else if (tid > t && tid < nb) acc -= Ld[tid * (CB + 1) + t] * yt;
+            }
+            if (tid < nb) rhs[jb + tid] = acc;
+        }
+        __syncthreads();
+        for (int i = jb + nb + tid; i < n; i += T) {
+            const double *row = A + (long)i * n + jb;
+            double p0 = 0, p1 = 0, p2 = 0, p3 = 0; // four short chains instead of one of 32 dependent FMAs
+            int c = 0;
+            for (; c + 3 < nb; c += 4) { p0 += row[c] * rhs[jb + c]; p1 += row[c + 1] * rhs[jb + c + 1]; p2 += row[c + 2] * rhs[jb + c + 2]; p3 += row[c + 3] * rhs[jb + c + 3]; }
+            for (; c < nb; c++) p0 += row[c] * rhs[jb + c];
+            rhs[i] -= (p0 + p1) + (p2 + p3);
+        }
+    }
+    for (int bi = nblk - 1; bi >= 0; bi--) {
+        const int jb = bi * CB, nb = min(CB, n - jb);
+        __syncthreads();
+        for (int e = tid; e < CB * CB; e += T) Ld[(e / CB) * (CB + 1) + e % CB] = Dg[(long)bi * CB * CB + e];
+        __syncthreads();
+        if (tid < 64) {
+            double acc = tid < nb ? rhs[jb + tid] : 0.0;
+            const double rd = tid < nb ? 1.0 / Ld[tid * (CB + 1) + tid] : 0.0;
+            for (int t = nb - 1; t >= 0; t--) {
+                const double xt = __shfl(acc, t) * __shfl(rd, t);
+                if (tid == t) acc = xt;
+                else if (tid < t) acc -= Ld[t * (CB + 1) + tid] * xt; // L^T: column tid of row t
+            }
+            if (tid < nb) rhs[jb + tid] = acc;
+        }
+        __syncthreads();
+        for (int k = tid; k < jb; k += T) {
+            double p0 = 0, p1 = 0, p2 = 0, p3 = 0;
+            int c = 0;
+            for (; c + 3 < nb; c += 4) {
+                p0 += A[(long)(jb + c) * n + k] * rhs[jb + c]; p1 += A[(long)(jb + c + 1) * n + k] * rhs[jb + c + 1];
+                p2 += A[(long)(jb + c + 2) * n + k] * rhs[jb + c + 2]; p3 += A[(long)(jb + c + 3) * n + k] * rhs[jb + c + 3];
+            }
+            for (; c < nb; c++) p0 += A[(long)(jb + c) * n + k] * rhs[jb + c];
+            rhs[k] -= (p0 + p1) + (p2 + p3);
+        }
+    }
+    __syncthreads();
+    for (int i = tid; i < n; i += T) x[i] = rhs[i];
+}
+
 } // namespace
 
 struct cs_ba_dyn {
     DynG G;
     std::vector<void *> bufs;
-    int n_edges = 0, n_vertices = 0, max_part = 0;
+    int n_edges = 0, n_vertices = 0, max_part = 0, n_slots = 0, simple_chol = 0;
+    double *d_Dg = nullptr;
     size_t state_doubles = 0;
     double *d_state = nullptr, *d_bak = nullptr, *d_partials = nullptr, *d_diag = nullptr;
     int *d_status = nullptr;
@@ -158,7 +343,12 @@ int dyn_reduce(cs_ctx *ctx, cs_ba_dyn *b, double lambda) { // Schur complement o
     const DynG &G = b->G;
     const long n2 = std::max<long>((long)G.NP * G.NP, G.NP);
     if (n2 > 0) CS_LAUNCH(ctx, "badyn_schur_init", badyn_schur_init, dim3((unsigned)((n2 + 255) / 256)), dim3(256), 0, G, lambda);
-    if (G.L > 0) CS_LAUNCH(ctx, "badyn_schur", badyn_schur, dim3((G.L + 63) / 64), dim3(64), 0, G, lambda);
+    if (G.L > 0) {
+        CS_LAUNCH(ctx, "badyn_dinv", badyn_dinv, dim3((G.L + 63) / 64), dim3(64), 0, G, lambda);
+        if (b->n_slots > 0) CS_LAUNCH(ctx, "badyn_bd", badyn_bd, dim3((b->n_slots + 63) / 64), dim3(64), 0, G, b->n_slots);
+        if (G.n_blocks > 0) CS_LAUNCH(ctx, "badyn_schur_blocks", badyn_schur_blocks, dim3(G.n_blocks), dim3(256), 0, G);
+        if (G.n_vtx > 0) CS_LAUNCH(ctx, "badyn_schur_rhs", badyn_schur_rhs, dim3(G.n_vtx), dim3(64), 0, G);
+    }
     return CS_OK;
 }
 int dyn_solve(cs_ctx *ctx, cs_ba_dyn *b, double lambda) { // BlockSolver::solve: reduce, dense solve, back substitution; status on the device
@@ -168,7 +358,17 @@ int dyn_solve(cs_ctx *ctx, cs_ba_dyn *b, double lambda) { // BlockSolver::solve:
     if (r) return r;
     if (G.NP > 0) {
         CS_HIP(ctx, hipMemcpyAsync(G.xp, G.bs, sizeof(double) * G.NP, hipMemcpyDeviceToDevice, ctx->stream));
-        CS_LAUNCH(ctx, "badyn_chol_solve", badyn_chol_solve, dim3(1), dim3(1024), sizeof(double) * 2 * (size_t)G.NP, G.NP, G.S, G.xp, b->d_status);
+        if (b->simple_chol) {
+            CS_LAUNCH(ctx, "badyn_chol_solve", badyn_chol_solve, dim3(1), dim3(1024), sizeof(double) * 2 * (size_t)G.NP, G.NP, G.S, G.xp, b->d_status);
+        } else {
+            const int n = G.NP;
+            for (int jb = 0; jb < n; jb += CB) {
+                const int nb = std::min(CB, n - jb), m = n - jb - nb; // rows behind the panel
+                CS_LAUNCH(ctx, "badyn_chol_panel", badyn_chol_panel, dim3(std::max(1, (m + 255) / 256)), dim3(256), 0, n, jb, G.S, b->d_Dg, b->d_status);
+                if (m > 0) { const int T = (m + CB - 1) / CB; CS_LAUNCH(ctx, "badyn_chol_update", badyn_chol_update, dim3(T, T), dim3(256), 0, n, jb, G.S); }
+            }
+            CS_LAUNCH(ctx, "badyn_chol_tri", badyn_chol_tri, dim3(1), dim3(1024), sizeof(double) * ((size_t)n + CB * (CB + 1)), n, G.S, b->d_Dg, G.xp);
+        }
     }
     if (G.L > 0) CS_LAUNCH(ctx, "badyn_backsub", badyn_backsub, dim3((G.L + 63) / 64), dim3(64), 0, G);
     return CS_OK;
@@ -211,31 +411,14 @@ int cs_ba_dyn_create(cs_ctx *ctx, const cs_ba_dyn_problem *p, cs_ba_dyn **out) {
     G.huber_obj = p->huber_obj; G.ulp_info = p->ulp_info; G.ulp_ratio = p->ulp_ratio; G.pc_ratio = p->pc_ratio;
     for (int k = 0; k < 9; k++) G.K[k] = p->K[k];
     for (int k = 0; k < 3; k++) { G.ulp_scale[k] = p->ulp_scale[k]; G.mot_info[k] = p->mot_info[k]; }
-    // pose-system offsets: non-fixed cameras, object poses, velocities
-    std::vector<int> cam_off(p->n_cams, -1), obj_off(std::max(p->n_objs, 1), -1), vel_off(std::max(p->n_vels, 1), -1);
-    int NP = 0;
-    for (int i = 0; i < p->n_cams; i++) if (!p->cam_fixed[i]) { cam_off[i] = NP; NP += 6; }
-    for (int i = 0; i < p->n_objs; i++) { obj_off[i] = NP; NP += 6; }
-    for (int i = 0; i < p->n_vels; i++) { vel_off[i] = NP; NP += 2; }
+    DynLists X; // pose-system offsets, pose-landmark slots, Schur target blocks
+    dyn_build_lists(p, X);
+    const int NP = X.NP;
     if (NP > DYN_MAX_NP) { delete b; ctx->err = "dynamic BA: pose system larger than DYN_MAX_NP scalars"; return CS_ERR_BAD_ARG; }
-    G.NP = NP; G.L = G.fix_points ? 0 : p->n_points + p->n_dpoints;
-    // pose-landmark slots and the per-landmark lists
-    const int n_slots = p->n_obs + 2 * p->n_dobs;
-    std::vector<int> slot_off(std::max(n_slots, 1), -1), lm_start((size_t)G.L + 1, 0), lm_slots(std::max(n_slots, 1), 0);
-    if (G.L > 0) {
-        auto lvl = [](const uint8_t *a, int o) { return a && a[o]; };
-        std::vector<int> slot_lm(std::max(n_slots, 1), -1);
-        for (int o = 0; o < p->n_obs; o++) if (!lvl(p->obs_level, o)) { slot_off[o] = cam_off[p->obs_cam[o]]; slot_lm[o] = p->obs_point[o]; }
-        for (int o = 0; o < p->n_dobs; o++) if (!lvl(p->dobs_level, o)) {
-            const int s = p->n_obs + 2 * o;
-            slot_off[s] = cam_off[p->dobs_cam[o]]; slot_off[s + 1] = obj_off[p->dobs_obj[o]];
-            slot_lm[s] = slot_lm[s + 1] = p->n_points + p->dobs_point[o];
-        }
-        for (int s = 0; s < n_slots; s++) if (slot_off[s] >= 0) lm_start[slot_lm[s] + 1]++;
-        for (int l = 0; l < G.L; l++) lm_start[l + 1] += lm_start[l];
-        std::vector<int> pos(lm_start.begin(), lm_start.end() - 1);
-        for (int s = 0; s < n_slots; s++) if (slot_off[s] >= 0) lm_slots[pos[slot_lm[s]]++] = s;
-    }
+    G.NP = NP; G.L = X.L;
+    const int n_slots = b->n_slots = X.n_slots;
+    G.n_blocks = (int)X.blk_ou.size(); G.n_vtx = (int)X.vtx_off.size();
+    { const char *ce = getenv("CUBESLAM_BADYN_CHOL"); b->simple_chol = ce && !strcmp(ce, "simple"); }
     b->n_edges = p->n_obs + p->n_dobs + p->n_mot + p->n_cobs + p->n_pc + p->n_dpoints;
     b->n_vertices = p->n_cams + p->n_objs + p->n_vels + p->n_points + p->n_dpoints;
     b->max_part = std::max(1, (b->n_edges + 255) / 256);
@@ -254,8 +437,8 @@ int cs_ba_dyn_create(cs_ctx *ctx, const cs_ba_dyn_problem *p, cs_ba_dyn **out) {
     D_(dyn_upload(ctx, b, &b->d_bak, (const double *)nullptr, st.size()));
     G.cam = b->d_state + o_cam; G.obj = b->d_state + o_obj; G.vel = b->d_state + o_vel; G.pts = b->d_state + o_pts; G.dpts = b->d_state + o_dp;
     D_(dyn_upload(ctx, b, &G.obj_scale, p->obj_scale, (size_t)p->n_objs * 3)); D_(dyn_upload(ctx, b, &G.obj_flags, p->obj_flags, (size_t)p->n_objs));
-    D_(dyn_upload(ctx, b, &G.cam_off, cam_off.data(), cam_off.size())); D_(dyn_upload(ctx, b, &G.obj_off, obj_off.data(), obj_off.size()));
-    D_(dyn_upload(ctx, b, &G.vel_off, vel_off.data(), vel_off.size()));
+    D_(dyn_upload(ctx, b, &G.cam_off, X.cam_off.data(), X.cam_off.size())); D_(dyn_upload(ctx, b, &G.obj_off, X.obj_off.data(), X.obj_off.size()));
+    D_(dyn_upload(ctx, b, &G.vel_off, X.vel_off.data(), X.vel_off.size()));
     D_(dyn_upload(ctx, b, &G.o_cam, p->obs_cam, (size_t)p->n_obs)); D_(dyn_upload(ctx, b, &G.o_pt, p->obs_point, (size_t)p->n_obs));
     D_(dyn_upload(ctx, b, &G.o_uv, p->obs_uv, (size_t)p->n_obs * 2)); D_(dyn_upload(ctx, b, &G.o_w, p->obs_inv_sigma2, (size_t)p->n_obs));
     if (p->obs_ur && p->n_obs) D_(dyn_upload(ctx, b, &G.o_ur, p->obs_ur, (size_t)p->n_obs));
@@ -281,8 +464,14 @@ int cs_ba_dyn_create(cs_ctx *ctx, const cs_ba_dyn_problem *p, cs_ba_dyn **out) {
     D_(dyn_upload(ctx, b, &G.Hll, (const double *)nullptr, (size_t)G.L * 9)); D_(dyn_upload(ctx, b, &G.Dinv, (const double *)nullptr, (size_t)G.L * 9));
     D_(dyn_upload(ctx, b, &G.bl, (const double *)nullptr, (size_t)G.L * 3)); D_(dyn_upload(ctx, b, &G.xl, (const double *)nullptr, (size_t)G.L * 3));
     D_(dyn_upload(ctx, b, &G.Bslot, (const double *)nullptr, (size_t)n_slots * 18));
-    D_(dyn_upload(ctx, b, &G.slot_off, slot_off.data(), slot_off.size())); D_(dyn_upload(ctx, b, &G.lm_start, lm_start.data(), lm_start.size()));
-    D_(dyn_upload(ctx, b, &G.lm_slots, lm_slots.data(), lm_slots.size()));
+    D_(dyn_upload(ctx, b, &G.slot_off, X.slot_off.data(), X.slot_off.size())); D_(dyn_upload(ctx, b, &G.lm_start, X.lm_start.data(), X.lm_start.size()));
+    D_(dyn_upload(ctx, b, &G.lm_slots, X.lm_slots.data(), X.lm_slots.size())); D_(dyn_upload(ctx, b, &G.slot_lm, X.slot_lm.data(), X.slot_lm.size()));
+    D_(dyn_upload(ctx, b, &G.BD, (const double *)nullptr, (size_t)n_slots * 18)); D_(dyn_upload(ctx, b, &G.bsub, (const double *)nullptr, (size_t)n_slots * 6));
+    D_(dyn_upload(ctx, b, &G.blk_ou, X.blk_ou.data(), X.blk_ou.size())); D_(dyn_upload(ctx, b, &G.blk_ot, X.blk_ot.data(), X.blk_ot.size()));
+    D_(dyn_upload(ctx, b, &G.blk_start, X.blk_start.data(), X.blk_start.size())); D_(dyn_upload(ctx, b, &G.pair_u, X.pair_u.data(), X.pair_u.size()));
+    D_(dyn_upload(ctx, b, &G.pair_t, X.pair_t.data(), X.pair_t.size())); D_(dyn_upload(ctx, b, &G.vtx_off, X.vtx_off.data(), X.vtx_off.size()));
+    D_(dyn_upload(ctx, b, &G.vtx_start, X.vtx_start.data(), X.vtx_start.size())); D_(dyn_upload(ctx, b, &G.vtx_slots, X.vtx_slots.data(), X.vtx_slots.size()));
+    D_(dyn_upload(ctx, b, &b->d_Dg, (const double *)nullptr, (size_t)((NP + CB - 1) / CB) * CB * CB));
     D_(dyn_upload(ctx, b, &b->d_partials, (const double *)nullptr, (size_t)b->max_part));
     D_(dyn_upload(ctx, b, &b->d_diag, (const double *)nullptr, (size_t)NP + 3 * (size_t)G.L));
     D_(dyn_upload(ctx, b, &b->d_status, (const int *)nullptr, 1));

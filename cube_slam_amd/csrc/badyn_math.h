@@ -40,6 +40,10 @@ struct DynG {
     const int *slot_off;               // pose-system offset of a slot's six rows, -1 = unused slot (fixed camera / inactive edge)
     const int *lm_start, *lm_slots;    // CSR: the slots of every landmark
     double *S, *bs, *Dinv, *xp, *xl;
+    // Schur complement without atomics: B D^-1 and B D^-1 b_l per slot, then one wave per target block / one thread per right-hand-side row
+    double *BD, *bsub; const int *slot_lm;
+    int n_blocks, n_vtx;
+    const int *blk_ou, *blk_ot, *blk_start, *pair_u, *pair_t, *vtx_off, *vtx_start, *vtx_slots;
 };
 
 HD int dyn_n_edges(const DynG &G) { return G.n_obs + G.n_dobs + G.n_mot + G.n_cobs + G.n_pc + G.n_dpts; }
@@ -354,34 +358,49 @@ HD void dyn_inv3(const double *D, double *Di) { // Eigen's fixed-size 3x3 invers
     Di[3] = (D[5] * D[6] - D[3] * D[8]) * inv; Di[4] = (D[8] * D[0] - D[6] * D[2]) * inv; Di[5] = (D[2] * D[3] - D[0] * D[5]) * inv;
     Di[6] = (D[3] * D[7] - D[4] * D[6]) * inv; Di[7] = (D[6] * D[1] - D[7] * D[0]) * inv; Di[8] = (D[0] * D[4] - D[1] * D[3]) * inv;
 }
-// landmark li: (Hll + lambda I)^-1, then S -= B_u D^-1 B_t^T for every pair of its slots and bs -= B_u D^-1 b_l (block_solver.hpp:378-432)
-HD void dyn_schur_item(const DynG &G, int li, double lambda) {
+// The Schur complement S = Hpp + lambda I - sum_l B_l (Hll_l + lambda I)^-1 B_l^T (block_solver.hpp:378-432) in three gather steps, so that no
+// two work items write the same word: (1) per landmark the 3x3 inverse, (2) per slot B D^-1 (6x3) and B D^-1 b_l (6), (3) per element of a
+// target block the sum over the slot pairs the host listed for it, per right-hand-side row the sum over the vertex' slots.
+HD void dyn_dinv_item(const DynG &G, int li, double lambda) {
     double D[9], Di[9];
     for (int k = 0; k < 9; k++) D[k] = G.Hll[(long)li * 9 + k];
     D[0] += lambda; D[4] += lambda; D[8] += lambda;
     dyn_inv3(D, Di);
     for (int k = 0; k < 9; k++) G.Dinv[(long)li * 9 + k] = Di[k];
-    const double *b3 = G.bl + (long)li * 3;
-    double db[3];
-    for (int a = 0; a < 3; a++) db[a] = (Di[a * 3] * b3[0] + Di[a * 3 + 1] * b3[1]) + Di[a * 3 + 2] * b3[2];
-    const int s0 = G.lm_start[li], s1 = G.lm_start[li + 1];
-    for (int u = s0; u < s1; u++) {
-        const int su = G.lm_slots[u], ou = G.slot_off[su];
-        if (ou < 0) continue;
-        const double *Bu = G.Bslot + (long)su * 18;
-        double BD[18];
-        for (int a = 0; a < 6; a++) for (int c = 0; c < 3; c++) BD[a * 3 + c] = (Bu[a * 3] * Di[c] + Bu[a * 3 + 1] * Di[3 + c]) + Bu[a * 3 + 2] * Di[6 + c];
-        for (int a = 0; a < 6; a++) BD_ATOMIC_ADD(G.bs + ou + a, -((Bu[a * 3] * db[0] + Bu[a * 3 + 1] * db[1]) + Bu[a * 3 + 2] * db[2]));
-        for (int t = s0; t < s1; t++) {
-            const int st = G.lm_slots[t], ot = G.slot_off[st];
-            if (ot < 0) continue;
-            const double *Bt = G.Bslot + (long)st * 18;
-            for (int a = 0; a < 6; a++)
-                for (int c = 0; c < 6; c++)
-                    BD_ATOMIC_ADD(G.S + (long)(ou + a) * G.NP + ot + c, -((BD[a * 3] * Bt[c * 3] + BD[a * 3 + 1] * Bt[c * 3 + 1]) + BD[a * 3 + 2] * Bt[c * 3 + 2]));
-        }
+}
+HD void dyn_bd_item(const DynG &G, int s) {
+    if (G.slot_off[s] < 0) return;
+    const int li = G.slot_lm[s];
+    const double *B = G.Bslot + (long)s * 18, *Di = G.Dinv + (long)li * 9, *b3 = G.bl + (long)li * 3;
+    for (int a = 0; a < 6; a++) {
+        double r[3];
+        for (int c = 0; c < 3; c++) r[c] = (B[a * 3] * Di[c] + B[a * 3 + 1] * Di[3 + c]) + B[a * 3 + 2] * Di[6 + c];
+        for (int c = 0; c < 3; c++) G.BD[(long)s * 18 + a * 3 + c] = r[c];
+        G.bsub[(long)s * 6 + a] = (r[0] * b3[0] + r[1] * b3[1]) + r[2] * b3[2];
     }
 }
+// partial sums over every ng-th pair / slot starting at g, so that several lanes can share a long list (the diagonal block of a camera
+// collects one pair per point it sees); the caller adds the partials in the order g = 0 .. ng-1 and stores
+HD double dyn_schur_block_partial(const DynG &G, int blk, int e, int g, int ng) { // element e = a * 6 + c of target block blk
+    const int a = e / 6, c = e % 6;
+    double acc = 0;
+    for (int q = G.blk_start[blk] + g; q < G.blk_start[blk + 1]; q += ng) {
+        const double *BD = G.BD + (long)G.pair_u[q] * 18 + a * 3, *Bt = G.Bslot + (long)G.pair_t[q] * 18 + c * 3;
+        acc += (BD[0] * Bt[0] + BD[1] * Bt[1]) + BD[2] * Bt[2];
+    }
+    return acc;
+}
+HD void dyn_schur_block_store(const DynG &G, int blk, int e, double acc) {
+    const int a = e / 6, c = e % 6, ou = G.blk_ou[blk], ot = G.blk_ot[blk];
+    G.S[(long)(ou + a) * G.NP + ot + c] -= acc;
+    if (ou != ot) G.S[(long)(ot + c) * G.NP + ou + a] -= acc;
+}
+HD double dyn_rhs_partial(const DynG &G, int v, int a, int g, int ng) { // row a of pose vertex v (of those that own slots)
+    double acc = 0;
+    for (int q = G.vtx_start[v] + g; q < G.vtx_start[v + 1]; q += ng) acc += G.bsub[(long)G.vtx_slots[q] * 6 + a];
+    return acc;
+}
+HD void dyn_rhs_store(const DynG &G, int v, int a, double acc) { G.bs[G.vtx_off[v] + a] -= acc; }
 HD void dyn_backsub_item(const DynG &G, int li) { // x_l = (Hll + lambda I)^-1 (b_l - B^T x_p), block_solver.hpp:459-485
     double cl[3] = {G.bl[(long)li * 3], G.bl[(long)li * 3 + 1], G.bl[(long)li * 3 + 2]};
     for (int u = G.lm_start[li]; u < G.lm_start[li + 1]; u++) {

@@ -990,7 +990,7 @@ template <int CFG> __device__ __forceinline__ void score_one(const Unit &U, int 
 }
 __global__ void __launch_bounds__(256) cuboid_sweep_score(const Unit *units, int n_units, int blocks_per_unit, const VPEntry *vpt, const float *dist,
                                                           const double *corners, long hyp_total, const int *vcount, const int *vlist, double *derr,
-                                                          double *aerr) {
+                                                          double *aerr, int lds_px) {
     __shared__ double s_c[16 * 256]; // the thread's proposal corners: column threadIdx.x, no sharing between threads
     __shared__ float s_cp[8 * 256];  // distance-map values at the corners
     double *sc = s_c + threadIdx.x;
@@ -1003,12 +1003,212 @@ __global__ void __launch_bounds__(256) cuboid_sweep_score(const Unit *units, int
     const int c1 = vcount[2 * u], c2 = vcount[2 * u + 1];
     const int nb1 = (c1 + SCORE_PB - 1) / SCORE_PB;
     const Unit &U = units[u];
+    if (U.roi_w * U.roi_h <= lds_px) return; // scored by cuboid_sweep_score_lds
     if (blk < nb1) {
         const int s = blk * SCORE_PB + threadIdx.x;
         if (s < c1) score_one<1>(U, vlist[U.hyp_off + s], vpt, dist, corners, hyp_total, sc, scp, derr, aerr);
     } else {
         const int s = (blk - nb1) * SCORE_PB + threadIdx.x;
         if (s < c2) score_one<2>(U, vlist[U.hyp_off + U.hyp_cap - 1 - s], vpt, dist, corners, hyp_total, sc, scp, derr, aerr);
+    }
+}
+
+// ---- cuboid_sweep_score_lds: the same scores with the unit's distance map resident in LDS (CUBESLAM_SCORE=lds) ------------------------
+// The chamfer values are t * 2^-16 with t = i*DT_HV + j*DT_DIAG (i horizontal/vertical and j diagonal steps of the shortest path), so a
+// pixel with i, j < 256 is exactly the 16-bit code i | j << 8 and a 640x480 box ROI (<= SLDS_MAP_PX pixels) fits the 160 KB of one CU.
+// Encoding while the workgroup copies the map: t = d * 65536 (exact for d < 256), floor(t / HV) from one float FMA (the fractional part of
+// t / HV is (j * DIAG mod HV) / HV: 0 or in [0.00155, 0.99845], so a bias of 0.0005 absorbs the rounding), j from a 978-entry table indexed
+// by (t mod HV) >> 6 (the 256 residues j * DIAG mod HV are >= 97 apart: one per 64-wide bucket, checked in tests/test_cabi.py), i = floor(t /
+// HV) - floor(j * DIAG / HV); the pair is verified (i * HV + j * DIAG == t) and anything else -- d >= 256, maps without edges -- becomes the
+// escape code 0xFFFF = (255, 255), whose t is above 2^24: a proposal that touched one (max of the decoded t) is re-scored from the float map.
+// Persistent 512-thread workgroups (one per CU: the map takes the whole LDS) pull (unit, configuration, 1024-proposal chunk) items from a
+// device-built list; corners in registers (everything unrolled, constant corner indices); the gathers are
+// ds_read_u16 instead of 41 M texture-path lanes.  Units whose ROI does not fit stay with cuboid_sweep_score.
+constexpr int SLDS_T = 512;                                              // threads per workgroup: 2 waves per SIMD, 256 VGPRs each
+constexpr int SLDS_PW = 1024;                                            // proposals per work item (two per thread)
+constexpr int SLDS_LUT = (DT_HV + 63) / 64;                               // 978
+constexpr int SLDS_BYTES = 160 * 1024;
+constexpr int SLDS_MAP_PX = (SLDS_BYTES - SLDS_LUT * 4 - 16) / 2 & ~3;    // 79 956 pixels (16 bytes at the end: the work item broadcast)
+constexpr int K_VIS1[9][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 0}, {1, 5}, {2, 4}, {3, 7}, {4, 7}, {4, 5}};
+constexpr int K_VIS2[7][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 0}, {1, 5}, {2, 4}, {4, 5}};
+constexpr int K_VPE1[3][4] = {{0, 1, 7, 4}, {3, 0, 4, 5}, {3, 7, 1, 5}};
+constexpr int K_VPE2[3][4] = {{0, 1, 2, 3}, {3, 0, 4, 5}, {2, 4, 1, 5}};
+
+__device__ __forceinline__ unsigned slds_encode(float d, const unsigned *lut) {
+    const float tf = d * 65536.0f;
+    const int t = (int)tf;
+    const int qn = (int)__fmaf_rn(tf, 1.0f / (float)DT_HV, 0.0005f);
+    const int q = t - __mul24(qn, DT_HV);
+    const unsigned e = lut[min((unsigned)q >> 6, (unsigned)(SLDS_LUT - 1))];
+    const int j = (int)(e & 0xffu), i = qn - (int)(e >> 8);
+    const bool ok = d < 256.0f && (unsigned)i < 256u && __mul24(i, DT_HV) + __mul24(j, DT_DIAG) == t;
+    return ok ? (unsigned)(i | (j << 8)) : 0xffffu;
+}
+struct FetchLds {
+    const unsigned short *m; unsigned tmax;
+    __device__ __forceinline__ float operator()(int idx) {
+        const unsigned c = m[idx];
+        const unsigned t = __umul24(c & 0xffu, (unsigned)DT_HV) + __umul24(c >> 8, (unsigned)DT_DIAG);
+        tmax = max(tmax, t);
+        return (float)t * (1.f / 65536.f);
+    }
+};
+struct FetchGlobal {
+    const float *m;
+    __device__ __forceinline__ float operator()(int idx) { return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(m) + ((unsigned)idx << 2)); }
+};
+// box_edge_sum_dists with the corners in registers: same samples, same order of float additions as edge_sum_dists_lds
+template <int CFG, class F> __device__ __forceinline__ float edge_sum_dists_reg(const double (&cx)[8], const double (&cy)[8], int w, int last, double rx, double ry, F &fetch) {
+    constexpr int NE = CFG == 1 ? 9 : 7;
+    float cp[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        if (CFG == 2 && k >= 6) { cp[k] = 0; continue; }
+        int idx = __mul24(int(cy[k] - ry), w) + int(cx[k] - rx);
+        idx = min(max(idx, 0), last);
+        cp[k] = fetch(idx);
+    }
+    float sum_dist = 0;
+#pragma unroll
+    for (int e = 0; e < NE; e++) {
+        const int ia = CFG == 1 ? K_VIS1[e][0] : K_VIS2[e][0], ib = CFG == 1 ? K_VIS1[e][1] : K_VIS2[e][1];
+        const double x1 = cx[ia] - rx, y1 = cy[ia] - ry, x2 = cx[ib] - rx, y2 = cy[ib] - ry; // :423-425
+        const float wgt = (CFG == 2 && (e == 4 || e == 5)) ? 1.5f : ((CFG == 2 && e == 6) ? 2.0f : 1.0f);
+#pragma unroll
+        for (int si = 0; si < 11; si++) {
+            float d;
+            if (si == 0) d = cp[ib];
+            else if (si == 10) d = cp[ia];
+            else {
+                const double s = (double)si;
+                const double px = s / 10.0 * x1 + (1 - s / 10.0) * x2;
+                const double py = s / 10.0 * y1 + (1 - s / 10.0) * y2;
+                int idx = __mul24(int(py), w) + int(px);
+                idx = min(max(idx, 0), last);
+                d = fetch(idx);
+            }
+            if (CFG == 2) d = d * wgt;
+            sum_dist = sum_dist + d;
+        }
+        __builtin_amdgcn_sched_barrier(0); // keep the 9 gathers of one edge together instead of hoisting all 99: the register budget is 128
+    }
+    return sum_dist;
+}
+template <int CFG> __device__ __forceinline__ double edge_angle_error_reg(const VPEntry &E, const double (&cx)[8], const double (&cy)[8]) {
+    double total = 0;
+    const double not_found_penalty = 30.0 / 180.0 * PI * 2;
+#pragma unroll
+    for (int vp = 0; vp < 3; vp++) {
+        const double a0 = E.ang[vp * 2], a1 = E.ang[vp * 2 + 1];
+        const bool v0 = !isnan(a0), v1 = !isnan(a1);
+        if (v0 || v1) {
+#pragma unroll
+            for (int ee = 0; ee < 2; ee++) {
+                const int a = CFG == 1 ? K_VPE1[vp][2 * ee] : K_VPE2[vp][2 * ee], b = CFG == 1 ? K_VPE1[vp][2 * ee + 1] : K_VPE2[vp][2 * ee + 1];
+                const double ang = normalize_to_pi(atan2(cy[b] - cy[a], cx[b] - cx[a]));
+                double best = 100;
+                if (v0) { double t = fabs(ang - a0); t = fmin(t, PI - t); if (t < best) best = t; }
+                if (v1) { double t = fabs(ang - a1); t = fmin(t, PI - t); if (t < best) best = t; }
+                total = total + best;
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        } else
+            total = total + not_found_penalty;
+    }
+    return total;
+}
+template <int CFG> __device__ __forceinline__ void score_one_lds(const Unit &U, int h, const VPEntry *vpt, const float *dist, const unsigned short *lmap, const double *corners,
+                                                                 long hyp_total, double *derr, double *aerr) {
+    const long g = U.hyp_off + h;
+    const int q = (h >> 1) / U.n_tops;
+    double cx[8], cy[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { cx[k] = corners[(long)k * hyp_total + g]; cy[k] = corners[(long)(8 + k) * hyp_total + g]; }
+    const int last = U.roi_w * U.roi_h - 1;
+    FetchLds fl{lmap, 0u};
+    float sum_dist = edge_sum_dists_reg<CFG>(cx, cy, U.roi_w, last, (double)U.roi_x, (double)U.roi_y, fl);
+    if (fl.tmax >= (1u << 24)) { // an escape code was sampled: this proposal reads the float map
+        FetchGlobal fg{dist + U.pix_off};
+        sum_dist = edge_sum_dists_reg<CFG>(cx, cy, U.roi_w, last, (double)U.roi_x, (double)U.roi_y, fg);
+    }
+    derr[g] = double(sum_dist) / U.diag; // :451
+    aerr[g] = edge_angle_error_reg<CFG>(vpt[(long)U.vp_off + q], cx, cy);
+}
+// Work list of the LDS kernel, built on the device because the list lengths are: one item per SLDS_PW proposals of one configuration of
+// one unit that fits.  work_n[0] = number of items, work_n[1] = the dynamic work counter (reset here).
+__global__ void __launch_bounds__(256) cuboid_score_worklist(const Unit *units, int n_units, const int *vcount, int2 *work, int *work_n) {
+    __shared__ int s_n[256];
+    __shared__ int s_base;
+    if (threadIdx.x == 0) s_base = 0;
+    __syncthreads();
+    for (int u0 = 0; u0 < n_units; u0 += 256) {
+        const int u = u0 + threadIdx.x;
+        int n = 0;
+        if (u < n_units && units[u].roi_w * units[u].roi_h <= SLDS_MAP_PX) n = (vcount[2 * u] + SLDS_PW - 1) / SLDS_PW + (vcount[2 * u + 1] + SLDS_PW - 1) / SLDS_PW;
+        s_n[threadIdx.x] = n;
+        __syncthreads();
+        if (threadIdx.x == 0) { int acc = s_base; for (int i = 0; i < 256; i++) { const int v = s_n[i]; s_n[i] = acc; acc += v; } s_base = acc; }
+        __syncthreads();
+        for (int k = 0; k < n; k++) work[s_n[threadIdx.x] + k] = make_int2(u, k);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) { work_n[0] = s_base; work_n[1] = 0; }
+}
+__global__ void __launch_bounds__(SLDS_T) cuboid_sweep_score_lds(const Unit *units, const int2 *work, int *work_n, const VPEntry *vpt, const float *dist,
+                                                                 const double *corners, long hyp_total, const int *vcount, const int *vlist, double *derr, double *aerr) {
+    extern __shared__ unsigned char slds_mem[];
+    unsigned *lut = reinterpret_cast<unsigned *>(slds_mem);
+    unsigned short *lmap = reinterpret_cast<unsigned short *>(slds_mem + SLDS_LUT * 4);
+    int *s_item = reinterpret_cast<int *>(slds_mem + SLDS_BYTES - 16);
+    const int tid = threadIdx.x;
+    for (int i = tid; i < SLDS_LUT; i += SLDS_T) lut[i] = 0xffffffffu;
+    __syncthreads();
+    if (tid < 256) { const int r = (tid * DT_DIAG) % DT_HV; lut[r >> 6] = (unsigned)tid | ((unsigned)((tid * DT_DIAG) / DT_HV) << 8); }
+    const int n_work = work_n[0];
+    int cur_u = -1;
+    for (;;) {
+        __syncthreads(); // the LUT is complete / everybody is done with the previous item's map and s_item
+        if (tid == 0) *s_item = atomicAdd(&work_n[1], 1);
+        __syncthreads();
+        const int wi = *s_item;
+        if (wi >= n_work) return;
+        const int2 it = work[wi];
+        const int u = it.x, blk = it.y;
+        const Unit &U = units[u];
+        if (u != cur_u) { // encode the unit's distance map into LDS, 16 pixels per thread and step (four loads in flight)
+            cur_u = u;
+            const int A = U.roi_w * U.roi_h, A4 = A >> 2;
+            const float4 *dm4 = reinterpret_cast<const float4 *>(dist + U.pix_off); // 256-byte aligned slice
+            uint2 *lm2 = reinterpret_cast<uint2 *>(lmap);
+            for (int k0 = tid; k0 < A4; k0 += 4 * SLDS_T) {
+                float4 v[4];
+#pragma unroll
+                for (int r = 0; r < 4; r++) { const int k = k0 + r * SLDS_T; v[r] = k < A4 ? dm4[k] : make_float4(0.f, 0.f, 0.f, 0.f); }
+#pragma unroll
+                for (int r = 0; r < 4; r++) {
+                    const int k = k0 + r * SLDS_T;
+                    if (k < A4) {
+                        const unsigned e0 = slds_encode(v[r].x, lut), e1 = slds_encode(v[r].y, lut), e2 = slds_encode(v[r].z, lut), e3 = slds_encode(v[r].w, lut);
+                        lm2[k] = make_uint2(e0 | (e1 << 16), e2 | (e3 << 16));
+                    }
+                }
+            }
+            const float *dm = dist + U.pix_off;
+            for (int k = (A4 << 2) + tid; k < A; k += SLDS_T) lmap[k] = (unsigned short)slds_encode(dm[k], lut);
+            __syncthreads();
+        }
+        const int c1 = vcount[2 * u], c2 = vcount[2 * u + 1];
+        const int nb1 = (c1 + SLDS_PW - 1) / SLDS_PW;
+#pragma unroll 1
+        for (int r = 0; r < SLDS_PW / SLDS_T; r++) {
+            if (blk < nb1) {
+                const int sidx = blk * SLDS_PW + r * SLDS_T + tid;
+                if (sidx < c1) score_one_lds<1>(U, vlist[U.hyp_off + sidx], vpt, dist, lmap, corners, hyp_total, derr, aerr);
+            } else {
+                const int sidx = (blk - nb1) * SLDS_PW + r * SLDS_T + tid;
+                if (sidx < c2) score_one_lds<2>(U, vlist[U.hyp_off + U.hyp_cap - 1 - sidx], vpt, dist, lmap, corners, hyp_total, derr, aerr);
+            }
+        }
     }
 }
 
@@ -1416,7 +1616,9 @@ struct cs_cuboid_batch {
     uint8_t *d_gray = nullptr, *d_emap = nullptr, *d_flag = nullptr;
     int *d_lab = nullptr; // aliases d_dist
     float *d_dist = nullptr;
-    int *d_dttmp = nullptr; long *d_dttmp_off = nullptr; int dt_C = 0; // wave-per-ROI distance transform: int map between the passes, lane-major
+    int *d_dttmp = nullptr; long *d_dttmp_off = nullptr; int2 *d_work = nullptr; int *d_work_n = nullptr; // work list of cuboid_sweep_score_lds
+    int score_lds = 0; // CUBESLAM_SCORE=lds: cuboid_sweep_score_lds for the units whose ROI fits one CU's LDS
+    int dt_C = 0; // wave-per-ROI distance transform: int map between the passes, lane-major
     FrameInfo *d_fi = nullptr; FrameDyn *d_fd = nullptr; CamRP *d_cam = nullptr;
     double *d_yaw = nullptr, *d_lines_in = nullptr, *d_lines_al = nullptr, *d_mlines = nullptr, *d_mangle = nullptr, *d_mmid = nullptr;
     Unit *d_units = nullptr; UnitDyn *d_ud = nullptr; int *d_box_first = nullptr, *d_status = nullptr, *d_counts = nullptr;
@@ -1442,7 +1644,7 @@ void cs_cuboid_batch_destroy(cs_ctx *ctx, cs_cuboid_batch *b) {
     if (ctx) { hipSetDevice(ctx->device); hipStreamSynchronize(ctx->stream); }
     void *ptrs[] = {b->d_gray, b->d_emap, b->d_flag, b->d_dist, b->d_dttmp, b->d_dttmp_off, b->d_fi, b->d_fd, b->d_cam, b->d_yaw, b->d_lines_in, b->d_lines_al,
                     b->d_mlines, b->d_mangle, b->d_mmid, b->d_units, b->d_ud, b->d_box_first, b->d_status, b->d_counts, b->d_vp,
-                    b->d_derr, b->d_aerr, b->d_corners, b->d_score, b->d_nscore, b->d_ckd, b->d_cka, b->d_cidx, b->d_out, b->d_vcount, b->d_vlist};
+                    b->d_derr, b->d_aerr, b->d_corners, b->d_score, b->d_nscore, b->d_ckd, b->d_cka, b->d_cidx, b->d_out, b->d_vcount, b->d_vlist, b->d_work, b->d_work_n};
     for (void *p : ptrs) if (p) hipFree(p);
     delete b;
 }
@@ -1553,6 +1755,18 @@ int cs_cuboid_batch_create(cs_ctx *ctx, int n_frames, int width, int height, con
             A_(cs_h2d(ctx, b->d_dttmp_off, off.data(), off.size()));
         }
     }
+    {
+        const char *se = getenv("CUBESLAM_SCORE");
+        if (se && !strcmp(se, "lds")) {
+            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(cuboid_sweep_score_lds), hipFuncAttributeMaxDynamicSharedMemorySize, SLDS_BYTES);
+            if (e != hipSuccess) { ctx->err = hipGetErrorString(e); cs_cuboid_batch_destroy(ctx, b); return CS_ERR_HIP; }
+            b->score_lds = 1;
+            long items = 0;
+            for (const Unit &U : b->units) items += (U.hyp_cap + SLDS_PW - 1) / SLDS_PW + 2;
+            A_(cs_dalloc(ctx, &b->d_work, (size_t)items));
+            A_(cs_dalloc(ctx, &b->d_work_n, 2));
+        }
+    }
     A_(cs_dalloc(ctx, &b->d_dist, (size_t)b->pix_total));
     b->d_lab = (int *)b->d_dist;
     A_(cs_dalloc(ctx, &b->d_fi, (size_t)n_frames));
@@ -1630,7 +1844,12 @@ int cs_cuboid_batch_run(cs_ctx *ctx, cs_cuboid_batch *b) {
               b->blocks_per_unit, b->d_fd, b->o, b->d_vp, b->d_flag, b->d_corners, b->hyp_total, b->d_vcount, b->d_vlist);
     const int score_bpu = b->blocks_per_unit * (SWEEP_HB / SCORE_PB) + 1; // +1: each of the two lists may end in a partial workgroup
     CS_LAUNCH(ctx, "cuboid_sweep_score", cuboid_sweep_score, dim3(groups * score_bpu * 8), dim3(256), 0, b->d_units, U, score_bpu, b->d_vp,
-              b->d_dist, b->d_corners, b->hyp_total, b->d_vcount, b->d_vlist, b->d_derr, b->d_aerr);
+              b->d_dist, b->d_corners, b->hyp_total, b->d_vcount, b->d_vlist, b->d_derr, b->d_aerr, b->score_lds ? SLDS_MAP_PX : 0);
+    if (b->score_lds) {
+        CS_LAUNCH(ctx, "cuboid_score_worklist", cuboid_score_worklist, dim3(1), dim3(256), 0, b->d_units, U, b->d_vcount, b->d_work, b->d_work_n);
+        CS_LAUNCH(ctx, "cuboid_sweep_score_lds", cuboid_sweep_score_lds, dim3(512), dim3(SLDS_T), SLDS_BYTES, b->d_units, b->d_work, b->d_work_n, b->d_vp, b->d_dist,
+                  b->d_corners, b->hyp_total, b->d_vcount, b->d_vlist, b->d_derr, b->d_aerr);
+    }
     CS_LAUNCH(ctx, "cuboid_select", cuboid_select, dim3(b->n_boxes), dim3(256), 0, b->d_units, b->d_ud, b->d_box_first, b->d_fd, b->d_fi,
               b->d_cam, b->d_yaw, b->cal, b->o, b->d_flag, b->d_derr, b->d_aerr, b->d_corners, b->hyp_total, b->d_score, b->d_nscore,
               b->d_ckd, b->d_cka, b->d_cidx, b->d_out, b->d_counts);
