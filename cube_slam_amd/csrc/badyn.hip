@@ -45,9 +45,9 @@ __global__ void __launch_bounds__(256) badyn_errors(DynG G, int n_edges, double 
     const int e = blockIdx.x * 256 + threadIdx.x;
     dyn_block_sum_store(e < n_edges ? dyn_error_item(G, e) : 0.0, partials);
 }
-__global__ void __launch_bounds__(64) badyn_linearize(DynG G, int n_edges) {
+template <int ONLY> __global__ void __launch_bounds__(64) badyn_linearize(DynG G, int e0, int n) { // edges [e0, e0 + n) of the concatenated list
     const int e = blockIdx.x * 64 + threadIdx.x;
-    if (e < n_edges) dyn_lin_item(G, e);
+    if (e < n) dyn_lin_item<ONLY>(G, e0 + e);
 }
 __global__ void __launch_bounds__(256) badyn_schur_init(DynG G, double lambda) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x, n2 = (long)G.NP * G.NP;
@@ -143,64 +143,44 @@ __global__ void __launch_bounds__(1024) badyn_chol_solve(int n, double *A, doubl
 // ---- blocked Cholesky: A (n x n row-major, lower triangle) -> strictly-lower panels in place, pivot blocks in Dg (one 32x32 row-major
 // block per step, the upper part zero).
 constexpr int CB = 32;
-__global__ void __launch_bounds__(256) badyn_chol_panel(int n, int jb, double *A, double *Dg, int *status) {
+constexpr int CP_T = 128; // rows (= threads) per panel workgroup
+__global__ void __launch_bounds__(CP_T) badyn_chol_panel(int n, int jb, double *A, double *Dg, int *status) {
     __shared__ double Ld[CB][CB + 1];
-    const int tid = threadIdx.x, nb = min(CB, n - jb);
-    for (int e = tid; e < CB * CB; e += 256) { const int r = e / CB, c = e % CB; Ld[r][c] = (r < nb && c <= r) ? A[(long)(jb + r) * n + jb + c] : 0.0; }
-    __syncthreads();
-    __shared__ int s_fail;
+    __shared__ double xs[CB][CP_T]; // the thread's panel row, column-major so that neighbouring threads hit neighbouring banks
     __shared__ double rdiag[CB];
-    if (tid == 0) s_fail = 0;
+    const int tid = threadIdx.x, nb = min(CB, n - jb);
+    for (int e = tid; e < CB * CB; e += CP_T) { const int r = e / CB, c = e % CB; Ld[r][c] = (r < nb && c <= r) ? A[(long)(jb + r) * n + jb + c] : 0.0; }
     __syncthreads();
-    if (tid < 64) { // wave 0 factors the pivot block (every workgroup its own copy): lane r keeps row r in registers, pivots travel by readlane
-        const int r = tid & 31;
-        double v[CB];
-#pragma unroll
-        for (int c = 0; c < CB; c++) v[c] = (r >= nb && c == r) ? 1.0 : Ld[r][c]; // rows beyond a ragged last block: identity
-        bool bad = false;
-#pragma unroll
-        for (int c = 0; c < CB; c++) {
-            const double d = __shfl(v[c], c);
-            bad = bad || !(d > 0);
-            const double rt = sqrt(d);
-            if (r == c) v[c] = rt; else if (r > c) v[c] = v[c] / rt;
-#pragma unroll
-            for (int k = c + 1; k < CB; k++) {
-                const double lkc = __shfl(v[c], k);
-                if (r >= k) v[k] -= v[c] * lkc;
-            }
-            __builtin_amdgcn_sched_barrier(0);
-        }
-        if (tid < CB) {
-#pragma unroll
-            for (int c = 0; c < CB; c++) Ld[r][c] = c <= r ? v[c] : 0.0;
-            double dr = 1.0;
-#pragma unroll
-            for (int c = 0; c < CB; c++) if (c == r) dr = v[c];
-            rdiag[r] = 1.0 / dr;
-        }
-        if (bad && tid == 0) s_fail = 1;
+    // every workgroup factors the pivot block itself, in LDS (loops stay rolled: an unrolled register version of this kernel spilled 620
+    // VGPRs and took 68 us per panel)
+#pragma unroll 1
+    for (int c = 0; c < nb; c++) {
+        const double d = Ld[c][c];
+        if (!(d > 0)) { if (blockIdx.x == 0 && tid == 0) *status = 1; return; } // uniform
+        const double r = sqrt(d);
+        __syncthreads();
+        if (tid == c) Ld[c][c] = r;
+        else if (tid > c && tid < nb) Ld[tid][c] = Ld[tid][c] / r;
+        __syncthreads();
+#pragma unroll 1
+        for (int e = tid; e < CB * CB; e += CP_T) { const int i = e / CB, k = e % CB; if (k > c && k <= i && i < nb) Ld[i][k] -= Ld[i][c] * Ld[k][c]; }
+        __syncthreads();
     }
+    if (tid < CB) rdiag[tid] = tid < nb ? 1.0 / Ld[tid][tid] : 1.0;
+    if (blockIdx.x == 0) for (int e = tid; e < CB * CB; e += CP_T) Dg[(long)(jb / CB) * CB * CB + e] = Ld[e / CB][e % CB];
     __syncthreads();
-    if (s_fail) { if (blockIdx.x == 0 && tid == 0) *status = 1; return; }
-    if (blockIdx.x == 0) for (int e = tid; e < CB * CB; e += 256) Dg[(long)(jb / CB) * CB * CB + e] = Ld[e / CB][e % CB];
-    const int i = jb + nb + blockIdx.x * 256 + tid; // this thread's row of the panel: x L^T = a
+    const int i = jb + nb + blockIdx.x * CP_T + tid; // this thread's row of the panel: x L^T = a, right-looking
     if (i >= n) return;
-    double x[CB];
     double *row = A + (long)i * n + jb;
-#pragma unroll
-    for (int c = 0; c < CB; c++) x[c] = c < nb ? row[c] : 0.0;
-    // right-looking: once x_t is final every later column takes its share at once (independent FMAs instead of one chain per column);
-    // the pivot divisions are multiplications by the reciprocals wave 0 left in LDS
-#pragma unroll
-    for (int t = 0; t < CB; t++) {
-        x[t] = x[t] * rdiag[t];
-#pragma unroll
-        for (int c = t + 1; c < CB; c++) x[c] -= x[t] * Ld[c][t];
-        __builtin_amdgcn_sched_barrier(0); // without it the scheduler hoists all 496 LDS reads and spills 600 registers
+#pragma unroll 1
+    for (int c = 0; c < nb; c++) xs[c][tid] = row[c];
+#pragma unroll 1
+    for (int t = 0; t < nb; t++) {
+        const double xt = xs[t][tid] * rdiag[t];
+        row[t] = xt;
+#pragma unroll 1
+        for (int c = t + 1; c < nb; c++) xs[c][tid] -= xt * Ld[c][t];
     }
-#pragma unroll
-    for (int c = 0; c < CB; c++) if (c < nb) row[c] = x[c];
 }
 // trailing update: tile (ti, tk), tk <= ti, of the rows / columns behind the panel: A_ik -= P_i P_k^T
 __global__ void __launch_bounds__(256) badyn_chol_update(int n, int jb, double *A) {
@@ -336,7 +316,10 @@ int dyn_build(cs_ctx *ctx, cs_ba_dyn *b) { // BlockSolver::buildSystem: zero, th
     CS_HIP(ctx, hipMemsetAsync(G.bp, 0, sizeof(double) * std::max(G.NP, 1), ctx->stream));
     CS_HIP(ctx, hipMemsetAsync(G.Hll, 0, sizeof(double) * std::max<size_t>((size_t)G.L * 9, 1), ctx->stream));
     CS_HIP(ctx, hipMemsetAsync(G.bl, 0, sizeof(double) * std::max<size_t>((size_t)G.L * 3, 1), ctx->stream));
-    if (b->n_edges) CS_LAUNCH(ctx, "badyn_linearize", badyn_linearize, dim3((b->n_edges + 63) / 64), dim3(64), 0, G, b->n_edges);
+    const int n_rest = b->n_edges - G.n_obs - G.n_dobs; // motion, camera-object, point-object, local-point edges: few, numeric Jacobians
+    if (G.n_obs) CS_LAUNCH(ctx, "badyn_linearize", badyn_linearize<0>, dim3((G.n_obs + 63) / 64), dim3(64), 0, G, 0, G.n_obs);
+    if (G.n_dobs) CS_LAUNCH(ctx, "badyn_linearize_dyn", badyn_linearize<1>, dim3((G.n_dobs + 63) / 64), dim3(64), 0, G, G.n_obs, G.n_dobs);
+    if (n_rest) CS_LAUNCH(ctx, "badyn_linearize_num", badyn_linearize<-1>, dim3((n_rest + 63) / 64), dim3(64), 0, G, G.n_obs + G.n_dobs, n_rest);
     return CS_OK;
 }
 int dyn_reduce(cs_ctx *ctx, cs_ba_dyn *b, double lambda) { // Schur complement of the marginalised points
@@ -364,7 +347,7 @@ int dyn_solve(cs_ctx *ctx, cs_ba_dyn *b, double lambda) { // BlockSolver::solve:
             const int n = G.NP;
             for (int jb = 0; jb < n; jb += CB) {
                 const int nb = std::min(CB, n - jb), m = n - jb - nb; // rows behind the panel
-                CS_LAUNCH(ctx, "badyn_chol_panel", badyn_chol_panel, dim3(std::max(1, (m + 255) / 256)), dim3(256), 0, n, jb, G.S, b->d_Dg, b->d_status);
+                CS_LAUNCH(ctx, "badyn_chol_panel", badyn_chol_panel, dim3(std::max(1, (m + CP_T - 1) / CP_T)), dim3(CP_T), 0, n, jb, G.S, b->d_Dg, b->d_status);
                 if (m > 0) { const int T = (m + CB - 1) / CB; CS_LAUNCH(ctx, "badyn_chol_update", badyn_chol_update, dim3(T, T), dim3(256), 0, n, jb, G.S); }
             }
             CS_LAUNCH(ctx, "badyn_chol_tri", badyn_chol_tri, dim3(1), dim3(1024), sizeof(double) * ((size_t)n + CB * (CB + 1)), n, G.S, b->d_Dg, G.xp);

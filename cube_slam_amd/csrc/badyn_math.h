@@ -187,31 +187,44 @@ HD void dyn_lin_init(DynLin &E, int nv, int D) {
     E.nv = nv; E.D = D; E.delta = 0;
     for (int v = 0; v < 3; v++) { E.off[v] = -1; E.dim[v] = 0; E.lm[v] = -1; E.slot[v] = -1; }
 }
-HD void dyn_add_edge(const DynG &G, const DynLin &E) {
+template <int NV, int D> HD void dyn_add_edge(const DynG &G, const DynLin &E) { // vertex count and residual dimension at compile time: everything unrolls, E stays in registers
     double rw = 1.0;
-    if (E.delta > 0) { double rho[3]; huber(dyn_chi2(E.e, E.w, E.D), E.delta, rho); rw = rho[1]; }
-    double omr[4], W[4];
-    for (int k = 0; k < E.D; k++) { omr[k] = -E.w[k] * E.e[k] * rw; W[k] = rw * E.w[k]; }
-    for (int i = 0; i < E.nv; i++) {
-        if (E.off[i] < 0 && E.lm[i] < 0) continue;
-        for (int a = 0; a < E.dim[i]; a++) {
-            double g = 0;
-            for (int k = 0; k < E.D; k++) g += E.J[i][k * 6 + a] * omr[k];
-            if (E.lm[i] >= 0) BD_ATOMIC_ADD(G.bl + (long)E.lm[i] * 3 + a, g); else BD_ATOMIC_ADD(G.bp + E.off[i] + a, g);
+    if (E.delta > 0) { double rho[3]; huber(dyn_chi2(E.e, E.w, D), E.delta, rho); rw = rho[1]; }
+    double omr[D], W[D];
+#pragma unroll
+    for (int k = 0; k < D; k++) { omr[k] = -E.w[k] * E.e[k] * rw; W[k] = rw * E.w[k]; }
+#pragma unroll
+    for (int i = 0; i < NV; i++) {
+        const bool free_i = E.off[i] >= 0 || E.lm[i] >= 0;
+#pragma unroll
+        for (int a = 0; a < 6; a++) {
+            if (free_i && a < E.dim[i]) {
+                double g = 0;
+#pragma unroll
+                for (int k = 0; k < D; k++) g += E.J[i][k * 6 + a] * omr[k];
+                if (E.lm[i] >= 0) BD_ATOMIC_ADD(G.bl + (long)E.lm[i] * 3 + a, g); else BD_ATOMIC_ADD(G.bp + E.off[i] + a, g);
+            }
         }
-        for (int j = i; j < E.nv; j++) {
-            if (E.off[j] < 0 && E.lm[j] < 0) continue;
-            for (int a = 0; a < E.dim[i]; a++)
-                for (int c = 0; c < E.dim[j]; c++) {
-                    double h = 0;
-                    for (int k = 0; k < E.D; k++) h += (E.J[i][k * 6 + a] * W[k]) * E.J[j][k * 6 + c];
-                    if (E.lm[i] >= 0) BD_ATOMIC_ADD(G.Hll + (long)E.lm[i] * 9 + a * 3 + c, h);              // landmark x landmark (i == j)
-                    else if (E.lm[j] >= 0) G.Bslot[(long)E.slot[i] * 18 + a * 3 + c] = h;                     // pose rows x landmark columns: own slot
-                    else {
-                        BD_ATOMIC_ADD(G.Hpp + (long)(E.off[i] + a) * G.NP + E.off[j] + c, h);
-                        if (i != j) BD_ATOMIC_ADD(G.Hpp + (long)(E.off[j] + c) * G.NP + E.off[i] + a, h);
+#pragma unroll
+        for (int j = 0; j < NV; j++) {
+            const bool free_j = j >= i && (E.off[j] >= 0 || E.lm[j] >= 0); // upper triangle of the edge's vertex pairs
+#pragma unroll
+            for (int a = 0; a < 6; a++) {
+#pragma unroll
+                for (int c = 0; c < 6; c++) {
+                    if (free_i && free_j && a < E.dim[i] && c < E.dim[j]) {
+                        double h = 0;
+#pragma unroll
+                        for (int k = 0; k < D; k++) h += (E.J[i][k * 6 + a] * W[k]) * E.J[j][k * 6 + c];
+                        if (E.lm[i] >= 0) BD_ATOMIC_ADD(G.Hll + (long)E.lm[i] * 9 + a * 3 + c, h);              // landmark x landmark (i == j)
+                        else if (E.lm[j] >= 0) G.Bslot[(long)E.slot[i] * 18 + a * 3 + c] = h;                     // pose rows x landmark columns: own slot
+                        else {
+                            BD_ATOMIC_ADD(G.Hpp + (long)(E.off[i] + a) * G.NP + E.off[j] + c, h);
+                            if (i != j) BD_ATOMIC_ADD(G.Hpp + (long)(E.off[j] + c) * G.NP + E.off[i] + a, h);
+                        }
                     }
                 }
+            }
         }
     }
 }
@@ -221,10 +234,11 @@ HD void dyn_reproj_cam_jac(double X, double Y, double Z, double fx, double fy, d
     J[6] = (1 + Y * Y / Z2) * fy; J[7] = -X * Y / Z2 * fy; J[8] = -X / Z * fy; J[9] = 0; J[10] = -1. / Z * fy; J[11] = Y / Z2 * fy;
 }
 
-// linearizeOplus + constructQuadraticForm of one active edge (BlockSolver::buildSystem block_solver.hpp:502-560)
-HD void dyn_lin_item(const DynG &G, int e) {
+// linearizeOplus + constructQuadraticForm of one active edge (BlockSolver::buildSystem block_solver.hpp:502-560).  ONLY >= 0 compiles the
+// body of that edge class alone (the kernels launch the two big classes separately: the generic body needs 256 VGPRs plus scratch).
+template <int ONLY> HD void dyn_lin_item(const DynG &G, int e) {
     int o;
-    const int cls = dyn_edge_class(G, e, o);
+    const int cls = ONLY >= 0 ? (dyn_edge_class(G, e, o), ONLY) : dyn_edge_class(G, e, o);
     const double delta = 1e-9, scalar = 1.0 / (2 * delta);
     DynLin E;
     if (cls == 0) {
@@ -252,8 +266,10 @@ HD void dyn_lin_item(const DynG &G, int e) {
         }
         dyn_reproj_cam_jac(X, Y, Z, fx, fy, Jc);
         if (st) { Jc[12] = Jc[0] - G.bf * Y / Z2; Jc[13] = Jc[1] + G.bf * X / Z2; Jc[14] = Jc[2]; Jc[15] = Jc[3]; Jc[16] = 0; Jc[17] = Jc[5] - G.bf / Z2; }
-        for (int k = 0; k < E.D; k++) { E.e[k] = G.e_obs[(long)o * 3 + k]; E.w[k] = G.o_w[o]; }
+        for (int k = 0; k < 3; k++) { E.e[k] = G.e_obs[(long)o * 3 + k]; E.w[k] = G.o_w[o]; } // the third residual of a monocular edge is stored as 0
         E.delta = st ? G.huber_stereo : G.huber_mono;
+        if (!st) { for (int c = 0; c < 6; c++) Jc[12 + c] = 0; for (int c = 0; c < 3; c++) Jp[12 + c] = 0; } // a zero third row adds exact zeros
+        dyn_add_edge<2, 3>(G, E);
     } else if (cls == 1) { // EdgeDynamicPointCuboidCamera::linearizeOplus g2o_Object.cpp:167-233
         if (dyn_lvl(G.d_lvl, o)) return;
         const int ci = G.d_cam[o], oi = G.d_obj[o], li = G.d_pt[o];
@@ -278,6 +294,7 @@ HD void dyn_lin_item(const DynG &G, int e) {
         if (fl & 2) { Jo[0] = 0; Jo[1] = 0; Jo[6] = 0; Jo[7] = 0; Jo[2] = 0; Jo[8] = 0; }    // whether_fixrotation
         for (int k = 0; k < 2; k++) { E.e[k] = G.e_dobs[(long)o * 2 + k]; E.w[k] = G.d_w[o]; }
         E.delta = G.huber_dyn;
+        dyn_add_edge<3, 2>(G, E);
     } else if (cls == 2) { // EdgeObjectMotion: numeric, three vertices
         const int a = G.m_from[o], b = G.m_to[o], vi = G.m_vel[o];
         dyn_lin_init(E, 3, 3);
@@ -301,6 +318,7 @@ HD void dyn_lin_item(const DynG &G, int e) {
             for (int k = 0; k < 3; k++) E.J[2][k * 6 + d] = scalar * (e1[k] - e2[k]);
         }
         for (int k = 0; k < 3; k++) { E.e[k] = G.e_mot[(long)o * 3 + k]; E.w[k] = G.mot_info[k]; }
+        dyn_add_edge<3, 3>(G, E);
     } else if (cls == 3) { // EdgeSE3CuboidFixScaleProj: numeric, camera and object
         if (dyn_lvl(G.c_lvl, o)) return;
         const int ci = G.c_cam[o], oi = G.c_obj[o];
@@ -321,6 +339,7 @@ HD void dyn_lin_item(const DynG &G, int e) {
         }
         for (int k = 0; k < 4; k++) { E.e[k] = G.e_cobs[(long)o * 4 + k]; E.w[k] = G.c_info[(long)o * 4 + k]; }
         E.delta = G.huber_obj;
+        dyn_add_edge<2, 4>(G, E);
     } else if (cls == 4) { // EdgePointCuboidOnlyObjectFixScale: numeric unary
         const int oi = G.pc_obj[o];
         dyn_lin_init(E, 1, 3);
@@ -333,6 +352,7 @@ HD void dyn_lin_item(const DynG &G, int e) {
             for (int k = 0; k < 3; k++) E.J[0][k * 6 + d] = scalar * (e1[k] - e2[k]);
         }
         for (int k = 0; k < 3; k++) { E.e[k] = G.e_pc[(long)o * 3 + k]; E.w[k] = 1.0; }
+        dyn_add_edge<1, 3>(G, E);
     } else { // UnaryLocalPoint: numeric unary on the dynamic point
         if (G.fix_points) return;
         dyn_lin_init(E, 1, 3);
@@ -346,8 +366,8 @@ HD void dyn_lin_item(const DynG &G, int e) {
             for (int k = 0; k < 3; k++) E.J[0][k * 6 + d] = scalar * (e1[k] - e2[k]);
         }
         for (int k = 0; k < 3; k++) { E.e[k] = G.e_ulp[(long)o * 3 + k]; E.w[k] = G.ulp_info; }
+        dyn_add_edge<1, 3>(G, E);
     }
-    dyn_add_edge(G, E);
 }
 
 // ---------------------------------------------------------------------------------------------------- Schur complement, back substitution, update

@@ -61,7 +61,7 @@ struct Host {
     }
     double errors() { double chi = 0; for (int e2 = 0; e2 < n_edges; e2++) chi += dyn_error_item(G, e2); return chi; }
     void reduce(double lambda) {
-        for (int e2 = 0; e2 < n_edges; e2++) dyn_lin_item(G, e2);
+        for (int e2 = 0; e2 < n_edges; e2++) dyn_lin_item<-1>(G, e2);
         for (int i = 0; i < G.NP; i++) { for (int j = 0; j < G.NP; j++) S[(size_t)i * G.NP + j] = Hpp[(size_t)i * G.NP + j] + (i == j ? lambda : 0.0); bs[i] = bp[i]; }
         for (int l = 0; l < G.L; l++) dyn_dinv_item(G, l, lambda);
         for (int sl = 0; sl < X.n_slots; sl++) dyn_bd_item(G, sl);
