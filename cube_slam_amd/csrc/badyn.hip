@@ -11,9 +11,9 @@
 //                     slot, one wave per 6x6 target block summing over the slot pairs the host listed for it, one thread per reduced
 //                     right-hand-side row (a first version with fp64 atomics from a thread per landmark took 21 ms on 2 200 landmarks:
 //                     all landmarks of a camera pair hit the same 36 words)
-//   badyn_chol_panel / badyn_chol_update / badyn_chol_tri   blocked right-looking Cholesky of S (32 columns per step: every workgroup
-//                     factors the 32x32 pivot block in LDS and solves its rows of the panel, then 32x32 tiles of the trailing matrix are
-//                     updated by independent workgroups), then one workgroup for both triangular solves (a single-workgroup
+//   badyn_chol_diag / badyn_chol_panel / badyn_chol_update / badyn_chol_tri   blocked right-looking Cholesky of S (32 columns per step:
+//                     one workgroup factors the 32x32 pivot block in LDS, the rows of the panel are solved against it one per thread, then
+//                     32x32 tiles of the trailing matrix are updated by independent workgroups), then one workgroup for both triangular solves (a single-workgroup
 //                     column-by-column version -- badyn_chol_solve, CUBESLAM_BADYN_CHOL=simple -- took 26 ms at 840 unknowns: every
 //                     trailing update waits for its own global load)
 //   badyn_backsub     thread per landmark, badyn_update thread per vertex (oplus), badyn_diag gathers diag(H) for computeLambdaInit
@@ -143,33 +143,39 @@ __global__ void __launch_bounds__(1024) badyn_chol_solve(int n, double *A, doubl
 // ---- blocked Cholesky: A (n x n row-major, lower triangle) -> strictly-lower panels in place, pivot blocks in Dg (one 32x32 row-major
 // block per step, the upper part zero).
 constexpr int CB = 32;
-constexpr int CP_T = 128; // rows (= threads) per panel workgroup
-__global__ void __launch_bounds__(CP_T) badyn_chol_panel(int n, int jb, double *A, double *Dg, int *status) {
+// pivot block: one workgroup, one thread per element, three barriers per column (as a redundant prologue of every panel workgroup, 128
+// threads looping over the elements, this took 60 us per step: the panel kernel's whole duration)
+__global__ void __launch_bounds__(CB * CB) badyn_chol_diag(int n, int jb, const double *A, double *Dg, double *rd, int *status) {
     __shared__ double Ld[CB][CB + 1];
-    __shared__ double xs[CB][CP_T]; // the thread's panel row, column-major so that neighbouring threads hit neighbouring banks
-    __shared__ double rdiag[CB];
-    const int tid = threadIdx.x, nb = min(CB, n - jb);
-    for (int e = tid; e < CB * CB; e += CP_T) { const int r = e / CB, c = e % CB; Ld[r][c] = (r < nb && c <= r) ? A[(long)(jb + r) * n + jb + c] : 0.0; }
+    const int tid = threadIdx.x, i = tid / CB, k = tid % CB, nb = min(CB, n - jb);
+    Ld[i][k] = (i < nb && k <= i) ? A[(long)(jb + i) * n + jb + k] : (i == k ? 1.0 : 0.0); // a ragged last block is padded with the identity
     __syncthreads();
-    // every workgroup factors the pivot block itself, in LDS (loops stay rolled: an unrolled register version of this kernel spilled 620
-    // VGPRs and took 68 us per panel)
 #pragma unroll 1
-    for (int c = 0; c < nb; c++) {
+    for (int c = 0; c < CB; c++) {
         const double d = Ld[c][c];
-        if (!(d > 0)) { if (blockIdx.x == 0 && tid == 0) *status = 1; return; } // uniform
+        if (!(d > 0)) { if (tid == 0) *status = 1; return; } // uniform
         const double r = sqrt(d);
         __syncthreads();
-        if (tid == c) Ld[c][c] = r;
-        else if (tid > c && tid < nb) Ld[tid][c] = Ld[tid][c] / r;
+        if (k == c && i >= c) Ld[i][c] = (i == c) ? r : Ld[i][c] / r;
         __syncthreads();
-#pragma unroll 1
-        for (int e = tid; e < CB * CB; e += CP_T) { const int i = e / CB, k = e % CB; if (k > c && k <= i && i < nb) Ld[i][k] -= Ld[i][c] * Ld[k][c]; }
+        if (k > c && k <= i) Ld[i][k] -= Ld[i][c] * Ld[k][c];
         __syncthreads();
     }
-    if (tid < CB) rdiag[tid] = tid < nb ? 1.0 / Ld[tid][tid] : 1.0;
-    if (blockIdx.x == 0) for (int e = tid; e < CB * CB; e += CP_T) Dg[(long)(jb / CB) * CB * CB + e] = Ld[e / CB][e % CB];
+    Dg[(long)(jb / CB) * CB * CB + tid] = k <= i ? Ld[i][k] : 0.0;
+    if (tid < CB) rd[(jb / CB) * CB + tid] = 1.0 / Ld[tid][tid];
+}
+constexpr int CP_T = 128; // rows (= threads) per panel workgroup
+// the rows behind the pivot block: x L^T = a, right-looking, the thread's row in an LDS column (rolled loops: an unrolled register version
+// spilled 620 VGPRs)
+__global__ void __launch_bounds__(CP_T) badyn_chol_panel(int n, int jb, double *A, const double *Dg, const double *rd) {
+    __shared__ double Ld[CB][CB + 1];
+    __shared__ double xs[CB][CP_T];
+    __shared__ double rdiag[CB];
+    const int tid = threadIdx.x, nb = min(CB, n - jb);
+    for (int e = tid; e < CB * CB; e += CP_T) Ld[e / CB][e % CB] = Dg[(long)(jb / CB) * CB * CB + e];
+    if (tid < CB) rdiag[tid] = rd[(jb / CB) * CB + tid];
     __syncthreads();
-    const int i = jb + nb + blockIdx.x * CP_T + tid; // this thread's row of the panel: x L^T = a, right-looking
+    const int i = jb + nb + blockIdx.x * CP_T + tid;
     if (i >= n) return;
     double *row = A + (long)i * n + jb;
 #pragma unroll 1
@@ -275,7 +281,7 @@ struct cs_ba_dyn {
     DynG G;
     std::vector<void *> bufs;
     int n_edges = 0, n_vertices = 0, max_part = 0, n_slots = 0, simple_chol = 0;
-    double *d_Dg = nullptr;
+    double *d_Dg = nullptr, *d_rd = nullptr;
     size_t state_doubles = 0;
     double *d_state = nullptr, *d_bak = nullptr, *d_partials = nullptr, *d_diag = nullptr;
     int *d_status = nullptr;
@@ -347,7 +353,8 @@ int dyn_solve(cs_ctx *ctx, cs_ba_dyn *b, double lambda) { // BlockSolver::solve:
             const int n = G.NP;
             for (int jb = 0; jb < n; jb += CB) {
                 const int nb = std::min(CB, n - jb), m = n - jb - nb; // rows behind the panel
-                CS_LAUNCH(ctx, "badyn_chol_panel", badyn_chol_panel, dim3(std::max(1, (m + CP_T - 1) / CP_T)), dim3(CP_T), 0, n, jb, G.S, b->d_Dg, b->d_status);
+                CS_LAUNCH(ctx, "badyn_chol_diag", badyn_chol_diag, dim3(1), dim3(CB * CB), 0, n, jb, G.S, b->d_Dg, b->d_rd, b->d_status);
+                if (m > 0) CS_LAUNCH(ctx, "badyn_chol_panel", badyn_chol_panel, dim3((m + CP_T - 1) / CP_T), dim3(CP_T), 0, n, jb, G.S, b->d_Dg, b->d_rd);
                 if (m > 0) { const int T = (m + CB - 1) / CB; CS_LAUNCH(ctx, "badyn_chol_update", badyn_chol_update, dim3(T, T), dim3(256), 0, n, jb, G.S); }
             }
             CS_LAUNCH(ctx, "badyn_chol_tri", badyn_chol_tri, dim3(1), dim3(1024), sizeof(double) * ((size_t)n + CB * (CB + 1)), n, G.S, b->d_Dg, G.xp);
@@ -455,6 +462,7 @@ int cs_ba_dyn_create(cs_ctx *ctx, const cs_ba_dyn_problem *p, cs_ba_dyn **out) {
     D_(dyn_upload(ctx, b, &G.pair_t, X.pair_t.data(), X.pair_t.size())); D_(dyn_upload(ctx, b, &G.vtx_off, X.vtx_off.data(), X.vtx_off.size()));
     D_(dyn_upload(ctx, b, &G.vtx_start, X.vtx_start.data(), X.vtx_start.size())); D_(dyn_upload(ctx, b, &G.vtx_slots, X.vtx_slots.data(), X.vtx_slots.size()));
     D_(dyn_upload(ctx, b, &b->d_Dg, (const double *)nullptr, (size_t)((NP + CB - 1) / CB) * CB * CB));
+    D_(dyn_upload(ctx, b, &b->d_rd, (const double *)nullptr, (size_t)((NP + CB - 1) / CB) * CB));
     D_(dyn_upload(ctx, b, &b->d_partials, (const double *)nullptr, (size_t)b->max_part));
     D_(dyn_upload(ctx, b, &b->d_diag, (const double *)nullptr, (size_t)NP + 3 * (size_t)G.L));
     D_(dyn_upload(ctx, b, &b->d_status, (const int *)nullptr, 1));
