@@ -1,5 +1,6 @@
 """CPU tests of the drop-in boundary: the C-ABI library loads and exports every symbol include/*.h declares
 (no compute calls without a GPU), struct layouts match the Python mirrors, and there is no CPU fallback."""
+import numpy as np
 import ctypes as C
 import glob
 import os
@@ -77,3 +78,25 @@ def test_short_edge_threshold_without_sqrt():
     rng = np.random.default_rng(0)
     d2 = np.concatenate([rng.uniform(0, 800, 200000), 400.0 + rng.normal(0, 1e-12, 200000)])
     assert np.array_equal(np.sqrt(d2) < 20.0, d2 < T)
+
+
+def test_chamfer_code_number_theory():
+    """cuboid_sweep_score_lds (cuboid.hip) stores a chamfer value t = i*62587 + j*89738 (t * 2^-16 px) as the 16-bit code i | j << 8 and
+    recovers (i, j) from t with one float FMA, a 978-entry table and a verification.  The facts its encoder relies on: the 256 residues
+    j*89738 mod 62587 fall into distinct 64-wide buckets (they are >= 97 apart), floor(t / 62587) comes out right from
+    float(t) * float(1/62587) + 0.0005 for every representable pair, and i = floor(t/62587) - floor(j*89738/62587)."""
+    a, b = 62587, 89738
+    res = [(j * b) % a for j in range(256)]
+    assert len({r >> 6 for r in res}) == 256 and max(r >> 6 for r in res) < (a + 63) // 64
+    srt = sorted(res)
+    assert min(y - x for x, y in zip(srt, srt[1:])) >= 97 and srt[1] >= 97 and a - srt[-1] >= 97
+    I, J = np.meshgrid(np.arange(256), np.arange(256), indexing="ij")
+    t = I * a + J * b
+    ok = t < (1 << 24)  # the codes the encoder accepts: d < 256 px
+    tf = t.astype(np.float32)
+    qn = np.floor(tf.astype(np.float64) * np.float64(np.float32(1.0 / 62587.0)) + np.float64(np.float32(0.0005)))  # one rounding at most below the true FMA
+    qn32 = np.floor((tf * np.float32(1.0 / 62587.0)).astype(np.float32) + np.float32(0.0005))
+    assert np.array_equal(qn[ok], (t // a)[ok]) and np.array_equal(qn32[ok], (t // a)[ok])
+    assert np.array_equal((t // a - (J * b) // a)[ok], I[ok]) and ((J * b) // a).max() < 1 << 16
+    assert 255 * a + 255 * b >= 1 << 24, "the escape code (255, 255) decodes above every valid t"
+    assert np.array_equal((tf * np.float32(1.0 / 65536.0))[ok].astype(np.float64), t[ok] / 65536.0), "decode: float(t) * 2^-16 is exact"
