@@ -5,7 +5,8 @@
 //   cubeslam::ORBextractor      ORB_SLAM2::ORBextractor      (orb_object_slam/include/ORBextractor.h:44-112)
 //   cubeslam::line_lbd_detect   line_lbd_detect              (line_lbd/include/line_lbd/line_lbd_allclass.h:22-70)
 //   cubeslam::Optimizer         ORB_SLAM2::Optimizer         (orb_object_slam/include/Optimizer.h:39-62): BundleAdjustment over the
-//                               flattened graph (cs_ba_problem), PoseOptimization over flattened matches
+//                               flattened graph (cs_ba_problem), PoseOptimization over flattened matches,
+//                               LocalBACameraPointObjectsDynamic over the flattened dynamic graph (cs_ba_dyn_problem)
 #pragma once
 #include <cstdint>
 #include <stdexcept>
@@ -119,6 +120,50 @@ struct Optimizer {
         check(c.ctx, cs_pose_optimization(c.ctx, 1, off, Xw, obs, inv_sigma2, intr, pose_in, pose_out, mvbOutlier.data(), &n_inl), "cs_pose_optimization");
         mvbOutlier.resize((size_t)n);
         return n_inl;
+    }
+    // Optimizer::LocalBACameraPointObjectsDynamic (Optimizer.cc:2353-2415) on a graph the caller flattened from the map (:1684-2344):
+    // optimize(5); reprojection edges with chi2 > 5.991 / 7.815 or a non-positive depth and dynamic-point edges with chi2 > 8 go to level 1
+    // and all of them lose their kernel, camera-object edges with |error| > 80 go to level 1; optimize(10).  The estimates in `g` are
+    // updated in place; the returned levels are what :2418-2447 turns into vToErase.
+    struct DynamicGraph { // owns the arrays cs_ba_dyn_problem points into
+        cs_ba_dyn_problem P{};
+        std::vector<double> cam_pose, obj_pose, vel, points, dpoints;
+        std::vector<uint8_t> obs_level, dobs_level, cobs_level;
+        void bind() {
+            P.cam_pose = cam_pose.data(); P.obj_pose = obj_pose.data(); P.vel = vel.data(); P.points = points.data(); P.dpoints = dpoints.data();
+            P.obs_level = obs_level.data(); P.dobs_level = dobs_level.data(); P.cobs_level = cobs_level.data();
+        }
+    };
+    static void LocalBACameraPointObjectsDynamic(Context &c, DynamicGraph &g, const volatile int *pbStopFlag = nullptr, cs_ba_stats *st1 = nullptr, cs_ba_stats *st2 = nullptr) {
+        cs_ba_dyn_problem &P = g.P;
+        g.obs_level.resize((size_t)P.n_obs + 1, 0); g.dobs_level.resize((size_t)P.n_dobs + 1, 0); g.cobs_level.resize((size_t)P.n_cobs + 1, 0);
+        g.bind();
+        auto stage = [&](int iterations, cs_ba_stats *st, std::vector<double> &eo, std::vector<double> &ed, std::vector<double> &ec) {
+            cs_ba_dyn *ba = nullptr;
+            check(c.ctx, cs_ba_dyn_create(c.ctx, &P, &ba), "cs_ba_dyn_create");
+            int r = cs_ba_dyn_optimize(c.ctx, ba, iterations, pbStopFlag, st);
+            if (!r) r = cs_ba_dyn_read(c.ctx, ba, g.cam_pose.data(), g.obj_pose.data(), g.vel.data(), g.points.data(), g.dpoints.data());
+            eo.assign((size_t)P.n_obs * 3 + 1, 0.0); ed.assign((size_t)P.n_dobs * 2 + 1, 0.0); ec.assign((size_t)P.n_cobs * 4 + 1, 0.0);
+            if (!r) r = cs_ba_dyn_errors(c.ctx, ba, nullptr, eo.data(), ed.data(), nullptr, ec.data(), nullptr, nullptr);
+            cs_ba_dyn_destroy(c.ctx, ba);
+            check(c.ctx, r, "cs_ba_dyn stage");
+        };
+        std::vector<double> eo, ed, ec;
+        stage(5, st1, eo, ed, ec);
+        if (pbStopFlag && *pbStopFlag) return; // bDoMore = false
+        for (int o = 0; o < P.n_obs; o++) { // :2366-2394
+            const double *e = &eo[(size_t)o * 3], w = P.obs_inv_sigma2[o];
+            const bool stereo = P.obs_ur && P.obs_ur[o] >= 0;
+            const double chi2 = stereo ? ((e[0] * e[0] + e[1] * e[1]) + e[2] * e[2]) * w : (e[0] * e[0] + e[1] * e[1]) * w;
+            const double *T = &g.cam_pose[(size_t)P.obs_cam[o] * 7], *X = &g.points[(size_t)P.obs_point[o] * 3];
+            const double qx = T[3], qy = T[4], qz = T[5], qw = T[6]; // third row of R(q) times X plus t_z: isDepthPositive
+            const double z = (2 * (qx * qz - qy * qw)) * X[0] + (2 * (qy * qz + qx * qw)) * X[1] + (1 - 2 * (qx * qx + qy * qy)) * X[2] + T[2];
+            if (chi2 > (stereo ? 7.815 : 5.991) || !(z > 0)) g.obs_level[o] = 1;
+        }
+        for (int o = 0; o < P.n_dobs; o++) { const double *e = &ed[(size_t)o * 2]; if ((e[0] * e[0] + e[1] * e[1]) * P.dobs_inv_sigma2[o] > 8) g.dobs_level[o] = 1; } // :2396-2404
+        for (int o = 0; o < P.n_cobs; o++) { const double *e = &ec[(size_t)o * 4]; if (((e[0] * e[0] + e[1] * e[1]) + e[2] * e[2]) + e[3] * e[3] > 80.0 * 80.0) g.cobs_level[o] = 1; } // :2406-2411
+        P.huber_mono = P.huber_stereo = P.huber_dyn = 0; // setRobustKernel(0)
+        stage(10, st2, eo, ed, ec);
     }
 };
 

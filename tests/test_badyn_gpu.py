@@ -44,8 +44,8 @@ def test_optimize_matches_oracle(ctx, oracle, seed, kw):
     assert st["iterations"] == st_o["iterations"] and st["lm_trials"] == st_o["lm_trials"]
     assert np.isclose(st["chi2_init"], st_o["chi2_init"], rtol=1e-10) and _close(st["chi2_trace"], st_o["chi2_trace"]) and np.isclose(st["lambda_final"], st_o["lambda_final"], rtol=1e-4)
     assert st["chi2_final"] < 0.3 * st["chi2_init"]
-    for k in res_o:
-        assert _close(res[k], res_o[k]), k
+    for k in res_o:  # estimates: looser than chi2 -- atomics reorder the sums, weakly observed directions amplify it at equal chi2
+        assert _close(res[k], res_o[k], 1e-3), k
     chi, _ = ba.errors()
     assert np.isclose(chi, st["chi2_final"], rtol=1e-9), "the residuals on the device are those of the accepted state"
     ba.close()
@@ -66,7 +66,7 @@ def test_two_stage_local_ba(ctx, oracle):
     assert st1["iterations"] == s1["iterations"] and st2["iterations"] == s2["iterations"] and st2["lm_trials"] == s2["lm_trials"]
     assert _close(st2["chi2_trace"], s2["chi2_trace"])
     for k in r2:
-        assert _close(res[k], r2[k]), k
+        assert _close(res[k], r2[k], 1e-3), k
     err0 = np.abs(d["cam_pose"][:, :3] - d["cam_true"][:, :3]).max(); err2 = np.abs(res["cam_pose"][:, :3] - d["cam_true"][:, :3]).max()
     assert err2 < 0.5 * err0
 
