@@ -436,3 +436,21 @@ def ba_dyn_problem(seed, n_kf=12, n_points=400, n_objects=3, pts_per_obj=30, fix
         "pc_ratio": 2.0,
         "cam_true": cam_true, "obj_true": obj_true, "vel_true": vel_true, "points_true": pts, "dpoints_true": np.array(dpts).reshape(-1, 3),
     }
+
+
+def ba_dyn_strip(d, objects=True, dynamic=True, static=True):
+    """The window without its cars / dynamic points / static points (ragged and empty inputs)."""
+    d = dict(d)
+    if not static:
+        d["points"] = np.zeros((0, 3)); d["obs_cam"] = np.zeros(0, np.int32); d["obs_point"] = np.zeros(0, np.int32); d["obs_uv"] = np.zeros((0, 2))
+        d["obs_ur"] = np.zeros(0); d["obs_inv_sigma2"] = np.zeros(0); d["obs_level"] = np.zeros(0, np.uint8)
+    if not dynamic or not objects:
+        d["dpoints"] = np.zeros((0, 3)); d["dobs_cam"] = np.zeros(0, np.int32); d["dobs_obj"] = np.zeros(0, np.int32); d["dobs_point"] = np.zeros(0, np.int32)
+        d["dobs_uv"] = np.zeros((0, 2)); d["dobs_inv_sigma2"] = np.zeros(0); d["dobs_level"] = np.zeros(0, np.uint8)
+    if not objects:
+        d["obj_pose"] = np.zeros((0, 7)); d["obj_scale"] = np.zeros((0, 3)); d["obj_flags"] = np.zeros(0, np.uint8); d["vel"] = np.zeros((0, 2))
+        for k in ("mot_from", "mot_to", "mot_vel", "cobs_cam", "cobs_obj", "pc_obj"):
+            d[k] = np.zeros(0, np.int32)
+        d["mot_dt"] = np.zeros(0); d["cobs_bbox"] = np.zeros((0, 4)); d["cobs_info"] = np.zeros((0, 4)); d["cobs_level"] = np.zeros(0, np.uint8)
+        d["pc_offsets"] = np.zeros(1, np.int32); d["pc_points"] = np.zeros((0, 3))
+    return d

@@ -76,3 +76,22 @@ def test_rejects_bad_graph(ctx):
     d["dobs_obj"] = d["dobs_obj"].copy(); d["dobs_obj"][0] = len(d["obj_pose"])
     with pytest.raises(RuntimeError):
         DynamicBundleAdjuster(d, ctx=ctx)
+
+
+@pytest.mark.parametrize("kw", [dict(objects=False), dict(dynamic=False), dict(static=False), dict(static=False, dynamic=False)])
+def test_empty_edge_classes(ctx, oracle, kw):
+    """Windows without cars (a plain local BA), without dynamic points, without static points: empty arrays on every class."""
+    d = synth.ba_dyn_strip(synth.ba_dyn_problem(23, n_kf=6, n_points=80, n_objects=2, pts_per_obj=10), **kw)
+    ba = DynamicBundleAdjuster(d, ctx=ctx)
+    chi, _ = ba.errors()
+    assert np.isclose(chi, oracle.badyn_errors(d)[0], rtol=1e-10)
+    H, b = ba.reduced_dense(1e-2)
+    H_o, b_o = oracle.badyn_reduced_dense(d, 1e-2)
+    assert H.shape == H_o.shape and np.abs(H - H_o).max() <= 1e-8 * np.abs(H_o).max() and np.abs(b - b_o).max() <= 1e-8 * max(np.abs(b_o).max(), 1e-300)
+    st = ba.optimize(4)
+    res = ba.read()
+    res_o, st_o = oracle.badyn_optimize(d, 4)
+    assert st["iterations"] == st_o["iterations"] and _close(st["chi2_trace"], st_o["chi2_trace"])
+    for k in res_o:
+        assert res[k].shape == res_o[k].shape and _close(res[k], res_o[k], 1e-3), k
+    ba.close()

@@ -71,3 +71,21 @@ def test_items_second_stage(items, oracle):
     chi_o, _ = oracle.badyn_errors(d2)
     H_o, b_o = oracle.badyn_reduced_dense(d2, 1e-2)
     assert np.isclose(chi, chi_o, rtol=1e-12) and np.abs(S - H_o).max() <= 1e-9 * np.abs(H_o).max() and np.abs(bs - b_o).max() <= 1e-9 * np.abs(b_o).max()
+
+
+@pytest.mark.parametrize("kw", [dict(objects=False), dict(dynamic=False), dict(static=False), dict(static=False, dynamic=False)])
+def test_items_empty_classes(items, oracle, kw):
+    """Windows without cars (a static local BA), without dynamic points, without static points: every edge class may be empty."""
+    d = synth.ba_dyn_strip(synth.ba_dyn_problem(23, n_kf=6, n_points=80, n_objects=2, pts_per_obj=10), **kw)
+    chi_o, _ = oracle.badyn_errors(d)
+    chi, errs, S, bs = _reduced(items, d, 1e-2)
+    H_o, b_o = oracle.badyn_reduced_dense(d, 1e-2)
+    assert np.isclose(chi, chi_o, rtol=1e-12) and S.shape == H_o.shape and S.shape[0] > 0
+    assert np.abs(S - H_o).max() <= 1e-9 * np.abs(H_o).max() and np.abs(bs - b_o).max() <= 1e-9 * max(np.abs(b_o).max(), 1e-300)
+    rc, st = _step(items, d, 1e-2)
+    so, rco = oracle.badyn_step(d, 1e-2)
+    assert rc == rco == 0
+    for k in st:
+        assert st[k].shape == so[k].shape and np.allclose(st[k], so[k], rtol=1e-8, atol=1e-9), k
+    res, stt = oracle.badyn_optimize(d, 4)
+    assert stt["chi2_final"] < stt["chi2_init"]
