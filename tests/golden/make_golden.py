@@ -7,6 +7,13 @@
   output for this demo (it only draws it), so this pins the oracle against regressions, not against the reference:
   parity stays "unpinned" (DESIGN.md).
 * cuboid_synth.npz    : oracle outputs for seeded synthetic scenes (regression vectors for CPU + GPU tests).
+* object_slam_seq.npz : the reference's bundled TUM-cabinet sequence (object_slam/data: 58 frames, YOLO boxes, pop_cam_poses_saved.txt) with
+  the ONE set of expected outputs the reference ships for this path: detect_cuboids_saved.txt, the author's offline (MATLAB) detections
+  `frame x y z yaw l w h err` that object_slam consumes when online_detect_mode is off (main_obj.cpp:475-497).  The C++ detector "differs
+  slightly from MATLAB due to different canny edge and distance transform" (detect_3d_cuboid/README.md), so this is a LOOSE pin of the whole
+  chain (BGR2GRAY -> LSD + length filter -> Canny / chamfer map -> proposal sweep -> scoring -> selection -> 3-D box) against an independent
+  implementation by the reference's author, not a bit-level one: the oracle's best cuboid per frame is stored next to the saved rows
+  (tests/test_cuboid_oracle.py checks their agreement), and four frames are stored as images so that the oracle is re-run in the test.
 """
 import os
 import sys
@@ -75,7 +82,46 @@ def lines_cabinet():
     print("lines_cabinet:", len(kl), "lines")
 
 
+def object_slam_seq():
+    import math
+    from PIL import Image
+    base = os.path.join(REF, "object_slam/data")
+    K = np.array([[535.4, 0, 320.1], [0, 539.2, 247.6], [0, 0, 1.0]])  # main_obj.cpp:347-349
+    rows = np.loadtxt(os.path.join(base, "detect_cuboids_saved.txt")).reshape(-1, 9)
+    poses = np.loadtxt(os.path.join(base, "pop_cam_poses_saved.txt")).reshape(-1, 8)
+
+    def twc(p):  # `t x y z qx qy qz qw` -> 4x4 (g2o::SE3Quat(Vector7d) normalises the quaternion)
+        x, y, z, w = p[4:8] / np.linalg.norm(p[4:8])
+        T = np.eye(4)
+        T[:3, :3] = [[1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)], [2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)],
+                     [2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)]]
+        T[:3, 3] = p[1:4]
+        return T
+    opts = dict(whether_sample_bbox_height=0, nominal_skew_ratio=2.0, max_cuboid_num=1)  # main_obj.cpp:359-360
+    keep = {0, 4, 20, 40}
+    ours, boxes, Twcs, grays, n_lines = [], [], [], {}, []
+    for r, row in enumerate(rows):
+        f = int(row[0])
+        rgb = np.asarray(Image.open(os.path.join(base, "raw_imgs/%04d_rgb_raw.jpg" % f)).convert("RGB"))
+        gray = po.bgr2gray(np.ascontiguousarray(rgb[:, :, ::-1]))
+        lines = po.lsd_detect_filter_lines(gray, 15.0)  # line_lbd_obj.use_LSD = true, line_length_thres = 15 (:364-366)
+        box = np.loadtxt(os.path.join(base, "filter_2d_obj_txts/%04d_yolo2_0.15.txt" % f)).reshape(-1, 5)[:1].copy()
+        box[:, :2] -= 1  # MATLAB -> C++ coordinates (:441)
+        T = twc(poses[f])
+        res, _ = po.detect_cuboid(gray, K, T, box, lines, opts=po.cuboid_opts(**opts), debug=True)
+        c = res[0][0] if len(res[0]) else None
+        ours.append([np.nan] * 8 if c is None else [*c["pos"], c["rotY"], *c["scale"], c["normalized_error"]])
+        boxes.append(box[0]); Twcs.append(T); n_lines.append(len(lines))
+        if r in keep:
+            grays[r] = gray
+    np.savez_compressed(os.path.join(HERE, "object_slam_seq.npz"), K=K, matlab_rows=rows, ours=np.array(ours), boxes=np.array(boxes), Twc=np.array(Twcs),
+                        n_lines=np.array(n_lines), kept=np.array(sorted(keep)), **{"gray_%d" % r: g for r, g in grays.items()})
+    o = np.array(ours)
+    print("object_slam_seq: %d rows, median position difference %.3f m" % (len(rows), np.nanmedian(np.linalg.norm(o[:, :3] - rows[:, 1:4], axis=1))))
+
+
 if __name__ == "__main__":
+    object_slam_seq()
     cuboid_ref()
     cuboid_synth()
     orb_cabinet()

@@ -153,3 +153,31 @@ def test_stateful_yaw_quirk_is_isolated(oracle):
     b, _ = oracle.detect_cuboid(s["gray"], s["K"], s["Twc"], s["boxes"], s["lines"], opts=oracle.cuboid_opts(stateful_cam_pose=1))
     for x, y in zip(a, b):
         assert x.tobytes() == y.tobytes()
+
+
+def test_agrees_with_the_authors_saved_detections(oracle):
+    """The one set of expected outputs the reference ships for this path: object_slam/data/detect_cuboids_saved.txt, the author's offline
+    (MATLAB) detections for the bundled 58-frame sequence (`frame x y z yaw l w h err`, consumed by main_obj.cpp:475-497 when
+    online_detect_mode is off).  The C++ detector "differs slightly from MATLAB due to different canny edge and distance transform"
+    (detect_3d_cuboid/README.md), so this is a loose pin -- but of the whole chain (BGR2GRAY, LSD + length filter, Canny, chamfer map,
+    proposal sweep, scoring, selection, 3-D box) against an independent implementation: the oracle's best cuboid per frame
+    (tests/golden/make_golden.py::object_slam_seq, same boxes / poses / options as main_obj.cpp:347-366,:441) lands on the author's."""
+    g = np.load(os.path.join(GOLD, "object_slam_seq.npz"))
+    rows, ours = g["matlab_rows"], g["ours"]
+    assert len(rows) == 51 and not np.isnan(ours).any(), "a cuboid on every frame the author has one for"
+    pos_err = np.linalg.norm(ours[:, :3] - rows[:, 1:4], axis=1)
+    assert np.median(pos_err) < 0.05 and np.percentile(pos_err, 80) < 0.12 and pos_err.max() < 0.30, "centres: 3 cm median on a 0.9 x 0.6 x 0.5 m cabinet 1-2 m away"
+    dyaw = np.abs((ours[:, 3] - rows[:, 4] + np.pi / 2) % np.pi - np.pi / 2)  # a box is the same box after half a turn
+    assert (dyaw < 0.006).mean() > 0.5 and (dyaw <= 0.11).mean() > 0.8, "same sample of the 6-degree yaw grid on most frames, a neighbour on most others"
+    sc_err = np.abs(ours[:, 4:7] - rows[:, 5:8]).max(axis=1)
+    assert np.median(sc_err) < 0.05 and np.percentile(sc_err, 80) < 0.10, "half extents"
+    assert np.abs(ours[:, 2] - ours[:, 6]).max() < 1e-9, "the box stands on the ground plane: centre height = half height"
+    # the stored frames re-run through today's oracle give the stored results (ties the fixture to the code under test)
+    for r in g["kept"]:
+        gray = g["gray_%d" % r]
+        lines = oracle.lsd_detect_filter_lines(gray, 15.0)
+        assert len(lines) == g["n_lines"][r]
+        res, _ = oracle.detect_cuboid(gray, g["K"], g["Twc"][r], g["boxes"][r][None], lines,
+                                      opts=oracle.cuboid_opts(whether_sample_bbox_height=0, nominal_skew_ratio=2.0, max_cuboid_num=1), debug=True)
+        c = res[0][0]
+        assert np.array_equal(np.array([*c["pos"], c["rotY"], *c["scale"], c["normalized_error"]]), ours[r])
