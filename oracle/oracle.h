@@ -11,7 +11,10 @@
  * cannot be compiled in this environment (needs OpenCV/Eigen/ROS, all absent),
  * see DESIGN.md "Oracle".  Third-party semantics (OpenCV imgproc/features2d,
  * Eigen) are restated from their published algorithms; every function cites
- * the reference file:line it follows.
+ * the reference file:line it follows.  The only expected outputs the
+ * reference ships (object_slam/data/detect_cuboids_saved.txt, the author's
+ * offline MATLAB detections for the bundled sequence) pin the line + cuboid
+ * chain loosely, not bit for bit: tests/test_cuboid_oracle.py, DESIGN.md 3.
  */
 #ifndef CUBESLAM_ORACLE_H
 #define CUBESLAM_ORACLE_H
