@@ -74,8 +74,12 @@ int main(int argc, char **argv) {
             P.huber_obj = q[25]; P.pc_ratio = q[26];
             cs_ba_stats s1, s2;
             cubeslam::Optimizer::LocalBACameraPointObjectsDynamic(ctx, g, nullptr, &s1, &s2);
-            printf("dynba %d %d %.12g %.12g %llx %llx %llx\n", s1.iterations, s2.iterations, s1.chi2_final, s2.chi2_final, fnv(g.obs_level.data(), (size_t)P.n_obs),
-                   fnv(g.dobs_level.data(), (size_t)P.n_dobs), fnv(g.cobs_level.data(), (size_t)P.n_cobs));
+            long n1[3] = {0, 0, 0};
+            for (int o = 0; o < P.n_obs; o++) n1[0] += g.obs_level[o];
+            for (int o = 0; o < P.n_dobs; o++) n1[1] += g.dobs_level[o];
+            for (int o = 0; o < P.n_cobs; o++) n1[2] += g.cobs_level[o];
+            printf("dynba %d %d %.12g %.12g %llx %llx %llx %ld %ld %ld\n", s1.iterations, s2.iterations, s1.chi2_final, s2.chi2_final, fnv(g.obs_level.data(), (size_t)P.n_obs),
+                   fnv(g.dobs_level.data(), (size_t)P.n_dobs), fnv(g.cobs_level.data(), (size_t)P.n_cobs), n1[0], n1[1], n1[2]);
             printf("dynpose %.12g %.12g %.12g %.12g\n", g.cam_pose[(size_t)(P.n_cams - 1) * 7], g.obj_pose[0], g.vel[0], g.dpoints[0]);
         }
     } catch (const std::exception &e) { fprintf(stderr, "%s\n", e.what()); return 1; }
