@@ -104,3 +104,26 @@ def test_golden_orb_cabinet(oracle):
     assert len(k) == int(g["n"])
     assert hashlib.sha256(k.tobytes()).hexdigest() == str(g["kp_sha"]) and hashlib.sha256(d.tobytes()).hexdigest() == str(g["desc_sha"])
     assert np.array_equal(k[:16], g["kp_head"]) and np.array_equal(d[:16], g["desc_head"])
+
+
+def test_bit_pattern_is_the_references_table():
+    """The 256 x 4 BRIEF test-point table is data the reference embeds (ORBextractor.cc:152-410); both the oracle and the HIP kernel include a
+    generated copy (tools/gen_orb_pattern.py).  Where the reference tree is mounted (the build container), check both copies number by
+    number against the source; everywhere, that the two copies are the same file."""
+    import os
+    import re
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    a = open(os.path.join(root, "oracle", "orb_pattern.inc")).read()
+    b = open(os.path.join(root, "cube_slam_amd", "csrc", "orb_pattern.inc")).read()
+    assert a == b
+    nums = [int(x) for x in re.findall(r"-?\d+", re.sub(r"//.*", "", a))]
+    assert len(nums) == 1024 and max(abs(v) for v in nums) <= 15, "points inside the 31 x 31 patch"
+    ref = "/root/reference/orb_object_slam/src/ORBextractor.cc"
+    if os.path.exists(ref):
+        src = open(ref).read()
+        i = src.index("static int bit_pattern_31_")
+        body = src[src.index("{", i) + 1: src.index("};", i)]
+        body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+        body = re.sub(r"//.*", "", body)
+        assert [int(x) for x in re.findall(r"-?\d+", body)] == nums
