@@ -7,6 +7,7 @@
   output for this demo (it only draws it), so this pins the oracle against regressions, not against the reference:
   parity stays "unpinned" (DESIGN.md).
 * cuboid_synth.npz    : oracle outputs for seeded synthetic scenes (regression vectors for CPU + GPU tests).
+* badyn_synth.npz     : the dynamic-object BA oracle on one seeded window (chi2 trace, estimates, reduced system): regression vector.
 * object_slam_seq.npz : the reference's bundled TUM-cabinet sequence (object_slam/data: 58 frames, YOLO boxes, pop_cam_poses_saved.txt) with
   the ONE set of expected outputs the reference ships for this path: detect_cuboids_saved.txt, the author's offline (MATLAB) detections
   `frame x y z yaw l w h err` that object_slam consumes when online_detect_mode is off (main_obj.cpp:475-497).  The C++ detector "differs
@@ -120,7 +121,18 @@ def object_slam_seq():
     print("object_slam_seq: %d rows, median position difference %.3f m" % (len(rows), np.nanmedian(np.linalg.norm(o[:, :3] - rows[:, 1:4], axis=1))))
 
 
+def badyn_synth():
+    """Regression vector of the dynamic-object BA oracle: chi2 trace and a digest of the estimates for one seeded window."""
+    d = synth.ba_dyn_problem(101, n_kf=8, n_points=150, n_objects=2, pts_per_obj=14)
+    res, st = po.badyn_optimize(d, 6)
+    H, b = po.badyn_reduced_dense(d, 1e-3)
+    np.savez_compressed(os.path.join(HERE, "badyn_synth.npz"), chi2_init=st["chi2_init"], chi2_trace=np.array(st["chi2_trace"]), lm_trials=st["lm_trials"],
+                        cam_pose=res["cam_pose"], obj_pose=res["obj_pose"], vel=res["vel"], H_diag=np.diag(H).copy(), b=b)
+    print("badyn_synth: chi2", st["chi2_init"], "->", st["chi2_final"])
+
+
 if __name__ == "__main__":
+    badyn_synth()
     object_slam_seq()
     cuboid_ref()
     cuboid_synth()

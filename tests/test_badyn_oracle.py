@@ -172,3 +172,17 @@ def test_two_stage_optimisation(oracle):
     err0 = np.abs(d["cam_pose"][:, :3] - d["cam_true"][:, :3]).max(); err2 = np.abs(res2["cam_pose"][:, :3] - d["cam_true"][:, :3]).max()
     assert err2 < 0.5 * err0
     assert np.abs(res2["vel"][:, 0] - d["vel_true"][:, 0]).max() < np.abs(d["vel"][:, 0] - d["vel_true"][:, 0]).max()
+
+
+def test_golden_window(oracle):
+    """Regression vector (tests/golden/make_golden.py::badyn_synth): the oracle's LM trace, estimates and reduced system for one seeded window."""
+    import os
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "badyn_synth.npz"))
+    d = synth.ba_dyn_problem(101, n_kf=8, n_points=150, n_objects=2, pts_per_obj=14)
+    res, st = oracle.badyn_optimize(d, 6)
+    assert st["lm_trials"] == int(g["lm_trials"]) and np.isclose(st["chi2_init"], float(g["chi2_init"]), rtol=1e-12)
+    assert np.allclose(st["chi2_trace"], g["chi2_trace"], rtol=1e-9)
+    for k in ("cam_pose", "obj_pose", "vel"):
+        assert np.allclose(res[k], g[k], rtol=1e-8, atol=1e-10), k
+    H, b = oracle.badyn_reduced_dense(d, 1e-3)
+    assert np.allclose(np.diag(H), g["H_diag"], rtol=1e-10) and np.allclose(b, g["b"], rtol=1e-9, atol=1e-9)
