@@ -1,4 +1,5 @@
-"""GPU parity of the dynamic-object bundle adjustment (cs_ba_dyn_*, cube_slam_amd/csrc/badyn.hip) against the oracle (oracle/badyn_oracle.cpp):
+"""(Runs late on purpose -- file name -- so that `pytest -x` reaches every bit-exact path first: this is the one engine with run-dependent low bits.)
+GPU parity of the dynamic-object bundle adjustment (cs_ba_dyn_*, cube_slam_amd/csrc/badyn.hip) against the oracle (oracle/badyn_oracle.cpp):
 residuals bit-for-bit up to libm, the reduced pose system, the LM trace of optimize() and the two-stage flow of
 Optimizer::LocalBACameraPointObjectsDynamic (Optimizer.cc:2353-2415).  Tolerance: 1e-5 relative on chi2 / residuals / estimates (BASELINE
 north_star's floating-point bar); the fp64 atomics reorder sums, so bit-equality is not expected beyond the residuals."""
