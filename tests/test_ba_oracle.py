@@ -211,3 +211,26 @@ def test_reduced_system_is_additive_over_landmark_shards(oracle):
         assert np.allclose(Hs, H, rtol=1e-10, atol=1e-8 * np.abs(H).max()) and np.allclose(bs, b, rtol=1e-10, atol=1e-8 * np.abs(b).max())
     w = np.linalg.eigvalsh(H)
     assert w.min() > 0, "damped reduced camera system is positive definite"
+
+
+def test_se3_exp_against_matrix_exponential(oracle):
+    """SE3Quat::exp (se3quat.h:272-306, restated in oracle/se3_util.h and used by every vertex update) is the matrix exponential of the 4x4
+    twist [[skew(omega), upsilon], [0, 0]]: checked against scipy.linalg.expm through VertexCuboid::oplusImpl on an identity pose
+    (pose * exp(update), g2o_Object.cpp:58-64), including the small-angle branch (theta < 1e-5)."""
+    from scipy.linalg import expm
+    rng = np.random.default_rng(0)
+    upd = np.zeros((6, 9))
+    upd[:4, :6] = rng.normal(0, 0.7, (4, 6))
+    upd[4, :6] = [3e-6, -2e-6, 1e-6, 0.4, -0.2, 0.1]      # small-angle branch
+    upd[5, :6] = [0, 0, 3.0, 1.0, 2.0, 3.0]                # close to half a turn about z
+    cub = np.tile(np.array([0, 0, 0, 0, 0, 0, 1.0, 1.0, 1.0, 1.0]), (6, 1))
+    out = oracle.cuboid9_oplus(cub, upd)
+    for u, o in zip(upd, out):
+        w, v = u[:3], u[3:6]
+        X = np.zeros((4, 4)); X[:3, :3] = [[0, -w[2], w[1]], [w[2], 0, -w[0]], [-w[1], w[0], 0]]; X[:3, 3] = v
+        T = expm(X)
+        x, y, z, qw = o[3:7]
+        R = np.array([[1 - 2 * (y * y + z * z), 2 * (x * y - z * qw), 2 * (x * z + y * qw)], [2 * (x * y + z * qw), 1 - 2 * (x * x + z * z), 2 * (y * z - x * qw)],
+                      [2 * (x * z - y * qw), 2 * (y * z + x * qw), 1 - 2 * (x * x + y * y)]])
+        assert np.allclose(R, T[:3, :3], atol=1e-10) and np.allclose(o[:3], T[:3, 3], atol=1e-10)
+        assert qw >= 0 and abs(x * x + y * y + z * z + qw * qw - 1) < 1e-12, "normalizeRotation: unit quaternion with w >= 0"
