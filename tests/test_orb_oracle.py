@@ -127,3 +127,62 @@ def test_bit_pattern_is_the_references_table():
         body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
         body = re.sub(r"//.*", "", body)
         assert [int(x) for x in re.findall(r"-?\d+", body)] == nums
+
+
+def test_pyramid_and_blur_against_float_restatements(oracle):
+    """Independent float restatements of the two image operators ORBextractor::ComputePyramid / operator() lean on (ORBextractor.cc:1101-1130,
+    :1069): cv::resize INTER_LINEAR (pixel centres: src = (dst + 0.5) * scale - 0.5, border replicated) from one level to the next, and
+    GaussianBlur 7x7 sigma 2 BORDER_REFLECT_101 (scipy's mirror mode).  The oracle's fixed-point arithmetic must stay within a grey level or
+    two of them everywhere."""
+    from scipy.ndimage import gaussian_filter
+    e = oracle.ORBextractor(500, 1.2, 4, 20, 7)
+    tex = synth.texture_image(5, 320, 240)
+    e(tex)
+
+    def resize_float(src, h, w):
+        sy, sx = src.shape[0] / h, src.shape[1] / w
+        fy = np.clip((np.arange(h) + 0.5) * sy - 0.5, 0, src.shape[0] - 1); fx = np.clip((np.arange(w) + 0.5) * sx - 0.5, 0, src.shape[1] - 1)
+        y0 = np.floor(fy).astype(int); x0 = np.floor(fx).astype(int)
+        y1 = np.minimum(y0 + 1, src.shape[0] - 1); x1 = np.minimum(x0 + 1, src.shape[1] - 1)
+        wy = (fy - y0)[:, None]; wx = (fx - x0)[None, :]
+        s = src.astype(np.float64)
+        return (s[y0][:, x0] * (1 - wx) + s[y0][:, x1] * wx) * (1 - wy) + (s[y1][:, x0] * (1 - wx) + s[y1][:, x1] * wx) * wy
+    for l in range(1, 4):
+        prev, cur = e.level(l - 1), e.level(l)
+        ref = resize_float(prev, *cur.shape)
+        assert np.abs(cur.astype(np.float64) - ref).max() <= 1.0 + 1e-9, l
+    bl = e.level(0, blurred=True).astype(np.float64)
+    ref = gaussian_filter(tex.astype(np.float64), sigma=2.0, truncate=1.5, mode="mirror")  # radius 3: the 7-tap kernel
+    assert np.abs(bl - ref).max() <= 2.5 and abs((bl - ref).mean()) < 1.2
+
+
+def test_orientation_and_descriptor_against_numpy_restatement(oracle):
+    """IC_Angle (ORBextractor.cc:74-104: intensity centroid over the circular patch, rows bounded by umax) and computeOrbDescriptor
+    (:107-149: the 256 test pairs rotated by the keypoint angle in float, cvRound, compared on the blurred level) restated in numpy for the
+    level-0 keypoints of a textured image: angles agree to fastAtan2's 0.3 degrees, descriptors bit for bit."""
+    import re
+    e = oracle.ORBextractor(500, 1.2, 4, 20, 7)
+    tex = synth.texture_image(7, 320, 240)
+    k, d = e(tex)
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    pat = np.array([int(x) for x in re.findall(r"-?\d+", re.sub(r"//.*", "", open(os.path.join(root, "oracle", "orb_pattern.inc")).read()))], np.float32).reshape(512, 2)
+    umax = [15, 15, 15, 15, 14, 14, 14, 13, 13, 12, 11, 10, 9, 8, 6, 3]  # the table the constructor builds for HALF_PATCH_SIZE 15 (:433-452)
+    img = e.level(0).astype(np.int64); bl = e.level(0, blurred=True)
+    sel = np.nonzero(k["octave"] == 0)[0]
+    assert len(sel) > 100
+    for i in sel:
+        x, y = int(round(float(k["x"][i]))), int(round(float(k["y"][i])))
+        m10 = m01 = 0
+        for v in range(-15, 16):
+            u = umax[abs(v)]
+            row = img[y + v, x - u:x + u + 1]
+            m10 += int((np.arange(-u, u + 1) * row).sum()); m01 += int(v * row.sum())
+        ang = np.degrees(np.arctan2(float(m01), float(m10))) % 360.0
+        assert abs((ang - float(k["angle"][i]) + 180) % 360 - 180) < 0.35
+        a32 = np.float32(k["angle"][i]) * np.float32(np.pi / 180.0)
+        a = np.float32(np.cos(np.float64(a32))); b = np.float32(np.sin(np.float64(a32)))
+        rx = np.rint((pat[:, 0] * a).astype(np.float32) - (pat[:, 1] * b).astype(np.float32)).astype(int)  # cvRound = round half to even
+        ry = np.rint((pat[:, 0] * b).astype(np.float32) + (pat[:, 1] * a).astype(np.float32)).astype(int)
+        vals = bl[y + ry, x + rx].astype(int)
+        bits = (vals[0::2] < vals[1::2]).astype(np.uint8)
+        assert np.array_equal(np.packbits(bits.reshape(32, 8)[:, ::-1], axis=1).reshape(32), d[i])
