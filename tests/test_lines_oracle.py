@@ -120,3 +120,22 @@ def test_golden_lines_cabinet(oracle):
     assert hashlib.sha256(kl.tobytes()).hexdigest() == str(ref["keylines_sha256"])
     assert np.array_equal(desc, ref["desc"])
     assert np.array_equal(oracle.lsd_detect_filter_lines(g, 15.0), ref["filter15"])
+
+
+def test_maps_against_scipy_restatements(oracle):
+    """Independent restatements of the image operators under the line path: the LBD Sobel maps (cv::Sobel ksize 3 on the 5x5 sigma-1 blurred
+    image, BORDER_REFLECT_101, binary_descriptor.cpp:620-640) equal scipy's correlation bit for bit and the blur stays within ~2 grey levels
+    of a float Gaussian; LSD's gradient (lsd.cpp ll_angle: 2x2 differences, norm / 2) follows its definition to round-off on the scaled image."""
+    from scipy.ndimage import correlate, gaussian_filter
+    from cube_slam_amd import synth
+    g = synth.texture_image(9, 200, 160)
+    b, dx, dy = oracle.lbd_maps(g)
+    assert np.abs(b.astype(float) - gaussian_filter(g.astype(np.float64), sigma=1.0, truncate=2.0, mode="mirror")).max() < 2.6
+    kx = np.array([[-1, 0, 1], [-2, 0, 2], [-1, 0, 1]])
+    assert np.array_equal(correlate(b.astype(np.int32), kx, mode="mirror"), dx.astype(np.int32))
+    assert np.array_equal(correlate(b.astype(np.int32), kx.T, mode="mirror"), dy.astype(np.int32))
+    sc, mg, an, order = oracle.lsd_maps(g)
+    assert sc.shape == (128, 160), "0.8 x the image (lsd.cpp scale)"
+    A, B, Cc, D = sc[:-1, :-1], sc[:-1, 1:], sc[1:, :-1], sc[1:, 1:]
+    gx = (B + D) - (A + Cc); gy = (Cc + D) - (A + B)
+    assert np.allclose(mg[:-1, :-1], np.sqrt((gx * gx + gy * gy) / 4.0), rtol=0, atol=1e-11)
