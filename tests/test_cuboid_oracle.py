@@ -181,3 +181,54 @@ def test_agrees_with_the_authors_saved_detections(oracle):
                                       opts=oracle.cuboid_opts(whether_sample_bbox_height=0, nominal_skew_ratio=2.0, max_cuboid_num=1), debug=True)
         c = res[0][0]
         assert np.array_equal(np.array([*c["pos"], c["rotY"], *c["scale"], c["normalized_error"]]), ours[r])
+
+
+def _canny_numpy(img, low, high):
+    """cv::Canny(aperture 3, L2gradient=false), OpenCV 3.x semantics, from its documentation / published algorithm."""
+    H, W = img.shape
+    p = np.pad(img.astype(np.int32), 1, mode="edge")  # BORDER_REPLICATE
+    dx = (p[:-2, 2:] + 2 * p[1:-1, 2:] + p[2:, 2:]) - (p[:-2, :-2] + 2 * p[1:-1, :-2] + p[2:, :-2])
+    dy = (p[2:, :-2] + 2 * p[2:, 1:-1] + p[2:, 2:]) - (p[:-2, :-2] + 2 * p[:-2, 1:-1] + p[:-2, 2:])
+    mag = np.abs(dx) + np.abs(dy)
+    mp = np.pad(mag, 1)  # magnitudes outside the image are zero
+    TG22 = int(0.4142135623730950488016887242097 * (1 << 15) + 0.5)
+    state = np.ones((H, W), np.uint8)  # 1 = not an edge, 0 = weak candidate, 2 = strong
+    for i in range(H):
+        for j in range(W):
+            m = mag[i, j]
+            if m <= low:
+                continue
+            x, y = abs(int(dx[i, j])), abs(int(dy[i, j])) << 15
+            t22 = x * TG22
+            I, J = i + 1, j + 1
+            if y < t22:
+                ok = m > mp[I, J - 1] and m >= mp[I, J + 1]
+            else:
+                t67 = t22 + (x << 16)
+                if y > t67:
+                    ok = m > mp[I - 1, J] and m >= mp[I + 1, J]
+                else:
+                    s = -1 if (int(dx[i, j]) ^ int(dy[i, j])) < 0 else 1
+                    ok = m > mp[I - 1, J - s] and m > mp[I + 1, J + s]
+            if ok:
+                state[i, j] = 2 if m > high else 0
+    out = state == 2
+    stack = list(zip(*np.nonzero(out)))
+    while stack:
+        i, j = stack.pop()
+        for di in (-1, 0, 1):
+            for dj in (-1, 0, 1):
+                a, b = i + di, j + dj
+                if 0 <= a < H and 0 <= b < W and state[a, b] == 0 and not out[a, b]:
+                    out[a, b] = True; stack.append((a, b))
+    return out.astype(np.uint8) * 255
+
+
+def test_canny_against_numpy_restatement(oracle):
+    """cv::Canny (aperture 3, L1 magnitude, the integer tangent tests of the non-maximum suppression, 8-connected hysteresis) written out
+    in numpy from the published algorithm: the oracle's edge map is the same set of pixels on a scene crop and on a noisy texture."""
+    crops = [synth.cuboid_scene(3, n_boxes=2)["gray"][100:260, 150:370].copy(), synth.texture_image(4, 120, 90)]
+    for g, (lo, hi) in zip(crops, ((80, 200), (60, 150))):
+        ours = np.asarray(oracle.canny_roi(g, 0, 0, g.shape[1], g.shape[0], lo, hi)) > 0
+        ref = _canny_numpy(g, lo, hi) > 0
+        assert ref.sum() > 100 and np.array_equal(ours, ref)
