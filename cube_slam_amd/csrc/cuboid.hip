@@ -33,6 +33,22 @@ constexpr int DT_INIT = INT_MAX >> 2;
 constexpr int DT_HV = 62587;    // cvRound(0.955f * 65536)
 constexpr int DT_DIAG = 89738;  // cvRound(1.3693f * 65536)  (checked against the float product on the host at create())
 constexpr double PI = 3.14159265358979323846;
+// cuboid_sweep_score (LDS-resident code map), see the kernel
+constexpr int SC_T = 512;                                             // threads per workgroup: 2 waves per SIMD, up to 256 VGPRs each
+constexpr int SC_LDS_BYTES = 160 * 1024;
+constexpr int SC_LUT_N = (DT_HV + 63) / 64;                            // 978 residue buckets
+constexpr int SC_MAP_OFF = 32;                                        // control words in front of the map
+constexpr int SC_MAP_ENTRIES = (SC_LDS_BYTES - SC_MAP_OFF) / 2;        // 80 920
+constexpr float SC_ESC_D = 244.0f;                                     // d < 244 => i <= 255 and j <= 178
+constexpr int SC_COST_PX_NUM = 3, SC_COST_TASK1 = 1700, SC_COST_TASK2 = 1350; // wave-instructions: map copy per 64 pixels / task of 64 proposals
+constexpr int SC_BIG_P = 32;                                          // proposals per work item of cuboid_sweep_score_big
+constexpr int SC_PFB = 16;                                            // 16-byte loads per thread in flight while a map is copied
+constexpr int K_VIS1[9][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 0}, {1, 5}, {2, 4}, {3, 7}, {4, 7}, {4, 5}};
+constexpr int K_VIS2[7][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 0}, {1, 5}, {2, 4}, {4, 5}};
+constexpr int K_VPE1[3][4] = {{0, 1, 7, 4}, {3, 0, 4, 5}, {3, 7, 1, 5}};
+constexpr int K_VPE2[3][4] = {{0, 1, 2, 3}, {3, 0, 4, 5}, {2, 4, 1, 5}};
+__host__ __device__ inline bool score_unit_fits(int roi_w, int roi_h) { return (long)roi_w * roi_h + roi_w + 2 <= (long)SC_MAP_ENTRIES; }
+
 
 struct Calib { double K[9]; double invK[9]; };
 
@@ -91,6 +107,36 @@ __device__ __forceinline__ double normalize_to_pi(double a) { // matrix_utils.cp
     if (a > PI / 2) return a - PI;
     else if (a < -PI / 2) return a + PI;
     else return a;
+}
+// normalize_to_pi(atan2(dy, dx)) (matrix_utils.cpp:326-335) to within 1e-16: the level-line angle of an edge in (-pi/2, pi/2].  One
+// division, a degree-10 polynomial in z^2 on |z| <= tan(pi/8) (argument reduction (mn - mx) / (mn + mx)), ~45 instructions against the 105
+// of the library atan2.  The sign at an exactly vertical edge (+-pi/2) is irrelevant to the callers (min(t, pi - t)).
+__device__ __forceinline__ double line_angle_fast(double dy, double dx) {
+    const double ax = fabs(dx), ay = fabs(dy);
+    const double mx = fmax(ax, ay), mn = fmin(ax, ay);
+    const bool big = mn > 0.41421356237309503 * mx;
+    const double num = big ? mn - mx : mn;
+    const double den = fmax(big ? mn + mx : mx, 1e-300);
+    double r = __builtin_amdgcn_rcp(den);
+    r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);
+    r = __builtin_fma(__builtin_fma(-den, r, 1.0), r, r);
+    double z = num * r;
+    z = __builtin_fma(__builtin_fma(-den, z, num), r, z);
+    const double w = z * z;
+    double p = 0.021135373157693246;
+    p = __builtin_fma(p, w, -0.04348052215716462);
+    p = __builtin_fma(p, w, 0.056883492268090106);
+    p = __builtin_fma(p, w, -0.06640233930429408);
+    p = __builtin_fma(p, w, 0.07689953496306857);
+    p = __builtin_fma(p, w, -0.09090773074808414);
+    p = __builtin_fma(p, w, 0.11111106180455946);
+    p = __builtin_fma(p, w, -0.14285714180976467);
+    p = __builtin_fma(p, w, 0.1999999999885511);
+    p = __builtin_fma(p, w, -0.3333333333332844);
+    double th = __builtin_fma(z * w, p, z);
+    th = big ? th + PI / 4 : th;
+    th = ay > ax ? PI / 2 - th : th;
+    return ((dx < 0) != (dy < 0)) ? -th : th;
 }
 __device__ __forceinline__ double dist2(V2 a, V2 b) { double dx = a.x - b.x, dy = a.y - b.y; return sqrt(dx * dx + dy * dy); }
 __device__ __forceinline__ bool inside_box(V2 p, double l, double t, double r, double b) {
@@ -827,81 +873,6 @@ __device__ inline int make_corners(const Unit &U, const VPEntry &E, int top_x, i
     return vp_1_position;
 }
 
-// box_edge_sum_dists (object_3d_util.cpp:427-453) + box_edge_alignment_angle_error (:455-492) of one proposal whose corners sit
-// in this thread's LDS column sc[k*256] (k = 0..7 x, 8..15 y; image coordinates).  Edges are a real loop (corner indices from the
-// constant tables, uniform per workgroup), the 11 samples of an edge are unrolled: ~50 live registers instead of ~220 when the
-// compiler unrolls all 99 samples, which is what lets 8 waves per SIMD hide the gather latency.
-//  * sample point = s/10*p1 + (1-s/10)*p2 in double, operation order of the reference; dist_map.at<float>(int(y),int(x)) has no
-//    bounds check and corners may sit on x==w / y==h: flat index clamped to the buffer;
-//  * float accumulation in edge/sample order; the cfg-2 weights `dist*3.0/2.0` and `dist*2.0` (float -> double -> float) equal
-//    the float products dist*1.5f and dist*2.0f bit for bit (3*x and x/2 are exact in double, so both round 1.5*x once).
-// The end samples of an edge are its corners (s = 0: 0*p1 + 1*p2 = p2, s = 10: 1*p1 + 0*p2 = p1, exactly), and every corner ends
-// two or three edges: the 8 corner pixels are fetched once (scp, the thread's LDS column of floats) and only the 9 interior
-// samples of an edge are gathered.
-template <int CFG> __device__ __forceinline__ void edge_gather(const double *sc, const float *scp, int e, const float *dm, int w, int last, double rx, double ry, float (&v)[11]) {
-    const int ia = CFG == 1 ? c_vis1[e][0] : c_vis2[e][0], ib = CFG == 1 ? c_vis1[e][1] : c_vis2[e][1];
-    const double x1 = sc[ia * 256] - rx, y1 = sc[(8 + ia) * 256] - ry, x2 = sc[ib * 256] - rx, y2 = sc[(8 + ib) * 256] - ry; // :423-425
-    v[0] = scp[ib * 256]; v[10] = scp[ia * 256];
-#pragma unroll
-    for (int si = 1; si < 10; si++) {
-        const double s = (double)si;
-        const double px = s / 10.0 * x1 + (1 - s / 10.0) * x2;
-        const double py = s / 10.0 * y1 + (1 - s / 10.0) * y2;
-        int idx = __mul24(int(py), w) + int(px);
-        idx = min(max(idx, 0), last);
-        v[si] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(dm) + ((unsigned)idx << 2));
-    }
-}
-template <int CFG> __device__ __forceinline__ float edge_weight(int e) { return (CFG == 2 && (e == 4 || e == 5)) ? 1.5f : ((CFG == 2 && e == 6) ? 2.0f : 1.0f); }
-// software-pipelined over edges: the 11 gathers of edge e+1 are in flight while the values of edge e are added
-template <int CFG> __device__ __forceinline__ float edge_sum_dists_lds(const double *sc, float *scp, const float *dm, int w, int last, double rx, double ry) {
-    constexpr int NE = CFG == 1 ? 9 : 7;
-    float sum_dist = 0;
-    float v[11];
-#pragma unroll
-    for (int k = 0; k < 8; k++) { // corner pixels (corners 6 and 7 are not on a visible edge of configuration 2)
-        if (CFG == 2 && k >= 6) break;
-        int idx = __mul24(int(sc[(8 + k) * 256] - ry), w) + int(sc[k * 256] - rx);
-        idx = min(max(idx, 0), last);
-        scp[k * 256] = *reinterpret_cast<const float *>(reinterpret_cast<const char *>(dm) + ((unsigned)idx << 2));
-    }
-    edge_gather<CFG>(sc, scp, 0, dm, w, last, rx, ry, v);
-#pragma unroll 1
-    for (int e = 1; e < NE; e++) {
-        float nv[11];
-        edge_gather<CFG>(sc, scp, e, dm, w, last, rx, ry, nv);
-        const float wgt = edge_weight<CFG>(e - 1);
-#pragma unroll
-        for (int si = 0; si < 11; si++) { float d = v[si]; if (CFG == 2) d = d * wgt; sum_dist = sum_dist + d; v[si] = nv[si]; }
-    }
-    const float wgt = edge_weight<CFG>(NE - 1);
-#pragma unroll
-    for (int si = 0; si < 11; si++) { float d = v[si]; if (CFG == 2) d = d * wgt; sum_dist = sum_dist + d; }
-    return sum_dist;
-}
-template <int CFG> __device__ __forceinline__ double edge_angle_error_lds(const VPEntry &E, const double *sc) {
-    double total = 0;
-    const double not_found_penalty = 30.0 / 180.0 * PI * 2;
-#pragma unroll 1
-    for (int vp = 0; vp < 3; vp++) {
-        const double a0 = E.ang[vp * 2], a1 = E.ang[vp * 2 + 1];
-        const bool v0 = !isnan(a0), v1 = !isnan(a1);
-        if (v0 || v1) {
-#pragma unroll 1
-            for (int ee = 0; ee < 2; ee++) {
-                const int a = CFG == 1 ? c_vpe1[vp][2 * ee] : c_vpe2[vp][2 * ee], b = CFG == 1 ? c_vpe1[vp][2 * ee + 1] : c_vpe2[vp][2 * ee + 1];
-                const double ang = normalize_to_pi(atan2(sc[(8 + b) * 256] - sc[(8 + a) * 256], sc[b * 256] - sc[a * 256]));
-                double best = 100;
-                if (v0) { double t = fabs(ang - a0); t = fmin(t, PI - t); if (t < best) best = t; }
-                if (v1) { double t = fabs(ang - a1); t = fmin(t, PI - t); if (t < best) best = t; }
-                total = total + best;
-            }
-        } else
-            total = total + not_found_penalty;
-    }
-    return total;
-}
-
 // hypothesis index h = ((rp*n_yaw + yaw)*n_tops + top)*2 + (cfg-1)   (the reference's loop nest :229-285)
 // SoA outputs over the global hypothesis index g = hyp_off + h:
 //   flag[g] u8: 0 rejected, 1/2 = vp_1_position; derr[g], aerr[g]; corners[p*hyp_total + g], p = 0..15 (x0..x7,y0..y7)
@@ -974,241 +945,383 @@ __global__ void __launch_bounds__(256) cuboid_sweep_corners(const Unit *units, i
     for (int s = threadIdx.x; s < c2; s += 256) d2[-s] = s_list[1][s];
 }
 
-// cuboid_sweep_score: the edge-scoring kernel.  One thread per surviving proposal: box_edge_sum_dists (99 / 77 distance-map
-// samples, float accumulation in the reference's order) and box_edge_alignment_angle_error.  SCORE_PB proposals per workgroup;
-// a unit's workgroups cover its configuration-1 list first, then its configuration-2 list.
-constexpr int SCORE_PB = 256;
-template <int CFG> __device__ __forceinline__ void score_one(const Unit &U, int h, const VPEntry *vpt, const float *dist, const double *corners, long hyp_total,
-                                                             double *sc, float *scp, double *derr, double *aerr) {
-    const long g = U.hyp_off + h;
-    const int q = (h >> 1) / U.n_tops;
-#pragma unroll
-    for (int k = 0; k < 16; k++) sc[k * 256] = corners[(long)k * hyp_total + g];
-    const float sum_dist = edge_sum_dists_lds<CFG>(sc, scp, dist + U.pix_off, U.roi_w, U.roi_w * U.roi_h - 1, (double)U.roi_x, (double)U.roi_y);
-    derr[g] = double(sum_dist) / U.diag; // :451
-    aerr[g] = edge_angle_error_lds<CFG>(vpt[(long)U.vp_off + q], sc);
-}
-__global__ void __launch_bounds__(256) cuboid_sweep_score(const Unit *units, int n_units, int blocks_per_unit, const VPEntry *vpt, const float *dist,
-                                                          const double *corners, long hyp_total, const int *vcount, const int *vlist, double *derr,
-                                                          double *aerr, int lds_px) {
-    __shared__ double s_c[16 * 256]; // the thread's proposal corners: column threadIdx.x, no sharing between threads
-    __shared__ float s_cp[8 * 256];  // distance-map values at the corners
-    double *sc = s_c + threadIdx.x;
-    float *scp = s_cp + threadIdx.x;
-    const int b = blockIdx.x;
-    const int xcd = b & 7, slot = b >> 3;
-    const int u = (slot / blocks_per_unit) * 8 + xcd;
-    int blk = slot % blocks_per_unit;
-    if (u >= n_units) return;
-    const int c1 = vcount[2 * u], c2 = vcount[2 * u + 1];
-    const int nb1 = (c1 + SCORE_PB - 1) / SCORE_PB;
-    const Unit &U = units[u];
-    if (U.roi_w * U.roi_h <= lds_px) return; // scored by cuboid_sweep_score_lds
-    if (blk < nb1) {
-        const int s = blk * SCORE_PB + threadIdx.x;
-        if (s < c1) score_one<1>(U, vlist[U.hyp_off + s], vpt, dist, corners, hyp_total, sc, scp, derr, aerr);
-    } else {
-        const int s = (blk - nb1) * SCORE_PB + threadIdx.x;
-        if (s < c2) score_one<2>(U, vlist[U.hyp_off + U.hyp_cap - 1 - s], vpt, dist, corners, hyp_total, sc, scp, derr, aerr);
-    }
-}
+// ---- cuboid_sweep_score: the edge-scoring kernel, with the unit's distance map resident in LDS ---------------------------------------------
+// Why LDS: the kernel is a gather kernel (41 M samples per bench launch at positions that differ from lane to lane); through global memory
+// every gathered lane costs the texture-address path about one CU-cycle (round 1: 103 us, TA_BUSY 80 %).  LDS serves 32 lanes per cycle.
+//
+// Representation (cuboid_dt_codes).  The chamfer values are t * 2^-16 with t = i*DT_HV + j*DT_DIAG (i straight and j diagonal steps of the
+// shortest path, unique for t < 2^24), so a pixel less than 244 px from the nearest edge (i <= 255, j <= 178) is exactly the 16-bit code
+// i | j << 8, and 80 920 codes fit one CU's 160 KB.  A unit with a pixel farther than that (an edge-free 244-px disc: never on real scenes)
+// or with a larger ROI is scored by cuboid_sweep_score_big from the float map.
+//   encode: t = d * 65536 exactly; qn = floor(t / HV) from one float FMA (the fractional part of t / HV is (j * DIAG mod HV) / HV: 0 or in
+//     [0.00155, 0.99845], a bias of 0.0005 absorbs the rounding); the residue q = t - qn * HV identifies j (the 256 residues j * DIAG mod
+//     HV are >= 97 apart: one per 64-wide bucket, tests/test_cabi.py) and code = qn + lut[q >> 6] with lut = (j << 8) - floor(j * DIAG /
+//     HV), because i = qn - floor(j * DIAG / HV).
+//   decode: d = fma(float(j), DIAG * 2^-16, float(i) * HV * 2^-16) -- the product is exact (< 2^24) and the fused sum rounds t once, like
+//     the distance transform's int -> float conversion: v_cvt_f32_ubyte0, v_cvt_f32_ubyte1, v_mul_f32, v_fma_f32.
+// One lane scores one proposal (the float sum of box_edge_sum_dists is a chain of 99 / 77 ordered additions, so a proposal cannot be
+// spread over lanes without paying for a transpose); corners live in registers, all samples are unrolled with constant corner indices.
+// D2 (unchecked dist_map.at on x == w / y == h) without a per-sample clamp: corners are inside the ROI inclusive, so the flat index is at
+// most w*h + w, and the w + 1 entries after the map repeat its last pixel -- the value the clamp of round 1 produced.
+//
+// Work distribution.  cuboid_score_plan lays every LDS unit on a cost line (copy cost ~ pixels, then one task per 64 proposals of one
+// configuration) and cuts the line into G equal segments; workgroup g (one per CU: the map takes the whole LDS) owns segment g, copies each
+// unit it touches once and lets its waves pull tasks from an LDS counter.  A unit cut by a segment border is copied by both neighbours;
+// odd segments run backwards so that both reach the shared unit at the same time and the second read hits the XCD's L2 (workgroup b runs
+// on XCD b % 8 and takes segment (b % 8) * G/8 + b / 8: neighbouring segments share an XCD).
+struct ScoreSeg { int unit, task; }; // segment border: task index inside the unit (0 .. number of tasks)
+__device__ long g_sc_dbg[4096 * 4]; // experiment: per-workgroup start / end clock, tasks, units (mode & 8)
+struct BigItem { int unit, cfg, first; };
 
-// ---- cuboid_sweep_score_lds: the same scores with the unit's distance map resident in LDS (CUBESLAM_SCORE=lds) ------------------------
-// The chamfer values are t * 2^-16 with t = i*DT_HV + j*DT_DIAG (i horizontal/vertical and j diagonal steps of the shortest path), so a
-// pixel with i, j < 256 is exactly the 16-bit code i | j << 8 and a 640x480 box ROI (<= SLDS_MAP_PX pixels) fits the 160 KB of one CU.
-// Encoding while the workgroup copies the map: t = d * 65536 (exact for d < 256), floor(t / HV) from one float FMA (the fractional part of
-// t / HV is (j * DIAG mod HV) / HV: 0 or in [0.00155, 0.99845], so a bias of 0.0005 absorbs the rounding), j from a 978-entry table indexed
-// by (t mod HV) >> 6 (the 256 residues j * DIAG mod HV are >= 97 apart: one per 64-wide bucket, checked in tests/test_cabi.py), i = floor(t /
-// HV) - floor(j * DIAG / HV); the pair is verified (i * HV + j * DIAG == t) and anything else -- d >= 256, maps without edges -- becomes the
-// escape code 0xFFFF = (255, 255), whose t is above 2^24: a proposal that touched one (max of the decoded t) is re-scored from the float map.
-// Persistent 512-thread workgroups (one per CU: the map takes the whole LDS) pull (unit, configuration, 1024-proposal chunk) items from a
-// device-built list; corners in registers (everything unrolled, constant corner indices); the gathers are
-// ds_read_u16 instead of 41 M texture-path lanes.  Units whose ROI does not fit stay with cuboid_sweep_score.
-constexpr int SLDS_T = 512;                                              // threads per workgroup: 2 waves per SIMD, 256 VGPRs each
-constexpr int SLDS_PW = 1024;                                            // proposals per work item (two per thread)
-constexpr int SLDS_LUT = (DT_HV + 63) / 64;                               // 978
-constexpr int SLDS_BYTES = 160 * 1024;
-constexpr int SLDS_MAP_PX = (SLDS_BYTES - SLDS_LUT * 4 - 16) / 2 & ~3;    // 79 956 pixels (16 bytes at the end: the work item broadcast)
-constexpr int K_VIS1[9][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 0}, {1, 5}, {2, 4}, {3, 7}, {4, 7}, {4, 5}};
-constexpr int K_VIS2[7][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 0}, {1, 5}, {2, 4}, {4, 5}};
-constexpr int K_VPE1[3][4] = {{0, 1, 7, 4}, {3, 0, 4, 5}, {3, 7, 1, 5}};
-constexpr int K_VPE2[3][4] = {{0, 1, 2, 3}, {3, 0, 4, 5}, {2, 4, 1, 5}};
+__device__ __forceinline__ int sc_tasks(int c) { return (c + 63) >> 6; }
+__device__ __forceinline__ bool sc_unit_lds(const Unit &U, const int *uflag, int u) { return score_unit_fits(U.roi_w, U.roi_h) && !(uflag[u] & 1); }
 
-__device__ __forceinline__ unsigned slds_encode(float d, const unsigned *lut) {
+__device__ __forceinline__ unsigned sc_encode(float d, const unsigned short *lut) {
     const float tf = d * 65536.0f;
     const int t = (int)tf;
-    const int qn = (int)__fmaf_rn(tf, 1.0f / (float)DT_HV, 0.0005f);
-    const int q = t - __mul24(qn, DT_HV);
-    const unsigned e = lut[min((unsigned)q >> 6, (unsigned)(SLDS_LUT - 1))];
-    const int j = (int)(e & 0xffu), i = qn - (int)(e >> 8);
-    const bool ok = d < 256.0f && (unsigned)i < 256u && __mul24(i, DT_HV) + __mul24(j, DT_DIAG) == t;
-    return ok ? (unsigned)(i | (j << 8)) : 0xffffu;
+    const int qn = (int)__builtin_fmaf(tf, 1.0f / (float)DT_HV, 0.0005f);
+    const unsigned q = (unsigned)(t - __mul24(qn, DT_HV));
+    const unsigned e = lut[min(q >> 6, (unsigned)(SC_LUT_N - 1))];
+    return d < SC_ESC_D ? (unsigned)qn + e : 0xffffu;
 }
-struct FetchLds {
-    const unsigned short *m; unsigned tmax;
-    __device__ __forceinline__ float operator()(int idx) {
-        const unsigned c = m[idx];
-        const unsigned t = __umul24(c & 0xffu, (unsigned)DT_HV) + __umul24(c >> 8, (unsigned)DT_DIAG);
-        tmax = max(tmax, t);
-        return (float)t * (1.f / 65536.f);
-    }
-};
-struct FetchGlobal {
-    const float *m;
-    __device__ __forceinline__ float operator()(int idx) { return *reinterpret_cast<const float *>(reinterpret_cast<const char *>(m) + ((unsigned)idx << 2)); }
-};
-// box_edge_sum_dists with the corners in registers: same samples, same order of float additions as edge_sum_dists_lds
-template <int CFG, class F> __device__ __forceinline__ float edge_sum_dists_reg(const double (&cx)[8], const double (&cy)[8], int w, int last, double rx, double ry, F &fetch) {
-    constexpr int NE = CFG == 1 ? 9 : 7;
-    float cp[8];
+// float map -> code map, 8 pixels per thread (two 16-byte loads, one 16-byte store); uflag[u] |= 1 when the unit holds an escape pixel
+__global__ void __launch_bounds__(256) cuboid_dt_codes(const Unit *units, const float *dist, unsigned short *codes, int *uflag) {
+    __shared__ unsigned short lut[SC_LUT_N];
+    const int u = blockIdx.y;
+    const Unit &U = units[u];
+    const int A8 = (U.roi_w * U.roi_h + 7) >> 3; // slices are padded to 64 pixels
+    if (blockIdx.x * 512 >= A8) return;
+    for (int i = threadIdx.x; i < SC_LUT_N; i += 256) lut[i] = 0;
+    __syncthreads();
+    { const int j = threadIdx.x, r = (j * DT_DIAG) % DT_HV; lut[r >> 6] = (unsigned short)((j << 8) - (j * DT_DIAG) / DT_HV); }
+    __syncthreads();
+    const float4 *dm4 = reinterpret_cast<const float4 *>(dist + U.pix_off);
+    uint4 *cm4 = reinterpret_cast<uint4 *>(codes + U.pix_off);
+    const int A = U.roi_w * U.roi_h;
+    bool esc = false;
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        if (CFG == 2 && k >= 6) { cp[k] = 0; continue; }
-        int idx = __mul24(int(cy[k] - ry), w) + int(cx[k] - rx);
-        idx = min(max(idx, 0), last);
-        cp[k] = fetch(idx);
-    }
-    float sum_dist = 0;
+    for (int r = 0; r < 2; r++) {
+        const int k = blockIdx.x * 512 + r * 256 + threadIdx.x;
+        if (k < A8) {
+            const float4 a = dm4[2 * k], b = dm4[2 * k + 1];
+            const unsigned e0 = sc_encode(a.x, lut), e1 = sc_encode(a.y, lut), e2 = sc_encode(a.z, lut), e3 = sc_encode(a.w, lut);
+            const unsigned e4 = sc_encode(b.x, lut), e5 = sc_encode(b.y, lut), e6 = sc_encode(b.z, lut), e7 = sc_encode(b.w, lut);
+            cm4[k] = make_uint4(e0 | (e1 << 16), e2 | (e3 << 16), e4 | (e5 << 16), e6 | (e7 << 16));
+            const unsigned e[8] = {e0, e1, e2, e3, e4, e5, e6, e7};
 #pragma unroll
-    for (int e = 0; e < NE; e++) {
-        const int ia = CFG == 1 ? K_VIS1[e][0] : K_VIS2[e][0], ib = CFG == 1 ? K_VIS1[e][1] : K_VIS2[e][1];
-        const double x1 = cx[ia] - rx, y1 = cy[ia] - ry, x2 = cx[ib] - rx, y2 = cy[ib] - ry; // :423-425
-        const float wgt = (CFG == 2 && (e == 4 || e == 5)) ? 1.5f : ((CFG == 2 && e == 6) ? 2.0f : 1.0f);
-#pragma unroll
-        for (int si = 0; si < 11; si++) {
-            float d;
-            if (si == 0) d = cp[ib];
-            else if (si == 10) d = cp[ia];
-            else {
-                const double s = (double)si;
-                const double px = s / 10.0 * x1 + (1 - s / 10.0) * x2;
-                const double py = s / 10.0 * y1 + (1 - s / 10.0) * y2;
-                int idx = __mul24(int(py), w) + int(px);
-                idx = min(max(idx, 0), last);
-                d = fetch(idx);
-            }
-            if (CFG == 2) d = d * wgt;
-            sum_dist = sum_dist + d;
+            for (int i = 0; i < 8; i++) esc = esc || (e[i] == 0xffffu && 8 * k + i < A);
         }
-        __builtin_amdgcn_sched_barrier(0); // keep the 9 gathers of one edge together instead of hoisting all 99: the register budget is 128
     }
-    return sum_dist;
+    if (esc) atomicOr(&uflag[u], 1);
 }
-template <int CFG> __device__ __forceinline__ double edge_angle_error_reg(const VPEntry &E, const double (&cx)[8], const double (&cy)[8]) {
+
+// one workgroup: cost line of the LDS units -> G + 1 segment borders; work items of the other units -> big list
+__device__ __forceinline__ long sc_copy_cost(const Unit &U) { return ((long)U.roi_w * U.roi_h * SC_COST_PX_NUM) >> 6; }
+__global__ void __launch_bounds__(1024) cuboid_score_plan(const Unit *units, int n_units, const int *vcount, const int *uflag, long *cost /*n_units + 1*/, ScoreSeg *seg, int G,
+                                                          BigItem *big, int *big_n) {
+    __shared__ long s_part[1024];
+    __shared__ int s_bign;
+    const int tid = threadIdx.x;
+    if (tid == 0) s_bign = 0;
+    const int per = (n_units + 1023) / 1024;
+    const int u0 = min(n_units, tid * per), u1 = min(n_units, u0 + per);
+    auto unit_cost = [&](int u) -> long {
+        const int n1 = sc_tasks(vcount[2 * u]), n2 = sc_tasks(vcount[2 * u + 1]);
+        if (n1 + n2 == 0 || !sc_unit_lds(units[u], uflag, u)) return 0;
+        return sc_copy_cost(units[u]) + (long)n1 * SC_COST_TASK1 + (long)n2 * SC_COST_TASK2;
+    };
+    long acc = 0;
+    for (int u = u0; u < u1; u++) acc += unit_cost(u);
+    s_part[tid] = acc;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) { // inclusive scan of the per-thread sums
+        const long v = tid >= off ? s_part[tid - off] : 0;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    long run = s_part[tid] - acc;
+    for (int u = u0; u < u1; u++) {
+        cost[u] = run; run += unit_cost(u);
+        if (!sc_unit_lds(units[u], uflag, u)) { // chunks of SC_BIG_P proposals for cuboid_sweep_score_big
+            for (int cfg = 1; cfg <= 2; cfg++) {
+                const int c = vcount[2 * u + cfg - 1], n = (c + SC_BIG_P - 1) / SC_BIG_P;
+                if (n > 0) { const int base = atomicAdd(&s_bign, n); for (int k = 0; k < n; k++) big[base + k] = BigItem{u, cfg, k * SC_BIG_P}; }
+            }
+        }
+    }
+    if (tid == 1023) cost[n_units] = s_part[1023];
+    __syncthreads(); // the workgroup's own global writes are visible to it after the barrier
+    if (tid == 0) *big_n = s_bign;
+    const long total = s_part[1023];
+    for (int g = tid; g <= G; g += 1024) {
+        ScoreSeg sg{n_units, 0};
+        if (g < G && total > 0) {
+            const long P = (long)((__int128)total * g / G);
+            int lo = 0, hi = n_units; // last unit with cost[u] <= P
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (cost[mid] <= P) lo = mid; else hi = mid; }
+            int u = lo;
+            while (u < n_units && cost[u + 1] == cost[u]) u++; // units without work start at the same point of the line
+            if (u < n_units) {
+                const int n1 = sc_tasks(vcount[2 * u]), n2 = sc_tasks(vcount[2 * u + 1]);
+                const long o = P - cost[u] - sc_copy_cost(units[u]);
+                int k = 0;
+                if (o > 0) {
+                    if (o < (long)n1 * SC_COST_TASK1) k = (int)(o / SC_COST_TASK1);
+                    else k = n1 + (int)min((long)n2, (o - (long)n1 * SC_COST_TASK1) / SC_COST_TASK2);
+                }
+                if (k < 2) k = 0;                                // a border this close to the unit's ends moves to the end: no map is copied for
+                else if (n1 + n2 - k < 2) { u++; k = 0; }        // one or two tasks
+                sg.unit = u; sg.task = k;
+            }
+        }
+        seg[g] = sg;
+    }
+}
+
+// box_edge_alignment_angle_error (object_3d_util.cpp:455-492), branch-free: a NaN boundary angle never wins `t < best`
+__device__ __forceinline__ double angle_best(double ang, double a0, double a1) {
+    double bst = 100;
+    double t = fabs(ang - a0); t = fmin(t, PI - t); bst = t < bst ? t : bst;
+    t = fabs(ang - a1); t = fmin(t, PI - t); bst = t < bst ? t : bst;
+    return bst;
+}
+template <int CFG> __device__ __forceinline__ double edge_angle_error_reg(const double *ang6, const double (&cx)[8], const double (&cy)[8]) {
     double total = 0;
     const double not_found_penalty = 30.0 / 180.0 * PI * 2;
 #pragma unroll
     for (int vp = 0; vp < 3; vp++) {
-        const double a0 = E.ang[vp * 2], a1 = E.ang[vp * 2 + 1];
-        const bool v0 = !isnan(a0), v1 = !isnan(a1);
-        if (v0 || v1) {
+        const double a0 = ang6[vp * 2], a1 = ang6[vp * 2 + 1];
+        const bool any = !isnan(a0) || !isnan(a1);
+        double best[2];
 #pragma unroll
-            for (int ee = 0; ee < 2; ee++) {
-                const int a = CFG == 1 ? K_VPE1[vp][2 * ee] : K_VPE2[vp][2 * ee], b = CFG == 1 ? K_VPE1[vp][2 * ee + 1] : K_VPE2[vp][2 * ee + 1];
-                const double ang = normalize_to_pi(atan2(cy[b] - cy[a], cx[b] - cx[a]));
-                double best = 100;
-                if (v0) { double t = fabs(ang - a0); t = fmin(t, PI - t); if (t < best) best = t; }
-                if (v1) { double t = fabs(ang - a1); t = fmin(t, PI - t); if (t < best) best = t; }
-                total = total + best;
-                __builtin_amdgcn_sched_barrier(0);
-            }
-        } else
-            total = total + not_found_penalty;
+        for (int ee = 0; ee < 2; ee++) {
+            const int a = CFG == 1 ? K_VPE1[vp][2 * ee] : K_VPE2[vp][2 * ee], b = CFG == 1 ? K_VPE1[vp][2 * ee + 1] : K_VPE2[vp][2 * ee + 1];
+            best[ee] = angle_best(line_angle_fast(cy[b] - cy[a], cx[b] - cx[a]), a0, a1);
+        }
+        const double x = total + (any ? best[0] : not_found_penalty);
+        total = any ? x + best[1] : x;
     }
     return total;
 }
-template <int CFG> __device__ __forceinline__ void score_one_lds(const Unit &U, int h, const VPEntry *vpt, const float *dist, const unsigned short *lmap, const double *corners,
-                                                                 long hyp_total, double *derr, double *aerr) {
+
+// box_edge_sum_dists (object_3d_util.cpp:427-453) with ROI-relative corners in registers and the code map in LDS.  Sample s of an edge is
+// s/10 * p1 + (1 - s/10) * p2 in double, in the reference's operation order; s = 0 and s = 10 reproduce the corners exactly (0*p1 + 1*p2),
+// and every corner ends two or three edges: the corner pixels are decoded once.  The cfg-2 weights `dist*3.0/2.0` and `dist*2.0` (float ->
+// double -> float) equal the float products dist*1.5f and dist*2.0f bit for bit (3*x and x/2 are exact in double: one rounding of 1.5*x).
+template <int CFG> __device__ __forceinline__ float edge_sum_dists_code(const double (&rx)[8], const double (&ry)[8], int w, const unsigned short *lmap) {
+    constexpr int NE = CFG == 1 ? 9 : 7;
+    constexpr float HVS = (float)DT_HV / 65536.0f, DGS = (float)DT_DIAG / 65536.0f;
+    auto gather = [&](double px, double py) -> unsigned { // the raw code: its consumer comes a whole edge later
+        const int idx = __mul24(int(py), w) + int(px);
+        return *reinterpret_cast<const unsigned short *>(reinterpret_cast<const char *>(lmap) + ((unsigned)idx << 1));
+    };
+    auto decode = [&](unsigned c) -> float { return __builtin_fmaf((float)((c >> 8) & 0xffu), DGS, (float)(c & 0xffu) * HVS); };
+    auto gather_edge = [&](int e, unsigned (&c)[9]) {
+        const int ia = CFG == 1 ? K_VIS1[e][0] : K_VIS2[e][0], ib = CFG == 1 ? K_VIS1[e][1] : K_VIS2[e][1];
+        const double x1 = rx[ia], y1 = ry[ia], x2 = rx[ib], y2 = ry[ib];
+#pragma unroll
+        for (int si = 1; si < 10; si++) {
+            const double s = (double)si;
+            c[si - 1] = gather(s / 10.0 * x1 + (1 - s / 10.0) * x2, s / 10.0 * y1 + (1 - s / 10.0) * y2);
+        }
+    };
+    // software pipeline, written out because the compiler keeps the source order of this (fully unrolled) block: the 9 LDS gathers of
+    // edge e+1 are issued before the codes of edge e are decoded and added
+    unsigned cc[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) cc[k] = (CFG == 2 && k >= 6) ? 0u : gather(rx[k], ry[k]);
+    unsigned cur[9], nxt[9];
+    gather_edge(0, cur);
+    __builtin_amdgcn_sched_barrier(0);
+    float cp[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) cp[k] = decode(cc[k]);
+    float sum_dist = 0;
+#pragma unroll
+    for (int e = 0; e < NE; e++) {
+        if (e + 1 < NE) gather_edge(e + 1, nxt);
+        __builtin_amdgcn_sched_barrier(0);
+        const int ia = CFG == 1 ? K_VIS1[e][0] : K_VIS2[e][0], ib = CFG == 1 ? K_VIS1[e][1] : K_VIS2[e][1];
+        const float wgt = (CFG == 2 && (e == 4 || e == 5)) ? 1.5f : ((CFG == 2 && e == 6) ? 2.0f : 1.0f);
+#pragma unroll
+        for (int si = 0; si < 11; si++) {
+            float d = si == 0 ? cp[ib] : (si == 10 ? cp[ia] : decode(cur[si - 1]));
+            if (CFG == 2) d = d * wgt;
+            sum_dist = sum_dist + d;
+        }
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int k = 0; k < 9; k++) cur[k] = nxt[k];
+    }
+    return sum_dist;
+}
+
+template <int CFG> __device__ __forceinline__ void sc_score_task(const Unit &U, int first, int count, int lane, const VPEntry *vpt, const double *corners,
+                                                                 long hyp_total, const int *vlist, const unsigned short *lmap, double *derr, double *aerr) {
+    const int s = first + lane;
+    const bool live = s < count;
+    const int sc = live ? s : count - 1;
+    const int h = CFG == 1 ? vlist[U.hyp_off + sc] : vlist[U.hyp_off + U.hyp_cap - 1 - sc];
     const long g = U.hyp_off + h;
     const int q = (h >> 1) / U.n_tops;
     double cx[8], cy[8];
 #pragma unroll
-    for (int k = 0; k < 8; k++) { cx[k] = corners[(long)k * hyp_total + g]; cy[k] = corners[(long)(8 + k) * hyp_total + g]; }
-    const int last = U.roi_w * U.roi_h - 1;
-    FetchLds fl{lmap, 0u};
-    float sum_dist = edge_sum_dists_reg<CFG>(cx, cy, U.roi_w, last, (double)U.roi_x, (double)U.roi_y, fl);
-    if (fl.tmax >= (1u << 24)) { // an escape code was sampled: this proposal reads the float map
-        FetchGlobal fg{dist + U.pix_off};
-        sum_dist = edge_sum_dists_reg<CFG>(cx, cy, U.roi_w, last, (double)U.roi_x, (double)U.roi_y, fg);
+    for (int k = 0; k < 8; k++) {
+        if (CFG == 2 && k >= 6) { cx[k] = 0; cy[k] = 0; continue; } // corners 7 and 8 are on no edge of configuration 2
+        cx[k] = corners[(long)k * hyp_total + g]; cy[k] = corners[(long)(8 + k) * hyp_total + g];
     }
-    derr[g] = double(sum_dist) / U.diag; // :451
-    aerr[g] = edge_angle_error_reg<CFG>(vpt[(long)U.vp_off + q], cx, cy);
-}
-// Work list of the LDS kernel, built on the device because the list lengths are: one item per SLDS_PW proposals of one configuration of
-// one unit that fits.  work_n[0] = number of items, work_n[1] = the dynamic work counter (reset here).
-__global__ void __launch_bounds__(256) cuboid_score_worklist(const Unit *units, int n_units, const int *vcount, int2 *work, int *work_n) {
-    __shared__ int s_n[256];
-    __shared__ int s_base;
-    if (threadIdx.x == 0) s_base = 0;
-    __syncthreads();
-    for (int u0 = 0; u0 < n_units; u0 += 256) {
-        const int u = u0 + threadIdx.x;
-        int n = 0;
-        if (u < n_units && units[u].roi_w * units[u].roi_h <= SLDS_MAP_PX) n = (vcount[2 * u] + SLDS_PW - 1) / SLDS_PW + (vcount[2 * u + 1] + SLDS_PW - 1) / SLDS_PW;
-        s_n[threadIdx.x] = n;
-        __syncthreads();
-        if (threadIdx.x == 0) { int acc = s_base; for (int i = 0; i < 256; i++) { const int v = s_n[i]; s_n[i] = acc; acc += v; } s_base = acc; }
-        __syncthreads();
-        for (int k = 0; k < n; k++) work[s_n[threadIdx.x] + k] = make_int2(u, k);
-        __syncthreads();
+    const double *ang6 = vpt[(long)U.vp_off + q].ang;
+    double ang[6];
+#pragma unroll
+    for (int k = 0; k < 6; k++) ang[k] = ang6[k];
+    const double ae = edge_angle_error_reg<CFG>(ang, cx, cy);
+    const double rx = (double)U.roi_x, ry = (double)U.roi_y;
+#pragma unroll
+    for (int k = 0; k < 8; k++) { cx[k] = cx[k] - rx; cy[k] = cy[k] - ry; } // :423-425
+    const float sum_dist = edge_sum_dists_code<CFG>(cx, cy, U.roi_w, lmap);
+    if (live) {
+        derr[g] = double(sum_dist) / U.diag; // :451
+        aerr[g] = ae;
     }
-    if (threadIdx.x == 0) { work_n[0] = s_base; work_n[1] = 0; }
 }
-__global__ void __launch_bounds__(SLDS_T) cuboid_sweep_score_lds(const Unit *units, const int2 *work, int *work_n, const VPEntry *vpt, const float *dist,
-                                                                 const double *corners, long hyp_total, const int *vcount, const int *vlist, double *derr, double *aerr) {
-    extern __shared__ unsigned char slds_mem[];
-    unsigned *lut = reinterpret_cast<unsigned *>(slds_mem);
-    unsigned short *lmap = reinterpret_cast<unsigned short *>(slds_mem + SLDS_LUT * 4);
-    int *s_item = reinterpret_cast<int *>(slds_mem + SLDS_BYTES - 16);
-    const int tid = threadIdx.x;
-    for (int i = tid; i < SLDS_LUT; i += SLDS_T) lut[i] = 0xffffffffu;
-    __syncthreads();
-    if (tid < 256) { const int r = (tid * DT_DIAG) % DT_HV; lut[r >> 6] = (unsigned)tid | ((unsigned)((tid * DT_DIAG) / DT_HV) << 8); }
-    const int n_work = work_n[0];
-    int cur_u = -1;
-    for (;;) {
-        __syncthreads(); // the LUT is complete / everybody is done with the previous item's map and s_item
-        if (tid == 0) *s_item = atomicAdd(&work_n[1], 1);
-        __syncthreads();
-        const int wi = *s_item;
-        if (wi >= n_work) return;
-        const int2 it = work[wi];
-        const int u = it.x, blk = it.y;
+
+__global__ void __launch_bounds__(SC_T) cuboid_sweep_score(const Unit *units, int n_units, const ScoreSeg *seg, int G, const VPEntry *vpt, const unsigned short *codes,
+                                                           const double *corners, long hyp_total, const int *vcount, const int *uflag, const int *vlist, double *derr, double *aerr, int mode) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sc_mem[];
+    int *ctrl = reinterpret_cast<int *>(sc_mem);
+    unsigned short *lmap = reinterpret_cast<unsigned short *>(sc_mem + SC_MAP_OFF);
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int b = blockIdx.x;
+    const int sg = (G & 7) == 0 ? (b & 7) * (G >> 3) + (b >> 3) : b; // neighbouring segments on one XCD
+    const ScoreSeg s0 = seg[sg], s1 = seg[sg + 1];
+    if (s0.unit >= n_units || (s0.unit == s1.unit && s0.task >= s1.task)) return;
+    const long dbg_t0 = wall_clock64(); int dbg_tasks = 0, dbg_units = 0;
+    const int u_last = s1.task > 0 ? s1.unit : s1.unit - 1; // last unit this segment touches
+    const bool backwards = sg & 1;
+    const int n_pos = u_last - s0.unit + 1;
+    auto unit_at = [&](int pos) { return backwards ? u_last - pos : s0.unit + pos; };
+    auto task_range = [&](int u, int &t0, int &t1, int &n1, int &c1, int &c2) {
+        c1 = vcount[2 * u]; c2 = vcount[2 * u + 1];
+        n1 = sc_tasks(c1);
+        t0 = u == s0.unit ? s0.task : 0;
+        t1 = u == s1.unit ? s1.task : n1 + sc_tasks(c2);
+        if (!sc_unit_lds(units[u], uflag, u)) t1 = t0; // scored by cuboid_sweep_score_big
+    };
+    auto next_pos = [&](int pos) { // first position >= pos with work
+        for (; pos < n_pos; pos++) { int t0, t1, n1, c1, c2; task_range(unit_at(pos), t0, t1, n1, c1, c2); if (t0 < t1) break; }
+        return pos;
+    };
+    for (int pos = next_pos(0); pos < n_pos; pos = next_pos(pos + 1)) {
+        const int u = unit_at(pos);
         const Unit &U = units[u];
-        if (u != cur_u) { // encode the unit's distance map into LDS, 16 pixels per thread and step (four loads in flight)
-            cur_u = u;
-            const int A = U.roi_w * U.roi_h, A4 = A >> 2;
-            const float4 *dm4 = reinterpret_cast<const float4 *>(dist + U.pix_off); // 256-byte aligned slice
-            uint2 *lm2 = reinterpret_cast<uint2 *>(lmap);
-            for (int k0 = tid; k0 < A4; k0 += 4 * SLDS_T) {
-                float4 v[4];
-#pragma unroll
-                for (int r = 0; r < 4; r++) { const int k = k0 + r * SLDS_T; v[r] = k < A4 ? dm4[k] : make_float4(0.f, 0.f, 0.f, 0.f); }
-#pragma unroll
-                for (int r = 0; r < 4; r++) {
-                    const int k = k0 + r * SLDS_T;
-                    if (k < A4) {
-                        const unsigned e0 = slds_encode(v[r].x, lut), e1 = slds_encode(v[r].y, lut), e2 = slds_encode(v[r].z, lut), e3 = slds_encode(v[r].w, lut);
-                        lm2[k] = make_uint2(e0 | (e1 << 16), e2 | (e3 << 16));
-                    }
-                }
-            }
-            const float *dm = dist + U.pix_off;
-            for (int k = (A4 << 2) + tid; k < A; k += SLDS_T) lmap[k] = (unsigned short)slds_encode(dm[k], lut);
-            __syncthreads();
-        }
-        const int c1 = vcount[2 * u], c2 = vcount[2 * u + 1];
-        const int nb1 = (c1 + SLDS_PW - 1) / SLDS_PW;
+        int t0, t1, n1, c1, c2;
+        task_range(u, t0, t1, n1, c1, c2);
+        const int A = U.roi_w * U.roi_h;
+        dbg_units++; dbg_tasks += t1 - t0;
+        __syncthreads(); // every wave is done with the previous unit's map
+        if (!(mode & 2)) { // copy the code map, SC_PFB 16-byte loads per thread in flight
+            const int A8 = (A + 7) >> 3; // slices are padded to 64 pixels
+            const uint4 *cm4 = reinterpret_cast<const uint4 *>(codes + U.pix_off);
+            uint4 *lm4 = reinterpret_cast<uint4 *>(lmap);
 #pragma unroll 1
-        for (int r = 0; r < SLDS_PW / SLDS_T; r++) {
-            if (blk < nb1) {
-                const int sidx = blk * SLDS_PW + r * SLDS_T + tid;
-                if (sidx < c1) score_one_lds<1>(U, vlist[U.hyp_off + sidx], vpt, dist, lmap, corners, hyp_total, derr, aerr);
-            } else {
-                const int sidx = (blk - nb1) * SLDS_PW + r * SLDS_T + tid;
-                if (sidx < c2) score_one_lds<2>(U, vlist[U.hyp_off + U.hyp_cap - 1 - sidx], vpt, dist, lmap, corners, hyp_total, derr, aerr);
+            for (int k0 = tid; k0 < A8; k0 += SC_PFB * SC_T) {
+                uint4 pf[SC_PFB];
+#pragma unroll
+                for (int r = 0; r < SC_PFB; r++) pf[r] = cm4[min(k0 + r * SC_T, A8 - 1)]; // branch-free: a tail thread re-copies the last 16 bytes
+#pragma unroll
+                for (int r = 0; r < SC_PFB; r++) lm4[min(k0 + r * SC_T, A8 - 1)] = pf[r];
             }
+        } else for (int k = tid; k < A; k += SC_T) lmap[k] = 0x0101; // experiment: scoring alone
+        if (tid == 0) ctrl[0] = t0;
+        __syncthreads();
+        {
+            const unsigned short lastc = lmap[A - 1];
+            for (int k = tid; k < U.roi_w + 2; k += SC_T) lmap[A + k] = lastc; // D2: indices past the map read its last pixel
         }
+        __syncthreads();
+        if (!(mode & 1)) for (;;) { // waves pull tasks of 64 proposals of one configuration
+            int t = 0;
+            if (lane == 0) t = atomicAdd(&ctrl[0], 1);
+            t = __builtin_amdgcn_readfirstlane(t);
+            if (t >= t1) break;
+            if (t < n1) sc_score_task<1>(U, t << 6, c1, lane, vpt, corners, hyp_total, vlist, lmap, derr, aerr);
+            else sc_score_task<2>(U, (t - n1) << 6, c2, lane, vpt, corners, hyp_total, vlist, lmap, derr, aerr);
+        }
+    }
+    if ((mode & 8) && b < 4096) {
+        __syncthreads();
+        if (tid == 0) { g_sc_dbg[b * 4] = dbg_t0; g_sc_dbg[b * 4 + 1] = wall_clock64(); g_sc_dbg[b * 4 + 2] = dbg_tasks; g_sc_dbg[b * 4 + 3] = dbg_units; }
+    }
+}
+
+// cuboid_sweep_score_big: the units cuboid_sweep_score cannot take (ROI larger than one CU's LDS, or an escape pixel), from the float map
+// in global memory.  Sample-parallel, so that no thread waits on a chain of 99 dependent gathers: a workgroup takes SC_BIG_P proposals of
+// one configuration, its threads evaluate (proposal, sample) pairs with every gather independent, the values go through LDS and one thread
+// per proposal adds them in the reference's order; the six edge angles of a proposal are computed by six threads.
+template <int CFG> __device__ __forceinline__ void sc_big_item(const Unit &U, int first, int count, const VPEntry *vpt, const float *dist, const double *corners, long hyp_total,
+                                                               const int *vlist, double *derr, double *aerr, double (*s_c)[16], float (*s_v)[100], double (*s_a)[6], int *s_h) {
+    constexpr int NS = CFG == 1 ? 99 : 77;
+    const int tid = threadIdx.x, n = min(SC_BIG_P, count - first);
+    __syncthreads();
+    for (int i = tid; i < n * 16; i += 256) {
+        const int p = i >> 4, k = i & 15;
+        const int h = CFG == 1 ? vlist[U.hyp_off + first + p] : vlist[U.hyp_off + U.hyp_cap - 1 - (first + p)];
+        if (k == 0) s_h[p] = h;
+        s_c[p][k] = corners[(long)k * hyp_total + U.hyp_off + h];
+    }
+    __syncthreads();
+    const float *dm = dist + U.pix_off;
+    const int w = U.roi_w, last = U.roi_w * U.roi_h - 1;
+    const double rx = (double)U.roi_x, ry = (double)U.roi_y;
+    for (int i = tid; i < n * NS; i += 256) {
+        const int p = i / NS, k = i - p * NS, e = k / 11, si = k - e * 11;
+        const int ia = CFG == 1 ? c_vis1[e][0] : c_vis2[e][0], ib = CFG == 1 ? c_vis1[e][1] : c_vis2[e][1];
+        const double x1 = s_c[p][ia] - rx, y1 = s_c[p][8 + ia] - ry, x2 = s_c[p][ib] - rx, y2 = s_c[p][8 + ib] - ry; // :423-425
+        const double s = (double)si;
+        const double px = s / 10.0 * x1 + (1 - s / 10.0) * x2;
+        const double py = s / 10.0 * y1 + (1 - s / 10.0) * y2;
+        int idx = __mul24(int(py), w) + int(px);
+        idx = min(max(idx, 0), last); // D2
+        float d = dm[idx];
+        if (CFG == 2) d = d * ((e == 4 || e == 5) ? 1.5f : (e == 6 ? 2.0f : 1.0f));
+        s_v[p][k] = d;
+    }
+    for (int i = tid; i < n * 6; i += 256) {
+        const int p = i / 6, k = i - p * 6, vp = k >> 1, ee = k & 1;
+        const int a = CFG == 1 ? c_vpe1[vp][2 * ee] : c_vpe2[vp][2 * ee], b = CFG == 1 ? c_vpe1[vp][2 * ee + 1] : c_vpe2[vp][2 * ee + 1];
+        const double *ang6 = vpt[(long)U.vp_off + (s_h[p] >> 1) / U.n_tops].ang;
+        s_a[p][k] = angle_best(line_angle_fast(s_c[p][8 + b] - s_c[p][8 + a], s_c[p][b] - s_c[p][a]), ang6[vp * 2], ang6[vp * 2 + 1]);
+    }
+    __syncthreads();
+    if (tid < n) {
+        float sum_dist = 0;
+        for (int k = 0; k < NS; k++) sum_dist = sum_dist + s_v[tid][k];
+        const double *ang6 = vpt[(long)U.vp_off + (s_h[tid] >> 1) / U.n_tops].ang;
+        double total = 0;
+        const double not_found_penalty = 30.0 / 180.0 * PI * 2;
+        for (int vp = 0; vp < 3; vp++) {
+            const bool any = !isnan(ang6[vp * 2]) || !isnan(ang6[vp * 2 + 1]);
+            const double x = total + (any ? s_a[tid][vp * 2] : not_found_penalty);
+            total = any ? x + s_a[tid][vp * 2 + 1] : x;
+        }
+        const long g = U.hyp_off + s_h[tid];
+        derr[g] = double(sum_dist) / U.diag; // :451
+        aerr[g] = total;
+    }
+}
+__global__ void __launch_bounds__(256) cuboid_sweep_score_big(const Unit *units, const BigItem *big, const int *big_n, const VPEntry *vpt, const float *dist,
+                                                              const double *corners, long hyp_total, const int *vcount, const int *vlist, double *derr, double *aerr) {
+    __shared__ double s_c[SC_BIG_P][16];
+    __shared__ float s_v[SC_BIG_P][100];
+    __shared__ double s_a[SC_BIG_P][6];
+    __shared__ int s_h[SC_BIG_P];
+    const int n_items = *big_n;
+    for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
+        const BigItem I = big[it];
+        const Unit &U = units[I.unit];
+        if (I.cfg == 1) sc_big_item<1>(U, I.first, vcount[2 * I.unit], vpt, dist, corners, hyp_total, vlist, derr, aerr, s_c, s_v, s_a, s_h);
+        else sc_big_item<2>(U, I.first, vcount[2 * I.unit + 1], vpt, dist, corners, hyp_total, vlist, derr, aerr, s_c, s_v, s_a, s_h);
     }
 }
 
@@ -1616,8 +1729,11 @@ struct cs_cuboid_batch {
     uint8_t *d_gray = nullptr, *d_emap = nullptr, *d_flag = nullptr;
     int *d_lab = nullptr; // aliases d_dist
     float *d_dist = nullptr;
-    int *d_dttmp = nullptr; long *d_dttmp_off = nullptr; int2 *d_work = nullptr; int *d_work_n = nullptr; // work list of cuboid_sweep_score_lds
-    int score_lds = 0; // CUBESLAM_SCORE=lds: cuboid_sweep_score_lds for the units whose ROI fits one CU's LDS
+    int *d_dttmp = nullptr; long *d_dttmp_off = nullptr;
+    long *d_score_cost = nullptr; ScoreSeg *d_score_seg = nullptr; // cuboid_score_plan -> cuboid_sweep_score
+    unsigned short *d_codes = nullptr; int *d_uflag = nullptr;      // cuboid_dt_codes: 16-bit chamfer codes, per-unit escape flag
+    BigItem *d_big = nullptr; int *d_big_n = nullptr;               // work list of cuboid_sweep_score_big
+    int score_G = 256;      // segments = workgroups of cuboid_sweep_score (one per CU)
     int dt_C = 0; // wave-per-ROI distance transform: int map between the passes, lane-major
     FrameInfo *d_fi = nullptr; FrameDyn *d_fd = nullptr; CamRP *d_cam = nullptr;
     double *d_yaw = nullptr, *d_lines_in = nullptr, *d_lines_al = nullptr, *d_mlines = nullptr, *d_mangle = nullptr, *d_mmid = nullptr;
@@ -1644,7 +1760,7 @@ void cs_cuboid_batch_destroy(cs_ctx *ctx, cs_cuboid_batch *b) {
     if (ctx) { hipSetDevice(ctx->device); hipStreamSynchronize(ctx->stream); }
     void *ptrs[] = {b->d_gray, b->d_emap, b->d_flag, b->d_dist, b->d_dttmp, b->d_dttmp_off, b->d_fi, b->d_fd, b->d_cam, b->d_yaw, b->d_lines_in, b->d_lines_al,
                     b->d_mlines, b->d_mangle, b->d_mmid, b->d_units, b->d_ud, b->d_box_first, b->d_status, b->d_counts, b->d_vp,
-                    b->d_derr, b->d_aerr, b->d_corners, b->d_score, b->d_nscore, b->d_ckd, b->d_cka, b->d_cidx, b->d_out, b->d_vcount, b->d_vlist, b->d_work, b->d_work_n};
+                    b->d_derr, b->d_aerr, b->d_corners, b->d_score, b->d_nscore, b->d_ckd, b->d_cka, b->d_cidx, b->d_out, b->d_vcount, b->d_vlist, b->d_score_cost, b->d_score_seg, b->d_codes, b->d_uflag, b->d_big, b->d_big_n};
     for (void *p : ptrs) if (p) hipFree(p);
     delete b;
 }
@@ -1756,16 +1872,20 @@ int cs_cuboid_batch_create(cs_ctx *ctx, int n_frames, int width, int height, con
         }
     }
     {
-        const char *se = getenv("CUBESLAM_SCORE");
-        if (se && !strcmp(se, "lds")) {
-            hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(cuboid_sweep_score_lds), hipFuncAttributeMaxDynamicSharedMemorySize, SLDS_BYTES);
-            if (e != hipSuccess) { ctx->err = hipGetErrorString(e); cs_cuboid_batch_destroy(ctx, b); return CS_ERR_HIP; }
-            b->score_lds = 1;
-            long items = 0;
-            for (const Unit &U : b->units) items += (U.hyp_cap + SLDS_PW - 1) / SLDS_PW + 2;
-            A_(cs_dalloc(ctx, &b->d_work, (size_t)items));
-            A_(cs_dalloc(ctx, &b->d_work_n, 2));
-        }
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(cuboid_sweep_score), hipFuncAttributeMaxDynamicSharedMemorySize, SC_LDS_BYTES);
+        if (e != hipSuccess) { ctx->err = hipGetErrorString(e); cs_cuboid_batch_destroy(ctx, b); return CS_ERR_HIP; }
+        hipDeviceProp_t prop;
+        if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) b->score_G = prop.multiProcessorCount;
+        const char *ge = getenv("CUBESLAM_SCORE_SEGMENTS"); // tuning knob: segments (= workgroups) of cuboid_sweep_score
+        if (ge && atoi(ge) > 0) b->score_G = atoi(ge);
+        A_(cs_dalloc(ctx, &b->d_score_cost, (size_t)b->n_units + 1));
+        A_(cs_dalloc(ctx, &b->d_score_seg, (size_t)b->score_G + 1));
+        A_(cs_dalloc(ctx, &b->d_codes, (size_t)b->pix_total + 64));
+        A_(cs_dalloc(ctx, &b->d_uflag, (size_t)b->n_units));
+        long items = 0;
+        for (const Unit &U : b->units) items += 2 * ((U.hyp_cap / 2 + SC_BIG_P - 1) / SC_BIG_P + 1);
+        A_(cs_dalloc(ctx, &b->d_big, (size_t)items));
+        A_(cs_dalloc(ctx, &b->d_big_n, 1));
     }
     A_(cs_dalloc(ctx, &b->d_dist, (size_t)b->pix_total));
     b->d_lab = (int *)b->d_dist;
@@ -1836,24 +1956,30 @@ int cs_cuboid_batch_run(cs_ctx *ctx, cs_cuboid_batch *b) {
         const int wbuf = b->W + 2;
         CS_LAUNCH(ctx, "cuboid_dt", cuboid_dt, dim3((U + 3) / 4), dim3(256), (size_t)wbuf * 2 * 4 * sizeof(int), b->d_units, U, b->d_emap, b->d_dist, wbuf);
     }
+    CS_HIP(ctx, hipMemsetAsync(b->d_uflag, 0, sizeof(int) * (size_t)U, ctx->stream));
+    CS_LAUNCH(ctx, "cuboid_dt_codes", cuboid_dt_codes, dim3(b->max_cc_blocks, U), dim3(256), 0, b->d_units, b->d_dist, b->d_codes, b->d_uflag);
     CS_LAUNCH(ctx, "cuboid_vp", cuboid_vp, dim3(b->max_vp_blocks, U), dim3(256), 0, b->d_units, b->d_ud, b->d_fd, b->d_cam, b->d_yaw, b->o,
               b->d_mangle, b->d_mmid, b->d_vp);
     const int groups = (U + 7) / 8;
     CS_HIP(ctx, hipMemsetAsync(b->d_vcount, 0, sizeof(int) * 2 * (size_t)U, ctx->stream));
     CS_LAUNCH(ctx, "cuboid_sweep_corners", cuboid_sweep_corners, dim3(groups * b->blocks_per_unit * 8), dim3(256), 0, b->d_units, U,
               b->blocks_per_unit, b->d_fd, b->o, b->d_vp, b->d_flag, b->d_corners, b->hyp_total, b->d_vcount, b->d_vlist);
-    const int score_bpu = b->blocks_per_unit * (SWEEP_HB / SCORE_PB) + 1; // +1: each of the two lists may end in a partial workgroup
-    CS_LAUNCH(ctx, "cuboid_sweep_score", cuboid_sweep_score, dim3(groups * score_bpu * 8), dim3(256), 0, b->d_units, U, score_bpu, b->d_vp,
-              b->d_dist, b->d_corners, b->hyp_total, b->d_vcount, b->d_vlist, b->d_derr, b->d_aerr, b->score_lds ? SLDS_MAP_PX : 0);
-    if (b->score_lds) {
-        CS_LAUNCH(ctx, "cuboid_score_worklist", cuboid_score_worklist, dim3(1), dim3(256), 0, b->d_units, U, b->d_vcount, b->d_work, b->d_work_n);
-        CS_LAUNCH(ctx, "cuboid_sweep_score_lds", cuboid_sweep_score_lds, dim3(512), dim3(SLDS_T), SLDS_BYTES, b->d_units, b->d_work, b->d_work_n, b->d_vp, b->d_dist,
-                  b->d_corners, b->hyp_total, b->d_vcount, b->d_vlist, b->d_derr, b->d_aerr);
-    }
+    CS_LAUNCH(ctx, "cuboid_score_plan", cuboid_score_plan, dim3(1), dim3(1024), 0, b->d_units, U, b->d_vcount, b->d_uflag, b->d_score_cost, b->d_score_seg, b->score_G,
+              b->d_big, b->d_big_n);
+    CS_LAUNCH(ctx, "cuboid_sweep_score", cuboid_sweep_score, dim3(b->score_G), dim3(SC_T), SC_LDS_BYTES, b->d_units, U, b->d_score_seg, b->score_G, b->d_vp,
+              b->d_codes, b->d_corners, b->hyp_total, b->d_vcount, b->d_uflag, b->d_vlist, b->d_derr, b->d_aerr, getenv("CUBESLAM_SCORE_MODE") ? atoi(getenv("CUBESLAM_SCORE_MODE")) : 0);
+    CS_LAUNCH(ctx, "cuboid_sweep_score_big", cuboid_sweep_score_big, dim3(1024), dim3(256), 0, b->d_units, b->d_big, b->d_big_n, b->d_vp, b->d_dist, b->d_corners,
+              b->hyp_total, b->d_vcount, b->d_vlist, b->d_derr, b->d_aerr);
     CS_LAUNCH(ctx, "cuboid_select", cuboid_select, dim3(b->n_boxes), dim3(256), 0, b->d_units, b->d_ud, b->d_box_first, b->d_fd, b->d_fi,
               b->d_cam, b->d_yaw, b->cal, b->o, b->d_flag, b->d_derr, b->d_aerr, b->d_corners, b->hyp_total, b->d_score, b->d_nscore,
               b->d_ckd, b->d_cka, b->d_cidx, b->d_out, b->d_counts);
     CS_HIP(ctx, hipGetLastError());
+    return CS_OK;
+}
+
+int cs_debug_score_dbg(cs_ctx *ctx, long *out, int n) { // experiment helper (tools/score_dbg.py), not part of the C-ABI header
+    CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    CS_HIP(ctx, hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sc_dbg), sizeof(long) * 4 * (size_t)n));
     return CS_OK;
 }
 

@@ -132,30 +132,36 @@ def test_distance_transform_variants_agree(ctx, oracle, monkeypatch, W, H):
     assert max(r[0][2] for r in maps["wave"]) > 560
 
 
-def test_score_variants_agree(ctx, oracle, monkeypatch):
-    """cuboid_sweep_score_lds (CUBESLAM_SCORE=lds: the chamfer map as exact 16-bit (i, j) codes in LDS, escape code for pixels >= 256 px
-    from every edge) scores every proposal bit for bit like the float-map kernel: identical cuboids, including a box whose ROI does not fit
-    one CU's LDS (stays with the default kernel) and a flat image whose distance map is all escape codes (every proposal takes the
-    re-score path)."""
+def test_score_paths_agree(ctx, oracle, monkeypatch):
+    """cuboid_sweep_score keeps a unit's chamfer map in LDS as exact 16-bit (i, j) codes and cuts the batch's work line into segments
+    (one workgroup each).  Whatever the number of segments, the cuboids are byte-identical, and they equal the oracle's -- including a box
+    whose ROI does not fit one CU's LDS (cuboid_sweep_score_gmem) and a flat image whose distance map is all escape codes (every
+    proposal is re-scored from the float map)."""
     det = detect_3d_cuboid(ctx)
     det.yaw_step_deg = 2.0
     scenes = [synth.cuboid_scene(70 + i, n_boxes=3) for i in range(3)]
     flat = dict(scenes[0]); flat["gray"] = np.full_like(scenes[0]["gray"], 128)
     scenes.append(flat)
     boxes = [np.array(s["boxes"], np.float64) for s in scenes]
-    boxes[1] = np.concatenate([boxes[1], [[20, 20, 560, 400, 0.5]]])  # 600 x 440 ROI: 264 000 pixels > SLDS_MAP_PX
+    boxes[1] = np.concatenate([boxes[1], [[20, 20, 560, 400, 0.5]]])  # 600 x 440 ROI: 264 000 pixels do not fit
     det.set_calibration(scenes[0]["K"])
     out = {}
-    for mode in ("global", "lds"):
-        if mode == "lds":
-            monkeypatch.setenv("CUBESLAM_SCORE", "lds")
+    for segs in ("default", "1", "7", "64", "1000"):
+        if segs != "default":
+            monkeypatch.setenv("CUBESLAM_SCORE_SEGMENTS", segs)
         b = CuboidBatch(ctx, np.stack([s["gray"] for s in scenes]), scenes[0]["K"], np.stack([s["Twc"] for s in scenes]), boxes, [s["lines"] for s in scenes], det.opts())
         b.run()
-        out[mode] = b.read()
+        out[segs] = b.read()
         b.close()
-    monkeypatch.delenv("CUBESLAM_SCORE")
+    monkeypatch.delenv("CUBESLAM_SCORE_SEGMENTS")
     n = 0
-    for g, l in zip(out["global"], out["lds"]):
-        assert len(g) == len(l) and np.array_equal(np.asarray(g).view(np.uint8), np.asarray(l).view(np.uint8))
-        n += len(g)
+    for segs in ("1", "7", "64", "1000"):
+        for g, l in zip(out["default"], out[segs]):
+            assert len(g) == len(l) and np.array_equal(np.asarray(g).view(np.uint8), np.asarray(l).view(np.uint8)), segs
+            n += len(g)
     assert n > 5
+    oo = _oracle_opts(oracle, det)
+    ref = []
+    for s, bx in zip(scenes, boxes):
+        ref += oracle.detect_cuboid(s["gray"], scenes[0]["K"], s["Twc"], bx, s["lines"], opts=oo)[0]
+    _cmp_cuboids(out["default"], ref)
