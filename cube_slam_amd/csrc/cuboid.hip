@@ -41,6 +41,7 @@ constexpr int SC_MAP_OFF = 32;                                        // control
 constexpr int SC_MAP_ENTRIES = (SC_LDS_BYTES - SC_MAP_OFF) / 2;        // 80 920
 constexpr float SC_ESC_D = 244.0f;                                     // d < 244 => i <= 255 and j <= 178
 constexpr int SC_COST_PX_NUM = 3, SC_COST_TASK1 = 1700, SC_COST_TASK2 = 1350; // wave-instructions: map copy per 64 pixels / task of 64 proposals
+constexpr int SC_PLAN_LDS_UNITS = 4096;                                // cuboid_score_plan keeps the cost line of this many units in LDS
 constexpr int SC_BIG_P = 32;                                          // proposals per work item of cuboid_sweep_score_big
 constexpr int SC_PFB = 16;                                            // 16-byte loads per thread in flight while a map is copied
 constexpr int K_VIS1[9][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 0}, {1, 5}, {2, 4}, {3, 7}, {4, 7}, {4, 5}};
@@ -970,7 +971,6 @@ __global__ void __launch_bounds__(256) cuboid_sweep_corners(const Unit *units, i
 // odd segments run backwards so that both reach the shared unit at the same time and the second read hits the XCD's L2 (workgroup b runs
 // on XCD b % 8 and takes segment (b % 8) * G/8 + b / 8: neighbouring segments share an XCD).
 struct ScoreSeg { int unit, task; }; // segment border: task index inside the unit (0 .. number of tasks)
-__device__ long g_sc_dbg[4096 * 4]; // experiment: per-workgroup start / end clock, tasks, units (mode & 8)
 struct BigItem { int unit, cfg, first; };
 
 __device__ __forceinline__ int sc_tasks(int c) { return (c + 63) >> 6; }
@@ -1019,10 +1019,12 @@ __global__ void __launch_bounds__(256) cuboid_dt_codes(const Unit *units, const 
 __device__ __forceinline__ long sc_copy_cost(const Unit &U) { return ((long)U.roi_w * U.roi_h * SC_COST_PX_NUM) >> 6; }
 __global__ void __launch_bounds__(1024) cuboid_score_plan(const Unit *units, int n_units, const int *vcount, const int *uflag, long *cost /*n_units + 1*/, ScoreSeg *seg, int G,
                                                           BigItem *big, int *big_n) {
-    __shared__ long s_part[1024];
+    __shared__ long s_part[16];
+    __shared__ long s_cost[SC_PLAN_LDS_UNITS + 1];
     __shared__ int s_bign;
     const int tid = threadIdx.x;
     if (tid == 0) s_bign = 0;
+    __syncthreads();
     const int per = (n_units + 1023) / 1024;
     const int u0 = min(n_units, tid * per), u1 = min(n_units, u0 + per);
     auto unit_cost = [&](int u) -> long {
@@ -1032,17 +1034,21 @@ __global__ void __launch_bounds__(1024) cuboid_score_plan(const Unit *units, int
     };
     long acc = 0;
     for (int u = u0; u < u1; u++) acc += unit_cost(u);
-    s_part[tid] = acc;
+    // exclusive scan of the per-thread sums: shuffles inside a wave, the 16 wave totals through LDS (two barriers instead of twenty)
+    const int lane = tid & 63, wave = tid >> 6;
+    long incl = acc;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) { const long v = __shfl_up(incl, off); if (lane >= off) incl += v; }
+    if (lane == 63) s_part[wave] = incl;
     __syncthreads();
-    for (int off = 1; off < 1024; off <<= 1) { // inclusive scan of the per-thread sums
-        const long v = tid >= off ? s_part[tid - off] : 0;
-        __syncthreads();
-        s_part[tid] += v;
-        __syncthreads();
-    }
-    long run = s_part[tid] - acc;
+    long wave_base = 0, total = 0;
+#pragma unroll
+    for (int w = 0; w < 16; w++) { const long v = s_part[w]; if (w < wave) wave_base += v; total += v; }
+    long run = wave_base + incl - acc;
+    const bool in_lds = n_units <= SC_PLAN_LDS_UNITS; // the cost line in LDS: the borders' binary searches never leave the CU
     for (int u = u0; u < u1; u++) {
-        cost[u] = run; run += unit_cost(u);
+        cost[u] = run; if (in_lds) s_cost[u] = run;
+        run += unit_cost(u);
         if (!sc_unit_lds(units[u], uflag, u)) { // chunks of SC_BIG_P proposals for cuboid_sweep_score_big
             for (int cfg = 1; cfg <= 2; cfg++) {
                 const int c = vcount[2 * u + cfg - 1], n = (c + SC_BIG_P - 1) / SC_BIG_P;
@@ -1050,21 +1056,21 @@ __global__ void __launch_bounds__(1024) cuboid_score_plan(const Unit *units, int
             }
         }
     }
-    if (tid == 1023) cost[n_units] = s_part[1023];
+    if (tid == 0) { cost[n_units] = total; if (in_lds) s_cost[n_units] = total; }
     __syncthreads(); // the workgroup's own global writes are visible to it after the barrier
     if (tid == 0) *big_n = s_bign;
-    const long total = s_part[1023];
+    const long *cl = in_lds ? s_cost : cost;
     for (int g = tid; g <= G; g += 1024) {
         ScoreSeg sg{n_units, 0};
         if (g < G && total > 0) {
-            const long P = (long)((__int128)total * g / G);
+            const long P = (long)((double)total * (double)g / (double)G); // where on the line: rounding only moves a border by a task
             int lo = 0, hi = n_units; // last unit with cost[u] <= P
-            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (cost[mid] <= P) lo = mid; else hi = mid; }
+            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (cl[mid] <= P) lo = mid; else hi = mid; }
             int u = lo;
-            while (u < n_units && cost[u + 1] == cost[u]) u++; // units without work start at the same point of the line
+            while (u < n_units && cl[u + 1] == cl[u]) u++; // units without work start at the same point of the line
             if (u < n_units) {
                 const int n1 = sc_tasks(vcount[2 * u]), n2 = sc_tasks(vcount[2 * u + 1]);
-                const long o = P - cost[u] - sc_copy_cost(units[u]);
+                const long o = P - cl[u] - sc_copy_cost(units[u]);
                 int k = 0;
                 if (o > 0) {
                     if (o < (long)n1 * SC_COST_TASK1) k = (int)(o / SC_COST_TASK1);
@@ -1187,7 +1193,7 @@ template <int CFG> __device__ __forceinline__ void sc_score_task(const Unit &U, 
 }
 
 __global__ void __launch_bounds__(SC_T) cuboid_sweep_score(const Unit *units, int n_units, const ScoreSeg *seg, int G, const VPEntry *vpt, const unsigned short *codes,
-                                                           const double *corners, long hyp_total, const int *vcount, const int *uflag, const int *vlist, double *derr, double *aerr, int mode) {
+                                                           const double *corners, long hyp_total, const int *vcount, const int *uflag, const int *vlist, double *derr, double *aerr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sc_mem[];
     int *ctrl = reinterpret_cast<int *>(sc_mem);
     unsigned short *lmap = reinterpret_cast<unsigned short *>(sc_mem + SC_MAP_OFF);
@@ -1196,7 +1202,6 @@ __global__ void __launch_bounds__(SC_T) cuboid_sweep_score(const Unit *units, in
     const int sg = (G & 7) == 0 ? (b & 7) * (G >> 3) + (b >> 3) : b; // neighbouring segments on one XCD
     const ScoreSeg s0 = seg[sg], s1 = seg[sg + 1];
     if (s0.unit >= n_units || (s0.unit == s1.unit && s0.task >= s1.task)) return;
-    const long dbg_t0 = wall_clock64(); int dbg_tasks = 0, dbg_units = 0;
     const int u_last = s1.task > 0 ? s1.unit : s1.unit - 1; // last unit this segment touches
     const bool backwards = sg & 1;
     const int n_pos = u_last - s0.unit + 1;
@@ -1218,9 +1223,8 @@ __global__ void __launch_bounds__(SC_T) cuboid_sweep_score(const Unit *units, in
         int t0, t1, n1, c1, c2;
         task_range(u, t0, t1, n1, c1, c2);
         const int A = U.roi_w * U.roi_h;
-        dbg_units++; dbg_tasks += t1 - t0;
         __syncthreads(); // every wave is done with the previous unit's map
-        if (!(mode & 2)) { // copy the code map, SC_PFB 16-byte loads per thread in flight
+        { // copy the code map, SC_PFB 16-byte loads per thread in flight
             const int A8 = (A + 7) >> 3; // slices are padded to 64 pixels
             const uint4 *cm4 = reinterpret_cast<const uint4 *>(codes + U.pix_off);
             uint4 *lm4 = reinterpret_cast<uint4 *>(lmap);
@@ -1232,7 +1236,7 @@ __global__ void __launch_bounds__(SC_T) cuboid_sweep_score(const Unit *units, in
 #pragma unroll
                 for (int r = 0; r < SC_PFB; r++) lm4[min(k0 + r * SC_T, A8 - 1)] = pf[r];
             }
-        } else for (int k = tid; k < A; k += SC_T) lmap[k] = 0x0101; // experiment: scoring alone
+        }
         if (tid == 0) ctrl[0] = t0;
         __syncthreads();
         {
@@ -1240,7 +1244,7 @@ __global__ void __launch_bounds__(SC_T) cuboid_sweep_score(const Unit *units, in
             for (int k = tid; k < U.roi_w + 2; k += SC_T) lmap[A + k] = lastc; // D2: indices past the map read its last pixel
         }
         __syncthreads();
-        if (!(mode & 1)) for (;;) { // waves pull tasks of 64 proposals of one configuration
+        for (;;) { // waves pull tasks of 64 proposals of one configuration
             int t = 0;
             if (lane == 0) t = atomicAdd(&ctrl[0], 1);
             t = __builtin_amdgcn_readfirstlane(t);
@@ -1249,10 +1253,6 @@ __global__ void __launch_bounds__(SC_T) cuboid_sweep_score(const Unit *units, in
             else sc_score_task<2>(U, (t - n1) << 6, c2, lane, vpt, corners, hyp_total, vlist, lmap, derr, aerr);
         }
     }
-    if ((mode & 8) && b < 4096) {
-        __syncthreads();
-        if (tid == 0) { g_sc_dbg[b * 4] = dbg_t0; g_sc_dbg[b * 4 + 1] = wall_clock64(); g_sc_dbg[b * 4 + 2] = dbg_tasks; g_sc_dbg[b * 4 + 3] = dbg_units; }
-    }
 }
 
 // cuboid_sweep_score_big: the units cuboid_sweep_score cannot take (ROI larger than one CU's LDS, or an escape pixel), from the float map
@@ -1260,7 +1260,7 @@ __global__ void __launch_bounds__(SC_T) cuboid_sweep_score(const Unit *units, in
 // one configuration, its threads evaluate (proposal, sample) pairs with every gather independent, the values go through LDS and one thread
 // per proposal adds them in the reference's order; the six edge angles of a proposal are computed by six threads.
 template <int CFG> __device__ __forceinline__ void sc_big_item(const Unit &U, int first, int count, const VPEntry *vpt, const float *dist, const double *corners, long hyp_total,
-                                                               const int *vlist, double *derr, double *aerr, double (*s_c)[16], float (*s_v)[100], double (*s_a)[6], int *s_h) {
+                                                               const int *vlist, double *derr, double *aerr, double (*s_c)[16], float (*s_v)[100], double (*s_a)[6], int *s_h, const double *s_s10) {
     constexpr int NS = CFG == 1 ? 99 : 77;
     const int tid = threadIdx.x, n = min(SC_BIG_P, count - first);
     __syncthreads();
@@ -1274,18 +1274,29 @@ template <int CFG> __device__ __forceinline__ void sc_big_item(const Unit &U, in
     const float *dm = dist + U.pix_off;
     const int w = U.roi_w, last = U.roi_w * U.roi_h - 1;
     const double rx = (double)U.roi_x, ry = (double)U.roi_y;
-    for (int i = tid; i < n * NS; i += 256) {
-        const int p = i / NS, k = i - p * NS, e = k / 11, si = k - e * 11;
-        const int ia = CFG == 1 ? c_vis1[e][0] : c_vis2[e][0], ib = CFG == 1 ? c_vis1[e][1] : c_vis2[e][1];
-        const double x1 = s_c[p][ia] - rx, y1 = s_c[p][8 + ia] - ry, x2 = s_c[p][ib] - rx, y2 = s_c[p][8 + ib] - ry; // :423-425
-        const double s = (double)si;
-        const double px = s / 10.0 * x1 + (1 - s / 10.0) * x2;
-        const double py = s / 10.0 * y1 + (1 - s / 10.0) * y2;
-        int idx = __mul24(int(py), w) + int(px);
-        idx = min(max(idx, 0), last); // D2
-        float d = dm[idx];
-        if (CFG == 2) d = d * ((e == 4 || e == 5) ? 1.5f : (e == 6 ? 2.0f : 1.0f));
-        s_v[p][k] = d;
+    constexpr int IT = 4; // samples per thread and round: the index computations first, then the gathers in flight together
+#pragma unroll 1
+    for (int i0 = tid; i0 < n * NS; i0 += IT * 256) {
+        int sidx[IT], slot[IT];
+        float sw[IT], sv[IT];
+#pragma unroll
+        for (int r = 0; r < IT; r++) {
+            const int i = i0 + r * 256;
+            const int p = min(i / NS, n - 1), k = i - (i / NS) * NS, e = k / 11, si = k - e * 11;
+            const int ia = CFG == 1 ? c_vis1[e][0] : c_vis2[e][0], ib = CFG == 1 ? c_vis1[e][1] : c_vis2[e][1];
+            const double x1 = s_c[p][ia] - rx, y1 = s_c[p][8 + ia] - ry, x2 = s_c[p][ib] - rx, y2 = s_c[p][8 + ib] - ry; // :423-425
+            const double sa = s_s10[si], sb = 1 - sa; // s / 10.0 and 1 - s / 10.0 as the reference computes them
+            const double px = sa * x1 + sb * x2;
+            const double py = sa * y1 + sb * y2;
+            const int idx = __mul24(int(py), w) + int(px);
+            sidx[r] = min(max(idx, 0), last); // D2
+            slot[r] = i < n * NS ? p * 100 + k : -1;
+            sw[r] = CFG == 2 ? ((e == 4 || e == 5) ? 1.5f : (e == 6 ? 2.0f : 1.0f)) : 1.0f;
+        }
+#pragma unroll
+        for (int r = 0; r < IT; r++) sv[r] = dm[sidx[r]];
+#pragma unroll
+        for (int r = 0; r < IT; r++) if (slot[r] >= 0) (&s_v[0][0])[slot[r]] = CFG == 2 ? sv[r] * sw[r] : sv[r];
     }
     for (int i = tid; i < n * 6; i += 256) {
         const int p = i / 6, k = i - p * 6, vp = k >> 1, ee = k & 1;
@@ -1310,18 +1321,20 @@ template <int CFG> __device__ __forceinline__ void sc_big_item(const Unit &U, in
         aerr[g] = total;
     }
 }
-__global__ void __launch_bounds__(256) cuboid_sweep_score_big(const Unit *units, const BigItem *big, const int *big_n, const VPEntry *vpt, const float *dist,
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) cuboid_sweep_score_big(const Unit *units, const BigItem *big, const int *big_n, const VPEntry *vpt, const float *dist,
                                                               const double *corners, long hyp_total, const int *vcount, const int *vlist, double *derr, double *aerr) {
     __shared__ double s_c[SC_BIG_P][16];
     __shared__ float s_v[SC_BIG_P][100];
     __shared__ double s_a[SC_BIG_P][6];
     __shared__ int s_h[SC_BIG_P];
+    __shared__ double s_s10[11];
+    if (threadIdx.x < 11) s_s10[threadIdx.x] = (double)threadIdx.x / 10.0; // sample_ind / 10.0, object_3d_util.cpp:439
     const int n_items = *big_n;
     for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
         const BigItem I = big[it];
         const Unit &U = units[I.unit];
-        if (I.cfg == 1) sc_big_item<1>(U, I.first, vcount[2 * I.unit], vpt, dist, corners, hyp_total, vlist, derr, aerr, s_c, s_v, s_a, s_h);
-        else sc_big_item<2>(U, I.first, vcount[2 * I.unit + 1], vpt, dist, corners, hyp_total, vlist, derr, aerr, s_c, s_v, s_a, s_h);
+        if (I.cfg == 1) sc_big_item<1>(U, I.first, vcount[2 * I.unit], vpt, dist, corners, hyp_total, vlist, derr, aerr, s_c, s_v, s_a, s_h, s_s10);
+        else sc_big_item<2>(U, I.first, vcount[2 * I.unit + 1], vpt, dist, corners, hyp_total, vlist, derr, aerr, s_c, s_v, s_a, s_h, s_s10);
     }
 }
 
@@ -1967,19 +1980,13 @@ int cs_cuboid_batch_run(cs_ctx *ctx, cs_cuboid_batch *b) {
     CS_LAUNCH(ctx, "cuboid_score_plan", cuboid_score_plan, dim3(1), dim3(1024), 0, b->d_units, U, b->d_vcount, b->d_uflag, b->d_score_cost, b->d_score_seg, b->score_G,
               b->d_big, b->d_big_n);
     CS_LAUNCH(ctx, "cuboid_sweep_score", cuboid_sweep_score, dim3(b->score_G), dim3(SC_T), SC_LDS_BYTES, b->d_units, U, b->d_score_seg, b->score_G, b->d_vp,
-              b->d_codes, b->d_corners, b->hyp_total, b->d_vcount, b->d_uflag, b->d_vlist, b->d_derr, b->d_aerr, getenv("CUBESLAM_SCORE_MODE") ? atoi(getenv("CUBESLAM_SCORE_MODE")) : 0);
-    CS_LAUNCH(ctx, "cuboid_sweep_score_big", cuboid_sweep_score_big, dim3(1024), dim3(256), 0, b->d_units, b->d_big, b->d_big_n, b->d_vp, b->d_dist, b->d_corners,
+              b->d_codes, b->d_corners, b->hyp_total, b->d_vcount, b->d_uflag, b->d_vlist, b->d_derr, b->d_aerr);
+    CS_LAUNCH(ctx, "cuboid_sweep_score_big", cuboid_sweep_score_big, dim3(4096), dim3(256), 0, b->d_units, b->d_big, b->d_big_n, b->d_vp, b->d_dist, b->d_corners,
               b->hyp_total, b->d_vcount, b->d_vlist, b->d_derr, b->d_aerr);
     CS_LAUNCH(ctx, "cuboid_select", cuboid_select, dim3(b->n_boxes), dim3(256), 0, b->d_units, b->d_ud, b->d_box_first, b->d_fd, b->d_fi,
               b->d_cam, b->d_yaw, b->cal, b->o, b->d_flag, b->d_derr, b->d_aerr, b->d_corners, b->hyp_total, b->d_score, b->d_nscore,
               b->d_ckd, b->d_cka, b->d_cidx, b->d_out, b->d_counts);
     CS_HIP(ctx, hipGetLastError());
-    return CS_OK;
-}
-
-int cs_debug_score_dbg(cs_ctx *ctx, long *out, int n) { // experiment helper (tools/score_dbg.py), not part of the C-ABI header
-    CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    CS_HIP(ctx, hipMemcpyFromSymbol(out, HIP_SYMBOL(g_sc_dbg), sizeof(long) * 4 * (size_t)n));
     return CS_OK;
 }
 

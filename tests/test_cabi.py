@@ -81,10 +81,12 @@ def test_short_edge_threshold_without_sqrt():
 
 
 def test_chamfer_code_number_theory():
-    """cuboid_sweep_score_lds (cuboid.hip) stores a chamfer value t = i*62587 + j*89738 (t * 2^-16 px) as the 16-bit code i | j << 8 and
-    recovers (i, j) from t with one float FMA, a 978-entry table and a verification.  The facts its encoder relies on: the 256 residues
-    j*89738 mod 62587 fall into distinct 64-wide buckets (they are >= 97 apart), floor(t / 62587) comes out right from
-    float(t) * float(1/62587) + 0.0005 for every representable pair, and i = floor(t/62587) - floor(j*89738/62587)."""
+    """cuboid_dt_codes (cuboid.hip) stores a chamfer value t = i*62587 + j*89738 (t * 2^-16 px) as the 16-bit code i | j << 8 for
+    cuboid_sweep_score and recovers (i, j) from t with one float FMA and a 978-entry table.  The facts its encoder relies on: the 256
+    residues j*89738 mod 62587 fall into distinct 64-wide buckets (they are >= 97 apart), floor(t / 62587) comes out right from
+    float(t) * float(1/62587) + 0.0005 for every representable pair, i = floor(t/62587) - floor(j*89738/62587), the table entry
+    (j << 8) - floor(j*89738/62587) fits 16 bits, d < 244 px bounds i <= 255 and j <= 178, and the decode fma(j, 89738 * 2^-16,
+    i * 62587 * 2^-16) in float equals float(t) * 2^-16."""
     a, b = 62587, 89738
     res = [(j * b) % a for j in range(256)]
     assert len({r >> 6 for r in res}) == 256 and max(r >> 6 for r in res) < (a + 63) // 64
@@ -99,4 +101,12 @@ def test_chamfer_code_number_theory():
     assert np.array_equal(qn[ok], (t // a)[ok]) and np.array_equal(qn32[ok], (t // a)[ok])
     assert np.array_equal((t // a - (J * b) // a)[ok], I[ok]) and ((J * b) // a).max() < 1 << 16
     assert 255 * a + 255 * b >= 1 << 24, "the escape code (255, 255) decodes above every valid t"
+    lut = (np.arange(256) << 8) - (np.arange(256) * b) // a
+    assert lut.min() >= 0 and lut.max() < 1 << 16
+    assert np.array_equal((t // a + lut[J])[ok], (I | (J << 8))[ok]), "code = qn + lut[bucket of the residue]"
+    near = t < 244 * 65536  # what the encoder accepts (farther pixels become the escape code)
+    assert I[near].max() <= 255 and J[near].max() <= 178
+    assert np.array_equal((I.astype(np.float32) * np.float32(a / 65536.0)).astype(np.float64), I * (a / 65536.0)), "float(i) * HV * 2^-16 is exact"
+    dec = J * (b / 65536.0) + I * (a / 65536.0)  # the fused multiply-add: exact in double, rounded to float once
+    assert np.array_equal(dec.astype(np.float32)[near], (tf * np.float32(1.0 / 65536.0))[near])
     assert np.array_equal((tf * np.float32(1.0 / 65536.0))[ok].astype(np.float64), t[ok] / 65536.0), "decode: float(t) * 2^-16 is exact"
