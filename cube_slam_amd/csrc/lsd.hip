@@ -5,7 +5,7 @@
 //   lsd_blur_hv               GaussianBlur(7x7, sigma 0.75) u8 -> double, REFLECT_101, symmetric summation order, both passes fused
 //   lsd_resize                cv::resize(0.8, 0.8, INTER_LINEAR) on CV_64F with float coefficients (tables from the host)
 //   lsd_gradient              ll_angle (:538-585): 2x2 gradient, norm, level-line angle via cv::fastAtan2, NOTDEF below rho
-// Host, per frame (OpenMP across frames): 1024-bin pseudo-ordering (:588-634) and the sequential part of the algorithm --
+// Host, per frame (OpenMP across frames): the sequential part of the algorithm, seeds in address order (see LsdHost::run) --
 // region_grow (each accepted pixel updates the region angle that the next test uses, :665-683), region2rect, refine,
 // rect_improve, rect_nfa, nfa -- which has no order-preserving parallel form.  Double precision as in the reference.
 #include "common.h"
@@ -428,8 +428,6 @@ class LsdHost {
     bool timed = false;
     double t_sort = 0, t_grow = 0, t_rect = 0; long n_seeds = 0, n_regions = 0, n_pix = 0; // stage timers (ms) of this thread, reported by the caller
     std::vector<double> dang, dmod; // dense maps of this thread, NOTDEF / untouched outside the current frame's defined pixels
-    std::vector<int> order;
-    int cnt[1025];
     // flsd :464-535 (LSD_REFINE_ADV, scale 0.8): segments as x1 y1 x2 y2 floats.  Input: the frame's defined pixels in address
     // order (the undefined ones are skipped by the reference's seed loop and fail every alignment test, so they never matter).
     void run(int w_, int h_, int ne, const int *e_addr, const double *e_ang, const double *e_mod, std::vector<float> &lines) {
@@ -439,26 +437,21 @@ class LsdHost {
         if (dang.size() != n) { dang.assign(n, NOTDEF); dmod.assign(n, 0.0); used.assign(n, 2); rx.resize(n); ry.resize(n); rang.resize(n); rmod.resize(n); }
         angles = dang.data(); modgrad = dmod.data();
         const double prec = PI_ * 22.5 / 180, p = 22.5 / 180;
-        // pseudo-ordering (:588-634): 1024 bins by gradient norm, descending bins, pixel (address) order inside a bin
-        double max_grad = -1;
+        // Seed order = address order.  ll_angle links the 1024-bin pseudo-ordering through `next` pointers (:588-634), but flsd walks the
+        // `list` vector by index (:477-480) and its entries were appended in raster order: the gradient ordering has no effect on the
+        // reference's output (established by running the reference's own lsd.cpp: oracle/_ref, tests/test_ref_pins.py).
         constexpr int PFD = 24; // the scatter is sparse in three maps of 1.5 MB + 1.5 MB + 0.2 MB: ask for the lines a few entries ahead
         for (int i = 0; i < ne; i++) {
             if (i + PFD < ne) { const int a = e_addr[i + PFD]; __builtin_prefetch(&dang[a], 1); __builtin_prefetch(&dmod[a], 1); __builtin_prefetch(&used[a], 1); }
-            dang[e_addr[i]] = e_ang[i]; dmod[e_addr[i]] = e_mod[i]; used[e_addr[i]] = 0; if (e_mod[i] > max_grad) max_grad = e_mod[i];
+            dang[e_addr[i]] = e_ang[i]; dmod[e_addr[i]] = e_mod[i]; used[e_addr[i]] = 0;
         }
-        const double bin_coef = (max_grad > 0) ? double(1024 - 1) / max_grad : 0;
-        for (int i = 0; i < 1025; i++) cnt[i] = 0;
-        for (int i = 0; i < ne; i++) cnt[1023 - int(e_mod[i] * bin_coef) + 1]++;
-        for (int i = 0; i < 1024; i++) cnt[i + 1] += cnt[i];
-        order.resize((size_t)ne);
-        for (int i = 0; i < ne; i++) order[cnt[1023 - int(e_mod[i] * bin_coef)]++] = e_addr[i];
         LOG_NT = 5 * (std::log10(double(w)) + std::log10(double(h))) / 2 + std::log10(11.0);
         const int min_reg_size = int(-LOG_NT / std::log10(p));
         lines.clear();
         const double *ang = angles;
         if (timed) t_sort += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tt0).count();
-        for (size_t i = 0; i < order.size(); ++i) {
-            const int adx = order[i];
+        for (int i = 0; i < ne; ++i) {
+            const int adx = e_addr[i];
             if (used[adx] != 0 || ang[adx] == NOTDEF) continue;
             int rn; double reg_angle;
             const auto tg0 = timed ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();

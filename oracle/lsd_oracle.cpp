@@ -9,6 +9,7 @@
  * LineIterator::count (8-connected, rounded end points).  Quirks kept: integer division and `tailp->p.x` in rect_nfa.
  */
 #include "oracle.h"
+#include "cv_prims.h"
 
 #include <algorithm>
 #include <cfloat>
@@ -33,6 +34,44 @@ static float fastAtan2(float y, float x) {
 }
 static inline int reflect101(int p, int len) { if (len == 1) return 0; while (p < 0 || p >= len) { if (p < 0) p = -p; else p = 2 * len - 2 - p; } return p; }
 
+// cv::GaussianBlur on CV_64F: getGaussianKernel(ksize, sigma, CV_64F), separable, rows then columns, symmetric taps summed pairwise
+// (SymmRowFilter / SymmColumnFilter), BORDER_REFLECT_101
+static void gaussian_blur_f64(const double *src, int W, int H, int ks, double sigma, double *dst) {
+    const int hk = ks / 2;
+    std::vector<double> k(ks);
+    { double sum = 0, scale2X = -0.5 / (sigma * sigma); for (int i = 0; i < ks; i++) { double x = i - (ks - 1) * 0.5; k[i] = std::exp(scale2X * x * x); sum += k[i]; } sum = 1. / sum; for (int i = 0; i < ks; i++) k[i] *= sum; }
+    std::vector<double> tmp((size_t)W * H);
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            double s = k[hk] * src[(size_t)y * W + x];
+            for (int t = 1; t <= hk; t++) s += k[hk + t] * (src[(size_t)y * W + reflect101(x - t, W)] + src[(size_t)y * W + reflect101(x + t, W)]);
+            tmp[(size_t)y * W + x] = s;
+        }
+    for (int y = 0; y < H; y++)
+        for (int x = 0; x < W; x++) {
+            double s = k[hk] * tmp[(size_t)y * W + x];
+            for (int t = 1; t <= hk; t++) s += k[hk + t] * (tmp[(size_t)reflect101(y - t, H) * W + x] + tmp[(size_t)reflect101(y + t, H) * W + x]);
+            dst[(size_t)y * W + x] = s;
+        }
+}
+// cv::resize(INTER_LINEAR) on CV_64F: float coefficients, double accumulation (HResizeLinear<double,double,float>, VResizeLinear)
+// scale_x, scale_y: 1 / fx, 1 / fy when the caller gave factors (cv::resize keeps them: inv_scale = fx), source / destination size otherwise
+static void resize_linear_f64(const double *src, int W, int H, double *dst, int w, int h, double scale_x, double scale_y) {
+    std::vector<int> xofs(w), yofs(h);
+    std::vector<float> ax((size_t)w * 2), ay((size_t)h * 2);
+    for (int dx = 0; dx < w; dx++) { float fx = (float)((dx + 0.5) * scale_x - 0.5); int sx = cvFloor(fx); fx -= sx; if (sx < 0) { fx = 0; sx = 0; } if (sx >= W - 1) { fx = 0; sx = W - 1; } xofs[dx] = sx; ax[dx * 2] = 1.f - fx; ax[dx * 2 + 1] = fx; }
+    for (int dy = 0; dy < h; dy++) { float fy = (float)((dy + 0.5) * scale_y - 0.5); int sy = cvFloor(fy); fy -= sy; if (sy < 0) { fy = 0; sy = 0; } if (sy >= H - 1) { fy = 0; sy = H - 1; } yofs[dy] = sy; ay[dy * 2] = 1.f - fy; ay[dy * 2 + 1] = fy; }
+    for (int dy = 0; dy < h; dy++) {
+        const int sy0 = yofs[dy], sy1 = std::min(sy0 + 1, H - 1);
+        for (int dx = 0; dx < w; dx++) {
+            const int sx0 = xofs[dx], sx1 = std::min(sx0 + 1, W - 1);
+            const double r0 = src[(size_t)sy0 * W + sx0] * ax[dx * 2] + src[(size_t)sy0 * W + sx1] * ax[dx * 2 + 1];
+            const double r1 = src[(size_t)sy1 * W + sx0] * ax[dx * 2] + src[(size_t)sy1 * W + sx1] * ax[dx * 2 + 1];
+            dst[(size_t)dy * w + dx] = r0 * ay[dy * 2] + r1 * ay[dy * 2 + 1];
+        }
+    }
+}
+
 struct Rect { double x1, y1, x2, y2, width, x, y, theta, dx, dy, prec, p; };
 struct RegionPoint { int x, y; double angle, modgrad; };
 
@@ -48,39 +87,12 @@ struct LSD {
     void prepare(const uint8_t *gray, int W, int H) { // flsd :440-462: GaussianBlur + resize, then ll_angle
         const double sigma = SIGMA_SCALE / SCALE, sprec = 3;
         const int hk = (int)(std::ceil(sigma * std::sqrt(2 * sprec * std::log(10.0))));
-        const int ks = 1 + 2 * hk;
-        std::vector<double> k(ks);
-        { double sum = 0, scale2X = -0.5 / (sigma * sigma); for (int i = 0; i < ks; i++) { double x = i - (ks - 1) * 0.5; k[i] = std::exp(scale2X * x * x); sum += k[i]; } sum = 1. / sum; for (int i = 0; i < ks; i++) k[i] *= sum; }
-        std::vector<double> tmp((size_t)W * H), blur((size_t)W * H);
-        for (int y = 0; y < H; y++)
-            for (int x = 0; x < W; x++) {
-                double s = k[hk] * gray[(size_t)y * W + x];
-                for (int t = 1; t <= hk; t++) s += k[hk + t] * ((double)gray[(size_t)y * W + reflect101(x - t, W)] + (double)gray[(size_t)y * W + reflect101(x + t, W)]);
-                tmp[(size_t)y * W + x] = s;
-            }
-        for (int y = 0; y < H; y++)
-            for (int x = 0; x < W; x++) {
-                double s = k[hk] * tmp[(size_t)y * W + x];
-                for (int t = 1; t <= hk; t++) s += k[hk + t] * (tmp[(size_t)reflect101(y - t, H) * W + x] + tmp[(size_t)reflect101(y + t, H) * W + x]);
-                blur[(size_t)y * W + x] = s;
-            }
-        // resize(gaussian_img, scaled_image, Size(), SCALE, SCALE): INTER_LINEAR, CV_64F, float coefficients
-        w = cvRound(W * SCALE); h = cvRound(H * SCALE);
-        const double scale_x = 1. / SCALE, scale_y = 1. / SCALE;
-        std::vector<int> xofs(w), yofs(h);
-        std::vector<float> ax((size_t)w * 2), ay((size_t)h * 2);
-        for (int dx = 0; dx < w; dx++) { float fx = (float)((dx + 0.5) * scale_x - 0.5); int sx = cvFloor(fx); fx -= sx; if (sx < 0) { fx = 0; sx = 0; } if (sx >= W - 1) { fx = 0; sx = W - 1; } xofs[dx] = sx; ax[dx * 2] = 1.f - fx; ax[dx * 2 + 1] = fx; }
-        for (int dy = 0; dy < h; dy++) { float fy = (float)((dy + 0.5) * scale_y - 0.5); int sy = cvFloor(fy); fy -= sy; if (sy < 0) { fy = 0; sy = 0; } if (sy >= H - 1) { fy = 0; sy = H - 1; } yofs[dy] = sy; ay[dy * 2] = 1.f - fy; ay[dy * 2 + 1] = fy; }
+        std::vector<double> img((size_t)W * H), blur((size_t)W * H);
+        for (size_t i = 0; i < img.size(); i++) img[i] = gray[i]; // img.convertTo(image, CV_64FC1), :421
+        gaussian_blur_f64(img.data(), W, H, 1 + 2 * hk, sigma, blur.data());
+        w = cvRound(W * SCALE); h = cvRound(H * SCALE); // resize(gaussian_img, scaled_image, Size(), SCALE, SCALE)
         scaled.resize((size_t)w * h);
-        for (int dy = 0; dy < h; dy++) {
-            const int sy0 = yofs[dy], sy1 = std::min(sy0 + 1, H - 1);
-            for (int dx = 0; dx < w; dx++) {
-                const int sx0 = xofs[dx], sx1 = std::min(sx0 + 1, W - 1);
-                const double r0 = blur[(size_t)sy0 * W + sx0] * ax[dx * 2] + blur[(size_t)sy0 * W + sx1] * ax[dx * 2 + 1];
-                const double r1 = blur[(size_t)sy1 * W + sx0] * ax[dx * 2] + blur[(size_t)sy1 * W + sx1] * ax[dx * 2 + 1];
-                scaled[(size_t)dy * w + dx] = r0 * ay[dy * 2] + r1 * ay[dy * 2 + 1];
-            }
-        }
+        resize_linear_f64(blur.data(), W, H, scaled.data(), w, h, 1. / SCALE, 1. / SCALE);
         ll_angle();
     }
 
@@ -97,13 +109,14 @@ struct LSD {
                 if (norm <= threshold) angles[addr] = NOTDEF;
                 else { angles[addr] = fastAtan2(float(gx), float(-gy)) * DEG_TO_RADS; if (norm > max_grad) max_grad = norm; }
             }
-        // bucket sort by gradient norm, largest bin first, insertion order inside a bin (:588-634)
-        const double bin_coef = (max_grad > 0) ? double(N_BINS - 1) / max_grad : 0;
-        std::vector<std::vector<int>> bins(N_BINS);
-        for (int y = 0; y < h - 1; ++y)
-            for (int x = 0; x < w - 1; ++x) bins[int(modgrad[(size_t)y * w + x] * bin_coef)].push_back(x + y * w);
+        // Seed order.  ll_angle builds the 1024-bin pseudo-ordering as `next` links between the entries of `list` (:588-634), but flsd then
+        // walks `list` BY INDEX (:477-480), and the entries were appended in raster order (:600-617): the seeds are visited in raster order
+        // over x < w-1, y < h-1 and the gradient ordering has no effect (the trailing, never-filled entries are (0,0), used by then).
+        // Found by running the reference's own lsd.cpp (oracle/_ref, tests/test_ref_pins.py); round 1 had restated the intended ordering.
+        (void)max_grad;
         order.clear();
-        for (int i = N_BINS - 1; i >= 0; --i) order.insert(order.end(), bins[i].begin(), bins[i].end());
+        for (int y = 0; y < h - 1; ++y)
+            for (int x = 0; x < w - 1; ++x) order.push_back(x + y * w);
     }
 
     inline bool isAligned(int address, double theta, double prec) const { // :1138-1154
@@ -408,3 +421,9 @@ int orc_lsd_maps(const uint8_t *gray, int W, int H, int *sw, int *sh, double *sc
 }
 
 } // extern "C"
+
+// the OpenCV restatements above, for oracle/ref_shim (cv_prims.h)
+namespace orc_cv {
+void gaussian_blur_f64(const double *src, int w, int h, int ksize, double sigma, double *dst) { ::gaussian_blur_f64(src, w, h, ksize, sigma, dst); }
+void resize_linear_f64(const double *src, int sw, int sh, double *dst, int dw, int dh, double scale_x, double scale_y) { ::resize_linear_f64(src, sw, sh, dst, dw, dh, scale_x, scale_y); }
+}

@@ -17,6 +17,7 @@
  *     with a fixed polynomial, so that CPU and GPU agree bit for bit).
  */
 #include "oracle.h"
+#include "cv_prims.h"
 
 #include <algorithm>
 #include <cfloat>
@@ -565,3 +566,11 @@ float orc_fast_atan2(float y, float x) { return fastAtan2(y, x); }
 void orc_sincos_f(float angle_rad, float *s, float *c) { sincos_f(angle_rad, s, c); }
 
 } // extern "C"
+
+// the OpenCV restatements above, for oracle/ref_shim (cv_prims.h)
+namespace orc_cv {
+void resize_linear_u8(const uint8_t *src, int sw, int sh, uint8_t *dst, int dw, int dh) { ::resize_linear_u8(src, sw, sh, dst, dw, dh); }
+void gaussian_blur7_u8(const uint8_t *src, int w, int h, uint8_t *dst) { ::gaussian_blur7_u8(src, w, h, dst); }
+int reflect101(int p, int len) { return ::reflect101(p, len); }
+}
+
