@@ -468,3 +468,10 @@ int orc_search_by_bow_kf(const orc_frame *K1, const int *node1, const uint8_t *s
     }
     return nmatches;
 }
+
+extern "C" void orc_three_maxima(const int *counts, int L, int *ind) { /* ComputeThreeMaxima over histogram bins holding counts[i] entries */
+    std::vector<std::vector<int>> histo(L);
+    for (int i = 0; i < L; i++) histo[i].resize(counts[i]);
+    ind[0] = ind[1] = ind[2] = -1;
+    three_maxima(histo.data(), L, ind[0], ind[1], ind[2]);
+}

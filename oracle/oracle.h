@@ -142,6 +142,7 @@ typedef struct orc_frame {      /* the parts of ORB_SLAM2::Frame the matchers re
 } orc_frame;
 
 int orc_descriptor_distance(const uint8_t *a, const uint8_t *b);                 /* ORBmatcher.cc:1905-1921 */
+void orc_three_maxima(const int *counts, int L, int *ind /*3*/);                  /* ORBmatcher::ComputeThreeMaxima :1860-1901 on bin sizes */
 int orc_get_features_in_area(const orc_frame *F, float x, float y, float r, int minLevel, int maxLevel, int *out, int cap);
 /* SearchByProjection(Frame &Cur, const Frame &Last, th, bMono=true) (:1373-1522).  Per last-frame keypoint: valid (has a
  * non-outlier, non-dynamic map point), world_pos (float xyz), the map point's descriptor, its octave and angle; blocks[i]

@@ -83,3 +83,72 @@ def test_lsd_equals_reference(ref, oracle):
         assert m >= n  # detectImpl drops segments along the image border
         total += n
     assert total > 300
+
+
+def _dp(a):
+    return a.ctypes.data_as(C.c_void_p)
+
+
+def test_cuboid_scoring_functions_equal_reference(ref, oracle):
+    """box_edge_sum_dists, box_edge_alignment_angle_error, fuse_normalize_scores_v2, merge_break_lines (object_3d_util.cpp:300-565) with
+    atan2_vector / fast_RemoveRow / sort_indexes / normalize_to_pi -- the reference's own definitions, cut out of its files at build time
+    and compiled against a coefficient-wise stand-in for the Eigen types -- against the oracle: identical doubles on seeded inputs."""
+    ref.ref_box_edge_sum_dists.restype = C.c_double
+    ref.ref_box_edge_angle_error.restype = C.c_double
+    lib = oracle.lib()
+    lib.orc_box_edge_sum_dists.restype = C.c_double
+    lib.orc_box_edge_angle_error.restype = C.c_double
+    rng = np.random.default_rng(20260924)
+    for it in range(300):
+        w, h = int(rng.integers(40, 300)), int(rng.integers(40, 300))
+        dm = np.ascontiguousarray(rng.uniform(0, 40, (h, w)).astype(np.float32))
+        corners = np.stack([rng.uniform(0, w - 1, 8), rng.uniform(0, h - 1, 8)])
+        if it % 3 == 0:
+            corners = np.floor(corners)  # integer corners: samples land exactly on pixel borders (the int() truncation case)
+        corners = np.ascontiguousarray(corners)
+        ang = rng.uniform(-np.pi / 2, np.pi / 2, (3, 2))
+        ang[rng.uniform(size=(3, 2)) < 0.3] = np.nan
+        ang = np.ascontiguousarray(ang)
+        for cfg in (1, 2):
+            a = ref.ref_box_edge_sum_dists(_dp(dm), w, h, _dp(corners), cfg)
+            b = lib.orc_box_edge_sum_dists(_dp(dm), w, h, _dp(corners), cfg)
+            assert a == b, (it, cfg, a, b)
+            a = ref.ref_box_edge_angle_error(_dp(ang), _dp(corners), cfg)
+            b = lib.orc_box_edge_angle_error(_dp(ang), _dp(corners), cfg)
+            assert a == b or (np.isnan(a) and np.isnan(b)), (it, cfg, a, b)
+    for it in range(200):
+        n = int(rng.integers(0, 60)) if it % 4 else int(rng.integers(0, 6))
+        d = rng.uniform(0, 5, n); a = rng.uniform(0, 2, n)
+        # no exact ties here: the reference keeps whatever std::partial_sort (libstdc++'s heap select) leaves in front, the oracle and the
+        # product break ties by index (pin D3, DESIGN.md) -- they differ only when bit-equal errors straddle the 2/3 cut
+        keep = np.zeros(max(n, 1), np.int32); sc = np.zeros(max(n, 1))
+        m = ref.ref_fuse_normalize_scores(_dp(d), _dp(a), n, C.c_double(0.8), 1, _dp(keep), _dp(sc))
+        ok, osc = oracle.fuse_normalize_scores(d, a, 0.8, True)
+        assert m == len(ok) and np.array_equal(keep[:m], ok) and np.array_equal(sc[:m], osc), it
+    for it in range(200):
+        n = int(rng.integers(1, 40))
+        x1 = rng.uniform(0, 600, n); y1 = rng.uniform(0, 400, n)
+        lines = np.stack([x1, y1, x1 + rng.uniform(1, 120, n), y1 + rng.uniform(-60, 60, n)], axis=1)
+        if it % 2:  # chains of nearly collinear pieces, so that merges happen
+            k = n // 2
+            lines[1:k + 1, 0] = lines[:k, 2] + rng.uniform(0, 8, k); lines[1:k + 1, 1] = lines[:k, 3] + rng.uniform(-2, 2, k)
+            lines[1:k + 1, 2] = lines[1:k + 1, 0] + (lines[:k, 2] - lines[:k, 0]); lines[1:k + 1, 3] = lines[1:k + 1, 1] + (lines[:k, 3] - lines[:k, 1])
+        lines = np.ascontiguousarray(lines)
+        out = np.zeros_like(lines)
+        m = ref.ref_merge_break_lines(_dp(lines), n, C.c_double(20.0), C.c_double(5.0), C.c_double(30.0), _dp(out))
+        o = oracle.merge_break_lines(lines, 20.0, 5.0, 30.0)
+        assert m == len(o) and np.array_equal(out[:m], o), it
+
+
+def test_matcher_primitives_equal_reference(ref, oracle):
+    """ORBmatcher::DescriptorDistance and ComputeThreeMaxima (ORBmatcher.cc:1860-1921), the reference's definitions."""
+    rng = np.random.default_rng(7)
+    for _ in range(2000):
+        a = rng.integers(0, 256, 32, dtype=np.uint8); b = rng.integers(0, 256, 32, dtype=np.uint8)
+        assert ref.ref_descriptor_distance(_dp(a), _dp(b)) == oracle.descriptor_distance(a, b) == int(np.unpackbits(a ^ b).sum())
+    for it in range(2000):
+        cnt = rng.integers(0, 12 if it % 2 else 200, 30).astype(np.int32)
+        r = np.zeros(3, np.int32); o = np.zeros(3, np.int32)
+        ref.ref_three_maxima(_dp(cnt), 30, _dp(r))
+        oracle.lib().orc_three_maxima(_dp(cnt), 30, _dp(o))
+        assert np.array_equal(r, o), (cnt, r, o)
