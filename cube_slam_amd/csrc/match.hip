@@ -445,7 +445,7 @@ int cs_matcher_features_in_area(cs_ctx *ctx, cs_matcher *m, float x, float y, fl
 
 int cs_match_by_projection_frame(cs_ctx *ctx, cs_matcher *m, int n_last, const float *world_pos, const uint8_t *valid, const uint8_t *blocks,
                                  const uint8_t *mp_desc, const int *last_octave, const float *last_angle, const float *Tcw, float fx, float fy, float cx,
-                                 float cy, const float *scale_factors, int n_levels, float th, int check_orientation, int *train_match, int *nmatches) {
+                                 float cy, const float *scale_factors, int n_levels, float th, int check_orientation, const uint8_t *train_blocked, int *train_match, int *nmatches) {
     if (!ctx || !m || n_last < 0 || n_last > m->max_q || !world_pos || !valid || !blocks || !mp_desc || !last_octave || !last_angle || !Tcw ||
         !scale_factors || n_levels < 1 || n_levels > 32 || !train_match || !nmatches)
         return CS_ERR_BAD_ARG;
@@ -474,6 +474,7 @@ int cs_match_by_projection_frame(cs_ctx *ctx, cs_matcher *m, int n_last, const f
         for (int p = b; p < e; p++) {
             const int i2 = m->cands[p].x;
             if (train_match[i2] >= 0 && blocks[train_match[i2]]) continue;
+            if (train_blocked && train_blocked[i2]) continue; // map point from before the call / KeysStatic[i2] == false, :1451-1457
             const int dist = m->cands[p].y;
             if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
         }

@@ -49,7 +49,7 @@ class ORBmatcher:
                                                               _p(out, C.c_int), len(out), C.byref(n)), "cs_matcher_features_in_area")
         return out[:n.value].copy()
 
-    def SearchByProjectionFrame(self, world_pos, valid, blocks, mp_desc, last_octave, last_angle, Tcw, fx, fy, cx, cy, scale_factors, th):
+    def SearchByProjectionFrame(self, world_pos, valid, blocks, mp_desc, last_octave, last_angle, Tcw, fx, fy, cx, cy, scale_factors, th, train_blocked=None):
         wp = np.ascontiguousarray(world_pos, np.float32); va = np.ascontiguousarray(valid, np.uint8); bl = np.ascontiguousarray(blocks, np.uint8)
         md = np.ascontiguousarray(mp_desc, np.uint8); lo = np.ascontiguousarray(last_octave, np.int32); la = np.ascontiguousarray(last_angle, np.float32)
         T = np.ascontiguousarray(Tcw, np.float32).reshape(-1)[:12].copy(); sf = np.ascontiguousarray(scale_factors, np.float32)
@@ -57,7 +57,8 @@ class ORBmatcher:
         check(self.ctx.ptr, lib().cs_match_by_projection_frame(self.ctx.ptr, self._m, len(va), _p(wp, C.c_float), _p(va, C.c_uint8), _p(bl, C.c_uint8),
                                                                _p(md, C.c_uint8), _p(lo, C.c_int), _p(la, C.c_float), _p(T, C.c_float), C.c_float(fx),
                                                                C.c_float(fy), C.c_float(cx), C.c_float(cy), _p(sf, C.c_float), len(sf), C.c_float(th),
-                                                               int(self.mbCheckOrientation), _p(tm, C.c_int), C.byref(n)), "cs_match_by_projection_frame")
+                                                               int(self.mbCheckOrientation), None if train_blocked is None else _p(np.ascontiguousarray(train_blocked, np.uint8), C.c_uint8),
+                                                               _p(tm, C.c_int), C.byref(n)), "cs_match_by_projection_frame")
         return tm[:self.N].copy(), n.value
 
     def SearchByProjectionLocalMap(self, proj_xy, view_cos, pred_level, in_view, blocks, mp_desc, scale_factors, th, train_blocked=None):

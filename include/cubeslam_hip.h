@@ -206,11 +206,13 @@ int cs_matcher_features_in_area(cs_ctx *ctx, cs_matcher *m, float x, float y, fl
 /* ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, th, bMono=true) (ORBmatcher.cc:1373-1522).
  * Per last-frame keypoint i: valid[i] (map point present, not outlier/dynamic), world_pos (float xyz), blocks[i] (map point
  * has Observations() > 0), the map point descriptor, LastFrame.mvKeys[i].octave and mvKeysUn[i].angle.  Tcw: 3x4 float
- * row-major.  train_match[N] receives the last-frame index matched to each current keypoint or -1. */
+ * row-major.  train_blocked (N bytes, may be NULL): current-frame keypoints a candidate loop must skip -- the ones that already carry a
+ * map point with Observations() > 0 before the call, and, in dynamic-object mode, the ones with KeysStatic[i2] == false
+ * (ORBmatcher.cc:1451-1457).  train_match[N] receives the last-frame index matched to each current keypoint or -1. */
 int cs_match_by_projection_frame(cs_ctx *ctx, cs_matcher *m, int n_last, const float *world_pos, const uint8_t *valid,
                                  const uint8_t *blocks, const uint8_t *mp_desc, const int *last_octave, const float *last_angle,
                                  const float *Tcw, float fx, float fy, float cx, float cy, const float *scale_factors, int n_levels,
-                                 float th, int check_orientation, int *train_match, int *nmatches);
+                                 float th, int check_orientation, const uint8_t *train_blocked, int *train_match, int *nmatches);
 /* ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*>&, th) (:50-142). */
 int cs_match_local_map(cs_ctx *ctx, cs_matcher *m, int n_mp, const float *proj_xy, const float *view_cos, const int *pred_level,
                        const uint8_t *in_view, const uint8_t *blocks, const uint8_t *mp_desc, const float *scale_factors, int n_levels,

@@ -102,7 +102,7 @@ int orc_get_features_in_area(const orc_frame *F, float x, float y, float r, int 
 
 int orc_search_by_projection_frame(const orc_frame *cur, int n_last, const float *world_pos, const uint8_t *valid, const uint8_t *blocks,
                                    const uint8_t *mp_desc, const int *last_octave, const float *last_angle, const float *T, float fx, float fy,
-                                   float cx, float cy, const float *scale_factors, float th, int check_orientation, int *train_match) {
+                                   float cx, float cy, const float *scale_factors, float th, int check_orientation, const uint8_t *train_blocked, int *train_match) {
     Grid g(cur);
     int nmatches = 0;
     std::vector<int> rotHist[HISTO_LENGTH];
@@ -130,7 +130,8 @@ int orc_search_by_projection_frame(const orc_frame *cur, int n_last, const float
         const uint8_t *dMP = mp_desc + (size_t)i * 32;
         int bestDist = 256, bestIdx2 = -1;
         for (int i2 : vIndices2) {
-            if (train_match[i2] >= 0 && blocks[train_match[i2]]) continue; // mvpMapPoints[i2] && Observations() > 0
+            if (train_match[i2] >= 0 && blocks[train_match[i2]]) continue; // mvpMapPoints[i2] && Observations() > 0 (set during this call)
+            if (train_blocked && train_blocked[i2]) continue;             // ... set before the call, or KeysStatic[i2] == false (:1451-1457)
             const int dist = descriptor_distance(dMP, cur->desc + (size_t)i2 * 32);
             if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
         }

@@ -150,7 +150,7 @@ int orc_get_features_in_area(const orc_frame *F, float x, float y, float r, int 
 int orc_search_by_projection_frame(const orc_frame *cur, int n_last, const float *world_pos, const uint8_t *valid,
                                    const uint8_t *blocks, const uint8_t *mp_desc, const int *last_octave, const float *last_angle,
                                    const float *Tcw12, float fx, float fy, float cx, float cy, const float *scale_factors,
-                                   float th, int check_orientation, int *train_match);
+                                   float th, int check_orientation, const uint8_t *train_blocked /* may be NULL */, int *train_match);
 /* SearchByProjection(Frame &F, vector<MapPoint*>, th) (:50-142): proj_xy (mTrackProjX/Y), view_cos, pred_level, in_view,
  * blocks, mp_desc per map point; train_blocked[N] marks keypoints that already hold a map point with observations. */
 int orc_search_local_map(const orc_frame *F, int n_mp, const float *proj_xy, const float *view_cos, const int *pred_level,

@@ -245,14 +245,15 @@ def get_features_in_area(frame, x, y, r, minLevel=-1, maxLevel=-1):
     return out[:n].copy()
 
 
-def search_by_projection_frame(cur, world_pos, valid, blocks, mp_desc, last_octave, last_angle, Tcw, fx, fy, cx, cy, scale_factors, th, check_ori=True):
+def search_by_projection_frame(cur, world_pos, valid, blocks, mp_desc, last_octave, last_angle, Tcw, fx, fy, cx, cy, scale_factors, th, check_ori=True, train_blocked=None):
     wp = np.ascontiguousarray(world_pos, np.float32); va = np.ascontiguousarray(valid, np.uint8); bl = np.ascontiguousarray(blocks, np.uint8)
     md = np.ascontiguousarray(mp_desc, np.uint8); lo = np.ascontiguousarray(last_octave, np.int32); la = np.ascontiguousarray(last_angle, np.float32)
     T = np.ascontiguousarray(Tcw, np.float32).reshape(-1)[:12].copy(); sf = np.ascontiguousarray(scale_factors, np.float32)
     tm = np.zeros(max(cur.N, 1), np.int32)
     n = lib().orc_search_by_projection_frame(C.byref(cur), len(va), _p(wp, C.c_float), _p(va, C.c_uint8), _p(bl, C.c_uint8), _p(md, C.c_uint8),
                                              _p(lo, C.c_int), _p(la, C.c_float), _p(T, C.c_float), C.c_float(fx), C.c_float(fy), C.c_float(cx),
-                                             C.c_float(cy), _p(sf, C.c_float), C.c_float(th), int(check_ori), _p(tm, C.c_int))
+                                             C.c_float(cy), _p(sf, C.c_float), C.c_float(th), int(check_ori),
+                                             None if train_blocked is None else _p(np.ascontiguousarray(train_blocked, np.uint8), C.c_uint8), _p(tm, C.c_int))
     return tm[:cur.N].copy(), n
 
 

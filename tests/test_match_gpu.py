@@ -67,6 +67,12 @@ def test_search_by_projection_frame(ctx, oracle, frames, th):
     ref, nr = oracle.search_by_projection_frame(F2, wp, valid, blocks, d1, k1["octave"], k1["angle"], Tcw, FX, FY, CX, CY, SF, th)
     assert np.array_equal(got, ref) and ng == nr
     assert ng > 300
+    # current-frame keypoints that must not be matched: a map point from before the call, or KeysStatic == false (ORBmatcher.cc:1451-1457)
+    blocked = (rng.uniform(size=len(k2)) < 0.3).astype(np.uint8)
+    got_b, ng_b = m.SearchByProjectionFrame(wp, valid, blocks, d1, k1["octave"], k1["angle"], Tcw, FX, FY, CX, CY, SF, th, train_blocked=blocked)
+    ref_b, nr_b = oracle.search_by_projection_frame(F2, wp, valid, blocks, d1, k1["octave"], k1["angle"], Tcw, FX, FY, CX, CY, SF, th, train_blocked=blocked)
+    assert np.array_equal(got_b, ref_b) and ng_b == nr_b
+    assert not np.any(got_b[blocked != 0] >= 0) and 100 < ng_b < ng and not np.array_equal(got_b, got)
     m.close()
 
 
