@@ -1,15 +1,22 @@
 #!/usr/bin/env python3
 """bench.py -- throughput of the hot path on N MI355X GPUs of one node (contract in the task statement).
 
-Workload at N=1 (BASELINE.json configs[1]): synthetic 640x480 frames with 3 boxes each, `--frames` frames resident in HBM per
-GPU; one step = one pass of the front-end over that batch: ORBextractor (1000 features, 8 levels, FAST 20/7) + LSD line
-detection with LBD descriptors (line_lbd defaults) + detect_3d_cuboid with a 180-yaw x 3-VP proposal sweep (yaw step 0.5 deg over +-45 deg; Canny + distance transform + line merge + VP support +
-sweep/score + selection).  N>1: every rank owns its own block of frames (no data-path collective, weak scaling).
-The second half of BASELINE's metric (BA iterations/s at 1k keyframes) is measured in the same run and reported under "ba".
+Workload at N=1 (BASELINE.json configs[1]): synthetic 640x480 frames -- three drawn cuboids over a band-limited texture, so that ORB, LSD and
+Canny see real content (asserted: >= 800 key points and >= 100 line segments per frame) -- with 3 boxes each, `--frames` frames resident in
+HBM per GPU; one step = one pass of the front-end over that batch: ORBextractor (1000 features, 8 levels, FAST 20/7) + LSD line detection
+with LBD descriptors (line_lbd defaults) + detect_3d_cuboid with a 180-yaw x 3-VP proposal sweep (yaw step 0.5 deg over +-45 deg; Canny +
+distance transform + line merge + VP support + sweep / score + selection).  N>1: every rank owns its own block of frames (no data-path
+collective, weak scaling).  The same JSON line carries, measured in the same run on rank 0 at N=1:
+  "ba"   the second half of BASELINE's metric (LM iterations/s of the object BA at 1000 key frames),
+  "c3"   config 3: the 1241x376 stream, 2000 ORB features + LSD/LBD + frame-to-frame SearchByProjection, with the matcher's own roofline,
+  "c4"   config 4's per-GPU share: 64 frames x 8 boxes through the cuboid path,
+  "pcie_inclusive"  the drop-in calls frame by frame, host buffers in and out,
+  "cpu_baseline" / "cpu_baseline_mt"  the CPU port (oracle, built -march=native on this box) on 1 thread / frame-parallel on the host cores.
 """
 import argparse
 import json
 import os
+import subprocess
 import sys
 import time
 
@@ -18,42 +25,118 @@ import numpy as np
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (6.29 TB/s measured copy)
+HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8.0 TB/s spec (~6.3 TB/s achievable)
+BG_TEXTURE = 0.5
 
 
-def make_frames(n_frames, n_boxes, seed0):
+def make_frames(n_frames, n_boxes, seed0, bg_texture=BG_TEXTURE):
     from cube_slam_amd import synth
     scenes = []
     seed = seed0
     while len(scenes) < n_frames:
-        s = synth.cuboid_scene(seed, n_boxes=n_boxes)
+        s = synth.cuboid_scene(seed, n_boxes=n_boxes, bg_texture=bg_texture)
         seed += 1
         if len(s["boxes"]) == n_boxes:
             scenes.append(s)
     return scenes
 
 
-def cpu_baseline(scenes, yaw_step, budget_s=12.0, with_orb=True, nfeat=1000, with_lines=True):
-    """Reference CPU path (the oracle restatement, single thread like the reference) on a bounded sample."""
+# ---------------------------------------------------------------------------------------------------------------- CPU baseline
+def native_oracle():
+    """The oracle rebuilt -O3 -march=native for THIS box's host CPU (the in-tree liboracle.so is generic because it travels)."""
+    from oracle import pyoracle as po
+    out = "/tmp/liboracle_native.so"
+    try:
+        srcs = sorted(f for f in os.listdir(os.path.join(ROOT, "oracle")) if f.endswith("_oracle.cpp"))
+        subprocess.check_call(["g++", "-O3", "-march=native", "-ffp-contract=off", "-fno-fast-math", "-std=c++17", "-fPIC", "-shared", "-w", "-o", out] + srcs +
+                              ["-lpthread"], cwd=os.path.join(ROOT, "oracle"), timeout=600)
+        import ctypes
+        h = ctypes.CDLL(out)
+        h.orc_box_edge_sum_dists.restype = ctypes.c_double
+        h.orc_box_edge_angle_error.restype = ctypes.c_double
+        po._LIB = h  # pyoracle.lib() returns the cached handle
+        return "-O3 -march=native"
+    except Exception as e:  # keep the generic build
+        return "-O3 (generic build: %s)" % type(e).__name__
+
+
+def _cpu_frame(po, s, o, ext, with_lines):
+    if ext is not None:
+        ext(s["gray"])
+    if with_lines:
+        po.lbd_compute(s["gray"], po.lsd_detect(s["gray"]))
+    po.detect_cuboid(s["gray"], s["K"], s["Twc"], s["boxes"], s["lines"], opts=o)
+
+
+def cpu_baseline(scenes, yaw_step, flags, budget_s=10.0, with_orb=True, nfeat=1000, with_lines=True, threads=1):
+    """The CPU port on a bounded sample of the same frames: 1 thread like the reference, or frame-parallel on `threads` host cores."""
     from oracle import pyoracle as po
     o = po.cuboid_opts(yaw_step_deg=yaw_step)
-    ext = po.ORBextractor(nfeat, 1.2, 8, 20, 7) if with_orb else None
-    po.detect_cuboid(scenes[0]["gray"], scenes[0]["K"], scenes[0]["Twc"], scenes[0]["boxes"], scenes[0]["lines"], opts=o)
-    t0 = time.perf_counter()
-    n = 0
-    while time.perf_counter() - t0 < budget_s:
-        s = scenes[n % len(scenes)]
-        if ext is not None:
-            ext(s["gray"])
-        if with_lines:
-            po.lbd_compute(s["gray"], po.lsd_detect(s["gray"]))
-        po.detect_cuboid(s["gray"], s["K"], s["Twc"], s["boxes"], s["lines"], opts=o)
-        n += 1
-    dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "port",
-            "sample": "%d frames of the same workload in %.1f s, oracle/{orb,lsd,lbd,cuboid}_oracle.cpp, 1 thread" % (n, dt)}
+    _cpu_frame(po, scenes[0], o, po.ORBextractor(nfeat, 1.2, 8, 20, 7) if with_orb else None, with_lines)
+    if threads <= 1:
+        ext = po.ORBextractor(nfeat, 1.2, 8, 20, 7) if with_orb else None
+        t0 = time.perf_counter()
+        n = 0
+        while time.perf_counter() - t0 < budget_s:
+            _cpu_frame(po, scenes[n % len(scenes)], o, ext, with_lines)
+            n += 1
+        dt = time.perf_counter() - t0
+    else:
+        from concurrent.futures import ThreadPoolExecutor  # the ctypes calls release the GIL
+        deadline = time.perf_counter() + budget_s
+
+        def worker(tid):
+            ext = po.ORBextractor(nfeat, 1.2, 8, 20, 7) if with_orb else None
+            k = 0
+            while time.perf_counter() < deadline:
+                _cpu_frame(po, scenes[(tid + k * threads) % len(scenes)], o, ext, with_lines)
+                k += 1
+            return k
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(threads) as ex:
+            n = sum(ex.map(worker, range(threads)))
+        dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "frames/s", "cores": threads, "kind": "port", "build": flags,
+            "sample": "%d frames of the same workload in %.1f s, oracle/{orb,lsd,lbd,cuboid}_oracle.cpp, %d thread%s" % (n, dt, threads, "" if threads == 1 else "s (frame-parallel)")}
 
 
+# ---------------------------------------------------------------------------------------------------------------- HBM traffic (PMC)
+def measure_traffic(frames, boxes, yaw_step):
+    """HBM-side bytes per launch of cuboid_sweep_score from rocprofv3 --pmc passes of tools/pmc_run.py (the same batch), collected in their
+    own runs (no tracing).  TCC_EA0 requests by size (MI355X_MICROARCH.md 'HBM': memory-side requests of the L2s, Infinity-Cache hits
+    included; sizes counted explicitly instead of FETCH_SIZE's flat 64 B).  None when rocprofv3 is not available."""
+    import csv
+    import glob
+    import shutil
+    import tempfile
+    if shutil.which("rocprofv3") is None:
+        return None
+    res = {}
+    try:
+        for tag, ctrs in (("rd", "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum"), ("wr", "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum")):
+            d = tempfile.mkdtemp(prefix="pmc_" + tag, dir="/tmp")
+            env = dict(os.environ, TMPDIR="/tmp")
+            subprocess.run(["rocprofv3", "--pmc"] + ctrs.split() + ["--output-format", "csv", "-d", d, "-o", "res", "--", sys.executable, os.path.join(ROOT, "tools", "pmc_run.py"),
+                            str(frames), str(boxes), str(yaw_step), str(BG_TEXTURE)], cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
+            acc = {}
+            for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
+                for r in csv.DictReader(open(f)):
+                    if "cuboid_sweep_score(" in r["Kernel_Name"].replace("(anonymous namespace)::", "") or r["Kernel_Name"].replace("(anonymous namespace)::", "").startswith("cuboid_sweep_score("):
+                        acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+            res.update({k: sum(v) / len(v) for k, v in acc.items() if v})
+            shutil.rmtree(d, ignore_errors=True)
+        n, n32, n64, n128 = (res.get("TCC_EA0_RDREQ_sum", 0), res.get("TCC_EA0_RDREQ_32B_sum", 0), res.get("TCC_EA0_RDREQ_64B_sum", 0), res.get("TCC_EA0_RDREQ_128B_sum", 0))
+        if n <= 0:
+            return None
+        rd = 32 * n32 + 64 * n64 + 128 * n128 + 64 * max(0.0, n - n32 - n64 - n128)
+        w, w64 = res.get("TCC_EA0_WRREQ_sum", 0), res.get("TCC_EA0_WRREQ_64B_sum", 0)
+        wr = 64 * w64 + 32 * max(0.0, w - w64)
+        return {"bytes": rd + wr, "read_bytes": rd, "write_bytes": wr, "source": "rocprofv3 --pmc TCC_EA0_{RDREQ,WRREQ}* in this run (separate passes, tools/pmc_run.py)"}
+    except Exception:
+        return None
+
+
+# ---------------------------------------------------------------------------------------------------------------- object BA
 def ba_bench(ctx, rank, world, iters, with_cpu):
     """LM iterations/s of the object BA at 1000 keyframes / 100k points / 500 cuboids."""
     from cube_slam_amd import synth
@@ -103,15 +186,8 @@ def ba_bench(ctx, rank, world, iters, with_cpu):
     if "ba_schur_slots" in kern:
         alg = 144.0 * O / world + 72.0 * Lm / world + 288.0 * 5 * C
         ach = alg / (kern["ba_schur_slots"] * 1e-6) / 1e9
-        traffic = None
-        if world == 1 and (len(d["cam_pose"]), len(d["points"])) == (1000, 100000):  # the committed PMC pass is of exactly this graph on one GPU
-            try:
-                tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["ba_schur_slots"]
-                traffic = tj["read_bytes"] + tj["write_bytes"]
-            except Exception:
-                traffic = None
         out["roofline"] = {"bound": "hbm", "kernel": "ba_schur_slots", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                           "traffic": traffic, "algorithmic_bytes_per_launch": alg}
+                           "traffic": None, "algorithmic_bytes_per_launch": alg}
     if with_cpu:
         from oracle import pyoracle as po
         t0 = time.perf_counter()
@@ -123,11 +199,144 @@ def ba_bench(ctx, rank, world, iters, with_cpu):
     return out
 
 
+# ---------------------------------------------------------------------------------------------------------------- config 3
+def c3_bench(ctx, frames, steps, with_cpu):
+    """BASELINE config 3: 1241x376 stream (1/f texture moving 3 px per frame), 2000 ORB features + LSD/LBD lines per frame and the
+    tracking thread's frame-to-frame ORBmatcher::SearchByProjection (th = 15) from the extractor's device buffers."""
+    from cube_slam_amd import synth
+    from cube_slam_amd.lsd import line_lbd_detect
+    from cube_slam_amd.matcher import ORBmatcher
+    from cube_slam_amd.orb import ORBextractor
+    W, H = 1241, 376
+    fx, fy, cx, cy = 721.5377, 721.5377, 609.5593, 172.854
+    imgs = np.stack([synth.texture_image(77, W, H, shift=3 * i) for i in range(frames)])
+    orb = ORBextractor(2000, 1.2, 8, 20, 7, W, H, max_frames=frames, ctx=ctx)
+    orb.upload(imgs)
+    lsd = line_lbd_detect(W, H, max_frames=frames, ctx=ctx)
+    lsd.upload(imgs)
+    m = ORBmatcher(0.9, True, ctx=ctx, max_queries=4096)
+    K4 = np.array([fx, fy, cx, cy], np.float32)
+    bounds = (0.0, float(W), 0.0, float(H))
+    sf = np.array([1.2 ** i for i in range(8)], np.float32)
+    Tcw = np.eye(4, dtype=np.float32)[:3]
+
+    def one_pass():
+        orb.run()
+        lsd.run(True)
+        per = orb.read()  # key points + descriptors of every frame (the map points' descriptors are host data in the reference too)
+        n_q = n_m = 0
+        for f in range(1, frames):  # the tracking thread: key points of frame f-1 projected into frame f (known 3 px shift)
+            m.set_frame_from_orb(orb, f, K4, None, bounds)
+            pk, pd = per[f - 1]
+            z = np.full(len(pk), 10.0, np.float32)
+            wp = np.stack([(pk["x"] - 3.0 - cx) / fx * z, (pk["y"] - cy) / fy * z, z], axis=1).astype(np.float32)
+            ones = np.ones(len(pk), np.uint8)
+            tm, nm = m.SearchByProjectionFrame(wp, ones, ones, pd, pk["octave"], pk["angle"], Tcw, fx, fy, cx, cy, sf, 15.0)
+            n_q += len(pk); n_m += nm
+        return n_q, n_m
+
+    one_pass()
+    ctx.sync()
+    ctx.timing(True); ctx.timing_reset()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        n_q, n_m = one_pass()
+    ctx.sync()
+    dt = time.perf_counter() - t0
+    kern = {}
+    for nme in ("orb_resize", "orb_fast_score", "orb_cells", "orb_quadtree", "orb_blur", "orb_angle", "orb_desc", "host_lsd_regions", "lsd_blur_hv", "lsd_resize", "lsd_gradient",
+                "lbd_blur5", "lbd_sobel", "lbd_line_desc", "match_undistort", "match_grid", "match_project", "match_candidates", "match_scan"):
+        ms, n = ctx.timing_get(nme)
+        if n:
+            kern[nme] = round(1e3 * ms / n, 2)
+    cand_ms, cand_n = ctx.timing_get("match_candidates")
+    ctx.timing(False)
+    n_kp = sum(len(k) for k, _ in orb.read())
+    n_lines = sum(len(lsd.read(f, with_desc=False)) for f in range(frames))
+    cstat = m.last_candidate_stats()
+    out = {"metric": "frames/s, 1241x376 stream: ORB 2000 + LSD/LBD + frame-to-frame SearchByProjection", "value": frames * steps / dt, "unit": "frames/s",
+           "ms_per_frame": 1e3 * dt / (frames * steps), "frames": frames, "keypoints_per_frame": n_kp / frames, "keylines_per_frame": n_lines / frames,
+           "queries_per_pass": n_q, "matches_per_pass": n_m, "kernels_us": kern}
+    if cand_n and cstat is not None:
+        # SURVEY 8d "Hamming window match, per query: 32 + 32 c + 8 B" with c = candidates the window enumerated
+        alg = 40.0 * cstat["queries"] + 32.0 * cstat["candidates"]
+        us = 1e3 * cand_ms / cand_n
+        ach = alg / (us * 1e-6) / 1e9
+        out["roofline"] = {"bound": "hbm", "kernel": "match_candidates", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
+                           "avg_kernel_us": us, "algorithmic_bytes_per_launch": alg, "queries_per_launch": cstat["queries"], "candidates_per_launch": cstat["candidates"],
+                           "note": "one launch per frame (2000 queries): launch-latency-bound at this size; batching frames is what the stream forbids"}
+    if with_cpu:
+        from oracle import pyoracle as po
+        ext = po.ORBextractor(2000, 1.2, 8, 20, 7)
+        t0 = time.perf_counter(); n = 0; prev = None
+        while time.perf_counter() - t0 < 8.0:
+            g = imgs[n % frames]
+            k, dsc = ext(g)
+            po.lbd_compute(g, po.lsd_detect(g))
+            if prev is not None and n % frames:
+                pk, pd = prev
+                F2 = po.make_frame(k, dsc, bounds)
+                z = np.full(len(pk), 10.0, np.float32)
+                wp = np.stack([(pk["x"] - 3.0 - cx) / fx * z, (pk["y"] - cy) / fy * z, z], axis=1).astype(np.float32)
+                ones = np.ones(len(pk), np.uint8)
+                po.search_by_projection_frame(F2, wp, ones, ones, pd, pk["octave"], pk["angle"], Tcw, fx, fy, cx, cy, sf, 15.0)
+            prev = (k, dsc); n += 1
+        dtc = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": n / dtc, "unit": "frames/s", "cores": 1, "kind": "port", "sample": "%d frames of the same stream in %.1f s, 1 thread" % (n, dtc)}
+    m.close()
+    return out
+
+
+def c4_bench(ctx, frames, boxes, yaw_step, steps):
+    """BASELINE config 4, one GPU's share: `frames` frames x `boxes` boxes through the cuboid path (512 frames shard as 64 per GPU)."""
+    from cube_slam_amd.cuboid import CuboidBatch, detect_3d_cuboid
+    scenes = make_frames(frames, boxes, seed0=500000)
+    det = detect_3d_cuboid(ctx)
+    det.set_calibration(scenes[0]["K"])
+    det.yaw_step_deg = yaw_step
+    b = CuboidBatch(ctx, np.stack([s["gray"] for s in scenes]), scenes[0]["K"], np.stack([s["Twc"] for s in scenes]), [s["boxes"] for s in scenes], [s["lines"] for s in scenes], det.opts())
+    b.run(); ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        b.run()
+    ctx.sync()
+    dt = time.perf_counter() - t0
+    st = b.stats()
+    n_out = sum(len(g) for g in b.read())
+    b.close()
+    return {"metric": "frames/s, detect_3d_cuboid on %d frames x %d boxes per GPU" % (frames, boxes), "value": frames * steps / dt, "unit": "frames/s", "boxes_per_s": frames * boxes * steps / dt,
+            "ms_per_batch": 1e3 * dt / steps, "valid_proposals_per_batch": st["n_valid"], "roi_pixels_per_batch": st["roi_pixels"], "cuboids_out": n_out}
+
+
+def pcie_inclusive(ctx, scenes, yaw_step, nfeat, n=24):
+    """The drop-in calls, one frame at a time with host buffers in and out (H2D + plan + kernels + D2H): what a ROS node sees per frame."""
+    from cube_slam_amd.cuboid import detect_3d_cuboid
+    from cube_slam_amd.lsd import line_lbd_detect
+    from cube_slam_amd.orb import ORBextractor
+    det = detect_3d_cuboid(ctx)
+    det.set_calibration(scenes[0]["K"])
+    det.yaw_step_deg = yaw_step
+    ext = ORBextractor(nfeat, 1.2, 8, 20, 7, 640, 480, ctx=ctx)
+    ll = line_lbd_detect(640, 480, ctx=ctx)
+
+    def one(s):
+        ext(s["gray"])
+        kl = ll.detect_raw_lines(s["gray"])
+        ll.get_line_descriptors(s["gray"], kl)
+        det.detect_cuboid(s["gray"], s["Twc"], s["boxes"], s["lines"])
+    one(scenes[0])
+    t0 = time.perf_counter()
+    for i in range(n):
+        one(scenes[i % len(scenes)])
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "frames/s", "ms_per_frame": 1e3 * dt / n, "sample": "%d frames, ORBextractor::operator() + detect_raw_lines + LBD + detect_cuboid per frame, host in / host out" % n}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames", type=int, default=128, help="frames resident per GPU")
     ap.add_argument("--boxes", type=int, default=3)
     ap.add_argument("--yaw-step", type=float, default=0.5)
@@ -135,10 +344,14 @@ def main():
     ap.add_argument("--no-ba", action="store_true")
     ap.add_argument("--no-orb", action="store_true")
     ap.add_argument("--no-lines", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the c3 / c4 / pcie_inclusive / traffic blocks")
     ap.add_argument("--ba-iters", type=int, default=10)
     ap.add_argument("--orb-features", type=int, default=1000)
     args = ap.parse_args()
 
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:  # `python bench.py --gpus N` launches its own ranks (the driver uses torch.distributed.run directly)
+        os.execvp(sys.executable, [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus), "--master-addr", "127.0.0.1",
+                                   "--master-port", str(29500 + os.getpid() % 2000)] + sys.argv)
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -180,14 +393,8 @@ def main():
     from cube_slam_amd.frontend import Frontend
     fe = Frontend(ctx, orb=orb, batch=batch, line_detectors=lsds if lsd is not None else ())
 
-    def step():
-        fe.step()
-
-    def drain():
-        fe.drain()
-
     def barrier():
-        drain()
+        fe.drain()
         ctx.sync()
         if lsd is not None:
             for c in ctx_lines:
@@ -197,14 +404,14 @@ def main():
             dist.barrier()
 
     for _ in range(args.warmup):
-        step()
+        fe.step()
     barrier()
     for c in ([ctx] + ctx_lines if lsd is not None else [ctx]):
         c.timing(True)
         c.timing_reset()
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        step()
+        fe.step()
     barrier()
     elapsed = time.perf_counter() - t0
     if world > 1:
@@ -212,8 +419,9 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     kernels = {}
-    for name in ("host_orb_quadtree", "orb_resize", "orb_fast_score", "orb_cells", "orb_scan", "orb_quadtree", "orb_blur", "orb_angle", "orb_desc", "host_lsd_regions", "lsd_blur_hv", "lsd_resize", "lsd_gradient", "lbd_blur5", "lbd_sobel", "lbd_line_desc", "cuboid_frame_prep", "cuboid_unit_lines", "cuboid_canny_nms", "cuboid_canny_cc", "cuboid_dt", "cuboid_vp",
-                 "cuboid_sweep_corners", "cuboid_sweep_score", "cuboid_select"):
+    for name in ("host_orb_quadtree", "orb_resize", "orb_fast_score", "orb_cells", "orb_scan", "orb_quadtree", "orb_blur", "orb_angle", "orb_desc", "host_lsd_regions", "lsd_blur_hv", "lsd_resize",
+                 "lsd_gradient", "lbd_blur5", "lbd_sobel", "lbd_line_desc", "cuboid_frame_prep", "cuboid_unit_lines", "cuboid_canny_nms", "cuboid_canny_cc", "cuboid_dt", "cuboid_dt_codes",
+                 "cuboid_vp", "cuboid_sweep_corners", "cuboid_score_plan", "cuboid_sweep_score", "cuboid_sweep_score_big", "cuboid_select"):
         ms, n = ctx.timing_get(name)
         if n == 0 and lsd is not None:
             parts = [c.timing_get(name) for c in ctx_lines]
@@ -225,57 +433,74 @@ def main():
             c.timing(False)
     # the same kernel without kernels of the other paths sharing the GPU (the timed region overlaps three streams)
     ctx.timing(True); ctx.timing_reset()
-    for _ in range(max(3, args.steps // 2)):
+    for _ in range(10):
         batch.run()
     ctx.sync()
     iso_ms, iso_n = ctx.timing_get("cuboid_sweep_score")
     ctx.timing(False)
     st = batch.stats()
+    ss = batch.score_stats()
     got = batch.read()
     assert sum(len(g) for g in got) > 0
     n_kp = sum(len(k) for k, _ in orb.read()) if orb is not None else 0
     n_lines = sum(len(lsd.read(f, with_desc=False)) for f in range(args.frames)) if lsd is not None else 0
+    if orb is not None and BG_TEXTURE > 0 and args.orb_features >= 1000:
+        assert n_kp >= 800 * args.frames, "the frames are too empty for the ORB quota: %d key points per frame" % (n_kp // args.frames)
+    if lsd is not None and BG_TEXTURE > 0:
+        assert n_lines >= 100 * args.frames, "the frames are too empty for LSD: %d segments per frame" % (n_lines // args.frames)
+
+    solo = rank == 0 and world == 1
+    extra = {}
+    if solo and not args.no_extra:
+        tr = measure_traffic(args.frames, args.boxes, args.yaw_step)
+        extra["c3"] = c3_bench(ctx, 24, 3, with_cpu=not args.no_cpu)
+        extra["c4"] = c4_bench(ctx, 64, 8, args.yaw_step, 10)
+        extra["pcie_inclusive"] = pcie_inclusive(ctx, scenes, args.yaw_step, args.orb_features)
+    else:
+        tr = None
     ba_out = None
     if not args.no_ba:
-        ba_out = ba_bench(ctx, rank, world, args.ba_iters, with_cpu=(rank == 0 and world == 1 and not args.no_cpu))
+        ba_out = ba_bench(ctx, rank, world, args.ba_iters, with_cpu=(solo and not args.no_cpu))
 
     if rank == 0:
         total_frames = args.frames * world * args.steps
-        # algorithmic bytes of one cuboid_sweep_score launch (SURVEY 8d "edge scoring kernel"): each distance-map ROI
-        # read once (4*A); per surviving proposal 16 corner doubles read, 2 error doubles written.
-        alg_bytes = 4.0 * st["roi_pixels"] + 144.0 * st["n_valid"]
+        # Algorithmic bytes of one cuboid_sweep_score launch: each LDS-resident distance map read once -- as the 2-byte chamfer code the
+        # distance transform's last stage writes for this kernel (2*A; SURVEY 8d writes 4*A for a float map) -- plus, per surviving
+        # proposal, 16 corner doubles read and 2 error doubles written (144 B).  Units that do not fit LDS are cuboid_sweep_score_big's.
+        alg_bytes = 2.0 * ss["lds_pixels"] + 144.0 * ss["lds_valid"]
         k_us = kernels["cuboid_sweep_score"]["avg_us"]
-        traffic = None  # HBM-side bytes per launch: from the committed rocprofv3 --pmc pass of this workload (bench.py cannot host the profiler)
-        try:
-            tj = json.load(open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")))["cuboid_sweep_score"]
-            if args.frames == 128 and args.boxes == 3 and args.yaw_step == 0.5:
-                traffic = tj["read_bytes"] + tj["write_bytes"]
-        except Exception:
-            traffic = None
         achieved = alg_bytes / (k_us * 1e-6) / 1e9 if k_us > 0 else 0.0
+        iso_us = 1e3 * iso_ms / max(iso_n, 1)
         out = {
             "metric": "frames/sec front-end (%s%scuboid: Canny+DT+sweep+score+select) @640x480" % ("ORB extract + " if orb is not None else "", "LSD+LBD lines + " if lsd is not None else ""),
             "value": total_frames / elapsed, "unit": "frames/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "front-end per frame: ORB extract + LSD/LBD lines + detect_3d_cuboid: 640x480 frames x %d boxes, 180-yaw x 3-VP sweep "
-                                   "(yaw step %.2f deg), %d frames resident per GPU" % (args.boxes, args.yaw_step, args.frames),
-                       "lines": None if lsd is None else {"keylines_per_step": n_lines, "descriptor": "LBD 32 B"},
-                       "orb": None if orb is None else {"nfeatures": args.orb_features, "levels": 8, "keypoints_per_step": n_kp},
+            "config": {"workload": "front-end per frame: ORB extract + LSD/LBD lines + detect_3d_cuboid: 640x480 frames (3 drawn cuboids over a 1/f texture, amplitude %.2f) x %d boxes, "
+                                   "180-yaw x 3-VP sweep (yaw step %.2f deg), %d frames resident per GPU; detect_cuboid is fed the scene's own edge list (cuboid edges + 40 clutter "
+                                   "segments), not this step's LSD output (decoupled, SURVEY 8d C2)" % (BG_TEXTURE, args.boxes, args.yaw_step, args.frames),
+                       "lines": None if lsd is None else {"keylines_per_step": n_lines, "keylines_per_frame": n_lines / args.frames, "descriptor": "LBD 32 B"},
+                       "orb": None if orb is None else {"nfeatures": args.orb_features, "levels": 8, "keypoints_per_step": n_kp, "keypoints_per_frame": n_kp / args.frames},
                        "frames_per_gpu": args.frames, "boxes_per_frame": args.boxes,
                        "hypotheses_per_step": st["n_hypotheses"], "valid_proposals_per_step": st["n_valid"],
-                       "roi_pixels_per_step": st["roi_pixels"], "parallelism": "frames sharded, no collective"},
+                       "roi_pixels_per_step": st["roi_pixels"], "score_kernels": ss, "parallelism": "frames sharded, no collective"},
             "roofline": {"bound": "hbm", "kernel": "cuboid_sweep_score", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "avg_kernel_us": k_us,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None if tr is None else tr["bytes"], "traffic_detail": tr, "avg_kernel_us": k_us,
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "isolated": {"avg_kernel_us": 1e3 * iso_ms / max(iso_n, 1), "frac": (alg_bytes / (1e3 * iso_ms / max(iso_n, 1) * 1e-6) / 1e9 / HBM_PEAK_GBS) if iso_n else None,
+                         "algorithmic_bytes_formula": "2*A_lds + 144*n_valid_lds (16-bit code map read once; the float-map formula 4*A + 144*n of SURVEY 8d gives %.0f)" % (4.0 * ss["lds_pixels"] + 144.0 * ss["lds_valid"]),
+                         "isolated": {"avg_kernel_us": iso_us, "frac": (alg_bytes / (iso_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if iso_n else None,
                                       "note": "cuboid path alone on the GPU; the timed region runs ORB, line and cuboid kernels concurrently on three streams"}},
             "kernels_us": {k: round(v["avg_us"], 2) for k, v in kernels.items()},
             "host_threads": _lib.lib().cs_host_thread_count(),
         }
+        out.update(extra)
         if not args.no_cpu and world == 1:
-            out["cpu_baseline"] = cpu_baseline(scenes[:16], args.yaw_step, with_orb=orb is not None, nfeat=args.orb_features, with_lines=lsd is not None)
-            out["cpu_baseline"]["host_cores_available"] = _lib.lib().cs_host_thread_count()
+            flags = native_oracle()
+            cores = _lib.lib().cs_host_thread_count()
+            out["cpu_baseline"] = cpu_baseline(scenes[:16], args.yaw_step, flags, with_orb=orb is not None, nfeat=args.orb_features, with_lines=lsd is not None)
+            out["cpu_baseline"]["host_cores_available"] = cores
+            out["cpu_baseline_mt"] = cpu_baseline(scenes[:max(16, cores)], args.yaw_step, flags, budget_s=8.0, with_orb=orb is not None, nfeat=args.orb_features,
+                                                  with_lines=lsd is not None, threads=cores)
         if ba_out is not None:
             out["ba"] = ba_out
         print(json.dumps(out))

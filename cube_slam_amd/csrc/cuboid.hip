@@ -2023,6 +2023,21 @@ int cs_cuboid_batch_stats(cs_ctx *ctx, cs_cuboid_batch *b, long *n_units, long *
     return CS_OK;
 }
 
+int cs_cuboid_batch_score_stats(cs_ctx *ctx, cs_cuboid_batch *b, long out[6]) {
+    if (!ctx || !b || !out) return CS_ERR_BAD_ARG;
+    std::vector<int> vc(2 * (size_t)b->n_units + 1), uf((size_t)b->n_units + 1);
+    int r = cs_d2h(ctx, vc.data(), b->d_vcount, 2 * (size_t)b->n_units); if (r) return r;
+    r = cs_d2h(ctx, uf.data(), b->d_uflag, (size_t)b->n_units); if (r) return r;
+    CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < 6; i++) out[i] = 0;
+    for (int u = 0; u < b->n_units; u++) {
+        const Unit &U = b->units[u];
+        const int k = (score_unit_fits(U.roi_w, U.roi_h) && !(uf[u] & 1)) ? 0 : 3;
+        out[k] += 1; out[k + 1] += (long)U.roi_w * U.roi_h; out[k + 2] += vc[2 * u] + vc[2 * u + 1];
+    }
+    return CS_OK;
+}
+
 int cs_cuboid_batch_unit(cs_ctx *ctx, cs_cuboid_batch *b, int unit, int dims[12], uint8_t *edges, float *dist, double *rows, long rows_cap,
                          double *merged, long merged_cap) {
     if (!ctx || !b || unit < 0 || unit >= b->n_units || !dims) return CS_ERR_BAD_ARG;

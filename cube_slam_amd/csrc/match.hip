@@ -352,6 +352,13 @@ void cs_matcher_destroy(cs_ctx *ctx, cs_matcher *m) {
     delete m;
 }
 
+int cs_matcher_last_counts(const cs_matcher *m, int *queries, long *candidates) { // workload facts of the last search, for roofline accounting
+    if (!m || !queries || !candidates) return CS_ERR_BAD_ARG;
+    *queries = m->offsets.empty() ? 0 : (int)m->offsets.size() - 1;
+    *candidates = m->offsets.empty() ? 0 : (long)m->offsets.back();
+    return CS_OK;
+}
+
 int cs_matcher_create(cs_ctx *ctx, int max_keypoints, int max_queries, long max_candidates, cs_matcher **out) {
     if (!ctx || !out || max_keypoints < 1 || max_queries < 1 || max_candidates < 1) return CS_ERR_BAD_ARG;
     *out = nullptr;

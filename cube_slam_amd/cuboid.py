@@ -124,6 +124,11 @@ class CuboidBatch:
         check(self.ctx.ptr, lib().cs_cuboid_batch_stats(self.ctx.ptr, self._b, *[C.byref(x) for x in v]), "cs_cuboid_batch_stats")
         return dict(zip(("n_units", "roi_pixels", "n_hypotheses", "n_valid"), [x.value for x in v]))
 
+    def score_stats(self):
+        v = (C.c_long * 6)()
+        check(self.ctx.ptr, lib().cs_cuboid_batch_score_stats(self.ctx.ptr, self._b, v), "cs_cuboid_batch_score_stats")
+        return dict(zip(("lds_units", "lds_pixels", "lds_valid", "big_units", "big_pixels", "big_valid"), list(v)))
+
     def unit(self, u, rows_cap=400000):
         dims = (C.c_int * 12)()
         check(self.ctx.ptr, lib().cs_cuboid_batch_unit(self.ctx.ptr, self._b, u, dims, None, None, None, 0, None, 0), "cs_cuboid_batch_unit")

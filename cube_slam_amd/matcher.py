@@ -43,6 +43,12 @@ class ORBmatcher:
         self.N = n.value
         return out[:n.value].copy(), tuple(float(b) for b in bounds)
 
+    def last_candidate_stats(self):
+        q, c = C.c_int(), C.c_long()
+        if lib().cs_matcher_last_counts(self._m, C.byref(q), C.byref(c)) != 0:
+            return None
+        return {"queries": q.value, "candidates": c.value}
+
     def GetFeaturesInArea(self, x, y, r, minLevel=-1, maxLevel=-1):
         out = np.zeros(max(self.N, 1), np.int32); n = C.c_int()
         check(self.ctx.ptr, lib().cs_matcher_features_in_area(self.ctx.ptr, self._m, C.c_float(x), C.c_float(y), C.c_float(r), minLevel, maxLevel,

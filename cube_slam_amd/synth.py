@@ -41,9 +41,11 @@ def _project(K, Twc, pts_w):
     return uv[:2] / uv[2], pc[2]
 
 
-def cuboid_scene(seed, W=640, H=480, n_boxes=3, K=K_TUM, n_clutter=40, noise_sigma=2.0):
+def cuboid_scene(seed, W=640, H=480, n_boxes=3, K=K_TUM, n_clutter=40, noise_sigma=2.0, bg_texture=0.0):
     """One synthetic frame: gray u8 image with `n_boxes` drawn cuboids standing on the ground,
-    their tight 2-D boxes [x y w h prob], the line segments (cuboid edges + clutter) and T_wc."""
+    their tight 2-D boxes [x y w h prob], the line segments (cuboid edges + clutter) and T_wc.
+    bg_texture > 0 lays a band-limited 1/f texture (texture_image, scaled by bg_texture) under the cuboids, so that the data-dependent
+    stages see real content: ~1000 ORB key points and a few hundred LSD segments per frame at 0.5 instead of ~150 / ~25 on the flat floor."""
     from PIL import Image, ImageDraw
 
     rng = np.random.default_rng(seed)
@@ -89,8 +91,11 @@ def cuboid_scene(seed, W=640, H=480, n_boxes=3, K=K_TUM, n_clutter=40, noise_sig
             shade = int(40 + 35 * fi + 11 * ci) % 200 + 30
             faces.append((depth, [(float(uv[0, k]), float(uv[1, k])) for k in f], shade))
     faces.sort(key=lambda t: -t[0])
+    mask = Image.new("L", (W, H), 0)
+    mdrw = ImageDraw.Draw(mask)
     for _, poly, shade in faces:
         drw.polygon(poly, fill=shade)
+        mdrw.polygon(poly, fill=255)
     for pts, uv, z in placed:
         x0, y0, x1, y1 = uv[0].min(), uv[1].min(), uv[0].max(), uv[1].max()
         bx, by = math.floor(x0), math.floor(y0)
@@ -107,6 +112,8 @@ def cuboid_scene(seed, W=640, H=480, n_boxes=3, K=K_TUM, n_clutter=40, noise_sig
         p[[1, 3]] = np.clip(p[[1, 3]], 0, H - 1)
         lines.append(p)
     g = np.asarray(img, np.float64) + rng.normal(0, noise_sigma, (H, W))
+    if bg_texture > 0:
+        g = g + (np.asarray(mask) == 0) * bg_texture * (texture_image(seed, W, H).astype(np.float64) - 128.0)
     gray = np.clip(np.rint(g), 0, 255).astype(np.uint8)
     return {
         "gray": gray, "K": K.copy(), "Twc": Twc,

@@ -129,6 +129,10 @@ void cs_cuboid_batch_destroy(cs_ctx *ctx, cs_cuboid_batch *b);
  * pixels A, total enumerated hypotheses, total valid proposals. */
 int cs_cuboid_batch_stats(cs_ctx *ctx, cs_cuboid_batch *b, long *n_units, long *roi_pixels, long *n_hypotheses,
                           long *n_valid);
+/* The same facts split by scoring kernel (valid after run + sync).  out[0..2] = units, ROI pixels, valid proposals scored by
+ * cuboid_sweep_score (the unit's 16-bit chamfer code map fits one CU's LDS); out[3..5] = the same for cuboid_sweep_score_big (larger
+ * ROIs, or a pixel farther than 244 px from every edge), which gathers from the float map. */
+int cs_cuboid_batch_score_stats(cs_ctx *ctx, cs_cuboid_batch *b, long out[6]);
 
 /* Introspection for parity tests (after run).  unit = index over (frame, box, height-sample) in that order.
  *   dims    : [roi_x, roi_y, roi_w, roi_h, n_hyp_capacity, n_valid, n_merged_lines, n_yaw, frame, box, height_sample, n_height_samples]
@@ -200,6 +204,8 @@ int cs_matcher_set_frame_from_orb(cs_ctx *ctx, cs_matcher *m, const cs_orb *orb,
                                   float maxY, cs_keypoint *keysUn_out, int *n_out);
 /* Frame::ComputeImageBounds (Frame.cc:578-609): bounds = mnMinX, mnMaxX, mnMinY, mnMaxY of the undistorted image corners. */
 int cs_frame_image_bounds(int cols, int rows, const float *K4, const float *dist5, float *bounds);
+/* Workload facts of the last search on this matcher (queries, candidates the search windows enumerated), for roofline accounting. */
+int cs_matcher_last_counts(const cs_matcher *m, int *queries, long *candidates);
 /* Frame::GetFeaturesInArea(x, y, r, minLevel, maxLevel) on the frame set above; *n = count (may exceed cap). */
 int cs_matcher_features_in_area(cs_ctx *ctx, cs_matcher *m, float x, float y, float r, int minLevel, int maxLevel,
                                 int *out, int cap, int *n);
