@@ -300,6 +300,8 @@ void pyrDown(InputArray src, OutputArray dst, const Size &dstsize = Size(), int 
 void merge(const std::vector<Mat> &mv, OutputArray dst);      // drawing helpers of lsd.cpp: never called, declared so the file compiles
 void bitwise_xor(InputArray a, InputArray b, OutputArray dst);
 int countNonZero(InputArray a);
+inline void imshow(const String &, InputArray) {}
+inline int waitKey(int = 0) { return -1; }
 void line(InputOutputArray img, Point pt1, Point pt2, const Scalar &color, int thickness = 1, int lineType = 8, int shift = 0);
 inline Mat operator-(const Scalar &s, const Mat &m) { // only `255 - edges` on CV_8U (box_proposal_detail.cpp)
     Mat r(m.rows, m.cols, m.type());

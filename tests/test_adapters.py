@@ -1,0 +1,35 @@
+"""The drop-in translation units under adapters/ compile against the REFERENCE'S OWN headers (the class definitions are the reference's):
+adapters/ORBextractor_hip.cc and adapters/line_lbd_allclass_hip.cpp for real (objects + oracle/_ref/libadapters.so, with oracle/ref_shim/ standing
+in for the OpenCV headers), adapters/detect_3d_cuboid_hip.cpp with -fsyntax-only against a syntax-level Eigen stand-in.  The GPU box then runs
+the first two through the reference's class interfaces (tests/test_adapters_gpu.py)."""
+import os
+import subprocess
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = "/root/reference"
+pytestmark = pytest.mark.skipif(not os.path.isdir(REF), reason="the adapters are compiled against the reference's headers under /root/reference")
+
+
+def test_orb_and_line_adapters_build_against_the_reference_headers(oracle):
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "cube_slam_amd", "csrc")])
+    subprocess.check_call(["make", "-s", "-C", os.path.join(ROOT, "oracle"), "-f", "Makefile.ref"])
+    so = os.path.join(ROOT, "oracle", "_ref", "libadapters.so")
+    assert os.path.exists(so)
+    undefined = subprocess.check_output(["nm", "-D", "--undefined-only", so], text=True)
+    ours = [l.split()[-1] for l in undefined.splitlines() if " cs_" in l]
+    assert {"cs_orb_create", "cs_orb_extract", "cs_orb_get_level", "cs_lsd_detect", "cs_lbd_compute", "cs_lbd_match"} <= set(ours)  # the C-ABI is the only way in
+    exported = subprocess.check_output(["nm", "-D", "--defined-only", so], text=True)
+    for sym in ("_ZN9ORB_SLAM212ORBextractorclERKN2cv11_InputArrayES4_RSt6vectorINS1_8KeyPointESaIS6_EERKNS1_12_OutputArrayE",  # ORBextractor::operator()
+                "_ZN15line_lbd_detect19detect_filter_linesERKN2cv3MatERS1_"):                                                        # detect_filter_lines(Mat, Mat&)
+        assert sym in exported, sym
+
+
+def test_cuboid_adapter_type_checks_against_the_reference_header():
+    """detect_3d_cuboid::set_calibration / set_cam_pose / detect_cuboid as members of the reference's class (detect_3d_cuboid.h:53-79),
+    including cam_pose, cam_pose_raw and cuboids_2d_img."""
+    cmd = ["g++", "-std=c++14", "-fsyntax-only", "-w", "-I" + os.path.join(ROOT, "oracle", "ref_shim", "syntax"), "-I" + os.path.join(ROOT, "oracle", "ref_shim"),
+           "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(REF, "detect_3d_cuboid", "include"), os.path.join(ROOT, "adapters", "detect_3d_cuboid_hip.cpp")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
