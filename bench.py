@@ -142,19 +142,7 @@ def ba_bench(ctx, rank, world, iters, with_cpu):
     from cube_slam_amd import synth
     from cube_slam_amd.ba import BundleAdjuster
     d = synth.ba_problem(20260923, n_kf=1000, n_points=100000, n_cuboids=500)
-    allreduce = None
-    if world > 1:
-        import torch
-        import torch.distributed as dist
-
-        class _Dev:  # wraps the raw device pointer for torch (no copy)
-            def __init__(self, ptr, n):
-                self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 3}
-
-        def allreduce(ptr, n):
-            t = torch.as_tensor(_Dev(ptr, n), device="cuda")
-            dist.all_reduce(t)
-            torch.cuda.synchronize()
+    allreduce = None  # world > 1: the library's own RCCL communicator (cs_comm_init in main) all-reduces the reduced camera system
     ba = BundleAdjuster(d, ctx=ctx, rank=rank, world=world, allreduce=allreduce)
     ba.optimize(1)  # warm-up (also pages the kernels in)
     ba.close()
@@ -365,6 +353,12 @@ def main():
     from cube_slam_amd.cuboid import CuboidBatch, detect_3d_cuboid
 
     ctx = _lib.Context(local_rank, priority=1)  # ORB + cuboid: the path a tracking thread waits for
+    if world > 1:  # RCCL inside the library: rank 0's ncclUniqueId travels through the process group that the timing barrier uses anyway
+        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
+        if rank == 0:
+            uid.copy_(torch.frombuffer(bytearray(_lib.Context.comm_unique_id()), dtype=torch.uint8))
+        dist.broadcast(uid, 0)
+        ctx.comm_init(rank, world, bytes(uid.cpu().numpy().tobytes()))
     scenes = make_frames(args.frames, args.boxes, seed0=1000 + 100000 * rank)
     det = detect_3d_cuboid(ctx)
     det.set_calibration(scenes[0]["K"])

@@ -66,6 +66,20 @@ class Context:
         check(self._ctx, lib().cs_timing_get(self._ctx, name.encode(), C.byref(ms), C.byref(n)), "cs_timing_get")
         return ms.value, n.value
 
+    @staticmethod
+    def comm_unique_id():
+        """ncclUniqueId (128 bytes): rank 0 creates it, every rank passes the same bytes to comm_init."""
+        buf = (C.c_ubyte * 128)()
+        r = lib().cs_comm_unique_id(buf)
+        if r != CS_OK:
+            raise CubeSlamError("cs_comm_unique_id failed: %s" % STATUS.get(r, r))
+        return bytes(buf)
+
+    def comm_init(self, rank, world, unique_id):
+        """RCCL communicator of this rank on the context's stream (cs_comm_init)."""
+        buf = (C.c_ubyte * 128).from_buffer_copy(bytes(unique_id))
+        check(self._ctx, lib().cs_comm_init(self._ctx, int(rank), int(world), buf), "cs_comm_init")
+
     def close(self):
         if self._ctx:
             lib().cs_destroy(self._ctx)

@@ -1372,12 +1372,22 @@ static double sum_partials(cs_ctx *ctx, cs_ba *b, int n, bool is_max = false) {
     for (int i = 0; i < n; i++) s = is_max ? std::max(s, b->h_partials[i]) : s + b->h_partials[i];
     return s;
 }
-// sum of k host scalars across ranks (uses the device all-reduce callback)
+// all-reduce(sum) of n doubles in device memory across the ranks: the caller's callback when one is registered (it may use another stream or
+// library, so the context's stream is drained first), else RCCL on the context's own stream (cs_comm_init), which needs no host round trip
+static int ba_allreduce(cs_ctx *ctx, cs_ba *b, double *dbuf, long n) {
+    if (b->world <= 1) return CS_OK;
+    if (b->allreduce) {
+        CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        if (b->allreduce(b->ar_user, dbuf, n) != 0) { ctx->err = "all-reduce callback failed"; return CS_ERR_HIP; }
+        return CS_OK;
+    }
+    return cs_comm_allreduce_sum_f64(ctx, dbuf, n);
+}
+// sum of k host scalars across ranks (k <= the size of d_scal: 6 P + world + 64)
 static int allreduce_scalars(cs_ctx *ctx, cs_ba *b, double *v, int k) {
-    if (b->world <= 1 || !b->allreduce) return CS_OK;
+    if (b->world <= 1) return CS_OK;
     int r = cs_h2d(ctx, b->d_scal, v, (size_t)k); if (r) return r;
-    CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (b->allreduce(b->ar_user, b->d_scal, k) != 0) { ctx->err = "all-reduce callback failed"; return CS_ERR_HIP; }
+    r = ba_allreduce(ctx, b, b->d_scal, k); if (r) return r;
     r = cs_d2h(ctx, v, b->d_scal, (size_t)k); if (r) return r;
     CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return CS_OK;
@@ -1419,12 +1429,11 @@ static int ba_schur(cs_ctx *ctx, cs_ba *b, double lambda) { // Schur part of Blo
 static int ba_solve(cs_ctx *ctx, cs_ba *b, double lambda, bool *ok, bool defer_status = false) { // BlockSolver::solve; defer_status: the caller reads d_status later
     const Params &G = b->G;
     int r = ba_schur(ctx, b, lambda); if (r) return r;
-    if (b->world > 1 && b->allreduce) {
-        CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (b->world > 1) { // one fused buffer [36 * slots | 6 * P] per LM trial
         ctx->begin("ba_allreduce");
-        int rc = b->allreduce(b->ar_user, b->d_reduce, b->reduce_len);
+        const int rc = ba_allreduce(ctx, b, b->d_reduce, b->reduce_len);
         ctx->end();
-        if (rc != 0) { ctx->err = "all-reduce callback failed"; return CS_ERR_HIP; }
+        if (rc != CS_OK) return rc;
     }
     const int nl = G.lm_e - G.lm_b;
     if (b->use_band) {
@@ -1805,7 +1814,7 @@ int cs_ba_create(cs_ctx *ctx, const cs_ba_problem *p, int rank, int world, cs_ba
     A_(dalloc_copy(ctx, b, &b->d_band, (const double *)nullptr, (size_t)b->band_len));
     A_(dalloc_copy(ctx, b, &b->d_xperm, (const double *)nullptr, (size_t)P * 6));
     A_(dalloc_copy(ctx, b, &b->d_partials, (const double *)nullptr, (size_t)b->max_part * 3)); // three regions: scale | chi2 of the observations | chi2 of the pose edges
-    A_(dalloc_copy(ctx, b, &b->d_scal, (const double *)nullptr, (size_t)std::max(64, world)));
+    A_(dalloc_copy(ctx, b, &b->d_scal, (const double *)nullptr, (size_t)G.P * 6 + (size_t)world + 64));
     A_(dalloc_copy(ctx, b, &b->d_bak_cam, (const double *)nullptr, (size_t)p->n_cams * 7));
     A_(dalloc_copy(ctx, b, &b->d_bak_pts, (const double *)nullptr, (size_t)std::max(p->n_points, 1) * 3));
     A_(dalloc_copy(ctx, b, &b->d_bak_cub, (const double *)nullptr, (size_t)std::max(p->n_cuboids, 1) * 7));
@@ -1888,7 +1897,7 @@ int cs_ba_read(cs_ctx *ctx, cs_ba *b, double *cam_pose, double *points, double *
 int cs_ba_optimize(cs_ctx *ctx, cs_ba *b, int iterations, const volatile int *stop_flag, cs_ba_stats *st) {
     if (!ctx || !b || iterations < 0) return CS_ERR_BAD_ARG;
     CS_HIP(ctx, hipSetDevice(ctx->device));
-    if (b->world > 1 && !b->allreduce) { ctx->err = "sharded BA needs cs_ba_set_allreduce"; return CS_ERR_BAD_ARG; }
+    if (b->world > 1 && !b->allreduce && !(ctx->comm && ctx->comm_world == b->world)) { ctx->err = "sharded BA needs cs_comm_init (RCCL) or cs_ba_set_allreduce"; return CS_ERR_BAD_ARG; }
     const Params &G = b->G;
     cs_ba_stats S;
     memset(&S, 0, sizeof(S));
@@ -1916,7 +1925,7 @@ int cs_ba_optimize(cs_ctx *ctx, cs_ba *b, int iterations, const volatile int *st
                 std::vector<double> buf((size_t)G.P * 6 + b->world, 0.0);
                 for (int i = 0; i < G.P; i++) for (int k = 0; k < 6; k++) buf[(size_t)i * 6 + k] = hpp[(size_t)i * 36 + k * 7];
                 buf[(size_t)G.P * 6 + b->rank] = mxl;
-                for (size_t o0 = 0; o0 < buf.size(); o0 += 64) { int k = (int)std::min<size_t>(64, buf.size() - o0); r = allreduce_scalars(ctx, b, &buf[o0], k); if (r) return r; }
+                r = allreduce_scalars(ctx, b, buf.data(), (int)buf.size()); if (r) return r; // one collective (it was one per 64 scalars)
                 mx = 0;
                 for (double d : buf) mx = std::max(mx, std::fabs(d));
             } else

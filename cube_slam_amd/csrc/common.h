@@ -16,6 +16,8 @@ struct cs_timing_rec {
 };
 
 int cs_host_threads(); // ctx.hip
+struct cs_ctx;
+int cs_comm_allreduce_sum_f64(cs_ctx *ctx, double *device_buf, long n); // ctx.hip: ncclAllReduce(sum, double) in place on the context's stream
 void cs_omp_prepare();
 // orb.hip: device-resident results of the last cs_orb_run for one frame (keypoints in mvKeys order, 4 x u64 descriptors), for
 // consumers inside the library that must not round-trip through the host (match.hip)
@@ -28,6 +30,8 @@ struct cs_ctx {
     std::string err;
     bool timing = false;
     int host_threads = 1; // CPUs this process may really use (affinity mask and cgroup CPU quota), see cs_host_threads()
+    void *comm = nullptr;  // RCCL communicator of this rank (cs_comm_init, ctx.hip); collectives run on `stream`
+    int comm_rank = 0, comm_world = 1;
     std::map<std::string, cs_timing_rec> timings;
     struct pending_ev { std::string name; hipEvent_t a, b; };
     std::vector<pending_ev> pending;

@@ -1,6 +1,7 @@
 // ctx.hip -- context lifecycle + timing queries of the C-ABI (include/cubeslam_hip.h)
 #include "common.h"
 
+#include <dlfcn.h>
 #include <omp.h>
 #include <sched.h>
 
@@ -41,7 +42,71 @@ void cs_omp_prepare() {
     if (!done) { kmp_set_blocktime(0); done = true; }
 }
 
+// ---- RCCL (xGMI) inside the library.  librccl.so is opened at cs_comm_init, not linked: a single-GPU host needs no RCCL, and in a process
+// that already holds a copy (PyTorch ships one) the same soname resolves to that copy instead of a second runtime.
+namespace {
+typedef struct { char internal[128]; } rccl_unique_id; // ncclUniqueId
+struct Rccl {
+    void *h = nullptr;
+    int (*GetUniqueId)(rccl_unique_id *) = nullptr;
+    int (*CommInitRank)(void **, int, rccl_unique_id, int) = nullptr;
+    int (*AllReduce)(const void *, void *, size_t, int, int, void *, hipStream_t) = nullptr;
+    int (*CommDestroy)(void *) = nullptr;
+    const char *(*GetErrorString)(int) = nullptr;
+    bool load() {
+        if (h) return true;
+        for (const char *n : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) { h = dlopen(n, RTLD_NOW | RTLD_GLOBAL); if (h) break; }
+        if (!h) return false;
+        GetUniqueId = (int (*)(rccl_unique_id *))dlsym(h, "ncclGetUniqueId");
+        CommInitRank = (int (*)(void **, int, rccl_unique_id, int))dlsym(h, "ncclCommInitRank");
+        AllReduce = (int (*)(const void *, void *, size_t, int, int, void *, hipStream_t))dlsym(h, "ncclAllReduce");
+        CommDestroy = (int (*)(void *))dlsym(h, "ncclCommDestroy");
+        GetErrorString = (const char *(*)(int))dlsym(h, "ncclGetErrorString");
+        return GetUniqueId && CommInitRank && AllReduce && CommDestroy;
+    }
+} g_rccl;
+constexpr int RCCL_DOUBLE = 8, RCCL_SUM = 0; // ncclFloat64, ncclSum (nccl.h enums)
+} // namespace
+
+int cs_comm_allreduce_sum_f64(cs_ctx *ctx, double *device_buf, long n) {
+    if (!ctx || !ctx->comm || n < 0) return CS_ERR_BAD_ARG;
+    if (n == 0) return CS_OK;
+    const int rc = g_rccl.AllReduce(device_buf, device_buf, (size_t)n, RCCL_DOUBLE, RCCL_SUM, ctx->comm, ctx->stream);
+    if (rc != 0) { ctx->err = std::string("ncclAllReduce: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error"); return CS_ERR_HIP; }
+    return CS_OK;
+}
+
 extern "C" {
+
+int cs_comm_unique_id(void *id128) {
+    if (!id128) return CS_ERR_BAD_ARG;
+    if (!g_rccl.load()) return CS_ERR_NO_DEVICE;
+    rccl_unique_id id;
+    if (g_rccl.GetUniqueId(&id) != 0) return CS_ERR_HIP;
+    memcpy(id128, &id, sizeof(id));
+    return CS_OK;
+}
+int cs_comm_init(cs_ctx *ctx, int rank, int world, const void *id128) {
+    if (!ctx || !id128 || world < 1 || rank < 0 || rank >= world) return CS_ERR_BAD_ARG;
+    if (ctx->comm) return CS_ERR_BAD_ARG;
+    if (!g_rccl.load()) { ctx->err = "librccl.so not found"; return CS_ERR_NO_DEVICE; }
+    CS_HIP(ctx, hipSetDevice(ctx->device));
+    rccl_unique_id id;
+    memcpy(&id, id128, sizeof(id));
+    void *comm = nullptr;
+    const int rc = g_rccl.CommInitRank(&comm, world, id, rank);
+    if (rc != 0) { ctx->err = std::string("ncclCommInitRank: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "error"); return CS_ERR_HIP; }
+    ctx->comm = comm; ctx->comm_rank = rank; ctx->comm_world = world;
+    return CS_OK;
+}
+int cs_comm_allreduce_f64(cs_ctx *ctx, double *device_buf, long n) { return cs_comm_allreduce_sum_f64(ctx, device_buf, n); }
+void cs_comm_destroy(cs_ctx *ctx) {
+    if (!ctx || !ctx->comm) return;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    g_rccl.CommDestroy(ctx->comm);
+    ctx->comm = nullptr; ctx->comm_rank = 0; ctx->comm_world = 1;
+}
 
 int cs_host_thread_count(void) { return cs_host_threads(); }
 
@@ -74,6 +139,7 @@ void cs_destroy(cs_ctx *ctx) {
     if (!ctx) return;
     hipSetDevice(ctx->device);
     ctx->flush();
+    cs_comm_destroy(ctx);
     for (auto e : ctx->pool) hipEventDestroy(e);
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;

@@ -37,6 +37,18 @@ int cs_create(int device_id, cs_ctx **out);
 int cs_create_with_priority(int device_id, int priority, cs_ctx **out);
 void cs_destroy(cs_ctx *ctx);
 const char *cs_last_error(const cs_ctx *ctx);
+
+/* RCCL over xGMI inside the library (one process per GPU).  Rank 0 calls cs_comm_unique_id and hands the 128 bytes to the other ranks by
+ * any out-of-band means (MPI, a socket, torch.distributed, a file); every rank then calls cs_comm_init on its context.  A sharded cs_ba
+ * (world > 1) without a cs_ba_set_allreduce callback all-reduces the reduced camera system with ncclAllReduce(ncclDouble, ncclSum) on the
+ * context's own stream: one fused buffer [36 * slots | 6 * P] per LM trial, no host synchronisation around it.  librccl.so is opened at
+ * cs_comm_init (not a link-time dependency). */
+#define CS_COMM_ID_BYTES 128
+int cs_comm_unique_id(void *id128);
+int cs_comm_init(cs_ctx *ctx, int rank, int world, const void *id128);
+void cs_comm_destroy(cs_ctx *ctx);
+/* ncclAllReduce(ncclDouble, ncclSum) in place over n doubles of device memory, enqueued on the context's stream (no synchronisation). */
+int cs_comm_allreduce_f64(cs_ctx *ctx, double *device_buf, long n);
 int cs_version(void);
 /* Blocks until all work queued on the context's stream is done. */
 int cs_sync(cs_ctx *ctx);
