@@ -9,6 +9,7 @@
 // region_grow (each accepted pixel updates the region angle that the next test uses, :665-683), region2rect, refine,
 // rect_improve, rect_nfa, nfa -- which has no order-preserving parallel form.  Double precision as in the reference.
 #include "common.h"
+#include "lsd_regions.h"
 
 #include <cfloat>
 #include <chrono>
@@ -524,6 +525,8 @@ struct cs_lsd {
     std::vector<int> line_off;       // per frame offset into the concatenated line list
     std::vector<uint8_t> h_desc;     // concatenated n x 32
     bool have_desc = false;
+    LsdRegions *regions = nullptr;   // device buffers of the region stage (lsd_regions.hip)
+    long rg_stats[5] = {0, 0, 0, 0, 0}; // last batch: rounds, transactions, candidate regions, 1 = fell back to the host stage, lane steps
 };
 
 int cs_lbd_batch_maps(cs_ctx *ctx, const uint8_t *d_gray, int W, int H, int F, uint8_t *d_blur, uint32_t *d_dxy);
@@ -573,7 +576,22 @@ static int lsd_run(cs_ctx *ctx, cs_lsd *l, int with_lbd) {
         r = cs_dalloc(ctx, &l->d_cmod, cap); if (r) return r;
         l->ccap = cap;
     }
-    if (total > l->hcap) {
+    // region growing / rectangles / NFA: the host stage below, or with CUBESLAM_LSD_REGIONS=device the device stage (lsd_regions.hip: the same
+    // segments bit for bit, but a latency-bound fixed point that is slower than 16 host threads on this box -- DESIGN.md has the numbers)
+    std::vector<std::vector<float>> dev_lines;
+    bool on_device = false;
+    if (total > 0) CS_LAUNCH(ctx, "lsd_emit", lsd_emit, dim3(nbx, h, F), dim3(256), 0, l->d_mod, l->d_ang, w, h, l->d_seg_base, l->d_caddr, l->d_cang, l->d_cmod);
+    {
+        const char *mode = getenv("CUBESLAM_LSD_REGIONS");
+        if (total > 0 && mode && strcmp(mode, "device") == 0) {
+            long st[4] = {0, 0, 0, 0};
+            r = lsd_regions_run(ctx, &l->regions, F, w, h, l->d_ang, l->d_mod, l->d_caddr, l->frame_base.data(), dev_lines, st);
+            l->rg_stats[0] = st[0]; l->rg_stats[1] = st[1]; l->rg_stats[2] = st[2]; l->rg_stats[3] = r == CS_OK ? 0 : 1; l->rg_stats[4] = st[3];
+            if (r == CS_OK) on_device = true;
+            else if (r != CS_ERR_CAPACITY) return r; // a frame outgrew a device buffer or did not settle: the host stage takes the batch
+        }
+    }
+    if (!on_device && total > l->hcap) {
         if (l->h_caddr) hipHostFree(l->h_caddr); if (l->h_cang) hipHostFree(l->h_cang); if (l->h_cmod) hipHostFree(l->h_cmod);
         l->h_caddr = nullptr; l->h_cang = nullptr; l->h_cmod = nullptr; l->hcap = 0;
         const size_t cap = total + total / 4 + 4096;
@@ -581,8 +599,7 @@ static int lsd_run(cs_ctx *ctx, cs_lsd *l, int with_lbd) {
             hipHostMalloc((void **)&l->h_cmod, cap * sizeof(double), hipHostMallocDefault) != hipSuccess) return CS_ERR_NOMEM;
         l->hcap = cap;
     }
-    if (total > 0) {
-        CS_LAUNCH(ctx, "lsd_emit", lsd_emit, dim3(nbx, h, F), dim3(256), 0, l->d_mod, l->d_ang, w, h, l->d_seg_base, l->d_caddr, l->d_cang, l->d_cmod);
+    if (!on_device && total > 0) {
         r = cs_d2h(ctx, l->h_caddr, l->d_caddr, total); if (r) return r;
         r = cs_d2h(ctx, l->h_cang, l->d_cang, total); if (r) return r;
         r = cs_d2h(ctx, l->h_cmod, l->d_cmod, total); if (r) return r;
@@ -601,6 +618,7 @@ static int lsd_run(cs_ctx *ctx, cs_lsd *l, int with_lbd) {
     ctx->pool.push_back(ev);
     // one host stage at a time per process: two line detectors that alternate batches (bench.py) overlap their GPU phases with
     // the other's region growing instead of splitting the host cores between two OpenMP teams
+    if (!on_device) {
     static std::mutex host_stage;
     std::unique_lock<std::mutex> host_lock(host_stage);
     const auto t0 = std::chrono::steady_clock::now();
@@ -633,6 +651,10 @@ static int lsd_run(cs_ctx *ctx, cs_lsd *l, int with_lbd) {
     }
     if (ctx->timing) { auto &rec = ctx->timings["host_lsd_regions"]; rec.total_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); rec.count++; }
     host_lock.unlock();
+    } else {
+        l->keylines.assign((size_t)F, {});
+        for (int f = 0; f < F; f++) to_keylines(dev_lines[f], W, H, l->keylines[f]);
+    }
     l->line_off.assign((size_t)F + 1, 0);
     for (int f = 0; f < F; f++) l->line_off[f + 1] = l->line_off[f] + (int)l->keylines[f].size();
     if (with_lbd) {
@@ -673,6 +695,7 @@ void cs_lsd_destroy(cs_ctx *ctx, cs_lsd *l) {
     void *ptrs[] = {l->d_gray, l->d_tmp, l->d_blur, l->d_scaled, l->d_mod, l->d_ang, l->d_xofs, l->d_yofs, l->d_ax, l->d_ay, l->d_lblur, l->d_dxy};
     for (void *p : ptrs) if (p) hipFree(p);
     lsd_free_lines(l);
+    lsd_regions_destroy(l->regions);
     void *more[] = {l->d_seg_cnt, l->d_seg_base, l->d_blk_tot, l->d_caddr, l->d_cang, l->d_cmod};
     for (void *p : more) if (p) hipFree(p);
     if (l->h_caddr) hipHostFree(l->h_caddr);
@@ -754,6 +777,12 @@ int cs_lsd_upload(cs_ctx *ctx, cs_lsd *l, const uint8_t *gray, int n_frames, int
 }
 
 int cs_lsd_run(cs_ctx *ctx, cs_lsd *l, int with_lbd) { return lsd_run(ctx, l, with_lbd); }
+
+int cs_lsd_region_stats(cs_ctx *ctx, cs_lsd *l, long out[5]) {
+    if (!ctx || !l || !out) return CS_ERR_BAD_ARG;
+    for (int i = 0; i < 5; i++) out[i] = l->rg_stats[i];
+    return CS_OK;
+}
 
 int cs_lsd_read(cs_ctx *ctx, cs_lsd *l, int frame, cs_keyline *out, int cap, int *count, uint8_t *desc) {
     if (!ctx || !l || frame < 0 || frame >= l->n_frames || !count || (int)l->keylines.size() <= frame || (desc && !l->have_desc)) return CS_ERR_BAD_ARG;

@@ -44,6 +44,12 @@ class line_lbd_detect:
     def run(self, with_lbd=True):
         check(self.ctx.ptr, lib().cs_lsd_run(self.ctx.ptr, self._l, int(with_lbd)), "cs_lsd_run")
 
+    def region_stats(self):
+        """Region stage of the last batch: dict(rounds, transactions, candidates, host_fallback) -- see cs_lsd_region_stats."""
+        st = (C.c_long * 5)()
+        check(self.ctx.ptr, lib().cs_lsd_region_stats(self.ctx.ptr, self._l, st), "cs_lsd_region_stats")
+        return {"rounds": st[0], "transactions": st[1], "candidates": st[2], "host_fallback": bool(st[3]), "lane_steps": st[4]}
+
     def read(self, frame, with_desc=True):
         n = C.c_int()
         check(self.ctx.ptr, lib().cs_lsd_read(self.ctx.ptr, self._l, frame, None, 0, C.byref(n), None), "cs_lsd_read")

@@ -36,3 +36,18 @@ def test_other_sizes_and_flat(ctx, oracle):
     assert det.detect_raw_lines(img).tobytes() == oracle.lsd_detect(img).tobytes()
     assert len(det.detect_raw_lines(np.full((376, 1241), 90, np.uint8))) == 0
     det.close()
+
+
+def test_device_region_stage_equals_host_stage(ctx, oracle, monkeypatch):
+    """CUBESLAM_LSD_REGIONS=device: region growing / rectangles / NFA as a speculative fixed point on the device (lsd_regions.hip)."""
+    imgs = [np.load(os.path.join(GOLD, "orb_cabinet.npz"))["gray"], synth.cuboid_scene(7, n_boxes=3, bg_texture=0.5)["gray"], synth.texture_image(8, 640, 480)]
+    det = line_lbd_detect(640, 480, max_frames=3, ctx=ctx)
+    host = det.detect_raw_lines(np.stack(imgs))
+    monkeypatch.setenv("CUBESLAM_LSD_REGIONS", "device")
+    dev = det.detect_raw_lines(np.stack(imgs))
+    st = det.region_stats()
+    assert not st["host_fallback"] and st["rounds"] > 3 and st["candidates"] > 100
+    for f, img in enumerate(imgs):
+        assert dev[f].tobytes() == host[f].tobytes()
+        assert dev[f].tobytes() == oracle.lsd_detect(img).tobytes()
+    det.close()
