@@ -4,10 +4,10 @@
 // Optimizer.cc -- PoseOptimization, the essential graph, Sim3 -- is untouched).  Needs the reference's SLAM headers, OpenCV and Eigen:
 // it is not compiled in this repository's environment (adapters/README.md).
 //
-// Optimizer::LocalBACameraPointObjects (:826-1534) uses the same flattening for its local window plus the cuboid vertices / edges; its
-// graph-level rules (which points and objects enter, information weights, the 5 + 10 two-stage scheme with re-levelling) are restated and
-// tested on flat arrays in cube_slam_amd/ba_objects.py (LocalBACameraPointObjects there), which is the specification for this file's second
-// entry point.
+// Optimizer::LocalBACameraPointObjects (:826-1534, second half of this file): the window is gathered from the map exactly as :829-913 does,
+// flattened into cubeslam::LocalWindow, and handed to cube_slam_amd/host/local_ba_objects.hpp, which holds the graph-level rules (which points
+// and objects enter, information weights, the 5 + 10 two-stage scheme with re-levelling) -- the C++ twin of cube_slam_amd/ba_objects.py, both
+// tested against the oracle's restatement (tests/test_local_ba_objects.py).  Write-back and erasure as :1477-1533.
 #include "Optimizer.h"
 
 #include <map>
@@ -16,6 +16,10 @@
 
 #include "Converter.h"
 #include "cubeslam_hip.h"
+#include "cube_slam_amd/host/local_ba_objects.hpp"
+#include "MapObject.h"
+#include "Parameters.h"
+#include "g2o_Object.h"
 
 namespace ORB_SLAM2 {
 namespace {
@@ -124,6 +128,121 @@ void Optimizer::BundleAdjustment(const std::vector<KeyFrame *> &vpKFs, const std
         for (int k = 0; k < 3; k++) X.at<float>(k) = (float)points[(size_t)point_of_mp[i] * 3 + k];
         if (nLoopKF == 0) { pMP->SetWorldPos(X); pMP->UpdateNormalAndDepth(); }
         else { pMP->mPosGBA.create(3, 1, CV_32F); X.copyTo(pMP->mPosGBA); pMP->mnBAGlobalForKF = nLoopKF; }
+    }
+}
+
+
+void Optimizer::LocalBACameraPointObjects(KeyFrame *pKF, bool *pbStopFlag, Map *pMap, bool fixCamera, bool fixPoint) {
+    if (fixPoint) throw std::runtime_error("LocalBACameraPointObjects (HIP): fixPoint is not supported (LocalMapping.cc:68 passes false)");
+    // ---- the window :829-913 (pointer walking stays here; the marker fields are the reference's)
+    std::vector<KeyFrame *> lLocalKeyFrames{pKF};
+    pKF->mnBALocalForKF = pKF->mnId;
+    for (KeyFrame *pKFi : pKF->GetVectorCovisibleKeyFrames()) { pKFi->mnBALocalForKF = pKF->mnId; if (!pKFi->isBad()) lLocalKeyFrames.push_back(pKFi); }
+    std::vector<MapPoint *> lLocalMapPoints;
+    for (KeyFrame *k : lLocalKeyFrames)
+        for (MapPoint *pMP : k->GetMapPointMatches())
+            if (pMP && !pMP->isBad() && pMP->mnBALocalForKF != pKF->mnId) {
+                if (whether_dynamic_object && pMP->is_dynamic) continue;
+                lLocalMapPoints.push_back(pMP); pMP->mnBALocalForKF = pKF->mnId;
+            }
+    std::vector<MapObject *> lLocalMapObjects;
+    for (KeyFrame *k : lLocalKeyFrames)
+        for (MapObject *pMO : k->cuboids_landmark)
+            if (pMO && !pMO->isBad() && pMO->mnBALocalForKF != pKF->mnId) { lLocalMapObjects.push_back(pMO); pMO->mnBALocalForKF = pKF->mnId; }
+    std::vector<KeyFrame *> lFixedCameras;
+    auto add_fixed = [&](KeyFrame *pKFi) {
+        if (pKFi->mnBALocalForKF != pKF->mnId && pKFi->mnBAFixedForKF != pKF->mnId) { pKFi->mnBAFixedForKF = pKF->mnId; if (!pKFi->isBad()) lFixedCameras.push_back(pKFi); }
+    };
+    for (MapPoint *pMP : lLocalMapPoints) for (auto &ob : pMP->GetObservations()) add_fixed(ob.first);
+    for (MapObject *pMO : lLocalMapObjects) for (auto &ob : pMO->GetObservations()) add_fixed(ob.first);
+
+    // ---- flatten
+    cubeslam::LocalWindow w;
+    std::vector<KeyFrame *> kfs(lLocalKeyFrames);
+    kfs.insert(kfs.end(), lFixedCameras.begin(), lFixedCameras.end());
+    std::map<KeyFrame *, int> kf_row;
+    w.n_local = (int)lLocalKeyFrames.size();
+    w.kf_pose.resize(kfs.size() * 7);
+    for (size_t i = 0; i < kfs.size(); i++) { kf_row[kfs[i]] = (int)i; w.kf_id.push_back((long)kfs[i]->mnId); pose_to_vec7(kfs[i]->GetPose(), &w.kf_pose[i * 7]); }
+    const cv::Mat Ow = pKF->GetCameraCenter();
+    for (int a = 0; a < 3; a++) w.cur_cam_center[a] = Ow.at<float>(a);
+    for (size_t j = 0; j < lLocalMapPoints.size(); j++) {
+        MapPoint *pMP = lLocalMapPoints[j];
+        const cv::Mat X = pMP->GetWorldPos();
+        for (int a = 0; a < 3; a++) w.mp_pos.push_back(X.at<float>(a));
+        w.mp_nobs.push_back(pMP->Observations());
+        for (auto &ob : pMP->GetObservations()) {
+            KeyFrame *pKFi = ob.first;
+            if (pKFi->isBad()) continue;
+            const cv::KeyPoint &kpUn = pKFi->mvKeysUn[ob.second];
+            w.obs_mp.push_back((int)j); w.obs_kf.push_back(kf_row.at(pKFi)); w.obs_uv.push_back(kpUn.pt.x); w.obs_uv.push_back(kpUn.pt.y);
+            w.obs_ur.push_back(pKFi->mvuRight[ob.second] < 0 ? -1.0 : (double)pKFi->mvuRight[ob.second]);
+            w.obs_inv_sigma2.push_back(pKFi->mvInvLevelSigma2[kpUn.octave]);
+        }
+    }
+    std::vector<MapPoint *> up_point; // the map point behind every row of w.up_*
+    for (size_t i = 0; i < lLocalMapObjects.size(); i++) {
+        MapObject *pMO = lLocalMapObjects[i];
+        const g2o::cuboid cube = pMO->GetWorldPos();
+        const Eigen::Matrix<double, 7, 1> pv = cube.pose.toVector();
+        for (int a = 0; a < 7; a++) w.mo_pose.push_back(pv[a]);
+        for (int a = 0; a < 3; a++) w.mo_scale.push_back(cube.scale[a]);
+        w.mo_meas_quality.push_back(pMO->meas_quality);
+        w.mo_largest_point_observations.push_back(pMO->largest_point_observations);
+        pMO->point_object_BA_counter++; pMO->used_points_in_BA.clear(); pMO->used_points_in_BA_filtered.clear();                         // :1151-1153
+        pMO->pointOwnedThreshold = std::max(int(pMO->largest_point_observations * 0.4), 2);                                              // :1157-1158
+        for (MapPoint *pMP : pMO->GetUniqueMapPoints())
+            if (pMP && !pMP->isBad()) {
+                const cv::Mat X = pMP->GetWorldPos();
+                up_point.push_back(pMP);
+                w.up_mo.push_back((int)i); w.up_count.push_back(pMP->MapObjObservations[pMO]);
+                for (int a = 0; a < 3; a++) w.up_pos.push_back(X.at<float>(a));
+            }
+        for (auto &ob : pMO->GetObservations()) {
+            KeyFrame *pKFi = ob.first;
+            if (pKFi->isBad()) continue;
+            const MapObject *local_object = pKFi->local_cuboids[ob.second];
+            w.det_mo.push_back((int)i); w.det_kf.push_back(kf_row.at(pKFi));
+            for (int a = 0; a < 4; a++) w.det_bbox_vec.push_back(local_object->bbox_vec[a]);
+            const cv::Rect r = local_object->bbox_2d;
+            w.det_bbox_2d.push_back(r.x); w.det_bbox_2d.push_back(r.y); w.det_bbox_2d.push_back(r.width); w.det_bbox_2d.push_back(r.height);
+            w.det_left_right_to_car.push_back(local_object->left_right_to_car);
+        }
+    }
+    cubeslam::LocalBAParams prm;
+    for (int r = 0; r < 3; r++) for (int c = 0; c < 3; c++) prm.K[r * 3 + c] = pMap->Kalib(r, c);
+    prm.img_width = pMap->img_width; prm.img_height = pMap->img_height; prm.bf = pKF->mbf; prm.camera_object_BA_weight = camera_object_BA_weight;
+    prm.kitti = scene_unique_id == kitti; prm.build_worldframe_on_ground = build_worldframe_on_ground; prm.fixCamera = fixCamera;
+    if (pbStopFlag && *pbStopFlag) return;                                                                                               // :1386-1388
+
+    static cubeslam::Context ctx(0); // throws without a device: there is no CPU path
+    cubeslam::LocalBAResult res;
+    volatile int stop = 0; // bool* -> the int flag the C-ABI polls; LocalMapping sets *pbStopFlag from another thread, so mirror it on entry only
+    cubeslam::LocalBACameraPointObjects(ctx, w, prm, res, pbStopFlag ? &stop : nullptr);
+
+    for (int u : res.up_used) lLocalMapObjects[w.up_mo[u]]->used_points_in_BA.push_back(up_point[u]);                     // :1164, read by Tracking.cc:2012 / MapDrawer.cc:146
+    for (int u : res.up_filtered) lLocalMapObjects[w.up_mo[u]]->used_points_in_BA_filtered.push_back(up_point[u]);       // :1209
+    // ---- erase, write back :1477-1533
+    if (parallel_mapping) std::unique_lock<std::mutex> lock(pMap->mMutexMapUpdate);
+    for (auto &e : res.erase) { KeyFrame *pKFi = kfs[e.first]; MapPoint *pMPi = lLocalMapPoints[e.second]; pKFi->EraseMapPointMatch(pMPi); pMPi->EraseObservation(pKFi); }
+    for (size_t i = 0; i < lLocalKeyFrames.size(); i++) { lLocalKeyFrames[i]->mnBALocalForKF = 0; lLocalKeyFrames[i]->SetPose(vec7_to_pose(&res.kf_pose[i * 7])); }
+    for (MapPoint *pMP : lLocalMapPoints) pMP->mnBALocalForKF = 0;
+    for (size_t k = 0; k < res.point_rows.size(); k++) {
+        MapPoint *pMP = lLocalMapPoints[res.point_rows[k]];
+        cv::Mat X(3, 1, CV_32F);
+        for (int a = 0; a < 3; a++) X.at<float>(a) = (float)res.point_pos[k * 3 + a];
+        pMP->SetWorldPos(X); pMP->UpdateNormalAndDepth();
+    }
+    for (KeyFrame *k : lFixedCameras) { k->mnBAFixedForKF = 0; k->mnBALocalForKF = 0; }
+    for (size_t i = 0; i < lLocalMapObjects.size(); i++) {
+        MapObject *pMO = lLocalMapObjects[i];
+        pMO->mnBALocalForKF = 0; pMO->obj_been_optimized = true;
+        g2o::cuboid cube;
+        Eigen::Matrix<double, 7, 1> pv;
+        for (int a = 0; a < 7; a++) pv[a] = res.object_pose[i * 7 + a];
+        cube.pose.fromVector(pv);
+        for (int a = 0; a < 3; a++) cube.scale[a] = res.object_scale[i * 3 + a];
+        pMO->SetWorldPos(cube);
     }
 }
 

@@ -1,0 +1,88 @@
+"""A synthetic local map in the shape LocalMapping hands to Optimizer::LocalBACameraPointObjects: key frames with key points and per-frame
+cuboid detections, map points, map objects with their unique points.  Built on synth.ba_problem (a KITTI-like drive) and decorated with the
+cases the graph-level flow branches on: a key frame with id 0, fixed key frames outside the covisibility list, a bad key frame, points
+with a single observation, gross reprojection outliers, objects seen once / outside the field-of-view margin / with too few points,
+object points 3.5 m and 6 m off, more than five objects, a left-heavy set of detections."""
+import numpy as np
+
+from cube_slam_amd import synth
+from oracle import local_ba_objects as lo
+
+
+def build(seed, n_kf=12, n_points=500, n_cuboids=16, left_heavy=True):
+    rng = np.random.default_rng(seed + 1000)
+    d = synth.ba_problem(seed, n_kf=n_kf, n_points=n_points, n_cuboids=n_cuboids, k_obs=8, stereo_frac=0.3)
+    W, H = 1241, 376
+    sig = (np.float32(1.0) / (np.float32(1.2) ** np.arange(8, dtype=np.float32)) ** 2).astype(np.float64)
+    ids = [0] + list(np.cumsum(rng.integers(1, 4, n_kf - 1)))
+    kfs = []
+    for i in range(n_kf):
+        sel = np.nonzero(d["obs_cam"] == i)[0]
+        w = d["obs_inv_sigma2"][sel]
+        octave = np.array([int(np.argmin(np.abs(sig - x))) for x in w], int)
+        kf = lo.KeyFrame(int(ids[i]), d["cam_pose"][i], d["obs_uv"][sel].copy(), d["obs_ur"][sel].copy(), octave, sig)
+        kf._obs_rows = sel
+        kfs.append(kf)
+    mps = [lo.MapPoint(100 + j, d["points"][j]) for j in range(len(d["points"]))]
+    for i, kf in enumerate(kfs):
+        kf.map_point_matches = []
+        for k, row in enumerate(kf._obs_rows):
+            mp = mps[d["obs_point"][row]]
+            mp.observations[kf] = k
+            kf.map_point_matches.append(mp)
+    # 5 % of the points keep a single observation (they are skipped, Optimizer.cc:1052)
+    for mp in mps:
+        if mp.observations and rng.uniform() < 0.05:
+            last = list(mp.observations)[-1]
+            for kf, k in list(mp.observations.items()):
+                if kf is not last:
+                    kf.map_point_matches[k] = None
+                    del mp.observations[kf]
+    # gross outliers: 3 % of the observations move by 25 px
+    for kf in kfs:
+        bad = rng.uniform(size=len(kf.mvKeysUn)) < 0.03
+        kf.mvKeysUn[bad] += rng.choice([-25.0, 25.0], (int(bad.sum()), 2))
+    mos = [lo.MapObject(c, d["cuboid_pose"][c], np.array([2.0, 0.9, 0.8]), float(rng.uniform(0.5, 1.0))) for c in range(len(d["cuboid_pose"]))]
+    for k in range(len(d["cobs_cam"])):
+        kf, mo = kfs[d["cobs_cam"][k]], mos[d["cobs_cuboid"][k]]
+        if kf in mo.observations:
+            continue
+        bb = d["cobs_bbox"][k]
+        x, y = int(bb[0] - bb[2] / 2), int(bb[1] - bb[3] / 2)
+        side = 1 if (left_heavy and rng.uniform() < 0.85) or bb[0] < W / 3 else (2 if bb[0] > 2 * W / 3 else 0)
+        kf.local_cuboids.append({"bbox_vec": bb.copy(), "bbox_2d": (x, y, int(bb[2]), int(bb[3])), "left_right_to_car": side})
+        kf.cuboids_landmark.append(mo)
+        mo.observations[kf] = len(kf.local_cuboids) - 1
+    seen = [mo for mo in mos if len(mo.observations) >= 2]
+    for c, mo in enumerate(mos):
+        a, b = d["pc_offsets"][c], d["pc_offsets"][c + 1]
+        centre = d["cuboid_true"][c][:3]
+        pts = list(d["pc_points"][a:b]) + [centre + np.array([3.5, 0, 0]), centre + np.array([0, 0, -3.4]), centre + np.array([6.0, 0, 1.0])]
+        if len(seen) > 1 and mo is seen[1]:
+            pts = pts[:8]   # too few points for the unary edge, enough for the centroid reset
+        if len(seen) > 2 and mo is seen[2]:
+            pts = pts[:4]   # neither
+        counts = rng.integers(1, 9, len(pts))
+        counts[:4] = 8
+        mo.largest_point_observations = 8
+        for k, p in enumerate(pts):
+            mp = lo.MapPoint(5000 + 100 * c + k, p)
+            mp.MapObjObservations[mo] = int(counts[k])
+            mo.unique_points.append(mp)
+        mo.unique_points.insert(3, None)
+    # an object seen once, a detection at the image border
+    for mo in mos:
+        if len(mo.observations) >= 3:
+            first = next(iter(mo.observations))
+            det = first.local_cuboids[mo.observations[first]]
+            det["bbox_2d"] = (3, det["bbox_2d"][1], det["bbox_2d"][2], det["bbox_2d"][3])
+            break
+    seen_once = [mo for mo in mos if len(mo.observations) >= 2][-1]
+    keep = next(iter(seen_once.observations))
+    seen_once.observations = {keep: seen_once.observations[keep]}
+    # the window: key frame 6 is current, seven others are covisible (one of them bad, one with id 0), the rest only enter as fixed key frames
+    cur = kfs[6]
+    cur.covisible = [kfs[i] for i in (5, 4, 3, 2, 0, 7, 8)]
+    kfs[3].bad = True
+    params = {"K": synth.K_KITTI, "img_width": W, "img_height": H, "bf": d["bf"], "camera_object_BA_weight": 1.0, "kitti": True, "build_worldframe_on_ground": False}
+    return cur, params, {"kfs": kfs, "mps": mps, "mos": mos, "truth": d}
