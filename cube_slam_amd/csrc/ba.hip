@@ -20,6 +20,7 @@
 //   ba_backsub        thread per landmark: x_l = D^-1 (b_l - B^T x_p)
 //   ba_update         oplus per vertex (cameras: exp(dx) * T; cuboids: T * exp(dx) with the fix-roll-pitch / height / scale flags)
 #include "common.h"
+#include "ba_cr.h"
 #include "se3_math.h"
 
 #include <algorithm>
@@ -1348,7 +1349,8 @@ struct cs_ba {
     double *d_bak_cam = nullptr, *d_bak_pts = nullptr, *d_bak_cub = nullptr;
     long reduce_len = 0, band_len = 0; // band_len: doubles of the factor storage
     // band path (see ba_band_chol): cuboids eliminated first, cameras block-banded with half-width band_bc
-    bool use_band = false, band_twist = false; int band_C = 0, band_Q = 0, band_bc = 0, band_targets = 0;
+    bool use_band = false, band_twist = false, band_cr = false; int band_C = 0, band_Q = 0, band_bc = 0, band_targets = 0;
+    BaCr *cr = nullptr; // nested-dissection solver of the band system (ba_cr.hip)
     int *d_tgt_slot = nullptr, *d_ct_off = nullptr, *d_ct_list = nullptr, *d_cr_off = nullptr, *d_cr_list = nullptr, *d_cq_off = nullptr, *d_cq_list = nullptr;
     uint8_t *d_tgt_tr = nullptr;
     double *d_bandA = nullptr, *d_bandL = nullptr, *d_cubD = nullptr, *d_cubg = nullptr, *d_brhs = nullptr, *d_ybuf = nullptr, *d_mid = nullptr, *d_xmid = nullptr, *d_bw = nullptr;
@@ -1445,7 +1447,9 @@ static int ba_solve(cs_ctx *ctx, cs_ba *b, double lambda, bool *ok, bool defer_s
                   b->d_ct_list, S, b->d_cubD, b->d_bandA);
         CS_LAUNCH(ctx, "ba_band_rhs", ba_band_rhs, dim3((C * 6 + 255) / 256), dim3(256), 0, C, b->d_cr_off, b->d_cr_list, S, bs, b->d_cubg, b->d_brhs);
         const size_t lds = band_lds_bytes(Bc);
-        if (b->band_twist) { // both ends at once (see the comment above band_factor)
+        if (b->band_cr) { // nested dissection over super-blocks of Bc cameras: log2(C / Bc) parallel levels (ba_cr.hip)
+            r = ba_cr_solve(ctx, &b->cr, C, Bc, b->d_bandA, b->d_brhs, G.x, b->d_status); if (r) return r;
+        } else if (b->band_twist) { // both ends at once (see the comment above band_factor)
             const size_t lds_mid = sizeof(double) * ((size_t)36 * Bc * Bc + 6 * (size_t)Bc);
             if (lds > 64 * 1024) {
                 CS_HIP(ctx, hipFuncSetAttribute((const void *)ba_band_twist_factor, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
@@ -1459,7 +1463,7 @@ static int ba_solve(cs_ctx *ctx, cs_ba *b, double lambda, bool *ok, bool defer_s
             if (lds > 64 * 1024) CS_HIP(ctx, hipFuncSetAttribute((const void *)ba_band_chol, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
             CS_LAUNCH(ctx, "ba_band_chol", ba_band_chol, dim3(1), dim3(BAND_NT), lds, C, Bc, b->d_bandA, b->d_bandL, b->d_brhs, b->d_ybuf, b->d_status);
         }
-        if (!b->band_twist) CS_HIP(ctx, hipMemcpyAsync(G.x, b->d_brhs, sizeof(double) * (size_t)C * 6, hipMemcpyDeviceToDevice, ctx->stream));
+        if (!b->band_twist && !b->band_cr) CS_HIP(ctx, hipMemcpyAsync(G.x, b->d_brhs, sizeof(double) * (size_t)C * 6, hipMemcpyDeviceToDevice, ctx->stream));
         if (Q > 0) CS_LAUNCH(ctx, "ba_cub_back", ba_cub_back, dim3((Q + 63) / 64), dim3(64), 0, C, Q, b->d_cq_off, b->d_cq_list, S, b->d_cubD, b->d_cubg, G.x);
         if (nl > 0) CS_LAUNCH(ctx, "ba_backsub", ba_backsub, dim3((nl + 255) / 256), dim3(256), 0, G);
         if (defer_status) return CS_OK;
@@ -1492,6 +1496,7 @@ void cs_ba_destroy(cs_ctx *ctx, cs_ba *b) {
     if (!b) return;
     if (ctx) { hipSetDevice(ctx->device); hipStreamSynchronize(ctx->stream); }
     for (void *p : b->owned) if (p) hipFree(p);
+    ba_cr_destroy(b->cr);
     delete b;
 }
 int cs_ba_set_allreduce(cs_ba *b, cs_allreduce_fn fn, void *user) {
@@ -1609,6 +1614,8 @@ int cs_ba_create(cs_ctx *ctx, const cs_ba_problem *p, int rank, int world, cs_ba
         if (okb) {
             b->use_band = true; b->band_C = C; b->band_Q = Q; b->band_bc = Bc; b->band_targets = C * (Bc + 1);
             b->band_twist = Bc >= 1 && C >= 6 * (Bc + 1) && !(force && !strcmp(force, "band1")); // two-sided elimination once the chain is long enough to split
+            // nested dissection (ba_cr.hip) once there are enough super-blocks to split; CUBESLAM_BA_SOLVER=band keeps the two-sided chain, =cr forces this
+            b->band_cr = ba_cr_supported(C, Bc) && ((force && !strcmp(force, "cr")) || (!force && C >= 16 * Bc));
             tgt_slot.assign((size_t)C * (Bc + 1), -1); tgt_tr.assign((size_t)C * (Bc + 1), 0);
             for (int s2 = 0; s2 < (int)slot_rc.size(); s2++) {
                 const int r0 = slot_rc[s2].first, c0 = slot_rc[s2].second;

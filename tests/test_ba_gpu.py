@@ -198,32 +198,37 @@ def test_two_sided_band_solver_agrees_with_one_sided(ctx, monkeypatch):
     system as the one-workgroup band solver and the sparse solver: identical LM decisions, chi2 within round-off."""
     d = synth.ba_problem(31, n_kf=160, n_points=6000, n_cuboids=30)
     res = {}
-    for solver in ("band", "band1", "sparse"):
-        monkeypatch.setenv("CUBESLAM_BA_SOLVER", solver)
+    for solver in ("band", "band1", "sparse", "cr", None):
+        if solver is None:
+            monkeypatch.delenv("CUBESLAM_BA_SOLVER")
+        else:
+            monkeypatch.setenv("CUBESLAM_BA_SOLVER", solver)
         ctx.timing(True); ctx.timing_reset()
         ba = BundleAdjuster(d, ctx=ctx)
         st = ba.optimize(6)
-        res[solver] = (st, ba.read(), ctx.timing_get("ba_band_twist_factor")[1], ctx.timing_get("ba_band_chol")[1])
+        res[solver] = (st, ba.read(), ctx.timing_get("ba_band_twist_factor")[1], ctx.timing_get("ba_band_chol")[1], ctx.timing_get("ba_cr_eliminate")[1])
         ctx.timing(False)
         ba.close()
-    assert res["band"][2] > 0 and res["band"][3] == 0, "the default band path of a 160-keyframe chain is the two-sided one"
+    assert res["band"][2] > 0 and res["band"][3] == 0 and res["band"][4] == 0, "CUBESLAM_BA_SOLVER=band: the two-sided chain"
     assert res["band1"][2] == 0 and res["band1"][3] > 0
+    assert res["cr"][4] > 0 and res["cr"][2] == 0 and res[None][4] > 0, "nested dissection (ba_cr.hip) is the default of a 160-keyframe chain"
     a = res["band1"]
-    for other in ("band", "sparse"):
+    for other in ("band", "sparse", "cr"):
         b = res[other]
         assert a[0]["iterations"] == b[0]["iterations"] and a[0]["lm_trials"] == b[0]["lm_trials"]
-        assert np.allclose(a[0]["chi2_trace"], b[0]["chi2_trace"], rtol=1e-6 if other == "band" else 1e-4)
+        assert np.allclose(a[0]["chi2_trace"], b[0]["chi2_trace"], rtol=1e-4 if other == "sparse" else 1e-6)
         assert abs(a[0]["chi2_final"] - b[0]["chi2_final"]) <= 1e-6 * b[0]["chi2_final"]
         tol = 1e-4  # numeric-Jacobian noise of the cuboid edges (see test_lm_trajectory); the cuboid-free run below is tight
         assert np.abs(a[1][0] - b[1][0]).max() <= tol and np.abs(a[1][2] - b[1][2]).max() <= tol, (other, np.abs(a[1][0] - b[1][0]).max(), np.abs(a[1][2] - b[1][2]).max())
     # without cuboid edges every Jacobian is analytic: the two band variants must then agree to solver round-off
     d0 = synth.ba_problem(32, n_kf=160, n_points=6000, n_cuboids=0)
     out = {}
-    for solver in ("band", "band1"):
+    for solver in ("band", "band1", "cr"):
         monkeypatch.setenv("CUBESLAM_BA_SOLVER", solver)
         ba = BundleAdjuster(d0, ctx=ctx)
         out[solver] = (ba.optimize(8), ba.read())
         ba.close()
-    assert out["band"][0]["lm_trials"] == out["band1"][0]["lm_trials"]
-    assert np.allclose(out["band"][0]["chi2_trace"], out["band1"][0]["chi2_trace"], rtol=1e-10)
-    assert np.abs(out["band"][1][0] - out["band1"][1][0]).max() <= 1e-8 and np.abs(out["band"][1][1] - out["band1"][1][1]).max() <= 1e-7
+    for other in ("band", "cr"):
+        assert out[other][0]["lm_trials"] == out["band1"][0]["lm_trials"]
+        assert np.allclose(out[other][0]["chi2_trace"], out["band1"][0]["chi2_trace"], rtol=1e-10)
+        assert np.abs(out[other][1][0] - out["band1"][1][0]).max() <= 1e-8 and np.abs(out[other][1][1] - out["band1"][1][1]).max() <= 1e-7
