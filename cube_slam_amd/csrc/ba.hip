@@ -181,14 +181,15 @@ __global__ void __launch_bounds__(256) ba_lin_lm(Params G) { // thread per landm
     for (int k = 0; k < 3; k++) G.bl[(long)li * 3 + k] = b[k];
 }
 
-// wave per pose block: observations of this rank that involve the camera (CSR pose_off / pose_obs)
+// workgroup per pose block (four waves share the camera's observation list: a thousand single waves leave the SIMDs one wave deep and the
+// Jacobian chain exposed): observations of this rank that involve the camera (CSR pose_off / pose_obs); wave sums by shuffles, then in wave order
 __global__ void __launch_bounds__(256) ba_lin_pose(Params G, const int *pose_off, const int *pose_obs) {
-    const int pi = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (pi >= G.P) return;
+    __shared__ double part[4][42];
+    const int pi = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     double acc[42];
 #pragma unroll
     for (int k = 0; k < 42; k++) acc[k] = 0;
-    for (int q = pose_off[pi] + lane; q < pose_off[pi + 1]; q += 64) {
+    for (int q = pose_off[pi] + (int)threadIdx.x; q < pose_off[pi + 1]; q += 256) {
         double Ji[3][3], Jj[3][6], omr[3], W;
         obs_jac(G, pose_obs[q], Ji, Jj, omr, W);
 #pragma unroll
@@ -200,9 +201,12 @@ __global__ void __launch_bounds__(256) ba_lin_pose(Params G, const int *pose_off
     }
 #pragma unroll
     for (int k = 0; k < 42; k++) for (int off = 32; off > 0; off >>= 1) acc[k] += __shfl_xor(acc[k], off);
-    if (lane == 0) {
-        for (int k = 0; k < 36; k++) G.Hpp[(long)pi * 36 + k] = acc[k];
-        for (int k = 0; k < 6; k++) G.bp[(long)pi * 6 + k] = acc[36 + k];
+    if (lane == 0) for (int k = 0; k < 42; k++) part[wv][k] = acc[k];
+    __syncthreads();
+    if (threadIdx.x < 42) {
+        const int k = threadIdx.x;
+        const double v = ((part[0][k] + part[1][k]) + part[2][k]) + part[3][k];
+        if (k < 36) G.Hpp[(long)pi * 36 + k] = v; else G.bp[(long)pi * 6 + k - 36] = v;
     }
 }
 
@@ -380,18 +384,20 @@ __global__ void __launch_bounds__(256) ba_schur_slots(Params G, int n_slots, con
     }
 }
 // per-pose sums of the rows w = B (D^-1 b_l) that ba_schur_bd wrote (48 bytes per observation instead of a 168-byte gather)
-__global__ void __launch_bounds__(256) ba_schur_b(Params G, const int *pose_off, const int *pose_obs, const double *w, double *bs) {
-    const int pi = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (pi >= G.P) return;
+__global__ void __launch_bounds__(256) ba_schur_b(Params G, const int *pose_off, const int *pose_obs, const double *w, double *bs) { // workgroup per pose, as ba_lin_pose
+    __shared__ double part[4][6];
+    const int pi = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     double acc[6] = {0, 0, 0, 0, 0, 0};
-    for (int q = pose_off[pi] + lane; q < pose_off[pi + 1]; q += 64) {
+    for (int q = pose_off[pi] + (int)threadIdx.x; q < pose_off[pi + 1]; q += 256) {
         const double2 *wo = reinterpret_cast<const double2 *>(__builtin_assume_aligned(w + (long)pose_obs[q] * 6, 16));
         const double2 w0 = wo[0], w1 = wo[1], w2 = wo[2];
         acc[0] -= w0.x; acc[1] -= w0.y; acc[2] -= w1.x; acc[3] -= w1.y; acc[4] -= w2.x; acc[5] -= w2.y;
     }
 #pragma unroll
     for (int k = 0; k < 6; k++) for (int off = 32; off > 0; off >>= 1) acc[k] += __shfl_xor(acc[k], off);
-    if (lane == 0) for (int k = 0; k < 6; k++) bs[(long)pi * 6 + k] = G.bp[(long)pi * 6 + k] + acc[k];
+    if (lane == 0) for (int k = 0; k < 6; k++) part[wv][k] = acc[k];
+    __syncthreads();
+    if (threadIdx.x < 6) { const int k = threadIdx.x; bs[(long)pi * 6 + k] = G.bp[(long)pi * 6 + k] + (((part[0][k] + part[1][k]) + part[2][k]) + part[3][k]); }
 }
 
 // ------------------------------------------------------------------------------------------------ band path of the reduced solve
@@ -1412,7 +1418,7 @@ static int ba_build_system(cs_ctx *ctx, cs_ba *b) { // BlockSolver::buildSystem
     const Params &G = b->G;
     const int nl = G.lm_e - G.lm_b;
     if (nl > 0) CS_LAUNCH(ctx, "ba_lin_lm", ba_lin_lm, dim3((nl + 255) / 256), dim3(256), 0, G);
-    if (G.P > 0) CS_LAUNCH(ctx, "ba_lin_pose", ba_lin_pose, dim3((G.P + 3) / 4), dim3(256), 0, G, b->d_pose_off, b->d_pose_obs);
+    if (G.P > 0) CS_LAUNCH(ctx, "ba_lin_pose", ba_lin_pose, dim3(G.P), dim3(256), 0, G, b->d_pose_off, b->d_pose_obs);
     if (G.pose_edges && G.n_cobs + G.n_pc > 0) {
         CS_LAUNCH(ctx, "ba_num_cols", ba_num_cols, dim3((G.n_cobs * 12 + G.n_pc * 6 + 255) / 256), dim3(256), 0, G);
         CS_LAUNCH(ctx, "ba_lin_pose_edges", ba_lin_pose_edges, dim3((G.P + G.n_cobs + 255) / 256), dim3(256), 0, G, b->d_pe_off, b->d_pe_list);
@@ -1425,7 +1431,7 @@ static int ba_schur(cs_ctx *ctx, cs_ba *b, double lambda) { // Schur part of Blo
     if (nl > 0) CS_LAUNCH(ctx, "ba_lm_dinv", ba_lm_dinv, dim3((nl + 255) / 256), dim3(256), 0, G, lambda);
     if (G.o_e > G.o_b) CS_LAUNCH(ctx, "ba_schur_bd", ba_schur_bd, dim3((int)(((long)(G.o_e - G.o_b) * 6 + 255) / 256)), dim3(256), 0, G, b->d_bw);
     CS_LAUNCH(ctx, "ba_schur_slots", ba_schur_slots, dim3((b->n_slots + 3) / 4), dim3(256), 0, G, b->n_slots, b->d_slot_perm, b->d_slot_off, b->d_trips, lambda, b->d_reduce);
-    CS_LAUNCH(ctx, "ba_schur_b", ba_schur_b, dim3((G.P + 3) / 4), dim3(256), 0, G, b->d_pose_off, b->d_pose_obs, b->d_bw, b->d_reduce + (long)b->n_slots * 36);
+    CS_LAUNCH(ctx, "ba_schur_b", ba_schur_b, dim3(G.P), dim3(256), 0, G, b->d_pose_off, b->d_pose_obs, b->d_bw, b->d_reduce + (long)b->n_slots * 36);
     return CS_OK;
 }
 static int ba_solve(cs_ctx *ctx, cs_ba *b, double lambda, bool *ok, bool defer_status = false) { // BlockSolver::solve; defer_status: the caller reads d_status later

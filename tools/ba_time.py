@@ -11,6 +11,10 @@ for solver in ("band", "cr"):
     ba.optimize(2)
     ba.close()
     ba = BundleAdjuster(d, ctx=ctx)
+    t0 = time.time(); st = ba.optimize(20); dt = time.time() - t0
+    print(solver, "untimed: it/s %.1f" % (st["iterations"] / dt), "trials", st["lm_trials"])
+    ba.close()
+    ba = BundleAdjuster(d, ctx=ctx)
     ctx.timing(True); ctx.timing_reset()
     t0 = time.time(); st = ba.optimize(10); dt = time.time() - t0
     print(solver, "it/s %.1f" % (st["iterations"] / dt), "trials", st["lm_trials"], "chi2", st["chi2_final"])
