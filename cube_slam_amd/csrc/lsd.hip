@@ -9,6 +9,7 @@
 // region_grow (each accepted pixel updates the region angle that the next test uses, :665-683), region2rect, refine,
 // rect_improve, rect_nfa, nfa -- which has no order-preserving parallel form.  Double precision as in the reference.
 #include "common.h"
+#include "glibc_sincosf.h"
 #include "lsd_regions.h"
 
 #include <cfloat>
@@ -175,7 +176,9 @@ __global__ void __launch_bounds__(1024) lsd_scan_add(int *out, int n, const int 
     if (i < n) out[i] += block_base[blockIdx.x];
 }
 // ordered compaction of the defined pixels (address order inside a frame): address, level-line angle, gradient norm
-__global__ void __launch_bounds__(256) lsd_emit(const double *modgrad, const double *angles, int w, int h, const int *seg_base, int *c_addr, double *c_ang, double *c_mod) {
+// c_deg: the angle as cv::fastAtan2 returned it (float degrees; the level-line angle is exactly double(c_deg) * DEG_TO_RADS, lsd.cpp:566), c_cs: cos / sin
+// of float(angle) as region_grow adds them up (:676-677, glibc's cosf / sinf restated) -- computed here once per pixel instead of by the host per visit
+__global__ void __launch_bounds__(256) lsd_emit(const double *modgrad, const double *angles, int w, int h, const int *seg_base, int *c_addr, float *c_deg, float2 *c_cs, double *c_mod) {
     __shared__ int wc[4];
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
     const long o = ((long)blockIdx.z * h + y) * w + x;
@@ -189,7 +192,10 @@ __global__ void __launch_bounds__(256) lsd_emit(const double *modgrad, const dou
     if (!def) return;
     int pos = seg_base[((long)blockIdx.z * h + y) * gridDim.x + blockIdx.x] + __popcll(m & ((1ull << (threadIdx.x & 63)) - 1));
     for (int i = 0; i < wv; i++) pos += wc[i];
-    c_addr[pos] = y * w + x; c_ang[pos] = a; c_mod[pos] = modgrad[o];
+    float d = (float)(a / DEG_TO_RADS); // the float whose product with DEG_TO_RADS is a: the quotient rounded, or a neighbour of it
+    if ((double)d * DEG_TO_RADS != a) { const float up = nextafterf(d, 1e9f), dn = nextafterf(d, -1e9f); d = ((double)up * DEG_TO_RADS == a) ? up : dn; }
+    c_addr[pos] = y * w + x; c_deg[pos] = d; c_mod[pos] = modgrad[o];
+    c_cs[pos] = make_float2(glibc_sincosf::cosf_(float(a)), glibc_sincosf::sinf_(float(a)));
 }
 
 // ------------------------------------------------------------------------------------------------ host: sequential LSD stages
@@ -198,16 +204,20 @@ struct RectH { double x1, y1, x2, y2, width, x, y, theta, dx, dy, prec, p; };
 class LsdHost {
   public:
     int w = 0, h = 0;
-    const double *angles = nullptr, *modgrad = nullptr;
-    std::vector<unsigned char> used;
+    // Dense per-pixel maps of this thread.  free_deg: the level-line angle in float degrees while the pixel is defined AND unused, NOTDEF_F
+    // otherwise -- region_grow's "used == 0 && isAligned" reads one 4-byte value per neighbour; deg: the same without the used marks (rect_nfa
+    // counts aligned pixels whatever their use); aux: what an accepted pixel contributes (gradient norm, cos / sin of its angle).
+    static constexpr float NOTDEF_F = -1024.0f;
+    struct Aux { double mod; float c, s; };
+    std::vector<float> free_deg, deg;
+    std::vector<Aux> aux;
     std::vector<int> rx, ry;          // region points (structure of arrays)
     std::vector<double> rang, rmod;
     double LOG_NT = 0;
 
-    inline bool aligned(int address, double theta, double prec) const { // isAligned lsd.cpp:1138-1154
-        if (address < 0) return false;
-        const double a = angles[address];
-        if (a == NOTDEF) return false;
+    static inline bool aligned_deg(float af, double theta, double prec) { // isAligned lsd.cpp:1138-1154 on a stored angle
+        if (af == NOTDEF_F) return false;
+        const double a = double(af) * DEG_TO_RADS; // the map value, exactly (:566)
         double n_theta = theta - a;
         if (n_theta < 0) n_theta = -n_theta;
         if (n_theta > (3 * PI_) / 2) { n_theta -= 2 * PI_; if (n_theta < 0) n_theta = -n_theta; }
@@ -219,24 +229,27 @@ class LsdHost {
     void grow(int sx, int sy, int &n, double &reg_angle, double prec) { // region_grow :637-688
         n = 1;
         int addr = sx + sy * w;
-        rx[0] = sx; ry[0] = sy; rang[0] = angles[addr]; rmod[0] = modgrad[addr];
-        reg_angle = angles[addr];
+        reg_angle = double(deg[addr]) * DEG_TO_RADS;
+        rx[0] = sx; ry[0] = sy; rang[0] = reg_angle; rmod[0] = aux[addr].mod;
         float sumdx = float(std::cos(reg_angle)), sumdy = float(std::sin(reg_angle));
-        used[addr] = 1;
+        free_deg[addr] = NOTDEF_F;
         for (int i = 0; i < n; ++i) {
-            const int x0 = std::max(rx[i] - 1, 0), x1 = std::min(rx[i] + 1, w - 1), y0 = std::max(ry[i] - 1, 0), y1 = std::min(ry[i] + 1, h - 1);
+            const int px = rx[i], py = ry[i];
+            const int x0 = std::max(px - 1, 0), x1 = std::min(px + 1, w - 1), y0 = std::max(py - 1, 0), y1 = std::min(py + 1, h - 1);
             for (int yy = y0; yy <= y1; ++yy) {
                 int c = x0 + yy * w;
-                for (int xx = x0; xx <= x1; ++xx, ++c)
-                    if (used[c] == 0 && aligned(c, reg_angle, prec)) { // 0 = defined and free; undefined pixels carry 2 and never reach the angle test
-                        used[c] = 1;
-                        const double a = angles[c];
-                        rx[n] = xx; ry[n] = yy; rang[n] = a; rmod[n] = modgrad[c];
+                for (int xx = x0; xx <= x1; ++xx, ++c) {
+                    const float af = free_deg[c];
+                    if (aligned_deg(af, reg_angle, prec)) { // defined, unused and aligned
+                        free_deg[c] = NOTDEF_F;
+                        const Aux &ax = aux[c];
+                        rx[n] = xx; ry[n] = yy; rang[n] = double(af) * DEG_TO_RADS; rmod[n] = ax.mod;
                         ++n;
-                        sumdx += std::cos(float(a));
-                        sumdy += std::sin(float(a));
+                        sumdx += ax.c; // cos(float(angle)), sin(float(angle)) :676-677, computed by lsd_emit
+                        sumdy += ax.s;
                         reg_angle = fast_atan2f_(sumdy, sumdx) * DEG_TO_RADS;
                     }
+                }
             }
         }
     }
@@ -270,7 +283,7 @@ class LsdHost {
             radSq *= 0.75 * 0.75;
             for (int i = 0; i < n; ++i)
                 if (dsq(xc, yc, double(rx[i]), double(ry[i])) > radSq) {
-                    used[rx[i] + ry[i] * w] = 0;
+                    { const int q = rx[i] + ry[i] * w; free_deg[q] = deg[q]; }
                     std::swap(rx[i], rx[n - 1]); std::swap(ry[i], ry[n - 1]); std::swap(rang[i], rang[n - 1]); std::swap(rmod[i], rmod[n - 1]);
                     --n; --i;
                 }
@@ -287,7 +300,7 @@ class LsdHost {
         double sum = 0, s_sum = 0;
         int cnt = 0;
         for (int i = 0; i < n; ++i) {
-            used[rx[i] + ry[i] * w] = 0;
+            { const int q = rx[i] + ry[i] * w; free_deg[q] = deg[q]; }
             if (dist(xc, yc, rx[i], ry[i]) < rec.width) { const double d = sdiff(rang[i], ang_c); sum += d; s_sum += d * d; ++cnt; }
         }
         const double mean_angle = sum / double(cnt);
@@ -371,13 +384,14 @@ class LsdHost {
             const int xa = std::max(int(left_x), 0), xb = std::min(int(right_x), w - 1);
             if (xb >= xa) {
                 total += xb - xa + 1;
-                const double *row = angles + (size_t)y * w;
+                const float *row = deg.data() + (size_t)y * w;
                 for (int x = xa; x <= xb; ++x) { // isAligned :1138-1154
-                    const double a = row[x];
+                    const float af = row[x];
+                    const double a = double(af) * DEG_TO_RADS;
                     double d = std::fabs(theta - a);
                     const double d2 = std::fabs(d - two_pi);
                     d = d > wrap ? d2 : d;
-                    const int def = a != NOTDEF;
+                    const int def = af != NOTDEF_F;
                     for (int k = 0; k < NP; k++) alg[k] += def & (d <= precs[k]);
                 }
             }
@@ -428,32 +442,30 @@ class LsdHost {
     }
     bool timed = false;
     double t_sort = 0, t_grow = 0, t_rect = 0; long n_seeds = 0, n_regions = 0, n_pix = 0; // stage timers (ms) of this thread, reported by the caller
-    std::vector<double> dang, dmod; // dense maps of this thread, NOTDEF / untouched outside the current frame's defined pixels
     // flsd :464-535 (LSD_REFINE_ADV, scale 0.8): segments as x1 y1 x2 y2 floats.  Input: the frame's defined pixels in address
     // order (the undefined ones are skipped by the reference's seed loop and fail every alignment test, so they never matter).
-    void run(int w_, int h_, int ne, const int *e_addr, const double *e_ang, const double *e_mod, std::vector<float> &lines) {
+    void run(int w_, int h_, int ne, const int *e_addr, const float *e_deg, const float2 *e_cs, const double *e_mod, std::vector<float> &lines) {
         const auto tt0 = timed ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
         w = w_; h = h_;
         const size_t n = (size_t)w * h;
-        if (dang.size() != n) { dang.assign(n, NOTDEF); dmod.assign(n, 0.0); used.assign(n, 2); rx.resize(n); ry.resize(n); rang.resize(n); rmod.resize(n); }
-        angles = dang.data(); modgrad = dmod.data();
+        if (deg.size() != n) { deg.assign(n, NOTDEF_F); free_deg.assign(n, NOTDEF_F); aux.assign(n, Aux{0.0, 0.f, 0.f}); rx.resize(n); ry.resize(n); rang.resize(n); rmod.resize(n); }
         const double prec = PI_ * 22.5 / 180, p = 22.5 / 180;
         // Seed order = address order.  ll_angle links the 1024-bin pseudo-ordering through `next` pointers (:588-634), but flsd walks the
         // `list` vector by index (:477-480) and its entries were appended in raster order: the gradient ordering has no effect on the
         // reference's output (established by running the reference's own lsd.cpp: oracle/_ref, tests/test_ref_pins.py).
-        constexpr int PFD = 24; // the scatter is sparse in three maps of 1.5 MB + 1.5 MB + 0.2 MB: ask for the lines a few entries ahead
+        constexpr int PFD = 24; // the scatter is sparse in the dense maps: ask for the lines a few entries ahead
         for (int i = 0; i < ne; i++) {
-            if (i + PFD < ne) { const int a = e_addr[i + PFD]; __builtin_prefetch(&dang[a], 1); __builtin_prefetch(&dmod[a], 1); __builtin_prefetch(&used[a], 1); }
-            dang[e_addr[i]] = e_ang[i]; dmod[e_addr[i]] = e_mod[i]; used[e_addr[i]] = 0;
+            if (i + PFD < ne) { const int a = e_addr[i + PFD]; __builtin_prefetch(&deg[a], 1); __builtin_prefetch(&free_deg[a], 1); __builtin_prefetch(&aux[a], 1); }
+            const int q = e_addr[i];
+            deg[q] = e_deg[i]; free_deg[q] = e_deg[i]; aux[q] = Aux{e_mod[i], e_cs[i].x, e_cs[i].y};
         }
         LOG_NT = 5 * (std::log10(double(w)) + std::log10(double(h))) / 2 + std::log10(11.0);
         const int min_reg_size = int(-LOG_NT / std::log10(p));
         lines.clear();
-        const double *ang = angles;
         if (timed) t_sort += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tt0).count();
         for (int i = 0; i < ne; ++i) {
             const int adx = e_addr[i];
-            if (used[adx] != 0 || ang[adx] == NOTDEF) continue;
+            if (free_deg[adx] == NOTDEF_F) continue; // used
             int rn; double reg_angle;
             const auto tg0 = timed ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
             grow(adx % w, adx / w, rn, reg_angle, prec);
@@ -471,8 +483,8 @@ class LsdHost {
             lines.push_back(float(rec.x1)); lines.push_back(float(rec.y1)); lines.push_back(float(rec.x2)); lines.push_back(float(rec.y2));
         }
         for (int i = 0; i < ne; i++) { // leave the dense maps clean for the next frame
-            if (i + PFD < ne) { const int a = e_addr[i + PFD]; __builtin_prefetch(&dang[a], 1); __builtin_prefetch(&used[a], 1); }
-            dang[e_addr[i]] = NOTDEF; used[e_addr[i]] = 2;
+            if (i + PFD < ne) { const int a = e_addr[i + PFD]; __builtin_prefetch(&deg[a], 1); __builtin_prefetch(&free_deg[a], 1); }
+            deg[e_addr[i]] = NOTDEF_F; free_deg[e_addr[i]] = NOTDEF_F;
         }
     }
 };
@@ -514,8 +526,8 @@ struct cs_lsd {
     int nbx = 0;                                            // 256-pixel segments per scaled row
     int *d_seg_cnt = nullptr, *d_seg_base = nullptr;        // per (frame, row, segment) defined-pixel count / exclusive scan
     int *d_blk_tot = nullptr;                               // totals of the 1024-segment scan blocks
-    int *d_caddr = nullptr; double *d_cang = nullptr, *d_cmod = nullptr; size_t ccap = 0;   // compacted defined pixels (device)
-    int *h_caddr = nullptr; double *h_cang = nullptr, *h_cmod = nullptr; size_t hcap = 0;   // same, pinned host
+    int *d_caddr = nullptr; float *d_cdeg = nullptr; float2 *d_ccs = nullptr; double *d_cmod = nullptr; size_t ccap = 0;   // compacted defined pixels (device): address, angle, cos / sin, norm
+    int *h_caddr = nullptr; float *h_cdeg = nullptr; float2 *h_ccs = nullptr; double *h_cmod = nullptr; size_t hcap = 0;   // same, pinned host
     std::vector<int> frame_base;
     std::vector<std::vector<cs_keyline>> keylines;
     // LBD descriptors of the detected lines (optional second half of cs_lsd_run)
@@ -567,12 +579,13 @@ static int lsd_run(cs_ctx *ctx, cs_lsd *l, int with_lbd) {
     const size_t total = (size_t)l->frame_base[F];
     int r;
     if (total > l->ccap) {
-        void *old[] = {l->d_caddr, l->d_cang, l->d_cmod};
+        void *old[] = {l->d_caddr, l->d_cdeg, l->d_ccs, l->d_cmod};
         for (void *q : old) if (q) hipFree(q);
-        l->d_caddr = nullptr; l->d_cang = nullptr; l->d_cmod = nullptr; l->ccap = 0;
+        l->d_caddr = nullptr; l->d_cdeg = nullptr; l->d_ccs = nullptr; l->d_cmod = nullptr; l->ccap = 0;
         const size_t cap = total + total / 4 + 4096;
         r = cs_dalloc(ctx, &l->d_caddr, cap); if (r) return r;
-        r = cs_dalloc(ctx, &l->d_cang, cap); if (r) return r;
+        r = cs_dalloc(ctx, &l->d_cdeg, cap); if (r) return r;
+        r = cs_dalloc(ctx, &l->d_ccs, cap); if (r) return r;
         r = cs_dalloc(ctx, &l->d_cmod, cap); if (r) return r;
         l->ccap = cap;
     }
@@ -580,7 +593,7 @@ static int lsd_run(cs_ctx *ctx, cs_lsd *l, int with_lbd) {
     // segments bit for bit, but a latency-bound fixed point that is slower than 16 host threads on this box -- DESIGN.md has the numbers)
     std::vector<std::vector<float>> dev_lines;
     bool on_device = false;
-    if (total > 0) CS_LAUNCH(ctx, "lsd_emit", lsd_emit, dim3(nbx, h, F), dim3(256), 0, l->d_mod, l->d_ang, w, h, l->d_seg_base, l->d_caddr, l->d_cang, l->d_cmod);
+    if (total > 0) CS_LAUNCH(ctx, "lsd_emit", lsd_emit, dim3(nbx, h, F), dim3(256), 0, l->d_mod, l->d_ang, w, h, l->d_seg_base, l->d_caddr, l->d_cdeg, l->d_ccs, l->d_cmod);
     {
         const char *mode = getenv("CUBESLAM_LSD_REGIONS");
         if (total > 0 && mode && strcmp(mode, "device") == 0) {
@@ -592,16 +605,17 @@ static int lsd_run(cs_ctx *ctx, cs_lsd *l, int with_lbd) {
         }
     }
     if (!on_device && total > l->hcap) {
-        if (l->h_caddr) hipHostFree(l->h_caddr); if (l->h_cang) hipHostFree(l->h_cang); if (l->h_cmod) hipHostFree(l->h_cmod);
-        l->h_caddr = nullptr; l->h_cang = nullptr; l->h_cmod = nullptr; l->hcap = 0;
+        if (l->h_caddr) hipHostFree(l->h_caddr); if (l->h_cdeg) hipHostFree(l->h_cdeg); if (l->h_ccs) hipHostFree(l->h_ccs); if (l->h_cmod) hipHostFree(l->h_cmod);
+        l->h_caddr = nullptr; l->h_cdeg = nullptr; l->h_ccs = nullptr; l->h_cmod = nullptr; l->hcap = 0;
         const size_t cap = total + total / 4 + 4096;
-        if (hipHostMalloc((void **)&l->h_caddr, cap * sizeof(int), hipHostMallocDefault) != hipSuccess || hipHostMalloc((void **)&l->h_cang, cap * sizeof(double), hipHostMallocDefault) != hipSuccess ||
+        if (hipHostMalloc((void **)&l->h_caddr, cap * sizeof(int), hipHostMallocDefault) != hipSuccess || hipHostMalloc((void **)&l->h_cdeg, cap * sizeof(float), hipHostMallocDefault) != hipSuccess || hipHostMalloc((void **)&l->h_ccs, cap * sizeof(float2), hipHostMallocDefault) != hipSuccess ||
             hipHostMalloc((void **)&l->h_cmod, cap * sizeof(double), hipHostMallocDefault) != hipSuccess) return CS_ERR_NOMEM;
         l->hcap = cap;
     }
     if (!on_device && total > 0) {
         r = cs_d2h(ctx, l->h_caddr, l->d_caddr, total); if (r) return r;
-        r = cs_d2h(ctx, l->h_cang, l->d_cang, total); if (r) return r;
+        r = cs_d2h(ctx, l->h_cdeg, l->d_cdeg, total); if (r) return r;
+        r = cs_d2h(ctx, l->h_ccs, l->d_ccs, total); if (r) return r;
         r = cs_d2h(ctx, l->h_cmod, l->d_cmod, total); if (r) return r;
     }
     hipEvent_t ev = ctx->get_event();
@@ -636,7 +650,7 @@ static int lsd_run(cs_ctx *ctx, cs_lsd *l, int with_lbd) {
         for (int fi = 0; fi < F; fi++) {
             const int f = lpt[fi]; // most defined pixels first: the tail of the dynamic schedule is made of the cheapest frames
             const int b0 = l->frame_base[f];
-            host.run(w, h, l->frame_base[f + 1] - b0, l->h_caddr + b0, l->h_cang + b0, l->h_cmod + b0, lines);
+            host.run(w, h, l->frame_base[f + 1] - b0, l->h_caddr + b0, l->h_cdeg + b0, l->h_ccs + b0, l->h_cmod + b0, lines);
             to_keylines(lines, W, H, l->keylines[f]);
         }
         if (ctx->timing) {
@@ -696,10 +710,11 @@ void cs_lsd_destroy(cs_ctx *ctx, cs_lsd *l) {
     for (void *p : ptrs) if (p) hipFree(p);
     lsd_free_lines(l);
     lsd_regions_destroy(l->regions);
-    void *more[] = {l->d_seg_cnt, l->d_seg_base, l->d_blk_tot, l->d_caddr, l->d_cang, l->d_cmod};
+    void *more[] = {l->d_seg_cnt, l->d_seg_base, l->d_blk_tot, l->d_caddr, l->d_cdeg, l->d_ccs, l->d_cmod};
     for (void *p : more) if (p) hipFree(p);
     if (l->h_caddr) hipHostFree(l->h_caddr);
-    if (l->h_cang) hipHostFree(l->h_cang);
+    if (l->h_cdeg) hipHostFree(l->h_cdeg);
+    if (l->h_ccs) hipHostFree(l->h_ccs);
     if (l->h_cmod) hipHostFree(l->h_cmod);
     delete l;
 }
