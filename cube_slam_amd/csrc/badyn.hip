@@ -49,6 +49,46 @@ template <int ONLY> __global__ void __launch_bounds__(64) badyn_linearize(DynG G
     const int e = blockIdx.x * 64 + threadIdx.x;
     if (e < n) dyn_lin_item<ONLY>(G, e0 + e);
 }
+// ---- deterministic build: the per-edge pieces (DynG::stage) added per target in edge order, one lane per element, eight loads in flight
+__global__ void __launch_bounds__(64) badyn_gather_blocks(DynG G) { // one wave per pose x pose block
+    const int t = blockIdx.x, lane = threadIdx.x, a = lane / 6, c = lane % 6;
+    const int lo = G.pb_lo[t], hi = G.pb_hi[t], dr = G.pb_dim[t] & 0xff, dc = G.pb_dim[t] >> 8;
+    if (lane >= 36 || a >= dr || c >= dc) return;
+    double acc = 0;
+    const int q0 = G.pb_start[t], q1 = G.pb_start[t + 1];
+    for (int q = q0; q < q1; q += 8) {
+        double v[8];
+#pragma unroll
+        for (int u = 0; u < 8; u++) {
+            const int s = G.pb_src[min(q + u, q1 - 1)], tr = s & 1; // (edge * 6 + pair) * 2 + transposed
+            v[u] = G.stage[(long)(s >> 1) / 6 * DYN_STAGE + 18 + ((s >> 1) % 6) * 36 + (tr ? c * 6 + a : a * 6 + c)];
+        }
+#pragma unroll
+        for (int u = 0; u < 8; u++) if (q + u < q1) acc += v[u];
+    }
+    G.Hpp[(long)(lo + a) * G.NP + hi + c] = acc;
+    if (lo != hi) G.Hpp[(long)(hi + c) * G.NP + lo + a] = acc;
+}
+__global__ void __launch_bounds__(64) badyn_gather_grad(DynG G) { // a lane per row of a pose vertex' gradient, 10 vertices per workgroup
+    const int t = blockIdx.x * 10 + threadIdx.x / 6, a = threadIdx.x % 6;
+    if (threadIdx.x >= 60 || t >= G.n_pg || a >= G.pg_dim[t]) return;
+    double acc = 0;
+    for (int q = G.pg_start[t]; q < G.pg_start[t + 1]; q++) { const int s = G.pg_src[q]; acc += G.stage[(long)(s / 3) * DYN_STAGE + (s % 3) * 6 + a]; }
+    G.bp[G.pg_off[t] + a] = acc;
+}
+__global__ void __launch_bounds__(64) badyn_gather_lm(DynG G) { // a thread per landmark: 3x3 block and gradient
+    const int l = blockIdx.x * 64 + threadIdx.x;
+    if (l >= G.L) return;
+    double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, g[3] = {0, 0, 0};
+    for (int q = G.lg_start[l]; q < G.lg_start[l + 1]; q++) {
+        const int s = G.lg_src[q], e = s / 3, i = s % 3;
+        const double *st = G.stage + (long)e * DYN_STAGE;
+        const double *hb = st + 18 + dyn_pair_index(i, i) * 36;
+        for (int r = 0; r < 3; r++) { g[r] += st[i * 6 + r]; for (int c = 0; c < 3; c++) H[r * 3 + c] += hb[r * 6 + c]; }
+    }
+    for (int k = 0; k < 9; k++) G.Hll[(long)l * 9 + k] = H[k];
+    for (int k = 0; k < 3; k++) G.bl[(long)l * 3 + k] = g[k];
+}
 __global__ void __launch_bounds__(256) badyn_schur_init(DynG G, double lambda) {
     const long i = (long)blockIdx.x * 256 + threadIdx.x, n2 = (long)G.NP * G.NP;
     if (i < n2) { const int r = (int)(i / G.NP), c = (int)(i % G.NP); G.S[i] = G.Hpp[i] + (r == c ? lambda : 0.0); }
@@ -316,16 +356,16 @@ int dyn_errors(cs_ctx *ctx, cs_ba_dyn *b, double *chi) {
     *chi = s;
     return CS_OK;
 }
-int dyn_build(cs_ctx *ctx, cs_ba_dyn *b) { // BlockSolver::buildSystem: zero, then one thread per edge
+int dyn_build(cs_ctx *ctx, cs_ba_dyn *b) { // BlockSolver::buildSystem: one thread per edge writes its pieces, then they are added per target in edge order
     const DynG &G = b->G;
-    CS_HIP(ctx, hipMemsetAsync(G.Hpp, 0, sizeof(double) * std::max<size_t>((size_t)G.NP * G.NP, 1), ctx->stream));
-    CS_HIP(ctx, hipMemsetAsync(G.bp, 0, sizeof(double) * std::max(G.NP, 1), ctx->stream));
-    CS_HIP(ctx, hipMemsetAsync(G.Hll, 0, sizeof(double) * std::max<size_t>((size_t)G.L * 9, 1), ctx->stream));
-    CS_HIP(ctx, hipMemsetAsync(G.bl, 0, sizeof(double) * std::max<size_t>((size_t)G.L * 3, 1), ctx->stream));
     const int n_rest = b->n_edges - G.n_obs - G.n_dobs; // motion, camera-object, point-object, local-point edges: few, numeric Jacobians
     if (G.n_obs) CS_LAUNCH(ctx, "badyn_linearize", badyn_linearize<0>, dim3((G.n_obs + 63) / 64), dim3(64), 0, G, 0, G.n_obs);
     if (G.n_dobs) CS_LAUNCH(ctx, "badyn_linearize_dyn", badyn_linearize<1>, dim3((G.n_dobs + 63) / 64), dim3(64), 0, G, G.n_obs, G.n_dobs);
     if (n_rest) CS_LAUNCH(ctx, "badyn_linearize_num", badyn_linearize<-1>, dim3((n_rest + 63) / 64), dim3(64), 0, G, G.n_obs + G.n_dobs, n_rest);
+    // Hpp / bp / Hll / bl were zeroed once at creation: the targets below are the only words ever written, and every one of them is rewritten here
+    if (G.n_pb) CS_LAUNCH(ctx, "badyn_gather_blocks", badyn_gather_blocks, dim3(G.n_pb), dim3(64), 0, G);
+    if (G.n_pg) CS_LAUNCH(ctx, "badyn_gather_grad", badyn_gather_grad, dim3((G.n_pg + 9) / 10), dim3(64), 0, G);
+    if (G.L) CS_LAUNCH(ctx, "badyn_gather_lm", badyn_gather_lm, dim3((G.L + 63) / 64), dim3(64), 0, G);
     return CS_OK;
 }
 int dyn_reduce(cs_ctx *ctx, cs_ba_dyn *b, double lambda) { // Schur complement of the marginalised points
@@ -454,6 +494,13 @@ int cs_ba_dyn_create(cs_ctx *ctx, const cs_ba_dyn_problem *p, cs_ba_dyn **out) {
     D_(dyn_upload(ctx, b, &G.Hll, (const double *)nullptr, (size_t)G.L * 9)); D_(dyn_upload(ctx, b, &G.Dinv, (const double *)nullptr, (size_t)G.L * 9));
     D_(dyn_upload(ctx, b, &G.bl, (const double *)nullptr, (size_t)G.L * 3)); D_(dyn_upload(ctx, b, &G.xl, (const double *)nullptr, (size_t)G.L * 3));
     D_(dyn_upload(ctx, b, &G.Bslot, (const double *)nullptr, (size_t)n_slots * 18));
+    D_(dyn_upload(ctx, b, &G.stage, (const double *)nullptr, (size_t)b->n_edges * DYN_STAGE));
+    G.n_pb = (int)X.pb_lo.size(); G.n_pg = (int)X.pg_off.size();
+    D_(dyn_upload(ctx, b, &G.pb_lo, X.pb_lo.data(), X.pb_lo.size())); D_(dyn_upload(ctx, b, &G.pb_hi, X.pb_hi.data(), X.pb_hi.size())); D_(dyn_upload(ctx, b, &G.pb_dim, X.pb_dim.data(), X.pb_dim.size()));
+    D_(dyn_upload(ctx, b, &G.pb_start, X.pb_start.data(), X.pb_start.size())); D_(dyn_upload(ctx, b, &G.pb_src, X.pb_src.data(), X.pb_src.size()));
+    D_(dyn_upload(ctx, b, &G.pg_off, X.pg_off.data(), X.pg_off.size())); D_(dyn_upload(ctx, b, &G.pg_dim, X.pg_dim.data(), X.pg_dim.size()));
+    D_(dyn_upload(ctx, b, &G.pg_start, X.pg_start.data(), X.pg_start.size())); D_(dyn_upload(ctx, b, &G.pg_src, X.pg_src.data(), X.pg_src.size()));
+    D_(dyn_upload(ctx, b, &G.lg_start, X.lg_start.data(), X.lg_start.size())); D_(dyn_upload(ctx, b, &G.lg_src, X.lg_src.data(), X.lg_src.size()));
     D_(dyn_upload(ctx, b, &G.slot_off, X.slot_off.data(), X.slot_off.size())); D_(dyn_upload(ctx, b, &G.lm_start, X.lm_start.data(), X.lm_start.size()));
     D_(dyn_upload(ctx, b, &G.lm_slots, X.lm_slots.data(), X.lm_slots.size())); D_(dyn_upload(ctx, b, &G.slot_lm, X.slot_lm.data(), X.slot_lm.size()));
     D_(dyn_upload(ctx, b, &G.BD, (const double *)nullptr, (size_t)n_slots * 18)); D_(dyn_upload(ctx, b, &G.bsub, (const double *)nullptr, (size_t)n_slots * 6));

@@ -37,6 +37,11 @@ struct DynG {
     const int *pc_obj, *pc_off; const double *pc_pts;
     double *e_obs, *e_dobs, *e_mot, *e_cobs, *e_pc, *e_ulp;
     double *Hpp, *bp, *Hll, *bl, *Bslot;
+    // Deterministic build (device): every edge writes its J^T W J blocks and J^T W e vectors into its own DYN_STAGE doubles of `stage`; the gather
+    // kernels of badyn.hip then add them per target in edge order -- the order a sequential loop over the edges (g2o, the oracle) adds them in.
+    // stage == nullptr (host harness, oracle-style use): accumulate in place.
+    double *stage;
+    int n_pb, n_pg; const int *pb_lo, *pb_hi, *pb_dim, *pb_start, *pb_src, *pg_off, *pg_dim, *pg_start, *pg_src, *lg_start, *lg_src;
     const int *slot_off;               // pose-system offset of a slot's six rows, -1 = unused slot (fixed camera / inactive edge)
     const int *lm_start, *lm_slots;    // CSR: the slots of every landmark
     double *S, *bs, *Dinv, *xp, *xl;
@@ -179,12 +184,14 @@ HD double dyn_error_item(const DynG &G, int e) {
 }
 
 // ---------------------------------------------------------------------------------------------------- quadratic form
+constexpr int DYN_STAGE = 18 + 6 * 36; // per edge: three gradients of six, then the blocks of the vertex pairs (0,0) (0,1) (0,2) (1,1) (1,2) (2,2)
+HD int dyn_pair_index(int i, int j) { return i * 3 + j - i * (i + 1) / 2; }
 struct DynLin { // one linearised edge; vertex v: pose-system offset off[v] (dim 6 or 2), landmark lm[v] (dim 3, always the last vertex), or fixed
-    int nv, D, off[3], dim[3], lm[3], slot[3];
+    int nv, D, off[3], dim[3], lm[3], slot[3], eid;
     double e[4], w[4], J[3][24], delta;
 };
 HD void dyn_lin_init(DynLin &E, int nv, int D) {
-    E.nv = nv; E.D = D; E.delta = 0;
+    E.nv = nv; E.D = D; E.delta = 0; E.eid = -1;
     for (int v = 0; v < 3; v++) { E.off[v] = -1; E.dim[v] = 0; E.lm[v] = -1; E.slot[v] = -1; }
 }
 template <int NV, int D> HD void dyn_add_edge(const DynG &G, const DynLin &E) { // vertex count and residual dimension at compile time: everything unrolls, E stays in registers
@@ -202,7 +209,8 @@ template <int NV, int D> HD void dyn_add_edge(const DynG &G, const DynLin &E) { 
                 double g = 0;
 #pragma unroll
                 for (int k = 0; k < D; k++) g += E.J[i][k * 6 + a] * omr[k];
-                if (E.lm[i] >= 0) BD_ATOMIC_ADD(G.bl + (long)E.lm[i] * 3 + a, g); else BD_ATOMIC_ADD(G.bp + E.off[i] + a, g);
+                if (G.stage) G.stage[(long)E.eid * DYN_STAGE + i * 6 + a] = g;
+                else if (E.lm[i] >= 0) BD_ATOMIC_ADD(G.bl + (long)E.lm[i] * 3 + a, g); else BD_ATOMIC_ADD(G.bp + E.off[i] + a, g);
             }
         }
 #pragma unroll
@@ -216,8 +224,9 @@ template <int NV, int D> HD void dyn_add_edge(const DynG &G, const DynLin &E) { 
                         double h = 0;
 #pragma unroll
                         for (int k = 0; k < D; k++) h += (E.J[i][k * 6 + a] * W[k]) * E.J[j][k * 6 + c];
-                        if (E.lm[i] >= 0) BD_ATOMIC_ADD(G.Hll + (long)E.lm[i] * 9 + a * 3 + c, h);              // landmark x landmark (i == j)
-                        else if (E.lm[j] >= 0) G.Bslot[(long)E.slot[i] * 18 + a * 3 + c] = h;                     // pose rows x landmark columns: own slot
+                        if (E.lm[i] < 0 && E.lm[j] >= 0) G.Bslot[(long)E.slot[i] * 18 + a * 3 + c] = h;                // pose rows x landmark columns: own slot
+                        else if (G.stage) G.stage[(long)E.eid * DYN_STAGE + 18 + dyn_pair_index(i, j) * 36 + a * 6 + c] = h;
+                        else if (E.lm[i] >= 0) BD_ATOMIC_ADD(G.Hll + (long)E.lm[i] * 9 + a * 3 + c, h);         // landmark x landmark (i == j)
                         else {
                             BD_ATOMIC_ADD(G.Hpp + (long)(E.off[i] + a) * G.NP + E.off[j] + c, h);
                             if (i != j) BD_ATOMIC_ADD(G.Hpp + (long)(E.off[j] + c) * G.NP + E.off[i] + a, h);
@@ -245,7 +254,7 @@ template <int ONLY> HD void dyn_lin_item(const DynG &G, int e) {
         if (dyn_lvl(G.o_lvl, o)) return;
         const int ci = G.o_cam[o], li = G.o_pt[o];
         const bool st = dyn_stereo(G, o);
-        dyn_lin_init(E, 2, st ? 3 : 2);
+        dyn_lin_init(E, 2, st ? 3 : 2); E.eid = e;
         E.off[0] = G.cam_off[ci]; E.dim[0] = 6; E.slot[0] = o; E.lm[1] = G.fix_points ? -1 : li; E.dim[1] = 3;
         if (E.off[0] < 0 && E.lm[1] < 0) return;
         const SE3 T = se3_load(G.cam + (long)ci * 7);
@@ -273,7 +282,7 @@ template <int ONLY> HD void dyn_lin_item(const DynG &G, int e) {
     } else if (cls == 1) { // EdgeDynamicPointCuboidCamera::linearizeOplus g2o_Object.cpp:167-233
         if (dyn_lvl(G.d_lvl, o)) return;
         const int ci = G.d_cam[o], oi = G.d_obj[o], li = G.d_pt[o];
-        dyn_lin_init(E, 3, 2);
+        dyn_lin_init(E, 3, 2); E.eid = e;
         E.off[0] = G.cam_off[ci]; E.dim[0] = 6; E.slot[0] = G.n_obs + 2 * o;
         E.off[1] = G.obj_off[oi]; E.dim[1] = 6; E.slot[1] = G.n_obs + 2 * o + 1;
         E.lm[2] = G.fix_points ? -1 : G.n_pts + li; E.dim[2] = 3;
@@ -297,7 +306,7 @@ template <int ONLY> HD void dyn_lin_item(const DynG &G, int e) {
         dyn_add_edge<3, 2>(G, E);
     } else if (cls == 2) { // EdgeObjectMotion: numeric, three vertices
         const int a = G.m_from[o], b = G.m_to[o], vi = G.m_vel[o];
-        dyn_lin_init(E, 3, 3);
+        dyn_lin_init(E, 3, 3); E.eid = e;
         E.off[0] = G.obj_off[a]; E.dim[0] = 6; E.off[1] = G.obj_off[b]; E.dim[1] = 6; E.off[2] = G.vel_off[vi]; E.dim[2] = 2;
         const Cuboid ca = dyn_obj(G, a), cb = dyn_obj(G, b);
         const double v[2] = {G.vel[(long)vi * 2], G.vel[(long)vi * 2 + 1]};
@@ -322,7 +331,7 @@ template <int ONLY> HD void dyn_lin_item(const DynG &G, int e) {
     } else if (cls == 3) { // EdgeSE3CuboidFixScaleProj: numeric, camera and object
         if (dyn_lvl(G.c_lvl, o)) return;
         const int ci = G.c_cam[o], oi = G.c_obj[o];
-        dyn_lin_init(E, 2, 4);
+        dyn_lin_init(E, 2, 4); E.eid = e;
         E.off[0] = G.cam_off[ci]; E.dim[0] = 6; E.off[1] = G.obj_off[oi]; E.dim[1] = 6;
         const SE3 T = se3_load(G.cam + (long)ci * 7);
         const Cuboid c0 = dyn_obj(G, oi);
@@ -342,7 +351,7 @@ template <int ONLY> HD void dyn_lin_item(const DynG &G, int e) {
         dyn_add_edge<2, 4>(G, E);
     } else if (cls == 4) { // EdgePointCuboidOnlyObjectFixScale: numeric unary
         const int oi = G.pc_obj[o];
-        dyn_lin_init(E, 1, 3);
+        dyn_lin_init(E, 1, 3); E.eid = e;
         E.off[0] = G.obj_off[oi]; E.dim[0] = 6;
         const Cuboid c0 = dyn_obj(G, oi);
         for (int d = 0; d < 6; d++) {
@@ -355,7 +364,7 @@ template <int ONLY> HD void dyn_lin_item(const DynG &G, int e) {
         dyn_add_edge<1, 3>(G, E);
     } else { // UnaryLocalPoint: numeric unary on the dynamic point
         if (G.fix_points) return;
-        dyn_lin_init(E, 1, 3);
+        dyn_lin_init(E, 1, 3); E.eid = e;
         E.lm[0] = G.n_pts + o; E.dim[0] = 3;
         const double *X = G.dpts + (long)o * 3;
         for (int d = 0; d < 3; d++) {

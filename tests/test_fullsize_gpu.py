@@ -70,6 +70,6 @@ def test_config5_object_ba_2000_keyframes(ctx, oracle):
     assert all(b <= a for a, b in zip(tr, tr[1:])) and tr[-1] < 0.9 * tr[0]
     _, _, _, rst = oracle.ba_optimize(d, 3)
     assert rst["iterations"] == st["iterations"] and rst["lm_trials"] == st["lm_trials"]
-    assert np.allclose(st["chi2_trace"], rst["chi2_trace"], rtol=1e-4)
+    assert np.allclose(st["chi2_trace"], rst["chi2_trace"], rtol=1e-5)
     assert abs(st["chi2_final"] - rst["chi2_final"]) <= 1e-5 * rst["chi2_final"]
     assert np.allclose(np.linalg.norm(cam[:, 3:], axis=1), 1.0, atol=1e-12)
