@@ -232,3 +232,23 @@ def test_two_sided_band_solver_agrees_with_one_sided(ctx, monkeypatch):
         assert out[other][0]["lm_trials"] == out["band1"][0]["lm_trials"]
         assert np.allclose(out[other][0]["chi2_trace"], out["band1"][0]["chi2_trace"], rtol=1e-10)
         assert np.abs(out[other][1][0] - out["band1"][1][0]).max() <= 1e-8 and np.abs(out[other][1][1] - out["band1"][1][1]).max() <= 1e-7
+
+
+@pytest.mark.parametrize("k_obs", [3, 5, 7, 9])
+def test_nested_dissection_for_every_super_block_size(ctx, monkeypatch, k_obs):
+    """ba_cr.hip is instantiated for super-blocks of 2, 4, 6, 8 and 10 cameras (the band half-width rounded up): chains whose landmarks are seen by
+    k_obs consecutive key frames have half-width k_obs - 1; a chain length that is not a multiple of the super-block exercises the identity padding."""
+    d = synth.ba_problem(60 + k_obs, n_kf=163, n_points=5000, n_cuboids=0, k_obs=k_obs)
+    out = {}
+    for solver in ("band1", "cr"):
+        monkeypatch.setenv("CUBESLAM_BA_SOLVER", solver)
+        ctx.timing(True); ctx.timing_reset()
+        ba = BundleAdjuster(d, ctx=ctx)
+        st = ba.optimize(5)
+        out[solver] = (st, ba.read(), ctx.timing_get("ba_cr_eliminate")[1])
+        ctx.timing(False)
+        ba.close()
+    assert out["cr"][2] > 0 and out["band1"][2] == 0
+    assert out["cr"][0]["lm_trials"] == out["band1"][0]["lm_trials"]
+    assert np.allclose(out["cr"][0]["chi2_trace"], out["band1"][0]["chi2_trace"], rtol=1e-10)
+    assert np.abs(out["cr"][1][0] - out["band1"][1][0]).max() <= 1e-8 and np.abs(out["cr"][1][1] - out["band1"][1][1]).max() <= 1e-7
