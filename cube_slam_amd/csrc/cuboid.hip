@@ -2096,11 +2096,17 @@ int cs_cuboid_detect(cs_ctx *ctx, const uint8_t *img, int width, int height, int
         uint8_t *d_bgr = nullptr, *d_g = nullptr;
         CS_HIP(ctx, hipMalloc((void **)&d_bgr, (size_t)stride * height));
         if (hipMalloc((void **)&d_g, (size_t)width * height) != hipSuccess) { hipFree(d_bgr); return CS_ERR_NOMEM; }
-        hipMemcpyAsync(d_bgr, img, (size_t)stride * height, hipMemcpyHostToDevice, ctx->stream);
-        CS_LAUNCH(ctx, "cuboid_bgr2gray", cuboid_bgr2gray, dim3((width + 255) / 256, height), dim3(256), 0, d_bgr, stride, width, height, d_g);
-        hipMemcpyAsync(gray.data(), d_g, (size_t)width * height, hipMemcpyDeviceToHost, ctx->stream);
-        hipError_t e = hipStreamSynchronize(ctx->stream);
-        hipFree(d_bgr); hipFree(d_g);
+        hipError_t e = hipMemcpyAsync(d_bgr, img, (size_t)stride * height, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) {
+            ctx->begin("cuboid_bgr2gray");
+            hipLaunchKernelGGL(cuboid_bgr2gray, dim3((width + 255) / 256, height), dim3(256), 0, ctx->stream, d_bgr, stride, width, height, d_g);
+            ctx->end();
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) e = hipMemcpyAsync(gray.data(), d_g, (size_t)width * height, hipMemcpyDeviceToHost, ctx->stream);
+        const hipError_t es = hipStreamSynchronize(ctx->stream);
+        hipFree(d_bgr); hipFree(d_g); // on every path
+        if (e == hipSuccess) e = es;
         if (e != hipSuccess) { ctx->err = hipGetErrorString(e); return CS_ERR_HIP; }
     }
     int bo[2] = {0, n_boxes}, lo[2] = {0, n_lines};

@@ -8,6 +8,22 @@ from . import _lib
 from ._lib import check, lib
 
 
+
+def _boxes5(x):
+    """obj_bbox_coors as the reference reads it: a matrix with one row per box of which columns 0-3 (x y w h) are used (box_proposal_detail.cpp:102-108;
+    a fifth column is the detection probability of the txt files).  -> (n, 5) float64."""
+    b = np.asarray(x, np.float64)
+    if b.ndim == 1:
+        if b.size % 5 != 0:
+            raise ValueError("obj_bbox_coors: a flat array must hold 5 numbers per box (x y w h prob), got %d numbers" % b.size)
+        b = b.reshape(-1, 5)
+    if b.ndim != 2 or (len(b) and b.shape[1] < 4):
+        raise ValueError("obj_bbox_coors: expected an (n, >= 4) matrix, got shape %r" % (b.shape,))
+    out = np.zeros((len(b), 5))
+    out[:, :min(5, b.shape[1])] = b[:, :5]
+    return np.ascontiguousarray(out)
+
+
 class CuboidOpts(C.Structure):
     _fields_ = [
         ("consider_config_1", C.c_int), ("consider_config_2", C.c_int),
@@ -72,7 +88,7 @@ class detect_3d_cuboid:
         ch = 1 if img.ndim == 2 else img.shape[2]
         H, W = img.shape[:2]
         T = np.ascontiguousarray(transToWolrd, np.float64).reshape(4, 4)
-        boxes = np.ascontiguousarray(obj_bbox_coors, np.float64).reshape(-1, 5)
+        boxes = _boxes5(obj_bbox_coors)
         lines = np.ascontiguousarray(edges, np.float64).reshape(-1, 4)
         nb = len(boxes)
         out = np.zeros((max(nb, 1), self.max_cuboid_num), CUBOID_DTYPE)
@@ -99,7 +115,7 @@ class CuboidBatch:
         for f in range(self.F):
             bo[f + 1] = bo[f] + len(boxes_list[f])
             lo[f + 1] = lo[f] + len(lines_list[f])
-        boxes = np.ascontiguousarray(np.concatenate([np.asarray(b, np.float64).reshape(-1, 5) for b in boxes_list] + [np.zeros((0, 5))]))
+        boxes = np.ascontiguousarray(np.concatenate([_boxes5(b) for b in boxes_list] + [np.zeros((0, 5))]))
         lines = np.ascontiguousarray(np.concatenate([np.asarray(l, np.float64).reshape(-1, 4) for l in lines_list] + [np.zeros((1, 4))]))
         self.n_boxes = int(bo[-1])
         self.max_cuboid_num = opts.max_cuboid_num

@@ -28,9 +28,9 @@ def read_all_number_txt(path, cols=10, dtype=np.float64):
             if not line.strip("\n"):
                 continue  # `if (!line.empty())`; a line of blanks parses to zero numbers and still makes a row, like the reference
             v = _numbers(line.split())
-            if len(v) > cols:
-                raise ValueError("%s: %d numbers in a row of a %d-column matrix (the reference writes out of bounds here)" % (path, len(v), cols))
-            rows.append(v + [0.0] * (cols - len(v)))
+            # more numbers than columns: the reference keeps writing read_number_mat(row, colu++) without a bound (matrix_utils.cpp:217-221), which is
+            # outside the matrix (undefined).  Kept: the first `cols` numbers.
+            rows.append((v + [0.0] * cols)[:cols])
     return np.array(rows, dtype).reshape(-1, cols)
 
 

@@ -18,8 +18,8 @@ def test_number_matrix_semantics(tmp_path):
     # blank line skipped; parsing stops at the first non-number; a whitespace-only line is a row of zeros (the reference counts it)
     assert np.array_equal(m, [[1, 2, 3, 0], [4.5, -0.6, 7, 0], [0, 0, 0, 0], [8, 9, 10, 11]])
     assert cio.read_all_number_txt(str(p)).shape == (4, 10)
-    with pytest.raises(ValueError):
-        cio.read_all_number_txt(str(p), cols=3)
+    # more numbers than columns: the reference writes past the row (undefined); kept: the first `cols` numbers
+    assert np.array_equal(cio.read_all_number_txt(str(p), cols=3), [[1, 2, 3], [4.5, -0.6, 7], [0, 0, 0], [8, 9, 10]])
     with pytest.raises(FileNotFoundError):
         cio.read_all_number_txt(str(tmp_path / "missing.txt"))
 
@@ -76,3 +76,17 @@ def test_cpp_twin_matches_python(tmp_path):
         tok = line.split()
         assert tok[0] == nm and np.array_equal(np.array(tok[1:], float), row)
     assert (tmp_path / "e.txt").read_text() == "467.435\t0.526885\t453.015\t285.683\n"
+
+
+def test_boxes_matrix_with_four_or_more_columns():
+    """detect_cuboid reads columns 0-3 of obj_bbox_coors (box_proposal_detail.cpp:102-108): an (n, 4) matrix is as good as the (n, 5) rows of the txt files."""
+    from cube_slam_amd.cuboid import _boxes5
+    b4 = np.array([[10, 20, 30, 40], [1, 2, 3, 4]], float)
+    assert np.array_equal(_boxes5(b4), [[10, 20, 30, 40, 0], [1, 2, 3, 4, 0]])
+    assert np.array_equal(_boxes5(np.hstack([b4, [[0.9, 7], [0.5, 8]]])), [[10, 20, 30, 40, 0.9], [1, 2, 3, 4, 0.5]])
+    assert np.array_equal(_boxes5([10, 20, 30, 40, 0.9]), [[10, 20, 30, 40, 0.9]])
+    assert _boxes5(np.zeros((0, 5))).shape == (0, 5)
+    with pytest.raises(ValueError):
+        _boxes5([1, 2, 3, 4])
+    with pytest.raises(ValueError):
+        _boxes5(np.zeros((2, 3)))
