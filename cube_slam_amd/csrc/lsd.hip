@@ -245,6 +245,8 @@ class LsdHost {
                         const Aux &ax = aux[c];
                         rx[n] = xx; ry[n] = yy; rang[n] = double(af) * DEG_TO_RADS; rmod[n] = ax.mod;
                         ++n;
+                        // its own neighbourhood is read when the list reaches it: ask for the two rows not in cache yet (the walk is bound by these misses)
+                        __builtin_prefetch(&free_deg[c - w - 1 < 0 ? 0 : c - w - 1]); __builtin_prefetch(&free_deg[c + w + 1 >= w * h ? c : c + w + 1]);
                         sumdx += ax.c; // cos(float(angle)), sin(float(angle)) :676-677, computed by lsd_emit
                         sumdy += ax.s;
                         reg_angle = fast_atan2f_(sumdy, sumdx) * DEG_TO_RADS;
