@@ -194,7 +194,22 @@ __global__ void __launch_bounds__(256) lsd_emit(const double *modgrad, const dou
     for (int i = 0; i < wv; i++) pos += wc[i];
     float d = (float)(a / DEG_TO_RADS); // the float whose product with DEG_TO_RADS is a: the quotient rounded, or a neighbour of it
     if ((double)d * DEG_TO_RADS != a) { const float up = nextafterf(d, 1e9f), dn = nextafterf(d, -1e9f); d = ((double)up * DEG_TO_RADS == a) ? up : dn; }
-    c_addr[pos] = y * w + x; c_deg[pos] = d; c_mod[pos] = modgrad[o];
+    // bit 31 of the address: no neighbour is aligned with this pixel's own angle (angles never change), so as a seed it stays alone -- region_grow's
+    // first nine tests use exactly that angle -- and the host marks it used without testing anything (12 k of 25 k seeds on a textured frame are single)
+    bool alone = true;
+    const double prec = PI_ * 22.5 / 180;
+    for (int dy = -1; dy <= 1; dy++)
+        for (int dx = -1; dx <= 1; dx++) {
+            const int xx = x + dx, yy = y + dy;
+            if ((dx == 0 && dy == 0) || xx < 0 || yy < 0 || xx >= w || yy >= h) continue;
+            const double b = angles[((long)blockIdx.z * h + yy) * w + xx];
+            if (b == NOTDEF) continue;
+            double n_theta = a - b; // isAligned(neighbour, a, prec) :1138-1154
+            if (n_theta < 0) n_theta = -n_theta;
+            if (n_theta > (3 * PI_) / 2) { n_theta -= 2 * PI_; if (n_theta < 0) n_theta = -n_theta; }
+            if (n_theta <= prec) alone = false;
+        }
+    c_addr[pos] = (y * w + x) | (alone ? (int)0x80000000 : 0); c_deg[pos] = d; c_mod[pos] = modgrad[o];
     c_cs[pos] = make_float2(glibc_sincosf::cosf_(float(a)), glibc_sincosf::sinf_(float(a)));
 }
 
@@ -231,7 +246,8 @@ class LsdHost {
         int addr = sx + sy * w;
         reg_angle = double(deg[addr]) * DEG_TO_RADS;
         rx[0] = sx; ry[0] = sy; rang[0] = reg_angle; rmod[0] = aux[addr].mod;
-        float sumdx = float(std::cos(reg_angle)), sumdy = float(std::sin(reg_angle));
+        float sumdx = 0, sumdy = 0; // cos / sin of the seed angle (:651-652, doubles): only needed once a second pixel joins -- half the seeds stay alone
+        bool have_sums = false;
         free_deg[addr] = NOTDEF_F;
         for (int i = 0; i < n; ++i) {
             const int px = rx[i], py = ry[i];
@@ -245,6 +261,7 @@ class LsdHost {
                         const Aux &ax = aux[c];
                         rx[n] = xx; ry[n] = yy; rang[n] = double(af) * DEG_TO_RADS; rmod[n] = ax.mod;
                         ++n;
+                        if (!have_sums) { const double a0 = rang[0]; sumdx = float(std::cos(a0)); sumdy = float(std::sin(a0)); have_sums = true; }
                         // its own neighbourhood is read when the list reaches it: ask for the two rows not in cache yet (the walk is bound by these misses)
                         __builtin_prefetch(&free_deg[c - w - 1 < 0 ? 0 : c - w - 1]); __builtin_prefetch(&free_deg[c + w + 1 >= w * h ? c : c + w + 1]);
                         sumdx += ax.c; // cos(float(angle)), sin(float(angle)) :676-677, computed by lsd_emit
@@ -457,8 +474,8 @@ class LsdHost {
         // reference's output (established by running the reference's own lsd.cpp: oracle/_ref, tests/test_ref_pins.py).
         constexpr int PFD = 24; // the scatter is sparse in the dense maps: ask for the lines a few entries ahead
         for (int i = 0; i < ne; i++) {
-            if (i + PFD < ne) { const int a = e_addr[i + PFD]; __builtin_prefetch(&deg[a], 1); __builtin_prefetch(&free_deg[a], 1); __builtin_prefetch(&aux[a], 1); }
-            const int q = e_addr[i];
+            if (i + PFD < ne) { const int a = e_addr[i + PFD] & 0x7fffffff; __builtin_prefetch(&deg[a], 1); __builtin_prefetch(&free_deg[a], 1); __builtin_prefetch(&aux[a], 1); }
+            const int q = e_addr[i] & 0x7fffffff;
             deg[q] = e_deg[i]; free_deg[q] = e_deg[i]; aux[q] = Aux{e_mod[i], e_cs[i].x, e_cs[i].y};
         }
         LOG_NT = 5 * (std::log10(double(w)) + std::log10(double(h))) / 2 + std::log10(11.0);
@@ -466,8 +483,9 @@ class LsdHost {
         lines.clear();
         if (timed) t_sort += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tt0).count();
         for (int i = 0; i < ne; ++i) {
-            const int adx = e_addr[i];
+            const int adx = e_addr[i] & 0x7fffffff;
             if (free_deg[adx] == NOTDEF_F) continue; // used
+            if (e_addr[i] < 0) { free_deg[adx] = NOTDEF_F; if (timed) n_seeds++; continue; } // a region of one pixel (flagged by lsd_emit): used, nothing else
             int rn; double reg_angle;
             const auto tg0 = timed ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
             grow(adx % w, adx / w, rn, reg_angle, prec);
@@ -485,8 +503,8 @@ class LsdHost {
             lines.push_back(float(rec.x1)); lines.push_back(float(rec.y1)); lines.push_back(float(rec.x2)); lines.push_back(float(rec.y2));
         }
         for (int i = 0; i < ne; i++) { // leave the dense maps clean for the next frame
-            if (i + PFD < ne) { const int a = e_addr[i + PFD]; __builtin_prefetch(&deg[a], 1); __builtin_prefetch(&free_deg[a], 1); }
-            deg[e_addr[i]] = NOTDEF_F; free_deg[e_addr[i]] = NOTDEF_F;
+            if (i + PFD < ne) { const int a = e_addr[i + PFD] & 0x7fffffff; __builtin_prefetch(&deg[a], 1); __builtin_prefetch(&free_deg[a], 1); }
+            { const int q = e_addr[i] & 0x7fffffff; deg[q] = NOTDEF_F; free_deg[q] = NOTDEF_F; }
         }
     }
 };

@@ -300,7 +300,7 @@ RG_HD void step(const Frame &F, Txn &T, const int *dirty, int n_dirty, int *ctl)
         const int k = add32(&ctl[2], 1);
         if (k >= n_dirty) { T.phase = PH_DONE; return; }
         const int s = dirty[k];
-        T.s = s; T.saddr = F.caddr[s];
+        T.s = s; T.saddr = F.caddr[s] & 0x7fffffff; // (bit 31 is lsd_emit's single-pixel flag for the host stage)
         const unsigned e = F.execs[s]++;
         T.word = ((u64)(uint32_t)s << 32) | (u64)(0xFFFFFFF0u - 2u * e);
         T.j = 0; T.ne = 0; T.np1 = 0; T.n = 0;
@@ -336,7 +336,7 @@ RG_HD void step(const Frame &F, Txn &T, const int *dirty, int n_dirty, int *ctl)
 
 // does seed i run in the next round?  (after a round, before the tile marks are cleared)
 RG_HD bool is_dirty(const Frame &F, int i) {
-    const uint32_t o = rank_of(ld64(&F.own[F.caddr[i]]));
+    const uint32_t o = rank_of(ld64(&F.own[F.caddr[i] & 0x7fffffff]));
     if (F.flag[i] & 1) {
         if (o != (uint32_t)i) return true;
         const int *tl = F.pool + F.fp_off[i] + F.fp_cnt[i];
@@ -347,7 +347,7 @@ RG_HD bool is_dirty(const Frame &F, int i) {
 }
 // first round: seeds without an aligned defined neighbour of lower rank (the others are almost always swallowed by an earlier region)
 RG_HD bool is_initial(const Frame &F, int i) {
-    const int s = F.caddr[i], x = s % F.w, y = s / F.w;
+    const int s = F.caddr[i] & 0x7fffffff, x = s % F.w, y = s / F.w;
     const double a = F.ang[s], prec = PI_ * ANG_TH / 180;
     const int nb[4][2] = {{-1, -1}, {0, -1}, {1, -1}, {-1, 0}};
     for (int k = 0; k < 4; k++) { const int xx = x + nb[k][0], yy = y + nb[k][1]; if (xx < 0 || yy < 0 || xx >= F.w) continue; if (aligned_ang(F.ang[xx + yy * F.w], a, prec)) return false; }
