@@ -80,13 +80,13 @@ __global__ void __launch_bounds__(64) lsd_blur_hv(const uint8_t *gray, int W, in
                 if (tid < 3) line[tid] = curh[u];
                 else if (tid < 6) line[3 + 64 + (tid - 3)] = curh[u];
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                double px[7];
+                double pix[7];
 #pragma unroll
-                for (int t = 0; t < 7; t++) px[t] = (double)line[tid + t]; // columns x-3 .. x+3
+                for (int t = 0; t < 7; t++) pix[t] = (double)line[tid + t]; // columns x-3 .. x+3
                 asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-                double h = g.k[KH] * px[3];
+                double h = g.k[KH] * pix[3];
 #pragma unroll
-                for (int t = 1; t <= KH; t++) h += g.k[KH + t] * (px[3 - t] + px[3 + t]);
+                for (int t = 1; t <= KH; t++) h += g.k[KH + t] * (pix[3 - t] + pix[3 + t]);
 #pragma unroll
                 for (int t = 0; t < 6; t++) ring[t] = ring[t + 1];
                 ring[6] = h;
@@ -219,15 +219,16 @@ struct RectH { double x1, y1, x2, y2, width, x, y, theta, dx, dy, prec, p; };
 class LsdHost {
   public:
     int w = 0, h = 0;
-    // Dense per-pixel maps of this thread.  free_deg: the level-line angle in float degrees while the pixel is defined AND unused, NOTDEF_F
+    // Dense per-pixel map of this thread, one 16-byte record per pixel so that what an accepted pixel contributes sits in the cache line its test
+    // just loaded (the stage is bound by the misses of the nine-neighbour walk; most regions are a handful of pixels).  free_deg: the level-line angle in float degrees while the pixel is defined AND unused, NOTDEF_F
     // otherwise -- region_grow's "used == 0 && isAligned" reads one 4-byte value per neighbour; deg: the same without the used marks (rect_nfa
     // counts aligned pixels whatever their use); aux: what an accepted pixel contributes (gradient norm, cos / sin of its angle).
     static constexpr float NOTDEF_F = -1024.0f;
-    struct Aux { double mod; float c, s; };
-    std::vector<float> free_deg, deg;
-    std::vector<Aux> aux;
+    struct Px { float free_deg, c, s, deg; }; // c, s: cos / sin of float(angle); deg: the angle whatever the use
+    std::vector<Px> pix;
+    std::vector<double> dmod;         // gradient norm, dense: only read for the pixels of regions that reach the rectangle stage
     std::vector<int> rx, ry;          // region points (structure of arrays)
-    std::vector<double> rang, rmod;
+    std::vector<double> rang;
     double LOG_NT = 0;
 
     static inline bool aligned_deg(float af, double theta, double prec) { // isAligned lsd.cpp:1138-1154 on a stored angle
@@ -244,26 +245,26 @@ class LsdHost {
     void grow(int sx, int sy, int &n, double &reg_angle, double prec) { // region_grow :637-688
         n = 1;
         int addr = sx + sy * w;
-        reg_angle = double(deg[addr]) * DEG_TO_RADS;
-        rx[0] = sx; ry[0] = sy; rang[0] = reg_angle; rmod[0] = aux[addr].mod;
+        reg_angle = double(pix[addr].deg) * DEG_TO_RADS;
+        rx[0] = sx; ry[0] = sy; rang[0] = reg_angle;
         float sumdx = 0, sumdy = 0; // cos / sin of the seed angle (:651-652, doubles): only needed once a second pixel joins -- half the seeds stay alone
         bool have_sums = false;
-        free_deg[addr] = NOTDEF_F;
+        pix[addr].free_deg = NOTDEF_F;
         for (int i = 0; i < n; ++i) {
             const int px = rx[i], py = ry[i];
             const int x0 = std::max(px - 1, 0), x1 = std::min(px + 1, w - 1), y0 = std::max(py - 1, 0), y1 = std::min(py + 1, h - 1);
             for (int yy = y0; yy <= y1; ++yy) {
                 int c = x0 + yy * w;
                 for (int xx = x0; xx <= x1; ++xx, ++c) {
-                    const float af = free_deg[c];
+                    Px &ax = pix[c];
+                    const float af = ax.free_deg;
                     if (aligned_deg(af, reg_angle, prec)) { // defined, unused and aligned
-                        free_deg[c] = NOTDEF_F;
-                        const Aux &ax = aux[c];
-                        rx[n] = xx; ry[n] = yy; rang[n] = double(af) * DEG_TO_RADS; rmod[n] = ax.mod;
+                        ax.free_deg = NOTDEF_F;
+                        rx[n] = xx; ry[n] = yy; rang[n] = double(af) * DEG_TO_RADS;
                         ++n;
                         if (!have_sums) { const double a0 = rang[0]; sumdx = float(std::cos(a0)); sumdy = float(std::sin(a0)); have_sums = true; }
                         // its own neighbourhood is read when the list reaches it: ask for the two rows not in cache yet (the walk is bound by these misses)
-                        __builtin_prefetch(&free_deg[c - w - 1 < 0 ? 0 : c - w - 1]); __builtin_prefetch(&free_deg[c + w + 1 >= w * h ? c : c + w + 1]);
+                        __builtin_prefetch(&pix[c - w - 1 < 0 ? 0 : c - w - 1]); __builtin_prefetch(&pix[c + w + 1 >= w * h ? c : c + w + 1]);
                         sumdx += ax.c; // cos(float(angle)), sin(float(angle)) :676-677, computed by lsd_emit
                         sumdy += ax.s;
                         reg_angle = fast_atan2f_(sumdy, sumdx) * DEG_TO_RADS;
@@ -274,10 +275,10 @@ class LsdHost {
     }
     void to_rect(int n, double reg_angle, double prec, double p, RectH &rec) const { // region2rect :690-746 + get_theta :748-784
         double x = 0, y = 0, sum = 0;
-        for (int i = 0; i < n; ++i) { x += double(rx[i]) * rmod[i]; y += double(ry[i]) * rmod[i]; sum += rmod[i]; }
+        for (int i = 0; i < n; ++i) { const double wg = dmod[(size_t)ry[i] * w + rx[i]]; x += double(rx[i]) * wg; y += double(ry[i]) * wg; sum += wg; }
         x /= sum; y /= sum;
         double Ixx = 0, Iyy = 0, Ixy = 0;
-        for (int i = 0; i < n; ++i) { const double dx = (double)rx[i] - x, dy = (double)ry[i] - y, wg = rmod[i]; Ixx += dy * dy * wg; Iyy += dx * dx * wg; Ixy -= dx * dy * wg; }
+        for (int i = 0; i < n; ++i) { const double dx = (double)rx[i] - x, dy = (double)ry[i] - y, wg = dmod[(size_t)ry[i] * w + rx[i]]; Ixx += dy * dy * wg; Iyy += dx * dx * wg; Ixy -= dx * dy * wg; }
         const double lambda = 0.5 * (Ixx + Iyy - std::sqrt((Ixx - Iyy) * (Ixx - Iyy) + 4.0 * Ixy * Ixy));
         double theta = (std::fabs(Ixx) > std::fabs(Iyy)) ? double(fast_atan2f_(float(lambda - Ixx), float(Ixy))) : double(fast_atan2f_(float(Ixy), float(lambda - Iyy)));
         theta *= DEG_TO_RADS;
@@ -302,8 +303,8 @@ class LsdHost {
             radSq *= 0.75 * 0.75;
             for (int i = 0; i < n; ++i)
                 if (dsq(xc, yc, double(rx[i]), double(ry[i])) > radSq) {
-                    { const int q = rx[i] + ry[i] * w; free_deg[q] = deg[q]; }
-                    std::swap(rx[i], rx[n - 1]); std::swap(ry[i], ry[n - 1]); std::swap(rang[i], rang[n - 1]); std::swap(rmod[i], rmod[n - 1]);
+                    { Px &q = pix[rx[i] + ry[i] * w]; q.free_deg = q.deg; }
+                    std::swap(rx[i], rx[n - 1]); std::swap(ry[i], ry[n - 1]); std::swap(rang[i], rang[n - 1]);
                     --n; --i;
                 }
             if (n < 2) return false;
@@ -319,7 +320,7 @@ class LsdHost {
         double sum = 0, s_sum = 0;
         int cnt = 0;
         for (int i = 0; i < n; ++i) {
-            { const int q = rx[i] + ry[i] * w; free_deg[q] = deg[q]; }
+            { Px &q = pix[rx[i] + ry[i] * w]; q.free_deg = q.deg; }
             if (dist(xc, yc, rx[i], ry[i]) < rec.width) { const double d = sdiff(rang[i], ang_c); sum += d; s_sum += d * d; ++cnt; }
         }
         const double mean_angle = sum / double(cnt);
@@ -403,9 +404,9 @@ class LsdHost {
             const int xa = std::max(int(left_x), 0), xb = std::min(int(right_x), w - 1);
             if (xb >= xa) {
                 total += xb - xa + 1;
-                const float *row = deg.data() + (size_t)y * w;
+                const Px *row = pix.data() + (size_t)y * w;
                 for (int x = xa; x <= xb; ++x) { // isAligned :1138-1154
-                    const float af = row[x];
+                    const float af = row[x].deg;
                     const double a = double(af) * DEG_TO_RADS;
                     double d = std::fabs(theta - a);
                     const double d2 = std::fabs(d - two_pi);
@@ -467,16 +468,16 @@ class LsdHost {
         const auto tt0 = timed ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
         w = w_; h = h_;
         const size_t n = (size_t)w * h;
-        if (deg.size() != n) { deg.assign(n, NOTDEF_F); free_deg.assign(n, NOTDEF_F); aux.assign(n, Aux{0.0, 0.f, 0.f}); rx.resize(n); ry.resize(n); rang.resize(n); rmod.resize(n); }
+        if (pix.size() != n) { pix.assign(n, Px{NOTDEF_F, 0.f, 0.f, NOTDEF_F}); dmod.assign(n, 0.0); rx.resize(n); ry.resize(n); rang.resize(n); }
         const double prec = PI_ * 22.5 / 180, p = 22.5 / 180;
         // Seed order = address order.  ll_angle links the 1024-bin pseudo-ordering through `next` pointers (:588-634), but flsd walks the
         // `list` vector by index (:477-480) and its entries were appended in raster order: the gradient ordering has no effect on the
         // reference's output (established by running the reference's own lsd.cpp: oracle/_ref, tests/test_ref_pins.py).
         constexpr int PFD = 24; // the scatter is sparse in the dense maps: ask for the lines a few entries ahead
         for (int i = 0; i < ne; i++) {
-            if (i + PFD < ne) { const int a = e_addr[i + PFD] & 0x7fffffff; __builtin_prefetch(&deg[a], 1); __builtin_prefetch(&free_deg[a], 1); __builtin_prefetch(&aux[a], 1); }
+            if (i + PFD < ne) { const int a = e_addr[i + PFD] & 0x7fffffff; __builtin_prefetch(&pix[a], 1); __builtin_prefetch(&dmod[a], 1); }
             const int q = e_addr[i] & 0x7fffffff;
-            deg[q] = e_deg[i]; free_deg[q] = e_deg[i]; aux[q] = Aux{e_mod[i], e_cs[i].x, e_cs[i].y};
+            pix[q] = Px{e_deg[i], e_cs[i].x, e_cs[i].y, e_deg[i]}; dmod[q] = e_mod[i];
         }
         LOG_NT = 5 * (std::log10(double(w)) + std::log10(double(h))) / 2 + std::log10(11.0);
         const int min_reg_size = int(-LOG_NT / std::log10(p));
@@ -484,8 +485,8 @@ class LsdHost {
         if (timed) t_sort += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - tt0).count();
         for (int i = 0; i < ne; ++i) {
             const int adx = e_addr[i] & 0x7fffffff;
-            if (free_deg[adx] == NOTDEF_F) continue; // used
-            if (e_addr[i] < 0) { free_deg[adx] = NOTDEF_F; if (timed) n_seeds++; continue; } // a region of one pixel (flagged by lsd_emit): used, nothing else
+            if (pix[adx].free_deg == NOTDEF_F) continue; // used
+            if (e_addr[i] < 0) { pix[adx].free_deg = NOTDEF_F; if (timed) n_seeds++; continue; } // a region of one pixel (flagged by lsd_emit): used, nothing else
             int rn; double reg_angle;
             const auto tg0 = timed ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
             grow(adx % w, adx / w, rn, reg_angle, prec);
@@ -503,8 +504,8 @@ class LsdHost {
             lines.push_back(float(rec.x1)); lines.push_back(float(rec.y1)); lines.push_back(float(rec.x2)); lines.push_back(float(rec.y2));
         }
         for (int i = 0; i < ne; i++) { // leave the dense maps clean for the next frame
-            if (i + PFD < ne) { const int a = e_addr[i + PFD] & 0x7fffffff; __builtin_prefetch(&deg[a], 1); __builtin_prefetch(&free_deg[a], 1); }
-            { const int q = e_addr[i] & 0x7fffffff; deg[q] = NOTDEF_F; free_deg[q] = NOTDEF_F; }
+            if (i + PFD < ne) { const int a = e_addr[i + PFD] & 0x7fffffff; __builtin_prefetch(&pix[a], 1); }
+            { Px &q = pix[e_addr[i] & 0x7fffffff]; q.deg = NOTDEF_F; q.free_deg = NOTDEF_F; }
         }
     }
 };
