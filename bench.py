@@ -117,7 +117,7 @@ def measure_traffic(frames, boxes, yaw_step):
             d = tempfile.mkdtemp(prefix="pmc_" + tag, dir="/tmp")
             env = dict(os.environ, TMPDIR="/tmp")
             subprocess.run(["rocprofv3", "--pmc"] + ctrs.split() + ["--output-format", "csv", "-d", d, "-o", "res", "--", sys.executable, os.path.join(ROOT, "tools", "pmc_run.py"),
-                            str(frames), str(boxes), str(yaw_step), str(BG_TEXTURE)], cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=240, check=True)
+                            str(frames), str(boxes), str(yaw_step), str(BG_TEXTURE)], cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=90, check=True)
             acc = {}
             for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
                 for r in csv.DictReader(open(f)):
@@ -459,10 +459,12 @@ def main():
 
     if rank == 0:
         total_frames = args.frames * world * args.steps
-        # Algorithmic bytes of one cuboid_sweep_score launch: each LDS-resident distance map read once -- as the 2-byte chamfer code the
-        # distance transform's last stage writes for this kernel (2*A; SURVEY 8d writes 4*A for a float map) -- plus, per surviving
-        # proposal, 16 corner doubles read and 2 error doubles written (144 B).  Units that do not fit LDS are cuboid_sweep_score_big's.
-        alg_bytes = 2.0 * ss["lds_pixels"] + 144.0 * ss["lds_valid"]
+        # Algorithmic bytes of one cuboid_sweep_score launch, as SURVEY 8d defines them for the edge-scoring kernel and as round 1 counted them: every
+        # distance-map ROI it covers read once as the float map the distance transform produces (4*A), plus per surviving proposal 16 corner
+        # doubles read and 2 error doubles written (144 B).  Two other accountings ride along in roofline["accountings"]: what THIS kernel has to
+        # move now that it reads the map as 2-byte codes (2*A + 144*n_valid, the strictest), and SURVEY 8d's literal per-box figure with all
+        # hypotheses (4*A + 144*n_h) over both score kernels.  Units that do not fit LDS are cuboid_sweep_score_big's.
+        alg_bytes = 4.0 * ss["lds_pixels"] + 144.0 * ss["lds_valid"]
         k_us = kernels["cuboid_sweep_score"]["avg_us"]
         achieved = alg_bytes / (k_us * 1e-6) / 1e9 if k_us > 0 else 0.0
         iso_us = 1e3 * iso_ms / max(iso_n, 1)
@@ -482,7 +484,15 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "cuboid_sweep_score", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None if tr is None else tr["bytes"], "traffic_detail": tr, "avg_kernel_us": k_us,
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "algorithmic_bytes_formula": "2*A_lds + 144*n_valid_lds (16-bit code map read once; the float-map formula 4*A + 144*n of SURVEY 8d gives %.0f)" % (4.0 * ss["lds_pixels"] + 144.0 * ss["lds_valid"]),
+                         "algorithmic_bytes_formula": "4*A_lds + 144*n_valid_lds (SURVEY 8d: distance-map ROI read once + corners in + errors out; round 1's accounting)",
+                         "accountings": {
+                             "code_map_2A_plus_144_n_valid": {"bytes": 2.0 * ss["lds_pixels"] + 144.0 * ss["lds_valid"],
+                                                              "frac": (2.0 * ss["lds_pixels"] + 144.0 * ss["lds_valid"]) / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBS if k_us > 0 else None,
+                                                              "note": "what this kernel must move: the map as 16-bit codes (cuboid_dt_codes wrote them), valid proposals only"},
+                             "survey_8d_4A_plus_144_n_h_both_kernels": {"bytes": 4.0 * st["roi_pixels"] + 144.0 * st["n_hypotheses"],
+                                                                        "us": k_us + kernels["cuboid_sweep_score_big"]["avg_us"],
+                                                                        "frac": (4.0 * st["roi_pixels"] + 144.0 * st["n_hypotheses"]) / ((k_us + kernels["cuboid_sweep_score_big"]["avg_us"]) * 1e-6) / 1e9 / HBM_PEAK_GBS if k_us > 0 else None,
+                                                                        "note": "SURVEY 8d's per-box figure (all hypotheses' corners, 0.85 MB/box) over cuboid_sweep_score + cuboid_sweep_score_big"}},
                          "isolated": {"avg_kernel_us": iso_us, "frac": (alg_bytes / (iso_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if iso_n else None,
                                       "note": "cuboid path alone on the GPU; the timed region runs ORB, line and cuboid kernels concurrently on three streams"}},
             "kernels_us": {k: round(v["avg_us"], 2) for k, v in kernels.items()},
