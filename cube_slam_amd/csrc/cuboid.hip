@@ -974,7 +974,7 @@ struct ScoreSeg { int unit, task; }; // segment border: task index inside the un
 struct BigItem { int unit, cfg, first; };
 
 __device__ __forceinline__ int sc_tasks(int c) { return (c + 63) >> 6; }
-__device__ __forceinline__ bool sc_unit_lds(const Unit &U, const int *uflag, int u) { return score_unit_fits(U.roi_w, U.roi_h) && !(uflag[u] & 1); }
+__device__ __forceinline__ bool sc_unit_lds(const Unit &U, const int *uflag, int u) { return !(uflag[u] & 1); } // an escape code (a pixel 244 px from every edge) needs the float map
 
 __device__ __forceinline__ unsigned sc_encode(float d, const unsigned short *lut) {
     const float tf = d * 65536.0f;
@@ -1016,9 +1016,11 @@ __global__ void __launch_bounds__(256) cuboid_dt_codes(const Unit *units, const 
 }
 
 // one workgroup: cost line of the LDS units -> G + 1 segment borders; work items of the other units -> big list
-__device__ __forceinline__ long sc_copy_cost(const Unit &U) { return ((long)U.roi_w * U.roi_h * SC_COST_PX_NUM) >> 6; }
+// tasks of a unit whose map does not fit LDS gather part of their samples from global memory: costed higher so the segments stay balanced
+__device__ __forceinline__ long sc_task_cost(const Unit &U, int cfg, int hyb_num) { const long c = cfg == 1 ? SC_COST_TASK1 : SC_COST_TASK2; return score_unit_fits(U.roi_w, U.roi_h) ? c : c * hyb_num / 4; }
+__device__ __forceinline__ long sc_copy_cost(const Unit &U) { return (min((long)U.roi_w * U.roi_h, (long)SC_MAP_ENTRIES) * SC_COST_PX_NUM) >> 6; }
 __global__ void __launch_bounds__(1024) cuboid_score_plan(const Unit *units, int n_units, const int *vcount, const int *uflag, long *cost /*n_units + 1*/, ScoreSeg *seg, int G,
-                                                          BigItem *big, int *big_n) {
+                                                          BigItem *big, int *big_n, int hyb_num /* cost of an oversize unit's task in quarters of a resident one's */) {
     __shared__ long s_part[16];
     __shared__ long s_cost[SC_PLAN_LDS_UNITS + 1];
     __shared__ int s_bign;
@@ -1030,7 +1032,7 @@ __global__ void __launch_bounds__(1024) cuboid_score_plan(const Unit *units, int
     auto unit_cost = [&](int u) -> long {
         const int n1 = sc_tasks(vcount[2 * u]), n2 = sc_tasks(vcount[2 * u + 1]);
         if (n1 + n2 == 0 || !sc_unit_lds(units[u], uflag, u)) return 0;
-        return sc_copy_cost(units[u]) + (long)n1 * SC_COST_TASK1 + (long)n2 * SC_COST_TASK2;
+        return sc_copy_cost(units[u]) + (long)n1 * sc_task_cost(units[u], 1, hyb_num) + (long)n2 * sc_task_cost(units[u], 2, hyb_num);
     };
     long acc = 0;
     for (int u = u0; u < u1; u++) acc += unit_cost(u);
@@ -1073,8 +1075,9 @@ __global__ void __launch_bounds__(1024) cuboid_score_plan(const Unit *units, int
                 const long o = P - cl[u] - sc_copy_cost(units[u]);
                 int k = 0;
                 if (o > 0) {
-                    if (o < (long)n1 * SC_COST_TASK1) k = (int)(o / SC_COST_TASK1);
-                    else k = n1 + (int)min((long)n2, (o - (long)n1 * SC_COST_TASK1) / SC_COST_TASK2);
+                    const long ct1 = sc_task_cost(units[u], 1, hyb_num), ct2 = sc_task_cost(units[u], 2, hyb_num);
+                    if (o < (long)n1 * ct1) k = (int)(o / ct1);
+                    else k = n1 + (int)min((long)n2, (o - (long)n1 * ct1) / ct2);
                 }
                 if (k < 2) k = 0;                                // a border this close to the unit's ends moves to the end: no map is copied for
                 else if (n1 + n2 - k < 2) { u++; k = 0; }        // one or two tasks
@@ -1115,12 +1118,19 @@ template <int CFG> __device__ __forceinline__ double edge_angle_error_reg(const 
 // s/10 * p1 + (1 - s/10) * p2 in double, in the reference's operation order; s = 0 and s = 10 reproduce the corners exactly (0*p1 + 1*p2),
 // and every corner ends two or three edges: the corner pixels are decoded once.  The cfg-2 weights `dist*3.0/2.0` and `dist*2.0` (float ->
 // double -> float) equal the float products dist*1.5f and dist*2.0f bit for bit (3*x and x/2 are exact in double: one rounding of 1.5*x).
-template <int CFG> __device__ __forceinline__ float edge_sum_dists_code(const double (&rx)[8], const double (&ry)[8], int w, const unsigned short *lmap) {
+// HYB: the unit's map is larger than LDS -- the first n_res codes are resident, a sample past them is fetched from the code slice in global memory
+// (index clamped to the slice: D2), so an oversize ROI costs the texture path only for its last rows instead of sending the whole unit to
+// cuboid_sweep_score_big
+template <int CFG, bool HYB> __device__ __forceinline__ float edge_sum_dists_code(const double (&rx)[8], const double (&ry)[8], int w, const unsigned short *lmap, const unsigned short *gmap,
+                                                                               int n_res, int a_last) {
     constexpr int NE = CFG == 1 ? 9 : 7;
     constexpr float HVS = (float)DT_HV / 65536.0f, DGS = (float)DT_DIAG / 65536.0f;
     auto gather = [&](double px, double py) -> unsigned { // the raw code: its consumer comes a whole edge later
         const int idx = __mul24(int(py), w) + int(px);
-        return *reinterpret_cast<const unsigned short *>(reinterpret_cast<const char *>(lmap) + ((unsigned)idx << 1));
+        if (!HYB) return *reinterpret_cast<const unsigned short *>(reinterpret_cast<const char *>(lmap) + ((unsigned)idx << 1));
+        unsigned v = *reinterpret_cast<const unsigned short *>(reinterpret_cast<const char *>(lmap) + ((unsigned)min(idx, n_res - 1) << 1));
+        if (idx >= n_res) v = gmap[min(idx, a_last)];
+        return v;
     };
     auto decode = [&](unsigned c) -> float { return __builtin_fmaf((float)((c >> 8) & 0xffu), DGS, (float)(c & 0xffu) * HVS); };
     auto gather_edge = [&](int e, unsigned (&c)[9]) {
@@ -1163,8 +1173,9 @@ template <int CFG> __device__ __forceinline__ float edge_sum_dists_code(const do
     return sum_dist;
 }
 
-template <int CFG> __device__ __forceinline__ void sc_score_task(const Unit &U, int first, int count, int lane, const VPEntry *vpt, const double *corners,
-                                                                 long hyp_total, const int *vlist, const unsigned short *lmap, double *derr, double *aerr) {
+template <int CFG, bool HYB> __device__ __forceinline__ void sc_score_task(const Unit &U, int first, int count, int lane, const VPEntry *vpt, const double *corners,
+                                                                           long hyp_total, const int *vlist, const unsigned short *lmap, const unsigned short *gmap, int n_res,
+                                                                           double *derr, double *aerr) {
     const int s = first + lane;
     const bool live = s < count;
     const int sc = live ? s : count - 1;
@@ -1185,7 +1196,7 @@ template <int CFG> __device__ __forceinline__ void sc_score_task(const Unit &U, 
     const double rx = (double)U.roi_x, ry = (double)U.roi_y;
 #pragma unroll
     for (int k = 0; k < 8; k++) { cx[k] = cx[k] - rx; cy[k] = cy[k] - ry; } // :423-425
-    const float sum_dist = edge_sum_dists_code<CFG>(cx, cy, U.roi_w, lmap);
+    const float sum_dist = edge_sum_dists_code<CFG, HYB>(cx, cy, U.roi_w, lmap, gmap, n_res, U.roi_w * U.roi_h - 1);
     if (live) {
         derr[g] = double(sum_dist) / U.diag; // :451
         aerr[g] = ae;
@@ -1223,9 +1234,11 @@ __global__ void __launch_bounds__(SC_T) cuboid_sweep_score(const Unit *units, in
         int t0, t1, n1, c1, c2;
         task_range(u, t0, t1, n1, c1, c2);
         const int A = U.roi_w * U.roi_h;
+        const bool hyb = !score_unit_fits(U.roi_w, U.roi_h);   // larger than LDS: the first n_res codes are resident, the tail is gathered from global memory
+        const int n_res = hyb ? (SC_MAP_ENTRIES & ~7) : A;
         __syncthreads(); // every wave is done with the previous unit's map
         { // copy the code map, SC_PFB 16-byte loads per thread in flight
-            const int A8 = (A + 7) >> 3; // slices are padded to 64 pixels
+            const int A8 = hyb ? n_res >> 3 : (A + 7) >> 3; // slices are padded to 64 pixels
             const uint4 *cm4 = reinterpret_cast<const uint4 *>(codes + U.pix_off);
             uint4 *lm4 = reinterpret_cast<uint4 *>(lmap);
 #pragma unroll 1
@@ -1239,18 +1252,24 @@ __global__ void __launch_bounds__(SC_T) cuboid_sweep_score(const Unit *units, in
         }
         if (tid == 0) ctrl[0] = t0;
         __syncthreads();
-        {
+        if (!hyb) {
             const unsigned short lastc = lmap[A - 1];
             for (int k = tid; k < U.roi_w + 2; k += SC_T) lmap[A + k] = lastc; // D2: indices past the map read its last pixel
         }
         __syncthreads();
+        const unsigned short *gmap = codes + U.pix_off;
         for (;;) { // waves pull tasks of 64 proposals of one configuration
             int t = 0;
             if (lane == 0) t = atomicAdd(&ctrl[0], 1);
             t = __builtin_amdgcn_readfirstlane(t);
             if (t >= t1) break;
-            if (t < n1) sc_score_task<1>(U, t << 6, c1, lane, vpt, corners, hyp_total, vlist, lmap, derr, aerr);
-            else sc_score_task<2>(U, (t - n1) << 6, c2, lane, vpt, corners, hyp_total, vlist, lmap, derr, aerr);
+            if (!hyb) {
+                if (t < n1) sc_score_task<1, false>(U, t << 6, c1, lane, vpt, corners, hyp_total, vlist, lmap, gmap, n_res, derr, aerr);
+                else sc_score_task<2, false>(U, (t - n1) << 6, c2, lane, vpt, corners, hyp_total, vlist, lmap, gmap, n_res, derr, aerr);
+            } else {
+                if (t < n1) sc_score_task<1, true>(U, t << 6, c1, lane, vpt, corners, hyp_total, vlist, lmap, gmap, n_res, derr, aerr);
+                else sc_score_task<2, true>(U, (t - n1) << 6, c2, lane, vpt, corners, hyp_total, vlist, lmap, gmap, n_res, derr, aerr);
+            }
         }
     }
 }
@@ -1747,6 +1766,7 @@ struct cs_cuboid_batch {
     unsigned short *d_codes = nullptr; int *d_uflag = nullptr;      // cuboid_dt_codes: 16-bit chamfer codes, per-unit escape flag
     BigItem *d_big = nullptr; int *d_big_n = nullptr;               // work list of cuboid_sweep_score_big
     int score_G = 256;      // segments = workgroups of cuboid_sweep_score (one per CU)
+    int score_hyb = 6;      // cost of a task of a unit larger than LDS (tail of the map gathered from global memory), in quarters of a resident unit's task
     int dt_C = 0; // wave-per-ROI distance transform: int map between the passes, lane-major
     FrameInfo *d_fi = nullptr; FrameDyn *d_fd = nullptr; CamRP *d_cam = nullptr;
     double *d_yaw = nullptr, *d_lines_in = nullptr, *d_lines_al = nullptr, *d_mlines = nullptr, *d_mangle = nullptr, *d_mmid = nullptr;
@@ -1891,6 +1911,8 @@ int cs_cuboid_batch_create(cs_ctx *ctx, int n_frames, int width, int height, con
         if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) b->score_G = prop.multiProcessorCount;
         const char *ge = getenv("CUBESLAM_SCORE_SEGMENTS"); // tuning knob: segments (= workgroups) of cuboid_sweep_score
         if (ge && atoi(ge) > 0) b->score_G = atoi(ge);
+        const char *he = getenv("CUBESLAM_SCORE_HYB_COST"); // tuning knob: cost of an oversize unit's task, in quarters of a resident unit's
+        if (he && atoi(he) > 0) b->score_hyb = atoi(he);
         A_(cs_dalloc(ctx, &b->d_score_cost, (size_t)b->n_units + 1));
         A_(cs_dalloc(ctx, &b->d_score_seg, (size_t)b->score_G + 1));
         A_(cs_dalloc(ctx, &b->d_codes, (size_t)b->pix_total + 64));
@@ -1978,7 +2000,7 @@ int cs_cuboid_batch_run(cs_ctx *ctx, cs_cuboid_batch *b) {
     CS_LAUNCH(ctx, "cuboid_sweep_corners", cuboid_sweep_corners, dim3(groups * b->blocks_per_unit * 8), dim3(256), 0, b->d_units, U,
               b->blocks_per_unit, b->d_fd, b->o, b->d_vp, b->d_flag, b->d_corners, b->hyp_total, b->d_vcount, b->d_vlist);
     CS_LAUNCH(ctx, "cuboid_score_plan", cuboid_score_plan, dim3(1), dim3(1024), 0, b->d_units, U, b->d_vcount, b->d_uflag, b->d_score_cost, b->d_score_seg, b->score_G,
-              b->d_big, b->d_big_n);
+              b->d_big, b->d_big_n, b->score_hyb);
     CS_LAUNCH(ctx, "cuboid_sweep_score", cuboid_sweep_score, dim3(b->score_G), dim3(SC_T), SC_LDS_BYTES, b->d_units, U, b->d_score_seg, b->score_G, b->d_vp,
               b->d_codes, b->d_corners, b->hyp_total, b->d_vcount, b->d_uflag, b->d_vlist, b->d_derr, b->d_aerr);
     CS_LAUNCH(ctx, "cuboid_sweep_score_big", cuboid_sweep_score_big, dim3(4096), dim3(256), 0, b->d_units, b->d_big, b->d_big_n, b->d_vp, b->d_dist, b->d_corners,
@@ -2032,7 +2054,7 @@ int cs_cuboid_batch_score_stats(cs_ctx *ctx, cs_cuboid_batch *b, long out[6]) {
     for (int i = 0; i < 6; i++) out[i] = 0;
     for (int u = 0; u < b->n_units; u++) {
         const Unit &U = b->units[u];
-        const int k = (score_unit_fits(U.roi_w, U.roi_h) && !(uf[u] & 1)) ? 0 : 3;
+        const int k = !(uf[u] & 1) ? 0 : 3; // (oversize units keep the head of their map in LDS and gather the tail: same kernel)
         out[k] += 1; out[k + 1] += (long)U.roi_w * U.roi_h; out[k + 2] += vc[2 * u] + vc[2 * u + 1];
     }
     return CS_OK;
