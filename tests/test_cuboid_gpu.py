@@ -135,8 +135,8 @@ def test_distance_transform_variants_agree(ctx, oracle, monkeypatch, W, H):
 def test_score_paths_agree(ctx, oracle, monkeypatch):
     """cuboid_sweep_score keeps a unit's chamfer map in LDS as exact 16-bit (i, j) codes and cuts the batch's work line into segments
     (one workgroup each).  Whatever the number of segments, the cuboids are byte-identical, and they equal the oracle's -- including a box
-    whose ROI does not fit one CU's LDS (cuboid_sweep_score_gmem) and a flat image whose distance map is all escape codes (every
-    proposal is re-scored from the float map)."""
+    whose ROI does not fit one CU's LDS (the head of its code map is resident, samples past it are gathered from global memory) and a flat
+    image whose distance map is all escape codes (its units go to cuboid_sweep_score_big, which reads the float map)."""
     det = detect_3d_cuboid(ctx)
     det.yaw_step_deg = 2.0
     scenes = [synth.cuboid_scene(70 + i, n_boxes=3) for i in range(3)]
