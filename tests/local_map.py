@@ -9,7 +9,7 @@ from cube_slam_amd import synth
 from oracle import local_ba_objects as lo
 
 
-def build(seed, n_kf=12, n_points=500, n_cuboids=16, left_heavy=True):
+def build(seed, n_kf=12, n_points=500, n_cuboids=16, left_heavy=True, with_objects=True):
     rng = np.random.default_rng(seed + 1000)
     d = synth.ba_problem(seed, n_kf=n_kf, n_points=n_points, n_cuboids=n_cuboids, k_obs=8, stereo_frac=0.3)
     W, H = 1241, 376
@@ -43,7 +43,7 @@ def build(seed, n_kf=12, n_points=500, n_cuboids=16, left_heavy=True):
         bad = rng.uniform(size=len(kf.mvKeysUn)) < 0.03
         kf.mvKeysUn[bad] += rng.choice([-25.0, 25.0], (int(bad.sum()), 2))
     mos = [lo.MapObject(c, d["cuboid_pose"][c], np.array([2.0, 0.9, 0.8]), float(rng.uniform(0.5, 1.0))) for c in range(len(d["cuboid_pose"]))]
-    for k in range(len(d["cobs_cam"])):
+    for k in range(len(d["cobs_cam"]) if with_objects else 0):
         kf, mo = kfs[d["cobs_cam"][k]], mos[d["cobs_cuboid"][k]]
         if kf in mo.observations:
             continue
@@ -77,9 +77,10 @@ def build(seed, n_kf=12, n_points=500, n_cuboids=16, left_heavy=True):
             det = first.local_cuboids[mo.observations[first]]
             det["bbox_2d"] = (3, det["bbox_2d"][1], det["bbox_2d"][2], det["bbox_2d"][3])
             break
-    seen_once = [mo for mo in mos if len(mo.observations) >= 2][-1]
-    keep = next(iter(seen_once.observations))
-    seen_once.observations = {keep: seen_once.observations[keep]}
+    if with_objects:
+        seen_once = [mo for mo in mos if len(mo.observations) >= 2][-1]
+        keep = next(iter(seen_once.observations))
+        seen_once.observations = {keep: seen_once.observations[keep]}
     # the window: key frame 6 is current, seven others are covisible (one of them bad, one with id 0), the rest only enter as fixed key frames
     cur = kfs[6]
     cur.covisible = [kfs[i] for i in (5, 4, 3, 2, 0, 7, 8)]

@@ -88,12 +88,28 @@ def test_two_stage_flow_matches_oracle(ctx, seed):
 
 
 @pytest.mark.gpu
-def test_cpp_mirror_equals_python_mirror(ctx, tmp_path):
+def test_window_without_objects(ctx):
+    """Most local windows of a sequence hold no object at all: the flow is then the point-only local BA with the same two stages."""
+    cur, params, _ = local_map.build(4, with_objects=False)
+    ref = lo.local_ba_camera_point_objects(cur, params)
+    w = lo.flatten_window(cur)
+    assert len(w["mo_id"]) == 0 and len(w["det_mo"]) == 0
+    got = ba_objects.LocalBACameraPointObjects(w, params, ctx=ctx)
+    assert np.array_equal(got["obs_level"], ref["obs_level"]) and len(got["cobs_level"]) == 0
+    kf_id, mp_id = w["kf_id"], w["mp_id"]
+    assert [(int(kf_id[a]), int(mp_id[b])) for a, b in got["erase"]] == ref["erase"]
+    for i in range(w["n_local"]):
+        assert np.allclose(got["kf_pose"][i], ref["kf_pose"][int(kf_id[i])], atol=1e-6, rtol=0)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("with_objects", [True, False])
+def test_cpp_mirror_equals_python_mirror(ctx, tmp_path, with_objects):
     """cube_slam_amd/host/local_ba_objects.hpp (what adapters/Optimizer_hip.cc calls) against cube_slam_amd/ba_objects.py on the same window."""
     import os
     import subprocess
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    cur, params, _ = local_map.build(2)
+    cur, params, _ = local_map.build(2, with_objects=with_objects)
     w = lo.flatten_window(cur)
     types = {"kf_id": np.int64, "kf_pose": np.float64, "mp_pos": np.float64, "mp_nobs": np.int32, "obs_mp": np.int32, "obs_kf": np.int32, "obs_uv": np.float64, "obs_ur": np.float64,
              "obs_inv_sigma2": np.float64, "mo_pose": np.float64, "mo_scale": np.float64, "mo_meas_quality": np.float64, "mo_largest_point_observations": np.int32,
