@@ -12,8 +12,12 @@
 //   cuboid_canny_union/mark/resolve : hysteresis as union-find connected components (same result as the stack flood)
 //   cuboid_dt           per unit  : 3x3 chamfer distance transform, one wave per ROI, rows as DPP min-plus scans
 //   cuboid_vp           per (unit,roll,pitch,yaw): getVanishingPoints + VP_support_edge_infos (:380-425,:602-607)
-//   cuboid_sweep_score  per hypothesis: corner construction with all reject tests (:254-418) then, for the compacted
-//                                   valid ones, box_edge_sum_dists + box_edge_alignment_angle_error (:427-492)
+//   cuboid_dt_codes     per pixel : the float distances as exact 16-bit (straight, diagonal) step codes for the score kernel
+//   cuboid_sweep_corners per hypothesis: corner construction with all reject tests (:254-418), survivors compacted per unit
+//   cuboid_score_plan   one workgroup: the units' proposal lists laid on a cost line and cut into one segment per CU
+//   cuboid_sweep_score  per surviving proposal: box_edge_sum_dists + box_edge_alignment_angle_error (:427-492), the unit's code map
+//                                   resident in LDS (its tail gathered from global memory when it is larger than LDS)
+//   cuboid_sweep_score_big          the same from the float map, for units with a pixel too far from every edge for a code
 //   cuboid_select       per box   : fuse_normalize_scores_v2 (:495-565) by radix selection, 2D->3D
 //                                   (change_2d_corner_to_3d_object :610-648), final ranking (:517-536)
 #include "common.h"
@@ -38,7 +42,7 @@ constexpr int SC_T = 512;                                             // threads
 constexpr int SC_LDS_BYTES = 160 * 1024;
 constexpr int SC_LUT_N = (DT_HV + 63) / 64;                            // 978 residue buckets
 constexpr int SC_MAP_OFF = 32;                                        // control words in front of the map
-constexpr int SC_MAP_ENTRIES = (SC_LDS_BYTES - SC_MAP_OFF) / 2;        // 80 920
+constexpr int SC_MAP_ENTRIES = (SC_LDS_BYTES - SC_MAP_OFF) / 2;        // 81 904
 constexpr float SC_ESC_D = 244.0f;                                     // d < 244 => i <= 255 and j <= 178
 constexpr int SC_COST_PX_NUM = 3, SC_COST_TASK1 = 1700, SC_COST_TASK2 = 1350; // wave-instructions: map copy per 64 pixels / task of 64 proposals
 constexpr int SC_PLAN_LDS_UNITS = 4096;                                // cuboid_score_plan keeps the cost line of this many units in LDS
