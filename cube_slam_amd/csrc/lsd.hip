@@ -461,7 +461,7 @@ class LsdHost {
         return best;
     }
     bool timed = false;
-    double t_sort = 0, t_grow = 0, t_rect = 0; long n_seeds = 0, n_regions = 0, n_pix = 0; // stage timers (ms) of this thread, reported by the caller
+    double t_imp = 0, t_sort = 0, t_grow = 0, t_rect = 0; long n_seeds = 0, n_regions = 0, n_pix = 0; // stage timers (ms) of this thread, reported by the caller
     // flsd :464-535 (LSD_REFINE_ADV, scale 0.8): segments as x1 y1 x2 y2 floats.  Input: the frame's defined pixels in address
     // order (the undefined ones are skipped by the reference's seed loop and fail every alignment test, so they never matter).
     void run(int w_, int h_, int ne, const int *e_addr, const float *e_deg, const float2 *e_cs, const double *e_mod, std::vector<float> &lines) {
@@ -498,7 +498,10 @@ class LsdHost {
             RectH rec;
             to_rect(rn, reg_angle, prec, p, rec);
             if (!refine(rn, reg_angle, prec, p, rec, 0.7)) continue;
-            if (improve(rec) <= 0) continue;
+            const auto ti0 = timed ? std::chrono::steady_clock::now() : std::chrono::steady_clock::time_point();
+            const double imp = improve(rec);
+            if (timed) t_imp += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - ti0).count();
+            if (imp <= 0) continue;
             rec.x1 += 0.5; rec.y1 += 0.5; rec.x2 += 0.5; rec.y2 += 0.5;
             rec.x1 /= 0.8; rec.y1 /= 0.8; rec.x2 /= 0.8; rec.y2 /= 0.8;
             lines.push_back(float(rec.x1)); lines.push_back(float(rec.y1)); lines.push_back(float(rec.x2)); lines.push_back(float(rec.y2));
@@ -677,7 +680,7 @@ static int lsd_run(cs_ctx *ctx, cs_lsd *l, int with_lbd) {
         if (ctx->timing) {
 #pragma omp critical
             { // CPU-milliseconds summed over the threads (divide by the thread count for wall time)
-                ctx->timings["host_lsd_cpu_sort"].total_ms += host.t_sort; ctx->timings["host_lsd_cpu_grow"].total_ms += host.t_grow; ctx->timings["host_lsd_cpu_rect"].total_ms += host.t_rect;
+                ctx->timings["host_lsd_cpu_sort"].total_ms += host.t_sort; ctx->timings["host_lsd_cpu_grow"].total_ms += host.t_grow; ctx->timings["host_lsd_cpu_rect"].total_ms += host.t_rect; ctx->timings["host_lsd_cpu_improve"].total_ms += host.t_imp; ctx->timings["host_lsd_cpu_improve"].count = 1;
                 ctx->timings["host_lsd_n_seeds"].total_ms += (double)host.n_seeds; ctx->timings["host_lsd_n_regions"].total_ms += (double)host.n_regions; ctx->timings["host_lsd_n_pix"].total_ms += (double)host.n_pix;
                 ctx->timings["host_lsd_n_def"].total_ms += (double)l->frame_base[F] / omp_get_num_threads();
                 for (const char *k : {"host_lsd_cpu_sort", "host_lsd_cpu_grow", "host_lsd_cpu_rect", "host_lsd_n_seeds", "host_lsd_n_regions", "host_lsd_n_pix", "host_lsd_n_def"}) ctx->timings[k].count = 1;

@@ -24,6 +24,6 @@ for _ in range(R):
     det.run(with_lbd=False)
 dt = (time.time() - t0) / R
 print("frames %d  ms/batch %.2f  frames/s %.0f" % (F, dt * 1e3, F / dt))
-for k in () if not timed else ("host_lsd_regions", "host_lsd_cpu_sort", "host_lsd_cpu_grow", "host_lsd_cpu_rect", "host_lsd_n_seeds", "host_lsd_n_regions", "host_lsd_n_pix", "host_lsd_n_def"):
+for k in () if not timed else ("host_lsd_regions", "host_lsd_cpu_sort", "host_lsd_cpu_grow", "host_lsd_cpu_rect", "host_lsd_cpu_improve", "host_lsd_n_seeds", "host_lsd_n_regions", "host_lsd_n_pix", "host_lsd_n_def"):
     t = ctx.timing_get(k)
     print("  %-20s total %12.2f  per batch %10.2f" % (k, t[0], t[0] / R))
