@@ -722,6 +722,50 @@ extern "C" int orc_cuboid9_edge_error(int n, const double *cam_Tcw, const double
     }
     return 0;
 }
+// Test hook for tests/test_ref_pins.py: the pose helpers of this file and se3_util.h one at a time, to be held against the reference's own
+// se3quat.h / g2o_Object code (oracle/_ref).  op: 0 SE3Quat::exp(a[6]) 1 log(a[7]) 2 a*b 3 inverse(a) 4 a*point b[3] 5 exptwist_norollpitch(a[6])
+// 6 cuboid(a[10]).exp_update(b[9]) 7 min_log_error(self a[10], new b[10]) 8 cube_log_error 9 rotate_cuboid(a[10], s) 10 transform_from(a[10], Twc b[7])
+// 11 transform_to 12 point_boundary_error(a[10], point b[3], ratio s).  Poses come in as [t, qx qy qz qw] and are normalised like SE3Quat(Vector7d).
+extern "C" int orc_se3_op(int op, const double *a, const double *b, double s, double *out) {
+    auto load10 = [](const double *v) { Cub9 c = cub9_load(v); normalize_rotation(c.pose); return c; };
+    switch (op) {
+    case 0: se3_to7(se3_exp(a), out); return 0;
+    case 1: se3_log(se3_from7(a), out); return 0;
+    case 2: se3_to7(se3_mul(se3_from7(a), se3_from7(b)), out); return 0;
+    case 3: se3_to7(se3_inv(se3_from7(a)), out); return 0;
+    case 4: se3_map(se3_from7(a), b, out); return 0;
+    case 5: se3_to7(exptwist_norollpitch(a), out); return 0;
+    case 6: return orc_cuboid9_oplus(1, a, b, out);
+    case 7: cub9_min_log_error(load10(a), load10(b), out); return 0;
+    case 8: cub9_log_error(load10(a), load10(b), out); return 0;
+    case 9: cub9_store(cub9_rotate(load10(a), s), out); return 0;
+    case 10: case 11: {
+        const Cub9 c = load10(a); Cub9 r;
+        const SE3 T = se3_from7(b);
+        r.pose = se3_mul(op == 10 ? T : se3_inv(T), c.pose);
+        for (int k = 0; k < 3; k++) r.scale[k] = c.scale[k];
+        cub9_store(r, out); return 0;
+    }
+    case 12: { // cuboid::point_boundary_error g2o_Object.cpp:280-298 (the per-point term of err_pc above, before its fabs / mean / scale division)
+        const Cub9 c = load10(a);
+        double lp[3];
+        se3_map(se3_inv(c.pose), b, lp);
+        for (int k = 0; k < 3; k++) {
+            const double v = 1.0 * std::fabs(lp[k]);
+            out[k] = v < c.scale[k] ? 0.0 : (v < (s + 1) * c.scale[k] ? v - c.scale[k] : s * c.scale[k]);
+        }
+        return 0;
+    }
+    case 13: { // cuboid::projectOntoImageBbox g2o_Object.h:197-205: b = Tcw (7) then K (9, row-major)
+        const Cub9 c9 = load10(a);
+        Cuboid c; c.pose = c9.pose;
+        for (int k = 0; k < 3; k++) c.scale[k] = c9.scale[k];
+        project_bbox(c, se3_from7(b), b + 7, out);
+        return 0;
+    }
+    }
+    return -1;
+}
 // numeric Jacobians of EdgeSE3Cuboid the way BaseBinaryEdge::linearizeOplus does (base_binary_edge.hpp:55-120): central differences, delta 1e-9,
 // column d of vertex i: (e(+delta) - e(-delta)) / (2 delta).  Jcam: 9 x 6 (row-major), Jcub: 9 x 9.
 extern "C" int orc_cuboid9_edge_linearize(int n, const double *cam_Tcw, const double *cub_global, const double *cub_meas_local, double *err, double *Jcam, double *Jcub) {

@@ -257,6 +257,9 @@ int orc_pose_optimization(int n, const double *Xw, const double *obs, const doub
 int orc_cuboid9_oplus(int n, const double *cub, const double *upd, double *out);
 int orc_cuboid9_edge_error(int n, const double *cam_Tcw, const double *cub_global, const double *cub_meas_local, double *err);
 int orc_cuboid9_edge_linearize(int n, const double *cam_Tcw, const double *cub_global, const double *cub_meas_local, double *err, double *Jcam, double *Jcub);
+/* test hook: one pose helper at a time (SE3Quat exp / log / product / inverse, exptwist_norollpitch, the cuboid's log errors, rotations and
+ * transforms, point_boundary_error) -- see ba_oracle.cpp; tests/test_ref_pins.py holds them against the reference's own code */
+int orc_se3_op(int op, const double *a, const double *b, double s, double *out);
 
 /* --------------------------------------------------------------------------------------------------------------------
  * Optimizer::LocalBACameraPointObjectsDynamic (orb_object_slam/src/Optimizer.cc:1537-2573): the graph it hands to g2o

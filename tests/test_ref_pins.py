@@ -152,3 +152,83 @@ def test_matcher_primitives_equal_reference(ref, oracle):
         ref.ref_three_maxima(_dp(cnt), 30, _dp(r))
         oracle.lib().orc_three_maxima(_dp(cnt), 30, _dp(o))
         assert np.array_equal(r, o), (cnt, r, o)
+
+
+def test_pose_math_equals_reference(ref, oracle):
+    """The oracle's SE3 / cuboid pose helpers (oracle/se3_util.h, ba_oracle.cpp) against the reference's own code: the vendored g2o SE3Quat
+    (Thirdparty/g2o/g2o/types/se3quat.h: exp :272-306, log :229-266, operator* :110-116, inverse :129-134) compiled whole, and exptwist_norollpitch
+    (g2o_Object.cpp:24-54), cuboid::exp_update / cube_log_error / min_log_error / rotate_cuboid / transform_from / transform_to
+    (g2o_Object.h:60-135), cuboid::point_boundary_error (g2o_Object.cpp:280-298) and cuboid::projectOntoImageBbox with the corner / similarity
+    / homogeneous-coordinate helpers under it (g2o_Object.h:137-205, matrix_utils.cpp real_to_homo_coord / homo_to_real_coord) cut out of the
+    reference at build time -- all over oracle/ref_shim/eigen_mini, which evaluates in Eigen's coefficient order.  Equal to the last bit."""
+    import oracle.pyoracle as po
+    olib = po.lib()
+    rng = np.random.default_rng(5)
+    D = C.POINTER(C.c_double)
+
+    def arr(x):
+        return np.ascontiguousarray(x, np.float64)
+
+    def orc(op, a, b=None, s=0.0, n=7):
+        out = np.zeros(n); a = arr(a); b = arr(b if b is not None else np.zeros(1))
+        assert olib.orc_se3_op(op, a.ctypes.data_as(D), b.ctypes.data_as(D), C.c_double(s), out.ctypes.data_as(D)) == 0
+        return out
+
+    def rcall(name, n, *args):
+        out = np.zeros(n)
+        cargs = [C.c_double(x) if np.isscalar(x) else arr(x).ctypes.data_as(D) for x in args]
+        keep = [arr(x) for x in args if not np.isscalar(x)]  # noqa: F841 (the arrays above are temporaries of arr(): rebuild to keep alive)
+        cargs = []
+        for x in args:
+            if np.isscalar(x):
+                cargs.append(C.c_double(x))
+            else:
+                k = arr(x); keep.append(k); cargs.append(k.ctypes.data_as(D))
+        getattr(ref, name)(*cargs, out.ctypes.data_as(D))
+        return out
+
+    def pose():
+        q = rng.normal(size=4); q /= np.linalg.norm(q)
+        return np.concatenate([rng.normal(0, 3, 3), q * rng.uniform(0.5, 2.0)])  # not unit length: both sides normalise like SE3Quat(Vector7d)
+
+    def cuboid():
+        return np.concatenate([pose(), rng.uniform(0.3, 2.5, 3)])
+
+    n_checked = 0
+    for it in range(300):
+        small = it % 5 == 0
+        u = np.concatenate([rng.normal(0, 1e-7 if small else 0.8, 3), rng.normal(0, 2, 3)])  # theta below and above the 1e-5 switch of exp
+        assert np.array_equal(orc(0, u), rcall("ref_se3_exp", 7, u)), ("exp", u)
+        assert np.array_equal(orc(5, u), rcall("ref_exptwist_norollpitch", 7, u)), ("exptwist", u)
+        a, b = pose(), pose()
+        if small:  # rotation close to the identity: the d > 0.99999 branch of log
+            b = np.concatenate([rng.normal(0, 2, 3), [1e-4 * rng.normal(), 1e-4 * rng.normal(), 1e-4 * rng.normal(), 1.0]])
+        assert np.array_equal(orc(1, b, n=6), rcall("ref_se3_log", 6, b)), ("log", b)
+        assert np.array_equal(orc(2, a, b), rcall("ref_se3_mul", 7, a, b))
+        assert np.array_equal(orc(3, a), rcall("ref_se3_inverse", 7, a))
+        p3 = rng.normal(0, 5, 3)
+        assert np.array_equal(orc(4, a, p3, n=3), rcall("ref_se3_map", 3, a, p3))
+        c1, c2 = cuboid(), cuboid()
+        if it % 3 == 0:  # a cuboid and a slightly moved copy rotated by a quarter turn: min_log_error has to pick the rotation
+            c2 = rcall("ref_cuboid_rotate", 10, c1, [-np.pi / 2, np.pi / 2, np.pi][it % 3 if it % 9 else 0]); c2[:3] += rng.normal(0, 0.05, 3)
+        u9 = np.concatenate([u, rng.normal(0, 0.1, 3)])
+        assert np.array_equal(orc(6, c1, u9, n=10), rcall("ref_cuboid_exp_update", 10, c1, u9))
+        assert np.array_equal(orc(8, c1, c2, n=9), rcall("ref_cuboid_cube_log_error", 9, c1, c2), equal_nan=True)
+        # (a relative rotation of exactly half a turn makes SE3Quat::log divide by zero, :253: the reference returns inf / nan there and so does the oracle)
+        assert np.array_equal(orc(7, c1, c2, n=9), rcall("ref_cuboid_min_log_error", 9, c1, c2), equal_nan=True)
+        for yaw in (-np.pi / 2, 0.0, np.pi / 2, np.pi, 0.3):
+            assert np.array_equal(orc(9, c1, None, yaw, n=10), rcall("ref_cuboid_rotate", 10, c1, yaw)), yaw
+        assert np.array_equal(orc(10, c1, a, n=10), rcall("ref_cuboid_transform_from", 10, c1, a))
+        assert np.array_equal(orc(11, c1, a, n=10), rcall("ref_cuboid_transform_to", 10, c1, a))
+        for ratio in (1.0, 2.0):
+            pt = c1[:3] + rng.normal(0, 2.5, 3)
+            assert np.array_equal(orc(12, c1, pt, ratio, n=3), rcall("ref_point_boundary_error", 3, c1, pt, ratio))
+        # the camera-cuboid edge's measurement function: the cuboid in front of a camera looking roughly at it
+        K = np.array([[535.4 + rng.normal(0, 20), 0, 320.1 + rng.normal(0, 5)], [0, 539.2 + rng.normal(0, 20), 247.6 + rng.normal(0, 5)], [0, 0, 1.0]])
+        cam = pose(); cam[3:] = [0.02 * rng.normal(), 0.02 * rng.normal(), 0.02 * rng.normal(), 1.0]; cam[:3] = [0, 0, 0]
+        front = np.concatenate([[rng.normal(0, 1.5), rng.normal(0, 1.0), rng.uniform(4, 12)], c1[3:]])
+        assert np.array_equal(orc(13, front, np.concatenate([cam, K.ravel()]), n=4), rcall("ref_project_bbox", 4, front, cam, K.ravel())), front
+        # ... and an arbitrary one (corners behind the camera included: the reference divides all the same)
+        assert np.array_equal(orc(13, c1, np.concatenate([a, K.ravel()]), n=4), rcall("ref_project_bbox", 4, c1, a, K.ravel()))
+        n_checked += 1
+    assert n_checked == 300
