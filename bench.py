@@ -30,14 +30,19 @@ BG_TEXTURE = 0.5
 
 
 def make_frames(n_frames, n_boxes, seed0, bg_texture=BG_TEXTURE):
+    """n_frames scenes with exactly n_boxes boxes, seeds seed0, seed0 + 1, ... in order (the ones with fewer boxes skipped); drawn on the host's threads."""
+    from concurrent.futures import ThreadPoolExecutor
+
     from cube_slam_amd import synth
     scenes = []
     seed = seed0
-    while len(scenes) < n_frames:
-        s = synth.cuboid_scene(seed, n_boxes=n_boxes, bg_texture=bg_texture)
-        seed += 1
-        if len(s["boxes"]) == n_boxes:
-            scenes.append(s)
+    with ThreadPoolExecutor(min(16, os.cpu_count() or 1)) as ex:
+        while len(scenes) < n_frames:
+            chunk = max(16, n_frames - len(scenes))
+            for s in ex.map(lambda sd: synth.cuboid_scene(sd, n_boxes=n_boxes, bg_texture=bg_texture), range(seed, seed + chunk)):
+                if len(s["boxes"]) == n_boxes and len(scenes) < n_frames:
+                    scenes.append(s)
+            seed += chunk
     return scenes
 
 

@@ -39,6 +39,7 @@
 
 #include "lsd_regions.h"
 #include "lsd_rg_txn.h"
+#include "lsd_rg_seq.h"
 
 namespace {
 constexpr double PI_ = rg::PI_, LOG_EPS = 0.0, LSD_SCALE = 0.8;
@@ -130,11 +131,14 @@ __device__ double rg_log_gamma(double x) { // lsd.cpp:70,124-160
     for (int n = 0; n < 7; ++n) { a -= log(x + double(n)); b += q[n] * pow(x, double(n)); }
     return a + log(b);
 }
-__device__ double rg_nfa(int n, int k, double p, double LOG_NT) { // :1100-1136
+constexpr int LG_N = 32768; // log_gamma of the integers below this: a table filled by the same function (its arguments are pixel counts; each call costs 16 log + 14 pow)
+__global__ void __launch_bounds__(256) lsd_rg_lgamma_table(double *t) { const int i = blockIdx.x * 256 + threadIdx.x; if (i < LG_N) t[i] = i > 0 ? rg_log_gamma(double(i)) : 0.0; }
+__device__ __forceinline__ double rg_lgam_int(int x, const double *lgt) { return (lgt && x > 0 && x < LG_N) ? lgt[x] : rg_log_gamma(double(x)); }
+__device__ double rg_nfa(int n, int k, double p, double LOG_NT, const double *lgt) { // :1100-1136
     if (n == 0 || k == 0) return -LOG_NT;
     if (n == k) return -LOG_NT - double(n) * log10(p);
     const double p_term = p / (1 - p);
-    const double log1term = (double(n) + 1) - rg_log_gamma(double(k) + 1) - rg_log_gamma(double(n - k) + 1) + double(k) * log(p) + double(n - k) * log(1.0 - p);
+    const double log1term = (double(n) + 1) - rg_lgam_int(k + 1, lgt) - rg_lgam_int(n - k + 1, lgt) + double(k) * log(p) + double(n - k) * log(1.0 - p);
     double term = exp(log1term);
     const double RELATIVE_ERROR_FACTOR = 100.0;
     auto double_equal = [&](double a, double b) { if (a == b) return true; double abs_diff = fabs(a - b), aa = fabs(a), bb = fabs(b); double abs_max = aa > bb ? aa : bb; if (abs_max < DBL_MIN) abs_max = DBL_MIN; return (abs_diff / abs_max) <= (RELATIVE_ERROR_FACTOR * DBL_EPSILON); };
@@ -153,7 +157,7 @@ __device__ double rg_nfa(int n, int k, double p, double LOG_NT) { // :1100-1136
     return -log10(bin_tail) - LOG_NT;
 }
 // rect_nfa (:977-1098): the four corners ordered like the reference's std::sort + selection, rows counted by the lanes of the wave
-__device__ double rg_rect_nfa(const rg::Frame &F, const rg::Rect &rec, double LOG_NT, int lane) {
+__device__ double rg_rect_nfa(const rg::Frame &F, const rg::Rect &rec, double LOG_NT, int lane, const double *lgt) {
     const double half_width = rec.width / 2.0, dyhw = rec.dy * half_width, dxhw = rec.dx * half_width;
     int ox[4], oy[4]; bool taken[4] = {false, false, false, false};
     ox[0] = int(rec.x1 - dyhw); oy[0] = int(rec.y1 + dxhw); ox[1] = int(rec.x2 - dyhw); oy[1] = int(rec.y2 + dxhw);
@@ -193,39 +197,35 @@ __device__ double rg_rect_nfa(const rg::Frame &F, const rg::Rect &rec, double LO
         }
     }
     for (int off = 32; off > 0; off >>= 1) { total_pts += __shfl_xor(total_pts, off); alg_pts += __shfl_xor(alg_pts, off); }
-    return rg_nfa(total_pts, alg_pts, rec.p, LOG_NT);
+    return rg_nfa(total_pts, alg_pts, rec.p, LOG_NT, lgt);
 }
-__device__ double rg_rect_improve(const rg::Frame &F, rg::Rect &rec, double LOG_NT, int lane) { // :873-975
+__device__ double rg_rect_improve(const rg::Frame &F, rg::Rect &rec, double LOG_NT, int lane, const double *lgt = nullptr) { // :873-975
     const double delta = 0.5, delta_2 = delta / 2.0;
-    double log_nfa = rg_rect_nfa(F, rec, LOG_NT, lane);
+    double log_nfa = rg_rect_nfa(F, rec, LOG_NT, lane, lgt);
     if (log_nfa > LOG_EPS) return log_nfa;
     rg::Rect r = rec;
-    for (int n = 0; n < 5; ++n) { r.p /= 2; r.prec = r.p * PI_; const double v = rg_rect_nfa(F, r, LOG_NT, lane); if (v > log_nfa) { log_nfa = v; rec = r; } }
+    for (int n = 0; n < 5; ++n) { r.p /= 2; r.prec = r.p * PI_; const double v = rg_rect_nfa(F, r, LOG_NT, lane, lgt); if (v > log_nfa) { log_nfa = v; rec = r; } }
     if (log_nfa > LOG_EPS) return log_nfa;
     r = rec;
-    for (int n = 0; n < 5; ++n) if ((r.width - delta) >= 0.5) { r.width -= delta; const double v = rg_rect_nfa(F, r, LOG_NT, lane); if (v > log_nfa) { rec = r; log_nfa = v; } }
+    for (int n = 0; n < 5; ++n) if ((r.width - delta) >= 0.5) { r.width -= delta; const double v = rg_rect_nfa(F, r, LOG_NT, lane, lgt); if (v > log_nfa) { rec = r; log_nfa = v; } }
     if (log_nfa > LOG_EPS) return log_nfa;
     r = rec;
     for (int n = 0; n < 5; ++n) if ((r.width - delta) >= 0.5) {
         r.x1 += -r.dy * delta_2; r.y1 += r.dx * delta_2; r.x2 += -r.dy * delta_2; r.y2 += r.dx * delta_2; r.width -= delta;
-        const double v = rg_rect_nfa(F, r, LOG_NT, lane); if (v > log_nfa) { rec = r; log_nfa = v; } }
+        const double v = rg_rect_nfa(F, r, LOG_NT, lane, lgt); if (v > log_nfa) { rec = r; log_nfa = v; } }
     if (log_nfa > LOG_EPS) return log_nfa;
     r = rec;
     for (int n = 0; n < 5; ++n) if ((r.width - delta) >= 0.5) {
         r.x1 -= -r.dy * delta_2; r.y1 -= r.dx * delta_2; r.x2 -= -r.dy * delta_2; r.y2 -= r.dx * delta_2; r.width -= delta;
-        const double v = rg_rect_nfa(F, r, LOG_NT, lane); if (v > log_nfa) { rec = r; log_nfa = v; } }
+        const double v = rg_rect_nfa(F, r, LOG_NT, lane, lgt); if (v > log_nfa) { rec = r; log_nfa = v; } }
     if (log_nfa > LOG_EPS) return log_nfa;
     r = rec;
-    for (int n = 0; n < 5; ++n) if ((r.width - delta) >= 0.5) { r.p /= 2; r.prec = r.p * PI_; const double v = rg_rect_nfa(F, r, LOG_NT, lane); if (v > log_nfa) { rec = r; log_nfa = v; } }
+    for (int n = 0; n < 5; ++n) if ((r.width - delta) >= 0.5) { r.p /= 2; r.prec = r.p * PI_; const double v = rg_rect_nfa(F, r, LOG_NT, lane, lgt); if (v > log_nfa) { rec = r; log_nfa = v; } }
     return log_nfa;
 }
 
-// candidate list: (frame, rank) pairs; one wave each.  line[rank] = x1 y1 x2 y2 (original-image coordinates), has[rank] = 1
-__global__ void __launch_bounds__(256) lsd_rg_lines(RgParams P, const int2 *cand, int n_cand, float4 *line, uint8_t *has) {
-    const int wv = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (wv >= n_cand) return;
-    const int f = cand[wv].x, s = cand[wv].y;
-    const int base = P.frame_base[f];
+// one wave: the region of rank s of frame f from its footprint to a segment (original-image coordinates) or nothing
+__device__ bool rg_region_line(const RgParams &P, int f, int s, int lane, float4 &out) {
     const rg::Frame Fr = rg_frame(P, f, nullptr);
     const int *L = Fr.pool + Fr.fp_off[s];
     const int n = Fr.fp_cnt[s];
@@ -234,14 +234,23 @@ __global__ void __launch_bounds__(256) lsd_rg_lines(RgParams P, const int2 *cand
     rg::Rect rec;
     rg::region2rect(Fr, L, n, Fr.reg_angle[s], prec, p, rec); // every lane the same sums, in list order
     const double log_nfa = rg_rect_improve(Fr, rec, LOG_NT, lane);
+    if (!(log_nfa > LOG_EPS)) return false;
+    rec.x1 += 0.5; rec.y1 += 0.5; rec.x2 += 0.5; rec.y2 += 0.5;
+    rec.x1 /= LSD_SCALE; rec.y1 /= LSD_SCALE; rec.x2 /= LSD_SCALE; rec.y2 /= LSD_SCALE;
+    out = make_float4(float(rec.x1), float(rec.y1), float(rec.x2), float(rec.y2));
+    return true;
+}
+// candidate list: (frame, rank) pairs; one wave each.  line[rank] = x1 y1 x2 y2, has[rank] = 1 -- or, compact, line[candidate] / has[candidate]
+__global__ void __launch_bounds__(256) lsd_rg_lines(RgParams P, const int2 *cand, int n_cand, float4 *line, uint8_t *has, int compact) {
+    const int wv = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (wv >= n_cand) return;
+    const int f = cand[wv].x, s = cand[wv].y;
+    float4 out = make_float4(0, 0, 0, 0);
+    const bool ok = rg_region_line(P, f, s, lane, out);
     if (lane == 0) {
-        if (log_nfa > LOG_EPS) {
-            rec.x1 += 0.5; rec.y1 += 0.5; rec.x2 += 0.5; rec.y2 += 0.5;
-            rec.x1 /= LSD_SCALE; rec.y1 /= LSD_SCALE; rec.x2 /= LSD_SCALE; rec.y2 /= LSD_SCALE;
-            line[base + s] = make_float4(float(rec.x1), float(rec.y1), float(rec.x2), float(rec.y2));
-            has[base + s] = 1;
-        } else
-            has[base + s] = 0;
+        const size_t o = compact ? (size_t)wv : (size_t)P.frame_base[f] + s;
+        if (ok) line[o] = out;
+        has[o] = ok ? 1 : 0;
     }
 }
 
@@ -252,6 +261,82 @@ __global__ void __launch_bounds__(256) lsd_rg_candidates(RgParams P, int2 *cand,
     if (i >= ne) return;
     has[base + i] = 0;
     if ((P.flag[base + i] & 3) == 3) cand[atomicAdd(n_cand, 1)] = make_int2(f, i); // (a refined region may end below min_reg_size, down to 2 pixels)
+}
+
+// ---- the sequential stage: one wave per frame (lsd_rg_seq.h) ------------------------------------------------------------------------------
+struct SeqParams {
+    int F, w, h;
+    const int *caddr; const int *frame_base; const float *cdeg; const float2 *ccs; const double *mod, *ang;
+    rgs::Px *pix; int *glist; double *rect; int cand_cap; int *cand_cnt; int *status;
+    int min_reg_size;
+    unsigned long long *prof;
+};
+__global__ void __launch_bounds__(256) lsd_rg_fill(rgs::Px *pix, size_t n) {
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n) reinterpret_cast<float4 *>(pix)[i] = make_float4(rgs::NOTDEF_F, 0.f, 0.f, rgs::NOTDEF_F);
+}
+// the defined pixels' records from lsd_emit's compact lists
+__global__ void __launch_bounds__(256) lsd_rg_scatter(SeqParams P) {
+    const int f = blockIdx.y, base = P.frame_base[f], ne = P.frame_base[f + 1] - base;
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= ne) return;
+    const int q = P.caddr[base + i] & 0x7fffffff;
+    const float d = P.cdeg[base + i];
+    const float2 cs = P.ccs[base + i];
+    reinterpret_cast<float4 *>(P.pix + (size_t)f * P.w * P.h)[q] = make_float4(d, cs.x, cs.y, d);
+}
+// A workgroup is a bundle of independent waves, one frame each (no LDS, no barrier).  Sixteen waves fill a CU (4 a SIMD, 128 VGPRs each): the frames
+// of a batch then sit on F / 16 CUs and leave the others EMPTY -- cuboid_sweep_score's workgroups need a whole CU (160 KB of LDS, 2 x 240 VGPRs a
+// SIMD) and would otherwise wait for a frame's 100 ms to pass.
+__global__ void __launch_bounds__(1024) lsd_rg_seq(SeqParams P) {
+    const int f = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    if (f >= P.F) return;
+    const int base = P.frame_base[f];
+    rgs::Frame Fr;
+    Fr.w = P.w; Fr.h = P.h; Fr.ne = P.frame_base[f + 1] - base;
+    Fr.caddr = P.caddr + base; Fr.pix = P.pix + (size_t)f * P.w * P.h; Fr.mod = P.mod + (size_t)f * P.w * P.h;
+    Fr.rect = P.rect + (size_t)f * P.cand_cap * 12; Fr.cand_cap = P.cand_cap; Fr.cand_cnt = P.cand_cnt + f;
+    Fr.status = P.status + 4 * f; Fr.min_reg_size = P.min_reg_size; Fr.prof = P.prof ? P.prof + 16 * (size_t)f : nullptr;
+    rgs::List L;
+    L.glob = P.glist + (size_t)f * rgs::CAP; L.ring[0] = 0;
+    rgs::run_frame<rgs::Wave>(Fr, L);
+}
+// the frames' rectangle lists one after the other (frames in order, seeds in order): cand_base[f] = rectangles of the frames before f
+__global__ void __launch_bounds__(1024) lsd_rg_cand_scan(const int *cand_cnt, int F, int *cand_base) {
+    __shared__ int part[1024];
+    const int t = threadIdx.x, per = (F + 1023) / 1024;
+    int sum = 0;
+    for (int k = 0; k < per; k++) { const int f = t * per + k; if (f < F) sum += cand_cnt[f]; }
+    part[t] = sum;
+    __syncthreads();
+    for (int d = 1; d < 1024; d <<= 1) { const int v = t >= d ? part[t - d] : 0; __syncthreads(); part[t] += v; __syncthreads(); }
+    int run = part[t] - sum;
+    for (int k = 0; k < per; k++) { const int f = t * per + k; if (f < F) { cand_base[f] = run; run += cand_cnt[f]; } }
+    if (t == 1023) cand_base[F] = part[1023];
+}
+// rect_improve + the NFA test (lsd.cpp:873-975, :503-505) of one rectangle per wave; line[k] / has[k] in the order of the scan above
+__global__ void __launch_bounds__(256) lsd_rg_improve(SeqParams P, const int *cand_base, int n_cand, const double *lgt, float4 *line, uint8_t *has) {
+    const int wv = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (wv >= n_cand) return;
+    int lo = 0, hi = P.F; // the frame: cand_base[f] <= wv < cand_base[f + 1]
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (cand_base[mid] <= wv) lo = mid; else hi = mid; }
+    const int f = lo;
+    const double *o = P.rect + ((size_t)f * P.cand_cap + (wv - cand_base[f])) * 12;
+    rg::Rect rec;
+    rec.x1 = o[0]; rec.y1 = o[1]; rec.x2 = o[2]; rec.y2 = o[3]; rec.width = o[4]; rec.x = o[5]; rec.y = o[6]; rec.theta = o[7]; rec.dx = o[8]; rec.dy = o[9]; rec.prec = o[10]; rec.p = o[11];
+    rg::Frame Fr = {};
+    Fr.w = P.w; Fr.h = P.h; Fr.ang = P.ang + (size_t)f * P.w * P.h;
+    const double LOG_NT = 5 * (log10(double(P.w)) + log10(double(P.h))) / 2 + log10(11.0);
+    const double log_nfa = rg_rect_improve(Fr, rec, LOG_NT, lane, lgt);
+    if (lane == 0) {
+        const bool ok = log_nfa > LOG_EPS;
+        if (ok) {
+            rec.x1 += 0.5; rec.y1 += 0.5; rec.x2 += 0.5; rec.y2 += 0.5;
+            rec.x1 /= LSD_SCALE; rec.y1 /= LSD_SCALE; rec.x2 /= LSD_SCALE; rec.y2 /= LSD_SCALE;
+            line[wv] = make_float4(float(rec.x1), float(rec.y1), float(rec.x2), float(rec.y2));
+        }
+        has[wv] = ok ? 1 : 0;
+    }
 }
 } // namespace
 
@@ -342,7 +427,7 @@ int lsd_regions_run(cs_ctx *ctx, LsdRegions **handle, int F, int w, int h, const
 #endif
     if (stats) { stats[0] = max_rounds; stats[1] = execs; stats[2] = n_cand; stats[3] = steps; }
     if (bad) return CS_ERR_CAPACITY;
-    if (n_cand > 0) CS_LAUNCH(ctx, "lsd_rg_lines", lsd_rg_lines, dim3((n_cand + 3) / 4), dim3(256), 0, P, r->d_cand, n_cand, r->d_line, r->d_has);
+    if (n_cand > 0) CS_LAUNCH(ctx, "lsd_rg_lines", lsd_rg_lines, dim3((n_cand + 3) / 4), dim3(256), 0, P, r->d_cand, n_cand, r->d_line, r->d_has, 0);
     std::vector<uint8_t> has(total);
     std::vector<float4> line(total);
     rc = cs_d2h(ctx, has.data(), r->d_has, total); if (rc) return rc;
@@ -352,5 +437,99 @@ int lsd_regions_run(cs_ctx *ctx, LsdRegions **handle, int F, int w, int h, const
     for (int f = 0; f < F; f++)
         for (int i = frame_base[f]; i < frame_base[f + 1]; i++)
             if (has[i]) { lines[f].push_back(line[i].x); lines[f].push_back(line[i].y); lines[f].push_back(line[i].z); lines[f].push_back(line[i].w); }
+    return CS_OK;
+}
+
+// ---- host side of the sequential stage ----------------------------------------------------------------------------------------------------
+struct LsdSeq {
+    int F = 0, w = 0, h = 0; int cand_cap = 0; size_t cap_lines = 0;
+    rgs::Px *d_pix = nullptr;
+    int *d_glist = nullptr, *d_cand_cnt = nullptr, *d_cand_base = nullptr, *d_status = nullptr, *d_frame_base = nullptr;
+    double *d_rect = nullptr, *d_lgt = nullptr;
+    uint8_t *d_has = nullptr;
+    float4 *d_line = nullptr;
+    std::vector<int> h_base, h_status; std::vector<uint8_t> h_has; std::vector<float4> h_line;
+};
+void lsd_seq_destroy(LsdSeq *r) {
+    if (!r) return;
+    void *ptrs[] = {r->d_pix, r->d_glist, r->d_cand_cnt, r->d_cand_base, r->d_status, r->d_frame_base, r->d_rect, r->d_lgt, r->d_has, r->d_line};
+    for (void *p : ptrs) if (p) hipFree(p);
+    delete r;
+}
+// The region stage of F frames, one wave per frame.  lines[f] = x1 y1 x2 y2 floats in the reference's emission order.  CS_ERR_CAPACITY: a region
+// outgrew the wave's list (rgs::CAP pixels) or a frame its rectangle list -- the caller then runs the host stage for the batch.
+int lsd_seq_run(cs_ctx *ctx, LsdSeq **handle, int F, int w, int h, const double *d_ang, const double *d_mod, const int *d_caddr, const float *d_cdeg, const float2 *d_ccs, const int *frame_base,
+                std::vector<std::vector<float>> &lines, long *stats /* [0] region_grow calls, [1] window fetches, [2] rectangles at rect_improve, [3] regions at the rectangle stage */) {
+    LsdSeq *r = *handle;
+    if (w > 0xffff || h > 0x7fff) return CS_ERR_CAPACITY; // (the region list packs x | y << 16)
+    int max_ne = 0;
+    for (int f = 0; f < F; f++) max_ne = std::max(max_ne, frame_base[f + 1] - frame_base[f]);
+    int rc;
+#define RA_(call) do { rc = (call); if (rc != CS_OK) return rc; } while (0)
+    if (!r || r->F < F || r->w != w || r->h != h) {
+        lsd_seq_destroy(r);
+        r = new LsdSeq();
+        *handle = r;
+        r->F = F; r->w = w; r->h = h; r->cand_cap = 4096;
+        RA_(cs_dalloc(ctx, &r->d_pix, (size_t)F * w * h)); RA_(cs_dalloc(ctx, &r->d_glist, (size_t)F * rgs::CAP)); RA_(cs_dalloc(ctx, &r->d_rect, (size_t)F * r->cand_cap * 12));
+        RA_(cs_dalloc(ctx, &r->d_cand_cnt, (size_t)F)); RA_(cs_dalloc(ctx, &r->d_cand_base, (size_t)F + 1));
+        RA_(cs_dalloc(ctx, &r->d_status, (size_t)F * 4)); RA_(cs_dalloc(ctx, &r->d_frame_base, (size_t)F + 1));
+        RA_(cs_dalloc(ctx, &r->d_lgt, (size_t)LG_N));
+        CS_LAUNCH(ctx, "lsd_rg_lgamma_table", lsd_rg_lgamma_table, dim3(LG_N / 256), dim3(256), 0, r->d_lgt);
+    }
+    RA_(cs_h2d(ctx, r->d_frame_base, frame_base, (size_t)F + 1));
+    SeqParams S;
+    S.F = F; S.w = w; S.h = h; S.caddr = d_caddr; S.frame_base = r->d_frame_base; S.cdeg = d_cdeg; S.ccs = d_ccs; S.mod = d_mod; S.ang = d_ang;
+    S.pix = r->d_pix; S.glist = r->d_glist; S.rect = r->d_rect; S.cand_cap = r->cand_cap; S.cand_cnt = r->d_cand_cnt; S.status = r->d_status;
+    const double LOG_NT = 5 * (std::log10(double(w)) + std::log10(double(h))) / 2 + std::log10(11.0);
+    S.min_reg_size = int(-LOG_NT / std::log10(rg::ANG_TH / 180));
+    S.prof = nullptr;
+#if defined(RGS_PROFILE)
+    static unsigned long long *d_prof = nullptr;
+    if (!d_prof) hipMalloc((void **)&d_prof, 4096 * 16 * sizeof(unsigned long long));
+    hipMemsetAsync(d_prof, 0, 4096 * 16 * sizeof(unsigned long long), ctx->stream);
+    S.prof = d_prof;
+#endif
+    const size_t npx = (size_t)F * w * h;
+    CS_LAUNCH(ctx, "lsd_rg_fill", lsd_rg_fill, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, r->d_pix, npx);
+    CS_LAUNCH(ctx, "lsd_rg_scatter", lsd_rg_scatter, dim3((max_ne + 255) / 256, F), dim3(256), 0, S);
+    int wpb = 16; // waves (= frames) per workgroup
+    if (const char *e = getenv("CUBESLAM_LSD_SEQ_WPB")) wpb = std::max(1, std::min(16, atoi(e)));
+    CS_LAUNCH(ctx, "lsd_rg_seq", lsd_rg_seq, dim3((F + wpb - 1) / wpb), dim3(64 * wpb), 0, S);
+    CS_LAUNCH(ctx, "lsd_rg_cand_scan", lsd_rg_cand_scan, dim3(1), dim3(1024), 0, r->d_cand_cnt, F, r->d_cand_base);
+    r->h_base.resize((size_t)F + 1); r->h_status.resize((size_t)F * 4);
+    RA_(cs_d2h(ctx, r->h_base.data(), r->d_cand_base, (size_t)F + 1));
+    RA_(cs_d2h(ctx, r->h_status.data(), r->d_status, (size_t)F * 4));
+    CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+#if defined(RGS_PROFILE)
+    { std::vector<unsigned long long> all((size_t)F * 16); hipMemcpy(all.data(), S.prof, all.size() * 8, hipMemcpyDeviceToHost);
+      unsigned long long hp[16] = {0}; for (int f = 0; f < F; f++) for (int k = 0; k < 16; k++) hp[k] += all[(size_t)f * 16 + k];
+      const char *nm[6] = {"fetch", "expand", "grow", "rect+refine", "seed batch", "frame"};
+      for (int k = 0; k < 6; k++) fprintf(stderr, "[rgs prof] %-12s entries/frame %9.0f  ms/frame %8.2f  us/entry %6.2f\n", nm[k], double(hp[2 * k + 1]) / F, hp[2 * k] / 1e5 / F, hp[2 * k + 1] ? hp[2 * k] / 100.0 / hp[2 * k + 1] : 0.0); }
+#endif
+    long grows = 0, fetches = 0, nreg = 0;
+    bool bad = false;
+    for (int f = 0; f < F; f++) { grows += r->h_status[4 * f]; bad = bad || r->h_status[4 * f + 1] != 0; nreg += r->h_status[4 * f + 2]; fetches += r->h_status[4 * f + 3]; }
+    const int n_cand = r->h_base[F];
+    if (stats) { stats[0] = grows; stats[1] = fetches; stats[2] = n_cand; stats[3] = nreg; }
+    if (bad) return CS_ERR_CAPACITY;
+    lines.assign((size_t)F, {});
+    if (n_cand == 0) return CS_OK;
+    if ((size_t)n_cand > r->cap_lines) {
+        if (r->d_line) hipFree(r->d_line); if (r->d_has) hipFree(r->d_has);
+        r->d_line = nullptr; r->d_has = nullptr; r->cap_lines = 0;
+        const size_t cap = (size_t)n_cand + n_cand / 4 + 1024;
+        RA_(cs_dalloc(ctx, &r->d_line, cap)); RA_(cs_dalloc(ctx, &r->d_has, cap));
+        r->cap_lines = cap;
+    }
+    CS_LAUNCH(ctx, "lsd_rg_improve", lsd_rg_improve, dim3((n_cand + 3) / 4), dim3(256), 0, S, r->d_cand_base, n_cand, r->d_lgt, r->d_line, r->d_has);
+    r->h_has.resize((size_t)n_cand); r->h_line.resize((size_t)n_cand);
+    RA_(cs_d2h(ctx, r->h_has.data(), r->d_has, (size_t)n_cand));
+    RA_(cs_d2h(ctx, r->h_line.data(), r->d_line, (size_t)n_cand));
+    CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+#undef RA_
+    for (int f = 0; f < F; f++)
+        for (int k = r->h_base[f]; k < r->h_base[f + 1]; k++)
+            if (r->h_has[k]) { const float4 v = r->h_line[k]; lines[f].push_back(v.x); lines[f].push_back(v.y); lines[f].push_back(v.z); lines[f].push_back(v.w); }
     return CS_OK;
 }

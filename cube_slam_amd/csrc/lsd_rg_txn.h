@@ -35,7 +35,7 @@ using std::max;
 using std::min;
 #endif
 typedef unsigned long long u64;
-constexpr double NOTDEF = -1024.0, PI_ = 3.1415926535897932384626433832795, DEG_TO_RADS = PI_ / 180, M_3_2_PI_ = 4.71238898038, M_2__PI_ = 6.28318530718;
+constexpr double NOTDEF = -1024.0, PI_ = 3.1415926535897932384626433832795, DEG_TO_RADS = PI_ / 180, M_3_2_PI_ = (3 * PI_) / 2, M_2__PI_ = 2 * PI_; // lsd.cpp:54-55
 constexpr double ANG_TH = 22.5, DENSITY_TH = 0.7;
 constexpr u64 FREE = ~0ull;
 constexpr int CAP = 4096;   // pixels of one region (three scratch lists per lane); a larger region sends the frame to the host stage

@@ -38,15 +38,18 @@ def test_other_sizes_and_flat(ctx, oracle):
     det.close()
 
 
-def test_device_region_stage_equals_host_stage(ctx, oracle, monkeypatch):
-    """CUBESLAM_LSD_REGIONS=device: region growing / rectangles / NFA as a speculative fixed point on the device (lsd_regions.hip)."""
+@pytest.mark.parametrize("mode", ["seq", "device"])
+def test_device_region_stage_equals_host_stage(ctx, oracle, monkeypatch, mode):
+    """Region growing / rectangles / NFA on the device (lsd_regions.hip) -- CUBESLAM_LSD_REGIONS=seq: one wave per frame walking the reference's
+    sequence (lsd_rg_seq.h); =device: the speculative fixed point over an owner map (lsd_rg_txn.h) -- against the host stage and the oracle."""
     imgs = [np.load(os.path.join(GOLD, "orb_cabinet.npz"))["gray"], synth.cuboid_scene(7, n_boxes=3, bg_texture=0.5)["gray"], synth.texture_image(8, 640, 480)]
     det = line_lbd_detect(640, 480, max_frames=3, ctx=ctx)
+    monkeypatch.setenv("CUBESLAM_LSD_REGIONS", "host")
     host = det.detect_raw_lines(np.stack(imgs))
-    monkeypatch.setenv("CUBESLAM_LSD_REGIONS", "device")
+    monkeypatch.setenv("CUBESLAM_LSD_REGIONS", mode)
     dev = det.detect_raw_lines(np.stack(imgs))
     st = det.region_stats()
-    assert not st["host_fallback"] and st["rounds"] > 3 and st["candidates"] > 100
+    assert not st["host_fallback"] and st["candidates"] > 100 and (st["rounds"] > 3 if mode == "device" else st["rounds"] == 1)
     for f, img in enumerate(imgs):
         assert dev[f].tobytes() == host[f].tobytes()
         assert dev[f].tobytes() == oracle.lsd_detect(img).tobytes()
