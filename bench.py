@@ -329,9 +329,10 @@ def pcie_inclusive(ctx, scenes, yaw_step, nfeat, n=24):
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
-    ap.add_argument("--frames", type=int, default=128, help="frames resident per GPU")
+    ap.add_argument("--frames", type=int, default=1024, help="frames resident per GPU = frames per step (the line detector's region stage runs on the device from 512 on)")
+    ap.add_argument("--line-workers", type=int, default=2, help="line detectors that alternate steps on their own streams (1-4)")
     ap.add_argument("--boxes", type=int, default=3)
     ap.add_argument("--yaw-step", type=float, default=0.5)
     ap.add_argument("--no-cpu", action="store_true")
@@ -382,10 +383,11 @@ def main():
     if not args.no_lines:
         from cube_slam_amd.lsd import line_lbd_detect
         # The library's front-end runner (cs_frontend_*, csrc/frontend.hip) runs ORB + cuboid on this thread and the line path on worker
-        # threads with their own contexts (= HIP streams).  Two detectors alternate steps: the GPU phases of one step (gradient maps
-        # before, LBD descriptors after the host stage) overlap the region growing of the neighbouring step; the library serialises
-        # the host stages, so the cores are never split between two OpenMP teams.
-        ctx_lines = [_lib.Context(local_rank, priority=-1), _lib.Context(local_rank, priority=-1)]  # device phases of the line detectors: background
+        # threads with their own contexts (= HIP streams).  The detectors alternate steps.  From 512 frames per step on, region growing runs on
+        # the device, one wave per frame for ~100-180 ms (lsd_regions.hip): sixteen frames fill a CU, so two detectors in flight sit on half of
+        # the CUs and the ORB / cuboid kernels of the steps in between find the other half empty.  Below that the 16 host threads grow the
+        # regions, the GPU phases of one step overlap the host stage of the neighbouring one, and the library serialises the host stages.
+        ctx_lines = [_lib.Context(local_rank, priority=-1) for _ in range(max(1, min(4, args.line_workers)))]  # device phases of the line detectors: background
         lsds = [line_lbd_detect(640, 480, max_frames=args.frames, ctx=c) for c in ctx_lines]
         for d_ in lsds:
             d_.upload(np.stack([s["gray"] for s in scenes]))
@@ -420,7 +422,7 @@ def main():
         elapsed = float(t.item())
     kernels = {}
     for name in ("host_orb_quadtree", "orb_resize", "orb_fast_score", "orb_cells", "orb_scan", "orb_quadtree", "orb_blur", "orb_angle", "orb_desc", "host_lsd_regions", "lsd_blur_hv", "lsd_resize",
-                 "lsd_gradient", "lbd_blur5", "lbd_sobel", "lbd_line_desc", "cuboid_frame_prep", "cuboid_unit_lines", "cuboid_canny_nms", "cuboid_canny_cc", "cuboid_dt", "cuboid_dt_codes",
+                 "lsd_gradient", "lsd_emit", "lsd_rg_fill", "lsd_rg_scatter", "lsd_rg_seq", "lsd_rg_improve", "lbd_blur5", "lbd_sobel", "lbd_line_desc", "cuboid_frame_prep", "cuboid_unit_lines", "cuboid_canny_nms", "cuboid_canny_cc", "cuboid_dt", "cuboid_dt_codes",
                  "cuboid_vp", "cuboid_sweep_corners", "cuboid_score_plan", "cuboid_sweep_score", "cuboid_sweep_score_big", "cuboid_select"):
         ms, n = ctx.timing_get(name)
         if n == 0 and lsd is not None:
@@ -481,7 +483,8 @@ def main():
             "config": {"workload": "front-end per frame: ORB extract + LSD/LBD lines + detect_3d_cuboid: 640x480 frames (3 drawn cuboids over a 1/f texture, amplitude %.2f) x %d boxes, "
                                    "180-yaw x 3-VP sweep (yaw step %.2f deg), %d frames resident per GPU; detect_cuboid is fed the scene's own edge list (cuboid edges + 40 clutter "
                                    "segments), not this step's LSD output (decoupled, SURVEY 8d C2)" % (BG_TEXTURE, args.boxes, args.yaw_step, args.frames),
-                       "lines": None if lsd is None else {"keylines_per_step": n_lines, "keylines_per_frame": n_lines / args.frames, "descriptor": "LBD 32 B"},
+                       "lines": None if lsd is None else {"keylines_per_step": n_lines, "keylines_per_frame": n_lines / args.frames, "descriptor": "LBD 32 B", "detectors_in_flight": len(ctx_lines),
+                                                                "region_stage": ("device: one wave per frame (lsd_rg_seq)" if lsd.region_stats()["device"] else "host: %d OpenMP threads" % _lib.lib().cs_host_thread_count())},
                        "orb": None if orb is None else {"nfeatures": args.orb_features, "levels": 8, "keypoints_per_step": n_kp, "keypoints_per_frame": n_kp / args.frames},
                        "frames_per_gpu": args.frames, "boxes_per_frame": args.boxes,
                        "hypotheses_per_step": st["n_hypotheses"], "valid_proposals_per_step": st["n_valid"],

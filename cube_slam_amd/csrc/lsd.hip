@@ -561,9 +561,8 @@ struct cs_lsd {
     std::vector<int> line_off;       // per frame offset into the concatenated line list
     std::vector<uint8_t> h_desc;     // concatenated n x 32
     bool have_desc = false;
-    LsdRegions *regions = nullptr;   // device buffers of the region stage (lsd_regions.hip)
-    LsdSeq *seq = nullptr;
-    long rg_stats[5] = {0, 0, 0, 0, 0}; // last batch: rounds, transactions, candidate regions, 1 = fell back to the host stage, lane steps
+    LsdSeq *seq = nullptr;           // device buffers of the region stage (lsd_regions.hip)
+    long rg_stats[5] = {0, 0, 0, 0, 0}; // last batch: 1 = device stage asked for, region_grow calls, rectangles at rect_improve, 1 = fell back to the host stage, window fetches
 };
 
 int cs_lbd_batch_maps(cs_ctx *ctx, const uint8_t *d_gray, int W, int H, int F, uint8_t *d_blur, uint32_t *d_dxy);
@@ -614,31 +613,25 @@ static int lsd_run(cs_ctx *ctx, cs_lsd *l, int with_lbd) {
         r = cs_dalloc(ctx, &l->d_cmod, cap); if (r) return r;
         l->ccap = cap;
     }
-    // region growing / rectangles / NFA (a15): three interchangeable stages with byte-identical KeyLines (tests/test_lsd_gpu.py).
-    //   seq    one wave per frame walks the reference's sequence on the device (lsd_rg_seq.h).  A frame takes ~100 ms whatever the batch, so it
-    //          pays from ~500 frames per batch on (2048 resident frames: > 2 x the 16 host threads) -- the default from 512 frames on;
-    //   host   the OpenMP stage below, one frame per thread -- the default for smaller batches (one frame: 4 ms);
-    //   device the speculative fixed point over an owner map (lsd_regions.hip / lsd_rg_txn.h): exact, but slower than either.
-    // CUBESLAM_LSD_REGIONS = seq | host | device overrides the choice.
+    // region growing / rectangles / NFA (a15): two interchangeable stages with byte-identical KeyLines (tests/test_lsd_gpu.py).
+    //   seq    one wave per frame walks the reference's sequence on the device (lsd_regions.hip / lsd_rg_seq.h).  A frame takes 100-180 ms whatever
+    //          the batch, so it pays from ~500 frames per batch on (2048 resident frames: 2.5 x the 16 host threads) -- the default from 512 on;
+    //   host   the OpenMP stage below, one frame per thread -- the default for smaller batches (one frame: 4 ms).
+    // CUBESLAM_LSD_REGIONS = seq | host overrides the choice.
     std::vector<std::vector<float>> dev_lines;
     bool on_device = false;
     if (total > 0) CS_LAUNCH(ctx, "lsd_emit", lsd_emit, dim3(nbx, h, F), dim3(256), 0, l->d_mod, l->d_ang, w, h, l->d_seg_base, l->d_caddr, l->d_cdeg, l->d_ccs, l->d_cmod);
     {
         const char *mode = getenv("CUBESLAM_LSD_REGIONS");
         if (!mode || !*mode) mode = F >= 512 ? "seq" : "host";
-        if (total > 0 && strcmp(mode, "seq") == 0) { // one wave per frame walks the reference's sequence (lsd_rg_seq.h)
+        if (total > 0 && strcmp(mode, "seq") == 0) {
             long st[4] = {0, 0, 0, 0};
             r = lsd_seq_run(ctx, &l->seq, F, w, h, l->d_ang, l->d_mod, l->d_caddr, l->d_cdeg, l->d_ccs, l->frame_base.data(), dev_lines, st);
             l->rg_stats[0] = 1; l->rg_stats[1] = st[0]; l->rg_stats[2] = st[2]; l->rg_stats[3] = r == CS_OK ? 0 : 1; l->rg_stats[4] = st[1];
             if (r == CS_OK) on_device = true;
-            else if (r != CS_ERR_CAPACITY) return r;
-        } else if (total > 0 && strcmp(mode, "device") == 0) {
-            long st[4] = {0, 0, 0, 0};
-            r = lsd_regions_run(ctx, &l->regions, F, w, h, l->d_ang, l->d_mod, l->d_caddr, l->frame_base.data(), dev_lines, st);
-            l->rg_stats[0] = st[0]; l->rg_stats[1] = st[1]; l->rg_stats[2] = st[2]; l->rg_stats[3] = r == CS_OK ? 0 : 1; l->rg_stats[4] = st[3];
-            if (r == CS_OK) on_device = true;
-            else if (r != CS_ERR_CAPACITY) return r; // a frame outgrew a device buffer or did not settle: the host stage takes the batch
-        }
+            else if (r != CS_ERR_CAPACITY) return r; // a region outgrew the wave's list: the host stage takes the batch
+        } else
+            for (int k = 0; k < 5; k++) l->rg_stats[k] = 0;
     }
     if (!on_device && total > l->hcap) {
         if (l->h_caddr) hipHostFree(l->h_caddr); if (l->h_cdeg) hipHostFree(l->h_cdeg); if (l->h_ccs) hipHostFree(l->h_ccs); if (l->h_cmod) hipHostFree(l->h_cmod);
@@ -745,7 +738,6 @@ void cs_lsd_destroy(cs_ctx *ctx, cs_lsd *l) {
     void *ptrs[] = {l->d_gray, l->d_tmp, l->d_blur, l->d_scaled, l->d_mod, l->d_ang, l->d_xofs, l->d_yofs, l->d_ax, l->d_ay, l->d_lblur, l->d_dxy};
     for (void *p : ptrs) if (p) hipFree(p);
     lsd_free_lines(l);
-    lsd_regions_destroy(l->regions);
     lsd_seq_destroy(l->seq);
     void *more[] = {l->d_seg_cnt, l->d_seg_base, l->d_blk_tot, l->d_caddr, l->d_cdeg, l->d_ccs, l->d_cmod};
     for (void *p : more) if (p) hipFree(p);

@@ -4,10 +4,6 @@
 
 #include <hip/hip_runtime.h>
 struct cs_ctx;
-struct LsdRegions;
-int lsd_regions_run(cs_ctx *ctx, LsdRegions **handle, int F, int w, int h, const double *d_ang, const double *d_mod, const int *d_caddr, const int *frame_base,
-                    std::vector<std::vector<float>> &lines, long *stats);
-void lsd_regions_destroy(LsdRegions *r);
 struct LsdSeq;
 int lsd_seq_run(cs_ctx *ctx, LsdSeq **handle, int F, int w, int h, const double *d_ang, const double *d_mod, const int *d_caddr, const float *d_cdeg, const float2 *d_ccs, const int *frame_base,
                 std::vector<std::vector<float>> &lines, long *stats);

@@ -13,7 +13,45 @@
 // values are PerLane<T>, per-lane code sits in W::each bodies, everything else is wave-uniform.
 // A body must not read what another lane's part of the SAME body writes (on the device the lanes run it together).
 #pragma once
-#include "lsd_rg_txn.h"
+#include <algorithm>
+#include <cfloat>
+#include <climits>
+#include <cmath>
+#include <cstdint>
+
+#if defined(__HIPCC__)
+#define RG_HD __host__ __device__ inline
+#else
+#define RG_HD inline
+#endif
+
+namespace rg { // arithmetic shared by the sequential stage and the rectangle kernel (lsd_regions.hip)
+typedef unsigned long long u64;
+constexpr double NOTDEF = -1024.0, PI_ = 3.1415926535897932384626433832795, DEG_TO_RADS = PI_ / 180, M_3_2_PI_ = (3 * PI_) / 2, M_2__PI_ = 2 * PI_; // lsd.cpp:54-55
+constexpr double ANG_TH = 22.5, DENSITY_TH = 0.7;
+
+RG_HD float fast_atan2(float y, float x) { // cv::fastAtan2, the polynomial of lsd.hip / the oracle
+    const float p1 = 0.9997878412794807f * (float)(180 / PI_), p3 = -0.3258083974640975f * (float)(180 / PI_), p5 = 0.1555786518463281f * (float)(180 / PI_),
+                p7 = -0.04432655554792128f * (float)(180 / PI_);
+    float ax = fabsf(x), ay = fabsf(y), a, c, c2;
+    if (ax >= ay) { c = ay / (ax + (float)DBL_EPSILON); c2 = c * c; a = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c; }
+    else { c = ax / (ay + (float)DBL_EPSILON); c2 = c * c; a = 90.f - (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c; }
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
+RG_HD bool aligned_ang(double a, double theta, double prec) { // isAligned lsd.cpp:1138-1154 on a fetched angle
+    if (a == NOTDEF) return false;
+    double n_theta = theta - a;
+    if (n_theta < 0) n_theta = -n_theta;
+    if (n_theta > M_3_2_PI_) { n_theta -= M_2__PI_; if (n_theta < 0) n_theta = -n_theta; }
+    return n_theta <= prec;
+}
+RG_HD double dist(double x1, double y1, double x2, double y2) { return sqrt((x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1)); }
+RG_HD double angle_diff_signed(double a, double b) { double diff = a - b; while (diff <= -PI_) diff += M_2__PI_; while (diff > PI_) diff -= M_2__PI_; return diff; }
+
+struct Rect { double x1, y1, x2, y2, width, x, y, theta, dx, dy, prec, p; };
+} // namespace rg
 
 namespace rgs {
 using rg::u64;

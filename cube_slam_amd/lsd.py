@@ -45,10 +45,11 @@ class line_lbd_detect:
         check(self.ctx.ptr, lib().cs_lsd_run(self.ctx.ptr, self._l, int(with_lbd)), "cs_lsd_run")
 
     def region_stats(self):
-        """Region stage of the last batch: dict(rounds, transactions, candidates, host_fallback) -- see cs_lsd_region_stats."""
+        """Region stage of the last batch (see cs_lsd_region_stats): device = the one-wave-per-frame stage ran, grows = region_grow calls,
+        candidates = rectangles at rect_improve, host_fallback, fetches = pixel-window fetches.  All zero for the host stage."""
         st = (C.c_long * 5)()
         check(self.ctx.ptr, lib().cs_lsd_region_stats(self.ctx.ptr, self._l, st), "cs_lsd_region_stats")
-        return {"rounds": st[0], "transactions": st[1], "candidates": st[2], "host_fallback": bool(st[3]), "lane_steps": st[4]}
+        return {"device": bool(st[0]), "grows": st[1], "candidates": st[2], "host_fallback": bool(st[3]), "fetches": st[4]}
 
     def read(self, frame, with_desc=True):
         n = C.c_int()

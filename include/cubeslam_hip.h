@@ -392,11 +392,11 @@ int cs_lsd_get_maps(cs_ctx *ctx, cs_lsd *l, int frame, double *scaled, double *m
  * class/line_lbd_allclass.cpp:222-256); cs_lsd_read returns one frame's lines (out == NULL: count only) and descriptors. */
 int cs_lsd_upload(cs_ctx *ctx, cs_lsd *l, const uint8_t *gray, int n_frames, int stride);
 int cs_lsd_run(cs_ctx *ctx, cs_lsd *l, int with_lbd);
-/* The region stage of the last batch when CUBESLAM_LSD_REGIONS=device selects the device formulation (lsd.cpp:464-535 as a speculative
- * fixed point, cube_slam_amd/csrc/lsd_regions.hip; the default is the host stage, which is faster on 16 cores -- DESIGN.md):
- * out[0] rounds of the slowest frame, out[1] region transactions executed, out[2] regions that reached rect_improve,
- * out[3] 1 when the batch fell back to the host stage (a device buffer too small or no fixed point within the round limit),
- * out[4] pixel steps summed over the lanes. */
+/* The region stage (lsd.cpp:464-535: region_grow ... rect_improve) of the last batch.  Batches of 512 frames and more run it on the device, one
+ * wave per frame walking the reference's sequence (cube_slam_amd/csrc/lsd_regions.hip); smaller ones on the host's cores, one frame per thread;
+ * CUBESLAM_LSD_REGIONS = seq | host overrides the choice.  Both give the same KeyLines byte for byte.
+ * out[0] 1 when the device stage was chosen, out[1] region_grow calls, out[2] rectangles that reached rect_improve,
+ * out[3] 1 when the batch fell back to the host stage (a region larger than the device list), out[4] pixel-window fetches.  All 0 for the host stage. */
 int cs_lsd_region_stats(cs_ctx *ctx, cs_lsd *l, long out[5]);
 int cs_lsd_read(cs_ctx *ctx, cs_lsd *l, int frame, cs_keyline *out, int cap, int *count, uint8_t *desc /* cap x 32 or NULL */);
 

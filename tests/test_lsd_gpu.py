@@ -38,19 +38,38 @@ def test_other_sizes_and_flat(ctx, oracle):
     det.close()
 
 
-@pytest.mark.parametrize("mode", ["seq", "device"])
-def test_device_region_stage_equals_host_stage(ctx, oracle, monkeypatch, mode):
-    """Region growing / rectangles / NFA on the device (lsd_regions.hip) -- CUBESLAM_LSD_REGIONS=seq: one wave per frame walking the reference's
-    sequence (lsd_rg_seq.h); =device: the speculative fixed point over an owner map (lsd_rg_txn.h) -- against the host stage and the oracle."""
+def test_device_region_stage_equals_host_stage(ctx, oracle, monkeypatch):
+    """Region growing / rectangles / NFA on the device (lsd_regions.hip: one wave per frame walking the reference's sequence, lsd_rg_seq.h) against
+    the host stage and the oracle: KeyLines byte for byte.  The batch is small, so the stage is asked for; large batches take it by themselves."""
     imgs = [np.load(os.path.join(GOLD, "orb_cabinet.npz"))["gray"], synth.cuboid_scene(7, n_boxes=3, bg_texture=0.5)["gray"], synth.texture_image(8, 640, 480)]
     det = line_lbd_detect(640, 480, max_frames=3, ctx=ctx)
-    monkeypatch.setenv("CUBESLAM_LSD_REGIONS", "host")
     host = det.detect_raw_lines(np.stack(imgs))
-    monkeypatch.setenv("CUBESLAM_LSD_REGIONS", mode)
+    assert not det.region_stats()["device"]
+    monkeypatch.setenv("CUBESLAM_LSD_REGIONS", "seq")
     dev = det.detect_raw_lines(np.stack(imgs))
     st = det.region_stats()
-    assert not st["host_fallback"] and st["candidates"] > 100 and (st["rounds"] > 3 if mode == "device" else st["rounds"] == 1)
+    assert st["device"] and not st["host_fallback"] and st["candidates"] > 100 and st["fetches"] > 1000
     for f, img in enumerate(imgs):
         assert dev[f].tobytes() == host[f].tobytes()
         assert dev[f].tobytes() == oracle.lsd_detect(img).tobytes()
+    det.close()
+
+
+def test_large_batches_take_the_device_region_stage(ctx, oracle, monkeypatch):
+    """512 frames (16 distinct ones, repeated) through the resident-batch form: the device stage is the default there, all frames give their own lines."""
+    monkeypatch.delenv("CUBESLAM_LSD_REGIONS", raising=False)
+    base = [synth.cuboid_scene(40 + i, n_boxes=3, bg_texture=0.5)["gray"] for i in range(16)]
+    F = 512
+    det = line_lbd_detect(640, 480, max_frames=F, ctx=ctx)
+    det.upload(np.stack([base[i % 16] for i in range(F)]))
+    det.run(with_lbd=True)
+    st = det.region_stats()
+    assert st["device"] and not st["host_fallback"]
+    want = [oracle.lsd_detect(b) for b in base[:4]]
+    for f in (0, 1, 2, 3, 16, 17, 258, 511):
+        kl, desc = det.read(f)
+        assert kl.tobytes() == want[f % 16].tobytes() if f % 16 < 4 else len(kl) > 50
+        if f >= 16:
+            k0, d0 = det.read(f % 16)
+            assert kl.tobytes() == k0.tobytes() and desc.tobytes() == d0.tobytes()
     det.close()

@@ -1,6 +1,6 @@
 """CPU checks of the device region stage of the line detector (cube_slam_amd/csrc/lsd_regions.hip):
-  * the transaction source the kernel compiles (lsd_rg_txn.h), run on the host with 256 interleaved lanes, reaches the owner map and the
-    line candidates of the oracle's sequential algorithm (tools/lsd_sim/txn_sim.cpp);
+  * the source the kernel compiles (lsd_rg_seq.h: one wave per frame), run on the host with the 64 lanes as loops, leaves the `used` map and
+    hands over the rectangles of the oracle's sequential algorithm, bit for bit and in the same order (tools/lsd_sim/seq_sim.cpp);
   * the cosf / sinf restatement the device uses equals the host's libm (glibc_sincosf.h)."""
 import os
 import subprocess
@@ -23,12 +23,19 @@ def test_sincosf_restatement_equals_libm(tmp_path):
     assert out.returncode == 0, out.stdout
 
 
-def test_interleaved_transactions_reach_the_sequential_result(tmp_path):
-    exe = str(tmp_path / "txn_sim")
-    _build("tools/lsd_sim/txn_sim.cpp", exe)
-    for seed, tex, lanes in ((11, 0.5, 256), (12, 0.0, 1024)):
+def test_wave_per_frame_stage_equals_the_sequential_algorithm(tmp_path):
+    exe = str(tmp_path / "seq_sim")
+    _build("tools/lsd_sim/seq_sim.cpp", exe)
+    exe4 = str(tmp_path / "seq_sim4")  # the list's register ring cut to 4 entries: the growth reads the list from memory
+    _build("tools/lsd_sim/seq_sim.cpp", exe4, ["-DRGS_RING=4"])
+    for seed, tex in ((11, 0.5), (12, 0.0), (13, 1.0), (14, 0.25), (3, 1.0)):
         raw = str(tmp_path / ("f%d.raw" % seed))
         synth.cuboid_scene(seed, n_boxes=3, bg_texture=tex)["gray"].astype(np.uint8).tofile(raw)
-        out = subprocess.run([exe, raw, "640", "480", str(lanes)], capture_output=True, text=True)
-        assert out.returncode == 0, out.stdout[-600:]
-        assert "owner map wrong 0" in out.stdout and "EQUAL" in out.stdout
+        for e in (exe, exe4) if seed in (11, 3) else (exe,):
+            out = subprocess.run([e, raw, "640", "480"], capture_output=True, text=True)
+            assert out.returncode == 0, out.stdout[-600:]
+            assert "used map wrong 0" in out.stdout and "EQUAL" in out.stdout
+    raw = str(tmp_path / "tex.raw")  # dense texture: the most seeds and refinements
+    synth.texture_image(8, 640, 480).astype(np.uint8).tofile(raw)
+    out = subprocess.run([exe, raw, "640", "480"], capture_output=True, text=True)
+    assert out.returncode == 0 and "EQUAL" in out.stdout, out.stdout[-600:]
