@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(256) lsd_rg_scatter(SeqParams P) {
 // A workgroup is a bundle of independent waves, one frame each (no LDS, no barrier).  Sixteen waves fill a CU (4 a SIMD, 128 VGPRs each): the frames
 // of a batch then sit on F / 16 CUs and leave the others EMPTY -- cuboid_sweep_score's workgroups need a whole CU (160 KB of LDS, 2 x 240 VGPRs a
 // SIMD) and would otherwise wait for a frame's 100 ms to pass.
-__global__ void __launch_bounds__(1024) lsd_rg_seq(SeqParams P) {
+__device__ __forceinline__ void lsd_rg_seq_body(const SeqParams &P) {
     const int f = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     if (f >= P.F) return;
     const int base = P.frame_base[f];
@@ -177,6 +177,9 @@ __global__ void __launch_bounds__(1024) lsd_rg_seq(SeqParams P) {
     L.glob = P.glist + (size_t)f * rgs::CAP; L.ring[0] = 0;
     rgs::run_frame<rgs::Wave>(Fr, L);
 }
+// (Smaller workgroups do not pack: the dispatcher spreads them over the emptiest CUs.  A 96-VGPR build in workgroups of ten frames, meant to sit two
+// to a CU, took one CU each, 206 CUs for two detectors, and cuboid_sweep_score waited 27 ms per launch.)
+__global__ void __launch_bounds__(1024) lsd_rg_seq(SeqParams P) { lsd_rg_seq_body(P); }
 // the frames' rectangle lists one after the other (frames in order, seeds in order): cand_base[f] = rectangles of the frames before f
 __global__ void __launch_bounds__(1024) lsd_rg_cand_scan(const int *cand_cnt, int F, int *cand_base) {
     __shared__ int part[1024];
