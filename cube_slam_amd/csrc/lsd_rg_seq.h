@@ -141,13 +141,11 @@ struct List {
 };
 template <class W> RGS_FN int list_head(const List &L, int i, int n) { return n - i <= RGS_RING ? W::bc(L.ring, i & (RGS_RING - 1)) : W::uni(L.glob[i]); }
 
-RGS_FN bool aligned_deg(float af, double theta, double prec) { // isAligned lsd.cpp:1138-1154 on a stored angle (float degrees: the map value exactly, :566)
-    if (af == NOTDEF_F) return false;
-    const double a = double(af) * rg::DEG_TO_RADS;
-    double n_theta = theta - a;
-    if (n_theta < 0) n_theta = -n_theta;
-    if (n_theta > rg::M_3_2_PI_) { n_theta -= rg::M_2__PI_; if (n_theta < 0) n_theta = -n_theta; }
-    return n_theta <= prec;
+// isAligned lsd.cpp:1138-1154 on an angle in radians (or FAR), without branches: the same IEEE operations in the same order -- |theta - a|, then
+// |that - 2 pi| if it exceeds 3 pi / 2 -- the conditional negations written as fabs
+RGS_FN bool aligned_rad(double a, double theta, double prec) {
+    const double d = fabs(theta - a), d2 = fabs(d - rg::M_2__PI_);
+    return (d > rg::M_3_2_PI_ ? d2 : d) <= prec;
 }
 
 #if defined(RGS_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
@@ -170,29 +168,37 @@ struct Seeds { // the 64 seeds the seed loop is looking at
 // neighbours in raster order and most regions are a handful of pixels, so most region_grow calls need no fetch at all.
 struct Win {
     int wx, wy;
-    PerLane<float> af, pc, ps; // free angle (NOTDEF_F: used, undefined or outside the image), cos, sin
+    PerLane<double> ar;        // level-line angle in radians (the map value exactly, :566) while the pixel is defined and unused; FAR otherwise (used, undefined, outside)
+    PerLane<float> pc, ps;     // cos, sin of float(angle)
     u64 am; bool am_ok;        // lanes aligned with the current region angle / tolerance, while am_ok
 };
-struct Wins { Win a, b; int last; };
+struct Wins { Win a, b; }; // a: the window used last; b: the one before (replaced on a miss)
+template <class W> RGS_FN void win_swap(Wins &V) {
+    const int wx = V.a.wx, wy = V.a.wy; V.a.wx = V.b.wx; V.a.wy = V.b.wy; V.b.wx = wx; V.b.wy = wy;
+    const u64 am = V.a.am; V.a.am = V.b.am; V.b.am = am;
+    const bool ok = V.a.am_ok; V.a.am_ok = V.b.am_ok; V.b.am_ok = ok;
+    W::each([&](int l) { const double r = V.a.ar[l]; V.a.ar[l] = V.b.ar[l]; V.b.ar[l] = r; const float c = V.a.pc[l]; V.a.pc[l] = V.b.pc[l]; V.b.pc[l] = c; const float q = V.a.ps[l]; V.a.ps[l] = V.b.ps[l]; V.b.ps[l] = q; });
+}
 constexpr int WIN_NONE = -(1 << 20);
+constexpr double FAR = 1e300; // an "angle" no region angle is within any tolerance of
 
 RGS_FN bool win_covers(const Win &w, int px, int py) { return px > w.wx && px < w.wx + 7 && py > w.wy && py < w.wy + 7; }
 template <class W> RGS_FN void win_fetch(const Frame &F, Win &w, int wx, int wy) {
     w.wx = wx; w.wy = wy; w.am_ok = false;
     W::each([&](int l) {
         const int xx = wx + (l & 7), yy = wy + (l >> 3);
-        w.af[l] = NOTDEF_F; w.pc[l] = 0; w.ps[l] = 0;
-        if (xx >= 0 && xx < F.w && yy >= 0 && yy < F.h) { const Px r = ld_px(&F.pix[xx + yy * F.w]); w.af[l] = r.free_deg; w.pc[l] = r.c; w.ps[l] = r.s; }
+        w.ar[l] = FAR; w.pc[l] = 0; w.ps[l] = 0;
+        if (xx >= 0 && xx < F.w && yy >= 0 && yy < F.h) { const Px r = ld_px(&F.pix[xx + yy * F.w]); w.ar[l] = r.free_deg == NOTDEF_F ? FAR : double(r.free_deg) * rg::DEG_TO_RADS; w.pc[l] = r.c; w.ps[l] = r.s; }
     });
 #if defined(RGS_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
-    { PerLane<bool> z; W::each([&](int l) { z[l] = w.af[l] == 12345.f; }); if (W::ballot(z)) w.wx = WIN_NONE; } // (the data has to arrive inside the timed part)
+    { PerLane<bool> z; W::each([&](int l) { z[l] = w.ar[l] == 12345.0; }); if (W::ballot(z)) w.wx = WIN_NONE; } // (the data has to arrive inside the timed part)
 #endif
 }
 template <class W> RGS_FN void win_strike(Win &w, int x, int y) { // pixel (x, y) is used now
     const int lx = x - w.wx, ly = y - w.wy;
     if (lx < 0 || lx > 7 || ly < 0 || ly > 7) return;
     const int lane = ly * 8 + lx;
-    W::each([&](int l) { if (l == lane) w.af[l] = NOTDEF_F; });
+    W::each([&](int l) { if (l == lane) w.ar[l] = FAR; });
     w.am &= ~(1ull << lane);
 }
 
@@ -209,7 +215,7 @@ template <class W> RGS_FN void expand(const Frame &F, Win &w, Win &other, int px
     for (;;) {
         if (!w.am_ok) { // the tests of all 64 pixels at once; they hold until the region angle changes, so a pixel that accepts nothing costs no vector work
             PerLane<bool> al;
-            W::each([&](int l) { al[l] = aligned_deg(w.af[l], reg_angle, prec); });
+            W::each([&](int l) { al[l] = aligned_rad(w.ar[l], reg_angle, prec); });
             w.am = W::ballot(al); w.am_ok = true;
         }
         const u64 m = w.am & nb & (~0ull << cur);
@@ -220,7 +226,7 @@ template <class W> RGS_FN void expand(const Frame &F, Win &w, Win &other, int px
         if (n >= CAP) { overflow = true; return; }
         PerLane<bool> hit;
         W::each([&](int l) {
-            if (l == l0) { st_free(&F.pix[cs], NOTDEF_F); L.glob[n] = xy_pack(cx, cy); w.af[l] = NOTDEF_F; }
+            if (l == l0) { st_free(&F.pix[cs], NOTDEF_F); L.glob[n] = xy_pack(cx, cy); w.ar[l] = FAR; }
             if (l == (n & (RGS_RING - 1))) L.ring[l] = xy_pack(cx, cy);
             hit[l] = S.sa[l] == cs;
         });
@@ -253,19 +259,18 @@ template <class W> RGS_FN void grow(const Frame &F, Wins &V, List &L, int &n, do
     }
     for (int i = 0; i < n && !overflow; ++i) {
         const int q = list_head<W>(L, i, n), px = q & 0xffff, py = q >> 16;
-        const bool in_a = win_covers(V.a, px, py), in_b = !in_a && win_covers(V.b, px, py);
-        if (!in_a && !in_b) { // fetch around the pixel, leaning away from the seed (the region grows outwards); the window used last stays
-            const int ox = px > sx ? 2 : (px < sx ? 5 : (i == 0 ? 2 : 3)), oy = py > sy ? 2 : (py < sy ? 5 : 3);
-            RGS_T0(0);
-            if (V.last == 0) win_fetch<W>(F, V.b, px - ox, py - oy); else win_fetch<W>(F, V.a, px - ox, py - oy);
-            RGS_T1(0);
-            V.last ^= 1;
-            fetches++;
-        } else
-            V.last = in_a ? 0 : 1;
+        if (!win_covers(V.a, px, py)) {
+            if (!win_covers(V.b, px, py)) { // fetch around the pixel, leaning away from the seed (the region grows outwards), over the window used longest ago
+                const int ox = px > sx ? 2 : (px < sx ? 5 : (i == 0 ? 2 : 3)), oy = py > sy ? 2 : (py < sy ? 5 : 3);
+                RGS_T0(0);
+                win_fetch<W>(F, V.b, px - ox, py - oy);
+                RGS_T1(0);
+                fetches++;
+            }
+            win_swap<W>(V);
+        }
         RGS_T0(1);
-        if (V.last == 0) expand<W>(F, V.a, V.b, px, py, L, n, reg_angle, prec, a0, sumdx, sumdy, have_sums, S, overflow);
-        else expand<W>(F, V.b, V.a, px, py, L, n, reg_angle, prec, a0, sumdx, sumdy, have_sums, S, overflow);
+        expand<W>(F, V.a, V.b, px, py, L, n, reg_angle, prec, a0, sumdx, sumdy, have_sums, S, overflow);
         RGS_T1(1);
     }
 }
@@ -386,8 +391,8 @@ template <class W> RGS_FN void run_frame(const Frame &F, List &L) {
     int n_grow = 0, n_reg = 0, fetches = 0, n_cand = 0;
     bool overflow = false;
     Wins V;
-    V.a.wx = WIN_NONE; V.a.wy = 0; V.b.wx = WIN_NONE; V.b.wy = 0; V.last = 0; V.a.am = 0; V.b.am = 0; V.a.am_ok = false; V.b.am_ok = false;
-    W::each([&](int l) { V.a.af[l] = NOTDEF_F; V.a.pc[l] = 0; V.a.ps[l] = 0; V.b.af[l] = NOTDEF_F; V.b.pc[l] = 0; V.b.ps[l] = 0; });
+    V.a.wx = WIN_NONE; V.a.wy = 0; V.b.wx = WIN_NONE; V.b.wy = 0; V.a.am = 0; V.b.am = 0; V.a.am_ok = false; V.b.am_ok = false;
+    W::each([&](int l) { V.a.ar[l] = FAR; V.a.pc[l] = 0; V.a.ps[l] = 0; V.b.ar[l] = FAR; V.b.pc[l] = 0; V.b.ps[l] = 0; });
     RGS_T0(5);
     for (int i0 = 0; i0 < F.ne && !overflow; i0 += 64) {
         RGS_T0(4);
