@@ -143,7 +143,7 @@ __device__ double rg_rect_improve(const AngMap &F, rg::Rect &rec, double LOG_NT,
 struct SeqParams {
     int F, w, h;
     const int *caddr; const int *frame_base; const float *cdeg; const float2 *ccs; const double *mod, *ang;
-    rgs::Px *pix; int *glist; double *rect; int cand_cap; int *cand_cnt; int *status;
+    rgs::Px *pix; float *seed_cs; int *glist; double *rect; int cand_cap; int *cand_cnt; int *status;
     int min_reg_size;
     unsigned long long *prof;
 };
@@ -151,7 +151,7 @@ __global__ void __launch_bounds__(256) lsd_rg_fill(rgs::Px *pix, size_t n) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) reinterpret_cast<float4 *>(pix)[i] = make_float4(rgs::NOTDEF_F, 0.f, 0.f, rgs::NOTDEF_F);
 }
-// the defined pixels' records from lsd_emit's compact lists
+// the defined pixels' records from lsd_emit's compact lists, and what each would start a region with as a seed
 __global__ void __launch_bounds__(256) lsd_rg_scatter(SeqParams P) {
     const int f = blockIdx.y, base = P.frame_base[f], ne = P.frame_base[f + 1] - base;
     const int i = blockIdx.x * 256 + threadIdx.x;
@@ -160,6 +160,8 @@ __global__ void __launch_bounds__(256) lsd_rg_scatter(SeqParams P) {
     const float d = P.cdeg[base + i];
     const float2 cs = P.ccs[base + i];
     reinterpret_cast<float4 *>(P.pix + (size_t)f * P.w * P.h)[q] = make_float4(d, cs.x, cs.y, d);
+    const double a = double(d) * rg::DEG_TO_RADS; // the map value (:566); region_grow starts a region's sums with cos / sin of it as a double (:651-652)
+    reinterpret_cast<float2 *>(P.seed_cs)[base + i] = make_float2(float(cos(a)), float(sin(a)));
 }
 // A workgroup is a bundle of independent waves, one frame each (no LDS, no barrier).  Sixteen waves fill a CU (4 a SIMD, 128 VGPRs each): the frames
 // of a batch then sit on F / 16 CUs and leave the others EMPTY -- cuboid_sweep_score's workgroups need a whole CU (160 KB of LDS, 2 x 240 VGPRs a
@@ -170,7 +172,7 @@ __device__ __forceinline__ void lsd_rg_seq_body(const SeqParams &P) {
     const int base = P.frame_base[f];
     rgs::Frame Fr;
     Fr.w = P.w; Fr.h = P.h; Fr.ne = P.frame_base[f + 1] - base;
-    Fr.caddr = P.caddr + base; Fr.pix = P.pix + (size_t)f * P.w * P.h; Fr.mod = P.mod + (size_t)f * P.w * P.h;
+    Fr.caddr = P.caddr + base; Fr.pix = P.pix + (size_t)f * P.w * P.h; Fr.mod = P.mod + (size_t)f * P.w * P.h; Fr.seed_cs = P.seed_cs + 2 * (size_t)base;
     Fr.rect = P.rect + (size_t)f * P.cand_cap * 12; Fr.cand_cap = P.cand_cap; Fr.cand_cnt = P.cand_cnt + f;
     Fr.status = P.status + 4 * f; Fr.min_reg_size = P.min_reg_size; Fr.prof = P.prof ? P.prof + 16 * (size_t)f : nullptr;
     rgs::List L;
@@ -220,8 +222,9 @@ __global__ void __launch_bounds__(256) lsd_rg_improve(SeqParams P, const int *ca
 
 // ---- host side of the sequential stage ----------------------------------------------------------------------------------------------------
 struct LsdSeq {
-    int F = 0, w = 0, h = 0; int cand_cap = 0; size_t cap_lines = 0;
+    int F = 0, w = 0, h = 0; int cand_cap = 0; size_t cap_lines = 0, cap_def = 0;
     rgs::Px *d_pix = nullptr;
+    float *d_seed_cs = nullptr;
     int *d_glist = nullptr, *d_cand_cnt = nullptr, *d_cand_base = nullptr, *d_status = nullptr, *d_frame_base = nullptr;
     double *d_rect = nullptr, *d_lgt = nullptr;
     uint8_t *d_has = nullptr;
@@ -230,7 +233,7 @@ struct LsdSeq {
 };
 void lsd_seq_destroy(LsdSeq *r) {
     if (!r) return;
-    void *ptrs[] = {r->d_pix, r->d_glist, r->d_cand_cnt, r->d_cand_base, r->d_status, r->d_frame_base, r->d_rect, r->d_lgt, r->d_has, r->d_line};
+    void *ptrs[] = {r->d_pix, r->d_seed_cs, r->d_glist, r->d_cand_cnt, r->d_cand_base, r->d_status, r->d_frame_base, r->d_rect, r->d_lgt, r->d_has, r->d_line};
     for (void *p : ptrs) if (p) hipFree(p);
     delete r;
 }
@@ -255,10 +258,17 @@ int lsd_seq_run(cs_ctx *ctx, LsdSeq **handle, int F, int w, int h, const double 
         RA_(cs_dalloc(ctx, &r->d_lgt, (size_t)LG_N));
         CS_LAUNCH(ctx, "lsd_rg_lgamma_table", lsd_rg_lgamma_table, dim3(LG_N / 256), dim3(256), 0, r->d_lgt);
     }
+    if (r->cap_def < (size_t)frame_base[F]) {
+        if (r->d_seed_cs) hipFree(r->d_seed_cs);
+        r->d_seed_cs = nullptr; r->cap_def = 0;
+        const size_t cap = (size_t)frame_base[F] + frame_base[F] / 4 + 4096;
+        RA_(cs_dalloc(ctx, &r->d_seed_cs, 2 * cap));
+        r->cap_def = cap;
+    }
     RA_(cs_h2d(ctx, r->d_frame_base, frame_base, (size_t)F + 1));
     SeqParams S;
     S.F = F; S.w = w; S.h = h; S.caddr = d_caddr; S.frame_base = r->d_frame_base; S.cdeg = d_cdeg; S.ccs = d_ccs; S.mod = d_mod; S.ang = d_ang;
-    S.pix = r->d_pix; S.glist = r->d_glist; S.rect = r->d_rect; S.cand_cap = r->cand_cap; S.cand_cnt = r->d_cand_cnt; S.status = r->d_status;
+    S.pix = r->d_pix; S.seed_cs = r->d_seed_cs; S.glist = r->d_glist; S.rect = r->d_rect; S.cand_cap = r->cand_cap; S.cand_cnt = r->d_cand_cnt; S.status = r->d_status;
     const double LOG_NT = 5 * (std::log10(double(w)) + std::log10(double(h))) / 2 + std::log10(11.0);
     S.min_reg_size = int(-LOG_NT / std::log10(rg::ANG_TH / 180));
     S.prof = nullptr;

@@ -65,6 +65,7 @@ struct Frame {
     const int *caddr;   // defined pixels in address order (bit 31: lsd_emit's "stays alone as a seed" flag)
     Px *pix;            // dense w*h
     const double *mod;  // dense gradient norms
+    const float *seed_cs; // per rank: float(cos(angle)), float(sin(angle)) of the pixel's angle as a double -- what a seed starts its sums with (:651-652)
     double *rect; int cand_cap; int *cand_cnt; // the rectangles (12 doubles each, rg::Rect) that reach rect_improve, in seed order
     unsigned long long *prof; // RGS_PROFILE
     int *status;        // [0] region_grow calls, [1] failure (capacity), [2] regions at the rectangle stage, [3] neighbourhood fetches
@@ -182,7 +183,7 @@ template <class W> RGS_FN void win_swap(Wins &V) {
 constexpr int WIN_NONE = -(1 << 20);
 constexpr double FAR = 1e300; // an "angle" no region angle is within any tolerance of
 
-RGS_FN bool win_covers(const Win &w, int px, int py) { return px > w.wx && px < w.wx + 7 && py > w.wy && py < w.wy + 7; }
+RGS_FN bool win_covers(const Win &w, int px, int py) { return (unsigned)(px - w.wx - 1) < 6u && (unsigned)(py - w.wy - 1) < 6u; } // the pixel's 3 x 3 neighbourhood is inside
 template <class W> RGS_FN void win_fetch(const Frame &F, Win &w, int wx, int wy) {
     w.wx = wx; w.wy = wy; w.am_ok = false;
     W::each([&](int l) {
@@ -207,10 +208,9 @@ RGS_FN int xy_pack(int x, int y) { return x | (y << 16); }
 RGS_FN int xy_addr(int xy, int w) { return (xy & 0xffff) + (xy >> 16) * w; }
 
 // one pixel of region_grow (lsd.cpp:660-686) against the window that covers it; other: the second window, kept current
-template <class W> RGS_FN void expand(const Frame &F, Win &w, Win &other, int px, int py, List &L, int &n, double &reg_angle, double prec, double a0, float &sumdx, float &sumdy, bool &have_sums,
-                                      Seeds &S, bool &overflow) {
+template <class W> RGS_FN void expand(const Frame &F, Win &w, Win &other, int px, int py, List &L, int &n, double &reg_angle, double prec, float &sumdx, float &sumdy, Seeds &S, bool &overflow) {
     const int b0 = (py - 1 - w.wy) * 8 + (px - 1 - w.wx); // lane of the first neighbour; the nine in the reference's order (yy outer, xx inner) are ascending lanes
-    const u64 nb = (7ull << b0) | (7ull << (b0 + 8)) | (7ull << (b0 + 16));
+    const u64 nb = 0x070707ull << b0;
     int cur = 0;
     for (;;) {
         if (!w.am_ok) { // the tests of all 64 pixels at once; they hold until the region angle changes, so a pixel that accepts nothing costs no vector work
@@ -233,7 +233,6 @@ template <class W> RGS_FN void expand(const Frame &F, Win &w, Win &other, int px
         S.freem &= ~W::ballot(hit);
         win_strike<W>(other, cx, cy);
         ++n;
-        if (!have_sums) { sumdx = float(cos(a0)); sumdy = float(sin(a0)); have_sums = true; }
         sumdx += cc; sumdy += ss; // cos(float(angle)), sin(float(angle)) :676-677, from lsd_emit
         reg_angle = rg::fast_atan2(sumdy, sumdx) * rg::DEG_TO_RADS;
         w.am_ok = false; other.am_ok = false;
@@ -243,12 +242,10 @@ template <class W> RGS_FN void expand(const Frame &F, Win &w, Win &other, int px
 }
 
 // region_grow lsd.cpp:637-688 from the pixel (sx, sy) (angle sdeg, float degrees)
-template <class W> RGS_FN void grow(const Frame &F, Wins &V, List &L, int &n, double &reg_angle, double prec, int sx, int sy, float sdeg, Seeds &S, bool &overflow, int &fetches) {
+template <class W> RGS_FN void grow(const Frame &F, Wins &V, List &L, int &n, double &reg_angle, double prec, int sx, int sy, float sdeg, float scos, float ssin, Seeds &S, bool &overflow, int &fetches) {
     n = 1;
     reg_angle = double(sdeg) * rg::DEG_TO_RADS;
-    const double a0 = reg_angle;
-    float sumdx = 0, sumdy = 0; // cos / sin of the seed angle (:651-652, doubles) join when a second pixel does
-    bool have_sums = false;
+    float sumdx = scos, sumdy = ssin; // cos / sin of the seed angle as a double (:651-652), computed once per pixel by lsd_rg_scatter
     const int saddr = sx + sy * F.w;
     V.a.am_ok = false; V.b.am_ok = false;
     {
@@ -270,7 +267,7 @@ template <class W> RGS_FN void grow(const Frame &F, Wins &V, List &L, int &n, do
             win_swap<W>(V);
         }
         RGS_T0(1);
-        expand<W>(F, V.a, V.b, px, py, L, n, reg_angle, prec, a0, sumdx, sumdy, have_sums, S, overflow);
+        expand<W>(F, V.a, V.b, px, py, L, n, reg_angle, prec, sumdx, sumdy, S, overflow);
         RGS_T1(1);
     }
 }
@@ -328,7 +325,7 @@ template <class W> RGS_FN void to_rect(const Frame &F, const List &L, int n, dou
 }
 
 // refine lsd.cpp:786-832 + reduce_region_radius :834-871.  released: pixels went back to "unused" (the seed loop re-reads its 64 seeds)
-template <class W> RGS_FN bool refine(const Frame &F, Wins &V, List &L, int &n, double &reg_angle, double prec, double p, rg::Rect &rec, int sx, int sy, float sdeg, Seeds &S, bool &overflow, int &fetches,
+template <class W> RGS_FN bool refine(const Frame &F, Wins &V, List &L, int &n, double &reg_angle, double prec, double p, rg::Rect &rec, int sx, int sy, float sdeg, float scos, float ssin, Seeds &S, bool &overflow, int &fetches,
                                       bool &released) {
     double density = double(n) / (rg::dist(rec.x1, rec.y1, rec.x2, rec.y2) * rec.width);
     if (density >= rg::DENSITY_TH) return true;
@@ -356,7 +353,7 @@ template <class W> RGS_FN bool refine(const Frame &F, Wins &V, List &L, int &n, 
     }
     const double mean_angle = sum / double(cnt);
     const double tau = 2.0 * sqrt((s_sum - 2.0 * mean_angle * sum) / double(cnt) + mean_angle * mean_angle);
-    grow<W>(F, V, L, n, reg_angle, tau, sx, sy, sdeg, S, overflow, fetches);
+    grow<W>(F, V, L, n, reg_angle, tau, sx, sy, sdeg, scos, ssin, S, overflow, fetches);
     if (overflow) return false;
     if (n < 2) return false;
     to_rect<W>(F, L, n, reg_angle, prec, p, rec);
@@ -397,11 +394,11 @@ template <class W> RGS_FN void run_frame(const Frame &F, List &L) {
     for (int i0 = 0; i0 < F.ne && !overflow; i0 += 64) {
         RGS_T0(4);
         Seeds S;
-        PerLane<int> iso; PerLane<float> dg; PerLane<bool> fr;
+        PerLane<int> iso, sxy; PerLane<float> dg, sc, ss; PerLane<bool> fr;
         W::each([&](int l) {
             const int idx = i0 + l;
-            S.sa[l] = -1; iso[l] = 0; dg[l] = NOTDEF_F; fr[l] = false;
-            if (idx < F.ne) { const int ca = F.caddr[idx]; S.sa[l] = ca & 0x7fffffff; iso[l] = ca < 0; const Px r = ld_px(&F.pix[S.sa[l]]); dg[l] = r.deg; fr[l] = r.free_deg != NOTDEF_F; }
+            S.sa[l] = -1; iso[l] = 0; sxy[l] = 0; dg[l] = NOTDEF_F; sc[l] = 0; ss[l] = 0; fr[l] = false;
+            if (idx < F.ne) { const int ca = F.caddr[idx]; S.sa[l] = ca & 0x7fffffff; iso[l] = ca < 0; { const int yy = S.sa[l] / F.w; sxy[l] = xy_pack(S.sa[l] - yy * F.w, yy); } const Px r = ld_px(&F.pix[S.sa[l]]); sc[l] = F.seed_cs[2 * idx]; ss[l] = F.seed_cs[2 * idx + 1]; dg[l] = r.deg; fr[l] = r.free_deg != NOTDEF_F; }
         });
         S.freem = W::ballot(fr);
         RGS_T1(4);
@@ -417,17 +414,17 @@ template <class W> RGS_FN void run_frame(const Frame &F, List &L) {
             if (!m) break;
             const int j = ctz64(m);
             pos = j + 1;
-            const int saddr = W::bc(S.sa, j), sy = W::uni(saddr / F.w), sx = saddr - sy * F.w;
+            const int saddr = W::bc(S.sa, j), sq = W::bc(sxy, j), sx = sq & 0xffff, sy = sq >> 16;
             if (W::bc(iso, j)) { // no neighbour is aligned with this pixel's own angle: a region of one pixel
                 W::each([&](int l) { if (l == j) st_free(&F.pix[saddr], NOTDEF_F); });
                 win_strike<W>(V.a, sx, sy); win_strike<W>(V.b, sx, sy);
                 S.freem &= ~(1ull << j);
                 continue;
             }
-            const float sdeg = W::bc(dg, j);
+            const float sdeg = W::bc(dg, j), scos = W::bc(sc, j), ssin = W::bc(ss, j);
             int n; double reg_angle;
             RGS_T0(2);
-            grow<W>(F, V, L, n, reg_angle, prec, sx, sy, sdeg, S, overflow, fetches);
+            grow<W>(F, V, L, n, reg_angle, prec, sx, sy, sdeg, scos, ssin, S, overflow, fetches);
             RGS_T1(2);
             n_grow++;
             if (overflow) break;
@@ -437,7 +434,7 @@ template <class W> RGS_FN void run_frame(const Frame &F, List &L) {
             RGS_T0(3);
             to_rect<W>(F, L, n, reg_angle, prec, p, rec);
             bool released = false;
-            const bool ok = refine<W>(F, V, L, n, reg_angle, prec, p, rec, sx, sy, sdeg, S, overflow, fetches, released);
+            const bool ok = refine<W>(F, V, L, n, reg_angle, prec, p, rec, sx, sy, sdeg, scos, ssin, S, overflow, fetches, released);
             if (released) reload = true;
             RGS_T1(3);
             if (overflow) break;

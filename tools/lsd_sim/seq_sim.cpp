@@ -37,12 +37,14 @@ int main(int argc, char **argv) {
     }
     // what lsd_emit hands over: float degrees, cosf / sinf of float(angle), the "stays alone" flag
     vector<rgs::Px> pix(N, rgs::Px{rgs::NOTDEF_F, 0.f, 0.f, rgs::NOTDEF_F});
+    vector<float> seed_cs(2 * (size_t)caddr.size());
     for (int i = 0; i < ne; i++) {
         const int q = caddr[i]; const double a = L.angles[q];
         float d = (float)(a / DEG_TO_RADS);
         if ((double)d * DEG_TO_RADS != a) { const float up = nextafterf(d, 1e9f), dn = nextafterf(d, -1e9f); d = ((double)up * DEG_TO_RADS == a) ? up : dn; }
         if ((double)d * DEG_TO_RADS != a) { printf("angle %d is not a float degree\n", q); return 3; }
         pix[q] = rgs::Px{d, cosf(float(a)), sinf(float(a)), d};
+        seed_cs[2 * i] = float(cos(a)); seed_cs[2 * i + 1] = float(sin(a));
         bool alone = true;
         const int x = q % w, y = q / w;
         for (int yy = max(y - 1, 0); yy <= min(y + 1, h - 1); yy++) for (int xx = max(x - 1, 0); xx <= min(x + 1, w - 1); xx++) {
@@ -59,7 +61,7 @@ int main(int argc, char **argv) {
     rgs::List Llist; Llist.glob = Lglob.data();
     vector<double> rect((size_t)12 * ne); int cand_cnt = 0;
     rgs::Frame F;
-    F.w = w; F.h = h; F.ne = ne; F.caddr = caddr.data(); F.pix = pix.data(); F.mod = L.modgrad.data(); F.rect = rect.data(); F.cand_cap = ne; F.cand_cnt = &cand_cnt;
+    F.w = w; F.h = h; F.ne = ne; F.caddr = caddr.data(); F.pix = pix.data(); F.mod = L.modgrad.data(); F.seed_cs = seed_cs.data(); F.rect = rect.data(); F.cand_cap = ne; F.cand_cnt = &cand_cnt;
     F.status = status.data(); F.min_reg_size = min_reg_size;
     rgs::run_frame<rgs::Wave>(F, Llist);
     long wrong_used = 0;
