@@ -144,7 +144,7 @@ struct SeqParams {
     int F, w, h;
     const int *caddr; const int *frame_base; const float *cdeg; const float2 *ccs; const double *mod, *ang;
     rgs::Px *pix; float *seed_cs; int *glist; double *rect; int cand_cap; int *cand_cnt; int *status;
-    int min_reg_size;
+    int min_reg_size, list_cap;
     unsigned long long *prof;
 };
 __global__ void __launch_bounds__(256) lsd_rg_fill(rgs::Px *pix, size_t n) {
@@ -174,7 +174,7 @@ __device__ __forceinline__ void lsd_rg_seq_body(const SeqParams &P) {
     Fr.w = P.w; Fr.h = P.h; Fr.ne = P.frame_base[f + 1] - base;
     Fr.caddr = P.caddr + base; Fr.pix = P.pix + (size_t)f * P.w * P.h; Fr.mod = P.mod + (size_t)f * P.w * P.h; Fr.seed_cs = P.seed_cs + 2 * (size_t)base;
     Fr.rect = P.rect + (size_t)f * P.cand_cap * 12; Fr.cand_cap = P.cand_cap; Fr.cand_cnt = P.cand_cnt + f;
-    Fr.status = P.status + 4 * f; Fr.min_reg_size = P.min_reg_size; Fr.prof = P.prof ? P.prof + 16 * (size_t)f : nullptr;
+    Fr.status = P.status + 4 * f; Fr.min_reg_size = P.min_reg_size; Fr.list_cap = P.list_cap; Fr.prof = P.prof ? P.prof + 16 * (size_t)f : nullptr;
     rgs::List L;
     L.glob = P.glist + (size_t)f * rgs::CAP; L.ring[0] = 0;
     rgs::run_frame<rgs::Wave>(Fr, L);
@@ -271,6 +271,8 @@ int lsd_seq_run(cs_ctx *ctx, LsdSeq **handle, int F, int w, int h, const double 
     S.pix = r->d_pix; S.seed_cs = r->d_seed_cs; S.glist = r->d_glist; S.rect = r->d_rect; S.cand_cap = r->cand_cap; S.cand_cnt = r->d_cand_cnt; S.status = r->d_status;
     const double LOG_NT = 5 * (std::log10(double(w)) + std::log10(double(h))) / 2 + std::log10(11.0);
     S.min_reg_size = int(-LOG_NT / std::log10(rg::ANG_TH / 180));
+    S.list_cap = rgs::CAP;
+    if (const char *e = getenv("CUBESLAM_LSD_SEQ_CAP")) S.list_cap = std::max(2, std::min(rgs::CAP, atoi(e))); // (tests: a small cap walks the fallback to the host stage)
     S.prof = nullptr;
 #if defined(RGS_PROFILE)
     static unsigned long long *d_prof = nullptr;

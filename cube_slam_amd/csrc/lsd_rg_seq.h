@@ -70,6 +70,7 @@ struct Frame {
     unsigned long long *prof; // RGS_PROFILE
     int *status;        // [0] region_grow calls, [1] failure (capacity), [2] regions at the rectangle stage, [3] neighbourhood fetches
     int min_reg_size;
+    int list_cap;       // pixels of one region before the frame gives up (<= CAP)
 };
 
 #if defined(__HIPCC__)
@@ -223,7 +224,7 @@ template <class W> RGS_FN void expand(const Frame &F, Win &w, Win &other, int px
         const int l0 = ctz64(m);
         const int cx = w.wx + (l0 & 7), cy = w.wy + (l0 >> 3), cs = cx + cy * F.w;
         const float cc = W::bc(w.pc, l0), ss = W::bc(w.ps, l0);
-        if (n >= CAP) { overflow = true; return; }
+        if (n >= F.list_cap) { overflow = true; return; }
         PerLane<bool> hit;
         W::each([&](int l) {
             if (l == l0) { st_free(&F.pix[cs], NOTDEF_F); L.glob[n] = xy_pack(cx, cy); w.ar[l] = FAR; }

@@ -55,6 +55,27 @@ def test_device_region_stage_equals_host_stage(ctx, oracle, monkeypatch):
     det.close()
 
 
+def test_device_region_stage_other_size_and_capacity_fallback(ctx, oracle, monkeypatch):
+    """The device stage on KITTI-sized frames, and its way out: a region larger than the wave's list (here cut to 64 pixels) hands the batch to the
+    host stage -- same KeyLines, and the statistics say so."""
+    monkeypatch.setenv("CUBESLAM_LSD_REGIONS", "seq")
+    imgs = [synth.cuboid_scene(5 + i, W=1241, H=376, bg_texture=0.5 * i)["gray"] for i in range(2)]
+    det = line_lbd_detect(1241, 376, max_frames=2, ctx=ctx)
+    got = det.detect_raw_lines(np.stack(imgs))
+    st = det.region_stats()
+    assert st["device"] and not st["host_fallback"]
+    want = [oracle.lsd_detect(im) for im in imgs]
+    for f in range(2):
+        assert got[f].tobytes() == want[f].tobytes() and len(want[f]) > 10
+    monkeypatch.setenv("CUBESLAM_LSD_SEQ_CAP", "64")
+    got = det.detect_raw_lines(np.stack(imgs))
+    st = det.region_stats()
+    assert st["device"] and st["host_fallback"]
+    for f in range(2):
+        assert got[f].tobytes() == want[f].tobytes()
+    det.close()
+
+
 def test_large_batches_take_the_device_region_stage(ctx, oracle, monkeypatch):
     """512 frames (16 distinct ones, repeated) through the resident-batch form: the device stage is the default there, all frames give their own lines."""
     monkeypatch.delenv("CUBESLAM_LSD_REGIONS", raising=False)

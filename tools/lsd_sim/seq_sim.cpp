@@ -62,7 +62,7 @@ int main(int argc, char **argv) {
     vector<double> rect((size_t)12 * ne); int cand_cnt = 0;
     rgs::Frame F;
     F.w = w; F.h = h; F.ne = ne; F.caddr = caddr.data(); F.pix = pix.data(); F.mod = L.modgrad.data(); F.seed_cs = seed_cs.data(); F.rect = rect.data(); F.cand_cap = ne; F.cand_cnt = &cand_cnt;
-    F.status = status.data(); F.min_reg_size = min_reg_size;
+    F.status = status.data(); F.min_reg_size = min_reg_size; F.list_cap = rgs::CAP;
     rgs::run_frame<rgs::Wave>(F, Llist);
     long wrong_used = 0;
     for (int q = 0; q < N; q++) if (L.angles[q] != NOTDEF) { const bool u = pix[q].free_deg == rgs::NOTDEF_F; if (u != (L.used[q] != 0)) wrong_used++; }
