@@ -696,6 +696,8 @@ static int lsd_run(cs_ctx *ctx, cs_lsd *l, int with_lbd) {
     host_lock.unlock();
     } else {
         l->keylines.assign((size_t)F, {});
+        cs_omp_prepare();
+#pragma omp parallel for schedule(static) num_threads(std::max(1, std::min(ctx->host_threads, F)))
         for (int f = 0; f < F; f++) to_keylines(dev_lines[f], W, H, l->keylines[f]);
     }
     l->line_off.assign((size_t)F + 1, 0);

@@ -72,7 +72,10 @@ __device__ double rg_nfa(int n, int k, double p, double LOG_NT, const double *lg
     return -log10(bin_tail) - LOG_NT;
 }
 // rect_nfa (:977-1098): the four corners ordered like the reference's std::sort + selection, rows counted by the lanes of the wave
-__device__ double rg_rect_nfa(const AngMap &F, const rg::Rect &rec, double LOG_NT, int lane, const double *lgt) {
+// The pixel walk of rect_nfa (:977-1098): the four corners ordered like the reference's std::sort + selection, the rows counted by the lanes of the
+// wave.  total = pixels of the rectangle inside the image; algs[k] = those aligned with rec.theta within precs[k] (several tolerances share a walk:
+// rect_improve's first and last loop only halve the tolerance of an unchanged rectangle).  Every lane gets the sums.
+template <int NP> __device__ void rg_rect_count(const AngMap &F, const rg::Rect &rec, const double *precs, int lane, int &total, int *algs) {
     const double half_width = rec.width / 2.0, dyhw = rec.dy * half_width, dxhw = rec.dx * half_width;
     int ox[4], oy[4]; bool taken[4] = {false, false, false, false};
     ox[0] = int(rec.x1 - dyhw); oy[0] = int(rec.y1 + dxhw); ox[1] = int(rec.x2 - dyhw); oy[1] = int(rec.y2 + dxhw);
@@ -97,7 +100,8 @@ __device__ double rg_rect_nfa(const AngMap &F, const rg::Rect &rec, double LOG_N
     const int srstep = (oy[rm] != ox[tl]) ? (ox[rm] - ox[tl]) / (oy[rm] - ox[tl]) : 0;
     // the limits move after every row INSIDE the image (the reference `continue`s past the stepping for the others): by the first step while
     // y < leftmost.y (rightmost.y), by the second from then on -- a closed form per row, so the lanes take rows independently
-    int total_pts = 0, alg_pts = 0;
+    int total_pts = 0, alg_pts[NP];
+    for (int k = 0; k < NP; k++) alg_pts[k] = 0;
     const int y_lo = oy[mn], y_hi = min(oy[mx], F.h - 1), y_first = max(y_lo, 0);
     for (int y = y_first + lane; y <= y_hi; y += 64) {
         const long r = (long)y - y_first; // rows stepped before this one: y_first .. y-1
@@ -108,34 +112,67 @@ __device__ double rg_rect_nfa(const AngMap &F, const rg::Rect &rec, double LOG_N
         const long lx = max((long)ox[mn] + adv(flstep, slstep, oy[lm]), 0L), rx = min((long)ox[mn] + adv(frstep, srstep, oy[rm]), (long)F.w - 1);
         for (long x = lx; x <= rx; ++x) {
             ++total_pts;
-            if (rg::aligned_ang(F.ang[(int)(y * F.w + x)], rec.theta, rec.prec)) ++alg_pts;
+            const double a = F.ang[(int)(y * F.w + x)];
+            if (a == rg::NOTDEF) continue;
+            const double d = fabs(rec.theta - a), d2 = fabs(d - rg::M_2__PI_), nt = d > rg::M_3_2_PI_ ? d2 : d; // isAligned :1138-1154
+            for (int k = 0; k < NP; k++) alg_pts[k] += nt <= precs[k];
         }
     }
-    for (int off = 32; off > 0; off >>= 1) { total_pts += __shfl_xor(total_pts, off); alg_pts += __shfl_xor(alg_pts, off); }
-    return rg_nfa(total_pts, alg_pts, rec.p, LOG_NT, lgt);
+    for (int off = 32; off > 0; off >>= 1) {
+        total_pts += __shfl_xor(total_pts, off);
+        for (int k = 0; k < NP; k++) alg_pts[k] += __shfl_xor(alg_pts[k], off);
+    }
+    total = total_pts;
+    for (int k = 0; k < NP; k++) algs[k] = alg_pts[k];
 }
-__device__ double rg_rect_improve(const AngMap &F, rg::Rect &rec, double LOG_NT, int lane, const double *lgt) { // :873-975
+// nfa() of up to five (n, k, p) triples at once: lane v computes triple v -- the loops inside nfa are sequential, the triples independent
+__device__ void rg_nfa5(const int *n, const int *k, const double *p, int cnt, double LOG_NT, const double *lgt, int lane, double *out) {
+    int nn = n[0], kk = k[0]; double pp = p[0];
+    for (int v = 1; v < 5; v++) if (v < cnt && lane == v) { nn = n[v]; kk = k[v]; pp = p[v]; }
+    const double r = rg_nfa(nn, kk, pp, LOG_NT, lgt);
+    for (int v = 0; v < 5; v++) out[v] = __shfl(r, v);
+}
+// rect_improve lsd.cpp:873-975.  The five variants of each of its loops do not depend on each other's result (only the best is remembered), so
+// their pixel walks run one after the other -- or as one walk where only the tolerance changes -- and their five nfa() side by side in five lanes.
+__device__ double rg_rect_improve(const AngMap &F, rg::Rect &rec, double LOG_NT, int lane, const double *lgt) {
     const double delta = 0.5, delta_2 = delta / 2.0;
-    double log_nfa = rg_rect_nfa(F, rec, LOG_NT, lane, lgt);
+    double log_nfa;
+    { int tot, alg; rg_rect_count<1>(F, rec, &rec.prec, lane, tot, &alg); log_nfa = rg_nfa(tot, alg, rec.p, LOG_NT, lgt); }
+    if (log_nfa > LOG_EPS) return log_nfa;
+    rg::Rect rs[5];
+    int tot[5], alg[5], cnt; double ps[5], v[5];
+    auto tolerances = [&]() { // r.p /= 2 five times on the rectangle `rec`: one walk, five counts
+        rg::Rect r = rec; double precs[5];
+        for (int n = 0; n < 5; ++n) { r.p /= 2; r.prec = r.p * PI_; rs[n] = r; precs[n] = r.prec; ps[n] = r.p; }
+        int t; rg_rect_count<5>(F, rec, precs, lane, t, alg);
+        for (int n = 0; n < 5; ++n) tot[n] = t;
+        cnt = 5;
+    };
+    auto take_best = [&]() {
+        rg_nfa5(tot, alg, ps, cnt, LOG_NT, lgt, lane, v);
+        for (int n = 0; n < cnt; ++n) if (v[n] > log_nfa) { log_nfa = v[n]; rec = rs[n]; }
+    };
+    auto walks = [&]() { for (int n = 0; n < cnt; ++n) { rg_rect_count<1>(F, rs[n], &rs[n].prec, lane, tot[n], &alg[n]); ps[n] = rs[n].p; } };
+    tolerances(); take_best();
     if (log_nfa > LOG_EPS) return log_nfa;
     rg::Rect r = rec;
-    for (int n = 0; n < 5; ++n) { r.p /= 2; r.prec = r.p * PI_; const double v = rg_rect_nfa(F, r, LOG_NT, lane, lgt); if (v > log_nfa) { log_nfa = v; rec = r; } }
+    cnt = 0;
+    for (int n = 0; n < 5; ++n) if ((r.width - delta) >= 0.5) { r.width -= delta; rs[cnt++] = r; }
+    walks(); if (cnt) take_best();
     if (log_nfa > LOG_EPS) return log_nfa;
-    r = rec;
-    for (int n = 0; n < 5; ++n) if ((r.width - delta) >= 0.5) { r.width -= delta; const double v = rg_rect_nfa(F, r, LOG_NT, lane, lgt); if (v > log_nfa) { rec = r; log_nfa = v; } }
-    if (log_nfa > LOG_EPS) return log_nfa;
-    r = rec;
-    for (int n = 0; n < 5; ++n) if ((r.width - delta) >= 0.5) {
-        r.x1 += -r.dy * delta_2; r.y1 += r.dx * delta_2; r.x2 += -r.dy * delta_2; r.y2 += r.dx * delta_2; r.width -= delta;
-        const double v = rg_rect_nfa(F, r, LOG_NT, lane, lgt); if (v > log_nfa) { rec = r; log_nfa = v; } }
-    if (log_nfa > LOG_EPS) return log_nfa;
-    r = rec;
-    for (int n = 0; n < 5; ++n) if ((r.width - delta) >= 0.5) {
-        r.x1 -= -r.dy * delta_2; r.y1 -= r.dx * delta_2; r.x2 -= -r.dy * delta_2; r.y2 -= r.dx * delta_2; r.width -= delta;
-        const double v = rg_rect_nfa(F, r, LOG_NT, lane, lgt); if (v > log_nfa) { rec = r; log_nfa = v; } }
-    if (log_nfa > LOG_EPS) return log_nfa;
-    r = rec;
-    for (int n = 0; n < 5; ++n) if ((r.width - delta) >= 0.5) { r.p /= 2; r.prec = r.p * PI_; const double v = rg_rect_nfa(F, r, LOG_NT, lane, lgt); if (v > log_nfa) { rec = r; log_nfa = v; } }
+    for (int side = 0; side < 2; side++) {
+        r = rec;
+        cnt = 0;
+        for (int n = 0; n < 5; ++n) if ((r.width - delta) >= 0.5) {
+            if (side == 0) { r.x1 += -r.dy * delta_2; r.y1 += r.dx * delta_2; r.x2 += -r.dy * delta_2; r.y2 += r.dx * delta_2; }
+            else { r.x1 -= -r.dy * delta_2; r.y1 -= r.dx * delta_2; r.x2 -= -r.dy * delta_2; r.y2 -= r.dx * delta_2; }
+            r.width -= delta;
+            rs[cnt++] = r;
+        }
+        walks(); if (cnt) take_best();
+        if (log_nfa > LOG_EPS) return log_nfa;
+    }
+    if ((rec.width - delta) >= 0.5) { tolerances(); take_best(); } // (the width does not change in the last loop: all five or none)
     return log_nfa;
 }
 
@@ -318,6 +355,7 @@ int lsd_seq_run(cs_ctx *ctx, LsdSeq **handle, int F, int w, int h, const double 
     RA_(cs_d2h(ctx, r->h_line.data(), r->d_line, (size_t)n_cand));
     CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
 #undef RA_
+#pragma omp parallel for schedule(static) num_threads(std::max(1, std::min(ctx->host_threads, F)))
     for (int f = 0; f < F; f++)
         for (int k = r->h_base[f]; k < r->h_base[f + 1]; k++)
             if (r->h_has[k]) { const float4 v = r->h_line[k]; lines[f].push_back(v.x); lines[f].push_back(v.y); lines[f].push_back(v.z); lines[f].push_back(v.w); }
