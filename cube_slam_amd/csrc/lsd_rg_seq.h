@@ -8,8 +8,9 @@
 //     changes the region angle for the tests after it -- one ballot + two lane reads + the fastAtan2 polynomial per accepted pixel.  The
 //     windows outlive the region: the wave is the only writer of its frame's map, and the next seed is usually next door;
 //   * the ordered double sums of region2rect / refine take their terms from the lanes (products computed in parallel, added in list order).
-// Throughput comes from frames, not from inside a frame: a wave is latency-bound, so thousands of frames are resident and every SIMD holds
-// a few of them.  Written once for the device and for a host model (tools/lsd_sim/seq_sim.cpp) that runs the 64 lanes as loops: per-lane
+// Throughput comes from frames, not from inside a frame: a frame is a chain of dependent instructions (about 90 per accepted pixel), so thousands
+// of frames are resident, four to a SIMD.  No LDS, every wave-uniform value marked as such (W::uni): the bookkeeping runs on the scalar unit.
+// Written once for the device and for a host model (tools/lsd_sim/seq_sim.cpp) that runs the 64 lanes as loops: per-lane
 // values are PerLane<T>, per-lane code sits in W::each bodies, everything else is wave-uniform.
 // A body must not read what another lane's part of the SAME body writes (on the device the lanes run it together).
 #pragma once
@@ -40,13 +41,6 @@ RG_HD float fast_atan2(float y, float x) { // cv::fastAtan2, the polynomial of l
     if (y < 0) a = 360.f - a;
     return a;
 }
-RG_HD bool aligned_ang(double a, double theta, double prec) { // isAligned lsd.cpp:1138-1154 on a fetched angle
-    if (a == NOTDEF) return false;
-    double n_theta = theta - a;
-    if (n_theta < 0) n_theta = -n_theta;
-    if (n_theta > M_3_2_PI_) { n_theta -= M_2__PI_; if (n_theta < 0) n_theta = -n_theta; }
-    return n_theta <= prec;
-}
 RG_HD double dist(double x1, double y1, double x2, double y2) { return sqrt((x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1)); }
 RG_HD double angle_diff_signed(double a, double b) { double diff = a - b; while (diff <= -PI_) diff += M_2__PI_; while (diff > PI_) diff -= M_2__PI_; return diff; }
 
@@ -68,7 +62,7 @@ struct Frame {
     const float *seed_cs; // per rank: float(cos(angle)), float(sin(angle)) of the pixel's angle as a double -- what a seed starts its sums with (:651-652)
     double *rect; int cand_cap; int *cand_cnt; // the rectangles (12 doubles each, rg::Rect) that reach rect_improve, in seed order
     unsigned long long *prof; // RGS_PROFILE
-    int *status;        // [0] region_grow calls, [1] failure (capacity), [2] regions at the rectangle stage, [3] neighbourhood fetches
+    int *status;        // [0] region_grow calls, [1] failure (capacity), [2] regions at the rectangle stage, [3] window fetches
     int min_reg_size;
     int list_cap;       // pixels of one region before the frame gives up (<= CAP)
 };
@@ -102,7 +96,7 @@ struct Wave { // the 64 lanes of the calling wave
     }
     static __device__ __forceinline__ double vmax(const PerLane<double> &x) { double m = x.v; for (int o = 32; o > 0; o >>= 1) m = fmax(m, __shfl_xor(m, o)); return uni(m); }
     static __device__ __forceinline__ double vmin(const PerLane<double> &x) { double m = x.v; for (int o = 32; o > 0; o >>= 1) m = fmin(m, __shfl_xor(m, o)); return uni(m); }
-    // LDS written by one lane and read by the others: the wave's DS instructions execute in order, so only the compiler has to be held back
+    // memory written by one lane and read by another lane of the wave: its memory instructions execute in order, so only the compiler has to be held back
     static __device__ __forceinline__ void sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
     static __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); } // a value every lane holds (tells the compiler so)
 };
