@@ -213,7 +213,7 @@ __device__ __forceinline__ void lsd_rg_seq_body(const SeqParams &P) {
     Fr.rect = P.rect + (size_t)f * P.cand_cap * 12; Fr.cand_cap = P.cand_cap; Fr.cand_cnt = P.cand_cnt + f;
     Fr.status = P.status + 4 * f; Fr.min_reg_size = P.min_reg_size; Fr.list_cap = P.list_cap; Fr.prof = P.prof ? P.prof + 16 * (size_t)f : nullptr;
     rgs::List L;
-    L.glob = P.glist + (size_t)f * rgs::CAP; L.ring[0] = 0; L.ring_ok = false;
+    L.glob = P.glist + (size_t)f * rgs::CAP; L.ring[0] = 0;
     rgs::run_frame<rgs::Wave>(Fr, L);
 }
 // (Smaller workgroups do not pack: the dispatcher spreads them over the emptiest CUs.  A 96-VGPR build in workgroups of ten frames, meant to sit two

@@ -134,7 +134,6 @@ RGS_FN int ctz64(u64 m) { return __builtin_ctzll(m); }
 struct List {
     int *glob;
     PerLane<int> ring;
-    bool ring_ok; // the ring mirrors the list's tail (not after reduce_region_radius swapped entries in memory)
 };
 template <class W> RGS_FN int list_head(const List &L, int i, int n) { return n - i <= RGS_RING ? W::bc(L.ring, i & (RGS_RING - 1)) : W::uni(L.glob[i]); }
 
@@ -244,7 +243,6 @@ template <class W> RGS_FN void grow(const Frame &F, Wins &V, List &L, int &n, do
     float sumdx = scos, sumdy = ssin; // cos / sin of the seed angle as a double (:651-652), computed once per pixel by lsd_rg_scatter
     const int saddr = sx + sy * F.w;
     V.a.am_ok = false; V.b.am_ok = false;
-    L.ring_ok = true;
     {
         PerLane<bool> hit;
         W::each([&](int l) { if (l == 0) { L.glob[0] = xy_pack(sx, sy); L.ring[l] = xy_pack(sx, sy); st_free(&F.pix[saddr], NOTDEF_F); } hit[l] = S.sa[l] == saddr; });
@@ -272,32 +270,16 @@ template <class W> RGS_FN void grow(const Frame &F, Wins &V, List &L, int &n, do
 // region2rect + get_theta lsd.cpp:690-784 over L[0..n): the terms come from the lanes, the sums run in list order
 template <class W> RGS_FN void to_rect(const Frame &F, const List &L, int n, double reg_angle, double prec, double p, rg::Rect &rec) {
     W::sync();
-    // the first 64 pixels and their gradient norms stay in registers for the three passes (most regions are not longer; a list of at most 64 entries
-    // is still complete in the ring, so it is not even read from memory)
-    PerLane<int> q0; PerLane<double> m0;
-    W::each([&](int l) {
-        q0[l] = 0; m0[l] = 0;
-        if (l < n) { q0[l] = (L.ring_ok && n <= RGS_RING) ? L.ring[l] : L.glob[l]; m0[l] = F.mod[(q0[l] & 0xffff) + (q0[l] >> 16) * F.w]; }
-    });
     double x = 0, y = 0, sum = 0;
     for (int b = 0; b < n; b += 64) {
         PerLane<double> xw, yw, wg;
         W::each([&](int l) {
             const int idx = b + l;
             xw[l] = 0; yw[l] = 0; wg[l] = 0;
-            if (idx < n) { const int q = b == 0 ? q0[l] : L.glob[idx], qx = q & 0xffff, qy = q >> 16; const double m = b == 0 ? m0[l] : F.mod[qx + qy * F.w]; wg[l] = m; xw[l] = double(qx) * m; yw[l] = double(qy) * m; }
+            if (idx < n) { const int q = L.glob[idx], qx = q & 0xffff, qy = q >> 16; const double m = F.mod[qx + qy * F.w]; wg[l] = m; xw[l] = double(qx) * m; yw[l] = double(qy) * m; }
         });
-        // in list order, sixteen lanes at a time with constant lane numbers (the lanes past the end hold +0.0, which changes no sum)
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-        for (int g = 0; g < 64; g += 16) {
-            if (b + g >= n) break;
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-            for (int j = 0; j < 16; j++) { x += W::bc(xw, g + j); y += W::bc(yw, g + j); sum += W::bc(wg, g + j); }
-        }
+        const int cnt = n - b < 64 ? n - b : 64;
+        for (int j = 0; j < cnt; j++) { x += W::bc(xw, j); y += W::bc(yw, j); sum += W::bc(wg, j); }
     }
     x /= sum; y /= sum;
     double Ixx = 0, Iyy = 0, Ixy = 0;
@@ -306,18 +288,10 @@ template <class W> RGS_FN void to_rect(const Frame &F, const List &L, int n, dou
         W::each([&](int l) {
             const int idx = b + l;
             t1[l] = 0; t2[l] = 0; t3[l] = 0;
-            if (idx < n) { const int q = b == 0 ? q0[l] : L.glob[idx], qx = q & 0xffff, qy = q >> 16; const double m = b == 0 ? m0[l] : F.mod[qx + qy * F.w], dx = double(qx) - x, dy = double(qy) - y; t1[l] = dy * dy * m; t2[l] = dx * dx * m; t3[l] = dx * dy * m; }
+            if (idx < n) { const int q = L.glob[idx], qx = q & 0xffff, qy = q >> 16; const double m = F.mod[qx + qy * F.w], dx = double(qx) - x, dy = double(qy) - y; t1[l] = dy * dy * m; t2[l] = dx * dx * m; t3[l] = dx * dy * m; }
         });
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-        for (int g = 0; g < 64; g += 16) {
-            if (b + g >= n) break;
-#if defined(__HIP_DEVICE_COMPILE__)
-#pragma unroll
-#endif
-            for (int j = 0; j < 16; j++) { Ixx += W::bc(t1, g + j); Iyy += W::bc(t2, g + j); Ixy -= W::bc(t3, g + j); }
-        }
+        const int cnt = n - b < 64 ? n - b : 64;
+        for (int j = 0; j < cnt; j++) { Ixx += W::bc(t1, j); Iyy += W::bc(t2, j); Ixy -= W::bc(t3, j); }
     }
     const double lambda = 0.5 * (Ixx + Iyy - sqrt((Ixx - Iyy) * (Ixx - Iyy) + 4.0 * Ixy * Ixy));
     double theta = (fabs(Ixx) > fabs(Iyy)) ? double(rg::fast_atan2(float(lambda - Ixx), float(Ixy))) : double(rg::fast_atan2(float(Ixy), float(lambda - Iyy)));
@@ -331,7 +305,7 @@ template <class W> RGS_FN void to_rect(const Frame &F, const List &L, int n, dou
         W::each([&](int l) {
             const int idx = b + l;
             if (idx < n) {
-                const int q = b == 0 ? q0[l] : L.glob[idx];
+                const int q = L.glob[idx];
                 const double rdx = double(q & 0xffff) - x, rdy = double(q >> 16) - y, ll = rdx * dx + rdy * dy, ww = -rdx * dy + rdy * dx;
                 if (ll > lmx[l]) lmx[l] = ll;
                 if (ll < lmn[l]) lmn[l] = ll;
@@ -392,7 +366,6 @@ template <class W> RGS_FN bool refine(const Frame &F, Wins &V, List &L, int &n, 
                 const int last = W::uni(L.glob[n - 1]);
                 W::each([&](int l) { if (l == 0) { Px *px = &F.pix[xy_addr(q, F.w)]; st_free(px, px->deg); L.glob[i] = last; L.glob[n - 1] = q; } });
                 W::sync();
-                L.ring_ok = false;
                 --n; --i;
             }
         }

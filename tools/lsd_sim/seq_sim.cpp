@@ -58,7 +58,7 @@ int main(int argc, char **argv) {
         if (alone) caddr[i] |= (int)0x80000000;
     }
     vector<int> status(4, 0), Lglob(rgs::CAP);
-    rgs::List Llist; Llist.glob = Lglob.data(); Llist.ring_ok = false;
+    rgs::List Llist; Llist.glob = Lglob.data();
     vector<double> rect((size_t)12 * ne); int cand_cnt = 0;
     rgs::Frame F;
     F.w = w; F.h = h; F.ne = ne; F.caddr = caddr.data(); F.pix = pix.data(); F.mod = L.modgrad.data(); F.seed_cs = seed_cs.data(); F.rect = rect.data(); F.cand_cap = ne; F.cand_cnt = &cand_cnt;
