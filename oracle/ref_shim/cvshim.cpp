@@ -87,7 +87,14 @@ void GaussianBlur(InputArray _src, OutputArray _dst, Size ksize, double sigmaX, 
     CV_Assert((borderType & ~BORDER_ISOLATED) == BORDER_REFLECT_101 && src.channels() == 1 && (sigmaY == 0 || sigmaY == sigmaX));
     _dst.create(src.size(), src.type());
     Mat dst = _dst.getMat();
-    if (src.depth() == CV_8U) {
+    if (src.depth() == CV_8U && ksize.width == 5) { // BinaryDescriptor::computeGaussianPyramid (binary_descriptor.cpp:359): 5 x 5, sigma 1, 8-bit fixed point
+        CV_Assert(ksize.height == 5 && sigmaX == 1);
+        const std::vector<uchar> s = packed_u8(src);
+        std::vector<uchar> d(s.size());
+        std::vector<int16_t> gx(s.size()), gy(s.size());
+        orc_lbd_maps(s.data(), src.cols, src.rows, d.data(), gx.data(), gy.data());
+        for (int r = 0; r < src.rows; r++) std::memcpy(dst.ptr(r), d.data() + (size_t)r * src.cols, src.cols);
+    } else if (src.depth() == CV_8U) {
         CV_Assert(ksize.width == 7 && ksize.height == 7 && sigmaX == 2);
         const std::vector<uchar> s = packed_u8(src);
         std::vector<uchar> d(s.size());
@@ -96,6 +103,27 @@ void GaussianBlur(InputArray _src, OutputArray _dst, Size ksize, double sigmaX, 
     } else {
         CV_Assert(src.depth() == CV_64F && src.isContinuous() && dst.isContinuous() && ksize.width == ksize.height);
         orc_cv::gaussian_blur_f64(src.ptr<double>(), src.cols, src.rows, ksize.width, sigmaX, dst.ptr<double>());
+    }
+}
+// cv::Sobel as BinaryDescriptor::computeSobel calls it (binary_descriptor.cpp:396-397): 8-bit source, CV_16S result, 3 x 3, first derivative in x or
+// y -- the separable kernels [-1 0 1] and [1 2 1], no scaling, BORDER_REFLECT_101.  Written from the definition (the oracle's own maps come from
+// lbd_oracle.cpp; tests/test_ref_pins.py has the two agree).
+void Sobel(InputArray _src, OutputArray _dst, int ddepth, int dx, int dy, int ksize, double scale, double delta, int borderType) {
+    const Mat src = _src.getMat().clone();
+    CV_Assert(src.type() == CV_8UC1 && CV_MAT_DEPTH(ddepth) == CV_16S && ksize == 3 && scale == 1 && delta == 0 && dx + dy == 1 && (borderType & ~BORDER_ISOLATED) == BORDER_REFLECT_101);
+    _dst.create(src.rows, src.cols, CV_16SC1);
+    Mat dst = _dst.getMat();
+    const std::vector<uchar> s = packed_u8(src);
+    const int W = src.cols, H = src.rows;
+    for (int y = 0; y < H; y++) {
+        const int ym = orc_cv::reflect101(y - 1, H), yp = orc_cv::reflect101(y + 1, H);
+        for (int x = 0; x < W; x++) {
+            const int xm = orc_cv::reflect101(x - 1, W), xp = orc_cv::reflect101(x + 1, W);
+            auto px = [&](int yy, int xx) { return (int)s[(size_t)yy * W + xx]; };
+            const int v = dx ? (px(ym, xp) - px(ym, xm)) + 2 * (px(y, xp) - px(y, xm)) + (px(yp, xp) - px(yp, xm))
+                             : (px(yp, xm) - px(ym, xm)) + 2 * (px(yp, x) - px(ym, x)) + (px(yp, xp) - px(ym, xp));
+            dst.at<short>(y, x) = (short)v;
+        }
     }
 }
 void copyMakeBorder(InputArray _src, OutputArray _dst, int top, int bottom, int left, int right, int borderType, const Scalar &) {

@@ -297,6 +297,7 @@ void cvtColor(InputArray src, OutputArray dst, int code, int dstCn = 0);
 void Canny(InputArray image, OutputArray edges, double threshold1, double threshold2, int apertureSize = 3, bool L2gradient = false);
 void distanceTransform(InputArray src, OutputArray dst, int distanceType, int maskSize, int dstType = CV_32F);
 void pyrDown(InputArray src, OutputArray dst, const Size &dstsize = Size(), int borderType = BORDER_DEFAULT);
+void Sobel(InputArray src, OutputArray dst, int ddepth, int dx, int dy, int ksize = 3, double scale = 1, double delta = 0, int borderType = BORDER_DEFAULT);
 void merge(const std::vector<Mat> &mv, OutputArray dst);      // drawing helpers of lsd.cpp: never called, declared so the file compiles
 void bitwise_xor(InputArray a, InputArray b, OutputArray dst);
 int countNonZero(InputArray a);

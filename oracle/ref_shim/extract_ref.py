@@ -26,6 +26,13 @@ WANT = [  # (file, signatures, output include)
                                                "Eigen::Matrix<T, Eigen::Dynamic, Eigen::Dynamic> homo_to_real_coord(const Eigen::Matrix<T, Eigen::Dynamic, Eigen::Dynamic> &pts_homo_in)"], "extracted_g2o_utils.inc"),
     # ... and the free / out-of-line functions of g2o_Object.cpp that need nothing but SE3Quat and fixed-size vectors
     ("orb_object_slam/src/g2o_Object.cpp", ["SE3Quat exptwist_norollpitch(const Vector6d &update)", "Vector3d cuboid::point_boundary_error("], "extracted_g2o_cpp.inc"),
+    # the LBD descriptor: BinaryDescriptor's compute path (the rest of binary_descriptor.cpp is the EDLine detector, which CubeSLAM does not use)
+    ("line_lbd/libs/binary_descriptor.cpp", ["static const int combinations[32][2] =", "BinaryDescriptor::Params::Params()", "BinaryDescriptor::BinaryDescriptor( const BinaryDescriptor::Params &parameters ) :",
+                                             "BinaryDescriptor::~BinaryDescriptor()", "static inline int get2Pow( int i )", "void BinaryDescriptor::computeGaussianPyramid( const Mat& image, const int numOctaves )",
+                                             "void BinaryDescriptor::computeSobel( const cv::Mat& image, const int numOctaves )", "unsigned char BinaryDescriptor::binaryConversion( float* f1, float* f2 )",
+                                             "void BinaryDescriptor::compute( const Mat& image, CV_OUT CV_IN_OUT std::vector<KeyLine>& keylines, CV_OUT Mat& descriptors,",
+                                             "void BinaryDescriptor::computeImpl( const Mat& imageSrc, std::vector<KeyLine>& keylines, Mat& descriptors, bool returnFloatDescr,",
+                                             "int BinaryDescriptor::computeLBD( ScaleLines &keyLines, bool useDetectionData )"], "extracted_lbd.inc"),
 ]
 
 
@@ -53,7 +60,7 @@ for rel, sigs, dst in WANT:
     out = outs.setdefault(dst, ["// generated by oracle/ref_shim/extract_ref.py from %s -- not tracked" % REF])
     for s in sigs:
         out.append("// ---- %s : %s" % (rel, s))
-        out.append(cut(text, s))
+        out.append(cut(text, s) + (";" if s.rstrip().endswith("=") else ""))
 os.makedirs(OUT, exist_ok=True)
 for dst, out in outs.items():
     open(os.path.join(OUT, dst), "w").write("\n".join(out) + "\n")

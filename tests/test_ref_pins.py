@@ -85,6 +85,43 @@ def test_lsd_equals_reference(ref, oracle):
     assert total > 300
 
 
+def test_lbd_descriptor_equals_reference(ref, oracle):
+    """BinaryDescriptor's compute path -- the band weights of its constructor, computeGaussianPyramid, computeSobel, computeImpl (KeyLine -> ScaleLines,
+    the 32 byte comparisons), computeLBD, binaryConversion (line_lbd/libs/binary_descriptor.cpp:218-260, 352-416, 588-790, 1146-1509) -- cut out of
+    the reference at build time and compiled against the class declaration of its own header: the descriptors of every line the detector finds,
+    byte for byte.  (cv::GaussianBlur and cv::Sobel under it are the OpenCV stand-in's: the blur is the oracle's own, the Sobel is written from the definition
+    independently of the oracle's -- equal descriptors mean the two agree.)"""
+    total = 0
+    for name, gray in _images():
+        gray = np.ascontiguousarray(gray, np.uint8)
+        H, W = gray.shape
+        kl = oracle.lsd_detect(gray)
+        n = len(kl)
+        assert n > 0
+        want = np.zeros((n, 32), np.uint8)
+        got_n = ref.ref_lbd_compute(gray.ctypes.data_as(C.c_void_p), W, H, np.ascontiguousarray(kl).ctypes.data_as(C.c_void_p), n, want.ctypes.data_as(C.c_void_p))
+        assert got_n == n, (name, got_n, n)
+        have = oracle.lbd_compute(gray, kl)
+        assert np.array_equal(have, want), (name, int((have != want).any(axis=1).sum()), n)
+        assert len(np.unique(want, axis=0)) > n // 2  # (not all the same bytes)
+        total += n
+    assert total > 300
+    # lines that leave the image: the support region is cut at the border (computeLBD :1253-1290)
+    gray = np.ascontiguousarray(synth.texture_image(3, 640, 480), np.uint8)
+    kl = oracle.lsd_detect(gray)[:8].copy()
+    for i, (sx, sy, ex, ey) in enumerate([(1, 1, 60, 3), (630, 2, 638, 470), (5, 476, 300, 478), (0, 0, 639, 479), (320, 1, 321, 60), (2, 200, 2, 300), (637, 10, 600, 90), (10, 470, 90, 478)]):
+        for a, b in (("startPointX", sx), ("startPointY", sy), ("endPointX", ex), ("endPointY", ey), ("sPointInOctaveX", sx), ("sPointInOctaveY", sy), ("ePointInOctaveX", ex), ("ePointInOctaveY", ey)):
+            kl[a][i] = b
+        kl["lineLength"][i] = np.hypot(ex - sx, ey - sy); kl["class_id"][i] = i
+        kl["angle"][i] = np.arctan2(ey - sy, ex - sx)
+    want = np.zeros((8, 32), np.uint8)
+    assert ref.ref_lbd_compute(gray.ctypes.data_as(C.c_void_p), 640, 480, kl.ctypes.data_as(C.c_void_p), 8, want.ctypes.data_as(C.c_void_p)) == 8
+    assert np.array_equal(oracle.lbd_compute(gray, kl), want)
+    wl, wg = np.zeros(21), np.zeros(63)
+    ref.ref_lbd_weights(wl.ctypes.data_as(C.c_void_p), wg.ctypes.data_as(C.c_void_p))
+    assert wl.max() <= 1.0 and wl[10] == 1.0 and wg[31] == 1.0 and np.all(np.diff(wg[:32]) > 0)
+
+
 def _dp(a):
     return a.ctypes.data_as(C.c_void_p)
 
