@@ -1,6 +1,8 @@
 /*
  * oracle/lbd_oracle.cpp -- CPU oracle for the LBD line descriptor of line_lbd.
- * TEST INFRASTRUCTURE ONLY (see oracle.h).  PARITY UNPINNED.  Restated from /root/reference/line_lbd/libs/binary_descriptor.cpp
+ * TEST INFRASTRUCTURE ONLY (see oracle.h).  Pinned: tests/test_ref_pins.py::test_lbd_descriptor_equals_reference compares its descriptors byte for
+ * byte with the reference's own compute path (oracle/_ref, cut out of binary_descriptor.cpp at build time); the two OpenCV primitives under it
+ * (GaussianBlur, Sobel) stay restated.  Restated from /root/reference/line_lbd/libs/binary_descriptor.cpp
  * (constructor weights :218-260, computeGaussianPyramid :352-370, computeSobel :373-402, binaryConversion :405-416,
  * computeImpl :603-790, computeLBD :1146-1509).  OpenCV semantics assumed: GaussianBlur 5x5 sigma 1 on u8 in 8-bit fixed point
  * (as for ORB, see orb_oracle.cpp), Sobel 3x3 -> CV_16S with BORDER_REFLECT_101.  cos/sin of the float line direction are
