@@ -188,6 +188,7 @@ public:
     template <typename T> const T &at(int i) const { return rows == 1 ? ((const T *)data)[i] : *(const T *)(data + (size_t)i * step); }
     Mat operator()(const Rect &r) const { return Mat(*this, r); }
     Mat clone() const { Mat m; copyTo(m); return m; }
+    Mat t() const { Mat m(cols, rows, flags_type); for (int r = 0; r < rows; r++) for (int c = 0; c < cols; c++) std::memcpy(m.data + (size_t)c * m.step + (size_t)r * elemSize(), data + (size_t)r * step + (size_t)c * elemSize(), elemSize()); return m; } // (a copy: the few callers only read it)
     void copyTo(Mat &m) const {
         m.create(rows, cols, flags_type);
         for (int r = 0; r < rows; r++) std::memmove(m.data + (size_t)r * m.step, data + (size_t)r * step, (size_t)cols * elemSize());

@@ -26,6 +26,14 @@ WANT = [  # (file, signatures, output include)
                                                "Eigen::Matrix<T, Eigen::Dynamic, Eigen::Dynamic> homo_to_real_coord(const Eigen::Matrix<T, Eigen::Dynamic, Eigen::Dynamic> &pts_homo_in)"], "extracted_g2o_utils.inc"),
     # ... and the free / out-of-line functions of g2o_Object.cpp that need nothing but SE3Quat and fixed-size vectors
     ("orb_object_slam/src/g2o_Object.cpp", ["SE3Quat exptwist_norollpitch(const Vector6d &update)", "Vector3d cuboid::point_boundary_error("], "extracted_g2o_cpp.inc"),
+    # the ORB matcher's three window searches with what they call, and the Frame grid they search (compiled against stand-ins for Frame / MapPoint, ref_match_api.cpp)
+    ("orb_object_slam/src/ORBmatcher.cc", ["const int ORBmatcher::TH_HIGH = 100;", "const int ORBmatcher::TH_LOW = 50;", "const int ORBmatcher::HISTO_LENGTH = 30;",
+                                           "int ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint *> &vpMapPoints, const float th)", "float ORBmatcher::RadiusByViewingCos(const float &viewCos)",
+                                           "int ORBmatcher::SearchForInitialization(Frame &F1, Frame &F2, vector<cv::Point2f> &vbPrevMatched, vector<int> &vnMatches12, int windowSize)",
+                                           "int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono)",
+                                           "void ORBmatcher::ComputeThreeMaxima(", "int ORBmatcher::DescriptorDistance("], "extracted_match.inc"),
+    ("orb_object_slam/src/Frame.cc", ["void Frame::AssignFeaturesToGrid()", "vector<size_t> Frame::GetFeaturesInArea(const float &x, const float &y, const float &r, const int minLevel, const int maxLevel) const",
+                                      "bool Frame::PosInGrid(const cv::KeyPoint &kp, int &posX, int &posY)"], "extracted_match.inc"),
     # the LBD descriptor: BinaryDescriptor's compute path (the rest of binary_descriptor.cpp is the EDLine detector, which CubeSLAM does not use)
     ("line_lbd/libs/binary_descriptor.cpp", ["static const int combinations[32][2] =", "BinaryDescriptor::Params::Params()", "BinaryDescriptor::BinaryDescriptor( const BinaryDescriptor::Params &parameters ) :",
                                              "BinaryDescriptor::~BinaryDescriptor()", "static inline int get2Pow( int i )", "void BinaryDescriptor::computeGaussianPyramid( const Mat& image, const int numOctaves )",
@@ -38,6 +46,8 @@ WANT = [  # (file, signatures, output include)
 
 def cut(text, sig):
     i = text.index(sig)
+    if sig.endswith(";"):  # a one-line definition
+        return sig
     start = text.rfind("\n", 0, i) + 1
     if text[max(0, start - 20):start].strip().startswith("template") or text[text.rfind("\n", 0, start - 1) + 1:start].startswith("template"):
         start = text.rfind("\n", 0, start - 1) + 1  # keep the `template <class T>` line

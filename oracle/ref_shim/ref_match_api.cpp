@@ -1,0 +1,196 @@
+// TEST INFRASTRUCTURE (never linked into the product): the reference's ORB matcher searches -- ORBmatcher::SearchByProjection(Frame&, const Frame&)
+// (orb_object_slam/src/ORBmatcher.cc:1373-1522), SearchByProjection(Frame&, vector<MapPoint*>) (:50-142), SearchForInitialization (:429-542) with
+// RadiusByViewingCos, ComputeThreeMaxima, DescriptorDistance and the constants they use, and Frame::GetFeaturesInArea / PosInGrid /
+// AssignFeaturesToGrid (src/Frame.cc:303-318, 404-459, 525-535) -- cut out of the reference at build time (oracle/_ref/extracted_match.inc) and
+// compiled against stand-ins for the SLAM classes they touch.  The reference's headers pull in DBoW2, g2o, Eigen and the whole map, so Frame,
+// MapPoint and the ORBmatcher declaration below carry just the members those functions read, under the reference's names; every statement of the
+// searches themselves is the reference's.  tests/test_ref_pins.py runs them next to the oracle's restatement on the same inputs.
+#include <climits>
+#include <cmath>
+#include <cstring>
+#include <map>
+#include <vector>
+
+#include "cvshim.hpp"
+#include "../oracle.h"
+
+// ---- float matrices the way cv::MatExpr evaluates them: A * B (+ C) is one gemm with double accumulation and a single rounding to float
+namespace cv {
+struct MulExpr {
+    Mat a, b; double alpha;
+    Mat eval(const Mat *c) const {
+        Mat r(a.rows, b.cols, CV_32F);
+        for (int i = 0; i < a.rows; i++) for (int j = 0; j < b.cols; j++) {
+            double s = 0;
+            for (int k = 0; k < a.cols; k++) s += (double)a.at<float>(i, k) * (double)b.at<float>(k, j);
+            r.at<float>(i, j) = (float)(s * alpha + (c ? (double)c->at<float>(i, j) * 1.0 : 0.0));
+        }
+        return r;
+    }
+    operator Mat() const { return eval(nullptr); }
+};
+struct NegExpr { Mat m; };
+inline MulExpr operator*(const Mat &a, const Mat &b) { return MulExpr{a, b, 1.0}; }
+inline MulExpr operator*(const NegExpr &a, const Mat &b) { return MulExpr{a.m, b, -1.0}; }
+inline Mat operator+(const MulExpr &e, const Mat &c) { return e.eval(&c); }
+inline NegExpr operator-(const Mat &m) { return NegExpr{m}; }
+} // namespace cv
+
+namespace ORB_SLAM2_m { // (its own namespace: ref_extract_api.cpp holds another stand-in ORBmatcher for the two primitives)
+#define FRAME_GRID_ROWS 48 // Frame.h:32-33
+#define FRAME_GRID_COLS 64
+
+class MapPoint {
+  public:
+    bool is_dynamic = false, mbTrackInView = false, bad = false;
+    int mnTrackScaleLevel = 0, nobs = 0;
+    float mTrackViewCos = 0, mTrackProjX = 0, mTrackProjY = 0, mTrackProjXR = 0;
+    cv::Mat pos, desc;
+    cv::Mat GetWorldPos() { return pos.clone(); }
+    cv::Mat GetDescriptor() { return desc.clone(); }
+    int Observations() { return nobs; }
+    bool isBad() { return bad; }
+};
+class Frame {
+  public:
+    cv::Mat mTcw;
+    float mb = 0, mbf = 0, fx = 0, fy = 0, cx = 0, cy = 0, mnMinX = 0, mnMaxX = 0, mnMinY = 0, mnMaxY = 0, mfGridElementWidthInv = 0, mfGridElementHeightInv = 0;
+    int N = 0;
+    std::vector<MapPoint *> mvpMapPoints;
+    std::vector<bool> mvbOutlier, KeysStatic;
+    std::vector<cv::KeyPoint> mvKeys, mvKeysUn;
+    std::vector<float> mvScaleFactors, mvuRight;
+    cv::Mat mDescriptors;
+    std::vector<std::size_t> mGrid[FRAME_GRID_COLS][FRAME_GRID_ROWS];
+    void AssignFeaturesToGrid();
+    std::vector<size_t> GetFeaturesInArea(const float &x, const float &y, const float &r, const int minLevel = -1, const int maxLevel = -1) const;
+    bool PosInGrid(const cv::KeyPoint &kp, int &posX, int &posY);
+};
+class ORBmatcher {
+  public:
+    ORBmatcher(float nnratio = 0.6, bool checkOri = true) : mfNNratio(nnratio), mbCheckOrientation(checkOri) {}
+    static int DescriptorDistance(const cv::Mat &a, const cv::Mat &b);
+    int SearchByProjection(Frame &F, const std::vector<MapPoint *> &vpMapPoints, const float th = 3);
+    int SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono);
+    int SearchForInitialization(Frame &F1, Frame &F2, std::vector<cv::Point2f> &vbPrevMatched, std::vector<int> &vnMatches12, int windowSize = 10);
+    static const int TH_LOW, TH_HIGH, HISTO_LENGTH;
+  protected:
+    float RadiusByViewingCos(const float &viewCos);
+    void ComputeThreeMaxima(std::vector<int> *histo, const int L, int &ind1, int &ind2, int &ind3);
+    float mfNNratio;
+    bool mbCheckOrientation;
+};
+using namespace std;
+} // namespace ORB_SLAM2_m
+
+
+namespace ORB_SLAM2_m { // (its own namespace: ref_extract_api.cpp holds another stand-in ORBmatcher for the two primitives)
+#include "extracted_match.inc"
+} // namespace ORB_SLAM2_m
+
+namespace {
+using ORB_SLAM2_m::Frame; using ORB_SLAM2_m::MapPoint; using ORB_SLAM2_m::ORBmatcher;
+void fill_frame(Frame &F, const orc_frame *f, const float *scale_factors, int n_levels) {
+    F.N = f->N;
+    F.mnMinX = f->minX; F.mnMaxX = f->maxX; F.mnMinY = f->minY; F.mnMaxY = f->maxY;
+    F.mfGridElementWidthInv = static_cast<float>(FRAME_GRID_COLS) / (F.mnMaxX - F.mnMinX);   // Frame.cc:128-129
+    F.mfGridElementHeightInv = static_cast<float>(FRAME_GRID_ROWS) / (F.mnMaxY - F.mnMinY);
+    F.mvKeysUn.resize(f->N);
+    for (int i = 0; i < f->N; i++) { const orc_keypoint &k = f->keysUn[i]; F.mvKeysUn[i] = cv::KeyPoint(k.x, k.y, k.size, k.angle, k.response, k.octave, k.class_id); }
+    F.mvKeys = F.mvKeysUn;
+    F.mDescriptors = cv::Mat(f->N, 32, CV_8UC1);
+    for (int i = 0; i < f->N; i++) std::memcpy(F.mDescriptors.ptr<uchar>(i), f->desc + (size_t)i * 32, 32);
+    F.mvpMapPoints.assign(f->N, nullptr);
+    F.mvbOutlier.assign(f->N, false);
+    F.mvuRight.assign(f->N, -1.0f); // monocular
+    if (scale_factors) F.mvScaleFactors.assign(scale_factors, scale_factors + n_levels);
+    F.AssignFeaturesToGrid();
+}
+cv::Mat desc_row(const uint8_t *d) { cv::Mat m(1, 32, CV_8UC1); std::memcpy(m.ptr<uchar>(0), d, 32); return m; }
+// keypoints that may not be matched: the odd ones are not static (KeysStatic, which GetFeaturesInArea drops too), the even ones hold a map point with observations
+void block_train(Frame &F, const uint8_t *train_blocked, std::vector<MapPoint> &holders) {
+    if (!train_blocked) return;
+    bool any_static = false;
+    for (int i = 0; i < F.N; i++) if (train_blocked[i] && (i & 1)) any_static = true;
+    if (any_static) F.KeysStatic.assign(F.N, true);
+    holders.resize(F.N);
+    for (int i = 0; i < F.N; i++) if (train_blocked[i]) {
+        if (i & 1) F.KeysStatic[i] = false;
+        else { holders[i].nobs = 1; F.mvpMapPoints[i] = &holders[i]; }
+    }
+}
+} // namespace
+
+extern "C" {
+int ref_get_features_in_area(const orc_frame *f, float x, float y, float r, int minLevel, int maxLevel, int *out, int cap) {
+    Frame F; fill_frame(F, f, nullptr, 0);
+    const std::vector<size_t> v = F.GetFeaturesInArea(x, y, r, minLevel, maxLevel);
+    for (size_t i = 0; i < v.size() && (int)i < cap; i++) out[i] = (int)v[i];
+    return (int)v.size();
+}
+// the arguments of orc_search_by_projection_frame (oracle.h); bMono = true
+int ref_search_by_projection_frame(const orc_frame *cur, int n_last, const float *world_pos, const uint8_t *valid, const uint8_t *blocks, const uint8_t *mp_desc,
+                                   const int *last_octave, const float *last_angle, const float *Tcw12, float fx, float fy, float cx, float cy, const float *scale_factors,
+                                   int n_levels, float th, int check_orientation, const uint8_t *train_blocked, int *train_match) {
+    Frame C; fill_frame(C, cur, scale_factors, n_levels);
+    C.fx = fx; C.fy = fy; C.cx = cx; C.cy = cy; C.mb = 0.1f; C.mbf = 40.f;
+    C.mTcw = cv::Mat(4, 4, CV_32F);
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 4; j++) C.mTcw.at<float>(i, j) = Tcw12[i * 4 + j];
+    C.mTcw.at<float>(3, 0) = 0; C.mTcw.at<float>(3, 1) = 0; C.mTcw.at<float>(3, 2) = 0; C.mTcw.at<float>(3, 3) = 1;
+    std::vector<MapPoint> holders;
+    block_train(C, train_blocked, holders);
+    Frame L;
+    L.N = n_last; L.mTcw = C.mTcw.clone();
+    L.mvKeys.resize(n_last); L.mvKeysUn.resize(n_last); L.mvpMapPoints.assign(n_last, nullptr); L.mvbOutlier.assign(n_last, false);
+    std::vector<MapPoint> pts(n_last);
+    for (int i = 0; i < n_last; i++) {
+        L.mvKeys[i].octave = last_octave[i]; L.mvKeysUn[i].octave = last_octave[i]; L.mvKeys[i].angle = last_angle[i]; L.mvKeysUn[i].angle = last_angle[i];
+        MapPoint &p = pts[i];
+        p.pos = cv::Mat(3, 1, CV_32F); for (int k = 0; k < 3; k++) p.pos.at<float>(k) = world_pos[i * 3 + k];
+        p.desc = desc_row(mp_desc + (size_t)i * 32); p.nobs = blocks[i] ? 1 : 0;
+        L.mvpMapPoints[i] = &p;
+        if (!valid[i]) { // the three ways a last-frame feature drops out (:1399-1405)
+            if (i % 3 == 0) L.mvpMapPoints[i] = nullptr; else if (i % 3 == 1) L.mvbOutlier[i] = true; else p.is_dynamic = true;
+        }
+    }
+    ORBmatcher m(0.9f, check_orientation != 0);
+    const int n = m.SearchByProjection(C, L, th, true);
+    for (int i = 0; i < C.N; i++) {
+        MapPoint *p = C.mvpMapPoints[i];
+        train_match[i] = (p && p >= pts.data() && p < pts.data() + n_last) ? (int)(p - pts.data()) : -1;
+    }
+    return n;
+}
+// the arguments of orc_search_local_map
+int ref_search_local_map(const orc_frame *f, int n_mp, const float *proj_xy, const float *view_cos, const int *pred_level, const uint8_t *in_view, const uint8_t *blocks,
+                         const uint8_t *mp_desc, const float *scale_factors, int n_levels, float th, float nnratio, const uint8_t *train_blocked, int *train_match) {
+    Frame F; fill_frame(F, f, scale_factors, n_levels);
+    std::vector<MapPoint> holders;
+    block_train(F, train_blocked, holders);
+    std::vector<MapPoint> pts(n_mp);
+    std::vector<MapPoint *> vp(n_mp);
+    for (int i = 0; i < n_mp; i++) {
+        MapPoint &p = pts[i];
+        p.mbTrackInView = in_view[i] != 0; p.mnTrackScaleLevel = pred_level[i]; p.mTrackViewCos = view_cos[i]; p.mTrackProjX = proj_xy[2 * i]; p.mTrackProjY = proj_xy[2 * i + 1];
+        p.desc = desc_row(mp_desc + (size_t)i * 32); p.nobs = blocks[i] ? 1 : 0;
+        vp[i] = &p;
+    }
+    ORBmatcher m(nnratio, true);
+    const int n = m.SearchByProjection(F, vp, th);
+    for (int i = 0; i < F.N; i++) {
+        MapPoint *p = F.mvpMapPoints[i];
+        train_match[i] = (p && p >= pts.data() && p < pts.data() + n_mp) ? (int)(p - pts.data()) : -1;
+    }
+    return n;
+}
+int ref_search_for_initialization(const orc_frame *f1, const orc_frame *f2, float *prev_matched, int window_size, float nnratio, int check_orientation, int *matches12) {
+    Frame F1, F2; fill_frame(F1, f1, nullptr, 0); fill_frame(F2, f2, nullptr, 0);
+    std::vector<cv::Point2f> prev(f1->N);
+    for (int i = 0; i < f1->N; i++) prev[i] = cv::Point2f(prev_matched[2 * i], prev_matched[2 * i + 1]);
+    std::vector<int> m12;
+    ORBmatcher m(nnratio, check_orientation != 0);
+    const int n = m.SearchForInitialization(F1, F2, prev, m12, window_size);
+    for (int i = 0; i < f1->N; i++) { matches12[i] = m12[i]; prev_matched[2 * i] = prev[i].x; prev_matched[2 * i + 1] = prev[i].y; }
+    return n;
+}
+}

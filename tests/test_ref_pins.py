@@ -122,6 +122,67 @@ def test_lbd_descriptor_equals_reference(ref, oracle):
     assert wl.max() <= 1.0 and wl[10] == 1.0 and wg[31] == 1.0 and np.all(np.diff(wg[:32]) > 0)
 
 
+def test_matcher_searches_equal_reference(ref, oracle):
+    """ORBmatcher::SearchByProjection(Frame&, const Frame&), SearchByProjection(Frame&, vector<MapPoint*>), SearchForInitialization with
+    RadiusByViewingCos / ComputeThreeMaxima / DescriptorDistance and their constants (ORBmatcher.cc:42-44, 50-150, 429-542, 1373-1522, 1860-1921) and
+    Frame::GetFeaturesInArea / PosInGrid / AssignFeaturesToGrid (Frame.cc:303-318, 404-459, 525-535) -- the reference's own text, cut out at build time and
+    compiled against stand-ins for Frame / MapPoint that carry just the members it reads (ref_shim/ref_match_api.cpp): match lists, counts, candidate
+    lists and the updated previous-match points equal the oracle's exactly.  The drop-outs of a last-frame feature (no map point, outlier, dynamic)
+    and of a current-frame key point (holds a map point with observations, not static) go through the reference's own tests."""
+    import oracle.pyoracle as po
+    Wk, Hk = 1241, 376
+    fx, fy, cx, cy = 721.5377, 721.5377, 609.5593, 172.854
+    bounds = (0.0, float(Wk), 0.0, float(Hk))
+    SF = (np.float32(1.2) ** np.arange(8, dtype=np.float32)).astype(np.float32)
+    e = oracle.ORBextractor(2000, 1.2, 8, 20, 7)
+    (k1, d1), (k2, d2) = [e(synth.texture_image(77, Wk, Hk, shift=4 * i)) for i in range(2)]
+    F1, F2 = oracle.make_frame(k1, d1, bounds), oracle.make_frame(k2, d2, bounds)
+    u8, i32, f32 = (lambda a: np.ascontiguousarray(a, np.uint8)), (lambda a: np.ascontiguousarray(a, np.int32)), (lambda a: np.ascontiguousarray(a, np.float32))
+    P = lambda a: None if a is None else a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    rng = np.random.default_rng(2)
+    # GetFeaturesInArea: the candidate lists in the reference's order
+    for _ in range(60):
+        x, y, r = rng.uniform(-50, Wk + 50), rng.uniform(-50, Hk + 50), rng.uniform(1, 120)
+        lv = int(rng.integers(-1, 8))
+        out = np.zeros(len(k2), np.int32)
+        n = ref.ref_get_features_in_area(C.byref(F2), C.c_float(x), C.c_float(y), C.c_float(r), lv - 1, lv + 1, P(out), len(out))
+        assert np.array_equal(out[:n], oracle.get_features_in_area(F2, x, y, r, lv - 1, lv + 1))
+    # SearchByProjection(Frame, Frame)
+    n1 = len(k1)
+    z = rng.uniform(4, 40, n1).astype(np.float32)
+    wp = np.stack([(k1["x"] - cx) / fx * z, (k1["y"] - cy) / fy * z, z], axis=1).astype(np.float32)
+    wp[:, 0] += (-4.0 / fx) * z
+    wp[::50, 2] *= -1  # a few points behind the camera (invzc < 0)
+    Tcw = np.eye(4, dtype=np.float32)[:3].copy(); Tcw[0, 3] = 0.02
+    valid = u8(rng.uniform(size=n1) < 0.85); blocks = u8(rng.uniform(size=n1) < 0.9)
+    for th, ori, blocked in ((15.0, 1, None), (30.0, 1, u8(rng.uniform(size=len(k2)) < 0.3)), (7.0, 0, u8(rng.uniform(size=len(k2)) < 0.1))):
+        want = np.zeros(len(k2), np.int32)
+        nr = ref.ref_search_by_projection_frame(C.byref(F2), n1, P(f32(wp)), P(valid), P(blocks), P(u8(d1)), P(i32(k1["octave"])), P(f32(k1["angle"])), P(f32(Tcw)),
+                                                C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy), P(SF), len(SF), C.c_float(th), ori, P(blocked), P(want))
+        got, ng = po.search_by_projection_frame(F2, wp, valid, blocks, d1, k1["octave"], k1["angle"], Tcw, fx, fy, cx, cy, SF, th, check_ori=bool(ori), train_blocked=blocked)
+        assert ng == nr and np.array_equal(got, want), (th, ori, ng, nr, int((got != want).sum()))
+        assert ng > 200
+    # SearchByProjection(Frame, map points)
+    proj = np.stack([k1["x"] - 4 + rng.normal(0, 1, n1), k1["y"] + rng.normal(0, 1, n1)], axis=1).astype(np.float32)
+    view_cos = f32(rng.uniform(0.99, 1.0, n1)); in_view = u8(rng.uniform(size=n1) < 0.9); blk = u8(rng.uniform(size=n1) < 0.9)
+    tb = u8(rng.uniform(size=len(k2)) < 0.2)
+    for th, nnratio, tblocked in ((1.0, 0.8, tb), (3.0, 0.8, tb), (3.0, 0.6, None)):
+        want = np.zeros(len(k2), np.int32)
+        nr = ref.ref_search_local_map(C.byref(F2), n1, P(proj), P(view_cos), P(i32(k1["octave"])), P(in_view), P(blk), P(u8(d1)), P(SF), len(SF), C.c_float(th), C.c_float(nnratio),
+                                      P(tblocked), P(want))
+        got, ng = po.search_local_map(F2, proj, view_cos, k1["octave"], in_view, blk, d1, SF, th, nnratio, tblocked)
+        assert ng == nr and np.array_equal(got, want), (th, nnratio, ng, nr)
+        assert ng > 100
+    # SearchForInitialization
+    for window, nnratio, ori in ((100, 0.9, 1), (30, 0.7, 0)):
+        prev0 = np.stack([k1["x"], k1["y"]], axis=1).astype(np.float32)
+        prev = prev0.copy(); want = np.zeros(n1, np.int32)
+        nr = ref.ref_search_for_initialization(C.byref(F1), C.byref(F2), P(prev), window, C.c_float(nnratio), ori, P(want))
+        got, gprev, ng = po.search_for_initialization(F1, F2, prev0, window, nnratio, bool(ori))
+        assert ng == nr and np.array_equal(got, want) and np.array_equal(gprev, prev), (window, ng, nr)
+        assert ng > 50
+
+
 def _dp(a):
     return a.ctypes.data_as(C.c_void_p)
 
