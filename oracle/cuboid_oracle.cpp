@@ -449,6 +449,47 @@ static void change_2d_corner_to_3d_object(const double *c /*2x8*/, double config
     }
 }
 
+// The geometry helpers above one at a time (test hook: tests/test_ref_pins.py compares each with the reference's own function, oracle/_ref).
+//   0 check_inside_box(pt, lt, rb)                  in: 6            out: 1
+//   1 seg_hit_boundary(ps, pe, seg4)                in: 8            out: 2
+//   2 lineSegmentIntersect(..., infinite_line=true) in: 8            out: 2
+//   3 getVanishingPoints(KinvR 3x3, yaw)            in: 10           out: 6
+//   4 plane_hits_3d(T 4x4, invK 3x3, plane4, px,py) in: 31           out: 3
+//   5 change_2d_corner_to_3d_object(corners 2x8, config id, vp_1_position, yaw, ground plane 4, T 4x4, invK 3x3) in: 48
+//                                                   out: pos 3, rotY, scale 3, box_config_type 2, corners 2D 16 (as doubles), corners 3D 24 = 49
+//   6 VP_support_edge_infos(vps 3x2, thresholds 2, n, mids n x 2, angles n)                                      out: 6
+extern "C" int orc_cuboid_geom(int op, const double *in, double *out) {
+    auto V = [&](int i) { return V2{in[i], in[i + 1]}; };
+    auto M3_ = [&](int o) { M3 m; for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) m.m[i][j] = in[o + i * 3 + j]; return m; };
+    auto M4_ = [&](int o) { M4 m; for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) m.m[i][j] = in[o + i * 4 + j]; return m; };
+    switch (op) {
+    case 0: out[0] = check_inside_box(V(0), V(2), V(4)) ? 1.0 : 0.0; return 0;
+    case 1: { const V2 h = seg_hit_boundary(V(0), V(2), in[4], in[5], in[6], in[7]); out[0] = h.x; out[1] = h.y; return 0; }
+    case 2: { const V2 h = line_intersect_inf(V(0), V(2), V(4), V(6)); out[0] = h.x; out[1] = h.y; return 0; }
+    case 3: { V2 a, b, c; getVanishingPoints(M3_(0), in[9], a, b, c); out[0] = a.x; out[1] = a.y; out[2] = b.x; out[3] = b.y; out[4] = c.x; out[5] = c.y; return 0; }
+    case 4: { const V3 w = plane_hit_3d(M4_(0), M3_(16), V4{{in[25], in[26], in[27], in[28]}}, in[29], in[30]); out[0] = w.v[0]; out[1] = w.v[1]; out[2] = w.v[2]; return 0; }
+    case 5: {
+        orc_cuboid o;
+        std::memset(&o, 0, sizeof o);
+        change_2d_corner_to_3d_object(in, in[16], in[17], in[18], V4{{in[19], in[20], in[21], in[22]}}, M4_(23), M3_(39), o);
+        for (int i = 0; i < 3; i++) { out[i] = o.pos[i]; out[4 + i] = o.scale[i]; }
+        out[3] = o.rotY; out[7] = o.box_config_type[0]; out[8] = o.box_config_type[1];
+        for (int i = 0; i < 16; i++) out[9 + i] = (double)o.box_corners_2d[i];
+        for (int i = 0; i < 24; i++) out[25 + i] = o.box_corners_3d_world[i];
+        return 0;
+    }
+    case 6: {
+        const V2 vps[3] = {V(0), V(2), V(4)};
+        const int n = (int)in[8];
+        std::vector<V2> mid((size_t)n); std::vector<double> ang((size_t)n);
+        for (int i = 0; i < n; i++) { mid[i] = V2{in[9 + 2 * i], in[10 + 2 * i]}; ang[i] = in[9 + 2 * n + i]; }
+        VP_support_edge_infos(vps, mid, ang, in[6], in[7], out);
+        return 0;
+    }
+    }
+    return -1;
+}
+
 // ----------------------------------------------------------------------------- OpenCV imgproc restatements
 // Sobel 3x3 on the parent image (cv::Canny calls cv::Sobel(..., BORDER_REPLICATE) on the ROI *view*, so the
 // filter reads real pixels outside the ROI and replicates only at the image border).

@@ -77,6 +77,8 @@ void orc_canny_roi(const uint8_t *gray, int W, int H, int x0, int y0, int w, int
 void orc_dist_transform_3x3(const uint8_t *src, int w, int h, float *dist);
 
 /* merge_break_lines (object_3d_util.cpp:300-376); out has room for n*4; returns rows */
+/* the geometry helpers of the proposal construction one at a time (test hook, see cuboid_oracle.cpp) */
+int orc_cuboid_geom(int op, const double *in, double *out);
 int orc_merge_break_lines(const double *lines, int n, double dist_thre, double angle_thre_deg,
                           double len_thre, double *out);
 

@@ -26,6 +26,23 @@ WANT = [  # (file, signatures, output include)
                                                "Eigen::Matrix<T, Eigen::Dynamic, Eigen::Dynamic> homo_to_real_coord(const Eigen::Matrix<T, Eigen::Dynamic, Eigen::Dynamic> &pts_homo_in)"], "extracted_g2o_utils.inc"),
     # ... and the free / out-of-line functions of g2o_Object.cpp that need nothing but SE3Quat and fixed-size vectors
     ("orb_object_slam/src/g2o_Object.cpp", ["SE3Quat exptwist_norollpitch(const Vector6d &update)", "Vector3d cuboid::point_boundary_error("], "extracted_g2o_cpp.inc"),
+    # geometry of the cuboid proposals: vanishing points, their supporting edges, the boundary / intersection predicates of the corner construction,
+    # 2D corners -> 3D cuboid (compiled against eigdyn.hpp, ref_geom_api.cpp)
+    ("detect_3d_cuboid/src/matrix_utils.cpp", ["T normalize_to_pi(T angle)",
+                                               "Eigen::Matrix<T, Eigen::Dynamic, Eigen::Dynamic> real_to_homo_coord(const Eigen::Matrix<T, Eigen::Dynamic, Eigen::Dynamic> &pts_in)",
+                                               "Eigen::Matrix<T, Eigen::Dynamic, Eigen::Dynamic> homo_to_real_coord(const Eigen::Matrix<T, Eigen::Dynamic, Eigen::Dynamic> &pts_homo_in)",
+                                               "Eigen::Matrix<T, Eigen::Dynamic, 1> homo_to_real_coord_vec(const Eigen::Matrix<T, Eigen::Dynamic, 1> &pts_homo_in)"], "extracted_geom.inc"),
+    ("detect_3d_cuboid/src/object_3d_util.cpp", ["Matrix4d similarityTransformation(const cuboid &cube_obj)", "Matrix3Xd compute3D_BoxCorner(const cuboid &cube_obj)",
+                                                 "bool check_inside_box(const Vector2d &pt, const Vector2d &box_left_top, const Vector2d &box_right_bottom)",
+                                                 "void smooth_jump_angles(const VectorXd &raw_angles, VectorXd &new_angles)",
+                                                 "Vector2d seg_hit_boundary(const Vector2d &pt_start, const Vector2d &pt_end, const Vector4d &line_segment2)",
+                                                 "Vector2d lineSegmentIntersect(const Vector2d &pt1_start, const Vector2d &pt1_end, const Vector2d &pt2_start, const Vector2d &pt2_end,",
+                                                 "Eigen::MatrixXd VP_support_edge_infos(Eigen::MatrixXd &VPs, Eigen::MatrixXd &edge_mid_pts, Eigen::VectorXd &edge_angles,",
+                                                 "void ray_plane_interact(const MatrixXd &rays, const Eigen::Vector4d &plane, MatrixXd &intersections)",
+                                                 "void plane_hits_3d(const Matrix4d &transToWolrd, const Matrix3d &invK, const Vector4d &plane_sensor, MatrixXd pixels, Matrix3Xd &pts_3d_world)",
+                                                 "Vector4d get_wall_plane_equation(const Vector3d &gnd_seg_pt1, const Vector3d &gnd_seg_pt2)",
+                                                 "void getVanishingPoints(const Matrix3d &KinvR, double yaw_esti, Vector2d &vp_1, Vector2d &vp_2, Vector2d &vp_3)",
+                                                 "void change_2d_corner_to_3d_object(const MatrixXd &box_corners_2d_float, const Vector3d &configs, const Vector4d &ground_plane_sensor,"], "extracted_geom.inc"),
     # the ORB matcher's three window searches with what they call, and the Frame grid they search (compiled against stand-ins for Frame / MapPoint, ref_match_api.cpp)
     ("orb_object_slam/src/ORBmatcher.cc", ["const int ORBmatcher::TH_HIGH = 100;", "const int ORBmatcher::TH_LOW = 50;", "const int ORBmatcher::HISTO_LENGTH = 30;",
                                            "int ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint *> &vpMapPoints, const float th)", "float ORBmatcher::RadiusByViewingCos(const float &viewCos)",

@@ -183,6 +183,89 @@ def test_matcher_searches_equal_reference(ref, oracle):
         assert ng > 50
 
 
+def test_cuboid_geometry_equals_reference(ref, oracle):
+    """The geometry of the cuboid proposals: getVanishingPoints, VP_support_edge_infos (+ smooth_jump_angles, normalize_to_pi), check_inside_box,
+    seg_hit_boundary, lineSegmentIntersect, plane_hits_3d (+ ray_plane_interact, real_to_homo_coord / homo_to_real_coord) and
+    change_2d_corner_to_3d_object (+ get_wall_plane_equation, similarityTransformation, compute3D_BoxCorner) -- object_3d_util.cpp:14-50, 141-145,
+    175-252, 380-425, 566-648 and matrix_utils.cpp, the reference's own text cut out at build time and compiled against a stand-in for Eigen that
+    evaluates in Eigen's coefficient order (ref_shim/eigdyn) -- against the oracle's restatements (cuboid_oracle.cpp): identical doubles (one stated exception: the last bit of the 3D corners)."""
+    import oracle.pyoracle as po
+    olib = po.lib()
+    D = C.POINTER(C.c_double)
+    rng = np.random.default_rng(11)
+
+    def orc(op, vals, n_out):
+        a = np.ascontiguousarray(np.concatenate([np.ravel(v) for v in vals]), np.float64); out = np.zeros(n_out)
+        assert olib.orc_cuboid_geom(op, a.ctypes.data_as(D), out.ctypes.data_as(D)) == 0
+        return out
+
+    def P(a):
+        return np.ascontiguousarray(a, np.float64).ctypes.data_as(D)
+
+    K = np.array([[535.4, 0, 320.1], [0, 539.2, 247.6], [0, 0, 1.0]])
+    invK = np.linalg.inv(K)
+    for it in range(200):
+        # a camera 1-2 m above the ground looking slightly down, as set_cam_pose builds it
+        pitch, roll, yaw_c = rng.uniform(-0.5, -0.05), rng.normal(0, 0.03), rng.uniform(-3, 3)
+        cz, sz, cp, sp, cr, sr = np.cos(yaw_c), np.sin(yaw_c), np.cos(pitch), np.sin(pitch), np.cos(roll), np.sin(roll)
+        Rz = np.array([[cz, -sz, 0], [sz, cz, 0], [0, 0, 1]]); Rx = np.array([[1, 0, 0], [0, cp, -sp], [0, sp, cp]]); Ry = np.array([[cr, 0, sr], [0, 1, 0], [-sr, 0, cr]])
+        R = Rz @ np.array([[0, 0, 1.0], [-1, 0, 0], [0, -1, 0]]) @ Rx @ Ry
+        T = np.eye(4); T[:3, :3] = R; T[:3, 3] = [rng.normal(0, 2), rng.normal(0, 2), rng.uniform(0.8, 2.0)]
+        KinvR = K @ R.T
+        yaw = rng.uniform(-np.pi, np.pi)
+        want = np.zeros(6); ref.ref_vanishing_points(P(KinvR), C.c_double(yaw), want.ctypes.data_as(D))
+        assert np.array_equal(orc(3, [KinvR, [yaw]], 6), want), ("vp", it)
+        # predicates
+        a, b = rng.uniform(0, 640, 2), rng.uniform(0, 480, 2)
+        box = [min(a), min(b), max(a), max(b)]
+        pt = [rng.uniform(-20, 660), rng.uniform(-20, 500)]
+        if it % 7 == 0:
+            pt[0] = box[0]  # on the boundary
+        assert ref.ref_check_inside_box(P(pt), P(box[:2]), P(box[2:])) == int(orc(0, [pt, box[:2], box[2:]], 1)[0])
+        ps, pe = rng.uniform(0, 640, 2), rng.uniform(0, 640, 2)
+        seg = [box[0], box[1], box[2], box[1]] if it % 2 else [box[2], box[1], box[2], box[3]]  # a horizontal / a vertical box side
+        if it % 11 == 0:
+            pe = np.array([ps[0], pe[1]])  # a vertical ray: the division by zero of the reference
+        want2 = np.zeros(2); ref.ref_seg_hit_boundary(P(ps), P(pe), P(seg), want2.ctypes.data_as(D))
+        assert np.array_equal(orc(1, [ps, pe, seg], 2), want2, equal_nan=True), ("seg_hit", it)
+        q = rng.uniform(0, 640, 8)
+        ref.ref_line_segment_intersect(P(q[0:2]), P(q[2:4]), P(q[4:6]), P(q[6:8]), 1, want2.ctypes.data_as(D))
+        assert np.array_equal(orc(2, [q], 2), want2, equal_nan=True), ("intersect", it)
+        # rays onto planes, 2D corners -> cuboid
+        ground = T.T @ np.array([0, 0, 1.0, 0])
+        corners = np.zeros((2, 8))
+        cub_c = np.array([rng.uniform(2, 6), rng.normal(0, 1.0), 0.0])
+        Lh, Wh, Hh, ycub = rng.uniform(0.2, 0.8), rng.uniform(0.2, 0.8), rng.uniform(0.2, 0.8), rng.uniform(-np.pi, np.pi)
+        cam_c = T[:3, 3] + R @ np.array([0, 0, 1.0]) * 0  # noqa: F841
+        body = np.array([[1, 1, -1, -1, 1, 1, -1, -1], [1, -1, -1, 1, 1, -1, -1, 1], [-1, -1, -1, -1, 1, 1, 1, 1.0]])
+        Rc = np.array([[np.cos(ycub), -np.sin(ycub), 0], [np.sin(ycub), np.cos(ycub), 0], [0, 0, 1]])
+        world = (Rc @ (body * np.array([[Lh], [Wh], [Hh]]))) + (T[:3, 3] + R @ np.array([0, 0.3, 4.0]))[:, None]
+        world[2] -= world[2].min()
+        cam = R.T @ (world - T[:3, 3][:, None]); uv = (K @ cam); uv = uv[:2] / uv[2]
+        corners[:, :4] = uv[:, 4:]; corners[:, 4:] = uv[:, :4]  # upper four first, the ground corners in the right columns
+        want3 = np.zeros(3 * 4); ref.ref_plane_hits_3d(P(T), P(invK), P(ground), P(corners[:, 4:]), 4, want3.ctypes.data_as(D))
+        for k in range(4):
+            assert np.array_equal(orc(4, [T, invK, ground, corners[:, 4 + k]], 3), want3.reshape(3, 4)[:, k]), ("plane_hits", it, k)
+        cfg = [float(1 + it % 2), float(1 + (it // 2) % 2), yaw]
+        pos, rotY, scale, cfg2, c2d, c3d = np.zeros(3), C.c_double(), np.zeros(3), np.zeros(2), np.zeros(16, np.int32), np.zeros(24)
+        ref.ref_change_2d_corner_to_3d_object(P(corners), P(cfg), P(ground), P(T), P(invK), pos.ctypes.data_as(D), C.byref(rotY), scale.ctypes.data_as(D), cfg2.ctypes.data_as(D),
+                                              c2d.ctypes.data_as(C.c_void_p), c3d.ctypes.data_as(D))
+        got = orc(5, [corners, cfg, ground, T, invK], 49)
+        assert np.array_equal(got[0:3], pos) and got[3] == rotY.value and np.array_equal(got[4:7], scale) and np.array_equal(got[7:9], cfg2), ("cuboid", it)
+        assert np.array_equal(got[9:25], c2d.astype(np.float64)), ("corners 2D", it)
+        # The 3D corners go through cos / sin of the yaw (similarityTransformation :16-19).  glibc's sincos() -- what a compiler makes of a cos and a sin of
+        # the same argument when it can pair them, as in the oracle -- differs from its separate cos() and sin() in the last bit on 0.13 % of the
+        # arguments, and whether the reference's build pairs them is the compiler's choice: equal to within that bit, not bit for bit.
+        assert np.allclose(got[25:49], c3d, rtol=4e-16, atol=1e-15), ("corners 3D", it)
+        # edges that support the vanishing points
+        n = int(rng.integers(0, 40))
+        mids = rng.uniform(0, 640, (n, 2)); ang = rng.uniform(-np.pi / 2, np.pi / 2, n)
+        vps = want.reshape(3, 2)
+        thre = [15.0, 10.0] if it % 3 else [60.0, 50.0]
+        want6 = np.zeros(6); ref.ref_vp_support_edge_infos(P(vps), P(mids), P(ang), n, P(thre), want6.ctypes.data_as(D))
+        assert np.array_equal(orc(6, [vps, thre, [float(n)], mids, ang], 6), want6, equal_nan=True), ("vp_support", it, n)
+
+
 def _dp(a):
     return a.ctypes.data_as(C.c_void_p)
 
