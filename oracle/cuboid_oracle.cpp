@@ -1,9 +1,12 @@
 /*
  * oracle/cuboid_oracle.cpp -- CPU oracle for the detect_3d_cuboid path.
  *
- * TEST INFRASTRUCTURE ONLY (see oracle.h).  PARITY UNPINNED: restated from
+ * TEST INFRASTRUCTURE ONLY (see oracle.h).  Restated from
  * /root/reference/detect_3d_cuboid/src/{box_proposal_detail,object_3d_util,matrix_utils}.cpp
- * plus the OpenCV / Eigen semantics those files reach (documented per function).
+ * plus the OpenCV / Eigen semantics those files reach (documented per function).  PINNED: tests/test_ref_pins.py runs
+ * detect_3d_cuboid::detect_cuboid and every function it calls -- the reference's own text, cut out at build time (oracle/_ref) -- next to
+ * orc_detect_cuboid in five settings: identical cuboid records.  What stays restated are the library primitives underneath (Eigen's
+ * inverses and rotation -> quaternion, OpenCV's Canny / distanceTransform / cvtColor), which are not in the reference tree.
  * Build WITHOUT floating-point contraction (-ffp-contract=off): the reference is built
  * Release without -march=native (detect_3d_cuboid/CMakeLists.txt:2,56-57), i.e. no FMA, and
  * int() truncation of sample points that lie exactly on integer box edges depends on it.

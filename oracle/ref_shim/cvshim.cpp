@@ -159,9 +159,12 @@ void Canny(InputArray _image, OutputArray _edges, double t1, double t2, int aper
     _edges.create(img.size(), CV_8UC1);
     Mat e = _edges.getMat();
     // cv::Canny on a view reads the parent image around it (Sobel with BORDER_REPLICATE at the PARENT's border only when the view touches
-    // it): the oracle's ROI entry takes the parent.  A view's parent extent is not recoverable from this shim's Mat, so whole images only.
-    CV_Assert(img.isContinuous());
-    orc_canny_roi(img.data, img.cols, img.rows, 0, 0, img.cols, img.rows, (int)t1, (int)t2, e.data);
+    // it): the oracle's ROI entry takes the parent and the window.
+    CV_Assert(img.datastart && img.step == (size_t)img.whole_cols);
+    const size_t off = (size_t)(img.data - img.datastart);
+    std::vector<uchar> edges((size_t)img.cols * img.rows);
+    orc_canny_roi(img.datastart, img.whole_cols, img.whole_rows, (int)(off % img.step), (int)(off / img.step), img.cols, img.rows, (int)t1, (int)t2, edges.data());
+    for (int r = 0; r < img.rows; r++) std::memcpy(e.ptr(r), edges.data() + (size_t)r * img.cols, img.cols);
 }
 void distanceTransform(InputArray _src, OutputArray _dst, int distanceType, int maskSize, int) {
     const Mat src = _src.getMat();

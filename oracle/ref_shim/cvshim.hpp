@@ -140,22 +140,24 @@ public:
     size_t step = 0; // bytes per row
     uchar *data = nullptr;
     std::shared_ptr<std::vector<uchar>> buf;
+    uchar *datastart = nullptr; int whole_rows = 0, whole_cols = 0; // the matrix a view was cut from (cv::Mat::locateROI): Canny on a view reads around it
 
     Mat() {}
     Mat(int r, int c, int type) { create(r, c, type); }
     Mat(Size sz, int type) { create(sz.height, sz.width, type); }
     Mat(int r, int c, int type, const Scalar &s) { create(r, c, type); setTo(s); }
     Mat(Size sz, int type, const Scalar &s) { create(sz.height, sz.width, type); setTo(s); }
-    Mat(int r, int c, int type, void *d, size_t st = 0) : flags_type(type), rows(r), cols(c), data((uchar *)d) { step = st ? st : (size_t)c * elemSize(); }
+    Mat(int r, int c, int type, void *d, size_t st = 0) : flags_type(type), rows(r), cols(c), data((uchar *)d), datastart((uchar *)d), whole_rows(r), whole_cols(c) { step = st ? st : (size_t)c * elemSize(); }
     Mat(Size sz, int type, void *d, size_t st = 0) : Mat(sz.height, sz.width, type, d, st) {}
     template <typename T> explicit Mat(const std::vector<T> &v) : flags_type(DataType<T>::type), rows((int)v.size()), cols(1), data((uchar *)v.data()) { step = sizeof(T); }
-    Mat(const Mat &m, const Rect &r) : flags_type(m.flags_type), rows(r.height), cols(r.width), step(m.step), data(m.data + (size_t)r.y * m.step + (size_t)r.x * m.elemSize()), buf(m.buf) {}
+    Mat(const Mat &m, const Rect &r) : flags_type(m.flags_type), rows(r.height), cols(r.width), step(m.step), data(m.data + (size_t)r.y * m.step + (size_t)r.x * m.elemSize()), buf(m.buf), datastart(m.datastart), whole_rows(m.whole_rows), whole_cols(m.whole_cols) {}
 
     void create(int r, int c, int type) {
         if (data && rows == r && cols == c && flags_type == type) return;
         flags_type = type; rows = r; cols = c; step = (size_t)c * elemSize();
         buf = std::make_shared<std::vector<uchar>>((size_t)r * step + 64);
         data = buf->data();
+        datastart = data; whole_rows = r; whole_cols = c;
     }
     void create(Size sz, int type) { create(sz.height, sz.width, type); }
     void release() { rows = cols = 0; data = nullptr; buf.reset(); step = 0; }

@@ -32,6 +32,9 @@ template <typename T> class View { // a rectangular window of an M (rows r0.., c
     template <int N> View tail() const { return tail(N); }
     View row(int i) const { return View(m, r0 + i, c0, 1, nc); }
     View col(int j) const { return View(m, r0, c0 + j, nr, 1); }
+    template <int N> View segment(int i) const { return nc == 1 ? View(m, r0 + i, c0, N, 1) : View(m, r0, c0 + i, 1, N); }
+    T maxCoeff() const { return eval().maxCoeff(); }
+    T minCoeff() const { return eval().minCoeff(); }
     M<T> eval() const;
     const View &operator=(const M<T> &o) const; // by linear index when the shapes are transposes of each other (vectors)
     const View &operator=(const View &o) const { return *this = o.eval(); }
@@ -80,9 +83,17 @@ template <typename T> class M {
     View<T> bottomRows(int n) const { return block(nr - n, 0, n, nc); }
     View<T> topRows(int n) const { return block(0, 0, n, nc); }
     template <int H, int W> View<T> topLeftCorner() const { return block(0, 0, H, W); }
+    View<T> topLeftCorner(int h, int w) const { return block(0, 0, h, w); }
+    View<T> topRightCorner(int h, int w) const { return block(0, nc - w, h, w); }
     M transpose() const { M r(nc, nr); for (int i = 0; i < nr; i++) for (int j = 0; j < nc; j++) r(j, i) = (*this)(i, j); return r; }
     double norm() const { double s = 0; for (const T &v : d) s += (double)v * v; return std::sqrt(s); } // (sum in storage order: a vector's natural order)
     T mean() const { T s = d[0]; for (size_t i = 1; i < d.size(); i++) s += d[i]; return s / (T)d.size(); }
+    T maxCoeff() const { T v = d[0]; for (const T &x : d) if (v < x) v = x; return v; }
+    T minCoeff() const { T v = d[0]; for (const T &x : d) if (x < v) v = x; return v; }
+    template <int N> View<T> topRows() const { return block(0, 0, N, nc); }
+    struct Rowwise { const M *m; M norm() const { M r(m->nr); for (int i = 0; i < m->nr; i++) { double q = 0; for (int j = 0; j < m->nc; j++) q += (*m)(i, j) * (*m)(i, j); r(i) = std::sqrt(q); } return r; } };
+    Rowwise rowwise() const { return Rowwise{this}; }
+    M inverse() const;
     T maxCoeff(int *idx) const { int b = 0; for (int i = 1; i < size(); i++) if (d[i] > d[b]) b = i; *idx = b; return d[b]; }  // first occurrence
     T minCoeff(int *idx) const { int b = 0; for (int i = 1; i < size(); i++) if (d[i] < d[b]) b = i; *idx = b; return d[b]; }
     M cross(const M &o) const { M r(3); r(0) = d[1] * o.d[2] - d[2] * o.d[1]; r(1) = d[2] * o.d[0] - d[0] * o.d[2]; r(2) = d[0] * o.d[1] - d[1] * o.d[0]; return r; }
@@ -117,6 +128,10 @@ template <typename T> class Arr {
     explicit Arr(const M<T> &m) : v(m) {}
     Arr operator/(const Arr &o) const { Arr r(v); for (size_t i = 0; i < r.v.d.size(); i++) r.v.d[i] = v.d[i] / o.v.d[i]; return r; }
     Arr operator*(const Arr &o) const { Arr r(v); for (size_t i = 0; i < r.v.d.size(); i++) r.v.d[i] = v.d[i] * o.v.d[i]; return r; }
+    Arr operator-(double s) const { Arr r(v); for (T &x : r.v.d) x = (T)(x - s); return r; }
+    Arr operator/(double s) const { Arr r(v); for (T &x : r.v.d) x = (T)(x / s); return r; }
+    struct Bools { std::vector<bool> b; bool any() const { for (bool x : b) if (x) return true; return false; } };
+    Bools operator<(double s) const { Bools r; for (const T &x : v.d) r.b.push_back(x < s); return r; }
 };
 template <typename T> Arr<T> operator/(T s, const Arr<T> &a) { Arr<T> r(a.v); for (T &x : r.v.d) x = s / x; return r; }
 template <typename T> M<T>::M(const Arr<T> &a) : nr(a.v.nr), nc(a.v.nc), d(a.v.d) {}
@@ -124,12 +139,19 @@ template <typename T> Arr<T> M<T>::array() const { return Arr<T>(*this); }
 template <typename T> Arr<T> View<T>::array() const { return Arr<T>(eval()); }
 template <typename T> const View<T> &View<T>::operator=(const Arr<T> &a) const { return *this = a.v; }
 // `v.array() /= s` on a named vector
-template <typename T> struct ArrRef { M<T> &m; ArrRef &operator/=(T s) { for (T &x : m.d) x = x / s; return *this; } };
+template <typename T> struct ArrRef {
+    M<T> &m;
+    ArrRef &operator/=(T s) { for (T &x : m.d) x = x / s; return *this; }
+    ArrRef &operator-=(T s) { for (T &x : m.d) x = x - s; return *this; }
+    Arr<T> operator-(double s) const { return Arr<T>(m) - s; }
+    typename Arr<T>::Bools operator<(double s) const { return Arr<T>(m) < s; }
+};
 
 template <typename T> M<T> operator+(const M<T> &a, const M<T> &b) { M<T> r(a.nr, a.nc); for (size_t i = 0; i < r.d.size(); i++) r.d[i] = a.d[i] + b.d[i]; return r; }
 template <typename T> M<T> operator-(const M<T> &a, const M<T> &b) { M<T> r(a.nr, a.nc); for (size_t i = 0; i < r.d.size(); i++) r.d[i] = a.d[i] - b.d[i]; return r; }
 template <typename T> M<T> operator-(const M<T> &a) { M<T> r(a.nr, a.nc); for (size_t i = 0; i < r.d.size(); i++) r.d[i] = -a.d[i]; return r; }
 template <typename T> M<T> operator-(const View<T> &a, const View<T> &b) { return a.eval() - b.eval(); }
+template <typename T> M<T> operator+(const View<T> &a, const View<T> &b) { return a.eval() + b.eval(); }
 template <typename T> M<T> operator*(double s, const M<T> &a) { M<T> r(a.nr, a.nc); for (size_t i = 0; i < r.d.size(); i++) r.d[i] = s * a.d[i]; return r; }
 template <typename T> M<T> operator*(const M<T> &a, double s) { M<T> r(a.nr, a.nc); for (size_t i = 0; i < r.d.size(); i++) r.d[i] = a.d[i] * s; return r; }
 template <typename T> M<T> operator/(const M<T> &a, double s) { M<T> r(a.nr, a.nc); for (size_t i = 0; i < r.d.size(); i++) r.d[i] = a.d[i] / s; return r; }
@@ -141,6 +163,68 @@ template <typename T> M<T> operator*(const M<T> &a, const M<T> &b) { // sum over
     return r;
 }
 template <typename T> M<T> operator*(const M<T> &a, const View<T> &b) { return a * b.eval(); }
+
+// inverse(): Eigen's own algorithms are not here to compile; the 3 x 3 one is its cofactor formula (cofactors * (1 / det), det along the first column), the
+// 4 x 4 one a Gauss-Jordan elimination with partial pivoting (it only feeds cam_pose.projectionMatrix, which no output of detect_cuboid reads) -- the
+// same two restatements the oracle carries (cuboid_oracle.cpp): what this file pins is everything AROUND them.
+template <typename T> M<T> M<T>::inverse() const {
+    const M &a = *this;
+    if (nr == 3 && nc == 3) {
+        auto cof = [&](int i, int j) { const int i1 = (i + 1) % 3, i2 = (i + 2) % 3, j1 = (j + 1) % 3, j2 = (j + 2) % 3; return a(i1, j1) * a(i2, j2) - a(i1, j2) * a(i2, j1); };
+        const T c00 = cof(0, 0), c10 = cof(1, 0), c20 = cof(2, 0);
+        const T det = (c00 * a(0, 0) + c10 * a(1, 0)) + c20 * a(2, 0);
+        const T invdet = T(1) / det;
+        M r(3, 3);
+        r(0, 0) = c00 * invdet; r(0, 1) = c10 * invdet; r(0, 2) = c20 * invdet;
+        r(1, 0) = cof(0, 1) * invdet; r(1, 1) = cof(1, 1) * invdet; r(1, 2) = cof(2, 1) * invdet;
+        r(2, 0) = cof(0, 2) * invdet; r(2, 1) = cof(1, 2) * invdet; r(2, 2) = cof(2, 2) * invdet;
+        return r;
+    }
+    assert(nr == 4 && nc == 4);
+    T w[4][8];
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) { w[i][j] = a(i, j); w[i][4 + j] = (i == j) ? T(1) : T(0); }
+    for (int c = 0; c < 4; c++) {
+        int p = c;
+        for (int r = c + 1; r < 4; r++) if (std::fabs(w[r][c]) > std::fabs(w[p][c])) p = r;
+        if (p != c) for (int j = 0; j < 8; j++) { const T t = w[p][j]; w[p][j] = w[c][j]; w[c][j] = t; }
+        const T d = T(1) / w[c][c];
+        for (int j = 0; j < 8; j++) w[c][j] *= d;
+        for (int r = 0; r < 4; r++) if (r != c) { const T f = w[r][c]; for (int j = 0; j < 8; j++) w[r][j] -= f * w[c][j]; }
+    }
+    M r(4, 4);
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) r(i, j) = w[i][4 + j];
+    return r;
+}
+// Quaternion from a rotation matrix: Eigen's quaternionbase_assign_impl<Other, 3, 3> as the oracle restates it
+template <typename T> class Quaternion {
+  public:
+    T qw, qx, qy, qz;
+    Quaternion(T w, T x, T y, T z) : qw(w), qx(x), qy(y), qz(z) {}
+    Quaternion(const M<T> &m) {
+        T t = m(0, 0) + m(1, 1) + m(2, 2);
+        T q[3];
+        if (t > 0) {
+            t = std::sqrt(t + T(1));
+            qw = T(0.5) * t;
+            t = T(0.5) / t;
+            qx = (m(2, 1) - m(1, 2)) * t; qy = (m(0, 2) - m(2, 0)) * t; qz = (m(1, 0) - m(0, 1)) * t;
+        } else {
+            int i = 0;
+            if (m(1, 1) > m(0, 0)) i = 1;
+            if (m(2, 2) > m(i, i)) i = 2;
+            const int j = (i + 1) % 3, k = (j + 1) % 3;
+            t = std::sqrt(m(i, i) - m(j, j) - m(k, k) + T(1));
+            q[i] = T(0.5) * t;
+            t = T(0.5) / t;
+            qw = (m(k, j) - m(j, k)) * t;
+            q[j] = (m(j, i) + m(i, j)) * t;
+            q[k] = (m(k, i) + m(i, k)) * t;
+            qx = q[0]; qy = q[1]; qz = q[2];
+        }
+    }
+    T w() const { return qw; } T x() const { return qx; } T y() const { return qy; } T z() const { return qz; }
+};
+typedef Quaternion<double> Quaterniond;
 
 // the named types: sized (or not) flavours of M
 template <typename T, int R, int C> class Matrix : public M<T> {

@@ -31,18 +31,28 @@ WANT = [  # (file, signatures, output include)
     ("detect_3d_cuboid/src/matrix_utils.cpp", ["T normalize_to_pi(T angle)",
                                                "Eigen::Matrix<T, Eigen::Dynamic, Eigen::Dynamic> real_to_homo_coord(const Eigen::Matrix<T, Eigen::Dynamic, Eigen::Dynamic> &pts_in)",
                                                "Eigen::Matrix<T, Eigen::Dynamic, Eigen::Dynamic> homo_to_real_coord(const Eigen::Matrix<T, Eigen::Dynamic, Eigen::Dynamic> &pts_homo_in)",
-                                               "Eigen::Matrix<T, Eigen::Dynamic, 1> homo_to_real_coord_vec(const Eigen::Matrix<T, Eigen::Dynamic, 1> &pts_homo_in)"], "extracted_geom.inc"),
+                                               "Eigen::Matrix<T, Eigen::Dynamic, 1> homo_to_real_coord_vec(const Eigen::Matrix<T, Eigen::Dynamic, 1> &pts_homo_in)",
+                                               "void quat_to_euler_zyx(const Eigen::Quaternion<T> &q, T &roll, T &pitch, T &yaw)",
+                                               "Eigen::Matrix<T, 3, 3> euler_zyx_to_rot(const T &roll, const T &pitch, const T &yaw)",
+                                               "void linespace(T starting, T ending, T step, std::vector<T> &res)",
+                                               "void fast_RemoveRow(", "void sort_indexes(const Eigen::VectorXd &vec, std::vector<int> &idx, int top_k)"], "extracted_geom.inc"),
     ("detect_3d_cuboid/src/object_3d_util.cpp", ["Matrix4d similarityTransformation(const cuboid &cube_obj)", "Matrix3Xd compute3D_BoxCorner(const cuboid &cube_obj)",
                                                  "bool check_inside_box(const Vector2d &pt, const Vector2d &box_left_top, const Vector2d &box_right_bottom)",
+                                                 "void align_left_right_edges(MatrixXd &all_lines)", "void atan2_vector(",
                                                  "void smooth_jump_angles(const VectorXd &raw_angles, VectorXd &new_angles)",
                                                  "Vector2d seg_hit_boundary(const Vector2d &pt_start, const Vector2d &pt_end, const Vector4d &line_segment2)",
                                                  "Vector2d lineSegmentIntersect(const Vector2d &pt1_start, const Vector2d &pt1_end, const Vector2d &pt2_start, const Vector2d &pt2_end,",
+                                                 "void merge_break_lines(",
                                                  "Eigen::MatrixXd VP_support_edge_infos(Eigen::MatrixXd &VPs, Eigen::MatrixXd &edge_mid_pts, Eigen::VectorXd &edge_angles,",
+                                                 "double box_edge_sum_dists(", "double box_edge_alignment_angle_error(", "void fuse_normalize_scores_v2(",
                                                  "void ray_plane_interact(const MatrixXd &rays, const Eigen::Vector4d &plane, MatrixXd &intersections)",
                                                  "void plane_hits_3d(const Matrix4d &transToWolrd, const Matrix3d &invK, const Vector4d &plane_sensor, MatrixXd pixels, Matrix3Xd &pts_3d_world)",
                                                  "Vector4d get_wall_plane_equation(const Vector3d &gnd_seg_pt1, const Vector3d &gnd_seg_pt2)",
                                                  "void getVanishingPoints(const Matrix3d &KinvR, double yaw_esti, Vector2d &vp_1, Vector2d &vp_2, Vector2d &vp_3)",
                                                  "void change_2d_corner_to_3d_object(const MatrixXd &box_corners_2d_float, const Vector3d &configs, const Vector4d &ground_plane_sensor,"], "extracted_geom.inc"),
+    # ... and detect_cuboid itself, with the two setters it relies on
+    ("detect_3d_cuboid/src/box_proposal_detail.cpp", ["void detect_3d_cuboid::set_calibration(const Matrix3d &Kalib)", "void detect_3d_cuboid::set_cam_pose(const Matrix4d &transToWolrd)",
+                                                      "void detect_3d_cuboid::detect_cuboid(const cv::Mat &rgb_img, const Matrix4d &transToWolrd, const MatrixXd &obj_bbox_coors,"], "extracted_geom.inc"),
     # the ORB matcher's three window searches with what they call, and the Frame grid they search (compiled against stand-ins for Frame / MapPoint, ref_match_api.cpp)
     ("orb_object_slam/src/ORBmatcher.cc", ["const int ORBmatcher::TH_HIGH = 100;", "const int ORBmatcher::TH_LOW = 50;", "const int ORBmatcher::HISTO_LENGTH = 30;",
                                            "int ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint *> &vpMapPoints, const float th)", "float ORBmatcher::RadiusByViewingCos(const float &viewCos)",

@@ -6,18 +6,25 @@
 // (oracle/_ref/extracted_geom.inc) and compiled against eigdyn.hpp.  tests/test_ref_pins.py compares the oracle's restatements with these.
 #include <algorithm>
 #include <cmath>
+#include <cstdio>
 #include <cstring>
 #include <iostream>
+#include <numeric>
+#include <string>
 #include <vector>
 
+#include "cvshim.hpp"
+#include "../oracle.h"
 #include "eigdyn/eigdyn.hpp"
 namespace Eigen = EigenDyn;
 
 using namespace Eigen;
 using namespace std;
 
+namespace cv { enum { NORM_MINMAX = 32 }; inline void normalize(const Mat &, Mat &, double, double, int) {} } // behind the plot flags (off)
+
 namespace { // (internal linkage: ref_extract_api.cpp cuts some of the same helpers against another stand-in)
-class cuboid { // detect_3d_cuboid.h:15-36: the members the functions below touch
+class cuboid { // detect_3d_cuboid.h:15-36
   public:
     Eigen::Vector3d pos;
     Eigen::Vector3d scale;
@@ -25,7 +32,54 @@ class cuboid { // detect_3d_cuboid.h:15-36: the members the functions below touc
     Eigen::Vector2d box_config_type;
     Eigen::Matrix2Xi box_corners_2d;
     Eigen::Matrix3Xd box_corners_3d_world;
+    Eigen::Vector4d rect_detect_2d;
+    double edge_distance_error;
+    double edge_angle_error;
+    double normalized_error;
+    double skew_ratio;
+    double down_expand_height;
+    double camera_roll_delta;
+    double camera_pitch_delta;
 };
+typedef std::vector<cuboid *> ObjectSet;
+struct cam_pose_infos { // detect_3d_cuboid.h:39-51
+    Eigen::Matrix4d transToWolrd;
+    Eigen::Matrix3d Kalib;
+    Eigen::Matrix3d rotationToWorld;
+    Eigen::Vector3d euler_angle;
+    Eigen::Matrix3d invR;
+    Eigen::Matrix3d invK;
+    Eigen::Matrix<double, 3, 4> projectionMatrix;
+    Eigen::Matrix3d KinvR;
+    double camera_yaw;
+};
+class detect_3d_cuboid { // detect_3d_cuboid.h:53-80: the members detect_cuboid and the two setters use, with the header's defaults
+  public:
+    cam_pose_infos cam_pose;
+    cam_pose_infos cam_pose_raw;
+    void set_calibration(const Eigen::Matrix3d &Kalib);
+    void set_cam_pose(const Eigen::Matrix4d &transToWolrd);
+    void detect_cuboid(const cv::Mat &rgb_img, const Eigen::Matrix4d &transToWolrd, const Eigen::MatrixXd &obj_bbox_coors, Eigen::MatrixXd edges, std::vector<ObjectSet> &all_object_cuboids);
+    bool whether_plot_detail_images = false;
+    bool whether_plot_final_images = false;
+    bool whether_save_final_images = false;
+    cv::Mat cuboids_2d_img;
+    bool print_details = false;
+    bool consider_config_1 = true;
+    bool consider_config_2 = true;
+    bool whether_sample_cam_roll_pitch = false;
+    bool whether_sample_bbox_height = false;
+    int max_cuboid_num = 1;
+    double nominal_skew_ratio = 1;
+    double max_cut_skew = 3;
+};
+namespace ca { struct Profiler { static void tictoc(const char *) {} }; } // tictoc_profiler: timing only
+// drawing helpers behind the plot flags (off): declared so that the text compiles, never called
+void plot_image_with_edges(const cv::Mat &, cv::Mat &, MatrixXd &, const cv::Scalar &) {}
+void plot_image_with_cuboid(cv::Mat &, const cuboid *) {}
+// the defaults of the header's declarations (object_3d_util.h)
+double box_edge_sum_dists(const cv::Mat &dist_map, const MatrixXd &box_corners_2d, const MatrixXi &edge_pt_ids, bool reweight_edge_distance = false);
+template <class T> void quat_to_euler_zyx(const Eigen::Quaternion<T> &q, T &roll, T &pitch, T &yaw);
 
 #include "extracted_geom.inc"
 } // namespace
@@ -76,5 +130,36 @@ void ref_change_2d_corner_to_3d_object(const double *corners16, const double *co
     *rotY = o.rotY; cfg2[0] = o.box_config_type(0); cfg2[1] = o.box_config_type(1);
     for (int i = 0; i < 2; i++) for (int j = 0; j < 8; j++) corners2d16[i * 8 + j] = o.box_corners_2d(i, j);
     for (int i = 0; i < 3; i++) for (int j = 0; j < 8; j++) corners3d24[i * 8 + j] = o.box_corners_3d_world(i, j);
+}
+// detect_3d_cuboid::detect_cuboid with the arguments of orc_detect_cuboid (oracle.h): gray W x H, K 3 x 3, Twc 4 x 4, boxes nb x 5, lines nl x 4.
+// out: room for nb * opts->max_cuboid_num records, counts[nb].
+int ref_detect_cuboid(const uint8_t *gray, int W, int H, const double *K9, const double *Twc16, const double *boxes, int nb, const double *lines, int nl, const orc_cuboid_opts *opts,
+                      orc_cuboid *out, int *counts) {
+    detect_3d_cuboid det;
+    det.consider_config_1 = opts->consider_config_1; det.consider_config_2 = opts->consider_config_2;
+    det.whether_sample_cam_roll_pitch = opts->whether_sample_cam_roll_pitch; det.whether_sample_bbox_height = opts->whether_sample_bbox_height;
+    det.max_cuboid_num = opts->max_cuboid_num; det.nominal_skew_ratio = opts->nominal_skew_ratio; det.max_cut_skew = opts->max_cut_skew;
+    det.set_calibration(m3(K9));
+    cv::Mat img(H, W, CV_8UC1, (void *)gray);
+    MatrixXd bb(nb, 5), ln(nl, 4);
+    for (int i = 0; i < nb; i++) for (int j = 0; j < 5; j++) bb(i, j) = boxes[i * 5 + j];
+    for (int i = 0; i < nl; i++) for (int j = 0; j < 4; j++) ln(i, j) = lines[i * 4 + j];
+    std::vector<ObjectSet> all;
+    det.detect_cuboid(img, m4(Twc16), bb, ln, all);
+    for (int b = 0; b < nb; b++) {
+        counts[b] = (int)all[b].size();
+        for (int k = 0; k < counts[b] && k < opts->max_cuboid_num; k++) {
+            const cuboid &c = *all[b][k];
+            orc_cuboid &o = out[(size_t)b * opts->max_cuboid_num + k];
+            for (int i = 0; i < 3; i++) { o.pos[i] = c.pos(i); o.scale[i] = c.scale(i); }
+            o.rotY = c.rotY; o.box_config_type[0] = c.box_config_type(0); o.box_config_type[1] = c.box_config_type(1);
+            for (int i = 0; i < 2; i++) for (int j = 0; j < 8; j++) o.box_corners_2d[i * 8 + j] = c.box_corners_2d(i, j);
+            for (int i = 0; i < 3; i++) for (int j = 0; j < 8; j++) o.box_corners_3d_world[i * 8 + j] = c.box_corners_3d_world(i, j);
+            for (int i = 0; i < 4; i++) o.rect_detect_2d[i] = c.rect_detect_2d(i);
+            o.edge_distance_error = c.edge_distance_error; o.edge_angle_error = c.edge_angle_error; o.normalized_error = c.normalized_error; o.skew_ratio = c.skew_ratio;
+            o.down_expand_height = c.down_expand_height; o.camera_roll_delta = c.camera_roll_delta; o.camera_pitch_delta = c.camera_pitch_delta;
+        }
+    }
+    return 0;
 }
 }

@@ -266,6 +266,50 @@ def test_cuboid_geometry_equals_reference(ref, oracle):
         assert np.array_equal(orc(6, [vps, thre, [float(n)], mids, ang], 6), want6, equal_nan=True), ("vp_support", it, n)
 
 
+@pytest.mark.parametrize("mode", ["default", "height", "rollpitch", "config1", "top3"])
+def test_detect_cuboid_equals_reference(ref, oracle, mode):
+    """detect_3d_cuboid::detect_cuboid ITSELF (box_proposal_detail.cpp:56-557) with set_calibration / set_cam_pose (:36-53) and every function it calls
+    in object_3d_util.cpp / matrix_utils.cpp -- the reference's own text, cut out at build time and compiled against stand-ins for its class
+    declarations, for Eigen (ref_shim/eigdyn: its two matrix inverses and the rotation -> quaternion conversion are the oracle's restatements, Eigen
+    not being here) and for OpenCV (Canny, distanceTransform, cvtColor: the oracle's restatements): the whole proposal sweep -- height samples, yaw
+    samples, top-point samples, both configurations, the corner construction with its ten ways to fail, scoring, normalisation, selection -- is
+    the reference's control flow.  Cuboid records against orc_detect_cuboid: integers and errors identical, doubles to the last bit except
+    where cos / sin of the yaw enter (the compiler's sincos pairing, see test_cuboid_geometry_equals_reference)."""
+    import oracle.pyoracle as po
+    total = 0
+    for seed in (synth.SEED, 5, 9):
+        s = synth.cuboid_scene(seed, n_boxes=3, bg_texture=0.0 if seed != 9 else 0.5)
+        opts = po.cuboid_opts()
+        if mode == "height":
+            opts.whether_sample_bbox_height = 1
+        if mode == "rollpitch":
+            opts.whether_sample_cam_roll_pitch = 1; opts.stateful_cam_pose = 1  # (the reference carries cam_pose from box to box, :126 after :237 / :485)
+        if mode == "config1":
+            opts.consider_config_2 = 0
+        if mode == "top3":
+            opts.max_cuboid_num = 3
+        gray = np.ascontiguousarray(s["gray"], np.uint8); H, W = gray.shape
+        K = np.ascontiguousarray(s["K"], np.float64); Twc = np.ascontiguousarray(s["Twc"], np.float64)
+        boxes = np.ascontiguousarray(s["boxes"], np.float64).reshape(-1, 5); lines = np.ascontiguousarray(s["lines"], np.float64).reshape(-1, 4)
+        nb = len(boxes)
+        want = np.zeros((nb, opts.max_cuboid_num), po.CUBOID_DTYPE); cnt = np.zeros(nb, np.int32)
+        assert ref.ref_detect_cuboid(gray.ctypes.data_as(C.c_void_p), W, H, K.ctypes.data_as(C.c_void_p), Twc.ctypes.data_as(C.c_void_p), boxes.ctypes.data_as(C.c_void_p), nb,
+                                     lines.ctypes.data_as(C.c_void_p), len(lines), C.byref(opts), want.ctypes.data_as(C.c_void_p), cnt.ctypes.data_as(C.c_void_p)) == 0
+        got, _ = po.detect_cuboid(gray, K, Twc, boxes, lines, opts)
+        for b in range(nb):
+            assert len(got[b]) == min(cnt[b], opts.max_cuboid_num), (seed, b, len(got[b]), cnt[b])
+            for k in range(len(got[b])):
+                g, w = got[b][k], want[b, k]
+                for f in po.CUBOID_DTYPE.names:
+                    if f in ("box_corners_3d_world", "pos", "scale"):
+                        assert np.allclose(g[f], w[f], rtol=4e-16, atol=1e-15), (seed, b, k, f)
+                    else:
+                        assert np.array_equal(g[f], w[f]), (seed, b, k, f, g[f], w[f])
+                total += 1
+                assert g["edge_distance_error"] > 0 and g["scale"].min() > 0
+    assert total >= (9 if mode != "top3" else 20), total
+
+
 def _dp(a):
     return a.ctypes.data_as(C.c_void_p)
 
