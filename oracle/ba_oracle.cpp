@@ -1,7 +1,10 @@
 /*
  * oracle/ba_oracle.cpp -- CPU oracle for the g2o object bundle adjustment (BlockSolver_6_3 + Levenberg + Schur).
  *
- * TEST INFRASTRUCTURE ONLY (see oracle.h).  PARITY UNPINNED: restated from the vendored g2o under
+ * TEST INFRASTRUCTURE ONLY (see oracle.h).  PARTLY PINNED (tests/test_ref_pins.py, oracle/_ref): the SE3 / cuboid vertex and edge math equals the
+ * reference's se3quat.h / g2o_Object functions bit for bit, and a run driven by the reference's own OptimizationAlgorithmLevenberg::solve +
+ * SparseOptimizer::optimize + RobustKernelHuber over this file's pieces equals orc_ba_optimize bit for bit; the linear side (block solver, edge
+ * linearisation) is unpinned.  Restated from the vendored g2o under
  * /root/reference/orb_object_slam/Thirdparty/g2o/g2o (core/optimization_algorithm_levenberg.cpp:61-189,
  * core/block_solver.hpp:354-604, core/base_binary_edge.hpp:55-320, core/base_unary_edge.hpp:43-123,
  * core/sparse_optimizer.cpp:61-114, core/robust_kernel_impl.cpp:78-91, types/se3quat.h, types/types_six_dof_expmap.*)
@@ -500,6 +503,33 @@ int orc_ba_optimize(const orc_ba_problem *p, int iterations, double *cam_pose_ou
     for (int i = 0; i < p->n_cuboids; i++) se3_to7(ba.s.cubs[i].pose, cuboid_pose_out + (size_t)i * 7);
     std::memcpy(points_out, ba.s.pts.data(), ba.s.pts.size() * sizeof(double));
     return 0;
+}
+
+// ---- the pieces of the LM loop one at a time (test hook): tests/test_ref_pins.py drives them from the REFERENCE'S OWN OptimizationAlgorithmLevenberg::solve /
+// SparseOptimizer::optimize (oracle/_ref, cut out of the vendored g2o) and compares the run with orc_ba_optimize
+struct orc_ba_handle { BA ba; orc_ba_handle(const orc_ba_problem *p) : ba(p) {} };
+void orc_huber(double e, double delta, double *rho3) { BA::huber(e, delta, rho3); }
+orc_ba_handle *orc_ba_open(const orc_ba_problem *p) { return new orc_ba_handle(p); }
+void orc_ba_close(orc_ba_handle *h) { delete h; }
+void orc_ba_compute_errors(orc_ba_handle *h) { h->ba.compute_errors(); }
+double orc_ba_robust_chi2(orc_ba_handle *h) { return h->ba.robust_chi2(); }
+void orc_ba_build_system(orc_ba_handle *h) { h->ba.build_system(0, h->ba.L, true); }
+void orc_ba_sizes(orc_ba_handle *h, int *P, int *L) { *P = h->ba.P; *L = h->ba.L; }
+double orc_ba_hessian_diag(orc_ba_handle *h, int block, int j) { // block < P: pose block (6), else landmark block - P (3)
+    return block < h->ba.P ? h->ba.Hpp_diag[(size_t)block * 36 + j * 7] : h->ba.Hll[(size_t)(block - h->ba.P) * 9 + j * 4];
+}
+int orc_ba_solve(orc_ba_handle *h, double lambda) { return h->ba.solve(lambda) ? 1 : 0; }
+void orc_ba_update(orc_ba_handle *h) { h->ba.update(); }
+void orc_ba_push(orc_ba_handle *h) { h->ba.stack.push_back(h->ba.s); }
+void orc_ba_pop(orc_ba_handle *h) { h->ba.s = h->ba.stack.back(); h->ba.stack.pop_back(); }
+void orc_ba_discard_top(orc_ba_handle *h) { h->ba.stack.pop_back(); }
+const double *orc_ba_x(orc_ba_handle *h, long *n) { if (n) *n = (long)h->ba.x.size(); return h->ba.x.data(); }
+const double *orc_ba_b(orc_ba_handle *h) { return h->ba.b.data(); }
+void orc_ba_read(orc_ba_handle *h, double *cam_pose_out, double *points_out, double *cuboid_pose_out) {
+    const orc_ba_problem *p = h->ba.p;
+    for (int i = 0; i < p->n_cams; i++) se3_to7(h->ba.s.cams[i], cam_pose_out + (size_t)i * 7);
+    for (int i = 0; i < p->n_cuboids; i++) se3_to7(h->ba.s.cubs[i].pose, cuboid_pose_out + (size_t)i * 7);
+    std::memcpy(points_out, h->ba.s.pts.data(), h->ba.s.pts.size() * sizeof(double));
 }
 
 } // extern "C"

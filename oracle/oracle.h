@@ -261,6 +261,24 @@ int orc_cuboid9_edge_error(int n, const double *cam_Tcw, const double *cub_globa
 int orc_cuboid9_edge_linearize(int n, const double *cam_Tcw, const double *cub_global, const double *cub_meas_local, double *err, double *Jcam, double *Jcub);
 /* test hook: one pose helper at a time (SE3Quat exp / log / product / inverse, exptwist_norollpitch, the cuboid's log errors, rotations and
  * transforms, point_boundary_error) -- see ba_oracle.cpp; tests/test_ref_pins.py holds them against the reference's own code */
+/* the LM loop's pieces one at a time (test hook, see ba_oracle.cpp) */
+void orc_huber(double e, double delta, double *rho3); /* RobustKernelHuber::robustify as the BA uses it */
+typedef struct orc_ba_handle orc_ba_handle;
+orc_ba_handle *orc_ba_open(const orc_ba_problem *p);
+void orc_ba_close(orc_ba_handle *h);
+void orc_ba_compute_errors(orc_ba_handle *h);
+double orc_ba_robust_chi2(orc_ba_handle *h);
+void orc_ba_build_system(orc_ba_handle *h);
+void orc_ba_sizes(orc_ba_handle *h, int *P, int *L);
+double orc_ba_hessian_diag(orc_ba_handle *h, int block, int j);
+int orc_ba_solve(orc_ba_handle *h, double lambda);
+void orc_ba_update(orc_ba_handle *h);
+void orc_ba_push(orc_ba_handle *h);
+void orc_ba_pop(orc_ba_handle *h);
+void orc_ba_discard_top(orc_ba_handle *h);
+const double *orc_ba_x(orc_ba_handle *h, long *n);
+const double *orc_ba_b(orc_ba_handle *h);
+void orc_ba_read(orc_ba_handle *h, double *cam_pose_out, double *points_out, double *cuboid_pose_out);
 int orc_se3_op(int op, const double *a, const double *b, double s, double *out);
 
 /* --------------------------------------------------------------------------------------------------------------------

@@ -61,6 +61,14 @@ WANT = [  # (file, signatures, output include)
                                            "void ORBmatcher::ComputeThreeMaxima(", "int ORBmatcher::DescriptorDistance("], "extracted_match.inc"),
     ("orb_object_slam/src/Frame.cc", ["void Frame::AssignFeaturesToGrid()", "vector<size_t> Frame::GetFeaturesInArea(const float &x, const float &y, const float &r, const int minLevel, const int maxLevel) const",
                                       "bool Frame::PosInGrid(const cv::KeyPoint &kp, int &posX, int &posY)"], "extracted_match.inc"),
+    # g2o's Levenberg-Marquardt schedule and the optimiser's iteration loop (compiled against stand-ins for Solver / SparseOptimizer, ref_levenberg_api.cpp)
+    ("orb_object_slam/Thirdparty/g2o/g2o/core/optimization_algorithm_levenberg.cpp", ["OptimizationAlgorithmLevenberg::OptimizationAlgorithmLevenberg(Solver* solver) :",
+                                                                                      "OptimizationAlgorithm::SolverResult OptimizationAlgorithmLevenberg::solve(int iteration, bool online)",
+                                                                                      "double OptimizationAlgorithmLevenberg::computeLambdaInit() const",
+                                                                                      "double OptimizationAlgorithmLevenberg::computeScale() const",
+                                                                                      "void OptimizationAlgorithmLevenberg::printVerbose(std::ostream& os) const"], "extracted_levenberg.inc"),
+    ("orb_object_slam/Thirdparty/g2o/g2o/core/sparse_optimizer.cpp", ["int SparseOptimizer::optimize(int iterations, bool online)"], "extracted_levenberg.inc"),
+    ("orb_object_slam/Thirdparty/g2o/g2o/core/robust_kernel_impl.cpp", ["void RobustKernelHuber::setDelta(double delta)", "void RobustKernelHuber::robustify(double e, Eigen::Vector3d& rho) const"], "extracted_huber.inc"),
     # the LBD descriptor: BinaryDescriptor's compute path (the rest of binary_descriptor.cpp is the EDLine detector, which CubeSLAM does not use)
     ("line_lbd/libs/binary_descriptor.cpp", ["static const int combinations[32][2] =", "BinaryDescriptor::Params::Params()", "BinaryDescriptor::BinaryDescriptor( const BinaryDescriptor::Params &parameters ) :",
                                              "BinaryDescriptor::~BinaryDescriptor()", "static inline int get2Pow( int i )", "void BinaryDescriptor::computeGaussianPyramid( const Mat& image, const int numOctaves )",

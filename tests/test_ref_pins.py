@@ -310,6 +310,45 @@ def test_detect_cuboid_equals_reference(ref, oracle, mode):
     assert total >= (9 if mode != "top3" else 20), total
 
 
+def test_levenberg_schedule_equals_reference(ref, oracle):
+    """g2o's Levenberg-Marquardt as the reference vendors it: OptimizationAlgorithmLevenberg::solve / computeLambdaInit / computeScale and its
+    constructor's constants (Thirdparty/g2o/g2o/core/optimization_algorithm_levenberg.cpp:43-56, 61-189) and SparseOptimizer::optimize
+    (sparse_optimizer.cpp:354-419), cut out at build time and compiled against stand-ins for Solver / SparseOptimizer whose methods hand the work to
+    the oracle's pieces (residuals, quadratic form, Schur solve, state stack), plus RobustKernelHuber::robustify.  The schedule is then the reference's: a run driven by it must equal
+    orc_ba_optimize, whose loop restates it -- iterations, linear solves, the final lambda and chi2, every pose, point and cuboid, to the last bit."""
+    import oracle.pyoracle as po
+    ref.ref_ba_levenberg.restype = C.c_int
+    n_rejected = 0
+    for seed, kw, iters in ((1, dict(n_kf=6, n_points=60, n_cuboids=2), 10), (2, dict(n_kf=8, n_points=90, n_cuboids=3, noise_pose=0.15), 15),
+                            (3, dict(n_kf=5, n_points=40, n_cuboids=0), 8), (4, dict(n_kf=7, n_points=70, n_cuboids=2, noise_pose=0.4, noise_point=0.5), 20),
+                            (5, dict(n_kf=6, n_points=50, n_cuboids=2, noise_pose=1.0, noise_point=1.5), 20)):
+        try:
+            d = synth.ba_problem(seed, **kw)
+        except TypeError:
+            d = synth.ba_problem(seed, **{k: v for k, v in kw.items() if not k.startswith("noise")})
+        p = po.ba_struct(d)
+        cam = np.zeros((p.n_cams, 7)); pts = np.zeros((p.n_points, 3)); cub = np.zeros((max(p.n_cuboids, 1), 7))
+        trials, lam, chi = C.c_int(), C.c_double(), C.c_double()
+        done = ref.ref_ba_levenberg(C.byref(p), iters, cam.ctypes.data_as(C.c_void_p), pts.ctypes.data_as(C.c_void_p), cub.ctypes.data_as(C.c_void_p),
+                                    C.byref(trials), C.byref(lam), C.byref(chi))
+        ocam, opts_, ocub, st = po.ba_optimize(d, iters)
+        assert done == st["iterations"] and trials.value == st["lm_trials"], (seed, done, st["iterations"], trials.value, st["lm_trials"])
+        assert lam.value == st["lambda_final"] and chi.value == st["chi2_final"], (seed, lam.value, st["lambda_final"], chi.value, st["chi2_final"])
+        assert np.array_equal(cam, ocam) and np.array_equal(pts, opts_) and np.array_equal(cub[:p.n_cuboids], ocub), seed
+        assert st["chi2_final"] < st["chi2_init"]
+        n_rejected += st["lm_trials"] - st["iterations"]
+    assert n_rejected > 0  # (some trial was rejected somewhere: the lambda growth branch ran)
+    # RobustKernelHuber::robustify (robust_kernel_impl.cpp:78-91) on squared errors around the threshold
+    olib = po.lib()
+    rng = np.random.default_rng(3)
+    for delta in (np.sqrt(5.991), np.sqrt(7.815), 30.0):
+        for e in list(rng.uniform(0, 4 * delta * delta, 200)) + [delta * delta, 0.0, 1e-300, 1e12]:
+            a, b = np.zeros(3), np.zeros(3)
+            ref.ref_huber_robustify(C.c_double(e), C.c_double(delta), a.ctypes.data_as(C.c_void_p))
+            olib.orc_huber(C.c_double(e), C.c_double(delta), b.ctypes.data_as(C.c_void_p))
+            assert np.array_equal(a, b), (delta, e)
+
+
 def _dp(a):
     return a.ctypes.data_as(C.c_void_p)
 
