@@ -1,8 +1,14 @@
-"""Pins of the oracle against the REFERENCE'S OWN CODE: oracle/_ref/libref.so is built (oracle/Makefile.ref) from the reference's
-translation units where they lie under /root/reference -- orb_object_slam/src/ORBextractor.cc, line_lbd/libs/lsd.cpp,
-line_lbd/libs/LSDDetector.cpp, ... -- against a stand-in for the OpenCV headers (oracle/ref_shim/).  Every function the reference itself
-wrote is therefore the real thing; only the OpenCV primitives underneath (resize, GaussianBlur, FAST, ...) are the oracle's restatements
-(SURVEY.md Appendix B).  The oracle's restatement must reproduce the reference bit for bit on the same inputs."""
+"""Pins of the oracle against the REFERENCE'S OWN CODE: oracle/_ref/libref.so is built (oracle/Makefile.ref) from the reference's text where it lies under
+/root/reference, against stand-ins for the libraries and headers that are not here (oracle/ref_shim/):
+  * whole translation units: orb_object_slam/src/ORBextractor.cc, line_lbd/libs/lsd.cpp, line_lbd/libs/LSDDetector.cpp, Thirdparty/g2o/g2o/types/se3quat.h;
+  * functions cut out at build time (extract_ref.py) where the rest of the file needs what cannot be built: detect_3d_cuboid::detect_cuboid with every
+    function it calls (box_proposal_detail.cpp, object_3d_util.cpp, matrix_utils.cpp), BinaryDescriptor's compute path (binary_descriptor.cpp), the ORB
+    matcher's three window searches with the Frame grid (ORBmatcher.cc, Frame.cc), the cuboid vertex / edge functions of g2o_Object.{h,cpp}, g2o's
+    Levenberg-Marquardt schedule, optimize() loop and Huber kernel (Thirdparty/g2o/g2o/core).
+Every statement the reference itself wrote is therefore the real thing; what stays restated are the library primitives underneath -- OpenCV's resize,
+GaussianBlur, Sobel, FAST, Canny, distanceTransform, Eigen's inverses / quaternion conversion / sparse solver.  The oracle's
+restatement must reproduce the reference bit for bit on the same inputs; the two places where that cannot be asked (the allocator-dependent tie-break of
+the ORB quadtree, the compiler's pairing of cos / sin into sincos) are stated in the tests that meet them."""
 import ctypes as C
 import os
 import subprocess
