@@ -44,18 +44,53 @@ def test_config4_batched_cuboids_8_boxes(ctx, oracle):
         o2 = 0 if j == 0 else nb[41]
         for k in range(nb[f]):
             assert full[off[f] + k].tobytes() == sub[o2 + k].tobytes()
-    # oracle agreement on one frame of the big batch
+    # oracle agreement on six frames spread over the big batch
     oo = oracle.cuboid_opts(yaw_step_deg=0.5)
-    ref, _ = oracle.detect_cuboid(scenes[17]["gray"], scenes[17]["K"], scenes[17]["Twc"], scenes[17]["boxes"], scenes[17]["lines"], opts=oo)
-    for k, r in enumerate(ref):
-        g = full[off[17] + k]
-        assert len(g) == len(r)
-        for name in g.dtype.names:
-            if name == "box_corners_2d":
-                assert np.array_equal(g[name], r[name])
-            else:
-                assert np.allclose(g[name], r[name], rtol=1e-5, atol=1e-9), name
+    for f in (0, 9, 17, 30, 48, 63):
+        ref, _ = oracle.detect_cuboid(scenes[f]["gray"], scenes[f]["K"], scenes[f]["Twc"], scenes[f]["boxes"], scenes[f]["lines"], opts=oo)
+        for k, r in enumerate(ref):
+            g = full[off[f] + k]
+            assert len(g) == len(r), (f, k)
+            for name in g.dtype.names:
+                if name == "box_corners_2d":
+                    assert np.array_equal(g[name], r[name]), (f, k)
+                else:
+                    assert np.allclose(g[name], r[name], rtol=1e-5, atol=1e-9), (f, k, name)
     assert sum(len(c) for c in full) > 64
+
+
+def test_bench_sized_batches(ctx, oracle):
+    """The sizes bench.py runs at: 1 024 frames resident in the extractor and in the cuboid batch (16 different scenes, repeated).  Every copy of a
+    scene gives the bytes of its first copy wherever it sits in the batch, and the first copies equal the oracle."""
+    from cube_slam_amd.orb import ORBextractor
+    F, D = 1024, 16
+    base = [synth.cuboid_scene(8100 + i, n_boxes=3, bg_texture=0.5) for i in range(D)]
+    scenes = [base[i % D] for i in range(F)]
+    det = detect_3d_cuboid(ctx)
+    det.set_calibration(base[0]["K"])
+    cub = _batch(ctx, det, scenes)
+    nb = [len(s["boxes"]) for s in scenes]
+    off = np.concatenate([[0], np.cumsum(nb)])
+    for f in range(D, F):
+        for k in range(nb[f]):
+            assert cub[off[f] + k].tobytes() == cub[off[f % D] + k].tobytes(), (f, k)
+    for f in (0, 7):
+        ref, _ = oracle.detect_cuboid(base[f]["gray"], base[f]["K"], base[f]["Twc"], base[f]["boxes"], base[f]["lines"], opts=oracle.cuboid_opts())
+        for k, r in enumerate(ref):
+            g = cub[off[f] + k]
+            assert len(g) == len(r) and np.array_equal(g["box_corners_2d"], r["box_corners_2d"])
+            assert np.allclose(g["pos"], r["pos"], rtol=1e-5, atol=1e-9) and np.allclose(g["edge_distance_error"], r["edge_distance_error"], rtol=1e-5)
+    orb = ORBextractor(1000, 1.2, 8, 20, 7, 640, 480, max_frames=F, ctx=ctx)
+    orb.upload(np.stack([s["gray"] for s in scenes]))
+    orb.run()
+    per = orb.read()
+    for f in range(D, F, 37):
+        assert per[f][0].tobytes() == per[f % D][0].tobytes() and per[f][1].tobytes() == per[f % D][1].tobytes(), f
+    ext = oracle.ORBextractor(1000, 1.2, 8, 20, 7)
+    for f in (0, 7):
+        k, d = ext(base[f]["gray"])
+        assert per[f][0].tobytes() == k.tobytes() and np.array_equal(per[f][1], d)
+    orb.close()
 
 
 def test_config5_object_ba_2000_keyframes(ctx, oracle):
