@@ -502,7 +502,12 @@ def main():
                                                                         "frac": (4.0 * st["roi_pixels"] + 144.0 * st["n_hypotheses"]) / ((k_us + kernels["cuboid_sweep_score_big"]["avg_us"]) * 1e-6) / 1e9 / HBM_PEAK_GBS if k_us > 0 else None,
                                                                         "note": "SURVEY 8d's per-box figure (all hypotheses' corners, 0.85 MB/box) over cuboid_sweep_score + cuboid_sweep_score_big"}},
                          "isolated": {"avg_kernel_us": iso_us, "frac": (alg_bytes / (iso_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if iso_n else None,
-                                      "note": "cuboid path alone on the GPU; the timed region runs ORB, line and cuboid kernels concurrently on three streams"}},
+                                      "note": "cuboid path alone on the GPU; the timed region runs ORB, line and cuboid kernels concurrently on three streams"},
+                         "in_run_note": (None if lsd is None or not lsd.region_stats()["device"] else
+                                         "in the timed region each line detector in flight holds frames / 16 CUs for its whole lsd_rg_seq (one wave per frame, sixteen per CU); "
+                                         "this kernel's workgroups need whole CUs (160 KB LDS, 2 x 240 VGPRs per SIMD), so its %d persistent workgroups run in rounds on the CUs left free "
+                                         "(%d of 256 with %d detectors x %d frames): `frac` is the in-run figure, `isolated.frac` the kernel's own"
+                                         % (256, max(0, 256 - len(ctx_lines) * ((args.frames + 15) // 16)), len(ctx_lines), args.frames))},
             "kernels_us": {k: round(v["avg_us"], 2) for k, v in kernels.items()},
             "host_threads": _lib.lib().cs_host_thread_count(),
             "hbm_in_use_gb": round((lambda fr_to: (fr_to[1] - fr_to[0]) / 1e9)(torch.cuda.mem_get_info()), 1),  # everything resident for the run (all blocks of this line)
