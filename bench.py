@@ -332,7 +332,8 @@ def main():
     ap.add_argument("--steps", type=int, default=100)
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames", type=int, default=1024, help="frames resident per GPU = frames per step (the line detector's region stage runs on the device from 512 on)")
-    ap.add_argument("--line-workers", type=int, default=2, help="line detectors that alternate steps on their own streams (1-4)")
+    ap.add_argument("--line-workers", type=int, default=4, help="line detectors that alternate steps on their own streams (1-4)")
+    ap.add_argument("--phased", type=int, default=1, help="1 (default): the runner's phased mode (the detectors' device region stages run together once per --line-workers steps, with the ORB / cuboid stream idle)")
     ap.add_argument("--boxes", type=int, default=3)
     ap.add_argument("--yaw-step", type=float, default=0.5)
     ap.add_argument("--no-cpu", action="store_true")
@@ -382,18 +383,21 @@ def main():
     lsd = None
     if not args.no_lines:
         from cube_slam_amd.lsd import line_lbd_detect
+        args.phased = 1 if args.phased and args.frames >= 512 and os.environ.get("CUBESLAM_LSD_REGIONS", "seq") == "seq" else 0
         # The library's front-end runner (cs_frontend_*, csrc/frontend.hip) runs ORB + cuboid on this thread and the line path on worker
         # threads with their own contexts (= HIP streams).  The detectors alternate steps.  From 512 frames per step on, region growing runs on
-        # the device, one wave per frame for ~100-180 ms (lsd_regions.hip): sixteen frames fill a CU, so two detectors in flight sit on half of
-        # the CUs and the ORB / cuboid kernels of the steps in between find the other half empty.  Below that the 16 host threads grow the
-        # regions, the GPU phases of one step overlap the host stage of the neighbouring one, and the library serialises the host stages.
+        # the device, one wave per frame for ~110 ms (lsd_regions.hip), sixteen frames to a CU.  The runner's phased mode (default) lets four
+        # detectors queue their map kernels beside ORB / cuboid of four steps and then runs the four region stages together (4096 waves = every
+        # CU) with the ORB / cuboid stream idle; --phased 0 --line-workers 2 is the alternating runner (two detectors sit on half of the CUs, the
+        # ORB / cuboid kernels use the other half).  Below 512 frames the 16 host threads grow the regions, the GPU phases of one step overlap
+        # the host stage of the neighbouring one, the library serialises the host stages, and the runner is not phased.
         ctx_lines = [_lib.Context(local_rank, priority=-1) for _ in range(max(1, min(4, args.line_workers)))]  # device phases of the line detectors: background
         lsds = [line_lbd_detect(640, 480, max_frames=args.frames, ctx=c) for c in ctx_lines]
         for d_ in lsds:
             d_.upload(np.stack([s["gray"] for s in scenes]))
         lsd = lsds[0]
     from cube_slam_amd.frontend import Frontend
-    fe = Frontend(ctx, orb=orb, batch=batch, line_detectors=lsds if lsd is not None else ())
+    fe = Frontend(ctx, orb=orb, batch=batch, line_detectors=lsds if lsd is not None else (), phased=bool(args.phased) and lsd is not None)
 
     def barrier():
         fe.drain()
@@ -483,7 +487,7 @@ def main():
             "config": {"workload": "front-end per frame: ORB extract + LSD/LBD lines + detect_3d_cuboid: 640x480 frames (3 drawn cuboids over a 1/f texture, amplitude %.2f) x %d boxes, "
                                    "180-yaw x 3-VP sweep (yaw step %.2f deg), %d frames resident per GPU; detect_cuboid is fed the scene's own edge list (cuboid edges + 40 clutter "
                                    "segments), not this step's LSD output (decoupled, SURVEY 8d C2)" % (BG_TEXTURE, args.boxes, args.yaw_step, args.frames),
-                       "lines": None if lsd is None else {"keylines_per_step": n_lines, "keylines_per_frame": n_lines / args.frames, "descriptor": "LBD 32 B", "detectors_in_flight": len(ctx_lines),
+                       "lines": None if lsd is None else {"keylines_per_step": n_lines, "keylines_per_frame": n_lines / args.frames, "descriptor": "LBD 32 B", "detectors_in_flight": len(ctx_lines), "runner": "phased" if args.phased else "alternating",
                                                                 "region_stage": ("device: one wave per frame (lsd_rg_seq)" if lsd.region_stats()["device"] else "host: %d OpenMP threads" % _lib.lib().cs_host_thread_count())},
                        "orb": None if orb is None else {"nfeatures": args.orb_features, "levels": 8, "keypoints_per_step": n_kp, "keypoints_per_frame": n_kp / args.frames},
                        "frames_per_gpu": args.frames, "boxes_per_frame": args.boxes,
@@ -504,10 +508,13 @@ def main():
                          "isolated": {"avg_kernel_us": iso_us, "frac": (alg_bytes / (iso_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if iso_n else None,
                                       "note": "cuboid path alone on the GPU; the timed region runs ORB, line and cuboid kernels concurrently on three streams"},
                          "in_run_note": (None if lsd is None or not lsd.region_stats()["device"] else
-                                         "in the timed region each line detector in flight holds frames / 16 CUs for its whole lsd_rg_seq (one wave per frame, sixteen per CU); "
-                                         "this kernel's workgroups need whole CUs (160 KB LDS, 2 x 240 VGPRs per SIMD), so its %d persistent workgroups run in rounds on the CUs left free "
-                                         "(%d of 256 with %d detectors x %d frames): `frac` is the in-run figure, `isolated.frac` the kernel's own"
-                                         % (256, max(0, 256 - len(ctx_lines) * ((args.frames + 15) // 16)), len(ctx_lines), args.frames))},
+                                         ("phased runner: lsd_rg_seq (one wave per frame, sixteen per CU) of the %d detectors runs between the super-steps with this stream idle, so this kernel never "
+                                          "shares a CU with it; in the timed region it shares the chip with the detectors' map / rectangle / LBD kernels on their own streams (HBM-bound, many "
+                                          "workgroups): `frac` is the in-run figure, `isolated.frac` the kernel's own" % len(ctx_lines)) if args.phased else
+                                         ("in the timed region each line detector in flight holds frames / 16 CUs for its whole lsd_rg_seq (one wave per frame, sixteen per CU); "
+                                          "this kernel's workgroups need whole CUs (160 KB LDS, 2 x 240 VGPRs per SIMD), so its %d persistent workgroups run in rounds on the CUs left free "
+                                          "(%d of 256 with %d detectors x %d frames): `frac` is the in-run figure, `isolated.frac` the kernel's own"
+                                          % (256, max(0, 256 - len(ctx_lines) * ((args.frames + 15) // 16)), len(ctx_lines), args.frames)))},
             "kernels_us": {k: round(v["avg_us"], 2) for k, v in kernels.items()},
             "host_threads": _lib.lib().cs_host_thread_count(),
             "hbm_in_use_gb": round((lambda fr_to: (fr_to[1] - fr_to[0]) / 1e9)(torch.cuda.mem_get_info()), 1),  # everything resident for the run (all blocks of this line)

@@ -5,6 +5,13 @@
 // lsd.hip) between two GPU phases; two line detectors alternate passes so that the GPU phases of one pass and the ORB / cuboid
 // kernels run while the other pass grows regions (the host stages themselves are serialised inside lsd.hip).  At most one pass
 // per worker is in flight; cs_frontend_step blocks until the worker it needs is free.
+//
+// Phased mode (cs_frontend_set_phased): the device region stage of LSD (lsd_rg_seq, one wave per frame, 16 frames per CU) and the
+// cuboid score kernel (one workgroup owns a CU's LDS) do not share a CU well, so the runner separates them in time.  A super-step =
+// one pass per line worker: the workers run their map kernels beside ORB / cuboid of the same passes and stop at a gate in front of
+// the region stage; after the last pass of the super-step the caller's stream is idle, the gate opens, the region stages of all
+// workers fill the chip together, and cs_frontend_step returns when they have left the GPU (the workers go on with rectangles,
+// KeyLines and LBD beside the next super-step).
 #include "common.h"
 
 #include <condition_variable>
@@ -13,12 +20,32 @@
 #include <vector>
 
 extern "C" int cs_lsd_run(cs_ctx *ctx, cs_lsd *l, int with_lbd);
+void cs_lsd_set_gate(cs_lsd *l, void (*wait)(void *), void (*done)(void *), void *arg); // lsd.hip
 extern "C" int cs_orb_run(cs_ctx *ctx, cs_orb *e);
 extern "C" int cs_cuboid_batch_run(cs_ctx *ctx, cs_cuboid_batch *b);
 
 namespace {
+struct Gate { // phase gate of one runner: tickets are pass numbers, the gate is open for every ticket <= target
+    std::mutex m; std::condition_variable cv;
+    bool phased = false;
+    long submitted = 0, target = 0, done = 0;
+};
 struct LineWorker {
     cs_ctx *ctx = nullptr; cs_lsd *lsd = nullptr;
+    Gate *gate = nullptr; long ticket = 0; bool marked = true; // (ticket, marked) belong to the pass in flight, guarded by gate->m
+    static void gate_wait(void *arg) {
+        LineWorker *w = (LineWorker *)arg; Gate *g = w->gate;
+        std::unique_lock<std::mutex> lk(g->m);
+        if (w->marked) return; // not a phased pass
+        g->cv.wait(lk, [&] { return w->ticket <= g->target; });
+    }
+    static void gate_done(void *arg) {
+        LineWorker *w = (LineWorker *)arg; Gate *g = w->gate;
+        std::lock_guard<std::mutex> lk(g->m);
+        if (w->marked) return;
+        w->marked = true; g->done++;
+        g->cv.notify_all();
+    }
     std::thread th;
     std::mutex m; std::condition_variable cv;
     bool busy = false, have_job = false, quit = false;
@@ -31,6 +58,7 @@ struct LineWorker {
             have_job = false;
             lk.unlock();
             const int r = cs_lsd_run(ctx, lsd, 1);
+            gate_done(this); // a pass that failed, fell back to the host stage or had nothing to grow never reached the device stage's own call
             lk.lock();
             if (r != CS_OK && last_status == CS_OK) last_status = r;
             busy = false;
@@ -40,6 +68,10 @@ struct LineWorker {
     void submit() {
         std::unique_lock<std::mutex> lk(m);
         cv.wait(lk, [&] { return !busy; });
+        {
+            std::lock_guard<std::mutex> gl(gate->m);
+            if (gate->phased) { ticket = ++gate->submitted; marked = false; } else marked = true;
+        }
         busy = true; have_job = true;
         cv.notify_all();
     }
@@ -56,6 +88,17 @@ struct cs_frontend {
     cs_ctx *ctx = nullptr; cs_orb *orb = nullptr; cs_cuboid_batch *batch = nullptr;
     std::vector<LineWorker *> workers;
     unsigned long step_no = 0;
+    Gate gate;
+    unsigned long in_phase = 0; // passes submitted since the gate last opened
+    int open_gate() { // caller's stream idle -> region stages of every waiting pass -> return when they have left the GPU
+        const int r = hipStreamSynchronize(ctx->stream) == hipSuccess ? CS_OK : CS_ERR_HIP; // (the gate opens either way: a waiting pass must not be left behind)
+        std::unique_lock<std::mutex> lk(gate.m);
+        gate.target = gate.submitted;
+        gate.cv.notify_all();
+        gate.cv.wait(lk, [&] { return gate.done == gate.target; });
+        in_phase = 0;
+        return r;
+    }
 };
 
 extern "C" {
@@ -68,7 +111,8 @@ int cs_frontend_create(cs_ctx *ctx, cs_orb *orb, cs_cuboid_batch *batch, int n_l
     fe->ctx = ctx; fe->orb = orb; fe->batch = batch;
     for (int i = 0; i < n_line_workers; i++) {
         LineWorker *w = new LineWorker();
-        w->ctx = line_ctx[i]; w->lsd = lsd[i];
+        w->ctx = line_ctx[i]; w->lsd = lsd[i]; w->gate = &fe->gate;
+        cs_lsd_set_gate(w->lsd, LineWorker::gate_wait, LineWorker::gate_done, w);
         w->th = std::thread([w] { w->loop(); });
         fe->workers.push_back(w);
     }
@@ -83,20 +127,32 @@ int cs_frontend_step(cs_frontend *fe) {
     int r = CS_OK;
     if (fe->orb) r = cs_orb_run(fe->ctx, fe->orb);
     if (r == CS_OK && fe->batch) r = cs_cuboid_batch_run(fe->ctx, fe->batch);
+    if (fe->gate.phased && !fe->workers.empty() && ++fe->in_phase >= fe->workers.size()) { const int g = fe->open_gate(); if (r == CS_OK) r = g; }
+    return r;
+}
+
+int cs_frontend_set_phased(cs_frontend *fe, int on) {
+    if (!fe) return CS_ERR_BAD_ARG;
+    int r = cs_frontend_drain(fe); // no pass in flight across the switch
+    std::lock_guard<std::mutex> lk(fe->gate.m);
+    fe->gate.phased = on != 0;
     return r;
 }
 
 int cs_frontend_drain(cs_frontend *fe) {
     if (!fe) return CS_ERR_BAD_ARG;
     int r = CS_OK;
+    if (fe->in_phase) r = fe->open_gate(); // an incomplete super-step
     for (LineWorker *w : fe->workers) { const int s = w->wait(); if (r == CS_OK) r = s; }
     return r;
 }
 
 void cs_frontend_destroy(cs_frontend *fe) {
     if (!fe) return;
+    if (fe->in_phase) fe->open_gate();
     for (LineWorker *w : fe->workers) {
         w->wait();
+        cs_lsd_set_gate(w->lsd, nullptr, nullptr, nullptr);
         { std::lock_guard<std::mutex> lk(w->m); w->quit = true; }
         w->cv.notify_all();
         w->th.join();

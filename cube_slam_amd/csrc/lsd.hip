@@ -562,6 +562,7 @@ struct cs_lsd {
     std::vector<uint8_t> h_desc;     // concatenated n x 32
     bool have_desc = false;
     LsdSeq *seq = nullptr;           // device buffers of the region stage (lsd_regions.hip)
+    void (*gate_wait)(void *) = nullptr; void (*gate_done)(void *) = nullptr; void *gate_arg = nullptr; // the front-end runner's phase gate around the region stage (frontend.hip)
     long rg_stats[5] = {0, 0, 0, 0, 0}; // last batch: 1 = device stage asked for, region_grow calls, rectangles at rect_improve, 1 = fell back to the host stage, window fetches
 };
 
@@ -621,18 +622,28 @@ static int lsd_run(cs_ctx *ctx, cs_lsd *l, int with_lbd) {
     std::vector<std::vector<float>> dev_lines;
     bool on_device = false;
     if (total > 0) CS_LAUNCH(ctx, "lsd_emit", lsd_emit, dim3(nbx, h, F), dim3(256), 0, l->d_mod, l->d_ang, w, h, l->d_seg_base, l->d_caddr, l->d_cdeg, l->d_ccs, l->d_cmod);
-    {
-        const char *mode = getenv("CUBESLAM_LSD_REGIONS");
-        if (!mode || !*mode) mode = F >= 512 ? "seq" : "host";
-        if (total > 0 && strcmp(mode, "seq") == 0) {
-            long st[4] = {0, 0, 0, 0};
-            r = lsd_seq_run(ctx, &l->seq, F, w, h, l->d_ang, l->d_mod, l->d_caddr, l->d_cdeg, l->d_ccs, l->frame_base.data(), dev_lines, st);
-            l->rg_stats[0] = 1; l->rg_stats[1] = st[0]; l->rg_stats[2] = st[2]; l->rg_stats[3] = r == CS_OK ? 0 : 1; l->rg_stats[4] = st[1];
-            if (r == CS_OK) on_device = true;
-            else if (r != CS_ERR_CAPACITY) return r; // a region outgrew the wave's list: the host stage takes the batch
-        } else
-            for (int k = 0; k < 5; k++) l->rg_stats[k] = 0;
-    }
+    const char *mode = getenv("CUBESLAM_LSD_REGIONS");
+    if (!mode || !*mode) mode = F >= 512 ? "seq" : "host";
+    const bool use_seq = total > 0 && strcmp(mode, "seq") == 0;
+    auto lbd_maps = [&]() -> int { // the derivative maps only depend on the gray frames
+        if (!l->d_lblur) {
+            const size_t N = (size_t)W * H * l->max_frames;
+            int q = cs_dalloc(ctx, &l->d_lblur, N); if (q) return q;
+            q = cs_dalloc(ctx, &l->d_dxy, N); if (q) return q;
+        }
+        return cs_lbd_batch_maps(ctx, l->d_gray, W, H, F, l->d_lblur, l->d_dxy);
+    };
+    bool maps_done = false;
+    if (use_seq && with_lbd) { r = lbd_maps(); if (r) return r; maps_done = true; } // ahead of the region stage: every map kernel of the batch is on the GPU before the phase gate
+    if (l->gate_wait && !use_seq) l->gate_wait(l->gate_arg); // (phased front-end: the region stage starts when the caller's own GPU work of the phase is done; the device stage waits inside lsd_seq_run, in front of its one long kernel)
+    if (use_seq) {
+        long st[4] = {0, 0, 0, 0};
+        r = lsd_seq_run(ctx, &l->seq, F, w, h, l->d_ang, l->d_mod, l->d_caddr, l->d_cdeg, l->d_ccs, l->frame_base.data(), dev_lines, st, l->gate_wait, l->gate_done, l->gate_arg);
+        l->rg_stats[0] = 1; l->rg_stats[1] = st[0]; l->rg_stats[2] = st[2]; l->rg_stats[3] = r == CS_OK ? 0 : 1; l->rg_stats[4] = st[1];
+        if (r == CS_OK) on_device = true;
+        else if (r != CS_ERR_CAPACITY) return r; // a region outgrew the wave's list: the host stage takes the batch
+    } else
+        for (int k = 0; k < 5; k++) l->rg_stats[k] = 0;
     if (!on_device && total > l->hcap) {
         if (l->h_caddr) hipHostFree(l->h_caddr); if (l->h_cdeg) hipHostFree(l->h_cdeg); if (l->h_ccs) hipHostFree(l->h_ccs); if (l->h_cmod) hipHostFree(l->h_cmod);
         l->h_caddr = nullptr; l->h_cdeg = nullptr; l->h_ccs = nullptr; l->h_cmod = nullptr; l->hcap = 0;
@@ -649,14 +660,7 @@ static int lsd_run(cs_ctx *ctx, cs_lsd *l, int with_lbd) {
     }
     hipEvent_t ev = ctx->get_event();
     CS_HIP(ctx, hipEventRecord(ev, ctx->stream));
-    if (with_lbd) { // the derivative maps only depend on the gray frames: they run while the host grows regions
-        if (!l->d_lblur) {
-            const size_t N = (size_t)W * H * l->max_frames;
-            r = cs_dalloc(ctx, &l->d_lblur, N); if (r) return r;
-            r = cs_dalloc(ctx, &l->d_dxy, N); if (r) return r;
-        }
-        r = cs_lbd_batch_maps(ctx, l->d_gray, W, H, F, l->d_lblur, l->d_dxy); if (r) return r;
-    }
+    if (with_lbd && !maps_done) { r = lbd_maps(); if (r) return r; } // they run while the host grows regions
     CS_HIP(ctx, hipEventSynchronize(ev));
     ctx->pool.push_back(ev);
     // one host stage at a time per process: two line detectors that alternate batches (bench.py) overlap their GPU phases with
@@ -854,3 +858,6 @@ int cs_lsd_get_maps(cs_ctx *ctx, cs_lsd *l, int frame, double *scaled, double *m
 }
 
 } // extern "C"
+
+// internal (frontend.hip): the runner's phase gate around the region stage; wait() is called before it, done() once lsd_rg_seq has left the GPU
+void cs_lsd_set_gate(cs_lsd *l, void (*wait)(void *), void (*done)(void *), void *arg) { l->gate_wait = wait; l->gate_done = done; l->gate_arg = arg; }

@@ -277,7 +277,8 @@ void lsd_seq_destroy(LsdSeq *r) {
 // The region stage of F frames, one wave per frame.  lines[f] = x1 y1 x2 y2 floats in the reference's emission order.  CS_ERR_CAPACITY: a region
 // outgrew the wave's list (rgs::CAP pixels) or a frame its rectangle list -- the caller then runs the host stage for the batch.
 int lsd_seq_run(cs_ctx *ctx, LsdSeq **handle, int F, int w, int h, const double *d_ang, const double *d_mod, const int *d_caddr, const float *d_cdeg, const float2 *d_ccs, const int *frame_base,
-                std::vector<std::vector<float>> &lines, long *stats /* [0] region_grow calls, [1] window fetches, [2] rectangles at rect_improve, [3] regions at the rectangle stage */) {
+                std::vector<std::vector<float>> &lines, long *stats /* [0] region_grow calls, [1] window fetches, [2] rectangles at rect_improve, [3] regions at the rectangle stage */,
+                void (*before_seq)(void *), void (*after_seq)(void *), void *gate_arg /* the front-end runner's phase gate: called in front of the lsd_rg_seq launch and once it has left the GPU; may be NULL */) {
     LsdSeq *r = *handle;
     if (w > 0xffff || h > 0x7fff) return CS_ERR_CAPACITY; // (the region list packs x | y << 16)
     int max_ne = 0;
@@ -322,12 +323,15 @@ int lsd_seq_run(cs_ctx *ctx, LsdSeq **handle, int F, int w, int h, const double 
     CS_LAUNCH(ctx, "lsd_rg_scatter", lsd_rg_scatter, dim3((max_ne + 255) / 256, F), dim3(256), 0, S);
     int wpb = 16; // waves (= frames) per workgroup
     if (const char *e = getenv("CUBESLAM_LSD_SEQ_WPB")) wpb = std::max(1, std::min(16, atoi(e)));
+    if (before_seq) before_seq(gate_arg);
     CS_LAUNCH(ctx, "lsd_rg_seq", lsd_rg_seq, dim3((F + wpb - 1) / wpb), dim3(64 * wpb), 0, S);
     CS_LAUNCH(ctx, "lsd_rg_cand_scan", lsd_rg_cand_scan, dim3(1), dim3(1024), 0, r->d_cand_cnt, F, r->d_cand_base);
     r->h_base.resize((size_t)F + 1); r->h_status.resize((size_t)F * 4);
     RA_(cs_d2h(ctx, r->h_base.data(), r->d_cand_base, (size_t)F + 1));
     RA_(cs_d2h(ctx, r->h_status.data(), r->d_status, (size_t)F * 4));
     CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    const bool gate_late = getenv("CUBESLAM_FE_GATE_LATE") != nullptr; // (experiment: the gate also covers lsd_rg_improve)
+    if (after_seq && !gate_late) after_seq(gate_arg);
 #if defined(RGS_PROFILE)
     { std::vector<unsigned long long> all((size_t)F * 16); hipMemcpy(all.data(), S.prof, all.size() * 8, hipMemcpyDeviceToHost);
       unsigned long long hp[16] = {0}; for (int f = 0; f < F; f++) for (int k = 0; k < 16; k++) hp[k] += all[(size_t)f * 16 + k];
@@ -354,6 +358,7 @@ int lsd_seq_run(cs_ctx *ctx, LsdSeq **handle, int F, int w, int h, const double 
     RA_(cs_d2h(ctx, r->h_has.data(), r->d_has, (size_t)n_cand));
     RA_(cs_d2h(ctx, r->h_line.data(), r->d_line, (size_t)n_cand));
     CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (after_seq && gate_late) after_seq(gate_arg);
 #undef RA_
 #pragma omp parallel for schedule(static) num_threads(std::max(1, std::min(ctx->host_threads, F)))
     for (int f = 0; f < F; f++)

@@ -6,8 +6,10 @@ from ._lib import check, lib
 
 
 class Frontend:
-    def __init__(self, ctx, orb=None, batch=None, line_detectors=()):
-        """line_detectors: line_lbd_detect objects, each created on its own Context and holding the same uploaded frames."""
+    def __init__(self, ctx, orb=None, batch=None, line_detectors=(), phased=False):
+        """line_detectors: line_lbd_detect objects, each created on its own Context and holding the same uploaded frames.
+        phased: the detectors' device region stages run together after one pass per detector, with the caller's stream idle
+        (cs_frontend_set_phased)."""
         self.ctx, self.orb, self.batch, self.lines = ctx, orb, batch, list(line_detectors)
         n = len(self.lines)
         ctxs = (C.c_void_p * max(n, 1))(*[d.ctx.ptr for d in self.lines])
@@ -15,6 +17,11 @@ class Frontend:
         self._fe = C.c_void_p()
         check(ctx.ptr, lib().cs_frontend_create(ctx.ptr, orb._e if orb is not None else None, batch._b if batch is not None else None, n, ctxs, lsds, C.byref(self._fe)),
               "cs_frontend_create")
+        if phased:
+            self.set_phased(True)
+
+    def set_phased(self, on):
+        check(self.ctx.ptr, lib().cs_frontend_set_phased(self._fe, 1 if on else 0), "cs_frontend_set_phased")
 
     def step(self):
         check(self.ctx.ptr, lib().cs_frontend_step(self._fe), "cs_frontend_step")

@@ -433,6 +433,11 @@ int cs_frontend_create(cs_ctx *ctx, cs_orb *orb /* nullable */, cs_cuboid_batch 
                        cs_lsd *const *lsd, cs_frontend **out);
 int cs_frontend_step(cs_frontend *fe);
 int cs_frontend_drain(cs_frontend *fe);
+/* Phased passes (off by default; results are the same either way).  With the device region stage of LSD (batches of >= 512 frames) a
+ * super-step = one pass per line detector: the detectors stop in front of the region stage, and after the last pass of the super-step
+ * (or at cs_frontend_drain) the region stages of all of them run together while `ctx`'s stream is idle -- that cs_frontend_step
+ * returns when they have left the GPU.  The cuboid score kernel and the one-wave-per-frame region kernel then never share a CU. */
+int cs_frontend_set_phased(cs_frontend *fe, int on);
 void cs_frontend_destroy(cs_frontend *fe);
 
 /* ===================================================================== 9-dof g2o::cuboid of object_slam

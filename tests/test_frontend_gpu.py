@@ -41,3 +41,39 @@ def test_frontend_equals_separate_calls(ctx, oracle):
     fe.close()
     with pytest.raises(Exception):
         Frontend(ctx, orb=orb, batch=batch, line_detectors=[line_lbd_detect(640, 480, ctx=ctx)])  # a worker may not share the caller's context
+
+
+def test_frontend_phased_passes(ctx, oracle, monkeypatch):
+    """Phased runner (cs_frontend_set_phased): the detectors wait in front of the device region stage until one pass per detector is
+    submitted; incomplete super-steps are released by drain; lines and descriptors equal the oracle's either way."""
+    monkeypatch.setenv("CUBESLAM_LSD_REGIONS", "seq")  # the device stage at a test-sized batch
+    scenes = [synth.cuboid_scene(900 + i, n_boxes=2) for i in range(4)]
+    gray = np.stack([s["gray"] for s in scenes])
+    det = detect_3d_cuboid(ctx); det.set_calibration(scenes[0]["K"])
+    batch = CuboidBatch(ctx, gray, scenes[0]["K"], np.stack([s["Twc"] for s in scenes]), [s["boxes"] for s in scenes], [s["lines"] for s in scenes], det.opts())
+    orb = ORBextractor(500, 1.2, 8, 20, 7, 640, 480, max_frames=len(scenes), ctx=ctx); orb.upload(gray)
+    lctx = [_lib.Context(0) for _ in range(3)]
+    lsds = [line_lbd_detect(640, 480, max_frames=len(scenes), ctx=c) for c in lctx]
+    for d in lsds:
+        d.upload(gray)
+    fe = Frontend(ctx, orb=orb, batch=batch, line_detectors=lsds, phased=True)
+    for _ in range(7):  # two full super-steps and one pass of a third
+        fe.step()
+    fe.drain()
+    fe.drain()
+    fe.step()  # a single pass after a drain
+    fe.drain()
+    fe.set_phased(False)
+    fe.step()
+    fe.drain()
+    for d in lsds:
+        assert d.region_stats()["device"] == 1
+    for f, s in enumerate(scenes):
+        ref_kl = oracle.lsd_detect(s["gray"])
+        for d in lsds:
+            kl, desc = d.read(f)
+            assert kl.tobytes() == ref_kl.tobytes() and np.array_equal(desc, oracle.lbd_compute(s["gray"], ref_kl))
+    fe.close()
+    # a detector that was under a runner runs on its own afterwards
+    lsds[0].run(); kl, _ = lsds[0].read(0)
+    assert kl.tobytes() == oracle.lsd_detect(scenes[0]["gray"]).tobytes()
