@@ -99,7 +99,7 @@ __global__ void __launch_bounds__(256) ba_err_obs(Params G, double *partials) {
         if (obs_stereo(G, o)) { // EdgeStereoSE3ProjectXYZ::cam_project (types_six_dof_expmap.cpp:182-189): invz and bf are floats there
             const float invz = (float)(1.0 / pc[2]);
             const double u = pc[0] * invz * G.fx + G.cx;
-            e0 = G.o_uv[o * 2] - u; e1 = G.o_uv[o * 2 + 1] - (pc[1] * invz * G.fy + G.cy); e2 = G.o_ur[o] - (u - (double)(float)G.bf * invz);
+            e0 = G.o_uv[o * 2] - u; e1 = G.o_uv[o * 2 + 1] - (pc[1] * invz * G.fy + G.cy); e2 = G.o_ur[o] - (u - (double)((float)G.bf * invz)); // (bf arrives as const float&: the product is a float product)
             chi = ((e0 * e0 + e1 * e1) + e2 * e2) * G.o_w[o];
             delta = G.huber_stereo;
         } else {
@@ -1188,10 +1188,17 @@ struct PoseFrame { int e0, e1; double fx, fy, cx, cy, bf; };
 __device__ __forceinline__ void pose_edge_eval(const SE3 &T, const double *Xw, const double *ob, const PoseFrame &F, double *e) {
     double pc[3];
     se3_map(T, Xw, pc);
-    const double invz = 1.0 / pc[2];
-    e[0] = ob[0] - (pc[0] * invz * F.fx + F.cx);
-    e[1] = ob[1] - (pc[1] * invz * F.fy + F.cy);
-    e[2] = ob[2] >= 0 ? ob[2] - ((pc[0] * invz * F.fx + F.cx) - F.bf * invz) : 0.0;
+    if (ob[2] >= 0) { // EdgeStereoSE3ProjectXYZOnlyPose::cam_project (types_six_dof_expmap.cpp:331-338): invz is a float there
+        const float invz = (float)(1.0 / pc[2]);
+        const double u = pc[0] * invz * F.fx + F.cx;
+        e[0] = ob[0] - u;
+        e[1] = ob[1] - (pc[1] * invz * F.fy + F.cy);
+        e[2] = ob[2] - (u - F.bf * invz);
+    } else { // EdgeSE3ProjectXYZOnlyPose::cam_project over project2d (:37-42, 322-328): a division per coordinate
+        e[0] = ob[0] - (pc[0] / pc[2] * F.fx + F.cx);
+        e[1] = ob[1] - (pc[1] / pc[2] * F.fy + F.cy);
+        e[2] = 0.0;
+    }
 }
 __device__ __forceinline__ double pose_edge_chi2(const double *e, double w, bool stereo) {
     return stereo ? ((e[0] * w * e[0] + e[1] * w * e[1]) + e[2] * w * e[2]) : (e[0] * w * e[0] + e[1] * w * e[1]);

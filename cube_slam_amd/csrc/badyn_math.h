@@ -70,7 +70,7 @@ HD void dyn_err_obs(const DynG &G, int o, const SE3 &T, const double *X, double 
         const double u = pc[0] * invz * G.fx + G.cx;
         e[0] = G.o_uv[o * 2] - u;
         e[1] = G.o_uv[o * 2 + 1] - (pc[1] * invz * G.fy + G.cy);
-        e[2] = G.o_ur[o] - (u - (double)(float)G.bf * invz);
+        e[2] = G.o_ur[o] - (u - (double)((float)G.bf * invz)); // (bf arrives as const float&: the product is a float product)
         return;
     }
     e[0] = G.o_uv[o * 2] - (pc[0] / pc[2] * G.fx + G.cx);

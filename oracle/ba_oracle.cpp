@@ -69,7 +69,7 @@ struct BA {
             const double u = pc[0] * invz * p->fx + p->cx;
             e[0] = p->obs_uv[o * 2] - u;
             e[1] = p->obs_uv[o * 2 + 1] - (pc[1] * invz * p->fy + p->cy);
-            e[2] = p->obs_ur[o] - (u - (double)(float)p->bf * invz);
+            e[2] = p->obs_ur[o] - (u - (double)((float)p->bf * invz)); // `bf*invz` with bf a const float& parameter: a float product
             return;
         }
         const double px = pc[0] / pc[2], py = pc[1] / pc[2];
@@ -114,7 +114,8 @@ struct BA {
         if (e <= dsqr) { rho[0] = e; rho[1] = 1.; rho[2] = 0.; }
         else { const double sq = std::sqrt(e); rho[0] = 2 * sq * delta - dsqr; rho[1] = delta / sq; rho[2] = -0.5 * rho[1] / e; }
     }
-    double chi2_obs(int o) const { const double *e = &e_obs[(size_t)o * 3]; return stereo(o) ? ((e[0] * e[0] + e[1] * e[1]) + e[2] * e[2]) * p->obs_inv_sigma2[o] : (e[0] * e[0] + e[1] * e[1]) * p->obs_inv_sigma2[o]; }
+    // BaseEdge::chi2 = _error.dot(information() * _error) (base_edge.h:58-61): each term is e_k * (w * e_k), summed left to right
+    double chi2_obs(int o) const { const double *e = &e_obs[(size_t)o * 3]; const double w = p->obs_inv_sigma2[o]; return stereo(o) ? (e[0] * (w * e[0]) + e[1] * (w * e[1])) + e[2] * (w * e[2]) : e[0] * (w * e[0]) + e[1] * (w * e[1]); }
     double chi2_cobs(int o) const { const double *e = &e_cobs[(size_t)o * 4]; const double *w = p->cobs_info + (size_t)o * 4; return ((e[0] * w[0] * e[0] + e[1] * w[1] * e[1]) + e[2] * w[2] * e[2]) + e[3] * w[3] * e[3]; }
     double chi2_pc(int o) const { const double *e = &e_pc[(size_t)o * 3]; return (e[0] * e[0] + e[1] * e[1]) + e[2] * e[2]; }
     double robust_chi2() const { // sparse_optimizer.cpp:100-114
@@ -179,7 +180,9 @@ struct BA {
                 for (int a = 0; a < 6; a++) {
                     bp[a] += (Jj[0][a] * omr[0] + Jj[1][a] * omr[1]) + Jj[2][a] * omr[2];
                     for (int c = 0; c < 6; c++) hp[a * 6 + c] += ((Jj[0][a] * W) * Jj[0][c] + (Jj[1][a] * W) * Jj[1][c]) + (Jj[2][a] * W) * Jj[2][c];
-                    for (int c = 0; c < 3; c++) hx[a * 3 + c] += ((Jj[0][a] * W) * Ji[0][c] + (Jj[1][a] * W) * Ji[1][c]) + (Jj[2][a] * W) * Ji[2][c];
+                    // the transposed block: B^T * weightedOmega * A under a kernel, B^T * (A^T * omega)^T without one (base_binary_edge.hpp:84-87, 108-111)
+                    if (obs_delta(o) > 0) for (int c = 0; c < 3; c++) hx[a * 3 + c] += ((Jj[0][a] * W) * Ji[0][c] + (Jj[1][a] * W) * Ji[1][c]) + (Jj[2][a] * W) * Ji[2][c];
+                    else for (int c = 0; c < 3; c++) hx[a * 3 + c] += (Jj[0][a] * (Ji[0][c] * W) + Jj[1][a] * (Ji[1][c] * W)) + Jj[2][a] * (Ji[2][c] * W);
                 }
             }
         }
@@ -525,6 +528,16 @@ void orc_ba_pop(orc_ba_handle *h) { h->ba.s = h->ba.stack.back(); h->ba.stack.po
 void orc_ba_discard_top(orc_ba_handle *h) { h->ba.stack.pop_back(); }
 const double *orc_ba_x(orc_ba_handle *h, long *n) { if (n) *n = (long)h->ba.x.size(); return h->ba.x.data(); }
 const double *orc_ba_b(orc_ba_handle *h) { return h->ba.b.data(); }
+int orc_ba_block(orc_ba_handle *h, int kind, int i, int j, double *out) { // after orc_ba_build_system.  kind 0: Hpp(i, i) 36; 1: Hpp(i, j), i < j, 36; 2: Hll(i) 9; 3: Hpl of observation i, 18 (6 x 3)
+    const BA &ba = h->ba;
+    if (kind == 0) { if (i < 0 || i >= ba.P) return 0; std::copy(&ba.Hpp_diag[(size_t)i * 36], &ba.Hpp_diag[(size_t)i * 36] + 36, out); return 36; }
+    if (kind == 1) { auto it = ba.Hpp_off.find(std::make_pair(i, j)); if (it == ba.Hpp_off.end()) return 0; std::copy(it->second.begin(), it->second.end(), out); return 36; }
+    if (kind == 2) { if (i < 0 || i >= ba.L) return 0; std::copy(&ba.Hll[(size_t)i * 9], &ba.Hll[(size_t)i * 9] + 9, out); return 9; }
+    if (kind == 3) { if (i < 0 || i >= ba.p->n_obs) return 0; std::copy(&ba.Hpl[(size_t)i * 18], &ba.Hpl[(size_t)i * 18] + 18, out); return 18; }
+    return 0;
+}
+int orc_ba_pose_index(orc_ba_handle *h, int is_cuboid, int i) { return is_cuboid ? h->ba.cub_idx[i] : h->ba.cam_idx[i]; } // Hessian block of a camera / cuboid, -1 if fixed
+double orc_ba_edge_chi2(orc_ba_handle *h, int kind, int o) { return kind == 0 ? h->ba.chi2_obs(o) : kind == 1 ? h->ba.chi2_cobs(o) : h->ba.chi2_pc(o); } // after orc_ba_compute_errors
 void orc_ba_read(orc_ba_handle *h, double *cam_pose_out, double *points_out, double *cuboid_pose_out) {
     const orc_ba_problem *p = h->ba.p;
     for (int i = 0; i < p->n_cams; i++) se3_to7(h->ba.s.cams[i], cam_pose_out + (size_t)i * 7);
@@ -553,11 +566,18 @@ struct PoseOpt {
     void eval(int i) { // computeError
         double pc[3];
         se3_map(T, Xw + (size_t)i * 3, pc);
-        const double invz = 1.0 / pc[2];
         double *e = &err[(size_t)i * 3];
-        e[0] = obs[(size_t)i * 3] - (pc[0] * invz * fx + cx);
-        e[1] = obs[(size_t)i * 3 + 1] - (pc[1] * invz * fy + cy);
-        e[2] = stereo(i) ? obs[(size_t)i * 3 + 2] - ((pc[0] * invz * fx + cx) - bf * invz) : 0.0;
+        if (stereo(i)) { // EdgeStereoSE3ProjectXYZOnlyPose::cam_project (types_six_dof_expmap.cpp:331-338): invz is a float there, bf the edge's double
+            const float invz = (float)(1.0 / pc[2]);
+            const double u = pc[0] * invz * fx + cx;
+            e[0] = obs[(size_t)i * 3] - u;
+            e[1] = obs[(size_t)i * 3 + 1] - (pc[1] * invz * fy + cy);
+            e[2] = obs[(size_t)i * 3 + 2] - (u - bf * invz);
+        } else { // EdgeSE3ProjectXYZOnlyPose::cam_project (:322-328) over project2d (:37-42): a division per coordinate
+            e[0] = obs[(size_t)i * 3] - (pc[0] / pc[2] * fx + cx);
+            e[1] = obs[(size_t)i * 3 + 1] - (pc[1] / pc[2] * fy + cy);
+            e[2] = 0.0;
+        }
     }
     double chi2(int i) const { const double *e = &err[(size_t)i * 3]; return stereo(i) ? ((e[0] * w[i] * e[0] + e[1] * w[i] * e[1]) + e[2] * w[i] * e[2]) : (e[0] * w[i] * e[0] + e[1] * w[i] * e[1]); }
     double delta(int i) const { return stereo(i) ? (double)(float)std::sqrt(7.815) : (double)(float)std::sqrt(5.991); } // const float deltaMono = sqrt(5.991)
@@ -583,9 +603,9 @@ struct PoseOpt {
             if (robust) { BA::huber(chi2(i), delta(i), rho); rw = rho[1]; }
             const double *e = &err[(size_t)i * 3];
             for (int a = 0; a < 6; a++) {
-                double acc = 0;
-                for (int d = 0; d < dim; d++) acc += J[d * 6 + a] * (-(w[i] * e[d]));
-                b[a] += rw * acc;
+                double acc = 0; // b -= rho[1] * A^T * omega * e (base_unary_edge.hpp:43-76), products left to right
+                for (int d = 0; d < dim; d++) acc += ((rw * J[d * 6 + a]) * w[i]) * e[d];
+                b[a] -= acc;
                 for (int c = 0; c < 6; c++) { double h = 0; for (int d = 0; d < dim; d++) h += J[d * 6 + a] * (rw * w[i]) * J[d * 6 + c]; H[a * 6 + c] += h; }
             }
         }
@@ -674,6 +694,19 @@ extern "C" int orc_pose_optimization(int n, const double *Xw, const double *obs,
     }
     se3_to7(P.T, pose_out);
     return n - nBad;
+}
+
+// Test hook (tests/test_ref_pins.py): one computeActiveErrors + linearisation of PoseOptimization's graph at pose_in, to be held against the reference's own
+// pose-only edges (oracle/_ref).  H 6 x 6, b 6, chi2 n.
+extern "C" void orc_pose_linearize(int n, const double *Xw, const double *obs, const double *inv_sigma2, double fx, double fy, double cx, double cy, double bf, const double *pose_in,
+                                   int robust, double *H, double *b, double *chi2) {
+    PoseOpt P;
+    P.n = n; P.Xw = Xw; P.obs = obs; P.w = inv_sigma2; P.fx = fx; P.fy = fy; P.cx = cx; P.cy = cy; P.bf = bf;
+    P.err.assign((size_t)n * 3, 0.0); P.level1.assign((size_t)n, 0);
+    P.T = se3_from7(pose_in); P.robust = robust != 0;
+    P.compute_active_errors();
+    for (int i = 0; i < n; i++) chi2[i] = P.chi2(i);
+    P.build(H, b);
 }
 
 // ------------------------------------------------------------------------------------------------ 9-dof g2o::cuboid (object_slam's graph)

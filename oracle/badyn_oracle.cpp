@@ -72,7 +72,7 @@ struct DynBA {
             const double u = pc[0] * invz * p->fx + p->cx;
             e[0] = p->obs_uv[o * 2] - u;
             e[1] = p->obs_uv[o * 2 + 1] - (pc[1] * invz * p->fy + p->cy);
-            e[2] = p->obs_ur[o] - (u - (double)(float)p->bf * invz);
+            e[2] = p->obs_ur[o] - (u - (double)((float)p->bf * invz)); // `bf*invz` with bf a const float& parameter: a float product
             return;
         }
         e[0] = p->obs_uv[o * 2] - (pc[0] / pc[2] * p->fx + p->cx);

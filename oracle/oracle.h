@@ -278,8 +278,13 @@ void orc_ba_pop(orc_ba_handle *h);
 void orc_ba_discard_top(orc_ba_handle *h);
 const double *orc_ba_x(orc_ba_handle *h, long *n);
 const double *orc_ba_b(orc_ba_handle *h);
+int orc_ba_block(orc_ba_handle *h, int kind, int i, int j, double *out); /* blocks of the system orc_ba_build_system left: 0 Hpp(i,i) 1 Hpp(i,j) i<j 2 Hll(i) 3 Hpl of observation i (6 x 3) */
+int orc_ba_pose_index(orc_ba_handle *h, int is_cuboid, int i);
+double orc_ba_edge_chi2(orc_ba_handle *h, int kind, int o); /* BaseEdge::chi2 of an edge: 0 point observation 1 camera-cuboid 2 point-cuboid */
 void orc_ba_read(orc_ba_handle *h, double *cam_pose_out, double *points_out, double *cuboid_pose_out);
 int orc_se3_op(int op, const double *a, const double *b, double s, double *out);
+void orc_pose_linearize(int n, const double *Xw, const double *obs, const double *inv_sigma2, double fx, double fy, double cx, double cy, double bf, const double *pose_in,
+                        int robust, double *H, double *b, double *chi2);
 
 /* --------------------------------------------------------------------------------------------------------------------
  * Optimizer::LocalBACameraPointObjectsDynamic (orb_object_slam/src/Optimizer.cc:1537-2573): the graph it hands to g2o

@@ -69,6 +69,14 @@ template <typename T, int R, int C> class Matrix : public MatrixBase<Matrix<T, R
         return r;
     }
     Matrix<T, C, R> transpose() const { Matrix<T, C, R> r; for (int i = 0; i < R; i++) for (int j = 0; j < C; j++) r.d[j * R + i] = d[i * C + j]; return r; }
+    Matrix &noalias() { return *this; }
+    T dot(const Matrix &o) const { T s = d[0] * o.d[0]; for (int i = 1; i < R * C; i++) s += d[i] * o.d[i]; return s; }
+    struct ArrF { // .array(): coefficient-wise quotient, assignable back to a matrix
+        Matrix m;
+        ArrF operator/(const ArrF &o) const { ArrF r{m}; for (int i = 0; i < R * C; i++) r.m.d[i] = m.d[i] / o.m.d[i]; return r; }
+    };
+    ArrF array() const { return ArrF{*this}; }
+    Matrix(const ArrF &a) { for (int i = 0; i < R * C; i++) d[i] = a.m.d[i]; }
     Matrix cwiseAbs() const { Matrix r; for (int i = 0; i < R * C; i++) r.d[i] = std::fabs(d[i]); return r; }
     T minCoeff(int *idx) const { int b = 0; for (int i = 1; i < R * C; i++) if (d[i] < d[b]) b = i; *idx = b; return d[b]; }
     // segments of a vector: assignable views on a non-const object, values on a const one

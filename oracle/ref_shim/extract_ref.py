@@ -69,6 +69,37 @@ WANT = [  # (file, signatures, output include)
                                                                                       "void OptimizationAlgorithmLevenberg::printVerbose(std::ostream& os) const"], "extracted_levenberg.inc"),
     ("orb_object_slam/Thirdparty/g2o/g2o/core/sparse_optimizer.cpp", ["int SparseOptimizer::optimize(int iterations, bool online)"], "extracted_levenberg.inc"),
     ("orb_object_slam/Thirdparty/g2o/g2o/core/robust_kernel_impl.cpp", ["void RobustKernelHuber::setDelta(double delta)", "void RobustKernelHuber::robustify(double e, Eigen::Vector3d& rho) const"], "extracted_huber.inc"),
+    # the BA's linear side per edge: g2o's numeric Jacobians and quadratic forms (templates of base_binary_edge.hpp / base_unary_edge.hpp), the two one-liners of
+    # base_edge.h they call, the vertex / edge classes of the object BA with their out-of-line members (compiled against stand-ins for BaseVertex / BaseEdge,
+    # ref_linearize_api.cpp)
+    ("orb_object_slam/Thirdparty/g2o/g2o/core/base_binary_edge.hpp", ["void BaseBinaryEdge<D, E, VertexXiType, VertexXjType>::constructQuadraticForm()",
+                                                                      "void BaseBinaryEdge<D, E, VertexXiType, VertexXjType>::linearizeOplus()",
+                                                                      "void BaseBinaryEdge<D, E, VertexXiType, VertexXjType>::linearizeOplusXi()",
+                                                                      "void BaseBinaryEdge<D, E, VertexXiType, VertexXjType>::linearizeOplusXj()"], "extracted_lin_core.inc"),
+    ("orb_object_slam/Thirdparty/g2o/g2o/core/base_unary_edge.hpp", ["void BaseUnaryEdge<D, E, VertexXiType>::constructQuadraticForm()",
+                                                                     "void BaseUnaryEdge<D, E, VertexXiType>::linearizeOplus()"], "extracted_lin_core.inc"),
+    ("orb_object_slam/Thirdparty/g2o/g2o/core/base_edge.h", ["virtual double chi2() const", "InformationType robustInformation(const Eigen::Vector3d& rho)"], "extracted_lin_edge_members.inc"),
+    ("orb_object_slam/Thirdparty/g2o/g2o/types/types_sba.h", ["class VertexSBAPointXYZ : public BaseVertex<3, Vector3d>"], "extracted_lin_types.inc"),
+    ("orb_object_slam/Thirdparty/g2o/g2o/types/types_six_dof_expmap.h", ["class  VertexSE3Expmap : public BaseVertex<6, SE3Quat>{",
+                                                                         "class  EdgeSE3ProjectXYZ: public  BaseBinaryEdge<2, Vector2d, VertexSBAPointXYZ, VertexSE3Expmap>{",
+                                                                         "class  EdgeStereoSE3ProjectXYZ: public  BaseBinaryEdge<3, Vector3d, VertexSBAPointXYZ, VertexSE3Expmap>{",
+                                                                         "class  EdgeSE3ProjectXYZOnlyPose: public  BaseUnaryEdge<2, Vector2d, VertexSE3Expmap>{",
+                                                                         "class  EdgeStereoSE3ProjectXYZOnlyPose: public  BaseUnaryEdge<3, Vector3d, VertexSE3Expmap>{"], "extracted_lin_types.inc"),
+    ("orb_object_slam/include/g2o_Object.h", ["class VertexCuboidFixScale : public BaseVertex<6, cuboid>",
+                                              "class EdgeSE3CuboidFixScaleProj : public BaseBinaryEdge<4, Vector4d, VertexSE3Expmap, VertexCuboidFixScale>",
+                                              "class EdgePointCuboidOnlyObjectFixScale : public BaseUnaryEdge<3, Vector3d, VertexCuboidFixScale>"], "extracted_lin_types.inc"),
+    ("orb_object_slam/Thirdparty/g2o/g2o/types/types_sba.cpp", ["VertexSBAPointXYZ::VertexSBAPointXYZ() : BaseVertex<3, Vector3d>()"], "extracted_lin_cpp.inc"),
+    ("orb_object_slam/Thirdparty/g2o/g2o/types/types_six_dof_expmap.cpp", ["Vector2d project2d(const Vector3d& v)  {", "VertexSE3Expmap::VertexSE3Expmap() : BaseVertex<6, SE3Quat>() {",
+                                                                           "EdgeSE3ProjectXYZ::EdgeSE3ProjectXYZ() : BaseBinaryEdge<2, Vector2d, VertexSBAPointXYZ, VertexSE3Expmap>() {",
+                                                                           "void EdgeSE3ProjectXYZ::linearizeOplus() {", "Vector2d EdgeSE3ProjectXYZ::cam_project(const Vector3d & trans_xyz) const{",
+                                                                           "Vector3d EdgeStereoSE3ProjectXYZ::cam_project(const Vector3d & trans_xyz, const float &bf) const{",
+                                                                           "EdgeStereoSE3ProjectXYZ::EdgeStereoSE3ProjectXYZ() : BaseBinaryEdge<3, Vector3d, VertexSBAPointXYZ, VertexSE3Expmap>() {",
+                                                                           "void EdgeStereoSE3ProjectXYZ::linearizeOplus() {",
+                                                                           "void EdgeSE3ProjectXYZOnlyPose::linearizeOplus() {", "Vector2d EdgeSE3ProjectXYZOnlyPose::cam_project(const Vector3d & trans_xyz) const{",
+                                                                           "Vector3d EdgeStereoSE3ProjectXYZOnlyPose::cam_project(const Vector3d & trans_xyz) const{",
+                                                                           "void EdgeStereoSE3ProjectXYZOnlyPose::linearizeOplus() {"], "extracted_lin_cpp.inc"),
+    ("orb_object_slam/src/g2o_Object.cpp", ["void VertexCuboidFixScale::oplusImpl(const double *update_)", "void EdgeSE3CuboidFixScaleProj::computeError()",
+                                            "void EdgePointCuboidOnlyObjectFixScale::computeError()"], "extracted_lin_cpp.inc"),
     # the LBD descriptor: BinaryDescriptor's compute path (the rest of binary_descriptor.cpp is the EDLine detector, which CubeSLAM does not use)
     ("line_lbd/libs/binary_descriptor.cpp", ["static const int combinations[32][2] =", "BinaryDescriptor::Params::Params()", "BinaryDescriptor::BinaryDescriptor( const BinaryDescriptor::Params &parameters ) :",
                                              "BinaryDescriptor::~BinaryDescriptor()", "static inline int get2Pow( int i )", "void BinaryDescriptor::computeGaussianPyramid( const Mat& image, const int numOctaves )",
@@ -105,7 +136,7 @@ for rel, sigs, dst in WANT:
     out = outs.setdefault(dst, ["// generated by oracle/ref_shim/extract_ref.py from %s -- not tracked" % REF])
     for s in sigs:
         out.append("// ---- %s : %s" % (rel, s))
-        out.append(cut(text, s) + (";" if s.rstrip().endswith("=") else ""))
+        out.append(cut(text, s) + (";" if s.rstrip().endswith("=") or s.lstrip().startswith("class ") else ""))
 os.makedirs(OUT, exist_ok=True)
 for dst, out in outs.items():
     open(os.path.join(OUT, dst), "w").write("\n".join(out) + "\n")

@@ -4,31 +4,9 @@
 //   * members of class g2o::cuboid (exp_update, cube_log_error, min_log_error, rotate_cuboid, transform_from / _to) cut out of
 //     include/g2o_Object.h, and exptwist_norollpitch / cuboid::point_boundary_error cut out of src/g2o_Object.cpp, by extract_ref.py at build time.
 // tests/test_ref_pins.py compares the oracle's restatement (oracle/se3_util.h, ba_oracle.cpp) with these.
-#include <algorithm>
-#include <cmath>
-#include <iostream>
-
-#include "Thirdparty/g2o/g2o/types/se3quat.h"
-
-typedef Eigen::Matrix<double, 9, 1> Vector9d;
-typedef Eigen::Matrix<double, 10, 1> Vector10d;
-typedef Eigen::Matrix<double, 6, 1> Vector6d;
-
-using namespace Eigen;
-#include "extracted_g2o_utils.inc"
+#include "ref_g2o_types.hpp"
 
 namespace g2o {
-using namespace Eigen;
-class cuboid { // g2o_Object.h:29-35: the two data members and the default constructor; the member functions below are the reference's text
-  public:
-    SE3Quat pose;
-    Vector3d scale;
-    cuboid() { pose = SE3Quat(); scale.setZero(); }
-    inline const Vector3d &translation() const { return pose.translation(); }
-    inline void setTranslation(const Vector3d &t_) { pose.setTranslation(t_); }
-#include "extracted_g2o_members.inc"
-    Vector3d point_boundary_error(const Vector3d &point, const double max_outside_margin_ratio, double point_scale = 1) const;
-};
 using namespace std;
 #include "extracted_g2o_cpp.inc"
 } // namespace g2o

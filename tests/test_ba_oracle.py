@@ -63,7 +63,7 @@ def test_stereo_error_known_answer(oracle):
         if d["obs_ur"][o] >= 0:
             invz = np.float64(np.float32(1.0 / X[2]))
             u = X[0] * invz * fx + cx
-            exp[o] = [d["obs_uv"][o, 0] - u, d["obs_uv"][o, 1] - (X[1] * invz * fy + cy), d["obs_ur"][o] - (u - np.float64(np.float32(bf)) * invz)]
+            exp[o] = [d["obs_uv"][o, 0] - u, d["obs_uv"][o, 1] - (X[1] * invz * fy + cy), d["obs_ur"][o] - (u - np.float64(np.float32(bf) * np.float32(invz)))]  # bf*invz: a float product (bf is a const float& there)
         else:
             exp[o, :2] = d["obs_uv"][o] - [X[0] / X[2] * fx + cx, X[1] / X[2] * fy + cy]
     assert np.array_equal(eo, exp), "bit-exact incl. the float reciprocal"

@@ -502,3 +502,92 @@ def test_pose_math_equals_reference(ref, oracle):
         assert np.array_equal(orc(13, c1, np.concatenate([a, K.ravel()]), n=4), rcall("ref_project_bbox", 4, c1, a, K.ravel()))
         n_checked += 1
     assert n_checked == 300
+
+
+def test_edge_linearisation_equals_reference(ref, oracle):
+    """The BA's linear side edge by edge: g2o's BaseBinaryEdge / BaseUnaryEdge linearizeOplus (central differences, delta 1e-9, through push / oplus /
+    computeError / pop) and constructQuadraticForm (with and without a robust kernel, both block layouts), BaseEdge::chi2 / robustInformation, and the
+    vertex / edge classes of the object BA whole (VertexSE3Expmap, VertexSBAPointXYZ, EdgeSE3ProjectXYZ and its stereo twin with their analytic Jacobians,
+    VertexCuboidFixScale, EdgeSE3CuboidFixScaleProj, EdgePointCuboidOnlyObjectFixScale) -- the reference's own text, cut out at build time and compiled
+    against stand-ins for BaseVertex / BaseEdge (oracle/ref_shim/ref_linearize_api.cpp) -- against the oracle's build_system: every residual, every chi2,
+    every block of Hpp, Hll, Hpl and the right-hand side, to the last bit."""
+    import oracle.pyoracle as po
+    olib = po.lib()
+    olib.orc_ba_open.restype = C.c_void_p
+    olib.orc_ba_edge_chi2.restype = C.c_double
+    olib.orc_ba_b.restype = C.POINTER(C.c_double)
+    cases = ((11, dict(n_kf=6, n_points=60, n_cuboids=2), {}), (12, dict(n_kf=8, n_points=90, n_cuboids=3, stereo_frac=0.5), {}),
+             (13, dict(n_kf=5, n_points=40, n_cuboids=2), dict(flags=2 | 8, fix_more=True)), (14, dict(n_kf=7, n_points=70, n_cuboids=2, stereo_frac=1.0), dict(flags=4, no_huber=True)),
+             (15, dict(n_kf=6, n_points=50, n_cuboids=3), dict(flags=0)))
+    n_blocks = 0
+    for seed, kw, mod in cases:
+        d = synth.ba_problem(seed, **kw)
+        if "flags" in mod:
+            d["cuboid_flags"] = np.full(len(d["cuboid_pose"]), mod["flags"], np.uint8)
+        if mod.get("fix_more"):
+            d["cam_fixed"][2] = 1
+        if mod.get("no_huber"):
+            d["huber_mono"] = 0.0; d["huber_stereo"] = 0.0; d["huber_obj"] = 0.0
+        p = po.ba_struct(d)
+        n_edges = p.n_obs + p.n_cobs + p.n_pc
+        n_err = 3 * p.n_obs + 4 * p.n_cobs + 3 * p.n_pc
+        P_max = p.n_cams + p.n_cuboids
+        Hpp, Hll, Hpl, Hcc = np.zeros((P_max, 36)), np.zeros((p.n_points, 9)), np.zeros((p.n_obs, 18)), np.zeros((max(p.n_cobs, 1), 36))
+        b, err, chi = np.zeros(6 * P_max + 3 * p.n_points), np.zeros(n_err), np.zeros(n_edges)
+        P = ref.ref_ba_linearize(C.byref(p), _dp(Hpp), _dp(Hll), _dp(Hpl), _dp(Hcc), _dp(b), _dp(err), _dp(chi))
+        h = C.c_void_p(olib.orc_ba_open(C.byref(p)))
+        olib.orc_ba_compute_errors(h); olib.orc_ba_build_system(h)
+        Po, Lo = C.c_int(), C.c_int()
+        olib.orc_ba_sizes(h, C.byref(Po), C.byref(Lo))
+        assert P == Po.value == int((d["cam_fixed"] == 0).sum()) + p.n_cuboids and Lo.value == p.n_points
+        _, eo, ec, ep = po.ba_errors(d)
+        assert np.array_equal(err, np.concatenate([np.asarray(eo).ravel(), np.asarray(ec).ravel(), np.asarray(ep).ravel()])), seed
+        ochi = [olib.orc_ba_edge_chi2(h, 0, o) for o in range(p.n_obs)] + [olib.orc_ba_edge_chi2(h, 1, o) for o in range(p.n_cobs)] + [olib.orc_ba_edge_chi2(h, 2, o) for o in range(p.n_pc)]
+        assert np.array_equal(chi, np.array(ochi)), (seed, np.abs(chi - np.array(ochi)).max())
+        ob = np.ctypeslib.as_array(olib.orc_ba_b(h), shape=(6 * P + 3 * p.n_points,))
+        assert np.array_equal(b[:6 * P + 3 * p.n_points], ob), (seed, np.abs(b[:len(ob)] - ob).max())
+        blk = np.zeros(36)
+        for i in range(P):
+            assert olib.orc_ba_block(h, 0, i, i, _dp(blk)) == 36 and np.array_equal(blk, Hpp[i]), (seed, "Hpp", i); n_blocks += 1
+        for i in range(p.n_points):
+            assert olib.orc_ba_block(h, 2, i, 0, _dp(blk)) == 9 and np.array_equal(blk[:9], Hll[i]), (seed, "Hll", i); n_blocks += 1
+        for o in range(p.n_obs):
+            if d["cam_fixed"][d["obs_cam"][o]]:
+                continue
+            assert olib.orc_ba_block(h, 3, o, 0, _dp(blk)) == 18 and np.array_equal(blk[:18], Hpl[o]), (seed, "Hpl", o); n_blocks += 1
+        seen = set()
+        for o in range(p.n_cobs):
+            ci, cj = olib.orc_ba_pose_index(h, 0, int(d["cobs_cam"][o])), olib.orc_ba_pose_index(h, 1, int(d["cobs_cuboid"][o]))
+            if ci < 0:
+                continue
+            assert (ci, cj) not in seen  # (one edge per camera-cuboid pair: the oracle's block is that edge's)
+            seen.add((ci, cj))
+            assert olib.orc_ba_block(h, 1, ci, cj, _dp(blk)) == 36 and np.array_equal(blk, Hcc[o]), (seed, "Hcc", o); n_blocks += 1
+        olib.orc_ba_close(h)
+    assert n_blocks > 900
+
+
+def test_pose_only_edges_equal_reference(ref, oracle):
+    """Optimizer::PoseOptimization's graph, one linearisation: EdgeSE3ProjectXYZOnlyPose / EdgeStereoSE3ProjectXYZOnlyPose (computeError with their
+    cam_project, analytic linearizeOplus: types_six_dof_expmap.h:227-290, .cpp:298-392) under BaseUnaryEdge::constructQuadraticForm with and without
+    the Huber kernel -- the reference's text -- against the oracle's PoseOpt::eval / build: chi2 per edge, H and b to the last bit."""
+    import oracle.pyoracle as po
+    olib = po.lib()
+    for seed, stereo_frac, robust in ((1, 0.0, 1), (2, 0.4, 1), (3, 1.0, 1), (4, 0.3, 0)):
+        f = synth.pose_frame(seed, n=300, stereo_frac=stereo_frac)
+        n = len(f["Xw"])
+        Xw, obs, w = np.ascontiguousarray(f["Xw"], np.float64), np.ascontiguousarray(f["obs"], np.float64), np.ascontiguousarray(f["inv_sigma2"], np.float64)
+        assert obs.shape == (n, 3) and ((obs[:, 2] >= 0).any() == (stereo_frac > 0))
+        fx, fy, cx, cy, bf = [float(v) for v in f["intr"]]
+        pose = np.ascontiguousarray(f["pose"], np.float64)
+        uv, ur = np.ascontiguousarray(obs[:, :2]), np.ascontiguousarray(obs[:, 2])
+        dm, ds = float(np.float32(np.sqrt(5.991))), float(np.float32(np.sqrt(7.815)))  # const float deltaMono = sqrt(5.991) (Optimizer.cc:278-279)
+        H, b, chi = np.zeros(36), np.zeros(6), np.zeros(n)
+        ref.ref_pose_linearize(n, _dp(Xw), _dp(uv), _dp(ur), _dp(w), C.c_double(fx), C.c_double(fy), C.c_double(cx), C.c_double(cy), C.c_double(bf), _dp(pose),
+                               C.c_double(dm if robust else 0.0), C.c_double(ds if robust else 0.0), _dp(H), _dp(b), _dp(chi))
+        oH, ob, ochi = np.zeros(36), np.zeros(6), np.zeros(n)
+        olib.orc_pose_linearize(n, _dp(Xw), _dp(obs), _dp(w), C.c_double(fx), C.c_double(fy), C.c_double(cx), C.c_double(cy), C.c_double(bf), _dp(pose), robust, _dp(oH), _dp(ob), _dp(ochi))
+        assert np.array_equal(chi, ochi), (seed, np.abs(chi - ochi).max())
+        assert np.array_equal(b, ob), (seed, np.abs(b - ob).max())
+        assert np.array_equal(H, oH), (seed, np.abs(H - oH).max())
+        assert np.abs(H).max() > 0 and (chi > (dm * dm)).any()
