@@ -1,7 +1,9 @@
 /*
  * oracle/badyn_oracle.cpp -- CPU oracle for the dynamic-object bundle adjustment (Optimizer::LocalBACameraPointObjectsDynamic).
  *
- * TEST INFRASTRUCTURE ONLY (see oracle.h).  PARITY UNPINNED: restated from /root/reference/orb_object_slam/src/Optimizer.cc:1537-2573
+ * TEST INFRASTRUCTURE ONLY (see oracle.h).  EDGES PINNED (tests/test_ref_pins.py::test_dynamic_ba_edges_equal_reference, oracle/_ref): computeError of every
+ * edge type and the Jacobians of the two three-vertex types equal the reference's own classes (cut out whole, g2o's numeric differentiation under them) bit for
+ * bit; the graph construction, the block solver and the LM loop are unpinned.  Restated from /root/reference/orb_object_slam/src/Optimizer.cc:1537-2573
  * (the graph), orb_object_slam/{include/g2o_Object.h, src/g2o_Object.cpp} (VertexCuboidFixScale :88-116, VelocityPlanarVelocity
  * g2o_Object.h:288-308, EdgeDynamicPointCuboidCamera :154-233, EdgeObjectMotion :241-272, UnaryLocalPoint :378-398,
  * EdgeSE3CuboidFixScaleProj :118-128, EdgePointCuboidOnlyObjectFixScale :336-354) and the vendored g2o under
@@ -207,6 +209,42 @@ struct DynBA {
     Cuboid obj_plus(int i, const double *add) const { return cuboid_oplus(s.objs[i], add, p->obj_flags[i], p->obj_scale + (size_t)i * 3); }
     SE3 cam_plus(int i, const double *add) const { return se3_mul(se3_exp(add), s.cams[i]); }
 
+    Lin lin_dobs(int o) { // EdgeDynamicPointCuboidCamera::linearizeOplus :167-233
+            const int ci = p->dobs_cam[o], oi = p->dobs_obj[o], li = p->dobs_point[o];
+            Lin E; E.nv = 3; E.D = 2;
+            E.off[0] = cam_off[ci]; E.dim[0] = 6; E.off[1] = obj_off[oi]; E.dim[1] = 6; E.lm[2] = lm_dynamic(li); E.dim[2] = 3;
+            const double *objectpt = &s.dpts[(size_t)li * 3];
+            const SE3 combinedT = se3_mul(s.cams[ci], s.objs[oi].pose);
+            double cp[3];
+            se3_map(combinedT, objectpt, cp);
+            const double fx = p->K[0], fy = p->K[4], x = cp[0], y = cp[1], z = cp[2], z_2 = z * z;
+            const double P[2][3] = {{fx / z, 0, -x * fx / z_2}, {0, fy / z, -y * fy / z_2}};
+            M3 R; qtoR(combinedT.r, R);
+            double (*Jc)[6] = reinterpret_cast<double (*)[6]>(E.J[0]), (*Jo)[6] = reinterpret_cast<double (*)[6]>(E.J[1]), (*Jp)[6] = reinterpret_cast<double (*)[6]>(E.J[2]);
+            for (int r = 0; r < 2; r++) for (int c = 0; c < 3; c++) Jp[r][c] = ((-P[r][0]) * R[0][c] + (-P[r][1]) * R[1][c]) + (-P[r][2]) * R[2][c];
+            Jc[0][0] = x * y / z_2 * fx; Jc[0][1] = -(1 + (x * x / z_2)) * fx; Jc[0][2] = y / z * fx; Jc[0][3] = -1. / z * fx; Jc[0][4] = 0; Jc[0][5] = x / z_2 * fx;
+            Jc[1][0] = (1 + y * y / z_2) * fy; Jc[1][1] = -x * y / z_2 * fy; Jc[1][2] = -x / z * fy; Jc[1][3] = 0; Jc[1][4] = -1. / z * fy; Jc[1][5] = y / z_2 * fy;
+            const double S[3][6] = {{-0.0, objectpt[2], -objectpt[1], 1, 0, 0}, {-objectpt[2], -0.0, objectpt[0], 0, 1, 0}, {objectpt[1], -objectpt[0], -0.0, 0, 0, 1}}; // [-skew(p) | I]
+            for (int r = 0; r < 2; r++) for (int c = 0; c < 6; c++) Jo[r][c] = (Jp[r][0] * S[0][c] + Jp[r][1] * S[1][c]) + Jp[r][2] * S[2][c];
+            const int fl = p->obj_flags[oi];
+            if (fl & 1) { Jo[0][0] = 0; Jo[0][1] = 0; Jo[1][0] = 0; Jo[1][1] = 0; }
+            if (fl & 2) { Jo[0][0] = 0; Jo[0][1] = 0; Jo[1][0] = 0; Jo[1][1] = 0; Jo[0][2] = 0; Jo[1][2] = 0; }
+            for (int k = 0; k < 2; k++) { E.e[k] = e_dobs[(size_t)o * 2 + k]; E.w[k] = p->dobs_inv_sigma2[o]; }
+            E.delta = p->huber_dyn;
+            return E;
+    }
+    Lin lin_mot(int o) { // EdgeObjectMotion: numeric Jacobians for the three vertices (base_multi_edge.hpp:62-133)
+            const int a = p->mot_from[o], b2 = p->mot_to[o], vi = p->mot_vel[o];
+            Lin E; E.nv = 3; E.D = 3;
+            E.off[0] = obj_off[a]; E.dim[0] = 6; E.off[1] = obj_off[b2]; E.dim[1] = 6; E.off[2] = vel_off[vi]; E.dim[2] = 2;
+            const double *v = &s.vels[(size_t)vi * 2];
+            numeric(E, 0, 3, [&](const double *add, double *e) { err_mot(o, obj_plus(a, add), s.objs[b2], v, e); });
+            numeric(E, 1, 3, [&](const double *add, double *e) { err_mot(o, s.objs[a], obj_plus(b2, add), v, e); });
+            numeric(E, 2, 3, [&](const double *add, double *e) { const double v2[2] = {v[0] + add[0], v[1] + add[1]}; err_mot(o, s.objs[a], s.objs[b2], v2, e); });
+            for (int k = 0; k < 3; k++) { E.e[k] = e_mot[(size_t)o * 3 + k]; E.w[k] = p->mot_info[k]; }
+            return E;
+    }
+
     void build_system() { // BlockSolver::buildSystem block_solver.hpp:502-560
         Hpp.assign((size_t)NP * NP, 0.0); bp.assign(NP, 0.0); Hll.assign((size_t)L * 9, 0.0); bl.assign((size_t)L * 3, 0.0);
         Hpl.assign(L, std::vector<PL>());
@@ -238,42 +276,8 @@ struct DynBA {
             E.delta = stereo(o) ? p->huber_stereo : p->huber_mono;
             add_edge(E);
         }
-        for (int o = 0; o < p->n_dobs; o++) { // EdgeDynamicPointCuboidCamera::linearizeOplus :167-233
-            if (lvl(p->dobs_level, o)) continue;
-            const int ci = p->dobs_cam[o], oi = p->dobs_obj[o], li = p->dobs_point[o];
-            Lin E; E.nv = 3; E.D = 2;
-            E.off[0] = cam_off[ci]; E.dim[0] = 6; E.off[1] = obj_off[oi]; E.dim[1] = 6; E.lm[2] = lm_dynamic(li); E.dim[2] = 3;
-            const double *objectpt = &s.dpts[(size_t)li * 3];
-            const SE3 combinedT = se3_mul(s.cams[ci], s.objs[oi].pose);
-            double cp[3];
-            se3_map(combinedT, objectpt, cp);
-            const double fx = p->K[0], fy = p->K[4], x = cp[0], y = cp[1], z = cp[2], z_2 = z * z;
-            const double P[2][3] = {{fx / z, 0, -x * fx / z_2}, {0, fy / z, -y * fy / z_2}};
-            M3 R; qtoR(combinedT.r, R);
-            double (*Jc)[6] = reinterpret_cast<double (*)[6]>(E.J[0]), (*Jo)[6] = reinterpret_cast<double (*)[6]>(E.J[1]), (*Jp)[6] = reinterpret_cast<double (*)[6]>(E.J[2]);
-            for (int r = 0; r < 2; r++) for (int c = 0; c < 3; c++) Jp[r][c] = ((-P[r][0]) * R[0][c] + (-P[r][1]) * R[1][c]) + (-P[r][2]) * R[2][c];
-            Jc[0][0] = x * y / z_2 * fx; Jc[0][1] = -(1 + (x * x / z_2)) * fx; Jc[0][2] = y / z * fx; Jc[0][3] = -1. / z * fx; Jc[0][4] = 0; Jc[0][5] = x / z_2 * fx;
-            Jc[1][0] = (1 + y * y / z_2) * fy; Jc[1][1] = -x * y / z_2 * fy; Jc[1][2] = -x / z * fy; Jc[1][3] = 0; Jc[1][4] = -1. / z * fy; Jc[1][5] = y / z_2 * fy;
-            const double S[3][6] = {{-0.0, objectpt[2], -objectpt[1], 1, 0, 0}, {-objectpt[2], -0.0, objectpt[0], 0, 1, 0}, {objectpt[1], -objectpt[0], -0.0, 0, 0, 1}}; // [-skew(p) | I]
-            for (int r = 0; r < 2; r++) for (int c = 0; c < 6; c++) Jo[r][c] = (Jp[r][0] * S[0][c] + Jp[r][1] * S[1][c]) + Jp[r][2] * S[2][c];
-            const int fl = p->obj_flags[oi];
-            if (fl & 1) { Jo[0][0] = 0; Jo[0][1] = 0; Jo[1][0] = 0; Jo[1][1] = 0; }
-            if (fl & 2) { Jo[0][0] = 0; Jo[0][1] = 0; Jo[1][0] = 0; Jo[1][1] = 0; Jo[0][2] = 0; Jo[1][2] = 0; }
-            for (int k = 0; k < 2; k++) { E.e[k] = e_dobs[(size_t)o * 2 + k]; E.w[k] = p->dobs_inv_sigma2[o]; }
-            E.delta = p->huber_dyn;
-            add_edge(E);
-        }
-        for (int o = 0; o < p->n_mot; o++) { // EdgeObjectMotion: numeric Jacobians for the three vertices
-            const int a = p->mot_from[o], b2 = p->mot_to[o], vi = p->mot_vel[o];
-            Lin E; E.nv = 3; E.D = 3;
-            E.off[0] = obj_off[a]; E.dim[0] = 6; E.off[1] = obj_off[b2]; E.dim[1] = 6; E.off[2] = vel_off[vi]; E.dim[2] = 2;
-            const double *v = &s.vels[(size_t)vi * 2];
-            numeric(E, 0, 3, [&](const double *add, double *e) { err_mot(o, obj_plus(a, add), s.objs[b2], v, e); });
-            numeric(E, 1, 3, [&](const double *add, double *e) { err_mot(o, s.objs[a], obj_plus(b2, add), v, e); });
-            numeric(E, 2, 3, [&](const double *add, double *e) { const double v2[2] = {v[0] + add[0], v[1] + add[1]}; err_mot(o, s.objs[a], s.objs[b2], v2, e); });
-            for (int k = 0; k < 3; k++) { E.e[k] = e_mot[(size_t)o * 3 + k]; E.w[k] = p->mot_info[k]; }
-            add_edge(E);
-        }
+        for (int o = 0; o < p->n_dobs; o++) if (!lvl(p->dobs_level, o)) add_edge(lin_dobs(o));
+        for (int o = 0; o < p->n_mot; o++) add_edge(lin_mot(o));
         for (int o = 0; o < p->n_cobs; o++) { // EdgeSE3CuboidFixScaleProj: numeric (base_binary_edge.hpp:216-320)
             if (lvl(p->cobs_level, o)) continue;
             const int ci = p->cobs_cam[o], oi = p->cobs_obj[o];
@@ -393,6 +397,15 @@ double orc_badyn_errors(const orc_badyn_problem *p, double *e_obs, double *e_dob
     return ba.robust_chi2();
 }
 
+// Test hook (tests/test_ref_pins.py): the Jacobians of the two three-vertex edge types at the problem's estimates, to be held against the reference's own
+// EdgeDynamicPointCuboidCamera::linearizeOplus and BaseMultiEdge::linearizeOplus over EdgeObjectMotion (oracle/_ref).  J_dobs: n_dobs x 3 vertices (camera, object,
+// point) x 2 rows x 6 (row stride 6, unused columns zero); J_mot: n_mot x 3 vertices (from, to, velocity) x 3 rows x 6.
+void orc_badyn_edge_jacobians(const orc_badyn_problem *p, double *J_dobs, double *J_mot) {
+    DynBA ba(p);
+    ba.compute_errors();
+    for (int o = 0; o < p->n_dobs; o++) { const Lin E = ba.lin_dobs(o); for (int v = 0; v < 3; v++) for (int k = 0; k < 12; k++) J_dobs[(size_t)o * 36 + v * 12 + k] = (k % 6) < E.dim[v] ? E.J[v][k] : 0.0; }
+    for (int o = 0; o < p->n_mot; o++) { const Lin E = ba.lin_mot(o); for (int v = 0; v < 3; v++) for (int k = 0; k < 18; k++) J_mot[(size_t)o * 54 + v * 18 + k] = (k % 6) < E.dim[v] ? E.J[v][k] : 0.0; }
+}
 int orc_badyn_reduced_dense(const orc_badyn_problem *p, double lambda, double *H, double *bvec) {
     DynBA ba(p);
     if (!H) return ba.NP;

@@ -321,6 +321,7 @@ double orc_badyn_errors(const orc_badyn_problem *p, double *e_obs, double *e_dob
 /* reduced pose system (Hpp + lambda I - Hpl (Hll + lambda I)^-1 Hlp, bp - Hpl (Hll + lambda I)^-1 bl) at the given estimates, dense row-major;
  * pose scalars are ordered cameras (6 each, non-fixed), object poses (6), velocities (2).  Returns the dimension; H may be NULL to query it. */
 int orc_badyn_reduced_dense(const orc_badyn_problem *p, double lambda, double *H, double *bvec);
+void orc_badyn_edge_jacobians(const orc_badyn_problem *p, double *J_dobs, double *J_mot); /* test hook: per-edge Jacobians of the three-vertex edges */
 /* one linear step with a given damping (computeActiveErrors, buildSystem, solve, update); returns 1 if the factorisation failed */
 int orc_badyn_step(const orc_badyn_problem *p, double lambda, double *cam_pose, double *obj_pose, double *vel, double *points, double *dpoints);
 /* SparseOptimizer::optimize(iterations) */

@@ -113,6 +113,12 @@ template <typename T, int R, int C> class Matrix : public MatrixBase<Matrix<T, R
         Corner &operator=(const Matrix<T, RR, CC> &v) { for (int i = 0; i < RR; i++) for (int j = 0; j < CC; j++) m.d[i * C + j] = v.d[i * CC + j]; return *this; }
     };
     template <int RR, int CC> Corner<RR, CC> topLeftCorner() { return Corner<RR, CC>{*this}; }
+    template <int N> struct Cols { // leftCols<N>() / rightCols<N>(): assignable
+        Matrix &m; int j0;
+        Cols &operator=(const Matrix<T, R, N> &v) { for (int i = 0; i < R; i++) for (int j = 0; j < N; j++) m.d[i * C + j0 + j] = v.d[i * N + j]; return *this; }
+    };
+    template <int N> Cols<N> leftCols() { return Cols<N>{*this, 0}; }
+    template <int N> Cols<N> rightCols() { return Cols<N>{*this, C - N}; }
     Matrix<T, R, R> asDiagonal() const { static_assert(C == 1, ""); Matrix<T, R, R> r; for (int i = 0; i < R; i++) r.d[i * R + i] = d[i]; return r; }
     DynMat<T> operator*(const DynMat<T> &o) const; // fixed x dynamic
 };
@@ -137,6 +143,15 @@ template <typename T> class DynMat {
     T operator()(int i, int j) const { return d[(size_t)i * c + j]; }
     T operator()(int i) const { return d[i]; }
     static DynMat Ones(int n) { DynMat m(1, n); for (auto &v : m.d) v = T(1); return m; }
+    template <int R, int C> DynMat &operator=(const Matrix<T, R, C> &m) { r = R; c = C; d.assign(m.d, m.d + R * C); return *this; }
+    template <int R, int C> DynMat operator*(const Matrix<T, R, C> &o) const { // coefficient-based product, k ascending
+        assert(c == R);
+        DynMat x(r, C);
+        for (int i = 0; i < r; i++) for (int j = 0; j < C; j++) { T s = (*this)(i, 0) * o.d[j]; for (int k = 1; k < R; k++) s += (*this)(i, k) * o.d[k * C + j]; x(i, j) = s; }
+        return x;
+    }
+    struct ColRef { DynMat &m; int j; template <int N> ColRef &operator=(const Matrix<T, N, 1> &v) { assert(N == m.r); for (int i = 0; i < N; i++) m(i, j) = v.d[i]; return *this; } };
+    ColRef col(int j) { return ColRef{*this, j}; }
     struct Comma { // Eigen's comma initialiser: scalars and blocks, left to right, then the next rows
         DynMat &m; int row, col, bh;
         void put(const DynMat &b) { if (col == m.c) { row += bh; col = 0; } for (int i = 0; i < b.r; i++) for (int j = 0; j < b.c; j++) m(row + i, col + j) = b(i, j); col += b.c; bh = b.r; }

@@ -100,6 +100,12 @@ WANT = [  # (file, signatures, output include)
                                                                            "void EdgeStereoSE3ProjectXYZOnlyPose::linearizeOplus() {"], "extracted_lin_cpp.inc"),
     ("orb_object_slam/src/g2o_Object.cpp", ["void VertexCuboidFixScale::oplusImpl(const double *update_)", "void EdgeSE3CuboidFixScaleProj::computeError()",
                                             "void EdgePointCuboidOnlyObjectFixScale::computeError()"], "extracted_lin_cpp.inc"),
+    # ... and the three-vertex edges of the dynamic-object BA with g2o's numeric Jacobians for them
+    ("orb_object_slam/Thirdparty/g2o/g2o/core/base_multi_edge.hpp", ["void BaseMultiEdge<D, E>::linearizeOplus()", "void BaseMultiEdge<D, E>::linearizeOplusXid(int variable_id)"], "extracted_lin_multi.inc"),
+    ("orb_object_slam/include/g2o_Object.h", ["class VelocityPlanarVelocity : public BaseVertex<2, Vector2d>", "class UnaryLocalPoint : public BaseUnaryEdge<3, Vector3d, VertexSBAPointXYZ>",
+                                              "class EdgeDynamicPointCuboidCamera : public BaseMultiEdge<2, Vector2d>", "class EdgeObjectMotion : public BaseMultiEdge<3, Vector3d>"], "extracted_lin_dyn.inc"),
+    ("orb_object_slam/src/g2o_Object.cpp", ["void EdgeDynamicPointCuboidCamera::computeError()", "void EdgeDynamicPointCuboidCamera::linearizeOplus()", "void EdgeObjectMotion::computeError()",
+                                            "void UnaryLocalPoint::computeError()"], "extracted_lin_dyn.inc"),
     # the LBD descriptor: BinaryDescriptor's compute path (the rest of binary_descriptor.cpp is the EDLine detector, which CubeSLAM does not use)
     ("line_lbd/libs/binary_descriptor.cpp", ["static const int combinations[32][2] =", "BinaryDescriptor::Params::Params()", "BinaryDescriptor::BinaryDescriptor( const BinaryDescriptor::Params &parameters ) :",
                                              "BinaryDescriptor::~BinaryDescriptor()", "static inline int get2Pow( int i )", "void BinaryDescriptor::computeGaussianPyramid( const Mat& image, const int numOctaves )",

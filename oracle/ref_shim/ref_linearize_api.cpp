@@ -25,13 +25,22 @@ namespace g2o {
 using namespace Eigen;
 using namespace std;
 
+#define OptimizableGraph OptimizableGraphLin // (ref_levenberg_api.cpp has its own stand-in of that name in this library)
 struct JacobianWorkspace {};
 class RobustKernel { // core/robust_kernel.h: what an edge asks of its kernel
   public:
     double delta = 1;
     void robustify(double e, Eigen::Vector3d &rho) const { double r[3]; ref_huber_robustify(e, delta, r); rho[0] = r[0]; rho[1] = r[1]; rho[2] = r[2]; }
 };
-struct VertexBase { virtual ~VertexBase() {} };
+struct VertexBase { // what base_multi_edge.hpp asks of an OptimizableGraph::Vertex
+    virtual ~VertexBase() {}
+    virtual int dimension() const = 0;
+    virtual bool fixed() const = 0;
+    virtual void push() = 0;
+    virtual void pop() = 0;
+    virtual void oplus(const double *v) = 0;
+};
+struct OptimizableGraph { typedef VertexBase Vertex; };
 
 template <int D, typename T> class BaseVertex : public VertexBase { // core/base_vertex.h, core/optimizable_graph.h (Vertex): the members the cut-out texts use
   public:
@@ -39,12 +48,13 @@ template <int D, typename T> class BaseVertex : public VertexBase { // core/base
     BaseVertex() {}
     const T &estimate() const { return _estimate; }
     void setEstimate(const T &et) { _estimate = et; }           // base_vertex.h:101
-    void push() { _backup.push(_estimate); }                    // base_vertex.h:89
-    void pop() { _estimate = _backup.top(); _backup.pop(); }    // base_vertex.h:90
-    void oplus(const double *v) { oplusImpl(v); }               // optimizable_graph.h: Vertex::oplus = oplusImpl + updateCache
+    int dimension() const override { return D; }
+    void push() override { _backup.push(_estimate); }                    // base_vertex.h:89
+    void pop() override { _estimate = _backup.top(); _backup.pop(); }    // base_vertex.h:90
+    void oplus(const double *v) override { oplusImpl(v); }               // optimizable_graph.h: Vertex::oplus = oplusImpl + updateCache
     virtual void oplusImpl(const double *v) = 0;
     virtual void setToOriginImpl() = 0;
-    bool fixed() const { return _fixed; }
+    bool fixed() const override { return _fixed; }
     void setFixed(bool f) { _fixed = f; }
     Matrix<double, D, 1> &b() { return _b; }                     // (the real b() / A() are maps into the solver's vector and diagonal block)
     Matrix<double, D, D> &A() { return _A; }
@@ -130,9 +140,32 @@ template <int D, typename E, typename VertexXi> class BaseUnaryEdge : public Bas
     JacobianXiOplusType _jacobianOplusXi;
 };
 
+template <int D, typename E> class BaseMultiEdge : public BaseEdge<D, E> { // core/base_multi_edge.h (this fork adds analytical_jaco_id / linearizeOplusXid)
+  public:
+    typedef typename BaseEdge<D, E>::ErrorVector ErrorVector;
+    typedef typename BaseEdge<D, E>::InformationType InformationType;
+    typedef DynMat<double> JacobianType; // (the real one maps D x dim of a JacobianWorkspace)
+    BaseMultiEdge() { analytical_jaco_id = -1; _dimension = D; }
+    void resize(size_t n) { _vertices.resize(n); _jacobianOplus.resize(n); }
+    void sizeJacobians() { for (size_t i = 0; i < _vertices.size(); i++) _jacobianOplus[i].resize(D, _vertices[i]->dimension()); } // linearizeOplus(JacobianWorkspace&), base_multi_edge.hpp:51-60
+    using BaseEdge<D, E>::computeError;
+    virtual void linearizeOplus();
+    virtual void linearizeOplusXid(int variable_id);
+    int analytical_jaco_id;
+    std::vector<JacobianType> _jacobianOplus;
+  protected:
+    using BaseEdge<D, E>::_measurement;
+    using BaseEdge<D, E>::_information;
+    using BaseEdge<D, E>::_error;
+    using BaseEdge<D, E>::_vertices;
+    int _dimension;
+};
+
 #include "extracted_lin_core.inc"
+#include "extracted_lin_multi.inc"
 #include "extracted_lin_types.inc"
 #include "extracted_lin_cpp.inc"
+#include "extracted_lin_dyn.inc"
 
 // (declared virtual by the classes above; the graph-file readers are not on the path)
 bool VertexSBAPointXYZ::read(std::istream &) { return false; }
@@ -276,5 +309,77 @@ void ref_pose_linearize(int n, const double *Xw, const double *uv, const double 
         }
     }
     put(v.A(), H); put(v.b(), b);
+}
+
+// The edges of Optimizer::LocalBACameraPointObjectsDynamic's graph (Optimizer.cc:1537-2573) at the problem's estimates: computeError of every edge type, and the
+// Jacobians of the two three-vertex types -- EdgeDynamicPointCuboidCamera's own linearizeOplus and BaseMultiEdge::linearizeOplus (central differences) over
+// EdgeObjectMotion.  Layouts as orc_badyn_errors / orc_badyn_edge_jacobians.
+void ref_badyn_edges(const orc_badyn_problem *p, double *e_obs, double *e_dobs, double *e_mot, double *e_cobs, double *e_pc, double *e_ulp, double *J_dobs, double *J_mot) {
+    using namespace g2o;
+    std::vector<VertexSE3Expmap> cams(p->n_cams);
+    std::vector<VertexCuboidFixScale> objs(p->n_objs);
+    std::vector<VelocityPlanarVelocity> vels(p->n_vels);
+    std::vector<VertexSBAPointXYZ> pts(p->n_points), dpts(p->n_dpoints);
+    for (int i = 0; i < p->n_cams; i++) { cams[i].setEstimate(se3(p->cam_pose + (size_t)i * 7)); cams[i].setFixed(p->cam_fixed[i] != 0); }
+    for (int i = 0; i < p->n_objs; i++) {
+        cuboid c; c.pose = se3(p->obj_pose + (size_t)i * 7);
+        for (int k = 0; k < 3; k++) c.scale[k] = p->obj_scale[i * 3 + k];
+        objs[i].setEstimate(c);
+        const int fl = p->obj_flags[i];
+        objs[i].whether_fixrollpitch = fl & 1; objs[i].whether_fixrotation = (fl & 2) != 0; objs[i].whether_fixheight = (fl & 4) != 0;
+        if (fl & 8) for (int k = 0; k < 3; k++) objs[i].fixedscale[k] = p->obj_scale[i * 3 + k];
+    }
+    for (int i = 0; i < p->n_vels; i++) vels[i].setEstimate(Eigen::Vector2d(p->vel[i * 2], p->vel[i * 2 + 1]));
+    for (int i = 0; i < p->n_points; i++) { pts[i].setEstimate(Eigen::Vector3d(p->points[i * 3], p->points[i * 3 + 1], p->points[i * 3 + 2])); pts[i].setFixed(p->fix_points != 0); }
+    for (int i = 0; i < p->n_dpoints; i++) { dpts[i].setEstimate(Eigen::Vector3d(p->dpoints[i * 3], p->dpoints[i * 3 + 1], p->dpoints[i * 3 + 2])); dpts[i].setFixed(p->fix_points != 0); }
+    Eigen::Matrix3d K;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) K(i, j) = p->K[i * 3 + j];
+    for (int o = 0; o < p->n_obs; o++) {
+        double *e = e_obs + (size_t)o * 3;
+        if (!(p->obs_ur && p->obs_ur[o] >= 0)) {
+            EdgeSE3ProjectXYZ ed; ed.setVertex(0, &pts[p->obs_point[o]]); ed.setVertex(1, &cams[p->obs_cam[o]]);
+            ed.setMeasurement(Eigen::Vector2d(p->obs_uv[o * 2], p->obs_uv[o * 2 + 1])); ed.fx = p->fx; ed.fy = p->fy; ed.cx = p->cx; ed.cy = p->cy;
+            ed.computeError(); e[0] = ed.error()[0]; e[1] = ed.error()[1]; e[2] = 0;
+        } else {
+            EdgeStereoSE3ProjectXYZ ed; ed.setVertex(0, &pts[p->obs_point[o]]); ed.setVertex(1, &cams[p->obs_cam[o]]);
+            ed.setMeasurement(Eigen::Vector3d(p->obs_uv[o * 2], p->obs_uv[o * 2 + 1], p->obs_ur[o])); ed.fx = p->fx; ed.fy = p->fy; ed.cx = p->cx; ed.cy = p->cy; ed.bf = p->bf;
+            ed.computeError(); for (int k = 0; k < 3; k++) e[k] = ed.error()[k];
+        }
+    }
+    for (int o = 0; o < p->n_dobs; o++) {
+        EdgeDynamicPointCuboidCamera ed;
+        ed.setVertex(0, &cams[p->dobs_cam[o]]); ed.setVertex(1, &objs[p->dobs_obj[o]]); ed.setVertex(2, &dpts[p->dobs_point[o]]);
+        ed.setMeasurement(Eigen::Vector2d(p->dobs_uv[o * 2], p->dobs_uv[o * 2 + 1])); ed.Kalib = K;
+        ed.sizeJacobians();
+        ed.computeError(); e_dobs[o * 2] = ed.error()[0]; e_dobs[o * 2 + 1] = ed.error()[1];
+        ed.linearizeOplus();
+        for (int v = 0; v < 3; v++) for (int k = 0; k < 2; k++) for (int a = 0; a < 6; a++) J_dobs[(size_t)o * 36 + v * 12 + k * 6 + a] = a < ed._jacobianOplus[v].cols() ? ed._jacobianOplus[v](k, a) : 0.0;
+    }
+    for (int o = 0; o < p->n_mot; o++) {
+        EdgeObjectMotion ed;
+        ed.setVertex(0, &objs[p->mot_from[o]]); ed.setVertex(1, &objs[p->mot_to[o]]); ed.setVertex(2, &vels[p->mot_vel[o]]);
+        ed.delta_t = p->mot_dt[o];
+        ed.sizeJacobians();
+        ed.computeError(); for (int k = 0; k < 3; k++) e_mot[o * 3 + k] = ed.error()[k];
+        ed.linearizeOplus();
+        for (int v = 0; v < 3; v++) for (int k = 0; k < 3; k++) for (int a = 0; a < 6; a++) J_mot[(size_t)o * 54 + v * 18 + k * 6 + a] = a < ed._jacobianOplus[v].cols() ? ed._jacobianOplus[v](k, a) : 0.0;
+    }
+    for (int o = 0; o < p->n_cobs; o++) {
+        EdgeSE3CuboidFixScaleProj ed; ed.setVertex(0, &cams[p->cobs_cam[o]]); ed.setVertex(1, &objs[p->cobs_obj[o]]);
+        ed.setMeasurement(Eigen::Vector4d(p->cobs_bbox[o * 4], p->cobs_bbox[o * 4 + 1], p->cobs_bbox[o * 4 + 2], p->cobs_bbox[o * 4 + 3])); ed.Kalib = K;
+        ed.computeError(); for (int k = 0; k < 4; k++) e_cobs[o * 4 + k] = ed.error()[k];
+    }
+    for (int o = 0; o < p->n_pc; o++) {
+        EdgePointCuboidOnlyObjectFixScale ed; ed.setVertex(0, &objs[p->pc_obj[o]]);
+        for (int i = p->pc_offsets[o]; i < p->pc_offsets[o + 1]; i++) ed.object_points.push_back(Eigen::Vector3d(p->pc_points[i * 3], p->pc_points[i * 3 + 1], p->pc_points[i * 3 + 2]));
+        ed.max_outside_margin_ratio = p->pc_ratio;
+        ed.computeError(); for (int k = 0; k < 3; k++) e_pc[o * 3 + k] = ed.error()[k];
+    }
+    for (int i = 0; i < p->n_dpoints; i++) {
+        UnaryLocalPoint ed; ed.setVertex(0, &dpts[i]);
+        for (int k = 0; k < 3; k++) ed.objectscale[k] = p->ulp_scale[k];
+        ed.max_outside_margin_ratio = p->ulp_ratio;
+        ed.computeError(); for (int k = 0; k < 3; k++) e_ulp[i * 3 + k] = ed.error()[k];
+    }
 }
 }

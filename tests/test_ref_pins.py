@@ -591,3 +591,35 @@ def test_pose_only_edges_equal_reference(ref, oracle):
         assert np.array_equal(b, ob), (seed, np.abs(b - ob).max())
         assert np.array_equal(H, oH), (seed, np.abs(H - oH).max())
         assert np.abs(H).max() > 0 and (chi > (dm * dm)).any()
+
+
+def test_dynamic_ba_edges_equal_reference(ref, oracle):
+    """The edges of Optimizer::LocalBACameraPointObjectsDynamic's graph: computeError of all six edge types (EdgeSE3ProjectXYZ and its stereo twin,
+    EdgeDynamicPointCuboidCamera, EdgeObjectMotion, EdgeSE3CuboidFixScaleProj, EdgePointCuboidOnlyObjectFixScale, UnaryLocalPoint) and the Jacobians of the
+    two three-vertex types -- EdgeDynamicPointCuboidCamera::linearizeOplus (g2o_Object.cpp:167-233) and BaseMultiEdge::linearizeOplus (central differences,
+    base_multi_edge.hpp:62-133) over EdgeObjectMotion with VertexCuboidFixScale / VelocityPlanarVelocity::oplusImpl under it -- the reference's own classes,
+    cut out whole at build time (oracle/ref_shim/ref_linearize_api.cpp), against the dynamic-BA oracle: every residual and every Jacobian entry, to the last bit."""
+    import oracle.pyoracle as po
+    olib = po.lib()
+    n_j = 0
+    for seed, kw, flags in ((21, dict(n_kf=8, n_points=150, n_objects=2, pts_per_obj=20), None), (22, dict(n_kf=6, n_points=80, n_objects=3, pts_per_obj=12, stereo_frac=0.6), 2 | 8),
+                            (23, dict(n_kf=7, n_points=100, n_objects=2, pts_per_obj=16, fix_points=True), 0), (24, dict(n_kf=5, n_points=60, n_objects=2, pts_per_obj=10, stereo_frac=0.0), 4 | 8)):
+        d = dict(synth.ba_dyn_problem(seed, **kw))
+        if flags is not None:
+            d["obj_flags"] = np.full(len(d["obj_pose"]), flags, np.uint8)
+        p = po.badyn_struct(d)
+        shapes = ((p.n_obs, 3), (p.n_dobs, 2), (p.n_mot, 3), (p.n_cobs, 4), (p.n_pc, 3), (p.n_dpoints, 3))
+        re = [np.zeros((max(n, 1), k)) for n, k in shapes]
+        rJd, rJm = np.zeros((max(p.n_dobs, 1), 36)), np.zeros((max(p.n_mot, 1), 54))
+        ref.ref_badyn_edges(C.byref(p), *[_dp(a) for a in re], _dp(rJd), _dp(rJm))
+        _, oe = po.badyn_errors(d)
+        for (n, k), a, name in zip(shapes, re, ("obs", "dobs", "mot", "cobs", "pc", "ulp")):
+            assert n > 0 or name in ("cobs",), (seed, name)
+            assert np.array_equal(a[:n], oe[name]), (seed, name, np.abs(a[:n] - oe[name]).max())
+        oJd, oJm = np.zeros_like(rJd), np.zeros_like(rJm)
+        olib.orc_badyn_edge_jacobians(C.byref(p), _dp(oJd), _dp(oJm))
+        assert np.array_equal(rJd, oJd), (seed, "J dobs", np.abs(rJd - oJd).max())
+        assert np.array_equal(rJm, oJm), (seed, "J mot", np.abs(rJm - oJm).max())
+        assert np.abs(oJm).max() > 0 and np.abs(oJd).max() > 0
+        n_j += p.n_dobs + p.n_mot
+    assert n_j > 300
