@@ -58,6 +58,8 @@ WANT = [  # (file, signatures, output include)
                                            "int ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint *> &vpMapPoints, const float th)", "float ORBmatcher::RadiusByViewingCos(const float &viewCos)",
                                            "int ORBmatcher::SearchForInitialization(Frame &F1, Frame &F2, vector<cv::Point2f> &vbPrevMatched, vector<int> &vnMatches12, int windowSize)",
                                            "int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono)",
+                                           "int ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, vector<MapPoint *> &vpMapPointMatches)",
+                                           "int ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint *> &vpMatches12)",
                                            "void ORBmatcher::ComputeThreeMaxima(", "int ORBmatcher::DescriptorDistance("], "extracted_match.inc"),
     ("orb_object_slam/src/Frame.cc", ["void Frame::AssignFeaturesToGrid()", "vector<size_t> Frame::GetFeaturesInArea(const float &x, const float &y, const float &r, const int minLevel, const int maxLevel) const",
                                       "bool Frame::PosInGrid(const cv::KeyPoint &kp, int &posX, int &posY)"], "extracted_match.inc"),

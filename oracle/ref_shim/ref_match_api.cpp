@@ -36,6 +36,8 @@ inline Mat operator+(const MulExpr &e, const Mat &c) { return e.eval(&c); }
 inline NegExpr operator-(const Mat &m) { return NegExpr{m}; }
 } // namespace cv
 
+namespace DBoW2 { typedef std::map<unsigned int, std::vector<unsigned int>> FeatureVector; } // DBoW2/FeatureVector.h: a std::map<NodeId, std::vector<unsigned int>>
+
 namespace ORB_SLAM2_m { // (its own namespace: ref_extract_api.cpp holds another stand-in ORBmatcher for the two primitives)
 #define FRAME_GRID_ROWS 48 // Frame.h:32-33
 #define FRAME_GRID_COLS 64
@@ -62,12 +64,24 @@ class Frame {
     std::vector<float> mvScaleFactors, mvuRight;
     cv::Mat mDescriptors;
     std::vector<std::size_t> mGrid[FRAME_GRID_COLS][FRAME_GRID_ROWS];
+    DBoW2::FeatureVector mFeatVec;
     void AssignFeaturesToGrid();
     std::vector<size_t> GetFeaturesInArea(const float &x, const float &y, const float &r, const int minLevel = -1, const int maxLevel = -1) const;
     bool PosInGrid(const cv::KeyPoint &kp, int &posX, int &posY);
 };
+class KeyFrame { // the members the two SearchByBoW read
+  public:
+    std::vector<cv::KeyPoint> mvKeysUn;
+    DBoW2::FeatureVector mFeatVec;
+    cv::Mat mDescriptors;
+    std::vector<bool> KeysStatic;
+    std::vector<MapPoint *> mvpMapPoints;
+    std::vector<MapPoint *> GetMapPointMatches() { return mvpMapPoints; }
+};
 class ORBmatcher {
   public:
+    int SearchByBoW(KeyFrame *pKF, Frame &F, std::vector<MapPoint *> &vpMapPointMatches);
+    int SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, std::vector<MapPoint *> &vpMatches12);
     ORBmatcher(float nnratio = 0.6, bool checkOri = true) : mfNNratio(nnratio), mbCheckOrientation(checkOri) {}
     static int DescriptorDistance(const cv::Mat &a, const cv::Mat &b);
     int SearchByProjection(Frame &F, const std::vector<MapPoint *> &vpMapPoints, const float th = 3);
@@ -191,6 +205,50 @@ int ref_search_for_initialization(const orc_frame *f1, const orc_frame *f2, floa
     ORBmatcher m(nnratio, check_orientation != 0);
     const int n = m.SearchForInitialization(F1, F2, prev, m12, window_size);
     for (int i = 0; i < f1->N; i++) { matches12[i] = m12[i]; prev_matched[2 * i] = prev[i].x; prev_matched[2 * i + 1] = prev[i].y; }
+    return n;
+}
+
+// ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...) (ORBmatcher.cc:171-307) with the arguments of orc_search_by_bow: a skipped key-frame feature has, by turns, no map
+// point / a bad one / a dynamic one / a non-static key point; a skipped frame feature is a non-static key point.
+static void fill_kf(ORB_SLAM2_m::KeyFrame &K, const orc_frame *f, const int *node, const uint8_t *skip, std::vector<MapPoint> &pts, bool all_ways) {
+    K.mvKeysUn.resize(f->N);
+    for (int i = 0; i < f->N; i++) { const orc_keypoint &k = f->keysUn[i]; K.mvKeysUn[i] = cv::KeyPoint(k.x, k.y, k.size, k.angle, k.response, k.octave, k.class_id); }
+    K.mDescriptors = cv::Mat(f->N, 32, CV_8UC1);
+    for (int i = 0; i < f->N; i++) std::memcpy(K.mDescriptors.ptr<uchar>(i), f->desc + (size_t)i * 32, 32);
+    pts.assign(f->N, MapPoint());
+    K.mvpMapPoints.assign(f->N, nullptr);
+    if (all_ways) K.KeysStatic.assign(f->N, true);
+    for (int i = 0; i < f->N; i++) {
+        K.mvpMapPoints[i] = &pts[i];
+        if (skip && skip[i]) {
+            const int way = all_ways ? i % 4 : i % 2;
+            if (way == 0) K.mvpMapPoints[i] = nullptr; else if (way == 1) pts[i].bad = true; else if (way == 2) pts[i].is_dynamic = true; else K.KeysStatic[i] = false;
+        }
+        if (node[i] >= 0) K.mFeatVec[(unsigned)node[i]].push_back((unsigned)i);
+    }
+}
+int ref_search_by_bow(const orc_frame *KF, const int *nodeKF, const uint8_t *skipKF, const orc_frame *Ff, const int *nodeF, const uint8_t *skipF, float nnratio, int check_orientation,
+                      int *matchesF) {
+    ORB_SLAM2_m::KeyFrame K; std::vector<MapPoint> pts;
+    fill_kf(K, KF, nodeKF, skipKF, pts, true);
+    Frame F; fill_frame(F, Ff, nullptr, 0);
+    for (int i = 0; i < Ff->N; i++) if (nodeF[i] >= 0) F.mFeatVec[(unsigned)nodeF[i]].push_back((unsigned)i);
+    if (skipF) { F.KeysStatic.assign(Ff->N, true); for (int i = 0; i < Ff->N; i++) if (skipF[i]) F.KeysStatic[i] = false; }
+    std::vector<MapPoint *> m;
+    ORBmatcher matcher(nnratio, check_orientation != 0);
+    const int n = matcher.SearchByBoW(&K, F, m);
+    for (int i = 0; i < Ff->N; i++) matchesF[i] = m[i] ? (int)(m[i] - pts.data()) : -1;
+    return n;
+}
+// ORBmatcher::SearchByBoW(KeyFrame*, KeyFrame*, ...) (:544-677) with the arguments of orc_search_by_bow_kf: a skipped feature has no map point or a bad one
+int ref_search_by_bow_kf(const orc_frame *K1f, const int *node1, const uint8_t *skip1, const orc_frame *K2f, const int *node2, const uint8_t *skip2, float nnratio, int check_orientation,
+                         int *matches12) {
+    ORB_SLAM2_m::KeyFrame K1, K2; std::vector<MapPoint> p1, p2;
+    fill_kf(K1, K1f, node1, skip1, p1, false); fill_kf(K2, K2f, node2, skip2, p2, false);
+    std::vector<MapPoint *> m;
+    ORBmatcher matcher(nnratio, check_orientation != 0);
+    const int n = matcher.SearchByBoW(&K1, &K2, m);
+    for (int i = 0; i < K1f->N; i++) matches12[i] = m[i] ? (int)(m[i] - p2.data()) : -1;
     return n;
 }
 }

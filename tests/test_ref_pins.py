@@ -623,3 +623,37 @@ def test_dynamic_ba_edges_equal_reference(ref, oracle):
         assert np.abs(oJm).max() > 0 and np.abs(oJd).max() > 0
         n_j += p.n_dobs + p.n_mot
     assert n_j > 300
+
+
+def test_bow_searches_equal_reference(ref, oracle):
+    """ORBmatcher::SearchByBoW(KeyFrame*, Frame&, ...) and SearchByBoW(KeyFrame*, KeyFrame*, ...) (ORBmatcher.cc:171-307, 544-677: the walk over the two
+    feature vectors, greedy claims in (node, index) order, TH_LOW and ratio tests, the rotation histogram) -- the reference's own text, cut out at build time
+    and compiled against stand-ins for KeyFrame / Frame / MapPoint / DBoW2::FeatureVector (ref_shim/ref_match_api.cpp) -- against the oracle: match lists and
+    counts identical.  The ways a feature drops out (no map point, a bad one, a dynamic one, a non-static key point) go through the reference's own tests."""
+    import oracle.pyoracle as po
+    Wk, Hk = 1241, 376
+    bounds = (0.0, float(Wk), 0.0, float(Hk))
+    e = oracle.ORBextractor(2000, 1.2, 8, 20, 7)
+    (k1, d1), (k2, d2) = [e(synth.texture_image(78, Wk, Hk, shift=4 * i)) for i in range(2)]
+    K1, K2 = oracle.make_frame(k1, d1, bounds), oracle.make_frame(k2, d2, bounds)
+    i32, u8 = (lambda a: np.ascontiguousarray(a, np.int32)), (lambda a: np.ascontiguousarray(a, np.uint8))
+    rng = np.random.default_rng(5)
+    node = lambda k, dx: i32((np.clip(k["x"] + dx, 0, Wk - 1) // 60).astype(np.int32) * 8 + (k["y"] // 50).astype(np.int32))  # noqa: E731
+    total = 0
+    for trial, (ratio, ori) in enumerate(((0.75, True), (0.9, False), (0.6, True), (0.95, True))):
+        node1, node2 = node(k1, 0.0), node(k2, 4.0)
+        node1[rng.uniform(size=len(k1)) < 0.03] = -1
+        node2[rng.uniform(size=len(k2)) < 0.03] = -1
+        skip1, skip2 = u8(rng.uniform(size=len(k1)) < 0.25), u8(rng.uniform(size=len(k2)) < 0.1)
+        sf = None if trial == 0 else skip2
+        out = np.zeros(len(k2), np.int32)
+        n = ref.ref_search_by_bow(C.byref(K1), _dp(node1), _dp(skip1), C.byref(K2), _dp(node2), None if sf is None else _dp(sf), C.c_float(ratio), int(ori), _dp(out))
+        r, nr = po.search_by_bow(K1, node1, skip1, K2, node2, sf, ratio, ori)
+        assert n == nr and np.array_equal(out, r), (trial, n, nr)
+        total += n
+        out12 = np.zeros(len(k1), np.int32)
+        n = ref.ref_search_by_bow_kf(C.byref(K1), _dp(node1), _dp(skip1), C.byref(K2), _dp(node2), _dp(skip2), C.c_float(ratio), int(ori), _dp(out12))
+        r, nr = po.search_by_bow_kf(K1, node1, skip1, K2, node2, skip2, ratio, ori)
+        assert n == nr and np.array_equal(out12, r), (trial, n, nr)
+        total += n
+    assert total > 1500
