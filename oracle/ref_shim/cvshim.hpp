@@ -186,6 +186,7 @@ public:
     Mat row(int r) const { return rowRange(r, r + 1); }
     Mat col(int c) const { return colRange(c, c + 1); }
     int checkVector(int elemChannels, int = -1, bool = true) const { return (cols == 1 && channels() == elemChannels) ? rows : ((channels() == 1 && cols == elemChannels) ? rows : -1); }
+    double dot(const Mat &m) const { double s = 0; for (int i = 0; i < rows * cols; i++) s += (double)at<float>(i) * (double)m.at<float>(i); return s; } // CV_32F vectors: cv::Mat::dot accumulates in double
     template <typename T> T &at(int i) { return rows == 1 ? ((T *)data)[i] : *(T *)(data + (size_t)i * step); }
     template <typename T> const T &at(int i) const { return rows == 1 ? ((const T *)data)[i] : *(const T *)(data + (size_t)i * step); }
     Mat operator()(const Rect &r) const { return Mat(*this, r); }

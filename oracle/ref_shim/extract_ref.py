@@ -60,7 +60,12 @@ WANT = [  # (file, signatures, output include)
                                            "int ORBmatcher::SearchByProjection(Frame &CurrentFrame, const Frame &LastFrame, const float th, const bool bMono)",
                                            "int ORBmatcher::SearchByBoW(KeyFrame *pKF, Frame &F, vector<MapPoint *> &vpMapPointMatches)",
                                            "int ORBmatcher::SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, vector<MapPoint *> &vpMatches12)",
+                                           "bool ORBmatcher::CheckDistEpipolarLine(const cv::KeyPoint &kp1, const cv::KeyPoint &kp2, const cv::Mat &F12, const KeyFrame *pKF2)",
+                                           "int ORBmatcher::SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, cv::Mat F12,",
+                                           "int ORBmatcher::Fuse(KeyFrame *pKF, const vector<MapPoint *> &vpMapPoints, const float th)",
                                            "void ORBmatcher::ComputeThreeMaxima(", "int ORBmatcher::DescriptorDistance("], "extracted_match.inc"),
+    ("orb_object_slam/src/KeyFrame.cc", ["vector<size_t> KeyFrame::GetFeaturesInArea(const float &x, const float &y, const float &r) const",
+                                         "bool KeyFrame::IsInImage(const float &x, const float &y) const"], "extracted_match.inc"),
     ("orb_object_slam/src/Frame.cc", ["void Frame::AssignFeaturesToGrid()", "vector<size_t> Frame::GetFeaturesInArea(const float &x, const float &y, const float &r, const int minLevel, const int maxLevel) const",
                                       "bool Frame::PosInGrid(const cv::KeyPoint &kp, int &posX, int &posY)"], "extracted_match.inc"),
     # g2o's Levenberg-Marquardt schedule and the optimiser's iteration loop (compiled against stand-ins for Solver / SparseOptimizer, ref_levenberg_api.cpp)

@@ -34,6 +34,8 @@ inline MulExpr operator*(const Mat &a, const Mat &b) { return MulExpr{a, b, 1.0}
 inline MulExpr operator*(const NegExpr &a, const Mat &b) { return MulExpr{a.m, b, -1.0}; }
 inline Mat operator+(const MulExpr &e, const Mat &c) { return e.eval(&c); }
 inline NegExpr operator-(const Mat &m) { return NegExpr{m}; }
+inline Mat operator-(const Mat &a, const Mat &b) { Mat r(a.rows, a.cols, CV_32F); for (int i = 0; i < a.rows * a.cols; i++) r.at<float>(i) = a.at<float>(i) - b.at<float>(i); return r; } // CV_32F vectors
+inline double norm(const Mat &m) { double s = 0; for (int i = 0; i < m.rows * m.cols; i++) s += (double)m.at<float>(i) * (double)m.at<float>(i); return std::sqrt(s); } // NORM_L2 of CV_32F: double accumulation
 } // namespace cv
 
 namespace DBoW2 { typedef std::map<unsigned int, std::vector<unsigned int>> FeatureVector; } // DBoW2/FeatureVector.h: a std::map<NodeId, std::vector<unsigned int>>
@@ -42,14 +44,25 @@ namespace ORB_SLAM2_m { // (its own namespace: ref_extract_api.cpp holds another
 #define FRAME_GRID_ROWS 48 // Frame.h:32-33
 #define FRAME_GRID_COLS 64
 
+class KeyFrame;
 class MapPoint {
   public:
+    // ... and what Fuse asks of a map point: the scale prediction and the distance / normal data are the map's, given here; Replace / AddObservation are recorded
+    int pred_level = 0; cv::Mat normal; MapPoint *replaced_by = nullptr; long added_idx = -1;
+    bool IsInKeyFrame(KeyFrame *) { return false; }
+    float GetMaxDistanceInvariance() { return 1e9f; }
+    float GetMinDistanceInvariance() { return 0.f; }
+    cv::Mat GetNormal() { return normal.clone(); }
+    int PredictScale(const float &, const float &) { return pred_level; }
+    void Replace(MapPoint *p) { replaced_by = p; }
+    void AddObservation(KeyFrame *, size_t idx) { added_idx = (long)idx; }
     bool is_dynamic = false, mbTrackInView = false, bad = false;
     int mnTrackScaleLevel = 0, nobs = 0;
     float mTrackViewCos = 0, mTrackProjX = 0, mTrackProjY = 0, mTrackProjXR = 0;
     cv::Mat pos, desc;
     cv::Mat GetWorldPos() { return pos.clone(); }
-    cv::Mat GetDescriptor() { return desc.clone(); }
+    static MapPoint *&current() { static MapPoint *p = nullptr; return p; } // the map point whose descriptor was fetched last (Fuse: the one being searched for)
+    cv::Mat GetDescriptor() { current() = this; return desc.clone(); }
     int Observations() { return nobs; }
     bool isBad() { return bad; }
 };
@@ -77,11 +90,32 @@ class KeyFrame { // the members the two SearchByBoW read
     std::vector<bool> KeysStatic;
     std::vector<MapPoint *> mvpMapPoints;
     std::vector<MapPoint *> GetMapPointMatches() { return mvpMapPoints; }
+    // ... and SearchForTriangulation
+    int N = 0;
+    float fx = 0, fy = 0, cx = 0, cy = 0;
+    cv::Mat Ow, Rcw, tcw;
+    std::vector<float> mvuRight, mvLevelSigma2, mvScaleFactors;
+    cv::Mat GetCameraCenter() { return Ow.clone(); }
+    cv::Mat GetRotation() { return Rcw.clone(); }
+    cv::Mat GetTranslation() { return tcw.clone(); }
+    std::vector<size_t> queried; std::vector<MapPoint *> queried_for; // (the indices GetMapPoint was asked for, in order: Fuse asks once per fused map point, with its bestIdx)
+    MapPoint *GetMapPoint(const size_t &idx) { queried.push_back(idx); queried_for.push_back(MapPoint::current()); return mvpMapPoints[idx]; }
+    // ... and Fuse
+    float mbf = 0, mfLogScaleFactor = 0, mnMinX = 0, mnMaxX = 0, mnMinY = 0, mnMaxY = 0, mfGridElementWidthInv = 0, mfGridElementHeightInv = 0;
+    int mnGridCols = FRAME_GRID_COLS, mnGridRows = FRAME_GRID_ROWS;
+    std::vector<float> mvInvLevelSigma2;
+    std::vector<std::vector<std::vector<size_t>>> mGrid;
+    std::vector<size_t> GetFeaturesInArea(const float &x, const float &y, const float &r) const;
+    bool IsInImage(const float &x, const float &y) const;
+    void AddMapPoint(MapPoint *pMP, const size_t &idx) { mvpMapPoints[idx] = pMP; }
 };
 class ORBmatcher {
   public:
     int SearchByBoW(KeyFrame *pKF, Frame &F, std::vector<MapPoint *> &vpMapPointMatches);
     int SearchByBoW(KeyFrame *pKF1, KeyFrame *pKF2, std::vector<MapPoint *> &vpMatches12);
+    int SearchForTriangulation(KeyFrame *pKF1, KeyFrame *pKF2, cv::Mat F12, std::vector<std::pair<size_t, size_t>> &vMatchedPairs, const bool bOnlyStereo);
+    int Fuse(KeyFrame *pKF, const std::vector<MapPoint *> &vpMapPoints, const float th = 3.0);
+    bool CheckDistEpipolarLine(const cv::KeyPoint &kp1, const cv::KeyPoint &kp2, const cv::Mat &F12, const KeyFrame *pKF2);
     ORBmatcher(float nnratio = 0.6, bool checkOri = true) : mfNNratio(nnratio), mbCheckOrientation(checkOri) {}
     static int DescriptorDistance(const cv::Mat &a, const cv::Mat &b);
     int SearchByProjection(Frame &F, const std::vector<MapPoint *> &vpMapPoints, const float th = 3);
@@ -249,6 +283,72 @@ int ref_search_by_bow_kf(const orc_frame *K1f, const int *node1, const uint8_t *
     ORBmatcher matcher(nnratio, check_orientation != 0);
     const int n = matcher.SearchByBoW(&K1, &K2, m);
     for (int i = 0; i < K1f->N; i++) matches12[i] = m[i] ? (int)(m[i] - p2.data()) : -1;
+    return n;
+}
+
+// ORBmatcher::SearchForTriangulation (:679-850) with CheckDistEpipolarLine (:152-169), the arguments of orc_search_for_triangulation except the epipole, which the
+// reference computes itself from the first key frame's centre Ow (given in the second camera's frame: R2w = I, t2w = 0).  skip = the feature has a map point.
+int ref_search_for_triangulation(const orc_frame *F1, const int *node1, const uint8_t *skip1, const float *u_right1, const uint8_t *static1, const orc_frame *F2, const int *node2,
+                                 const uint8_t *skip2, const float *u_right2, const uint8_t *static2, const float *F12, const float *Ow3, float fx, float fy, float cx, float cy,
+                                 const float *scale_factors2, const float *level_sigma2_2, int n_levels, int only_stereo, int check_orientation, int *matches12) {
+    ORB_SLAM2_m::KeyFrame K1, K2; std::vector<MapPoint> p1, p2;
+    auto fill = [&](ORB_SLAM2_m::KeyFrame &K, const orc_frame *f, const int *node, const uint8_t *skip, const float *ur, const uint8_t *stat, std::vector<MapPoint> &pts) {
+        fill_kf(K, f, node, nullptr, pts, false);
+        K.N = f->N;
+        for (int i = 0; i < f->N; i++) K.mvpMapPoints[i] = skip[i] ? &pts[i] : nullptr;
+        K.mvuRight.assign(ur, ur + f->N);
+        if (stat) { K.KeysStatic.assign(f->N, true); for (int i = 0; i < f->N; i++) K.KeysStatic[i] = stat[i] != 0; }
+    };
+    fill(K1, F1, node1, skip1, u_right1, static1, p1); fill(K2, F2, node2, skip2, u_right2, static2, p2);
+    K2.fx = fx; K2.fy = fy; K2.cx = cx; K2.cy = cy;
+    K2.mvScaleFactors.assign(scale_factors2, scale_factors2 + n_levels); K2.mvLevelSigma2.assign(level_sigma2_2, level_sigma2_2 + n_levels);
+    K1.Ow = cv::Mat(3, 1, CV_32F); for (int k = 0; k < 3; k++) K1.Ow.at<float>(k) = Ow3[k];
+    K2.Rcw = cv::Mat(3, 3, CV_32F); for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) K2.Rcw.at<float>(i, j) = i == j ? 1.f : 0.f;
+    K2.tcw = cv::Mat(3, 1, CV_32F); for (int k = 0; k < 3; k++) K2.tcw.at<float>(k) = 0.f;
+    cv::Mat Fm(3, 3, CV_32F); for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) Fm.at<float>(i, j) = F12[i * 3 + j];
+    std::vector<std::pair<size_t, size_t>> pairs;
+    ORBmatcher matcher(0.6f, check_orientation != 0);
+    const int n = matcher.SearchForTriangulation(&K1, &K2, Fm, pairs, only_stereo != 0);
+    for (int i = 0; i < F1->N; i++) matches12[i] = -1;
+    for (auto &pr : pairs) matches12[pr.first] = (int)pr.second;
+    return n;
+}
+
+// ORBmatcher::Fuse(KeyFrame*, vector<MapPoint*>, th) (:852-1003) whole, over a key frame at the origin (Rcw = I, tcw = 0, so that the camera coordinates are the
+// world coordinates and the caller can state the projection the oracle is given in the same float arithmetic).  KeyFrame::GetFeaturesInArea / IsInImage are the
+// reference's (KeyFrame.cc:627-673); the grid is filled like KeyFrame's constructor copies it from the Frame (Frame::AssignFeaturesToGrid).  A map point drops out, by
+// turns, as NULL / bad / dynamic.  Out: for every fused map point in order, its index and the key point it went to; returns nFused.
+int ref_fuse(const orc_frame *f, const float *u_right, const float *inv_level_sigma2, const uint8_t *keys_static, int n_mp, const float *world_pos, const int *pred_level,
+             const uint8_t *drop, const uint8_t *mp_desc, const float *scale_factors, int n_levels, float fx, float fy, float cx, float cy, float bf, float th, int *fused_mp, int *fused_idx) {
+    ORB_SLAM2_m::KeyFrame K; std::vector<MapPoint> holders;
+    std::vector<int> node(f->N, -1);
+    fill_kf(K, f, node.data(), nullptr, holders, false);
+    K.mvpMapPoints.assign(f->N, nullptr);
+    K.N = f->N; K.fx = fx; K.fy = fy; K.cx = cx; K.cy = cy; K.mbf = bf;
+    K.mnMinX = f->minX; K.mnMaxX = f->maxX; K.mnMinY = f->minY; K.mnMaxY = f->maxY;
+    K.mfGridElementWidthInv = static_cast<float>(FRAME_GRID_COLS) / (K.mnMaxX - K.mnMinX);
+    K.mfGridElementHeightInv = static_cast<float>(FRAME_GRID_ROWS) / (K.mnMaxY - K.mnMinY);
+    K.mvuRight.assign(u_right, u_right + f->N);
+    K.mvScaleFactors.assign(scale_factors, scale_factors + n_levels); K.mvInvLevelSigma2.assign(inv_level_sigma2, inv_level_sigma2 + n_levels);
+    if (keys_static) { K.KeysStatic.assign(f->N, true); for (int i = 0; i < f->N; i++) K.KeysStatic[i] = keys_static[i] != 0; }
+    { Frame F; fill_frame(F, f, nullptr, 0); // the grid of the frame the key frame was made from (KeyFrame.cc:51-57)
+      K.mGrid.resize(FRAME_GRID_COLS);
+      for (int i = 0; i < FRAME_GRID_COLS; i++) { K.mGrid[i].resize(FRAME_GRID_ROWS); for (int j = 0; j < FRAME_GRID_ROWS; j++) K.mGrid[i][j] = F.mGrid[i][j]; } }
+    K.Rcw = cv::Mat(3, 3, CV_32F); for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) K.Rcw.at<float>(i, j) = i == j ? 1.f : 0.f;
+    K.tcw = cv::Mat(3, 1, CV_32F); K.Ow = cv::Mat(3, 1, CV_32F); for (int k = 0; k < 3; k++) { K.tcw.at<float>(k) = 0.f; K.Ow.at<float>(k) = 0.f; }
+    std::vector<MapPoint> pts(n_mp); std::vector<MapPoint *> vp(n_mp);
+    for (int i = 0; i < n_mp; i++) {
+        MapPoint &p = pts[i];
+        p.pos = cv::Mat(3, 1, CV_32F); p.normal = cv::Mat(3, 1, CV_32F);
+        for (int k = 0; k < 3; k++) { p.pos.at<float>(k) = world_pos[i * 3 + k]; p.normal.at<float>(k) = world_pos[i * 3 + k]; } // seen head-on: PO . Pn = |PO|^2 >= 0.5 |PO|
+        p.desc = desc_row(mp_desc + (size_t)i * 32); p.pred_level = pred_level[i];
+        vp[i] = &p;
+        if (drop[i]) { if (i % 3 == 0) vp[i] = nullptr; else if (i % 3 == 1) p.bad = true; else p.is_dynamic = true; }
+    }
+    ORBmatcher matcher(0.6f, true);
+    const int n = matcher.Fuse(&K, vp, th);
+    int k = 0;
+    for (size_t q = 0; q < K.queried.size(); q++, k++) { fused_idx[k] = (int)K.queried[q]; fused_mp[k] = (int)(K.queried_for[q] - pts.data()); }
     return n;
 }
 }

@@ -657,3 +657,100 @@ def test_bow_searches_equal_reference(ref, oracle):
         assert n == nr and np.array_equal(out12, r), (trial, n, nr)
         total += n
     assert total > 1500
+
+
+def test_search_for_triangulation_equals_reference(ref, oracle):
+    """ORBmatcher::SearchForTriangulation (ORBmatcher.cc:679-850) with CheckDistEpipolarLine (:152-169) and the epipole it computes from the two key frames'
+    poses -- the reference's own text against stand-ins for KeyFrame / MapPoint (ref_shim/ref_match_api.cpp) -- against the oracle: the pairs and their count
+    identical, with map-point holders, stereo flags, non-static key points, the epipole exclusion zone and bOnlyStereo all exercised."""
+    import oracle.pyoracle as po
+    Wk, Hk = 1241, 376
+    bounds = (0.0, float(Wk), 0.0, float(Hk))
+    f32 = np.float32
+    fx, fy, cx, cy = f32(721.5377), f32(721.5377), f32(609.5593), f32(172.854)
+    e = oracle.ORBextractor(2000, 1.2, 8, 20, 7)
+    (k1, d1), (k2, d2) = [e(synth.texture_image(79, Wk, Hk, shift=4 * i)) for i in range(2)]
+    K1, K2 = oracle.make_frame(k1, d1, bounds), oracle.make_frame(k2, d2, bounds)
+    i32, u8 = (lambda a: np.ascontiguousarray(a, np.int32)), (lambda a: np.ascontiguousarray(a, np.uint8))
+    rng = np.random.default_rng(6)
+    node = lambda k, dx: i32((np.clip(k["x"] + dx, 0, Wk - 1) // 60).astype(np.int32) * 8 + (k["y"] // 50).astype(np.int32))  # noqa: E731
+    SF = (f32(1.2) ** np.arange(8, dtype=f32)).astype(f32)
+    SG = (SF * SF).astype(f32)
+    total = 0
+    for trial, (only_stereo, ori) in enumerate(((False, True), (False, False), (True, True), (False, True))):
+        node1, node2 = node(k1, 0.0), node(k2, 4.0)
+        node2[rng.uniform(size=len(k2)) < 0.03] = -1
+        skip1, skip2 = u8(rng.uniform(size=len(k1)) < 0.3), u8(rng.uniform(size=len(k2)) < 0.3)
+        ur1 = np.where(rng.uniform(size=len(k1)) < 0.4, k1["x"] - 5.0, -1.0).astype(f32)
+        ur2 = np.where(rng.uniform(size=len(k2)) < 0.4, k2["x"] - 5.0, -1.0).astype(f32)
+        st1 = u8(rng.uniform(size=len(k1)) > 0.1) if trial == 3 else None
+        st2 = u8(rng.uniform(size=len(k2)) > 0.1) if trial == 3 else None
+        F12 = (np.array([[0, 0, 0], [0, 0, 1], [0, -1, 0]], f32) + rng.normal(0, 2e-5, (3, 3)).astype(f32)).astype(f32)  # horizontal epipolar lines, slightly tilted
+        Ow = np.array([0.05, -0.02, 1.0], f32) if trial != 1 else np.array([3.0, 0.1, 0.4], f32)
+        invz = f32(1.0) / Ow[2]
+        ex, ey = f32(f32(fx * Ow[0]) * invz) + cx, f32(f32(fy * Ow[1]) * invz) + cy  # the reference's float arithmetic (:688-690)
+        out = np.zeros(len(k1), np.int32)
+        n = ref.ref_search_for_triangulation(C.byref(K1), _dp(node1), _dp(skip1), _dp(ur1), None if st1 is None else _dp(st1), C.byref(K2), _dp(node2), _dp(skip2), _dp(ur2),
+                                             None if st2 is None else _dp(st2), _dp(F12), _dp(Ow), C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy), _dp(SF), _dp(SG), 8,
+                                             int(only_stereo), int(ori), _dp(out))
+        olib = po.lib()
+        m12 = np.zeros(len(k1), np.int32)
+        no = olib.orc_search_for_triangulation(C.byref(K1), _dp(node1), _dp(skip1), _dp(ur1), None if st1 is None else _dp(st1), C.byref(K2), _dp(node2), _dp(skip2), _dp(ur2),
+                                               None if st2 is None else _dp(st2), _dp(F12), C.c_float(ex), C.c_float(ey), _dp(SF), _dp(SG), int(only_stereo), int(ori), _dp(m12))
+        assert n == no and np.array_equal(out, m12), (trial, n, no, int((out != m12).sum()))
+        total += n
+    assert total > 400
+
+
+def test_fuse_equals_reference(ref, oracle):
+    """ORBmatcher::Fuse(KeyFrame*, vector<MapPoint*>, th) (ORBmatcher.cc:852-1003) whole, with KeyFrame::GetFeaturesInArea / IsInImage (KeyFrame.cc:627-673) -- the
+    reference's own text against stand-ins for KeyFrame / MapPoint (ref_shim/ref_match_api.cpp) -- against the oracle's search part fed with the projections
+    the reference computes itself (stated here in the same float arithmetic, :884-900): which map points fuse, into which key point, and the count."""
+    import oracle.pyoracle as po
+    olib = po.lib()
+    Wk, Hk = 1241, 376
+    bounds = (0.0, float(Wk), 0.0, float(Hk))
+    f32 = np.float32
+    fx, fy, cx, cy, bf = f32(721.5377), f32(721.5377), f32(609.5593), f32(172.854), f32(386.1448)
+    e = oracle.ORBextractor(2000, 1.2, 8, 20, 7)
+    k, d = e(synth.texture_image(80, Wk, Hk))
+    F = oracle.make_frame(k, d, bounds)
+    u8 = lambda a: np.ascontiguousarray(a, np.uint8)  # noqa: E731
+    SF = (f32(1.2) ** np.arange(8, dtype=f32)).astype(f32)
+    ISG = (f32(1.0) / (SF * SF)).astype(f32)
+    rng = np.random.default_rng(7)
+    total = 0
+    for trial, th in enumerate((3.0, 5.0, 2.5)):
+        n_mp = 1500
+        src = rng.integers(0, len(k), n_mp)  # map points that project near key points of the frame (and some far from any, some behind the camera, some outside)
+        z = rng.uniform(4, 40, n_mp).astype(f32)
+        du, dv = rng.normal(0, 1.5, n_mp), rng.normal(0, 1.5, n_mp)
+        du[::17] += 900.0
+        X = ((k["x"][src] + du - cx) / fx * z).astype(f32); Y = ((k["y"][src] + dv - cy) / fy * z).astype(f32)
+        z[::29] *= f32(-1)
+        wp = np.ascontiguousarray(np.stack([X, Y, z], axis=1), f32)
+        mp_desc = d[src].copy()
+        flip = rng.integers(0, 256, (n_mp, 4)); mp_desc[np.arange(n_mp)[:, None], rng.integers(0, 32, (n_mp, 4))] ^= (1 << (flip % 8)).astype(np.uint8)
+        mp_desc = u8(mp_desc)
+        pred = np.clip(k["octave"][src] + rng.integers(0, 2, n_mp), 0, 7).astype(np.int32)
+        drop = u8(rng.uniform(size=n_mp) < 0.1)
+        ur_kp = np.where(rng.uniform(size=len(k)) < 0.4, k["x"] - bf / 20.0, -1.0).astype(f32)
+        ks = u8(rng.uniform(size=len(k)) > 0.08) if trial == 1 else None
+        # the reference's projection (:884-900), in its float arithmetic: invz = 1 / z; u = fx * (X * invz) + cx; ur = u - bf * invz
+        with np.errstate(divide="ignore", invalid="ignore"):
+            invz = (f32(1.0) / wp[:, 2]).astype(f32)
+            u = (fx * (wp[:, 0] * invz).astype(f32)).astype(f32) + cx; v = (fy * (wp[:, 1] * invz).astype(f32)).astype(f32) + cy
+            ur = (u - (bf * invz).astype(f32)).astype(f32)
+        valid = u8((drop == 0) & ~(wp[:, 2] < 0) & (u >= 0) & (u < Wk) & (v >= 0) & (v < Hk))
+        uv = np.ascontiguousarray(np.stack([u, v], axis=1), f32)
+        bi, bd = np.zeros(n_mp, np.int32), np.zeros(n_mp, np.int32)
+        no = olib.orc_fuse(C.byref(F), _dp(ur_kp), _dp(ISG), None if ks is None else _dp(ks), n_mp, _dp(uv), _dp(ur), _dp(pred), _dp(valid), _dp(mp_desc), _dp(SF), C.c_float(th), _dp(bi), _dp(bd))
+        fmp, fidx = np.zeros(n_mp, np.int32), np.zeros(n_mp, np.int32)
+        n = ref.ref_fuse(C.byref(F), _dp(ur_kp), _dp(ISG), None if ks is None else _dp(ks), n_mp, _dp(wp), _dp(pred), _dp(drop), _dp(mp_desc), _dp(SF), 8,
+                         C.c_float(fx), C.c_float(fy), C.c_float(cx), C.c_float(cy), C.c_float(bf), C.c_float(th), _dp(fmp), _dp(fidx))
+        fused = np.nonzero((valid != 0) & (bd <= 50))[0]
+        assert n == no == len(fused), (trial, n, no, len(fused))
+        assert np.array_equal(fmp[:n], fused) and np.array_equal(fidx[:n], bi[fused]), trial
+        assert 0 < (valid == 0).sum() < n_mp
+        total += n
+    assert total > 1500
