@@ -1,6 +1,8 @@
 /*
  * oracle/lsd_oracle.cpp -- CPU oracle for the LSD line detector of line_lbd.
- * TEST INFRASTRUCTURE ONLY (see oracle.h).  PARITY UNPINNED.  Restated from /root/reference/line_lbd/libs/lsd.cpp
+ * TEST INFRASTRUCTURE ONLY (see oracle.h).  PINNED: tests/test_ref_pins.py runs the reference's own lsd.cpp / LSDDetector.cpp, compiled whole from /root/reference
+ * (oracle/_ref), on the same images -- KeyLines and the intermediate maps identical bit for bit; the OpenCV primitives under it stay restated.
+ * Restated from /root/reference/line_lbd/libs/lsd.cpp
  * (LineSegmentDetectorImpl: flsd :440-536, ll_angle :538-635, region_grow :637-688, region2rect :690-746, get_theta :748-784,
  * refine :786-832, reduce_region_radius :834-871, rect_improve :873-975, rect_nfa :977-1098, nfa :1100-1136, isAligned
  * :1138-1154), libs/LSDDetector.cpp:75-101,153-287 and class/line_lbd_allclass.cpp:26-36,125-148,200-221.

@@ -1,8 +1,8 @@
 /*
  * oracle/match_oracle.cpp -- CPU oracle for ORB_SLAM2::ORBmatcher's Hamming searches.
- * TEST INFRASTRUCTURE ONLY (see oracle.h).  Pinned for the three window searches, the Frame grid, DescriptorDistance and ComputeThreeMaxima:
- * tests/test_ref_pins.py runs the reference's own text (oracle/_ref, cut out at build time) on the same inputs -- identical match lists; Fuse,
- * SearchForTriangulation and the SearchByBoW overloads are anchored on known-answer tests only.  Restated from
+ * TEST INFRASTRUCTURE ONLY (see oracle.h).  PINNED: the three window searches, the Frame grid, DescriptorDistance, ComputeThreeMaxima, both SearchByBoW
+ * overloads, SearchForTriangulation (with CheckDistEpipolarLine) and Fuse -- tests/test_ref_pins.py runs the reference's own text (oracle/_ref, cut out at
+ * build time, against stand-ins for Frame / KeyFrame / MapPoint) on the same inputs: identical match lists and counts.  Restated from
  * /root/reference/orb_object_slam/src/ORBmatcher.cc and src/Frame.cc (grid).  Monocular paths only (mvuRight < 0,
  * bForward = bBackward = false); cv::Mat float products Rcw*x+tcw follow cv::gemm (double accumulation, one rounding).
  */

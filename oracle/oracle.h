@@ -7,14 +7,21 @@
  * product (cube_slam_amd/, include/) never includes, links or calls anything
  * in this directory.
  *
- * PARITY UNPINNED: the reference has no tests/golden vectors for this path and
- * cannot be compiled in this environment (needs OpenCV/Eigen/ROS, all absent),
- * see DESIGN.md "Oracle".  Third-party semantics (OpenCV imgproc/features2d,
- * Eigen) are restated from their published algorithms; every function cites
- * the reference file:line it follows.  The only expected outputs the
- * reference ships (object_slam/data/detect_cuboids_saved.txt, the author's
- * offline MATLAB detections for the bundled sequence) pin the line + cuboid
- * chain loosely, not bit for bit: tests/test_cuboid_oracle.py, DESIGN.md 3.
+ * PINNED TO THE REFERENCE'S OWN CODE: the reference has no
+ * tests or golden vectors for this path and its build needs OpenCV / Eigen /
+ * ROS, all absent here; oracle/Makefile.ref therefore compiles the reference's
+ * translation units where they lie under /root/reference -- whole where they
+ * need nothing but OpenCV (against a stand-in for its headers), cut out
+ * function by function at build time where they need Eigen / g2o / the SLAM
+ * classes (against stand-ins for those) -- into oracle/_ref/libref.so, and
+ * tests/test_ref_pins.py demands bit equality of every oracle of the path with
+ * it.  What stays restated and unpinned: the third-party primitives that are
+ * not in the reference tree (OpenCV imgproc / features2d, Eigen's sparse
+ * Cholesky and g2o's block solver over it); each file's header says which.
+ * Every function cites the reference file:line it follows.  The expected
+ * outputs the reference ships (object_slam/data/detect_cuboids_saved.txt, the
+ * author's offline MATLAB detections) pin the line + cuboid chain loosely:
+ * tests/test_cuboid_oracle.py.
  */
 #ifndef CUBESLAM_ORACLE_H
 #define CUBESLAM_ORACLE_H

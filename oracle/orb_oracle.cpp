@@ -1,7 +1,9 @@
 /*
  * oracle/orb_oracle.cpp -- CPU oracle for ORB_SLAM2::ORBextractor.
  *
- * TEST INFRASTRUCTURE ONLY (see oracle.h).  PARITY UNPINNED: restated from
+ * TEST INFRASTRUCTURE ONLY (see oracle.h).  PINNED: tests/test_ref_pins.py runs the reference's own ORBextractor.cc, compiled whole from /root/reference
+ * (oracle/_ref) against a stand-in for the OpenCV headers, on the same images -- key points, descriptors and pyramid levels identical bit for bit; the
+ * OpenCV primitives under it (FAST, resize, GaussianBlur, fastAtan2) stay restated from their published algorithms.  Restated from
  * /root/reference/orb_object_slam/src/ORBextractor.cc and include/ORBextractor.h, plus the OpenCV semantics its call
  * sites reach.  OpenCV version pinned by assumption to the 2.4 / 3.0-3.3 family (the reference's prebuilt examples link
  * libopencv 2.4): cv::FAST (FAST-9/16 + cornerScore + strict 3x3 NMS), cv::resize(INTER_LINEAR) 8-bit fixed point
