@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "se3_util.h"
+#include "ba_iface.h"
 
 namespace {
 
@@ -511,24 +512,33 @@ int orc_ba_optimize(const orc_ba_problem *p, int iterations, double *cam_pose_ou
 
 // ---- the pieces of the LM loop one at a time (test hook): tests/test_ref_pins.py drives them from the REFERENCE'S OWN OptimizationAlgorithmLevenberg::solve /
 // SparseOptimizer::optimize (oracle/_ref, cut out of the vendored g2o) and compares the run with orc_ba_optimize
-struct orc_ba_handle { BA ba; orc_ba_handle(const orc_ba_problem *p) : ba(p) {} };
+struct orc_ba_handle { // the static BA's own pieces, or (dyn) another oracle's behind the same calls
+    BA ba; OrcBAIface *dyn = nullptr;
+    explicit orc_ba_handle(const orc_ba_problem *p) : ba(p) {}
+    ~orc_ba_handle() { delete dyn; }
+};
+static const orc_ba_problem *empty_problem() { static orc_ba_problem z; static bool init = false; if (!init) { std::memset(&z, 0, sizeof(z)); init = true; } return &z; }
 void orc_huber(double e, double delta, double *rho3) { BA::huber(e, delta, rho3); }
 orc_ba_handle *orc_ba_open(const orc_ba_problem *p) { return new orc_ba_handle(p); }
+orc_ba_handle *orc_badyn_open(const orc_badyn_problem *p) { orc_ba_handle *h = new orc_ba_handle(empty_problem()); h->dyn = orc_badyn_make_iface(p); return h; }
 void orc_ba_close(orc_ba_handle *h) { delete h; }
-void orc_ba_compute_errors(orc_ba_handle *h) { h->ba.compute_errors(); }
-double orc_ba_robust_chi2(orc_ba_handle *h) { return h->ba.robust_chi2(); }
-void orc_ba_build_system(orc_ba_handle *h) { h->ba.build_system(0, h->ba.L, true); }
-void orc_ba_sizes(orc_ba_handle *h, int *P, int *L) { *P = h->ba.P; *L = h->ba.L; }
+void orc_ba_compute_errors(orc_ba_handle *h) { if (h->dyn) return h->dyn->compute_errors(); h->ba.compute_errors(); }
+double orc_ba_robust_chi2(orc_ba_handle *h) { if (h->dyn) return h->dyn->robust_chi2(); return h->ba.robust_chi2(); }
+void orc_ba_build_system(orc_ba_handle *h) { if (h->dyn) return h->dyn->build_system(); h->ba.build_system(0, h->ba.L, true); }
+void orc_ba_sizes(orc_ba_handle *h, int *P, int *L) { if (h->dyn) { *P = h->dyn->n_pose_blocks(); *L = h->dyn->n_blocks() - *P; return; } *P = h->ba.P; *L = h->ba.L; }
+int orc_ba_block_dim(orc_ba_handle *h, int block) { if (h->dyn) return h->dyn->block_dim(block); return block < h->ba.P ? 6 : 3; }
 double orc_ba_hessian_diag(orc_ba_handle *h, int block, int j) { // block < P: pose block (6), else landmark block - P (3)
+    if (h->dyn) return h->dyn->hessian_diag(block, j);
     return block < h->ba.P ? h->ba.Hpp_diag[(size_t)block * 36 + j * 7] : h->ba.Hll[(size_t)(block - h->ba.P) * 9 + j * 4];
 }
-int orc_ba_solve(orc_ba_handle *h, double lambda) { return h->ba.solve(lambda) ? 1 : 0; }
-void orc_ba_update(orc_ba_handle *h) { h->ba.update(); }
-void orc_ba_push(orc_ba_handle *h) { h->ba.stack.push_back(h->ba.s); }
-void orc_ba_pop(orc_ba_handle *h) { h->ba.s = h->ba.stack.back(); h->ba.stack.pop_back(); }
-void orc_ba_discard_top(orc_ba_handle *h) { h->ba.stack.pop_back(); }
-const double *orc_ba_x(orc_ba_handle *h, long *n) { if (n) *n = (long)h->ba.x.size(); return h->ba.x.data(); }
-const double *orc_ba_b(orc_ba_handle *h) { return h->ba.b.data(); }
+int orc_ba_solve(orc_ba_handle *h, double lambda) { if (h->dyn) return h->dyn->solve(lambda) ? 1 : 0; return h->ba.solve(lambda) ? 1 : 0; }
+void orc_ba_update(orc_ba_handle *h) { if (h->dyn) return h->dyn->update(); h->ba.update(); }
+void orc_ba_push(orc_ba_handle *h) { if (h->dyn) return h->dyn->push(); h->ba.stack.push_back(h->ba.s); }
+void orc_ba_pop(orc_ba_handle *h) { if (h->dyn) return h->dyn->pop(); h->ba.s = h->ba.stack.back(); h->ba.stack.pop_back(); }
+void orc_ba_discard_top(orc_ba_handle *h) { if (h->dyn) return h->dyn->discard_top(); h->ba.stack.pop_back(); }
+const double *orc_ba_x(orc_ba_handle *h, long *n) { if (h->dyn) return h->dyn->x(n); if (n) *n = (long)h->ba.x.size(); return h->ba.x.data(); }
+const double *orc_ba_b(orc_ba_handle *h) { if (h->dyn) return h->dyn->b(); return h->ba.b.data(); }
+void orc_badyn_read(orc_ba_handle *h, double *cam_pose, double *obj_pose, double *vel, double *points, double *dpoints) { if (h->dyn) h->dyn->read(cam_pose, obj_pose, vel, points, dpoints); }
 int orc_ba_block(orc_ba_handle *h, int kind, int i, int j, double *out) { // after orc_ba_build_system.  kind 0: Hpp(i, i) 36; 1: Hpp(i, j), i < j, 36; 2: Hll(i) 9; 3: Hpl of observation i, 18 (6 x 3)
     const BA &ba = h->ba;
     if (kind == 0) { if (i < 0 || i >= ba.P) return 0; std::copy(&ba.Hpp_diag[(size_t)i * 36], &ba.Hpp_diag[(size_t)i * 36] + 36, out); return 36; }

@@ -3,7 +3,8 @@
  *
  * TEST INFRASTRUCTURE ONLY (see oracle.h).  EDGES PINNED (tests/test_ref_pins.py::test_dynamic_ba_edges_equal_reference, oracle/_ref): computeError of every
  * edge type and the Jacobians of the two three-vertex types equal the reference's own classes (cut out whole, g2o's numeric differentiation under them) bit for
- * bit; the graph construction, the block solver and the LM loop are unpinned.  Restated from /root/reference/orb_object_slam/src/Optimizer.cc:1537-2573
+ * bit, and a run driven by the reference's own OptimizationAlgorithmLevenberg::solve + SparseOptimizer::optimize over this file's pieces equals
+ * orc_badyn_optimize bit for bit (::test_dynamic_ba_schedule_equals_reference); the graph construction and the block solver are unpinned.  Restated from /root/reference/orb_object_slam/src/Optimizer.cc:1537-2573
  * (the graph), orb_object_slam/{include/g2o_Object.h, src/g2o_Object.cpp} (VertexCuboidFixScale :88-116, VelocityPlanarVelocity
  * g2o_Object.h:288-308, EdgeDynamicPointCuboidCamera :154-233, EdgeObjectMotion :241-272, UnaryLocalPoint :378-398,
  * EdgeSE3CuboidFixScaleProj :118-128, EdgePointCuboidOnlyObjectFixScale :336-354) and the vendored g2o under
@@ -21,6 +22,7 @@
 #include <vector>
 
 #include "se3_util.h"
+#include "ba_iface.h"
 
 namespace {
 
@@ -385,7 +387,43 @@ struct DynBA {
     }
 };
 
+struct DynIface : OrcBAIface { // the pieces of DynBA one at a time (ba_iface.h)
+    DynBA ba; std::vector<double> xc, bc; std::vector<int> blk_off, blk_dim;
+    explicit DynIface(const orc_badyn_problem *p) : ba(p) {
+        for (int i = 0; i < p->n_cams; i++) if (ba.cam_off[i] >= 0) { blk_off.push_back(ba.cam_off[i]); blk_dim.push_back(6); }
+        for (int i = 0; i < p->n_objs; i++) { blk_off.push_back(ba.obj_off[i]); blk_dim.push_back(6); }
+        for (int i = 0; i < p->n_vels; i++) { blk_off.push_back(ba.vel_off[i]); blk_dim.push_back(2); }
+    }
+    void compute_errors() override { ba.compute_errors(); }
+    double robust_chi2() override { return ba.robust_chi2(); }
+    void build_system() override { ba.build_system(); }
+    int n_blocks() override { return (int)blk_off.size() + ba.L; }
+    int n_pose_blocks() override { return (int)blk_off.size(); }
+    int block_dim(int k) override { return k < (int)blk_off.size() ? blk_dim[k] : 3; }
+    double hessian_diag(int k, int j) override {
+        if (k < (int)blk_off.size()) { const size_t r = (size_t)blk_off[k] + j; return ba.Hpp[r * ba.NP + r]; }
+        return ba.Hll[(size_t)(k - (int)blk_off.size()) * 9 + j * 4];
+    }
+    bool solve(double lambda) override { return ba.solve(lambda); }
+    void update() override { ba.update(); }
+    void push() override { ba.stack.push_back(ba.s); }
+    void pop() override { ba.s = ba.stack.back(); ba.stack.pop_back(); }
+    void discard_top() override { ba.stack.pop_back(); }
+    const double *x(long *n) override { xc = ba.xp; xc.insert(xc.end(), ba.xl.begin(), ba.xl.end()); xc.resize((size_t)ba.NP + (size_t)ba.L * 3, 0.0); if (n) *n = (long)xc.size(); return xc.data(); }
+    const double *b() override { bc = ba.bp; bc.insert(bc.end(), ba.bl.begin(), ba.bl.end()); return bc.data(); }
+    void read(double *cam_pose, double *obj_pose, double *vel, double *points, double *dpoints) override {
+        const orc_badyn_problem *p = ba.p;
+        for (int i = 0; i < p->n_cams; i++) se3_to7(ba.s.cams[i], cam_pose + (size_t)i * 7);
+        for (int i = 0; i < p->n_objs; i++) se3_to7(ba.s.objs[i].pose, obj_pose + (size_t)i * 7);
+        if (p->n_vels) std::memcpy(vel, ba.s.vels.data(), ba.s.vels.size() * sizeof(double));
+        if (p->n_points) std::memcpy(points, ba.s.pts.data(), ba.s.pts.size() * sizeof(double));
+        if (p->n_dpoints) std::memcpy(dpoints, ba.s.dpts.data(), ba.s.dpts.size() * sizeof(double));
+    }
+};
+
 } // namespace
+
+OrcBAIface *orc_badyn_make_iface(const orc_badyn_problem *p) { return new DynIface(p); }
 
 extern "C" {
 

@@ -272,6 +272,10 @@ int orc_cuboid9_edge_linearize(int n, const double *cam_Tcw, const double *cub_g
 void orc_huber(double e, double delta, double *rho3); /* RobustKernelHuber::robustify as the BA uses it */
 typedef struct orc_ba_handle orc_ba_handle;
 orc_ba_handle *orc_ba_open(const orc_ba_problem *p);
+struct orc_badyn_problem;
+orc_ba_handle *orc_badyn_open(const struct orc_badyn_problem *p); /* the same pieces of the dynamic-object BA oracle (read with orc_badyn_read) */
+int orc_ba_block_dim(orc_ba_handle *h, int block);
+void orc_badyn_read(orc_ba_handle *h, double *cam_pose, double *obj_pose, double *vel, double *points, double *dpoints);
 void orc_ba_close(orc_ba_handle *h);
 void orc_ba_compute_errors(orc_ba_handle *h);
 double orc_ba_robust_chi2(orc_ba_handle *h);

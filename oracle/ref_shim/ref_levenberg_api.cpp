@@ -142,6 +142,27 @@ int ref_ba_levenberg(const orc_ba_problem *p, int iterations, double *cam_pose_o
     orc_ba_close(h);
     return done;
 }
+// The same schedule over the dynamic-object BA oracle's pieces (Optimizer::LocalBACameraPointObjectsDynamic's `optimizer.optimize(...)`, Optimizer.cc:2336, 2451):
+// vertices are the non-fixed cameras, the objects (6), the velocities (2), then the marginalised points (3).
+int ref_badyn_levenberg(const orc_badyn_problem *p, int iterations, double *cam_pose, double *obj_pose, double *vel, double *points, double *dpoints, int *trials, double *lambda_final,
+                        double *chi2_final) {
+    orc_ba_handle *h = orc_badyn_open(p);
+    g2o::SparseOptimizer opt; g2o::Solver solver;
+    opt.h = h; solver.h = h; solver.opt = &opt;
+    int P = 0, L = 0;
+    orc_ba_sizes(h, &P, &L);
+    std::vector<g2o::OptimizableGraph::Vertex> verts((size_t)P + L);
+    for (int k = 0; k < P + L; k++) { verts[k] = g2o::OptimizableGraph::Vertex{h, k, orc_ba_block_dim(h, k)}; opt._ivMap.push_back(&verts[k]); }
+    g2o::OptimizationAlgorithmLevenberg alg(&solver);
+    alg._optimizer = &opt; opt._algorithm = &alg;
+    const int done = opt.optimize(iterations);
+    orc_ba_compute_errors(h);
+    *chi2_final = orc_ba_robust_chi2(h);
+    *trials = solver.solves; *lambda_final = alg.currentLambda();
+    orc_badyn_read(h, cam_pose, obj_pose, vel, points, dpoints);
+    orc_ba_close(h);
+    return done;
+}
 void ref_huber_robustify(double e, double delta, double *rho3) {
     g2o::RobustKernelHuber k; k.setDelta(delta);
     EigenK::Vector3d r; k.robustify(e, r);

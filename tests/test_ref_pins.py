@@ -754,3 +754,34 @@ def test_fuse_equals_reference(ref, oracle):
         assert 0 < (valid == 0).sum() < n_mp
         total += n
     assert total > 1500
+
+
+def test_dynamic_ba_schedule_equals_reference(ref, oracle):
+    """The dynamic-object BA oracle's LM loop against g2o's own OptimizationAlgorithmLevenberg::solve / SparseOptimizer::optimize text (as
+    test_levenberg_schedule_equals_reference does for the static BA) driven over the same oracle's pieces: iterations, trials, lambda, chi2 and every estimate
+    to the last bit -- vertices of three sizes (6, 2, 3) in computeLambdaInit / computeScale, fixed and free points."""
+    import oracle.pyoracle as po
+    ref.ref_badyn_levenberg.restype = C.c_int
+    rejected = 0
+    for seed, kw, iters in ((31, dict(n_kf=8, n_points=150, n_objects=2, pts_per_obj=20), 6), (32, dict(n_kf=6, n_points=80, n_objects=3, pts_per_obj=12, stereo_frac=0.6), 10),
+                            (33, dict(n_kf=7, n_points=100, n_objects=2, pts_per_obj=16, fix_points=True), 8), (34, dict(n_kf=6, n_points=80, n_objects=2, pts_per_obj=12), 15),
+                            (37, dict(n_kf=6, n_points=80, n_objects=2, pts_per_obj=12), 15)):
+        d = dict(synth.ba_dyn_problem(seed, **kw))
+        if seed == 32:
+            d["obs_uv"] = d["obs_uv"].copy(); d["obs_uv"][::23] += 35.0  # gross outliers
+        if seed in (34, 37):  # a start far enough off for rejected trials (lambda grows, the state is restored) and, for 37, an early stop
+            rng = np.random.default_rng(seed)
+            d["obj_pose"] = d["obj_pose"].copy(); d["obj_pose"][:, :3] += rng.normal(0, 1.5, d["obj_pose"][:, :3].shape)
+            d["cam_pose"] = d["cam_pose"].copy(); d["cam_pose"][1:, :3] += rng.normal(0, 0.5, d["cam_pose"][1:, :3].shape)
+        p = po.badyn_struct(d)
+        out = [np.zeros((max(n, 1), k)) for n, k in ((p.n_cams, 7), (p.n_objs, 7), (p.n_vels, 2), (p.n_points, 3), (p.n_dpoints, 3))]
+        trials, lam, chi = C.c_int(), C.c_double(), C.c_double()
+        done = ref.ref_badyn_levenberg(C.byref(p), iters, *[_dp(a) for a in out], C.byref(trials), C.byref(lam), C.byref(chi))
+        res, st = po.badyn_optimize(d, iters)
+        assert done == st["iterations"] and trials.value == st["lm_trials"], (seed, done, st["iterations"], trials.value, st["lm_trials"])
+        assert lam.value == st["lambda_final"] and chi.value == st["chi2_final"], (seed, lam.value, st["lambda_final"], chi.value, st["chi2_final"])
+        for a, name, n in zip(out, ("cam_pose", "obj_pose", "vel", "points", "dpoints"), (p.n_cams, p.n_objs, p.n_vels, p.n_points, p.n_dpoints)):
+            assert np.array_equal(a[:n], res[name]), (seed, name)
+        assert st["chi2_final"] < st["chi2_init"]
+        rejected += st["lm_trials"] - st["iterations"]
+    assert rejected >= 10
