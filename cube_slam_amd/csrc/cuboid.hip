@@ -37,22 +37,18 @@ constexpr int DT_INIT = INT_MAX >> 2;
 constexpr int DT_HV = 62587;    // cvRound(0.955f * 65536)
 constexpr int DT_DIAG = 89738;  // cvRound(1.3693f * 65536)  (checked against the float product on the host at create())
 constexpr double PI = 3.14159265358979323846;
-// cuboid_sweep_score (LDS-resident code map), see the kernel
-constexpr int SC_T = 512;                                             // threads per workgroup: 2 waves per SIMD, up to 256 VGPRs each
+// cuboid_sweep_score (corner construction + edge scoring, the unit's chamfer map resident in LDS as 16-bit codes), see the kernel
 constexpr int SC_LDS_BYTES = 160 * 1024;
 constexpr int SC_LUT_N = (DT_HV + 63) / 64;                            // 978 residue buckets
-constexpr int SC_MAP_OFF = 32;                                        // control words in front of the map
-constexpr int SC_MAP_ENTRIES = (SC_LDS_BYTES - SC_MAP_OFF) / 2;        // 81 904
+constexpr int SC_CTRL_BYTES = 64;                                     // control words in front of the table
+constexpr int SC_MAP_OFF = SC_CTRL_BYTES + 2048;                       // control words + the encoder's residue table (978 x 2 B, padded)
+constexpr int SC_MAP_ENTRIES = (SC_LDS_BYTES - SC_MAP_OFF) / 2;        // 80 864
 constexpr float SC_ESC_D = 244.0f;                                     // d < 244 => i <= 255 and j <= 178
-constexpr int SC_COST_PX_NUM = 3, SC_COST_TASK1 = 1700, SC_COST_TASK2 = 1350; // wave-instructions: map copy per 64 pixels / task of 64 proposals
-constexpr int SC_PLAN_LDS_UNITS = 4096;                                // cuboid_score_plan keeps the cost line of this many units in LDS
-constexpr int SC_BIG_P = 32;                                          // proposals per work item of cuboid_sweep_score_big
-constexpr int SC_PFB = 16;                                            // 16-byte loads per thread in flight while a map is copied
 constexpr int K_VIS1[9][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 0}, {1, 5}, {2, 4}, {3, 7}, {4, 7}, {4, 5}};
 constexpr int K_VIS2[7][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 0}, {1, 5}, {2, 4}, {4, 5}};
 constexpr int K_VPE1[3][4] = {{0, 1, 7, 4}, {3, 0, 4, 5}, {3, 7, 1, 5}};
 constexpr int K_VPE2[3][4] = {{0, 1, 2, 3}, {3, 0, 4, 5}, {2, 4, 1, 5}};
-__host__ __device__ inline bool score_unit_fits(int roi_w, int roi_h) { return (long)roi_w * roi_h + roi_w + 2 <= (long)SC_MAP_ENTRIES; }
+__host__ __device__ inline bool score_unit_fits(int roi_w, int roi_h) { return (long)roi_w * roi_h + (roi_w + 2 > 8 ? roi_w + 2 : 8) <= (long)SC_MAP_ENTRIES; }
 
 
 struct Calib { double K[9]; double invK[9]; };
@@ -73,6 +69,7 @@ struct Unit {        // host-filled plan of one (frame, box, height-sample)
     int left, top, right, width_raw, height_raw;
     int down_expand, down_y_expan;
     int n_tops, top_start, top_step;
+    unsigned tops_magic; // floor(2^32 / n_tops) + 1 when __umulhi(p, tops_magic) == p / n_tops for every pair index p of the unit, else 0 (divide)
     int roi_x, roi_y, roi_w, roi_h, roi_r, roi_b;
     int hyp_cap;
     int vp_off;      // entries
