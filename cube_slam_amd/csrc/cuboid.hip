@@ -44,10 +44,10 @@ constexpr int SC_CTRL_BYTES = 64;                                     // control
 constexpr int SC_MAP_OFF = SC_CTRL_BYTES + 2048;                       // control words + the encoder's residue table (978 x 2 B, padded)
 constexpr int SC_MAP_ENTRIES = (SC_LDS_BYTES - SC_MAP_OFF) / 2;        // 80 864
 constexpr float SC_ESC_D = 244.0f;                                     // d < 244 => i <= 255 and j <= 178
-constexpr int K_VIS1[9][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 0}, {1, 5}, {2, 4}, {3, 7}, {4, 7}, {4, 5}};
-constexpr int K_VIS2[7][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 0}, {1, 5}, {2, 4}, {4, 5}};
-constexpr int K_VPE1[3][4] = {{0, 1, 7, 4}, {3, 0, 4, 5}, {3, 7, 1, 5}};
-constexpr int K_VPE2[3][4] = {{0, 1, 2, 3}, {3, 0, 4, 5}, {2, 4, 1, 5}};
+constexpr int K_VIS1[9][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 0}, {1, 5}, {2, 4}, {3, 7}, {4, 7}, {4, 5}}; // box_proposal_detail.cpp:432
+constexpr int K_VIS2[7][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 0}, {1, 5}, {2, 4}, {4, 5}};                 // :442
+constexpr int K_VPE1[3][4] = {{0, 1, 7, 4}, {3, 0, 4, 5}, {3, 7, 1, 5}};                               // :434
+constexpr int K_VPE2[3][4] = {{0, 1, 2, 3}, {3, 0, 4, 5}, {2, 4, 1, 5}};                               // :444
 __host__ __device__ inline bool score_unit_fits(int roi_w, int roi_h) { return (long)roi_w * roi_h + (roi_w + 2 > 8 ? roi_w + 2 : 8) <= (long)SC_MAP_ENTRIES; }
 
 
@@ -817,113 +817,116 @@ __global__ void __launch_bounds__(256) cuboid_vp(const Unit *units, const UnitDy
     vpt[(long)U.vp_off + e] = E;
 }
 
-// ------------------------------------------------------------------------------------------------ sweep + score
-__constant__ int c_vis1[9][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 0}, {1, 5}, {2, 4}, {3, 7}, {4, 7}, {4, 5}}; // box_proposal_detail.cpp:432
-__constant__ int c_vis2[7][2] = {{0, 1}, {1, 2}, {2, 3}, {3, 0}, {1, 5}, {2, 4}, {4, 5}};                 // :442
-__constant__ int c_vpe1[3][4] = {{0, 1, 7, 4}, {3, 0, 4, 5}, {3, 7, 1, 5}};                               // :434
-__constant__ int c_vpe2[3][4] = {{0, 1, 2, 3}, {3, 0, 4, 5}, {2, 4, 1, 5}};                               // :444
+// ------------------------------------------------------------------------------------------------ sweep: filter + score
+// hypothesis index h = ((rp*n_yaw + yaw)*n_tops + top)*2 + (cfg-1)   (the reference's loop nest :229-285); q = rp*n_yaw + yaw indexes the VP table
+// per global hypothesis index g = hyp_off + h: flag[g] u8 (0 rejected, 1/2 = vp_1_position), derr[g], aerr[g] (survivors only).
+// The corners of a hypothesis are a pure function of (unit, q, top sample, configuration): they are never stored -- the filter, the score
+// kernel and the selection each build the ones they need from the same function, so all three see the same doubles.
+__device__ __forceinline__ void hyp_decode(const Unit &U, int h, int &q, int &ti) {
+    const unsigned p = (unsigned)h >> 1;
+    q = U.tops_magic ? (int)__umulhi(p, U.tops_magic) : (int)(p / (unsigned)U.n_tops);
+    ti = (int)p - q * U.n_tops;
+}
 
-// corner construction with every reject test of box_proposal_detail.cpp:254-418; returns vp_1_position (0 = rejected)
-__device__ inline int make_corners(const Unit &U, const VPEntry &E, int top_x, int cfg, V2 c[8]) {
+// seg_hit_boundary (object_3d_util.cpp:194-230) against a vertical boundary x = bx, by0 <= y <= by1 (its `bx0 == bx1` branch; the `by0 == by1`
+// branch needs a box of height zero, whose top samples can never produce the t.x == bx it asks for) and against a horizontal one y = by.
+// A miss is (-1, -1) like the reference's initial value.
+__device__ __forceinline__ V2 hit_vertical(V2 ps, V2 pe, double bx, double by0, double by1) {
+    const double dx = pe.x - ps.x, dy = pe.y - ps.y;
+    const double lambd = (bx - ps.x) / dx;
+    const double ty = ps.y + lambd * dy;
+    const bool hit = lambd >= 0 && by0 <= ty && ty <= by1;
+    return V2{hit ? bx : -1.0, hit ? ty : -1.0};
+}
+__device__ __forceinline__ V2 hit_horizontal(V2 ps, V2 pe, double by, double bx0, double bx1) {
+    const double dx = pe.x - ps.x, dy = pe.y - ps.y;
+    const double lambd = (by - ps.y) / dy;
+    const double tx = ps.x + lambd * dx;
+    const bool hit = lambd >= 0 && bx0 <= tx && tx <= bx1;
+    return V2{hit ? tx : -1.0, hit ? by : -1.0};
+}
+
+// Corner construction of box_proposal_detail.cpp:254-418 for one hypothesis, branch-free across the two configurations: configuration 1 finds
+// corner 4 from corner 1 and intersects for corner 3, configuration 2 finds corner 3 from corner 2 and intersects for corner 4 -- the same
+// two steps on (S, other) = (c1, c2) / (c2, c1), the arguments of line_intersect_inf picked per lane.  TESTS: with every reject test of the
+// reference (returns vp_1_position, 0 = rejected; a wave leaves as soon as all its lanes are dead); without them for a hypothesis already
+// known to survive.  N78 = false skips corners 7 and 8 (no edge of configuration 2 uses them).  Same operations in the same order as the
+// reference: the result does not depend on TESTS.
+template <bool TESTS, bool N78>
+__device__ __forceinline__ int corners_build(const Unit &U, const double *vp, int top_x, int cfg, V2 (&c)[8], bool live = true) {
     // `dist(a, b) < 20` (shorted_edge_thre :81) without the square root: sqrt is monotone and correctly rounded, and the largest double
     // whose root rounds below 20 is pred(pred(400)), so sqrt(d2) < 20 <=> d2 < pred(400) = 0x4078ffffffffffff (tests/test_cabi.py checks it)
     auto short_edge = [](V2 a, V2 b) { const double dx = a.x - b.x, dy = a.y - b.y; return dx * dx + dy * dy < __longlong_as_double(0x4078ffffffffffffll); };
-    const V2 vp_1{E.vp[0], E.vp[1]}, vp_2{E.vp[2], E.vp[3]}, vp_3{E.vp[4], E.vp[5]};
+    const V2 vp_1{vp[0], vp[1]}, vp_2{vp[2], vp[3]}, vp_3{vp[4], vp[5]};
     const double left = U.left, right = U.right, top = U.top, down = U.down_y_expan;
-    V2 c1{(double)top_x, top};
-    int vp_1_position = 0;
-    V2 c2 = seg_hit_boundary(vp_1, c1, right, top, right, down);
-    if (c2.x == -1) {
-        c2 = seg_hit_boundary(vp_1, c1, left, top, left, down);
-        if (c2.x != -1) vp_1_position = 2;
-    } else
-        vp_1_position = 1;
-    if (!(vp_1_position > 0)) return 0;
-    if (short_edge(c1, c2)) return 0;
-    V2 c3, c4;
-    if (cfg == 1) {
-        if (vp_1_position == 1) c4 = seg_hit_boundary(vp_2, c1, left, top, left, down);
-        else c4 = seg_hit_boundary(vp_2, c1, right, top, right, down);
-        if (c4.y == -1) return 0;
-        if (short_edge(c1, c4)) return 0;
-        c3 = line_intersect_inf(vp_2, c2, vp_1, c4);
-        if (!inside_box(c3, left, top, right, down)) return 0;
-        if ((short_edge(c3, c4)) || (short_edge(c3, c2))) return 0;
-    } else {
-        if (vp_1_position == 1) c3 = seg_hit_boundary(vp_2, c2, left, top, left, down);
-        else c3 = seg_hit_boundary(vp_2, c2, right, top, right, down);
-        if (c3.y == -1) return 0;
-        if (short_edge(c2, c3)) return 0;
-        c4 = line_intersect_inf(vp_1, c3, vp_2, c1);
-        if (!inside_box(c4, left, (double)U.roi_y, right, (double)U.roi_b)) return 0; // :347 uses the expanded y-range
-        if ((short_edge(c3, c4)) || (short_edge(c4, c1))) return 0;
+    const V2 c1{(double)top_x, top};
+    const V2 c2r = hit_vertical(vp_1, c1, right, top, down), c2l = hit_vertical(vp_1, c1, left, top, down); // :257-268: the right edge first
+    const int pos = c2r.x != -1 ? 1 : (c2l.x != -1 ? 2 : 0);
+    const V2 c2 = pos == 1 ? c2r : c2l;
+    bool alive = live && pos > 0;
+    if (TESTS) { alive = alive && !short_edge(c1, c2); if (!__any(alive)) return 0; }
+    const bool k1 = cfg == 1;
+    const V2 S = k1 ? c1 : c2, other = k1 ? c2 : c1;
+    const V2 X = hit_vertical(vp_2, S, pos == 1 ? left : right, top, down); // :296-300 / :331-335
+    if (TESTS) { alive = alive && X.y != -1 && !short_edge(S, X); if (!__any(alive)) return 0; }
+    const V2 Y = k1 ? line_intersect_inf(vp_2, other, vp_1, X) : line_intersect_inf(vp_1, X, vp_2, other); // :306 / :342
+    if (TESTS) { // configuration 2 tests corner 4 against the expanded y-range (:347), configuration 1 corner 3 against the box (:311)
+        alive = alive && inside_box(Y, left, k1 ? top : (double)U.roi_y, right, k1 ? down : (double)U.roi_b) && !short_edge(Y, X) && !short_edge(Y, other);
+        if (!__any(alive)) return 0;
     }
+    const V2 c3 = k1 ? Y : X, c4 = k1 ? X : Y;
     const double el = U.roi_x, et = U.roi_y, er = U.roi_r, eb = U.roi_b;
-    V2 c5 = seg_hit_boundary(vp_3, c3, left, down, right, down);
-    if (c5.y == -1) return 0;
-    if (short_edge(c3, c5)) return 0;
-    V2 c6 = line_intersect_inf(vp_2, c5, vp_3, c2);
-    if (!inside_box(c6, el, et, er, eb)) return 0;
-    if ((short_edge(c6, c2)) || (short_edge(c6, c5))) return 0;
-    V2 c7 = line_intersect_inf(vp_1, c6, vp_3, c1);
-    if (!inside_box(c7, el, et, er, eb)) return 0;
-    if ((short_edge(c7, c1)) || (short_edge(c7, c6))) return 0;
-    V2 c8 = line_intersect_inf(vp_1, c5, vp_2, c7);
-    if (!inside_box(c8, el, et, er, eb)) return 0;
-    if ((short_edge(c8, c4)) || (short_edge(c8, c5)) || (short_edge(c8, c7))) return 0;
-    c[0] = c1; c[1] = c2; c[2] = c3; c[3] = c4; c[4] = c5; c[5] = c6; c[6] = c7; c[7] = c8;
-    return vp_1_position;
+    const V2 c5 = hit_horizontal(vp_3, c3, down, left, right);
+    if (TESTS) { alive = alive && c5.y != -1 && !short_edge(c3, c5); if (!__any(alive)) return 0; }
+    const V2 c6 = line_intersect_inf(vp_2, c5, vp_3, c2);
+    if (TESTS) { alive = alive && inside_box(c6, el, et, er, eb) && !short_edge(c6, c2) && !short_edge(c6, c5); if (!__any(alive)) return 0; }
+    c[0] = c1; c[1] = c2; c[2] = c3; c[3] = c4; c[4] = c5; c[5] = c6;
+    if (TESTS || N78) {
+        const V2 c7 = line_intersect_inf(vp_1, c6, vp_3, c1);
+        if (TESTS) { alive = alive && inside_box(c7, el, et, er, eb) && !short_edge(c7, c1) && !short_edge(c7, c6); if (!__any(alive)) return 0; }
+        const V2 c8 = line_intersect_inf(vp_1, c5, vp_2, c7);
+        if (TESTS) alive = alive && inside_box(c8, el, et, er, eb) && !short_edge(c8, c4) && !short_edge(c8, c5) && !short_edge(c8, c7);
+        c[6] = c7; c[7] = c8;
+    } else { c[6] = V2{0, 0}; c[7] = V2{0, 0}; }
+    return alive ? pos : 0;
 }
 
-// hypothesis index h = ((rp*n_yaw + yaw)*n_tops + top)*2 + (cfg-1)   (the reference's loop nest :229-285)
-// SoA outputs over the global hypothesis index g = hyp_off + h:
-//   flag[g] u8: 0 rejected, 1/2 = vp_1_position; derr[g], aerr[g]; corners[p*hyp_total + g], p = 0..15 (x0..x7,y0..y7)
-// Both grids are 1-D and XCD-aware: workgroup b runs on XCD b%8 (observed dispatch rule), so all workgroups of one unit are
-// given the same b%8 and the unit's distance map is fetched into a single XCD's L2.
-//
-// cuboid_sweep_corners: corner construction with all reject tests for SWEEP_HB hypotheses per workgroup; the surviving
-// hypotheses are appended to the unit's two proposal lists -- configuration 1 grows from vlist[hyp_off] upwards, configuration 2
-// from vlist[hyp_off + hyp_cap - 1] downwards, counts in vcount[2u], vcount[2u+1] -- so that the scoring workgroups are
-// configuration-uniform.  Ordered compaction (ballot ranks, no atomics inside the workgroup): a list is in hypothesis order inside
-// every workgroup's segment; the order only decides which thread scores which proposal.
-__global__ void __launch_bounds__(256) cuboid_sweep_corners(const Unit *units, int n_units, int blocks_per_unit, const FrameDyn *fd, Opts o,
-                                                            const VPEntry *vpt, uint8_t *flag, double *corners, long hyp_total, int *vcount,
-                                                            int *vlist) {
+// cuboid_sweep_filter: the reject tests of every hypothesis (SWEEP_HB per workgroup, one per lane).  The surviving hypotheses are appended to
+// the unit's two proposal lists -- configuration 1 grows from vlist[hyp_off] upwards, configuration 2 from vlist[hyp_off + hyp_cap - 1]
+// downwards, counts in vcount[2u], vcount[2u+1] -- so that the scoring tasks are configuration-uniform.  Ordered compaction (ballot ranks, no
+// atomics inside the workgroup): a list is in hypothesis order inside every workgroup's stretch, neighbouring lanes of a scoring task sample
+// neighbouring pixels.  Nothing else leaves the kernel: 1 B of flag per hypothesis, 4 B per survivor.
+__global__ void __launch_bounds__(256) cuboid_sweep_filter(const Unit *units, int n_units, int blocks_per_unit, const FrameDyn *fd, Opts o,
+                                                           const VPEntry *vpt, uint8_t *flag, int *vcount, int *vlist) {
     __shared__ int s_list[2][SWEEP_HB / 2];
     __shared__ int s_wc[2][SWEEP_HB / 64]; // survivors per (round, wave) and configuration
     __shared__ int s_base[2];
     const int b = blockIdx.x;
-    const int xcd = b & 7, slot = b >> 3;
-    const int u = (slot / blocks_per_unit) * 8 + xcd, blk = slot % blocks_per_unit;
+    const int u = b / blocks_per_unit, blk = b - u * blocks_per_unit;
     if (u >= n_units) return;
     const Unit &U = units[u];
     const FrameDyn &D = fd[U.frame];
-    const int n_yaw = D.n_yaw, n_rp = D.n_roll * D.n_pitch;
-    const int n_hyp = n_rp * n_yaw * U.n_tops * 2;
+    const int n_hyp = D.n_roll * D.n_pitch * D.n_yaw * U.n_tops * 2;
     const int h0 = blk * SWEEP_HB;
     if (h0 >= U.hyp_cap) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     int rank[SWEEP_HB / 256]; // rank among the survivors of the same configuration in this wave and round, -1 = rejected
     for (int r = 0; r < SWEEP_HB / 256; r++) {
-        int h = h0 + r * 256 + threadIdx.x;
+        const int h = h0 + r * 256 + threadIdx.x;
         int pos = 0;
-        if (h < U.hyp_cap) {
-            long g = U.hyp_off + h;
-            if (h < n_hyp) {
-                int cfg = (h & 1) + 1, q = h >> 1;
-                int ti = q % U.n_tops; q /= U.n_tops;
-                if ((cfg == 1 && o.cfg1) || (cfg == 2 && o.cfg2)) {
-                    const VPEntry &E = vpt[(long)U.vp_off + q];
-                    V2 c[8];
-                    pos = make_corners(U, E, U.top_start + ti * U.top_step, cfg, c);
-                    if (pos) {
+        if (h0 + r * 256 + (wave << 6) < n_hyp) { // (wave-uniform: the early exits of corners_build vote over the wave)
+            const int cfg = (h & 1) + 1;
+            const bool on = h < n_hyp && ((cfg == 1 && o.cfg1) || (cfg == 2 && o.cfg2));
+            int q, ti;
+            hyp_decode(U, on ? h : h0 + r * 256 + (wave << 6), q, ti);
+            const double *vpq = vpt[(long)U.vp_off + q].vp;
+            double vp[6];
 #pragma unroll
-                        for (int k = 0; k < 8; k++) { corners[(long)k * hyp_total + g] = c[k].x; corners[(long)(8 + k) * hyp_total + g] = c[k].y; }
-                    }
-                }
-            }
-            flag[g] = (uint8_t)pos;
+            for (int k = 0; k < 6; k++) vp[k] = vpq[k];
+            V2 c[8];
+            pos = corners_build<true, true>(U, vp, U.top_start + ti * U.top_step, cfg, c, on);
         }
+        if (h < U.hyp_cap) flag[U.hyp_off + h] = (uint8_t)pos;
         // h0 and r*256 are even, so lane parity = configuration: even lanes are configuration 1
         const unsigned long long m = __ballot(pos != 0);
         const unsigned long long mine = (lane & 1) ? (m & 0xAAAAAAAAAAAAAAAAull) : (m & 0x5555555555555555ull);
@@ -947,35 +950,45 @@ __global__ void __launch_bounds__(256) cuboid_sweep_corners(const Unit *units, i
     for (int s = threadIdx.x; s < c2; s += 256) d2[-s] = s_list[1][s];
 }
 
-// ---- cuboid_sweep_score: the edge-scoring kernel, with the unit's distance map resident in LDS ---------------------------------------------
-// Why LDS: the kernel is a gather kernel (41 M samples per bench launch at positions that differ from lane to lane); through global memory
-// every gathered lane costs the texture-address path about one CU-cycle (round 1: 103 us, TA_BUSY 80 %).  LDS serves 32 lanes per cycle.
+// test / debug access (cs_cuboid_batch_unit): the 16 corner coordinates of every surviving hypothesis of one unit, planes of n_hyp doubles
+__global__ void __launch_bounds__(256) cuboid_unit_corners(const Unit *units, int u, int n_hyp, const VPEntry *vpt, const uint8_t *flag, double *out) {
+    const Unit &U = units[u];
+    const int h = blockIdx.x * 256 + threadIdx.x;
+    if (h >= n_hyp || !(flag[U.hyp_off + h] & 3)) return;
+    int q, ti;
+    hyp_decode(U, h, q, ti);
+    V2 c[8];
+    corners_build<false, true>(U, vpt[(long)U.vp_off + q].vp, U.top_start + ti * U.top_step, (h & 1) + 1, c);
+    for (int k = 0; k < 8; k++) { out[(long)k * n_hyp + h] = c[k].x; out[(long)(8 + k) * n_hyp + h] = c[k].y; }
+}
+
+// ---- cuboid_sweep_score: corner construction + edge scoring of the surviving proposals, the unit's distance map resident in LDS -------------
+// Why LDS: scoring is a gather (99 / 77 samples per proposal at positions that differ from lane to lane); through global memory every
+// gathered lane costs the texture-address path about one CU-cycle (round 1: TA_BUSY 80 %).  LDS serves 32 lanes per cycle.
 //
-// Representation (cuboid_dt_codes).  The chamfer values are t * 2^-16 with t = i*DT_HV + j*DT_DIAG (i straight and j diagonal steps of the
-// shortest path, unique for t < 2^24), so a pixel less than 244 px from the nearest edge (i <= 255, j <= 178) is exactly the 16-bit code
-// i | j << 8, and 80 920 codes fit one CU's 160 KB.  A unit with a pixel farther than that (an edge-free 244-px disc: never on real scenes)
-// or with a larger ROI is scored by cuboid_sweep_score_big from the float map.
+// Representation.  The chamfer values are t * 2^-16 with t = i*DT_HV + j*DT_DIAG (i straight and j diagonal steps of the shortest path,
+// unique for t < 2^24), so a pixel less than 244 px from the nearest edge (i <= 255, j <= 178) is exactly the 16-bit code i | j << 8, and
+// 80 864 codes fit one CU's 160 KB.  The workgroup reads the unit's FLOAT map once (the distance transform's output: 4 B per ROI pixel, the
+// bytes SURVEY 8d counts) and encodes while it copies:
 //   encode: t = d * 65536 exactly; qn = floor(t / HV) from one float FMA (the fractional part of t / HV is (j * DIAG mod HV) / HV: 0 or in
 //     [0.00155, 0.99845], a bias of 0.0005 absorbs the rounding); the residue q = t - qn * HV identifies j (the 256 residues j * DIAG mod
 //     HV are >= 97 apart: one per 64-wide bucket, tests/test_cabi.py) and code = qn + lut[q >> 6] with lut = (j << 8) - floor(j * DIAG /
 //     HV), because i = qn - floor(j * DIAG / HV).
 //   decode: d = fma(float(j), DIAG * 2^-16, float(i) * HV * 2^-16) -- the product is exact (< 2^24) and the fused sum rounds t once, like
 //     the distance transform's int -> float conversion: v_cvt_f32_ubyte0, v_cvt_f32_ubyte1, v_mul_f32, v_fma_f32.
+// A unit with a pixel farther than 244 px from every edge (an edge-free disc: never on real scenes) samples the float map in global memory
+// instead; a unit whose ROI is larger than LDS keeps the head of its map resident and reads the float map for samples past it.
 // One lane scores one proposal (the float sum of box_edge_sum_dists is a chain of 99 / 77 ordered additions, so a proposal cannot be
-// spread over lanes without paying for a transpose); corners live in registers, all samples are unrolled with constant corner indices.
+// spread over lanes without paying for a transpose); the lane builds the proposal's corners from (VP entry, top sample) -- no corner ever
+// touches HBM -- and keeps them in registers, all samples unrolled with constant corner indices.
 // D2 (unchecked dist_map.at on x == w / y == h) without a per-sample clamp: corners are inside the ROI inclusive, so the flat index is at
-// most w*h + w, and the w + 1 entries after the map repeat its last pixel -- the value the clamp of round 1 produced.
+// most w*h + w, and the w + 2 entries after the map repeat its last pixel -- the value the clamp of round 1 produced.
 //
-// Work distribution.  cuboid_score_plan lays every LDS unit on a cost line (copy cost ~ pixels, then one task per 64 proposals of one
-// configuration) and cuts the line into G equal segments; workgroup g (one per CU: the map takes the whole LDS) owns segment g, copies each
-// unit it touches once and lets its waves pull tasks from an LDS counter.  A unit cut by a segment border is copied by both neighbours;
-// odd segments run backwards so that both reach the shared unit at the same time and the second read hits the XCD's L2 (workgroup b runs
-// on XCD b % 8 and takes segment (b % 8) * G/8 + b / 8: neighbouring segments share an XCD).
-struct ScoreSeg { int unit, task; }; // segment border: task index inside the unit (0 .. number of tasks)
-struct BigItem { int unit, cfg, first; };
-
+// Work distribution.  Persistent workgroups, one per CU (the map takes the whole LDS), pull (unit, slice) items from a global cursor; the host
+// lists the units by falling cost estimate, so the big ones go first and the tail is made of small ones.  With fewer units than CUs a unit
+// is cut into n_slices items (task t belongs to slice t % n_slices; every slice copies the map).  Inside a unit the waves pull tasks of 64
+// proposals of one configuration from an LDS counter.
 __device__ __forceinline__ int sc_tasks(int c) { return (c + 63) >> 6; }
-__device__ __forceinline__ bool sc_unit_lds(const Unit &U, const int *uflag, int u) { return !(uflag[u] & 1); } // an escape code (a pixel 244 px from every edge) needs the float map
 
 __device__ __forceinline__ unsigned sc_encode(float d, const unsigned short *lut) {
     const float tf = d * 65536.0f;
@@ -983,110 +996,7 @@ __device__ __forceinline__ unsigned sc_encode(float d, const unsigned short *lut
     const int qn = (int)__builtin_fmaf(tf, 1.0f / (float)DT_HV, 0.0005f);
     const unsigned q = (unsigned)(t - __mul24(qn, DT_HV));
     const unsigned e = lut[min(q >> 6, (unsigned)(SC_LUT_N - 1))];
-    return d < SC_ESC_D ? (unsigned)qn + e : 0xffffu;
-}
-// float map -> code map, 8 pixels per thread (two 16-byte loads, one 16-byte store); uflag[u] |= 1 when the unit holds an escape pixel
-__global__ void __launch_bounds__(256) cuboid_dt_codes(const Unit *units, const float *dist, unsigned short *codes, int *uflag) {
-    __shared__ unsigned short lut[SC_LUT_N];
-    const int u = blockIdx.y;
-    const Unit &U = units[u];
-    const int A8 = (U.roi_w * U.roi_h + 7) >> 3; // slices are padded to 64 pixels
-    if (blockIdx.x * 512 >= A8) return;
-    for (int i = threadIdx.x; i < SC_LUT_N; i += 256) lut[i] = 0;
-    __syncthreads();
-    { const int j = threadIdx.x, r = (j * DT_DIAG) % DT_HV; lut[r >> 6] = (unsigned short)((j << 8) - (j * DT_DIAG) / DT_HV); }
-    __syncthreads();
-    const float4 *dm4 = reinterpret_cast<const float4 *>(dist + U.pix_off);
-    uint4 *cm4 = reinterpret_cast<uint4 *>(codes + U.pix_off);
-    const int A = U.roi_w * U.roi_h;
-    bool esc = false;
-#pragma unroll
-    for (int r = 0; r < 2; r++) {
-        const int k = blockIdx.x * 512 + r * 256 + threadIdx.x;
-        if (k < A8) {
-            const float4 a = dm4[2 * k], b = dm4[2 * k + 1];
-            const unsigned e0 = sc_encode(a.x, lut), e1 = sc_encode(a.y, lut), e2 = sc_encode(a.z, lut), e3 = sc_encode(a.w, lut);
-            const unsigned e4 = sc_encode(b.x, lut), e5 = sc_encode(b.y, lut), e6 = sc_encode(b.z, lut), e7 = sc_encode(b.w, lut);
-            cm4[k] = make_uint4(e0 | (e1 << 16), e2 | (e3 << 16), e4 | (e5 << 16), e6 | (e7 << 16));
-            const unsigned e[8] = {e0, e1, e2, e3, e4, e5, e6, e7};
-#pragma unroll
-            for (int i = 0; i < 8; i++) esc = esc || (e[i] == 0xffffu && 8 * k + i < A);
-        }
-    }
-    if (esc) atomicOr(&uflag[u], 1);
-}
-
-// one workgroup: cost line of the LDS units -> G + 1 segment borders; work items of the other units -> big list
-// tasks of a unit whose map does not fit LDS gather part of their samples from global memory: costed higher so the segments stay balanced
-__device__ __forceinline__ long sc_task_cost(const Unit &U, int cfg, int hyb_num) { const long c = cfg == 1 ? SC_COST_TASK1 : SC_COST_TASK2; return score_unit_fits(U.roi_w, U.roi_h) ? c : c * hyb_num / 4; }
-__device__ __forceinline__ long sc_copy_cost(const Unit &U) { return (min((long)U.roi_w * U.roi_h, (long)SC_MAP_ENTRIES) * SC_COST_PX_NUM) >> 6; }
-__global__ void __launch_bounds__(1024) cuboid_score_plan(const Unit *units, int n_units, const int *vcount, const int *uflag, long *cost /*n_units + 1*/, ScoreSeg *seg, int G,
-                                                          BigItem *big, int *big_n, int hyb_num /* cost of an oversize unit's task in quarters of a resident one's */) {
-    __shared__ long s_part[16];
-    __shared__ long s_cost[SC_PLAN_LDS_UNITS + 1];
-    __shared__ int s_bign;
-    const int tid = threadIdx.x;
-    if (tid == 0) s_bign = 0;
-    __syncthreads();
-    const int per = (n_units + 1023) / 1024;
-    const int u0 = min(n_units, tid * per), u1 = min(n_units, u0 + per);
-    auto unit_cost = [&](int u) -> long {
-        const int n1 = sc_tasks(vcount[2 * u]), n2 = sc_tasks(vcount[2 * u + 1]);
-        if (n1 + n2 == 0 || !sc_unit_lds(units[u], uflag, u)) return 0;
-        return sc_copy_cost(units[u]) + (long)n1 * sc_task_cost(units[u], 1, hyb_num) + (long)n2 * sc_task_cost(units[u], 2, hyb_num);
-    };
-    long acc = 0;
-    for (int u = u0; u < u1; u++) acc += unit_cost(u);
-    // exclusive scan of the per-thread sums: shuffles inside a wave, the 16 wave totals through LDS (two barriers instead of twenty)
-    const int lane = tid & 63, wave = tid >> 6;
-    long incl = acc;
-#pragma unroll
-    for (int off = 1; off < 64; off <<= 1) { const long v = __shfl_up(incl, off); if (lane >= off) incl += v; }
-    if (lane == 63) s_part[wave] = incl;
-    __syncthreads();
-    long wave_base = 0, total = 0;
-#pragma unroll
-    for (int w = 0; w < 16; w++) { const long v = s_part[w]; if (w < wave) wave_base += v; total += v; }
-    long run = wave_base + incl - acc;
-    const bool in_lds = n_units <= SC_PLAN_LDS_UNITS; // the cost line in LDS: the borders' binary searches never leave the CU
-    for (int u = u0; u < u1; u++) {
-        cost[u] = run; if (in_lds) s_cost[u] = run;
-        run += unit_cost(u);
-        if (!sc_unit_lds(units[u], uflag, u)) { // chunks of SC_BIG_P proposals for cuboid_sweep_score_big
-            for (int cfg = 1; cfg <= 2; cfg++) {
-                const int c = vcount[2 * u + cfg - 1], n = (c + SC_BIG_P - 1) / SC_BIG_P;
-                if (n > 0) { const int base = atomicAdd(&s_bign, n); for (int k = 0; k < n; k++) big[base + k] = BigItem{u, cfg, k * SC_BIG_P}; }
-            }
-        }
-    }
-    if (tid == 0) { cost[n_units] = total; if (in_lds) s_cost[n_units] = total; }
-    __syncthreads(); // the workgroup's own global writes are visible to it after the barrier
-    if (tid == 0) *big_n = s_bign;
-    const long *cl = in_lds ? s_cost : cost;
-    for (int g = tid; g <= G; g += 1024) {
-        ScoreSeg sg{n_units, 0};
-        if (g < G && total > 0) {
-            const long P = (long)((double)total * (double)g / (double)G); // where on the line: rounding only moves a border by a task
-            int lo = 0, hi = n_units; // last unit with cost[u] <= P
-            while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (cl[mid] <= P) lo = mid; else hi = mid; }
-            int u = lo;
-            while (u < n_units && cl[u + 1] == cl[u]) u++; // units without work start at the same point of the line
-            if (u < n_units) {
-                const int n1 = sc_tasks(vcount[2 * u]), n2 = sc_tasks(vcount[2 * u + 1]);
-                const long o = P - cl[u] - sc_copy_cost(units[u]);
-                int k = 0;
-                if (o > 0) {
-                    const long ct1 = sc_task_cost(units[u], 1, hyb_num), ct2 = sc_task_cost(units[u], 2, hyb_num);
-                    if (o < (long)n1 * ct1) k = (int)(o / ct1);
-                    else k = n1 + (int)min((long)n2, (o - (long)n1 * ct1) / ct2);
-                }
-                if (k < 2) k = 0;                                // a border this close to the unit's ends moves to the end: no map is copied for
-                else if (n1 + n2 - k < 2) { u++; k = 0; }        // one or two tasks
-                sg.unit = u; sg.task = k;
-            }
-        }
-        seg[g] = sg;
-    }
+    return d < SC_ESC_D ? ((unsigned)qn + e) & 0xffffu : 0xffffu;
 }
 
 // box_edge_alignment_angle_error (object_3d_util.cpp:455-492), branch-free: a NaN boundary angle never wins `t < best`
@@ -1119,242 +1029,196 @@ template <int CFG> __device__ __forceinline__ double edge_angle_error_reg(const 
 // s/10 * p1 + (1 - s/10) * p2 in double, in the reference's operation order; s = 0 and s = 10 reproduce the corners exactly (0*p1 + 1*p2),
 // and every corner ends two or three edges: the corner pixels are decoded once.  The cfg-2 weights `dist*3.0/2.0` and `dist*2.0` (float ->
 // double -> float) equal the float products dist*1.5f and dist*2.0f bit for bit (3*x and x/2 are exact in double: one rounding of 1.5*x).
-// HYB: the unit's map is larger than LDS -- the first n_res codes are resident, a sample past them is fetched from the code slice in global memory
-// (index clamped to the slice: D2), so an oversize ROI costs the texture path only for its last rows instead of sending the whole unit to
-// cuboid_sweep_score_big
-template <int CFG, bool HYB> __device__ __forceinline__ float edge_sum_dists_code(const double (&rx)[8], const double (&ry)[8], int w, const unsigned short *lmap, const unsigned short *gmap,
+// HYB: only the first n_res pixels are resident (n_res = 0: none, the unit holds a pixel without a code); a sample past them is read from the
+// float map in global memory (index clamped to the slice: D2).
+// LEAN (1024-thread workgroups, 128 registers per lane): no cross-edge prefetch and the samples' address computations kept in source order, so
+// that the live set stays at the corners + one edge of codes; the other three waves of the SIMD cover the LDS latency instead.
+template <int CFG, bool HYB, bool LEAN> __device__ __forceinline__ float edge_sum_dists_code(const double (&rx)[8], const double (&ry)[8], int w, const unsigned short *lmap, const float *gdist,
                                                                                int n_res, int a_last) {
     constexpr int NE = CFG == 1 ? 9 : 7;
     constexpr float HVS = (float)DT_HV / 65536.0f, DGS = (float)DT_DIAG / 65536.0f;
-    auto gather = [&](double px, double py) -> unsigned { // the raw code: its consumer comes a whole edge later
+    auto decode = [&](unsigned c) -> float { return __builtin_fmaf((float)((c >> 8) & 0xffu), DGS, (float)(c & 0xffu) * HVS); };
+    // the raw code (its consumer comes a whole edge later); HYB: the float's bits
+    auto gather = [&](double px, double py) -> unsigned {
         const int idx = __mul24(int(py), w) + int(px);
         if (!HYB) return *reinterpret_cast<const unsigned short *>(reinterpret_cast<const char *>(lmap) + ((unsigned)idx << 1));
-        unsigned v = *reinterpret_cast<const unsigned short *>(reinterpret_cast<const char *>(lmap) + ((unsigned)min(idx, n_res - 1) << 1));
-        if (idx >= n_res) v = gmap[min(idx, a_last)];
-        return v;
+        float v;
+        if (idx < n_res) v = decode(*reinterpret_cast<const unsigned short *>(reinterpret_cast<const char *>(lmap) + ((unsigned)idx << 1)));
+        else v = gdist[min(idx, a_last)];
+        return __float_as_uint(v);
     };
-    auto decode = [&](unsigned c) -> float { return __builtin_fmaf((float)((c >> 8) & 0xffu), DGS, (float)(c & 0xffu) * HVS); };
+    auto value = [&](unsigned c) -> float { return HYB ? __uint_as_float(c) : decode(c); };
     auto gather_edge = [&](int e, unsigned (&c)[9]) {
         const int ia = CFG == 1 ? K_VIS1[e][0] : K_VIS2[e][0], ib = CFG == 1 ? K_VIS1[e][1] : K_VIS2[e][1];
-        const double x1 = rx[ia], y1 = ry[ia], x2 = rx[ib], y2 = ry[ib];
+        double x1 = rx[ia], y1 = ry[ia], x2 = rx[ib], y2 = ry[ib];
+        // LEAN: the products s/10 * corner are shared by the edges that meet in the corner, and the compiler would keep all of them alive across
+        // the edges (242 registers); an opaque copy per edge keeps the live set at one edge
+        if (LEAN) asm volatile("" : "+v"(x1), "+v"(y1), "+v"(x2), "+v"(y2));
 #pragma unroll
         for (int si = 1; si < 10; si++) {
             const double s = (double)si;
             c[si - 1] = gather(s / 10.0 * x1 + (1 - s / 10.0) * x2, s / 10.0 * y1 + (1 - s / 10.0) * y2);
+            if (LEAN) __builtin_amdgcn_sched_barrier(0);
         }
     };
     // software pipeline, written out because the compiler keeps the source order of this (fully unrolled) block: the 9 LDS gathers of
     // edge e+1 are issued before the codes of edge e are decoded and added
     unsigned cc[8];
 #pragma unroll
-    for (int k = 0; k < 8; k++) cc[k] = (CFG == 2 && k >= 6) ? 0u : gather(rx[k], ry[k]);
+    for (int k = 0; k < 8; k++) { cc[k] = (CFG == 2 && k >= 6) ? 0u : gather(rx[k], ry[k]); if (LEAN) __builtin_amdgcn_sched_barrier(0); }
     unsigned cur[9], nxt[9];
-    gather_edge(0, cur);
+    if (!LEAN) gather_edge(0, cur);
     __builtin_amdgcn_sched_barrier(0);
     float cp[8];
 #pragma unroll
-    for (int k = 0; k < 8; k++) cp[k] = decode(cc[k]);
+    for (int k = 0; k < 8; k++) cp[k] = value(cc[k]);
     float sum_dist = 0;
 #pragma unroll
     for (int e = 0; e < NE; e++) {
-        if (e + 1 < NE) gather_edge(e + 1, nxt);
+        if (LEAN) gather_edge(e, cur);
+        else if (e + 1 < NE) gather_edge(e + 1, nxt);
         __builtin_amdgcn_sched_barrier(0);
         const int ia = CFG == 1 ? K_VIS1[e][0] : K_VIS2[e][0], ib = CFG == 1 ? K_VIS1[e][1] : K_VIS2[e][1];
         const float wgt = (CFG == 2 && (e == 4 || e == 5)) ? 1.5f : ((CFG == 2 && e == 6) ? 2.0f : 1.0f);
 #pragma unroll
         for (int si = 0; si < 11; si++) {
-            float d = si == 0 ? cp[ib] : (si == 10 ? cp[ia] : decode(cur[si - 1]));
+            float d = si == 0 ? cp[ib] : (si == 10 ? cp[ia] : value(cur[si - 1]));
             if (CFG == 2) d = d * wgt;
             sum_dist = sum_dist + d;
         }
         __builtin_amdgcn_sched_barrier(0);
+        if (!LEAN) {
 #pragma unroll
-        for (int k = 0; k < 9; k++) cur[k] = nxt[k];
+            for (int k = 0; k < 9; k++) cur[k] = nxt[k];
+        }
     }
     return sum_dist;
 }
 
-template <int CFG, bool HYB> __device__ __forceinline__ void sc_score_task(const Unit &U, int first, int count, int lane, const VPEntry *vpt, const double *corners,
-                                                                           long hyp_total, const int *vlist, const unsigned short *lmap, const unsigned short *gmap, int n_res,
-                                                                           double *derr, double *aerr) {
+template <int CFG, bool HYB, bool LEAN> __device__ __forceinline__ void sc_score_task(const Unit &U, int first, int count, int lane, const VPEntry *vpt, const int *vlist,
+                                                                           const unsigned short *lmap, const float *gdist, int n_res, double *derr, double *aerr) {
     const int s = first + lane;
     const bool live = s < count;
     const int sc = live ? s : count - 1;
     const int h = CFG == 1 ? vlist[U.hyp_off + sc] : vlist[U.hyp_off + U.hyp_cap - 1 - sc];
     const long g = U.hyp_off + h;
-    const int q = (h >> 1) / U.n_tops;
+    int q, ti;
+    hyp_decode(U, h, q, ti);
+    const VPEntry &E = vpt[(long)U.vp_off + q];
     double cx[8], cy[8];
+    {
+        double vp[6];
 #pragma unroll
-    for (int k = 0; k < 8; k++) {
-        if (CFG == 2 && k >= 6) { cx[k] = 0; cy[k] = 0; continue; } // corners 7 and 8 are on no edge of configuration 2
-        cx[k] = corners[(long)k * hyp_total + g]; cy[k] = corners[(long)(8 + k) * hyp_total + g];
+        for (int k = 0; k < 6; k++) vp[k] = E.vp[k];
+        V2 c[8];
+        corners_build<false, CFG == 1>(U, vp, U.top_start + ti * U.top_step, CFG, c); // :254-418, the corners of a survivor
+#pragma unroll
+        for (int k = 0; k < 8; k++) { cx[k] = c[k].x; cy[k] = c[k].y; }
     }
-    const double *ang6 = vpt[(long)U.vp_off + q].ang;
     double ang[6];
 #pragma unroll
-    for (int k = 0; k < 6; k++) ang[k] = ang6[k];
+    for (int k = 0; k < 6; k++) ang[k] = E.ang[k];
+#ifdef NO_ANGLE
+    const double ae = ang[0];
+#else
     const double ae = edge_angle_error_reg<CFG>(ang, cx, cy);
+#endif
     const double rx = (double)U.roi_x, ry = (double)U.roi_y;
 #pragma unroll
     for (int k = 0; k < 8; k++) { cx[k] = cx[k] - rx; cy[k] = cy[k] - ry; } // :423-425
-    const float sum_dist = edge_sum_dists_code<CFG, HYB>(cx, cy, U.roi_w, lmap, gmap, n_res, U.roi_w * U.roi_h - 1);
+#ifdef NO_SUM
+    const float sum_dist = (float)(cx[0] + cy[1] + cx[2] + cy[3] + cx[4] + cy[5] + cx[6] + cy[7]);
+#else
+    const float sum_dist = edge_sum_dists_code<CFG, HYB, LEAN>(cx, cy, U.roi_w, lmap, gdist, n_res, U.roi_w * U.roi_h - 1);
+#endif
     if (live) {
         derr[g] = double(sum_dist) / U.diag; // :451
         aerr[g] = ae;
     }
 }
 
-__global__ void __launch_bounds__(SC_T) cuboid_sweep_score(const Unit *units, int n_units, const ScoreSeg *seg, int G, const VPEntry *vpt, const unsigned short *codes,
-                                                           const double *corners, long hyp_total, const int *vcount, const int *uflag, const int *vlist, double *derr, double *aerr) {
+template <int NT>
+__global__ void __launch_bounds__(NT) cuboid_sweep_score(const Unit *units, const int *order, int n_items, int n_slices, int *cursor, const VPEntry *vpt, const float *dist,
+                                                         const int *vcount, const int *vlist, int *uflag, double *derr, double *aerr) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sc_mem[];
-    int *ctrl = reinterpret_cast<int *>(sc_mem);
+    int *ctrl = reinterpret_cast<int *>(sc_mem); // [0] task counter, [2] escape flag of the unit being copied, [4], [5] next item (alternating)
+    unsigned short *lut = reinterpret_cast<unsigned short *>(sc_mem + SC_CTRL_BYTES);
     unsigned short *lmap = reinterpret_cast<unsigned short *>(sc_mem + SC_MAP_OFF);
     const int tid = threadIdx.x, lane = tid & 63;
-    const int b = blockIdx.x;
-    const int sg = (G & 7) == 0 ? (b & 7) * (G >> 3) + (b >> 3) : b; // neighbouring segments on one XCD
-    const ScoreSeg s0 = seg[sg], s1 = seg[sg + 1];
-    if (s0.unit >= n_units || (s0.unit == s1.unit && s0.task >= s1.task)) return;
-    const int u_last = s1.task > 0 ? s1.unit : s1.unit - 1; // last unit this segment touches
-    const bool backwards = sg & 1;
-    const int n_pos = u_last - s0.unit + 1;
-    auto unit_at = [&](int pos) { return backwards ? u_last - pos : s0.unit + pos; };
-    auto task_range = [&](int u, int &t0, int &t1, int &n1, int &c1, int &c2) {
-        c1 = vcount[2 * u]; c2 = vcount[2 * u + 1];
-        n1 = sc_tasks(c1);
-        t0 = u == s0.unit ? s0.task : 0;
-        t1 = u == s1.unit ? s1.task : n1 + sc_tasks(c2);
-        if (!sc_unit_lds(units[u], uflag, u)) t1 = t0; // scored by cuboid_sweep_score_big
-    };
-    auto next_pos = [&](int pos) { // first position >= pos with work
-        for (; pos < n_pos; pos++) { int t0, t1, n1, c1, c2; task_range(unit_at(pos), t0, t1, n1, c1, c2); if (t0 < t1) break; }
-        return pos;
-    };
-    for (int pos = next_pos(0); pos < n_pos; pos = next_pos(pos + 1)) {
-        const int u = unit_at(pos);
+    for (int i = tid; i < SC_LUT_N; i += NT) lut[i] = 0;
+    if (tid == 0) { ctrl[2] = 0; ctrl[5] = atomicAdd(cursor, 1); }
+    __syncthreads();
+    if (tid < 256) { const int j = tid, r = (j * DT_DIAG) % DT_HV; lut[r >> 6] = (unsigned short)((j << 8) - (j * DT_DIAG) / DT_HV); }
+    __syncthreads();
+    int item = __builtin_amdgcn_readfirstlane(ctrl[5]); // (uniform by construction; tell the compiler: the unit's fields then live in scalar registers)
+    constexpr bool LEAN = NT >= 1024;
+    constexpr int NPF = NT >= 1024 ? 4 : 8; // groups of 8 pixels (two 16-byte loads) per thread in flight while a map is copied
+    for (int it = 0; item < n_items; it++) {
+        const int u = __builtin_amdgcn_readfirstlane(order[n_slices == 1 ? item : item / n_slices]), slice = n_slices == 1 ? 0 : item % n_slices;
         const Unit &U = units[u];
-        int t0, t1, n1, c1, c2;
-        task_range(u, t0, t1, n1, c1, c2);
+        const int c1 = vcount[2 * u], c2 = vcount[2 * u + 1];
+        const int n1 = sc_tasks(c1), nt = n1 + sc_tasks(c2);
+        const bool work = slice < nt;
+        if (tid == 0) { ctrl[4 + (it & 1)] = atomicAdd(cursor, 1); ctrl[0] = slice; }
         const int A = U.roi_w * U.roi_h;
-        const bool hyb = !score_unit_fits(U.roi_w, U.roi_h);   // larger than LDS: the first n_res codes are resident, the tail is gathered from global memory
-        const int n_res = hyb ? (SC_MAP_ENTRIES & ~7) : A;
-        __syncthreads(); // every wave is done with the previous unit's map
-        { // copy the code map, SC_PFB 16-byte loads per thread in flight
-            const int A8 = hyb ? n_res >> 3 : (A + 7) >> 3; // slices are padded to 64 pixels
-            const uint4 *cm4 = reinterpret_cast<const uint4 *>(codes + U.pix_off);
+        const bool fits = score_unit_fits(U.roi_w, U.roi_h); // else: the first n_res pixels are resident, the tail is read from the float map
+        int n_res = fits ? A : (SC_MAP_ENTRIES & ~7);
+        const float *gdist = dist + U.pix_off;
+        if (work) { // copy + encode the float map, NPF groups per thread in flight
+            const int A8 = (n_res + 7) >> 3; // slices are padded to 64 pixels
+            const float4 *dm4 = reinterpret_cast<const float4 *>(gdist);
             uint4 *lm4 = reinterpret_cast<uint4 *>(lmap);
+            bool esc = false;
 #pragma unroll 1
-            for (int k0 = tid; k0 < A8; k0 += SC_PFB * SC_T) {
-                uint4 pf[SC_PFB];
+            for (int k0 = tid; k0 < A8; k0 += NPF * NT) {
+                float4 pa[NPF], pb[NPF];
 #pragma unroll
-                for (int r = 0; r < SC_PFB; r++) pf[r] = cm4[min(k0 + r * SC_T, A8 - 1)]; // branch-free: a tail thread re-copies the last 16 bytes
+                for (int r = 0; r < NPF; r++) { const int k = min(k0 + r * NT, A8 - 1); pa[r] = dm4[2 * k]; pb[r] = dm4[2 * k + 1]; } // branch-free: a tail thread re-copies the last group
 #pragma unroll
-                for (int r = 0; r < SC_PFB; r++) lm4[min(k0 + r * SC_T, A8 - 1)] = pf[r];
+                for (int r = 0; r < NPF; r++) {
+                    const int k = min(k0 + r * NT, A8 - 1);
+                    const unsigned e0 = sc_encode(pa[r].x, lut), e1 = sc_encode(pa[r].y, lut), e2 = sc_encode(pa[r].z, lut), e3 = sc_encode(pa[r].w, lut);
+                    const unsigned e4 = sc_encode(pb[r].x, lut), e5 = sc_encode(pb[r].y, lut), e6 = sc_encode(pb[r].z, lut), e7 = sc_encode(pb[r].w, lut);
+                    lm4[k] = make_uint4(e0 | (e1 << 16), e2 | (e3 << 16), e4 | (e5 << 16), e6 | (e7 << 16));
+                    const unsigned e[8] = {e0, e1, e2, e3, e4, e5, e6, e7};
+#pragma unroll
+                    for (int i = 0; i < 8; i++) esc = esc || (e[i] == 0xffffu && 8 * k + i < A);
+                }
             }
-        }
-        if (tid == 0) ctrl[0] = t0;
-        __syncthreads();
-        if (!hyb) {
-            const unsigned short lastc = lmap[A - 1];
-            for (int k = tid; k < U.roi_w + 2; k += SC_T) lmap[A + k] = lastc; // D2: indices past the map read its last pixel
+            if (esc) atomicOr(&ctrl[2], 1);
         }
         __syncthreads();
-        const unsigned short *gmap = codes + U.pix_off;
-        for (;;) { // waves pull tasks of 64 proposals of one configuration
-            int t = 0;
-            if (lane == 0) t = atomicAdd(&ctrl[0], 1);
-            t = __builtin_amdgcn_readfirstlane(t);
-            if (t >= t1) break;
-            if (!hyb) {
-                if (t < n1) sc_score_task<1, false>(U, t << 6, c1, lane, vpt, corners, hyp_total, vlist, lmap, gmap, n_res, derr, aerr);
-                else sc_score_task<2, false>(U, (t - n1) << 6, c2, lane, vpt, corners, hyp_total, vlist, lmap, gmap, n_res, derr, aerr);
-            } else {
-                if (t < n1) sc_score_task<1, true>(U, t << 6, c1, lane, vpt, corners, hyp_total, vlist, lmap, gmap, n_res, derr, aerr);
-                else sc_score_task<2, true>(U, (t - n1) << 6, c2, lane, vpt, corners, hyp_total, vlist, lmap, gmap, n_res, derr, aerr);
+        const int next = __builtin_amdgcn_readfirstlane(ctrl[4 + (it & 1)]);
+        const bool escape = __builtin_amdgcn_readfirstlane(ctrl[2]) != 0; // a pixel without a code: the whole unit samples the float map
+        if (work) {
+            if (fits && !escape) {
+                const unsigned short lastc = lmap[A - 1];
+                for (int k = tid; k < max(U.roi_w + 2, 8); k += NT) lmap[A + k] = lastc; // D2: indices past the map read its last pixel
             }
+            __syncthreads();
+            if (tid == 0) { ctrl[2] = 0; if (slice == 0) uflag[u] = escape ? 1 : 0; }
+            if (escape) n_res = 0;
+#ifdef NO_HYB
+            const bool hyb = false;
+#else
+            const bool hyb = escape || !fits;
+#endif
+            for (;;) { // waves pull tasks of 64 proposals of one configuration
+                int t = 0;
+                if (lane == 0) t = atomicAdd(&ctrl[0], n_slices);
+                t = __builtin_amdgcn_readfirstlane(t);
+                if (t >= nt) break;
+                if (!hyb) {
+                    if (t < n1) sc_score_task<1, false, LEAN>(U, t << 6, c1, lane, vpt, vlist, lmap, gdist, n_res, derr, aerr);
+                    else sc_score_task<2, false, LEAN>(U, (t - n1) << 6, c2, lane, vpt, vlist, lmap, gdist, n_res, derr, aerr);
+                } else {
+                    if (t < n1) sc_score_task<1, true, LEAN>(U, t << 6, c1, lane, vpt, vlist, lmap, gdist, n_res, derr, aerr);
+                    else sc_score_task<2, true, LEAN>(U, (t - n1) << 6, c2, lane, vpt, vlist, lmap, gdist, n_res, derr, aerr);
+                }
+            }
+            __syncthreads(); // every wave is done with this unit's map
         }
-    }
-}
-
-// cuboid_sweep_score_big: the units cuboid_sweep_score cannot take (ROI larger than one CU's LDS, or an escape pixel), from the float map
-// in global memory.  Sample-parallel, so that no thread waits on a chain of 99 dependent gathers: a workgroup takes SC_BIG_P proposals of
-// one configuration, its threads evaluate (proposal, sample) pairs with every gather independent, the values go through LDS and one thread
-// per proposal adds them in the reference's order; the six edge angles of a proposal are computed by six threads.
-template <int CFG> __device__ __forceinline__ void sc_big_item(const Unit &U, int first, int count, const VPEntry *vpt, const float *dist, const double *corners, long hyp_total,
-                                                               const int *vlist, double *derr, double *aerr, double (*s_c)[16], float (*s_v)[100], double (*s_a)[6], int *s_h, const double *s_s10) {
-    constexpr int NS = CFG == 1 ? 99 : 77;
-    const int tid = threadIdx.x, n = min(SC_BIG_P, count - first);
-    __syncthreads();
-    for (int i = tid; i < n * 16; i += 256) {
-        const int p = i >> 4, k = i & 15;
-        const int h = CFG == 1 ? vlist[U.hyp_off + first + p] : vlist[U.hyp_off + U.hyp_cap - 1 - (first + p)];
-        if (k == 0) s_h[p] = h;
-        s_c[p][k] = corners[(long)k * hyp_total + U.hyp_off + h];
-    }
-    __syncthreads();
-    const float *dm = dist + U.pix_off;
-    const int w = U.roi_w, last = U.roi_w * U.roi_h - 1;
-    const double rx = (double)U.roi_x, ry = (double)U.roi_y;
-    constexpr int IT = 4; // samples per thread and round: the index computations first, then the gathers in flight together
-#pragma unroll 1
-    for (int i0 = tid; i0 < n * NS; i0 += IT * 256) {
-        int sidx[IT], slot[IT];
-        float sw[IT], sv[IT];
-#pragma unroll
-        for (int r = 0; r < IT; r++) {
-            const int i = i0 + r * 256;
-            const int p = min(i / NS, n - 1), k = i - (i / NS) * NS, e = k / 11, si = k - e * 11;
-            const int ia = CFG == 1 ? c_vis1[e][0] : c_vis2[e][0], ib = CFG == 1 ? c_vis1[e][1] : c_vis2[e][1];
-            const double x1 = s_c[p][ia] - rx, y1 = s_c[p][8 + ia] - ry, x2 = s_c[p][ib] - rx, y2 = s_c[p][8 + ib] - ry; // :423-425
-            const double sa = s_s10[si], sb = 1 - sa; // s / 10.0 and 1 - s / 10.0 as the reference computes them
-            const double px = sa * x1 + sb * x2;
-            const double py = sa * y1 + sb * y2;
-            const int idx = __mul24(int(py), w) + int(px);
-            sidx[r] = min(max(idx, 0), last); // D2
-            slot[r] = i < n * NS ? p * 100 + k : -1;
-            sw[r] = CFG == 2 ? ((e == 4 || e == 5) ? 1.5f : (e == 6 ? 2.0f : 1.0f)) : 1.0f;
-        }
-#pragma unroll
-        for (int r = 0; r < IT; r++) sv[r] = dm[sidx[r]];
-#pragma unroll
-        for (int r = 0; r < IT; r++) if (slot[r] >= 0) (&s_v[0][0])[slot[r]] = CFG == 2 ? sv[r] * sw[r] : sv[r];
-    }
-    for (int i = tid; i < n * 6; i += 256) {
-        const int p = i / 6, k = i - p * 6, vp = k >> 1, ee = k & 1;
-        const int a = CFG == 1 ? c_vpe1[vp][2 * ee] : c_vpe2[vp][2 * ee], b = CFG == 1 ? c_vpe1[vp][2 * ee + 1] : c_vpe2[vp][2 * ee + 1];
-        const double *ang6 = vpt[(long)U.vp_off + (s_h[p] >> 1) / U.n_tops].ang;
-        s_a[p][k] = angle_best(line_angle_fast(s_c[p][8 + b] - s_c[p][8 + a], s_c[p][b] - s_c[p][a]), ang6[vp * 2], ang6[vp * 2 + 1]);
-    }
-    __syncthreads();
-    if (tid < n) {
-        float sum_dist = 0;
-        for (int k = 0; k < NS; k++) sum_dist = sum_dist + s_v[tid][k];
-        const double *ang6 = vpt[(long)U.vp_off + (s_h[tid] >> 1) / U.n_tops].ang;
-        double total = 0;
-        const double not_found_penalty = 30.0 / 180.0 * PI * 2;
-        for (int vp = 0; vp < 3; vp++) {
-            const bool any = !isnan(ang6[vp * 2]) || !isnan(ang6[vp * 2 + 1]);
-            const double x = total + (any ? s_a[tid][vp * 2] : not_found_penalty);
-            total = any ? x + s_a[tid][vp * 2 + 1] : x;
-        }
-        const long g = U.hyp_off + s_h[tid];
-        derr[g] = double(sum_dist) / U.diag; // :451
-        aerr[g] = total;
-    }
-}
-__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(3, 8))) cuboid_sweep_score_big(const Unit *units, const BigItem *big, const int *big_n, const VPEntry *vpt, const float *dist,
-                                                              const double *corners, long hyp_total, const int *vcount, const int *vlist, double *derr, double *aerr) {
-    __shared__ double s_c[SC_BIG_P][16];
-    __shared__ float s_v[SC_BIG_P][100];
-    __shared__ double s_a[SC_BIG_P][6];
-    __shared__ int s_h[SC_BIG_P];
-    __shared__ double s_s10[11];
-    if (threadIdx.x < 11) s_s10[threadIdx.x] = (double)threadIdx.x / 10.0; // sample_ind / 10.0, object_3d_util.cpp:439
-    const int n_items = *big_n;
-    for (int it = blockIdx.x; it < n_items; it += gridDim.x) {
-        const BigItem I = big[it];
-        const Unit &U = units[I.unit];
-        if (I.cfg == 1) sc_big_item<1>(U, I.first, vcount[2 * I.unit], vpt, dist, corners, hyp_total, vlist, derr, aerr, s_c, s_v, s_a, s_h, s_s10);
-        else sc_big_item<2>(U, I.first, vcount[2 * I.unit + 1], vpt, dist, corners, hyp_total, vlist, derr, aerr, s_c, s_v, s_a, s_h, s_s10);
+        item = next;
     }
 }
 
@@ -1481,8 +1345,8 @@ __device__ inline void corners_to_3d(const double *cx, const double *cy, const C
 // flag bits after selection: bits 0-1 vp_1_position, bit 2 kept by fuse_normalize, bit 3 candidate for final ranking
 __global__ void __launch_bounds__(256) cuboid_select(const Unit *units, UnitDyn *ud, const int *box_first_unit, const FrameDyn *fd,
                                                      const FrameInfo *fi, const CamRP *cam, const double *yaw, Calib cal, Opts o,
-                                                     uint8_t *flag, const double *derr, const double *aerr, const double *corners,
-                                                     long hyp_total, double *score, double *nscore, unsigned long long *ckey_d, unsigned long long *ckey_a,
+                                                     uint8_t *flag, const double *derr, const double *aerr, const VPEntry *vpt,
+                                                     double *score, double *nscore, unsigned long long *ckey_d, unsigned long long *ckey_a,
                                                      int *cidx, cs_cuboid *out, int *counts) {
     __shared__ int hist[256];
     __shared__ int s_misc[8];
@@ -1596,9 +1460,15 @@ __global__ void __launch_bounds__(256) cuboid_select(const Unit *units, UnitDyn 
             } else
                 comb = (dk + weight_vp_angle * ak) / (1 + weight_vp_angle);
             long g = U.hyp_off + i;
-            int rp = (i >> 1) / U.n_tops / D.n_yaw;
+            int q, ti;
+            hyp_decode(U, i, q, ti);
+            int rp = q / D.n_yaw;
             double cx[8], cy[8];
-            for (int k = 0; k < 8; k++) { cx[k] = corners[(long)k * hyp_total + g]; cy[k] = corners[(long)(8 + k) * hyp_total + g]; }
+            { // the proposal's corners, rebuilt (box_proposal_detail.cpp:254-418): nothing stores them
+                V2 c[8];
+                corners_build<false, true>(U, vpt[(long)U.vp_off + q].vp, U.top_start + ti * U.top_step, (i & 1) + 1, c);
+                for (int k = 0; k < 8; k++) { cx[k] = c[k].x; cy[k] = c[k].y; }
+            }
             Conv3D c3;
             corners_to_3d(cx, cy, cam[(long)U.frame * RP_CAP + rp], cal.invK, c3);
             if (c3.scale[0] < 0 || c3.scale[1] < 0 || c3.scale[2] < 0) continue; // :493
@@ -1656,11 +1526,16 @@ __global__ void __launch_bounds__(256) cuboid_select(const Unit *units, UnitDyn 
             long g = U.hyp_off + bi;
             flag[g] &= ~8;
             // full record: change_2d_corner_to_3d_object + fields (:489-513)
-            int cfg = (bi & 1) + 1, q = (bi >> 1) / U.n_tops;
+            int cfg = (bi & 1) + 1, q, ti;
+            hyp_decode(U, bi, q, ti);
             int yi = q % D.n_yaw, rp = q / D.n_yaw;
             const CamRP &C = cam[(long)U.frame * RP_CAP + rp];
             double cx[8], cy[8];
-            for (int k = 0; k < 8; k++) { cx[k] = corners[(long)k * hyp_total + g]; cy[k] = corners[(long)(8 + k) * hyp_total + g]; }
+            {
+                V2 c[8];
+                corners_build<false, true>(U, vpt[(long)U.vp_off + q].vp, U.top_start + ti * U.top_step, cfg, c);
+                for (int k = 0; k < 8; k++) { cx[k] = c[k].x; cy[k] = c[k].y; }
+            }
             Conv3D c3;
             corners_to_3d(cx, cy, C, cal.invK, c3);
             cs_cuboid &O = out[(long)box * o.max_cuboid_num + pick];
@@ -1763,18 +1638,18 @@ struct cs_cuboid_batch {
     int *d_lab = nullptr; // aliases d_dist
     float *d_dist = nullptr;
     int *d_dttmp = nullptr; long *d_dttmp_off = nullptr;
-    long *d_score_cost = nullptr; ScoreSeg *d_score_seg = nullptr; // cuboid_score_plan -> cuboid_sweep_score
-    unsigned short *d_codes = nullptr; int *d_uflag = nullptr;      // cuboid_dt_codes: 16-bit chamfer codes, per-unit escape flag
-    BigItem *d_big = nullptr; int *d_big_n = nullptr;               // work list of cuboid_sweep_score_big
-    int score_G = 256;      // segments = workgroups of cuboid_sweep_score (one per CU)
-    int score_hyb = 6;      // cost of a task of a unit larger than LDS (tail of the map gathered from global memory), in quarters of a resident unit's task
+    int *d_order = nullptr, *d_cursor = nullptr; // cuboid_sweep_score: units by falling cost estimate, the work cursor
+    int *d_uflag = nullptr;                      // per unit: 1 = a pixel without a 16-bit code (scored from the float map)
+    int score_G = 256;      // workgroups of cuboid_sweep_score (one per CU)
+    int score_T = 1024;     // threads per workgroup (CUBESLAM_SCORE_THREADS = 512 | 1024)
+    int score_slices = 1;   // items per unit (more than one when there are fewer units than CUs)
     int dt_C = 0; // wave-per-ROI distance transform: int map between the passes, lane-major
     FrameInfo *d_fi = nullptr; FrameDyn *d_fd = nullptr; CamRP *d_cam = nullptr;
     double *d_yaw = nullptr, *d_lines_in = nullptr, *d_lines_al = nullptr, *d_mlines = nullptr, *d_mangle = nullptr, *d_mmid = nullptr;
     Unit *d_units = nullptr; UnitDyn *d_ud = nullptr; int *d_box_first = nullptr, *d_status = nullptr, *d_counts = nullptr;
     VPEntry *d_vp = nullptr;
     int *d_vcount = nullptr, *d_vlist = nullptr; // per unit: number of surviving proposals and their hypothesis indices
-    double *d_derr = nullptr, *d_aerr = nullptr, *d_corners = nullptr, *d_score = nullptr, *d_nscore = nullptr;
+    double *d_derr = nullptr, *d_aerr = nullptr, *d_score = nullptr, *d_nscore = nullptr;
     unsigned long long *d_ckd = nullptr, *d_cka = nullptr; int *d_cidx = nullptr;
     cs_cuboid *d_out = nullptr;
 };
@@ -1794,7 +1669,7 @@ void cs_cuboid_batch_destroy(cs_ctx *ctx, cs_cuboid_batch *b) {
     if (ctx) { hipSetDevice(ctx->device); hipStreamSynchronize(ctx->stream); }
     void *ptrs[] = {b->d_gray, b->d_emap, b->d_flag, b->d_dist, b->d_dttmp, b->d_dttmp_off, b->d_fi, b->d_fd, b->d_cam, b->d_yaw, b->d_lines_in, b->d_lines_al,
                     b->d_mlines, b->d_mangle, b->d_mmid, b->d_units, b->d_ud, b->d_box_first, b->d_status, b->d_counts, b->d_vp,
-                    b->d_derr, b->d_aerr, b->d_corners, b->d_score, b->d_nscore, b->d_ckd, b->d_cka, b->d_cidx, b->d_out, b->d_vcount, b->d_vlist, b->d_score_cost, b->d_score_seg, b->d_codes, b->d_uflag, b->d_big, b->d_big_n};
+                    b->d_derr, b->d_aerr, b->d_score, b->d_nscore, b->d_ckd, b->d_cka, b->d_cidx, b->d_out, b->d_vcount, b->d_vlist, b->d_order, b->d_cursor, b->d_uflag};
     for (void *p : ptrs) if (p) hipFree(p);
     delete b;
 }
@@ -1863,6 +1738,11 @@ int cs_cuboid_batch_create(cs_ctx *ctx, int n_frames, int width, int height, con
                     while (s <= e) { n++; s += res; if (n > 1000) break; }
                     U.n_tops = n; U.top_start = left_x_raw + 5; U.top_step = res;
                 }
+                if (U.n_tops > 1) { // pair index / n_tops by one multiply when that is exact for every pair index of the unit (p * e < 2^32, e = magic * n - 2^32)
+                    const unsigned long long magic = (1ull << 32) / (unsigned)U.n_tops + 1, e = magic * (unsigned)U.n_tops - (1ull << 32);
+                    const unsigned long long pmax = (unsigned long long)rp_cap * o.yaw_cap * U.n_tops;
+                    U.tops_magic = (magic < (1ull << 32) && pmax * e < (1ull << 32)) ? (unsigned)magic : 0u;
+                }
                 int ew = std::min(std::max(std::min(20, obj_width_raw - 100), 10), std::max(std::min(20, obj_height_expan - 100), 10)); // :155
                 U.roi_x = std::max(0, left_x_raw - ew);
                 U.roi_r = std::min(width - 1, right_x_raw + ew);
@@ -1906,22 +1786,28 @@ int cs_cuboid_batch_create(cs_ctx *ctx, int n_frames, int width, int height, con
         }
     }
     {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(cuboid_sweep_score), hipFuncAttributeMaxDynamicSharedMemorySize, SC_LDS_BYTES);
-        if (e != hipSuccess) { ctx->err = hipGetErrorString(e); cs_cuboid_batch_destroy(ctx, b); return CS_ERR_HIP; }
+        for (const void *fn : {reinterpret_cast<const void *>(cuboid_sweep_score<512>), reinterpret_cast<const void *>(cuboid_sweep_score<1024>)}) { // (per call: the attribute is per device)
+            hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, SC_LDS_BYTES);
+            if (e != hipSuccess) { ctx->err = hipGetErrorString(e); cs_cuboid_batch_destroy(ctx, b); return CS_ERR_HIP; }
+        }
         hipDeviceProp_t prop;
         if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) b->score_G = prop.multiProcessorCount;
-        const char *ge = getenv("CUBESLAM_SCORE_SEGMENTS"); // tuning knob: segments (= workgroups) of cuboid_sweep_score
+        const char *ge = getenv("CUBESLAM_SCORE_SEGMENTS"); // tuning knob: workgroups of cuboid_sweep_score
         if (ge && atoi(ge) > 0) b->score_G = atoi(ge);
-        const char *he = getenv("CUBESLAM_SCORE_HYB_COST"); // tuning knob: cost of an oversize unit's task, in quarters of a resident unit's
-        if (he && atoi(he) > 0) b->score_hyb = atoi(he);
-        A_(cs_dalloc(ctx, &b->d_score_cost, (size_t)b->n_units + 1));
-        A_(cs_dalloc(ctx, &b->d_score_seg, (size_t)b->score_G + 1));
-        A_(cs_dalloc(ctx, &b->d_codes, (size_t)b->pix_total + 64));
+        const char *te = getenv("CUBESLAM_SCORE_THREADS"); // tuning knob: 512 (2 waves per SIMD, 256 registers) or 1024 (4 waves per SIMD, 128 registers)
+        if (te && atoi(te) == 512) b->score_T = 512;
+        b->score_slices = b->n_units >= 2 * b->score_G ? 1 : std::min(16, (2 * b->score_G + b->n_units - 1) / std::max(1, b->n_units));
+        const char *se = getenv("CUBESLAM_SCORE_SLICES"); // tuning knob / tests: items per unit
+        if (se && atoi(se) > 0) b->score_slices = std::min(64, atoi(se));
+        // units by falling cost estimate (map copy ~ pixels, scoring ~ hypotheses): the persistent workgroups take the big ones first
+        std::vector<int> order(b->units.size());
+        for (size_t i = 0; i < order.size(); i++) order[i] = (int)i;
+        auto cost = [&](int u) { const Unit &U = b->units[u]; return 0.19 * (double)U.roi_w * U.roi_h + 10.8 * (double)U.hyp_cap; };
+        std::stable_sort(order.begin(), order.end(), [&](int a, int c) { return cost(a) > cost(c); });
+        A_(cs_dalloc(ctx, &b->d_order, std::max<size_t>(1, order.size())));
+        A_(cs_h2d(ctx, b->d_order, order.data(), order.size()));
+        A_(cs_dalloc(ctx, &b->d_cursor, (size_t)1));
         A_(cs_dalloc(ctx, &b->d_uflag, (size_t)b->n_units));
-        long items = 0;
-        for (const Unit &U : b->units) items += 2 * ((U.hyp_cap / 2 + SC_BIG_P - 1) / SC_BIG_P + 1);
-        A_(cs_dalloc(ctx, &b->d_big, (size_t)items));
-        A_(cs_dalloc(ctx, &b->d_big_n, 1));
     }
     A_(cs_dalloc(ctx, &b->d_dist, (size_t)b->pix_total));
     b->d_lab = (int *)b->d_dist;
@@ -1945,7 +1831,6 @@ int cs_cuboid_batch_create(cs_ctx *ctx, int n_frames, int width, int height, con
     A_(cs_dalloc(ctx, &b->d_vlist, (size_t)b->hyp_total));
     A_(cs_dalloc(ctx, &b->d_derr, (size_t)b->hyp_total));
     A_(cs_dalloc(ctx, &b->d_aerr, (size_t)b->hyp_total));
-    A_(cs_dalloc(ctx, &b->d_corners, (size_t)b->hyp_total * 16));
     A_(cs_dalloc(ctx, &b->d_score, (size_t)b->hyp_total));
     A_(cs_dalloc(ctx, &b->d_nscore, (size_t)b->hyp_total));
     A_(cs_dalloc(ctx, &b->d_ckd, (size_t)b->hyp_total));
@@ -1992,22 +1877,24 @@ int cs_cuboid_batch_run(cs_ctx *ctx, cs_cuboid_batch *b) {
         const int wbuf = b->W + 2;
         CS_LAUNCH(ctx, "cuboid_dt", cuboid_dt, dim3((U + 3) / 4), dim3(256), (size_t)wbuf * 2 * 4 * sizeof(int), b->d_units, U, b->d_emap, b->d_dist, wbuf);
     }
-    CS_HIP(ctx, hipMemsetAsync(b->d_uflag, 0, sizeof(int) * (size_t)U, ctx->stream));
-    CS_LAUNCH(ctx, "cuboid_dt_codes", cuboid_dt_codes, dim3(b->max_cc_blocks, U), dim3(256), 0, b->d_units, b->d_dist, b->d_codes, b->d_uflag);
     CS_LAUNCH(ctx, "cuboid_vp", cuboid_vp, dim3(b->max_vp_blocks, U), dim3(256), 0, b->d_units, b->d_ud, b->d_fd, b->d_cam, b->d_yaw, b->o,
               b->d_mangle, b->d_mmid, b->d_vp);
-    const int groups = (U + 7) / 8;
     CS_HIP(ctx, hipMemsetAsync(b->d_vcount, 0, sizeof(int) * 2 * (size_t)U, ctx->stream));
-    CS_LAUNCH(ctx, "cuboid_sweep_corners", cuboid_sweep_corners, dim3(groups * b->blocks_per_unit * 8), dim3(256), 0, b->d_units, U,
-              b->blocks_per_unit, b->d_fd, b->o, b->d_vp, b->d_flag, b->d_corners, b->hyp_total, b->d_vcount, b->d_vlist);
-    CS_LAUNCH(ctx, "cuboid_score_plan", cuboid_score_plan, dim3(1), dim3(1024), 0, b->d_units, U, b->d_vcount, b->d_uflag, b->d_score_cost, b->d_score_seg, b->score_G,
-              b->d_big, b->d_big_n, b->score_hyb);
-    CS_LAUNCH(ctx, "cuboid_sweep_score", cuboid_sweep_score, dim3(b->score_G), dim3(SC_T), SC_LDS_BYTES, b->d_units, U, b->d_score_seg, b->score_G, b->d_vp,
-              b->d_codes, b->d_corners, b->hyp_total, b->d_vcount, b->d_uflag, b->d_vlist, b->d_derr, b->d_aerr);
-    CS_LAUNCH(ctx, "cuboid_sweep_score_big", cuboid_sweep_score_big, dim3(4096), dim3(256), 0, b->d_units, b->d_big, b->d_big_n, b->d_vp, b->d_dist, b->d_corners,
-              b->hyp_total, b->d_vcount, b->d_vlist, b->d_derr, b->d_aerr);
+    CS_LAUNCH(ctx, "cuboid_sweep_filter", cuboid_sweep_filter, dim3(U * b->blocks_per_unit), dim3(256), 0, b->d_units, U, b->blocks_per_unit, b->d_fd, b->o, b->d_vp,
+              b->d_flag, b->d_vcount, b->d_vlist);
+    CS_HIP(ctx, hipMemsetAsync(b->d_cursor, 0, sizeof(int), ctx->stream));
+    CS_HIP(ctx, hipMemsetAsync(b->d_uflag, 0, sizeof(int) * (size_t)U, ctx->stream));
+    {
+        const int items = U * b->score_slices, grid = std::min(b->score_G, items);
+        if (b->score_T == 512)
+            CS_LAUNCH(ctx, "cuboid_sweep_score", cuboid_sweep_score<512>, dim3(grid), dim3(512), SC_LDS_BYTES, b->d_units, b->d_order, items, b->score_slices, b->d_cursor, b->d_vp,
+                      b->d_dist, b->d_vcount, b->d_vlist, b->d_uflag, b->d_derr, b->d_aerr);
+        else
+            CS_LAUNCH(ctx, "cuboid_sweep_score", cuboid_sweep_score<1024>, dim3(grid), dim3(1024), SC_LDS_BYTES, b->d_units, b->d_order, items, b->score_slices, b->d_cursor, b->d_vp,
+                      b->d_dist, b->d_vcount, b->d_vlist, b->d_uflag, b->d_derr, b->d_aerr);
+    }
     CS_LAUNCH(ctx, "cuboid_select", cuboid_select, dim3(b->n_boxes), dim3(256), 0, b->d_units, b->d_ud, b->d_box_first, b->d_fd, b->d_fi,
-              b->d_cam, b->d_yaw, b->cal, b->o, b->d_flag, b->d_derr, b->d_aerr, b->d_corners, b->hyp_total, b->d_score, b->d_nscore,
+              b->d_cam, b->d_yaw, b->cal, b->o, b->d_flag, b->d_derr, b->d_aerr, b->d_vp, b->d_score, b->d_nscore,
               b->d_ckd, b->d_cka, b->d_cidx, b->d_out, b->d_counts);
     CS_HIP(ctx, hipGetLastError());
     return CS_OK;
@@ -2083,7 +1970,16 @@ int cs_cuboid_batch_unit(cs_ctx *ctx, cs_cuboid_batch *b, int unit, int dims[12]
         r = cs_d2h(ctx, fl.data(), b->d_flag + U.hyp_off, (size_t)n_hyp); if (r) return r;
         r = cs_d2h(ctx, de.data(), b->d_derr + U.hyp_off, (size_t)n_hyp); if (r) return r;
         r = cs_d2h(ctx, ae.data(), b->d_aerr + U.hyp_off, (size_t)n_hyp); if (r) return r;
-        for (int p = 0; p < 16; p++) { r = cs_d2h(ctx, co.data() + (size_t)p * n_hyp, b->d_corners + (long)p * b->hyp_total + U.hyp_off, (size_t)n_hyp); if (r) return r; }
+        { // the corners are not stored anywhere: rebuilt for this unit by the function the kernels use
+            double *d_co = nullptr;
+            CS_HIP(ctx, hipMalloc((void **)&d_co, sizeof(double) * 16 * (size_t)std::max(1, n_hyp)));
+            hipMemsetAsync(d_co, 0, sizeof(double) * 16 * (size_t)std::max(1, n_hyp), ctx->stream);
+            if (n_hyp > 0) hipLaunchKernelGGL(cuboid_unit_corners, dim3((n_hyp + 255) / 256), dim3(256), 0, ctx->stream, b->d_units, unit, n_hyp, b->d_vp, b->d_flag, d_co);
+            r = cs_d2h(ctx, co.data(), d_co, (size_t)n_hyp * 16);
+            hipStreamSynchronize(ctx->stream);
+            hipFree(d_co);
+            if (r) return r;
+        }
         r = cs_d2h(ctx, yw.data(), b->d_yaw + (long)U.frame * b->o.yaw_cap, (size_t)b->o.yaw_cap); if (r) return r;
         CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
         long nr = 0;

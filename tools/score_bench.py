@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
-"""Isolated per-kernel times of the cuboid path on the bench batch (128 frames x 3 boxes, yaw step 0.5 deg) for several settings of
-CUBESLAM_SCORE_SEGMENTS (workgroups of cuboid_sweep_score).  python tools/score_bench.py [frames] [segments ...]"""
+"""Isolated per-kernel times of the cuboid path on the bench batch (frames x 3 boxes, yaw step 0.5 deg) for several settings of the score
+kernel's knobs: python tools/score_bench.py [frames] [setting ...], a setting is `default` or KEY=VALUE[,KEY=VALUE] over
+CUBESLAM_SCORE_THREADS (512 | 1024), CUBESLAM_SCORE_SEGMENTS (workgroups), CUBESLAM_SCORE_SLICES (items per unit)."""
 import os
 import sys
 
@@ -23,8 +24,12 @@ def main():
     det.yaw_step_deg = 0.5
     ref = None
     for sg in segs:
+        for k in ("CUBESLAM_SCORE_THREADS", "CUBESLAM_SCORE_SEGMENTS", "CUBESLAM_SCORE_SLICES"):
+            os.environ.pop(k, None)
         if sg != "default":
-            os.environ["CUBESLAM_SCORE_SEGMENTS"] = sg
+            for kv in sg.split(","):
+                k, v = kv.split("=")
+                os.environ[k] = v
         b = CuboidBatch(ctx, np.stack([s["gray"] for s in scenes]), scenes[0]["K"], np.stack([s["Twc"] for s in scenes]),
                         [s["boxes"] for s in scenes], [s["lines"] for s in scenes], det.opts())
         for _ in range(2):
@@ -34,8 +39,7 @@ def main():
         for _ in range(5):
             b.run()
         ctx.sync()
-        names = ("cuboid_frame_prep", "cuboid_unit_lines", "cuboid_canny_nms", "cuboid_canny_cc", "cuboid_dt", "cuboid_vp", "cuboid_sweep_corners",
-                 "cuboid_dt_codes", "cuboid_score_plan", "cuboid_sweep_score", "cuboid_sweep_score_big", "cuboid_select")
+        names = ("cuboid_frame_prep", "cuboid_unit_lines", "cuboid_canny_nms", "cuboid_canny_cc", "cuboid_dt", "cuboid_vp", "cuboid_sweep_filter", "cuboid_sweep_score", "cuboid_select")
         t = {}
         for k in names:
             ms, n = ctx.timing_get(k)
@@ -43,13 +47,13 @@ def main():
                 t[k] = round(1e3 * ms / n, 1)
         ctx.timing(False)
         st = b.stats()
-        alg = 4.0 * st["roi_pixels"] + 144.0 * st["n_valid"]
+        alg = 4.0 * st["roi_pixels"] + 200.0 * st["n_valid"]  # SURVEY 8d, corner construction fused into the score kernel
         us = t.get("cuboid_sweep_score", 0)
         got = b.read()
         raw = b"".join(np.asarray(g).tobytes() for g in got)
         if ref is None:
             ref = raw
-        print("segments=%s  %s  alg %.1f MB -> %.2f TB/s (%.3f of 8)  identical=%s" % (sg, t, alg / 1e6, alg / (us * 1e-6) / 1e12 if us else 0,
+        print("setting=%s  %s  alg %.1f MB -> %.2f TB/s (%.3f of 8)  identical=%s" % (sg, t, alg / 1e6, alg / (us * 1e-6) / 1e12 if us else 0,
                                                                                     alg / (us * 1e-6) / 8e12 if us else 0, raw == ref), flush=True)
         b.close()
 
