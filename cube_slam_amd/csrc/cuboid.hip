@@ -39,7 +39,7 @@ constexpr int DT_DIAG = 89738;  // cvRound(1.3693f * 65536)  (checked against th
 constexpr double PI = 3.14159265358979323846;
 // cuboid_sweep_score (corner construction + edge scoring, the unit's chamfer map resident in LDS as 16-bit codes), see the kernel
 constexpr int SC_LDS_BYTES = 160 * 1024;
-constexpr int SC_LUT_N = (DT_HV + 63) / 64;                            // 978 residue buckets
+constexpr int SC_LUT_N = 1024;                                         // residue buckets of 64: (DT_HV + 63) / 64 = 978 used
 constexpr int SC_CTRL_BYTES = 64;                                     // control words in front of the table
 constexpr int SC_MAP_OFF = SC_CTRL_BYTES + 2048;                       // control words + the encoder's residue table (978 x 2 B, padded)
 constexpr int SC_MAP_ENTRIES = (SC_LDS_BYTES - SC_MAP_OFF) / 2;        // 80 864
@@ -990,13 +990,19 @@ __global__ void __launch_bounds__(256) cuboid_unit_corners(const Unit *units, in
 // proposals of one configuration from an LDS counter.
 __device__ __forceinline__ int sc_tasks(int c) { return (c + 63) >> 6; }
 
-__device__ __forceinline__ unsigned sc_encode(float d, const unsigned short *lut) {
-    const float tf = d * 65536.0f;
-    const int t = (int)tf;
-    const int qn = (int)__builtin_fmaf(tf, 1.0f / (float)DT_HV, 0.0005f);
-    const unsigned q = (unsigned)(t - __mul24(qn, DT_HV));
-    const unsigned e = lut[min(q >> 6, (unsigned)(SC_LUT_N - 1))];
-    return d < SC_ESC_D ? ((unsigned)qn + e) & 0xffffu : 0xffffu;
+// two pixels at a time (packed f32 multiply / fma); a pixel without a code (d >= SC_ESC_D, or not a number) sets `esc` and its code is garbage:
+// the unit is then scored from the float map and its codes are never read.  The table has 1024 entries, so a 10-bit field of the residue
+// cannot leave it.
+typedef float sc_f2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ unsigned sc_encode2(float d0, float d1, const unsigned short *lut, bool &esc) {
+    const sc_f2 d = {d0, d1};
+    const sc_f2 tf = d * 65536.0f;
+    const sc_f2 qf = __builtin_elementwise_fma(tf, (sc_f2){1.0f / (float)DT_HV, 1.0f / (float)DT_HV}, (sc_f2){0.0005f, 0.0005f});
+    const int t0 = (int)tf.x, t1 = (int)tf.y, q0n = (int)qf.x, q1n = (int)qf.y;
+    const unsigned r0 = (unsigned)(t0 - __mul24(q0n, DT_HV)), r1 = (unsigned)(t1 - __mul24(q1n, DT_HV));
+    const unsigned e0 = lut[(r0 >> 6) & (SC_LUT_N - 1)], e1 = lut[(r1 >> 6) & (SC_LUT_N - 1)];
+    esc = esc || !(d0 < SC_ESC_D) || !(d1 < SC_ESC_D);
+    return ((unsigned)q0n + e0) | (((unsigned)q1n + e1) << 16);
 }
 
 // box_edge_alignment_angle_error (object_3d_util.cpp:455-492), branch-free: a NaN boundary angle never wins `t < best`
@@ -1152,7 +1158,7 @@ __global__ void __launch_bounds__(NT) cuboid_sweep_score(const Unit *units, cons
     __syncthreads();
     int item = __builtin_amdgcn_readfirstlane(ctrl[5]); // (uniform by construction; tell the compiler: the unit's fields then live in scalar registers)
     constexpr bool LEAN = NT >= 1024;
-    constexpr int NPF = NT >= 1024 ? 4 : 8; // groups of 8 pixels (two 16-byte loads) per thread in flight while a map is copied
+    constexpr int NPF = NT >= 768 ? 4 : 8; // groups of 8 pixels (two 16-byte loads) per thread in flight while a map is copied
     for (int it = 0; item < n_items; it++) {
         const int u = __builtin_amdgcn_readfirstlane(order[n_slices == 1 ? item : item / n_slices]), slice = n_slices == 1 ? 0 : item % n_slices;
         const Unit &U = units[u];
@@ -1177,12 +1183,8 @@ __global__ void __launch_bounds__(NT) cuboid_sweep_score(const Unit *units, cons
 #pragma unroll
                 for (int r = 0; r < NPF; r++) {
                     const int k = min(k0 + r * NT, A8 - 1);
-                    const unsigned e0 = sc_encode(pa[r].x, lut), e1 = sc_encode(pa[r].y, lut), e2 = sc_encode(pa[r].z, lut), e3 = sc_encode(pa[r].w, lut);
-                    const unsigned e4 = sc_encode(pb[r].x, lut), e5 = sc_encode(pb[r].y, lut), e6 = sc_encode(pb[r].z, lut), e7 = sc_encode(pb[r].w, lut);
-                    lm4[k] = make_uint4(e0 | (e1 << 16), e2 | (e3 << 16), e4 | (e5 << 16), e6 | (e7 << 16));
-                    const unsigned e[8] = {e0, e1, e2, e3, e4, e5, e6, e7};
-#pragma unroll
-                    for (int i = 0; i < 8; i++) esc = esc || (e[i] == 0xffffu && 8 * k + i < A);
+                    // (the padding of a slice past its A pixels is zero: cs_cuboid_batch_create clears the arena once and nothing writes there)
+                    lm4[k] = make_uint4(sc_encode2(pa[r].x, pa[r].y, lut, esc), sc_encode2(pa[r].z, pa[r].w, lut, esc), sc_encode2(pb[r].x, pb[r].y, lut, esc), sc_encode2(pb[r].z, pb[r].w, lut, esc));
                 }
             }
             if (esc) atomicOr(&ctrl[2], 1);
@@ -1641,7 +1643,7 @@ struct cs_cuboid_batch {
     int *d_order = nullptr, *d_cursor = nullptr; // cuboid_sweep_score: units by falling cost estimate, the work cursor
     int *d_uflag = nullptr;                      // per unit: 1 = a pixel without a 16-bit code (scored from the float map)
     int score_G = 256;      // workgroups of cuboid_sweep_score (one per CU)
-    int score_T = 1024;     // threads per workgroup (CUBESLAM_SCORE_THREADS = 512 | 1024)
+    int score_T = 512;      // threads per workgroup (CUBESLAM_SCORE_THREADS = 512 | 768 | 1024: 2 / 3 / 4 waves per SIMD with 256 / 168 / 128 registers)
     int score_slices = 1;   // items per unit (more than one when there are fewer units than CUs)
     int dt_C = 0; // wave-per-ROI distance transform: int map between the passes, lane-major
     FrameInfo *d_fi = nullptr; FrameDyn *d_fd = nullptr; CamRP *d_cam = nullptr;
@@ -1786,7 +1788,7 @@ int cs_cuboid_batch_create(cs_ctx *ctx, int n_frames, int width, int height, con
         }
     }
     {
-        for (const void *fn : {reinterpret_cast<const void *>(cuboid_sweep_score<512>), reinterpret_cast<const void *>(cuboid_sweep_score<1024>)}) { // (per call: the attribute is per device)
+        for (const void *fn : {reinterpret_cast<const void *>(cuboid_sweep_score<512>), reinterpret_cast<const void *>(cuboid_sweep_score<768>), reinterpret_cast<const void *>(cuboid_sweep_score<1024>)}) { // (per call: the attribute is per device)
             hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, SC_LDS_BYTES);
             if (e != hipSuccess) { ctx->err = hipGetErrorString(e); cs_cuboid_batch_destroy(ctx, b); return CS_ERR_HIP; }
         }
@@ -1795,7 +1797,7 @@ int cs_cuboid_batch_create(cs_ctx *ctx, int n_frames, int width, int height, con
         const char *ge = getenv("CUBESLAM_SCORE_SEGMENTS"); // tuning knob: workgroups of cuboid_sweep_score
         if (ge && atoi(ge) > 0) b->score_G = atoi(ge);
         const char *te = getenv("CUBESLAM_SCORE_THREADS"); // tuning knob: 512 (2 waves per SIMD, 256 registers) or 1024 (4 waves per SIMD, 128 registers)
-        if (te && atoi(te) == 512) b->score_T = 512;
+        if (te && (atoi(te) == 512 || atoi(te) == 768 || atoi(te) == 1024)) b->score_T = atoi(te);
         b->score_slices = b->n_units >= 2 * b->score_G ? 1 : std::min(16, (2 * b->score_G + b->n_units - 1) / std::max(1, b->n_units));
         const char *se = getenv("CUBESLAM_SCORE_SLICES"); // tuning knob / tests: items per unit
         if (se && atoi(se) > 0) b->score_slices = std::min(64, atoi(se));
@@ -1810,6 +1812,7 @@ int cs_cuboid_batch_create(cs_ctx *ctx, int n_frames, int width, int height, con
         A_(cs_dalloc(ctx, &b->d_uflag, (size_t)b->n_units));
     }
     A_(cs_dalloc(ctx, &b->d_dist, (size_t)b->pix_total));
+    CS_HIP(ctx, hipMemsetAsync(b->d_dist, 0, sizeof(float) * (size_t)b->pix_total, ctx->stream)); // the slices' padding (to 64 pixels) stays zero: cuboid_sweep_score encodes whole groups of 8
     b->d_lab = (int *)b->d_dist;
     A_(cs_dalloc(ctx, &b->d_fi, (size_t)n_frames));
     A_(cs_dalloc(ctx, &b->d_fd, (size_t)n_frames));
@@ -1888,6 +1891,9 @@ int cs_cuboid_batch_run(cs_ctx *ctx, cs_cuboid_batch *b) {
         const int items = U * b->score_slices, grid = std::min(b->score_G, items);
         if (b->score_T == 512)
             CS_LAUNCH(ctx, "cuboid_sweep_score", cuboid_sweep_score<512>, dim3(grid), dim3(512), SC_LDS_BYTES, b->d_units, b->d_order, items, b->score_slices, b->d_cursor, b->d_vp,
+                      b->d_dist, b->d_vcount, b->d_vlist, b->d_uflag, b->d_derr, b->d_aerr);
+        else if (b->score_T == 768)
+            CS_LAUNCH(ctx, "cuboid_sweep_score", cuboid_sweep_score<768>, dim3(grid), dim3(768), SC_LDS_BYTES, b->d_units, b->d_order, items, b->score_slices, b->d_cursor, b->d_vp,
                       b->d_dist, b->d_vcount, b->d_vlist, b->d_uflag, b->d_derr, b->d_aerr);
         else
             CS_LAUNCH(ctx, "cuboid_sweep_score", cuboid_sweep_score<1024>, dim3(grid), dim3(1024), SC_LDS_BYTES, b->d_units, b->d_order, items, b->score_slices, b->d_cursor, b->d_vp,
