@@ -99,16 +99,18 @@ void Optimizer::BundleAdjustment(const std::vector<KeyFrame *> &vpKFs, const std
     p.obs_ur = any_stereo ? obs_ur.data() : nullptr;
     KeyFrame *k0 = cams[0]; // one camera model per map (the reference copies pKF->fx ... into every edge)
     p.fx = k0->fx; p.fy = k0->fy; p.cx = k0->cx; p.cy = k0->cy; p.bf = k0->mbf;
-    p.huber_mono = bRobust ? std::sqrt(5.99f) : 0.0;    // thHuber2D, float like :103
-    p.huber_stereo = bRobust ? std::sqrt(7.815f) : 0.0; // thHuber3D
+    p.huber_mono = bRobust ? (double)(float)std::sqrt(5.99) : 0.0;    // `const float thHuber2D = sqrt(5.99)` :100: the double root, rounded to float
+    p.huber_stereo = bRobust ? (double)(float)std::sqrt(7.815) : 0.0; // thHuber3D :101
 
     cs_ctx *ctx = shared_ctx();
     cs_ba *ba = nullptr;
     if (cs_ba_create(ctx, &p, 0, 1, &ba) != CS_OK) throw std::runtime_error(std::string("Optimizer (HIP): ") + cs_last_error(ctx));
-    volatile int stop = 0; // g2o polls *pbStopFlag (a bool); the library polls an int: mirror it before the call (a flag raised during the solve ends the NEXT call early)
-    if (pbStopFlag && *pbStopFlag) stop = 1;
+    // optimizer.setForceStopFlag(pbStopFlag) :80-81: the caller's bool itself is polled between iterations and LM trials (GlobalBundleAdjustemnt hands in
+    // mbStopGBA, which another thread raises)
+    cs_ba_set_stop_flag_bool(ba, reinterpret_cast<const volatile unsigned char *>(pbStopFlag));
+    static_assert(sizeof(bool) == 1, "the library polls the caller's bool as one byte");
     cs_ba_stats st;
-    const int r = cs_ba_optimize(ctx, ba, nIterations, pbStopFlag ? &stop : nullptr, &st);
+    const int r = cs_ba_optimize(ctx, ba, nIterations, nullptr, &st);
     if (r == CS_OK) cs_ba_read(ctx, ba, cam_pose.data(), points.data(), nullptr);
     cs_ba_destroy(ctx, ba);
     if (r != CS_OK) throw std::runtime_error(std::string("Optimizer (HIP): ") + cs_last_error(ctx));
@@ -217,8 +219,8 @@ void Optimizer::LocalBACameraPointObjects(KeyFrame *pKF, bool *pbStopFlag, Map *
 
     static cubeslam::Context ctx(0); // throws without a device: there is no CPU path
     cubeslam::LocalBAResult res;
-    volatile int stop = 0; // bool* -> the int flag the C-ABI polls; LocalMapping sets *pbStopFlag from another thread, so mirror it on entry only
-    cubeslam::LocalBACameraPointObjects(ctx, w, prm, res, pbStopFlag ? &stop : nullptr);
+    // LocalMapping::InterruptBA raises *pbStopFlag from another thread: the flag itself goes down (setForceStopFlag :943-944; re-checked between the stages :1392-1396)
+    cubeslam::LocalBACameraPointObjects(ctx, w, prm, res, nullptr, pbStopFlag);
 
     for (int u : res.up_used) lLocalMapObjects[w.up_mo[u]]->used_points_in_BA.push_back(up_point[u]);                     // :1164, read by Tracking.cc:2012 / MapDrawer.cc:146
     for (int u : res.up_filtered) lLocalMapObjects[w.up_mo[u]]->used_points_in_BA_filtered.push_back(up_point[u]);       // :1209

@@ -106,10 +106,11 @@ def cpu_baseline(scenes, yaw_step, flags, budget_s=10.0, with_orb=True, nfeat=10
 
 
 # ---------------------------------------------------------------------------------------------------------------- HBM traffic (PMC)
-def measure_traffic(frames, boxes, yaw_step):
-    """HBM-side bytes per launch of cuboid_sweep_score from rocprofv3 --pmc passes of tools/pmc_run.py (the same batch), collected in their
-    own runs (no tracing).  TCC_EA0 requests by size (MI355X_MICROARCH.md 'HBM': memory-side requests of the L2s, Infinity-Cache hits
-    included; sizes counted explicitly instead of FETCH_SIZE's flat 64 B).  None when rocprofv3 is not available."""
+def measure_traffic(kernel, script, script_args):
+    """HBM-side bytes per launch of `kernel` from rocprofv3 --pmc passes of a small script that runs the same workload (tools/pmc_run.py: the
+    cuboid path on the bench batch; tools/pmc_ba.py: the object BA), collected in their own runs (no tracing).  TCC_EA0 requests by size
+    (MI355X_MICROARCH.md 'HBM': memory-side requests of the L2s, Infinity-Cache hits included; sizes counted explicitly instead of
+    FETCH_SIZE's flat 64 B).  None when rocprofv3 is not available."""
     import csv
     import glob
     import shutil
@@ -121,12 +122,13 @@ def measure_traffic(frames, boxes, yaw_step):
         for tag, ctrs in (("rd", "TCC_EA0_RDREQ_sum TCC_EA0_RDREQ_32B_sum TCC_EA0_RDREQ_64B_sum TCC_EA0_RDREQ_128B_sum"), ("wr", "TCC_EA0_WRREQ_sum TCC_EA0_WRREQ_64B_sum")):
             d = tempfile.mkdtemp(prefix="pmc_" + tag, dir="/tmp")
             env = dict(os.environ, TMPDIR="/tmp")
-            subprocess.run(["rocprofv3", "--pmc"] + ctrs.split() + ["--output-format", "csv", "-d", d, "-o", "res", "--", sys.executable, os.path.join(ROOT, "tools", "pmc_run.py"),
-                            str(frames), str(boxes), str(yaw_step), str(BG_TEXTURE)], cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=90, check=True)
+            subprocess.run(["rocprofv3", "--pmc"] + ctrs.split() + ["--output-format", "csv", "-d", d, "-o", "res", "--", sys.executable, os.path.join(ROOT, "tools", script)] + [str(a) for a in script_args],
+                           cwd="/tmp", env=env, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL, timeout=120, check=True)
             acc = {}
             for f in glob.glob(d + "/**/*counter_collection.csv", recursive=True):
                 for r in csv.DictReader(open(f)):
-                    if "cuboid_sweep_score(" in r["Kernel_Name"].replace("(anonymous namespace)::", "") or r["Kernel_Name"].replace("(anonymous namespace)::", "").startswith("cuboid_sweep_score("):
+                    name = r["Kernel_Name"].replace("(anonymous namespace)::", "").replace("void ", "")
+                    if name.split("(")[0].split("<")[0] == kernel:
                         acc.setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
             res.update({k: sum(v) / len(v) for k, v in acc.items() if v})
             shutil.rmtree(d, ignore_errors=True)
@@ -136,13 +138,13 @@ def measure_traffic(frames, boxes, yaw_step):
         rd = 32 * n32 + 64 * n64 + 128 * n128 + 64 * max(0.0, n - n32 - n64 - n128)
         w, w64 = res.get("TCC_EA0_WRREQ_sum", 0), res.get("TCC_EA0_WRREQ_64B_sum", 0)
         wr = 64 * w64 + 32 * max(0.0, w - w64)
-        return {"bytes": rd + wr, "read_bytes": rd, "write_bytes": wr, "source": "rocprofv3 --pmc TCC_EA0_{RDREQ,WRREQ}* in this run (separate passes, tools/pmc_run.py)"}
+        return {"bytes": rd + wr, "read_bytes": rd, "write_bytes": wr, "source": "rocprofv3 --pmc TCC_EA0_{RDREQ,WRREQ}* in this run (separate passes, tools/%s)" % script}
     except Exception:
         return None
 
 
 # ---------------------------------------------------------------------------------------------------------------- object BA
-def ba_bench(ctx, rank, world, iters, with_cpu):
+def ba_bench(ctx, rank, world, iters, with_cpu, with_traffic=False):
     """LM iterations/s of the object BA at 1000 keyframes / 100k points / 500 cuboids."""
     from cube_slam_amd import synth
     from cube_slam_amd.ba import BundleAdjuster
@@ -180,8 +182,9 @@ def ba_bench(ctx, rank, world, iters, with_cpu):
     if "ba_schur_slots" in kern:
         alg = 144.0 * O / world + 72.0 * Lm / world + 288.0 * 5 * C
         ach = alg / (kern["ba_schur_slots"] * 1e-6) / 1e9
+        tr = measure_traffic("ba_schur_slots", "pmc_ba.py", []) if with_traffic else None
         out["roofline"] = {"bound": "hbm", "kernel": "ba_schur_slots", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS,
-                           "traffic": None, "algorithmic_bytes_per_launch": alg}
+                           "traffic": None if tr is None else tr["bytes"], "traffic_detail": tr, "algorithmic_bytes_per_launch": alg}
     if with_cpu:
         from oracle import pyoracle as po
         t0 = time.perf_counter()
@@ -277,11 +280,32 @@ def c3_bench(ctx, frames, steps, with_cpu):
             prev = (k, dsc); n += 1
         dtc = time.perf_counter() - t0
         out["cpu_baseline"] = {"value": n / dtc, "unit": "frames/s", "cores": 1, "kind": "port", "sample": "%d frames of the same stream in %.1f s, 1 thread" % (n, dtc)}
+        # frame-parallel on the host cores (extraction + lines; the matcher needs the previous frame and stays out: 3 % of a frame)
+        from concurrent.futures import ThreadPoolExecutor
+        from cube_slam_amd import _lib
+        cores = _lib.lib().cs_host_thread_count()
+        deadline = time.perf_counter() + 6.0
+
+        def worker(tid):
+            e2 = po.ORBextractor(2000, 1.2, 8, 20, 7)
+            k = 0
+            while time.perf_counter() < deadline:
+                g = imgs[(tid + k * cores) % frames]
+                e2(g)
+                po.lbd_compute(g, po.lsd_detect(g))
+                k += 1
+            return k
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(cores) as ex:
+            nmt = sum(ex.map(worker, range(cores)))
+        dtm = time.perf_counter() - t0
+        out["cpu_baseline_mt"] = {"value": nmt / dtm, "unit": "frames/s", "cores": cores, "kind": "port",
+                                  "sample": "%d frames of the same stream in %.1f s, %d threads (frame-parallel ORB + LSD/LBD, no matching)" % (nmt, dtm, cores)}
     m.close()
     return out
 
 
-def c4_bench(ctx, frames, boxes, yaw_step, steps):
+def c4_bench(ctx, frames, boxes, yaw_step, steps, with_cpu):
     """BASELINE config 4, one GPU's share: `frames` frames x `boxes` boxes through the cuboid path (512 frames shard as 64 per GPU)."""
     from cube_slam_amd.cuboid import CuboidBatch, detect_3d_cuboid
     scenes = make_frames(frames, boxes, seed0=500000)
@@ -295,11 +319,36 @@ def c4_bench(ctx, frames, boxes, yaw_step, steps):
         b.run()
     ctx.sync()
     dt = time.perf_counter() - t0
+    ctx.timing(True); ctx.timing_reset()  # the same batch again with event pairs: the score kernel's own duration
+    for _ in range(steps):
+        b.run()
+    ctx.sync()
+    k_ms, k_n = ctx.timing_get("cuboid_sweep_score")
+    f_ms, f_n = ctx.timing_get("cuboid_sweep_filter")
+    ctx.timing(False)
     st = b.stats()
     n_out = sum(len(g) for g in b.read())
     b.close()
-    return {"metric": "frames/s, detect_3d_cuboid on %d frames x %d boxes per GPU" % (frames, boxes), "value": frames * steps / dt, "unit": "frames/s", "boxes_per_s": frames * boxes * steps / dt,
-            "ms_per_batch": 1e3 * dt / steps, "valid_proposals_per_batch": st["n_valid"], "roi_pixels_per_batch": st["roi_pixels"], "cuboids_out": n_out}
+    out = {"metric": "frames/s, detect_3d_cuboid on %d frames x %d boxes per GPU" % (frames, boxes), "value": frames * steps / dt, "unit": "frames/s", "boxes_per_s": frames * boxes * steps / dt,
+           "ms_per_batch": 1e3 * dt / steps, "valid_proposals_per_batch": st["n_valid"], "roi_pixels_per_batch": st["roi_pixels"], "hypotheses_per_batch": st["n_hypotheses"], "cuboids_out": n_out}
+    if k_n:
+        us = 1e3 * k_ms / k_n
+        alg = 4.0 * st["roi_pixels"] + 200.0 * st["n_valid"]
+        out["roofline"] = {"bound": "hbm", "kernel": "cuboid_sweep_score", "achieved": alg / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                           "traffic": None, "avg_kernel_us": us, "filter_kernel_us": 1e3 * f_ms / max(f_n, 1), "algorithmic_bytes_per_launch": alg,
+                           "algorithmic_bytes_formula": "4*A + 200*n_valid (SURVEY 8d, corner construction fused)",
+                           "note": "512 units on 256 CUs: two units per persistent workgroup, the kernel is a third of the way into its steady state (see the N=1 line's roofline for 3072 units)"}
+    if with_cpu:
+        from oracle import pyoracle as po
+        o = po.cuboid_opts(yaw_step_deg=yaw_step)
+        t0 = time.perf_counter(); n = 0
+        while time.perf_counter() - t0 < 6.0:
+            sc = scenes[n % len(scenes)]
+            po.detect_cuboid(sc["gray"], sc["K"], sc["Twc"], sc["boxes"], sc["lines"], opts=o)
+            n += 1
+        dtc = time.perf_counter() - t0
+        out["cpu_baseline"] = {"value": n / dtc, "unit": "frames/s", "cores": 1, "kind": "port", "sample": "%d frames x %d boxes of the same batch in %.1f s, oracle/cuboid_oracle.cpp, 1 thread" % (n, boxes, dtc)}
+    return out
 
 
 def pcie_inclusive(ctx, scenes, yaw_step, nfeat, n=24):
@@ -426,8 +475,8 @@ def main():
         elapsed = float(t.item())
     kernels = {}
     for name in ("host_orb_quadtree", "orb_resize", "orb_fast_score", "orb_cells", "orb_scan", "orb_quadtree", "orb_blur", "orb_angle", "orb_desc", "host_lsd_regions", "lsd_blur_hv", "lsd_resize",
-                 "lsd_gradient", "lsd_emit", "lsd_rg_fill", "lsd_rg_scatter", "lsd_rg_seq", "lsd_rg_improve", "lbd_blur5", "lbd_sobel", "lbd_line_desc", "cuboid_frame_prep", "cuboid_unit_lines", "cuboid_canny_nms", "cuboid_canny_cc", "cuboid_dt", "cuboid_dt_codes",
-                 "cuboid_vp", "cuboid_sweep_corners", "cuboid_score_plan", "cuboid_sweep_score", "cuboid_sweep_score_big", "cuboid_select"):
+                 "lsd_gradient", "lsd_emit", "lsd_rg_fill", "lsd_rg_scatter", "lsd_rg_seq", "lsd_rg_improve", "lbd_blur5", "lbd_sobel", "lbd_line_desc", "cuboid_frame_prep", "cuboid_unit_lines", "cuboid_canny_nms", "cuboid_canny_cc", "cuboid_dt",
+                 "cuboid_vp", "cuboid_sweep_filter", "cuboid_sweep_score", "cuboid_select"):
         ms, n = ctx.timing_get(name)
         if n == 0 and lsd is not None:
             parts = [c.timing_get(name) for c in ctx_lines]
@@ -458,24 +507,26 @@ def main():
     solo = rank == 0 and world == 1
     extra = {}
     if solo and not args.no_extra:
-        tr = measure_traffic(args.frames, args.boxes, args.yaw_step)
+        tr = measure_traffic("cuboid_sweep_score", "pmc_run.py", [args.frames, args.boxes, args.yaw_step, BG_TEXTURE])
+        if not args.no_cpu:
+            native_oracle()  # the c3 / c4 CPU legs use the -march=native build too
         extra["c3"] = c3_bench(ctx, 24, 3, with_cpu=not args.no_cpu)
-        extra["c4"] = c4_bench(ctx, 64, 8, args.yaw_step, 10)
+        extra["c4"] = c4_bench(ctx, 64, 8, args.yaw_step, 10, with_cpu=not args.no_cpu)
         extra["pcie_inclusive"] = pcie_inclusive(ctx, scenes, args.yaw_step, args.orb_features)
     else:
         tr = None
     ba_out = None
     if not args.no_ba:
-        ba_out = ba_bench(ctx, rank, world, args.ba_iters, with_cpu=(solo and not args.no_cpu))
+        ba_out = ba_bench(ctx, rank, world, args.ba_iters, with_cpu=(solo and not args.no_cpu), with_traffic=solo and not args.no_extra)
 
     if rank == 0:
         total_frames = args.frames * world * args.steps
-        # Algorithmic bytes of one cuboid_sweep_score launch, as SURVEY 8d defines them for the edge-scoring kernel and as round 1 counted them: every
-        # distance-map ROI it covers read once as the float map the distance transform produces (4*A), plus per surviving proposal 16 corner
-        # doubles read and 2 error doubles written (144 B).  Two other accountings ride along in roofline["accountings"]: what THIS kernel has to
-        # move now that it reads the map as 2-byte codes (2*A + 144*n_valid, the strictest), and SURVEY 8d's literal per-box figure with all
-        # hypotheses (4*A + 144*n_h) over both score kernels.  Units that do not fit LDS are cuboid_sweep_score_big's.
-        alg_bytes = 4.0 * ss["lds_pixels"] + 144.0 * ss["lds_valid"]
+        # Algorithmic bytes of one cuboid_sweep_score launch, SURVEY 8d's figure for the edge-scoring kernel with corner construction fused into it
+        # (K3 + K4): every distance-map ROI read once as the float map the distance transform writes (4*A) + 200 B per surviving proposal (the 9 + 16
+        # doubles the reference stores per valid proposal, box_proposal_detail.cpp:450-456).  The kernel reads exactly that float map (it encodes it
+        # into LDS itself) and no corner ever touches HBM; what it physically moves per proposal is 4 B of list in and 16 B of errors out, so
+        # `traffic` (PMC) sits below the credited bytes.  `accountings` also gives the fraction by the bytes it must move.
+        alg_bytes = 4.0 * st["roi_pixels"] + 200.0 * st["n_valid"]
         k_us = kernels["cuboid_sweep_score"]["avg_us"]
         achieved = alg_bytes / (k_us * 1e-6) / 1e9 if k_us > 0 else 0.0
         iso_us = 1e3 * iso_ms / max(iso_n, 1)
@@ -496,15 +547,14 @@ def main():
             "roofline": {"bound": "hbm", "kernel": "cuboid_sweep_score", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None if tr is None else tr["bytes"], "traffic_detail": tr, "avg_kernel_us": k_us,
                          "algorithmic_bytes_per_launch": alg_bytes,
-                         "algorithmic_bytes_formula": "4*A_lds + 144*n_valid_lds (SURVEY 8d: distance-map ROI read once + corners in + errors out; round 1's accounting)",
+                         "algorithmic_bytes_formula": "4*A + 200*n_valid (SURVEY 8d, fused K3+K4: float distance-map ROI read once + the reference's 25 doubles per valid proposal)",
                          "accountings": {
-                             "code_map_2A_plus_144_n_valid": {"bytes": 2.0 * ss["lds_pixels"] + 144.0 * ss["lds_valid"],
-                                                              "frac": (2.0 * ss["lds_pixels"] + 144.0 * ss["lds_valid"]) / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBS if k_us > 0 else None,
-                                                              "note": "what this kernel must move: the map as 16-bit codes (cuboid_dt_codes wrote them), valid proposals only"},
-                             "survey_8d_4A_plus_144_n_h_both_kernels": {"bytes": 4.0 * st["roi_pixels"] + 144.0 * st["n_hypotheses"],
-                                                                        "us": k_us + kernels["cuboid_sweep_score_big"]["avg_us"],
-                                                                        "frac": (4.0 * st["roi_pixels"] + 144.0 * st["n_hypotheses"]) / ((k_us + kernels["cuboid_sweep_score_big"]["avg_us"]) * 1e-6) / 1e9 / HBM_PEAK_GBS if k_us > 0 else None,
-                                                                        "note": "SURVEY 8d's per-box figure (all hypotheses' corners, 0.85 MB/box) over cuboid_sweep_score + cuboid_sweep_score_big"}},
+                             "must_move_4A_plus_20_n_valid": {"bytes": 4.0 * st["roi_pixels"] + 20.0 * st["n_valid"],
+                                                              "frac": (4.0 * st["roi_pixels"] + 20.0 * st["n_valid"]) / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBS if k_us > 0 else None,
+                                                              "note": "what this kernel has to move: the float map once, 4 B of proposal list in and 2 error doubles out per valid proposal"},
+                             "edge_scoring_stage_filter_plus_score": {"us": k_us + kernels["cuboid_sweep_filter"]["avg_us"],
+                                                                      "frac": alg_bytes / ((k_us + kernels["cuboid_sweep_filter"]["avg_us"]) * 1e-6) / 1e9 / HBM_PEAK_GBS if k_us > 0 else None,
+                                                                      "note": "the same bytes over cuboid_sweep_filter (reject tests of all hypotheses) + cuboid_sweep_score: everything between the distance transform and the selection"}},
                          "isolated": {"avg_kernel_us": iso_us, "frac": (alg_bytes / (iso_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if iso_n else None,
                                       "note": "cuboid path alone on the GPU; the timed region runs ORB, line and cuboid kernels concurrently on three streams"},
                          "in_run_note": (None if lsd is None or not lsd.region_stats()["device"] else

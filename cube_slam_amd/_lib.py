@@ -5,7 +5,7 @@ import os
 import subprocess
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libcubeslam_hip.so")
+LIB_PATH = os.environ.get("CUBESLAM_LIB") or os.path.join(_HERE, "libcubeslam_hip.so")  # CUBESLAM_LIB: a development build of the same library (profiling variants)
 _LIB = None
 
 CS_OK = 0
@@ -23,6 +23,16 @@ def build(force=False):
     subprocess.check_call(["make", "-s", "-C", os.path.join(_HERE, "csrc")])
 
 
+def header_version():
+    """CS_VERSION of include/cubeslam_hip.h in this tree (None when the header is not there)."""
+    try:
+        import re
+        m = re.search(r"#define\s+CS_VERSION\s+(\d+)", open(os.path.join(os.path.dirname(_HERE), "include", "cubeslam_hip.h")).read())
+        return int(m.group(1)) if m else None
+    except OSError:
+        return None
+
+
 def lib():
     global _LIB
     if _LIB is None:
@@ -30,6 +40,9 @@ def lib():
             raise CubeSlamError("libcubeslam_hip.so is not built (run python -c 'import __graft_entry__ as g; g.build()')")
         _LIB = C.CDLL(LIB_PATH)
         _LIB.cs_last_error.restype = C.c_char_p
+        want = header_version()
+        if want is not None and _LIB.cs_version() != want:  # an ABI-changing header with a stale library (or the reverse) must not get as far as a call
+            raise CubeSlamError("libcubeslam_hip.so is version %d, include/cubeslam_hip.h is %d: rebuild" % (_LIB.cs_version(), want))
     return _LIB
 
 

@@ -88,6 +88,11 @@ class BundleAdjuster:
             self._cb = ALLREDUCE_FN(_cb)
             check(self.ctx.ptr, lib().cs_ba_set_allreduce(self._b, self._cb, None), "cs_ba_set_allreduce")
 
+    def set_stop_flag_bool(self, flag):
+        """flag: a ctypes c_ubyte another thread raises (the reference's `bool *pbStopFlag`, setForceStopFlag), or None; polled during every later optimize()."""
+        self._stop8 = flag  # keep it alive
+        check(self.ctx.ptr, lib().cs_ba_set_stop_flag_bool(self._b, None if flag is None else C.byref(flag)), "cs_ba_set_stop_flag_bool")
+
     def optimize(self, iterations, stop_flag=None):
         st = BAStats()
         check(self.ctx.ptr, lib().cs_ba_optimize(self.ctx.ptr, self._b, iterations, stop_flag, C.byref(st)), "cs_ba_optimize")

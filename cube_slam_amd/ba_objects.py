@@ -111,9 +111,9 @@ def build_graph(w, params, fixCamera=False):
          "obs_cam": np.asarray(w["obs_kf"], np.int32)[obs_rows], "obs_point": prow[np.asarray(w["obs_mp"], int)[obs_rows]].astype(np.int32),
          "obs_uv": np.asarray(w["obs_uv"], float).reshape(-1, 2)[obs_rows], "obs_inv_sigma2": np.asarray(w["obs_inv_sigma2"], float)[obs_rows],
          "obs_ur": np.asarray(w["obs_ur"], float)[obs_rows], "fx": K[0, 0], "fy": K[1, 1], "cx": K[0, 2], "cy": K[1, 2],
-         "huber_mono": math.sqrt(5.991), "huber_stereo": math.sqrt(7.815), "bf": params.get("bf", 0.0),
+         "huber_mono": float(np.float32(math.sqrt(5.991))), "huber_stereo": float(np.float32(math.sqrt(7.815))), "bf": params.get("bf", 0.0),
          "cobs_cam": np.asarray(w["det_kf"], np.int32)[det_rows], "cobs_cuboid": det_mo.astype(np.int32),
-         "cobs_bbox": np.asarray(w["det_bbox_vec"], float).reshape(-1, 4)[det_rows], "cobs_info": cobs_info, "K": K, "huber_obj": math.sqrt(900.0),
+         "cobs_bbox": np.asarray(w["det_bbox_vec"], float).reshape(-1, 4)[det_rows], "cobs_info": cobs_info, "K": K, "huber_obj": float(np.float32(math.sqrt(900.0))),  # the widths are `const float` in the reference (:1043-1044, :1292): float-rounded roots
          "pc_cuboid": np.array(pc_cub, np.int32), "pc_offsets": np.array(pc_off, np.int32),
          "pc_points": np.concatenate(pc_pts).reshape(-1, 3) if pc_pts else np.zeros((0, 3)), "max_outside_margin_ratio": 2.0 if kitti else 1.0}
     return {"problem": d, "cobs_level": cobs_level, "point_rows": point_rows, "obs_rows": obs_rows, "det_rows": det_rows}

@@ -1354,6 +1354,7 @@ struct cs_ba {
     Params G{};
     int rank = 0, world = 1, n_slots = 0, max_col = 0, max_part = 0;
     cs_allreduce_fn allreduce = nullptr; void *ar_user = nullptr;
+    const volatile unsigned char *stop8 = nullptr; // the caller's bool (setForceStopFlag)
     std::vector<void *> owned;
     int *d_pose_off = nullptr, *d_pose_obs = nullptr, *d_pe_off = nullptr, *d_pe_list = nullptr, *d_slot_off = nullptr, *d_slot_perm = nullptr, *d_slot_dst = nullptr, *d_col_off = nullptr,
         *d_rows = nullptr, *d_pair_off = nullptr, *d_upd_tgt = nullptr, *d_pos = nullptr, *d_status = nullptr;
@@ -1914,6 +1915,8 @@ int cs_ba_read(cs_ctx *ctx, cs_ba *b, double *cam_pose, double *points, double *
     return CS_OK;
 }
 
+int cs_ba_set_stop_flag_bool(cs_ba *b, const volatile unsigned char *flag) { if (!b) return CS_ERR_BAD_ARG; b->stop8 = flag; return CS_OK; }
+
 int cs_ba_optimize(cs_ctx *ctx, cs_ba *b, int iterations, const volatile int *stop_flag, cs_ba_stats *st) {
     if (!ctx || !b || iterations < 0) return CS_ERR_BAD_ARG;
     CS_HIP(ctx, hipSetDevice(ctx->device));
@@ -1924,7 +1927,7 @@ int cs_ba_optimize(cs_ctx *ctx, cs_ba *b, int iterations, const volatile int *st
     double lambda = 0, ni = 2, currentChi = 0;
     int nBad = 0, r;
     const int nl = G.lm_e - G.lm_b;
-    auto terminate = [&]() { return stop_flag && *stop_flag; }; // sparse_optimizer.cpp:376, optimization_algorithm_levenberg.cpp:149
+    auto terminate = [&]() { return (stop_flag && *stop_flag) || (b->stop8 && *b->stop8); }; // sparse_optimizer.cpp:376, optimization_algorithm_levenberg.cpp:149
     for (int it = 0; it < iterations && !terminate(); it++) { // OptimizationAlgorithmLevenberg::solve :61-164
         // computeActiveErrors: after an accepted trial the residual arrays and chi2 on the device are those of the current state (every
         // way out of the trial loop with a rejected last trial also leaves this loop), so only the first iteration evaluates them

@@ -319,6 +319,7 @@ __global__ void __launch_bounds__(1024) badyn_chol_tri(int n, const double *A, c
 
 struct cs_ba_dyn {
     DynG G;
+    const volatile unsigned char *stop8 = nullptr; // the caller's bool (setForceStopFlag)
     std::vector<void *> bufs;
     int n_edges = 0, n_vertices = 0, max_part = 0, n_slots = 0, simple_chol = 0;
     double *d_Dg = nullptr, *d_rd = nullptr;
@@ -524,6 +525,8 @@ int cs_ba_dyn_create(cs_ctx *ctx, const cs_ba_dyn_problem *p, cs_ba_dyn **out) {
     return CS_OK;
 }
 
+int cs_ba_dyn_set_stop_flag_bool(cs_ba_dyn *b, const volatile unsigned char *flag) { if (!b) return CS_ERR_BAD_ARG; b->stop8 = flag; return CS_OK; }
+
 int cs_ba_dyn_optimize(cs_ctx *ctx, cs_ba_dyn *b, int iterations, const volatile int *stop_flag, cs_ba_stats *st) {
     if (!ctx || !b || iterations < 0) return CS_ERR_BAD_ARG;
     CS_HIP(ctx, hipSetDevice(ctx->device));
@@ -534,7 +537,7 @@ int cs_ba_dyn_optimize(cs_ctx *ctx, cs_ba_dyn *b, int iterations, const volatile
     int nBad = 0, r;
     bool accepted = false;
     const size_t nx = (size_t)G.NP + 3 * (size_t)G.L;
-    auto terminate = [&]() { return stop_flag && *stop_flag; };
+    auto terminate = [&]() { return (stop_flag && *stop_flag) || (b->stop8 && *b->stop8); };
     for (int it = 0; it < iterations && !terminate(); it++) { // OptimizationAlgorithmLevenberg::solve :61-164
         double tempChi;
         if (it == 0 || !accepted) { r = dyn_errors(ctx, b, &currentChi); if (r) return r; } // otherwise the residuals of the accepted trial are current

@@ -143,7 +143,7 @@ class CuboidBatch:
     def score_stats(self):
         v = (C.c_long * 6)()
         check(self.ctx.ptr, lib().cs_cuboid_batch_score_stats(self.ctx.ptr, self._b, v), "cs_cuboid_batch_score_stats")
-        return dict(zip(("lds_units", "lds_pixels", "lds_valid", "big_units", "big_pixels", "big_valid"), list(v)))
+        return dict(zip(("code_units", "code_pixels", "code_valid", "float_units", "float_pixels", "float_valid"), list(v)))
 
     def unit(self, u, rows_cap=400000):
         dims = (C.c_int * 12)()

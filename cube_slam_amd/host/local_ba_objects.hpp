@@ -102,7 +102,8 @@ inline Graph active_subgraph(const Graph &d, const std::vector<uint8_t> &keep_ob
     return s;
 }
 // one SparseOptimizer::optimize over the active part; estimates written back into d
-inline void solve(Context &c, Graph &d, const std::vector<uint8_t> &keep_obs, const std::vector<uint8_t> &keep_cobs, int iterations, const volatile int *stop, cs_ba_stats *st) {
+inline void solve(Context &c, Graph &d, const std::vector<uint8_t> &keep_obs, const std::vector<uint8_t> &keep_cobs, int iterations, const volatile int *stop, cs_ba_stats *st,
+                  const volatile bool *stop_bool = nullptr) {
     std::vector<int> pu, cu;
     Graph s = active_subgraph(d, keep_obs, keep_cobs, pu, cu);
     if (s.obs_cam.empty() && s.cobs_cam.empty() && s.pc_cuboid.empty()) return;
@@ -111,6 +112,7 @@ inline void solve(Context &c, Graph &d, const std::vector<uint8_t> &keep_obs, co
     cs_ba *ba = nullptr;
     check(c.ctx, cs_ba_create(c.ctx, &p, 0, 1, &ba), "cs_ba_create");
     std::vector<double> pts((size_t)pu.size() * 3 + 3), cub((size_t)cu.size() * 7 + 7);
+    cs_ba_set_stop_flag_bool(ba, reinterpret_cast<const volatile unsigned char *>(stop_bool)); // optimizer.setForceStopFlag(pbStopFlag), Optimizer.cc:943-944: live during the solve
     int r = cs_ba_optimize(c.ctx, ba, iterations, stop, st);
     if (!r) r = cs_ba_read(c.ctx, ba, d.cam_pose.data(), pts.data(), cub.data());
     cs_ba_destroy(c.ctx, ba);
@@ -144,7 +146,10 @@ inline void residuals(Context &c, const Graph &d, std::vector<double> &chi2, std
 }
 } // namespace local_ba_detail
 
-inline void LocalBACameraPointObjects(Context &c, const LocalWindow &w, const LocalBAParams &prm, LocalBAResult &out, const volatile int *pbStopFlag = nullptr) {
+// pbStopFlag: an int flag (this library's convention); pbStopBool: the reference's `bool *pbStopFlag` as it is (another thread raises it): both are
+// polled during the solves (between iterations and LM trials) and between the two stages (:1392-1396)
+inline void LocalBACameraPointObjects(Context &c, const LocalWindow &w, const LocalBAParams &prm, LocalBAResult &out, const volatile int *pbStopFlag = nullptr,
+                                      const volatile bool *pbStopBool = nullptr) {
     using namespace local_ba_detail;
     const int n_kf = (int)w.kf_id.size(), n_obj = (int)w.mo_meas_quality.size(), n_mp = (int)w.mp_nobs.size();
     Graph d;
@@ -221,24 +226,25 @@ inline void LocalBACameraPointObjects(Context &c, const LocalWindow &w, const Lo
     }
     d.fx = prm.K[0]; d.fy = prm.K[4]; d.cx = prm.K[2]; d.cy = prm.K[5];
     for (int i = 0; i < 9; i++) d.K[i] = prm.K[i];
-    d.huber_mono = std::sqrt(5.991); d.huber_stereo = std::sqrt(7.815); d.huber_obj = std::sqrt(900.0); d.bf = prm.bf; d.ratio = prm.kitti ? 2.0 : 1.0;
+    // `const float thHuberMono = sqrt(5.991)` :1043-1044, thHuberObject :1292: setDelta receives the float-rounded width
+    d.huber_mono = (double)(float)std::sqrt(5.991); d.huber_stereo = (double)(float)std::sqrt(7.815); d.huber_obj = (double)(float)std::sqrt(900.0); d.bf = prm.bf; d.ratio = prm.kitti ? 2.0 : 1.0;
     out.object_scale = d.cuboid_scale;
     // two stages :1389-1438
     std::vector<uint8_t> keep_obs(n_obs + 1, 1), keep_cobs(n_cobs + 1, 1);
     keep_obs.resize(n_obs); keep_cobs.resize(n_cobs);
     for (size_t k = 0; k < n_cobs; k++) keep_cobs[k] = out.cobs_level[k] == 0;
-    solve(c, d, keep_obs, keep_cobs, 5, pbStopFlag, &out.st1);
+    solve(c, d, keep_obs, keep_cobs, 5, pbStopFlag, &out.st1, pbStopBool);
     out.obs_level.assign(n_obs, 0); out.cobs_level2 = out.cobs_level;
     std::vector<double> chi1, z1, cn;
     residuals(c, d, chi1, z1, cn);
-    const bool more = !(pbStopFlag && *pbStopFlag);
+    const bool more = !(pbStopFlag && *pbStopFlag) && !(pbStopBool && *pbStopBool);
     if (more) {
         for (size_t o = 0; o < n_obs; o++) if (chi1[o] > (d.obs_ur[o] >= 0 ? 7.815 : 5.991) || !(z1[o] > 0)) out.obs_level[o] = 1;
         for (size_t k = 0; k < n_cobs; k++) if (out.cobs_level[k] == 0 && cn[k] > 80) out.cobs_level2[k] = 1;
         d.huber_mono = 0; d.huber_stereo = 0;
         for (size_t o = 0; o < n_obs; o++) keep_obs[o] = out.obs_level[o] == 0;
         for (size_t k = 0; k < n_cobs; k++) keep_cobs[k] = out.cobs_level2[k] == 0;
-        solve(c, d, keep_obs, keep_cobs, 10, pbStopFlag, &out.st2);
+        solve(c, d, keep_obs, keep_cobs, 10, pbStopFlag, &out.st2, pbStopBool);
     }
     std::vector<double> chi2, z2;
     residuals(c, d, chi2, z2, cn);

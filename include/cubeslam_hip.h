@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define CS_VERSION 100
+#define CS_VERSION 101 /* 101: cs_ba_set_stop_flag_bool / cs_ba_dyn_set_stop_flag_bool; cs_match_by_projection_frame takes train_blocked */
 
 typedef enum cs_status {
     CS_OK = 0,
@@ -312,8 +312,12 @@ typedef int (*cs_allreduce_fn)(void *user, double *device_buf, long n);
 int cs_ba_create(cs_ctx *ctx, const cs_ba_problem *p, int rank, int world, cs_ba **out);
 void cs_ba_destroy(cs_ctx *ctx, cs_ba *b);
 int cs_ba_set_allreduce(cs_ba *b, cs_allreduce_fn fn, void *user);
-/* SparseOptimizer::optimize(iterations).  stop_flag (may be NULL) is polled between LM trials like g2o's forceStopFlag. */
+/* SparseOptimizer::optimize(iterations).  stop_flag (may be NULL) is polled between iterations and LM trials like g2o's forceStopFlag
+ * (sparse_optimizer.cpp:376, optimization_algorithm_levenberg.cpp:149). */
 int cs_ba_optimize(cs_ctx *ctx, cs_ba *b, int iterations, const volatile int *stop_flag, cs_ba_stats *stats);
+/* SparseOptimizer::setForceStopFlag(bool*) (Optimizer.cc:80-81, 943-944): a second flag, ONE BYTE wide -- the C++ `bool` another thread of the
+ * caller raises (LocalMapping::InterruptBA, mbStopGBA) -- polled at the same points of every later cs_ba_optimize on this graph; NULL removes it. */
+int cs_ba_set_stop_flag_bool(cs_ba *b, const volatile unsigned char *flag);
 /* current estimates (any pointer may be NULL) */
 int cs_ba_read(cs_ctx *ctx, cs_ba *b, double *cam_pose, double *points, double *cuboid_pose);
 /* computeActiveErrors + activeRobustChi2 at the current estimates (this rank's share when sharded); err_* may be NULL */
@@ -356,6 +360,7 @@ int cs_ba_dyn_create(cs_ctx *ctx, const cs_ba_dyn_problem *p, cs_ba_dyn **out);
 void cs_ba_dyn_destroy(cs_ctx *ctx, cs_ba_dyn *b);
 /* SparseOptimizer::optimize(iterations); stop_flag as in cs_ba_optimize */
 int cs_ba_dyn_optimize(cs_ctx *ctx, cs_ba_dyn *b, int iterations, const volatile int *stop_flag, cs_ba_stats *stats);
+int cs_ba_dyn_set_stop_flag_bool(cs_ba_dyn *b, const volatile unsigned char *flag); /* as cs_ba_set_stop_flag_bool */
 /* current estimates (any pointer may be NULL) */
 int cs_ba_dyn_read(cs_ctx *ctx, cs_ba_dyn *b, double *cam_pose, double *obj_pose, double *vel, double *points, double *dpoints);
 /* computeError of every edge + activeRobustChi2 over the active ones: e_obs n x 3 (third 0 for mono), e_dobs n x 2, e_mot n x 3,

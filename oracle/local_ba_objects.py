@@ -214,9 +214,9 @@ def local_ba_camera_point_objects(pKF, params, fixCamera=False):
          "cuboid_flags": np.full(len(objects), 1 | 8, np.uint8),
          "obs_cam": np.array(obs_cam, np.int32), "obs_point": np.array(obs_pt, np.int32), "obs_uv": np.array(obs_uv, float).reshape(-1, 2),
          "obs_inv_sigma2": np.array(obs_w, float), "obs_ur": np.array(obs_ur, float), "fx": K[0, 0], "fy": K[1, 1], "cx": K[0, 2], "cy": K[1, 2],
-         "huber_mono": math.sqrt(5.991), "huber_stereo": math.sqrt(7.815), "bf": params.get("bf", 0.0),
+         "huber_mono": float(np.float32(math.sqrt(5.991))), "huber_stereo": float(np.float32(math.sqrt(7.815))), "bf": params.get("bf", 0.0),
          "cobs_cam": np.array(cobs_cam, np.int32), "cobs_cuboid": np.array(cobs_cub, np.int32), "cobs_bbox": np.array(cobs_bbox, float).reshape(-1, 4),
-         "cobs_info": np.array(cobs_info, float).reshape(-1, 4), "K": K, "huber_obj": math.sqrt(900.0),
+         "cobs_info": np.array(cobs_info, float).reshape(-1, 4), "K": K, "huber_obj": float(np.float32(math.sqrt(900.0))),  # the widths are `const float` in the reference (:1043-1044, :1292): float-rounded roots
          "pc_cuboid": np.array(pc_cub, np.int32), "pc_offsets": np.array(pc_off, np.int32),
          "pc_points": np.concatenate(pc_pts).reshape(-1, 3) if pc_pts else np.zeros((0, 3)), "max_outside_margin_ratio": 2.0 if kitti else 1.0}
     cobs_level = np.array(cobs_level, int)

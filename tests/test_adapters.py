@@ -1,7 +1,9 @@
 """The drop-in translation units under adapters/ compile against the REFERENCE'S OWN headers (the class definitions are the reference's):
 adapters/ORBextractor_hip.cc and adapters/line_lbd_allclass_hip.cpp for real (objects + oracle/_ref/libadapters.so, with oracle/ref_shim/ standing
 in for the OpenCV headers), adapters/detect_3d_cuboid_hip.cpp with -fsyntax-only against a syntax-level Eigen stand-in.  The GPU box then runs
-the first two through the reference's class interfaces (tests/test_adapters_gpu.py)."""
+the first two through the reference's class interfaces (tests/test_adapters_gpu.py).  adapters/Optimizer_hip.cc is type-checked against the
+reference's own `class Optimizer` declaration (cut out of include/Optimizer.h here) over stand-in declarations of the SLAM classes it walks
+(oracle/ref_shim/slam_syntax/: KeyFrame.h and friends need DBoW2, g2o's core and the full Eigen)."""
 import os
 import subprocess
 
@@ -33,3 +35,27 @@ def test_cuboid_adapter_type_checks_against_the_reference_header():
            "-I" + os.path.join(ROOT, "include"), "-I" + os.path.join(REF, "detect_3d_cuboid", "include"), os.path.join(ROOT, "adapters", "detect_3d_cuboid_hip.cpp")]
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
+
+
+def test_optimizer_adapter_type_checks_against_the_reference_declaration():
+    """Optimizer::BundleAdjustment / LocalBACameraPointObjects as members of the reference's class: the declaration is cut from
+    orb_object_slam/include/Optimizer.h (a changed signature there fails this test), the SLAM classes are stand-in declarations with the
+    reference's member names and types.  Also pinned here: the adapter hands the caller's `bool *pbStopFlag` itself to the library
+    (cs_ba_set_stop_flag_bool, polled during the solve like g2o's setForceStopFlag), not a copy made on entry."""
+    import re
+    hdr = open(os.path.join(REF, "orb_object_slam", "include", "Optimizer.h")).read()
+    m = re.search(r"class Optimizer\s*\{.*?\n\};", hdr, re.S)
+    assert m, "class Optimizer not found in the reference header"
+    decl = m.group(0)
+    for sig in ("BundleAdjustment(const std::vector<KeyFrame *> &vpKF, const std::vector<MapPoint *> &vpMP", "LocalBACameraPointObjects(KeyFrame *pKF, bool *pbStopFlag, Map *pMap"):
+        assert sig in decl, sig
+    shim = os.path.join(ROOT, "oracle", "ref_shim", "slam_syntax")
+    with open(os.path.join(shim, "Optimizer_decl.inc"), "w") as f:
+        f.write(decl + "\n")
+    cmd = ["g++", "-std=c++14", "-fsyntax-only", "-w", "-I" + shim, "-I" + os.path.join(ROOT, "oracle", "ref_shim", "syntax"), "-I" + os.path.join(ROOT, "oracle", "ref_shim"),
+           "-I" + os.path.join(ROOT, "include"), "-I" + ROOT, os.path.join(ROOT, "adapters", "Optimizer_hip.cc")]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-3000:]
+    src = open(os.path.join(ROOT, "adapters", "Optimizer_hip.cc")).read()
+    assert src.count("cs_ba_set_stop_flag_bool") >= 1 and "LocalBACameraPointObjects(ctx, w, prm, res, nullptr, pbStopFlag)" in src
+    assert "volatile int stop = 0" not in src  # (round 2's copy-on-entry)

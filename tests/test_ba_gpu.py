@@ -78,6 +78,38 @@ def test_all_cameras_fixed_but_one_and_stop_flag(ctx, oracle):
     ba.close()
 
 
+def test_stop_flag_raised_by_another_thread_ends_the_solve(ctx):
+    """g2o polls the caller's `bool *pbStopFlag` between iterations and LM trials (sparse_optimizer.cpp:376, optimization_algorithm_levenberg.cpp:149;
+    LocalMapping::InterruptBA raises it from another thread).  cs_ba_set_stop_flag_bool hands the library that byte itself: a flag raised while
+    cs_ba_optimize runs ends it early, with the estimates of the last finished iteration."""
+    import ctypes as C
+    import threading
+    import time
+    d = synth.ba_problem(11, n_kf=200, n_points=20000, n_cuboids=50)
+    ba = BundleAdjuster(d, ctx=ctx)
+    ba.optimize(1)  # (kernels paged in)
+    flag = C.c_ubyte(0)
+    ba.set_stop_flag_bool(flag)
+    t0 = time.perf_counter()
+    full = ba.optimize(3)
+    per_it = (time.perf_counter() - t0) / max(full["iterations"], 1)
+    assert full["iterations"] == 3
+
+    def raise_later():
+        time.sleep(max(4 * per_it, 0.002))
+        flag.value = 1
+    th = threading.Thread(target=raise_later)
+    th.start()
+    st = ba.optimize(100000)  # would take minutes
+    th.join()
+    assert 0 < st["iterations"] < 100000, st["iterations"]
+    assert ba.optimize(5)["iterations"] == 0  # still raised: nothing runs (Optimizer.cc:1386-1388)
+    flag.value = 0
+    assert ba.optimize(2)["iterations"] >= 1
+    ba.set_stop_flag_bool(None)
+    ba.close()
+
+
 def test_band_and_sparse_solvers_agree(ctx, small, monkeypatch):
     """The two reduced-solve paths (cuboid elimination + LDS-window block-band Cholesky; minimum-degree sparse block Cholesky)
     solve the same damped system: identical LM decisions, chi2 within round-off."""
