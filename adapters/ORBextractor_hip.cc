@@ -17,9 +17,11 @@ namespace {
 struct Dev { cs_ctx *ctx = nullptr; cs_orb *orb = nullptr; int w = 0, h = 0; };
 std::mutex g_mu;
 std::map<const ORBextractor *, Dev> g_dev;
-cs_ctx *shared_ctx() { // one context (device + stream) per process for the extractors: Tracking owns them and calls them from one thread
-    static cs_ctx *ctx = nullptr;
-    if (!ctx && cs_create(0, &ctx) != CS_OK) throw std::runtime_error("ORBextractor (HIP): no device -- there is no CPU path");
+// One context (device + stream) PER EXTRACTOR: a cs_ctx is not thread-safe, and the stereo Frame constructor runs the left and the right extractor in
+// two concurrent threads (Frame.cc:106-107).  An extractor itself is only ever called by one thread at a time.
+cs_ctx *new_ctx() {
+    cs_ctx *ctx = nullptr;
+    if (cs_create(0, &ctx) != CS_OK) throw std::runtime_error("ORBextractor (HIP): no device -- there is no CPU path");
     return ctx;
 }
 } // namespace
@@ -32,12 +34,14 @@ ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int
     mnFeaturesPerLevel.resize(nlevels);
     mvImagePyramid.resize(nlevels);
     cs_orb *probe = nullptr;
-    if (cs_orb_create(shared_ctx(), nfeatures, (float)scaleFactor, nlevels, iniThFAST, minThFAST, 64, 64, 1, &probe) != CS_OK)
-        throw std::runtime_error(std::string("ORBextractor (HIP): ") + cs_last_error(shared_ctx()));
+    cs_ctx *my_ctx = new_ctx();
+    { std::lock_guard<std::mutex> lk(g_mu); g_dev[this].ctx = my_ctx; }
+    if (cs_orb_create(my_ctx, nfeatures, (float)scaleFactor, nlevels, iniThFAST, minThFAST, 64, 64, 1, &probe) != CS_OK)
+        throw std::runtime_error(std::string("ORBextractor (HIP): ") + cs_last_error(my_ctx));
     cs_orb_get_table(probe, 0, mvScaleFactor.data()); cs_orb_get_table(probe, 1, mvInvScaleFactor.data());
     cs_orb_get_table(probe, 2, mvLevelSigma2.data()); cs_orb_get_table(probe, 3, mvInvLevelSigma2.data());
     cs_orb_get_table(probe, 4, mnFeaturesPerLevel.data());
-    cs_orb_destroy(shared_ctx(), probe);
+    cs_orb_destroy(my_ctx, probe);
 }
 
 void ORBextractor::operator()(cv::InputArray _image, cv::InputArray /*_mask: unused by the reference as well*/, std::vector<cv::KeyPoint> &_keypoints,
@@ -51,7 +55,8 @@ void ORBextractor::operator()(cv::InputArray _image, cv::InputArray /*_mask: unu
         Dev &e = g_dev[this];
         if (!e.orb || e.w != image.cols || e.h != image.rows) { // first frame, or the camera changed resolution
             if (e.orb) cs_orb_destroy(e.ctx, e.orb);
-            e.ctx = shared_ctx(); e.w = image.cols; e.h = image.rows; e.orb = nullptr;
+            if (!e.ctx) e.ctx = new_ctx(); // (an extractor copied from another one)
+            e.w = image.cols; e.h = image.rows; e.orb = nullptr;
             if (cs_orb_create(e.ctx, nfeatures, (float)scaleFactor, nlevels, iniThFAST, minThFAST, e.w, e.h, 1, &e.orb) != CS_OK)
                 throw std::runtime_error(std::string("ORBextractor (HIP): ") + cs_last_error(e.ctx));
         }
@@ -97,5 +102,5 @@ void ExtractorNode::DivideNode(ExtractorNode &, ExtractorNode &, ExtractorNode &
 extern "C" void ORBextractor_hip_release(const void *extractor) { // optional: free the device buffers of one extractor
     std::lock_guard<std::mutex> lk(ORB_SLAM2::g_mu);
     auto it = ORB_SLAM2::g_dev.find(static_cast<const ORB_SLAM2::ORBextractor *>(extractor));
-    if (it != ORB_SLAM2::g_dev.end()) { if (it->second.orb) cs_orb_destroy(it->second.ctx, it->second.orb); ORB_SLAM2::g_dev.erase(it); }
+    if (it != ORB_SLAM2::g_dev.end()) { if (it->second.orb) cs_orb_destroy(it->second.ctx, it->second.orb); if (it->second.ctx) cs_destroy(it->second.ctx); ORB_SLAM2::g_dev.erase(it); }
 }

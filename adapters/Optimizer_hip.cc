@@ -23,10 +23,13 @@
 
 namespace ORB_SLAM2 {
 namespace {
+// One context (device + stream) per CALLING THREAD: a cs_ctx is not thread-safe, and the SLAM system calls into this unit from several threads
+// (tracking, local mapping, the detached global-BA thread).  Created at the thread's first call, destroyed when the thread exits.
+struct ThreadCtx { cs_ctx *c = nullptr; ~ThreadCtx() { if (c) cs_destroy(c); } };
 cs_ctx *shared_ctx() {
-    static cs_ctx *ctx = nullptr;
-    if (!ctx && cs_create(0, &ctx) != CS_OK) throw std::runtime_error("Optimizer (HIP): no device -- there is no CPU path");
-    return ctx;
+    thread_local ThreadCtx t;
+    if (!t.c && cs_create(0, &t.c) != CS_OK) throw std::runtime_error("Optimizer (HIP): no device -- there is no CPU path");
+    return t.c;
 }
 void pose_to_vec7(const cv::Mat &Tcw, double *v) { // SE3Quat::toVector of Converter::toSE3Quat(Tcw): t, then the unit quaternion (x y z w)
     const g2o::SE3Quat q = Converter::toSE3Quat(Tcw);
@@ -217,7 +220,7 @@ void Optimizer::LocalBACameraPointObjects(KeyFrame *pKF, bool *pbStopFlag, Map *
     prm.kitti = scene_unique_id == kitti; prm.build_worldframe_on_ground = build_worldframe_on_ground; prm.fixCamera = fixCamera;
     if (pbStopFlag && *pbStopFlag) return;                                                                                               // :1386-1388
 
-    static cubeslam::Context ctx(0); // throws without a device: there is no CPU path
+    thread_local cubeslam::Context ctx(0); // one per calling thread (LocalMapping); throws without a device: there is no CPU path
     cubeslam::LocalBAResult res;
     // LocalMapping::InterruptBA raises *pbStopFlag from another thread: the flag itself goes down (setForceStopFlag :943-944; re-checked between the stages :1392-1396)
     cubeslam::LocalBACameraPointObjects(ctx, w, prm, res, nullptr, pbStopFlag);

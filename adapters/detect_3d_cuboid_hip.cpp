@@ -13,10 +13,13 @@
 #include "detect_3d_cuboid/object_3d_util.h" // plot_image_with_cuboid (object_3d_util.cpp stays in the reference's library)
 
 namespace {
+// One context (device + stream) per CALLING THREAD: a cs_ctx is not thread-safe, and the SLAM system calls into this unit from several threads
+// (tracking, local mapping, the detached global-BA thread).  Created at the thread's first call, destroyed when the thread exits.
+struct ThreadCtx { cs_ctx *c = nullptr; ~ThreadCtx() { if (c) cs_destroy(c); } };
 cs_ctx *shared_ctx() {
-    static cs_ctx *ctx = nullptr;
-    if (!ctx && cs_create(0, &ctx) != CS_OK) throw std::runtime_error("detect_3d_cuboid (HIP): no device -- there is no CPU path");
-    return ctx;
+    thread_local ThreadCtx t;
+    if (!t.c && cs_create(0, &t.c) != CS_OK) throw std::runtime_error("detect_3d_cuboid (HIP): no device -- there is no CPU path");
+    return t.c;
 }
 } // namespace
 

@@ -18,10 +18,13 @@ namespace {
 struct Dev { cs_ctx *ctx = nullptr; cs_lsd *lsd = nullptr; int w = 0, h = 0; };
 std::mutex g_mu;
 std::map<const line_lbd_detect *, Dev> g_dev;
+// One context (device + stream) per CALLING THREAD: a cs_ctx is not thread-safe, and the SLAM system calls into this unit from several threads
+// (tracking, local mapping, the detached global-BA thread).  Created at the thread's first call, destroyed when the thread exits.
+struct ThreadCtx { cs_ctx *c = nullptr; ~ThreadCtx() { if (c) cs_destroy(c); } };
 cs_ctx *shared_ctx() {
-    static cs_ctx *ctx = nullptr;
-    if (!ctx && cs_create(0, &ctx) != CS_OK) throw std::runtime_error("line_lbd_detect (HIP): no device -- there is no CPU path");
-    return ctx;
+    thread_local ThreadCtx t;
+    if (!t.c && cs_create(0, &t.c) != CS_OK) throw std::runtime_error("line_lbd_detect (HIP): no device -- there is no CPU path");
+    return t.c;
 }
 Dev device_for(const line_lbd_detect *self, int w, int h) {
     std::lock_guard<std::mutex> lk(g_mu);

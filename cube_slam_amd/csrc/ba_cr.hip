@@ -268,8 +268,7 @@ template <int BC> __global__ void __launch_bounds__(64 * ((6 * BC + 63) / 64)) b
 template <int BC> int cr_run(cs_ctx *ctx, const CrView &W) {
     constexpr int NB = 6 * BC, NBP = (NB + 15) / 16 * 16, NCOL = 4 * NB + 1, NT = 256, LDW = 2 * NBP + 1, RPT = (NB + 7) / 8, CPT = (NCOL + 31) / 32;
     const size_t lds = sizeof(double) * (4 * 8 * (size_t)RPT + 4 * 32 * (size_t)CPT + (size_t)NB + (size_t)NBP * LDW);
-    static bool attr = false;
-    if (!attr) { CS_HIP(ctx, hipFuncSetAttribute((const void *)ba_cr_eliminate<BC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); attr = true; }
+    CS_HIP(ctx, hipFuncSetAttribute((const void *)ba_cr_eliminate<BC>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds)); // per device, so on every call (a cheap host-side setting)
     int levels = 0;
     while ((1 << levels) < W.M) levels++;
     for (int l = 0; l < levels; l++) {
@@ -292,7 +291,17 @@ struct BaCr {
     double *buf = nullptr;
 };
 void ba_cr_destroy(BaCr *w) { if (w) { if (w->buf) hipFree(w->buf); delete w; } }
-bool ba_cr_supported(int C, int Bc) { return Bc >= 1 && Bc <= 10 && C >= 4 * Bc; }
+// the elimination kernel of the super-block size the solve would instantiate keeps NBP * LDW + ... doubles in dynamic LDS (77 KB at 10 cameras per
+// super-block): a device that does not offer that much per workgroup takes the band solver instead
+bool ba_cr_supported(int C, int Bc) {
+    if (!(Bc >= 1 && Bc <= 10 && C >= 4 * Bc)) return false;
+    const int BCT = Bc <= 2 ? 2 : Bc <= 4 ? 4 : Bc <= 6 ? 6 : Bc <= 8 ? 8 : 10;
+    const int NB = 6 * BCT, NBP = (NB + 15) / 16 * 16, NCOL = 4 * NB + 1, LDW = 2 * NBP + 1, RPT = (NB + 7) / 8, CPT = (NCOL + 31) / 32;
+    const size_t lds = sizeof(double) * (4 * 8 * (size_t)RPT + 4 * 32 * (size_t)CPT + (size_t)NB + (size_t)NBP * LDW);
+    int dev = 0, cap = 0;
+    if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cap, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) return false;
+    return lds <= (size_t)cap;
+}
 
 // Solves the band system (A, rhs) of C cameras, half bandwidth Bc, into x (6C); *status is set to 1 on a non-positive pivot.
 int ba_cr_solve(cs_ctx *ctx, BaCr **handle, int C, int Bc, const double *d_bandA, const double *d_brhs, double *d_x, int *d_status) {
