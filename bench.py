@@ -351,28 +351,67 @@ def c4_bench(ctx, frames, boxes, yaw_step, steps, with_cpu):
     return out
 
 
-def pcie_inclusive(ctx, scenes, yaw_step, nfeat, n=24):
-    """The drop-in calls, one frame at a time with host buffers in and out (H2D + plan + kernels + D2H): what a ROS node sees per frame."""
+def pcie_inclusive(ctx, scenes, yaw_step, nfeat, n=24, local_rank=0):
+    """The drop-in calls, one frame at a time with host buffers in and out (H2D + plan + kernels + D2H): what a ROS node sees per frame.  One caller
+    thread, every call synchronous like the reference's; then the same calls from T caller threads at once, each with its own context (= stream) and
+    its own extractor / detector objects -- the reference system calls these entry points from several threads (tracking, object thread), a
+    multi-camera node or a bag replayer from as many as it likes.  The per-call breakdown says where a frame's time goes: the LSD region stage
+    (lsd.cpp:637-1136) is a greedy sequence over the frame's seeds and runs on ONE host core below 512 frames per batch."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    from cube_slam_amd import _lib
     from cube_slam_amd.cuboid import detect_3d_cuboid
     from cube_slam_amd.lsd import line_lbd_detect
     from cube_slam_amd.orb import ORBextractor
-    det = detect_3d_cuboid(ctx)
-    det.set_calibration(scenes[0]["K"])
-    det.yaw_step_deg = yaw_step
-    ext = ORBextractor(nfeat, 1.2, 8, 20, 7, 640, 480, ctx=ctx)
-    ll = line_lbd_detect(640, 480, ctx=ctx)
 
-    def one(s):
+    def objects(c):
+        det = detect_3d_cuboid(c)
+        det.set_calibration(scenes[0]["K"])
+        det.yaw_step_deg = yaw_step
+        return det, ORBextractor(nfeat, 1.2, 8, 20, 7, 640, 480, ctx=c), line_lbd_detect(640, 480, ctx=c)
+
+    det, ext, ll = objects(ctx)
+    calls = {"ORBextractor::operator()": 0.0, "detect_raw_lines": 0.0, "get_line_descriptors": 0.0, "detect_cuboid": 0.0}
+
+    def one(s, det=det, ext=ext, ll=ll, acc=None):
+        t0 = time.perf_counter()
         ext(s["gray"])
+        t1 = time.perf_counter()
         kl = ll.detect_raw_lines(s["gray"])
+        t2 = time.perf_counter()
         ll.get_line_descriptors(s["gray"], kl)
+        t3 = time.perf_counter()
         det.detect_cuboid(s["gray"], s["Twc"], s["boxes"], s["lines"])
+        t4 = time.perf_counter()
+        if acc is not None:
+            for k, v in zip(acc, (t1 - t0, t2 - t1, t3 - t2, t4 - t3)):
+                acc[k] += v
     one(scenes[0])
     t0 = time.perf_counter()
     for i in range(n):
-        one(scenes[i % len(scenes)])
+        one(scenes[i % len(scenes)], acc=calls)
     dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "frames/s", "ms_per_frame": 1e3 * dt / n, "sample": "%d frames, ORBextractor::operator() + detect_raw_lines + LBD + detect_cuboid per frame, host in / host out" % n}
+    out = {"value": n / dt, "unit": "frames/s", "ms_per_frame": 1e3 * dt / n, "callers": 1,
+           "ms_per_call": {k: round(1e3 * v / n, 3) for k, v in calls.items()},
+           "sample": "%d frames, ORBextractor::operator() + detect_raw_lines + LBD + detect_cuboid per frame, host in / host out, one caller thread" % n}
+    T = min(16, _lib.lib().cs_host_thread_count())
+    if T > 1:
+        ctxs = [_lib.Context(local_rank) for _ in range(T)]
+        objs = [objects(c) for c in ctxs]
+        for o in objs:
+            one(scenes[0], *o)
+        per = max(8, n // 2)
+
+        def worker(t):
+            for i in range(per):
+                one(scenes[(t + i * T) % len(scenes)], *objs[t])
+        t0 = time.perf_counter()
+        with ThreadPoolExecutor(T) as ex:
+            list(ex.map(worker, range(T)))
+        dtm = time.perf_counter() - t0
+        out["multi_caller"] = {"value": T * per / dtm, "unit": "frames/s", "callers": T,
+                               "sample": "%d caller threads x %d frames, each thread its own context and objects, every call synchronous" % (T, per)}
+    return out
 
 
 def main():
@@ -510,9 +549,9 @@ def main():
         tr = measure_traffic("cuboid_sweep_score", "pmc_run.py", [args.frames, args.boxes, args.yaw_step, BG_TEXTURE])
         if not args.no_cpu:
             native_oracle()  # the c3 / c4 CPU legs use the -march=native build too
-        extra["c3"] = c3_bench(ctx, 24, 3, with_cpu=not args.no_cpu)
+        extra["c3"] = c3_bench(ctx, 2 * _lib.lib().cs_host_thread_count(), 3, with_cpu=not args.no_cpu)  # a stream window of two frames per host thread (the region stage's workers)
         extra["c4"] = c4_bench(ctx, 64, 8, args.yaw_step, 10, with_cpu=not args.no_cpu)
-        extra["pcie_inclusive"] = pcie_inclusive(ctx, scenes, args.yaw_step, args.orb_features)
+        extra["pcie_inclusive"] = pcie_inclusive(ctx, scenes, args.yaw_step, args.orb_features, local_rank=local_rank)
     else:
         tr = None
     ba_out = None

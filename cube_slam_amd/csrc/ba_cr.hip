@@ -298,9 +298,10 @@ bool ba_cr_supported(int C, int Bc) {
     const int BCT = Bc <= 2 ? 2 : Bc <= 4 ? 4 : Bc <= 6 ? 6 : Bc <= 8 ? 8 : 10;
     const int NB = 6 * BCT, NBP = (NB + 15) / 16 * 16, NCOL = 4 * NB + 1, LDW = 2 * NBP + 1, RPT = (NB + 7) / 8, CPT = (NCOL + 31) / 32;
     const size_t lds = sizeof(double) * (4 * 8 * (size_t)RPT + 4 * 32 * (size_t)CPT + (size_t)NB + (size_t)NBP * LDW);
-    int dev = 0, cap = 0;
+    int dev = 0, cap = 0, optin = 0;
     if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&cap, hipDeviceAttributeMaxSharedMemoryPerBlock, dev) != hipSuccess) return false;
-    return lds <= (size_t)cap;
+    if (hipDeviceGetAttribute(&optin, hipDeviceAttributeSharedMemPerBlockOptin, dev) != hipSuccess) optin = 0; // what hipFuncSetAttribute can raise a kernel to
+    return lds <= (size_t)std::max(cap, optin);
 }
 
 // Solves the band system (A, rhs) of C cameras, half bandwidth Bc, into x (6C); *status is set to 1 on a non-positive pivot.

@@ -663,18 +663,22 @@ static int lsd_run(cs_ctx *ctx, cs_lsd *l, int with_lbd) {
     if (with_lbd && !maps_done) { r = lbd_maps(); if (r) return r; } // they run while the host grows regions
     CS_HIP(ctx, hipEventSynchronize(ev));
     ctx->pool.push_back(ev);
-    // one host stage at a time per process: two line detectors that alternate batches (bench.py) overlap their GPU phases with
-    // the other's region growing instead of splitting the host cores between two OpenMP teams
+    // one BATCHED host stage at a time per process: two line detectors that alternate batches (bench.py) overlap their GPU phases with
+    // the other's region growing instead of splitting the host cores between two OpenMP teams.  A single frame (the drop-in call of one
+    // camera frame) is one core's work: it runs on the calling thread, outside the lock and without a team, so that callers on several
+    // threads (each with its own context) grow their frames side by side.
     if (!on_device) {
     static std::mutex host_stage;
-    std::unique_lock<std::mutex> host_lock(host_stage);
+    std::unique_lock<std::mutex> host_lock(host_stage, std::defer_lock);
+    const bool solo = F == 1;
+    if (!solo) host_lock.lock();
     const auto t0 = std::chrono::steady_clock::now();
     l->keylines.assign((size_t)F, {});
     std::vector<int> lpt((size_t)F);
     for (int f = 0; f < F; f++) lpt[f] = f;
     std::stable_sort(lpt.begin(), lpt.end(), [&](int a, int b) { return l->frame_base[a + 1] - l->frame_base[a] > l->frame_base[b + 1] - l->frame_base[b]; });
-    cs_omp_prepare();
-#pragma omp parallel num_threads(std::max(1, std::min(ctx->host_threads, F)))
+    if (!solo) cs_omp_prepare();
+#pragma omp parallel num_threads(std::max(1, std::min(ctx->host_threads, F))) if (!solo)
     {
         LsdHost host;
         host.timed = ctx->timing;
@@ -697,7 +701,7 @@ static int lsd_run(cs_ctx *ctx, cs_lsd *l, int with_lbd) {
         }
     }
     if (ctx->timing) { auto &rec = ctx->timings["host_lsd_regions"]; rec.total_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(); rec.count++; }
-    host_lock.unlock();
+    if (!solo) host_lock.unlock();
     } else {
         l->keylines.assign((size_t)F, {});
         cs_omp_prepare();
