@@ -1632,6 +1632,8 @@ struct cs_cuboid_batch {
     Opts o{};
     Calib cal{};
     std::vector<Unit> units;
+    std::vector<FrameInfo> fi;   // host copy (cs_cuboid_batch_set_lines rewrites the line ranges)
+    long cap_lines_in = 0, cap_line_rows = 0;
     std::vector<int> box_first_unit;
     long pix_total = 0, hyp_total = 0, vp_total = 0, line_rows = 0;
     int max_tiles = 0, max_cc_blocks = 0, max_vp_blocks = 0, blocks_per_unit = 0, max_roi_w = 0;
@@ -1703,7 +1705,8 @@ int cs_cuboid_batch_create(cs_ctx *ctx, int n_frames, int width, int height, con
     }
     const int n_boxes = box_offsets[n_frames], n_lines = line_offsets[n_frames];
     b->n_boxes = n_boxes;
-    std::vector<FrameInfo> fi(n_frames);
+    std::vector<FrameInfo> &fi = b->fi;
+    fi.resize(n_frames);
     for (int f = 0; f < n_frames; f++) {
         for (int i = 0; i < 16; i++) fi[f].T[i] = Twc[(long)f * 16 + i];
         host_euler_from_T(fi[f].T, fi[f].euler);
@@ -1823,6 +1826,7 @@ int cs_cuboid_batch_create(cs_ctx *ctx, int n_frames, int width, int height, con
     A_(cs_dalloc(ctx, &b->d_mlines, (size_t)b->line_rows * 4));
     A_(cs_dalloc(ctx, &b->d_mangle, (size_t)b->line_rows));
     A_(cs_dalloc(ctx, &b->d_mmid, (size_t)b->line_rows * 2));
+    b->cap_lines_in = n_lines; b->cap_line_rows = b->line_rows;
     A_(cs_dalloc(ctx, &b->d_units, (size_t)b->n_units));
     A_(cs_dalloc(ctx, &b->d_ud, (size_t)b->n_units));
     A_(cs_dalloc(ctx, &b->d_box_first, (size_t)n_boxes));
@@ -1848,6 +1852,40 @@ int cs_cuboid_batch_create(cs_ctx *ctx, int n_frames, int width, int height, con
     { hipError_t e = hipStreamSynchronize(ctx->stream); if (e != hipSuccess) { ctx->err = hipGetErrorString(e); cs_cuboid_batch_destroy(ctx, b); return CS_ERR_HIP; } }
 #undef A_
     *out = b;
+    return CS_OK;
+}
+
+// New edge lists for the frames of an existing batch (same frames, boxes and options): what a step of the chain detect_filter_lines ->
+// detect_cuboid (main_obj.cpp:428-449) hands over when the frames stay resident.  Only the line ranges of the plan change.
+int cs_cuboid_batch_set_lines(cs_ctx *ctx, cs_cuboid_batch *b, const int *line_offsets, const double *lines) {
+    if (!ctx || !b || !line_offsets || (line_offsets[b->n_frames] > 0 && !lines)) return CS_ERR_BAD_ARG;
+    CS_HIP(ctx, hipSetDevice(ctx->device));
+    CS_HIP(ctx, hipStreamSynchronize(ctx->stream)); // (a run still reading the old lists)
+    const int n_lines = line_offsets[b->n_frames];
+    for (int f = 0; f < b->n_frames; f++) { b->fi[f].line_off = line_offsets[f]; b->fi[f].n_lines = line_offsets[f + 1] - line_offsets[f]; }
+    long rows = 0;
+    for (Unit &U : b->units) { U.line_off = (int)rows; rows += std::min(b->fi[U.frame].n_lines, CS_MAX_ROI_LINES); if (rows > INT_MAX) return CS_ERR_CAPACITY; }
+    b->line_rows = rows;
+    int r;
+    if (n_lines > b->cap_lines_in) {
+        hipFree(b->d_lines_in); hipFree(b->d_lines_al); b->d_lines_in = b->d_lines_al = nullptr;
+        const size_t cap = (size_t)n_lines + n_lines / 4 + 64;
+        r = cs_dalloc(ctx, &b->d_lines_in, cap * 4); if (r) return r;
+        r = cs_dalloc(ctx, &b->d_lines_al, cap * 4); if (r) return r;
+        b->cap_lines_in = (long)cap;
+    }
+    if (rows > b->cap_line_rows) {
+        hipFree(b->d_mlines); hipFree(b->d_mangle); hipFree(b->d_mmid); b->d_mlines = b->d_mangle = b->d_mmid = nullptr;
+        const size_t cap = (size_t)rows + rows / 4 + 64;
+        r = cs_dalloc(ctx, &b->d_mlines, cap * 4); if (r) return r;
+        r = cs_dalloc(ctx, &b->d_mangle, cap); if (r) return r;
+        r = cs_dalloc(ctx, &b->d_mmid, cap * 2); if (r) return r;
+        b->cap_line_rows = (long)cap;
+    }
+    if (n_lines > 0) { r = cs_h2d(ctx, b->d_lines_in, lines, (size_t)n_lines * 4); if (r) return r; }
+    r = cs_h2d(ctx, b->d_fi, b->fi.data(), (size_t)b->n_frames); if (r) return r;
+    r = cs_h2d(ctx, b->d_units, b->units.data(), (size_t)b->n_units); if (r) return r;
+    CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return CS_OK;
 }
 

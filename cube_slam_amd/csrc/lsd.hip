@@ -824,6 +824,24 @@ int cs_lsd_detect_filter_lines(cs_ctx *ctx, cs_lsd *l, const uint8_t *gray, int 
     return status;
 }
 
+// filter_lines (:200-207) + keylines_to_mat (:26-36) over the KeyLines of the last cs_lsd_run of the resident frames: what detect_filter_lines returns,
+// without a second pass over the images (the chain's hand-over to cs_cuboid_batch_set_lines)
+int cs_lsd_read_filter_lines(cs_ctx *ctx, cs_lsd *l, float length_thres, float *lines, int cap, int *counts) {
+    if (!ctx || !l || !lines || !counts || cap < 1) return CS_ERR_BAD_ARG;
+    int status = CS_OK;
+    for (size_t f = 0; f < l->keylines.size(); f++) {
+        int n = 0;
+        for (const cs_keyline &k : l->keylines[f])
+            if (k.octave == 0 && k.lineLength > length_thres) {
+                if (n < cap) { float *o = lines + (f * cap + n) * 4; o[0] = k.startPointX * 1.f; o[1] = k.startPointY * 1.f; o[2] = k.endPointX * 1.f; o[3] = k.endPointY * 1.f; }
+                n++;
+            }
+        counts[f] = std::min(n, cap);
+        if (n > cap) status = CS_ERR_CAPACITY;
+    }
+    return status;
+}
+
 int cs_lsd_upload(cs_ctx *ctx, cs_lsd *l, const uint8_t *gray, int n_frames, int stride) {
     int r = lsd_upload(ctx, l, gray, n_frames, stride); if (r) return r;
     CS_HIP(ctx, hipStreamSynchronize(ctx->stream));

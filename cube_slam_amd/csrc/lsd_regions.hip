@@ -46,6 +46,9 @@ __device__ double rg_log_gamma(double x) { // lsd.cpp:70,124-160
     for (int n = 0; n < 7; ++n) { a -= log(x + double(n)); b += q[n] * pow(x, double(n)); }
     return a + log(b);
 }
+#ifndef RG_IMPROVE_WAVES
+#define RG_IMPROVE_WAVES 3 // waves per SIMD the register allocation of lsd_rg_improve aims at (latency-bound: pixel gathers and double transcendentals; measured 9.1 / 7.2 / 8.3 ms per 1024 frames at 2 / 3 / 4)
+#endif
 constexpr int LG_N = 32768; // log_gamma of the integers below this: a table filled by the same function (its arguments are pixel counts; each call costs 16 log + 14 pow)
 __global__ void __launch_bounds__(256) lsd_rg_lgamma_table(double *t) { const int i = blockIdx.x * 256 + threadIdx.x; if (i < LG_N) t[i] = i > 0 ? rg_log_gamma(double(i)) : 0.0; }
 __device__ __forceinline__ double rg_lgam_int(int x, const double *lgt) { return (lgt && x > 0 && x < LG_N) ? lgt[x] : rg_log_gamma(double(x)); }
@@ -233,7 +236,7 @@ __global__ void __launch_bounds__(1024) lsd_rg_cand_scan(const int *cand_cnt, in
     if (t == 1023) cand_base[F] = part[1023];
 }
 // rect_improve + the NFA test (lsd.cpp:873-975, :503-505) of one rectangle per wave; line[k] / has[k] in the order of the scan above
-__global__ void __launch_bounds__(256) lsd_rg_improve(SeqParams P, const int *cand_base, int n_cand, const double *lgt, float4 *line, uint8_t *has) {
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RG_IMPROVE_WAVES, RG_IMPROVE_WAVES))) lsd_rg_improve(SeqParams P, const int *cand_base, int n_cand, const double *lgt, float4 *line, uint8_t *has) {
     const int wv = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
     if (wv >= n_cand) return;
     int lo = 0, hi = P.F; // the frame: cand_base[f] <= wv < cand_base[f + 1]

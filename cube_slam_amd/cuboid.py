@@ -125,6 +125,14 @@ class CuboidBatch:
                                          C.byref(opts), C.byref(self._b))
         check(ctx.ptr, r, "cs_cuboid_batch_create")
 
+    def set_lines(self, lines_list):
+        """New edge lists (one (m, 4) array per frame) for the resident frames: the hand-over of detect_filter_lines -> detect_cuboid."""
+        lo = np.zeros(self.F + 1, np.int32)
+        for f in range(self.F):
+            lo[f + 1] = lo[f] + len(lines_list[f])
+        lines = np.ascontiguousarray(np.concatenate([np.asarray(l, np.float64).reshape(-1, 4) for l in lines_list] + [np.zeros((1, 4))]))
+        check(self.ctx.ptr, lib().cs_cuboid_batch_set_lines(self.ctx.ptr, self._b, _p(lo, C.c_int), _p(lines, C.c_double)), "cs_cuboid_batch_set_lines")
+
     def run(self):
         check(self.ctx.ptr, lib().cs_cuboid_batch_run(self.ctx.ptr, self._b), "cs_cuboid_batch_run")
 

@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define CS_VERSION 101 /* 101: cs_ba_set_stop_flag_bool / cs_ba_dyn_set_stop_flag_bool; cs_match_by_projection_frame takes train_blocked */
+#define CS_VERSION 102 /* 102: cs_cuboid_batch_set_lines, cs_lsd_read_filter_lines; 101: cs_ba_set_stop_flag_bool / cs_ba_dyn_set_stop_flag_bool; cs_match_by_projection_frame takes train_blocked */
 
 typedef enum cs_status {
     CS_OK = 0,
@@ -133,6 +133,9 @@ int cs_cuboid_batch_create(cs_ctx *ctx, int n_frames, int width, int height, con
                            const int *line_offsets, const double *lines, const cs_cuboid_opts *opts,
                            cs_cuboid_batch **out);
 int cs_cuboid_batch_run(cs_ctx *ctx, cs_cuboid_batch *b);
+/* New edge lists (line_offsets[n_frames + 1], lines m x 4 as in cs_cuboid_batch_create) for the frames of an existing batch: the hand-over of the
+ * chain detect_filter_lines -> detect_cuboid (main_obj.cpp:428-449) when frames and boxes stay resident. */
+int cs_cuboid_batch_set_lines(cs_ctx *ctx, cs_cuboid_batch *b, const int *line_offsets, const double *lines);
 /* out: total_boxes * max_cuboid_num, counts: total_boxes */
 int cs_cuboid_batch_read(cs_ctx *ctx, cs_cuboid_batch *b, cs_cuboid *out, int *counts);
 void cs_cuboid_batch_destroy(cs_ctx *ctx, cs_cuboid_batch *b);
@@ -389,6 +392,8 @@ int cs_lsd_detect(cs_ctx *ctx, cs_lsd *l, const uint8_t *gray, int n_frames, int
 /* detect_filter_lines(gray, linesmat): octave 0, lineLength > length_thres; lines: [f][cap_per_frame][4] floats (CV_32F N x 4) */
 int cs_lsd_detect_filter_lines(cs_ctx *ctx, cs_lsd *l, const uint8_t *gray, int n_frames, int stride, float length_thres,
                                float *lines, int cap_per_frame, int *counts);
+/* the same rows from the KeyLines of the last cs_lsd_run over the resident frames (counts[f] rows of frame f at lines + f * cap * 4) */
+int cs_lsd_read_filter_lines(cs_ctx *ctx, cs_lsd *l, float length_thres, float *lines, int cap, int *counts);
 /* introspection after a detect call: scaled image, gradient norm and level-line angle maps (sw x sh doubles each) */
 int cs_lsd_get_maps(cs_ctx *ctx, cs_lsd *l, int frame, double *scaled, double *modgrad, double *angles, int *sw, int *sh);
 

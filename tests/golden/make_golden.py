@@ -99,7 +99,7 @@ def object_slam_seq():
         T[:3, 3] = p[1:4]
         return T
     opts = dict(whether_sample_bbox_height=0, nominal_skew_ratio=2.0, max_cuboid_num=1)  # main_obj.cpp:359-360
-    keep = {0, 4, 20, 40}
+    keep = set(range(len(rows)))  # every frame of the sequence (round 3: the chain detect_filter_lines -> detect_cuboid is run on all of them on the device)
     ours, boxes, Twcs, grays, n_lines = [], [], [], {}, []
     for r, row in enumerate(rows):
         f = int(row[0])

@@ -165,3 +165,27 @@ def test_score_paths_agree(ctx, oracle, monkeypatch):
     for s, bx in zip(scenes, boxes):
         ref += oracle.detect_cuboid(s["gray"], scenes[0]["K"], s["Twc"], bx, s["lines"], opts=oo)[0]
     _cmp_cuboids(out["default"], ref)
+
+
+def test_set_lines_equals_a_fresh_batch(ctx):
+    """cs_cuboid_batch_set_lines: new edge lists for resident frames (longer and shorter than the ones the batch was created with) give the
+    cuboids of a batch created with them."""
+    det = detect_3d_cuboid(ctx)
+    det.yaw_step_deg = 3.0
+    scenes = [synth.cuboid_scene(300 + i, n_boxes=3) for i in range(3)]
+    det.set_calibration(scenes[0]["K"])
+    args = (np.stack([s["gray"] for s in scenes]), scenes[0]["K"], np.stack([s["Twc"] for s in scenes]), [s["boxes"] for s in scenes])
+    rng = np.random.default_rng(5)
+    variants = [[s["lines"] for s in scenes], [s["lines"][::3] for s in scenes], [np.concatenate([s["lines"], rng.uniform(0, 470, (300, 4))]) for s in scenes]]
+    b = CuboidBatch(ctx, *args, variants[1], det.opts())
+    for v in (variants[0], variants[2], variants[1]):
+        b.set_lines(v)
+        b.run()
+        got = b.read()
+        f = CuboidBatch(ctx, *args, v, det.opts())
+        f.run()
+        ref = f.read()
+        f.close()
+        for a, c in zip(got, ref):
+            assert len(a) == len(c) and np.array_equal(np.asarray(a).view(np.uint8), np.asarray(c).view(np.uint8))
+    b.close()
