@@ -10,7 +10,8 @@ collective, weak scaling).  The same JSON line carries, measured in the same run
   "ba"   the second half of BASELINE's metric (LM iterations/s of the object BA at 1000 key frames),
   "c3"   config 3: the 1241x376 stream, 2000 ORB features + LSD/LBD + frame-to-frame SearchByProjection, with the matcher's own roofline,
   "c4"   config 4's per-GPU share: 64 frames x 8 boxes through the cuboid path,
-  "pcie_inclusive"  the drop-in calls frame by frame, host buffers in and out,
+  "chained"  the reference's chain: detect_cuboid fed the lines detect_filter_lines found in the same step,
+  "pcie_inclusive"  the drop-in calls frame by frame, host buffers in and out (one caller thread, and sixteen),
   "cpu_baseline" / "cpu_baseline_mt"  the CPU port (oracle, built -march=native on this box) on 1 thread / frame-parallel on the host cores.
 """
 import argparse
@@ -351,6 +352,34 @@ def c4_bench(ctx, frames, boxes, yaw_step, steps, with_cpu):
     return out
 
 
+def chained_bench(ctx, ctx_line, orb, lsd, batch, scenes, frames, steps):
+    """The reference's chain (main_obj.cpp:428-449) with the frames resident: every step's detect_cuboid is fed the lines detect_filter_lines
+    found in THAT step (cs_lsd_read_filter_lines -> cs_cuboid_batch_set_lines), beside ORB extraction.  One stream of dependent stages, no
+    overlap between steps: the hand-over goes through the host (KeyLines are assembled there), so this is a lower bound of a chained runner."""
+    lsd.line_length_thres = 15.0  # main_obj.cpp:366
+
+    def step():
+        lsd.run(True)
+        ctx_line.sync()
+        lines = lsd.read_filter_lines(frames)
+        batch.set_lines(lines)
+        if orb is not None:
+            orb.run()
+        batch.run()
+        return lines
+    lines = step()
+    ctx.sync()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step()
+    ctx.sync()
+    dt = time.perf_counter() - t0
+    n_out = sum(len(g) for g in batch.read())
+    batch.set_lines([s["lines"] for s in scenes])  # back to the decoupled edge lists
+    return {"value": frames * steps / dt, "unit": "frames/s", "ms_per_step": 1e3 * dt / steps, "frames": frames, "steps": steps, "lines_per_frame_handed_over": sum(len(l) for l in lines) / frames,
+            "cuboids_out": n_out, "note": "ORB + LSD/LBD + detect_cuboid fed this step's detect_filter_lines output (length > 15), stages in sequence on one stream"}
+
+
 def pcie_inclusive(ctx, scenes, yaw_step, nfeat, n=24, local_rank=0):
     """The drop-in calls, one frame at a time with host buffers in and out (H2D + plan + kernels + D2H): what a ROS node sees per frame.  One caller
     thread, every call synchronous like the reference's; then the same calls from T caller threads at once, each with its own context (= stream) and
@@ -551,6 +580,8 @@ def main():
             native_oracle()  # the c3 / c4 CPU legs use the -march=native build too
         extra["c3"] = c3_bench(ctx, 2 * _lib.lib().cs_host_thread_count(), 3, with_cpu=not args.no_cpu)  # a stream window of two frames per host thread (the region stage's workers)
         extra["c4"] = c4_bench(ctx, 64, 8, args.yaw_step, 10, with_cpu=not args.no_cpu)
+        if lsd is not None:
+            extra["chained"] = chained_bench(ctx, ctx_lines[0], orb, lsd, batch, scenes, args.frames, 3)
         extra["pcie_inclusive"] = pcie_inclusive(ctx, scenes, args.yaw_step, args.orb_features, local_rank=local_rank)
     else:
         tr = None

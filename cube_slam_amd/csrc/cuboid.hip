@@ -1145,27 +1145,33 @@ template <int CFG, bool HYB, bool LEAN> __device__ __forceinline__ void sc_score
 
 template <int NT>
 __global__ void __launch_bounds__(NT) cuboid_sweep_score(const Unit *units, const int *order, int n_items, int n_slices, int *cursor, const VPEntry *vpt, const float *dist,
-                                                         const int *vcount, const int *vlist, int *uflag, double *derr, double *aerr) {
+                                                         const int *vcount, const int *vlist, int *uflag, double *derr, double *aerr, unsigned long long *prof) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sc_mem[];
-    int *ctrl = reinterpret_cast<int *>(sc_mem); // [0] task counter, [2] escape flag of the unit being copied, [4], [5] next item (alternating)
+    // (development, CUBESLAM_SCORE_PROF) wall-clock ticks of this wave in the three parts of a unit: copy + encode, scoring tasks, waiting at the barriers
+    unsigned long long t_copy = 0, t_task = 0, t_wait = 0, t_mark = prof ? wall_clock64() : 0, n_task = 0;
+    auto lap = [&](unsigned long long &acc) { if (prof) { const unsigned long long t = wall_clock64(); acc += t - t_mark; t_mark = t; } };
+    int *ctrl = reinterpret_cast<int *>(sc_mem); // control words, see the loop
     unsigned short *lut = reinterpret_cast<unsigned short *>(sc_mem + SC_CTRL_BYTES);
     unsigned short *lmap = reinterpret_cast<unsigned short *>(sc_mem + SC_MAP_OFF);
     const int tid = threadIdx.x, lane = tid & 63;
     for (int i = tid; i < SC_LUT_N; i += NT) lut[i] = 0;
-    if (tid == 0) { ctrl[2] = 0; ctrl[5] = atomicAdd(cursor, 1); }
+    if (tid == 0) { ctrl[2] = 0; ctrl[3] = 0; ctrl[5] = atomicAdd(cursor, 1); }
     __syncthreads();
     if (tid < 256) { const int j = tid, r = (j * DT_DIAG) % DT_HV; lut[r >> 6] = (unsigned short)((j << 8) - (j * DT_DIAG) / DT_HV); }
     __syncthreads();
     int item = __builtin_amdgcn_readfirstlane(ctrl[5]); // (uniform by construction; tell the compiler: the unit's fields then live in scalar registers)
     constexpr bool LEAN = NT >= 1024;
     constexpr int NPF = NT >= 768 ? 4 : 8; // groups of 8 pixels (two 16-byte loads) per thread in flight while a map is copied
+    auto unit_of = [&](int itm, int &uu, int &sl) { uu = __builtin_amdgcn_readfirstlane(order[n_slices == 1 ? itm : itm / n_slices]); sl = n_slices == 1 ? 0 : itm % n_slices; };
     for (int it = 0; item < n_items; it++) {
-        const int u = __builtin_amdgcn_readfirstlane(order[n_slices == 1 ? item : item / n_slices]), slice = n_slices == 1 ? 0 : item % n_slices;
+        int u, slice;
+        unit_of(item, u, slice);
         const Unit &U = units[u];
         const int c1 = vcount[2 * u], c2 = vcount[2 * u + 1];
         const int n1 = sc_tasks(c1), nt = n1 + sc_tasks(c2);
         const bool work = slice < nt;
-        if (tid == 0) { ctrl[4 + (it & 1)] = atomicAdd(cursor, 1); ctrl[0] = slice; }
+        // ctrl: [0] task counter; [2], [3] "a pixel without a code" of the unit being copied, by iteration parity; [4], [5] the next item, likewise
+        if (tid == 0) { ctrl[4 + (it & 1)] = atomicAdd(cursor, 1); ctrl[0] = slice; ctrl[2 + ((it + 1) & 1)] = 0; }
         const int A = U.roi_w * U.roi_h;
         const bool fits = score_unit_fits(U.roi_w, U.roi_h); // else: the first n_res pixels are resident, the tail is read from the float map
         int n_res = fits ? A : (SC_MAP_ENTRIES & ~7);
@@ -1175,30 +1181,43 @@ __global__ void __launch_bounds__(NT) cuboid_sweep_score(const Unit *units, cons
             const float4 *dm4 = reinterpret_cast<const float4 *>(gdist);
             uint4 *lm4 = reinterpret_cast<uint4 *>(lmap);
             bool esc = false;
+            // D2 (unchecked dist_map.at on x == w / y == h): the w + 2 entries after the map repeat its last pixel, written in this same phase
+            const float dlast = gdist[A - 1];
+            const unsigned lastc = sc_encode2(dlast, dlast, lut, esc);
+            auto consume = [&](const float4 (&pa)[NPF], const float4 (&pb)[NPF], int k0) {
+#pragma unroll
+                for (int r = 0; r < NPF; r++) {
+                    const int k = min(k0 + r * NT, A8 - 1);
+                    // (the padding of a slice past its A pixels is zero: cs_cuboid_batch_create clears the arena once and nothing writes there)
+                    uint4 c = make_uint4(sc_encode2(pa[r].x, pa[r].y, lut, esc), sc_encode2(pa[r].z, pa[r].w, lut, esc), sc_encode2(pb[r].x, pb[r].y, lut, esc), sc_encode2(pb[r].z, pb[r].w, lut, esc));
+                    if (fits && 8 * k + 8 > A) { // the group that holds the end of the map: the entries past it are the last pixel's
+                        unsigned w4[4] = {c.x, c.y, c.z, c.w};
+#pragma unroll
+                        for (int i = 0; i < 8; i++) if (8 * k + i >= A) w4[i >> 1] = (i & 1) ? (w4[i >> 1] & 0xffffu) | (lastc & 0xffff0000u) : (w4[i >> 1] & 0xffff0000u) | (lastc & 0xffffu);
+                        c = make_uint4(w4[0], w4[1], w4[2], w4[3]);
+                    }
+                    lm4[k] = c;
+                }
+            };
+            // (requesting the next unit's first groups before the end-of-unit barrier was measured: the copy phase fell from 135 to 118 us per wave and the
+            // tasks grew by as much -- the phase is bound by the encoder's VALU + table work and the CU's share of the memory system, not by one round trip)
 #pragma unroll 1
             for (int k0 = tid; k0 < A8; k0 += NPF * NT) {
                 float4 pa[NPF], pb[NPF];
 #pragma unroll
                 for (int r = 0; r < NPF; r++) { const int k = min(k0 + r * NT, A8 - 1); pa[r] = dm4[2 * k]; pb[r] = dm4[2 * k + 1]; } // branch-free: a tail thread re-copies the last group
-#pragma unroll
-                for (int r = 0; r < NPF; r++) {
-                    const int k = min(k0 + r * NT, A8 - 1);
-                    // (the padding of a slice past its A pixels is zero: cs_cuboid_batch_create clears the arena once and nothing writes there)
-                    lm4[k] = make_uint4(sc_encode2(pa[r].x, pa[r].y, lut, esc), sc_encode2(pa[r].z, pa[r].w, lut, esc), sc_encode2(pb[r].x, pb[r].y, lut, esc), sc_encode2(pb[r].z, pb[r].w, lut, esc));
-                }
+                consume(pa, pb, k0);
             }
-            if (esc) atomicOr(&ctrl[2], 1);
+            if (fits) for (int k = 8 * A8 + tid; k < A + max(U.roi_w + 2, 8); k += NT) lmap[k] = (unsigned short)lastc;
+            if (esc) atomicOr(&ctrl[2 + (it & 1)], 1);
         }
+        lap(t_copy);
         __syncthreads();
+        lap(t_wait);
         const int next = __builtin_amdgcn_readfirstlane(ctrl[4 + (it & 1)]);
-        const bool escape = __builtin_amdgcn_readfirstlane(ctrl[2]) != 0; // a pixel without a code: the whole unit samples the float map
+        const bool escape = __builtin_amdgcn_readfirstlane(ctrl[2 + (it & 1)]) != 0; // a pixel without a code: the whole unit samples the float map
         if (work) {
-            if (fits && !escape) {
-                const unsigned short lastc = lmap[A - 1];
-                for (int k = tid; k < max(U.roi_w + 2, 8); k += NT) lmap[A + k] = lastc; // D2: indices past the map read its last pixel
-            }
-            __syncthreads();
-            if (tid == 0) { ctrl[2] = 0; if (slice == 0) uflag[u] = escape ? 1 : 0; }
+            if (tid == 0 && slice == 0) uflag[u] = escape ? 1 : 0;
             if (escape) n_res = 0;
 #ifdef NO_HYB
             const bool hyb = false;
@@ -1210,6 +1229,7 @@ __global__ void __launch_bounds__(NT) cuboid_sweep_score(const Unit *units, cons
                 if (lane == 0) t = atomicAdd(&ctrl[0], n_slices);
                 t = __builtin_amdgcn_readfirstlane(t);
                 if (t >= nt) break;
+                n_task++;
                 if (!hyb) {
                     if (t < n1) sc_score_task<1, false, LEAN>(U, t << 6, c1, lane, vpt, vlist, lmap, gdist, n_res, derr, aerr);
                     else sc_score_task<2, false, LEAN>(U, (t - n1) << 6, c2, lane, vpt, vlist, lmap, gdist, n_res, derr, aerr);
@@ -1218,10 +1238,13 @@ __global__ void __launch_bounds__(NT) cuboid_sweep_score(const Unit *units, cons
                     else sc_score_task<2, true, LEAN>(U, (t - n1) << 6, c2, lane, vpt, vlist, lmap, gdist, n_res, derr, aerr);
                 }
             }
+            lap(t_task);
             __syncthreads(); // every wave is done with this unit's map
+            lap(t_wait);
         }
         item = next;
     }
+    if (prof && lane == 0) { unsigned long long *o = prof + ((size_t)blockIdx.x * (NT / 64) + (tid >> 6)) * 4; o[0] = t_copy; o[1] = t_task; o[2] = t_wait; o[3] = n_task; }
 }
 
 // ------------------------------------------------------------------------------------------------ selection
@@ -1644,6 +1667,7 @@ struct cs_cuboid_batch {
     int *d_dttmp = nullptr; long *d_dttmp_off = nullptr;
     int *d_order = nullptr, *d_cursor = nullptr; // cuboid_sweep_score: units by falling cost estimate, the work cursor
     int *d_uflag = nullptr;                      // per unit: 1 = a pixel without a 16-bit code (scored from the float map)
+    unsigned long long *d_prof = nullptr;        // CUBESLAM_SCORE_PROF: per wave {copy, tasks, barrier wait} ticks and task count of the last launch
     int score_G = 256;      // workgroups of cuboid_sweep_score (one per CU)
     int score_T = 512;      // threads per workgroup (CUBESLAM_SCORE_THREADS = 512 | 768 | 1024: 2 / 3 / 4 waves per SIMD with 256 / 168 / 128 registers)
     int score_slices = 1;   // items per unit (more than one when there are fewer units than CUs)
@@ -1673,7 +1697,7 @@ void cs_cuboid_batch_destroy(cs_ctx *ctx, cs_cuboid_batch *b) {
     if (ctx) { hipSetDevice(ctx->device); hipStreamSynchronize(ctx->stream); }
     void *ptrs[] = {b->d_gray, b->d_emap, b->d_flag, b->d_dist, b->d_dttmp, b->d_dttmp_off, b->d_fi, b->d_fd, b->d_cam, b->d_yaw, b->d_lines_in, b->d_lines_al,
                     b->d_mlines, b->d_mangle, b->d_mmid, b->d_units, b->d_ud, b->d_box_first, b->d_status, b->d_counts, b->d_vp,
-                    b->d_derr, b->d_aerr, b->d_score, b->d_nscore, b->d_ckd, b->d_cka, b->d_cidx, b->d_out, b->d_vcount, b->d_vlist, b->d_order, b->d_cursor, b->d_uflag};
+                    b->d_derr, b->d_aerr, b->d_score, b->d_nscore, b->d_ckd, b->d_cka, b->d_cidx, b->d_out, b->d_vcount, b->d_vlist, b->d_order, b->d_cursor, b->d_uflag, b->d_prof};
     for (void *p : ptrs) if (p) hipFree(p);
     delete b;
 }
@@ -1813,6 +1837,7 @@ int cs_cuboid_batch_create(cs_ctx *ctx, int n_frames, int width, int height, con
         A_(cs_h2d(ctx, b->d_order, order.data(), order.size()));
         A_(cs_dalloc(ctx, &b->d_cursor, (size_t)1));
         A_(cs_dalloc(ctx, &b->d_uflag, (size_t)b->n_units));
+        if (getenv("CUBESLAM_SCORE_PROF")) A_(cs_dalloc(ctx, &b->d_prof, (size_t)b->score_G * 16 * 4));
     }
     A_(cs_dalloc(ctx, &b->d_dist, (size_t)b->pix_total));
     CS_HIP(ctx, hipMemsetAsync(b->d_dist, 0, sizeof(float) * (size_t)b->pix_total, ctx->stream)); // the slices' padding (to 64 pixels) stays zero: cuboid_sweep_score encodes whole groups of 8
@@ -1929,13 +1954,13 @@ int cs_cuboid_batch_run(cs_ctx *ctx, cs_cuboid_batch *b) {
         const int items = U * b->score_slices, grid = std::min(b->score_G, items);
         if (b->score_T == 512)
             CS_LAUNCH(ctx, "cuboid_sweep_score", cuboid_sweep_score<512>, dim3(grid), dim3(512), SC_LDS_BYTES, b->d_units, b->d_order, items, b->score_slices, b->d_cursor, b->d_vp,
-                      b->d_dist, b->d_vcount, b->d_vlist, b->d_uflag, b->d_derr, b->d_aerr);
+                      b->d_dist, b->d_vcount, b->d_vlist, b->d_uflag, b->d_derr, b->d_aerr, b->d_prof);
         else if (b->score_T == 768)
             CS_LAUNCH(ctx, "cuboid_sweep_score", cuboid_sweep_score<768>, dim3(grid), dim3(768), SC_LDS_BYTES, b->d_units, b->d_order, items, b->score_slices, b->d_cursor, b->d_vp,
-                      b->d_dist, b->d_vcount, b->d_vlist, b->d_uflag, b->d_derr, b->d_aerr);
+                      b->d_dist, b->d_vcount, b->d_vlist, b->d_uflag, b->d_derr, b->d_aerr, b->d_prof);
         else
             CS_LAUNCH(ctx, "cuboid_sweep_score", cuboid_sweep_score<1024>, dim3(grid), dim3(1024), SC_LDS_BYTES, b->d_units, b->d_order, items, b->score_slices, b->d_cursor, b->d_vp,
-                      b->d_dist, b->d_vcount, b->d_vlist, b->d_uflag, b->d_derr, b->d_aerr);
+                      b->d_dist, b->d_vcount, b->d_vlist, b->d_uflag, b->d_derr, b->d_aerr, b->d_prof);
     }
     CS_LAUNCH(ctx, "cuboid_select", cuboid_select, dim3(b->n_boxes), dim3(256), 0, b->d_units, b->d_ud, b->d_box_first, b->d_fd, b->d_fi,
               b->d_cam, b->d_yaw, b->cal, b->o, b->d_flag, b->d_derr, b->d_aerr, b->d_vp, b->d_score, b->d_nscore,
@@ -1979,6 +2004,17 @@ int cs_cuboid_batch_stats(cs_ctx *ctx, cs_cuboid_batch *b, long *n_units, long *
 
 int cs_cuboid_batch_score_stats(cs_ctx *ctx, cs_cuboid_batch *b, long out[6]) {
     if (!ctx || !b || !out) return CS_ERR_BAD_ARG;
+    if (b->d_prof) { // (development) where the waves of the last cuboid_sweep_score launch spent their time
+        const int grid = std::min(b->score_G, b->n_units * b->score_slices), nw = grid * (b->score_T / 64);
+        std::vector<unsigned long long> h((size_t)nw * 4);
+        hipStreamSynchronize(ctx->stream);
+        if (hipMemcpy(h.data(), b->d_prof, h.size() * 8, hipMemcpyDeviceToHost) == hipSuccess) {
+            double c = 0, t = 0, w = 0, n = 0, mx = 0;
+            for (int i = 0; i < nw; i++) { c += (double)h[4 * i]; t += (double)h[4 * i + 1]; w += (double)h[4 * i + 2]; n += (double)h[4 * i + 3]; mx = std::max(mx, (double)(h[4 * i] + h[4 * i + 1] + h[4 * i + 2])); }
+            fprintf(stderr, "[score prof] %d waves: copy %.1f us, tasks %.1f us (%.1f tasks, %.2f us each), barrier wait %.1f us per wave; longest wave %.1f us\n", nw, c / nw / 100, t / nw / 100, n / nw,
+                    n > 0 ? t / n / 100 : 0.0, w / nw / 100, mx / 100);
+        }
+    }
     std::vector<int> vc(2 * (size_t)b->n_units + 1), uf((size_t)b->n_units + 1);
     int r = cs_d2h(ctx, vc.data(), b->d_vcount, 2 * (size_t)b->n_units); if (r) return r;
     r = cs_d2h(ctx, uf.data(), b->d_uflag, (size_t)b->n_units); if (r) return r;

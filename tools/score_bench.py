@@ -47,6 +47,7 @@ def main():
                 t[k] = round(1e3 * ms / n, 1)
         ctx.timing(False)
         st = b.stats()
+        b.score_stats()  # (prints the in-kernel phase profile under CUBESLAM_SCORE_PROF)
         alg = 4.0 * st["roi_pixels"] + 200.0 * st["n_valid"]  # SURVEY 8d, corner construction fused into the score kernel
         us = t.get("cuboid_sweep_score", 0)
         got = b.read()
