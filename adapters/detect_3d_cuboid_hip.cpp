@@ -47,8 +47,7 @@ void detect_3d_cuboid::detect_cuboid(const cv::Mat &rgb_img, const Eigen::Matrix
     set_cam_pose(transToWolrd);
     cam_pose_raw = cam_pose; // :59
     const int nb = (int)obj_bbox_coors.rows(), nl = (int)edges.rows();
-    all_object_cuboids.clear();
-    all_object_cuboids.resize(nb); // :72
+    all_object_cuboids.resize(nb); // :72: resized, not cleared -- what a caller left in the first nb entries is appended to, like the reference's push_back (:536)
     cs_cuboid_opts o;
     cs_cuboid_default_opts(&o);
     o.consider_config_1 = consider_config_1; o.consider_config_2 = consider_config_2;

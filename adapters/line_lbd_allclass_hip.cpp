@@ -64,7 +64,9 @@ void lbd_compute(const Mat &gray_img, const std::vector<KeyLine> &keylines, Mat 
     const int n = (int)keylines.size();
     if (n == 0) { descriptors = Mat(); return; }
     std::vector<cs_keyline> kl(n);
-    for (int i = 0; i < n; i++) kl[i] = from_keyline(keylines[i]);
+    // class_id / octave of a KeyLine made by mat_to_keylines are whatever KeyLine() left there (see above); the descriptor of a line of the only octave
+    // depends on neither, so the library is handed octave 0 and the running index
+    for (int i = 0; i < n; i++) { kl[i] = from_keyline(keylines[i]); kl[i].octave = 0; kl[i].class_id = i; }
     descriptors.create(n, 32, CV_8UC1);
     std::vector<uint8_t> d((size_t)n * 32);
     cs_ctx *ctx = shared_ctx();
@@ -111,7 +113,7 @@ void mat_to_keylines(const cv::Mat &linesmat_src, std::vector<KeyLine> &keylines
         kl.numOfPixels = li.count;
         keylines_out.push_back(kl);
         line_ind++;
-        keylines_out.back().class_id = line_ind; keylines_out.back().octave = octave_id;
+        kl.class_id = line_ind; kl.octave = octave_id; // :104-105 as written: on the local, AFTER its copy was stored (the stored KeyLine keeps what KeyLine() left in the two fields)
     }
 }
 
