@@ -438,9 +438,110 @@ __device__ inline void uf_union(int *lab, int a, int b, int A) {
     }
 }
 
-// stage 0: union with W / NW / N / NE candidate neighbours; stage 1: candidates become 255 iff their root is a strong
-// pixel.  The kernel boundary is the global sync.  16 pixels per thread (one 16-byte load; edge maps are sparse).
-__global__ void __launch_bounds__(256) cuboid_canny_cc(const Unit *units, uint8_t *emap, int *lab, int stage) {
+// Hysteresis = connected components of the candidate pixels (8-neighbourhood); a component is an edge iff it holds a strong pixel.  Three kernels,
+// the kernel boundaries are the global syncs:
+//   cuboid_canny_cc_local   a workgroup takes 4096 consecutive pixels of the ROI (a band of whole rows): union-find of the band's candidates in LDS
+//                           (LDS atomics: W / NW / N / NE neighbours inside the band), then every candidate's global parent = its band-local root
+//   cuboid_canny_cc_border  the first w + 1 pixels of every band: unions with the neighbours in the band above (global atomics, few pixels)
+//   cuboid_canny_cc         candidates become 255 iff their root is a strong pixel (paths are at most band root -> chain of band roots)
+// Node ids, locally and globally: pixel index if strong, + the pixel count if weak; the root of a component is its smallest id, so it is strong iff
+// the id is below the count.  A band's row-major order is the ROI's, so a band-local root is the global minimum of its part of the component.
+constexpr int CC_BAND = 4096;
+__device__ __forceinline__ int ufl_find(int *par, int x) { // LDS, path halving
+    while (true) {
+        int *px = par + (x & (CC_BAND - 1));
+        const int v = __hip_atomic_load(px, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (v == x) return x;
+        const int g = __hip_atomic_load(par + (v & (CC_BAND - 1)), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+        if (g == v) return v;
+        atomicMin(px, g);
+        x = g;
+    }
+}
+__device__ inline void ufl_union(int *par, int a, int b) {
+    while (true) {
+        a = ufl_find(par, a);
+        b = ufl_find(par, b);
+        if (a == b) return;
+        if (a < b) { const int t = a; a = b; b = t; } // a > b: hook a under b
+        const int old = atomicMin(par + (a & (CC_BAND - 1)), b);
+        if (old == a) return;
+        a = old;
+    }
+}
+__global__ void __launch_bounds__(256) cuboid_canny_cc_local(const Unit *units, const uint8_t *emap, int *lab) {
+    __shared__ int s_par[CC_BAND];      // parent id: local index (strong) or local index + CC_BAND (weak)
+    __shared__ uint8_t s_code[CC_BAND];
+    __shared__ unsigned short s_list[CC_BAND];
+    __shared__ int s_n;
+    const Unit &U = units[blockIdx.y];
+    const int A = U.roi_w * U.roi_h, w = U.roi_w;
+    const int p0b = blockIdx.x * CC_BAND;
+    if (p0b >= A) return;
+    const uint8_t *em = emap + U.pix_off;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    {
+        const int l0 = threadIdx.x * 16, p0 = p0b + l0;
+        uint4 v = make_uint4(0, 0, 0, 0);
+        if (p0 < A) v = *reinterpret_cast<const uint4 *>(em + p0); // pix_off and the arena padding are multiples of 64
+        *reinterpret_cast<uint4 *>(s_code + l0) = v;
+        if ((v.x | v.y | v.z | v.w) != 0) {
+            const unsigned wd[4] = {v.x, v.y, v.z, v.w};
+            for (int k = 0; k < 16; k++) {
+                const unsigned c = (wd[k >> 2] >> ((k & 3) * 8)) & 255u;
+                if (c && p0 + k < A) { s_par[l0 + k] = c == 2 ? l0 + k : l0 + k + CC_BAND; s_list[atomicAdd(&s_n, 1)] = (unsigned short)(l0 + k); }
+            }
+        }
+    }
+    __syncthreads();
+    const int n = s_n;
+    auto nid = [&](int l) -> int { const uint8_t c = s_code[l]; return c == 0 ? -1 : (c == 2 ? l : l + CC_BAND); };
+    for (int e = threadIdx.x; e < n; e += 256) {
+        const int l = s_list[e], p = p0b + l, x = p % w, id = nid(l);
+        int nb;
+        if (x > 0 && l >= 1 && (nb = nid(l - 1)) >= 0) ufl_union(s_par, id, nb);
+        if (l >= w) { // the row above is inside the band (p >= w then as well)
+            const int q = l - w;
+            if (x > 0 && q >= 1 && (nb = nid(q - 1)) >= 0) ufl_union(s_par, id, nb);
+            if ((nb = nid(q)) >= 0) ufl_union(s_par, id, nb);
+            if (x + 1 < w && (nb = nid(q + 1)) >= 0) ufl_union(s_par, id, nb);
+        } else if (l + 1 >= w && x + 1 < w && l - w + 1 >= 0) { // only the NE neighbour is inside (first row of the band, shifted by one)
+            if ((nb = nid(l - w + 1)) >= 0) ufl_union(s_par, id, nb);
+        }
+    }
+    __syncthreads();
+    int *lb = lab + U.pix_off;
+    for (int e = threadIdx.x; e < n; e += 256) {
+        const int l = s_list[e], r = ufl_find(s_par, nid(l));
+        lb[p0b + l] = r >= CC_BAND ? p0b + (r - CC_BAND) + A : p0b + r;
+    }
+}
+__global__ void __launch_bounds__(256) cuboid_canny_cc_border(const Unit *units, const uint8_t *emap, int *lab) { // one workgroup per unit: all its band heads
+    const Unit &U = units[blockIdx.x];
+    const int A = U.roi_w * U.roi_h, w = U.roi_w;
+    const uint8_t *em = emap + U.pix_off;
+    int *lb = lab + U.pix_off;
+    auto nid = [&](int q) { const uint8_t cq = em[q]; return cq == 0 ? -1 : (cq == 2 ? q : q + A); };
+    const int n_heads = (A - 1) / CC_BAND; // bands 1 .. n_heads start inside the ROI (band 0 has nothing above it)
+    for (int i = blockIdx.y * 256 + threadIdx.x; i < n_heads * (w + 1); i += 256 * gridDim.y) {
+        const int band = i / (w + 1) + 1, k = i - (band - 1) * (w + 1); // the band's first w + 1 pixels are the ones with a neighbour in front of the band
+        const int p0b = band * CC_BAND, p = p0b + k;
+        if (p >= A) continue;
+        const uint8_t c = em[p];
+        if (!c) continue;
+        const int id = c == 2 ? p : p + A, x = p % w;
+        int nb;
+        if (x > 0 && p - 1 < p0b && (nb = nid(p - 1)) >= 0) uf_union(lb, id, nb, A);
+        const int q = p - w; // (>= 0 unless a row is longer than a band)
+        if (q < 0) continue;
+        if (x > 0 && q - 1 < p0b && (nb = nid(q - 1)) >= 0) uf_union(lb, id, nb, A);
+        if (q < p0b && (nb = nid(q)) >= 0) uf_union(lb, id, nb, A);
+        if (x + 1 < w && q + 1 < p0b && (nb = nid(q + 1)) >= 0) uf_union(lb, id, nb, A);
+    }
+}
+// candidates become 255 iff their root is a strong pixel.  16 pixels per thread (one 16-byte load; edge maps are sparse).
+__global__ void __launch_bounds__(256) cuboid_canny_cc(const Unit *units, uint8_t *emap, int *lab) {
     __shared__ int s_list[4096];
     __shared__ int s_n;
     const Unit &U = units[blockIdx.y];
@@ -466,20 +567,7 @@ __global__ void __launch_bounds__(256) cuboid_canny_cc(const Unit *units, uint8_
     for (int e = threadIdx.x; e < n; e += 256) { // one candidate per thread: the dependent L2 round trips run in parallel
         const int p = s_list[e] >> 1;
         const int idp = (s_list[e] & 1) ? p : p + iA;
-        if (stage == 0) {
-            int x = p % U.roi_w, y = p / U.roi_w;
-            auto nid = [&](int q) { uint8_t cq = em[q]; return cq == 0 ? -1 : (cq == 2 ? q : q + iA); };
-            int nb;
-            if (x > 0 && (nb = nid(p - 1)) >= 0) uf_union(lb, idp, nb, iA);
-            if (y > 0) {
-                int q = p - U.roi_w;
-                if (x > 0 && (nb = nid(q - 1)) >= 0) uf_union(lb, idp, nb, iA);
-                if ((nb = nid(q)) >= 0) uf_union(lb, idp, nb, iA);
-                if (x + 1 < U.roi_w && (nb = nid(q + 1)) >= 0) uf_union(lb, idp, nb, iA);
-            }
-        } else {
-            em[p] = uf_find(lb, idp, iA) < iA ? 255 : 0;
-        }
+        em[p] = uf_find(lb, idp, iA) < iA ? 255 : 0;
     }
 }
 
@@ -1928,8 +2016,10 @@ int cs_cuboid_batch_run(cs_ctx *ctx, cs_cuboid_batch *b) {
     CS_HIP(ctx, hipMemsetAsync(b->d_emap, 0, (size_t)b->pix_total, ctx->stream));
     CS_LAUNCH(ctx, "cuboid_canny_nms", cuboid_canny_nms, dim3(b->max_tiles, U), dim3(256), 0, b->d_units, b->d_gray, b->W, b->H, b->d_emap,
               b->d_lab, b->o.canny_low, b->o.canny_high);
-    for (int stage = 0; stage < 2; stage++)
-        CS_LAUNCH(ctx, "cuboid_canny_cc", cuboid_canny_cc, dim3(b->max_cc_blocks, U), dim3(256), 0, b->d_units, b->d_emap, b->d_lab, stage);
+    CS_LAUNCH(ctx, "cuboid_canny_cc_local", cuboid_canny_cc_local, dim3(b->max_cc_blocks, U), dim3(256), 0, b->d_units, b->d_emap, b->d_lab);
+    if (b->max_cc_blocks > 1)
+        CS_LAUNCH(ctx, "cuboid_canny_cc_border", cuboid_canny_cc_border, dim3(U, 4), dim3(256), 0, b->d_units, b->d_emap, b->d_lab);
+    CS_LAUNCH(ctx, "cuboid_canny_cc", cuboid_canny_cc, dim3(b->max_cc_blocks, U), dim3(256), 0, b->d_units, b->d_emap, b->d_lab);
     if (b->dt_C) {
         const dim3 g((U + 3) / 4), t(256);
         switch (b->dt_C) {

@@ -39,7 +39,7 @@ def main():
         for _ in range(5):
             b.run()
         ctx.sync()
-        names = ("cuboid_frame_prep", "cuboid_unit_lines", "cuboid_canny_nms", "cuboid_canny_cc", "cuboid_dt", "cuboid_vp", "cuboid_sweep_filter", "cuboid_sweep_score", "cuboid_select")
+        names = ("cuboid_frame_prep", "cuboid_unit_lines", "cuboid_canny_nms", "cuboid_canny_cc_local", "cuboid_canny_cc_border", "cuboid_canny_cc", "cuboid_dt", "cuboid_vp", "cuboid_sweep_filter", "cuboid_sweep_score", "cuboid_select")
         t = {}
         for k in names:
             ms, n = ctx.timing_get(k)
