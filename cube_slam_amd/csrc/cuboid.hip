@@ -1456,7 +1456,10 @@ __device__ inline void corners_to_3d(const double *cx, const double *cy, const C
 }
 
 // flag bits after selection: bits 0-1 vp_1_position, bit 2 kept by fuse_normalize, bit 3 candidate for final ranking
-__global__ void __launch_bounds__(256) cuboid_select(const Unit *units, UnitDyn *ud, const int *box_first_unit, const FrameDyn *fd,
+#ifndef SELECT_WAVES
+#define SELECT_WAVES 2
+#endif
+__global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SELECT_WAVES, SELECT_WAVES))) cuboid_select(const Unit *units, UnitDyn *ud, const int *box_first_unit, const FrameDyn *fd,
                                                      const FrameInfo *fi, const CamRP *cam, const double *yaw, Calib cal, Opts o,
                                                      uint8_t *flag, const double *derr, const double *aerr, const VPEntry *vpt,
                                                      double *score, double *nscore, unsigned long long *ckey_d, unsigned long long *ckey_a,
