@@ -36,6 +36,37 @@ struct cs_ctx {
     struct pending_ev { std::string name; hipEvent_t a, b; };
     std::vector<pending_ev> pending;
     std::vector<hipEvent_t> pool;
+    // Device blocks kept for reuse while `pooling` is on (the per-frame drop-in calls build and drop a whole batch per call: ~35 hipMalloc / hipFree,
+    // which the driver serialises across threads).  Sizes are rounded up to a quarter-octave bucket; at most POOL_CAP bytes stay cached.
+    bool pooling = false;
+    std::map<void *, size_t> pool_live;
+    std::multimap<size_t, void *> pool_free;
+    size_t pool_cached = 0;
+    static size_t pool_bucket(size_t n) {
+        size_t b = 4096;
+        while (b < n) b <<= 1;                       // next power of two
+        const size_t q = b >> 3;                     // ... refined downwards in eighths of it
+        while (b - q >= n && b - q > (b >> 1)) b -= q;
+        return b;
+    }
+    hipError_t pool_alloc(void **p, size_t n) {
+        const size_t b = pool_bucket(n);
+        auto it = pool_free.find(b);
+        if (it != pool_free.end()) { *p = it->second; pool_free.erase(it); pool_cached -= b; pool_live[*p] = b; return hipSuccess; }
+        const hipError_t e = hipMalloc(p, b);
+        if (e == hipSuccess) pool_live[*p] = b;
+        return e;
+    }
+    void pool_release(void *p) { // a block of the pool goes back to it (or to the driver when the cache is full); anything else is freed
+        auto it = pool_live.find(p);
+        if (it == pool_live.end()) { hipFree(p); return; }
+        const size_t b = it->second;
+        pool_live.erase(it);
+        constexpr size_t POOL_CAP = (size_t)1 << 30;
+        if (pool_cached + b > POOL_CAP) { hipFree(p); return; }
+        pool_free.emplace(b, p); pool_cached += b;
+    }
+    void pool_drop() { for (auto &kv : pool_free) hipFree(kv.second); pool_free.clear(); pool_cached = 0; }
 
     hipEvent_t get_event() {
         if (!pool.empty()) { hipEvent_t e = pool.back(); pool.pop_back(); return e; }
@@ -84,9 +115,11 @@ struct cs_ctx {
 
 template <class T> static inline int cs_dalloc(cs_ctx *ctx, T **p, size_t n) {
     if (n == 0) n = 1;
-    CS_HIP(ctx, hipMalloc((void **)p, n * sizeof(T)));
+    if (ctx->pooling) CS_HIP(ctx, ctx->pool_alloc((void **)p, n * sizeof(T)));
+    else CS_HIP(ctx, hipMalloc((void **)p, n * sizeof(T)));
     return CS_OK;
 }
+static inline void cs_dfree(cs_ctx *ctx, void *p) { if (!p) return; if (ctx && !ctx->pool_live.empty()) ctx->pool_release(p); else hipFree(p); }
 template <class T> static inline int cs_h2d(cs_ctx *ctx, T *d, const T *h, size_t n) {
     if (n == 0) return CS_OK;
     CS_HIP(ctx, hipMemcpyAsync(d, h, n * sizeof(T), hipMemcpyHostToDevice, ctx->stream));

@@ -141,6 +141,7 @@ void cs_destroy(cs_ctx *ctx) {
     ctx->flush();
     cs_comm_destroy(ctx);
     for (auto e : ctx->pool) hipEventDestroy(e);
+    ctx->pool_drop();
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -1789,7 +1789,7 @@ void cs_cuboid_batch_destroy(cs_ctx *ctx, cs_cuboid_batch *b) {
     void *ptrs[] = {b->d_gray, b->d_emap, b->d_flag, b->d_dist, b->d_dttmp, b->d_dttmp_off, b->d_fi, b->d_fd, b->d_cam, b->d_yaw, b->d_lines_in, b->d_lines_al,
                     b->d_mlines, b->d_mangle, b->d_mmid, b->d_units, b->d_ud, b->d_box_first, b->d_status, b->d_counts, b->d_vp,
                     b->d_derr, b->d_aerr, b->d_score, b->d_nscore, b->d_ckd, b->d_cka, b->d_cidx, b->d_out, b->d_vcount, b->d_vlist, b->d_order, b->d_cursor, b->d_uflag, b->d_prof};
-    for (void *p : ptrs) if (p) hipFree(p);
+    for (void *p : ptrs) cs_dfree(ctx, p);
     delete b;
 }
 
@@ -1910,8 +1910,13 @@ int cs_cuboid_batch_create(cs_ctx *ctx, int n_frames, int width, int height, con
             hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, SC_LDS_BYTES);
             if (e != hipSuccess) { ctx->err = hipGetErrorString(e); cs_cuboid_batch_destroy(ctx, b); return CS_ERR_HIP; }
         }
-        hipDeviceProp_t prop;
-        if (hipGetDeviceProperties(&prop, ctx->device) == hipSuccess && prop.multiProcessorCount > 0) b->score_G = prop.multiProcessorCount;
+        {
+            static int cu_of_device[64]; // (hipGetDeviceProperties is slow enough to show in the per-frame call: asked once per device)
+            const int dv = ctx->device & 63;
+            int cus = __atomic_load_n(&cu_of_device[dv], __ATOMIC_RELAXED);
+            if (cus == 0 && hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, ctx->device) == hipSuccess && cus > 0) __atomic_store_n(&cu_of_device[dv], cus, __ATOMIC_RELAXED);
+            if (cus > 0) b->score_G = cus;
+        }
         const char *ge = getenv("CUBESLAM_SCORE_SEGMENTS"); // tuning knob: workgroups of cuboid_sweep_score
         if (ge && atoi(ge) > 0) b->score_G = atoi(ge);
         const char *te = getenv("CUBESLAM_SCORE_THREADS"); // tuning knob: 512 (2 waves per SIMD, 256 registers) or 1024 (4 waves per SIMD, 128 registers)
@@ -1984,14 +1989,14 @@ int cs_cuboid_batch_set_lines(cs_ctx *ctx, cs_cuboid_batch *b, const int *line_o
     b->line_rows = rows;
     int r;
     if (n_lines > b->cap_lines_in) {
-        hipFree(b->d_lines_in); hipFree(b->d_lines_al); b->d_lines_in = b->d_lines_al = nullptr;
+        cs_dfree(ctx, b->d_lines_in); cs_dfree(ctx, b->d_lines_al); b->d_lines_in = b->d_lines_al = nullptr;
         const size_t cap = (size_t)n_lines + n_lines / 4 + 64;
         r = cs_dalloc(ctx, &b->d_lines_in, cap * 4); if (r) return r;
         r = cs_dalloc(ctx, &b->d_lines_al, cap * 4); if (r) return r;
         b->cap_lines_in = (long)cap;
     }
     if (rows > b->cap_line_rows) {
-        hipFree(b->d_mlines); hipFree(b->d_mangle); hipFree(b->d_mmid); b->d_mlines = b->d_mangle = b->d_mmid = nullptr;
+        cs_dfree(ctx, b->d_mlines); cs_dfree(ctx, b->d_mangle); cs_dfree(ctx, b->d_mmid); b->d_mlines = b->d_mangle = b->d_mmid = nullptr;
         const size_t cap = (size_t)rows + rows / 4 + 64;
         r = cs_dalloc(ctx, &b->d_mlines, cap * 4); if (r) return r;
         r = cs_dalloc(ctx, &b->d_mangle, cap); if (r) return r;
@@ -2204,7 +2209,10 @@ int cs_cuboid_detect(cs_ctx *ctx, const uint8_t *img, int width, int height, int
     int bo[2] = {0, n_boxes}, lo[2] = {0, n_lines};
     cs_cuboid_batch *b = nullptr;
     double dummy[4] = {0, 0, 0, 0};
+    // the frame's batch is built from (and dropped back into) the context's block pool: a camera stream asks for the same sizes frame after frame
+    ctx->pooling = true;
     int r = cs_cuboid_batch_create(ctx, 1, width, height, gray.data(), K, Twc, bo, boxes, lo, n_lines ? lines : dummy, opts, &b);
+    ctx->pooling = false;
     if (r != CS_OK) return r;
     r = cs_cuboid_batch_run(ctx, b);
     if (r == CS_OK) r = cs_cuboid_batch_read(ctx, b, out, counts);
