@@ -62,7 +62,7 @@ def test_product_does_not_import_oracle():
 
 
 def test_short_edge_threshold_without_sqrt():
-    """cuboid_sweep_corners tests `dist < 20` as `dx*dx + dy*dy < pred(400)`: equivalent for correctly rounded sqrt."""
+    """corners_build (cuboid_sweep_filter) tests `dist < 20` as `dx*dx + dy*dy < pred(400)`: equivalent for correctly rounded sqrt."""
     import struct
     import numpy as np
     T = struct.unpack("<d", struct.pack("<Q", 0x4078ffffffffffff))[0]
@@ -81,7 +81,7 @@ def test_short_edge_threshold_without_sqrt():
 
 
 def test_chamfer_code_number_theory():
-    """cuboid_dt_codes (cuboid.hip) stores a chamfer value t = i*62587 + j*89738 (t * 2^-16 px) as the 16-bit code i | j << 8 for
+    """cuboid_sweep_score (cuboid.hip) keeps a chamfer value t = i*62587 + j*89738 (t * 2^-16 px) as the 16-bit code i | j << 8 for
     cuboid_sweep_score and recovers (i, j) from t with one float FMA and a 978-entry table.  The facts its encoder relies on: the 256
     residues j*89738 mod 62587 fall into distinct 64-wide buckets (they are >= 97 apart), floor(t / 62587) comes out right from
     float(t) * float(1/62587) + 0.0005 for every representable pair, i = floor(t/62587) - floor(j*89738/62587), the table entry

@@ -133,10 +133,11 @@ def test_distance_transform_variants_agree(ctx, oracle, monkeypatch, W, H):
 
 
 def test_score_paths_agree(ctx, oracle, monkeypatch):
-    """cuboid_sweep_score keeps a unit's chamfer map in LDS as exact 16-bit (i, j) codes and cuts the batch's work line into segments
-    (one workgroup each).  Whatever the number of segments, the cuboids are byte-identical, and they equal the oracle's -- including a box
-    whose ROI does not fit one CU's LDS (the head of its code map is resident, samples past it are gathered from global memory) and a flat
-    image whose distance map is all escape codes (its units go to cuboid_sweep_score_big, which reads the float map)."""
+    """cuboid_sweep_score keeps a unit's chamfer map in LDS as exact 16-bit (i, j) codes (it encodes the float map itself) and hands units -- or
+    slices of units, when there are fewer units than CUs -- to persistent workgroups.  Whatever the number of workgroups, slices per unit and
+    threads per workgroup (512: shared corner products; 768 / 1024: the lean body), the cuboids are byte-identical, and they equal the
+    oracle's -- including a box whose ROI does not fit one CU's LDS (the head of its code map is resident, samples past it read the float map
+    in global memory) and a flat image whose distance map has no codes at all (its units sample the float map only)."""
     det = detect_3d_cuboid(ctx)
     det.yaw_step_deg = 2.0
     scenes = [synth.cuboid_scene(70 + i, n_boxes=3) for i in range(3)]
@@ -145,26 +146,30 @@ def test_score_paths_agree(ctx, oracle, monkeypatch):
     boxes = [np.array(s["boxes"], np.float64) for s in scenes]
     boxes[1] = np.concatenate([boxes[1], [[20, 20, 560, 400, 0.5]]])  # 600 x 440 ROI: 264 000 pixels do not fit
     det.set_calibration(scenes[0]["K"])
-    out = {}
-    for segs in ("default", "1", "7", "64", "1000"):
-        if segs != "default":
-            monkeypatch.setenv("CUBESLAM_SCORE_SEGMENTS", segs)
+    settings = [{}, {"CUBESLAM_SCORE_SEGMENTS": "1"}, {"CUBESLAM_SCORE_SEGMENTS": "7", "CUBESLAM_SCORE_SLICES": "1"}, {"CUBESLAM_SCORE_SEGMENTS": "1000", "CUBESLAM_SCORE_SLICES": "5"},
+                {"CUBESLAM_SCORE_THREADS": "1024"}, {"CUBESLAM_SCORE_THREADS": "768", "CUBESLAM_SCORE_SLICES": "64"}]
+    out = []
+    for env in settings:
+        for k, v in env.items():
+            monkeypatch.setenv(k, v)
         b = CuboidBatch(ctx, np.stack([s["gray"] for s in scenes]), scenes[0]["K"], np.stack([s["Twc"] for s in scenes]), boxes, [s["lines"] for s in scenes], det.opts())
         b.run()
-        out[segs] = b.read()
+        out.append(b.read())
+        if not env:
+            ss = b.score_stats()
+            assert ss["float_units"] == 3 and ss["code_units"] == len(np.concatenate(boxes)) - 3  # the flat frame's three boxes have no codes
         b.close()
-    monkeypatch.delenv("CUBESLAM_SCORE_SEGMENTS")
-    n = 0
-    for segs in ("1", "7", "64", "1000"):
-        for g, l in zip(out["default"], out[segs]):
-            assert len(g) == len(l) and np.array_equal(np.asarray(g).view(np.uint8), np.asarray(l).view(np.uint8)), segs
-            n += len(g)
-    assert n > 5
-    oo = _oracle_opts(oracle, det)
+        for k in env:
+            monkeypatch.delenv(k)
+    for other in out[1:]:
+        for g, l in zip(out[0], other):
+            assert len(g) == len(l) and np.array_equal(np.asarray(g).view(np.uint8), np.asarray(l).view(np.uint8))
     ref = []
+    oo = _oracle_opts(oracle, det)
     for s, bx in zip(scenes, boxes):
-        ref += oracle.detect_cuboid(s["gray"], scenes[0]["K"], s["Twc"], bx, s["lines"], opts=oo)[0]
-    _cmp_cuboids(out["default"], ref)
+        r, _ = oracle.detect_cuboid(s["gray"], s["K"], s["Twc"], bx, s["lines"], opts=oo)
+        ref += r
+    _cmp_cuboids(out[0], ref)
 
 
 def test_set_lines_equals_a_fresh_batch(ctx):
