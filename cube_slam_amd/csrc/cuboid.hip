@@ -356,16 +356,26 @@ __global__ void __launch_bounds__(256) cuboid_canny_nms(const Unit *units, const
     const int tiles_x = (U.roi_w + NMS_TW - 1) / NMS_TW, tiles_y = (U.roi_h + NMS_TH - 1) / NMS_TH;
     if ((int)blockIdx.x >= tiles_x * tiles_y) return;
     const int tx0 = (blockIdx.x % tiles_x) * NMS_TW, ty0 = (blockIdx.x / tiles_x) * NMS_TH;
-    __shared__ uint8_t g[NMS_TH + 4][NMS_TW + 4];
+    __shared__ __attribute__((aligned(4))) uint8_t g[NMS_TH + 4][NMS_TW + 4];
     __shared__ short mg[NMS_TH + 2][NMS_TW + 2];
     const uint8_t *img = gray + (long)U.frame * W * H;
     const int tid = threadIdx.x;
-    for (int i = tid; i < (NMS_TH + 4) * (NMS_TW + 4); i += 256) {
-        int ly = i / (NMS_TW + 4), lx = i % (NMS_TW + 4);
-        int X = U.roi_x + tx0 + lx - 2, Y = U.roi_y + ty0 + ly - 2;
-        X = X < 0 ? 0 : (X >= W ? W - 1 : X); // BORDER_REPLICATE at the image border; real pixels outside the ROI view
+    // four pixels per lane and step (unaligned dwords); a dword that touches the image border is built from clamped bytes (BORDER_REPLICATE at the image
+    // border; real pixels outside the ROI view)
+    static_assert((NMS_TW + 4) % 4 == 0, "tile rows are whole dwords");
+    for (int i = tid; i < (NMS_TH + 4) * ((NMS_TW + 4) / 4); i += 256) {
+        const int ly = i / ((NMS_TW + 4) / 4), k4 = i - ly * ((NMS_TW + 4) / 4);
+        const int X0 = U.roi_x + tx0 + 4 * k4 - 2;
+        int Y = U.roi_y + ty0 + ly - 2;
         Y = Y < 0 ? 0 : (Y >= H ? H - 1 : Y);
-        g[ly][lx] = img[(long)Y * W + X];
+        const uint8_t *row = img + (long)Y * W;
+        uint32_t v;
+        if (X0 >= 0 && X0 + 3 < W) v = load_u32_unaligned(row + X0);
+        else {
+            v = 0;
+            for (int c = 0; c < 4; c++) { int X = X0 + c; X = X < 0 ? 0 : (X >= W ? W - 1 : X); v |= (uint32_t)row[X] << (8 * c); }
+        }
+        reinterpret_cast<uint32_t *>(&g[ly][0])[k4] = v;
     }
     __syncthreads();
     for (int i = tid; i < (NMS_TH + 2) * (NMS_TW + 2); i += 256) {
