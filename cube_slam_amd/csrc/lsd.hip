@@ -180,18 +180,34 @@ __global__ void __launch_bounds__(1024) lsd_scan_add(int *out, int n, const int 
 // of float(angle) as region_grow adds them up (:676-677, glibc's cosf / sinf restated) -- computed here once per pixel instead of by the host per visit
 __global__ void __launch_bounds__(256) lsd_emit(const double *modgrad, const double *angles, int w, int h, const int *seg_base, int *c_addr, float *c_deg, float2 *c_cs, double *c_mod) {
     __shared__ int wc[4];
-    const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
-    const long o = ((long)blockIdx.z * h + y) * w + x;
-    double a = NOTDEF;
-    if (x < w) a = angles[o];
-    const bool def = a != NOTDEF;
-    const unsigned long long m = __ballot(def);
-    const int wv = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) wc[wv] = __popcll(m);
-    __syncthreads();
-    if (!def) return;
-    int pos = seg_base[((long)blockIdx.z * h + y) * gridDim.x + blockIdx.x] + __popcll(m & ((1ull << (threadIdx.x & 63)) - 1));
-    for (int i = 0; i < wv; i++) pos += wc[i];
+    __shared__ short s_x[256];
+    __shared__ double s_a[256];
+    const int y = blockIdx.y;
+    const long row = ((long)blockIdx.z * h + y) * w;
+    {   // phase 1, a lane per pixel: which pixels of the segment are defined; they are packed (in address order) into the workgroup's list, so that the
+        // expensive part below -- an IEEE division, eight double alignment tests, the double-precision polynomial of glibc's cosf / sinf -- runs on full
+        // waves of defined pixels only (37 % of the pixels of a textured frame)
+        const int x = blockIdx.x * 256 + threadIdx.x;
+        double a = NOTDEF;
+        if (x < w) a = angles[row + x];
+        const bool def = a != NOTDEF;
+        const unsigned long long m = __ballot(def);
+        const int wv = threadIdx.x >> 6;
+        if ((threadIdx.x & 63) == 0) wc[wv] = __popcll(m);
+        __syncthreads();
+        if (def) {
+            int r = __popcll(m & ((1ull << (threadIdx.x & 63)) - 1));
+            for (int i = 0; i < wv; i++) r += wc[i];
+            s_x[r] = (short)x; s_a[r] = a;
+        }
+        __syncthreads();
+    }
+    const int n_def = wc[0] + wc[1] + wc[2] + wc[3];
+    if ((int)threadIdx.x >= n_def) return;
+    const int x = s_x[threadIdx.x];
+    const double a = s_a[threadIdx.x];
+    const long o = row + x;
+    const int pos = seg_base[((long)blockIdx.z * h + y) * gridDim.x + blockIdx.x] + threadIdx.x;
     float d = (float)(a / DEG_TO_RADS); // the float whose product with DEG_TO_RADS is a: the quotient rounded, or a neighbour of it
     if ((double)d * DEG_TO_RADS != a) { const float up = nextafterf(d, 1e9f), dn = nextafterf(d, -1e9f); d = ((double)up * DEG_TO_RADS == a) ? up : dn; }
     // bit 31 of the address: no neighbour is aligned with this pixel's own angle (angles never change), so as a seed it stays alone -- region_grow's
