@@ -367,23 +367,39 @@ __device__ __forceinline__ float fast_atan2f(float y, float x) { // cv::fastAtan
 }
 
 // IC_Angle (:74-101): one wave per keypoint, lane = patch row v = lane-15
+// IC_Angle (ORBextractor.cc:76-103): half a wave per key point, a lane per patch row; the row's 31 bytes arrive as eight unaligned dwords, the sums are byte
+// dot products (weights u + 15 >= 0 for the unsigned dot: sum u val = sum (u + 15) val - 15 sum val).  Integer sums: any order is exact.
+__device__ __forceinline__ uint32_t low_bytes(int n) { return n >= 4 ? 0xffffffffu : (n <= 0 ? 0u : ((1u << (8 * n)) - 1)); } // bytes [0, n) set
 __global__ void __launch_bounds__(256) orb_angle(Pyr P, const uint8_t *pyr, const SelKP *sel, int n, float *angle) {
-    const int k = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (k >= n) return;
-    const SelKP kp = sel[k];
+    static_assert(PATCH == 31 && HALF_PATCH == 15, "a patch row is 31 bytes around the centre");
+    const int k = blockIdx.x * 8 + (threadIdx.x >> 5), lane = threadIdx.x & 31;
+    const bool live = k < n;
+    const SelKP kp = sel[live ? k : n - 1];
     const Lvl &L = P.l[kp.level];
     const uint8_t *img = pyr + (long)kp.frame * P.frame_stride + L.off;
     const int cx = __float2int_rn(kp.x), cy = __float2int_rn(kp.y);
     int m10 = 0, m01 = 0;
     if (lane < PATCH) {
         const int v = lane - HALF_PATCH, d = P.umax[v < 0 ? -v : v];
-        const uint8_t *row = img + (long)(cy + v) * L.w + cx;
-        int s1 = 0;
-        for (int u = -d; u <= d; u++) { int val = row[u]; s1 += val; m10 += u * val; }
-        m01 = v * s1;
+        const uint8_t *row = img + (long)(cy + v) * L.w + cx - HALF_PATCH; // byte j of the row is u = j - 15
+        uint32_t wd[8];
+#pragma unroll
+        for (int q = 0; q < 8; q++) wd[q] = load_u32_unaligned(row + 4 * q); // (byte 31, u = 16, is inside the level's 19-pixel frame and masked below)
+        const int lo = HALF_PATCH - d, hi = HALF_PATCH + d; // bytes lo .. hi take part
+        uint32_t s1 = 0, sw = 0;
+#pragma unroll
+        for (int q = 0; q < 8; q++) {
+            const uint32_t m = low_bytes(hi + 1 - 4 * q) & ~low_bytes(lo - 4 * q);
+            const uint32_t x = wd[q] & m;
+            const uint32_t wts = (uint32_t)(4 * q) * 0x01010101u + 0x03020100u; // u + 15 = j of the four bytes
+            s1 = __builtin_amdgcn_udot4(x, 0x01010101u, s1, false);
+            sw = __builtin_amdgcn_udot4(x, wts, sw, false);
+        }
+        m10 = (int)sw - HALF_PATCH * (int)s1;
+        m01 = v * (int)s1;
     }
-    for (int off = 32; off > 0; off >>= 1) { m10 += __shfl_xor(m10, off); m01 += __shfl_xor(m01, off); }
-    if (lane == 0) angle[k] = fast_atan2f((float)m01, (float)m10);
+    for (int off = 16; off > 0; off >>= 1) { m10 += __shfl_xor(m10, off); m01 += __shfl_xor(m01, off); }
+    if (lane == 0 && live) angle[k] = fast_atan2f((float)m01, (float)m10);
 }
 
 __device__ __forceinline__ int reflect101(int p, int len) {
@@ -1103,7 +1119,7 @@ int cs_orb_run(cs_ctx *ctx, cs_orb *e) {
             if (n > e->sel_cap) { ctx->err = "ORB keypoint capacity exceeded"; return CS_ERR_CAPACITY; }
             if (n == 0) return CS_OK;
             CS_LAUNCH(ctx, "orb_compact_sel", orb_compact_sel, dim3(NL, F), dim3(256), 0, e->Q, e->d_slots, e->d_slot_cnt, e->d_sel_base, e->d_sel);
-            CS_LAUNCH(ctx, "orb_angle", orb_angle, dim3((n + 3) / 4), dim3(256), 0, P, e->d_pyr, e->d_sel, n, e->d_angle);
+            CS_LAUNCH(ctx, "orb_angle", orb_angle, dim3((n + 7) / 8), dim3(256), 0, P, e->d_pyr, e->d_sel, n, e->d_angle);
             CS_LAUNCH(ctx, "orb_desc", orb_desc, dim3((n + 3) / 4), dim3(256), 0, P, e->d_blur, e->d_sel, e->d_angle, n, e->d_kps, e->d_desc);
             CS_HIP(ctx, hipGetLastError());
             return CS_OK;
@@ -1161,7 +1177,7 @@ int cs_orb_run(cs_ctx *ctx, cs_orb *e) {
     if (n == 0) return CS_OK;
     // ---- GPU phase B: orientation, descriptors
     r = cs_h2d(ctx, e->d_sel, e->sel.data(), (size_t)n); if (r) return r;
-    CS_LAUNCH(ctx, "orb_angle", orb_angle, dim3((n + 3) / 4), dim3(256), 0, P, e->d_pyr, e->d_sel, n, e->d_angle);
+    CS_LAUNCH(ctx, "orb_angle", orb_angle, dim3((n + 7) / 8), dim3(256), 0, P, e->d_pyr, e->d_sel, n, e->d_angle);
     CS_LAUNCH(ctx, "orb_desc", orb_desc, dim3((n + 3) / 4), dim3(256), 0, P, e->d_blur, e->d_sel, e->d_angle, n, e->d_kps, e->d_desc);
     CS_HIP(ctx, hipGetLastError());
     return CS_OK;
