@@ -535,15 +535,32 @@ __global__ void __launch_bounds__(256) orb_desc(Pyr P, const uint8_t *blur, cons
     sincos_f(ang * factorPI, b, a);
     const long cidx = (long)__float2int_rn(kp.y) * L.w + __float2int_rn(kp.x);
     const long last = (long)L.w * L.h - 1;
+    // The 512 test points lie within 18.4 pixels of the centre (bit_pattern_31_), so every rotated, rounded offset is inside a 37 x 37 window: the wave stages
+    // that window in LDS with coalesced dword loads -- byte (ry, rx) = img[clamp(cidx + ry * w + rx)], the flat, clamped addressing of the tests themselves --
+    // and gathers from there (eight 64-line gathers per key point through the texture path were this kernel's time).
+    constexpr int DR = 18, DW = 10; // window radius; dwords per staged row (40 bytes for 37)
+    __shared__ __attribute__((aligned(4))) uint8_t s_patch[4][2 * DR + 1][4 * DW];
+    uint8_t (*pt)[4 * DW] = s_patch[threadIdx.x >> 6];
+    for (int j = lane; j < (2 * DR + 1) * DW; j += 64) {
+        const int row = j / DW, q = j - row * DW;
+        const long o0 = cidx + (long)(row - DR) * L.w - DR + 4 * q;
+        uint32_t v;
+        if (o0 >= 0 && o0 + 3 <= last) v = load_u32_unaligned(img + o0);
+        else {
+            v = 0;
+            for (int c = 0; c < 4; c++) { long o = o0 + c; o = o < 0 ? 0 : (o > last ? last : o); v |= (uint32_t)img[o] << (8 * c); } // unchecked addressing of the reference, clamped
+        }
+        reinterpret_cast<uint32_t *>(&pt[row][0])[q] = v;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); // the wave's own LDS writes, read by its other lanes
+    __builtin_amdgcn_wave_barrier();
     for (int r = 0; r < 4; r++) {
         const int t = r * 64 + lane;
         int val[2];
 #pragma unroll
         for (int e = 0; e < 2; e++) {
             const float px = (float)d_pattern[4 * t + 2 * e], py = (float)d_pattern[4 * t + 2 * e + 1];
-            long o = cidx + (long)__float2int_rn(px * b + py * a) * L.w + __float2int_rn(px * a - py * b);
-            o = o < 0 ? 0 : (o > last ? last : o); // unchecked addressing of the reference, clamped
-            val[e] = img[o];
+            val[e] = pt[__float2int_rn(px * b + py * a) + DR][__float2int_rn(px * a - py * b) + DR];
         }
         unsigned long long m = __ballot(val[0] < val[1]);
         if (lane == 0) desc[(long)k * 4 + r] = m;
