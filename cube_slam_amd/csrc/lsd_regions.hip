@@ -78,7 +78,16 @@ __device__ double rg_nfa(int n, int k, double p, double LOG_NT, const double *lg
 // The pixel walk of rect_nfa (:977-1098): the four corners ordered like the reference's std::sort + selection, the rows counted by the lanes of the
 // wave.  total = pixels of the rectangle inside the image; algs[k] = those aligned with rec.theta within precs[k] (several tolerances share a walk:
 // rect_improve's first and last loop only halve the tolerance of an unchanged rectangle).  Every lane gets the sums.
+#if defined(RGI_PROF)
+__device__ unsigned long long g_rgi_prof[4]; // ticks in rectangle walks, in nfa(), calls of each
+#define RGI_T0 const unsigned long long rgi_t0 = wall_clock64()
+#define RGI_T1(k) do { if ((threadIdx.x & 63) == 0) { atomicAdd(&g_rgi_prof[k], wall_clock64() - rgi_t0); atomicAdd(&g_rgi_prof[2 + (k)], 1ull); } } while (0)
+#else
+#define RGI_T0
+#define RGI_T1(k)
+#endif
 template <int NP> __device__ void rg_rect_count(const AngMap &F, const rg::Rect &rec, const double *precs, int lane, int &total, int *algs) {
+    RGI_T0;
     const double half_width = rec.width / 2.0, dyhw = rec.dy * half_width, dxhw = rec.dx * half_width;
     int ox[4], oy[4]; bool taken[4] = {false, false, false, false};
     ox[0] = int(rec.x1 - dyhw); oy[0] = int(rec.y1 + dxhw); ox[1] = int(rec.x2 - dyhw); oy[1] = int(rec.y2 + dxhw);
@@ -127,6 +136,7 @@ template <int NP> __device__ void rg_rect_count(const AngMap &F, const rg::Rect 
     }
     total = total_pts;
     for (int k = 0; k < NP; k++) algs[k] = alg_pts[k];
+    RGI_T1(0);
 }
 // nfa() of up to five (n, k, p) triples at once: lane v computes triple v -- the loops inside nfa are sequential, the triples independent
 __device__ void rg_nfa5(const int *n, const int *k, const double *p, int cnt, double LOG_NT, const double *lgt, int lane, double *out) {
@@ -140,7 +150,7 @@ __device__ void rg_nfa5(const int *n, const int *k, const double *p, int cnt, do
 __device__ double rg_rect_improve(const AngMap &F, rg::Rect &rec, double LOG_NT, int lane, const double *lgt) {
     const double delta = 0.5, delta_2 = delta / 2.0;
     double log_nfa;
-    { int tot, alg; rg_rect_count<1>(F, rec, &rec.prec, lane, tot, &alg); log_nfa = rg_nfa(tot, alg, rec.p, LOG_NT, lgt); }
+    { int tot, alg; rg_rect_count<1>(F, rec, &rec.prec, lane, tot, &alg); RGI_T0; log_nfa = rg_nfa(tot, alg, rec.p, LOG_NT, lgt); RGI_T1(1); }
     if (log_nfa > LOG_EPS) return log_nfa;
     rg::Rect rs[5];
     int tot[5], alg[5], cnt; double ps[5], v[5];
@@ -152,7 +162,9 @@ __device__ double rg_rect_improve(const AngMap &F, rg::Rect &rec, double LOG_NT,
         cnt = 5;
     };
     auto take_best = [&]() {
+        RGI_T0;
         rg_nfa5(tot, alg, ps, cnt, LOG_NT, lgt, lane, v);
+        RGI_T1(1);
         for (int n = 0; n < cnt; ++n) if (v[n] > log_nfa) { log_nfa = v[n]; rec = rs[n]; }
     };
     auto walks = [&]() { for (int n = 0; n < cnt; ++n) { rg_rect_count<1>(F, rs[n], &rs[n].prec, lane, tot[n], &alg[n]); ps[n] = rs[n].p; } };
@@ -357,6 +369,11 @@ int lsd_seq_run(cs_ctx *ctx, LsdSeq **handle, int F, int w, int h, const double 
         r->cap_lines = cap;
     }
     CS_LAUNCH(ctx, "lsd_rg_improve", lsd_rg_improve, dim3((n_cand + 3) / 4), dim3(256), 0, S, r->d_cand_base, n_cand, r->d_lgt, r->d_line, r->d_has);
+#if defined(RGI_PROF)
+    { unsigned long long h[4]; hipDeviceSynchronize(); hipMemcpyFromSymbol(h, HIP_SYMBOL(g_rgi_prof), sizeof h); unsigned long long z[4] = {0, 0, 0, 0}; hipMemcpyToSymbol(HIP_SYMBOL(g_rgi_prof), z, sizeof z);
+      fprintf(stderr, "[rgi prof] %d rectangles: walks %.0f calls %.2f us each = %.1f us per rectangle; nfa %.0f calls %.2f us each = %.1f us per rectangle\n", n_cand, (double)h[2], h[2] ? h[0] / 100.0 / h[2] : 0.0,
+              h[0] / 100.0 / n_cand, (double)h[3], h[3] ? h[1] / 100.0 / h[3] : 0.0, h[1] / 100.0 / n_cand); }
+#endif
     r->h_has.resize((size_t)n_cand); r->h_line.resize((size_t)n_cand);
     RA_(cs_d2h(ctx, r->h_has.data(), r->d_has, (size_t)n_cand));
     RA_(cs_d2h(ctx, r->h_line.data(), r->d_line, (size_t)n_cand));
