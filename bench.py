@@ -450,7 +450,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=5)
     ap.add_argument("--frames", type=int, default=1024, help="frames resident per GPU = frames per step (the line detector's region stage runs on the device from 512 on)")
     ap.add_argument("--line-workers", type=int, default=4, help="line detectors that alternate steps on their own streams (1-4)")
-    ap.add_argument("--phased", type=int, default=1, help="1 (default): the runner's phased mode (the detectors' device region stages run together once per --line-workers steps, with the ORB / cuboid stream idle)")
+    ap.add_argument("--phased", type=int, default=0, help="0 (default): the alternating runner -- the detectors' region walks hold most CUs all the time and every other kernel runs beside them, the edge-scoring kernel in "
+                    "the launch shape that fits into a CU's leftovers; 1: the phased runner (the region stages of --line-workers steps run together with the ORB / cuboid stream idle)")
     ap.add_argument("--boxes", type=int, default=3)
     ap.add_argument("--yaw-step", type=float, default=0.5)
     ap.add_argument("--no-cpu", action="store_true")
@@ -503,12 +504,14 @@ def main():
         args.phased = 1 if args.phased and args.frames >= 512 and os.environ.get("CUBESLAM_LSD_REGIONS", "seq") == "seq" else 0
         # The library's front-end runner (cs_frontend_*, csrc/frontend.hip) runs ORB + cuboid on this thread and the line path on worker
         # threads with their own contexts (= HIP streams).  The detectors alternate steps.  From 512 frames per step on, region growing runs on
-        # the device, one wave per frame for ~110 ms (lsd_regions.hip), sixteen frames to a CU.  The runner's phased mode (default) lets four
-        # detectors queue their map kernels beside ORB / cuboid of four steps and then runs the four region stages together (4096 waves = every
-        # CU) with the ORB / cuboid stream idle; --phased 0 --line-workers 2 is the alternating runner (two detectors sit on half of the CUs, the
-        # ORB / cuboid kernels use the other half).  Below 512 frames the 16 host threads grow the regions, the GPU phases of one step overlap
-        # the host stage of the neighbouring one, the library serialises the host stages, and the runner is not phased.
-        ctx_lines = [_lib.Context(local_rank, priority=-1) for _ in range(max(1, min(4, args.line_workers)))]  # device phases of the line detectors: background
+        # the device, one wave per frame for ~110 ms (lsd_regions.hip), sixteen frames to a CU.  Default: the ALTERNATING runner with four
+        # detectors -- their walks (4 x 64 CUs, scalar-unit-bound) hold the chip all the time and every other kernel of the step runs in the
+        # wave slot and the vector-ALU time they leave; the edge-scoring kernel, which otherwise needs whole CUs, takes its 256-thread shape for
+        # that (cs_cuboid_batch_set_shared_gpu).  It is the faster runner (19.0 k against 16.5 k frames/s); the PHASED runner (--phased 1: four
+        # detectors queue their map kernels beside ORB / cuboid of four steps, then the four region stages run together with the ORB / cuboid
+        # stream idle) keeps the score kernel away from the walks and is timed beside it (`phased_runner`).  Below 512 frames the 16 host
+        # threads grow the regions and the GPU phases of one step overlap the host stage of the neighbouring one.
+        ctx_lines = [_lib.Context(local_rank, priority=-1) for _ in range(max(1, min(8, args.line_workers)))]  # device phases of the line detectors: background
         lsds = [line_lbd_detect(640, 480, max_frames=args.frames, ctx=c) for c in ctx_lines]
         for d_ in lsds:
             d_.upload(np.stack([s["gray"] for s in scenes]))
@@ -554,13 +557,37 @@ def main():
     if lsd is not None:
         for c in ctx_lines:
             c.timing(False)
-    # the same kernel without kernels of the other paths sharing the GPU (the timed region overlaps three streams)
-    ctx.timing(True); ctx.timing_reset()
-    for _ in range(10):
-        batch.run()
-    ctx.sync()
-    iso_ms, iso_n = ctx.timing_get("cuboid_sweep_score")
-    ctx.timing(False)
+    # the phased runner on the same objects, shortly: its throughput and the score kernel's time in ITS timed region (the kernel never meets a region walk there)
+    phased_alt = None
+    if lsd is not None and not args.phased and args.frames >= 512 and os.environ.get("CUBESLAM_LSD_REGIONS", "seq") == "seq" and len(ctx_lines) >= 2 and rank == 0 and world == 1:
+        fe.set_phased(True)
+        for _ in range(len(ctx_lines)):
+            fe.step()
+        barrier()
+        ctx.timing(True); ctx.timing_reset()
+        n_ph = 4 * len(ctx_lines)
+        t0 = time.perf_counter()
+        for _ in range(n_ph):
+            fe.step()
+        barrier()
+        dt_ph = time.perf_counter() - t0
+        ph_ms, ph_n = ctx.timing_get("cuboid_sweep_score")
+        ctx.timing(False)
+        phased_alt = {"value": args.frames * n_ph / dt_ph, "unit": "frames/s", "ms_per_step": 1e3 * dt_ph / n_ph, "steps": n_ph, "score_kernel_us_in_run": 1e3 * ph_ms / max(ph_n, 1)}
+        fe.set_phased(False)
+    # the same kernel without kernels of the other paths sharing the GPU: in the launch shape of the timed region, and in the 512-thread shape it has when it owns the CUs
+    iso = {}
+    for shared in ((True, False) if (lsd is not None and not args.phased) else (False,)):
+        batch.set_shared_gpu(shared)
+        batch.run(); ctx.sync()
+        ctx.timing(True); ctx.timing_reset()
+        for _ in range(10):
+            batch.run()
+        ctx.sync()
+        iso[shared] = ctx.timing_get("cuboid_sweep_score")
+        ctx.timing(False)
+    iso_ms, iso_n = iso[False]
+    batch.set_shared_gpu(lsd is not None and not args.phased)
     st = batch.stats()
     ss = batch.score_stats()
     got = batch.read()
@@ -625,16 +652,23 @@ def main():
                              "edge_scoring_stage_filter_plus_score": {"us": k_us + kernels["cuboid_sweep_filter"]["avg_us"],
                                                                       "frac": alg_bytes / ((k_us + kernels["cuboid_sweep_filter"]["avg_us"]) * 1e-6) / 1e9 / HBM_PEAK_GBS if k_us > 0 else None,
                                                                       "note": "the same bytes over cuboid_sweep_filter (reject tests of all hypotheses) + cuboid_sweep_score: everything between the distance transform and the selection"}},
-                         "isolated": {"avg_kernel_us": iso_us, "frac": (alg_bytes / (iso_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if iso_n else None,
-                                      "note": "cuboid path alone on the GPU; the timed region runs ORB, line and cuboid kernels concurrently on three streams"},
+                         "isolated": {"avg_kernel_us": iso_us, "frac": (alg_bytes / (iso_us * 1e-6) / 1e9 / HBM_PEAK_GBS) if iso_n else None, "threads_per_workgroup": 512,
+                                      "note": "cuboid path alone on the GPU, the kernel in the shape it has when it owns the CUs (512 threads, 2 waves per SIMD)"},
+                         "isolated_shared_shape": None if True not in iso else {"avg_kernel_us": 1e3 * iso[True][0] / max(iso[True][1], 1), "threads_per_workgroup": 256,
+                                                                                  "frac": alg_bytes / (1e3 * iso[True][0] / max(iso[True][1], 1) * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                                                                  "note": "alone on the GPU in the shape of the timed region: 256 threads of at most 128 registers, which fit beside a CU's sixteen lsd_rg_seq waves"},
+                         "phased_runner": None if phased_alt is None else dict(phased_alt, frac_in_run=alg_bytes / (phased_alt["score_kernel_us_in_run"] * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                                                               note="the other runner on the same objects: the region stages of the detectors run together with the ORB / cuboid stream idle, the score kernel "
+                                                                                    "(512-thread shape) only meets the detectors' map / rectangle / LBD kernels"),
                          "in_run_note": (None if lsd is None or not lsd.region_stats()["device"] else
                                          ("phased runner: lsd_rg_seq (one wave per frame, sixteen per CU) of the %d detectors runs between the super-steps with this stream idle, so this kernel never "
                                           "shares a CU with it; in the timed region it shares the chip with the detectors' map / rectangle / LBD kernels on their own streams (HBM-bound, many "
                                           "workgroups): `frac` is the in-run figure, `isolated.frac` the kernel's own" % len(ctx_lines)) if args.phased else
-                                         ("in the timed region each line detector in flight holds frames / 16 CUs for its whole lsd_rg_seq (one wave per frame, sixteen per CU); "
-                                          "this kernel's workgroups need whole CUs (160 KB LDS, 2 x 240 VGPRs per SIMD), so its %d persistent workgroups run in rounds on the CUs left free "
-                                          "(%d of 256 with %d detectors x %d frames): `frac` is the in-run figure, `isolated.frac` the kernel's own"
-                                          % (256, max(0, 256 - len(ctx_lines) * ((args.frames + 15) // 16)), len(ctx_lines), args.frames)))},
+                                         ("alternating runner (the faster one): every line detector in flight holds frames / 16 CUs for its whole lsd_rg_seq (one wave per frame, sixteen per CU) -- "
+                                          "%d of 256 CUs with %d detectors x %d frames -- and this kernel runs BESIDE those walks in its 256-thread shape (one wave per SIMD in the slot the walks leave, "
+                                          "the LDS they do not use), sharing every SIMD with four walking waves: `frac` is that in-run figure; `isolated` is the kernel alone in its own shape, "
+                                          "`phased_runner` what the runner that keeps it away from the walks measures"
+                                          % (min(256, len(ctx_lines) * ((args.frames + 15) // 16)), len(ctx_lines), args.frames)))},
             "kernels_us": {k: round(v["avg_us"], 2) for k, v in kernels.items()},
             "host_threads": _lib.lib().cs_host_thread_count(),
             "hbm_in_use_gb": round((lambda fr_to: (fr_to[1] - fr_to[0]) / 1e9)(torch.cuda.mem_get_info()), 1),  # everything resident for the run (all blocks of this line)

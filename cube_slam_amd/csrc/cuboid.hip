@@ -1241,8 +1241,10 @@ template <int CFG, bool HYB, bool LEAN> __device__ __forceinline__ void sc_score
     }
 }
 
+// NT = 256 is the variant that fits BESIDE a CU's sixteen lsd_rg_seq waves (4 x 96 registers per SIMD leave 128, no LDS in use there): four waves of at most 128
+// registers and the whole LDS -- the score kernel of the alternating runner, where region walks hold most CUs all the time.
 template <int NT>
-__global__ void __launch_bounds__(NT) cuboid_sweep_score(const Unit *units, const int *order, int n_items, int n_slices, int *cursor, const VPEntry *vpt, const float *dist,
+__global__ void __launch_bounds__(NT) __attribute__((amdgpu_waves_per_eu(NT == 256 ? 4 : 1, NT == 256 ? 4 : 8))) cuboid_sweep_score(const Unit *units, const int *order, int n_items, int n_slices, int *cursor, const VPEntry *vpt, const float *dist,
                                                          const int *vcount, const int *vlist, int *uflag, double *derr, double *aerr, unsigned long long *prof) {
     extern __shared__ __attribute__((aligned(16))) unsigned char sc_mem[];
     // (development, CUBESLAM_SCORE_PROF) wall-clock ticks of this wave in the three parts of a unit: copy + encode, scoring tasks, waiting at the barriers
@@ -1252,13 +1254,15 @@ __global__ void __launch_bounds__(NT) cuboid_sweep_score(const Unit *units, cons
     unsigned short *lut = reinterpret_cast<unsigned short *>(sc_mem + SC_CTRL_BYTES);
     unsigned short *lmap = reinterpret_cast<unsigned short *>(sc_mem + SC_MAP_OFF);
     const int tid = threadIdx.x, lane = tid & 63;
+    // beside a CU's region walks (the 256-thread shape) this wave is one of five on its SIMD and the only one somebody waits for: it goes first
+    if (NT == 256) __builtin_amdgcn_s_setprio(3);
     for (int i = tid; i < SC_LUT_N; i += NT) lut[i] = 0;
     if (tid == 0) { ctrl[2] = 0; ctrl[3] = 0; ctrl[5] = atomicAdd(cursor, 1); }
     __syncthreads();
     if (tid < 256) { const int j = tid, r = (j * DT_DIAG) % DT_HV; lut[r >> 6] = (unsigned short)((j << 8) - (j * DT_DIAG) / DT_HV); }
     __syncthreads();
     int item = __builtin_amdgcn_readfirstlane(ctrl[5]); // (uniform by construction; tell the compiler: the unit's fields then live in scalar registers)
-    constexpr bool LEAN = NT >= 1024;
+    constexpr bool LEAN = NT != 512; // (512: 2 waves per SIMD with 256 registers each; every other shape lives on 128)
     constexpr int NPF = NT >= 768 ? 4 : 8; // groups of 8 pixels (two 16-byte loads) per thread in flight while a map is copied
     auto unit_of = [&](int itm, int &uu, int &sl) { uu = __builtin_amdgcn_readfirstlane(order[n_slices == 1 ? itm : itm / n_slices]); sl = n_slices == 1 ? 0 : itm % n_slices; };
     for (int it = 0; item < n_items; it++) {
@@ -1770,7 +1774,8 @@ struct cs_cuboid_batch {
     int *d_uflag = nullptr;                      // per unit: 1 = a pixel without a 16-bit code (scored from the float map)
     unsigned long long *d_prof = nullptr;        // CUBESLAM_SCORE_PROF: per wave {copy, tasks, barrier wait} ticks and task count of the last launch
     int score_G = 256;      // workgroups of cuboid_sweep_score (one per CU)
-    int score_T = 512;      // threads per workgroup (CUBESLAM_SCORE_THREADS = 512 | 768 | 1024: 2 / 3 / 4 waves per SIMD with 256 / 168 / 128 registers)
+    int score_T = 512;      // threads per workgroup (CUBESLAM_SCORE_THREADS = 256 | 512 | 768 | 1024: 1 / 2 / 3 / 4 waves per SIMD with 128 / 256 / 168 / 128 registers)
+    bool score_T_forced = false; // set by the environment: cs_cuboid_batch_set_shared_gpu leaves it alone
     int score_slices = 1;   // items per unit (more than one when there are fewer units than CUs)
     int dt_C = 0; // wave-per-ROI distance transform: int map between the passes, lane-major
     FrameInfo *d_fi = nullptr; FrameDyn *d_fd = nullptr; CamRP *d_cam = nullptr;
@@ -1916,7 +1921,8 @@ int cs_cuboid_batch_create(cs_ctx *ctx, int n_frames, int width, int height, con
         }
     }
     {
-        for (const void *fn : {reinterpret_cast<const void *>(cuboid_sweep_score<512>), reinterpret_cast<const void *>(cuboid_sweep_score<768>), reinterpret_cast<const void *>(cuboid_sweep_score<1024>)}) { // (per call: the attribute is per device)
+        for (const void *fn : {reinterpret_cast<const void *>(cuboid_sweep_score<256>), reinterpret_cast<const void *>(cuboid_sweep_score<512>), reinterpret_cast<const void *>(cuboid_sweep_score<768>),
+                               reinterpret_cast<const void *>(cuboid_sweep_score<1024>)}) { // (per call: the attribute is per device)
             hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, SC_LDS_BYTES);
             if (e != hipSuccess) { ctx->err = hipGetErrorString(e); cs_cuboid_batch_destroy(ctx, b); return CS_ERR_HIP; }
         }
@@ -1930,7 +1936,7 @@ int cs_cuboid_batch_create(cs_ctx *ctx, int n_frames, int width, int height, con
         const char *ge = getenv("CUBESLAM_SCORE_SEGMENTS"); // tuning knob: workgroups of cuboid_sweep_score
         if (ge && atoi(ge) > 0) b->score_G = atoi(ge);
         const char *te = getenv("CUBESLAM_SCORE_THREADS"); // tuning knob: 512 (2 waves per SIMD, 256 registers) or 1024 (4 waves per SIMD, 128 registers)
-        if (te && (atoi(te) == 512 || atoi(te) == 768 || atoi(te) == 1024)) b->score_T = atoi(te);
+        if (te && (atoi(te) == 256 || atoi(te) == 512 || atoi(te) == 768 || atoi(te) == 1024)) { b->score_T = atoi(te); b->score_T_forced = true; }
         b->score_slices = b->n_units >= 2 * b->score_G ? 1 : std::min(16, (2 * b->score_G + b->n_units - 1) / std::max(1, b->n_units));
         const char *se = getenv("CUBESLAM_SCORE_SLICES"); // tuning knob / tests: items per unit
         if (se && atoi(se) > 0) b->score_slices = std::min(64, atoi(se));
@@ -2020,6 +2026,15 @@ int cs_cuboid_batch_set_lines(cs_ctx *ctx, cs_cuboid_batch *b, const int *line_o
     return CS_OK;
 }
 
+// shared != 0: kernels that hold whole CUs for a long time run beside this batch (the line detectors' one-wave-per-frame region walks of the alternating
+// front-end runner): cuboid_sweep_score then takes the shape that fits into what those leave of a CU (256 threads of at most 128 registers + the LDS they do
+// not use) instead of waiting for CUs to come free.  Same results either way.
+int cs_cuboid_batch_set_shared_gpu(cs_cuboid_batch *b, int shared) {
+    if (!b) return CS_ERR_BAD_ARG;
+    if (!b->score_T_forced) b->score_T = shared ? 256 : 512;
+    return CS_OK;
+}
+
 int cs_cuboid_batch_run(cs_ctx *ctx, cs_cuboid_batch *b) {
     if (!ctx || !b) return CS_ERR_BAD_ARG;
     CS_HIP(ctx, hipSetDevice(ctx->device));
@@ -2060,7 +2075,10 @@ int cs_cuboid_batch_run(cs_ctx *ctx, cs_cuboid_batch *b) {
     CS_HIP(ctx, hipMemsetAsync(b->d_uflag, 0, sizeof(int) * (size_t)U, ctx->stream));
     {
         const int items = U * b->score_slices, grid = std::min(b->score_G, items);
-        if (b->score_T == 512)
+        if (b->score_T == 256)
+            CS_LAUNCH(ctx, "cuboid_sweep_score", cuboid_sweep_score<256>, dim3(grid), dim3(256), SC_LDS_BYTES, b->d_units, b->d_order, items, b->score_slices, b->d_cursor, b->d_vp,
+                      b->d_dist, b->d_vcount, b->d_vlist, b->d_uflag, b->d_derr, b->d_aerr, b->d_prof);
+        else if (b->score_T == 512)
             CS_LAUNCH(ctx, "cuboid_sweep_score", cuboid_sweep_score<512>, dim3(grid), dim3(512), SC_LDS_BYTES, b->d_units, b->d_order, items, b->score_slices, b->d_cursor, b->d_vp,
                       b->d_dist, b->d_vcount, b->d_vlist, b->d_uflag, b->d_derr, b->d_aerr, b->d_prof);
         else if (b->score_T == 768)

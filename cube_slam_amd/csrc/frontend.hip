@@ -23,6 +23,7 @@ extern "C" int cs_lsd_run(cs_ctx *ctx, cs_lsd *l, int with_lbd);
 void cs_lsd_set_gate(cs_lsd *l, void (*wait)(void *), void (*done)(void *), void *arg); // lsd.hip
 extern "C" int cs_orb_run(cs_ctx *ctx, cs_orb *e);
 extern "C" int cs_cuboid_batch_run(cs_ctx *ctx, cs_cuboid_batch *b);
+extern "C" int cs_cuboid_batch_set_shared_gpu(cs_cuboid_batch *b, int shared);
 
 namespace {
 struct Gate { // phase gate of one runner: tickets are pass numbers, the gate is open for every ticket <= target
@@ -104,7 +105,7 @@ struct cs_frontend {
 extern "C" {
 
 int cs_frontend_create(cs_ctx *ctx, cs_orb *orb, cs_cuboid_batch *batch, int n_line_workers, cs_ctx *const *line_ctx, cs_lsd *const *lsd, cs_frontend **out) {
-    if (!ctx || !out || n_line_workers < 0 || n_line_workers > 4 || (n_line_workers && (!line_ctx || !lsd))) return CS_ERR_BAD_ARG;
+    if (!ctx || !out || n_line_workers < 0 || n_line_workers > 8 || (n_line_workers && (!line_ctx || !lsd))) return CS_ERR_BAD_ARG;
     for (int i = 0; i < n_line_workers; i++) if (!line_ctx[i] || !lsd[i] || line_ctx[i] == ctx) return CS_ERR_BAD_ARG; // a worker needs its own context (stream, timing records)
     cs_frontend *fe = new (std::nothrow) cs_frontend();
     if (!fe) return CS_ERR_NOMEM;
@@ -116,6 +117,7 @@ int cs_frontend_create(cs_ctx *ctx, cs_orb *orb, cs_cuboid_batch *batch, int n_l
         w->th = std::thread([w] { w->loop(); });
         fe->workers.push_back(w);
     }
+    if (fe->batch) cs_cuboid_batch_set_shared_gpu(fe->batch, n_line_workers > 0); // alternating runner: the detectors' region walks hold most CUs all the time
     *out = fe;
     return CS_OK;
 }
@@ -136,6 +138,7 @@ int cs_frontend_set_phased(cs_frontend *fe, int on) {
     int r = cs_frontend_drain(fe); // no pass in flight across the switch
     std::lock_guard<std::mutex> lk(fe->gate.m);
     fe->gate.phased = on != 0;
+    if (fe->batch) cs_cuboid_batch_set_shared_gpu(fe->batch, !on && !fe->workers.empty()); // phased: the score kernel never meets a region walk
     return r;
 }
 

@@ -133,6 +133,10 @@ class CuboidBatch:
         lines = np.ascontiguousarray(np.concatenate([np.asarray(l, np.float64).reshape(-1, 4) for l in lines_list] + [np.zeros((1, 4))]))
         check(self.ctx.ptr, lib().cs_cuboid_batch_set_lines(self.ctx.ptr, self._b, _p(lo, C.c_int), _p(lines, C.c_double)), "cs_cuboid_batch_set_lines")
 
+    def set_shared_gpu(self, shared):
+        """Speed hint: long-running kernels of other streams hold most CUs while this batch runs (cs_cuboid_batch_set_shared_gpu)."""
+        check(self.ctx.ptr, lib().cs_cuboid_batch_set_shared_gpu(self._b, 1 if shared else 0), "cs_cuboid_batch_set_shared_gpu")
+
     def run(self):
         check(self.ctx.ptr, lib().cs_cuboid_batch_run(self.ctx.ptr, self._b), "cs_cuboid_batch_run")
 
