@@ -21,6 +21,7 @@
 
 extern "C" int cs_lsd_run(cs_ctx *ctx, cs_lsd *l, int with_lbd);
 void cs_lsd_set_gate(cs_lsd *l, void (*wait)(void *), void (*done)(void *), void *arg); // lsd.hip
+void cs_lsd_set_shared_gpu(cs_lsd *l, int shared);                                                // lsd.hip
 extern "C" int cs_orb_run(cs_ctx *ctx, cs_orb *e);
 extern "C" int cs_cuboid_batch_run(cs_ctx *ctx, cs_cuboid_batch *b);
 extern "C" int cs_cuboid_batch_set_shared_gpu(cs_cuboid_batch *b, int shared);
@@ -118,6 +119,7 @@ int cs_frontend_create(cs_ctx *ctx, cs_orb *orb, cs_cuboid_batch *batch, int n_l
         fe->workers.push_back(w);
     }
     if (fe->batch) cs_cuboid_batch_set_shared_gpu(fe->batch, n_line_workers > 0); // alternating runner: the detectors' region walks hold most CUs all the time
+    for (LineWorker *w : fe->workers) cs_lsd_set_shared_gpu(w->lsd, n_line_workers > 1);
     *out = fe;
     return CS_OK;
 }
@@ -139,6 +141,7 @@ int cs_frontend_set_phased(cs_frontend *fe, int on) {
     std::lock_guard<std::mutex> lk(fe->gate.m);
     fe->gate.phased = on != 0;
     if (fe->batch) cs_cuboid_batch_set_shared_gpu(fe->batch, !on && !fe->workers.empty()); // phased: the score kernel never meets a region walk
+    for (LineWorker *w : fe->workers) cs_lsd_set_shared_gpu(w->lsd, !on && fe->workers.size() > 1); // phased: sixteen frames per CU, the walks packed
     return r;
 }
 

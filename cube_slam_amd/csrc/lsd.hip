@@ -578,6 +578,7 @@ struct cs_lsd {
     std::vector<uint8_t> h_desc;     // concatenated n x 32
     bool have_desc = false;
     LsdSeq *seq = nullptr;           // device buffers of the region stage (lsd_regions.hip)
+    int seq_wpb = 16; // frames per workgroup of the device region stage (cs_lsd_set_shared_gpu)
     void (*gate_wait)(void *) = nullptr; void (*gate_done)(void *) = nullptr; void *gate_arg = nullptr; // the front-end runner's phase gate around the region stage (frontend.hip)
     long rg_stats[5] = {0, 0, 0, 0, 0}; // last batch: 1 = device stage asked for, region_grow calls, rectangles at rect_improve, 1 = fell back to the host stage, window fetches
 };
@@ -654,7 +655,7 @@ static int lsd_run(cs_ctx *ctx, cs_lsd *l, int with_lbd) {
     if (l->gate_wait && !use_seq) l->gate_wait(l->gate_arg); // (phased front-end: the region stage starts when the caller's own GPU work of the phase is done; the device stage waits inside lsd_seq_run, in front of its one long kernel)
     if (use_seq) {
         long st[4] = {0, 0, 0, 0};
-        r = lsd_seq_run(ctx, &l->seq, F, w, h, l->d_ang, l->d_mod, l->d_caddr, l->d_cdeg, l->d_ccs, l->frame_base.data(), dev_lines, st, l->gate_wait, l->gate_done, l->gate_arg);
+        r = lsd_seq_run(ctx, &l->seq, F, w, h, l->d_ang, l->d_mod, l->d_caddr, l->d_cdeg, l->d_ccs, l->frame_base.data(), dev_lines, st, l->gate_wait, l->gate_done, l->gate_arg, l->seq_wpb);
         l->rg_stats[0] = 1; l->rg_stats[1] = st[0]; l->rg_stats[2] = st[2]; l->rg_stats[3] = r == CS_OK ? 0 : 1; l->rg_stats[4] = st[1];
         if (r == CS_OK) on_device = true;
         else if (r != CS_ERR_CAPACITY) return r; // a region outgrew the wave's list: the host stage takes the batch
@@ -899,3 +900,5 @@ int cs_lsd_get_maps(cs_ctx *ctx, cs_lsd *l, int frame, double *scaled, double *m
 
 // internal (frontend.hip): the runner's phase gate around the region stage; wait() is called before it, done() once lsd_rg_seq has left the GPU
 void cs_lsd_set_gate(cs_lsd *l, void (*wait)(void *), void (*done)(void *), void *arg) { l->gate_wait = wait; l->gate_done = done; l->gate_arg = arg; }
+// shared: other detectors' walks and the other streams' kernels keep every CU busy anyway (the alternating front-end runner): the region stage spreads over the chip
+void cs_lsd_set_shared_gpu(cs_lsd *l, int shared) { l->seq_wpb = shared ? 4 : 16; }

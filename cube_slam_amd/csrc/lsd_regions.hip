@@ -293,7 +293,9 @@ void lsd_seq_destroy(LsdSeq *r) {
 // outgrew the wave's list (rgs::CAP pixels) or a frame its rectangle list -- the caller then runs the host stage for the batch.
 int lsd_seq_run(cs_ctx *ctx, LsdSeq **handle, int F, int w, int h, const double *d_ang, const double *d_mod, const int *d_caddr, const float *d_cdeg, const float2 *d_ccs, const int *frame_base,
                 std::vector<std::vector<float>> &lines, long *stats /* [0] region_grow calls, [1] window fetches, [2] rectangles at rect_improve, [3] regions at the rectangle stage */,
-                void (*before_seq)(void *), void (*after_seq)(void *), void *gate_arg /* the front-end runner's phase gate: called in front of the lsd_rg_seq launch and once it has left the GPU; may be NULL */) {
+                void (*before_seq)(void *), void (*after_seq)(void *), void *gate_arg /* the front-end runner's phase gate: called in front of the lsd_rg_seq launch and once it has left the GPU; may be NULL */,
+                int waves_per_workgroup /* frames per workgroup of lsd_rg_seq: 16 packs a batch onto F / 16 CUs and leaves the others empty; 4 spreads it over the chip (the alternating runner, where
+                                           every CU is busy anyway: 128 -> 104 ms per launch there) */) {
     LsdSeq *r = *handle;
     if (w > 0xffff || h > 0x7fff) return CS_ERR_CAPACITY; // (the region list packs x | y << 16)
     int max_ne = 0;
@@ -336,7 +338,7 @@ int lsd_seq_run(cs_ctx *ctx, LsdSeq **handle, int F, int w, int h, const double 
     const size_t npx = (size_t)F * w * h;
     CS_LAUNCH(ctx, "lsd_rg_fill", lsd_rg_fill, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, r->d_pix, npx);
     CS_LAUNCH(ctx, "lsd_rg_scatter", lsd_rg_scatter, dim3((max_ne + 255) / 256, F), dim3(256), 0, S);
-    int wpb = 16; // waves (= frames) per workgroup
+    int wpb = std::max(1, std::min(16, waves_per_workgroup)); // waves (= frames) per workgroup
     if (const char *e = getenv("CUBESLAM_LSD_SEQ_WPB")) wpb = std::max(1, std::min(16, atoi(e)));
     if (before_seq) before_seq(gate_arg);
     CS_LAUNCH(ctx, "lsd_rg_seq", lsd_rg_seq, dim3((F + wpb - 1) / wpb), dim3(64 * wpb), 0, S);
