@@ -234,6 +234,7 @@ void Optimizer::LocalBACameraPointObjects(KeyFrame *pKF, bool *pbStopFlag, Map *
     for (MapPoint *pMP : lLocalMapPoints) pMP->mnBALocalForKF = 0;
     for (size_t k = 0; k < res.point_rows.size(); k++) {
         MapPoint *pMP = lLocalMapPoints[res.point_rows[k]];
+        if (pMP->Observations() == 1) continue; // :1511-1512, read AFTER the erasures above: a point they left with one observation keeps its position (res.point_unwritten)
         cv::Mat X(3, 1, CV_32F);
         for (int a = 0; a < 3; a++) X.at<float>(a) = (float)res.point_pos[k * 3 + a];
         pMP->SetWorldPos(X); pMP->UpdateNormalAndDepth();

@@ -169,7 +169,7 @@ def _residuals(d, ctx):
 
 
 def LocalBACameraPointObjects(window, params, ctx=None, fixCamera=False, stop_flag=None):
-    """-> dict(kf_pose (n_local,7), point_pos {row of mp_*: xyz}, object_pose (c,7), object_scale (c,3), erase [(kf row, mp row)],
+    """-> dict(kf_pose (n_local,7), point_pos {row of mp_*: xyz}, point_unwritten [rows of mp_* the caller leaves as they are], object_pose (c,7), object_scale (c,3), erase [(kf row, mp row)],
     obs_level, cobs_level (after stage 1), stats).  The caller writes the poses back (SetPose / SetWorldPos / UpdateNormalAndDepth) and
     erases the listed observations (:1477-1533)."""
     g = build_graph(window, params, fixCamera)
@@ -188,6 +188,12 @@ def LocalBACameraPointObjects(window, params, ctx=None, fixCamera=False, stop_fl
     order = [k for k in range(n_obs) if not stereo[k]] + [k for k in range(n_obs) if stereo[k]]         # vpEdgesMono, then vpEdgesStereo
     rows = g["obs_rows"]
     erase = [(int(window["obs_kf"][rows[k]]), int(window["obs_mp"][rows[k]])) for k in order if bad[k]]
+    # the reference's write-back re-reads MapPoint::Observations() after the erasures (:1486-1496 before :1509-1516): a point they leave with exactly one
+    # observation is NOT written back -- `point_unwritten` lists those rows of mp_*
+    left = np.asarray(window["mp_nobs"], int).copy()
+    for _, r in erase:
+        left[r] -= 1
+    unwritten = [int(r) for r in g["point_rows"] if left[r] == 1]
     return {"kf_pose": fin["cam_pose"][:int(window["n_local"])], "point_pos": {int(r): fin["points"][j] for j, r in enumerate(g["point_rows"])},
-            "object_pose": fin["cuboid_pose"], "object_scale": d["cuboid_scale"], "erase": erase, "obs_level": obs_level, "cobs_level": cobs_level,
+            "object_pose": fin["cuboid_pose"], "object_scale": d["cuboid_scale"], "erase": erase, "point_unwritten": unwritten, "obs_level": obs_level, "cobs_level": cobs_level,
             "cobs_level2": cobs_level2, "stats": (st1, st2), "graph": g}

@@ -36,6 +36,7 @@ struct LocalBAParams {
 struct LocalBAResult {
     std::vector<double> kf_pose;                       // n_local x 7
     std::vector<int> point_rows; std::vector<double> point_pos; // rows of mp_* that were vertices, and their positions
+    std::vector<int> point_unwritten;                          // of those, the rows the erase list leaves with exactly one observation: the reference does not write them back (:1511-1512 after :1486-1496)
     std::vector<double> object_pose, object_scale;     // objects x 7, x 3
     std::vector<std::pair<int, int>> erase;            // (row of kf_*, row of mp_*)
     std::vector<uint8_t> obs_level, cobs_level, cobs_level2; std::vector<int> obs_rows, det_rows;
@@ -258,6 +259,10 @@ inline void LocalBACameraPointObjects(Context &c, const LocalWindow &w, const Lo
         }
     out.kf_pose.assign(d.cam_pose.begin(), d.cam_pose.begin() + (size_t)w.n_local * 7);
     out.point_pos = d.points; out.object_pose = d.cuboid_pose;
+    std::vector<int> left(w.mp_nobs);
+    for (auto &e : out.erase) left[e.second]--;
+    out.point_unwritten.clear();
+    for (int r : out.point_rows) if (left[r] == 1) out.point_unwritten.push_back(r);
 }
 
 } // namespace cubeslam

@@ -34,7 +34,9 @@ class KeyFrame:
         self.map_point_matches = []  # MapPoint or None per key point
         self.covisible = []          # GetVectorCovisibleKeyFrames()
 
-    def camera_center(self):  # GetCameraCenter(): -R^T t
+    def camera_center(self):  # GetCameraCenter(): -R^T t; `Ow` (3 floats), when a test sets it, is the value KeyFrame::SetPose stored (float arithmetic on the float pose)
+        if getattr(self, "Ow", None) is not None:
+            return np.asarray(self.Ow, float)
         t, q = self.Tcw[:3], self.Tcw[3:]
         return -_rot(q).T @ t
 
@@ -256,10 +258,15 @@ def local_ba_camera_point_objects(pKF, params, fixCamera=False):
     bad = (chi_used > np.where(st, 7.815, 5.991)) | ~(z2 > 0)
     order = [k for k in range(n_obs) if not st[k]] + [k for k in range(n_obs) if st[k]]  # vpEdgesMono first, then vpEdgesStereo
     erase = [(obs_kf[k].mnId, obs_mp[k].mnId) for k in order if bad[k] and not obs_mp[k].bad]
+    # write-back :1509-1516 re-reads Observations() AFTER the erasures (:1486-1496): a point they leave with exactly one observation keeps its old position
+    n_erased = {}
+    for _, m in erase:
+        n_erased[m] = n_erased.get(m, 0) + 1
+    unwritten = [mp.mnId for mp in pt_mp if mp.Observations() - n_erased.get(mp.mnId, 0) == 1]
     return {"kf_pose": {k.mnId: fin["cam_pose"][i] for i, k in enumerate(local_kfs)},
             "point_pos": {mp.mnId: fin["points"][j] for j, mp in enumerate(pt_mp)},
             "object_pose": {mo.mnId: fin["cuboid_pose"][i] for i, mo in enumerate(objects)}, "object_scale": {mo.mnId: d["cuboid_scale"][i] for i, mo in enumerate(objects)},
-            "erase": erase, "stats": (st1, st2), "problem": d, "obs_level": obs_level, "cobs_level": cobs_level, "cobs_level2": cobs_level2,
+            "erase": erase, "point_unwritten": unwritten, "stats": (st1, st2), "problem": d, "obs_level": obs_level, "cobs_level": cobs_level, "cobs_level2": cobs_level2,
             "order": {"kfs": [k.mnId for k in kfs], "n_local": len(local_kfs), "points": [mp.mnId for mp in pt_mp], "objects": [mo.mnId for mo in objects]}}
 
 

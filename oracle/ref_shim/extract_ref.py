@@ -113,6 +113,13 @@ WANT = [  # (file, signatures, output include)
                                               "class EdgeDynamicPointCuboidCamera : public BaseMultiEdge<2, Vector2d>", "class EdgeObjectMotion : public BaseMultiEdge<3, Vector3d>"], "extracted_lin_dyn.inc"),
     ("orb_object_slam/src/g2o_Object.cpp", ["void EdgeDynamicPointCuboidCamera::computeError()", "void EdgeDynamicPointCuboidCamera::linearizeOplus()", "void EdgeObjectMotion::computeError()",
                                             "void UnaryLocalPoint::computeError()"], "extracted_lin_dyn.inc"),
+    # the graph-level optimisation functions, whole, with the conversions they call (compiled against the reference's own g2o and stand-ins for the map classes,
+    # ref_graph_api.cpp / slam_graph_standins.hpp)
+    ("orb_object_slam/src/Converter.cc", ["g2o::SE3Quat Converter::toSE3Quat(const cv::Mat &cvT)", "cv::Mat Converter::toCvMat(const g2o::SE3Quat &SE3)",
+                                          "cv::Mat Converter::toCvMat(const Eigen::Matrix<double, 4, 4> &m)", "cv::Mat Converter::toCvMat(const Eigen::Matrix<double, 3, 1> &m)",
+                                          "Eigen::Matrix<double, 3, 1> Converter::toVector3d(const cv::Mat &cvVector)"], "extracted_graph.inc"),
+    ("orb_object_slam/src/Optimizer.cc", ["void Optimizer::BundleAdjustment(const vector<KeyFrame *> &vpKFs, const vector<MapPoint *> &vpMP,", "int Optimizer::PoseOptimization(Frame *pFrame)",
+                                          "void Optimizer::LocalBACameraPointObjects(KeyFrame *pKF, bool *pbStopFlag, Map *pMap, bool fixCamera, bool fixPoint)"], "extracted_graph.inc"),
     # the LBD descriptor: BinaryDescriptor's compute path (the rest of binary_descriptor.cpp is the EDLine detector, which CubeSLAM does not use)
     ("line_lbd/libs/binary_descriptor.cpp", ["static const int combinations[32][2] =", "BinaryDescriptor::Params::Params()", "BinaryDescriptor::BinaryDescriptor( const BinaryDescriptor::Params &parameters ) :",
                                              "BinaryDescriptor::~BinaryDescriptor()", "static inline int get2Pow( int i )", "void BinaryDescriptor::computeGaussianPyramid( const Mat& image, const int numOctaves )",

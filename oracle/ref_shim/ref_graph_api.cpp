@@ -1,0 +1,187 @@
+// TEST INFRASTRUCTURE (never linked into the product): the reference's graph-level optimisation functions, run as they are written.
+//   Optimizer::BundleAdjustment (orb_object_slam/src/Optimizer.cc:64-251), Optimizer::PoseOptimization (:253-472) and
+//   Optimizer::LocalBACameraPointObjects (:826-1534) are cut out of the reference at build time (oracle/_ref/extracted_graph.inc, extract_ref.py) together
+//   with the Converter functions they call (src/Converter.cc:36-52, 62-70, 82-89, 109-115) and compiled here against
+//     * the reference's vendored g2o, WHOLE, from where it lies (Thirdparty/g2o/g2o/{core,types,stuff}: SparseOptimizer, BlockSolver with its Schur complement
+//       block_solver.hpp:354-486, OptimizationAlgorithmLevenberg, LinearSolverDense, the robust kernels) and the reference's g2o_Object.{h,cpp} and matrix_utils.cpp,
+//     * a stand-in for Eigen (oracle/ref_shim/eigen_full: Eigen is not in this image) and for LinearSolverEigen (g2o_shadow: a wrapper of Eigen's sparse Cholesky),
+//     * stand-ins for the map classes that hold the data those functions read (slam_graph_standins.hpp).
+// tests/test_ref_graph_pins.py fills a window through the C entry points below, runs the reference's function and holds the oracle's graph-level restatements
+// (oracle/local_ba_objects.py, orc_ba_optimize, orc_pose_optimization) to what it leaves in the map.
+#include "slam_graph_standins.hpp"
+
+#include <cstring>
+#include <memory>
+
+using namespace std;
+using namespace Eigen;
+
+namespace ORB_SLAM2 {
+bool standin_verbose = false;
+bool parallel_mapping = false, whether_dynamic_object = false, build_worldframe_on_ground = false, whether_detect_object = true, associate_point_with_object = true, bundle_object_opti = true;
+bool remove_dynamic_features = false, use_dynamic_klt_features = false, mono_firstframe_truth_depth_init = false, mono_firstframe_Obj_depth_init = false, mono_allframe_Obj_depth_init = false;
+bool enable_ground_height_scale = false, ba_dyna_pt_obj_cam = false, ba_dyna_obj_velo = false, ba_dyna_obj_cam = false, draw_map_truth_paths = false, draw_nonlocal_mappoint = false;
+double camera_object_BA_weight = 1.0, object_velocity_BA_weight = 1.0, delta_t = 0.1;
+Scene_Name scene_unique_id = kitti;
+EraseLog *standin_log = nullptr;
+std::mutex MapPoint::mGlobalMutex;
+
+#include "extracted_graph.inc"
+} // namespace ORB_SLAM2
+
+using namespace ORB_SLAM2;
+#define API extern "C" __attribute__((visibility("default")))
+
+struct ref_graph {
+    std::vector<std::unique_ptr<KeyFrame>> kfs;
+    std::vector<std::unique_ptr<MapPoint>> mps;
+    std::vector<std::unique_ptr<MapObject>> mos, dets; // landmarks; per-frame detections (KeyFrame::local_cuboids)
+    ORB_SLAM2::Map map;
+    EraseLog log;
+    std::streambuf *cout_was = nullptr;
+};
+
+static cv::Mat mat_f(int r, int c, const float *v) { cv::Mat m(r, c, CV_32F); for (int i = 0; i < r; i++) for (int j = 0; j < c; j++) m.at<float>(i, j) = v[i * c + j]; return m; }
+static g2o::cuboid cuboid_of(const double *pose7, const double *scale3) {
+    g2o::cuboid c;
+    c.pose = g2o::SE3Quat(Eigen::Quaterniond(pose7[6], pose7[3], pose7[4], pose7[5]), Eigen::Vector3d(pose7[0], pose7[1], pose7[2]));
+    c.scale = Eigen::Vector3d(scale3[0], scale3[1], scale3[2]);
+    return c;
+}
+
+API ref_graph *ref_graph_open() { return new ref_graph(); }
+API void ref_graph_close(ref_graph *g) { delete g; }
+API void ref_graph_set_params(ref_graph *g, int is_kitti, int worldframe_on_ground, double cam_obj_weight, int dynamic_objects, int img_w, int img_h, const double *K9, int verbose) {
+    scene_unique_id = is_kitti ? kitti : voidtype;
+    build_worldframe_on_ground = worldframe_on_ground != 0; camera_object_BA_weight = cam_obj_weight; whether_dynamic_object = dynamic_objects != 0; standin_verbose = verbose != 0;
+    g->map.img_width = img_w; g->map.img_height = img_h;
+    for (int i = 0; i < 3; i++) for (int j = 0; j < 3; j++) { g->map.Kalib(i, j) = K9[i * 3 + j]; g->map.Kalib_f(i, j) = (float)K9[i * 3 + j]; }
+    g->map.invKalib = g->map.Kalib.inverse();
+}
+// a key frame: pose as the 4 x 4 float matrix KeyFrame::GetPose returns, camera centre as GetCameraCenter returns it (3 floats), undistorted key points
+API int ref_graph_add_kf(ref_graph *g, long id, int bad, const float *Tcw16, const float *Ow3, int n_keys, const float *keys_xy, const float *u_right, const int *octave, int n_levels,
+                         const float *inv_level_sigma2, float fx, float fy, float cx, float cy, float bf) {
+    std::unique_ptr<KeyFrame> k(new KeyFrame());
+    k->mnId = (unsigned long)id; k->mnFrameId = (unsigned long)id; k->bad = bad != 0;
+    k->Tcw = mat_f(4, 4, Tcw16); k->Ow = mat_f(3, 1, Ow3);
+    k->mvKeysUn.resize(n_keys); k->mvuRight.assign(u_right, u_right + n_keys); k->mvpMapPoints.assign(n_keys, nullptr);
+    for (int i = 0; i < n_keys; i++) { k->mvKeysUn[i].pt.x = keys_xy[2 * i]; k->mvKeysUn[i].pt.y = keys_xy[2 * i + 1]; k->mvKeysUn[i].octave = octave[i]; }
+    k->mvInvLevelSigma2.assign(inv_level_sigma2, inv_level_sigma2 + n_levels);
+    k->fx = fx; k->fy = fy; k->cx = cx; k->cy = cy; k->mbf = bf;
+    g->kfs.push_back(std::move(k));
+    return (int)g->kfs.size() - 1;
+}
+API int ref_graph_add_mp(ref_graph *g, long id, int bad, const float *pos3, int is_dynamic) {
+    std::unique_ptr<MapPoint> p(new MapPoint());
+    p->mnId = (unsigned long)id; p->bad = bad != 0; p->is_dynamic = is_dynamic != 0; p->mWorldPos = mat_f(3, 1, pos3);
+    g->mps.push_back(std::move(p));
+    return (int)g->mps.size() - 1;
+}
+API int ref_graph_add_mo(ref_graph *g, long id, int bad, const double *pose7, const double *scale3, double meas_quality, int largest_point_observations) {
+    std::unique_ptr<MapObject> o(new MapObject());
+    o->mnId = id; o->bad = bad != 0; o->pose_Twc = cuboid_of(pose7, scale3); o->meas_quality = meas_quality; o->largest_point_observations = largest_point_observations;
+    g->mos.push_back(std::move(o));
+    return (int)g->mos.size() - 1;
+}
+API void ref_graph_kf_covisible(ref_graph *g, int kf, int other) { g->kfs[kf]->covisible.push_back(g->kfs[other].get()); }
+API void ref_graph_kf_match(ref_graph *g, int kf, int key, int mp) { g->kfs[kf]->mvpMapPoints[key] = mp < 0 ? nullptr : g->mps[mp].get(); }
+API void ref_graph_mp_observe(ref_graph *g, int mp, int kf, int key) { g->mps[mp]->mObservations[g->kfs[kf].get()] = (size_t)key; }
+// a detection of a key frame (KeyFrame::local_cuboids entry) and the landmark it was associated with (KeyFrame::cuboids_landmark entry, -1: NULL, -2: no entry)
+API int ref_graph_kf_detection(ref_graph *g, int kf, const double *bbox_vec4, const int *bbox_2d4, int left_right_to_car, double meas_quality, int landmark) {
+    std::unique_ptr<MapObject> d(new MapObject());
+    d->bbox_vec = Eigen::Vector4d(bbox_vec4[0], bbox_vec4[1], bbox_vec4[2], bbox_vec4[3]);
+    d->bbox_2d = cv::Rect(bbox_2d4[0], bbox_2d4[1], bbox_2d4[2], bbox_2d4[3]);
+    d->left_right_to_car = left_right_to_car; d->meas_quality = meas_quality;
+    KeyFrame *k = g->kfs[kf].get();
+    d->object_id_in_localKF = (int)k->local_cuboids.size();
+    k->local_cuboids.push_back(d.get());
+    if (landmark >= -1) k->cuboids_landmark.push_back(landmark < 0 ? nullptr : g->mos[landmark].get());
+    g->dets.push_back(std::move(d));
+    return (int)k->local_cuboids.size() - 1;
+}
+API void ref_graph_mo_observe(ref_graph *g, int mo, int kf, int det) { g->mos[mo]->mObservations[g->kfs[kf].get()] = (size_t)det; g->mos[mo]->observed_frames.push_back(g->kfs[kf].get()); }
+API void ref_graph_mo_unique_point(ref_graph *g, int mo, int mp, int count) {
+    g->mos[mo]->unique_points.push_back(mp < 0 ? nullptr : g->mps[mp].get());
+    if (mp >= 0) g->mps[mp]->MapObjObservations[g->mos[mo].get()] = count;
+}
+
+// Converter::toSE3Quat of a 4 x 4 float pose: the estimate a pose vertex starts from (7 doubles [t, qx qy qz qw], SE3Quat::toVector)
+API void ref_graph_pose_from_cvmat(const float *Tcw16, double *pose7) {
+    g2o::SE3Quat s = Converter::toSE3Quat(mat_f(4, 4, Tcw16));
+    g2o::Vector7d v = s.toVector();
+    for (int i = 0; i < 7; i++) pose7[i] = v[i];
+}
+// Converter::toCvMat of a pose: the 4 x 4 float matrix SetPose receives
+API void ref_graph_cvmat_from_pose(const double *pose7, float *Tcw16) {
+    g2o::SE3Quat s(Eigen::Quaterniond(pose7[6], pose7[3], pose7[4], pose7[5]), Eigen::Vector3d(pose7[0], pose7[1], pose7[2]));
+    cv::Mat m = Converter::toCvMat(s);
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) Tcw16[i * 4 + j] = m.at<float>(i, j);
+}
+
+namespace {
+struct Quiet { // the functions narrate on std::cout
+    std::streambuf *was;
+    Quiet() : was(standin_verbose ? nullptr : std::cout.rdbuf(nullptr)) {}
+    ~Quiet() { if (was) std::cout.rdbuf(was); }
+};
+} // namespace
+
+// the functions themselves.  stop: NULL or the flag g2o polls
+API void ref_graph_local_ba_objects(ref_graph *g, int kf, int fix_camera, int fix_point, bool *stop) {
+    Quiet q; standin_log = &g->log;
+    Optimizer::LocalBACameraPointObjects(g->kfs[kf].get(), stop, &g->map, fix_camera != 0, fix_point != 0);
+    standin_log = nullptr;
+}
+API void ref_graph_bundle_adjustment(ref_graph *g, int iterations, unsigned long loop_kf, int robust, bool *stop) {
+    Quiet q; standin_log = &g->log;
+    std::vector<KeyFrame *> kfs; std::vector<MapPoint *> mps;
+    for (auto &k : g->kfs) kfs.push_back(k.get());
+    for (auto &p : g->mps) mps.push_back(p.get());
+    Optimizer::BundleAdjustment(kfs, mps, iterations, stop, loop_kf, robust != 0);
+    standin_log = nullptr;
+}
+// PoseOptimization of a frame made of key frame `kf`'s pose, key points and matches; outliers out (n_keys bytes), returns the inlier count
+API int ref_graph_pose_optimization(ref_graph *g, int kf, float *Tcw16_out, unsigned char *outlier) {
+    Quiet q;
+    KeyFrame *k = g->kfs[kf].get();
+    Frame f;
+    f.mTcw = k->Tcw.clone(); f.N = (int)k->mvKeysUn.size(); f.mvpMapPoints = k->mvpMapPoints; f.mvbOutlier.assign(f.N, false);
+    f.mvKeysUn = k->mvKeysUn; f.mvuRight = k->mvuRight; f.mvInvLevelSigma2 = k->mvInvLevelSigma2;
+    f.fx = k->fx; f.fy = k->fy; f.cx = k->cx; f.cy = k->cy; f.mbf = k->mbf;
+    const int n = Optimizer::PoseOptimization(&f);
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) Tcw16_out[i * 4 + j] = f.mTcw.at<float>(i, j);
+    for (int i = 0; i < f.N; i++) outlier[i] = f.mvbOutlier[i] ? 1 : 0;
+    return n;
+}
+
+// what the functions left in the map
+API void ref_graph_kf_pose(ref_graph *g, int kf, float *Tcw16, int *n_writes, float *TcwGBA16) {
+    KeyFrame *k = g->kfs[kf].get();
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) Tcw16[i * 4 + j] = k->Tcw.at<float>(i, j);
+    if (n_writes) *n_writes = k->n_pose_writes;
+    if (TcwGBA16 && !k->mTcwGBA.empty()) for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) TcwGBA16[i * 4 + j] = k->mTcwGBA.at<float>(i, j);
+}
+API void ref_graph_kf_markers(ref_graph *g, int kf, long *local_for, long *fixed_for) { *local_for = (long)g->kfs[kf]->mnBALocalForKF; *fixed_for = (long)g->kfs[kf]->mnBAFixedForKF; }
+API void ref_graph_mp_pos(ref_graph *g, int mp, float *pos3, int *n_writes, int *n_normal_updates) {
+    MapPoint *p = g->mps[mp].get();
+    for (int i = 0; i < 3; i++) pos3[i] = p->mWorldPos.at<float>(i);
+    if (n_writes) *n_writes = p->n_pos_writes;
+    if (n_normal_updates) *n_normal_updates = p->n_normal_updates;
+}
+API void ref_graph_mo_state(ref_graph *g, int mo, double *pose7, double *scale3, int *n_writes, int *been_optimized, int *point_threshold, int *n_used, int *n_filtered) {
+    MapObject *o = g->mos[mo].get();
+    g2o::Vector7d v = o->pose_Twc.pose.toVector();
+    for (int i = 0; i < 7; i++) pose7[i] = v[i];
+    for (int i = 0; i < 3; i++) scale3[i] = o->pose_Twc.scale[i];
+    if (n_writes) *n_writes = o->n_pose_writes;
+    if (been_optimized) *been_optimized = o->obj_been_optimized ? 1 : 0;
+    if (point_threshold) *point_threshold = o->pointOwnedThreshold;
+    if (n_used) *n_used = (int)o->used_points_in_BA.size();
+    if (n_filtered) *n_filtered = (int)o->used_points_in_BA_filtered.size();
+}
+// the (key frame id, map point id) pairs of EraseMapPointMatch, in call order; returns their number
+API int ref_graph_erased(ref_graph *g, long *pairs, int cap) {
+    int n = 0;
+    for (auto &e : g->log.match_erased) { if (n < cap) { pairs[2 * n] = (long)e.first->mnId; pairs[2 * n + 1] = (long)e.second->mnId; } n++; }
+    return n;
+}

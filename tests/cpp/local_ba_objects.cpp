@@ -46,6 +46,7 @@ int main(int argc, char **argv) {
         printf("kf"); for (double v : r.kf_pose) printf(" %.17g", v);
         printf("\npoints"); for (double v : r.point_pos) printf(" %.17g", v);
         printf("\nobjects"); for (double v : r.object_pose) printf(" %.17g", v);
+        printf("\nunwritten %zu", r.point_unwritten.size()); for (int v : r.point_unwritten) printf(" %d", v);
         printf("\n");
     } catch (const std::exception &e) { fprintf(stderr, "error: %s\n", e.what()); return 1; }
     return 0;

@@ -74,6 +74,7 @@ def test_two_stage_flow_matches_oracle(ctx, seed):
     assert np.array_equal(got["obs_level"], ref["obs_level"]) and 0 < got["obs_level"].sum() < len(got["obs_level"]) // 4
     kf_id, mp_id = w["kf_id"], w["mp_id"]
     assert [(int(kf_id[a]), int(mp_id[b])) for a, b in got["erase"]] == ref["erase"] and len(ref["erase"]) > 0
+    assert [int(mp_id[r]) for r in got["point_unwritten"]] == ref["point_unwritten"] and len(ref["point_unwritten"]) > 0, "points the erasures leave with one observation are not written back"
     for i in range(w["n_local"]):
         assert np.allclose(got["kf_pose"][i], ref["kf_pose"][int(kf_id[i])], atol=1e-6, rtol=0)
     for r, x in got["point_pos"].items():
@@ -136,6 +137,7 @@ def test_cpp_mirror_equals_python_mirror(ctx, tmp_path, with_objects):
     assert int(tok["levels"][3], 16) == fnv(got["cobs_level"].astype(np.uint8).tobytes()) and int(tok["levels"][4], 16) == fnv(got["cobs_level2"].astype(np.uint8).tobytes())
     assert [tuple(int(v) for v in e.split(":")) for e in tok["erase"][1:]] == got["erase"] and int(tok["erase"][0]) == len(got["erase"])
     assert int(tok["stats"][0]) == got["stats"][0]["iterations"] and int(tok["stats"][1]) == got["stats"][1]["iterations"]
+    assert [int(v) for v in tok["unwritten"][1:]] == got["point_unwritten"] and int(tok["unwritten"][0]) == len(got["point_unwritten"])
     # two runs of the solver differ in the last digits (fp64 atomics in the Hessian accumulation): the same bars as against the oracle
     assert np.allclose([float(v) for v in tok["kf"]], got["kf_pose"].reshape(-1), atol=1e-6, rtol=0)
     assert np.allclose([float(v) for v in tok["points"]], np.concatenate([got["point_pos"][int(r)] for r in got["graph"]["point_rows"]]), atol=1e-5, rtol=1e-6)

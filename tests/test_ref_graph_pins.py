@@ -1,0 +1,176 @@
+"""Graph-level pins of the BA oracles against the REFERENCE'S OWN FUNCTIONS run on the reference's own g2o (oracle/_ref/libref_graph.so, oracle/Makefile.ref):
+  Optimizer::LocalBACameraPointObjects (orb_object_slam/src/Optimizer.cc:826-1534), Optimizer::BundleAdjustment (:64-251) and Optimizer::PoseOptimization
+  (:253-472) are cut out of the reference at build time and compiled against the vendored g2o WHOLE (SparseOptimizer, BlockSolver_6_3 with its Schur complement
+  block_solver.hpp:354-486, OptimizationAlgorithmLevenberg, the robust kernels, LinearSolverDense), the reference's g2o_Object.{h,cpp}, stand-ins for Eigen and for
+  Eigen's sparse Cholesky (absent from the image) and stand-ins for the map classes (oracle/ref_shim/slam_graph_standins.hpp).  The oracle's restatements
+  (oracle/local_ba_objects.py, orc_ba_optimize, orc_pose_optimization) are held to what the reference's functions leave in the map.
+
+Tolerances.  The reference stores key-frame poses and map points as FLOAT cv::Mat, so those are compared as floats (a few units in the last place of a float);
+object poses are doubles on both sides.  The two sides factor the same reduced system in different elimination orders and sum edges in different orders (the
+reference iterates std::map<KeyFrame *> in pointer order), so nothing here is bit for bit: the discrete outcome (which observations are erased, which points are
+written back, thresholds, counters) must be IDENTICAL, the numbers agree to round-off amplified by fifteen LM iterations."""
+import math
+
+import numpy as np
+import pytest
+
+from oracle import local_ba_objects as lo
+from oracle import pyoracle as po
+from tests import local_map
+from tests import ref_graph as rg
+
+pytestmark = pytest.mark.skipif(not __import__("os").path.exists(rg.SO), reason="oracle/_ref/libref_graph.so is built from /root/reference, which is not present here")
+
+
+def _float_close(a, b, ulps=4):
+    a, b = np.asarray(a, np.float32), np.asarray(b, np.float32)
+    return bool((np.abs(a.astype(np.float64) - b.astype(np.float64)) <= ulps * np.spacing(np.maximum(np.abs(a), np.abs(b)).astype(np.float32)).astype(np.float64) + 1e-7).all())
+
+
+def _pose_close(T, To, tol=2e-6):
+    """4 x 4 float poses: rotation entries and translation within `tol` (x the translation's size beyond a metre)."""
+    T, To = np.asarray(T, np.float64), np.asarray(To, np.float64)
+    return bool(np.abs(T[:3, :3] - To[:3, :3]).max() <= tol and np.abs(T[:3, 3] - To[:3, 3]).max() <= tol * max(1.0, float(np.abs(To[:3, 3]).max())))
+
+
+@pytest.mark.parametrize("seed,kwargs", [(1, {}), (2, {}), (3, {"left_heavy": True}), (4, {"with_objects": False})])
+def test_local_ba_camera_point_objects_equals_reference(seed, kwargs):
+    cur, params, extra = local_map.build(seed, **kwargs)
+    rg.quantize(cur, params, extra)
+    ref = lo.local_ba_camera_point_objects(cur, params)
+    G = rg.Graph(cur, params, extra)
+    try:
+        G.local_ba_objects(cur)
+        kid = {k.mnId: k for k in extra["kfs"]}
+        # the erase list: the same (key frame, map point) pairs (the reference walks its edge vectors in std::map pointer order: compared as sets)
+        assert sorted(G.erased()) == sorted(ref["erase"]) and (len(ref["erase"]) > 0)
+        # key frames: every local key frame written once, to the oracle's pose as a float matrix; markers reset (:1500-1507, :1519-1524)
+        moved = 0.0
+        for mn, pose in ref["kf_pose"].items():
+            T, n, _ = G.kf_pose(kid[mn])
+            assert n == 1 and _pose_close(T, rg.cvmat_from_pose(pose)), mn
+            moved = max(moved, float(np.abs(T - kid[mn].T_f32).max()))
+            assert G.kf_markers(kid[mn]) == (0, 0)
+        assert moved > 1e-3
+        for k in extra["kfs"]:
+            if k.mnId not in ref["kf_pose"]:
+                T, n, _ = G.kf_pose(k)
+                assert n == 0 and np.array_equal(T, k.T_f32), "fixed key frames and key frames outside the window are not written"
+        # points: written (SetWorldPos + UpdateNormalAndDepth) unless the erasures left exactly one observation (:1511-1512) or the point was no vertex (:1052)
+        mid = {m.mnId: m for m in G.mps}
+        unwritten = set(ref["point_unwritten"])
+        assert len(unwritten) > 0
+        n_written = 0
+        for mn, p in ref["point_pos"].items():
+            got, nw, nu = G.mp_pos(mid[mn])
+            if mn in unwritten:
+                assert nw == 0 and nu == 0 and np.array_equal(got, np.float32(mid[mn].pos)), mn
+            else:
+                assert nw == 1 and nu == 1, mn
+                # the depth of a far point seen over a short baseline is the loosest number here: 1e-6 relative to its distance
+                assert np.abs(got.astype(np.float64) - p).max() <= 2e-6 * max(1.0, float(np.linalg.norm(p))), (mn, got, p)
+                n_written += 1
+        assert n_written > 100
+        for m in G.mps:
+            if m.mnId not in ref["point_pos"]:
+                assert G.mp_pos(m)[1] == 0
+        # objects: pose written for every local object, fixed KITTI half size, the association counters of :1149-1209
+        oid = {o.mnId: o for o in extra["mos"]}
+        for mn, p in ref["object_pose"].items():
+            s = G.mo_state(oid[mn])
+            assert s["writes"] == 1 and s["been_optimized"]
+            assert np.allclose(s["pose"], p, rtol=0, atol=5e-6), (mn, np.abs(s["pose"] - p).max())
+            assert np.array_equal(s["scale"], ref["object_scale"][mn])
+            assert s["point_threshold"] == max(int(oid[mn].largest_point_observations * 0.4), 2)
+        for o in extra["mos"]:
+            if o.mnId not in ref["object_pose"]:
+                assert G.mo_state(o)["writes"] == 0
+        if kwargs.get("with_objects", True):
+            assert len(ref["object_pose"]) > 5
+    finally:
+        G.close()
+
+
+def _all_frames_problem(kfs, mps, params, huber_mono):
+    ki = {id(k): i for i, k in enumerate(kfs)}
+    oc, op, uv, w, ur = [], [], [], [], []
+    for j, m in enumerate(mps):
+        for k, i in m.observations.items():
+            oc.append(ki[id(k)]); op.append(j); uv.append(k.mvKeysUn[i]); w.append(k.mvInvLevelSigma2[k.octave[i]]); ur.append(k.mvuRight[i] if k.mvuRight[i] >= 0 else -1.0)
+    K = params["K"]
+    return {"cam_pose": np.stack([k.Tcw for k in kfs]), "cam_fixed": np.array([k.mnId == 0 for k in kfs], np.uint8), "points": np.stack([m.pos for m in mps]),
+            "cuboid_pose": np.zeros((0, 7)), "cuboid_scale": np.zeros((0, 3)), "cuboid_flags": np.zeros(0, np.uint8),
+            "obs_cam": np.array(oc, np.int32), "obs_point": np.array(op, np.int32), "obs_uv": np.array(uv, float).reshape(-1, 2), "obs_inv_sigma2": np.array(w, float),
+            "obs_ur": np.array(ur, float), "fx": K[0, 0], "fy": K[1, 1], "cx": K[0, 2], "cy": K[1, 2], "huber_mono": huber_mono,
+            "huber_stereo": float(np.float32(math.sqrt(7.815))) if huber_mono else 0.0, "bf": params["bf"],
+            "cobs_cam": np.zeros(0, np.int32), "cobs_cuboid": np.zeros(0, np.int32), "cobs_bbox": np.zeros((0, 4)), "cobs_info": np.zeros((0, 4)), "K": K, "huber_obj": 0.0,
+            "pc_cuboid": np.zeros(0, np.int32), "pc_offsets": np.zeros(1, np.int32), "pc_points": np.zeros((0, 3)), "max_outside_margin_ratio": 1.0}
+
+
+@pytest.mark.parametrize("iterations,robust,loop_kf", [(1, True, 0), (10, True, 0), (20, False, 7)])
+def test_bundle_adjustment_equals_reference(iterations, robust, loop_kf):
+    """Optimizer::BundleAdjustment: BlockSolver_6_3 over the whole map -- the Schur complement, the landmark back-substitution and the LM loop of the reference's g2o
+    against orc_ba_optimize (ba_oracle.cpp), iteration counts included.  With nLoopKF != 0 the result goes to mTcwGBA / mPosGBA and the poses stay (:222-250)."""
+    cur, params, extra = local_map.build(1, n_kf=10, n_points=80, n_cuboids=3)
+    rg.quantize(cur, params, extra)
+    for k in extra["kfs"]:
+        k.bad = False; k.local_cuboids, k.cuboids_landmark = [], []
+    kfs, mps = extra["kfs"], [m for m in extra["mps"] if m.observations]
+    extra["mps"], extra["mos"] = mps, []
+    d = _all_frames_problem(kfs, mps, params, float(np.float32(math.sqrt(5.99))) if robust else 0.0)
+    cam, pts, _, st = po.ba_optimize(d, iterations)
+    assert st["iterations"] >= min(iterations, 5)
+    G = rg.Graph(cur, params, extra)
+    try:
+        G.bundle_adjustment(iterations, loop_kf=loop_kf, robust=robust)
+        moved = 0.0
+        for i, k in enumerate(kfs):
+            T, n, Tg = G.kf_pose(k)
+            if loop_kf:
+                assert n == 0 and np.array_equal(T, k.T_f32)
+                T = Tg
+            else:
+                assert n == 1
+            assert _float_close(T, rg.cvmat_from_pose(cam[i])), k.mnId
+            moved = max(moved, float(np.abs(T - k.T_f32).max()))
+        assert moved > 1e-2
+        if not loop_kf:
+            for j, m in enumerate(mps):
+                got, nw, nu = G.mp_pos(m)
+                assert nw == 1 and nu == 1 and np.abs(got.astype(np.float64) - pts[j]).max() <= 2e-6 * max(1.0, float(np.linalg.norm(pts[j])))
+    finally:
+        G.close()
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_pose_optimization_equals_reference(seed):
+    """Optimizer::PoseOptimization: the four rounds of ten iterations with the outlier re-classification between them (:401-461), LinearSolverDense under
+    BlockSolver_6_3, against orc_pose_optimization: inlier count, outlier flags, pose."""
+    cur, params, extra = local_map.build(seed)
+    rg.quantize(cur, params, extra)
+    G = rg.Graph(cur, params, extra)
+    K = params["K"]
+    try:
+        n_checked = 0
+        for k in extra["kfs"][2:8]:
+            rows = [i for i, m in enumerate(k.map_point_matches) if m is not None]
+            Xw = np.array([k.map_point_matches[i].pos for i in rows]); obs = np.array([[k.mvKeysUn[i][0], k.mvKeysUn[i][1], k.mvuRight[i] if k.mvuRight[i] >= 0 else -1.0] for i in rows])
+            w = np.array([k.mvInvLevelSigma2[k.octave[i]] for i in rows])
+            # a start a few centimetres off, as a float pose
+            T0 = k.T_f32.copy(); T0[:3, 3] += np.float32([0.05, -0.02, 0.08])
+            start = rg.pose_from_cvmat(T0)
+            pose, outl, n_in = po.pose_optimization(Xw, obs, w, (K[0, 0], K[1, 1], K[0, 2], K[1, 2], params["bf"]), start)
+            k_T = k.T_f32; k.T_f32 = T0
+            H = rg.Graph(cur, params, extra)
+            k.T_f32 = k_T
+            try:
+                n_ref, T, out_ref = H.pose_optimization(k)
+            finally:
+                H.close()
+            assert n_ref == n_in and np.array_equal(out_ref[rows], outl.astype(bool)) and not out_ref[[i for i in range(len(out_ref)) if i not in rows]].any()
+            assert _float_close(T, rg.cvmat_from_pose(pose)), k.mnId
+            assert outl.any() and not outl.all()
+            n_checked += 1
+        assert n_checked == 6
+    finally:
+        G.close()
