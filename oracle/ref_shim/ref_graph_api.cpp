@@ -25,6 +25,7 @@ double camera_object_BA_weight = 1.0, object_velocity_BA_weight = 1.0, delta_t =
 Scene_Name scene_unique_id = kitti;
 EraseLog *standin_log = nullptr;
 std::mutex MapPoint::mGlobalMutex;
+long int MapObject::nNextId = 0;
 
 #include "extracted_graph.inc"
 } // namespace ORB_SLAM2
@@ -40,6 +41,14 @@ struct ref_graph {
     EraseLog log;
     std::streambuf *cout_was = nullptr;
 };
+
+namespace {
+struct Quiet { // the functions narrate on std::cout
+    std::streambuf *was;
+    Quiet() : was(standin_verbose ? nullptr : std::cout.rdbuf(nullptr)) {}
+    ~Quiet() { if (was) std::cout.rdbuf(was); }
+};
+} // namespace
 
 static cv::Mat mat_f(int r, int c, const float *v) { cv::Mat m(r, c, CV_32F); for (int i = 0; i < r; i++) for (int j = 0; j < c; j++) m.at<float>(i, j) = v[i * c + j]; return m; }
 static g2o::cuboid cuboid_of(const double *pose7, const double *scale3) {
@@ -80,6 +89,7 @@ API int ref_graph_add_mp(ref_graph *g, long id, int bad, const float *pos3, int 
 API int ref_graph_add_mo(ref_graph *g, long id, int bad, const double *pose7, const double *scale3, double meas_quality, int largest_point_observations) {
     std::unique_ptr<MapObject> o(new MapObject());
     o->mnId = id; o->bad = bad != 0; o->pose_Twc = cuboid_of(pose7, scale3); o->meas_quality = meas_quality; o->largest_point_observations = largest_point_observations;
+    o->already_associated = true; o->associated_landmark = o.get(); // the state of every landmark: it was a candidate once (Tracking.cc:1945-1951)
     g->mos.push_back(std::move(o));
     return (int)g->mos.size() - 1;
 }
@@ -99,10 +109,55 @@ API int ref_graph_kf_detection(ref_graph *g, int kf, const double *bbox_vec4, co
     g->dets.push_back(std::move(d));
     return (int)k->local_cuboids.size() - 1;
 }
-API void ref_graph_mo_observe(ref_graph *g, int mo, int kf, int det) { g->mos[mo]->mObservations[g->kfs[kf].get()] = (size_t)det; g->mos[mo]->observed_frames.push_back(g->kfs[kf].get()); }
+API void ref_graph_mo_observe(ref_graph *g, int mo, int kf, int det) { g->mos[mo]->addObservation(g->kfs[kf].get(), (size_t)det); } // MapObject::addObservation (MapObject.cc:117-131)
 API void ref_graph_mo_unique_point(ref_graph *g, int mo, int mp, int count) {
-    g->mos[mo]->unique_points.push_back(mp < 0 ? nullptr : g->mps[mp].get());
+    g->mos[mo]->mappoints_unique_own.insert(mp < 0 ? nullptr : g->mps[mp].get());
     if (mp >= 0) g->mps[mp]->MapObjObservations[g->mos[mo].get()] = count;
+}
+// ---- Tracking::AssociateCuboids: candidates are detections (KeyFrame::local_cuboids entries) that gathered potential points
+API void ref_graph_det_candidate(ref_graph *g, int kf, int det, int become_candidate, int already_associated, const double *pose7, const double *scale3) {
+    KeyFrame *k = g->kfs[kf].get(); MapObject *d = k->local_cuboids[det];
+    d->become_candidate = become_candidate != 0; d->already_associated = already_associated != 0; d->moRefKF = k; d->pose_Twc = cuboid_of(pose7, scale3);
+}
+API void ref_graph_det_potential_point(ref_graph *g, int kf, int det, int mp) { g->mps[mp]->AddObjectObservation(g->kfs[kf]->local_cuboids[det]); } // a local object: LocalObjObservations + AddPotentialMapPoint
+API void ref_graph_mp_vote(ref_graph *g, int mp, int mo, int count) { g->mps[mp]->MapObjObservations[g->mos[mo].get()] = count; }
+API void ref_graph_mp_best(ref_graph *g, int mp, int mo, int max_vote) { g->mps[mp]->best_object = mo < 0 ? nullptr : g->mos[mo].get(); g->mps[mp]->max_object_vote = max_vote; }
+API void ref_graph_associate_cuboids(ref_graph *g, int cur_kf, const int *local_kfs, int n_local, long next_id, int mono_allframe_depth_init) {
+    Quiet q;
+    Tracking t; t.mpMap = &g->map;
+    for (auto &o : g->mos) g->map.AddMapObject(o.get());
+    for (int i = 0; i < n_local; i++) t.mvpLocalKeyFrames.push_back(g->kfs[local_kfs[i]].get());
+    MapObject::nNextId = next_id; mono_allframe_Obj_depth_init = mono_allframe_depth_init != 0;
+    t.AssociateCuboids(g->kfs[cur_kf].get());
+}
+// an object pointer as (kind, index): 0 = landmark g->mos[index], 1 = detection (index = its creation order over all key frames), -1 = NULL
+static void obj_ref(ref_graph *g, MapObject *o, int *kind, int *index) {
+    *kind = -1; *index = -1;
+    if (!o) return;
+    for (size_t i = 0; i < g->mos.size(); i++) if (g->mos[i].get() == o) { *kind = 0; *index = (int)i; return; }
+    for (size_t i = 0; i < g->dets.size(); i++) if (g->dets[i].get() == o) { *kind = 1; *index = (int)i; return; }
+}
+API int ref_graph_det_global_index(ref_graph *g, int kf, int det) { int k, i; obj_ref(g, g->kfs[kf]->local_cuboids[det], &k, &i); return i; }
+API void ref_graph_det_state(ref_graph *g, int kf, int det, int *assoc_kind, int *assoc_index, long *mnId, int *already_associated, int *n_obs, double *scale3) {
+    MapObject *d = g->kfs[kf]->local_cuboids[det];
+    obj_ref(g, d->associated_landmark, assoc_kind, assoc_index);
+    *mnId = d->mnId; *already_associated = d->already_associated ? 1 : 0; *n_obs = d->Observations();
+    for (int i = 0; i < 3; i++) scale3[i] = d->pose_Twc.scale[i];
+}
+// the votes of a point: (kind, index, count) triples + best object and its vote; returns the number of triples
+API int ref_graph_mp_votes(ref_graph *g, int mp, int *triples, int cap, int *best_kind, int *best_index, int *max_vote) {
+    MapPoint *p = g->mps[mp].get();
+    int n = 0;
+    for (auto &v : p->MapObjObservations) { if (n < cap) { obj_ref(g, v.first, &triples[3 * n], &triples[3 * n + 1]); triples[3 * n + 2] = v.second; } n++; }
+    obj_ref(g, p->best_object, best_kind, best_index); *max_vote = p->max_object_vote;
+    return n;
+}
+API void ref_graph_mo_flags(ref_graph *g, int mo, int *n_obs, int *bad, int *is_good, int *n_unique, int *largest_point_observations, int *n_cuboids_landmark_refs) {
+    MapObject *o = g->mos[mo].get();
+    *n_obs = o->Observations(); *bad = o->bad ? 1 : 0; *is_good = o->isGood ? 1 : 0; *n_unique = o->NumUniqueMapPoints(); *largest_point_observations = o->largest_point_observations;
+    int refs = 0;
+    for (auto &k : g->kfs) for (MapObject *l : k->cuboids_landmark) if (l == o) refs++;
+    *n_cuboids_landmark_refs = refs;
 }
 
 // Converter::toSE3Quat of a 4 x 4 float pose: the estimate a pose vertex starts from (7 doubles [t, qx qy qz qw], SE3Quat::toVector)
@@ -117,14 +172,6 @@ API void ref_graph_cvmat_from_pose(const double *pose7, float *Tcw16) {
     cv::Mat m = Converter::toCvMat(s);
     for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) Tcw16[i * 4 + j] = m.at<float>(i, j);
 }
-
-namespace {
-struct Quiet { // the functions narrate on std::cout
-    std::streambuf *was;
-    Quiet() : was(standin_verbose ? nullptr : std::cout.rdbuf(nullptr)) {}
-    ~Quiet() { if (was) std::cout.rdbuf(was); }
-};
-} // namespace
 
 // the functions themselves.  stop: NULL or the flag g2o polls
 API void ref_graph_local_ba_objects(ref_graph *g, int kf, int fix_camera, int fix_point, bool *stop) {

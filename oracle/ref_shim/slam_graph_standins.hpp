@@ -61,8 +61,12 @@ class MapPoint {
     std::map<MapObject *, int> MapObjObservations;
     int n_pos_writes = 0, n_normal_updates = 0;
     static std::mutex mGlobalMutex;
-    // dynamic-object BA (:1537-2573)
-    MapObject *best_object = nullptr; // the object a dynamic point lives on
+    // object votes (MapPoint.h:133-137; AddObjectObservation is the reference's text, MapPoint.cc:219-247)
+    MapObject *best_object = nullptr; // one point can only belong to at most one object
+    int max_object_vote = 0;
+    std::set<MapObject *> LocalObjObservations;
+    std::mutex mMutexObject;
+    void AddObjectObservation(MapObject *obj);
     cv::Mat mWorldPos_latestKF;
     std::map<KeyFrame *, size_t> GetObservations() { return mObservations; }
     int Observations() { return (int)mObservations.size(); }
@@ -106,7 +110,11 @@ class MapObject {
     bool bad = false, obj_been_optimized = false, is_dynamic = false, isGood = false, already_associated = false, become_candidate = false;
     int point_object_BA_counter = -1, largest_point_observations = 0, pointOwnedThreshold = 0, left_right_to_car = -1, object_id_in_localKF = 0, truth_tracklet_id = -1;
     long unsigned int association_refid_in_tracking = 0;
-    std::vector<MapPoint *> used_points_in_BA, used_points_in_BA_filtered, unique_points, potential_points;
+    std::vector<MapPoint *> used_points_in_BA, used_points_in_BA_filtered;
+    std::set<MapPoint *> mappoints_unique_own, mappoints_potential_own; // MapObject.h:171-172 (pointer order, like the reference)
+    std::mutex mMutexFeatures, mMutexPos, mMutexParam;
+    int nObs = 0, n_bad_flags = 0;
+    static long int nNextId;
     std::unordered_map<KeyFrame *, size_t> mObservations;
     std::vector<KeyFrame *> observed_frames;
     cv::Rect bbox_2d, bbox_2d_tight;
@@ -126,8 +134,19 @@ class MapObject {
     void SetWorldPos(const g2o::cuboid &c) { pose_Twc = c; n_pose_writes++; }
     std::unordered_map<KeyFrame *, size_t> GetObservations() { return mObservations; }
     int Observations() { return (int)mObservations.size(); }
-    std::vector<MapPoint *> GetUniqueMapPoints() { return unique_points; }
-    std::vector<MapPoint *> GetPotentialMapPoints() { return potential_points; }
+    // the reference's text (MapObject.cc:44-131), cut out at build time
+    static long int getIncrementedIndex();
+    std::vector<MapPoint *> GetUniqueMapPoints();
+    int NumUniqueMapPoints();
+    void AddUniqueMapPoint(MapPoint *pMP, int obs_num);
+    void EraseUniqueMapPoint(MapPoint *pMP, int obs_num);
+    std::vector<MapPoint *> GetPotentialMapPoints();
+    void AddPotentialMapPoint(MapPoint *pMP);
+    bool check_whether_valid_object(int own_point_thre = 30);
+    void SetAsLandmark();
+    void MergeIntoLandmark(MapObject *otherLocalObject);
+    void addObservation(KeyFrame *pKF, size_t idx);
+    void SetBadFlag() { bad = true; n_bad_flags++; } // (the real one also unhooks the object from its key frames and points: map bookkeeping)
     std::vector<KeyFrame *> GetObserveFrames() { std::vector<KeyFrame *> v; for (auto &o : mObservations) v.push_back(o.first); return v; }
     std::vector<KeyFrame *> GetObserveFramesSequential() { return observed_frames; }
     KeyFrame *GetReferenceKeyFrame() { return moRefKF; }
@@ -138,6 +157,9 @@ class MapObject {
 
 class Map {
   public:
+    std::set<MapObject *> mspMapObjects;
+    void AddMapObject(MapObject *pMO) { mspMapObjects.insert(pMO); }
+    std::vector<MapObject *> GetAllMapObjects() { return std::vector<MapObject *>(mspMapObjects.begin(), mspMapObjects.end()); }
     int img_width = 0, img_height = 0;
     Eigen::Matrix3d Kalib, invKalib;
     Eigen::Matrix3f Kalib_f, invKalib_f;
@@ -164,6 +186,15 @@ class Converter { // Converter.h: the conversions the cut functions call (bodies
     static cv::Mat toCvMat(const Eigen::Matrix<double, 4, 4> &m);
     static cv::Mat toCvMat(const Eigen::Matrix<double, 3, 1> &m);
     static Eigen::Matrix<double, 3, 1> toVector3d(const cv::Mat &cvVector);
+};
+
+class Tracking { // what Tracking::AssociateCuboids (Tracking.cc:1848-2043) touches
+  public:
+    std::vector<KeyFrame *> mvpLocalKeyFrames;
+    Map *mpMap = nullptr;
+    bool use_truth_trackid = false;
+    std::unordered_map<int, MapObject *> trackletid_to_landmark;
+    void AssociateCuboids(KeyFrame *pKF);
 };
 
 class Optimizer { // Optimizer.h:36-49

@@ -174,3 +174,138 @@ def test_pose_optimization_equals_reference(seed):
         assert n_checked == 6
     finally:
         G.close()
+
+
+def _assoc_scene(rng, n_points=400, n_land=5, n_cand=8):
+    votes = [dict() for _ in range(n_points)]
+    land_pts = [rng.choice(n_points, 60, replace=False) for _ in range(n_land)]
+    for o, pts in enumerate(land_pts):
+        for p in pts:
+            votes[int(p)][100 + o] = int(rng.integers(1, 4))
+    cands = []
+    for i in range(n_cand):
+        if i % 4 == 2:
+            pts = rng.choice(n_points, 30, replace=False)            # mostly unseen points: a new landmark
+        elif i % 4 == 3 and cands:
+            pts = np.array(cands[-1][:24] + [int(p) for p in rng.choice(n_points, 6, replace=False)])  # shares the points of the landmark just created
+        else:
+            base = land_pts[i % n_land]
+            pts = np.concatenate([rng.choice(base, int(rng.integers(8, 30)), replace=False), rng.choice(n_points, 10, replace=False)])
+        cands.append(sorted(set(int(p) for p in pts)))
+    return votes, cands
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_associate_cuboids_equals_reference(seed):
+    """Tracking::AssociateCuboids (Tracking.cc:1848-2043) with the vote bookkeeping it drives (MapObject::SetAsLandmark / MergeIntoLandmark / addObservation,
+    MapPoint::AddObjectObservation: the reference's text) against pyoracle.associate_cuboids: which landmark every candidate ends up in, which candidates become
+    landmarks, every point's votes, best object and best vote afterwards.  Also what the oracle leaves to the caller: the gathering of candidates and landmarks
+    from the local key frames (:1858-1876) and the ageing of rarely seen objects (:1992-2043)."""
+    import ctypes as C
+    rng = np.random.default_rng(100 + seed)
+    votes, cands = _assoc_scene(rng)
+    n_land = 5
+    land_bad = [0, seed % 2, 0, 0, 0]
+    L = rg.lib()
+    h = C.c_void_p(L.ref_graph_open())
+    try:
+        K = np.eye(3)
+        L.ref_graph_set_params(h, 1, 0, C.c_double(1.0), 0, 1241, 376, rg._p(K.reshape(-1), C.c_double), 0)
+        eye = np.eye(4, dtype=np.float32).reshape(-1); z3 = np.zeros(3, np.float32)
+        one = np.ones(1, np.float32); zi = np.zeros(1, np.int32)
+
+        def add_kf(mnid):
+            return L.ref_graph_add_kf(h, C.c_long(mnid), 0, rg._p(eye, C.c_float), rg._p(z3, C.c_float), 0, rg._p(one, C.c_float), rg._p(one, C.c_float), rg._p(zi, C.c_int), 1, rg._p(one, C.c_float),
+                                      C.c_float(1), C.c_float(1), C.c_float(0), C.c_float(0), C.c_float(0))
+        local = [add_kf(30), add_kf(31), add_kf(32)]
+        cur, old = add_kf(40), add_kf(5)
+        mps = [L.ref_graph_add_mp(h, C.c_long(p), 0, rg._p(z3, C.c_float), 0) for p in range(len(votes))]
+        pose = np.array([1.0, 2.0, 3.0, 0, 0, 0, 1.0]); scale = np.array([2.0, 1.0, 0.9]); bv = np.zeros(4); b2 = np.zeros(4, np.int32)
+        mos = [L.ref_graph_add_mo(h, C.c_long(100 + i), land_bad[i], rg._p(pose, C.c_double), rg._p(scale, C.c_double), C.c_double(1.0), 0) for i in range(n_land)]
+        # landmarks hang on the local key frames (KeyFrame::cuboids_landmark), landmark 0 on two of them (gathered once: association_refid_in_tracking)
+        refs0 = [0] * n_land
+        gathered = []
+        attach = {0: [0, 3, 0], 1: [1, 0], 2: [2, 4]}
+        for kf_i, ls in attach.items():
+            for li in ls:
+                det = L.ref_graph_kf_detection(h, local[kf_i], rg._p(bv, C.c_double), rg._p(b2, C.c_int), 0, C.c_double(1.0), li)
+                L.ref_graph_mo_observe(h, mos[li], local[kf_i], det)
+                refs0[li] += 1
+                if not land_bad[li] and li not in gathered:
+                    gathered.append(li)
+        # two objects the local key frames do not hold, last seen 35 key frames ago: one seen once (-> bad), one seen three times (-> good)
+        aged = [L.ref_graph_add_mo(h, C.c_long(900 + i), 0, rg._p(pose, C.c_double), rg._p(scale, C.c_double), C.c_double(1.0), 0) for i in range(2)]
+        L.ref_graph_mo_observe(h, aged[0], old, 0)
+        for k in (old, add_kf(3), add_kf(4)):
+            L.ref_graph_mo_observe(h, aged[1], k, 0)
+        # votes and best objects as MapPoint::AddObjectObservation would have left them
+        best = np.full(len(votes), -1, np.int32); mv = np.zeros(len(votes), np.int32)
+        for p, d in enumerate(votes):
+            for o, c in d.items():
+                L.ref_graph_mp_vote(h, mps[p], mos[o - 100], c)
+                if c > mv[p]:
+                    best[p] = o; mv[p] = c
+            L.ref_graph_mp_best(h, mps[p], -1 if best[p] < 0 else mos[best[p] - 100], int(mv[p]))
+        # candidates: detections with potential points, spread over the local key frames; one detection that is no candidate, one already associated
+        cand_at = []
+        for i, pts in enumerate(cands):
+            kf_i = i % 3
+            det = L.ref_graph_kf_detection(h, local[kf_i], rg._p(bv, C.c_double), rg._p(b2, C.c_int), 0, C.c_double(1.0), -2)
+            L.ref_graph_det_candidate(h, local[kf_i], det, 1, 0, rg._p(pose, C.c_double), rg._p(scale, C.c_double))
+            for p in pts:
+                L.ref_graph_det_potential_point(h, local[kf_i], det, mps[p])
+            cand_at.append((kf_i, det))
+        for flags in ((0, 0), (1, 1)):
+            det = L.ref_graph_kf_detection(h, local[0], rg._p(bv, C.c_double), rg._p(b2, C.c_int), 0, C.c_double(1.0), -2)
+            L.ref_graph_det_candidate(h, local[0], det, flags[0], flags[1], rg._p(pose, C.c_double), rg._p(scale, C.c_double))
+            for p in range(40 if not flags[1] else 0):
+                L.ref_graph_det_potential_point(h, local[0], det, mps[p])
+        # the reference walks key frames, then their detections: that is the candidate order
+        order = sorted(range(len(cands)), key=lambda i: (cand_at[i][0], cand_at[i][1]))
+        cand_id = [200 + i for i in order]
+        v = [dict(d) for d in votes]
+        assoc, created = po.associate_cuboids(cand_id, [cands[i] for i in order], [100 + li for li in gathered], [0] * len(gathered), v, 10, best, mv)
+        assert created.sum() >= 2 and (created == 0).sum() >= 2, "both branches"
+        L.ref_graph_associate_cuboids(h, cur, rg._p(np.array(local, np.int32), C.c_int), 3, C.c_long(500), 0)
+        gidx = {L.ref_graph_det_global_index(h, local[cand_at[i][0]], cand_at[i][1]): 200 + i for i in range(len(cands))}
+
+        def oid(kind, index):
+            return -1 if kind < 0 else (100 + index if kind == 0 and index < n_land else (900 + index - n_land if kind == 0 else gidx[index]))
+        merged_into = [0] * n_land
+        n_created = 0
+        if __import__("os").environ.get("ASSOC_DEBUG"):
+            for k, i in enumerate(order):
+                ak, ai, mnid, aa, nobs = C.c_int(), C.c_int(), C.c_long(), C.c_int(), C.c_int()
+                sc = np.zeros(3)
+                L.ref_graph_det_state(h, local[cand_at[i][0]], cand_at[i][1], C.byref(ak), C.byref(ai), C.byref(mnid), C.byref(aa), C.byref(nobs), rg._p(sc, C.c_double))
+                print(k, i, "oracle", assoc[k], created[k], "ref", oid(ak.value, ai.value), mnid.value, "gathered", gathered)
+        for k, i in enumerate(order):
+            ak, ai, mnid, aa, nobs = C.c_int(), C.c_int(), C.c_long(), C.c_int(), C.c_int()
+            sc = np.zeros(3)
+            L.ref_graph_det_state(h, local[cand_at[i][0]], cand_at[i][1], C.byref(ak), C.byref(ai), C.byref(mnid), C.byref(aa), C.byref(nobs), rg._p(sc, C.c_double))
+            assert oid(ak.value, ai.value) == assoc[k] and aa.value == 1, (k, i)
+            if created[k]:
+                n_created += 1
+                assert assoc[k] == 200 + i and mnid.value == 500 + n_created and nobs.value >= 1 and np.array_equal(sc, [1.9420, 0.8143, 0.7631])
+            elif assoc[k] < 200:
+                merged_into[assoc[k] - 100] += 1
+        # votes, best object, best vote of every point
+        tri = np.zeros(3 * 64, np.int32)
+        for p in range(len(votes)):
+            bk, bi, m = C.c_int(), C.c_int(), C.c_int()
+            n = L.ref_graph_mp_votes(h, mps[p], rg._p(tri, C.c_int), 64, C.byref(bk), C.byref(bi), C.byref(m))
+            got = {oid(int(tri[3 * j]), int(tri[3 * j + 1])): int(tri[3 * j + 2]) for j in range(n)}
+            assert got == v[p], p
+            assert oid(bk.value, bi.value) == best[p] and m.value == mv[p], p
+        # landmarks: one more KeyFrame::cuboids_landmark entry per merged candidate; the aged objects
+        for li in range(n_land):
+            f = [C.c_int() for _ in range(6)]
+            L.ref_graph_mo_flags(h, mos[li], *[C.byref(x) for x in f])
+            assert f[5].value == refs0[li] + merged_into[li], li
+        f = [C.c_int() for _ in range(6)]
+        L.ref_graph_mo_flags(h, aged[0], *[C.byref(x) for x in f])
+        assert f[1].value == 1 and f[2].value == 0, "seen once, not for more than 15 key frames: bad (:2021-2028)"
+        L.ref_graph_mo_flags(h, aged[1], *[C.byref(x) for x in f])
+        assert f[1].value == 0 and f[2].value == 1, "seen three times: good (:2029-2032)"
+    finally:
+        L.ref_graph_close(h)
