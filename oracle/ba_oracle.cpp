@@ -1,11 +1,13 @@
 /*
  * oracle/ba_oracle.cpp -- CPU oracle for the g2o object bundle adjustment (BlockSolver_6_3 + Levenberg + Schur).
  *
- * TEST INFRASTRUCTURE ONLY (see oracle.h).  PINNED except for the Schur solve (tests/test_ref_pins.py, oracle/_ref): the SE3 / cuboid vertex and edge math
+ * TEST INFRASTRUCTURE ONLY (see oracle.h).  PINNED (tests/test_ref_pins.py, tests/test_ref_graph_pins.py, oracle/_ref): the SE3 / cuboid vertex and edge math
  * equals the reference's se3quat.h / g2o_Object functions bit for bit; a run driven by the reference's own OptimizationAlgorithmLevenberg::solve +
  * SparseOptimizer::optimize + RobustKernelHuber over this file's pieces equals orc_ba_optimize bit for bit; build_system and PoseOpt::eval / build equal
- * g2o's own linearizeOplus / constructQuadraticForm under the reference's vertex / edge classes block for block, bit for bit.  The block solver's Schur
- * complement and the sparse Cholesky under it are unpinned.  Restated from the vendored g2o under
+ * g2o's own linearizeOplus / constructQuadraticForm under the reference's vertex / edge classes block for block, bit for bit.  The Schur solve, the landmark
+ * back-substitution and whole runs of orc_ba_optimize / orc_pose_optimization are held (to round-off: another elimination order) to the reference's own
+ * Optimizer::BundleAdjustment / LocalBACameraPointObjects / PoseOptimization running on the reference's vendored g2o compiled whole (oracle/_ref/libref_graph.so);
+ * Eigen's sparse Cholesky itself is absent from the image and stays replaced.  Restated from the vendored g2o under
  * /root/reference/orb_object_slam/Thirdparty/g2o/g2o (core/optimization_algorithm_levenberg.cpp:61-189,
  * core/block_solver.hpp:354-604, core/base_binary_edge.hpp:55-320, core/base_unary_edge.hpp:43-123,
  * core/sparse_optimizer.cpp:61-114, core/robust_kernel_impl.cpp:78-91, types/se3quat.h, types/types_six_dof_expmap.*)

@@ -3,6 +3,9 @@ objects (reference orb_object_slam/src/Optimizer.cc:826-1534), with the CPU rest
 pyoracle.ba_optimize / ba_errors) as the solver.  Only tests/ may import this module; the product counterpart is
 cube_slam_amd/ba_objects.py, which works on flattened arrays through the C-ABI.
 
+PINNED: tests/test_ref_graph_pins.py runs the reference's own function text on the reference's own g2o (oracle/_ref/libref_graph.so) over the same windows and
+holds this restatement to what it leaves in the map (erase list, written and unwritten points, poses, objects, counters).
+
 The graph-level steps and the lines they follow:
   gather_local_window          :829-913   local key frames (current + covisible), their points and objects, the fixed key frames that see them
   object vertices              :983-1026  KITTI fixed half size (1.9420, 0.8143, 0.7631), height reset from the current camera, roll/pitch fixed

@@ -663,7 +663,8 @@ def associate_keypoints(kp_xy, boxes, enable_ground_height_scale=False):
 
 
 def associate_cuboids(cand_id, cand_pts, landmark_id, landmark_bad, point_votes, thres, best_object=None, max_vote=None):
-    """Tracking::AssociateCuboids (Tracking.cc:1848-1990, use_truth_trackid off) on ids.  cand_pts: list of point-id lists
+    """Tracking::AssociateCuboids (Tracking.cc:1848-1990, use_truth_trackid off) on ids.  PINNED to the reference's own text (that function with
+    MapObject::SetAsLandmark / MergeIntoLandmark and MapPoint::AddObjectObservation, tests/test_ref_graph_pins.py).  cand_pts: list of point-id lists
     (GetPotentialMapPoints); point_votes: list of dicts object id -> count (MapPoint::MapObjObservations), updated in place like
     SetAsLandmark / MergeIntoLandmark -> MapPoint::AddObjectObservation do (MapObject.cc:100-115, MapPoint.cc:219-242)."""
     L = list(landmark_id)
