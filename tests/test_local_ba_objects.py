@@ -89,6 +89,46 @@ def test_two_stage_flow_matches_oracle(ctx, seed):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("seed", [1, 2])
+def test_two_stage_flow_matches_the_reference_itself(ctx, seed):
+    """The HIP path against the REFERENCE'S OWN Optimizer::LocalBACameraPointObjects (its text, running on its vendored g2o: oracle/_ref/libref_graph.so,
+    tests/ref_graph.py) on the same window, without the oracle in between: erase list, which points are written back, poses, points, objects."""
+    import os
+    from tests import ref_graph as rg
+    if not os.path.exists(rg.SO):
+        pytest.skip("oracle/_ref/libref_graph.so is built from /root/reference")
+    cur, params, extra = local_map.build(seed)
+    rg.quantize(cur, params, extra)
+    w = lo.flatten_window(cur)
+    got = ba_objects.LocalBACameraPointObjects(w, params, ctx=ctx)
+    G = rg.Graph(cur, params, extra)
+    try:
+        G.local_ba_objects(cur)
+        kf_id, mp_id = w["kf_id"], w["mp_id"]
+        assert sorted((int(kf_id[a]), int(mp_id[b])) for a, b in got["erase"]) == sorted(G.erased()) and len(got["erase"]) > 0
+        kid = {k.mnId: k for k in extra["kfs"]}
+        for i in range(w["n_local"]):
+            T, n, _ = G.kf_pose(kid[int(kf_id[i])])
+            To = rg.cvmat_from_pose(got["kf_pose"][i]).astype(np.float64)
+            assert n == 1 and np.abs(T[:3, :3] - To[:3, :3]).max() <= 2e-6 and np.abs(T[:3, 3] - To[:3, 3]).max() <= 2e-6 * max(1.0, np.abs(To[:3, 3]).max()), int(kf_id[i])
+        mid = {m.mnId: m for m in G.mps}
+        unwritten = set(got["point_unwritten"])
+        assert len(unwritten) > 0
+        for r, x in got["point_pos"].items():
+            ref_p, nw, _ = G.mp_pos(mid[int(mp_id[r])])
+            assert nw == (0 if r in unwritten else 1), int(mp_id[r])
+            if nw:
+                assert np.abs(ref_p.astype(np.float64) - x).max() <= 1e-5 * max(1.0, float(np.linalg.norm(x))), (int(mp_id[r]), ref_p, x)
+        oid = {o.mnId: o for o in extra["mos"]}
+        for i, mn in enumerate(w["mo_id"]):
+            st = G.mo_state(oid[int(mn)])
+            assert st["writes"] == 1 and np.allclose(st["pose"], got["object_pose"][i], rtol=0, atol=2e-5), (int(mn), np.abs(st["pose"] - got["object_pose"][i]).max())
+            assert np.array_equal(st["scale"], got["object_scale"][i])
+    finally:
+        G.close()
+
+
+@pytest.mark.gpu
 def test_window_without_objects(ctx):
     """Most local windows of a sequence hold no object at all: the flow is then the point-only local BA with the same two stages."""
     cur, params, _ = local_map.build(4, with_objects=False)

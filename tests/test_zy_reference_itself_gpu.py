@@ -1,0 +1,71 @@
+"""The HIP paths against the REFERENCE'S OWN functions, without the oracle in between: Optimizer::BundleAdjustment and Optimizer::PoseOptimization as text, running on the
+reference's vendored g2o compiled whole (oracle/_ref/libref_graph.so, built here from /root/reference and carried to the GPU box; tests/ref_graph.py).  The
+two-stage local BA with objects has the same kind of test in tests/test_local_ba_objects.py.  The reference stores poses and points as float cv::Mat: that is the
+precision of the comparison."""
+import math
+import os
+
+import numpy as np
+import pytest
+
+from cube_slam_amd.ba import BundleAdjuster
+from cube_slam_amd.optimizer import PoseOptimization
+from tests import local_map
+from tests import ref_graph as rg
+from tests.test_ref_graph_pins import _all_frames_problem, _float_close
+
+pytestmark = [pytest.mark.gpu, pytest.mark.skipif(not os.path.exists(rg.SO), reason="oracle/_ref/libref_graph.so is built from /root/reference")]
+
+
+@pytest.mark.parametrize("iterations,robust", [(10, True), (20, False)])
+def test_bundle_adjustment_equals_the_reference_itself(ctx, iterations, robust):
+    cur, params, extra = local_map.build(1, n_kf=10, n_points=80, n_cuboids=3)
+    rg.quantize(cur, params, extra)
+    for k in extra["kfs"]:
+        k.bad = False; k.local_cuboids, k.cuboids_landmark = [], []
+    kfs, mps = extra["kfs"], [m for m in extra["mps"] if m.observations]
+    extra["mps"], extra["mos"] = mps, []
+    d = _all_frames_problem(kfs, mps, params, float(np.float32(math.sqrt(5.99))) if robust else 0.0)
+    ba = BundleAdjuster(d, ctx=ctx)
+    st = ba.optimize(iterations)
+    cam, pts, _ = ba.read()
+    ba.close()
+    assert st["iterations"] >= 5
+    G = rg.Graph(cur, params, extra)
+    try:
+        G.bundle_adjustment(iterations, robust=robust)
+        moved = 0.0
+        for i, k in enumerate(kfs):
+            T, n, _ = G.kf_pose(k)
+            assert n == 1 and _float_close(T, rg.cvmat_from_pose(cam[i]), ulps=8), k.mnId
+            moved = max(moved, float(np.abs(T - k.T_f32).max()))
+        assert moved > 1e-2
+        for j, m in enumerate(mps):
+            got, nw, _ = G.mp_pos(m)
+            assert nw == 1 and np.abs(got.astype(np.float64) - pts[j]).max() <= 2e-6 * max(1.0, float(np.linalg.norm(pts[j])))
+    finally:
+        G.close()
+
+
+def test_pose_optimization_equals_the_reference_itself(ctx):
+    cur, params, extra = local_map.build(2)
+    rg.quantize(cur, params, extra)
+    K = params["K"]
+    frames, starts, rows_of = [], [], []
+    for k in extra["kfs"][2:8]:
+        rows = [i for i, m in enumerate(k.map_point_matches) if m is not None]
+        T0 = k.T_f32.copy(); T0[:3, 3] += np.float32([0.05, -0.02, 0.08])
+        frames.append({"Xw": np.array([k.map_point_matches[i].pos for i in rows]), "obs": np.array([[k.mvKeysUn[i][0], k.mvKeysUn[i][1], k.mvuRight[i] if k.mvuRight[i] >= 0 else -1.0] for i in rows]),
+                       "inv_sigma2": np.array([k.mvInvLevelSigma2[k.octave[i]] for i in rows]), "intr": (K[0, 0], K[1, 1], K[0, 2], K[1, 2], params["bf"]), "pose": rg.pose_from_cvmat(T0)})
+        starts.append(T0); rows_of.append(rows)
+    got = PoseOptimization(frames, ctx=ctx)
+    for k, T0, rows, (pose, flags, ninl) in zip(extra["kfs"][2:8], starts, rows_of, got):
+        keep = k.T_f32; k.T_f32 = T0
+        H = rg.Graph(cur, params, extra)
+        k.T_f32 = keep
+        try:
+            n_ref, T, out_ref = H.pose_optimization(k)
+        finally:
+            H.close()
+        assert n_ref == ninl and np.array_equal(out_ref[rows], np.asarray(flags, bool))
+        assert _float_close(T, rg.cvmat_from_pose(pose), ulps=8), k.mnId
