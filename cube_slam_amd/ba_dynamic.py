@@ -151,9 +151,28 @@ class DynamicBundleAdjuster:
             pass
 
 
+def erase_rows(d1, e1, d2, fin, e2):
+    """vToErase (Optimizer.cc:2417-2444) as rows of obs_*: the static point edges whose stored chi2 exceeds 5.991 (mono) / 7.815 (stereo) or whose point lies behind
+    the camera at the final estimates, monocular edges first.  An edge at level 1 in the second stage keeps the error it had after the first."""
+    eo1, eo2 = np.asarray(e1["obs"]), np.asarray(e2["obs"])
+    w = np.asarray(d1["obs_inv_sigma2"])
+    ur = d1.get("obs_ur")
+    st = np.zeros(len(eo1), bool) if ur is None else np.asarray(ur) >= 0
+    chi1 = np.where(st, (eo1 ** 2).sum(1), (eo1[:, :2] ** 2).sum(1)) * w
+    chi2 = np.where(st, (eo2 ** 2).sum(1), (eo2[:, :2] ** 2).sum(1)) * w
+    lvl = np.asarray(d2["obs_level"])
+    first = np.zeros(len(eo1), bool) if d1.get("obs_level") is None else np.asarray(d1["obs_level"]) != 0   # never in the graph: not in vpEdgesMono / vpEdgesStereo
+    chi = np.where(lvl == 0, chi2, chi1)
+    R, t = _rot_t(np.asarray(fin["cam_pose"])[np.asarray(d1["obs_cam"], int)])
+    z = np.einsum("nj,nj->n", R[:, 2, :], np.asarray(fin["points"])[np.asarray(d1["obs_point"], int)]) + t[:, 2]
+    bad = ((chi > np.where(st, 7.815, 5.991)) | ~(z > 0)) & ~first
+    return np.array([k for k in np.nonzero(~st)[0] if bad[k]] + [k for k in np.nonzero(st)[0] if bad[k]], int)
+
+
 def LocalBACameraPointObjectsDynamic(problem, ctx=None):
-    """Optimizer.cc:2353-2415: optimize(5), outlier levels + kernel removal, optimize(10).  Returns the final estimates, the stage-2 problem
-    (its levels are what the reference turns into vToErase) and both stages' statistics."""
+    """Optimizer.cc:2353-2444: optimize(5), outlier levels + kernel removal, optimize(10), the observations to erase.  Returns the final estimates (with
+    `erase_obs`: the rows of obs_* the caller erases, in the reference's order), the stage-2 problem and both stages' statistics.  The caller writes back what
+    :2446-2572 writes: poses, static points unless the erasures leave them one observation, every object vertex into allDynamicPoses, velocities, dynamic points."""
     ba = DynamicBundleAdjuster(problem, ctx=ctx)
     st1 = ba.optimize(5)
     d1 = dict(problem); d1.update(ba.read())
@@ -163,5 +182,7 @@ def LocalBACameraPointObjectsDynamic(problem, ctx=None):
     ba2 = DynamicBundleAdjuster(d2, ctx=ctx or ba.ctx)
     st2 = ba2.optimize(10)
     res = ba2.read()
+    _, e2 = ba2.errors()
     ba2.close()
+    res["erase_obs"] = erase_rows(d1, e1, d2, res, e2)
     return res, d2, (st1, st2)

@@ -1,0 +1,301 @@
+"""TEST INFRASTRUCTURE (oracle): Optimizer::LocalBACameraPointObjectsDynamic restated over a small pointer graph of KeyFrame / MapPoint / MapObject objects
+(reference orb_object_slam/src/Optimizer.cc:1537-2573), with the CPU restatement of the g2o machinery for this graph (oracle/badyn_oracle.cpp through
+pyoracle.badyn_optimize / badyn_errors) as the solver.  Only tests/ may import this module; the product takes the flattened arrays this module builds
+(cs_ba_dyn_problem through cube_slam_amd/ba_dynamic.py).
+
+PINNED: tests/test_ref_graph_pins.py runs the reference's own function text on the reference's own g2o (oracle/_ref/libref_graph.so) over the same windows and holds
+this restatement to what it leaves in the map.
+
+The steps and the lines they follow:
+  gather_dynamic_window     :1540-1665  local key frames; their points (a dynamic point of another key frame with one observation is SET BAD on the way, :1566-1570,
+                                        and stays in the list); their objects; fixed key frames from the points' observations -- an object's observers only when
+                                        they are 8 s NEWER than the current frame (:1655), i.e. never in a sequence
+  pose vertices             :1689-1713  as in the static function
+  object vertices           :1727-1786  one VertexCuboidFixScale per (object, observing key frame that is a vertex): pose allDynamicPoses[kf], KITTI half size,
+                                        height reset from THAT key frame's camera when the world is not ground-based, whether_fixrotation
+  static points + edges     :1808-1906  points with one observation and dynamic points skipped
+  dynamic points            :1919-2001  (ba_dyna_pt_obj_cam) >= 4 observations, owned by a local object: PosToObj, UnaryLocalPoint (10 I, ratio 2), one three-vertex edge per
+                                        observing key frame in which the object has a vertex
+  point-object association  :2008-2115  as in the static function -- but its `optimizer.vertex(mnId + maxKFid + 1)` is the STATIC function's id scheme: here it names
+                                        whichever object vertex was created (mnId + 1)-th, in std::unordered_map order.  Restated with the creation order of this
+                                        module; the pin's windows keep every object at <= 5 qualifying points, so that neither side takes the aliased branches
+  velocity + motion edges   :2137-2237  (ba_dyna_obj_velo) objects with >= 4 vertices: VelocityPlanarVelocity, EdgeObjectMotion between consecutive observing key frames
+                                        of the last 5 s (sequential observation order), information ((1, 1, 5) w)^2; a zero velocity is initialised to (distance / time, 0)
+                                        and WRITTEN to the object (:2231)
+  camera-object edges       :2243-2340  (ba_dyna_obj_cam) as in the static function without the halving for > 5 objects; key frames older than 5 s skipped when the
+                                        velocity edges are on
+  two stages                :2353-2415  optimize(5); point edges as in the static function, three-vertex edges with chi2 > 8 to level 1 and their kernel off,
+                                        |bbox error| > 80 to level 1; optimize(10)
+  outcome                   :2417-2572  erase list from the static point edges; poses; static points (unless one observation is left); per object every vertex pose into
+                                        allDynamicPoses, the pose of the observing key frame with the largest id as world pose, the velocity; dynamic points: PosToObj
+                                        and world position = latest object pose * PosToObj"""
+import math
+
+import numpy as np
+
+from . import local_ba_objects as lo
+from . import pyoracle as po
+
+KITTI_HALF = lo.KITTI_HALF
+
+
+class KeyFrame(lo.KeyFrame):
+    def __init__(self, mnId, Tcw, keys_un, u_right, octave, inv_level_sigma2, stamp, bad=False):
+        super().__init__(mnId, Tcw, keys_un, u_right, octave, inv_level_sigma2, bad)
+        self.mTimeStamp = float(stamp)
+
+
+class MapPoint(lo.MapPoint):
+    def __init__(self, mnId, pos, is_dynamic=False, PosToObj=None, best_object=None, bad=False):
+        super().__init__(mnId, pos, bad)
+        self.is_dynamic, self.PosToObj, self.best_object = is_dynamic, (None if PosToObj is None else np.asarray(PosToObj, float)), best_object
+
+
+class MapObject(lo.MapObject):
+    def __init__(self, mnId, pose, scale, meas_quality, bad=False):
+        super().__init__(mnId, pose, scale, meas_quality, bad)
+        self.allDynamicPoses = {}          # KeyFrame -> pose7 (the scale is the object's)
+        self.velocityPlanar = np.zeros(2)
+        self.observed_frames = []          # GetObserveFramesSequential()
+
+
+def gather_dynamic_window(pKF):
+    """:1540-1665 -> (local key frames, local map points, local map objects, fixed key frames, points set bad on the way)."""
+    local_kfs = [pKF]
+    marked_local = {id(pKF)}
+    for kf in pKF.covisible:
+        marked_local.add(id(kf))
+        if not kf.bad:
+            local_kfs.append(kf)
+    points, seen, set_bad = [], set(), []
+    for kf in local_kfs:
+        for mp in kf.map_point_matches:
+            if mp is not None and not mp.bad:
+                if kf is not pKF and mp.is_dynamic and mp.Observations() == 1:
+                    mp.bad = True; set_bad.append(mp)      # SetBadFlag(): (the real one also erases its observations; the stand-ins of the pin do not either)
+                if id(mp) not in seen:
+                    seen.add(id(mp)); points.append(mp)
+    objects, seen_o = [], set()
+    for kf in local_kfs:
+        for mo in kf.cuboids_landmark:
+            if mo is not None and not mo.bad and id(mo) not in seen_o:
+                seen_o.add(id(mo)); objects.append(mo)
+    fixed, marked_fixed = [], set()
+    for mp in points:
+        for kf in mp.observations:
+            if id(kf) not in marked_local and id(kf) not in marked_fixed:
+                marked_fixed.add(id(kf))
+                if not kf.bad:
+                    fixed.append(kf)
+    for mo in objects:
+        for kf in mo.observations:
+            if (kf.mTimeStamp - pKF.mTimeStamp) > 8.0 and id(kf) not in marked_local and id(kf) not in marked_fixed:
+                marked_fixed.add(id(kf))
+                if not kf.bad:
+                    fixed.append(kf)
+    return local_kfs, points, objects, fixed, set_bad, marked_local | marked_fixed
+
+
+def build_dynamic_graph(pKF, params, fixCamera=False, fixPoint=False):
+    """The graph of :1667-2340 as the arrays of orc_badyn_problem plus the objects every row stands for."""
+    kitti = params.get("kitti", True)
+    local_kfs, points, objects, fixed_kfs, set_bad, marked = gather_dynamic_window(pKF)
+    kfs = local_kfs + fixed_kfs
+    cam_index = {id(k): i for i, k in enumerate(kfs)}
+    cam_fixed = np.array([(k.mnId == 0 or fixCamera) if i < len(local_kfs) else True for i, k in enumerate(kfs)], np.uint8)
+    # object vertices :1727-1786
+    obj_pose, obj_key, vertex_of = [], [], {}
+    for mo in objects:
+        vertex_of[id(mo)] = {}
+        for kf in mo.observations:
+            if kf.bad or id(kf) not in marked:
+                continue
+            if kf not in mo.allDynamicPoses:
+                raise RuntimeError("BA not found frame object pose")   # :1752-1757: exit(0)
+            pose = np.array(mo.allDynamicPoses[kf], float).copy()
+            if kitti and not params.get("build_worldframe_on_ground", False):
+                pose[1] = np.float32(kf.camera_center()[1]) + 1.0
+            vertex_of[id(mo)][id(kf)] = len(obj_pose)
+            obj_pose.append(pose); obj_key.append((mo, kf))
+    # static points and their edges :1808-1906
+    pts, pt_mp, oc, op, ouv, ow, our, okf, omp = [], [], [], [], [], [], [], [], []
+    for mp in points:
+        if mp.Observations() == 1 or mp.is_dynamic:
+            continue
+        j = len(pts); pts.append(mp.pos.copy()); pt_mp.append(mp)
+        for kf, idx in mp.observations.items():
+            if kf.bad:
+                continue
+            oc.append(cam_index[id(kf)]); op.append(j); ouv.append(kf.mvKeysUn[idx]); ow.append(float(kf.mvInvLevelSigma2[kf.octave[idx]]))
+            our.append(float(kf.mvuRight[idx]) if kf.mvuRight[idx] >= 0 else -1.0); okf.append(kf); omp.append(mp)
+    # dynamic points :1919-2001
+    dpts, dp_mp, dc, do, dp, duv, dw = [], [], [], [], [], [], []
+    if params.get("ba_dyna_pt_obj_cam", True):
+        local_obj = {id(mo) for mo in objects}
+        for mp in points:
+            if not mp.is_dynamic or mp.Observations() < 4:
+                continue
+            mo = mp.best_object
+            if mo is None or id(mo) not in local_obj:
+                continue
+            j = len(dpts); dpts.append(np.asarray(mp.PosToObj, float).copy()); dp_mp.append(mp)
+            for kf, idx in mp.observations.items():
+                if id(kf) not in vertex_of[id(mo)] or kf.bad:
+                    continue
+                dc.append(cam_index[id(kf)]); do.append(vertex_of[id(mo)][id(kf)]); dp.append(j); duv.append(kf.mvKeysUn[idx]); dw.append(float(kf.mvInvLevelSigma2[kf.octave[idx]]))
+    # point-object association :2008-2115 (the static function's text over this function's vertex ids: see the module docstring)
+    pc_obj, pc_off, pc_pts = [], [0], []
+    for i, mo in enumerate(objects):
+        thr = max(int(mo.largest_point_observations * 0.4), 2)
+        cand = [mp.pos for mp in mo.unique_points if mp is not None and not mp.bad and mp.MapObjObservations.get(mo, 0) > thr]
+        good = []
+        if cand:
+            P = np.stack(cand)
+            mean = P.sum(0) / float(len(P))
+            near = [p for p in P if np.linalg.norm(mean - p) < (4.0 if kitti else 1.5)]
+            mean2 = np.sum(near, 0) / float(len(near)) if near else np.full(3, np.nan)
+            good = [p for p in P if np.linalg.norm(mean2 - p) < (3.0 if kitti else 0.8)]
+        aliased = mo.mnId  # `mnId + maxKFid + 1` with maxKFid already incremented = the (mnId + 1)-th object vertex created
+        if len(good) > 5:
+            if not 0 <= aliased < len(obj_pose):
+                raise RuntimeError("the aliased vertex id of :2075 names no object vertex (the reference dereferences a null pointer here)")
+            obj_pose[aliased][:3] = np.sum(good, 0) / float(len(good))
+        if len(good) > 10:
+            pc_obj.append(aliased); pc_pts.append(np.stack(good)); pc_off.append(pc_off[-1] + len(good))
+    # velocity vertices and motion edges :2137-2237
+    vels, vel_obj, mf, mt, mv, mdt = [], [], [], [], [], []
+    velocity_written = {}
+    if params.get("ba_dyna_obj_velo", True):
+        for mo in objects:
+            if len(vertex_of[id(mo)]) < 4:
+                continue
+            vi = len(vels); vels.append(np.asarray(mo.velocityPlanar, float).copy()); vel_obj.append(mo)
+            first = last = prev = None
+            for kf in mo.observed_frames:
+                if kf.bad or id(kf) not in vertex_of[id(mo)] or (pKF.mTimeStamp - kf.mTimeStamp) > 5.0:
+                    continue
+                if prev is None:
+                    prev = first = kf
+                else:
+                    mf.append(vertex_of[id(mo)][id(prev)]); mt.append(vertex_of[id(mo)][id(kf)]); mv.append(vi); mdt.append(kf.mTimeStamp - prev.mTimeStamp)
+                    prev = last = kf
+            if mo.velocityPlanar[0] == 0 and mo.velocityPlanar[1] == 0 and first is not None and last is not None:
+                a, b = np.asarray(mo.allDynamicPoses[first], float)[:3], np.asarray(mo.allDynamicPoses[last], float)[:3]
+                lin = float(np.linalg.norm(b - a)) / (last.mTimeStamp - first.mTimeStamp)
+                vels[vi] = np.array([lin, 0.0]); velocity_written[mo.mnId] = vels[vi].copy()
+    # camera-object edges :2243-2340
+    w_co = 1.0 * params.get("camera_object_BA_weight", 1.0)
+    margin, Wimg, Himg = 10, params["img_width"], params["img_height"]
+    cc, co, cb, ci, cl, clr = [], [], [], [], [], []
+    if params.get("ba_dyna_obj_cam", True):
+        for mo in objects:
+            mine = []
+            for kf, idx in mo.observations.items():
+                if id(kf) not in vertex_of[id(mo)]:
+                    continue
+                if params.get("ba_dyna_obj_velo", True) and (pKF.mTimeStamp - kf.mTimeStamp) > 5.0:
+                    continue
+                if kf.bad:
+                    continue
+                det = kf.local_cuboids[idx]
+                x, y, w, h = det["bbox_2d"]
+                if x > margin and y > margin and x + w < Wimg - margin and y + h < Himg - margin:
+                    mine.append(len(cc))
+                    cc.append(cam_index[id(kf)]); co.append(vertex_of[id(mo)][id(kf)]); cb.append(np.asarray(det["bbox_vec"], float))
+                    ci.append(np.full(4, w_co * w_co) * mo.meas_quality * mo.meas_quality); cl.append(0); clr.append(det["left_right_to_car"] if kitti else -1)
+            if len(mine) == 1:
+                cl[mine[0]] = 1
+        if kitti:
+            lr = np.array(clr, int)
+            tl, tr, tm = int((lr == 1).sum()), int((lr == 2).sum()), int((lr == 0).sum())
+            if tl > 2 * (tr + tm):
+                for k in np.nonzero(lr == 1)[0]:
+                    ci[k] = ci[k] / 2.0
+            if tr > 2 * (tl + tm):
+                for k in np.nonzero(lr == 2)[0]:
+                    ci[k] = ci[k] / 2.0
+    K = np.asarray(params["K"], float)
+    wv = params.get("object_velocity_BA_weight", 1.0)
+    n_o = len(obj_pose)
+    d = {"cam_pose": np.stack([k.Tcw for k in kfs]), "cam_fixed": cam_fixed,
+         "obj_pose": np.array(obj_pose, float).reshape(-1, 7), "obj_scale": np.tile(np.array(KITTI_HALF), (n_o, 1)).reshape(-1, 3), "obj_flags": np.full(n_o, 2 | 8, np.uint8),
+         "vel": np.array(vels, float).reshape(-1, 2), "points": np.array(pts, float).reshape(-1, 3), "dpoints": np.array(dpts, float).reshape(-1, 3), "fix_points": int(fixPoint),
+         "obs_cam": np.array(oc, np.int32), "obs_point": np.array(op, np.int32), "obs_uv": np.array(ouv, float).reshape(-1, 2), "obs_ur": np.array(our, float),
+         "obs_inv_sigma2": np.array(ow, float), "obs_level": np.zeros(len(oc), np.uint8),
+         "fx": K[0, 0], "fy": K[1, 1], "cx": K[0, 2], "cy": K[1, 2], "bf": params.get("bf", 0.0),
+         "huber_mono": float(np.float32(math.sqrt(5.991))), "huber_stereo": float(np.float32(math.sqrt(7.815))),
+         "ulp_info": 10.0, "ulp_scale": np.array(KITTI_HALF), "ulp_ratio": 2.0,
+         "dobs_cam": np.array(dc, np.int32), "dobs_obj": np.array(do, np.int32), "dobs_point": np.array(dp, np.int32), "dobs_uv": np.array(duv, float).reshape(-1, 2),
+         "dobs_inv_sigma2": np.array(dw, float), "dobs_level": np.zeros(len(dc), np.uint8), "K": K, "huber_dyn": float(np.float32(math.sqrt(5.991))),
+         "mot_from": np.array(mf, np.int32), "mot_to": np.array(mt, np.int32), "mot_vel": np.array(mv, np.int32), "mot_dt": np.array(mdt, float),
+         "mot_info": (np.array([1.0, 1.0, 5.0]) * wv) ** 2,
+         "cobs_cam": np.array(cc, np.int32), "cobs_obj": np.array(co, np.int32), "cobs_bbox": np.array(cb, float).reshape(-1, 4), "cobs_info": np.array(ci, float).reshape(-1, 4),
+         "cobs_level": np.array(cl, np.uint8), "huber_obj": float(np.float32(math.sqrt(900.0))),
+         "pc_obj": np.array(pc_obj, np.int32), "pc_offsets": np.array(pc_off, np.int32), "pc_points": np.concatenate(pc_pts).reshape(-1, 3) if pc_pts else np.zeros((0, 3)),
+         "pc_ratio": 2.0 if kitti else 1.0}
+    return {"problem": d, "kfs": kfs, "n_local": len(local_kfs), "objects": objects, "obj_key": obj_key, "vertex_of": vertex_of, "vel_obj": vel_obj, "points": pt_mp, "dpoints": dp_mp,
+            "obs_kf": okf, "obs_mp": omp, "local_points": points, "set_bad": set_bad, "velocity_written": velocity_written}
+
+
+def _rot(q):
+    return lo._rot(q)
+
+
+def local_ba_dynamic(pKF, params, fixCamera=False, fixPoint=False):
+    """-> the outcome of :2353-2572 as dictionaries over mnIds (see the module docstring) plus the graph."""
+    g = build_dynamic_graph(pKF, params, fixCamera, fixPoint)
+    d = g["problem"]
+    # stage 1 :2353-2354
+    r1, st1 = po.badyn_optimize(d, 5)
+    est = dict(d); est.update(r1)
+    _, e1 = po.badyn_errors(est)
+    st = est["obs_ur"] >= 0
+    chi = np.where(st, (e1["obs"] ** 2).sum(1), (e1["obs"][:, :2] ** 2).sum(1)) * est["obs_inv_sigma2"] if len(st) else np.zeros(0)
+
+    def depth(x):
+        return np.array([(_rot(x["cam_pose"][c][3:]) @ x["points"][p] + x["cam_pose"][c][:3])[2] for c, p in zip(x["obs_cam"], x["obs_point"])]) if len(x["obs_cam"]) else np.zeros(0)
+    z = depth(est)
+    obs_level = ((chi > np.where(st, 7.815, 5.991)) | ~(z > 0)).astype(np.uint8) if len(st) else np.zeros(0, np.uint8)
+    dobs_level = ((e1["dobs"] ** 2).sum(1) * est["dobs_inv_sigma2"] > 8).astype(np.uint8) if len(est["dobs_cam"]) else np.zeros(0, np.uint8)
+    cobs_level = np.asarray(d["cobs_level"], np.uint8).copy()
+    if len(cobs_level):
+        cobs_level[(cobs_level == 0) & (np.sqrt((e1["cobs"] ** 2).sum(1)) > 80)] = 1   # an edge at level 1 holds the zero error it was created with
+    # stage 2 :2410-2411: the three kinds of point edges lose their kernel, the camera-object edges keep theirs
+    s2 = dict(est); s2.update(obs_level=obs_level, dobs_level=dobs_level, cobs_level=cobs_level, huber_mono=0.0, huber_stereo=0.0, huber_dyn=0.0)
+    r2, st2 = po.badyn_optimize(s2, 10)
+    fin = dict(s2); fin.update(r2)
+    _, e2 = po.badyn_errors(fin)
+    chi2 = np.where(st, (e2["obs"] ** 2).sum(1), (e2["obs"][:, :2] ** 2).sum(1)) * fin["obs_inv_sigma2"] if len(st) else np.zeros(0)
+    chi_used = np.where(obs_level == 0, chi2, chi)   # a level-1 edge keeps the error of stage 1
+    z2 = depth(fin)
+    bad = (chi_used > np.where(st, 7.815, 5.991)) | ~(z2 > 0) if len(st) else np.zeros(0, bool)
+    n_obs = len(st)
+    order = [k for k in range(n_obs) if not st[k]] + [k for k in range(n_obs) if st[k]]
+    erase = [(g["obs_kf"][k].mnId, g["obs_mp"][k].mnId) for k in order if bad[k] and not g["obs_mp"][k].bad]
+    n_erased = {}
+    for _, m in erase:
+        n_erased[m] = n_erased.get(m, 0) + 1
+    unwritten = [mp.mnId for mp in g["points"] if mp.Observations() - n_erased.get(mp.mnId, 0) == 1]
+    # objects :2493-2533
+    frame_pose = {(mo.mnId, kf.mnId): fin["obj_pose"][i] for i, (mo, kf) in enumerate(g["obj_key"])}
+    latest = {}
+    for mo in g["objects"]:
+        ks = [kf for kf in mo.observations if not kf.bad and id(kf) in g["vertex_of"][id(mo)]]
+        if ks:
+            kf = max(ks, key=lambda k: k.mnId)
+            latest[mo.mnId] = fin["obj_pose"][g["vertex_of"][id(mo)][id(kf)]]
+    velocity = {mo.mnId: fin["vel"][i] for i, mo in enumerate(g["vel_obj"])}
+    # dynamic points :2536-2563 (the erasures touch static points only: a dynamic vertex has >= 4 observations)
+    dlocal, dworld = {}, {}
+    for j, mp in enumerate(g["dpoints"]):
+        p32 = np.float32(fin["dpoints"][j])
+        dlocal[mp.mnId] = fin["dpoints"][j]
+        mo = mp.best_object
+        if mo.mnId in latest:
+            T = latest[mo.mnId]
+            dworld[mp.mnId] = _rot(T[3:]) @ fin["dpoints"][j] + T[:3]   # pose_Twc_latestKF.pose * vPoint->estimate() (the double estimate, not the float PosToObj)
+        del p32
+    return {"kf_pose": {k.mnId: fin["cam_pose"][i] for i, k in enumerate(g["kfs"][:g["n_local"]])}, "point_pos": {mp.mnId: fin["points"][j] for j, mp in enumerate(g["points"])},
+            "point_unwritten": unwritten, "erase": erase, "object_frame_pose": frame_pose, "object_latest": latest, "velocity": velocity,
+            "velocity_written": g["velocity_written"], "dpoint_local": dlocal, "dpoint_world": dworld, "set_bad": [mp.mnId for mp in g["set_bad"]],
+            "obs_level": obs_level, "dobs_level": dobs_level, "cobs_level2": cobs_level, "stats": (st1, st2), "graph": g}

@@ -160,6 +160,50 @@ API void ref_graph_mo_flags(ref_graph *g, int mo, int *n_obs, int *bad, int *is_
     *n_cuboids_landmark_refs = refs;
 }
 
+// ---- the dynamic-object BA (Optimizer.cc:1537-2573)
+API void ref_graph_set_dyn_params(ref_graph *, int pt_obj_cam, int obj_velo, int obj_cam, double velocity_weight, int dynamic_objects) {
+    ba_dyna_pt_obj_cam = pt_obj_cam != 0; ba_dyna_obj_velo = obj_velo != 0; ba_dyna_obj_cam = obj_cam != 0; object_velocity_BA_weight = velocity_weight;
+    whether_dynamic_object = dynamic_objects != 0; use_dynamic_klt_features = false;
+}
+API void ref_graph_kf_stamp(ref_graph *g, int kf, double t) { g->kfs[kf]->mTimeStamp = t; }
+API void ref_graph_mp_dynamic(ref_graph *g, int mp, const float *pos_to_obj3, int best_mo) {
+    MapPoint *p = g->mps[mp].get();
+    p->is_dynamic = true; p->PosToObj = mat_f(3, 1, pos_to_obj3); p->best_object = best_mo < 0 ? nullptr : g->mos[best_mo].get();
+}
+API void ref_graph_mo_dynamic_pose(ref_graph *g, int mo, int kf, const double *pose7, const double *scale3) {
+    g->mos[mo]->allDynamicPoses[g->kfs[kf].get()] = std::make_pair(cuboid_of(pose7, scale3), false);
+}
+API void ref_graph_mo_velocity(ref_graph *g, int mo, const double *v2) { g->mos[mo]->velocityPlanar = Eigen::Vector2d(v2[0], v2[1]); g->mos[mo]->is_dynamic = true; }
+API void ref_graph_local_ba_dynamic(ref_graph *g, int kf, int fix_camera, int fix_point, bool *stop) {
+    Quiet q; standin_log = &g->log;
+    Optimizer::LocalBACameraPointObjectsDynamic(g->kfs[kf].get(), stop, &g->map, fix_camera != 0, fix_point != 0);
+    standin_log = nullptr;
+}
+// an object's pose in a key frame after the BA (allDynamicPoses[kf]): returns 1 if there is an entry; *baed = its flag
+API int ref_graph_mo_dynamic_pose_out(ref_graph *g, int mo, int kf, double *pose7, int *baed) {
+    MapObject *o = g->mos[mo].get();
+    auto it = o->allDynamicPoses.find(g->kfs[kf].get());
+    if (it == o->allDynamicPoses.end()) return 0;
+    g2o::Vector7d v = it->second.first.pose.toVector();
+    for (int i = 0; i < 7; i++) pose7[i] = v[i];
+    *baed = it->second.second ? 1 : 0;
+    return 1;
+}
+API void ref_graph_mo_dynamic_state(ref_graph *g, int mo, double *latest7, double *afterba7, double *velocity2, int *n_history, double *history2, long *local_for) {
+    MapObject *o = g->mos[mo].get();
+    g2o::Vector7d a = o->pose_Twc_latestKF.pose.toVector(), b = o->pose_Twc_afterba.pose.toVector();
+    for (int i = 0; i < 7; i++) { latest7[i] = a[i]; afterba7[i] = b[i]; }
+    velocity2[0] = o->velocityPlanar[0]; velocity2[1] = o->velocityPlanar[1];
+    *n_history = (int)o->velocityhistory.size();
+    if (!o->velocityhistory.empty()) { history2[0] = o->velocityhistory.rbegin()->second[0]; history2[1] = o->velocityhistory.rbegin()->second[1]; }
+    *local_for = (long)o->mnBALocalForKF;
+}
+API void ref_graph_mp_dynamic_out(ref_graph *g, int mp, float *pos_to_obj3, float *latest3, int *is_optimized, int *bad, long *local_for) {
+    MapPoint *p = g->mps[mp].get();
+    for (int i = 0; i < 3; i++) { pos_to_obj3[i] = p->PosToObj.empty() ? 0.f : p->PosToObj.at<float>(i); latest3[i] = p->mWorldPos_latestKF.empty() ? 0.f : p->mWorldPos_latestKF.at<float>(i); }
+    *is_optimized = p->is_optimized ? 1 : 0; *bad = p->bad ? 1 : 0; *local_for = (long)p->mnBALocalForKF;
+}
+
 // Converter::toSE3Quat of a 4 x 4 float pose: the estimate a pose vertex starts from (7 doubles [t, qx qy qz qw], SE3Quat::toVector)
 API void ref_graph_pose_from_cvmat(const float *Tcw16, double *pose7) {
     g2o::SE3Quat s = Converter::toSE3Quat(mat_f(4, 4, Tcw16));

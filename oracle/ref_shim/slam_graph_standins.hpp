@@ -67,7 +67,11 @@ class MapPoint {
     std::set<MapObject *> LocalObjObservations;
     std::mutex mMutexObject;
     void AddObjectObservation(MapObject *obj);
-    cv::Mat mWorldPos_latestKF;
+    // dynamic-object BA (:1537-2573)
+    cv::Mat mWorldPos_latestKF, PosToObj; // world position at the latest key frame; position in the object's frame
+    bool is_optimized = false;
+    int n_bad_flags = 0;
+    void SetBadFlag() { bad = true; n_bad_flags++; } // (the real one also erases the point's observations: map bookkeeping)
     std::map<KeyFrame *, size_t> GetObservations() { return mObservations; }
     int Observations() { return (int)mObservations.size(); }
     bool isBad() { return bad; }
@@ -86,6 +90,9 @@ class KeyFrame {
     std::vector<cv::KeyPoint> mvKeysUn;
     std::vector<float> mvuRight, mvInvLevelSigma2;
     float fx = 0, fy = 0, cx = 0, cy = 0, mbf = 0;
+    double mTimeStamp = 0;
+    std::vector<cv::KeyPoint> mvKeysHarris;
+    std::vector<MapPoint *> GetHarrisMapPointMatches() { return std::vector<MapPoint *>(); }
     std::vector<MapPoint *> mvpMapPoints;
     std::vector<KeyFrame *> covisible;
     std::vector<MapObject *> local_cuboids, cuboids_landmark;
@@ -202,6 +209,7 @@ class Optimizer { // Optimizer.h:36-49
     void static BundleAdjustment(const std::vector<KeyFrame *> &vpKF, const std::vector<MapPoint *> &vpMP, int nIterations = 5, bool *pbStopFlag = NULL, const unsigned long nLoopKF = 0,
                                  const bool bRobust = true);
     void static LocalBACameraPointObjects(KeyFrame *pKF, bool *pbStopFlag, Map *pMap, bool fixCamera = false, bool fixPoint = false);
+    void static LocalBACameraPointObjectsDynamic(KeyFrame *pKF, bool *pbStopFlag, Map *pMap, bool fixCamera = false, bool fixPoint = false);
     int static PoseOptimization(Frame *pFrame);
 };
 } // namespace ORB_SLAM2

@@ -68,6 +68,8 @@ def quantize(cur, params, extra):
         pts += [mp for mp in mo.unique_points if mp is not None]
     for mp in pts:
         mp.pos = np.asarray(mp.pos, np.float32).astype(np.float64)
+        if getattr(mp, "PosToObj", None) is not None:
+            mp.PosToObj = np.asarray(mp.PosToObj, np.float32).astype(np.float64)
     params["K"] = np.asarray(params["K"], np.float32).astype(np.float64)
     params["bf"] = float(np.float32(params["bf"]))
     return cur, params, extra
@@ -115,6 +117,21 @@ class Graph:
             for m in o.unique_points:
                 L.ref_graph_mo_unique_point(self.h, self.mo[id(o)], -1 if m is None else self.mp[id(m)], 0 if m is None else int(m.MapObjObservations.get(o, 0)))
         self.kfs, self.mps, self.mos = kfs, mps, list(extra["mos"])
+        # the dynamic-object BA's extra state: time stamps, dynamic points, per-frame object poses, velocities
+        for k in kfs:
+            if hasattr(k, "mTimeStamp"):
+                L.ref_graph_kf_stamp(self.h, self.kf[id(k)], C.c_double(k.mTimeStamp))
+        for m in mps:
+            if getattr(m, "is_dynamic", False):
+                L.ref_graph_mp_dynamic(self.h, self.mp[id(m)], _p(_f32(m.PosToObj), C.c_float), -1 if m.best_object is None else self.mo[id(m.best_object)])
+        for o in self.mos:
+            for k, pose in getattr(o, "allDynamicPoses", {}).items():
+                L.ref_graph_mo_dynamic_pose(self.h, self.mo[id(o)], self.kf[id(k)], _p(np.ascontiguousarray(pose, np.float64), C.c_double), _p(np.ascontiguousarray(o.scale, np.float64), C.c_double))
+            if hasattr(o, "velocityPlanar"):
+                L.ref_graph_mo_velocity(self.h, self.mo[id(o)], _p(np.ascontiguousarray(o.velocityPlanar, np.float64), C.c_double))
+        if "ba_dyna_obj_velo" in params:
+            L.ref_graph_set_dyn_params(self.h, int(params["ba_dyna_pt_obj_cam"]), int(params["ba_dyna_obj_velo"]), int(params["ba_dyna_obj_cam"]),
+                                       C.c_double(params.get("object_velocity_BA_weight", 1.0)), 1)
 
     def close(self):
         if self.h:
@@ -122,6 +139,27 @@ class Graph:
 
     def local_ba_objects(self, cur, fix_camera=False, fix_point=False):
         self.L.ref_graph_local_ba_objects(self.h, self.kf[id(cur)], int(fix_camera), int(fix_point), None)
+
+    def local_ba_dynamic(self, cur, fix_camera=False, fix_point=False):
+        self.L.ref_graph_local_ba_dynamic(self.h, self.kf[id(cur)], int(fix_camera), int(fix_point), None)
+
+    def mo_dynamic_pose(self, mo, kf):
+        pose = np.zeros(7); baed = C.c_int(0)
+        self.L.ref_graph_mo_dynamic_pose_out.restype = C.c_int
+        ok = self.L.ref_graph_mo_dynamic_pose_out(self.h, self.mo[id(mo)], self.kf[id(kf)], _p(pose, C.c_double), C.byref(baed))
+        return (pose, bool(baed.value)) if ok else (None, False)
+
+    def mo_dynamic_state(self, mo):
+        a, b, v, hst = np.zeros(7), np.zeros(7), np.zeros(2), np.zeros(2)
+        n, lf = C.c_int(0), C.c_long(0)
+        self.L.ref_graph_mo_dynamic_state(self.h, self.mo[id(mo)], _p(a, C.c_double), _p(b, C.c_double), _p(v, C.c_double), C.byref(n), _p(hst, C.c_double), C.byref(lf))
+        return {"latest": a, "afterba": b, "velocity": v, "n_history": n.value, "history": hst, "local_for": lf.value}
+
+    def mp_dynamic(self, mp):
+        a, b = np.zeros(3, np.float32), np.zeros(3, np.float32)
+        o, bad, lf = C.c_int(0), C.c_int(0), C.c_long(0)
+        self.L.ref_graph_mp_dynamic_out(self.h, self.mp[id(mp)], _p(a, C.c_float), _p(b, C.c_float), C.byref(o), C.byref(bad), C.byref(lf))
+        return {"PosToObj": a, "latest": b, "is_optimized": bool(o.value), "bad": bool(bad.value), "local_for": lf.value}
 
     def bundle_adjustment(self, iterations, loop_kf=0, robust=True):
         self.L.ref_graph_bundle_adjustment(self.h, int(iterations), C.c_ulong(loop_kf), int(robust), None)
