@@ -4,7 +4,7 @@
  * TEST INFRASTRUCTURE ONLY (see oracle.h).  EDGES PINNED (tests/test_ref_pins.py::test_dynamic_ba_edges_equal_reference, oracle/_ref): computeError of every
  * edge type and the Jacobians of the two three-vertex types equal the reference's own classes (cut out whole, g2o's numeric differentiation under them) bit for
  * bit, and a run driven by the reference's own OptimizationAlgorithmLevenberg::solve + SparseOptimizer::optimize over this file's pieces equals
- * orc_badyn_optimize bit for bit (::test_dynamic_ba_schedule_equals_reference); the graph construction (Optimizer.cc:1537-2350) is unpinned; the block solver it shares with the static BA runs as the reference wrote it in tests/test_ref_graph_pins.py.  Restated from /root/reference/orb_object_slam/src/Optimizer.cc:1537-2573
+ * orc_badyn_optimize bit for bit (::test_dynamic_ba_schedule_equals_reference); the graph construction (Optimizer.cc:1537-2350) is restated in oracle/local_ba_dynamic.py and held, with whole runs of orc_badyn_optimize under it, to the reference's own function text running on the reference's g2o (tests/test_ref_graph_pins.py).  Restated from /root/reference/orb_object_slam/src/Optimizer.cc:1537-2573
  * (the graph), orb_object_slam/{include/g2o_Object.h, src/g2o_Object.cpp} (VertexCuboidFixScale :88-116, VelocityPlanarVelocity
  * g2o_Object.h:288-308, EdgeDynamicPointCuboidCamera :154-233, EdgeObjectMotion :241-272, UnaryLocalPoint :378-398,
  * EdgeSE3CuboidFixScaleProj :118-128, EdgePointCuboidOnlyObjectFixScale :336-354) and the vendored g2o under

@@ -15,14 +15,15 @@
  * function by function at build time where they need Eigen / g2o / the SLAM
  * classes (against stand-ins for those) -- into oracle/_ref/libref.so, and
  * tests/test_ref_pins.py demands bit equality of every oracle of the path with
- * it.  The graph-level functions (Optimizer::LocalBACameraPointObjects,
- * BundleAdjustment, PoseOptimization, Tracking::AssociateCuboids) run as text
+ * it.  The graph-level functions (Optimizer::LocalBACameraPointObjects and
+ * its Dynamic variant, BundleAdjustment, PoseOptimization,
+ * Tracking::AssociateCuboids) run as text
  * on the reference's vendored g2o, compiled WHOLE against a stand-in for
  * Eigen's interface (oracle/_ref/libref_graph.so): tests/test_ref_graph_pins.py
  * holds the graph-level oracles to what they leave in the map.  What stays
  * restated and unpinned: the third-party primitives that are not in the
- * reference tree (OpenCV imgproc / features2d, Eigen's sparse Cholesky) and
- * the graph construction of the dynamic-object BA; each file's header says which.
+ * reference tree (OpenCV imgproc / features2d, Eigen's sparse Cholesky); each
+ * file's header says which.
  * Every function cites the reference file:line it follows.  The expected
  * outputs the reference ships (object_slam/data/detect_cuboids_saved.txt, the
  * author's offline MATLAB detections) pin the line + cuboid chain loosely:

@@ -69,3 +69,37 @@ def test_pose_optimization_equals_the_reference_itself(ctx):
             H.close()
         assert n_ref == ninl and np.array_equal(out_ref[rows], np.asarray(flags, bool))
         assert _float_close(T, rg.cvmat_from_pose(pose), ulps=8), k.mnId
+
+
+@pytest.mark.parametrize("seed", [1, 3])
+def test_dynamic_local_ba_equals_the_reference_itself(ctx, seed):
+    """The HIP dynamic-object BA (cs_ba_dyn_* through cube_slam_amd.ba_dynamic, fed the arrays an adapter would gather: oracle/local_ba_dynamic.build_dynamic_graph)
+    against the reference's own Optimizer::LocalBACameraPointObjectsDynamic on the same window: the observations erased, key-frame poses, per-frame object poses,
+    velocities, dynamic points."""
+    from cube_slam_amd.ba_dynamic import LocalBACameraPointObjectsDynamic
+    from oracle import local_ba_dynamic as ld
+    from tests import local_map_dynamic as lmd
+    cur, params, extra = lmd.build(seed)
+    rg.quantize(cur, params, extra)
+    g = ld.build_dynamic_graph(cur, params)
+    res, d2, _ = LocalBACameraPointObjectsDynamic(g["problem"], ctx=ctx)
+    G = rg.Graph(cur, params, extra)
+    try:
+        G.local_ba_dynamic(cur)
+        erase = sorted((g["obs_kf"][k].mnId, g["obs_mp"][k].mnId) for k in res["erase_obs"])
+        assert erase == sorted(G.erased()) and len(erase) > 50
+        for i, k in enumerate(g["kfs"][:g["n_local"]]):
+            T, n, _ = G.kf_pose(k)
+            To = rg.cvmat_from_pose(res["cam_pose"][i]).astype(np.float64)
+            assert n == 1 and np.abs(T[:3, :3] - To[:3, :3]).max() <= 2e-6 and np.abs(T[:3, 3] - To[:3, 3]).max() <= 2e-6 * max(1.0, np.abs(To[:3, 3]).max()), k.mnId
+        for i, (mo, kf) in enumerate(g["obj_key"]):
+            got, baed = G.mo_dynamic_pose(mo, kf)
+            assert baed and np.allclose(got, res["obj_pose"][i], rtol=0, atol=5e-4), (mo.mnId, kf.mnId, np.abs(got - res["obj_pose"][i]).max())
+        for i, mo in enumerate(g["vel_obj"]):
+            assert np.allclose(G.mo_dynamic_state(mo)["velocity"], res["vel"][i], rtol=0, atol=5e-4)
+        n_vert = {id(mo): len(g["vertex_of"][id(mo)]) for mo in g["objects"]}
+        for j, mp in enumerate(g["dpoints"]):
+            s = G.mp_dynamic(mp)
+            assert s["is_optimized"] and np.abs(s["PosToObj"].astype(np.float64) - res["dpoints"][j]).max() <= (1e-3 if n_vert[id(mp.best_object)] >= 4 else 3e-3), mp.mnId
+    finally:
+        G.close()
