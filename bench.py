@@ -507,7 +507,7 @@ def main():
         # the device, one wave per frame for ~110 ms (lsd_regions.hip), sixteen frames to a CU.  Default: the ALTERNATING runner with four
         # detectors -- their walks (4 x 64 CUs, scalar-unit-bound) hold the chip all the time and every other kernel of the step runs in the
         # wave slot and the vector-ALU time they leave; the edge-scoring kernel, which otherwise needs whole CUs, takes its 256-thread shape for
-        # that (cs_cuboid_batch_set_shared_gpu).  It is the faster runner (19.0 k against 16.5 k frames/s); the PHASED runner (--phased 1: four
+        # that (cs_cuboid_batch_set_shared_gpu).  It is the faster runner (20.0 k against 16.7 k frames/s); the PHASED runner (--phased 1: four
         # detectors queue their map kernels beside ORB / cuboid of four steps, then the four region stages run together with the ORB / cuboid
         # stream idle) keeps the score kernel away from the walks and is timed beside it (`phased_runner`).  Below 512 frames the 16 host
         # threads grow the regions and the GPU phases of one step overlap the host stage of the neighbouring one.
