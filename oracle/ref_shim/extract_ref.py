@@ -117,7 +117,7 @@ WANT = [  # (file, signatures, output include)
     # ref_graph_api.cpp / slam_graph_standins.hpp)
     ("orb_object_slam/src/Converter.cc", ["g2o::SE3Quat Converter::toSE3Quat(const cv::Mat &cvT)", "cv::Mat Converter::toCvMat(const g2o::SE3Quat &SE3)",
                                           "cv::Mat Converter::toCvMat(const Eigen::Matrix<double, 4, 4> &m)", "cv::Mat Converter::toCvMat(const Eigen::Matrix<double, 3, 1> &m)",
-                                          "Eigen::Matrix<double, 3, 1> Converter::toVector3d(const cv::Mat &cvVector)"], "extracted_graph.inc"),
+                                          "Eigen::Matrix<double, 3, 1> Converter::toVector3d(const cv::Mat &cvVector)"], "extracted_graph_conv.inc"),
     ("orb_object_slam/src/Optimizer.cc", ["void Optimizer::BundleAdjustment(const vector<KeyFrame *> &vpKFs, const vector<MapPoint *> &vpMP,", "int Optimizer::PoseOptimization(Frame *pFrame)",
                                           "void Optimizer::LocalBACameraPointObjects(KeyFrame *pKF, bool *pbStopFlag, Map *pMap, bool fixCamera, bool fixPoint)",
                                           "void Optimizer::LocalBACameraPointObjectsDynamic(KeyFrame *pKF, bool *pbStopFlag, Map *pMap, bool fixCamera, bool fixPoint)"], "extracted_graph.inc"),
@@ -126,8 +126,8 @@ WANT = [  # (file, signatures, output include)
                                           "void MapObject::AddUniqueMapPoint(MapPoint *pMP, int obs_num)", "void MapObject::EraseUniqueMapPoint(MapPoint *pMP, int obs_num)",
                                           "vector<MapPoint *> MapObject::GetPotentialMapPoints()", "void MapObject::AddPotentialMapPoint(MapPoint *pMP)",
                                           "bool MapObject::check_whether_valid_object(int own_point_thre)", "void MapObject::SetAsLandmark()",
-                                          "void MapObject::MergeIntoLandmark(MapObject *otherLocalObject)", "void MapObject::addObservation(KeyFrame *pKF, size_t idx)"], "extracted_graph.inc"),
-    ("orb_object_slam/src/MapPoint.cc", ["void MapPoint::AddObjectObservation(MapObject *obj)"], "extracted_graph.inc"),
+                                          "void MapObject::MergeIntoLandmark(MapObject *otherLocalObject)", "void MapObject::addObservation(KeyFrame *pKF, size_t idx)"], "extracted_graph_map.inc"),
+    ("orb_object_slam/src/MapPoint.cc", ["void MapPoint::AddObjectObservation(MapObject *obj)"], "extracted_graph_map.inc"),
     ("orb_object_slam/src/Tracking.cc", ["void Tracking::AssociateCuboids(KeyFrame *pKF)"], "extracted_graph.inc"),
     # the LBD descriptor: BinaryDescriptor's compute path (the rest of binary_descriptor.cpp is the EDLine detector, which CubeSLAM does not use)
     ("line_lbd/libs/binary_descriptor.cpp", ["static const int combinations[32][2] =", "BinaryDescriptor::Params::Params()", "BinaryDescriptor::BinaryDescriptor( const BinaryDescriptor::Params &parameters ) :",

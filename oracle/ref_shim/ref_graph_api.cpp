@@ -27,20 +27,15 @@ EraseLog *standin_log = nullptr;
 std::mutex MapPoint::mGlobalMutex;
 long int MapObject::nNextId = 0;
 
+#include "extracted_graph_conv.inc"
+#include "extracted_graph_map.inc"
 #include "extracted_graph.inc"
 } // namespace ORB_SLAM2
 
 using namespace ORB_SLAM2;
 #define API extern "C" __attribute__((visibility("default")))
 
-struct ref_graph {
-    std::vector<std::unique_ptr<KeyFrame>> kfs;
-    std::vector<std::unique_ptr<MapPoint>> mps;
-    std::vector<std::unique_ptr<MapObject>> mos, dets; // landmarks; per-frame detections (KeyFrame::local_cuboids)
-    ORB_SLAM2::Map map;
-    EraseLog log;
-    std::streambuf *cout_was = nullptr;
-};
+#include "ref_graph_types.hpp"
 
 namespace {
 struct Quiet { // the functions narrate on std::cout

@@ -62,3 +62,78 @@ def test_line_lbd_detect_adapter_equals_reference_class(libs, oracle):
         assert na == nr > 20 and kl_a[:na].tobytes() == kl_r[:nr].tobytes()
         want = oracle.lsd_detect_filter_lines(gray, 15.0)
         assert nfilt.value == len(want) and np.array_equal(filt[:nfilt.value], want)
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------------------------
+# b3: adapters/Optimizer_hip.cc RUN -- its two member functions over a stand-in map (oracle/_ref/libadapter_graph.so: the adapter compiled against the runnable
+# stand-ins of KeyFrame / MapPoint / MapObject / Map and linked with libcubeslam_hip.so) against the reference's own function text running on the reference's own
+# g2o over the same map (oracle/_ref/libref_graph.so).  Map in, map out: what SetPose / SetWorldPos / EraseMapPointMatch left behind.
+ADP_GRAPH_SO = os.path.join(ROOT, "oracle", "_ref", "libadapter_graph.so")
+
+
+def _adapter_graph():
+    from tests import ref_graph as rg
+    if not (os.path.exists(ADP_GRAPH_SO) and os.path.exists(rg.SO)):
+        pytest.skip("oracle/_ref/libadapter_graph.so / libref_graph.so are built from /root/reference")
+    return rg, C.CDLL(ADP_GRAPH_SO)
+
+
+@pytest.mark.parametrize("seed", [1, 2])
+def test_optimizer_adapter_local_ba_equals_the_reference(seed):
+    rg, A = _adapter_graph()
+    from tests import local_map
+    cur, params, extra = local_map.build(seed)
+    rg.quantize(cur, params, extra)
+    Gr, Ga = rg.Graph(cur, params, extra), rg.Graph(cur, params, extra)
+    try:
+        Gr.local_ba_objects(cur)
+        A.adp_graph_set_params(1, 0, C.c_double(params["camera_object_BA_weight"]))
+        err = C.create_string_buffer(512)
+        assert A.adp_graph_local_ba_objects(Ga.h, Ga.kf[id(cur)], 0, None, err, 512) == 0, err.value
+        assert sorted(Ga.erased()) == sorted(Gr.erased()) and len(Gr.erased()) > 0
+        moved = 0.0
+        for k in extra["kfs"]:
+            Tr, nr, _ = Gr.kf_pose(k); Ta, na, _ = Ga.kf_pose(k)
+            assert na == nr and Ga.kf_markers(k) == Gr.kf_markers(k)   # (a bad covisible key frame keeps its mnBALocalForKF mark in the reference: it is in no list that is reset)
+            assert np.abs(Tr[:3, :3] - Ta[:3, :3]).max() <= 2e-6 and np.abs(Tr[:3, 3] - Ta[:3, 3]).max() <= 2e-6 * max(1.0, float(np.abs(Tr[:3, 3]).max())), k.mnId
+            moved = max(moved, float(np.abs(Ta - k.T_f32).max()))
+        assert moved > 1e-3
+        n_unwritten = 0
+        for m in Gr.mps:
+            pr, nr, ur = Gr.mp_pos(m); pa, na, ua = Ga.mp_pos(m)
+            assert (na, ua) == (nr, ur), m.mnId   # written (or left alone: no vertex, or one observation left after the erasures) on both sides
+            n_unwritten += int(nr == 0 and len(m.observations) > 1)
+            assert np.abs(pr.astype(np.float64) - pa.astype(np.float64)).max() <= 1e-5 * max(1.0, float(np.linalg.norm(pr))), (m.mnId, pr, pa)
+        assert n_unwritten > 0
+        for o in extra["mos"]:
+            sr, sa = Gr.mo_state(o), Ga.mo_state(o)
+            assert (sa["writes"], sa["been_optimized"], sa["n_used"], sa["n_filtered"]) == (sr["writes"], sr["been_optimized"], sr["n_used"], sr["n_filtered"]), o.mnId
+            assert np.allclose(sa["pose"], sr["pose"], rtol=0, atol=2e-5) and np.array_equal(sa["scale"], sr["scale"])
+    finally:
+        Gr.close(); Ga.close()
+
+
+@pytest.mark.parametrize("loop_kf", [0, 7])
+def test_optimizer_adapter_bundle_adjustment_equals_the_reference(loop_kf):
+    rg, A = _adapter_graph()
+    from tests import local_map
+    cur, params, extra = local_map.build(1, n_kf=10, n_points=80, n_cuboids=3)
+    rg.quantize(cur, params, extra)
+    for k in extra["kfs"]:
+        k.bad = False; k.local_cuboids, k.cuboids_landmark = [], []
+    extra["mps"], extra["mos"] = [m for m in extra["mps"] if m.observations], []
+    Gr, Ga = rg.Graph(cur, params, extra), rg.Graph(cur, params, extra)
+    try:
+        Gr.bundle_adjustment(10, loop_kf=loop_kf)
+        err = C.create_string_buffer(512)
+        assert A.adp_graph_bundle_adjustment(Ga.h, 10, C.c_ulong(loop_kf), 1, None, err, 512) == 0, err.value
+        for k in extra["kfs"]:
+            Tr, nr, Gr_gba = Gr.kf_pose(k); Ta, na, Ga_gba = Ga.kf_pose(k)
+            assert na == nr == (0 if loop_kf else 1)
+            a, b = (Gr_gba, Ga_gba) if loop_kf else (Tr, Ta)
+            assert np.abs(a - b).max() <= 2e-6 * max(1.0, float(np.abs(a[:3, 3]).max())), k.mnId
+        for m in Gr.mps:
+            pr, nr, _ = Gr.mp_pos(m); pa, na, _ = Ga.mp_pos(m)
+            assert na == nr and np.abs(pr.astype(np.float64) - pa.astype(np.float64)).max() <= 1e-5 * max(1.0, float(np.linalg.norm(pr)))
+    finally:
+        Gr.close(); Ga.close()

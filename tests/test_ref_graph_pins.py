@@ -51,6 +51,7 @@ def test_local_ba_camera_point_objects_equals_reference(seed, kwargs):
             assert n == 1 and _pose_close(T, rg.cvmat_from_pose(pose)), mn
             moved = max(moved, float(np.abs(T - kid[mn].T_f32).max()))
             assert G.kf_markers(kid[mn]) == (0, 0)
+        assert any(G.kf_markers(k)[0] == cur.mnId for k in cur.covisible if k.bad), "a bad covisible key frame keeps its mark (it is in no list that :1500-1524 resets)"
         assert moved > 1e-3
         for k in extra["kfs"]:
             if k.mnId not in ref["kf_pose"]:
