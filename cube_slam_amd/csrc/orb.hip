@@ -57,10 +57,17 @@ __device__ const int d_pattern[1024] = {
 // descriptor -> tables -> pixels) with a handful of instructions in between, and the launch was bound by that latency (95 us for
 // the 27 Mpixel level 1, 12x its memory time).  Products are 24-bit multiplies (pixel < 2^8, coefficients <= 2^11, r >> 4 < 2^15): a
 // plain int product is v_mul_lo_u32, a quarter-rate instruction.  Same integer arithmetic as cv::resize's 8-bit fixed-point path.
-constexpr int RS_ROWS = 8;
-__global__ void __launch_bounds__(256) orb_resize(Pyr P, int level, uint8_t *pyr, const int *xofs, const short *ialpha, const int *yofs, const short *ibeta) {
+#ifndef ORB_RS_ROWS
+#define ORB_RS_ROWS 8
+#endif
+constexpr int RS_ROWS = ORB_RS_ROWS;
+__global__ void __launch_bounds__(256) orb_resize(Pyr P, int level, uint8_t *__restrict__ pyr, const int *__restrict__ xofs, const short *__restrict__ ialpha, const int *__restrict__ yofs, const short *__restrict__ ibeta) {
     const Lvl &D = P.l[level], &S = P.l[level - 1];
-    const int dx = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, dy0 = (blockIdx.y * 4 + (threadIdx.x >> 6)) * RS_ROWS;
+    // a wave works on ONE group of rows: said so to the compiler, the row tables (yofs, ibeta) and the row base addresses are scalar loads / registers and the pixel
+    // windows of all rows leave as one burst of vector loads instead of a load-wait chain per row (level 1 of 1 024 frames: 485 -> 371 us).  The kernel is bound by the
+    // instructions its waves issue, whatever their lanes do: measured and dropped -- sixteen rows per thread (464 us), the row's last narrow tile folded into the previous
+    // tile's lanes (492) or packed four row groups to a wave (312, but every other level slower through the second copy of the body)
+    const int dx = (blockIdx.x * 64 + (threadIdx.x & 63)) * 4, dy0 = (blockIdx.y * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6)) * RS_ROWS;
     if (dx >= D.w || dy0 >= D.h) return;
     uint8_t *base = pyr + (long)blockIdx.z * P.frame_stride;
     const uint8_t *src = base + S.off;
@@ -69,7 +76,8 @@ __global__ void __launch_bounds__(256) orb_resize(Pyr P, int level, uint8_t *pyr
 #pragma unroll
     for (int c = 0; c < 4; c++) {
         const int x = min(dx + c, D.w - 1);
-        sx[c] = xofs[D.tab_x + x]; a0[c] = ialpha[(D.tab_x + x) * 2]; a1[c] = ialpha[(D.tab_x + x) * 2 + 1];
+        const int aa = reinterpret_cast<const int *>(ialpha)[D.tab_x + x]; // the coefficient pair of a column as one dword
+        sx[c] = xofs[D.tab_x + x]; a0[c] = (short)(aa & 0xffff); a1[c] = aa >> 16;
     }
     const bool fast = dx + 3 < D.w && sx[3] - sx[0] <= 4 && sx[0] + 7 < S.w; // one 8-byte window per source row, always inside the row
     if (fast) {
@@ -78,7 +86,8 @@ __global__ void __launch_bounds__(256) orb_resize(Pyr P, int level, uint8_t *pyr
         for (int r = 0; r < RS_ROWS; r++) {
             const int dy = min(dy0 + r, D.h - 1);
             const int sy = yofs[D.tab_y + dy], sy1 = min(sy + 1, S.h - 1);
-            b0[r] = ibeta[(D.tab_y + dy) * 2]; b1[r] = ibeta[(D.tab_y + dy) * 2 + 1];
+            const int bb = reinterpret_cast<const int *>(ibeta)[D.tab_y + dy]; // (uniform over the wave: a scalar load)
+            b0[r] = (short)(bb & 0xffff); b1[r] = bb >> 16;
             const uint8_t *row0 = src + (long)sy * S.w + sx[0], *row1 = src + (long)sy1 * S.w + sx[0];
             lo0[r] = load_u32_unaligned(row0); hi0[r] = load_u32_unaligned(row0 + 4);
             lo1[r] = load_u32_unaligned(row1); hi1[r] = load_u32_unaligned(row1 + 4);
@@ -1098,9 +1107,10 @@ int cs_orb_run(cs_ctx *ctx, cs_orb *e) {
     const Pyr &P = e->P;
     const int F = e->n_frames, NL = P.nlevels;
     // ---- GPU phase A: pyramid, FAST score map, per-cell NMS + ordered compaction
-    for (int l = 1; l < NL; l++)
+    for (int l = 1; l < NL; l++) {
         CS_LAUNCH(ctx, "orb_resize", orb_resize, dim3((P.l[l].w + 255) / 256, (P.l[l].h + 4 * RS_ROWS - 1) / (4 * RS_ROWS), F), dim3(256), 0, P, l, e->d_pyr, e->d_xofs, e->d_ialpha,
                   e->d_yofs, e->d_ibeta);
+    }
     CS_HIP(ctx, hipMemsetAsync(e->d_smap, 0, (size_t)P.frame_stride * F, ctx->stream)); // orb_fast_score only writes scores above the threshold
     CS_LAUNCH(ctx, "orb_fast_score", orb_fast_score, dim3(e->max_tiles, NL, F), dim3(256), 0, P, e->d_pyr, e->d_smap);
     CS_LAUNCH(ctx, "orb_cells", orb_cells, dim3((P.cells_per_frame + CELLS_PER_WG - 1) / CELLS_PER_WG, F), dim3(64 * CELLS_PER_WG), 0, P, e->d_smap, 0, e->d_cell_count, e->d_cell_base, e->d_cand, e->d_cell_mask);
