@@ -263,6 +263,37 @@ def c3_bench(ctx, frames, steps, with_cpu):
         out["roofline"] = {"bound": "hbm", "kernel": "match_candidates", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
                            "avg_kernel_us": us, "algorithmic_bytes_per_launch": alg, "queries_per_launch": cstat["queries"], "candidates_per_launch": cstat["candidates"],
                            "note": "one launch per frame (2000 queries): launch-latency-bound at this size; batching frames is what the stream forbids"}
+    # The kernel at the size TrackLocalMap gives it: ORBmatcher::SearchByProjection(F, vpMapPoints, th) (ORBmatcher.cc:50-142) with a local map of 10 000 points in view
+    # of one frame -- the key points of five frames of the stream stand in for the map points (projections, descriptors, predicted levels) -- one launch, no frame loop.
+    try:
+        per = orb.read()
+        take = [per[f] for f in range(min(5, frames))]
+        pk = np.concatenate([k for k, _ in take]); pd = np.concatenate([dd for _, dd in take])
+        rng = np.random.default_rng(5)
+        proj = np.stack([pk["x"] + rng.normal(0, 1.0, len(pk)), pk["y"] + rng.normal(0, 1.0, len(pk))], axis=1).astype(np.float32)
+        ones = np.ones(len(pk), np.uint8)
+        mm = ORBmatcher(0.8, True, ctx=ctx, max_queries=16384)
+        mm.set_frame_from_orb(orb, min(5, frames - 1), K4, None, bounds)
+        vc = np.full(len(pk), 0.999, np.float32)
+        mm.SearchByProjectionLocalMap(proj, vc, pk["octave"], ones, ones, pd, sf, 3.0)
+        ctx.sync(); ctx.timing(True); ctx.timing_reset()
+        reps = 20
+        for _ in range(reps):
+            _, n_lm = mm.SearchByProjectionLocalMap(proj, vc, pk["octave"], ones, ones, pd, sf, 3.0)
+        ctx.sync()
+        lm_ms, lm_n = ctx.timing_get("match_candidates")
+        ctx.timing(False)
+        st_lm = mm.last_candidate_stats()
+        if lm_n and st_lm is not None:
+            alg_lm = 40.0 * st_lm["queries"] + 32.0 * st_lm["candidates"]
+            us_lm = 1e3 * lm_ms / lm_n
+            out["local_map"] = {"what": "SearchByProjection(F, 10^4 map points, th 3): one launch", "map_points": int(len(pk)), "matches": int(n_lm), "queries_per_launch": st_lm["queries"],
+                                "candidates_per_launch": st_lm["candidates"], "match_candidates_us": us_lm, "algorithmic_bytes_per_launch": alg_lm,
+                                "achieved_GBps": alg_lm / (us_lm * 1e-6) / 1e9, "frac": alg_lm / (us_lm * 1e-6) / 1e9 / HBM_PEAK_GBS,
+                                "note": "five times the queries of the per-frame search for a fifth more time: the launch is latency-bound at every size the tracking thread produces"}
+        mm.close()
+    except Exception as e:  # the stream measurement above stands on its own
+        out["local_map"] = {"error": str(e)[:200]}
     if with_cpu:
         from oracle import pyoracle as po
         ext = po.ORBextractor(2000, 1.2, 8, 20, 7)
