@@ -52,8 +52,10 @@ def test_lm_trajectory(ctx, oracle, kw):
     rcam, rpts, rcub, rst = oracle.ba_optimize(d, 10)
     assert st["iterations"] == rst["iterations"] and st["lm_trials"] == rst["lm_trials"]
     # g2o differentiates the cuboid edges numerically with delta = 1e-9: a 1-ulp difference of the state (device vs host
-    # sin/cos/pow) becomes ~1e-7 relative noise in those Jacobians, which wobbles the intermediate iterates (observed up to
-    # 2e-5) before both runs settle on the same minimum; without cuboid edges the traces agree to 1e-12.
+    # sin/cos, or simply the reduced system factored in another order) becomes ~1e-7 relative noise in those Jacobians, which
+    # wobbles the intermediate iterates (observed up to 2e-5) before both runs settle on the same minimum; without cuboid edges
+    # the traces agree to 1e-12.  The reference does the same to itself: its own function text moves its results by 3e-6 when
+    # only the order of its edges changes (tests/test_ref_graph_pins.py).
     assert np.allclose(st["chi2_trace"], rst["chi2_trace"], rtol=(1e-4 if kw["n_cuboids"] else 1e-9))
     assert abs(st["chi2_final"] - rst["chi2_final"]) <= REL * rst["chi2_final"]
     assert st["chi2_final"] < 0.1 * st["chi2_init"]
