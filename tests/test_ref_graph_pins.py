@@ -385,3 +385,39 @@ def test_local_ba_dynamic_equals_reference(seed):
         assert sorted(m.mnId for m in G.mps if G.mp_dynamic(m)["bad"]) == sorted(ref["set_bad"])
     finally:
         G.close()
+
+
+def test_local_ba_again_on_its_own_result_equals_reference():
+    """The window after a local BA, optimised again (and again): the second stage stops early (three or four iterations), a few more observations cross the
+    thresholds.  The oracle's early stops and its outlier classification (pin D4 of DESIGN.md: it reads the residuals at the accepted estimate, g2o the edges'
+    stored errors) stay on the reference's: the same observations erased, round after round."""
+    cur, params, extra = local_map.build(1)
+    rg.quantize(cur, params, extra)
+    early = 0
+    for rnd in range(3):
+        ref = lo.local_ba_camera_point_objects(cur, params)
+        G = rg.Graph(cur, params, extra)
+        try:
+            G.local_ba_objects(cur)
+            assert sorted(G.erased()) == sorted(ref["erase"]), rnd
+            kid = {k.mnId: k for k in extra["kfs"]}
+            for mn, pose in ref["kf_pose"].items():
+                assert _pose_close(G.kf_pose(kid[mn])[0], rg.cvmat_from_pose(pose)), (rnd, mn)
+        finally:
+            G.close()
+        early += int(ref["stats"][1]["iterations"] < 10)
+        # the result becomes the next round's window
+        mid = {m.mnId: m for m in extra["mps"]}; oid = {o.mnId: o for o in extra["mos"]}
+        for mn, p in ref["kf_pose"].items():
+            kid[mn].Tcw = p
+        un = set(ref["point_unwritten"])
+        for mn, p in ref["point_pos"].items():
+            if mn not in un:
+                mid[mn].pos = p
+        for mn, p in ref["object_pose"].items():
+            oid[mn].pose = p
+        for kfid, mpid in ref["erase"]:
+            k, m = kid[kfid], mid[mpid]
+            k.map_point_matches[m.observations.pop(k)] = None
+        rg.quantize(cur, params, extra)
+    assert early >= 1, "a later round ends its second stage before the tenth iteration"
