@@ -95,7 +95,7 @@ def test_optimizer_adapter_local_ba_equals_the_reference(seed):
         for k in extra["kfs"]:
             Tr, nr, _ = Gr.kf_pose(k); Ta, na, _ = Ga.kf_pose(k)
             assert na == nr and Ga.kf_markers(k) == Gr.kf_markers(k)   # (a bad covisible key frame keeps its mnBALocalForKF mark in the reference: it is in no list that is reset)
-            assert np.abs(Tr[:3, :3] - Ta[:3, :3]).max() <= 2e-6 and np.abs(Tr[:3, 3] - Ta[:3, 3]).max() <= 2e-6 * max(1.0, float(np.abs(Tr[:3, 3]).max())), k.mnId
+            assert np.abs(Tr[:3, :3] - Ta[:3, :3]).max() <= 5e-6 and np.abs(Tr[:3, 3] - Ta[:3, 3]).max() <= 5e-6 * max(1.0, float(np.abs(Tr[:3, 3]).max())), k.mnId
             moved = max(moved, float(np.abs(Ta - k.T_f32).max()))
         assert moved > 1e-3
         n_unwritten = 0

