@@ -186,3 +186,32 @@ def test_detect_cuboid_adapter_equals_reference_class(libs, oracle, mode):
                 total += 1
         assert np.isfinite(euler).all()
     assert total >= (3 if mode == "rollpitch_one_box" else (9 if mode != "top3" else 20)), total
+
+
+def test_optimizer_adapter_honours_a_raised_stop_flag_like_the_reference():
+    """*pbStopFlag already true: the reference builds its graph and returns before optimising (Optimizer.cc:1386-1388) -- nothing is written, nothing erased, the marker
+    fields stay as the gathering left them; the adapter returns at the same place."""
+    rg, A = _adapter_graph()
+    from tests import local_map
+    cur, params, extra = local_map.build(1)
+    rg.quantize(cur, params, extra)
+    Gr, Ga = rg.Graph(cur, params, extra), rg.Graph(cur, params, extra)
+    try:
+        stop = C.c_bool(True)
+        Gr.L.ref_graph_local_ba_objects(Gr.h, Gr.kf[id(cur)], 0, 0, C.byref(stop))
+        A.adp_graph_set_params(1, 0, C.c_double(params["camera_object_BA_weight"]))
+        err = C.create_string_buffer(512)
+        assert A.adp_graph_local_ba_objects(Ga.h, Ga.kf[id(cur)], 0, C.byref(stop), err, 512) == 0, err.value
+        assert Gr.erased() == [] and Ga.erased() == []
+        marked = 0
+        for k in extra["kfs"]:
+            assert Gr.kf_pose(k)[1] == 0 and Ga.kf_pose(k)[1] == 0
+            assert Ga.kf_markers(k) == Gr.kf_markers(k)
+            marked += int(Gr.kf_markers(k) != (0, 0))
+        assert marked >= 5, "local and fixed key frames keep their marks when the function returns early"
+        for m in Gr.mps:
+            assert Gr.mp_pos(m)[1] == 0 and Ga.mp_pos(m)[1] == 0
+        for o in extra["mos"]:
+            assert Gr.mo_state(o)["writes"] == 0 and Ga.mo_state(o)["writes"] == 0
+    finally:
+        Gr.close(); Ga.close()
