@@ -91,6 +91,7 @@ void detect_3d_cuboid::detect_cuboid(const cv::Mat &rgb_img, const Eigen::Matrix
         }
     if (whether_save_final_images) cuboids_2d_img = frame_all_cubes_img; // :548-549
     if (whether_plot_final_images) { cv::imshow("frame_all_cubes_img", frame_all_cubes_img); cv::waitKey(0); } // :550-554
-    // roll / pitch sampling leaves the sampled pose of the LAST box in cam_pose in the reference (:237, :485; pin D1 of DESIGN.md): the
-    // caller-visible cam_pose here is the raw pose, which is what main_obj.cpp uses (it reads cam_pose_raw)
+    // roll / pitch sampling leaves the sampled pose of the LAST box in cam_pose in the reference (:237, :485; pin D1 of DESIGN.md).  Inside the call the library
+    // chains the boxes through that pose like the reference does (cs_cuboid_detect); the caller-visible cam_pose here is the raw pose, which is what main_obj.cpp
+    // uses (it reads cam_pose_raw)
 }

@@ -55,6 +55,7 @@ struct Calib { double K[9]; double invK[9]; };
 
 struct FrameInfo {   // host-filled
     double euler[3]; // raw camera roll/pitch/yaw (quat_to_euler_zyx(Quaterniond(R)), computed with the host libm)
+    double yaw_src;  // cam_pose.camera_yaw as box_proposal_detail.cpp:126 reads it: the raw yaw, or (cs_cuboid_detect's box-to-box chain, D1) what the previous box left in cam_pose
     double T[16];
     int line_off, n_lines;
 };
@@ -197,7 +198,7 @@ __global__ void __launch_bounds__(64) cuboid_frame_prep(const FrameInfo *fi, Fra
         } else {
             D.n_roll = 1; D.n_pitch = 1; D.roll[0] = F.euler[0]; D.pitch[0] = F.euler[1];
         }
-        double yaw_init = F.euler[2] - 90.0 / 180.0 * PI; // :126 (pinned to the raw pose for every box)
+        double yaw_init = F.yaw_src - 90.0 / 180.0 * PI; // :126 (the raw yaw for every box of a batch; cs_cuboid_detect chains the boxes of its frame like the reference)
         D.n_yaw = linespace_dev(yaw_init - o.yaw_range_deg / 180.0 * PI, yaw_init + o.yaw_range_deg / 180.0 * PI,
                                 o.yaw_step_deg / 180.0 * PI, yaw + (long)f * o.yaw_cap, o.yaw_cap);
     }
@@ -1477,8 +1478,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SELECT
                                                      const FrameInfo *fi, const CamRP *cam, const double *yaw, Calib cal, Opts o,
                                                      uint8_t *flag, const double *derr, const double *aerr, const VPEntry *vpt,
                                                      double *score, double *nscore, unsigned long long *ckey_d, unsigned long long *ckey_a,
-                                                     int *cidx, cs_cuboid *out, int *counts) {
+                                                     int *cidx, cs_cuboid *out, int *counts, int *carry_rp) {
     __shared__ int hist[256];
+    __shared__ int s_last; // entry (rank among the valid proposals) of the proposal the reference's loop :479-546 processes last
     __shared__ int s_misc[8];
     __shared__ int s_wave[8];
     __shared__ double s_red[4][4];
@@ -1510,6 +1512,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SELECT
 #pragma unroll
         for (int k = 0; k < SEL_R; k++) { int e = tid + 256 * k; kd.v[k] = e < n ? ckd[e] : 0; ka.v[k] = e < n ? cka[e] : 0; }
         int branch_b = 0, n_kept = 0;
+        if (tid == 0) s_last = n - 1; // n <= 4: all of them, in index order
         if (n > 4) {
             int breaking_num = (int)round(float(n) / 3.0 * 2.0);
             int k = breaking_num - 1; // elements kept per criterion
@@ -1549,10 +1552,30 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SELECT
                 if (use_angle) ok = ok && cka[e] <= va;
                 if (ok) fl[ch[e]] |= 4;
             }
+            if (hs == n_hs - 1) { // the last entry of final_keep_inds: the largest index of the intersection, or the last of the (distance, index) order
+                __syncthreads();
+                if (tid == 0) s_last = -1;
+                __syncthreads();
+                int mine = -1;
+                for (int e = tid; e < n; e += 256) {
+                    const bool kept = (ckd[e] < vd || (ckd[e] == vd && e <= e_star)) && (!use_angle || cka[e] <= va);
+                    if (kept && (use_angle || ckd[e] == vd)) mine = e; // (ascending e per thread: the last one stays)
+                }
+                if (mine >= 0) atomicMax(&s_last, mine);
+                __syncthreads();
+            }
         } else {
             for (int e = tid; e < n; e += 256) fl[ch[e]] |= 4;
         }
         __syncthreads();
+        if (hs == n_hs - 1 && carry_rp) { // what cam_pose holds after this box: the roll / pitch sample of the last good proposal (:481-487), or of the last loop pass (:233-239)
+            __syncthreads();
+            if (tid == 0) {
+                int rp = n_rp - 1;
+                if (n > 0 && s_last >= 0) { int q, ti; hyp_decode(U, ch[s_last], q, ti); rp = q / D.n_yaw; }
+                carry_rp[box] = rp;
+            }
+        }
         // min / max over the kept set
         double mn_d = 1e6, mx_d = -1, mn_a = 1e6, mx_a = -1;
         int cntk = 0;
@@ -1780,7 +1803,7 @@ struct cs_cuboid_batch {
     int dt_C = 0; // wave-per-ROI distance transform: int map between the passes, lane-major
     FrameInfo *d_fi = nullptr; FrameDyn *d_fd = nullptr; CamRP *d_cam = nullptr;
     double *d_yaw = nullptr, *d_lines_in = nullptr, *d_lines_al = nullptr, *d_mlines = nullptr, *d_mangle = nullptr, *d_mmid = nullptr;
-    Unit *d_units = nullptr; UnitDyn *d_ud = nullptr; int *d_box_first = nullptr, *d_status = nullptr, *d_counts = nullptr;
+    Unit *d_units = nullptr; UnitDyn *d_ud = nullptr; int *d_box_first = nullptr, *d_status = nullptr, *d_counts = nullptr, *d_carry = nullptr;
     VPEntry *d_vp = nullptr;
     int *d_vcount = nullptr, *d_vlist = nullptr; // per unit: number of surviving proposals and their hypothesis indices
     double *d_derr = nullptr, *d_aerr = nullptr, *d_score = nullptr, *d_nscore = nullptr;
@@ -1802,7 +1825,7 @@ void cs_cuboid_batch_destroy(cs_ctx *ctx, cs_cuboid_batch *b) {
     if (!b) return;
     if (ctx) { hipSetDevice(ctx->device); hipStreamSynchronize(ctx->stream); }
     void *ptrs[] = {b->d_gray, b->d_emap, b->d_flag, b->d_dist, b->d_dttmp, b->d_dttmp_off, b->d_fi, b->d_fd, b->d_cam, b->d_yaw, b->d_lines_in, b->d_lines_al,
-                    b->d_mlines, b->d_mangle, b->d_mmid, b->d_units, b->d_ud, b->d_box_first, b->d_status, b->d_counts, b->d_vp,
+                    b->d_mlines, b->d_mangle, b->d_mmid, b->d_units, b->d_ud, b->d_box_first, b->d_status, b->d_counts, b->d_carry, b->d_vp,
                     b->d_derr, b->d_aerr, b->d_score, b->d_nscore, b->d_ckd, b->d_cka, b->d_cidx, b->d_out, b->d_vcount, b->d_vlist, b->d_order, b->d_cursor, b->d_uflag, b->d_prof};
     for (void *p : ptrs) cs_dfree(ctx, p);
     delete b;
@@ -1840,6 +1863,7 @@ int cs_cuboid_batch_create(cs_ctx *ctx, int n_frames, int width, int height, con
     for (int f = 0; f < n_frames; f++) {
         for (int i = 0; i < 16; i++) fi[f].T[i] = Twc[(long)f * 16 + i];
         host_euler_from_T(fi[f].T, fi[f].euler);
+        fi[f].yaw_src = fi[f].euler[2];
         fi[f].line_off = line_offsets[f]; fi[f].n_lines = line_offsets[f + 1] - line_offsets[f];
     }
     const int rp_cap = o.sample_rp ? 25 : 1; // 5x5 at most (linespace +-6 deg step 3 deg gives 4 or 5 per axis)
@@ -1969,6 +1993,7 @@ int cs_cuboid_batch_create(cs_ctx *ctx, int n_frames, int width, int height, con
     A_(cs_dalloc(ctx, &b->d_box_first, (size_t)n_boxes));
     A_(cs_dalloc(ctx, &b->d_status, (size_t)1));
     A_(cs_dalloc(ctx, &b->d_counts, (size_t)n_boxes));
+    A_(cs_dalloc(ctx, &b->d_carry, (size_t)n_boxes));
     A_(cs_dalloc(ctx, &b->d_vp, (size_t)b->vp_total));
     A_(cs_dalloc(ctx, &b->d_flag, (size_t)b->hyp_total));
     A_(cs_dalloc(ctx, &b->d_vcount, (size_t)std::max<size_t>(1, 2 * b->units.size())));
@@ -2090,7 +2115,7 @@ int cs_cuboid_batch_run(cs_ctx *ctx, cs_cuboid_batch *b) {
     }
     CS_LAUNCH(ctx, "cuboid_select", cuboid_select, dim3(b->n_boxes), dim3(256), 0, b->d_units, b->d_ud, b->d_box_first, b->d_fd, b->d_fi,
               b->d_cam, b->d_yaw, b->cal, b->o, b->d_flag, b->d_derr, b->d_aerr, b->d_vp, b->d_score, b->d_nscore,
-              b->d_ckd, b->d_cka, b->d_cidx, b->d_out, b->d_counts);
+              b->d_ckd, b->d_cka, b->d_cidx, b->d_out, b->d_counts, b->d_carry);
     CS_HIP(ctx, hipGetLastError());
     return CS_OK;
 }
@@ -2234,17 +2259,49 @@ int cs_cuboid_detect(cs_ctx *ctx, const uint8_t *img, int width, int height, int
         if (e == hipSuccess) e = es;
         if (e != hipSuccess) { ctx->err = hipGetErrorString(e); return CS_ERR_HIP; }
     }
-    int bo[2] = {0, n_boxes}, lo[2] = {0, n_lines};
-    cs_cuboid_batch *b = nullptr;
+    int lo[2] = {0, n_lines};
     double dummy[4] = {0, 0, 0, 0};
-    // the frame's batch is built from (and dropped back into) the context's block pool: a camera stream asks for the same sizes frame after frame
-    ctx->pooling = true;
-    int r = cs_cuboid_batch_create(ctx, 1, width, height, gray.data(), K, Twc, bo, boxes, lo, n_lines ? lines : dummy, opts, &b);
-    ctx->pooling = false;
-    if (r != CS_OK) return r;
-    r = cs_cuboid_batch_run(ctx, b);
-    if (r == CS_OK) r = cs_cuboid_batch_read(ctx, b, out, counts);
-    cs_cuboid_batch_destroy(ctx, b);
+    // The reference reads cam_pose.camera_yaw at :126 and, while it samples camera roll / pitch, leaves in cam_pose the pose of the last proposal it turned into a cuboid
+    // (:481-487; of the last loop pass :233-239 when there was none): box b + 1 of a frame starts its yaw samples from what box b left (pin D1 of DESIGN.md:
+    // object_slam/src/main_obj.cpp:442 samples on every frame but the first).  A frame's boxes are therefore chained here, one after the other; without sampling, or with one
+    // box, they go as one batch.
+    const bool chained = opts->whether_sample_cam_roll_pitch && n_boxes > 1;
+    int r = CS_OK;
+    double yaw_src = 0; bool have_src = false;
+    for (int first = 0; first < n_boxes && r == CS_OK; first += chained ? 1 : n_boxes) {
+        const int nb = chained ? 1 : n_boxes;
+        int bo[2] = {0, nb};
+        cs_cuboid_batch *b = nullptr;
+        // the frame's batch is built from (and dropped back into) the context's block pool: a camera stream asks for the same sizes frame after frame
+        ctx->pooling = true;
+        r = cs_cuboid_batch_create(ctx, 1, width, height, gray.data(), K, Twc, bo, boxes + (size_t)first * 5, lo, n_lines ? lines : dummy, opts, &b);
+        ctx->pooling = false;
+        if (r != CS_OK) return r;
+        if (have_src) { // what the previous box left in cam_pose
+            b->fi[0].yaw_src = yaw_src;
+            r = cs_h2d(ctx, b->d_fi, b->fi.data(), 1);
+        }
+        if (r == CS_OK) r = cs_cuboid_batch_run(ctx, b);
+        if (r == CS_OK) r = cs_cuboid_batch_read(ctx, b, out + (size_t)first * opts->max_cuboid_num, counts + first);
+        if (r == CS_OK && chained && first + 1 < n_boxes) {
+            int rp = 0; FrameDyn fdh;
+            r = cs_d2h(ctx, &rp, b->d_carry, 1);
+            if (r == CS_OK) r = cs_d2h(ctx, &fdh, b->d_fd, 1);
+            if (r == CS_OK) {
+                CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                const double roll = fdh.roll[rp / fdh.n_pitch], pitch = fdh.pitch[rp % fdh.n_pitch], yw = b->fi[0].euler[2];
+                // euler_zyx_to_rot (matrix_utils.cpp:74-89) with the host libm, then set_cam_pose's way back to the yaw (:45-48)
+                const double cp = std::cos(pitch), sp = std::sin(pitch), sr = std::sin(roll), cr = std::cos(roll), sy = std::sin(yw), cy = std::cos(yw);
+                double Tn[16] = {0}, e3[3];
+                Tn[0] = cp * cy; Tn[1] = (sr * sp * cy) - (cr * sy); Tn[2] = (cr * sp * cy) + (sr * sy);
+                Tn[4] = cp * sy; Tn[5] = (sr * sp * sy) + (cr * cy); Tn[6] = (cr * sp * sy) - (sr * cy);
+                Tn[8] = -sp;     Tn[9] = sr * cp;                    Tn[10] = cr * cp;
+                host_euler_from_T(Tn, e3);
+                yaw_src = e3[2]; have_src = true;
+            }
+        }
+        cs_cuboid_batch_destroy(ctx, b);
+    }
     return r;
 }
 

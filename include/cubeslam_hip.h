@@ -112,6 +112,9 @@ void cs_cuboid_default_opts(cs_cuboid_opts *opts);
  *   lines    : n_lines x 4  [x1 y1 x2 y2] (all_lines_raw; copied, like the by-value MatrixXd of the reference)
  *   out      : n_boxes * max_cuboid_num records; box b's cuboids are out[b*max_cuboid_num + i], i < counts[b],
  *              sorted by combined score (ObjectSet order, box_proposal_detail.cpp:517-536)
+ * With whether_sample_cam_roll_pitch and more than one box the boxes are taken one after the other, like the reference's loop
+ * over objects: box b + 1 reads the camera yaw that box b left in cam_pose (box_proposal_detail.cpp:126 after :233-239 /
+ * :481-487) -- the configuration of object_slam/src/main_obj.cpp:442.  A cs_cuboid_batch starts every box from the raw pose.
  */
 int cs_cuboid_detect(cs_ctx *ctx, const uint8_t *img, int width, int height, int channels, int stride,
                      const double *K, const double *Twc, const double *boxes, int n_boxes,

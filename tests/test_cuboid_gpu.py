@@ -194,3 +194,27 @@ def test_set_lines_equals_a_fresh_batch(ctx):
         for a, c in zip(got, ref):
             assert len(a) == len(c) and np.array_equal(np.asarray(a).view(np.uint8), np.asarray(c).view(np.uint8))
     b.close()
+
+
+@pytest.mark.parametrize("seed,kw", [(1, {}), (19, {}), (36, {"max_cuboid_num": 3}), (7, {"whether_sample_bbox_height": True})])
+def test_per_frame_call_chains_the_boxes_like_the_reference(ctx, oracle, seed, kw):
+    """cs_cuboid_detect with camera roll / pitch sampling and several boxes: box b + 1 starts its yaw samples from the camera pose box b left behind (the pose of the
+    last proposal it turned into a cuboid, box_proposal_detail.cpp:126 after :481-487 -- the configuration of object_slam/src/main_obj.cpp:442).  Against the oracle in
+    its stateful mode, which is held to the reference's own text (tests/test_ref_pins.py::test_detect_cuboid_equals_reference[rollpitch])."""
+    det = detect_3d_cuboid(ctx)
+    det.whether_sample_cam_roll_pitch = True
+    for k, v in kw.items():
+        setattr(det, k, v)
+    s = synth.cuboid_scene(seed, n_boxes=3, bg_texture=0.5 if seed == 9 else 0.0)
+    assert len(s["boxes"]) >= 2
+    det.set_calibration(s["K"])
+    got = det.detect_cuboid(s["gray"], s["Twc"], s["boxes"], s["lines"])
+    oo = _oracle_opts(oracle, det)
+    oo.stateful_cam_pose = 1
+    ref, _ = oracle.detect_cuboid(s["gray"], s["K"], s["Twc"], s["boxes"], s["lines"], opts=oo)
+    _cmp_cuboids(got, ref)
+    assert sum(len(g) for g in got) >= 3
+    if seed in (1, 19, 36):   # frames on which the chain changes a later box: the stateless variant (every box from the raw pose, what a batch computes) gives something else
+        oo.stateful_cam_pose = 0
+        other, _ = oracle.detect_cuboid(s["gray"], s["K"], s["Twc"], s["boxes"], s["lines"], opts=oo)
+        assert any(len(a) != len(b) or any(not np.array_equal(a[f], b[f]) for f in a.dtype.names) for a, b in zip(ref, other))
