@@ -1552,7 +1552,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SELECT
                 if (use_angle) ok = ok && cka[e] <= va;
                 if (ok) fl[ch[e]] |= 4;
             }
-            if (hs == n_hs - 1) { // the last entry of final_keep_inds: the largest index of the intersection, or the last of the (distance, index) order
+            if (hs == n_hs - 1 && carry_rp) { // (only for cs_cuboid_detect's chain) the last entry of final_keep_inds: the largest index of the intersection, or the last of the (distance, index) order
                 __syncthreads();
                 if (tid == 0) s_last = -1;
                 __syncthreads();
@@ -1804,6 +1804,7 @@ struct cs_cuboid_batch {
     FrameInfo *d_fi = nullptr; FrameDyn *d_fd = nullptr; CamRP *d_cam = nullptr;
     double *d_yaw = nullptr, *d_lines_in = nullptr, *d_lines_al = nullptr, *d_mlines = nullptr, *d_mangle = nullptr, *d_mmid = nullptr;
     Unit *d_units = nullptr; UnitDyn *d_ud = nullptr; int *d_box_first = nullptr, *d_status = nullptr, *d_counts = nullptr, *d_carry = nullptr;
+    bool want_carry = false; // cs_cuboid_detect's box-to-box chain asks cuboid_select which roll / pitch sample the last kept proposal carries
     VPEntry *d_vp = nullptr;
     int *d_vcount = nullptr, *d_vlist = nullptr; // per unit: number of surviving proposals and their hypothesis indices
     double *d_derr = nullptr, *d_aerr = nullptr, *d_score = nullptr, *d_nscore = nullptr;
@@ -2115,7 +2116,7 @@ int cs_cuboid_batch_run(cs_ctx *ctx, cs_cuboid_batch *b) {
     }
     CS_LAUNCH(ctx, "cuboid_select", cuboid_select, dim3(b->n_boxes), dim3(256), 0, b->d_units, b->d_ud, b->d_box_first, b->d_fd, b->d_fi,
               b->d_cam, b->d_yaw, b->cal, b->o, b->d_flag, b->d_derr, b->d_aerr, b->d_vp, b->d_score, b->d_nscore,
-              b->d_ckd, b->d_cka, b->d_cidx, b->d_out, b->d_counts, b->d_carry);
+              b->d_ckd, b->d_cka, b->d_cidx, b->d_out, b->d_counts, b->want_carry ? b->d_carry : nullptr);
     CS_HIP(ctx, hipGetLastError());
     return CS_OK;
 }
@@ -2277,6 +2278,7 @@ int cs_cuboid_detect(cs_ctx *ctx, const uint8_t *img, int width, int height, int
         r = cs_cuboid_batch_create(ctx, 1, width, height, gray.data(), K, Twc, bo, boxes + (size_t)first * 5, lo, n_lines ? lines : dummy, opts, &b);
         ctx->pooling = false;
         if (r != CS_OK) return r;
+        b->want_carry = chained;
         if (have_src) { // what the previous box left in cam_pose
             b->fi[0].yaw_src = yaw_src;
             r = cs_h2d(ctx, b->d_fi, b->fi.data(), 1);
