@@ -61,4 +61,24 @@ GS_FN float sinf_(float y) {
     const double s = ((n & 3) == 1 || (n & 3) == 2) ? -1.0 : 1.0;
     return poly(x * s, x * x, n, (n & 2) != 0);
 }
+// cosf_(y) and sinf_(y) together and without branches, for 0 <= y < 120 (the level-line angles are in [0, 2 pi]): the fast reduction also covers
+// |y| < pi / 4 (there n = 0 and x is unchanged) and the tiny arguments (the polynomials round to 1.0f and to y there); the two polynomials are
+// evaluated once and dealt to the two results by the quadrant, the negated coefficient table is the negated result (rounding is symmetric).
+// Equal to cosf_ / sinf_ -- and so to glibc -- on every float of [0, 6.3]: tests/cpp/sincosf_check.cpp.
+GS_FN void sincosf_pos(float y, float *sn, float *cs) {
+    const double c0 = 0x1p0, c1 = -0x1.ffffffd0c621cp-2, c2 = 0x1.55553e1068f19p-5, c3 = -0x1.6c087e89a359dp-10, c4 = 0x1.99343027bf8c3p-16;
+    const double s1 = -0x1.555545995a603p-3, s2 = 0x1.1107605230bc4p-7, s3 = -0x1.994eb3774cf24p-13;
+    const double hpi_inv = 0x1.45F306DC9C883p+23, hpi = 0x1.921FB54442D18p0;
+    const double x0 = y;
+    const int n = ((int32_t)(x0 * hpi_inv) + 0x800000) >> 24;
+    const double xr = x0 - n * hpi;
+    const bool flip = (n & 3) == 1 || (n & 3) == 2, neg = (n & 2) != 0;
+    const double x = flip ? -xr : xr, x2 = xr * xr; // (x * s with s = +-1; x * x)
+    const double x3 = x * x2, ts = s2 + x2 * s3, x5 = x3 * x2, ss = x + x3 * s1;
+    const float A = (float)(ss + x5 * ts); // the sine polynomial
+    const double x4 = x2 * x2, t2 = c3 + x2 * c4, t1 = c0 + x2 * c1, x6 = x4 * x2, cc = t1 + x4 * c2;
+    const float Bp = (float)(cc + x6 * t2), B = neg ? -Bp : Bp; // the cosine polynomial
+    *sn = (n & 1) ? B : A;
+    *cs = (n & 1) ? A : B;
+}
 } // namespace glibc_sincosf

@@ -631,17 +631,20 @@ static int lsd_run(cs_ctx *ctx, cs_lsd *l, int with_lbd) {
         r = cs_dalloc(ctx, &l->d_cmod, cap); if (r) return r;
         l->ccap = cap;
     }
-    // region growing / rectangles / NFA (a15): two interchangeable stages with byte-identical KeyLines (tests/test_lsd_gpu.py).
-    //   seq    one wave per frame walks the reference's sequence on the device (lsd_regions.hip / lsd_rg_seq.h).  A frame takes 100-180 ms whatever
-    //          the batch, so it pays from ~500 frames per batch on (2048 resident frames: 2.5 x the 16 host threads) -- the default from 512 on;
+    // region growing / rectangles / NFA (a15): interchangeable stages with byte-identical KeyLines (tests/test_lsd_gpu.py).
+    //   grp    eight frames per wave walk the reference's sequence on the device (lsd_regions.hip / lsd_rg_grp.h): 128 waves per 1024 frames, packed onto a
+    //          dozen CUs; a frame takes ~200 ms whatever the batch (113 k frames/s with the whole chip full of them) -- the default from 512 frames on;
+    //   grp2   the same with four frames per wave (two list pixels per step: 10 % less time per frame, 1.6 x the instructions);
+    //   seq    one wave per frame (lsd_rg_seq.h): ~110 ms per frame, 36 k frames/s with the chip full -- round 2's stage, kept as a cross-check;
     //   host   the OpenMP stage below, one frame per thread -- the default for smaller batches (one frame: 4 ms).
-    // CUBESLAM_LSD_REGIONS = seq | host overrides the choice.
+    // CUBESLAM_LSD_REGIONS = grp | grp2 | seq | host overrides the choice.
     std::vector<std::vector<float>> dev_lines;
     bool on_device = false;
     if (total > 0) CS_LAUNCH(ctx, "lsd_emit", lsd_emit, dim3(nbx, h, F), dim3(256), 0, l->d_mod, l->d_ang, w, h, l->d_seg_base, l->d_caddr, l->d_cdeg, l->d_ccs, l->d_cmod);
     const char *mode = getenv("CUBESLAM_LSD_REGIONS");
-    if (!mode || !*mode) mode = F >= 512 ? "seq" : "host";
-    const bool use_seq = total > 0 && strcmp(mode, "seq") == 0;
+    if (!mode || !*mode) mode = F >= 512 ? "grp" : "host";
+    const int grp_p = strcmp(mode, "grp") == 0 ? 1 : (strcmp(mode, "grp2") == 0 ? 2 : 0); // lsd_rg_grp<P>: several frames per wave
+    const bool use_seq = total > 0 && (strcmp(mode, "seq") == 0 || grp_p);
     auto lbd_maps = [&]() -> int { // the derivative maps only depend on the gray frames
         if (!l->d_lblur) {
             const size_t N = (size_t)W * H * l->max_frames;
@@ -655,7 +658,7 @@ static int lsd_run(cs_ctx *ctx, cs_lsd *l, int with_lbd) {
     if (l->gate_wait && !use_seq) l->gate_wait(l->gate_arg); // (phased front-end: the region stage starts when the caller's own GPU work of the phase is done; the device stage waits inside lsd_seq_run, in front of its one long kernel)
     if (use_seq) {
         long st[4] = {0, 0, 0, 0};
-        r = lsd_seq_run(ctx, &l->seq, F, w, h, l->d_ang, l->d_mod, l->d_caddr, l->d_cdeg, l->d_ccs, l->frame_base.data(), dev_lines, st, l->gate_wait, l->gate_done, l->gate_arg, l->seq_wpb);
+        r = lsd_seq_run(ctx, &l->seq, F, w, h, l->d_ang, l->d_mod, l->d_caddr, l->d_cdeg, l->d_ccs, l->frame_base.data(), dev_lines, st, l->gate_wait, l->gate_done, l->gate_arg, grp_p, l->seq_wpb);
         l->rg_stats[0] = 1; l->rg_stats[1] = st[0]; l->rg_stats[2] = st[2]; l->rg_stats[3] = r == CS_OK ? 0 : 1; l->rg_stats[4] = st[1];
         if (r == CS_OK) on_device = true;
         else if (r != CS_ERR_CAPACITY) return r; // a region outgrew the wave's list: the host stage takes the batch

@@ -33,8 +33,10 @@
 
 #include "lsd_regions.h"
 #include "lsd_rg_seq.h"
+#include "lsd_rg_grp.h"
 
 namespace {
+constexpr int PAD_PX = 272, PAD_LIST = 272, PAD_RECT = 34; // (lsd_rg_grp) 4352 / 4352 / 272 bytes between the frames' slices: see rgg::Batch
 constexpr double PI_ = rg::PI_, LOG_EPS = 0.0, LSD_SCALE = 0.8;
 struct AngMap { int w, h; const double *ang; }; // a frame's level-line angles (doubles, NOTDEF where the gradient is below the threshold)
 
@@ -195,13 +197,18 @@ __device__ double rg_rect_improve(const AngMap &F, rg::Rect &rec, double LOG_NT,
 struct SeqParams {
     int F, w, h;
     const int *caddr; const int *frame_base; const float *cdeg; const float2 *ccs; const double *mod, *ang;
-    rgs::Px *pix; float *seed_cs; int *glist; double *rect; int cand_cap; int *cand_cnt; int *status;
+    rgs::Px *pix; float *ang32; float *seed_cs; int *glist; double *rect; size_t rect_stride; int cand_cap; int *cand_cnt; int *status;
     int min_reg_size, list_cap;
     unsigned long long *prof;
+    size_t pix_stride; // elements from one frame's records (pix, or ang32: lsd_rg_grp's float map) to the next
 };
 __global__ void __launch_bounds__(256) lsd_rg_fill(rgs::Px *pix, size_t n) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) reinterpret_cast<float4 *>(pix)[i] = make_float4(rgs::NOTDEF_F, 0.f, 0.f, rgs::NOTDEF_F);
+}
+__global__ void __launch_bounds__(256) lsd_rg_fill32(float4 *ang, size_t n4) { // lsd_rg_grp's map: one float per pixel
+    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+    if (i < n4) ang[i] = make_float4(rgs::NOTDEF_F, rgs::NOTDEF_F, rgs::NOTDEF_F, rgs::NOTDEF_F);
 }
 // the defined pixels' records from lsd_emit's compact lists, and what each would start a region with as a seed
 __global__ void __launch_bounds__(256) lsd_rg_scatter(SeqParams P) {
@@ -211,7 +218,8 @@ __global__ void __launch_bounds__(256) lsd_rg_scatter(SeqParams P) {
     const int q = P.caddr[base + i] & 0x7fffffff;
     const float d = P.cdeg[base + i];
     const float2 cs = P.ccs[base + i];
-    reinterpret_cast<float4 *>(P.pix + (size_t)f * P.w * P.h)[q] = make_float4(d, cs.x, cs.y, d);
+    if (P.ang32) P.ang32[(size_t)f * P.pix_stride + q] = d;
+    else reinterpret_cast<float4 *>(P.pix + (size_t)f * P.pix_stride)[q] = make_float4(d, cs.x, cs.y, d);
     const double a = double(d) * rg::DEG_TO_RADS; // the map value (:566); region_grow starts a region's sums with cos / sin of it as a double (:651-652)
     reinterpret_cast<float2 *>(P.seed_cs)[base + i] = make_float2(float(cos(a)), float(sin(a)));
 }
@@ -224,8 +232,8 @@ __device__ __forceinline__ void lsd_rg_seq_body(const SeqParams &P) {
     const int base = P.frame_base[f];
     rgs::Frame Fr;
     Fr.w = P.w; Fr.h = P.h; Fr.ne = P.frame_base[f + 1] - base;
-    Fr.caddr = P.caddr + base; Fr.pix = P.pix + (size_t)f * P.w * P.h; Fr.mod = P.mod + (size_t)f * P.w * P.h; Fr.seed_cs = P.seed_cs + 2 * (size_t)base;
-    Fr.rect = P.rect + (size_t)f * P.cand_cap * 12; Fr.cand_cap = P.cand_cap; Fr.cand_cnt = P.cand_cnt + f;
+    Fr.caddr = P.caddr + base; Fr.pix = P.pix + (size_t)f * P.pix_stride; Fr.mod = P.mod + (size_t)f * P.w * P.h; Fr.seed_cs = P.seed_cs + 2 * (size_t)base;
+    Fr.rect = P.rect + (size_t)f * P.rect_stride; Fr.cand_cap = P.cand_cap; Fr.cand_cnt = P.cand_cnt + f;
     Fr.status = P.status + 4 * f; Fr.min_reg_size = P.min_reg_size; Fr.list_cap = P.list_cap; Fr.prof = P.prof ? P.prof + 16 * (size_t)f : nullptr;
     rgs::List L;
     L.glob = P.glist + (size_t)f * rgs::CAP; L.ring[0] = 0;
@@ -234,6 +242,21 @@ __device__ __forceinline__ void lsd_rg_seq_body(const SeqParams &P) {
 // (Smaller workgroups do not pack: the dispatcher spreads them over the emptiest CUs.  A 96-VGPR build in workgroups of ten frames, meant to sit two
 // to a CU, took one CU each, 206 CUs for two detectors, and cuboid_sweep_score waited 27 ms per launch.)
 __global__ void __launch_bounds__(1024) lsd_rg_seq(SeqParams P) { lsd_rg_seq_body(P); }
+// Several frames per wave (lsd_rg_grp.h): a group of 8 P lanes per frame, 64 / (8 P) frames per wave, no LDS.  A launch is 8 (4) times fewer waves than
+// lsd_rg_seq's and the frames' bookkeeping is vector work shared by the frames of a wave.
+// A launch walks up to GRP_SLICES slices of a batch side by side (inside a slice every offset fits 32 bits: lsd_rg_grp.h addresses base + offset).
+constexpr int GRP_SLICES = 8;
+struct GrpLaunch { rgg::Batch slice[GRP_SLICES]; int n_slices, waves_per_slice; };
+template <int P, int LB> __global__ void __launch_bounds__(LB) lsd_rg_grp(GrpLaunch L) { // LB: 256 = up to four waves a workgroup (one per SIMD), 512 / 1024 = two / four per SIMD (the register allocation follows)
+    constexpr int G = 8 * P;
+    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    const int c = wave / L.waves_per_slice;
+    if (c >= L.n_slices) return;
+    const rgg::Batch &B = L.slice[c];
+    const int f0 = (wave - c * L.waves_per_slice) * (64 / G);
+    if (f0 >= B.F) return;
+    rgg::run_wave<P, rgg::GWave<G>>(B, f0);
+}
 // the frames' rectangle lists one after the other (frames in order, seeds in order): cand_base[f] = rectangles of the frames before f
 __global__ void __launch_bounds__(1024) lsd_rg_cand_scan(const int *cand_cnt, int F, int *cand_base) {
     __shared__ int part[1024];
@@ -254,7 +277,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RG_IMP
     int lo = 0, hi = P.F; // the frame: cand_base[f] <= wv < cand_base[f + 1]
     while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (cand_base[mid] <= wv) lo = mid; else hi = mid; }
     const int f = lo;
-    const double *o = P.rect + ((size_t)f * P.cand_cap + (wv - cand_base[f])) * 12;
+    const double *o = P.rect + (size_t)f * P.rect_stride + (size_t)(wv - cand_base[f]) * 12;
     rg::Rect rec;
     rec.x1 = o[0]; rec.y1 = o[1]; rec.x2 = o[2]; rec.y2 = o[3]; rec.width = o[4]; rec.x = o[5]; rec.y = o[6]; rec.theta = o[7]; rec.dx = o[8]; rec.dy = o[9]; rec.prec = o[10]; rec.p = o[11];
     const AngMap Fr = {P.w, P.h, P.ang + (size_t)f * P.w * P.h};
@@ -276,6 +299,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RG_IMP
 struct LsdSeq {
     int F = 0, w = 0, h = 0; int cand_cap = 0; size_t cap_lines = 0, cap_def = 0;
     rgs::Px *d_pix = nullptr;
+    rgg::Ent *d_elist = nullptr; float *d_ang32 = nullptr; int *d_order = nullptr; // the several-frames-per-wave walk: region lists of 8-byte entries, a float per pixel, the frames sorted by work
     float *d_seed_cs = nullptr;
     int *d_glist = nullptr, *d_cand_cnt = nullptr, *d_cand_base = nullptr, *d_status = nullptr, *d_frame_base = nullptr;
     double *d_rect = nullptr, *d_lgt = nullptr;
@@ -285,7 +309,7 @@ struct LsdSeq {
 };
 void lsd_seq_destroy(LsdSeq *r) {
     if (!r) return;
-    void *ptrs[] = {r->d_pix, r->d_seed_cs, r->d_glist, r->d_cand_cnt, r->d_cand_base, r->d_status, r->d_frame_base, r->d_rect, r->d_lgt, r->d_has, r->d_line};
+    void *ptrs[] = {r->d_elist, r->d_ang32, r->d_order, r->d_pix, r->d_seed_cs, r->d_glist, r->d_cand_cnt, r->d_cand_base, r->d_status, r->d_frame_base, r->d_rect, r->d_lgt, r->d_has, r->d_line};
     for (void *p : ptrs) if (p) hipFree(p);
     delete r;
 }
@@ -294,6 +318,7 @@ void lsd_seq_destroy(LsdSeq *r) {
 int lsd_seq_run(cs_ctx *ctx, LsdSeq **handle, int F, int w, int h, const double *d_ang, const double *d_mod, const int *d_caddr, const float *d_cdeg, const float2 *d_ccs, const int *frame_base,
                 std::vector<std::vector<float>> &lines, long *stats /* [0] region_grow calls, [1] window fetches, [2] rectangles at rect_improve, [3] regions at the rectangle stage */,
                 void (*before_seq)(void *), void (*after_seq)(void *), void *gate_arg /* the front-end runner's phase gate: called in front of the lsd_rg_seq launch and once it has left the GPU; may be NULL */,
+                int grp_p /* 0: lsd_rg_seq, one wave per frame; 1 / 2: lsd_rg_grp<P>, 8 / 4 frames per wave */,
                 int waves_per_workgroup /* frames per workgroup of lsd_rg_seq: 16 packs a batch onto F / 16 CUs and leaves the others empty; 4 spreads it over the chip (the alternating runner, where
                                            every CU is busy anyway: 128 -> 104 ms per launch there) */) {
     LsdSeq *r = *handle;
@@ -307,7 +332,8 @@ int lsd_seq_run(cs_ctx *ctx, LsdSeq **handle, int F, int w, int h, const double 
         r = new LsdSeq();
         *handle = r;
         r->F = F; r->w = w; r->h = h; r->cand_cap = 4096;
-        RA_(cs_dalloc(ctx, &r->d_pix, (size_t)F * w * h)); RA_(cs_dalloc(ctx, &r->d_glist, (size_t)F * rgs::CAP)); RA_(cs_dalloc(ctx, &r->d_rect, (size_t)F * r->cand_cap * 12));
+        // (d_pix, d_glist: lsd_rg_seq's; d_ang32, d_elist: lsd_rg_grp's -- allocated by the mode that runs)
+        RA_(cs_dalloc(ctx, &r->d_order, (size_t)F)); RA_(cs_dalloc(ctx, &r->d_rect, (size_t)F * (r->cand_cap * 12 + PAD_RECT)));
         RA_(cs_dalloc(ctx, &r->d_cand_cnt, (size_t)F)); RA_(cs_dalloc(ctx, &r->d_cand_base, (size_t)F + 1));
         RA_(cs_dalloc(ctx, &r->d_status, (size_t)F * 4)); RA_(cs_dalloc(ctx, &r->d_frame_base, (size_t)F + 1));
         RA_(cs_dalloc(ctx, &r->d_lgt, (size_t)LG_N));
@@ -323,11 +349,14 @@ int lsd_seq_run(cs_ctx *ctx, LsdSeq **handle, int F, int w, int h, const double 
     RA_(cs_h2d(ctx, r->d_frame_base, frame_base, (size_t)F + 1));
     SeqParams S;
     S.F = F; S.w = w; S.h = h; S.caddr = d_caddr; S.frame_base = r->d_frame_base; S.cdeg = d_cdeg; S.ccs = d_ccs; S.mod = d_mod; S.ang = d_ang;
-    S.pix = r->d_pix; S.seed_cs = r->d_seed_cs; S.glist = r->d_glist; S.rect = r->d_rect; S.cand_cap = r->cand_cap; S.cand_cnt = r->d_cand_cnt; S.status = r->d_status;
+    S.pix = r->d_pix; S.ang32 = nullptr; S.seed_cs = r->d_seed_cs; S.glist = r->d_glist; S.rect = r->d_rect; S.cand_cap = r->cand_cap; S.cand_cnt = r->d_cand_cnt; S.status = r->d_status;
     const double LOG_NT = 5 * (std::log10(double(w)) + std::log10(double(h))) / 2 + std::log10(11.0);
     S.min_reg_size = int(-LOG_NT / std::log10(rg::ANG_TH / 180));
     S.list_cap = rgs::CAP;
     if (const char *e = getenv("CUBESLAM_LSD_SEQ_CAP")) S.list_cap = std::max(2, std::min(rgs::CAP, atoi(e))); // (tests: a small cap walks the fallback to the host stage)
+    const bool grp = grp_p == 1 || grp_p == 2, pad = grp && !getenv("CUBESLAM_LSD_NOPAD"); // (the variable: to measure what the padding is worth)
+    const size_t rect_stride = (size_t)r->cand_cap * 12 + (pad ? PAD_RECT : 0), list_stride = (size_t)rgg::CAP + (pad ? PAD_LIST : 0);
+    S.pix_stride = (size_t)w * h + (pad ? PAD_PX : 0); S.rect_stride = rect_stride;
     S.prof = nullptr;
 #if defined(RGS_PROFILE)
     static unsigned long long *d_prof = nullptr;
@@ -335,12 +364,65 @@ int lsd_seq_run(cs_ctx *ctx, LsdSeq **handle, int F, int w, int h, const double 
     hipMemsetAsync(d_prof, 0, 4096 * 16 * sizeof(unsigned long long), ctx->stream);
     S.prof = d_prof;
 #endif
-    const size_t npx = (size_t)F * w * h;
-    CS_LAUNCH(ctx, "lsd_rg_fill", lsd_rg_fill, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, r->d_pix, npx);
+    const size_t npx = (size_t)F * S.pix_stride;
+    if (grp) {
+        if (!r->d_ang32) RA_(cs_dalloc(ctx, &r->d_ang32, (size_t)r->F * ((size_t)w * h + PAD_PX) + 4));
+        if (!r->d_elist) RA_(cs_dalloc(ctx, &r->d_elist, (size_t)r->F * ((size_t)rgg::CAP + PAD_LIST) + 16));
+        S.ang32 = r->d_ang32;
+        CS_LAUNCH(ctx, "lsd_rg_fill", lsd_rg_fill32, dim3((unsigned)((npx / 4 + 1 + 255) / 256)), dim3(256), 0, reinterpret_cast<float4 *>(r->d_ang32), npx / 4 + 1);
+    } else {
+        if (!r->d_pix) RA_(cs_dalloc(ctx, &r->d_pix, (size_t)r->F * w * h));
+        if (!r->d_glist) RA_(cs_dalloc(ctx, &r->d_glist, (size_t)r->F * rgs::CAP));
+        S.pix = r->d_pix; S.glist = r->d_glist;
+        CS_LAUNCH(ctx, "lsd_rg_fill", lsd_rg_fill, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, r->d_pix, npx);
+    }
     CS_LAUNCH(ctx, "lsd_rg_scatter", lsd_rg_scatter, dim3((max_ne + 255) / 256, F), dim3(256), 0, S);
     int wpb = std::max(1, std::min(16, waves_per_workgroup)); // waves (= frames) per workgroup
     if (const char *e = getenv("CUBESLAM_LSD_SEQ_WPB")) wpb = std::max(1, std::min(16, atoi(e)));
     if (before_seq) before_seq(gate_arg);
+    if (grp_p == 1 || grp_p == 2) {
+        const size_t npx = (size_t)w * h;
+        int chunk = (int)std::min<size_t>(4096, 0xffffffffull / (npx * sizeof(double))); // (the norms: the widest per-pixel array the walk reads) // every offset of a launch fits 32 bits (lsd_rg_grp.h addresses base + offset)
+        chunk = std::min(chunk, 1024);
+        if (chunk < 1) return CS_ERR_CAPACITY;
+        std::vector<int> order((size_t)F);
+        for (int c0 = 0; c0 < F; c0 += chunk) { // per launch: its frames sorted by their number of defined pixels, so that frames of similar work share a wave
+            const int fc = std::min(chunk, F - c0);
+            for (int k = 0; k < fc; k++) order[(size_t)c0 + k] = k;
+            std::stable_sort(order.begin() + c0, order.begin() + c0 + fc, [&](int a, int b) { return frame_base[c0 + a + 1] - frame_base[c0 + a] > frame_base[c0 + b + 1] - frame_base[c0 + b]; });
+        }
+        RA_(cs_h2d(ctx, r->d_order, order.data(), (size_t)F));
+        CS_HIP(ctx, hipStreamSynchronize(ctx->stream)); // (order is a local)
+        const int G = 8 * grp_p, fpw = 64 / G;
+        int wpg = 12; // waves per workgroup: three per SIMD of a CU (167 registers each) -- the most a CU takes, and the most it delivers: 441 frames/s per CU against 326 with two per
+                      // SIMD and 43 with one wave alone on the CU (a wave waits on its one memory round trip per step two thirds of the time); 1024 frames sit on 11 CUs
+        if (const char *e = getenv("CUBESLAM_LSD_GRP_WPB")) wpg = std::max(1, std::min(16, atoi(e)));
+        for (int l0 = 0; l0 < F; l0 += chunk * GRP_SLICES) { // one launch per GRP_SLICES slices
+            GrpLaunch L;
+            L.n_slices = 0; L.waves_per_slice = (chunk + fpw - 1) / fpw;
+            for (int c0 = l0; c0 < F && L.n_slices < GRP_SLICES; c0 += chunk) {
+                const int fc = std::min(chunk, F - c0);
+                rgg::Batch &B = L.slice[L.n_slices++];
+                B.F = fc; B.w = w; B.h = h; B.npx = (int)npx; B.order = r->d_order + c0; B.ang_stride = (int)S.pix_stride; B.list_stride = (int)list_stride; B.rect_stride = (int)rect_stride;
+                B.caddr = d_caddr + frame_base[c0]; B.frame_base = r->d_frame_base + c0; B.ang = r->d_ang32 + (size_t)c0 * S.pix_stride; B.mod = d_mod + (size_t)c0 * npx; B.seed_cs = r->d_seed_cs + 2 * (size_t)frame_base[c0];
+                B.list = r->d_elist + (size_t)c0 * list_stride; B.list_cap = std::min(S.list_cap, rgg::CAP); B.rect = r->d_rect + (size_t)c0 * rect_stride; B.cand_cap = r->cand_cap; B.cand_cnt = r->d_cand_cnt + c0; B.status = r->d_status + 4 * (size_t)c0;
+                B.min_reg_size = S.min_reg_size; B.max_iters = (int)std::min<size_t>(64 * npx, 0x7fffffff);
+                B.prof = nullptr;
+            }
+            const int waves = L.n_slices * L.waves_per_slice, groups = (waves + wpg - 1) / wpg;
+            if (grp_p == 1) {
+                if (wpg <= 4) CS_LAUNCH(ctx, "lsd_rg_grp", (lsd_rg_grp<1, 256>), dim3(groups), dim3(64 * wpg), 0, L);
+                else if (wpg <= 8) CS_LAUNCH(ctx, "lsd_rg_grp", (lsd_rg_grp<1, 512>), dim3(groups), dim3(64 * wpg), 0, L);
+                else if (wpg <= 12) CS_LAUNCH(ctx, "lsd_rg_grp", (lsd_rg_grp<1, 768>), dim3(groups), dim3(64 * wpg), 0, L);
+                else CS_LAUNCH(ctx, "lsd_rg_grp", (lsd_rg_grp<1, 1024>), dim3(groups), dim3(64 * wpg), 0, L);
+            } else {
+                if (wpg <= 4) CS_LAUNCH(ctx, "lsd_rg_grp", (lsd_rg_grp<2, 256>), dim3(groups), dim3(64 * wpg), 0, L);
+                else if (wpg <= 8) CS_LAUNCH(ctx, "lsd_rg_grp", (lsd_rg_grp<2, 512>), dim3(groups), dim3(64 * wpg), 0, L);
+                else if (wpg <= 12) CS_LAUNCH(ctx, "lsd_rg_grp", (lsd_rg_grp<2, 768>), dim3(groups), dim3(64 * wpg), 0, L);
+                else CS_LAUNCH(ctx, "lsd_rg_grp", (lsd_rg_grp<2, 1024>), dim3(groups), dim3(64 * wpg), 0, L);
+            }
+        }
+    } else
     CS_LAUNCH(ctx, "lsd_rg_seq", lsd_rg_seq, dim3((F + wpb - 1) / wpb), dim3(64 * wpb), 0, S);
     CS_LAUNCH(ctx, "lsd_rg_cand_scan", lsd_rg_cand_scan, dim3(1), dim3(1024), 0, r->d_cand_cnt, F, r->d_cand_base);
     r->h_base.resize((size_t)F + 1); r->h_status.resize((size_t)F * 4);
