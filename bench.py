@@ -509,7 +509,7 @@ def main():
     from cube_slam_amd import _lib
     from cube_slam_amd.cuboid import CuboidBatch, detect_3d_cuboid
 
-    ctx = _lib.Context(local_rank, priority=1)  # ORB + cuboid: the path a tracking thread waits for
+    ctx = _lib.Context(local_rank, priority=int(os.environ.get("BENCH_PRIO_MAIN", "1")))  # ORB + cuboid: the path a tracking thread waits for
     if world > 1:  # RCCL inside the library: rank 0's ncclUniqueId travels through the process group that the timing barrier uses anyway
         uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
         if rank == 0:
@@ -532,7 +532,7 @@ def main():
     lsd = None
     if not args.no_lines:
         from cube_slam_amd.lsd import line_lbd_detect
-        args.phased = 1 if args.phased and args.frames >= 512 and os.environ.get("CUBESLAM_LSD_REGIONS", "seq") == "seq" else 0
+        args.phased = 1 if args.phased and args.frames >= 512 and os.environ.get("CUBESLAM_LSD_REGIONS", "grp") == "seq" else 0
         # The library's front-end runner (cs_frontend_*, csrc/frontend.hip) runs ORB + cuboid on this thread and the line path on worker
         # threads with their own contexts (= HIP streams).  The detectors alternate steps.  From 512 frames per step on, region growing runs on
         # the device, one wave per frame for ~110 ms (lsd_regions.hip), sixteen frames to a CU.  Default: the ALTERNATING runner with four
@@ -542,7 +542,7 @@ def main():
         # detectors queue their map kernels beside ORB / cuboid of four steps, then the four region stages run together with the ORB / cuboid
         # stream idle) keeps the score kernel away from the walks and is timed beside it (`phased_runner`).  Below 512 frames the 16 host
         # threads grow the regions and the GPU phases of one step overlap the host stage of the neighbouring one.
-        ctx_lines = [_lib.Context(local_rank, priority=-1) for _ in range(max(1, min(8, args.line_workers)))]  # device phases of the line detectors: background
+        ctx_lines = [_lib.Context(local_rank, priority=int(os.environ.get("BENCH_PRIO_LINES", "-1"))) for _ in range(max(1, min(8, args.line_workers)))]  # device phases of the line detectors: background
         lsds = [line_lbd_detect(640, 480, max_frames=args.frames, ctx=c) for c in ctx_lines]
         for d_ in lsds:
             d_.upload(np.stack([s["gray"] for s in scenes]))
@@ -577,7 +577,7 @@ def main():
         elapsed = float(t.item())
     kernels = {}
     for name in ("host_orb_quadtree", "orb_resize", "orb_fast_score", "orb_cells", "orb_scan", "orb_quadtree", "orb_blur", "orb_angle", "orb_desc", "host_lsd_regions", "lsd_blur_hv", "lsd_resize",
-                 "lsd_gradient", "lsd_emit", "lsd_rg_fill", "lsd_rg_scatter", "lsd_rg_seq", "lsd_rg_improve", "lbd_blur5", "lbd_sobel", "lbd_line_desc", "cuboid_frame_prep", "cuboid_unit_lines", "cuboid_canny_nms", "cuboid_canny_cc_local", "cuboid_canny_cc_border", "cuboid_canny_cc", "cuboid_dt",
+                 "lsd_gradient", "lsd_emit", "lsd_rg_fill", "lsd_rg_scatter", "lsd_rg_seq", "lsd_rg_grp", "lsd_rg_improve", "lbd_blur5", "lbd_sobel", "lbd_line_desc", "cuboid_frame_prep", "cuboid_unit_lines", "cuboid_canny_nms", "cuboid_canny_cc_local", "cuboid_canny_cc_border", "cuboid_canny_cc", "cuboid_dt",
                  "cuboid_vp", "cuboid_sweep_filter", "cuboid_sweep_score", "cuboid_select"):
         ms, n = ctx.timing_get(name)
         if n == 0 and lsd is not None:
@@ -590,7 +590,7 @@ def main():
             c.timing(False)
     # the phased runner on the same objects, shortly: its throughput and the score kernel's time in ITS timed region (the kernel never meets a region walk there)
     phased_alt = None
-    if lsd is not None and not args.phased and args.frames >= 512 and os.environ.get("CUBESLAM_LSD_REGIONS", "seq") == "seq" and len(ctx_lines) >= 2 and rank == 0 and world == 1:
+    if lsd is not None and not args.phased and args.frames >= 512 and os.environ.get("CUBESLAM_LSD_REGIONS", "grp") == "seq" and len(ctx_lines) >= 2 and rank == 0 and world == 1:
         fe.set_phased(True)
         for _ in range(len(ctx_lines)):
             fe.step()

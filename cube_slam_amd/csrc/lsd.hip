@@ -642,8 +642,8 @@ static int lsd_run(cs_ctx *ctx, cs_lsd *l, int with_lbd) {
     bool on_device = false;
     if (total > 0) CS_LAUNCH(ctx, "lsd_emit", lsd_emit, dim3(nbx, h, F), dim3(256), 0, l->d_mod, l->d_ang, w, h, l->d_seg_base, l->d_caddr, l->d_cdeg, l->d_ccs, l->d_cmod);
     const char *mode = getenv("CUBESLAM_LSD_REGIONS");
-    if (!mode || !*mode) mode = F >= 512 ? "grp" : "host";
-    const int grp_p = strcmp(mode, "grp") == 0 ? 1 : (strcmp(mode, "grp2") == 0 ? 2 : 0); // lsd_rg_grp<P>: several frames per wave
+    if (!mode || !*mode) mode = F >= 512 ? "seq" : "host";
+    const int grp_p = strcmp(mode, "grp") == 0 ? 1 : (strcmp(mode, "grp2") == 0 ? 2 : (strcmp(mode, "lpf") == 0 ? 64 : 0)); // lsd_rg_grp<P>: several frames per wave; lsd_rg_lpf: one lane per frame
     const bool use_seq = total > 0 && (strcmp(mode, "seq") == 0 || grp_p);
     auto lbd_maps = [&]() -> int { // the derivative maps only depend on the gray frames
         if (!l->d_lblur) {

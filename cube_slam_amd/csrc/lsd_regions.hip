@@ -34,6 +34,7 @@
 #include "lsd_regions.h"
 #include "lsd_rg_seq.h"
 #include "lsd_rg_grp.h"
+#include "lsd_rg_lpf.h"
 
 namespace {
 constexpr int PAD_PX = 272, PAD_LIST = 272, PAD_RECT = 34; // (lsd_rg_grp) 4352 / 4352 / 272 bytes between the frames' slices: see rgg::Batch
@@ -257,6 +258,17 @@ template <int P, int LB> __global__ void __launch_bounds__(LB) lsd_rg_grp(GrpLau
     if (f0 >= B.F) return;
     rgg::run_wave<P, rgg::GWave<G>>(B, f0);
 }
+// One lane per frame (lsd_rg_lpf.h): 64 frames per wave, no lane talks to another, no LDS.
+struct LpfLaunch { rgl::Batch slice[GRP_SLICES]; int n_slices, waves_per_slice; };
+template <int LB> __global__ void __launch_bounds__(LB) lsd_rg_lpf(LpfLaunch L) {
+    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
+    const int c = wave / L.waves_per_slice;
+    if (c >= L.n_slices) return;
+    const rgl::Batch &B = L.slice[c];
+    const int f0 = (wave - c * L.waves_per_slice) * 64;
+    if (f0 >= B.F) return;
+    rgl::run_wave<rgl::LWave>(B, f0);
+}
 // the frames' rectangle lists one after the other (frames in order, seeds in order): cand_base[f] = rectangles of the frames before f
 __global__ void __launch_bounds__(1024) lsd_rg_cand_scan(const int *cand_cnt, int F, int *cand_base) {
     __shared__ int part[1024];
@@ -318,7 +330,7 @@ void lsd_seq_destroy(LsdSeq *r) {
 int lsd_seq_run(cs_ctx *ctx, LsdSeq **handle, int F, int w, int h, const double *d_ang, const double *d_mod, const int *d_caddr, const float *d_cdeg, const float2 *d_ccs, const int *frame_base,
                 std::vector<std::vector<float>> &lines, long *stats /* [0] region_grow calls, [1] window fetches, [2] rectangles at rect_improve, [3] regions at the rectangle stage */,
                 void (*before_seq)(void *), void (*after_seq)(void *), void *gate_arg /* the front-end runner's phase gate: called in front of the lsd_rg_seq launch and once it has left the GPU; may be NULL */,
-                int grp_p /* 0: lsd_rg_seq, one wave per frame; 1 / 2: lsd_rg_grp<P>, 8 / 4 frames per wave */,
+                int grp_p /* 0: lsd_rg_seq, one wave per frame; 1 / 2: lsd_rg_grp<P>, 8 / 4 frames per wave; 64: lsd_rg_lpf, one lane per frame */,
                 int waves_per_workgroup /* frames per workgroup of lsd_rg_seq: 16 packs a batch onto F / 16 CUs and leaves the others empty; 4 spreads it over the chip (the alternating runner, where
                                            every CU is busy anyway: 128 -> 104 ms per launch there) */) {
     LsdSeq *r = *handle;
@@ -354,7 +366,8 @@ int lsd_seq_run(cs_ctx *ctx, LsdSeq **handle, int F, int w, int h, const double 
     S.min_reg_size = int(-LOG_NT / std::log10(rg::ANG_TH / 180));
     S.list_cap = rgs::CAP;
     if (const char *e = getenv("CUBESLAM_LSD_SEQ_CAP")) S.list_cap = std::max(2, std::min(rgs::CAP, atoi(e))); // (tests: a small cap walks the fallback to the host stage)
-    const bool grp = grp_p == 1 || grp_p == 2, pad = grp && !getenv("CUBESLAM_LSD_NOPAD"); // (the variable: to measure what the padding is worth)
+    const bool lpf = grp_p == 64; // one lane per frame
+    const bool grp = grp_p == 1 || grp_p == 2 || lpf, pad = grp && !getenv("CUBESLAM_LSD_NOPAD"); // (the variable: to measure what the padding is worth)
     const size_t rect_stride = (size_t)r->cand_cap * 12 + (pad ? PAD_RECT : 0), list_stride = (size_t)rgg::CAP + (pad ? PAD_LIST : 0);
     S.pix_stride = (size_t)w * h + (pad ? PAD_PX : 0); S.rect_stride = rect_stride;
     S.prof = nullptr;
@@ -366,10 +379,11 @@ int lsd_seq_run(cs_ctx *ctx, LsdSeq **handle, int F, int w, int h, const double 
 #endif
     const size_t npx = (size_t)F * S.pix_stride;
     if (grp) {
-        if (!r->d_ang32) RA_(cs_dalloc(ctx, &r->d_ang32, (size_t)r->F * ((size_t)w * h + PAD_PX) + 4));
+        const size_t head = (size_t)((w + 8 + 3) & ~3); // undefined pixels in front of frame 0 (lsd_rg_lpf reads "row -1" without a test)
+        if (!r->d_ang32) RA_(cs_dalloc(ctx, &r->d_ang32, head + (size_t)r->F * ((size_t)w * h + PAD_PX) + 16));
         if (!r->d_elist) RA_(cs_dalloc(ctx, &r->d_elist, (size_t)r->F * ((size_t)rgg::CAP + PAD_LIST) + 16));
-        S.ang32 = r->d_ang32;
-        CS_LAUNCH(ctx, "lsd_rg_fill", lsd_rg_fill32, dim3((unsigned)((npx / 4 + 1 + 255) / 256)), dim3(256), 0, reinterpret_cast<float4 *>(r->d_ang32), npx / 4 + 1);
+        S.ang32 = r->d_ang32 + head;
+        CS_LAUNCH(ctx, "lsd_rg_fill", lsd_rg_fill32, dim3((unsigned)(((npx + head) / 4 + 1 + 255) / 256)), dim3(256), 0, reinterpret_cast<float4 *>(r->d_ang32), (npx + head) / 4 + 1);
     } else {
         if (!r->d_pix) RA_(cs_dalloc(ctx, &r->d_pix, (size_t)r->F * w * h));
         if (!r->d_glist) RA_(cs_dalloc(ctx, &r->d_glist, (size_t)r->F * rgs::CAP));
@@ -380,8 +394,8 @@ int lsd_seq_run(cs_ctx *ctx, LsdSeq **handle, int F, int w, int h, const double 
     int wpb = std::max(1, std::min(16, waves_per_workgroup)); // waves (= frames) per workgroup
     if (const char *e = getenv("CUBESLAM_LSD_SEQ_WPB")) wpb = std::max(1, std::min(16, atoi(e)));
     if (before_seq) before_seq(gate_arg);
-    if (grp_p == 1 || grp_p == 2) {
-        const size_t npx = (size_t)w * h;
+    if (grp) {
+        const size_t npx = (size_t)w * h, head = (size_t)((w + 8 + 3) & ~3);
         int chunk = (int)std::min<size_t>(4096, 0xffffffffull / (npx * sizeof(double))); // (the norms: the widest per-pixel array the walk reads) // every offset of a launch fits 32 bits (lsd_rg_grp.h addresses base + offset)
         chunk = std::min(chunk, 1024);
         if (chunk < 1) return CS_ERR_CAPACITY;
@@ -393,10 +407,30 @@ int lsd_seq_run(cs_ctx *ctx, LsdSeq **handle, int F, int w, int h, const double 
         }
         RA_(cs_h2d(ctx, r->d_order, order.data(), (size_t)F));
         CS_HIP(ctx, hipStreamSynchronize(ctx->stream)); // (order is a local)
-        const int G = 8 * grp_p, fpw = 64 / G;
+        const int fpw = lpf ? 64 : 64 / (8 * grp_p); // frames per wave
         int wpg = 12; // waves per workgroup: three per SIMD of a CU (167 registers each) -- the most a CU takes, and the most it delivers: 441 frames/s per CU against 326 with two per
                       // SIMD and 43 with one wave alone on the CU (a wave waits on its one memory round trip per step two thirds of the time); 1024 frames sit on 11 CUs
         if (const char *e = getenv("CUBESLAM_LSD_GRP_WPB")) wpg = std::max(1, std::min(16, atoi(e)));
+        if (lpf) {
+            int wpl = 4; // waves per workgroup: one per SIMD
+            if (const char *e = getenv("CUBESLAM_LSD_LPF_WPB")) wpl = std::max(1, std::min(16, atoi(e)));
+            for (int l0 = 0; l0 < F; l0 += chunk * GRP_SLICES) {
+                LpfLaunch L;
+                L.n_slices = 0; L.waves_per_slice = (chunk + 63) / 64;
+                for (int c0 = l0; c0 < F && L.n_slices < GRP_SLICES; c0 += chunk) {
+                    const int fc = std::min(chunk, F - c0);
+                    rgl::Batch &B = L.slice[L.n_slices++];
+                    B.F = fc; B.w = w; B.h = h; B.npx = (int)npx; B.order = r->d_order + c0; B.ang_stride = (int)S.pix_stride; B.list_stride = (int)list_stride; B.rect_stride = (int)rect_stride; B.ang_head = (int)head;
+                    B.caddr = d_caddr + frame_base[c0]; B.frame_base = r->d_frame_base + c0; B.ang = r->d_ang32 + (size_t)c0 * S.pix_stride; B.mod = d_mod + (size_t)c0 * npx; B.seed_cs = r->d_seed_cs + 2 * (size_t)frame_base[c0];
+                    B.list = reinterpret_cast<rgl::Ent *>(r->d_elist) + (size_t)c0 * list_stride; B.list_cap = std::min(S.list_cap, rgl::CAP); B.rect = r->d_rect + (size_t)c0 * rect_stride; B.cand_cap = r->cand_cap; B.cand_cnt = r->d_cand_cnt + c0; B.status = r->d_status + 4 * (size_t)c0;
+                    B.min_reg_size = S.min_reg_size; B.max_iters = (int)std::min<size_t>(64 * npx, 0x7fffffff);
+                }
+                const int waves = L.n_slices * L.waves_per_slice, groups = (waves + wpl - 1) / wpl;
+                if (wpl <= 4) CS_LAUNCH(ctx, "lsd_rg_lpf", (lsd_rg_lpf<256>), dim3(groups), dim3(64 * wpl), 0, L);
+                else if (wpl <= 8) CS_LAUNCH(ctx, "lsd_rg_lpf", (lsd_rg_lpf<512>), dim3(groups), dim3(64 * wpl), 0, L);
+                else CS_LAUNCH(ctx, "lsd_rg_lpf", (lsd_rg_lpf<1024>), dim3(groups), dim3(64 * wpl), 0, L);
+            }
+        } else
         for (int l0 = 0; l0 < F; l0 += chunk * GRP_SLICES) { // one launch per GRP_SLICES slices
             GrpLaunch L;
             L.n_slices = 0; L.waves_per_slice = (chunk + fpw - 1) / fpw;
@@ -404,7 +438,7 @@ int lsd_seq_run(cs_ctx *ctx, LsdSeq **handle, int F, int w, int h, const double 
                 const int fc = std::min(chunk, F - c0);
                 rgg::Batch &B = L.slice[L.n_slices++];
                 B.F = fc; B.w = w; B.h = h; B.npx = (int)npx; B.order = r->d_order + c0; B.ang_stride = (int)S.pix_stride; B.list_stride = (int)list_stride; B.rect_stride = (int)rect_stride;
-                B.caddr = d_caddr + frame_base[c0]; B.frame_base = r->d_frame_base + c0; B.ang = r->d_ang32 + (size_t)c0 * S.pix_stride; B.mod = d_mod + (size_t)c0 * npx; B.seed_cs = r->d_seed_cs + 2 * (size_t)frame_base[c0];
+                B.caddr = d_caddr + frame_base[c0]; B.frame_base = r->d_frame_base + c0; B.ang = r->d_ang32 + head + (size_t)c0 * S.pix_stride; B.mod = d_mod + (size_t)c0 * npx; B.seed_cs = r->d_seed_cs + 2 * (size_t)frame_base[c0];
                 B.list = r->d_elist + (size_t)c0 * list_stride; B.list_cap = std::min(S.list_cap, rgg::CAP); B.rect = r->d_rect + (size_t)c0 * rect_stride; B.cand_cap = r->cand_cap; B.cand_cnt = r->d_cand_cnt + c0; B.status = r->d_status + 4 * (size_t)c0;
                 B.min_reg_size = S.min_reg_size; B.max_iters = (int)std::min<size_t>(64 * npx, 0x7fffffff);
                 B.prof = nullptr;

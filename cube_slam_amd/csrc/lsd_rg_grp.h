@@ -40,18 +40,6 @@ constexpr int SHRINK_B = 4;                    // list entries per iteration of 
 enum : int { PH_SEED = 0, PH_GROW, PH_P0, PH_P1, PH_P2, PH_P3, PH_STAT, PH_SHRINK, PH_DONE };
 enum : int { AF_CHECK = 0, AF_REGROWN, AF_SHRUNK };
 
-RGS_FN float fast_atan2_1(float y, float x) { // rg::fast_atan2 with ONE division: the two branches divide min by max + eps, the same IEEE operations on the same operands
-    const float p1 = 0.9997878412794807f * (float)(180 / rg::PI_), p3 = -0.3258083974640975f * (float)(180 / rg::PI_), p5 = 0.1555786518463281f * (float)(180 / rg::PI_),
-                p7 = -0.04432655554792128f * (float)(180 / rg::PI_);
-    const float ax = fabsf(x), ay = fabsf(y);
-    const bool hi = ax >= ay;
-    const float c = (hi ? ay : ax) / ((hi ? ax : ay) + (float)DBL_EPSILON), c2 = c * c;
-    const float q = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
-    float a = hi ? q : 90.f - q;
-    if (x < 0) a = 180.f - a;
-    if (y < 0) a = 360.f - a;
-    return a;
-}
 
 #if defined(RGG_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
 // (development) shader-clock ticks per part of the iteration, summed per wave: prof[16 * wave + k]
@@ -336,7 +324,7 @@ template <int P, class W> RGS_FN void run_wave(const Batch &B, int f0) {
                     float cc, sn;
                     glibc_sincosf::sincosf_pos(float(double(cdeg) * rg::DEG_TO_RADS), &sn, &cc); // cos(float(angle)), sin(float(angle)) :676-677 with glibc's values
                     s.sumdx += cc; s.sumdy += sn;
-                    s.reg_angle = fast_atan2_1(s.sumdy, s.sumdx) * rg::DEG_TO_RADS;
+                    s.reg_angle = rg::fast_atan2_1(s.sumdy, s.sumdx) * rg::DEG_TO_RADS;
                     t.cur = first + 1;
                 });
             }

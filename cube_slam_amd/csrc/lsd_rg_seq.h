@@ -41,6 +41,18 @@ RG_HD float fast_atan2(float y, float x) { // cv::fastAtan2, the polynomial of l
     if (y < 0) a = 360.f - a;
     return a;
 }
+RG_HD float fast_atan2_1(float y, float x) { // fast_atan2 with ONE division: the two branches divide min by max + eps -- the same IEEE operations on the same operands, bit for bit the same result
+    const float p1 = 0.9997878412794807f * (float)(180 / PI_), p3 = -0.3258083974640975f * (float)(180 / PI_), p5 = 0.1555786518463281f * (float)(180 / PI_),
+                p7 = -0.04432655554792128f * (float)(180 / PI_);
+    const float ax = fabsf(x), ay = fabsf(y);
+    const bool hi = ax >= ay;
+    const float c = (hi ? ay : ax) / ((hi ? ax : ay) + (float)DBL_EPSILON), c2 = c * c;
+    const float q = (((p7 * c2 + p5) * c2 + p3) * c2 + p1) * c;
+    float a = hi ? q : 90.f - q;
+    if (x < 0) a = 180.f - a;
+    if (y < 0) a = 360.f - a;
+    return a;
+}
 RG_HD double dist(double x1, double y1, double x2, double y2) { return sqrt((x2 - x1) * (x2 - x1) + (y2 - y1) * (y2 - y1)); }
 RG_HD double angle_diff_signed(double a, double b) { double diff = a - b; while (diff <= -PI_) diff += M_2__PI_; while (diff > PI_) diff -= M_2__PI_; return diff; }
 
@@ -229,7 +241,7 @@ template <class W> RGS_FN void expand(const Frame &F, Win &w, Win &other, int px
         win_strike<W>(other, cx, cy);
         ++n;
         sumdx += cc; sumdy += ss; // cos(float(angle)), sin(float(angle)) :676-677, from lsd_emit
-        reg_angle = rg::fast_atan2(sumdy, sumdx) * rg::DEG_TO_RADS;
+        reg_angle = rg::fast_atan2_1(sumdy, sumdx) * rg::DEG_TO_RADS;
         w.am_ok = false; other.am_ok = false;
         if (l0 == 63) break;
         cur = l0 + 1;

@@ -38,11 +38,11 @@ def test_other_sizes_and_flat(ctx, oracle):
     det.close()
 
 
-@pytest.mark.parametrize("stage", ["grp", "grp2", "seq"])
+@pytest.mark.parametrize("stage", ["seq", "grp", "grp2", "lpf"])
 def test_device_region_stage_equals_host_stage(ctx, oracle, monkeypatch, stage):
-    """Region growing / rectangles / NFA on the device (lsd_regions.hip: the reference's sequence walked by eight or four frames per wave, lsd_rg_grp.h,
-    or by one wave per frame, lsd_rg_seq.h) against the host stage and the oracle: KeyLines byte for byte.  The batch is small, so the stage is asked
-    for; large batches take `grp` by themselves.  Eleven frames: a wave of eight and a ragged one."""
+    """Region growing / rectangles / NFA on the device (lsd_regions.hip: the reference's sequence walked by one wave per frame, lsd_rg_seq.h; by eight
+    or four frames per wave, lsd_rg_grp.h; by one lane per frame, lsd_rg_lpf.h) against the host stage and the oracle: KeyLines byte for byte.  The
+    batch is small, so the stage is asked for; large batches take `seq` by themselves.  Eleven frames: a wave of eight and a ragged one."""
     imgs = [np.load(os.path.join(GOLD, "orb_cabinet.npz"))["gray"], synth.cuboid_scene(7, n_boxes=3, bg_texture=0.5)["gray"], synth.texture_image(8, 640, 480)]
     imgs += [synth.cuboid_scene(60 + i, n_boxes=3, bg_texture=0.125 * i)["gray"] for i in range(8)]
     det = line_lbd_detect(640, 480, max_frames=len(imgs), ctx=ctx)
@@ -59,7 +59,7 @@ def test_device_region_stage_equals_host_stage(ctx, oracle, monkeypatch, stage):
     det.close()
 
 
-@pytest.mark.parametrize("stage", ["grp", "seq"])
+@pytest.mark.parametrize("stage", ["seq", "grp", "lpf"])
 def test_device_region_stage_other_size_and_capacity_fallback(ctx, oracle, monkeypatch, stage):
     """The device stage on KITTI-sized frames, and its way out: a region larger than the wave's list (here cut to 64 pixels) hands the batch to the
     host stage -- same KeyLines, and the statistics say so."""
@@ -82,8 +82,7 @@ def test_device_region_stage_other_size_and_capacity_fallback(ctx, oracle, monke
 
 
 def test_large_batches_take_the_device_region_stage(ctx, oracle, monkeypatch):
-    """512 frames (16 distinct ones, repeated) through the resident-batch form: the device stage (lsd_rg_grp, eight frames per wave, the frames of a
-    launch sorted by their work) is the default there, all frames give their own lines."""
+    """512 frames (16 distinct ones, repeated) through the resident-batch form: the device stage is the default there, all frames give their own lines."""
     monkeypatch.delenv("CUBESLAM_LSD_REGIONS", raising=False)
     base = [synth.cuboid_scene(40 + i, n_boxes=3, bg_texture=0.5)["gray"] for i in range(16)]
     F = 512

@@ -1,7 +1,7 @@
 """CPU checks of the device region stage of the line detector (cube_slam_amd/csrc/lsd_regions.hip):
-  * the sources the kernels compile (lsd_rg_grp.h: eight or four frames per wave, the default; lsd_rg_seq.h: one wave per frame), run on the host with
-    the 64 lanes as loops, leave the `used` map and hand over the rectangles of the oracle's sequential algorithm, bit for bit and in the same order
-    (tools/lsd_sim/grp_sim.cpp, seq_sim.cpp);
+  * the sources the kernels compile (lsd_rg_seq.h: one wave per frame, the default of large batches; lsd_rg_grp.h: eight or four frames per wave;
+    lsd_rg_lpf.h: one lane per frame), run on the host with the 64 lanes as loops, leave the `used` map and hand over the rectangles of the oracle's
+    sequential algorithm, bit for bit and in the same order (tools/lsd_sim/seq_sim.cpp, grp_sim.cpp, lpf_sim.cpp);
   * the cosf / sinf restatement the device uses equals the host's libm (glibc_sincosf.h)."""
 import os
 import subprocess
@@ -60,4 +60,21 @@ def test_frames_per_wave_stage_equals_the_sequential_algorithm(tmp_path):
     out = subprocess.run([exes[2], "640", "480", raws[0], raws[2], raws[4], raws[7]], capture_output=True, text=True)
     assert out.returncode == 0 and out.stdout.count("EQUAL") == 4 and "DIFFERENT" not in out.stdout, out.stdout[-1200:]
     out = subprocess.run([exes[1], "640", "480", raws[0], raws[1]], capture_output=True, text=True, env=dict(os.environ, GRP_CAP="64"))
+    assert out.returncode == 2 and out.stdout.count("fail 1") == 2, out.stdout[-600:]
+
+
+def test_lane_per_frame_stage_equals_the_sequential_algorithm(tmp_path):
+    """lsd_rg_lpf.h on the host: a wave whose lanes walk eleven different frames (flat to densely textured), every one of them held to the oracle's
+    sequence; also with a list capacity that the regions outgrow."""
+    exe = str(tmp_path / "lpf_sim")
+    _build("tools/lsd_sim/lpf_sim.cpp", exe)
+    raws = []
+    for seed, tex in ((11, 0.5), (12, 0.0), (13, 1.0), (14, 0.25), (3, 1.0), (21, 0.5), (22, 0.75), (31, 0.6), (32, 0.4), (33, 0.9)):
+        raws.append(str(tmp_path / ("l%d.raw" % seed)))
+        synth.cuboid_scene(seed, n_boxes=3, bg_texture=tex)["gray"].astype(np.uint8).tofile(raws[-1])
+    raws.append(str(tmp_path / "ltex.raw"))
+    synth.texture_image(8, 640, 480).astype(np.uint8).tofile(raws[-1])
+    out = subprocess.run([exe, "640", "480", *raws], capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.count("EQUAL") == len(raws) and "DIFFERENT" not in out.stdout, out.stdout[-1500:]
+    out = subprocess.run([exe, "640", "480", raws[0], raws[1]], capture_output=True, text=True, env=dict(os.environ, GRP_CAP="64"))
     assert out.returncode == 2 and out.stdout.count("fail 1") == 2, out.stdout[-600:]

@@ -14,11 +14,13 @@ from oracle import pyoracle as po  # noqa: E402
 F = int(sys.argv[1]) if len(sys.argv) > 1 else 1024
 D = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 ctx = _lib.Context(0)
-base = [synth.cuboid_scene(100 + i, n_boxes=3, bg_texture=0.5)["gray"] for i in range(D - 2)]
+from concurrent.futures import ThreadPoolExecutor  # noqa: E402
+with ThreadPoolExecutor(16) as ex:  # D distinct scenes (frames that repeat walk in lockstep inside a wave and flatter the several-frames-per-wave stages)
+    base = list(ex.map(lambda i: synth.cuboid_scene(100 + i, n_boxes=3, bg_texture=0.5)["gray"], range(D - 2)))
 base += [np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "orb_cabinet.npz"))["gray"], synth.texture_image(8, 640, 480)]
 g = np.stack([base[i % D] for i in range(F)])
 det = line_lbd_detect(640, 480, max_frames=F, ctx=ctx)
-variants = [("host", None), ("seq", None)] + [(m, w) for m in ("grp", "grp2") for w in [int(x) for x in os.environ.get("WPBS", "1,4,8,16").split(",")]]
+variants = [("host", None), ("seq", None)] + [(m, w) for m in ("grp", "grp2", "lpf") for w in [int(x) for x in os.environ.get("WPBS", "1,4,8,16").split(",")]]
 if len(sys.argv) > 3:
     variants = [v for v in variants if v[0] in sys.argv[3].split(",")]
 res = {}
@@ -26,6 +28,7 @@ for mode, wpb in variants:
     os.environ["CUBESLAM_LSD_REGIONS"] = mode
     if wpb:
         os.environ["CUBESLAM_LSD_GRP_WPB"] = str(wpb)
+        os.environ["CUBESLAM_LSD_LPF_WPB"] = str(wpb)
     det.upload(g)
     det.run(with_lbd=False)
     ctx.timing(True); ctx.timing_reset()
@@ -34,7 +37,7 @@ for mode, wpb in variants:
     for _ in range(R):
         det.run(with_lbd=False)
     dt = (time.time() - t0) / R
-    ks = {k: ctx.timing_get(k)[0] / R for k in ("lsd_rg_seq", "lsd_rg_grp", "lsd_rg_improve", "lsd_rg_fill", "lsd_rg_scatter", "host_lsd_regions")}
+    ks = {k: ctx.timing_get(k)[0] / R for k in ("lsd_rg_seq", "lsd_rg_grp", "lsd_rg_lpf", "lsd_rg_improve", "lsd_rg_fill", "lsd_rg_scatter", "host_lsd_regions")}
     ctx.timing(False)
     key = mode + ("/%d" % wpb if wpb else "")
     res[key] = [det.read(f, with_desc=False) for f in range(min(F, D))]
@@ -43,7 +46,7 @@ ref = res.get("host") or next(iter(res.values()))
 for key, r in res.items():
     bad = sum(ref[f].tobytes() != r[f].tobytes() for f in range(min(F, D)))
     print(key, "frames differing from", "host" if "host" in res else "first", ":", bad, "of", min(F, D), flush=True)
-chk = [0, 1, D - 2, D - 1]
+chk = [0, 1, D - 2, D - 1] if os.environ.get("CHECK_ORACLE", "1") == "1" else []
 for key, r in res.items():
     print(key, "== oracle on", sum(r[f].tobytes() == po.lsd_detect(base[f]).tobytes() for f in chk), "of", len(chk), flush=True)
 det.close()
