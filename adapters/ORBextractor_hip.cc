@@ -35,7 +35,14 @@ ORBextractor::ORBextractor(int _nfeatures, float _scaleFactor, int _nlevels, int
     mvImagePyramid.resize(nlevels);
     cs_orb *probe = nullptr;
     cs_ctx *my_ctx = new_ctx();
-    { std::lock_guard<std::mutex> lk(g_mu); g_dev[this].ctx = my_ctx; }
+    { // (an extractor constructed at the address of one that was never released: its stale device side goes first)
+        std::lock_guard<std::mutex> lk(g_mu);
+        Dev &e = g_dev[this];
+        if (e.orb) cs_orb_destroy(e.ctx, e.orb);
+        if (e.ctx) cs_destroy(e.ctx);
+        e = Dev();
+        e.ctx = my_ctx;
+    }
     if (cs_orb_create(my_ctx, nfeatures, (float)scaleFactor, nlevels, iniThFAST, minThFAST, 64, 64, 1, &probe) != CS_OK)
         throw std::runtime_error(std::string("ORBextractor (HIP): ") + cs_last_error(my_ctx));
     cs_orb_get_table(probe, 0, mvScaleFactor.data()); cs_orb_get_table(probe, 1, mvInvScaleFactor.data());

@@ -15,26 +15,36 @@ using namespace cv;
 using namespace cv::line_descriptor;
 
 namespace {
-struct Dev { cs_ctx *ctx = nullptr; cs_lsd *lsd = nullptr; int w = 0, h = 0; };
+// One context (device + stream) and one detector PER line_lbd_detect OBJECT, and a lock around its use: a cs_ctx is not thread-safe, the object may be
+// called from any thread of the SLAM system and outlives the thread that first used it (a context that belonged to a thread would dangle in this table
+// once that thread exits).  Released by line_lbd_detect_hip_release() or at process exit (the reference's class has no destructor to hook).
+struct Dev { cs_ctx *ctx = nullptr; cs_lsd *lsd = nullptr; int w = 0, h = 0; std::mutex *use = nullptr; };
 std::mutex g_mu;
 std::map<const line_lbd_detect *, Dev> g_dev;
-// One context (device + stream) per CALLING THREAD: a cs_ctx is not thread-safe, and the SLAM system calls into this unit from several threads
-// (tracking, local mapping, the detached global-BA thread).  Created at the thread's first call, destroyed when the thread exits.
+// The functions that need no detector (LBD descriptors, the matcher) take a context of the CALLING THREAD: created at the thread's first call, destroyed when
+// the thread exits, never handed to another thread.
 struct ThreadCtx { cs_ctx *c = nullptr; ~ThreadCtx() { if (c) cs_destroy(c); } };
 cs_ctx *shared_ctx() {
     thread_local ThreadCtx t;
     if (!t.c && cs_create(0, &t.c) != CS_OK) throw std::runtime_error("line_lbd_detect (HIP): no device -- there is no CPU path");
     return t.c;
 }
-Dev device_for(const line_lbd_detect *self, int w, int h) {
+Dev device_for(const line_lbd_detect *self) { // the object's entry (its context is created at the first call)
     std::lock_guard<std::mutex> lk(g_mu);
     Dev &e = g_dev[self];
-    if (!e.lsd || e.w != w || e.h != h) {
-        if (e.lsd) cs_lsd_destroy(e.ctx, e.lsd);
-        e.ctx = shared_ctx(); e.w = w; e.h = h; e.lsd = nullptr;
-        if (cs_lsd_create(e.ctx, w, h, 1, &e.lsd) != CS_OK) throw std::runtime_error(std::string("line_lbd_detect (HIP): ") + cs_last_error(e.ctx));
+    if (!e.ctx) {
+        if (cs_create(0, &e.ctx) != CS_OK) { e.ctx = nullptr; throw std::runtime_error("line_lbd_detect (HIP): no device -- there is no CPU path"); }
+        e.use = new std::mutex();
     }
     return e;
+}
+void size_detector(const line_lbd_detect *self, int w, int h, Dev &d) { // called with d.use held: the detector of the frame size
+    if (d.lsd && d.w == w && d.h == h) return;
+    if (d.lsd) cs_lsd_destroy(d.ctx, d.lsd);
+    d.lsd = nullptr; d.w = w; d.h = h;
+    const int r = cs_lsd_create(d.ctx, w, h, 1, &d.lsd);
+    { std::lock_guard<std::mutex> lk(g_mu); Dev &e = g_dev[self]; e.lsd = d.lsd; e.w = w; e.h = h; }
+    if (r != CS_OK) throw std::runtime_error(std::string("line_lbd_detect (HIP): ") + cs_last_error(d.ctx));
 }
 Mat as_gray(const Mat &img) {
     if (img.channels() == 1) return img;
@@ -131,11 +141,16 @@ line_lbd_detect::line_lbd_detect(int numoctaves, float octaveratio) : numoctaves
 void line_lbd_detect::detect_raw_lines(const cv::Mat &gray_img, std::vector<KeyLine> &keylines_out) {
     if (use_LSD && numoctaves_ == 1) { // LSDDetector::detect(gray, keylines, (int)octaveratio_, 1, opts): LSD_REFINE_ADV, reference defaults
         const Mat g = as_gray(gray_img);
-        const Dev d = device_for(this, g.cols, g.rows);
+        Dev d = device_for(this);
         const int cap = 16384;
         std::vector<cs_keyline> kl(cap);
         int n = 0;
-        if (cs_lsd_detect(d.ctx, d.lsd, g.data, 1, (int)g.step, kl.data(), cap, &n) != CS_OK) throw std::runtime_error(std::string("line_lbd_detect (HIP): ") + cs_last_error(d.ctx));
+        {
+            std::lock_guard<std::mutex> use(*d.use); // one caller at a time per object
+            { std::lock_guard<std::mutex> lk(g_mu); d = g_dev[this]; }
+            size_detector(this, g.cols, g.rows, d);
+            if (cs_lsd_detect(d.ctx, d.lsd, g.data, 1, (int)g.step, kl.data(), cap, &n) != CS_OK) throw std::runtime_error(std::string("line_lbd_detect (HIP): ") + cs_last_error(d.ctx));
+        }
         keylines_out.clear();
         for (int i = 0; i < n; i++) keylines_out.push_back(to_keyline(kl[i]));
     } else if (use_LSD) { // several octaves: the reference's pyramid loop (pyrDown) stays on the host
@@ -211,4 +226,14 @@ void line_lbd_detect::match_line_descrip(const cv::Mat &descrips_query, const cv
     if (cs_lbd_match(ctx, q.data(), nq, t.data(), nt, matching_dist_thres, qi.data(), ti.data(), di.data(), &n) != CS_OK)
         throw std::runtime_error(std::string("line_lbd_detect (HIP): ") + cs_last_error(ctx));
     for (int i = 0; i < n; i++) { cv::DMatch m; m.queryIdx = qi[i]; m.trainIdx = ti[i]; m.imgIdx = 0; m.distance = (float)di[i]; good_matches.push_back(m); }
+}
+
+extern "C" void line_lbd_detect_hip_release(const void *detector) { // optional: free the device side of one line_lbd_detect (no call on it may be in flight)
+    std::lock_guard<std::mutex> lk(g_mu);
+    auto it = g_dev.find(static_cast<const line_lbd_detect *>(detector));
+    if (it == g_dev.end()) return;
+    if (it->second.lsd) cs_lsd_destroy(it->second.ctx, it->second.lsd);
+    if (it->second.ctx) cs_destroy(it->second.ctx);
+    delete it->second.use;
+    g_dev.erase(it);
 }

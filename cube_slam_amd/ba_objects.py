@@ -5,7 +5,7 @@ The caller hands over the local window as arrays (what adapters/Optimizer_hip.cc
 reference's iteration order; the key-frame selection of :829-913 walks pointer containers and stays on the caller's side):
 
   kf_id, kf_pose (n,7 world-to-camera [t q]), n_local (the first n_local are lLocalKeyFrames, the rest lFixedCameras), cur_cam_center (3)
-  mp_id, mp_pos (m,3), mp_nobs (MapPoint::Observations())
+  mp_id, mp_pos (m,3), mp_nobs (MapPoint::Observations(): nObs, a stereo observation counts twice, MapPoint.cc:78-81)
   obs_mp, obs_kf, obs_uv (o,2), obs_ur (o; < 0 = monocular), obs_inv_sigma2 (o)                 observations by key frames that are not bad
   mo_id, mo_pose (c,7 object-to-world), mo_scale (c,3), mo_meas_quality (c), mo_largest_point_observations (c)
   up_mo, up_pos (u,3), up_count (u)              GetUniqueMapPoints() of each object (not bad) with MapObjObservations[object]
@@ -188,12 +188,13 @@ def LocalBACameraPointObjects(window, params, ctx=None, fixCamera=False, stop_fl
     order = [k for k in range(n_obs) if not stereo[k]] + [k for k in range(n_obs) if stereo[k]]         # vpEdgesMono, then vpEdgesStereo
     rows = g["obs_rows"]
     erase = [(int(window["obs_kf"][rows[k]]), int(window["obs_mp"][rows[k]])) for k in order if bad[k]]
+    erase_stereo = [bool(stereo[k]) for k in order if bad[k]]
     # the reference's write-back re-reads MapPoint::Observations() after the erasures (:1486-1496 before :1509-1516): a point they leave with exactly one
     # observation is NOT written back -- `point_unwritten` lists those rows of mp_*
     left = np.asarray(window["mp_nobs"], int).copy()
-    for _, r in erase:
-        left[r] -= 1
+    for (_, r), st_ in zip(erase, erase_stereo):
+        left[r] -= 2 if st_ else 1  # mp_nobs is MapPoint::Observations() = nObs: a stereo observation counts twice (MapPoint.cc:78-81, 186-189)
     unwritten = [int(r) for r in g["point_rows"] if left[r] == 1]
     return {"kf_pose": fin["cam_pose"][:int(window["n_local"])], "point_pos": {int(r): fin["points"][j] for j, r in enumerate(g["point_rows"])},
-            "object_pose": fin["cuboid_pose"], "object_scale": d["cuboid_scale"], "erase": erase, "point_unwritten": unwritten, "obs_level": obs_level, "cobs_level": cobs_level,
+            "object_pose": fin["cuboid_pose"], "object_scale": d["cuboid_scale"], "erase": erase, "erase_stereo": erase_stereo, "point_unwritten": unwritten, "obs_level": obs_level, "cobs_level": cobs_level,
             "cobs_level2": cobs_level2, "stats": (st1, st2), "graph": g}

@@ -53,7 +53,8 @@ struct cs_ctx {
         const size_t b = pool_bucket(n);
         auto it = pool_free.find(b);
         if (it != pool_free.end()) { *p = it->second; pool_free.erase(it); pool_cached -= b; pool_live[*p] = b; return hipSuccess; }
-        const hipError_t e = hipMalloc(p, b);
+        hipError_t e = hipMalloc(p, b);
+        if (e != hipSuccess && !pool_free.empty()) { (void)hipGetLastError(); pool_drop(); e = hipMalloc(p, b); } // out of memory with blocks of other sizes cached: give those back and ask again
         if (e == hipSuccess) pool_live[*p] = b;
         return e;
     }

@@ -2025,26 +2025,35 @@ int cs_cuboid_batch_set_lines(cs_ctx *ctx, cs_cuboid_batch *b, const int *line_o
     CS_HIP(ctx, hipSetDevice(ctx->device));
     CS_HIP(ctx, hipStreamSynchronize(ctx->stream)); // (a run still reading the old lists)
     const int n_lines = line_offsets[b->n_frames];
-    for (int f = 0; f < b->n_frames; f++) { b->fi[f].line_off = line_offsets[f]; b->fi[f].n_lines = line_offsets[f + 1] - line_offsets[f]; }
+    // the new plan is worked out beside the old one and committed only when every check and allocation has succeeded: a failure leaves the batch as it was
+    std::vector<int> unit_off(b->units.size());
     long rows = 0;
-    for (Unit &U : b->units) { U.line_off = (int)rows; rows += std::min(b->fi[U.frame].n_lines, CS_MAX_ROI_LINES); if (rows > INT_MAX) return CS_ERR_CAPACITY; }
-    b->line_rows = rows;
+    for (size_t u = 0; u < b->units.size(); u++) {
+        const int f = b->units[u].frame;
+        unit_off[u] = (int)rows; rows += std::min(line_offsets[f + 1] - line_offsets[f], CS_MAX_ROI_LINES);
+        if (rows > INT_MAX) return CS_ERR_CAPACITY;
+    }
     int r;
     if (n_lines > b->cap_lines_in) {
-        cs_dfree(ctx, b->d_lines_in); cs_dfree(ctx, b->d_lines_al); b->d_lines_in = b->d_lines_al = nullptr;
         const size_t cap = (size_t)n_lines + n_lines / 4 + 64;
-        r = cs_dalloc(ctx, &b->d_lines_in, cap * 4); if (r) return r;
-        r = cs_dalloc(ctx, &b->d_lines_al, cap * 4); if (r) return r;
-        b->cap_lines_in = (long)cap;
+        double *a = nullptr, *c = nullptr;
+        r = cs_dalloc(ctx, &a, cap * 4); if (r) return r;
+        r = cs_dalloc(ctx, &c, cap * 4); if (r) { cs_dfree(ctx, a); return r; }
+        cs_dfree(ctx, b->d_lines_in); cs_dfree(ctx, b->d_lines_al);
+        b->d_lines_in = a; b->d_lines_al = c; b->cap_lines_in = (long)cap;
     }
     if (rows > b->cap_line_rows) {
-        cs_dfree(ctx, b->d_mlines); cs_dfree(ctx, b->d_mangle); cs_dfree(ctx, b->d_mmid); b->d_mlines = b->d_mangle = b->d_mmid = nullptr;
         const size_t cap = (size_t)rows + rows / 4 + 64;
-        r = cs_dalloc(ctx, &b->d_mlines, cap * 4); if (r) return r;
-        r = cs_dalloc(ctx, &b->d_mangle, cap); if (r) return r;
-        r = cs_dalloc(ctx, &b->d_mmid, cap * 2); if (r) return r;
-        b->cap_line_rows = (long)cap;
+        decltype(b->d_mlines) m1 = nullptr; decltype(b->d_mangle) m2 = nullptr; decltype(b->d_mmid) m3 = nullptr;
+        r = cs_dalloc(ctx, &m1, cap * 4); if (r) return r;
+        r = cs_dalloc(ctx, &m2, cap); if (r) { cs_dfree(ctx, m1); return r; }
+        r = cs_dalloc(ctx, &m3, cap * 2); if (r) { cs_dfree(ctx, m1); cs_dfree(ctx, m2); return r; }
+        cs_dfree(ctx, b->d_mlines); cs_dfree(ctx, b->d_mangle); cs_dfree(ctx, b->d_mmid);
+        b->d_mlines = m1; b->d_mangle = m2; b->d_mmid = m3; b->cap_line_rows = (long)cap;
     }
+    for (int f = 0; f < b->n_frames; f++) { b->fi[f].line_off = line_offsets[f]; b->fi[f].n_lines = line_offsets[f + 1] - line_offsets[f]; }
+    for (size_t u = 0; u < b->units.size(); u++) b->units[u].line_off = unit_off[u];
+    b->line_rows = rows;
     if (n_lines > 0) { r = cs_h2d(ctx, b->d_lines_in, lines, (size_t)n_lines * 4); if (r) return r; }
     r = cs_h2d(ctx, b->d_fi, b->fi.data(), (size_t)b->n_frames); if (r) return r;
     r = cs_h2d(ctx, b->d_units, b->units.data(), (size_t)b->n_units); if (r) return r;

@@ -846,8 +846,8 @@ int cs_lsd_detect_filter_lines(cs_ctx *ctx, cs_lsd *l, const uint8_t *gray, int 
 
 // filter_lines (:200-207) + keylines_to_mat (:26-36) over the KeyLines of the last cs_lsd_run of the resident frames: what detect_filter_lines returns,
 // without a second pass over the images (the chain's hand-over to cs_cuboid_batch_set_lines)
-int cs_lsd_read_filter_lines(cs_ctx *ctx, cs_lsd *l, float length_thres, float *lines, int cap, int *counts) {
-    if (!ctx || !l || !lines || !counts || cap < 1) return CS_ERR_BAD_ARG;
+int cs_lsd_read_filter_lines(cs_ctx *ctx, cs_lsd *l, float length_thres, float *lines, int cap, int *counts, int n_frames) {
+    if (!ctx || !l || !lines || !counts || cap < 1 || n_frames < 0 || (size_t)n_frames < l->keylines.size()) return CS_ERR_BAD_ARG; // (the caller's arrays hold n_frames frames)
     int status = CS_OK;
     for (size_t f = 0; f < l->keylines.size(); f++) {
         int n = 0;

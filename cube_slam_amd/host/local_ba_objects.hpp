@@ -39,6 +39,7 @@ struct LocalBAResult {
     std::vector<int> point_unwritten;                          // of those, the rows the erase list leaves with exactly one observation: the reference does not write them back (:1511-1512 after :1486-1496)
     std::vector<double> object_pose, object_scale;     // objects x 7, x 3
     std::vector<std::pair<int, int>> erase;            // (row of kf_*, row of mp_*)
+    std::vector<uint8_t> erase_stereo;                 // per entry of `erase`: the observation has a right coordinate -- MapPoint::EraseObservation takes 2 off the point's count for it (MapPoint.cc:186-189)
     std::vector<uint8_t> obs_level, cobs_level, cobs_level2; std::vector<int> obs_rows, det_rows;
     std::vector<int> up_used, up_filtered;             // rows of up_*: MapObject::used_points_in_BA (count above the threshold) and used_points_in_BA_filtered (within 3 m)
     cs_ba_stats st1{}, st2{};
@@ -249,18 +250,18 @@ inline void LocalBACameraPointObjects(Context &c, const LocalWindow &w, const Lo
     }
     std::vector<double> chi2, z2;
     residuals(c, d, chi2, z2, cn);
-    out.erase.clear();
+    out.erase.clear(); out.erase_stereo.clear();
     for (int pass = 0; pass < 2; pass++)   // vpEdgesMono first, then vpEdgesStereo (:1445-1475)
         for (size_t o = 0; o < n_obs; o++) {
             const bool stereo = d.obs_ur[o] >= 0;
             if (stereo != (pass == 1)) continue;
             const double chi = out.obs_level[o] == 0 ? chi2[o] : chi1[o]; // a level-1 edge keeps the error of stage 1
-            if (chi > (stereo ? 7.815 : 5.991) || !(z2[o] > 0)) out.erase.emplace_back(w.obs_kf[out.obs_rows[o]], w.obs_mp[out.obs_rows[o]]);
+            if (chi > (stereo ? 7.815 : 5.991) || !(z2[o] > 0)) { out.erase.emplace_back(w.obs_kf[out.obs_rows[o]], w.obs_mp[out.obs_rows[o]]); out.erase_stereo.push_back(stereo ? 1 : 0); }
         }
     out.kf_pose.assign(d.cam_pose.begin(), d.cam_pose.begin() + (size_t)w.n_local * 7);
     out.point_pos = d.points; out.object_pose = d.cuboid_pose;
     std::vector<int> left(w.mp_nobs);
-    for (auto &e : out.erase) left[e.second]--;
+    for (size_t k = 0; k < out.erase.size(); k++) left[out.erase[k].second] -= out.erase_stereo[k] ? 2 : 1; // mp_nobs is MapPoint::Observations() = nObs: a stereo observation counts twice
     out.point_unwritten.clear();
     for (int r : out.point_rows) if (left[r] == 1) out.point_unwritten.push_back(r);
 }

@@ -62,7 +62,7 @@ class line_lbd_detect:
     def read_filter_lines(self, n_frames, cap=1024):
         """detect_filter_lines' rows (x1 y1 x2 y2, float32) for the resident frames, from the KeyLines of the last run()."""
         out = np.zeros((n_frames, cap, 4), np.float32); counts = np.zeros(n_frames, np.int32)
-        check(self.ctx.ptr, lib().cs_lsd_read_filter_lines(self.ctx.ptr, self._l, C.c_float(self.line_length_thres), _p(out, C.c_float), cap, _p(counts, C.c_int)), "cs_lsd_read_filter_lines")
+        check(self.ctx.ptr, lib().cs_lsd_read_filter_lines(self.ctx.ptr, self._l, C.c_float(self.line_length_thres), _p(out, C.c_float), cap, _p(counts, C.c_int), int(n_frames)), "cs_lsd_read_filter_lines")
         return [out[f, :counts[f]] for f in range(n_frames)]
 
     def detect_raw_lines(self, gray):

@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define CS_VERSION 102 /* 102: cs_cuboid_batch_set_lines, cs_cuboid_batch_set_shared_gpu, cs_lsd_read_filter_lines; 101: cs_ba_set_stop_flag_bool / cs_ba_dyn_set_stop_flag_bool; cs_match_by_projection_frame takes train_blocked */
+#define CS_VERSION 103 /* 103: cs_lsd_read_filter_lines takes the caller's frame count; 102: cs_cuboid_batch_set_lines, cs_cuboid_batch_set_shared_gpu, cs_lsd_read_filter_lines; 101: cs_ba_set_stop_flag_bool / cs_ba_dyn_set_stop_flag_bool; cs_match_by_projection_frame takes train_blocked */
 
 typedef enum cs_status {
     CS_OK = 0,
@@ -398,8 +398,9 @@ int cs_lsd_detect(cs_ctx *ctx, cs_lsd *l, const uint8_t *gray, int n_frames, int
 /* detect_filter_lines(gray, linesmat): octave 0, lineLength > length_thres; lines: [f][cap_per_frame][4] floats (CV_32F N x 4) */
 int cs_lsd_detect_filter_lines(cs_ctx *ctx, cs_lsd *l, const uint8_t *gray, int n_frames, int stride, float length_thres,
                                float *lines, int cap_per_frame, int *counts);
-/* the same rows from the KeyLines of the last cs_lsd_run over the resident frames (counts[f] rows of frame f at lines + f * cap * 4) */
-int cs_lsd_read_filter_lines(cs_ctx *ctx, cs_lsd *l, float length_thres, float *lines, int cap, int *counts);
+/* the same rows from the KeyLines of the last cs_lsd_run over the resident frames (counts[f] rows of frame f at lines + f * cap * 4); n_frames: the frames
+ * `lines` and `counts` have room for -- CS_ERR_BAD_ARG when the last run processed more */
+int cs_lsd_read_filter_lines(cs_ctx *ctx, cs_lsd *l, float length_thres, float *lines, int cap, int *counts, int n_frames);
 /* introspection after a detect call: scaled image, gradient norm and level-line angle maps (sw x sh doubles each) */
 int cs_lsd_get_maps(cs_ctx *ctx, cs_lsd *l, int frame, double *scaled, double *modgrad, double *angles, int *sw, int *sh);
 

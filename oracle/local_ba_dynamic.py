@@ -273,8 +273,10 @@ def local_ba_dynamic(pKF, params, fixCamera=False, fixPoint=False):
     order = [k for k in range(n_obs) if not st[k]] + [k for k in range(n_obs) if st[k]]
     erase = [(g["obs_kf"][k].mnId, g["obs_mp"][k].mnId) for k in order if bad[k] and not g["obs_mp"][k].bad]
     n_erased = {}
-    for _, m in erase:
-        n_erased[m] = n_erased.get(m, 0) + 1
+    for k in order:
+        if bad[k] and not g["obs_mp"][k].bad:
+            m = g["obs_mp"][k].mnId
+            n_erased[m] = n_erased.get(m, 0) + (2 if st[k] else 1)  # MapPoint::EraseObservation takes a stereo observation off twice (MapPoint.cc:186-189)
     unwritten = [mp.mnId for mp in g["points"] if mp.Observations() - n_erased.get(mp.mnId, 0) == 1]
     # objects :2493-2533
     frame_pose = {(mo.mnId, kf.mnId): fin["obj_pose"][i] for i, (mo, kf) in enumerate(g["obj_key"])}

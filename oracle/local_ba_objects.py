@@ -50,8 +50,8 @@ class MapPoint:
         self.observations = {}        # KeyFrame -> key point index (insertion order stands in for the std::map order)
         self.MapObjObservations = {}  # MapObject -> count
 
-    def Observations(self):
-        return len(self.observations)
+    def Observations(self):  # nObs: MapPoint::AddObservation counts a stereo observation twice (MapPoint.cc:78-81), EraseObservation takes it back the same way (:186-189)
+        return sum(2 if kf.mvuRight[idx] >= 0 else 1 for kf, idx in self.observations.items())
 
 
 class MapObject:
@@ -263,8 +263,9 @@ def local_ba_camera_point_objects(pKF, params, fixCamera=False):
     erase = [(obs_kf[k].mnId, obs_mp[k].mnId) for k in order if bad[k] and not obs_mp[k].bad]
     # write-back :1509-1516 re-reads Observations() AFTER the erasures (:1486-1496): a point they leave with exactly one observation keeps its old position
     n_erased = {}
-    for _, m in erase:
-        n_erased[m] = n_erased.get(m, 0) + 1
+    for k in order:
+        if bad[k] and not obs_mp[k].bad:
+            n_erased[obs_mp[k].mnId] = n_erased.get(obs_mp[k].mnId, 0) + (2 if st[k] else 1)  # MapPoint.cc:186-189
     unwritten = [mp.mnId for mp in pt_mp if mp.Observations() - n_erased.get(mp.mnId, 0) == 1]
     return {"kf_pose": {k.mnId: fin["cam_pose"][i] for i, k in enumerate(local_kfs)},
             "point_pos": {mp.mnId: fin["points"][j] for j, mp in enumerate(pt_mp)},

@@ -73,7 +73,7 @@ class MapPoint {
     int n_bad_flags = 0;
     void SetBadFlag() { bad = true; n_bad_flags++; } // (the real one also erases the point's observations: map bookkeeping)
     std::map<KeyFrame *, size_t> GetObservations() { return mObservations; }
-    int Observations() { return (int)mObservations.size(); }
+    int Observations(); // nObs: a stereo observation counts twice (MapPoint.cc:78-81, 186-189); defined below KeyFrame
     bool isBad() { return bad; }
     cv::Mat GetWorldPos() { return mWorldPos.clone(); }
     void SetWorldPos(const cv::Mat &p) { p.copyTo(mWorldPos); n_pos_writes++; }
@@ -108,6 +108,7 @@ class KeyFrame {
         for (auto &m : mvpMapPoints) if (m == mp) m = nullptr; // KeyFrame.cc: the slot the point's observation names is set to NULL
     }
 };
+inline int MapPoint::Observations() { int n = 0; for (auto &o : mObservations) n += o.first->mvuRight[o.second] >= 0 ? 2 : 1; return n; }
 inline bool cmpKeyframe::operator()(const KeyFrame *a, const KeyFrame *b) const { return a->mnId < b->mnId; }
 
 class MapObject {
