@@ -383,32 +383,29 @@ def c4_bench(ctx, frames, boxes, yaw_step, steps, with_cpu):
     return out
 
 
-def chained_bench(ctx, ctx_line, orb, lsd, batch, scenes, frames, steps):
-    """The reference's chain (main_obj.cpp:428-449) with the frames resident: every step's detect_cuboid is fed the lines detect_filter_lines
-    found in THAT step (cs_lsd_read_filter_lines -> cs_cuboid_batch_set_lines), beside ORB extraction.  One stream of dependent stages, no
-    overlap between steps: the hand-over goes through the host (KeyLines are assembled there), so this is a lower bound of a chained runner."""
-    lsd.line_length_thres = 15.0  # main_obj.cpp:366
-
-    def step():
-        lsd.run(True)
-        ctx_line.sync()
-        lines = lsd.read_filter_lines(frames)
-        batch.set_lines(lines)
-        if orb is not None:
-            orb.run()
-        batch.run()
-        return lines
-    lines = step()
-    ctx.sync()
+def chained_bench(ctx, fe, lsds, batch, scenes, frames, steps, barrier):
+    """The reference's chain (main_obj.cpp:428-449) with the frames resident, PIPELINED by the runner (cs_frontend_set_chain): every step's detect_cuboid is
+    fed the lines detect_filter_lines found for the same frames in the pass its line worker finished last -- with W workers that pass was submitted W steps
+    earlier, so no step waits for a line pass; the hand-over goes through the host (KeyLines are assembled there) and costs the step one synchronisation
+    of the ORB / cuboid stream.  Same runner, same detectors and batch as the headline; only the edge lists change."""
+    for d_ in lsds:
+        d_.line_length_thres = 15.0  # main_obj.cpp:366
+    fe.set_chain(True, 15.0)
+    for _ in range(2 * len(lsds)):  # every worker's lines have reached the batch
+        fe.step()
+    barrier()
     t0 = time.perf_counter()
     for _ in range(steps):
-        step()
-    ctx.sync()
+        fe.step()
+    barrier()
     dt = time.perf_counter() - t0
     n_out = sum(len(g) for g in batch.read())
+    lines = lsds[0].read_filter_lines(frames)
+    fe.set_chain(False)
     batch.set_lines([s["lines"] for s in scenes])  # back to the decoupled edge lists
     return {"value": frames * steps / dt, "unit": "frames/s", "ms_per_step": 1e3 * dt / steps, "frames": frames, "steps": steps, "lines_per_frame_handed_over": sum(len(l) for l in lines) / frames,
-            "cuboids_out": n_out, "note": "ORB + LSD/LBD + detect_cuboid fed this step's detect_filter_lines output (length > 15), stages in sequence on one stream"}
+            "cuboids_out": n_out, "pipeline_depth_steps": len(lsds),
+            "note": "ORB + LSD/LBD + detect_cuboid fed detect_filter_lines' output (length > 15) of the same frames, the line pass running %d steps ahead of the cuboid pass" % len(lsds)}
 
 
 def pcie_inclusive(ctx, scenes, yaw_step, nfeat, n=24, local_rank=0):
@@ -639,7 +636,7 @@ def main():
         extra["c3"] = c3_bench(ctx, 2 * _lib.lib().cs_host_thread_count(), 3, with_cpu=not args.no_cpu)  # a stream window of two frames per host thread (the region stage's workers)
         extra["c4"] = c4_bench(ctx, 64, 8, args.yaw_step, 10, with_cpu=not args.no_cpu)
         if lsd is not None:
-            extra["chained"] = chained_bench(ctx, ctx_lines[0], orb, lsd, batch, scenes, args.frames, 3)
+            extra["chained"] = chained_bench(ctx, fe, lsds, batch, scenes, args.frames, 10, barrier)
         extra["pcie_inclusive"] = pcie_inclusive(ctx, scenes, args.yaw_step, args.orb_features, local_rank=local_rank)
     else:
         tr = None

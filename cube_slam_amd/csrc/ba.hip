@@ -11,7 +11,7 @@
 //   ba_lin_pose       wave per pose block: sum_obs Jj^T W Jj and Jj^T W r (lane = observation, shuffle-tree reduce)
 //   ba_num_cols       thread per (cuboid edge, perturbed dimension): central difference with delta 1e-9 through the same
 //                     oplus (exp map, exptwist_norollpitch) as g2o's numeric linearizeOplus
-//   ba_lin_pose_edges thread per pose block: camera-cuboid and point-cuboid terms into Hpp / b
+//   ba_lin_pose_edges lane per element of a pose block: camera-cuboid and point-cuboid terms into Hpp / b
 //   ba_lm_dinv        thread per landmark: (Hll + lambda I)^-1 and D^-1 b_l
 //   ba_schur_slots    wave per block of the reduced camera system: Hpp - sum_l B D^-1 B^T (lane = contributing landmark)
 //   ba_schur_b        wave per pose block: b_p - sum B D^-1 b_l
@@ -210,44 +210,56 @@ __global__ void __launch_bounds__(256) ba_lin_pose(Params G, const int *pose_off
     }
 }
 
-// numeric Jacobian columns (base_binary_edge.hpp:216-320, base_unary_edge.hpp:82-123): delta = 1e-9, central difference
+// numeric Jacobian columns (base_binary_edge.hpp:216-320, base_unary_edge.hpp:82-123): delta = 1e-9, central difference.  A lane per (edge, column,
+// SIGN): the even lane evaluates the error at +delta, its odd neighbour at -delta (the two evaluations are the whole cost: se3 exponential, cuboid
+// retraction, projection), the difference is taken by the even lane -- the same two values, the same subtraction.
 __global__ void __launch_bounds__(256) ba_num_cols(Params G) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    const double delta = 1e-9, scalar = 1.0 / (2 * delta);
+    const int tt = blockIdx.x * 256 + threadIdx.x, t = tt >> 1;
+    const bool minus = tt & 1;
+    const double delta = 1e-9, scalar = 1.0 / (2 * delta), dd = minus ? -delta : delta;
+    double ev[4] = {0, 0, 0, 0};
+    int kind = 0, o = 0, d = 0; // 1: camera-cuboid column, 2: point-cuboid column
     if (t < G.n_cobs * 12) {
-        const int o = t / 12, d = t % 12;
+        o = t / 12; d = t % 12;
         const int ci = G.c_cam[o], oi = G.c_cub[o];
-        const SE3 T = se3_load(G.cam + (long)ci * 7);
-        const Cuboid C = load_cuboid(G, oi);
-        double add[6] = {0, 0, 0, 0, 0, 0}, e1[4], e2[4];
-        if (d < 6) { // camera: VertexSE3Expmap::oplusImpl = exp(update) * estimate
-            if (G.cam_idx[ci] < 0) return;
-            add[d] = delta; err_cobs_eval(G, o, se3_mul(se3_exp(add), T), C, e1);
-            add[d] = -delta; err_cobs_eval(G, o, se3_mul(se3_exp(add), T), C, e2);
-        } else {
-            add[d - 6] = delta; err_cobs_eval(G, o, T, cuboid_oplus(C, add, G.cub_flags[oi], G.cub_scale + (long)oi * 3), e1);
-            add[d - 6] = -delta; err_cobs_eval(G, o, T, cuboid_oplus(C, add, G.cub_flags[oi], G.cub_scale + (long)oi * 3), e2);
+        if (d >= 6 || G.cam_idx[ci] >= 0) {
+            kind = 1;
+            const SE3 T = se3_load(G.cam + (long)ci * 7);
+            const Cuboid C = load_cuboid(G, oi);
+            double add[6] = {0, 0, 0, 0, 0, 0};
+            if (d < 6) { add[d] = dd; err_cobs_eval(G, o, se3_mul(se3_exp(add), T), C, ev); } // camera: VertexSE3Expmap::oplusImpl = exp(update) * estimate
+            else { add[d - 6] = dd; err_cobs_eval(G, o, T, cuboid_oplus(C, add, G.cub_flags[oi], G.cub_scale + (long)oi * 3), ev); }
         }
-        for (int k = 0; k < 4; k++) G.Jc[((long)o * 12 + d) * 4 + k] = scalar * (e1[k] - e2[k]);
     } else if (t < G.n_cobs * 12 + G.n_pc * 6) {
-        const int u = t - G.n_cobs * 12, o = u / 6, d = u % 6, oi = G.pc_cub[o];
+        kind = 2;
+        const int u = t - G.n_cobs * 12;
+        o = u / 6; d = u % 6;
+        const int oi = G.pc_cub[o];
         const Cuboid C = load_cuboid(G, oi);
-        double add[6] = {0, 0, 0, 0, 0, 0}, e1[3], e2[3];
-        add[d] = delta; err_pc_eval(G, o, cuboid_oplus(C, add, G.cub_flags[oi], G.cub_scale + (long)oi * 3), e1);
-        add[d] = -delta; err_pc_eval(G, o, cuboid_oplus(C, add, G.cub_flags[oi], G.cub_scale + (long)oi * 3), e2);
-        for (int k = 0; k < 3; k++) G.Jp[((long)o * 6 + d) * 3 + k] = scalar * (e1[k] - e2[k]);
+        double add[6] = {0, 0, 0, 0, 0, 0};
+        add[d] = dd; err_pc_eval(G, o, cuboid_oplus(C, add, G.cub_flags[oi], G.cub_scale + (long)oi * 3), ev);
     }
+    double em[4];
+#pragma unroll
+    for (int k = 0; k < 4; k++) em[k] = __shfl_xor(ev[k], 1); // the other sign's errors (both lanes of a pair take the same branch)
+    if (minus) return;
+    if (kind == 1) for (int k = 0; k < 4; k++) G.Jc[((long)o * 12 + d) * 4 + k] = scalar * (ev[k] - em[k]);
+    else if (kind == 2) for (int k = 0; k < 3; k++) G.Jp[((long)o * 6 + d) * 3 + k] = scalar * (ev[k] - em[k]);
 }
 
-// thread per pose block: adds the camera-cuboid / point-cuboid terms (constructQuadraticForm) in edge order; thread per
-// camera-cuboid edge: the off-diagonal Hpp block.  pe_off/pe_list: per pose block, incident edges encoded as
-// (edge << 2) | kind, kind 0 = cobs seen from the camera, 1 = cobs seen from the cuboid, 2 = point-cuboid edge
+// A lane per ELEMENT of a pose block (36 of H, 6 of b; a wave per pose): adds the camera-cuboid / point-cuboid terms (constructQuadraticForm) in edge
+// order -- every element is the same sum in the same order as with a thread per block, 42 lanes wide instead of a chain of 42 accumulators per thread
+// (1500 threads had the six workgroups of the launch walk their edge lists alone: 71 us).  The same for the off-diagonal Hpp block of a
+// camera-cuboid edge: a lane per element.  pe_off/pe_list: per pose block, incident edges encoded as (edge << 2) | kind, kind 0 = cobs seen from
+// the camera, 1 = cobs seen from the cuboid, 2 = point-cuboid edge
 __global__ void __launch_bounds__(256) ba_lin_pose_edges(Params G, const int *pe_off, const int *pe_list) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
-    if (t < G.P) {
-        double H[36], b[6];
-        for (int k = 0; k < 36; k++) H[k] = G.Hpp[(long)t * 36 + k];
-        for (int k = 0; k < 6; k++) b[k] = G.bp[(long)t * 6 + k];
+    const int wave = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (wave < G.P) {
+        const int t = wave;
+        if (lane >= 42) return;
+        const bool isb = lane >= 36;
+        const int a = isb ? lane - 36 : lane / 6, c = isb ? 0 : lane % 6;
+        double acc = isb ? G.bp[(long)t * 6 + a] : G.Hpp[(long)t * 36 + lane];
         for (int q = pe_off[t]; q < pe_off[t + 1]; q++) {
             const int kind = pe_list[q] & 3, o = pe_list[q] >> 2;
             if (kind < 2) {
@@ -255,29 +267,25 @@ __global__ void __launch_bounds__(256) ba_lin_pose_edges(Params G, const int *pe
                 const double *e = G.e_cobs + (long)o * 4, *w = G.c_info + (long)o * 4;
                 double rw = 1.0;
                 if (G.huber_obj > 0) { double rho[3]; huber(((e[0] * w[0] * e[0] + e[1] * w[1] * e[1]) + e[2] * w[2] * e[2]) + e[3] * w[3] * e[3], G.huber_obj, rho); rw = rho[1]; }
-                for (int a = 0; a < 6; a++) {
-                    double sb = 0;
-                    for (int k = 0; k < 4; k++) sb += J[a * 4 + k] * (-w[k] * e[k] * rw);
-                    b[a] += sb;
-                    for (int c = 0; c < 6; c++) { double sh = 0; for (int k = 0; k < 4; k++) sh += (J[a * 4 + k] * (rw * w[k])) * J[c * 4 + k]; H[a * 6 + c] += sh; }
-                }
+                if (isb) { double sb = 0; for (int k = 0; k < 4; k++) sb += J[a * 4 + k] * (-w[k] * e[k] * rw); acc += sb; }
+                else { double sh = 0; for (int k = 0; k < 4; k++) sh += (J[a * 4 + k] * (rw * w[k])) * J[c * 4 + k]; acc += sh; }
             } else {
                 const double *J = G.Jp + (long)o * 18, *e = G.e_pc + (long)o * 3; // information = I, no kernel
-                for (int a = 0; a < 6; a++) {
-                    b[a] += ((J[a * 3] * -e[0]) + (J[a * 3 + 1] * -e[1])) + (J[a * 3 + 2] * -e[2]);
-                    for (int c = 0; c < 6; c++) H[a * 6 + c] += ((J[a * 3] * J[c * 3]) + (J[a * 3 + 1] * J[c * 3 + 1])) + (J[a * 3 + 2] * J[c * 3 + 2]);
-                }
+                if (isb) acc += ((J[a * 3] * -e[0]) + (J[a * 3 + 1] * -e[1])) + (J[a * 3 + 2] * -e[2]);
+                else acc += ((J[a * 3] * J[c * 3]) + (J[a * 3 + 1] * J[c * 3 + 1])) + (J[a * 3 + 2] * J[c * 3 + 2]);
             }
         }
-        for (int k = 0; k < 36; k++) G.Hpp[(long)t * 36 + k] = H[k];
-        for (int k = 0; k < 6; k++) G.bp[(long)t * 6 + k] = b[k];
-    } else if (t < G.P + G.n_cobs) {
-        const int o = t - G.P;
-        if (G.cam_idx[G.c_cam[o]] < 0) return;
+        if (isb) G.bp[(long)t * 6 + a] = acc; else G.Hpp[(long)t * 36 + lane] = acc;
+    } else if (wave < G.P + G.n_cobs) {
+        const int o = wave - G.P;
+        if (lane >= 36 || G.cam_idx[G.c_cam[o]] < 0) return;
+        const int a = lane / 6, c = lane % 6;
         const double *Ja = G.Jc + (long)o * 48, *Jb = Ja + 24, *e = G.e_cobs + (long)o * 4, *w = G.c_info + (long)o * 4;
         double rw = 1.0;
         if (G.huber_obj > 0) { double rho[3]; huber(((e[0] * w[0] * e[0] + e[1] * w[1] * e[1]) + e[2] * w[2] * e[2]) + e[3] * w[3] * e[3], G.huber_obj, rho); rw = rho[1]; }
-        for (int a = 0; a < 6; a++) for (int c = 0; c < 6; c++) { double sh = 0; for (int k = 0; k < 4; k++) sh += (Ja[a * 4 + k] * (rw * w[k])) * Jb[c * 4 + k]; G.Hoff[(long)o * 36 + a * 6 + c] = sh; }
+        double sh = 0;
+        for (int k = 0; k < 4; k++) sh += (Ja[a * 4 + k] * (rw * w[k])) * Jb[c * 4 + k];
+        G.Hoff[(long)o * 36 + lane] = sh;
     }
 }
 
@@ -1428,8 +1436,8 @@ static int ba_build_system(cs_ctx *ctx, cs_ba *b) { // BlockSolver::buildSystem
     if (nl > 0) CS_LAUNCH(ctx, "ba_lin_lm", ba_lin_lm, dim3((nl + 255) / 256), dim3(256), 0, G);
     if (G.P > 0) CS_LAUNCH(ctx, "ba_lin_pose", ba_lin_pose, dim3(G.P), dim3(256), 0, G, b->d_pose_off, b->d_pose_obs);
     if (G.pose_edges && G.n_cobs + G.n_pc > 0) {
-        CS_LAUNCH(ctx, "ba_num_cols", ba_num_cols, dim3((G.n_cobs * 12 + G.n_pc * 6 + 255) / 256), dim3(256), 0, G);
-        CS_LAUNCH(ctx, "ba_lin_pose_edges", ba_lin_pose_edges, dim3((G.P + G.n_cobs + 255) / 256), dim3(256), 0, G, b->d_pe_off, b->d_pe_list);
+        CS_LAUNCH(ctx, "ba_num_cols", ba_num_cols, dim3((2 * (G.n_cobs * 12 + G.n_pc * 6) + 255) / 256), dim3(256), 0, G); // a lane per (edge, column, sign)
+        CS_LAUNCH(ctx, "ba_lin_pose_edges", ba_lin_pose_edges, dim3((G.P + G.n_cobs + 3) / 4), dim3(256), 0, G, b->d_pe_off, b->d_pe_list); // a wave per pose block / per camera-cuboid edge
     }
     return CS_OK;
 }

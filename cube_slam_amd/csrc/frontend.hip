@@ -25,6 +25,8 @@ void cs_lsd_set_shared_gpu(cs_lsd *l, int shared);                              
 extern "C" int cs_orb_run(cs_ctx *ctx, cs_orb *e);
 extern "C" int cs_cuboid_batch_run(cs_ctx *ctx, cs_cuboid_batch *b);
 extern "C" int cs_cuboid_batch_set_shared_gpu(cs_cuboid_batch *b, int shared);
+extern "C" int cs_cuboid_batch_set_lines(cs_ctx *ctx, cs_cuboid_batch *b, const int *line_offsets, const double *lines);
+int cs_lsd_filter_lines_packed(cs_lsd *l, float length_thres, std::vector<int> &offsets, std::vector<double> &lines); // lsd.hip
 
 namespace {
 struct Gate { // phase gate of one runner: tickets are pass numbers, the gate is open for every ticket <= target
@@ -92,6 +94,10 @@ struct cs_frontend {
     unsigned long step_no = 0;
     Gate gate;
     unsigned long in_phase = 0; // passes submitted since the gate last opened
+    // chained mode (cs_frontend_set_chain): detect_cuboid of a pass is fed the lines detect_filter_lines found in the pass the same worker finished
+    // last -- the reference's chain (main_obj.cpp:428-449), pipelined: the line pass of a batch runs W steps ahead of the batch's cuboid pass
+    bool chain = false; float chain_thres = 0;
+    std::vector<char> worker_ran; std::vector<int> chain_off; std::vector<double> chain_lines;
     int open_gate() { // caller's stream idle -> region stages of every waiting pass -> return when they have left the GPU
         const int r = hipStreamSynchronize(ctx->stream) == hipSuccess ? CS_OK : CS_ERR_HIP; // (the gate opens either way: a waiting pass must not be left behind)
         std::unique_lock<std::mutex> lk(gate.m);
@@ -126,9 +132,21 @@ int cs_frontend_create(cs_ctx *ctx, cs_orb *orb, cs_cuboid_batch *batch, int n_l
 
 int cs_frontend_step(cs_frontend *fe) {
     if (!fe) return CS_ERR_BAD_ARG;
-    if (!fe->workers.empty()) fe->workers[fe->step_no % fe->workers.size()]->submit();
-    fe->step_no++;
     int r = CS_OK;
+    if (!fe->workers.empty()) {
+        const size_t wi = fe->step_no % fe->workers.size();
+        LineWorker *w = fe->workers[wi];
+        if (fe->chain && fe->batch && fe->worker_ran.size() > wi && fe->worker_ran[wi]) { // the pass this worker ran W steps ago: its lines are this step's edges
+            r = w->wait();
+            if (r == CS_OK) r = cs_lsd_filter_lines_packed(w->lsd, fe->chain_thres, fe->chain_off, fe->chain_lines);
+            if (r == CS_OK) r = cs_cuboid_batch_set_lines(fe->ctx, fe->batch, fe->chain_off.data(), fe->chain_lines.data());
+            if (r != CS_OK) return r;
+        }
+        w->submit();
+        if (fe->worker_ran.size() <= wi) fe->worker_ran.resize(fe->workers.size(), 0);
+        fe->worker_ran[wi] = 1;
+    }
+    fe->step_no++;
     if (fe->orb) r = cs_orb_run(fe->ctx, fe->orb);
     if (r == CS_OK && fe->batch) r = cs_cuboid_batch_run(fe->ctx, fe->batch);
     if (fe->gate.phased && !fe->workers.empty() && ++fe->in_phase >= fe->workers.size()) { const int g = fe->open_gate(); if (r == CS_OK) r = g; }
@@ -142,6 +160,17 @@ int cs_frontend_set_phased(cs_frontend *fe, int on) {
     fe->gate.phased = on != 0;
     if (fe->batch) cs_cuboid_batch_set_shared_gpu(fe->batch, !on && !fe->workers.empty()); // phased: the score kernel never meets a region walk
     for (LineWorker *w : fe->workers) cs_lsd_set_shared_gpu(w->lsd, !on && fe->workers.size() > 1); // phased: sixteen frames per CU, the walks packed
+    return r;
+}
+
+// on != 0: from now on a step's cuboid pass takes its edge lists from the line pass the step's worker finished last (filter_lines with `length_thres`,
+// main_obj.cpp:366) -- with W workers the lines of a batch are ready W steps before its cuboids are asked for, and nothing waits.  The first W steps
+// after the switch still run on the lists the batch was created with.  Needs a batch and at least one line worker.
+int cs_frontend_set_chain(cs_frontend *fe, int on, float length_thres) {
+    if (!fe || (on && (!fe->batch || fe->workers.empty()))) return CS_ERR_BAD_ARG;
+    const int r = cs_frontend_drain(fe);
+    fe->chain = on != 0; fe->chain_thres = length_thres;
+    fe->worker_ran.assign(fe->workers.size(), 0);
     return r;
 }
 

@@ -901,6 +901,18 @@ int cs_lsd_get_maps(cs_ctx *ctx, cs_lsd *l, int frame, double *scaled, double *m
 
 } // extern "C"
 
+// internal (frontend.hip): filter_lines (:200-207) + keylines_to_mat (:26-36) over the KeyLines of the last run as cs_cuboid_batch_set_lines wants them
+int cs_lsd_filter_lines_packed(cs_lsd *l, float length_thres, std::vector<int> &offsets, std::vector<double> &lines) {
+    if (!l) return CS_ERR_BAD_ARG;
+    offsets.assign(l->keylines.size() + 1, 0); lines.clear();
+    for (size_t f = 0; f < l->keylines.size(); f++) {
+        for (const cs_keyline &k : l->keylines[f])
+            if (k.octave == 0 && k.lineLength > length_thres) { lines.push_back((double)(k.startPointX * 1.f)); lines.push_back((double)(k.startPointY * 1.f)); lines.push_back((double)(k.endPointX * 1.f)); lines.push_back((double)(k.endPointY * 1.f)); }
+        offsets[f + 1] = (int)(lines.size() / 4);
+    }
+    if (lines.empty()) lines.push_back(0.0); // (a valid pointer for an empty hand-over)
+    return CS_OK;
+}
 // internal (frontend.hip): the runner's phase gate around the region stage; wait() is called before it, done() once lsd_rg_seq has left the GPU
 void cs_lsd_set_gate(cs_lsd *l, void (*wait)(void *), void (*done)(void *), void *arg) { l->gate_wait = wait; l->gate_done = done; l->gate_arg = arg; }
 // shared: other detectors' walks and the other streams' kernels keep every CU busy anyway (the alternating front-end runner): the region stage spreads over the chip

@@ -23,6 +23,10 @@ class Frontend:
     def set_phased(self, on):
         check(self.ctx.ptr, lib().cs_frontend_set_phased(self._fe, 1 if on else 0), "cs_frontend_set_phased")
 
+    def set_chain(self, on, length_thres=15.0):
+        """The reference's chain, pipelined: a step's cuboid pass takes the lines its line worker's last pass found (cs_frontend_set_chain)."""
+        check(self.ctx.ptr, lib().cs_frontend_set_chain(self._fe, 1 if on else 0, C.c_float(length_thres)), "cs_frontend_set_chain")
+
     def step(self):
         check(self.ctx.ptr, lib().cs_frontend_step(self._fe), "cs_frontend_step")
 

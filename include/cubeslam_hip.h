@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define CS_VERSION 103 /* 103: cs_lsd_read_filter_lines takes the caller's frame count; 102: cs_cuboid_batch_set_lines, cs_cuboid_batch_set_shared_gpu, cs_lsd_read_filter_lines; 101: cs_ba_set_stop_flag_bool / cs_ba_dyn_set_stop_flag_bool; cs_match_by_projection_frame takes train_blocked */
+#define CS_VERSION 103 /* 103: cs_lsd_read_filter_lines takes the caller's frame count, cs_frontend_set_chain; 102: cs_cuboid_batch_set_lines, cs_cuboid_batch_set_shared_gpu, cs_lsd_read_filter_lines; 101: cs_ba_set_stop_flag_bool / cs_ba_dyn_set_stop_flag_bool; cs_match_by_projection_frame takes train_blocked */
 
 typedef enum cs_status {
     CS_OK = 0,
@@ -455,6 +455,10 @@ int cs_frontend_drain(cs_frontend *fe);
  * (or at cs_frontend_drain) the region stages of all of them run together while `ctx`'s stream is idle -- that cs_frontend_step
  * returns when they have left the GPU.  The cuboid score kernel and the one-wave-per-frame region kernel then never share a CU. */
 int cs_frontend_set_phased(cs_frontend *fe, int on);
+/* The reference's chain (object_slam/src/main_obj.cpp:428-449: detect_cuboid consumes this frame's detect_filter_lines) as a pipeline: on != 0 makes
+ * every step hand the lines of the pass its line worker finished last (octave 0, lineLength > length_thres) to the cuboid batch before that batch
+ * runs; with W workers a batch's lines are W steps old, so no step waits for a line pass.  Needs a cuboid batch and >= 1 line worker. */
+int cs_frontend_set_chain(cs_frontend *fe, int on, float length_thres);
 void cs_frontend_destroy(cs_frontend *fe);
 
 /* ===================================================================== 9-dof g2o::cuboid of object_slam

@@ -77,3 +77,51 @@ def test_frontend_phased_passes(ctx, oracle, monkeypatch):
     # a detector that was under a runner runs on its own afterwards
     lsds[0].run(); kl, _ = lsds[0].read(0)
     assert kl.tobytes() == oracle.lsd_detect(scenes[0]["gray"]).tobytes()
+
+
+def test_frontend_chain_is_the_reference_chain_pipelined(ctx, oracle):
+    """cs_frontend_set_chain: a step's cuboid pass is fed the lines detect_filter_lines found in the pass its line worker finished last (the reference's
+    chain, object_slam/src/main_obj.cpp:428-449, with the line pass running W steps ahead).  After the first W steps every frame's cuboids equal the
+    sequential chain (line pass, hand-over, cuboid pass) on the same frames, and the oracle's chain on a frame."""
+    scenes = [synth.cuboid_scene(700 + i, n_boxes=2, bg_texture=0.5) for i in range(5)]
+    gray = np.stack([s["gray"] for s in scenes])
+    det = detect_3d_cuboid(ctx); det.set_calibration(scenes[0]["K"])
+    args = (gray, scenes[0]["K"], np.stack([s["Twc"] for s in scenes]), [s["boxes"] for s in scenes])
+    batch = CuboidBatch(ctx, *args, [s["lines"] for s in scenes], det.opts())
+    batch.run()
+    decoupled = batch.read()
+    lctx = [_lib.Context(0) for _ in range(3)]
+    lsds = [line_lbd_detect(640, 480, max_frames=len(scenes), ctx=c) for c in lctx]
+    for d in lsds:
+        d.upload(gray)
+        d.line_length_thres = 15.0
+    # the sequential chain
+    lsds[0].run(False)
+    lines = lsds[0].read_filter_lines(len(scenes))
+    seq = CuboidBatch(ctx, *args, [np.asarray(l, np.float64) for l in lines], det.opts())
+    seq.run()
+    want = seq.read()
+    seq.close()
+    fe = Frontend(ctx, orb=None, batch=batch, line_detectors=lsds)
+    fe.set_chain(True, 15.0)
+    for k in range(3):  # the workers' first passes: the batch still runs on the lists it was created with
+        fe.step()
+    ctx.sync()
+    first = batch.read()
+    assert all(len(a) == len(b) and (len(a) == 0 or np.array_equal(a["box_corners_2d"], b["box_corners_2d"])) for a, b in zip(first, decoupled))
+    for k in range(4):
+        fe.step()
+    fe.drain(); ctx.sync()
+    got = batch.read()
+    differs = 0
+    for a, b, c in zip(got, want, decoupled):
+        assert len(a) == len(b) and (len(a) == 0 or (np.array_equal(a["box_corners_2d"], b["box_corners_2d"]) and np.array_equal(a["normalized_error"], b["normalized_error"])))
+        differs += len(a) != len(c) or (len(a) > 0 and not np.array_equal(a["box_corners_2d"], c["box_corners_2d"]))
+    assert differs > 0, "the handed-over lines change some cuboid"
+    s = scenes[1]
+    ref, _ = oracle.detect_cuboid(s["gray"], s["K"], s["Twc"], s["boxes"], np.asarray(oracle.lsd_detect_filter_lines(s["gray"], 15.0), np.float64), opts=oracle.cuboid_opts())
+    off = sum(len(x["boxes"]) for x in scenes[:1])
+    for k, r in enumerate(ref):
+        assert len(got[off + k]) == len(r) and np.array_equal(got[off + k]["box_corners_2d"], r["box_corners_2d"])
+    fe.set_chain(False)
+    fe.close()
