@@ -2,7 +2,7 @@
 import numpy as np
 import pytest
 
-from cube_slam_amd import synth
+from cube_slam_amd import _lib, synth
 from cube_slam_amd.ba import BundleAdjuster
 
 pytestmark = pytest.mark.gpu
@@ -191,6 +191,72 @@ def test_allreduce_callback_on_device_pointer(ctx, small):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+def test_two_ranks_on_one_gpu_sum_to_the_single_rank_solve(small):
+    """The sharded BA with world = 2 on ONE GPU: two cs_ba instances (rank 0 and rank 1, each with its own context = stream) driven in lock-step by two
+    threads; their cs_ba_set_allreduce callbacks meet at a barrier and add the two device buffers in place (what ncclAllReduce(ncclSum) does between two
+    GPUs).  Proves on hardware that the shard systems sum to the single-rank system: same LM trace, same estimates on both ranks as one rank alone.
+    (tests/test_rccl_gpu.py runs the same split over RCCL when two GPUs are visible.)"""
+    import threading
+
+    import torch
+
+    class _Dev:
+        def __init__(self, ptr, n):
+            self.__cuda_array_interface__ = {"shape": (n,), "typestr": "<f8", "data": (ptr, False), "version": 3}
+
+    one = BundleAdjuster(small, ctx=_lib.Context(0))
+    st_one = one.optimize(4); cam_one, pts_one, cub_one = one.read(); one.close()
+
+    meet = threading.Barrier(2, timeout=60)
+    slot = [None, None]
+    n_calls = [0, 0]
+
+    def make_allreduce(rank):
+        def allreduce(ptr, n):  # the library drained its stream before the call
+            slot[rank] = torch.as_tensor(_Dev(ptr, n), device="cuda")
+            meet.wait()
+            if rank == 0:
+                total = slot[0] + slot[1]
+                slot[0].copy_(total); slot[1].copy_(total)
+                torch.cuda.synchronize()
+            meet.wait()
+            n_calls[rank] += 1
+        return allreduce
+
+    out = [None, None]
+    err = []
+
+    def run(rank):
+        try:
+            ba = BundleAdjuster(small, ctx=_lib.Context(0), rank=rank, world=2, allreduce=make_allreduce(rank))
+            st = ba.optimize(4)
+            out[rank] = (st, *ba.read())
+            ba.close()
+        except Exception as e:  # pragma: no cover
+            err.append(e)
+            meet.abort()
+
+    th = [threading.Thread(target=run, args=(r,)) for r in range(2)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join(120)
+    assert not err, err
+    assert n_calls[0] == n_calls[1] and n_calls[0] >= 4
+    (st0, cam0, pts0, cub0), (st1, cam1, pts1, cub1) = out
+    assert st0["iterations"] == st1["iterations"] == st_one["iterations"] and st0["lm_trials"] == st_one["lm_trials"]
+    assert st0["chi2_trace"] == st1["chi2_trace"], "the ranks hold the same sums bit for bit"
+    # one rank alone adds the same terms in another order (per-rank partial sums first); the numeric Jacobians (delta = 1e-9) carry that round-off
+    # into the iterates: first chi2 to 1e-14, the fourth to 1e-8 -- the level the reference's own text moves at when its heap layout changes
+    assert abs(st0["chi2_trace"][0] - st_one["chi2_trace"][0]) <= 1e-12 * st_one["chi2_trace"][0]
+    assert np.allclose(st0["chi2_trace"], st_one["chi2_trace"], rtol=1e-6)
+    assert np.array_equal(cam0, cam1) and np.array_equal(cub0, cub1)
+    assert np.allclose(cam0, cam_one, rtol=0, atol=1e-5) and np.allclose(cub0, cub_one, rtol=0, atol=1e-5)
+    from cube_slam_amd.ba import shard_landmarks
+    lo1, hi1 = shard_landmarks(len(small["points"]), 1, 2)
+    assert np.allclose(pts0[:lo1], pts_one[:lo1], rtol=0, atol=1e-5) and np.allclose(pts1[lo1:hi1], pts_one[lo1:hi1], rtol=0, atol=1e-5), "every rank owns its landmarks' estimates"
 
 
 def test_stereo_edges_match_oracle(ctx, oracle):
