@@ -8,6 +8,11 @@
 // flattened into cubeslam::LocalWindow, and handed to cube_slam_amd/host/local_ba_objects.hpp, which holds the graph-level rules (which points
 // and objects enter, information weights, the 5 + 10 two-stage scheme with re-levelling) -- the C++ twin of cube_slam_amd/ba_objects.py, both
 // tested against the oracle's restatement (tests/test_local_ba_objects.py).  Write-back and erasure as :1477-1533.
+//
+// Also here, with the reference's signatures (include/Optimizer.h:42-51): Optimizer::GlobalBundleAdjustemnt (:57-62: all key frames and map points into
+// BundleAdjustment), Optimizer::LocalBundleAdjustment (:474-825: the same window and two-stage scheme as LocalBACameraPointObjects without the objects -- the
+// fallback LocalMapping.cc:74 takes when no object BA is wanted) and Optimizer::PoseOptimization(Frame *) (:253-472: the frame's matches flattened into
+// cs_pose_optimization, which runs the 4 x 10 rounds with the re-classification in between; three calls per frame, Tracking.cc:1180,1321,1366).
 #include "Optimizer.h"
 
 #include <map>
@@ -15,6 +20,7 @@
 #include <vector>
 
 #include "Converter.h"
+#include "Frame.h"
 #include "cubeslam_hip.h"
 #include "cube_slam_amd/host/local_ba_objects.hpp"
 #include "MapObject.h"
@@ -137,8 +143,10 @@ void Optimizer::BundleAdjustment(const std::vector<KeyFrame *> &vpKFs, const std
 }
 
 
-void Optimizer::LocalBACameraPointObjects(KeyFrame *pKF, bool *pbStopFlag, Map *pMap, bool fixCamera, bool fixPoint) {
-    if (fixPoint) throw std::runtime_error("LocalBACameraPointObjects (HIP): fixPoint is not supported (LocalMapping.cc:68 passes false)");
+namespace {
+// the window BA of LocalBACameraPointObjects (with_objects) and of LocalBundleAdjustment (!with_objects: :474-825 is the same function without the object
+// vertices and edges; what differs is noted where it differs)
+void local_window_ba(KeyFrame *pKF, bool *pbStopFlag, Map *pMap, bool fixCamera, bool with_objects) {
     // ---- the window :829-913 (pointer walking stays here; the marker fields are the reference's)
     std::vector<KeyFrame *> lLocalKeyFrames{pKF};
     pKF->mnBALocalForKF = pKF->mnId;
@@ -151,6 +159,7 @@ void Optimizer::LocalBACameraPointObjects(KeyFrame *pKF, bool *pbStopFlag, Map *
                 lLocalMapPoints.push_back(pMP); pMP->mnBALocalForKF = pKF->mnId;
             }
     std::vector<MapObject *> lLocalMapObjects;
+    if (with_objects)
     for (KeyFrame *k : lLocalKeyFrames)
         for (MapObject *pMO : k->cuboids_landmark)
             if (pMO && !pMO->isBad() && pMO->mnBALocalForKF != pKF->mnId) { lLocalMapObjects.push_back(pMO); pMO->mnBALocalForKF = pKF->mnId; }
@@ -179,6 +188,7 @@ void Optimizer::LocalBACameraPointObjects(KeyFrame *pKF, bool *pbStopFlag, Map *
         for (auto &ob : pMP->GetObservations()) {
             KeyFrame *pKFi = ob.first;
             if (pKFi->isBad()) continue;
+            if (!with_objects && pKFi->KeysStatic.size() > 0 && !pKFi->KeysStatic[ob.second]) continue; // :603-607 (LocalBundleAdjustment only): a dynamic 2D feature
             const cv::KeyPoint &kpUn = pKFi->mvKeysUn[ob.second];
             w.obs_mp.push_back((int)j); w.obs_kf.push_back(kf_row.at(pKFi)); w.obs_uv.push_back(kpUn.pt.x); w.obs_uv.push_back(kpUn.pt.y);
             w.obs_ur.push_back(pKFi->mvuRight[ob.second] < 0 ? -1.0 : (double)pKFi->mvuRight[ob.second]);
@@ -239,7 +249,7 @@ void Optimizer::LocalBACameraPointObjects(KeyFrame *pKF, bool *pbStopFlag, Map *
         for (int a = 0; a < 3; a++) X.at<float>(a) = (float)res.point_pos[k * 3 + a];
         pMP->SetWorldPos(X); pMP->UpdateNormalAndDepth();
     }
-    for (KeyFrame *k : lFixedCameras) { k->mnBAFixedForKF = 0; k->mnBALocalForKF = 0; }
+    for (KeyFrame *k : lFixedCameras) { k->mnBAFixedForKF = 0; if (with_objects) k->mnBALocalForKF = 0; } // (:1521-1523 resets both marks, :820-824 the first)
     for (size_t i = 0; i < lLocalMapObjects.size(); i++) {
         MapObject *pMO = lLocalMapObjects[i];
         pMO->mnBALocalForKF = 0; pMO->obj_been_optimized = true;
@@ -250,6 +260,60 @@ void Optimizer::LocalBACameraPointObjects(KeyFrame *pKF, bool *pbStopFlag, Map *
         for (int a = 0; a < 3; a++) cube.scale[a] = res.object_scale[i * 3 + a];
         pMO->SetWorldPos(cube);
     }
+}
+} // namespace
+
+void Optimizer::LocalBACameraPointObjects(KeyFrame *pKF, bool *pbStopFlag, Map *pMap, bool fixCamera, bool fixPoint) {
+    if (fixPoint) throw std::runtime_error("LocalBACameraPointObjects (HIP): fixPoint is not supported (LocalMapping.cc:68 passes false)");
+    local_window_ba(pKF, pbStopFlag, pMap, fixCamera, true);
+}
+
+void Optimizer::LocalBundleAdjustment(KeyFrame *pKF, bool *pbStopFlag, Map *pMap) { local_window_ba(pKF, pbStopFlag, pMap, false, false); }
+
+void Optimizer::GlobalBundleAdjustemnt(Map *pMap, int nIterations, bool *pbStopFlag, const unsigned long nLoopKF, const bool bRobust) { // :57-62
+    const std::vector<KeyFrame *> vpKFs = pMap->GetAllKeyFrames();
+    const std::vector<MapPoint *> vpMP = pMap->GetAllMapPoints();
+    BundleAdjustment(vpKFs, vpMP, nIterations, pbStopFlag, nLoopKF, bRobust);
+}
+
+int Optimizer::PoseOptimization(Frame *pFrame) {
+    // ---- the unary edges :283-379, in key point order (the engine keeps mono and stereo apart like vpEdgesMono / vpEdgesStereo)
+    const int N = pFrame->N;
+    std::vector<int> idx;
+    std::vector<double> Xw, obs, w;
+    int nInitialCorrespondences = 0, n_no_edge = 0;
+    {
+        std::unique_lock<std::mutex> lock(MapPoint::mGlobalMutex);
+        for (int i = 0; i < N; i++) {
+            MapPoint *pMP = pFrame->mvpMapPoints[i];
+            if (!pMP) continue;
+            if (whether_dynamic_object && pMP->is_dynamic) continue;
+            const bool mono = pFrame->mvuRight[i] < 0;
+            nInitialCorrespondences++;
+            pFrame->mvbOutlier[i] = false;
+            if (mono && pFrame->KeysStatic.size() > 0 && !pFrame->KeysStatic[i]) { n_no_edge++; continue; } // :305-309: counted, never an edge (so never an outlier)
+            const cv::KeyPoint &kpUn = pFrame->mvKeysUn[i];
+            const cv::Mat X = pMP->GetWorldPos();
+            idx.push_back(i);
+            for (int a = 0; a < 3; a++) Xw.push_back(X.at<float>(a));
+            obs.push_back(kpUn.pt.x); obs.push_back(kpUn.pt.y); obs.push_back(mono ? -1.0 : (double)pFrame->mvuRight[i]);
+            w.push_back(pFrame->mvInvLevelSigma2[kpUn.octave]);
+        }
+    }
+    if (nInitialCorrespondences < 3) return 0; // :381-382
+    const int edge_off[2] = {0, (int)idx.size()};
+    const double intr[5] = {pFrame->fx, pFrame->fy, pFrame->cx, pFrame->cy, pFrame->mbf};
+    double pose_in[7], pose_out[7];
+    pose_to_vec7(pFrame->mTcw, pose_in);
+    std::vector<uint8_t> outlier(idx.size() + 1, 0);
+    int n_inliers = 0;
+    if (Xw.empty()) { Xw.assign(3, 0.0); obs.assign(3, 0.0); w.assign(1, 0.0); }
+    cs_ctx *ctx = shared_ctx();
+    if (cs_pose_optimization(ctx, 1, edge_off, Xw.data(), obs.data(), w.data(), intr, pose_in, pose_out, outlier.data(), &n_inliers) != CS_OK)
+        throw std::runtime_error(std::string("Optimizer (HIP): ") + cs_last_error(ctx));
+    for (size_t k = 0; k < idx.size(); k++) pFrame->mvbOutlier[idx[k]] = outlier[k] != 0; // :400-445
+    pFrame->SetPose(vec7_to_pose(pose_out));                                                // :466-469
+    return n_inliers + n_no_edge;                                                           // nInitialCorrespondences - nBad
 }
 
 } // namespace ORB_SLAM2

@@ -52,3 +52,33 @@ API int adp_graph_bundle_adjustment(ref_graph *g, int iterations, unsigned long 
     standin_log = nullptr;
     return rc;
 }
+API int adp_graph_local_ba(ref_graph *g, int kf, bool *stop, char *err, int err_cap) { // Optimizer::LocalBundleAdjustment
+    standin_log = &g->log;
+    int rc = 0;
+    try { Optimizer::LocalBundleAdjustment(g->kfs[kf].get(), stop, &g->map); }
+    catch (const std::exception &e) { rc = 1; if (err && err_cap > 0) { std::strncpy(err, e.what(), err_cap - 1); err[err_cap - 1] = 0; } }
+    standin_log = nullptr;
+    return rc;
+}
+API int adp_graph_global_ba(ref_graph *g, int iterations, unsigned long loop_kf, int robust, bool *stop, char *err, int err_cap) { // Optimizer::GlobalBundleAdjustemnt
+    standin_log = &g->log;
+    int rc = 0;
+    try { Optimizer::GlobalBundleAdjustemnt(&g->map, iterations, stop, loop_kf, robust != 0); }
+    catch (const std::exception &e) { rc = 1; if (err && err_cap > 0) { std::strncpy(err, e.what(), err_cap - 1); err[err_cap - 1] = 0; } }
+    standin_log = nullptr;
+    return rc;
+}
+// Optimizer::PoseOptimization over a Frame made of key frame `kf`'s pose, key points and matches (like ref_graph_pose_optimization); -1 on an exception
+API int adp_graph_pose_optimization(ref_graph *g, int kf, float *Tcw16_out, unsigned char *outlier, char *err, int err_cap) {
+    KeyFrame *k = g->kfs[kf].get();
+    Frame f;
+    f.mTcw = k->Tcw.clone(); f.N = (int)k->mvKeysUn.size(); f.mvpMapPoints = k->mvpMapPoints; f.mvbOutlier.assign(f.N, false);
+    f.mvKeysUn = k->mvKeysUn; f.mvuRight = k->mvuRight; f.mvInvLevelSigma2 = k->mvInvLevelSigma2;
+    f.fx = k->fx; f.fy = k->fy; f.cx = k->cx; f.cy = k->cy; f.mbf = k->mbf;
+    int n = -1;
+    try { n = Optimizer::PoseOptimization(&f); }
+    catch (const std::exception &e) { if (err && err_cap > 0) { std::strncpy(err, e.what(), err_cap - 1); err[err_cap - 1] = 0; } return -1; }
+    for (int i = 0; i < 4; i++) for (int j = 0; j < 4; j++) Tcw16_out[i * 4 + j] = f.mTcw.at<float>(i, j);
+    for (int i = 0; i < f.N; i++) outlier[i] = f.mvbOutlier[i] ? 1 : 0;
+    return n;
+}

@@ -120,7 +120,9 @@ WANT = [  # (file, signatures, output include)
                                           "Eigen::Matrix<double, 3, 1> Converter::toVector3d(const cv::Mat &cvVector)"], "extracted_graph_conv.inc"),
     ("orb_object_slam/src/Optimizer.cc", ["void Optimizer::BundleAdjustment(const vector<KeyFrame *> &vpKFs, const vector<MapPoint *> &vpMP,", "int Optimizer::PoseOptimization(Frame *pFrame)",
                                           "void Optimizer::LocalBACameraPointObjects(KeyFrame *pKF, bool *pbStopFlag, Map *pMap, bool fixCamera, bool fixPoint)",
-                                          "void Optimizer::LocalBACameraPointObjectsDynamic(KeyFrame *pKF, bool *pbStopFlag, Map *pMap, bool fixCamera, bool fixPoint)"], "extracted_graph.inc"),
+                                          "void Optimizer::LocalBACameraPointObjectsDynamic(KeyFrame *pKF, bool *pbStopFlag, Map *pMap, bool fixCamera, bool fixPoint)",
+                                          "void Optimizer::GlobalBundleAdjustemnt(Map *pMap, int nIterations, bool *pbStopFlag, const unsigned long nLoopKF, const bool bRobust)",
+                                          "void Optimizer::LocalBundleAdjustment(KeyFrame *pKF, bool *pbStopFlag, Map *pMap)"], "extracted_graph.inc"),
     # object association: Tracking::AssociateCuboids with the MapObject / MapPoint vote bookkeeping it drives
     ("orb_object_slam/src/MapObject.cc", ["long int MapObject::getIncrementedIndex()", "vector<MapPoint *> MapObject::GetUniqueMapPoints()", "int MapObject::NumUniqueMapPoints()",
                                           "void MapObject::AddUniqueMapPoint(MapPoint *pMP, int obs_num)", "void MapObject::EraseUniqueMapPoint(MapPoint *pMP, int obs_num)",

@@ -72,12 +72,14 @@ API int ref_graph_add_kf(ref_graph *g, long id, int bad, const float *Tcw16, con
     for (int i = 0; i < n_keys; i++) { k->mvKeysUn[i].pt.x = keys_xy[2 * i]; k->mvKeysUn[i].pt.y = keys_xy[2 * i + 1]; k->mvKeysUn[i].octave = octave[i]; }
     k->mvInvLevelSigma2.assign(inv_level_sigma2, inv_level_sigma2 + n_levels);
     k->fx = fx; k->fy = fy; k->cx = cx; k->cy = cy; k->mbf = bf;
+    g->map.all_kfs.push_back(k.get());
     g->kfs.push_back(std::move(k));
     return (int)g->kfs.size() - 1;
 }
 API int ref_graph_add_mp(ref_graph *g, long id, int bad, const float *pos3, int is_dynamic) {
     std::unique_ptr<MapPoint> p(new MapPoint());
     p->mnId = (unsigned long)id; p->bad = bad != 0; p->is_dynamic = is_dynamic != 0; p->mWorldPos = mat_f(3, 1, pos3);
+    g->map.all_mps.push_back(p.get());
     g->mps.push_back(std::move(p));
     return (int)g->mps.size() - 1;
 }
@@ -224,6 +226,16 @@ API void ref_graph_bundle_adjustment(ref_graph *g, int iterations, unsigned long
     for (auto &k : g->kfs) kfs.push_back(k.get());
     for (auto &p : g->mps) mps.push_back(p.get());
     Optimizer::BundleAdjustment(kfs, mps, iterations, stop, loop_kf, robust != 0);
+    standin_log = nullptr;
+}
+API void ref_graph_local_ba(ref_graph *g, int kf, bool *stop) { // Optimizer::LocalBundleAdjustment (:474-825): the window without objects
+    Quiet q; standin_log = &g->log;
+    Optimizer::LocalBundleAdjustment(g->kfs[kf].get(), stop, &g->map);
+    standin_log = nullptr;
+}
+API void ref_graph_global_ba(ref_graph *g, int iterations, unsigned long loop_kf, int robust, bool *stop) { // Optimizer::GlobalBundleAdjustemnt (:57-62)
+    Quiet q; standin_log = &g->log;
+    Optimizer::GlobalBundleAdjustemnt(&g->map, iterations, stop, loop_kf, robust != 0);
     standin_log = nullptr;
 }
 // PoseOptimization of a frame made of key frame `kf`'s pose, key points and matches; outliers out (n_keys bytes), returns the inlier count

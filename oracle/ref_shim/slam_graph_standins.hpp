@@ -89,6 +89,7 @@ class KeyFrame {
     cv::Mat Tcw, Ow, mTcwGBA; // 4 x 4 and 3 x 1 float
     std::vector<cv::KeyPoint> mvKeysUn;
     std::vector<float> mvuRight, mvInvLevelSigma2;
+    std::vector<bool> KeysStatic; // KeyFrame.h: per key point, empty unless dynamic features are tracked (LocalBundleAdjustment skips the others, Optimizer.cc:603-607)
     float fx = 0, fy = 0, cx = 0, cy = 0, mbf = 0;
     double mTimeStamp = 0;
     std::vector<cv::KeyPoint> mvKeysHarris;
@@ -166,6 +167,9 @@ class MapObject {
 class Map {
   public:
     std::set<MapObject *> mspMapObjects;
+    std::vector<KeyFrame *> all_kfs; std::vector<MapPoint *> all_mps; // what GetAllKeyFrames / GetAllMapPoints return (Map.cc: copies of the sets)
+    std::vector<KeyFrame *> GetAllKeyFrames() { return all_kfs; }
+    std::vector<MapPoint *> GetAllMapPoints() { return all_mps; }
     void AddMapObject(MapObject *pMO) { mspMapObjects.insert(pMO); }
     std::vector<MapObject *> GetAllMapObjects() { return std::vector<MapObject *>(mspMapObjects.begin(), mspMapObjects.end()); }
     int img_width = 0, img_height = 0;
@@ -212,5 +216,7 @@ class Optimizer { // Optimizer.h:36-49
     void static LocalBACameraPointObjects(KeyFrame *pKF, bool *pbStopFlag, Map *pMap, bool fixCamera = false, bool fixPoint = false);
     void static LocalBACameraPointObjectsDynamic(KeyFrame *pKF, bool *pbStopFlag, Map *pMap, bool fixCamera = false, bool fixPoint = false);
     int static PoseOptimization(Frame *pFrame);
+    void static GlobalBundleAdjustemnt(Map *pMap, int nIterations = 5, bool *pbStopFlag = NULL, const unsigned long nLoopKF = 0, const bool bRobust = true);
+    void static LocalBundleAdjustment(KeyFrame *pKF, bool *pbStopFlag, Map *pMap);
 };
 } // namespace ORB_SLAM2

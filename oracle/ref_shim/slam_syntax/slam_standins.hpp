@@ -55,6 +55,21 @@ public:
     const std::vector<cv::KeyPoint> mvKeysUn;                  // :208
     const std::vector<float> mvuRight;                         // :209
     const std::vector<float> mvInvLevelSigma2;                 // :226
+    std::vector<bool> KeysStatic;                              // :146
+};
+class Frame { // Frame.h (what PoseOptimization touches)
+public:
+    void SetPose(cv::Mat Tcw);                                 // :66
+    std::vector<bool> KeysStatic;                              // :109
+    static float fx, fy, cx, cy;                               // :136-139
+    float mbf;                                                 // :145
+    int N;                                                     // :155
+    std::vector<cv::KeyPoint> mvKeysUn;                        // :162
+    std::vector<float> mvuRight;                               // :166
+    std::vector<MapPoint *> mvpMapPoints;                      // :181
+    std::vector<bool> mvbOutlier;                              // :184
+    cv::Mat mTcw;                                              // :192
+    std::vector<float> mvInvLevelSigma2;                       // :209
 };
 class MapPoint { // MapPoint.h
 public:
@@ -66,6 +81,7 @@ public:
     bool isBad();                                              // :63
     void UpdateNormalAndDepth();                               // :80
     long unsigned int mnBALocalForKF;                          // :112
+    static std::mutex mGlobalMutex;                            // :122
     cv::Mat mPosGBA;                                           // :119
     long unsigned int mnBAGlobalForKF;                         // :120
     bool is_dynamic = false;                                   // :125
@@ -92,6 +108,8 @@ public:
 };
 class Map { // Map.h
 public:
+    std::vector<KeyFrame *> GetAllKeyFrames();                 // :52
+    std::vector<MapPoint *> GetAllMapPoints();                 // :54
     std::mutex mMutexMapUpdate;                                // :70
     Eigen::Matrix3d Kalib, invKalib;                           // :80
     int img_width, img_height;                                 // :82

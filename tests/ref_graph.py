@@ -164,6 +164,14 @@ class Graph:
     def bundle_adjustment(self, iterations, loop_kf=0, robust=True):
         self.L.ref_graph_bundle_adjustment(self.h, int(iterations), C.c_ulong(loop_kf), int(robust), None)
 
+    def local_ba(self, kf):
+        """Optimizer::LocalBundleAdjustment (Optimizer.cc:474-825)."""
+        self.L.ref_graph_local_ba(self.h, self.kf[id(kf)], None)
+
+    def global_ba(self, iterations, loop_kf=0, robust=True):
+        """Optimizer::GlobalBundleAdjustemnt (Optimizer.cc:57-62)."""
+        self.L.ref_graph_global_ba(self.h, int(iterations), C.c_ulong(loop_kf), int(robust), None)
+
     def pose_optimization(self, kf):
         T = np.zeros(16, np.float32); out = np.zeros(len(kf.mvKeysUn), np.uint8)
         n = self.L.ref_graph_pose_optimization(self.h, self.kf[id(kf)], _p(T, C.c_float), _p(out, C.c_ubyte))

@@ -38,7 +38,7 @@ def test_cuboid_adapter_type_checks_against_the_reference_header():
 
 
 def test_optimizer_adapter_type_checks_against_the_reference_declaration():
-    """Optimizer::BundleAdjustment / LocalBACameraPointObjects as members of the reference's class: the declaration is cut from
+    """Optimizer::BundleAdjustment / GlobalBundleAdjustemnt / LocalBundleAdjustment / LocalBACameraPointObjects / PoseOptimization as members of the reference's class: the declaration is cut from
     orb_object_slam/include/Optimizer.h (a changed signature there fails this test), the SLAM classes are stand-in declarations with the
     reference's member names and types.  Also pinned here: the adapter hands the caller's `bool *pbStopFlag` itself to the library
     (cs_ba_set_stop_flag_bool, polled during the solve like g2o's setForceStopFlag), not a copy made on entry."""
@@ -47,7 +47,8 @@ def test_optimizer_adapter_type_checks_against_the_reference_declaration():
     m = re.search(r"class Optimizer\s*\{.*?\n\};", hdr, re.S)
     assert m, "class Optimizer not found in the reference header"
     decl = m.group(0)
-    for sig in ("BundleAdjustment(const std::vector<KeyFrame *> &vpKF, const std::vector<MapPoint *> &vpMP", "LocalBACameraPointObjects(KeyFrame *pKF, bool *pbStopFlag, Map *pMap"):
+    for sig in ("BundleAdjustment(const std::vector<KeyFrame *> &vpKF, const std::vector<MapPoint *> &vpMP", "LocalBACameraPointObjects(KeyFrame *pKF, bool *pbStopFlag, Map *pMap",
+                "GlobalBundleAdjustemnt(Map *pMap", "LocalBundleAdjustment(KeyFrame *pKF, bool *pbStopFlag, Map *pMap)", "PoseOptimization(Frame *pFrame)"):
         assert sig in decl, sig
     shim = os.path.join(ROOT, "oracle", "ref_shim", "slam_syntax")
     with open(os.path.join(shim, "Optimizer_decl.inc"), "w") as f:

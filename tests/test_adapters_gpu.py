@@ -139,6 +139,93 @@ def test_optimizer_adapter_bundle_adjustment_equals_the_reference(loop_kf):
         Gr.close(); Ga.close()
 
 
+def test_optimizer_adapter_local_bundle_adjustment_equals_the_reference():
+    """Optimizer::LocalBundleAdjustment (Optimizer.cc:474-825, the no-object fallback of the mapping thread, LocalMapping.cc:74) through the adapter against the
+    reference's own text on the same window: erase list, key-frame poses, points written or left alone, marker fields."""
+    rg, A = _adapter_graph()
+    from tests import local_map
+    cur, params, extra = local_map.build(4, with_objects=False)
+    rg.quantize(cur, params, extra)
+    Gr, Ga = rg.Graph(cur, params, extra), rg.Graph(cur, params, extra)
+    try:
+        Gr.local_ba(cur)
+        err = C.create_string_buffer(512)
+        assert A.adp_graph_local_ba(Ga.h, Ga.kf[id(cur)], None, err, 512) == 0, err.value
+        assert sorted(Ga.erased()) == sorted(Gr.erased()) and len(Gr.erased()) > 0
+        moved = 0.0
+        for k in extra["kfs"]:
+            Tr, nr, _ = Gr.kf_pose(k); Ta, na, _ = Ga.kf_pose(k)
+            assert na == nr and Ga.kf_markers(k) == Gr.kf_markers(k), k.mnId
+            assert np.abs(Tr[:3, :3] - Ta[:3, :3]).max() <= 5e-6 and np.abs(Tr[:3, 3] - Ta[:3, 3]).max() <= 5e-6 * max(1.0, float(np.abs(Tr[:3, 3]).max())), k.mnId
+            moved = max(moved, float(np.abs(Ta - k.T_f32).max()))
+        assert moved > 1e-3
+        n_written = 0
+        for m in Gr.mps:
+            pr, nr, ur = Gr.mp_pos(m); pa, na, ua = Ga.mp_pos(m)
+            assert (na, ua) == (nr, ur), m.mnId
+            n_written += nr
+            assert np.abs(pr.astype(np.float64) - pa.astype(np.float64)).max() <= 1e-5 * max(1.0, float(np.linalg.norm(pr))), (m.mnId, pr, pa)
+        assert n_written > 50
+    finally:
+        Gr.close(); Ga.close()
+
+
+@pytest.mark.parametrize("loop_kf", [0, 9])
+def test_optimizer_adapter_global_bundle_adjustment_equals_the_reference(loop_kf):
+    """Optimizer::GlobalBundleAdjustemnt (:57-62; LoopClosing.cc:641, Tracking.cc:1073): the map's key frames and points through BundleAdjustment."""
+    rg, A = _adapter_graph()
+    from tests import local_map
+    cur, params, extra = local_map.build(2, n_kf=10, n_points=80, n_cuboids=3)
+    rg.quantize(cur, params, extra)
+    for k in extra["kfs"]:
+        k.bad = False; k.local_cuboids, k.cuboids_landmark = [], []
+    extra["mps"], extra["mos"] = [m for m in extra["mps"] if m.observations], []
+    Gr, Ga = rg.Graph(cur, params, extra), rg.Graph(cur, params, extra)
+    try:
+        Gr.global_ba(10, loop_kf=loop_kf)
+        err = C.create_string_buffer(512)
+        assert A.adp_graph_global_ba(Ga.h, 10, C.c_ulong(loop_kf), 1, None, err, 512) == 0, err.value
+        for k in extra["kfs"]:
+            Tr, nr, Gr_gba = Gr.kf_pose(k); Ta, na, Ga_gba = Ga.kf_pose(k)
+            assert na == nr == (0 if loop_kf else 1)
+            a, b = (Gr_gba, Ga_gba) if loop_kf else (Tr, Ta)
+            assert np.abs(a - b).max() <= 2e-6 * max(1.0, float(np.abs(a[:3, 3]).max())), k.mnId
+        for m in Gr.mps:
+            pr, nr, _ = Gr.mp_pos(m); pa, na, _ = Ga.mp_pos(m)
+            assert na == nr and np.abs(pr.astype(np.float64) - pa.astype(np.float64)).max() <= 1e-5 * max(1.0, float(np.linalg.norm(pr)))
+    finally:
+        Gr.close(); Ga.close()
+
+
+def test_optimizer_adapter_pose_optimization_equals_the_reference():
+    """int Optimizer::PoseOptimization(Frame *) (:253-472) through the adapter against the reference's own text: a frame made of a key frame's key points and matches,
+    started off its pose -- the same inlier count, the same mvbOutlier flags, the pose to a few float ulps."""
+    rg, A = _adapter_graph()
+    from tests import local_map
+    cur, params, extra = local_map.build(2)
+    rg.quantize(cur, params, extra)
+    n_frames = 0
+    for k in extra["kfs"][2:8]:
+        keep = k.T_f32
+        T0 = keep.copy(); T0[:3, 3] += np.float32([0.05, -0.02, 0.08])
+        k.T_f32 = T0
+        Gr, Ga = rg.Graph(cur, params, extra), rg.Graph(cur, params, extra)
+        k.T_f32 = keep
+        try:
+            n_ref, Tr, out_ref = Gr.pose_optimization(k)
+            Ta = np.zeros(16, np.float32); out = np.zeros(len(k.mvKeysUn), np.uint8); err = C.create_string_buffer(512)
+            n_adp = A.adp_graph_pose_optimization(Ga.h, Ga.kf[id(k)], Ta.ctypes.data_as(C.POINTER(C.c_float)), out.ctypes.data_as(C.POINTER(C.c_ubyte)), err, 512)
+            assert n_adp == n_ref > 10, (err.value, n_adp, n_ref)
+            assert np.array_equal(out.astype(bool), out_ref) and out_ref.any()
+            Ta = Ta.reshape(4, 4)
+            assert np.abs(Ta - Tr).max() <= 4e-6 * max(1.0, float(np.abs(Tr[:3, 3]).max())), k.mnId
+            assert np.abs(Ta - T0).max() > 1e-3
+            n_frames += 1
+        finally:
+            Gr.close(); Ga.close()
+    assert n_frames == 6
+
+
 # ---------------------------------------------------------------------------------------------------------------------------------------------------
 # b1: adapters/detect_3d_cuboid_hip.cpp RUN through the reference's own class (oracle/_ref/libadapter_cuboid.so: the adapter's three member functions under the class
 # definition of detect_3d_cuboid/include/detect_3d_cuboid/detect_3d_cuboid.h) next to the reference's own detect_cuboid text (libref.so::ref_detect_cuboid).

@@ -452,3 +452,28 @@ def test_local_ba_again_on_its_own_result_equals_reference():
             k.map_point_matches[m.observations.pop(k)] = None
         rg.quantize(cur, params, extra)
     assert early >= 1, "a later round ends its second stage before the tenth iteration"
+
+
+
+def test_local_bundle_adjustment_is_the_object_window_without_objects():
+    """Optimizer::LocalBundleAdjustment (Optimizer.cc:474-825), the reference's own text, on a window without objects against oracle/local_ba_objects.py -- the restatement
+    of LocalBACameraPointObjects: without object vertices the two functions build the same graph (same windows, same skip of points seen once, same two stages), so one
+    restatement serves both.  What differs is bookkeeping: the fixed key frames keep their mnBALocalForKF mark here (:820-824 resets mnBAFixedForKF only)."""
+    cur, params, extra = local_map.build(4, with_objects=False)
+    rg.quantize(cur, params, extra)
+    ref = lo.local_ba_camera_point_objects(cur, params)
+    G = rg.Graph(cur, params, extra)
+    try:
+        G.local_ba(cur)
+        kid = {k.mnId: k for k in extra["kfs"]}
+        assert sorted(G.erased()) == sorted(ref["erase"]) and len(ref["erase"]) > 0
+        for mn, pose in ref["kf_pose"].items():
+            T, n, _ = G.kf_pose(kid[mn])
+            assert n == 1 and _pose_close(T, rg.cvmat_from_pose(pose)), mn
+        unwritten = set(ref["point_unwritten"])
+        for m in extra["mps"]:
+            if m.mnId in ref["point_pos"]:
+                p, n, _ = G.mp_pos(m)
+                assert n == (0 if m.mnId in unwritten else 1), m.mnId
+    finally:
+        G.close()
