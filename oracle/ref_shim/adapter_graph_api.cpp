@@ -82,3 +82,16 @@ API int adp_graph_pose_optimization(ref_graph *g, int kf, float *Tcw16_out, unsi
     for (int i = 0; i < f.N; i++) outlier[i] = f.mvbOutlier[i] ? 1 : 0;
     return n;
 }
+// Optimizer::LocalBACameraPointObjectsDynamic; the switches of Parameters.h the function reads first
+API void adp_graph_set_dyn_params(int pt_obj_cam, int obj_velo, int obj_cam, double velocity_weight, int dynamic_objects) {
+    ba_dyna_pt_obj_cam = pt_obj_cam != 0; ba_dyna_obj_velo = obj_velo != 0; ba_dyna_obj_cam = obj_cam != 0; object_velocity_BA_weight = velocity_weight;
+    whether_dynamic_object = dynamic_objects != 0; use_dynamic_klt_features = false;
+}
+API int adp_graph_local_ba_dynamic(ref_graph *g, int kf, int fix_camera, int fix_point, bool *stop, char *err, int err_cap) {
+    standin_log = &g->log;
+    int rc = 0;
+    try { Optimizer::LocalBACameraPointObjectsDynamic(g->kfs[kf].get(), stop, &g->map, fix_camera != 0, fix_point != 0); }
+    catch (const std::exception &e) { rc = 1; if (err && err_cap > 0) { std::strncpy(err, e.what(), err_cap - 1); err[err_cap - 1] = 0; } }
+    standin_log = nullptr;
+    return rc;
+}

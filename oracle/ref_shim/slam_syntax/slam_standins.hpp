@@ -56,6 +56,9 @@ public:
     const std::vector<float> mvuRight;                         // :209
     const std::vector<float> mvInvLevelSigma2;                 // :226
     std::vector<bool> KeysStatic;                              // :146
+    std::vector<cv::KeyPoint> mvKeysHarris;                    // :141
+    std::vector<MapPoint *> GetHarrisMapPointMatches();        // :144
+    const double mTimeStamp = 0;                               // :169
 };
 class Frame { // Frame.h (what PoseOptimization touches)
 public:
@@ -86,7 +89,13 @@ public:
     long unsigned int mnBAGlobalForKF;                         // :120
     bool is_dynamic = false;                                   // :125
     std::map<MapObject *, int> MapObjObservations;             // :136
+    void SetBadFlag();                                         // :62
+    MapObject *GetBelongedObject();                            // :92
+    cv::Mat mWorldPos_latestKF;                                // :126
+    cv::Mat PosToObj;                                          // :128
+    bool is_optimized = false;                                 // :131
 };
+struct cmpKeyframe { bool operator()(const KeyFrame *a, const KeyFrame *b) const { return a->mnId < b->mnId; } }; // MapObject.h:20-26
 class MapObject { // MapObject.h
 public:
     void SetWorldPos(const g2o::cuboid &Pos);                  // :34
@@ -105,6 +114,14 @@ public:
     Eigen::Vector4d bbox_vec;                                  // :108
     double meas_quality;                                       // :110
     int left_right_to_car;                                     // :115
+    std::vector<KeyFrame *> GetObserveFramesSequential();      // :45
+    long int mnId;                                             // :48
+    Eigen::Vector2d velocityPlanar;                            // :91
+    g2o::cuboid pose_Twc_latestKF;                             // :92
+    std::map<KeyFrame *, Eigen::Vector2d, cmpKeyframe> velocityhistory; // :93
+    g2o::cuboid pose_Twc_afterba;                              // :94
+    std::map<KeyFrame *, std::pair<g2o::cuboid, bool>, cmpKeyframe> allDynamicPoses; // :96
+    std::unordered_map<KeyFrame *, int> bundle_vertex_ids;     // :97
 };
 class Map { // Map.h
 public:
@@ -127,7 +144,10 @@ public:
 extern bool parallel_mapping;
 extern bool whether_dynamic_object;
 extern bool build_worldframe_on_ground;
+extern bool use_dynamic_klt_features;
+extern bool ba_dyna_pt_obj_cam, ba_dyna_obj_velo, ba_dyna_obj_cam;
 extern double camera_object_BA_weight;
+extern double object_velocity_BA_weight;
 enum Scene_Name { voidtype = 0, kitti };
 extern Scene_Name scene_unique_id;
 } // namespace ORB_SLAM2

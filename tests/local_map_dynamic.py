@@ -117,3 +117,75 @@ def build(seed, n_kf=12, n_points=300, n_objects=4, pts_per_obj=24):
     params = {"K": synth.K_KITTI, "img_width": W, "img_height": H, "bf": d["bf"], "camera_object_BA_weight": 2.0, "object_velocity_BA_weight": 0.5, "kitti": True,
               "build_worldframe_on_ground": True, "ba_dyna_pt_obj_cam": True, "ba_dyna_obj_velo": True, "ba_dyna_obj_cam": True}
     return cur, params, {"kfs": kfs, "mps": mps + dmps, "mos": mos + [outside], "truth": d}
+
+
+def flatten_window(pKF):
+    """The window as the flat arrays cube_slam_amd.ba_dynamic.LocalBACameraPointObjectsDynamic takes -- the pointer walk of Optimizer.cc:1540-1665 that
+    adapters/Optimizer_hip.cc does over KeyFrame* / MapPoint* / MapObject* -- plus the objects behind the rows."""
+    local_kfs, marked = [pKF], {id(pKF)}
+    for kf in pKF.covisible:
+        marked.add(id(kf))
+        if not kf.bad:
+            local_kfs.append(kf)
+    points, seen, set_bad = [], set(), []
+    for kf in local_kfs:
+        for mp in kf.map_point_matches:
+            if mp is None or mp.bad:
+                continue
+            if kf is not pKF and mp.is_dynamic and mp.Observations() == 1:
+                mp.bad = True; set_bad.append(mp)
+            if id(mp) not in seen:
+                seen.add(id(mp)); points.append(mp)
+    objects = []
+    for kf in local_kfs:
+        for mo in kf.cuboids_landmark:
+            if mo is not None and not mo.bad and all(mo is not o for o in objects):
+                objects.append(mo)
+    fixed = []
+    for mp in points:
+        for kf in mp.observations:
+            if id(kf) not in marked:
+                marked.add(id(kf))
+                if not kf.bad:
+                    fixed.append(kf)
+    for mo in objects:
+        for kf in mo.observations:
+            if (kf.mTimeStamp - pKF.mTimeStamp) > 8.0 and id(kf) not in marked:
+                marked.add(id(kf))
+                if not kf.bad:
+                    fixed.append(kf)
+    kfs = local_kfs + fixed
+    row = {id(k): i for i, k in enumerate(kfs)}
+    mo_row = {id(m): i for i, m in enumerate(objects)}
+    w = {"kf_id": np.array([k.mnId for k in kfs]), "kf_pose": np.stack([k.Tcw for k in kfs]), "kf_stamp": np.array([k.mTimeStamp for k in kfs]),
+         "kf_cam_center": np.stack([k.camera_center() for k in kfs]), "n_local": len(local_kfs),
+         "mp_pos": np.array([m.pos for m in points]).reshape(-1, 3), "mp_nobs": np.array([m.Observations() for m in points]), "mp_dynamic": np.array([bool(m.is_dynamic) for m in points]),
+         "mp_pos_to_obj": np.array([m.PosToObj if m.PosToObj is not None else np.zeros(3) for m in points]).reshape(-1, 3),
+         "mp_best_mo": np.array([mo_row.get(id(m.best_object), -1) if m.best_object is not None else -1 for m in points])}
+    om, ok, ouv, our, ow = [], [], [], [], []
+    for j, mp in enumerate(points):
+        for kf, idx in mp.observations.items():
+            if not kf.bad:
+                om.append(j); ok.append(row[id(kf)]); ouv.append(kf.mvKeysUn[idx]); our.append(float(kf.mvuRight[idx]) if kf.mvuRight[idx] >= 0 else -1.0)
+                ow.append(float(kf.mvInvLevelSigma2[kf.octave[idx]]))
+    w.update(obs_mp=np.array(om, int), obs_kf=np.array(ok, int), obs_uv=np.array(ouv, float).reshape(-1, 2), obs_ur=np.array(our, float), obs_inv_sigma2=np.array(ow, float))
+    vm, vk, vp, vb, vr, vl, sm, sk, um, up, uc, ov_key = [], [], [], [], [], [], [], [], [], [], [], []
+    for i, mo in enumerate(objects):
+        for kf, idx in mo.observations.items():
+            if kf.bad or id(kf) not in row:
+                continue
+            det = kf.local_cuboids[idx]
+            vm.append(i); vk.append(row[id(kf)]); vp.append(np.asarray(mo.allDynamicPoses[kf], float)); vb.append(det["bbox_vec"]); vr.append(det["bbox_2d"]); vl.append(det["left_right_to_car"])
+            ov_key.append((mo, kf))
+        for kf in mo.observed_frames:
+            if not kf.bad and id(kf) in row:
+                sm.append(i); sk.append(row[id(kf)])
+        for mp in mo.unique_points:
+            if mp is not None and not mp.bad:
+                um.append(i); up.append(mp.pos); uc.append(mp.MapObjObservations.get(mo, 0))
+    w.update(mo_id=np.array([m.mnId for m in objects]), mo_meas_quality=np.array([m.meas_quality for m in objects], float),
+             mo_largest_point_observations=np.array([m.largest_point_observations for m in objects], int), mo_velocity=np.array([m.velocityPlanar for m in objects], float).reshape(-1, 2),
+             ov_mo=np.array(vm, int), ov_kf=np.array(vk, int), ov_pose=np.array(vp, float).reshape(-1, 7), ov_bbox_vec=np.array(vb, float).reshape(-1, 4),
+             ov_bbox_2d=np.array(vr, int).reshape(-1, 4), ov_left_right_to_car=np.array(vl, int), seq_mo=np.array(sm, int), seq_kf=np.array(sk, int),
+             up_mo=np.array(um, int), up_pos=np.array(up, float).reshape(-1, 3), up_count=np.array(uc, int))
+    return w, {"kfs": kfs, "points": points, "objects": objects, "ov_key": ov_key, "set_bad": set_bad}

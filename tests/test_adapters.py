@@ -38,7 +38,7 @@ def test_cuboid_adapter_type_checks_against_the_reference_header():
 
 
 def test_optimizer_adapter_type_checks_against_the_reference_declaration():
-    """Optimizer::BundleAdjustment / GlobalBundleAdjustemnt / LocalBundleAdjustment / LocalBACameraPointObjects / PoseOptimization as members of the reference's class: the declaration is cut from
+    """Optimizer::BundleAdjustment / GlobalBundleAdjustemnt / LocalBundleAdjustment / LocalBACameraPointObjects / LocalBACameraPointObjectsDynamic / PoseOptimization as members of the reference's class: the declaration is cut from
     orb_object_slam/include/Optimizer.h (a changed signature there fails this test), the SLAM classes are stand-in declarations with the
     reference's member names and types.  Also pinned here: the adapter hands the caller's `bool *pbStopFlag` itself to the library
     (cs_ba_set_stop_flag_bool, polled during the solve like g2o's setForceStopFlag), not a copy made on entry."""
@@ -48,7 +48,8 @@ def test_optimizer_adapter_type_checks_against_the_reference_declaration():
     assert m, "class Optimizer not found in the reference header"
     decl = m.group(0)
     for sig in ("BundleAdjustment(const std::vector<KeyFrame *> &vpKF, const std::vector<MapPoint *> &vpMP", "LocalBACameraPointObjects(KeyFrame *pKF, bool *pbStopFlag, Map *pMap",
-                "GlobalBundleAdjustemnt(Map *pMap", "LocalBundleAdjustment(KeyFrame *pKF, bool *pbStopFlag, Map *pMap)", "PoseOptimization(Frame *pFrame)"):
+                "GlobalBundleAdjustemnt(Map *pMap", "LocalBundleAdjustment(KeyFrame *pKF, bool *pbStopFlag, Map *pMap)", "PoseOptimization(Frame *pFrame)",
+                "LocalBACameraPointObjectsDynamic(KeyFrame *pKF, bool *pbStopFlag, Map *pMap"):
         assert sig in decl, sig
     shim = os.path.join(ROOT, "oracle", "ref_shim", "slam_syntax")
     with open(os.path.join(shim, "Optimizer_decl.inc"), "w") as f:
@@ -58,5 +59,5 @@ def test_optimizer_adapter_type_checks_against_the_reference_declaration():
     r = subprocess.run(cmd, capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-3000:]
     src = open(os.path.join(ROOT, "adapters", "Optimizer_hip.cc")).read()
-    assert src.count("cs_ba_set_stop_flag_bool") >= 1 and "LocalBACameraPointObjects(ctx, w, prm, res, nullptr, pbStopFlag)" in src
+    assert src.count("cs_ba_set_stop_flag_bool") >= 1 and "LocalBACameraPointObjects(ctx, w, prm, res, nullptr, pbStopFlag)" in src and "LocalBACameraPointObjectsDynamic(ctx, w, prm, res, nullptr, pbStopFlag)" in src
     assert "volatile int stop = 0" not in src  # (round 2's copy-on-entry)

@@ -113,6 +113,65 @@ def test_optimizer_adapter_local_ba_equals_the_reference(seed):
         Gr.close(); Ga.close()
 
 
+@pytest.mark.parametrize("seed", [1, 3])
+def test_optimizer_adapter_dynamic_local_ba_equals_the_reference(seed):
+    """Optimizer::LocalBACameraPointObjectsDynamic of adapters/Optimizer_hip.cc -- window gathering from the map, cube_slam_amd/host/local_ba_dynamic.hpp, cs_ba_dyn_*, write-back --
+    against the reference's own function text on its own g2o over the same map (tests/local_map_dynamic.py: every branch but the aliased vertex id).  Identical: the observations erased,
+    the dynamic points set bad while the window is gathered, which poses / points / velocities were written and how often, every marker field, the bookkeeping fields of the objects.
+    Numbers: the tolerances of tests/test_ref_graph_pins.py::test_dynamic_local_ba_equals_reference (several times what the reference's own result moves with its heap layout)."""
+    rg, A = _adapter_graph()
+    from tests import local_map_dynamic as lmd
+    cur, params, extra = lmd.build(seed)
+    rg.quantize(cur, params, extra)
+    Gr, Ga = rg.Graph(cur, params, extra), rg.Graph(cur, params, extra)
+    try:
+        Gr.local_ba_dynamic(cur)
+        A.adp_graph_set_params(1, int(params["build_worldframe_on_ground"]), C.c_double(params["camera_object_BA_weight"]))
+        A.adp_graph_set_dyn_params(int(params["ba_dyna_pt_obj_cam"]), int(params["ba_dyna_obj_velo"]), int(params["ba_dyna_obj_cam"]), C.c_double(params["object_velocity_BA_weight"]), 1)
+        err = C.create_string_buffer(512)
+        assert A.adp_graph_local_ba_dynamic(Ga.h, Ga.kf[id(cur)], 0, 0, None, err, 512) == 0, err.value
+        assert sorted(Ga.erased()) == sorted(Gr.erased()) and len(Gr.erased()) > 50
+        moved = 0.0
+        for k in extra["kfs"]:
+            Tr, nr, _ = Gr.kf_pose(k); Ta, na, _ = Ga.kf_pose(k)
+            assert na == nr and Ga.kf_markers(k) == Gr.kf_markers(k), k.mnId
+            assert np.abs(Tr[:3, :3] - Ta[:3, :3]).max() <= 3e-5 and np.abs(Tr[:3, 3] - Ta[:3, 3]).max() <= 3e-5 * max(1.0, float(np.abs(Tr[:3, 3]).max())), k.mnId
+            moved = max(moved, float(np.abs(Ta - k.T_f32).max()))
+        assert moved > 1e-3
+        n_static = n_dyn = n_bad = 0
+        for m in Gr.mps:
+            pr, nr, ur = Gr.mp_pos(m); pa, na, ua = Ga.mp_pos(m)
+            assert (na, ua) == (nr, ur), m.mnId
+            sr, sa = Gr.mp_dynamic(m), Ga.mp_dynamic(m)
+            assert (sa["is_optimized"], sa["bad"], sa["local_for"]) == (sr["is_optimized"], sr["bad"], sr["local_for"]), m.mnId
+            n_bad += int(sr["bad"])
+            if getattr(m, "is_dynamic", False):
+                tol = 1e-2 if sr["is_optimized"] else 0.0
+                n_dyn += int(sr["is_optimized"])
+                assert np.abs(sr["PosToObj"].astype(np.float64) - sa["PosToObj"]).max() <= tol and np.abs(sr["latest"].astype(np.float64) - sa["latest"]).max() <= tol, m.mnId
+                assert np.abs(pr.astype(np.float64) - pa).max() <= tol
+            else:
+                n_static += int(nr)
+                assert np.abs(pr.astype(np.float64) - pa.astype(np.float64)).max() <= 2e-4 * max(1.0, float(np.linalg.norm(pr))), (m.mnId, pr, pa)
+        assert n_static > 100 and n_dyn > 30 and n_bad >= 1
+        n_vel = 0
+        for o in extra["mos"]:
+            sr, sa = Gr.mo_state(o), Ga.mo_state(o)
+            assert (sa["writes"], sa["been_optimized"], sa["n_used"], sa["n_filtered"], sa["point_threshold"]) == (sr["writes"], sr["been_optimized"], sr["n_used"], sr["n_filtered"], sr["point_threshold"]), o.mnId
+            assert np.allclose(sa["pose"], sr["pose"], rtol=0, atol=1e-3) and np.array_equal(sa["scale"], sr["scale"])
+            dr, da = Gr.mo_dynamic_state(o), Ga.mo_dynamic_state(o)
+            assert (da["n_history"], da["local_for"]) == (dr["n_history"], dr["local_for"]), o.mnId
+            assert np.allclose(da["latest"], dr["latest"], rtol=0, atol=1e-3) and np.allclose(da["afterba"], dr["afterba"], rtol=0, atol=1e-3)
+            assert np.allclose(da["velocity"], dr["velocity"], rtol=0, atol=1e-3) and np.allclose(da["history"], dr["history"], rtol=0, atol=1e-3)
+            n_vel += dr["n_history"]
+            for kf in getattr(o, "allDynamicPoses", {}):
+                (pr, br), (pa, ba) = Gr.mo_dynamic_pose(o, kf), Ga.mo_dynamic_pose(o, kf)
+                assert br == ba and np.allclose(pa, pr, rtol=0, atol=1e-3 if br else 0.0), (o.mnId, kf.mnId)
+        assert n_vel >= 2
+    finally:
+        Gr.close(); Ga.close()
+
+
 @pytest.mark.parametrize("loop_kf", [0, 7])
 def test_optimizer_adapter_bundle_adjustment_equals_the_reference(loop_kf):
     rg, A = _adapter_graph()

@@ -31,7 +31,7 @@ def test_cpp_mirrors_match_python(ctx, tmp_path):
     subprocess.check_call(["g++", "-std=c++17", "-O1", "-I", ROOT, os.path.join(ROOT, "tests", "cpp", "host_mirrors.cpp"), "-o", str(exe), "-L", lib_dir, "-lcubeslam_hip",
                            "-Wl,-rpath," + lib_dir])
     # a dynamic-BA window for Optimizer::LocalBACameraPointObjectsDynamic, dumped as raw arrays
-    from cube_slam_amd.ba_dynamic import LocalBACameraPointObjectsDynamic
+    from cube_slam_amd.ba_dynamic import optimize_two_stages as LocalBACameraPointObjectsDynamic
     d = dict(synth.ba_dyn_problem(81, n_kf=8, n_points=150, n_objects=2, pts_per_obj=14))
     d["obs_uv"] = d["obs_uv"].copy(); d["obs_uv"][::23] += 40.0
     gdir = tmp_path / "dyn"; gdir.mkdir()

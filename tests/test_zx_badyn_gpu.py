@@ -7,7 +7,7 @@ import numpy as np
 import pytest
 
 from cube_slam_amd import synth
-from cube_slam_amd.ba_dynamic import DynamicBundleAdjuster, LocalBACameraPointObjectsDynamic, second_stage_problem
+from cube_slam_amd.ba_dynamic import DynamicBundleAdjuster, optimize_two_stages as LocalBACameraPointObjectsDynamic, second_stage_problem
 
 pytestmark = pytest.mark.gpu
 

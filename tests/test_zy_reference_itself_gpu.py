@@ -73,33 +73,41 @@ def test_pose_optimization_equals_the_reference_itself(ctx):
 
 @pytest.mark.parametrize("seed", [1, 3])
 def test_dynamic_local_ba_equals_the_reference_itself(ctx, seed):
-    """The HIP dynamic-object BA (cs_ba_dyn_* through cube_slam_amd.ba_dynamic, fed the arrays an adapter would gather: oracle/local_ba_dynamic.build_dynamic_graph)
-    against the reference's own Optimizer::LocalBACameraPointObjectsDynamic on the same window: the observations erased, key-frame poses, per-frame object poses,
-    velocities, dynamic points."""
+    """The HIP dynamic-object BA from the map to the values written back, all of it product code -- the window as flat arrays (tests/local_map_dynamic.flatten_window: the pointer walk
+    an adapter does), cube_slam_amd.ba_dynamic.LocalBACameraPointObjectsDynamic (graph construction, two stages over cs_ba_dyn_*, erase list) -- against the reference's own
+    Optimizer::LocalBACameraPointObjectsDynamic on the same window: the observations erased, key-frame poses, per-frame object poses, velocities, dynamic points."""
     from cube_slam_amd.ba_dynamic import LocalBACameraPointObjectsDynamic
-    from oracle import local_ba_dynamic as ld
     from tests import local_map_dynamic as lmd
     cur, params, extra = lmd.build(seed)
     rg.quantize(cur, params, extra)
-    g = ld.build_dynamic_graph(cur, params)
-    res, d2, _ = LocalBACameraPointObjectsDynamic(g["problem"], ctx=ctx)
     G = rg.Graph(cur, params, extra)
+    w, rows = lmd.flatten_window(cur)
+    res = LocalBACameraPointObjectsDynamic(w, params, ctx=ctx)
     try:
         G.local_ba_dynamic(cur)
-        erase = sorted((g["obs_kf"][k].mnId, g["obs_mp"][k].mnId) for k in res["erase_obs"])
+        erase = sorted((rows["kfs"][k].mnId, rows["points"][r].mnId) for k, r in res["erase"])
         assert erase == sorted(G.erased()) and len(erase) > 50
-        for i, k in enumerate(g["kfs"][:g["n_local"]]):
+        for i, k in enumerate(rows["kfs"][:int(w["n_local"])]):
             T, n, _ = G.kf_pose(k)
-            To = rg.cvmat_from_pose(res["cam_pose"][i]).astype(np.float64)
+            To = rg.cvmat_from_pose(res["kf_pose"][i]).astype(np.float64)
             assert n == 1 and np.abs(T[:3, :3] - To[:3, :3]).max() <= 3e-5 and np.abs(T[:3, 3] - To[:3, 3]).max() <= 3e-5 * max(1.0, np.abs(To[:3, 3]).max()), k.mnId
-        for i, (mo, kf) in enumerate(g["obj_key"]):
+        for r, p in res["point_pos"].items():
+            got, nw, _ = G.mp_pos(rows["points"][r])
+            assert nw == (0 if r in res["point_unwritten"] else 1), rows["points"][r].mnId
+            if nw:
+                assert np.abs(got.astype(np.float64) - p).max() <= 2e-4 * max(1.0, float(np.linalg.norm(p)))
+        for v, (mo, kf) in enumerate(rows["ov_key"]):
             got, baed = G.mo_dynamic_pose(mo, kf)
-            assert baed and np.allclose(got, res["obj_pose"][i], rtol=0, atol=1e-3), (mo.mnId, kf.mnId, np.abs(got - res["obj_pose"][i]).max())
-        for i, mo in enumerate(g["vel_obj"]):
-            assert np.allclose(G.mo_dynamic_state(mo)["velocity"], res["vel"][i], rtol=0, atol=1e-3)
-        n_vert = {id(mo): len(g["vertex_of"][id(mo)]) for mo in g["objects"]}
-        for j, mp in enumerate(g["dpoints"]):
-            s = G.mp_dynamic(mp)
-            assert s["is_optimized"] and np.abs(s["PosToObj"].astype(np.float64) - res["dpoints"][j]).max() <= 1e-2, mp.mnId   # (tests/test_ref_graph_pins.py: several times what the reference's own result moves with the heap layout)
+            assert baed and np.allclose(got, res["vertex_pose"][v], rtol=0, atol=1e-3), (mo.mnId, kf.mnId, np.abs(got - res["vertex_pose"][v]).max())
+        for i, v in res["object_latest"].items():
+            assert np.allclose(G.mo_dynamic_state(rows["objects"][i])["latest"], res["vertex_pose"][v], rtol=0, atol=1e-3)
+        assert len(res["velocity"]) >= 2
+        for i, vel in res["velocity"].items():
+            assert np.allclose(G.mo_dynamic_state(rows["objects"][i])["velocity"], vel, rtol=0, atol=1e-3)
+        assert len(res["dpoint_local"]) > 30
+        for r, p in res["dpoint_local"].items():
+            s = G.mp_dynamic(rows["points"][r])
+            assert s["is_optimized"] and np.abs(s["PosToObj"].astype(np.float64) - p).max() <= 1e-2, rows["points"][r].mnId   # (tests/test_ref_graph_pins.py: several times what the reference's own result moves with the heap layout)
+            assert np.abs(s["latest"].astype(np.float64) - res["dpoint_world"][r]).max() <= 1e-2
     finally:
         G.close()
