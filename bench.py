@@ -514,17 +514,20 @@ def main():
         dist.broadcast(uid, 0)
         ctx.comm_init(rank, world, bytes(uid.cpu().numpy().tobytes()))
     scenes = make_frames(args.frames, args.boxes, seed0=1000 + 100000 * rank)
+    hbm_marks = [("start", torch.cuda.mem_get_info()[0])]   # free bytes after each engine is resident: the front-end's working set by path
     det = detect_3d_cuboid(ctx)
     det.set_calibration(scenes[0]["K"])
     det.yaw_step_deg = args.yaw_step
     batch = CuboidBatch(ctx, np.stack([s["gray"] for s in scenes]), scenes[0]["K"], np.stack([s["Twc"] for s in scenes]),
                         [s["boxes"] for s in scenes], [s["lines"] for s in scenes], det.opts())
 
+    hbm_marks.append(("cuboid", torch.cuda.mem_get_info()[0]))
     orb = None
     if not args.no_orb:
         from cube_slam_amd.orb import ORBextractor
         orb = ORBextractor(args.orb_features, 1.2, 8, 20, 7, 640, 480, max_frames=args.frames, ctx=ctx)
         orb.upload(np.stack([s["gray"] for s in scenes]))
+    hbm_marks.append(("orb", torch.cuda.mem_get_info()[0]))
 
     lsd = None
     if not args.no_lines:
@@ -557,9 +560,11 @@ def main():
         if world > 1:
             dist.barrier()
 
+    hbm_marks.append(("lines_created", torch.cuda.mem_get_info()[0]))
     for _ in range(args.warmup):
         fe.step()
     barrier()
+    hbm_marks.append(("after_warmup", torch.cuda.mem_get_info()[0]))
     for c in ([ctx] + ctx_lines if lsd is not None else [ctx]):
         c.timing(True)
         c.timing_reset()
@@ -704,6 +709,7 @@ def main():
             "kernels_us": {k: round(v["avg_us"], 2) for k, v in kernels.items()},
             "host_threads": _lib.lib().cs_host_thread_count(),
             "hbm_in_use_gb": round((lambda fr_to: (fr_to[1] - fr_to[0]) / 1e9)(torch.cuda.mem_get_info()), 1),  # everything resident for the run (all blocks of this line)
+            "hbm_by_path_gb": {b[0]: round((a[1] - b[1]) / 1e9, 2) for a, b in zip(hbm_marks[:-1], hbm_marks[1:])},  # the front-end's own working set, engine by engine (after_warmup: buffers sized at the first run)
         }
         out.update(extra)
         if not args.no_cpu and world == 1:

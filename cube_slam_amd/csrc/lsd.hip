@@ -21,6 +21,7 @@
 
 namespace {
 constexpr double NOTDEF = -1024.0, PI_ = 3.1415926535897932384626433832795, DEG_TO_RADS = PI_ / 180;
+constexpr float NOTDEF_DEG = -1024.0f; // the undefined mark of the float-degree angle map
 constexpr int KH = 3; // half kernel: ceil(0.75 * sqrt(6 ln 10)) = 3
 
 __host__ __device__ inline float fast_atan2f_(float y, float x) { // cv::fastAtan2
@@ -113,14 +114,16 @@ __global__ void __launch_bounds__(256) lsd_resize(const double *blur, int W, int
     scaled[((long)blockIdx.z * h + dy) * w + dx] = r0 * ay[dy * 2] + r1 * ay[dy * 2 + 1];
 }
 // also counts the defined pixels of its 256-pixel row segment: seg_cnt[(frame * h + y) * gridDim.x + blockIdx.x]
-__global__ void __launch_bounds__(256) lsd_gradient(const double *scaled, int w, int h, double threshold, double *modgrad, double *angles, int *seg_cnt) {
+// The level-line angle is kept as what ll_angle computes it from: cv::fastAtan2's FLOAT DEGREES (NOTDEF_DEG where undefined).  The map value of the reference is that float times
+// DEG_TO_RADS in double (:566), which every reader forms itself -- 4 bytes per pixel instead of 8, and lsd_emit no longer has to divide its way back to the float.
+__global__ void __launch_bounds__(256) lsd_gradient(const double *scaled, int w, int h, double threshold, double *modgrad, float *angles, int *seg_cnt) {
     __shared__ int wc[4];
     const int x = blockIdx.x * 256 + threadIdx.x, y = blockIdx.y;
     bool def = false;
     if (x < w) {
         const double *img = scaled + (long)blockIdx.z * w * h;
         const long o = ((long)blockIdx.z * h + y) * w + x;
-        if (x >= w - 1 || y >= h - 1) { modgrad[o] = 0; angles[o] = NOTDEF; } // down / right boundaries undefined (:553-554)
+        if (x >= w - 1 || y >= h - 1) { modgrad[o] = 0; angles[o] = NOTDEF_DEG; } // down / right boundaries undefined (:553-554)
         else {
             const int addr = y * w + x;
             const double DA = img[addr + w + 1] - img[addr], BC = img[addr + 1] - img[addr + w];
@@ -128,7 +131,7 @@ __global__ void __launch_bounds__(256) lsd_gradient(const double *scaled, int w,
             const double norm = sqrt((gx * gx + gy * gy) / 4);
             modgrad[o] = norm;
             def = !(norm <= threshold);
-            angles[o] = def ? fast_atan2f_(float(gx), float(-gy)) * DEG_TO_RADS : NOTDEF;
+            angles[o] = def ? fast_atan2f_(float(gx), float(-gy)) : NOTDEF_DEG;
         }
     }
     const unsigned long long m = __ballot(def);
@@ -178,19 +181,19 @@ __global__ void __launch_bounds__(1024) lsd_scan_add(int *out, int n, const int 
 // ordered compaction of the defined pixels (address order inside a frame): address, level-line angle, gradient norm
 // c_deg: the angle as cv::fastAtan2 returned it (float degrees; the level-line angle is exactly double(c_deg) * DEG_TO_RADS, lsd.cpp:566), c_cs: cos / sin
 // of float(angle) as region_grow adds them up (:676-677, glibc's cosf / sinf restated) -- computed here once per pixel instead of by the host per visit
-__global__ void __launch_bounds__(256) lsd_emit(const double *modgrad, const double *angles, int w, int h, const int *seg_base, int *c_addr, float *c_deg, float2 *c_cs, double *c_mod) {
+__global__ void __launch_bounds__(256) lsd_emit(const double *modgrad, const float *angles, int w, int h, const int *seg_base, int *c_addr, float *c_deg, float2 *c_cs, double *c_mod) {
     __shared__ int wc[4];
     __shared__ short s_x[256];
-    __shared__ double s_a[256];
+    __shared__ float s_a[256];
     const int y = blockIdx.y;
     const long row = ((long)blockIdx.z * h + y) * w;
     {   // phase 1, a lane per pixel: which pixels of the segment are defined; they are packed (in address order) into the workgroup's list, so that the
         // expensive part below -- an IEEE division, eight double alignment tests, the double-precision polynomial of glibc's cosf / sinf -- runs on full
         // waves of defined pixels only (37 % of the pixels of a textured frame)
         const int x = blockIdx.x * 256 + threadIdx.x;
-        double a = NOTDEF;
+        float a = NOTDEF_DEG;
         if (x < w) a = angles[row + x];
-        const bool def = a != NOTDEF;
+        const bool def = a != NOTDEF_DEG;
         const unsigned long long m = __ballot(def);
         const int wv = threadIdx.x >> 6;
         if ((threadIdx.x & 63) == 0) wc[wv] = __popcll(m);
@@ -205,11 +208,10 @@ __global__ void __launch_bounds__(256) lsd_emit(const double *modgrad, const dou
     const int n_def = wc[0] + wc[1] + wc[2] + wc[3];
     if ((int)threadIdx.x >= n_def) return;
     const int x = s_x[threadIdx.x];
-    const double a = s_a[threadIdx.x];
+    const float d = s_a[threadIdx.x];
+    const double a = double(d) * DEG_TO_RADS; // the map value (:566)
     const long o = row + x;
     const int pos = seg_base[((long)blockIdx.z * h + y) * gridDim.x + blockIdx.x] + threadIdx.x;
-    float d = (float)(a / DEG_TO_RADS); // the float whose product with DEG_TO_RADS is a: the quotient rounded, or a neighbour of it
-    if ((double)d * DEG_TO_RADS != a) { const float up = nextafterf(d, 1e9f), dn = nextafterf(d, -1e9f); d = ((double)up * DEG_TO_RADS == a) ? up : dn; }
     // bit 31 of the address: no neighbour is aligned with this pixel's own angle (angles never change), so as a seed it stays alone -- region_grow's
     // first nine tests use exactly that angle -- and the host marks it used without testing anything (12 k of 25 k seeds on a textured frame are single)
     bool alone = true;
@@ -218,14 +220,16 @@ __global__ void __launch_bounds__(256) lsd_emit(const double *modgrad, const dou
         for (int dx = -1; dx <= 1; dx++) {
             const int xx = x + dx, yy = y + dy;
             if ((dx == 0 && dy == 0) || xx < 0 || yy < 0 || xx >= w || yy >= h) continue;
-            const double b = angles[((long)blockIdx.z * h + yy) * w + xx];
-            if (b == NOTDEF) continue;
+            const float bd = angles[((long)blockIdx.z * h + yy) * w + xx];
+            if (bd == NOTDEF_DEG) continue;
+            const double b = double(bd) * DEG_TO_RADS;
             double n_theta = a - b; // isAligned(neighbour, a, prec) :1138-1154
             if (n_theta < 0) n_theta = -n_theta;
             if (n_theta > (3 * PI_) / 2) { n_theta -= 2 * PI_; if (n_theta < 0) n_theta = -n_theta; }
             if (n_theta <= prec) alone = false;
         }
-    c_addr[pos] = (y * w + x) | (alone ? (int)0x80000000 : 0); c_deg[pos] = d; c_mod[pos] = modgrad[o];
+    c_addr[pos] = (y * w + x) | (alone ? (int)0x80000000 : 0); c_deg[pos] = d;
+    if (c_mod) c_mod[pos] = modgrad[o]; // (the host stage's copy of the norms; the device stage reads the dense map)
     c_cs[pos] = make_float2(glibc_sincosf::cosf_(float(a)), glibc_sincosf::sinf_(float(a)));
 }
 
@@ -561,7 +565,8 @@ struct cs_lsd {
     int W = 0, H = 0, w = 0, h = 0, max_frames = 0, n_frames = 0;
     GK gk{};
     double threshold = 0;
-    uint8_t *d_gray = nullptr; double *d_tmp = nullptr, *d_blur = nullptr, *d_scaled = nullptr, *d_mod = nullptr, *d_ang = nullptr;
+    size_t pix_bytes = 0; bool scaled_kept = true;           // the arena d_tmp = [d_blur | d_scaled], later [region stage's pixel records (pix_bytes) | LBD blur]
+    uint8_t *d_gray = nullptr; double *d_tmp = nullptr, *d_blur = nullptr, *d_scaled = nullptr, *d_mod = nullptr; float *d_ang = nullptr; // d_ang: float degrees (see lsd_gradient)
     int *d_xofs = nullptr, *d_yofs = nullptr; float *d_ax = nullptr, *d_ay = nullptr;
     int nbx = 0;                                            // 256-pixel segments per scaled row
     int *d_seg_cnt = nullptr, *d_seg_base = nullptr;        // per (frame, row, segment) defined-pixel count / exclusive scan
@@ -571,7 +576,7 @@ struct cs_lsd {
     std::vector<int> frame_base;
     std::vector<std::vector<cs_keyline>> keylines;
     // LBD descriptors of the detected lines (optional second half of cs_lsd_run)
-    uint8_t *d_lblur = nullptr; uint32_t *d_dxy = nullptr; // LBD: blurred frames, interleaved Sobel dx | dy << 16
+    uint8_t *d_lblur = nullptr; uint32_t *d_dxy = nullptr, *dxy_cur = nullptr; // LBD: blurred frames, interleaved Sobel dx | dy << 16 (dxy_cur: where the last batch's map is -- d_dxy or the arena)
     cs_keyline *d_kl = nullptr; int *d_line_frame = nullptr; uint8_t *d_desc = nullptr;
     size_t line_cap = 0;
     std::vector<int> line_off;       // per frame offset into the concatenated line list
@@ -605,7 +610,9 @@ static int lsd_run(cs_ctx *ctx, cs_lsd *l, int with_lbd) {
     if (!ctx || !l || l->n_frames < 1) return CS_ERR_BAD_ARG;
     CS_HIP(ctx, hipSetDevice(ctx->device));
     const int W = l->W, H = l->H, w = l->w, h = l->h, F = l->n_frames;
-    l->have_desc = false;
+    l->have_desc = false; l->scaled_kept = true;
+    // d_blur and d_scaled (doubles: 2.5 + 1.6 MB per frame) only live from one kernel to the next: they are the two halves of one arena (d_tmp) that the device region stage
+    // takes over for its pixel records once lsd_gradient is through, and the LBD blur for its one-kernel life (see below): 4.0 MB per frame that are not allocated twice
     CS_LAUNCH(ctx, "lsd_blur_hv", lsd_blur_hv, dim3(((W + 63) / 64) * ((H + LSD_ROWS - 1) / LSD_ROWS), 1, F), dim3(64), 0, l->d_gray, W, H, l->gk, l->d_blur);
     CS_LAUNCH(ctx, "lsd_resize", lsd_resize, dim3((w + 255) / 256, h, F), dim3(256), 0, l->d_blur, W, H, w, h, l->d_xofs, l->d_ax, l->d_yofs, l->d_ay, l->d_scaled);
     const int nbx = l->nbx, n_seg = F * h * nbx;
@@ -624,11 +631,10 @@ static int lsd_run(cs_ctx *ctx, cs_lsd *l, int with_lbd) {
         void *old[] = {l->d_caddr, l->d_cdeg, l->d_ccs, l->d_cmod};
         for (void *q : old) if (q) hipFree(q);
         l->d_caddr = nullptr; l->d_cdeg = nullptr; l->d_ccs = nullptr; l->d_cmod = nullptr; l->ccap = 0;
-        const size_t cap = total + total / 4 + 4096;
+        const size_t cap = total + total / 16 + 4096; // (16 B per defined pixel, 75 M of them in a 1 024-frame batch: a sixteenth of headroom, a larger batch reallocates)
         r = cs_dalloc(ctx, &l->d_caddr, cap); if (r) return r;
         r = cs_dalloc(ctx, &l->d_cdeg, cap); if (r) return r;
         r = cs_dalloc(ctx, &l->d_ccs, cap); if (r) return r;
-        r = cs_dalloc(ctx, &l->d_cmod, cap); if (r) return r;
         l->ccap = cap;
     }
     // region growing / rectangles / NFA (a15): interchangeable stages with byte-identical KeyLines (tests/test_lsd_gpu.py).
@@ -640,28 +646,41 @@ static int lsd_run(cs_ctx *ctx, cs_lsd *l, int with_lbd) {
     // CUBESLAM_LSD_REGIONS = grp | grp2 | seq | host overrides the choice.
     std::vector<std::vector<float>> dev_lines;
     bool on_device = false;
-    if (total > 0) CS_LAUNCH(ctx, "lsd_emit", lsd_emit, dim3(nbx, h, F), dim3(256), 0, l->d_mod, l->d_ang, w, h, l->d_seg_base, l->d_caddr, l->d_cdeg, l->d_ccs, l->d_cmod);
     const char *mode = getenv("CUBESLAM_LSD_REGIONS");
     if (!mode || !*mode) mode = F >= 512 ? "seq" : "host";
     const int grp_p = strcmp(mode, "grp") == 0 ? 1 : (strcmp(mode, "grp2") == 0 ? 2 : (strcmp(mode, "lpf") == 0 ? 64 : 0)); // lsd_rg_grp<P>: several frames per wave; lsd_rg_lpf: one lane per frame
     const bool use_seq = total > 0 && (strcmp(mode, "seq") == 0 || grp_p);
+    auto emit = [&](bool with_norms) -> int { // the compacted norms (8 B per defined pixel) are the host stage's: the device stage reads the dense map
+        if (with_norms && !l->d_cmod) { const int q = cs_dalloc(ctx, &l->d_cmod, l->ccap); if (q) return q; }
+        CS_LAUNCH(ctx, "lsd_emit", lsd_emit, dim3(nbx, h, F), dim3(256), 0, l->d_mod, l->d_ang, w, h, l->d_seg_base, l->d_caddr, l->d_cdeg, l->d_ccs, with_norms ? l->d_cmod : (double *)nullptr);
+        return CS_OK;
+    };
+    if (total > 0) { r = emit(!use_seq); if (r) return r; }
+    const bool late_maps = [&] { const char *e = getenv("CUBESLAM_LBD_MAPS"); return !(e && !strcmp(e, "early")); }();
     auto lbd_maps = [&]() -> int { // the derivative maps only depend on the gray frames
-        if (!l->d_lblur) {
-            const size_t N = (size_t)W * H * l->max_frames;
-            int q = cs_dalloc(ctx, &l->d_lblur, N); if (q) return q;
-            q = cs_dalloc(ctx, &l->d_dxy, N); if (q) return q;
-        }
-        return cs_lbd_batch_maps(ctx, l->d_gray, W, H, F, l->d_lblur, l->d_dxy);
+        // device region stage: the Sobel map (4 B per pixel) is made once the stage is through, in the arena it has left -- [dxy | ... | blurred frames behind the pixel records' place];
+        // CUBESLAM_LBD_MAPS=early makes it ahead of the stage in a buffer of its own (the phased runner wants every map kernel of a batch on the GPU before its gate)
+        uint8_t *lblur = l->d_lblur;
+        uint32_t *dxy = l->d_dxy;
+        if (use_seq) lblur = reinterpret_cast<uint8_t *>(l->d_tmp) + l->pix_bytes; // the blurred frames are the Sobel kernel's input and nothing else
+        else if (!lblur) { const int q = cs_dalloc(ctx, &l->d_lblur, (size_t)W * H * l->max_frames); if (q) return q; lblur = l->d_lblur; }
+        if (use_seq && late_maps) dxy = reinterpret_cast<uint32_t *>(l->d_tmp);
+        else if (!dxy) { const int q = cs_dalloc(ctx, &l->d_dxy, (size_t)W * H * l->max_frames); if (q) return q; dxy = l->d_dxy; }
+        l->dxy_cur = dxy;
+        return cs_lbd_batch_maps(ctx, l->d_gray, W, H, F, lblur, dxy);
     };
     bool maps_done = false;
-    if (use_seq && with_lbd) { r = lbd_maps(); if (r) return r; maps_done = true; } // ahead of the region stage: every map kernel of the batch is on the GPU before the phase gate
+    if (use_seq && with_lbd && !late_maps) { r = lbd_maps(); if (r) return r; maps_done = true; } // ahead of the region stage: every map kernel of the batch is on the GPU before the phase gate
     if (l->gate_wait && !use_seq) l->gate_wait(l->gate_arg); // (phased front-end: the region stage starts when the caller's own GPU work of the phase is done; the device stage waits inside lsd_seq_run, in front of its one long kernel)
     if (use_seq) {
         long st[4] = {0, 0, 0, 0};
-        r = lsd_seq_run(ctx, &l->seq, F, w, h, l->d_ang, l->d_mod, l->d_caddr, l->d_cdeg, l->d_ccs, l->frame_base.data(), dev_lines, st, l->gate_wait, l->gate_done, l->gate_arg, grp_p, l->seq_wpb);
+        l->scaled_kept = false; // the arena is the region stage's from here on
+        r = lsd_seq_run(ctx, &l->seq, F, w, h, l->d_ang, l->d_mod, l->d_caddr, l->d_cdeg, l->d_ccs, l->frame_base.data(), dev_lines, st, l->gate_wait, l->gate_done, l->gate_arg, grp_p, l->seq_wpb,
+                        l->d_tmp, l->pix_bytes);
         l->rg_stats[0] = 1; l->rg_stats[1] = st[0]; l->rg_stats[2] = st[2]; l->rg_stats[3] = r == CS_OK ? 0 : 1; l->rg_stats[4] = st[1];
         if (r == CS_OK) on_device = true;
         else if (r != CS_ERR_CAPACITY) return r; // a region outgrew the wave's list: the host stage takes the batch
+        else { r = emit(true); if (r) return r; }
     } else
         for (int k = 0; k < 5; k++) l->rg_stats[k] = 0;
     if (!on_device && total > l->hcap) {
@@ -680,7 +699,7 @@ static int lsd_run(cs_ctx *ctx, cs_lsd *l, int with_lbd) {
     }
     hipEvent_t ev = ctx->get_event();
     CS_HIP(ctx, hipEventRecord(ev, ctx->stream));
-    if (with_lbd && !maps_done) { r = lbd_maps(); if (r) return r; } // they run while the host grows regions
+    if (with_lbd && !maps_done && !(use_seq && late_maps && on_device)) { r = lbd_maps(); if (r) return r; maps_done = true; } // they run while the host grows regions
     CS_HIP(ctx, hipEventSynchronize(ev));
     ctx->pool.push_back(ev);
     // one BATCHED host stage at a time per process: two line detectors that alternate batches (bench.py) overlap their GPU phases with
@@ -751,7 +770,8 @@ static int lsd_run(cs_ctx *ctx, cs_lsd *l, int with_lbd) {
             r = cs_h2d(ctx, l->d_kl, kl.data(), (size_t)nl); if (r) return r;
             r = cs_h2d(ctx, l->d_line_frame, lf.data(), (size_t)nl); if (r) return r;
             CS_HIP(ctx, hipStreamSynchronize(ctx->stream)); // kl, lf are locals
-            r = cs_lbd_batch_desc(ctx, l->d_kl, l->d_line_frame, nl, l->d_dxy, W, H, l->d_desc, nullptr); if (r) return r;
+            if (!maps_done) { r = lbd_maps(); if (r) return r; } // (device region stage: its pixel records are dead now, the Sobel map takes their place)
+            r = cs_lbd_batch_desc(ctx, l->d_kl, l->d_line_frame, nl, l->dxy_cur, W, H, l->d_desc, nullptr); if (r) return r;
             r = cs_d2h(ctx, l->h_desc.data(), l->d_desc, (size_t)nl * 32); if (r) return r;
         }
         CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
@@ -765,7 +785,7 @@ extern "C" {
 void cs_lsd_destroy(cs_ctx *ctx, cs_lsd *l) {
     if (!l) return;
     if (ctx) { hipSetDevice(ctx->device); hipStreamSynchronize(ctx->stream); }
-    void *ptrs[] = {l->d_gray, l->d_tmp, l->d_blur, l->d_scaled, l->d_mod, l->d_ang, l->d_xofs, l->d_yofs, l->d_ax, l->d_ay, l->d_lblur, l->d_dxy};
+    void *ptrs[] = {l->d_gray, l->d_tmp, l->d_mod, l->d_ang, l->d_xofs, l->d_yofs, l->d_ax, l->d_ay, l->d_lblur, l->d_dxy};
     for (void *p : ptrs) if (p) hipFree(p);
     lsd_free_lines(l);
     lsd_seq_destroy(l->seq);
@@ -798,8 +818,10 @@ int cs_lsd_create(cs_ctx *ctx, int width, int height, int max_frames, cs_lsd **o
     for (int dy = 0; dy < l->h; dy++) { float fy = (float)((dy + 0.5) * sx - 0.5); int s = fl(fy); fy -= s; if (s < 0) { fy = 0; s = 0; } if (s >= height - 1) { fy = 0; s = height - 1; } yofs[dy] = s; ay[dy * 2] = 1.f - fy; ay[dy * 2 + 1] = fy; }
     const size_t N = (size_t)width * height * max_frames, n = (size_t)l->w * l->h * max_frames;
 #define A_(call) do { int r__ = (call); if (r__ != CS_OK) { cs_lsd_destroy(ctx, l); return r__; } } while (0)
-    A_(cs_dalloc(ctx, &l->d_gray, N)); A_(cs_dalloc(ctx, &l->d_blur, N));
-    A_(cs_dalloc(ctx, &l->d_scaled, n)); A_(cs_dalloc(ctx, &l->d_mod, n)); A_(cs_dalloc(ctx, &l->d_ang, n));
+    // one arena for [blurred | scaled] frames; afterwards [pixel records of the device region stage (16 B per scaled pixel) | LBD blur (1 B per pixel)]: 16 n + N <= 8 N + 8 n bytes
+    l->pix_bytes = n * 16;
+    A_(cs_dalloc(ctx, &l->d_gray, N)); A_(cs_dalloc(ctx, &l->d_tmp, N + n)); l->d_blur = l->d_tmp; l->d_scaled = l->d_tmp + N;
+    A_(cs_dalloc(ctx, &l->d_mod, n)); A_(cs_dalloc(ctx, &l->d_ang, n));
     A_(cs_dalloc(ctx, &l->d_xofs, xofs.size())); A_(cs_dalloc(ctx, &l->d_yofs, yofs.size())); A_(cs_dalloc(ctx, &l->d_ax, ax.size())); A_(cs_dalloc(ctx, &l->d_ay, ay.size()));
     l->nbx = (l->w + 255) / 256;
     A_(cs_dalloc(ctx, &l->d_seg_cnt, (size_t)max_frames * l->h * l->nbx)); A_(cs_dalloc(ctx, &l->d_seg_base, (size_t)max_frames * l->h * l->nbx + 1));
@@ -892,10 +914,15 @@ int cs_lsd_get_maps(cs_ctx *ctx, cs_lsd *l, int frame, double *scaled, double *m
     *sw = l->w; *sh = l->h;
     const size_t n = (size_t)l->w * l->h;
     int r;
-    if (scaled) { r = cs_d2h(ctx, scaled, l->d_scaled + n * frame, n); if (r) return r; }
+    if (scaled) {
+        if (!l->scaled_kept) { ctx->err = "cs_lsd_get_maps: the scaled frames are gone once the device region stage ran (it takes their buffer over); modgrad and angles are kept"; return CS_ERR_BAD_ARG; }
+        r = cs_d2h(ctx, scaled, l->d_scaled + n * frame, n); if (r) return r;
+    }
     if (modgrad) { r = cs_d2h(ctx, modgrad, l->d_mod + n * frame, n); if (r) return r; }
-    if (angles) { r = cs_d2h(ctx, angles, l->d_ang + n * frame, n); if (r) return r; }
+    std::vector<float> deg;
+    if (angles) { deg.resize(n); r = cs_d2h(ctx, deg.data(), l->d_ang + n * frame, n); if (r) return r; }
     CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (angles) for (size_t i = 0; i < n; i++) angles[i] = deg[i] == NOTDEF_DEG ? NOTDEF : double(deg[i]) * DEG_TO_RADS; // the reference's map value (:566)
     return CS_OK;
 }
 

@@ -39,7 +39,7 @@
 namespace {
 constexpr int PAD_PX = 272, PAD_LIST = 272, PAD_RECT = 34; // (lsd_rg_grp) 4352 / 4352 / 272 bytes between the frames' slices: see rgg::Batch
 constexpr double PI_ = rg::PI_, LOG_EPS = 0.0, LSD_SCALE = 0.8;
-struct AngMap { int w, h; const double *ang; }; // a frame's level-line angles (doubles, NOTDEF where the gradient is below the threshold)
+struct AngMap { int w, h; const float *deg; }; // a frame's level-line angles as lsd_gradient leaves them: float degrees, NOTDEF_F where the gradient is below the threshold; the map value is deg * DEG_TO_RADS in double
 
 // ---- rect_improve / rect_nfa / nfa: one wave per rectangle -------------------------------------------------------------------------------
 __device__ double rg_log_gamma(double x) { // lsd.cpp:70,124-160
@@ -127,8 +127,9 @@ template <int NP> __device__ void rg_rect_count(const AngMap &F, const rg::Rect 
         const long lx = max((long)ox[mn] + adv(flstep, slstep, oy[lm]), 0L), rx = min((long)ox[mn] + adv(frstep, srstep, oy[rm]), (long)F.w - 1);
         for (long x = lx; x <= rx; ++x) {
             ++total_pts;
-            const double a = F.ang[(int)(y * F.w + x)];
-            if (a == rg::NOTDEF) continue;
+            const float ad = F.deg[(int)(y * F.w + x)];
+            if (ad == rgs::NOTDEF_F) continue;
+            const double a = double(ad) * rg::DEG_TO_RADS;
             const double d = fabs(rec.theta - a), d2 = fabs(d - rg::M_2__PI_), nt = d > rg::M_3_2_PI_ ? d2 : d; // isAligned :1138-1154
             for (int k = 0; k < NP; k++) alg_pts[k] += nt <= precs[k];
         }
@@ -197,7 +198,7 @@ __device__ double rg_rect_improve(const AngMap &F, rg::Rect &rec, double LOG_NT,
 // ---- the sequential stage: one wave per frame (lsd_rg_seq.h) ------------------------------------------------------------------------------
 struct SeqParams {
     int F, w, h;
-    const int *caddr; const int *frame_base; const float *cdeg; const float2 *ccs; const double *mod, *ang;
+    const int *caddr; const int *frame_base; const float *cdeg; const float2 *ccs; const double *mod; const float *ang;
     rgs::Px *pix; float *ang32; float *seed_cs; int *glist; double *rect; size_t rect_stride; int cand_cap; int *cand_cnt; int *status;
     int min_reg_size, list_cap;
     unsigned long long *prof;
@@ -309,10 +310,9 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RG_IMP
 
 // ---- host side of the sequential stage ----------------------------------------------------------------------------------------------------
 struct LsdSeq {
-    int F = 0, w = 0, h = 0; int cand_cap = 0; size_t cap_lines = 0, cap_def = 0;
-    rgs::Px *d_pix = nullptr;
+    int F = 0, w = 0, h = 0; int cand_cap = 0; size_t cap_lines = 0;
+    rgs::Px *d_pix = nullptr; bool pix_borrowed = false; // (borrowed: the caller's scratch, not freed here)
     rgg::Ent *d_elist = nullptr; float *d_ang32 = nullptr; int *d_order = nullptr; // the several-frames-per-wave walk: region lists of 8-byte entries, a float per pixel, the frames sorted by work
-    float *d_seed_cs = nullptr;
     int *d_glist = nullptr, *d_cand_cnt = nullptr, *d_cand_base = nullptr, *d_status = nullptr, *d_frame_base = nullptr;
     double *d_rect = nullptr, *d_lgt = nullptr;
     uint8_t *d_has = nullptr;
@@ -321,18 +321,19 @@ struct LsdSeq {
 };
 void lsd_seq_destroy(LsdSeq *r) {
     if (!r) return;
-    void *ptrs[] = {r->d_elist, r->d_ang32, r->d_order, r->d_pix, r->d_seed_cs, r->d_glist, r->d_cand_cnt, r->d_cand_base, r->d_status, r->d_frame_base, r->d_rect, r->d_lgt, r->d_has, r->d_line};
+    void *ptrs[] = {r->d_elist, r->d_ang32, r->d_order, r->pix_borrowed ? nullptr : r->d_pix, r->d_glist, r->d_cand_cnt, r->d_cand_base, r->d_status, r->d_frame_base, r->d_rect, r->d_lgt, r->d_has, r->d_line};
     for (void *p : ptrs) if (p) hipFree(p);
     delete r;
 }
 // The region stage of F frames, one wave per frame.  lines[f] = x1 y1 x2 y2 floats in the reference's emission order.  CS_ERR_CAPACITY: a region
 // outgrew the wave's list (rgs::CAP pixels) or a frame its rectangle list -- the caller then runs the host stage for the batch.
-int lsd_seq_run(cs_ctx *ctx, LsdSeq **handle, int F, int w, int h, const double *d_ang, const double *d_mod, const int *d_caddr, const float *d_cdeg, const float2 *d_ccs, const int *frame_base,
+int lsd_seq_run(cs_ctx *ctx, LsdSeq **handle, int F, int w, int h, const float *d_ang, const double *d_mod, const int *d_caddr, const float *d_cdeg, const float2 *d_ccs, const int *frame_base,
                 std::vector<std::vector<float>> &lines, long *stats /* [0] region_grow calls, [1] window fetches, [2] rectangles at rect_improve, [3] regions at the rectangle stage */,
                 void (*before_seq)(void *), void (*after_seq)(void *), void *gate_arg /* the front-end runner's phase gate: called in front of the lsd_rg_seq launch and once it has left the GPU; may be NULL */,
                 int grp_p /* 0: lsd_rg_seq, one wave per frame; 1 / 2: lsd_rg_grp<P>, 8 / 4 frames per wave; 64: lsd_rg_lpf, one lane per frame */,
                 int waves_per_workgroup /* frames per workgroup of lsd_rg_seq: 16 packs a batch onto F / 16 CUs and leaves the others empty; 4 spreads it over the chip (the alternating runner, where
-                                           every CU is busy anyway: 128 -> 104 ms per launch there) */) {
+                                           every CU is busy anyway: 128 -> 104 ms per launch there) */,
+                void *scratch, size_t scratch_bytes /* memory the caller has no use for while the stage runs: lsd_rg_seq's pixel records go there when it is large enough */) {
     LsdSeq *r = *handle;
     if (w > 0xffff || h > 0x7fff) return CS_ERR_CAPACITY; // (the region list packs x | y << 16)
     int max_ne = 0;
@@ -351,17 +352,10 @@ int lsd_seq_run(cs_ctx *ctx, LsdSeq **handle, int F, int w, int h, const double 
         RA_(cs_dalloc(ctx, &r->d_lgt, (size_t)LG_N));
         CS_LAUNCH(ctx, "lsd_rg_lgamma_table", lsd_rg_lgamma_table, dim3(LG_N / 256), dim3(256), 0, r->d_lgt);
     }
-    if (r->cap_def < (size_t)frame_base[F]) {
-        if (r->d_seed_cs) hipFree(r->d_seed_cs);
-        r->d_seed_cs = nullptr; r->cap_def = 0;
-        const size_t cap = (size_t)frame_base[F] + frame_base[F] / 4 + 4096;
-        RA_(cs_dalloc(ctx, &r->d_seed_cs, 2 * cap));
-        r->cap_def = cap;
-    }
     RA_(cs_h2d(ctx, r->d_frame_base, frame_base, (size_t)F + 1));
     SeqParams S;
     S.F = F; S.w = w; S.h = h; S.caddr = d_caddr; S.frame_base = r->d_frame_base; S.cdeg = d_cdeg; S.ccs = d_ccs; S.mod = d_mod; S.ang = d_ang;
-    S.pix = r->d_pix; S.ang32 = nullptr; S.seed_cs = r->d_seed_cs; S.glist = r->d_glist; S.rect = r->d_rect; S.cand_cap = r->cand_cap; S.cand_cnt = r->d_cand_cnt; S.status = r->d_status;
+    S.pix = r->d_pix; S.ang32 = nullptr; S.seed_cs = reinterpret_cast<float *>(const_cast<float2 *>(d_ccs)); /* in place: lsd_rg_scatter reads a pixel's cos / sin (floats of the float angle) and leaves the seed's (of the double angle) in the same 8 bytes */ S.glist = r->d_glist; S.rect = r->d_rect; S.cand_cap = r->cand_cap; S.cand_cnt = r->d_cand_cnt; S.status = r->d_status;
     const double LOG_NT = 5 * (std::log10(double(w)) + std::log10(double(h))) / 2 + std::log10(11.0);
     S.min_reg_size = int(-LOG_NT / std::log10(rg::ANG_TH / 180));
     S.list_cap = rgs::CAP;
@@ -385,7 +379,10 @@ int lsd_seq_run(cs_ctx *ctx, LsdSeq **handle, int F, int w, int h, const double 
         S.ang32 = r->d_ang32 + head;
         CS_LAUNCH(ctx, "lsd_rg_fill", lsd_rg_fill32, dim3((unsigned)(((npx + head) / 4 + 1 + 255) / 256)), dim3(256), 0, reinterpret_cast<float4 *>(r->d_ang32), (npx + head) / 4 + 1);
     } else {
-        if (!r->d_pix) RA_(cs_dalloc(ctx, &r->d_pix, (size_t)r->F * w * h));
+        if (!r->d_pix) {
+            if (scratch && scratch_bytes >= (size_t)r->F * w * h * sizeof(rgs::Px)) { r->d_pix = static_cast<rgs::Px *>(scratch); r->pix_borrowed = true; }
+            else RA_(cs_dalloc(ctx, &r->d_pix, (size_t)r->F * w * h));
+        }
         if (!r->d_glist) RA_(cs_dalloc(ctx, &r->d_glist, (size_t)r->F * rgs::CAP));
         S.pix = r->d_pix; S.glist = r->d_glist;
         CS_LAUNCH(ctx, "lsd_rg_fill", lsd_rg_fill, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, r->d_pix, npx);
@@ -421,7 +418,7 @@ int lsd_seq_run(cs_ctx *ctx, LsdSeq **handle, int F, int w, int h, const double 
                     const int fc = std::min(chunk, F - c0);
                     rgl::Batch &B = L.slice[L.n_slices++];
                     B.F = fc; B.w = w; B.h = h; B.npx = (int)npx; B.order = r->d_order + c0; B.ang_stride = (int)S.pix_stride; B.list_stride = (int)list_stride; B.rect_stride = (int)rect_stride; B.ang_head = (int)head;
-                    B.caddr = d_caddr + frame_base[c0]; B.frame_base = r->d_frame_base + c0; B.ang = r->d_ang32 + (size_t)c0 * S.pix_stride; B.mod = d_mod + (size_t)c0 * npx; B.seed_cs = r->d_seed_cs + 2 * (size_t)frame_base[c0];
+                    B.caddr = d_caddr + frame_base[c0]; B.frame_base = r->d_frame_base + c0; B.ang = r->d_ang32 + (size_t)c0 * S.pix_stride; B.mod = d_mod + (size_t)c0 * npx; B.seed_cs = S.seed_cs + 2 * (size_t)frame_base[c0];
                     B.list = reinterpret_cast<rgl::Ent *>(r->d_elist) + (size_t)c0 * list_stride; B.list_cap = std::min(S.list_cap, rgl::CAP); B.rect = r->d_rect + (size_t)c0 * rect_stride; B.cand_cap = r->cand_cap; B.cand_cnt = r->d_cand_cnt + c0; B.status = r->d_status + 4 * (size_t)c0;
                     B.min_reg_size = S.min_reg_size; B.max_iters = (int)std::min<size_t>(64 * npx, 0x7fffffff);
                 }
@@ -438,7 +435,7 @@ int lsd_seq_run(cs_ctx *ctx, LsdSeq **handle, int F, int w, int h, const double 
                 const int fc = std::min(chunk, F - c0);
                 rgg::Batch &B = L.slice[L.n_slices++];
                 B.F = fc; B.w = w; B.h = h; B.npx = (int)npx; B.order = r->d_order + c0; B.ang_stride = (int)S.pix_stride; B.list_stride = (int)list_stride; B.rect_stride = (int)rect_stride;
-                B.caddr = d_caddr + frame_base[c0]; B.frame_base = r->d_frame_base + c0; B.ang = r->d_ang32 + head + (size_t)c0 * S.pix_stride; B.mod = d_mod + (size_t)c0 * npx; B.seed_cs = r->d_seed_cs + 2 * (size_t)frame_base[c0];
+                B.caddr = d_caddr + frame_base[c0]; B.frame_base = r->d_frame_base + c0; B.ang = r->d_ang32 + head + (size_t)c0 * S.pix_stride; B.mod = d_mod + (size_t)c0 * npx; B.seed_cs = S.seed_cs + 2 * (size_t)frame_base[c0];
                 B.list = r->d_elist + (size_t)c0 * list_stride; B.list_cap = std::min(S.list_cap, rgg::CAP); B.rect = r->d_rect + (size_t)c0 * rect_stride; B.cand_cap = r->cand_cap; B.cand_cnt = r->d_cand_cnt + c0; B.status = r->d_status + 4 * (size_t)c0;
                 B.min_reg_size = S.min_reg_size; B.max_iters = (int)std::min<size_t>(64 * npx, 0x7fffffff);
                 B.prof = nullptr;

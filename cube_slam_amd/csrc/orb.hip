@@ -900,7 +900,7 @@ struct cs_orb {
     std::vector<int> mnFeaturesPerLevel;
     Pyr P{};
     int max_tiles = 0, max_blur_blocks = 0;
-    long cand_cap = 0; // total candidates capacity (all frames)
+    long cand_cap = 0, cand_alloc = 0; // candidates of all frames: the worst case, and what d_cand / d_qperm / d_qtmp hold room for (grown to a batch's count, cs_orb_run)
     // device
     uint8_t *d_pyr = nullptr, *d_smap = nullptr, *d_blur = nullptr;
     unsigned long long *d_cell_mask = nullptr; // per cell: the NMS survivors of orb_cells' counting pass, one bit per pixel of the cell's window
@@ -1041,7 +1041,8 @@ int cs_orb_create(cs_ctx *ctx, int nfeatures, float scaleFactor, int nlevels, in
     A_(cs_dalloc(ctx, &e->d_cell_base, (size_t)cells * max_frames));
     A_(cs_dalloc(ctx, &e->d_level_total, (size_t)nlevels * max_frames));
     A_(cs_dalloc(ctx, &e->d_level_base, (size_t)nlevels * max_frames + 1));
-    A_(cs_dalloc(ctx, &e->d_cand, (size_t)e->cand_cap * 3));
+    // (d_cand and the quadtree's two permutation arrays are sized by the candidates a batch really has, known before they are written: cs_orb_run.  Their worst case,
+    // a corner in every other pixel of every level, would be 4.9 MB per frame)
     A_(cs_dalloc(ctx, &e->d_sel, (size_t)e->sel_cap));
     A_(cs_dalloc(ctx, &e->d_angle, (size_t)e->sel_cap));
     A_(cs_dalloc(ctx, &e->d_kps, (size_t)e->sel_cap));
@@ -1066,7 +1067,6 @@ int cs_orb_create(cs_ctx *ctx, int nfeatures, float scaleFactor, int nlevels, in
         const char *force = getenv("CUBESLAM_ORB_QUADTREE"); // "host": keep DistributeOctTree on the host (tests compare both)
         e->gpu_quadtree = ok && maxN >= 1 && CAPN < 32768 && e->qt_lds <= 150 * 1024 && !(force && !strcmp(force, "host"));
         if (e->gpu_quadtree) {
-            A_(cs_dalloc(ctx, &e->d_qperm, (size_t)e->cand_cap)); A_(cs_dalloc(ctx, &e->d_qtmp, (size_t)e->cand_cap));
             A_(cs_dalloc(ctx, &e->d_qnodes, (size_t)Q.nodes_per_frame * max_frames)); A_(cs_dalloc(ctx, &e->d_slots, (size_t)Q.slots_per_frame * max_frames));
             A_(cs_dalloc(ctx, &e->d_slot_cnt, (size_t)nlevels * max_frames)); A_(cs_dalloc(ctx, &e->d_sel_base, (size_t)nlevels * max_frames + 1));
             A_(cs_dalloc(ctx, &e->d_qstatus, (size_t)1));
@@ -1122,6 +1122,15 @@ int cs_orb_run(cs_ctx *ctx, cs_orb *e) {
     CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const long total = e->level_base[(size_t)F * NL];
     if (total > e->cand_cap) { ctx->err = "ORB candidate capacity exceeded"; return CS_ERR_CAPACITY; }
+    if (total > e->cand_alloc) { // the second pass of orb_cells writes `total` candidates: room for them and a quarter more
+        void *old[] = {e->d_cand, e->d_qperm, e->d_qtmp};
+        for (void *q : old) if (q) hipFree(q);
+        e->d_cand = nullptr; e->d_qperm = nullptr; e->d_qtmp = nullptr; e->cand_alloc = 0;
+        const long cap = std::min<long>(e->cand_cap, total + total / 4 + 4096);
+        r = cs_dalloc(ctx, &e->d_cand, (size_t)cap * 3); if (r) return r;
+        if (e->gpu_quadtree) { r = cs_dalloc(ctx, &e->d_qperm, (size_t)cap); if (r) return r; r = cs_dalloc(ctx, &e->d_qtmp, (size_t)cap); if (r) return r; }
+        e->cand_alloc = cap;
+    }
     CS_LAUNCH(ctx, "orb_cells", orb_cells, dim3((P.cells_per_frame + CELLS_PER_WG - 1) / CELLS_PER_WG, F), dim3(64 * CELLS_PER_WG), 0, P, e->d_smap, 1, e->d_cell_count, e->d_cell_base, e->d_cand, e->d_cell_mask);
     bool on_device = e->gpu_quadtree;
     if (on_device) {
