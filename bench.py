@@ -198,7 +198,7 @@ def ba_bench(ctx, rank, world, iters, with_cpu, with_traffic=False):
 
 
 # ---------------------------------------------------------------------------------------------------------------- config 3
-def c3_bench(ctx, frames, steps, with_cpu):
+def c3_bench(ctx, frames, steps, with_cpu, with_traffic=False):
     """BASELINE config 3: 1241x376 stream (1/f texture moving 3 px per frame), 2000 ORB features + LSD/LBD lines per frame and the
     tracking thread's frame-to-frame ORBmatcher::SearchByProjection (th = 15) from the extractor's device buffers."""
     from cube_slam_amd import synth
@@ -260,8 +260,9 @@ def c3_bench(ctx, frames, steps, with_cpu):
         alg = 40.0 * cstat["queries"] + 32.0 * cstat["candidates"]
         us = 1e3 * cand_ms / cand_n
         ach = alg / (us * 1e-6) / 1e9
-        out["roofline"] = {"bound": "hbm", "kernel": "match_candidates", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None,
-                           "avg_kernel_us": us, "algorithmic_bytes_per_launch": alg, "queries_per_launch": cstat["queries"], "candidates_per_launch": cstat["candidates"],
+        tr = measure_traffic("match_candidates", "pmc_c3.py", [8]) if with_traffic else None  # (its launches on eight frames of the same stream, the local-map launch among them)
+        out["roofline"] = {"bound": "hbm", "kernel": "match_candidates", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None if tr is None else tr["bytes"],
+                           "traffic_detail": tr, "avg_kernel_us": us, "algorithmic_bytes_per_launch": alg, "queries_per_launch": cstat["queries"], "candidates_per_launch": cstat["candidates"],
                            "note": "one launch per frame (2000 queries): launch-latency-bound at this size; batching frames is what the stream forbids"}
     # The kernel at the size TrackLocalMap gives it: ORBmatcher::SearchByProjection(F, vpMapPoints, th) (ORBmatcher.cc:50-142) with a local map of 10 000 points in view
     # of one frame -- the key points of five frames of the stream stand in for the map points (projections, descriptors, predicted levels) -- one launch, no frame loop.
@@ -337,7 +338,7 @@ def c3_bench(ctx, frames, steps, with_cpu):
     return out
 
 
-def c4_bench(ctx, frames, boxes, yaw_step, steps, with_cpu):
+def c4_bench(ctx, frames, boxes, yaw_step, steps, with_cpu, with_traffic=False):
     """BASELINE config 4, one GPU's share: `frames` frames x `boxes` boxes through the cuboid path (512 frames shard as 64 per GPU)."""
     from cube_slam_amd.cuboid import CuboidBatch, detect_3d_cuboid
     scenes = make_frames(frames, boxes, seed0=500000)
@@ -366,8 +367,9 @@ def c4_bench(ctx, frames, boxes, yaw_step, steps, with_cpu):
     if k_n:
         us = 1e3 * k_ms / k_n
         alg = 4.0 * st["roi_pixels"] + 200.0 * st["n_valid"]
+        tr = measure_traffic("cuboid_sweep_score", "pmc_run.py", [frames, boxes, yaw_step, BG_TEXTURE, 500000]) if with_traffic else None
         out["roofline"] = {"bound": "hbm", "kernel": "cuboid_sweep_score", "achieved": alg / (us * 1e-6) / 1e9, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": alg / (us * 1e-6) / 1e9 / HBM_PEAK_GBS,
-                           "traffic": None, "avg_kernel_us": us, "filter_kernel_us": 1e3 * f_ms / max(f_n, 1), "algorithmic_bytes_per_launch": alg,
+                           "traffic": None if tr is None else tr["bytes"], "traffic_detail": tr, "frac_by_traffic": None if tr is None else tr["bytes"] / (us * 1e-6) / 1e9 / HBM_PEAK_GBS, "avg_kernel_us": us, "filter_kernel_us": 1e3 * f_ms / max(f_n, 1), "algorithmic_bytes_per_launch": alg,
                            "algorithmic_bytes_formula": "4*A + 200*n_valid (SURVEY 8d, corner construction fused)",
                            "note": "512 units on 256 CUs: two units per persistent workgroup, the kernel is a third of the way into its steady state (see the N=1 line's roofline for 3072 units)"}
     if with_cpu:
@@ -638,8 +640,8 @@ def main():
         tr = measure_traffic("cuboid_sweep_score", "pmc_run.py", [args.frames, args.boxes, args.yaw_step, BG_TEXTURE])
         if not args.no_cpu:
             native_oracle()  # the c3 / c4 CPU legs use the -march=native build too
-        extra["c3"] = c3_bench(ctx, 2 * _lib.lib().cs_host_thread_count(), 3, with_cpu=not args.no_cpu)  # a stream window of two frames per host thread (the region stage's workers)
-        extra["c4"] = c4_bench(ctx, 64, 8, args.yaw_step, 10, with_cpu=not args.no_cpu)
+        extra["c3"] = c3_bench(ctx, 2 * _lib.lib().cs_host_thread_count(), 3, with_cpu=not args.no_cpu, with_traffic=True)  # a stream window of two frames per host thread (the region stage's workers)
+        extra["c4"] = c4_bench(ctx, 64, 8, args.yaw_step, 10, with_cpu=not args.no_cpu, with_traffic=True)
         if lsd is not None:
             extra["chained"] = chained_bench(ctx, fe, lsds, batch, scenes, args.frames, 10, barrier)
         extra["pcie_inclusive"] = pcie_inclusive(ctx, scenes, args.yaw_step, args.orb_features, local_rank=local_rank)

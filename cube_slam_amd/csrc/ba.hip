@@ -1379,6 +1379,7 @@ struct cs_ba {
     std::vector<int> h_slot_dst, h_pos, h_col_off, h_rows; std::vector<uint8_t> h_slot_tr;
     std::vector<int> obs_perm; // sorted-by-landmark position -> caller's observation index
     std::vector<double> h_partials;
+    double *h_pin = nullptr; size_t pin_cap = 0; hipEvent_t ev_trial = nullptr; // pinned [status | partials] of a trial and the event behind their copies (cs_ba_optimize)
 };
 
 namespace {
@@ -1518,6 +1519,8 @@ void cs_ba_destroy(cs_ctx *ctx, cs_ba *b) {
     if (!b) return;
     if (ctx) { hipSetDevice(ctx->device); hipStreamSynchronize(ctx->stream); }
     for (void *p : b->owned) if (p) hipFree(p);
+    if (b->h_pin) hipHostFree(b->h_pin);
+    if (b->ev_trial) hipEventDestroy(b->ev_trial);
     ba_cr_destroy(b->cr);
     delete b;
 }
@@ -1936,6 +1939,12 @@ int cs_ba_optimize(cs_ctx *ctx, cs_ba *b, int iterations, const volatile int *st
     int nBad = 0, r;
     const int nl = G.lm_e - G.lm_b;
     auto terminate = [&]() { return (stop_flag && *stop_flag) || (b->stop8 && *b->stop8); }; // sparse_optimizer.cpp:376, optimization_algorithm_levenberg.cpp:149
+    // A trial is accepted nearly always, and the next iteration then starts by linearising at the state the trial left.  So that system is BUILT AHEAD: enqueued behind the
+    // trial's residual kernels before the host waits for their sums, and the GPU goes from one iteration into the next without the round trip (copy back, decision, launch)
+    // in between.  A rejected trial restores the estimates and rebuilds what the build-ahead overwrote -- residuals, then the system -- from the restored state: the same
+    // kernels on the same bits, so the retried solve sees the system it would have kept (CUBESLAM_BA_AHEAD=0: the plain order).
+    const bool ahead_on = b->world == 1 && !(getenv("CUBESLAM_BA_AHEAD") && atoi(getenv("CUBESLAM_BA_AHEAD")) == 0);
+    bool built_ahead = false;
     for (int it = 0; it < iterations && !terminate(); it++) { // OptimizationAlgorithmLevenberg::solve :61-164
         // computeActiveErrors: after an accepted trial the residual arrays and chi2 on the device are those of the current state (every
         // way out of the trial loop with a rejected last trial also leaves this loop), so only the first iteration evaluates them
@@ -1944,7 +1953,8 @@ int cs_ba_optimize(cs_ctx *ctx, cs_ba *b, int iterations, const volatile int *st
         tempChi = currentChi;
         const double iniChi = currentChi;
         if (it == 0) S.chi2_init = currentChi;
-        r = ba_build_system(ctx, b); if (r) return r;
+        if (!built_ahead) { r = ba_build_system(ctx, b); if (r) return r; }
+        built_ahead = false;
         if (it == 0) { // computeLambdaInit :166-180: tau * max |diag(H)| over all active vertices
             std::vector<double> v((size_t)G.P * 6 + (size_t)b->world, 0.0), hpp((size_t)G.P * 36);
             r = cs_d2h(ctx, hpp.data(), G.Hpp, hpp.size()); if (r) return r;
@@ -1980,17 +1990,28 @@ int cs_ba_optimize(cs_ctx *ctx, cs_ba *b, int iterations, const volatile int *st
                 CS_LAUNCH(ctx, "ba_update", ba_update, dim3((G.n_cams + G.n_cub + nl * 3 + 255) / 256), dim3(256), 0, G);
                 if (nb1 > 0) CS_LAUNCH(ctx, "ba_err_obs", ba_err_obs, dim3(nb1), dim3(256), 0, G, b->d_partials + mp);
                 if (nb2 > 0) CS_LAUNCH(ctx, "ba_err_pose_edges", ba_err_pose_edges, dim3(nb2), dim3(256), 0, G, b->d_partials + 2 * mp);
-                int status = 0;
-                b->h_partials.resize((size_t)mp * 3);
-                r = cs_d2h(ctx, &status, b->d_status, 1); if (r) return r;
-                r = cs_d2h(ctx, b->h_partials.data(), b->d_partials, (size_t)mp * 3); if (r) return r;
-                CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+                const size_t need = (size_t)mp * 3 + 1;
+                if (b->pin_cap < need) {
+                    if (b->h_pin) hipHostFree(b->h_pin);
+                    b->h_pin = nullptr; b->pin_cap = 0;
+                    CS_HIP(ctx, hipHostMalloc((void **)&b->h_pin, need * sizeof(double), hipHostMallocDefault));
+                    b->pin_cap = need;
+                }
+                if (!b->ev_trial) CS_HIP(ctx, hipEventCreateWithFlags(&b->ev_trial, hipEventDisableTiming));
+                int *h_status = reinterpret_cast<int *>(b->h_pin + (size_t)mp * 3);
+                r = cs_d2h(ctx, h_status, b->d_status, 1); if (r) return r;
+                r = cs_d2h(ctx, b->h_pin, b->d_partials, (size_t)mp * 3); if (r) return r;
+                CS_HIP(ctx, hipEventRecord(b->ev_trial, ctx->stream));
+                if (ahead_on && it + 1 < iterations) { r = ba_build_system(ctx, b); if (r) return r; built_ahead = true; } // (the last iteration has no successor to build for)
+                CS_HIP(ctx, hipEventSynchronize(b->ev_trial));
+                const int status = *h_status;
+                const double *hp = b->h_pin;
                 ok2 = status == 0;
                 scale = 0;
-                for (int i = 0; i < nbs; i++) scale += b->h_partials[i];
+                for (int i = 0; i < nbs; i++) scale += hp[i];
                 double chi = 0, c1 = 0, c2 = 0; // same order of additions as ba_compute_errors
-                for (int i = 0; i < nb1; i++) c1 += b->h_partials[(size_t)mp + i];
-                for (int i = 0; i < nb2; i++) c2 += b->h_partials[(size_t)2 * mp + i];
+                for (int i = 0; i < nb1; i++) c1 += hp[(size_t)mp + i];
+                for (int i = 0; i < nb2; i++) c2 += hp[(size_t)2 * mp + i];
                 if (nb1 > 0) chi += c1;
                 if (nb2 > 0) chi += c2;
                 tempChi = chi;
@@ -2019,6 +2040,11 @@ int cs_ba_optimize(cs_ctx *ctx, cs_ba *b, int iterations, const volatile int *st
                 CS_HIP(ctx, hipMemcpyAsync(G.cam, b->d_bak_cam, sizeof(double) * (size_t)G.n_cams * 7, hipMemcpyDeviceToDevice, ctx->stream));
                 if (G.L) CS_HIP(ctx, hipMemcpyAsync(G.pts, b->d_bak_pts, sizeof(double) * (size_t)G.L * 3, hipMemcpyDeviceToDevice, ctx->stream));
                 if (G.n_cub) CS_HIP(ctx, hipMemcpyAsync(G.cub, b->d_bak_cub, sizeof(double) * (size_t)G.n_cub * 7, hipMemcpyDeviceToDevice, ctx->stream));
+                if (built_ahead) { // the system in the buffers is the rejected state's: residuals and system of the restored one again (the retry solves that)
+                    double unused; r = ba_compute_errors(ctx, b, &unused); if (r) return r;
+                    r = ba_build_system(ctx, b); if (r) return r;
+                    built_ahead = false;
+                }
             }
             qmax++;
             S.lm_trials++;

@@ -35,6 +35,7 @@ struct CrView { // device buffers; every per-node array is indexed by the super-
     double *x;                  // solution, 6 per camera (padded to M NB)
     const double *zero, *one;   // a 0.0 and a 1.0 in device memory (branch-free panel loads)
     int *status;
+    int *done; int epoch;    // the chained way back: done[i] == epoch once x of node i is in memory (this solve)
     unsigned long long *dbg; // CUBESLAM_CR_PROF: wall-clock stamps of block 0 at the phase boundaries of every level (100 MHz)
 };
 
@@ -265,6 +266,57 @@ template <int BC> __global__ void __launch_bounds__(64 * ((6 * BC + 63) / 64)) b
     if (tid < NB) W.x[(long)i * NB + tid] = x0 + x1;
 }
 
+// The whole way back as ONE launch: a workgroup per node, in dependency order (root, then the levels from the top: a node's two neighbours were eliminated later
+// than it, so their workgroups have smaller indices and never wait for a larger one -- no deadlock whatever the GPU holds at a time).  A node requests everything
+// of its own first, then waits for done[a] / done[b] to show this solve's epoch, reads the neighbours' solutions past the caches (another XCD's L2 may have
+// written them), and publishes its own behind an agent-scope fence.  Nine dependent launches of ~11 us become one whose levels cost a flag round trip each.
+template <int BC> __global__ void __launch_bounds__(64 * ((6 * BC + 63) / 64)) ba_cr_back_chain(CrView W, int levels) {
+    constexpr int NB = 6 * BC;
+    __shared__ double tv[NB], xn[2 * NB];
+    const int tid = threadIdx.x, nb2 = NB * NB;
+    int level = levels, m = 0, i = 0;
+    bool root = blockIdx.x == 0;
+    if (!root) {
+        int left = (int)blockIdx.x - 1;
+        for (level = levels - 1; level >= 0; level--) {
+            const int step = 1 << level, n = (W.M - step + 2 * step - 1) / (2 * step);
+            if (left < n) break;
+            left -= n;
+        }
+        m = left; i = (1 << level) * (2 * m + 1);
+    }
+    const int step = root ? 0 : 1 << level;
+    const int a = root ? -1 : i - step, b = (root || i + step >= W.M) ? -1 : i + step;
+    const int t = min(tid, NB - 1);
+    double xa_col[NB], xb_col[NB], g_col[NB];
+    const double *XA = W.XaT + (long)i * nb2 + t, *XB = W.XbT + (long)i * nb2 + t, *G = W.Ginv + (long)i * nb2 + t;
+    const double y = W.y[(long)i * NB + t];
+#pragma unroll
+    for (int c = 0; c < NB; c++) { xa_col[c] = a >= 0 ? XA[c * NB] : 0.0; xb_col[c] = b >= 0 ? XB[c * NB] : 0.0; g_col[c] = c >= t ? G[(long)c * NB] : 0.0; }
+    if (tid == 0) {
+        if (a >= 0) while (__hip_atomic_load(&W.done[a], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != W.epoch) __builtin_amdgcn_s_sleep(1);
+        if (b >= 0) while (__hip_atomic_load(&W.done[b], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != W.epoch) __builtin_amdgcn_s_sleep(1);
+    }
+    __syncthreads();
+    if (tid < NB) {
+        xn[tid] = a >= 0 ? __hip_atomic_load(&W.x[(long)a * NB + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+        xn[NB + tid] = b >= 0 ? __hip_atomic_load(&W.x[(long)b * NB + tid], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) : 0.0;
+    }
+    __syncthreads();
+    double v = y, v2 = 0;
+#pragma unroll
+    for (int c = 0; c < NB; c++) { v -= xa_col[c] * xn[c]; v2 -= xb_col[c] * xn[NB + c]; }
+    if (tid < NB) tv[tid] = v + v2;
+    __syncthreads();
+    double x0 = 0, x1 = 0;
+#pragma unroll
+    for (int k = 0; k < NB; k += 2) { x0 += g_col[k] * tv[k]; x1 += g_col[k + 1] * tv[k + 1]; }
+    if (tid < NB) __hip_atomic_store(&W.x[(long)i * NB + tid], x0 + x1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __threadfence();
+    __syncthreads();
+    if (tid == 0) __hip_atomic_store(&W.done[i], W.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 template <int BC> int cr_run(cs_ctx *ctx, const CrView &W) {
     constexpr int NB = 6 * BC, NBP = (NB + 15) / 16 * 16, NCOL = 4 * NB + 1, NT = 256, LDW = 2 * NBP + 1, RPT = (NB + 7) / 8, CPT = (NCOL + 31) / 32;
     const size_t lds = sizeof(double) * (4 * 8 * (size_t)RPT + 4 * 32 * (size_t)CPT + (size_t)NB + (size_t)NBP * LDW);
@@ -277,6 +329,11 @@ template <int BC> int cr_run(cs_ctx *ctx, const CrView &W) {
     }
     CS_LAUNCH(ctx, "ba_cr_eliminate", ba_cr_eliminate<BC>, dim3(1), dim3(NT), lds, W, levels, 1);
     constexpr int BT = 64 * ((NB + 63) / 64);
+    static const bool chain = !(getenv("CUBESLAM_CR_CHAIN") && atoi(getenv("CUBESLAM_CR_CHAIN")) == 0);
+    if (chain) { // (CUBESLAM_CR_CHAIN=0: a launch per level, the cross-check)
+        CS_LAUNCH(ctx, "ba_cr_back", ba_cr_back_chain<BC>, dim3(W.M), dim3(BT), 0, W, levels);
+        return CS_OK;
+    }
     CS_LAUNCH(ctx, "ba_cr_back", ba_cr_back<BC>, dim3(1), dim3(BT), 0, W, levels, 1);
     for (int l = levels - 1; l >= 0; l--) {
         const int step = 1 << l, n = (W.M - step + 2 * step - 1) / (2 * step);
@@ -289,8 +346,9 @@ template <int BC> int cr_run(cs_ctx *ctx, const CrView &W) {
 struct BaCr {
     int C = 0, Bc = 0, BCT = 0, M = 0;
     double *buf = nullptr;
+    int *done = nullptr; int epoch = 0; // ba_cr_back_chain's flags (zeroed once; a solve's epoch never repeats)
 };
-void ba_cr_destroy(BaCr *w) { if (w) { if (w->buf) hipFree(w->buf); delete w; } }
+void ba_cr_destroy(BaCr *w) { if (w) { if (w->buf) hipFree(w->buf); if (w->done) hipFree(w->done); delete w; } }
 // the elimination kernel of the super-block size the solve would instantiate keeps NBP * LDW + ... doubles in dynamic LDS (77 KB at 10 cameras per
 // super-block): a device that does not offer that much per workgroup takes the band solver instead
 bool ba_cr_supported(int C, int Bc) {
@@ -316,9 +374,12 @@ int ba_cr_solve(cs_ctx *ctx, BaCr **handle, int C, int Bc, const double *d_bandA
         w = new BaCr(); *handle = w;
         w->C = C; w->Bc = Bc; w->BCT = BCT; w->M = M;
         int rc = cs_dalloc(ctx, &w->buf, per * (size_t)M + 64); if (rc) return rc;
+        rc = cs_dalloc(ctx, &w->done, (size_t)M + 1); if (rc) return rc;
+        CS_HIP(ctx, hipMemsetAsync(w->done, 0, sizeof(int) * ((size_t)M + 1), ctx->stream));
     }
     CrView V;
     V.C = C; V.Bc = BCT; V.Bt = Bc; V.M = M; V.NB = NB; V.bandA = d_bandA; V.brhs = d_brhs; V.status = d_status;
+    V.done = w->done; V.epoch = ++w->epoch;
     double *p = w->buf;
     V.accL = p; p += nb2 * M; V.accR = p; p += nb2 * M; V.accrL = p; p += (size_t)NB * M; V.accrR = p; p += (size_t)NB * M; // zeroed every solve
     const size_t zero_bytes = sizeof(double) * (size_t)(p - w->buf);
