@@ -482,6 +482,7 @@ def main():
     ap.add_argument("--line-workers", type=int, default=4, help="line detectors that alternate steps on their own streams (1-4)")
     ap.add_argument("--phased", type=int, default=0, help="0 (default): the alternating runner -- the detectors' region walks hold most CUs all the time and every other kernel runs beside them, the edge-scoring kernel in "
                     "the launch shape that fits into a CU's leftovers; 1: the phased runner (the region stages of --line-workers steps run together with the ORB / cuboid stream idle)")
+    ap.add_argument("--cuboid-stream", type=int, default=0, help="1: the cuboid batch on a stream of its own beside the ORB pass of the same step (cs_frontend_set_cuboid_ctx); 0 (default): behind it on the caller's stream -- measured equal (20.77 k against 20.71 k frames/s: the kernels of both stretch by what they overlap), and the score kernel keeps more of the GPU to itself")
     ap.add_argument("--boxes", type=int, default=3)
     ap.add_argument("--yaw-step", type=float, default=0.5)
     ap.add_argument("--no-cpu", action="store_true")
@@ -534,7 +535,7 @@ def main():
     lsd = None
     if not args.no_lines:
         from cube_slam_amd.lsd import line_lbd_detect
-        args.phased = 1 if args.phased and args.frames >= 512 and os.environ.get("CUBESLAM_LSD_REGIONS", "grp") == "seq" else 0
+        args.phased = 1 if args.phased and args.frames >= 512 and os.environ.get("CUBESLAM_LSD_REGIONS", "seq") == "seq" else 0
         # The library's front-end runner (cs_frontend_*, csrc/frontend.hip) runs ORB + cuboid on this thread and the line path on worker
         # threads with their own contexts (= HIP streams).  The detectors alternate steps.  From 512 frames per step on, region growing runs on
         # the device, one wave per frame for ~110 ms (lsd_regions.hip), sixteen frames to a CU.  Default: the ALTERNATING runner with four
@@ -552,9 +553,17 @@ def main():
     from cube_slam_amd.frontend import Frontend
     fe = Frontend(ctx, orb=orb, batch=batch, line_detectors=lsds if lsd is not None else (), phased=bool(args.phased) and lsd is not None)
 
+    ctx_cub = None
+    if args.cuboid_stream and orb is not None:
+        ctx_cub = _lib.Context(local_rank, priority=int(os.environ.get("BENCH_PRIO_MAIN", "1")))
+        fe.set_cuboid_ctx(ctx_cub)
+    side_ctxs = (ctx_lines if lsd is not None else []) + ([ctx_cub] if ctx_cub is not None else [])
+
     def barrier():
         fe.drain()
         ctx.sync()
+        if ctx_cub is not None:
+            ctx_cub.sync()
         if lsd is not None:
             for c in ctx_lines:
                 c.sync()
@@ -567,7 +576,7 @@ def main():
         fe.step()
     barrier()
     hbm_marks.append(("after_warmup", torch.cuda.mem_get_info()[0]))
-    for c in ([ctx] + ctx_lines if lsd is not None else [ctx]):
+    for c in [ctx] + side_ctxs:
         c.timing(True)
         c.timing_reset()
     t0 = time.perf_counter()
@@ -584,30 +593,30 @@ def main():
                  "lsd_gradient", "lsd_emit", "lsd_rg_fill", "lsd_rg_scatter", "lsd_rg_seq", "lsd_rg_grp", "lsd_rg_improve", "lbd_blur5", "lbd_sobel", "lbd_line_desc", "cuboid_frame_prep", "cuboid_unit_lines", "cuboid_canny_nms", "cuboid_canny_cc_local", "cuboid_canny_cc_border", "cuboid_canny_cc", "cuboid_dt",
                  "cuboid_vp", "cuboid_sweep_filter", "cuboid_sweep_score", "cuboid_select"):
         ms, n = ctx.timing_get(name)
-        if n == 0 and lsd is not None:
-            parts = [c.timing_get(name) for c in ctx_lines]
+        if n == 0 and side_ctxs:
+            parts = [c.timing_get(name) for c in side_ctxs]
             ms, n = sum(p_[0] for p_ in parts), sum(p_[1] for p_ in parts)
         kernels[name] = {"avg_us": 1e3 * ms / max(n, 1), "launches": n}
     ctx.timing(False)
-    if lsd is not None:
-        for c in ctx_lines:
-            c.timing(False)
+    for c in side_ctxs:
+        c.timing(False)
     # the phased runner on the same objects, shortly: its throughput and the score kernel's time in ITS timed region (the kernel never meets a region walk there)
     phased_alt = None
-    if lsd is not None and not args.phased and args.frames >= 512 and os.environ.get("CUBESLAM_LSD_REGIONS", "grp") == "seq" and len(ctx_lines) >= 2 and rank == 0 and world == 1:
+    if lsd is not None and not args.phased and args.frames >= 512 and os.environ.get("CUBESLAM_LSD_REGIONS", "seq") == "seq" and len(ctx_lines) >= 2 and rank == 0 and world == 1:
         fe.set_phased(True)
         for _ in range(len(ctx_lines)):
             fe.step()
         barrier()
-        ctx.timing(True); ctx.timing_reset()
+        tctx = ctx_cub if ctx_cub is not None else ctx  # (the context the cuboid batch's launches are timed on)
+        tctx.timing(True); tctx.timing_reset()
         n_ph = 4 * len(ctx_lines)
         t0 = time.perf_counter()
         for _ in range(n_ph):
             fe.step()
         barrier()
         dt_ph = time.perf_counter() - t0
-        ph_ms, ph_n = ctx.timing_get("cuboid_sweep_score")
-        ctx.timing(False)
+        ph_ms, ph_n = tctx.timing_get("cuboid_sweep_score")
+        tctx.timing(False)
         phased_alt = {"value": args.frames * n_ph / dt_ph, "unit": "frames/s", "ms_per_step": 1e3 * dt_ph / n_ph, "steps": n_ph, "score_kernel_us_in_run": 1e3 * ph_ms / max(ph_n, 1)}
         fe.set_phased(False)
     # the same kernel without kernels of the other paths sharing the GPU: in the launch shape of the timed region, and in the 512-thread shape it has when it owns the CUs

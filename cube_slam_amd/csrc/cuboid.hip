@@ -1471,8 +1471,10 @@ __device__ inline void corners_to_3d(const double *cx, const double *cy, const C
 }
 
 // flag bits after selection: bits 0-1 vp_1_position, bit 2 kept by fuse_normalize, bit 3 candidate for final ranking
+// Register budget: two waves per SIMD (225 registers) is the kernel's best alone (0.66 ms per 3 072 boxes) -- and a workgroup that needs 4 x 225 registers free on one CU
+// waits for them when region walks hold 2-3 x 96 on every SIMD: 9.4 ms per launch in the batch runner.  Three waves (168 registers, 216 B of scratch): 2.9 ms there.
 #ifndef SELECT_WAVES
-#define SELECT_WAVES 2
+#define SELECT_WAVES 3
 #endif
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(SELECT_WAVES, SELECT_WAVES))) cuboid_select(const Unit *units, UnitDyn *ud, const int *box_first_unit, const FrameDyn *fd,
                                                      const FrameInfo *fi, const CamRP *cam, const double *yaw, Calib cal, Opts o,

@@ -90,6 +90,7 @@ struct LineWorker {
 
 struct cs_frontend {
     cs_ctx *ctx = nullptr; cs_orb *orb = nullptr; cs_cuboid_batch *batch = nullptr;
+    cs_ctx *cub_ctx = nullptr; // cs_frontend_set_cuboid_ctx: the context (stream) the cuboid batch is enqueued on -- the caller's own unless set
     std::vector<LineWorker *> workers;
     unsigned long step_no = 0;
     Gate gate;
@@ -139,7 +140,7 @@ int cs_frontend_step(cs_frontend *fe) {
         if (fe->chain && fe->batch && fe->worker_ran.size() > wi && fe->worker_ran[wi]) { // the pass this worker ran W steps ago: its lines are this step's edges
             r = w->wait();
             if (r == CS_OK) r = cs_lsd_filter_lines_packed(w->lsd, fe->chain_thres, fe->chain_off, fe->chain_lines);
-            if (r == CS_OK) r = cs_cuboid_batch_set_lines(fe->ctx, fe->batch, fe->chain_off.data(), fe->chain_lines.data());
+            if (r == CS_OK) r = cs_cuboid_batch_set_lines(fe->cub_ctx ? fe->cub_ctx : fe->ctx, fe->batch, fe->chain_off.data(), fe->chain_lines.data());
             if (r != CS_OK) return r;
         }
         w->submit();
@@ -147,8 +148,11 @@ int cs_frontend_step(cs_frontend *fe) {
         fe->worker_ran[wi] = 1;
     }
     fe->step_no++;
-    if (fe->orb) r = cs_orb_run(fe->ctx, fe->orb);
-    if (r == CS_OK && fe->batch) r = cs_cuboid_batch_run(fe->ctx, fe->batch);
+    // the cuboid pass is a chain of launches without a host round trip: on a stream of its own (cs_frontend_set_cuboid_ctx) it is enqueued first and runs beside the ORB
+    // pass, whose two read-backs would otherwise wait behind it
+    if (fe->batch && fe->cub_ctx) r = cs_cuboid_batch_run(fe->cub_ctx, fe->batch);
+    if (r == CS_OK && fe->orb) r = cs_orb_run(fe->ctx, fe->orb);
+    if (r == CS_OK && fe->batch && !fe->cub_ctx) r = cs_cuboid_batch_run(fe->ctx, fe->batch);
     if (fe->gate.phased && !fe->workers.empty() && ++fe->in_phase >= fe->workers.size()) { const int g = fe->open_gate(); if (r == CS_OK) r = g; }
     return r;
 }
@@ -174,9 +178,21 @@ int cs_frontend_set_chain(cs_frontend *fe, int on, float length_thres) {
     return r;
 }
 
+// ORB and the cuboid batch are independent: with a second context the batch's launches go to that context's stream and overlap the ORB pass of the same step (NULL: back
+// onto the caller's stream).  cs_frontend_drain then also waits for that stream.  The batch may have been created on any context of the same device.
+int cs_frontend_set_cuboid_ctx(cs_frontend *fe, cs_ctx *cuboid_ctx) {
+    if (!fe || cuboid_ctx == fe->ctx) return CS_ERR_BAD_ARG;
+    for (LineWorker *w : fe->workers) if (w->ctx == cuboid_ctx) return CS_ERR_BAD_ARG;
+    if (fe->cub_ctx && hipStreamSynchronize(fe->cub_ctx->stream) != hipSuccess) return CS_ERR_HIP;
+    if (hipStreamSynchronize(fe->ctx->stream) != hipSuccess) return CS_ERR_HIP; // no cuboid pass in flight across the switch
+    fe->cub_ctx = cuboid_ctx;
+    return CS_OK;
+}
+
 int cs_frontend_drain(cs_frontend *fe) {
     if (!fe) return CS_ERR_BAD_ARG;
     int r = CS_OK;
+    if (fe->cub_ctx && hipStreamSynchronize(fe->cub_ctx->stream) != hipSuccess) r = CS_ERR_HIP;
     if (fe->in_phase) r = fe->open_gate(); // an incomplete super-step
     for (LineWorker *w : fe->workers) { const int s = w->wait(); if (r == CS_OK) r = s; }
     return r;

@@ -181,7 +181,10 @@ __global__ void __launch_bounds__(1024) lsd_scan_add(int *out, int n, const int 
 // ordered compaction of the defined pixels (address order inside a frame): address, level-line angle, gradient norm
 // c_deg: the angle as cv::fastAtan2 returned it (float degrees; the level-line angle is exactly double(c_deg) * DEG_TO_RADS, lsd.cpp:566), c_cs: cos / sin
 // of float(angle) as region_grow adds them up (:676-677, glibc's cosf / sinf restated) -- computed here once per pixel instead of by the host per visit
-__global__ void __launch_bounds__(256) lsd_emit(const double *modgrad, const float *angles, int w, int h, const int *seg_base, int *c_addr, float *c_deg, float2 *c_cs, double *c_mod) {
+// PIX (the device region stage one wave per frame, lsd_rg_seq): the kernel also leaves that stage's 16-byte record of EVERY pixel of its segment -- (angle while free, cos, sin, angle)
+// for a defined pixel, (NOTDEF, 0, 0, NOTDEF) for the others -- and the seeds' cos / sin (of the angle as a double, region_grow's start values :651-652) in place of the pixels'
+// own: what lsd_rg_fill + lsd_rg_scatter did in two more passes over the frame, from lists this kernel had just written (c_deg is not written then).
+template <bool PIX> __global__ void __launch_bounds__(256) lsd_emit(const double *modgrad, const float *angles, int w, int h, const int *seg_base, int *c_addr, float *c_deg, float2 *c_cs, double *c_mod, float4 *pix) {
     __shared__ int wc[4];
     __shared__ short s_x[256];
     __shared__ float s_a[256];
@@ -197,6 +200,7 @@ __global__ void __launch_bounds__(256) lsd_emit(const double *modgrad, const flo
         const unsigned long long m = __ballot(def);
         const int wv = threadIdx.x >> 6;
         if ((threadIdx.x & 63) == 0) wc[wv] = __popcll(m);
+        if (PIX && x < w && !def) pix[row + x] = make_float4(NOTDEF_DEG, 0.f, 0.f, NOTDEF_DEG);
         __syncthreads();
         if (def) {
             int r = __popcll(m & ((1ull << (threadIdx.x & 63)) - 1));
@@ -228,9 +232,16 @@ __global__ void __launch_bounds__(256) lsd_emit(const double *modgrad, const flo
             if (n_theta > (3 * PI_) / 2) { n_theta -= 2 * PI_; if (n_theta < 0) n_theta = -n_theta; }
             if (n_theta <= prec) alone = false;
         }
-    c_addr[pos] = (y * w + x) | (alone ? (int)0x80000000 : 0); c_deg[pos] = d;
-    if (c_mod) c_mod[pos] = modgrad[o]; // (the host stage's copy of the norms; the device stage reads the dense map)
-    c_cs[pos] = make_float2(glibc_sincosf::cosf_(float(a)), glibc_sincosf::sinf_(float(a)));
+    c_addr[pos] = (y * w + x) | (alone ? (int)0x80000000 : 0);
+    const float pc = glibc_sincosf::cosf_(float(a)), ps = glibc_sincosf::sinf_(float(a));
+    if (PIX) {
+        pix[o] = make_float4(d, pc, ps, d);
+        c_cs[pos] = make_float2(float(cos(a)), float(sin(a)));
+    } else {
+        c_deg[pos] = d;
+        if (c_mod) c_mod[pos] = modgrad[o]; // (the host stage's copy of the norms; the device stage reads the dense map)
+        c_cs[pos] = make_float2(pc, ps);
+    }
 }
 
 // ------------------------------------------------------------------------------------------------ host: sequential LSD stages
@@ -611,6 +622,11 @@ static int lsd_run(cs_ctx *ctx, cs_lsd *l, int with_lbd) {
     CS_HIP(ctx, hipSetDevice(ctx->device));
     const int W = l->W, H = l->H, w = l->w, h = l->h, F = l->n_frames;
     l->have_desc = false; l->scaled_kept = true;
+    // CUBESLAM_LSD_HOSTPROF: wall clock of a pass's phases as the calling thread sees them (maps + counts back | region stage | KeyLines on the host | LBD)
+    static const bool hostprof = getenv("CUBESLAM_LSD_HOSTPROF") != nullptr;
+    double tp[5] = {0, 0, 0, 0, 0};
+    auto now_ms = [] { return std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now().time_since_epoch()).count(); };
+    tp[0] = now_ms();
     // d_blur and d_scaled (doubles: 2.5 + 1.6 MB per frame) only live from one kernel to the next: they are the two halves of one arena (d_tmp) that the device region stage
     // takes over for its pixel records once lsd_gradient is through, and the LBD blur for its one-kernel life (see below): 4.0 MB per frame that are not allocated twice
     CS_LAUNCH(ctx, "lsd_blur_hv", lsd_blur_hv, dim3(((W + 63) / 64) * ((H + LSD_ROWS - 1) / LSD_ROWS), 1, F), dim3(64), 0, l->d_gray, W, H, l->gk, l->d_blur);
@@ -626,6 +642,7 @@ static int lsd_run(cs_ctx *ctx, cs_lsd *l, int with_lbd) {
     CS_HIP(ctx, hipMemcpy2DAsync(l->frame_base.data(), sizeof(int), l->d_seg_base, sizeof(int) * (size_t)h * nbx, sizeof(int), (size_t)F + 1, hipMemcpyDeviceToHost, ctx->stream));
     CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     const size_t total = (size_t)l->frame_base[F];
+    tp[1] = now_ms();
     int r;
     if (total > l->ccap) {
         void *old[] = {l->d_caddr, l->d_cdeg, l->d_ccs, l->d_cmod};
@@ -650,9 +667,14 @@ static int lsd_run(cs_ctx *ctx, cs_lsd *l, int with_lbd) {
     if (!mode || !*mode) mode = F >= 512 ? "seq" : "host";
     const int grp_p = strcmp(mode, "grp") == 0 ? 1 : (strcmp(mode, "grp2") == 0 ? 2 : (strcmp(mode, "lpf") == 0 ? 64 : 0)); // lsd_rg_grp<P>: several frames per wave; lsd_rg_lpf: one lane per frame
     const bool use_seq = total > 0 && (strcmp(mode, "seq") == 0 || grp_p);
+    // lsd_rg_seq's records are written by the emit kernel itself when they live in the arena (always, unless a caller's frames outgrew it): no fill, no scatter
+    const bool pix_by_emit = use_seq && grp_p == 0 && l->pix_bytes >= (size_t)F * w * h * 16 && !(getenv("CUBESLAM_LSD_EMIT_PIX") && atoi(getenv("CUBESLAM_LSD_EMIT_PIX")) == 0);
     auto emit = [&](bool with_norms) -> int { // the compacted norms (8 B per defined pixel) are the host stage's: the device stage reads the dense map
         if (with_norms && !l->d_cmod) { const int q = cs_dalloc(ctx, &l->d_cmod, l->ccap); if (q) return q; }
-        CS_LAUNCH(ctx, "lsd_emit", lsd_emit, dim3(nbx, h, F), dim3(256), 0, l->d_mod, l->d_ang, w, h, l->d_seg_base, l->d_caddr, l->d_cdeg, l->d_ccs, with_norms ? l->d_cmod : (double *)nullptr);
+        if (pix_by_emit && !with_norms)
+            CS_LAUNCH(ctx, "lsd_emit", lsd_emit<true>, dim3(nbx, h, F), dim3(256), 0, l->d_mod, l->d_ang, w, h, l->d_seg_base, l->d_caddr, l->d_cdeg, l->d_ccs, (double *)nullptr, reinterpret_cast<float4 *>(l->d_tmp));
+        else
+            CS_LAUNCH(ctx, "lsd_emit", lsd_emit<false>, dim3(nbx, h, F), dim3(256), 0, l->d_mod, l->d_ang, w, h, l->d_seg_base, l->d_caddr, l->d_cdeg, l->d_ccs, with_norms ? l->d_cmod : (double *)nullptr, (float4 *)nullptr);
         return CS_OK;
     };
     if (total > 0) { r = emit(!use_seq); if (r) return r; }
@@ -676,7 +698,8 @@ static int lsd_run(cs_ctx *ctx, cs_lsd *l, int with_lbd) {
         long st[4] = {0, 0, 0, 0};
         l->scaled_kept = false; // the arena is the region stage's from here on
         r = lsd_seq_run(ctx, &l->seq, F, w, h, l->d_ang, l->d_mod, l->d_caddr, l->d_cdeg, l->d_ccs, l->frame_base.data(), dev_lines, st, l->gate_wait, l->gate_done, l->gate_arg, grp_p, l->seq_wpb,
-                        l->d_tmp, l->pix_bytes);
+                        l->d_tmp, l->pix_bytes, pix_by_emit);
+        tp[2] = now_ms();
         l->rg_stats[0] = 1; l->rg_stats[1] = st[0]; l->rg_stats[2] = st[2]; l->rg_stats[3] = r == CS_OK ? 0 : 1; l->rg_stats[4] = st[1];
         if (r == CS_OK) on_device = true;
         else if (r != CS_ERR_CAPACITY) return r; // a region outgrew the wave's list: the host stage takes the batch
@@ -747,6 +770,7 @@ static int lsd_run(cs_ctx *ctx, cs_lsd *l, int with_lbd) {
 #pragma omp parallel for schedule(static) num_threads(std::max(1, std::min(ctx->host_threads, F)))
         for (int f = 0; f < F; f++) to_keylines(dev_lines[f], W, H, l->keylines[f]);
     }
+    tp[3] = now_ms();
     l->line_off.assign((size_t)F + 1, 0);
     for (int f = 0; f < F; f++) l->line_off[f + 1] = l->line_off[f] + (int)l->keylines[f].size();
     if (with_lbd) {
@@ -777,6 +801,7 @@ static int lsd_run(cs_ctx *ctx, cs_lsd *l, int with_lbd) {
         CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
         l->have_desc = true;
     }
+    if (hostprof) { tp[4] = now_ms(); fprintf(stderr, "[lsd pass %p] maps+counts %.1f  regions %.1f  keylines %.1f  lbd %.1f  total %.1f ms\n", (void *)l, tp[1] - tp[0], tp[2] ? tp[2] - tp[1] : 0.0, tp[3] - (tp[2] ? tp[2] : tp[1]), tp[4] - tp[3], tp[4] - tp[0]); }
     return CS_OK;
 }
 

@@ -50,7 +50,9 @@ __device__ double rg_log_gamma(double x) { // lsd.cpp:70,124-160
     return a + log(b);
 }
 #ifndef RG_IMPROVE_WAVES
-#define RG_IMPROVE_WAVES 3 // waves per SIMD the register allocation of lsd_rg_improve aims at (latency-bound: pixel gathers and double transcendentals; measured 9.1 / 7.2 / 8.3 ms per 1024 frames at 2 / 3 / 4)
+#ifndef RG_IMPROVE_WAVES
+#define RG_IMPROVE_WAVES 3
+#endif // waves per SIMD the register allocation of lsd_rg_improve aims at (latency-bound: pixel gathers and double transcendentals; measured 9.1 / 7.2 / 8.3 ms per 1024 frames at 2 / 3 / 4)
 #endif
 constexpr int LG_N = 32768; // log_gamma of the integers below this: a table filled by the same function (its arguments are pixel counts; each call costs 16 log + 14 pow)
 __global__ void __launch_bounds__(256) lsd_rg_lgamma_table(double *t) { const int i = blockIdx.x * 256 + threadIdx.x; if (i < LG_N) t[i] = i > 0 ? rg_log_gamma(double(i)) : 0.0; }
@@ -243,7 +245,11 @@ __device__ __forceinline__ void lsd_rg_seq_body(const SeqParams &P) {
 }
 // (Smaller workgroups do not pack: the dispatcher spreads them over the emptiest CUs.  A 96-VGPR build in workgroups of ten frames, meant to sit two
 // to a CU, took one CU each, 206 CUs for two detectors, and cuboid_sweep_score waited 27 ms per launch.)
+#ifdef RGS_WAVES // (experiment: the walk squeezed into fewer registers -- 6: 80 VGPRs + 32 B of scratch per lane, 8: 64 + 92 B -- to leave more of a SIMD's file to the kernels beside it)
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(RGS_WAVES, RGS_WAVES))) lsd_rg_seq(SeqParams P) { lsd_rg_seq_body(P); }
+#else
 __global__ void __launch_bounds__(1024) lsd_rg_seq(SeqParams P) { lsd_rg_seq_body(P); }
+#endif
 // Several frames per wave (lsd_rg_grp.h): a group of 8 P lanes per frame, 64 / (8 P) frames per wave, no LDS.  A launch is 8 (4) times fewer waves than
 // lsd_rg_seq's and the frames' bookkeeping is vector work shared by the frames of a wave.
 // A launch walks up to GRP_SLICES slices of a batch side by side (inside a slice every offset fits 32 bits: lsd_rg_grp.h addresses base + offset).
@@ -333,7 +339,8 @@ int lsd_seq_run(cs_ctx *ctx, LsdSeq **handle, int F, int w, int h, const float *
                 int grp_p /* 0: lsd_rg_seq, one wave per frame; 1 / 2: lsd_rg_grp<P>, 8 / 4 frames per wave; 64: lsd_rg_lpf, one lane per frame */,
                 int waves_per_workgroup /* frames per workgroup of lsd_rg_seq: 16 packs a batch onto F / 16 CUs and leaves the others empty; 4 spreads it over the chip (the alternating runner, where
                                            every CU is busy anyway: 128 -> 104 ms per launch there) */,
-                void *scratch, size_t scratch_bytes /* memory the caller has no use for while the stage runs: lsd_rg_seq's pixel records go there when it is large enough */) {
+                void *scratch, size_t scratch_bytes /* memory the caller has no use for while the stage runs: lsd_rg_seq's pixel records go there when it is large enough */,
+                bool pix_ready /* lsd_emit<true> already left the pixel records at the head of `scratch` and the seeds' cos / sin in d_ccs: no fill, no scatter */) {
     LsdSeq *r = *handle;
     if (w > 0xffff || h > 0x7fff) return CS_ERR_CAPACITY; // (the region list packs x | y << 16)
     int max_ne = 0;
@@ -385,9 +392,10 @@ int lsd_seq_run(cs_ctx *ctx, LsdSeq **handle, int F, int w, int h, const float *
         }
         if (!r->d_glist) RA_(cs_dalloc(ctx, &r->d_glist, (size_t)r->F * rgs::CAP));
         S.pix = r->d_pix; S.glist = r->d_glist;
-        CS_LAUNCH(ctx, "lsd_rg_fill", lsd_rg_fill, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, r->d_pix, npx);
+        if (pix_ready && !r->pix_borrowed) { ctx->err = "lsd_seq_run: the pixel records were announced in the scratch buffer, but the stage does not use it for this batch"; return CS_ERR_BAD_ARG; }
+        if (!pix_ready) CS_LAUNCH(ctx, "lsd_rg_fill", lsd_rg_fill, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, r->d_pix, npx);
     }
-    CS_LAUNCH(ctx, "lsd_rg_scatter", lsd_rg_scatter, dim3((max_ne + 255) / 256, F), dim3(256), 0, S);
+    if (!pix_ready) CS_LAUNCH(ctx, "lsd_rg_scatter", lsd_rg_scatter, dim3((max_ne + 255) / 256, F), dim3(256), 0, S);
     int wpb = std::max(1, std::min(16, waves_per_workgroup)); // waves (= frames) per workgroup
     if (const char *e = getenv("CUBESLAM_LSD_SEQ_WPB")) wpb = std::max(1, std::min(16, atoi(e)));
     if (before_seq) before_seq(gate_arg);

@@ -27,6 +27,11 @@ class Frontend:
         """The reference's chain, pipelined: a step's cuboid pass takes the lines its line worker's last pass found (cs_frontend_set_chain)."""
         check(self.ctx.ptr, lib().cs_frontend_set_chain(self._fe, 1 if on else 0, C.c_float(length_thres)), "cs_frontend_set_chain")
 
+    def set_cuboid_ctx(self, ctx):
+        """The cuboid batch on its own Context (stream), beside the ORB pass of the same step (cs_frontend_set_cuboid_ctx); None: the caller's stream."""
+        check(self.ctx.ptr, lib().cs_frontend_set_cuboid_ctx(self._fe, ctx.ptr if ctx is not None else None), "cs_frontend_set_cuboid_ctx")
+        self._cub_ctx = ctx
+
     def step(self):
         check(self.ctx.ptr, lib().cs_frontend_step(self._fe), "cs_frontend_step")
 

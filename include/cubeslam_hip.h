@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define CS_VERSION 103 /* 103: cs_lsd_read_filter_lines takes the caller's frame count, cs_frontend_set_chain; 102: cs_cuboid_batch_set_lines, cs_cuboid_batch_set_shared_gpu, cs_lsd_read_filter_lines; 101: cs_ba_set_stop_flag_bool / cs_ba_dyn_set_stop_flag_bool; cs_match_by_projection_frame takes train_blocked */
+#define CS_VERSION 104 /* 104: cs_frontend_set_cuboid_ctx; 103: cs_lsd_read_filter_lines takes the caller's frame count, cs_frontend_set_chain; 102: cs_cuboid_batch_set_lines, cs_cuboid_batch_set_shared_gpu, cs_lsd_read_filter_lines; 101: cs_ba_set_stop_flag_bool / cs_ba_dyn_set_stop_flag_bool; cs_match_by_projection_frame takes train_blocked */
 
 typedef enum cs_status {
     CS_OK = 0,
@@ -459,6 +459,9 @@ int cs_frontend_set_phased(cs_frontend *fe, int on);
  * every step hand the lines of the pass its line worker finished last (octave 0, lineLength > length_thres) to the cuboid batch before that batch
  * runs; with W workers a batch's lines are W steps old, so no step waits for a line pass.  Needs a cuboid batch and >= 1 line worker. */
 int cs_frontend_set_chain(cs_frontend *fe, int on, float length_thres);
+/* The cuboid batch on a stream of its own: its launches (no host round trip among them) are enqueued on `cuboid_ctx` and run beside the ORB pass of the same step
+ * instead of in front of the next one.  NULL: back onto the caller's stream.  cs_frontend_drain waits for that stream too. */
+int cs_frontend_set_cuboid_ctx(cs_frontend *fe, cs_ctx *cuboid_ctx);
 void cs_frontend_destroy(cs_frontend *fe);
 
 /* ===================================================================== 9-dof g2o::cuboid of object_slam

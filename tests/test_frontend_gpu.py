@@ -38,6 +38,17 @@ def test_frontend_equals_separate_calls(ctx, oracle):
     off = sum(len(s["boxes"]) for s in scenes[:2])
     for k, r in enumerate(ref):
         assert len(cub[off + k]) == len(r) and np.array_equal(cub[off + k]["box_corners_2d"], r["box_corners_2d"])
+    # the cuboid batch on a stream of its own beside the ORB pass (cs_frontend_set_cuboid_ctx): the same cuboids, the same key points
+    cctx = _lib.Context(0)
+    fe.set_cuboid_ctx(cctx)
+    for _ in range(3):
+        fe.step()
+    fe.drain(); ctx.sync()
+    cub2, kps2 = batch.read(), orb.read()
+    assert all(a.tobytes() == b.tobytes() for a, b in zip(cub, cub2)) and all(a[0].tobytes() == b[0].tobytes() and np.array_equal(a[1], b[1]) for a, b in zip(kps, kps2))
+    with pytest.raises(Exception):
+        fe.set_cuboid_ctx(lctx[0])  # (a line worker's context is taken)
+    fe.set_cuboid_ctx(None)
     fe.close()
     with pytest.raises(Exception):
         Frontend(ctx, orb=orb, batch=batch, line_detectors=[line_lbd_detect(640, 480, ctx=ctx)])  # a worker may not share the caller's context
