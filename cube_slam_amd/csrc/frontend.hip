@@ -52,6 +52,7 @@ struct LineWorker {
     }
     std::thread th;
     std::mutex m; std::condition_variable cv;
+    std::mutex *any_m = nullptr; std::condition_variable *any_cv = nullptr; // the runner's "a worker has finished" signal
     bool busy = false, have_job = false, quit = false;
     int last_status = CS_OK;
     void loop() {
@@ -67,8 +68,11 @@ struct LineWorker {
             if (r != CS_OK && last_status == CS_OK) last_status = r;
             busy = false;
             cv.notify_all();
+            lk.unlock();
+            if (any_m) { std::lock_guard<std::mutex> g(*any_m); any_cv->notify_all(); }
         }
     }
+    bool is_free() { std::lock_guard<std::mutex> lk(m); return !busy; }
     void submit() {
         std::unique_lock<std::mutex> lk(m);
         cv.wait(lk, [&] { return !busy; });
@@ -94,6 +98,8 @@ struct cs_frontend {
     std::vector<LineWorker *> workers;
     unsigned long step_no = 0;
     Gate gate;
+    std::mutex any_m; std::condition_variable any_cv; // a worker has finished a pass
+    size_t next_worker = 0;
     unsigned long in_phase = 0; // passes submitted since the gate last opened
     // chained mode (cs_frontend_set_chain): detect_cuboid of a pass is fed the lines detect_filter_lines found in the pass the same worker finished
     // last -- the reference's chain (main_obj.cpp:428-449), pipelined: the line pass of a batch runs W steps ahead of the batch's cuboid pass
@@ -120,7 +126,7 @@ int cs_frontend_create(cs_ctx *ctx, cs_orb *orb, cs_cuboid_batch *batch, int n_l
     fe->ctx = ctx; fe->orb = orb; fe->batch = batch;
     for (int i = 0; i < n_line_workers; i++) {
         LineWorker *w = new LineWorker();
-        w->ctx = line_ctx[i]; w->lsd = lsd[i]; w->gate = &fe->gate;
+        w->ctx = line_ctx[i]; w->lsd = lsd[i]; w->gate = &fe->gate; w->any_m = &fe->any_m; w->any_cv = &fe->any_cv;
         cs_lsd_set_gate(w->lsd, LineWorker::gate_wait, LineWorker::gate_done, w);
         w->th = std::thread([w] { w->loop(); });
         fe->workers.push_back(w);
@@ -135,7 +141,22 @@ int cs_frontend_step(cs_frontend *fe) {
     if (!fe) return CS_ERR_BAD_ARG;
     int r = CS_OK;
     if (!fe->workers.empty()) {
-        const size_t wi = fe->step_no % fe->workers.size();
+        // the pass goes to the first worker that is free, looked for from the one behind the last choice: passes take 110 - 220 ms beside each other, and a strict
+        // rotation made the caller wait for a slow one with idle ones beside it (phased passes keep the rotation: their gate counts one pass per detector)
+        size_t wi = fe->step_no % fe->workers.size();
+        if (!fe->gate.phased) {
+            std::unique_lock<std::mutex> lk(fe->any_m);
+            for (;;) {
+                bool found = false;
+                for (size_t k = 0; k < fe->workers.size(); k++) {
+                    const size_t c = (fe->next_worker + k) % fe->workers.size();
+                    if (fe->workers[c]->is_free()) { wi = c; found = true; break; }
+                }
+                if (found) break;
+                fe->any_cv.wait_for(lk, std::chrono::milliseconds(2));
+            }
+            fe->next_worker = (wi + 1) % fe->workers.size();
+        }
         LineWorker *w = fe->workers[wi];
         if (fe->chain && fe->batch && fe->worker_ran.size() > wi && fe->worker_ran[wi]) { // the pass this worker ran W steps ago: its lines are this step's edges
             r = w->wait();
