@@ -170,6 +170,7 @@ __global__ void __launch_bounds__(256) orb_fast_score(Pyr P, const uint8_t *pyr,
             const bool k0 = d0 > tq, k4 = d4 > tq, k8 = d8 > tq, k12 = d12 > tq, b0 = d0 < -tq, b4 = d4 < -tq, b8 = d8 < -tq, b12 = d12 < -tq;
             cand = (k0 && k4) || (k4 && k8) || (k8 && k12) || (k12 && k0) || (b0 && b4) || (b4 && b8) || (b8 && b12) || (b12 && b0);
         }
+        if (!cand && x < L.w && y < L.h) smap[(long)blockIdx.z * P.frame_stride + L.off + (long)y * L.w + x] = 0; // every pixel of the map is written here or below: no fill pass in front of the launch
         const unsigned long long m = __ballot(cand);
         if (m) {
             int base = 0;
@@ -183,24 +184,34 @@ __global__ void __launch_bounds__(256) orb_fast_score(Pyr P, const uint8_t *pyr,
     for (int i = threadIdx.x; i < n; i += 256) {
         const int ly = s_list[i] >> 8, px = s_list[i] & 255;
         const int v = g[ly + 3][px + 3];
-        int d[16];
+        // the min / max network of cornerScore on PAIRS: P[j] = (d[j], d[j + 8]) in the two 16-bit halves of a register (|d| <= 255), so that a packed min / max serves two
+        // arcs; element j + 8 of a packed array is element j with its halves swapped, which the instruction's operand select does for nothing
+        typedef short v2s __attribute__((ext_vector_type(2)));
+        auto swp = [](v2s a) -> v2s { return __builtin_shufflevector(a, a, 1, 0); };
+        v2s Pk[8];
 #pragma unroll
-        for (int k = 0; k < 16; k++) d[k] = v - (int)g[ly + 3 + c_ring[k][1]][px + 3 + c_ring[k][0]];
-        int lo2[16], hi2[16], lo4[16], hi4[16];
-#pragma unroll
-        for (int k = 0; k < 16; k++) { lo2[k] = min(d[k], d[(k + 1) & 15]); hi2[k] = max(d[k], d[(k + 1) & 15]); }
-#pragma unroll
-        for (int k = 0; k < 16; k++) { lo4[k] = min(lo2[k], lo2[(k + 2) & 15]); hi4[k] = max(hi2[k], hi2[(k + 2) & 15]); }
-        int sd = -1000, sb = 1000;
-#pragma unroll
-        for (int k = 0; k < 16; k++) {
-            int lo9 = min(min(lo4[k], lo4[(k + 4) & 15]), d[(k + 8) & 15]); // min over ring[k..k+8]
-            int hi9 = max(max(hi4[k], hi4[(k + 4) & 15]), d[(k + 8) & 15]);
-            sd = max(sd, lo9);  // darker arc: v - p > t on the whole arc
-            sb = min(sb, hi9);  // brighter arc: p - v > t  <=>  max(v - p) < -t
+        for (int k = 0; k < 8; k++) {
+            const int ra = g[ly + 3 + c_ring[k][1]][px + 3 + c_ring[k][0]], rb = g[ly + 3 + c_ring[k + 8][1]][px + 3 + c_ring[k + 8][0]];
+            v2s r; r.x = (short)(v - ra); r.y = (short)(v - rb);
+            Pk[k] = r;
         }
+        auto at = [&](const v2s (&X)[8], int k) -> v2s { k &= 15; return k < 8 ? X[k] : swp(X[k - 8]); };
+        v2s lo2[8], hi2[8], lo4[8], hi4[8];
+#pragma unroll
+        for (int k = 0; k < 8; k++) { lo2[k] = __builtin_elementwise_min(Pk[k], at(Pk, k + 1)); hi2[k] = __builtin_elementwise_max(Pk[k], at(Pk, k + 1)); }
+#pragma unroll
+        for (int k = 0; k < 8; k++) { lo4[k] = __builtin_elementwise_min(lo2[k], at(lo2, k + 2)); hi4[k] = __builtin_elementwise_max(hi2[k], at(hi2, k + 2)); }
+        v2s sdp = {-1000, -1000}, sbp = {1000, 1000};
+#pragma unroll
+        for (int k = 0; k < 8; k++) {
+            const v2s lo9 = __builtin_elementwise_min(__builtin_elementwise_min(lo4[k], at(lo4, k + 4)), swp(Pk[k])); // min over ring[k .. k+8] and ring[k+8 .. k+16]
+            const v2s hi9 = __builtin_elementwise_max(__builtin_elementwise_max(hi4[k], at(hi4, k + 4)), swp(Pk[k]));
+            sdp = __builtin_elementwise_max(sdp, lo9);  // darker arc: v - p > t on the whole arc
+            sbp = __builtin_elementwise_min(sbp, hi9);  // brighter arc: p - v > t  <=>  max(v - p) < -t
+        }
+        const int sd = max((int)sdp.x, (int)sdp.y), sb = min((int)sbp.x, (int)sbp.y);
         const int S = max(max(sd, -sb), 0);
-        if (S > tq) smap[(long)blockIdx.z * P.frame_stride + L.off + (long)(ty0 + ly) * L.w + tx0 + px] = (uint8_t)S; // the map is zero-filled before the launch
+        smap[(long)blockIdx.z * P.frame_stride + L.off + (long)(ty0 + ly) * L.w + tx0 + px] = S > tq ? (uint8_t)S : (uint8_t)0;
     }
 }
 
@@ -1111,7 +1122,6 @@ int cs_orb_run(cs_ctx *ctx, cs_orb *e) {
         CS_LAUNCH(ctx, "orb_resize", orb_resize, dim3((P.l[l].w + 255) / 256, (P.l[l].h + 4 * RS_ROWS - 1) / (4 * RS_ROWS), F), dim3(256), 0, P, l, e->d_pyr, e->d_xofs, e->d_ialpha,
                   e->d_yofs, e->d_ibeta);
     }
-    CS_HIP(ctx, hipMemsetAsync(e->d_smap, 0, (size_t)P.frame_stride * F, ctx->stream)); // orb_fast_score only writes scores above the threshold
     CS_LAUNCH(ctx, "orb_fast_score", orb_fast_score, dim3(e->max_tiles, NL, F), dim3(256), 0, P, e->d_pyr, e->d_smap);
     CS_LAUNCH(ctx, "orb_cells", orb_cells, dim3((P.cells_per_frame + CELLS_PER_WG - 1) / CELLS_PER_WG, F), dim3(64 * CELLS_PER_WG), 0, P, e->d_smap, 0, e->d_cell_count, e->d_cell_base, e->d_cand, e->d_cell_mask);
     CS_LAUNCH(ctx, "orb_scan", orb_scan_cells, dim3(NL, F), dim3(64), 0, P, e->d_cell_count, e->d_cell_base, e->d_level_total);
