@@ -43,6 +43,28 @@ def test_reduced_camera_system(ctx, oracle, small):
     ba.close()
 
 
+def test_build_ahead_equals_plain_order_with_rejected_trials(ctx, monkeypatch):
+    """cs_ba_optimize enqueues the next iteration's system behind a trial's residual kernels before it knows the trial's verdict; a rejected trial rebuilds residuals and system from the
+    restored estimates.  Same bits as the plain order (CUBESLAM_BA_AHEAD=0) -- also on graphs whose LM rejects trials (the points far off, the step overshoots)."""
+    rejected = 0
+    for seed, noise in ((3, 1.0), (4, 25.0), (6, 60.0)):
+        d = dict(synth.ba_problem(seed, n_kf=30, n_points=900, n_cuboids=6, noise_px=noise))
+        rng = np.random.default_rng(seed)
+        d["points"] = d["points"] + rng.normal(0, 0.02 * noise, d["points"].shape)
+        out = []
+        for ahead in ("1", "0"):
+            monkeypatch.setenv("CUBESLAM_BA_AHEAD", ahead)
+            ba = BundleAdjuster(d, ctx=ctx)
+            st = ba.optimize(12)
+            out.append((st, ba.read()))
+            ba.close()
+        (sa, ra), (sb, rb) = out
+        assert sa["iterations"] == sb["iterations"] and sa["lm_trials"] == sb["lm_trials"] and sa["chi2_trace"] == sb["chi2_trace"]
+        assert all(x.tobytes() == y.tobytes() for x, y in zip(ra, rb))
+        rejected += sa["lm_trials"] - sa["iterations"]
+    assert rejected > 0, "no graph of this test made the LM reject a trial"
+
+
 @pytest.mark.parametrize("kw", [dict(n_kf=40, n_points=1500, n_cuboids=8), dict(n_kf=25, n_points=800, n_cuboids=0), dict(n_kf=60, n_points=2500, n_cuboids=15)])
 def test_lm_trajectory(ctx, oracle, kw):
     d = synth.ba_problem(11, **kw)
