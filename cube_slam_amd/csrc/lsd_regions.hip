@@ -233,6 +233,9 @@ __global__ void __launch_bounds__(256) lsd_rg_scatter(SeqParams P) {
 __device__ __forceinline__ void lsd_rg_seq_body(const SeqParams &P) {
     const int f = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
     if (f >= P.F) return;
+#ifdef RGS_PRIO
+    __builtin_amdgcn_s_setprio(RGS_PRIO); // (experiment: the walk's instructions ahead of the other waves of its SIMD)
+#endif
     const int base = P.frame_base[f];
     rgs::Frame Fr;
     Fr.w = P.w; Fr.h = P.h; Fr.ne = P.frame_base[f + 1] - base;
