@@ -166,7 +166,7 @@ def ba_bench(ctx, rank, world, iters, with_cpu, with_traffic=False):
     ctx.timing(True); ctx.timing_reset()
     ba.optimize(iters)
     ctx.sync()
-    names = ("ba_err_obs", "ba_lin_lm", "ba_lin_pose", "ba_num_cols", "ba_lin_pose_edges", "ba_lm_dinv", "ba_schur_bd", "ba_schur_slots", "ba_schur_b", "ba_chol_factor",
+    names = ("ba_err_obs", "ba_build_abc", "ba_lin_lm", "ba_lin_pose", "ba_num_cols", "ba_lin_pose_edges", "ba_lm_dinv", "ba_schur_bd", "ba_schur_slots", "ba_schur_b", "ba_chol_factor",
              "ba_chol_solve", "ba_cub_inv", "ba_band_assemble", "ba_band_rhs", "ba_band_chol", "ba_band_twist_factor", "ba_band_mid", "ba_band_twist_back", "ba_cr_assemble", "ba_cr_eliminate",
              "ba_cr_back", "ba_cub_back", "ba_backsub", "ba_update", "ba_allreduce")
     kern = {}

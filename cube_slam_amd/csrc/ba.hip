@@ -79,17 +79,18 @@ __device__ inline void err_pc_eval(const Params &G, int o, const Cuboid &c, doub
 }
 
 // block partial sums, then a fixed-order final sum on the host side of the tiny partial array
-__device__ inline void block_sum_store(double v, double *partials) {
+__device__ inline void block_sum_store(double v, double *partials, int bid) {
     __shared__ double s[4];
     for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
     if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
     __syncthreads();
-    if (threadIdx.x == 0) partials[blockIdx.x] = (s[0] + s[1]) + (s[2] + s[3]);
+    if (threadIdx.x == 0) partials[bid] = (s[0] + s[1]) + (s[2] + s[3]);
 }
+__device__ inline void block_sum_store(double v, double *partials) { block_sum_store(v, partials, (int)blockIdx.x); }
 
 __device__ inline bool obs_stereo(const Params &G, int o) { return G.o_ur && G.o_ur[o] >= 0; }
-__global__ void __launch_bounds__(256) ba_err_obs(Params G, double *partials) {
-    const int o = G.o_b + blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void ba_err_obs_body(const Params &G, double *partials, const int bid) {
+    const int o = G.o_b + bid * 256 + threadIdx.x;
     double chi = 0;
     if (o < G.o_e) { // EdgeSE3ProjectXYZ::computeError
         const SE3 T = se3_load(G.cam + (long)G.o_cam[o] * 7);
@@ -109,10 +110,11 @@ __global__ void __launch_bounds__(256) ba_err_obs(Params G, double *partials) {
         G.e_obs[(long)o * 3] = e0; G.e_obs[(long)o * 3 + 1] = e1; G.e_obs[(long)o * 3 + 2] = e2;
         if (delta > 0) { double rho[3]; huber(chi, delta, rho); chi = rho[0]; }
     }
-    block_sum_store(chi, partials);
+    block_sum_store(chi, partials, bid);
 }
-__global__ void __launch_bounds__(256) ba_err_pose_edges(Params G, double *partials) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
+__global__ void __launch_bounds__(256) ba_err_obs(Params G, double *partials) { ba_err_obs_body(G, partials, (int)blockIdx.x); }
+__device__ __forceinline__ void ba_err_pose_edges_body(const Params &G, double *partials, const int bid) {
+    const int t = bid * 256 + threadIdx.x;
     double chi = 0;
     if (t < G.n_cobs) {
         double e[4];
@@ -128,8 +130,9 @@ __global__ void __launch_bounds__(256) ba_err_pose_edges(Params G, double *parti
         for (int k = 0; k < 3; k++) G.e_pc[(long)o * 3 + k] = e[k];
         chi = (e[0] * e[0] + e[1] * e[1]) + e[2] * e[2];
     }
-    block_sum_store(chi, partials);
+    block_sum_store(chi, partials, bid);
 }
+__global__ void __launch_bounds__(256) ba_err_pose_edges(Params G, double *partials) { ba_err_pose_edges_body(G, partials, (int)blockIdx.x); }
 
 // analytic Jacobians of one reprojection edge + weights.  Monocular: EdgeSE3ProjectXYZ::linearizeOplus (types_six_dof_expmap.cpp:135-171),
 // third row exactly zero.  Stereo: EdgeStereoSE3ProjectXYZ::linearizeOplus (:220-266).
@@ -163,8 +166,8 @@ __device__ inline void obs_jac(const Params &G, int o, double Ji[3][3], double J
     W = rw * w;                                                          // robustInformation = rho' * Omega (base_edge.h:96-102)
 }
 
-__global__ void __launch_bounds__(256) ba_lin_lm(Params G) { // thread per landmark of this rank
-    const int li = G.lm_b + blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void ba_lin_lm_body(const Params &G, const int bid) { // thread per landmark of this rank
+    const int li = G.lm_b + bid * 256 + threadIdx.x;
     if (li >= G.lm_e) return;
     double H[9] = {0, 0, 0, 0, 0, 0, 0, 0, 0}, b[3] = {0, 0, 0};
     for (int o = G.lm_off[li]; o < G.lm_off[li + 1]; o++) {
@@ -180,12 +183,13 @@ __global__ void __launch_bounds__(256) ba_lin_lm(Params G) { // thread per landm
     for (int k = 0; k < 9; k++) G.Hll[(long)li * 9 + k] = H[k];
     for (int k = 0; k < 3; k++) G.bl[(long)li * 3 + k] = b[k];
 }
+__global__ void __launch_bounds__(256) ba_lin_lm(Params G) { ba_lin_lm_body(G, (int)blockIdx.x); }
 
 // workgroup per pose block (four waves share the camera's observation list: a thousand single waves leave the SIMDs one wave deep and the
 // Jacobian chain exposed): observations of this rank that involve the camera (CSR pose_off / pose_obs); wave sums by shuffles, then in wave order
-__global__ void __launch_bounds__(256) ba_lin_pose(Params G, const int *pose_off, const int *pose_obs) {
+__device__ __forceinline__ void ba_lin_pose_body(const Params &G, const int *pose_off, const int *pose_obs, const int bid) {
     __shared__ double part[4][42];
-    const int pi = blockIdx.x, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int pi = bid, lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     double acc[42];
 #pragma unroll
     for (int k = 0; k < 42; k++) acc[k] = 0;
@@ -209,12 +213,13 @@ __global__ void __launch_bounds__(256) ba_lin_pose(Params G, const int *pose_off
         if (k < 36) G.Hpp[(long)pi * 36 + k] = v; else G.bp[(long)pi * 6 + k - 36] = v;
     }
 }
+__global__ void __launch_bounds__(256) ba_lin_pose(Params G, const int *pose_off, const int *pose_obs) { ba_lin_pose_body(G, pose_off, pose_obs, (int)blockIdx.x); }
 
 // numeric Jacobian columns (base_binary_edge.hpp:216-320, base_unary_edge.hpp:82-123): delta = 1e-9, central difference.  A lane per (edge, column,
 // SIGN): the even lane evaluates the error at +delta, its odd neighbour at -delta (the two evaluations are the whole cost: se3 exponential, cuboid
 // retraction, projection), the difference is taken by the even lane -- the same two values, the same subtraction.
-__global__ void __launch_bounds__(256) ba_num_cols(Params G) {
-    const int tt = blockIdx.x * 256 + threadIdx.x, t = tt >> 1;
+__device__ __forceinline__ void ba_num_cols_body(const Params &G, const int bid) {
+    const int tt = bid * 256 + threadIdx.x, t = tt >> 1;
     const bool minus = tt & 1;
     const double delta = 1e-9, scalar = 1.0 / (2 * delta), dd = minus ? -delta : delta;
     double ev[4] = {0, 0, 0, 0};
@@ -245,6 +250,16 @@ __global__ void __launch_bounds__(256) ba_num_cols(Params G) {
     if (minus) return;
     if (kind == 1) for (int k = 0; k < 4; k++) G.Jc[((long)o * 12 + d) * 4 + k] = scalar * (ev[k] - em[k]);
     else if (kind == 2) for (int k = 0; k < 3; k++) G.Jp[((long)o * 6 + d) * 3 + k] = scalar * (ev[k] - em[k]);
+}
+__global__ void __launch_bounds__(256) ba_num_cols(Params G) { ba_num_cols_body(G, (int)blockIdx.x); }
+// The three launches of buildSystem that read nothing of each other, as ONE grid: workgroups [0, n_pose) are ba_lin_pose's, the next n_cols ba_num_cols', the rest
+// ba_lin_lm's (the longest first).  At 1 000 key frames each of them fills part of the chip for 30 - 65 us; in a row they were 141 us, side by side they are the longest
+// of them.  (Two more streams with event joins were measured first: a join costs more than the kernels it orders, 1 040 -> 544 it/s.)
+__global__ void __launch_bounds__(256) ba_build_abc(Params G, const int *pose_off, const int *pose_obs, int n_pose, int n_cols) {
+    const int bid = (int)blockIdx.x;
+    if (bid < n_pose) ba_lin_pose_body(G, pose_off, pose_obs, bid);
+    else if (bid < n_pose + n_cols) ba_num_cols_body(G, bid - n_pose);
+    else ba_lin_lm_body(G, bid - n_pose - n_cols);
 }
 
 // A lane per ELEMENT of a pose block (36 of H, 6 of b; a wave per pose): adds the camera-cuboid / point-cuboid terms (constructQuadraticForm) in edge
@@ -449,9 +464,9 @@ __global__ void __launch_bounds__(64) ba_cub_inv(int C, int Q, const double *S, 
 }
 // band[target] = camera block of the reduced system - sum over the cuboids seen by both cameras of H_iq D_q H_kq^T.
 // One thread per (target block, element); fixed summation order.  ct_list: (cuboid, slot of edge (i,q), slot of edge (k,q)).
-__global__ void __launch_bounds__(256) ba_band_assemble(int n_targets, const int *tgt_slot, const uint8_t *tgt_tr, const int *ct_off, const int *ct_list, const double *S,
-                                                        const double *cubD, double *band) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void ba_band_assemble_body(int n_targets, const int *tgt_slot, const uint8_t *tgt_tr, const int *ct_off, const int *ct_list, const double *S,
+                                                        const double *cubD, double *band, const int bid) {
+    const int t = bid * 256 + threadIdx.x;
     if (t >= n_targets * 36) return;
     const int tg = t / 36, k = t % 36, r = k / 6, c = k % 6;
     double acc = 0;
@@ -465,9 +480,11 @@ __global__ void __launch_bounds__(256) ba_band_assemble(int n_targets, const int
     }
     band[t] = acc;
 }
+__global__ void __launch_bounds__(256) ba_band_assemble(int n_targets, const int *tgt_slot, const uint8_t *tgt_tr, const int *ct_off, const int *ct_list, const double *S,
+                                                        const double *cubD, double *band) { ba_band_assemble_body(n_targets, tgt_slot, tgt_tr, ct_off, ct_list, S, cubD, band, (int)blockIdx.x); }
 // rhs_i = b_i - sum over the cuboids seen by camera i of H_iq g_q.  cr_list: (cuboid, slot)
-__global__ void __launch_bounds__(256) ba_band_rhs(int C, const int *cr_off, const int *cr_list, const double *S, const double *bs, const double *cubg, double *rhs) {
-    const int t = blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void ba_band_rhs_body(int C, const int *cr_off, const int *cr_list, const double *S, const double *bs, const double *cubg, double *rhs, const int bid) {
+    const int t = bid * 256 + threadIdx.x;
     if (t >= C * 6) return;
     const int i = t / 6, r = t % 6;
     double acc = bs[t];
@@ -479,9 +496,9 @@ __global__ void __launch_bounds__(256) ba_band_rhs(int C, const int *cr_off, con
     }
     rhs[t] = acc;
 }
+__global__ void __launch_bounds__(256) ba_band_rhs(int C, const int *cr_off, const int *cr_list, const double *S, const double *bs, const double *cubg, double *rhs) { ba_band_rhs_body(C, cr_off, cr_list, S, bs, cubg, rhs, (int)blockIdx.x); }
 // x_q = g_q - D_q sum over the cameras that see cuboid q of H_iq^T x_i.  cq_list: (slot, camera)
-__global__ void __launch_bounds__(64) ba_cub_back(int C, int Q, const int *cq_off, const int *cq_list, const double *S, const double *cubD, const double *cubg, double *x) {
-    const int q = blockIdx.x * 64 + threadIdx.x;
+__device__ __forceinline__ void ba_cub_back_body(int C, int Q, const int *cq_off, const int *cq_list, const double *S, const double *cubD, const double *cubg, double *x, const int q) {
     if (q >= Q) return;
     double w[6] = {0, 0, 0, 0, 0, 0};
     for (int e = cq_off[q]; e < cq_off[q + 1]; e++) {
@@ -490,6 +507,15 @@ __global__ void __launch_bounds__(64) ba_cub_back(int C, int Q, const int *cq_of
     }
     const double *D = cubD + (long)q * 36, *g = cubg + (long)q * 6;
     for (int r = 0; r < 6; r++) { double v = 0; for (int c = 0; c < 6; c++) v += D[r * 6 + c] * w[c]; x[(long)(C + q) * 6 + r] = g[r] - v; }
+}
+__global__ void __launch_bounds__(64) ba_cub_back(int C, int Q, const int *cq_off, const int *cq_list, const double *S, const double *cubD, const double *cubg, double *x) { ba_cub_back_body(C, Q, cq_off, cq_list, S, cubD, cubg, x, (int)(blockIdx.x * 64 + threadIdx.x)); }
+// Pairs of small launches that read nothing of each other, as one grid each (every one of them is 10 - 40 us of mostly launch and tail at 1 000 key frames):
+// the band's blocks and its right-hand side; the cuboids' and the landmarks' back-substitution; the scale of the step and the update of the estimates.
+__global__ void __launch_bounds__(256) ba_band_both(int nb_a, int n_targets, const int *tgt_slot, const uint8_t *tgt_tr, const int *ct_off, const int *ct_list, const double *S, const double *cubD, double *band,
+                                                    int C, const int *cr_off, const int *cr_list, const double *bs, const double *cubg, double *rhs) {
+    const int bid = (int)blockIdx.x;
+    if (bid < nb_a) ba_band_assemble_body(n_targets, tgt_slot, tgt_tr, ct_off, ct_list, S, cubD, band, bid);
+    else ba_band_rhs_body(C, cr_off, cr_list, S, bs, cubg, rhs, bid - nb_a);
 }
 // ---- block-band Cholesky of the camera system.  A: C columns x (Bc+1) blocks (block d of column j = block (j+d, j), row-major 6x6).
 // The elimination is a serial chain over the columns (each step: 6x6 pivot, Bc panel blocks, Bc(Bc+1)/2 trailing blocks, all in
@@ -1050,8 +1076,8 @@ __global__ void ba_permute(int P, const int *pos, const double *src, double *dst
     if (forward) dst[(long)pos[i] * 6 + k] = src[t]; else dst[t] = src[(long)pos[i] * 6 + k];
 }
 
-__global__ void __launch_bounds__(256) ba_backsub(Params G) { // x_l = Dinv (b_l - B^T x_p), block_solver.hpp:459-485
-    const int li = G.lm_b + blockIdx.x * 256 + threadIdx.x;
+__device__ __forceinline__ void ba_backsub_body(const Params &G, const int bid) { // x_l = Dinv (b_l - B^T x_p), block_solver.hpp:459-485
+    const int li = G.lm_b + bid * 256 + threadIdx.x;
     if (li >= G.lm_e) return;
     double cl[3] = {G.bl[(long)li * 3], G.bl[(long)li * 3 + 1], G.bl[(long)li * 3 + 2]};
     for (int o = G.lm_off[li]; o < G.lm_off[li + 1]; o++) {
@@ -1063,17 +1089,19 @@ __global__ void __launch_bounds__(256) ba_backsub(Params G) { // x_l = Dinv (b_l
     const double *Di = G.Dinv + (long)li * 9;
     for (int a = 0; a < 3; a++) G.x[(long)G.P * 6 + (long)li * 3 + a] = (Di[a * 3] * cl[0] + Di[a * 3 + 1] * cl[1]) + Di[a * 3 + 2] * cl[2];
 }
+__global__ void __launch_bounds__(256) ba_backsub(Params G) { ba_backsub_body(G, (int)blockIdx.x); }
 
 // sum_j x_j (lambda x_j + b_j) (computeScale :182-189): landmark part of this rank + pose part (b_p partial; lambda term once)
-__global__ void __launch_bounds__(256) ba_scale(Params G, double lambda, double *partials) {
-    const long t = (long)blockIdx.x * 256 + threadIdx.x, nP = (long)G.P * 6, nL = (long)(G.lm_e - G.lm_b) * 3;
+__device__ __forceinline__ void ba_scale_body(const Params &G, double lambda, double *partials, const int bid) {
+    const long t = (long)bid * 256 + threadIdx.x, nP = (long)G.P * 6, nL = (long)(G.lm_e - G.lm_b) * 3;
     double v = 0;
     if (t < nP) v = G.x[t] * ((G.pose_edges ? lambda * G.x[t] : 0.0) + G.bp[t]);
     else if (t < nP + nL) { const long k = (long)G.lm_b * 3 + (t - nP); v = G.x[nP + k] * (lambda * G.x[nP + k] + G.bl[k]); }
-    block_sum_store(v, partials);
+    block_sum_store(v, partials, bid);
 }
-__global__ void __launch_bounds__(256) ba_update(Params G) { // SparseOptimizer::update -> oplus per vertex
-    const int t = blockIdx.x * 256 + threadIdx.x;
+__global__ void __launch_bounds__(256) ba_scale(Params G, double lambda, double *partials) { ba_scale_body(G, lambda, partials, (int)blockIdx.x); }
+__device__ __forceinline__ void ba_update_body(const Params &G, const int bid) { // SparseOptimizer::update -> oplus per vertex
+    const int t = bid * 256 + threadIdx.x;
     if (t < G.n_cams) {
         const int pi = G.cam_idx[t];
         if (pi < 0) return;
@@ -1087,6 +1115,17 @@ __global__ void __launch_bounds__(256) ba_update(Params G) { // SparseOptimizer:
         const long k = (long)(t - G.n_cams - G.n_cub);
         if (k < (long)(G.lm_e - G.lm_b) * 3) { const long q = (long)G.lm_b * 3 + k; G.pts[q] += G.x[(long)G.P * 6 + q]; } // VertexSBAPointXYZ::oplusImpl
     }
+}
+__global__ void __launch_bounds__(256) ba_update(Params G) { ba_update_body(G, (int)blockIdx.x); }
+__global__ void __launch_bounds__(256) ba_back_both(Params G, int nb_l, int C, int Q, const int *cq_off, const int *cq_list, const double *S, const double *cubD, const double *cubg) {
+    const int bid = (int)blockIdx.x, nb_q = (Q + 255) / 256; // the cuboids' few workgroups first: theirs is the longer chain
+    if (bid < nb_q) ba_cub_back_body(C, Q, cq_off, cq_list, S, cubD, cubg, G.x, bid * 256 + (int)threadIdx.x);
+    else ba_backsub_body(G, bid - nb_q);
+}
+__global__ void __launch_bounds__(256) ba_scale_update(Params G, double lambda, double *partials, int nb_s) {
+    const int bid = (int)blockIdx.x;
+    if (bid < nb_s) ba_scale_body(G, lambda, partials, bid);
+    else ba_update_body(G, bid - nb_s);
 }
 __global__ void __launch_bounds__(256) ba_maxdiag(Params G, double *partials) { // max |H_jj| of this rank's landmark blocks (computeLambdaInit)
     const int li = G.lm_b + blockIdx.x * 256 + threadIdx.x;
@@ -1434,12 +1473,16 @@ static int ba_compute_errors(cs_ctx *ctx, cs_ba *b, double *chi2) { // computeAc
 static int ba_build_system(cs_ctx *ctx, cs_ba *b) { // BlockSolver::buildSystem
     const Params &G = b->G;
     const int nl = G.lm_e - G.lm_b;
-    if (nl > 0) CS_LAUNCH(ctx, "ba_lin_lm", ba_lin_lm, dim3((nl + 255) / 256), dim3(256), 0, G);
-    if (G.P > 0) CS_LAUNCH(ctx, "ba_lin_pose", ba_lin_pose, dim3(G.P), dim3(256), 0, G, b->d_pose_off, b->d_pose_obs);
-    if (G.pose_edges && G.n_cobs + G.n_pc > 0) {
-        CS_LAUNCH(ctx, "ba_num_cols", ba_num_cols, dim3((2 * (G.n_cobs * 12 + G.n_pc * 6) + 255) / 256), dim3(256), 0, G); // a lane per (edge, column, sign)
-        CS_LAUNCH(ctx, "ba_lin_pose_edges", ba_lin_pose_edges, dim3((G.P + G.n_cobs + 3) / 4), dim3(256), 0, G, b->d_pe_off, b->d_pe_list); // a wave per pose block / per camera-cuboid edge
+    const bool edges = G.pose_edges && G.n_cobs + G.n_pc > 0;
+    const int n_pose = G.P, n_cols = edges ? (2 * (G.n_cobs * 12 + G.n_pc * 6) + 255) / 256 : 0, n_lm = (nl + 255) / 256;
+    static const bool fused = !(getenv("CUBESLAM_BA_FUSED") && atoi(getenv("CUBESLAM_BA_FUSED")) == 0); // (0: a launch per kernel, the cross-check)
+    if (fused && n_pose + n_cols + n_lm > 0) CS_LAUNCH(ctx, "ba_build_abc", ba_build_abc, dim3(n_pose + n_cols + n_lm), dim3(256), 0, G, b->d_pose_off, b->d_pose_obs, n_pose, n_cols);
+    else {
+        if (nl > 0) CS_LAUNCH(ctx, "ba_lin_lm", ba_lin_lm, dim3(n_lm), dim3(256), 0, G);
+        if (G.P > 0) CS_LAUNCH(ctx, "ba_lin_pose", ba_lin_pose, dim3(G.P), dim3(256), 0, G, b->d_pose_off, b->d_pose_obs);
+        if (edges) CS_LAUNCH(ctx, "ba_num_cols", ba_num_cols, dim3(n_cols), dim3(256), 0, G); // a lane per (edge, column, sign)
     }
+    if (edges) CS_LAUNCH(ctx, "ba_lin_pose_edges", ba_lin_pose_edges, dim3((G.P + G.n_cobs + 3) / 4), dim3(256), 0, G, b->d_pe_off, b->d_pe_list); // a wave per pose block / per camera-cuboid edge: adds to what ba_lin_pose left
     return CS_OK;
 }
 static int ba_schur(cs_ctx *ctx, cs_ba *b, double lambda) { // Schur part of BlockSolver::solve, result in d_reduce = [slots | bschur]
@@ -1466,9 +1509,9 @@ static int ba_solve(cs_ctx *ctx, cs_ba *b, double lambda, bool *ok, bool defer_s
         const double *S = b->d_reduce, *bs = b->d_reduce + (long)b->n_slots * 36;
         CS_HIP(ctx, hipMemsetAsync(b->d_status, 0, sizeof(int), ctx->stream));
         if (Q > 0) CS_LAUNCH(ctx, "ba_cub_inv", ba_cub_inv, dim3((Q + 63) / 64), dim3(64), 0, C, Q, S, bs, b->d_cubD, b->d_cubg, b->d_status);
-        CS_LAUNCH(ctx, "ba_band_assemble", ba_band_assemble, dim3((b->band_targets * 36 + 255) / 256), dim3(256), 0, b->band_targets, b->d_tgt_slot, b->d_tgt_tr, b->d_ct_off,
-                  b->d_ct_list, S, b->d_cubD, b->d_bandA);
-        CS_LAUNCH(ctx, "ba_band_rhs", ba_band_rhs, dim3((C * 6 + 255) / 256), dim3(256), 0, C, b->d_cr_off, b->d_cr_list, S, bs, b->d_cubg, b->d_brhs);
+        { const int nb_a = (b->band_targets * 36 + 255) / 256, nb_r = (C * 6 + 255) / 256;
+          CS_LAUNCH(ctx, "ba_band_assemble", ba_band_both, dim3(nb_a + nb_r), dim3(256), 0, nb_a, b->band_targets, b->d_tgt_slot, b->d_tgt_tr, b->d_ct_off, b->d_ct_list, S, b->d_cubD, b->d_bandA,
+                    C, b->d_cr_off, b->d_cr_list, bs, b->d_cubg, b->d_brhs); }
         const size_t lds = band_lds_bytes(Bc);
         if (b->band_cr) { // nested dissection over super-blocks of Bc cameras: log2(C / Bc) parallel levels (ba_cr.hip)
             r = ba_cr_solve(ctx, &b->cr, C, Bc, b->d_bandA, b->d_brhs, G.x, b->d_status); if (r) return r;
@@ -1487,8 +1530,7 @@ static int ba_solve(cs_ctx *ctx, cs_ba *b, double lambda, bool *ok, bool defer_s
             CS_LAUNCH(ctx, "ba_band_chol", ba_band_chol, dim3(1), dim3(BAND_NT), lds, C, Bc, b->d_bandA, b->d_bandL, b->d_brhs, b->d_ybuf, b->d_status);
         }
         if (!b->band_twist && !b->band_cr) CS_HIP(ctx, hipMemcpyAsync(G.x, b->d_brhs, sizeof(double) * (size_t)C * 6, hipMemcpyDeviceToDevice, ctx->stream));
-        if (Q > 0) CS_LAUNCH(ctx, "ba_cub_back", ba_cub_back, dim3((Q + 63) / 64), dim3(64), 0, C, Q, b->d_cq_off, b->d_cq_list, S, b->d_cubD, b->d_cubg, G.x);
-        if (nl > 0) CS_LAUNCH(ctx, "ba_backsub", ba_backsub, dim3((nl + 255) / 256), dim3(256), 0, G);
+        if (nl > 0 || Q > 0) CS_LAUNCH(ctx, "ba_backsub", ba_back_both, dim3((nl + 255) / 256 + (Q + 255) / 256), dim3(256), 0, G, (nl + 255) / 256, C, Q, b->d_cq_off, b->d_cq_list, S, b->d_cubD, b->d_cubg);
         if (defer_status) return CS_OK;
         int status = 0;
         r = cs_d2h(ctx, &status, b->d_status, 1); if (r) return r;
@@ -1986,10 +2028,9 @@ int cs_ba_optimize(cs_ctx *ctx, cs_ba *b, int iterations, const volatile int *st
             if (b->world == 1) { // one host round trip per trial: solve, scale, update and the new residuals are enqueued back to back
                 r = ba_solve(ctx, b, lambda, &ok2, true); if (r) return r;
                 const int nb1 = (G.o_e - G.o_b + 255) / 256, nb2 = (G.pose_edges && G.n_cobs + G.n_pc > 0) ? (G.n_cobs + G.n_pc + 255) / 256 : 0, mp = b->max_part;
-                CS_LAUNCH(ctx, "ba_scale", ba_scale, dim3(nbs), dim3(256), 0, G, lambda, b->d_partials);
-                CS_LAUNCH(ctx, "ba_update", ba_update, dim3((G.n_cams + G.n_cub + nl * 3 + 255) / 256), dim3(256), 0, G);
+                CS_LAUNCH(ctx, "ba_update", ba_scale_update, dim3(nbs + (G.n_cams + G.n_cub + nl * 3 + 255) / 256), dim3(256), 0, G, lambda, b->d_partials, nbs);
                 if (nb1 > 0) CS_LAUNCH(ctx, "ba_err_obs", ba_err_obs, dim3(nb1), dim3(256), 0, G, b->d_partials + mp);
-                if (nb2 > 0) CS_LAUNCH(ctx, "ba_err_pose_edges", ba_err_pose_edges, dim3(nb2), dim3(256), 0, G, b->d_partials + 2 * mp);
+                if (nb2 > 0) CS_LAUNCH(ctx, "ba_err_pose_edges", ba_err_pose_edges, dim3(nb2), dim3(256), 0, G, b->d_partials + 2 * mp); // (one grid for both measured no faster: 36 us against 14 + 20, the cuboid edges' registers halve the reprojection edges' occupancy)
                 const size_t need = (size_t)mp * 3 + 1;
                 if (b->pin_cap < need) {
                     if (b->h_pin) hipHostFree(b->h_pin);
