@@ -198,7 +198,7 @@ def ba_bench(ctx, rank, world, iters, with_cpu, with_traffic=False):
 
 
 # ---------------------------------------------------------------------------------------------------------------- config 3
-def c3_bench(ctx, frames, steps, with_cpu, with_traffic=False):
+def c3_bench(ctx, frames, steps, with_cpu, with_traffic=False, with_batch_window=0):
     """BASELINE config 3: 1241x376 stream (1/f texture moving 3 px per frame), 2000 ORB features + LSD/LBD lines per frame and the
     tracking thread's frame-to-frame ORBmatcher::SearchByProjection (th = 15) from the extractor's device buffers."""
     from cube_slam_amd import synth
@@ -207,11 +207,19 @@ def c3_bench(ctx, frames, steps, with_cpu, with_traffic=False):
     from cube_slam_amd.orb import ORBextractor
     W, H = 1241, 376
     fx, fy, cx, cy = 721.5377, 721.5377, 609.5593, 172.854
-    imgs = np.stack([synth.texture_image(77, W, H, shift=3 * i) for i in range(frames)])
+    imgs = synth.texture_stream(77, W, H, frames, step=3)
     orb = ORBextractor(2000, 1.2, 8, 20, 7, W, H, max_frames=frames, ctx=ctx)
     orb.upload(imgs)
-    lsd = line_lbd_detect(W, H, max_frames=frames, ctx=ctx)
-    lsd.upload(imgs)
+    # the stream through the library's runner (cs_frontend_*): ORB on this thread's context, the line path of the same window on two worker contexts that alternate
+    # passes -- a window's host region stage (frames < 512: the OpenMP threads grow the regions) runs beside ORB + matching of the next window
+    from cube_slam_amd import _lib
+    from cube_slam_amd.frontend import Frontend
+    lctx = [_lib.Context(0) for _ in range(4 if frames >= 512 else 2)]  # (from 512 frames per window the region stage runs on the device: four detectors in flight, like the headline)
+    lsds = [line_lbd_detect(W, H, max_frames=frames, ctx=c) for c in lctx]
+    for d_ in lsds:
+        d_.upload(imgs)
+    lsd = lsds[0]
+    fe = Frontend(ctx, orb=orb, batch=None, line_detectors=lsds)
     m = ORBmatcher(0.9, True, ctx=ctx, max_queries=4096)
     K4 = np.array([fx, fy, cx, cy], np.float32)
     bounds = (0.0, float(W), 0.0, float(H))
@@ -219,8 +227,7 @@ def c3_bench(ctx, frames, steps, with_cpu, with_traffic=False):
     Tcw = np.eye(4, dtype=np.float32)[:3]
 
     def one_pass():
-        orb.run()
-        lsd.run(True)
+        fe.step()  # ORB of this window here, its line pass (LSD + LBD) on a worker
         per = orb.read()  # key points + descriptors of every frame (the map points' descriptors are host data in the reference too)
         n_q = n_m = 0
         for f in range(1, frames):  # the tracking thread: key points of frame f-1 projected into frame f (known 3 px shift)
@@ -233,28 +240,40 @@ def c3_bench(ctx, frames, steps, with_cpu, with_traffic=False):
             n_q += len(pk); n_m += nm
         return n_q, n_m
 
-    one_pass()
-    ctx.sync()
-    ctx.timing(True); ctx.timing_reset()
+    def sync_all():
+        fe.drain(); ctx.sync()
+        for c in lctx:
+            c.sync()
+
+    one_pass(); one_pass()
+    sync_all()
+    for c in [ctx] + lctx:
+        c.timing(True); c.timing_reset()
     t0 = time.perf_counter()
+    fe.set_backlog(steps)
     for _ in range(steps):
         n_q, n_m = one_pass()
-    ctx.sync()
+    sync_all()
     dt = time.perf_counter() - t0
     kern = {}
     for nme in ("orb_resize", "orb_fast_score", "orb_cells", "orb_quadtree", "orb_blur", "orb_angle", "orb_desc", "host_lsd_regions", "lsd_blur_hv", "lsd_resize", "lsd_gradient",
                 "lbd_blur5", "lbd_sobel", "lbd_line_desc", "match_undistort", "match_grid", "match_project", "match_candidates", "match_scan"):
-        ms, n = ctx.timing_get(nme)
+        parts = [c.timing_get(nme) for c in [ctx] + lctx]
+        ms, n = sum(p_[0] for p_ in parts), sum(p_[1] for p_ in parts)
         if n:
             kern[nme] = round(1e3 * ms / n, 2)
     cand_ms, cand_n = ctx.timing_get("match_candidates")
-    ctx.timing(False)
+    for c in [ctx] + lctx:
+        c.timing(False)
     n_kp = sum(len(k) for k, _ in orb.read())
     n_lines = sum(len(lsd.read(f, with_desc=False)) for f in range(frames))
     cstat = m.last_candidate_stats()
     out = {"metric": "frames/s, 1241x376 stream: ORB 2000 + LSD/LBD + frame-to-frame SearchByProjection", "value": frames * steps / dt, "unit": "frames/s",
            "ms_per_frame": 1e3 * dt / (frames * steps), "frames": frames, "keypoints_per_frame": n_kp / frames, "keylines_per_frame": n_lines / frames,
-           "queries_per_pass": n_q, "matches_per_pass": n_m, "kernels_us": kern}
+           "queries_per_pass": n_q, "matches_per_pass": n_m, "kernels_us": kern,
+           "region_stage": ("device: one wave per frame (lsd_rg_seq)" if lsd.region_stats()["device"] else "host: %d OpenMP threads" % _lib.lib().cs_host_thread_count()),
+           "runner": "cs_frontend: ORB + the tracking thread's matching on the caller's context, the line path of the same window on %d worker contexts (a window's region stage "
+                     "beside ORB + matching of the next one); %d windows of %d frames timed, drained inside the clock" % (len(lctx), steps, frames)}
     if cand_n and cstat is not None:
         # SURVEY 8d "Hamming window match, per query: 32 + 32 c + 8 B" with c = candidates the window enumerated
         alg = 40.0 * cstat["queries"] + 32.0 * cstat["candidates"]
@@ -335,6 +354,14 @@ def c3_bench(ctx, frames, steps, with_cpu, with_traffic=False):
         out["cpu_baseline_mt"] = {"value": nmt / dtm, "unit": "frames/s", "cores": cores, "kind": "port",
                                   "sample": "%d frames of the same stream in %.1f s, %d threads (frame-parallel ORB + LSD/LBD, no matching)" % (nmt, dtm, cores)}
     m.close()
+    fe.close()
+    if with_batch_window:
+        # the same stream in windows large enough for the device region stage (what the headline does at 640x480): throughput for a backlog, at a window's latency
+        for o_ in (orb, *lsds):
+            o_.close()
+        bw = c3_bench(ctx, with_batch_window, 4, with_cpu=False)
+        out["batch_window"] = {k: bw[k] for k in ("value", "unit", "ms_per_frame", "frames", "keypoints_per_frame", "keylines_per_frame", "region_stage", "runner", "kernels_us")}
+        out["batch_window"]["note"] = "per-frame matching launches are issued from Python, one frame at a time, inside the clock"
     return out
 
 
@@ -385,10 +412,10 @@ def c4_bench(ctx, frames, boxes, yaw_step, steps, with_cpu, with_traffic=False):
     return out
 
 
-def chained_bench(ctx, fe, lsds, batch, scenes, frames, steps, barrier):
+def chained_bench(ctx, fe, lsds, batch, scenes, frames, steps, barrier, backlog=True):
     """The reference's chain (main_obj.cpp:428-449) with the frames resident, PIPELINED by the runner (cs_frontend_set_chain): every step's detect_cuboid is
-    fed the lines detect_filter_lines found for the same frames in the pass its line worker finished last -- with W workers that pass was submitted W steps
-    earlier, so no step waits for a line pass; the hand-over goes through the host (KeyLines are assembled there) and costs the step one synchronisation
+    fed the lines detect_filter_lines found for the same frames in line pass k - W (k: the step, W: the line workers) -- a pass started at least W steps
+    earlier, so in the steady state no step waits for a line pass; the hand-over goes through the host (KeyLines are assembled there) and costs the step one synchronisation
     of the ORB / cuboid stream.  Same runner, same detectors and batch as the headline; only the edge lists change."""
     for d_ in lsds:
         d_.line_length_thres = 15.0  # main_obj.cpp:366
@@ -397,6 +424,8 @@ def chained_bench(ctx, fe, lsds, batch, scenes, frames, steps, barrier):
         fe.step()
     barrier()
     t0 = time.perf_counter()
+    if backlog:
+        fe.set_backlog(steps)
     for _ in range(steps):
         fe.step()
     barrier()
@@ -483,6 +512,9 @@ def main():
     ap.add_argument("--phased", type=int, default=0, help="0 (default): the alternating runner -- the detectors' region walks hold most CUs all the time and every other kernel runs beside them, the edge-scoring kernel in "
                     "the launch shape that fits into a CU's leftovers; 1: the phased runner (the region stages of --line-workers steps run together with the ORB / cuboid stream idle)")
     ap.add_argument("--cuboid-stream", type=int, default=0, help="1: the cuboid batch on a stream of its own beside the ORB pass of the same step (cs_frontend_set_cuboid_ctx); 0 (default): behind it on the caller's stream -- measured equal (20.77 k against 20.71 k frames/s: the kernels of both stretch by what they overlap), and the score kernel keeps more of the GPU to itself")
+    ap.add_argument("--backlog", type=int, default=1, help="1 (default): the runner is told how many steps follow (cs_frontend_set_backlog) -- the line passes of those steps start as soon as a worker is free, "
+                    "at most 2 W ahead of the ORB / cuboid pass of their step, so the line pipeline is full from the first timed step and does not drain behind the last one; 0: one line pass is started per step")
+    ap.add_argument("--sweep", action="store_true", help="(development) after the timed region, time the same steps again under other runner settings: `runner_variants`")
     ap.add_argument("--boxes", type=int, default=3)
     ap.add_argument("--yaw-step", type=float, default=0.5)
     ap.add_argument("--no-cpu", action="store_true")
@@ -572,6 +604,8 @@ def main():
             dist.barrier()
 
     hbm_marks.append(("lines_created", torch.cuda.mem_get_info()[0]))
+    if args.backlog and args.warmup:
+        fe.set_backlog(args.warmup)
     for _ in range(args.warmup):
         fe.step()
     barrier()
@@ -580,6 +614,8 @@ def main():
         c.timing(True)
         c.timing_reset()
     t0 = time.perf_counter()
+    if args.backlog:
+        fe.set_backlog(args.steps)  # inside the timed region: every line pass of these steps starts after t0 and is waited for by the barrier below
     for _ in range(args.steps):
         fe.step()
     barrier()
@@ -600,6 +636,25 @@ def main():
     ctx.timing(False)
     for c in side_ctxs:
         c.timing(False)
+    variants = None
+    if args.sweep and rank == 0 and world == 1 and lsd is not None:
+        variants = []
+        sweep_ctx = _lib.Context(local_rank, priority=int(os.environ.get("BENCH_PRIO_MAIN", "1")))
+        for name, bl, cub in (("backlog", 1, 0), ("step_by_step", 0, 0), ("backlog+cuboid_stream", 1, 1), ("step_by_step+cuboid_stream", 0, 1), ("backlog", 1, 0)):
+            fe.set_cuboid_ctx(sweep_ctx if cub else None)
+
+            def bar2():
+                barrier(); sweep_ctx.sync()
+            bar2()
+            t0 = time.perf_counter()
+            if bl:
+                fe.set_backlog(args.steps)
+            for _ in range(args.steps):
+                fe.step()
+            bar2()
+            dtv = time.perf_counter() - t0
+            variants.append({"runner": name, "value": args.frames * args.steps / dtv, "ms_per_step": 1e3 * dtv / args.steps})
+        fe.set_cuboid_ctx(ctx_cub)
     # the phased runner on the same objects, shortly: its throughput and the score kernel's time in ITS timed region (the kernel never meets a region walk there)
     phased_alt = None
     if lsd is not None and not args.phased and args.frames >= 512 and os.environ.get("CUBESLAM_LSD_REGIONS", "seq") == "seq" and len(ctx_lines) >= 2 and rank == 0 and world == 1:
@@ -649,10 +704,10 @@ def main():
         tr = measure_traffic("cuboid_sweep_score", "pmc_run.py", [args.frames, args.boxes, args.yaw_step, BG_TEXTURE])
         if not args.no_cpu:
             native_oracle()  # the c3 / c4 CPU legs use the -march=native build too
-        extra["c3"] = c3_bench(ctx, 2 * _lib.lib().cs_host_thread_count(), 3, with_cpu=not args.no_cpu, with_traffic=True)  # a stream window of two frames per host thread (the region stage's workers)
+        extra["c3"] = c3_bench(ctx, 2 * _lib.lib().cs_host_thread_count(), 12, with_cpu=not args.no_cpu, with_traffic=True)  # (with_batch_window=1024: the same stream in device-stage windows -- bound by the per-frame matching loop in Python, not reported)  # a stream window of two frames per host thread (the region stage's workers)
         extra["c4"] = c4_bench(ctx, 64, 8, args.yaw_step, 10, with_cpu=not args.no_cpu, with_traffic=True)
         if lsd is not None:
-            extra["chained"] = chained_bench(ctx, fe, lsds, batch, scenes, args.frames, 10, barrier)
+            extra["chained"] = chained_bench(ctx, fe, lsds, batch, scenes, args.frames, args.steps, barrier, backlog=bool(args.backlog))
         extra["pcie_inclusive"] = pcie_inclusive(ctx, scenes, args.yaw_step, args.orb_features, local_rank=local_rank)
     else:
         tr = None
@@ -723,6 +778,8 @@ def main():
             "hbm_by_path_gb": {b[0]: round((a[1] - b[1]) / 1e9, 2) for a, b in zip(hbm_marks[:-1], hbm_marks[1:])},  # the front-end's own working set, engine by engine (after_warmup: buffers sized at the first run)
         }
         out.update(extra)
+        if variants is not None:
+            out["runner_variants"] = variants
         if not args.no_cpu and world == 1:
             flags = native_oracle()
             cores = _lib.lib().cs_host_thread_count()

@@ -6,6 +6,11 @@
 // kernels run while the other pass grows regions (the host stages themselves are serialised inside lsd.hip).  At most one pass
 // per worker is in flight; cs_frontend_step blocks until the worker it needs is free.
 //
+// Passes are numbered: line pass k belongs to step k.  cs_frontend_step(k) makes sure pass k has been started, no more; with a BACKLOG announced
+// (cs_frontend_set_backlog: "n more steps will follow on these frames") a worker that finishes a pass takes the next pass of the backlog at once, up to
+// 2 W passes ahead of the caller, instead of waiting for the step that asks for it -- the line pipeline fills at the first step and does not drain behind the
+// last one.  Chained mode hands pass k's lines to step k + W through a queue of packets keyed by the pass number.
+//
 // Phased mode (cs_frontend_set_phased): the device region stage of LSD (lsd_rg_seq, one wave per frame, 16 frames per CU) and the
 // cuboid score kernel (one workgroup owns a CU's LDS) do not share a CU well, so the runner separates them in time.  A super-step =
 // one pass per line worker: the workers run their map kernels beside ORB / cuboid of the same passes and stop at a gate in front of
@@ -15,6 +20,7 @@
 #include "common.h"
 
 #include <condition_variable>
+#include <map>
 #include <mutex>
 #include <thread>
 #include <vector>
@@ -28,7 +34,9 @@ extern "C" int cs_cuboid_batch_set_shared_gpu(cs_cuboid_batch *b, int shared);
 extern "C" int cs_cuboid_batch_set_lines(cs_ctx *ctx, cs_cuboid_batch *b, const int *line_offsets, const double *lines);
 int cs_lsd_filter_lines_packed(cs_lsd *l, float length_thres, std::vector<int> &offsets, std::vector<double> &lines); // lsd.hip
 
+struct cs_frontend;
 namespace {
+struct LinePacket { std::vector<int> off; std::vector<double> lines; int status = CS_OK; }; // detect_filter_lines of one pass, packed per frame (chained mode)
 struct Gate { // phase gate of one runner: tickets are pass numbers, the gate is open for every ticket <= target
     std::mutex m; std::condition_variable cv;
     bool phased = false;
@@ -55,6 +63,8 @@ struct LineWorker {
     std::mutex *any_m = nullptr; std::condition_variable *any_cv = nullptr; // the runner's "a worker has finished" signal
     bool busy = false, have_job = false, quit = false;
     int last_status = CS_OK;
+    cs_frontend *fe = nullptr; long pass_no = -1; // the runner and the number of the pass in flight (set by whoever starts it, under fe->any_m)
+    bool after_pass(int r); // hands the pass's lines over (chained mode); true: this worker has taken the next pass of the backlog
     void loop() {
         for (;;) {
             std::unique_lock<std::mutex> lk(m);
@@ -62,10 +72,13 @@ struct LineWorker {
             if (quit) return;
             have_job = false;
             lk.unlock();
-            const int r = cs_lsd_run(ctx, lsd, 1);
-            gate_done(this); // a pass that failed, fell back to the host stage or had nothing to grow never reached the device stage's own call
+            int r;
+            do {
+                r = cs_lsd_run(ctx, lsd, 1);
+                gate_done(this); // a pass that failed, fell back to the host stage or had nothing to grow never reached the device stage's own call
+                if (r != CS_OK) { std::lock_guard<std::mutex> g(m); if (last_status == CS_OK) last_status = r; }
+            } while (after_pass(r));
             lk.lock();
-            if (r != CS_OK && last_status == CS_OK) last_status = r;
             busy = false;
             cv.notify_all();
             lk.unlock();
@@ -96,15 +109,18 @@ struct cs_frontend {
     cs_ctx *ctx = nullptr; cs_orb *orb = nullptr; cs_cuboid_batch *batch = nullptr;
     cs_ctx *cub_ctx = nullptr; // cs_frontend_set_cuboid_ctx: the context (stream) the cuboid batch is enqueued on -- the caller's own unless set
     std::vector<LineWorker *> workers;
-    unsigned long step_no = 0;
     Gate gate;
+    // guarded by any_m: the step counter, the pass counters and the packets of chained mode.  Line pass k belongs to step k: passes_started > k once it has been
+    // handed to a worker; passes_target: passes [0, passes_target) may be started (a step raises it to its own number + 1, cs_frontend_set_backlog further)
     std::mutex any_m; std::condition_variable any_cv; // a worker has finished a pass
+    long step_no = 0, passes_started = 0, passes_target = 0;
     size_t next_worker = 0;
     unsigned long in_phase = 0; // passes submitted since the gate last opened
-    // chained mode (cs_frontend_set_chain): detect_cuboid of a pass is fed the lines detect_filter_lines found in the pass the same worker finished
-    // last -- the reference's chain (main_obj.cpp:428-449), pipelined: the line pass of a batch runs W steps ahead of the batch's cuboid pass
-    bool chain = false; float chain_thres = 0;
-    std::vector<char> worker_ran; std::vector<int> chain_off; std::vector<double> chain_lines;
+    // chained mode (cs_frontend_set_chain): detect_cuboid of step k is fed the lines detect_filter_lines found in line pass k - W -- the reference's chain
+    // (main_obj.cpp:428-449), pipelined: the line pass of a batch runs at least W steps ahead of the batch's cuboid pass
+    bool chain = false; float chain_thres = 0; long chain_first = 0; // passes from chain_first on leave a packet
+    std::map<long, LinePacket> packets;
+    long lead_max() const { return 2 * (long)workers.size(); }
     int open_gate() { // caller's stream idle -> region stages of every waiting pass -> return when they have left the GPU
         const int r = hipStreamSynchronize(ctx->stream) == hipSuccess ? CS_OK : CS_ERR_HIP; // (the gate opens either way: a waiting pass must not be left behind)
         std::unique_lock<std::mutex> lk(gate.m);
@@ -114,7 +130,34 @@ struct cs_frontend {
         in_phase = 0;
         return r;
     }
+    bool may_start() const { return passes_started < passes_target && passes_started < step_no + lead_max(); } // any_m held
+    void kick_idle() { // any_m held: free workers take the passes that may be started, looked for from the one behind the last choice (a strict rotation made the caller
+                       // wait for a slow pass with idle workers beside it: passes take 110 - 220 ms beside each other)
+        for (size_t k = 0; k < workers.size() && may_start(); k++) {
+            const size_t c = (next_worker + k) % workers.size();
+            if (!workers[c]->is_free()) continue;
+            workers[c]->pass_no = passes_started++;
+            workers[c]->submit();
+            next_worker = (c + 1) % workers.size();
+        }
+    }
 };
+
+namespace {
+bool LineWorker::after_pass(int r) {
+    if (!fe) return false;
+    LinePacket pk; bool leave = false;
+    if (fe->chain && pass_no >= fe->chain_first) { // (chain / chain_first only change with no pass in flight)
+        leave = true; pk.status = r;
+        if (r == CS_OK) pk.status = cs_lsd_filter_lines_packed(lsd, fe->chain_thres, pk.off, pk.lines);
+    }
+    std::lock_guard<std::mutex> lk(fe->any_m);
+    if (leave) { fe->packets[pass_no] = std::move(pk); fe->any_cv.notify_all(); }
+    if (r != CS_OK || fe->gate.phased || !fe->may_start()) return false;
+    pass_no = fe->passes_started++;
+    return true;
+}
+} // namespace
 
 extern "C" {
 
@@ -126,7 +169,7 @@ int cs_frontend_create(cs_ctx *ctx, cs_orb *orb, cs_cuboid_batch *batch, int n_l
     fe->ctx = ctx; fe->orb = orb; fe->batch = batch;
     for (int i = 0; i < n_line_workers; i++) {
         LineWorker *w = new LineWorker();
-        w->ctx = line_ctx[i]; w->lsd = lsd[i]; w->gate = &fe->gate; w->any_m = &fe->any_m; w->any_cv = &fe->any_cv;
+        w->ctx = line_ctx[i]; w->lsd = lsd[i]; w->gate = &fe->gate; w->any_m = &fe->any_m; w->any_cv = &fe->any_cv; w->fe = fe;
         cs_lsd_set_gate(w->lsd, LineWorker::gate_wait, LineWorker::gate_done, w);
         w->th = std::thread([w] { w->loop(); });
         fe->workers.push_back(w);
@@ -141,41 +184,51 @@ int cs_frontend_step(cs_frontend *fe) {
     if (!fe) return CS_ERR_BAD_ARG;
     int r = CS_OK;
     if (!fe->workers.empty()) {
-        // the pass goes to the first worker that is free, looked for from the one behind the last choice: passes take 110 - 220 ms beside each other, and a strict
-        // rotation made the caller wait for a slow one with idle ones beside it (phased passes keep the rotation: their gate counts one pass per detector)
-        size_t wi = fe->step_no % fe->workers.size();
-        if (!fe->gate.phased) {
+        const long W = (long)fe->workers.size();
+        LinePacket pk; bool have_pk = false;
+        {
             std::unique_lock<std::mutex> lk(fe->any_m);
-            for (;;) {
-                bool found = false;
-                for (size_t k = 0; k < fe->workers.size(); k++) {
-                    const size_t c = (fe->next_worker + k) % fe->workers.size();
-                    if (fe->workers[c]->is_free()) { wi = c; found = true; break; }
-                }
-                if (found) break;
-                fe->any_cv.wait_for(lk, std::chrono::milliseconds(2));
+            const long k = fe->step_no;
+            if (fe->passes_target < k + 1) fe->passes_target = k + 1;
+            if (fe->gate.phased) { // one pass per detector and super-step, in rotation (the gate counts them)
+                if (fe->passes_started <= k) { LineWorker *w = fe->workers[(size_t)(k % W)]; w->pass_no = fe->passes_started++; lk.unlock(); w->submit(); lk.lock(); fe->in_phase++; }
+            } else {
+                fe->kick_idle();
+                while (fe->passes_started <= k) { fe->any_cv.wait_for(lk, std::chrono::milliseconds(2)); fe->kick_idle(); } // pass k has been started: the line path is at most W passes behind
             }
-            fe->next_worker = (wi + 1) % fe->workers.size();
+            if (fe->chain && fe->batch && k - W >= fe->chain_first) { // the lines of pass k - W are this step's edges (the first W steps after the switch run on the lists the batch holds)
+                fe->any_cv.wait(lk, [&] { return fe->packets.count(k - W) != 0; });
+                pk = std::move(fe->packets[k - W]); fe->packets.erase(k - W); have_pk = true;
+            }
+            fe->step_no = k + 1;
         }
-        LineWorker *w = fe->workers[wi];
-        if (fe->chain && fe->batch && fe->worker_ran.size() > wi && fe->worker_ran[wi]) { // the pass this worker ran W steps ago: its lines are this step's edges
-            r = w->wait();
-            if (r == CS_OK) r = cs_lsd_filter_lines_packed(w->lsd, fe->chain_thres, fe->chain_off, fe->chain_lines);
-            if (r == CS_OK) r = cs_cuboid_batch_set_lines(fe->cub_ctx ? fe->cub_ctx : fe->ctx, fe->batch, fe->chain_off.data(), fe->chain_lines.data());
+        if (have_pk) {
+            r = pk.status;
+            if (r == CS_OK) r = cs_cuboid_batch_set_lines(fe->cub_ctx ? fe->cub_ctx : fe->ctx, fe->batch, pk.off.data(), pk.lines.data());
             if (r != CS_OK) return r;
         }
-        w->submit();
-        if (fe->worker_ran.size() <= wi) fe->worker_ran.resize(fe->workers.size(), 0);
-        fe->worker_ran[wi] = 1;
+    } else {
+        std::lock_guard<std::mutex> lk(fe->any_m);
+        fe->step_no++;
     }
-    fe->step_no++;
     // the cuboid pass is a chain of launches without a host round trip: on a stream of its own (cs_frontend_set_cuboid_ctx) it is enqueued first and runs beside the ORB
     // pass, whose two read-backs would otherwise wait behind it
     if (fe->batch && fe->cub_ctx) r = cs_cuboid_batch_run(fe->cub_ctx, fe->batch);
     if (r == CS_OK && fe->orb) r = cs_orb_run(fe->ctx, fe->orb);
     if (r == CS_OK && fe->batch && !fe->cub_ctx) r = cs_cuboid_batch_run(fe->ctx, fe->batch);
-    if (fe->gate.phased && !fe->workers.empty() && ++fe->in_phase >= fe->workers.size()) { const int g = fe->open_gate(); if (r == CS_OK) r = g; }
+    if (fe->gate.phased && !fe->workers.empty() && fe->in_phase >= fe->workers.size()) { const int g = fe->open_gate(); if (r == CS_OK) r = g; }
     return r;
+}
+
+// n more steps will follow on the frames the detectors hold: the line passes of those steps may be started as soon as a worker is free (at most 2 W passes ahead of the
+// caller's step) instead of one per step.  Work is neither added nor dropped -- step k still needs line pass k, and cs_frontend_drain still waits for every pass that has
+// been started; a backlog that is not followed by its steps leaves passes that later steps find done.  No effect on phased passes.
+int cs_frontend_set_backlog(cs_frontend *fe, int n_steps) {
+    if (!fe || n_steps < 0) return CS_ERR_BAD_ARG;
+    std::lock_guard<std::mutex> lk(fe->any_m);
+    if (fe->passes_target < fe->step_no + n_steps) fe->passes_target = fe->step_no + n_steps;
+    if (!fe->gate.phased && !fe->workers.empty()) fe->kick_idle();
+    return CS_OK;
 }
 
 int cs_frontend_set_phased(cs_frontend *fe, int on) {
@@ -188,14 +241,16 @@ int cs_frontend_set_phased(cs_frontend *fe, int on) {
     return r;
 }
 
-// on != 0: from now on a step's cuboid pass takes its edge lists from the line pass the step's worker finished last (filter_lines with `length_thres`,
-// main_obj.cpp:366) -- with W workers the lines of a batch are ready W steps before its cuboids are asked for, and nothing waits.  The first W steps
-// after the switch still run on the lists the batch was created with.  Needs a batch and at least one line worker.
+// on != 0: from now on the cuboid pass of step k takes its edge lists from line pass k - W (filter_lines with `length_thres`, main_obj.cpp:366) -- a pass
+// that was started at least W steps earlier, so in the steady state nothing waits.  The first W steps after the switch still run on the lists the batch
+// holds.  Needs a batch and at least one line worker.
 int cs_frontend_set_chain(cs_frontend *fe, int on, float length_thres) {
     if (!fe || (on && (!fe->batch || fe->workers.empty()))) return CS_ERR_BAD_ARG;
     const int r = cs_frontend_drain(fe);
+    std::lock_guard<std::mutex> lk(fe->any_m);
     fe->chain = on != 0; fe->chain_thres = length_thres;
-    fe->worker_ran.assign(fe->workers.size(), 0);
+    fe->chain_first = std::max(fe->passes_started, fe->step_no); // (passes a cut backlog left done have no packet)
+    fe->packets.clear();
     return r;
 }
 
@@ -214,6 +269,7 @@ int cs_frontend_drain(cs_frontend *fe) {
     if (!fe) return CS_ERR_BAD_ARG;
     int r = CS_OK;
     if (fe->cub_ctx && hipStreamSynchronize(fe->cub_ctx->stream) != hipSuccess) r = CS_ERR_HIP;
+    { std::lock_guard<std::mutex> lk(fe->any_m); fe->passes_target = fe->passes_started; } // what is left of a backlog is not started behind the caller's back
     if (fe->in_phase) r = fe->open_gate(); // an incomplete super-step
     for (LineWorker *w : fe->workers) { const int s = w->wait(); if (r == CS_OK) r = s; }
     return r;
@@ -221,6 +277,7 @@ int cs_frontend_drain(cs_frontend *fe) {
 
 void cs_frontend_destroy(cs_frontend *fe) {
     if (!fe) return;
+    { std::lock_guard<std::mutex> lk(fe->any_m); fe->passes_target = fe->passes_started; }
     if (fe->in_phase) fe->open_gate();
     for (LineWorker *w : fe->workers) {
         w->wait();

@@ -24,13 +24,17 @@ class Frontend:
         check(self.ctx.ptr, lib().cs_frontend_set_phased(self._fe, 1 if on else 0), "cs_frontend_set_phased")
 
     def set_chain(self, on, length_thres=15.0):
-        """The reference's chain, pipelined: a step's cuboid pass takes the lines its line worker's last pass found (cs_frontend_set_chain)."""
+        """The reference's chain, pipelined: the cuboid pass of step k takes the lines of line pass k - W (cs_frontend_set_chain)."""
         check(self.ctx.ptr, lib().cs_frontend_set_chain(self._fe, 1 if on else 0, C.c_float(length_thres)), "cs_frontend_set_chain")
 
     def set_cuboid_ctx(self, ctx):
         """The cuboid batch on its own Context (stream), beside the ORB pass of the same step (cs_frontend_set_cuboid_ctx); None: the caller's stream."""
         check(self.ctx.ptr, lib().cs_frontend_set_cuboid_ctx(self._fe, ctx.ptr if ctx is not None else None), "cs_frontend_set_cuboid_ctx")
         self._cub_ctx = ctx
+
+    def set_backlog(self, n_steps):
+        """n_steps more step() calls follow on the same frames: their line passes may start as soon as a worker is free (cs_frontend_set_backlog)."""
+        check(self.ctx.ptr, lib().cs_frontend_set_backlog(self._fe, int(n_steps)), "cs_frontend_set_backlog")
 
     def step(self):
         check(self.ctx.ptr, lib().cs_frontend_step(self._fe), "cs_frontend_step")

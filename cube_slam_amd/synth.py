@@ -122,8 +122,7 @@ def cuboid_scene(seed, W=640, H=480, n_boxes=3, K=K_TUM, n_clutter=40, noise_sig
     }
 
 
-def texture_image(seed, W, H, shift=0):
-    """Band-limited (1/f) noise texture, translated by `shift` px -- FAST fires everywhere (SURVEY 8d, C3)."""
+def _texture_base(seed, W, H):
     rng = np.random.default_rng(seed)
     big_w = W + 1024
     fy = np.fft.fftfreq(H)[:, None]
@@ -135,8 +134,19 @@ def texture_image(seed, W, H, shift=0):
     im = np.fft.irfft2(spec, s=(H, big_w))
     im = (im - im.mean()) / im.std()
     im = np.clip(128 + 48 * im, 0, 255)
+    return np.rint(im).astype(np.uint8)
+
+
+def texture_image(seed, W, H, shift=0):
+    """Band-limited (1/f) noise texture, translated by `shift` px -- FAST fires everywhere (SURVEY 8d, C3)."""
     s = int(shift) % 1024
-    return np.ascontiguousarray(np.rint(im[:, s:s + W]).astype(np.uint8))
+    return np.ascontiguousarray(_texture_base(seed, W, H)[:, s:s + W])
+
+
+def texture_stream(seed, W, H, n, step=3):
+    """texture_image(seed, W, H, shift=step * i) for i < n as one array (the base texture is made once)."""
+    base = _texture_base(seed, W, H)
+    return np.stack([base[:, (step * i) % 1024:(step * i) % 1024 + W] for i in range(n)])
 
 
 # ----------------------------------------------------------------------------------------------- object BA (SURVEY 8d, C5)

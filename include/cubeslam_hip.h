@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define CS_VERSION 104 /* 104: cs_frontend_set_cuboid_ctx; 103: cs_lsd_read_filter_lines takes the caller's frame count, cs_frontend_set_chain; 102: cs_cuboid_batch_set_lines, cs_cuboid_batch_set_shared_gpu, cs_lsd_read_filter_lines; 101: cs_ba_set_stop_flag_bool / cs_ba_dyn_set_stop_flag_bool; cs_match_by_projection_frame takes train_blocked */
+#define CS_VERSION 105 /* 105: cs_frontend_set_backlog; 104: cs_frontend_set_cuboid_ctx; 103: cs_lsd_read_filter_lines takes the caller's frame count, cs_frontend_set_chain; 102: cs_cuboid_batch_set_lines, cs_cuboid_batch_set_shared_gpu, cs_lsd_read_filter_lines; 101: cs_ba_set_stop_flag_bool / cs_ba_dyn_set_stop_flag_bool; cs_match_by_projection_frame takes train_blocked */
 
 typedef enum cs_status {
     CS_OK = 0,
@@ -456,9 +456,15 @@ int cs_frontend_drain(cs_frontend *fe);
  * returns when they have left the GPU.  The cuboid score kernel and the one-wave-per-frame region kernel then never share a CU. */
 int cs_frontend_set_phased(cs_frontend *fe, int on);
 /* The reference's chain (object_slam/src/main_obj.cpp:428-449: detect_cuboid consumes this frame's detect_filter_lines) as a pipeline: on != 0 makes
- * every step hand the lines of the pass its line worker finished last (octave 0, lineLength > length_thres) to the cuboid batch before that batch
- * runs; with W workers a batch's lines are W steps old, so no step waits for a line pass.  Needs a cuboid batch and >= 1 line worker. */
+ * step k hand the lines of line pass k - W (octave 0, lineLength > length_thres; line pass k belongs to step k, W = number of line workers) to the cuboid
+ * batch before that batch runs: a pass that was started at least W steps earlier, so in the steady state no step waits for a line pass.  The first W steps
+ * after the switch run on the lists the batch holds.  Needs a cuboid batch and >= 1 line worker. */
 int cs_frontend_set_chain(cs_frontend *fe, int on, float length_thres);
+/* A backlog: `n_steps` more cs_frontend_step calls will follow on the frames the detectors hold.  The line passes of those steps are then started as soon as a
+ * worker is free -- at most 2 W passes ahead of the caller's step -- instead of one per step, so the line pipeline is full from the first step and does not
+ * drain behind the last one.  Nothing is added or dropped: step k still needs line pass k to have been started, cs_frontend_drain waits for every pass in
+ * flight and cuts what is left of the backlog (passes already done are found done by the steps that follow).  No effect on phased passes. */
+int cs_frontend_set_backlog(cs_frontend *fe, int n_steps);
 /* The cuboid batch on a stream of its own: its launches (no host round trip among them) are enqueued on `cuboid_ctx` and run beside the ORB pass of the same step
  * instead of in front of the next one.  NULL: back onto the caller's stream.  cs_frontend_drain waits for that stream too. */
 int cs_frontend_set_cuboid_ctx(cs_frontend *fe, cs_ctx *cuboid_ctx);

@@ -136,3 +136,72 @@ def test_frontend_chain_is_the_reference_chain_pipelined(ctx, oracle):
         assert len(got[off + k]) == len(r) and np.array_equal(got[off + k]["box_corners_2d"], r["box_corners_2d"])
     fe.set_chain(False)
     fe.close()
+
+
+def test_frontend_backlog_runs_the_same_passes_ahead_of_the_caller(ctx, oracle):
+    """cs_frontend_set_backlog: the line passes of the announced steps start as soon as a worker is free (up to 2 W ahead of the caller) -- the same number of
+    passes, the same results; a backlog cut by a drain leaves passes that the following steps find done; the chain under a backlog is the chain."""
+    scenes = [synth.cuboid_scene(700 + i, n_boxes=2, bg_texture=0.5) for i in range(5)]
+    gray = np.stack([s["gray"] for s in scenes])
+    det = detect_3d_cuboid(ctx); det.set_calibration(scenes[0]["K"])
+    args = (gray, scenes[0]["K"], np.stack([s["Twc"] for s in scenes]), [s["boxes"] for s in scenes])
+    batch = CuboidBatch(ctx, *args, [s["lines"] for s in scenes], det.opts())
+    orb = ORBextractor(500, 1.2, 8, 20, 7, 640, 480, max_frames=len(scenes), ctx=ctx); orb.upload(gray)
+    lctx = [_lib.Context(0) for _ in range(3)]
+    lsds = [line_lbd_detect(640, 480, max_frames=len(scenes), ctx=c) for c in lctx]
+    for d in lsds:
+        d.upload(gray)
+        d.line_length_thres = 15.0
+    fe = Frontend(ctx, orb=orb, batch=batch, line_detectors=lsds)
+
+    def passes():  # line passes run so far: launches of a kernel every pass makes once
+        return sum(c.timing_get("lsd_gradient")[1] for c in lctx)
+    for c in lctx:
+        c.timing(True); c.timing_reset()
+    fe.set_backlog(7)
+    for _ in range(7):
+        fe.step()
+    fe.drain(); ctx.sync()
+    assert passes() == 7
+    cub, kps = batch.read(), orb.read()
+    for f, s in enumerate(scenes):
+        rk, rd = oracle.ORBextractor(500, 1.2, 8, 20, 7)(s["gray"])
+        assert kps[f][0].tobytes() == rk.tobytes() and np.array_equal(kps[f][1], rd)
+        ref_kl = oracle.lsd_detect(s["gray"])
+        for d in lsds:
+            kl, desc = d.read(f)
+            assert kl.tobytes() == ref_kl.tobytes() and np.array_equal(desc, oracle.lbd_compute(s["gray"], ref_kl))
+    # a backlog of 6, cut after 2 steps: the workers have started at most 2 + 2 W passes and at least the two asked for; the steps that follow start what is missing, no more
+    fe.set_backlog(6)
+    fe.step(); fe.step()
+    fe.drain()
+    ahead = passes() - 9
+    assert 0 <= ahead <= 6
+    for _ in range(6):
+        fe.step()
+    fe.drain(); ctx.sync()
+    assert passes() == 15
+    assert all(a.tobytes() == b.tobytes() for a, b in zip(cub, batch.read()))
+    for c in lctx:
+        c.timing(False)
+    # the chain under a backlog: step k is fed the lines of pass k - W
+    lsds[0].run(False)
+    lines = lsds[0].read_filter_lines(len(scenes))
+    seq = CuboidBatch(ctx, *args, [np.asarray(l, np.float64) for l in lines], det.opts())
+    seq.run()
+    want = seq.read()
+    seq.close()
+    fe.set_chain(True, 15.0)
+    fe.set_backlog(8)
+    for k in range(3):
+        fe.step()
+    ctx.sync()
+    assert all(a.tobytes() == b.tobytes() for a, b in zip(cub, batch.read()))  # the first W steps: the lists the batch holds
+    for k in range(5):
+        fe.step()
+    fe.drain(); ctx.sync()
+    got = batch.read()
+    assert all(len(a) == len(b) and (len(a) == 0 or (np.array_equal(a["box_corners_2d"], b["box_corners_2d"]) and np.array_equal(a["normalized_error"], b["normalized_error"]))) for a, b in zip(got, want))
+    assert any(a.tobytes() != b.tobytes() for a, b in zip(got, cub)), "the handed-over lines change some cuboid"
+    fe.set_chain(False)
+    fe.close()
