@@ -79,10 +79,6 @@ __device__ double rg_nfa(int n, int k, double p, double LOG_NT, const double *lg
     }
     return -log10(bin_tail) - LOG_NT;
 }
-// rect_nfa (:977-1098): the four corners ordered like the reference's std::sort + selection, rows counted by the lanes of the wave
-// The pixel walk of rect_nfa (:977-1098): the four corners ordered like the reference's std::sort + selection, the rows counted by the lanes of the
-// wave.  total = pixels of the rectangle inside the image; algs[k] = those aligned with rec.theta within precs[k] (several tolerances share a walk:
-// rect_improve's first and last loop only halve the tolerance of an unchanged rectangle).  Every lane gets the sums.
 #if defined(RGI_PROF)
 __device__ unsigned long long g_rgi_prof[4]; // ticks in rectangle walks, in nfa(), calls of each
 #define RGI_T0 const unsigned long long rgi_t0 = wall_clock64()
@@ -91,50 +87,82 @@ __device__ unsigned long long g_rgi_prof[4]; // ticks in rectangle walks, in nfa
 #define RGI_T0
 #define RGI_T1(k)
 #endif
-template <int NP> __device__ void rg_rect_count(const AngMap &F, const rg::Rect &rec, const double *precs, int lane, int &total, int *algs) {
-    RGI_T0;
-    const double half_width = rec.width / 2.0, dyhw = rec.dy * half_width, dxhw = rec.dx * half_width;
-    int ox[4], oy[4]; bool taken[4] = {false, false, false, false};
-    ox[0] = int(rec.x1 - dyhw); oy[0] = int(rec.y1 + dxhw); ox[1] = int(rec.x2 - dyhw); oy[1] = int(rec.y2 + dxhw);
-    ox[2] = int(rec.x2 + dyhw); oy[2] = int(rec.y2 - dxhw); ox[3] = int(rec.x1 + dyhw); oy[3] = int(rec.y1 - dxhw);
-    for (int i = 1; i < 4; i++) // std::sort by (x, y): insertion sort gives the same order for distinct keys, ties are equal points
-        for (int j = i; j > 0 && (ox[j] < ox[j - 1] || (ox[j] == ox[j - 1] && oy[j] < oy[j - 1])); j--) { int t = ox[j]; ox[j] = ox[j - 1]; ox[j - 1] = t; t = oy[j]; oy[j] = oy[j - 1]; oy[j - 1] = t; }
-    int mn = 0, mx = 0;
-    for (int i = 1; i < 4; ++i) { if (oy[mn] > oy[i]) mn = i; if (oy[mx] < oy[i]) mx = i; }
-    taken[mn] = true;
-    int lm = -1;
-    for (int i = 0; i < 4; ++i) if (!taken[i]) { if (lm < 0) lm = i; else if (ox[lm] > ox[i]) lm = i; }
-    taken[lm] = true;
-    int rm = -1;
-    for (int i = 0; i < 4; ++i) if (!taken[i]) { if (rm < 0) rm = i; else if (ox[rm] < ox[i]) rm = i; }
-    taken[rm] = true;
-    int tl = -1;
-    for (int i = 0; i < 4; ++i) if (!taken[i]) { if (tl < 0) tl = i; else if (ox[tl] > ox[i]) tl = i; }
-    // integer divisions and the tailp->x comparisons are the reference's (:1057-1065); the steps are integers
-    const int flstep = (oy[mn] != oy[lm]) ? (ox[mn] - ox[lm]) / (oy[mn] - oy[lm]) : 0;
-    const int slstep = (oy[lm] != ox[tl]) ? (ox[lm] - ox[tl]) / (oy[lm] - ox[tl]) : 0;
-    const int frstep = (oy[mn] != oy[rm]) ? (ox[mn] - ox[rm]) / (oy[mn] - oy[rm]) : 0;
-    const int srstep = (oy[rm] != ox[tl]) ? (ox[rm] - ox[tl]) / (oy[rm] - ox[tl]) : 0;
+// What rect_nfa's row walk needs of a rectangle: the first and last row inside the image and, per row, the closed form of the reference's stepping limits.
+struct RectSpan {
+    int mnX, lmY, rmY, flstep, slstep, frstep, srstep, y_first, y_hi;
+    // The four corners ordered like the reference's std::sort by (x, y) -- a sorting network gives the same order for distinct keys, ties are equal points -- and its
+    // selection of the lowest / leftmost / rightmost / remaining corner, written on VALUES: indexing the sorted arrays with run-time indices cost ~600 compare / select
+    // instructions per walk, a third of this kernel.  In the sorted order the first corner not taken has the smallest x (the reference's strict `>` keeps the first of
+    // equals), so leftmost = corner 1 if the lowest is corner 0, else corner 0; the rightmost is the later of the remaining two unless the earlier has the larger x.
+    __device__ __forceinline__ void set(const rg::Rect &rec, int h) {
+        const double half_width = rec.width / 2.0, dyhw = rec.dy * half_width, dxhw = rec.dx * half_width;
+        int x0 = int(rec.x1 - dyhw), y0 = int(rec.y1 + dxhw), x1 = int(rec.x2 - dyhw), y1 = int(rec.y2 + dxhw);
+        int x2 = int(rec.x2 + dyhw), y2 = int(rec.y2 - dxhw), x3 = int(rec.x1 + dyhw), y3 = int(rec.y1 - dxhw);
+        auto cswap = [](int &xa, int &ya, int &xb, int &yb) {
+            const bool sw = xa > xb || (xa == xb && ya > yb);
+            const int tx = sw ? xb : xa, ty = sw ? yb : ya; xb = sw ? xa : xb; yb = sw ? ya : yb; xa = tx; ya = ty;
+        };
+        cswap(x0, y0, x1, y1); cswap(x2, y2, x3, y3); cswap(x0, y0, x2, y2); cswap(x1, y1, x3, y3); cswap(x1, y1, x2, y2);
+        int mnI = 0, mnY = y0; mnX = x0; // min_y: the first corner with the smallest y
+        { bool c = mnY > y1; mnI = c ? 1 : mnI; mnX = c ? x1 : mnX; mnY = c ? y1 : mnY; c = mnY > y2; mnI = c ? 2 : mnI; mnX = c ? x2 : mnX; mnY = c ? y2 : mnY; c = mnY > y3; mnI = c ? 3 : mnI; mnX = c ? x3 : mnX; mnY = c ? y3 : mnY; }
+        const int mxY = max(max(y0, y1), max(y2, y3));
+        const bool m0 = mnI == 0, le1 = mnI <= 1, is3 = mnI == 3;
+        const int lmX = m0 ? x1 : x0; lmY = m0 ? y1 : y0;                                                 // leftmost
+        const int iX = le1 ? x2 : x1, iY = le1 ? y2 : y1, jX = is3 ? x2 : x3, jY = is3 ? y2 : y3;         // the two that are left, in order
+        const bool rj = iX < jX;
+        const int rmX = rj ? jX : iX, tlX = rj ? iX : jX; rmY = rj ? jY : iY;                             // rightmost; of the last one only x is ever used
+        // integer divisions and the tailp->x comparisons are the reference's (:1057-1065); the steps are integers
+        flstep = (mnY != lmY) ? (mnX - lmX) / (mnY - lmY) : 0;
+        slstep = (lmY != tlX) ? (lmX - tlX) / (lmY - tlX) : 0;
+        frstep = (mnY != rmY) ? (mnX - rmX) / (mnY - rmY) : 0;
+        srstep = (rmY != tlX) ? (rmX - tlX) / (rmY - tlX) : 0;
+        y_hi = min(mxY, h - 1); y_first = max(mnY, 0);
+    }
     // the limits move after every row INSIDE the image (the reference `continue`s past the stepping for the others): by the first step while
     // y < leftmost.y (rightmost.y), by the second from then on -- a closed form per row, so the lanes take rows independently
-    int total_pts = 0, alg_pts[NP];
-    for (int k = 0; k < NP; k++) alg_pts[k] = 0;
-    const int y_lo = oy[mn], y_hi = min(oy[mx], F.h - 1), y_first = max(y_lo, 0);
-    for (int y = y_first + lane; y <= y_hi; y += 64) {
+    __device__ __forceinline__ bool row(int y, int w, int &lx, int &rx) const {
         const long r = (long)y - y_first; // rows stepped before this one: y_first .. y-1
         auto adv = [&](int first, int second, int ysw) -> long { // sum over y' in [y_first, y) of (y' >= ysw ? second : first)
             long nf = (long)ysw - y_first; if (nf < 0) nf = 0; if (nf > r) nf = r;
             return nf * first + (r - nf) * second;
         };
-        const long lx = max((long)ox[mn] + adv(flstep, slstep, oy[lm]), 0L), rx = min((long)ox[mn] + adv(frstep, srstep, oy[rm]), (long)F.w - 1);
-        for (long x = lx; x <= rx; ++x) {
-            ++total_pts;
-            const float ad = F.deg[(int)(y * F.w + x)];
-            if (ad == rgs::NOTDEF_F) continue;
-            const double a = double(ad) * rg::DEG_TO_RADS;
-            const double d = fabs(rec.theta - a), d2 = fabs(d - rg::M_2__PI_), nt = d > rg::M_3_2_PI_ ? d2 : d; // isAligned :1138-1154
-            for (int k = 0; k < NP; k++) alg_pts[k] += nt <= precs[k];
+        const long lxl = max((long)mnX + adv(flstep, slstep, lmY), 0L), rxl = min((long)mnX + adv(frstep, srstep, rmY), (long)w - 1);
+        lx = (int)lxl; rx = (int)rxl; // both inside [0, w) when the row is not empty
+        return rxl >= lxl;
+    }
+};
+// the pixels [lx + g, rx] of a row in steps of G against the tolerances precs[0 .. NP): four requested before the first is tested
+template <int NP> __device__ __forceinline__ void rg_row_count(const float *row, int lx, int rx, int g, int G, double theta, const double *precs, int *alg_pts) {
+    for (int x = lx + g; x <= rx; x += 4 * G) {
+        float ad[4];
+#pragma unroll
+        for (int u = 0; u < 4; u++) { const int xx = x + u * G; ad[u] = row[xx <= rx ? xx : rx]; } // (a valid address either way; a value past the end is not counted)
+#pragma unroll
+        for (int u = 0; u < 4; u++) {
+            const bool in = x + u * G <= rx && ad[u] != rgs::NOTDEF_F;
+            const double a = double(ad[u]) * rg::DEG_TO_RADS;
+            const double d = fabs(theta - a), d2 = fabs(d - rg::M_2__PI_), nt = d > rg::M_3_2_PI_ ? d2 : d; // isAligned :1138-1154
+            for (int k = 0; k < NP; k++) alg_pts[k] += in && nt <= precs[k];
         }
+    }
+}
+// The pixel walk of rect_nfa (:977-1098).  total = pixels of the rectangle inside the image; algs[k] = those aligned with rec.theta within precs[k] (several
+// tolerances share a walk: rect_improve's first and last loop only halve the tolerance of an unchanged rectangle).  Every lane gets the sums.  The counts are
+// integers, so the pixels may be visited in any order: G = 64 / rows lanes share a row (the rectangles that reach this stage hold 28 pixels in 7 rows on average).
+template <int NP> __device__ void rg_rect_count(const AngMap &F, const rg::Rect &rec, const double *precs, int lane, int &total, int *algs) {
+    RGI_T0;
+    RectSpan S; S.set(rec, F.h);
+    int total_pts = 0, alg_pts[NP];
+    for (int k = 0; k < NP; k++) alg_pts[k] = 0;
+    const int rows = S.y_hi - S.y_first + 1;
+    const int G = (rows > 0 && rows < 64) ? 64 / rows : 1, RB = 64 / G; // lanes per row, rows per pass (64 % G lanes idle)
+    const int lrow = lane / G, g = lane - lrow * G;
+    for (int yb = S.y_first; yb <= S.y_hi; yb += RB) {
+        const int y = yb + lrow;
+        int lx, rx;
+        if (y > S.y_hi || lrow >= RB || !S.row(y, F.w, lx, rx)) continue;
+        if (g == 0) total_pts += rx - lx + 1;
+        rg_row_count<NP>(F.deg + (size_t)y * F.w, lx, rx, g, G, rec.theta, precs, alg_pts);
     }
     for (int off = 32; off > 0; off >>= 1) {
         total_pts += __shfl_xor(total_pts, off);
@@ -142,6 +170,27 @@ template <int NP> __device__ void rg_rect_count(const AngMap &F, const rg::Rect 
     }
     total = total_pts;
     for (int k = 0; k < NP; k++) algs[k] = alg_pts[k];
+    RGI_T1(0);
+}
+// The walks of up to five rectangles at once (rect_improve's loops try five variants of a rectangle that do not depend on each other): eight lanes per rectangle,
+// lane s of them takes the rows y_first + s, y_first + s + 8, ...  One preamble, one round trip and one (three-step) reduction instead of five of each -- with 28
+// pixels per rectangle a walk is all fixed cost.  rs: this lane's copy of the variants (every lane holds the same five).
+__device__ void rg_rect_count_five(const AngMap &F, const rg::Rect *rs, int cnt, int lane, int *tot, int *alg) {
+    RGI_T0;
+    const int grp = lane >> 3, sub = lane & 7;
+    const bool on = grp < cnt;
+    const rg::Rect rec = rs[on ? grp : 0];
+    RectSpan S; S.set(rec, F.h);
+    int total_pts = 0, alg_pts[1] = {0};
+    if (on)
+        for (int y = S.y_first + sub; y <= S.y_hi; y += 8) {
+            int lx, rx;
+            if (!S.row(y, F.w, lx, rx)) continue;
+            total_pts += rx - lx + 1;
+            rg_row_count<1>(F.deg + (size_t)y * F.w, lx, rx, 0, 1, rec.theta, &rec.prec, alg_pts);
+        }
+    for (int off = 1; off < 8; off <<= 1) { total_pts += __shfl_xor(total_pts, off); alg_pts[0] += __shfl_xor(alg_pts[0], off); }
+    for (int n = 0; n < 5; n++) { tot[n] = __shfl(total_pts, 8 * n); alg[n] = __shfl(alg_pts[0], 8 * n); }
     RGI_T1(0);
 }
 // nfa() of up to five (n, k, p) triples at once: lane v computes triple v -- the loops inside nfa are sequential, the triples independent
@@ -173,7 +222,7 @@ __device__ double rg_rect_improve(const AngMap &F, rg::Rect &rec, double LOG_NT,
         RGI_T1(1);
         for (int n = 0; n < cnt; ++n) if (v[n] > log_nfa) { log_nfa = v[n]; rec = rs[n]; }
     };
-    auto walks = [&]() { for (int n = 0; n < cnt; ++n) { rg_rect_count<1>(F, rs[n], &rs[n].prec, lane, tot[n], &alg[n]); ps[n] = rs[n].p; } };
+    auto walks = [&]() { if (cnt) rg_rect_count_five(F, rs, cnt, lane, tot, alg); for (int n = 0; n < cnt; ++n) ps[n] = rs[n].p; };
     tolerances(); take_best();
     if (log_nfa > LOG_EPS) return log_nfa;
     rg::Rect r = rec;
