@@ -10,8 +10,9 @@
 //     whatever the batch -- the chain of dependent instructions per accepted pixel, not memory -- so thousands of frames have to be
 //     resident: sixteen waves (frames) per workgroup fill a CU and leave the other CUs empty for the kernels of the other streams.
 //     Output: the rectangles that reach rect_improve (after refine / reduce_region_radius), per frame in seed order.
-//   * lsd_rg_improve: one wave per rectangle: rect_improve / rect_nfa with the rectangle's rows spread over the lanes (the row limits advance
-//     by integer steps, lsd.cpp:1057-1095, so they have a closed form), nfa on every lane with log_gamma of the pixel counts from a table.
+//   * lsd_rg_improve: eight rectangles per wave for rect_improve's first rect_nfa (two thirds are accepted there), the others improved one at a time by
+//     the whole wave; the rows of a rectangle spread over lanes (the row limits advance by integer steps, lsd.cpp:1057-1095, so they have a closed form),
+//     the five variants of a rect_improve loop walked and their nfa() evaluated side by side, log_gamma of the pixel counts from a table.
 //   * the segments leave in the reference's emission order (frames in order, seeds in order).
 //
 // tools/lsd_sim/seq_sim.cpp compiles lsd_rg_seq.h for the host (the lanes as loops) and demands the oracle's sequential result: the same
@@ -202,10 +203,9 @@ __device__ void rg_nfa5(const int *n, const int *k, const double *p, int cnt, do
 }
 // rect_improve lsd.cpp:873-975.  The five variants of each of its loops do not depend on each other's result (only the best is remembered), so
 // their pixel walks run one after the other -- or as one walk where only the tolerance changes -- and their five nfa() side by side in five lanes.
-__device__ double rg_rect_improve(const AngMap &F, rg::Rect &rec, double LOG_NT, int lane, const double *lgt) {
+// log_nfa: rect_nfa of the rectangle as it comes (the kernel computes it for eight rectangles at once).
+__device__ double rg_rect_improve(const AngMap &F, rg::Rect &rec, double LOG_NT, int lane, const double *lgt, double log_nfa) {
     const double delta = 0.5, delta_2 = delta / 2.0;
-    double log_nfa;
-    { int tot, alg; rg_rect_count<1>(F, rec, &rec.prec, lane, tot, &alg); RGI_T0; log_nfa = rg_nfa(tot, alg, rec.p, LOG_NT, lgt); RGI_T1(1); }
     if (log_nfa > LOG_EPS) return log_nfa;
     rg::Rect rs[5];
     int tot[5], alg[5], cnt; double ps[5], v[5];
@@ -342,19 +342,19 @@ __global__ void __launch_bounds__(1024) lsd_rg_cand_scan(const int *cand_cnt, in
     if (t == 1023) cand_base[F] = part[1023];
 }
 // rect_improve + the NFA test (lsd.cpp:873-975, :503-505) of one rectangle per wave; line[k] / has[k] in the order of the scan above
+// Eight rectangles per wave.  rect_improve starts with rect_nfa of the rectangle as it is, and two thirds of the rectangles are accepted there: that first walk (28
+// pixels in 7 rows on average) and its nfa() run for eight rectangles at once, eight lanes each -- every lane of a group evaluates its rectangle's nfa(), which costs
+// the wave what one evaluation costs.  The rectangles that go on are then improved one after the other by the whole wave.
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RG_IMPROVE_WAVES, RG_IMPROVE_WAVES))) lsd_rg_improve(SeqParams P, const int *cand_base, int n_cand, const double *lgt, float4 *line, uint8_t *has) {
-    const int wv = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (wv >= n_cand) return;
-    int lo = 0, hi = P.F; // the frame: cand_base[f] <= wv < cand_base[f + 1]
-    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (cand_base[mid] <= wv) lo = mid; else hi = mid; }
-    const int f = lo;
-    const double *o = P.rect + (size_t)f * P.rect_stride + (size_t)(wv - cand_base[f]) * 12;
-    rg::Rect rec;
-    rec.x1 = o[0]; rec.y1 = o[1]; rec.x2 = o[2]; rec.y2 = o[3]; rec.width = o[4]; rec.x = o[5]; rec.y = o[6]; rec.theta = o[7]; rec.dx = o[8]; rec.dy = o[9]; rec.prec = o[10]; rec.p = o[11];
-    const AngMap Fr = {P.w, P.h, P.ang + (size_t)f * P.w * P.h};
+    const int base = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 8, lane = threadIdx.x & 63, grp = lane >> 3, sub = lane & 7;
+    if (base >= n_cand) return;
     const double LOG_NT = 5 * (log10(double(P.w)) + log10(double(P.h))) / 2 + log10(11.0);
-    const double log_nfa = rg_rect_improve(Fr, rec, LOG_NT, lane, lgt);
-    if (lane == 0) {
+    auto frame_of = [&](int wv) { int lo = 0, hi = P.F; while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (cand_base[mid] <= wv) lo = mid; else hi = mid; } return lo; }; // cand_base[f] <= wv < cand_base[f + 1]
+    auto load_rect = [&](int wv, int f, rg::Rect &rec) {
+        const double *o = P.rect + (size_t)f * P.rect_stride + (size_t)(wv - cand_base[f]) * 12;
+        rec.x1 = o[0]; rec.y1 = o[1]; rec.x2 = o[2]; rec.y2 = o[3]; rec.width = o[4]; rec.x = o[5]; rec.y = o[6]; rec.theta = o[7]; rec.dx = o[8]; rec.dy = o[9]; rec.prec = o[10]; rec.p = o[11];
+    };
+    auto emit = [&](int wv, rg::Rect rec, double log_nfa) {
         const bool ok = log_nfa > LOG_EPS;
         if (ok) {
             rec.x1 += 0.5; rec.y1 += 0.5; rec.x2 += 0.5; rec.y2 += 0.5;
@@ -362,6 +362,43 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RG_IMP
             line[wv] = make_float4(float(rec.x1), float(rec.y1), float(rec.x2), float(rec.y2));
         }
         has[wv] = ok ? 1 : 0;
+    };
+    // ---- rect_nfa of eight rectangles
+    const int mine = base + grp;
+    const bool on = mine < n_cand;
+    const int f1 = frame_of(on ? mine : n_cand - 1);
+    rg::Rect r1;
+    load_rect(on ? mine : n_cand - 1, f1, r1);
+    double log1;
+    {
+        RGI_T0;
+        RectSpan S; S.set(r1, P.h);
+        const float *deg = P.ang + (size_t)f1 * P.w * P.h;
+        int tot = 0, alg[1] = {0};
+        if (on)
+            for (int y = S.y_first + sub; y <= S.y_hi; y += 8) {
+                int lx, rx;
+                if (!S.row(y, P.w, lx, rx)) continue;
+                tot += rx - lx + 1;
+                rg_row_count<1>(deg + (size_t)y * P.w, lx, rx, 0, 1, r1.theta, &r1.prec, alg);
+            }
+        for (int off = 1; off < 8; off <<= 1) { tot += __shfl_xor(tot, off); alg[0] += __shfl_xor(alg[0], off); }
+        RGI_T1(0);
+        { RGI_T0; log1 = rg_nfa(tot, alg[0], r1.p, LOG_NT, lgt); RGI_T1(1); }
+    }
+    if (on && sub == 0 && log1 > LOG_EPS) emit(mine, r1, log1);
+    // ---- the others, one at a time
+    unsigned long long todo = __ballot(on && sub == 0 && !(log1 > LOG_EPS));
+    while (todo) {
+        const int l = __ffsll((long long)todo) - 1;
+        todo &= todo - 1;
+        const int wv = base + (l >> 3), f = __shfl(f1, l);
+        const double first = __shfl(log1, l);
+        rg::Rect rec;
+        load_rect(wv, f, rec);
+        const AngMap Fr = {P.w, P.h, P.ang + (size_t)f * P.w * P.h};
+        const double log_nfa = rg_rect_improve(Fr, rec, LOG_NT, lane, lgt, first);
+        if (lane == 0) emit(wv, rec, log_nfa);
     }
 }
 } // namespace
@@ -543,7 +580,7 @@ int lsd_seq_run(cs_ctx *ctx, LsdSeq **handle, int F, int w, int h, const float *
         RA_(cs_dalloc(ctx, &r->d_line, cap)); RA_(cs_dalloc(ctx, &r->d_has, cap));
         r->cap_lines = cap;
     }
-    CS_LAUNCH(ctx, "lsd_rg_improve", lsd_rg_improve, dim3((n_cand + 3) / 4), dim3(256), 0, S, r->d_cand_base, n_cand, r->d_lgt, r->d_line, r->d_has);
+    CS_LAUNCH(ctx, "lsd_rg_improve", lsd_rg_improve, dim3((n_cand + 31) / 32), dim3(256), 0, S, r->d_cand_base, n_cand, r->d_lgt, r->d_line, r->d_has); // eight rectangles per wave
 #if defined(RGI_PROF)
     { unsigned long long h[4]; hipDeviceSynchronize(); hipMemcpyFromSymbol(h, HIP_SYMBOL(g_rgi_prof), sizeof h); unsigned long long z[4] = {0, 0, 0, 0}; hipMemcpyToSymbol(HIP_SYMBOL(g_rgi_prof), z, sizeof z);
       fprintf(stderr, "[rgi prof] %d rectangles: walks %.0f calls %.2f us each = %.1f us per rectangle; nfa %.0f calls %.2f us each = %.1f us per rectangle\n", n_cand, (double)h[2], h[2] ? h[0] / 100.0 / h[2] : 0.0,
