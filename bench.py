@@ -21,6 +21,11 @@ import subprocess
 import sys
 import time
 
+# The runner keeps up to ten HIP streams busy (the caller's, four line workers' and their background streams for the region walk); the HIP runtime maps streams onto
+# GPU_MAX_HW_QUEUES hardware queues (default 4) and serialises the streams that share one -- a 100 ms region walk then blocks another stream's kernels.  Must be set
+# before the runtime initialises.
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 import numpy as np
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -577,7 +582,7 @@ def main():
         # detectors queue their map kernels beside ORB / cuboid of four steps, then the four region stages run together with the ORB / cuboid
         # stream idle) keeps the score kernel away from the walks and is timed beside it (`phased_runner`).  Below 512 frames the 16 host
         # threads grow the regions and the GPU phases of one step overlap the host stage of the neighbouring one.
-        ctx_lines = [_lib.Context(local_rank, priority=int(os.environ.get("BENCH_PRIO_LINES", "-1"))) for _ in range(max(1, min(8, args.line_workers)))]  # device phases of the line detectors: background
+        ctx_lines = [_lib.Context(local_rank, priority=int(os.environ.get("BENCH_PRIO_LINES", "1"))) for _ in range(max(1, min(8, args.line_workers)))]  # the line detectors' short kernels at the caller's priority; their region walks go to the contexts' lowest-priority background streams (cs_ctx::bg_begin)
         lsds = [line_lbd_detect(640, 480, max_frames=args.frames, ctx=c) for c in ctx_lines]
         for d_ in lsds:
             d_.upload(np.stack([s["gray"] for s in scenes]))

@@ -83,6 +83,26 @@ struct cs_ctx {
         if (!timing) return;
         hipEventRecord(pending.back().b, stream);
     }
+    // A second, lowest-priority stream of this context for ONE kind of launch: a kernel that holds its wave slots for ~100 ms and paces itself (the LSD region
+    // walk).  Everything else of the context then runs at the context's own priority beside it, ordered against it by two events.
+    hipStream_t bg_stream = nullptr; hipEvent_t bg_in = nullptr, bg_out = nullptr;
+    hipError_t bg_begin() { // work queued on `stream` so far precedes what is queued on bg_stream from here on
+        hipError_t e = hipSuccess;
+        if (!bg_stream) {
+            int lo = 0, hi = 0;
+            if (hipDeviceGetStreamPriorityRange(&lo, &hi) == hipSuccess && lo != hi) e = hipStreamCreateWithPriority(&bg_stream, hipStreamNonBlocking, lo);
+            else e = hipStreamCreateWithFlags(&bg_stream, hipStreamNonBlocking);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&bg_in, hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&bg_out, hipEventDisableTiming);
+            if (e != hipSuccess) return e;
+        }
+        e = hipEventRecord(bg_in, stream);
+        return e == hipSuccess ? hipStreamWaitEvent(bg_stream, bg_in, 0) : e;
+    }
+    hipError_t bg_end() { // ... and `stream` goes on behind it
+        const hipError_t e = hipEventRecord(bg_out, bg_stream);
+        return e == hipSuccess ? hipStreamWaitEvent(stream, bg_out, 0) : e;
+    }
     void flush() {
         if (pending.empty()) return;
         hipStreamSynchronize(stream);

@@ -142,6 +142,7 @@ void cs_destroy(cs_ctx *ctx) {
     cs_comm_destroy(ctx);
     for (auto e : ctx->pool) hipEventDestroy(e);
     ctx->pool_drop();
+    if (ctx->bg_stream) { hipStreamSynchronize(ctx->bg_stream); hipStreamDestroy(ctx->bg_stream); hipEventDestroy(ctx->bg_in); hipEventDestroy(ctx->bg_out); }
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -595,6 +595,7 @@ struct cs_lsd {
     bool have_desc = false;
     LsdSeq *seq = nullptr;           // device buffers of the region stage (lsd_regions.hip)
     int seq_wpb = 16; // frames per workgroup of the device region stage (cs_lsd_set_shared_gpu)
+    bool walk_bg = false; // the region walk on the context's background stream (cs_lsd_set_shared_gpu; CUBESLAM_LSD_WALK_BG=0 keeps it on the context's own)
     void (*gate_wait)(void *) = nullptr; void (*gate_done)(void *) = nullptr; void *gate_arg = nullptr; // the front-end runner's phase gate around the region stage (frontend.hip)
     long rg_stats[5] = {0, 0, 0, 0, 0}; // last batch: 1 = device stage asked for, region_grow calls, rectangles at rect_improve, 1 = fell back to the host stage, window fetches
 };
@@ -698,7 +699,7 @@ static int lsd_run(cs_ctx *ctx, cs_lsd *l, int with_lbd) {
         long st[4] = {0, 0, 0, 0};
         l->scaled_kept = false; // the arena is the region stage's from here on
         r = lsd_seq_run(ctx, &l->seq, F, w, h, l->d_ang, l->d_mod, l->d_caddr, l->d_cdeg, l->d_ccs, l->frame_base.data(), dev_lines, st, l->gate_wait, l->gate_done, l->gate_arg, grp_p, l->seq_wpb,
-                        l->d_tmp, l->pix_bytes, pix_by_emit);
+                        l->d_tmp, l->pix_bytes, pix_by_emit, l->walk_bg);
         tp[2] = now_ms();
         l->rg_stats[0] = 1; l->rg_stats[1] = st[0]; l->rg_stats[2] = st[2]; l->rg_stats[3] = r == CS_OK ? 0 : 1; l->rg_stats[4] = st[1];
         if (r == CS_OK) on_device = true;
@@ -968,4 +969,7 @@ int cs_lsd_filter_lines_packed(cs_lsd *l, float length_thres, std::vector<int> &
 // internal (frontend.hip): the runner's phase gate around the region stage; wait() is called before it, done() once lsd_rg_seq has left the GPU
 void cs_lsd_set_gate(cs_lsd *l, void (*wait)(void *), void (*done)(void *), void *arg) { l->gate_wait = wait; l->gate_done = done; l->gate_arg = arg; }
 // shared: other detectors' walks and the other streams' kernels keep every CU busy anyway (the alternating front-end runner): the region stage spreads over the chip
-void cs_lsd_set_shared_gpu(cs_lsd *l, int shared) { l->seq_wpb = shared ? 4 : 16; }
+void cs_lsd_set_shared_gpu(cs_lsd *l, int shared) {
+    l->seq_wpb = shared ? 4 : 16;
+    l->walk_bg = shared && !(getenv("CUBESLAM_LSD_WALK_BG") && atoi(getenv("CUBESLAM_LSD_WALK_BG")) == 0);
+}

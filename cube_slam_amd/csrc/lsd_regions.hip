@@ -429,7 +429,9 @@ int lsd_seq_run(cs_ctx *ctx, LsdSeq **handle, int F, int w, int h, const float *
                 int waves_per_workgroup /* frames per workgroup of lsd_rg_seq: 16 packs a batch onto F / 16 CUs and leaves the others empty; 4 spreads it over the chip (the alternating runner, where
                                            every CU is busy anyway: 128 -> 104 ms per launch there) */,
                 void *scratch, size_t scratch_bytes /* memory the caller has no use for while the stage runs: lsd_rg_seq's pixel records go there when it is large enough */,
-                bool pix_ready /* lsd_emit<true> already left the pixel records at the head of `scratch` and the seeds' cos / sin in d_ccs: no fill, no scatter */) {
+                bool pix_ready /* lsd_emit<true> already left the pixel records at the head of `scratch` and the seeds' cos / sin in d_ccs: no fill, no scatter */,
+                bool walk_bg /* lsd_rg_seq on the context's lowest-priority background stream (cs_ctx::bg_begin): the walk paces itself (it takes its ~100 ms whatever runs beside it),
+                                so the context's own stream can have the priority of the short kernels in front of it and behind it */) {
     LsdSeq *r = *handle;
     if (w > 0xffff || h > 0x7fff) return CS_ERR_CAPACITY; // (the region list packs x | y << 16)
     int max_ne = 0;
@@ -550,6 +552,13 @@ int lsd_seq_run(cs_ctx *ctx, LsdSeq **handle, int F, int w, int h, const float *
                 else CS_LAUNCH(ctx, "lsd_rg_grp", (lsd_rg_grp<2, 1024>), dim3(groups), dim3(64 * wpg), 0, L);
             }
         }
+    } else if (walk_bg) {
+        CS_HIP(ctx, ctx->bg_begin());
+        cs_ctx::pending_ev pe;
+        if (ctx->timing) { pe.name = "lsd_rg_seq"; pe.a = ctx->get_event(); pe.b = ctx->get_event(); hipEventRecord(pe.a, ctx->bg_stream); }
+        hipLaunchKernelGGL(lsd_rg_seq, dim3((F + wpb - 1) / wpb), dim3(64 * wpb), 0, ctx->bg_stream, S);
+        if (ctx->timing) { hipEventRecord(pe.b, ctx->bg_stream); ctx->pending.push_back(pe); }
+        CS_HIP(ctx, ctx->bg_end());
     } else
     CS_LAUNCH(ctx, "lsd_rg_seq", lsd_rg_seq, dim3((F + wpb - 1) / wpb), dim3(64 * wpb), 0, S);
     CS_LAUNCH(ctx, "lsd_rg_cand_scan", lsd_rg_cand_scan, dim3(1), dim3(1024), 0, r->d_cand_cnt, F, r->d_cand_base);
