@@ -444,7 +444,10 @@ int cs_pose_optimization(cs_ctx *ctx, int n_frames, const int *edge_off, const d
  * what Tracking / main_obj.cpp call per frame, object_slam/src/main_obj.cpp:395-470) over a batch that is resident in HBM.  Handles
  * are borrowed: orb / batch run on `ctx` in the calling thread, every line detector on its own context in a worker thread; with two
  * detectors (both holding the same frames) consecutive passes alternate between them, so the host stage of LSD overlaps GPU work.
- * cs_frontend_step returns when ORB and the cuboid batch of this pass are done; cs_frontend_drain waits for the line passes. */
+ * cs_frontend_step returns when ORB and the cuboid batch of this pass are done; cs_frontend_drain waits for the line passes.
+ * Streams: the caller's, one per line detector and, for batches whose region stage runs on the device, one lowest-priority background stream per detector for
+ * that stage's one long kernel.  The HIP runtime serialises streams that share a hardware queue and creates four by default: export GPU_MAX_HW_QUEUES=16 (or
+ * more) before the runtime starts in a process that uses the runner. */
 typedef struct cs_frontend cs_frontend;
 int cs_frontend_create(cs_ctx *ctx, cs_orb *orb /* nullable */, cs_cuboid_batch *batch /* nullable */, int n_line_workers, cs_ctx *const *line_ctx,
                        cs_lsd *const *lsd, cs_frontend **out);
