@@ -160,24 +160,34 @@ __global__ void __launch_bounds__(256) orb_fast_score(Pyr P, const uint8_t *pyr,
     __syncthreads();
     // pass 1: the compass test on every pixel; the few that pass are appended to the workgroup's list, so that the min/max network
     // below runs with full waves instead of once per wave that holds a single candidate
-    const int lx = threadIdx.x & 63;
-    for (int ly = threadIdx.x >> 6; ly < TH; ly += 4) {
-        const int x = tx0 + lx, y = ty0 + ly;
-        bool cand = false;
-        if (x >= 3 && y >= 3 && x < L.w - 3 && y < L.h - 3) {
-            const int v = g[ly + 3][lx + 3];
-            const int d0 = v - (int)g[ly + 6][lx + 3], d4 = v - (int)g[ly + 3][lx + 6], d8 = v - (int)g[ly][lx + 3], d12 = v - (int)g[ly + 3][lx];
-            const bool k0 = d0 > tq, k4 = d4 > tq, k8 = d8 > tq, k12 = d12 > tq, b0 = d0 < -tq, b4 = d4 < -tq, b8 = d8 < -tq, b12 = d12 < -tq;
-            cand = (k0 && k4) || (k4 && k8) || (k8 && k12) || (k12 && k0) || (b0 && b4) || (b4 && b8) || (b8 && b12) || (b12 && b0);
-        }
+    const int lx = threadIdx.x & 63, wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); // (the row of a wave is uniform: its address arithmetic is the scalar unit's)
+    static_assert(TH == 16, "four rows per wave");
+    unsigned long long cm[4];
+    const int x = tx0 + lx;
+    const unsigned long long lt = (1ull << lx) - 1;
+#pragma unroll
+    for (int r = 0; r < 4; r++) {
+        const int ly = wv + 4 * r, y = ty0 + ly;
+        // Two neighbouring compass points both darker than v - tq  <=>  the largest of the four neighbouring pairs' minima of (v - p) exceeds tq; both brighter: the smallest
+        // of the pairs' maxima is below -tq.  Written as min / max on purpose: the boolean form compiled to five branches and twenty-five mask operations per row.
+        const int v = g[ly + 3][lx + 3];
+        const int d0 = v - (int)g[ly + 6][lx + 3], d4 = v - (int)g[ly + 3][lx + 6], d8 = v - (int)g[ly][lx + 3], d12 = v - (int)g[ly + 3][lx];
+        const int dark = max(max(min(d0, d4), min(d4, d8)), max(min(d8, d12), min(d12, d0)));
+        const int bright = min(min(max(d0, d4), max(d4, d8)), min(max(d8, d12), max(d12, d0)));
+        const bool inb = (unsigned)(x - 3) < (unsigned)(L.w - 6) & (unsigned)(y - 3) < (unsigned)(L.h - 6); // (levels are wider and higher than 6)
+        const bool cand = inb & ((dark > tq) | (bright < -tq));
         if (!cand && x < L.w && y < L.h) smap[(long)blockIdx.z * P.frame_stride + L.off + (long)y * L.w + x] = 0; // every pixel of the map is written here or below: no fill pass in front of the launch
-        const unsigned long long m = __ballot(cand);
-        if (m) {
-            int base = 0;
-            if (lx == 0) base = atomicAdd(&s_n, __popcll(m));
-            base = __shfl(base, 0);
-            if (cand) s_list[base + __popcll(m & ((1ull << lx) - 1))] = (unsigned short)(ly << 8 | lx);
-        }
+        cm[r] = __ballot(cand);
+    }
+    const int c0 = __popcll(cm[0]), c1 = __popcll(cm[1]), c2 = __popcll(cm[2]), c3 = __popcll(cm[3]);
+    if (c0 + c1 + c2 + c3) { // one slot request per wave for its four rows
+        int base = 0;
+        if (lx == 0) base = atomicAdd(&s_n, c0 + c1 + c2 + c3);
+        base = __builtin_amdgcn_readfirstlane(base);
+        const int off[4] = {base, base + c0, base + c0 + c1, base + c0 + c1 + c2};
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+            if ((cm[r] >> lx) & 1ull) s_list[off[r] + __popcll(cm[r] & lt)] = (unsigned short)((wv + 4 * r) << 8 | lx);
     }
     __syncthreads();
     const int n = s_n;
