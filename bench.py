@@ -713,7 +713,13 @@ def main():
         extra["c4"] = c4_bench(ctx, 64, 8, args.yaw_step, 10, with_cpu=not args.no_cpu, with_traffic=True)
         if lsd is not None:
             extra["chained"] = chained_bench(ctx, fe, lsds, batch, scenes, args.frames, args.steps, barrier, backlog=bool(args.backlog))
-        extra["pcie_inclusive"] = pcie_inclusive(ctx, scenes, args.yaw_step, args.orb_features, local_rank=local_rank)
+        # the drop-in calls belong to another kind of process than the batch runner: measured in one, with the runtime's default hardware queues (tools/pcie_probe.py)
+        try:
+            pr = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pcie_probe.py"), "default", str(args.yaw_step), str(args.orb_features)], capture_output=True, text=True, timeout=300, check=True)
+            extra["pcie_inclusive"] = json.loads(pr.stdout.strip().splitlines()[-1])
+        except Exception:
+            extra["pcie_inclusive"] = pcie_inclusive(ctx, scenes, args.yaw_step, args.orb_features, local_rank=local_rank)
+            extra["pcie_inclusive"]["hw_queues"] = os.environ.get("GPU_MAX_HW_QUEUES", "runtime default (4)") + " (in this process)"
     else:
         tr = None
     ba_out = None
