@@ -247,7 +247,10 @@ void local_window_ba(KeyFrame *pKF, bool *pbStopFlag, Map *pMap, bool fixCamera,
     for (int u : res.up_used) lLocalMapObjects[w.up_mo[u]]->used_points_in_BA.push_back(up_point[u]);                     // :1164, read by Tracking.cc:2012 / MapDrawer.cc:146
     for (int u : res.up_filtered) lLocalMapObjects[w.up_mo[u]]->used_points_in_BA_filtered.push_back(up_point[u]);       // :1209
     // ---- erase, write back :1477-1533
-    if (parallel_mapping) std::unique_lock<std::mutex> lock(pMap->mMutexMapUpdate);
+    // (the reference writes `if (parallel_mapping) unique_lock<mutex> lock(...)`, Optimizer.cc:1478 / :2447: the lock is the body of the if and is gone before the
+    //  write-back starts -- a slip that races Tracking when parallel_mapping is on.  The adapter holds the map mutex over the write-back, which is what the line means.)
+    std::unique_lock<std::mutex> lock(pMap->mMutexMapUpdate, std::defer_lock);
+    if (parallel_mapping) lock.lock();
     for (auto &e : res.erase) { KeyFrame *pKFi = kfs[e.first]; MapPoint *pMPi = lLocalMapPoints[e.second]; pKFi->EraseMapPointMatch(pMPi); pMPi->EraseObservation(pKFi); }
     for (size_t i = 0; i < lLocalKeyFrames.size(); i++) { lLocalKeyFrames[i]->mnBALocalForKF = 0; lLocalKeyFrames[i]->SetPose(vec7_to_pose(&res.kf_pose[i * 7])); }
     for (MapPoint *pMP : lLocalMapPoints) pMP->mnBALocalForKF = 0;
@@ -389,7 +392,10 @@ void Optimizer::LocalBACameraPointObjectsDynamic(KeyFrame *pKF, bool *pbStopFlag
     if (!res.solved) return;                                                                                           // :2344-2346: stopped before the first optimize -- the marks stay, like there
 
     // ---- erase, write back :2446-2572
-    if (parallel_mapping) std::unique_lock<std::mutex> lock(pMap->mMutexMapUpdate);
+    // (the reference writes `if (parallel_mapping) unique_lock<mutex> lock(...)`, Optimizer.cc:1478 / :2447: the lock is the body of the if and is gone before the
+    //  write-back starts -- a slip that races Tracking when parallel_mapping is on.  The adapter holds the map mutex over the write-back, which is what the line means.)
+    std::unique_lock<std::mutex> lock(pMap->mMutexMapUpdate, std::defer_lock);
+    if (parallel_mapping) lock.lock();
     for (auto &e : res.erase) { KeyFrame *pKFi = kfs[e.first]; MapPoint *pMPi = lLocalMapPoints[e.second]; pKFi->EraseMapPointMatch(pMPi); pMPi->EraseObservation(pKFi); }
     for (size_t i = 0; i < lLocalKeyFrames.size(); i++) { lLocalKeyFrames[i]->mnBALocalForKF = 0; lLocalKeyFrames[i]->SetPose(vec7_to_pose(&res.kf_pose[i * 7])); }
     for (MapPoint *pMP : lLocalMapPoints) pMP->mnBALocalForKF = 0;

@@ -631,7 +631,7 @@ def main():
         elapsed = float(t.item())
     kernels = {}
     for name in ("host_orb_quadtree", "orb_resize", "orb_fast_score", "orb_cells", "orb_scan", "orb_quadtree", "orb_blur", "orb_angle", "orb_desc", "host_lsd_regions", "lsd_blur_hv", "lsd_resize",
-                 "lsd_gradient", "lsd_emit", "lsd_rg_fill", "lsd_rg_scatter", "lsd_rg_seq", "lsd_rg_grp", "lsd_rg_improve", "lbd_blur5", "lbd_sobel", "lbd_line_desc", "cuboid_frame_prep", "cuboid_unit_lines", "cuboid_canny_nms", "cuboid_canny_cc_local", "cuboid_canny_cc_border", "cuboid_canny_cc", "cuboid_dt",
+                 "lsd_gradient", "lsd_emit", "lsd_rg_fill", "lsd_rg_scatter", "lsd_rg_seq", "lsd_rg_wlk", "lsd_rg_improve", "lbd_blur5", "lbd_sobel", "lbd_line_desc", "cuboid_frame_prep", "cuboid_unit_lines", "cuboid_canny_nms", "cuboid_canny_cc_local", "cuboid_canny_cc_border", "cuboid_canny_cc", "cuboid_dt",
                  "cuboid_vp", "cuboid_sweep_filter", "cuboid_sweep_score", "cuboid_select"):
         ms, n = ctx.timing_get(name)
         if n == 0 and side_ctxs:

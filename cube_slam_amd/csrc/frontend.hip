@@ -32,6 +32,7 @@ extern "C" int cs_orb_run(cs_ctx *ctx, cs_orb *e);
 extern "C" int cs_cuboid_batch_run(cs_ctx *ctx, cs_cuboid_batch *b);
 extern "C" int cs_cuboid_batch_set_shared_gpu(cs_cuboid_batch *b, int shared);
 extern "C" int cs_cuboid_batch_set_lines(cs_ctx *ctx, cs_cuboid_batch *b, const int *line_offsets, const double *lines);
+extern "C" int cs_cuboid_batch_n_frames(const cs_cuboid_batch *b);
 int cs_lsd_filter_lines_packed(cs_lsd *l, float length_thres, std::vector<int> &offsets, std::vector<double> &lines); // lsd.hip
 
 struct cs_frontend;
@@ -86,9 +87,11 @@ struct LineWorker {
         }
     }
     bool is_free() { std::lock_guard<std::mutex> lk(m); return !busy; }
-    void submit() {
+    void submit(long no) { // `no`: the number of the pass; taken over only when the pass before has left the worker (a phased worker still runs rectangles / LBD of pass k - W when
+                           // step k hands over the next one: after_pass of that earlier pass must file ITS packet under ITS number)
         std::unique_lock<std::mutex> lk(m);
         cv.wait(lk, [&] { return !busy; });
+        pass_no = no;
         {
             std::lock_guard<std::mutex> gl(gate->m);
             if (gate->phased) { ticket = ++gate->submitted; marked = false; } else marked = true;
@@ -136,8 +139,7 @@ struct cs_frontend {
         for (size_t k = 0; k < workers.size() && may_start(); k++) {
             const size_t c = (next_worker + k) % workers.size();
             if (!workers[c]->is_free()) continue;
-            workers[c]->pass_no = passes_started++;
-            workers[c]->submit();
+            workers[c]->submit(passes_started++);
             next_worker = (c + 1) % workers.size();
         }
     }
@@ -191,7 +193,7 @@ int cs_frontend_step(cs_frontend *fe) {
             const long k = fe->step_no;
             if (fe->passes_target < k + 1) fe->passes_target = k + 1;
             if (fe->gate.phased) { // one pass per detector and super-step, in rotation (the gate counts them)
-                if (fe->passes_started <= k) { LineWorker *w = fe->workers[(size_t)(k % W)]; w->pass_no = fe->passes_started++; lk.unlock(); w->submit(); lk.lock(); fe->in_phase++; }
+                if (fe->passes_started <= k) { LineWorker *w = fe->workers[(size_t)(k % W)]; const long no = fe->passes_started++; lk.unlock(); w->submit(no); lk.lock(); fe->in_phase++; }
             } else {
                 fe->kick_idle();
                 while (fe->passes_started <= k) { fe->any_cv.wait_for(lk, std::chrono::milliseconds(2)); fe->kick_idle(); } // pass k has been started: the line path is at most W passes behind
@@ -204,6 +206,7 @@ int cs_frontend_step(cs_frontend *fe) {
         }
         if (have_pk) {
             r = pk.status;
+            if (r == CS_OK && (long)pk.off.size() != (long)cs_cuboid_batch_n_frames(fe->batch) + 1) r = CS_ERR_BAD_ARG; // the detectors and the batch must hold the same number of frames: set_lines reads one offset per frame of the batch
             if (r == CS_OK) r = cs_cuboid_batch_set_lines(fe->cub_ctx ? fe->cub_ctx : fe->ctx, fe->batch, pk.off.data(), pk.lines.data());
             if (r != CS_OK) return r;
         }

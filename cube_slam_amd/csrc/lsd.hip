@@ -656,17 +656,16 @@ static int lsd_run(cs_ctx *ctx, cs_lsd *l, int with_lbd) {
         l->ccap = cap;
     }
     // region growing / rectangles / NFA (a15): interchangeable stages with byte-identical KeyLines (tests/test_lsd_gpu.py).
-    //   grp    eight frames per wave walk the reference's sequence on the device (lsd_regions.hip / lsd_rg_grp.h): 128 waves per 1024 frames, packed onto a
-    //          dozen CUs; a frame takes ~200 ms whatever the batch (113 k frames/s with the whole chip full of them) -- the default from 512 frames on;
-    //   grp2   the same with four frames per wave (two list pixels per step: 10 % less time per frame, 1.6 x the instructions);
-    //   seq    one wave per frame (lsd_rg_seq.h): ~110 ms per frame, 36 k frames/s with the chip full -- round 2's stage, kept as a cross-check;
+    //   seq    one wave per frame (lsd_rg_seq.h): ~110 ms per frame, 36 k frames/s with the chip full of them -- the default from 512 frames on;
+    //   wlk    a walker wave with one lane per frame that seeds and grows + rectangle waves for the regions it parks, one workgroup (lsd_rg_wlk.h): 64 frames per
+    //          wave slot instead of one, ~450 ms per frame -- for a backlog nobody waits for, by name only (round 4's grp / grp2 / lpf are gone);
     //   host   the OpenMP stage below, one frame per thread -- the default for smaller batches (one frame: 4 ms).
-    // CUBESLAM_LSD_REGIONS = grp | grp2 | seq | host overrides the choice.
+    // CUBESLAM_LSD_REGIONS = seq | wlk | host overrides the choice.
     std::vector<std::vector<float>> dev_lines;
     bool on_device = false;
     const char *mode = getenv("CUBESLAM_LSD_REGIONS");
     if (!mode || !*mode) mode = F >= 512 ? "seq" : "host";
-    const int grp_p = strcmp(mode, "grp") == 0 ? 1 : (strcmp(mode, "grp2") == 0 ? 2 : (strcmp(mode, "lpf") == 0 ? 64 : 0)); // lsd_rg_grp<P>: several frames per wave; lsd_rg_lpf: one lane per frame
+    const int grp_p = strcmp(mode, "wlk") == 0 ? 65 : 0; // lsd_rg_wlk: walker waves with one lane per frame + rectangle waves
     const bool use_seq = total > 0 && (strcmp(mode, "seq") == 0 || grp_p);
     // lsd_rg_seq's records are written by the emit kernel itself when they live in the arena (always, unless a caller's frames outgrew it): no fill, no scatter
     const bool pix_by_emit = use_seq && grp_p == 0 && l->pix_bytes >= (size_t)F * w * h * 16 && !(getenv("CUBESLAM_LSD_EMIT_PIX") && atoi(getenv("CUBESLAM_LSD_EMIT_PIX")) == 0);

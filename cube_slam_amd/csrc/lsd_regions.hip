@@ -34,11 +34,10 @@
 
 #include "lsd_regions.h"
 #include "lsd_rg_seq.h"
-#include "lsd_rg_grp.h"
-#include "lsd_rg_lpf.h"
+#include "lsd_rg_wlk.h"
 
 namespace {
-constexpr int PAD_PX = 272, PAD_LIST = 272, PAD_RECT = 34; // (lsd_rg_grp) 4352 / 4352 / 272 bytes between the frames' slices: see rgg::Batch
+constexpr int PAD_PX = 272, PAD_LIST = 272, PAD_RECT = 34; // (lsd_rg_wlk) 1088 / 2176 / 272 bytes between the frames' maps / lists / rectangles: the strides are not multiples of a large power of two (64 lanes, 64 frames: one channel otherwise)
 constexpr double PI_ = rg::PI_, LOG_EPS = 0.0, LSD_SCALE = 0.8;
 struct AngMap { int w, h; const float *deg; }; // a frame's level-line angles as lsd_gradient leaves them: float degrees, NOTDEF_F where the gradient is below the threshold; the map value is deg * DEG_TO_RADS in double
 
@@ -253,13 +252,13 @@ struct SeqParams {
     rgs::Px *pix; float *ang32; float *seed_cs; int *glist; double *rect; size_t rect_stride; int cand_cap; int *cand_cnt; int *status;
     int min_reg_size, list_cap;
     unsigned long long *prof;
-    size_t pix_stride; // elements from one frame's records (pix, or ang32: lsd_rg_grp's float map) to the next
+    size_t pix_stride; // elements from one frame's records (pix, or ang32: lsd_rg_wlk's float map) to the next
 };
 __global__ void __launch_bounds__(256) lsd_rg_fill(rgs::Px *pix, size_t n) {
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n) reinterpret_cast<float4 *>(pix)[i] = make_float4(rgs::NOTDEF_F, 0.f, 0.f, rgs::NOTDEF_F);
 }
-__global__ void __launch_bounds__(256) lsd_rg_fill32(float4 *ang, size_t n4) { // lsd_rg_grp's map: one float per pixel
+__global__ void __launch_bounds__(256) lsd_rg_fill32(float4 *ang, size_t n4) { // lsd_rg_wlk's map: one float per pixel
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n4) ang[i] = make_float4(rgs::NOTDEF_F, rgs::NOTDEF_F, rgs::NOTDEF_F, rgs::NOTDEF_F);
 }
@@ -302,31 +301,61 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(RGS_W
 #else
 __global__ void __launch_bounds__(1024) lsd_rg_seq(SeqParams P) { lsd_rg_seq_body(P); }
 #endif
-// Several frames per wave (lsd_rg_grp.h): a group of 8 P lanes per frame, 64 / (8 P) frames per wave, no LDS.  A launch is 8 (4) times fewer waves than
-// lsd_rg_seq's and the frames' bookkeeping is vector work shared by the frames of a wave.
-// A launch walks up to GRP_SLICES slices of a batch side by side (inside a slice every offset fits 32 bits: lsd_rg_grp.h addresses base + offset).
-constexpr int GRP_SLICES = 8;
-struct GrpLaunch { rgg::Batch slice[GRP_SLICES]; int n_slices, waves_per_slice; };
-template <int P, int LB> __global__ void __launch_bounds__(LB) lsd_rg_grp(GrpLaunch L) { // LB: 256 = up to four waves a workgroup (one per SIMD), 512 / 1024 = two / four per SIMD (the register allocation follows)
-    constexpr int G = 8 * P;
-    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
-    const int c = wave / L.waves_per_slice;
-    if (c >= L.n_slices) return;
-    const rgg::Batch &B = L.slice[c];
-    const int f0 = (wave - c * L.waves_per_slice) * (64 / G);
-    if (f0 >= B.F) return;
-    rgg::run_wave<P, rgg::GWave<G>>(B, f0);
-}
-// One lane per frame (lsd_rg_lpf.h): 64 frames per wave, no lane talks to another, no LDS.
-struct LpfLaunch { rgl::Batch slice[GRP_SLICES]; int n_slices, waves_per_slice; };
-template <int LB> __global__ void __launch_bounds__(LB) lsd_rg_lpf(LpfLaunch L) {
-    const int wave = __builtin_amdgcn_readfirstlane(blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6));
-    const int c = wave / L.waves_per_slice;
-    if (c >= L.n_slices) return;
+// A launch walks up to WLK_SLICES slices of a batch side by side (inside a slice every offset fits 32 bits: lsd_rg_wlk.h addresses base + offset).
+constexpr int WLK_SLICES = 8;
+struct WlkLaunch { rgl::Batch slice[WLK_SLICES]; int n_slices, waves_per_slice; };
+// Two roles per workgroup (lsd_rg_wlk.h): WK walker waves (one lane per frame: seeds and growth), the other waves take the regions the walkers park (rectangle stage),
+// through a mailbox in LDS.  A workgroup never waits for another one; its roles share a CU, so workgroup-scope ordering is all the hand-over needs.
+template <int NS> struct WlkMail { // the walkers' side of the mailbox policy
+    rgw::Mail<NS> &m; int base;
+    __device__ __forceinline__ rgw::Mail<NS> &mail() { return m; }
+    __device__ __forceinline__ int slot_of(int l) const { return base + l; }
+    __device__ __forceinline__ int ring_size() const { return NS; }
+    __device__ __forceinline__ void after_iteration(const rgl::Batch &) {}
+};
+template <int WK, int NWAVES, int ACC> __global__ void __launch_bounds__(64 * NWAVES) lsd_rg_wlk(WlkLaunch L, int blocks_per_slice) {
+    constexpr int NS = WK * 64;
+    __shared__ rgw::Mail<NS> mail;
+    for (int k = threadIdx.x; k < NS; k += 64 * NWAVES) { mail.slot[k].state = 0; mail.slot[k].fl = 0; mail.ring_id[k] = 0; mail.ring_tick[k] = 0; }
+    if (threadIdx.x == 0) { mail.tail = 0; mail.head = 0; mail.walkers_done = 0; }
+    __syncthreads();
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int c = blockIdx.x / blocks_per_slice;
     const rgl::Batch &B = L.slice[c];
-    const int f0 = (wave - c * L.waves_per_slice) * 64;
-    if (f0 >= B.F) return;
-    rgl::run_wave<rgl::LWave>(B, f0);
+    if (wv < WK) {
+        const int f0 = ((blockIdx.x - c * blocks_per_slice) * WK + wv) * 64;
+        if (f0 < B.F) { WlkMail<NS> mp{mail, wv * 64}; rgw::run_walker<rgl::LWave, ACC>(B, f0, mp); }
+        rgw::wg_release();
+        if (lane == 0) rgw::lds_add(&mail.walkers_done, 1);
+        return;
+    }
+#if defined(RGW_PROF)
+    unsigned long long rgw_job = 0, rgw_jobs = 0, rgw_idle = 0;
+#endif
+    for (;;) { // a rectangle wave: the next ticket, its region, the answer
+#if defined(RGW_PROF)
+        const unsigned long long rgw_t0 = clock64();
+#endif
+        int t = 0;
+        if (lane == 0) t = rgw::lds_add(&mail.head, 1);
+        t = __builtin_amdgcn_readfirstlane(t);
+        bool quit = false;
+        while (__builtin_amdgcn_readfirstlane(rgw::lds_ld(&mail.ring_tick[t % NS])) != t + 1) {
+            if (__builtin_amdgcn_readfirstlane(rgw::lds_ld(&mail.walkers_done)) == WK && __builtin_amdgcn_readfirstlane(rgw::lds_ld(&mail.tail)) <= t) { quit = true; break; } // (a walker is done when its last region has been answered)
+            __builtin_amdgcn_s_sleep(4);
+        }
+        if (quit) break;
+#if defined(RGW_PROF)
+        const unsigned long long rgw_t1 = clock64();
+#endif
+        rgw::serve_ticket<rgs::Wave, NS>(B, mail, t);
+#if defined(RGW_PROF)
+        rgw_idle += rgw_t1 - rgw_t0; rgw_job += clock64() - rgw_t1; rgw_jobs++;
+#endif
+    }
+#if defined(RGW_PROF)
+    if (lane == 0) { atomicAdd(&rgw::g_rgw_prof[8], rgw_job); atomicAdd(&rgw::g_rgw_prof[9], rgw_jobs); atomicAdd(&rgw::g_rgw_prof[10], rgw_idle); }
+#endif
 }
 // the frames' rectangle lists one after the other (frames in order, seeds in order): cand_base[f] = rectangles of the frames before f
 __global__ void __launch_bounds__(1024) lsd_rg_cand_scan(const int *cand_cnt, int F, int *cand_base) {
@@ -407,7 +436,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RG_IMP
 struct LsdSeq {
     int F = 0, w = 0, h = 0; int cand_cap = 0; size_t cap_lines = 0;
     rgs::Px *d_pix = nullptr; bool pix_borrowed = false; // (borrowed: the caller's scratch, not freed here)
-    rgg::Ent *d_elist = nullptr; float *d_ang32 = nullptr; int *d_order = nullptr; // the several-frames-per-wave walk: region lists of 8-byte entries, a float per pixel, the frames sorted by work
+    rgl::Ent *d_elist = nullptr; float *d_ang32 = nullptr; int *d_order = nullptr; // the lane-per-frame walk (lsd_rg_wlk): region lists of 8-byte entries, a float per pixel, the frames sorted by work
     int *d_glist = nullptr, *d_cand_cnt = nullptr, *d_cand_base = nullptr, *d_status = nullptr, *d_frame_base = nullptr;
     double *d_rect = nullptr, *d_lgt = nullptr;
     uint8_t *d_has = nullptr;
@@ -425,7 +454,7 @@ void lsd_seq_destroy(LsdSeq *r) {
 int lsd_seq_run(cs_ctx *ctx, LsdSeq **handle, int F, int w, int h, const float *d_ang, const double *d_mod, const int *d_caddr, const float *d_cdeg, const float2 *d_ccs, const int *frame_base,
                 std::vector<std::vector<float>> &lines, long *stats /* [0] region_grow calls, [1] window fetches, [2] rectangles at rect_improve, [3] regions at the rectangle stage */,
                 void (*before_seq)(void *), void (*after_seq)(void *), void *gate_arg /* the front-end runner's phase gate: called in front of the lsd_rg_seq launch and once it has left the GPU; may be NULL */,
-                int grp_p /* 0: lsd_rg_seq, one wave per frame; 1 / 2: lsd_rg_grp<P>, 8 / 4 frames per wave; 64: lsd_rg_lpf, one lane per frame */,
+                int grp_p /* 0: lsd_rg_seq, one wave per frame; 65: lsd_rg_wlk, walker waves with one lane per frame + rectangle waves */,
                 int waves_per_workgroup /* frames per workgroup of lsd_rg_seq: 16 packs a batch onto F / 16 CUs and leaves the others empty; 4 spreads it over the chip (the alternating runner, where
                                            every CU is busy anyway: 128 -> 104 ms per launch there) */,
                 void *scratch, size_t scratch_bytes /* memory the caller has no use for while the stage runs: lsd_rg_seq's pixel records go there when it is large enough */,
@@ -443,7 +472,7 @@ int lsd_seq_run(cs_ctx *ctx, LsdSeq **handle, int F, int w, int h, const float *
         r = new LsdSeq();
         *handle = r;
         r->F = F; r->w = w; r->h = h; r->cand_cap = 4096;
-        // (d_pix, d_glist: lsd_rg_seq's; d_ang32, d_elist: lsd_rg_grp's -- allocated by the mode that runs)
+        // (d_pix, d_glist: lsd_rg_seq's; d_ang32, d_elist: lsd_rg_wlk's -- allocated by the mode that runs)
         RA_(cs_dalloc(ctx, &r->d_order, (size_t)F)); RA_(cs_dalloc(ctx, &r->d_rect, (size_t)F * (r->cand_cap * 12 + PAD_RECT)));
         RA_(cs_dalloc(ctx, &r->d_cand_cnt, (size_t)F)); RA_(cs_dalloc(ctx, &r->d_cand_base, (size_t)F + 1));
         RA_(cs_dalloc(ctx, &r->d_status, (size_t)F * 4)); RA_(cs_dalloc(ctx, &r->d_frame_base, (size_t)F + 1));
@@ -458,9 +487,9 @@ int lsd_seq_run(cs_ctx *ctx, LsdSeq **handle, int F, int w, int h, const float *
     S.min_reg_size = int(-LOG_NT / std::log10(rg::ANG_TH / 180));
     S.list_cap = rgs::CAP;
     if (const char *e = getenv("CUBESLAM_LSD_SEQ_CAP")) S.list_cap = std::max(2, std::min(rgs::CAP, atoi(e))); // (tests: a small cap walks the fallback to the host stage)
-    const bool lpf = grp_p == 64; // one lane per frame
-    const bool grp = grp_p == 1 || grp_p == 2 || lpf, pad = grp && !getenv("CUBESLAM_LSD_NOPAD"); // (the variable: to measure what the padding is worth)
-    const size_t rect_stride = (size_t)r->cand_cap * 12 + (pad ? PAD_RECT : 0), list_stride = (size_t)rgg::CAP + (pad ? PAD_LIST : 0);
+    if (grp_p != 0 && grp_p != 65) return CS_ERR_BAD_ARG;
+    const bool grp = grp_p == 65, pad = grp; // walker + rectangle waves (lsd_rg_wlk.h): a float per pixel, 8-byte list entries, padded strides
+    const size_t rect_stride = (size_t)r->cand_cap * 12 + (pad ? PAD_RECT : 0), list_stride = (size_t)rgl::CAP + (pad ? PAD_LIST : 0);
     S.pix_stride = (size_t)w * h + (pad ? PAD_PX : 0); S.rect_stride = rect_stride;
     S.prof = nullptr;
 #if defined(RGS_PROFILE)
@@ -471,9 +500,9 @@ int lsd_seq_run(cs_ctx *ctx, LsdSeq **handle, int F, int w, int h, const float *
 #endif
     const size_t npx = (size_t)F * S.pix_stride;
     if (grp) {
-        const size_t head = (size_t)((w + 8 + 3) & ~3); // undefined pixels in front of frame 0 (lsd_rg_lpf reads "row -1" without a test)
+        const size_t head = (size_t)((w + 8 + 3) & ~3); // undefined pixels in front of frame 0 (the walkers read "row -1" without a test)
         if (!r->d_ang32) RA_(cs_dalloc(ctx, &r->d_ang32, head + (size_t)r->F * ((size_t)w * h + PAD_PX) + 16));
-        if (!r->d_elist) RA_(cs_dalloc(ctx, &r->d_elist, (size_t)r->F * ((size_t)rgg::CAP + PAD_LIST) + 16));
+        if (!r->d_elist) RA_(cs_dalloc(ctx, &r->d_elist, (size_t)r->F * ((size_t)rgl::CAP + PAD_LIST) + 16));
         S.ang32 = r->d_ang32 + head;
         CS_LAUNCH(ctx, "lsd_rg_fill", lsd_rg_fill32, dim3((unsigned)(((npx + head) / 4 + 1 + 255) / 256)), dim3(256), 0, reinterpret_cast<float4 *>(r->d_ang32), (npx + head) / 4 + 1);
     } else {
@@ -492,7 +521,7 @@ int lsd_seq_run(cs_ctx *ctx, LsdSeq **handle, int F, int w, int h, const float *
     if (before_seq) before_seq(gate_arg);
     if (grp) {
         const size_t npx = (size_t)w * h, head = (size_t)((w + 8 + 3) & ~3);
-        int chunk = (int)std::min<size_t>(4096, 0xffffffffull / (npx * sizeof(double))); // (the norms: the widest per-pixel array the walk reads) // every offset of a launch fits 32 bits (lsd_rg_grp.h addresses base + offset)
+        int chunk = (int)std::min<size_t>(4096, 0xffffffffull / (npx * sizeof(double))); // (the norms: the widest per-pixel array the walk reads) // every offset of a launch fits 32 bits (lsd_rg_wlk.h addresses base + offset)
         chunk = std::min(chunk, 1024);
         if (chunk < 1) return CS_ERR_CAPACITY;
         std::vector<int> order((size_t)F);
@@ -503,54 +532,31 @@ int lsd_seq_run(cs_ctx *ctx, LsdSeq **handle, int F, int w, int h, const float *
         }
         RA_(cs_h2d(ctx, r->d_order, order.data(), (size_t)F));
         CS_HIP(ctx, hipStreamSynchronize(ctx->stream)); // (order is a local)
-        const int fpw = lpf ? 64 : 64 / (8 * grp_p); // frames per wave
-        int wpg = 12; // waves per workgroup: three per SIMD of a CU (167 registers each) -- the most a CU takes, and the most it delivers: 441 frames/s per CU against 326 with two per
-                      // SIMD and 43 with one wave alone on the CU (a wave waits on its one memory round trip per step two thirds of the time); 1024 frames sit on 11 CUs
-        if (const char *e = getenv("CUBESLAM_LSD_GRP_WPB")) wpg = std::max(1, std::min(16, atoi(e)));
-        if (lpf) {
-            int wpl = 4; // waves per workgroup: one per SIMD
-            if (const char *e = getenv("CUBESLAM_LSD_LPF_WPB")) wpl = std::max(1, std::min(16, atoi(e)));
-            for (int l0 = 0; l0 < F; l0 += chunk * GRP_SLICES) {
-                LpfLaunch L;
-                L.n_slices = 0; L.waves_per_slice = (chunk + 63) / 64;
-                for (int c0 = l0; c0 < F && L.n_slices < GRP_SLICES; c0 += chunk) {
-                    const int fc = std::min(chunk, F - c0);
-                    rgl::Batch &B = L.slice[L.n_slices++];
-                    B.F = fc; B.w = w; B.h = h; B.npx = (int)npx; B.order = r->d_order + c0; B.ang_stride = (int)S.pix_stride; B.list_stride = (int)list_stride; B.rect_stride = (int)rect_stride; B.ang_head = (int)head;
-                    B.caddr = d_caddr + frame_base[c0]; B.frame_base = r->d_frame_base + c0; B.ang = r->d_ang32 + (size_t)c0 * S.pix_stride; B.mod = d_mod + (size_t)c0 * npx; B.seed_cs = S.seed_cs + 2 * (size_t)frame_base[c0];
-                    B.list = reinterpret_cast<rgl::Ent *>(r->d_elist) + (size_t)c0 * list_stride; B.list_cap = std::min(S.list_cap, rgl::CAP); B.rect = r->d_rect + (size_t)c0 * rect_stride; B.cand_cap = r->cand_cap; B.cand_cnt = r->d_cand_cnt + c0; B.status = r->d_status + 4 * (size_t)c0;
-                    B.min_reg_size = S.min_reg_size; B.max_iters = (int)std::min<size_t>(64 * npx, 0x7fffffff);
-                }
-                const int waves = L.n_slices * L.waves_per_slice, groups = (waves + wpl - 1) / wpl;
-                if (wpl <= 4) CS_LAUNCH(ctx, "lsd_rg_lpf", (lsd_rg_lpf<256>), dim3(groups), dim3(64 * wpl), 0, L);
-                else if (wpl <= 8) CS_LAUNCH(ctx, "lsd_rg_lpf", (lsd_rg_lpf<512>), dim3(groups), dim3(64 * wpl), 0, L);
-                else CS_LAUNCH(ctx, "lsd_rg_lpf", (lsd_rg_lpf<1024>), dim3(groups), dim3(64 * wpl), 0, L);
-            }
-        } else
-        for (int l0 = 0; l0 < F; l0 += chunk * GRP_SLICES) { // one launch per GRP_SLICES slices
-            GrpLaunch L;
-            L.n_slices = 0; L.waves_per_slice = (chunk + fpw - 1) / fpw;
-            for (int c0 = l0; c0 < F && L.n_slices < GRP_SLICES; c0 += chunk) {
+        for (int l0 = 0; l0 < F; l0 += chunk * WLK_SLICES) { // one launch per WLK_SLICES slices
+            WlkLaunch L;
+            L.n_slices = 0; L.waves_per_slice = (chunk + 63) / 64;
+            for (int c0 = l0; c0 < F && L.n_slices < WLK_SLICES; c0 += chunk) {
                 const int fc = std::min(chunk, F - c0);
-                rgg::Batch &B = L.slice[L.n_slices++];
-                B.F = fc; B.w = w; B.h = h; B.npx = (int)npx; B.order = r->d_order + c0; B.ang_stride = (int)S.pix_stride; B.list_stride = (int)list_stride; B.rect_stride = (int)rect_stride;
-                B.caddr = d_caddr + frame_base[c0]; B.frame_base = r->d_frame_base + c0; B.ang = r->d_ang32 + head + (size_t)c0 * S.pix_stride; B.mod = d_mod + (size_t)c0 * npx; B.seed_cs = S.seed_cs + 2 * (size_t)frame_base[c0];
-                B.list = r->d_elist + (size_t)c0 * list_stride; B.list_cap = std::min(S.list_cap, rgg::CAP); B.rect = r->d_rect + (size_t)c0 * rect_stride; B.cand_cap = r->cand_cap; B.cand_cnt = r->d_cand_cnt + c0; B.status = r->d_status + 4 * (size_t)c0;
+                rgl::Batch &B = L.slice[L.n_slices++];
+                B.F = fc; B.w = w; B.h = h; B.npx = (int)npx; B.order = r->d_order + c0; B.ang_stride = (int)S.pix_stride; B.list_stride = (int)list_stride; B.rect_stride = (int)rect_stride; B.ang_head = (int)head;
+                B.caddr = d_caddr + frame_base[c0]; B.frame_base = r->d_frame_base + c0; B.ang = r->d_ang32 + (size_t)c0 * S.pix_stride; B.mod = d_mod + (size_t)c0 * npx; B.seed_cs = S.seed_cs + 2 * (size_t)frame_base[c0];
+                B.list = r->d_elist + (size_t)c0 * list_stride; B.list_cap = std::min(S.list_cap, rgl::CAP); B.rect = r->d_rect + (size_t)c0 * rect_stride; B.cand_cap = r->cand_cap; B.cand_cnt = r->d_cand_cnt + c0; B.status = r->d_status + 4 * (size_t)c0;
                 B.min_reg_size = S.min_reg_size; B.max_iters = (int)std::min<size_t>(64 * npx, 0x7fffffff);
-                B.prof = nullptr;
             }
-            const int waves = L.n_slices * L.waves_per_slice, groups = (waves + wpg - 1) / wpg;
-            if (grp_p == 1) {
-                if (wpg <= 4) CS_LAUNCH(ctx, "lsd_rg_grp", (lsd_rg_grp<1, 256>), dim3(groups), dim3(64 * wpg), 0, L);
-                else if (wpg <= 8) CS_LAUNCH(ctx, "lsd_rg_grp", (lsd_rg_grp<1, 512>), dim3(groups), dim3(64 * wpg), 0, L);
-                else if (wpg <= 12) CS_LAUNCH(ctx, "lsd_rg_grp", (lsd_rg_grp<1, 768>), dim3(groups), dim3(64 * wpg), 0, L);
-                else CS_LAUNCH(ctx, "lsd_rg_grp", (lsd_rg_grp<1, 1024>), dim3(groups), dim3(64 * wpg), 0, L);
-            } else {
-                if (wpg <= 4) CS_LAUNCH(ctx, "lsd_rg_grp", (lsd_rg_grp<2, 256>), dim3(groups), dim3(64 * wpg), 0, L);
-                else if (wpg <= 8) CS_LAUNCH(ctx, "lsd_rg_grp", (lsd_rg_grp<2, 512>), dim3(groups), dim3(64 * wpg), 0, L);
-                else if (wpg <= 12) CS_LAUNCH(ctx, "lsd_rg_grp", (lsd_rg_grp<2, 768>), dim3(groups), dim3(64 * wpg), 0, L);
-                else CS_LAUNCH(ctx, "lsd_rg_grp", (lsd_rg_grp<2, 1024>), dim3(groups), dim3(64 * wpg), 0, L);
-            }
+            int wk = 1, nw = 8, acc = 1; // walker waves / waves per workgroup / accepted pixels per iteration (measured on 1 024 distinct frames: 454 ms a pass for 1,8,1; 466 for 2,8,1 on half the CUs; 505 for 1,8,2)
+            if (const char *e = getenv("CUBESLAM_LSD_WLK")) sscanf(e, "%d,%d,%d", &wk, &nw, &acc);
+            const int bps = (L.waves_per_slice + wk - 1) / wk, groups = L.n_slices * bps;
+#define WLK_(WK, NW, AC) else if (wk == WK && nw == NW && acc == AC) CS_LAUNCH(ctx, "lsd_rg_wlk", (lsd_rg_wlk<WK, NW, AC>), dim3(groups), dim3(64 * NW), 0, L, bps)
+            if (false) {}
+            WLK_(1, 8, 1); WLK_(1, 8, 2); WLK_(1, 4, 1); WLK_(2, 8, 1); WLK_(2, 16, 1); WLK_(4, 16, 1); WLK_(8, 16, 1);
+            else { ctx->err = "CUBESLAM_LSD_WLK: no such shape (walkers,waves,accepts)"; return CS_ERR_BAD_ARG; }
+#undef WLK_
+#if defined(RGW_PROF)
+            { unsigned long long h[16]; hipDeviceSynchronize(); hipMemcpyFromSymbol(h, HIP_SYMBOL(rgw::g_rgw_prof), sizeof h); unsigned long long z[16] = {0}; hipMemcpyToSymbol(HIP_SYMBOL(rgw::g_rgw_prof), z, sizeof z);
+              const double it = (double)std::max<unsigned long long>(h[5], 1);
+              fprintf(stderr, "[rgw prof] walker iterations %.0f (all waves); clocks per iteration: issue %.0f wait %.0f grow %.0f seed %.0f mail %.0f = %.0f; rectangle waves: %.0f jobs, %.0f clocks each, waiting %.0f clocks per job\n", it, h[0] / it, h[1] / it, h[2] / it,
+                      h[3] / it, h[4] / it, (h[0] + h[1] + h[2] + h[3] + h[4]) / it, (double)h[9], h[9] ? (double)h[8] / h[9] : 0.0, h[9] ? (double)h[10] / h[9] : 0.0); }
+#endif
         }
     } else if (walk_bg) {
         CS_HIP(ctx, ctx->bg_begin());

@@ -130,6 +130,7 @@ struct Wave { // host model: the lanes of a body run one after the other
     static RGS_FN double vmin(const PerLane<double> &x) { double m = x.v[0]; for (int l = 1; l < 64; l++) m = fmin(m, x.v[l]); return m; }
     static RGS_FN void sync() {}
     static RGS_FN int uni(int v) { return v; }
+    static RGS_FN double uni(double v) { return v; }
 };
 RGS_FN Px ld_px(const Px *p) { return *p; }
 RGS_FN void st_free(Px *p, float v) { p->free_deg = v; }

@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define CS_VERSION 105 /* 105: cs_frontend_set_backlog; 104: cs_frontend_set_cuboid_ctx; 103: cs_lsd_read_filter_lines takes the caller's frame count, cs_frontend_set_chain; 102: cs_cuboid_batch_set_lines, cs_cuboid_batch_set_shared_gpu, cs_lsd_read_filter_lines; 101: cs_ba_set_stop_flag_bool / cs_ba_dyn_set_stop_flag_bool; cs_match_by_projection_frame takes train_blocked */
+#define CS_VERSION 106 /* 106: cs_cuboid_batch_n_frames; 105: cs_frontend_set_backlog; 104: cs_frontend_set_cuboid_ctx; 103: cs_lsd_read_filter_lines takes the caller's frame count, cs_frontend_set_chain; 102: cs_cuboid_batch_set_lines, cs_cuboid_batch_set_shared_gpu, cs_lsd_read_filter_lines; 101: cs_ba_set_stop_flag_bool / cs_ba_dyn_set_stop_flag_bool; cs_match_by_projection_frame takes train_blocked */
 
 typedef enum cs_status {
     CS_OK = 0,
@@ -139,6 +139,8 @@ int cs_cuboid_batch_run(cs_ctx *ctx, cs_cuboid_batch *b);
 /* New edge lists (line_offsets[n_frames + 1], lines m x 4 as in cs_cuboid_batch_create) for the frames of an existing batch: the hand-over of the
  * chain detect_filter_lines -> detect_cuboid (main_obj.cpp:428-449) when frames and boxes stay resident. */
 int cs_cuboid_batch_set_lines(cs_ctx *ctx, cs_cuboid_batch *b, const int *line_offsets, const double *lines);
+/* frames the batch was created with (line_offsets of cs_cuboid_batch_set_lines holds one more entry); -1 for NULL */
+int cs_cuboid_batch_n_frames(const cs_cuboid_batch *b);
 /* shared != 0: long-running kernels of other streams hold most CUs while this batch runs (cs_frontend's alternating runner does this itself): the edge-scoring
  * kernel takes the launch shape that fits beside them.  A speed hint only. */
 int cs_cuboid_batch_set_shared_gpu(cs_cuboid_batch *b, int shared);

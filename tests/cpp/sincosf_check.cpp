@@ -13,7 +13,7 @@ int main(int argc, char **argv) {
         n += 4;
         bad += cosf(x) != glibc_sincosf::cosf_(x); bad += sinf(x) != glibc_sincosf::sinf_(x);
         bad += cosf(-x) != glibc_sincosf::cosf_(-x); bad += sinf(-x) != glibc_sincosf::sinf_(-x);
-        { float sn, cs; glibc_sincosf::sincosf_pos(x, &sn, &cs); n += 2; bad += cosf(x) != cs; bad += sinf(x) != sn; } // the branch-free pair of lsd_rg_grp.h
+        { float sn, cs; glibc_sincosf::sincosf_pos(x, &sn, &cs); n += 2; bad += cosf(x) != cs; bad += sinf(x) != sn; } // the branch-free pair of lsd_rg_wlk.h
     }
     const float edge[] = {0.0f, 1e-30f, 0x1p-12f, 0x1.921FB6p-1f, 0x1.921FB4p-1f, 3.14159274f, 6.28318548f, 6.2831850f};
     for (float x : edge) { n += 2; bad += cosf(x) != glibc_sincosf::cosf_(x); bad += sinf(x) != glibc_sincosf::sinf_(x); float sn, cs; glibc_sincosf::sincosf_pos(x, &sn, &cs); n += 2; bad += cosf(x) != cs; bad += sinf(x) != sn; }

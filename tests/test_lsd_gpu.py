@@ -38,11 +38,13 @@ def test_other_sizes_and_flat(ctx, oracle):
     det.close()
 
 
-@pytest.mark.parametrize("stage", ["seq", "grp", "grp2", "lpf"])
-def test_device_region_stage_equals_host_stage(ctx, oracle, monkeypatch, stage):
-    """Region growing / rectangles / NFA on the device (lsd_regions.hip: the reference's sequence walked by one wave per frame, lsd_rg_seq.h; by eight
-    or four frames per wave, lsd_rg_grp.h; by one lane per frame, lsd_rg_lpf.h) against the host stage and the oracle: KeyLines byte for byte.  The
-    batch is small, so the stage is asked for; large batches take `seq` by themselves.  Eleven frames: a wave of eight and a ragged one."""
+@pytest.mark.parametrize("stage,shape", [("seq", ""), ("wlk", "1,8,1"), ("wlk", "1,8,2"), ("wlk", "2,8,1"), ("wlk", "8,16,1")])
+def test_device_region_stage_equals_host_stage(ctx, oracle, monkeypatch, stage, shape):
+    """Region growing / rectangles / NFA on the device (lsd_regions.hip: the reference's sequence walked by one wave per frame, lsd_rg_seq.h; by walker
+    waves with one lane per frame + rectangle waves, lsd_rg_wlk.h, in several workgroup shapes: walkers, waves, accepted pixels per iteration) against
+    the host stage and the oracle: KeyLines byte for byte.  The batch is small, so the stage is asked for; large batches take `seq` by themselves."""
+    if shape:
+        monkeypatch.setenv("CUBESLAM_LSD_WLK", shape)
     imgs = [np.load(os.path.join(GOLD, "orb_cabinet.npz"))["gray"], synth.cuboid_scene(7, n_boxes=3, bg_texture=0.5)["gray"], synth.texture_image(8, 640, 480)]
     imgs += [synth.cuboid_scene(60 + i, n_boxes=3, bg_texture=0.125 * i)["gray"] for i in range(8)]
     det = line_lbd_detect(640, 480, max_frames=len(imgs), ctx=ctx)
@@ -59,7 +61,7 @@ def test_device_region_stage_equals_host_stage(ctx, oracle, monkeypatch, stage):
     det.close()
 
 
-@pytest.mark.parametrize("stage", ["seq", "grp", "lpf"])
+@pytest.mark.parametrize("stage", ["seq", "wlk"])
 def test_device_region_stage_other_size_and_capacity_fallback(ctx, oracle, monkeypatch, stage):
     """The device stage on KITTI-sized frames, and its way out: a region larger than the wave's list (here cut to 64 pixels) hands the batch to the
     host stage -- same KeyLines, and the statistics say so."""

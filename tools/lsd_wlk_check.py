@@ -1,5 +1,6 @@
-"""Region stage of the line detector with several frames per wave (CUBESLAM_LSD_REGIONS=grp | grp2: lsd_rg_grp.h) against the host stage, the one-wave-per-frame
-stage and the oracle, with kernel timings (run on the GPU box).  usage: python tools/lsd_grp_check.py [frames] [distinct_scenes] [modes,comma-separated]"""
+"""Region stage of the line detector with walker + rectangle waves (CUBESLAM_LSD_REGIONS=wlk: lsd_rg_wlk.h) against the host stage, the one-wave-per-frame
+stage and the oracle, with kernel timings (run on the GPU box).  usage: python tools/lsd_wlk_check.py [frames] [distinct_scenes] [modes,comma-separated]
+WLK_SHAPES="1,8,1;2,8,1;..." = walkers, waves per workgroup, accepted pixels per iteration."""
 import os
 import sys
 import time
@@ -20,15 +21,15 @@ with ThreadPoolExecutor(16) as ex:  # D distinct scenes (frames that repeat walk
 base += [np.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "orb_cabinet.npz"))["gray"], synth.texture_image(8, 640, 480)]
 g = np.stack([base[i % D] for i in range(F)])
 det = line_lbd_detect(640, 480, max_frames=F, ctx=ctx)
-variants = [("host", None), ("seq", None)] + [(m, w) for m in ("grp", "grp2", "lpf") for w in [int(x) for x in os.environ.get("WPBS", "1,4,8,16").split(",")]]
+variants = [("host", None), ("seq", None)]
+variants += [("wlk", shape) for shape in os.environ.get("WLK_SHAPES", "1,8,1;1,8,2;1,4,1;2,8,1;2,16,1;4,16,1;8,16,1").split(";")]  # walkers, waves per workgroup, accepts per iteration
 if len(sys.argv) > 3:
     variants = [v for v in variants if v[0] in sys.argv[3].split(",")]
 res = {}
 for mode, wpb in variants:
     os.environ["CUBESLAM_LSD_REGIONS"] = mode
-    if wpb:
-        os.environ["CUBESLAM_LSD_GRP_WPB"] = str(wpb)
-        os.environ["CUBESLAM_LSD_LPF_WPB"] = str(wpb)
+    if mode == "wlk":
+        os.environ["CUBESLAM_LSD_WLK"] = wpb
     det.upload(g)
     det.run(with_lbd=False)
     ctx.timing(True); ctx.timing_reset()
@@ -37,9 +38,9 @@ for mode, wpb in variants:
     for _ in range(R):
         det.run(with_lbd=False)
     dt = (time.time() - t0) / R
-    ks = {k: ctx.timing_get(k)[0] / R for k in ("lsd_rg_seq", "lsd_rg_grp", "lsd_rg_lpf", "lsd_rg_improve", "lsd_rg_fill", "lsd_rg_scatter", "host_lsd_regions")}
+    ks = {k: ctx.timing_get(k)[0] / R for k in ("lsd_rg_seq", "lsd_rg_wlk", "lsd_rg_improve", "lsd_rg_fill", "lsd_rg_scatter", "host_lsd_regions")}
     ctx.timing(False)
-    key = mode + ("/%d" % wpb if wpb else "")
+    key = mode + ("/%s" % wpb if wpb else "")
     res[key] = [det.read(f, with_desc=False) for f in range(min(F, D))]
     print("F", F, key, "ms/batch %.2f  frames/s %.0f" % (dt * 1e3, F / dt), det.region_stats(), {k: round(v, 2) for k, v in ks.items() if v}, flush=True)
 ref = res.get("host") or next(iter(res.values()))
