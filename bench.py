@@ -13,6 +13,7 @@ collective, weak scaling).  The same JSON line carries, measured in the same run
   "chained"  the reference's chain: detect_cuboid fed the lines detect_filter_lines found in the same step,
   "pcie_inclusive"  the drop-in calls frame by frame, host buffers in and out (one caller thread, and sixteen),
   "cpu_baseline" / "cpu_baseline_mt"  the CPU port (oracle, built -march=native on this box) on 1 thread / frame-parallel on the host cores.
+  "cpu_baseline_ref"  the reference's own text (oracle/_ref/libref.so, prebuilt from /root/reference by oracle/Makefile.ref), 1 thread, beside the port.
 """
 import argparse
 import json
@@ -109,6 +110,48 @@ def cpu_baseline(scenes, yaw_step, flags, budget_s=10.0, with_orb=True, nfeat=10
         dt = time.perf_counter() - t0
     return {"value": n / dt, "unit": "frames/s", "cores": threads, "kind": "port", "build": flags,
             "sample": "%d frames of the same workload in %.1f s, oracle/{orb,lsd,lbd,cuboid}_oracle.cpp, %d thread%s" % (n, dt, threads, "" if threads == 1 else "s (frame-parallel)")}
+
+
+def cpu_baseline_ref(scenes, yaw_step, budget_s=8.0, with_orb=True, nfeat=1000, with_lines=True):
+    """The same bounded sample through the REFERENCE'S OWN TEXT: oracle/_ref/libref.so (oracle/Makefile.ref: ORBextractor.cc, lsd.cpp, LSDDetector.cpp whole; detect_cuboid and
+    BinaryDescriptor's compute path cut out of the reference at build time) on the OpenCV / Eigen stand-ins of oracle/ref_shim, 1 thread.  Built -O3 without -march=native (the
+    library is prebuilt where /root/reference exists and travels).  None when the library is not there."""
+    import ctypes as C
+    from oracle import pyoracle as po
+    so = os.path.join(ROOT, "oracle", "_ref", "libref.so")
+    if not os.path.exists(so):
+        return None
+    ref = C.CDLL(so)
+    o = po.cuboid_opts(yaw_step_deg=yaw_step)
+    vp = lambda a: a.ctypes.data_as(C.c_void_p)  # noqa: E731
+    cap = nfeat * 2 + 64
+    kps, desc = np.zeros(cap, po.KEYPOINT_DTYPE), np.zeros((cap, 32), np.uint8)
+    kl, ldesc = np.zeros(20000, po.KEYLINE_DTYPE), np.zeros((20000, 32), np.uint8)
+
+    def frame(s):
+        gray = np.ascontiguousarray(s["gray"], np.uint8)
+        H, W = gray.shape
+        if with_orb:
+            levels, dims = np.zeros(4 * W * H + 64, np.uint8), np.zeros(16, np.int32)
+            ref.ref_orb_extract(nfeat, C.c_float(1.2), 8, 20, 7, vp(gray), W, H, vp(kps), vp(desc), cap, vp(levels), vp(dims))
+        if with_lines:
+            n = ref.ref_lsd_keylines(vp(gray), W, H, vp(kl), len(kl))
+            ref.ref_lbd_compute(vp(gray), W, H, vp(kl), n, vp(ldesc))
+        K, Twc = np.ascontiguousarray(s["K"], np.float64), np.ascontiguousarray(s["Twc"], np.float64)
+        boxes, lines = np.ascontiguousarray(s["boxes"], np.float64).reshape(-1, 5), np.ascontiguousarray(s["lines"], np.float64).reshape(-1, 4)
+        out, cnt = np.zeros((len(boxes), o.max_cuboid_num), po.CUBOID_DTYPE), np.zeros(len(boxes), np.int32)
+        if ref.ref_detect_cuboid(vp(gray), W, H, vp(K), vp(Twc), vp(boxes), len(boxes), vp(lines), len(lines), C.byref(o), vp(out), vp(cnt)) != 0:
+            raise RuntimeError("ref_detect_cuboid failed")
+    frame(scenes[0])
+    t0 = time.perf_counter()
+    n = 0
+    while time.perf_counter() - t0 < budget_s:
+        frame(scenes[n % len(scenes)])
+        n += 1
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "frames/s", "cores": 1, "kind": "reference", "build": "-O3 (prebuilt, generic)",
+            "sample": "%d frames of the same workload in %.1f s through oracle/_ref/libref.so: the reference's ORBextractor.cc, lsd.cpp, LSDDetector.cpp, BinaryDescriptor compute path and "
+                      "detect_cuboid text on the OpenCV / Eigen stand-ins of oracle/ref_shim, 1 thread" % (n, dt)}
 
 
 # ---------------------------------------------------------------------------------------------------------------- HBM traffic (PMC)
@@ -798,6 +841,12 @@ def main():
             out["cpu_baseline"]["host_cores_available"] = cores
             out["cpu_baseline_mt"] = cpu_baseline(scenes[:max(16, cores)], args.yaw_step, flags, budget_s=8.0, with_orb=orb is not None, nfeat=args.orb_features,
                                                   with_lines=lsd is not None, threads=cores)
+            try:
+                rb = cpu_baseline_ref(scenes[:16], args.yaw_step, with_orb=orb is not None, nfeat=args.orb_features, with_lines=lsd is not None)
+            except Exception as e:  # (a checker library that does not load must not cost the line)
+                rb = {"error": "%s: %s" % (type(e).__name__, e)}
+            if rb is not None:
+                out["cpu_baseline_ref"] = rb
         if ba_out is not None:
             out["ba"] = ba_out
         print(json.dumps(out))

@@ -112,6 +112,7 @@ struct cs_frontend {
     cs_ctx *ctx = nullptr; cs_orb *orb = nullptr; cs_cuboid_batch *batch = nullptr;
     cs_ctx *cub_ctx = nullptr; // cs_frontend_set_cuboid_ctx: the context (stream) the cuboid batch is enqueued on -- the caller's own unless set
     std::vector<LineWorker *> workers;
+    int streams = 1, hw_queues = 4; // cs_frontend_queues
     Gate gate;
     // guarded by any_m: the step counter, the pass counters and the packets of chained mode.  Line pass k belongs to step k: passes_started > k once it has been
     // handed to a worker; passes_target: passes [0, passes_target) may be started (a step raises it to its own number + 1, cs_frontend_set_backlog further)
@@ -176,10 +177,26 @@ int cs_frontend_create(cs_ctx *ctx, cs_orb *orb, cs_cuboid_batch *batch, int n_l
         w->th = std::thread([w] { w->loop(); });
         fe->workers.push_back(w);
     }
+    // the runner keeps 1 + 2 W streams busy (the caller's, every worker's and its background stream for the region walk); the HIP runtime maps streams onto
+    // GPU_MAX_HW_QUEUES hardware queues (4 unless the variable was set before the runtime started) and serialises the streams that share one: say so once, loudly
+    fe->streams = 1 + 2 * n_line_workers;
+    { const char *q = getenv("GPU_MAX_HW_QUEUES"); fe->hw_queues = q && atoi(q) > 0 ? atoi(q) : 4; }
+    if (fe->hw_queues < fe->streams) {
+        static bool said = false;
+        if (!said) { said = true; fprintf(stderr, "[cubeslam-hip] cs_frontend_create: %d streams on %d hardware queues (GPU_MAX_HW_QUEUES%s): streams that share a queue run one after the other -- a 100 ms region walk then "
+                                          "stalls another stream's kernels (up to -25 %% measured).  Export GPU_MAX_HW_QUEUES=16 before the HIP runtime starts (INTEGRATION.md).\n", fe->streams, fe->hw_queues, getenv("GPU_MAX_HW_QUEUES") ? "" : " unset: the runtime's default"); }
+    }
     if (fe->batch) cs_cuboid_batch_set_shared_gpu(fe->batch, n_line_workers > 0); // alternating runner: the detectors' region walks hold most CUs all the time
     for (LineWorker *w : fe->workers) cs_lsd_set_shared_gpu(w->lsd, n_line_workers > 1);
     *out = fe;
     return CS_OK;
+}
+
+int cs_frontend_queues(const cs_frontend *fe, int *streams, int *hw_queues) {
+    if (!fe) return CS_ERR_BAD_ARG;
+    if (streams) *streams = fe->streams;
+    if (hw_queues) *hw_queues = fe->hw_queues;
+    return fe->hw_queues >= fe->streams ? 1 : 0;
 }
 
 int cs_frontend_step(cs_frontend *fe) {

@@ -36,6 +36,14 @@ class Frontend:
         """n_steps more step() calls follow on the same frames: their line passes may start as soon as a worker is free (cs_frontend_set_backlog)."""
         check(self.ctx.ptr, lib().cs_frontend_set_backlog(self._fe, int(n_steps)), "cs_frontend_set_backlog")
 
+    def queues(self):
+        """(enough, streams the runner keeps busy, hardware queues of this process) -- cs_frontend_queues."""
+        a, b = C.c_int(0), C.c_int(0)
+        r = lib().cs_frontend_queues(self._fe, C.byref(a), C.byref(b))
+        if r < 0:
+            check(self.ctx.ptr, r, "cs_frontend_queues")
+        return bool(r), a.value, b.value
+
     def step(self):
         check(self.ctx.ptr, lib().cs_frontend_step(self._fe), "cs_frontend_step")
 

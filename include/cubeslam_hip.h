@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define CS_VERSION 106 /* 106: cs_cuboid_batch_n_frames; 105: cs_frontend_set_backlog; 104: cs_frontend_set_cuboid_ctx; 103: cs_lsd_read_filter_lines takes the caller's frame count, cs_frontend_set_chain; 102: cs_cuboid_batch_set_lines, cs_cuboid_batch_set_shared_gpu, cs_lsd_read_filter_lines; 101: cs_ba_set_stop_flag_bool / cs_ba_dyn_set_stop_flag_bool; cs_match_by_projection_frame takes train_blocked */
+#define CS_VERSION 106 /* 106: cs_cuboid_batch_n_frames, cs_frontend_queues; 105: cs_frontend_set_backlog; 104: cs_frontend_set_cuboid_ctx; 103: cs_lsd_read_filter_lines takes the caller's frame count, cs_frontend_set_chain; 102: cs_cuboid_batch_set_lines, cs_cuboid_batch_set_shared_gpu, cs_lsd_read_filter_lines; 101: cs_ba_set_stop_flag_bool / cs_ba_dyn_set_stop_flag_bool; cs_match_by_projection_frame takes train_blocked */
 
 typedef enum cs_status {
     CS_OK = 0,
@@ -453,6 +453,9 @@ int cs_pose_optimization(cs_ctx *ctx, int n_frames, const int *edge_off, const d
 typedef struct cs_frontend cs_frontend;
 int cs_frontend_create(cs_ctx *ctx, cs_orb *orb /* nullable */, cs_cuboid_batch *batch /* nullable */, int n_line_workers, cs_ctx *const *line_ctx,
                        cs_lsd *const *lsd, cs_frontend **out);
+/* 1: the process offers at least as many hardware queues (GPU_MAX_HW_QUEUES as the process saw it at cs_frontend_create, 4 when unset) as the runner keeps streams
+ * busy (1 + 2 per line worker); 0: it does not -- cs_frontend_create has said so on stderr -- and streams that share a queue serialise; < 0: error. */
+int cs_frontend_queues(const cs_frontend *fe, int *streams, int *hw_queues);
 int cs_frontend_step(cs_frontend *fe);
 int cs_frontend_drain(cs_frontend *fe);
 /* Phased passes (off by default; results are the same either way).  With the device region stage of LSD (batches of >= 512 frames) a
