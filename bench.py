@@ -246,12 +246,14 @@ def ba_bench(ctx, rank, world, iters, with_cpu, with_traffic=False):
 
 
 # ---------------------------------------------------------------------------------------------------------------- config 3
-def c3_bench(ctx, frames, steps, with_cpu, with_traffic=False, with_batch_window=0):
+def c3_bench(ctx, frames, steps, with_cpu, with_traffic=False, with_small_window=0, window_match=True):
     """BASELINE config 3: 1241x376 stream (1/f texture moving 3 px per frame), 2000 ORB features + LSD/LBD lines per frame and the
-    tracking thread's frame-to-frame ORBmatcher::SearchByProjection (th = 15) from the extractor's device buffers."""
+    tracking thread's frame-to-frame ORBmatcher::SearchByProjection (th = 15) from the extractor's device buffers.  The stream is cut into windows of `frames` frames
+    (from 512 on the line detector's region stage runs on the device); window_match: the searches of a window's pairs as ONE cs_match_by_projection_stream call instead of
+    five launches per frame issued from Python."""
     from cube_slam_amd import synth
     from cube_slam_amd.lsd import line_lbd_detect
-    from cube_slam_amd.matcher import ORBmatcher
+    from cube_slam_amd.matcher import ORBmatcher, ORBmatcherStream
     from cube_slam_amd.orb import ORBextractor
     W, H = 1241, 376
     fx, fy, cx, cy = 721.5377, 721.5377, 609.5593, 172.854
@@ -269,6 +271,7 @@ def c3_bench(ctx, frames, steps, with_cpu, with_traffic=False, with_batch_window
     lsd = lsds[0]
     fe = Frontend(ctx, orb=orb, batch=None, line_detectors=lsds)
     m = ORBmatcher(0.9, True, ctx=ctx, max_queries=4096)
+    mstream = ORBmatcherStream(True, ctx=ctx) if window_match else None
     K4 = np.array([fx, fy, cx, cy], np.float32)
     bounds = (0.0, float(W), 0.0, float(H))
     sf = np.array([1.2 ** i for i in range(8)], np.float32)
@@ -278,6 +281,14 @@ def c3_bench(ctx, frames, steps, with_cpu, with_traffic=False, with_batch_window
         fe.step()  # ORB of this window here, its line pass (LSD + LBD) on a worker
         per = orb.read()  # key points + descriptors of every frame (the map points' descriptors are host data in the reference too)
         n_q = n_m = 0
+        if mstream is not None:  # the tracking thread's searches of the whole window: key points of frame f-1 projected into frame f (known 3 px shift), every pair in one call
+            pk = np.concatenate([per[f][0] for f in range(frames - 1)])
+            z = np.full(len(pk), 10.0, np.float32)
+            wp = np.stack([(pk["x"] - 3.0 - cx) / fx * z, (pk["y"] - cy) / fy * z, z], axis=1).astype(np.float32)
+            ones = np.ones(len(pk), np.uint8)
+            _, nm = mstream.search(orb, 0, frames - 1, K4, None, bounds, wp, ones, ones, np.broadcast_to(Tcw, (frames - 1, 3, 4)), fx, fy, cx, cy, sf, 15.0,
+                              sum(len(per[f][0]) for f in range(1, frames)))
+            return len(pk), int(nm.sum())
         for f in range(1, frames):  # the tracking thread: key points of frame f-1 projected into frame f (known 3 px shift)
             m.set_frame_from_orb(orb, f, K4, None, bounds)
             pk, pd = per[f - 1]
@@ -315,11 +326,13 @@ def c3_bench(ctx, frames, steps, with_cpu, with_traffic=False, with_batch_window
         c.timing(False)
     n_kp = sum(len(k) for k, _ in orb.read())
     n_lines = sum(len(lsd.read(f, with_desc=False)) for f in range(frames))
-    cstat = m.last_candidate_stats()
+    cstat = m.last_candidate_stats() if mstream is None else mstream.last_counts()
     out = {"metric": "frames/s, 1241x376 stream: ORB 2000 + LSD/LBD + frame-to-frame SearchByProjection", "value": frames * steps / dt, "unit": "frames/s",
            "ms_per_frame": 1e3 * dt / (frames * steps), "frames": frames, "keypoints_per_frame": n_kp / frames, "keylines_per_frame": n_lines / frames,
            "queries_per_pass": n_q, "matches_per_pass": n_m, "kernels_us": kern,
            "region_stage": ("device: one wave per frame (lsd_rg_seq)" if lsd.region_stats()["device"] else "host: %d OpenMP threads" % _lib.lib().cs_host_thread_count()),
+           "matching": ("one cs_match_by_projection_stream call per window: frame post-processing + SearchByProjection of its %d pairs in a handful of launches" % (frames - 1)) if mstream is not None
+                       else "per frame from Python: cs_matcher_set_frame_from_orb + cs_match_by_projection_frame (five launches, three host round trips a frame)",
            "runner": "cs_frontend: ORB + the tracking thread's matching on the caller's context, the line path of the same window on %d worker contexts (a window's region stage "
                      "beside ORB + matching of the next one); %d windows of %d frames timed, drained inside the clock" % (len(lctx), steps, frames)}
     if cand_n and cstat is not None:
@@ -330,7 +343,7 @@ def c3_bench(ctx, frames, steps, with_cpu, with_traffic=False, with_batch_window
         tr = measure_traffic("match_candidates", "pmc_c3.py", [8]) if with_traffic else None  # (its launches on eight frames of the same stream, the local-map launch among them)
         out["roofline"] = {"bound": "hbm", "kernel": "match_candidates", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None if tr is None else tr["bytes"],
                            "traffic_detail": tr, "avg_kernel_us": us, "algorithmic_bytes_per_launch": alg, "queries_per_launch": cstat["queries"], "candidates_per_launch": cstat["candidates"],
-                           "note": "one launch per frame (2000 queries): launch-latency-bound at this size; batching frames is what the stream forbids"}
+                           "note": ("a window's queries per launch; avg_kernel_us averages the counting and the filling pass" if mstream is not None else "one launch per frame (2000 queries): launch-latency-bound at this size")}
     # The kernel at the size TrackLocalMap gives it: ORBmatcher::SearchByProjection(F, vpMapPoints, th) (ORBmatcher.cc:50-142) with a local map of 10 000 points in view
     # of one frame -- the key points of five frames of the stream stand in for the map points (projections, descriptors, predicted levels) -- one launch, no frame loop.
     try:
@@ -402,14 +415,15 @@ def c3_bench(ctx, frames, steps, with_cpu, with_traffic=False, with_batch_window
         out["cpu_baseline_mt"] = {"value": nmt / dtm, "unit": "frames/s", "cores": cores, "kind": "port",
                                   "sample": "%d frames of the same stream in %.1f s, %d threads (frame-parallel ORB + LSD/LBD, no matching)" % (nmt, dtm, cores)}
     m.close()
+    if mstream is not None:
+        mstream.close()
     fe.close()
-    if with_batch_window:
-        # the same stream in windows large enough for the device region stage (what the headline does at 640x480): throughput for a backlog, at a window's latency
+    if with_small_window:
+        # the same stream in windows of two frames per host thread with the per-frame calls: the latency-oriented form (a window's region stage on the host cores), round 4's c3
         for o_ in (orb, *lsds):
             o_.close()
-        bw = c3_bench(ctx, with_batch_window, 4, with_cpu=False)
-        out["batch_window"] = {k: bw[k] for k in ("value", "unit", "ms_per_frame", "frames", "keypoints_per_frame", "keylines_per_frame", "region_stage", "runner", "kernels_us")}
-        out["batch_window"]["note"] = "per-frame matching launches are issued from Python, one frame at a time, inside the clock"
+        bw = c3_bench(ctx, with_small_window, 6, with_cpu=False, window_match=False)
+        out["small_window"] = {k: bw[k] for k in ("value", "unit", "ms_per_frame", "frames", "keypoints_per_frame", "keylines_per_frame", "region_stage", "matching", "runner", "kernels_us")}
     return out
 
 
@@ -752,7 +766,7 @@ def main():
         tr = measure_traffic("cuboid_sweep_score", "pmc_run.py", [args.frames, args.boxes, args.yaw_step, BG_TEXTURE])
         if not args.no_cpu:
             native_oracle()  # the c3 / c4 CPU legs use the -march=native build too
-        extra["c3"] = c3_bench(ctx, 2 * _lib.lib().cs_host_thread_count(), 12, with_cpu=not args.no_cpu, with_traffic=True)  # (with_batch_window=1024: the same stream in device-stage windows -- bound by the per-frame matching loop in Python, not reported)  # a stream window of two frames per host thread (the region stage's workers)
+        extra["c3"] = c3_bench(ctx, 512, 8, with_cpu=not args.no_cpu, with_traffic=True, with_small_window=2 * _lib.lib().cs_host_thread_count())  # windows of 512 frames: the region stage on the device, a window's searches in one call; small_window: two frames per host thread, the per-frame calls (round 4's form)
         extra["c4"] = c4_bench(ctx, 64, 8, args.yaw_step, 10, with_cpu=not args.no_cpu, with_traffic=True)
         if lsd is not None:
             extra["chained"] = chained_bench(ctx, fe, lsds, batch, scenes, args.frames, args.steps, barrier, backlog=bool(args.backlog))

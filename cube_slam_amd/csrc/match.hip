@@ -291,6 +291,160 @@ __global__ void __launch_bounds__(256) match_bow_dists(int NK, const unsigned lo
     for (int p = lane; p < n; p += 64) dists[out_off[ik] + p] = hamming256(descF + (long)node_items[b + p] * 4, a0, a1, a2, a3);
 }
 
+
+// ---- a whole window of a stream at once (cs_match_by_projection_stream): pair p = (last frame f0 + p, current frame f0 + p + 1) of the frames an extractor holds in HBM.
+// Frame post-processing of every current frame and the searches of all pairs in a handful of launches -- the per-frame calls take five launches, six copies and three
+// host round trips per frame, and at 2 000 queries a launch is all latency.  Same arithmetic, same candidate order, same claims as the per-frame calls.
+struct QueryS { float x, y, r; int minLevel, maxLevel, valid, pair; };
+// AssignFeaturesToGrid of the current frames: one workgroup per frame, key points kfirst[p] .. kfirst[p + 1] of `keys`; cell lists relative to the frame
+__global__ void __launch_bounds__(1024) match_grid_batch(FrameP F, const cs_keypoint *keys, const int *kfirst, int *cell_start_all /*P x (NCELL+1)*/, int *cell_items_all, int *kp_cell_all) {
+    __shared__ int cnt[NCELL];
+    __shared__ int s_part[1024];
+    const int tid = threadIdx.x, p = blockIdx.x, kb = kfirst[p], N = kfirst[p + 1] - kb;
+    const cs_keypoint *k = keys + kb;
+    int *cell_start = cell_start_all + (size_t)p * (NCELL + 1), *cell_items = cell_items_all + kb, *kp_cell = kp_cell_all + kb;
+    for (int c = tid; c < NCELL; c += 1024) cnt[c] = 0;
+    __syncthreads();
+    for (int i = tid; i < N; i += 1024) { // PosInGrid, Frame.cc:525-535
+        int px = (int)roundf((k[i].x - F.minX) * F.wInv), py = (int)roundf((k[i].y - F.minY) * F.hInv);
+        int c = (px < 0 || px >= GRID_COLS || py < 0 || py >= GRID_ROWS) ? -1 : px * GRID_ROWS + py;
+        kp_cell[i] = c;
+        if (c >= 0) atomicAdd(&cnt[c], 1);
+    }
+    __syncthreads();
+    int c0 = cnt[tid * 3], c1 = cnt[tid * 3 + 1], c2 = cnt[tid * 3 + 2];
+    s_part[tid] = c0 + c1 + c2;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) {
+        int v = tid >= off ? s_part[tid - off] : 0;
+        __syncthreads();
+        s_part[tid] += v;
+        __syncthreads();
+    }
+    int base = s_part[tid] - (c0 + c1 + c2);
+    cell_start[tid * 3] = base; cell_start[tid * 3 + 1] = base + c0; cell_start[tid * 3 + 2] = base + c0 + c1;
+    if (tid == 1023) cell_start[NCELL] = s_part[1023];
+    __syncthreads();
+    cnt[tid * 3] = base; cnt[tid * 3 + 1] = base + c0; cnt[tid * 3 + 2] = base + c0 + c1;
+    __syncthreads();
+    for (int i = tid; i < N; i += 1024) { int c = kp_cell[i]; if (c >= 0) cell_items[atomicAdd(&cnt[c], 1)] = i; }
+    __syncthreads();
+    for (int c = tid; c < NCELL; c += 1024) { // mGrid[x][y] holds the indices in ascending key point order
+        int b = cell_start[c], e = cnt[c];
+        for (int i = b + 1; i < e; i++) {
+            int v = cell_items[i], j = i - 1;
+            while (j >= b && cell_items[j] > v) { cell_items[j + 1] = cell_items[j]; j--; }
+            cell_items[j + 1] = v;
+        }
+    }
+}
+// the queries of all pairs: query j belongs to pair p with qfirst[p] <= j < qfirst[p + 1]; its level is the last frame's key point's (ORBmatcher.cc:1424)
+__global__ void __launch_bounds__(256) match_project_stream(int nq, int n_pairs, const int *qfirst, const float *world_pos, const uint8_t *valid, const cs_keypoint *last_keys /* raw key points of frame f0 on: query j = last_keys[j] */,
+                                                           const float *T_all, float fx, float fy, float cx, float cy, const float *scale_factors, float th, FrameP F, QueryS *q) {
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    if (i >= nq) return;
+    int lo = 0, hi = n_pairs; // qfirst[lo] <= i < qfirst[hi]
+    while (hi - lo > 1) { const int mid = (lo + hi) >> 1; if (qfirst[mid] <= i) lo = mid; else hi = mid; }
+    const float *T = T_all + 12 * lo;
+    QueryS Q{0, 0, 0, 0, 0, 0, lo};
+    if (valid[i]) {
+        float x3Dc[3];
+        for (int r = 0; r < 3; r++) {
+            double sacc = 0;
+            for (int k = 0; k < 3; k++) sacc += (double)T[r * 4 + k] * (double)world_pos[(size_t)i * 3 + k];
+            x3Dc[r] = (float)(sacc * 1.0 + (double)T[r * 4 + 3] * 1.0);
+        }
+        const float xc = x3Dc[0], yc = x3Dc[1];
+        const float invzc = (float)(1.0 / x3Dc[2]);
+        if (!(invzc < 0)) {
+            float u = fx * xc * invzc + cx;
+            float v = fy * yc * invzc + cy;
+            if (!(u < F.minX || u > F.maxX) && !(v < F.minY || v > F.maxY)) {
+                int o = last_keys[i].octave;
+                Q.x = u; Q.y = v; Q.r = th * scale_factors[o]; Q.minLevel = o - 1; Q.maxLevel = o + 1; Q.valid = 1;
+            }
+        }
+    }
+    q[i] = Q;
+}
+// match_candidates over the queries of every pair: the train frame of pair p is key points kfirst[p] .. of `keys` (undistorted) / `desc`, its cell lists at p x (NCELL + 1) / kfirst[p]
+__global__ void __launch_bounds__(256) match_candidates_stream(FrameP F, const cs_keypoint *keys, const unsigned long long *desc, const int *kfirst, const int *cell_start_all, const int *cell_items_all, int nq,
+                                                               const QueryS *q, const unsigned long long *qdesc, int pass, int *counts, const long *offsets, int2 *cands) {
+    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (qi >= nq) return;
+    const QueryS Q = q[qi];
+    int total = 0;
+    if (Q.valid) {
+        const int kb = kfirst[Q.pair];
+        const cs_keypoint *tk = keys + kb; const unsigned long long *td = desc + (size_t)kb * 4;
+        const int *cell_start = cell_start_all + (size_t)Q.pair * (NCELL + 1), *cell_items = cell_items_all + kb;
+        const float x = Q.x, y = Q.y, r = Q.r;
+        const int nMinCellX = max(0, (int)floorf((x - F.minX - r) * F.wInv));
+        const int nMaxCellX = min(GRID_COLS - 1, (int)ceilf((x - F.minX + r) * F.wInv));
+        const int nMinCellY = max(0, (int)floorf((y - F.minY - r) * F.hInv));
+        const int nMaxCellY = min(GRID_ROWS - 1, (int)ceilf((y - F.minY + r) * F.hInv));
+        if (!(nMinCellX >= GRID_COLS || nMaxCellX < 0 || nMinCellY >= GRID_ROWS || nMaxCellY < 0)) {
+            const bool bCheckLevels = (Q.minLevel > 0) || (Q.maxLevel >= 0);
+            const int ny = nMaxCellY - nMinCellY + 1, ncell = (nMaxCellX - nMinCellX + 1) * ny;
+            unsigned long long d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+            if (pass == 1) { d0 = qdesc[(size_t)qi * 4]; d1 = qdesc[(size_t)qi * 4 + 1]; d2 = qdesc[(size_t)qi * 4 + 2]; d3 = qdesc[(size_t)qi * 4 + 3]; }
+            const long base = pass == 1 ? offsets[qi] : 0;
+            for (int k0 = 0; k0 < ncell; k0 += 64) {
+                const int k = k0 + lane;
+                int b = 0, e = 0;
+                if (k < ncell) { int c = (nMinCellX + k / ny) * GRID_ROWS + nMinCellY + k % ny; b = cell_start[c]; e = cell_start[c + 1]; }
+                int mine = 0;
+                for (int p = b; p < e; p++) {
+                    const cs_keypoint kp = tk[cell_items[p]];
+                    bool ok = true;
+                    if (bCheckLevels) { if (kp.octave < Q.minLevel) ok = false; if (Q.maxLevel >= 0 && kp.octave > Q.maxLevel) ok = false; }
+                    const float distx = kp.x - x, disty = kp.y - y;
+                    ok = ok && fabsf(distx) < r && fabsf(disty) < r;
+                    mine += ok;
+                }
+                int inc = mine;
+                for (int off = 1; off < 64; off <<= 1) { int t = __shfl_up(inc, off); if (lane >= off) inc += t; }
+                if (pass == 1 && mine) {
+                    long o = base + total + inc - mine;
+                    for (int p = b; p < e; p++) {
+                        const int id = cell_items[p];
+                        const cs_keypoint kp = tk[id];
+                        bool ok = true;
+                        if (bCheckLevels) { if (kp.octave < Q.minLevel) ok = false; if (Q.maxLevel >= 0 && kp.octave > Q.maxLevel) ok = false; }
+                        const float distx = kp.x - x, disty = kp.y - y;
+                        ok = ok && fabsf(distx) < r && fabsf(disty) < r;
+                        if (ok) { cands[o] = make_int2(id, hamming256(td + (size_t)id * 4, d0, d1, d2, d3)); o++; }
+                    }
+                }
+                total += __shfl(inc, 63);
+            }
+        }
+    }
+    if (pass == 0 && lane == 0) counts[qi] = total;
+}
+// exclusive scan of n counts into 64-bit offsets (offsets[n] = total): per-block sums, then the blocks' bases, then the fill
+__global__ void __launch_bounds__(1024) match_scan_blocks(int n, const int *counts, long *block_sum) {
+    __shared__ long s[16];
+    const int i = blockIdx.x * 1024 + threadIdx.x;
+    long v = i < n ? counts[i] : 0;
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off);
+    if ((threadIdx.x & 63) == 0) s[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) { long t = 0; for (int k = 0; k < 16; k++) t += s[k]; block_sum[blockIdx.x] = t; }
+}
+__global__ void __launch_bounds__(1024) match_scan_fill(int n, int n_blocks, const int *counts, const long *block_sum, long *offsets) {
+    __shared__ long s[1024];
+    __shared__ long s_base;
+    const int tid = threadIdx.x, i = blockIdx.x * 1024 + tid;
+    if (tid == 0) { long t = 0; for (int b = 0; b < (int)blockIdx.x; b++) t += block_sum[b]; s_base = t; }
+    const long v = i < n ? counts[i] : 0;
+    s[tid] = v;
+    __syncthreads();
+    for (int off = 1; off < 1024; off <<= 1) { const long t = tid >= off ? s[tid - off] : 0; __syncthreads(); s[tid] += t; __syncthreads(); }
+    if (i < n) offsets[i] = s_base + s[tid] - v;
+    if (blockIdx.x == (unsigned)n_blocks - 1 && tid == 1023) offsets[n] = s_base + s[1023];
+}
+
 static void three_maxima(const int *sizes, int L, int &ind1, int &ind2, int &ind3) { // ORBmatcher.cc:1860-1901
     int max1 = 0, max2 = 0, max3 = 0;
     for (int i = 0; i < L; i++) {
@@ -341,6 +495,21 @@ static int run_candidates(cs_ctx *ctx, cs_matcher *m, int nq, bool with_desc) {
     return CS_OK;
 }
 
+struct cs_match_stream {
+    size_t cap_k = 0, cap_q = 0, cap_pairs = 0; long cap_c = 0;
+    cs_keypoint *d_keys = nullptr; int *d_cell_start = nullptr, *d_cell_items = nullptr, *d_kp_cell = nullptr, *d_kfirst = nullptr, *d_qfirst = nullptr, *d_counts = nullptr;
+    long *d_offsets = nullptr, *d_bsum = nullptr; QueryS *d_q = nullptr; int2 *d_cands = nullptr; float *d_wp = nullptr, *d_T = nullptr, *d_sf = nullptr; uint8_t *d_valid = nullptr; unsigned long long *d_qdesc = nullptr;
+    std::vector<cs_keypoint> keys; std::vector<long> offsets; std::vector<int2> cands;
+    long last_q = 0, last_c = 0;
+};
+template <class T> static int ms_grow(cs_ctx *ctx, T **p, size_t *cap, size_t need, size_t unit = 1) { // (cap in elements of `unit` T's; a shared cap is raised by its first array: call in groups)
+    if (*p && need <= *cap) return CS_OK;
+    if (*p) { hipFree(*p); *p = nullptr; }
+    const size_t c = need + need / 4 + 64;
+    const int r = cs_dalloc(ctx, p, c * unit);
+    if (r == CS_OK && cap) *cap = c;
+    return r;
+}
 extern "C" {
 
 void cs_matcher_destroy(cs_ctx *ctx, cs_matcher *m) {
@@ -500,6 +669,127 @@ int cs_match_by_projection_frame(cs_ctx *ctx, cs_matcher *m, int n_last, const f
                 for (int id : rot_items[i]) { train_match[id] = -1; nm--; }
     }
     *nmatches = nm;
+    return CS_OK;
+}
+
+
+// ORBmatcher::SearchByProjection(CurrentFrame, LastFrame, th, bMono) (ORBmatcher.cc:1373-1522) for the pairs (f0 + p, f0 + p + 1), p < n_pairs, of the frames `orb` holds in HBM, with
+// Frame::UndistortKeyPoints + AssignFeaturesToGrid (Frame.cc:303-318, 546-576) of every current frame: see include/cubeslam_hip.h.
+void cs_match_stream_destroy(cs_ctx *ctx, cs_match_stream *m) {
+    if (!m) return;
+    if (ctx) { hipSetDevice(ctx->device); hipStreamSynchronize(ctx->stream); }
+    void *ptrs[] = {m->d_keys, m->d_cell_start, m->d_cell_items, m->d_kp_cell, m->d_kfirst, m->d_qfirst, m->d_counts, m->d_offsets, m->d_bsum, m->d_q, m->d_cands, m->d_wp, m->d_T, m->d_sf, m->d_valid, m->d_qdesc};
+    for (void *p : ptrs) if (p) hipFree(p);
+    delete m;
+}
+int cs_match_stream_create(cs_match_stream **out) {
+    if (!out) return CS_ERR_BAD_ARG;
+    *out = new (std::nothrow) cs_match_stream();
+    return *out ? CS_OK : CS_ERR_NOMEM;
+}
+int cs_match_stream_last_counts(const cs_match_stream *m, long *queries, long *candidates) {
+    if (!m || !queries || !candidates) return CS_ERR_BAD_ARG;
+    *queries = m->last_q; *candidates = m->last_c;
+    return CS_OK;
+}
+int cs_match_by_projection_stream(cs_ctx *ctx, cs_match_stream *m, const cs_orb *orb, int f0, int n_pairs, const float *K4, const float *dist5, float minX, float maxX, float minY, float maxY,
+                                  const float *world_pos, const uint8_t *valid, const uint8_t *blocks, const uint8_t *mp_desc, const float *Tcw, float fx, float fy, float cx, float cy,
+                                  const float *scale_factors, int n_levels, float th, int check_orientation, int *train_match, int *nmatches) {
+    if (!ctx || !m || !orb || n_pairs < 1 || f0 < 0 || !K4 || !(maxX > minX) || !(maxY > minY) || !world_pos || !valid || !blocks || !Tcw || !scale_factors || n_levels < 1 || n_levels > 32 || !train_match || !nmatches)
+        return CS_ERR_BAD_ARG;
+    CS_HIP(ctx, hipSetDevice(ctx->device));
+    // the frames f0 .. f0 + n_pairs lie one behind the other in the extractor's buffers
+    std::vector<int> first((size_t)n_pairs + 2);
+    const cs_keypoint *d_k0 = nullptr; const unsigned long long *d_d0 = nullptr;
+    { int n0 = 0; int r = cs_orb_device_frame(orb, f0, &d_k0, &d_d0, &n0); if (r) return r; first[0] = 0; first[1] = n0; }
+    for (int p = 1; p <= n_pairs; p++) {
+        const cs_keypoint *dk; const unsigned long long *dd; int n = 0;
+        int r = cs_orb_device_frame(orb, f0 + p, &dk, &dd, &n); if (r) return r;
+        if (dk != d_k0 + first[p]) { ctx->err = "cs_match_by_projection_stream: the extractor's frames are not contiguous"; return CS_ERR_BAD_ARG; }
+        first[p + 1] = first[p] + n;
+    }
+    const int nq = first[n_pairs], nk_all = first[n_pairs + 1]; // queries: key points of frames f0 .. f0 + n_pairs - 1; train key points: frames f0 + 1 .. f0 + n_pairs (indices first[1] ..)
+    for (int p = 0; p < n_pairs; p++) nmatches[p] = 0;
+    const int nk = nk_all - first[1];
+    for (int i = 0; i < nk; i++) train_match[i] = -1;
+    m->last_q = nq; m->last_c = 0;
+    if (nq == 0 || nk == 0) return CS_OK;
+    FrameP F; F.N = 0; F.minX = minX; F.maxX = maxX; F.minY = minY; F.maxY = maxY;
+    F.wInv = static_cast<float>(GRID_COLS) / static_cast<float>(maxX - minX); F.hInv = static_cast<float>(GRID_ROWS) / static_cast<float>(maxY - minY);
+    int r;
+#define G_(call) do { r = (call); if (r != CS_OK) return r; } while (0)
+    { size_t c = m->cap_k; G_(ms_grow(ctx, &m->d_keys, &c, (size_t)nk_all)); c = m->cap_k; G_(ms_grow(ctx, &m->d_cell_items, &c, (size_t)nk_all)); G_(ms_grow(ctx, &m->d_kp_cell, &m->cap_k, (size_t)nk_all)); }
+    { size_t c = m->cap_pairs; G_(ms_grow(ctx, &m->d_cell_start, &c, (size_t)n_pairs, (size_t)NCELL + 1)); c = m->cap_pairs; G_(ms_grow(ctx, &m->d_kfirst, &c, (size_t)n_pairs + 2)); c = m->cap_pairs; G_(ms_grow(ctx, &m->d_qfirst, &c, (size_t)n_pairs + 2));
+      G_(ms_grow(ctx, &m->d_T, &m->cap_pairs, (size_t)n_pairs, 12)); }
+    { size_t c = m->cap_q; G_(ms_grow(ctx, &m->d_counts, &c, (size_t)nq)); c = m->cap_q; G_(ms_grow(ctx, &m->d_offsets, &c, (size_t)nq + 1)); c = m->cap_q; G_(ms_grow(ctx, &m->d_bsum, &c, (size_t)nq / 1024 + 2)); c = m->cap_q; G_(ms_grow(ctx, &m->d_q, &c, (size_t)nq));
+      c = m->cap_q; G_(ms_grow(ctx, &m->d_wp, &c, (size_t)nq, 3)); c = m->cap_q; G_(ms_grow(ctx, &m->d_valid, &c, (size_t)nq)); G_(ms_grow(ctx, &m->d_qdesc, &m->cap_q, (size_t)nq, 4)); }
+    if (!m->d_sf) G_(cs_dalloc(ctx, &m->d_sf, (size_t)32));
+    // UndistortKeyPoints of every frame of the window (device to device), AssignFeaturesToGrid of the current frames
+    CS_LAUNCH(ctx, "match_undistort", match_undistort, dim3((nk_all + 255) / 256), dim3(256), 0, nk_all, d_k0, make_undp(K4, dist5), m->d_keys);
+    std::vector<int> kfirst((size_t)n_pairs + 1);
+    for (int p = 0; p <= n_pairs; p++) kfirst[p] = first[p + 1]; // train frame of pair p: key points kfirst[p] .. kfirst[p + 1] of the window's list
+    G_(cs_h2d(ctx, m->d_kfirst, kfirst.data(), (size_t)n_pairs + 1));
+    G_(cs_h2d(ctx, m->d_qfirst, first.data(), (size_t)n_pairs + 1));
+    G_(cs_h2d(ctx, m->d_T, Tcw, (size_t)n_pairs * 12));
+    G_(cs_h2d(ctx, m->d_sf, scale_factors, (size_t)n_levels));
+    G_(cs_h2d(ctx, m->d_wp, world_pos, (size_t)nq * 3));
+    G_(cs_h2d(ctx, m->d_valid, valid, (size_t)nq));
+    if (mp_desc) G_(cs_h2d(ctx, (uint8_t *)m->d_qdesc, mp_desc, (size_t)nq * 32));
+    const unsigned long long *d_qdesc = mp_desc ? m->d_qdesc : d_d0; // NULL: a last frame's key point is matched with its own descriptor
+    CS_LAUNCH(ctx, "match_grid", match_grid_batch, dim3(n_pairs), dim3(1024), 0, F, m->d_keys, m->d_kfirst, m->d_cell_start, m->d_cell_items, m->d_kp_cell);
+    CS_LAUNCH(ctx, "match_project", match_project_stream, dim3((nq + 255) / 256), dim3(256), 0, nq, n_pairs, m->d_qfirst, m->d_wp, m->d_valid, d_k0, m->d_T, fx, fy, cx, cy, m->d_sf, th, F, m->d_q);
+    CS_LAUNCH(ctx, "match_candidates", match_candidates_stream, dim3((nq + 3) / 4), dim3(256), 0, F, m->d_keys, d_d0, m->d_kfirst, m->d_cell_start, m->d_cell_items, nq, m->d_q, d_qdesc, 0, m->d_counts, m->d_offsets, m->d_cands);
+    const int nblk = (nq + 1023) / 1024;
+    CS_LAUNCH(ctx, "match_scan", match_scan_blocks, dim3(nblk), dim3(1024), 0, nq, m->d_counts, m->d_bsum);
+    CS_LAUNCH(ctx, "match_scan", match_scan_fill, dim3(nblk), dim3(1024), 0, nq, nblk, m->d_counts, m->d_bsum, m->d_offsets);
+    m->offsets.resize((size_t)nq + 1);
+    G_(cs_d2h(ctx, m->offsets.data(), m->d_offsets, (size_t)nq + 1));
+    m->keys.resize((size_t)nk_all); // (angles / levels of the candidates for the host pass; also what a caller reads as mvKeysUn)
+    G_(cs_d2h(ctx, m->keys.data(), m->d_keys, (size_t)nk_all));
+    CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int i = 0; i < nq; i++) if (valid[i] && (m->keys[i].octave < 0 || m->keys[i].octave >= n_levels)) return CS_ERR_BAD_ARG;
+    const long total = m->offsets[nq];
+    m->last_c = total;
+    if (total > m->cap_c || !m->d_cands) { if (m->d_cands) hipFree(m->d_cands); m->d_cands = nullptr; m->cap_c = total + total / 4 + 1024; G_(cs_dalloc(ctx, &m->d_cands, (size_t)m->cap_c)); }
+    CS_LAUNCH(ctx, "match_candidates", match_candidates_stream, dim3((nq + 3) / 4), dim3(256), 0, F, m->d_keys, d_d0, m->d_kfirst, m->d_cell_start, m->d_cell_items, nq, m->d_q, d_qdesc, 1, m->d_counts, m->d_offsets, m->d_cands);
+    m->cands.resize((size_t)std::max<long>(total, 1));
+    G_(cs_d2h(ctx, m->cands.data(), m->d_cands, (size_t)total));
+    CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+#undef G_
+    // the sequential greedy pass of every pair (:1397-1494), the pairs side by side
+#pragma omp parallel for schedule(dynamic, 4) num_threads(std::max(1, std::min(ctx->host_threads, n_pairs)))
+    for (int p = 0; p < n_pairs; p++) {
+        int *tm = train_match + (first[p + 1] - first[1]);
+        const cs_keypoint *tkeys = m->keys.data() + first[p + 1];
+        const int q0 = first[p], q1 = first[p + 1];
+        int nm = 0;
+        std::vector<int> rot_items[HISTO_LENGTH];
+        for (int i = q0; i < q1; i++) {
+            const long b = m->offsets[i], e = m->offsets[i + 1];
+            if (e == b) continue;
+            int bestDist = 256, bestIdx2 = -1;
+            for (long c = b; c < e; c++) {
+                const int i2 = m->cands[c].x;
+                if (tm[i2] >= 0 && blocks[q0 + tm[i2]]) continue;
+                const int dist = m->cands[c].y;
+                if (dist < bestDist) { bestDist = dist; bestIdx2 = i2; }
+            }
+            if (bestDist <= TH_HIGH) {
+                tm[bestIdx2] = i - q0;
+                nm++;
+                if (check_orientation) rot_items[rot_bin(m->keys[i].angle, tkeys[bestIdx2].angle)].push_back(bestIdx2);
+            }
+        }
+        if (check_orientation) {
+            int sizes[HISTO_LENGTH], ind1 = -1, ind2 = -1, ind3 = -1;
+            for (int i = 0; i < HISTO_LENGTH; i++) sizes[i] = (int)rot_items[i].size();
+            three_maxima(sizes, HISTO_LENGTH, ind1, ind2, ind3);
+            for (int i = 0; i < HISTO_LENGTH; i++)
+                if (i != ind1 && i != ind2 && i != ind3)
+                    for (int id : rot_items[i]) { tm[id] = -1; nm--; }
+        }
+        nmatches[p] = nm;
+    }
     return CS_OK;
 }
 

@@ -152,6 +152,47 @@ class ORBmatcher:
             pass
 
 
+class ORBmatcherStream:
+    """SearchByProjection(CurrentFrame, LastFrame) for a whole window of a stream that an ORBextractor holds in HBM (cs_match_by_projection_stream)."""
+
+    def __init__(self, mbCheckOrientation=True, ctx=None):
+        self.ctx = ctx
+        self.mbCheckOrientation = bool(mbCheckOrientation)
+        self._m = C.c_void_p()
+        check(ctx.ptr, lib().cs_match_stream_create(C.byref(self._m)), "cs_match_stream_create")
+
+    def search(self, orb, f0, n_pairs, K4, dist5, bounds, world_pos, valid, blocks, Tcw, fx, fy, cx, cy, scale_factors, th, n_train, mp_desc=None):
+        """world_pos / valid / blocks: concatenated over the last frames f0 .. f0 + n_pairs - 1; Tcw: (n_pairs, 3, 4); n_train: key points of frames f0 + 1 .. f0 + n_pairs.
+        Returns (train_match concatenated over the current frames, nmatches per pair)."""
+        k4 = np.ascontiguousarray(K4, np.float32); d5 = None if dist5 is None else np.ascontiguousarray(dist5, np.float32)
+        wp = np.ascontiguousarray(world_pos, np.float32); va = np.ascontiguousarray(valid, np.uint8); bl = np.ascontiguousarray(blocks, np.uint8)
+        T = np.ascontiguousarray(np.asarray(Tcw, np.float32).reshape(n_pairs, -1)[:, :12]); sf = np.ascontiguousarray(scale_factors, np.float32)
+        md = None if mp_desc is None else np.ascontiguousarray(mp_desc, np.uint8)
+        tm = np.zeros(max(int(n_train), 1), np.int32); nm = np.zeros(n_pairs, np.int32)
+        check(self.ctx.ptr, lib().cs_match_by_projection_stream(self.ctx.ptr, self._m, orb._e, int(f0), int(n_pairs), _p(k4, C.c_float), None if d5 is None else _p(d5, C.c_float),
+                                                                C.c_float(bounds[0]), C.c_float(bounds[1]), C.c_float(bounds[2]), C.c_float(bounds[3]), _p(wp, C.c_float), _p(va, C.c_uint8),
+                                                                _p(bl, C.c_uint8), None if md is None else _p(md, C.c_uint8), _p(T, C.c_float), C.c_float(fx), C.c_float(fy), C.c_float(cx),
+                                                                C.c_float(cy), _p(sf, C.c_float), len(sf), C.c_float(th), int(self.mbCheckOrientation), _p(tm, C.c_int), _p(nm, C.c_int)),
+              "cs_match_by_projection_stream")
+        return tm[:int(n_train)], nm
+
+    def last_counts(self):
+        q, c = C.c_long(), C.c_long()
+        check(self.ctx.ptr, lib().cs_match_stream_last_counts(self._m, C.byref(q), C.byref(c)), "cs_match_stream_last_counts")
+        return {"queries": q.value, "candidates": c.value}
+
+    def close(self):
+        if self._m:
+            lib().cs_match_stream_destroy(self.ctx.ptr, self._m)
+            self._m = C.c_void_p()
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
 def hamming_knn2(ctx, q, t):
     q = np.ascontiguousarray(q, np.uint8); t = np.ascontiguousarray(t, np.uint8)
     bi = np.zeros(max(len(q), 1), np.int32); bd = np.zeros(max(len(q), 1), np.int32); sd = np.zeros(max(len(q), 1), np.int32)

@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define CS_VERSION 106 /* 106: cs_cuboid_batch_n_frames, cs_frontend_queues; 105: cs_frontend_set_backlog; 104: cs_frontend_set_cuboid_ctx; 103: cs_lsd_read_filter_lines takes the caller's frame count, cs_frontend_set_chain; 102: cs_cuboid_batch_set_lines, cs_cuboid_batch_set_shared_gpu, cs_lsd_read_filter_lines; 101: cs_ba_set_stop_flag_bool / cs_ba_dyn_set_stop_flag_bool; cs_match_by_projection_frame takes train_blocked */
+#define CS_VERSION 106 /* 106: cs_cuboid_batch_n_frames, cs_frontend_queues, cs_match_by_projection_stream; 105: cs_frontend_set_backlog; 104: cs_frontend_set_cuboid_ctx; 103: cs_lsd_read_filter_lines takes the caller's frame count, cs_frontend_set_chain; 102: cs_cuboid_batch_set_lines, cs_cuboid_batch_set_shared_gpu, cs_lsd_read_filter_lines; 101: cs_ba_set_stop_flag_bool / cs_ba_dyn_set_stop_flag_bool; cs_match_by_projection_frame takes train_blocked */
 
 typedef enum cs_status {
     CS_OK = 0,
@@ -242,6 +242,22 @@ int cs_match_by_projection_frame(cs_ctx *ctx, cs_matcher *m, int n_last, const f
                                  const uint8_t *blocks, const uint8_t *mp_desc, const int *last_octave, const float *last_angle,
                                  const float *Tcw, float fx, float fy, float cx, float cy, const float *scale_factors, int n_levels,
                                  float th, int check_orientation, const uint8_t *train_blocked, int *train_match, int *nmatches);
+/* The same search for a whole WINDOW of a stream whose frames an extractor holds in HBM: pair p = (last frame f0 + p, current frame f0 + p + 1), p < n_pairs.  Frame
+ * post-processing of every current frame (UndistortKeyPoints + AssignFeaturesToGrid, Frame.cc:303-318, 546-576, from the extractor's device buffers) and the searches of all
+ * pairs run as a handful of launches over the window (the per-frame calls take five launches and three host round trips per frame); results equal the per-frame calls'.
+ * Queries: the key points of the last frames, concatenated over the pairs in order (n_q = key points of frames f0 .. f0 + n_pairs - 1): world_pos (3 floats each), valid,
+ * blocks; their level and angle are the last frame's key points' (ORBmatcher.cc:1424, 1483); mp_desc: the map points' descriptors (32 B per query) or NULL = the last
+ * frame's own descriptors.  Tcw: 12 floats per pair.  train_match: concatenated over the current frames f0 + 1 .. f0 + n_pairs (key point counts as the extractor reports
+ * them), the matched query's index WITHIN its last frame or -1; nmatches[n_pairs]. */
+typedef struct cs_match_stream cs_match_stream;
+int cs_match_stream_create(cs_match_stream **out);
+void cs_match_stream_destroy(cs_ctx *ctx, cs_match_stream *m);
+int cs_match_by_projection_stream(cs_ctx *ctx, cs_match_stream *m, const cs_orb *orb, int f0, int n_pairs, const float *K4, const float *dist5 /* nullable */,
+                                  float minX, float maxX, float minY, float maxY, const float *world_pos, const uint8_t *valid, const uint8_t *blocks,
+                                  const uint8_t *mp_desc /* nullable */, const float *Tcw, float fx, float fy, float cx, float cy, const float *scale_factors, int n_levels,
+                                  float th, int check_orientation, int *train_match, int *nmatches);
+/* queries and window candidates of the last call (roofline accounting) */
+int cs_match_stream_last_counts(const cs_match_stream *m, long *queries, long *candidates);
 /* ORBmatcher::SearchByProjection(Frame &F, const vector<MapPoint*>&, th) (:50-142). */
 int cs_match_local_map(cs_ctx *ctx, cs_matcher *m, int n_mp, const float *proj_xy, const float *view_cos, const int *pred_level,
                        const uint8_t *in_view, const uint8_t *blocks, const uint8_t *mp_desc, const float *scale_factors, int n_levels,

@@ -209,6 +209,57 @@ def test_frame_postprocessing_on_device(ctx, oracle):
     orb.close()
 
 
+def test_search_by_projection_over_a_window_equals_the_per_frame_calls(ctx, oracle):
+    """cs_match_by_projection_stream: frame post-processing + SearchByProjection(CurrentFrame, LastFrame) of every pair of a window of the stream the extractor holds, as a
+    handful of launches -- train_match and nmatches of every pair equal the per-frame calls' (set_frame_from_orb + SearchByProjectionFrame) and the oracle's, with and
+    without distortion, with dropped queries, `blocks` cleared for some and the map points' own descriptors given explicitly."""
+    from cube_slam_amd.orb import ORBextractor
+    from cube_slam_amd.matcher import ORBmatcherStream, frame_image_bounds
+    Wt, Ht, NF = 640, 480, 6
+    imgs = synth.texture_stream(31, Wt, Ht, NF, step=3)
+    orb = ORBextractor(1000, 1.2, 8, 20, 7, Wt, Ht, max_frames=NF, ctx=ctx)
+    res = orb.extract_batch(imgs)
+    fx, fy, cx, cy = 517.3, 516.5, 318.6, 255.3
+    K4 = (fx, fy, cx, cy)
+    sf = np.float32(1.2) ** np.arange(8, dtype=np.float32)
+    rng = np.random.default_rng(3)
+    ms = ORBmatcherStream(True, ctx=ctx)
+    for dist in (None, (0.2624, -0.9531, -0.0054, 0.0026, 1.1633)):
+        bounds = tuple(float(b) for b in frame_image_bounds(Wt, Ht, np.array(K4, np.float32), None if dist is None else np.array(dist, np.float32)))
+        for f0, n_pairs, own_desc in ((0, NF - 1, True), (2, 2, False)):
+            wps, vas, bls, Ts, mds = [], [], [], [], []
+            for p in range(n_pairs):
+                pk, pd = res[f0 + p]
+                z = rng.uniform(5.0, 20.0, len(pk)).astype(np.float32)
+                wps.append(np.stack([(pk["x"] - 3.0 - cx) / fx * z, (pk["y"] - cy) / fy * z, z], axis=1).astype(np.float32))
+                vas.append((rng.uniform(size=len(pk)) < 0.9).astype(np.uint8)); bls.append((rng.uniform(size=len(pk)) < 0.8).astype(np.uint8))
+                T = np.eye(4, dtype=np.float32)[:3].copy(); T[0, 3] = 0.01 * p
+                Ts.append(T)
+                mds.append(pd if own_desc else np.roll(pd, 1, axis=0))  # (not own_desc: some other descriptor per map point)
+            n_train = sum(len(res[f0 + p + 1][0]) for p in range(n_pairs))
+            tm, nm = ms.search(orb, f0, n_pairs, K4, dist, bounds, np.concatenate(wps), np.concatenate(vas), np.concatenate(bls), np.stack(Ts), fx, fy, cx, cy, sf, 15.0, n_train,
+                               mp_desc=None if own_desc else np.concatenate(mds))
+            off = 0
+            m = ORBmatcher(0.9, True, ctx=ctx, max_queries=4096)
+            for p in range(n_pairs):
+                pk, pd = res[f0 + p]
+                keysUn, _ = m.set_frame_from_orb(orb, f0 + p + 1, K4, dist, bounds)
+                want, nw = m.SearchByProjectionFrame(wps[p], vas[p], bls[p], mds[p], pk["octave"], pk["angle"], Ts[p], fx, fy, cx, cy, sf, 15.0)
+                got = tm[off:off + len(keysUn)]
+                assert nm[p] == nw and np.array_equal(got, want), (dist is not None, f0, p, nm[p], nw)
+                if p == 0:
+                    Fo = oracle.make_frame(keysUn, res[f0 + p + 1][1], bounds)
+                    otm, onm = oracle.search_by_projection_frame(Fo, wps[p], vas[p], bls[p], mds[p], pk["octave"], pk["angle"], Ts[p], fx, fy, cx, cy, sf, 15.0)
+                    assert onm == nw and np.array_equal(otm, want)
+                assert nw > 100
+                off += len(keysUn)
+            assert off == n_train
+            st = ms.last_counts()
+            assert st["queries"] == sum(len(w) for w in wps) and st["candidates"] > st["queries"]
+            m.close()
+    ms.close(); orb.close()
+
+
 def test_search_by_bow(ctx, oracle, frames):
     """ORBmatcher::SearchByBoW(KeyFrame, Frame): same-node candidates, greedy claims in (node, index) order, ratio test, rotation histogram."""
     (k1, d1), (k2, d2) = frames
