@@ -154,6 +154,67 @@ def cpu_baseline_ref(scenes, yaw_step, budget_s=8.0, with_orb=True, nfeat=1000, 
                       "detect_cuboid text on the OpenCV / Eigen stand-ins of oracle/ref_shim, 1 thread" % (n, dt)}
 
 
+def streamed_bench(fe, ctx, side_ctxs, orb, batch, lsds, gray, steps, warmup, torch):
+    """The front-end with frames that ARRIVE: every step takes 1 024 new frames from pinned host memory through the runner's ring (cs_frontend_stream_*: H2D on a copy stream of
+    its own while the step before computes, device copies into ORB, the cuboid batch and the step's line pass) and its results go back to the host inside the clock -- ORB key
+    points + descriptors (cs_orb_read_packed) and the cuboids (cs_cuboid_batch_read) on the caller's thread at the end of the step, KeyLines + LBD descriptors by the line
+    worker at the end of its pass (they are host data when the pass completes; the drain inside the clock waits for the last pass).  No step repeats another's pixels: set k
+    is the scenes' pixels with the low bit flipped by a pattern of its own (the 2-D boxes, poses and the cuboid plan are external inputs and stay)."""
+    F, H, W = gray.shape
+    n_sets = warmup + steps
+    rng = np.random.default_rng(11)
+    host = torch.empty((n_sets, F, H, W), dtype=torch.uint8, pin_memory=True)
+    sets = host.numpy()
+    for k in range(n_sets):
+        np.bitwise_xor(gray, rng.integers(0, 2, (1, H, W), dtype=np.uint8), out=sets[k])
+    kps_buf = torch.empty((F * orb.cap * 28,), dtype=torch.uint8, pin_memory=True).numpy().view(orb_keypoint_dtype()) if orb is not None else None
+    desc_buf = torch.empty((F * orb.cap, 32), dtype=torch.uint8, pin_memory=True).numpy() if orb is not None else None
+
+    def barrier():
+        fe.drain(); ctx.sync()
+        for c in side_ctxs:
+            c.sync()
+        torch.cuda.synchronize()
+
+    d2h = [0]
+
+    def one(k):
+        if k + 1 < n_sets:
+            fe.stream_push(sets[k + 1])
+        fe.step()
+        if orb is not None:
+            kp, de, _ = orb.read_packed(kps_buf, desc_buf)
+            d2h[0] += kp.nbytes + de.nbytes
+        cub = batch.read()
+        d2h[0] += sum(c.nbytes for c in cub)
+    fe.stream_begin(F, W, H, 3)
+    fe.stream_push(sets[0])
+    for k in range(warmup):
+        one(k)
+    barrier()
+    d2h[0] = 0
+    t0 = time.perf_counter()
+    for k in range(warmup, n_sets):
+        one(k)
+    barrier()
+    dt = time.perf_counter() - t0
+    n_lines = sum(len(lsds[0].read(f, with_desc=False)) for f in range(F)) if lsds else 0
+    line_bytes = n_lines * (72 + 32)  # one pass's KeyLines + descriptors (cs_keyline is 72 B)
+    fe.stream_end()
+    h2d = steps * F * H * W
+    return {"metric": "frames/s front-end with 1 024 NEW frames per step: H2D, ORB + cuboid + line pass, results D2H, all inside the clock", "value": F * steps / dt, "unit": "frames/s",
+            "ms_per_step": 1e3 * dt / steps, "steps": steps, "warmup": warmup,
+            "h2d_GBps": h2d / dt / 1e9, "d2h_GBps": (d2h[0] + steps * line_bytes) / dt / 1e9, "h2d_MB_per_step": F * H * W / 1e6, "d2h_MB_per_step": (d2h[0] / steps + line_bytes) / 1e6,
+            "ring_slots": 3, "distinct_pixel_sets": n_sets,
+            "what": "cs_frontend_stream_push of step k + 1 before cs_frontend_step of step k (pinned memory, a copy stream of its own); every step's pixels differ (low bit flipped by a per-step "
+                    "pattern), boxes / poses / plan stay; ORB + cuboid results read back synchronously at the end of each step, line results by the workers at the end of each pass"}
+
+
+def orb_keypoint_dtype():
+    from cube_slam_amd.orb import KEYPOINT_DTYPE
+    return KEYPOINT_DTYPE
+
+
 # ---------------------------------------------------------------------------------------------------------------- HBM traffic (PMC)
 def measure_traffic(kernel, script, script_args):
     """HBM-side bytes per launch of `kernel` from rocprofv3 --pmc passes of a small script that runs the same workload (tools/pmc_run.py: the
@@ -770,6 +831,10 @@ def main():
         extra["c4"] = c4_bench(ctx, 64, 8, args.yaw_step, 10, with_cpu=not args.no_cpu, with_traffic=True)
         if lsd is not None:
             extra["chained"] = chained_bench(ctx, fe, lsds, batch, scenes, args.frames, args.steps, barrier, backlog=bool(args.backlog))
+            try:
+                extra["streamed"] = streamed_bench(fe, ctx, side_ctxs, orb, batch, lsds, np.stack([s_["gray"] for s_ in scenes]), args.steps, 3, torch)
+            except Exception as e:  # (the block stands beside the headline; a failure must not cost the line)
+                extra["streamed"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
         # the drop-in calls belong to another kind of process than the batch runner: measured in one, with the runtime's default hardware queues (tools/pcie_probe.py)
         try:
             pr = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pcie_probe.py"), "default", str(args.yaw_step), str(args.orb_features)], capture_output=True, text=True, timeout=300, check=True)

@@ -33,6 +33,9 @@ extern "C" int cs_cuboid_batch_run(cs_ctx *ctx, cs_cuboid_batch *b);
 extern "C" int cs_cuboid_batch_set_shared_gpu(cs_cuboid_batch *b, int shared);
 extern "C" int cs_cuboid_batch_set_lines(cs_ctx *ctx, cs_cuboid_batch *b, const int *line_offsets, const double *lines);
 extern "C" int cs_cuboid_batch_n_frames(const cs_cuboid_batch *b);
+extern "C" int cs_cuboid_batch_set_gray_device(cs_ctx *ctx, cs_cuboid_batch *b, const uint8_t *d_gray);
+extern "C" int cs_orb_set_frames_device(cs_ctx *ctx, cs_orb *e, const uint8_t *d_gray, int n_frames);
+extern "C" int cs_lsd_set_frames_device(cs_ctx *ctx, cs_lsd *l, const uint8_t *d_gray, int n_frames);
 int cs_lsd_filter_lines_packed(cs_lsd *l, float length_thres, std::vector<int> &offsets, std::vector<double> &lines); // lsd.hip
 
 struct cs_frontend;
@@ -42,6 +45,18 @@ struct Gate { // phase gate of one runner: tickets are pass numbers, the gate is
     std::mutex m; std::condition_variable cv;
     bool phased = false;
     long submitted = 0, target = 0, done = 0;
+};
+// Streaming source (cs_frontend_stream_*): the frames of step k arrive from the host while step k - 1 computes.  A ring of device slots filled by a copy stream of its own;
+// slot k % n feeds ORB and the cuboid batch of step k (the caller's stream) and line pass k (its worker's stream), each by a device-to-device copy behind the slot's
+// `uploaded` event; a slot is refilled behind the events its consumers recorded -- and, on the host, once line pass k has enqueued its copy.
+struct FrameRing {
+    int n_slots = 0, n_frames = 0; size_t bytes = 0;
+    hipStream_t copy = nullptr;
+    std::vector<uint8_t *> d;
+    std::vector<hipEvent_t> uploaded, used_main, used_line;
+    std::vector<long> main_gen, line_gen; // the step / pass whose copy out of the slot has been enqueued (-1: none yet)
+    std::mutex m; std::condition_variable cv;
+    long pushed = 0, first = 0; // steps first .. pushed - 1 have frames
 };
 struct LineWorker {
     cs_ctx *ctx = nullptr; cs_lsd *lsd = nullptr;
@@ -65,6 +80,7 @@ struct LineWorker {
     bool busy = false, have_job = false, quit = false;
     int last_status = CS_OK;
     cs_frontend *fe = nullptr; long pass_no = -1; // the runner and the number of the pass in flight (set by whoever starts it, under fe->any_m)
+    int take_frames();
     bool after_pass(int r); // hands the pass's lines over (chained mode); true: this worker has taken the next pass of the backlog
     void loop() {
         for (;;) {
@@ -75,7 +91,8 @@ struct LineWorker {
             lk.unlock();
             int r;
             do {
-                r = cs_lsd_run(ctx, lsd, 1);
+                r = take_frames(); // (streaming source: this pass's frames out of their ring slot)
+                if (r == CS_OK) r = cs_lsd_run(ctx, lsd, 1);
                 gate_done(this); // a pass that failed, fell back to the host stage or had nothing to grow never reached the device stage's own call
                 if (r != CS_OK) { std::lock_guard<std::mutex> g(m); if (last_status == CS_OK) last_status = r; }
             } while (after_pass(r));
@@ -113,6 +130,7 @@ struct cs_frontend {
     cs_ctx *cub_ctx = nullptr; // cs_frontend_set_cuboid_ctx: the context (stream) the cuboid batch is enqueued on -- the caller's own unless set
     std::vector<LineWorker *> workers;
     int streams = 1, hw_queues = 4; // cs_frontend_queues
+    FrameRing *ring = nullptr;      // cs_frontend_stream_begin
     Gate gate;
     // guarded by any_m: the step counter, the pass counters and the packets of chained mode.  Line pass k belongs to step k: passes_started > k once it has been
     // handed to a worker; passes_target: passes [0, passes_target) may be started (a step raises it to its own number + 1, cs_frontend_set_backlog further)
@@ -134,7 +152,7 @@ struct cs_frontend {
         in_phase = 0;
         return r;
     }
-    bool may_start() const { return passes_started < passes_target && passes_started < step_no + lead_max(); } // any_m held
+    bool may_start() const { return passes_started < passes_target && passes_started < step_no + lead_max() && (!ring || passes_started < ring->pushed); } // any_m held (ring->pushed only grows, and only on the caller's thread)
     void kick_idle() { // any_m held: free workers take the passes that may be started, looked for from the one behind the last choice (a strict rotation made the caller
                        // wait for a slow pass with idle workers beside it: passes take 110 - 220 ms beside each other)
         for (size_t k = 0; k < workers.size() && may_start(); k++) {
@@ -147,6 +165,17 @@ struct cs_frontend {
 };
 
 namespace {
+int LineWorker::take_frames() {
+    if (!fe || !fe->ring) return CS_OK;
+    FrameRing *R = fe->ring;
+    const int slot = (int)(pass_no % R->n_slots);
+    if (hipSetDevice(ctx->device) != hipSuccess || hipStreamWaitEvent(ctx->stream, R->uploaded[slot], 0) != hipSuccess) return CS_ERR_HIP;
+    int r = cs_lsd_set_frames_device(ctx, lsd, R->d[slot], R->n_frames);
+    if (r == CS_OK && hipEventRecord(R->used_line[slot], ctx->stream) != hipSuccess) r = CS_ERR_HIP;
+    { std::lock_guard<std::mutex> lk(R->m); R->line_gen[slot] = pass_no; }
+    R->cv.notify_all();
+    return r;
+}
 bool LineWorker::after_pass(int r) {
     if (!fe) return false;
     LinePacket pk; bool leave = false;
@@ -202,6 +231,10 @@ int cs_frontend_queues(const cs_frontend *fe, int *streams, int *hw_queues) {
 int cs_frontend_step(cs_frontend *fe) {
     if (!fe) return CS_ERR_BAD_ARG;
     int r = CS_OK;
+    if (fe->ring) { // streaming source: this step's frames must have been pushed (its line pass cannot start without them)
+        std::lock_guard<std::mutex> lk(fe->any_m);
+        if (fe->step_no >= fe->ring->pushed) { fe->ctx->err = "cs_frontend_step: the streaming source holds no frames for this step (cs_frontend_stream_push first)"; return CS_ERR_BAD_ARG; }
+    }
     if (!fe->workers.empty()) {
         const long W = (long)fe->workers.size();
         LinePacket pk; bool have_pk = false;
@@ -231,6 +264,22 @@ int cs_frontend_step(cs_frontend *fe) {
         std::lock_guard<std::mutex> lk(fe->any_m);
         fe->step_no++;
     }
+    if (fe->ring && r == CS_OK) { // streaming source: this step's frames out of their ring slot
+        FrameRing *R = fe->ring;
+        long k; { std::lock_guard<std::mutex> lk(fe->any_m); k = fe->step_no - 1; }
+        const int slot = (int)(k % R->n_slots);
+        cs_ctx *cc = fe->cub_ctx ? fe->cub_ctx : fe->ctx;
+        if (hipStreamWaitEvent(fe->ctx->stream, R->uploaded[slot], 0) != hipSuccess) return CS_ERR_HIP;
+        if (fe->orb) r = cs_orb_set_frames_device(fe->ctx, fe->orb, R->d[slot], R->n_frames);
+        if (r == CS_OK && fe->batch) {
+            if (cc != fe->ctx && hipStreamWaitEvent(cc->stream, R->uploaded[slot], 0) != hipSuccess) return CS_ERR_HIP;
+            r = cs_cuboid_batch_set_gray_device(cc, fe->batch, R->d[slot]);
+            if (r == CS_OK && cc != fe->ctx) { hipEvent_t e = R->used_main[slot]; if (hipEventRecord(e, cc->stream) != hipSuccess || hipStreamWaitEvent(fe->ctx->stream, e, 0) != hipSuccess) return CS_ERR_HIP; }
+        }
+        if (r == CS_OK && hipEventRecord(R->used_main[slot], fe->ctx->stream) != hipSuccess) r = CS_ERR_HIP;
+        { std::lock_guard<std::mutex> lk(R->m); R->main_gen[slot] = k; }
+        if (r != CS_OK) return r;
+    }
     // the cuboid pass is a chain of launches without a host round trip: on a stream of its own (cs_frontend_set_cuboid_ctx) it is enqueued first and runs beside the ORB
     // pass, whose two read-backs would otherwise wait behind it
     if (fe->batch && fe->cub_ctx) r = cs_cuboid_batch_run(fe->cub_ctx, fe->batch);
@@ -249,6 +298,62 @@ int cs_frontend_set_backlog(cs_frontend *fe, int n_steps) {
     if (fe->passes_target < fe->step_no + n_steps) fe->passes_target = fe->step_no + n_steps;
     if (!fe->gate.phased && !fe->workers.empty()) fe->kick_idle();
     return CS_OK;
+}
+
+// ---- streaming source
+static void ring_free(FrameRing *R) {
+    if (!R) return;
+    if (R->copy) { hipStreamSynchronize(R->copy); hipStreamDestroy(R->copy); }
+    for (uint8_t *p : R->d) if (p) hipFree(p);
+    for (auto *v : {&R->uploaded, &R->used_main, &R->used_line}) for (hipEvent_t e : *v) if (e) hipEventDestroy(e);
+    delete R;
+}
+int cs_frontend_stream_begin(cs_frontend *fe, int n_frames, int width, int height, int n_slots) {
+    if (!fe || n_frames < 1 || width < 1 || height < 1 || n_slots < 2 || n_slots > 8 || fe->gate.phased) return CS_ERR_BAD_ARG;
+    int r = cs_frontend_drain(fe);
+    if (r != CS_OK) return r;
+    if (hipSetDevice(fe->ctx->device) != hipSuccess) return CS_ERR_HIP;
+    ring_free(fe->ring); fe->ring = nullptr;
+    FrameRing *R = new FrameRing();
+    R->n_slots = n_slots; R->n_frames = n_frames; R->bytes = (size_t)n_frames * width * height;
+    R->d.assign((size_t)n_slots, nullptr); R->uploaded.assign((size_t)n_slots, nullptr); R->used_main.assign((size_t)n_slots, nullptr); R->used_line.assign((size_t)n_slots, nullptr);
+    R->main_gen.assign((size_t)n_slots, -1); R->line_gen.assign((size_t)n_slots, -1);
+    bool ok = hipStreamCreateWithFlags(&R->copy, hipStreamNonBlocking) == hipSuccess;
+    for (int i = 0; i < n_slots && ok; i++)
+        ok = hipMalloc((void **)&R->d[(size_t)i], R->bytes) == hipSuccess && hipEventCreateWithFlags(&R->uploaded[(size_t)i], hipEventDisableTiming) == hipSuccess &&
+             hipEventCreateWithFlags(&R->used_main[(size_t)i], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&R->used_line[(size_t)i], hipEventDisableTiming) == hipSuccess;
+    if (!ok) { ring_free(R); return CS_ERR_NOMEM; }
+    std::lock_guard<std::mutex> lk(fe->any_m);
+    R->pushed = R->first = fe->step_no; // step numbers go on: the next step takes slot step_no % n_slots
+    fe->ring = R;
+    return CS_OK;
+}
+// The frames of the next step that has none yet (n_frames x height x width bytes; pinned host memory makes the call asynchronous): an H2D copy on the ring's own
+// stream behind everything that still reads the slot.  Blocks only while the line pass that last used the slot has not taken its frames yet.
+int cs_frontend_stream_push(cs_frontend *fe, const uint8_t *gray) {
+    if (!fe || !fe->ring || !gray) return CS_ERR_BAD_ARG;
+    FrameRing *R = fe->ring;
+    if (hipSetDevice(fe->ctx->device) != hipSuccess) return CS_ERR_HIP;
+    const long k = R->pushed; const int slot = (int)(k % R->n_slots); const long prev = k - R->n_slots; // the step that used the slot before
+    {
+        std::unique_lock<std::mutex> lk(fe->any_m);
+        if (k >= fe->step_no + R->n_slots) { fe->ctx->err = "cs_frontend_stream_push: every slot holds frames of a step that has not run"; return CS_ERR_CAPACITY; }
+    }
+    if (prev >= R->first) {
+        if (!fe->workers.empty()) { std::unique_lock<std::mutex> lk(R->m); R->cv.wait(lk, [&] { return R->line_gen[(size_t)slot] >= prev; }); if (hipStreamWaitEvent(R->copy, R->used_line[(size_t)slot], 0) != hipSuccess) return CS_ERR_HIP; }
+        if (hipStreamWaitEvent(R->copy, R->used_main[(size_t)slot], 0) != hipSuccess) return CS_ERR_HIP; // (step prev has run: k < step_no + n_slots)
+    }
+    if (hipMemcpyAsync(R->d[(size_t)slot], gray, R->bytes, hipMemcpyHostToDevice, R->copy) != hipSuccess || hipEventRecord(R->uploaded[(size_t)slot], R->copy) != hipSuccess) return CS_ERR_HIP;
+    { std::lock_guard<std::mutex> lk(fe->any_m); R->pushed = k + 1; if (!fe->gate.phased && !fe->workers.empty()) fe->kick_idle(); }
+    return CS_OK;
+}
+int cs_frontend_stream_end(cs_frontend *fe) {
+    if (!fe) return CS_ERR_BAD_ARG;
+    const int r = cs_frontend_drain(fe);
+    if (fe->ring) { hipStreamSynchronize(fe->ctx->stream); if (fe->cub_ctx) hipStreamSynchronize(fe->cub_ctx->stream); }
+    std::lock_guard<std::mutex> lk(fe->any_m);
+    ring_free(fe->ring); fe->ring = nullptr;
+    return r;
 }
 
 int cs_frontend_set_phased(cs_frontend *fe, int on) {
@@ -307,6 +412,7 @@ void cs_frontend_destroy(cs_frontend *fe) {
         w->th.join();
         delete w;
     }
+    ring_free(fe->ring);
     delete fe;
 }
 

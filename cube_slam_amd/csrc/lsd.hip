@@ -915,6 +915,15 @@ int cs_lsd_upload(cs_ctx *ctx, cs_lsd *l, const uint8_t *gray, int n_frames, int
     return CS_OK;
 }
 
+// the frames of the next run from DEVICE memory (n_frames x H x W bytes): a copy on the context's stream, nothing waits (the streaming front-end's hand-over)
+int cs_lsd_set_frames_device(cs_ctx *ctx, cs_lsd *l, const uint8_t *d_gray, int n_frames) {
+    if (!ctx || !l || !d_gray || n_frames < 1 || n_frames > l->max_frames) return CS_ERR_BAD_ARG;
+    CS_HIP(ctx, hipSetDevice(ctx->device));
+    l->n_frames = n_frames; l->have_desc = false;
+    CS_HIP(ctx, hipMemcpyAsync(l->d_gray, d_gray, (size_t)n_frames * l->W * l->H, hipMemcpyDeviceToDevice, ctx->stream));
+    return CS_OK;
+}
+
 int cs_lsd_run(cs_ctx *ctx, cs_lsd *l, int with_lbd) { return lsd_run(ctx, l, with_lbd); }
 
 int cs_lsd_region_stats(cs_ctx *ctx, cs_lsd *l, long out[5]) {

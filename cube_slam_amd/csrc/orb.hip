@@ -1122,6 +1122,17 @@ int cs_orb_upload(cs_ctx *ctx, cs_orb *e, const uint8_t *gray, int n_frames, int
     return CS_OK;
 }
 
+// The frames of a run from DEVICE memory (n_frames x height rows of `width` bytes, one frame behind the other): a copy on the context's stream, nothing waits.  The
+// streaming front-end (cs_frontend_stream_*) feeds the extractor from the ring slot a copy stream filled.
+int cs_orb_set_frames_device(cs_ctx *ctx, cs_orb *e, const uint8_t *d_gray, int n_frames) {
+    if (!ctx || !e || !d_gray || n_frames < 1 || n_frames > e->max_frames) return CS_ERR_BAD_ARG;
+    CS_HIP(ctx, hipSetDevice(ctx->device));
+    e->n_frames = n_frames;
+    const size_t fb = (size_t)e->W * e->H; // level 0 of frame f sits at f * frame_stride of the pyramid arena, rows of W bytes
+    CS_HIP(ctx, hipMemcpy2DAsync(e->d_pyr, (size_t)e->P.frame_stride, d_gray, fb, fb, (size_t)n_frames, hipMemcpyDeviceToDevice, ctx->stream));
+    return CS_OK;
+}
+
 int cs_orb_run(cs_ctx *ctx, cs_orb *e) {
     if (!ctx || !e || e->n_frames < 1) return CS_ERR_BAD_ARG;
     CS_HIP(ctx, hipSetDevice(ctx->device));
@@ -1251,6 +1262,23 @@ int cs_orb_read(cs_ctx *ctx, cs_orb *e, cs_keypoint *kps, uint8_t *desc, int cap
     }
     CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return status;
+}
+
+// the key points and descriptors of every frame of the last run, one frame behind the other (two copies instead of two per frame): frame f is
+// first[f] .. first[f + 1] (first: n_frames + 1 entries).  *total = key points of the run; CS_ERR_CAPACITY (nothing copied) when cap_total is too small.
+int cs_orb_read_packed(cs_ctx *ctx, cs_orb *e, cs_keypoint *kps, uint8_t *desc, long cap_total, int *first, long *total) {
+    if (!ctx || !e || !first || !total || (int)e->frame_first.size() < e->n_frames + 1) return CS_ERR_BAD_ARG;
+    const int b0 = e->frame_first[0];
+    const long n = e->frame_first[(size_t)e->n_frames] - b0;
+    *total = n;
+    for (int f = 0; f <= e->n_frames; f++) first[f] = e->frame_first[(size_t)f] - b0;
+    if (!kps || !desc) return CS_OK; // size query
+    if (n > cap_total) return CS_ERR_CAPACITY;
+    if (n == 0) return CS_OK;
+    int r = cs_d2h(ctx, kps, e->d_kps + b0, (size_t)n); if (r) return r;
+    r = cs_d2h(ctx, desc, (const uint8_t *)(e->d_desc + (size_t)b0 * 4), (size_t)n * 32); if (r) return r;
+    CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CS_OK;
 }
 
 int cs_orb_extract(cs_ctx *ctx, cs_orb *e, const uint8_t *gray, int n_frames, int stride, cs_keypoint *kps, uint8_t *desc, int cap_per_frame,

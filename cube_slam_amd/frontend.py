@@ -44,6 +44,18 @@ class Frontend:
             check(self.ctx.ptr, r, "cs_frontend_queues")
         return bool(r), a.value, b.value
 
+    def stream_begin(self, n_frames, width, height, n_slots=3):
+        """From now on every step takes its frames from the host through a ring of device slots (cs_frontend_stream_begin)."""
+        check(self.ctx.ptr, lib().cs_frontend_stream_begin(self._fe, int(n_frames), int(width), int(height), int(n_slots)), "cs_frontend_stream_begin")
+
+    def stream_push(self, gray):
+        """The frames (uint8, C-contiguous; pinned memory makes this asynchronous) of the next step that has none yet.  The array must stay alive until that step has run."""
+        assert gray.dtype.name == "uint8" and gray.flags["C_CONTIGUOUS"]
+        check(self.ctx.ptr, lib().cs_frontend_stream_push(self._fe, gray.ctypes.data_as(C.POINTER(C.c_uint8))), "cs_frontend_stream_push")
+
+    def stream_end(self):
+        check(self.ctx.ptr, lib().cs_frontend_stream_end(self._fe), "cs_frontend_stream_end")
+
     def step(self):
         check(self.ctx.ptr, lib().cs_frontend_step(self._fe), "cs_frontend_step")
 

@@ -66,6 +66,20 @@ class ORBextractor:
               "cs_orb_read")
         return [(kps[f, :counts[f]].copy(), desc[f, :counts[f]].copy()) for f in range(F)]
 
+    def read_packed(self, kps=None, desc=None):
+        """(key points of every frame one behind the other, descriptors likewise, first[n_frames + 1]) -- two device-to-host copies for the whole batch (cs_orb_read_packed).
+        kps / desc: caller's buffers to fill (e.g. pinned), at least n_frames * cap entries."""
+        F = self.n_frames
+        first = np.zeros(F + 1, np.int32)
+        total = C.c_long()
+        if kps is None:
+            kps = np.zeros(F * self.cap, KEYPOINT_DTYPE)
+        if desc is None:
+            desc = np.zeros((F * self.cap, 32), np.uint8)
+        check(self.ctx.ptr, lib().cs_orb_read_packed(self.ctx.ptr, self._e, kps.ctypes.data_as(C.c_void_p), desc.ctypes.data_as(C.POINTER(C.c_uint8)), len(kps), _p(first, C.c_int), C.byref(total)),
+              "cs_orb_read_packed")
+        return kps[:total.value], desc[:total.value], first
+
     def extract_batch(self, images):
         self.upload(images)
         self.run()

@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define CS_VERSION 106 /* 106: cs_cuboid_batch_n_frames, cs_frontend_queues, cs_match_by_projection_stream; 105: cs_frontend_set_backlog; 104: cs_frontend_set_cuboid_ctx; 103: cs_lsd_read_filter_lines takes the caller's frame count, cs_frontend_set_chain; 102: cs_cuboid_batch_set_lines, cs_cuboid_batch_set_shared_gpu, cs_lsd_read_filter_lines; 101: cs_ba_set_stop_flag_bool / cs_ba_dyn_set_stop_flag_bool; cs_match_by_projection_frame takes train_blocked */
+#define CS_VERSION 106 /* 106: cs_cuboid_batch_n_frames, cs_frontend_queues, cs_match_by_projection_stream, cs_frontend_stream_*, cs_*_set_frames_device, cs_orb_read_packed; 105: cs_frontend_set_backlog; 104: cs_frontend_set_cuboid_ctx; 103: cs_lsd_read_filter_lines takes the caller's frame count, cs_frontend_set_chain; 102: cs_cuboid_batch_set_lines, cs_cuboid_batch_set_shared_gpu, cs_lsd_read_filter_lines; 101: cs_ba_set_stop_flag_bool / cs_ba_dyn_set_stop_flag_bool; cs_match_by_projection_frame takes train_blocked */
 
 typedef enum cs_status {
     CS_OK = 0,
@@ -201,6 +201,9 @@ int cs_orb_extract(cs_ctx *ctx, cs_orb *e, const uint8_t *gray, int n_frames, in
 int cs_orb_upload(cs_ctx *ctx, cs_orb *e, const uint8_t *gray, int n_frames, int stride);
 int cs_orb_run(cs_ctx *ctx, cs_orb *e);
 int cs_orb_read(cs_ctx *ctx, cs_orb *e, cs_keypoint *kps, uint8_t *desc, int cap_per_frame, int *counts);
+/* The same results packed: every frame's key points / descriptors one frame behind the other, frame f = first[f] .. first[f + 1] (n_frames + 1 entries), two copies
+ * for the whole batch.  kps / desc NULL: only *total and first are filled (size query); CS_ERR_CAPACITY when cap_total < *total. */
+int cs_orb_read_packed(cs_ctx *ctx, cs_orb *e, cs_keypoint *kps, uint8_t *desc, long cap_total, int *first, long *total);
 /* Introspection for parity tests (after run): pyramid level (mvImagePyramid, ORBextractor.h:85) or its blurred copy;
  * the FAST keypoints handed to DistributeOctTree (x, y, response; cell-major order). */
 int cs_orb_get_level(cs_ctx *ctx, cs_orb *e, int frame, int level, int blurred, uint8_t *out, int *w, int *h);
@@ -474,6 +477,20 @@ int cs_frontend_create(cs_ctx *ctx, cs_orb *orb /* nullable */, cs_cuboid_batch 
 int cs_frontend_queues(const cs_frontend *fe, int *streams, int *hw_queues);
 int cs_frontend_step(cs_frontend *fe);
 int cs_frontend_drain(cs_frontend *fe);
+/* Streaming source: the frames of every step arrive from the HOST (main_obj.cpp:420-449 / Frame.cc:320-326 take a new image per call) instead of staying resident.
+ * cs_frontend_stream_begin gives the runner a ring of n_slots (2..8) device slots of n_frames x height x width bytes and a copy stream of its own;
+ * cs_frontend_stream_push(gray) enqueues the H2D copy of the frames of the next step that has none yet (pinned host memory: asynchronous; it waits on the device for the
+ * slot's last readers, on the host only for the line pass that last used the slot to have taken its frames) -- push step k + 1 before calling step k and the upload
+ * overlaps step k; cs_frontend_step then feeds ORB, the cuboid batch (same boxes / poses / plan, new pixels) and the step's line pass from the slot by device copies.
+ * A step without pushed frames is CS_ERR_BAD_ARG, a push with every slot waiting for its step CS_ERR_CAPACITY.  Not with phased passes.  cs_frontend_stream_end drains
+ * and returns to resident frames. */
+int cs_frontend_stream_begin(cs_frontend *fe, int n_frames, int width, int height, int n_slots);
+int cs_frontend_stream_push(cs_frontend *fe, const uint8_t *gray);
+int cs_frontend_stream_end(cs_frontend *fe);
+/* the device-side hand-overs the streaming source uses (a copy on the context's stream, nothing waits): frames one behind the other, rows of `width` bytes */
+int cs_orb_set_frames_device(cs_ctx *ctx, cs_orb *e, const uint8_t *d_gray, int n_frames);
+int cs_lsd_set_frames_device(cs_ctx *ctx, cs_lsd *l, const uint8_t *d_gray, int n_frames);
+int cs_cuboid_batch_set_gray_device(cs_ctx *ctx, cs_cuboid_batch *b, const uint8_t *d_gray);
 /* Phased passes (off by default; results are the same either way).  With the device region stage of LSD (batches of >= 512 frames) a
  * super-step = one pass per line detector: the detectors stop in front of the region stage, and after the last pass of the super-step
  * (or at cs_frontend_drain) the region stages of all of them run together while `ctx`'s stream is idle -- that cs_frontend_step

@@ -205,3 +205,94 @@ def test_frontend_backlog_runs_the_same_passes_ahead_of_the_caller(ctx, oracle):
     assert any(a.tobytes() != b.tobytes() for a, b in zip(got, cub)), "the handed-over lines change some cuboid"
     fe.set_chain(False)
     fe.close()
+
+
+def test_streaming_source_equals_resident_frames(ctx, oracle):
+    """cs_frontend_stream_*: every step takes NEW pixels from the host through the ring (H2D on a copy stream, device copies into ORB, the cuboid batch and the step's line
+    pass).  Five steps over three distinct pixel sets: ORB key points / descriptors, KeyLines / LBD descriptors of every pass and the cuboids equal objects that were
+    created on those pixels; a step without pushed frames and a push beyond the ring are refused."""
+    scenes = [synth.cuboid_scene(700 + i, n_boxes=2) for i in range(4)]
+    base = np.stack([s["gray"] for s in scenes])
+    rng = np.random.default_rng(5)
+    sets = [np.ascontiguousarray(base ^ rng.integers(0, 4, base.shape, dtype=np.uint8)) for _ in range(3)]  # the same geometry, other pixels
+    det = detect_3d_cuboid(ctx); det.set_calibration(scenes[0]["K"])
+    mk = lambda g: CuboidBatch(ctx, g, scenes[0]["K"], np.stack([s["Twc"] for s in scenes]), [s["boxes"] for s in scenes], [s["lines"] for s in scenes], det.opts())  # noqa: E731
+    batch = mk(base)
+    orb = ORBextractor(500, 1.2, 8, 20, 7, 640, 480, max_frames=len(scenes), ctx=ctx); orb.upload(base)
+    lctx = [_lib.Context(0), _lib.Context(0)]
+    lsds = [line_lbd_detect(640, 480, max_frames=len(scenes), ctx=c) for c in lctx]
+    for d in lsds:
+        d.upload(base)
+    fe = Frontend(ctx, orb=orb, batch=batch, line_detectors=lsds)
+    fe.step(); fe.drain()  # (a resident step first: the ring takes over at step 1)
+    fe.stream_begin(len(scenes), 640, 480, n_slots=2)
+    with pytest.raises(Exception):
+        fe.step()  # nothing pushed
+    order = [0, 1, 2, 1, 0]
+    fe.stream_push(sets[order[0]])
+    for k, which in enumerate(order):
+        if k + 1 < len(order):
+            fe.stream_push(sets[order[k + 1]])  # the next step's frames while this one runs
+        if k == 0:
+            with pytest.raises(Exception):
+                fe.stream_push(sets[0])  # both slots hold frames of steps that have not run
+        fe.step()
+        ctx.sync()
+        kps, cub = orb.read(), batch.read()
+        want_b = mk(sets[which]); want_b.run(); want_c = want_b.read(); want_b.close()
+        assert all(a.tobytes() == b.tobytes() for a, b in zip(cub, want_c)), k
+        for f in range(len(scenes)):
+            rk, rd = oracle.ORBextractor(500, 1.2, 8, 20, 7)(sets[which][f])
+            assert kps[f][0].tobytes() == rk.tobytes() and np.array_equal(kps[f][1], rd), (k, f)
+    fe.drain()
+    # the last two passes sit in the two detectors: pass 4 (set order[4]) and pass 3 (set order[3]) -- a pass goes to the first free worker, so look at the pixels it holds
+    seen = set()
+    for d in lsds:
+        got = [d.read(f) for f in range(len(scenes))]
+        hit = [w for w in (order[3], order[4]) if got[0][0].tobytes() == oracle.lsd_detect(sets[w][0]).tobytes()]
+        assert hit, "a detector holds lines of no streamed set"
+        w = hit[0]; seen.add(w)
+        for f in range(len(scenes)):
+            ref_kl = oracle.lsd_detect(sets[w][f])
+            assert got[f][0].tobytes() == ref_kl.tobytes() and np.array_equal(got[f][1], oracle.lbd_compute(sets[w][f], ref_kl))
+    assert seen == {order[3], order[4]}
+    fe.stream_end()
+    fe.step(); fe.drain()  # resident again (the objects keep the last streamed pixels)
+    fe.close(); batch.close(); orb.close()
+    for d in lsds:
+        d.close()
+
+
+def test_phased_passes_with_the_chain(ctx, oracle, monkeypatch):
+    """Phased runner + chained hand-over together (a phased worker still runs rectangles / LBD of pass k - W when step k hands it the next pass; its packet must be
+    filed under ITS number): ten steps complete, and the cuboids from the chained lines equal a batch that was given detect_filter_lines' lists directly."""
+    monkeypatch.setenv("CUBESLAM_LSD_REGIONS", "seq")
+    scenes = [synth.cuboid_scene(800 + i, n_boxes=2) for i in range(4)]
+    gray = np.stack([s["gray"] for s in scenes])
+    det = detect_3d_cuboid(ctx); det.set_calibration(scenes[0]["K"])
+    batch = CuboidBatch(ctx, gray, scenes[0]["K"], np.stack([s["Twc"] for s in scenes]), [s["boxes"] for s in scenes], [s["lines"] for s in scenes], det.opts())
+    lctx = [_lib.Context(0), _lib.Context(0)]
+    lsds = [line_lbd_detect(640, 480, max_frames=len(scenes), ctx=c) for c in lctx]
+    for d in lsds:
+        d.upload(gray)
+    fe = Frontend(ctx, orb=None, batch=batch, line_detectors=lsds, phased=True)
+    fe.set_chain(True, 15.0)
+    import threading
+    done = threading.Event()
+
+    def run():
+        for _ in range(10):
+            fe.step()
+        fe.drain()
+        done.set()
+    th = threading.Thread(target=run, daemon=True); th.start()
+    assert done.wait(120), "phased + chained steps did not complete (the gate never opened)"
+    cub = batch.read()
+    lines = [lsds[0].filter_lines(f, 15.0) if hasattr(lsds[0], "filter_lines") else None for f in range(len(scenes))]
+    if all(l is not None for l in lines):
+        ref_b = CuboidBatch(ctx, gray, scenes[0]["K"], np.stack([s["Twc"] for s in scenes]), [s["boxes"] for s in scenes], lines, det.opts())
+        ref_b.run(); ref = ref_b.read(); ref_b.close()
+        assert all(a.tobytes() == b.tobytes() for a, b in zip(cub, ref))
+    fe.close(); batch.close()
+    for d in lsds:
+        d.close()
