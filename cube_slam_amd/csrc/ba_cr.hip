@@ -293,9 +293,18 @@ template <int BC> __global__ void __launch_bounds__(64 * ((6 * BC + 63) / 64)) b
     const double y = W.y[(long)i * NB + t];
 #pragma unroll
     for (int c = 0; c < NB; c++) { xa_col[c] = a >= 0 ? XA[c * NB] : 0.0; xb_col[c] = b >= 0 ? XB[c * NB] : 0.0; g_col[c] = c >= t ? G[(long)c * NB] : 0.0; }
+    // the hand-over follows the write-through recipe (MI355X_MICROARCH.md, "handoff-flag"): the producer's solution goes out as sc1 (agent-scope relaxed atomic) stores, every
+    // storing wave drains them (s_waitcnt vmcnt(0)), one barrier, then ONE relaxed agent-scope flag store; the consumer polls that flag with relaxed loads and reads the
+    // solution with sc1 loads, which are served past its L1 and its XCD's L2 copy -- no buffer_wbl2 / buffer_inv per level (a __threadfence() is ~3.5 us, an acquire poll
+    // invalidates the L1 on every turn: the way back was 66 us for eight levels of flag round trips)
     if (tid == 0) {
-        if (a >= 0) while (__hip_atomic_load(&W.done[a], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != W.epoch) __builtin_amdgcn_s_sleep(1);
-        if (b >= 0) while (__hip_atomic_load(&W.done[b], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) != W.epoch) __builtin_amdgcn_s_sleep(1);
+        // (a node only waits for nodes with SMALLER workgroup indices, and the dispatcher hands workgroups out in index order, so a waiting workgroup never holds a slot its
+        //  producer needs; should that ever not hold -- the programming model does not promise it -- the spin is bounded: ~0.5 s, then the solve is flagged as failed (status 2)
+        //  instead of hanging the stream)
+        long spins = 0;
+        if (a >= 0) while (__hip_atomic_load(&W.done[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != W.epoch && ++spins < (1L << 22)) __builtin_amdgcn_s_sleep(1);
+        if (b >= 0) while (__hip_atomic_load(&W.done[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != W.epoch && ++spins < (1L << 22)) __builtin_amdgcn_s_sleep(1);
+        if (spins >= (1L << 22)) *W.status = 2;
     }
     __syncthreads();
     if (tid < NB) {
@@ -312,9 +321,13 @@ template <int BC> __global__ void __launch_bounds__(64 * ((6 * BC + 63) / 64)) b
 #pragma unroll
     for (int k = 0; k < NB; k += 2) { x0 += g_col[k] * tv[k]; x1 += g_col[k + 1] * tv[k + 1]; }
     if (tid < NB) __hip_atomic_store(&W.x[(long)i * NB + tid], x0 + x1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#ifdef CR_BACK_FENCE
     __threadfence();
+#else
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's write-through stores have left
+#endif
     __syncthreads();
-    if (tid == 0) __hip_atomic_store(&W.done[i], W.epoch, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    if (tid == 0) __hip_atomic_store(&W.done[i], W.epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
 
 template <int BC> int cr_run(cs_ctx *ctx, const CrView &W) {

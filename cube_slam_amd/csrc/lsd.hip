@@ -184,7 +184,7 @@ __global__ void __launch_bounds__(1024) lsd_scan_add(int *out, int n, const int 
 // PIX (the device region stage one wave per frame, lsd_rg_seq): the kernel also leaves that stage's 16-byte record of EVERY pixel of its segment -- (angle while free, cos, sin, angle)
 // for a defined pixel, (NOTDEF, 0, 0, NOTDEF) for the others -- and the seeds' cos / sin (of the angle as a double, region_grow's start values :651-652) in place of the pixels'
 // own: what lsd_rg_fill + lsd_rg_scatter did in two more passes over the frame, from lists this kernel had just written (c_deg is not written then).
-template <bool PIX> __global__ void __launch_bounds__(256) lsd_emit(const double *modgrad, const float *angles, int w, int h, const int *seg_base, int *c_addr, float *c_deg, float2 *c_cs, double *c_mod, float4 *pix) {
+template <bool PIX> __global__ void __launch_bounds__(256) lsd_emit(const double *modgrad, const float *angles, int w, int h, const int *seg_base, int *c_addr, float *c_deg, float2 *c_cs, double *c_mod, float *fre /* PIX: the region walk's own copy of the angle map, a float per pixel */) {
     __shared__ int wc[4];
     __shared__ short s_x[256];
     __shared__ float s_a[256];
@@ -200,7 +200,7 @@ template <bool PIX> __global__ void __launch_bounds__(256) lsd_emit(const double
         const unsigned long long m = __ballot(def);
         const int wv = threadIdx.x >> 6;
         if ((threadIdx.x & 63) == 0) wc[wv] = __popcll(m);
-        if (PIX && x < w && !def) pix[row + x] = make_float4(NOTDEF_DEG, 0.f, 0.f, NOTDEF_DEG);
+        if (PIX && x < w) fre[row + x] = a;
         __syncthreads();
         if (def) {
             int r = __popcll(m & ((1ull << (threadIdx.x & 63)) - 1));
@@ -233,11 +233,10 @@ template <bool PIX> __global__ void __launch_bounds__(256) lsd_emit(const double
             if (n_theta <= prec) alone = false;
         }
     c_addr[pos] = (y * w + x) | (alone ? (int)0x80000000 : 0);
-    const float pc = glibc_sincosf::cosf_(float(a)), ps = glibc_sincosf::sinf_(float(a));
-    if (PIX) {
-        pix[o] = make_float4(d, pc, ps, d);
+    if (PIX) { // (the device walk computes cos / sin of float(angle) at its window fetches; a seed starts its sums with cos / sin of the angle as a double :651-652)
         c_cs[pos] = make_float2(float(cos(a)), float(sin(a)));
     } else {
+        const float pc = glibc_sincosf::cosf_(float(a)), ps = glibc_sincosf::sinf_(float(a));
         c_deg[pos] = d;
         if (c_mod) c_mod[pos] = modgrad[o]; // (the host stage's copy of the norms; the device stage reads the dense map)
         c_cs[pos] = make_float2(pc, ps);
@@ -668,13 +667,13 @@ static int lsd_run(cs_ctx *ctx, cs_lsd *l, int with_lbd) {
     const int grp_p = strcmp(mode, "wlk") == 0 ? 65 : 0; // lsd_rg_wlk: walker waves with one lane per frame + rectangle waves
     const bool use_seq = total > 0 && (strcmp(mode, "seq") == 0 || grp_p);
     // lsd_rg_seq's records are written by the emit kernel itself when they live in the arena (always, unless a caller's frames outgrew it): no fill, no scatter
-    const bool pix_by_emit = use_seq && grp_p == 0 && l->pix_bytes >= (size_t)F * w * h * 16 && !(getenv("CUBESLAM_LSD_EMIT_PIX") && atoi(getenv("CUBESLAM_LSD_EMIT_PIX")) == 0);
+    const bool pix_by_emit = use_seq && grp_p == 0 && l->pix_bytes >= (size_t)F * w * h * 4 + 64 && !(getenv("CUBESLAM_LSD_EMIT_PIX") && atoi(getenv("CUBESLAM_LSD_EMIT_PIX")) == 0);
     auto emit = [&](bool with_norms) -> int { // the compacted norms (8 B per defined pixel) are the host stage's: the device stage reads the dense map
         if (with_norms && !l->d_cmod) { const int q = cs_dalloc(ctx, &l->d_cmod, l->ccap); if (q) return q; }
         if (pix_by_emit && !with_norms)
-            CS_LAUNCH(ctx, "lsd_emit", lsd_emit<true>, dim3(nbx, h, F), dim3(256), 0, l->d_mod, l->d_ang, w, h, l->d_seg_base, l->d_caddr, l->d_cdeg, l->d_ccs, (double *)nullptr, reinterpret_cast<float4 *>(l->d_tmp));
+            CS_LAUNCH(ctx, "lsd_emit", lsd_emit<true>, dim3(nbx, h, F), dim3(256), 0, l->d_mod, l->d_ang, w, h, l->d_seg_base, l->d_caddr, l->d_cdeg, l->d_ccs, (double *)nullptr, reinterpret_cast<float *>(l->d_tmp));
         else
-            CS_LAUNCH(ctx, "lsd_emit", lsd_emit<false>, dim3(nbx, h, F), dim3(256), 0, l->d_mod, l->d_ang, w, h, l->d_seg_base, l->d_caddr, l->d_cdeg, l->d_ccs, with_norms ? l->d_cmod : (double *)nullptr, (float4 *)nullptr);
+            CS_LAUNCH(ctx, "lsd_emit", lsd_emit<false>, dim3(nbx, h, F), dim3(256), 0, l->d_mod, l->d_ang, w, h, l->d_seg_base, l->d_caddr, l->d_cdeg, l->d_ccs, with_norms ? l->d_cmod : (double *)nullptr, (float *)nullptr);
         return CS_OK;
     };
     if (total > 0) { r = emit(!use_seq); if (r) return r; }
@@ -684,7 +683,7 @@ static int lsd_run(cs_ctx *ctx, cs_lsd *l, int with_lbd) {
         // CUBESLAM_LBD_MAPS=early makes it ahead of the stage in a buffer of its own (the phased runner wants every map kernel of a batch on the GPU before its gate)
         uint8_t *lblur = l->d_lblur;
         uint32_t *dxy = l->d_dxy;
-        if (use_seq) lblur = reinterpret_cast<uint8_t *>(l->d_tmp) + l->pix_bytes; // the blurred frames are the Sobel kernel's input and nothing else
+        if (use_seq) lblur = reinterpret_cast<uint8_t *>(l->d_tmp) + std::max(l->pix_bytes, (size_t)W * H * l->max_frames * 4); // the blurred frames are the Sobel kernel's input and nothing else; behind the walk's map AND behind the Sobel map that is written at the arena's head while they are read (4 B per pixel)
         else if (!lblur) { const int q = cs_dalloc(ctx, &l->d_lblur, (size_t)W * H * l->max_frames); if (q) return q; lblur = l->d_lblur; }
         if (use_seq && late_maps) dxy = reinterpret_cast<uint32_t *>(l->d_tmp);
         else if (!dxy) { const int q = cs_dalloc(ctx, &l->d_dxy, (size_t)W * H * l->max_frames); if (q) return q; dxy = l->d_dxy; }
@@ -843,8 +842,8 @@ int cs_lsd_create(cs_ctx *ctx, int width, int height, int max_frames, cs_lsd **o
     for (int dy = 0; dy < l->h; dy++) { float fy = (float)((dy + 0.5) * sx - 0.5); int s = fl(fy); fy -= s; if (s < 0) { fy = 0; s = 0; } if (s >= height - 1) { fy = 0; s = height - 1; } yofs[dy] = s; ay[dy * 2] = 1.f - fy; ay[dy * 2 + 1] = fy; }
     const size_t N = (size_t)width * height * max_frames, n = (size_t)l->w * l->h * max_frames;
 #define A_(call) do { int r__ = (call); if (r__ != CS_OK) { cs_lsd_destroy(ctx, l); return r__; } } while (0)
-    // one arena for [blurred | scaled] frames; afterwards [pixel records of the device region stage (16 B per scaled pixel) | LBD blur (1 B per pixel)]: 16 n + N <= 8 N + 8 n bytes
-    l->pix_bytes = n * 16;
+    // one arena for [blurred | scaled] frames; afterwards [the device region stage's own copy of the angle map (4 B per scaled pixel) | LBD blur (1 B per pixel)]: 4 n + N <= 8 N + 8 n bytes
+    l->pix_bytes = (n * 4 + 64 + 255) / 256 * 256;
     A_(cs_dalloc(ctx, &l->d_gray, N)); A_(cs_dalloc(ctx, &l->d_tmp, N + n)); l->d_blur = l->d_tmp; l->d_scaled = l->d_tmp + N;
     A_(cs_dalloc(ctx, &l->d_mod, n)); A_(cs_dalloc(ctx, &l->d_ang, n));
     A_(cs_dalloc(ctx, &l->d_xofs, xofs.size())); A_(cs_dalloc(ctx, &l->d_yofs, yofs.size())); A_(cs_dalloc(ctx, &l->d_ax, ax.size())); A_(cs_dalloc(ctx, &l->d_ay, ay.size()));

@@ -249,15 +249,11 @@ __device__ double rg_rect_improve(const AngMap &F, rg::Rect &rec, double LOG_NT,
 struct SeqParams {
     int F, w, h;
     const int *caddr; const int *frame_base; const float *cdeg; const float2 *ccs; const double *mod; const float *ang;
-    rgs::Px *pix; float *ang32; float *seed_cs; int *glist; double *rect; size_t rect_stride; int cand_cap; int *cand_cnt; int *status;
+    float *ang32; float *seed_cs; int *glist; double *rect; size_t rect_stride; int cand_cap; int *cand_cnt; int *status;
     int min_reg_size, list_cap;
     unsigned long long *prof;
-    size_t pix_stride; // elements from one frame's records (pix, or ang32: lsd_rg_wlk's float map) to the next
+    size_t pix_stride; // elements from one frame's map (ang32: the walk's own copy of the angles, a float per pixel: the angle while the pixel is defined and unused) to the next
 };
-__global__ void __launch_bounds__(256) lsd_rg_fill(rgs::Px *pix, size_t n) {
-    const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
-    if (i < n) reinterpret_cast<float4 *>(pix)[i] = make_float4(rgs::NOTDEF_F, 0.f, 0.f, rgs::NOTDEF_F);
-}
 __global__ void __launch_bounds__(256) lsd_rg_fill32(float4 *ang, size_t n4) { // lsd_rg_wlk's map: one float per pixel
     const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
     if (i < n4) ang[i] = make_float4(rgs::NOTDEF_F, rgs::NOTDEF_F, rgs::NOTDEF_F, rgs::NOTDEF_F);
@@ -269,9 +265,7 @@ __global__ void __launch_bounds__(256) lsd_rg_scatter(SeqParams P) {
     if (i >= ne) return;
     const int q = P.caddr[base + i] & 0x7fffffff;
     const float d = P.cdeg[base + i];
-    const float2 cs = P.ccs[base + i];
-    if (P.ang32) P.ang32[(size_t)f * P.pix_stride + q] = d;
-    else reinterpret_cast<float4 *>(P.pix + (size_t)f * P.pix_stride)[q] = make_float4(d, cs.x, cs.y, d);
+    P.ang32[(size_t)f * P.pix_stride + q] = d;
     const double a = double(d) * rg::DEG_TO_RADS; // the map value (:566); region_grow starts a region's sums with cos / sin of it as a double (:651-652)
     reinterpret_cast<float2 *>(P.seed_cs)[base + i] = make_float2(float(cos(a)), float(sin(a)));
 }
@@ -287,7 +281,7 @@ __device__ __forceinline__ void lsd_rg_seq_body(const SeqParams &P) {
     const int base = P.frame_base[f];
     rgs::Frame Fr;
     Fr.w = P.w; Fr.h = P.h; Fr.ne = P.frame_base[f + 1] - base;
-    Fr.caddr = P.caddr + base; Fr.pix = P.pix + (size_t)f * P.pix_stride; Fr.mod = P.mod + (size_t)f * P.w * P.h; Fr.seed_cs = P.seed_cs + 2 * (size_t)base;
+    Fr.caddr = P.caddr + base; Fr.fre = P.ang32 + (size_t)f * P.pix_stride; Fr.ang = P.ang + (size_t)f * P.w * P.h; Fr.mod = P.mod + (size_t)f * P.w * P.h; Fr.seed_cs = P.seed_cs + 2 * (size_t)base;
     Fr.rect = P.rect + (size_t)f * P.rect_stride; Fr.cand_cap = P.cand_cap; Fr.cand_cnt = P.cand_cnt + f;
     Fr.status = P.status + 4 * f; Fr.min_reg_size = P.min_reg_size; Fr.list_cap = P.list_cap; Fr.prof = P.prof ? P.prof + 16 * (size_t)f : nullptr;
     rgs::List L;
@@ -435,7 +429,7 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(RG_IMP
 // ---- host side of the sequential stage ----------------------------------------------------------------------------------------------------
 struct LsdSeq {
     int F = 0, w = 0, h = 0; int cand_cap = 0; size_t cap_lines = 0;
-    rgs::Px *d_pix = nullptr; bool pix_borrowed = false; // (borrowed: the caller's scratch, not freed here)
+    float *d_pix = nullptr; bool pix_borrowed = false; // lsd_rg_seq's map, a float per pixel (borrowed: the caller's scratch, not freed here)
     rgl::Ent *d_elist = nullptr; float *d_ang32 = nullptr; int *d_order = nullptr; // the lane-per-frame walk (lsd_rg_wlk): region lists of 8-byte entries, a float per pixel, the frames sorted by work
     int *d_glist = nullptr, *d_cand_cnt = nullptr, *d_cand_base = nullptr, *d_status = nullptr, *d_frame_base = nullptr;
     double *d_rect = nullptr, *d_lgt = nullptr;
@@ -482,7 +476,7 @@ int lsd_seq_run(cs_ctx *ctx, LsdSeq **handle, int F, int w, int h, const float *
     RA_(cs_h2d(ctx, r->d_frame_base, frame_base, (size_t)F + 1));
     SeqParams S;
     S.F = F; S.w = w; S.h = h; S.caddr = d_caddr; S.frame_base = r->d_frame_base; S.cdeg = d_cdeg; S.ccs = d_ccs; S.mod = d_mod; S.ang = d_ang;
-    S.pix = r->d_pix; S.ang32 = nullptr; S.seed_cs = reinterpret_cast<float *>(const_cast<float2 *>(d_ccs)); /* in place: lsd_rg_scatter reads a pixel's cos / sin (floats of the float angle) and leaves the seed's (of the double angle) in the same 8 bytes */ S.glist = r->d_glist; S.rect = r->d_rect; S.cand_cap = r->cand_cap; S.cand_cnt = r->d_cand_cnt; S.status = r->d_status;
+    S.ang32 = nullptr; S.seed_cs = reinterpret_cast<float *>(const_cast<float2 *>(d_ccs)); /* in place: lsd_rg_scatter reads a pixel's cos / sin (floats of the float angle) and leaves the seed's (of the double angle) in the same 8 bytes */ S.glist = r->d_glist; S.rect = r->d_rect; S.cand_cap = r->cand_cap; S.cand_cnt = r->d_cand_cnt; S.status = r->d_status;
     const double LOG_NT = 5 * (std::log10(double(w)) + std::log10(double(h))) / 2 + std::log10(11.0);
     S.min_reg_size = int(-LOG_NT / std::log10(rg::ANG_TH / 180));
     S.list_cap = rgs::CAP;
@@ -507,13 +501,13 @@ int lsd_seq_run(cs_ctx *ctx, LsdSeq **handle, int F, int w, int h, const float *
         CS_LAUNCH(ctx, "lsd_rg_fill", lsd_rg_fill32, dim3((unsigned)(((npx + head) / 4 + 1 + 255) / 256)), dim3(256), 0, reinterpret_cast<float4 *>(r->d_ang32), (npx + head) / 4 + 1);
     } else {
         if (!r->d_pix) {
-            if (scratch && scratch_bytes >= (size_t)r->F * w * h * sizeof(rgs::Px)) { r->d_pix = static_cast<rgs::Px *>(scratch); r->pix_borrowed = true; }
-            else RA_(cs_dalloc(ctx, &r->d_pix, (size_t)r->F * w * h));
+            if (scratch && scratch_bytes >= (size_t)r->F * w * h * sizeof(float) + 64) { r->d_pix = static_cast<float *>(scratch); r->pix_borrowed = true; }
+            else RA_(cs_dalloc(ctx, &r->d_pix, (size_t)r->F * w * h + 16));
         }
         if (!r->d_glist) RA_(cs_dalloc(ctx, &r->d_glist, (size_t)r->F * rgs::CAP));
-        S.pix = r->d_pix; S.glist = r->d_glist;
+        S.ang32 = r->d_pix; S.glist = r->d_glist;
         if (pix_ready && !r->pix_borrowed) { ctx->err = "lsd_seq_run: the pixel records were announced in the scratch buffer, but the stage does not use it for this batch"; return CS_ERR_BAD_ARG; }
-        if (!pix_ready) CS_LAUNCH(ctx, "lsd_rg_fill", lsd_rg_fill, dim3((unsigned)((npx + 255) / 256)), dim3(256), 0, r->d_pix, npx);
+        if (!pix_ready) CS_LAUNCH(ctx, "lsd_rg_fill", lsd_rg_fill32, dim3((unsigned)((npx / 4 + 1 + 255) / 256)), dim3(256), 0, reinterpret_cast<float4 *>(r->d_pix), npx / 4 + 1);
     }
     if (!pix_ready) CS_LAUNCH(ctx, "lsd_rg_scatter", lsd_rg_scatter, dim3((max_ne + 255) / 256, F), dim3(256), 0, S);
     int wpb = std::max(1, std::min(16, waves_per_workgroup)); // waves (= frames) per workgroup

@@ -3,7 +3,8 @@
 // Nothing is speculated; the 64 lanes serve the latency of the sequence instead:
 //   * the seed loop fetches the state of 64 seeds at a time and keeps it current in registers (every accepted pixel is compared with the 64
 //     seed addresses), so a seed that an earlier region swallowed costs no memory round trip;
-//   * region_grow works on two 8 x 8 windows of pixel records held in the lanes' registers (one 16-byte load per lane); a list pixel inside a
+//   * region_grow works on two 8 x 8 windows of the pixel map held in the lanes' registers (one 4-byte load per lane: the map is ONE FLOAT per pixel, the level-line
+//     angle in float degrees while the pixel is defined and unused; cos / sin of a window's pixels are computed in place at the fetch, glibc's values); a list pixel inside a
 //     window is expanded without touching memory, its nine tests in the reference's order; an accepted pixel is struck from the windows and
 //     changes the region angle for the tests after it -- one ballot + two lane reads + the fastAtan2 polynomial per accepted pixel.  The
 //     windows outlive the region: the wave is the only writer of its frame's map, and the next seed is usually next door;
@@ -14,6 +15,7 @@
 // values are PerLane<T>, per-lane code sits in W::each bodies, everything else is wave-uniform.
 // A body must not read what another lane's part of the SAME body writes (on the device the lanes run it together).
 #pragma once
+#include "glibc_sincosf.h"
 #include <algorithm>
 #include <cfloat>
 #include <climits>
@@ -64,12 +66,12 @@ using rg::u64;
 constexpr float NOTDEF_F = -1024.0f;
 constexpr int CAP = 32768; // pixels of one region (its list lives in global memory); a larger region sends the batch to the host stage
 
-struct Px { float free_deg, c, s, deg; }; // level-line angle in degrees while the pixel is defined and unused (else NOTDEF_F); cos / sin of float(angle); the angle whatever the use
 
 struct Frame {
     int w, h, ne;
     const int *caddr;   // defined pixels in address order (bit 31: lsd_emit's "stays alone as a seed" flag)
-    Px *pix;            // dense w*h
+    float *fre;         // dense w*h, the walk's own: the level-line angle in float degrees while the pixel is defined and unused, NOTDEF_F otherwise (used = NOTDEF_F)
+    const float *ang;   // dense w*h, read-only: the angle whatever the use (lsd_gradient's map) -- what a release puts back
     const double *mod;  // dense gradient norms
     const float *seed_cs; // per rank: float(cos(angle)), float(sin(angle)) of the pixel's angle as a double -- what a seed starts its sums with (:651-652)
     double *rect; int cand_cap; int *cand_cnt; // the rectangles (12 doubles each, rg::Rect) that reach rect_improve, in seed order
@@ -112,9 +114,8 @@ struct Wave { // the 64 lanes of the calling wave
     static __device__ __forceinline__ void sync() { __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "wavefront"); }
     static __device__ __forceinline__ int uni(int v) { return __builtin_amdgcn_readfirstlane(v); } // a value every lane holds (tells the compiler so)
 };
-__device__ __forceinline__ Px ld_px(const Px *p) { const float4 v = *reinterpret_cast<const float4 *>(p); return Px{v.x, v.y, v.z, v.w}; }
-__device__ __forceinline__ void st_free(Px *p, float v) { __hip_atomic_store(&p->free_deg, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
-__device__ __forceinline__ float ld_free(const Px *p) { return __hip_atomic_load(&p->free_deg, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ void st_free(float *p, float v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
+__device__ __forceinline__ float ld_free(const float *p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP); }
 __device__ __forceinline__ int ctz64(u64 m) { return __ffsll((long long)m) - 1; }
 #else
 template <class T> struct PerLane {
@@ -132,9 +133,8 @@ struct Wave { // host model: the lanes of a body run one after the other
     static RGS_FN int uni(int v) { return v; }
     static RGS_FN double uni(double v) { return v; }
 };
-RGS_FN Px ld_px(const Px *p) { return *p; }
-RGS_FN void st_free(Px *p, float v) { p->free_deg = v; }
-RGS_FN float ld_free(const Px *p) { return p->free_deg; }
+RGS_FN void st_free(float *p, float v) { *p = v; }
+RGS_FN float ld_free(const float *p) { return *p; }
 RGS_FN int ctz64(u64 m) { return __builtin_ctzll(m); }
 #endif
 
@@ -197,7 +197,14 @@ template <class W> RGS_FN void win_fetch(const Frame &F, Win &w, int wx, int wy)
     W::each([&](int l) {
         const int xx = wx + (l & 7), yy = wy + (l >> 3);
         w.ar[l] = FAR; w.pc[l] = 0; w.ps[l] = 0;
-        if (xx >= 0 && xx < F.w && yy >= 0 && yy < F.h) { const Px r = ld_px(&F.pix[xx + yy * F.w]); w.ar[l] = r.free_deg == NOTDEF_F ? FAR : double(r.free_deg) * rg::DEG_TO_RADS; w.pc[l] = r.c; w.ps[l] = r.s; }
+        if (xx >= 0 && xx < F.w && yy >= 0 && yy < F.h) {
+            const float fd = ld_free(&F.fre[xx + yy * F.w]);
+            const bool fr = fd != NOTDEF_F;
+            const double a = double(fr ? fd : 0.f) * rg::DEG_TO_RADS; // the map value (:566)
+            float sn, cc;
+            glibc_sincosf::sincosf_pos(float(a), &sn, &cc); // cos(float(angle)), sin(float(angle)) :676-677 with glibc's values, for the 64 pixels at once
+            w.ar[l] = fr ? a : FAR; w.pc[l] = cc; w.ps[l] = sn;
+        }
     });
 #if defined(RGS_PROFILE) && defined(__HIP_DEVICE_COMPILE__)
     { PerLane<bool> z; W::each([&](int l) { z[l] = w.ar[l] == 12345.0; }); if (W::ballot(z)) w.wx = WIN_NONE; } // (the data has to arrive inside the timed part)
@@ -234,7 +241,7 @@ template <class W> RGS_FN void expand(const Frame &F, Win &w, Win &other, int px
         if (n >= F.list_cap) { overflow = true; return; }
         PerLane<bool> hit;
         W::each([&](int l) {
-            if (l == l0) { st_free(&F.pix[cs], NOTDEF_F); L.glob[n] = xy_pack(cx, cy); w.ar[l] = FAR; }
+            if (l == l0) { st_free(&F.fre[cs], NOTDEF_F); L.glob[n] = xy_pack(cx, cy); w.ar[l] = FAR; }
             if (l == (n & (RGS_RING - 1))) L.ring[l] = xy_pack(cx, cy);
             hit[l] = S.sa[l] == cs;
         });
@@ -258,7 +265,7 @@ template <class W> RGS_FN void grow(const Frame &F, Wins &V, List &L, int &n, do
     V.a.am_ok = false; V.b.am_ok = false;
     {
         PerLane<bool> hit;
-        W::each([&](int l) { if (l == 0) { L.glob[0] = xy_pack(sx, sy); L.ring[l] = xy_pack(sx, sy); st_free(&F.pix[saddr], NOTDEF_F); } hit[l] = S.sa[l] == saddr; });
+        W::each([&](int l) { if (l == 0) { L.glob[0] = xy_pack(sx, sy); L.ring[l] = xy_pack(sx, sy); st_free(&F.fre[saddr], NOTDEF_F); } hit[l] = S.sa[l] == saddr; });
         S.freem &= ~W::ballot(hit);
         win_strike<W>(V.a, sx, sy); win_strike<W>(V.b, sx, sy);
     }
@@ -350,9 +357,8 @@ template <class W> RGS_FN bool refine(const Frame &F, Wins &V, List &L, int &n, 
             near[l] = false; d[l] = 0; dd[l] = 0;
             if (idx < n) {
                 const int q = L.glob[idx], qx = q & 0xffff, qy = q >> 16;
-                Px *px = &F.pix[qx + qy * F.w];
-                const float dg = px->deg;
-                st_free(px, dg); // :800 used = NOTUSED
+                const float dg = F.ang[qx + qy * F.w];
+                st_free(&F.fre[qx + qy * F.w], dg); // :800 used = NOTUSED
                 if (rg::dist(xc, yc, double(qx), double(qy)) < rec.width) { const double a = rg::angle_diff_signed(double(dg) * rg::DEG_TO_RADS, ang_c); d[l] = a; dd[l] = a * a; near[l] = true; }
             }
         });
@@ -377,7 +383,7 @@ template <class W> RGS_FN bool refine(const Frame &F, Wins &V, List &L, int &n, 
             const double ddx = double(q & 0xffff) - xc, ddy = double(q >> 16) - yc;
             if (ddx * ddx + ddy * ddy > radSq) {
                 const int last = W::uni(L.glob[n - 1]);
-                W::each([&](int l) { if (l == 0) { Px *px = &F.pix[xy_addr(q, F.w)]; st_free(px, px->deg); L.glob[i] = last; L.glob[n - 1] = q; } });
+                W::each([&](int l) { if (l == 0) { const int ad = xy_addr(q, F.w); st_free(&F.fre[ad], F.ang[ad]); L.glob[i] = last; L.glob[n - 1] = q; } });
                 W::sync();
                 --n; --i;
             }
@@ -406,7 +412,7 @@ template <class W> RGS_FN void run_frame(const Frame &F, List &L) {
         W::each([&](int l) {
             const int idx = i0 + l;
             S.sa[l] = -1; iso[l] = 0; sxy[l] = 0; dg[l] = NOTDEF_F; sc[l] = 0; ss[l] = 0; fr[l] = false;
-            if (idx < F.ne) { const int ca = F.caddr[idx]; S.sa[l] = ca & 0x7fffffff; iso[l] = ca < 0; { const int yy = S.sa[l] / F.w; sxy[l] = xy_pack(S.sa[l] - yy * F.w, yy); } const Px r = ld_px(&F.pix[S.sa[l]]); sc[l] = F.seed_cs[2 * idx]; ss[l] = F.seed_cs[2 * idx + 1]; dg[l] = r.deg; fr[l] = r.free_deg != NOTDEF_F; }
+            if (idx < F.ne) { const int ca = F.caddr[idx]; S.sa[l] = ca & 0x7fffffff; iso[l] = ca < 0; { const int yy = S.sa[l] / F.w; sxy[l] = xy_pack(S.sa[l] - yy * F.w, yy); } sc[l] = F.seed_cs[2 * idx]; ss[l] = F.seed_cs[2 * idx + 1]; dg[l] = F.ang[S.sa[l]]; fr[l] = ld_free(&F.fre[S.sa[l]]) != NOTDEF_F; }
         });
         S.freem = W::ballot(fr);
         RGS_T1(4);
@@ -414,7 +420,7 @@ template <class W> RGS_FN void run_frame(const Frame &F, List &L) {
         int pos = 0;
         while (pos < 64) {
             if (reload) { // a refinement gave pixels back: some of the seeds ahead may be free again
-                W::each([&](int l) { fr[l] = S.sa[l] >= 0 && ld_free(&F.pix[S.sa[l]]) != NOTDEF_F; });
+                W::each([&](int l) { fr[l] = S.sa[l] >= 0 && ld_free(&F.fre[S.sa[l]]) != NOTDEF_F; });
                 S.freem = W::ballot(fr);
                 reload = false;
             }
@@ -424,7 +430,7 @@ template <class W> RGS_FN void run_frame(const Frame &F, List &L) {
             pos = j + 1;
             const int saddr = W::bc(S.sa, j), sq = W::bc(sxy, j), sx = sq & 0xffff, sy = sq >> 16;
             if (W::bc(iso, j)) { // no neighbour is aligned with this pixel's own angle: a region of one pixel
-                W::each([&](int l) { if (l == j) st_free(&F.pix[saddr], NOTDEF_F); });
+                W::each([&](int l) { if (l == j) st_free(&F.fre[saddr], NOTDEF_F); });
                 win_strike<W>(V.a, sx, sy); win_strike<W>(V.b, sx, sy);
                 S.freem &= ~(1ull << j);
                 continue;

@@ -35,15 +35,15 @@ int main(int argc, char **argv) {
             rect_true.push_back(rec);
         }
     }
-    // what lsd_emit hands over: float degrees, cosf / sinf of float(angle), the "stays alone" flag
-    vector<rgs::Px> pix(N, rgs::Px{rgs::NOTDEF_F, 0.f, 0.f, rgs::NOTDEF_F});
+    // what lsd_emit hands over: the map of float degrees (the walk's own copy and the read-only one), the seeds' cos / sin, the "stays alone" flag
+    vector<float> fre(N, rgs::NOTDEF_F), ang(N, rgs::NOTDEF_F);
     vector<float> seed_cs(2 * (size_t)caddr.size());
     for (int i = 0; i < ne; i++) {
         const int q = caddr[i]; const double a = L.angles[q];
         float d = (float)(a / DEG_TO_RADS);
         if ((double)d * DEG_TO_RADS != a) { const float up = nextafterf(d, 1e9f), dn = nextafterf(d, -1e9f); d = ((double)up * DEG_TO_RADS == a) ? up : dn; }
         if ((double)d * DEG_TO_RADS != a) { printf("angle %d is not a float degree\n", q); return 3; }
-        pix[q] = rgs::Px{d, cosf(float(a)), sinf(float(a)), d};
+        fre[q] = d; ang[q] = d;
         seed_cs[2 * i] = float(cos(a)); seed_cs[2 * i + 1] = float(sin(a));
         bool alone = true;
         const int x = q % w, y = q / w;
@@ -61,11 +61,11 @@ int main(int argc, char **argv) {
     rgs::List Llist; Llist.glob = Lglob.data();
     vector<double> rect((size_t)12 * ne); int cand_cnt = 0;
     rgs::Frame F;
-    F.w = w; F.h = h; F.ne = ne; F.caddr = caddr.data(); F.pix = pix.data(); F.mod = L.modgrad.data(); F.seed_cs = seed_cs.data(); F.rect = rect.data(); F.cand_cap = ne; F.cand_cnt = &cand_cnt;
+    F.w = w; F.h = h; F.ne = ne; F.caddr = caddr.data(); F.fre = fre.data(); F.ang = ang.data(); F.mod = L.modgrad.data(); F.seed_cs = seed_cs.data(); F.rect = rect.data(); F.cand_cap = ne; F.cand_cnt = &cand_cnt;
     F.status = status.data(); F.min_reg_size = min_reg_size; F.list_cap = rgs::CAP;
     rgs::run_frame<rgs::Wave>(F, Llist);
     long wrong_used = 0;
-    for (int q = 0; q < N; q++) if (L.angles[q] != NOTDEF) { const bool u = pix[q].free_deg == rgs::NOTDEF_F; if (u != (L.used[q] != 0)) wrong_used++; }
+    for (int q = 0; q < N; q++) if (L.angles[q] != NOTDEF) { const bool u = fre[q] == rgs::NOTDEF_F; if (u != (L.used[q] != 0)) wrong_used++; }
     long n_c = cand_cnt, bad_c = 0;
     static_assert(sizeof(Rect) == 12 * sizeof(double), "");
     for (int k = 0; k < cand_cnt && k < (int)rect_true.size(); k++) if (memcmp(&rect_true[k], &rect[(size_t)12 * k], sizeof(Rect)) != 0) bad_c++; // the rectangles, bit for bit, in seed order
