@@ -157,7 +157,7 @@ def cpu_baseline_ref(scenes, yaw_step, budget_s=8.0, with_orb=True, nfeat=1000, 
 def streamed_bench(fe, ctx, side_ctxs, orb, batch, lsds, gray, steps, warmup, torch):
     """The front-end with frames that ARRIVE: every step takes 1 024 new frames from pinned host memory through the runner's ring (cs_frontend_stream_*: H2D on a copy stream of
     its own while the step before computes, device copies into ORB, the cuboid batch and the step's line pass) and its results go back to the host inside the clock -- ORB key
-    points + descriptors (cs_orb_read_packed) and the cuboids (cs_cuboid_batch_read) on the caller's thread at the end of the step, KeyLines + LBD descriptors by the line
+    points + descriptors and the cuboids on a second copy stream behind the step's kernels (cs_frontend_stream_read_async), KeyLines + LBD descriptors by the line
     worker at the end of its pass (they are host data when the pass completes; the drain inside the clock waits for the last pass).  No step repeats another's pixels: set k
     is the scenes' pixels with the low bit flipped by a pattern of its own (the 2-D boxes, poses and the cuboid plan are external inputs and stay)."""
     F, H, W = gray.shape
@@ -167,10 +167,16 @@ def streamed_bench(fe, ctx, side_ctxs, orb, batch, lsds, gray, steps, warmup, to
     sets = host.numpy()
     for k in range(n_sets):
         np.bitwise_xor(gray, rng.integers(0, 2, (1, H, W), dtype=np.uint8), out=sets[k])
-    kps_buf = torch.empty((F * orb.cap * 28,), dtype=torch.uint8, pin_memory=True).numpy().view(orb_keypoint_dtype()) if orb is not None else None
-    desc_buf = torch.empty((F * orb.cap, 32), dtype=torch.uint8, pin_memory=True).numpy() if orb is not None else None
+    from cube_slam_amd.cuboid import CUBOID_DTYPE
+    pin = lambda nbytes: torch.empty((nbytes,), dtype=torch.uint8, pin_memory=True).numpy()  # noqa: E731
+    bufs = []
+    for _ in range(2):  # two sets of result buffers: step k's copies land while step k - 1's are the caller's
+        bufs.append({"kps": pin(F * orb.cap * 28).view(orb_keypoint_dtype()) if orb is not None else None, "desc": pin(F * orb.cap * 32).reshape(-1, 32) if orb is not None else None,
+                     "cub": pin(batch.n_boxes * batch.max_cuboid_num * CUBOID_DTYPE.itemsize).view(CUBOID_DTYPE).reshape(batch.n_boxes, batch.max_cuboid_num),
+                     "cnt": pin(4 * batch.n_boxes).view(np.int32)})
 
     def barrier():
+        fe.stream_read_wait()
         fe.drain(); ctx.sync()
         for c in side_ctxs:
             c.sync()
@@ -182,11 +188,10 @@ def streamed_bench(fe, ctx, side_ctxs, orb, batch, lsds, gray, steps, warmup, to
         if k + 1 < n_sets:
             fe.stream_push(sets[k + 1])
         fe.step()
-        if orb is not None:
-            kp, de, _ = orb.read_packed(kps_buf, desc_buf)
-            d2h[0] += kp.nbytes + de.nbytes
-        cub = batch.read()
-        d2h[0] += sum(c.nbytes for c in cub)
+        fe.stream_read_wait()  # the copies of step k - 1 (long done: its buffers are the caller's now)
+        b = bufs[k & 1]
+        _, total = fe.stream_read_async(b["kps"], b["desc"], b["cub"], b["cnt"])
+        d2h[0] += total * (28 + 32) + b["cub"].nbytes + b["cnt"].nbytes
     fe.stream_begin(F, W, H, 3)
     fe.stream_push(sets[0])
     for k in range(warmup):
@@ -207,7 +212,8 @@ def streamed_bench(fe, ctx, side_ctxs, orb, batch, lsds, gray, steps, warmup, to
             "h2d_GBps": h2d / dt / 1e9, "d2h_GBps": (d2h[0] + steps * line_bytes) / dt / 1e9, "h2d_MB_per_step": F * H * W / 1e6, "d2h_MB_per_step": (d2h[0] / steps + line_bytes) / 1e6,
             "ring_slots": 3, "distinct_pixel_sets": n_sets,
             "what": "cs_frontend_stream_push of step k + 1 before cs_frontend_step of step k (pinned memory, a copy stream of its own); every step's pixels differ (low bit flipped by a per-step "
-                    "pattern), boxes / poses / plan stay; ORB + cuboid results read back synchronously at the end of each step, line results by the workers at the end of each pass"}
+                    "pattern), boxes / poses / plan stay; ORB + cuboid results copied to pinned host buffers on a second copy stream behind each step's kernels (cs_frontend_stream_read_async; the next step's kernels wait for "
+                    "the copies on the device), line results by the workers at the end of each pass"}
 
 
 def orb_keypoint_dtype():

@@ -2151,6 +2151,16 @@ int cs_cuboid_batch_read(cs_ctx *ctx, cs_cuboid_batch *b, cs_cuboid *out, int *c
     return CS_OK;
 }
 
+// cs_cuboid_batch_read's copies on a stream of the caller's choice, nothing waits; *status_out is valid once the stream has passed them
+int cs_cuboid_batch_read_on(cs_cuboid_batch *b, void *stream, cs_cuboid *out, int *counts, int *status_out) {
+    if (!b || !out || !counts || !status_out) return CS_ERR_BAD_ARG;
+    hipStream_t s = (hipStream_t)stream;
+    if (hipMemcpyAsync(out, b->d_out, sizeof(cs_cuboid) * (size_t)b->n_boxes * b->o.max_cuboid_num, hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipMemcpyAsync(counts, b->d_counts, sizeof(int) * (size_t)b->n_boxes, hipMemcpyDeviceToHost, s) != hipSuccess ||
+        hipMemcpyAsync(status_out, b->d_status, sizeof(int), hipMemcpyDeviceToHost, s) != hipSuccess) return CS_ERR_HIP;
+    return CS_OK;
+}
+
 int cs_cuboid_batch_stats(cs_ctx *ctx, cs_cuboid_batch *b, long *n_units, long *roi_pixels, long *n_hypotheses, long *n_valid) {
     if (!ctx || !b) return CS_ERR_BAD_ARG;
     std::vector<UnitDyn> ud(b->n_units);

@@ -36,6 +36,8 @@ extern "C" int cs_cuboid_batch_n_frames(const cs_cuboid_batch *b);
 extern "C" int cs_cuboid_batch_set_gray_device(cs_ctx *ctx, cs_cuboid_batch *b, const uint8_t *d_gray);
 extern "C" int cs_orb_set_frames_device(cs_ctx *ctx, cs_orb *e, const uint8_t *d_gray, int n_frames);
 extern "C" int cs_lsd_set_frames_device(cs_ctx *ctx, cs_lsd *l, const uint8_t *d_gray, int n_frames);
+extern "C" int cs_orb_read_packed_on(cs_orb *e, void *stream, cs_keypoint *kps, uint8_t *desc, long cap_total, int *first, long *total);
+extern "C" int cs_cuboid_batch_read_on(cs_cuboid_batch *b, void *stream, cs_cuboid *out, int *counts, int *status_out);
 int cs_lsd_filter_lines_packed(cs_lsd *l, float length_thres, std::vector<int> &offsets, std::vector<double> &lines); // lsd.hip
 
 struct cs_frontend;
@@ -51,7 +53,8 @@ struct Gate { // phase gate of one runner: tickets are pass numbers, the gate is
 // `uploaded` event; a slot is refilled behind the events its consumers recorded -- and, on the host, once line pass k has enqueued its copy.
 struct FrameRing {
     int n_slots = 0, n_frames = 0; size_t bytes = 0;
-    hipStream_t copy = nullptr;
+    hipStream_t copy = nullptr, copy_out = nullptr; // H2D of the frames; D2H of a step's results (cs_frontend_stream_read_async)
+    hipEvent_t step_done = nullptr, cub_done = nullptr, results_out = nullptr; bool results_pending = false; int *h_status = nullptr;
     std::vector<uint8_t *> d;
     std::vector<hipEvent_t> uploaded, used_main, used_line;
     std::vector<long> main_gen, line_gen; // the step / pass whose copy out of the slot has been enqueued (-1: none yet)
@@ -270,6 +273,9 @@ int cs_frontend_step(cs_frontend *fe) {
         const int slot = (int)(k % R->n_slots);
         cs_ctx *cc = fe->cub_ctx ? fe->cub_ctx : fe->ctx;
         if (hipStreamWaitEvent(fe->ctx->stream, R->uploaded[slot], 0) != hipSuccess) return CS_ERR_HIP;
+        if (R->results_pending) { // the copies of the step before read what this step overwrites
+            if (hipStreamWaitEvent(fe->ctx->stream, R->results_out, 0) != hipSuccess || (cc != fe->ctx && hipStreamWaitEvent(cc->stream, R->results_out, 0) != hipSuccess)) return CS_ERR_HIP;
+        }
         if (fe->orb) r = cs_orb_set_frames_device(fe->ctx, fe->orb, R->d[slot], R->n_frames);
         if (r == CS_OK && fe->batch) {
             if (cc != fe->ctx && hipStreamWaitEvent(cc->stream, R->uploaded[slot], 0) != hipSuccess) return CS_ERR_HIP;
@@ -304,6 +310,9 @@ int cs_frontend_set_backlog(cs_frontend *fe, int n_steps) {
 static void ring_free(FrameRing *R) {
     if (!R) return;
     if (R->copy) { hipStreamSynchronize(R->copy); hipStreamDestroy(R->copy); }
+    if (R->copy_out) { hipStreamSynchronize(R->copy_out); hipStreamDestroy(R->copy_out); }
+    for (hipEvent_t e : {R->step_done, R->cub_done, R->results_out}) if (e) hipEventDestroy(e);
+    if (R->h_status) hipHostFree(R->h_status);
     for (uint8_t *p : R->d) if (p) hipFree(p);
     for (auto *v : {&R->uploaded, &R->used_main, &R->used_line}) for (hipEvent_t e : *v) if (e) hipEventDestroy(e);
     delete R;
@@ -318,7 +327,9 @@ int cs_frontend_stream_begin(cs_frontend *fe, int n_frames, int width, int heigh
     R->n_slots = n_slots; R->n_frames = n_frames; R->bytes = (size_t)n_frames * width * height;
     R->d.assign((size_t)n_slots, nullptr); R->uploaded.assign((size_t)n_slots, nullptr); R->used_main.assign((size_t)n_slots, nullptr); R->used_line.assign((size_t)n_slots, nullptr);
     R->main_gen.assign((size_t)n_slots, -1); R->line_gen.assign((size_t)n_slots, -1);
-    bool ok = hipStreamCreateWithFlags(&R->copy, hipStreamNonBlocking) == hipSuccess;
+    bool ok = hipStreamCreateWithFlags(&R->copy, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&R->copy_out, hipStreamNonBlocking) == hipSuccess &&
+              hipEventCreateWithFlags(&R->step_done, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&R->cub_done, hipEventDisableTiming) == hipSuccess &&
+              hipEventCreateWithFlags(&R->results_out, hipEventDisableTiming) == hipSuccess && hipHostMalloc((void **)&R->h_status, sizeof(int), hipHostMallocDefault) == hipSuccess;
     for (int i = 0; i < n_slots && ok; i++)
         ok = hipMalloc((void **)&R->d[(size_t)i], R->bytes) == hipSuccess && hipEventCreateWithFlags(&R->uploaded[(size_t)i], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&R->used_main[(size_t)i], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&R->used_line[(size_t)i], hipEventDisableTiming) == hipSuccess;
@@ -347,8 +358,33 @@ int cs_frontend_stream_push(cs_frontend *fe, const uint8_t *gray) {
     { std::lock_guard<std::mutex> lk(fe->any_m); R->pushed = k + 1; if (!fe->gate.phased && !fe->workers.empty()) fe->kick_idle(); }
     return CS_OK;
 }
+// The results of the step that has just been enqueued -- ORB key points / descriptors packed like cs_orb_read_packed, the cuboids like cs_cuboid_batch_read (either may be
+// NULL) -- copied to the caller's (pinned) buffers on a copy stream of the ring, behind the step's kernels: the call returns at once, the NEXT step's kernels wait on the
+// device for the copies before they overwrite what is being read, and cs_frontend_stream_read_wait blocks the host until the copies of the last call have arrived.
+int cs_frontend_stream_read_async(cs_frontend *fe, cs_keypoint *kps, uint8_t *desc, long cap_total, int *first, long *total, cs_cuboid *cuboids, int *counts) {
+    if (!fe || !fe->ring) return CS_ERR_BAD_ARG;
+    FrameRing *R = fe->ring;
+    if (hipSetDevice(fe->ctx->device) != hipSuccess) return CS_ERR_HIP;
+    if (hipEventRecord(R->step_done, fe->ctx->stream) != hipSuccess || hipStreamWaitEvent(R->copy_out, R->step_done, 0) != hipSuccess) return CS_ERR_HIP;
+    if (fe->cub_ctx && (hipEventRecord(R->cub_done, fe->cub_ctx->stream) != hipSuccess || hipStreamWaitEvent(R->copy_out, R->cub_done, 0) != hipSuccess)) return CS_ERR_HIP;
+    int r = CS_OK;
+    if (fe->orb && kps && desc) { if (!first || !total) return CS_ERR_BAD_ARG; r = cs_orb_read_packed_on(fe->orb, R->copy_out, kps, desc, cap_total, first, total); }
+    if (r == CS_OK && fe->batch && cuboids && counts) r = cs_cuboid_batch_read_on(fe->batch, R->copy_out, cuboids, counts, R->h_status);
+    if (hipEventRecord(R->results_out, R->copy_out) != hipSuccess) return CS_ERR_HIP;
+    R->results_pending = true;
+    return r;
+}
+int cs_frontend_stream_read_wait(cs_frontend *fe) {
+    if (!fe || !fe->ring) return CS_ERR_BAD_ARG;
+    FrameRing *R = fe->ring;
+    if (!R->results_pending) return CS_OK;
+    if (hipEventSynchronize(R->results_out) != hipSuccess) return CS_ERR_HIP;
+    if (fe->batch && *R->h_status != 0) { fe->ctx->err = "more than CS_MAX_ROI_LINES lines inside one box"; const int st = *R->h_status; *R->h_status = 0; return st; }
+    return CS_OK;
+}
 int cs_frontend_stream_end(cs_frontend *fe) {
     if (!fe) return CS_ERR_BAD_ARG;
+    if (fe->ring && fe->ring->results_pending) hipEventSynchronize(fe->ring->results_out);
     const int r = cs_frontend_drain(fe);
     if (fe->ring) { hipStreamSynchronize(fe->ctx->stream); if (fe->cub_ctx) hipStreamSynchronize(fe->cub_ctx->stream); }
     std::lock_guard<std::mutex> lk(fe->any_m);

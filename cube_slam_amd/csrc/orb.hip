@@ -1281,6 +1281,20 @@ int cs_orb_read_packed(cs_ctx *ctx, cs_orb *e, cs_keypoint *kps, uint8_t *desc, 
     return CS_OK;
 }
 
+// cs_orb_read_packed's copies on a stream of the caller's choice, nothing waits (the streaming front-end reads a step's results on its own copy stream behind an event)
+int cs_orb_read_packed_on(cs_orb *e, void *stream, cs_keypoint *kps, uint8_t *desc, long cap_total, int *first, long *total) {
+    if (!e || !first || !total || !kps || !desc || (int)e->frame_first.size() < e->n_frames + 1) return CS_ERR_BAD_ARG;
+    const int b0 = e->frame_first[0];
+    const long n = e->frame_first[(size_t)e->n_frames] - b0;
+    *total = n;
+    for (int f = 0; f <= e->n_frames; f++) first[f] = e->frame_first[(size_t)f] - b0;
+    if (n > cap_total) return CS_ERR_CAPACITY;
+    if (n == 0) return CS_OK;
+    if (hipMemcpyAsync(kps, e->d_kps + b0, sizeof(cs_keypoint) * (size_t)n, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return CS_ERR_HIP;
+    if (hipMemcpyAsync(desc, e->d_desc + (size_t)b0 * 4, (size_t)n * 32, hipMemcpyDeviceToHost, (hipStream_t)stream) != hipSuccess) return CS_ERR_HIP;
+    return CS_OK;
+}
+
 int cs_orb_extract(cs_ctx *ctx, cs_orb *e, const uint8_t *gray, int n_frames, int stride, cs_keypoint *kps, uint8_t *desc, int cap_per_frame,
                    int *counts) {
     int r = cs_orb_upload(ctx, e, gray, n_frames, stride);

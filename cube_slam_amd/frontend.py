@@ -53,6 +53,23 @@ class Frontend:
         assert gray.dtype.name == "uint8" and gray.flags["C_CONTIGUOUS"]
         check(self.ctx.ptr, lib().cs_frontend_stream_push(self._fe, gray.ctypes.data_as(C.POINTER(C.c_uint8))), "cs_frontend_stream_push")
 
+    def stream_read_async(self, kps=None, desc=None, cuboids=None, counts=None):
+        """The results of the step just enqueued into the caller's (pinned) arrays, on a copy stream behind the step's kernels (cs_frontend_stream_read_async): kps
+        (KEYPOINT_DTYPE) / desc ((n, 32) uint8) packed over the frames, cuboids ((n_boxes, max_cuboid_num) CUBOID_DTYPE) / counts (int32).  Returns (first, total) of the
+        packed key points (or None).  stream_read_wait() before the arrays are read."""
+        import numpy as np
+        first, total = None, C.c_long(0)
+        if kps is not None:
+            first = np.zeros(self.orb.n_frames + 1, np.int32)
+        check(self.ctx.ptr, lib().cs_frontend_stream_read_async(self._fe, None if kps is None else kps.ctypes.data_as(C.c_void_p), None if desc is None else desc.ctypes.data_as(C.POINTER(C.c_uint8)),
+                                                                0 if kps is None else len(kps), None if first is None else first.ctypes.data_as(C.POINTER(C.c_int)), C.byref(total),
+                                                                None if cuboids is None else cuboids.ctypes.data_as(C.c_void_p), None if counts is None else counts.ctypes.data_as(C.POINTER(C.c_int))),
+              "cs_frontend_stream_read_async")
+        return first, total.value
+
+    def stream_read_wait(self):
+        check(self.ctx.ptr, lib().cs_frontend_stream_read_wait(self._fe), "cs_frontend_stream_read_wait")
+
     def stream_end(self):
         check(self.ctx.ptr, lib().cs_frontend_stream_end(self._fe), "cs_frontend_stream_end")
 

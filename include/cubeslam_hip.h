@@ -487,6 +487,12 @@ int cs_frontend_drain(cs_frontend *fe);
 int cs_frontend_stream_begin(cs_frontend *fe, int n_frames, int width, int height, int n_slots);
 int cs_frontend_stream_push(cs_frontend *fe, const uint8_t *gray);
 int cs_frontend_stream_end(cs_frontend *fe);
+/* The results of the step that has just been enqueued, copied to the caller's (pinned) buffers on a copy stream of the ring behind the step's kernels: ORB key points /
+ * descriptors packed like cs_orb_read_packed (first / total are filled at once), the cuboids like cs_cuboid_batch_read; either pair may be NULL.  Returns at once; the next
+ * step's kernels wait on the device for the copies before they overwrite what is read; cs_frontend_stream_read_wait blocks until the copies of the last call have arrived
+ * (and reports the batch's status).  One call per step at most. */
+int cs_frontend_stream_read_async(cs_frontend *fe, cs_keypoint *kps, uint8_t *desc, long cap_total, int *first, long *total, cs_cuboid *cuboids, int *counts);
+int cs_frontend_stream_read_wait(cs_frontend *fe);
 /* the device-side hand-overs the streaming source uses (a copy on the context's stream, nothing waits): frames one behind the other, rows of `width` bytes */
 int cs_orb_set_frames_device(cs_ctx *ctx, cs_orb *e, const uint8_t *d_gray, int n_frames);
 int cs_lsd_set_frames_device(cs_ctx *ctx, cs_lsd *l, const uint8_t *d_gray, int n_frames);
