@@ -883,8 +883,8 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": None if tr is None else tr["bytes"], "traffic_detail": tr, "avg_kernel_us": k_us,
                          "frac_by_traffic": None if tr is None or k_us <= 0 else tr["bytes"] / (k_us * 1e-6) / 1e9 / HBM_PEAK_GBS,  # the bytes that crossed HBM (PMC) over the same time
                          "peak_note": "peak = 8000 GB/s, the spec figure of MI355X_MICROARCH.md; a device copy reaches 6290 GB/s on this part: frac x 1.27 is the fraction of that",
-                         "limiter": "vector-ALU issue, not HBM: one launch is 151.6 M wave-instructions (profiles/r03_pmc_sweep_score.txt: f64 sample addressing, six f64 atan2, corner "
-                                    "construction), 247 us at one instruction per SIMD per 4 cycles -- `bound` stays \"hbm\" because SURVEY 8d prices this kernel in bytes",
+                         "limiter": "vector-ALU issue, not HBM: one launch is 144.1 M vector + 14.5 M scalar wave-instructions (profiles/r05_pmc_sweep_score.txt; per 64-proposal task ~2 180: f64 sample addressing "
+                                    "and decode ~1 380, six f64 atan2 ~340, corner construction ~400), 235 us at one vector instruction per SIMD per 4 cycles -- `bound` stays \"hbm\" because SURVEY 8d prices this kernel in bytes",
                          "algorithmic_bytes_per_launch": alg_bytes,
                          "algorithmic_bytes_formula": "4*A + 200*n_valid (SURVEY 8d, fused K3+K4: float distance-map ROI read once + the reference's 25 doubles per valid proposal)",
                          "accountings": {
