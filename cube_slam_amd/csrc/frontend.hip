@@ -59,7 +59,7 @@ struct FrameRing {
     std::vector<hipEvent_t> uploaded, used_main, used_line;
     std::vector<long> main_gen, line_gen; // the step / pass whose copy out of the slot has been enqueued (-1: none yet)
     std::mutex m; std::condition_variable cv;
-    long pushed = 0, first = 0; // steps first .. pushed - 1 have frames
+    long pushed = 0, first = 0, first_line = 0; // steps first .. pushed - 1 have frames; line passes from first_line on take theirs from the ring (a cut backlog may have left earlier passes done)
 };
 struct LineWorker {
     cs_ctx *ctx = nullptr; cs_lsd *lsd = nullptr;
@@ -336,6 +336,7 @@ int cs_frontend_stream_begin(cs_frontend *fe, int n_frames, int width, int heigh
     if (!ok) { ring_free(R); return CS_ERR_NOMEM; }
     std::lock_guard<std::mutex> lk(fe->any_m);
     R->pushed = R->first = fe->step_no; // step numbers go on: the next step takes slot step_no % n_slots
+    R->first_line = std::max(fe->passes_started, fe->step_no); // (passes a cut backlog left done ran on the resident frames and never touch a slot)
     fe->ring = R;
     return CS_OK;
 }
@@ -351,7 +352,7 @@ int cs_frontend_stream_push(cs_frontend *fe, const uint8_t *gray) {
         if (k >= fe->step_no + R->n_slots) { fe->ctx->err = "cs_frontend_stream_push: every slot holds frames of a step that has not run"; return CS_ERR_CAPACITY; }
     }
     if (prev >= R->first) {
-        if (!fe->workers.empty()) { std::unique_lock<std::mutex> lk(R->m); R->cv.wait(lk, [&] { return R->line_gen[(size_t)slot] >= prev; }); if (hipStreamWaitEvent(R->copy, R->used_line[(size_t)slot], 0) != hipSuccess) return CS_ERR_HIP; }
+        if (!fe->workers.empty() && prev >= R->first_line) { std::unique_lock<std::mutex> lk(R->m); R->cv.wait(lk, [&] { return R->line_gen[(size_t)slot] >= prev; }); if (hipStreamWaitEvent(R->copy, R->used_line[(size_t)slot], 0) != hipSuccess) return CS_ERR_HIP; }
         if (hipStreamWaitEvent(R->copy, R->used_main[(size_t)slot], 0) != hipSuccess) return CS_ERR_HIP; // (step prev has run: k < step_no + n_slots)
     }
     if (hipMemcpyAsync(R->d[(size_t)slot], gray, R->bytes, hipMemcpyHostToDevice, R->copy) != hipSuccess || hipEventRecord(R->uploaded[(size_t)slot], R->copy) != hipSuccess) return CS_ERR_HIP;
@@ -393,7 +394,7 @@ int cs_frontend_stream_end(cs_frontend *fe) {
 }
 
 int cs_frontend_set_phased(cs_frontend *fe, int on) {
-    if (!fe) return CS_ERR_BAD_ARG;
+    if (!fe || (on && fe->ring)) return CS_ERR_BAD_ARG; // (the streaming source hands a pass its frames when it starts: not with gated passes)
     int r = cs_frontend_drain(fe); // no pass in flight across the switch
     std::lock_guard<std::mutex> lk(fe->gate.m);
     fe->gate.phased = on != 0;
