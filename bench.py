@@ -331,7 +331,7 @@ def c3_bench(ctx, frames, steps, with_cpu, with_traffic=False, with_small_window
     # passes -- a window's host region stage (frames < 512: the OpenMP threads grow the regions) runs beside ORB + matching of the next window
     from cube_slam_amd import _lib
     from cube_slam_amd.frontend import Frontend
-    lctx = [_lib.Context(0) for _ in range(4 if frames >= 512 else 2)]  # (from 512 frames per window the region stage runs on the device: four detectors in flight, like the headline)
+    lctx = [_lib.Context(0) for _ in range(int(os.environ.get("BENCH_C3_WORKERS", "6")) if frames >= 512 else 2)]  # (from 512 frames per window the region stage runs on the device, half a detector's CUs of the headline's: six detectors in flight)
     lsds = [line_lbd_detect(W, H, max_frames=frames, ctx=c) for c in lctx]
     for d_ in lsds:
         d_.upload(imgs)
@@ -346,16 +346,16 @@ def c3_bench(ctx, frames, steps, with_cpu, with_traffic=False, with_small_window
 
     def one_pass():
         fe.step()  # ORB of this window here, its line pass (LSD + LBD) on a worker
-        per = orb.read()  # key points + descriptors of every frame (the map points' descriptors are host data in the reference too)
         n_q = n_m = 0
         if mstream is not None:  # the tracking thread's searches of the whole window: key points of frame f-1 projected into frame f (known 3 px shift), every pair in one call
-            pk = np.concatenate([per[f][0] for f in range(frames - 1)])
+            kall, _, first = orb.read_packed()  # key points + descriptors of every frame, two copies for the window (the map points' positions are host data in the reference too)
+            pk = kall[:first[frames - 1]]
             z = np.full(len(pk), 10.0, np.float32)
             wp = np.stack([(pk["x"] - 3.0 - cx) / fx * z, (pk["y"] - cy) / fy * z, z], axis=1).astype(np.float32)
             ones = np.ones(len(pk), np.uint8)
-            _, nm = mstream.search(orb, 0, frames - 1, K4, None, bounds, wp, ones, ones, np.broadcast_to(Tcw, (frames - 1, 3, 4)), fx, fy, cx, cy, sf, 15.0,
-                              sum(len(per[f][0]) for f in range(1, frames)))
+            _, nm = mstream.search(orb, 0, frames - 1, K4, None, bounds, wp, ones, ones, np.broadcast_to(Tcw, (frames - 1, 3, 4)), fx, fy, cx, cy, sf, 15.0, int(first[frames] - first[1]))
             return len(pk), int(nm.sum())
+        per = orb.read()  # key points + descriptors of every frame (the map points' descriptors are host data in the reference too)
         for f in range(1, frames):  # the tracking thread: key points of frame f-1 projected into frame f (known 3 px shift)
             m.set_frame_from_orb(orb, f, K4, None, bounds)
             pk, pd = per[f - 1]
