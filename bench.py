@@ -331,7 +331,7 @@ def c3_bench(ctx, frames, steps, with_cpu, with_traffic=False, with_small_window
     # passes -- a window's host region stage (frames < 512: the OpenMP threads grow the regions) runs beside ORB + matching of the next window
     from cube_slam_amd import _lib
     from cube_slam_amd.frontend import Frontend
-    lctx = [_lib.Context(0) for _ in range(int(os.environ.get("BENCH_C3_WORKERS", "6")) if frames >= 512 else 2)]  # (from 512 frames per window the region stage runs on the device, half a detector's CUs of the headline's: six detectors in flight)
+    lctx = [_lib.Context(0) for _ in range(int(os.environ.get("BENCH_C3_WORKERS", "4")) if frames >= 512 else 2)]  # (from 512 frames per window the region stage runs on the device: four detectors in flight, like the headline.  Six give 7.9 k against 7.2 k frames/s here -- and the blocks that run BEHIND this one in the same process then lose 10 % (chained 24.5 -> 22.3 k, streamed 23.3 -> 20.0 k, two runs each): left at four)
     lsds = [line_lbd_detect(W, H, max_frames=frames, ctx=c) for c in lctx]
     for d_ in lsds:
         d_.upload(imgs)
@@ -833,7 +833,10 @@ def main():
         tr = measure_traffic("cuboid_sweep_score", "pmc_run.py", [args.frames, args.boxes, args.yaw_step, BG_TEXTURE])
         if not args.no_cpu:
             native_oracle()  # the c3 / c4 CPU legs use the -march=native build too
-        extra["c3"] = c3_bench(ctx, 512, 8, with_cpu=not args.no_cpu, with_traffic=True, with_small_window=2 * _lib.lib().cs_host_thread_count())  # windows of 512 frames: the region stage on the device, a window's searches in one call; small_window: two frames per host thread, the per-frame calls (round 4's form)
+        if os.environ.get("BENCH_SKIP_C3"):  # (development: the blocks behind c3 without it in front of them)
+            extra["c3"] = {"skipped": True}
+        else:
+            extra["c3"] = c3_bench(ctx, 512, 8, with_cpu=not args.no_cpu, with_traffic=True, with_small_window=2 * _lib.lib().cs_host_thread_count())  # windows of 512 frames: the region stage on the device, a window's searches in one call; small_window: two frames per host thread, the per-frame calls (round 4's form)
         extra["c4"] = c4_bench(ctx, 64, 8, args.yaw_step, 10, with_cpu=not args.no_cpu, with_traffic=True)
         if lsd is not None:
             extra["chained"] = chained_bench(ctx, fe, lsds, batch, scenes, args.frames, args.steps, barrier, backlog=bool(args.backlog))
