@@ -83,3 +83,28 @@ def test_device_and_host_quadtree_agree(ctx, monkeypatch):
         for (ka, da), (kb, db) in zip(res[("host", nfeat)], res[("device", nfeat)]):
             assert len(ka) == len(kb) and len(ka) > 50
             assert ka.tobytes() == kb.tobytes() and np.array_equal(da, db)
+
+
+def test_packed_read_and_device_frames_equal_the_per_frame_paths(ctx):
+    """cs_orb_read_packed (two copies for the whole batch) returns what cs_orb_read returns frame by frame, and frames handed over from DEVICE memory
+    (cs_orb_set_frames_device, the streaming front-end's hand-over) give the key points of the same frames uploaded from the host."""
+    import ctypes as C
+    import torch
+    from cube_slam_amd._lib import check, lib
+    W, H = 640, 480
+    imgs = np.stack([synth.texture_image(60 + i, W, H, shift=2 * i) for i in range(3)])
+    ext = ORBextractor(800, 1.2, 8, 20, 7, W, H, max_frames=3, ctx=ctx)
+    want = ext.extract_batch(imgs)
+    kps, desc, first = ext.read_packed()
+    assert first[0] == 0 and first[-1] == len(kps) == sum(len(k) for k, _ in want)
+    for f in range(3):
+        assert kps[first[f]:first[f + 1]].tobytes() == want[f][0].tobytes() and np.array_equal(desc[first[f]:first[f + 1]], want[f][1])
+    other = np.ascontiguousarray(imgs[::-1])  # the same frames in another order, from device memory
+    d = torch.from_numpy(other).to("cuda:0")
+    torch.cuda.synchronize()
+    check(ctx.ptr, lib().cs_orb_set_frames_device(ctx.ptr, ext._e, C.c_void_p(d.data_ptr()), 3), "cs_orb_set_frames_device")
+    ext.run()
+    got = ext.read()
+    for f in range(3):
+        assert got[f][0].tobytes() == want[2 - f][0].tobytes() and np.array_equal(got[f][1], want[2 - f][1])
+    ext.close()
