@@ -246,10 +246,15 @@ __global__ void __launch_bounds__(64) cuboid_frame_prep(const FrameInfo *fi, Fra
 // ------------------------------------------------------------------------------------------------ lines per unit
 // One wave per unit.  merge_break_lines is order dependent (restart after every merge, removed row replaced by the
 // last one), so each round finds the FIRST (seg1,seg2) in row-major order that merges: lane = seg1, serial seg2.
+// The line lists live in DYNAMIC LDS sized by the batch's longest edge list (`cap` rows of 5 doubles; CS_MAX_ROI_LINES at most).  With the static 40 KB for 1024 rows the
+// compiler derived "one wave per SIMD" from the LDS size and then RESERVED the register file of such a wave in the kernel descriptor (next_free_vgpr 257 for a kernel that uses 122):
+// a wave that asks for 264 registers only starts on a SIMD that holds at most two region-walk waves, and beside the alternating runner's walks -- four waves of 96 registers on
+// every SIMD -- this 47 us kernel took 2.4 ms of every step waiting for such SIMDs.
 __global__ void __launch_bounds__(64) cuboid_unit_lines(const Unit *units, UnitDyn *ud, const FrameInfo *fi, const double *lines_al,
-                                                        double *mlines, double *mangle, double *mmid, int *status) {
-    __shared__ double L[CS_MAX_ROI_LINES][4];
-    __shared__ double ang[CS_MAX_ROI_LINES];
+                                                        double *mlines, double *mangle, double *mmid, int *status, int cap) {
+    extern __shared__ double ul_sh[];
+    double (*L)[4] = reinterpret_cast<double (*)[4]>(ul_sh);
+    double *ang = ul_sh + 4 * (size_t)cap;
     const int u = blockIdx.x, lane = threadIdx.x;
     const Unit &U = units[u];
     const FrameInfo &F = fi[U.frame];
@@ -266,7 +271,7 @@ __global__ void __launch_bounds__(64) cuboid_unit_lines(const Unit *units, UnitD
         }
         unsigned long long m = __ballot(in);
         int pos = total + __popcll(m & ((1ull << lane) - 1));
-        if (in && pos < CS_MAX_ROI_LINES) { L[pos][0] = a0; L[pos][1] = a1; L[pos][2] = a2; L[pos][3] = a3; }
+        if (in && pos < cap) { L[pos][0] = a0; L[pos][1] = a1; L[pos][2] = a2; L[pos][3] = a3; } // (cap = min(the longest list, CS_MAX_ROI_LINES) >= this frame's lines unless the list is longer than CS_MAX_ROI_LINES)
         total += __popcll(m);
     }
     if (total > CS_MAX_ROI_LINES) { if (lane == 0) atomicMin(status, CS_ERR_CAPACITY); total = CS_MAX_ROI_LINES; }
@@ -2089,8 +2094,10 @@ int cs_cuboid_batch_run(cs_ctx *ctx, cs_cuboid_batch *b) {
     const int U = b->n_units;
     CS_LAUNCH(ctx, "cuboid_frame_prep", cuboid_frame_prep, dim3(b->n_frames), dim3(64), 0, b->d_fi, b->d_fd, b->d_cam, b->d_yaw, b->cal, b->o,
               b->d_lines_in, b->d_lines_al);
-    CS_LAUNCH(ctx, "cuboid_unit_lines", cuboid_unit_lines, dim3(U), dim3(64), 0, b->d_units, b->d_ud, b->d_fi, b->d_lines_al, b->d_mlines,
-              b->d_mangle, b->d_mmid, b->d_status);
+    int ul_cap = 1;
+    for (const FrameInfo &fi_ : b->fi) ul_cap = std::max(ul_cap, std::min(fi_.n_lines, CS_MAX_ROI_LINES));
+    CS_LAUNCH(ctx, "cuboid_unit_lines", cuboid_unit_lines, dim3(U), dim3(64), sizeof(double) * 5 * (size_t)ul_cap, b->d_units, b->d_ud, b->d_fi, b->d_lines_al, b->d_mlines,
+              b->d_mangle, b->d_mmid, b->d_status, ul_cap);
     CS_HIP(ctx, hipMemsetAsync(b->d_emap, 0, (size_t)b->pix_total, ctx->stream));
     CS_LAUNCH(ctx, "cuboid_canny_nms", cuboid_canny_nms, dim3(b->max_tiles, U), dim3(256), 0, b->d_units, b->d_gray, b->W, b->H, b->d_emap,
               b->d_lab, b->o.canny_low, b->o.canny_high);
