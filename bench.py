@@ -407,7 +407,7 @@ def c3_bench(ctx, frames, steps, with_cpu, with_traffic=False, with_small_window
         alg = 40.0 * cstat["queries"] + 32.0 * cstat["candidates"]
         us = 1e3 * cand_ms / cand_n
         ach = alg / (us * 1e-6) / 1e9
-        tr = measure_traffic("match_candidates", "pmc_c3.py", [8]) if with_traffic else None  # (its launches on eight frames of the same stream, the local-map launch among them)
+        tr = (measure_traffic("match_candidates_stream", "pmc_c3_match.py", [frames]) if mstream is not None else measure_traffic("match_candidates", "pmc_c3.py", [8])) if with_traffic else None  # (the window's search alone on the same frames: count + fill launches averaged, like avg_kernel_us)
         out["roofline"] = {"bound": "hbm", "kernel": "match_candidates", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None if tr is None else tr["bytes"],
                            "traffic_detail": tr, "avg_kernel_us": us, "algorithmic_bytes_per_launch": alg, "queries_per_launch": cstat["queries"], "candidates_per_launch": cstat["candidates"],
                            "note": ("a window's queries per launch; avg_kernel_us averages the counting and the filling pass" if mstream is not None else "one launch per frame (2000 queries): launch-latency-bound at this size")}
