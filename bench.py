@@ -357,7 +357,7 @@ def c3_bench(ctx, frames, steps, with_cpu, with_traffic=False, with_small_window
             return len(pk), int(nm.sum())
         per = orb.read()  # key points + descriptors of every frame (the map points' descriptors are host data in the reference too)
         for f in range(1, frames):  # the tracking thread: key points of frame f-1 projected into frame f (known 3 px shift)
-            m.set_frame_from_orb(orb, f, K4, None, bounds)
+            m.set_frame_from_orb(orb, f, K4, None, bounds, read_keys=False)
             pk, pd = per[f - 1]
             z = np.full(len(pk), 10.0, np.float32)
             wp = np.stack([(pk["x"] - 3.0 - cx) / fx * z, (pk["y"] - cy) / fy * z, z], axis=1).astype(np.float32)
@@ -383,7 +383,7 @@ def c3_bench(ctx, frames, steps, with_cpu, with_traffic=False, with_small_window
     dt = time.perf_counter() - t0
     kern = {}
     for nme in ("orb_resize", "orb_fast_score", "orb_cells", "orb_quadtree", "orb_blur", "orb_angle", "orb_desc", "host_lsd_regions", "lsd_blur_hv", "lsd_resize", "lsd_gradient",
-                "lbd_blur5", "lbd_sobel", "lbd_line_desc", "match_undistort", "match_grid", "match_project", "match_candidates", "match_scan"):
+                "lbd_blur5", "lbd_sobel", "lbd_line_desc", "match_undistort", "match_grid", "match_project", "match_candidates", "match_resolve"):
         parts = [c.timing_get(nme) for c in [ctx] + lctx]
         ms, n = sum(p_[0] for p_ in parts), sum(p_[1] for p_ in parts)
         if n:
@@ -399,7 +399,7 @@ def c3_bench(ctx, frames, steps, with_cpu, with_traffic=False, with_small_window
            "queries_per_pass": n_q, "matches_per_pass": n_m, "kernels_us": kern,
            "region_stage": ("device: one wave per frame (lsd_rg_seq)" if lsd.region_stats()["device"] else "host: %d OpenMP threads" % _lib.lib().cs_host_thread_count()),
            "matching": ("one cs_match_by_projection_stream call per window: frame post-processing + SearchByProjection of its %d pairs in a handful of launches" % (frames - 1)) if mstream is not None
-                       else "per frame from Python: cs_matcher_set_frame_from_orb + cs_match_by_projection_frame (five launches, three host round trips a frame)",
+                       else "per frame from Python: cs_matcher_set_frame_from_orb + cs_match_by_projection_frame (five launches -- undistort, grid, project, candidates, resolve -- and one host round trip a frame)",
            "runner": "cs_frontend: ORB + the tracking thread's matching on the caller's context, the line path of the same window on %d worker contexts (a window's region stage "
                      "beside ORB + matching of the next one); %d windows of %d frames timed, drained inside the clock" % (len(lctx), steps, frames)}
     if cand_n and cstat is not None:
@@ -407,10 +407,10 @@ def c3_bench(ctx, frames, steps, with_cpu, with_traffic=False, with_small_window
         alg = 40.0 * cstat["queries"] + 32.0 * cstat["candidates"]
         us = 1e3 * cand_ms / cand_n
         ach = alg / (us * 1e-6) / 1e9
-        tr = (measure_traffic("match_candidates_stream", "pmc_c3_match.py", [frames]) if mstream is not None else measure_traffic("match_candidates", "pmc_c3.py", [8])) if with_traffic else None  # (the window's search alone on the same frames: count + fill launches averaged, like avg_kernel_us)
+        tr = (measure_traffic("match_candidates", "pmc_c3_match.py", [frames]) if mstream is not None else measure_traffic("match_candidates", "pmc_c3.py", [8])) if with_traffic else None  # (the window's search alone on the same frames: count + fill launches averaged, like avg_kernel_us)
         out["roofline"] = {"bound": "hbm", "kernel": "match_candidates", "achieved": ach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": ach / HBM_PEAK_GBS, "traffic": None if tr is None else tr["bytes"],
                            "traffic_detail": tr, "avg_kernel_us": us, "algorithmic_bytes_per_launch": alg, "queries_per_launch": cstat["queries"], "candidates_per_launch": cstat["candidates"],
-                           "note": ("a window's queries per launch; avg_kernel_us averages the counting and the filling pass" if mstream is not None else "one launch per frame (2000 queries): launch-latency-bound at this size")}
+                           "note": ("a window's queries in ONE launch (a wave counts, takes a slice of the arena from a cursor and fills it); the claims run in match_resolve, one wave per pair" if mstream is not None else "one launch per frame (2000 queries): launch-latency-bound at this size")}
     # The kernel at the size TrackLocalMap gives it: ORBmatcher::SearchByProjection(F, vpMapPoints, th) (ORBmatcher.cc:50-142) with a local map of 10 000 points in view
     # of one frame -- the key points of five frames of the stream stand in for the map points (projections, descriptors, predicted levels) -- one launch, no frame loop.
     try:

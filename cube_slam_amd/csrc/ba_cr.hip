@@ -299,12 +299,13 @@ template <int BC> __global__ void __launch_bounds__(64 * ((6 * BC + 63) / 64)) b
     // invalidates the L1 on every turn: the way back was 66 us for eight levels of flag round trips)
     if (tid == 0) {
         // (a node only waits for nodes with SMALLER workgroup indices, and the dispatcher hands workgroups out in index order, so a waiting workgroup never holds a slot its
-        //  producer needs; should that ever not hold -- the programming model does not promise it -- the spin is bounded: ~0.5 s, then the solve is flagged as failed (status 2)
-        //  instead of hanging the stream)
-        long spins = 0;
-        if (a >= 0) while (__hip_atomic_load(&W.done[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != W.epoch && ++spins < (1L << 22)) __builtin_amdgcn_s_sleep(1);
-        if (b >= 0) while (__hip_atomic_load(&W.done[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != W.epoch && ++spins < (1L << 22)) __builtin_amdgcn_s_sleep(1);
-        if (spins >= (1L << 22)) *W.status = 2;
+        //  producer needs; should that ever not hold -- the programming model does not promise it -- the spin is bounded by the wall clock (100 MHz: 0.5 s), then the solve
+        //  is flagged as failed (status 2) instead of hanging the stream)
+        const unsigned long long t_give_up = wall_clock64() + 50000000ull;
+        bool late = false;
+        if (a >= 0) while (__hip_atomic_load(&W.done[a], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != W.epoch && !(late = wall_clock64() > t_give_up)) __builtin_amdgcn_s_sleep(1);
+        if (b >= 0) while (__hip_atomic_load(&W.done[b], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != W.epoch && !(late = late || wall_clock64() > t_give_up)) __builtin_amdgcn_s_sleep(1);
+        if (late) *W.status = 2;
     }
     __syncthreads();
     if (tid < NB) {
@@ -321,7 +322,9 @@ template <int BC> __global__ void __launch_bounds__(64 * ((6 * BC + 63) / 64)) b
 #pragma unroll
     for (int k = 0; k < NB; k += 2) { x0 += g_col[k] * tv[k]; x1 += g_col[k + 1] * tv[k + 1]; }
     if (tid < NB) __hip_atomic_store(&W.x[(long)i * NB + tid], x0 + x1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-#ifdef CR_BACK_FENCE
+    // The drained-store hand-over relies on gfx9-family behaviour (stores counted by vmcnt, sc1 stores written through to memory-side coherence): it is what this library
+    // is built for (gfx942 / gfx950).  Any other target -- the Makefile's ARCH can be overridden -- and -DCR_BACK_FENCE take the memory model's own release fence.
+#if defined(CR_BACK_FENCE) || !(defined(__gfx942__) || defined(__gfx950__))
     __threadfence();
 #else
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); // this wave's write-through stores have left

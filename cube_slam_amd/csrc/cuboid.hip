@@ -2028,6 +2028,11 @@ int cs_cuboid_batch_create(cs_ctx *ctx, int n_frames, int width, int height, con
 // New edge lists for the frames of an existing batch (same frames, boxes and options): what a step of the chain detect_filter_lines ->
 // detect_cuboid (main_obj.cpp:428-449) hands over when the frames stay resident.  Only the line ranges of the plan change.
 int cs_cuboid_batch_n_frames(const cs_cuboid_batch *b) { return b ? b->n_frames : -1; }
+int cs_cuboid_batch_geometry(const cs_cuboid_batch *b, int *width, int *height, int *n_frames) { // (library-internal, see cs_orb_geometry)
+    if (!b) return CS_ERR_BAD_ARG;
+    *width = b->W; *height = b->H; *n_frames = b->n_frames;
+    return CS_OK;
+}
 // new pixels for the frames of the batch (same boxes, poses and plan) from DEVICE memory: a copy on the context's stream, nothing waits
 int cs_cuboid_batch_set_gray_device(cs_ctx *ctx, cs_cuboid_batch *b, const uint8_t *d_gray) {
     if (!ctx || !b || !d_gray) return CS_ERR_BAD_ARG;

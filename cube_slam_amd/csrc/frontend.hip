@@ -35,6 +35,9 @@ extern "C" int cs_cuboid_batch_set_lines(cs_ctx *ctx, cs_cuboid_batch *b, const 
 extern "C" int cs_cuboid_batch_n_frames(const cs_cuboid_batch *b);
 extern "C" int cs_cuboid_batch_set_gray_device(cs_ctx *ctx, cs_cuboid_batch *b, const uint8_t *d_gray);
 extern "C" int cs_orb_set_frames_device(cs_ctx *ctx, cs_orb *e, const uint8_t *d_gray, int n_frames);
+extern "C" int cs_orb_geometry(const cs_orb *e, int *width, int *height, int *max_frames);
+extern "C" int cs_lsd_geometry(const cs_lsd *l, int *width, int *height, int *max_frames);
+extern "C" int cs_cuboid_batch_geometry(const cs_cuboid_batch *b, int *width, int *height, int *n_frames);
 extern "C" int cs_lsd_set_frames_device(cs_ctx *ctx, cs_lsd *l, const uint8_t *d_gray, int n_frames);
 extern "C" int cs_orb_read_packed_on(cs_orb *e, void *stream, cs_keypoint *kps, uint8_t *desc, long cap_total, int *first, long *total);
 extern "C" int cs_cuboid_batch_read_on(cs_cuboid_batch *b, void *stream, cs_cuboid *out, int *counts, int *status_out);
@@ -54,7 +57,7 @@ struct Gate { // phase gate of one runner: tickets are pass numbers, the gate is
 struct FrameRing {
     int n_slots = 0, n_frames = 0; size_t bytes = 0;
     hipStream_t copy = nullptr, copy_out = nullptr; // H2D of the frames; D2H of a step's results (cs_frontend_stream_read_async)
-    hipEvent_t step_done = nullptr, cub_done = nullptr, results_out = nullptr; bool results_pending = false; int *h_status = nullptr;
+    hipEvent_t step_done = nullptr, cub_done = nullptr, results_out = nullptr; bool results_pending = false, status_read = false; int *h_status = nullptr;
     std::vector<uint8_t *> d;
     std::vector<hipEvent_t> uploaded, used_main, used_line;
     std::vector<long> main_gen, line_gen; // the step / pass whose copy out of the slot has been enqueued (-1: none yet)
@@ -319,6 +322,14 @@ static void ring_free(FrameRing *R) {
 }
 int cs_frontend_stream_begin(cs_frontend *fe, int n_frames, int width, int height, int n_slots) {
     if (!fe || n_frames < 1 || width < 1 || height < 1 || n_slots < 2 || n_slots > 8 || fe->gate.phased) return CS_ERR_BAD_ARG;
+    // a slot is handed to the attached objects as n_frames x height x width bytes: it must be exactly what each of them copies out of it
+    {
+        int w = 0, h = 0, n = 0;
+        if (fe->orb && (cs_orb_geometry(fe->orb, &w, &h, &n) != CS_OK || w != width || h != height || n_frames > n)) { fe->ctx->err = "cs_frontend_stream_begin: the ring's geometry is not the extractor's"; return CS_ERR_BAD_ARG; }
+        if (fe->batch && (cs_cuboid_batch_geometry(fe->batch, &w, &h, &n) != CS_OK || w != width || h != height || n_frames != n)) { fe->ctx->err = "cs_frontend_stream_begin: the ring's geometry is not the cuboid batch's"; return CS_ERR_BAD_ARG; }
+        for (LineWorker *lw : fe->workers)
+            if (cs_lsd_geometry(lw->lsd, &w, &h, &n) != CS_OK || w != width || h != height || n_frames > n) { fe->ctx->err = "cs_frontend_stream_begin: the ring's geometry is not the line detectors'"; return CS_ERR_BAD_ARG; }
+    }
     int r = cs_frontend_drain(fe);
     if (r != CS_OK) return r;
     if (hipSetDevice(fe->ctx->device) != hipSuccess) return CS_ERR_HIP;
@@ -334,6 +345,7 @@ int cs_frontend_stream_begin(cs_frontend *fe, int n_frames, int width, int heigh
         ok = hipMalloc((void **)&R->d[(size_t)i], R->bytes) == hipSuccess && hipEventCreateWithFlags(&R->uploaded[(size_t)i], hipEventDisableTiming) == hipSuccess &&
              hipEventCreateWithFlags(&R->used_main[(size_t)i], hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&R->used_line[(size_t)i], hipEventDisableTiming) == hipSuccess;
     if (!ok) { ring_free(R); return CS_ERR_NOMEM; }
+    *R->h_status = 0;
     std::lock_guard<std::mutex> lk(fe->any_m);
     R->pushed = R->first = fe->step_no; // step numbers go on: the next step takes slot step_no % n_slots
     R->first_line = std::max(fe->passes_started, fe->step_no); // (passes a cut backlog left done ran on the resident frames and never touch a slot)
@@ -370,7 +382,8 @@ int cs_frontend_stream_read_async(cs_frontend *fe, cs_keypoint *kps, uint8_t *de
     if (fe->cub_ctx && (hipEventRecord(R->cub_done, fe->cub_ctx->stream) != hipSuccess || hipStreamWaitEvent(R->copy_out, R->cub_done, 0) != hipSuccess)) return CS_ERR_HIP;
     int r = CS_OK;
     if (fe->orb && kps && desc) { if (!first || !total) return CS_ERR_BAD_ARG; r = cs_orb_read_packed_on(fe->orb, R->copy_out, kps, desc, cap_total, first, total); }
-    if (r == CS_OK && fe->batch && cuboids && counts) r = cs_cuboid_batch_read_on(fe->batch, R->copy_out, cuboids, counts, R->h_status);
+    R->status_read = r == CS_OK && fe->batch && cuboids && counts; // (the status word is only written by the cuboid copy)
+    if (R->status_read) r = cs_cuboid_batch_read_on(fe->batch, R->copy_out, cuboids, counts, R->h_status);
     if (hipEventRecord(R->results_out, R->copy_out) != hipSuccess) return CS_ERR_HIP;
     R->results_pending = true;
     return r;
@@ -380,7 +393,8 @@ int cs_frontend_stream_read_wait(cs_frontend *fe) {
     FrameRing *R = fe->ring;
     if (!R->results_pending) return CS_OK;
     if (hipEventSynchronize(R->results_out) != hipSuccess) return CS_ERR_HIP;
-    if (fe->batch && *R->h_status != 0) { fe->ctx->err = "more than CS_MAX_ROI_LINES lines inside one box"; const int st = *R->h_status; *R->h_status = 0; return st; }
+    R->results_pending = false;
+    if (R->status_read && *R->h_status != 0) { fe->ctx->err = "more than CS_MAX_ROI_LINES lines inside one box"; const int st = *R->h_status; *R->h_status = 0; return st; }
     return CS_OK;
 }
 int cs_frontend_stream_end(cs_frontend *fe) {

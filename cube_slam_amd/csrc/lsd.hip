@@ -915,6 +915,11 @@ int cs_lsd_upload(cs_ctx *ctx, cs_lsd *l, const uint8_t *gray, int n_frames, int
 }
 
 // the frames of the next run from DEVICE memory (n_frames x H x W bytes): a copy on the context's stream, nothing waits (the streaming front-end's hand-over)
+int cs_lsd_geometry(const cs_lsd *l, int *width, int *height, int *max_frames) { // (library-internal, see cs_orb_geometry)
+    if (!l) return CS_ERR_BAD_ARG;
+    *width = l->W; *height = l->H; *max_frames = l->max_frames;
+    return CS_OK;
+}
 int cs_lsd_set_frames_device(cs_ctx *ctx, cs_lsd *l, const uint8_t *d_gray, int n_frames) {
     if (!ctx || !l || !d_gray || n_frames < 1 || n_frames > l->max_frames) return CS_ERR_BAD_ARG;
     CS_HIP(ctx, hipSetDevice(ctx->device));

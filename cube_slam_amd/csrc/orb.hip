@@ -1124,6 +1124,11 @@ int cs_orb_upload(cs_ctx *ctx, cs_orb *e, const uint8_t *gray, int n_frames, int
 
 // The frames of a run from DEVICE memory (n_frames x height rows of `width` bytes, one frame behind the other): a copy on the context's stream, nothing waits.  The
 // streaming front-end (cs_frontend_stream_*) feeds the extractor from the ring slot a copy stream filled.
+int cs_orb_geometry(const cs_orb *e, int *width, int *height, int *max_frames) { // (library-internal: the streaming runner checks its ring against the objects it feeds)
+    if (!e) return CS_ERR_BAD_ARG;
+    *width = e->W; *height = e->H; *max_frames = e->max_frames;
+    return CS_OK;
+}
 int cs_orb_set_frames_device(cs_ctx *ctx, cs_orb *e, const uint8_t *d_gray, int n_frames) {
     if (!ctx || !e || !d_gray || n_frames < 1 || n_frames > e->max_frames) return CS_ERR_BAD_ARG;
     CS_HIP(ctx, hipSetDevice(ctx->device));

@@ -29,19 +29,20 @@ class ORBmatcher:
         check(self.ctx.ptr, lib().cs_matcher_set_frame(self.ctx.ptr, self._m, k.ctypes.data_as(C.c_void_p), _p(d, C.c_uint8), self.N,
                                                        *[C.c_float(b) for b in bounds]), "cs_matcher_set_frame")
 
-    def set_frame_from_orb(self, orb, frame, K4, dist5=None, bounds=None, width=None, height=None):
+    def set_frame_from_orb(self, orb, frame, K4, dist5=None, bounds=None, width=None, height=None, read_keys=True):
         """Frame post-processing on the device: keypoints / descriptors of frame `frame` of the extractor's last run are undistorted
-        (Frame::UndistortKeyPoints) and binned (AssignFeaturesToGrid) without leaving HBM.  Returns (mvKeysUn, bounds)."""
+        (Frame::UndistortKeyPoints) and binned (AssignFeaturesToGrid) without leaving HBM.  Returns (mvKeysUn, bounds); read_keys=False: (None, bounds) and the
+        frame's key points stay on the device (every search but SearchForInitialization's vbPrevMatched update works from the device copy)."""
         k4 = np.ascontiguousarray(K4, np.float32)
         d5 = None if dist5 is None else np.ascontiguousarray(dist5, np.float32)
         if bounds is None:
             bounds = frame_image_bounds(width, height, k4, d5)
         out = np.zeros(max(orb.cap, 1), KEYPOINT_DTYPE); n = C.c_int()
         check(self.ctx.ptr, lib().cs_matcher_set_frame_from_orb(self.ctx.ptr, self._m, orb._e, int(frame), _p(k4, C.c_float), None if d5 is None else _p(d5, C.c_float),
-                                                                *[C.c_float(float(b)) for b in bounds], out.ctypes.data_as(C.c_void_p), C.byref(n)),
+                                                                *[C.c_float(float(b)) for b in bounds], out.ctypes.data_as(C.c_void_p) if read_keys else None, C.byref(n)),
               "cs_matcher_set_frame_from_orb")
         self.N = n.value
-        return out[:n.value].copy(), tuple(float(b) for b in bounds)
+        return (out[:n.value].copy() if read_keys else None), tuple(float(b) for b in bounds)
 
     def last_candidate_stats(self):
         q, c = C.c_int(), C.c_long()
@@ -170,7 +171,7 @@ class ORBmatcherStream:
         md = None if mp_desc is None else np.ascontiguousarray(mp_desc, np.uint8)
         tm = np.zeros(max(int(n_train), 1), np.int32); nm = np.zeros(n_pairs, np.int32)
         check(self.ctx.ptr, lib().cs_match_by_projection_stream(self.ctx.ptr, self._m, orb._e, int(f0), int(n_pairs), _p(k4, C.c_float), None if d5 is None else _p(d5, C.c_float),
-                                                                C.c_float(bounds[0]), C.c_float(bounds[1]), C.c_float(bounds[2]), C.c_float(bounds[3]), _p(wp, C.c_float), _p(va, C.c_uint8),
+                                                                C.c_float(bounds[0]), C.c_float(bounds[1]), C.c_float(bounds[2]), C.c_float(bounds[3]), len(va), int(n_train), _p(wp, C.c_float), _p(va, C.c_uint8),
                                                                 _p(bl, C.c_uint8), None if md is None else _p(md, C.c_uint8), _p(T, C.c_float), C.c_float(fx), C.c_float(fy), C.c_float(cx),
                                                                 C.c_float(cy), _p(sf, C.c_float), len(sf), C.c_float(th), int(self.mbCheckOrientation), _p(tm, C.c_int), _p(nm, C.c_int)),
               "cs_match_by_projection_stream")

@@ -17,7 +17,7 @@
 extern "C" {
 #endif
 
-#define CS_VERSION 106 /* 106: cs_cuboid_batch_n_frames, cs_frontend_queues, cs_match_by_projection_stream, cs_frontend_stream_*, cs_*_set_frames_device, cs_orb_read_packed; 105: cs_frontend_set_backlog; 104: cs_frontend_set_cuboid_ctx; 103: cs_lsd_read_filter_lines takes the caller's frame count, cs_frontend_set_chain; 102: cs_cuboid_batch_set_lines, cs_cuboid_batch_set_shared_gpu, cs_lsd_read_filter_lines; 101: cs_ba_set_stop_flag_bool / cs_ba_dyn_set_stop_flag_bool; cs_match_by_projection_frame takes train_blocked */
+#define CS_VERSION 107 /* 107: cs_match_by_projection_stream takes n_queries / n_train, cs_cuboid_batch_set_boxes, the matchers' claim passes run on the device; 106: cs_cuboid_batch_n_frames, cs_frontend_queues, cs_match_by_projection_stream, cs_frontend_stream_*, cs_*_set_frames_device, cs_orb_read_packed; 105: cs_frontend_set_backlog; 104: cs_frontend_set_cuboid_ctx; 103: cs_lsd_read_filter_lines takes the caller's frame count, cs_frontend_set_chain; 102: cs_cuboid_batch_set_lines, cs_cuboid_batch_set_shared_gpu, cs_lsd_read_filter_lines; 101: cs_ba_set_stop_flag_bool / cs_ba_dyn_set_stop_flag_bool; cs_match_by_projection_frame takes train_blocked */
 
 typedef enum cs_status {
     CS_OK = 0,
@@ -225,7 +225,8 @@ int cs_matcher_set_frame(cs_ctx *ctx, cs_matcher *m, const cs_keypoint *keysUn, 
  * cs_orb_run stay in HBM; Frame::UndistortKeyPoints (Frame.cc:546-576: copy when dist[0] == 0, else cv::undistortPoints(K, dist, P = K),
  * classic five-iteration form) and Frame::AssignFeaturesToGrid (:303-318) run on the device and the matcher is ready for the searches.
  * K4 = fx fy cx cy, dist5 = k1 k2 p1 p2 k3 (NULL = none); bounds from cs_frame_image_bounds.  keysUn_out (nullable, room for the
- * frame's keypoints) receives mvKeysUn. */
+ * frame's keypoints) receives mvKeysUn; with NULL nothing is copied back and the call does not wait for the device (every search reads what it needs of a train key point
+ * from the device copy; only cs_match_for_initialization, which updates vbPrevMatched on the host, needs a frame set WITH the copy). */
 int cs_matcher_set_frame_from_orb(cs_ctx *ctx, cs_matcher *m, const cs_orb *orb, int frame, const float *K4, const float *dist5, float minX, float maxX, float minY,
                                   float maxY, cs_keypoint *keysUn_out, int *n_out);
 /* Frame::ComputeImageBounds (Frame.cc:578-609): bounds = mnMinX, mnMaxX, mnMinY, mnMaxY of the undistorted image corners. */
@@ -251,12 +252,15 @@ int cs_match_by_projection_frame(cs_ctx *ctx, cs_matcher *m, int n_last, const f
  * Queries: the key points of the last frames, concatenated over the pairs in order (n_q = key points of frames f0 .. f0 + n_pairs - 1): world_pos (3 floats each), valid,
  * blocks; their level and angle are the last frame's key points' (ORBmatcher.cc:1424, 1483); mp_desc: the map points' descriptors (32 B per query) or NULL = the last
  * frame's own descriptors.  Tcw: 12 floats per pair.  train_match: concatenated over the current frames f0 + 1 .. f0 + n_pairs (key point counts as the extractor reports
- * them), the matched query's index WITHIN its last frame or -1; nmatches[n_pairs]. */
+ * them), the matched query's index WITHIN its last frame or -1; nmatches[n_pairs].  n_queries / n_train: what the caller sized the per-query arrays and train_match for -- the
+ * call fails with CS_ERR_BAD_ARG when they are not the extractor's counts for the window (an extractor that ran again in between).  There is no train_blocked here: a current frame
+ * of the window carries no map points before its own search.  The claims (a key point claimed by a map point with observations is skipped by later queries), the rotation
+ * histogram and its three-maxima cut run on the device, one wave per pair; candidates never leave HBM. */
 typedef struct cs_match_stream cs_match_stream;
 int cs_match_stream_create(cs_match_stream **out);
 void cs_match_stream_destroy(cs_ctx *ctx, cs_match_stream *m);
 int cs_match_by_projection_stream(cs_ctx *ctx, cs_match_stream *m, const cs_orb *orb, int f0, int n_pairs, const float *K4, const float *dist5 /* nullable */,
-                                  float minX, float maxX, float minY, float maxY, const float *world_pos, const uint8_t *valid, const uint8_t *blocks,
+                                  float minX, float maxX, float minY, float maxY, int n_queries, int n_train, const float *world_pos, const uint8_t *valid, const uint8_t *blocks,
                                   const uint8_t *mp_desc /* nullable */, const float *Tcw, float fx, float fy, float cx, float cy, const float *scale_factors, int n_levels,
                                   float th, int check_orientation, int *train_match, int *nmatches);
 /* queries and window candidates of the last call (roofline accounting) */

@@ -48,7 +48,7 @@ def test_features_in_area(ctx, oracle, frames):
     m.close()
 
 
-@pytest.mark.parametrize("th", [15.0, 30.0])
+@pytest.mark.parametrize("th", [15.0, 30.0, 90.0])  # (90: dozens of candidates per query -- lists longer than the resolve kernel keeps in registers, most batches with competing claims)
 def test_search_by_projection_frame(ctx, oracle, frames, th):
     (k1, d1), (k2, d2) = frames
     rng = np.random.default_rng(2)
@@ -59,7 +59,7 @@ def test_search_by_projection_frame(ctx, oracle, frames, th):
     Tcw[0, 3] = 0.02  # tiny motion; the image shift does the rest
     wp[:, 0] += (-4.0 / FX) * z  # the texture moved 4 px to the left
     valid = (rng.uniform(size=n) < 0.85).astype(np.uint8)
-    blocks = (rng.uniform(size=n) < 0.9).astype(np.uint8)
+    blocks = (rng.uniform(size=n) < (0.5 if th > 50 else 0.9)).astype(np.uint8)  # (a claim by a map point without observations is overwritten by a later query)
     m = ORBmatcher(0.9, True, ctx=ctx)
     m.set_frame(k2, d2, BOUNDS)
     F2 = oracle.make_frame(k2, d2, BOUNDS)
@@ -247,16 +247,39 @@ def test_search_by_projection_over_a_window_equals_the_per_frame_calls(ctx, orac
                 want, nw = m.SearchByProjectionFrame(wps[p], vas[p], bls[p], mds[p], pk["octave"], pk["angle"], Ts[p], fx, fy, cx, cy, sf, 15.0)
                 got = tm[off:off + len(keysUn)]
                 assert nm[p] == nw and np.array_equal(got, want), (dist is not None, f0, p, nm[p], nw)
-                if p == 0:
-                    Fo = oracle.make_frame(keysUn, res[f0 + p + 1][1], bounds)
-                    otm, onm = oracle.search_by_projection_frame(Fo, wps[p], vas[p], bls[p], mds[p], pk["octave"], pk["angle"], Ts[p], fx, fy, cx, cy, sf, 15.0)
-                    assert onm == nw and np.array_equal(otm, want)
+                Fo = oracle.make_frame(keysUn, res[f0 + p + 1][1], bounds)
+                otm, onm = oracle.search_by_projection_frame(Fo, wps[p], vas[p], bls[p], mds[p], pk["octave"], pk["angle"], Ts[p], fx, fy, cx, cy, sf, 15.0)
+                assert onm == nw and np.array_equal(otm, want)
                 assert nw > 100
                 off += len(keysUn)
             assert off == n_train
             st = ms.last_counts()
             assert st["queries"] == sum(len(w) for w in wps) and st["candidates"] > st["queries"]
             m.close()
+    ms.close()
+    # a matcher whose FIRST window is small and whose second is the large one (arrays that shared one capacity), through an arena that starts too small
+    # for the second window's candidates (the cursor reports the need and the search runs again); and counts that are not the extractor's are refused
+    ms = ORBmatcherStream(True, ctx=ctx)
+    bounds = (0.0, float(Wt), 0.0, float(Ht))
+    for f0, n_pairs, th in ((4, 1, 15.0), (0, NF - 1, 60.0)):
+        wps, ones, Ts = [], [], []
+        for p in range(n_pairs):
+            pk, _ = res[f0 + p]
+            z = np.full(len(pk), 10.0, np.float32)
+            wps.append(np.stack([(pk["x"] - 3.0 - cx) / fx * z, (pk["y"] - cy) / fy * z, z], axis=1).astype(np.float32)); ones.append(np.ones(len(pk), np.uint8))
+            Ts.append(np.eye(4, dtype=np.float32)[:3])
+        n_train = sum(len(res[f0 + p + 1][0]) for p in range(n_pairs))
+        tm, nm = ms.search(orb, f0, n_pairs, K4, None, bounds, np.concatenate(wps), np.concatenate(ones), np.concatenate(ones), np.stack(Ts), fx, fy, cx, cy, sf, th, n_train)
+        off = 0
+        for p in range(n_pairs):
+            pk, pd = res[f0 + p]
+            ck, cd = res[f0 + p + 1]
+            Fo = oracle.make_frame(ck, cd, bounds)
+            otm, onm = oracle.search_by_projection_frame(Fo, wps[p], ones[p], ones[p], pd, pk["octave"], pk["angle"], Ts[p], fx, fy, cx, cy, sf, th)
+            assert onm == nm[p] and np.array_equal(otm, tm[off:off + len(ck)]) and onm > 100
+            off += len(ck)
+        with pytest.raises(Exception):
+            ms.search(orb, f0, n_pairs, K4, None, bounds, np.concatenate(wps), np.concatenate(ones), np.concatenate(ones), np.stack(Ts), fx, fy, cx, cy, sf, th, n_train + 1)
     ms.close(); orb.close()
 
 

@@ -1,5 +1,5 @@
 """Config 3's window search alone (ORB on `frames` frames of the 1241x376 stream, then ONE cs_match_by_projection_stream over the window's pairs), nothing else: the process the
-rocprofv3 --pmc passes of bench.py's measure_traffic wrap for `match_candidates_stream` (its two launches per call -- count, fill -- are averaged, like avg_kernel_us).
+rocprofv3 --pmc passes of bench.py's measure_traffic wrap for `match_candidates` (one launch per window since round 6: count, slice from a cursor, fill).
 python tools/pmc_c3_match.py [frames]"""
 import os
 import sys
