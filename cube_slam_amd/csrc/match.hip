@@ -139,65 +139,71 @@ __device__ __forceinline__ int hamming256(const unsigned long long *a, unsigned 
 // on the atomics' order and on nothing else: cstart / ccount address it, and nothing reads the arena in another way.  A slice that would end past `cap` is not written and
 // its count reads 0; the cursor still advances, so the host sees what the arena should have held and calls again.  The train frame of query q is key points
 // kfirst[q.pair] .. of `keys` / `desc`, its cell lists at q.pair x (NCELL + 1) / kfirst[q.pair].  A candidate is (index | level << 24, distance).
-__global__ void __launch_bounds__(256) match_candidates(FrameP F, const cs_keypoint *keys, const unsigned long long *desc, const int *kfirst, const int *cell_start_all, const int *cell_items_all, int nq,
-                                                        const QueryS *q, const unsigned long long *qdesc, unsigned long long *cursor, long cap, long *cstart, int *ccount, int2 *cands) {
-    const int qi = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
-    if (qi >= nq) return;
-    const QueryS Q = q[qi];
+constexpr int MC_WAVES = 4; // queries (waves) per workgroup, ONE cursor update per workgroup.  (Sixteen were measured: alone the same 2.6 ms per window of 10^6 queries, beside the line detectors' region walks 13 ms -- a workgroup of sixteen waves waits for a CU with four free slots per SIMD)
+__global__ void __launch_bounds__(64 * MC_WAVES) match_candidates(FrameP F, const cs_keypoint *keys, const unsigned long long *desc, const int *kfirst, const int *cell_start_all, const int *cell_items_all, int nq,
+                                                                  const QueryS *q, const unsigned long long *qdesc, unsigned long long *cursor, long cap, long *cstart, int *ccount, int2 *cands) {
+    __shared__ int s_tot[MC_WAVES];
+    __shared__ unsigned long long s_base;
+    const int wv = threadIdx.x >> 6, qi = blockIdx.x * MC_WAVES + wv, lane = threadIdx.x & 63;
+    QueryS Q{0, 0, 0, 0, 0, 0, 0};
+    if (qi < nq) Q = q[qi];
     int total = 0;
     long base = 0;
-    if (Q.valid) {
-        const int kb = kfirst ? kfirst[Q.pair] : 0;
-        const cs_keypoint *tk = keys + kb; const unsigned long long *td = desc + (size_t)kb * 4;
-        const int *cell_start = cell_start_all + (size_t)Q.pair * (NCELL + 1), *cell_items = cell_items_all + kb;
-        const float x = Q.x, y = Q.y, r = Q.r;
-        const int nMinCellX = max(0, (int)floorf((x - F.minX - r) * F.wInv));
-        const int nMaxCellX = min(GRID_COLS - 1, (int)ceilf((x - F.minX + r) * F.wInv));
-        const int nMinCellY = max(0, (int)floorf((y - F.minY - r) * F.hInv));
-        const int nMaxCellY = min(GRID_ROWS - 1, (int)ceilf((y - F.minY + r) * F.hInv));
-        if (!(nMinCellX >= GRID_COLS || nMaxCellX < 0 || nMinCellY >= GRID_ROWS || nMaxCellY < 0)) {
-            const bool bCheckLevels = (Q.minLevel > 0) || (Q.maxLevel >= 0);
-            const int ny = nMaxCellY - nMinCellY + 1, ncell = (nMaxCellX - nMinCellX + 1) * ny;
-            unsigned long long d0 = 0, d1 = 0, d2 = 0, d3 = 0;
-            if (qdesc) { d0 = qdesc[(size_t)qi * 4]; d1 = qdesc[(size_t)qi * 4 + 1]; d2 = qdesc[(size_t)qi * 4 + 2]; d3 = qdesc[(size_t)qi * 4 + 3]; }
-            auto passes = [&](const cs_keypoint &kp) {
-                bool ok = true;
-                if (bCheckLevels) { if (kp.octave < Q.minLevel) ok = false; if (Q.maxLevel >= 0 && kp.octave > Q.maxLevel) ok = false; }
-                const float distx = kp.x - x, disty = kp.y - y;
-                return ok && fabsf(distx) < r && fabsf(disty) < r;
-            };
-            auto walk = [&](bool fill) {
-                int tot = 0;
-                for (int k0 = 0; k0 < ncell; k0 += 64) {
-                    const int k = k0 + lane;
-                    int b = 0, e = 0;
-                    if (k < ncell) { int c = (nMinCellX + k / ny) * GRID_ROWS + nMinCellY + k % ny; b = cell_start[c]; e = cell_start[c + 1]; }
-                    int mine = 0;
-                    for (int p = b; p < e; p++) mine += passes(tk[cell_items[p]]);
-                    int inc = mine;
-                    for (int off = 1; off < 64; off <<= 1) { int t = __shfl_up(inc, off); if (lane >= off) inc += t; }
-                    if (fill && mine) {
-                        long o = base + tot + inc - mine;
-                        for (int p = b; p < e; p++) {
-                            const int id = cell_items[p];
-                            const cs_keypoint kp = tk[id];
-                            if (passes(kp)) { cands[o] = make_int2(id | ((kp.octave & 0xff) << 24), qdesc ? hamming256(td + (size_t)id * 4, d0, d1, d2, d3) : 0); o++; }
-                        }
-                    }
-                    tot += __shfl(inc, 63);
+    // (the window and the walk are the same for the counting and the filling half; the workgroup's waves meet in between to share one cursor update)
+    const int kb = (Q.valid && kfirst) ? kfirst[Q.pair] : 0;
+    const cs_keypoint *tk = keys + kb; const unsigned long long *td = desc + (size_t)kb * 4;
+    const int *cell_start = cell_start_all + (size_t)Q.pair * (NCELL + 1), *cell_items = cell_items_all + kb;
+    const float x = Q.x, y = Q.y, r = Q.r;
+    const int nMinCellX = max(0, (int)floorf((x - F.minX - r) * F.wInv));
+    const int nMaxCellX = min(GRID_COLS - 1, (int)ceilf((x - F.minX + r) * F.wInv));
+    const int nMinCellY = max(0, (int)floorf((y - F.minY - r) * F.hInv));
+    const int nMaxCellY = min(GRID_ROWS - 1, (int)ceilf((y - F.minY + r) * F.hInv));
+    const bool window = Q.valid && !(nMinCellX >= GRID_COLS || nMaxCellX < 0 || nMinCellY >= GRID_ROWS || nMaxCellY < 0);
+    const bool bCheckLevels = (Q.minLevel > 0) || (Q.maxLevel >= 0);
+    const int ny = nMaxCellY - nMinCellY + 1, ncell = window ? (nMaxCellX - nMinCellX + 1) * ny : 0;
+    unsigned long long d0 = 0, d1 = 0, d2 = 0, d3 = 0;
+    if (window && qdesc) { d0 = qdesc[(size_t)qi * 4]; d1 = qdesc[(size_t)qi * 4 + 1]; d2 = qdesc[(size_t)qi * 4 + 2]; d3 = qdesc[(size_t)qi * 4 + 3]; }
+    auto passes = [&](const cs_keypoint &kp) {
+        bool ok = true;
+        if (bCheckLevels) { if (kp.octave < Q.minLevel) ok = false; if (Q.maxLevel >= 0 && kp.octave > Q.maxLevel) ok = false; }
+        const float distx = kp.x - x, disty = kp.y - y;
+        return ok && fabsf(distx) < r && fabsf(disty) < r;
+    };
+    auto walk = [&](bool fill) {
+        int tot = 0;
+        for (int k0 = 0; k0 < ncell; k0 += 64) {
+            const int k = k0 + lane;
+            int b = 0, e = 0;
+            if (k < ncell) { int c = (nMinCellX + k / ny) * GRID_ROWS + nMinCellY + k % ny; b = cell_start[c]; e = cell_start[c + 1]; }
+            int mine = 0;
+            for (int p = b; p < e; p++) mine += passes(tk[cell_items[p]]);
+            int inc = mine;
+            for (int off = 1; off < 64; off <<= 1) { int t = __shfl_up(inc, off); if (lane >= off) inc += t; }
+            if (fill && mine) {
+                long o = base + tot + inc - mine;
+                for (int p = b; p < e; p++) {
+                    const int id = cell_items[p];
+                    const cs_keypoint kp = tk[id];
+                    if (passes(kp)) { cands[o] = make_int2(id | ((kp.octave & 0xff) << 24), qdesc ? hamming256(td + (size_t)id * 4, d0, d1, d2, d3) : 0); o++; }
                 }
-                return tot;
-            };
-            total = walk(false);
-            if (total) {
-                unsigned long long b = 0;
-                if (lane == 0) b = atomicAdd(cursor, (unsigned long long)total);
-                base = (long)__shfl((long long)b, 0);
-                if (base + total <= cap) walk(true); else total = 0;
             }
+            tot += __shfl(inc, 63);
         }
+        return tot;
+    };
+    total = walk(false);
+    if (lane == 0) s_tot[wv] = total;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        int sum = 0;
+        for (int k = 0; k < MC_WAVES; k++) sum += s_tot[k];
+        s_base = sum ? atomicAdd(cursor, (unsigned long long)sum) : 0ull;
     }
-    if (lane == 0) { cstart[qi] = base; ccount[qi] = total; }
+    __syncthreads();
+    base = (long)s_base;
+    for (int k = 0; k < wv; k++) base += s_tot[k];
+    if (total) { if (base + total <= cap) walk(true); else total = 0; }
+    if (lane == 0 && qi < nq) { cstart[qi] = base; ccount[qi] = total; }
 }
 
 // ---- the order-dependent half of the searches: claims, best / second, ratio tests, rotation histogram (match_resolve) ---------------------------------------------------
@@ -610,7 +616,7 @@ struct cs_matcher {
 // the window enumeration of nq queries in m->d_q against the frame set with cs_matcher_set_frame: cursor reset + one launch, nothing waits
 static int mt_candidates(cs_ctx *ctx, cs_matcher *m, int nq, bool with_desc) {
     CS_HIP(ctx, hipMemsetAsync(m->d_cursor, 0, 16, ctx->stream));
-    CS_LAUNCH(ctx, "match_candidates", match_candidates, dim3((nq + 3) / 4), dim3(256), 0, m->F, m->d_keys, m->d_desc, (const int *)nullptr, m->d_cell_start, m->d_cell_items, nq, m->d_q,
+    CS_LAUNCH(ctx, "match_candidates", match_candidates, dim3((nq + MC_WAVES - 1) / MC_WAVES), dim3(64 * MC_WAVES), 0, m->F, m->d_keys, m->d_desc, (const int *)nullptr, m->d_cell_start, m->d_cell_items, nq, m->d_q,
               with_desc ? m->d_qdesc : (const unsigned long long *)nullptr, m->d_cursor, m->max_cand, m->d_cstart, m->d_ccount, m->d_cands);
     m->last_q = nq;
     return CS_OK;
@@ -889,7 +895,7 @@ int cs_match_by_projection_stream(cs_ctx *ctx, cs_match_stream *m, const cs_orb 
     // size is last call's need; a window that needs more says so through the cursor and the two launches run again on a larger one.
     unsigned long long cur[2] = {0, 0};
     for (int attempt = 0;; attempt++) {
-        CS_LAUNCH(ctx, "match_candidates", match_candidates, dim3((nq + 3) / 4), dim3(256), 0, F, m->keys.p, d_d0, m->kfirst.p, m->cell_start.p, m->cell_items.p, nq, m->q.p, d_qdesc, m->d_cursor, (long)m->cands.cap,
+        CS_LAUNCH(ctx, "match_candidates", match_candidates, dim3((nq + MC_WAVES - 1) / MC_WAVES), dim3(64 * MC_WAVES), 0, F, m->keys.p, d_d0, m->kfirst.p, m->cell_start.p, m->cell_items.p, nq, m->q.p, d_qdesc, m->d_cursor, (long)m->cands.cap,
                   m->cstart.p, m->ccount.p, m->cands.p);
         ResolveP P{};
         P.cstart = m->cstart.p; P.ccount = m->ccount.p; P.cands = m->cands.p; P.pfirst = m->qfirst.p; P.kfirst = m->kfirst.p; P.tkeys = m->keys.p; P.qkeys = m->keys.p; P.blocks = m->blocks.p;
