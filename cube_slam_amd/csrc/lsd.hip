@@ -573,6 +573,7 @@ static void to_keylines(const std::vector<float> &lines, int W, int H, std::vect
 
 struct cs_lsd {
     int W = 0, H = 0, w = 0, h = 0, max_frames = 0, n_frames = 0;
+    int region_stage = 0; // cs_lsd_set_region_stage: CS_LSD_REGIONS_AUTO / _HOST / _WAVE_PER_FRAME / _BACKLOG
     GK gk{};
     double threshold = 0;
     size_t pix_bytes = 0; bool scaled_kept = true;           // the arena d_tmp = [d_blur | d_scaled], later [region stage's pixel records (pix_bytes) | LBD blur]
@@ -659,11 +660,12 @@ static int lsd_run(cs_ctx *ctx, cs_lsd *l, int with_lbd) {
     //   wlk    a walker wave with one lane per frame that seeds and grows + rectangle waves for the regions it parks, one workgroup (lsd_rg_wlk.h): 64 frames per
     //          wave slot instead of one, ~450 ms per frame -- for a backlog nobody waits for, by name only (round 4's grp / grp2 / lpf are gone);
     //   host   the OpenMP stage below, one frame per thread -- the default for smaller batches (one frame: 4 ms).
-    // CUBESLAM_LSD_REGIONS = seq | wlk | host overrides the choice.
+    // cs_lsd_set_region_stage picks one per detector (a caller with a backlog nobody waits for takes wlk: 3.7 x seq's frames/s with the chip full of it); the
+    // development override CUBESLAM_LSD_REGIONS = seq | wlk | host comes first (tests, tools).
     std::vector<std::vector<float>> dev_lines;
     bool on_device = false;
     const char *mode = getenv("CUBESLAM_LSD_REGIONS");
-    if (!mode || !*mode) mode = F >= 512 ? "seq" : "host";
+    if (!mode || !*mode) mode = l->region_stage == CS_LSD_REGIONS_HOST ? "host" : l->region_stage == CS_LSD_REGIONS_WAVE_PER_FRAME ? "seq" : l->region_stage == CS_LSD_REGIONS_BACKLOG ? "wlk" : (F >= 512 ? "seq" : "host");
     const int grp_p = strcmp(mode, "wlk") == 0 ? 65 : 0; // lsd_rg_wlk: walker waves with one lane per frame + rectangle waves
     const bool use_seq = total > 0 && (strcmp(mode, "seq") == 0 || grp_p);
     // lsd_rg_seq's records are written by the emit kernel itself when they live in the arena (always, unless a caller's frames outgrew it): no fill, no scatter
@@ -929,6 +931,12 @@ int cs_lsd_set_frames_device(cs_ctx *ctx, cs_lsd *l, const uint8_t *d_gray, int 
 }
 
 int cs_lsd_run(cs_ctx *ctx, cs_lsd *l, int with_lbd) { return lsd_run(ctx, l, with_lbd); }
+
+int cs_lsd_set_region_stage(cs_lsd *l, int stage) {
+    if (!l || stage < CS_LSD_REGIONS_AUTO || stage > CS_LSD_REGIONS_BACKLOG) return CS_ERR_BAD_ARG;
+    l->region_stage = stage;
+    return CS_OK;
+}
 
 int cs_lsd_region_stats(cs_ctx *ctx, cs_lsd *l, long out[5]) {
     if (!ctx || !l || !out) return CS_ERR_BAD_ARG;

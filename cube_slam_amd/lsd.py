@@ -44,6 +44,10 @@ class line_lbd_detect:
     def run(self, with_lbd=True):
         check(self.ctx.ptr, lib().cs_lsd_run(self.ctx.ptr, self._l, int(with_lbd)), "cs_lsd_run")
 
+    def set_region_stage(self, stage):
+        """'auto' | 'host' | 'wave_per_frame' | 'backlog' (cs_lsd_set_region_stage): the formulation of region_grow ... rect_improve of the next runs."""
+        check(self.ctx.ptr, lib().cs_lsd_set_region_stage(self._l, {"auto": 0, "host": 1, "wave_per_frame": 2, "backlog": 3}[stage]), "cs_lsd_set_region_stage")
+
     def region_stats(self):
         """Region stage of the last batch (see cs_lsd_region_stats): device = the one-wave-per-frame stage ran, grows = region_grow calls,
         candidates = rectangles at rect_improve, host_fallback, fetches = pixel-window fetches.  All zero for the host stage."""

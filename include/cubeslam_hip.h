@@ -436,10 +436,18 @@ int cs_lsd_upload(cs_ctx *ctx, cs_lsd *l, const uint8_t *gray, int n_frames, int
 int cs_lsd_run(cs_ctx *ctx, cs_lsd *l, int with_lbd);
 /* The region stage (lsd.cpp:464-535: region_grow ... rect_improve) of the last batch.  Batches of 512 frames and more run it on the device, one
  * wave per frame walking the reference's sequence (cube_slam_amd/csrc/lsd_regions.hip); smaller ones on the host's cores, one frame per thread;
- * CUBESLAM_LSD_REGIONS = seq | host overrides the choice.  Both give the same KeyLines byte for byte.
+ * cs_lsd_set_region_stage picks the stage for a detector's later runs.  Every stage gives the same KeyLines byte for byte.
  * out[0] 1 when the device stage was chosen, out[1] region_grow calls, out[2] rectangles that reached rect_improve,
  * out[3] 1 when the batch fell back to the host stage (a region larger than the device list), out[4] pixel-window fetches.  All 0 for the host stage. */
 int cs_lsd_region_stats(cs_ctx *ctx, cs_lsd *l, long out[5]);
+/* Which formulation of the region stage the detector's next runs take:
+ *   CS_LSD_REGIONS_AUTO            the host stage below 512 frames per run, one wave per frame from 512 on (the default);
+ *   CS_LSD_REGIONS_HOST            one frame per host thread (a frame: ~3.5 ms);
+ *   CS_LSD_REGIONS_WAVE_PER_FRAME  one wave walks a frame's sequence (~110 ms per frame whatever the batch; 36 k frames/s with the chip full of frames);
+ *   CS_LSD_REGIONS_BACKLOG         a walker lane per frame + rectangle waves (64 frames per wave slot, ~450 ms per frame, 134 k frames/s with the chip full): for an offline
+ *                                  backlog of tens of thousands of frames whose lines nobody waits for. */
+enum { CS_LSD_REGIONS_AUTO = 0, CS_LSD_REGIONS_HOST = 1, CS_LSD_REGIONS_WAVE_PER_FRAME = 2, CS_LSD_REGIONS_BACKLOG = 3 };
+int cs_lsd_set_region_stage(cs_lsd *l, int stage);
 int cs_lsd_read(cs_ctx *ctx, cs_lsd *l, int frame, cs_keyline *out, int cap, int *count, uint8_t *desc /* cap x 32 or NULL */);
 
 /* ===================================================================== LBD line descriptor + matcher

@@ -83,6 +83,23 @@ def test_device_region_stage_other_size_and_capacity_fallback(ctx, oracle, monke
     det.close()
 
 
+def test_region_stage_by_the_api(ctx, oracle, monkeypatch):
+    """cs_lsd_set_region_stage: the caller's choice per detector (the backlog stage has no other way in), same KeyLines from every stage."""
+    monkeypatch.delenv("CUBESLAM_LSD_REGIONS", raising=False)
+    imgs = [synth.cuboid_scene(90 + i, n_boxes=3, bg_texture=0.25 * i)["gray"] for i in range(4)]
+    det = line_lbd_detect(640, 480, max_frames=len(imgs), ctx=ctx)
+    want = [oracle.lsd_detect(im) for im in imgs]
+    for stage, device in (("auto", False), ("backlog", True), ("wave_per_frame", True), ("host", False)):
+        det.set_region_stage(stage)
+        got = det.detect_raw_lines(np.stack(imgs))
+        assert det.region_stats()["device"] == device, stage
+        for f in range(len(imgs)):
+            assert got[f].tobytes() == want[f].tobytes(), (stage, f)
+    from cube_slam_amd._lib import lib
+    assert lib().cs_lsd_set_region_stage(det._l, 9) != 0  # not a stage
+    det.close()
+
+
 def test_large_batches_take_the_device_region_stage(ctx, oracle, monkeypatch):
     """512 frames (16 distinct ones, repeated) through the resident-batch form: the device stage is the default there, all frames give their own lines."""
     monkeypatch.delenv("CUBESLAM_LSD_REGIONS", raising=False)
