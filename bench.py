@@ -154,19 +154,30 @@ def cpu_baseline_ref(scenes, yaw_step, budget_s=8.0, with_orb=True, nfeat=1000, 
                       "detect_cuboid text on the OpenCV / Eigen stand-ins of oracle/ref_shim, 1 thread" % (n, dt)}
 
 
-def streamed_bench(fe, ctx, side_ctxs, orb, batch, lsds, gray, steps, warmup, torch):
+def streamed_bench(fe, ctx, side_ctxs, orb, batch, lsds, scenes, steps, warmup, torch):
     """The front-end with frames that ARRIVE: every step takes 1 024 new frames from pinned host memory through the runner's ring (cs_frontend_stream_*: H2D on a copy stream of
-    its own while the step before computes, device copies into ORB, the cuboid batch and the step's line pass) and its results go back to the host inside the clock -- ORB key
-    points + descriptors and the cuboids on a second copy stream behind the step's kernels (cs_frontend_stream_read_async), KeyLines + LBD descriptors by the line
-    worker at the end of its pass (they are host data when the pass completes; the drain inside the clock waits for the last pass).  No step repeats another's pixels: set k
-    is the scenes' pixels with the low bit flipped by a pattern of its own (the 2-D boxes, poses and the cuboid plan are external inputs and stay)."""
-    F, H, W = gray.shape
+    its own while the step before computes, device copies into ORB, the cuboid batch and the step's line pass) WITH what detect_cuboid takes beside the pixels -- the frames'
+    2-D boxes, camera poses and edge lists (cs_frontend_stream_push_scene): the cuboid batch's plan is rebuilt for every step inside the clock -- and its results go back to
+    the host inside the clock: ORB key points + descriptors and the cuboids on a second copy stream behind the step's kernels (cs_frontend_stream_read_async), KeyLines + LBD
+    descriptors by the line worker at the end of its pass (they are host data when the pass completes; the drain inside the clock waits for the last pass).  No two steps
+    hold the same scenes: every step's frames are a draw (without replacement) from a pool of twice as many distinct scenes as a step holds -- other pixels, other geometry,
+    other proposal counts, another unit plan per step."""
+    from cube_slam_amd.cuboid import CuboidBatch
+    F = len(scenes)
+    H, W = scenes[0]["gray"].shape
     n_sets = warmup + steps
+    n_boxes_per = len(scenes[0]["boxes"])
+    pool = list(scenes) + make_frames(F, n_boxes_per, seed0=7000000)  # as many scenes again that nothing has seen yet
     rng = np.random.default_rng(11)
     host = torch.empty((n_sets, F, H, W), dtype=torch.uint8, pin_memory=True)
     sets = host.numpy()
+    packs, box_area = [], []
     for k in range(n_sets):
-        np.bitwise_xor(gray, rng.integers(0, 2, (1, H, W), dtype=np.uint8), out=sets[k])
+        pick = rng.permutation(len(pool))[:F]
+        for f, i in enumerate(pick):
+            sets[k, f] = pool[i]["gray"]
+        packs.append(CuboidBatch.pack_scene(np.stack([pool[i]["Twc"] for i in pick]), [pool[i]["boxes"] for i in pick], [pool[i]["lines"] for i in pick]))
+        box_area.append(float(sum((pool[i]["boxes"][:, 2] * pool[i]["boxes"][:, 3]).sum() for i in pick)))
     from cube_slam_amd.cuboid import CUBOID_DTYPE
     pin = lambda nbytes: torch.empty((nbytes,), dtype=torch.uint8, pin_memory=True).numpy()  # noqa: E731
     bufs = []
@@ -186,14 +197,14 @@ def streamed_bench(fe, ctx, side_ctxs, orb, batch, lsds, gray, steps, warmup, to
 
     def one(k):
         if k + 1 < n_sets:
-            fe.stream_push(sets[k + 1])
+            fe.stream_push_scene(sets[k + 1], packs[k + 1])
         fe.step()
         fe.stream_read_wait()  # the copies of step k - 1 (long done: its buffers are the caller's now)
         b = bufs[k & 1]
         _, total = fe.stream_read_async(b["kps"], b["desc"], b["cub"], b["cnt"])
         d2h[0] += total * (28 + 32) + b["cub"].nbytes + b["cnt"].nbytes
     fe.stream_begin(F, W, H, 3)
-    fe.stream_push(sets[0])
+    fe.stream_push_scene(sets[0], packs[0])
     for k in range(warmup):
         one(k)
     barrier()
@@ -210,9 +221,9 @@ def streamed_bench(fe, ctx, side_ctxs, orb, batch, lsds, gray, steps, warmup, to
     return {"metric": "frames/s front-end with 1 024 NEW frames per step: H2D, ORB + cuboid + line pass, results D2H, all inside the clock", "value": F * steps / dt, "unit": "frames/s",
             "ms_per_step": 1e3 * dt / steps, "steps": steps, "warmup": warmup,
             "h2d_GBps": h2d / dt / 1e9, "d2h_GBps": (d2h[0] + steps * line_bytes) / dt / 1e9, "h2d_MB_per_step": F * H * W / 1e6, "d2h_MB_per_step": (d2h[0] / steps + line_bytes) / 1e6,
-            "ring_slots": 3, "distinct_pixel_sets": n_sets,
-            "what": "cs_frontend_stream_push of step k + 1 before cs_frontend_step of step k (pinned memory, a copy stream of its own); every step's pixels differ (low bit flipped by a per-step "
-                    "pattern), boxes / poses / plan stay; ORB + cuboid results copied to pinned host buffers on a second copy stream behind each step's kernels (cs_frontend_stream_read_async; the next step's kernels wait for "
+            "ring_slots": 3, "distinct_scene_sets": n_sets, "scene_pool": len(pool), "box_area_per_step_Mpx": [round(min(box_area) / 1e6, 2), round(max(box_area) / 1e6, 2)],
+            "what": "cs_frontend_stream_push_scene of step k + 1 before cs_frontend_step of step k (pinned memory, a copy stream of its own): every step brings its own frames WITH their boxes, "
+                    "poses and edge lists (a draw of 1 024 from a pool of 2 048 distinct scenes; the cuboid plan is rebuilt per step inside the clock); ORB + cuboid results copied to pinned host buffers on a second copy stream behind each step's kernels (cs_frontend_stream_read_async; the next step's kernels wait for "
                     "the copies on the device), line results by the workers at the end of each pass"}
 
 
@@ -841,7 +852,7 @@ def main():
         if lsd is not None:
             extra["chained"] = chained_bench(ctx, fe, lsds, batch, scenes, args.frames, args.steps, barrier, backlog=bool(args.backlog))
             try:
-                extra["streamed"] = streamed_bench(fe, ctx, side_ctxs, orb, batch, lsds, np.stack([s_["gray"] for s_ in scenes]), args.steps, 3, torch)
+                extra["streamed"] = streamed_bench(fe, ctx, side_ctxs, orb, batch, lsds, scenes, args.steps, 3, torch)
             except Exception as e:  # (the block stands beside the headline; a failure must not cost the line)
                 extra["streamed"] = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
         # the drop-in calls belong to another kind of process than the batch runner: measured in one, with the runtime's default hardware queues (tools/pcie_probe.py)

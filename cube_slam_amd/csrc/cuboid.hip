@@ -1066,6 +1066,15 @@ __global__ void __launch_bounds__(256) cuboid_unit_corners(const Unit *units, in
     for (int k = 0; k < 8; k++) { out[(long)k * n_hyp + h] = c[k].x; out[(long)(8 + k) * n_hyp + h] = c[k].y; }
 }
 
+// the padding of every unit's map slice (its A pixels are rounded up to 64) back to zero: cuboid_sweep_score copies and encodes whole groups of eight floats, and after
+// cs_cuboid_batch_set_scene the slices lie where other units' pixels were
+__global__ void __launch_bounds__(256) cuboid_clear_pad(const Unit *units, int n_units, float *dist) {
+    const int u = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (u >= n_units) return;
+    const long A = (long)units[u].roi_w * units[u].roi_h, Ap = (A + 63) / 64 * 64;
+    if (A + lane < Ap) dist[units[u].pix_off + A + lane] = 0.0f;
+}
+
 // ---- cuboid_sweep_score: corner construction + edge scoring of the surviving proposals, the unit's distance map resident in LDS -------------
 // Why LDS: scoring is a gather (99 / 77 samples per proposal at positions that differ from lane to lane); through global memory every
 // gathered lane costs the texture-address path about one CU-cycle (round 1: TA_BUSY 80 %).  LDS serves 32 lanes per cycle.
@@ -1792,6 +1801,9 @@ struct cs_cuboid_batch {
     std::vector<Unit> units;
     std::vector<FrameInfo> fi;   // host copy (cs_cuboid_batch_set_lines rewrites the line ranges)
     long cap_lines_in = 0, cap_line_rows = 0;
+    // capacities of the plan-sized device arrays (cs_cuboid_batch_set_scene grows them when another set of boxes needs more) and the pinned staging of its uploads
+    long cap_pix = 0, cap_hyp = 0, cap_vp = 0, cap_dttmp = 0; int cap_units = 0, cap_boxes = 0, sample_bbox_height = 0;
+    uint8_t *h_stage[2] = {nullptr, nullptr}; size_t stage_cap[2] = {0, 0}; hipEvent_t stage_ev[2] = {nullptr, nullptr}; int stage_k = 0;
     std::vector<int> box_first_unit;
     long pix_total = 0, hyp_total = 0, vp_total = 0, line_rows = 0;
     int max_tiles = 0, max_cc_blocks = 0, max_vp_blocks = 0, blocks_per_unit = 0, max_roi_w = 0;
@@ -1819,6 +1831,111 @@ struct cs_cuboid_batch {
     cs_cuboid *d_out = nullptr;
 };
 
+
+// The plan of a batch: one Unit per (frame, box, height sample) with its ROI, top samples and its slices of the pixel / hypothesis / vanishing-point / merged-line arenas
+// (box_proposal_detail.cpp:107-161), and the per-frame pose record.  Built on the host from the boxes and poses alone (3 072 units: ~0.2 ms), by cs_cuboid_batch_create and
+// again by cs_cuboid_batch_set_scene when a step brings other boxes.  keep_lines: the frames' line ranges when the edge lists stay (line_offsets NULL).
+struct Plan {
+    std::vector<Unit> units; std::vector<FrameInfo> fi; std::vector<int> box_first_unit;
+    long pix_total = 0, hyp_total = 0, vp_total = 0, line_rows = 0;
+    int max_tiles = 0, max_cc_blocks = 0, max_vp_blocks = 0, blocks_per_unit = 0, max_roi_w = 0, n_boxes = 0;
+};
+static int plan_build(const Opts &o, int sample_bbox_height, int n_frames, int width, int height, const double *Twc, const int *box_offsets, const double *boxes, const int *line_offsets,
+                      const std::vector<FrameInfo> *keep_lines, Plan &P) {
+    P.n_boxes = box_offsets[n_frames];
+    std::vector<FrameInfo> &fi = P.fi;
+    fi.resize(n_frames);
+    for (int f = 0; f < n_frames; f++) {
+        for (int i = 0; i < 16; i++) fi[f].T[i] = Twc[(long)f * 16 + i];
+        host_euler_from_T(fi[f].T, fi[f].euler);
+        fi[f].yaw_src = fi[f].euler[2];
+        if (line_offsets) { fi[f].line_off = line_offsets[f]; fi[f].n_lines = line_offsets[f + 1] - line_offsets[f]; }
+        else { fi[f].line_off = (*keep_lines)[f].line_off; fi[f].n_lines = (*keep_lines)[f].n_lines; }
+    }
+    const int rp_cap = o.sample_rp ? 25 : 1; // 5x5 at most (linespace +-6 deg step 3 deg gives 4 or 5 per axis)
+    for (int f = 0; f < n_frames; f++)
+        for (int bi = box_offsets[f]; bi < box_offsets[f + 1]; bi++) {
+            const double *bb = boxes + (long)bi * 5;
+            // box_proposal_detail.cpp:107-123
+            int left_x_raw = (int)bb[0], top_y_raw = (int)bb[1], obj_width_raw = (int)bb[2], obj_height_raw = (int)bb[3];
+            int right_x_raw = (int)(left_x_raw + bb[2]);
+            int hs_list[3], n_hs = 0;
+            hs_list[n_hs++] = 0;
+            if (sample_bbox_height) {
+                int r = std::max(std::min(20, obj_height_raw - 90), 20);
+                r = std::min(r, height - top_y_raw - obj_height_raw - 1);
+                if (r > 10) hs_list[n_hs++] = (int)std::round(r / 2);
+                hs_list[n_hs++] = r;
+            }
+            P.box_first_unit.push_back((int)P.units.size());
+            for (int hs = 0; hs < n_hs; hs++) {
+                Unit U{};
+                U.frame = f; U.box = bi; U.hs = hs; U.n_hs = n_hs;
+                U.left = left_x_raw; U.top = top_y_raw; U.right = right_x_raw; U.width_raw = obj_width_raw; U.height_raw = obj_height_raw;
+                U.down_expand = hs_list[hs];
+                int obj_height_expan = obj_height_raw + U.down_expand; // :139-141
+                U.down_y_expan = top_y_raw + obj_height_expan;
+                U.diag = std::sqrt((double)(obj_width_raw * obj_width_raw + obj_height_expan * obj_height_expan));
+                int res = (int)std::round((double)std::min(20, obj_width_raw / 10)); // :144-146
+                {
+                    int s = left_x_raw + 5, e = right_x_raw - 5, n = 0;
+                    while (s <= e) { n++; s += res; if (n > 1000) break; }
+                    U.n_tops = n; U.top_start = left_x_raw + 5; U.top_step = res;
+                }
+                if (U.n_tops > 1) { // pair index / n_tops by one multiply when that is exact for every pair index of the unit (p * e < 2^32, e = magic * n - 2^32)
+                    const unsigned long long magic = (1ull << 32) / (unsigned)U.n_tops + 1, e = magic * (unsigned)U.n_tops - (1ull << 32);
+                    const unsigned long long pmax = (unsigned long long)rp_cap * o.yaw_cap * U.n_tops;
+                    U.tops_magic = (magic < (1ull << 32) && pmax * e < (1ull << 32)) ? (unsigned)magic : 0u;
+                }
+                int ew = std::min(std::max(std::min(20, obj_width_raw - 100), 10), std::max(std::min(20, obj_height_expan - 100), 10)); // :155
+                U.roi_x = std::max(0, left_x_raw - ew);
+                U.roi_r = std::min(width - 1, right_x_raw + ew);
+                U.roi_y = std::max(0, top_y_raw - ew);
+                U.roi_b = std::min(height - 1, U.down_y_expan + ew);
+                U.roi_w = U.roi_r - U.roi_x; U.roi_h = U.roi_b - U.roi_y;
+                if (U.roi_w <= 0 || U.roi_h <= 0 || U.roi_x + U.roi_w > width || U.roi_y + U.roi_h > height) return CS_ERR_BAD_ARG;
+                U.pix_off = P.pix_total; P.pix_total += ((long)U.roi_w * U.roi_h + 63) / 64 * 64;
+                U.hyp_cap = rp_cap * o.yaw_cap * U.n_tops * 2;
+                U.hyp_off = P.hyp_total; P.hyp_total += ((long)U.hyp_cap + 63) / 64 * 64;
+                U.vp_off = (int)P.vp_total; P.vp_total += (long)rp_cap * o.yaw_cap;
+                U.line_off = (int)P.line_rows; P.line_rows += std::min(fi[f].n_lines, CS_MAX_ROI_LINES);
+                P.max_roi_w = std::max(P.max_roi_w, U.roi_w);
+                P.max_tiles = std::max(P.max_tiles, ((U.roi_w + NMS_TW - 1) / NMS_TW) * ((U.roi_h + NMS_TH - 1) / NMS_TH));
+                P.max_cc_blocks = std::max(P.max_cc_blocks, (int)(((long)U.roi_w * U.roi_h + 4095) / 4096));
+                P.blocks_per_unit = std::max(P.blocks_per_unit, (U.hyp_cap + SWEEP_HB - 1) / SWEEP_HB);
+                P.units.push_back(U);
+            }
+        }
+    P.max_vp_blocks = (rp_cap * o.yaw_cap + 255) / 256;
+    if (P.vp_total > INT_MAX || P.line_rows > INT_MAX) return CS_ERR_CAPACITY;
+    return CS_OK;
+}
+static void plan_commit(cs_cuboid_batch *b, Plan &P) {
+    b->units.swap(P.units); b->fi.swap(P.fi); b->box_first_unit.swap(P.box_first_unit);
+    b->n_boxes = P.n_boxes; b->n_units = (int)b->units.size();
+    b->pix_total = P.pix_total; b->hyp_total = P.hyp_total; b->vp_total = P.vp_total; b->line_rows = P.line_rows;
+    b->max_tiles = P.max_tiles; b->max_cc_blocks = P.max_cc_blocks; b->max_vp_blocks = P.max_vp_blocks; b->blocks_per_unit = P.blocks_per_unit; b->max_roi_w = P.max_roi_w;
+}
+// the distance transform's column count per lane, its scratch offsets, the score kernel's item split and the units by falling cost estimate: functions of the plan
+static void plan_derived(cs_cuboid_batch *b, std::vector<long> &dt_off, std::vector<int> &order) {
+    static const int CS_[] = {4, 5, 6, 8, 10, 12, 16, 20};
+    const int need = (b->max_roi_w + 63) / 64;
+    b->dt_C = 0;
+    for (int c : CS_) if (c >= need) { b->dt_C = c; break; }
+    const char *dte = getenv("CUBESLAM_DT"); // "block": the workgroup-per-ROI variant
+    if (dte && !strcmp(dte, "block")) b->dt_C = 0;
+    dt_off.assign(b->units.size() + 1, 0);
+    if (b->dt_C) for (size_t u = 0; u < b->units.size(); u++) dt_off[u + 1] = dt_off[u] + (long)b->units[u].roi_h * b->dt_C * 64;
+    b->score_slices = b->n_units >= 2 * b->score_G ? 1 : std::min(16, (2 * b->score_G + b->n_units - 1) / std::max(1, b->n_units));
+    const char *se = getenv("CUBESLAM_SCORE_SLICES"); // tuning knob / tests: items per unit
+    if (se && atoi(se) > 0) b->score_slices = std::min(64, atoi(se));
+    // units by falling cost estimate (map copy ~ pixels, scoring ~ hypotheses): the persistent workgroups take the big ones first
+    order.resize(b->units.size());
+    for (size_t i = 0; i < order.size(); i++) order[i] = (int)i;
+    auto cost = [&](int u) { const Unit &U = b->units[u]; return 0.19 * (double)U.roi_w * U.roi_h + 10.8 * (double)U.hyp_cap; };
+    std::stable_sort(order.begin(), order.end(), [&](int a, int c) { return cost(a) > cost(c); });
+}
+
 extern "C" {
 
 void cs_cuboid_default_opts(cs_cuboid_opts *o) {
@@ -1836,6 +1953,7 @@ void cs_cuboid_batch_destroy(cs_ctx *ctx, cs_cuboid_batch *b) {
                     b->d_mlines, b->d_mangle, b->d_mmid, b->d_units, b->d_ud, b->d_box_first, b->d_status, b->d_counts, b->d_carry, b->d_vp,
                     b->d_derr, b->d_aerr, b->d_score, b->d_nscore, b->d_ckd, b->d_cka, b->d_cidx, b->d_out, b->d_vcount, b->d_vlist, b->d_order, b->d_cursor, b->d_uflag, b->d_prof};
     for (void *p : ptrs) cs_dfree(ctx, p);
+    for (int k = 0; k < 2; k++) { if (b->h_stage[k]) hipHostFree(b->h_stage[k]); if (b->stage_ev[k]) hipEventDestroy(b->stage_ev[k]); }
     delete b;
 }
 
@@ -1865,93 +1983,20 @@ int cs_cuboid_batch_create(cs_ctx *ctx, int n_frames, int width, int height, con
         ctx->err = "chamfer constants mismatch"; delete b; return CS_ERR_BAD_ARG;
     }
     const int n_boxes = box_offsets[n_frames], n_lines = line_offsets[n_frames];
-    b->n_boxes = n_boxes;
-    std::vector<FrameInfo> &fi = b->fi;
-    fi.resize(n_frames);
-    for (int f = 0; f < n_frames; f++) {
-        for (int i = 0; i < 16; i++) fi[f].T[i] = Twc[(long)f * 16 + i];
-        host_euler_from_T(fi[f].T, fi[f].euler);
-        fi[f].yaw_src = fi[f].euler[2];
-        fi[f].line_off = line_offsets[f]; fi[f].n_lines = line_offsets[f + 1] - line_offsets[f];
+    b->sample_bbox_height = opts->whether_sample_bbox_height;
+    {
+        Plan P;
+        const int status = plan_build(o, b->sample_bbox_height, n_frames, width, height, Twc, box_offsets, boxes, line_offsets, nullptr, P);
+        if (status == CS_ERR_CAPACITY) { delete b; return status; }
+        if (status != CS_OK) { ctx->err = "box ROI outside the image"; delete b; return status; }
+        plan_commit(b, P);
     }
-    const int rp_cap = o.sample_rp ? 25 : 1; // 5x5 at most (linespace +-6 deg step 3 deg gives 4 or 5 per axis)
-    int status = CS_OK;
-    for (int f = 0; f < n_frames && status == CS_OK; f++)
-        for (int bi = box_offsets[f]; bi < box_offsets[f + 1]; bi++) {
-            const double *bb = boxes + (long)bi * 5;
-            // box_proposal_detail.cpp:107-123
-            int left_x_raw = (int)bb[0], top_y_raw = (int)bb[1], obj_width_raw = (int)bb[2], obj_height_raw = (int)bb[3];
-            int right_x_raw = (int)(left_x_raw + bb[2]);
-            int hs_list[3], n_hs = 0;
-            hs_list[n_hs++] = 0;
-            if (opts->whether_sample_bbox_height) {
-                int r = std::max(std::min(20, obj_height_raw - 90), 20);
-                r = std::min(r, height - top_y_raw - obj_height_raw - 1);
-                if (r > 10) hs_list[n_hs++] = (int)std::round(r / 2);
-                hs_list[n_hs++] = r;
-            }
-            b->box_first_unit.push_back((int)b->units.size());
-            for (int hs = 0; hs < n_hs; hs++) {
-                Unit U{};
-                U.frame = f; U.box = bi; U.hs = hs; U.n_hs = n_hs;
-                U.left = left_x_raw; U.top = top_y_raw; U.right = right_x_raw; U.width_raw = obj_width_raw; U.height_raw = obj_height_raw;
-                U.down_expand = hs_list[hs];
-                int obj_height_expan = obj_height_raw + U.down_expand; // :139-141
-                U.down_y_expan = top_y_raw + obj_height_expan;
-                U.diag = std::sqrt((double)(obj_width_raw * obj_width_raw + obj_height_expan * obj_height_expan));
-                int res = (int)std::round((double)std::min(20, obj_width_raw / 10)); // :144-146
-                {
-                    int s = left_x_raw + 5, e = right_x_raw - 5, n = 0;
-                    while (s <= e) { n++; s += res; if (n > 1000) break; }
-                    U.n_tops = n; U.top_start = left_x_raw + 5; U.top_step = res;
-                }
-                if (U.n_tops > 1) { // pair index / n_tops by one multiply when that is exact for every pair index of the unit (p * e < 2^32, e = magic * n - 2^32)
-                    const unsigned long long magic = (1ull << 32) / (unsigned)U.n_tops + 1, e = magic * (unsigned)U.n_tops - (1ull << 32);
-                    const unsigned long long pmax = (unsigned long long)rp_cap * o.yaw_cap * U.n_tops;
-                    U.tops_magic = (magic < (1ull << 32) && pmax * e < (1ull << 32)) ? (unsigned)magic : 0u;
-                }
-                int ew = std::min(std::max(std::min(20, obj_width_raw - 100), 10), std::max(std::min(20, obj_height_expan - 100), 10)); // :155
-                U.roi_x = std::max(0, left_x_raw - ew);
-                U.roi_r = std::min(width - 1, right_x_raw + ew);
-                U.roi_y = std::max(0, top_y_raw - ew);
-                U.roi_b = std::min(height - 1, U.down_y_expan + ew);
-                U.roi_w = U.roi_r - U.roi_x; U.roi_h = U.roi_b - U.roi_y;
-                if (U.roi_w <= 0 || U.roi_h <= 0 || U.roi_x + U.roi_w > width || U.roi_y + U.roi_h > height) { status = CS_ERR_BAD_ARG; break; }
-                U.pix_off = b->pix_total; b->pix_total += ((long)U.roi_w * U.roi_h + 63) / 64 * 64;
-                U.hyp_cap = rp_cap * o.yaw_cap * U.n_tops * 2;
-                U.hyp_off = b->hyp_total; b->hyp_total += ((long)U.hyp_cap + 63) / 64 * 64;
-                U.vp_off = (int)b->vp_total; b->vp_total += (long)rp_cap * o.yaw_cap;
-                U.line_off = (int)b->line_rows; b->line_rows += std::min(fi[f].n_lines, CS_MAX_ROI_LINES);
-                b->max_roi_w = std::max(b->max_roi_w, U.roi_w);
-                b->max_tiles = std::max(b->max_tiles, ((U.roi_w + NMS_TW - 1) / NMS_TW) * ((U.roi_h + NMS_TH - 1) / NMS_TH));
-                b->max_cc_blocks = std::max(b->max_cc_blocks, (int)(((long)U.roi_w * U.roi_h + 4095) / 4096));
-                b->blocks_per_unit = std::max(b->blocks_per_unit, (U.hyp_cap + SWEEP_HB - 1) / SWEEP_HB);
-                b->units.push_back(U);
-            }
-        }
-    if (status != CS_OK) { ctx->err = "box ROI outside the image"; delete b; return status; }
-    b->n_units = (int)b->units.size();
-    b->max_vp_blocks = (rp_cap * o.yaw_cap + 255) / 256;
-    if (b->vp_total > INT_MAX || b->line_rows > INT_MAX) { delete b; return CS_ERR_CAPACITY; }
+    b->cap_pix = b->pix_total; b->cap_hyp = b->hyp_total; b->cap_vp = b->vp_total; b->cap_units = b->n_units; b->cap_boxes = n_boxes;
 
 #define A_(call) do { int r__ = (call); if (r__ != CS_OK) { cs_cuboid_batch_destroy(ctx, b); return r__; } } while (0)
     const size_t npx = (size_t)n_frames * width * height;
     A_(cs_dalloc(ctx, &b->d_gray, npx));
     A_(cs_dalloc(ctx, &b->d_emap, (size_t)b->pix_total + 256)); // slack: the wave distance transform reads whole dwords at the row ends
-    {
-        static const int CS_[] = {4, 5, 6, 8, 10, 12, 16, 20};
-        const int need = (b->max_roi_w + 63) / 64;
-        for (int c : CS_) if (c >= need) { b->dt_C = c; break; }
-        const char *dte = getenv("CUBESLAM_DT"); // "block": the workgroup-per-ROI variant
-        if (dte && !strcmp(dte, "block")) b->dt_C = 0;
-        if (b->dt_C) {
-            std::vector<long> off(b->units.size() + 1, 0);
-            for (size_t u = 0; u < b->units.size(); u++) off[u + 1] = off[u] + (long)b->units[u].roi_h * b->dt_C * 64;
-            A_(cs_dalloc(ctx, &b->d_dttmp, (size_t)std::max<long>(off.back(), 1)));
-            A_(cs_dalloc(ctx, &b->d_dttmp_off, off.size()));
-            A_(cs_h2d(ctx, b->d_dttmp_off, off.data(), off.size()));
-        }
-    }
     {
         for (const void *fn : {reinterpret_cast<const void *>(cuboid_sweep_score<256>), reinterpret_cast<const void *>(cuboid_sweep_score<512>), reinterpret_cast<const void *>(cuboid_sweep_score<768>),
                                reinterpret_cast<const void *>(cuboid_sweep_score<1024>)}) { // (per call: the attribute is per device)
@@ -1969,18 +2014,17 @@ int cs_cuboid_batch_create(cs_ctx *ctx, int n_frames, int width, int height, con
         if (ge && atoi(ge) > 0) b->score_G = atoi(ge);
         const char *te = getenv("CUBESLAM_SCORE_THREADS"); // tuning knob: 512 (2 waves per SIMD, 256 registers) or 1024 (4 waves per SIMD, 128 registers)
         if (te && (atoi(te) == 256 || atoi(te) == 512 || atoi(te) == 768 || atoi(te) == 1024)) { b->score_T = atoi(te); b->score_T_forced = true; }
-        b->score_slices = b->n_units >= 2 * b->score_G ? 1 : std::min(16, (2 * b->score_G + b->n_units - 1) / std::max(1, b->n_units));
-        const char *se = getenv("CUBESLAM_SCORE_SLICES"); // tuning knob / tests: items per unit
-        if (se && atoi(se) > 0) b->score_slices = std::min(64, atoi(se));
-        // units by falling cost estimate (map copy ~ pixels, scoring ~ hypotheses): the persistent workgroups take the big ones first
-        std::vector<int> order(b->units.size());
-        for (size_t i = 0; i < order.size(); i++) order[i] = (int)i;
-        auto cost = [&](int u) { const Unit &U = b->units[u]; return 0.19 * (double)U.roi_w * U.roi_h + 10.8 * (double)U.hyp_cap; };
-        std::stable_sort(order.begin(), order.end(), [&](int a, int c) { return cost(a) > cost(c); });
+        std::vector<long> dt_off; std::vector<int> order;
+        plan_derived(b, dt_off, order);
+        b->cap_dttmp = std::max<long>(dt_off.back(), 1);
+        A_(cs_dalloc(ctx, &b->d_dttmp, (size_t)b->cap_dttmp));
+        A_(cs_dalloc(ctx, &b->d_dttmp_off, dt_off.size()));
+        A_(cs_h2d(ctx, b->d_dttmp_off, dt_off.data(), dt_off.size()));
         A_(cs_dalloc(ctx, &b->d_order, std::max<size_t>(1, order.size())));
         A_(cs_h2d(ctx, b->d_order, order.data(), order.size()));
+        CS_HIP(ctx, hipStreamSynchronize(ctx->stream)); // (the two vectors are locals)
         A_(cs_dalloc(ctx, &b->d_cursor, (size_t)1));
-        A_(cs_dalloc(ctx, &b->d_uflag, (size_t)b->n_units));
+        A_(cs_dalloc(ctx, &b->d_uflag, (size_t)std::max(1, b->n_units)));
         if (getenv("CUBESLAM_SCORE_PROF")) A_(cs_dalloc(ctx, &b->d_prof, (size_t)b->score_G * 16 * 4));
     }
     A_(cs_dalloc(ctx, &b->d_dist, (size_t)b->pix_total));
@@ -2015,7 +2059,7 @@ int cs_cuboid_batch_create(cs_ctx *ctx, int n_frames, int width, int height, con
     A_(cs_dalloc(ctx, &b->d_cidx, (size_t)b->hyp_total));
     A_(cs_dalloc(ctx, &b->d_out, (size_t)n_boxes * o.max_cuboid_num));
     A_(cs_h2d(ctx, b->d_gray, gray, npx));
-    A_(cs_h2d(ctx, b->d_fi, fi.data(), (size_t)n_frames));
+    A_(cs_h2d(ctx, b->d_fi, b->fi.data(), (size_t)n_frames));
     A_(cs_h2d(ctx, b->d_lines_in, lines, (size_t)n_lines * 4));
     A_(cs_h2d(ctx, b->d_units, b->units.data(), (size_t)b->n_units));
     A_(cs_h2d(ctx, b->d_box_first, b->box_first_unit.data(), (size_t)n_boxes));
@@ -2028,6 +2072,7 @@ int cs_cuboid_batch_create(cs_ctx *ctx, int n_frames, int width, int height, con
 // New edge lists for the frames of an existing batch (same frames, boxes and options): what a step of the chain detect_filter_lines ->
 // detect_cuboid (main_obj.cpp:428-449) hands over when the frames stay resident.  Only the line ranges of the plan change.
 int cs_cuboid_batch_n_frames(const cs_cuboid_batch *b) { return b ? b->n_frames : -1; }
+int cs_cuboid_batch_n_boxes(const cs_cuboid_batch *b) { return b ? b->n_boxes : -1; }
 int cs_cuboid_batch_geometry(const cs_cuboid_batch *b, int *width, int *height, int *n_frames) { // (library-internal, see cs_orb_geometry)
     if (!b) return CS_ERR_BAD_ARG;
     *width = b->W; *height = b->H; *n_frames = b->n_frames;
@@ -2078,6 +2123,78 @@ int cs_cuboid_batch_set_lines(cs_ctx *ctx, cs_cuboid_batch *b, const int *line_o
     r = cs_h2d(ctx, b->d_fi, b->fi.data(), (size_t)b->n_frames); if (r) return r;
     r = cs_h2d(ctx, b->d_units, b->units.data(), (size_t)b->n_units); if (r) return r;
     CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return CS_OK;
+}
+
+// Other 2-D boxes, camera poses and (optionally) edge lists for the frames of an existing batch -- what every call of detect_cuboid brings with its pixels
+// (detect_3d_cuboid.h:62-63, main_obj.cpp:420-449).  The plan (ROIs, top samples, arena slices: box_proposal_detail.cpp:107-161) is rebuilt on the host -- it is a function
+// of the boxes and poses alone, ~0.2 ms for 3 072 units -- and goes to the device from pinned staging as copies on the context's stream behind whatever run still reads the
+// old plan: nothing waits unless an arena has to grow.  line_offsets NULL: the edge lists stay (a chained runner brings them from its line pass).  The frame count, the
+// image size and the options are the batch's.
+int cs_cuboid_batch_set_scene(cs_ctx *ctx, cs_cuboid_batch *b, const double *Twc, const int *box_offsets, const double *boxes, const int *line_offsets, const double *lines) {
+    if (!ctx || !b || !Twc || !box_offsets || (box_offsets[b->n_frames] > 0 && !boxes) || (line_offsets && line_offsets[b->n_frames] > 0 && !lines)) return CS_ERR_BAD_ARG;
+    CS_HIP(ctx, hipSetDevice(ctx->device));
+    Plan P;
+    int r = plan_build(b->o, b->sample_bbox_height, b->n_frames, b->W, b->H, Twc, box_offsets, boxes, line_offsets, &b->fi, P);
+    if (r == CS_ERR_BAD_ARG) ctx->err = "box ROI outside the image";
+    if (r != CS_OK) return r; // (the batch is as it was)
+    const int n_lines = line_offsets ? line_offsets[b->n_frames] : 0, n_units = (int)P.units.size(), n_boxes = P.n_boxes;
+    // arenas that are too small for this plan: wait for the runs that read them, then grow (a quarter of headroom: a stream's box sizes wander)
+    bool synced = false;
+    auto grow = [&](auto **p, size_t n) -> int { if (!synced) { CS_HIP(ctx, hipStreamSynchronize(ctx->stream)); synced = true; } cs_dfree(ctx, *p); *p = nullptr; return cs_dalloc(ctx, p, n); };
+#define G_(call) do { r = (call); if (r != CS_OK) return r; } while (0)
+    if (P.pix_total > b->cap_pix) {
+        const long c = P.pix_total + P.pix_total / 4;
+        G_(grow(&b->d_emap, (size_t)c + 256)); G_(grow(&b->d_dist, (size_t)c)); b->d_lab = (int *)b->d_dist; b->cap_pix = c;
+    }
+    if (P.hyp_total > b->cap_hyp) {
+        const long c = P.hyp_total + P.hyp_total / 4;
+        G_(grow(&b->d_flag, (size_t)c)); G_(grow(&b->d_vlist, (size_t)c)); G_(grow(&b->d_derr, (size_t)c)); G_(grow(&b->d_aerr, (size_t)c)); G_(grow(&b->d_score, (size_t)c)); G_(grow(&b->d_nscore, (size_t)c));
+        G_(grow(&b->d_ckd, (size_t)c)); G_(grow(&b->d_cka, (size_t)c)); G_(grow(&b->d_cidx, (size_t)c)); b->cap_hyp = c;
+    }
+    if (P.vp_total > b->cap_vp) { const long c = P.vp_total + P.vp_total / 4; G_(grow(&b->d_vp, (size_t)c)); b->cap_vp = c; }
+    if (n_units > b->cap_units) {
+        const int c = n_units + n_units / 4;
+        G_(grow(&b->d_units, (size_t)c)); G_(grow(&b->d_ud, (size_t)c)); G_(grow(&b->d_order, (size_t)c)); G_(grow(&b->d_uflag, (size_t)c)); G_(grow(&b->d_vcount, (size_t)2 * c)); G_(grow(&b->d_dttmp_off, (size_t)c + 1));
+        b->cap_units = c;
+    }
+    if (n_boxes > b->cap_boxes) {
+        const int c = n_boxes + n_boxes / 4;
+        G_(grow(&b->d_box_first, (size_t)c)); G_(grow(&b->d_counts, (size_t)c)); G_(grow(&b->d_carry, (size_t)c)); G_(grow(&b->d_out, (size_t)c * b->o.max_cuboid_num)); b->cap_boxes = c;
+    }
+    if (line_offsets && n_lines > b->cap_lines_in) { const long c = (long)n_lines + n_lines / 4 + 64; G_(grow(&b->d_lines_in, (size_t)c * 4)); G_(grow(&b->d_lines_al, (size_t)c * 4)); b->cap_lines_in = c; }
+    if (P.line_rows > b->cap_line_rows) { const long c = P.line_rows + P.line_rows / 4 + 64; G_(grow(&b->d_mlines, (size_t)c * 4)); G_(grow(&b->d_mangle, (size_t)c)); G_(grow(&b->d_mmid, (size_t)c * 2)); b->cap_line_rows = c; }
+    plan_commit(b, P);
+    std::vector<long> dt_off; std::vector<int> order;
+    plan_derived(b, dt_off, order);
+    if (std::max<long>(dt_off.back(), 1) > b->cap_dttmp) { const long c = dt_off.back() + dt_off.back() / 4; G_(grow(&b->d_dttmp, (size_t)c)); b->cap_dttmp = c; }
+    // one pinned block: units | frame records | first unit of every box | order | scratch offsets | edge lists; two blocks alternate, a block is reused once its copies are through
+    const int k = b->stage_k; b->stage_k ^= 1;
+    auto al = [](size_t x) { return (x + 63) & ~(size_t)63; };
+    const size_t o_units = 0, o_fi = al(o_units + sizeof(Unit) * (size_t)n_units), o_bf = al(o_fi + sizeof(FrameInfo) * (size_t)b->n_frames), o_ord = al(o_bf + sizeof(int) * (size_t)n_boxes),
+                 o_dt = al(o_ord + sizeof(int) * (size_t)n_units), o_ln = al(o_dt + sizeof(long) * ((size_t)n_units + 1)), total = al(o_ln + sizeof(double) * 4 * (size_t)n_lines);
+    if (!b->stage_ev[k]) CS_HIP(ctx, hipEventCreateWithFlags(&b->stage_ev[k], hipEventDisableTiming));
+    else CS_HIP(ctx, hipEventSynchronize(b->stage_ev[k]));
+    if (total > b->stage_cap[k]) {
+        if (b->h_stage[k]) hipHostFree(b->h_stage[k]);
+        b->h_stage[k] = nullptr; b->stage_cap[k] = 0;
+        CS_HIP(ctx, hipHostMalloc((void **)&b->h_stage[k], total + total / 4, hipHostMallocDefault));
+        b->stage_cap[k] = total + total / 4;
+    }
+    uint8_t *h = b->h_stage[k];
+    memcpy(h + o_units, b->units.data(), sizeof(Unit) * (size_t)n_units); memcpy(h + o_fi, b->fi.data(), sizeof(FrameInfo) * (size_t)b->n_frames);
+    memcpy(h + o_bf, b->box_first_unit.data(), sizeof(int) * (size_t)n_boxes); memcpy(h + o_ord, order.data(), sizeof(int) * (size_t)n_units);
+    memcpy(h + o_dt, dt_off.data(), sizeof(long) * ((size_t)n_units + 1));
+    if (n_lines) memcpy(h + o_ln, lines, sizeof(double) * 4 * (size_t)n_lines);
+    G_(cs_h2d(ctx, b->d_units, reinterpret_cast<const Unit *>(h + o_units), (size_t)n_units));
+    G_(cs_h2d(ctx, b->d_fi, reinterpret_cast<const FrameInfo *>(h + o_fi), (size_t)b->n_frames));
+    G_(cs_h2d(ctx, b->d_box_first, reinterpret_cast<const int *>(h + o_bf), (size_t)n_boxes));
+    G_(cs_h2d(ctx, b->d_order, reinterpret_cast<const int *>(h + o_ord), (size_t)n_units));
+    G_(cs_h2d(ctx, b->d_dttmp_off, reinterpret_cast<const long *>(h + o_dt), (size_t)n_units + 1));
+    if (n_lines) G_(cs_h2d(ctx, b->d_lines_in, reinterpret_cast<const double *>(h + o_ln), (size_t)n_lines * 4));
+    CS_HIP(ctx, hipEventRecord(b->stage_ev[k], ctx->stream));
+    if (n_units) CS_LAUNCH(ctx, "cuboid_clear_pad", cuboid_clear_pad, dim3((n_units + 3) / 4), dim3(256), 0, b->d_units, n_units, b->d_dist);
+#undef G_
     return CS_OK;
 }
 

@@ -34,6 +34,7 @@ extern "C" int cs_cuboid_batch_set_shared_gpu(cs_cuboid_batch *b, int shared);
 extern "C" int cs_cuboid_batch_set_lines(cs_ctx *ctx, cs_cuboid_batch *b, const int *line_offsets, const double *lines);
 extern "C" int cs_cuboid_batch_n_frames(const cs_cuboid_batch *b);
 extern "C" int cs_cuboid_batch_set_gray_device(cs_ctx *ctx, cs_cuboid_batch *b, const uint8_t *d_gray);
+extern "C" int cs_cuboid_batch_set_scene(cs_ctx *ctx, cs_cuboid_batch *b, const double *Twc, const int *box_offsets, const double *boxes, const int *line_offsets, const double *lines);
 extern "C" int cs_orb_set_frames_device(cs_ctx *ctx, cs_orb *e, const uint8_t *d_gray, int n_frames);
 extern "C" int cs_orb_geometry(const cs_orb *e, int *width, int *height, int *max_frames);
 extern "C" int cs_lsd_geometry(const cs_lsd *l, int *width, int *height, int *max_frames);
@@ -61,6 +62,8 @@ struct FrameRing {
     std::vector<uint8_t *> d;
     std::vector<hipEvent_t> uploaded, used_main, used_line;
     std::vector<long> main_gen, line_gen; // the step / pass whose copy out of the slot has been enqueued (-1: none yet)
+    struct Scene { bool has = false, has_lines = false; std::vector<double> Twc, boxes, lines; std::vector<int> box_off, line_off; }; // what a step's frames bring besides pixels (cs_frontend_stream_push_scene)
+    std::vector<Scene> scene;
     std::mutex m; std::condition_variable cv;
     long pushed = 0, first = 0, first_line = 0; // steps first .. pushed - 1 have frames; line passes from first_line on take theirs from the ring (a cut backlog may have left earlier passes done)
 };
@@ -283,6 +286,10 @@ int cs_frontend_step(cs_frontend *fe) {
         if (r == CS_OK && fe->batch) {
             if (cc != fe->ctx && hipStreamWaitEvent(cc->stream, R->uploaded[slot], 0) != hipSuccess) return CS_ERR_HIP;
             r = cs_cuboid_batch_set_gray_device(cc, fe->batch, R->d[slot]);
+            if (r == CS_OK && R->scene[(size_t)slot].has) { // the step's own boxes, poses (and edge lists): the plan is rebuilt and uploaded behind the last run on cc's stream
+                const FrameRing::Scene &S = R->scene[(size_t)slot];
+                r = cs_cuboid_batch_set_scene(cc, fe->batch, S.Twc.data(), S.box_off.data(), S.boxes.data(), S.has_lines ? S.line_off.data() : nullptr, S.has_lines ? S.lines.data() : nullptr);
+            }
             if (r == CS_OK && cc != fe->ctx) { hipEvent_t e = R->used_main[slot]; if (hipEventRecord(e, cc->stream) != hipSuccess || hipStreamWaitEvent(fe->ctx->stream, e, 0) != hipSuccess) return CS_ERR_HIP; }
         }
         if (r == CS_OK && hipEventRecord(R->used_main[slot], fe->ctx->stream) != hipSuccess) r = CS_ERR_HIP;
@@ -337,7 +344,7 @@ int cs_frontend_stream_begin(cs_frontend *fe, int n_frames, int width, int heigh
     FrameRing *R = new FrameRing();
     R->n_slots = n_slots; R->n_frames = n_frames; R->bytes = (size_t)n_frames * width * height;
     R->d.assign((size_t)n_slots, nullptr); R->uploaded.assign((size_t)n_slots, nullptr); R->used_main.assign((size_t)n_slots, nullptr); R->used_line.assign((size_t)n_slots, nullptr);
-    R->main_gen.assign((size_t)n_slots, -1); R->line_gen.assign((size_t)n_slots, -1);
+    R->main_gen.assign((size_t)n_slots, -1); R->line_gen.assign((size_t)n_slots, -1); R->scene.assign((size_t)n_slots, FrameRing::Scene());
     bool ok = hipStreamCreateWithFlags(&R->copy, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&R->copy_out, hipStreamNonBlocking) == hipSuccess &&
               hipEventCreateWithFlags(&R->step_done, hipEventDisableTiming) == hipSuccess && hipEventCreateWithFlags(&R->cub_done, hipEventDisableTiming) == hipSuccess &&
               hipEventCreateWithFlags(&R->results_out, hipEventDisableTiming) == hipSuccess && hipHostMalloc((void **)&R->h_status, sizeof(int), hipHostMallocDefault) == hipSuccess;
@@ -354,7 +361,16 @@ int cs_frontend_stream_begin(cs_frontend *fe, int n_frames, int width, int heigh
 }
 // The frames of the next step that has none yet (n_frames x height x width bytes; pinned host memory makes the call asynchronous): an H2D copy on the ring's own
 // stream behind everything that still reads the slot.  Blocks only while the line pass that last used the slot has not taken its frames yet.
-int cs_frontend_stream_push(cs_frontend *fe, const uint8_t *gray) {
+static int stream_push(cs_frontend *fe, const uint8_t *gray, const double *Twc, const int *box_offsets, const double *boxes, const int *line_offsets, const double *lines);
+int cs_frontend_stream_push(cs_frontend *fe, const uint8_t *gray) { return stream_push(fe, gray, nullptr, nullptr, nullptr, nullptr, nullptr); }
+// ... and with what detect_cuboid takes beside the pixels (detect_3d_cuboid.h:62-63): the frames' camera poses (n_frames x 16), their 2-D boxes (box_offsets[n_frames + 1],
+// rows of 5) and -- unless the runner's chain brings them from its line passes -- their edge lists (line_offsets NULL: the batch's lists stay).  The step that takes the
+// slot rebuilds the cuboid batch's plan for them (cs_cuboid_batch_set_scene).
+int cs_frontend_stream_push_scene(cs_frontend *fe, const uint8_t *gray, const double *Twc, const int *box_offsets, const double *boxes, const int *line_offsets, const double *lines) {
+    if (!fe || !fe->batch || !Twc || !box_offsets) return CS_ERR_BAD_ARG;
+    return stream_push(fe, gray, Twc, box_offsets, boxes, line_offsets, lines);
+}
+static int stream_push(cs_frontend *fe, const uint8_t *gray, const double *Twc, const int *box_offsets, const double *boxes, const int *line_offsets, const double *lines) {
     if (!fe || !fe->ring || !gray) return CS_ERR_BAD_ARG;
     FrameRing *R = fe->ring;
     if (hipSetDevice(fe->ctx->device) != hipSuccess) return CS_ERR_HIP;
@@ -368,6 +384,15 @@ int cs_frontend_stream_push(cs_frontend *fe, const uint8_t *gray) {
         if (hipStreamWaitEvent(R->copy, R->used_main[(size_t)slot], 0) != hipSuccess) return CS_ERR_HIP; // (step prev has run: k < step_no + n_slots)
     }
     if (hipMemcpyAsync(R->d[(size_t)slot], gray, R->bytes, hipMemcpyHostToDevice, R->copy) != hipSuccess || hipEventRecord(R->uploaded[(size_t)slot], R->copy) != hipSuccess) return CS_ERR_HIP;
+    { // (the slot's scene is host data of the runner until its step has handed it to the batch; the step that used the slot before has run: k < step_no + n_slots)
+        FrameRing::Scene &S = R->scene[(size_t)slot];
+        S.has = Twc != nullptr; S.has_lines = S.has && line_offsets != nullptr;
+        if (S.has) {
+            const int F = R->n_frames, nb = box_offsets[F];
+            S.Twc.assign(Twc, Twc + (size_t)F * 16); S.box_off.assign(box_offsets, box_offsets + F + 1); S.boxes.assign(boxes, boxes + (size_t)nb * 5);
+            if (S.has_lines) { const int nl = line_offsets[F]; S.line_off.assign(line_offsets, line_offsets + F + 1); S.lines.assign(lines, lines + (size_t)nl * 4); }
+        }
+    }
     { std::lock_guard<std::mutex> lk(fe->any_m); R->pushed = k + 1; if (!fe->gate.phased && !fe->workers.empty()) fe->kick_idle(); }
     return CS_OK;
 }

@@ -133,6 +133,31 @@ class CuboidBatch:
         lines = np.ascontiguousarray(np.concatenate([np.asarray(l, np.float64).reshape(-1, 4) for l in lines_list] + [np.zeros((1, 4))]))
         check(self.ctx.ptr, lib().cs_cuboid_batch_set_lines(self.ctx.ptr, self._b, _p(lo, C.c_int), _p(lines, C.c_double)), "cs_cuboid_batch_set_lines")
 
+    @staticmethod
+    def pack_scene(Twcs, boxes_list, lines_list=None):
+        """(Twc (F, 16), box_offsets, boxes (n, 5), line_offsets | None, lines | None) as cs_cuboid_batch_set_scene / cs_frontend_stream_push_scene take them."""
+        F = len(boxes_list)
+        T = np.ascontiguousarray(Twcs, np.float64).reshape(F, 16)
+        bo = np.zeros(F + 1, np.int32)
+        for f in range(F):
+            bo[f + 1] = bo[f] + len(boxes_list[f])
+        boxes = np.ascontiguousarray(np.concatenate([_boxes5(b) for b in boxes_list] + [np.zeros((0, 5))]))
+        lo = lines = None
+        if lines_list is not None:
+            lo = np.zeros(F + 1, np.int32)
+            for f in range(F):
+                lo[f + 1] = lo[f] + len(lines_list[f])
+            lines = np.ascontiguousarray(np.concatenate([np.asarray(l, np.float64).reshape(-1, 4) for l in lines_list] + [np.zeros((1, 4))]))
+        return T, bo, boxes, lo, lines
+
+    def set_scene(self, Twcs, boxes_list, lines_list=None, packed=None):
+        """Other boxes, poses and (lines_list given) edge lists for the frames of the batch: what every detect_cuboid call brings with its pixels (cs_cuboid_batch_set_scene)."""
+        T, bo, boxes, lo, lines = packed if packed is not None else self.pack_scene(Twcs, boxes_list, lines_list)
+        assert len(bo) == self.F + 1
+        check(self.ctx.ptr, lib().cs_cuboid_batch_set_scene(self.ctx.ptr, self._b, _p(T, C.c_double), _p(bo, C.c_int), _p(boxes, C.c_double), None if lo is None else _p(lo, C.c_int),
+                                                            None if lines is None else _p(lines, C.c_double)), "cs_cuboid_batch_set_scene")
+        self.n_boxes = int(bo[-1])
+
     def set_shared_gpu(self, shared):
         """Speed hint: long-running kernels of other streams hold most CUs while this batch runs (cs_cuboid_batch_set_shared_gpu)."""
         check(self.ctx.ptr, lib().cs_cuboid_batch_set_shared_gpu(self._b, 1 if shared else 0), "cs_cuboid_batch_set_shared_gpu")

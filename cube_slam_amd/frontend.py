@@ -53,6 +53,17 @@ class Frontend:
         assert gray.dtype.name == "uint8" and gray.flags["C_CONTIGUOUS"]
         check(self.ctx.ptr, lib().cs_frontend_stream_push(self._fe, gray.ctypes.data_as(C.POINTER(C.c_uint8))), "cs_frontend_stream_push")
 
+    def stream_push_scene(self, gray, packed):
+        """stream_push with the frames' poses, boxes and (optionally) edge lists: packed = CuboidBatch.pack_scene(...) (cs_frontend_stream_push_scene; the runner copies them)."""
+        assert gray.dtype.name == "uint8" and gray.flags["C_CONTIGUOUS"]
+        T, bo, boxes, lo, lines = packed
+        dp = lambda a: a.ctypes.data_as(C.POINTER(C.c_double))  # noqa: E731
+        ip = lambda a: a.ctypes.data_as(C.POINTER(C.c_int))  # noqa: E731
+        check(self.ctx.ptr, lib().cs_frontend_stream_push_scene(self._fe, gray.ctypes.data_as(C.POINTER(C.c_uint8)), dp(T), ip(bo), dp(boxes), None if lo is None else ip(lo),
+                                                                None if lines is None else dp(lines)), "cs_frontend_stream_push_scene")
+        if self.batch is not None:
+            self.batch.n_boxes = int(bo[-1])
+
     def stream_read_async(self, kps=None, desc=None, cuboids=None, counts=None):
         """The results of the step just enqueued into the caller's (pinned) arrays, on a copy stream behind the step's kernels (cs_frontend_stream_read_async): kps
         (KEYPOINT_DTYPE) / desc ((n, 32) uint8) packed over the frames, cuboids ((n_boxes, max_cuboid_num) CUBOID_DTYPE) / counts (int32).  Returns (first, total) of the

@@ -141,6 +141,13 @@ int cs_cuboid_batch_run(cs_ctx *ctx, cs_cuboid_batch *b);
 int cs_cuboid_batch_set_lines(cs_ctx *ctx, cs_cuboid_batch *b, const int *line_offsets, const double *lines);
 /* frames the batch was created with (line_offsets of cs_cuboid_batch_set_lines holds one more entry); -1 for NULL */
 int cs_cuboid_batch_n_frames(const cs_cuboid_batch *b);
+/* Other 2-D boxes, camera poses and (line_offsets non-NULL) edge lists for the frames of an existing batch -- the arguments every call of detect_cuboid brings with its
+ * pixels (detect_3d_cuboid.h:62-63).  Same frame count, image size and options; layouts as in cs_cuboid_batch_create.  The plan of the sweep (ROIs, top samples, arena
+ * slices: box_proposal_detail.cpp:107-161) is rebuilt for them on the host (a function of boxes and poses alone) and uploaded from pinned staging on the context's stream
+ * behind the run that still reads the old one; the call waits only when an arena has to grow.  A box whose ROI leaves the image: CS_ERR_BAD_ARG, the batch stays as it was.
+ * Results (cs_cuboid_batch_read) then hold box_offsets[n_frames] boxes. */
+int cs_cuboid_batch_set_scene(cs_ctx *ctx, cs_cuboid_batch *b, const double *Twc, const int *box_offsets, const double *boxes, const int *line_offsets, const double *lines);
+int cs_cuboid_batch_n_boxes(const cs_cuboid_batch *b);
 /* shared != 0: long-running kernels of other streams hold most CUs while this batch runs (cs_frontend's alternating runner does this itself): the edge-scoring
  * kernel takes the launch shape that fits beside them.  A speed hint only. */
 int cs_cuboid_batch_set_shared_gpu(cs_cuboid_batch *b, int shared);
@@ -498,6 +505,10 @@ int cs_frontend_drain(cs_frontend *fe);
  * and returns to resident frames. */
 int cs_frontend_stream_begin(cs_frontend *fe, int n_frames, int width, int height, int n_slots);
 int cs_frontend_stream_push(cs_frontend *fe, const uint8_t *gray);
+/* ... with what detect_cuboid takes beside the pixels (detect_3d_cuboid/include/detect_3d_cuboid/detect_3d_cuboid.h:62-63, object_slam/src/main_obj.cpp:420-449): the
+ * frames' camera poses (n_frames x 16), their 2-D boxes (box_offsets[n_frames + 1], rows of 5) and their edge lists (line_offsets NULL: the batch's lists stay -- a chained
+ * runner brings them from its line passes).  The step that takes the slot hands them to the cuboid batch (cs_cuboid_batch_set_scene: the plan is rebuilt for them). */
+int cs_frontend_stream_push_scene(cs_frontend *fe, const uint8_t *gray, const double *Twc, const int *box_offsets, const double *boxes, const int *line_offsets, const double *lines);
 int cs_frontend_stream_end(cs_frontend *fe);
 /* The results of the step that has just been enqueued, copied to the caller's (pinned) buffers on a copy stream of the ring behind the step's kernels: ORB key points /
  * descriptors packed like cs_orb_read_packed (first / total are filled at once), the cuboids like cs_cuboid_batch_read; either pair may be NULL.  Returns at once; the next

@@ -274,6 +274,73 @@ def test_streaming_source_equals_resident_frames(ctx, oracle):
         d.close()
 
 
+def test_streaming_source_carries_boxes_poses_and_lines(ctx, oracle):
+    """cs_frontend_stream_push_scene / cs_cuboid_batch_set_scene: every step brings its own frames WITH their 2-D boxes, camera poses and edge lists -- other geometry, other box
+    counts (the third set has three boxes in two of its frames: the arenas grow), other proposal counts -- and the cuboids of every step equal a fresh batch created on that
+    step's scenes (and, for one frame per step, the oracle's detect_cuboid).  A scene whose box leaves the image is refused and leaves the batch as it was."""
+    F = 3
+    sets = []
+    for k, nb in enumerate((2, 1, 3, 2)):
+        sc = [synth.cuboid_scene(900 + 10 * k + i, n_boxes=nb if i else max(1, nb - 1), bg_texture=0.25 * k) for i in range(F)]
+        sets.append(sc)
+    K = sets[0][0]["K"]
+    det = detect_3d_cuboid(ctx); det.set_calibration(K)
+    gray_of = lambda sc: np.ascontiguousarray(np.stack([s["gray"] for s in sc]))  # noqa: E731
+    mk = lambda sc: CuboidBatch(ctx, gray_of(sc), K, np.stack([s["Twc"] for s in sc]), [s["boxes"] for s in sc], [s["lines"] for s in sc], det.opts())  # noqa: E731
+    pack = lambda sc: CuboidBatch.pack_scene(np.stack([s["Twc"] for s in sc]), [s["boxes"] for s in sc], [s["lines"] for s in sc])  # noqa: E731
+    batch = mk(sets[0])
+    fe = Frontend(ctx, orb=None, batch=batch, line_detectors=[])
+    fe.stream_begin(F, 640, 480, n_slots=2)
+    order = [1, 2, 0, 3, 2]
+    grays = [gray_of(sc) for sc in sets]
+    fe.stream_push_scene(grays[order[0]], pack(sets[order[0]]))
+    from cube_slam_amd.cuboid import CUBOID_DTYPE
+    for k, which in enumerate(order):
+        if k + 1 < len(order):
+            fe.stream_push_scene(grays[order[k + 1]], pack(sets[order[k + 1]]))
+        fe.step()
+        nb = sum(len(s["boxes"]) for s in sets[which])
+        if k % 2 == 0:
+            a_c, a_n = np.zeros((nb, batch.max_cuboid_num), CUBOID_DTYPE), np.zeros(nb, np.int32)
+            fe.stream_read_async(None, None, a_c, a_n)
+            fe.stream_read_wait()
+            cub = [a_c[i, :a_n[i]] for i in range(nb)]
+        else:
+            ctx.sync()
+            batch.n_boxes = nb
+            cub = batch.read()
+        want_b = mk(sets[which]); want_b.run(); want_c = want_b.read(); want_b.close()
+        assert len(cub) == len(want_c) == nb and sum(len(c) for c in want_c) >= 1
+        assert all(a.tobytes() == b.tobytes() for a, b in zip(cub, want_c)), (k, which)
+        s0 = sets[which][0]
+        ref, _ = oracle.detect_cuboid(s0["gray"], K, s0["Twc"], s0["boxes"], s0["lines"])
+        for g, r in zip(cub[:len(ref)], ref):
+            assert len(g) == len(r)
+            for name in ("pos", "scale", "rotY", "edge_distance_error", "edge_angle_error"):
+                assert np.allclose(g[name], r[name], rtol=1e-5, atol=1e-9), (k, name)
+    fe.stream_end()
+    # directly on the batch: a box outside the image is refused, the batch still holds the last scene
+    bad = [dict(s) for s in sets[0]]
+    bad[1] = dict(bad[1], boxes=np.array([[700.0, 100.0, 50.0, 50.0, 0.9]]))
+    ctx.sync()
+    with pytest.raises(Exception):
+        batch.set_scene(np.stack([s["Twc"] for s in bad]), [s["boxes"] for s in bad], [s["lines"] for s in bad])
+    batch.run(); ctx.sync()
+    batch.n_boxes = sum(len(s["boxes"]) for s in sets[order[-1]])
+    again = batch.read()
+    want_b = mk(sets[order[-1]]); want_b.run(); want_c = want_b.read(); want_b.close()
+    assert all(a.tobytes() == b.tobytes() for a, b in zip(again, want_c))
+    # ... and the edge lists may stay (line_offsets NULL): other boxes over the same frames' lines
+    sc = sets[order[-1]]
+    alt = [dict(s, boxes=s["boxes"][:1]) for s in sc]
+    batch.set_scene(np.stack([s["Twc"] for s in alt]), [s["boxes"] for s in alt], None)
+    batch.run(); ctx.sync()
+    got = batch.read()
+    want_b = mk(alt); want_b.run(); want_c = want_b.read(); want_b.close()
+    assert len(got) == len(want_c) and all(a.tobytes() == b.tobytes() for a, b in zip(got, want_c))
+    fe.close(); batch.close()
+
+
 def test_phased_passes_with_the_chain(ctx, oracle, monkeypatch):
     """Phased runner + chained hand-over together (a phased worker still runs rectangles / LBD of pass k - W when step k hands it the next pass; its packet must be
     filed under ITS number): ten steps complete, and the cuboids from the chained lines equal a batch that was given detect_filter_lines' lists directly."""
