@@ -683,11 +683,8 @@ def main():
 
     ctx = _lib.Context(local_rank, priority=int(os.environ.get("BENCH_PRIO_MAIN", "1")))  # ORB + cuboid: the path a tracking thread waits for
     if world > 1:  # RCCL inside the library: rank 0's ncclUniqueId travels through the process group that the timing barrier uses anyway
-        uid = torch.zeros(128, dtype=torch.uint8, device="cuda")
-        if rank == 0:
-            uid.copy_(torch.frombuffer(bytearray(_lib.Context.comm_unique_id()), dtype=torch.uint8))
-        dist.broadcast(uid, 0)
-        ctx.comm_init(rank, world, bytes(uid.cpu().numpy().tobytes()))
+        from cube_slam_amd import shard
+        shard.comm_init_from_process_group(ctx, rank, world, device="cuda")  # (the same call tests/test_rccl_gpu.py's two-rank worker makes)
     scenes = make_frames(args.frames, args.boxes, seed0=1000 + 100000 * rank)
     hbm_marks = [("start", torch.cuda.mem_get_info()[0])]   # free bytes after each engine is resident: the front-end's working set by path
     det = detect_3d_cuboid(ctx)

@@ -266,22 +266,44 @@ template <int V> __global__ void __launch_bounds__(64) match_resolve(ResolveP P)
     const int qsub = P.qlist ? 0 : s0;
     unsigned long long *mask = reinterpret_cast<unsigned long long *>(rs_mem); // lanes of the current batch that claim the key point
     int *owner = reinterpret_cast<int *>(mask + N2); // RV_PROJ / RV_LOCAL: -1 free, -2 never, else query << 1 | its map point has observations; others: -1 free, -2 never, else query
-    int *mdist = owner + N2;                         // RV_INIT: vMatchedDistance
-    for (int i = lane; i < N2; i += 64) { mask[i] = 0; owner[i] = (P.tblocked && P.tblocked[kb + i]) ? -2 : -1; if (V == RV_INIT) mdist[i] = INT_MAX; }
+    float *tang = reinterpret_cast<float *>(owner + N2); // the train key points' angles (the rotation bin of a claim without a global round trip)
+    int *mdist = reinterpret_cast<int *>(tang + N2);     // RV_INIT: vMatchedDistance
+    for (int i = lane; i < N2; i += 64) {
+        mask[i] = 0; owner[i] = (P.tblocked && P.tblocked[kb + i]) ? -2 : -1; tang[i] = P.check_orientation ? P.tkeys[kb + i].angle : 0.0f;
+        if (V == RV_INIT) mdist[i] = INT_MAX;
+    }
     if (lane < 32) s_hist[lane] = 0;
     __syncthreads();
     const unsigned long long bit = 1ull << lane, below = bit - 1;
     int n_claims = 0;
-    for (int b0 = s0; b0 < s1; b0 += 64) {
+    // A batch's global reads are issued one (the first candidates) and two (start, count, flags, angle) batches ahead.  (Measured on a one-pair search of 2 000 queries:
+    // 262 -> 230 us.  What is left is the rounds' walk over the lists -- a lane per query pays an LDS round trip per candidate, and the coarse levels' windows hold dozens:
+    // staging a batch's lists in LDS cooperatively, or reading eight candidates' words at once, both measured slower, 368 and 329 us.)
+    struct Meta { int q; long cs; int cnt; bool act, blk; float ang; };
+    auto load_meta = [&](int b0) {
+        Meta M{0, 0, 0, false, false, 0.0f};
         const int step = b0 + lane;
-        const bool act = step < s1;
-        const int q = act ? (P.qlist ? P.qlist[step] : step) : 0;
-        long cs = 0; int cnt = 0;
-        if (act) { cs = P.cstart[q]; cnt = P.ccount[q]; }
-        int2 rc[RS_NC];
+        M.act = step < s1;
+        if (M.act) {
+            M.q = P.qlist ? P.qlist[step] : step;
+            M.cs = P.cstart[M.q]; M.cnt = P.ccount[M.q];
+            if (V == RV_PROJ || V == RV_LOCAL) M.blk = P.blocks[M.q] != 0;
+            if (P.check_orientation) M.ang = P.qkeys ? P.qkeys[M.q].angle : P.qangle[M.q];
+        }
+        return M;
+    };
+    Meta Mc = load_meta(s0), Mn = load_meta(s0 + 64);
+    int2 rc[RS_NC], rn[RS_NC];
 #pragma unroll
-        for (int c = 0; c < RS_NC; c++) rc[c] = c < cnt ? P.cands[cs + c] : make_int2(0, 0);
-        const bool myblk = (V == RV_PROJ || V == RV_LOCAL) && act && P.blocks[q];
+    for (int c = 0; c < RS_NC; c++) rc[c] = c < Mc.cnt ? P.cands[Mc.cs + c] : make_int2(0, 0);
+    for (int b0 = s0; b0 < s1; b0 += 64) {
+#pragma unroll
+        for (int c = 0; c < RS_NC; c++) rn[c] = c < Mn.cnt ? P.cands[Mn.cs + c] : make_int2(0, 0);
+        const Meta Mnn = load_meta(b0 + 128);
+        const bool act = Mc.act;
+        const int q = Mc.q, cnt = Mc.cnt;
+        const long cs = Mc.cs;
+        const bool myblk = Mc.blk;
         const unsigned long long blkmask = __ballot(myblk);
         int claim = -1, cdist = 0;
         for (;;) {
@@ -335,7 +357,7 @@ template <int V> __global__ void __launch_bounds__(64) match_resolve(ResolveP P)
         bool top = false; int bin = 0;
         if (claim >= 0) {
             top = (mask[claim] >> lane) == 1ull;
-            if (P.check_orientation) bin = rot_bin(P.qkeys ? P.qkeys[q].angle : P.qangle[q], P.tkeys[kb + claim].angle) & 31;
+            if (P.check_orientation) bin = rot_bin(Mc.ang, tang[claim]) & 31;
         }
         __syncthreads();
         if (claim >= 0) {
@@ -349,6 +371,9 @@ template <int V> __global__ void __launch_bounds__(64) match_resolve(ResolveP P)
         if (act) P.q_rec[q] = claim >= 0 ? (claim | (bin << 24)) : -1;
         n_claims += __popcll(__ballot(claim >= 0));
         __syncthreads();
+        Mc = Mn; Mn = Mnn;
+#pragma unroll
+        for (int c = 0; c < RS_NC; c++) rc[c] = rn[c];
     }
     // the rotation histogram's three maxima and the cut (:1496-1517, :506-527, :271-292, :630-651)
     const bool cut = P.check_orientation && V != RV_LOCAL;
@@ -622,7 +647,7 @@ static int mt_candidates(cs_ctx *ctx, cs_matcher *m, int nq, bool with_desc) {
     return CS_OK;
 }
 template <int V> static int mt_resolve(cs_ctx *ctx, const ResolveP &P, int n_problems, int n2max) {
-    const size_t lds = (size_t)std::max(n2max, 1) * (V == RV_INIT ? 16 : 12) + 16;
+    const size_t lds = (size_t)std::max(n2max, 1) * (V == RV_INIT ? 20 : 16) + 16;
     if (lds > 150 * 1024) { ctx->err = "match_resolve: more train key points than one workgroup's LDS holds"; return CS_ERR_CAPACITY; }
     if (lds > 48 * 1024) CS_HIP(ctx, hipFuncSetAttribute((const void *)match_resolve<V>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds));
     CS_LAUNCH(ctx, "match_resolve", match_resolve<V>, dim3(n_problems), dim3(64), lds, P);

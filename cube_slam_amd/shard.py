@@ -42,3 +42,17 @@ def allreduce_sum_f64(array, group=None):
     dist.all_reduce(t, group=group)
     array[...] = t.numpy()
     return array
+
+
+def comm_init_from_process_group(ctx, rank, world, device=None, group=None):
+    """The library's own RCCL communicator of this rank (cs_comm_init) from a torch.distributed process group that is already up: rank 0 makes the ncclUniqueId, a broadcast of
+    128 bytes carries it (on `device` when the group's backend is nccl, on the host for gloo).  bench.py --gpus N and tests/test_rccl_gpu.py's two-rank worker both come through
+    here, so the first multi-GPU run of the bench exercises nothing the test has not."""
+    import torch
+    import torch.distributed as dist
+    from cube_slam_amd import _lib
+    uid = torch.zeros(128, dtype=torch.uint8, device=device if device is not None else "cpu")
+    if rank == 0:
+        uid.copy_(torch.frombuffer(bytearray(_lib.Context.comm_unique_id()), dtype=torch.uint8))
+    dist.broadcast(uid, 0, group=group)
+    ctx.comm_init(rank, world, bytes(uid.cpu().numpy().tobytes()))

@@ -34,13 +34,11 @@ import torch, torch.distributed as dist
 sys.path.insert(0, %r)
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
 torch.cuda.set_device(rank)
-dist.init_process_group("gloo")
-from cube_slam_amd import _lib, synth
+dist.init_process_group("nccl", device_id=torch.device("cuda", rank))  # (what bench.py --gpus N brings up)
+from cube_slam_amd import _lib, shard, synth
 from cube_slam_amd.ba import BundleAdjuster
 ctx = _lib.Context(rank)
-uid = [ _lib.Context.comm_unique_id() if rank == 0 else None ]
-dist.broadcast_object_list(uid, 0)
-ctx.comm_init(rank, world, uid[0])
+shard.comm_init_from_process_group(ctx, rank, world, device="cuda")  # bench.py's own call
 d = synth.ba_problem(11, n_kf=40, n_points=3000, n_cuboids=6)
 st = BundleAdjuster(d, ctx=ctx, rank=rank, world=world).optimize(4)
 if rank == 0:
