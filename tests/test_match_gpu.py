@@ -331,3 +331,43 @@ def test_search_by_bow_key_frames(ctx, oracle, frames):
     g, ng = m.SearchByBoWKeyFrames(k1[:0], d1[:0], node1[:0], skip1[:0], k2, d2, node2, skip2)
     assert len(g) == 0 and ng == 0
     m.close()
+
+
+def test_matcher_edge_cases(ctx, oracle, frames):
+    """Empty and degenerate inputs of the device searches: no queries, no valid query, a frame without key points, a candidate arena that is too small (reported, not
+    overrun), every query competing for the same few key points (one batch settles over many rounds)."""
+    (k1, d1), (k2, d2) = frames
+    n = len(k1)
+    Tcw = np.eye(4, dtype=np.float32)[:3]
+    z = np.full(n, 10.0, np.float32)
+    wp = np.stack([(k1["x"] - 4.0 - CX) / FX * z, (k1["y"] - CY) / FY * z, z], axis=1).astype(np.float32)
+    ones = np.ones(n, np.uint8)
+    m = ORBmatcher(0.9, True, ctx=ctx)
+    m.set_frame(k2, d2, BOUNDS)
+    tm, nm = m.SearchByProjectionFrame(wp[:0], ones[:0], ones[:0], d1[:0], k1["octave"][:0], k1["angle"][:0], Tcw, FX, FY, CX, CY, SF, 15.0)
+    assert nm == 0 and (tm == -1).all() and len(tm) == len(k2)
+    tm, nm = m.SearchByProjectionFrame(wp, np.zeros(n, np.uint8), ones, d1, k1["octave"], k1["angle"], Tcw, FX, FY, CX, CY, SF, 15.0)
+    assert nm == 0 and (tm == -1).all()
+    # all queries at ONE place with the same descriptor: the first query with observations takes the best key point, the next takes the second best, ...
+    wp1 = np.repeat(wp[:1], 200, axis=0); d_same = np.repeat(d1[:1], 200, axis=0); oc = np.repeat(k1["octave"][:1], 200); an = np.repeat(k1["angle"][:1], 200)
+    F2 = oracle.make_frame(k2, d2, BOUNDS)
+    for bl in (np.ones(200, np.uint8), (np.arange(200) % 3 != 0).astype(np.uint8)):
+        got, ng = m.SearchByProjectionFrame(wp1, np.ones(200, np.uint8), bl, d_same, oc, an, Tcw, FX, FY, CX, CY, SF, 40.0)
+        ref, nr = oracle.search_by_projection_frame(F2, wp1, np.ones(200, np.uint8), bl, d_same, oc, an, Tcw, FX, FY, CX, CY, SF, 40.0)
+        assert np.array_equal(got, ref) and ng == nr
+    m.close()
+    # an arena of 64 candidates for a search that enumerates thousands: CS_ERR_CAPACITY, and the matcher still works afterwards with a smaller search
+    small = ORBmatcher(0.9, True, ctx=ctx, max_candidates=64)
+    small.set_frame(k2, d2, BOUNDS)
+    with pytest.raises(Exception):
+        small.SearchByProjectionFrame(wp, ones, ones, d1, k1["octave"], k1["angle"], Tcw, FX, FY, CX, CY, SF, 15.0)
+    got, ng = small.SearchByProjectionFrame(wp[:5], ones[:5], ones[:5], d1[:5], k1["octave"][:5], k1["angle"][:5], Tcw, FX, FY, CX, CY, SF, 15.0)
+    ref, nr = oracle.search_by_projection_frame(F2, wp[:5], ones[:5], ones[:5], d1[:5], k1["octave"][:5], k1["angle"][:5], Tcw, FX, FY, CX, CY, SF, 15.0)
+    assert np.array_equal(got, ref) and ng == nr
+    small.close()
+    # a frame without key points
+    e = ORBmatcher(0.9, True, ctx=ctx)
+    e.set_frame(k2[:0], d2[:0], BOUNDS)
+    tm, nm = e.SearchByProjectionFrame(wp, ones, ones, d1, k1["octave"], k1["angle"], Tcw, FX, FY, CX, CY, SF, 15.0)
+    assert nm == 0 and len(tm) == 0
+    e.close()
