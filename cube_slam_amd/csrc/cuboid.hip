@@ -2129,7 +2129,7 @@ int cs_cuboid_batch_set_lines(cs_ctx *ctx, cs_cuboid_batch *b, const int *line_o
 // Other 2-D boxes, camera poses and (optionally) edge lists for the frames of an existing batch -- what every call of detect_cuboid brings with its pixels
 // (detect_3d_cuboid.h:62-63, main_obj.cpp:420-449).  The plan (ROIs, top samples, arena slices: box_proposal_detail.cpp:107-161) is rebuilt on the host -- it is a function
 // of the boxes and poses alone, ~0.2 ms for 3 072 units -- and goes to the device from pinned staging as copies on the context's stream behind whatever run still reads the
-// old plan: nothing waits unless an arena has to grow.  line_offsets NULL: the edge lists stay (a chained runner brings them from its line pass).  The frame count, the
+// old plan: nothing waits unless an arena has to grow.  line_offsets NULL: the edge lists stay.  The frame count, the
 // image size and the options are the batch's.
 int cs_cuboid_batch_set_scene(cs_ctx *ctx, cs_cuboid_batch *b, const double *Twc, const int *box_offsets, const double *boxes, const int *line_offsets, const double *lines) {
     if (!ctx || !b || !Twc || !box_offsets || (box_offsets[b->n_frames] > 0 && !boxes) || (line_offsets && line_offsets[b->n_frames] > 0 && !lines)) return CS_ERR_BAD_ARG;

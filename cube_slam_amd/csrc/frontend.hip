@@ -364,7 +364,7 @@ int cs_frontend_stream_begin(cs_frontend *fe, int n_frames, int width, int heigh
 static int stream_push(cs_frontend *fe, const uint8_t *gray, const double *Twc, const int *box_offsets, const double *boxes, const int *line_offsets, const double *lines);
 int cs_frontend_stream_push(cs_frontend *fe, const uint8_t *gray) { return stream_push(fe, gray, nullptr, nullptr, nullptr, nullptr, nullptr); }
 // ... and with what detect_cuboid takes beside the pixels (detect_3d_cuboid.h:62-63): the frames' camera poses (n_frames x 16), their 2-D boxes (box_offsets[n_frames + 1],
-// rows of 5) and -- unless the runner's chain brings them from its line passes -- their edge lists (line_offsets NULL: the batch's lists stay).  The step that takes the
+// rows of 5) and their edge lists (line_offsets NULL: the batch's lists stay).  The step that takes the
 // slot rebuilds the cuboid batch's plan for them (cs_cuboid_batch_set_scene).
 int cs_frontend_stream_push_scene(cs_frontend *fe, const uint8_t *gray, const double *Twc, const int *box_offsets, const double *boxes, const int *line_offsets, const double *lines) {
     if (!fe || !fe->batch || !Twc || !box_offsets) return CS_ERR_BAD_ARG;

@@ -506,8 +506,7 @@ int cs_frontend_drain(cs_frontend *fe);
 int cs_frontend_stream_begin(cs_frontend *fe, int n_frames, int width, int height, int n_slots);
 int cs_frontend_stream_push(cs_frontend *fe, const uint8_t *gray);
 /* ... with what detect_cuboid takes beside the pixels (detect_3d_cuboid/include/detect_3d_cuboid/detect_3d_cuboid.h:62-63, object_slam/src/main_obj.cpp:420-449): the
- * frames' camera poses (n_frames x 16), their 2-D boxes (box_offsets[n_frames + 1], rows of 5) and their edge lists (line_offsets NULL: the batch's lists stay -- a chained
- * runner brings them from its line passes).  The step that takes the slot hands them to the cuboid batch (cs_cuboid_batch_set_scene: the plan is rebuilt for them). */
+ * frames' camera poses (n_frames x 16), their 2-D boxes (box_offsets[n_frames + 1], rows of 5) and their edge lists (line_offsets NULL: the batch's lists stay).  The step that takes the slot hands them to the cuboid batch (cs_cuboid_batch_set_scene: the plan is rebuilt for them). */
 int cs_frontend_stream_push_scene(cs_frontend *fe, const uint8_t *gray, const double *Twc, const int *box_offsets, const double *boxes, const int *line_offsets, const double *lines);
 int cs_frontend_stream_end(cs_frontend *fe);
 /* The results of the step that has just been enqueued, copied to the caller's (pinned) buffers on a copy stream of the ring behind the step's kernels: ORB key points /
