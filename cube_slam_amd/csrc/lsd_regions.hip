@@ -566,8 +566,7 @@ int lsd_seq_run(cs_ctx *ctx, LsdSeq **handle, int F, int w, int h, const float *
     RA_(cs_d2h(ctx, r->h_base.data(), r->d_cand_base, (size_t)F + 1));
     RA_(cs_d2h(ctx, r->h_status.data(), r->d_status, (size_t)F * 4));
     CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    const bool gate_late = getenv("CUBESLAM_FE_GATE_LATE") != nullptr; // (experiment: the gate also covers lsd_rg_improve)
-    if (after_seq && !gate_late) after_seq(gate_arg);
+    if (after_seq) after_seq(gate_arg);
 #if defined(RGS_PROFILE)
     { std::vector<unsigned long long> all((size_t)F * 16); hipMemcpy(all.data(), S.prof, all.size() * 8, hipMemcpyDeviceToHost);
       unsigned long long hp[16] = {0}; for (int f = 0; f < F; f++) for (int k = 0; k < 16; k++) hp[k] += all[(size_t)f * 16 + k];
@@ -599,7 +598,6 @@ int lsd_seq_run(cs_ctx *ctx, LsdSeq **handle, int F, int w, int h, const float *
     RA_(cs_d2h(ctx, r->h_has.data(), r->d_has, (size_t)n_cand));
     RA_(cs_d2h(ctx, r->h_line.data(), r->d_line, (size_t)n_cand));
     CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    if (after_seq && gate_late) after_seq(gate_arg);
 #undef RA_
 #pragma omp parallel for schedule(static) num_threads(std::max(1, std::min(ctx->host_threads, F)))
     for (int f = 0; f < F; f++)
