@@ -26,8 +26,11 @@ constexpr int GRID_ROWS = 48, GRID_COLS = 64, NCELL = GRID_ROWS * GRID_COLS; // 
 constexpr int TH_HIGH = 100, TH_LOW = 50, HISTO_LENGTH = 30;                // ORBmatcher.cc:42-44
 
 struct FrameP { int N; float minX, maxX, minY, maxY, wInv, hInv; };
+// What a window search reads of a key point of the searched frame, laid out in CELL order (the entries of a cell -- and of the cells of a grid column -- lie one behind the
+// other): a window's walk streams 16-byte records instead of chasing cell list -> index -> 28-byte key point record
+struct CellRec { float x, y; int id, octave; };
 
-__global__ void __launch_bounds__(1024) match_grid(FrameP F, const cs_keypoint *keys, int *cell_start /*NCELL+1*/, int *cell_items, int *kp_cell) {
+__global__ void __launch_bounds__(1024) match_grid(FrameP F, const cs_keypoint *keys, int *cell_start /*NCELL+1*/, int *cell_items, int *kp_cell, CellRec *cell_recs) {
     __shared__ int cnt[NCELL];
     __shared__ int s_part[1024];
     const int tid = threadIdx.x;
@@ -67,6 +70,8 @@ __global__ void __launch_bounds__(1024) match_grid(FrameP F, const cs_keypoint *
             cell_items[j + 1] = v;
         }
     }
+    __syncthreads();
+    for (int i = tid; i < cell_start[NCELL]; i += 1024) { const int id = cell_items[i]; const cs_keypoint k = keys[id]; cell_recs[i] = CellRec{k.x, k.y, id, k.octave}; }
 }
 
 // cv::undistortPoints(src, dst, K, D, Mat(), K) as Frame::UndistortKeyPoints / ComputeImageBounds call it (Frame.cc:546-609): the
@@ -139,20 +144,25 @@ __device__ __forceinline__ int hamming256(const unsigned long long *a, unsigned 
 // on the atomics' order and on nothing else: cstart / ccount address it, and nothing reads the arena in another way.  A slice that would end past `cap` is not written and
 // its count reads 0; the cursor still advances, so the host sees what the arena should have held and calls again.  The train frame of query q is key points
 // kfirst[q.pair] .. of `keys` / `desc`, its cell lists at q.pair x (NCELL + 1) / kfirst[q.pair].  A candidate is (index | level << 24, distance).
-constexpr int MC_WAVES = 4; // queries (waves) per workgroup, ONE cursor update per workgroup.  (Sixteen were measured: alone the same 2.6 ms per window of 10^6 queries, beside the line detectors' region walks 13 ms -- a workgroup of sixteen waves waits for a CU with four free slots per SIMD)
-__global__ void __launch_bounds__(64 * MC_WAVES) match_candidates(FrameP F, const cs_keypoint *keys, const unsigned long long *desc, const int *kfirst, const int *cell_start_all, const int *cell_items_all, int nq,
-                                                                  const QueryS *q, const unsigned long long *qdesc, unsigned long long *cursor, long cap, long *cstart, int *ccount, int2 *cands) {
-    __shared__ int s_tot[MC_WAVES];
+// MC_G lanes per query, MC_Q queries per 256-thread workgroup, ONE cursor update per workgroup.  A window at th 15 covers 8 - 80 cells: with a whole wave per query most lanes had
+// no cell, and the kernel is bound by the number of waves that wait out its seven dependent round trips (query -> frame -> cell bounds -> records, the cursor, records ->
+// descriptors), not by bytes: 3.1 ms per window of 10^6 queries with 64 lanes per query whether the walk read 28-byte key point records through an index (654 MB) or
+// cell-ordered 16-byte records (521 MB).  (Sixteen-wave workgroups were measured too: the same alone, 13 ms beside the region walks -- they wait for a CU with four free
+// slots per SIMD.)
+constexpr int MC_G = 16, MC_Q = 256 / MC_G;
+__global__ void __launch_bounds__(256) match_candidates(FrameP F, const unsigned long long *desc, const int *kfirst, const int *cell_start_all, const CellRec *cell_recs_all, int nq,
+                                                        const QueryS *q, const unsigned long long *qdesc, unsigned long long *cursor, long cap, long *cstart, int *ccount, int2 *cands) {
+    __shared__ int s_tot[MC_Q];
     __shared__ unsigned long long s_base;
-    const int wv = threadIdx.x >> 6, qi = blockIdx.x * MC_WAVES + wv, lane = threadIdx.x & 63;
+    const int grp = threadIdx.x / MC_G, qi = blockIdx.x * MC_Q + grp, lane = threadIdx.x % MC_G;
     QueryS Q{0, 0, 0, 0, 0, 0, 0};
     if (qi < nq) Q = q[qi];
     int total = 0;
     long base = 0;
-    // (the window and the walk are the same for the counting and the filling half; the workgroup's waves meet in between to share one cursor update)
+    // (the window and the walk are the same for the counting and the filling half; the workgroup's groups meet in between to share one cursor update)
     const int kb = (Q.valid && kfirst) ? kfirst[Q.pair] : 0;
-    const cs_keypoint *tk = keys + kb; const unsigned long long *td = desc + (size_t)kb * 4;
-    const int *cell_start = cell_start_all + (size_t)Q.pair * (NCELL + 1), *cell_items = cell_items_all + kb;
+    const unsigned long long *td = desc + (size_t)kb * 4;
+    const int *cell_start = cell_start_all + (size_t)Q.pair * (NCELL + 1); const CellRec *recs = cell_recs_all + kb;
     const float x = Q.x, y = Q.y, r = Q.r;
     const int nMinCellX = max(0, (int)floorf((x - F.minX - r) * F.wInv));
     const int nMaxCellX = min(GRID_COLS - 1, (int)ceilf((x - F.minX + r) * F.wInv));
@@ -163,46 +173,50 @@ __global__ void __launch_bounds__(64 * MC_WAVES) match_candidates(FrameP F, cons
     const int ny = nMaxCellY - nMinCellY + 1, ncell = window ? (nMaxCellX - nMinCellX + 1) * ny : 0;
     unsigned long long d0 = 0, d1 = 0, d2 = 0, d3 = 0;
     if (window && qdesc) { d0 = qdesc[(size_t)qi * 4]; d1 = qdesc[(size_t)qi * 4 + 1]; d2 = qdesc[(size_t)qi * 4 + 2]; d3 = qdesc[(size_t)qi * 4 + 3]; }
-    auto passes = [&](const cs_keypoint &kp) {
+    auto passes = [&](const CellRec &kp) {
         bool ok = true;
         if (bCheckLevels) { if (kp.octave < Q.minLevel) ok = false; if (Q.maxLevel >= 0 && kp.octave > Q.maxLevel) ok = false; }
         const float distx = kp.x - x, disty = kp.y - y;
         return ok && fabsf(distx) < r && fabsf(disty) < r;
     };
+    // (the groups of a wave walk in lockstep: the trip count is the longest window of the four; a group past its window does nothing)
+    int ncell_w = ncell;
+    for (int off = MC_G; off < 64; off <<= 1) ncell_w = max(ncell_w, __shfl_xor(ncell_w, off));
     auto walk = [&](bool fill) {
         int tot = 0;
-        for (int k0 = 0; k0 < ncell; k0 += 64) {
+        for (int k0 = 0; k0 < ncell_w; k0 += MC_G) {
             const int k = k0 + lane;
             int b = 0, e = 0;
             if (k < ncell) { int c = (nMinCellX + k / ny) * GRID_ROWS + nMinCellY + k % ny; b = cell_start[c]; e = cell_start[c + 1]; }
             int mine = 0;
-            for (int p = b; p < e; p++) mine += passes(tk[cell_items[p]]);
+            for (int p = b; p < e; p++) mine += passes(recs[p]);
             int inc = mine;
-            for (int off = 1; off < 64; off <<= 1) { int t = __shfl_up(inc, off); if (lane >= off) inc += t; }
+            for (int off = 1; off < MC_G; off <<= 1) { int t = __shfl_up(inc, off, MC_G); if (lane >= off) inc += t; }
             if (fill && mine) {
                 long o = base + tot + inc - mine;
                 for (int p = b; p < e; p++) {
-                    const int id = cell_items[p];
-                    const cs_keypoint kp = tk[id];
-                    if (passes(kp)) { cands[o] = make_int2(id | ((kp.octave & 0xff) << 24), qdesc ? hamming256(td + (size_t)id * 4, d0, d1, d2, d3) : 0); o++; }
+                    const CellRec kp = recs[p];
+                    if (passes(kp)) { cands[o] = make_int2(kp.id | ((kp.octave & 0xff) << 24), qdesc ? hamming256(td + (size_t)kp.id * 4, d0, d1, d2, d3) : 0); o++; }
                 }
             }
-            tot += __shfl(inc, 63);
+            tot += __shfl(inc, MC_G - 1, MC_G);
         }
         return tot;
     };
     total = walk(false);
-    if (lane == 0) s_tot[wv] = total;
+    if (lane == 0) s_tot[grp] = total;
     __syncthreads();
     if (threadIdx.x == 0) {
         int sum = 0;
-        for (int k = 0; k < MC_WAVES; k++) sum += s_tot[k];
+        for (int k = 0; k < MC_Q; k++) sum += s_tot[k];
         s_base = sum ? atomicAdd(cursor, (unsigned long long)sum) : 0ull;
     }
     __syncthreads();
     base = (long)s_base;
-    for (int k = 0; k < wv; k++) base += s_tot[k];
-    if (total) { if (base + total <= cap) walk(true); else total = 0; }
+    for (int k = 0; k < grp; k++) base += s_tot[k];
+    const bool fits = base + total <= cap;
+    if (!fits) total = 0;
+    if (total) walk(true); // (the shuffles of a walk stay inside a group of MC_G lanes: a group without candidates may sit this one out)
     if (lane == 0 && qi < nq) { cstart[qi] = base; ccount[qi] = total; }
 }
 
@@ -540,7 +554,7 @@ __global__ void __launch_bounds__(256) match_bow_dists(int NK, const unsigned lo
 // ---- a whole window of a stream at once (cs_match_by_projection_stream): pair p = (last frame f0 + p, current frame f0 + p + 1) of the frames an extractor holds in HBM.
 // Frame post-processing of every current frame and the searches of all pairs in a handful of launches.  Same arithmetic, same candidate order, same claims as the per-frame calls.
 // AssignFeaturesToGrid of the current frames: one workgroup per frame, key points kfirst[p] .. kfirst[p + 1] of `keys`; cell lists relative to the frame
-__global__ void __launch_bounds__(1024) match_grid_batch(FrameP F, const cs_keypoint *keys, const int *kfirst, int *cell_start_all /*P x (NCELL+1)*/, int *cell_items_all, int *kp_cell_all) {
+__global__ void __launch_bounds__(1024) match_grid_batch(FrameP F, const cs_keypoint *keys, const int *kfirst, int *cell_start_all /*P x (NCELL+1)*/, int *cell_items_all, int *kp_cell_all, CellRec *cell_recs_all) {
     __shared__ int cnt[NCELL];
     __shared__ int s_part[1024];
     const int tid = threadIdx.x, p = blockIdx.x, kb = kfirst[p], N = kfirst[p + 1] - kb;
@@ -580,6 +594,8 @@ __global__ void __launch_bounds__(1024) match_grid_batch(FrameP F, const cs_keyp
             cell_items[j + 1] = v;
         }
     }
+    __syncthreads();
+    for (int i = tid; i < cell_start[NCELL]; i += 1024) { const int id = cell_items[i]; const cs_keypoint kk = k[id]; cell_recs_all[kb + i] = CellRec{kk.x, kk.y, id, kk.octave}; }
 }// the queries of all pairs: query j belongs to pair p with qfirst[p] <= j < qfirst[p + 1]; its level is the last frame's key point's (ORBmatcher.cc:1424)
 __global__ void __launch_bounds__(256) match_project_stream(int nq, int n_pairs, const int *qfirst, const float *world_pos, const uint8_t *valid, const cs_keypoint *last_keys /* raw key points of frame f0 on: query j = last_keys[j] */,
                                                            const float *T_all, float fx, float fy, float cx, float cy, const float *scale_factors, int n_levels, float th, FrameP F, QueryS *q, int *err) {
@@ -629,7 +645,7 @@ struct cs_matcher {
     FrameP F{};
     std::vector<cs_keypoint> keys; // host copy of mvKeysUn (what set_frame_from_orb hands back; the vbPrevMatched update of SearchForInitialization)
     cs_keypoint *d_keys = nullptr; unsigned long long *d_desc = nullptr, *d_qdesc = nullptr;
-    int *d_cell_start = nullptr, *d_cell_items = nullptr, *d_kp_cell = nullptr, *d_ccount = nullptr;
+    int *d_cell_start = nullptr, *d_cell_items = nullptr, *d_kp_cell = nullptr, *d_ccount = nullptr; CellRec *d_cell_recs = nullptr;
     long *d_cstart = nullptr; unsigned long long *d_cursor = nullptr; // [0] the arena's cursor, [1] an error flag (its low word)
     QueryS *d_q = nullptr; int2 *d_cands = nullptr;
     int *d_qrec = nullptr, *d_tm = nullptr /* max_kp + 1: train_match, nmatches behind its N entries */, *d_qm = nullptr /* max_q + 1 */;
@@ -641,7 +657,7 @@ struct cs_matcher {
 // the window enumeration of nq queries in m->d_q against the frame set with cs_matcher_set_frame: cursor reset + one launch, nothing waits
 static int mt_candidates(cs_ctx *ctx, cs_matcher *m, int nq, bool with_desc) {
     CS_HIP(ctx, hipMemsetAsync(m->d_cursor, 0, 16, ctx->stream));
-    CS_LAUNCH(ctx, "match_candidates", match_candidates, dim3((nq + MC_WAVES - 1) / MC_WAVES), dim3(64 * MC_WAVES), 0, m->F, m->d_keys, m->d_desc, (const int *)nullptr, m->d_cell_start, m->d_cell_items, nq, m->d_q,
+    CS_LAUNCH(ctx, "match_candidates", match_candidates, dim3((nq + MC_Q - 1) / MC_Q), dim3(256), 0, m->F, m->d_desc, (const int *)nullptr, m->d_cell_start, m->d_cell_recs, nq, m->d_q,
               with_desc ? m->d_qdesc : (const unsigned long long *)nullptr, m->d_cursor, m->max_cand, m->d_cstart, m->d_ccount, m->d_cands);
     m->last_q = nq;
     return CS_OK;
@@ -668,7 +684,7 @@ static int mt_finish(cs_ctx *ctx, cs_matcher *m, const int *d_res, int n_res, in
 }
 
 struct cs_match_stream {
-    DBuf<cs_keypoint> keys; DBuf<int> cell_start, cell_items, kp_cell, kfirst, qfirst, ccount, qrec, tm, nm; DBuf<long> cstart; DBuf<QueryS> q; DBuf<int2> cands;
+    DBuf<cs_keypoint> keys; DBuf<int> cell_start, cell_items, kp_cell, kfirst, qfirst, ccount, qrec, tm, nm; DBuf<CellRec> cell_recs; DBuf<long> cstart; DBuf<QueryS> q; DBuf<int2> cands;
     DBuf<float> wp, T; DBuf<uint8_t> valid, blocks; DBuf<unsigned long long> qdesc;
     float *d_sf = nullptr; unsigned long long *d_cursor = nullptr;
     std::vector<int> h_tm;
@@ -679,7 +695,7 @@ extern "C" {
 void cs_matcher_destroy(cs_ctx *ctx, cs_matcher *m) {
     if (!m) return;
     if (ctx) { hipSetDevice(ctx->device); hipStreamSynchronize(ctx->stream); }
-    void *ptrs[] = {m->d_keys, m->d_desc, m->d_qdesc, m->d_cell_start, m->d_cell_items, m->d_kp_cell, m->d_ccount, m->d_cstart, m->d_cursor, m->d_q, m->d_cands,
+    void *ptrs[] = {m->d_keys, m->d_desc, m->d_qdesc, m->d_cell_start, m->d_cell_items, m->d_cell_recs, m->d_kp_cell, m->d_ccount, m->d_cstart, m->d_cursor, m->d_q, m->d_cands,
                     m->d_qrec, m->d_tm, m->d_qm, m->d_f, m->d_ang, m->d_ur, m->d_u8, m->d_tb, m->d_i};
     for (void *p : ptrs) if (p) cs_dfree(ctx, p);
     delete m;
@@ -705,6 +721,7 @@ int cs_matcher_create(cs_ctx *ctx, int max_keypoints, int max_queries, long max_
     A_(cs_dalloc(ctx, &m->d_qdesc, (size_t)max_queries * 4));
     A_(cs_dalloc(ctx, &m->d_cell_start, (size_t)NCELL + 1));
     A_(cs_dalloc(ctx, &m->d_cell_items, (size_t)max_keypoints));
+    A_(cs_dalloc(ctx, &m->d_cell_recs, (size_t)max_keypoints));
     A_(cs_dalloc(ctx, &m->d_kp_cell, (size_t)max_keypoints));
     A_(cs_dalloc(ctx, &m->d_ccount, (size_t)max_queries));
     A_(cs_dalloc(ctx, &m->d_cstart, (size_t)max_queries));
@@ -735,7 +752,7 @@ int cs_matcher_set_frame(cs_ctx *ctx, cs_matcher *m, const cs_keypoint *keysUn, 
     m->keys.assign(keysUn, keysUn + N);
     int r = cs_h2d(ctx, m->d_keys, keysUn, (size_t)N); if (r) return r;
     r = cs_h2d(ctx, (uint8_t *)m->d_desc, desc, (size_t)N * 32); if (r) return r;
-    CS_LAUNCH(ctx, "match_grid", match_grid, dim3(1), dim3(1024), 0, m->F, m->d_keys, m->d_cell_start, m->d_cell_items, m->d_kp_cell);
+    CS_LAUNCH(ctx, "match_grid", match_grid, dim3(1), dim3(1024), 0, m->F, m->d_keys, m->d_cell_start, m->d_cell_items, m->d_kp_cell, m->d_cell_recs);
     CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
     return CS_OK;
 }
@@ -771,7 +788,7 @@ int cs_matcher_set_frame_from_orb(cs_ctx *ctx, cs_matcher *m, const cs_orb *orb,
         CS_LAUNCH(ctx, "match_undistort", match_undistort, dim3((N + 255) / 256), dim3(256), 0, N, d_k, make_undp(K4, dist5), m->d_keys);
         CS_HIP(ctx, hipMemcpyAsync(m->d_desc, d_d, (size_t)N * 32, hipMemcpyDeviceToDevice, ctx->stream));
     }
-    CS_LAUNCH(ctx, "match_grid", match_grid, dim3(1), dim3(1024), 0, m->F, m->d_keys, m->d_cell_start, m->d_cell_items, m->d_kp_cell);
+    CS_LAUNCH(ctx, "match_grid", match_grid, dim3(1), dim3(1024), 0, m->F, m->d_keys, m->d_cell_start, m->d_cell_items, m->d_kp_cell, m->d_cell_recs);
     // mvKeysUn for the caller (and for SearchForInitialization's vbPrevMatched update); a caller that wants neither passes NULL and the frame stays on the device:
     // every search takes what it needs of a train key point from the device copy
     if (keysUn_out) {
@@ -846,7 +863,7 @@ int cs_match_by_projection_frame(cs_ctx *ctx, cs_matcher *m, int n_last, const f
 void cs_match_stream_destroy(cs_ctx *ctx, cs_match_stream *m) {
     if (!m) return;
     if (ctx) { hipSetDevice(ctx->device); hipStreamSynchronize(ctx->stream); }
-    m->keys.release(ctx); m->cell_start.release(ctx); m->cell_items.release(ctx); m->kp_cell.release(ctx); m->kfirst.release(ctx); m->qfirst.release(ctx); m->ccount.release(ctx); m->qrec.release(ctx);
+    m->keys.release(ctx); m->cell_start.release(ctx); m->cell_items.release(ctx); m->cell_recs.release(ctx); m->kp_cell.release(ctx); m->kfirst.release(ctx); m->qfirst.release(ctx); m->ccount.release(ctx); m->qrec.release(ctx);
     m->tm.release(ctx); m->nm.release(ctx); m->cstart.release(ctx); m->q.release(ctx); m->cands.release(ctx); m->wp.release(ctx); m->T.release(ctx); m->valid.release(ctx); m->blocks.release(ctx); m->qdesc.release(ctx);
     if (m->d_sf) cs_dfree(ctx, m->d_sf);
     if (m->d_cursor) cs_dfree(ctx, m->d_cursor);
@@ -891,7 +908,7 @@ int cs_match_by_projection_stream(cs_ctx *ctx, cs_match_stream *m, const cs_orb 
     F.wInv = static_cast<float>(GRID_COLS) / static_cast<float>(maxX - minX); F.hInv = static_cast<float>(GRID_ROWS) / static_cast<float>(maxY - minY);
     int r;
 #define G_(call) do { r = (call); if (r != CS_OK) return r; } while (0)
-    G_(m->keys.grow(ctx, (size_t)nk_all)); G_(m->cell_items.grow(ctx, (size_t)nk_all)); G_(m->kp_cell.grow(ctx, (size_t)nk_all)); G_(m->tm.grow(ctx, (size_t)nk));
+    G_(m->keys.grow(ctx, (size_t)nk_all)); G_(m->cell_items.grow(ctx, (size_t)nk_all)); G_(m->cell_recs.grow(ctx, (size_t)nk_all)); G_(m->kp_cell.grow(ctx, (size_t)nk_all)); G_(m->tm.grow(ctx, (size_t)nk));
     G_(m->cell_start.grow(ctx, (size_t)n_pairs * (NCELL + 1))); G_(m->kfirst.grow(ctx, (size_t)n_pairs + 2)); G_(m->qfirst.grow(ctx, (size_t)n_pairs + 2)); G_(m->T.grow(ctx, (size_t)n_pairs * 12)); G_(m->nm.grow(ctx, (size_t)n_pairs));
     G_(m->ccount.grow(ctx, (size_t)nq)); G_(m->cstart.grow(ctx, (size_t)nq)); G_(m->qrec.grow(ctx, (size_t)nq)); G_(m->q.grow(ctx, (size_t)nq)); G_(m->wp.grow(ctx, (size_t)nq * 3)); G_(m->valid.grow(ctx, (size_t)nq));
     G_(m->blocks.grow(ctx, (size_t)nq)); if (mp_desc) G_(m->qdesc.grow(ctx, (size_t)nq * 4));
@@ -914,13 +931,13 @@ int cs_match_by_projection_stream(cs_ctx *ctx, cs_match_stream *m, const cs_orb 
     const unsigned long long *d_qdesc = mp_desc ? m->qdesc.p : d_d0; // NULL: a last frame's key point is matched with its own descriptor
     int *d_err = reinterpret_cast<int *>(m->d_cursor + 1);
     CS_HIP(ctx, hipMemsetAsync(m->d_cursor, 0, 16, ctx->stream));
-    CS_LAUNCH(ctx, "match_grid", match_grid_batch, dim3(n_pairs), dim3(1024), 0, F, m->keys.p, m->kfirst.p, m->cell_start.p, m->cell_items.p, m->kp_cell.p);
+    CS_LAUNCH(ctx, "match_grid", match_grid_batch, dim3(n_pairs), dim3(1024), 0, F, m->keys.p, m->kfirst.p, m->cell_start.p, m->cell_items.p, m->kp_cell.p, m->cell_recs.p);
     CS_LAUNCH(ctx, "match_project", match_project_stream, dim3((nq + 255) / 256), dim3(256), 0, nq, n_pairs, m->qfirst.p, m->wp.p, m->valid.p, d_k0, m->T.p, fx, fy, cx, cy, m->d_sf, n_levels, th, F, m->q.p, d_err);
     // every pair's window enumeration (one launch) and its greedy pass + rotation cut (:1397-1517; one wave per pair): nothing of a candidate leaves the device.  The arena's
     // size is last call's need; a window that needs more says so through the cursor and the two launches run again on a larger one.
     unsigned long long cur[2] = {0, 0};
     for (int attempt = 0;; attempt++) {
-        CS_LAUNCH(ctx, "match_candidates", match_candidates, dim3((nq + MC_WAVES - 1) / MC_WAVES), dim3(64 * MC_WAVES), 0, F, m->keys.p, d_d0, m->kfirst.p, m->cell_start.p, m->cell_items.p, nq, m->q.p, d_qdesc, m->d_cursor, (long)m->cands.cap,
+        CS_LAUNCH(ctx, "match_candidates", match_candidates, dim3((nq + MC_Q - 1) / MC_Q), dim3(256), 0, F, d_d0, m->kfirst.p, m->cell_start.p, m->cell_recs.p, nq, m->q.p, d_qdesc, m->d_cursor, (long)m->cands.cap,
                   m->cstart.p, m->ccount.p, m->cands.p);
         ResolveP P{};
         P.cstart = m->cstart.p; P.ccount = m->ccount.p; P.cands = m->cands.p; P.pfirst = m->qfirst.p; P.kfirst = m->kfirst.p; P.tkeys = m->keys.p; P.qkeys = m->keys.p; P.blocks = m->blocks.p;
