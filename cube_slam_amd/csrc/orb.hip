@@ -661,7 +661,10 @@ __device__ __forceinline__ void qt_child_box(const int4 nd, int k, int &x0, int 
 __global__ void __launch_bounds__(256) orb_quadtree(QtParams Q, const int *level_base, const float *cand, int *perm_all, int *tmp_all, int4 *nodes_all, SelKP *slots, int *slot_cnt,
                                                    int *status) {
     extern __shared__ int qsh[];
-    const int lv = blockIdx.x, f = blockIdx.y, fl = f * Q.nlevels + lv, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    // Frame in x, level in y.  The dispatcher deals consecutive workgroups to the eight XCDs in turn: with the eight LEVELS in x every level-0 workgroup -- the largest
+    // tree of a frame -- landed on the same XCD and the launch took as long as that XCD needed (2.29 ms per 1 024 frames against 0.93 with the frames in x; 4.98 against
+    // 1.55 ms per 512 frames of 1241 x 376 with 2 000 features).  One wave per small level was measured on top: slower.
+    const int lv = blockIdx.y, f = blockIdx.x, fl = f * Q.nlevels + lv, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     const QtLevel L = Q.l[lv];
     const int b0 = level_base[fl], n = level_base[fl + 1] - b0;
     const float *K = cand + (long)b0 * 3;
@@ -1173,7 +1176,7 @@ int cs_orb_run(cs_ctx *ctx, cs_orb *e) {
         // ---- DistributeOctTree on the device: no candidate round trip; the blur runs behind it
         CS_HIP(ctx, hipMemsetAsync(e->d_qstatus, 0, sizeof(int), ctx->stream));
         if (e->qt_lds > 64 * 1024) CS_HIP(ctx, hipFuncSetAttribute((const void *)orb_quadtree, hipFuncAttributeMaxDynamicSharedMemorySize, (int)e->qt_lds));
-        CS_LAUNCH(ctx, "orb_quadtree", orb_quadtree, dim3(NL, F), dim3(256), e->qt_lds, e->Q, e->d_level_base, e->d_cand, e->d_qperm, e->d_qtmp, e->d_qnodes, e->d_slots,
+        CS_LAUNCH(ctx, "orb_quadtree", orb_quadtree, dim3(F, NL), dim3(256), e->qt_lds, e->Q, e->d_level_base, e->d_cand, e->d_qperm, e->d_qtmp, e->d_qnodes, e->d_slots,
                   e->d_slot_cnt, e->d_qstatus);
         CS_LAUNCH(ctx, "orb_scan", orb_scan_levels, dim3(1), dim3(64), 0, F * NL, e->d_slot_cnt, e->d_sel_base);
         e->sel_base.resize((size_t)F * NL + 1);
