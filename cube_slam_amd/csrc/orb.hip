@@ -42,6 +42,7 @@ struct Pyr {
     long frame_stride;
     int umax[HALF_PATCH + 1];
     int gk[7];
+    int tile_off[MAXL + 1], blur_off[MAXL + 1]; // first workgroup of every level in the grids of orb_fast_score / orb_blur (a grid of max-tiles x levels was 61 % workgroups that found nothing to do)
     Lvl l[MAXL];
 };
 
@@ -133,10 +134,12 @@ __global__ void __launch_bounds__(256) orb_resize(Pyr P, int level, uint8_t *__r
 // (or both brighter) than the centre by more than tq the score cannot exceed tq and the min/max network is skipped.  (A
 // row-streaming variant like orb_blur was tried: 715 us vs 383 us, the per-column byte extraction costs more than the tile loads.)
 __global__ void __launch_bounds__(256) orb_fast_score(Pyr P, const uint8_t *pyr, uint8_t *smap) {
-    const Lvl &L = P.l[blockIdx.y];
-    const int tiles_x = (L.w + TW - 1) / TW, tiles_y = (L.h + TH - 1) / TH;
-    if ((int)blockIdx.x >= tiles_x * tiles_y) return;
-    const int tx0 = (blockIdx.x % tiles_x) * TW, ty0 = (blockIdx.x / tiles_x) * TH;
+    int lvq = 0;
+    while (lvq + 1 < P.nlevels && (int)blockIdx.x >= P.tile_off[lvq + 1]) lvq++;
+    const int lv_u = __builtin_amdgcn_readfirstlane(lvq), tile = (int)blockIdx.x - P.tile_off[lv_u];
+    const Lvl &L = P.l[lv_u];
+    const int tiles_x = (L.w + TW - 1) / TW;
+    const int tx0 = (tile % tiles_x) * TW, ty0 = (tile / tiles_x) * TH;
     __shared__ uint32_t g32[TH + 6][(TW + 8) / 4];
     __shared__ unsigned short s_list[TW * TH];
     __shared__ int s_n;
@@ -445,10 +448,12 @@ __device__ __forceinline__ int reflect101(int p, int len) {
 // kernel 10x slower: 1.45 ms vs 0.13 ms without the store).  No workgroup barrier: a single wave orders its own LDS traffic.
 // Same integer arithmetic as the tile version: sum_h = sum g[x+t-3] k[t]; out = (sum_t h[y+t-3] k[t] + 2^15) >> 16, clamped.
 __global__ void __launch_bounds__(64) orb_blur(Pyr P, const uint8_t *pyr, uint8_t *blur) {
-    const Lvl &L = P.l[blockIdx.y];
-    const int strips = (L.w + 255) / 256, chunks = (L.h + BLUR_ROWS - 1) / BLUR_ROWS;
-    if ((int)blockIdx.x >= strips * chunks) return;
-    const int sx = (blockIdx.x % strips) * 256, y0 = (blockIdx.x / strips) * BLUR_ROWS, tid = threadIdx.x;
+    int lvq = 0;
+    while (lvq + 1 < P.nlevels && (int)blockIdx.x >= P.blur_off[lvq + 1]) lvq++;
+    const int lv_u = __builtin_amdgcn_readfirstlane(lvq), blk = (int)blockIdx.x - P.blur_off[lv_u];
+    const Lvl &L = P.l[lv_u];
+    const int strips = (L.w + 255) / 256;
+    const int sx = (blk % strips) * 256, y0 = (blk / strips) * BLUR_ROWS, tid = threadIdx.x;
     const int rows = min(BLUR_ROWS, L.h - y0);
     __shared__ uint32_t line32[(256 + 16) / 4]; // bytes: [0,3) left halo pad .. laid out so that column sx + c sits at byte 4 + c
     uint8_t *line = reinterpret_cast<uint8_t *>(line32);
@@ -1047,6 +1052,8 @@ int cs_orb_create(cs_ctx *ctx, int nfeatures, float scaleFactor, int nlevels, in
         }
         e->max_tiles = std::max(e->max_tiles, ((L.w + TW - 1) / TW) * ((L.h + TH - 1) / TH));
         e->max_blur_blocks = std::max(e->max_blur_blocks, ((L.w + 255) / 256) * ((L.h + BLUR_ROWS - 1) / BLUR_ROWS));
+        P.tile_off[l + 1] = P.tile_off[l] + ((L.w + TW - 1) / TW) * ((L.h + TH - 1) / TH);
+        P.blur_off[l + 1] = P.blur_off[l] + ((L.w + 255) / 256) * ((L.h + BLUR_ROWS - 1) / BLUR_ROWS);
         cand_per_frame += (long)((L.w + 1) / 2) * ((L.h + 1) / 2);
     }
     P.frame_stride = off; P.cells_per_frame = cells;
@@ -1151,7 +1158,7 @@ int cs_orb_run(cs_ctx *ctx, cs_orb *e) {
         CS_LAUNCH(ctx, "orb_resize", orb_resize, dim3((P.l[l].w + 255) / 256, (P.l[l].h + 4 * RS_ROWS - 1) / (4 * RS_ROWS), F), dim3(256), 0, P, l, e->d_pyr, e->d_xofs, e->d_ialpha,
                   e->d_yofs, e->d_ibeta);
     }
-    CS_LAUNCH(ctx, "orb_fast_score", orb_fast_score, dim3(e->max_tiles, NL, F), dim3(256), 0, P, e->d_pyr, e->d_smap);
+    CS_LAUNCH(ctx, "orb_fast_score", orb_fast_score, dim3(P.tile_off[NL], 1, F), dim3(256), 0, P, e->d_pyr, e->d_smap);
     CS_LAUNCH(ctx, "orb_cells", orb_cells, dim3((P.cells_per_frame + CELLS_PER_WG - 1) / CELLS_PER_WG, F), dim3(64 * CELLS_PER_WG), 0, P, e->d_smap, 0, e->d_cell_count, e->d_cell_base, e->d_cand, e->d_cell_mask);
     CS_LAUNCH(ctx, "orb_scan", orb_scan_cells, dim3(NL, F), dim3(64), 0, P, e->d_cell_count, e->d_cell_base, e->d_level_total);
     CS_LAUNCH(ctx, "orb_scan", orb_scan_levels, dim3(1), dim3(64), 0, F * NL, e->d_level_total, e->d_level_base);
@@ -1183,7 +1190,7 @@ int cs_orb_run(cs_ctx *ctx, cs_orb *e) {
         int qstatus = 0;
         r = cs_d2h(ctx, e->sel_base.data(), e->d_sel_base, e->sel_base.size()); if (r) return r;
         r = cs_d2h(ctx, &qstatus, e->d_qstatus, 1); if (r) return r;
-        CS_LAUNCH(ctx, "orb_blur", orb_blur, dim3(e->max_blur_blocks, NL, F), dim3(64), 0, P, e->d_pyr, e->d_blur);
+        CS_LAUNCH(ctx, "orb_blur", orb_blur, dim3(P.blur_off[NL], 1, F), dim3(64), 0, P, e->d_pyr, e->d_blur);
         CS_HIP(ctx, hipStreamSynchronize(ctx->stream));
         e->cand_valid = false;
         if (qstatus != 0) on_device = false; // panorama / pool overflow: redo this batch on the host
@@ -1206,7 +1213,7 @@ int cs_orb_run(cs_ctx *ctx, cs_orb *e) {
     hipEvent_t ev_cand = ctx->get_event();
     CS_HIP(ctx, hipEventRecord(ev_cand, ctx->stream));
     // the blur does not depend on the selection: queued behind the candidate copy, it overlaps the host quadtree
-    if (!blur_done) CS_LAUNCH(ctx, "orb_blur", orb_blur, dim3(e->max_blur_blocks, NL, F), dim3(64), 0, P, e->d_pyr, e->d_blur);
+    if (!blur_done) CS_LAUNCH(ctx, "orb_blur", orb_blur, dim3(P.blur_off[NL], 1, F), dim3(64), 0, P, e->d_pyr, e->d_blur);
     CS_HIP(ctx, hipEventSynchronize(ev_cand));
     e->cand_valid = true;
     ctx->pool.push_back(ev_cand);
