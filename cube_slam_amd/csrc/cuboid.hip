@@ -78,6 +78,8 @@ struct Unit {        // host-filled plan of one (frame, box, height-sample)
     double diag;
     long pix_off;
     long hyp_off;
+    int nms_off, cc_off, hb_off; // first workgroup of the unit in the grids of cuboid_canny_nms (64 x 16 tiles), cuboid_canny_cc_local / _cc (4 096-pixel bands) and
+    int pad_;                    // cuboid_sweep_filter (1 024 hypotheses): a workgroup per piece that EXISTS (grids of max-pieces x units were 40 - 50 % empty workgroups)
 };
 struct UnitDyn { int n_merged, n_valid, n_kept, branch_b; double pad; };
 
@@ -356,12 +358,11 @@ __global__ void __launch_bounds__(64) cuboid_unit_lines(const Unit *units, UnitD
 
 // ------------------------------------------------------------------------------------------------ Canny
 // NMS codes in emap: 0 none, 1 weak candidate (mag > low, local max), 2 strong candidate (mag > high).
-__global__ void __launch_bounds__(256) cuboid_canny_nms(const Unit *units, const uint8_t *gray, int W, int H, uint8_t *emap, int *lab,
+__global__ void __launch_bounds__(256) cuboid_canny_nms(const Unit *units, const int *wg_unit, const uint8_t *gray, int W, int H, uint8_t *emap, int *lab,
                                                         int low, int high) {
-    const Unit &U = units[blockIdx.y];
-    const int tiles_x = (U.roi_w + NMS_TW - 1) / NMS_TW, tiles_y = (U.roi_h + NMS_TH - 1) / NMS_TH;
-    if ((int)blockIdx.x >= tiles_x * tiles_y) return;
-    const int tx0 = (blockIdx.x % tiles_x) * NMS_TW, ty0 = (blockIdx.x / tiles_x) * NMS_TH;
+    const Unit &U = units[__builtin_amdgcn_readfirstlane(wg_unit[blockIdx.x])];
+    const int tiles_x = (U.roi_w + NMS_TW - 1) / NMS_TW, tile = (int)blockIdx.x - U.nms_off;
+    const int tx0 = (tile % tiles_x) * NMS_TW, ty0 = (tile / tiles_x) * NMS_TH;
     __shared__ __attribute__((aligned(4))) uint8_t g[NMS_TH + 4][NMS_TW + 4];
     __shared__ short mg[NMS_TH + 2][NMS_TW + 2];
     const uint8_t *img = gray + (long)U.frame * W * H;
@@ -485,15 +486,14 @@ __device__ inline void ufl_union(int *par, int a, int b) {
         a = old;
     }
 }
-__global__ void __launch_bounds__(256) cuboid_canny_cc_local(const Unit *units, const uint8_t *emap, int *lab) {
+__global__ void __launch_bounds__(256) cuboid_canny_cc_local(const Unit *units, const int *wg_unit, const uint8_t *emap, int *lab) {
     __shared__ int s_par[CC_BAND];      // parent id: local index (strong) or local index + CC_BAND (weak)
     __shared__ uint8_t s_code[CC_BAND];
     __shared__ unsigned short s_list[CC_BAND];
     __shared__ int s_n;
-    const Unit &U = units[blockIdx.y];
+    const Unit &U = units[__builtin_amdgcn_readfirstlane(wg_unit[blockIdx.x])];
     const int A = U.roi_w * U.roi_h, w = U.roi_w;
-    const int p0b = blockIdx.x * CC_BAND;
-    if (p0b >= A) return;
+    const int p0b = ((int)blockIdx.x - U.cc_off) * CC_BAND;
     const uint8_t *em = emap + U.pix_off;
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
@@ -557,17 +557,17 @@ __global__ void __launch_bounds__(256) cuboid_canny_cc_border(const Unit *units,
     }
 }
 // candidates become 255 iff their root is a strong pixel.  16 pixels per thread (one 16-byte load; edge maps are sparse).
-__global__ void __launch_bounds__(256) cuboid_canny_cc(const Unit *units, uint8_t *emap, int *lab) {
+__global__ void __launch_bounds__(256) cuboid_canny_cc(const Unit *units, const int *wg_unit, uint8_t *emap, int *lab) {
     __shared__ int s_list[4096];
     __shared__ int s_n;
-    const Unit &U = units[blockIdx.y];
+    const Unit &U = units[__builtin_amdgcn_readfirstlane(wg_unit[blockIdx.x])];
     const long A = (long)U.roi_w * U.roi_h;
-    if ((long)blockIdx.x * 4096 >= A) return;
+    const int cb = (int)blockIdx.x - U.cc_off;
     uint8_t *em = emap + U.pix_off;
     int *lb = lab + U.pix_off;
     if (threadIdx.x == 0) s_n = 0;
     __syncthreads();
-    const long p0 = ((long)blockIdx.x * 256 + threadIdx.x) * 16;
+    const long p0 = ((long)cb * 256 + threadIdx.x) * 16;
     if (p0 < A) {
         uint4 v = *reinterpret_cast<const uint4 *>(em + p0); // pix_off and the arena padding are multiples of 64
         if ((v.x | v.y | v.z | v.w) != 0) {
@@ -1000,15 +1000,14 @@ __device__ __forceinline__ int corners_build(const Unit &U, const double *vp, in
 // downwards, counts in vcount[2u], vcount[2u+1] -- so that the scoring tasks are configuration-uniform.  Ordered compaction (ballot ranks, no
 // atomics inside the workgroup): a list is in hypothesis order inside every workgroup's stretch, neighbouring lanes of a scoring task sample
 // neighbouring pixels.  Nothing else leaves the kernel: 1 B of flag per hypothesis, 4 B per survivor.
-__global__ void __launch_bounds__(256) cuboid_sweep_filter(const Unit *units, int n_units, int blocks_per_unit, const FrameDyn *fd, Opts o,
+__global__ void __launch_bounds__(256) cuboid_sweep_filter(const Unit *units, const int *wg_unit, const FrameDyn *fd, Opts o,
                                                            const VPEntry *vpt, uint8_t *flag, int *vcount, int *vlist) {
     __shared__ int s_list[2][SWEEP_HB / 2];
     __shared__ int s_wc[2][SWEEP_HB / 64]; // survivors per (round, wave) and configuration
     __shared__ int s_base[2];
-    const int b = blockIdx.x;
-    const int u = b / blocks_per_unit, blk = b - u * blocks_per_unit;
-    if (u >= n_units) return;
+    const int u = __builtin_amdgcn_readfirstlane(wg_unit[blockIdx.x]);
     const Unit &U = units[u];
+    const int blk = (int)blockIdx.x - U.hb_off;
     const FrameDyn &D = fd[U.frame];
     const int n_hyp = D.n_roll * D.n_pitch * D.n_yaw * U.n_tops * 2;
     const int h0 = blk * SWEEP_HB;
@@ -1807,6 +1806,8 @@ struct cs_cuboid_batch {
     std::vector<int> box_first_unit;
     long pix_total = 0, hyp_total = 0, vp_total = 0, line_rows = 0;
     int max_tiles = 0, max_cc_blocks = 0, max_vp_blocks = 0, blocks_per_unit = 0, max_roi_w = 0;
+    int n_nms = 0, n_cc = 0, n_hb = 0, cap_wgmap = 0; // workgroups of the compact grids; d_wgmap = [unit of every NMS tile | of every 4 096-pixel band | of every hypothesis block]
+    int *d_wgmap = nullptr;
     // device
     uint8_t *d_gray = nullptr, *d_emap = nullptr, *d_flag = nullptr;
     int *d_lab = nullptr; // aliases d_dist
@@ -1839,6 +1840,7 @@ struct Plan {
     std::vector<Unit> units; std::vector<FrameInfo> fi; std::vector<int> box_first_unit;
     long pix_total = 0, hyp_total = 0, vp_total = 0, line_rows = 0;
     int max_tiles = 0, max_cc_blocks = 0, max_vp_blocks = 0, blocks_per_unit = 0, max_roi_w = 0, n_boxes = 0;
+    int n_nms = 0, n_cc = 0, n_hb = 0; // workgroups of the compact grids
 };
 static int plan_build(const Opts &o, int sample_bbox_height, int n_frames, int width, int height, const double *Twc, const int *box_offsets, const double *boxes, const int *line_offsets,
                       const std::vector<FrameInfo> *keep_lines, Plan &P) {
@@ -1899,6 +1901,9 @@ static int plan_build(const Opts &o, int sample_bbox_height, int n_frames, int w
                 U.hyp_off = P.hyp_total; P.hyp_total += ((long)U.hyp_cap + 63) / 64 * 64;
                 U.vp_off = (int)P.vp_total; P.vp_total += (long)rp_cap * o.yaw_cap;
                 U.line_off = (int)P.line_rows; P.line_rows += std::min(fi[f].n_lines, CS_MAX_ROI_LINES);
+                U.nms_off = P.n_nms; P.n_nms += ((U.roi_w + NMS_TW - 1) / NMS_TW) * ((U.roi_h + NMS_TH - 1) / NMS_TH);
+                U.cc_off = P.n_cc; P.n_cc += (int)(((long)U.roi_w * U.roi_h + 4095) / 4096);
+                U.hb_off = P.n_hb; P.n_hb += (U.hyp_cap + SWEEP_HB - 1) / SWEEP_HB;
                 P.max_roi_w = std::max(P.max_roi_w, U.roi_w);
                 P.max_tiles = std::max(P.max_tiles, ((U.roi_w + NMS_TW - 1) / NMS_TW) * ((U.roi_h + NMS_TH - 1) / NMS_TH));
                 P.max_cc_blocks = std::max(P.max_cc_blocks, (int)(((long)U.roi_w * U.roi_h + 4095) / 4096));
@@ -1914,10 +1919,19 @@ static void plan_commit(cs_cuboid_batch *b, Plan &P) {
     b->units.swap(P.units); b->fi.swap(P.fi); b->box_first_unit.swap(P.box_first_unit);
     b->n_boxes = P.n_boxes; b->n_units = (int)b->units.size();
     b->pix_total = P.pix_total; b->hyp_total = P.hyp_total; b->vp_total = P.vp_total; b->line_rows = P.line_rows;
+    b->n_nms = P.n_nms; b->n_cc = P.n_cc; b->n_hb = P.n_hb;
     b->max_tiles = P.max_tiles; b->max_cc_blocks = P.max_cc_blocks; b->max_vp_blocks = P.max_vp_blocks; b->blocks_per_unit = P.blocks_per_unit; b->max_roi_w = P.max_roi_w;
 }
 // the distance transform's column count per lane, its scratch offsets, the score kernel's item split and the units by falling cost estimate: functions of the plan
-static void plan_derived(cs_cuboid_batch *b, std::vector<long> &dt_off, std::vector<int> &order) {
+static void plan_derived(cs_cuboid_batch *b, std::vector<long> &dt_off, std::vector<int> &order, std::vector<int> &wgmap) {
+    wgmap.resize((size_t)b->n_nms + b->n_cc + b->n_hb);
+    for (size_t u = 0; u < b->units.size(); u++) {
+        const Unit &U = b->units[u];
+        const int e_nms = u + 1 < b->units.size() ? b->units[u + 1].nms_off : b->n_nms, e_cc = u + 1 < b->units.size() ? b->units[u + 1].cc_off : b->n_cc, e_hb = u + 1 < b->units.size() ? b->units[u + 1].hb_off : b->n_hb;
+        for (int k = U.nms_off; k < e_nms; k++) wgmap[(size_t)k] = (int)u;
+        for (int k = U.cc_off; k < e_cc; k++) wgmap[(size_t)b->n_nms + k] = (int)u;
+        for (int k = U.hb_off; k < e_hb; k++) wgmap[(size_t)b->n_nms + b->n_cc + k] = (int)u;
+    }
     static const int CS_[] = {4, 5, 6, 8, 10, 12, 16, 20};
     const int need = (b->max_roi_w + 63) / 64;
     b->dt_C = 0;
@@ -1951,7 +1965,7 @@ void cs_cuboid_batch_destroy(cs_ctx *ctx, cs_cuboid_batch *b) {
     if (ctx) { hipSetDevice(ctx->device); hipStreamSynchronize(ctx->stream); }
     void *ptrs[] = {b->d_gray, b->d_emap, b->d_flag, b->d_dist, b->d_dttmp, b->d_dttmp_off, b->d_fi, b->d_fd, b->d_cam, b->d_yaw, b->d_lines_in, b->d_lines_al,
                     b->d_mlines, b->d_mangle, b->d_mmid, b->d_units, b->d_ud, b->d_box_first, b->d_status, b->d_counts, b->d_carry, b->d_vp,
-                    b->d_derr, b->d_aerr, b->d_score, b->d_nscore, b->d_ckd, b->d_cka, b->d_cidx, b->d_out, b->d_vcount, b->d_vlist, b->d_order, b->d_cursor, b->d_uflag, b->d_prof};
+                    b->d_derr, b->d_aerr, b->d_score, b->d_nscore, b->d_ckd, b->d_cka, b->d_cidx, b->d_out, b->d_vcount, b->d_vlist, b->d_order, b->d_cursor, b->d_uflag, b->d_prof, b->d_wgmap};
     for (void *p : ptrs) cs_dfree(ctx, p);
     for (int k = 0; k < 2; k++) { if (b->h_stage[k]) hipHostFree(b->h_stage[k]); if (b->stage_ev[k]) hipEventDestroy(b->stage_ev[k]); }
     delete b;
@@ -2014,8 +2028,11 @@ int cs_cuboid_batch_create(cs_ctx *ctx, int n_frames, int width, int height, con
         if (ge && atoi(ge) > 0) b->score_G = atoi(ge);
         const char *te = getenv("CUBESLAM_SCORE_THREADS"); // tuning knob: 512 (2 waves per SIMD, 256 registers) or 1024 (4 waves per SIMD, 128 registers)
         if (te && (atoi(te) == 256 || atoi(te) == 512 || atoi(te) == 768 || atoi(te) == 1024)) { b->score_T = atoi(te); b->score_T_forced = true; }
-        std::vector<long> dt_off; std::vector<int> order;
-        plan_derived(b, dt_off, order);
+        std::vector<long> dt_off; std::vector<int> order, wgmap;
+        plan_derived(b, dt_off, order, wgmap);
+        b->cap_wgmap = (int)std::max<size_t>(wgmap.size(), 1);
+        A_(cs_dalloc(ctx, &b->d_wgmap, (size_t)b->cap_wgmap));
+        A_(cs_h2d(ctx, b->d_wgmap, wgmap.data(), wgmap.size()));
         b->cap_dttmp = std::max<long>(dt_off.back(), 1);
         A_(cs_dalloc(ctx, &b->d_dttmp, (size_t)b->cap_dttmp));
         A_(cs_dalloc(ctx, &b->d_dttmp_off, dt_off.size()));
@@ -2165,14 +2182,15 @@ int cs_cuboid_batch_set_scene(cs_ctx *ctx, cs_cuboid_batch *b, const double *Twc
     if (line_offsets && n_lines > b->cap_lines_in) { const long c = (long)n_lines + n_lines / 4 + 64; G_(grow(&b->d_lines_in, (size_t)c * 4)); G_(grow(&b->d_lines_al, (size_t)c * 4)); b->cap_lines_in = c; }
     if (P.line_rows > b->cap_line_rows) { const long c = P.line_rows + P.line_rows / 4 + 64; G_(grow(&b->d_mlines, (size_t)c * 4)); G_(grow(&b->d_mangle, (size_t)c)); G_(grow(&b->d_mmid, (size_t)c * 2)); b->cap_line_rows = c; }
     plan_commit(b, P);
-    std::vector<long> dt_off; std::vector<int> order;
-    plan_derived(b, dt_off, order);
+    std::vector<long> dt_off; std::vector<int> order, wgmap;
+    plan_derived(b, dt_off, order, wgmap);
+    if ((int)wgmap.size() > b->cap_wgmap) { const int c = (int)(wgmap.size() + wgmap.size() / 4); G_(grow(&b->d_wgmap, (size_t)c)); b->cap_wgmap = c; }
     if (std::max<long>(dt_off.back(), 1) > b->cap_dttmp) { const long c = dt_off.back() + dt_off.back() / 4; G_(grow(&b->d_dttmp, (size_t)c)); b->cap_dttmp = c; }
     // one pinned block: units | frame records | first unit of every box | order | scratch offsets | edge lists; two blocks alternate, a block is reused once its copies are through
     const int k = b->stage_k; b->stage_k ^= 1;
     auto al = [](size_t x) { return (x + 63) & ~(size_t)63; };
     const size_t o_units = 0, o_fi = al(o_units + sizeof(Unit) * (size_t)n_units), o_bf = al(o_fi + sizeof(FrameInfo) * (size_t)b->n_frames), o_ord = al(o_bf + sizeof(int) * (size_t)n_boxes),
-                 o_dt = al(o_ord + sizeof(int) * (size_t)n_units), o_ln = al(o_dt + sizeof(long) * ((size_t)n_units + 1)), total = al(o_ln + sizeof(double) * 4 * (size_t)n_lines);
+                 o_dt = al(o_ord + sizeof(int) * (size_t)n_units), o_wg = al(o_dt + sizeof(long) * ((size_t)n_units + 1)), o_ln = al(o_wg + sizeof(int) * wgmap.size()), total = al(o_ln + sizeof(double) * 4 * (size_t)n_lines);
     if (!b->stage_ev[k]) CS_HIP(ctx, hipEventCreateWithFlags(&b->stage_ev[k], hipEventDisableTiming));
     else CS_HIP(ctx, hipEventSynchronize(b->stage_ev[k]));
     if (total > b->stage_cap[k]) {
@@ -2185,12 +2203,14 @@ int cs_cuboid_batch_set_scene(cs_ctx *ctx, cs_cuboid_batch *b, const double *Twc
     memcpy(h + o_units, b->units.data(), sizeof(Unit) * (size_t)n_units); memcpy(h + o_fi, b->fi.data(), sizeof(FrameInfo) * (size_t)b->n_frames);
     memcpy(h + o_bf, b->box_first_unit.data(), sizeof(int) * (size_t)n_boxes); memcpy(h + o_ord, order.data(), sizeof(int) * (size_t)n_units);
     memcpy(h + o_dt, dt_off.data(), sizeof(long) * ((size_t)n_units + 1));
+    memcpy(h + o_wg, wgmap.data(), sizeof(int) * wgmap.size());
     if (n_lines) memcpy(h + o_ln, lines, sizeof(double) * 4 * (size_t)n_lines);
     G_(cs_h2d(ctx, b->d_units, reinterpret_cast<const Unit *>(h + o_units), (size_t)n_units));
     G_(cs_h2d(ctx, b->d_fi, reinterpret_cast<const FrameInfo *>(h + o_fi), (size_t)b->n_frames));
     G_(cs_h2d(ctx, b->d_box_first, reinterpret_cast<const int *>(h + o_bf), (size_t)n_boxes));
     G_(cs_h2d(ctx, b->d_order, reinterpret_cast<const int *>(h + o_ord), (size_t)n_units));
     G_(cs_h2d(ctx, b->d_dttmp_off, reinterpret_cast<const long *>(h + o_dt), (size_t)n_units + 1));
+    G_(cs_h2d(ctx, b->d_wgmap, reinterpret_cast<const int *>(h + o_wg), wgmap.size()));
     if (n_lines) G_(cs_h2d(ctx, b->d_lines_in, reinterpret_cast<const double *>(h + o_ln), (size_t)n_lines * 4));
     CS_HIP(ctx, hipEventRecord(b->stage_ev[k], ctx->stream));
     if (n_units) CS_LAUNCH(ctx, "cuboid_clear_pad", cuboid_clear_pad, dim3((n_units + 3) / 4), dim3(256), 0, b->d_units, n_units, b->d_dist);
@@ -2221,12 +2241,12 @@ int cs_cuboid_batch_run(cs_ctx *ctx, cs_cuboid_batch *b) {
     CS_LAUNCH(ctx, "cuboid_unit_lines", cuboid_unit_lines, dim3(U), dim3(64), sizeof(double) * 5 * (size_t)ul_cap, b->d_units, b->d_ud, b->d_fi, b->d_lines_al, b->d_mlines,
               b->d_mangle, b->d_mmid, b->d_status, ul_cap);
     CS_HIP(ctx, hipMemsetAsync(b->d_emap, 0, (size_t)b->pix_total, ctx->stream));
-    CS_LAUNCH(ctx, "cuboid_canny_nms", cuboid_canny_nms, dim3(b->max_tiles, U), dim3(256), 0, b->d_units, b->d_gray, b->W, b->H, b->d_emap,
+    CS_LAUNCH(ctx, "cuboid_canny_nms", cuboid_canny_nms, dim3(b->n_nms), dim3(256), 0, b->d_units, b->d_wgmap, b->d_gray, b->W, b->H, b->d_emap,
               b->d_lab, b->o.canny_low, b->o.canny_high);
-    CS_LAUNCH(ctx, "cuboid_canny_cc_local", cuboid_canny_cc_local, dim3(b->max_cc_blocks, U), dim3(256), 0, b->d_units, b->d_emap, b->d_lab);
+    CS_LAUNCH(ctx, "cuboid_canny_cc_local", cuboid_canny_cc_local, dim3(b->n_cc), dim3(256), 0, b->d_units, b->d_wgmap + b->n_nms, b->d_emap, b->d_lab);
     if (b->max_cc_blocks > 1)
         CS_LAUNCH(ctx, "cuboid_canny_cc_border", cuboid_canny_cc_border, dim3(U, 4), dim3(256), 0, b->d_units, b->d_emap, b->d_lab);
-    CS_LAUNCH(ctx, "cuboid_canny_cc", cuboid_canny_cc, dim3(b->max_cc_blocks, U), dim3(256), 0, b->d_units, b->d_emap, b->d_lab);
+    CS_LAUNCH(ctx, "cuboid_canny_cc", cuboid_canny_cc, dim3(b->n_cc), dim3(256), 0, b->d_units, b->d_wgmap + b->n_nms, b->d_emap, b->d_lab);
     if (b->dt_C) {
         const dim3 g((U + 3) / 4), t(256);
         switch (b->dt_C) {
@@ -2243,7 +2263,7 @@ int cs_cuboid_batch_run(cs_ctx *ctx, cs_cuboid_batch *b) {
     CS_LAUNCH(ctx, "cuboid_vp", cuboid_vp, dim3(b->max_vp_blocks, U), dim3(256), 0, b->d_units, b->d_ud, b->d_fd, b->d_cam, b->d_yaw, b->o,
               b->d_mangle, b->d_mmid, b->d_vp);
     CS_HIP(ctx, hipMemsetAsync(b->d_vcount, 0, sizeof(int) * 2 * (size_t)U, ctx->stream));
-    CS_LAUNCH(ctx, "cuboid_sweep_filter", cuboid_sweep_filter, dim3(U * b->blocks_per_unit), dim3(256), 0, b->d_units, U, b->blocks_per_unit, b->d_fd, b->o, b->d_vp,
+    CS_LAUNCH(ctx, "cuboid_sweep_filter", cuboid_sweep_filter, dim3(b->n_hb), dim3(256), 0, b->d_units, b->d_wgmap + b->n_nms + b->n_cc, b->d_fd, b->o, b->d_vp,
               b->d_flag, b->d_vcount, b->d_vlist);
     CS_HIP(ctx, hipMemsetAsync(b->d_cursor, 0, sizeof(int), ctx->stream));
     CS_HIP(ctx, hipMemsetAsync(b->d_uflag, 0, sizeof(int) * (size_t)U, ctx->stream));
