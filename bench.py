@@ -863,7 +863,10 @@ def main():
         tr = None
     ba_out = None
     if not args.no_ba:
-        ba_out = ba_bench(ctx, rank, world, args.ba_iters, with_cpu=(solo and not args.no_cpu), with_traffic=solo and not args.no_extra)
+        try:
+            ba_out = ba_bench(ctx, rank, world, args.ba_iters, with_cpu=(solo and not args.no_cpu), with_traffic=solo and not args.no_extra)
+        except Exception as e:  # (the BA block stands beside the headline: with world > 1 its in-library RCCL all-reduce runs for the first time on the driver's node -- a failure there must not cost the front-end's line)
+            ba_out = {"error": "%s: %s" % (type(e).__name__, str(e)[:300])}
 
     if rank == 0:
         total_frames = args.frames * world * args.steps
