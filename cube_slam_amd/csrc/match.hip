@@ -324,6 +324,9 @@ template <int V> __global__ void __launch_bounds__(64) match_resolve(ResolveP P)
             int best = V == RV_INIT ? INT_MAX : 256, best2 = best, bidx = -1, blev = -1, blev2 = -1;
             auto visit = [&](int2 cd) {
                 const int idx = cd.x & 0xffffff, dist = cd.y;
+                // (frame to frame only the minimum matters, and only if it is at most TH_HIGH: a candidate that cannot become the accepted minimum is dropped before its
+                //  key point's words are read -- most of a window's candidates are other corners at a Hamming distance near 128)
+                if (V == RV_PROJ && (dist > TH_HIGH || dist >= best)) return;
                 const unsigned long long m = mask[idx] & below;
                 if (V == RV_PROJ || V == RV_LOCAL) {
                     bool blk;
