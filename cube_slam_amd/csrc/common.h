@@ -86,6 +86,7 @@ struct cs_ctx {
     // A second, lowest-priority stream of this context for ONE kind of launch: a kernel that holds its wave slots for ~100 ms and paces itself (the LSD region
     // walk).  Everything else of the context then runs at the context's own priority beside it, ordered against it by two events.
     hipStream_t bg_stream = nullptr; hipEvent_t bg_in = nullptr, bg_out = nullptr;
+    hipStream_t aux_stream = nullptr; // a second stream at the context's priority for a branch of a launch chain that reads nothing of the other branch (cs_cuboid_batch_run); created on first use
     hipError_t bg_begin() { // work queued on `stream` so far precedes what is queued on bg_stream from here on
         hipError_t e = hipSuccess;
         if (!bg_stream) {

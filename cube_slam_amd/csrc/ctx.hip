@@ -143,6 +143,7 @@ void cs_destroy(cs_ctx *ctx) {
     for (auto e : ctx->pool) hipEventDestroy(e);
     ctx->pool_drop();
     if (ctx->bg_stream) { hipStreamSynchronize(ctx->bg_stream); hipStreamDestroy(ctx->bg_stream); hipEventDestroy(ctx->bg_in); hipEventDestroy(ctx->bg_out); }
+    if (ctx->aux_stream) { hipStreamSynchronize(ctx->aux_stream); hipStreamDestroy(ctx->aux_stream); }
     if (ctx->stream) hipStreamDestroy(ctx->stream);
     delete ctx;
 }

@@ -1808,6 +1808,10 @@ struct cs_cuboid_batch {
     int max_tiles = 0, max_cc_blocks = 0, max_vp_blocks = 0, blocks_per_unit = 0, max_roi_w = 0;
     int n_nms = 0, n_cc = 0, n_hb = 0, cap_wgmap = 0; // workgroups of the compact grids; d_wgmap = [unit of every NMS tile | of every 4 096-pixel band | of every hypothesis block]
     int *d_wgmap = nullptr;
+    // the two branches of a run that read nothing of each other -- poses / edge lists / vanishing points, and the image: Canny, components, distance transform -- on two
+    // streams, joined before the sweep (cs_cuboid_batch_run): a small batch (one frame of a drop-in call, config 4's 512 units) does not fill the chip and its kernels are
+    // per-unit latency chains, so the branches cost their sum when queued behind each other
+    hipEvent_t ev_fork = nullptr, ev_join = nullptr; // (the second stream is the context's: cs_ctx::aux_stream)
     // device
     uint8_t *d_gray = nullptr, *d_emap = nullptr, *d_flag = nullptr;
     int *d_lab = nullptr; // aliases d_dist
@@ -1968,6 +1972,8 @@ void cs_cuboid_batch_destroy(cs_ctx *ctx, cs_cuboid_batch *b) {
                     b->d_derr, b->d_aerr, b->d_score, b->d_nscore, b->d_ckd, b->d_cka, b->d_cidx, b->d_out, b->d_vcount, b->d_vlist, b->d_order, b->d_cursor, b->d_uflag, b->d_prof, b->d_wgmap};
     for (void *p : ptrs) cs_dfree(ctx, p);
     for (int k = 0; k < 2; k++) { if (b->h_stage[k]) hipHostFree(b->h_stage[k]); if (b->stage_ev[k]) hipEventDestroy(b->stage_ev[k]); }
+    if (b->ev_fork) hipEventDestroy(b->ev_fork);
+    if (b->ev_join) hipEventDestroy(b->ev_join);
     delete b;
 }
 
@@ -2234,12 +2240,29 @@ int cs_cuboid_batch_run(cs_ctx *ctx, cs_cuboid_batch *b) {
     CS_HIP(ctx, hipMemsetAsync(b->d_out, 0, sizeof(cs_cuboid) * (size_t)std::max(1, b->n_boxes * b->o.max_cuboid_num), ctx->stream));
     if (b->n_units == 0) return CS_OK;
     const int U = b->n_units;
-    CS_LAUNCH(ctx, "cuboid_frame_prep", cuboid_frame_prep, dim3(b->n_frames), dim3(64), 0, b->d_fi, b->d_fd, b->d_cam, b->d_yaw, b->cal, b->o,
-              b->d_lines_in, b->d_lines_al);
     int ul_cap = 1;
     for (const FrameInfo &fi_ : b->fi) ul_cap = std::max(ul_cap, std::min(fi_.n_lines, CS_MAX_ROI_LINES));
-    CS_LAUNCH(ctx, "cuboid_unit_lines", cuboid_unit_lines, dim3(U), dim3(64), sizeof(double) * 5 * (size_t)ul_cap, b->d_units, b->d_ud, b->d_fi, b->d_lines_al, b->d_mlines,
-              b->d_mangle, b->d_mmid, b->d_status, ul_cap);
+    // (per-kernel event timing reads one stream: a timed run keeps everything on it)
+    const bool fork = !ctx->timing;
+    if (fork) {
+        if (!ctx->aux_stream) CS_HIP(ctx, hipStreamCreateWithFlags(&ctx->aux_stream, hipStreamNonBlocking));
+        hipStream_t side = ctx->aux_stream;
+        if (!b->ev_fork) {
+            CS_HIP(ctx, hipEventCreateWithFlags(&b->ev_fork, hipEventDisableTiming));
+            CS_HIP(ctx, hipEventCreateWithFlags(&b->ev_join, hipEventDisableTiming));
+        }
+        CS_HIP(ctx, hipEventRecord(b->ev_fork, ctx->stream)); // behind the two memsets above, the batch's uploads and the last run's readers
+        CS_HIP(ctx, hipStreamWaitEvent(side, b->ev_fork, 0));
+        hipLaunchKernelGGL(cuboid_frame_prep, dim3(b->n_frames), dim3(64), 0, side, b->d_fi, b->d_fd, b->d_cam, b->d_yaw, b->cal, b->o, b->d_lines_in, b->d_lines_al);
+        hipLaunchKernelGGL(cuboid_unit_lines, dim3(U), dim3(64), sizeof(double) * 5 * (size_t)ul_cap, side, b->d_units, b->d_ud, b->d_fi, b->d_lines_al, b->d_mlines, b->d_mangle, b->d_mmid, b->d_status, ul_cap);
+        hipLaunchKernelGGL(cuboid_vp, dim3(b->max_vp_blocks, U), dim3(256), 0, side, b->d_units, b->d_ud, b->d_fd, b->d_cam, b->d_yaw, b->o, b->d_mangle, b->d_mmid, b->d_vp);
+        CS_HIP(ctx, hipEventRecord(b->ev_join, side));
+    } else {
+        CS_LAUNCH(ctx, "cuboid_frame_prep", cuboid_frame_prep, dim3(b->n_frames), dim3(64), 0, b->d_fi, b->d_fd, b->d_cam, b->d_yaw, b->cal, b->o,
+                  b->d_lines_in, b->d_lines_al);
+        CS_LAUNCH(ctx, "cuboid_unit_lines", cuboid_unit_lines, dim3(U), dim3(64), sizeof(double) * 5 * (size_t)ul_cap, b->d_units, b->d_ud, b->d_fi, b->d_lines_al, b->d_mlines,
+                  b->d_mangle, b->d_mmid, b->d_status, ul_cap);
+    }
     CS_HIP(ctx, hipMemsetAsync(b->d_emap, 0, (size_t)b->pix_total, ctx->stream));
     CS_LAUNCH(ctx, "cuboid_canny_nms", cuboid_canny_nms, dim3(b->n_nms), dim3(256), 0, b->d_units, b->d_wgmap, b->d_gray, b->W, b->H, b->d_emap,
               b->d_lab, b->o.canny_low, b->o.canny_high);
@@ -2260,8 +2283,10 @@ int cs_cuboid_batch_run(cs_ctx *ctx, cs_cuboid_batch *b) {
         const int wbuf = b->W + 2;
         CS_LAUNCH(ctx, "cuboid_dt", cuboid_dt, dim3((U + 3) / 4), dim3(256), (size_t)wbuf * 2 * 4 * sizeof(int), b->d_units, U, b->d_emap, b->d_dist, wbuf);
     }
-    CS_LAUNCH(ctx, "cuboid_vp", cuboid_vp, dim3(b->max_vp_blocks, U), dim3(256), 0, b->d_units, b->d_ud, b->d_fd, b->d_cam, b->d_yaw, b->o,
-              b->d_mangle, b->d_mmid, b->d_vp);
+    if (fork) CS_HIP(ctx, hipStreamWaitEvent(ctx->stream, b->ev_join, 0));
+    else
+        CS_LAUNCH(ctx, "cuboid_vp", cuboid_vp, dim3(b->max_vp_blocks, U), dim3(256), 0, b->d_units, b->d_ud, b->d_fd, b->d_cam, b->d_yaw, b->o,
+                  b->d_mangle, b->d_mmid, b->d_vp);
     CS_HIP(ctx, hipMemsetAsync(b->d_vcount, 0, sizeof(int) * 2 * (size_t)U, ctx->stream));
     CS_LAUNCH(ctx, "cuboid_sweep_filter", cuboid_sweep_filter, dim3(b->n_hb), dim3(256), 0, b->d_units, b->d_wgmap + b->n_nms + b->n_cc, b->d_fd, b->o, b->d_vp,
               b->d_flag, b->d_vcount, b->d_vlist);
